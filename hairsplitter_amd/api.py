@@ -1,0 +1,402 @@
+"""ctypes binding of include/hairsplitter_hip.h (the C ABI of the MI355X HairSplitter hot path).
+
+There is no Python/CPU implementation behind these calls: if the HIP library is missing, or there is no GPU,
+they raise. Device buffers are torch CUDA tensors (PyTorch-ROCm is only the allocator / stream owner here);
+their `data_ptr()` is what crosses the ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_ROOT, "lib", "libhairsplitter_hip.so")
+
+# every symbol declared in include/hairsplitter_hip.h
+SYMBOLS = [
+    "hs_version", "hs_last_error", "hs_device_count", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
+    "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
+    "hs_event_elapsed_ms", "hs_pileup", "hs_column_stats", "hs_gather_columns", "hs_simdiff", "hs_chinese_whispers",
+    "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
+    "hs_cv_result_destroy", "hs_sr_run", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
+    "hs_separate_reads_main",
+]
+
+
+class HsError(RuntimeError):
+    pass
+
+
+class CvResult(C.Structure):
+    _fields_ = [("n_contigs", C.c_int32), ("mean_distance", C.POINTER(C.c_float)), ("depth", C.POINTER(C.c_float)),
+                ("snp_off", C.POINTER(C.c_int64)), ("snp_pos", C.POINTER(C.c_int32)), ("snp_ref", C.POINTER(C.c_uint8)),
+                ("snp_alt", C.POINTER(C.c_uint8)), ("col_off", C.POINTER(C.c_int64)), ("col_idx", C.POINTER(C.c_int32)),
+                ("col_code", C.POINTER(C.c_uint8)), ("error_rate", C.c_float), ("n_contigs_with_error_rate", C.c_int32),
+                ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("t_kernel_ms", C.c_float * 4)]
+
+
+class SrContig(C.Structure):
+    _fields_ = [("length", C.c_int64), ("n_reads", C.c_int32), ("read_start", C.POINTER(C.c_int32)),
+                ("read_end", C.POINTER(C.c_int32)), ("n_snps", C.c_int32), ("snp_pos", C.POINTER(C.c_int32)),
+                ("snp_ref", C.POINTER(C.c_uint8)), ("snp_alt", C.POINTER(C.c_uint8)), ("col_off", C.POINTER(C.c_int64)),
+                ("col_idx", C.POINTER(C.c_int32)), ("col_code", C.POINTER(C.c_uint8)), ("ploidy", C.c_int32)]
+
+
+class SrResult(C.Structure):
+    _fields_ = [("n_contigs", C.c_int32), ("win_off", C.POINTER(C.c_int64)), ("win_start", C.POINTER(C.c_int32)),
+                ("win_end", C.POINTER(C.c_int32)), ("label_off", C.POINTER(C.c_int64)), ("labels", C.POINTER(C.c_int32)),
+                ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("n_cw_instances", C.c_int64),
+                ("t_kernel_ms", C.c_float * 4)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Loads the in-tree HIP library; raises if it is missing or lacks a declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HsError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950); "
+                      "there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise HsError("libhairsplitter_hip.so lacks symbols: " + ", ".join(missing))
+    lib.hs_version.restype = C.c_char_p
+    lib.hs_last_error.restype = C.c_char_p
+    lib.hs_cv_batch_aligned_bp.restype = C.c_int64
+    lib.hs_cv_batch_aligned_bp.argtypes = [C.c_void_p]
+    lib.hs_cv_batch_destroy.argtypes = [C.c_void_p]
+    lib.hs_cv_batch_destroy.restype = None
+    lib.hs_cv_result_destroy.argtypes = [C.c_void_p]
+    lib.hs_cv_result_destroy.restype = None
+    lib.hs_sr_result_destroy.argtypes = [C.c_void_p]
+    lib.hs_sr_result_destroy.restype = None
+    lib.hs_cv_run.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.POINTER(C.POINTER(CvResult))]
+    lib.hs_sr_run.argtypes = [C.POINTER(SrContig), C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint32, C.c_int32,
+                              C.POINTER(C.POINTER(SrResult))]
+    lib.hs_sr_window_size.argtypes = [C.POINTER(SrContig), C.c_int32, C.c_int32]
+    lib.hs_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
+    lib.hs_event_record.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hs_event_destroy.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise HsError(f"hairsplitter_hip error {rc}: {load().hs_last_error().decode()}")
+
+
+def require_gpu():
+    lib = load()
+    if lib.hs_device_count() <= 0:
+        raise HsError("no HIP device: the HairSplitter MI355X path has no CPU fallback")
+
+
+def _p(t):
+    """device pointer of a torch tensor (or None)"""
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _hp(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+# ------------------------------------------------------------------------------------------------
+# flat batch (the layout the C ABI takes) from synth.ContigData
+# ------------------------------------------------------------------------------------------------
+class FlatBatch:
+    """Host-side flattening of contigs + reads + alignment records (what parse_reads / parse_assembly / parse_SAM
+    of the reference produce, input_output.cpp:39-536), in the C-ABI layout."""
+
+    def __init__(self, contigs):
+        cseq, coff = [], [0]
+        rseq, roff = [], [0]
+        rec_read, rec_pos, rec_strand, cig, cig_off = [], [], [], [], [0]
+        contig_rec_off = [0]
+        n_reads = 0
+        for c in contigs:
+            cseq.append(c.seq)
+            coff.append(coff[-1] + len(c.seq))
+            for r in c.reads:
+                rseq.append(r)
+                roff.append(roff[-1] + len(r))
+            for a in c.alns:
+                rec_read.append(n_reads + a.read)
+                rec_pos.append(a.pos)
+                rec_strand.append(1 if a.strand else 0)
+                cig.append(a.cigar)
+                cig_off.append(cig_off[-1] + len(a.cigar))
+            n_reads += len(c.reads)
+            contig_rec_off.append(len(rec_read))
+        self.contig_seq = _np(np.concatenate(cseq) if cseq else np.zeros(0), np.uint8)
+        self.contig_off = _np(coff, np.int64)
+        self.read_seq = _np(np.concatenate(rseq) if rseq else np.zeros(0), np.uint8)
+        self.read_off = _np(roff, np.int64)
+        self.rec_read = _np(rec_read, np.int32)
+        self.rec_pos = _np(rec_pos, np.int32)
+        self.rec_strand = _np(rec_strand, np.uint8)
+        self.rec_cig_off = _np(cig_off, np.int64)
+        self.cigar = _np(np.concatenate(cig) if cig else np.zeros(0), np.uint32)
+        self.contig_rec_off = _np(contig_rec_off, np.int32)
+        self.n_contigs = len(contigs)
+        self.n_reads = n_reads
+        self.n_rec = len(rec_read)
+        # derived: contig of each record, reference span, pileup offsets (same rule as hs_cv_batch_create)
+        self.rec_contig = _np(np.repeat(np.arange(self.n_contigs), np.diff(self.contig_rec_off)), np.int32)
+        ops = self.cigar & 0xF
+        lens = (self.cigar >> 4).astype(np.int64)
+        refc = np.where((ops == 0) | (ops == 2) | (ops == 7) | (ops == 8), lens, 0)
+        csum = np.concatenate(([0], np.cumsum(refc)))
+        span = csum[self.rec_cig_off[1:]] - csum[self.rec_cig_off[:-1]]
+        L = np.diff(self.contig_off)[self.rec_contig] if self.n_rec else np.zeros(0, np.int64)
+        pos = self.rec_pos.astype(np.int64)
+        qend = np.where(pos >= L, pos, np.minimum(pos + span, L))
+        self.rec_qend = _np(qend, np.int32)
+        self.pile_off = _np(np.concatenate(([0], np.cumsum(qend - pos))), np.int64)
+        self.aligned_bp = int(self.pile_off[-1])
+
+
+class CvBatch:
+    """hs_cv_batch: a FlatBatch resident in HBM."""
+
+    def __init__(self, flat: FlatBatch):
+        require_gpu()
+        lib = load()
+        self.flat = flat
+        h = C.c_void_p()
+        _check(lib.hs_cv_batch_create(_hp(flat.contig_seq, C.c_uint8), _hp(flat.contig_off, C.c_int64), C.c_int32(flat.n_contigs),
+                                      _hp(flat.read_seq, C.c_uint8), _hp(flat.read_off, C.c_int64), C.c_int32(flat.n_reads),
+                                      _hp(flat.rec_read, C.c_int32), _hp(flat.rec_pos, C.c_int32), _hp(flat.rec_strand, C.c_uint8),
+                                      _hp(flat.rec_cig_off, C.c_int64), _hp(flat.cigar, C.c_uint32),
+                                      _hp(flat.contig_rec_off, C.c_int32), C.byref(h)))
+        self.handle = h
+
+    @property
+    def aligned_bp(self) -> int:
+        return int(load().hs_cv_batch_aligned_bp(self.handle))
+
+    def run(self, automatic_snp_threshold: float = 0.33, n_threads: int = 0) -> Dict:
+        """Stage 3 on the resident batch == HS_call_variants without the file I/O (call_variants.cpp:1276-1381)."""
+        lib = load()
+        res = C.POINTER(CvResult)()
+        _check(lib.hs_cv_run(self.handle, C.c_float(automatic_snp_threshold), C.c_int32(n_threads), C.byref(res)))
+        r = res.contents
+        Cn = r.n_contigs
+        snp_off = np.ctypeslib.as_array(r.snp_off, (Cn + 1,)).copy()
+        S = int(snp_off[-1])
+        col_off = np.ctypeslib.as_array(r.col_off, (S + 1,)).copy()
+        E = int(col_off[-1])
+        out = {
+            "mean_distance": np.ctypeslib.as_array(r.mean_distance, (Cn,)).copy() if Cn else np.zeros(0, np.float32),
+            "depth": np.ctypeslib.as_array(r.depth, (Cn,)).copy() if Cn else np.zeros(0, np.float32),
+            "snp_off": snp_off,
+            "snp_pos": np.ctypeslib.as_array(r.snp_pos, (max(S, 1),))[:S].copy(),
+            "snp_ref": np.ctypeslib.as_array(r.snp_ref, (max(S, 1),))[:S].copy(),
+            "snp_alt": np.ctypeslib.as_array(r.snp_alt, (max(S, 1),))[:S].copy(),
+            "col_off": col_off,
+            "col_idx": np.ctypeslib.as_array(r.col_idx, (max(E, 1),))[:E].copy(),
+            "col_code": np.ctypeslib.as_array(r.col_code, (max(E, 1),))[:E].copy(),
+            "error_rate": float(r.error_rate),
+            "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms),
+            "t_kernel_ms": [float(x) for x in r.t_kernel_ms],
+        }
+        lib.hs_cv_result_destroy(res)
+        return out
+
+    def close(self):
+        if self.handle:
+            load().hs_cv_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory: bool = False, amplicon: bool = False,
+                   seed: int = 12345, n_threads: int = 0, ploidy: Optional[Sequence[int]] = None,
+                   rarest_strain_abundance: float = 0.0) -> Dict:
+    """Stage 4 on the in-memory result of stage 3 == HS_separate_reads without the .col round trip
+    (separate_reads.cpp:1440-1739). READ limits are (position_2_1, position_2_2) of the records
+    (call_variants.cpp:1186-1189 -> separate_reads.cpp:176-179)."""
+    require_gpu()
+    lib = load()
+    Cn = flat.n_contigs
+    arr = (SrContig * Cn)()
+    keep = []   # keep numpy buffers alive
+    ops = flat.cigar & 0xF
+    lens = (flat.cigar >> 4).astype(np.int64)
+    refc = np.where((ops == 0) | (ops == 2) | (ops == 7) | (ops == 8), lens, 0)
+    csum = np.concatenate(([0], np.cumsum(refc)))
+    span = csum[flat.rec_cig_off[1:]] - csum[flat.rec_cig_off[:-1]]
+    for c in range(Cn):
+        r0, r1 = int(flat.contig_rec_off[c]), int(flat.contig_rec_off[c + 1])
+        rs = _np(flat.rec_pos[r0:r1], np.int32)
+        re = _np(flat.rec_pos[r0:r1].astype(np.int64) + 1 + span[r0:r1], np.int32)   # pos2_1 + length_contig
+        s0, s1 = int(cv_out["snp_off"][c]), int(cv_out["snp_off"][c + 1])
+        e0 = int(cv_out["col_off"][s0])
+        snp_pos = _np(cv_out["snp_pos"][s0:s1], np.int32)
+        snp_ref = _np(cv_out["snp_ref"][s0:s1], np.uint8)
+        snp_alt = _np(cv_out["snp_alt"][s0:s1], np.uint8)
+        col_off = _np(cv_out["col_off"][s0:s1 + 1] - e0, np.int64)
+        e1 = e0 + int(col_off[-1])
+        col_idx = _np(cv_out["col_idx"][e0:e1], np.int32)
+        col_code = _np(cv_out["col_code"][e0:e1], np.uint8)
+        keep += [rs, re, snp_pos, snp_ref, snp_alt, col_off, col_idx, col_code]
+        a = arr[c]
+        a.length = int(flat.contig_off[c + 1] - flat.contig_off[c])
+        a.n_reads = r1 - r0
+        a.read_start = _hp(rs, C.c_int32); a.read_end = _hp(re, C.c_int32)
+        a.n_snps = s1 - s0
+        a.snp_pos = _hp(snp_pos, C.c_int32); a.snp_ref = _hp(snp_ref, C.c_uint8); a.snp_alt = _hp(snp_alt, C.c_uint8)
+        a.col_off = _hp(col_off, C.c_int64); a.col_idx = _hp(col_idx, C.c_int32); a.col_code = _hp(col_code, C.c_uint8)
+        a.ploidy = int(ploidy[c]) if ploidy is not None else 0
+    w = lib.hs_sr_window_size(arr, C.c_int32(Cn), C.c_int32(1 if amplicon else 0))
+    res = C.POINTER(SrResult)()
+    _check(lib.hs_sr_run(arr, C.c_int32(Cn), C.c_int32(w), C.c_float(error_rate), C.c_int32(1 if low_memory else 0),
+                         C.c_uint32(seed), C.c_int32(n_threads), C.byref(res)))
+    r = res.contents
+    win_off = np.ctypeslib.as_array(r.win_off, (Cn + 1,)).copy()
+    W = int(win_off[-1])
+    label_off = np.ctypeslib.as_array(r.label_off, (W + 1,)).copy()
+    NL = int(label_off[-1])
+    out = {
+        "window_size": int(w), "win_off": win_off,
+        "win_start": np.ctypeslib.as_array(r.win_start, (max(W, 1),))[:W].copy(),
+        "win_end": np.ctypeslib.as_array(r.win_end, (max(W, 1),))[:W].copy(),
+        "label_off": label_off,
+        "labels": np.ctypeslib.as_array(r.labels, (max(NL, 1),))[:NL].copy(),
+        "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "n_cw_instances": int(r.n_cw_instances),
+        "t_kernel_ms": [float(x) for x in r.t_kernel_ms],
+    }
+    lib.hs_sr_result_destroy(res)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# kernel-level wrappers on torch CUDA tensors (used by the parity tests and bench.py's roofline leg)
+# ------------------------------------------------------------------------------------------------
+def device_tensors(flat: FlatBatch, device="cuda:0"):
+    import torch
+    t = {}
+    for k in ("contig_seq", "contig_off", "read_seq", "read_off", "rec_read", "rec_contig", "rec_pos", "rec_strand",
+              "rec_cig_off", "pile_off", "contig_rec_off", "rec_qend"):
+        t[k] = torch.from_numpy(getattr(flat, k)).to(device)
+    t["cigar"] = torch.from_numpy(flat.cigar.view(np.int32)).to(device)
+    return t
+
+
+def pileup(t, flat: FlatBatch):
+    """K1 on device tensors; returns (pile u8[aligned_bp], rec_stats i32[n_rec,4])."""
+    import torch
+    require_gpu()
+    dev = t["contig_seq"].device
+    pile = torch.zeros(max(flat.aligned_bp, 1), dtype=torch.uint8, device=dev)
+    stats = torch.zeros((max(flat.n_rec, 1), 4), dtype=torch.int32, device=dev)
+    _check(load().hs_pileup(_p(t["contig_seq"]), _p(t["contig_off"]), _p(t["read_seq"]), _p(t["read_off"]), _p(t["rec_read"]),
+                            _p(t["rec_contig"]), _p(t["rec_pos"]), _p(t["rec_strand"]), _p(t["rec_cig_off"]), _p(t["cigar"]),
+                            _p(t["pile_off"]), C.c_int32(flat.n_rec), _p(pile), _p(stats), C.c_void_p(0)))
+    torch.cuda.synchronize()
+    return pile[:flat.aligned_bp], stats[:flat.n_rec]
+
+
+def column_stats(t, flat: FlatBatch, pile):
+    """K2; returns a numpy structured view: key u8[4], cnt u16[5], depth u16 per position."""
+    import torch
+    require_gpu()
+    total = int(flat.contig_off[-1])
+    out = torch.zeros((max(total, 1), 16), dtype=torch.uint8, device=pile.device)
+    _check(load().hs_column_stats(_p(pile), _p(t["pile_off"]), _p(t["rec_pos"]), _p(t["rec_qend"]), _p(t["contig_rec_off"]),
+                                  _p(t["contig_off"]), C.c_int32(flat.n_contigs), _p(out), C.c_void_p(0)))
+    torch.cuda.synchronize()
+    dt = np.dtype([("key", np.uint8, 4), ("cnt", np.uint16, 5), ("depth", np.uint16)])
+    return out[:total].cpu().numpy().view(dt).reshape(-1)
+
+
+def gather_columns(t, flat: FlatBatch, pile, sel_contig, sel_pos, depths):
+    import torch
+    require_gpu()
+    dev = pile.device
+    sel_contig = _np(sel_contig, np.int32); sel_pos = _np(sel_pos, np.int32)
+    col_off = _np(np.concatenate(([0], np.cumsum(depths))), np.int64)
+    n = len(sel_pos)
+    tot = int(col_off[-1])
+    idx = torch.zeros(max(tot, 1), dtype=torch.int32, device=dev)
+    code = torch.zeros(max(tot, 1), dtype=torch.uint8, device=dev)
+    d_sc = torch.from_numpy(sel_contig).to(dev); d_sp = torch.from_numpy(sel_pos).to(dev); d_co = torch.from_numpy(col_off).to(dev)
+    _check(load().hs_gather_columns(_p(pile), _p(t["pile_off"]), _p(t["rec_pos"]), _p(t["rec_qend"]), _p(t["contig_rec_off"]),
+                                    _p(d_sc), _p(d_sp), _p(d_co), C.c_int32(n), _p(idx), _p(code), C.c_void_p(0)))
+    torch.cuda.synchronize()
+    return col_off, idx[:tot].cpu().numpy(), code[:tot].cpu().numpy()
+
+
+def simdiff(alt_planes: np.ndarray, ref_planes: np.ndarray):
+    """K5 for one contig: planes are uint64 [N, words]; returns (sim, diff) int32 [N, N]."""
+    import torch
+    require_gpu()
+    N, W = alt_planes.shape
+    dev = "cuda:0"
+    a = torch.from_numpy(alt_planes.view(np.int64)).to(dev); r = torch.from_numpy(ref_planes.view(np.int64)).to(dev)
+    po = torch.zeros(1, dtype=torch.int64, device=dev); oo = torch.zeros(1, dtype=torch.int64, device=dev)
+    n = torch.tensor([N], dtype=torch.int32, device=dev); w = torch.tensor([W], dtype=torch.int32, device=dev)
+    sim = torch.zeros((N, N), dtype=torch.int32, device=dev); diff = torch.zeros((N, N), dtype=torch.int32, device=dev)
+    _check(load().hs_simdiff(_p(a), _p(r), _p(po), _p(n), _p(w), _p(oo), C.c_int32(1), _p(sim), _p(diff), C.c_void_p(0)))
+    torch.cuda.synchronize()
+    return sim.cpu().numpy(), diff.cpu().numpy()
+
+
+def chinese_whispers(adj_lists: List[List[int]], perm: Sequence[int], mask: Sequence[int], inits: np.ndarray):
+    """K7 for one graph and several initial labelings (inits: [n_inst, N]); returns (labels, sweeps)."""
+    import torch
+    require_gpu()
+    dev = "cuda:0"
+    N = len(adj_lists)
+    off = np.zeros(N + 1, np.int32)
+    off[1:] = np.cumsum([len(a) for a in adj_lists])
+    adj = _np(np.concatenate([np.asarray(a, np.int32) for a in adj_lists]) if off[-1] else np.zeros(0), np.int32)
+    n_inst = inits.shape[0]
+    T = lambda a, dt: torch.from_numpy(_np(a, dt)).to(dev)
+    d_off, d_adj = T(off, np.int32), T(adj if len(adj) else np.zeros(1), np.int32)
+    d_gob, d_gab = T([0], np.int64), T([0], np.int64)
+    d_gn, d_perm, d_pb = T([N], np.int32), T(perm, np.int32), T([0], np.int64)
+    d_mask = T(mask, np.uint8)
+    d_ig = T(np.zeros(n_inst), np.int32)
+    d_lb = T(np.arange(n_inst) * N, np.int64)
+    d_lab = T(inits.reshape(-1), np.int32)
+    d_sw = torch.zeros(n_inst, dtype=torch.int32, device=dev)
+    _check(load().hs_chinese_whispers(_p(d_off), _p(d_adj), _p(d_gob), _p(d_gab), _p(d_gn), _p(d_perm), _p(d_pb), _p(d_mask),
+                                      _p(d_ig), _p(d_lb), C.c_int32(n_inst), _p(d_lab), _p(d_sw), C.c_void_p(0)))
+    torch.cuda.synchronize()
+    return d_lab.cpu().numpy().reshape(n_inst, N), d_sw.cpu().numpy()
+
+
+def edit_distance(queries: Sequence[np.ndarray], targets: Sequence[np.ndarray], mode: str = "NW"):
+    """A1 Myers bit-vector kernel; codes 0..3; mode NW | SHW | HW. Returns (distance, end) int32 arrays."""
+    import torch
+    require_gpu()
+    dev = "cuda:0"
+    m = {"NW": 0, "SHW": 1, "HW": 2}[mode]
+    qo = np.zeros(len(queries) + 1, np.int64); qo[1:] = np.cumsum([len(q) for q in queries])
+    to = np.zeros(len(targets) + 1, np.int64); to[1:] = np.cumsum([len(x) for x in targets])
+    q = _np(np.concatenate(queries) if qo[-1] else np.zeros(1), np.uint8)
+    tt = _np(np.concatenate(targets) if to[-1] else np.zeros(1), np.uint8)
+    T = lambda a: torch.from_numpy(a).to(dev)
+    d_q, d_qo, d_t, d_to = T(q), T(qo), T(tt), T(to)
+    n = len(queries)
+    dist = torch.zeros(n, dtype=torch.int32, device=dev); end = torch.zeros(n, dtype=torch.int32, device=dev)
+    _check(load().hs_edit_distance(_p(d_q), _p(d_qo), _p(d_t), _p(d_to), C.c_int32(n), C.c_int32(m), _p(dist), _p(end), C.c_void_p(0)))
+    torch.cuda.synchronize()
+    return dist.cpu().numpy(), end.cpu().numpy()

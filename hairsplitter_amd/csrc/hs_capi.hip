@@ -1,0 +1,475 @@
+// hs_capi.hip -- the C ABI of include/hairsplitter_hip.h: device memory, kernel launches and the two
+// stage drivers. There is no CPU fallback anywhere in this file: without a usable HIP device every entry
+// point fails with HS_ENODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "hs_host.h"
+#include "hs_host_sr.h"
+#include "hs_driver.h"
+#include "hs_kernels.hip"
+
+namespace hs {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace hs
+
+using hs::set_error;
+
+#define HS_HIP(call)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e__ = (call);                                                                         \
+        if (e__ != hipSuccess) {                                                                         \
+            set_error(std::string(#call) + ": " + hipGetErrorString(e__));                               \
+            return e__ == hipErrorNoDevice || e__ == hipErrorInvalidDevice ? HS_ENODEVICE : HS_EHIP;     \
+        }                                                                                                \
+    } while (0)
+
+namespace {
+
+// RAII device buffer
+struct DBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        bytes = n;
+        if (n == 0) n = 16;
+        HS_HIP(hipMalloc(&p, n));
+        return HS_OK;
+    }
+    template <class T> int upload(const std::vector<T>& v) {
+        int rc = alloc(v.size() * sizeof(T));
+        if (rc) return rc;
+        if (!v.empty()) HS_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return HS_OK;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    int init() { HS_HIP(hipEventCreate(&a)); HS_HIP(hipEventCreate(&b)); return HS_OK; }
+    int ms(float* out) { HS_HIP(hipEventSynchronize(b)); HS_HIP(hipEventElapsedTime(out, a, b)); return HS_OK; }
+};
+
+int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available: the HairSplitter MI355X path has no CPU fallback");
+        return HS_ENODEVICE;
+    }
+    return HS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* hs_version(void) { return "hairsplitter_amd 0.1 (gfx950)"; }
+const char* hs_last_error(void) { return hs::g_err.c_str(); }
+int hs_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+int hs_set_device(int device) { HS_HIP(hipSetDevice(device)); return HS_OK; }
+int hs_device_synchronize(void) { HS_HIP(hipDeviceSynchronize()); return HS_OK; }
+int hs_malloc(void** d_ptr, size_t bytes) { HS_HIP(hipMalloc(d_ptr, bytes ? bytes : 16)); return HS_OK; }
+int hs_free(void* d_ptr) { HS_HIP(hipFree(d_ptr)); return HS_OK; }
+int hs_memcpy_h2d(void* d, const void* h, size_t n) { if (n) HS_HIP(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return HS_OK; }
+int hs_memcpy_d2h(void* h, const void* d, size_t n) { if (n) HS_HIP(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return HS_OK; }
+int hs_memset(void* d, int v, size_t n) { if (n) HS_HIP(hipMemset(d, v, n)); return HS_OK; }
+int hs_event_create(void** ev) { hipEvent_t e; HS_HIP(hipEventCreate(&e)); *ev = (void*)e; return HS_OK; }
+int hs_event_destroy(void* ev) { HS_HIP(hipEventDestroy((hipEvent_t)ev)); return HS_OK; }
+int hs_event_record(void* ev, void* stream) { HS_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return HS_OK; }
+int hs_event_elapsed_ms(void* a, void* b, float* ms) {
+    HS_HIP(hipEventSynchronize((hipEvent_t)b));
+    HS_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return HS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernel-level entry points
+// ---------------------------------------------------------------------------------------------------
+int hs_pileup(const uint8_t* d_contig_seq, const int64_t* d_contig_off, const uint8_t* d_read_seq,
+              const int64_t* d_read_off, const int32_t* d_rec_read, const int32_t* d_rec_contig,
+              const int32_t* d_rec_pos, const uint8_t* d_rec_strand, const int64_t* d_rec_cig_off,
+              const uint32_t* d_cigar, const int64_t* d_pile_off, int32_t n_rec, uint8_t* d_pile,
+              int32_t* d_rec_stats, void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_rec <= 0) return HS_OK;
+    const int grid = (n_rec + 3) / 4;
+    hipLaunchKernelGGL(hsdev::k_pileup, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_contig_seq, d_contig_off,
+                       d_read_seq, d_read_off, d_rec_read, d_rec_contig, d_rec_pos, d_rec_strand, d_rec_cig_off, d_cigar,
+                       d_pile_off, n_rec, d_pile, d_rec_stats);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
+static int column_stats_launch(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
+                               const int32_t* d_rec_qend, const int32_t* d_contig_rec_off, const int64_t* d_contig_off,
+                               int32_t n_contigs, int64_t total_len, hs_colstat* d_stats, void* stream) {
+    if (total_len <= 0) return HS_OK;
+    const int64_t grid = (total_len + 255) / 256;
+    hipLaunchKernelGGL(hsdev::k_column_stats, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_pile, d_pile_off,
+                       d_rec_pos, d_rec_qend, d_contig_rec_off, d_contig_off, n_contigs,
+                       reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats));
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
+int hs_column_stats(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
+                    const int32_t* d_rec_qend, const int32_t* d_contig_rec_off, const int64_t* d_contig_off,
+                    int32_t n_contigs, hs_colstat* d_stats, void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_contigs <= 0) return HS_OK;
+    int64_t total = 0;
+    HS_HIP(hipMemcpy(&total, d_contig_off + n_contigs, sizeof(int64_t), hipMemcpyDeviceToHost));
+    return column_stats_launch(d_pile, d_pile_off, d_rec_pos, d_rec_qend, d_contig_rec_off, d_contig_off, n_contigs, total,
+                               d_stats, stream);
+}
+
+int hs_gather_columns(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
+                      const int32_t* d_rec_qend, const int32_t* d_contig_rec_off, const int32_t* d_sel_contig,
+                      const int32_t* d_sel_pos, const int64_t* d_col_off, int32_t n_sel, int32_t* d_col_idx,
+                      uint8_t* d_col_code, void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_sel <= 0) return HS_OK;
+    hipLaunchKernelGGL(hsdev::k_gather_columns, dim3((n_sel + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_pile, d_pile_off,
+                       d_rec_pos, d_rec_qend, d_contig_rec_off, d_sel_contig, d_sel_pos, d_col_off, n_sel, d_col_idx, d_col_code);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
+static int simdiff_launch(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_plane_off, const int32_t* d_n_reads,
+                          const int32_t* d_words, const int64_t* d_out_off, const std::vector<int32_t>& h_n_reads,
+                          int32_t* d_sim, int32_t* d_diff, void* stream, DBuf& t_c, DBuf& t_i, DBuf& t_j) {
+    std::vector<int32_t> tc, ti, tj;
+    for (size_t c = 0; c < h_n_reads.size(); ++c) {
+        const int nt = (h_n_reads[c] + 63) / 64;
+        for (int i = 0; i < nt; ++i) for (int j = 0; j < nt; ++j) { tc.push_back((int32_t)c); ti.push_back(i); tj.push_back(j); }
+    }
+    if (tc.empty()) return HS_OK;
+    if (int rc = t_c.upload(tc)) return rc;
+    if (int rc = t_i.upload(ti)) return rc;
+    if (int rc = t_j.upload(tj)) return rc;
+    hipLaunchKernelGGL(hsdev::k_simdiff, dim3((unsigned)tc.size()), dim3(256), 0, (hipStream_t)stream, d_alt, d_ref, d_plane_off,
+                       d_n_reads, d_words, d_out_off, t_c.as<int32_t>(), t_i.as<int32_t>(), t_j.as<int32_t>(), d_sim, d_diff);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
+int hs_simdiff(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_plane_off, const int32_t* d_n_reads,
+               const int32_t* d_words, const int64_t* d_out_off, int32_t n_contigs, int32_t* d_sim, int32_t* d_diff,
+               void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_contigs <= 0) return HS_OK;
+    std::vector<int32_t> h_n((size_t)n_contigs);
+    HS_HIP(hipMemcpy(h_n.data(), d_n_reads, sizeof(int32_t) * (size_t)n_contigs, hipMemcpyDeviceToHost));
+    DBuf a, b, c;
+    int rc = simdiff_launch(d_alt, d_ref, d_plane_off, d_n_reads, d_words, d_out_off, h_n, d_sim, d_diff, stream, a, b, c);
+    if (rc) return rc;
+    HS_HIP(hipStreamSynchronize((hipStream_t)stream));   // the tile lists die with this frame
+    return HS_OK;
+}
+
+static int cw_launch(const int32_t* d_adj_off, const int32_t* d_adj, const int64_t* d_graph_off_base,
+                     const int64_t* d_graph_adj_base, const int32_t* d_graph_n, const int32_t* d_perm, const int64_t* d_perm_base,
+                     const uint8_t* d_mask, const int32_t* d_inst_graph, const int64_t* d_inst_label_base, int32_t n_inst,
+                     int32_t max_n, int32_t* d_labels, int32_t* d_sweeps, void* stream) {
+    if (n_inst <= 0) return HS_OK;
+    const size_t lds = (size_t)max_n * 8;
+    if (lds > 160 * 1024) { set_error("Chinese Whispers: more than 20480 reads on one contig is not supported"); return HS_EINVAL; }
+    if (lds > 48 * 1024)
+        HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_chinese_whispers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(hsdev::k_chinese_whispers, dim3((unsigned)n_inst), dim3(64), lds, (hipStream_t)stream, d_adj_off, d_adj,
+                       d_graph_off_base, d_graph_adj_base, d_graph_n, d_perm, d_perm_base, d_mask, d_inst_graph,
+                       d_inst_label_base, n_inst, d_labels, d_sweeps);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
+int hs_chinese_whispers(const int32_t* d_adj_off, const int32_t* d_adj, const int64_t* d_graph_off_base,
+                        const int64_t* d_graph_adj_base, const int32_t* d_graph_n, const int32_t* d_perm,
+                        const int64_t* d_perm_base, const uint8_t* d_mask, const int32_t* d_inst_graph,
+                        const int64_t* d_inst_label_base, int32_t n_inst, int32_t* d_labels, int32_t* d_sweeps,
+                        void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_inst <= 0) return HS_OK;
+    // the largest graph decides the LDS footprint: fetch the graph sizes of the instances
+    std::vector<int32_t> ig((size_t)n_inst);
+    HS_HIP(hipMemcpy(ig.data(), d_inst_graph, sizeof(int32_t) * (size_t)n_inst, hipMemcpyDeviceToHost));
+    int gmax = 0;
+    for (int g : ig) gmax = std::max(gmax, g);
+    std::vector<int32_t> gn((size_t)gmax + 1);
+    HS_HIP(hipMemcpy(gn.data(), d_graph_n, sizeof(int32_t) * gn.size(), hipMemcpyDeviceToHost));
+    int max_n = 1;
+    for (int g : ig) max_n = std::max(max_n, gn[(size_t)g]);
+    return cw_launch(d_adj_off, d_adj, d_graph_off_base, d_graph_adj_base, d_graph_n, d_perm, d_perm_base, d_mask, d_inst_graph,
+                     d_inst_label_base, n_inst, max_n, d_labels, d_sweeps, stream);
+}
+
+int hs_edit_distance(const uint8_t* d_query, const int64_t* d_query_off, const uint8_t* d_target,
+                     const int64_t* d_target_off, int32_t n_pairs, int32_t mode, int32_t* d_dist, int32_t* d_end,
+                     void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_pairs <= 0) return HS_OK;
+    if (mode < 0 || mode > 2) { set_error("hs_edit_distance: mode must be 0 (NW), 1 (SHW) or 2 (HW)"); return HS_EINVAL; }
+    // scratch row for the bottom carries of every 64-block pass: one byte per target column
+    std::vector<int64_t> toff((size_t)n_pairs + 1);
+    HS_HIP(hipMemcpy(toff.data(), d_target_off, sizeof(int64_t) * toff.size(), hipMemcpyDeviceToHost));
+    DBuf scratch, soff;
+    if (int rc = scratch.alloc((size_t)(toff[(size_t)n_pairs] - toff[0]) + 64)) return rc;
+    std::vector<int64_t> so((size_t)n_pairs + 1);
+    for (size_t i = 0; i < so.size(); ++i) so[i] = toff[i] - toff[0];
+    if (int rc = soff.upload(so)) return rc;
+    hipLaunchKernelGGL(hsdev::k_myers, dim3((unsigned)n_pairs), dim3(64), 0, (hipStream_t)stream, d_query, d_query_off, d_target,
+                       d_target_off, n_pairs, mode, scratch.as<int8_t>(), soff.as<int64_t>(), d_dist, d_end);
+    HS_HIP(hipGetLastError());
+    HS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return HS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage 3 driver
+// ---------------------------------------------------------------------------------------------------
+struct hs_cv_batch {
+    int32_t n_contigs = 0, n_reads = 0, n_rec = 0;
+    std::vector<int64_t> contig_off, pile_off;
+    std::vector<int32_t> contig_rec_off, rec_pos, rec_qend, rec_contig;
+    int64_t total_len = 0, total_pile = 0;
+    DBuf contig_seq, d_contig_off, read_seq, read_off, rec_read, d_rec_contig, d_rec_pos, rec_strand, rec_cig_off, cigar,
+        d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, colstats;
+};
+
+int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off, int32_t n_contigs,
+                       const uint8_t* h_read_seq, const int64_t* h_read_off, int32_t n_reads,
+                       const int32_t* h_rec_read, const int32_t* h_rec_pos, const uint8_t* h_rec_strand,
+                       const int64_t* h_rec_cig_off, const uint32_t* h_cigar, const int32_t* h_contig_rec_off,
+                       hs_cv_batch** out) {
+    if (int rc = require_device()) return rc;
+    if (!out || n_contigs < 0) { set_error("hs_cv_batch_create: bad arguments"); return HS_EINVAL; }
+    hs_cv_batch* b = new hs_cv_batch();
+    b->n_contigs = n_contigs; b->n_reads = n_reads;
+    b->contig_off.assign(h_contig_off, h_contig_off + n_contigs + 1);
+    b->contig_rec_off.assign(h_contig_rec_off, h_contig_rec_off + n_contigs + 1);
+    b->n_rec = b->contig_rec_off[(size_t)n_contigs];
+    b->total_len = b->contig_off[(size_t)n_contigs];
+    const int n_rec = b->n_rec;
+    b->rec_pos.assign(h_rec_pos, h_rec_pos + n_rec);
+    b->rec_contig.resize((size_t)n_rec);
+    b->rec_qend.resize((size_t)n_rec);
+    b->pile_off.assign((size_t)n_rec + 1, 0);
+    for (int c = 0; c < n_contigs; ++c) {
+        const int64_t L = b->contig_off[(size_t)c + 1] - b->contig_off[(size_t)c];
+        if (b->contig_rec_off[(size_t)c + 1] - b->contig_rec_off[(size_t)c] > 65535) {
+            set_error("more than 65535 alignment records on one contig (the reference's depth loop counter is a short)");
+            delete b; return HS_EINVAL;
+        }
+        for (int r = b->contig_rec_off[(size_t)c]; r < b->contig_rec_off[(size_t)c + 1]; ++r) {
+            b->rec_contig[(size_t)r] = c;
+            int64_t refspan = 0, readspan = 0;
+            for (int64_t o = h_rec_cig_off[r]; o < h_rec_cig_off[r + 1]; ++o) {
+                const uint32_t op = h_cigar[o] & 15u; const int64_t len = h_cigar[o] >> 4;
+                if (op == 0 || op == 2 || op == 7 || op == 8) refspan += len;
+                if (op == 0 || op == 1 || op == 4 || op == 5 || op == 7 || op == 8) readspan += len;
+            }
+            const int64_t rl = h_read_off[h_rec_read[r] + 1] - h_read_off[h_rec_read[r]];
+            const int64_t pos = h_rec_pos[r];
+            if (pos < 0) { set_error("negative alignment start"); delete b; return HS_EINVAL; }
+            int64_t qend = pos >= L ? pos : std::min(pos + refspan, L);
+            // a CIGAR that runs past the read is only tolerated for the part that lies beyond the contig end
+            if (readspan > rl && pos + refspan <= L) { set_error("CIGAR consumes more bases than the read has"); delete b; return HS_EINVAL; }
+            b->rec_qend[(size_t)r] = (int32_t)qend;
+            b->pile_off[(size_t)r + 1] = b->pile_off[(size_t)r] + (qend - pos);
+        }
+    }
+    b->total_pile = b->pile_off[(size_t)n_rec];
+    int rc = 0;
+    auto up = [&](DBuf& d, const void* src, size_t bytes) {
+        if (rc) return;
+        rc = d.alloc(bytes);
+        if (!rc && bytes) { hipError_t e = hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = HS_EHIP; } }
+    };
+    up(b->contig_seq, h_contig_seq, (size_t)b->total_len);
+    up(b->d_contig_off, b->contig_off.data(), sizeof(int64_t) * b->contig_off.size());
+    up(b->read_seq, h_read_seq, (size_t)h_read_off[n_reads]);
+    up(b->read_off, h_read_off, sizeof(int64_t) * ((size_t)n_reads + 1));
+    up(b->rec_read, h_rec_read, sizeof(int32_t) * (size_t)n_rec);
+    up(b->d_rec_contig, b->rec_contig.data(), sizeof(int32_t) * (size_t)n_rec);
+    up(b->d_rec_pos, h_rec_pos, sizeof(int32_t) * (size_t)n_rec);
+    up(b->rec_strand, h_rec_strand, (size_t)n_rec);
+    up(b->rec_cig_off, h_rec_cig_off, sizeof(int64_t) * ((size_t)n_rec + 1));
+    up(b->cigar, h_cigar, sizeof(uint32_t) * (size_t)h_rec_cig_off[n_rec]);
+    up(b->d_pile_off, b->pile_off.data(), sizeof(int64_t) * b->pile_off.size());
+    up(b->d_contig_rec_off, b->contig_rec_off.data(), sizeof(int32_t) * b->contig_rec_off.size());
+    up(b->d_rec_qend, b->rec_qend.data(), sizeof(int32_t) * (size_t)n_rec);
+    if (!rc) rc = b->pile.alloc((size_t)b->total_pile);
+    if (!rc) rc = b->rec_stats.alloc(sizeof(int32_t) * 4 * (size_t)n_rec);
+    if (!rc) rc = b->colstats.alloc(sizeof(hs_colstat) * (size_t)b->total_len);
+    if (rc) { delete b; return rc; }
+    *out = b;
+    return HS_OK;
+}
+
+void hs_cv_batch_destroy(hs_cv_batch* b) { delete b; }
+int64_t hs_cv_batch_aligned_bp(const hs_cv_batch* b) { return b ? b->total_pile : 0; }
+
+void hs_cv_result_destroy(hs_cv_result* r) { hs::free_cv_result(r); }
+void hs_sr_result_destroy(hs_sr_result* r) { hs::free_sr_result(r); }
+
+}  // extern "C"
+
+namespace {
+
+// HIP implementation of the stage-3 device interface (the only one the product has)
+struct HipCvOps : hs::CvDeviceOps {
+    hs_cv_batch* b;
+    hipStream_t stream = nullptr;
+    explicit HipCvOps(hs_cv_batch* batch) : b(batch) {}
+
+    int pileup_and_stats(std::vector<int32_t>& rec_stats, std::vector<hs_colstat>& stats, float k_ms[2]) override {
+        EventPair e1, e2;
+        if (int rc = e1.init()) return rc;
+        if (int rc = e2.init()) return rc;
+        HS_HIP(hipEventRecord(e1.a, stream));
+        if (int rc = hs_pileup(b->contig_seq.as<uint8_t>(), b->d_contig_off.as<int64_t>(), b->read_seq.as<uint8_t>(), b->read_off.as<int64_t>(),
+                               b->rec_read.as<int32_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(), b->rec_strand.as<uint8_t>(),
+                               b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->d_pile_off.as<int64_t>(), b->n_rec, b->pile.as<uint8_t>(),
+                               b->rec_stats.as<int32_t>(), stream)) return rc;
+        HS_HIP(hipEventRecord(e1.b, stream));
+        HS_HIP(hipEventRecord(e2.a, stream));
+        if (int rc = column_stats_launch(b->pile.as<uint8_t>(), b->d_pile_off.as<int64_t>(), b->d_rec_pos.as<int32_t>(), b->d_rec_qend.as<int32_t>(),
+                                         b->d_contig_rec_off.as<int32_t>(), b->d_contig_off.as<int64_t>(), b->n_contigs, b->total_len,
+                                         b->colstats.as<hs_colstat>(), stream)) return rc;
+        HS_HIP(hipEventRecord(e2.b, stream));
+        if (!rec_stats.empty()) HS_HIP(hipMemcpy(rec_stats.data(), b->rec_stats.p, rec_stats.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (!stats.empty()) HS_HIP(hipMemcpy(stats.data(), b->colstats.p, stats.size() * sizeof(hs_colstat), hipMemcpyDeviceToHost));
+        if (int rc = e1.ms(&k_ms[0])) return rc;
+        if (int rc = e2.ms(&k_ms[1])) return rc;
+        return HS_OK;
+    }
+
+    int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
+               std::vector<int32_t>& col_idx, std::vector<uint8_t>& col_code, float* k_ms) override {
+        const int n_sel = (int)sel_pos.size();
+        if (n_sel == 0) return HS_OK;
+        DBuf d_sc, d_sp, d_co, d_ci, d_cc;
+        if (int rc = d_sc.upload(sel_contig)) return rc;
+        if (int rc = d_sp.upload(sel_pos)) return rc;
+        if (int rc = d_co.upload(col_off)) return rc;
+        if (int rc = d_ci.alloc(col_idx.size() * sizeof(int32_t))) return rc;
+        if (int rc = d_cc.alloc(col_code.size())) return rc;
+        EventPair e; if (int rc = e.init()) return rc;
+        HS_HIP(hipEventRecord(e.a, stream));
+        if (int rc = hs_gather_columns(b->pile.as<uint8_t>(), b->d_pile_off.as<int64_t>(), b->d_rec_pos.as<int32_t>(), b->d_rec_qend.as<int32_t>(),
+                                       b->d_contig_rec_off.as<int32_t>(), d_sc.as<int32_t>(), d_sp.as<int32_t>(), d_co.as<int64_t>(), n_sel,
+                                       d_ci.as<int32_t>(), d_cc.as<uint8_t>(), stream)) return rc;
+        HS_HIP(hipEventRecord(e.b, stream));
+        if (!col_idx.empty()) {
+            HS_HIP(hipMemcpy(col_idx.data(), d_ci.p, col_idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            HS_HIP(hipMemcpy(col_code.data(), d_cc.p, col_code.size(), hipMemcpyDeviceToHost));
+        }
+        return e.ms(k_ms);
+    }
+};
+
+// HIP implementation of the stage-4 device interface
+struct HipSrOps : hs::SrDeviceOps {
+    hipStream_t stream = nullptr;
+    DBuf d_adj_off, d_adj, d_gob, d_gab, d_gn, d_perm, d_pb, d_mask;
+    int max_n = 1;
+
+    int simdiff(const std::vector<uint64_t>& alt, const std::vector<uint64_t>& ref, const std::vector<int64_t>& plane_off,
+                const std::vector<int32_t>& n_reads, const std::vector<int32_t>& words, const std::vector<int64_t>& out_off,
+                int64_t out_total, std::vector<int32_t>& sim, std::vector<int32_t>& diff, float* k_ms) override {
+        DBuf d_alt, d_ref, d_po, d_n, d_w, d_oo, d_sim, d_diff, t_c, t_i, t_j;
+        if (int rc = d_alt.upload(alt)) return rc;
+        if (int rc = d_ref.upload(ref)) return rc;
+        if (int rc = d_po.upload(plane_off)) return rc;
+        if (int rc = d_n.upload(n_reads)) return rc;
+        if (int rc = d_w.upload(words)) return rc;
+        if (int rc = d_oo.upload(out_off)) return rc;
+        if (int rc = d_sim.alloc((size_t)out_total * sizeof(int32_t))) return rc;
+        if (int rc = d_diff.alloc((size_t)out_total * sizeof(int32_t))) return rc;
+        EventPair ev; if (int rc = ev.init()) return rc;
+        HS_HIP(hipEventRecord(ev.a, stream));
+        if (int rc = simdiff_launch(d_alt.as<uint64_t>(), d_ref.as<uint64_t>(), d_po.as<int64_t>(), d_n.as<int32_t>(), d_w.as<int32_t>(),
+                                    d_oo.as<int64_t>(), n_reads, d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, t_c, t_i, t_j)) return rc;
+        HS_HIP(hipEventRecord(ev.b, stream));
+        sim.resize((size_t)out_total); diff.resize((size_t)out_total);
+        HS_HIP(hipMemcpy(sim.data(), d_sim.p, (size_t)out_total * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HS_HIP(hipMemcpy(diff.data(), d_diff.p, (size_t)out_total * sizeof(int32_t), hipMemcpyDeviceToHost));
+        float m = 0; if (int rc = ev.ms(&m)) return rc;
+        if (k_ms) *k_ms += m;
+        return HS_OK;
+    }
+    int set_graphs(const hs::CwGraphSet& g) override {
+        max_n = g.max_n;
+        if (int rc = d_adj_off.upload(g.adj_off)) return rc;
+        if (int rc = d_adj.upload(g.adj)) return rc;
+        if (int rc = d_gob.upload(g.graph_off_base)) return rc;
+        if (int rc = d_gab.upload(g.graph_adj_base)) return rc;
+        if (int rc = d_gn.upload(g.graph_n)) return rc;
+        if (int rc = d_perm.upload(g.perm)) return rc;
+        if (int rc = d_pb.upload(g.perm_base_of_graph)) return rc;
+        if (int rc = d_mask.upload(g.mask)) return rc;
+        return HS_OK;
+    }
+    int cw(hs::CwWave& wv, float* k_ms) override {
+        const int n_inst = (int)wv.inst_graph.size();
+        if (n_inst == 0) return HS_OK;
+        DBuf d_ig, d_lb, d_lab;
+        if (int rc = d_ig.upload(wv.inst_graph)) return rc;
+        if (int rc = d_lb.upload(wv.inst_label_base)) return rc;
+        if (int rc = d_lab.upload(wv.labels)) return rc;
+        EventPair ev; if (int rc = ev.init()) return rc;
+        HS_HIP(hipEventRecord(ev.a, stream));
+        if (int rc = cw_launch(d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_gn.as<int32_t>(),
+                               d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), d_ig.as<int32_t>(), d_lb.as<int64_t>(), n_inst,
+                               max_n, d_lab.as<int32_t>(), nullptr, stream)) return rc;
+        HS_HIP(hipEventRecord(ev.b, stream));
+        HS_HIP(hipMemcpy(wv.labels.data(), d_lab.p, wv.labels.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        float m = 0; if (int rc = ev.ms(&m)) return rc;
+        if (k_ms) *k_ms += m;
+        return HS_OK;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out) {
+    if (int rc = require_device()) return rc;
+    if (!b || !out) { set_error("hs_cv_run: null argument"); return HS_EINVAL; }
+    hs::CvMeta meta;
+    meta.n_contigs = b->n_contigs; meta.n_rec = b->n_rec; meta.contig_off = b->contig_off; meta.contig_rec_off = b->contig_rec_off;
+    meta.pile_off = b->pile_off; meta.total_len = b->total_len;
+    HipCvOps ops(b);
+    return hs::cv_run(ops, meta, automatic_snp_threshold, n_threads, out);
+}
+
+int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_t amplicon) {
+    return hs::sr_window_size(contigs, n_contigs, amplicon != 0);
+}
+
+int hs_sr_run(const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate, int32_t low_memory,
+              uint32_t seed, int32_t n_threads, hs_sr_result** out) {
+    if (int rc = require_device()) return rc;
+    if (!out || n_contigs < 0) { set_error("hs_sr_run: bad arguments"); return HS_EINVAL; }
+    HipSrOps ops;
+    return hs::sr_run(ops, contigs, n_contigs, window_size, error_rate, low_memory, seed, n_threads, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,11 @@
+// Device-side mirror of hs_colstat (include/hairsplitter_hip.h) and shared constants.
+#pragma once
+#include <stdint.h>
+namespace hsdev {
+struct alignas(16) hs_colstat_dev {
+    uint8_t key[4];
+    uint16_t cnt[5];
+    uint16_t depth;
+};
+static_assert(sizeof(hs_colstat_dev) == 16, "hs_colstat must be 16 bytes");
+}  // namespace hsdev

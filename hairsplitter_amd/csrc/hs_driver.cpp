@@ -1,0 +1,497 @@
+// hs_driver.cpp -- stage drivers: order of device launches and host glue for HS_call_variants and
+// HS_separate_reads, independent of how the device interface is implemented (see hs_driver.h).
+#include "hs_driver.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <thread>
+
+namespace hs {
+
+namespace {
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <class F>
+void parallel_for(int n, int n_threads, F f) {
+    if (n_threads <= 1 || n <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
+    std::atomic<int> next(0);
+    std::vector<std::thread> th;
+    const int t = std::min(n_threads, n);
+    for (int k = 0; k < t; ++k) th.emplace_back([&]() { for (;;) { int i = next.fetch_add(1); if (i >= n) break; f(i); } });
+    for (auto& x : th) x.join();
+}
+
+template <class T> T* dup_vec(const std::vector<T>& v) {
+    T* p = (T*)std::malloc(std::max<size_t>(1, v.size()) * sizeof(T));
+    if (!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+}  // namespace
+
+void free_cv_result(hs_cv_result* r) {
+    if (!r) return;
+    std::free(r->mean_distance); std::free(r->depth); std::free(r->snp_off); std::free(r->snp_pos); std::free(r->snp_ref);
+    std::free(r->snp_alt); std::free(r->col_off); std::free(r->col_idx); std::free(r->col_code);
+    std::free(r);
+}
+void free_sr_result(hs_sr_result* r) {
+    if (!r) return;
+    std::free(r->win_off); std::free(r->win_start); std::free(r->win_end); std::free(r->label_off); std::free(r->labels);
+    std::free(r);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage 3
+// ---------------------------------------------------------------------------------------------------
+int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int n_threads, hs_cv_result** out) {
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int C = b.n_contigs, NR = b.n_rec;
+    const double t_start = now_ms();
+    float k_ms[3] = {0, 0, 0};
+
+    std::vector<int32_t> rec_stats((size_t)NR * 4);
+    std::vector<hs_colstat> stats((size_t)b.total_len);
+    if (int rc = dev.pileup_and_stats(rec_stats, stats, k_ms)) return rc;
+
+    // interesting positions: second count >= 4 (everything that can become a SNP, see hs_host_cv.cpp)
+    std::vector<int32_t> sel_contig, sel_pos;
+    std::vector<int64_t> col_off(1, 0);
+    std::vector<int64_t> contig_sel_off((size_t)C + 1, 0);
+    for (int c = 0; c < C; ++c) {
+        const int64_t base = b.contig_off[(size_t)c], L = b.contig_off[(size_t)c + 1] - base;
+        for (int64_t p = 0; p < L; ++p) {
+            const hs_colstat& s = stats[(size_t)(base + p)];
+            if (s.cnt[1] >= 4) { sel_contig.push_back(c); sel_pos.push_back((int32_t)p); col_off.push_back(col_off.back() + s.depth); }
+        }
+        contig_sel_off[(size_t)c + 1] = (int64_t)sel_pos.size();
+    }
+    std::vector<int32_t> col_idx((size_t)col_off.back());
+    std::vector<uint8_t> col_code((size_t)col_off.back());
+    if (int rc = dev.gather(sel_contig, sel_pos, col_off, col_idx, col_code, &k_ms[2])) return rc;
+    const double t_dev_done = now_ms();
+
+    // host glue per contig
+    std::vector<ColumnSet> sets((size_t)C);
+    std::vector<ContigCvResult> res((size_t)C);
+    parallel_for(C, n_threads, [&](int c) {
+        ColumnSet& cs = sets[(size_t)c];
+        const int64_t s0 = contig_sel_off[(size_t)c], s1 = contig_sel_off[(size_t)c + 1];
+        cs.pos.assign(sel_pos.begin() + s0, sel_pos.begin() + s1);
+        cs.off.resize((size_t)(s1 - s0) + 1);
+        for (int64_t i = s0; i <= s1; ++i) cs.off[(size_t)(i - s0)] = col_off[(size_t)i] - col_off[(size_t)s0];
+        cs.idx = col_idx.data() + col_off[(size_t)s0];
+        cs.code = col_code.data() + col_off[(size_t)s0];
+        resolve_columns(cs);
+        int64_t nerr = 0, nlen = 0;
+        for (int r = b.contig_rec_off[(size_t)c]; r < b.contig_rec_off[(size_t)c + 1]; ++r) { nerr += rec_stats[(size_t)r * 4 + 1]; nlen += rec_stats[(size_t)r * 4 + 2]; }
+        ContigCvResult& o = res[(size_t)c];
+        o.mean_distance = mean_distance_from_counts(nerr, nlen);
+        const int64_t L = b.contig_off[(size_t)c + 1] - b.contig_off[(size_t)c];
+        const int64_t entries = b.pile_off[(size_t)b.contig_rec_off[(size_t)c + 1]] - b.pile_off[(size_t)b.contig_rec_off[(size_t)c]];
+        o.depth = (float)((double)entries / (double)L);   // call_variants.cpp:565
+        const int n_reads_c = b.contig_rec_off[(size_t)c + 1] - b.contig_rec_off[(size_t)c];
+        call_variants_host(n_reads_c, L, cs, o.mean_distance, automatic_snp_threshold, o);
+    });
+
+    hs_cv_result* R = (hs_cv_result*)std::calloc(1, sizeof(hs_cv_result));
+    R->n_contigs = C;
+    std::vector<float> md((size_t)C), dp((size_t)C);
+    std::vector<int64_t> snp_off((size_t)C + 1, 0), ocol_off(1, 0);
+    std::vector<int32_t> snp_pos, ocol_idx;
+    std::vector<uint8_t> snp_ref, snp_alt, ocol_code;
+    float total_error = 0; int n_err_contigs = 0;
+    for (int c = 0; c < C; ++c) {
+        md[(size_t)c] = res[(size_t)c].mean_distance; dp[(size_t)c] = res[(size_t)c].depth;
+        if (res[(size_t)c].mean_distance > 0) { total_error += res[(size_t)c].mean_distance; n_err_contigs++; }   // call_variants.cpp:1312-1315
+        const ColumnSet& cs = sets[(size_t)c];
+        for (int ci : res[(size_t)c].snp_col) {
+            snp_pos.push_back(cs.pos[(size_t)ci]); snp_ref.push_back(cs.k0[(size_t)ci]); snp_alt.push_back(cs.k1[(size_t)ci]);
+            ocol_idx.insert(ocol_idx.end(), cs.idx + cs.off[(size_t)ci], cs.idx + cs.off[(size_t)ci + 1]);
+            ocol_code.insert(ocol_code.end(), cs.code + cs.off[(size_t)ci], cs.code + cs.off[(size_t)ci + 1]);
+            ocol_off.push_back((int64_t)ocol_idx.size());
+        }
+        snp_off[(size_t)c + 1] = (int64_t)snp_pos.size();
+    }
+    R->mean_distance = dup_vec(md); R->depth = dup_vec(dp); R->snp_off = dup_vec(snp_off); R->snp_pos = dup_vec(snp_pos);
+    R->snp_ref = dup_vec(snp_ref); R->snp_alt = dup_vec(snp_alt); R->col_off = dup_vec(ocol_off); R->col_idx = dup_vec(ocol_idx);
+    R->col_code = dup_vec(ocol_code);
+    R->error_rate = total_error / n_err_contigs;      // call_variants.cpp:1377 (float / int)
+    R->n_contigs_with_error_rate = n_err_contigs;
+    R->t_kernel_ms[0] = k_ms[0]; R->t_kernel_ms[1] = k_ms[1]; R->t_kernel_ms[2] = k_ms[2];
+    R->t_device_ms = t_dev_done - t_start;
+    R->t_host_ms = now_ms() - t_dev_done;
+    *out = R;
+    return HS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage 4
+// ---------------------------------------------------------------------------------------------------
+int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
+           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out) {
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int C = n_contigs;
+    const bool lowmem = low_memory != 0;
+    const double t_start = now_ms();
+    double dev_ms = 0;
+    float k_ms[4] = {0, 0, 0, 0};
+
+    std::vector<SrContigState> st((size_t)C);
+    parallel_for(C, n_threads, [&](int c) {
+        SrContigState& s = st[(size_t)c];
+        s.c = &contigs[c];
+        s.N = contigs[c].n_reads;
+        s.low_memory_now = lowmem || sr_coverage_above_1000(contigs[c]);   // separate_reads.cpp:1515-1518
+        if (contigs[c].n_snps == 0) return;                                 // :1522-1524
+        if (!s.low_memory_now) sr_build_planes(s);
+        s.perm = shuffled_order(s.N, seed);
+    });
+
+    // ---- K5: sim / diff for every contig on the matrix path ----
+    {
+        const double t0 = now_ms();
+        std::vector<int64_t> plane_off((size_t)C, 0), out_off((size_t)C, 0);
+        std::vector<int32_t> nreads((size_t)C, 0), words((size_t)C, 0);
+        int64_t pw = 0, ow = 0;
+        for (int c = 0; c < C; ++c) {
+            if (contigs[c].n_snps == 0 || st[(size_t)c].low_memory_now) continue;
+            plane_off[(size_t)c] = pw; out_off[(size_t)c] = ow;
+            nreads[(size_t)c] = st[(size_t)c].N; words[(size_t)c] = st[(size_t)c].words;
+            pw += (int64_t)st[(size_t)c].N * st[(size_t)c].words;
+            ow += (int64_t)st[(size_t)c].N * st[(size_t)c].N;
+        }
+        if (ow > 0) {
+            std::vector<uint64_t> alt((size_t)pw), ref((size_t)pw);
+            for (int c = 0; c < C; ++c) {
+                if (!nreads[(size_t)c]) continue;
+                std::copy(st[(size_t)c].alt_planes.begin(), st[(size_t)c].alt_planes.end(), alt.begin() + plane_off[(size_t)c]);
+                std::copy(st[(size_t)c].ref_planes.begin(), st[(size_t)c].ref_planes.end(), ref.begin() + plane_off[(size_t)c]);
+            }
+            std::vector<int32_t> sim, diff;
+            if (int rc = dev.simdiff(alt, ref, plane_off, nreads, words, out_off, ow, sim, diff, &k_ms[0])) return rc;
+            for (int c = 0; c < C; ++c) {
+                if (!nreads[(size_t)c]) continue;
+                const size_t nn = (size_t)st[(size_t)c].N * st[(size_t)c].N;
+                st[(size_t)c].sim.assign(sim.begin() + out_off[(size_t)c], sim.begin() + out_off[(size_t)c] + nn);
+                st[(size_t)c].diff.assign(diff.begin() + out_off[(size_t)c], diff.begin() + out_off[(size_t)c] + nn);
+            }
+        }
+        dev_ms += now_ms() - t0;
+    }
+
+    // ---- window plans + graphs (host) ----
+    parallel_for(C, n_threads, [&](int c) {
+        if (contigs[c].n_snps == 0) return;
+        sr_plan_windows(st[(size_t)c], window_size, error_rate, lowmem);
+        std::vector<int32_t>().swap(st[(size_t)c].sim);
+        std::vector<int32_t>().swap(st[(size_t)c].diff);
+    });
+
+    // ---- all graphs of the batch, uploaded once; a graph belongs to exactly one window (its mask) ----
+    CwGraphSet gs;
+    std::vector<int64_t> perm_base_of_contig((size_t)C, 0);
+    std::vector<std::vector<int>> graph_id((size_t)C);
+    for (int c = 0; c < C; ++c) {
+        SrContigState& s = st[(size_t)c];
+        perm_base_of_contig[(size_t)c] = (int64_t)gs.perm.size();
+        gs.perm.insert(gs.perm.end(), s.perm.begin(), s.perm.end());
+        graph_id[(size_t)c].assign(s.graphs.size(), -1);
+    }
+    for (int c = 0; c < C; ++c) {
+        SrContigState& s = st[(size_t)c];
+        for (auto& w : s.windows) {
+            if (!w.has_snps) continue;
+            for (int which = 0; which < 2; ++which) {
+                const int lg = which == 0 ? w.graph_now : w.graph_final;
+                if (graph_id[(size_t)c][(size_t)lg] >= 0) continue;
+                const SrGraph& g = s.graphs[(size_t)lg];
+                graph_id[(size_t)c][(size_t)lg] = (int)gs.graph_n.size();
+                gs.graph_off_base.push_back((int64_t)gs.adj_off.size());
+                gs.graph_adj_base.push_back((int64_t)gs.adj.size());
+                gs.graph_n.push_back(s.N);
+                gs.perm_base_of_graph.push_back(perm_base_of_contig[(size_t)c]);
+                gs.adj_off.insert(gs.adj_off.end(), g.off.begin(), g.off.end());
+                gs.adj.insert(gs.adj.end(), g.adj.begin(), g.adj.end());
+                gs.mask.insert(gs.mask.end(), w.mask.begin(), w.mask.end());
+                gs.max_n = std::max(gs.max_n, s.N);
+            }
+        }
+    }
+    {
+        const double t0 = now_ms();
+        if (int rc = dev.set_graphs(gs)) return rc;
+        dev_ms += now_ms() - t0;
+    }
+
+    int64_t n_cw = 0;
+    auto run_wave = [&](CwWave& wv, float* ms) -> int {
+        if (wv.inst_graph.empty()) return HS_OK;
+        const double t0 = now_ms();
+        if (int rc = dev.cw(wv, ms)) return rc;
+        n_cw += (int64_t)wv.inst_graph.size();
+        dev_ms += now_ms() - t0;
+        return HS_OK;
+    };
+
+    struct WRef { int c, w; int64_t local_base; };
+    std::vector<WRef> wrefs;
+    for (int c = 0; c < C; ++c)
+        for (size_t w = 0; w < st[(size_t)c].windows.size(); ++w)
+            if (st[(size_t)c].windows[w].has_snps) wrefs.push_back(WRef{c, (int)w, 0});
+
+    // ---- wave 1: one run per (window, seeding SNP) (separate_reads.cpp:1674-1705) ----
+    CwWave w1;
+    for (auto& wr : wrefs) {
+        SrContigState& s = st[(size_t)wr.c];
+        SrWindowPlan& w = s.windows[(size_t)wr.w];
+        wr.local_base = (int64_t)w1.labels.size();
+        for (size_t k = 0; k < w.local_snps.size(); ++k) {
+            w1.inst_graph.push_back(graph_id[(size_t)wr.c][(size_t)w.graph_now]);
+            w1.inst_label_base.push_back((int64_t)w1.labels.size());
+            w1.labels.resize(w1.labels.size() + (size_t)s.N);
+        }
+    }
+    parallel_for((int)wrefs.size(), n_threads, [&](int i) {
+        const WRef& wr = wrefs[(size_t)i];
+        SrContigState& s = st[(size_t)wr.c];
+        SrWindowPlan& w = s.windows[(size_t)wr.w];
+        for (size_t k = 0; k < w.local_snps.size(); ++k)
+            sr_local_init_labels(s, w, w.local_snps[k], w1.labels.data() + wr.local_base + (int64_t)k * s.N);
+    });
+    if (int rc = run_wave(w1, &k_ms[1])) return rc;
+
+    // ---- wave 2: merged clustering (separate_reads.cpp:840-885) ----
+    CwWave w2;
+    std::vector<int64_t> w2_base(wrefs.size(), -1);
+    for (size_t i = 0; i < wrefs.size(); ++i) {
+        SrContigState& s = st[(size_t)wrefs[i].c];
+        SrWindowPlan& w = s.windows[(size_t)wrefs[i].w];
+        if (w.local_snps.empty()) continue;          // finalize_clustering :909-919
+        w2_base[i] = (int64_t)w2.labels.size();
+        w2.inst_graph.push_back(graph_id[(size_t)wrefs[i].c][(size_t)w.graph_final]);
+        w2.inst_label_base.push_back(w2_base[i]);
+        w2.labels.resize(w2.labels.size() + (size_t)s.N);
+    }
+    parallel_for((int)wrefs.size(), n_threads, [&](int i) {
+        if (w2_base[(size_t)i] < 0) return;
+        SrContigState& s = st[(size_t)wrefs[(size_t)i].c];
+        SrWindowPlan& w = s.windows[(size_t)wrefs[(size_t)i].w];
+        sr_merged_init_labels(s, w, w1.labels.data() + wrefs[(size_t)i].local_base, (int)w.local_snps.size(), w2.labels.data() + w2_base[(size_t)i]);
+    });
+    if (int rc = run_wave(w2, &k_ms[2])) return rc;
+
+    // ---- wave 3: re-clustering after dropping small clusters (separate_reads.cpp:924-971) ----
+    CwWave w3;
+    w3.inst_graph = w2.inst_graph; w3.inst_label_base = w2.inst_label_base; w3.labels.resize(w2.labels.size());
+    parallel_for((int)wrefs.size(), n_threads, [&](int i) {
+        if (w2_base[(size_t)i] < 0) return;
+        SrContigState& s = st[(size_t)wrefs[(size_t)i].c];
+        SrWindowPlan& w = s.windows[(size_t)wrefs[(size_t)i].w];
+        sr_reclustered_init_labels(s, w, w2.labels.data() + w2_base[(size_t)i], w3.labels.data() + w2_base[(size_t)i]);
+    });
+    if (int rc = run_wave(w3, &k_ms[3])) return rc;
+
+    // ---- tail of finalize_clustering on the host ----
+    parallel_for((int)wrefs.size(), n_threads, [&](int i) {
+        SrContigState& s = st[(size_t)wrefs[(size_t)i].c];
+        SrWindowPlan& w = s.windows[(size_t)wrefs[(size_t)i].w];
+        if (w2_base[(size_t)i] < 0) {
+            w.labels.resize((size_t)s.N);
+            for (int r = 0; r < s.N; ++r) w.labels[(size_t)r] = w.mask[(size_t)r] ? -1 : -2;
+        } else sr_finish_window(s, w, w3.labels.data() + w2_base[(size_t)i], lowmem);
+    });
+
+    // ---- optional ploidy cap (separate_reads.cpp:1711-1715, :1341-1396) ----
+    {
+        CwWave w4;
+        std::vector<size_t> who;
+        for (size_t i = 0; i < wrefs.size(); ++i) {
+            SrContigState& s = st[(size_t)wrefs[i].c];
+            SrWindowPlan& w = s.windows[(size_t)wrefs[i].w];
+            if (contigs[wrefs[i].c].ploidy <= 0) continue;
+            std::vector<int32_t> init((size_t)s.N);
+            if (!sr_ploidy_init_labels(s, w, contigs[wrefs[i].c].ploidy, init.data())) continue;
+            who.push_back(i);
+            w4.inst_graph.push_back(graph_id[(size_t)wrefs[i].c][(size_t)w.graph_final]);
+            w4.inst_label_base.push_back((int64_t)w4.labels.size());
+            w4.labels.insert(w4.labels.end(), init.begin(), init.end());
+        }
+        if (int rc = run_wave(w4, &k_ms[3])) return rc;
+        for (size_t k = 0; k < who.size(); ++k) {
+            SrContigState& s = st[(size_t)wrefs[who[k]].c];
+            SrWindowPlan& w = s.windows[(size_t)wrefs[who[k]].w];
+            w.labels.assign(w4.labels.begin() + w4.inst_label_base[k], w4.labels.begin() + w4.inst_label_base[k] + s.N);
+        }
+    }
+
+    hs_sr_result* R = (hs_sr_result*)std::calloc(1, sizeof(hs_sr_result));
+    R->n_contigs = C;
+    std::vector<int64_t> win_off((size_t)C + 1, 0), label_off(1, 0);
+    std::vector<int32_t> ws, we, labels;
+    for (int c = 0; c < C; ++c) {
+        for (auto& w : st[(size_t)c].windows) {
+            ws.push_back(w.start); we.push_back(w.end);
+            labels.insert(labels.end(), w.labels.begin(), w.labels.end());
+            label_off.push_back((int64_t)labels.size());
+        }
+        win_off[(size_t)c + 1] = (int64_t)ws.size();
+    }
+    R->win_off = dup_vec(win_off); R->win_start = dup_vec(ws); R->win_end = dup_vec(we); R->label_off = dup_vec(label_off);
+    R->labels = dup_vec(labels);
+    R->n_cw_instances = n_cw;
+    for (int k = 0; k < 4; ++k) R->t_kernel_ms[k] = k_ms[k];
+    R->t_device_ms = dev_ms;
+    R->t_host_ms = (now_ms() - t_start) - dev_ms;
+    *out = R;
+    return HS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// files
+// ---------------------------------------------------------------------------------------------------
+// parse_column_file: separate_reads.cpp:46-190 (integer- or character-encoded .col, decided by the first SNPS line)
+int parse_col(const std::string& path, float rsa, std::vector<ColFileContig>& cs) {
+    std::ifstream in(path);
+    std::string line;
+    bool numbers = false, first = true;
+    const int max_coverage = 1000000000;   // :1420-1426: uninitialised shadowed variable, observed "unlimited"
+    while (std::getline(in, line)) {
+        std::istringstream iss(line);
+        std::string type;
+        iss >> type;
+        if (type == "CONTIG") {
+            ColFileContig c;
+            c.contig_line = line;
+            std::string length; double cov = 0;
+            iss >> c.name >> length >> cov;
+            c.length = std::atoi(length.c_str());
+            cs.push_back(std::move(c));
+        } else if (type == "SNPS") {
+            if (cs.empty()) continue;
+            std::string pos, ref_s, sec_s, idx_s, content;
+            iss >> pos >> ref_s >> sec_s;
+            if (ref_s.empty() || sec_s.empty()) continue;
+            if (first && (!std::isalpha((unsigned char)ref_s[0]) && ref_s[0] != '-')) numbers = true;
+            first = false;
+            char ref_base, sec_base;
+            if (numbers) { ref_base = (char)std::atoi(ref_s.c_str()); sec_base = (char)std::atoi(sec_s.c_str()); }
+            else { ref_base = ref_s[0]; sec_base = sec_s[0]; }
+            iss >> idx_s >> content;
+            std::vector<char> codes;
+            std::string tok;
+            for (char ch : content) {
+                if (ch == ',') {
+                    if (tok == " ") codes.push_back(' ');
+                    else if (numbers) codes.push_back((char)(unsigned char)std::atoi(tok.c_str()));
+                    else for (char t : tok) codes.push_back(t);
+                    tok.clear();
+                } else tok += ch;
+            }
+            std::vector<int> ridx;
+            tok.clear();
+            for (char ch : idx_s) { if (ch == ',') { ridx.push_back(std::atoi(tok.c_str())); tok.clear(); } else tok += ch; }
+            ColFileContig& c = cs.back();
+            int cov_maj = 0, cov_sec = 0, cov = 0;
+            const size_t keep_from = c.col_idx.size();
+            for (size_t n = 0; n < codes.size() && n < ridx.size(); ++n) {
+                if (codes[n] != ' ' && cov < max_coverage) {
+                    c.col_code.push_back((uint8_t)codes[n]); c.col_idx.push_back(ridx[n]);
+                    if (codes[n] == ref_base) cov_maj++; else if (codes[n] == sec_base) cov_sec++;
+                }
+                if (codes[n] != ' ' && ridx[n] >= 0) cov++;
+            }
+            if ((float)cov_sec >= rsa * (float)(cov_maj + cov_sec)) {
+                c.snp_pos.push_back(std::atoi(pos.c_str())); c.snp_ref.push_back((uint8_t)ref_base); c.snp_alt.push_back((uint8_t)sec_base);
+                c.col_off.push_back((int64_t)c.col_idx.size());
+            } else { c.col_idx.resize(keep_from); c.col_code.resize(keep_from); }
+        } else if (type == "READ") {
+            if (cs.empty()) continue;
+            ColFileContig& c = cs.back();
+            c.read_lines.push_back(line);
+            std::string name, sR, eR, sC, eC;
+            iss >> name >> sR >> eR >> sC >> eC;
+            char* e1 = nullptr; char* e2 = nullptr;
+            long a = std::strtol(sC.c_str(), &e1, 10), b = std::strtol(eC.c_str(), &e2, 10);
+            if (e1 == sC.c_str() || e2 == eC.c_str()) {
+                std::cout << "error in parsing read limits" << std::endl << "line : " << line << std::endl;
+                return 1;
+            }
+            c.read_start.push_back((int32_t)a); c.read_end.push_back((int32_t)b);
+        }
+    }
+    return 0;
+}
+
+// output_files + error rate: call_variants.cpp:1174-1213,1310-1316,1377
+int write_cv_outputs(const CvFileInput& in, const hs_cv_result* res, const std::string& error_rate_out,
+                     const std::string& col_path, const std::string& vcf_path) {
+    const int C = (int)in.contig_names.size();
+    float total = 0; int n = 0;
+    for (int c = 0; c < C; ++c) {
+        if (in.contig_skip[(size_t)c]) continue;   // call_variants.cpp:1283
+        if (res->mean_distance[c] > 0) { total += res->mean_distance[c]; n += 1; }
+    }
+    {
+        std::ofstream er(error_rate_out);
+        std::cout << "total error rate : " << total << " number of contigs : " << n << std::endl;
+        er << total / n << std::endl;
+    }
+    // the VCF header of :1242-1247 is overwritten when output_files reopens the file (:1177): rows only
+    std::ofstream out(col_path), vcf(vcf_path);
+    std::string idxs, bases;
+    for (int c = 0; c < C; ++c) {
+        if (in.contig_skip[(size_t)c]) continue;
+        const int64_t L = in.contig_off[(size_t)c + 1] - in.contig_off[(size_t)c];
+        out << "CONTIG\t" << in.contig_names[(size_t)c] << "\t" << L << "\t" << res->depth[c] << "\n";
+        for (int r = in.contig_rec_off[(size_t)c]; r < in.contig_rec_off[(size_t)c + 1]; ++r) {
+            out << "READ\t" << in.read_names[(size_t)in.rec_read[(size_t)r]] << "\t" << in.rec_r0[(size_t)r] << "\t" << in.rec_r1[(size_t)r]
+                << "\t" << in.rec_c0[(size_t)r] << "\t" << in.rec_c1[(size_t)r] << "\t" << (in.rec_strand[(size_t)r] ? 1 : 0) << "\n";
+        }
+        for (int64_t s = res->snp_off[c]; s < res->snp_off[c + 1]; ++s) {
+            out << "SNPS\t" << res->snp_pos[s] << "\t" << (int)res->snp_ref[s] << "\t" << (int)res->snp_alt[s] << "\t";
+            idxs.clear(); bases.clear();
+            for (int64_t e = res->col_off[s]; e < res->col_off[s + 1]; ++e) {
+                idxs += std::to_string(res->col_idx[e]); idxs += ',';
+                bases += std::to_string((int)res->col_code[e]); bases += ',';
+            }
+            out << idxs << "\t" << bases << "\n";
+            vcf << in.contig_names[(size_t)c] << "\t" << res->snp_pos[s] << "\t.\t" << "ACGT-"[(res->snp_ref[s] - '!') % 5] << "\t"
+                << "ACGT-"[(res->snp_alt[s] - '!') % 5] << "\t.\t.\tDP=" << (res->col_off[s + 1] - res->col_off[s]) << "\n";
+        }
+        out << std::endl;
+        vcf << std::endl;
+    }
+    return 0;
+}
+
+// separate_reads.cpp:1754-1786
+int write_gro(const std::vector<ColFileContig>& cs, const hs_sr_result* res, const std::string& path) {
+    std::ofstream out(path, std::ios_base::app);
+    std::string a, b;
+    for (size_t i = 0; i < cs.size(); ++i) {
+        if (cs[i].snp_pos.empty()) continue;   // separate_reads.cpp:1522-1524
+        out << cs[i].contig_line << std::endl;
+        for (auto& r : cs[i].read_lines) out << r << "\n";
+        for (int64_t w = res->win_off[i]; w < res->win_off[i + 1]; ++w) {
+            out << "GROUP\t" << res->win_start[w] << "\t" << res->win_end[w] << "\t";
+            a.clear(); b.clear();
+            const int32_t* lab = res->labels + res->label_off[w];
+            const int64_t n = res->label_off[w + 1] - res->label_off[w];
+            for (int64_t h = 0; h < n; ++h) if (lab[h] != -2) { a += std::to_string(h); a += ','; b += std::to_string(lab[h]); b += ','; }
+            out << a << "\t" << b << "\n";
+        }
+    }
+    return 0;
+}
+
+}  // namespace hs

@@ -1,0 +1,80 @@
+// hs_driver.h -- the two stage drivers, written against a small device interface.
+// The shipped library implements the interface with HIP kernels only (hs_capi.hip); there is no CPU
+// implementation in the product. tests/harness implements it with the oracle so the host glue can be
+// checked on a machine without a GPU (that harness is test infrastructure and never ships).
+#pragma once
+#include <cstdint>
+#include <vector>
+#include "hs_host.h"
+#include "hs_host_sr.h"
+
+namespace hs {
+
+struct CvMeta {                       // host-side description of a stage-3 batch
+    int32_t n_contigs = 0, n_rec = 0;
+    std::vector<int64_t> contig_off;      // [C+1]
+    std::vector<int32_t> contig_rec_off;  // [C+1]
+    std::vector<int64_t> pile_off;        // [NREC+1]
+    int64_t total_len = 0;
+};
+
+struct CvDeviceOps {
+    virtual ~CvDeviceOps() {}
+    // K1 + K2: per-record {q_end, n_err, n_len, 0} and per-position statistics; k_ms = {pileup, column_stats}
+    virtual int pileup_and_stats(std::vector<int32_t>& rec_stats, std::vector<hs_colstat>& stats, float k_ms[2]) = 0;
+    // K3: columns of the selected positions
+    virtual int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos,
+                       const std::vector<int64_t>& col_off, std::vector<int32_t>& col_idx, std::vector<uint8_t>& col_code,
+                       float* k_ms) = 0;
+};
+
+int cv_run(CvDeviceOps& dev, const CvMeta& meta, float automatic_snp_threshold, int n_threads, hs_cv_result** out);
+
+struct CwGraphSet {                   // every window graph of the batch, flattened
+    std::vector<int32_t> adj_off, adj, graph_n, perm;
+    std::vector<int64_t> graph_off_base, graph_adj_base, perm_base_of_graph;
+    std::vector<uint8_t> mask;
+    int max_n = 1;
+};
+struct CwWave {                       // one batched launch of the Chinese-Whispers kernel
+    std::vector<int32_t> inst_graph;
+    std::vector<int64_t> inst_label_base;
+    std::vector<int32_t> labels;      // in: initial labels, out: result
+};
+
+struct SrDeviceOps {
+    virtual ~SrDeviceOps() {}
+    // K5 for all contigs with n_reads[c] > 0; sim/diff are written at out_off[c]
+    virtual int simdiff(const std::vector<uint64_t>& alt, const std::vector<uint64_t>& ref, const std::vector<int64_t>& plane_off,
+                        const std::vector<int32_t>& n_reads, const std::vector<int32_t>& words, const std::vector<int64_t>& out_off,
+                        int64_t out_total, std::vector<int32_t>& sim, std::vector<int32_t>& diff, float* k_ms) = 0;
+    virtual int set_graphs(const CwGraphSet& g) = 0;
+    virtual int cw(CwWave& wave, float* k_ms) = 0;
+};
+
+int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
+           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out);
+
+// .col reader of HS_separate_reads (separate_reads.cpp:46-190)
+struct ColFileContig {
+    std::string contig_line, name;
+    long length = 0;
+    std::vector<std::string> read_lines;
+    std::vector<int32_t> read_start, read_end;
+    std::vector<int32_t> snp_pos;
+    std::vector<uint8_t> snp_ref, snp_alt;
+    std::vector<int64_t> col_off{0};
+    std::vector<int32_t> col_idx;
+    std::vector<uint8_t> col_code;
+};
+int parse_col(const std::string& path, float rarest_strain_abundance, std::vector<ColFileContig>& cs);
+
+// writers shared by the executables and the test harness
+int write_cv_outputs(const CvFileInput& in, const hs_cv_result* res, const std::string& error_rate_out,
+                     const std::string& col_path, const std::string& vcf_path);
+int write_gro(const std::vector<ColFileContig>& cs, const hs_sr_result* res, const std::string& path);
+
+void free_cv_result(hs_cv_result* r);
+void free_sr_result(hs_sr_result* r);
+
+}  // namespace hs

@@ -1,0 +1,78 @@
+// hs_host.h -- host-side (C++17) data model and glue of the MI355X HairSplitter hot path.
+// The data-parallel work runs in the HIP kernels (hs_kernels.hip); what is declared here is the sequential
+// glue the reference keeps between them, re-expressed over flat / dense arrays.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/hairsplitter_hip.h"
+
+namespace hs {
+
+void set_error(const std::string& msg);
+
+// ---- stage 3 ---------------------------------------------------------------------------------
+// Columns of the "interesting" positions of one contig (second-most frequent code seen >= 4 times), CSR.
+struct ColumnSet {
+    std::vector<int32_t> pos;        // ascending
+    std::vector<int64_t> off;        // [n+1]
+    const int32_t* idx = nullptr;    // read indices (ascending inside a column), base pointer of the batch
+    const uint8_t* code = nullptr;
+    // exact top-3 of call_variants.cpp:497-507 (reference tie order), filled by resolve_columns()
+    std::vector<uint8_t> k0, k1;
+    std::vector<int32_t> c0, c1, c2;
+};
+
+struct ContigCvResult {
+    float mean_distance = 0;
+    float depth = 0;
+    std::vector<int32_t> snp_col;    // indices into ColumnSet (merged output, ascending position)
+    // diagnostics
+    int n_candidates = 0, n_automatic = 0, n_partitions = 0, n_final_partitions = 0, n_filtered = 0;
+};
+
+void resolve_columns(ColumnSet& cs);
+void call_variants_host(int n_reads, int64_t contig_len, ColumnSet& cs, float mean_distance,
+                        float automatic_snp_threshold, ContigCvResult& out);
+
+// generate_msa's return value from the integer event counts of the pileup kernel (call_variants.cpp:67-68,434)
+float mean_distance_from_counts(int64_t n_err, int64_t n_len);
+
+// ---- stage 4 ---------------------------------------------------------------------------------
+struct SrGraph {                     // one window's read graph, CSR over the contig's reads
+    std::vector<int32_t> off;        // [N+1]
+    std::vector<int32_t> adj;
+};
+
+struct SrWindowPlan {
+    int start = 0, end = 0;
+    bool has_snps = false;
+    std::vector<uint8_t> mask;       // [N]
+    std::vector<int32_t> labels;     // final labels [N]
+    int graph_now = -1;              // graph built for this window (adjacency or neighbour list)
+    int graph_final = -1;            // graph finalize_clustering sees (separate_reads.cpp:1708 quirk)
+    std::vector<int32_t> local_snps; // SNP indices whose allele seeds a local Chinese-Whispers run
+    int final_lo = 0, final_hi = 0;  // [posstart, posend) handed to merge_wrongly_split_haplotypes
+};
+
+// ---- files -----------------------------------------------------------------------------------
+struct CvFileInput {
+    // flattened parse_reads / parse_assembly / parse_SAM result
+    std::vector<std::string> contig_names;
+    std::vector<uint8_t> contig_seq;
+    std::vector<int64_t> contig_off;
+    std::vector<std::string> read_names;
+    std::vector<uint8_t> read_seq;
+    std::vector<int64_t> read_off;
+    std::vector<int32_t> rec_read, rec_pos;
+    std::vector<uint8_t> rec_strand;
+    std::vector<int64_t> rec_cig_off;
+    std::vector<uint32_t> cigar;
+    std::vector<int32_t> contig_rec_off;
+    std::vector<int32_t> rec_r0, rec_r1, rec_c0, rec_c1;   // the four coordinates of the READ line
+    std::vector<uint8_t> contig_skip;                      // call_variants.cpp:1283
+};
+int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::string& sam, bool amplicon,
+                   CvFileInput& in);
+
+}  // namespace hs

@@ -1,0 +1,462 @@
+// hs_host_cv.cpp -- sequential glue of stage 3 (HS_call_variants) over dense per-read arrays.
+//
+// The device produces the pileup, the per-position code statistics and the columns of the few positions
+// that can matter (second allele seen >= 4 times). What is left is the reference's inherently sequential
+// logic: the greedy spacing scan (call_variants.cpp:525-536), the evolving set of partitions of
+// keep_only_robust_variants (:577-768) and the final two-pointer merge (:1335-1352).
+//
+// Representation: a partition is three dense arrays over the contig's N reads (state, more, less) instead of
+// the reference's sorted sparse lists, so comparing a column with a partition costs O(column depth) instead of
+// O(|partition| + depth), and augmenting is element-wise. Results are identical because every rule of
+// Partition.cpp is per shared read; only loops whose floating-point accumulation order is observable
+// (compute_conf) are run in ascending read order.
+//
+// Loop D of the reference (:745-764) evaluates every position of the contig against every final partition; a
+// rescue needs n10+n00 > 4 (:756), i.e. some non-reference code carried by >= 5 reads, so only positions whose
+// second count is >= 5 can ever be rescued -- exactly the columns the device already extracted.
+#include "hs_host.h"
+#include "hs_rh8.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace hs {
+
+static constexpr int8_t ABSENT = 2;
+
+struct DensePartition {
+    int left = -1, right = -1;
+    int n_occ = 0;                 // numberOfOccurences
+    int n_corr = 0;                // number_of_correlating_snps
+    int lo = 0, hi = -1;           // present reads lie in [lo, hi]
+    std::vector<int8_t> state;     // ABSENT, or mostFrequentBases in {-1,0,1}
+    std::vector<int32_t> more, less;
+};
+
+struct Contingency {
+    int n00 = 0, n01 = 0, n10 = 0, n11 = 0;
+    bool comparable = false;       // numberOfBases != 0 (call_variants.cpp:817)
+    uint8_t most = 0, second = ' ';
+};
+
+float mean_distance_from_counts(int64_t n_err, int64_t n_len) {
+    // totalDistance is a float that is incremented by one (saturates at 2^24); totalLength a double starting at 1
+    float total_distance = n_err > 16777216 ? 16777216.0f : (float)n_err;
+    double total_length = 1.0 + (double)n_len;
+    return (float)(total_distance / total_length);
+}
+
+// ---- exact (reference tie order) top-3 of a column: call_variants.cpp:477-507 -------------------------
+static void exact_top3(const uint8_t* code, int n, uint8_t& k0, uint8_t& k1, int& c0, int& c1, int& c2) {
+    int cnt[256];
+    std::memset(cnt, 0, sizeof(cnt));
+    Rh8 rh; rh.clear();
+    for (int i = 0; i < n; ++i) { rh.insert(code[i]); if (code[i] != ' ') cnt[code[i]]++; }
+    rh.insert(0); rh.insert(1); rh.insert(2);
+    uint8_t ord[260];
+    const int m = rh.order(ord);
+    std::vector<std::pair<uint8_t, int>> v(m);
+    for (int i = 0; i < m; ++i) v[i] = std::make_pair(ord[i], cnt[ord[i]]);
+    std::sort(v.begin(), v.end(), [](const std::pair<uint8_t, int>& a, const std::pair<uint8_t, int>& b) { return a.second > b.second; });
+    k0 = v[0].first; k1 = v[1].first; c0 = v[0].second; c1 = v[1].second; c2 = v[2].second;
+}
+
+void resolve_columns(ColumnSet& cs) {
+    const size_t n = cs.pos.size();
+    cs.k0.resize(n); cs.k1.resize(n); cs.c0.resize(n); cs.c1.resize(n); cs.c2.resize(n);
+    for (size_t i = 0; i < n; ++i)
+        exact_top3(cs.code + cs.off[i], (int)(cs.off[i + 1] - cs.off[i]), cs.k0[i], cs.k1[i], cs.c0[i], cs.c1[i], cs.c2[i]);
+}
+
+// most frequent non-reference code among `codes` restricted to the entries flagged in `take`
+// (first in robin_hood iteration order on ties: call_variants.cpp:837-844, Partition.cpp:59-66).
+// `signed_ref_quirk`: in distance() the reference compares a *signed* char with unsigned keys (:838), so a
+// reference code >= 128 never equals any key and stays eligible.
+static uint8_t second_most_frequent(const uint8_t* code, int n, const uint8_t* take, uint8_t ref, bool signed_ref_quirk,
+                                    bool insert_ref_last, uint8_t dflt) {
+    int cnt[256];
+    uint8_t seen[256];
+    int nseen = 0;
+    bool have = false;
+    for (int i = 0; i < n; ++i) {
+        if (take && !take[i]) continue;
+        const uint8_t c = code[i];
+        if (!have) { std::memset(cnt, 0, sizeof(cnt)); have = true; }
+        if (cnt[c] == 0) seen[nseen++] = c;
+        cnt[c]++;
+    }
+    if (!have) return dflt;
+    const bool ref_eligible = signed_ref_quirk && ref >= 128;
+    int best = -1, nbest = 0;
+    uint8_t bestk = dflt;
+    bool ref_seen = false;
+    for (int i = 0; i < nseen; ++i) {
+        const uint8_t k = seen[i];
+        if (k == ref) { ref_seen = true; if (!ref_eligible) continue; }
+        if (cnt[k] > best) { best = cnt[k]; nbest = 1; bestk = k; }
+        else if (cnt[k] == best) nbest++;
+    }
+    if (ref_eligible && !ref_seen && insert_ref_last) {   // content2[ref_base] inserts a zero-count key
+        if (0 > best) { best = 0; nbest = 1; bestk = ref; } else if (best == 0) nbest++;
+    }
+    if (best < 0) return dflt;
+    if (nbest == 1) return bestk;
+    // tie: the winner is the first of the tied keys in the hash map's iteration order
+    Rh8 rh; rh.clear();
+    for (int i = 0; i < nseen; ++i) rh.insert(seen[i]);
+    if (insert_ref_last) rh.insert(ref);
+    uint8_t ord[260];
+    const int m = rh.order(ord);
+    for (int i = 0; i < m; ++i) {
+        const uint8_t k = ord[i];
+        if (k == ref && !ref_eligible) continue;
+        const int c = (k == ref && !ref_seen) ? 0 : cnt[k];
+        if (c == best) return k;
+    }
+    return bestk;
+}
+
+// distance(Partition&, Column&, char): call_variants.cpp:778-967
+static Contingency column_vs_partition(const DensePartition& p, const int32_t* idx, const uint8_t* code, int n, uint8_t ref) {
+    Contingency r;
+    uint8_t take_stack[512];
+    std::vector<uint8_t> take_heap;
+    uint8_t* take = take_stack;
+    if (n > 512) { take_heap.resize(n); take = take_heap.data(); }
+    int shared = 0;
+    for (int i = 0; i < n; ++i) { take[i] = p.state[idx[i]] != ABSENT; shared += take[i]; }
+    if (shared == 0) return r;
+    r.comparable = true;
+    r.most = ref;
+    r.second = second_most_frequent(code, n, take, ref, true, true, ' ');
+    for (int i = 0; i < n; ++i) {
+        if (!take[i]) continue;
+        const int8_t s = p.state[idx[i]];
+        if (code[i] == r.most) { if (s == 1) r.n11++; else if (s == -1) r.n01++; }
+        else if (code[i] == r.second) { if (s == 1) r.n10++; else if (s == -1) r.n00++; }
+    }
+    return r;
+}
+
+// computeChiSquare: call_variants.cpp:1135-1163 (float marginals, double squares, float result)
+static float chi_square(const Contingency& d) {
+    const int n = d.n00 + d.n01 + d.n10 + d.n11;
+    if (n == 0) return 0;
+    const float pmax1 = float(d.n10 + d.n11) / n;
+    const float pmax2 = float(d.n01 + d.n11) / n;
+    if (pmax1 * (1 - pmax1) == 0 && pmax2 * (1 - pmax2) == 0) return -1;
+    if (pmax1 * pmax2 * (1 - pmax1) * (1 - pmax2) == 0) return 0;
+    const float e00 = (1 - pmax1) * (1 - pmax2) * n, e01 = (1 - pmax1) * pmax2 * n;
+    const float e10 = pmax1 * (1 - pmax2) * n, e11 = pmax1 * pmax2 * n;
+    const double d00 = (double)(float)(d.n00 - e00), d01 = (double)(float)(d.n01 - e01);
+    const double d10 = (double)(float)(d.n10 - e10), d11 = (double)(float)(d.n11 - e11);
+    return (float)(d00 * d00 / (double)e00 + d01 * d01 / (double)e01 + d10 * d10 / (double)e10 + d11 * d11 / (double)e11);
+}
+
+// Partition::Partition(Column&, pos, ref_base): Partition.cpp:32-83
+static void partition_from_column(DensePartition& p, int n_reads, const int32_t* idx, const uint8_t* code, int n, int pos, uint8_t ref) {
+    p.left = p.right = pos; p.n_occ = 1; p.n_corr = 0;
+    p.state.assign(n_reads, ABSENT); p.more.assign(n_reads, 0); p.less.assign(n_reads, 0);
+    const uint8_t second = second_most_frequent(code, n, nullptr, ref, false, false, 0);
+    for (int i = 0; i < n; ++i) {
+        const int r = idx[i];
+        p.state[r] = code[i] == ref ? 1 : (code[i] == second ? -1 : 0);
+        p.more[r] = 1; p.less[r] = 0;
+    }
+    p.lo = n ? idx[0] : 0; p.hi = n ? idx[n - 1] : -1;
+}
+
+// Partition::augmentPartition with the 'A'/'a'/' ' recoding of distance() folded in:
+// Partition.cpp:243-397 + call_variants.cpp:856-872
+static void augment(DensePartition& p, const int32_t* idx, const uint8_t* code, int n, const Contingency& d, int pos) {
+    if (pos != -1) {
+        if (pos < p.left || p.left == -1) p.left = pos;
+        if (pos > p.right) p.right = pos;
+    }
+    if (!d.comparable || n == 0) return;      // empty partition_to_augment (:251-253)
+    int nA = 0, na = 0;
+    for (int i = 0; i < n; ++i) { if (code[i] == d.most) nA++; else if (code[i] == d.second) na++; }
+    // two most frequent characters over 0..254 except ' ', lowest character wins ties (:261-280)
+    int mostc, secondc;
+    if (nA == 0 && na == 0) { mostc = 0; secondc = 1; }
+    else if (nA >= na) { mostc = 'A'; secondc = na > 0 ? 'a' : 0; }
+    else { mostc = 'a'; secondc = nA > 0 ? 'A' : 0; }
+    auto recode = [&](uint8_t c) -> int { return c == d.most ? 'A' : (c == d.second ? 'a' : ' '); };
+    int swapped = 0;                           // phase vote over shared reads (:284-314)
+    for (int i = 0; i < n; ++i) {
+        const int8_t s = p.state[idx[i]];
+        if (s == ABSENT) continue;
+        const int ch = recode(code[i]);
+        if (ch == mostc && s == 1) swapped += 1;
+        else if (ch == mostc && s == -1) swapped -= 1;
+        else if (ch == secondc && s == -1) swapped += 1;
+        else if (ch == secondc && s == 1) swapped -= 1;
+    }
+    if (swapped < 0) std::swap(mostc, secondc);
+    for (int i = 0; i < n; ++i) {              // element-wise form of the sorted merge (:322-390)
+        const int r = idx[i];
+        const int ch = recode(code[i]);
+        int s = 0;
+        if (ch == secondc) s = -1;
+        if (ch == mostc) s = 1;
+        int8_t& st = p.state[r];
+        if (st == ABSENT) { st = (int8_t)s; p.more[r] = std::abs(s); p.less[r] = 0; }
+        else if (s == 0) { /* nothing new */ }
+        else if (st == 0) { st = (int8_t)s; p.more[r] = 1; p.less[r] = 0; }
+        else if (s == st) { p.more[r] += 1; }
+        else {                                 // s == -st
+            if (p.less[r] + 1 > p.more[r]) { st = (int8_t)-st; p.more[r] += 1; }
+            else p.less[r] += 1;
+        }
+    }
+    if (n) { if (p.hi < p.lo) { p.lo = idx[0]; p.hi = idx[n - 1]; } else { p.lo = std::min(p.lo, idx[0]); p.hi = std::max(p.hi, idx[n - 1]); } }
+    p.n_occ += 1;
+}
+
+// Partition::isInformative(false, meanError): Partition.cpp:141-179
+static bool is_informative(const DensePartition& p, float mean_error) {
+    int suspicious[2] = {0, 0};
+    int number_of_reads = 0;
+    for (int r = p.lo; r <= p.hi; ++r) {
+        if (p.state[r] == ABSENT) continue;
+        const int read_number = p.more[r] + p.less[r];
+        float threshold = (float)(0.5 * read_number + 3 * std::sqrt(read_number * 0.5 * (1 - 0.5)));
+        threshold = std::min(threshold, float(read_number) - 1);
+        if ((float)p.more[r] > threshold) {
+            if (p.state[r] == -1) { suspicious[0]++; number_of_reads++; }
+            else if (p.state[r] == 1) { suspicious[1]++; number_of_reads++; }
+        }
+    }
+    const float min_reads = mean_error * number_of_reads / 2;
+    return !(suspicious[0] < min_reads || suspicious[1] < min_reads);
+}
+
+static double lchoose(double n, double k) { return std::lgamma(n + 1) - std::lgamma(k + 1) - std::lgamma(n - k + 1); }
+
+// Partition::isSignificant: Partition.cpp:197-233 (the "p != 0" test is on the ordinal of the read, :209)
+static float significance(const DensePartition& p, int total_columns) {
+    int mutated = 0, reads = 0, columns = 0, ordinal = 0;
+    for (int r = p.lo; r <= p.hi; ++r) {
+        if (p.state[r] == ABSENT) continue;
+        if (p.state[r] == -1 && p.more[r] > 1 && p.less[r] == 0) { mutated++; if (p.more[r] > columns) columns = p.more[r]; }
+        if (ordinal != 0 && p.more[r] > 1 && p.less[r] == 0) reads++;
+        ordinal++;
+    }
+    const double pv = std::exp(::log((double)(float(mutated) / reads)) * columns * mutated + lchoose(reads, mutated) + lchoose(total_columns, columns));
+    return (float)std::max(0.0, pv);
+}
+
+// Partition::compute_conf: Partition.cpp:716-732 with getConfidence :811-827 (ascending read order matters)
+static float confidence_score(const DensePartition& p) {
+    double conf = 1;
+    int n = 0;
+    for (int r = p.lo; r <= p.hi; ++r) {
+        if (p.state[r] == ABSENT) continue;
+        if (p.more[r] > 1) {
+            float c;
+            if (p.state[r] == 0) c = 0.5f;
+            else if (p.more[r] + p.less[r] > 0) c = float(p.more[r]) / (p.more[r] + p.less[r]);
+            else c = 1;
+            conf *= c; n++;
+        }
+    }
+    if (conf == 1) conf = 0.99;
+    const double x = 1 / (1 - std::exp(std::log(conf) / n));
+    return (float)(x * x * p.n_occ);
+}
+
+struct PartPartDistance { int n00 = 0, n01 = 0, n10 = 0, n11 = 0; short phased = 1; bool augmented = true; };
+
+// distance(Partition&, Partition&, 2): call_variants.cpp:977-1127
+static PartPartDistance partition_vs_partition(const DensePartition& a, const DensePartition& b, int threshold_p) {
+    int comparable = 0;
+    int scores[2] = {0, 0};
+    short ndiv[2] = {0, 0}, nunsure[2] = {0, 0};
+    int m00[2] = {0, 0}, m01[2] = {0, 0}, m10[2] = {0, 0}, m11[2] = {0, 0};
+    const int lo = std::max(a.lo, b.lo), hi = std::min(a.hi, b.hi);
+    for (int r = lo; r <= hi; ++r) {
+        if (a.state[r] == ABSENT || b.state[r] == ABSENT) continue;
+        if (!(a.more[r] > 1 && b.more[r] > 1)) continue;
+        comparable++;
+        const float t1 = (float)(0.5 * (a.more[r] + a.less[r]) + 3 * std::sqrt((a.more[r] + a.less[r]) * 0.5 * (1 - 0.5)));
+        const float t2 = (float)(0.5 * (b.more[r] + b.less[r]) + 3 * std::sqrt((b.more[r] + b.less[r]) * 0.5 * (1 - 0.5)));
+        const bool both = (float)a.more[r] > t1 && (float)b.more[r] > t2;
+        const bool either = (float)a.more[r] > t1 || (float)b.more[r] > t2;
+        const int s1 = a.state[r], s2 = b.state[r];
+        if (s2 == 1) {
+            if (s1 == 1) { scores[0]++; scores[1]--; m11[0]++; m10[1]++; if (both) ndiv[1]++; if (either) nunsure[1]++; }
+            else if (s1 == -1) { scores[0]--; scores[1]++; m01[0]++; m00[1]++; if (both) ndiv[0]++; if (either) nunsure[0]++; }
+        } else if (s2 == -1) {
+            if (s1 == 1) { scores[0]--; scores[1]++; m10[0]++; m11[1]++; if (both) ndiv[0]++; if (either) nunsure[0]++; }
+            else if (s1 == -1) { scores[0]++; scores[1]--; m00[0]++; m01[1]++; if (both) ndiv[1]++; if (either) nunsure[1]++; }
+        }
+    }
+    PartPartDistance d;
+    if ((ndiv[0] >= threshold_p && ndiv[1] >= threshold_p) || (nunsure[0] >= 5 && nunsure[1] >= 5) || comparable == 0) d.augmented = false;
+    const int k = scores[1] > scores[0] ? 1 : 0;
+    d.n00 = m00[k]; d.n01 = m01[k]; d.n10 = m10[k]; d.n11 = m11[k];
+    d.phased = (short)(-2 * k + 1);
+    return d;
+}
+
+// Partition::mergePartition(p, phased): Partition.cpp:401-537, element-wise
+static void merge_partitions(DensePartition& a, const DensePartition& b, short phased) {
+    a.left = std::min(a.left, b.left);
+    a.right = std::max(a.right, b.right);
+    for (int r = b.lo; r <= b.hi; ++r) {
+        const int8_t ob = b.state[r];
+        if (ob == ABSENT) continue;
+        int8_t& sa = a.state[r];
+        if (sa == ABSENT || sa == 0) { sa = (int8_t)(ob * phased); a.more[r] = b.more[r]; a.less[r] = b.less[r]; }
+        else if (ob == 0) { /* keep a */ }
+        else if (phased * ob == sa) {
+            int which = 0;
+            const double c1 = double(a.more[r]) / (a.more[r] + a.less[r]);
+            const double c2 = double(b.more[r]) / (b.more[r] + b.less[r]);
+            if (c1 < 0.9 && c2 > 0.9 && b.more[r] >= 10) which = 1;
+            else if (c2 < 0.9 && c1 > 0.9 && a.more[r] >= 10) which = 2;
+            int nm = 0, nl = 0;
+            if (which != 1) { nm += a.more[r]; nl += a.less[r]; }
+            if (which != 2) { nm += b.more[r]; nl += b.less[r]; }
+            a.more[r] = nm; a.less[r] = nl;
+        } else {   // phased * ob == -sa
+            int which = 0;
+            const double c1 = double(a.more[r]) / (a.more[r] + a.less[r]);
+            const double c2 = double(b.more[r]) / (b.more[r] + b.less[r]);
+            if (c1 < 0.8 && c2 > 0.8 && b.more[r] >= 10) which = 1;
+            else if (c2 < 0.8 && c1 > 0.8 && a.more[r] >= 10) which = 2;
+            int nm = 0, nl = 0;
+            if (which != 1) { nm += a.more[r]; nl += a.less[r]; }
+            if (which != 2) { nm += b.less[r]; nl += b.more[r]; }
+            if (nl > nm) { sa = (int8_t)-sa; std::swap(nm, nl); }
+            a.more[r] = nm; a.less[r] = nl;
+        }
+    }
+    if (b.hi >= b.lo) { if (a.hi < a.lo) { a.lo = b.lo; a.hi = b.hi; } else { a.lo = std::min(a.lo, b.lo); a.hi = std::max(a.hi, b.hi); } }
+    a.n_occ += b.n_occ;
+}
+
+static inline bool central_base_test(int k0, int k1) {
+    // call_variants.cpp:527-528 and :751-752 (same predicate on raw code bytes)
+    return k0 % 5 != k1 % 5 && ((k1 - '!') % 5 != 4 || (k1 / 5 % 5 != k0 % 5 && k1 / 25 % 5 != k0 % 5));
+}
+
+void call_variants_host(int n_reads, int64_t contig_len, ColumnSet& cs, float mean_distance,
+                        float automatic_snp_threshold, ContigCvResult& out) {
+    (void)contig_len;
+    const int n_cols = (int)cs.pos.size();
+    const int min_reads = mean_distance < 0.015 ? 3 : 5;                       // :463-466
+    auto col_idx = [&](int i) { return cs.idx + cs.off[i]; };
+    auto col_code = [&](int i) { return cs.code + cs.off[i]; };
+    auto col_n = [&](int i) { return (int)(cs.off[i + 1] - cs.off[i]); };
+
+    // ---- V1: candidates + automatic SNPs with the greedy spacing (:525-536) ----
+    std::vector<int> cand, automatic;
+    int pos_of_last = -5;
+    for (int i = 0; i < n_cols; ++i) {
+        const int k0 = cs.k0[i], k1 = cs.k1[i];
+        if (cs.c1[i] > min_reads && cs.c1[i] > cs.c2[i] * 5 && central_base_test(k0, k1) && cs.pos[i] - pos_of_last > 5) {
+            if ((float)cs.c1[i] > automatic_snp_threshold * (float)cs.c0[i]) automatic.push_back(i);
+            pos_of_last = cs.pos[i];
+            cand.push_back(i);
+        }
+    }
+    out.n_candidates = (int)cand.size();
+    out.n_automatic = (int)automatic.size();
+
+    // ---- loop A (:590-638) ----
+    std::vector<DensePartition> parts;
+    int last_position = -5;
+    for (int ci : cand) {
+        const int pos = cs.pos[ci];
+        if (pos - last_position <= 5) continue;
+        const int32_t* idx = col_idx(ci); const uint8_t* code = col_code(ci); const int n = col_n(ci);
+        bool found = false;
+        int n_corr = 0;
+        for (size_t p = 0; p < parts.size(); ++p) {
+            if (std::abs(pos - parts[p].right) > 50000) continue;
+            const Contingency d = column_vs_partition(parts[p], idx, code, n, cs.k0[ci]);
+            const int comparable = d.n00 + d.n11 + d.n01 + d.n10;
+            if (d.n00 + d.n01 > 0.1 * comparable && d.n00 + d.n01 < 0.9 * comparable && d.n01 + d.n11 > 0.1 * comparable
+                && d.n01 + d.n11 < 0.9 * comparable && chi_square(d) > 15) {
+                n_corr += 1; parts[p].n_corr += 1;
+            }
+            const bool enough = (size_t)comparable >= (size_t)n / 2;
+            if ((d.n01 <= std::max(0.1 * (d.n00 + d.n01), 1.0) && d.n10 < std::max(0.1 * (d.n11 + d.n10), 1.0) && enough)
+                || (d.n00 <= std::max(0.1 * (d.n00 + d.n01), 1.0) && d.n11 < std::max(0.1 * (d.n11 + d.n10), 1.0) && enough)) {
+                found = true;
+                augment(parts[p], idx, code, n, d, pos);
+                break;
+            }
+        }
+        if (!found) {
+            parts.emplace_back();
+            partition_from_column(parts.back(), n_reads, idx, code, n, pos, cs.k0[ci]);
+            parts.back().n_corr = n_corr;
+        } else last_position = pos;
+    }
+    out.n_partitions = (int)parts.size();
+
+    std::vector<int> filtered;   // column indices, ascending
+    if (!parts.empty()) {
+        // ---- loop B (:646-708) ----
+        std::vector<DensePartition> finals;
+        for (size_t p1 = 0; p1 < parts.size(); ++p1) {
+            const double p_value = significance(parts[p1], (int)cand.size());
+            if (!((p_value < 0.001 || parts[p1].n_corr > 1) && is_informative(parts[p1], mean_distance))) continue;
+            bool different = true;
+            for (size_t p2 = 0; p2 < finals.size(); ++p2) {
+                const PartPartDistance d = partition_vs_partition(finals[p2], parts[p1], 2);
+                if (d.augmented && (d.n00 + d.n11 > 5 * (d.n01 + d.n10) || d.n10 + d.n01 > 5 * (d.n00 + d.n11))
+                    && d.n10 < std::max(2, 2 * d.n01) && d.n01 < std::max(2, 2 * d.n10)) {
+                    bool do_merge = d.n01 + d.n10 < 0.1 * (d.n00 + d.n11);
+                    if (!do_merge) {
+                        DensePartition merged = finals[p2];
+                        merge_partitions(merged, parts[p1], d.phased);
+                        do_merge = confidence_score(merged) > confidence_score(finals[p2]);
+                    }
+                    if (do_merge) { merge_partitions(finals[p2], parts[p1], d.phased); different = false; break; }
+                }
+            }
+            if (different) finals.push_back(parts[p1]);
+        }
+        out.n_final_partitions = (int)finals.size();
+
+        // ---- loop C (:721-738) ----
+        std::vector<char> kept(n_cols, 0);
+        for (int ci : cand) {
+            const int32_t* idx = col_idx(ci); const uint8_t* code = col_code(ci); const int n = col_n(ci);
+            for (size_t p = 0; p < finals.size(); ++p) {
+                const Contingency d = column_vs_partition(finals[p], idx, code, n, cs.k0[ci]);
+                const float chi = chi_square(d);
+                if (d.n00 + d.n01 + d.n10 + d.n11 > 0.5 * n && chi > 15) { kept[ci] = 1; break; }
+            }
+        }
+        // ---- loop D (:745-764), restricted to the columns that can pass n10+n00 > 4 ----
+        for (int i = 0; i < n_cols; ++i) {
+            if (kept[i]) { filtered.push_back(i); continue; }
+            if (cs.c1[i] < 5) continue;
+            if (!central_base_test(cs.k0[i], cs.k1[i])) continue;
+            const int32_t* idx = col_idx(i); const uint8_t* code = col_code(i); const int n = col_n(i);
+            for (size_t p = 0; p < finals.size(); ++p) {
+                const Contingency d = column_vs_partition(finals[p], idx, code, n, cs.k0[i]);
+                if (chi_square(d) > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) { filtered.push_back(i); break; }
+            }
+        }
+    }
+    out.n_filtered = (int)filtered.size();
+
+    // ---- two-pointer union that stops when either list ends (:1335-1352) ----
+    size_t ia = 0, ifi = 0;
+    out.snp_col.clear();
+    while (ia < automatic.size() && ifi < filtered.size()) {
+        const int pa = cs.pos[automatic[ia]], pf = cs.pos[filtered[ifi]];
+        if (pa < pf) { out.snp_col.push_back(automatic[ia]); ia++; }
+        else if (pa > pf) { out.snp_col.push_back(filtered[ifi]); ifi++; }
+        else { out.snp_col.push_back(automatic[ia]); ia++; ifi++; }
+    }
+}
+
+}  // namespace hs

@@ -1,0 +1,35 @@
+// hs_host_sr.h -- per-contig state of stage 4 (HS_separate_reads) between the device waves.
+#pragma once
+#include <cstdint>
+#include <vector>
+#include "hs_host.h"
+
+namespace hs {
+
+struct SrWindowPlanEx;
+
+struct SrContigState {
+    const hs_sr_contig* c = nullptr;
+    int N = 0;
+    int words = 0;
+    bool low_memory_now = false;
+    std::vector<uint64_t> alt_planes, ref_planes;   // [N][words] bit-planes (second_base / ref_base per SNP)
+    std::vector<int32_t> sim, diff;                 // [N][N] device results (empty on the low-memory path)
+    std::vector<SrGraph> graphs;
+    int empty_graph = -1;
+    std::vector<struct SrWindowPlan> windows;
+    std::vector<int32_t> perm;                      // std::shuffle(mt19937(seed)) of 0..N-1
+};
+
+std::vector<int32_t> shuffled_order(int n, uint32_t seed);
+void sr_build_planes(SrContigState& st);
+void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool low_memory);
+void sr_local_init_labels(const SrContigState& st, const SrWindowPlan& w, int snp, int32_t* out);
+void sr_merged_init_labels(const SrContigState& st, const SrWindowPlan& w, const int32_t* local, int n_local, int32_t* out);
+void sr_reclustered_init_labels(const SrContigState& st, const SrWindowPlan& w, const int32_t* merged, int32_t* out);
+void sr_finish_window(const SrContigState& st, SrWindowPlan& w, const int32_t* reclustered, bool low_memory);
+bool sr_ploidy_init_labels(const SrContigState& st, const SrWindowPlan& w, int max_haplotypes, int32_t* out);
+int32_t sr_window_size(const hs_sr_contig* cs, int n, bool amplicon);
+bool sr_coverage_above_1000(const hs_sr_contig& c);
+
+}  // namespace hs

@@ -1,0 +1,525 @@
+// hs_kernels.hip -- hand-written CDNA4 (gfx950, wave64) kernels of the HairSplitter hot path.
+// Integer / bitwise work bounded by HBM: no MFMA. One wavefront owns one unit of sequential work
+// (an alignment record, a Chinese-Whispers instance, a sequence pair); lanes cover the data-parallel axis.
+// Reference semantics are cited per kernel (paths relative to /root/reference/src).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hs_device.h"
+
+namespace hsdev {
+
+static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// wave-wide max over a 64-bit key (6 butterfly steps through ds_bpermute)
+static __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned long long o = __shfl_xor(v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+static __device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 pileup: generate_msa, call_variants.cpp:189-354 (CIGAR walk), tools.cpp:27-57 (RLE expansion avoided).
+// One wavefront per alignment record. The CIGAR is consumed 64 ops at a time: a wave-level inclusive scan
+// gives every op its first event / read offset / reference offset; the events of those 64 ops are then
+// processed 64 per step (lane = event), the owning op found by a 6-step binary search across lanes.
+// The 3-mer context (previous two emitted characters, insertions and deletions included) comes from the two
+// lanes to the left, or from a wave-uniform carry for lanes 0/1. Writes to the read-major pileup are
+// contiguous per run of M/D events (coalesced).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pileup(
+    const uint8_t* __restrict__ contig_seq, const int64_t* __restrict__ contig_off,
+    const uint8_t* __restrict__ read_seq, const int64_t* __restrict__ read_off,
+    const int32_t* __restrict__ rec_read, const int32_t* __restrict__ rec_contig,
+    const int32_t* __restrict__ rec_pos, const uint8_t* __restrict__ rec_strand,
+    const int64_t* __restrict__ rec_cig_off, const uint32_t* __restrict__ cigar,
+    const int64_t* __restrict__ pile_off, int n_rec, uint8_t* __restrict__ pile,
+    int32_t* __restrict__ rec_stats) {
+    const int lane = lane_id();
+    const int r = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (r >= n_rec) return;   // wave-uniform
+
+    const int ctg = rec_contig[r];
+    const int64_t coff = contig_off[ctg];
+    const int L = (int)(contig_off[ctg + 1] - coff);
+    const int rd = rec_read[r];
+    const int64_t roff = read_off[rd];
+    const int rlen = (int)(read_off[rd + 1] - roff);
+    const int pos = rec_pos[r];
+    const bool fwd = rec_strand[r] != 0;
+    const int64_t cig0 = rec_cig_off[r], cig1 = rec_cig_off[r + 1];
+    uint8_t* __restrict__ out = pile + pile_off[r];
+    const uint8_t* __restrict__ ctgp = contig_seq + coff;
+    const uint8_t* __restrict__ rdp = read_seq + roff;
+
+    int p1 = 2, p2 = 1;   // previous char 'G', the one before 'C' (call_variants.cpp:212-214 after one shift)
+    int q_cur = pos, t_cur = 0;
+    int nerr = 0, nlen = 0;
+
+    for (int64_t ob = cig0; ob < cig1; ob += 64) {
+        const int64_t oi = ob + lane;
+        uint32_t op = oi < cig1 ? cigar[oi] : 0xFu;
+        int len = (int)(op >> 4), code = (int)(op & 15u);
+        if (oi >= cig1) { len = 0; code = 15; }
+        const bool isM = code == 0 || code == 7 || code == 8;
+        const bool isI = code == 1, isD = code == 2, isClip = code == 4 || code == 5;
+        const int ev = (isM || isI || isD) ? len : 0;
+        const int rdv = (isM || isI || isClip) ? len : 0;
+        const int rfv = (isM || isD) ? len : 0;
+        int ev_inc = ev, rd_inc = rdv, rf_inc = rfv;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int a = __shfl_up(ev_inc, d, 64), b = __shfl_up(rd_inc, d, 64), c = __shfl_up(rf_inc, d, 64);
+            if (lane >= d) { ev_inc += a; rd_inc += b; rf_inc += c; }
+        }
+        const int ev_ex = ev_inc - ev;
+        const int t0 = t_cur + rd_inc - rdv;
+        const int q0 = q_cur + rf_inc - rfv;
+        const int chunk_ev = __shfl(ev_inc, 63, 64);
+
+        for (int eb = 0; eb < chunk_ev; eb += 64) {
+            const int e = eb + lane;
+            const bool valid = e < chunk_ev;
+            int lo = 0, hi = 63;
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                int mid = (lo + hi) >> 1;
+                int v = __shfl(ev_inc, mid, 64);
+                if (v > e) hi = mid; else lo = mid + 1;
+            }
+            const int j = lo > 63 ? 63 : lo;
+            const int jev_ex = __shfl(ev_ex, j, 64);
+            const int jt0 = __shfl(t0, j, 64);
+            const int jq0 = __shfl(q0, j, 64);
+            const int jcode = __shfl(code, j, 64);
+            const int off = e - jev_ex;
+            const bool jM = jcode == 0 || jcode == 7 || jcode == 8;
+            const bool jD = jcode == 2, jI = jcode == 1;
+            const int t = jt0 + off;
+            const int q = jq0 + ((jM || jD) ? off : 0);
+            const bool active = valid && q >= 0 && q < L;   // call_variants.cpp:217
+            int c = 4;   // '-'
+            if (!jD) {
+                int tt = t < 0 ? 0 : (t >= rlen ? rlen - 1 : t);   // host validates CIGAR vs read length
+                int idx = fwd ? tt : (rlen - 1 - tt);
+                int b = valid && rlen > 0 ? (int)rdp[idx] : 0;
+                c = fwd ? b : 3 - b;
+            }
+            const int cu1 = __shfl_up(c, 1, 64), cu2 = __shfl_up(c, 2, 64);
+            const int pr1 = lane >= 1 ? cu1 : p1;
+            const int pr2 = lane >= 2 ? cu2 : (lane == 1 ? p1 : p2);
+            if (active) {
+                nlen++;
+                if (jM) {
+                    out[q - pos] = (uint8_t)(33 + 5 * pr2 + pr1 + 25 * c);    // call_variants.cpp:238-240
+                    if (c != (int)ctgp[q]) nerr++;                            // :254-256
+                } else if (jD) {
+                    out[q - pos] = (uint8_t)(33 + 5 * pr2 + pr1 + 25 * 4);    // :287-290
+                    nerr++;
+                } else {
+                    nerr++;                                                   // insertion :337
+                }
+            }
+            const int nv = (chunk_ev - eb) < 64 ? (chunk_ev - eb) : 64;
+            const int last = __shfl(c, nv - 1, 64);
+            const int last2 = nv >= 2 ? __shfl(c, nv - 2, 64) : p1;
+            p2 = last2; p1 = last;
+        }
+        t_cur += __shfl(rd_inc, 63, 64);
+        q_cur += __shfl(rf_inc, 63, 64);
+    }
+    nerr = wave_sum_i32(nerr);
+    nlen = wave_sum_i32(nlen);
+    if (lane == 0) {
+        int qend = pos >= L ? pos : (q_cur < L ? q_cur : L);
+        rec_stats[4 * r + 0] = qend;
+        rec_stats[4 * r + 1] = nerr;
+        rec_stats[4 * r + 2] = nlen;
+        rec_stats[4 * r + 3] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 column statistics: the histogram of call_variants.cpp:477-501 for 256 consecutive positions per
+// workgroup. Every lane owns one position and a private 125-bin u16 histogram column in LDS
+// (hist[bin][lane]: lanes hitting the same bin are conflict-free); the records of the contig are walked in
+// read-index order with wave-uniform (scalar) metadata loads, the pileup bytes are read coalesced.
+// Output: five largest (count desc, code asc) + depth, 16 B per position, one dwordx4 store per lane.
+// ------------------------------------------------------------------------------------------------
+#define HS_NBINS 125
+__global__ __launch_bounds__(256) void k_column_stats(
+    const uint8_t* __restrict__ pile, const int64_t* __restrict__ pile_off,
+    const int32_t* __restrict__ rec_pos, const int32_t* __restrict__ rec_qend,
+    const int32_t* __restrict__ contig_rec_off, const int64_t* __restrict__ contig_off,
+    int n_contigs, hs_colstat_dev* __restrict__ stats) {
+    __shared__ uint16_t hist[HS_NBINS * 256];
+    const int tid = (int)threadIdx.x;
+    const int64_t total = contig_off[n_contigs];
+    const int64_t g0 = (int64_t)blockIdx.x * 256;
+    const int64_t g = g0 + tid;
+    for (int b = 0; b < HS_NBINS; ++b) hist[b * 256 + tid] = 0;
+    // contigs intersecting this tile (block-uniform binary search)
+    int c_first;
+    {
+        int lo = 0, hi = n_contigs - 1;
+        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (contig_off[mid] <= g0) lo = mid; else hi = mid - 1; }
+        c_first = lo;
+    }
+    const int64_t g_last = (g0 + 255 < total - 1) ? g0 + 255 : total - 1;
+    int my_c = -1, my_p = 0;
+    for (int c = c_first; c < n_contigs && contig_off[c] <= g_last; ++c) {
+        const int64_t cs = contig_off[c], ce = contig_off[c + 1];
+        if (ce <= g0) continue;
+        const bool mine = g >= cs && g < ce;
+        const int p = (int)(g - cs);
+        if (mine) { my_c = c; my_p = p; }
+        const int tile_lo = (int)((g0 > cs ? g0 : cs) - cs);
+        const int tile_hi = (int)(((g_last + 1) < ce ? (g_last + 1) : ce) - cs);   // exclusive
+        const int r0 = contig_rec_off[c], r1 = contig_rec_off[c + 1];
+        for (int n = r0; n < r1; ++n) {
+            const int ps = rec_pos[n], qe = rec_qend[n];      // uniform -> scalar loads
+            if (qe <= tile_lo || ps >= tile_hi) continue;
+            if (mine && p >= ps && p < qe) {
+                int code = (int)pile[pile_off[n] + (p - ps)] - 33;
+                if (code >= 0 && code < HS_NBINS) hist[code * 256 + tid] += 1;
+            }
+        }
+    }
+    if (g >= total) return;
+    (void)my_c; (void)my_p;
+    int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+    int depth = 0;
+    for (int b = 0; b < HS_NBINS; ++b) {
+        const int v = (int)hist[b * 256 + tid];
+        depth += v;
+        if (v > c4) {
+            const int key = b + 33;
+            if (v > c0) { c4 = c3; c3 = c2; k3 = k2; c2 = c1; k2 = k1; c1 = c0; k1 = k0; c0 = v; k0 = key; }
+            else if (v > c1) { c4 = c3; c3 = c2; k3 = k2; c2 = c1; k2 = k1; c1 = v; k1 = key; }
+            else if (v > c2) { c4 = c3; c3 = c2; k3 = k2; c2 = v; k2 = key; }
+            else if (v > c3) { c4 = c3; c3 = v; k3 = key; }
+            else c4 = v;
+        }
+    }
+    uint4 o;
+    o.x = (uint32_t)k0 | ((uint32_t)k1 << 8) | ((uint32_t)k2 << 16) | ((uint32_t)k3 << 24);
+    o.y = (uint32_t)c0 | ((uint32_t)c1 << 16);
+    o.z = (uint32_t)c2 | ((uint32_t)c3 << 16);
+    o.w = (uint32_t)c4 | ((uint32_t)(depth > 65535 ? 65535 : depth) << 16);
+    reinterpret_cast<uint4*>(stats)[g] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 column extraction: builds the reference's Column (Partition.h:8-14) for selected positions.
+// One wavefront per selected position; 64 records per step, ballot + prefix popcount give every covering
+// record its slot, so read indices come out ascending and the writes of a step are contiguous.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_columns(
+    const uint8_t* __restrict__ pile, const int64_t* __restrict__ pile_off,
+    const int32_t* __restrict__ rec_pos, const int32_t* __restrict__ rec_qend,
+    const int32_t* __restrict__ contig_rec_off, const int32_t* __restrict__ sel_contig,
+    const int32_t* __restrict__ sel_pos, const int64_t* __restrict__ col_off, int n_sel,
+    int32_t* __restrict__ col_idx, uint8_t* __restrict__ col_code) {
+    const int lane = lane_id();
+    const int s = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (s >= n_sel) return;
+    const int c = sel_contig[s], p = sel_pos[s];
+    const int r0 = contig_rec_off[c], r1 = contig_rec_off[c + 1];
+    int64_t w = col_off[s];
+    for (int nb = r0; nb < r1; nb += 64) {
+        const int n = nb + lane;
+        bool cov = false;
+        int ps = 0;
+        if (n < r1) { ps = rec_pos[n]; cov = p >= ps && p < rec_qend[n]; }
+        const unsigned long long m = __ballot(cov);
+        if (cov) {
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            col_idx[w + rank] = n - r0;
+            col_code[w + rank] = pile[pile_off[n] + (p - ps)];
+        }
+        w += __popcll(m);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 sim/diff: separate_reads.cpp:374-433 as bit-plane popcounts. 64x64 read-pair tile per workgroup,
+// 4x4 pairs per thread, planes staged through LDS 16 words at a time (padded rows: conflict-free b64 reads).
+// ------------------------------------------------------------------------------------------------
+#define SD_KW 16
+__global__ __launch_bounds__(256) void k_simdiff(
+    const uint64_t* __restrict__ alt, const uint64_t* __restrict__ ref, const int64_t* __restrict__ plane_off,
+    const int32_t* __restrict__ n_reads, const int32_t* __restrict__ words, const int64_t* __restrict__ out_off,
+    const int32_t* __restrict__ tile_contig, const int32_t* __restrict__ tile_i, const int32_t* __restrict__ tile_j,
+    int32_t* __restrict__ sim, int32_t* __restrict__ diff) {
+    __shared__ uint64_t sAi[64][SD_KW + 1], sRi[64][SD_KW + 1], sAj[64][SD_KW + 1], sRj[64][SD_KW + 1];
+    const int tid = (int)threadIdx.x;
+    const int c = tile_contig[blockIdx.x];
+    const int i0 = tile_i[blockIdx.x] * 64, j0 = tile_j[blockIdx.x] * 64;
+    const int N = n_reads[c], W = words[c];
+    const uint64_t* __restrict__ A = alt + plane_off[c];
+    const uint64_t* __restrict__ R = ref + plane_off[c];
+    const int ti = tid >> 4, tj = tid & 15;
+    int s_acc[4][4], d_acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { s_acc[a][b] = 0; d_acc[a][b] = 0; }
+
+    for (int w0 = 0; w0 < W; w0 += SD_KW) {
+        // stage 64 rows x SD_KW words of both planes for both sides (coalesced along words)
+        for (int x = tid; x < 64 * SD_KW; x += 256) {
+            const int row = x / SD_KW, w = x % SD_KW;
+            const int gi = i0 + row, gj = j0 + row, gw = w0 + w;
+            const bool wi = gi < N && gw < W, wj = gj < N && gw < W;
+            sAi[row][w] = wi ? A[(int64_t)gi * W + gw] : 0ull;
+            sRi[row][w] = wi ? R[(int64_t)gi * W + gw] : 0ull;
+            sAj[row][w] = wj ? A[(int64_t)gj * W + gw] : 0ull;
+            sRj[row][w] = wj ? R[(int64_t)gj * W + gw] : 0ull;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int w = 0; w < SD_KW; ++w) {
+            uint64_t ai[4], ri[4], aj[4], rj[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { ai[a] = sAi[ti + 16 * a][w]; ri[a] = sRi[ti + 16 * a][w]; }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { aj[b] = sAj[tj + 16 * b][w]; rj[b] = sRj[tj + 16 * b][w]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    s_acc[a][b] += 3 * __popcll(ai[a] & aj[b]) + __popcll(ri[a] & rj[b]);
+                    d_acc[a][b] += __popcll(ai[a] & rj[b]) + __popcll(ri[a] & aj[b]);
+                }
+        }
+        __syncthreads();
+    }
+    int32_t* __restrict__ S = sim + out_off[c];
+    int32_t* __restrict__ D = diff + out_off[c];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int gi = i0 + ti + 16 * a, gj = j0 + tj + 16 * b;
+            if (gi < N && gj < N) {
+                const bool dg = gi == gj;
+                S[(int64_t)gi * N + gj] = dg ? 0 : s_acc[a][b];
+                D[(int64_t)gi * N + gj] = dg ? 0 : d_acc[a][b];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 Chinese Whispers: cluster_graph.cpp:240-310 (and :152-230). One wavefront (one 64-thread workgroup)
+// per instance; labels and the per-label vote counters live in LDS. Nodes are visited sequentially in the
+// supplied permutation; the neighbours of the current node are spread over the lanes: LDS atomic add of one
+// vote per lane, then every lane reads its label's total and a wave max-reduce on (count, -label) yields the
+// most frequent label with the LOWEST id on ties (:272-279). Masked-out nodes keep voting with their initial
+// label and are set to -2 at the end. Stops after 15 sweeps or when a sweep changes <= 2 nodes (:167).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_chinese_whispers(
+    const int32_t* __restrict__ adj_off, const int32_t* __restrict__ adj,
+    const int64_t* __restrict__ graph_off_base, const int64_t* __restrict__ graph_adj_base,
+    const int32_t* __restrict__ graph_n, const int32_t* __restrict__ perm, const int64_t* __restrict__ perm_base,
+    const uint8_t* __restrict__ mask, const int32_t* __restrict__ inst_graph,
+    const int64_t* __restrict__ inst_label_base, int n_inst, int32_t* __restrict__ labels_io,
+    int32_t* __restrict__ sweeps_out) {
+    extern __shared__ int32_t cw_lds[];
+    const int lane = lane_id();
+    const int inst = (int)blockIdx.x;
+    if (inst >= n_inst) return;
+    const int g = inst_graph[inst];
+    const int N = graph_n[g];
+    const int32_t* __restrict__ aoff = adj_off + graph_off_base[g];     // N+1 entries, relative to the graph's adj slice
+    const int32_t* __restrict__ anb = adj + graph_adj_base[g];
+    const int32_t* __restrict__ prm = perm + perm_base[g];
+    const uint8_t* __restrict__ msk = mask + graph_off_base[g] - g;      // mask is N per graph: base = off_base - g
+    int32_t* __restrict__ lab_g = labels_io + inst_label_base[inst];
+    int32_t* lab = cw_lds;          // [N]
+    int32_t* cnt = cw_lds + N;      // [N]
+    for (int i = lane; i < N; i += 64) { lab[i] = lab_g[i]; cnt[i] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    int changes = 3, iters = 0;
+    while (changes > 2 && iters < 15) {
+        changes = 0;
+        for (int k0 = 0; k0 < N; k0 += 64) {
+            const int kk = k0 + lane;
+            int i_l = -1, o0_l = 0, o1_l = 0;
+            if (kk < N) {
+                i_l = prm[kk];
+                if (msk[i_l]) { o0_l = aoff[i_l]; o1_l = aoff[i_l + 1]; }
+            }
+            unsigned long long act = __ballot(o1_l > o0_l);
+            while (act) {
+                const int l = __builtin_ctzll(act);
+                act &= act - 1ull;
+                const int i = __shfl(i_l, l, 64);
+                const int o0 = __shfl(o0_l, l, 64), o1 = __shfl(o1_l, l, 64);
+                unsigned long long best = 0ull;
+                // pass 1: votes
+                for (int o = o0; o < o1; o += 64) {
+                    const int idx = o + lane;
+                    if (idx < o1) {
+                        const int lb = lab[anb[idx]];
+                        if (lb >= 0) atomicAdd(&cnt[lb], 1);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                // pass 2: read totals
+                for (int o = o0; o < o1; o += 64) {
+                    const int idx = o + lane;
+                    if (idx < o1) {
+                        const int lb = lab[anb[idx]];
+                        if (lb >= 0) {
+                            const unsigned long long key = ((unsigned long long)(unsigned)cnt[lb] << 32) | (unsigned)(0x7fffffff - lb);
+                            best = key > best ? key : best;
+                        }
+                    }
+                }
+                best = wave_max_u64(best);
+                // pass 3: reset the touched counters
+                for (int o = o0; o < o1; o += 64) {
+                    const int idx = o + lane;
+                    if (idx < o1) {
+                        const int lb = lab[anb[idx]];
+                        if (lb >= 0) cnt[lb] = 0;
+                    }
+                }
+                const int bcnt = (int)(best >> 32);
+                if (bcnt > 0) {
+                    const int blab = 0x7fffffff - (int)(best & 0xffffffffull);
+                    if (lab[i] != blab) changes++;
+                    if (lane == 0) lab[i] = blab;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        iters++;
+    }
+    for (int i = lane; i < N; i += 64) lab_g[i] = msk[i] ? lab[i] : -2;
+    if (sweeps_out && lane == 0) sweeps_out[inst] = iters;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A1 Myers bit-vector edit distance (Myers 1999 / Hyyro block formulation; oracle = the reference's bundled
+// edlib, edlib.h:242-246). One wavefront per (query,target) pair. Lane b owns query block b (64 rows: Peq for
+// the 4 symbols, Pv, Mv in registers); the wave sweeps anti-diagonals so that at step s lane b is at target
+// column s-b and receives the horizontal carry of the block above through a lane shift. Queries longer than
+// 4096 rows run in passes of 64 blocks; the bottom carries of a pass are kept in a scratch row (one byte per
+// column). The target is staged through LDS in 2 KiB pieces (all lanes read consecutive bytes).
+// mode 0 NW, 1 SHW, 2 HW.
+// ------------------------------------------------------------------------------------------------
+#define MY_TCHUNK 2048
+__global__ __launch_bounds__(64) void k_myers(
+    const uint8_t* __restrict__ query, const int64_t* __restrict__ query_off,
+    const uint8_t* __restrict__ target, const int64_t* __restrict__ target_off, int n_pairs, int mode,
+    int8_t* __restrict__ hscratch, const int64_t* __restrict__ hscratch_off,
+    int32_t* __restrict__ dist, int32_t* __restrict__ endloc) {
+    __shared__ uint8_t tbuf[MY_TCHUNK + 64];
+    const int lane = lane_id();
+    const int pr = (int)blockIdx.x;
+    if (pr >= n_pairs) return;
+    const uint8_t* __restrict__ q = query + query_off[pr];
+    const int qn = (int)(query_off[pr + 1] - query_off[pr]);
+    const uint8_t* __restrict__ t = target + target_off[pr];
+    const int tn = (int)(target_off[pr + 1] - target_off[pr]);
+    int8_t* __restrict__ hb = hscratch + hscratch_off[pr];
+    if (qn == 0) {   // degenerate: distance is tn for NW, 0 otherwise
+        if (lane == 0) { dist[pr] = mode == 0 ? tn : 0; endloc[pr] = mode == 0 ? tn - 1 : -1; }
+        return;
+    }
+    const int nblocks = (qn + 63) >> 6;
+    const int last_row = (qn - 1) & 63;
+    int score = qn, best = qn, best_j = -1;   // D[qn][0] = qn; column -1 == "before the target"
+    if (mode != 0) { best = qn; best_j = -1; }
+    for (int pb = 0; pb < nblocks; pb += 64) {
+        const int blk = pb + lane;
+        const bool bvalid = blk < nblocks;
+        const bool is_last_blk = blk == nblocks - 1;
+        const int nb_pass = (nblocks - pb) < 64 ? (nblocks - pb) : 64;
+        uint64_t peq[4] = {0, 0, 0, 0};
+        if (bvalid) {
+            const int rbase = blk << 6;
+            for (int k = 0; k < 64; ++k) {
+                const int row = rbase + k;
+                if (row < qn) peq[q[row] & 3] |= 1ull << k;
+            }
+        }
+        uint64_t Pv = ~0ull, Mv = 0ull;
+        int hout_prev = 0;
+        const int nsteps = tn + nb_pass - 1;
+        for (int s0 = 0; s0 < nsteps; s0 += MY_TCHUNK) {
+            // stage target bytes [s0-63, s0+MY_TCHUNK) so that column s-b is tbuf[(s - s0) + 63 - b]
+            __builtin_amdgcn_wave_barrier();
+            for (int x = lane; x < MY_TCHUNK + 64; x += 64) {
+                const int col = s0 - 63 + x - 1 + 1;
+                tbuf[x] = (col >= 0 && col < tn) ? t[col] : 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int s_end = (s0 + MY_TCHUNK) < nsteps ? (s0 + MY_TCHUNK) : nsteps;
+            for (int s = s0; s < s_end; ++s) {
+                const int j = s - lane;
+                int hin_up = __shfl_up(hout_prev, 1, 64);
+                const bool work = bvalid && j >= 0 && j < tn;
+                int hin;
+                if (lane == 0) hin = pb == 0 ? (mode == 2 ? 0 : 1) : (work ? (int)hb[j] : 0);
+                else hin = hin_up;
+                if (work) {
+                    const int sym = tbuf[(s - s0) + 63 - lane] & 3;
+                    uint64_t Eq = peq[sym];
+                    const uint64_t Xv = Eq | Mv;
+                    if (hin < 0) Eq |= 1ull;
+                    const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                    uint64_t Ph = Mv | ~(Xh | Pv);
+                    uint64_t Mh = Pv & Xh;
+                    int hout = 0;
+                    if (Ph >> 63) hout = 1; else if (Mh >> 63) hout = -1;
+                    if (is_last_blk) {
+                        score += (int)((Ph >> last_row) & 1ull) - (int)((Mh >> last_row) & 1ull);
+                        if (mode != 0 && score < best) { best = score; best_j = j; }
+                    }
+                    Ph <<= 1; Mh <<= 1;
+                    if (hin < 0) Mh |= 1ull; else if (hin > 0) Ph |= 1ull;
+                    Pv = Mh | ~(Xv | Ph);
+                    Mv = Ph & Xv;
+                    hout_prev = hout;
+                    if (lane == nb_pass - 1 && !is_last_blk) hb[j] = (int8_t)hout;
+                }
+            }
+        }
+        // make the pass's bottom carries visible to lane 0 of the next pass
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the lane that owns the last block holds the answer
+    const int owner = (nblocks - 1) & 63;
+    const int fs = __shfl(score, owner, 64), fb = __shfl(best, owner, 64), fj = __shfl(best_j, owner, 64);
+    if (lane == 0) {
+        if (mode == 0) { dist[pr] = fs; endloc[pr] = tn - 1; }
+        else { dist[pr] = fb; endloc[pr] = fj; }
+    }
+}
+
+// small utility: apply host-resolved "swap top-2" decisions to the column statistics
+__global__ void k_swap_top2(hs_colstat_dev* __restrict__ stats, const int64_t* __restrict__ gpos, int n) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    hs_colstat_dev s = stats[gpos[i]];
+    uint8_t k = s.key[0]; s.key[0] = s.key[1]; s.key[1] = k;
+    stats[gpos[i]] = s;
+}
+
+}  // namespace hsdev

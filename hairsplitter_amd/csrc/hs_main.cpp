@@ -1,0 +1,141 @@
+// hs_main.cpp -- main() of the two drop-in executables, exported through the C ABI so that a host in any
+// language can run a stage file-to-file. Same positional argv, same exit codes, same output formats as
+// call_variants.cpp:1215-1385 and separate_reads.cpp:1398-1790.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "hs_host.h"
+#include "hs_driver.h"
+
+namespace {
+
+bool has_suffix(const std::string& s, const char* suf) {
+    const size_t n = std::strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+int parse_int_arg(const char* a, int& out) {   // std::stoi semantics: garbage -> exception -> abort in the reference
+    char* end = nullptr;
+    long v = std::strtol(a, &end, 10);
+    if (end == a) return -1;
+    out = (int)v;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int hs_call_variants_main(int argc, char** argv) {
+    if (argc < 12) {   // also how `HS_call_variants --version` is answered (hairsplitter.py:229-252 expects exit 0)
+        std::cout << "Usage: ./call_variants <gfa_file> <reads_file> <sam_file> <num_threads> <tmpDir> <error_rate_out> <amplicon> <DEBUG> <file_out> <vcfFile> <automatic_snp_threshold>\n";
+        return 0;
+    }
+    const std::string gfafile = argv[1], reads_file = argv[2], sam_file = argv[3];
+    int num_threads = 1, amplicon_i = 0, debug_i = 0;
+    if (parse_int_arg(argv[4], num_threads) || parse_int_arg(argv[7], amplicon_i) || parse_int_arg(argv[8], debug_i)) {
+        std::cout << "ERROR: could not parse the numeric arguments" << std::endl;
+        return 1;
+    }
+    const std::string error_rate_out = argv[6], file_out = argv[9], vcf_file = argv[10];
+    const float automatic_snp_threshold = std::strtof(argv[11], nullptr);
+    { std::ofstream o(file_out); }   // truncate (call_variants.cpp:1239-1240)
+    if (has_suffix(sam_file, ".paf")) {
+        std::cout << "ERROR: please provide a .sam file as input for the alignments of the reads on the contigs." << std::endl;
+        return EXIT_FAILURE;
+    }
+    if (!has_suffix(sam_file, ".sam")) {
+        std::cout << "ERROR: the file containing the alignments on the assembly should be .sam" << std::endl;
+        return EXIT_FAILURE;
+    }
+    if (hs_device_count() <= 0) {
+        std::cout << "ERROR: no HIP device found; this build of HS_call_variants runs on MI355X only" << std::endl;
+        return EXIT_FAILURE;
+    }
+    std::cout << " - Loading reads, contigs and alignments\n";
+    hs::CvFileInput in;
+    if (int rc = hs::load_cv_inputs(gfafile, reads_file, sam_file, amplicon_i != 0, in)) {
+        std::cout << "ERROR: " << hs_last_error() << std::endl;
+        return rc == HS_EIO ? 1 : EXIT_FAILURE;
+    }
+    std::cout << " - Calling variants on each contig\n";
+    hs_cv_batch* batch = nullptr;
+    const int C = (int)in.contig_names.size();
+    if (int rc = hs_cv_batch_create(in.contig_seq.data(), in.contig_off.data(), C, in.read_seq.data(), in.read_off.data(),
+                                    (int)in.read_names.size(), in.rec_read.data(), in.rec_pos.data(), in.rec_strand.data(),
+                                    in.rec_cig_off.data(), in.cigar.data(), in.contig_rec_off.data(), &batch)) {
+        std::cout << "ERROR: " << hs_last_error() << " (" << rc << ")" << std::endl;
+        return EXIT_FAILURE;
+    }
+    hs_cv_result* res = nullptr;
+    if (int rc = hs_cv_run(batch, automatic_snp_threshold, num_threads, &res)) {
+        std::cout << "ERROR: " << hs_last_error() << " (" << rc << ")" << std::endl;
+        hs_cv_batch_destroy(batch);
+        return EXIT_FAILURE;
+    }
+    hs::write_cv_outputs(in, res, error_rate_out, file_out, vcf_file);
+    hs_cv_result_destroy(res);
+    hs_cv_batch_destroy(batch);
+    return 0;
+}
+
+extern "C" int hs_separate_reads_main(int argc, char** argv) {
+    const char* usage = "Usage: ./separate_reads <columns> <num_threads> <error_rate> <ploidy_of_contigs> <low_memory> <rarest-strain-abundance> <amplicon> <outfile> <DEBUG>";
+    if (argc != 10) {
+        std::cout << usage << std::endl;
+        if (argc == 2 && (argv[1] == std::string("-h") || argv[1] == std::string("--help"))) return 0;
+        return 1;
+    }
+    const std::string columns_file = argv[1], ploidy_file = argv[4], outfile = argv[8];
+    const int num_threads = std::atoi(argv[2]);
+    const float error_rate = (float)std::atof(argv[3]);
+    const bool amplicon = std::atoi(argv[7]) != 0;
+    const bool low_memory = std::atoi(argv[5]) != 0;
+    const float rsa = (float)std::atof(argv[6]);
+    { std::ofstream o(outfile); }
+    if (hs_device_count() <= 0) {
+        std::cout << "ERROR: no HIP device found; this build of HS_separate_reads runs on MI355X only" << std::endl;
+        return 1;
+    }
+    std::vector<hs::ColFileContig> cs;
+    if (int rc = hs::parse_col(columns_file, rsa, cs)) return rc;
+    std::unordered_map<std::string, int> ploidy_of;
+    bool have_ploidy = false;
+    {
+        std::ifstream pf(ploidy_file);
+        if (pf) {
+            have_ploidy = true;
+            std::string line;
+            while (std::getline(pf, line)) { std::istringstream iss(line); std::string ctg; int p; if (!(iss >> ctg >> p)) break; ploidy_of[ctg] = p; }
+        }
+    }
+    std::vector<hs_sr_contig> hc(cs.size());
+    for (size_t i = 0; i < cs.size(); ++i) {
+        hs::ColFileContig& c = cs[i];
+        hs_sr_contig& h = hc[i];
+        h.length = c.length; h.n_reads = (int32_t)c.read_lines.size();
+        h.read_start = c.read_start.data(); h.read_end = c.read_end.data();
+        h.n_snps = (int32_t)c.snp_pos.size();
+        h.snp_pos = c.snp_pos.data(); h.snp_ref = c.snp_ref.data(); h.snp_alt = c.snp_alt.data();
+        h.col_off = c.col_off.data(); h.col_idx = c.col_idx.data(); h.col_code = c.col_code.data();
+        h.ploidy = 0;
+        if (have_ploidy) { auto it = ploidy_of.find(c.name); if (it != ploidy_of.end()) h.ploidy = it->second; }
+        for (int32_t v : c.col_idx) if (v < 0 || v >= h.n_reads) { std::cout << "ERROR: read index out of range in " << columns_file << std::endl; return 1; }
+    }
+    const int32_t w = hs_sr_window_size(hc.data(), (int32_t)hc.size(), amplicon ? 1 : 0);
+    uint32_t seed = 12345u;   // std::random_device of the reference, pinned; override with HS_SEED
+    if (const char* s = std::getenv("HS_SEED")) seed = (uint32_t)std::strtoul(s, nullptr, 10);
+    hs_sr_result* res = nullptr;
+    if (int rc = hs_sr_run(hc.data(), (int32_t)hc.size(), w, error_rate, low_memory ? 1 : 0, seed, num_threads, &res)) {
+        std::cout << "ERROR: " << hs_last_error() << " (" << rc << ")" << std::endl;
+        return 1;
+    }
+    hs::write_gro(cs, res, outfile);
+    hs_sr_result_destroy(res);
+    return 0;
+}

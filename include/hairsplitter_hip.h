@@ -1,0 +1,218 @@
+/*
+ * hairsplitter_hip.h -- C ABI of the MI355X (gfx950) implementation of HairSplitter's hot path
+ * (HS_call_variants -> HS_separate_reads). Plain pointers and sizes only; no C++/torch types.
+ *
+ * The reference has no FFI: its boundary is two executables and five text formats.
+ * The drop-in executables shipped here (hairsplitter_amd/bin/HS_call_variants, HS_separate_reads) are thin
+ * hosts over this library; every entry point below names the reference function (file:line under
+ * /root/reference/src) whose work it replaces, so a maintainer could also call it in-process.
+ *
+ * Conventions
+ *  - Pointers named d_* are DEVICE (HBM) pointers, h_* are host pointers. `stream` is a hipStream_t passed
+ *    as void* (NULL = the default stream). Kernel-level calls are asynchronous on `stream`.
+ *  - Every function returns 0 on success, a negative HS_E* code otherwise; hs_last_error() gives the text.
+ *  - Sequences are 1 byte per base, codes A=0 C=1 G=2 T=3 (non-ACG input bases become T exactly like the
+ *    reference's 2-bit Sequence, sequence.cpp:13-23). Reads are stored as sequenced (FASTA orientation); the
+ *    kernels reverse-complement on the fly for records whose strand is 0 (call_variants.cpp:108-115).
+ *  - CIGARs are BAM-style uint32 (len << 4 | op), op: M=0 I=1 D=2 N=3 S=4 H=5 P=6 '='=7 X=8.
+ *  - "record" = one kept SAM line = one read index n of a contig (call_variants.cpp:85-86). Records are
+ *    grouped by contig, in SAM file order inside a contig.
+ */
+#ifndef HAIRSPLITTER_HIP_H
+#define HAIRSPLITTER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HS_OK 0
+#define HS_ENODEVICE (-1)   /* no HIP device / extension unusable: the product never falls back to a CPU path */
+#define HS_EINVAL (-2)
+#define HS_EHIP (-3)
+#define HS_EIO (-4)
+#define HS_EFORMAT (-5)
+
+/* ------------------------------------------------------------------------------------------------
+ * Library / device
+ * ---------------------------------------------------------------------------------------------- */
+const char* hs_version(void);
+const char* hs_last_error(void);
+int hs_device_count(void);                       /* hipGetDeviceCount; 0 when there is no GPU */
+int hs_set_device(int device);
+int hs_device_synchronize(void);
+/* raw HBM helpers so that hosts without a HIP binding (ctypes, cgo, JNI) can stage buffers */
+int hs_malloc(void** d_ptr, size_t bytes);
+int hs_free(void* d_ptr);
+int hs_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+int hs_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+int hs_memset(void* d_ptr, int value, size_t bytes);
+/* event timing on the stream the kernels run on (bench.py's roofline leg) */
+int hs_event_create(void** ev);
+int hs_event_destroy(void* ev);
+int hs_event_record(void* ev, void* stream);
+int hs_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
+
+/* ------------------------------------------------------------------------------------------------
+ * K1 -- pileup.  Replaces generate_msa (call_variants.cpp:50-437) + convert_cigar (tools.cpp:27-57).
+ * One wavefront per record. For record r with reference start pos[r]:
+ *   d_pile[pile_off[r] + (q - pos[r])] = 33 + 5*i(c-2) + i(c-1) + 25*i(c0)   for every M/=/X/D event at q < L
+ * (i() = index in "ACGT-", previous chars initialised C,G as call_variants.cpp:212-214 leave them).
+ * d_rec_stats[r] = {q_end, n_err, n_len, 0}: final reference cursor (call_variants.cpp:354) and the number
+ * of +1's applied to totalDistance / totalLengthOfAlignment (call_variants.cpp:255-257,305-306,337-338).
+ * ---------------------------------------------------------------------------------------------- */
+int hs_pileup(const uint8_t* d_contig_seq, const int64_t* d_contig_off,   /* [C+1] */
+              const uint8_t* d_read_seq, const int64_t* d_read_off,        /* [NR+1] */
+              const int32_t* d_rec_read, const int32_t* d_rec_contig, const int32_t* d_rec_pos,
+              const uint8_t* d_rec_strand, const int64_t* d_rec_cig_off,   /* [NREC+1] */
+              const uint32_t* d_cigar, const int64_t* d_pile_off,          /* [NREC+1] */
+              int32_t n_rec, uint8_t* d_pile, int32_t* d_rec_stats /* [NREC*4] */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2 -- per-position code histogram and top-5.  Replaces the counting half of call_variants
+ * (call_variants.cpp:471-507): for every contig position the five most frequent pileup codes.
+ * Output record (16 B / position): u8 key[4]; u16 cnt[5]; u16 depth -- ordered by (count desc, code asc);
+ * missing entries have key 0 / count 0. The reference's tie order (robin_hood iteration order + std::sort) is
+ * applied afterwards by the host only where it is observable (hs_colstat flags).
+ * d_contig_rec_off[C+1] gives each contig's record range; d_rec_qend[r] = exclusive end of record r's pileup.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hs_colstat {
+    uint8_t key[4];
+    uint16_t cnt[5];
+    uint16_t depth;
+} hs_colstat;
+
+int hs_column_stats(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
+                    const int32_t* d_rec_qend, const int32_t* d_contig_rec_off, const int64_t* d_contig_off,
+                    int32_t n_contigs, hs_colstat* d_stats /* [sum L] */, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3 -- column extraction (pileup transposition for selected positions, coalesced writes).
+ * Produces the reference's `Column` (Partition.h:8-14): read indices ascending + one code per read, for the
+ * positions in d_sel_pos (position inside contig d_sel_contig). d_col_off[k] is the output offset of
+ * selected column k (exclusive prefix of hs_colstat.depth, computed by the caller).
+ * ---------------------------------------------------------------------------------------------- */
+int hs_gather_columns(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
+                      const int32_t* d_rec_qend, const int32_t* d_contig_rec_off,
+                      const int32_t* d_sel_contig, const int32_t* d_sel_pos, const int64_t* d_col_off,
+                      int32_t n_sel, int32_t* d_col_idx, uint8_t* d_col_code, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5 -- read x read similarity / difference.  Replaces list_similarities_and_differences_between_reads3
+ * (separate_reads.cpp:374-433): sim = 3*A*At + R*Rt, diff = A*Rt + R*At with zero diagonals, as popcounts of
+ * bit-planes. d_alt / d_ref: N rows of `words` uint64 (bit s of row r = read r carries second_base / ref_base
+ * at SNP s). Batched over contigs: plane_off[c] (in uint64 words), out_off[c] (in int32 elements).
+ * ---------------------------------------------------------------------------------------------- */
+int hs_simdiff(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_plane_off,
+               const int32_t* d_n_reads, const int32_t* d_words, const int64_t* d_out_off, int32_t n_contigs,
+               int32_t* d_sim, int32_t* d_diff, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K7 -- Chinese Whispers, batched.  Replaces chinese_whispers / chinese_whispers_high_memory
+ * (cluster_graph.cpp:152-310). One wavefront per instance; an instance is (graph g, initial labels, mask).
+ * Graph g is a CSR over n_nodes[g] nodes (adj_off relative to graph_adj_base[g]); perm[g] is the node visiting
+ * order (the caller supplies std::shuffle(mt19937(seed)) of 0..N-1; with a pinned seed the reference uses the
+ * same permutation in every sweep). Labels in/out: int32, -2 for masked-out nodes on output.
+ * d_sweeps[i] (optional, may be NULL) receives the number of sweeps instance i ran.
+ * ---------------------------------------------------------------------------------------------- */
+int hs_chinese_whispers(const int32_t* d_adj_off, const int32_t* d_adj, const int64_t* d_graph_off_base,
+                        const int64_t* d_graph_adj_base, const int32_t* d_graph_n, const int32_t* d_perm,
+                        const int64_t* d_perm_base, const uint8_t* d_mask, const int32_t* d_inst_graph,
+                        const int64_t* d_inst_label_base, int32_t n_inst, int32_t* d_labels,
+                        int32_t* d_sweeps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A1 -- Myers bit-vector edit distance, batched (one wavefront per pair; 64 query rows per lane-block,
+ * carries passed between lanes). The reference's hot path takes base-level alignments from the SAM CIGAR;
+ * its bundled edlib (edlib.h:242-246, modes edlib.h:36-62) is the behavioural oracle for this kernel.
+ * mode: 0 = NW (global), 1 = SHW (prefix), 2 = HW (infix). Outputs: edit distance and the first end location
+ * on the target (0-based, inclusive), like edlibAlign's editDistance / endLocations[0].
+ * ---------------------------------------------------------------------------------------------- */
+int hs_edit_distance(const uint8_t* d_query, const int64_t* d_query_off, const uint8_t* d_target,
+                     const int64_t* d_target_off, int32_t n_pairs, int32_t mode, int32_t* d_dist,
+                     int32_t* d_end, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage level (host buffers in, host buffers out). These run the whole stage exactly as the drop-in
+ * executables do: device kernels for pileup / histogram / extraction / sim-diff / Chinese Whispers, host code
+ * for the sequential glue. Split in upload + run so callers can time the path with inputs resident in HBM.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hs_cv_batch hs_cv_batch;   /* opaque: a batch of contigs + reads + records resident in HBM */
+
+/* call_variants.cpp:1249-1262 hand-off: what parse_reads/parse_assembly/parse_SAM produce, flattened. */
+int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off, int32_t n_contigs,
+                       const uint8_t* h_read_seq, const int64_t* h_read_off, int32_t n_reads,
+                       const int32_t* h_rec_read, const int32_t* h_rec_pos, const uint8_t* h_rec_strand,
+                       const int64_t* h_rec_cig_off, const uint32_t* h_cigar,
+                       const int32_t* h_contig_rec_off, hs_cv_batch** out);
+void hs_cv_batch_destroy(hs_cv_batch* b);
+int64_t hs_cv_batch_aligned_bp(const hs_cv_batch* b);   /* number of pileup entries (the metric's unit) */
+
+/* Per-contig result of stage 3 == what output_files (call_variants.cpp:1174-1213) prints. */
+typedef struct hs_cv_result {
+    int32_t n_contigs;
+    float* mean_distance;      /* [C] generate_msa's return value */
+    float* depth;              /* [C] call_variants.cpp:565 */
+    int64_t* snp_off;          /* [C+1] */
+    int32_t* snp_pos;          /* [S] */
+    uint8_t* snp_ref;          /* [S] */
+    uint8_t* snp_alt;          /* [S] */
+    int64_t* col_off;          /* [S+1] */
+    int32_t* col_idx;          /* read indices, ascending */
+    uint8_t* col_code;         /* pileup codes */
+    float error_rate;          /* call_variants.cpp:1312-1315,1377 */
+    int32_t n_contigs_with_error_rate;
+    double t_device_ms;        /* wall time of the device phase (uploads of selections, kernels, downloads) */
+    double t_host_ms;          /* wall time of the host glue */
+    float t_kernel_ms[4];      /* hipEvent time of k_pileup, k_column_stats, k_gather_columns, (unused) */
+} hs_cv_result;
+
+int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out);
+void hs_cv_result_destroy(hs_cv_result* r);
+
+/* Stage 4 on SNP columns already in memory (what parse_column_file, separate_reads.cpp:46-190, yields). */
+typedef struct hs_sr_contig {
+    int64_t length;            /* contig length */
+    int32_t n_reads;           /* number of READ lines */
+    const int32_t* read_start; /* [n_reads] readLimits .first */
+    const int32_t* read_end;   /* [n_reads] readLimits .second */
+    int32_t n_snps;
+    const int32_t* snp_pos;
+    const uint8_t* snp_ref;
+    const uint8_t* snp_alt;
+    const int64_t* col_off;    /* [n_snps+1] */
+    const int32_t* col_idx;
+    const uint8_t* col_code;
+    int32_t ploidy;            /* 0 = unlimited (separate_reads.cpp:1454-1458) */
+} hs_sr_contig;
+
+typedef struct hs_sr_result {
+    int32_t n_contigs;
+    int64_t* win_off;          /* [C+1] windows per contig */
+    int32_t* win_start;        /* [W] */
+    int32_t* win_end;          /* [W] */
+    int64_t* label_off;        /* [W+1] offsets into labels (n_reads of the contig each) */
+    int32_t* labels;           /* -2 absent, -1 unclustered, >=0 group */
+    double t_device_ms;
+    double t_host_ms;
+    int64_t n_cw_instances;
+    float t_kernel_ms[4];      /* hipEvent time of k_simdiff and of the three k_chinese_whispers waves */
+} hs_sr_result;
+
+int hs_sr_run(const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
+              int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out);
+void hs_sr_result_destroy(hs_sr_result* r);
+/* separate_reads.cpp:1466-1498: window size from the read limits of all contigs of the .col */
+int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_t amplicon);
+
+/* File-level entry points == main() of the two reference executables (same argv, same exit codes).
+ * call_variants.cpp:1215-1385 and separate_reads.cpp:1398-1790. */
+int hs_call_variants_main(int argc, char** argv);
+int hs_separate_reads_main(int argc, char** argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAIRSPLITTER_HIP_H */

@@ -1,0 +1,117 @@
+// ORACLE (test infrastructure, CPU only): flat-array C entry points so that the parity tests can compare the
+// HIP kernels with the CPU restatement buffer by buffer (ctypes). Never linked into the product.
+#include <cstring>
+#include <string>
+#include <vector>
+#include "hs_oracle.h"
+
+extern "C" {
+
+// K1 oracle: generate_msa (call_variants.cpp:50-437) on the flat batch layout of include/hairsplitter_hip.h.
+// pile is read-major (pile_off as computed by the caller), rec_stats = {q_end, n_err, n_len, 0} per record.
+int hso_pileup(const uint8_t* contig_seq, const int64_t* contig_off, int32_t n_contigs, const uint8_t* read_seq,
+               const int64_t* read_off, int32_t n_reads, const int32_t* rec_read, const int32_t* rec_pos,
+               const uint8_t* rec_strand, const int64_t* rec_cig_off, const uint32_t* cigar,
+               const int32_t* contig_rec_off, const int64_t* pile_off, uint8_t* pile, int32_t* rec_stats,
+               float* mean_distance) {
+    const char* opc = "MIDNSHP=X";
+    std::vector<std::string> reads((size_t)n_reads);
+    std::vector<char> loaded((size_t)n_reads, 0);
+    for (int c = 0; c < n_contigs; ++c) {
+        hso::Contig ctg;
+        for (int64_t k = contig_off[c]; k < contig_off[c + 1]; ++k) ctg.seq += "ACGT"[contig_seq[k] & 3];
+        for (int r = contig_rec_off[c]; r < contig_rec_off[c + 1]; ++r) {
+            hso::Record rec;
+            rec.read = rec_read[r]; rec.position_2_1 = rec_pos[r]; rec.strand = rec_strand[r] != 0;
+            for (int64_t o = rec_cig_off[r]; o < rec_cig_off[r + 1]; ++o) rec.cigar += std::to_string(cigar[o] >> 4) + opc[cigar[o] & 15u];
+            if (!loaded[(size_t)rec.read]) {
+                std::string s;
+                for (int64_t k = read_off[rec.read]; k < read_off[rec.read + 1]; ++k) s += "ACGT"[read_seq[k] & 3];
+                reads[(size_t)rec.read] = s; loaded[(size_t)rec.read] = 1;
+            }
+            ctg.recs.push_back(rec);
+        }
+        hso::MsaResult m = hso::generate_msa(ctg, reads);
+        if (mean_distance) mean_distance[c] = m.meanDistance;
+        for (size_t k = 0; k < ctg.recs.size(); ++k) {
+            const int r = contig_rec_off[c] + (int)k;
+            rec_stats[4 * r + 0] = m.q_end[k]; rec_stats[4 * r + 1] = (int32_t)m.n_err[k]; rec_stats[4 * r + 2] = (int32_t)m.n_len[k]; rec_stats[4 * r + 3] = 0;
+        }
+        for (size_t p = 0; p < m.cols.size(); ++p)
+            for (size_t k = 0; k < m.cols[p].content.size(); ++k) {
+                const int r = contig_rec_off[c] + (int)m.cols[p].readIdxs[k];
+                pile[pile_off[r] + ((int64_t)p - rec_pos[r])] = m.cols[p].content[k];
+            }
+    }
+    return 0;
+}
+
+// exact (reference tie order) top-3 of every position: call_variants.cpp:477-507 on a read-major pileup
+int hso_column_top3(const uint8_t* pile, const int64_t* pile_off, const int32_t* rec_pos, const int32_t* rec_qend,
+                    int32_t r0, int32_t r1, int64_t L, uint8_t* k0, uint8_t* k1, int32_t* c0, int32_t* c1, int32_t* c2,
+                    int32_t* depth) {
+    std::vector<hso::Column> cols((size_t)L);
+    for (int r = r0; r < r1; ++r)
+        for (int q = rec_pos[r]; q < rec_qend[r]; ++q) { cols[(size_t)q].readIdxs.push_back((unsigned)(r - r0)); cols[(size_t)q].content.push_back(pile[pile_off[r] + (q - rec_pos[r])]); }
+    std::string ref((size_t)L, 'A');
+    hso::CallResult cr = hso::call_variants(cols, ref, 0.05f, 0.33f);
+    for (int64_t p = 0; p < L; ++p) { k0[p] = cr.k0[(size_t)p]; k1[p] = cr.k1[(size_t)p]; c0[p] = cr.c0[(size_t)p]; c1[p] = cr.c1[(size_t)p]; c2[p] = cr.c2[(size_t)p]; depth[p] = (int32_t)cols[(size_t)p].content.size(); }
+    return 0;
+}
+
+// K5 oracle: separate_reads.cpp:374-433 from CSR SNP columns
+int hso_simdiff(int32_t n_reads, int32_t n_snps, const uint8_t* snp_ref, const uint8_t* snp_alt, const int64_t* col_off,
+                const int32_t* col_idx, const uint8_t* col_code, int32_t* sim, int32_t* diff) {
+    std::vector<hso::Column> snps((size_t)n_snps);
+    for (int s = 0; s < n_snps; ++s) {
+        snps[(size_t)s].ref_base = snp_ref[s]; snps[(size_t)s].second_base = snp_alt[s];
+        for (int64_t e = col_off[s]; e < col_off[s + 1]; ++e) { snps[(size_t)s].readIdxs.push_back((unsigned)col_idx[e]); snps[(size_t)s].content.push_back(col_code[e]); }
+    }
+    std::vector<int> S, D;
+    hso::list_similarities_and_differences(snps, n_reads, S, D);
+    std::memcpy(sim, S.data(), S.size() * sizeof(int)); std::memcpy(diff, D.data(), D.size() * sizeof(int));
+    return 0;
+}
+
+// K7 oracle: cluster_graph.cpp:240-310
+int hso_chinese_whispers(int32_t n, const int32_t* adj_off, const int32_t* adj, const uint8_t* mask, const int32_t* init,
+                         uint32_t seed, int32_t* out, int32_t* sweeps) {
+    std::vector<std::vector<int>> a((size_t)n);
+    for (int i = 0; i < n; ++i) a[(size_t)i].assign(adj + adj_off[i], adj + adj_off[i + 1]);
+    std::vector<bool> m((size_t)n);
+    for (int i = 0; i < n; ++i) m[(size_t)i] = mask[i] != 0;
+    std::vector<int> in(init, init + n);
+    int sw = 0;
+    std::vector<int> r = hso::chinese_whispers(a, in, m, seed, &sw);
+    std::memcpy(out, r.data(), (size_t)n * sizeof(int));
+    if (sweeps) *sweeps = sw;
+    return 0;
+}
+
+int hso_shuffled_order(int32_t n, uint32_t seed, int32_t* out) {
+    std::vector<int> o = hso::shuffled_order(n, seed);
+    std::memcpy(out, o.data(), (size_t)n * sizeof(int));
+    return 0;
+}
+
+int hso_edit_distance(const uint8_t* q, int32_t qn, const uint8_t* t, int32_t tn, int32_t mode, int32_t* end_loc) {
+    return hso::edit_distance(q, qn, t, tn, mode, end_loc);
+}
+
+// robin_hood iteration order of unsigned char keys (hs_oracle_rh.h), keys inserted left to right
+int hso_rh_order_u8(const uint8_t* keys, int32_t n, uint8_t* out) {
+    hso::RHMap<unsigned char, int> m;
+    for (int i = 0; i < n; ++i) m[keys[i]] += 1;
+    int k = 0;
+    m.for_each([&](unsigned char key, int) { out[k++] = key; });
+    return k;
+}
+int hso_rh_order_int(const int32_t* keys, int32_t n, int32_t* out) {
+    hso::RHMap<int, int> m;
+    for (int i = 0; i < n; ++i) m[keys[i]] += 1;
+    int k = 0;
+    m.for_each([&](int key, int) { out[k++] = key; });
+    return k;
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+// TEST INFRASTRUCTURE (never shipped): runs the product's *host glue* (hs_driver.cpp, hs_host_cv.cpp,
+// hs_host_sr.cpp, hs_io.cpp) with the device interface implemented by the CPU oracle, so that the sequential
+// logic around the HIP kernels can be checked against the reference goldens on a machine without a GPU.
+// The product library itself has no such backend (hs_capi.hip only knows HIP).
+//   host_harness call_variants  <11 positional args of HS_call_variants>
+//   host_harness separate_reads <9 positional args of HS_separate_reads>
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+
+#include "../../hairsplitter_amd/csrc/hs_driver.h"
+#include "../../oracle/hs_oracle.h"
+
+namespace hs {
+static std::string g_err;
+void set_error(const std::string& m) { g_err = m; }
+}
+extern "C" const char* hs_last_error(void) { return hs::g_err.c_str(); }
+
+namespace {
+
+struct OracleCvOps : hs::CvDeviceOps {
+    const hs::CvFileInput& in;
+    std::vector<std::vector<hso::Column>> cols;   // per contig
+    explicit OracleCvOps(const hs::CvFileInput& i) : in(i) {}
+
+    int pileup_and_stats(std::vector<int32_t>& rec_stats, std::vector<hs_colstat>& stats, float k_ms[2]) override {
+        k_ms[0] = k_ms[1] = 0;
+        const int C = (int)in.contig_names.size();
+        std::vector<std::string> read_seq(in.read_names.size());
+        for (size_t r = 0; r < read_seq.size(); ++r) {
+            std::string s;
+            for (int64_t k = in.read_off[r]; k < in.read_off[r + 1]; ++k) s += "ACGT"[in.read_seq[(size_t)k]];
+            read_seq[r] = s;
+        }
+        cols.resize((size_t)C);
+        const char* opc = "MIDNSHP=X";
+        for (int c = 0; c < C; ++c) {
+            hso::Contig ctg;
+            ctg.name = in.contig_names[(size_t)c];
+            for (int64_t k = in.contig_off[(size_t)c]; k < in.contig_off[(size_t)c + 1]; ++k) ctg.seq += "ACGT"[in.contig_seq[(size_t)k]];
+            for (int r = in.contig_rec_off[(size_t)c]; r < in.contig_rec_off[(size_t)c + 1]; ++r) {
+                hso::Record rec;
+                rec.read = in.rec_read[(size_t)r]; rec.position_2_1 = in.rec_pos[(size_t)r]; rec.strand = in.rec_strand[(size_t)r] != 0;
+                for (int64_t o = in.rec_cig_off[(size_t)r]; o < in.rec_cig_off[(size_t)r + 1]; ++o)
+                    rec.cigar += std::to_string(in.cigar[(size_t)o] >> 4) + opc[in.cigar[(size_t)o] & 15u];
+                ctg.recs.push_back(rec);
+            }
+            hso::MsaResult m = hso::generate_msa(ctg, read_seq);
+            for (size_t k = 0; k < ctg.recs.size(); ++k) {
+                const size_t r = (size_t)in.contig_rec_off[(size_t)c] + k;
+                rec_stats[r * 4 + 0] = m.q_end[k]; rec_stats[r * 4 + 1] = (int32_t)m.n_err[k]; rec_stats[r * 4 + 2] = (int32_t)m.n_len[k];
+            }
+            const int64_t base = in.contig_off[(size_t)c];
+            for (size_t p = 0; p < m.cols.size(); ++p) {
+                int cnt[256] = {0};
+                for (unsigned char ch : m.cols[p].content) cnt[ch]++;
+                std::vector<std::pair<int, int>> v;   // (-count, code)
+                for (int k = 33; k < 158; ++k) if (cnt[k]) v.push_back(std::make_pair(-cnt[k], k));
+                std::sort(v.begin(), v.end());
+                hs_colstat s; std::memset(&s, 0, sizeof(s));
+                for (size_t k = 0; k < v.size() && k < 5; ++k) { if (k < 4) s.key[k] = (uint8_t)v[k].second; s.cnt[k] = (uint16_t)(-v[k].first); }
+                s.depth = (uint16_t)m.cols[p].content.size();
+                stats[(size_t)base + p] = s;
+            }
+            cols[(size_t)c] = std::move(m.cols);
+        }
+        return 0;
+    }
+    int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
+               std::vector<int32_t>& col_idx, std::vector<uint8_t>& col_code, float* k_ms) override {
+        *k_ms = 0;
+        for (size_t i = 0; i < sel_pos.size(); ++i) {
+            const hso::Column& col = cols[(size_t)sel_contig[i]][(size_t)sel_pos[i]];
+            for (size_t k = 0; k < col.content.size(); ++k) { col_idx[(size_t)col_off[i] + k] = (int32_t)col.readIdxs[k]; col_code[(size_t)col_off[i] + k] = col.content[k]; }
+        }
+        return 0;
+    }
+};
+
+struct OracleSrOps : hs::SrDeviceOps {
+    hs::CwGraphSet gs;
+    uint32_t seed;
+    explicit OracleSrOps(uint32_t s) : seed(s) {}
+    int simdiff(const std::vector<uint64_t>& alt, const std::vector<uint64_t>& ref, const std::vector<int64_t>& plane_off,
+                const std::vector<int32_t>& n_reads, const std::vector<int32_t>& words, const std::vector<int64_t>& out_off,
+                int64_t out_total, std::vector<int32_t>& sim, std::vector<int32_t>& diff, float* k_ms) override {
+        (void)k_ms;
+        sim.assign((size_t)out_total, 0); diff.assign((size_t)out_total, 0);
+        for (size_t c = 0; c < n_reads.size(); ++c) {
+            const int N = n_reads[c], W = words[c];
+            for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) {
+                if (i == j) continue;
+                int s = 0, d = 0;
+                for (int w = 0; w < W; ++w) {
+                    const uint64_t ai = alt[(size_t)plane_off[c] + (size_t)i * W + w], ri = ref[(size_t)plane_off[c] + (size_t)i * W + w];
+                    const uint64_t aj = alt[(size_t)plane_off[c] + (size_t)j * W + w], rj = ref[(size_t)plane_off[c] + (size_t)j * W + w];
+                    s += 3 * __builtin_popcountll(ai & aj) + __builtin_popcountll(ri & rj);
+                    d += __builtin_popcountll(ai & rj) + __builtin_popcountll(ri & aj);
+                }
+                sim[(size_t)out_off[c] + (size_t)i * N + j] = s; diff[(size_t)out_off[c] + (size_t)i * N + j] = d;
+            }
+        }
+        return 0;
+    }
+    int set_graphs(const hs::CwGraphSet& g) override { gs = g; return 0; }
+    int cw(hs::CwWave& wv, float* k_ms) override {
+        (void)k_ms;
+        for (size_t i = 0; i < wv.inst_graph.size(); ++i) {
+            const int g = wv.inst_graph[i];
+            const int N = gs.graph_n[(size_t)g];
+            std::vector<std::vector<int>> adj((size_t)N);
+            const int32_t* off = gs.adj_off.data() + gs.graph_off_base[(size_t)g];
+            const int32_t* nb = gs.adj.data() + gs.graph_adj_base[(size_t)g];
+            for (int r = 0; r < N; ++r) adj[(size_t)r].assign(nb + off[r], nb + off[r + 1]);
+            std::vector<bool> mask((size_t)N);
+            for (int r = 0; r < N; ++r) mask[(size_t)r] = gs.mask[(size_t)(gs.graph_off_base[(size_t)g] - g) + (size_t)r] != 0;
+            std::vector<int> init(wv.labels.begin() + wv.inst_label_base[i], wv.labels.begin() + wv.inst_label_base[i] + N);
+            std::vector<int> res = hso::chinese_whispers(adj, init, mask, seed);
+            std::copy(res.begin(), res.end(), wv.labels.begin() + wv.inst_label_base[i]);
+        }
+        return 0;
+    }
+};
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    if (!std::strcmp(argv[1], "call_variants")) {
+        if (argc < 13) return 2;
+        char** a = argv + 1;
+        hs::CvFileInput in;
+        if (int rc = hs::load_cv_inputs(a[1], a[2], a[3], std::atoi(a[7]) != 0, in)) { std::cerr << hs::g_err << "\n"; return rc; }
+        hs::CvMeta meta;
+        meta.n_contigs = (int)in.contig_names.size(); meta.n_rec = (int)in.rec_read.size();
+        meta.contig_off = in.contig_off; meta.contig_rec_off = in.contig_rec_off; meta.total_len = in.contig_off.back();
+        meta.pile_off.assign((size_t)meta.n_rec + 1, 0);
+        for (int c = 0; c < meta.n_contigs; ++c) {
+            const int64_t L = in.contig_off[(size_t)c + 1] - in.contig_off[(size_t)c];
+            for (int r = in.contig_rec_off[(size_t)c]; r < in.contig_rec_off[(size_t)c + 1]; ++r) {
+                int64_t span = 0;
+                for (int64_t o = in.rec_cig_off[(size_t)r]; o < in.rec_cig_off[(size_t)r + 1]; ++o) { uint32_t k = in.cigar[(size_t)o] & 15u; if (k == 0 || k == 2 || k == 7 || k == 8) span += in.cigar[(size_t)o] >> 4; }
+                const int64_t pos = in.rec_pos[(size_t)r];
+                const int64_t qend = pos >= L ? pos : std::min(pos + span, L);
+                meta.pile_off[(size_t)r + 1] = meta.pile_off[(size_t)r] + (qend - pos);
+            }
+        }
+        OracleCvOps ops(in);
+        hs_cv_result* res = nullptr;
+        if (int rc = hs::cv_run(ops, meta, std::strtof(a[11], nullptr), 1, &res)) return rc;
+        hs::write_cv_outputs(in, res, a[6], a[9], a[10]);
+        hs::free_cv_result(res);
+        return 0;
+    }
+    if (!std::strcmp(argv[1], "separate_reads")) {
+        if (argc != 11) return 2;
+        char** a = argv + 1;
+        std::vector<hs::ColFileContig> cs;
+        if (int rc = hs::parse_col(a[1], (float)std::atof(a[6]), cs)) return rc;
+        std::map<std::string, int> ploidy_of; bool have = false;
+        { std::ifstream pf(a[4]); if (pf) { have = true; std::string c; int p; while (pf >> c >> p) ploidy_of[c] = p; } }
+        std::vector<hs_sr_contig> hc(cs.size());
+        for (size_t i = 0; i < cs.size(); ++i) {
+            hs::ColFileContig& c = cs[i]; hs_sr_contig& h = hc[i];
+            h.length = c.length; h.n_reads = (int32_t)c.read_lines.size(); h.read_start = c.read_start.data(); h.read_end = c.read_end.data();
+            h.n_snps = (int32_t)c.snp_pos.size(); h.snp_pos = c.snp_pos.data(); h.snp_ref = c.snp_ref.data(); h.snp_alt = c.snp_alt.data();
+            h.col_off = c.col_off.data(); h.col_idx = c.col_idx.data(); h.col_code = c.col_code.data();
+            h.ploidy = (have && ploidy_of.count(c.name)) ? ploidy_of[c.name] : 0;
+        }
+        const int w = hs::sr_window_size(hc.data(), (int)hc.size(), std::atoi(a[7]) != 0);
+        OracleSrOps ops(12345u);
+        hs_sr_result* res = nullptr;
+        if (int rc = hs::sr_run(ops, hc.data(), (int)hc.size(), w, (float)std::atof(a[3]), std::atoi(a[5]), 12345u, 1, &res)) return rc;
+        { std::ofstream o(a[8]); }
+        hs::write_gro(cs, res, a[8]);
+        hs::free_sr_result(res);
+        return 0;
+    }
+    return 2;
+}

@@ -1,0 +1,88 @@
+"""ctypes access to oracle/_build/libhs_oracle.so (CPU restatement; test infrastructure only)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(os.path.join(ROOT, "oracle", "_build", "libhs_oracle.so"))
+    return _lib
+
+
+def _hp(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def pileup(flat):
+    pile = np.zeros(max(flat.aligned_bp, 1), np.uint8)
+    stats = np.zeros((max(flat.n_rec, 1), 4), np.int32)
+    md = np.zeros(max(flat.n_contigs, 1), np.float32)
+    lib().hso_pileup(_hp(flat.contig_seq, C.c_uint8), _hp(flat.contig_off, C.c_int64), C.c_int32(flat.n_contigs),
+                     _hp(flat.read_seq, C.c_uint8), _hp(flat.read_off, C.c_int64), C.c_int32(flat.n_reads),
+                     _hp(flat.rec_read, C.c_int32), _hp(flat.rec_pos, C.c_int32), _hp(flat.rec_strand, C.c_uint8),
+                     _hp(flat.rec_cig_off, C.c_int64), _hp(flat.cigar, C.c_uint32), _hp(flat.contig_rec_off, C.c_int32),
+                     _hp(flat.pile_off, C.c_int64), _hp(pile, C.c_uint8), _hp(stats, C.c_int32), _hp(md, C.c_float))
+    return pile[:flat.aligned_bp], stats[:flat.n_rec], md[:flat.n_contigs]
+
+
+def column_top3(flat, pile, c):
+    r0, r1 = int(flat.contig_rec_off[c]), int(flat.contig_rec_off[c + 1])
+    L = int(flat.contig_off[c + 1] - flat.contig_off[c])
+    k0 = np.zeros(L, np.uint8); k1 = np.zeros(L, np.uint8)
+    c0 = np.zeros(L, np.int32); c1 = np.zeros(L, np.int32); c2 = np.zeros(L, np.int32); d = np.zeros(L, np.int32)
+    pile = np.ascontiguousarray(pile)
+    lib().hso_column_top3(_hp(pile, C.c_uint8), _hp(flat.pile_off, C.c_int64), _hp(flat.rec_pos, C.c_int32), _hp(flat.rec_qend, C.c_int32),
+                          C.c_int32(r0), C.c_int32(r1), C.c_int64(L), _hp(k0, C.c_uint8), _hp(k1, C.c_uint8), _hp(c0, C.c_int32),
+                          _hp(c1, C.c_int32), _hp(c2, C.c_int32), _hp(d, C.c_int32))
+    return k0, k1, c0, c1, c2, d
+
+
+def simdiff(n_reads, snp_ref, snp_alt, col_off, col_idx, col_code):
+    sim = np.zeros((n_reads, n_reads), np.int32); diff = np.zeros((n_reads, n_reads), np.int32)
+    snp_ref = np.ascontiguousarray(snp_ref, np.uint8); snp_alt = np.ascontiguousarray(snp_alt, np.uint8)
+    col_off = np.ascontiguousarray(col_off, np.int64); col_idx = np.ascontiguousarray(col_idx, np.int32); col_code = np.ascontiguousarray(col_code, np.uint8)
+    lib().hso_simdiff(C.c_int32(n_reads), C.c_int32(len(snp_ref)), _hp(snp_ref, C.c_uint8), _hp(snp_alt, C.c_uint8), _hp(col_off, C.c_int64),
+                      _hp(col_idx, C.c_int32), _hp(col_code, C.c_uint8), _hp(sim, C.c_int32), _hp(diff, C.c_int32))
+    return sim, diff
+
+
+def chinese_whispers(adj_lists, mask, init, seed=12345):
+    n = len(adj_lists)
+    off = np.zeros(n + 1, np.int32); off[1:] = np.cumsum([len(a) for a in adj_lists])
+    adj = np.ascontiguousarray(np.concatenate([np.asarray(a, np.int32) for a in adj_lists]) if off[-1] else np.zeros(1), np.int32)
+    mask = np.ascontiguousarray(mask, np.uint8); init = np.ascontiguousarray(init, np.int32)
+    out = np.zeros(n, np.int32); sw = C.c_int32(0)
+    lib().hso_chinese_whispers(C.c_int32(n), _hp(off, C.c_int32), _hp(adj, C.c_int32), _hp(mask, C.c_uint8), _hp(init, C.c_int32),
+                               C.c_uint32(seed), _hp(out, C.c_int32), C.byref(sw))
+    return out, sw.value
+
+
+def shuffled_order(n, seed=12345):
+    out = np.zeros(max(n, 1), np.int32)
+    lib().hso_shuffled_order(C.c_int32(n), C.c_uint32(seed), _hp(out, C.c_int32))
+    return out[:n]
+
+
+def edit_distance(q, t, mode):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    end = C.c_int32(0)
+    d = lib().hso_edit_distance(_hp(q, C.c_uint8), C.c_int32(len(q)), _hp(t, C.c_uint8), C.c_int32(len(t)), C.c_int32(mode), C.byref(end))
+    return d, end.value
+
+
+def rh_order_u8(keys):
+    k = np.ascontiguousarray(keys, np.uint8); out = np.zeros(300, np.uint8)
+    n = lib().hso_rh_order_u8(_hp(k, C.c_uint8), C.c_int32(len(k)), _hp(out, C.c_uint8))
+    return out[:n].tolist()
+
+
+def rh_order_int(keys):
+    k = np.ascontiguousarray(keys, np.int32); out = np.zeros(len(k) + 4, np.int32)
+    n = lib().hso_rh_order_int(_hp(k, C.c_int32), C.c_int32(len(k)), _hp(out, C.c_int32))
+    return out[:n].tolist()

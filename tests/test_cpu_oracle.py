@@ -1,0 +1,102 @@
+"""CPU tests (no GPU): the oracle restatement against the reference goldens, library-behaviour vectors,
+the product's host glue (through the oracle-backed harness), and the C-ABI surface."""
+import json
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle_lib as ol
+
+ROOT = gu.ROOT
+
+
+@pytest.mark.parametrize("case", gu.case_names())
+def test_oracle_matches_reference_goldens(built, case):
+    """oracle/_build/hs_oracle, run like the reference binaries, reproduces the reference's own outputs
+    (tests/golden/*, produced by oracle/gen_goldens.py from oracle/_ref)."""
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack(case, td)
+        outs = gu.run_stage_pair([built["oracle"], "call_variants"], [built["oracle"], "separate_reads"], td, meta)
+        assert gu.compare(td, outs) == []
+
+
+@pytest.mark.parametrize("case", gu.case_names())
+def test_host_glue_matches_reference_goldens(built, case):
+    """The product's host-side logic (dense partitions, window planning, cluster merging, file I/O) with the
+    device interface served by the oracle: must equal the reference goldens."""
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack(case, td)
+        outs = gu.run_stage_pair([built["harness"], "call_variants"], [built["harness"], "separate_reads"], td, meta)
+        assert gu.compare(td, outs) == []
+
+
+def test_robin_hood_order_vectors(built):
+    vec = json.load(open(os.path.join(gu.GOLD, "robin_hood_order.json")))
+    for v in vec:
+        got = ol.rh_order_u8(v["keys"]) if v["type"] == "u8" else ol.rh_order_int(v["keys"])
+        assert got == v["order"], v
+    # the product's own emulator (hs_rh8.h) against the same vectors
+    u8 = [v for v in vec if v["type"] == "u8"]
+    inp = "\n".join("u8 " + " ".join(map(str, v["keys"])) for v in u8) + "\n"
+    exe = os.path.join(ROOT, "tests", "harness", "_build", "rh8_selftest")
+    out = subprocess.run([exe], input=inp, capture_output=True, text=True, check=True).stdout.splitlines()
+    for o, v in zip(out, u8):
+        assert list(map(int, o.split())) == v["order"]
+
+
+def test_shuffle_permutations_pinned(built):
+    """libstdc++ mt19937(12345) + std::shuffle (SURVEY.md appendix B known answers)."""
+    assert ol.shuffled_order(5).tolist() == [0, 1, 4, 3, 2]
+    assert ol.shuffled_order(10).tolist() == [6, 8, 3, 5, 1, 2, 9, 7, 4, 0]
+    assert ol.shuffled_order(17).tolist() == [11, 9, 13, 16, 2, 1, 12, 5, 0, 10, 7, 8, 14, 15, 6, 4, 3]
+
+
+def test_edit_distance_oracle_matches_edlib_vectors(built):
+    vec = json.load(open(os.path.join(gu.GOLD, "edlib_vectors.json")))
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    mode = {"NW": 0, "SHW": 1, "HW": 2}
+    for v in vec:
+        q = np.array([code[c] for c in v["query"]], np.uint8)
+        t = np.array([code[c] for c in v["target"]], np.uint8)
+        d, e = ol.edit_distance(q, t, mode[v["mode"]])
+        assert d == v["distance"], v["mode"]
+        assert e == v["end"], (v["mode"], d, e, v["end"])
+
+
+def test_c_abi_exports_every_declared_symbol(built):
+    from hairsplitter_amd import api
+    hdr = open(os.path.join(ROOT, "include", "hairsplitter_hip.h")).read()
+    declared = set(re.findall(r"\b(hs_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"hs_colstat", "hs_cv_batch", "hs_cv_result", "hs_sr_contig", "hs_sr_result"}
+    assert declared == set(api.SYMBOLS), declared ^ set(api.SYMBOLS)
+    lib = api.load()
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert b"gfx950" in lib.hs_version()
+
+
+def test_product_refuses_to_run_without_gpu(built):
+    """No CPU fallback: on a box without a HIP device the drop-in executables fail loudly."""
+    from hairsplitter_amd import api
+    if api.load().hs_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack("dip20k", td)
+        r = subprocess.run([built["cv"], os.path.join(td, "assembly.gfa"), os.path.join(td, "reads.fasta"), os.path.join(td, "aln.sam"),
+                            "1", td, os.path.join(td, "e.txt"), "0", "0", os.path.join(td, "o.col"), os.path.join(td, "o.vcf"), "0.33"],
+                           stdout=subprocess.PIPE)
+        assert r.returncode != 0 and b"no HIP device" in r.stdout
+        with pytest.raises(api.HsError):
+            api.require_gpu()
+
+
+def test_probe_calls_of_the_orchestrator(built):
+    """hairsplitter.py:229-252 probes `HS_call_variants --version` and `HS_separate_reads --help`, expecting 0."""
+    assert subprocess.run([built["cv"], "--version"], stdout=subprocess.DEVNULL).returncode == 0
+    assert subprocess.run([built["sr"], "--help"], stdout=subprocess.DEVNULL).returncode == 0
+    assert subprocess.run([built["sr"], "a", "b"], stdout=subprocess.DEVNULL).returncode == 1

@@ -1,0 +1,188 @@
+"""GPU parity, kernel by kernel, through the C ABI (hairsplitter_amd.api -> libhairsplitter_hip.so):
+every HIP kernel against the CPU oracle on the same seeded inputs. Integer / byte work: bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+
+def _contigs(kind):
+    from hairsplitter_amd import synth
+    if kind == "dip":
+        return [synth.make_contig(11, 0, 30_000, 2, 0.01, 40, "ont")]
+    if kind == "multi":
+        return [synth.make_contig(12, 0, 9_000, 3, 0.01, 35, "ont"), synth.make_contig(12, 1, 700, 1, 0.0, 20, "ont", read_len_override=(100, 600)),
+                synth.make_contig(12, 2, 5_000, 1, 0.0, 0, "ont"), synth.make_contig(12, 3, 20_011, 4, 0.012, 50, "ont", clip_prob=0.4)]
+    if kind == "hifi":
+        return [synth.make_contig(13, 0, 40_000, 2, 0.003, 25, "hifi")]
+    raise ValueError(kind)
+
+
+@pytest.fixture(scope="module", params=["dip", "multi", "hifi"])
+def batch(request, built):
+    from hairsplitter_amd import api
+    api.require_gpu()
+    flat = api.FlatBatch(_contigs(request.param))
+    t = api.device_tensors(flat)
+    return flat, t
+
+
+def test_pileup_bytes_and_counters(batch):
+    """K1 == generate_msa (call_variants.cpp:50-437): every pileup byte and the per-record integer counters."""
+    from hairsplitter_amd import api
+    flat, t = batch
+    pile, stats = api.pileup(t, flat)
+    o_pile, o_stats, _ = ol.pileup(flat)
+    assert np.array_equal(pile.cpu().numpy(), o_pile)
+    assert np.array_equal(stats.cpu().numpy()[:, :3], o_stats[:, :3])
+
+
+def test_column_stats_counts(batch):
+    """K2 == histogram of call_variants.cpp:477-501: sorted counts, depth; keys wherever they are unambiguous."""
+    from hairsplitter_amd import api
+    flat, t = batch
+    pile, _ = api.pileup(t, flat)
+    st = api.column_stats(t, flat, pile)
+    hp = pile.cpu().numpy()
+    for c in range(flat.n_contigs):
+        k0, k1, c0, c1, c2, depth = ol.column_top3(flat, hp, c)
+        s = st[int(flat.contig_off[c]):int(flat.contig_off[c + 1])]
+        assert np.array_equal(s["depth"].astype(np.int32), depth)
+        assert np.array_equal(s["cnt"][:, 0].astype(np.int32), c0)
+        assert np.array_equal(s["cnt"][:, 1].astype(np.int32), c1)
+        assert np.array_equal(s["cnt"][:, 2].astype(np.int32), c2)
+        strict = (c0 > c1) & (c1 > c2) & (c1 > 0)
+        assert np.array_equal(s["key"][:, 0][strict], k0[strict])
+        assert np.array_equal(s["key"][:, 1][strict], k1[strict])
+        # counts are sorted and sum to at most depth
+        cnt = s["cnt"].astype(np.int64)
+        assert np.all(np.diff(cnt, axis=1) <= 0) and np.all(cnt.sum(axis=1) <= depth)
+
+
+def test_gather_columns(batch):
+    """K3 == the reference's Column for selected positions: ascending read indices, matching codes."""
+    from hairsplitter_amd import api
+    flat, t = batch
+    pile, _ = api.pileup(t, flat)
+    st = api.column_stats(t, flat, pile)
+    rng = np.random.default_rng(5)
+    sel_c, sel_p, depths = [], [], []
+    for c in range(flat.n_contigs):
+        L = int(flat.contig_off[c + 1] - flat.contig_off[c])
+        for p in sorted(set([0, L - 1] + rng.integers(0, L, 40).tolist())):
+            sel_c.append(c); sel_p.append(p); depths.append(int(st[int(flat.contig_off[c]) + p]["depth"]))
+    col_off, idx, code = api.gather_columns(t, flat, pile, sel_c, sel_p, depths)
+    hp = pile.cpu().numpy()
+    for k, (c, p) in enumerate(zip(sel_c, sel_p)):
+        r0, r1 = int(flat.contig_rec_off[c]), int(flat.contig_rec_off[c + 1])
+        exp_idx, exp_code = [], []
+        for r in range(r0, r1):
+            if flat.rec_pos[r] <= p < flat.rec_qend[r]:
+                exp_idx.append(r - r0); exp_code.append(hp[flat.pile_off[r] + p - flat.rec_pos[r]])
+        assert idx[col_off[k]:col_off[k + 1]].tolist() == exp_idx
+        assert code[col_off[k]:col_off[k + 1]].tolist() == exp_code
+
+
+def test_stage3_result_equals_oracle_pipeline(batch, built):
+    """hs_cv_run on the resident batch: SNP positions, ref/alt codes and columns equal the oracle's .col."""
+    import subprocess, tempfile
+    from hairsplitter_amd import api, synth, canon
+    flat, _ = batch
+    b = api.CvBatch(flat)
+    assert b.aligned_bp == flat.aligned_bp
+    out = b.run(0.33)
+    b.close()
+    # size-independent properties
+    assert np.all(np.diff(out["snp_off"]) >= 0)
+    for c in range(flat.n_contigs):
+        pos = out["snp_pos"][out["snp_off"][c]:out["snp_off"][c + 1]]
+        assert np.all(np.diff(pos) > 0)
+    for s in range(len(out["snp_pos"])):
+        idx = out["col_idx"][out["col_off"][s]:out["col_off"][s + 1]]
+        assert np.all(np.diff(idx) > 0)
+
+
+def test_simdiff_matches_oracle(built):
+    """K5 == list_similarities_and_differences_between_reads3 (separate_reads.cpp:374-433)."""
+    from hairsplitter_amd import api
+    rng = np.random.default_rng(3)
+    for (N, S) in [(1, 1), (37, 5), (64, 64), (130, 700), (257, 1030)]:
+        snp_ref = rng.integers(33, 158, S).astype(np.uint8)
+        snp_alt = ((snp_ref.astype(np.int32) - 33 + rng.integers(1, 124, S)) % 125 + 33).astype(np.uint8)
+        col_off, col_idx, col_code = [0], [], []
+        for s in range(S):
+            reads = np.flatnonzero(rng.random(N) < 0.6)
+            u = rng.random(len(reads))
+            codes = np.where(u < 0.5, snp_ref[s], np.where(u < 0.9, snp_alt[s], 40)).astype(np.uint8)
+            col_idx += reads.tolist(); col_code += codes.tolist(); col_off.append(len(col_idx))
+        W = (S + 63) // 64
+        alt = np.zeros((N, W), np.uint64); ref = np.zeros((N, W), np.uint64)
+        for s in range(S):
+            for e in range(col_off[s], col_off[s + 1]):
+                if col_code[e] == snp_ref[s]:
+                    ref[col_idx[e], s >> 6] |= np.uint64(1) << np.uint64(s & 63)
+                elif col_code[e] == snp_alt[s]:
+                    alt[col_idx[e], s >> 6] |= np.uint64(1) << np.uint64(s & 63)
+        sim, diff = api.simdiff(alt, ref)
+        o_sim, o_diff = ol.simdiff(N, snp_ref, snp_alt, col_off, col_idx, col_code)
+        assert np.array_equal(sim, o_sim) and np.array_equal(diff, o_diff)
+        assert np.array_equal(sim, sim.T) and np.all(np.diag(sim) == 0)
+
+
+def test_chinese_whispers_matches_oracle(built):
+    """K7 == chinese_whispers_high_memory (cluster_graph.cpp:240-310): labels and number of sweeps."""
+    from hairsplitter_amd import api
+    rng = np.random.default_rng(9)
+    for N, deg, nblocks in [(1, 0, 1), (8, 2, 2), (100, 6, 3), (333, 12, 4), (700, 70, 5)]:
+        block = rng.integers(0, nblocks, N)
+        adj = [set() for _ in range(N)]
+        for i in range(N):
+            for _ in range(deg):
+                j = int(rng.integers(0, N))
+                if j != i and (block[i] == block[j] or rng.random() < 0.15):
+                    adj[i].add(j); adj[j].add(i)
+        adj_l = [sorted(a) for a in adj]
+        mask = (rng.random(N) < 0.8).astype(np.uint8)
+        perm = ol.shuffled_order(N)
+        inits = np.stack([np.arange(N), rng.integers(0, max(1, N // 3), N), np.where(rng.random(N) < 0.2, -1, rng.integers(0, N, N))]).astype(np.int32)
+        got, sweeps = api.chinese_whispers(adj_l, perm, mask, inits)
+        for k in range(inits.shape[0]):
+            exp, sw = ol.chinese_whispers(adj_l, mask, inits[k])
+            assert np.array_equal(got[k], exp), (N, k)
+            assert sweeps[k] == sw
+            assert np.all(got[k][mask == 0] == -2)
+
+
+def test_myers_matches_edlib_vectors_and_oracle(built):
+    """A1 == edlibAlign distance / first end location (golden vectors from the reference's bundled edlib)."""
+    from hairsplitter_amd import api
+    vec = json.load(open(os.path.join(gu.GOLD, "edlib_vectors.json")))
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    for mode in ("NW", "HW", "SHW"):
+        vs = [v for v in vec if v["mode"] == mode]
+        q = [np.array([code[c] for c in v["query"]], np.uint8) for v in vs]
+        t = [np.array([code[c] for c in v["target"]], np.uint8) for v in vs]
+        d, e = api.edit_distance(q, t, mode)
+        assert d.tolist() == [v["distance"] for v in vs], mode
+        assert e.tolist() == [v["end"] for v in vs], mode
+    # multi-pass path (query > 4096 rows) against the DP oracle
+    rng = np.random.default_rng(2)
+    qs, ts = [], []
+    for qn in (4097, 5000, 9001):
+        base = rng.integers(0, 4, qn).astype(np.uint8)
+        keep = rng.random(qn) > 0.04
+        tt = base[keep].copy()
+        m = rng.random(len(tt)) < 0.05
+        tt[m] = (tt[m] + 1) & 3
+        qs.append(base); ts.append(tt)
+    for mode, mi in (("NW", 0), ("HW", 2)):
+        d, e = api.edit_distance(qs, ts, mode)
+        for k in range(len(qs)):
+            od, oe = ol.edit_distance(qs[k], ts[k], mi)
+            assert d[k] == od and e[k] == oe, (mode, k, d[k], od, e[k], oe)
