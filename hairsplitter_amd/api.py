@@ -60,6 +60,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; whichever HIP runtime is mapped first serves the whole process, and
+    # torch only finds the GPU through its own copy. Import torch first so that this library binds to the same runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+        pass
     if not os.path.exists(LIB_PATH):
         raise HsError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950); "
                       "there is no CPU fallback")
