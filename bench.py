@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned read-bp/s through call_variants + separate_reads on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the whole hot path (stage 3 + stage 4, device kernels and host glue) over one batch of
+synthetic contigs whose inputs are already resident in HBM. Workload at any N: BASELINE.json configs[1] (C2:
+100 kb contig, 2 haplotypes @1 %, 50x ONT-error reads), `--contigs` independent contigs of that shape per GPU
+(weak scaling: per-GPU work is fixed as N grows; contigs are sharded by index over the ranks, the only
+collectives are the tiny error-rate exchange and ONE gather of the partition labels to rank 0 per step).
+
+Launched by the driver as
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def py_error_rate(er32: float) -> float:
+    """What hairsplitter.py hands to stage 4: the float printed by stage 3 (6 significant digits), capped at 0.15
+    (hairsplitter.py:686-692,725)."""
+    e = float("%g" % er32)
+    return min(e, 0.15)
+
+
+def cpu_baseline(n_contigs: int, seed: int):
+    """The compiled reference (oracle/_ref, built from /root/reference by oracle/Makefile) timed file-to-file on this
+    box's host cores on a bounded sample of the same workload. Falls back to the oracle restatement ("port")."""
+    from hairsplitter_amd import synth
+    import __graft_entry__ as ge
+    p = ge.paths()
+    cores = os.cpu_count() or 1
+    kind = "reference" if os.path.exists(p["ref_cv"]) and os.path.exists(p["ref_sr"]) else "port"
+    if kind == "port" and not os.path.exists(p["oracle"]):
+        return None
+    contigs = [synth.make_contig(seed, 10_000 + i, 100_000, 2, 0.01, 50, "ont") for i in range(n_contigs)]
+    bp = sum(c.aligned_bp for c in contigs)
+    with tempfile.TemporaryDirectory() as td:
+        f = synth.write_files(contigs, td)
+        col, vcf, err, gro = (os.path.join(td, x) for x in ("v.col", "v.vcf", "e.txt", "r.gro"))
+        if kind == "reference":
+            cv, sr, threads = [p["ref_cv"]], [p["ref_sr"]], cores
+        else:
+            cv, sr, threads = [p["oracle"], "call_variants"], [p["oracle"], "separate_reads"], 1
+        t0 = time.perf_counter()
+        subprocess.run(cv + [f["gfa"], f["reads"], f["sam"], str(threads), td, err, "0", "0", col, vcf, "0.33"], check=True,
+                       stdout=subprocess.DEVNULL)
+        e = py_error_rate(float(open(err).read().strip()))
+        subprocess.run(sr + [col, str(threads), str(e), os.path.join(td, "no_ploidy"), "0", "0.01", "0", gro, "0"], check=True,
+                       stdout=subprocess.DEVNULL)
+        dt = time.perf_counter() - t0
+    return {"value": bp / dt, "unit": "aligned read-bp/s", "cores": threads if kind == "reference" else 1, "kind": kind,
+            "sample": f"{n_contigs} contigs of the C2 shape ({bp} aligned bp), stage 3+4 file-to-file, {dt:.2f} s wall"
+                      + (f", -t {threads}; contig-level OpenMP only" if kind == "reference" else ", single thread")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--contigs", type=int, default=16, help="C2-shaped contigs per GPU in one batch")
+    ap.add_argument("--threads", type=int, default=0, help="host threads for the sequential glue (0 = all cores / ranks)")
+    ap.add_argument("--cpu-contigs", type=int, default=8, help="size of the CPU-baseline sample (0 disables)")
+    ap.add_argument("--seed", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from hairsplitter_amd import api, synth, dist as hdist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    api.require_gpu()
+    api.load().hs_set_device(local_rank if world > 1 else 0)
+    n_threads = args.threads or max(1, (os.cpu_count() or 1) // world)
+
+    # ---- this rank's shard: contigs [rank*B, (rank+1)*B) of the job (weak scaling) ----
+    B = args.contigs
+    my_ids = list(range(rank * B, (rank + 1) * B))
+    contigs = [synth.make_contig(args.seed, i, 100_000, 2, 0.01, 50, "ont") for i in my_ids]
+    flat = api.FlatBatch(contigs)
+    batch = api.CvBatch(flat)          # inputs now resident in HBM
+    local_bp = flat.aligned_bp
+
+    def step():
+        cv = batch.run(0.33, n_threads)
+        er = hdist.global_error_rate(my_ids, cv["mean_distance"], world * B)
+        sr = api.separate_reads(cv, flat, py_error_rate(er), rarest_strain_abundance=0.01, n_threads=n_threads, window_size=2000 if world > 1 else None)
+        gathered = hdist.gather_labels(sr["labels"])
+        return cv, sr, gathered
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    k_cv = np.zeros(4); k_sr = np.zeros(4); t_dev = 0.0; t_host = 0.0
+    last = None
+    for _ in range(args.steps):
+        cv, sr, gathered = step()
+        k_cv += np.asarray(cv["t_kernel_ms"]); k_sr += np.asarray(sr["t_kernel_ms"])
+        t_dev += cv["t_device_ms"] + sr["t_device_ms"]; t_host += cv["t_host_ms"] + sr["t_host_ms"]
+        last = (cv, sr)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tot = torch.tensor([local_bp], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_bp = int(tot.item())
+    else:
+        total_bp = local_bp
+
+    if rank == 0:
+        K = args.steps
+        cv, sr = last
+        kernels = {"k_pileup": k_cv[0] / K, "k_column_stats": k_cv[1] / K, "k_gather_columns": k_cv[2] / K,
+                   "k_simdiff": k_sr[0] / K, "k_chinese_whispers": (k_sr[1] + k_sr[2] + k_sr[3]) / K}
+        # algorithmic bytes per launch: pileup = read base in + code out = 2 B / aligned bp;
+        # column_stats = 1 B / aligned bp in + 16 B / position out; chinese_whispers: see DESIGN.md
+        alg_bytes = {"k_pileup": 2.0 * local_bp, "k_column_stats": 1.0 * local_bp + 16.0 * float(flat.contig_off[-1])}
+        dom = max(("k_pileup", "k_column_stats"), key=lambda k: kernels[k])
+        achieved = alg_bytes[dom] / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "aligned read-bp/sec through call_variants+separate_reads",
+            "value": total_bp * K / dt, "unit": "aligned read-bp/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"C2 (BASELINE.json configs[1]): 100 kb contig, 2 haplotypes @1% divergence, 50x ONT-error reads; "
+                                   f"{B} such contigs per GPU per step, inputs resident in HBM",
+                       "contigs_per_gpu": B, "aligned_bp_per_gpu": local_bp, "parallelism": f"contig-sharded x{world}",
+                       "host_threads_per_rank": n_threads, "snps_rank0": int(cv["snp_off"][-1]), "cw_instances_rank0": sr["n_cw_instances"]},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kernels[dom],
+                         "algorithmic_bytes_per_launch": alg_bytes[dom]},
+            "kernel_ms_per_step": kernels,
+            "phase_ms_per_step": {"device_phases": t_dev / K, "host_glue": t_host / K},
+        }
+        if world == 1 and args.cpu_contigs > 0:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_contigs, args.seed)
+            except Exception as e:  # the baseline is informational; never fail the bench on it
+                out["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

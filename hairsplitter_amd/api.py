@@ -234,7 +234,7 @@ class CvBatch:
 
 def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory: bool = False, amplicon: bool = False,
                    seed: int = 12345, n_threads: int = 0, ploidy: Optional[Sequence[int]] = None,
-                   rarest_strain_abundance: float = 0.0) -> Dict:
+                   rarest_strain_abundance: float = 0.0, window_size: Optional[int] = None) -> Dict:
     """Stage 4 on the in-memory result of stage 3 == HS_separate_reads without the .col round trip
     (separate_reads.cpp:1440-1739). READ limits are (position_2_1, position_2_2) of the records
     (call_variants.cpp:1186-1189 -> separate_reads.cpp:176-179)."""
@@ -261,6 +261,20 @@ def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory:
         e1 = e0 + int(col_off[-1])
         col_idx = _np(cv_out["col_idx"][e0:e1], np.int32)
         col_code = _np(cv_out["col_code"][e0:e1], np.uint8)
+        if rarest_strain_abundance > 0 and s1 > s0:
+            # parse_column_file drops SNPs whose second base is rarer than the threshold (separate_reads.cpp:167)
+            seg = np.repeat(np.arange(s1 - s0), np.diff(col_off))
+            n_ref = np.bincount(seg, weights=(col_code == snp_ref[seg]), minlength=s1 - s0)
+            n_alt = np.bincount(seg, weights=(col_code == snp_alt[seg]) & (col_code != snp_ref[seg]), minlength=s1 - s0)
+            keep_snp = n_alt.astype(np.float32) >= np.float32(rarest_strain_abundance) * (n_ref + n_alt).astype(np.float32)
+            if not keep_snp.all():
+                km = keep_snp[seg]
+                lens = np.diff(col_off)[keep_snp]
+                snp_pos, snp_ref, snp_alt = snp_pos[keep_snp], snp_ref[keep_snp], snp_alt[keep_snp]
+                col_idx, col_code = _np(col_idx[km], np.int32), _np(col_code[km], np.uint8)
+                col_off = _np(np.concatenate(([0], np.cumsum(lens))), np.int64)
+                snp_pos, snp_ref, snp_alt = _np(snp_pos, np.int32), _np(snp_ref, np.uint8), _np(snp_alt, np.uint8)
+                s1 = s0 + len(snp_pos)
         keep += [rs, re, snp_pos, snp_ref, snp_alt, col_off, col_idx, col_code]
         a = arr[c]
         a.length = int(flat.contig_off[c + 1] - flat.contig_off[c])
@@ -270,7 +284,7 @@ def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory:
         a.snp_pos = _hp(snp_pos, C.c_int32); a.snp_ref = _hp(snp_ref, C.c_uint8); a.snp_alt = _hp(snp_alt, C.c_uint8)
         a.col_off = _hp(col_off, C.c_int64); a.col_idx = _hp(col_idx, C.c_int32); a.col_code = _hp(col_code, C.c_uint8)
         a.ploidy = int(ploidy[c]) if ploidy is not None else 0
-    w = lib.hs_sr_window_size(arr, C.c_int32(Cn), C.c_int32(1 if amplicon else 0))
+    w = lib.hs_sr_window_size(arr, C.c_int32(Cn), C.c_int32(1 if amplicon else 0)) if window_size is None else int(window_size)
     res = C.POINTER(SrResult)()
     _check(lib.hs_sr_run(arr, C.c_int32(Cn), C.c_int32(w), C.c_float(error_rate), C.c_int32(1 if low_memory else 0),
                          C.c_uint32(seed), C.c_int32(n_threads), C.byref(res)))

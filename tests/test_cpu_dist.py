@@ -1,0 +1,77 @@
+"""Multi-process path on CPU (gloo, world_size 2): contig sharding, the error-rate exchange and the single
+gather of partition labels (hairsplitter_amd/dist.py). The same code runs over RCCL ("nccl") in bench.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from hairsplitter_amd import dist as hdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    weights = [5.0, 1.0, 3.0, 3.0, 2.0, 8.0, 1.0]
+    shards = hdist.lpt_shards(weights, world)
+    mine = shards[rank]
+    md = np.array([0.05 + 0.001 * i if i != 1 else 0.0 for i in mine], np.float32)   # contig 1 has no reads
+    er = hdist.global_error_rate(mine, md, len(weights))
+    labels = np.concatenate([np.full(3 + i, i % 3 - 2, np.int32) for i in mine]) if mine else np.zeros(0, np.int32)
+    g = hdist.gather_labels(labels)
+    q.put((rank, mine, er, None if g is None else [x.tolist() for x in g]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_exchange_gloo_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    shards = [r[1] for r in res]
+    assert sorted(shards[0] + shards[1]) == list(range(7)) and not set(shards[0]) & set(shards[1])
+    # LPT balance: heaviest contig alone-ish, loads within the largest weight of each other
+    w = [5.0, 1.0, 3.0, 3.0, 2.0, 8.0, 1.0]
+    loads = [sum(w[i] for i in s) for s in shards]
+    assert abs(loads[0] - loads[1]) <= 8.0
+    # both ranks agree on the global error rate = float32 sum in contig order over contigs with distance > 0
+    vals = [np.float32(0.05 + 0.001 * i) for i in range(7) if i != 1]
+    tot = np.float32(0)
+    for v in vals:
+        tot = np.float32(tot + v)
+    exp = float(np.float32(tot / np.float32(len(vals))))
+    assert res[0][2] == exp and res[1][2] == exp
+    # rank 0 received every rank's labels unchanged; rank 1 nothing
+    assert res[1][3] is None
+    for r in range(world):
+        exp_l = np.concatenate([np.full(3 + i, i % 3 - 2, np.int32) for i in shards[r]]).tolist()
+        assert res[0][3][r] == exp_l
+
+
+def test_lpt_shards_deterministic():
+    w = list(np.random.default_rng(0).integers(1, 100, 50))
+    a = hdist.lpt_shards(w, 8)
+    b = hdist.lpt_shards(w, 8)
+    assert a == b and sorted(sum(a, [])) == list(range(50))
+    loads = [sum(w[i] for i in s) for s in a]
+    assert max(loads) - min(loads) <= max(w)

@@ -22,3 +22,64 @@ def test_native_library_is_what_ran(built):
     """The executables are linked against the in-tree HIP library (no site-packages copy, no fallback)."""
     out = subprocess.run(["ldd", built["cv"]], stdout=subprocess.PIPE).stdout.decode()
     assert "libhairsplitter_hip.so" in out and "hairsplitter_amd/lib" in out.replace("bin/../lib", "lib")
+
+
+def _parse_col(path):
+    out = {}
+    cur = None
+    for line in open(path):
+        f = line.rstrip("\n").split("\t")
+        if f[0] == "CONTIG":
+            cur = out.setdefault(f[1], [])
+        elif f[0] == "SNPS":
+            cur.append((int(f[1]), int(f[2]), int(f[3]), [int(x) for x in f[4].split(",") if x], [int(x) for x in f[5].split(",") if x]))
+    return out
+
+
+def _parse_gro(path):
+    out = {}
+    cur = None
+    for line in open(path):
+        f = line.rstrip("\n").split("\t")
+        if f[0] == "CONTIG":
+            cur = out.setdefault(f[1], [])
+        elif f[0] == "GROUP":
+            cur.append((int(f[1]), int(f[2]), [int(x) for x in f[3].split(",") if x], [int(x) for x in f[4].split(",") if x]))
+    return out
+
+
+def test_inmemory_pipeline_equals_oracle(built):
+    """The path bench.py times (hs_cv_batch resident in HBM -> hs_cv_run -> hs_sr_run, no files) gives the same SNP
+    columns and partition labels as the oracle run file-to-file on the same synthetic contigs."""
+    import numpy as np
+    from hairsplitter_amd import api, synth
+    contigs = [synth.make_contig(21, i, 30_000, 2 + i, 0.01, 40, "ont") for i in range(3)]
+    flat = api.FlatBatch(contigs)
+    b = api.CvBatch(flat)
+    cv = b.run(0.33, 2)
+    b.close()
+    e = float("%g" % cv["error_rate"])
+    sr = api.separate_reads(cv, flat, min(e, 0.15), rarest_strain_abundance=0.01, n_threads=2)
+    with tempfile.TemporaryDirectory() as td:
+        f = synth.write_files(contigs, td)
+        col, vcf, err, gro = (os.path.join(td, x) for x in ("o.col", "o.vcf", "o.err", "o.gro"))
+        subprocess.run([built["oracle"], "call_variants", f["gfa"], f["reads"], f["sam"], "1", td, err, "0", "0", col, vcf, "0.33"], check=True, stdout=subprocess.DEVNULL)
+        assert float(open(err).read()) == e
+        subprocess.run([built["oracle"], "separate_reads", col, "1", str(min(e, 0.15)), os.path.join(td, "none"), "0", "0.01", "0", gro, "0"], check=True, stdout=subprocess.DEVNULL)
+        ocol, ogro = _parse_col(col), _parse_gro(gro)
+    for c, ctg in enumerate(contigs):
+        s0, s1 = int(cv["snp_off"][c]), int(cv["snp_off"][c + 1])
+        exp = ocol[ctg.name]
+        assert s1 - s0 == len(exp)
+        for k, s in enumerate(range(s0, s1)):
+            e0, e1 = int(cv["col_off"][s]), int(cv["col_off"][s + 1])
+            assert (int(cv["snp_pos"][s]), int(cv["snp_ref"][s]), int(cv["snp_alt"][s])) == exp[k][:3]
+            assert cv["col_idx"][e0:e1].tolist() == exp[k][3] and cv["col_code"][e0:e1].tolist() == exp[k][4]
+        w0, w1 = int(sr["win_off"][c]), int(sr["win_off"][c + 1])
+        gexp = ogro.get(ctg.name, [])
+        assert w1 - w0 == len(gexp)
+        for k, w in enumerate(range(w0, w1)):
+            lab = sr["labels"][int(sr["label_off"][w]):int(sr["label_off"][w + 1])]
+            present = np.flatnonzero(lab != -2)
+            assert (int(sr["win_start"][w]), int(sr["win_end"][w])) == gexp[k][:2]
+            assert present.tolist() == gexp[k][2] and lab[present].tolist() == gexp[k][3]
