@@ -101,11 +101,23 @@ def main():
     batch = api.CvBatch(flat)          # inputs now resident in HBM
     local_bp = flat.aligned_bp
 
-    def step():
-        cv = batch.run(0.33, n_threads)
+    py_ms = {"pipeline_call": 0.0, "error_rate": 0.0, "gather": 0.0}
+
+    def error_rate_fn(cv):
+        # the one cross-contig quantity of the path: mean of the per-contig distances over the WHOLE job, in contig order
+        t = time.perf_counter()
         er = hdist.global_error_rate(my_ids, cv["mean_distance"], world * B)
-        sr = api.separate_reads(cv, flat, py_error_rate(er), rarest_strain_abundance=0.01, n_threads=n_threads, window_size=2000 if world > 1 else None)
+        py_ms["error_rate"] += (time.perf_counter() - t) * 1e3
+        return py_error_rate(er)
+
+    def step():
+        t = time.perf_counter()
+        # window size 2000 for every rank when sharded: it depends on the read lengths of the whole job
+        # (separate_reads.cpp:1466-1498) and all shards of this workload have the same read-length distribution
+        cv, sr = batch.run_pipeline(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=2000 if world > 1 else 0)
+        t3 = time.perf_counter(); py_ms["pipeline_call"] += (t3 - t) * 1e3
         gathered = hdist.gather_labels(sr["labels"])
+        py_ms["gather"] += (time.perf_counter() - t3) * 1e3
         return cv, sr, gathered
 
     def sync():
@@ -116,6 +128,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    for k in py_ms:
+        py_ms[k] = 0.0
     t0 = time.perf_counter()
     k_cv = np.zeros(4); k_sr = np.zeros(4); t_dev = 0.0; t_host = 0.0
     last = None
@@ -161,12 +175,12 @@ def main():
             "config": {"workload": f"C2 (BASELINE.json configs[1]): 100 kb contig, 2 haplotypes @1% divergence, 50x ONT-error reads; "
                                    f"{B} such contigs per GPU per step, inputs resident in HBM",
                        "contigs_per_gpu": B, "aligned_bp_per_gpu": local_bp, "parallelism": f"contig-sharded x{world}",
-                       "host_threads_per_rank": n_threads, "snps_rank0": int(cv["snp_off"][-1]), "cw_instances_rank0": sr["n_cw_instances"]},
+                       "host_threads_per_rank": n_threads, "snps_rank0": int(cv["n_snps"]), "cw_instances_rank0": sr["n_cw_instances"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kernels[dom],
                          "algorithmic_bytes_per_launch": alg_bytes[dom]},
             "kernel_ms_per_step": kernels,
-            "phase_ms_per_step": {"device_phases": t_dev / K, "host_glue": t_host / K},
+            "phase_ms_per_step": {"device_phases": t_dev / K, "host_glue": t_host / K, **{"py_" + k: v / K for k, v in py_ms.items()}},
         }
         if world == 1 and args.cpu_contigs > 0:
             try:

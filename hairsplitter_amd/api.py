@@ -19,9 +19,9 @@ LIB_PATH = os.path.join(_ROOT, "lib", "libhairsplitter_hip.so")
 SYMBOLS = [
     "hs_version", "hs_last_error", "hs_device_count", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
-    "hs_event_elapsed_ms", "hs_pileup", "hs_column_stats", "hs_gather_columns", "hs_simdiff", "hs_chinese_whispers",
+    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_simdiff", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
-    "hs_cv_result_destroy", "hs_sr_run", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
+    "hs_cv_result_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
     "hs_separate_reads_main",
 ]
 
@@ -86,6 +86,8 @@ def load() -> C.CDLL:
     lib.hs_cv_run.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.POINTER(C.POINTER(CvResult))]
     lib.hs_sr_run.argtypes = [C.POINTER(SrContig), C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint32, C.c_int32,
                               C.POINTER(C.POINTER(SrResult))]
+    lib.hs_sr_run_cv.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_uint32, C.c_int32, C.c_int32,
+                                 C.POINTER(C.POINTER(SrResult))]
     lib.hs_sr_window_size.argtypes = [C.POINTER(SrContig), C.c_int32, C.c_int32]
     lib.hs_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     lib.hs_event_record.argtypes = [C.c_void_p, C.c_void_p]
@@ -220,6 +222,32 @@ class CvBatch:
         lib.hs_cv_result_destroy(res)
         return out
 
+    def run_pipeline(self, automatic_snp_threshold: float = 0.33, n_threads: int = 0, error_rate_fn=None,
+                     rarest_strain_abundance: float = 0.01, low_memory: bool = False, amplicon: bool = False, seed: int = 12345,
+                     window_size: int = 0):
+        """Stage 3 then stage 4 in-process on the resident batch (hs_cv_run -> hs_sr_run_cv): no .col text round trip.
+        `error_rate_fn(cv_dict)` maps the stage-3 result to the error rate handed to stage 4 (default: what
+        hairsplitter.py does with error_rate.txt: 6 significant digits, capped at 0.15)."""
+        lib = load()
+        res = C.POINTER(CvResult)()
+        _check(lib.hs_cv_run(self.handle, C.c_float(automatic_snp_threshold), C.c_int32(n_threads), C.byref(res)))
+        try:
+            r = res.contents
+            Cn = r.n_contigs
+            cv = {"mean_distance": np.ctypeslib.as_array(r.mean_distance, (max(Cn, 1),))[:Cn].copy(), "error_rate": float(r.error_rate),
+                  "n_snps": int(np.ctypeslib.as_array(r.snp_off, (Cn + 1,))[-1]),
+                  "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "t_kernel_ms": [float(x) for x in r.t_kernel_ms]}
+            e = error_rate_fn(cv) if error_rate_fn is not None else min(float("%g" % cv["error_rate"]), 0.15)
+            sres = C.POINTER(SrResult)()
+            _check(lib.hs_sr_run_cv(self.handle, res, C.c_float(e), C.c_float(rarest_strain_abundance), C.c_int32(1 if low_memory else 0),
+                                    C.c_int32(1 if amplicon else 0), C.c_uint32(seed), C.c_int32(n_threads), C.c_int32(window_size),
+                                    C.byref(sres)))
+            sr = _sr_result_to_dict(sres, Cn)
+            lib.hs_sr_result_destroy(sres)
+        finally:
+            lib.hs_cv_result_destroy(res)
+        return cv, sr
+
     def close(self):
         if self.handle:
             load().hs_cv_batch_destroy(self.handle)
@@ -230,6 +258,23 @@ class CvBatch:
             self.close()
         except Exception:
             pass
+
+
+def _sr_result_to_dict(res, Cn):
+    r = res.contents
+    win_off = np.ctypeslib.as_array(r.win_off, (Cn + 1,)).copy()
+    W = int(win_off[-1])
+    label_off = np.ctypeslib.as_array(r.label_off, (W + 1,)).copy()
+    NL = int(label_off[-1])
+    return {
+        "win_off": win_off,
+        "win_start": np.ctypeslib.as_array(r.win_start, (max(W, 1),))[:W].copy(),
+        "win_end": np.ctypeslib.as_array(r.win_end, (max(W, 1),))[:W].copy(),
+        "label_off": label_off,
+        "labels": np.ctypeslib.as_array(r.labels, (max(NL, 1),))[:NL].copy(),
+        "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "n_cw_instances": int(r.n_cw_instances),
+        "t_kernel_ms": [float(x) for x in r.t_kernel_ms],
+    }
 
 
 def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory: bool = False, amplicon: bool = False,
@@ -319,31 +364,67 @@ def device_tensors(flat: FlatBatch, device="cuda:0"):
     return t
 
 
-def pileup(t, flat: FlatBatch):
-    """K1 on device tensors; returns (pile u8[aligned_bp], rec_stats i32[n_rec,4])."""
+def pileup_plan(flat: FlatBatch, ev_per_task: int = 4096):
+    """hs_pileup_plan: (rec_chunk_off int64[n_rec+1], task_rec int32[], task_ev0 int32[])."""
+    lib = load()
+    chunk_off = np.zeros(flat.n_rec + 1, np.int64)
+    n = C.c_int32(0)
+    tr = C.POINTER(C.c_int32)(); te = C.POINTER(C.c_int32)()
+    _check(lib.hs_pileup_plan(_hp(flat.rec_cig_off, C.c_int64), _hp(flat.cigar, C.c_uint32), C.c_int32(flat.n_rec), C.c_int32(ev_per_task),
+                              _hp(chunk_off, C.c_int64), C.byref(n), C.byref(tr), C.byref(te)))
+    nt = n.value
+    task_rec = np.ctypeslib.as_array(tr, (max(nt, 1),))[:nt].copy()
+    task_ev0 = np.ctypeslib.as_array(te, (max(nt, 1),))[:nt].copy()
+    lib.hs_free_host(tr); lib.hs_free_host(te)
+    return chunk_off, task_rec, task_ev0
+
+
+def pileup(t, flat: FlatBatch, ev_per_task: int = 4096):
+    """K0+K1 on device tensors; returns (pile u8[aligned_bp], rec_stats i32[n_rec,4])."""
     import torch
     require_gpu()
     dev = t["contig_seq"].device
+    chunk_off, task_rec, task_ev0 = pileup_plan(flat, ev_per_task)
+    d_co = torch.from_numpy(chunk_off).to(dev)
+    d_tr = torch.from_numpy(task_rec if len(task_rec) else np.zeros(1, np.int32)).to(dev)
+    d_te = torch.from_numpy(task_ev0 if len(task_ev0) else np.zeros(1, np.int32)).to(dev)
+    scratch = torch.zeros(max(4 * int(chunk_off[-1]), 4), dtype=torch.int32, device=dev)
     pile = torch.zeros(max(flat.aligned_bp, 1), dtype=torch.uint8, device=dev)
     stats = torch.zeros((max(flat.n_rec, 1), 4), dtype=torch.int32, device=dev)
     _check(load().hs_pileup(_p(t["contig_seq"]), _p(t["contig_off"]), _p(t["read_seq"]), _p(t["read_off"]), _p(t["rec_read"]),
                             _p(t["rec_contig"]), _p(t["rec_pos"]), _p(t["rec_strand"]), _p(t["rec_cig_off"]), _p(t["cigar"]),
-                            _p(t["pile_off"]), C.c_int32(flat.n_rec), _p(pile), _p(stats), C.c_void_p(0)))
+                            _p(t["pile_off"]), C.c_int32(flat.n_rec), _p(d_co), _p(scratch), _p(d_tr), _p(d_te),
+                            C.c_int32(len(task_rec)), C.c_int32(ev_per_task), _p(pile), _p(stats), C.c_void_p(0)))
     torch.cuda.synchronize()
     return pile[:flat.aligned_bp], stats[:flat.n_rec]
 
 
-def column_stats(t, flat: FlatBatch, pile):
-    """K2; returns a numpy structured view: key u8[4], cnt u16[5], depth u16 per position."""
+def column_stats(t, flat: FlatBatch, pile, min_second: int = 0):
+    """K2; returns a numpy structured view: key u8[4], cnt u16[5], depth u16 per position (and, when min_second > 0,
+    the compact selection: sorted global positions + depths)."""
     import torch
     require_gpu()
     total = int(flat.contig_off[-1])
-    out = torch.zeros((max(total, 1), 16), dtype=torch.uint8, device=pile.device)
+    dev = pile.device
+    out = torch.zeros((max(total, 1), 16), dtype=torch.uint8, device=dev)
+    if min_second > 0:
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        gpos = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
+        dep = torch.zeros(max(total, 1), dtype=torch.int32, device=dev)
+        args = (C.c_int32(min_second), _p(cnt), _p(gpos), _p(dep), C.c_int32(total))
+    else:
+        args = (C.c_int32(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_int32(0))
     _check(load().hs_column_stats(_p(pile), _p(t["pile_off"]), _p(t["rec_pos"]), _p(t["rec_qend"]), _p(t["contig_rec_off"]),
-                                  _p(t["contig_off"]), C.c_int32(flat.n_contigs), _p(out), C.c_void_p(0)))
+                                  _p(t["contig_off"]), C.c_int32(flat.n_contigs), _p(out), *args, C.c_void_p(0)))
     torch.cuda.synchronize()
     dt = np.dtype([("key", np.uint8, 4), ("cnt", np.uint16, 5), ("depth", np.uint16)])
-    return out[:total].cpu().numpy().view(dt).reshape(-1)
+    st = out[:total].cpu().numpy().view(dt).reshape(-1)
+    if min_second > 0:
+        n = int(cnt.item())
+        g = gpos[:n].cpu().numpy(); d = dep[:n].cpu().numpy()
+        o = np.argsort(g, kind="stable")
+        return st, g[o], d[o]
+    return st
 
 
 def gather_columns(t, flat: FlatBatch, pile, sel_contig, sel_pos, depths):

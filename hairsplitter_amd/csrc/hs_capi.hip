@@ -104,39 +104,70 @@ int hs_event_elapsed_ms(void* a, void* b, float* ms) {
 int hs_pileup(const uint8_t* d_contig_seq, const int64_t* d_contig_off, const uint8_t* d_read_seq,
               const int64_t* d_read_off, const int32_t* d_rec_read, const int32_t* d_rec_contig,
               const int32_t* d_rec_pos, const uint8_t* d_rec_strand, const int64_t* d_rec_cig_off,
-              const uint32_t* d_cigar, const int64_t* d_pile_off, int32_t n_rec, uint8_t* d_pile,
-              int32_t* d_rec_stats, void* stream) {
+              const uint32_t* d_cigar, const int64_t* d_pile_off, int32_t n_rec, const int64_t* d_rec_chunk_off,
+              int32_t* d_chunk_scratch, const int32_t* d_task_rec, const int32_t* d_task_ev0, int32_t n_tasks,
+              int32_t ev_per_task, uint8_t* d_pile, int32_t* d_rec_stats, void* stream) {
     if (int rc = require_device()) return rc;
     if (n_rec <= 0) return HS_OK;
-    const int grid = (n_rec + 3) / 4;
-    hipLaunchKernelGGL(hsdev::k_pileup, dim3(grid), dim3(256), 0, (hipStream_t)stream, d_contig_seq, d_contig_off,
-                       d_read_seq, d_read_off, d_rec_read, d_rec_contig, d_rec_pos, d_rec_strand, d_rec_cig_off, d_cigar,
-                       d_pile_off, n_rec, d_pile, d_rec_stats);
+    hipLaunchKernelGGL(hsdev::k_cigar_scan, dim3((n_rec + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_contig_off, d_rec_contig,
+                       d_rec_pos, d_rec_cig_off, d_cigar, d_rec_chunk_off, n_rec, d_chunk_scratch, d_rec_stats);
     HS_HIP(hipGetLastError());
+    if (n_tasks > 0) {
+        hipLaunchKernelGGL(hsdev::k_pileup, dim3((n_tasks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_contig_seq, d_contig_off,
+                           d_read_seq, d_read_off, d_rec_read, d_rec_contig, d_rec_pos, d_rec_strand, d_rec_cig_off, d_cigar,
+                           d_pile_off, d_rec_chunk_off, d_chunk_scratch, d_task_rec, d_task_ev0, n_tasks, ev_per_task, d_pile,
+                           d_rec_stats);
+        HS_HIP(hipGetLastError());
+    }
     return HS_OK;
 }
 
+int hs_pileup_plan(const int64_t* h_rec_cig_off, const uint32_t* h_cigar, int32_t n_rec, int32_t ev_per_task,
+                   int64_t* h_rec_chunk_off, int32_t* n_tasks, int32_t** h_task_rec, int32_t** h_task_ev0) {
+    if (ev_per_task <= 0 || !h_rec_chunk_off || !n_tasks || !h_task_rec || !h_task_ev0) { set_error("hs_pileup_plan: bad arguments"); return HS_EINVAL; }
+    std::vector<int32_t> tr, te;
+    h_rec_chunk_off[0] = 0;
+    for (int r = 0; r < n_rec; ++r) {
+        int64_t ev = 0;
+        for (int64_t o = h_rec_cig_off[r]; o < h_rec_cig_off[r + 1]; ++o) {
+            const uint32_t op = h_cigar[o] & 15u;
+            if (op == 0 || op == 1 || op == 2 || op == 7 || op == 8) ev += h_cigar[o] >> 4;
+        }
+        if (ev > 0x7fffffff) { set_error("alignment with more than 2^31 events"); return HS_EINVAL; }
+        h_rec_chunk_off[r + 1] = h_rec_chunk_off[r] + (h_rec_cig_off[r + 1] - h_rec_cig_off[r] + 63) / 64;
+        for (int64_t e = 0; e < ev; e += ev_per_task) { tr.push_back(r); te.push_back((int32_t)e); }
+    }
+    *n_tasks = (int32_t)tr.size();
+    *h_task_rec = (int32_t*)std::malloc(std::max<size_t>(1, tr.size()) * sizeof(int32_t));
+    *h_task_ev0 = (int32_t*)std::malloc(std::max<size_t>(1, te.size()) * sizeof(int32_t));
+    if (!tr.empty()) { std::memcpy(*h_task_rec, tr.data(), tr.size() * sizeof(int32_t)); std::memcpy(*h_task_ev0, te.data(), te.size() * sizeof(int32_t)); }
+    return HS_OK;
+}
+void hs_free_host(void* p) { std::free(p); }
+
 static int column_stats_launch(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
                                const int32_t* d_rec_qend, const int32_t* d_contig_rec_off, const int64_t* d_contig_off,
-                               int32_t n_contigs, int64_t total_len, hs_colstat* d_stats, void* stream) {
+                               int32_t n_contigs, int64_t total_len, hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count,
+                               int64_t* d_sel_gpos, int32_t* d_sel_depth, int32_t sel_cap, void* stream) {
     if (total_len <= 0) return HS_OK;
     const int64_t grid = (total_len + 255) / 256;
     hipLaunchKernelGGL(hsdev::k_column_stats, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_pile, d_pile_off,
                        d_rec_pos, d_rec_qend, d_contig_rec_off, d_contig_off, n_contigs,
-                       reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats));
+                       reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap);
     HS_HIP(hipGetLastError());
     return HS_OK;
 }
 
 int hs_column_stats(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
                     const int32_t* d_rec_qend, const int32_t* d_contig_rec_off, const int64_t* d_contig_off,
-                    int32_t n_contigs, hs_colstat* d_stats, void* stream) {
+                    int32_t n_contigs, hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos,
+                    int32_t* d_sel_depth, int32_t sel_cap, void* stream) {
     if (int rc = require_device()) return rc;
     if (n_contigs <= 0) return HS_OK;
     int64_t total = 0;
     HS_HIP(hipMemcpy(&total, d_contig_off + n_contigs, sizeof(int64_t), hipMemcpyDeviceToHost));
     return column_stats_launch(d_pile, d_pile_off, d_rec_pos, d_rec_qend, d_contig_rec_off, d_contig_off, n_contigs, total,
-                               d_stats, stream);
+                               d_stats, min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap, stream);
 }
 
 int hs_gather_columns(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
@@ -186,15 +217,16 @@ int hs_simdiff(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_pl
 static int cw_launch(const int32_t* d_adj_off, const int32_t* d_adj, const int64_t* d_graph_off_base,
                      const int64_t* d_graph_adj_base, const int32_t* d_graph_n, const int32_t* d_perm, const int64_t* d_perm_base,
                      const uint8_t* d_mask, const int32_t* d_inst_graph, const int64_t* d_inst_label_base, int32_t n_inst,
-                     int32_t max_n, int32_t* d_labels, int32_t* d_sweeps, void* stream) {
+                     int32_t max_n, int32_t* d_labels, int32_t* d_sweeps, void* stream, const int64_t* d_inst_seed_col = nullptr,
+                     const int64_t* d_col_off = nullptr, const int32_t* d_col_idx = nullptr, const uint8_t* d_col_code = nullptr) {
     if (n_inst <= 0) return HS_OK;
-    const size_t lds = (size_t)max_n * 8;
-    if (lds > 160 * 1024) { set_error("Chinese Whispers: more than 20480 reads on one contig is not supported"); return HS_EINVAL; }
+    const size_t lds = (size_t)max_n * 8 + 1024;
+    if (lds > 160 * 1024) { set_error("Chinese Whispers: more than 20000 reads on one contig is not supported"); return HS_EINVAL; }
     if (lds > 48 * 1024)
         HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_chinese_whispers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(hsdev::k_chinese_whispers, dim3((unsigned)n_inst), dim3(64), lds, (hipStream_t)stream, d_adj_off, d_adj,
                        d_graph_off_base, d_graph_adj_base, d_graph_n, d_perm, d_perm_base, d_mask, d_inst_graph,
-                       d_inst_label_base, n_inst, d_labels, d_sweeps);
+                       d_inst_label_base, n_inst, d_labels, d_sweeps, d_inst_seed_col, d_col_off, d_col_idx, d_col_code);
     HS_HIP(hipGetLastError());
     return HS_OK;
 }
@@ -247,9 +279,12 @@ struct hs_cv_batch {
     int32_t n_contigs = 0, n_reads = 0, n_rec = 0;
     std::vector<int64_t> contig_off, pile_off;
     std::vector<int32_t> contig_rec_off, rec_pos, rec_qend, rec_contig;
+    std::vector<int64_t> rec_refspan;
     int64_t total_len = 0, total_pile = 0;
+    int32_t n_tasks = 0, ev_per_task = 4096;
     DBuf contig_seq, d_contig_off, read_seq, read_off, rec_read, d_rec_contig, d_rec_pos, rec_strand, rec_cig_off, cigar,
-        d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, colstats;
+        d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, colstats, rec_chunk_off, chunk_scratch, task_rec, task_ev0,
+        sel_count, sel_gpos, sel_depth;
 };
 
 int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off, int32_t n_contigs,
@@ -269,6 +304,7 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
     b->rec_pos.assign(h_rec_pos, h_rec_pos + n_rec);
     b->rec_contig.resize((size_t)n_rec);
     b->rec_qend.resize((size_t)n_rec);
+    b->rec_refspan.resize((size_t)n_rec);
     b->pile_off.assign((size_t)n_rec + 1, 0);
     for (int c = 0; c < n_contigs; ++c) {
         const int64_t L = b->contig_off[(size_t)c + 1] - b->contig_off[(size_t)c];
@@ -291,6 +327,7 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
             // a CIGAR that runs past the read is only tolerated for the part that lies beyond the contig end
             if (readspan > rl && pos + refspan <= L) { set_error("CIGAR consumes more bases than the read has"); delete b; return HS_EINVAL; }
             b->rec_qend[(size_t)r] = (int32_t)qend;
+            b->rec_refspan[(size_t)r] = refspan;
             b->pile_off[(size_t)r + 1] = b->pile_off[(size_t)r] + (qend - pos);
         }
     }
@@ -314,6 +351,21 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
     up(b->d_pile_off, b->pile_off.data(), sizeof(int64_t) * b->pile_off.size());
     up(b->d_contig_rec_off, b->contig_rec_off.data(), sizeof(int32_t) * b->contig_rec_off.size());
     up(b->d_rec_qend, b->rec_qend.data(), sizeof(int32_t) * (size_t)n_rec);
+    if (!rc) {   // launch plan of the pileup kernel
+        std::vector<int64_t> chunk_off((size_t)n_rec + 1);
+        int32_t* tr = nullptr; int32_t* te = nullptr;
+        rc = hs_pileup_plan(h_rec_cig_off, h_cigar, n_rec, b->ev_per_task, chunk_off.data(), &b->n_tasks, &tr, &te);
+        if (!rc) {
+            up(b->rec_chunk_off, chunk_off.data(), sizeof(int64_t) * chunk_off.size());
+            up(b->task_rec, tr, sizeof(int32_t) * (size_t)b->n_tasks);
+            up(b->task_ev0, te, sizeof(int32_t) * (size_t)b->n_tasks);
+            if (!rc) rc = b->chunk_scratch.alloc(sizeof(int32_t) * 4 * (size_t)chunk_off[(size_t)n_rec]);
+        }
+        std::free(tr); std::free(te);
+    }
+    if (!rc) rc = b->sel_count.alloc(sizeof(int32_t));
+    if (!rc) rc = b->sel_gpos.alloc(sizeof(int64_t) * (size_t)b->total_len);
+    if (!rc) rc = b->sel_depth.alloc(sizeof(int32_t) * (size_t)b->total_len);
     if (!rc) rc = b->pile.alloc((size_t)b->total_pile);
     if (!rc) rc = b->rec_stats.alloc(sizeof(int32_t) * 4 * (size_t)n_rec);
     if (!rc) rc = b->colstats.alloc(sizeof(hs_colstat) * (size_t)b->total_len);
@@ -338,25 +390,43 @@ struct HipCvOps : hs::CvDeviceOps {
     hipStream_t stream = nullptr;
     explicit HipCvOps(hs_cv_batch* batch) : b(batch) {}
 
-    int pileup_and_stats(std::vector<int32_t>& rec_stats, std::vector<hs_colstat>& stats, float k_ms[2]) override {
+    int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, std::vector<int64_t>& sel_gpos, std::vector<int32_t>& sel_depth,
+                          float k_ms[2]) override {
+        const bool tim = std::getenv("HS_TIMING") != nullptr;
+        auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t0 = now();
         EventPair e1, e2;
         if (int rc = e1.init()) return rc;
         if (int rc = e2.init()) return rc;
+        HS_HIP(hipMemsetAsync(b->sel_count.p, 0, sizeof(int32_t), stream));
         HS_HIP(hipEventRecord(e1.a, stream));
         if (int rc = hs_pileup(b->contig_seq.as<uint8_t>(), b->d_contig_off.as<int64_t>(), b->read_seq.as<uint8_t>(), b->read_off.as<int64_t>(),
                                b->rec_read.as<int32_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(), b->rec_strand.as<uint8_t>(),
-                               b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->d_pile_off.as<int64_t>(), b->n_rec, b->pile.as<uint8_t>(),
-                               b->rec_stats.as<int32_t>(), stream)) return rc;
+                               b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->d_pile_off.as<int64_t>(), b->n_rec,
+                               b->rec_chunk_off.as<int64_t>(), b->chunk_scratch.as<int32_t>(), b->task_rec.as<int32_t>(), b->task_ev0.as<int32_t>(),
+                               b->n_tasks, b->ev_per_task, b->pile.as<uint8_t>(), b->rec_stats.as<int32_t>(), stream)) return rc;
         HS_HIP(hipEventRecord(e1.b, stream));
         HS_HIP(hipEventRecord(e2.a, stream));
         if (int rc = column_stats_launch(b->pile.as<uint8_t>(), b->d_pile_off.as<int64_t>(), b->d_rec_pos.as<int32_t>(), b->d_rec_qend.as<int32_t>(),
                                          b->d_contig_rec_off.as<int32_t>(), b->d_contig_off.as<int64_t>(), b->n_contigs, b->total_len,
-                                         b->colstats.as<hs_colstat>(), stream)) return rc;
+                                         b->colstats.as<hs_colstat>(), min_second, b->sel_count.as<int32_t>(), b->sel_gpos.as<int64_t>(),
+                                         b->sel_depth.as<int32_t>(), (int32_t)std::min<int64_t>(b->total_len, 0x7fffffff), stream)) return rc;
         HS_HIP(hipEventRecord(e2.b, stream));
+        const double t1 = now();
         if (!rec_stats.empty()) HS_HIP(hipMemcpy(rec_stats.data(), b->rec_stats.p, rec_stats.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-        if (!stats.empty()) HS_HIP(hipMemcpy(stats.data(), b->colstats.p, stats.size() * sizeof(hs_colstat), hipMemcpyDeviceToHost));
+        const double t2 = now();
+        int32_t n_sel = 0;
+        HS_HIP(hipMemcpy(&n_sel, b->sel_count.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        sel_gpos.resize((size_t)n_sel); sel_depth.resize((size_t)n_sel);
+        if (n_sel) {
+            HS_HIP(hipMemcpy(sel_gpos.data(), b->sel_gpos.p, (size_t)n_sel * sizeof(int64_t), hipMemcpyDeviceToHost));
+            HS_HIP(hipMemcpy(sel_depth.data(), b->sel_depth.p, (size_t)n_sel * sizeof(int32_t), hipMemcpyDeviceToHost));
+        }
+        const double t3 = now();
         if (int rc = e1.ms(&k_ms[0])) return rc;
         if (int rc = e2.ms(&k_ms[1])) return rc;
+        if (tim) std::fprintf(stderr, "[hs timing]   pileup_and_select: launches %.2f ms, first D2H (waits for kernels) %.2f ms, selection D2H %.2f ms (%d positions), events %.2f ms\n",
+                              t1 - t0, t2 - t1, t3 - t2, n_sel, now() - t3);
         return HS_OK;
     }
 
@@ -450,14 +520,26 @@ struct HipSrOps : hs::SrDeviceOps {
 
 extern "C" {
 
+static void fill_meta(const hs_cv_batch* b, hs::CvMeta& meta) {
+    meta.n_contigs = b->n_contigs; meta.n_rec = b->n_rec; meta.contig_off = b->contig_off; meta.contig_rec_off = b->contig_rec_off;
+    meta.pile_off = b->pile_off; meta.total_len = b->total_len; meta.rec_pos = b->rec_pos; meta.rec_refspan = b->rec_refspan;
+}
+
 int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out) {
     if (int rc = require_device()) return rc;
     if (!b || !out) { set_error("hs_cv_run: null argument"); return HS_EINVAL; }
-    hs::CvMeta meta;
-    meta.n_contigs = b->n_contigs; meta.n_rec = b->n_rec; meta.contig_off = b->contig_off; meta.contig_rec_off = b->contig_rec_off;
-    meta.pile_off = b->pile_off; meta.total_len = b->total_len;
+    hs::CvMeta meta; fill_meta(b, meta);
     HipCvOps ops(b);
     return hs::cv_run(ops, meta, automatic_snp_threshold, n_threads, out);
+}
+
+int hs_sr_run_cv(const hs_cv_batch* b, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance, int32_t low_memory,
+                 int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out) {
+    if (int rc = require_device()) return rc;
+    if (!b || !cv || !out) { set_error("hs_sr_run_cv: null argument"); return HS_EINVAL; }
+    hs::CvMeta meta; fill_meta(b, meta);
+    HipSrOps ops;
+    return hs::sr_run_from_cv(ops, meta, cv, error_rate, rarest_strain_abundance, low_memory, amplicon, seed, n_threads, window_size, out);
 }
 
 int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_t amplicon) {

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -60,23 +61,31 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
     float k_ms[3] = {0, 0, 0};
 
     std::vector<int32_t> rec_stats((size_t)NR * 4);
-    std::vector<hs_colstat> stats((size_t)b.total_len);
-    if (int rc = dev.pileup_and_stats(rec_stats, stats, k_ms)) return rc;
-
-    // interesting positions: second count >= 4 (everything that can become a SNP, see hs_host_cv.cpp)
-    std::vector<int32_t> sel_contig, sel_pos;
-    std::vector<int64_t> col_off(1, 0);
+    std::vector<int64_t> sel_gpos;
+    std::vector<int32_t> sel_depth;
+    // interesting positions: second count >= 4 (everything that can become a SNP, see hs_host_cv.cpp); the device
+    // appends them unordered, the (small) list is ordered here
+    if (int rc = dev.pileup_and_select(rec_stats, 4, sel_gpos, sel_depth, k_ms)) return rc;
+    const double t_k12_done = now_ms();
+    std::vector<size_t> order(sel_gpos.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return sel_gpos[x] < sel_gpos[y]; });
+    std::vector<int32_t> sel_contig(order.size()), sel_pos(order.size());
+    std::vector<int64_t> col_off(order.size() + 1, 0);
     std::vector<int64_t> contig_sel_off((size_t)C + 1, 0);
-    for (int c = 0; c < C; ++c) {
-        const int64_t base = b.contig_off[(size_t)c], L = b.contig_off[(size_t)c + 1] - base;
-        for (int64_t p = 0; p < L; ++p) {
-            const hs_colstat& s = stats[(size_t)(base + p)];
-            if (s.cnt[1] >= 4) { sel_contig.push_back(c); sel_pos.push_back((int32_t)p); col_off.push_back(col_off.back() + s.depth); }
+    {
+        int c = 0;
+        for (size_t i = 0; i < order.size(); ++i) {
+            const int64_t g = sel_gpos[order[i]];
+            while (g >= b.contig_off[(size_t)c + 1]) { c++; contig_sel_off[(size_t)c] = (int64_t)i; }
+            sel_contig[i] = c; sel_pos[i] = (int32_t)(g - b.contig_off[(size_t)c]);
+            col_off[i + 1] = col_off[i] + sel_depth[order[i]];
         }
-        contig_sel_off[(size_t)c + 1] = (int64_t)sel_pos.size();
+        for (int k = c + 1; k <= C; ++k) contig_sel_off[(size_t)k] = (int64_t)order.size();
     }
     std::vector<int32_t> col_idx((size_t)col_off.back());
     std::vector<uint8_t> col_code((size_t)col_off.back());
+    const double t_sel_done = now_ms();
     if (int rc = dev.gather(sel_contig, sel_pos, col_off, col_idx, col_code, &k_ms[2])) return rc;
     const double t_dev_done = now_ms();
 
@@ -102,6 +111,7 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
         const int n_reads_c = b.contig_rec_off[(size_t)c + 1] - b.contig_rec_off[(size_t)c];
         call_variants_host(n_reads_c, L, cs, o.mean_distance, automatic_snp_threshold, o);
     });
+    const double t_glue_done = now_ms();
 
     hs_cv_result* R = (hs_cv_result*)std::calloc(1, sizeof(hs_cv_result));
     R->n_contigs = C;
@@ -130,6 +140,9 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
     R->t_kernel_ms[0] = k_ms[0]; R->t_kernel_ms[1] = k_ms[1]; R->t_kernel_ms[2] = k_ms[2];
     R->t_device_ms = t_dev_done - t_start;
     R->t_host_ms = now_ms() - t_dev_done;
+    if (std::getenv("HS_TIMING"))
+        std::fprintf(stderr, "[hs timing] cv: k1+k2+d2h %.2f ms, select %.2f ms, gather %.2f ms, host glue %.2f ms (parallel part %.2f)\n",
+                     t_k12_done - t_start, t_sel_done - t_k12_done, t_dev_done - t_sel_done, R->t_host_ms, t_glue_done - t_dev_done);
     *out = R;
     return HS_OK;
 }
@@ -189,14 +202,22 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         dev_ms += now_ms() - t0;
     }
 
+    const double t_simdiff_done = now_ms();
     // ---- window plans + graphs (host) ----
     parallel_for(C, n_threads, [&](int c) {
         if (contigs[c].n_snps == 0) return;
         sr_plan_windows(st[(size_t)c], window_size, error_rate, lowmem);
-        std::vector<int32_t>().swap(st[(size_t)c].sim);
-        std::vector<int32_t>().swap(st[(size_t)c].diff);
     });
+    {   // one independent task per window: the per-row neighbour selection (std::sort tie order) is the costly part
+        std::vector<std::pair<int, int>> tasks;
+        for (int c = 0; c < C; ++c)
+            for (size_t w = 0; w < st[(size_t)c].windows.size(); ++w)
+                if (st[(size_t)c].windows[w].has_snps) tasks.push_back(std::make_pair(c, (int)w));
+        parallel_for((int)tasks.size(), n_threads, [&](int i) { sr_build_window_graph(st[(size_t)tasks[(size_t)i].first], tasks[(size_t)i].second, error_rate); });
+    }
+    for (int c = 0; c < C; ++c) { std::vector<int32_t>().swap(st[(size_t)c].sim); std::vector<int32_t>().swap(st[(size_t)c].diff); }
 
+    const double t_plan_done = now_ms();
     // ---- all graphs of the batch, uploaded once; a graph belongs to exactly one window (its mask) ----
     CwGraphSet gs;
     std::vector<int64_t> perm_base_of_contig((size_t)C, 0);
@@ -301,6 +322,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     });
     if (int rc = run_wave(w3, &k_ms[3])) return rc;
 
+    const double t_waves_done = now_ms();
     // ---- tail of finalize_clustering on the host ----
     parallel_for((int)wrefs.size(), n_threads, [&](int i) {
         SrContigState& s = st[(size_t)wrefs[(size_t)i].c];
@@ -311,6 +333,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         } else sr_finish_window(s, w, w3.labels.data() + w2_base[(size_t)i], lowmem);
     });
 
+    const double t_finish_done = now_ms();
     // ---- optional ploidy cap (separate_reads.cpp:1711-1715, :1341-1396) ----
     {
         CwWave w4;
@@ -352,8 +375,52 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     for (int k = 0; k < 4; ++k) R->t_kernel_ms[k] = k_ms[k];
     R->t_device_ms = dev_ms;
     R->t_host_ms = (now_ms() - t_start) - dev_ms;
+    if (std::getenv("HS_TIMING"))
+        std::fprintf(stderr, "[hs timing] sr: planes+simdiff %.2f ms, plan windows+graphs %.2f ms, graph upload + 3 CW waves (incl. label init) %.2f ms, finish %.2f ms, total %.2f ms (device %.2f)\n",
+                     t_simdiff_done - t_start, t_plan_done - t_simdiff_done, t_waves_done - t_plan_done, t_finish_done - t_waves_done, now_ms() - t_start, dev_ms);
     *out = R;
     return HS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage 3 -> stage 4 hand-over without the .col text round trip
+// ---------------------------------------------------------------------------------------------------
+int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, const hs_cv_result* cv, float error_rate, float rsa, int32_t low_memory,
+                   int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out) {
+    const int C = b.n_contigs;
+    std::vector<hs_sr_contig> hc((size_t)C);
+    std::vector<std::vector<int32_t>> rs((size_t)C), re((size_t)C), spos((size_t)C), cidx((size_t)C);
+    std::vector<std::vector<uint8_t>> sref((size_t)C), salt((size_t)C), ccode((size_t)C);
+    std::vector<std::vector<int64_t>> coff((size_t)C);
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    parallel_for(C, n_threads, [&](int c) {
+        const int r0 = b.contig_rec_off[(size_t)c], r1 = b.contig_rec_off[(size_t)c + 1];
+        rs[(size_t)c].resize((size_t)(r1 - r0)); re[(size_t)c].resize((size_t)(r1 - r0));
+        for (int r = r0; r < r1; ++r) {
+            // READ line limits = (position_2_1, position_2_2) = (POS-1, POS + reference span) (input_output.cpp:503-511)
+            rs[(size_t)c][(size_t)(r - r0)] = b.rec_pos[(size_t)r];
+            re[(size_t)c][(size_t)(r - r0)] = (int32_t)(b.rec_pos[(size_t)r] + 1 + b.rec_refspan[(size_t)r]);
+        }
+        coff[(size_t)c].assign(1, 0);
+        for (int64_t s = cv->snp_off[c]; s < cv->snp_off[c + 1]; ++s) {
+            const int64_t e0 = cv->col_off[s], e1 = cv->col_off[s + 1];
+            int maj = 0, sec = 0;
+            for (int64_t e = e0; e < e1; ++e) { if (cv->col_code[e] == cv->snp_ref[s]) maj++; else if (cv->col_code[e] == cv->snp_alt[s]) sec++; }
+            if (!((float)sec >= rsa * (float)(maj + sec))) continue;   // parse_column_file, separate_reads.cpp:167
+            spos[(size_t)c].push_back(cv->snp_pos[s]); sref[(size_t)c].push_back(cv->snp_ref[s]); salt[(size_t)c].push_back(cv->snp_alt[s]);
+            cidx[(size_t)c].insert(cidx[(size_t)c].end(), cv->col_idx + e0, cv->col_idx + e1);
+            ccode[(size_t)c].insert(ccode[(size_t)c].end(), cv->col_code + e0, cv->col_code + e1);
+            coff[(size_t)c].push_back((int64_t)cidx[(size_t)c].size());
+        }
+        hs_sr_contig& h = hc[(size_t)c];
+        h.length = b.contig_off[(size_t)c + 1] - b.contig_off[(size_t)c];
+        h.n_reads = r1 - r0; h.read_start = rs[(size_t)c].data(); h.read_end = re[(size_t)c].data();
+        h.n_snps = (int32_t)spos[(size_t)c].size(); h.snp_pos = spos[(size_t)c].data(); h.snp_ref = sref[(size_t)c].data(); h.snp_alt = salt[(size_t)c].data();
+        h.col_off = coff[(size_t)c].data(); h.col_idx = cidx[(size_t)c].data(); h.col_code = ccode[(size_t)c].data();
+        h.ploidy = 0;
+    });
+    const int32_t w = window_size > 0 ? window_size : sr_window_size(hc.data(), C, amplicon != 0);
+    return sr_run(dev, hc.data(), C, w, error_rate, low_memory, seed, n_threads, out);
 }
 
 // ---------------------------------------------------------------------------------------------------

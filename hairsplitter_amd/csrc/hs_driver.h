@@ -15,13 +15,17 @@ struct CvMeta {                       // host-side description of a stage-3 batc
     std::vector<int64_t> contig_off;      // [C+1]
     std::vector<int32_t> contig_rec_off;  // [C+1]
     std::vector<int64_t> pile_off;        // [NREC+1]
+    std::vector<int32_t> rec_pos;         // [NREC] POS-1
+    std::vector<int64_t> rec_refspan;     // [NREC] reference bases consumed by the CIGAR (unclipped)
     int64_t total_len = 0;
 };
 
 struct CvDeviceOps {
     virtual ~CvDeviceOps() {}
-    // K1 + K2: per-record {q_end, n_err, n_len, 0} and per-position statistics; k_ms = {pileup, column_stats}
-    virtual int pileup_and_stats(std::vector<int32_t>& rec_stats, std::vector<hs_colstat>& stats, float k_ms[2]) = 0;
+    // K0+K1 + K2: per-record {q_end, n_err, n_len, n_events}; the global positions (unordered) whose second count is
+    // >= min_second with their depth; k_ms = {cigar scan + pileup, column_stats}
+    virtual int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, std::vector<int64_t>& sel_gpos,
+                                  std::vector<int32_t>& sel_depth, float k_ms[2]) = 0;
     // K3: columns of the selected positions
     virtual int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos,
                        const std::vector<int64_t>& col_off, std::vector<int32_t>& col_idx, std::vector<uint8_t>& col_code,
@@ -54,6 +58,9 @@ struct SrDeviceOps {
 
 int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
            int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out);
+
+int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& meta, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance,
+                   int32_t low_memory, int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out);
 
 // .col reader of HS_separate_reads (separate_reads.cpp:46-190)
 struct ColFileContig {

@@ -149,6 +149,7 @@ static void build_graph_low_memory(const SrContigState& st, const uint8_t* mask,
 
 // Window / mask planning: separate_reads.cpp:1545-1622 (the running SNP cursor is carried across windows)
 void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool low_memory) {
+    (void)error_rate;
     const hs_sr_contig& c = *st.c;
     const int N = st.N;
     const long L = c.length;
@@ -193,10 +194,9 @@ void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool 
             idxmask++;
         }
         cur++;
-        // graph for this window
+        // graph slot for this window (filled by sr_build_window_graph, one independent task per window)
         st.graphs.emplace_back();
-        if (!st.low_memory_now) build_graph_matrix(st, w.mask.data(), error_rate, st.graphs.back());
-        else build_graph_low_memory(st, w.mask.data(), error_rate, st.graphs.back());
+        st.graphs.back().off.assign((size_t)N + 1, 0);
         w.graph_now = (int)st.graphs.size() - 1;
         // finalize_clustering is handed the *global* low_memory flag (:1708): with low_memory_now && !low_memory it
         // sees an Eigen matrix that was never filled
@@ -214,6 +214,14 @@ void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool 
         w.final_lo = chunk * window_size; w.final_hi = chunk * window_size + window_size;
         st.windows.push_back(std::move(w));
     }
+}
+
+void sr_build_window_graph(SrContigState& st, int window, float error_rate) {
+    SrWindowPlan& w = st.windows[(size_t)window];
+    if (!w.has_snps) return;
+    SrGraph& g = st.graphs[(size_t)w.graph_now];
+    if (!st.low_memory_now) build_graph_matrix(st, w.mask.data(), error_rate, g);
+    else build_graph_low_memory(st, w.mask.data(), error_rate, g);
 }
 
 // separate_reads.cpp:1678-1691: every masked read of the column starts in the cluster of the first read

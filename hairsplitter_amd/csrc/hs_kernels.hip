@@ -26,13 +26,58 @@ static __device__ __forceinline__ int wave_sum_i32(int v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1 pileup: generate_msa, call_variants.cpp:189-354 (CIGAR walk), tools.cpp:27-57 (RLE expansion avoided).
-// One wavefront per alignment record. The CIGAR is consumed 64 ops at a time: a wave-level inclusive scan
-// gives every op its first event / read offset / reference offset; the events of those 64 ops are then
-// processed 64 per step (lane = event), the owning op found by a 6-step binary search across lanes.
-// The 3-mer context (previous two emitted characters, insertions and deletions included) comes from the two
-// lanes to the left, or from a wave-uniform carry for lanes 0/1. Writes to the read-major pileup are
-// contiguous per run of M/D events (coalesced).
+// K0 CIGAR scan: per alignment record, the running (event, read, reference) offsets at every 64-op chunk
+// boundary, so that K1 can start in the middle of a record. One wavefront per record, lane = op, wave-level
+// inclusive scans. Also writes the record's final reference cursor (call_variants.cpp:354) and zeroes its
+// error/length counters. tools.cpp:27-57 (convert_cigar) never materialises: ops stay run-length encoded.
+// ------------------------------------------------------------------------------------------------
+struct OpAdv { int ev, rd, rf; };
+static __device__ __forceinline__ OpAdv op_advances(uint32_t op, bool in_range) {
+    OpAdv a; a.ev = 0; a.rd = 0; a.rf = 0;
+    if (!in_range) return a;
+    const int len = (int)(op >> 4), code = (int)(op & 15u);
+    const bool isM = code == 0 || code == 7 || code == 8;
+    if (isM || code == 1 || code == 2) a.ev = len;
+    if (isM || code == 1 || code == 4 || code == 5) a.rd = len;
+    if (isM || code == 2) a.rf = len;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_cigar_scan(
+    const int64_t* __restrict__ contig_off, const int32_t* __restrict__ rec_contig, const int32_t* __restrict__ rec_pos,
+    const int64_t* __restrict__ rec_cig_off, const uint32_t* __restrict__ cigar, const int64_t* __restrict__ rec_chunk_off,
+    int n_rec, int32_t* __restrict__ chunk_start /* [n_chunks][4] */, int32_t* __restrict__ rec_stats) {
+    const int lane = lane_id();
+    const int r = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (r >= n_rec) return;
+    const int64_t cig0 = rec_cig_off[r], cig1 = rec_cig_off[r + 1];
+    int32_t* __restrict__ cs = chunk_start + 4 * rec_chunk_off[r];
+    const int pos = rec_pos[r];
+    int ev_cur = 0, t_cur = 0, q_cur = pos;
+    int k = 0;
+    for (int64_t ob = cig0; ob < cig1; ob += 64, ++k) {
+        const int64_t oi = ob + lane;
+        const OpAdv a = op_advances(oi < cig1 ? cigar[oi] : 0u, oi < cig1);
+        const int ev = wave_sum_i32(a.ev), rd = wave_sum_i32(a.rd), rf = wave_sum_i32(a.rf);
+        if (lane == 0) { cs[4 * k + 0] = ev_cur; cs[4 * k + 1] = t_cur; cs[4 * k + 2] = q_cur; cs[4 * k + 3] = 0; }
+        ev_cur += ev; t_cur += rd; q_cur += rf;
+    }
+    if (lane == 0) {
+        const int ctg = rec_contig[r];
+        const int L = (int)(contig_off[ctg + 1] - contig_off[ctg]);
+        rec_stats[4 * r + 0] = pos >= L ? pos : (q_cur < L ? q_cur : L);
+        rec_stats[4 * r + 1] = 0; rec_stats[4 * r + 2] = 0; rec_stats[4 * r + 3] = ev_cur;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 pileup: generate_msa, call_variants.cpp:189-354. One wavefront per TASK = a fixed-size range of
+// alignment events of one record (balanced: a 60 kb read is 15+ tasks, not one long wave). The task finds its
+// 64-op chunk by bisection on K0's table, then walks chunks: wave inclusive scan of the ops (lane = op), events
+// processed 64 per step (lane = event), owning op by a 6-step binary search across lanes. The 3-mer context
+// (previous two emitted characters, insertions and deletions included) comes from the two lanes to the left or a
+// wave-uniform carry; a task warms the carry up by replaying the two events before its range without
+// committing them. Pileup writes are contiguous per run of M/D events (coalesced).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pileup(
     const uint8_t* __restrict__ contig_seq, const int64_t* __restrict__ contig_off,
@@ -40,11 +85,16 @@ __global__ __launch_bounds__(256) void k_pileup(
     const int32_t* __restrict__ rec_read, const int32_t* __restrict__ rec_contig,
     const int32_t* __restrict__ rec_pos, const uint8_t* __restrict__ rec_strand,
     const int64_t* __restrict__ rec_cig_off, const uint32_t* __restrict__ cigar,
-    const int64_t* __restrict__ pile_off, int n_rec, uint8_t* __restrict__ pile,
-    int32_t* __restrict__ rec_stats) {
+    const int64_t* __restrict__ pile_off, const int64_t* __restrict__ rec_chunk_off,
+    const int32_t* __restrict__ chunk_start, const int32_t* __restrict__ task_rec, const int32_t* __restrict__ task_ev0,
+    int n_tasks, int ev_per_task, uint8_t* __restrict__ pile, int32_t* __restrict__ rec_stats) {
     const int lane = lane_id();
-    const int r = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-    if (r >= n_rec) return;   // wave-uniform
+    const int task = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (task >= n_tasks) return;   // wave-uniform
+    const int r = task_rec[task];
+    const int e0 = task_ev0[task];
+    const int e1 = e0 + ev_per_task;
+    const int e_first = e0 >= 2 ? e0 - 2 : 0;
 
     const int ctg = rec_contig[r];
     const int64_t coff = contig_off[ctg];
@@ -55,43 +105,48 @@ __global__ __launch_bounds__(256) void k_pileup(
     const int pos = rec_pos[r];
     const bool fwd = rec_strand[r] != 0;
     const int64_t cig0 = rec_cig_off[r], cig1 = rec_cig_off[r + 1];
+    const int n_chunks = (int)((cig1 - cig0 + 63) >> 6);
+    const int32_t* __restrict__ cs = chunk_start + 4 * rec_chunk_off[r];
     uint8_t* __restrict__ out = pile + pile_off[r];
     const uint8_t* __restrict__ ctgp = contig_seq + coff;
     const uint8_t* __restrict__ rdp = read_seq + roff;
 
-    int p1 = 2, p2 = 1;   // previous char 'G', the one before 'C' (call_variants.cpp:212-214 after one shift)
-    int q_cur = pos, t_cur = 0;
-    int nerr = 0, nlen = 0;
+    // last chunk whose first event is <= e_first (uniform bisection)
+    int klo = 0, khi = n_chunks - 1;
+    while (klo < khi) { const int mid = (klo + khi + 1) >> 1; if (cs[4 * mid] <= e_first) klo = mid; else khi = mid - 1; }
 
-    for (int64_t ob = cig0; ob < cig1; ob += 64) {
-        const int64_t oi = ob + lane;
-        uint32_t op = oi < cig1 ? cigar[oi] : 0xFu;
-        int len = (int)(op >> 4), code = (int)(op & 15u);
-        if (oi >= cig1) { len = 0; code = 15; }
-        const bool isM = code == 0 || code == 7 || code == 8;
-        const bool isI = code == 1, isD = code == 2, isClip = code == 4 || code == 5;
-        const int ev = (isM || isI || isD) ? len : 0;
-        const int rdv = (isM || isI || isClip) ? len : 0;
-        const int rfv = (isM || isD) ? len : 0;
-        int ev_inc = ev, rd_inc = rdv, rf_inc = rfv;
+    int p1 = 2, p2 = 1;   // previous char 'G', the one before 'C' (call_variants.cpp:212-214 after one shift)
+    int nerr = 0, nlen = 0;
+    for (int k = klo; k < n_chunks; ++k) {
+        const int ev_base = cs[4 * k + 0];
+        if (ev_base >= e1) break;
+        const int t_cur = cs[4 * k + 1], q_cur = cs[4 * k + 2];
+        const int64_t oi = cig0 + ((int64_t)k << 6) + lane;
+        const bool in_range = oi < cig1;
+        const uint32_t op = in_range ? cigar[oi] : 0xFu;
+        const int code = in_range ? (int)(op & 15u) : 15;
+        const OpAdv a = op_advances(op, in_range);
+        int ev_inc = a.ev, rd_inc = a.rd, rf_inc = a.rf;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            int a = __shfl_up(ev_inc, d, 64), b = __shfl_up(rd_inc, d, 64), c = __shfl_up(rf_inc, d, 64);
-            if (lane >= d) { ev_inc += a; rd_inc += b; rf_inc += c; }
+            const int x = __shfl_up(ev_inc, d, 64), y = __shfl_up(rd_inc, d, 64), z = __shfl_up(rf_inc, d, 64);
+            if (lane >= d) { ev_inc += x; rd_inc += y; rf_inc += z; }
         }
-        const int ev_ex = ev_inc - ev;
-        const int t0 = t_cur + rd_inc - rdv;
-        const int q0 = q_cur + rf_inc - rfv;
+        const int ev_ex = ev_inc - a.ev;
+        const int t0 = t_cur + rd_inc - a.rd;
+        const int q0 = q_cur + rf_inc - a.rf;
         const int chunk_ev = __shfl(ev_inc, 63, 64);
+        const int lo_el = e_first > ev_base ? e_first - ev_base : 0;
+        const int hi_el = (e1 - ev_base) < chunk_ev ? (e1 - ev_base) : chunk_ev;
 
-        for (int eb = 0; eb < chunk_ev; eb += 64) {
+        for (int eb = lo_el; eb < hi_el; eb += 64) {
             const int e = eb + lane;
-            const bool valid = e < chunk_ev;
+            const bool valid = e < hi_el;
             int lo = 0, hi = 63;
 #pragma unroll
             for (int it = 0; it < 6; ++it) {
-                int mid = (lo + hi) >> 1;
-                int v = __shfl(ev_inc, mid, 64);
+                const int mid = (lo + hi) >> 1;
+                const int v = __shfl(ev_inc, mid, 64);
                 if (v > e) hi = mid; else lo = mid + 1;
             }
             const int j = lo > 63 ? 63 : lo;
@@ -101,16 +156,16 @@ __global__ __launch_bounds__(256) void k_pileup(
             const int jcode = __shfl(code, j, 64);
             const int off = e - jev_ex;
             const bool jM = jcode == 0 || jcode == 7 || jcode == 8;
-            const bool jD = jcode == 2, jI = jcode == 1;
+            const bool jD = jcode == 2;
             const int t = jt0 + off;
             const int q = jq0 + ((jM || jD) ? off : 0);
-            const bool active = valid && q >= 0 && q < L;   // call_variants.cpp:217
+            const bool active = valid && (ev_base + e) >= e0 && q >= 0 && q < L;   // call_variants.cpp:217
             int c = 4;   // '-'
             if (!jD) {
-                int tt = t < 0 ? 0 : (t >= rlen ? rlen - 1 : t);   // host validates CIGAR vs read length
-                int idx = fwd ? tt : (rlen - 1 - tt);
-                int b = valid && rlen > 0 ? (int)rdp[idx] : 0;
-                c = fwd ? b : 3 - b;
+                const int tt = t < 0 ? 0 : (t >= rlen ? rlen - 1 : t);   // the host validates CIGAR vs read length
+                const int idx = fwd ? tt : (rlen - 1 - tt);
+                const int bb = valid && rlen > 0 ? (int)rdp[idx] : 0;
+                c = fwd ? bb : 3 - bb;
             }
             const int cu1 = __shfl_up(c, 1, 64), cu2 = __shfl_up(c, 2, 64);
             const int pr1 = lane >= 1 ? cu1 : p1;
@@ -127,94 +182,141 @@ __global__ __launch_bounds__(256) void k_pileup(
                     nerr++;                                                   // insertion :337
                 }
             }
-            const int nv = (chunk_ev - eb) < 64 ? (chunk_ev - eb) : 64;
+            const int nv = (hi_el - eb) < 64 ? (hi_el - eb) : 64;
             const int last = __shfl(c, nv - 1, 64);
             const int last2 = nv >= 2 ? __shfl(c, nv - 2, 64) : p1;
             p2 = last2; p1 = last;
         }
-        t_cur += __shfl(rd_inc, 63, 64);
-        q_cur += __shfl(rf_inc, 63, 64);
     }
     nerr = wave_sum_i32(nerr);
     nlen = wave_sum_i32(nlen);
-    if (lane == 0) {
-        int qend = pos >= L ? pos : (q_cur < L ? q_cur : L);
-        rec_stats[4 * r + 0] = qend;
-        rec_stats[4 * r + 1] = nerr;
-        rec_stats[4 * r + 2] = nlen;
-        rec_stats[4 * r + 3] = 0;
+    if (lane == 0 && nlen > 0) {
+        atomicAdd(&rec_stats[4 * r + 1], nerr);
+        atomicAdd(&rec_stats[4 * r + 2], nlen);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // K2 column statistics: the histogram of call_variants.cpp:477-501 for 256 consecutive positions per
 // workgroup. Every lane owns one position and a private 125-bin u16 histogram column in LDS
-// (hist[bin][lane]: lanes hitting the same bin are conflict-free); the records of the contig are walked in
-// read-index order with wave-uniform (scalar) metadata loads, the pileup bytes are read coalesced.
-// Output: five largest (count desc, code asc) + depth, 16 B per position, one dwordx4 store per lane.
+// (hist[bin][lane]: lanes hitting the same bin are conflict-free). The records overlapping the tile are first
+// compacted into an LDS list (coalesced metadata loads + wave ballot), then walked four at a time so that the
+// pileup byte loads of a group are in flight together. Output: five largest (count desc, code asc) + depth,
+// one 16-B store per lane; positions whose second count reaches `min_second` are also appended to a compact
+// selection list (wave-aggregated atomic), so the host never scans the per-position array.
 // ------------------------------------------------------------------------------------------------
 #define HS_NBINS 125
+#define HS_LIST_CAP 1024
 __global__ __launch_bounds__(256) void k_column_stats(
     const uint8_t* __restrict__ pile, const int64_t* __restrict__ pile_off,
     const int32_t* __restrict__ rec_pos, const int32_t* __restrict__ rec_qend,
     const int32_t* __restrict__ contig_rec_off, const int64_t* __restrict__ contig_off,
-    int n_contigs, hs_colstat_dev* __restrict__ stats) {
+    int n_contigs, hs_colstat_dev* __restrict__ stats, int min_second, int32_t* __restrict__ sel_count,
+    int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int sel_cap) {
     __shared__ uint16_t hist[HS_NBINS * 256];
+    __shared__ int32_t s_ps[HS_LIST_CAP], s_qe[HS_LIST_CAP];
+    __shared__ int64_t s_po[HS_LIST_CAP];
+    __shared__ int s_n;
     const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
     const int64_t total = contig_off[n_contigs];
     const int64_t g0 = (int64_t)blockIdx.x * 256;
     const int64_t g = g0 + tid;
     for (int b = 0; b < HS_NBINS; ++b) hist[b * 256 + tid] = 0;
-    // contigs intersecting this tile (block-uniform binary search)
     int c_first;
     {
         int lo = 0, hi = n_contigs - 1;
-        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (contig_off[mid] <= g0) lo = mid; else hi = mid - 1; }
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (contig_off[mid] <= g0) lo = mid; else hi = mid - 1; }
         c_first = lo;
     }
     const int64_t g_last = (g0 + 255 < total - 1) ? g0 + 255 : total - 1;
-    int my_c = -1, my_p = 0;
     for (int c = c_first; c < n_contigs && contig_off[c] <= g_last; ++c) {
         const int64_t cs = contig_off[c], ce = contig_off[c + 1];
         if (ce <= g0) continue;
         const bool mine = g >= cs && g < ce;
         const int p = (int)(g - cs);
-        if (mine) { my_c = c; my_p = p; }
         const int tile_lo = (int)((g0 > cs ? g0 : cs) - cs);
         const int tile_hi = (int)(((g_last + 1) < ce ? (g_last + 1) : ce) - cs);   // exclusive
         const int r0 = contig_rec_off[c], r1 = contig_rec_off[c + 1];
-        for (int n = r0; n < r1; ++n) {
-            const int ps = rec_pos[n], qe = rec_qend[n];      // uniform -> scalar loads
-            if (qe <= tile_lo || ps >= tile_hi) continue;
-            if (mine && p >= ps && p < qe) {
-                int code = (int)pile[pile_off[n] + (p - ps)] - 33;
-                if (code >= 0 && code < HS_NBINS) hist[code * 256 + tid] += 1;
+        for (int rb = r0; rb < r1; rb += HS_LIST_CAP) {
+            const int rb_end = (rb + HS_LIST_CAP) < r1 ? (rb + HS_LIST_CAP) : r1;
+            __syncthreads();
+            if (tid == 0) s_n = 0;
+            __syncthreads();
+            // compact the records of [rb, rb_end) that overlap the tile
+            for (int nb = rb; nb < rb_end; nb += 256) {
+                const int n = nb + tid;
+                int ps = 0, qe = 0;
+                bool ov = false;
+                if (n < rb_end) { ps = rec_pos[n]; qe = rec_qend[n]; ov = qe > tile_lo && ps < tile_hi; }
+                const unsigned long long m = __ballot(ov);
+                int base = 0;
+                if (lane == 0 && m) base = atomicAdd(&s_n, __popcll(m));
+                base = __shfl(base, 0, 64);
+                if (ov) {
+                    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                    s_ps[slot] = ps; s_qe[slot] = qe; s_po[slot] = pile_off[n] - ps;
+                }
+            }
+            __syncthreads();
+            const int cnt = s_n;
+            int i = 0;
+            for (; i + 4 <= cnt; i += 4) {
+                int code[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ps = s_ps[i + u], qe = s_qe[i + u];
+                    code[u] = (mine && p >= ps && p < qe) ? (int)pile[s_po[i + u] + p] - 33 : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (code[u] >= 0 && code[u] < HS_NBINS) hist[code[u] * 256 + tid] += 1;
+            }
+            for (; i < cnt; ++i) {
+                const int ps = s_ps[i], qe = s_qe[i];
+                if (mine && p >= ps && p < qe) {
+                    const int code = (int)pile[s_po[i] + p] - 33;
+                    if (code >= 0 && code < HS_NBINS) hist[code * 256 + tid] += 1;
+                }
             }
         }
     }
-    if (g >= total) return;
-    (void)my_c; (void)my_p;
     int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
     int depth = 0;
-    for (int b = 0; b < HS_NBINS; ++b) {
-        const int v = (int)hist[b * 256 + tid];
-        depth += v;
-        if (v > c4) {
-            const int key = b + 33;
-            if (v > c0) { c4 = c3; c3 = c2; k3 = k2; c2 = c1; k2 = k1; c1 = c0; k1 = k0; c0 = v; k0 = key; }
-            else if (v > c1) { c4 = c3; c3 = c2; k3 = k2; c2 = c1; k2 = k1; c1 = v; k1 = key; }
-            else if (v > c2) { c4 = c3; c3 = c2; k3 = k2; c2 = v; k2 = key; }
-            else if (v > c3) { c4 = c3; c3 = v; k3 = key; }
-            else c4 = v;
+    if (g < total) {
+        for (int b = 0; b < HS_NBINS; ++b) {
+            const int v = (int)hist[b * 256 + tid];
+            depth += v;
+            if (v > c4) {
+                const int key = b + 33;
+                if (v > c0) { c4 = c3; c3 = c2; k3 = k2; c2 = c1; k2 = k1; c1 = c0; k1 = k0; c0 = v; k0 = key; }
+                else if (v > c1) { c4 = c3; c3 = c2; k3 = k2; c2 = c1; k2 = k1; c1 = v; k1 = key; }
+                else if (v > c2) { c4 = c3; c3 = c2; k3 = k2; c2 = v; k2 = key; }
+                else if (v > c3) { c4 = c3; c3 = v; k3 = key; }
+                else c4 = v;
+            }
+        }
+        uint4 o;
+        o.x = (uint32_t)k0 | ((uint32_t)k1 << 8) | ((uint32_t)k2 << 16) | ((uint32_t)k3 << 24);
+        o.y = (uint32_t)c0 | ((uint32_t)c1 << 16);
+        o.z = (uint32_t)c2 | ((uint32_t)c3 << 16);
+        o.w = (uint32_t)c4 | ((uint32_t)(depth > 65535 ? 65535 : depth) << 16);
+        reinterpret_cast<uint4*>(stats)[g] = o;
+    }
+    if (sel_count) {
+        const bool sel = g < total && c1 >= min_second;
+        const unsigned long long m = __ballot(sel);
+        if (m) {
+            int base = 0;
+            if (lane == __builtin_ctzll(m)) base = atomicAdd(sel_count, __popcll(m));
+            base = __shfl(base, __builtin_ctzll(m), 64);
+            if (sel) {
+                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < sel_cap) { sel_gpos[slot] = g; sel_depth[slot] = depth; }
+            }
         }
     }
-    uint4 o;
-    o.x = (uint32_t)k0 | ((uint32_t)k1 << 8) | ((uint32_t)k2 << 16) | ((uint32_t)k3 << 24);
-    o.y = (uint32_t)c0 | ((uint32_t)c1 << 16);
-    o.z = (uint32_t)c2 | ((uint32_t)c3 << 16);
-    o.w = (uint32_t)c4 | ((uint32_t)(depth > 65535 ? 65535 : depth) << 16);
-    reinterpret_cast<uint4*>(stats)[g] = o;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -331,7 +433,10 @@ __global__ __launch_bounds__(64) void k_chinese_whispers(
     const int32_t* __restrict__ graph_n, const int32_t* __restrict__ perm, const int64_t* __restrict__ perm_base,
     const uint8_t* __restrict__ mask, const int32_t* __restrict__ inst_graph,
     const int64_t* __restrict__ inst_label_base, int n_inst, int32_t* __restrict__ labels_io,
-    int32_t* __restrict__ sweeps_out) {
+    int32_t* __restrict__ sweeps_out,
+    // optional seeding from a SNP column (separate_reads.cpp:1678-1691); inst_seed_col == nullptr: labels_io holds the start
+    const int64_t* __restrict__ inst_seed_col, const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx,
+    const uint8_t* __restrict__ col_code) {
     extern __shared__ int32_t cw_lds[];
     const int lane = lane_id();
     const int inst = (int)blockIdx.x;
@@ -345,7 +450,22 @@ __global__ __launch_bounds__(64) void k_chinese_whispers(
     int32_t* __restrict__ lab_g = labels_io + inst_label_base[inst];
     int32_t* lab = cw_lds;          // [N]
     int32_t* cnt = cw_lds + N;      // [N]
-    for (int i = lane; i < N; i += 64) { lab[i] = lab_g[i]; cnt[i] = 0; }
+    int32_t* first = cw_lds + 2 * N;   // [256] first masked read carrying each code (seeding only)
+    if (inst_seed_col) {
+        // every read starts alone; masked reads of the seeding column start in the cluster of the first masked read
+        // that carries the same code
+        for (int i = lane; i < N; i += 64) { lab[i] = i; cnt[i] = 0; }
+        for (int i = lane; i < 256; i += 64) first[i] = 0x7fffffff;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int64_t c0 = col_off[inst_seed_col[inst]], c1 = col_off[inst_seed_col[inst] + 1];
+        for (int64_t e = c0 + lane; e < c1; e += 64) { const int r = col_idx[e]; if (msk[r]) atomicMin(&first[col_code[e]], r); }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t e = c0 + lane; e < c1; e += 64) { const int r = col_idx[e]; if (msk[r]) lab[r] = first[col_code[e]]; }
+    } else {
+        for (int i = lane; i < N; i += 64) { lab[i] = lab_g[i]; cnt[i] = 0; }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 
@@ -511,6 +631,109 @@ __global__ __launch_bounds__(64) void k_myers(
         if (mode == 0) { dist[pr] = fs; endloc[pr] = tn - 1; }
         else { dist[pr] = fb; endloc[pr] = fj; }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// First-appearance renumbering shared by the two bookkeeping kernels below: given first[j] (index of the first
+// element equal to element j, or -1 for "no label"), id[j] = number of distinct first-appearances before first[j].
+// One workgroup; `flag` and `pre` are N-int scratch arrays in global memory.
+// ------------------------------------------------------------------------------------------------
+static __device__ void first_seen_ids(const int32_t* first, int N, int32_t* pre, int32_t* out_id) {
+    __shared__ int s_carry;
+    __shared__ int s_wsum[4];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < N; b0 += 256) {
+        const int j = b0 + tid;
+        const int f = (j < N && first[j] == j) ? 1 : 0;
+        int incl = f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int x = __shfl_up(incl, d, 64); if (lane >= d) incl += x; }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wv; ++k) woff += s_wsum[k];
+        if (j < N) pre[j] = s_carry + woff + incl - f;     // exclusive count of first-appearances before j
+        __syncthreads();
+        if (tid == 0) s_carry += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        __syncthreads();
+    }
+    for (int j = tid; j < N; j += 256) { const int f = first[j]; out_id[j] = f >= 0 ? pre[f] : -1; }
+}
+
+// merge_clusterings, separate_reads.cpp:840-874: reads that were never separated by any per-SNP clustering share
+// an id. The reference keys a hash map on sum_i label_i[j] * 2^i accumulated in double; the same double is built
+// here in the same order, ids are handed out in order of first appearance, non-masked reads get -2.
+__global__ __launch_bounds__(256) void k_cw_merge_ids(
+    const int32_t* __restrict__ local_labels, const int64_t* __restrict__ win_local_base, const int32_t* __restrict__ win_k,
+    const int32_t* __restrict__ win_n, const int32_t* __restrict__ win_graph, const int64_t* __restrict__ graph_off_base,
+    const uint8_t* __restrict__ mask, const int64_t* __restrict__ win_out_base, double* __restrict__ agg_scratch,
+    int32_t* __restrict__ first_scratch, int32_t* __restrict__ pre_scratch, int32_t* __restrict__ out_labels) {
+    const int w = (int)blockIdx.x;
+    const int N = win_n[w], K = win_k[w];
+    const int32_t* __restrict__ loc = local_labels + win_local_base[w];
+    const int g = win_graph[w];
+    const uint8_t* __restrict__ msk = mask + graph_off_base[g] - g;
+    double* agg = agg_scratch + win_out_base[w];
+    int32_t* first = first_scratch + win_out_base[w];
+    int32_t* pre = pre_scratch + win_out_base[w];
+    int32_t* out = out_labels + win_out_base[w];
+    const int tid = (int)threadIdx.x;
+    for (int j = tid; j < N; j += 256) {
+        double a = 0.0, f = 1.0;
+        for (int i = 0; i < K; ++i) { a += (double)loc[(int64_t)i * N + j] * f; f *= 2.0; }   // exact powers of two
+        agg[j] = a;
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += 256) {
+        const double a = agg[j];
+        int k = 0;
+        while (agg[k] != a) ++k;      // terminates at k == j at the latest
+        first[j] = k;
+    }
+    __syncthreads();
+    first_seen_ids(first, N, pre, out);
+    __syncthreads();
+    for (int j = tid; j < N; j += 256) if (!msk[j]) out[j] = -2;
+}
+
+// finalize_clustering, separate_reads.cpp:924-955: clusters with fewer than 5 masked reads become -1, the others are
+// renumbered in order of first appearance; non-masked reads are -2.
+__global__ __launch_bounds__(256) void k_cw_drop_small(
+    const int32_t* __restrict__ in_labels, const int32_t* __restrict__ win_n, const int32_t* __restrict__ win_graph,
+    const int64_t* __restrict__ graph_off_base, const uint8_t* __restrict__ mask, const int64_t* __restrict__ win_base,
+    int32_t* __restrict__ size_scratch, int32_t* __restrict__ first_scratch, int32_t* __restrict__ pre_scratch,
+    int32_t* __restrict__ out_labels) {
+    const int w = (int)blockIdx.x;
+    const int N = win_n[w];
+    const int g = win_graph[w];
+    const uint8_t* __restrict__ msk = mask + graph_off_base[g] - g;
+    const int32_t* __restrict__ in = in_labels + win_base[w];
+    int32_t* size = size_scratch + win_base[w];      // per label
+    int32_t* fpos = first_scratch + win_base[w];     // reused: first position of a label, then first[] per read
+    int32_t* pre = pre_scratch + win_base[w];
+    int32_t* out = out_labels + win_base[w];
+    const int tid = (int)threadIdx.x;
+    for (int j = tid; j < N; j += 256) { size[j] = 0; pre[j] = 0x7fffffff; }
+    __syncthreads();
+    for (int j = tid; j < N; j += 256) { const int l = msk[j] ? in[j] : -2; if (l >= 0 && l < N) atomicAdd(&size[l], 1); }
+    __syncthreads();
+    // labels surviving the size filter; first position of each surviving label (in pre[], per label)
+    for (int j = tid; j < N; j += 256) {
+        int l = msk[j] ? in[j] : -2;
+        if (l != -2 && (l < 0 || l >= N || size[l] < 5)) l = -1;      // a label outside [0,N) has map-default size 0
+        out[j] = l;
+        if (l >= 0) atomicMin(&pre[l], j);
+    }
+    __syncthreads();
+    for (int j = tid; j < N; j += 256) fpos[j] = out[j] >= 0 ? pre[out[j]] : -1;
+    __syncthreads();
+    // keep -2 / -1 where they are, renumber the rest
+    int32_t* ids = size;   // size[] is dead now
+    first_seen_ids(fpos, N, pre, ids);
+    __syncthreads();
+    for (int j = tid; j < N; j += 256) if (out[j] >= 0) out[j] = ids[j];
 }
 
 // small utility: apply host-resolved "swap top-2" decisions to the column statistics

@@ -60,7 +60,7 @@ int hs_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchron
  * One wavefront per record. For record r with reference start pos[r]:
  *   d_pile[pile_off[r] + (q - pos[r])] = 33 + 5*i(c-2) + i(c-1) + 25*i(c0)   for every M/=/X/D event at q < L
  * (i() = index in "ACGT-", previous chars initialised C,G as call_variants.cpp:212-214 leave them).
- * d_rec_stats[r] = {q_end, n_err, n_len, 0}: final reference cursor (call_variants.cpp:354) and the number
+ * d_rec_stats[r] = {q_end, n_err, n_len, n_events}: final reference cursor (call_variants.cpp:354) and the number
  * of +1's applied to totalDistance / totalLengthOfAlignment (call_variants.cpp:255-257,305-306,337-338).
  * ---------------------------------------------------------------------------------------------- */
 int hs_pileup(const uint8_t* d_contig_seq, const int64_t* d_contig_off,   /* [C+1] */
@@ -68,7 +68,19 @@ int hs_pileup(const uint8_t* d_contig_seq, const int64_t* d_contig_off,   /* [C+
               const int32_t* d_rec_read, const int32_t* d_rec_contig, const int32_t* d_rec_pos,
               const uint8_t* d_rec_strand, const int64_t* d_rec_cig_off,   /* [NREC+1] */
               const uint32_t* d_cigar, const int64_t* d_pile_off,          /* [NREC+1] */
-              int32_t n_rec, uint8_t* d_pile, int32_t* d_rec_stats /* [NREC*4] */, void* stream);
+              int32_t n_rec,
+              /* launch plan from hs_pileup_plan (work is split in equal ranges of alignment events, not per record) */
+              const int64_t* d_rec_chunk_off, int32_t* d_chunk_scratch /* [4 * rec_chunk_off[NREC]] */,
+              const int32_t* d_task_rec, const int32_t* d_task_ev0, int32_t n_tasks, int32_t ev_per_task,
+              uint8_t* d_pile, int32_t* d_rec_stats /* [NREC*4] */, void* stream);
+
+/* Host-side launch plan of hs_pileup, from host copies of the CIGARs (the per-record aggregates parse_SAM also
+ * derives, input_output.cpp:486-505): rec_chunk_off[r] = number of 64-op chunks before record r; tasks = (record,
+ * first event) pairs covering every record in ranges of ev_per_task events. The two task arrays are malloc'ed;
+ * release them with hs_free_host. */
+int hs_pileup_plan(const int64_t* h_rec_cig_off, const uint32_t* h_cigar, int32_t n_rec, int32_t ev_per_task,
+                   int64_t* h_rec_chunk_off /* [NREC+1] out */, int32_t* n_tasks, int32_t** h_task_rec, int32_t** h_task_ev0);
+void hs_free_host(void* p);
 
 /* ------------------------------------------------------------------------------------------------
  * K2 -- per-position code histogram and top-5.  Replaces the counting half of call_variants
@@ -86,7 +98,11 @@ typedef struct hs_colstat {
 
 int hs_column_stats(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
                     const int32_t* d_rec_qend, const int32_t* d_contig_rec_off, const int64_t* d_contig_off,
-                    int32_t n_contigs, hs_colstat* d_stats /* [sum L] */, void* stream);
+                    int32_t n_contigs, hs_colstat* d_stats /* [sum L] */,
+                    /* optional compact selection (all NULL / 0 to skip): global positions (index into the concatenated
+                     * contigs) whose second count is >= min_second, unordered, with their depth; *d_sel_count must be 0 */
+                    int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth, int32_t sel_cap,
+                    void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K3 -- column extraction (pileup transposition for selected positions, coalesced writes).
@@ -204,6 +220,13 @@ typedef struct hs_sr_result {
 int hs_sr_run(const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
               int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out);
 void hs_sr_result_destroy(hs_sr_result* r);
+/* Stage 4 directly on the result of hs_cv_run, without the .col text round trip (call_variants.cpp:1197-1204 <->
+ * separate_reads.cpp:84-170). READ limits come from the records (input_output.cpp:503-511); SNPs whose second base is
+ * rarer than rarest_strain_abundance are dropped as parse_column_file does (separate_reads.cpp:167). window_size <= 0:
+ * computed as separate_reads.cpp:1466-1498 from this batch. */
+int hs_sr_run_cv(const hs_cv_batch* b, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance,
+                 int32_t low_memory, int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size,
+                 hs_sr_result** out);
 /* separate_reads.cpp:1466-1498: window size from the read limits of all contigs of the .col */
 int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_t amplicon);
 

@@ -26,8 +26,10 @@ struct OracleCvOps : hs::CvDeviceOps {
     std::vector<std::vector<hso::Column>> cols;   // per contig
     explicit OracleCvOps(const hs::CvFileInput& i) : in(i) {}
 
-    int pileup_and_stats(std::vector<int32_t>& rec_stats, std::vector<hs_colstat>& stats, float k_ms[2]) override {
+    int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, std::vector<int64_t>& sel_gpos, std::vector<int32_t>& sel_depth,
+                          float k_ms[2]) override {
         k_ms[0] = k_ms[1] = 0;
+        sel_gpos.clear(); sel_depth.clear();
         const int C = (int)in.contig_names.size();
         std::vector<std::string> read_seq(in.read_names.size());
         for (size_t r = 0; r < read_seq.size(); ++r) {
@@ -60,10 +62,10 @@ struct OracleCvOps : hs::CvDeviceOps {
                 std::vector<std::pair<int, int>> v;   // (-count, code)
                 for (int k = 33; k < 158; ++k) if (cnt[k]) v.push_back(std::make_pair(-cnt[k], k));
                 std::sort(v.begin(), v.end());
-                hs_colstat s; std::memset(&s, 0, sizeof(s));
-                for (size_t k = 0; k < v.size() && k < 5; ++k) { if (k < 4) s.key[k] = (uint8_t)v[k].second; s.cnt[k] = (uint16_t)(-v[k].first); }
-                s.depth = (uint16_t)m.cols[p].content.size();
-                stats[(size_t)base + p] = s;
+                if (v.size() >= 2 && -v[1].first >= min_second) {   // reversed on purpose: the device list is unordered
+                    sel_gpos.insert(sel_gpos.begin(), base + (int64_t)p);
+                    sel_depth.insert(sel_depth.begin(), (int32_t)m.cols[p].content.size());
+                }
             }
             cols[(size_t)c] = std::move(m.cols);
         }

@@ -83,3 +83,20 @@ def test_inmemory_pipeline_equals_oracle(built):
             present = np.flatnonzero(lab != -2)
             assert (int(sr["win_start"][w]), int(sr["win_end"][w])) == gexp[k][:2]
             assert present.tolist() == gexp[k][2] and lab[present].tolist() == gexp[k][3]
+
+
+def test_fused_pipeline_equals_two_step_path(built):
+    """hs_cv_run -> hs_sr_run_cv (what bench.py times) == hs_cv_run -> Python hand-over -> hs_sr_run."""
+    import numpy as np
+    from hairsplitter_amd import api, synth
+    contigs = [synth.make_contig(22, i, 25_000, 2 + (i % 3), 0.01, 40, "ont") for i in range(4)]
+    flat = api.FlatBatch(contigs)
+    b = api.CvBatch(flat)
+    cv = b.run(0.33, 2)
+    e = min(float("%g" % cv["error_rate"]), 0.15)
+    sr = api.separate_reads(cv, flat, e, rarest_strain_abundance=0.01, n_threads=2)
+    cv2, sr2 = b.run_pipeline(0.33, 2)
+    b.close()
+    assert cv2["n_snps"] == int(cv["snp_off"][-1]) and cv2["error_rate"] == cv["error_rate"]
+    for k in ("win_off", "win_start", "win_end", "label_off", "labels"):
+        assert np.array_equal(sr[k], sr2[k]), k

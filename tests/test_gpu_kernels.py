@@ -41,6 +41,11 @@ def test_pileup_bytes_and_counters(batch):
     o_pile, o_stats, _ = ol.pileup(flat)
     assert np.array_equal(pile.cpu().numpy(), o_pile)
     assert np.array_equal(stats.cpu().numpy()[:, :3], o_stats[:, :3])
+    # task granularity must not change a byte (tasks of 64 / 1000 / one huge range per record)
+    for ev in (64, 1000, 1 << 30):
+        p2, s2 = api.pileup(t, flat, ev_per_task=ev)
+        assert np.array_equal(p2.cpu().numpy(), o_pile), ev
+        assert np.array_equal(s2.cpu().numpy()[:, :3], o_stats[:, :3]), ev
 
 
 def test_column_stats_counts(batch):
@@ -48,8 +53,10 @@ def test_column_stats_counts(batch):
     from hairsplitter_amd import api
     flat, t = batch
     pile, _ = api.pileup(t, flat)
-    st = api.column_stats(t, flat, pile)
+    st, sel_g, sel_d = api.column_stats(t, flat, pile, min_second=4)
     hp = pile.cpu().numpy()
+    exp_sel = np.flatnonzero(st["cnt"][:, 1] >= 4)
+    assert np.array_equal(sel_g, exp_sel) and np.array_equal(sel_d, st["depth"][exp_sel].astype(np.int32))
     for c in range(flat.n_contigs):
         k0, k1, c0, c1, c2, depth = ol.column_top3(flat, hp, c)
         s = st[int(flat.contig_off[c]):int(flat.contig_off[c + 1])]
