@@ -496,6 +496,82 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = d_mask.upload(g.mask)) return rc;
         return HS_OK;
     }
+    int cw_chain(const hs::CwChain& ch, std::vector<int32_t>& labels, float k_ms[3]) override {
+        const int W = (int)ch.win_n.size();
+        const int64_t n_inst = (int64_t)ch.seed_col.size();
+        const int64_t total_n = ch.win_label_base.back();
+        // per-SNP instances: graph, label base inside the local-label slab (instances of a window are contiguous)
+        std::vector<int32_t> ig((size_t)n_inst), win_k((size_t)W);
+        std::vector<int64_t> ilb((size_t)n_inst), win_local_base((size_t)W);
+        int64_t slab = 0;
+        for (int w = 0; w < W; ++w) {
+            win_local_base[(size_t)w] = slab;
+            win_k[(size_t)w] = (int32_t)(ch.win_seed_begin[(size_t)w + 1] - ch.win_seed_begin[(size_t)w]);
+            for (int64_t i = ch.win_seed_begin[(size_t)w]; i < ch.win_seed_begin[(size_t)w + 1]; ++i) {
+                ig[(size_t)i] = ch.win_graph_now[(size_t)w]; ilb[(size_t)i] = slab; slab += ch.win_n[(size_t)w];
+            }
+        }
+        std::vector<int64_t> wbase(ch.win_label_base.begin(), ch.win_label_base.end() - 1);
+        DBuf d_col_off, d_col_idx, d_col_code, d_ig, d_ilb, d_seed, d_local, d_wk, d_wn, d_wgn, d_wgf, d_wlb, d_wob, d_lab2, d_lab3, d_agg,
+            d_s1, d_s2, d_s3;
+        if (int rc = d_col_off.upload(ch.col_off)) return rc;
+        if (int rc = d_col_idx.upload(ch.col_idx)) return rc;
+        if (int rc = d_col_code.upload(ch.col_code)) return rc;
+        if (int rc = d_ig.upload(ig)) return rc;
+        if (int rc = d_ilb.upload(ilb)) return rc;
+        if (int rc = d_seed.upload(ch.seed_col)) return rc;
+        if (int rc = d_local.alloc((size_t)slab * sizeof(int32_t))) return rc;
+        if (int rc = d_wk.upload(win_k)) return rc;
+        if (int rc = d_wn.upload(ch.win_n)) return rc;
+        if (int rc = d_wgn.upload(ch.win_graph_now)) return rc;
+        if (int rc = d_wgf.upload(ch.win_graph_final)) return rc;
+        if (int rc = d_wlb.upload(win_local_base)) return rc;
+        if (int rc = d_wob.upload(wbase)) return rc;
+        if (int rc = d_lab2.alloc((size_t)total_n * sizeof(int32_t))) return rc;
+        if (int rc = d_lab3.alloc((size_t)total_n * sizeof(int32_t))) return rc;
+        if (int rc = d_agg.alloc((size_t)total_n * sizeof(double))) return rc;
+        if (int rc = d_s1.alloc((size_t)total_n * sizeof(int32_t))) return rc;
+        if (int rc = d_s2.alloc((size_t)total_n * sizeof(int32_t))) return rc;
+        if (int rc = d_s3.alloc((size_t)total_n * sizeof(int32_t))) return rc;
+        EventPair e1, e2, e3;
+        if (int rc = e1.init()) return rc;
+        if (int rc = e2.init()) return rc;
+        if (int rc = e3.init()) return rc;
+        // wave 1: per-SNP runs, seeded on the device from the SNP columns
+        HS_HIP(hipEventRecord(e1.a, stream));
+        if (int rc = cw_launch(d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_gn.as<int32_t>(),
+                               d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), d_ig.as<int32_t>(), d_ilb.as<int64_t>(), (int32_t)n_inst,
+                               max_n, d_local.as<int32_t>(), nullptr, stream, d_seed.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
+                               d_col_code.as<uint8_t>())) return rc;
+        HS_HIP(hipEventRecord(e1.b, stream));
+        // merged ids -> wave 2 on the finalize graph
+        HS_HIP(hipEventRecord(e2.a, stream));
+        hipLaunchKernelGGL(hsdev::k_cw_merge_ids, dim3((unsigned)W), dim3(256), 0, stream, d_local.as<int32_t>(), d_wlb.as<int64_t>(), d_wk.as<int32_t>(),
+                           d_wn.as<int32_t>(), d_wgf.as<int32_t>(), d_gob.as<int64_t>(), d_mask.as<uint8_t>(), d_wob.as<int64_t>(), d_agg.as<double>(),
+                           d_s1.as<int32_t>(), d_s2.as<int32_t>(), d_lab2.as<int32_t>());
+        HS_HIP(hipGetLastError());
+        if (int rc = cw_launch(d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_gn.as<int32_t>(),
+                               d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), d_wgf.as<int32_t>(), d_wob.as<int64_t>(), W, max_n,
+                               d_lab2.as<int32_t>(), nullptr, stream)) return rc;
+        HS_HIP(hipEventRecord(e2.b, stream));
+        // small clusters dropped, renumbered -> wave 3
+        HS_HIP(hipEventRecord(e3.a, stream));
+        hipLaunchKernelGGL(hsdev::k_cw_drop_small, dim3((unsigned)W), dim3(256), 0, stream, d_lab2.as<int32_t>(), d_wn.as<int32_t>(), d_wgf.as<int32_t>(),
+                           d_gob.as<int64_t>(), d_mask.as<uint8_t>(), d_wob.as<int64_t>(), d_s1.as<int32_t>(), d_s2.as<int32_t>(), d_s3.as<int32_t>(),
+                           d_lab3.as<int32_t>());
+        HS_HIP(hipGetLastError());
+        if (int rc = cw_launch(d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_gn.as<int32_t>(),
+                               d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), d_wgf.as<int32_t>(), d_wob.as<int64_t>(), W, max_n,
+                               d_lab3.as<int32_t>(), nullptr, stream)) return rc;
+        HS_HIP(hipEventRecord(e3.b, stream));
+        labels.resize((size_t)total_n);
+        HS_HIP(hipMemcpy(labels.data(), d_lab3.p, (size_t)total_n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        float m = 0;
+        if (int rc = e1.ms(&m)) return rc; k_ms[0] += m;
+        if (int rc = e2.ms(&m)) return rc; k_ms[1] += m;
+        if (int rc = e3.ms(&m)) return rc; k_ms[2] += m;
+        return HS_OK;
+    }
     int cw(hs::CwWave& wv, float* k_ms) override {
         const int n_inst = (int)wv.inst_graph.size();
         if (n_inst == 0) return HS_OK;

@@ -270,57 +270,43 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         for (size_t w = 0; w < st[(size_t)c].windows.size(); ++w)
             if (st[(size_t)c].windows[w].has_snps) wrefs.push_back(WRef{c, (int)w, 0});
 
-    // ---- wave 1: one run per (window, seeding SNP) (separate_reads.cpp:1674-1705) ----
-    CwWave w1;
-    for (auto& wr : wrefs) {
-        SrContigState& s = st[(size_t)wr.c];
-        SrWindowPlan& w = s.windows[(size_t)wr.w];
-        wr.local_base = (int64_t)w1.labels.size();
-        for (size_t k = 0; k < w.local_snps.size(); ++k) {
-            w1.inst_graph.push_back(graph_id[(size_t)wr.c][(size_t)w.graph_now]);
-            w1.inst_label_base.push_back((int64_t)w1.labels.size());
-            w1.labels.resize(w1.labels.size() + (size_t)s.N);
+    // ---- the three dependent Chinese-Whispers waves, device resident (see CwChain) ----
+    CwChain ch;
+    std::vector<int64_t> w2_base(wrefs.size(), -1);
+    {
+        std::vector<int64_t> col_base_of_contig((size_t)C, 0);
+        ch.col_off.assign(1, 0);
+        for (int c = 0; c < C; ++c) {
+            col_base_of_contig[(size_t)c] = (int64_t)ch.col_off.size() - 1;
+            const hs_sr_contig& hc = contigs[c];
+            if (hc.n_snps == 0) continue;
+            const int64_t e_base = (int64_t)ch.col_idx.size();
+            for (int s = 0; s < hc.n_snps; ++s) ch.col_off.push_back(e_base + hc.col_off[s + 1]);
+            ch.col_idx.insert(ch.col_idx.end(), hc.col_idx, hc.col_idx + hc.col_off[hc.n_snps]);
+            ch.col_code.insert(ch.col_code.end(), hc.col_code, hc.col_code + hc.col_off[hc.n_snps]);
+        }
+        ch.win_seed_begin.assign(1, 0);
+        ch.win_label_base.assign(1, 0);
+        for (size_t i = 0; i < wrefs.size(); ++i) {
+            SrContigState& s = st[(size_t)wrefs[i].c];
+            SrWindowPlan& w = s.windows[(size_t)wrefs[i].w];
+            if (w.local_snps.empty()) continue;          // finalize_clustering :909-919
+            w2_base[i] = ch.win_label_base.back();
+            ch.win_graph_now.push_back(graph_id[(size_t)wrefs[i].c][(size_t)w.graph_now]);
+            ch.win_graph_final.push_back(graph_id[(size_t)wrefs[i].c][(size_t)w.graph_final]);
+            ch.win_n.push_back(s.N);
+            for (int snp : w.local_snps) ch.seed_col.push_back(col_base_of_contig[(size_t)wrefs[i].c] + snp);
+            ch.win_seed_begin.push_back((int64_t)ch.seed_col.size());
+            ch.win_label_base.push_back(ch.win_label_base.back() + s.N);
+            n_cw += (int64_t)w.local_snps.size() + 2;
         }
     }
-    parallel_for((int)wrefs.size(), n_threads, [&](int i) {
-        const WRef& wr = wrefs[(size_t)i];
-        SrContigState& s = st[(size_t)wr.c];
-        SrWindowPlan& w = s.windows[(size_t)wr.w];
-        for (size_t k = 0; k < w.local_snps.size(); ++k)
-            sr_local_init_labels(s, w, w.local_snps[k], w1.labels.data() + wr.local_base + (int64_t)k * s.N);
-    });
-    if (int rc = run_wave(w1, &k_ms[1])) return rc;
-
-    // ---- wave 2: merged clustering (separate_reads.cpp:840-885) ----
-    CwWave w2;
-    std::vector<int64_t> w2_base(wrefs.size(), -1);
-    for (size_t i = 0; i < wrefs.size(); ++i) {
-        SrContigState& s = st[(size_t)wrefs[i].c];
-        SrWindowPlan& w = s.windows[(size_t)wrefs[i].w];
-        if (w.local_snps.empty()) continue;          // finalize_clustering :909-919
-        w2_base[i] = (int64_t)w2.labels.size();
-        w2.inst_graph.push_back(graph_id[(size_t)wrefs[i].c][(size_t)w.graph_final]);
-        w2.inst_label_base.push_back(w2_base[i]);
-        w2.labels.resize(w2.labels.size() + (size_t)s.N);
+    std::vector<int32_t> chain_labels;
+    {
+        const double t0 = now_ms();
+        if (!ch.win_n.empty()) { if (int rc = dev.cw_chain(ch, chain_labels, &k_ms[1])) return rc; }
+        dev_ms += now_ms() - t0;
     }
-    parallel_for((int)wrefs.size(), n_threads, [&](int i) {
-        if (w2_base[(size_t)i] < 0) return;
-        SrContigState& s = st[(size_t)wrefs[(size_t)i].c];
-        SrWindowPlan& w = s.windows[(size_t)wrefs[(size_t)i].w];
-        sr_merged_init_labels(s, w, w1.labels.data() + wrefs[(size_t)i].local_base, (int)w.local_snps.size(), w2.labels.data() + w2_base[(size_t)i]);
-    });
-    if (int rc = run_wave(w2, &k_ms[2])) return rc;
-
-    // ---- wave 3: re-clustering after dropping small clusters (separate_reads.cpp:924-971) ----
-    CwWave w3;
-    w3.inst_graph = w2.inst_graph; w3.inst_label_base = w2.inst_label_base; w3.labels.resize(w2.labels.size());
-    parallel_for((int)wrefs.size(), n_threads, [&](int i) {
-        if (w2_base[(size_t)i] < 0) return;
-        SrContigState& s = st[(size_t)wrefs[(size_t)i].c];
-        SrWindowPlan& w = s.windows[(size_t)wrefs[(size_t)i].w];
-        sr_reclustered_init_labels(s, w, w2.labels.data() + w2_base[(size_t)i], w3.labels.data() + w2_base[(size_t)i]);
-    });
-    if (int rc = run_wave(w3, &k_ms[3])) return rc;
 
     const double t_waves_done = now_ms();
     // ---- tail of finalize_clustering on the host ----
@@ -330,7 +316,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         if (w2_base[(size_t)i] < 0) {
             w.labels.resize((size_t)s.N);
             for (int r = 0; r < s.N; ++r) w.labels[(size_t)r] = w.mask[(size_t)r] ? -1 : -2;
-        } else sr_finish_window(s, w, w3.labels.data() + w2_base[(size_t)i], lowmem);
+        } else sr_finish_window(s, w, chain_labels.data() + w2_base[(size_t)i], lowmem);
     });
 
     const double t_finish_done = now_ms();

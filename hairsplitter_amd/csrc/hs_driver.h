@@ -46,8 +46,22 @@ struct CwWave {                       // one batched launch of the Chinese-Whisp
     std::vector<int32_t> labels;      // in: initial labels, out: result
 };
 
+// The three dependent Chinese-Whispers waves of every clustering window, kept on the device end to end:
+// per-SNP runs seeded from the SNP columns (separate_reads.cpp:1674-1705) -> merged ids (:840-874) -> run on the
+// finalize graph (:881) -> small clusters dropped + renumbered (:924-955) -> run (:970). Only the last labels return.
+struct CwChain {
+    std::vector<int64_t> col_off;          // SNP columns of all contigs, concatenated CSR [S+1]
+    std::vector<int32_t> col_idx;
+    std::vector<uint8_t> col_code;
+    std::vector<int32_t> win_graph_now, win_graph_final, win_n;   // per clustering window (global graph ids of CwGraphSet)
+    std::vector<int64_t> win_seed_begin;   // [W+1] range of the window's seeding columns in seed_col
+    std::vector<int64_t> seed_col;         // global column index of every per-SNP run
+    std::vector<int64_t> win_label_base;   // [W+1] offset of the window's N output labels
+};
+
 struct SrDeviceOps {
     virtual ~SrDeviceOps() {}
+    virtual int cw_chain(const CwChain& chain, std::vector<int32_t>& labels, float k_ms[3]) = 0;
     // K5 for all contigs with n_reads[c] > 0; sim/diff are written at out_off[c]
     virtual int simdiff(const std::vector<uint64_t>& alt, const std::vector<uint64_t>& ref, const std::vector<int64_t>& plane_off,
                         const std::vector<int32_t>& n_reads, const std::vector<int32_t>& words, const std::vector<int64_t>& out_off,

@@ -224,58 +224,6 @@ void sr_build_window_graph(SrContigState& st, int window, float error_rate) {
     else build_graph_low_memory(st, w.mask.data(), error_rate, g);
 }
 
-// separate_reads.cpp:1678-1691: every masked read of the column starts in the cluster of the first read
-// that carries the same code; everybody else starts alone
-void sr_local_init_labels(const SrContigState& st, const SrWindowPlan& w, int snp, int32_t* out) {
-    const hs_sr_contig& c = *st.c;
-    for (int r = 0; r < st.N; ++r) out[r] = r;
-    int first_of_code[256];
-    for (int i = 0; i < 256; ++i) first_of_code[i] = -1;
-    for (int64_t e = c.col_off[snp]; e < c.col_off[snp + 1]; ++e) {
-        const int r = c.col_idx[e];
-        if (!w.mask[r]) continue;
-        const uint8_t code = c.col_code[e];
-        if (first_of_code[code] < 0) first_of_code[code] = r;
-        out[r] = first_of_code[code];
-    }
-}
-
-// merge_clusterings: separate_reads.cpp:840-874 (ids from sum label_i * 2^i accumulated in double)
-void sr_merged_init_labels(const SrContigState& st, const SrWindowPlan& w, const int32_t* local, int n_local, int32_t* out) {
-    const int N = st.N;
-    std::vector<double> agg((size_t)N, 0.0);
-    for (int i = 0; i < n_local; ++i) {
-        const double f = std::pow(2.0, (double)i);
-        const int32_t* l = local + (size_t)i * N;
-        for (int j = 0; j < N; ++j) agg[j] += l[j] * f;
-    }
-    std::unordered_map<double, int> ids;
-    int index = 0;
-    for (int j = 0; j < N; ++j) {
-        auto it = ids.find(agg[j]);
-        if (it == ids.end()) { ids.emplace(agg[j], index); out[j] = index; index++; }
-        else out[j] = it->second;
-    }
-    for (int j = 0; j < N; ++j) if (!w.mask[j]) out[j] = -2;
-}
-
-// finalize_clustering :924-955: drop clusters smaller than 5, renumber by first appearance
-void sr_reclustered_init_labels(const SrContigState& st, const SrWindowPlan& w, const int32_t* merged, int32_t* out) {
-    const int N = st.N;
-    std::unordered_map<int, int> sizes;
-    for (int r = 0; r < N; ++r) { out[r] = w.mask[r] ? merged[r] : -2; if (w.mask[r]) sizes[out[r]] += 1; }
-    for (int r = 0; r < N; ++r) if (out[r] != -2 && sizes[out[r]] < 5) out[r] = -1;
-    std::unordered_map<int, int> to_hap;
-    int hap = 0;
-    for (int r = 0; r < N; ++r) {
-        if (out[r] > -1) {
-            auto it = to_hap.find(out[r]);
-            if (it == to_hap.end()) { to_hap.emplace(out[r], hap); out[r] = hap; hap++; }
-            else out[r] = it->second;
-        }
-    }
-}
-
 // merge_close_clusters: cluster_graph.cpp:402-501
 static void merge_close_clusters(const SrGraph& g, bool low_memory, std::vector<int32_t>& clusters, const uint8_t* mask,
                                  const std::vector<int32_t>& order) {

@@ -25,9 +25,6 @@ std::vector<int32_t> shuffled_order(int n, uint32_t seed);
 void sr_build_planes(SrContigState& st);
 void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool low_memory);
 void sr_build_window_graph(SrContigState& st, int window, float error_rate);
-void sr_local_init_labels(const SrContigState& st, const SrWindowPlan& w, int snp, int32_t* out);
-void sr_merged_init_labels(const SrContigState& st, const SrWindowPlan& w, const int32_t* local, int n_local, int32_t* out);
-void sr_reclustered_init_labels(const SrContigState& st, const SrWindowPlan& w, const int32_t* merged, int32_t* out);
 void sr_finish_window(const SrContigState& st, SrWindowPlan& w, const int32_t* reclustered, bool low_memory);
 bool sr_ploidy_init_labels(const SrContigState& st, const SrWindowPlan& w, int max_haplotypes, int32_t* out);
 int32_t sr_window_size(const hs_sr_contig* cs, int n, bool amplicon);

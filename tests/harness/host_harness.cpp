@@ -8,7 +8,9 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <cmath>
 #include <map>
+#include <unordered_map>
 
 #include "../../hairsplitter_amd/csrc/hs_driver.h"
 #include "../../oracle/hs_oracle.h"
@@ -108,6 +110,59 @@ struct OracleSrOps : hs::SrDeviceOps {
         return 0;
     }
     int set_graphs(const hs::CwGraphSet& g) override { gs = g; return 0; }
+
+    std::vector<int> run_cw(int g, const std::vector<int>& init) {
+        const int N = gs.graph_n[(size_t)g];
+        std::vector<std::vector<int>> adj((size_t)N);
+        const int32_t* off = gs.adj_off.data() + gs.graph_off_base[(size_t)g];
+        const int32_t* nb = gs.adj.data() + gs.graph_adj_base[(size_t)g];
+        for (int r = 0; r < N; ++r) adj[(size_t)r].assign(nb + off[r], nb + off[r + 1]);
+        std::vector<bool> mask((size_t)N);
+        for (int r = 0; r < N; ++r) mask[(size_t)r] = gs.mask[(size_t)(gs.graph_off_base[(size_t)g] - g) + (size_t)r] != 0;
+        return hso::chinese_whispers(adj, init, mask, seed);
+    }
+    const uint8_t* mask_of(int g) const { return gs.mask.data() + (size_t)(gs.graph_off_base[(size_t)g] - g); }
+
+    // CPU statement of the device-resident chain (separate_reads.cpp:1674-1705, :840-885, :924-971)
+    int cw_chain(const hs::CwChain& ch, std::vector<int32_t>& labels, float k_ms[3]) override {
+        (void)k_ms;
+        const int W = (int)ch.win_n.size();
+        labels.assign((size_t)ch.win_label_base.back(), 0);
+        for (int w = 0; w < W; ++w) {
+            const int N = ch.win_n[(size_t)w];
+            const uint8_t* mask = mask_of(ch.win_graph_now[(size_t)w]);
+            std::vector<std::vector<int>> local;
+            for (int64_t i = ch.win_seed_begin[(size_t)w]; i < ch.win_seed_begin[(size_t)w + 1]; ++i) {
+                const int64_t s = ch.seed_col[(size_t)i];
+                std::vector<int> start((size_t)N);
+                for (int r = 0; r < N; ++r) start[(size_t)r] = r;
+                std::map<unsigned char, int> first;
+                for (int64_t e = ch.col_off[(size_t)s]; e < ch.col_off[(size_t)s + 1]; ++e) {
+                    const int r = ch.col_idx[(size_t)e];
+                    if (!mask[r]) continue;
+                    if (!first.count(ch.col_code[(size_t)e])) first[ch.col_code[(size_t)e]] = r;
+                    start[(size_t)r] = first[ch.col_code[(size_t)e]];
+                }
+                local.push_back(run_cw(ch.win_graph_now[(size_t)w], start));
+            }
+            // merge_clusterings :840-874
+            std::vector<double> agg((size_t)N, 0.0);
+            for (size_t i = 0; i < local.size(); ++i) for (int j = 0; j < N; ++j) agg[(size_t)j] += local[i][(size_t)j] * std::pow(2.0, (double)i);
+            std::unordered_map<double, int> ids; std::vector<int> merged((size_t)N); int index = 0;
+            for (int j = 0; j < N; ++j) { auto it = ids.find(agg[(size_t)j]); if (it == ids.end()) { ids[agg[(size_t)j]] = index; merged[(size_t)j] = index++; } else merged[(size_t)j] = it->second; }
+            for (int j = 0; j < N; ++j) if (!mask[j]) merged[(size_t)j] = -2;
+            std::vector<int> c2 = run_cw(ch.win_graph_final[(size_t)w], merged);
+            // finalize_clustering :924-955
+            std::map<int, int> sizes;
+            for (int r = 0; r < N; ++r) { if (!mask[r]) c2[(size_t)r] = -2; else sizes[c2[(size_t)r]] += 1; }
+            for (int r = 0; r < N; ++r) if (c2[(size_t)r] != -2 && sizes[c2[(size_t)r]] < 5) c2[(size_t)r] = -1;
+            std::map<int, int> to_hap; int hap = 0;
+            for (int r = 0; r < N; ++r) if (c2[(size_t)r] > -1) { if (!to_hap.count(c2[(size_t)r])) to_hap[c2[(size_t)r]] = hap++; c2[(size_t)r] = to_hap[c2[(size_t)r]]; }
+            std::vector<int> c3 = run_cw(ch.win_graph_final[(size_t)w], c2);
+            std::copy(c3.begin(), c3.end(), labels.begin() + ch.win_label_base[(size_t)w]);
+        }
+        return 0;
+    }
     int cw(hs::CwWave& wv, float* k_ms) override {
         (void)k_ms;
         for (size_t i = 0; i < wv.inst_graph.size(); ++i) {
