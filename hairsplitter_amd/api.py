@@ -401,7 +401,8 @@ def pileup(t, flat: FlatBatch, ev_per_task: int = 4096):
 
 def column_stats(t, flat: FlatBatch, pile, min_second: int = 0):
     """K2; returns a numpy structured view: key u8[4], cnt u16[5], depth u16 per position (and, when min_second > 0,
-    the compact selection: sorted global positions + depths)."""
+    the compact selection -- second count > min_second, or == min_second with no third allele -- as sorted global
+    positions + depths)."""
     import torch
     require_gpu()
     total = int(flat.contig_off[-1])

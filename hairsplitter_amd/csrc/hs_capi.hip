@@ -37,17 +37,40 @@ using hs::set_error;
 
 namespace {
 
-// RAII device buffer
+// Size-class pool of device / pinned-host blocks: the stage drivers allocate dozens of temporaries per call and
+// hipMalloc/hipFree (which synchronises) would dominate small batches. Blocks are kept for the life of the process.
+struct BlockPool {
+    std::mutex mu;
+    std::vector<std::pair<size_t, void*>> free_dev, free_host;
+    static size_t round_up(size_t n) { size_t c = 4096; while (c < n) c <<= 1; return c; }
+    int get(bool host, size_t n, void** out, size_t* cap) {
+        const size_t c = round_up(n);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto& fl = host ? free_host : free_dev;
+            for (size_t i = 0; i < fl.size(); ++i)
+                if (fl[i].first == c) { *out = fl[i].second; *cap = c; fl[i] = fl.back(); fl.pop_back(); return HS_OK; }
+        }
+        if (host) HS_HIP(hipHostMalloc(out, c, hipHostMallocDefault)); else HS_HIP(hipMalloc(out, c));
+        *cap = c;
+        return HS_OK;
+    }
+    void put(bool host, void* p, size_t cap) {
+        std::lock_guard<std::mutex> g(mu);
+        (host ? free_host : free_dev).push_back(std::make_pair(cap, p));
+    }
+};
+BlockPool& pool() { static BlockPool* p = new BlockPool(); return *p; }
+
+// RAII device buffer (pooled)
 struct DBuf {
     void* p = nullptr;
-    size_t bytes = 0;
-    ~DBuf() { if (p) (void)hipFree(p); }
+    size_t bytes = 0, cap = 0;
+    ~DBuf() { if (p) pool().put(false, p, cap); }
     int alloc(size_t n) {
-        if (p) { (void)hipFree(p); p = nullptr; }
+        if (p) { pool().put(false, p, cap); p = nullptr; }
         bytes = n;
-        if (n == 0) n = 16;
-        HS_HIP(hipMalloc(&p, n));
-        return HS_OK;
+        return pool().get(false, n ? n : 16, &p, &cap);
     }
     template <class T> int upload(const std::vector<T>& v) {
         int rc = alloc(v.size() * sizeof(T));
@@ -56,6 +79,17 @@ struct DBuf {
         return HS_OK;
     }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// pinned host buffer (pooled) for large downloads
+struct HBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~HBuf() { if (p) pool().put(true, p, cap); }
+    int alloc(size_t n) {
+        if (p) { pool().put(true, p, cap); p = nullptr; }
+        return pool().get(true, n ? n : 16, &p, &cap);
+    }
 };
 
 struct EventPair {
@@ -430,25 +464,30 @@ struct HipCvOps : hs::CvDeviceOps {
         return HS_OK;
     }
 
+    HBuf h_col_idx, h_col_code;
     int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
-               std::vector<int32_t>& col_idx, std::vector<uint8_t>& col_code, float* k_ms) override {
+               const int32_t** col_idx, const uint8_t** col_code, float* k_ms) override {
         const int n_sel = (int)sel_pos.size();
+        const size_t total = (size_t)col_off.back();
+        if (int rc = h_col_idx.alloc(total * sizeof(int32_t))) return rc;
+        if (int rc = h_col_code.alloc(total)) return rc;
+        *col_idx = (const int32_t*)h_col_idx.p; *col_code = (const uint8_t*)h_col_code.p;
         if (n_sel == 0) return HS_OK;
         DBuf d_sc, d_sp, d_co, d_ci, d_cc;
         if (int rc = d_sc.upload(sel_contig)) return rc;
         if (int rc = d_sp.upload(sel_pos)) return rc;
         if (int rc = d_co.upload(col_off)) return rc;
-        if (int rc = d_ci.alloc(col_idx.size() * sizeof(int32_t))) return rc;
-        if (int rc = d_cc.alloc(col_code.size())) return rc;
+        if (int rc = d_ci.alloc(total * sizeof(int32_t))) return rc;
+        if (int rc = d_cc.alloc(total)) return rc;
         EventPair e; if (int rc = e.init()) return rc;
         HS_HIP(hipEventRecord(e.a, stream));
         if (int rc = hs_gather_columns(b->pile.as<uint8_t>(), b->d_pile_off.as<int64_t>(), b->d_rec_pos.as<int32_t>(), b->d_rec_qend.as<int32_t>(),
                                        b->d_contig_rec_off.as<int32_t>(), d_sc.as<int32_t>(), d_sp.as<int32_t>(), d_co.as<int64_t>(), n_sel,
                                        d_ci.as<int32_t>(), d_cc.as<uint8_t>(), stream)) return rc;
         HS_HIP(hipEventRecord(e.b, stream));
-        if (!col_idx.empty()) {
-            HS_HIP(hipMemcpy(col_idx.data(), d_ci.p, col_idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-            HS_HIP(hipMemcpy(col_code.data(), d_cc.p, col_code.size(), hipMemcpyDeviceToHost));
+        if (total) {
+            HS_HIP(hipMemcpy(h_col_idx.p, d_ci.p, total * sizeof(int32_t), hipMemcpyDeviceToHost));
+            HS_HIP(hipMemcpy(h_col_code.p, d_cc.p, total, hipMemcpyDeviceToHost));
         }
         return e.ms(k_ms);
     }
@@ -458,11 +497,12 @@ struct HipCvOps : hs::CvDeviceOps {
 struct HipSrOps : hs::SrDeviceOps {
     hipStream_t stream = nullptr;
     DBuf d_adj_off, d_adj, d_gob, d_gab, d_gn, d_perm, d_pb, d_mask;
+    HBuf h_sim, h_diff;
     int max_n = 1;
 
     int simdiff(const std::vector<uint64_t>& alt, const std::vector<uint64_t>& ref, const std::vector<int64_t>& plane_off,
                 const std::vector<int32_t>& n_reads, const std::vector<int32_t>& words, const std::vector<int64_t>& out_off,
-                int64_t out_total, std::vector<int32_t>& sim, std::vector<int32_t>& diff, float* k_ms) override {
+                int64_t out_total, const int32_t** sim, const int32_t** diff, float* k_ms) override {
         DBuf d_alt, d_ref, d_po, d_n, d_w, d_oo, d_sim, d_diff, t_c, t_i, t_j;
         if (int rc = d_alt.upload(alt)) return rc;
         if (int rc = d_ref.upload(ref)) return rc;
@@ -477,9 +517,11 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = simdiff_launch(d_alt.as<uint64_t>(), d_ref.as<uint64_t>(), d_po.as<int64_t>(), d_n.as<int32_t>(), d_w.as<int32_t>(),
                                     d_oo.as<int64_t>(), n_reads, d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, t_c, t_i, t_j)) return rc;
         HS_HIP(hipEventRecord(ev.b, stream));
-        sim.resize((size_t)out_total); diff.resize((size_t)out_total);
-        HS_HIP(hipMemcpy(sim.data(), d_sim.p, (size_t)out_total * sizeof(int32_t), hipMemcpyDeviceToHost));
-        HS_HIP(hipMemcpy(diff.data(), d_diff.p, (size_t)out_total * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (int rc = h_sim.alloc((size_t)out_total * sizeof(int32_t))) return rc;
+        if (int rc = h_diff.alloc((size_t)out_total * sizeof(int32_t))) return rc;
+        HS_HIP(hipMemcpy(h_sim.p, d_sim.p, (size_t)out_total * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HS_HIP(hipMemcpy(h_diff.p, d_diff.p, (size_t)out_total * sizeof(int32_t), hipMemcpyDeviceToHost));
+        *sim = (const int32_t*)h_sim.p; *diff = (const int32_t*)h_diff.p;
         float m = 0; if (int rc = ev.ms(&m)) return rc;
         if (k_ms) *k_ms += m;
         return HS_OK;

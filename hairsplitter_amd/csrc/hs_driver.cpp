@@ -68,8 +68,17 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
     if (int rc = dev.pileup_and_select(rec_stats, 4, sel_gpos, sel_depth, k_ms)) return rc;
     const double t_k12_done = now_ms();
     std::vector<size_t> order(sel_gpos.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return sel_gpos[x] < sel_gpos[y]; });
+    {   // bucket by 256-position tile (the unit the device appends in), then order the few entries of each tile
+        const size_t n_tiles = (size_t)((b.total_len + 255) / 256);
+        std::vector<uint32_t> start(n_tiles + 1, 0);
+        for (int64_t g : sel_gpos) start[(size_t)(g >> 8) + 1]++;
+        for (size_t t = 0; t < n_tiles; ++t) start[t + 1] += start[t];
+        std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+        for (size_t i = 0; i < sel_gpos.size(); ++i) order[fill[(size_t)(sel_gpos[i] >> 8)]++] = i;
+        for (size_t t = 0; t < n_tiles; ++t)
+            if (start[t + 1] - start[t] > 1)
+                std::sort(order.begin() + start[t], order.begin() + start[t + 1], [&](size_t x, size_t y) { return sel_gpos[x] < sel_gpos[y]; });
+    }
     std::vector<int32_t> sel_contig(order.size()), sel_pos(order.size());
     std::vector<int64_t> col_off(order.size() + 1, 0);
     std::vector<int64_t> contig_sel_off((size_t)C + 1, 0);
@@ -83,10 +92,10 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
         }
         for (int k = c + 1; k <= C; ++k) contig_sel_off[(size_t)k] = (int64_t)order.size();
     }
-    std::vector<int32_t> col_idx((size_t)col_off.back());
-    std::vector<uint8_t> col_code((size_t)col_off.back());
+    const int32_t* col_idx = nullptr;
+    const uint8_t* col_code = nullptr;
     const double t_sel_done = now_ms();
-    if (int rc = dev.gather(sel_contig, sel_pos, col_off, col_idx, col_code, &k_ms[2])) return rc;
+    if (int rc = dev.gather(sel_contig, sel_pos, col_off, &col_idx, &col_code, &k_ms[2])) return rc;
     const double t_dev_done = now_ms();
 
     // host glue per contig
@@ -98,8 +107,8 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
         cs.pos.assign(sel_pos.begin() + s0, sel_pos.begin() + s1);
         cs.off.resize((size_t)(s1 - s0) + 1);
         for (int64_t i = s0; i <= s1; ++i) cs.off[(size_t)(i - s0)] = col_off[(size_t)i] - col_off[(size_t)s0];
-        cs.idx = col_idx.data() + col_off[(size_t)s0];
-        cs.code = col_code.data() + col_off[(size_t)s0];
+        cs.idx = col_idx + col_off[(size_t)s0];
+        cs.code = col_code + col_off[(size_t)s0];
         resolve_columns(cs);
         int64_t nerr = 0, nlen = 0;
         for (int r = b.contig_rec_off[(size_t)c]; r < b.contig_rec_off[(size_t)c + 1]; ++r) { nerr += rec_stats[(size_t)r * 4 + 1]; nlen += rec_stats[(size_t)r * 4 + 2]; }
@@ -116,25 +125,37 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
     hs_cv_result* R = (hs_cv_result*)std::calloc(1, sizeof(hs_cv_result));
     R->n_contigs = C;
     std::vector<float> md((size_t)C), dp((size_t)C);
-    std::vector<int64_t> snp_off((size_t)C + 1, 0), ocol_off(1, 0);
-    std::vector<int32_t> snp_pos, ocol_idx;
-    std::vector<uint8_t> snp_ref, snp_alt, ocol_code;
+    std::vector<int64_t> snp_off((size_t)C + 1, 0), ent_off((size_t)C + 1, 0);
     float total_error = 0; int n_err_contigs = 0;
     for (int c = 0; c < C; ++c) {
         md[(size_t)c] = res[(size_t)c].mean_distance; dp[(size_t)c] = res[(size_t)c].depth;
         if (res[(size_t)c].mean_distance > 0) { total_error += res[(size_t)c].mean_distance; n_err_contigs++; }   // call_variants.cpp:1312-1315
-        const ColumnSet& cs = sets[(size_t)c];
-        for (int ci : res[(size_t)c].snp_col) {
-            snp_pos.push_back(cs.pos[(size_t)ci]); snp_ref.push_back(cs.k0[(size_t)ci]); snp_alt.push_back(cs.k1[(size_t)ci]);
-            ocol_idx.insert(ocol_idx.end(), cs.idx + cs.off[(size_t)ci], cs.idx + cs.off[(size_t)ci + 1]);
-            ocol_code.insert(ocol_code.end(), cs.code + cs.off[(size_t)ci], cs.code + cs.off[(size_t)ci + 1]);
-            ocol_off.push_back((int64_t)ocol_idx.size());
-        }
-        snp_off[(size_t)c + 1] = (int64_t)snp_pos.size();
+        int64_t ent = 0;
+        for (int ci : res[(size_t)c].snp_col) ent += sets[(size_t)c].off[(size_t)ci + 1] - sets[(size_t)c].off[(size_t)ci];
+        snp_off[(size_t)c + 1] = snp_off[(size_t)c] + (int64_t)res[(size_t)c].snp_col.size();
+        ent_off[(size_t)c + 1] = ent_off[(size_t)c] + ent;
     }
-    R->mean_distance = dup_vec(md); R->depth = dup_vec(dp); R->snp_off = dup_vec(snp_off); R->snp_pos = dup_vec(snp_pos);
-    R->snp_ref = dup_vec(snp_ref); R->snp_alt = dup_vec(snp_alt); R->col_off = dup_vec(ocol_off); R->col_idx = dup_vec(ocol_idx);
-    R->col_code = dup_vec(ocol_code);
+    const int64_t S = snp_off[(size_t)C], E = ent_off[(size_t)C];
+    R->snp_pos = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t));
+    R->snp_ref = (uint8_t*)std::malloc(std::max<int64_t>(1, S));
+    R->snp_alt = (uint8_t*)std::malloc(std::max<int64_t>(1, S));
+    R->col_off = (int64_t*)std::malloc((S + 1) * sizeof(int64_t));
+    R->col_idx = (int32_t*)std::malloc(std::max<int64_t>(1, E) * sizeof(int32_t));
+    R->col_code = (uint8_t*)std::malloc(std::max<int64_t>(1, E));
+    R->col_off[0] = 0;
+    parallel_for(C, n_threads, [&](int c) {
+        const ColumnSet& cs = sets[(size_t)c];
+        int64_t s = snp_off[(size_t)c], e = ent_off[(size_t)c];
+        for (int ci : res[(size_t)c].snp_col) {
+            const int64_t n = cs.off[(size_t)ci + 1] - cs.off[(size_t)ci];
+            R->snp_pos[s] = cs.pos[(size_t)ci]; R->snp_ref[s] = cs.k0[(size_t)ci]; R->snp_alt[s] = cs.k1[(size_t)ci];
+            std::memcpy(R->col_idx + e, cs.idx + cs.off[(size_t)ci], (size_t)n * sizeof(int32_t));
+            std::memcpy(R->col_code + e, cs.code + cs.off[(size_t)ci], (size_t)n);
+            e += n; s++;
+            R->col_off[s] = e;
+        }
+    });
+    R->mean_distance = dup_vec(md); R->depth = dup_vec(dp); R->snp_off = dup_vec(snp_off);
     R->error_rate = total_error / n_err_contigs;      // call_variants.cpp:1377 (float / int)
     R->n_contigs_with_error_rate = n_err_contigs;
     R->t_kernel_ms[0] = k_ms[0]; R->t_kernel_ms[1] = k_ms[1]; R->t_kernel_ms[2] = k_ms[2];
@@ -190,13 +211,12 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
                 std::copy(st[(size_t)c].alt_planes.begin(), st[(size_t)c].alt_planes.end(), alt.begin() + plane_off[(size_t)c]);
                 std::copy(st[(size_t)c].ref_planes.begin(), st[(size_t)c].ref_planes.end(), ref.begin() + plane_off[(size_t)c]);
             }
-            std::vector<int32_t> sim, diff;
-            if (int rc = dev.simdiff(alt, ref, plane_off, nreads, words, out_off, ow, sim, diff, &k_ms[0])) return rc;
+            const int32_t* sim = nullptr; const int32_t* diff = nullptr;
+            if (int rc = dev.simdiff(alt, ref, plane_off, nreads, words, out_off, ow, &sim, &diff, &k_ms[0])) return rc;
             for (int c = 0; c < C; ++c) {
                 if (!nreads[(size_t)c]) continue;
-                const size_t nn = (size_t)st[(size_t)c].N * st[(size_t)c].N;
-                st[(size_t)c].sim.assign(sim.begin() + out_off[(size_t)c], sim.begin() + out_off[(size_t)c] + nn);
-                st[(size_t)c].diff.assign(diff.begin() + out_off[(size_t)c], diff.begin() + out_off[(size_t)c] + nn);
+                st[(size_t)c].sim = sim + out_off[(size_t)c];
+                st[(size_t)c].diff = diff + out_off[(size_t)c];
             }
         }
         dev_ms += now_ms() - t0;
@@ -215,7 +235,6 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
                 if (st[(size_t)c].windows[w].has_snps) tasks.push_back(std::make_pair(c, (int)w));
         parallel_for((int)tasks.size(), n_threads, [&](int i) { sr_build_window_graph(st[(size_t)tasks[(size_t)i].first], tasks[(size_t)i].second, error_rate); });
     }
-    for (int c = 0; c < C; ++c) { std::vector<int32_t>().swap(st[(size_t)c].sim); std::vector<int32_t>().swap(st[(size_t)c].diff); }
 
     const double t_plan_done = now_ms();
     // ---- all graphs of the batch, uploaded once; a graph belongs to exactly one window (its mask) ----
@@ -280,10 +299,10 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
             col_base_of_contig[(size_t)c] = (int64_t)ch.col_off.size() - 1;
             const hs_sr_contig& hc = contigs[c];
             if (hc.n_snps == 0) continue;
-            const int64_t e_base = (int64_t)ch.col_idx.size();
-            for (int s = 0; s < hc.n_snps; ++s) ch.col_off.push_back(e_base + hc.col_off[s + 1]);
-            ch.col_idx.insert(ch.col_idx.end(), hc.col_idx, hc.col_idx + hc.col_off[hc.n_snps]);
-            ch.col_code.insert(ch.col_code.end(), hc.col_code, hc.col_code + hc.col_off[hc.n_snps]);
+            const int64_t e_base = (int64_t)ch.col_idx.size(), o0 = hc.col_off[0];   // col_off need not start at 0
+            for (int s = 0; s < hc.n_snps; ++s) ch.col_off.push_back(e_base + hc.col_off[s + 1] - o0);
+            ch.col_idx.insert(ch.col_idx.end(), hc.col_idx + o0, hc.col_idx + hc.col_off[hc.n_snps]);
+            ch.col_code.insert(ch.col_code.end(), hc.col_code + o0, hc.col_code + hc.col_off[hc.n_snps]);
         }
         ch.win_seed_begin.assign(1, 0);
         ch.win_label_base.assign(1, 0);
@@ -374,9 +393,10 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
 int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, const hs_cv_result* cv, float error_rate, float rsa, int32_t low_memory,
                    int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out) {
     const int C = b.n_contigs;
+    const double t_prep0 = now_ms();
     std::vector<hs_sr_contig> hc((size_t)C);
-    std::vector<std::vector<int32_t>> rs((size_t)C), re((size_t)C), spos((size_t)C), cidx((size_t)C);
-    std::vector<std::vector<uint8_t>> sref((size_t)C), salt((size_t)C), ccode((size_t)C);
+    std::vector<std::vector<int32_t>> rs((size_t)C), re((size_t)C), spos((size_t)C);
+    std::vector<std::vector<uint8_t>> sref((size_t)C), salt((size_t)C);
     std::vector<std::vector<int64_t>> coff((size_t)C);
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
     parallel_for(C, n_threads, [&](int c) {
@@ -387,24 +407,52 @@ int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, const hs_cv_result* cv, fl
             rs[(size_t)c][(size_t)(r - r0)] = b.rec_pos[(size_t)r];
             re[(size_t)c][(size_t)(r - r0)] = (int32_t)(b.rec_pos[(size_t)r] + 1 + b.rec_refspan[(size_t)r]);
         }
-        coff[(size_t)c].assign(1, 0);
-        for (int64_t s = cv->snp_off[c]; s < cv->snp_off[c + 1]; ++s) {
-            const int64_t e0 = cv->col_off[s], e1 = cv->col_off[s + 1];
+        // SNPs whose second base is rarer than the threshold are dropped (parse_column_file, separate_reads.cpp:167).
+        // Offsets stay global: the columns themselves are not copied.
+        const int64_t s0 = cv->snp_off[c], s1 = cv->snp_off[c + 1];
+        bool all_kept = true;
+        std::vector<char> keep((size_t)(s1 - s0), 1);
+        for (int64_t s = s0; s < s1; ++s) {
             int maj = 0, sec = 0;
-            for (int64_t e = e0; e < e1; ++e) { if (cv->col_code[e] == cv->snp_ref[s]) maj++; else if (cv->col_code[e] == cv->snp_alt[s]) sec++; }
-            if (!((float)sec >= rsa * (float)(maj + sec))) continue;   // parse_column_file, separate_reads.cpp:167
-            spos[(size_t)c].push_back(cv->snp_pos[s]); sref[(size_t)c].push_back(cv->snp_ref[s]); salt[(size_t)c].push_back(cv->snp_alt[s]);
-            cidx[(size_t)c].insert(cidx[(size_t)c].end(), cv->col_idx + e0, cv->col_idx + e1);
-            ccode[(size_t)c].insert(ccode[(size_t)c].end(), cv->col_code + e0, cv->col_code + e1);
-            coff[(size_t)c].push_back((int64_t)cidx[(size_t)c].size());
+            for (int64_t e = cv->col_off[s]; e < cv->col_off[s + 1]; ++e) { if (cv->col_code[e] == cv->snp_ref[s]) maj++; else if (cv->col_code[e] == cv->snp_alt[s]) sec++; }
+            if (!((float)sec >= rsa * (float)(maj + sec))) { keep[(size_t)(s - s0)] = 0; all_kept = false; }
         }
         hs_sr_contig& h = hc[(size_t)c];
         h.length = b.contig_off[(size_t)c + 1] - b.contig_off[(size_t)c];
         h.n_reads = r1 - r0; h.read_start = rs[(size_t)c].data(); h.read_end = re[(size_t)c].data();
+        h.col_idx = cv->col_idx; h.col_code = cv->col_code; h.ploidy = 0;
+        if (all_kept) {
+            h.n_snps = (int32_t)(s1 - s0); h.snp_pos = cv->snp_pos + s0; h.snp_ref = cv->snp_ref + s0; h.snp_alt = cv->snp_alt + s0;
+            h.col_off = cv->col_off + s0;
+        } else {
+            // a dropped column leaves a hole a single offset array cannot express: private copies (rare path, below)
+            coff[(size_t)c].assign(1, 0);
+            for (int64_t s = s0; s < s1; ++s) {
+                if (!keep[(size_t)(s - s0)]) continue;
+                spos[(size_t)c].push_back(cv->snp_pos[s]); sref[(size_t)c].push_back(cv->snp_ref[s]); salt[(size_t)c].push_back(cv->snp_alt[s]);
+            }
+            h.n_snps = -1;   // marker: filled after the parallel loop (needs private entry storage)
+        }
+    });
+    // rare path: contigs that lost SNPs get private column storage
+    std::vector<std::vector<int32_t>> cidx((size_t)C);
+    std::vector<std::vector<uint8_t>> ccode((size_t)C);
+    for (int c = 0; c < C; ++c) {
+        hs_sr_contig& h = hc[(size_t)c];
+        if (h.n_snps != -1) continue;
+        size_t k = 0;
+        for (int64_t s = cv->snp_off[c]; s < cv->snp_off[c + 1]; ++s) {
+            if (k < spos[(size_t)c].size() && cv->snp_pos[s] == spos[(size_t)c][k]) {
+                cidx[(size_t)c].insert(cidx[(size_t)c].end(), cv->col_idx + cv->col_off[s], cv->col_idx + cv->col_off[s + 1]);
+                ccode[(size_t)c].insert(ccode[(size_t)c].end(), cv->col_code + cv->col_off[s], cv->col_code + cv->col_off[s + 1]);
+                coff[(size_t)c].push_back((int64_t)cidx[(size_t)c].size());
+                k++;
+            }
+        }
         h.n_snps = (int32_t)spos[(size_t)c].size(); h.snp_pos = spos[(size_t)c].data(); h.snp_ref = sref[(size_t)c].data(); h.snp_alt = salt[(size_t)c].data();
         h.col_off = coff[(size_t)c].data(); h.col_idx = cidx[(size_t)c].data(); h.col_code = ccode[(size_t)c].data();
-        h.ploidy = 0;
-    });
+    }
+    if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] sr hand-over from stage 3: %.2f ms\n", now_ms() - t_prep0);
     const int32_t w = window_size > 0 ? window_size : sr_window_size(hc.data(), C, amplicon != 0);
     return sr_run(dev, hc.data(), C, w, error_rate, low_memory, seed, n_threads, out);
 }

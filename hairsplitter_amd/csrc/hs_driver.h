@@ -22,13 +22,14 @@ struct CvMeta {                       // host-side description of a stage-3 batc
 
 struct CvDeviceOps {
     virtual ~CvDeviceOps() {}
-    // K0+K1 + K2: per-record {q_end, n_err, n_len, n_events}; the global positions (unordered) whose second count is
-    // >= min_second with their depth; k_ms = {cigar scan + pileup, column_stats}
+    // K0+K1 + K2: per-record {q_end, n_err, n_len, n_events}; the global positions (unordered) whose second count c1 is
+    // > min_second, or == min_second with a zero third count, with their depth; k_ms = {cigar scan + pileup, column_stats}
     virtual int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, std::vector<int64_t>& sel_gpos,
                                   std::vector<int32_t>& sel_depth, float k_ms[2]) = 0;
-    // K3: columns of the selected positions
+    // K3: columns of the selected positions; the two output arrays (col_off.back() entries) are owned by the
+    // implementation and stay valid until the next gather call or its destruction
     virtual int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos,
-                       const std::vector<int64_t>& col_off, std::vector<int32_t>& col_idx, std::vector<uint8_t>& col_code,
+                       const std::vector<int64_t>& col_off, const int32_t** col_idx, const uint8_t** col_code,
                        float* k_ms) = 0;
 };
 
@@ -62,10 +63,11 @@ struct CwChain {
 struct SrDeviceOps {
     virtual ~SrDeviceOps() {}
     virtual int cw_chain(const CwChain& chain, std::vector<int32_t>& labels, float k_ms[3]) = 0;
-    // K5 for all contigs with n_reads[c] > 0; sim/diff are written at out_off[c]
+    // K5 for all contigs with n_reads[c] > 0; results at out_off[c] of host buffers owned by the implementation
+    // (valid until the next simdiff call or the destruction of the interface)
     virtual int simdiff(const std::vector<uint64_t>& alt, const std::vector<uint64_t>& ref, const std::vector<int64_t>& plane_off,
                         const std::vector<int32_t>& n_reads, const std::vector<int32_t>& words, const std::vector<int64_t>& out_off,
-                        int64_t out_total, std::vector<int32_t>& sim, std::vector<int32_t>& diff, float* k_ms) = 0;
+                        int64_t out_total, const int32_t** sim, const int32_t** diff, float* k_ms) = 0;
     virtual int set_graphs(const CwGraphSet& g) = 0;
     virtual int cw(CwWave& wave, float* k_ms) = 0;
 };

@@ -85,8 +85,8 @@ static void build_graph_matrix(const SrContigState& st, const uint8_t* mask, flo
     std::vector<int> picked;
     for (int r1 = 0; r1 < N; ++r1) {
         if (!mask[r1]) continue;
-        const int32_t* srow = st.sim.data() + (size_t)r1 * N;    // symmetric: row r1 == column r1
-        const int32_t* drow = st.diff.data() + (size_t)r1 * N;
+        const int32_t* srow = st.sim + (size_t)r1 * N;    // symmetric: row r1 == column r1
+        const int32_t* drow = st.diff + (size_t)r1 * N;
         int max_compat = 0;
         for (int r = 0; r < N; ++r) {
             float d = 0;

@@ -14,7 +14,8 @@ struct SrContigState {
     int words = 0;
     bool low_memory_now = false;
     std::vector<uint64_t> alt_planes, ref_planes;   // [N][words] bit-planes (second_base / ref_base per SNP)
-    std::vector<int32_t> sim, diff;                 // [N][N] device results (empty on the low-memory path)
+    const int32_t* sim = nullptr;                   // [N][N] device results, owned by the device interface
+    const int32_t* diff = nullptr;                  // (null on the low-memory path)
     std::vector<SrGraph> graphs;
     int empty_graph = -1;
     std::vector<struct SrWindowPlan> windows;

@@ -305,7 +305,8 @@ __global__ __launch_bounds__(256) void k_column_stats(
         reinterpret_cast<uint4*>(stats)[g] = o;
     }
     if (sel_count) {
-        const bool sel = g < total && c1 >= min_second;
+        // second count above the floor, or exactly at it with no third allele at all (the only way c1 > 5*c2 can hold there)
+        const bool sel = g < total && (c1 > min_second || (c1 == min_second && c2 == 0));
         const unsigned long long m = __ballot(sel);
         if (m) {
             int base = 0;

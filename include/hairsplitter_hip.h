@@ -198,7 +198,7 @@ typedef struct hs_sr_contig {
     const int32_t* snp_pos;
     const uint8_t* snp_ref;
     const uint8_t* snp_alt;
-    const int64_t* col_off;    /* [n_snps+1] */
+    const int64_t* col_off;    /* [n_snps+1] offsets into col_idx / col_code (need not start at 0) */
     const int32_t* col_idx;
     const uint8_t* col_code;
     int32_t ploidy;            /* 0 = unlimited (separate_reads.cpp:1454-1458) */

@@ -26,6 +26,8 @@ namespace {
 struct OracleCvOps : hs::CvDeviceOps {
     const hs::CvFileInput& in;
     std::vector<std::vector<hso::Column>> cols;   // per contig
+    std::vector<int32_t> col_idx;
+    std::vector<uint8_t> col_code;
     explicit OracleCvOps(const hs::CvFileInput& i) : in(i) {}
 
     int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, std::vector<int64_t>& sel_gpos, std::vector<int32_t>& sel_depth,
@@ -64,7 +66,8 @@ struct OracleCvOps : hs::CvDeviceOps {
                 std::vector<std::pair<int, int>> v;   // (-count, code)
                 for (int k = 33; k < 158; ++k) if (cnt[k]) v.push_back(std::make_pair(-cnt[k], k));
                 std::sort(v.begin(), v.end());
-                if (v.size() >= 2 && -v[1].first >= min_second) {   // reversed on purpose: the device list is unordered
+                const int c1v = v.size() >= 2 ? -v[1].first : 0, c2v = v.size() >= 3 ? -v[2].first : 0;
+                if (c1v > min_second || (c1v == min_second && c2v == 0)) {   // reversed on purpose: the device list is unordered
                     sel_gpos.insert(sel_gpos.begin(), base + (int64_t)p);
                     sel_depth.insert(sel_depth.begin(), (int32_t)m.cols[p].content.size());
                 }
@@ -74,8 +77,10 @@ struct OracleCvOps : hs::CvDeviceOps {
         return 0;
     }
     int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
-               std::vector<int32_t>& col_idx, std::vector<uint8_t>& col_code, float* k_ms) override {
+               const int32_t** col_idx_out, const uint8_t** col_code_out, float* k_ms) override {
         *k_ms = 0;
+        col_idx.assign((size_t)col_off.back(), 0); col_code.assign((size_t)col_off.back(), 0);
+        *col_idx_out = col_idx.data(); *col_code_out = col_code.data();
         for (size_t i = 0; i < sel_pos.size(); ++i) {
             const hso::Column& col = cols[(size_t)sel_contig[i]][(size_t)sel_pos[i]];
             for (size_t k = 0; k < col.content.size(); ++k) { col_idx[(size_t)col_off[i] + k] = (int32_t)col.readIdxs[k]; col_code[(size_t)col_off[i] + k] = col.content[k]; }
@@ -86,13 +91,15 @@ struct OracleCvOps : hs::CvDeviceOps {
 
 struct OracleSrOps : hs::SrDeviceOps {
     hs::CwGraphSet gs;
+    std::vector<int32_t> sim, diff;
     uint32_t seed;
     explicit OracleSrOps(uint32_t s) : seed(s) {}
     int simdiff(const std::vector<uint64_t>& alt, const std::vector<uint64_t>& ref, const std::vector<int64_t>& plane_off,
                 const std::vector<int32_t>& n_reads, const std::vector<int32_t>& words, const std::vector<int64_t>& out_off,
-                int64_t out_total, std::vector<int32_t>& sim, std::vector<int32_t>& diff, float* k_ms) override {
+                int64_t out_total, const int32_t** sim_out, const int32_t** diff_out, float* k_ms) override {
         (void)k_ms;
         sim.assign((size_t)out_total, 0); diff.assign((size_t)out_total, 0);
+        *sim_out = sim.data(); *diff_out = diff.data();
         for (size_t c = 0; c < n_reads.size(); ++c) {
             const int N = n_reads[c], W = words[c];
             for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) {
