@@ -399,7 +399,7 @@ def pileup(t, flat: FlatBatch, ev_per_task: int = 4096):
     return pile[:flat.aligned_bp], stats[:flat.n_rec]
 
 
-def column_stats(t, flat: FlatBatch, pile, min_second: int = 0):
+def column_stats(t, flat: FlatBatch, pile, min_second: int = 0, max_depth: int = 0):
     """K2; returns a numpy structured view: key u8[4], cnt u16[5], depth u16 per position (and, when min_second > 0,
     the compact selection -- second count > min_second, or == min_second with no third allele -- as sorted global
     positions + depths)."""
@@ -416,7 +416,7 @@ def column_stats(t, flat: FlatBatch, pile, min_second: int = 0):
     else:
         args = (C.c_int32(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_int32(0))
     _check(load().hs_column_stats(_p(pile), _p(t["pile_off"]), _p(t["rec_pos"]), _p(t["rec_qend"]), _p(t["contig_rec_off"]),
-                                  _p(t["contig_off"]), C.c_int32(flat.n_contigs), _p(out), *args, C.c_void_p(0)))
+                                  _p(t["contig_off"]), C.c_int32(flat.n_contigs), _p(out), *args, C.c_int32(max_depth), C.c_void_p(0)))
     torch.cuda.synchronize()
     dt = np.dtype([("key", np.uint8, 4), ("cnt", np.uint16, 5), ("depth", np.uint16)])
     st = out[:total].cpu().numpy().view(dt).reshape(-1)

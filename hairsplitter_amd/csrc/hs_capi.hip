@@ -182,12 +182,17 @@ void hs_free_host(void* p) { std::free(p); }
 static int column_stats_launch(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
                                const int32_t* d_rec_qend, const int32_t* d_contig_rec_off, const int64_t* d_contig_off,
                                int32_t n_contigs, int64_t total_len, hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count,
-                               int64_t* d_sel_gpos, int32_t* d_sel_depth, int32_t sel_cap, void* stream) {
+                               int64_t* d_sel_gpos, int32_t* d_sel_depth, int32_t sel_cap, int32_t max_depth, void* stream) {
     if (total_len <= 0) return HS_OK;
     const int64_t grid = (total_len + 255) / 256;
-    hipLaunchKernelGGL(hsdev::k_column_stats, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_pile, d_pile_off,
-                       d_rec_pos, d_rec_qend, d_contig_rec_off, d_contig_off, n_contigs,
-                       reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap);
+    if (max_depth > 0 && max_depth <= 255)
+        hipLaunchKernelGGL(hsdev::k_column_stats<1>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_pile, d_pile_off,
+                           d_rec_pos, d_rec_qend, d_contig_rec_off, d_contig_off, n_contigs,
+                           reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap);
+    else
+        hipLaunchKernelGGL(hsdev::k_column_stats<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_pile, d_pile_off,
+                           d_rec_pos, d_rec_qend, d_contig_rec_off, d_contig_off, n_contigs,
+                           reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap);
     HS_HIP(hipGetLastError());
     return HS_OK;
 }
@@ -195,13 +200,13 @@ static int column_stats_launch(const uint8_t* d_pile, const int64_t* d_pile_off,
 int hs_column_stats(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
                     const int32_t* d_rec_qend, const int32_t* d_contig_rec_off, const int64_t* d_contig_off,
                     int32_t n_contigs, hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos,
-                    int32_t* d_sel_depth, int32_t sel_cap, void* stream) {
+                    int32_t* d_sel_depth, int32_t sel_cap, int32_t max_depth, void* stream) {
     if (int rc = require_device()) return rc;
     if (n_contigs <= 0) return HS_OK;
     int64_t total = 0;
     HS_HIP(hipMemcpy(&total, d_contig_off + n_contigs, sizeof(int64_t), hipMemcpyDeviceToHost));
     return column_stats_launch(d_pile, d_pile_off, d_rec_pos, d_rec_qend, d_contig_rec_off, d_contig_off, n_contigs, total,
-                               d_stats, min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap, stream);
+                               d_stats, min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap, max_depth, stream);
 }
 
 int hs_gather_columns(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
@@ -315,7 +320,7 @@ struct hs_cv_batch {
     std::vector<int32_t> contig_rec_off, rec_pos, rec_qend, rec_contig;
     std::vector<int64_t> rec_refspan;
     int64_t total_len = 0, total_pile = 0;
-    int32_t n_tasks = 0, ev_per_task = 4096;
+    int32_t n_tasks = 0, ev_per_task = 4096, max_depth = 0;
     DBuf contig_seq, d_contig_off, read_seq, read_off, rec_read, d_rec_contig, d_rec_pos, rec_strand, rec_cig_off, cigar,
         d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, colstats, rec_chunk_off, chunk_scratch, task_rec, task_ev0,
         sel_count, sel_gpos, sel_depth;
@@ -366,6 +371,17 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
         }
     }
     b->total_pile = b->pile_off[(size_t)n_rec];
+    {   // deepest position of the batch (sweep over record starts / ends): picks the histogram counter width of K2
+        std::vector<std::pair<int32_t, int32_t>> ev;
+        for (int c = 0; c < n_contigs; ++c) {
+            ev.clear();
+            for (int r = b->contig_rec_off[(size_t)c]; r < b->contig_rec_off[(size_t)c + 1]; ++r)
+                if (b->rec_qend[(size_t)r] > b->rec_pos[(size_t)r]) { ev.push_back(std::make_pair(b->rec_pos[(size_t)r], 1)); ev.push_back(std::make_pair(b->rec_qend[(size_t)r], -1)); }
+            std::sort(ev.begin(), ev.end());
+            int d = 0;
+            for (auto& e : ev) { d += e.second; b->max_depth = std::max(b->max_depth, d); }
+        }
+    }
     int rc = 0;
     auto up = [&](DBuf& d, const void* src, size_t bytes) {
         if (rc) return;
@@ -444,7 +460,7 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = column_stats_launch(b->pile.as<uint8_t>(), b->d_pile_off.as<int64_t>(), b->d_rec_pos.as<int32_t>(), b->d_rec_qend.as<int32_t>(),
                                          b->d_contig_rec_off.as<int32_t>(), b->d_contig_off.as<int64_t>(), b->n_contigs, b->total_len,
                                          b->colstats.as<hs_colstat>(), min_second, b->sel_count.as<int32_t>(), b->sel_gpos.as<int64_t>(),
-                                         b->sel_depth.as<int32_t>(), (int32_t)std::min<int64_t>(b->total_len, 0x7fffffff), stream)) return rc;
+                                         b->sel_depth.as<int32_t>(), (int32_t)std::min<int64_t>(b->total_len, 0x7fffffff), b->max_depth, stream)) return rc;
         HS_HIP(hipEventRecord(e2.b, stream));
         const double t1 = now();
         if (!rec_stats.empty()) HS_HIP(hipMemcpy(rec_stats.data(), b->rec_stats.p, rec_stats.size() * sizeof(int32_t), hipMemcpyDeviceToHost));

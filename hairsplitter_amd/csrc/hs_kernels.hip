@@ -207,13 +207,19 @@ __global__ __launch_bounds__(256) void k_pileup(
 // ------------------------------------------------------------------------------------------------
 #define HS_NBINS 125
 #define HS_LIST_CAP 1024
+// CB = bytes per counter: 1 when no position of the batch is deeper than 255 reads (32 KiB of LDS per workgroup, 4-5
+// workgroups per CU), 2 otherwise (63 KiB). Counters are packed 4 (or 2) per dword, dword-major ([word][lane]), so
+// the final scan reads one dword per 4 bins and skips empty ones.
+template <int CB>
 __global__ __launch_bounds__(256) void k_column_stats(
     const uint8_t* __restrict__ pile, const int64_t* __restrict__ pile_off,
     const int32_t* __restrict__ rec_pos, const int32_t* __restrict__ rec_qend,
     const int32_t* __restrict__ contig_rec_off, const int64_t* __restrict__ contig_off,
     int n_contigs, hs_colstat_dev* __restrict__ stats, int min_second, int32_t* __restrict__ sel_count,
     int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int sel_cap) {
-    __shared__ uint16_t hist[HS_NBINS * 256];
+    constexpr int PER_WORD = 4 / CB;
+    constexpr int NWORDS = (HS_NBINS + PER_WORD - 1) / PER_WORD;
+    __shared__ uint32_t hw[NWORDS * 256];
     __shared__ int32_t s_ps[HS_LIST_CAP], s_qe[HS_LIST_CAP];
     __shared__ int64_t s_po[HS_LIST_CAP];
     __shared__ int s_n;
@@ -222,7 +228,14 @@ __global__ __launch_bounds__(256) void k_column_stats(
     const int64_t total = contig_off[n_contigs];
     const int64_t g0 = (int64_t)blockIdx.x * 256;
     const int64_t g = g0 + tid;
-    for (int b = 0; b < HS_NBINS; ++b) hist[b * 256 + tid] = 0;
+#pragma unroll
+    for (int w = 0; w < NWORDS; ++w) hw[w * 256 + tid] = 0u;
+    uint8_t* const h8 = reinterpret_cast<uint8_t*>(hw);
+    uint16_t* const h16 = reinterpret_cast<uint16_t*>(hw);
+    auto bump = [&](int code) {
+        if (CB == 1) h8[(((code >> 2) * 256 + tid) << 2) + (code & 3)] += 1;
+        else h16[(((code >> 1) * 256 + tid) << 1) + (code & 1)] += 1;
+    };
     int c_first;
     {
         int lo = 0, hi = n_contigs - 1;
@@ -243,7 +256,6 @@ __global__ __launch_bounds__(256) void k_column_stats(
             __syncthreads();
             if (tid == 0) s_n = 0;
             __syncthreads();
-            // compact the records of [rb, rb_end) that overlap the tile
             for (int nb = rb; nb < rb_end; nb += 256) {
                 const int n = nb + tid;
                 int ps = 0, qe = 0;
@@ -261,22 +273,22 @@ __global__ __launch_bounds__(256) void k_column_stats(
             __syncthreads();
             const int cnt = s_n;
             int i = 0;
-            for (; i + 4 <= cnt; i += 4) {
-                int code[4];
+            for (; i + 8 <= cnt; i += 8) {
+                int code[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < 8; ++u) {
                     const int ps = s_ps[i + u], qe = s_qe[i + u];
                     code[u] = (mine && p >= ps && p < qe) ? (int)pile[s_po[i + u] + p] - 33 : -1;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (code[u] >= 0 && code[u] < HS_NBINS) hist[code[u] * 256 + tid] += 1;
+                for (int u = 0; u < 8; ++u)
+                    if (code[u] >= 0 && code[u] < HS_NBINS) bump(code[u]);
             }
             for (; i < cnt; ++i) {
                 const int ps = s_ps[i], qe = s_qe[i];
                 if (mine && p >= ps && p < qe) {
                     const int code = (int)pile[s_po[i] + p] - 33;
-                    if (code >= 0 && code < HS_NBINS) hist[code * 256 + tid] += 1;
+                    if (code >= 0 && code < HS_NBINS) bump(code);
                 }
             }
         }
@@ -285,16 +297,22 @@ __global__ __launch_bounds__(256) void k_column_stats(
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
     int depth = 0;
     if (g < total) {
-        for (int b = 0; b < HS_NBINS; ++b) {
-            const int v = (int)hist[b * 256 + tid];
-            depth += v;
-            if (v > c4) {
-                const int key = b + 33;
-                if (v > c0) { c4 = c3; c3 = c2; k3 = k2; c2 = c1; k2 = k1; c1 = c0; k1 = k0; c0 = v; k0 = key; }
-                else if (v > c1) { c4 = c3; c3 = c2; k3 = k2; c2 = c1; k2 = k1; c1 = v; k1 = key; }
-                else if (v > c2) { c4 = c3; c3 = c2; k3 = k2; c2 = v; k2 = key; }
-                else if (v > c3) { c4 = c3; c3 = v; k3 = key; }
-                else c4 = v;
+        for (int w = 0; w < NWORDS; ++w) {
+            const uint32_t word = hw[w * 256 + tid];
+            if (word == 0u) continue;
+#pragma unroll
+            for (int f = 0; f < PER_WORD; ++f) {
+                const int v = (int)((word >> (8 * CB * f)) & (CB == 1 ? 0xFFu : 0xFFFFu));
+                if (v == 0) continue;
+                depth += v;
+                if (v > c4) {
+                    const int key = w * PER_WORD + f + 33;
+                    if (v > c0) { c4 = c3; c3 = c2; k3 = k2; c2 = c1; k2 = k1; c1 = c0; k1 = k0; c0 = v; k0 = key; }
+                    else if (v > c1) { c4 = c3; c3 = c2; k3 = k2; c2 = c1; k2 = k1; c1 = v; k1 = key; }
+                    else if (v > c2) { c4 = c3; c3 = c2; k3 = k2; c2 = v; k2 = key; }
+                    else if (v > c3) { c4 = c3; c3 = v; k3 = key; }
+                    else c4 = v;
+                }
             }
         }
         uint4 o;

@@ -102,7 +102,8 @@ int hs_column_stats(const uint8_t* d_pile, const int64_t* d_pile_off, const int3
                     /* optional compact selection (all NULL / 0 to skip): global positions (index into the concatenated
                      * contigs) whose second count is >= min_second, unordered, with their depth; *d_sel_count must be 0 */
                     int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth, int32_t sel_cap,
-                    void* stream);
+                    /* upper bound on the depth of any position, if known (1..255 selects 8-bit LDS counters); 0 = unknown */
+                    int32_t max_depth, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K3 -- column extraction (pileup transposition for selected positions, coalesced writes).

@@ -54,6 +54,10 @@ def test_column_stats_counts(batch):
     flat, t = batch
     pile, _ = api.pileup(t, flat)
     st, sel_g, sel_d = api.column_stats(t, flat, pile, min_second=4)
+    # 8-bit counter variant (valid: no position of these batches is deeper than 255) must give the same bytes
+    st8, sel_g8, sel_d8 = api.column_stats(t, flat, pile, min_second=4, max_depth=255)
+    assert int(st["depth"].max()) <= 255
+    assert np.array_equal(st8.view(np.uint8), st.view(np.uint8)) and np.array_equal(sel_g8, sel_g) and np.array_equal(sel_d8, sel_d)
     hp = pile.cpu().numpy()
     exp_sel = np.flatnonzero((st["cnt"][:, 1] > 4) | ((st["cnt"][:, 1] == 4) & (st["cnt"][:, 2] == 0)))
     assert np.array_equal(sel_g, exp_sel) and np.array_equal(sel_d, st["depth"][exp_sel].astype(np.int32))
