@@ -19,10 +19,23 @@ static __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long 
     }
     return v;
 }
-static __device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+// wave64 inclusive prefix sum on the DPP network (row_shr within 16-lane rows, then row_bcast across rows): six
+// v_add_u32_dpp, no LDS round trips (hipcc lowers __shfl_* to ds_bpermute, ~10x the latency)
+static __device__ __forceinline__ int wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
     return v;
+}
+static __device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_incl(v), 63); }
+// value of the lane to the left (lane 0 receives `fill`)
+static __device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+static __device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -88,8 +101,14 @@ __global__ __launch_bounds__(256) void k_pileup(
     const int64_t* __restrict__ pile_off, const int64_t* __restrict__ rec_chunk_off,
     const int32_t* __restrict__ chunk_start, const int32_t* __restrict__ task_rec, const int32_t* __restrict__ task_ev0,
     int n_tasks, int ev_per_task, uint8_t* __restrict__ pile, int32_t* __restrict__ rec_stats) {
+    // per-wave LDS: the 64 ops of the current chunk (first event, read offset, reference offset, op code), the lanes of
+    // the ops that own events, and one "an op starts here" flag per event of the current 64-event window
+    __shared__ int4 s_op[4][64];
+    __shared__ uint8_t s_nzlane[4][64];
+    __shared__ uint8_t s_flag[4][64];
     const int lane = lane_id();
-    const int task = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int wv = (int)(threadIdx.x >> 6);
+    const int task = (int)blockIdx.x * 4 + wv;
     if (task >= n_tasks) return;   // wave-uniform
     const int r = task_rec[task];
     const int e0 = task_ev0[task];
@@ -110,6 +129,8 @@ __global__ __launch_bounds__(256) void k_pileup(
     uint8_t* __restrict__ out = pile + pile_off[r];
     const uint8_t* __restrict__ ctgp = contig_seq + coff;
     const uint8_t* __restrict__ rdp = read_seq + roff;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const unsigned long long le_mask = lt_mask | (1ull << lane);
 
     // last chunk whose first event is <= e_first (uniform bisection)
     int klo = 0, khi = n_chunks - 1;
@@ -126,39 +147,38 @@ __global__ __launch_bounds__(256) void k_pileup(
         const uint32_t op = in_range ? cigar[oi] : 0xFu;
         const int code = in_range ? (int)(op & 15u) : 15;
         const OpAdv a = op_advances(op, in_range);
-        int ev_inc = a.ev, rd_inc = a.rd, rf_inc = a.rf;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int x = __shfl_up(ev_inc, d, 64), y = __shfl_up(rd_inc, d, 64), z = __shfl_up(rf_inc, d, 64);
-            if (lane >= d) { ev_inc += x; rd_inc += y; rf_inc += z; }
-        }
+        const int ev_inc = wave_scan_incl(a.ev), rd_inc = wave_scan_incl(a.rd), rf_inc = wave_scan_incl(a.rf);
         const int ev_ex = ev_inc - a.ev;
-        const int t0 = t_cur + rd_inc - a.rd;
-        const int q0 = q_cur + rf_inc - a.rf;
-        const int chunk_ev = __shfl(ev_inc, 63, 64);
+        const int chunk_ev = __builtin_amdgcn_readlane(ev_inc, 63);
+        const bool nz = a.ev > 0;
+        const unsigned long long nzmask = __ballot(nz);
+        wave_lds_sync();   // the previous chunk's readers are done
+        s_op[wv][lane] = make_int4(ev_ex, t_cur + rd_inc - a.rd, q_cur + rf_inc - a.rf, code);
+        if (nz) s_nzlane[wv][__popcll(nzmask & lt_mask)] = (uint8_t)lane;
         const int lo_el = e_first > ev_base ? e_first - ev_base : 0;
         const int hi_el = (e1 - ev_base) < chunk_ev ? (e1 - ev_base) : chunk_ev;
 
         for (int eb = lo_el; eb < hi_el; eb += 64) {
+            // owner of every event of the window: ops that start inside it raise a flag at their first event; an event's
+            // owner is the (ops started before the window + flags at or left of it)-th op that owns events
+            s_flag[wv][lane] = 0;
+            wave_lds_sync();
+            const bool starts_here = nz && ev_ex >= eb && ev_ex < eb + 64;
+            if (starts_here) s_flag[wv][ev_ex - eb] = 1;
+            const int before = __popcll(__ballot(nz && ev_ex < eb));
+            wave_lds_sync();
+            const unsigned long long fm = __ballot(s_flag[wv][lane] != 0);
             const int e = eb + lane;
             const bool valid = e < hi_el;
-            int lo = 0, hi = 63;
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int mid = (lo + hi) >> 1;
-                const int v = __shfl(ev_inc, mid, 64);
-                if (v > e) hi = mid; else lo = mid + 1;
-            }
-            const int j = lo > 63 ? 63 : lo;
-            const int jev_ex = __shfl(ev_ex, j, 64);
-            const int jt0 = __shfl(t0, j, 64);
-            const int jq0 = __shfl(q0, j, 64);
-            const int jcode = __shfl(code, j, 64);
-            const int off = e - jev_ex;
+            int rank = before + __popcll(fm & le_mask) - 1;
+            rank = rank < 0 ? 0 : rank;
+            const int4 od = s_op[wv][s_nzlane[wv][rank]];
+            const int jcode = od.w;
+            const int off = e - od.x;
             const bool jM = jcode == 0 || jcode == 7 || jcode == 8;
             const bool jD = jcode == 2;
-            const int t = jt0 + off;
-            const int q = jq0 + ((jM || jD) ? off : 0);
+            const int t = od.y + off;
+            const int q = od.z + ((jM || jD) ? off : 0);
             const bool active = valid && (ev_base + e) >= e0 && q >= 0 && q < L;   // call_variants.cpp:217
             int c = 4;   // '-'
             if (!jD) {
@@ -167,24 +187,23 @@ __global__ __launch_bounds__(256) void k_pileup(
                 const int bb = valid && rlen > 0 ? (int)rdp[idx] : 0;
                 c = fwd ? bb : 3 - bb;
             }
-            const int cu1 = __shfl_up(c, 1, 64), cu2 = __shfl_up(c, 2, 64);
-            const int pr1 = lane >= 1 ? cu1 : p1;
-            const int pr2 = lane >= 2 ? cu2 : (lane == 1 ? p1 : p2);
+            const int cu1 = wave_shr1(c, p1);
+            const int cu2 = wave_shr1(cu1, p2);
             if (active) {
                 nlen++;
                 if (jM) {
-                    out[q - pos] = (uint8_t)(33 + 5 * pr2 + pr1 + 25 * c);    // call_variants.cpp:238-240
+                    out[q - pos] = (uint8_t)(33 + 5 * cu2 + cu1 + 25 * c);    // call_variants.cpp:238-240
                     if (c != (int)ctgp[q]) nerr++;                            // :254-256
                 } else if (jD) {
-                    out[q - pos] = (uint8_t)(33 + 5 * pr2 + pr1 + 25 * 4);    // :287-290
+                    out[q - pos] = (uint8_t)(33 + 5 * cu2 + cu1 + 25 * 4);    // :287-290
                     nerr++;
                 } else {
                     nerr++;                                                   // insertion :337
                 }
             }
             const int nv = (hi_el - eb) < 64 ? (hi_el - eb) : 64;
-            const int last = __shfl(c, nv - 1, 64);
-            const int last2 = nv >= 2 ? __shfl(c, nv - 2, 64) : p1;
+            const int last = __builtin_amdgcn_readlane(c, nv - 1);
+            const int last2 = nv >= 2 ? __builtin_amdgcn_readlane(c, nv - 2) : p1;
             p2 = last2; p1 = last;
         }
     }
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(256) void k_pileup(
 // selection list (wave-aggregated atomic), so the host never scans the per-position array.
 // ------------------------------------------------------------------------------------------------
 #define HS_NBINS 125
-#define HS_LIST_CAP 1024
+#define HS_LIST_CAP 512
 // CB = bytes per counter: 1 when no position of the batch is deeper than 255 reads (32 KiB of LDS per workgroup, 4-5
 // workgroups per CU), 2 otherwise (63 KiB). Counters are packed 4 (or 2) per dword, dword-major ([word][lane]), so
 // the final scan reads one dword per 4 bins and skips empty ones.
