@@ -180,26 +180,20 @@ __global__ __launch_bounds__(256) void k_pileup(
             const int t = od.y + off;
             const int q = od.z + ((jM || jD) ? off : 0);
             const bool active = valid && (ev_base + e) >= e0 && q >= 0 && q < L;   // call_variants.cpp:217
-            int c = 4;   // '-'
-            if (!jD) {
-                const int tt = t < 0 ? 0 : (t >= rlen ? rlen - 1 : t);   // the host validates CIGAR vs read length
-                const int idx = fwd ? tt : (rlen - 1 - tt);
-                const int bb = valid && rlen > 0 ? (int)rdp[idx] : 0;
-                c = fwd ? bb : 3 - bb;
-            }
+            // both loads are unconditional (indices clamped into the read / the contig) so that they issue back to back
+            const int tt = t < 0 ? 0 : (t >= rlen ? rlen - 1 : t);       // the host validates CIGAR vs read length
+            const int idx = fwd ? tt : (rlen - 1 - tt);
+            const int bb = (int)rdp[idx < 0 ? 0 : idx];
+            const int qq = q < 0 ? 0 : (q >= L ? L - 1 : q);
+            const int cref = (int)ctgp[qq];
+            const int c = jD ? 4 : (fwd ? bb : 3 - bb);                  // 4 == '-'
             const int cu1 = wave_shr1(c, p1);
             const int cu2 = wave_shr1(cu1, p2);
             if (active) {
                 nlen++;
-                if (jM) {
-                    out[q - pos] = (uint8_t)(33 + 5 * cu2 + cu1 + 25 * c);    // call_variants.cpp:238-240
-                    if (c != (int)ctgp[q]) nerr++;                            // :254-256
-                } else if (jD) {
-                    out[q - pos] = (uint8_t)(33 + 5 * cu2 + cu1 + 25 * 4);    // :287-290
-                    nerr++;
-                } else {
-                    nerr++;                                                   // insertion :337
-                }
+                // M: call_variants.cpp:238-240,254-256; D: :287-290; I: :337 (no column written)
+                nerr += (jM && c == cref) ? 0 : 1;
+                if (jM || jD) out[q - pos] = (uint8_t)(33 + 5 * cu2 + cu1 + 25 * c);
             }
             const int nv = (hi_el - eb) < 64 ? (hi_el - eb) : 64;
             const int last = __builtin_amdgcn_readlane(c, nv - 1);
@@ -291,24 +285,22 @@ __global__ __launch_bounds__(256) void k_column_stats(
             }
             __syncthreads();
             const int cnt = s_n;
-            int i = 0;
-            for (; i + 8 <= cnt; i += 8) {
+            // eight records per step; every load is unconditional (out-of-range lanes read byte 0 of the pileup and are
+            // masked afterwards) so that the eight byte loads are in flight together instead of one s_waitcnt each
+            for (int i = 0; i < cnt; i += 8) {
                 int code[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int ps = s_ps[i + u], qe = s_qe[i + u];
-                    code[u] = (mine && p >= ps && p < qe) ? (int)pile[s_po[i + u] + p] - 33 : -1;
+                    const int ii = (i + u) < cnt ? (i + u) : (cnt - 1);
+                    const int ps = s_ps[ii], qe = s_qe[ii];
+                    const bool in = mine && (i + u) < cnt && p >= ps && p < qe;
+                    const int64_t off = in ? (s_po[ii] + p) : 0;
+                    const int byte = (int)pile[off];
+                    code[u] = in ? byte - 33 : -1;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
                     if (code[u] >= 0 && code[u] < HS_NBINS) bump(code[u]);
-            }
-            for (; i < cnt; ++i) {
-                const int ps = s_ps[i], qe = s_qe[i];
-                if (mine && p >= ps && p < qe) {
-                    const int code = (int)pile[s_po[i] + p] - 33;
-                    if (code >= 0 && code < HS_NBINS) bump(code);
-                }
             }
         }
     }
