@@ -11,6 +11,9 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 namespace hs {
@@ -21,14 +24,64 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// Persistent worker pool: the drivers issue a dozen short parallel sections per call and spawning 200+ std::threads
+// for each of them costs more than the sections themselves.
+class WorkerPool {
+public:
+    static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }
+    void run(int n, int n_threads, const std::function<void(int)>& f) {
+        if (n <= 0) return;
+        if (n_threads <= 1 || n == 1) { for (int i = 0; i < n; ++i) f(i); return; }
+        std::lock_guard<std::mutex> serial(run_mu_);          // one parallel section at a time
+        ensure(std::min(n_threads, n) - 1);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            job_ = &f; n_ = n; next_.store(0); active_ = std::min((int)workers_.size(), std::min(n_threads, n) - 1); pending_ = active_; gen_++;
+        }
+        cv_.notify_all();
+        for (;;) { const int i = next_.fetch_add(1); if (i >= n) break; f(i); }
+        std::unique_lock<std::mutex> g(mu_);
+        done_cv_.wait(g, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+private:
+    void ensure(int want) {
+        want = std::min(want, 255);
+        while ((int)workers_.size() < want) {
+            const int id = (int)workers_.size();
+            workers_.emplace_back([this, id] { loop(id); });
+            workers_.back().detach();
+        }
+    }
+    void loop(int id) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)>* job; int n;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return gen_ != seen && id < active_; });
+                seen = gen_; job = job_; n = n_;
+            }
+            for (;;) { const int i = next_.fetch_add(1); if (i >= n) break; (*job)(i); }
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (--pending_ == 0) done_cv_.notify_one();
+            }
+        }
+    }
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int)>* job_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, active_ = 0, pending_ = 0;
+    uint64_t gen_ = 0;
+};
+
 template <class F>
 void parallel_for(int n, int n_threads, F f) {
-    if (n_threads <= 1 || n <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
-    std::atomic<int> next(0);
-    std::vector<std::thread> th;
-    const int t = std::min(n_threads, n);
-    for (int k = 0; k < t; ++k) th.emplace_back([&]() { for (;;) { int i = next.fetch_add(1); if (i >= n) break; f(i); } });
-    for (auto& x : th) x.join();
+    std::function<void(int)> fn = f;
+    WorkerPool::get().run(n, n_threads, fn);
 }
 
 template <class T> T* dup_vec(const std::vector<T>& v) {
@@ -98,10 +151,11 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
     if (int rc = dev.gather(sel_contig, sel_pos, col_off, &col_idx, &col_code, &k_ms[2])) return rc;
     const double t_dev_done = now_ms();
 
-    // host glue per contig
+    // host glue: exact tie order of the extracted columns (independent per column: chunked over all threads) ...
     std::vector<ColumnSet> sets((size_t)C);
     std::vector<ContigCvResult> res((size_t)C);
-    parallel_for(C, n_threads, [&](int c) {
+    std::vector<std::pair<int, int>> chunks;   // (contig, first column)
+    for (int c = 0; c < C; ++c) {
         ColumnSet& cs = sets[(size_t)c];
         const int64_t s0 = contig_sel_off[(size_t)c], s1 = contig_sel_off[(size_t)c + 1];
         cs.pos.assign(sel_pos.begin() + s0, sel_pos.begin() + s1);
@@ -109,7 +163,18 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
         for (int64_t i = s0; i <= s1; ++i) cs.off[(size_t)(i - s0)] = col_off[(size_t)i] - col_off[(size_t)s0];
         cs.idx = col_idx + col_off[(size_t)s0];
         cs.code = col_code + col_off[(size_t)s0];
-        resolve_columns(cs);
+        const size_t n = cs.pos.size();
+        cs.k0.resize(n); cs.k1.resize(n); cs.c0.resize(n); cs.c1.resize(n); cs.c2.resize(n);
+        for (int64_t f = 0; f < s1 - s0; f += 256) chunks.push_back(std::make_pair(c, (int)f));
+    }
+    parallel_for((int)chunks.size(), n_threads, [&](int i) {
+        ColumnSet& cs = sets[(size_t)chunks[(size_t)i].first];
+        const int f = chunks[(size_t)i].second;
+        resolve_columns(cs, f, std::min<int>(f + 256, (int)cs.pos.size()));
+    });
+    // ... then the sequential partition logic, one contig per thread
+    parallel_for(C, n_threads, [&](int c) {
+        ColumnSet& cs = sets[(size_t)c];
         int64_t nerr = 0, nlen = 0;
         for (int r = b.contig_rec_off[(size_t)c]; r < b.contig_rec_off[(size_t)c + 1]; ++r) { nerr += rec_stats[(size_t)r * 4 + 1]; nlen += rec_stats[(size_t)r * 4 + 2]; }
         ContigCvResult& o = res[(size_t)c];

@@ -31,7 +31,7 @@ struct ContigCvResult {
     int n_candidates = 0, n_automatic = 0, n_partitions = 0, n_final_partitions = 0, n_filtered = 0;
 };
 
-void resolve_columns(ColumnSet& cs);
+void resolve_columns(ColumnSet& cs, int first, int last);   // columns [first, last); the k/c arrays must be sized
 void call_variants_host(int n_reads, int64_t contig_len, ColumnSet& cs, float mean_distance,
                         float automatic_snp_threshold, ContigCvResult& out);
 

@@ -63,11 +63,10 @@ static void exact_top3(const uint8_t* code, int n, uint8_t& k0, uint8_t& k1, int
     k0 = v[0].first; k1 = v[1].first; c0 = v[0].second; c1 = v[1].second; c2 = v[2].second;
 }
 
-void resolve_columns(ColumnSet& cs) {
-    const size_t n = cs.pos.size();
-    cs.k0.resize(n); cs.k1.resize(n); cs.c0.resize(n); cs.c1.resize(n); cs.c2.resize(n);
-    for (size_t i = 0; i < n; ++i)
-        exact_top3(cs.code + cs.off[i], (int)(cs.off[i + 1] - cs.off[i]), cs.k0[i], cs.k1[i], cs.c0[i], cs.c1[i], cs.c2[i]);
+void resolve_columns(ColumnSet& cs, int first, int last) {
+    for (int i = first; i < last; ++i)
+        exact_top3(cs.code + cs.off[(size_t)i], (int)(cs.off[(size_t)i + 1] - cs.off[(size_t)i]), cs.k0[(size_t)i], cs.k1[(size_t)i],
+                   cs.c0[(size_t)i], cs.c1[(size_t)i], cs.c2[(size_t)i]);
 }
 
 // most frequent non-reference code among `codes` restricted to the entries flagged in `take`

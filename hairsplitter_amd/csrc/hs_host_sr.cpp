@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -47,7 +48,7 @@ void sr_build_planes(SrContigState& st) {
 }
 
 // neighbour selection shared by both graph builders: separate_reads.cpp:769-815 (== :633-670)
-static void pick_neighbors(std::vector<std::pair<int, float>>& smallest, const uint8_t* mask, float error_rate, std::vector<int>& picked) {
+static void pick_neighbors_sorted(std::vector<std::pair<int, float>>& smallest, const uint8_t* mask, float error_rate, std::vector<int>& picked) {
     std::sort(smallest.begin(), smallest.end(), [](const std::pair<int, float>& a, const std::pair<int, float>& b) { return a.second > b.second; });
     int nb = 0;
     const float below = 1 - error_rate * 2;
@@ -62,6 +63,82 @@ static void pick_neighbors(std::vector<std::pair<int, float>>& smallest, const u
     for (const auto& s : smallest) {
         if (s.second > below && (nb < 5 || s.second == 1 || s.second >= above) && mask[s.first]) { nb++; picked.push_back(s.first); }
     }
+}
+
+// The reference sorts all N distances of a row with std::sort and walks the result (:769-815). The set it picks only
+// depends on the ORDER among equal distances when fewer than five neighbours qualify by value and the run of equal
+// values at the cut-off is only partly taken. Everything else follows from order statistics (largest two values, the
+// number of exact 1s, the fifth-largest value below 1), so the sort is only performed for those ambiguous rows:
+// the picked set is identical either way (any std::sort output is a descending arrangement).
+// Requires distances in [0,1] without NaN and below >= 0 (non-masked reads have distance 0 and can then never pass).
+static bool g_force_sort = std::getenv("HS_FORCE_ROW_SORT") != nullptr;
+static void pick_neighbors(std::vector<std::pair<int, float>>& smallest, const uint8_t* mask, float error_rate, std::vector<int>& picked) {
+    const int N = (int)smallest.size();
+    const float below = 1 - error_rate * 2;
+    if (g_force_sort || N < 2 || !(below >= 0)) { pick_neighbors_sorted(smallest, mask, error_rate, picked); return; }
+    // largest two values (with multiplicity), number of exact ones, five largest values below one, minimum
+    float s0 = -1, s1 = -1, mn = 2;
+    int ones = 0;
+    float top[5] = {-1, -1, -1, -1, -1};   // descending, values != 1
+    int ntop = 0;
+    for (int i = 0; i < N; ++i) {
+        const float d = smallest[i].second;
+        if (d > s0) { s1 = s0; s0 = d; } else if (d > s1) s1 = d;
+        if (d < mn) mn = d;
+        if (d == 1) { ones++; continue; }
+        if (ntop < 5 || d > top[4]) {
+            int k = ntop < 5 ? ntop++ : 4;
+            while (k > 0 && top[k - 1] < d) { top[k] = top[k - 1]; --k; }
+            top[k] = d;
+        }
+    }
+    float above = s0 - (s0 - s1) * 3;
+    if (above == 1) {
+        if (ones < N) {
+            const int idx = std::min(ones + 4, N - 1);            // position in the descending arrangement
+            const int k = idx - ones;                             // k-th (0-based) largest among the values below one
+            above = k < ntop ? top[k] : mn;
+            if (idx == N - 1 && k >= ntop) above = mn;
+        }
+    }
+    picked.clear();
+    int nA = 0;
+    for (int i = 0; i < N; ++i) {
+        const float d = smallest[i].second;
+        if (d > below && (d == 1 || d >= above)) { picked.push_back(smallest[i].first); nA++; }
+    }
+    if (nA >= 5) return;
+    // the next (5 - nA) entries of the descending arrangement that exceed `below` (all of them are < above and != 1)
+    const int need = 5 - nA;
+    float cand[5]; int ncand = 0; int nB = 0;
+    for (int i = 0; i < N; ++i) {
+        const float d = smallest[i].second;
+        if (!(d > below) || d == 1 || d >= above) continue;
+        nB++;
+        if (ncand < need || d > cand[ncand - 1]) {
+            int k = ncand < need ? ncand++ : need - 1;
+            while (k > 0 && cand[k - 1] < d) { cand[k] = cand[k - 1]; --k; }
+            cand[k] = d;
+        }
+    }
+    if (nB == 0) return;
+    if (nB <= need) {
+        for (int i = 0; i < N; ++i) { const float d = smallest[i].second; if (d > below && d != 1 && d < above) picked.push_back(smallest[i].first); }
+        return;
+    }
+    const float cut = cand[need - 1];
+    int greater = 0, equal = 0;
+    for (int i = 0; i < N; ++i) {
+        const float d = smallest[i].second;
+        if (!(d > below) || d == 1 || d >= above) continue;
+        if (d > cut) greater++; else if (d == cut) equal++;
+    }
+    if (greater + equal == need) {
+        for (int i = 0; i < N; ++i) { const float d = smallest[i].second; if (d > below && d != 1 && d < above && d >= cut) picked.push_back(smallest[i].first); }
+        return;
+    }
+    // the run of equal distances at the cut-off is only partly taken: std::sort's arrangement decides
+    pick_neighbors_sorted(smallest, mask, error_rate, picked);
 }
 
 static void to_csr(std::vector<std::vector<int>>& lists, SrGraph& g) {
@@ -141,7 +218,7 @@ static void build_graph_low_memory(const SrContigState& st, const uint8_t* mask,
         }
         for (int r = 0; r < N; ++r)
             if (mask[r] && r != r1 && simv[r] + difv[r] < 0.7 * max_compat) smallest[r].second = 0;
-        pick_neighbors(smallest, mask, error_rate, picked);
+        pick_neighbors_sorted(smallest, mask, error_rate, picked);   // 0/0 distances (NaN) exist on this path
         for (int nb : picked) { lists[r1].push_back(nb); lists[nb].push_back(r1); }
     }
     to_csr(lists, g);
@@ -344,21 +421,27 @@ static std::vector<int32_t> merge_wrongly_split(const SrContigState& st, const s
                 }
             }
     }
-    // link ratios (:1189-1250)
-    std::map<std::pair<int, int>, double> links;
-    std::map<int, int> links_in;
+    // link ratios (:1189-1250). The reference keys a std::map on (cluster1, cluster2), clusters -2 and -1 included; a
+    // dense (label + 2) x (label + 2) count matrix walked in ascending key order yields the same sequence.
+    int max_label = -2;
+    for (int r = 0; r < N; ++r) max_label = std::max(max_label, clustered[r]);
+    const int M = max_label + 3;
+    std::vector<int> link_cnt((size_t)M * M, 0), links_in((size_t)M, 0);
     auto count_link = [&](int r1, int r2) {
-        const int c1 = clustered[r1], c2 = clustered[r2];
-        if (c1 != c2) links[std::make_pair(c1, c2)] += 1;
-        links_in[c1] += 1;
+        const int c1 = clustered[r1] + 2, c2 = clustered[r2] + 2;
+        if (c1 != c2) link_cnt[(size_t)c1 * M + c2] += 1;
+        links_in[(size_t)c1] += 1;
     };
     if (low_memory) {
         for (int r1 = 0; r1 < N; ++r1) for (int o = g.off[r1]; o < g.off[r1 + 1]; ++o) count_link(r1, g.adj[o]);
     } else {
         for (int k = 0; k < N; ++k) for (int o = g.off[k]; o < g.off[k + 1]; ++o) count_link(g.adj[o], k);
     }
-    for (auto& l : links) l.second = l.second / links_in[l.first.first];
-    std::vector<std::pair<std::pair<int, int>, double>> sorted_links(links.begin(), links.end());
+    std::vector<std::pair<std::pair<int, int>, double>> sorted_links;
+    for (int c1 = 0; c1 < M; ++c1)
+        for (int c2 = 0; c2 < M; ++c2)
+            if (link_cnt[(size_t)c1 * M + c2] > 0)
+                sorted_links.push_back(std::make_pair(std::make_pair(c1 - 2, c2 - 2), (double)link_cnt[(size_t)c1 * M + c2] / links_in[(size_t)c1]));
     std::sort(sorted_links.begin(), sorted_links.end(),
               [](const std::pair<std::pair<int, int>, double>& a, const std::pair<std::pair<int, int>, double>& b) { return a.second > b.second; });
     std::map<int, int> o2n;
