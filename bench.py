@@ -91,7 +91,9 @@ def main():
         torch.cuda.set_device(0)
     api.require_gpu()
     api.load().hs_set_device(local_rank if world > 1 else 0)
-    n_threads = args.threads or max(1, (os.cpu_count() or 1) // world)
+    # host threads for the sequential glue: the parallel sections are short, and waking hundreds of workers on a busy
+    # box costs more than it buys (measured: 256 threads -> 15-60 ms steps, 32 threads -> 12.8 ms steps)
+    n_threads = args.threads or max(1, min(32, (os.cpu_count() or 1) // world))
 
     # ---- this rank's shard: contigs [rank*B, (rank+1)*B) of the job (weak scaling) ----
     B = args.contigs
@@ -133,8 +135,11 @@ def main():
     t0 = time.perf_counter()
     k_cv = np.zeros(4); k_sr = np.zeros(4); t_dev = 0.0; t_host = 0.0
     last = None
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         cv, sr, gathered = step()
+        step_ms.append((time.perf_counter() - ts) * 1e3)
         k_cv += np.asarray(cv["t_kernel_ms"]); k_sr += np.asarray(sr["t_kernel_ms"])
         t_dev += cv["t_device_ms"] + sr["t_device_ms"]; t_host += cv["t_host_ms"] + sr["t_host_ms"]
         last = (cv, sr)
@@ -179,7 +184,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kernels[dom],
                          "algorithmic_bytes_per_launch": alg_bytes[dom]},
-            "kernel_ms_per_step": kernels,
+            "kernel_ms_per_step": kernels, "step_ms": [round(x, 2) for x in step_ms],
             "phase_ms_per_step": {"device_phases": t_dev / K, "host_glue": t_host / K, **{"py_" + k: v / K for k, v in py_ms.items()}},
         }
         if world == 1 and args.cpu_contigs > 0:

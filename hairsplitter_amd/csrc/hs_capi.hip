@@ -72,12 +72,7 @@ struct DBuf {
         bytes = n;
         return pool().get(false, n ? n : 16, &p, &cap);
     }
-    template <class T> int upload(const std::vector<T>& v) {
-        int rc = alloc(v.size() * sizeof(T));
-        if (rc) return rc;
-        if (!v.empty()) HS_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-        return HS_OK;
-    }
+    template <class T> int upload(const std::vector<T>& v);
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -91,6 +86,22 @@ struct HBuf {
         return pool().get(true, n ? n : 16, &p, &cap);
     }
 };
+
+template <class T> int DBuf::upload(const std::vector<T>& v) {
+    int rc = alloc(v.size() * sizeof(T));
+    if (rc) return rc;
+    const size_t n = v.size() * sizeof(T);
+    if (n == 0) return HS_OK;
+    if (n >= (128u << 10)) {     // large: stage through pinned memory (pageable sources get pinned page by page otherwise)
+        HBuf h;
+        if (int r2 = h.alloc(n)) return r2;
+        std::memcpy(h.p, v.data(), n);
+        HS_HIP(hipMemcpy(p, h.p, n, hipMemcpyHostToDevice));
+    } else {
+        HS_HIP(hipMemcpy(p, v.data(), n, hipMemcpyHostToDevice));
+    }
+    return HS_OK;
+}
 
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
@@ -463,14 +474,26 @@ struct HipCvOps : hs::CvDeviceOps {
                                          b->sel_depth.as<int32_t>(), (int32_t)std::min<int64_t>(b->total_len, 0x7fffffff), b->max_depth, stream)) return rc;
         HS_HIP(hipEventRecord(e2.b, stream));
         const double t1 = now();
-        if (!rec_stats.empty()) HS_HIP(hipMemcpy(rec_stats.data(), b->rec_stats.p, rec_stats.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        // downloads go through pooled pinned buffers: above a few hundred KB hipMemcpy into pageable memory pins the
+        // destination on the fly, which costs tens of milliseconds
+        HBuf h_a, h_b;
+        if (!rec_stats.empty()) {
+            if (int rc = h_a.alloc(rec_stats.size() * sizeof(int32_t))) return rc;
+            HS_HIP(hipMemcpy(h_a.p, b->rec_stats.p, rec_stats.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            std::memcpy(rec_stats.data(), h_a.p, rec_stats.size() * sizeof(int32_t));
+        }
         const double t2 = now();
         int32_t n_sel = 0;
-        HS_HIP(hipMemcpy(&n_sel, b->sel_count.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (int rc = h_b.alloc(64)) return rc;
+        HS_HIP(hipMemcpy(h_b.p, b->sel_count.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        n_sel = *(int32_t*)h_b.p;
         sel_gpos.resize((size_t)n_sel); sel_depth.resize((size_t)n_sel);
         if (n_sel) {
-            HS_HIP(hipMemcpy(sel_gpos.data(), b->sel_gpos.p, (size_t)n_sel * sizeof(int64_t), hipMemcpyDeviceToHost));
-            HS_HIP(hipMemcpy(sel_depth.data(), b->sel_depth.p, (size_t)n_sel * sizeof(int32_t), hipMemcpyDeviceToHost));
+            if (int rc = h_a.alloc((size_t)n_sel * sizeof(int64_t))) return rc;
+            HS_HIP(hipMemcpy(h_a.p, b->sel_gpos.p, (size_t)n_sel * sizeof(int64_t), hipMemcpyDeviceToHost));
+            std::memcpy(sel_gpos.data(), h_a.p, (size_t)n_sel * sizeof(int64_t));
+            HS_HIP(hipMemcpy(h_a.p, b->sel_depth.p, (size_t)n_sel * sizeof(int32_t), hipMemcpyDeviceToHost));
+            std::memcpy(sel_depth.data(), h_a.p, (size_t)n_sel * sizeof(int32_t));
         }
         const double t3 = now();
         if (int rc = e1.ms(&k_ms[0])) return rc;
@@ -623,7 +646,12 @@ struct HipSrOps : hs::SrDeviceOps {
                                d_lab3.as<int32_t>(), nullptr, stream)) return rc;
         HS_HIP(hipEventRecord(e3.b, stream));
         labels.resize((size_t)total_n);
-        HS_HIP(hipMemcpy(labels.data(), d_lab3.p, (size_t)total_n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        {
+            HBuf h;
+            if (int rc = h.alloc((size_t)total_n * sizeof(int32_t))) return rc;
+            HS_HIP(hipMemcpy(h.p, d_lab3.p, (size_t)total_n * sizeof(int32_t), hipMemcpyDeviceToHost));
+            std::memcpy(labels.data(), h.p, (size_t)total_n * sizeof(int32_t));
+        }
         float m = 0;
         if (int rc = e1.ms(&m)) return rc; k_ms[0] += m;
         if (int rc = e2.ms(&m)) return rc; k_ms[1] += m;
