@@ -92,8 +92,8 @@ def main():
     api.require_gpu()
     api.load().hs_set_device(local_rank if world > 1 else 0)
     # host threads for the sequential glue: the parallel sections are short, and waking hundreds of workers on a busy
-    # box costs more than it buys (measured: 256 threads -> 15-60 ms steps, 32 threads -> 12.8 ms steps)
-    n_threads = args.threads or max(1, min(32, (os.cpu_count() or 1) // world))
+    # box costs more than it buys (measured: 256 threads -> 15-60 ms steps, 64 threads -> 11.6 ms steps)
+    n_threads = args.threads or max(1, min(64, (os.cpu_count() or 1) // world))
 
     # ---- this rank's shard: contigs [rank*B, (rank+1)*B) of the job (weak scaling) ----
     B = args.contigs
