@@ -28,6 +28,28 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def effective_cores() -> int:
+    """CPUs this process can actually use: min(online, affinity mask, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
+
+
 def py_error_rate(er32: float) -> float:
     """What hairsplitter.py hands to stage 4: the float printed by stage 3 (6 significant digits), capped at 0.15
     (hairsplitter.py:686-692,725)."""
@@ -41,7 +63,7 @@ def cpu_baseline(n_contigs: int, seed: int):
     from hairsplitter_amd import synth
     import __graft_entry__ as ge
     p = ge.paths()
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     kind = "reference" if os.path.exists(p["ref_cv"]) and os.path.exists(p["ref_sr"]) else "port"
     if kind == "port" and not os.path.exists(p["oracle"]):
         return None
@@ -80,20 +102,30 @@ def main():
     import torch
     import torch.distributed as dist
     from hairsplitter_amd import api, synth, dist as hdist
+    # PyTorch is only the allocator / collective layer here: keep its CPU thread pools out of the way of the host glue
+    torch.set_num_threads(1)
+    try:
+        torch.set_num_interop_threads(1)
+    except RuntimeError:
+        pass
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # launched by torch.distributed.run
+    if use_dist:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
     else:
+        local_rank = 0
         torch.cuda.set_device(0)
+    # tiny host-side exchanges (error rate) go over gloo; RCCL is used for the one gather of labels per step
+    cpu_group = dist.new_group(backend="gloo") if use_dist else None
     api.require_gpu()
-    api.load().hs_set_device(local_rank if world > 1 else 0)
+    api.load().hs_set_device(local_rank)
     # host threads for the sequential glue: the parallel sections are short, and waking hundreds of workers on a busy
     # box costs more than it buys (measured: 256 threads -> 15-60 ms steps, 64 threads -> 11.6 ms steps)
-    n_threads = args.threads or max(1, min(64, (os.cpu_count() or 1) // world))
+    n_threads = args.threads or max(1, min(64, (4 * effective_cores()) // world))
 
     # ---- this rank's shard: contigs [rank*B, (rank+1)*B) of the job (weak scaling) ----
     B = args.contigs
@@ -104,11 +136,13 @@ def main():
     local_bp = flat.aligned_bp
 
     py_ms = {"pipeline_call": 0.0, "error_rate": 0.0, "gather": 0.0}
+    no_coll = bool(os.environ.get("HS_BENCH_NO_COLLECTIVES"))   # diagnostic only
+    cap = [None]
 
     def error_rate_fn(cv):
         # the one cross-contig quantity of the path: mean of the per-contig distances over the WHOLE job, in contig order
         t = time.perf_counter()
-        er = hdist.global_error_rate(my_ids, cv["mean_distance"], world * B)
+        er = hdist.global_error_rate(my_ids, cv["mean_distance"], world * B, group=cpu_group) if not no_coll else float(cv["error_rate"])
         py_ms["error_rate"] += (time.perf_counter() - t) * 1e3
         return py_error_rate(er)
 
@@ -118,12 +152,14 @@ def main():
         # (separate_reads.cpp:1466-1498) and all shards of this workload have the same read-length distribution
         cv, sr = batch.run_pipeline(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=2000 if world > 1 else 0)
         t3 = time.perf_counter(); py_ms["pipeline_call"] += (t3 - t) * 1e3
-        gathered = hdist.gather_labels(sr["labels"])
+        if cap[0] is None:
+            cap[0] = hdist.gather_capacity(int(sr["labels"].size))   # first (warm-up) step only
+        gathered = hdist.gather_labels(sr["labels"], capacity=cap[0]) if not no_coll else None
         py_ms["gather"] += (time.perf_counter() - t3) * 1e3
         return cv, sr, gathered
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,7 +181,7 @@ def main():
         last = (cv, sr)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -155,10 +191,22 @@ def main():
     else:
         total_bp = local_bp
 
+    if rank == 0 and os.environ.get("HS_BENCH_THREAD_CPU"):   # diagnostic: CPU seconds per thread of this process
+        rows = []
+        for t in os.listdir("/proc/self/task"):
+            try:
+                f = open(f"/proc/self/task/{t}/stat").read()
+                comm = f[f.index("(") + 1:f.rindex(")")]
+                rest = f[f.rindex(")") + 2:].split()
+                rows.append(((int(rest[11]) + int(rest[12])) / os.sysconf("SC_CLK_TCK"), comm, t))
+            except Exception:
+                pass
+        rows.sort(reverse=True)
+        sys.stderr.write("thread cpu_s: " + ", ".join(f"{c}:{u:.2f}" for u, c, t in rows[:30]) + f" (threads={len(rows)})\n")
     if rank == 0:
         K = args.steps
         cv, sr = last
-        kernels = {"k_pileup": k_cv[0] / K, "k_column_stats": k_cv[1] / K, "k_gather_columns": k_cv[2] / K,
+        kernels = {"k_cigar_scan": k_cv[3] / K, "k_pileup": k_cv[0] / K, "k_column_stats": k_cv[1] / K, "k_gather_columns": k_cv[2] / K,
                    "k_simdiff": k_sr[0] / K, "k_chinese_whispers": (k_sr[1] + k_sr[2] + k_sr[3]) / K}
         # algorithmic bytes per launch: pileup = read base in + code out = 2 B / aligned bp;
         # column_stats = 1 B / aligned bp in + 16 B / position out; chinese_whispers: see DESIGN.md
@@ -177,6 +225,7 @@ def main():
             "value": total_bp * K / dt, "unit": "aligned read-bp/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
+            "host": {"cpus_online": os.cpu_count(), "cpus_effective": effective_cores()},
             "config": {"workload": f"C2 (BASELINE.json configs[1]): 100 kb contig, 2 haplotypes @1% divergence, 50x ONT-error reads; "
                                    f"{B} such contigs per GPU per step, inputs resident in HBM",
                        "contigs_per_gpu": B, "aligned_bp_per_gpu": local_bp, "parallelism": f"contig-sharded x{world}",
@@ -194,7 +243,7 @@ def main():
                 out["cpu_baseline"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
     batch.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -111,7 +111,7 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
     const int C = b.n_contigs, NR = b.n_rec;
     const double t_start = now_ms();
-    float k_ms[3] = {0, 0, 0};
+    float k_ms[4] = {0, 0, 0, 0};   // pileup, column_stats, gather_columns, cigar_scan
 
     std::vector<int32_t> rec_stats((size_t)NR * 4);
     std::vector<int64_t> sel_gpos;
@@ -223,7 +223,7 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
     R->mean_distance = dup_vec(md); R->depth = dup_vec(dp); R->snp_off = dup_vec(snp_off);
     R->error_rate = total_error / n_err_contigs;      // call_variants.cpp:1377 (float / int)
     R->n_contigs_with_error_rate = n_err_contigs;
-    R->t_kernel_ms[0] = k_ms[0]; R->t_kernel_ms[1] = k_ms[1]; R->t_kernel_ms[2] = k_ms[2];
+    R->t_kernel_ms[0] = k_ms[0]; R->t_kernel_ms[1] = k_ms[1]; R->t_kernel_ms[2] = k_ms[2]; R->t_kernel_ms[3] = k_ms[3];
     R->t_device_ms = t_dev_done - t_start;
     R->t_host_ms = now_ms() - t_dev_done;
     if (std::getenv("HS_TIMING"))

@@ -24,8 +24,9 @@ struct CvDeviceOps {
     virtual ~CvDeviceOps() {}
     // K0+K1 + K2: per-record {q_end, n_err, n_len, n_events}; the global positions (unordered) whose second count c1 is
     // > min_second, or == min_second with a zero third count, with their depth; k_ms = {cigar scan + pileup, column_stats}
+    // k_ms[3] = cigar scan alone (k_ms[0] then is the pileup kernel alone)
     virtual int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, std::vector<int64_t>& sel_gpos,
-                                  std::vector<int32_t>& sel_depth, float k_ms[2]) = 0;
+                                  std::vector<int32_t>& sel_depth, float k_ms[4]) = 0;
     // K3: columns of the selected positions; the two output arrays (col_off.back() entries) are owned by the
     // implementation and stay valid until the next gather call or its destruction
     virtual int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos,

@@ -25,6 +25,7 @@ def lpt_shards(weights: Sequence[float], world: int) -> List[List[int]]:
 
 
 def global_error_rate(local_ids: Sequence[int], local_mean_distance: np.ndarray, n_contigs_total: int, group=None) -> float:
+    # `group` may be a gloo group on the same ranks: the payload is a few hundred floats, a host-side exchange is enough
     """Sum of the per-contig mean distances (> 0 only) in *contig index order* with float32 accumulation, divided by
     the number of such contigs -- what a 1-thread reference run prints to error_rate.txt."""
     import torch
@@ -32,7 +33,7 @@ def global_error_rate(local_ids: Sequence[int], local_mean_distance: np.ndarray,
     full = torch.zeros(n_contigs_total, dtype=torch.float32)
     if len(local_ids):
         full[torch.as_tensor(list(local_ids), dtype=torch.long)] = torch.from_numpy(np.asarray(local_mean_distance, np.float32))
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
         full = full.to(dev)
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)   # every contig is owned by exactly one rank: exact
@@ -46,27 +47,48 @@ def global_error_rate(local_ids: Sequence[int], local_mean_distance: np.ndarray,
     return float(np.float32(total / np.float32(n))) if n else float("nan")
 
 
-def gather_labels(labels: np.ndarray, group=None, dst: int = 0):
+def gather_capacity(local_n: int, group=None) -> int:
+    """One-off (outside the timed steps): the largest per-rank label count, so that the per-step gather is a single
+    fixed-size collective with the actual count carried in-band."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return int(local_n)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([int(local_n)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
+def gather_labels(labels: np.ndarray, group=None, dst: int = 0, capacity: int = None):
     """The single gather of partition labels at the end (int16 on the wire: labels are -2, -1 or a group id < N).
+    One collective: every rank sends `capacity` int16 labels preceded by its own count (two int16 words).
     Returns the list of per-rank label arrays on `dst`, None elsewhere."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return [labels]
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
     assert labels.size == 0 or (labels.min() >= -2 and labels.max() < 32767)
-    n = torch.tensor([labels.size], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    mx = int(max(int(s.item()) for s in sizes))
-    wire = torch.int16 if dist.get_backend(group) == "nccl" else torch.int32   # gloo has no int16 gather
-    buf = torch.full((max(mx, 1),), -2, dtype=wire, device=dev)
+    if capacity is None:
+        capacity = gather_capacity(labels.size, group)
+    assert labels.size <= capacity and labels.size < (1 << 30)
+    # int16 labels shipped as raw bytes: neither NCCL/RCCL nor gloo has an int16 datatype
+    buf16 = torch.full((capacity + 2,), -2, dtype=torch.int16)
+    buf16[0] = labels.size & 0x7fff
+    buf16[1] = labels.size >> 15
     if labels.size:
-        buf[:labels.size] = torch.from_numpy(labels.astype(np.int32)).to(dev).to(wire)
+        buf16[2:2 + labels.size] = torch.from_numpy(labels.astype(np.int16))
+    buf = buf16.view(torch.uint8).to(dev)
     out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
     dist.gather(buf, out, dst=dst, group=group)
     if rank != dst:
         return None
-    return [o[:int(s.item())].cpu().numpy().astype(np.int32) for o, s in zip(out, sizes)]
+    res = []
+    for o in out:
+        v = o.cpu().view(torch.int16).numpy()
+        n = int(v[0]) | (int(v[1]) << 15)
+        res.append(v[2:2 + n].astype(np.int32))
+    return res

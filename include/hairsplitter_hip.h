@@ -183,7 +183,7 @@ typedef struct hs_cv_result {
     int32_t n_contigs_with_error_rate;
     double t_device_ms;        /* wall time of the device phase (uploads of selections, kernels, downloads) */
     double t_host_ms;          /* wall time of the host glue */
-    float t_kernel_ms[4];      /* hipEvent time of k_pileup, k_column_stats, k_gather_columns, (unused) */
+    float t_kernel_ms[4];      /* hipEvent time of k_pileup, k_column_stats, k_gather_columns, k_cigar_scan */
 } hs_cv_result;
 
 int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out);

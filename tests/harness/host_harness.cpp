@@ -31,8 +31,8 @@ struct OracleCvOps : hs::CvDeviceOps {
     explicit OracleCvOps(const hs::CvFileInput& i) : in(i) {}
 
     int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, std::vector<int64_t>& sel_gpos, std::vector<int32_t>& sel_depth,
-                          float k_ms[2]) override {
-        k_ms[0] = k_ms[1] = 0;
+                          float k_ms[4]) override {
+        k_ms[0] = k_ms[1] = k_ms[3] = 0;
         sel_gpos.clear(); sel_depth.clear();
         const int C = (int)in.contig_names.size();
         std::vector<std::string> read_seq(in.read_names.size());
