@@ -215,14 +215,15 @@ static int column_stats_launch(const uint8_t* d_pile, const int64_t* d_pile_off,
                                int64_t* d_sel_gpos, int32_t* d_sel_depth, int32_t sel_cap, int32_t max_depth, void* stream) {
     if (total_len <= 0) return HS_OK;
     const int64_t grid = (total_len + 255) / 256;
-    if (max_depth > 0 && max_depth <= 255)
-        hipLaunchKernelGGL(hsdev::k_column_stats<1>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_pile, d_pile_off,
-                           d_rec_pos, d_rec_qend, d_contig_rec_off, d_contig_off, n_contigs,
-                           reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap);
-    else
-        hipLaunchKernelGGL(hsdev::k_column_stats<2>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_pile, d_pile_off,
-                           d_rec_pos, d_rec_qend, d_contig_rec_off, d_contig_off, n_contigs,
-                           reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap);
+    const bool full = d_stats != nullptr;     // the stage driver passes no statistics buffer: selection only
+    const bool narrow = max_depth > 0 && max_depth <= 255;
+    using KernelT = void (*)(const uint8_t*, const int64_t*, const int32_t*, const int32_t*, const int32_t*, const int64_t*, int,
+                             hsdev::hs_colstat_dev*, int, int32_t*, int64_t*, int32_t*, int);
+    KernelT kernel = narrow ? (full ? (KernelT)hsdev::k_column_stats<1, true> : (KernelT)hsdev::k_column_stats<1, false>)
+                            : (full ? (KernelT)hsdev::k_column_stats<2, true> : (KernelT)hsdev::k_column_stats<2, false>);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_pile, d_pile_off, d_rec_pos, d_rec_qend,
+                       d_contig_rec_off, d_contig_off, n_contigs, reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second,
+                       d_sel_count, d_sel_gpos, d_sel_depth, sel_cap);
     HS_HIP(hipGetLastError());
     return HS_OK;
 }
@@ -352,7 +353,7 @@ struct hs_cv_batch {
     int64_t total_len = 0, total_pile = 0;
     int32_t n_tasks = 0, ev_per_task = 4096, max_depth = 0;
     DBuf contig_seq, d_contig_off, read_seq, read_off, rec_read, d_rec_contig, d_rec_pos, rec_strand, rec_cig_off, cigar,
-        d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, colstats, rec_chunk_off, chunk_scratch, task_rec, task_ev0,
+        d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, rec_chunk_off, chunk_scratch, task_rec, task_ev0,
         sel_count, sel_gpos, sel_depth;
 };
 
@@ -448,7 +449,6 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
     if (!rc) rc = b->sel_depth.alloc(sizeof(int32_t) * (size_t)b->total_len);
     if (!rc) rc = b->pile.alloc((size_t)b->total_pile);
     if (!rc) rc = b->rec_stats.alloc(sizeof(int32_t) * 4 * (size_t)n_rec);
-    if (!rc) rc = b->colstats.alloc(sizeof(hs_colstat) * (size_t)b->total_len);
     if (rc) { delete b; return rc; }
     *out = b;
     return HS_OK;
@@ -496,7 +496,7 @@ struct HipCvOps : hs::CvDeviceOps {
         HS_HIP(hipEventRecord(e2.a, stream));
         if (int rc = column_stats_launch(b->pile.as<uint8_t>(), b->d_pile_off.as<int64_t>(), b->d_rec_pos.as<int32_t>(), b->d_rec_qend.as<int32_t>(),
                                          b->d_contig_rec_off.as<int32_t>(), b->d_contig_off.as<int64_t>(), b->n_contigs, b->total_len,
-                                         b->colstats.as<hs_colstat>(), min_second, b->sel_count.as<int32_t>(), b->sel_gpos.as<int64_t>(),
+                                         nullptr, min_second, b->sel_count.as<int32_t>(), b->sel_gpos.as<int64_t>(),
                                          b->sel_depth.as<int32_t>(), (int32_t)std::min<int64_t>(b->total_len, 0x7fffffff), b->max_depth, stream)) return rc;
         HS_HIP(hipEventRecord(e2.b, stream));
         const double t1 = now();

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void k_pileup(
     // the ops that own events, and one "an op starts here" flag per event of the current 64-event window
     __shared__ int4 s_op[4][64];
     __shared__ uint8_t s_nzlane[4][64];
-    __shared__ uint8_t s_flag[4][64];
+    constexpr int PU = 4;
+    __shared__ uint8_t s_flag[4][PU][64];
     const int lane = lane_id();
     const int wv = (int)(threadIdx.x >> 6);
     const int task = (int)blockIdx.x * 4 + wv;
@@ -158,47 +159,66 @@ __global__ __launch_bounds__(256) void k_pileup(
         const int lo_el = e_first > ev_base ? e_first - ev_base : 0;
         const int hi_el = (e1 - ev_base) < chunk_ev ? (e1 - ev_base) : chunk_ev;
 
-        for (int eb = lo_el; eb < hi_el; eb += 64) {
-            // owner of every event of the window: ops that start inside it raise a flag at their first event; an event's
-            // owner is the (ops started before the window + flags at or left of it)-th op that owns events
-            s_flag[wv][lane] = 0;
+        // K1 is bound by the latency chain "owner lookup -> read base / contig base -> code": four 64-event windows are
+        // decoded per iteration so that their eight loads are in flight together; the 3-mer carry is then resolved in order.
+        for (int eb = lo_el; eb < hi_el; eb += 64 * PU) {
+#pragma unroll
+            for (int u = 0; u < PU; ++u) s_flag[wv][u][lane] = 0;
             wave_lds_sync();
-            const bool starts_here = nz && ev_ex >= eb && ev_ex < eb + 64;
-            if (starts_here) s_flag[wv][ev_ex - eb] = 1;
-            const int before = __popcll(__ballot(nz && ev_ex < eb));
-            wave_lds_sync();
-            const unsigned long long fm = __ballot(s_flag[wv][lane] != 0);
-            const int e = eb + lane;
-            const bool valid = e < hi_el;
-            int rank = before + __popcll(fm & le_mask) - 1;
-            rank = rank < 0 ? 0 : rank;
-            const int4 od = s_op[wv][s_nzlane[wv][rank]];
-            const int jcode = od.w;
-            const int off = e - od.x;
-            const bool jM = jcode == 0 || jcode == 7 || jcode == 8;
-            const bool jD = jcode == 2;
-            const int t = od.y + off;
-            const int q = od.z + ((jM || jD) ? off : 0);
-            const bool active = valid && (ev_base + e) >= e0 && q >= 0 && q < L;   // call_variants.cpp:217
-            // both loads are unconditional (indices clamped into the read / the contig) so that they issue back to back
-            const int tt = t < 0 ? 0 : (t >= rlen ? rlen - 1 : t);       // the host validates CIGAR vs read length
-            const int idx = fwd ? tt : (rlen - 1 - tt);
-            const int bb = (int)rdp[idx < 0 ? 0 : idx];
-            const int qq = q < 0 ? 0 : (q >= L ? L - 1 : q);
-            const int cref = (int)ctgp[qq];
-            const int c = jD ? 4 : (fwd ? bb : 3 - bb);                  // 4 == '-'
-            const int cu1 = wave_shr1(c, p1);
-            const int cu2 = wave_shr1(cu1, p2);
-            if (active) {
-                nlen++;
-                // M: call_variants.cpp:238-240,254-256; D: :287-290; I: :337 (no column written)
-                nerr += (jM && c == cref) ? 0 : 1;
-                if (jM || jD) out[q - pos] = (uint8_t)(33 + 5 * cu2 + cu1 + 25 * c);
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int w0 = eb + 64 * u;
+                if (nz && ev_ex >= w0 && ev_ex < w0 + 64) s_flag[wv][u][ev_ex - w0] = 1;
             }
-            const int nv = (hi_el - eb) < 64 ? (hi_el - eb) : 64;
-            const int last = __builtin_amdgcn_readlane(c, nv - 1);
-            const int last2 = nv >= 2 ? __builtin_amdgcn_readlane(c, nv - 2) : p1;
-            p2 = last2; p1 = last;
+            wave_lds_sync();
+            int q_[PU], c_[PU], cref_[PU];
+            bool act_[PU], wr_[PU], jm_[PU];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                // owner of every event of the window: ops that start inside it raised a flag at their first event; an event's
+                // owner is the (ops started before the window + flags at or left of it)-th op that owns events
+                const int w0 = eb + 64 * u;
+                const int before = __popcll(__ballot(nz && ev_ex < w0));
+                const unsigned long long fm = __ballot(s_flag[wv][u][lane] != 0);
+                const int e = w0 + lane;
+                const bool valid = e < hi_el;
+                int rank = before + __popcll(fm & le_mask) - 1;
+                rank = rank < 0 ? 0 : rank;
+                const int4 od = s_op[wv][s_nzlane[wv][rank]];
+                const int jcode = od.w;
+                const int off = e - od.x;
+                const bool jM = jcode == 0 || jcode == 7 || jcode == 8;
+                const bool jD = jcode == 2;
+                const int t = od.y + off;
+                const int q = od.z + ((jM || jD) ? off : 0);
+                act_[u] = valid && (ev_base + e) >= e0 && q >= 0 && q < L;   // call_variants.cpp:217
+                wr_[u] = jM || jD; jm_[u] = jM; q_[u] = q;
+                // both loads are unconditional (indices clamped into the read / the contig) so that they issue back to back
+                const int tt = t < 0 ? 0 : (t >= rlen ? rlen - 1 : t);       // the host validates CIGAR vs read length
+                const int idx = fwd ? tt : (rlen - 1 - tt);
+                const int bb = (int)rdp[idx < 0 ? 0 : idx];
+                const int qq = q < 0 ? 0 : (q >= L ? L - 1 : q);
+                cref_[u] = (int)ctgp[qq];
+                c_[u] = jD ? 4 : (fwd ? bb : 3 - bb);                        // 4 == '-'
+            }
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int w0 = eb + 64 * u;
+                if (w0 >= hi_el) break;                                      // wave-uniform
+                const int c = c_[u];
+                const int cu1 = wave_shr1(c, p1);
+                const int cu2 = wave_shr1(cu1, p2);
+                if (act_[u]) {
+                    nlen++;
+                    // M: call_variants.cpp:238-240,254-256; D: :287-290; I: :337 (no column written)
+                    nerr += (jm_[u] && c == cref_[u]) ? 0 : 1;
+                    if (wr_[u]) out[q_[u] - pos] = (uint8_t)(33 + 5 * cu2 + cu1 + 25 * c);
+                }
+                const int nv = (hi_el - w0) < 64 ? (hi_el - w0) : 64;
+                const int last = __builtin_amdgcn_readlane(c, nv - 1);
+                const int last2 = nv >= 2 ? __builtin_amdgcn_readlane(c, nv - 2) : p1;
+                p2 = last2; p1 = last;
+            }
         }
     }
     nerr = wave_sum_i32(nerr);
@@ -223,7 +243,10 @@ __global__ __launch_bounds__(256) void k_pileup(
 // CB = bytes per counter: 1 when no position of the batch is deeper than 255 reads (32 KiB of LDS per workgroup, 4-5
 // workgroups per CU), 2 otherwise (63 KiB). Counters are packed 4 (or 2) per dword, dword-major ([word][lane]), so
 // the final scan reads one dword per 4 bins and skips empty ones.
-template <int CB>
+// FULL = false is the form the stage driver uses: it only needs the two largest counts, whether a third allele exists and
+// the depth (the exact top-3 of the selected columns is recomputed on the host in the reference's tie order), which takes a
+// handful of branch-free VALU instructions per dword of counters instead of a five-deep insertion per bin.
+template <int CB, bool FULL>
 __global__ __launch_bounds__(256) void k_column_stats(
     const uint8_t* __restrict__ pile, const int64_t* __restrict__ pile_off,
     const int32_t* __restrict__ rec_pos, const int32_t* __restrict__ rec_qend,
@@ -307,7 +330,30 @@ __global__ __launch_bounds__(256) void k_column_stats(
     int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
     int depth = 0;
-    if (g < total) {
+    if (!FULL) {
+        int nzb = 0;   // number of non-empty bins
+        if (g < total) {
+#pragma unroll 4
+            for (int w = 0; w < NWORDS; ++w) {
+                const uint32_t word = hw[w * 256 + tid];
+                if (CB == 1) {
+                    depth = (int)__builtin_amdgcn_sad_u8(word, 0u, (uint32_t)depth);      // sum of the four byte counters
+                    nzb += __popc((((word & 0x7f7f7f7fu) + 0x7f7f7f7fu) | word) & 0x80808080u);
+                } else {
+                    depth += (int)(word & 0xffffu) + (int)(word >> 16);
+                    nzb += ((word & 0xffffu) != 0) + ((word >> 16) != 0);
+                }
+#pragma unroll
+                for (int f = 0; f < PER_WORD; ++f) {
+                    const int v = (int)((word >> (8 * CB * f)) & (CB == 1 ? 0xFFu : 0xFFFFu));
+                    const int lo2 = v < c0 ? v : c0;     // branch-free two largest
+                    c1 = c1 > lo2 ? c1 : lo2;
+                    c0 = c0 > v ? c0 : v;
+                }
+            }
+        }
+        c2 = nzb > 2 ? 1 : 0;   // only "is there a third allele" is needed
+    } else if (g < total) {
         for (int w = 0; w < NWORDS; ++w) {
             const uint32_t word = hw[w * 256 + tid];
             if (word == 0u) continue;

@@ -98,7 +98,7 @@ typedef struct hs_colstat {
 
 int hs_column_stats(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
                     const int32_t* d_rec_qend, const int32_t* d_contig_rec_off, const int64_t* d_contig_off,
-                    int32_t n_contigs, hs_colstat* d_stats /* [sum L] */,
+                    int32_t n_contigs, hs_colstat* d_stats /* [sum L]; NULL = selection only (cheaper kernel, no per-position record) */,
                     /* optional compact selection (all NULL / 0 to skip): global positions (index into the concatenated
                      * contigs) whose second count is >= min_second, unordered, with their depth; *d_sel_count must be 0 */
                     int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth, int32_t sel_cap,
