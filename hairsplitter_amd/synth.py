@@ -67,7 +67,7 @@ def _read_lengths(rng, n, tech):
     raise ValueError(tech)
 
 
-def _simulate_read(rng, hap_seq: np.ndarray, start: int, span: int, err: float):
+def _simulate_read(rng, hap_seq: np.ndarray, start: int, span: int, err: float, eqx: bool = False):
     """Returns (aligned-orientation read codes, cigar uint32 array, NM)."""
     ref = hap_seq[start:start + span]
     u = rng.random(span)
@@ -87,7 +87,7 @@ def _simulate_read(rng, hap_seq: np.ndarray, start: int, span: int, err: float):
     nev = span + nins
     ev_op = np.empty(nev, dtype=np.uint8)
     ev_base = np.zeros(nev, dtype=np.uint8)
-    ev_op[ev_index] = np.where(dele, OP_D, OP_M)
+    ev_op[ev_index] = np.where(dele, OP_D, (np.where(sub, OP_X, OP_EQ) if eqx else OP_M))
     ev_base[ev_index] = bases
     if nins:
         ins_slots = ev_index[ins] + 1
@@ -107,7 +107,11 @@ def make_contig(seed: int, index: int, length: int, n_hap: int, div: float, dept
                 tech: str = "ont", name: Optional[str] = None, err: Optional[float] = None,
                 hap_weights: Optional[Sequence[float]] = None,
                 read_len_override: Optional[Sequence[int]] = None,
-                clip_prob: float = 0.0) -> ContigData:
+                clip_prob: float = 0.0, eqx: bool = False, overhang_prob: float = 0.0,
+                inert_ops_prob: float = 0.0) -> ContigData:
+    """eqx: write matches/mismatches as '=' / 'X' instead of 'M'. overhang_prob: with this probability a read near the
+    contig end is given a CIGAR that runs past the end of the contig (the reference stops at `indexQuery < L`,
+    call_variants.cpp:217)."""
     rng = np.random.default_rng([seed, index])
     if err is None:
         err = 0.05 if tech == "ont" else 0.002
@@ -136,7 +140,18 @@ def make_contig(seed: int, index: int, length: int, n_hap: int, div: float, dept
         strand = bool(rng.integers(0, 2))
         if span < 3:
             continue
-        read, cigar, nm = _simulate_read(rng, haps[h], start, span, err)
+        over = 0
+        if overhang_prob > 0.0 and rng.random() < overhang_prob:
+            over = int(rng.integers(1, 300))
+            start = max(0, length - span)          # touches the contig end; the alignment is then extended past it
+        src = haps[h] if not over else np.concatenate((haps[h], rng.integers(0, 4, size=over).astype(np.uint8)))
+        read, cigar, nm = _simulate_read(rng, src, start, span + over, err, eqx=eqx)
+        if inert_ops_prob > 0.0 and rng.random() < inert_ops_prob and len(cigar) > 4:
+            # 'N' and 'P' runs: the reference expands them but no branch of its CIGAR walk handles them
+            # (call_variants.cpp:226-342), so they consume nothing -- not even reference bases
+            k = int(rng.integers(1, len(cigar) - 1))
+            extra = np.array([(int(rng.integers(1, 50)) << 4) | (OP_N if rng.random() < 0.5 else OP_P)], dtype=np.uint32)
+            cigar = np.concatenate((cigar[:k], extra, cigar[k:]))
         if clip_prob > 0.0:
             # soft/hard clips: the FASTA read carries the clipped bases either way (the reference reloads reads
             # from the reads file, input_output.cpp:546-569, and steps over S and H alike, call_variants.cpp:269-273)

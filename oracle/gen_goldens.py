@@ -89,6 +89,8 @@ def cases():
     out.append(("multi", multi, extra, {}))
     out.append(("lowdepth", [synth.make_contig(105, 0, 20_000, 2, 0.01, 14, "ont")], None, {}))
     out.append(("clips", [synth.make_contig(109, 0, 15_000, 2, 0.01, 40, "ont", clip_prob=0.5)], None, {}))
+    out.append(("edge_ops", [synth.make_contig(110, 0, 12_000, 2, 0.01, 40, "ont", eqx=True, overhang_prob=0.2, inert_ops_prob=0.3,
+                                                 clip_prob=0.2, read_len_override=(800, 4000))], None, {}))
     out.append(("tetra25k_lowmem", [synth.make_contig(106, 0, 25_000, 4, 0.01, 50, "ont")], None, {"low_memory": 1}))
     out.append(("tetra25k_ploidy2", [synth.make_contig(106, 0, 25_000, 4, 0.01, 50, "ont")], None,
                 {"ploidy_lines": ["ctg0\t2\n"]}))

@@ -100,3 +100,28 @@ def test_fused_pipeline_equals_two_step_path(built):
     assert cv2["n_snps"] == int(cv["snp_off"][-1]) and cv2["error_rate"] == cv["error_rate"]
     for k in ("win_off", "win_start", "win_end", "label_off", "labels"):
         assert np.array_equal(sr[k], sr2[k]), k
+
+
+@pytest.mark.parametrize("shape", ["tetra100k", "hifi300k"])
+def test_dropin_equals_oracle_at_larger_sizes(built, shape):
+    """Beyond the committed fixtures: BASELINE-shaped contigs (tetraploid ONT as C3, HiFi 300 kb chunk as C5) through
+    the drop-in executables, against the oracle restatement run on the same files."""
+    from hairsplitter_amd import synth, canon
+    if shape == "tetra100k":
+        contigs = [synth.make_contig(41, 0, 100_000, 4, 0.01, 40, "ont")]
+    else:
+        contigs = [synth.make_contig(42, 0, 300_000, 2, 0.001, 30, "hifi")]
+    with tempfile.TemporaryDirectory() as td:
+        f = synth.write_files(contigs, td)
+        outs = {}
+        for tag, cv, sr in (("hip", [built["cv"]], [built["sr"]]), ("orc", [built["oracle"], "call_variants"], [built["oracle"], "separate_reads"])):
+            col, vcf, err, gro = (os.path.join(td, tag + x) for x in (".col", ".vcf", ".err", ".gro"))
+            subprocess.run(cv + [f["gfa"], f["reads"], f["sam"], "4", td, err, "0", "0", col, vcf, "0.33"], check=True, stdout=subprocess.DEVNULL)
+            e = min(float(open(err).read().strip()), 0.15)
+            subprocess.run(sr + [col, "4", str(e), os.path.join(td, "no_ploidy"), "0", "0.01", "0", gro, "0"], check=True, stdout=subprocess.DEVNULL)
+            outs[tag] = (col, vcf, err, gro)
+        assert canon.split_blocks(outs["hip"][0]) == canon.split_blocks(outs["orc"][0])
+        assert canon.vcf_blocks(outs["hip"][1]) == canon.vcf_blocks(outs["orc"][1])
+        assert open(outs["hip"][2]).read() == open(outs["orc"][2]).read()
+        assert canon.split_blocks(outs["hip"][3]) == canon.split_blocks(outs["orc"][3])
+        assert sum(1 for l in open(outs["hip"][3]) if l.startswith("GROUP")) > 40

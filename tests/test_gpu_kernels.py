@@ -19,12 +19,16 @@ def _contigs(kind):
     if kind == "multi":
         return [synth.make_contig(12, 0, 9_000, 3, 0.01, 35, "ont"), synth.make_contig(12, 1, 700, 1, 0.0, 20, "ont", read_len_override=(100, 600)),
                 synth.make_contig(12, 2, 5_000, 1, 0.0, 0, "ont"), synth.make_contig(12, 3, 20_011, 4, 0.012, 50, "ont", clip_prob=0.4)]
+    if kind == "edge":
+        return [synth.make_contig(14, 0, 15_000, 2, 0.01, 40, "ont", eqx=True, overhang_prob=0.2, inert_ops_prob=0.3, clip_prob=0.3,
+                                  read_len_override=(300, 5000)),
+                synth.make_contig(14, 1, 300, 1, 0.0, 30, "ont", read_len_override=(50, 300), overhang_prob=0.5)]
     if kind == "hifi":
         return [synth.make_contig(13, 0, 40_000, 2, 0.003, 25, "hifi")]
     raise ValueError(kind)
 
 
-@pytest.fixture(scope="module", params=["dip", "multi", "hifi"])
+@pytest.fixture(scope="module", params=["dip", "multi", "hifi", "edge"])
 def batch(request, built):
     from hairsplitter_amd import api
     api.require_gpu()
