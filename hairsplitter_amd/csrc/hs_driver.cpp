@@ -172,7 +172,9 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
         const int f = chunks[(size_t)i].second;
         resolve_columns(cs, f, std::min<int>(f + 256, (int)cs.pos.size()));
     });
-    // ... then the sequential partition logic, one contig per thread
+    // ... then the sequential partition logic (V1 scan, loops A and B), one contig per thread ...
+    std::vector<CvContigState*> cst((size_t)C, nullptr);
+    for (int c = 0; c < C; ++c) cst[(size_t)c] = cv_state_new();
     parallel_for(C, n_threads, [&](int c) {
         ColumnSet& cs = sets[(size_t)c];
         int64_t nerr = 0, nlen = 0;
@@ -183,8 +185,15 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
         const int64_t entries = b.pile_off[(size_t)b.contig_rec_off[(size_t)c + 1]] - b.pile_off[(size_t)b.contig_rec_off[(size_t)c]];
         o.depth = (float)((double)entries / (double)L);   // call_variants.cpp:565
         const int n_reads_c = b.contig_rec_off[(size_t)c + 1] - b.contig_rec_off[(size_t)c];
-        call_variants_host(n_reads_c, L, cs, o.mean_distance, automatic_snp_threshold, o);
+        cv_phase_ab(*cst[(size_t)c], n_reads_c, cs, o.mean_distance, automatic_snp_threshold, o);
     });
+    // ... loops C and D: one independent decision per extracted column, chunked over all threads ...
+    parallel_for((int)chunks.size(), n_threads, [&](int i) {
+        const int c = chunks[(size_t)i].first, f = chunks[(size_t)i].second;
+        cv_phase_cd(*cst[(size_t)c], sets[(size_t)c], f, std::min<int>(f + 256, (int)sets[(size_t)c].pos.size()));
+    });
+    // ... and the final merge
+    for (int c = 0; c < C; ++c) { cv_phase_merge(*cst[(size_t)c], sets[(size_t)c], res[(size_t)c]); cv_state_free(cst[(size_t)c]); }
     const double t_glue_done = now_ms();
 
     hs_cv_result* R = (hs_cv_result*)std::calloc(1, sizeof(hs_cv_result));

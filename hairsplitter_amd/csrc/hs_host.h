@@ -32,8 +32,12 @@ struct ContigCvResult {
 };
 
 void resolve_columns(ColumnSet& cs, int first, int last);   // columns [first, last); the k/c arrays must be sized
-void call_variants_host(int n_reads, int64_t contig_len, ColumnSet& cs, float mean_distance,
-                        float automatic_snp_threshold, ContigCvResult& out);
+struct CvContigState;   // per-contig state between the phases of the stage-3 glue (hs_host_cv.cpp)
+CvContigState* cv_state_new();
+void cv_state_free(CvContigState* st);
+void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out);
+void cv_phase_cd(CvContigState& st, const ColumnSet& cs, int first, int last);
+void cv_phase_merge(CvContigState& st, const ColumnSet& cs, ContigCvResult& out);
 
 // generate_msa's return value from the integer event counts of the pileup kernel (call_variants.cpp:67-68,434)
 float mean_distance_from_counts(int64_t n_err, int64_t n_len);

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -75,18 +76,19 @@ void resolve_columns(ColumnSet& cs, int first, int last) {
 // reference code >= 128 never equals any key and stays eligible.
 static uint8_t second_most_frequent(const uint8_t* code, int n, const uint8_t* take, uint8_t ref, bool signed_ref_quirk,
                                     bool insert_ref_last, uint8_t dflt) {
-    int cnt[256];
+    // distinct codes in first-appearance order with their counts (a column carries a dozen codes at most: linear search)
     uint8_t seen[256];
+    int cnt[256];
     int nseen = 0;
-    bool have = false;
     for (int i = 0; i < n; ++i) {
         if (take && !take[i]) continue;
         const uint8_t c = code[i];
-        if (!have) { std::memset(cnt, 0, sizeof(cnt)); have = true; }
-        if (cnt[c] == 0) seen[nseen++] = c;
-        cnt[c]++;
+        int k = 0;
+        while (k < nseen && seen[k] != c) ++k;
+        if (k == nseen) { seen[nseen] = c; cnt[nseen] = 0; nseen++; }
+        cnt[k]++;
     }
-    if (!have) return dflt;
+    if (nseen == 0) return dflt;
     const bool ref_eligible = signed_ref_quirk && ref >= 128;
     int best = -1, nbest = 0;
     uint8_t bestk = dflt;
@@ -94,8 +96,8 @@ static uint8_t second_most_frequent(const uint8_t* code, int n, const uint8_t* t
     for (int i = 0; i < nseen; ++i) {
         const uint8_t k = seen[i];
         if (k == ref) { ref_seen = true; if (!ref_eligible) continue; }
-        if (cnt[k] > best) { best = cnt[k]; nbest = 1; bestk = k; }
-        else if (cnt[k] == best) nbest++;
+        if (cnt[i] > best) { best = cnt[i]; nbest = 1; bestk = k; }
+        else if (cnt[i] == best) nbest++;
     }
     if (ref_eligible && !ref_seen && insert_ref_last) {   // content2[ref_base] inserts a zero-count key
         if (0 > best) { best = 0; nbest = 1; bestk = ref; } else if (best == 0) nbest++;
@@ -111,7 +113,8 @@ static uint8_t second_most_frequent(const uint8_t* code, int n, const uint8_t* t
     for (int i = 0; i < m; ++i) {
         const uint8_t k = ord[i];
         if (k == ref && !ref_eligible) continue;
-        const int c = (k == ref && !ref_seen) ? 0 : cnt[k];
+        int c = 0;
+        for (int j = 0; j < nseen; ++j) if (seen[j] == k) { c = cnt[j]; break; }
         if (c == best) return k;
     }
     return bestk;
@@ -342,17 +345,31 @@ static inline bool central_base_test(int k0, int k1) {
     return k0 % 5 != k1 % 5 && ((k1 - '!') % 5 != 4 || (k1 / 5 % 5 != k0 % 5 && k1 / 25 % 5 != k0 % 5));
 }
 
-void call_variants_host(int n_reads, int64_t contig_len, ColumnSet& cs, float mean_distance,
-                        float automatic_snp_threshold, ContigCvResult& out) {
-    (void)contig_len;
+// Stage-3 glue in three phases so that the embarrassingly parallel part (loops C and D: one independent decision per
+// extracted column) can be spread over all worker threads instead of one thread per contig.
+struct CvContigState {
+    int n_reads = 0;
+    float mean_distance = 0, threshold = 0;
+    std::vector<int> cand, automatic;
+    std::vector<DensePartition> finals;
+    std::vector<char> is_cand, keep;     // per extracted column
+    bool have_partitions = false;
+};
+
+CvContigState* cv_state_new() { return new CvContigState(); }
+void cv_state_free(CvContigState* st) { delete st; }
+
+// V1 scan + loops A and B (sequential per contig): call_variants.cpp:525-536, :590-708
+void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out) {
+    st.n_reads = n_reads; st.mean_distance = mean_distance; st.threshold = automatic_snp_threshold;
     const int n_cols = (int)cs.pos.size();
     const int min_reads = mean_distance < 0.015 ? 3 : 5;                       // :463-466
     auto col_idx = [&](int i) { return cs.idx + cs.off[i]; };
     auto col_code = [&](int i) { return cs.code + cs.off[i]; };
     auto col_n = [&](int i) { return (int)(cs.off[i + 1] - cs.off[i]); };
+    st.is_cand.assign((size_t)n_cols, 0); st.keep.assign((size_t)n_cols, 0);
 
-    // ---- V1: candidates + automatic SNPs with the greedy spacing (:525-536) ----
-    std::vector<int> cand, automatic;
+    std::vector<int>& cand = st.cand; std::vector<int>& automatic = st.automatic;
     int pos_of_last = -5;
     for (int i = 0; i < n_cols; ++i) {
         const int k0 = cs.k0[i], k1 = cs.k1[i];
@@ -360,6 +377,7 @@ void call_variants_host(int n_reads, int64_t contig_len, ColumnSet& cs, float me
             if ((float)cs.c1[i] > automatic_snp_threshold * (float)cs.c0[i]) automatic.push_back(i);
             pos_of_last = cs.pos[i];
             cand.push_back(i);
+            st.is_cand[(size_t)i] = 1;
         }
     }
     out.n_candidates = (int)cand.size();
@@ -397,57 +415,65 @@ void call_variants_host(int n_reads, int64_t contig_len, ColumnSet& cs, float me
         } else last_position = pos;
     }
     out.n_partitions = (int)parts.size();
+    st.have_partitions = !parts.empty();
+    if (parts.empty()) return;
 
-    std::vector<int> filtered;   // column indices, ascending
-    if (!parts.empty()) {
-        // ---- loop B (:646-708) ----
-        std::vector<DensePartition> finals;
-        for (size_t p1 = 0; p1 < parts.size(); ++p1) {
-            const double p_value = significance(parts[p1], (int)cand.size());
-            if (!((p_value < 0.001 || parts[p1].n_corr > 1) && is_informative(parts[p1], mean_distance))) continue;
-            bool different = true;
-            for (size_t p2 = 0; p2 < finals.size(); ++p2) {
-                const PartPartDistance d = partition_vs_partition(finals[p2], parts[p1], 2);
-                if (d.augmented && (d.n00 + d.n11 > 5 * (d.n01 + d.n10) || d.n10 + d.n01 > 5 * (d.n00 + d.n11))
-                    && d.n10 < std::max(2, 2 * d.n01) && d.n01 < std::max(2, 2 * d.n10)) {
-                    bool do_merge = d.n01 + d.n10 < 0.1 * (d.n00 + d.n11);
-                    if (!do_merge) {
-                        DensePartition merged = finals[p2];
-                        merge_partitions(merged, parts[p1], d.phased);
-                        do_merge = confidence_score(merged) > confidence_score(finals[p2]);
-                    }
-                    if (do_merge) { merge_partitions(finals[p2], parts[p1], d.phased); different = false; break; }
+    // ---- loop B (:646-708) ----
+    std::vector<DensePartition>& finals = st.finals;
+    for (size_t p1 = 0; p1 < parts.size(); ++p1) {
+        const double p_value = significance(parts[p1], (int)cand.size());
+        if (!((p_value < 0.001 || parts[p1].n_corr > 1) && is_informative(parts[p1], mean_distance))) continue;
+        bool different = true;
+        for (size_t p2 = 0; p2 < finals.size(); ++p2) {
+            const PartPartDistance d = partition_vs_partition(finals[p2], parts[p1], 2);
+            if (d.augmented && (d.n00 + d.n11 > 5 * (d.n01 + d.n10) || d.n10 + d.n01 > 5 * (d.n00 + d.n11))
+                && d.n10 < std::max(2, 2 * d.n01) && d.n01 < std::max(2, 2 * d.n10)) {
+                bool do_merge = d.n01 + d.n10 < 0.1 * (d.n00 + d.n11);
+                if (!do_merge) {
+                    DensePartition merged = finals[p2];
+                    merge_partitions(merged, parts[p1], d.phased);
+                    do_merge = confidence_score(merged) > confidence_score(finals[p2]);
                 }
-            }
-            if (different) finals.push_back(parts[p1]);
-        }
-        out.n_final_partitions = (int)finals.size();
-
-        // ---- loop C (:721-738) ----
-        std::vector<char> kept(n_cols, 0);
-        for (int ci : cand) {
-            const int32_t* idx = col_idx(ci); const uint8_t* code = col_code(ci); const int n = col_n(ci);
-            for (size_t p = 0; p < finals.size(); ++p) {
-                const Contingency d = column_vs_partition(finals[p], idx, code, n, cs.k0[ci]);
-                const float chi = chi_square(d);
-                if (d.n00 + d.n01 + d.n10 + d.n11 > 0.5 * n && chi > 15) { kept[ci] = 1; break; }
+                if (do_merge) { merge_partitions(finals[p2], parts[p1], d.phased); different = false; break; }
             }
         }
-        // ---- loop D (:745-764), restricted to the columns that can pass n10+n00 > 4 ----
-        for (int i = 0; i < n_cols; ++i) {
-            if (kept[i]) { filtered.push_back(i); continue; }
-            if (cs.c1[i] < 5) continue;
-            if (!central_base_test(cs.k0[i], cs.k1[i])) continue;
-            const int32_t* idx = col_idx(i); const uint8_t* code = col_code(i); const int n = col_n(i);
-            for (size_t p = 0; p < finals.size(); ++p) {
-                const Contingency d = column_vs_partition(finals[p], idx, code, n, cs.k0[i]);
-                if (chi_square(d) > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) { filtered.push_back(i); break; }
-            }
-        }
+        if (different) finals.push_back(parts[p1]);
     }
-    out.n_filtered = (int)filtered.size();
+    out.n_final_partitions = (int)finals.size();
+}
 
-    // ---- two-pointer union that stops when either list ends (:1335-1352) ----
+// loops C (:721-738) and D (:745-764) for the extracted columns [first, last): independent per column.
+// Loop D is restricted to the columns that can pass n10+n00 > 4 (second count >= 5).
+void cv_phase_cd(CvContigState& st, const ColumnSet& cs, int first, int last) {
+    if (!st.have_partitions) return;
+    const std::vector<DensePartition>& finals = st.finals;
+    for (int i = first; i < last; ++i) {
+        const int32_t* idx = cs.idx + cs.off[i]; const uint8_t* code = cs.code + cs.off[i];
+        const int n = (int)(cs.off[i + 1] - cs.off[i]);
+        bool kept = false;
+        if (st.is_cand[(size_t)i]) {
+            for (size_t p = 0; p < finals.size() && !kept; ++p) {
+                const Contingency d = column_vs_partition(finals[p], idx, code, n, cs.k0[i]);
+                const float chi = chi_square(d);
+                if (d.n00 + d.n01 + d.n10 + d.n11 > 0.5 * n && chi > 15) kept = true;
+            }
+        }
+        if (!kept && cs.c1[i] >= 5 && central_base_test(cs.k0[i], cs.k1[i])) {
+            for (size_t p = 0; p < finals.size() && !kept; ++p) {
+                const Contingency d = column_vs_partition(finals[p], idx, code, n, cs.k0[i]);
+                if (chi_square(d) > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) kept = true;
+            }
+        }
+        st.keep[(size_t)i] = kept ? 1 : 0;
+    }
+}
+
+// two-pointer union of automatic and filtered SNPs that stops when either list ends (:1335-1352)
+void cv_phase_merge(CvContigState& st, const ColumnSet& cs, ContigCvResult& out) {
+    std::vector<int> filtered;
+    for (int i = 0; i < (int)st.keep.size(); ++i) if (st.keep[(size_t)i]) filtered.push_back(i);
+    out.n_filtered = (int)filtered.size();
+    const std::vector<int>& automatic = st.automatic;
     size_t ia = 0, ifi = 0;
     out.snp_col.clear();
     while (ia < automatic.size() && ifi < filtered.size()) {
