@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_ROOT, "lib", "libhairsplitter_hip.so")
 SYMBOLS = [
     "hs_version", "hs_last_error", "hs_device_count", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
-    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_simdiff", "hs_chinese_whispers",
+    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_column_partition_test", "hs_simdiff", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
     "hs_separate_reads_main",
@@ -35,7 +35,7 @@ class CvResult(C.Structure):
                 ("snp_off", C.POINTER(C.c_int64)), ("snp_pos", C.POINTER(C.c_int32)), ("snp_ref", C.POINTER(C.c_uint8)),
                 ("snp_alt", C.POINTER(C.c_uint8)), ("col_off", C.POINTER(C.c_int64)), ("col_idx", C.POINTER(C.c_int32)),
                 ("col_code", C.POINTER(C.c_uint8)), ("error_rate", C.c_float), ("n_contigs_with_error_rate", C.c_int32),
-                ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("t_kernel_ms", C.c_float * 4)]
+                ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("t_kernel_ms", C.c_float * 4), ("t_kernel_k4_ms", C.c_float)]
 
 
 class SrContig(C.Structure):
@@ -236,7 +236,7 @@ class CvBatch:
             Cn = r.n_contigs
             cv = {"mean_distance": np.ctypeslib.as_array(r.mean_distance, (max(Cn, 1),))[:Cn].copy(), "error_rate": float(r.error_rate),
                   "n_snps": int(np.ctypeslib.as_array(r.snp_off, (Cn + 1,))[-1]),
-                  "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "t_kernel_ms": [float(x) for x in r.t_kernel_ms]}
+                  "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_k4_ms": float(r.t_kernel_k4_ms)}
             e = error_rate_fn(cv) if error_rate_fn is not None else min(float("%g" % cv["error_rate"]), 0.15)
             sres = C.POINTER(SrResult)()
             _check(lib.hs_sr_run_cv(self.handle, res, C.c_float(e), C.c_float(rarest_strain_abundance), C.c_int32(1 if low_memory else 0),
@@ -443,6 +443,24 @@ def gather_columns(t, flat: FlatBatch, pile, sel_contig, sel_pos, depths):
                                     _p(d_sc), _p(d_sp), _p(d_co), C.c_int32(n), _p(idx), _p(code), C.c_void_p(0)))
     torch.cuda.synchronize()
     return col_off, idx[:tot].cpu().numpy(), code[:tot].cpu().numpy()
+
+
+def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1, col_c1, col_is_cand, part_off, part_state_off, part_state):
+    """K4: loops C/D of keep_only_robust_variants (call_variants.cpp:721-764); returns keep uint8 [n_cols]."""
+    import torch
+    require_gpu()
+    dev = "cuda:0"
+    n = len(col_contig)
+    def up(a, dt):
+        a = _np(a, dt)
+        return torch.from_numpy(a if a.size else np.zeros(1, dt)).to(dev)
+    d = [up(col_off, np.int64), up(col_idx, np.int32), up(col_code, np.uint8), up(col_contig, np.int32), up(col_k0, np.uint8), up(col_k1, np.uint8),
+         up(col_c1, np.int32), up(col_is_cand, np.uint8)]
+    q = [up(part_off, np.int32), up(part_state_off, np.int64), up(part_state, np.int8)]
+    keep = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+    _check(load().hs_column_partition_test(*[_p(x) for x in d], C.c_int32(n), *[_p(x) for x in q], _p(keep), C.c_void_p(0)))
+    torch.cuda.synchronize()
+    return keep[:n].cpu().numpy()
 
 
 def simdiff(alt_planes: np.ndarray, ref_planes: np.ndarray):

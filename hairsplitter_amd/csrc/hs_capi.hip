@@ -252,6 +252,20 @@ int hs_gather_columns(const uint8_t* d_pile, const int64_t* d_pile_off, const in
     return HS_OK;
 }
 
+int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code,
+                             const int32_t* d_col_contig, const uint8_t* d_col_k0, const uint8_t* d_col_k1,
+                             const int32_t* d_col_c1, const uint8_t* d_col_is_cand, int32_t n_cols,
+                             const int32_t* d_part_off, const int64_t* d_part_state_off, const int8_t* d_part_state,
+                             uint8_t* d_keep, void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_cols <= 0) return HS_OK;
+    hipLaunchKernelGGL(hsdev::k_column_partition_test, dim3((n_cols + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_col_off, d_col_idx,
+                       d_col_code, d_col_contig, d_col_k0, d_col_k1, d_col_c1, d_col_is_cand, n_cols, d_part_off, d_part_state_off,
+                       d_part_state, d_keep);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
 static int simdiff_launch(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_plane_off, const int32_t* d_n_reads,
                           const int32_t* d_words, const int64_t* d_out_off, const std::vector<int32_t>& h_n_reads,
                           int32_t* d_sim, int32_t* d_diff, void* stream, DBuf& t_c, DBuf& t_i, DBuf& t_j) {
@@ -531,6 +545,31 @@ struct HipCvOps : hs::CvDeviceOps {
     }
 
     HBuf h_col_idx, h_col_code;
+    DBuf d_co, d_ci, d_cc;     // the extracted columns stay on the device for K4
+    int n_gathered = 0;
+    int column_partition_test(const hs::CvPartitionTest& t, std::vector<uint8_t>& keep, float* k_ms) override {
+        const int n = (int)t.col_contig.size();
+        if (n != n_gathered) { set_error("column_partition_test: column count differs from the last gather"); return HS_EINVAL; }
+        DBuf d_ctg, d_k0, d_k1, d_c1, d_cand, d_po, d_pso, d_ps, d_keep;
+        if (int rc = d_ctg.upload(t.col_contig)) return rc;
+        if (int rc = d_k0.upload(t.col_k0)) return rc;
+        if (int rc = d_k1.upload(t.col_k1)) return rc;
+        if (int rc = d_c1.upload(t.col_c1)) return rc;
+        if (int rc = d_cand.upload(t.col_is_cand)) return rc;
+        if (int rc = d_po.upload(t.part_off)) return rc;
+        if (int rc = d_pso.upload(t.part_state_off)) return rc;
+        if (int rc = d_ps.upload(t.part_state)) return rc;
+        if (int rc = d_keep.alloc((size_t)n)) return rc;
+        EventPair e; if (int rc = e.init()) return rc;
+        HS_HIP(hipEventRecord(e.a, stream));
+        if (int rc = hs_column_partition_test(d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), d_ctg.as<int32_t>(), d_k0.as<uint8_t>(),
+                                              d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), n, d_po.as<int32_t>(), d_pso.as<int64_t>(),
+                                              d_ps.as<int8_t>(), d_keep.as<uint8_t>(), stream)) return rc;
+        HS_HIP(hipEventRecord(e.b, stream));
+        keep.resize((size_t)n);
+        if (n) HS_HIP(hipMemcpy(keep.data(), d_keep.p, (size_t)n, hipMemcpyDeviceToHost));
+        return e.ms(k_ms);
+    }
     int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
                const int32_t** col_idx, const uint8_t** col_code, float* k_ms) override {
         const int n_sel = (int)sel_pos.size();
@@ -538,8 +577,9 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = h_col_idx.alloc(total * sizeof(int32_t))) return rc;
         if (int rc = h_col_code.alloc(total)) return rc;
         *col_idx = (const int32_t*)h_col_idx.p; *col_code = (const uint8_t*)h_col_code.p;
+        n_gathered = n_sel;
         if (n_sel == 0) return HS_OK;
-        DBuf d_sc, d_sp, d_co, d_ci, d_cc;
+        DBuf d_sc, d_sp;
         if (int rc = d_sc.upload(sel_contig)) return rc;
         if (int rc = d_sp.upload(sel_pos)) return rc;
         if (int rc = d_co.upload(col_off)) return rc;

@@ -112,6 +112,7 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
     const int C = b.n_contigs, NR = b.n_rec;
     const double t_start = now_ms();
     float k_ms[4] = {0, 0, 0, 0};   // pileup, column_stats, gather_columns, cigar_scan
+    float k_ms_k4 = 0;              // column x partition test
 
     std::vector<int32_t> rec_stats((size_t)NR * 4);
     std::vector<int64_t> sel_gpos;
@@ -187,11 +188,25 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
         const int n_reads_c = b.contig_rec_off[(size_t)c + 1] - b.contig_rec_off[(size_t)c];
         cv_phase_ab(*cst[(size_t)c], n_reads_c, cs, o.mean_distance, automatic_snp_threshold, o);
     });
-    // ... loops C and D: one independent decision per extracted column, chunked over all threads ...
-    parallel_for((int)chunks.size(), n_threads, [&](int i) {
-        const int c = chunks[(size_t)i].first, f = chunks[(size_t)i].second;
-        cv_phase_cd(*cst[(size_t)c], sets[(size_t)c], f, std::min<int>(f + 256, (int)sets[(size_t)c].pos.size()));
-    });
+    // ... loops C and D on the device: one wavefront per extracted column against the contig's final partitions ...
+    {
+        CvPartitionTest t;
+        const size_t n_sel = sel_pos.size();
+        t.col_contig = sel_contig;
+        t.col_c1.resize(n_sel); t.col_k0.resize(n_sel); t.col_k1.resize(n_sel); t.col_is_cand.resize(n_sel);
+        t.part_off.assign((size_t)C + 1, 0);
+        for (int c = 0; c < C; ++c) {
+            const ColumnSet& cs = sets[(size_t)c];
+            const size_t s0 = (size_t)contig_sel_off[(size_t)c];
+            for (size_t i = 0; i < cs.pos.size(); ++i) { t.col_c1[s0 + i] = cs.c1[i]; t.col_k0[s0 + i] = cs.k0[i]; t.col_k1[s0 + i] = cs.k1[i]; }
+            cv_export_candidates(*cst[(size_t)c], t.col_is_cand.data() + s0);
+            cv_export_partitions(*cst[(size_t)c], t.part_state, t.part_state_off);
+            t.part_off[(size_t)c + 1] = (int32_t)t.part_state_off.size();
+        }
+        std::vector<uint8_t> keep(n_sel, 0);
+        if (n_sel) { if (int rc = dev.column_partition_test(t, keep, &k_ms_k4)) return rc; }
+        for (int c = 0; c < C; ++c) cv_import_keep(*cst[(size_t)c], keep.data() + contig_sel_off[(size_t)c]);
+    }
     // ... and the final merge
     for (int c = 0; c < C; ++c) { cv_phase_merge(*cst[(size_t)c], sets[(size_t)c], res[(size_t)c]); cv_state_free(cst[(size_t)c]); }
     const double t_glue_done = now_ms();
@@ -232,7 +247,7 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
     R->mean_distance = dup_vec(md); R->depth = dup_vec(dp); R->snp_off = dup_vec(snp_off);
     R->error_rate = total_error / n_err_contigs;      // call_variants.cpp:1377 (float / int)
     R->n_contigs_with_error_rate = n_err_contigs;
-    R->t_kernel_ms[0] = k_ms[0]; R->t_kernel_ms[1] = k_ms[1]; R->t_kernel_ms[2] = k_ms[2]; R->t_kernel_ms[3] = k_ms[3];
+    R->t_kernel_ms[0] = k_ms[0]; R->t_kernel_ms[1] = k_ms[1]; R->t_kernel_ms[2] = k_ms[2]; R->t_kernel_ms[3] = k_ms[3]; R->t_kernel_k4_ms = k_ms_k4;
     R->t_device_ms = t_dev_done - t_start;
     R->t_host_ms = now_ms() - t_dev_done;
     if (std::getenv("HS_TIMING"))

@@ -20,6 +20,16 @@ struct CvMeta {                       // host-side description of a stage-3 batc
     int64_t total_len = 0;
 };
 
+// K4 input: the extracted columns (still resident on the device after gather()) with their exact top-2 codes, and the
+// final partitions of every contig as dense per-read state arrays (2 = read not in the partition)
+struct CvPartitionTest {
+    std::vector<int32_t> col_contig, col_c1;
+    std::vector<uint8_t> col_k0, col_k1, col_is_cand;
+    std::vector<int32_t> part_off;          // [C+1] range of partitions of each contig
+    std::vector<int64_t> part_state_off;    // [sum F] offset of each partition's state array
+    std::vector<int8_t> part_state;
+};
+
 struct CvDeviceOps {
     virtual ~CvDeviceOps() {}
     // K0+K1 + K2: per-record {q_end, n_err, n_len, n_events}; the global positions (unordered) whose second count c1 is
@@ -32,6 +42,8 @@ struct CvDeviceOps {
     virtual int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos,
                        const std::vector<int64_t>& col_off, const int32_t** col_idx, const uint8_t** col_code,
                        float* k_ms) = 0;
+    // K4: loops C and D of keep_only_robust_variants on the columns of the last gather(); keep[i] for column i
+    virtual int column_partition_test(const CvPartitionTest& t, std::vector<uint8_t>& keep, float* k_ms) = 0;
 };
 
 int cv_run(CvDeviceOps& dev, const CvMeta& meta, float automatic_snp_threshold, int n_threads, hs_cv_result** out);

@@ -36,7 +36,10 @@ struct CvContigState;   // per-contig state between the phases of the stage-3 gl
 CvContigState* cv_state_new();
 void cv_state_free(CvContigState* st);
 void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out);
-void cv_phase_cd(CvContigState& st, const ColumnSet& cs, int first, int last);
+// exports the final partitions / candidate flags for the device test (K4) and imports its verdict
+void cv_export_partitions(const CvContigState& st, std::vector<int8_t>& state, std::vector<int64_t>& state_off);
+void cv_export_candidates(const CvContigState& st, uint8_t* is_cand);
+void cv_import_keep(CvContigState& st, const uint8_t* keep);
 void cv_phase_merge(CvContigState& st, const ColumnSet& cs, ContigCvResult& out);
 
 // generate_msa's return value from the integer event counts of the pileup kernel (call_variants.cpp:67-68,434)

@@ -442,30 +442,19 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
     out.n_final_partitions = (int)finals.size();
 }
 
-// loops C (:721-738) and D (:745-764) for the extracted columns [first, last): independent per column.
-// Loop D is restricted to the columns that can pass n10+n00 > 4 (second count >= 5).
-void cv_phase_cd(CvContigState& st, const ColumnSet& cs, int first, int last) {
-    if (!st.have_partitions) return;
-    const std::vector<DensePartition>& finals = st.finals;
-    for (int i = first; i < last; ++i) {
-        const int32_t* idx = cs.idx + cs.off[i]; const uint8_t* code = cs.code + cs.off[i];
-        const int n = (int)(cs.off[i + 1] - cs.off[i]);
-        bool kept = false;
-        if (st.is_cand[(size_t)i]) {
-            for (size_t p = 0; p < finals.size() && !kept; ++p) {
-                const Contingency d = column_vs_partition(finals[p], idx, code, n, cs.k0[i]);
-                const float chi = chi_square(d);
-                if (d.n00 + d.n01 + d.n10 + d.n11 > 0.5 * n && chi > 15) kept = true;
-            }
-        }
-        if (!kept && cs.c1[i] >= 5 && central_base_test(cs.k0[i], cs.k1[i])) {
-            for (size_t p = 0; p < finals.size() && !kept; ++p) {
-                const Contingency d = column_vs_partition(finals[p], idx, code, n, cs.k0[i]);
-                if (chi_square(d) > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) kept = true;
-            }
-        }
-        st.keep[(size_t)i] = kept ? 1 : 0;
+// Loops C (:721-738) and D (:745-764) run on the device (k_column_partition_test): the final partitions leave as dense
+// state arrays, the verdict per extracted column comes back.
+void cv_export_partitions(const CvContigState& st, std::vector<int8_t>& state, std::vector<int64_t>& state_off) {
+    for (const DensePartition& p : st.finals) {
+        state_off.push_back((int64_t)state.size());
+        state.insert(state.end(), p.state.begin(), p.state.end());
     }
+}
+void cv_export_candidates(const CvContigState& st, uint8_t* is_cand) {
+    for (size_t i = 0; i < st.is_cand.size(); ++i) is_cand[i] = (uint8_t)st.is_cand[i];
+}
+void cv_import_keep(CvContigState& st, const uint8_t* keep) {
+    for (size_t i = 0; i < st.keep.size(); ++i) st.keep[i] = (st.have_partitions && keep[i]) ? 1 : 0;
 }
 
 // two-pointer union of automatic and filtered SNPs that stops when either list ends (:1335-1352)

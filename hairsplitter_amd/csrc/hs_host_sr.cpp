@@ -10,6 +10,8 @@
 #include "hs_rh8.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -72,9 +74,13 @@ static void pick_neighbors_sorted(std::vector<std::pair<int, float>>& smallest, 
 // the picked set is identical either way (any std::sort output is a descending arrangement).
 // Requires distances in [0,1] without NaN and below >= 0 (non-masked reads have distance 0 and can then never pass).
 static bool g_force_sort = std::getenv("HS_FORCE_ROW_SORT") != nullptr;
+static std::atomic<long> g_rows_total{0}, g_rows_sorted{0};
+struct RowStatPrinter { ~RowStatPrinter() { if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] graph rows: %ld, resolved by std::sort: %ld\n", g_rows_total.load(), g_rows_sorted.load()); } };
+static RowStatPrinter g_row_stat_printer;
 static void pick_neighbors(std::vector<std::pair<int, float>>& smallest, const uint8_t* mask, float error_rate, std::vector<int>& picked) {
     const int N = (int)smallest.size();
     const float below = 1 - error_rate * 2;
+    g_rows_total++;
     if (g_force_sort || N < 2 || !(below >= 0)) { pick_neighbors_sorted(smallest, mask, error_rate, picked); return; }
     // largest two values (with multiplicity), number of exact ones, five largest values below one, minimum
     float s0 = -1, s1 = -1, mn = 2;
@@ -138,6 +144,7 @@ static void pick_neighbors(std::vector<std::pair<int, float>>& smallest, const u
         return;
     }
     // the run of equal distances at the cut-off is only partly taken: std::sort's arrangement decides
+    g_rows_sorted++;
     pick_neighbors_sorted(smallest, mask, error_rate, picked);
 }
 

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "hs_device.h"
+#include "hs_rh8.h"
 
 namespace hsdev {
 
@@ -810,6 +811,171 @@ __global__ __launch_bounds__(256) void k_cw_drop_small(
     first_seen_ids(fpos, N, pre, ids);
     __syncthreads();
     for (int j = tid; j < N; j += 256) if (out[j] >= 0) out[j] = ids[j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 SNP column x partition correlation: distance(Partition&, Column&) + computeChiSquare
+// (call_variants.cpp:778-967, :1135-1163) for loops C (:721-738) and D (:745-764) of keep_only_robust_variants.
+// One wavefront per extracted column, lanes = reads of the column. For every final partition of the contig:
+//  * the reads present in both are found with one gather of the partition state per lane;
+//  * the codes carried by those reads are enumerated leader by leader (v_readlane + __ballot), each distinct code gets
+//    a slot (lane j holds slot j) with its total / "+1" / "-1" counts = __popcll of ballots -- the whole 2x2 table
+//    falls out of popcounts once the second allele is known;
+//  * second allele = most frequent non-reference code; ties go to the first key in the reference's hash-map iteration
+//    order (hs_rh8.h emulator, run by one lane, rare). A reference code >= 128 never equals a key in the reference's
+//    signed/unsigned comparison (:838) and then competes as well.
+//  * chi-square with the reference's operation types (float marginals, double squares, float result); hipcc is run
+//    with -ffp-contract=off and IEEE division so the bits match the host.
+// keep[col] = 1 if the column is kept by loop C (candidates) or rescued by loop D (second count >= 5 + byte predicate).
+// ------------------------------------------------------------------------------------------------
+struct Table2x2 { int n00, n01, n10, n11; };
+
+static __device__ __forceinline__ float chi_square_dev(const Table2x2& d) {
+    const int n = d.n00 + d.n01 + d.n10 + d.n11;
+    if (n == 0) return 0;
+    const float pmax1 = float(d.n10 + d.n11) / n;
+    const float pmax2 = float(d.n01 + d.n11) / n;
+    if (pmax1 * (1 - pmax1) == 0 && pmax2 * (1 - pmax2) == 0) return -1;
+    if (pmax1 * pmax2 * (1 - pmax1) * (1 - pmax2) == 0) return 0;
+    const float e00 = (1 - pmax1) * (1 - pmax2) * n, e01 = (1 - pmax1) * pmax2 * n;
+    const float e10 = pmax1 * (1 - pmax2) * n, e11 = pmax1 * pmax2 * n;
+    const double d00 = (double)(float)(d.n00 - e00), d01 = (double)(float)(d.n01 - e01);
+    const double d10 = (double)(float)(d.n10 - e10), d11 = (double)(float)(d.n11 - e11);
+    return (float)(d00 * d00 / (double)e00 + d01 * d01 / (double)e01 + d10 * d10 / (double)e10 + d11 * d11 / (double)e11);
+}
+
+static __device__ __forceinline__ bool central_base_test_dev(int k0, int k1) {
+    // call_variants.cpp:527-528 and :751-752 (same predicate on raw code bytes)
+    return k0 % 5 != k1 % 5 && ((k1 - '!') % 5 != 4 || (k1 / 5 % 5 != k0 % 5 && k1 / 25 % 5 != k0 % 5));
+}
+
+// the 2x2 table of one column against one partition; wave-uniform result
+static __device__ Table2x2 column_vs_partition_dev(const int32_t* __restrict__ idx, const uint8_t* __restrict__ code, int n,
+                                                   const int8_t* __restrict__ state, int ref, uint8_t* s_seen /* [128] */,
+                                                   uint8_t* s_ord /* [260] */, int* s_ord_n /* [1] */) {
+    const int lane = lane_id();
+    // slot j of the distinct-code table lives in lane j (codes 33..157: at most 125 distinct -> two slots per lane)
+    int sc[2] = {-1, -1}, st_tot[2] = {0, 0}, st_pos[2] = {0, 0}, st_neg[2] = {0, 0};
+    int nseen = 0, shared = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int e = base + lane;
+        const bool valid = e < n;
+        const int cd = valid ? (int)code[e] : -1;
+        const int stv = valid ? (int)state[idx[e]] : 2;
+        const bool take = valid && stv != 2;                 // 2 == read not in the partition
+        const unsigned long long plus = __ballot(take && stv == 1), minus = __ballot(take && stv == -1);
+        unsigned long long rem = __ballot(take);
+        shared += __popcll(rem);
+        while (rem) {
+            const int leader = __builtin_ctzll(rem);
+            const int c = __builtin_amdgcn_readlane(cd, leader);
+            const unsigned long long m = __ballot(take && cd == c);
+            rem &= ~m;
+            const int kt = __popcll(m), kp = __popcll(m & plus), kn = __popcll(m & minus);
+            const unsigned long long hit0 = __ballot(sc[0] == c), hit1 = __ballot(sc[1] == c);
+            if (hit0) { if (sc[0] == c) { st_tot[0] += kt; st_pos[0] += kp; st_neg[0] += kn; } }
+            else if (hit1) { if (sc[1] == c) { st_tot[1] += kt; st_pos[1] += kp; st_neg[1] += kn; } }
+            else {
+                const int slot = nseen & 63;
+                if (nseen < 64) { if (lane == slot) { sc[0] = c; st_tot[0] = kt; st_pos[0] = kp; st_neg[0] = kn; } }
+                else { if (lane == slot) { sc[1] = c; st_tot[1] = kt; st_pos[1] = kp; st_neg[1] = kn; } }
+                nseen++;
+            }
+        }
+    }
+    Table2x2 r; r.n00 = r.n01 = r.n10 = r.n11 = 0;
+    if (shared == 0) return r;                               // not comparable (call_variants.cpp:817-828)
+    // reference allele counts
+    const unsigned long long ref0 = __ballot(sc[0] == ref), ref1 = __ballot(sc[1] == ref);
+    const bool ref_seen = (ref0 | ref1) != 0ull;
+    if (ref0) { const int l = __builtin_ctzll(ref0); r.n11 = __builtin_amdgcn_readlane(st_pos[0], l); r.n01 = __builtin_amdgcn_readlane(st_neg[0], l); }
+    else if (ref1) { const int l = __builtin_ctzll(ref1); r.n11 = __builtin_amdgcn_readlane(st_pos[1], l); r.n01 = __builtin_amdgcn_readlane(st_neg[1], l); }
+    // second allele: most frequent eligible code (call_variants.cpp:832-844)
+    const bool ref_eligible = ref >= 128;
+    int key0 = (lane < nseen && (sc[0] != ref || ref_eligible)) ? st_tot[0] : -1;
+    int key1 = (lane + 64 < nseen && (sc[1] != ref || ref_eligible)) ? st_tot[1] : -1;
+    int best = key0 > key1 ? key0 : key1;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
+    int second = ' ';
+    bool second_is_unseen_ref = false;
+    if (ref_eligible && !ref_seen && best < 0) { second = ref; second_is_unseen_ref = true; best = 0; }   // content2[ref] inserts a zero-count key
+    if (best >= 0 && !second_is_unseen_ref) {
+        const unsigned long long b0 = __ballot(key0 == best), b1 = __ballot(key1 == best);
+        const int nbest = __popcll(b0) + __popcll(b1) + ((ref_eligible && !ref_seen && best == 0) ? 1 : 0);
+        if (nbest == 1) {
+            second = b0 ? __builtin_amdgcn_readlane(sc[0], __builtin_ctzll(b0)) : __builtin_amdgcn_readlane(sc[1], __builtin_ctzll(b1));
+        } else {
+            // tie: first of the tied keys in the hash map's iteration order (keys inserted in first-appearance order, then
+            // ref). One lane replays the insertions on the emulator and publishes the order; the tied slots are then
+            // looked up in that order.
+            if (lane < nseen) s_seen[lane] = (uint8_t)sc[0];
+            if (lane + 64 < nseen) s_seen[lane + 64] = (uint8_t)sc[1];
+            wave_lds_sync();
+            if (lane == 0) {
+                hs::Rh8 rh; rh.clear();
+                for (int i = 0; i < nseen; ++i) rh.insert(s_seen[i]);
+                rh.insert((uint8_t)ref);
+                s_ord_n[0] = rh.order(s_ord);
+            }
+            wave_lds_sync();
+            const int m = s_ord_n[0];
+            second = -1;
+            for (int i = 0; i < m && second < 0; ++i) {
+                const int k = s_ord[i];
+                if (k == ref && !ref_eligible) continue;
+                const unsigned long long h0 = __ballot(lane < nseen && sc[0] == k), h1 = __ballot(lane + 64 < nseen && sc[1] == k);
+                int cnt = 0;                                     // an unseen ref has count 0
+                if (h0) cnt = __builtin_amdgcn_readlane(st_tot[0], __builtin_ctzll(h0));
+                else if (h1) cnt = __builtin_amdgcn_readlane(st_tot[1], __builtin_ctzll(h1));
+                if (cnt == best) second = k;
+            }
+            if (second < 0) second = ' ';
+        }
+    }
+    if (second != ref) {   // c == mostFrequent is tested first in the reference (:899-936): nothing is left for an equal second
+        const unsigned long long s0 = __ballot(lane < nseen && sc[0] == second), s1 = __ballot(lane + 64 < nseen && sc[1] == second);
+        if (s0) { const int l = __builtin_ctzll(s0); r.n10 = __builtin_amdgcn_readlane(st_pos[0], l); r.n00 = __builtin_amdgcn_readlane(st_neg[0], l); }
+        else if (s1) { const int l = __builtin_ctzll(s1); r.n10 = __builtin_amdgcn_readlane(st_pos[1], l); r.n00 = __builtin_amdgcn_readlane(st_neg[1], l); }
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_column_partition_test(
+    const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
+    const int32_t* __restrict__ col_contig, const uint8_t* __restrict__ col_k0, const uint8_t* __restrict__ col_k1,
+    const int32_t* __restrict__ col_c1, const uint8_t* __restrict__ col_is_cand, int n_cols,
+    const int32_t* __restrict__ part_off /* [C+1] */, const int64_t* __restrict__ part_state_off /* [sum F] */,
+    const int8_t* __restrict__ part_state, uint8_t* __restrict__ keep) {
+    __shared__ uint8_t s_seen[4][128];
+    __shared__ uint8_t s_ord[4][264];
+    __shared__ int s_ord_n[4];
+    const int lane = lane_id();
+    const int wv = (int)(threadIdx.x >> 6);
+    const int col = (int)blockIdx.x * 4 + wv;
+    if (col >= n_cols) return;
+    const int c = col_contig[col];
+    const int p0 = part_off[c], p1 = part_off[c + 1];
+    const int64_t e0 = col_off[col];
+    const int n = (int)(col_off[col + 1] - e0);
+    const int32_t* __restrict__ idx = col_idx + e0;
+    const uint8_t* __restrict__ code = col_code + e0;
+    const int k0 = col_k0[col], k1 = col_k1[col];
+    bool kept = false;
+    if (col_is_cand[col]) {                                   // loop C (:721-738)
+        for (int p = p0; p < p1 && !kept; ++p) {
+            const Table2x2 d = column_vs_partition_dev(idx, code, n, part_state + part_state_off[p], k0, s_seen[wv], s_ord[wv], &s_ord_n[wv]);
+            const float chi = chi_square_dev(d);
+            if ((double)(d.n00 + d.n01 + d.n10 + d.n11) > 0.5 * (double)n && chi > 15) kept = true;
+        }
+    }
+    if (!kept && col_c1[col] >= 5 && central_base_test_dev(k0, k1)) {   // loop D (:745-764) on the columns that can be rescued
+        for (int p = p0; p < p1 && !kept; ++p) {
+            const Table2x2 d = column_vs_partition_dev(idx, code, n, part_state + part_state_off[p], k0, s_seen[wv], s_ord[wv], &s_ord_n[wv]);
+            if ((double)chi_square_dev(d) > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) kept = true;
+        }
+    }
+    if (lane == 0) keep[col] = kept ? 1 : 0;
 }
 
 // small utility: apply host-resolved "swap top-2" decisions to the column statistics

@@ -117,6 +117,21 @@ int hs_gather_columns(const uint8_t* d_pile, const int64_t* d_pile_off, const in
                       int32_t n_sel, int32_t* d_col_idx, uint8_t* d_col_code, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K4 -- SNP column x partition correlation.  Replaces distance(Partition&, Column&) + computeChiSquare
+ * (call_variants.cpp:778-967, :1135-1163) as used by loops C and D of keep_only_robust_variants (:721-764).
+ * Columns are the CSR produced by hs_gather_columns; col_k0 / col_k1 their two most frequent codes in the reference's
+ * tie order; col_c1 the second count; col_is_cand marks candidate SNPs (loop C). Partitions are dense int8 state
+ * arrays over the contig's reads (1, -1, 0, or 2 = read absent); contig c owns partitions [part_off[c], part_off[c+1]).
+ * d_keep[i] = 1 if column i is kept by loop C (chi2 > 15 on more than half of its reads) or rescued by loop D
+ * (chi2 > 20, both alleles carried by more than four partition reads).
+ * ---------------------------------------------------------------------------------------------- */
+int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code,
+                             const int32_t* d_col_contig, const uint8_t* d_col_k0, const uint8_t* d_col_k1,
+                             const int32_t* d_col_c1, const uint8_t* d_col_is_cand, int32_t n_cols,
+                             const int32_t* d_part_off, const int64_t* d_part_state_off, const int8_t* d_part_state,
+                             uint8_t* d_keep, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K5 -- read x read similarity / difference.  Replaces list_similarities_and_differences_between_reads3
  * (separate_reads.cpp:374-433): sim = 3*A*At + R*Rt, diff = A*Rt + R*At with zero diagonals, as popcounts of
  * bit-planes. d_alt / d_ref: N rows of `words` uint64 (bit s of row r = read r carries second_base / ref_base
@@ -184,6 +199,7 @@ typedef struct hs_cv_result {
     double t_device_ms;        /* wall time of the device phase (uploads of selections, kernels, downloads) */
     double t_host_ms;          /* wall time of the host glue */
     float t_kernel_ms[4];      /* hipEvent time of k_pileup, k_column_stats, k_gather_columns, k_cigar_scan */
+    float t_kernel_k4_ms;      /* hipEvent time of k_column_partition_test */
 } hs_cv_result;
 
 int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out);

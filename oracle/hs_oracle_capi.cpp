@@ -46,6 +46,54 @@ int hso_pileup(const uint8_t* contig_seq, const int64_t* contig_off, int32_t n_c
     return 0;
 }
 
+// K4 oracle: loops C and D of keep_only_robust_variants (call_variants.cpp:721-764) on flat arrays, through
+// distance(Partition, Column) (:778-967) and computeChiSquare (:1135-1163). Same argument meaning as
+// hs_column_partition_test; n_reads_of_contig[c] = length of every state array of contig c. chi_out (optional) receives
+// the chi-square of each column against the first partition of its contig, tab_out (optional) its 2x2 table.
+int hso_column_partition_test(const int64_t* col_off, const int32_t* col_idx, const uint8_t* col_code, const int32_t* col_contig,
+                              const uint8_t* col_k0, const uint8_t* col_k1, const int32_t* col_c1, const uint8_t* col_is_cand,
+                              int32_t n_cols, const int32_t* part_off, const int64_t* part_state_off, const int8_t* part_state,
+                              const int32_t* n_reads_of_contig, int32_t n_contigs, uint8_t* keep, float* chi_out, int32_t* tab_out) {
+    std::vector<std::vector<hso::Partition>> parts((size_t)n_contigs);
+    for (int c = 0; c < n_contigs; ++c)
+        for (int f = part_off[c]; f < part_off[c + 1]; ++f) {
+            hso::Partition P;
+            for (int r = 0; r < n_reads_of_contig[c]; ++r) {
+                const int8_t st = part_state[part_state_off[f] + r];
+                if (st == 2) continue;
+                P.readIdx.push_back(r); P.mostFrequentBases.push_back(st); P.moreFrequence.push_back(0); P.lessFrequence.push_back(0);
+            }
+            parts[(size_t)c].push_back(P);
+        }
+    for (int i = 0; i < n_cols; ++i) {
+        hso::Column col;
+        for (int64_t k = col_off[i]; k < col_off[i + 1]; ++k) { col.readIdxs.push_back((unsigned)col_idx[k]); col.content.push_back(col_code[k]); }
+        col.ref_base = col_k0[i]; col.second_base = col_k1[i];
+        const std::vector<hso::Partition>& fin = parts[(size_t)col_contig[i]];
+        if (!fin.empty() && (chi_out || tab_out)) {
+            hso::DistRes d = hso::distance(fin[0], col, (char)col.ref_base);
+            if (chi_out) chi_out[i] = hso::computeChiSquare(d);
+            if (tab_out) { tab_out[4 * i] = d.n00; tab_out[4 * i + 1] = d.n01; tab_out[4 * i + 2] = d.n10; tab_out[4 * i + 3] = d.n11; }
+        }
+        bool kept = false;
+        if (col_is_cand[i])
+            for (const hso::Partition& P : fin) {
+                hso::DistRes d = hso::distance(P, col, (char)col.ref_base);
+                if (d.n00 + d.n01 + d.n10 + d.n11 > 0.5 * col.content.size() && hso::computeChiSquare(d) > 15) { kept = true; break; }
+            }
+        if (!kept && col_c1[i] >= 5) {
+            const int rb = col.ref_base, sb = col.second_base;
+            if (rb % 5 != sb % 5 && ((sb - '!') % 5 != 4 || (sb / 5 % 5 != rb % 5 && sb / 25 % 5 != rb % 5)))
+                for (const hso::Partition& P : fin) {
+                    hso::DistRes d = hso::distance(P, col, (char)col.ref_base);
+                    if (hso::computeChiSquare(d) > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) { kept = true; break; }
+                }
+        }
+        keep[i] = kept ? 1 : 0;
+    }
+    return 0;
+}
+
 // exact (reference tie order) top-3 of every position: call_variants.cpp:477-507 on a read-major pileup
 int hso_column_top3(const uint8_t* pile, const int64_t* pile_off, const int32_t* rec_pos, const int32_t* rec_qend,
                     int32_t r0, int32_t r1, int64_t L, uint8_t* k0, uint8_t* k1, int32_t* c0, int32_t* c1, int32_t* c2,

@@ -79,6 +79,7 @@ struct OracleCvOps : hs::CvDeviceOps {
     int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
                const int32_t** col_idx_out, const uint8_t** col_code_out, float* k_ms) override {
         *k_ms = 0;
+        last_sel_pos = sel_pos;
         col_idx.assign((size_t)col_off.back(), 0); col_code.assign((size_t)col_off.back(), 0);
         *col_idx_out = col_idx.data(); *col_code_out = col_code.data();
         for (size_t i = 0; i < sel_pos.size(); ++i) {
@@ -87,6 +88,58 @@ struct OracleCvOps : hs::CvDeviceOps {
         }
         return 0;
     }
+    // loops C and D of keep_only_robust_variants through the oracle's distance()/computeChiSquare()
+    int column_partition_test(const hs::CvPartitionTest& t, std::vector<uint8_t>& keep, float* k_ms) override {
+        *k_ms = 0;
+        const size_t n = t.col_contig.size();
+        keep.assign(n, 0);
+        std::vector<int64_t> off(n + 1, 0);
+        // CSR offsets of the last gather: columns were stored back to back
+        {
+            size_t i = 0; int64_t o = 0;
+            for (; i < n; ++i) { off[i] = o; o += (int64_t)cols[(size_t)t.col_contig[i]][(size_t)last_sel_pos[i]].content.size(); }
+            off[n] = o;
+        }
+        const int C = (int)t.part_off.size() - 1;
+        std::vector<std::vector<hso::Partition>> parts((size_t)C);
+        for (int c = 0; c < C; ++c) {
+            const int nreads = in.contig_rec_off[(size_t)c + 1] - in.contig_rec_off[(size_t)c];
+            for (int f = t.part_off[(size_t)c]; f < t.part_off[(size_t)c + 1]; ++f) {
+                hso::Partition P;
+                for (int r = 0; r < nreads; ++r) {
+                    const int8_t st = t.part_state[(size_t)t.part_state_off[(size_t)f] + (size_t)r];
+                    if (st == 2) continue;
+                    P.readIdx.push_back(r); P.mostFrequentBases.push_back(st); P.moreFrequence.push_back(0); P.lessFrequence.push_back(0);
+                }
+                parts[(size_t)c].push_back(P);
+            }
+        }
+        for (size_t i = 0; i < n; ++i) {
+            hso::Column col;
+            for (int64_t k = off[i]; k < off[i + 1]; ++k) { col.readIdxs.push_back((unsigned)col_idx[(size_t)k]); col.content.push_back(col_code[(size_t)k]); }
+            col.ref_base = t.col_k0[i]; col.second_base = t.col_k1[i];
+            const std::vector<hso::Partition>& fin = parts[(size_t)t.col_contig[i]];
+            bool kept = false;
+            if (t.col_is_cand[i]) {
+                for (const hso::Partition& P : fin) {
+                    hso::DistRes d = hso::distance(P, col, (char)col.ref_base);
+                    if (d.n00 + d.n01 + d.n10 + d.n11 > 0.5 * col.content.size() && hso::computeChiSquare(d) > 15) { kept = true; break; }
+                }
+            }
+            if (!kept && t.col_c1[i] >= 5) {
+                const int rb = col.ref_base, sb = col.second_base;
+                if (rb % 5 != sb % 5 && ((sb - '!') % 5 != 4 || (sb / 5 % 5 != rb % 5 && sb / 25 % 5 != rb % 5))) {
+                    for (const hso::Partition& P : fin) {
+                        hso::DistRes d = hso::distance(P, col, (char)col.ref_base);
+                        if (hso::computeChiSquare(d) > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) { kept = true; break; }
+                    }
+                }
+            }
+            keep[i] = kept ? 1 : 0;
+        }
+        return 0;
+    }
+    std::vector<int32_t> last_sel_pos;
 };
 
 struct OracleSrOps : hs::SrDeviceOps {

@@ -43,6 +43,22 @@ def column_top3(flat, pile, c):
     return k0, k1, c0, c1, c2, d
 
 
+def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1, col_c1, col_is_cand, part_off, part_state_off, part_state,
+                          n_reads_of_contig):
+    n = len(col_contig)
+    a = lambda x, dt: np.ascontiguousarray(x if len(x) else np.zeros(1), dt)
+    col_off = a(col_off, np.int64); col_idx = a(col_idx, np.int32); col_code = a(col_code, np.uint8); col_contig = a(col_contig, np.int32)
+    col_k0 = a(col_k0, np.uint8); col_k1 = a(col_k1, np.uint8); col_c1 = a(col_c1, np.int32); col_is_cand = a(col_is_cand, np.uint8)
+    part_off = a(part_off, np.int32); part_state_off = a(part_state_off, np.int64); part_state = a(part_state, np.int8)
+    nr = a(n_reads_of_contig, np.int32)
+    keep = np.zeros(max(n, 1), np.uint8); chi = np.zeros(max(n, 1), np.float32); tab = np.zeros((max(n, 1), 4), np.int32)
+    lib().hso_column_partition_test(_hp(col_off, C.c_int64), _hp(col_idx, C.c_int32), _hp(col_code, C.c_uint8), _hp(col_contig, C.c_int32),
+                                    _hp(col_k0, C.c_uint8), _hp(col_k1, C.c_uint8), _hp(col_c1, C.c_int32), _hp(col_is_cand, C.c_uint8),
+                                    C.c_int32(n), _hp(part_off, C.c_int32), _hp(part_state_off, C.c_int64), _hp(part_state, C.c_int8),
+                                    _hp(nr, C.c_int32), C.c_int32(len(n_reads_of_contig)), _hp(keep, C.c_uint8), _hp(chi, C.c_float), _hp(tab, C.c_int32))
+    return keep[:n], chi[:n], tab[:n]
+
+
 def simdiff(n_reads, snp_ref, snp_alt, col_off, col_idx, col_code):
     sim = np.zeros((n_reads, n_reads), np.int32); diff = np.zeros((n_reads, n_reads), np.int32)
     snp_ref = np.ascontiguousarray(snp_ref, np.uint8); snp_alt = np.ascontiguousarray(snp_alt, np.uint8)

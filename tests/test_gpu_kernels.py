@@ -123,6 +123,69 @@ def test_stage3_result_equals_oracle_pipeline(batch, built):
         assert np.all(np.diff(idx) > 0)
 
 
+def _partition_test_case(rng, n_contigs, cols_per_contig, mode):
+    """random columns x partitions; mode picks the regime: 'snp' = correlated two-allele columns, 'ties' = many codes with equal counts
+    (exercises the robin_hood order of the second allele), 'high' = codes >= 128 as most frequent (signed-char quirk)"""
+    col_off = [0]; col_idx = []; col_code = []; col_contig = []; k0s = []; k1s = []; c1s = []; cand = []
+    part_off = [0]; pso = []; states = []; nreads = []
+    tot_state = 0
+    for c in range(n_contigs):
+        N = int(rng.integers(6, 180))
+        nreads.append(N)
+        F = int(rng.integers(0, 4))
+        hap = rng.integers(0, 2, N)
+        for f in range(F):
+            st = np.where(hap == 1, 1, -1).astype(np.int8)
+            st[rng.random(N) < 0.1] = 0
+            st[rng.random(N) < rng.choice([0.0, 0.3, 0.8])] = 2
+            if rng.random() < 0.3:
+                st = rng.choice(np.array([1, -1, 0, 2], np.int8), N)
+            pso.append(tot_state); states.append(st); tot_state += N
+        part_off.append(len(pso))
+        for _ in range(cols_per_contig):
+            n = int(rng.integers(1, N + 1))
+            idx = np.sort(rng.choice(N, n, replace=False)).astype(np.int32)
+            if mode == "snp":
+                a, b = rng.choice(np.arange(33, 158), 2, replace=False)
+                code = np.where(hap[idx] == 1, a, b)
+                noise = rng.random(n) < 0.08
+                code = np.where(noise, rng.integers(33, 158, n), code)
+            elif mode == "ties":
+                pool = rng.choice(np.arange(33, 158), int(rng.integers(3, 7)), replace=False)
+                alt = pool[1 + np.arange(n) % (len(pool) - 1)]          # the non-ref reads split evenly over several codes
+                if rng.random() < 0.5:
+                    alt = np.where(rng.random(n) < 0.5, alt, pool[1 + (np.arange(n) + 1) % (len(pool) - 1)])   # different codes per haplotype side
+                code = np.where(hap[idx] == 1, pool[0], alt)
+            else:
+                a, b = rng.choice(np.arange(128, 158), 2, replace=False)
+                code = np.where(hap[idx] == 1, a, b)
+            code = code.astype(np.uint8)
+            vals, cnt = np.unique(code, return_counts=True)
+            order = np.argsort(-cnt, kind="stable")
+            k0 = int(vals[order[0]]) if rng.random() < 0.9 else int(rng.integers(33, 158))   # sometimes a ref the column does not hold
+            rest = [(int(cnt[o]), int(vals[o])) for o in order if int(vals[o]) != k0]
+            k1 = rest[0][1] if rest else 32
+            c1 = rest[0][0] if rest else 0
+            col_idx.append(idx); col_code.append(code); col_off.append(col_off[-1] + n); col_contig.append(c)
+            k0s.append(k0); k1s.append(k1); c1s.append(c1); cand.append(int(rng.random() < 0.6))
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+    return dict(col_off=np.array(col_off, np.int64), col_idx=cat(col_idx, np.int32), col_code=cat(col_code, np.uint8),
+                col_contig=np.array(col_contig, np.int32), col_k0=np.array(k0s, np.uint8), col_k1=np.array(k1s, np.uint8),
+                col_c1=np.array(c1s, np.int32), col_is_cand=np.array(cand, np.uint8), part_off=np.array(part_off, np.int32),
+                part_state_off=np.array(pso, np.int64), part_state=cat(states, np.int8)), nreads
+
+
+@pytest.mark.parametrize("mode", ["snp", "ties", "high"])
+def test_column_partition_test_matches_oracle(built, mode):
+    from hairsplitter_amd import api
+    rng = np.random.default_rng({"snp": 11, "ties": 12, "high": 13}[mode])
+    case, nreads = _partition_test_case(rng, 24, 60, mode)
+    want, _, _ = ol.column_partition_test(n_reads_of_contig=nreads, **case)
+    got = api.column_partition_test(**case)
+    assert np.array_equal(got, want)
+    assert 0 < int(want.sum()) < len(want)          # both verdicts occur
+
+
 def test_simdiff_matches_oracle(built):
     """K5 == list_similarities_and_differences_between_reads3 (separate_reads.cpp:374-433)."""
     from hairsplitter_amd import api
