@@ -169,14 +169,14 @@ def main():
     for k in py_ms:
         py_ms[k] = 0.0
     t0 = time.perf_counter()
-    k_cv = np.zeros(4); k_sr = np.zeros(4); t_dev = 0.0; t_host = 0.0; k4 = 0.0
+    k_cv = np.zeros(4); k_sr = np.zeros(4); t_dev = 0.0; t_host = 0.0; k4 = 0.0; k6 = 0.0
     last = None
     step_ms = []
     for _ in range(args.steps):
         ts = time.perf_counter()
         cv, sr, gathered = step()
         step_ms.append((time.perf_counter() - ts) * 1e3)
-        k_cv += np.asarray(cv["t_kernel_ms"]); k_sr += np.asarray(sr["t_kernel_ms"]); k4 += cv.get("t_kernel_k4_ms", 0.0)
+        k_cv += np.asarray(cv["t_kernel_ms"]); k_sr += np.asarray(sr["t_kernel_ms"]); k4 += cv.get("t_kernel_k4_ms", 0.0); k6 += sr.get("t_kernel_graph_ms", 0.0)
         t_dev += cv["t_device_ms"] + sr["t_device_ms"]; t_host += cv["t_host_ms"] + sr["t_host_ms"]
         last = (cv, sr)
     sync()
@@ -207,7 +207,7 @@ def main():
         K = args.steps
         cv, sr = last
         kernels = {"k_cigar_scan": k_cv[3] / K, "k_pileup": k_cv[0] / K, "k_column_stats": k_cv[1] / K, "k_gather_columns": k_cv[2] / K, "k_column_partition_test": k4 / K,
-                   "k_simdiff": k_sr[0] / K, "k_chinese_whispers": (k_sr[1] + k_sr[2] + k_sr[3]) / K}
+                   "k_simdiff": k_sr[0] / K, "k_read_graph_rows": k6 / K, "k_chinese_whispers": (k_sr[1] + k_sr[2] + k_sr[3]) / K}
         # algorithmic bytes per launch: pileup = read base in + code out = 2 B / aligned bp;
         # column_stats = 1 B / aligned bp in + 16 B / position out; chinese_whispers: see DESIGN.md
         alg_bytes = {"k_pileup": 2.0 * local_bp, "k_column_stats": 1.0 * local_bp + 16.0 * float(flat.contig_off[-1])}

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_ROOT, "lib", "libhairsplitter_hip.so")
 SYMBOLS = [
     "hs_version", "hs_last_error", "hs_device_count", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
-    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_column_partition_test", "hs_simdiff", "hs_chinese_whispers",
+    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_column_partition_test", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
     "hs_separate_reads_main",
@@ -49,7 +49,7 @@ class SrResult(C.Structure):
     _fields_ = [("n_contigs", C.c_int32), ("win_off", C.POINTER(C.c_int64)), ("win_start", C.POINTER(C.c_int32)),
                 ("win_end", C.POINTER(C.c_int32)), ("label_off", C.POINTER(C.c_int64)), ("labels", C.POINTER(C.c_int32)),
                 ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("n_cw_instances", C.c_int64),
-                ("t_kernel_ms", C.c_float * 4)]
+                ("t_kernel_ms", C.c_float * 4), ("t_kernel_graph_ms", C.c_float), ("n_graph_rows_host", C.c_int64)]
 
 
 _lib = None
@@ -81,6 +81,8 @@ def load() -> C.CDLL:
     lib.hs_cv_batch_destroy.restype = None
     lib.hs_cv_result_destroy.argtypes = [C.c_void_p]
     lib.hs_cv_result_destroy.restype = None
+    lib.hs_free_host.argtypes = [C.c_void_p]
+    lib.hs_free_host.restype = None
     lib.hs_sr_result_destroy.argtypes = [C.c_void_p]
     lib.hs_sr_result_destroy.restype = None
     lib.hs_cv_run.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.POINTER(C.POINTER(CvResult))]
@@ -273,7 +275,8 @@ def _sr_result_to_dict(res, Cn):
         "label_off": label_off,
         "labels": np.ctypeslib.as_array(r.labels, (max(NL, 1),))[:NL].copy(),
         "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "n_cw_instances": int(r.n_cw_instances),
-        "t_kernel_ms": [float(x) for x in r.t_kernel_ms],
+        "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_graph_ms": float(r.t_kernel_graph_ms),
+        "n_graph_rows_host": int(r.n_graph_rows_host),
     }
 
 
@@ -345,7 +348,8 @@ def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory:
         "label_off": label_off,
         "labels": np.ctypeslib.as_array(r.labels, (max(NL, 1),))[:NL].copy(),
         "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "n_cw_instances": int(r.n_cw_instances),
-        "t_kernel_ms": [float(x) for x in r.t_kernel_ms],
+        "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_graph_ms": float(r.t_kernel_graph_ms),
+        "n_graph_rows_host": int(r.n_graph_rows_host),
     }
     lib.hs_sr_result_destroy(res)
     return out
@@ -476,6 +480,35 @@ def simdiff(alt_planes: np.ndarray, ref_planes: np.ndarray):
     _check(load().hs_simdiff(_p(a), _p(r), _p(po), _p(n), _p(w), _p(oo), C.c_int32(1), _p(sim), _p(diff), C.c_void_p(0)))
     torch.cuda.synchronize()
     return sim.cpu().numpy(), diff.cpu().numpy()
+
+
+def read_graphs(sim_list, diff_list, windows, error_rate):
+    """K6: sim_list/diff_list = per-contig int32 [N, N] matrices (uploaded here); windows = [(contig, ascending masked read ids)].
+    Returns (per window: dict read id -> sorted neighbour list, rows resolved on the host)."""
+    import torch
+    require_gpu()
+    dev = "cuda:0"
+    n = np.array([m.shape[0] for m in sim_list], np.int32)
+    off = np.zeros(len(n), np.int64)
+    if len(n) > 1:
+        off[1:] = np.cumsum(n[:-1].astype(np.int64) ** 2)
+    d_sim = torch.from_numpy(np.concatenate([np.ascontiguousarray(m, np.int32).ravel() for m in sim_list])).to(dev)
+    d_diff = torch.from_numpy(np.concatenate([np.ascontiguousarray(m, np.int32).ravel() for m in diff_list])).to(dev)
+    wc = np.array([w[0] for w in windows], np.int32)
+    moff = np.zeros(len(windows) + 1, np.int64); moff[1:] = np.cumsum([len(w[1]) for w in windows])
+    ids = _np(np.concatenate([np.asarray(w[1], np.int32) for w in windows]) if moff[-1] else np.zeros(1, np.int32), np.int32)
+    p_off = C.POINTER(C.c_int64)(); p_nbr = C.POINTER(C.c_int32)(); n_host = C.c_int64(0)
+    _check(load().hs_read_graphs(_p(d_sim), _p(d_diff), off.ctypes.data_as(C.c_void_p), n.ctypes.data_as(C.c_void_p), C.c_int32(len(n)),
+                                 wc.ctypes.data_as(C.c_void_p), moff.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), C.c_int32(len(windows)),
+                                 C.c_float(error_rate), C.byref(p_off), C.byref(p_nbr), C.byref(n_host), C.c_void_p(0)))
+    rows = int(moff[-1])
+    noff = np.ctypeslib.as_array(p_off, shape=(rows + 1,)).copy()
+    nbr = np.ctypeslib.as_array(p_nbr, shape=(max(int(noff[-1]), 1),)).copy()
+    load().hs_free_host(p_off); load().hs_free_host(p_nbr)
+    out = []
+    for w in range(len(windows)):
+        out.append({int(ids[r]): nbr[noff[r]:noff[r + 1]].tolist() for r in range(int(moff[w]), int(moff[w + 1]))})
+    return out, int(n_host.value)
 
 
 def chinese_whispers(adj_lists: List[List[int]], perm: Sequence[int], mask: Sequence[int], inits: np.ndarray):

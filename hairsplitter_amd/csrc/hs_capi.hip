@@ -18,6 +18,7 @@
 #include "hs_host_sr.h"
 #include "hs_driver.h"
 #include "hs_kernels.hip"
+#include "hs_kernels_graph.hip"
 
 namespace hs {
 static thread_local std::string g_err;
@@ -600,16 +601,156 @@ struct HipCvOps : hs::CvDeviceOps {
 };
 
 // HIP implementation of the stage-4 device interface
+// K6 driver: rows on the device, the few std::sort-dependent rows on the host, CSR on the device (see hs_kernels_graph.hip)
+static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const std::vector<int64_t>& ctg_out_off, const std::vector<int32_t>& ctg_n,
+                           const hs::ReadGraphJob& job, hs::ReadGraphResult& res, hipStream_t stream, float* k_ms) {
+    const int W = (int)job.win_contig.size();
+    const int64_t rows64 = job.win_mask_off.empty() ? 0 : job.win_mask_off.back();
+    res.nbr_off.assign((size_t)rows64 + 1, 0); res.nbr.clear(); res.rows_resolved_on_host = 0;
+    if (rows64 == 0) return HS_OK;
+    if (rows64 > 0x7fffffff) { set_error("read_graphs: too many rows"); return HS_EINVAL; }
+    const int rows = (int)rows64;
+    std::vector<int32_t> row_win((size_t)rows);
+    std::vector<int64_t> win_bits_off((size_t)W + 1, 0);
+    int max_m = 1;
+    for (int w = 0; w < W; ++w) {
+        const int64_t m0 = job.win_mask_off[(size_t)w], m = job.win_mask_off[(size_t)w + 1] - m0;
+        for (int64_t r = 0; r < m; ++r) row_win[(size_t)(m0 + r)] = w;
+        win_bits_off[(size_t)w + 1] = win_bits_off[(size_t)w] + m * ((m + 63) >> 6);
+        max_m = std::max(max_m, (int)m);
+    }
+    DBuf d_oo, d_n, d_wc, d_mo, d_ids, d_rw, d_bo, d_bits, d_ac, d_ar, d_deg, d_no, d_nbr;
+    if (int rc = d_oo.upload(ctg_out_off)) return rc;
+    if (int rc = d_n.upload(ctg_n)) return rc;
+    if (int rc = d_wc.upload(job.win_contig)) return rc;
+    if (int rc = d_mo.upload(job.win_mask_off)) return rc;
+    if (int rc = d_ids.upload(job.mask_ids)) return rc;
+    if (int rc = d_rw.upload(row_win)) return rc;
+    if (int rc = d_bo.upload(win_bits_off)) return rc;
+    const size_t bits_bytes = (size_t)win_bits_off.back() * 8;
+    if (int rc = d_bits.alloc(bits_bytes)) return rc;
+    if (int rc = d_ac.alloc(4)) return rc;
+    if (int rc = d_ar.alloc((size_t)rows * 4)) return rc;
+    HS_HIP(hipMemsetAsync(d_bits.p, 0, bits_bytes ? bits_bytes : 8, stream));
+    HS_HIP(hipMemsetAsync(d_ac.p, 0, 4, stream));
+    // per-wave LDS: cap distances + cap totals. Four waves per workgroup while they fit, else one; windows wider than that
+    // (m > 7168 masked reads) send their rows to the host
+    int cap = ((max_m + 63) / 64) * 64, waves = 4;
+    if ((size_t)cap * 8 * 4 > 57344) waves = 1;
+    if ((size_t)cap * 8 > 57344) cap = 7168;
+    const float below = 1 - job.error_rate * 2;   // :778
+    EventPair ev; if (int rc = ev.init()) return rc;
+    HS_HIP(hipEventRecord(ev.a, stream));
+    hipLaunchKernelGGL(hsdev::k_read_graph_rows, dim3((rows + waves - 1) / waves), dim3(64 * waves), (size_t)cap * 8 * waves, stream, d_sim, d_diff,
+                       d_oo.as<int64_t>(), d_n.as<int32_t>(), d_wc.as<int32_t>(), d_mo.as<int64_t>(), d_ids.as<int32_t>(), d_rw.as<int32_t>(),
+                       d_bo.as<int64_t>(), rows, below, cap, d_bits.as<unsigned long long>(), d_ac.as<int32_t>(), d_ar.as<int32_t>(), rows);
+    HS_HIP(hipGetLastError());
+    HS_HIP(hipEventRecord(ev.b, stream));
+    int32_t n_amb = 0;
+    HS_HIP(hipMemcpyAsync(&n_amb, d_ac.p, 4, hipMemcpyDeviceToHost, stream));
+    HS_HIP(hipStreamSynchronize(stream));
+    if (n_amb > 0) {
+        // rows where std::sort's arrangement of equal distances decides: fetch their sim/diff rows, do exactly what the reference does
+        std::vector<int32_t> amb((size_t)n_amb);
+        HS_HIP(hipMemcpy(amb.data(), d_ar.p, (size_t)n_amb * 4, hipMemcpyDeviceToHost));
+        std::sort(amb.begin(), amb.end());
+        std::vector<int64_t> src((size_t)n_amb), dst((size_t)n_amb + 1, 0);
+        std::vector<int32_t> len((size_t)n_amb);
+        for (int k = 0; k < n_amb; ++k) {
+            const int w = row_win[(size_t)amb[(size_t)k]];
+            const int c = job.win_contig[(size_t)w];
+            const int N = ctg_n[(size_t)c];
+            const int r1 = job.mask_ids[(size_t)amb[(size_t)k]];
+            src[(size_t)k] = ctg_out_off[(size_t)c] + (int64_t)r1 * N; len[(size_t)k] = N; dst[(size_t)k + 1] = dst[(size_t)k] + N;
+        }
+        DBuf d_src, d_len, d_dst, d_os, d_od;
+        if (int rc = d_src.upload(src)) return rc;
+        if (int rc = d_len.upload(len)) return rc;
+        if (int rc = d_dst.upload(dst)) return rc;
+        if (int rc = d_os.alloc((size_t)dst.back() * 4)) return rc;
+        if (int rc = d_od.alloc((size_t)dst.back() * 4)) return rc;
+        hipLaunchKernelGGL(hsdev::k_read_graph_fetch_rows, dim3(n_amb), dim3(256), 0, stream, d_sim, d_diff, d_src.as<int64_t>(), d_len.as<int32_t>(),
+                           d_dst.as<int64_t>(), d_os.as<int32_t>(), d_od.as<int32_t>());
+        HS_HIP(hipGetLastError());
+        std::vector<int32_t> hs_((size_t)dst.back()), hd_((size_t)dst.back());
+        HS_HIP(hipMemcpyAsync(hs_.data(), d_os.p, hs_.size() * 4, hipMemcpyDeviceToHost, stream));
+        HS_HIP(hipMemcpyAsync(hd_.data(), d_od.p, hd_.size() * 4, hipMemcpyDeviceToHost, stream));
+        HS_HIP(hipStreamSynchronize(stream));
+        std::vector<int64_t> pbase; std::vector<int32_t> pmw, pi, pj;
+        std::vector<uint8_t> mask;
+        std::vector<int> picked;
+        for (int k = 0; k < n_amb; ++k) {
+            const int row = amb[(size_t)k];
+            const int w = row_win[(size_t)row];
+            const int64_t m0 = job.win_mask_off[(size_t)w];
+            const int m = (int)(job.win_mask_off[(size_t)w + 1] - m0);
+            const int32_t* ids = job.mask_ids.data() + m0;
+            const int N = len[(size_t)k];
+            mask.assign((size_t)N, 0);
+            for (int j = 0; j < m; ++j) mask[(size_t)ids[j]] = 1;
+            hs::sr_pick_row_sorted(hs_.data() + dst[(size_t)k], hd_.data() + dst[(size_t)k], N, ids[row - m0], mask.data(), job.error_rate, picked);
+            for (int nb : picked) {
+                const int j = (int)(std::lower_bound(ids, ids + m, nb) - ids);
+                pbase.push_back(win_bits_off[(size_t)w]); pmw.push_back((m + 63) >> 6); pi.push_back((int32_t)(row - m0)); pj.push_back(j);
+            }
+        }
+        if (!pi.empty()) {
+            DBuf d_pb, d_pm, d_pi, d_pj;
+            if (int rc = d_pb.upload(pbase)) return rc;
+            if (int rc = d_pm.upload(pmw)) return rc;
+            if (int rc = d_pi.upload(pi)) return rc;
+            if (int rc = d_pj.upload(pj)) return rc;
+            const int np = (int)pi.size();
+            hipLaunchKernelGGL(hsdev::k_read_graph_patch, dim3((np + 255) / 256), dim3(256), 0, stream, d_pb.as<int64_t>(), d_pm.as<int32_t>(), d_pi.as<int32_t>(),
+                               d_pj.as<int32_t>(), np, d_bits.as<unsigned long long>());
+            HS_HIP(hipGetLastError());
+            HS_HIP(hipStreamSynchronize(stream));   // the patch arrays die with this scope
+        }
+        res.rows_resolved_on_host = n_amb;
+    }
+    if (int rc = d_deg.alloc((size_t)rows * 4)) return rc;
+    if (int rc = d_no.alloc(((size_t)rows + 1) * 8)) return rc;
+    hipLaunchKernelGGL(hsdev::k_read_graph_degrees, dim3((rows + 255) / 256), dim3(256), 0, stream, d_bits.as<unsigned long long>(), d_rw.as<int32_t>(),
+                       d_mo.as<int64_t>(), d_bo.as<int64_t>(), rows, d_deg.as<int32_t>());
+    hipLaunchKernelGGL(hsdev::k_exclusive_scan_i32, dim3(1), dim3(1024), 0, stream, d_deg.as<int32_t>(), rows, d_no.as<int64_t>());
+    HS_HIP(hipGetLastError());
+    HS_HIP(hipMemcpyAsync(res.nbr_off.data(), d_no.p, ((size_t)rows + 1) * 8, hipMemcpyDeviceToHost, stream));
+    HS_HIP(hipStreamSynchronize(stream));
+    const int64_t total = res.nbr_off.back();
+    res.nbr.resize((size_t)total);
+    if (total > 0) {
+        if (int rc = d_nbr.alloc((size_t)total * 4)) return rc;
+        hipLaunchKernelGGL(hsdev::k_read_graph_fill, dim3((rows + 255) / 256), dim3(256), 0, stream, d_bits.as<unsigned long long>(), d_rw.as<int32_t>(),
+                           d_mo.as<int64_t>(), d_bo.as<int64_t>(), d_ids.as<int32_t>(), d_no.as<int64_t>(), rows, d_nbr.as<int32_t>());
+        HS_HIP(hipGetLastError());
+        HBuf hb; if (int rc = hb.alloc((size_t)total * 4)) return rc;
+        HS_HIP(hipMemcpyAsync(hb.p, d_nbr.p, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+        HS_HIP(hipStreamSynchronize(stream));
+        std::memcpy(res.nbr.data(), hb.p, (size_t)total * 4);
+    }
+    float m = 0; if (int rc = ev.ms(&m)) return rc;
+    if (k_ms) *k_ms += m;
+    return HS_OK;
+}
+
 struct HipSrOps : hs::SrDeviceOps {
     hipStream_t stream = nullptr;
     DBuf d_adj_off, d_adj, d_gob, d_gab, d_gn, d_perm, d_pb, d_mask;
-    HBuf h_sim, h_diff;
+    DBuf d_sim, d_diff;                       // K5 results stay in HBM for K6
+    std::vector<int64_t> sd_out_off;
+    std::vector<int32_t> sd_n;
     int max_n = 1;
+
+    int read_graphs(const hs::ReadGraphJob& job, hs::ReadGraphResult& res, float* k_ms) override {
+        if (!d_sim.p) { set_error("read_graphs before simdiff"); return HS_EINVAL; }
+        return read_graphs_run(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, job, res, stream, k_ms);
+    }
 
     int simdiff(const std::vector<uint64_t>& alt, const std::vector<uint64_t>& ref, const std::vector<int64_t>& plane_off,
                 const std::vector<int32_t>& n_reads, const std::vector<int32_t>& words, const std::vector<int64_t>& out_off,
                 int64_t out_total, const int32_t** sim, const int32_t** diff, float* k_ms) override {
-        DBuf d_alt, d_ref, d_po, d_n, d_w, d_oo, d_sim, d_diff, t_c, t_i, t_j;
+        DBuf d_alt, d_ref, d_po, d_n, d_w, d_oo, t_c, t_i, t_j;
+        sd_out_off = out_off; sd_n = n_reads;
         if (int rc = d_alt.upload(alt)) return rc;
         if (int rc = d_ref.upload(ref)) return rc;
         if (int rc = d_po.upload(plane_off)) return rc;
@@ -623,11 +764,7 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = simdiff_launch(d_alt.as<uint64_t>(), d_ref.as<uint64_t>(), d_po.as<int64_t>(), d_n.as<int32_t>(), d_w.as<int32_t>(),
                                     d_oo.as<int64_t>(), n_reads, d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, t_c, t_i, t_j)) return rc;
         HS_HIP(hipEventRecord(ev.b, stream));
-        if (int rc = h_sim.alloc((size_t)out_total * sizeof(int32_t))) return rc;
-        if (int rc = h_diff.alloc((size_t)out_total * sizeof(int32_t))) return rc;
-        HS_HIP(hipMemcpy(h_sim.p, d_sim.p, (size_t)out_total * sizeof(int32_t), hipMemcpyDeviceToHost));
-        HS_HIP(hipMemcpy(h_diff.p, d_diff.p, (size_t)out_total * sizeof(int32_t), hipMemcpyDeviceToHost));
-        *sim = (const int32_t*)h_sim.p; *diff = (const int32_t*)h_diff.p;
+        *sim = nullptr; *diff = nullptr;   // resident: consumed by read_graphs()
         float m = 0; if (int rc = ev.ms(&m)) return rc;
         if (k_ms) *k_ms += m;
         return HS_OK;
@@ -760,6 +897,30 @@ int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, 
     hs::CvMeta meta; fill_meta(b, meta);
     HipCvOps ops(b);
     return hs::cv_run(ops, meta, automatic_snp_threshold, n_threads, out);
+}
+
+int hs_read_graphs(const int32_t* d_sim, const int32_t* d_diff, const int64_t* ctg_out_off, const int32_t* ctg_n_reads,
+                   int32_t n_contigs, const int32_t* win_contig, const int64_t* win_mask_off, const int32_t* mask_ids,
+                   int32_t n_windows, float error_rate, int64_t** nbr_off, int32_t** nbr, int64_t* n_rows_host, void* stream) {
+    if (int rc = require_device()) return rc;
+    if (!nbr_off || !nbr || n_windows < 0 || n_contigs < 0) { set_error("hs_read_graphs: bad arguments"); return HS_EINVAL; }
+    hs::ReadGraphJob job;
+    job.error_rate = error_rate;
+    job.win_contig.assign(win_contig, win_contig + n_windows);
+    job.win_mask_off.assign(win_mask_off, win_mask_off + n_windows + 1);
+    job.mask_ids.assign(mask_ids, mask_ids + win_mask_off[n_windows]);
+    for (int w = 0; w < n_windows; ++w) if (win_contig[w] < 0 || win_contig[w] >= n_contigs) { set_error("hs_read_graphs: window contig out of range"); return HS_EINVAL; }
+    hs::ReadGraphResult res;
+    float ms = 0;
+    if (int rc = read_graphs_run(d_sim, d_diff, std::vector<int64_t>(ctg_out_off, ctg_out_off + n_contigs), std::vector<int32_t>(ctg_n_reads, ctg_n_reads + n_contigs),
+                                 job, res, (hipStream_t)stream, &ms)) return rc;
+    *nbr_off = (int64_t*)std::malloc(res.nbr_off.size() * sizeof(int64_t));
+    *nbr = (int32_t*)std::malloc((res.nbr.size() + 1) * sizeof(int32_t));
+    if (!*nbr_off || !*nbr) { set_error("hs_read_graphs: out of memory"); return HS_EINVAL; }
+    std::memcpy(*nbr_off, res.nbr_off.data(), res.nbr_off.size() * sizeof(int64_t));
+    if (!res.nbr.empty()) std::memcpy(*nbr, res.nbr.data(), res.nbr.size() * sizeof(int32_t));
+    if (n_rows_host) *n_rows_host = res.rows_resolved_on_host;
+    return HS_OK;
 }
 
 int hs_sr_run_cv(const hs_cv_batch* b, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance, int32_t low_memory,

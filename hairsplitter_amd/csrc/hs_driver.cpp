@@ -260,8 +260,24 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
 // ---------------------------------------------------------------------------------------------------
 // stage 4
 // ---------------------------------------------------------------------------------------------------
+namespace {
+struct Laps {   // HS_TIMING: fine-grained wall clock of the stage-4 driver
+    bool on = std::getenv("HS_TIMING") != nullptr;
+    double t = now_ms();
+    std::string line;
+    void lap(const char* what) {
+        if (!on) return;
+        const double n = now_ms();
+        char buf[96]; std::snprintf(buf, sizeof buf, " %s %.2f", what, n - t);
+        line += buf; t = n;
+    }
+    ~Laps() { if (on) std::fprintf(stderr, "[hs timing] sr laps (ms):%s\n", line.c_str()); }
+};
+}  // namespace
+
 int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
            int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out) {
+    Laps laps;
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
     const int C = n_contigs;
     const bool lowmem = low_memory != 0;
@@ -280,6 +296,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         s.perm = shuffled_order(s.N, seed);
     });
 
+    laps.lap("planes+perm");
     // ---- K5: sim / diff for every contig on the matrix path ----
     {
         const double t0 = now_ms();
@@ -300,32 +317,57 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
                 std::copy(st[(size_t)c].alt_planes.begin(), st[(size_t)c].alt_planes.end(), alt.begin() + plane_off[(size_t)c]);
                 std::copy(st[(size_t)c].ref_planes.begin(), st[(size_t)c].ref_planes.end(), ref.begin() + plane_off[(size_t)c]);
             }
-            const int32_t* sim = nullptr; const int32_t* diff = nullptr;
+            const int32_t* sim = nullptr; const int32_t* diff = nullptr;   // stay with the device interface
             if (int rc = dev.simdiff(alt, ref, plane_off, nreads, words, out_off, ow, &sim, &diff, &k_ms[0])) return rc;
-            for (int c = 0; c < C; ++c) {
-                if (!nreads[(size_t)c]) continue;
-                st[(size_t)c].sim = sim + out_off[(size_t)c];
-                st[(size_t)c].diff = diff + out_off[(size_t)c];
-            }
         }
         dev_ms += now_ms() - t0;
     }
 
     const double t_simdiff_done = now_ms();
+    laps.lap("simdiff");
     // ---- window plans + graphs (host) ----
     parallel_for(C, n_threads, [&](int c) {
         if (contigs[c].n_snps == 0) return;
         sr_plan_windows(st[(size_t)c], window_size, error_rate, lowmem);
     });
-    {   // one independent task per window: the per-row neighbour selection (std::sort tie order) is the costly part
-        std::vector<std::pair<int, int>> tasks;
+    laps.lap("plan_windows");
+    int64_t rows_on_host = 0;
+    float k6_ms = 0;
+    {   // K6: the graphs of all matrix-path windows in one device pass over the resident sim/diff matrices
+        ReadGraphJob job;
+        job.error_rate = error_rate;
+        job.win_mask_off.assign(1, 0);
+        std::vector<std::pair<int, int>> who, lowmem_tasks;
         for (int c = 0; c < C; ++c)
-            for (size_t w = 0; w < st[(size_t)c].windows.size(); ++w)
-                if (st[(size_t)c].windows[w].has_snps) tasks.push_back(std::make_pair(c, (int)w));
-        parallel_for((int)tasks.size(), n_threads, [&](int i) { sr_build_window_graph(st[(size_t)tasks[(size_t)i].first], tasks[(size_t)i].second, error_rate); });
+            for (size_t w = 0; w < st[(size_t)c].windows.size(); ++w) {
+                const SrWindowPlan& wp = st[(size_t)c].windows[w];
+                if (!wp.has_snps) continue;
+                if (st[(size_t)c].low_memory_now) { lowmem_tasks.push_back(std::make_pair(c, (int)w)); continue; }
+                who.push_back(std::make_pair(c, (int)w));
+                job.win_contig.push_back(c);
+                for (int r = 0; r < st[(size_t)c].N; ++r) if (wp.mask[(size_t)r]) job.mask_ids.push_back(r);
+                job.win_mask_off.push_back((int64_t)job.mask_ids.size());
+            }
+        laps.lap("graph_job");
+        if (!who.empty()) {
+            ReadGraphResult res;
+            const double t0 = now_ms();
+            if (int rc = dev.read_graphs(job, res, &k6_ms)) return rc;
+            dev_ms += now_ms() - t0;
+            rows_on_host = res.rows_resolved_on_host;
+            laps.lap("read_graphs");
+            parallel_for((int)who.size(), n_threads, [&](int i) {
+                const int64_t m0 = job.win_mask_off[(size_t)i], m1 = job.win_mask_off[(size_t)i + 1];
+                sr_set_window_graph(st[(size_t)who[(size_t)i].first], who[(size_t)i].second, job.mask_ids.data() + m0, (int)(m1 - m0),
+                                    res.nbr_off.data() + m0, res.nbr.data());
+            });
+        }
+        // create_read_graph_low_memory (-l, or coverage > 1000): O(N^2 S) per window on the host, one task per window
+        parallel_for((int)lowmem_tasks.size(), n_threads, [&](int i) { sr_build_window_graph(st[(size_t)lowmem_tasks[(size_t)i].first], lowmem_tasks[(size_t)i].second, error_rate); });
     }
 
     const double t_plan_done = now_ms();
+    laps.lap("set_window_graphs");
     // ---- all graphs of the batch, uploaded once; a graph belongs to exactly one window (its mask) ----
     CwGraphSet gs;
     std::vector<int64_t> perm_base_of_contig((size_t)C, 0);
@@ -356,11 +398,13 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
             }
         }
     }
+    laps.lap("graphset_build");
     {
         const double t0 = now_ms();
         if (int rc = dev.set_graphs(gs)) return rc;
         dev_ms += now_ms() - t0;
     }
+    laps.lap("set_graphs");
 
     int64_t n_cw = 0;
     auto run_wave = [&](CwWave& wv, float* ms) -> int {
@@ -409,6 +453,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
             n_cw += (int64_t)w.local_snps.size() + 2;
         }
     }
+    laps.lap("chain_build");
     std::vector<int32_t> chain_labels;
     {
         const double t0 = now_ms();
@@ -417,6 +462,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     }
 
     const double t_waves_done = now_ms();
+    laps.lap("cw_chain");
     // ---- tail of finalize_clustering on the host ----
     parallel_for((int)wrefs.size(), n_threads, [&](int i) {
         SrContigState& s = st[(size_t)wrefs[(size_t)i].c];
@@ -428,6 +474,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     });
 
     const double t_finish_done = now_ms();
+    laps.lap("finish");
     // ---- optional ploidy cap (separate_reads.cpp:1711-1715, :1341-1396) ----
     {
         CwWave w4;
@@ -465,10 +512,14 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     }
     R->win_off = dup_vec(win_off); R->win_start = dup_vec(ws); R->win_end = dup_vec(we); R->label_off = dup_vec(label_off);
     R->labels = dup_vec(labels);
+    laps.lap("result");
     R->n_cw_instances = n_cw;
+    R->t_kernel_graph_ms = k6_ms; R->n_graph_rows_host = rows_on_host;
     for (int k = 0; k < 4; ++k) R->t_kernel_ms[k] = k_ms[k];
     R->t_device_ms = dev_ms;
     R->t_host_ms = (now_ms() - t_start) - dev_ms;
+    if (std::getenv("HS_TIMING"))
+        std::fprintf(stderr, "[hs timing] sr: graph rows resolved by std::sort on the host: %ld, k_read_graph_rows %.3f ms\n", (long)rows_on_host, k6_ms);
     if (std::getenv("HS_TIMING"))
         std::fprintf(stderr, "[hs timing] sr: planes+simdiff %.2f ms, plan windows+graphs %.2f ms, graph upload + 3 CW waves (incl. label init) %.2f ms, finish %.2f ms, total %.2f ms (device %.2f)\n",
                      t_simdiff_done - t_start, t_plan_done - t_simdiff_done, t_waves_done - t_plan_done, t_finish_done - t_waves_done, now_ms() - t_start, dev_ms);

@@ -73,11 +73,26 @@ struct CwChain {
     std::vector<int64_t> win_label_base;   // [W+1] offset of the window's N output labels
 };
 
+// K6 input: the clustering windows whose graph comes from the sim/diff matrices of the last simdiff() call
+struct ReadGraphJob {
+    std::vector<int32_t> win_contig;     // contig index (as passed to simdiff) of every window
+    std::vector<int64_t> win_mask_off;   // [W+1] range of the window's masked reads in mask_ids
+    std::vector<int32_t> mask_ids;       // ascending read ids
+    float error_rate = 0;
+};
+struct ReadGraphResult {                 // neighbour lists (ascending read ids) of every masked read, window after window
+    std::vector<int64_t> nbr_off;        // [rows+1], row = position in mask_ids
+    std::vector<int32_t> nbr;
+    int64_t rows_resolved_on_host = 0;   // rows whose cut-off fell inside a run of equal distances (std::sort order decides)
+};
+
 struct SrDeviceOps {
     virtual ~SrDeviceOps() {}
+    // K6: create_read_graph_matrix for every window of the job
+    virtual int read_graphs(const ReadGraphJob& job, ReadGraphResult& res, float* k_ms) = 0;
     virtual int cw_chain(const CwChain& chain, std::vector<int32_t>& labels, float k_ms[3]) = 0;
-    // K5 for all contigs with n_reads[c] > 0; results at out_off[c] of host buffers owned by the implementation
-    // (valid until the next simdiff call or the destruction of the interface)
+    // K5 for all contigs with n_reads[c] > 0; the matrices (contig c at out_off[c]) stay with the implementation for
+    // read_graphs(); *sim / *diff may come back null (the HIP implementation keeps them in HBM)
     virtual int simdiff(const std::vector<uint64_t>& alt, const std::vector<uint64_t>& ref, const std::vector<int64_t>& plane_off,
                         const std::vector<int32_t>& n_reads, const std::vector<int32_t>& words, const std::vector<int64_t>& out_off,
                         int64_t out_total, const int32_t** sim, const int32_t** diff, float* k_ms) = 0;

@@ -67,87 +67,6 @@ static void pick_neighbors_sorted(std::vector<std::pair<int, float>>& smallest, 
     }
 }
 
-// The reference sorts all N distances of a row with std::sort and walks the result (:769-815). The set it picks only
-// depends on the ORDER among equal distances when fewer than five neighbours qualify by value and the run of equal
-// values at the cut-off is only partly taken. Everything else follows from order statistics (largest two values, the
-// number of exact 1s, the fifth-largest value below 1), so the sort is only performed for those ambiguous rows:
-// the picked set is identical either way (any std::sort output is a descending arrangement).
-// Requires distances in [0,1] without NaN and below >= 0 (non-masked reads have distance 0 and can then never pass).
-static bool g_force_sort = std::getenv("HS_FORCE_ROW_SORT") != nullptr;
-static std::atomic<long> g_rows_total{0}, g_rows_sorted{0};
-struct RowStatPrinter { ~RowStatPrinter() { if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] graph rows: %ld, resolved by std::sort: %ld\n", g_rows_total.load(), g_rows_sorted.load()); } };
-static RowStatPrinter g_row_stat_printer;
-static void pick_neighbors(std::vector<std::pair<int, float>>& smallest, const uint8_t* mask, float error_rate, std::vector<int>& picked) {
-    const int N = (int)smallest.size();
-    const float below = 1 - error_rate * 2;
-    g_rows_total++;
-    if (g_force_sort || N < 2 || !(below >= 0)) { pick_neighbors_sorted(smallest, mask, error_rate, picked); return; }
-    // largest two values (with multiplicity), number of exact ones, five largest values below one, minimum
-    float s0 = -1, s1 = -1, mn = 2;
-    int ones = 0;
-    float top[5] = {-1, -1, -1, -1, -1};   // descending, values != 1
-    int ntop = 0;
-    for (int i = 0; i < N; ++i) {
-        const float d = smallest[i].second;
-        if (d > s0) { s1 = s0; s0 = d; } else if (d > s1) s1 = d;
-        if (d < mn) mn = d;
-        if (d == 1) { ones++; continue; }
-        if (ntop < 5 || d > top[4]) {
-            int k = ntop < 5 ? ntop++ : 4;
-            while (k > 0 && top[k - 1] < d) { top[k] = top[k - 1]; --k; }
-            top[k] = d;
-        }
-    }
-    float above = s0 - (s0 - s1) * 3;
-    if (above == 1) {
-        if (ones < N) {
-            const int idx = std::min(ones + 4, N - 1);            // position in the descending arrangement
-            const int k = idx - ones;                             // k-th (0-based) largest among the values below one
-            above = k < ntop ? top[k] : mn;
-            if (idx == N - 1 && k >= ntop) above = mn;
-        }
-    }
-    picked.clear();
-    int nA = 0;
-    for (int i = 0; i < N; ++i) {
-        const float d = smallest[i].second;
-        if (d > below && (d == 1 || d >= above)) { picked.push_back(smallest[i].first); nA++; }
-    }
-    if (nA >= 5) return;
-    // the next (5 - nA) entries of the descending arrangement that exceed `below` (all of them are < above and != 1)
-    const int need = 5 - nA;
-    float cand[5]; int ncand = 0; int nB = 0;
-    for (int i = 0; i < N; ++i) {
-        const float d = smallest[i].second;
-        if (!(d > below) || d == 1 || d >= above) continue;
-        nB++;
-        if (ncand < need || d > cand[ncand - 1]) {
-            int k = ncand < need ? ncand++ : need - 1;
-            while (k > 0 && cand[k - 1] < d) { cand[k] = cand[k - 1]; --k; }
-            cand[k] = d;
-        }
-    }
-    if (nB == 0) return;
-    if (nB <= need) {
-        for (int i = 0; i < N; ++i) { const float d = smallest[i].second; if (d > below && d != 1 && d < above) picked.push_back(smallest[i].first); }
-        return;
-    }
-    const float cut = cand[need - 1];
-    int greater = 0, equal = 0;
-    for (int i = 0; i < N; ++i) {
-        const float d = smallest[i].second;
-        if (!(d > below) || d == 1 || d >= above) continue;
-        if (d > cut) greater++; else if (d == cut) equal++;
-    }
-    if (greater + equal == need) {
-        for (int i = 0; i < N; ++i) { const float d = smallest[i].second; if (d > below && d != 1 && d < above && d >= cut) picked.push_back(smallest[i].first); }
-        return;
-    }
-    // the run of equal distances at the cut-off is only partly taken: std::sort's arrangement decides
-    g_rows_sorted++;
-    pick_neighbors_sorted(smallest, mask, error_rate, picked);
-}
-
 static void to_csr(std::vector<std::vector<int>>& lists, SrGraph& g) {
     const int N = (int)lists.size();
     g.off.assign((size_t)N + 1, 0);
@@ -161,32 +80,37 @@ static void to_csr(std::vector<std::vector<int>>& lists, SrGraph& g) {
     }
 }
 
-// create_read_graph_matrix: separate_reads.cpp:706-828 (sim/diff are the dense device results)
-static void build_graph_matrix(const SrContigState& st, const uint8_t* mask, float error_rate, SrGraph& g) {
-    const int N = st.N;
-    std::vector<std::vector<int>> lists((size_t)N);
+// One row of create_read_graph_matrix (separate_reads.cpp:745-815) exactly as the reference does it. The device (K6) builds
+// the graphs; it hands back the rare rows where fewer than five neighbours qualify by value and the run of equal distances
+// at the cut-off is only partly taken, i.e. where std::sort's arrangement of equal keys decides.
+void sr_pick_row_sorted(const int32_t* srow, const int32_t* drow, int N, int r1, const uint8_t* mask, float error_rate, std::vector<int>& picked) {
     std::vector<std::pair<int, float>> smallest((size_t)N);
-    std::vector<int> picked;
-    for (int r1 = 0; r1 < N; ++r1) {
-        if (!mask[r1]) continue;
-        const int32_t* srow = st.sim + (size_t)r1 * N;    // symmetric: row r1 == column r1
-        const int32_t* drow = st.diff + (size_t)r1 * N;
-        int max_compat = 0;
-        for (int r = 0; r < N; ++r) {
-            float d = 0;
-            if (mask[r] && r != r1 && srow[r] > 0) {
-                const float df = (float)std::max(0, drow[r] - 1);
-                d = 1 - df / float(srow[r] + drow[r]);
-                if (srow[r] > max_compat) max_compat = srow[r];
-            }
-            smallest[r] = std::make_pair(r, d);
+    int max_compat = 0;
+    for (int r = 0; r < N; ++r) {
+        float d = 0;
+        if (mask[r] && r != r1 && srow[r] > 0) {
+            const float df = (float)std::max(0, drow[r] - 1);
+            d = 1 - df / float(srow[r] + drow[r]);
+            if (srow[r] > max_compat) max_compat = srow[r];
         }
-        for (int r = 0; r < N; ++r)
-            if (mask[r] && r != r1 && srow[r] + drow[r] < 0.7 * max_compat) smallest[r].second = 0;
-        pick_neighbors(smallest, mask, error_rate, picked);
-        for (int nb : picked) { lists[r1].push_back(nb); lists[nb].push_back(r1); }
+        smallest[r] = std::make_pair(r, d);
     }
-    to_csr(lists, g);
+    for (int r = 0; r < N; ++r)
+        if (mask[r] && r != r1 && srow[r] + drow[r] < 0.7 * max_compat) smallest[r].second = 0;
+    pick_neighbors_sorted(smallest, mask, error_rate, picked);
+}
+
+void sr_set_window_graph(SrContigState& st, int window, const int32_t* ids, int m, const int64_t* nbr_off, const int32_t* nbr) {
+    SrWindowPlan& w = st.windows[(size_t)window];
+    SrGraph& g = st.graphs[(size_t)w.graph_now];
+    g.off.assign((size_t)st.N + 1, 0);
+    g.adj.assign(nbr + nbr_off[0], nbr + nbr_off[m]);
+    int j = 0;
+    for (int r = 0; r < st.N; ++r) {
+        g.off[(size_t)r] = (int)(j < m ? nbr_off[j] - nbr_off[0] : nbr_off[m] - nbr_off[0]);
+        if (j < m && ids[j] == r) j++;
+    }
+    g.off[(size_t)st.N] = (int)(nbr_off[m] - nbr_off[0]);
 }
 
 // create_read_graph_low_memory: separate_reads.cpp:538-693
@@ -304,8 +228,7 @@ void sr_build_window_graph(SrContigState& st, int window, float error_rate) {
     SrWindowPlan& w = st.windows[(size_t)window];
     if (!w.has_snps) return;
     SrGraph& g = st.graphs[(size_t)w.graph_now];
-    if (!st.low_memory_now) build_graph_matrix(st, w.mask.data(), error_rate, g);
-    else build_graph_low_memory(st, w.mask.data(), error_rate, g);
+    if (st.low_memory_now) build_graph_low_memory(st, w.mask.data(), error_rate, g);   // the matrix path is K6 (device)
 }
 
 // merge_close_clusters: cluster_graph.cpp:402-501

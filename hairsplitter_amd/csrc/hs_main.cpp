@@ -1,6 +1,7 @@
 // hs_main.cpp -- main() of the two drop-in executables, exported through the C ABI so that a host in any
 // language can run a stage file-to-file. Same positional argv, same exit codes, same output formats as
 // call_variants.cpp:1215-1385 and separate_reads.cpp:1398-1790.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -29,6 +30,17 @@ int parse_int_arg(const char* a, int& out) {   // std::stoi semantics: garbage -
     return 0;
 }
 
+struct StageClock {   // HS_TIMING=1: wall clock of each phase of a stage executable, on stderr
+    bool on = std::getenv("HS_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[hs timing] main: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 }  // namespace
 
 extern "C" int hs_call_variants_main(int argc, char** argv) {
@@ -44,6 +56,7 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
     }
     const std::string error_rate_out = argv[6], file_out = argv[9], vcf_file = argv[10];
     const float automatic_snp_threshold = std::strtof(argv[11], nullptr);
+    StageClock clk;
     { std::ofstream o(file_out); }   // truncate (call_variants.cpp:1239-1240)
     if (has_suffix(sam_file, ".paf")) {
         std::cout << "ERROR: please provide a .sam file as input for the alignments of the reads on the contigs." << std::endl;
@@ -57,12 +70,14 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
         std::cout << "ERROR: no HIP device found; this build of HS_call_variants runs on MI355X only" << std::endl;
         return EXIT_FAILURE;
     }
+    clk.lap("device probe");
     std::cout << " - Loading reads, contigs and alignments\n";
     hs::CvFileInput in;
     if (int rc = hs::load_cv_inputs(gfafile, reads_file, sam_file, amplicon_i != 0, in)) {
         std::cout << "ERROR: " << hs_last_error() << std::endl;
         return rc == HS_EIO ? 1 : EXIT_FAILURE;
     }
+    clk.lap("load gfa + reads + sam");
     std::cout << " - Calling variants on each contig\n";
     hs_cv_batch* batch = nullptr;
     const int C = (int)in.contig_names.size();
@@ -72,13 +87,16 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
         std::cout << "ERROR: " << hs_last_error() << " (" << rc << ")" << std::endl;
         return EXIT_FAILURE;
     }
+    clk.lap("batch create (H2D)");
     hs_cv_result* res = nullptr;
     if (int rc = hs_cv_run(batch, automatic_snp_threshold, num_threads, &res)) {
         std::cout << "ERROR: " << hs_last_error() << " (" << rc << ")" << std::endl;
         hs_cv_batch_destroy(batch);
         return EXIT_FAILURE;
     }
+    clk.lap("hs_cv_run");
     hs::write_cv_outputs(in, res, error_rate_out, file_out, vcf_file);
+    clk.lap("write .col/.vcf");
     hs_cv_result_destroy(res);
     hs_cv_batch_destroy(batch);
     return 0;
@@ -97,13 +115,16 @@ extern "C" int hs_separate_reads_main(int argc, char** argv) {
     const bool amplicon = std::atoi(argv[7]) != 0;
     const bool low_memory = std::atoi(argv[5]) != 0;
     const float rsa = (float)std::atof(argv[6]);
+    StageClock clk;
     { std::ofstream o(outfile); }
     if (hs_device_count() <= 0) {
         std::cout << "ERROR: no HIP device found; this build of HS_separate_reads runs on MI355X only" << std::endl;
         return 1;
     }
     std::vector<hs::ColFileContig> cs;
+    clk.lap("device probe");
     if (int rc = hs::parse_col(columns_file, rsa, cs)) return rc;
+    clk.lap("parse .col");
     std::unordered_map<std::string, int> ploidy_of;
     bool have_ploidy = false;
     {
@@ -135,7 +156,9 @@ extern "C" int hs_separate_reads_main(int argc, char** argv) {
         std::cout << "ERROR: " << hs_last_error() << " (" << rc << ")" << std::endl;
         return 1;
     }
+    clk.lap("hs_sr_run");
     hs::write_gro(cs, res, outfile);
+    clk.lap("write .gro");
     hs_sr_result_destroy(res);
     return 0;
 }

@@ -142,6 +142,19 @@ int hs_simdiff(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_pl
                int32_t* d_sim, int32_t* d_diff, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K6 -- read graph of every clustering window. Replaces create_read_graph_matrix (separate_reads.cpp:706-828).
+ * d_sim / d_diff: the matrices of hs_simdiff, contig c at ctg_out_off[c] with ctg_n_reads[c] rows. A window is
+ * (contig, ascending list of its masked read ids); row = one masked read. Output (malloc'ed, release with
+ * hs_free_host): nbr_off[rows+1] and nbr = the reads linked to every masked read, ascending (the symmetric adjacency
+ * the reference stores in its Eigen matrix / neighbour lists). Rows whose result depends on how std::sort arranges
+ * equal distances are finished on the host with std::sort itself; *n_rows_host reports how many.
+ * All array arguments except d_sim / d_diff are host pointers.
+ * ---------------------------------------------------------------------------------------------- */
+int hs_read_graphs(const int32_t* d_sim, const int32_t* d_diff, const int64_t* ctg_out_off, const int32_t* ctg_n_reads,
+                   int32_t n_contigs, const int32_t* win_contig, const int64_t* win_mask_off, const int32_t* mask_ids,
+                   int32_t n_windows, float error_rate, int64_t** nbr_off, int32_t** nbr, int64_t* n_rows_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K7 -- Chinese Whispers, batched.  Replaces chinese_whispers / chinese_whispers_high_memory
  * (cluster_graph.cpp:152-310). One wavefront per instance; an instance is (graph g, initial labels, mask).
  * Graph g is a CSR over n_nodes[g] nodes (adj_off relative to graph_adj_base[g]); perm[g] is the node visiting
@@ -232,6 +245,8 @@ typedef struct hs_sr_result {
     double t_host_ms;
     int64_t n_cw_instances;
     float t_kernel_ms[4];      /* hipEvent time of k_simdiff and of the three k_chinese_whispers waves */
+    float t_kernel_graph_ms;   /* hipEvent time of k_read_graph_rows */
+    int64_t n_graph_rows_host; /* graph rows whose neighbour cut-off depended on std::sort's order of equal keys */
 } hs_sr_result;
 
 int hs_sr_run(const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,

@@ -121,6 +121,22 @@ int hso_simdiff(int32_t n_reads, int32_t n_snps, const uint8_t* snp_ref, const u
     return 0;
 }
 
+// K6 oracle: create_read_graph_matrix (separate_reads.cpp:706-828) for one window. adj_off[N+1], adj (capacity N*N) =
+// sorted neighbour lists of the symmetric graph.
+int hso_read_graph(int32_t n, const int32_t* sim, const int32_t* diff, const uint8_t* mask, float error_rate, int32_t* adj_off, int32_t* adj) {
+    std::vector<bool> m((size_t)n);
+    for (int i = 0; i < n; ++i) m[(size_t)i] = mask[i] != 0;
+    std::vector<int> S(sim, sim + (size_t)n * n), D(diff, diff + (size_t)n * n);
+    std::vector<std::vector<int>> a;
+    hso::create_read_graph_matrix(m, S, D, n, error_rate, a);
+    adj_off[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        for (size_t k = 0; k < a[(size_t)i].size(); ++k) adj[adj_off[i] + (int)k] = a[(size_t)i][k];
+        adj_off[i + 1] = adj_off[i] + (int)a[(size_t)i].size();
+    }
+    return 0;
+}
+
 // K7 oracle: cluster_graph.cpp:240-310
 int hso_chinese_whispers(int32_t n, const int32_t* adj_off, const int32_t* adj, const uint8_t* mask, const int32_t* init,
                          uint32_t seed, int32_t* out, int32_t* sweeps) {

@@ -151,6 +151,7 @@ struct OracleSrOps : hs::SrDeviceOps {
                 const std::vector<int32_t>& n_reads, const std::vector<int32_t>& words, const std::vector<int64_t>& out_off,
                 int64_t out_total, const int32_t** sim_out, const int32_t** diff_out, float* k_ms) override {
         (void)k_ms;
+        sd_off = out_off; sd_n = n_reads;
         sim.assign((size_t)out_total, 0); diff.assign((size_t)out_total, 0);
         *sim_out = sim.data(); *diff_out = diff.data();
         for (size_t c = 0; c < n_reads.size(); ++c) {
@@ -165,6 +166,28 @@ struct OracleSrOps : hs::SrDeviceOps {
                     d += __builtin_popcountll(ai & rj) + __builtin_popcountll(ri & aj);
                 }
                 sim[(size_t)out_off[c] + (size_t)i * N + j] = s; diff[(size_t)out_off[c] + (size_t)i * N + j] = d;
+            }
+        }
+        return 0;
+    }
+    std::vector<int64_t> sd_off; std::vector<int32_t> sd_n;
+    // K6 through the oracle's create_read_graph_matrix
+    int read_graphs(const hs::ReadGraphJob& job, hs::ReadGraphResult& res, float* k_ms) override {
+        (void)k_ms;
+        res.nbr_off.assign(1, 0); res.nbr.clear(); res.rows_resolved_on_host = 0;
+        for (size_t w = 0; w < job.win_contig.size(); ++w) {
+            const int c = job.win_contig[w];
+            const int N = sd_n[(size_t)c];
+            std::vector<bool> mask((size_t)N, false);
+            for (int64_t k = job.win_mask_off[w]; k < job.win_mask_off[w + 1]; ++k) mask[(size_t)job.mask_ids[(size_t)k]] = true;
+            std::vector<int> S(sim.begin() + sd_off[(size_t)c], sim.begin() + sd_off[(size_t)c] + (size_t)N * N);
+            std::vector<int> D(diff.begin() + sd_off[(size_t)c], diff.begin() + sd_off[(size_t)c] + (size_t)N * N);
+            std::vector<std::vector<int>> adj;
+            hso::create_read_graph_matrix(mask, S, D, N, job.error_rate, adj);
+            for (int64_t k = job.win_mask_off[w]; k < job.win_mask_off[w + 1]; ++k) {
+                const std::vector<int>& a = adj[(size_t)job.mask_ids[(size_t)k]];
+                res.nbr.insert(res.nbr.end(), a.begin(), a.end());
+                res.nbr_off.push_back((int64_t)res.nbr.size());
             }
         }
         return 0;

@@ -68,6 +68,15 @@ def simdiff(n_reads, snp_ref, snp_alt, col_off, col_idx, col_code):
     return sim, diff
 
 
+def read_graph(sim, diff, mask, error_rate):
+    """create_read_graph_matrix for one window -> list of sorted neighbour lists"""
+    n = sim.shape[0]
+    sim = np.ascontiguousarray(sim, np.int32); diff = np.ascontiguousarray(diff, np.int32); mask = np.ascontiguousarray(mask, np.uint8)
+    off = np.zeros(n + 1, np.int32); adj = np.zeros(max(n * n, 1), np.int32)
+    lib().hso_read_graph(C.c_int32(n), _hp(sim, C.c_int32), _hp(diff, C.c_int32), _hp(mask, C.c_uint8), C.c_float(error_rate), _hp(off, C.c_int32), _hp(adj, C.c_int32))
+    return [adj[off[i]:off[i + 1]].tolist() for i in range(n)]
+
+
 def chinese_whispers(adj_lists, mask, init, seed=12345):
     n = len(adj_lists)
     off = np.zeros(n + 1, np.int32); off[1:] = np.cumsum([len(a) for a in adj_lists])

@@ -213,6 +213,48 @@ def test_simdiff_matches_oracle(built):
         assert np.array_equal(sim, sim.T) and np.all(np.diag(sim) == 0)
 
 
+def _simdiff_np(alt, ref):
+    a = alt.astype(np.int32); r = ref.astype(np.int32)
+    sim = 3 * a @ a.T + r @ r.T
+    diff = a @ r.T + r @ a.T
+    np.fill_diagonal(sim, 0); np.fill_diagonal(diff, 0)
+    return sim.astype(np.int32), diff.astype(np.int32)
+
+
+@pytest.mark.parametrize("regime", ["haplotypes", "ties", "sparse"])
+def test_read_graphs_match_oracle(built, regime):
+    """K6 against create_read_graph_matrix, window by window; 'ties' has so few SNPs that many rows fall back to std::sort"""
+    from hairsplitter_amd import api
+    rng = np.random.default_rng({"haplotypes": 21, "ties": 22, "sparse": 23}[regime])
+    sims, diffs, windows = [], [], []
+    for c in range(6):
+        N = int(rng.integers(2, 260)) if c else 70
+        S = {"haplotypes": 120, "ties": 16, "sparse": 30}[regime]
+        hap = rng.integers(0, 3, N)
+        truth = rng.integers(0, 2, (3, S))
+        cover = rng.random((N, S)) < {"haplotypes": 0.6, "ties": 1.0, "sparse": 0.15}[regime]
+        allele = truth[hap] ^ (rng.random((N, S)) < (0.15 if regime == "ties" else 0.05))
+        alt = (cover & (allele == 1)); ref = (cover & (allele == 0))
+        sim, diff = _simdiff_np(alt, ref)
+        sims.append(sim); diffs.append(diff)
+        for _ in range(5):
+            frac = rng.choice([0.1, 0.5, 1.0])
+            ids = np.flatnonzero(rng.random(N) < frac).astype(np.int32)
+            windows.append((c, ids))
+    windows.append((0, np.zeros(0, np.int32)))          # a window without masked reads
+    for err in (0.05, 0.15):
+        got, n_host = api.read_graphs(sims, diffs, windows, err)
+        for (c, ids), g in zip(windows, got):
+            N = sims[c].shape[0]
+            mask = np.zeros(N, np.uint8); mask[ids] = 1
+            want = ol.read_graph(sims[c], diffs[c], mask, err)
+            assert sorted(g.keys()) == ids.tolist()
+            for r in range(N):
+                assert g.get(r, []) == want[r], (regime, err, c, r)
+        if regime == "ties":
+            assert n_host > 0
+
+
 def test_chinese_whispers_matches_oracle(built):
     """K7 == chinese_whispers_high_memory (cluster_graph.cpp:240-310): labels and number of sweeps."""
     from hairsplitter_amd import api

@@ -1,0 +1,56 @@
+"""File-to-file wall clock of the two drop-in executables next to the compiled reference (metric ii).
+Usage: python tools/file_to_file.py [--contigs 16] [--threads T]      (prints one JSON line)"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run_pair(cv, sr, f, td, tag, threads, py_error_rate):
+    col, vcf, err, gro = (os.path.join(td, f"{tag}.{x}") for x in ("col", "vcf", "err", "gro"))
+    t0 = time.perf_counter()
+    subprocess.run([cv, f["gfa"], f["reads"], f["sam"], str(threads), td, err, "0", "0", col, vcf, "0.33"], check=True, stdout=subprocess.DEVNULL)
+    t1 = time.perf_counter()
+    e = py_error_rate(float(open(err).read().strip()))
+    subprocess.run([sr, col, str(threads), str(e), os.path.join(td, "no_ploidy"), "0", "0.01", "0", gro, "0"], check=True, stdout=subprocess.DEVNULL)
+    t2 = time.perf_counter()
+    return {"call_variants_s": t1 - t0, "separate_reads_s": t2 - t1, "total_s": t2 - t0}, col, gro
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--contigs", type=int, default=16)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=2)
+    a = ap.parse_args()
+    from hairsplitter_amd import synth, canon
+    import bench
+    import __graft_entry__ as ge
+    p = ge.paths()
+    threads = a.threads or bench.effective_cores()
+    contigs = [synth.make_contig(a.seed, 10_000 + i, 100_000, 2, 0.01, 50, "ont") for i in range(a.contigs)]
+    bp = sum(c.aligned_bp for c in contigs)
+    out = {"contigs": a.contigs, "aligned_bp": bp, "threads": threads}
+    with tempfile.TemporaryDirectory() as td:
+        f = synth.write_files(contigs, td)
+        out["input_bytes"] = {k: os.path.getsize(v) for k, v in f.items() if isinstance(v, str) and os.path.exists(v)}
+        for rep in range(2):   # second repetition = warm page cache / warm GPU runtime
+            ours, col_a, gro_a = run_pair(os.path.join(ROOT, "hairsplitter_amd", "bin", "HS_call_variants"),
+                                          os.path.join(ROOT, "hairsplitter_amd", "bin", "HS_separate_reads"), f, td, "hip", threads, bench.py_error_rate)
+        out["hip"] = ours; out["hip"]["bp_per_s"] = bp / ours["total_s"]
+        if os.path.exists(p["ref_cv"]) and os.path.exists(p["ref_sr"]):
+            ref, col_b, gro_b = run_pair(p["ref_cv"], p["ref_sr"], f, td, "ref", threads, bench.py_error_rate)
+            out["reference"] = ref; out["reference"]["bp_per_s"] = bp / ref["total_s"]
+            out["speedup"] = ref["total_s"] / ours["total_s"]
+            out["col_identical"] = canon.digest(canon.split_blocks(col_a)) == canon.digest(canon.split_blocks(col_b))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
