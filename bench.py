@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--contigs", type=int, default=16, help="C2-shaped contigs per GPU in one batch")
+    ap.add_argument("--groups", type=int, default=4, help="concurrent sub-batches (host thread + HIP stream each) per GPU")
     ap.add_argument("--threads", type=int, default=0, help="host threads for the sequential glue (0 = all cores / ranks)")
     ap.add_argument("--cpu-contigs", type=int, default=8, help="size of the CPU-baseline sample (0 disables)")
     ap.add_argument("--seed", type=int, default=2)
@@ -131,9 +132,9 @@ def main():
     B = args.contigs
     my_ids = list(range(rank * B, (rank + 1) * B))
     contigs = [synth.make_contig(args.seed, i, 100_000, 2, 0.01, 50, "ont") for i in my_ids]
-    flat = api.FlatBatch(contigs)
-    batch = api.CvBatch(flat)          # inputs now resident in HBM
-    local_bp = flat.aligned_bp
+    G = max(1, min(args.groups, B))
+    batch = api.PipelineGroups(contigs, G)   # inputs now resident in HBM; the streaming kernels run once per step over all of them
+    local_bp = batch.aligned_bp
 
     py_ms = {"pipeline_call": 0.0, "error_rate": 0.0, "gather": 0.0}
     no_coll = bool(os.environ.get("HS_BENCH_NO_COLLECTIVES"))   # diagnostic only
@@ -150,7 +151,7 @@ def main():
         t = time.perf_counter()
         # window size 2000 for every rank when sharded: it depends on the read lengths of the whole job
         # (separate_reads.cpp:1466-1498) and all shards of this workload have the same read-length distribution
-        cv, sr = batch.run_pipeline(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=2000 if world > 1 else 0)
+        cv, sr = batch.run(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=2000 if world > 1 else 0)
         t3 = time.perf_counter(); py_ms["pipeline_call"] += (t3 - t) * 1e3
         if cap[0] is None:
             cap[0] = hdist.gather_capacity(int(sr["labels"].size))   # first (warm-up) step only
@@ -210,7 +211,7 @@ def main():
                    "k_simdiff": k_sr[0] / K, "k_read_graph_rows": k6 / K, "k_chinese_whispers": (k_sr[1] + k_sr[2] + k_sr[3]) / K}
         # algorithmic bytes per launch: pileup = read base in + code out = 2 B / aligned bp;
         # column_stats = 1 B / aligned bp in + 16 B / position out; chinese_whispers: see DESIGN.md
-        alg_bytes = {"k_pileup": 2.0 * local_bp, "k_column_stats": 1.0 * local_bp + 16.0 * float(flat.contig_off[-1])}
+        alg_bytes = {"k_pileup": 2.0 * local_bp, "k_column_stats": 1.0 * local_bp + 16.0 * float(batch.total_len)}
         dom = max(("k_pileup", "k_column_stats"), key=lambda k: kernels[k])
         achieved = alg_bytes[dom] / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
         traffic = None
@@ -228,7 +229,7 @@ def main():
             "host": {"cpus_online": os.cpu_count(), "cpus_effective": effective_cores()},
             "config": {"workload": f"C2 (BASELINE.json configs[1]): 100 kb contig, 2 haplotypes @1% divergence, 50x ONT-error reads; "
                                    f"{B} such contigs per GPU per step, inputs resident in HBM",
-                       "contigs_per_gpu": B, "aligned_bp_per_gpu": local_bp, "parallelism": f"contig-sharded x{world}",
+                       "contigs_per_gpu": B, "aligned_bp_per_gpu": local_bp, "parallelism": f"contig-sharded x{world}", "groups_per_gpu": G,
                        "host_threads_per_rank": n_threads, "snps_rank0": int(cv["n_snps"]), "cw_instances_rank0": sr["n_cw_instances"]},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kernels[dom],

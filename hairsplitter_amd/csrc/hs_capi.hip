@@ -923,13 +923,47 @@ int hs_read_graphs(const int32_t* d_sim, const int32_t* d_diff, const int64_t* c
     return HS_OK;
 }
 
-int hs_sr_run_cv(const hs_cv_batch* b, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance, int32_t low_memory,
-                 int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out) {
+int hs_cv_select(hs_cv_batch* b, hs_cv_selection** out) {
     if (int rc = require_device()) return rc;
-    if (!b || !cv || !out) { set_error("hs_sr_run_cv: null argument"); return HS_EINVAL; }
+    if (!b || !out) { set_error("hs_cv_select: null argument"); return HS_EINVAL; }
+    hs::CvMeta meta; fill_meta(b, meta);
+    HipCvOps ops(b);
+    hs::CvSelection* sel = new hs::CvSelection();
+    if (int rc = hs::cv_select(ops, meta, *sel)) { delete sel; return rc; }
+    hs_cv_selection* o = (hs_cv_selection*)std::calloc(1, sizeof(hs_cv_selection));
+    o->n_selected = (int64_t)sel->sel_pos.size();
+    for (int k = 0; k < 4; ++k) o->t_kernel_ms[k] = sel->k_ms[k];
+    o->t_device_ms = sel->t_device_ms; o->t_host_ms = sel->t_host_ms;
+    o->impl = sel;
+    *out = o;
+    return HS_OK;
+}
+void hs_cv_selection_destroy(hs_cv_selection* s) {
+    if (!s) return;
+    delete (hs::CvSelection*)s->impl;
+    std::free(s);
+}
+int hs_cv_run_range(hs_cv_batch* b, const hs_cv_selection* sel, int32_t c0, int32_t c1, float automatic_snp_threshold, int32_t n_threads,
+                    hs_cv_result** out) {
+    if (int rc = require_device()) return rc;
+    if (!b || !sel || !sel->impl || !out) { set_error("hs_cv_run_range: null argument"); return HS_EINVAL; }
+    hs::CvMeta meta; fill_meta(b, meta);
+    HipCvOps ops(b);
+    return hs::cv_run_range(ops, meta, *(const hs::CvSelection*)sel->impl, c0, c1, automatic_snp_threshold, n_threads, out);
+}
+
+int hs_sr_run_cv_range(const hs_cv_batch* b, int32_t c0, int32_t c1, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance,
+                       int32_t low_memory, int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out) {
+    if (int rc = require_device()) return rc;
+    if (!b || !cv || !out) { set_error("hs_sr_run_cv_range: null argument"); return HS_EINVAL; }
     hs::CvMeta meta; fill_meta(b, meta);
     HipSrOps ops;
-    return hs::sr_run_from_cv(ops, meta, cv, error_rate, rarest_strain_abundance, low_memory, amplicon, seed, n_threads, window_size, out);
+    return hs::sr_run_from_cv(ops, meta, c0, c1, cv, error_rate, rarest_strain_abundance, low_memory, amplicon, seed, n_threads, window_size, out);
+}
+int hs_sr_run_cv(const hs_cv_batch* b, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance, int32_t low_memory,
+                 int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out) {
+    if (!b) { set_error("hs_sr_run_cv: null argument"); return HS_EINVAL; }
+    return hs_sr_run_cv_range(b, 0, b->n_contigs, cv, error_rate, rarest_strain_abundance, low_memory, amplicon, seed, n_threads, window_size, out);
 }
 
 int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_t amplicon) {

@@ -25,10 +25,11 @@ double now_ms() {
 }
 
 // Persistent worker pool: the drivers issue a dozen short parallel sections per call and spawning 200+ std::threads
-// for each of them costs more than the sections themselves.
+// for each of them costs more than the sections themselves. One pool per calling thread: independent batches driven from
+// different host threads (each on its own HIP stream) overlap their serial sections and device waits.
 class WorkerPool {
 public:
-    static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }
+    static WorkerPool& get() { static thread_local WorkerPool* p = new WorkerPool(); return *p; }
     void run(int n, int n_threads, const std::function<void(int)>& f) {
         if (n <= 0) return;
         if (n_threads <= 1 || n == 1) { for (int i = 0; i < n; ++i) f(i); return; }
@@ -104,22 +105,38 @@ void free_sr_result(hs_sr_result* r) {
     std::free(r);
 }
 
+namespace {
+struct Laps {   // HS_TIMING: fine-grained wall clock of a stage driver
+    bool on = std::getenv("HS_TIMING") != nullptr;
+    double t = now_ms();
+    std::string line;
+    const char* tag;
+    explicit Laps(const char* t_) : tag(t_) {}
+    void lap(const char* what) {
+        if (!on) return;
+        const double n = now_ms();
+        char buf[96]; std::snprintf(buf, sizeof buf, " %s %.2f", what, n - t);
+        line += buf; t = n;
+    }
+    ~Laps() { if (on) std::fprintf(stderr, "[hs timing] %s laps (ms):%s\n", tag, line.c_str()); }
+};
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------------
 // stage 3
 // ---------------------------------------------------------------------------------------------------
-int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int n_threads, hs_cv_result** out) {
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+// The whole-batch streaming pass (K0 CIGAR scan, K1 pileup, K2 column statistics + selection): one launch each over every
+// contig of the batch, then the (small) list of interesting positions ordered by (contig, position).
+int cv_select(CvDeviceOps& dev, const CvMeta& b, CvSelection& sel) {
     const int C = b.n_contigs, NR = b.n_rec;
     const double t_start = now_ms();
-    float k_ms[4] = {0, 0, 0, 0};   // pileup, column_stats, gather_columns, cigar_scan
-    float k_ms_k4 = 0;              // column x partition test
-
-    std::vector<int32_t> rec_stats((size_t)NR * 4);
+    for (int k = 0; k < 4; ++k) sel.k_ms[k] = 0;   // pileup, column_stats, (gather_columns), cigar_scan
+    sel.rec_stats.assign((size_t)NR * 4, 0);
     std::vector<int64_t> sel_gpos;
     std::vector<int32_t> sel_depth;
     // interesting positions: second count >= 4 (everything that can become a SNP, see hs_host_cv.cpp); the device
     // appends them unordered, the (small) list is ordered here
-    if (int rc = dev.pileup_and_select(rec_stats, 4, sel_gpos, sel_depth, k_ms)) return rc;
+    if (int rc = dev.pileup_and_select(sel.rec_stats, 4, sel_gpos, sel_depth, sel.k_ms)) return rc;
     const double t_k12_done = now_ms();
     std::vector<size_t> order(sel_gpos.size());
     {   // bucket by 256-position tile (the unit the device appends in), then order the few entries of each tile
@@ -133,24 +150,48 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
             if (start[t + 1] - start[t] > 1)
                 std::sort(order.begin() + start[t], order.begin() + start[t + 1], [&](size_t x, size_t y) { return sel_gpos[x] < sel_gpos[y]; });
     }
-    std::vector<int32_t> sel_contig(order.size()), sel_pos(order.size());
-    std::vector<int64_t> col_off(order.size() + 1, 0);
-    std::vector<int64_t> contig_sel_off((size_t)C + 1, 0);
+    sel.sel_contig.resize(order.size()); sel.sel_pos.resize(order.size()); sel.sel_depth.resize(order.size());
+    sel.contig_sel_off.assign((size_t)C + 1, 0);
     {
         int c = 0;
         for (size_t i = 0; i < order.size(); ++i) {
             const int64_t g = sel_gpos[order[i]];
-            while (g >= b.contig_off[(size_t)c + 1]) { c++; contig_sel_off[(size_t)c] = (int64_t)i; }
-            sel_contig[i] = c; sel_pos[i] = (int32_t)(g - b.contig_off[(size_t)c]);
-            col_off[i + 1] = col_off[i] + sel_depth[order[i]];
+            while (g >= b.contig_off[(size_t)c + 1]) { c++; sel.contig_sel_off[(size_t)c] = (int64_t)i; }
+            sel.sel_contig[i] = c; sel.sel_pos[i] = (int32_t)(g - b.contig_off[(size_t)c]);
+            sel.sel_depth[i] = sel_depth[order[i]];
         }
-        for (int k = c + 1; k <= C; ++k) contig_sel_off[(size_t)k] = (int64_t)order.size();
+        for (int k = c + 1; k <= C; ++k) sel.contig_sel_off[(size_t)k] = (int64_t)order.size();
     }
+    sel.t_device_ms = t_k12_done - t_start;
+    sel.t_host_ms = now_ms() - t_k12_done;
+    if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] cv select: k0+k1+k2+d2h %.2f ms, ordering %.2f ms\n", sel.t_device_ms, sel.t_host_ms);
+    return HS_OK;
+}
+
+// Stage 3 for the contigs [c0, c1) of the batch on top of a selection: column extraction (K3), the host partition logic,
+// the column x partition test (K4) and the merge. Ranges are independent: several may run concurrently from different host
+// threads, each with its own device interface (stream).
+int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int c0, int c1, float automatic_snp_threshold, int n_threads,
+                 hs_cv_result** out) {
+    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (c0 < 0 || c1 > b.n_contigs || c0 > c1) { set_error("cv_run_range: bad contig range"); return HS_EINVAL; }
+    const int C = c1 - c0;
+    const double t_start = now_ms();
+    float k_ms[4] = {0, 0, 0, 0};
+    float k_ms_k4 = 0;              // column x partition test
+    const std::vector<int32_t>& rec_stats = sel.rec_stats;
+    const int64_t g0 = sel.contig_sel_off[(size_t)c0], g1 = sel.contig_sel_off[(size_t)c1];
+    std::vector<int32_t> sel_contig(sel.sel_contig.begin() + g0, sel.sel_contig.begin() + g1);   // batch-global contig ids (K3 wants those)
+    std::vector<int32_t> sel_pos(sel.sel_pos.begin() + g0, sel.sel_pos.begin() + g1);
+    std::vector<int64_t> col_off((size_t)(g1 - g0) + 1, 0);
+    for (int64_t i = g0; i < g1; ++i) col_off[(size_t)(i - g0) + 1] = col_off[(size_t)(i - g0)] + sel.sel_depth[(size_t)i];
+    std::vector<int64_t> contig_sel_off((size_t)C + 1, 0);
+    for (int c = 0; c <= C; ++c) contig_sel_off[(size_t)c] = sel.contig_sel_off[(size_t)(c0 + c)] - g0;
     const int32_t* col_idx = nullptr;
     const uint8_t* col_code = nullptr;
-    const double t_sel_done = now_ms();
     if (int rc = dev.gather(sel_contig, sel_pos, col_off, &col_idx, &col_code, &k_ms[2])) return rc;
     const double t_dev_done = now_ms();
+    Laps laps("cv glue");
 
     // host glue: exact tie order of the extracted columns (independent per column: chunked over all threads) ...
     std::vector<ColumnSet> sets((size_t)C);
@@ -168,31 +209,36 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
         cs.k0.resize(n); cs.k1.resize(n); cs.c0.resize(n); cs.c1.resize(n); cs.c2.resize(n);
         for (int64_t f = 0; f < s1 - s0; f += 256) chunks.push_back(std::make_pair(c, (int)f));
     }
+    laps.lap("sets");
     parallel_for((int)chunks.size(), n_threads, [&](int i) {
         ColumnSet& cs = sets[(size_t)chunks[(size_t)i].first];
         const int f = chunks[(size_t)i].second;
         resolve_columns(cs, f, std::min<int>(f + 256, (int)cs.pos.size()));
     });
+    laps.lap("resolve_columns");
     // ... then the sequential partition logic (V1 scan, loops A and B), one contig per thread ...
     std::vector<CvContigState*> cst((size_t)C, nullptr);
     for (int c = 0; c < C; ++c) cst[(size_t)c] = cv_state_new();
     parallel_for(C, n_threads, [&](int c) {
         ColumnSet& cs = sets[(size_t)c];
         int64_t nerr = 0, nlen = 0;
-        for (int r = b.contig_rec_off[(size_t)c]; r < b.contig_rec_off[(size_t)c + 1]; ++r) { nerr += rec_stats[(size_t)r * 4 + 1]; nlen += rec_stats[(size_t)r * 4 + 2]; }
+        const int gc = c0 + c;   // index in the batch
+        for (int r = b.contig_rec_off[(size_t)gc]; r < b.contig_rec_off[(size_t)gc + 1]; ++r) { nerr += rec_stats[(size_t)r * 4 + 1]; nlen += rec_stats[(size_t)r * 4 + 2]; }
         ContigCvResult& o = res[(size_t)c];
         o.mean_distance = mean_distance_from_counts(nerr, nlen);
-        const int64_t L = b.contig_off[(size_t)c + 1] - b.contig_off[(size_t)c];
-        const int64_t entries = b.pile_off[(size_t)b.contig_rec_off[(size_t)c + 1]] - b.pile_off[(size_t)b.contig_rec_off[(size_t)c]];
+        const int64_t L = b.contig_off[(size_t)gc + 1] - b.contig_off[(size_t)gc];
+        const int64_t entries = b.pile_off[(size_t)b.contig_rec_off[(size_t)gc + 1]] - b.pile_off[(size_t)b.contig_rec_off[(size_t)gc]];
         o.depth = (float)((double)entries / (double)L);   // call_variants.cpp:565
-        const int n_reads_c = b.contig_rec_off[(size_t)c + 1] - b.contig_rec_off[(size_t)c];
+        const int n_reads_c = b.contig_rec_off[(size_t)gc + 1] - b.contig_rec_off[(size_t)gc];
         cv_phase_ab(*cst[(size_t)c], n_reads_c, cs, o.mean_distance, automatic_snp_threshold, o);
     });
+    laps.lap("phase_ab");
     // ... loops C and D on the device: one wavefront per extracted column against the contig's final partitions ...
     {
         CvPartitionTest t;
         const size_t n_sel = sel_pos.size();
-        t.col_contig = sel_contig;
+        t.col_contig.resize(n_sel);
+        for (size_t i = 0; i < n_sel; ++i) t.col_contig[i] = sel_contig[i] - c0;   // index into part_off
         t.col_c1.resize(n_sel); t.col_k0.resize(n_sel); t.col_k1.resize(n_sel); t.col_is_cand.resize(n_sel);
         t.part_off.assign((size_t)C + 1, 0);
         for (int c = 0; c < C; ++c) {
@@ -204,12 +250,15 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
             t.part_off[(size_t)c + 1] = (int32_t)t.part_state_off.size();
         }
         std::vector<uint8_t> keep(n_sel, 0);
+        laps.lap("k4_prep");
         if (n_sel) { if (int rc = dev.column_partition_test(t, keep, &k_ms_k4)) return rc; }
+        laps.lap("k4");
         for (int c = 0; c < C; ++c) cv_import_keep(*cst[(size_t)c], keep.data() + contig_sel_off[(size_t)c]);
     }
     // ... and the final merge
     for (int c = 0; c < C; ++c) { cv_phase_merge(*cst[(size_t)c], sets[(size_t)c], res[(size_t)c]); cv_state_free(cst[(size_t)c]); }
     const double t_glue_done = now_ms();
+    laps.lap("merge");
 
     hs_cv_result* R = (hs_cv_result*)std::calloc(1, sizeof(hs_cv_result));
     R->n_contigs = C;
@@ -244,6 +293,7 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
             R->col_off[s] = e;
         }
     });
+    laps.lap("result");
     R->mean_distance = dup_vec(md); R->depth = dup_vec(dp); R->snp_off = dup_vec(snp_off);
     R->error_rate = total_error / n_err_contigs;      // call_variants.cpp:1377 (float / int)
     R->n_contigs_with_error_rate = n_err_contigs;
@@ -251,33 +301,29 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
     R->t_device_ms = t_dev_done - t_start;
     R->t_host_ms = now_ms() - t_dev_done;
     if (std::getenv("HS_TIMING"))
-        std::fprintf(stderr, "[hs timing] cv: k1+k2+d2h %.2f ms, select %.2f ms, gather %.2f ms, host glue %.2f ms (parallel part %.2f)\n",
-                     t_k12_done - t_start, t_sel_done - t_k12_done, t_dev_done - t_sel_done, R->t_host_ms, t_glue_done - t_dev_done);
+        std::fprintf(stderr, "[hs timing] cv range [%d,%d): gather %.2f ms, host glue %.2f ms (parallel part %.2f)\n",
+                     c0, c1, t_dev_done - t_start, R->t_host_ms, t_glue_done - t_dev_done);
     *out = R;
+    return HS_OK;
+}
+
+
+int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int n_threads, hs_cv_result** out) {
+    CvSelection sel;
+    if (int rc = cv_select(dev, b, sel)) return rc;
+    if (int rc = cv_run_range(dev, b, sel, 0, b.n_contigs, automatic_snp_threshold, n_threads, out)) return rc;
+    hs_cv_result* R = *out;
+    R->t_kernel_ms[0] = sel.k_ms[0]; R->t_kernel_ms[1] = sel.k_ms[1]; R->t_kernel_ms[3] = sel.k_ms[3];
+    R->t_device_ms += sel.t_device_ms; R->t_host_ms += sel.t_host_ms;
     return HS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------
 // stage 4
 // ---------------------------------------------------------------------------------------------------
-namespace {
-struct Laps {   // HS_TIMING: fine-grained wall clock of the stage-4 driver
-    bool on = std::getenv("HS_TIMING") != nullptr;
-    double t = now_ms();
-    std::string line;
-    void lap(const char* what) {
-        if (!on) return;
-        const double n = now_ms();
-        char buf[96]; std::snprintf(buf, sizeof buf, " %s %.2f", what, n - t);
-        line += buf; t = n;
-    }
-    ~Laps() { if (on) std::fprintf(stderr, "[hs timing] sr laps (ms):%s\n", line.c_str()); }
-};
-}  // namespace
-
 int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
            int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out) {
-    Laps laps;
+    Laps laps("sr");
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
     const int C = n_contigs;
     const bool lowmem = low_memory != 0;
@@ -530,9 +576,10 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
 // ---------------------------------------------------------------------------------------------------
 // stage 3 -> stage 4 hand-over without the .col text round trip
 // ---------------------------------------------------------------------------------------------------
-int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, const hs_cv_result* cv, float error_rate, float rsa, int32_t low_memory,
+int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, int c0, int c1, const hs_cv_result* cv, float error_rate, float rsa, int32_t low_memory,
                    int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out) {
-    const int C = b.n_contigs;
+    if (c0 < 0 || c1 > b.n_contigs || c0 > c1 || cv->n_contigs != c1 - c0) { set_error("sr_run_from_cv: contig range does not match the stage-3 result"); return HS_EINVAL; }
+    const int C = c1 - c0;
     const double t_prep0 = now_ms();
     std::vector<hs_sr_contig> hc((size_t)C);
     std::vector<std::vector<int32_t>> rs((size_t)C), re((size_t)C), spos((size_t)C);
@@ -540,7 +587,8 @@ int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, const hs_cv_result* cv, fl
     std::vector<std::vector<int64_t>> coff((size_t)C);
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
     parallel_for(C, n_threads, [&](int c) {
-        const int r0 = b.contig_rec_off[(size_t)c], r1 = b.contig_rec_off[(size_t)c + 1];
+        const int gc = c0 + c;   // index in the batch
+        const int r0 = b.contig_rec_off[(size_t)gc], r1 = b.contig_rec_off[(size_t)gc + 1];
         rs[(size_t)c].resize((size_t)(r1 - r0)); re[(size_t)c].resize((size_t)(r1 - r0));
         for (int r = r0; r < r1; ++r) {
             // READ line limits = (position_2_1, position_2_2) = (POS-1, POS + reference span) (input_output.cpp:503-511)
@@ -558,7 +606,7 @@ int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, const hs_cv_result* cv, fl
             if (!((float)sec >= rsa * (float)(maj + sec))) { keep[(size_t)(s - s0)] = 0; all_kept = false; }
         }
         hs_sr_contig& h = hc[(size_t)c];
-        h.length = b.contig_off[(size_t)c + 1] - b.contig_off[(size_t)c];
+        h.length = b.contig_off[(size_t)gc + 1] - b.contig_off[(size_t)gc];
         h.n_reads = r1 - r0; h.read_start = rs[(size_t)c].data(); h.read_end = re[(size_t)c].data();
         h.col_idx = cv->col_idx; h.col_code = cv->col_code; h.ploidy = 0;
         if (all_kept) {

@@ -46,6 +46,17 @@ struct CvDeviceOps {
     virtual int column_partition_test(const CvPartitionTest& t, std::vector<uint8_t>& keep, float* k_ms) = 0;
 };
 
+// result of the whole-batch streaming pass (K0-K2): per-record counters and the interesting positions by (contig, position)
+struct CvSelection {
+    std::vector<int32_t> rec_stats;
+    std::vector<int32_t> sel_contig, sel_pos, sel_depth;
+    std::vector<int64_t> contig_sel_off;   // [C+1]
+    float k_ms[4] = {0, 0, 0, 0};          // pileup, column_stats, -, cigar_scan
+    double t_device_ms = 0, t_host_ms = 0;
+};
+int cv_select(CvDeviceOps& dev, const CvMeta& meta, CvSelection& sel);
+int cv_run_range(CvDeviceOps& dev, const CvMeta& meta, const CvSelection& sel, int c0, int c1, float automatic_snp_threshold, int n_threads,
+                 hs_cv_result** out);
 int cv_run(CvDeviceOps& dev, const CvMeta& meta, float automatic_snp_threshold, int n_threads, hs_cv_result** out);
 
 struct CwGraphSet {                   // every window graph of the batch, flattened
@@ -103,7 +114,7 @@ struct SrDeviceOps {
 int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
            int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out);
 
-int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& meta, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance,
+int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& meta, int c0, int c1, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance,
                    int32_t low_memory, int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out);
 
 // .col reader of HS_separate_reads (separate_reads.cpp:46-190)

@@ -216,6 +216,22 @@ typedef struct hs_cv_result {
 } hs_cv_result;
 
 int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out);
+
+/* hs_cv_run in two steps, for hosts that overlap the sequential glue of several contig groups:
+ * hs_cv_select = the streaming pass over the WHOLE batch (K0 CIGAR scan, K1 pileup, K2 column statistics; one launch each),
+ * hs_cv_run_range = everything after it (K3, partitions, K4, merge) for the contigs [c0, c1) of the batch. Contigs are
+ * independent (call_variants.cpp:1280): ranges may run concurrently from different host threads; the result of a range
+ * holds c1 - c0 contigs and its error_rate covers that range only (form the job-wide mean from mean_distance). */
+typedef struct hs_cv_selection {
+    int64_t n_selected;        /* positions whose second allele count makes them worth extracting */
+    float t_kernel_ms[4];      /* hipEvent time of k_pileup, k_column_stats, -, k_cigar_scan */
+    double t_device_ms, t_host_ms;
+    void* impl;
+} hs_cv_selection;
+int hs_cv_select(hs_cv_batch* b, hs_cv_selection** out);
+int hs_cv_run_range(hs_cv_batch* b, const hs_cv_selection* sel, int32_t c0, int32_t c1, float automatic_snp_threshold,
+                    int32_t n_threads, hs_cv_result** out);
+void hs_cv_selection_destroy(hs_cv_selection* sel);
 void hs_cv_result_destroy(hs_cv_result* r);
 
 /* Stage 4 on SNP columns already in memory (what parse_column_file, separate_reads.cpp:46-190, yields). */
@@ -256,6 +272,9 @@ void hs_sr_result_destroy(hs_sr_result* r);
  * separate_reads.cpp:84-170). READ limits come from the records (input_output.cpp:503-511); SNPs whose second base is
  * rarer than rarest_strain_abundance are dropped as parse_column_file does (separate_reads.cpp:167). window_size <= 0:
  * computed as separate_reads.cpp:1466-1498 from this batch. */
+int hs_sr_run_cv_range(const hs_cv_batch* b, int32_t c0, int32_t c1, const hs_cv_result* cv, float error_rate,
+                       float rarest_strain_abundance, int32_t low_memory, int32_t amplicon, uint32_t seed, int32_t n_threads,
+                       int32_t window_size, hs_sr_result** out);   /* cv = result of hs_cv_run_range(b, sel, c0, c1) */
 int hs_sr_run_cv(const hs_cv_batch* b, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance,
                  int32_t low_memory, int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size,
                  hs_sr_result** out);

@@ -3,6 +3,7 @@ import os
 import subprocess
 import tempfile
 
+import numpy as np
 import pytest
 
 import golden_util as gu
@@ -125,3 +126,20 @@ def test_dropin_equals_oracle_at_larger_sizes(built, shape):
         assert open(outs["hip"][2]).read() == open(outs["orc"][2]).read()
         assert canon.split_blocks(outs["hip"][3]) == canon.split_blocks(outs["orc"][3])
         assert sum(1 for l in open(outs["hip"][3]) if l.startswith("GROUP")) > 40
+
+
+def test_pipeline_groups_equal_single_batch(built):
+    """concurrent sub-batches (one host thread + HIP stream each) == the same contigs as one batch"""
+    from hairsplitter_amd import api, synth
+    contigs = [synth.make_contig(7, i, 30_000, 2 + (i % 3), 0.01, 40, "ont") for i in range(6)]
+    single = api.CvBatch(api.FlatBatch(contigs))
+    cv1, sr1 = single.run_pipeline(0.33, 8)
+    groups = api.PipelineGroups(contigs, 4)
+    for _ in range(2):
+        cv2, sr2 = groups.run(0.33, 8)
+        assert np.array_equal(cv1["mean_distance"], cv2["mean_distance"])
+        assert np.float32(cv1["error_rate"]) == np.float32(cv2["error_rate"])
+        assert cv1["n_snps"] == cv2["n_snps"]
+        assert np.array_equal(sr1["labels"], sr2["labels"])
+        assert np.array_equal(sr1["win_start"], sr2["win_start"]) and np.array_equal(sr1["win_end"], sr2["win_end"])
+    single.close(); groups.close()
