@@ -169,7 +169,7 @@ def main():
     sync()
     for k in py_ms:
         py_ms[k] = 0.0
-    t0 = time.perf_counter()
+    t0 = time.perf_counter(); cpu0 = time.process_time()
     k_cv = np.zeros(4); k_sr = np.zeros(4); t_dev = 0.0; t_host = 0.0; k4 = 0.0; k6 = 0.0
     last = None
     step_ms = []
@@ -182,6 +182,7 @@ def main():
         last = (cv, sr)
     sync()
     dt = time.perf_counter() - t0
+    cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -226,7 +227,7 @@ def main():
             "value": total_bp * K / dt, "unit": "aligned read-bp/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
-            "host": {"cpus_online": os.cpu_count(), "cpus_effective": effective_cores()},
+            "host": {"cpus_online": os.cpu_count(), "cpus_effective": effective_cores(), "process_cpu_ms_per_step": cpu_ms_per_step},
             "config": {"workload": f"C2 (BASELINE.json configs[1]): 100 kb contig, 2 haplotypes @1% divergence, 50x ONT-error reads; "
                                    f"{B} such contigs per GPU per step, inputs resident in HBM",
                        "contigs_per_gpu": B, "aligned_bp_per_gpu": local_bp, "parallelism": f"contig-sharded x{world}", "groups_per_gpu": G,

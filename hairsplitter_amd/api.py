@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_ROOT, "lib", "libhairsplitter_hip.so")
 
 # every symbol declared in include/hairsplitter_hip.h
 SYMBOLS = [
-    "hs_version", "hs_last_error", "hs_device_count", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
+    "hs_version", "hs_last_error", "hs_device_count", "hs_warmup", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
     "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_column_partition_test", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",

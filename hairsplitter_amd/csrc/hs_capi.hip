@@ -128,6 +128,16 @@ extern "C" {
 const char* hs_version(void) { return "hairsplitter_amd 0.1 (gfx950)"; }
 const char* hs_last_error(void) { return hs::g_err.c_str(); }
 int hs_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+int hs_warmup(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+    void* p = nullptr;
+    if (hipMalloc(&p, 256) != hipSuccess) return 0;
+    hipLaunchKernelGGL(hsdev::k_swap_top2, dim3(1), dim3(64), 0, 0, (hsdev::hs_colstat_dev*)p, (const int64_t*)p, 0);   // loads the code object
+    (void)hipDeviceSynchronize();
+    (void)hipFree(p);
+    return n;
+}
 int hs_set_device(int device) { HS_HIP(hipSetDevice(device)); return HS_OK; }
 int hs_device_synchronize(void) { HS_HIP(hipDeviceSynchronize()); return HS_OK; }
 int hs_malloc(void** d_ptr, size_t bytes) { HS_HIP(hipMalloc(d_ptr, bytes ? bytes : 16)); return HS_OK; }

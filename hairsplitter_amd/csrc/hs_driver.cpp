@@ -93,6 +93,8 @@ template <class T> T* dup_vec(const std::vector<T>& v) {
 
 }  // namespace
 
+void hs_parallel_for(int n, int n_threads, const std::function<void(int)>& f) { WorkerPool::get().run(n, n_threads, f); }
+
 void free_cv_result(hs_cv_result* r) {
     if (!r) return;
     std::free(r->mean_distance); std::free(r->depth); std::free(r->snp_off); std::free(r->snp_pos); std::free(r->snp_ref);

@@ -3,6 +3,7 @@
 // glue the reference keeps between them, re-expressed over flat / dense arrays.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/hairsplitter_hip.h"
@@ -80,6 +81,9 @@ struct CvFileInput {
     std::vector<uint8_t> contig_skip;                      // call_variants.cpp:1283
 };
 int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::string& sam, bool amplicon,
-                   CvFileInput& in);
+                   CvFileInput& in, int n_threads = 1);
+
+// the calling thread's persistent worker pool (hs_driver.cpp)
+void hs_parallel_for(int n, int n_threads, const std::function<void(int)>& f);
 
 }  // namespace hs

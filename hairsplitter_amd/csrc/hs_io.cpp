@@ -12,48 +12,100 @@
 #include <fstream>
 #include <iostream>
 #include <sstream>
+#include <string_view>
 #include <unordered_map>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace hs {
 
-static bool slurp(const std::string& path, std::string& out) {
-    std::ifstream in(path, std::ios::binary);
-    if (!in) return false;
-    in.seekg(0, std::ios::end);
-    std::streamoff n = in.tellg();
-    in.seekg(0);
-    out.resize((size_t)n);
-    if (n) in.read(&out[0], n);
-    return true;
-}
+// read-only view of a whole file (mmap; plain read() for things that cannot be mapped)
+struct FileView {
+    const char* p = nullptr;
+    size_t n = 0;
+    void* map = nullptr;
+    std::string fallback;
+    bool open(const std::string& path) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (::fstat(fd, &st) != 0) { ::close(fd); return false; }
+        if (S_ISREG(st.st_mode) && st.st_size > 0) {
+            void* m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (m != MAP_FAILED) { map = m; p = (const char*)m; n = (size_t)st.st_size; ::close(fd); return true; }
+        }
+        char buf[1 << 16];
+        ssize_t k;
+        while ((k = ::read(fd, buf, sizeof buf)) > 0) fallback.append(buf, (size_t)k);
+        ::close(fd);
+        p = fallback.data(); n = fallback.size();
+        return true;
+    }
+    ~FileView() { if (map) ::munmap(map, n); }
+};
 
-static inline uint8_t base_code(char c) {          // sequence.cpp:13-23: everything that is not A/C/G is T
-    return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3;
-}
+struct BaseLut {                                   // sequence.cpp:13-23: everything that is not A/C/G is T
+    uint8_t t[256];
+    BaseLut() { std::memset(t, 3, sizeof t); t[(unsigned char)'A'] = 0; t[(unsigned char)'C'] = 1; t[(unsigned char)'G'] = 2; }
+};
+static const BaseLut g_lut;
 
 struct Line { const char* p; size_t n; };
-static std::vector<Line> split_lines(const std::string& s) {
-    std::vector<Line> v;
-    size_t i = 0;
-    while (i < s.size()) {
-        size_t j = s.find('\n', i);
-        if (j == std::string::npos) j = s.size();
-        v.push_back(Line{s.data() + i, j - i});
-        i = j + 1;
+// lines of a buffer ('\n' separated, a last line without newline counts, no empty line after a final newline): the buffer
+// is cut into one piece per thread at line starts, the pieces are scanned with memchr and concatenated
+static std::vector<Line> split_lines(const char* s, size_t n, int n_threads) {
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, n_threads), n / (1 << 20) + 1));
+    std::vector<size_t> cut((size_t)T + 1, n);
+    cut[0] = 0;
+    for (int t = 1; t < T; ++t) {
+        const size_t raw = n / T * t;
+        const void* nl = std::memchr(s + raw - 1, '\n', n - (raw - 1));
+        cut[(size_t)t] = nl ? (size_t)((const char*)nl - s) + 1 : n;
     }
-    return v;
+    std::vector<std::vector<Line>> part((size_t)T);
+    hs_parallel_for(T, n_threads, [&](int t) {
+        std::vector<Line>& v = part[(size_t)t];
+        size_t i = cut[(size_t)t];
+        const size_t e = cut[(size_t)t + 1];
+        while (i < e) {
+            const void* nl = std::memchr(s + i, '\n', e - i);
+            const size_t j = nl ? (size_t)((const char*)nl - s) : e;
+            v.push_back(Line{s + i, j - i});
+            i = j + 1;
+        }
+    });
+    if (T == 1) return std::move(part[0]);
+    std::vector<Line> all;
+    size_t tot = 0;
+    for (auto& v : part) tot += v.size();
+    all.reserve(tot);
+    for (auto& v : part) all.insert(all.end(), v.begin(), v.end());
+    return all;
 }
-static std::string first_token(const char* p, size_t n) {   // name up to the first blank
+static std::string_view first_token(const char* p, size_t n) {   // name up to the first blank
     size_t k = 0;
     while (k < n && p[k] != ' ') k++;
-    return std::string(p, k);
+    return std::string_view(p, k);
+}
+static int atoi_n(const char* p, size_t n) {        // std::atoi on a field that is not NUL terminated
+    size_t i = 0;
+    while (i < n && (p[i] == ' ' || (p[i] >= '\t' && p[i] <= '\r'))) i++;
+    bool neg = false;
+    if (i < n && (p[i] == '+' || p[i] == '-')) { neg = p[i] == '-'; i++; }
+    long v = 0;
+    while (i < n && p[i] >= '0' && p[i] <= '9') { v = v * 10 + (p[i] - '0'); i++; }
+    return (int)(neg ? -v : v);
 }
 
-static int parse_cigar(const std::string& cg, std::vector<uint32_t>& ops) {
+static int parse_cigar(const char* cg, size_t n, std::vector<uint32_t>& ops) {
     // tools.cpp:27-57 semantics: digits accumulate, any other byte closes a run of that operation.
-    if (cg == "*") return 0;
+    if (n == 1 && cg[0] == '*') return 0;
     long num = -1;
-    for (char c : cg) {
+    for (size_t i = 0; i < n; ++i) {
+        const char c = cg[i];
         if (c >= '0' && c <= '9') { num = (num < 0 ? 0 : num) * 10 + (c - '0'); if (num > 0x0fffffff) return -1; }
         else {
             if (num < 0) return -1;   // the reference's stoi("") throws -> "could not convert" exit(1)
@@ -70,26 +122,110 @@ static int parse_cigar(const std::string& cg, std::vector<uint32_t>& ops) {
     return 0;
 }
 
-int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::string& sam, bool amplicon, CvFileInput& in) {
-    std::unordered_map<std::string, long> indices;
+namespace {
+struct SamRec { size_t line; int32_t contig; int32_t read, pos; uint8_t strand; int32_t r0, r1, c0, c1; int64_t need; std::vector<uint32_t> cig; };
+enum SamLineResult { SAM_SKIP = 0, SAM_REC = 1, SAM_DEFER = 2, SAM_BAD_CIGAR = 3 };
+
+// One alignment line (input_output.cpp:300-528). `lookup(name, is_query, &found)` resolves a name to its index in the
+// reference's single name table (reads first, then contigs); the parallel pass defers lines with unknown names.
+template <class Lookup>
+SamLineResult parse_sam_line(const Line& l, size_t line_no, long n_reads, long n_contigs, bool amplicon, Lookup&& lookup, SamRec& r, std::string* bad_cigar) {
+    const char* cg = nullptr; size_t cgn = 0;
+    long seq1 = -1, seq2 = -2;
+    int length1 = 0, pos2_1 = -1, flag = 0, nonmatching = 0;
+    bool positive = true, allgood = true;
+    int fieldnumber = 0;
+    size_t a = 0;
+    while (true) {
+        size_t b = a;
+        while (b < l.n && l.p[b] != '\t') b++;
+        const char* f = l.p + a; const size_t fn = b - a;
+        if (fieldnumber == 0) {
+            bool found = true, defer = false;
+            seq1 = lookup(std::string_view(f, fn), true, &found, &defer);
+            if (defer) return SAM_DEFER;
+            if (!found) {
+                std::cout << "WARNING: read in the sam file not found in reads file, ignoring: " << std::string(f, fn) << std::endl;
+                allgood = false;
+            }
+        } else if (fieldnumber == 1) {
+            flag = atoi_n(f, fn);
+            if (flag % 8 >= 4) allgood = false;
+            if (flag % 32 >= 16) positive = false;
+        } else if (fieldnumber == 2) {
+            bool found = true, defer = false;
+            seq2 = lookup(std::string_view(f, fn), false, &found, &defer);
+            if (defer) return SAM_DEFER;
+        } else if (fieldnumber == 3) pos2_1 = atoi_n(f, fn);
+        else if (fieldnumber == 5) { cg = f; cgn = fn; }
+        else if (fn >= 5 && std::memcmp(f, "LN:i:", 5) == 0) length1 = atoi_n(f + 5, fn - 5);
+        else if (fn >= 5 && std::memcmp(f, "NM:i:", 5) == 0) nonmatching = atoi_n(f + 5, fn - 5);
+        fieldnumber++;
+        if (b >= l.n) break;
+        a = b + 1;
+    }
+    if (!(allgood && fieldnumber > 10 && seq2 != seq1)) return SAM_SKIP;
+    r.cig.clear();
+    if (parse_cigar(cg, cgn, r.cig) != 0) { if (bad_cigar) bad_cigar->assign(cg, cgn); return SAM_BAD_CIGAR; }
+    auto clip = [&](bool front, uint32_t what) -> int {
+        if (r.cig.empty()) return 0;
+        uint32_t op = front ? r.cig.front() : r.cig.back();
+        return (op & 15u) == what ? (int)(op >> 4) : 0;
+    };
+    int nbH_start = clip(true, 5), nbH_end = clip(false, 5);
+    int nbS_start = clip(true, 4), nbS_end = clip(false, 4);
+    if (r.cig.size() == 1) {   // single-op CIGAR: the reference's backward scan sees the same run from both ends
+        nbH_end = nbH_start; nbS_end = nbS_start;
+    }
+    if (!positive) { std::swap(nbH_start, nbH_end); std::swap(nbS_start, nbS_end); }
+    if (nbH_start + nbH_end > 0.2 * length1 && flag < 2048) allgood = false;
+    else if (flag % 512 >= 256) allgood = false;
+    if (amplicon && nonmatching > 0.2 * length1) allgood = false;
+    if (!allgood) return SAM_SKIP;
+    int length_read = 0, length_contig = 0;
+    int64_t need = 0;
+    for (uint32_t op : r.cig) {
+        const uint32_t c = op & 15u; const int len = (int)(op >> 4);
+        if (c == 0 || c == 7 || c == 8) { length_read += len; length_contig += len; }
+        else if (c == 1) length_read += len;
+        else if (c == 2) length_contig += len;
+        if (c == 0 || c == 1 || c == 4 || c == 5 || c == 7 || c == 8) need += len;
+    }
+    r.line = line_no; r.need = need;
+    r.read = (int32_t)seq1; r.pos = pos2_1 - 1; r.strand = positive ? 1 : 0;
+    r.r0 = nbS_start + nbH_start; r.r1 = nbS_start + nbH_start + length_read;
+    r.c0 = pos2_1 - 1; r.c1 = pos2_1 + length_contig;
+    const long ci = seq2 - n_reads;
+    if (ci < 0 || ci >= n_contigs) return SAM_SKIP;   // target is not a contig of the GFA
+    if (seq1 >= n_reads) return SAM_SKIP;             // contig-on-contig records are outside this path's contract
+    r.contig = (int32_t)ci;
+    return SAM_REC;
+}
+}  // namespace
+
+int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::string& sam, bool amplicon, CvFileInput& in, int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    // one name table for reads and contigs, as in the reference (reads first, contigs appended: input_output.cpp:134,241);
+    // a later entry of the same name replaces the earlier one
+    std::unordered_map<std::string_view, long> indices;
     // ---- reads: names, lengths, sequence line of each record (input_output.cpp:39-109) ----
-    std::string rtxt;
-    if (!slurp(reads, rtxt)) {
+    FileView rtxt;
+    if (!rtxt.open(reads)) {
         std::cout << "problem reading files in index_reads, while trying to read " << reads << std::endl;
         set_error("Input file could not be read: " + reads);
         return HS_EIO;
     }
     char format = '@';
     if ((reads.size() > 6 && reads.substr(reads.size() - 6, 6) == ".fasta") || (reads.size() >= 3 && reads.substr(reads.size() - 3, 3) == ".fa")) format = '>';
-    std::vector<Line> rl = split_lines(rtxt);
+    std::vector<Line> rl = split_lines(rtxt.p, rtxt.n, n_threads);
     std::vector<Line> seq_of_read;
     {
         std::vector<size_t> buffer;   // line indices
         char lastlinestart = '+';
         auto flush = [&]() {
             const Line& h = rl[buffer[0]];
-            std::string name = first_token(h.p + (h.n ? 1 : 0), h.n ? h.n - 1 : 0);
-            in.read_names.push_back(name);
+            const std::string_view name = first_token(h.p + (h.n ? 1 : 0), h.n ? h.n - 1 : 0);
+            in.read_names.emplace_back(name);
             seq_of_read.push_back(rl[buffer[1]]);
             indices[name] = (long)in.read_names.size() - 1;
         };
@@ -108,144 +244,167 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
     const long n_reads = (long)in.read_names.size();
 
     // ---- contigs (input_output.cpp:120-264, S lines) ----
-    std::string gtxt;
-    if (!slurp(gfa, gtxt)) {
+    FileView gtxt;
+    if (!gtxt.open(gfa)) {
         std::cout << "problem reading files in index_reads, while trying to read " << gfa << std::endl;
         set_error("Input file could not be read: " + gfa);
         return HS_EIO;
     }
     in.contig_off.assign(1, 0);
-    for (const Line& l : split_lines(gtxt)) {
-        if (!l.n || l.p[0] != 'S') continue;
-        // fields are tab separated: S <name> <sequence> ...
-        size_t a = 0; int field = 0; std::string name;
-        while (a <= l.n) {
-            size_t b = a;
-            while (b < l.n && l.p[b] != '\t') b++;
-            if (field == 1) name = first_token(l.p + a, b - a);
-            else if (field == 2) {
-                for (size_t k = a; k < b; ++k) in.contig_seq.push_back(base_code(l.p[k]));
-                in.contig_off.push_back((int64_t)in.contig_seq.size());
-                indices[name] = n_reads + (long)in.contig_names.size();
-                in.contig_names.push_back(name);
-                in.contig_skip.push_back(name == "edge_124@009" ? 1 : 0);   // call_variants.cpp:1283
+    {
+        std::vector<Line> seqs;
+        for (const Line& l : split_lines(gtxt.p, gtxt.n, n_threads)) {
+            if (!l.n || l.p[0] != 'S') continue;
+            // fields are tab separated: S <name> <sequence> ...
+            size_t a = 0; int field = 0; std::string_view name;
+            while (a <= l.n) {
+                size_t b = a;
+                while (b < l.n && l.p[b] != '\t') b++;
+                if (field == 1) name = first_token(l.p + a, b - a);
+                else if (field == 2) {
+                    seqs.push_back(Line{l.p + a, b - a});
+                    in.contig_off.push_back(in.contig_off.back() + (int64_t)(b - a));
+                    indices[name] = n_reads + (long)in.contig_names.size();
+                    in.contig_names.emplace_back(name);
+                    in.contig_skip.push_back(name == "edge_124@009" ? 1 : 0);   // call_variants.cpp:1283
+                }
+                field++;
+                if (b >= l.n) break;
+                a = b + 1;
             }
-            field++;
-            if (b >= l.n) break;
-            a = b + 1;
         }
+        in.contig_seq.resize((size_t)in.contig_off.back());
+        hs_parallel_for((int)seqs.size(), n_threads, [&](int c) {
+            uint8_t* o = in.contig_seq.data() + in.contig_off[(size_t)c];
+            const Line& s = seqs[(size_t)c];
+            for (size_t k = 0; k < s.n; ++k) o[k] = g_lut.t[(unsigned char)s.p[k]];
+        });
     }
     const long n_contigs = (long)in.contig_names.size();
 
-    // ---- alignments (input_output.cpp:274-536) ----
-    std::string stxt;
-    if (!slurp(sam, stxt)) {
+    // ---- alignments (input_output.cpp:274-536): lines are independent once the names resolve, so they are parsed in
+    // blocks on all threads. A name that is in neither file goes through the reference's operator[] (:325), which inserts
+    // it with index 0: its first appearance as a query is refused, later ones are taken as read 0. Lines with such names are
+    // set aside and replayed in file order afterwards. ----
+    FileView stxt;
+    if (!stxt.open(sam)) {
         std::cout << "problem reading SAM file " << sam << std::endl;
         set_error("Input file '" + sam + "' could not be read");
         return HS_EIO;
     }
-    struct Rec { int32_t read, pos; uint8_t strand; int32_t r0, r1, c0, c1; std::vector<uint32_t> cig; };
-    std::vector<std::vector<Rec>> per_contig((size_t)n_contigs);
-    for (const Line& l : split_lines(stxt)) {
-        if (l.n && l.p[0] == '@') continue;
-        std::string cigar;
-        long seq1 = -1, seq2 = -2;
-        int length1 = 0, pos2_1 = -1, flag = 0, nonmatching = 0;
-        bool positive = true, allgood = true;
-        int fieldnumber = 0;
-        size_t a = 0;
-        if (l.n == 0) continue;
-        while (true) {
-            size_t b = a;
-            while (b < l.n && l.p[b] != '\t') b++;
-            std::string field(l.p + a, b - a);
-            if (fieldnumber == 0) {
-                if (indices.find(field) == indices.end()) {
-                    std::cout << "WARNING: read in the sam file not found in reads file, ignoring: " << field << std::endl;
-                    allgood = false;
-                }
-                seq1 = indices[field];   // default-inserts 0 for unknown names, as the reference's operator[] does
-            } else if (fieldnumber == 1) {
-                flag = std::atoi(field.c_str());
-                if (flag % 8 >= 4) allgood = false;
-                if (flag % 32 >= 16) positive = false;
-            } else if (fieldnumber == 2) seq2 = indices[field];
-            else if (fieldnumber == 3) pos2_1 = std::atoi(field.c_str());
-            else if (fieldnumber == 5) cigar = field;
-            else if (field.compare(0, 5, "LN:i:") == 0) length1 = std::atoi(field.c_str() + 5);
-            else if (field.compare(0, 5, "NM:i:") == 0) nonmatching = std::atoi(field.c_str() + 5);
-            fieldnumber++;
-            if (b >= l.n) break;
-            a = b + 1;
+    std::vector<Line> sl = split_lines(stxt.p, stxt.n, n_threads);
+    const int NB = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads * 4, sl.size() / 64 + 1));
+    struct Block { std::vector<SamRec> recs; std::vector<size_t> deferred; size_t bad_line = (size_t)-1; std::string bad_cigar; };
+    std::vector<Block> blocks((size_t)NB);
+    hs_parallel_for(NB, n_threads, [&](int bi) {
+        Block& B = blocks[(size_t)bi];
+        const size_t l0 = sl.size() * (size_t)bi / NB, l1 = sl.size() * ((size_t)bi + 1) / NB;
+        auto lookup = [&](std::string_view name, bool, bool* found, bool* defer) -> long {
+            auto it = indices.find(name);
+            if (it == indices.end()) { *found = false; *defer = true; return 0; }
+            return it->second;
+        };
+        SamRec r;
+        for (size_t li = l0; li < l1; ++li) {
+            const Line& l = sl[li];
+            if (l.n == 0 || l.p[0] == '@') continue;
+            const SamLineResult k = parse_sam_line(l, li, n_reads, n_contigs, amplicon, lookup, r, &B.bad_cigar);
+            if (k == SAM_REC) B.recs.push_back(std::move(r));
+            else if (k == SAM_DEFER) B.deferred.push_back(li);
+            else if (k == SAM_BAD_CIGAR) { B.bad_line = li; break; }
         }
-        if (!(allgood && fieldnumber > 10 && seq2 != seq1)) continue;
-        Rec r;
-        if (parse_cigar(cigar, r.cig) != 0) {
-            std::cout << "ERROR : could not convert " << cigar << " to int" << std::endl;
-            set_error("malformed CIGAR " + cigar);
+    });
+    for (const Block& B : blocks)
+        if (B.bad_line != (size_t)-1) {
+            std::cout << "ERROR : could not convert " << B.bad_cigar << " to int" << std::endl;
+            set_error("malformed CIGAR " + B.bad_cigar);
             return HS_EFORMAT;
         }
-        auto clip = [&](bool front, uint32_t what) -> int {
-            if (r.cig.empty()) return 0;
-            uint32_t op = front ? r.cig.front() : r.cig.back();
-            return (op & 15u) == what ? (int)(op >> 4) : 0;
-        };
-        int nbH_start = clip(true, 5), nbH_end = clip(false, 5);
-        int nbS_start = clip(true, 4), nbS_end = clip(false, 4);
-        if (r.cig.size() == 1) {   // single-op CIGAR: the reference's backward scan sees the same run from both ends
-            nbH_end = nbH_start; nbS_end = nbS_start;
-        }
-        if (!positive) { std::swap(nbH_start, nbH_end); std::swap(nbS_start, nbS_end); }
-        if (nbH_start + nbH_end > 0.2 * length1 && flag < 2048) allgood = false;
-        else if (flag % 512 >= 256) allgood = false;
-        if (amplicon && nonmatching > 0.2 * length1) allgood = false;
-        if (!allgood) continue;
-        int length_read = 0, length_contig = 0;
-        for (uint32_t op : r.cig) {
-            const uint32_t c = op & 15u; const int len = (int)(op >> 4);
-            if (c == 0 || c == 7 || c == 8) { length_read += len; length_contig += len; }
-            else if (c == 1) length_read += len;
-            else if (c == 2) length_contig += len;
-        }
-        r.read = (int32_t)seq1; r.pos = pos2_1 - 1; r.strand = positive ? 1 : 0;
-        r.r0 = nbS_start + nbH_start; r.r1 = nbS_start + nbH_start + length_read;
-        r.c0 = pos2_1 - 1; r.c1 = pos2_1 + length_contig;
-        const long ci = seq2 - n_reads;
-        if (ci < 0 || ci >= n_contigs) continue;   // target is not a contig of the GFA
-        if (seq1 >= n_reads) continue;             // contig-on-contig records are outside this path's contract
-        per_contig[(size_t)ci].push_back(std::move(r));
+    std::vector<SamRec> replayed;
+    {
+        std::unordered_map<std::string, long> inserted;   // names operator[] would have added, all with index 0
+        std::string bad;
+        for (const Block& B : blocks)
+            for (size_t li : B.deferred) {
+                auto lookup = [&](std::string_view name, bool, bool* found, bool* defer) -> long {
+                    *defer = false;
+                    auto it = indices.find(name);
+                    if (it != indices.end()) return it->second;
+                    auto ins = inserted.emplace(std::string(name), 0L);
+                    *found = !ins.second;
+                    return 0;
+                };
+                SamRec r;
+                const SamLineResult k = parse_sam_line(sl[li], li, n_reads, n_contigs, amplicon, lookup, r, &bad);
+                if (k == SAM_REC) replayed.push_back(std::move(r));
+                else if (k == SAM_BAD_CIGAR) {
+                    std::cout << "ERROR : could not convert " << bad << " to int" << std::endl;
+                    set_error("malformed CIGAR " + bad);
+                    return HS_EFORMAT;
+                }
+            }
+    }
+    // records of each contig in file order
+    std::vector<std::vector<SamRec*>> per_contig((size_t)n_contigs);
+    for (Block& B : blocks) for (SamRec& r : B.recs) per_contig[(size_t)r.contig].push_back(&r);
+    if (!replayed.empty()) {
+        for (SamRec& r : replayed) per_contig[(size_t)r.contig].push_back(&r);
+        for (auto& v : per_contig) std::stable_sort(v.begin(), v.end(), [](const SamRec* x, const SamRec* y) { return x->line < y->line; });
     }
 
     // ---- flatten; load only the reads that are aligned somewhere (input_output.cpp:546-569) ----
     std::vector<char> needed((size_t)n_reads, 0);
-    for (auto& v : per_contig) for (auto& r : v) needed[(size_t)r.read] = 1;
-    in.read_off.assign(1, 0);
-    for (long i = 0; i < n_reads; ++i) {
-        if (needed[(size_t)i]) {
-            const Line& s = seq_of_read[(size_t)i];
-            for (size_t k = 0; k < s.n; ++k) in.read_seq.push_back(base_code(s.p[k]));
-        }
-        in.read_off.push_back((int64_t)in.read_seq.size());
-    }
-    in.contig_rec_off.assign(1, 0);
-    in.rec_cig_off.assign(1, 0);
-    for (long c = 0; c < n_contigs; ++c) {
-        for (auto& r : per_contig[(size_t)c]) {
-            // validate: the CIGAR must not run past the read (the reference would index past the string)
-            int64_t need = 0;
-            for (uint32_t op : r.cig) { uint32_t k = op & 15u; if (k == 0 || k == 1 || k == 4 || k == 5 || k == 7 || k == 8) need += op >> 4; }
-            const int64_t have = in.read_off[(size_t)r.read + 1] - in.read_off[(size_t)r.read];
-            if (need > have) {
-                set_error("CIGAR of read " + in.read_names[(size_t)r.read] + " consumes more bases than the read has");
-                std::cout << "ERROR: CIGAR of read " << in.read_names[(size_t)r.read] << " is longer than the read" << std::endl;
-                return HS_EFORMAT;
+    for (auto& v : per_contig) for (SamRec* r : v) needed[(size_t)r->read] = 1;
+    in.read_off.assign((size_t)n_reads + 1, 0);
+    for (long i = 0; i < n_reads; ++i) in.read_off[(size_t)i + 1] = in.read_off[(size_t)i] + (needed[(size_t)i] ? (int64_t)seq_of_read[(size_t)i].n : 0);
+    in.read_seq.resize((size_t)in.read_off.back());
+    {
+        const int RB = (int)std::max<long>(1, std::min<long>((long)n_threads * 8, n_reads));
+        hs_parallel_for(RB, n_threads, [&](int bi) {
+            const long i0 = n_reads * bi / RB, i1 = n_reads * (bi + 1) / RB;
+            for (long i = i0; i < i1; ++i) {
+                if (!needed[(size_t)i]) continue;
+                const Line& s = seq_of_read[(size_t)i];
+                uint8_t* o = in.read_seq.data() + in.read_off[(size_t)i];
+                for (size_t k = 0; k < s.n; ++k) o[k] = g_lut.t[(unsigned char)s.p[k]];
             }
-            in.rec_read.push_back(r.read); in.rec_pos.push_back(r.pos); in.rec_strand.push_back(r.strand);
-            in.rec_r0.push_back(r.r0); in.rec_r1.push_back(r.r1); in.rec_c0.push_back(r.c0); in.rec_c1.push_back(r.c1);
-            in.cigar.insert(in.cigar.end(), r.cig.begin(), r.cig.end());
-            in.rec_cig_off.push_back((int64_t)in.cigar.size());
-        }
-        in.contig_rec_off.push_back((int32_t)in.rec_read.size());
+        });
+    }
+    size_t n_rec = 0;
+    in.contig_rec_off.assign(1, 0);
+    for (long c = 0; c < n_contigs; ++c) { n_rec += per_contig[(size_t)c].size(); in.contig_rec_off.push_back((int32_t)n_rec); }
+    in.rec_read.resize(n_rec); in.rec_pos.resize(n_rec); in.rec_strand.resize(n_rec);
+    in.rec_r0.resize(n_rec); in.rec_r1.resize(n_rec); in.rec_c0.resize(n_rec); in.rec_c1.resize(n_rec);
+    in.rec_cig_off.assign(n_rec + 1, 0);
+    std::vector<SamRec*> flat(n_rec);
+    {
+        size_t k = 0;
+        for (long c = 0; c < n_contigs; ++c)
+            for (SamRec* r : per_contig[(size_t)c]) {
+                // validate: the CIGAR must not run past the read (the reference would index past the string)
+                const int64_t have = in.read_off[(size_t)r->read + 1] - in.read_off[(size_t)r->read];
+                if (r->need > have) {
+                    set_error("CIGAR of read " + in.read_names[(size_t)r->read] + " consumes more bases than the read has");
+                    std::cout << "ERROR: CIGAR of read " << in.read_names[(size_t)r->read] << " is longer than the read" << std::endl;
+                    return HS_EFORMAT;
+                }
+                flat[k] = r;
+                in.rec_cig_off[k + 1] = in.rec_cig_off[k] + (int64_t)r->cig.size();
+                k++;
+            }
+    }
+    in.cigar.resize((size_t)in.rec_cig_off.back());
+    {
+        const int FB = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads * 4, n_rec));
+        hs_parallel_for(FB, n_threads, [&](int bi) {
+            const size_t k0 = n_rec * (size_t)bi / FB, k1 = n_rec * ((size_t)bi + 1) / FB;
+            for (size_t k = k0; k < k1; ++k) {
+                const SamRec* r = flat[k];
+                in.rec_read[k] = r->read; in.rec_pos[k] = r->pos; in.rec_strand[k] = r->strand;
+                in.rec_r0[k] = r->r0; in.rec_r1[k] = r->r1; in.rec_c0[k] = r->c0; in.rec_c1[k] = r->c1;
+                if (!r->cig.empty()) std::memcpy(in.cigar.data() + in.rec_cig_off[k], r->cig.data(), r->cig.size() * sizeof(uint32_t));
+            }
+        });
     }
     return HS_OK;
 }

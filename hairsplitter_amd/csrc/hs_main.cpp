@@ -9,6 +9,7 @@
 #include <iostream>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -66,18 +67,23 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
         std::cout << "ERROR: the file containing the alignments on the assembly should be .sam" << std::endl;
         return EXIT_FAILURE;
     }
-    if (hs_device_count() <= 0) {
+    // the HIP runtime, the context and the code object come up on a side thread while the inputs are parsed
+    int n_devices = 0;
+    std::thread warm([&n_devices] { n_devices = hs_warmup(); });
+    std::cout << " - Loading reads, contigs and alignments\n";
+    hs::CvFileInput in;
+    const int load_rc = hs::load_cv_inputs(gfafile, reads_file, sam_file, amplicon_i != 0, in, num_threads);
+    clk.lap("load gfa + reads + sam");
+    warm.join();
+    clk.lap("wait for the device");
+    if (n_devices <= 0) {
         std::cout << "ERROR: no HIP device found; this build of HS_call_variants runs on MI355X only" << std::endl;
         return EXIT_FAILURE;
     }
-    clk.lap("device probe");
-    std::cout << " - Loading reads, contigs and alignments\n";
-    hs::CvFileInput in;
-    if (int rc = hs::load_cv_inputs(gfafile, reads_file, sam_file, amplicon_i != 0, in)) {
+    if (load_rc) {
         std::cout << "ERROR: " << hs_last_error() << std::endl;
-        return rc == HS_EIO ? 1 : EXIT_FAILURE;
+        return load_rc == HS_EIO ? 1 : EXIT_FAILURE;
     }
-    clk.lap("load gfa + reads + sam");
     std::cout << " - Calling variants on each contig\n";
     hs_cv_batch* batch = nullptr;
     const int C = (int)in.contig_names.size();
@@ -117,14 +123,18 @@ extern "C" int hs_separate_reads_main(int argc, char** argv) {
     const float rsa = (float)std::atof(argv[6]);
     StageClock clk;
     { std::ofstream o(outfile); }
-    if (hs_device_count() <= 0) {
+    int n_devices = 0;
+    std::thread warm([&n_devices] { n_devices = hs_warmup(); });
+    std::vector<hs::ColFileContig> cs;
+    const int parse_rc = hs::parse_col(columns_file, rsa, cs);
+    clk.lap("parse .col");
+    warm.join();
+    clk.lap("wait for the device");
+    if (n_devices <= 0) {
         std::cout << "ERROR: no HIP device found; this build of HS_separate_reads runs on MI355X only" << std::endl;
         return 1;
     }
-    std::vector<hs::ColFileContig> cs;
-    clk.lap("device probe");
-    if (int rc = hs::parse_col(columns_file, rsa, cs)) return rc;
-    clk.lap("parse .col");
+    if (parse_rc) return parse_rc;
     std::unordered_map<std::string, int> ploidy_of;
     bool have_ploidy = false;
     {

@@ -41,6 +41,8 @@ extern "C" {
 const char* hs_version(void);
 const char* hs_last_error(void);
 int hs_device_count(void);                       /* hipGetDeviceCount; 0 when there is no GPU */
+int hs_warmup(void);                             /* runtime + context + code-object load (first launch); returns the device count.
+                                                    The executables run it on a side thread while they parse their inputs. */
 int hs_set_device(int device);
 int hs_device_synchronize(void);
 /* raw HBM helpers so that hosts without a HIP binding (ctypes, cgo, JNI) can stage buffers */

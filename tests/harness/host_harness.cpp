@@ -273,7 +273,7 @@ int main(int argc, char** argv) {
         if (argc < 13) return 2;
         char** a = argv + 1;
         hs::CvFileInput in;
-        if (int rc = hs::load_cv_inputs(a[1], a[2], a[3], std::atoi(a[7]) != 0, in)) { std::cerr << hs::g_err << "\n"; return rc; }
+        if (int rc = hs::load_cv_inputs(a[1], a[2], a[3], std::atoi(a[7]) != 0, in, 4)) { std::cerr << hs::g_err << "\n"; return rc; }
         hs::CvMeta meta;
         meta.n_contigs = (int)in.contig_names.size(); meta.n_rec = (int)in.rec_read.size();
         meta.contig_off = in.contig_off; meta.contig_rec_off = in.contig_rec_off; meta.total_len = in.contig_off.back();
