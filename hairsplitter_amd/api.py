@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_ROOT, "lib", "libhairsplitter_hip.so")
 SYMBOLS = [
     "hs_version", "hs_last_error", "hs_device_count", "hs_warmup", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
-    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_column_partition_test", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
+    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_column_top3", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
     "hs_separate_reads_main",
@@ -33,7 +33,8 @@ class HsError(RuntimeError):
 class CvResult(C.Structure):
     _fields_ = [("n_contigs", C.c_int32), ("mean_distance", C.POINTER(C.c_float)), ("depth", C.POINTER(C.c_float)),
                 ("snp_off", C.POINTER(C.c_int64)), ("snp_pos", C.POINTER(C.c_int32)), ("snp_ref", C.POINTER(C.c_uint8)),
-                ("snp_alt", C.POINTER(C.c_uint8)), ("col_off", C.POINTER(C.c_int64)), ("col_idx", C.POINTER(C.c_int32)),
+                ("snp_alt", C.POINTER(C.c_uint8)), ("snp_n_ref", C.POINTER(C.c_int32)), ("snp_n_alt", C.POINTER(C.c_int32)),
+                ("col_off", C.POINTER(C.c_int64)), ("col_idx", C.POINTER(C.c_int32)),
                 ("col_code", C.POINTER(C.c_uint8)), ("error_rate", C.c_float), ("n_contigs_with_error_rate", C.c_int32),
                 ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("t_kernel_ms", C.c_float * 4), ("t_kernel_k4_ms", C.c_float)]
 
@@ -588,6 +589,23 @@ def gather_columns(t, flat: FlatBatch, pile, sel_contig, sel_pos, depths):
     return col_off, idx[:tot].cpu().numpy(), code[:tot].cpu().numpy()
 
 
+def column_top3(col_off, col_code):
+    """K3b on host arrays (uploaded here): returns (c0, c1, c2, k0, k1, tie) per column"""
+    import torch
+    require_gpu()
+    dev = "cuda:0"
+    col_off = _np(col_off, np.int64); col_code = _np(col_code, np.uint8)
+    n = len(col_off) - 1
+    d_off = torch.from_numpy(col_off).to(dev)
+    d_code = torch.from_numpy(col_code if col_code.size else np.zeros(1, np.uint8)).to(dev)
+    out = torch.zeros((max(n, 1), 16), dtype=torch.uint8, device=dev)
+    _check(load().hs_column_top3(_p(d_off), _p(d_code), C.c_int32(n), _p(out), C.c_void_p(0)))
+    torch.cuda.synchronize()
+    raw = out[:n].cpu().numpy()
+    cnt = raw[:, :12].copy().view(np.int32).reshape(n, 3)
+    return cnt[:, 0], cnt[:, 1], cnt[:, 2], raw[:, 12], raw[:, 13], raw[:, 14]
+
+
 def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1, col_c1, col_is_cand, part_off, part_state_off, part_state):
     """K4: loops C/D of keep_only_robust_variants (call_variants.cpp:721-764); returns keep uint8 [n_cols]."""
     import torch
@@ -604,6 +622,22 @@ def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1
     _check(load().hs_column_partition_test(*[_p(x) for x in d], C.c_int32(n), *[_p(x) for x in q], _p(keep), C.c_void_p(0)))
     torch.cuda.synchronize()
     return keep[:n].cpu().numpy()
+
+
+def snp_planes(n_reads, snp_ref, snp_alt, col_off, col_idx, col_code):
+    """K5a for one contig: returns (alt, ref) uint64 [N, words] bit-planes"""
+    import torch
+    require_gpu()
+    dev = "cuda:0"
+    S = len(snp_ref)
+    W = (S + 63) // 64
+    up = lambda a, dt: torch.from_numpy(_np(a, dt) if len(a) else np.zeros(1, dt)).to(dev)
+    d = [up(col_off, np.int64), up(col_idx, np.int32), up(col_code, np.uint8), up(snp_ref, np.uint8), up(snp_alt, np.uint8),
+         up(np.zeros(S, np.int32), np.int32), up(np.zeros(1, np.int64), np.int64), up(np.zeros(1, np.int64), np.int64), up(np.array([W], np.int32), np.int32)]
+    alt = torch.zeros((n_reads, max(W, 1)), dtype=torch.int64, device=dev); ref = torch.zeros_like(alt)
+    _check(load().hs_snp_planes(*[_p(x) for x in d], C.c_int32(S), _p(alt), _p(ref), C.c_void_p(0)))
+    torch.cuda.synchronize()
+    return alt.cpu().numpy().view(np.uint64)[:, :W], ref.cpu().numpy().view(np.uint64)[:, :W]
 
 
 def simdiff(alt_planes: np.ndarray, ref_planes: np.ndarray):

@@ -263,6 +263,16 @@ int hs_gather_columns(const uint8_t* d_pile, const int64_t* d_pile_off, const in
     return HS_OK;
 }
 
+int hs_column_top3(const int64_t* d_col_off, const uint8_t* d_col_code, int32_t n_cols, hs_coltop* d_out, void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_cols <= 0) return HS_OK;
+    static_assert(sizeof(hs_coltop) == sizeof(hsdev::hs_coltop_dev), "hs_coltop layout");
+    hipLaunchKernelGGL(hsdev::k_column_top3, dim3((n_cols + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_col_off, d_col_code, n_cols,
+                       reinterpret_cast<hsdev::hs_coltop_dev*>(d_out));
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
 int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code,
                              const int32_t* d_col_contig, const uint8_t* d_col_k0, const uint8_t* d_col_k1,
                              const int32_t* d_col_c1, const uint8_t* d_col_is_cand, int32_t n_cols,
@@ -273,6 +283,17 @@ int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx,
     hipLaunchKernelGGL(hsdev::k_column_partition_test, dim3((n_cols + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_col_off, d_col_idx,
                        d_col_code, d_col_contig, d_col_k0, d_col_k1, d_col_c1, d_col_is_cand, n_cols, d_part_off, d_part_state_off,
                        d_part_state, d_keep);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
+int hs_snp_planes(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code, const uint8_t* d_snp_ref,
+                  const uint8_t* d_snp_alt, const int32_t* d_snp_contig, const int64_t* d_contig_snp_base,
+                  const int64_t* d_plane_off, const int32_t* d_words, int32_t n_snps, uint64_t* d_alt, uint64_t* d_ref, void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_snps <= 0) return HS_OK;
+    hipLaunchKernelGGL(hsdev::k_snp_planes, dim3((n_snps + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_col_off, d_col_idx, d_col_code, d_snp_ref,
+                       d_snp_alt, d_snp_contig, d_contig_snp_base, d_plane_off, d_words, n_snps, (unsigned long long*)d_alt, (unsigned long long*)d_ref);
     HS_HIP(hipGetLastError());
     return HS_OK;
 }
@@ -581,13 +602,15 @@ struct HipCvOps : hs::CvDeviceOps {
         if (n) HS_HIP(hipMemcpy(keep.data(), d_keep.p, (size_t)n, hipMemcpyDeviceToHost));
         return e.ms(k_ms);
     }
+    HBuf h_top;
     int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
-               const int32_t** col_idx, const uint8_t** col_code, float* k_ms) override {
+               const int32_t** col_idx, const uint8_t** col_code, const hs_coltop** top, float* k_ms) override {
         const int n_sel = (int)sel_pos.size();
         const size_t total = (size_t)col_off.back();
         if (int rc = h_col_idx.alloc(total * sizeof(int32_t))) return rc;
         if (int rc = h_col_code.alloc(total)) return rc;
-        *col_idx = (const int32_t*)h_col_idx.p; *col_code = (const uint8_t*)h_col_code.p;
+        if (int rc = h_top.alloc((size_t)n_sel * sizeof(hs_coltop))) return rc;
+        *col_idx = (const int32_t*)h_col_idx.p; *col_code = (const uint8_t*)h_col_code.p; *top = (const hs_coltop*)h_top.p;
         n_gathered = n_sel;
         if (n_sel == 0) return HS_OK;
         DBuf d_sc, d_sp;
@@ -601,11 +624,16 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = hs_gather_columns(b->pile.as<uint8_t>(), b->d_pile_off.as<int64_t>(), b->d_rec_pos.as<int32_t>(), b->d_rec_qend.as<int32_t>(),
                                        b->d_contig_rec_off.as<int32_t>(), d_sc.as<int32_t>(), d_sp.as<int32_t>(), d_co.as<int64_t>(), n_sel,
                                        d_ci.as<int32_t>(), d_cc.as<uint8_t>(), stream)) return rc;
+        DBuf d_top;
+        if (int rc = d_top.alloc((size_t)n_sel * sizeof(hs_coltop))) return rc;
+        if (int rc = hs_column_top3(d_co.as<int64_t>(), d_cc.as<uint8_t>(), n_sel, d_top.as<hs_coltop>(), stream)) return rc;
         HS_HIP(hipEventRecord(e.b, stream));
         if (total) {
-            HS_HIP(hipMemcpy(h_col_idx.p, d_ci.p, total * sizeof(int32_t), hipMemcpyDeviceToHost));
-            HS_HIP(hipMemcpy(h_col_code.p, d_cc.p, total, hipMemcpyDeviceToHost));
+            HS_HIP(hipMemcpyAsync(h_col_idx.p, d_ci.p, total * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            HS_HIP(hipMemcpyAsync(h_col_code.p, d_cc.p, total, hipMemcpyDeviceToHost, stream));
         }
+        HS_HIP(hipMemcpyAsync(h_top.p, d_top.p, (size_t)n_sel * sizeof(hs_coltop), hipMemcpyDeviceToHost, stream));
+        HS_HIP(hipStreamSynchronize(stream));
         return e.ms(k_ms);
     }
 };
@@ -756,26 +784,41 @@ struct HipSrOps : hs::SrDeviceOps {
         return read_graphs_run(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, job, res, stream, k_ms);
     }
 
-    int simdiff(const std::vector<uint64_t>& alt, const std::vector<uint64_t>& ref, const std::vector<int64_t>& plane_off,
-                const std::vector<int32_t>& n_reads, const std::vector<int32_t>& words, const std::vector<int64_t>& out_off,
-                int64_t out_total, const int32_t** sim, const int32_t** diff, float* k_ms) override {
-        DBuf d_alt, d_ref, d_po, d_n, d_w, d_oo, t_c, t_i, t_j;
-        sd_out_off = out_off; sd_n = n_reads;
-        if (int rc = d_alt.upload(alt)) return rc;
-        if (int rc = d_ref.upload(ref)) return rc;
-        if (int rc = d_po.upload(plane_off)) return rc;
-        if (int rc = d_n.upload(n_reads)) return rc;
-        if (int rc = d_w.upload(words)) return rc;
-        if (int rc = d_oo.upload(out_off)) return rc;
-        if (int rc = d_sim.alloc((size_t)out_total * sizeof(int32_t))) return rc;
-        if (int rc = d_diff.alloc((size_t)out_total * sizeof(int32_t))) return rc;
+    DBuf d_col_off, d_col_idx, d_col_code;    // SNP columns of the batch: uploaded once, read by K5a and the seeded CW wave
+    const hs::CwChain* resident_cols = nullptr;
+    int simdiff_columns(const hs::SimdiffJob& job, float* k_ms) override {
+        const hs::CwChain& ch = *job.cols;
+        if (int rc = d_col_off.upload(ch.col_off)) return rc;
+        if (int rc = d_col_idx.upload(ch.col_idx)) return rc;
+        if (int rc = d_col_code.upload(ch.col_code)) return rc;
+        resident_cols = job.cols;
+        sd_out_off = job.out_off; sd_n = job.n_reads;
+        if (job.out_total <= 0) return HS_OK;
+        DBuf d_alt, d_ref, d_sr, d_sa, d_sc, d_cb, d_po, d_n, d_w, d_oo, t_c, t_i, t_j;
+        if (int rc = d_sr.upload(job.snp_ref)) return rc;
+        if (int rc = d_sa.upload(job.snp_alt)) return rc;
+        if (int rc = d_sc.upload(job.snp_contig)) return rc;
+        if (int rc = d_cb.upload(job.contig_snp_base)) return rc;
+        if (int rc = d_po.upload(job.plane_off)) return rc;
+        if (int rc = d_n.upload(job.n_reads)) return rc;
+        if (int rc = d_w.upload(job.words)) return rc;
+        if (int rc = d_oo.upload(job.out_off)) return rc;
+        const size_t pbytes = (size_t)job.plane_total * sizeof(uint64_t);
+        if (int rc = d_alt.alloc(pbytes)) return rc;
+        if (int rc = d_ref.alloc(pbytes)) return rc;
+        if (int rc = d_sim.alloc((size_t)job.out_total * sizeof(int32_t))) return rc;
+        if (int rc = d_diff.alloc((size_t)job.out_total * sizeof(int32_t))) return rc;
+        HS_HIP(hipMemsetAsync(d_alt.p, 0, pbytes ? pbytes : 8, stream));
+        HS_HIP(hipMemsetAsync(d_ref.p, 0, pbytes ? pbytes : 8, stream));
+        if (int rc = hs_snp_planes(d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(), d_sr.as<uint8_t>(), d_sa.as<uint8_t>(),
+                                   d_sc.as<int32_t>(), d_cb.as<int64_t>(), d_po.as<int64_t>(), d_w.as<int32_t>(), (int32_t)job.snp_ref.size(),
+                                   d_alt.as<uint64_t>(), d_ref.as<uint64_t>(), stream)) return rc;
         EventPair ev; if (int rc = ev.init()) return rc;
         HS_HIP(hipEventRecord(ev.a, stream));
         if (int rc = simdiff_launch(d_alt.as<uint64_t>(), d_ref.as<uint64_t>(), d_po.as<int64_t>(), d_n.as<int32_t>(), d_w.as<int32_t>(),
-                                    d_oo.as<int64_t>(), n_reads, d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, t_c, t_i, t_j)) return rc;
+                                    d_oo.as<int64_t>(), job.n_reads, d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, t_c, t_i, t_j)) return rc;
         HS_HIP(hipEventRecord(ev.b, stream));
-        *sim = nullptr; *diff = nullptr;   // resident: consumed by read_graphs()
-        float m = 0; if (int rc = ev.ms(&m)) return rc;
+        float m = 0; if (int rc = ev.ms(&m)) return rc;   // also keeps the temporaries alive until the kernels are done
         if (k_ms) *k_ms += m;
         return HS_OK;
     }
@@ -807,11 +850,14 @@ struct HipSrOps : hs::SrDeviceOps {
             }
         }
         std::vector<int64_t> wbase(ch.win_label_base.begin(), ch.win_label_base.end() - 1);
-        DBuf d_col_off, d_col_idx, d_col_code, d_ig, d_ilb, d_seed, d_local, d_wk, d_wn, d_wgn, d_wgf, d_wlb, d_wob, d_lab2, d_lab3, d_agg,
+        DBuf d_ig, d_ilb, d_seed, d_local, d_wk, d_wn, d_wgn, d_wgf, d_wlb, d_wob, d_lab2, d_lab3, d_agg,
             d_s1, d_s2, d_s3;
-        if (int rc = d_col_off.upload(ch.col_off)) return rc;
-        if (int rc = d_col_idx.upload(ch.col_idx)) return rc;
-        if (int rc = d_col_code.upload(ch.col_code)) return rc;
+        if (resident_cols != &ch) {   // normally uploaded by simdiff_columns already
+            if (int rc = d_col_off.upload(ch.col_off)) return rc;
+            if (int rc = d_col_idx.upload(ch.col_idx)) return rc;
+            if (int rc = d_col_code.upload(ch.col_code)) return rc;
+            resident_cols = &ch;
+        }
         if (int rc = d_ig.upload(ig)) return rc;
         if (int rc = d_ilb.upload(ilb)) return rc;
         if (int rc = d_seed.upload(ch.seed_col)) return rc;

@@ -98,7 +98,7 @@ void hs_parallel_for(int n, int n_threads, const std::function<void(int)>& f) { 
 void free_cv_result(hs_cv_result* r) {
     if (!r) return;
     std::free(r->mean_distance); std::free(r->depth); std::free(r->snp_off); std::free(r->snp_pos); std::free(r->snp_ref);
-    std::free(r->snp_alt); std::free(r->col_off); std::free(r->col_idx); std::free(r->col_code);
+    std::free(r->snp_alt); std::free(r->snp_n_ref); std::free(r->snp_n_alt); std::free(r->col_off); std::free(r->col_idx); std::free(r->col_code);
     std::free(r);
 }
 void free_sr_result(hs_sr_result* r) {
@@ -191,7 +191,8 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
     for (int c = 0; c <= C; ++c) contig_sel_off[(size_t)c] = sel.contig_sel_off[(size_t)(c0 + c)] - g0;
     const int32_t* col_idx = nullptr;
     const uint8_t* col_code = nullptr;
-    if (int rc = dev.gather(sel_contig, sel_pos, col_off, &col_idx, &col_code, &k_ms[2])) return rc;
+    const hs_coltop* col_top = nullptr;
+    if (int rc = dev.gather(sel_contig, sel_pos, col_off, &col_idx, &col_code, &col_top, &k_ms[2])) return rc;
     const double t_dev_done = now_ms();
     Laps laps("cv glue");
 
@@ -207,6 +208,7 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         for (int64_t i = s0; i <= s1; ++i) cs.off[(size_t)(i - s0)] = col_off[(size_t)i] - col_off[(size_t)s0];
         cs.idx = col_idx + col_off[(size_t)s0];
         cs.code = col_code + col_off[(size_t)s0];
+        cs.top = col_top + s0;
         const size_t n = cs.pos.size();
         cs.k0.resize(n); cs.k1.resize(n); cs.c0.resize(n); cs.c1.resize(n); cs.c2.resize(n);
         for (int64_t f = 0; f < s1 - s0; f += 256) chunks.push_back(std::make_pair(c, (int)f));
@@ -279,6 +281,8 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
     R->snp_pos = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t));
     R->snp_ref = (uint8_t*)std::malloc(std::max<int64_t>(1, S));
     R->snp_alt = (uint8_t*)std::malloc(std::max<int64_t>(1, S));
+    R->snp_n_ref = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t));
+    R->snp_n_alt = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t));
     R->col_off = (int64_t*)std::malloc((S + 1) * sizeof(int64_t));
     R->col_idx = (int32_t*)std::malloc(std::max<int64_t>(1, E) * sizeof(int32_t));
     R->col_code = (uint8_t*)std::malloc(std::max<int64_t>(1, E));
@@ -289,6 +293,7 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         for (int ci : res[(size_t)c].snp_col) {
             const int64_t n = cs.off[(size_t)ci + 1] - cs.off[(size_t)ci];
             R->snp_pos[s] = cs.pos[(size_t)ci]; R->snp_ref[s] = cs.k0[(size_t)ci]; R->snp_alt[s] = cs.k1[(size_t)ci];
+            R->snp_n_ref[s] = cs.c0[(size_t)ci]; R->snp_n_alt[s] = cs.c1[(size_t)ci];
             std::memcpy(R->col_idx + e, cs.idx + cs.off[(size_t)ci], (size_t)n * sizeof(int32_t));
             std::memcpy(R->col_code + e, cs.code + cs.off[(size_t)ci], (size_t)n);
             e += n; s++;
@@ -340,34 +345,45 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         s.N = contigs[c].n_reads;
         s.low_memory_now = lowmem || sr_coverage_above_1000(contigs[c]);   // separate_reads.cpp:1515-1518
         if (contigs[c].n_snps == 0) return;                                 // :1522-1524
-        if (!s.low_memory_now) sr_build_planes(s);
+        s.words = (contigs[c].n_snps + 63) / 64;
         s.perm = shuffled_order(s.N, seed);
     });
 
-    laps.lap("planes+perm");
-    // ---- K5: sim / diff for every contig on the matrix path ----
+    laps.lap("perm");
+    // ---- the SNP columns of the batch, concatenated once: K5a/K5 (sim / diff) now, Chinese-Whispers seeding later ----
+    CwChain ch;
+    std::vector<int64_t> col_base_of_contig((size_t)C, 0);
     {
-        const double t0 = now_ms();
-        std::vector<int64_t> plane_off((size_t)C, 0), out_off((size_t)C, 0);
-        std::vector<int32_t> nreads((size_t)C, 0), words((size_t)C, 0);
-        int64_t pw = 0, ow = 0;
+        SimdiffJob job;
+        job.cols = &ch;
+        job.contig_snp_base.assign((size_t)C, 0); job.plane_off.assign((size_t)C, 0); job.out_off.assign((size_t)C, 0);
+        job.n_reads.assign((size_t)C, 0); job.words.assign((size_t)C, 0);
+        ch.col_off.assign(1, 0);
+        int64_t n_ent = 0, n_col = 0;
+        for (int c = 0; c < C; ++c) { n_col += contigs[c].n_snps; if (contigs[c].n_snps) n_ent += contigs[c].col_off[contigs[c].n_snps] - contigs[c].col_off[0]; }
+        ch.col_off.reserve((size_t)n_col + 1); ch.col_idx.reserve((size_t)n_ent); ch.col_code.reserve((size_t)n_ent);
+        job.snp_ref.reserve((size_t)n_col); job.snp_alt.reserve((size_t)n_col); job.snp_contig.reserve((size_t)n_col);
         for (int c = 0; c < C; ++c) {
-            if (contigs[c].n_snps == 0 || st[(size_t)c].low_memory_now) continue;
-            plane_off[(size_t)c] = pw; out_off[(size_t)c] = ow;
-            nreads[(size_t)c] = st[(size_t)c].N; words[(size_t)c] = st[(size_t)c].words;
-            pw += (int64_t)st[(size_t)c].N * st[(size_t)c].words;
-            ow += (int64_t)st[(size_t)c].N * st[(size_t)c].N;
+            col_base_of_contig[(size_t)c] = (int64_t)ch.col_off.size() - 1;
+            job.contig_snp_base[(size_t)c] = col_base_of_contig[(size_t)c];
+            const hs_sr_contig& hc = contigs[c];
+            if (hc.n_snps == 0) continue;
+            const int64_t e_base = (int64_t)ch.col_idx.size(), o0 = hc.col_off[0];   // col_off need not start at 0
+            for (int s = 0; s < hc.n_snps; ++s) ch.col_off.push_back(e_base + hc.col_off[s + 1] - o0);
+            ch.col_idx.insert(ch.col_idx.end(), hc.col_idx + o0, hc.col_idx + hc.col_off[hc.n_snps]);
+            ch.col_code.insert(ch.col_code.end(), hc.col_code + o0, hc.col_code + hc.col_off[hc.n_snps]);
+            job.snp_ref.insert(job.snp_ref.end(), hc.snp_ref, hc.snp_ref + hc.n_snps);
+            job.snp_alt.insert(job.snp_alt.end(), hc.snp_alt, hc.snp_alt + hc.n_snps);
+            job.snp_contig.insert(job.snp_contig.end(), (size_t)hc.n_snps, c);
+            if (st[(size_t)c].low_memory_now) continue;
+            job.plane_off[(size_t)c] = job.plane_total; job.out_off[(size_t)c] = job.out_total;
+            job.n_reads[(size_t)c] = st[(size_t)c].N; job.words[(size_t)c] = st[(size_t)c].words;
+            job.plane_total += (int64_t)st[(size_t)c].N * st[(size_t)c].words;
+            job.out_total += (int64_t)st[(size_t)c].N * st[(size_t)c].N;
         }
-        if (ow > 0) {
-            std::vector<uint64_t> alt((size_t)pw), ref((size_t)pw);
-            for (int c = 0; c < C; ++c) {
-                if (!nreads[(size_t)c]) continue;
-                std::copy(st[(size_t)c].alt_planes.begin(), st[(size_t)c].alt_planes.end(), alt.begin() + plane_off[(size_t)c]);
-                std::copy(st[(size_t)c].ref_planes.begin(), st[(size_t)c].ref_planes.end(), ref.begin() + plane_off[(size_t)c]);
-            }
-            const int32_t* sim = nullptr; const int32_t* diff = nullptr;   // stay with the device interface
-            if (int rc = dev.simdiff(alt, ref, plane_off, nreads, words, out_off, ow, &sim, &diff, &k_ms[0])) return rc;
-        }
+        laps.lap("columns");
+        const double t0 = now_ms();
+        if (int rc = dev.simdiff_columns(job, &k_ms[0])) return rc;
         dev_ms += now_ms() - t0;
     }
 
@@ -471,20 +487,8 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
             if (st[(size_t)c].windows[w].has_snps) wrefs.push_back(WRef{c, (int)w, 0});
 
     // ---- the three dependent Chinese-Whispers waves, device resident (see CwChain) ----
-    CwChain ch;
     std::vector<int64_t> w2_base(wrefs.size(), -1);
     {
-        std::vector<int64_t> col_base_of_contig((size_t)C, 0);
-        ch.col_off.assign(1, 0);
-        for (int c = 0; c < C; ++c) {
-            col_base_of_contig[(size_t)c] = (int64_t)ch.col_off.size() - 1;
-            const hs_sr_contig& hc = contigs[c];
-            if (hc.n_snps == 0) continue;
-            const int64_t e_base = (int64_t)ch.col_idx.size(), o0 = hc.col_off[0];   // col_off need not start at 0
-            for (int s = 0; s < hc.n_snps; ++s) ch.col_off.push_back(e_base + hc.col_off[s + 1] - o0);
-            ch.col_idx.insert(ch.col_idx.end(), hc.col_idx + o0, hc.col_idx + hc.col_off[hc.n_snps]);
-            ch.col_code.insert(ch.col_code.end(), hc.col_code + o0, hc.col_code + hc.col_off[hc.n_snps]);
-        }
         ch.win_seed_begin.assign(1, 0);
         ch.win_label_base.assign(1, 0);
         for (size_t i = 0; i < wrefs.size(); ++i) {
@@ -604,7 +608,8 @@ int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, int c0, int c1, const hs_c
         std::vector<char> keep((size_t)(s1 - s0), 1);
         for (int64_t s = s0; s < s1; ++s) {
             int maj = 0, sec = 0;
-            for (int64_t e = cv->col_off[s]; e < cv->col_off[s + 1]; ++e) { if (cv->col_code[e] == cv->snp_ref[s]) maj++; else if (cv->col_code[e] == cv->snp_alt[s]) sec++; }
+            if (cv->snp_n_ref && cv->snp_n_alt) { maj = cv->snp_n_ref[s]; sec = cv->snp_n_alt[s]; }   // counted by stage 3 already
+            else for (int64_t e = cv->col_off[s]; e < cv->col_off[s + 1]; ++e) { if (cv->col_code[e] == cv->snp_ref[s]) maj++; else if (cv->col_code[e] == cv->snp_alt[s]) sec++; }
             if (!((float)sec >= rsa * (float)(maj + sec))) { keep[(size_t)(s - s0)] = 0; all_kept = false; }
         }
         hs_sr_contig& h = hc[(size_t)c];

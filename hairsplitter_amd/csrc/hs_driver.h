@@ -37,11 +37,12 @@ struct CvDeviceOps {
     // k_ms[3] = cigar scan alone (k_ms[0] then is the pileup kernel alone)
     virtual int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, std::vector<int64_t>& sel_gpos,
                                   std::vector<int32_t>& sel_depth, float k_ms[4]) = 0;
-    // K3: columns of the selected positions; the two output arrays (col_off.back() entries) are owned by the
-    // implementation and stay valid until the next gather call or its destruction
+    // K3: columns of the selected positions, and K3b: their top-3 (tie = 1: the host must resolve the column in the
+    // reference's tie order). The output arrays are owned by the implementation and stay valid until the next gather
+    // call or its destruction
     virtual int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos,
                        const std::vector<int64_t>& col_off, const int32_t** col_idx, const uint8_t** col_code,
-                       float* k_ms) = 0;
+                       const hs_coltop** top, float* k_ms) = 0;
     // K4: loops C and D of keep_only_robust_variants on the columns of the last gather(); keep[i] for column i
     virtual int column_partition_test(const CvPartitionTest& t, std::vector<uint8_t>& keep, float* k_ms) = 0;
 };
@@ -84,6 +85,17 @@ struct CwChain {
     std::vector<int64_t> win_label_base;   // [W+1] offset of the window's N output labels
 };
 
+// K5 input: the SNP columns of every contig of the batch (concatenated in CwChain::col_*) with their two alleles
+struct SimdiffJob {
+    const CwChain* cols = nullptr;
+    std::vector<uint8_t> snp_ref, snp_alt;       // per column
+    std::vector<int32_t> snp_contig;             // per column
+    std::vector<int64_t> contig_snp_base;        // [C] first column of each contig
+    std::vector<int64_t> plane_off, out_off;     // [C] offsets of the contig's bit rows (uint64 words) / matrices (int32)
+    std::vector<int32_t> n_reads, words;         // [C]; n_reads == 0: contig not on the matrix path
+    int64_t plane_total = 0, out_total = 0;
+};
+
 // K6 input: the clustering windows whose graph comes from the sim/diff matrices of the last simdiff() call
 struct ReadGraphJob {
     std::vector<int32_t> win_contig;     // contig index (as passed to simdiff) of every window
@@ -102,11 +114,9 @@ struct SrDeviceOps {
     // K6: create_read_graph_matrix for every window of the job
     virtual int read_graphs(const ReadGraphJob& job, ReadGraphResult& res, float* k_ms) = 0;
     virtual int cw_chain(const CwChain& chain, std::vector<int32_t>& labels, float k_ms[3]) = 0;
-    // K5 for all contigs with n_reads[c] > 0; the matrices (contig c at out_off[c]) stay with the implementation for
-    // read_graphs(); *sim / *diff may come back null (the HIP implementation keeps them in HBM)
-    virtual int simdiff(const std::vector<uint64_t>& alt, const std::vector<uint64_t>& ref, const std::vector<int64_t>& plane_off,
-                        const std::vector<int32_t>& n_reads, const std::vector<int32_t>& words, const std::vector<int64_t>& out_off,
-                        int64_t out_total, const int32_t** sim, const int32_t** diff, float* k_ms) = 0;
+    // K5a + K5: bit-planes from the SNP columns, then sim / diff for every contig with n_reads[c] > 0. The columns (the same
+    // object cw_chain() receives later) and the matrices stay with the implementation.
+    virtual int simdiff_columns(const SimdiffJob& job, float* k_ms) = 0;
     virtual int set_graphs(const CwGraphSet& g) = 0;
     virtual int cw(CwWave& wave, float* k_ms) = 0;
 };

@@ -19,6 +19,7 @@ struct ColumnSet {
     std::vector<int64_t> off;        // [n+1]
     const int32_t* idx = nullptr;    // read indices (ascending inside a column), base pointer of the batch
     const uint8_t* code = nullptr;
+    const hs_coltop* top = nullptr;  // device top-3 of every column (K3b); tie = 1 -> resolved here in the reference's order
     // exact top-3 of call_variants.cpp:497-507 (reference tie order), filled by resolve_columns()
     std::vector<uint8_t> k0, k1;
     std::vector<int32_t> c0, c1, c2;

@@ -65,9 +65,15 @@ static void exact_top3(const uint8_t* code, int n, uint8_t& k0, uint8_t& k1, int
 }
 
 void resolve_columns(ColumnSet& cs, int first, int last) {
-    for (int i = first; i < last; ++i)
+    for (int i = first; i < last; ++i) {
+        if (cs.top && !cs.top[i].tie) {   // all three counts distinct: no order of equal keys involved
+            cs.k0[(size_t)i] = cs.top[i].k0; cs.k1[(size_t)i] = cs.top[i].k1;
+            cs.c0[(size_t)i] = cs.top[i].c0; cs.c1[(size_t)i] = cs.top[i].c1; cs.c2[(size_t)i] = cs.top[i].c2;
+            continue;
+        }
         exact_top3(cs.code + cs.off[(size_t)i], (int)(cs.off[(size_t)i + 1] - cs.off[(size_t)i]), cs.k0[(size_t)i], cs.k1[(size_t)i],
                    cs.c0[(size_t)i], cs.c1[(size_t)i], cs.c2[(size_t)i]);
+    }
 }
 
 // most frequent non-reference code among `codes` restricted to the entries flagged in `take`

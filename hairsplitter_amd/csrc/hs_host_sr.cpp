@@ -32,23 +32,6 @@ std::vector<int32_t> shuffled_order(int n, uint32_t seed) {
     return order;
 }
 
-void sr_build_planes(SrContigState& st) {
-    const hs_sr_contig& c = *st.c;
-    st.N = c.n_reads;
-    st.words = (c.n_snps + 63) / 64;
-    st.alt_planes.assign((size_t)st.N * st.words, 0ull);
-    st.ref_planes.assign((size_t)st.N * st.words, 0ull);
-    for (int s = 0; s < c.n_snps; ++s) {
-        const uint64_t bit = 1ull << (s & 63);
-        const int w = s >> 6;
-        for (int64_t e = c.col_off[s]; e < c.col_off[s + 1]; ++e) {
-            const int r = c.col_idx[e];
-            if (c.col_code[e] == c.snp_ref[s]) st.ref_planes[(size_t)r * st.words + w] |= bit;
-            else if (c.col_code[e] == c.snp_alt[s]) st.alt_planes[(size_t)r * st.words + w] |= bit;
-        }
-    }
-}
-
 // neighbour selection shared by both graph builders: separate_reads.cpp:769-815 (== :633-670)
 static void pick_neighbors_sorted(std::vector<std::pair<int, float>>& smallest, const uint8_t* mask, float error_rate, std::vector<int>& picked) {
     std::sort(smallest.begin(), smallest.end(), [](const std::pair<int, float>& a, const std::pair<int, float>& b) { return a.second > b.second; });

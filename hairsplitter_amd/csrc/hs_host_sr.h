@@ -13,7 +13,6 @@ struct SrContigState {
     int N = 0;
     int words = 0;
     bool low_memory_now = false;
-    std::vector<uint64_t> alt_planes, ref_planes;   // [N][words] bit-planes (second_base / ref_base per SNP)
     std::vector<SrGraph> graphs;
     int empty_graph = -1;
     std::vector<struct SrWindowPlan> windows;
@@ -21,7 +20,6 @@ struct SrContigState {
 };
 
 std::vector<int32_t> shuffled_order(int n, uint32_t seed);
-void sr_build_planes(SrContigState& st);
 void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool low_memory);
 void sr_build_window_graph(SrContigState& st, int window, float error_rate);   // low-memory path only
 // one row of create_read_graph_matrix in the reference's own way (std::sort + walk, separate_reads.cpp:745-815): used for

@@ -31,6 +31,16 @@ static __device__ __forceinline__ int wave_scan_incl(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
     return v;
 }
+static __device__ __forceinline__ int wave_max_i32(int v) {
+    int o;
+    o = __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false); v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false); v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false); v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false); v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false); v = o > v ? o : v;
+    o = __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false); v = o > v ? o : v;
+    return __builtin_amdgcn_readlane(v, 63);
+}
 static __device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_incl(v), 63); }
 // value of the lane to the left (lane 0 receives `fill`)
 static __device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
@@ -425,6 +435,36 @@ __global__ __launch_bounds__(256) void k_gather_columns(
             col_code[w + rank] = pile[pile_off[n] + (p - ps)];
         }
         w += __popcll(m);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5a SNP bit-planes: the 0/1 matrices A (read carries second_base) and R (read carries ref_base) of
+// list_similarities_and_differences_between_reads3 (separate_reads.cpp:386-405) as bit rows, built from the SNP columns that
+// are resident for the Chinese-Whispers seeding anyway. One wavefront per SNP column, one atomic OR per entry; the planes
+// must be zero on entry. Contigs with words[c] == 0 (low-memory path, no SNPs) are skipped.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_snp_planes(
+    const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
+    const uint8_t* __restrict__ snp_ref, const uint8_t* __restrict__ snp_alt, const int32_t* __restrict__ snp_contig,
+    const int64_t* __restrict__ contig_snp_base, const int64_t* __restrict__ plane_off, const int32_t* __restrict__ words, int n_snps,
+    unsigned long long* __restrict__ alt, unsigned long long* __restrict__ ref) {
+    const int lane = lane_id();
+    const int s = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (s >= n_snps) return;
+    const int c = snp_contig[s];
+    const int W = words[c];
+    if (W == 0) return;
+    const int sl = (int)(s - contig_snp_base[c]);
+    const unsigned long long bit = 1ull << (sl & 63);
+    const int64_t base = plane_off[c] + (sl >> 6);
+    const int rb = snp_ref[s], ab = snp_alt[s];
+    const int64_t e0 = col_off[s], e1 = col_off[s + 1];
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+        const int code = col_code[e];
+        const int64_t at = base + (int64_t)col_idx[e] * W;
+        if (code == rb) atomicOr(&ref[at], bit);
+        else if (code == ab) atomicOr(&alt[at], bit);
     }
 }
 
@@ -976,6 +1016,52 @@ __global__ __launch_bounds__(256) void k_column_partition_test(
         }
     }
     if (lane == 0) keep[col] = kept ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3b top-3 of the extracted columns (call_variants.cpp:477-507 for the selected positions only): one wavefront per column,
+// histogram over the 125 codes in LDS, three wave arg-max rounds. The reference orders equal counts by robin_hood iteration
+// order + std::sort; the device reports such columns (tie = 1: two largest counts equal, second and third equal, no second
+// allele, or a byte outside 33..157) and the host resolves those exactly.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_column_top3(const int64_t* __restrict__ col_off, const uint8_t* __restrict__ col_code, int n_cols,
+                                                     hs_coltop_dev* __restrict__ out) {
+    __shared__ int s_hist[4][128];
+    const int lane = lane_id();
+    const int wv = (int)(threadIdx.x >> 6);
+    const int col = (int)blockIdx.x * 4 + wv;
+    if (col >= n_cols) return;                   // wave-uniform
+    int* __restrict__ h = s_hist[wv];
+    h[lane] = 0; h[lane + 64] = 0;
+    wave_lds_sync();
+    const int64_t b = col_off[col];
+    const int n = (int)(col_off[col + 1] - b);
+    bool odd = false;
+    for (int j = lane; j < n; j += 64) {
+        const int c = (int)col_code[b + j] - 33;
+        if (c >= 0 && c < HS_NBINS) atomicAdd(&h[c], 1); else odd = true;
+    }
+    wave_lds_sync();
+    // key = count << 8 | (255 - bin): larger count first, then smaller code (only used when the counts differ)
+    int k_a = (h[lane] << 8) | (255 - lane), k_b = (h[lane + 64] << 8) | (255 - (lane + 64));
+    int top[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int mine = k_a > k_b ? k_a : k_b;
+        const int best = wave_max_i32(mine);
+        top[r] = best;
+        if (k_a == best) k_a = -1;
+        if (k_b == best) k_b = -1;
+    }
+    const bool any_odd = __ballot(odd) != 0ull;
+    if (lane == 0) {
+        hs_coltop_dev o;
+        o.c0 = top[0] >> 8; o.c1 = top[1] >> 8; o.c2 = top[2] >> 8;
+        o.k0 = (uint8_t)(33 + 255 - (top[0] & 255)); o.k1 = (uint8_t)(33 + 255 - (top[1] & 255));
+        o.tie = (uint8_t)((any_odd || o.c0 == o.c1 || o.c1 == o.c2 || o.c1 == 0) ? 1 : 0);
+        o.pad = 0;
+        out[col] = o;
+    }
 }
 
 // small utility: apply host-resolved "swap top-2" decisions to the column statistics

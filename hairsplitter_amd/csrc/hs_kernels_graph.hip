@@ -12,16 +12,6 @@
 
 namespace hsdev {
 
-static __device__ __forceinline__ int wave_max_i32(int v) {
-    int o;
-    o = __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false); v = o > v ? o : v;
-    o = __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false); v = o > v ? o : v;
-    o = __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false); v = o > v ? o : v;
-    o = __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false); v = o > v ? o : v;
-    o = __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false); v = o > v ? o : v;
-    o = __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false); v = o > v ? o : v;
-    return __builtin_amdgcn_readlane(v, 63);
-}
 // distances live in [0, 1]: their bit patterns order like the values
 static __device__ __forceinline__ float wave_max_f01(float v) { return __int_as_float(wave_max_i32(__float_as_int(v))); }
 

@@ -119,6 +119,17 @@ int hs_gather_columns(const uint8_t* d_pile, const int64_t* d_pile_off, const in
                       int32_t n_sel, int32_t* d_col_idx, uint8_t* d_col_code, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K3b -- the two most frequent codes and the three largest counts of every extracted column (call_variants.cpp:477-507
+ * restricted to the selected positions). tie = 1 where the reference's order of equal counts (robin_hood iteration order +
+ * std::sort) matters or the column has no second allele: the caller resolves those columns on the host.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hs_coltop {
+    int32_t c0, c1, c2;
+    uint8_t k0, k1, tie, pad;
+} hs_coltop;
+int hs_column_top3(const int64_t* d_col_off, const uint8_t* d_col_code, int32_t n_cols, hs_coltop* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K4 -- SNP column x partition correlation.  Replaces distance(Partition&, Column&) + computeChiSquare
  * (call_variants.cpp:778-967, :1135-1163) as used by loops C and D of keep_only_robust_variants (:721-764).
  * Columns are the CSR produced by hs_gather_columns; col_k0 / col_k1 their two most frequent codes in the reference's
@@ -132,6 +143,16 @@ int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx,
                              const int32_t* d_col_c1, const uint8_t* d_col_is_cand, int32_t n_cols,
                              const int32_t* d_part_off, const int64_t* d_part_state_off, const int8_t* d_part_state,
                              uint8_t* d_keep, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K5a -- SNP bit-planes for K5 from the SNP columns (separate_reads.cpp:386-405): bit s of row r of d_ref / d_alt = read r
+ * carries snp_ref[s] / snp_alt[s]. Columns of all contigs concatenated (CSR); snp_contig[s] = contig of column s,
+ * contig_snp_base[c] = first column of contig c; plane_off / words as for hs_simdiff (words[c] == 0 skips the contig).
+ * The planes must be zeroed by the caller.
+ * ---------------------------------------------------------------------------------------------- */
+int hs_snp_planes(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code, const uint8_t* d_snp_ref,
+                  const uint8_t* d_snp_alt, const int32_t* d_snp_contig, const int64_t* d_contig_snp_base,
+                  const int64_t* d_plane_off, const int32_t* d_words, int32_t n_snps, uint64_t* d_alt, uint64_t* d_ref, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K5 -- read x read similarity / difference.  Replaces list_similarities_and_differences_between_reads3
@@ -206,6 +227,8 @@ typedef struct hs_cv_result {
     int32_t* snp_pos;          /* [S] */
     uint8_t* snp_ref;          /* [S] */
     uint8_t* snp_alt;          /* [S] */
+    int32_t* snp_n_ref;        /* [S] reads carrying snp_ref / snp_alt (what parse_column_file recounts, separate_reads.cpp:151-167) */
+    int32_t* snp_n_alt;        /* [S] */
     int64_t* col_off;          /* [S+1] */
     int32_t* col_idx;          /* read indices, ascending */
     uint8_t* col_code;         /* pileup codes */

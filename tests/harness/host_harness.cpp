@@ -77,8 +77,11 @@ struct OracleCvOps : hs::CvDeviceOps {
         return 0;
     }
     int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
-               const int32_t** col_idx_out, const uint8_t** col_code_out, float* k_ms) override {
+               const int32_t** col_idx_out, const uint8_t** col_code_out, const hs_coltop** top_out, float* k_ms) override {
         *k_ms = 0;
+        // every column is handed to the host's exact (reference order) resolution: the device's own top-3 is covered by the GPU tests
+        tops.assign(sel_pos.size(), hs_coltop{0, 0, 0, 0, 0, 1, 0});
+        *top_out = tops.data();
         last_sel_pos = sel_pos;
         col_idx.assign((size_t)col_off.back(), 0); col_code.assign((size_t)col_off.back(), 0);
         *col_idx_out = col_idx.data(); *col_code_out = col_code.data();
@@ -140,6 +143,7 @@ struct OracleCvOps : hs::CvDeviceOps {
         return 0;
     }
     std::vector<int32_t> last_sel_pos;
+    std::vector<hs_coltop> tops;
 };
 
 struct OracleSrOps : hs::SrDeviceOps {
@@ -147,26 +151,29 @@ struct OracleSrOps : hs::SrDeviceOps {
     std::vector<int32_t> sim, diff;
     uint32_t seed;
     explicit OracleSrOps(uint32_t s) : seed(s) {}
-    int simdiff(const std::vector<uint64_t>& alt, const std::vector<uint64_t>& ref, const std::vector<int64_t>& plane_off,
-                const std::vector<int32_t>& n_reads, const std::vector<int32_t>& words, const std::vector<int64_t>& out_off,
-                int64_t out_total, const int32_t** sim_out, const int32_t** diff_out, float* k_ms) override {
+    // K5a + K5 through the oracle's list_similarities_and_differences (separate_reads.cpp:374-433) on the job's SNP columns
+    int simdiff_columns(const hs::SimdiffJob& job, float* k_ms) override {
         (void)k_ms;
-        sd_off = out_off; sd_n = n_reads;
-        sim.assign((size_t)out_total, 0); diff.assign((size_t)out_total, 0);
-        *sim_out = sim.data(); *diff_out = diff.data();
-        for (size_t c = 0; c < n_reads.size(); ++c) {
-            const int N = n_reads[c], W = words[c];
-            for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) {
-                if (i == j) continue;
-                int s = 0, d = 0;
-                for (int w = 0; w < W; ++w) {
-                    const uint64_t ai = alt[(size_t)plane_off[c] + (size_t)i * W + w], ri = ref[(size_t)plane_off[c] + (size_t)i * W + w];
-                    const uint64_t aj = alt[(size_t)plane_off[c] + (size_t)j * W + w], rj = ref[(size_t)plane_off[c] + (size_t)j * W + w];
-                    s += 3 * __builtin_popcountll(ai & aj) + __builtin_popcountll(ri & rj);
-                    d += __builtin_popcountll(ai & rj) + __builtin_popcountll(ri & aj);
-                }
-                sim[(size_t)out_off[c] + (size_t)i * N + j] = s; diff[(size_t)out_off[c] + (size_t)i * N + j] = d;
+        sd_off = job.out_off; sd_n = job.n_reads;
+        sim.assign((size_t)job.out_total, 0); diff.assign((size_t)job.out_total, 0);
+        const hs::CwChain& ch = *job.cols;
+        const int C = (int)job.n_reads.size();
+        for (int c = 0; c < C; ++c) {
+            const int N = job.n_reads[(size_t)c];
+            if (N == 0) continue;
+            const int64_t s0 = job.contig_snp_base[(size_t)c];
+            const int64_t s1 = c + 1 < C ? job.contig_snp_base[(size_t)c + 1] : (int64_t)job.snp_ref.size();
+            std::vector<hso::Column> snps;
+            for (int64_t s = s0; s < s1; ++s) {
+                hso::Column col;
+                col.ref_base = job.snp_ref[(size_t)s]; col.second_base = job.snp_alt[(size_t)s];
+                for (int64_t e = ch.col_off[(size_t)s]; e < ch.col_off[(size_t)s + 1]; ++e) { col.readIdxs.push_back((unsigned)ch.col_idx[(size_t)e]); col.content.push_back(ch.col_code[(size_t)e]); }
+                snps.push_back(std::move(col));
             }
+            std::vector<int> S, D;
+            hso::list_similarities_and_differences(snps, N, S, D);
+            std::copy(S.begin(), S.end(), sim.begin() + job.out_off[(size_t)c]);
+            std::copy(D.begin(), D.end(), diff.begin() + job.out_off[(size_t)c]);
         }
         return 0;
     }

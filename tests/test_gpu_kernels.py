@@ -104,6 +104,32 @@ def test_gather_columns(batch):
         assert code[col_off[k]:col_off[k + 1]].tolist() == exp_code
 
 
+def test_column_top3_of_extracted_columns(batch):
+    """K3b: where it reports no tie its result is the reference's (call_variants.cpp:477-507); ties are flagged, not guessed"""
+    from hairsplitter_amd import api
+    flat, t = batch
+    pile, _ = api.pileup(t, flat)
+    _, sel_g, sel_d = api.column_stats(t, flat, pile, min_second=2)
+    order = np.argsort(sel_g)
+    sel_g = sel_g[order]; sel_d = sel_d[order]
+    ctg = np.searchsorted(flat.contig_off, sel_g, side="right") - 1
+    pos = sel_g - flat.contig_off[ctg]
+    col_off, _, code = api.gather_columns(t, flat, pile, ctg, pos, sel_d)
+    c0, c1, c2, k0, k1, tie = api.column_top3(col_off, code)
+    pile_h = pile.cpu().numpy()
+    n_checked = 0
+    for c in range(flat.n_contigs):
+        ek0, ek1, ec0, ec1, ec2, _ = ol.column_top3(flat, pile_h, c)
+        for i in np.flatnonzero(ctg == c):
+            p = int(pos[i])
+            assert (c0[i], c1[i], c2[i]) == (ec0[p], ec1[p], ec2[p])
+            distinct = ec0[p] != ec1[p] and ec1[p] != ec2[p] and ec1[p] != 0
+            assert bool(tie[i]) == (not distinct)
+            if not tie[i]:
+                assert (k0[i], k1[i]) == (ek0[p], ek1[p]); n_checked += 1
+    assert n_checked > 0
+
+
 def test_stage3_result_equals_oracle_pipeline(batch, built):
     """hs_cv_run on the resident batch: SNP positions, ref/alt codes and columns equal the oracle's .col."""
     import subprocess, tempfile
@@ -207,6 +233,8 @@ def test_simdiff_matches_oracle(built):
                     ref[col_idx[e], s >> 6] |= np.uint64(1) << np.uint64(s & 63)
                 elif col_code[e] == snp_alt[s]:
                     alt[col_idx[e], s >> 6] |= np.uint64(1) << np.uint64(s & 63)
+        d_alt, d_ref = api.snp_planes(N, snp_ref, snp_alt, col_off, col_idx, col_code)      # K5a: the same planes, built on the device
+        assert np.array_equal(d_alt, alt) and np.array_equal(d_ref, ref)
         sim, diff = api.simdiff(alt, ref)
         o_sim, o_diff = ol.simdiff(N, snp_ref, snp_alt, col_off, col_idx, col_code)
         assert np.array_equal(sim, o_sim) and np.array_equal(diff, o_diff)
