@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_ROOT, "lib", "libhairsplitter_hip.so")
 SYMBOLS = [
     "hs_version", "hs_last_error", "hs_device_count", "hs_warmup", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
-    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_column_top3", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
+    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
     "hs_separate_reads_main",
@@ -543,7 +543,24 @@ def pileup(t, flat: FlatBatch, ev_per_task: int = 4096):
     return pile[:flat.aligned_bp], stats[:flat.n_rec]
 
 
-def column_stats(t, flat: FlatBatch, pile, min_second: int = 0, max_depth: int = 0):
+def tile_plan(flat: FlatBatch, device="cuda:0"):
+    """hs_tile_plan on the host arrays of a FlatBatch, uploaded: dict of device tensors (off int64, ent int64 [n,2] view of the 16-B entries, rec int32)"""
+    import torch
+    p_off = C.POINTER(C.c_int64)(); p_ent = C.c_void_p(); p_rec = C.POINTER(C.c_int32)(); n_tiles = C.c_int64(0)
+    _check(load().hs_tile_plan(_hp(flat.contig_off, C.c_int64), C.c_int32(flat.n_contigs), _hp(flat.contig_rec_off, C.c_int32),
+                               _hp(flat.rec_pos, C.c_int32), _hp(flat.rec_qend, C.c_int32), _hp(flat.pile_off, C.c_int64),
+                               C.byref(p_off), C.byref(p_ent), C.byref(p_rec), C.byref(n_tiles)))
+    nt = int(n_tiles.value)
+    off = np.ctypeslib.as_array(p_off, shape=(nt + 1,)).copy()
+    ne = int(off[-1])
+    ent = np.ctypeslib.as_array(C.cast(p_ent, C.POINTER(C.c_int64)), shape=(max(ne, 1) * 2,)).copy()
+    rec = np.ctypeslib.as_array(p_rec, shape=(max(ne, 1),)).copy()
+    load().hs_free_host(p_off); load().hs_free_host(p_ent); load().hs_free_host(p_rec)
+    return {"off": torch.from_numpy(off).to(device), "ent": torch.from_numpy(ent).to(device), "rec": torch.from_numpy(rec).to(device),
+            "h_off": off, "h_ent": ent.view(np.int32).reshape(-1, 4), "h_rec": rec}
+
+
+def column_stats(t, flat: FlatBatch, pile, min_second: int = 0, max_depth: int = 0, plan=None):
     """K2; returns a numpy structured view: key u8[4], cnt u16[5], depth u16 per position (and, when min_second > 0,
     the compact selection -- second count > min_second, or == min_second with no third allele -- as sorted global
     positions + depths)."""
@@ -559,8 +576,11 @@ def column_stats(t, flat: FlatBatch, pile, min_second: int = 0, max_depth: int =
         args = (C.c_int32(min_second), _p(cnt), _p(gpos), _p(dep), C.c_int32(total))
     else:
         args = (C.c_int32(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_int32(0))
-    _check(load().hs_column_stats(_p(pile), _p(t["pile_off"]), _p(t["rec_pos"]), _p(t["rec_qend"]), _p(t["contig_rec_off"]),
-                                  _p(t["contig_off"]), C.c_int32(flat.n_contigs), _p(out), *args, C.c_int32(max_depth), C.c_void_p(0)))
+    if plan is not None:
+        _check(load().hs_column_stats_tiled(_p(pile), _p(plan["off"]), _p(plan["ent"]), C.c_int64(total), _p(out), *args, C.c_int32(max_depth), C.c_void_p(0)))
+    else:
+        _check(load().hs_column_stats(_p(pile), _p(t["pile_off"]), _p(t["rec_pos"]), _p(t["rec_qend"]), _p(t["contig_rec_off"]),
+                                      _p(t["contig_off"]), C.c_int32(flat.n_contigs), _p(out), *args, C.c_int32(max_depth), C.c_void_p(0)))
     torch.cuda.synchronize()
     dt = np.dtype([("key", np.uint8, 4), ("cnt", np.uint16, 5), ("depth", np.uint16)])
     st = out[:total].cpu().numpy().view(dt).reshape(-1)
@@ -572,7 +592,7 @@ def column_stats(t, flat: FlatBatch, pile, min_second: int = 0, max_depth: int =
     return st
 
 
-def gather_columns(t, flat: FlatBatch, pile, sel_contig, sel_pos, depths):
+def gather_columns(t, flat: FlatBatch, pile, sel_contig, sel_pos, depths, plan=None):
     import torch
     require_gpu()
     dev = pile.device
@@ -583,8 +603,12 @@ def gather_columns(t, flat: FlatBatch, pile, sel_contig, sel_pos, depths):
     idx = torch.zeros(max(tot, 1), dtype=torch.int32, device=dev)
     code = torch.zeros(max(tot, 1), dtype=torch.uint8, device=dev)
     d_sc = torch.from_numpy(sel_contig).to(dev); d_sp = torch.from_numpy(sel_pos).to(dev); d_co = torch.from_numpy(col_off).to(dev)
-    _check(load().hs_gather_columns(_p(pile), _p(t["pile_off"]), _p(t["rec_pos"]), _p(t["rec_qend"]), _p(t["contig_rec_off"]),
-                                    _p(d_sc), _p(d_sp), _p(d_co), C.c_int32(n), _p(idx), _p(code), C.c_void_p(0)))
+    if plan is not None:
+        _check(load().hs_gather_columns_tiled(_p(pile), _p(plan["off"]), _p(plan["ent"]), _p(plan["rec"]), _p(t["contig_off"]), _p(t["contig_rec_off"]),
+                                              _p(d_sc), _p(d_sp), _p(d_co), C.c_int32(n), _p(idx), _p(code), C.c_void_p(0)))
+    else:
+        _check(load().hs_gather_columns(_p(pile), _p(t["pile_off"]), _p(t["rec_pos"]), _p(t["rec_qend"]), _p(t["contig_rec_off"]),
+                                        _p(d_sc), _p(d_sp), _p(d_co), C.c_int32(n), _p(idx), _p(code), C.c_void_p(0)))
     torch.cuda.synchronize()
     return col_off, idx[:tot].cpu().numpy(), code[:tot].cpu().numpy()
 

@@ -251,6 +251,83 @@ int hs_column_stats(const uint8_t* d_pile, const int64_t* d_pile_off, const int3
                                d_stats, min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap, max_depth, stream);
 }
 
+namespace {
+// the tile plan of include/hairsplitter_hip.h from host vectors
+void build_tile_plan(const int64_t* contig_off, int n_contigs, const int32_t* contig_rec_off, const int32_t* rec_pos, const int32_t* rec_qend,
+                     const int64_t* pile_off, std::vector<int64_t>& tile_off, std::vector<hs_tile_entry>& ent, std::vector<int32_t>& rec) {
+    const int64_t total = n_contigs > 0 ? contig_off[n_contigs] : 0;
+    const int64_t n_tiles = (total + 255) / 256;
+    tile_off.assign((size_t)n_tiles + 1, 0);
+    for (int c = 0; c < n_contigs; ++c)
+        for (int r = contig_rec_off[c]; r < contig_rec_off[c + 1]; ++r) {
+            if (rec_qend[r] <= rec_pos[r]) continue;
+            const int64_t gs = contig_off[c] + rec_pos[r], ge = contig_off[c] + rec_qend[r];
+            for (int64_t t = gs >> 8; t <= (ge - 1) >> 8; ++t) tile_off[(size_t)t + 1]++;
+        }
+    for (int64_t t = 0; t < n_tiles; ++t) tile_off[(size_t)t + 1] += tile_off[(size_t)t];
+    ent.resize((size_t)tile_off[(size_t)n_tiles]); rec.resize(ent.size());
+    std::vector<int64_t> fill(tile_off.begin(), tile_off.end() - 1);
+    for (int c = 0; c < n_contigs; ++c)
+        for (int r = contig_rec_off[c]; r < contig_rec_off[c + 1]; ++r) {   // ascending record id inside every tile
+            if (rec_qend[r] <= rec_pos[r]) continue;
+            const int64_t gs = contig_off[c] + rec_pos[r], ge = contig_off[c] + rec_qend[r];
+            for (int64_t t = gs >> 8; t <= (ge - 1) >> 8; ++t) {
+                const int64_t k = fill[(size_t)t]++;
+                const int32_t first = (int32_t)(gs - t * 256);
+                ent[(size_t)k] = hs_tile_entry{first, (int32_t)(ge - gs), pile_off[r] - first};
+                rec[(size_t)k] = r;
+            }
+        }
+}
+}  // namespace
+
+int hs_tile_plan(const int64_t* h_contig_off, int32_t n_contigs, const int32_t* h_contig_rec_off, const int32_t* h_rec_pos,
+                 const int32_t* h_rec_qend, const int64_t* h_pile_off, int64_t** tile_off, hs_tile_entry** tile_ent, int32_t** tile_rec,
+                 int64_t* n_tiles) {
+    if (!tile_off || !tile_ent || !tile_rec || !n_tiles || n_contigs < 0) { set_error("hs_tile_plan: bad arguments"); return HS_EINVAL; }
+    std::vector<int64_t> to; std::vector<hs_tile_entry> en; std::vector<int32_t> rc;
+    build_tile_plan(h_contig_off, n_contigs, h_contig_rec_off, h_rec_pos, h_rec_qend, h_pile_off, to, en, rc);
+    *n_tiles = (int64_t)to.size() - 1;
+    *tile_off = (int64_t*)std::malloc(to.size() * sizeof(int64_t));
+    *tile_ent = (hs_tile_entry*)std::malloc((en.size() + 1) * sizeof(hs_tile_entry));
+    *tile_rec = (int32_t*)std::malloc((rc.size() + 1) * sizeof(int32_t));
+    if (!*tile_off || !*tile_ent || !*tile_rec) { set_error("hs_tile_plan: out of memory"); return HS_EINVAL; }
+    std::memcpy(*tile_off, to.data(), to.size() * sizeof(int64_t));
+    if (!en.empty()) { std::memcpy(*tile_ent, en.data(), en.size() * sizeof(hs_tile_entry)); std::memcpy(*tile_rec, rc.data(), rc.size() * sizeof(int32_t)); }
+    return HS_OK;
+}
+
+int hs_column_stats_tiled(const uint8_t* d_pile, const int64_t* d_tile_off, const hs_tile_entry* d_tile_ent, int64_t total_len,
+                          hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth,
+                          int32_t sel_cap, int32_t max_depth, void* stream) {
+    if (int rc = require_device()) return rc;
+    if (total_len <= 0) return HS_OK;
+    static_assert(sizeof(hs_tile_entry) == sizeof(int4), "hs_tile_entry is read as one 16-byte load");
+    const int64_t grid = (total_len + 255) / 256;
+    const bool full = d_stats != nullptr;
+    const bool narrow = max_depth > 0 && max_depth <= 255;
+    using KernelT = void (*)(const uint8_t*, const int64_t*, const int4*, int64_t, hsdev::hs_colstat_dev*, int, int32_t*, int64_t*, int32_t*, int);
+    KernelT kernel = narrow ? (full ? (KernelT)hsdev::k_column_stats_tiled<1, true> : (KernelT)hsdev::k_column_stats_tiled<1, false>)
+                            : (full ? (KernelT)hsdev::k_column_stats_tiled<2, true> : (KernelT)hsdev::k_column_stats_tiled<2, false>);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_pile, d_tile_off, reinterpret_cast<const int4*>(d_tile_ent),
+                       total_len, reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
+int hs_gather_columns_tiled(const uint8_t* d_pile, const int64_t* d_tile_off, const hs_tile_entry* d_tile_ent, const int32_t* d_tile_rec,
+                            const int64_t* d_contig_off, const int32_t* d_contig_rec_off, const int32_t* d_sel_contig,
+                            const int32_t* d_sel_pos, const int64_t* d_col_off, int32_t n_sel, int32_t* d_col_idx, uint8_t* d_col_code,
+                            void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_sel <= 0) return HS_OK;
+    hipLaunchKernelGGL(hsdev::k_gather_columns_tiled, dim3((n_sel + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_pile, d_tile_off,
+                       reinterpret_cast<const int4*>(d_tile_ent), d_tile_rec, d_contig_off, d_contig_rec_off, d_sel_contig, d_sel_pos, d_col_off,
+                       n_sel, d_col_idx, d_col_code);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
 int hs_gather_columns(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
                       const int32_t* d_rec_qend, const int32_t* d_contig_rec_off, const int32_t* d_sel_contig,
                       const int32_t* d_sel_pos, const int64_t* d_col_off, int32_t n_sel, int32_t* d_col_idx,
@@ -400,7 +477,7 @@ struct hs_cv_batch {
     int32_t n_tasks = 0, ev_per_task = 4096, max_depth = 0;
     DBuf contig_seq, d_contig_off, read_seq, read_off, rec_read, d_rec_contig, d_rec_pos, rec_strand, rec_cig_off, cigar,
         d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, rec_chunk_off, chunk_scratch, task_rec, task_ev0,
-        sel_count, sel_gpos, sel_depth;
+        sel_count, sel_gpos, sel_depth, tile_off, tile_ent, tile_rec;
 };
 
 int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off, int32_t n_contigs,
@@ -476,6 +553,13 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
     up(b->rec_cig_off, h_rec_cig_off, sizeof(int64_t) * ((size_t)n_rec + 1));
     up(b->cigar, h_cigar, sizeof(uint32_t) * (size_t)h_rec_cig_off[n_rec]);
     up(b->d_pile_off, b->pile_off.data(), sizeof(int64_t) * b->pile_off.size());
+    {   // tile plan of K2 / K3
+        std::vector<int64_t> to; std::vector<hs_tile_entry> en; std::vector<int32_t> rc_;
+        build_tile_plan(b->contig_off.data(), n_contigs, b->contig_rec_off.data(), b->rec_pos.data(), b->rec_qend.data(), b->pile_off.data(), to, en, rc_);
+        up(b->tile_off, to.data(), sizeof(int64_t) * to.size());
+        up(b->tile_ent, en.data(), sizeof(hs_tile_entry) * en.size());
+        up(b->tile_rec, rc_.data(), sizeof(int32_t) * rc_.size());
+    }
     up(b->d_contig_rec_off, b->contig_rec_off.data(), sizeof(int32_t) * b->contig_rec_off.size());
     up(b->d_rec_qend, b->rec_qend.data(), sizeof(int32_t) * (size_t)n_rec);
     if (!rc) {   // launch plan of the pileup kernel
@@ -540,10 +624,9 @@ struct HipCvOps : hs::CvDeviceOps {
                                    b->n_tasks, b->ev_per_task, b->pile.as<uint8_t>(), b->rec_stats.as<int32_t>(), stream)) return rc;
         HS_HIP(hipEventRecord(e1.b, stream));
         HS_HIP(hipEventRecord(e2.a, stream));
-        if (int rc = column_stats_launch(b->pile.as<uint8_t>(), b->d_pile_off.as<int64_t>(), b->d_rec_pos.as<int32_t>(), b->d_rec_qend.as<int32_t>(),
-                                         b->d_contig_rec_off.as<int32_t>(), b->d_contig_off.as<int64_t>(), b->n_contigs, b->total_len,
-                                         nullptr, min_second, b->sel_count.as<int32_t>(), b->sel_gpos.as<int64_t>(),
-                                         b->sel_depth.as<int32_t>(), (int32_t)std::min<int64_t>(b->total_len, 0x7fffffff), b->max_depth, stream)) return rc;
+        if (int rc = hs_column_stats_tiled(b->pile.as<uint8_t>(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->total_len,
+                                           nullptr, min_second, b->sel_count.as<int32_t>(), b->sel_gpos.as<int64_t>(),
+                                           b->sel_depth.as<int32_t>(), (int32_t)std::min<int64_t>(b->total_len, 0x7fffffff), b->max_depth, stream)) return rc;
         HS_HIP(hipEventRecord(e2.b, stream));
         const double t1 = now();
         // downloads go through pooled pinned buffers: above a few hundred KB hipMemcpy into pageable memory pins the
@@ -621,9 +704,9 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = d_cc.alloc(total)) return rc;
         EventPair e; if (int rc = e.init()) return rc;
         HS_HIP(hipEventRecord(e.a, stream));
-        if (int rc = hs_gather_columns(b->pile.as<uint8_t>(), b->d_pile_off.as<int64_t>(), b->d_rec_pos.as<int32_t>(), b->d_rec_qend.as<int32_t>(),
-                                       b->d_contig_rec_off.as<int32_t>(), d_sc.as<int32_t>(), d_sp.as<int32_t>(), d_co.as<int64_t>(), n_sel,
-                                       d_ci.as<int32_t>(), d_cc.as<uint8_t>(), stream)) return rc;
+        if (int rc = hs_gather_columns_tiled(b->pile.as<uint8_t>(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->tile_rec.as<int32_t>(),
+                                             b->d_contig_off.as<int64_t>(), b->d_contig_rec_off.as<int32_t>(), d_sc.as<int32_t>(), d_sp.as<int32_t>(),
+                                             d_co.as<int64_t>(), n_sel, d_ci.as<int32_t>(), d_cc.as<uint8_t>(), stream)) return rc;
         DBuf d_top;
         if (int rc = d_top.alloc((size_t)n_sel * sizeof(hs_coltop))) return rc;
         if (int rc = hs_column_top3(d_co.as<int64_t>(), d_cc.as<uint8_t>(), n_sel, d_top.as<hs_coltop>(), stream)) return rc;

@@ -224,6 +224,8 @@ static void merge_close_clusters(const SrGraph& g, bool low_memory, std::vector<
     std::vector<int> votes((size_t)N, 0), touched;
     std::vector<int32_t> nc;
     std::vector<int> count;
+    std::vector<int32_t> order_masked;   // the shuffled order restricted to the window's reads (the others are skipped anyway)
+    for (int i : order) if (mask[i]) order_masked.push_back(i);
     for (int node = 0; node < N; ++node) {
         if (!(clusters[node] >= 0 && tested.find(clusters[node]) == tested.end())) continue;
         const int target = clusters[node];
@@ -231,8 +233,8 @@ static void merge_close_clusters(const SrGraph& g, bool low_memory, std::vector<
         int changes = 3, iters = 0;
         while (changes > 0 && iters < 10) {
             changes = 0;
-            for (int i : order) {
-                if (!mask[i] || nc[i] != target) continue;
+            for (int i : order_masked) {
+                if (nc[i] != target) continue;
                 touched.clear();
                 const int o0 = g.off[i], o1 = g.off[i + 1];
                 if (low_memory) {   // :441-445 iterates j < degree and asks whether j itself is a neighbour (sic)
@@ -288,13 +290,13 @@ static std::vector<int32_t> merge_wrongly_split(const SrContigState& st, const s
         for (size_t i = 0; i < glist.size(); ++i) slot_of_group[glist[i]] = (int)i;
     }
     std::vector<std::vector<uint8_t>> seen((size_t)G);
-    std::vector<std::vector<int>> cnts((size_t)G);
+    std::vector<std::vector<int>> cnts((size_t)G, std::vector<int>(256, 0));
     std::vector<int> nb_bases((size_t)G);
     std::vector<int> majority((size_t)G);   // 0 == the operator[] default for clusters absent at this SNP
     for (int s = 0; s < c.n_snps; ++s) {
         const int p = c.snp_pos[s];
         if (!(p >= posstart && p < posend)) continue;
-        for (int i = 0; i < G; ++i) { seen[i].clear(); cnts[i].assign(256, 0); nb_bases[i] = 0; majority[i] = 0; }
+        for (int i = 0; i < G; ++i) { nb_bases[i] = 0; majority[i] = 0; }
         for (int64_t e = c.col_off[s]; e < c.col_off[s + 1]; ++e) {
             const int cl = clustered[c.col_idx[e]];
             if (cl > -1) {
@@ -304,25 +306,26 @@ static std::vector<int32_t> merge_wrongly_split(const SrContigState& st, const s
                 nb_bases[sl]++;
             }
         }
-        std::set<int> maxbases;
+        // The reference walks the cluster's base counts in robin_hood order keeping (max, second max) with `>=` on the max
+        // (:1090-1099). The pair of values does not depend on the order, and neither does the verdict: a unique maximum names
+        // the base, a tied maximum gives second == max and is rejected by `second_max * 2 > max` just below.
+        int first_max = -1; bool several = false;
         for (int i = 0; i < G; ++i) {
             if (seen[i].empty()) continue;
-            Rh8 rh; rh.clear();
-            for (uint8_t b : seen[i]) rh.insert(b);
-            uint8_t ord[260];
-            const int m = rh.order(ord);
             int second_max = 0, mx = 0;
             int max_base = ' ';
-            for (int k = 0; k < m; ++k) {
-                const int v = cnts[i][ord[k]];
-                if (v >= mx) { max_base = (int)(signed char)ord[k]; second_max = mx; mx = v; }
+            for (uint8_t b : seen[i]) {
+                const int v = cnts[i][b];
+                if (v >= mx) { max_base = (int)(signed char)b; second_max = mx; mx = v; }
                 else if (v > second_max) second_max = v;
+                cnts[i][b] = 0;
             }
+            seen[i].clear();
             if (second_max * 2 > mx || nb_bases[i] * 0.5 > mx) max_base = ' ';
             majority[i] = (int)(uint8_t)max_base;
-            if (max_base != ' ') maxbases.insert((int)(uint8_t)max_base);
+            if (max_base != ' ') { const int mb = (int)(uint8_t)max_base; if (first_max < 0) first_max = mb; else if (mb != first_max) several = true; }
         }
-        if (maxbases.size() <= 1) continue;
+        if (!several) continue;
         for (int a = 0; a < G; ++a)
             for (int b = 0; b < G; ++b) {
                 if (majority[a] != ' ' && majority[b] != ' ' && glist[a] > glist[b]) {
@@ -384,12 +387,16 @@ static std::vector<int32_t> merge_wrongly_split(const SrContigState& st, const s
 void sr_finish_window(const SrContigState& st, SrWindowPlan& w, const int32_t* reclustered, bool low_memory) {
     const int N = st.N;
     std::vector<int32_t> hap(reclustered, reclustered + N);
-    std::unordered_map<int, int> to_index;
-    to_index[-1] = st.c->n_snps == 0 ? 0 : -1;
-    to_index[-2] = -2;
+    // first-seen renumbering of the non-negative labels (:973-984); -1 and -2 keep their meaning
+    int max_label = -1;
+    for (int h : hap) max_label = std::max(max_label, h);
+    std::vector<int> to_index((size_t)max_label + 1, -1);
     int index_h = 0;
-    for (int h : hap) if (to_index.find(h) == to_index.end()) to_index[h] = index_h++;
-    for (int r = 0; r < N; ++r) hap[r] = to_index[hap[r]];
+    for (int r = 0; r < N; ++r) {
+        const int h = hap[r];
+        if (h == -1) hap[r] = st.c->n_snps == 0 ? 0 : -1;
+        else if (h >= 0) { if (to_index[(size_t)h] < 0) to_index[(size_t)h] = index_h++; hap[r] = to_index[(size_t)h]; }
+    }
     const SrGraph& g = st.graphs[(size_t)w.graph_final];
     merge_close_clusters(g, low_memory, hap, w.mask.data(), st.perm);
     w.labels = merge_wrongly_split(st, hap, g, low_memory, w.final_lo, w.final_hi);

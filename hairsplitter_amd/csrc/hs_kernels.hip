@@ -10,6 +10,9 @@
 namespace hsdev {
 
 static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+// index of the wavefront in its workgroup, declared wave-uniform to the compiler: everything derived from it (the unit of
+// work, its metadata, loop bounds) then lives in SGPRs, loads through the scalar cache and branches on SCC instead of EXEC
+static __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // wave-wide max over a 64-bit key (6 butterfly steps through ds_bpermute)
 static __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
@@ -44,6 +47,12 @@ static __device__ __forceinline__ int wave_max_i32(int v) {
 static __device__ __forceinline__ int wave_sum_i32(int v) { return __builtin_amdgcn_readlane(wave_scan_incl(v), 63); }
 // value of the lane to the left (lane 0 receives `fill`)
 static __device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+// x clamped into [0, hi] (hi >= 0, wave-uniform): one v_med3_i32
+static __device__ __forceinline__ int clamp_i32(int x, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
+}
 static __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256) void k_cigar_scan(
     const int64_t* __restrict__ rec_cig_off, const uint32_t* __restrict__ cigar, const int64_t* __restrict__ rec_chunk_off,
     int n_rec, int32_t* __restrict__ chunk_start /* [n_chunks][4] */, int32_t* __restrict__ rec_stats) {
     const int lane = lane_id();
-    const int r = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int r = (int)blockIdx.x * 4 + wave_id();
     if (r >= n_rec) return;
     const int64_t cig0 = rec_cig_off[r], cig1 = rec_cig_off[r + 1];
     int32_t* __restrict__ cs = chunk_start + 4 * rec_chunk_off[r];
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(256) void k_pileup(
     constexpr int PU = 4;
     __shared__ uint8_t s_flag[4][PU][64];
     const int lane = lane_id();
-    const int wv = (int)(threadIdx.x >> 6);
+    const int wv = wave_id();
     const int task = (int)blockIdx.x * 4 + wv;
     if (task >= n_tasks) return;   // wave-uniform
     const int r = task_rec[task];
@@ -143,6 +152,8 @@ __global__ __launch_bounds__(256) void k_pileup(
     const uint8_t* __restrict__ rdp = read_seq + roff;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const unsigned long long le_mask = lt_mask | (1ull << lane);
+    // reverse-strand records read the reverse complement: index rlen - 1 - t == (t ^ -1) + rlen, base 3 - b == b ^ 3
+    const int rd_xor = fwd ? 0 : -1, rd_add = fwd ? 0 : rlen, rd_cmpl = fwd ? 0 : 3;
 
     // last chunk whose first event is <= e_first (uniform bisection)
     int klo = 0, khi = n_chunks - 1;
@@ -165,52 +176,53 @@ __global__ __launch_bounds__(256) void k_pileup(
         const bool nz = a.ev > 0;
         const unsigned long long nzmask = __ballot(nz);
         wave_lds_sync();   // the previous chunk's readers are done
-        s_op[wv][lane] = make_int4(ev_ex, t_cur + rd_inc - a.rd, q_cur + rf_inc - a.rf, code);
+        // op record: first event, read offset, reference offset, class (bit 0: the op consumes the reference (M/=/X/D), bit 1: deletion)
+        const bool isM = code == 0 || code == 7 || code == 8;
+        s_op[wv][lane] = make_int4(ev_ex, t_cur + rd_inc - a.rd, q_cur + rf_inc - a.rf, (isM ? 1 : 0) | (code == 2 ? 3 : 0));
         if (nz) s_nzlane[wv][__popcll(nzmask & lt_mask)] = (uint8_t)lane;
         const int lo_el = e_first > ev_base ? e_first - ev_base : 0;
         const int hi_el = (e1 - ev_base) < chunk_ev ? (e1 - ev_base) : chunk_ev;
+        const int lo_commit = e0 - ev_base;                                   // events before it only warm the 3-mer context up
+        const unsigned span_commit = hi_el > lo_commit ? (unsigned)(hi_el - lo_commit) : 0u;
 
-        // K1 is bound by the latency chain "owner lookup -> read base / contig base -> code": four 64-event windows are
-        // decoded per iteration so that their eight loads are in flight together; the 3-mer carry is then resolved in order.
+        // K1 is bound by VALU issue (a wave64 instruction takes four cycles per SIMD): four 64-event windows are decoded per
+        // iteration so that their eight loads are in flight together, predicates are kept as wave masks (counters are scalar
+        // popcounts of ballots), and the owner lookup shares one flag clear / one flag scatter between the four windows.
+        uint8_t* const flags = &s_flag[wv][0][0];
         for (int eb = lo_el; eb < hi_el; eb += 64 * PU) {
-#pragma unroll
-            for (int u = 0; u < PU; ++u) s_flag[wv][u][lane] = 0;
+            reinterpret_cast<uint32_t*>(flags)[lane] = 0u;                    // 64 lanes x 4 B = the 256 flags of the iteration
             wave_lds_sync();
-#pragma unroll
-            for (int u = 0; u < PU; ++u) {
-                const int w0 = eb + 64 * u;
-                if (nz && ev_ex >= w0 && ev_ex < w0 + 64) s_flag[wv][u][ev_ex - w0] = 1;
+            {
+                const int rel = ev_ex - eb;
+                if (nz && (unsigned)rel < (unsigned)(64 * PU)) flags[rel] = 1;   // an op starts at this event
             }
             wave_lds_sync();
+            int before = __popcll(__ballot(nz && ev_ex < eb));                // ops (owning events) that start before the iteration
             int q_[PU], c_[PU], cref_[PU];
             bool act_[PU], wr_[PU], jm_[PU];
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
-                // owner of every event of the window: ops that start inside it raised a flag at their first event; an event's
-                // owner is the (ops started before the window + flags at or left of it)-th op that owns events
+                // owner of every event of the window: the (ops started before the window + flags at or left of it)-th op that
+                // owns events
                 const int w0 = eb + 64 * u;
-                const int before = __popcll(__ballot(nz && ev_ex < w0));
-                const unsigned long long fm = __ballot(s_flag[wv][u][lane] != 0);
+                const unsigned long long fm = __ballot(flags[64 * u + lane] != 0);
                 const int e = w0 + lane;
-                const bool valid = e < hi_el;
                 int rank = before + __popcll(fm & le_mask) - 1;
                 rank = rank < 0 ? 0 : rank;
+                before += __popcll(fm);
                 const int4 od = s_op[wv][s_nzlane[wv][rank]];
-                const int jcode = od.w;
                 const int off = e - od.x;
-                const bool jM = jcode == 0 || jcode == 7 || jcode == 8;
-                const bool jD = jcode == 2;
+                const bool refc = (od.w & 1) != 0, jD = (od.w & 2) != 0;
                 const int t = od.y + off;
-                const int q = od.z + ((jM || jD) ? off : 0);
-                act_[u] = valid && (ev_base + e) >= e0 && q >= 0 && q < L;   // call_variants.cpp:217
-                wr_[u] = jM || jD; jm_[u] = jM; q_[u] = q;
+                const int q = od.z + (refc ? off : 0);
+                // committed: inside the task's event range and on the contig (call_variants.cpp:217)
+                act_[u] = (unsigned)(e - lo_commit) < span_commit && (unsigned)q < (unsigned)L;
+                wr_[u] = refc; jm_[u] = od.w == 1; q_[u] = q;
                 // both loads are unconditional (indices clamped into the read / the contig) so that they issue back to back
-                const int tt = t < 0 ? 0 : (t >= rlen ? rlen - 1 : t);       // the host validates CIGAR vs read length
-                const int idx = fwd ? tt : (rlen - 1 - tt);
-                const int bb = (int)rdp[idx < 0 ? 0 : idx];
-                const int qq = q < 0 ? 0 : (q >= L ? L - 1 : q);
-                cref_[u] = (int)ctgp[qq];
-                c_[u] = jD ? 4 : (fwd ? bb : 3 - bb);                        // 4 == '-'
+                const int tt = clamp_i32(t, rlen - 1);                         // the host validates CIGAR vs read length
+                const int bb = (int)rdp[(tt ^ rd_xor) + rd_add];               // forward: tt, reverse: rlen - 1 - tt
+                cref_[u] = (int)ctgp[clamp_i32(q, L - 1)];
+                c_[u] = jD ? 4 : (bb ^ rd_cmpl);                               // 4 == '-'; reverse strand reads the complement
             }
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
@@ -219,12 +231,10 @@ __global__ __launch_bounds__(256) void k_pileup(
                 const int c = c_[u];
                 const int cu1 = wave_shr1(c, p1);
                 const int cu2 = wave_shr1(cu1, p2);
-                if (act_[u]) {
-                    nlen++;
-                    // M: call_variants.cpp:238-240,254-256; D: :287-290; I: :337 (no column written)
-                    nerr += (jm_[u] && c == cref_[u]) ? 0 : 1;
-                    if (wr_[u]) out[q_[u] - pos] = (uint8_t)(33 + 5 * cu2 + cu1 + 25 * c);
-                }
+                // M: call_variants.cpp:238-240,254-256; D: :287-290; I: :337 (no column written)
+                nlen += __popcll(__ballot(act_[u]));
+                nerr += __popcll(__ballot(act_[u] && !(jm_[u] && c == cref_[u])));
+                if (act_[u] && wr_[u]) out[q_[u] - pos] = (uint8_t)(33 + 5 * cu2 + cu1 + 25 * c);
                 const int nv = (hi_el - w0) < 64 ? (hi_el - w0) : 64;
                 const int last = __builtin_amdgcn_readlane(c, nv - 1);
                 const int last2 = nv >= 2 ? __builtin_amdgcn_readlane(c, nv - 2) : p1;
@@ -232,9 +242,7 @@ __global__ __launch_bounds__(256) void k_pileup(
             }
         }
     }
-    nerr = wave_sum_i32(nerr);
-    nlen = wave_sum_i32(nlen);
-    if (lane == 0 && nlen > 0) {
+    if (lane == 0 && nlen > 0) {   // nlen / nerr are wave-uniform (scalar popcounts)
         atomicAdd(&rec_stats[4 * r + 1], nerr);
         atomicAdd(&rec_stats[4 * r + 2], nlen);
     }
@@ -257,110 +265,55 @@ __global__ __launch_bounds__(256) void k_pileup(
 // FULL = false is the form the stage driver uses: it only needs the two largest counts, whether a third allele exists and
 // the depth (the exact top-3 of the selected columns is recomputed on the host in the reference's tie order), which takes a
 // handful of branch-free VALU instructions per dword of counters instead of a five-deep insertion per bin.
+// The second half of K2, shared by both variants: scan of the lane's counters (two largest counts, third allele, depth -- or
+// the five largest with their codes when FULL), the 16-B record, and the wave-aggregated append to the selection list.
 template <int CB, bool FULL>
-__global__ __launch_bounds__(256) void k_column_stats(
-    const uint8_t* __restrict__ pile, const int64_t* __restrict__ pile_off,
-    const int32_t* __restrict__ rec_pos, const int32_t* __restrict__ rec_qend,
-    const int32_t* __restrict__ contig_rec_off, const int64_t* __restrict__ contig_off,
-    int n_contigs, hs_colstat_dev* __restrict__ stats, int min_second, int32_t* __restrict__ sel_count,
-    int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int sel_cap) {
+static __device__ __forceinline__ void column_stats_tail(const uint32_t* __restrict__ hw, int tid, int lane, int64_t g, int64_t total,
+                                                         hs_colstat_dev* __restrict__ stats, int min_second, int32_t* __restrict__ sel_count,
+                                                         int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int sel_cap) {
     constexpr int PER_WORD = 4 / CB;
     constexpr int NWORDS = (HS_NBINS + PER_WORD - 1) / PER_WORD;
-    __shared__ uint32_t hw[NWORDS * 256];
-    __shared__ int32_t s_ps[HS_LIST_CAP], s_qe[HS_LIST_CAP];
-    __shared__ int64_t s_po[HS_LIST_CAP];
-    __shared__ int s_n;
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63;
-    const int64_t total = contig_off[n_contigs];
-    const int64_t g0 = (int64_t)blockIdx.x * 256;
-    const int64_t g = g0 + tid;
-#pragma unroll
-    for (int w = 0; w < NWORDS; ++w) hw[w * 256 + tid] = 0u;
-    uint8_t* const h8 = reinterpret_cast<uint8_t*>(hw);
-    uint16_t* const h16 = reinterpret_cast<uint16_t*>(hw);
-    auto bump = [&](int code) {
-        if (CB == 1) h8[(((code >> 2) * 256 + tid) << 2) + (code & 3)] += 1;
-        else h16[(((code >> 1) * 256 + tid) << 1) + (code & 1)] += 1;
-    };
-    int c_first;
-    {
-        int lo = 0, hi = n_contigs - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (contig_off[mid] <= g0) lo = mid; else hi = mid - 1; }
-        c_first = lo;
-    }
-    const int64_t g_last = (g0 + 255 < total - 1) ? g0 + 255 : total - 1;
-    for (int c = c_first; c < n_contigs && contig_off[c] <= g_last; ++c) {
-        const int64_t cs = contig_off[c], ce = contig_off[c + 1];
-        if (ce <= g0) continue;
-        const bool mine = g >= cs && g < ce;
-        const int p = (int)(g - cs);
-        const int tile_lo = (int)((g0 > cs ? g0 : cs) - cs);
-        const int tile_hi = (int)(((g_last + 1) < ce ? (g_last + 1) : ce) - cs);   // exclusive
-        const int r0 = contig_rec_off[c], r1 = contig_rec_off[c + 1];
-        for (int rb = r0; rb < r1; rb += HS_LIST_CAP) {
-            const int rb_end = (rb + HS_LIST_CAP) < r1 ? (rb + HS_LIST_CAP) : r1;
-            __syncthreads();
-            if (tid == 0) s_n = 0;
-            __syncthreads();
-            for (int nb = rb; nb < rb_end; nb += 256) {
-                const int n = nb + tid;
-                int ps = 0, qe = 0;
-                bool ov = false;
-                if (n < rb_end) { ps = rec_pos[n]; qe = rec_qend[n]; ov = qe > tile_lo && ps < tile_hi; }
-                const unsigned long long m = __ballot(ov);
-                int base = 0;
-                if (lane == 0 && m) base = atomicAdd(&s_n, __popcll(m));
-                base = __shfl(base, 0, 64);
-                if (ov) {
-                    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-                    s_ps[slot] = ps; s_qe[slot] = qe; s_po[slot] = pile_off[n] - ps;
-                }
-            }
-            __syncthreads();
-            const int cnt = s_n;
-            // eight records per step; every load is unconditional (out-of-range lanes read byte 0 of the pileup and are
-            // masked afterwards) so that the eight byte loads are in flight together instead of one s_waitcnt each
-            for (int i = 0; i < cnt; i += 8) {
-                int code[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int ii = (i + u) < cnt ? (i + u) : (cnt - 1);
-                    const int ps = s_ps[ii], qe = s_qe[ii];
-                    const bool in = mine && (i + u) < cnt && p >= ps && p < qe;
-                    const int64_t off = in ? (s_po[ii] + p) : 0;
-                    const int byte = (int)pile[off];
-                    code[u] = in ? byte - 33 : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (code[u] >= 0 && code[u] < HS_NBINS) bump(code[u]);
-            }
-        }
-    }
     int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
     int depth = 0;
     if (!FULL) {
         int nzb = 0;   // number of non-empty bins
         if (g < total) {
+            // two largest counters over all bins with packed 16-bit maxima: the bytes of a word are split over two registers of
+            // two 16-bit fields; every field keeps its own (largest, runner-up); the four pairs are merged at the end
+            typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+            us2 m0a = {0, 0}, m1a = {0, 0}, m0b = {0, 0}, m1b = {0, 0};
 #pragma unroll 4
             for (int w = 0; w < NWORDS; ++w) {
                 const uint32_t word = hw[w * 256 + tid];
+                us2 va, vb;
                 if (CB == 1) {
                     depth = (int)__builtin_amdgcn_sad_u8(word, 0u, (uint32_t)depth);      // sum of the four byte counters
                     nzb += __popc((((word & 0x7f7f7f7fu) + 0x7f7f7f7fu) | word) & 0x80808080u);
+                    va = __builtin_bit_cast(us2, word & 0x00ff00ffu);
+                    vb = __builtin_bit_cast(us2, (word >> 8) & 0x00ff00ffu);
                 } else {
                     depth += (int)(word & 0xffffu) + (int)(word >> 16);
                     nzb += ((word & 0xffffu) != 0) + ((word >> 16) != 0);
+                    va = __builtin_bit_cast(us2, word);
+                    vb = us2{0, 0};
                 }
+                const us2 la = __builtin_elementwise_min(va, m0a);
+                m1a = __builtin_elementwise_max(m1a, la);
+                m0a = __builtin_elementwise_max(m0a, va);
+                if (CB == 1) {
+                    const us2 lb = __builtin_elementwise_min(vb, m0b);
+                    m1b = __builtin_elementwise_max(m1b, lb);
+                    m0b = __builtin_elementwise_max(m0b, vb);
+                }
+            }
+            const int tops[8] = {m0a.x, m1a.x, m0a.y, m1a.y, m0b.x, m1b.x, m0b.y, m1b.y};
 #pragma unroll
-                for (int f = 0; f < PER_WORD; ++f) {
-                    const int v = (int)((word >> (8 * CB * f)) & (CB == 1 ? 0xFFu : 0xFFFFu));
-                    const int lo2 = v < c0 ? v : c0;     // branch-free two largest
-                    c1 = c1 > lo2 ? c1 : lo2;
-                    c0 = c0 > v ? c0 : v;
-                }
+            for (int f = 0; f < 8; ++f) {
+                const int v = tops[f];
+                const int lo2 = v < c0 ? v : c0;     // branch-free two largest
+                c1 = c1 > lo2 ? c1 : lo2;
+                c0 = c0 > v ? c0 : v;
             }
         }
         c2 = nzb > 2 ? 1 : 0;   // only "is there a third allele" is needed
@@ -406,6 +359,143 @@ __global__ __launch_bounds__(256) void k_column_stats(
     }
 }
 
+template <int CB, bool FULL>
+__global__ __launch_bounds__(256) void k_column_stats(
+    const uint8_t* __restrict__ pile, const int64_t* __restrict__ pile_off,
+    const int32_t* __restrict__ rec_pos, const int32_t* __restrict__ rec_qend,
+    const int32_t* __restrict__ contig_rec_off, const int64_t* __restrict__ contig_off,
+    int n_contigs, hs_colstat_dev* __restrict__ stats, int min_second, int32_t* __restrict__ sel_count,
+    int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int sel_cap) {
+    constexpr int PER_WORD = 4 / CB;
+    constexpr int NWORDS = (HS_NBINS + PER_WORD - 1) / PER_WORD;
+    __shared__ uint32_t hw[NWORDS * 256];
+    __shared__ int4 s_rec[HS_LIST_CAP];   // records overlapping the tile: {first position, end position, pileup offset of position 0 (lo, hi)}
+    __shared__ int s_n;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int64_t total = contig_off[n_contigs];
+    const int64_t g0 = (int64_t)blockIdx.x * 256;
+    const int64_t g = g0 + tid;
+#pragma unroll
+    for (int w = 0; w < NWORDS; ++w) hw[w * 256 + tid] = 0u;
+    // one LDS add per (position, record): the counter of `code` lives in byte (or half) code % PER_WORD of the lane's word
+    // code / PER_WORD; lanes that are not covered add zero to word 0 (no divergence, no read-modify-write sequence)
+    auto bump = [&](unsigned code, bool valid) {
+        const unsigned cc = valid ? code : 0u;
+        const unsigned inc = valid ? (1u << ((cc & (PER_WORD - 1)) * (8 * CB))) : 0u;
+        __hip_atomic_fetch_add(&hw[(cc / PER_WORD) * 256 + tid], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    int c_first;
+    {
+        int lo = 0, hi = n_contigs - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (contig_off[mid] <= g0) lo = mid; else hi = mid - 1; }
+        c_first = lo;
+    }
+    const int64_t g_last = (g0 + 256 - 1 < total - 1) ? g0 + 256 - 1 : total - 1;
+    for (int c = c_first; c < n_contigs && contig_off[c] <= g_last; ++c) {
+        const int64_t cs = contig_off[c], ce = contig_off[c + 1];
+        if (ce <= g0) continue;
+        const bool mine = g >= cs && g < ce;
+        const int p = (int)(g - cs);
+        const int tile_lo = (int)((g0 > cs ? g0 : cs) - cs);
+        const int tile_hi = (int)(((g_last + 1) < ce ? (g_last + 1) : ce) - cs);   // exclusive
+        const int r0 = contig_rec_off[c], r1 = contig_rec_off[c + 1];
+        for (int rb = r0; rb < r1; rb += HS_LIST_CAP) {
+            const int rb_end = (rb + HS_LIST_CAP) < r1 ? (rb + HS_LIST_CAP) : r1;
+            __syncthreads();
+            if (tid == 0) s_n = 0;
+            __syncthreads();
+            for (int nb = rb; nb < rb_end; nb += 256) {
+                const int n = nb + tid;
+                int ps = 0, qe = 0;
+                bool ov = false;
+                if (n < rb_end) { ps = rec_pos[n]; qe = rec_qend[n]; ov = qe > tile_lo && ps < tile_hi; }
+                const unsigned long long m = __ballot(ov);
+                int base = 0;
+                if (lane == 0 && m) base = atomicAdd(&s_n, __popcll(m));
+                base = __shfl(base, 0, 64);
+                if (ov) {
+                    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                    const int64_t po = pile_off[n] - ps;
+                    s_rec[slot] = make_int4(ps, qe, (int)(uint32_t)(po & 0xffffffffll), (int)(po >> 32));
+                }
+            }
+            __syncthreads();
+            const int cnt = __builtin_amdgcn_readfirstlane(s_n);
+            // A record is wave-uniform. Lane j of a wave keeps record i0 + j of the list in registers; the fields of the record
+            // being processed come out with v_readlane (no LDS round trip, no wait), so a lane only pays a range compare, a
+            // select and a byte load with scalar base + 32-bit lane offset. Eight records per step, every load unconditional
+            // (lanes outside the record read its first byte and add zero), so that the eight loads are in flight together.
+            for (int i0 = 0; i0 < cnt; i0 += 64) {
+                const int nrec = (cnt - i0) < 64 ? (cnt - i0) : 64;
+                const int4 held = s_rec[i0 + (lane < nrec ? lane : nrec - 1)];
+                for (int i = 0; i < nrec; i += 8) {
+                    unsigned code[8]; bool in_[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int j = (i + u) < nrec ? (i + u) : (nrec - 1);
+                        const int ps = __builtin_amdgcn_readlane(held.x, j), qe = __builtin_amdgcn_readlane(held.y, j);
+                        const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane(held.z, j), phi = (uint32_t)__builtin_amdgcn_readlane(held.w, j);
+                        const uint8_t* __restrict__ base = pile + (int64_t)(((uint64_t)phi << 32) | plo);   // pileup byte of position 0
+                        const bool in = mine && (i + u) < nrec && (unsigned)(p - ps) < (unsigned)(qe - ps);
+                        const unsigned off = (unsigned)(in ? p : ps);
+                        code[u] = (unsigned)base[off] - 33u;
+                        in_[u] = in;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) bump(code[u], in_[u] && code[u] < (unsigned)HS_NBINS);
+                }
+            }
+        }
+    }
+    column_stats_tail<CB, FULL>(hw, tid, lane, g, total, stats, min_second, sel_count, sel_gpos, sel_depth, sel_cap);
+}
+
+// K2 with a tile plan (hs_tile_plan): the records overlapping each 256-position tile are listed by the host once per batch
+// ({first lane, length, pileup address of lane 0} per record and tile), so a wavefront goes straight from one coalesced 16-B
+// load per lane to the pileup bytes: no list compaction, no workgroup barrier, the four waves of a workgroup are independent.
+template <int CB, bool FULL>
+__global__ __launch_bounds__(256) void k_column_stats_tiled(
+    const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, int64_t total,
+    hs_colstat_dev* __restrict__ stats, int min_second, int32_t* __restrict__ sel_count, int64_t* __restrict__ sel_gpos,
+    int32_t* __restrict__ sel_depth, int sel_cap) {
+    constexpr int PER_WORD = 4 / CB;
+    constexpr int NWORDS = (HS_NBINS + PER_WORD - 1) / PER_WORD;
+    __shared__ uint32_t hw[NWORDS * 256];
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int64_t g = (int64_t)blockIdx.x * 256 + tid;
+#pragma unroll
+    for (int w = 0; w < NWORDS; ++w) hw[w * 256 + tid] = 0u;
+    auto bump = [&](unsigned code, bool valid) {
+        const unsigned cc = valid ? code : 0u;
+        const unsigned inc = valid ? (1u << ((cc & (PER_WORD - 1)) * (8 * CB))) : 0u;
+        __hip_atomic_fetch_add(&hw[(cc / PER_WORD) * 256 + tid], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    const int64_t e0 = tile_off[blockIdx.x], e1 = tile_off[blockIdx.x + 1];
+    for (int64_t i0 = e0; i0 < e1; i0 += 64) {
+        const int nrec = (e1 - i0) < 64 ? (int)(e1 - i0) : 64;
+        const int4 held = tile_ent[i0 + (lane < nrec ? lane : nrec - 1)];   // lane j keeps record i0 + j
+        for (int i = 0; i < nrec; i += 8) {
+            unsigned code[8]; bool in_[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = (i + u) < nrec ? (i + u) : (nrec - 1);
+                const int first = __builtin_amdgcn_readlane(held.x, j), len = __builtin_amdgcn_readlane(held.y, j);
+                const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane(held.z, j), phi = (uint32_t)__builtin_amdgcn_readlane(held.w, j);
+                const uint8_t* __restrict__ base = pile + (int64_t)(((uint64_t)phi << 32) | plo);   // pileup byte of lane 0 of the tile
+                const bool in = (i + u) < nrec && (unsigned)(tid - first) < (unsigned)len;
+                const unsigned off = (unsigned)(in ? tid : (first < 0 ? 0 : first));   // lanes outside the record re-read one of its bytes
+                code[u] = (unsigned)base[off] - 33u;
+                in_[u] = in;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bump(code[u], in_[u] && code[u] < (unsigned)HS_NBINS);
+        }
+    }
+    column_stats_tail<CB, FULL>(hw, tid, lane, g, total, stats, min_second, sel_count, sel_gpos, sel_depth, sel_cap);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3 column extraction: builds the reference's Column (Partition.h:8-14) for selected positions.
 // One wavefront per selected position; 64 records per step, ballot + prefix popcount give every covering
@@ -418,7 +508,7 @@ __global__ __launch_bounds__(256) void k_gather_columns(
     const int32_t* __restrict__ sel_pos, const int64_t* __restrict__ col_off, int n_sel,
     int32_t* __restrict__ col_idx, uint8_t* __restrict__ col_code) {
     const int lane = lane_id();
-    const int s = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int s = (int)blockIdx.x * 4 + wave_id();
     if (s >= n_sel) return;
     const int c = sel_contig[s], p = sel_pos[s];
     const int r0 = contig_rec_off[c], r1 = contig_rec_off[c + 1];
@@ -450,7 +540,7 @@ __global__ __launch_bounds__(256) void k_snp_planes(
     const int64_t* __restrict__ contig_snp_base, const int64_t* __restrict__ plane_off, const int32_t* __restrict__ words, int n_snps,
     unsigned long long* __restrict__ alt, unsigned long long* __restrict__ ref) {
     const int lane = lane_id();
-    const int s = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int s = (int)blockIdx.x * 4 + wave_id();
     if (s >= n_snps) return;
     const int c = snp_contig[s];
     const int W = words[c];
@@ -991,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_column_partition_test(
     __shared__ uint8_t s_ord[4][264];
     __shared__ int s_ord_n[4];
     const int lane = lane_id();
-    const int wv = (int)(threadIdx.x >> 6);
+    const int wv = wave_id();
     const int col = (int)blockIdx.x * 4 + wv;
     if (col >= n_cols) return;
     const int c = col_contig[col];
@@ -1018,6 +1108,38 @@ __global__ __launch_bounds__(256) void k_column_partition_test(
     if (lane == 0) keep[col] = kept ? 1 : 0;
 }
 
+// K3 with the tile plan: only the records of the position's tile are tested (one 64-record step for 50x data instead of
+// ten); the plan lists them in ascending record order, so the read indices still come out ascending.
+__global__ __launch_bounds__(256) void k_gather_columns_tiled(
+    const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent,
+    const int32_t* __restrict__ tile_rec, const int64_t* __restrict__ contig_off, const int32_t* __restrict__ contig_rec_off,
+    const int32_t* __restrict__ sel_contig, const int32_t* __restrict__ sel_pos, const int64_t* __restrict__ col_off, int n_sel,
+    int32_t* __restrict__ col_idx, uint8_t* __restrict__ col_code) {
+    const int lane = lane_id();
+    const int s = (int)blockIdx.x * 4 + wave_id();
+    if (s >= n_sel) return;
+    const int c = sel_contig[s];
+    const int64_t g = contig_off[c] + sel_pos[s];
+    const int64_t tile = g >> 8;
+    const int x = (int)(g & 255);
+    const int r0 = contig_rec_off[c];
+    int64_t w = col_off[s];
+    const int64_t e1 = tile_off[tile + 1];
+    for (int64_t eb = tile_off[tile]; eb < e1; eb += 64) {
+        const int64_t e = eb + lane;
+        bool cov = false;
+        int4 en = make_int4(0, 0, 0, 0);
+        if (e < e1) { en = tile_ent[e]; cov = (unsigned)(x - en.x) < (unsigned)en.y; }
+        const unsigned long long m = __ballot(cov);
+        if (cov) {
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            col_idx[w + rank] = tile_rec[e] - r0;
+            col_code[w + rank] = pile[(int64_t)(((uint64_t)(uint32_t)en.w << 32) | (uint32_t)en.z) + x];
+        }
+        w += __popcll(m);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3b top-3 of the extracted columns (call_variants.cpp:477-507 for the selected positions only): one wavefront per column,
 // histogram over the 125 codes in LDS, three wave arg-max rounds. The reference orders equal counts by robin_hood iteration
@@ -1028,7 +1150,7 @@ __global__ __launch_bounds__(256) void k_column_top3(const int64_t* __restrict__
                                                      hs_coltop_dev* __restrict__ out) {
     __shared__ int s_hist[4][128];
     const int lane = lane_id();
-    const int wv = (int)(threadIdx.x >> 6);
+    const int wv = wave_id();
     const int col = (int)blockIdx.x * 4 + wv;
     if (col >= n_cols) return;                   // wave-uniform
     int* __restrict__ h = s_hist[wv];

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_read_graph_rows(
     int32_t* __restrict__ amb_rows, int amb_cap) {
     extern __shared__ unsigned char s_dyn[];
     const int lane = lane_id();
-    const int wv = (int)(threadIdx.x >> 6), waves = (int)(blockDim.x >> 6);
+    const int wv = wave_id(), waves = (int)(blockDim.x >> 6);
     const int row = (int)blockIdx.x * waves + wv;
     if (row >= n_rows) return;                    // wave-uniform
     float* __restrict__ dv = reinterpret_cast<float*>(s_dyn) + (size_t)wv * 2 * cap;

@@ -108,6 +108,27 @@ int hs_column_stats(const uint8_t* d_pile, const int64_t* d_pile_off, const int3
                     int32_t max_depth, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Tile plan for K2 / K3: which records overlap each tile of 256 consecutive positions of the concatenated contigs, in
+ * ascending record order. Built on the host from the same per-record aggregates as the pileup layout (one pass over the
+ * records; the batch keeps it for its lifetime). entry.first = lane of the tile that holds the record's first position
+ * (negative when the record starts in an earlier tile), entry.len = positions the record covers from there,
+ * entry.base = offset in the pileup of the byte that lane 0 of the tile would read.
+ * Outputs are malloc'ed; release them with hs_free_host.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hs_tile_entry { int32_t first, len; int64_t base; } hs_tile_entry;
+int hs_tile_plan(const int64_t* h_contig_off, int32_t n_contigs, const int32_t* h_contig_rec_off, const int32_t* h_rec_pos,
+                 const int32_t* h_rec_qend, const int64_t* h_pile_off, int64_t** tile_off /* [n_tiles+1] */,
+                 hs_tile_entry** tile_ent, int32_t** tile_rec, int64_t* n_tiles);
+/* K2 / K3 on a tile plan (same outputs as hs_column_stats / hs_gather_columns; total_len = contig_off[C]) */
+int hs_column_stats_tiled(const uint8_t* d_pile, const int64_t* d_tile_off, const hs_tile_entry* d_tile_ent, int64_t total_len,
+                          hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos,
+                          int32_t* d_sel_depth, int32_t sel_cap, int32_t max_depth, void* stream);
+int hs_gather_columns_tiled(const uint8_t* d_pile, const int64_t* d_tile_off, const hs_tile_entry* d_tile_ent,
+                            const int32_t* d_tile_rec, const int64_t* d_contig_off, const int32_t* d_contig_rec_off,
+                            const int32_t* d_sel_contig, const int32_t* d_sel_pos, const int64_t* d_col_off, int32_t n_sel,
+                            int32_t* d_col_idx, uint8_t* d_col_code, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K3 -- column extraction (pileup transposition for selected positions, coalesced writes).
  * Produces the reference's `Column` (Partition.h:8-14): read indices ascending + one code per read, for the
  * positions in d_sel_pos (position inside contig d_sel_contig). d_col_off[k] is the output offset of

@@ -80,6 +80,28 @@ def test_column_stats_counts(batch):
         assert np.all(np.diff(cnt, axis=1) <= 0) and np.all(cnt.sum(axis=1) <= depth)
 
 
+def test_tiled_variants_equal_planless(batch):
+    """K2 / K3 on the host-built tile plan (what the stage driver runs) == the plan-less kernels, byte for byte"""
+    from hairsplitter_amd import api
+    flat, t = batch
+    pile, _ = api.pileup(t, flat)
+    plan = api.tile_plan(flat)
+    # the plan itself: every (tile, record) overlap once, ascending record ids per tile
+    for tl in range(len(plan["h_off"]) - 1):
+        recs = plan["h_rec"][plan["h_off"][tl]:plan["h_off"][tl + 1]]
+        assert np.all(np.diff(recs) > 0)
+    for md in (0, 255):
+        a = api.column_stats(t, flat, pile, min_second=4, max_depth=md)
+        b = api.column_stats(t, flat, pile, min_second=4, max_depth=md, plan=plan)
+        assert np.array_equal(a[0].view(np.uint8), b[0].view(np.uint8)) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    st, sel_g, sel_d = a
+    ctg = np.searchsorted(flat.contig_off, sel_g, side="right") - 1
+    pos = sel_g - flat.contig_off[ctg]
+    x = api.gather_columns(t, flat, pile, ctg, pos, sel_d)
+    y = api.gather_columns(t, flat, pile, ctg, pos, sel_d, plan=plan)
+    assert all(np.array_equal(u, v) for u, v in zip(x, y))
+
+
 def test_gather_columns(batch):
     """K3 == the reference's Column for selected positions: ascending read indices, matching codes."""
     from hairsplitter_amd import api
