@@ -220,6 +220,28 @@ int hs_pileup_plan(const int64_t* h_rec_cig_off, const uint32_t* h_cigar, int32_
 }
 void hs_free_host(void* p) { std::free(p); }
 
+// K2's selection list: the kernels fill 256 scratch slots + one count per tile; scan + compact give the sorted list and its
+// length (see column_stats_tail in hs_kernels.hip)
+struct SelectionScratch {
+    DBuf tile_cnt, tile_base, gpos, depth;
+    int64_t n_tiles = 0;
+    int prepare(int64_t total_len) {
+        n_tiles = (total_len + 255) / 256;
+        if (int rc = tile_cnt.alloc((size_t)n_tiles * 4)) return rc;
+        if (int rc = tile_base.alloc(((size_t)n_tiles + 1) * 8)) return rc;
+        if (int rc = gpos.alloc((size_t)n_tiles * 256 * 8)) return rc;
+        return depth.alloc((size_t)n_tiles * 256 * 4);
+    }
+    int finish(int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth, int32_t sel_cap, hipStream_t stream) {
+        if (n_tiles > 0x7fffffff) { set_error("too many tiles"); return HS_EINVAL; }
+        hipLaunchKernelGGL(hsdev::k_exclusive_scan_i32, dim3(1), dim3(1024), 0, stream, tile_cnt.as<int32_t>(), (int)n_tiles, tile_base.as<int64_t>());
+        hipLaunchKernelGGL(hsdev::k_selection_compact, dim3((unsigned)n_tiles), dim3(256), 0, stream, tile_cnt.as<int32_t>(), tile_base.as<int64_t>(),
+                           gpos.as<int64_t>(), depth.as<int32_t>(), n_tiles, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap);
+        HS_HIP(hipGetLastError());
+        return HS_OK;
+    }
+};
+
 static int column_stats_launch(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
                                const int32_t* d_rec_qend, const int32_t* d_contig_rec_off, const int64_t* d_contig_off,
                                int32_t n_contigs, int64_t total_len, hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count,
@@ -232,10 +254,16 @@ static int column_stats_launch(const uint8_t* d_pile, const int64_t* d_pile_off,
                              hsdev::hs_colstat_dev*, int, int32_t*, int64_t*, int32_t*, int);
     KernelT kernel = narrow ? (full ? (KernelT)hsdev::k_column_stats<1, true> : (KernelT)hsdev::k_column_stats<1, false>)
                             : (full ? (KernelT)hsdev::k_column_stats<2, true> : (KernelT)hsdev::k_column_stats<2, false>);
+    SelectionScratch sc;
+    if (d_sel_count) { if (int rc = sc.prepare(total_len)) return rc; }
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_pile, d_pile_off, d_rec_pos, d_rec_qend,
                        d_contig_rec_off, d_contig_off, n_contigs, reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second,
-                       d_sel_count, d_sel_gpos, d_sel_depth, sel_cap);
+                       d_sel_count ? sc.tile_cnt.as<int32_t>() : nullptr, sc.gpos.as<int64_t>(), sc.depth.as<int32_t>(), sel_cap);
     HS_HIP(hipGetLastError());
+    if (d_sel_count) {
+        if (int rc = sc.finish(d_sel_count, d_sel_gpos, d_sel_depth, sel_cap, (hipStream_t)stream)) return rc;
+        HS_HIP(hipStreamSynchronize((hipStream_t)stream));   // the scratch goes back to the pool with this scope
+    }
     return HS_OK;
 }
 
@@ -297,11 +325,11 @@ int hs_tile_plan(const int64_t* h_contig_off, int32_t n_contigs, const int32_t* 
     return HS_OK;
 }
 
-int hs_column_stats_tiled(const uint8_t* d_pile, const int64_t* d_tile_off, const hs_tile_entry* d_tile_ent, int64_t total_len,
-                          hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth,
-                          int32_t sel_cap, int32_t max_depth, void* stream) {
-    if (int rc = require_device()) return rc;
-    if (total_len <= 0) return HS_OK;
+// K2 on a tile plan; `sc` is caller-owned scratch (prepared); `after_main` (optional) is recorded right after the histogram
+// kernel so that its duration can be told apart from the two small selection kernels
+static int column_stats_tiled_launch(const uint8_t* d_pile, const int64_t* d_tile_off, const hs_tile_entry* d_tile_ent, int64_t total_len,
+                                     hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth,
+                                     int32_t sel_cap, int32_t max_depth, SelectionScratch* sc, hipEvent_t after_main, hipStream_t stream) {
     static_assert(sizeof(hs_tile_entry) == sizeof(int4), "hs_tile_entry is read as one 16-byte load");
     const int64_t grid = (total_len + 255) / 256;
     const bool full = d_stats != nullptr;
@@ -309,9 +337,25 @@ int hs_column_stats_tiled(const uint8_t* d_pile, const int64_t* d_tile_off, cons
     using KernelT = void (*)(const uint8_t*, const int64_t*, const int4*, int64_t, hsdev::hs_colstat_dev*, int, int32_t*, int64_t*, int32_t*, int);
     KernelT kernel = narrow ? (full ? (KernelT)hsdev::k_column_stats_tiled<1, true> : (KernelT)hsdev::k_column_stats_tiled<1, false>)
                             : (full ? (KernelT)hsdev::k_column_stats_tiled<2, true> : (KernelT)hsdev::k_column_stats_tiled<2, false>);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, d_pile, d_tile_off, reinterpret_cast<const int4*>(d_tile_ent),
-                       total_len, reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), 0, stream, d_pile, d_tile_off, reinterpret_cast<const int4*>(d_tile_ent),
+                       total_len, reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second, d_sel_count ? sc->tile_cnt.as<int32_t>() : nullptr,
+                       d_sel_count ? sc->gpos.as<int64_t>() : nullptr, d_sel_count ? sc->depth.as<int32_t>() : nullptr, sel_cap);
     HS_HIP(hipGetLastError());
+    if (after_main) HS_HIP(hipEventRecord(after_main, stream));
+    if (d_sel_count) return sc->finish(d_sel_count, d_sel_gpos, d_sel_depth, sel_cap, stream);
+    return HS_OK;
+}
+
+int hs_column_stats_tiled(const uint8_t* d_pile, const int64_t* d_tile_off, const hs_tile_entry* d_tile_ent, int64_t total_len,
+                          hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth,
+                          int32_t sel_cap, int32_t max_depth, void* stream) {
+    if (int rc = require_device()) return rc;
+    if (total_len <= 0) return HS_OK;
+    SelectionScratch sc;
+    if (d_sel_count) { if (int rc = sc.prepare(total_len)) return rc; }
+    if (int rc = column_stats_tiled_launch(d_pile, d_tile_off, d_tile_ent, total_len, d_stats, min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap,
+                                           max_depth, &sc, nullptr, (hipStream_t)stream)) return rc;
+    if (d_sel_count) HS_HIP(hipStreamSynchronize((hipStream_t)stream));   // the scratch goes back to the pool with this scope
     return HS_OK;
 }
 
@@ -478,6 +522,7 @@ struct hs_cv_batch {
     DBuf contig_seq, d_contig_off, read_seq, read_off, rec_read, d_rec_contig, d_rec_pos, rec_strand, rec_cig_off, cigar,
         d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, rec_chunk_off, chunk_scratch, task_rec, task_ev0,
         sel_count, sel_gpos, sel_depth, tile_off, tile_ent, tile_rec;
+    SelectionScratch sel_scratch;
 };
 
 int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off, int32_t n_contigs,
@@ -624,10 +669,11 @@ struct HipCvOps : hs::CvDeviceOps {
                                    b->n_tasks, b->ev_per_task, b->pile.as<uint8_t>(), b->rec_stats.as<int32_t>(), stream)) return rc;
         HS_HIP(hipEventRecord(e1.b, stream));
         HS_HIP(hipEventRecord(e2.a, stream));
-        if (int rc = hs_column_stats_tiled(b->pile.as<uint8_t>(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->total_len,
-                                           nullptr, min_second, b->sel_count.as<int32_t>(), b->sel_gpos.as<int64_t>(),
-                                           b->sel_depth.as<int32_t>(), (int32_t)std::min<int64_t>(b->total_len, 0x7fffffff), b->max_depth, stream)) return rc;
-        HS_HIP(hipEventRecord(e2.b, stream));
+        if (b->sel_scratch.n_tiles == 0) { if (int rc = b->sel_scratch.prepare(b->total_len)) return rc; }
+        if (int rc = column_stats_tiled_launch(b->pile.as<uint8_t>(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->total_len,
+                                               nullptr, min_second, b->sel_count.as<int32_t>(), b->sel_gpos.as<int64_t>(),
+                                               b->sel_depth.as<int32_t>(), (int32_t)std::min<int64_t>(b->total_len, 0x7fffffff), b->max_depth,
+                                               &b->sel_scratch, e2.b, stream)) return rc;
         const double t1 = now();
         // downloads go through pooled pinned buffers: above a few hundred KB hipMemcpy into pageable memory pins the
         // destination on the fly, which costs tens of milliseconds

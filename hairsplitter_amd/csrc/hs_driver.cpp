@@ -136,12 +136,13 @@ int cv_select(CvDeviceOps& dev, const CvMeta& b, CvSelection& sel) {
     sel.rec_stats.assign((size_t)NR * 4, 0);
     std::vector<int64_t> sel_gpos;
     std::vector<int32_t> sel_depth;
-    // interesting positions: second count >= 4 (everything that can become a SNP, see hs_host_cv.cpp); the device
-    // appends them unordered, the (small) list is ordered here
+    // interesting positions: second count >= 4 (everything that can become a SNP, see hs_host_cv.cpp), ordered by position
     if (int rc = dev.pileup_and_select(sel.rec_stats, 4, sel_gpos, sel_depth, sel.k_ms)) return rc;
     const double t_k12_done = now_ms();
     std::vector<size_t> order(sel_gpos.size());
-    {   // bucket by 256-position tile (the unit the device appends in), then order the few entries of each tile
+    if (std::is_sorted(sel_gpos.begin(), sel_gpos.end())) {   // the HIP implementation hands the list over sorted already
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    } else {   // bucket by 256-position tile, then order the few entries of each tile
         const size_t n_tiles = (size_t)((b.total_len + 255) / 256);
         std::vector<uint32_t> start(n_tiles + 1, 0);
         for (int64_t g : sel_gpos) start[(size_t)(g >> 8) + 1]++;

@@ -259,6 +259,9 @@ __global__ __launch_bounds__(256) void k_pileup(
 // ------------------------------------------------------------------------------------------------
 #define HS_NBINS 125
 #define HS_LIST_CAP 512
+#ifndef HS_K2_INFLIGHT
+#define HS_K2_INFLIGHT 16
+#endif
 // CB = bytes per counter: 1 when no position of the batch is deeper than 255 reads (32 KiB of LDS per workgroup, 4-5
 // workgroups per CU), 2 otherwise (63 KiB). Counters are packed 4 (or 2) per dword, dword-major ([word][lane]), so
 // the final scan reads one dword per 4 bins and skips empty ones.
@@ -344,18 +347,38 @@ static __device__ __forceinline__ void column_stats_tail(const uint32_t* __restr
         reinterpret_cast<uint4*>(stats)[g] = o;
     }
     if (sel_count) {
-        // second count above the floor, or exactly at it with no third allele at all (the only way c1 > 5*c2 can hold there)
+        // Selection: second count above the floor, or exactly at it with no third allele at all (the only way c1 > 5*c2 can
+        // hold there). Every tile owns 256 slots of a scratch list and writes its selected positions there in lane order with
+        // its count (no global atomic: ten thousand returning atomics on one counter cost more than the histogram itself);
+        // k_selection_compact then packs the tiles in order, so the list comes out sorted by position.
+        __shared__ int s_wc[4];
         const bool sel = g < total && (c1 > min_second || (c1 == min_second && c2 == 0));
         const unsigned long long m = __ballot(sel);
-        if (m) {
-            int base = 0;
-            if (lane == __builtin_ctzll(m)) base = atomicAdd(sel_count, __popcll(m));
-            base = __shfl(base, __builtin_ctzll(m), 64);
-            if (sel) {
-                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (slot < sel_cap) { sel_gpos[slot] = g; sel_depth[slot] = depth; }
-            }
+        const int wv = tid >> 6;
+        if (lane == 0) s_wc[wv] = __popcll(m);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < wv; ++w) base += s_wc[w];
+        const int64_t tile0 = (int64_t)blockIdx.x * 256;
+        if (sel) {
+            const int64_t slot = tile0 + base + __popcll(m & ((1ull << lane) - 1ull));
+            sel_gpos[slot] = g; sel_depth[slot] = depth;
         }
+        if (tid == 0) sel_count[blockIdx.x] = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+    }
+}
+
+// packs the per-tile selections (256 slots each, tile_base = exclusive prefix of the tile counts) into one sorted list
+__global__ __launch_bounds__(256) void k_selection_compact(const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_base,
+                                                          const int64_t* __restrict__ scratch_gpos, const int32_t* __restrict__ scratch_depth,
+                                                          int64_t n_tiles, int32_t* __restrict__ out_count, int64_t* __restrict__ out_gpos,
+                                                          int32_t* __restrict__ out_depth, int out_cap) {
+    const int64_t t = blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    if (t == 0 && tid == 0) *out_count = (int32_t)tile_base[n_tiles];
+    if (tid < tile_cnt[t]) {
+        const int64_t o = tile_base[t] + tid;
+        if (o < out_cap) { out_gpos[o] = scratch_gpos[t * 256 + tid]; out_depth[o] = scratch_depth[t * 256 + tid]; }
     }
 }
 
@@ -476,10 +499,12 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled(
     for (int64_t i0 = e0; i0 < e1; i0 += 64) {
         const int nrec = (e1 - i0) < 64 ? (int)(e1 - i0) : 64;
         const int4 held = tile_ent[i0 + (lane < nrec ? lane : nrec - 1)];   // lane j keeps record i0 + j
-        for (int i = 0; i < nrec; i += 8) {
-            unsigned code[8]; bool in_[8];
+        // HS_K2_INFLIGHT records per step: K2 waits on the pileup bytes (two thirds of its wave cycles are s_waitcnt), so the
+        // more byte loads are in flight per wait, the fewer waits a tile costs
+        for (int i = 0; i < nrec; i += HS_K2_INFLIGHT) {
+            unsigned code[HS_K2_INFLIGHT]; bool in_[HS_K2_INFLIGHT];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < HS_K2_INFLIGHT; ++u) {
                 const int j = (i + u) < nrec ? (i + u) : (nrec - 1);
                 const int first = __builtin_amdgcn_readlane(held.x, j), len = __builtin_amdgcn_readlane(held.y, j);
                 const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane(held.z, j), phi = (uint32_t)__builtin_amdgcn_readlane(held.w, j);
@@ -490,7 +515,7 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled(
                 in_[u] = in;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) bump(code[u], in_[u] && code[u] < (unsigned)HS_NBINS);
+            for (int u = 0; u < HS_K2_INFLIGHT; ++u) bump(code[u], in_[u] && code[u] < (unsigned)HS_NBINS);
         }
     }
     column_stats_tail<CB, FULL>(hw, tid, lane, g, total, stats, min_second, sel_count, sel_gpos, sel_depth, sel_cap);
