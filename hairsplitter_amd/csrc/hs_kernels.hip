@@ -151,7 +151,6 @@ __global__ __launch_bounds__(256) void k_pileup(
     const uint8_t* __restrict__ ctgp = contig_seq + coff;
     const uint8_t* __restrict__ rdp = read_seq + roff;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const unsigned long long le_mask = lt_mask | (1ull << lane);
     // reverse-strand records read the reverse complement: index rlen - 1 - t == (t ^ -1) + rlen, base 3 - b == b ^ 3
     const int rd_xor = fwd ? 0 : -1, rd_add = fwd ? 0 : rlen, rd_cmpl = fwd ? 0 : 3;
 
@@ -205,9 +204,11 @@ __global__ __launch_bounds__(256) void k_pileup(
                 // owner of every event of the window: the (ops started before the window + flags at or left of it)-th op that
                 // owns events
                 const int w0 = eb + 64 * u;
-                const unsigned long long fm = __ballot(flags[64 * u + lane] != 0);
+                const int own = (int)flags[64 * u + lane];                    // 1 when an op starts at this event
+                const unsigned long long fm = __ballot(own != 0);
                 const int e = w0 + lane;
-                int rank = before + __popcll(fm & le_mask) - 1;
+                // flags strictly left of the lane (v_mbcnt) + its own + ops started before the window - 1
+                int rank = before - 1 + own + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
                 rank = rank < 0 ? 0 : rank;
                 before += __popcll(fm);
                 const int4 od = s_op[wv][s_nzlane[wv][rank]];
@@ -220,8 +221,9 @@ __global__ __launch_bounds__(256) void k_pileup(
                 wr_[u] = refc; jm_[u] = od.w == 1; q_[u] = q;
                 // both loads are unconditional (indices clamped into the read / the contig) so that they issue back to back
                 const int tt = clamp_i32(t, rlen - 1);                         // the host validates CIGAR vs read length
-                const int bb = (int)rdp[(tt ^ rd_xor) + rd_add];               // forward: tt, reverse: rlen - 1 - tt
-                cref_[u] = (int)ctgp[clamp_i32(q, L - 1)];
+                // scalar base + unsigned 32-bit lane offset: no 64-bit address arithmetic per lane
+                const int bb = (int)rdp[(unsigned)((tt ^ rd_xor) + rd_add)];   // forward: tt, reverse: rlen - 1 - tt
+                cref_[u] = (int)ctgp[(unsigned)clamp_i32(q, L - 1)];
                 c_[u] = jD ? 4 : (bb ^ rd_cmpl);                               // 4 == '-'; reverse strand reads the complement
             }
 #pragma unroll
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void k_pileup(
                 // M: call_variants.cpp:238-240,254-256; D: :287-290; I: :337 (no column written)
                 nlen += __popcll(__ballot(act_[u]));
                 nerr += __popcll(__ballot(act_[u] && !(jm_[u] && c == cref_[u])));
-                if (act_[u] && wr_[u]) out[q_[u] - pos] = (uint8_t)(33 + 5 * cu2 + cu1 + 25 * c);
+                if (act_[u] && wr_[u]) out[(unsigned)(q_[u] - pos)] = (uint8_t)(33 + 5 * cu2 + cu1 + 25 * c);
                 const int nv = (hi_el - w0) < 64 ? (hi_el - w0) : 64;
                 const int last = __builtin_amdgcn_readlane(c, nv - 1);
                 const int last2 = nv >= 2 ? __builtin_amdgcn_readlane(c, nv - 2) : p1;
