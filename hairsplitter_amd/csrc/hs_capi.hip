@@ -67,9 +67,11 @@ BlockPool& pool() { static BlockPool* p = new BlockPool(); return *p; }
 struct DBuf {
     void* p = nullptr;
     size_t bytes = 0, cap = 0;
-    ~DBuf() { if (p) pool().put(false, p, cap); }
+    bool view = false;             // points into an UploadPack: not owned
+    ~DBuf() { if (p && !view) pool().put(false, p, cap); }
     int alloc(size_t n) {
-        if (p) { pool().put(false, p, cap); p = nullptr; }
+        if (p && !view) pool().put(false, p, cap);
+        p = nullptr; view = false;
         bytes = n;
         return pool().get(false, n ? n : 16, &p, &cap);
     }
@@ -103,6 +105,34 @@ template <class T> int DBuf::upload(const std::vector<T>& v) {
     }
     return HS_OK;
 }
+
+// Many small host arrays -> ONE pinned staging buffer -> ONE asynchronous host-to-device copy. Every hipMemcpy of a small
+// pageable array costs 10-20 us of latency on the calling thread (a blit kernel each); a stage call used to issue a dozen.
+// The DBufs handed to add() become views into the pack's device block; the pack (and its pinned buffer) must outlive the copy:
+// keep it in the scope that ends with a synchronising call, or as a member.
+struct UploadPack {
+    struct Item { const void* src; size_t bytes, off; DBuf* dst; };
+    std::vector<Item> items;
+    size_t total = 0;
+    DBuf dev;
+    HBuf host;
+    template <class T> void add(const std::vector<T>& v, DBuf& dst) {
+        items.push_back(Item{v.data(), v.size() * sizeof(T), total, &dst});
+        total = (total + v.size() * sizeof(T) + 255) & ~(size_t)255;
+    }
+    int commit(hipStream_t stream) {
+        if (int rc = dev.alloc(total ? total : 256)) return rc;
+        if (int rc = host.alloc(total ? total : 256)) return rc;
+        for (const Item& it : items) {
+            if (it.bytes) std::memcpy((char*)host.p + it.off, it.src, it.bytes);
+            if (it.dst->p && !it.dst->view) pool().put(false, it.dst->p, it.dst->cap);
+            it.dst->p = (char*)dev.p + it.off; it.dst->bytes = it.bytes; it.dst->cap = 0; it.dst->view = true;
+        }
+        if (total) HS_HIP(hipMemcpyAsync(dev.p, host.p, total, hipMemcpyHostToDevice, stream));
+        items.clear(); total = 0;
+        return HS_OK;
+    }
+};
 
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
@@ -707,19 +737,22 @@ struct HipCvOps : hs::CvDeviceOps {
 
     HBuf h_col_idx, h_col_code;
     DBuf d_co, d_ci, d_cc;     // the extracted columns stay on the device for K4
+    UploadPack gather_pack;
     int n_gathered = 0;
     int column_partition_test(const hs::CvPartitionTest& t, std::vector<uint8_t>& keep, float* k_ms) override {
         const int n = (int)t.col_contig.size();
         if (n != n_gathered) { set_error("column_partition_test: column count differs from the last gather"); return HS_EINVAL; }
         DBuf d_ctg, d_k0, d_k1, d_c1, d_cand, d_po, d_pso, d_ps, d_keep;
-        if (int rc = d_ctg.upload(t.col_contig)) return rc;
-        if (int rc = d_k0.upload(t.col_k0)) return rc;
-        if (int rc = d_k1.upload(t.col_k1)) return rc;
-        if (int rc = d_c1.upload(t.col_c1)) return rc;
-        if (int rc = d_cand.upload(t.col_is_cand)) return rc;
-        if (int rc = d_po.upload(t.part_off)) return rc;
-        if (int rc = d_pso.upload(t.part_state_off)) return rc;
-        if (int rc = d_ps.upload(t.part_state)) return rc;
+        UploadPack pk;
+        pk.add(t.col_contig, d_ctg);
+        pk.add(t.col_k0, d_k0);
+        pk.add(t.col_k1, d_k1);
+        pk.add(t.col_c1, d_c1);
+        pk.add(t.col_is_cand, d_cand);
+        pk.add(t.part_off, d_po);
+        pk.add(t.part_state_off, d_pso);
+        pk.add(t.part_state, d_ps);
+        if (int rc = pk.commit(stream)) return rc;
         if (int rc = d_keep.alloc((size_t)n)) return rc;
         EventPair e; if (int rc = e.init()) return rc;
         HS_HIP(hipEventRecord(e.a, stream));
@@ -743,9 +776,10 @@ struct HipCvOps : hs::CvDeviceOps {
         n_gathered = n_sel;
         if (n_sel == 0) return HS_OK;
         DBuf d_sc, d_sp;
-        if (int rc = d_sc.upload(sel_contig)) return rc;
-        if (int rc = d_sp.upload(sel_pos)) return rc;
-        if (int rc = d_co.upload(col_off)) return rc;
+        gather_pack.add(sel_contig, d_sc);
+        gather_pack.add(sel_pos, d_sp);
+        gather_pack.add(col_off, d_co);      // stays resident for K4 (member pack)
+        if (int rc = gather_pack.commit(stream)) return rc;
         if (int rc = d_ci.alloc(total * sizeof(int32_t))) return rc;
         if (int rc = d_cc.alloc(total)) return rc;
         EventPair e; if (int rc = e.init()) return rc;
@@ -787,13 +821,15 @@ static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const st
         max_m = std::max(max_m, (int)m);
     }
     DBuf d_oo, d_n, d_wc, d_mo, d_ids, d_rw, d_bo, d_bits, d_ac, d_ar, d_deg, d_no, d_nbr;
-    if (int rc = d_oo.upload(ctg_out_off)) return rc;
-    if (int rc = d_n.upload(ctg_n)) return rc;
-    if (int rc = d_wc.upload(job.win_contig)) return rc;
-    if (int rc = d_mo.upload(job.win_mask_off)) return rc;
-    if (int rc = d_ids.upload(job.mask_ids)) return rc;
-    if (int rc = d_rw.upload(row_win)) return rc;
-    if (int rc = d_bo.upload(win_bits_off)) return rc;
+    UploadPack pk;
+    pk.add(ctg_out_off, d_oo);
+    pk.add(ctg_n, d_n);
+    pk.add(job.win_contig, d_wc);
+    pk.add(job.win_mask_off, d_mo);
+    pk.add(job.mask_ids, d_ids);
+    pk.add(row_win, d_rw);
+    pk.add(win_bits_off, d_bo);
+    if (int rc = pk.commit(stream)) return rc;
     const size_t bits_bytes = (size_t)win_bits_off.back() * 8;
     if (int rc = d_bits.alloc(bits_bytes)) return rc;
     if (int rc = d_ac.alloc(4)) return rc;
@@ -914,24 +950,26 @@ struct HipSrOps : hs::SrDeviceOps {
     }
 
     DBuf d_col_off, d_col_idx, d_col_code;    // SNP columns of the batch: uploaded once, read by K5a and the seeded CW wave
+    UploadPack col_pack, graph_pack;          // their storage, and the storage of the graph set
     const hs::CwChain* resident_cols = nullptr;
     int simdiff_columns(const hs::SimdiffJob& job, float* k_ms) override {
         const hs::CwChain& ch = *job.cols;
-        if (int rc = d_col_off.upload(ch.col_off)) return rc;
-        if (int rc = d_col_idx.upload(ch.col_idx)) return rc;
-        if (int rc = d_col_code.upload(ch.col_code)) return rc;
+        col_pack.add(ch.col_off, d_col_off); col_pack.add(ch.col_idx, d_col_idx); col_pack.add(ch.col_code, d_col_code);
+        if (int rc = col_pack.commit(stream)) return rc;
         resident_cols = job.cols;
         sd_out_off = job.out_off; sd_n = job.n_reads;
         if (job.out_total <= 0) return HS_OK;
         DBuf d_alt, d_ref, d_sr, d_sa, d_sc, d_cb, d_po, d_n, d_w, d_oo, t_c, t_i, t_j;
-        if (int rc = d_sr.upload(job.snp_ref)) return rc;
-        if (int rc = d_sa.upload(job.snp_alt)) return rc;
-        if (int rc = d_sc.upload(job.snp_contig)) return rc;
-        if (int rc = d_cb.upload(job.contig_snp_base)) return rc;
-        if (int rc = d_po.upload(job.plane_off)) return rc;
-        if (int rc = d_n.upload(job.n_reads)) return rc;
-        if (int rc = d_w.upload(job.words)) return rc;
-        if (int rc = d_oo.upload(job.out_off)) return rc;
+        UploadPack pk;
+        pk.add(job.snp_ref, d_sr);
+        pk.add(job.snp_alt, d_sa);
+        pk.add(job.snp_contig, d_sc);
+        pk.add(job.contig_snp_base, d_cb);
+        pk.add(job.plane_off, d_po);
+        pk.add(job.n_reads, d_n);
+        pk.add(job.words, d_w);
+        pk.add(job.out_off, d_oo);
+        if (int rc = pk.commit(stream)) return rc;
         const size_t pbytes = (size_t)job.plane_total * sizeof(uint64_t);
         if (int rc = d_alt.alloc(pbytes)) return rc;
         if (int rc = d_ref.alloc(pbytes)) return rc;
@@ -953,14 +991,15 @@ struct HipSrOps : hs::SrDeviceOps {
     }
     int set_graphs(const hs::CwGraphSet& g) override {
         max_n = g.max_n;
-        if (int rc = d_adj_off.upload(g.adj_off)) return rc;
-        if (int rc = d_adj.upload(g.adj)) return rc;
-        if (int rc = d_gob.upload(g.graph_off_base)) return rc;
-        if (int rc = d_gab.upload(g.graph_adj_base)) return rc;
-        if (int rc = d_gn.upload(g.graph_n)) return rc;
-        if (int rc = d_perm.upload(g.perm)) return rc;
-        if (int rc = d_pb.upload(g.perm_base_of_graph)) return rc;
-        if (int rc = d_mask.upload(g.mask)) return rc;
+        graph_pack.add(g.adj_off, d_adj_off);
+        graph_pack.add(g.adj, d_adj);
+        graph_pack.add(g.graph_off_base, d_gob);
+        graph_pack.add(g.graph_adj_base, d_gab);
+        graph_pack.add(g.graph_n, d_gn);
+        graph_pack.add(g.perm, d_perm);
+        graph_pack.add(g.perm_base_of_graph, d_pb);
+        graph_pack.add(g.mask, d_mask);
+        if (int rc = graph_pack.commit(stream)) return rc;
         return HS_OK;
     }
     int cw_chain(const hs::CwChain& ch, std::vector<int32_t>& labels, float k_ms[3]) override {
@@ -982,21 +1021,16 @@ struct HipSrOps : hs::SrDeviceOps {
         DBuf d_ig, d_ilb, d_seed, d_local, d_wk, d_wn, d_wgn, d_wgf, d_wlb, d_wob, d_lab2, d_lab3, d_agg,
             d_s1, d_s2, d_s3;
         if (resident_cols != &ch) {   // normally uploaded by simdiff_columns already
-            if (int rc = d_col_off.upload(ch.col_off)) return rc;
-            if (int rc = d_col_idx.upload(ch.col_idx)) return rc;
-            if (int rc = d_col_code.upload(ch.col_code)) return rc;
+            col_pack.add(ch.col_off, d_col_off); col_pack.add(ch.col_idx, d_col_idx); col_pack.add(ch.col_code, d_col_code);
+            if (int rc = col_pack.commit(stream)) return rc;
             resident_cols = &ch;
         }
-        if (int rc = d_ig.upload(ig)) return rc;
-        if (int rc = d_ilb.upload(ilb)) return rc;
-        if (int rc = d_seed.upload(ch.seed_col)) return rc;
+        UploadPack pk;
+        pk.add(ig, d_ig); pk.add(ilb, d_ilb); pk.add(ch.seed_col, d_seed);
         if (int rc = d_local.alloc((size_t)slab * sizeof(int32_t))) return rc;
-        if (int rc = d_wk.upload(win_k)) return rc;
-        if (int rc = d_wn.upload(ch.win_n)) return rc;
-        if (int rc = d_wgn.upload(ch.win_graph_now)) return rc;
-        if (int rc = d_wgf.upload(ch.win_graph_final)) return rc;
-        if (int rc = d_wlb.upload(win_local_base)) return rc;
-        if (int rc = d_wob.upload(wbase)) return rc;
+        pk.add(win_k, d_wk); pk.add(ch.win_n, d_wn); pk.add(ch.win_graph_now, d_wgn); pk.add(ch.win_graph_final, d_wgf);
+        pk.add(win_local_base, d_wlb); pk.add(wbase, d_wob);
+        if (int rc = pk.commit(stream)) return rc;
         if (int rc = d_lab2.alloc((size_t)total_n * sizeof(int32_t))) return rc;
         if (int rc = d_lab3.alloc((size_t)total_n * sizeof(int32_t))) return rc;
         if (int rc = d_agg.alloc((size_t)total_n * sizeof(double))) return rc;
