@@ -18,6 +18,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
     for (d, c), v in per_dispatch.items():
         a = acc[(names[d], c)]
         a[0] += v; a[1] += 1
-print("kernel,counter,mean_per_dispatch,dispatches")
+w = csv.writer(sys.stdout)
+w.writerow(["kernel", "counter", "mean_per_dispatch", "dispatches"])
 for (k, c), (s, n) in sorted(acc.items()):
-    print(f"{k},{c},{s / n:.1f},{n}")
+    w.writerow([k, c, f"{s / n:.1f}", n])
