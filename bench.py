@@ -173,10 +173,13 @@ def main():
     k_cv = np.zeros(4); k_sr = np.zeros(4); t_dev = 0.0; t_host = 0.0; k4 = 0.0; k6 = 0.0
     last = None
     step_ms = []
+    wall = {}
     for _ in range(args.steps):
         ts = time.perf_counter()
         cv, sr, gathered = step()
         step_ms.append((time.perf_counter() - ts) * 1e3)
+        for kk, vv in sr.get("wall_ms", {}).items():
+            wall[kk] = wall.get(kk, 0.0) + vv
         k_cv += np.asarray(cv["t_kernel_ms"]); k_sr += np.asarray(sr["t_kernel_ms"]); k4 += cv.get("t_kernel_k4_ms", 0.0); k6 += sr.get("t_kernel_graph_ms", 0.0)
         t_dev += cv["t_device_ms"] + sr["t_device_ms"]; t_host += cv["t_host_ms"] + sr["t_host_ms"]
         last = (cv, sr)
@@ -236,6 +239,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kernels[dom],
                          "algorithmic_bytes_per_launch": alg_bytes[dom]},
             "kernel_ms_per_step": kernels, "step_ms": [round(x, 2) for x in step_ms],
+            "pipeline_wall_ms_per_step": {k: v / K for k, v in wall.items()},
             "phase_ms_per_step": {"device_phases": t_dev / K, "host_glue": t_host / K, **{"py_" + k: v / K for k, v in py_ms.items()}},
         }
         if world == 1 and args.cpu_contigs > 0:

@@ -317,12 +317,15 @@ class PipelineGroups:
 
     def run(self, automatic_snp_threshold=0.33, n_threads=0, error_rate_fn=None, rarest_strain_abundance=0.01, low_memory=False,
             amplicon=False, seed=12345, window_size=0):
+        import time
         lib = load()
         G = len(self.ranges)
         per = max(1, n_threads // G) if n_threads > 0 else 0
         h = self.batch.handle
         sel = C.POINTER(CvSelection)()
+        t_0 = time.perf_counter()
         _check(lib.hs_cv_select(h, C.byref(sel)))
+        t_1 = time.perf_counter()
 
         def cv_part(rg):
             res = C.POINTER(CvResult)()
@@ -335,6 +338,7 @@ class PipelineGroups:
 
         try:
             cvs = list(self.pool.map(cv_part, self.ranges))
+            t_2 = time.perf_counter()
             s = sel.contents
             md = np.concatenate([c[1]["mean_distance"] for c in cvs]) if cvs else np.zeros(0, np.float32)
             # call_variants.cpp:1312-1315,1377: float sum in contig order / number of contigs with a positive distance
@@ -368,13 +372,17 @@ class PipelineGroups:
                 lib.hs_cv_result_destroy(res)
             return sr
 
+        t_3 = time.perf_counter()
         srs = list(self.pool.map(sr_part, zip(self.ranges, cvs)))
+        t_4 = time.perf_counter()
         sr = {"labels": np.concatenate([x["labels"] for x in srs]),
               "win_start": np.concatenate([x["win_start"] for x in srs]), "win_end": np.concatenate([x["win_end"] for x in srs]),
               "t_device_ms": sum(x["t_device_ms"] for x in srs), "t_host_ms": sum(x["t_host_ms"] for x in srs),
               "n_cw_instances": sum(x["n_cw_instances"] for x in srs),
               "t_kernel_ms": np.sum([x["t_kernel_ms"] for x in srs], axis=0).tolist(),
               "t_kernel_graph_ms": sum(x["t_kernel_graph_ms"] for x in srs), "n_graph_rows_host": sum(x["n_graph_rows_host"] for x in srs)}
+        sr["wall_ms"] = {"select": (t_1 - t_0) * 1e3, "cv_groups": (t_2 - t_1) * 1e3, "between": (t_3 - t_2) * 1e3, "sr_groups": (t_4 - t_3) * 1e3,
+                         "collect": (time.perf_counter() - t_4) * 1e3}
         return cv, sr
 
     def window_size(self, amplicon=False):

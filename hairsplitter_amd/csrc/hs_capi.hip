@@ -485,7 +485,8 @@ static int cw_launch(const int32_t* d_adj_off, const int32_t* d_adj, const int64
                      const int64_t* d_graph_adj_base, const int32_t* d_graph_n, const int32_t* d_perm, const int64_t* d_perm_base,
                      const uint8_t* d_mask, const int32_t* d_inst_graph, const int64_t* d_inst_label_base, int32_t n_inst,
                      int32_t max_n, int32_t* d_labels, int32_t* d_sweeps, void* stream, const int64_t* d_inst_seed_col = nullptr,
-                     const int64_t* d_col_off = nullptr, const int32_t* d_col_idx = nullptr, const uint8_t* d_col_code = nullptr) {
+                     const int64_t* d_col_off = nullptr, const int32_t* d_col_idx = nullptr, const uint8_t* d_col_code = nullptr,
+                     const int32_t* d_visit = nullptr, const int32_t* d_visit_n = nullptr) {
     if (n_inst <= 0) return HS_OK;
     const size_t lds = (size_t)max_n * 8 + 1024;
     if (lds > 160 * 1024) { set_error("Chinese Whispers: more than 20000 reads on one contig is not supported"); return HS_EINVAL; }
@@ -493,7 +494,7 @@ static int cw_launch(const int32_t* d_adj_off, const int32_t* d_adj, const int64
         HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_chinese_whispers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(hsdev::k_chinese_whispers, dim3((unsigned)n_inst), dim3(64), lds, (hipStream_t)stream, d_adj_off, d_adj,
                        d_graph_off_base, d_graph_adj_base, d_graph_n, d_perm, d_perm_base, d_mask, d_inst_graph,
-                       d_inst_label_base, n_inst, d_labels, d_sweeps, d_inst_seed_col, d_col_off, d_col_idx, d_col_code);
+                       d_inst_label_base, n_inst, d_labels, d_sweeps, d_inst_seed_col, d_col_off, d_col_idx, d_col_code, d_visit, d_visit_n);
     HS_HIP(hipGetLastError());
     return HS_OK;
 }
@@ -951,6 +952,7 @@ struct HipSrOps : hs::SrDeviceOps {
 
     DBuf d_col_off, d_col_idx, d_col_code;    // SNP columns of the batch: uploaded once, read by K5a and the seeded CW wave
     UploadPack col_pack, graph_pack;          // their storage, and the storage of the graph set
+    DBuf d_visit, d_visit_n;                  // per-graph visiting lists of the Chinese-Whispers kernel
     const hs::CwChain* resident_cols = nullptr;
     int simdiff_columns(const hs::SimdiffJob& job, float* k_ms) override {
         const hs::CwChain& ch = *job.cols;
@@ -1000,6 +1002,16 @@ struct HipSrOps : hs::SrDeviceOps {
         graph_pack.add(g.perm_base_of_graph, d_pb);
         graph_pack.add(g.mask, d_mask);
         if (int rc = graph_pack.commit(stream)) return rc;
+        // visiting lists (masked nodes with neighbours, in permutation order), once per graph
+        const int n_graphs = (int)g.graph_n.size();
+        if (int rc = d_visit.alloc(g.mask.size() * sizeof(int32_t))) return rc;
+        if (int rc = d_visit_n.alloc((size_t)n_graphs * sizeof(int32_t))) return rc;
+        if (n_graphs > 0) {
+            hipLaunchKernelGGL(hsdev::k_cw_visit_lists, dim3((unsigned)n_graphs), dim3(64), 0, stream, d_adj_off.as<int32_t>(), d_gob.as<int64_t>(),
+                               d_gn.as<int32_t>(), d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), n_graphs, d_visit.as<int32_t>(),
+                               d_visit_n.as<int32_t>());
+            HS_HIP(hipGetLastError());
+        }
         return HS_OK;
     }
     int cw_chain(const hs::CwChain& ch, std::vector<int32_t>& labels, float k_ms[3]) override {
@@ -1046,7 +1058,7 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = cw_launch(d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_gn.as<int32_t>(),
                                d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), d_ig.as<int32_t>(), d_ilb.as<int64_t>(), (int32_t)n_inst,
                                max_n, d_local.as<int32_t>(), nullptr, stream, d_seed.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
-                               d_col_code.as<uint8_t>())) return rc;
+                               d_col_code.as<uint8_t>(), d_visit.as<int32_t>(), d_visit_n.as<int32_t>())) return rc;
         HS_HIP(hipEventRecord(e1.b, stream));
         // merged ids -> wave 2 on the finalize graph
         HS_HIP(hipEventRecord(e2.a, stream));
@@ -1056,7 +1068,7 @@ struct HipSrOps : hs::SrDeviceOps {
         HS_HIP(hipGetLastError());
         if (int rc = cw_launch(d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_gn.as<int32_t>(),
                                d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), d_wgf.as<int32_t>(), d_wob.as<int64_t>(), W, max_n,
-                               d_lab2.as<int32_t>(), nullptr, stream)) return rc;
+                               d_lab2.as<int32_t>(), nullptr, stream, nullptr, nullptr, nullptr, nullptr, d_visit.as<int32_t>(), d_visit_n.as<int32_t>())) return rc;
         HS_HIP(hipEventRecord(e2.b, stream));
         // small clusters dropped, renumbered -> wave 3
         HS_HIP(hipEventRecord(e3.a, stream));
@@ -1066,7 +1078,7 @@ struct HipSrOps : hs::SrDeviceOps {
         HS_HIP(hipGetLastError());
         if (int rc = cw_launch(d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_gn.as<int32_t>(),
                                d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), d_wgf.as<int32_t>(), d_wob.as<int64_t>(), W, max_n,
-                               d_lab3.as<int32_t>(), nullptr, stream)) return rc;
+                               d_lab3.as<int32_t>(), nullptr, stream, nullptr, nullptr, nullptr, nullptr, d_visit.as<int32_t>(), d_visit_n.as<int32_t>())) return rc;
         HS_HIP(hipEventRecord(e3.b, stream));
         labels.resize((size_t)total_n);
         {
@@ -1092,7 +1104,7 @@ struct HipSrOps : hs::SrDeviceOps {
         HS_HIP(hipEventRecord(ev.a, stream));
         if (int rc = cw_launch(d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_gn.as<int32_t>(),
                                d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), d_ig.as<int32_t>(), d_lb.as<int64_t>(), n_inst,
-                               max_n, d_lab.as<int32_t>(), nullptr, stream)) return rc;
+                               max_n, d_lab.as<int32_t>(), nullptr, stream, nullptr, nullptr, nullptr, nullptr, d_visit.as<int32_t>(), d_visit_n.as<int32_t>())) return rc;
         HS_HIP(hipEventRecord(ev.b, stream));
         HS_HIP(hipMemcpy(wv.labels.data(), d_lab.p, wv.labels.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
         float m = 0; if (int rc = ev.ms(&m)) return rc;

@@ -18,6 +18,7 @@
 #include "hs_rh8.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +35,17 @@ struct DensePartition {
     int lo = 0, hi = -1;           // present reads lie in [lo, hi]
     std::vector<int8_t> state;     // ABSENT, or mostFrequentBases in {-1,0,1}
     std::vector<int32_t> more, less;
+    // the same states as bit sets over the reads (loop A compares every candidate column with every live partition:
+    // popcounts of ANDs instead of a walk over the column entries); maintained by partition_from_column() and augment()
+    std::vector<uint64_t> present, plus, minus;
+    void sync_bits(int r) {
+        const uint64_t b = 1ull << (r & 63);
+        const size_t w = (size_t)r >> 6;
+        const int8_t s = state[(size_t)r];
+        if (s == 2) present[w] &= ~b; else present[w] |= b;
+        if (s == 1) plus[w] |= b; else plus[w] &= ~b;
+        if (s == -1) minus[w] |= b; else minus[w] &= ~b;
+    }
 };
 
 struct Contingency {
@@ -80,20 +92,9 @@ void resolve_columns(ColumnSet& cs, int first, int last) {
 // (first in robin_hood iteration order on ties: call_variants.cpp:837-844, Partition.cpp:59-66).
 // `signed_ref_quirk`: in distance() the reference compares a *signed* char with unsigned keys (:838), so a
 // reference code >= 128 never equals any key and stays eligible.
-static uint8_t second_most_frequent(const uint8_t* code, int n, const uint8_t* take, uint8_t ref, bool signed_ref_quirk,
-                                    bool insert_ref_last, uint8_t dflt) {
-    // distinct codes in first-appearance order with their counts (a column carries a dozen codes at most: linear search)
-    uint8_t seen[256];
-    int cnt[256];
-    int nseen = 0;
-    for (int i = 0; i < n; ++i) {
-        if (take && !take[i]) continue;
-        const uint8_t c = code[i];
-        int k = 0;
-        while (k < nseen && seen[k] != c) ++k;
-        if (k == nseen) { seen[nseen] = c; cnt[nseen] = 0; nseen++; }
-        cnt[k]++;
-    }
+// decision half of second_most_frequent(): `seen` = distinct codes in first-appearance order with their counts
+static uint8_t second_from_seen(const uint8_t* seen, const int* cnt, int nseen, uint8_t ref, bool signed_ref_quirk, bool insert_ref_last,
+                                uint8_t dflt) {
     if (nseen == 0) return dflt;
     const bool ref_eligible = signed_ref_quirk && ref >= 128;
     int best = -1, nbest = 0;
@@ -126,6 +127,24 @@ static uint8_t second_most_frequent(const uint8_t* code, int n, const uint8_t* t
     return bestk;
 }
 
+static uint8_t second_most_frequent(const uint8_t* code, int n, const uint8_t* take, uint8_t ref, bool signed_ref_quirk,
+                                    bool insert_ref_last, uint8_t dflt) {
+    // distinct codes in first-appearance order with their counts (a column carries a dozen codes at most: linear search)
+    uint8_t seen[256];
+    int cnt[256];
+    int nseen = 0;
+    for (int i = 0; i < n; ++i) {
+        if (take && !take[i]) continue;
+        const uint8_t c = code[i];
+        int k = 0;
+        while (k < nseen && seen[k] != c) ++k;
+        if (k == nseen) { seen[nseen] = c; cnt[nseen] = 0; nseen++; }
+        cnt[k]++;
+    }
+    return second_from_seen(seen, cnt, nseen, ref, signed_ref_quirk, insert_ref_last, dflt);
+}
+
+#ifdef HS_SELFCHECK   // entry-walk form, kept as the cross-check of the bit-set form in the test harness build
 // distance(Partition&, Column&, char): call_variants.cpp:778-967
 static Contingency column_vs_partition(const DensePartition& p, const int32_t* idx, const uint8_t* code, int n, uint8_t ref) {
     Contingency r;
@@ -145,6 +164,67 @@ static Contingency column_vs_partition(const DensePartition& p, const int32_t* i
         if (code[i] == r.most) { if (s == 1) r.n11++; else if (s == -1) r.n01++; }
         else if (code[i] == r.second) { if (s == 1) r.n10++; else if (s == -1) r.n00++; }
     }
+    return r;
+}
+#endif
+
+// A candidate column as one bit set per distinct code (the reads that carry it), in first-appearance order.
+struct ColumnBits {
+    int words = 0, nslots = 0;
+    uint8_t code_of[128];
+    std::vector<uint64_t> bits;   // [nslots][words]
+    std::vector<uint64_t> any;    // [words]
+    void build(const int32_t* idx, const uint8_t* code, int n, int n_reads) {
+        words = (n_reads + 63) >> 6;
+        nslots = 0;
+        any.assign((size_t)words, 0ull);
+        bits.clear();
+        for (int i = 0; i < n; ++i) {
+            int k = 0;
+            while (k < nslots && code_of[k] != code[i]) ++k;
+            if (k == nslots) {
+                if (nslots == 128) continue;   // cannot happen: 125 pileup codes
+                code_of[nslots++] = code[i];
+                bits.resize((size_t)nslots * words, 0ull);
+            }
+            const uint64_t b = 1ull << (idx[i] & 63);
+            bits[(size_t)k * words + ((size_t)idx[i] >> 6)] |= b;
+            any[(size_t)idx[i] >> 6] |= b;
+        }
+    }
+};
+
+// column_vs_partition() on bit sets: same result, popcounts of ANDs instead of a walk over the column entries
+static Contingency column_vs_partition_bits(const DensePartition& p, const ColumnBits& cb, uint8_t ref) {
+    Contingency r;
+    const int W = cb.words;
+    int shared = 0;
+    for (int w = 0; w < W; ++w) shared += __builtin_popcountll(cb.any[(size_t)w] & p.present[(size_t)w]);
+    if (shared == 0) return r;
+    r.comparable = true;
+    r.most = ref;
+    // counts among the shared reads; first appearance among them = lowest shared read index (column entries are ascending)
+    uint8_t seen[128]; int cnt[128]; int first[128];
+    int nseen = 0;
+    for (int k = 0; k < cb.nslots; ++k) {
+        const uint64_t* bk = cb.bits.data() + (size_t)k * W;
+        int c = 0, f = -1;
+        for (int w = 0; w < W; ++w) {
+            const uint64_t x = bk[w] & p.present[(size_t)w];
+            if (x) { if (f < 0) f = w * 64 + __builtin_ctzll(x); c += __builtin_popcountll(x); }
+        }
+        if (c) { seen[nseen] = cb.code_of[k]; cnt[nseen] = c; first[nseen] = f; nseen++; }
+    }
+    for (int i = 1; i < nseen; ++i)   // insertion sort by first shared appearance (a handful of codes)
+        for (int j = i; j > 0 && first[j] < first[j - 1]; --j) { std::swap(first[j], first[j - 1]); std::swap(seen[j], seen[j - 1]); std::swap(cnt[j], cnt[j - 1]); }
+    r.second = second_from_seen(seen, cnt, nseen, ref, true, true, ' ');
+    const uint64_t* bm = nullptr; const uint64_t* bs = nullptr;
+    for (int k = 0; k < cb.nslots; ++k) {
+        if (cb.code_of[k] == r.most) bm = cb.bits.data() + (size_t)k * W;
+        if (cb.code_of[k] == r.second) bs = cb.bits.data() + (size_t)k * W;
+    }
+    if (bm) for (int w = 0; w < W; ++w) { r.n11 += __builtin_popcountll(bm[w] & p.plus[(size_t)w]); r.n01 += __builtin_popcountll(bm[w] & p.minus[(size_t)w]); }
+    if (bs && r.second != r.most) for (int w = 0; w < W; ++w) { r.n10 += __builtin_popcountll(bs[w] & p.plus[(size_t)w]); r.n00 += __builtin_popcountll(bs[w] & p.minus[(size_t)w]); }
     return r;
 }
 
@@ -173,6 +253,9 @@ static void partition_from_column(DensePartition& p, int n_reads, const int32_t*
         p.state[r] = code[i] == ref ? 1 : (code[i] == second ? -1 : 0);
         p.more[r] = 1; p.less[r] = 0;
     }
+    const size_t words = ((size_t)n_reads + 63) >> 6;
+    p.present.assign(words, 0ull); p.plus.assign(words, 0ull); p.minus.assign(words, 0ull);
+    for (int i = 0; i < n; ++i) p.sync_bits(idx[i]);
     p.lo = n ? idx[0] : 0; p.hi = n ? idx[n - 1] : -1;
 }
 
@@ -218,6 +301,7 @@ static void augment(DensePartition& p, const int32_t* idx, const uint8_t* code, 
             if (p.less[r] + 1 > p.more[r]) { st = (int8_t)-st; p.more[r] += 1; }
             else p.less[r] += 1;
         }
+        p.sync_bits(r);
     }
     if (n) { if (p.hi < p.lo) { p.lo = idx[0]; p.hi = idx[n - 1]; } else { p.lo = std::min(p.lo, idx[0]); p.hi = std::max(p.hi, idx[n - 1]); } }
     p.n_occ += 1;
@@ -389,8 +473,13 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
     out.n_candidates = (int)cand.size();
     out.n_automatic = (int)automatic.size();
 
+    const bool tim = std::getenv("HS_TIMING_AB") != nullptr;
+    auto nowus = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a0 = tim ? nowus() : 0;
+    long n_cmp = 0, n_aug = 0;
     // ---- loop A (:590-638) ----
     std::vector<DensePartition> parts;
+    ColumnBits colbits;
     int last_position = -5;
     for (int ci : cand) {
         const int pos = cs.pos[ci];
@@ -398,9 +487,19 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
         const int32_t* idx = col_idx(ci); const uint8_t* code = col_code(ci); const int n = col_n(ci);
         bool found = false;
         int n_corr = 0;
+        if (!parts.empty()) colbits.build(idx, code, n, n_reads);
         for (size_t p = 0; p < parts.size(); ++p) {
             if (std::abs(pos - parts[p].right) > 50000) continue;
-            const Contingency d = column_vs_partition(parts[p], idx, code, n, cs.k0[ci]);
+            const Contingency d = column_vs_partition_bits(parts[p], colbits, cs.k0[ci]);
+            n_cmp++;
+#ifdef HS_SELFCHECK
+            {
+                const Contingency e = column_vs_partition(parts[p], idx, code, n, cs.k0[ci]);
+                if (e.n00 != d.n00 || e.n01 != d.n01 || e.n10 != d.n10 || e.n11 != d.n11 || e.comparable != d.comparable || e.second != d.second) {
+                    std::fprintf(stderr, "HS_SELFCHECK: bit-set column_vs_partition differs\n"); std::abort();
+                }
+            }
+#endif
             const int comparable = d.n00 + d.n11 + d.n01 + d.n10;
             if (d.n00 + d.n01 > 0.1 * comparable && d.n00 + d.n01 < 0.9 * comparable && d.n01 + d.n11 > 0.1 * comparable
                 && d.n01 + d.n11 < 0.9 * comparable && chi_square(d) > 15) {
@@ -409,7 +508,7 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
             const bool enough = (size_t)comparable >= (size_t)n / 2;
             if ((d.n01 <= std::max(0.1 * (d.n00 + d.n01), 1.0) && d.n10 < std::max(0.1 * (d.n11 + d.n10), 1.0) && enough)
                 || (d.n00 <= std::max(0.1 * (d.n00 + d.n01), 1.0) && d.n11 < std::max(0.1 * (d.n11 + d.n10), 1.0) && enough)) {
-                found = true;
+                found = true; n_aug++;
                 augment(parts[p], idx, code, n, d, pos);
                 break;
             }
@@ -424,6 +523,7 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
     st.have_partitions = !parts.empty();
     if (parts.empty()) return;
 
+    const double t_b0 = tim ? nowus() : 0;
     // ---- loop B (:646-708) ----
     std::vector<DensePartition>& finals = st.finals;
     for (size_t p1 = 0; p1 < parts.size(); ++p1) {
@@ -446,6 +546,8 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
         if (different) finals.push_back(parts[p1]);
     }
     out.n_final_partitions = (int)finals.size();
+    if (tim) std::fprintf(stderr, "[hs timing] phase_ab: %d candidates, %zu partitions, %ld comparisons, %ld augmentations, %zu finals; loop A %.0f us, loop B %.0f us\n",
+                          (int)cand.size(), parts.size(), n_cmp, n_aug, finals.size(), t_b0 - t_a0, nowus() - t_b0);
 }
 
 // Loops C (:721-738) and D (:745-764) run on the device (k_column_partition_test): the final partitions leave as dense

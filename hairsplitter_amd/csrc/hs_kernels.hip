@@ -661,6 +661,33 @@ __global__ __launch_bounds__(256) void k_simdiff(
 // most frequent label with the LOWEST id on ties (:272-279). Masked-out nodes keep voting with their initial
 // label and are set to -2 at the end. Stops after 15 sweeps or when a sweep changes <= 2 nodes (:167).
 // ------------------------------------------------------------------------------------------------
+// Visiting list of a graph: its masked nodes with at least one neighbour, in the order of the permutation. The order is the
+// same in every sweep of every instance on the graph, so it is built once per graph instead of re-scanning the N-entry
+// permutation (N ~ 10 x the masked reads of a window) in every sweep.
+__global__ __launch_bounds__(64) void k_cw_visit_lists(
+    const int32_t* __restrict__ adj_off, const int64_t* __restrict__ graph_off_base, const int32_t* __restrict__ graph_n,
+    const int32_t* __restrict__ perm, const int64_t* __restrict__ perm_base, const uint8_t* __restrict__ mask, int n_graphs,
+    int32_t* __restrict__ visit, int32_t* __restrict__ visit_n) {
+    const int lane = lane_id();
+    const int g = (int)blockIdx.x;
+    if (g >= n_graphs) return;
+    const int N = graph_n[g];
+    const int32_t* __restrict__ aoff = adj_off + graph_off_base[g];
+    const int32_t* __restrict__ prm = perm + perm_base[g];
+    const uint8_t* __restrict__ msk = mask + graph_off_base[g] - g;
+    int32_t* __restrict__ out = visit + graph_off_base[g] - g;
+    int count = 0;
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        const int kk = k0 + lane;
+        int i = 0; bool ok = false;
+        if (kk < N) { i = prm[kk]; ok = msk[i] && aoff[i + 1] > aoff[i]; }
+        const unsigned long long m = __ballot(ok);
+        if (ok) out[count + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        count += __popcll(m);
+    }
+    if (lane == 0) visit_n[g] = count;
+}
+
 __global__ __launch_bounds__(64) void k_chinese_whispers(
     const int32_t* __restrict__ adj_off, const int32_t* __restrict__ adj,
     const int64_t* __restrict__ graph_off_base, const int64_t* __restrict__ graph_adj_base,
@@ -670,7 +697,9 @@ __global__ __launch_bounds__(64) void k_chinese_whispers(
     int32_t* __restrict__ sweeps_out,
     // optional seeding from a SNP column (separate_reads.cpp:1678-1691); inst_seed_col == nullptr: labels_io holds the start
     const int64_t* __restrict__ inst_seed_col, const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx,
-    const uint8_t* __restrict__ col_code) {
+    const uint8_t* __restrict__ col_code,
+    // optional visiting lists (k_cw_visit_lists); nullptr: the permutation is scanned in every sweep
+    const int32_t* __restrict__ visit, const int32_t* __restrict__ visit_n) {
     extern __shared__ int32_t cw_lds[];
     const int lane = lane_id();
     const int inst = (int)blockIdx.x;
@@ -681,6 +710,8 @@ __global__ __launch_bounds__(64) void k_chinese_whispers(
     const int32_t* __restrict__ anb = adj + graph_adj_base[g];
     const int32_t* __restrict__ prm = perm + perm_base[g];
     const uint8_t* __restrict__ msk = mask + graph_off_base[g] - g;      // mask is N per graph: base = off_base - g
+    const int32_t* __restrict__ vis = visit ? visit + graph_off_base[g] - g : nullptr;
+    const int n_visit = visit ? visit_n[g] : N;
     int32_t* __restrict__ lab_g = labels_io + inst_label_base[inst];
     int32_t* lab = cw_lds;          // [N]
     int32_t* cnt = cw_lds + N;      // [N]
@@ -706,55 +737,60 @@ __global__ __launch_bounds__(64) void k_chinese_whispers(
     int changes = 3, iters = 0;
     while (changes > 2 && iters < 15) {
         changes = 0;
-        for (int k0 = 0; k0 < N; k0 += 64) {
+        for (int k0 = 0; k0 < n_visit; k0 += 64) {
             const int kk = k0 + lane;
             int i_l = -1, o0_l = 0, o1_l = 0;
-            if (kk < N) {
-                i_l = prm[kk];
-                if (msk[i_l]) { o0_l = aoff[i_l]; o1_l = aoff[i_l + 1]; }
+            if (kk < n_visit) {
+                i_l = vis ? vis[kk] : prm[kk];
+                if (vis || msk[i_l]) { o0_l = aoff[i_l]; o1_l = aoff[i_l + 1]; }
             }
             unsigned long long act = __ballot(o1_l > o0_l);
             while (act) {
                 const int l = __builtin_ctzll(act);
                 act &= act - 1ull;
-                const int i = __shfl(i_l, l, 64);
-                const int o0 = __shfl(o0_l, l, 64), o1 = __shfl(o1_l, l, 64);
-                unsigned long long best = 0ull;
-                // pass 1: votes
-                for (int o = o0; o < o1; o += 64) {
-                    const int idx = o + lane;
-                    if (idx < o1) {
-                        const int lb = lab[anb[idx]];
-                        if (lb >= 0) atomicAdd(&cnt[lb], 1);
+                const int i = __builtin_amdgcn_readlane(i_l, l);
+                const int o0 = __builtin_amdgcn_readlane(o0_l, l), o1 = __builtin_amdgcn_readlane(o1_l, l);
+                int best_cnt = 0, best_lab = -1;
+                if (o1 - o0 <= 64) {
+                    // the usual case: all neighbours in one step, their labels stay in registers for the three phases
+                    const int idx = o0 + lane;
+                    const int lb = idx < o1 ? lab[anb[idx]] : -1;
+                    if (lb >= 0) atomicAdd(&cnt[lb], 1);                       // votes
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    const int c = lb >= 0 ? cnt[lb] : 0;                       // totals
+                    best_cnt = wave_max_i32(c);
+                    best_lab = 0x7fffffff - wave_max_i32((lb >= 0 && c == best_cnt) ? 0x7fffffff - lb : 0);   // lowest label among the maxima
+                    if (lb >= 0) cnt[lb] = 0;                                  // reset the touched counters
+                } else {
+                    for (int o = o0; o < o1; o += 64) {
+                        const int idx = o + lane;
+                        if (idx < o1) { const int lb = lab[anb[idx]]; if (lb >= 0) atomicAdd(&cnt[lb], 1); }
                     }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                // pass 2: read totals
-                for (int o = o0; o < o1; o += 64) {
-                    const int idx = o + lane;
-                    if (idx < o1) {
-                        const int lb = lab[anb[idx]];
-                        if (lb >= 0) {
-                            const unsigned long long key = ((unsigned long long)(unsigned)cnt[lb] << 32) | (unsigned)(0x7fffffff - lb);
-                            best = key > best ? key : best;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    unsigned long long best = 0ull;
+                    for (int o = o0; o < o1; o += 64) {
+                        const int idx = o + lane;
+                        if (idx < o1) {
+                            const int lb = lab[anb[idx]];
+                            if (lb >= 0) {
+                                const unsigned long long key = ((unsigned long long)(unsigned)cnt[lb] << 32) | (unsigned)(0x7fffffff - lb);
+                                best = key > best ? key : best;
+                            }
                         }
                     }
-                }
-                best = wave_max_u64(best);
-                // pass 3: reset the touched counters
-                for (int o = o0; o < o1; o += 64) {
-                    const int idx = o + lane;
-                    if (idx < o1) {
-                        const int lb = lab[anb[idx]];
-                        if (lb >= 0) cnt[lb] = 0;
+                    best = wave_max_u64(best);
+                    for (int o = o0; o < o1; o += 64) {
+                        const int idx = o + lane;
+                        if (idx < o1) { const int lb = lab[anb[idx]]; if (lb >= 0) cnt[lb] = 0; }
                     }
+                    best_cnt = (int)(best >> 32);
+                    best_lab = 0x7fffffff - (int)(best & 0xffffffffull);
                 }
-                const int bcnt = (int)(best >> 32);
-                if (bcnt > 0) {
-                    const int blab = 0x7fffffff - (int)(best & 0xffffffffull);
-                    if (lab[i] != blab) changes++;
-                    if (lane == 0) lab[i] = blab;
+                if (best_cnt > 0) {
+                    if (lab[i] != best_lab) changes++;
+                    if (lane == 0) lab[i] = best_lab;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
