@@ -21,7 +21,7 @@ SYMBOLS = [
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
     "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
-    "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
+    "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_cv", "hs_pipeline_sr", "hs_pipeline_destroy", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
     "hs_separate_reads_main",
 ]
 
@@ -82,6 +82,8 @@ def load() -> C.CDLL:
     lib.hs_cv_batch_destroy.restype = None
     lib.hs_cv_result_destroy.argtypes = [C.c_void_p]
     lib.hs_cv_result_destroy.restype = None
+    lib.hs_pipeline_destroy.argtypes = [C.c_void_p]
+    lib.hs_pipeline_destroy.restype = None
     lib.hs_cv_selection_destroy.argtypes = [C.c_void_p]
     lib.hs_cv_selection_destroy.restype = None
     lib.hs_free_host.argtypes = [C.c_void_p]
@@ -296,22 +298,25 @@ class CvSelection(C.Structure):
                 ("impl", C.c_void_p)]
 
 
+class PipelineStats(C.Structure):
+    _fields_ = [("n_snps", C.c_int64), ("n_cw_instances", C.c_int64), ("n_graph_rows_host", C.c_int64),
+                ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("t_kernel_cv_ms", C.c_float * 4), ("t_kernel_k4_ms", C.c_float),
+                ("t_kernel_sr_ms", C.c_float * 4), ("t_kernel_graph_ms", C.c_float)]
+
+
 class PipelineGroups:
-    """One resident batch whose contigs are processed as G consecutive groups. The streaming kernels (CIGAR scan, pileup,
-    column statistics) run ONCE over the whole batch (hs_cv_select); everything after them runs per group, one host thread and
-    one HIP stream per group (hs_cv_run_range / hs_sr_run_cv_range), so that the sequential host sections and device waits of
-    one group overlap the work of the others. Contigs are independent in both stages (call_variants.cpp:1280,
-    separate_reads.cpp:1508); the one cross-contig quantity, the error rate, is formed between the stages over ALL contigs
-    in contig order, exactly as for a single call."""
+    """One resident batch whose contigs are processed as G consecutive groups (hs_pipeline_*). The streaming kernels (CIGAR scan,
+    pileup, column statistics) run ONCE over the whole batch; everything after them runs per group, one persistent host
+    thread and one HIP stream per group inside the library, so that the sequential host sections and device waits of one group
+    overlap the work of the others. Contigs are independent in both stages (call_variants.cpp:1280, separate_reads.cpp:1508);
+    the one cross-contig quantity, the error rate, is formed between the stages over ALL contigs in contig order, exactly as
+    for a single call."""
 
     def __init__(self, contigs, n_groups):
-        from concurrent.futures import ThreadPoolExecutor
         self.flat = FlatBatch(contigs)
         self.batch = CvBatch(self.flat)
-        B = self.flat.n_contigs
-        G = max(1, min(n_groups, max(B, 1)))
-        self.ranges = [(B * g // G, B * (g + 1) // G) for g in range(G)]
-        self.pool = ThreadPoolExecutor(max_workers=G)
+        self.handle = C.c_void_p()
+        _check(load().hs_pipeline_create(self.batch.handle, C.c_int32(n_groups), C.byref(self.handle)))
         self.aligned_bp = self.flat.aligned_bp
         self.total_len = int(self.flat.contig_off[-1])
 
@@ -319,70 +324,34 @@ class PipelineGroups:
             amplicon=False, seed=12345, window_size=0):
         import time
         lib = load()
-        G = len(self.ranges)
-        per = max(1, n_threads // G) if n_threads > 0 else 0
-        h = self.batch.handle
-        sel = C.POINTER(CvSelection)()
+        Cn = self.flat.n_contigs
+        md = np.zeros(max(Cn, 1), np.float32)
+        st = PipelineStats()
         t_0 = time.perf_counter()
-        _check(lib.hs_cv_select(h, C.byref(sel)))
+        _check(lib.hs_pipeline_cv(self.handle, C.c_float(automatic_snp_threshold), C.c_int32(n_threads), _hp(md, C.c_float), C.byref(st)))
         t_1 = time.perf_counter()
-
-        def cv_part(rg):
-            res = C.POINTER(CvResult)()
-            _check(lib.hs_cv_run_range(h, sel, C.c_int32(rg[0]), C.c_int32(rg[1]), C.c_float(automatic_snp_threshold), C.c_int32(per), C.byref(res)))
-            r = res.contents
-            Cn = r.n_contigs
-            return res, {"mean_distance": np.ctypeslib.as_array(r.mean_distance, (max(Cn, 1),))[:Cn].copy(),
-                         "n_snps": int(np.ctypeslib.as_array(r.snp_off, (Cn + 1,))[-1]), "t_device_ms": float(r.t_device_ms),
-                         "t_host_ms": float(r.t_host_ms), "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_k4_ms": float(r.t_kernel_k4_ms)}
-
-        try:
-            cvs = list(self.pool.map(cv_part, self.ranges))
-            t_2 = time.perf_counter()
-            s = sel.contents
-            md = np.concatenate([c[1]["mean_distance"] for c in cvs]) if cvs else np.zeros(0, np.float32)
-            # call_variants.cpp:1312-1315,1377: float sum in contig order / number of contigs with a positive distance
-            tot = np.float32(0); n_pos = 0
-            for v in md:
-                if v > 0:
-                    tot = np.float32(tot + np.float32(v)); n_pos += 1
-            kt = np.sum([c[1]["t_kernel_ms"] for c in cvs], axis=0)
-            kt[0] += s.t_kernel_ms[0]; kt[1] += s.t_kernel_ms[1]; kt[3] += s.t_kernel_ms[3]
-            cv = {"mean_distance": md, "error_rate": float(np.float32(tot) / np.float32(n_pos)) if n_pos else float("nan"),
-                  "n_snps": sum(c[1]["n_snps"] for c in cvs),
-                  "t_device_ms": float(s.t_device_ms) + sum(c[1]["t_device_ms"] for c in cvs),
-                  "t_host_ms": float(s.t_host_ms) + sum(c[1]["t_host_ms"] for c in cvs),
-                  "t_kernel_ms": kt.tolist(), "t_kernel_k4_ms": sum(c[1]["t_kernel_k4_ms"] for c in cvs)}
-        finally:
-            lib.hs_cv_selection_destroy(sel)
+        md = md[:Cn]
+        # call_variants.cpp:1312-1315,1377: float sum in contig order / number of contigs with a positive distance
+        tot = np.float32(0); n_pos = 0
+        for v in md:
+            if v > 0:
+                tot = np.float32(tot + np.float32(v)); n_pos += 1
+        cv = {"mean_distance": md, "error_rate": float(np.float32(tot) / np.float32(n_pos)) if n_pos else float("nan"),
+              "n_snps": int(st.n_snps), "t_device_ms": float(st.t_device_ms), "t_host_ms": float(st.t_host_ms),
+              "t_kernel_ms": [float(x) for x in st.t_kernel_cv_ms], "t_kernel_k4_ms": float(st.t_kernel_k4_ms)}
         e = error_rate_fn(cv) if error_rate_fn is not None else min(float("%g" % cv["error_rate"]), 0.15)
         if window_size <= 0:
             window_size = self.window_size(amplicon)
-
-        def sr_part(x):
-            rg, (res, _) = x
-            try:
-                sres = C.POINTER(SrResult)()
-                _check(lib.hs_sr_run_cv_range(h, C.c_int32(rg[0]), C.c_int32(rg[1]), res, C.c_float(e), C.c_float(rarest_strain_abundance),
-                                              C.c_int32(1 if low_memory else 0), C.c_int32(1 if amplicon else 0), C.c_uint32(seed), C.c_int32(per),
-                                              C.c_int32(window_size), C.byref(sres)))
-                sr = _sr_result_to_dict(sres, rg[1] - rg[0])
-                lib.hs_sr_result_destroy(sres)
-            finally:
-                lib.hs_cv_result_destroy(res)
-            return sr
-
+        sres = C.POINTER(SrResult)()
+        st2 = PipelineStats()
+        t_2 = time.perf_counter()
+        _check(lib.hs_pipeline_sr(self.handle, C.c_float(e), C.c_float(rarest_strain_abundance), C.c_int32(1 if low_memory else 0),
+                                  C.c_int32(1 if amplicon else 0), C.c_uint32(seed), C.c_int32(n_threads), C.c_int32(window_size),
+                                  C.byref(sres), C.byref(st2)))
         t_3 = time.perf_counter()
-        srs = list(self.pool.map(sr_part, zip(self.ranges, cvs)))
-        t_4 = time.perf_counter()
-        sr = {"labels": np.concatenate([x["labels"] for x in srs]),
-              "win_start": np.concatenate([x["win_start"] for x in srs]), "win_end": np.concatenate([x["win_end"] for x in srs]),
-              "t_device_ms": sum(x["t_device_ms"] for x in srs), "t_host_ms": sum(x["t_host_ms"] for x in srs),
-              "n_cw_instances": sum(x["n_cw_instances"] for x in srs),
-              "t_kernel_ms": np.sum([x["t_kernel_ms"] for x in srs], axis=0).tolist(),
-              "t_kernel_graph_ms": sum(x["t_kernel_graph_ms"] for x in srs), "n_graph_rows_host": sum(x["n_graph_rows_host"] for x in srs)}
-        sr["wall_ms"] = {"select": (t_1 - t_0) * 1e3, "cv_groups": (t_2 - t_1) * 1e3, "between": (t_3 - t_2) * 1e3, "sr_groups": (t_4 - t_3) * 1e3,
-                         "collect": (time.perf_counter() - t_4) * 1e3}
+        sr = _sr_result_to_dict(sres, Cn)
+        lib.hs_sr_result_destroy(sres)
+        sr["wall_ms"] = {"cv": (t_1 - t_0) * 1e3, "between": (t_2 - t_1) * 1e3, "sr": (t_3 - t_2) * 1e3, "collect": (time.perf_counter() - t_3) * 1e3}
         return cv, sr
 
     def window_size(self, amplicon=False):
@@ -406,8 +375,10 @@ class PipelineGroups:
         return 2000
 
     def close(self):
+        if self.handle:
+            load().hs_pipeline_destroy(self.handle)
+            self.handle = None
         self.batch.close()
-        self.pool.shutdown(wait=True)
 
 
 def _sr_result_to_dict(res, Cn):

@@ -2,6 +2,9 @@
 // stage drivers. There is no CPU fallback anywhere in this file: without a usable HIP device every entry
 // point fails with HS_ENODEVICE.
 #include <hip/hip_runtime.h>
+#include <condition_variable>
+#include <functional>
+#include <thread>
 
 #include <algorithm>
 #include <atomic>
@@ -1195,6 +1198,154 @@ int hs_sr_run_cv(const hs_cv_batch* b, const hs_cv_result* cv, float error_rate,
                  int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out) {
     if (!b) { set_error("hs_sr_run_cv: null argument"); return HS_EINVAL; }
     return hs_sr_run_cv_range(b, 0, b->n_contigs, cv, error_rate, rarest_strain_abundance, low_memory, amplicon, seed, n_threads, window_size, out);
+}
+
+// ---- contig groups on persistent threads (see the header) ----
+struct hs_pipeline {
+    hs_cv_batch* batch = nullptr;
+    std::vector<std::pair<int, int>> ranges;
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<int(int)> job;
+    uint64_t gen = 0;
+    int pending = 0;
+    bool quit = false;
+    std::vector<int> rcs;
+    std::vector<std::string> errs;
+    hs_cv_selection* sel = nullptr;
+    std::vector<hs_cv_result*> cv;
+
+    void worker(int g) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<int(int)> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_go.wait(lk, [&] { return quit || gen != seen; });
+                if (quit) return;
+                seen = gen; f = job;
+            }
+            const int rc = f(g);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                rcs[(size_t)g] = rc;
+                if (rc) errs[(size_t)g] = hs_last_error();
+                if (--pending == 0) cv_done.notify_one();
+            }
+        }
+    }
+    int run(const std::function<int(int)>& f) {   // f(group) on every group thread; first failure wins
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = f; pending = (int)threads.size(); gen++;
+        }
+        cv_go.notify_all();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        for (size_t g = 0; g < rcs.size(); ++g) if (rcs[g]) { set_error(errs[g]); return rcs[g]; }
+        return HS_OK;
+    }
+    void drop_cv() {
+        for (hs_cv_result*& r : cv) { if (r) hs::free_cv_result(r); r = nullptr; }
+        if (sel) { hs_cv_selection_destroy(sel); sel = nullptr; }
+    }
+};
+
+int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out) {
+    if (int rc = require_device()) return rc;
+    if (!b || !out) { set_error("hs_pipeline_create: null argument"); return HS_EINVAL; }
+    hs_pipeline* p = new hs_pipeline();
+    p->batch = b;
+    const int C = b->n_contigs;
+    const int G = std::max(1, std::min<int>(n_groups, std::max(C, 1)));
+    for (int g = 0; g < G; ++g) p->ranges.push_back(std::make_pair((int)((int64_t)C * g / G), (int)((int64_t)C * (g + 1) / G)));
+    p->rcs.assign((size_t)G, 0); p->errs.assign((size_t)G, std::string()); p->cv.assign((size_t)G, nullptr);
+    for (int g = 0; g < G; ++g) p->threads.emplace_back([p, g] { p->worker(g); });
+    *out = p;
+    return HS_OK;
+}
+
+void hs_pipeline_destroy(hs_pipeline* p) {
+    if (!p) return;
+    { std::lock_guard<std::mutex> lk(p->mu); p->quit = true; }
+    p->cv_go.notify_all();
+    for (std::thread& t : p->threads) t.join();
+    p->drop_cv();
+    delete p;
+}
+
+int hs_pipeline_cv(hs_pipeline* p, float automatic_snp_threshold, int32_t n_threads, float* mean_distance, hs_pipeline_stats* st) {
+    if (!p || !mean_distance) { set_error("hs_pipeline_cv: null argument"); return HS_EINVAL; }
+    p->drop_cv();
+    if (int rc = hs_cv_select(p->batch, &p->sel)) return rc;
+    const int G = (int)p->ranges.size();
+    const int per = n_threads > 0 ? std::max(1, n_threads / G) : 0;
+    if (int rc = p->run([&](int g) {
+            return hs_cv_run_range(p->batch, p->sel, p->ranges[(size_t)g].first, p->ranges[(size_t)g].second, automatic_snp_threshold, per, &p->cv[(size_t)g]);
+        })) return rc;
+    if (st) {
+        std::memset(st, 0, sizeof *st);
+        st->t_device_ms = p->sel->t_device_ms; st->t_host_ms = p->sel->t_host_ms;
+        st->t_kernel_cv_ms[0] = p->sel->t_kernel_ms[0]; st->t_kernel_cv_ms[1] = p->sel->t_kernel_ms[1]; st->t_kernel_cv_ms[3] = p->sel->t_kernel_ms[3];
+    }
+    for (int g = 0; g < G; ++g) {
+        const hs_cv_result* r = p->cv[(size_t)g];
+        std::memcpy(mean_distance + p->ranges[(size_t)g].first, r->mean_distance, (size_t)r->n_contigs * sizeof(float));
+        if (st) {
+            st->n_snps += r->snp_off[r->n_contigs];
+            st->t_device_ms += r->t_device_ms; st->t_host_ms += r->t_host_ms;
+            st->t_kernel_cv_ms[2] += r->t_kernel_ms[2]; st->t_kernel_k4_ms += r->t_kernel_k4_ms;
+        }
+    }
+    return HS_OK;
+}
+
+int hs_pipeline_sr(hs_pipeline* p, float error_rate, float rarest_strain_abundance, int32_t low_memory, int32_t amplicon, uint32_t seed,
+                   int32_t n_threads, int32_t window_size, hs_sr_result** out, hs_pipeline_stats* st) {
+    if (!p || !out) { set_error("hs_pipeline_sr: null argument"); return HS_EINVAL; }
+    const int G = (int)p->ranges.size();
+    for (int g = 0; g < G; ++g) if (!p->cv[(size_t)g]) { set_error("hs_pipeline_sr: run hs_pipeline_cv first"); return HS_EINVAL; }
+    const int per = n_threads > 0 ? std::max(1, n_threads / G) : 0;
+    std::vector<hs_sr_result*> parts((size_t)G, nullptr);
+    const int rc = p->run([&](int g) {
+        return hs_sr_run_cv_range(p->batch, p->ranges[(size_t)g].first, p->ranges[(size_t)g].second, p->cv[(size_t)g], error_rate, rarest_strain_abundance,
+                                  low_memory, amplicon, seed, per, window_size, &parts[(size_t)g]);
+    });
+    if (rc) { for (hs_sr_result* r : parts) if (r) hs::free_sr_result(r); return rc; }
+    // concatenate in contig order
+    hs_sr_result* R = (hs_sr_result*)std::calloc(1, sizeof(hs_sr_result));
+    int64_t W = 0, NL = 0;
+    for (hs_sr_result* r : parts) { W += r->win_off[r->n_contigs]; NL += r->label_off[r->win_off[r->n_contigs]]; }
+    R->n_contigs = p->batch->n_contigs;
+    R->win_off = (int64_t*)std::malloc(((size_t)R->n_contigs + 1) * sizeof(int64_t));
+    R->win_start = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, W) * sizeof(int32_t));
+    R->win_end = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, W) * sizeof(int32_t));
+    R->label_off = (int64_t*)std::malloc(((size_t)W + 1) * sizeof(int64_t));
+    R->labels = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, NL) * sizeof(int32_t));
+    int64_t w0 = 0, l0 = 0; int c0 = 0;
+    R->win_off[0] = 0; R->label_off[0] = 0;
+    for (hs_sr_result* r : parts) {
+        const int64_t w = r->win_off[r->n_contigs], nl = r->label_off[w];
+        for (int c = 0; c < r->n_contigs; ++c) R->win_off[c0 + c + 1] = w0 + r->win_off[c + 1];
+        if (w) { std::memcpy(R->win_start + w0, r->win_start, (size_t)w * sizeof(int32_t)); std::memcpy(R->win_end + w0, r->win_end, (size_t)w * sizeof(int32_t)); }
+        for (int64_t k = 0; k < w; ++k) R->label_off[w0 + k + 1] = l0 + r->label_off[k + 1];
+        if (nl) std::memcpy(R->labels + l0, r->labels, (size_t)nl * sizeof(int32_t));
+        R->t_device_ms += r->t_device_ms; R->t_host_ms += r->t_host_ms; R->n_cw_instances += r->n_cw_instances;
+        for (int k = 0; k < 4; ++k) R->t_kernel_ms[k] += r->t_kernel_ms[k];
+        R->t_kernel_graph_ms += r->t_kernel_graph_ms; R->n_graph_rows_host += r->n_graph_rows_host;
+        w0 += w; l0 += nl; c0 += r->n_contigs;
+        hs::free_sr_result(r);
+    }
+    if (st) {
+        st->n_cw_instances = R->n_cw_instances; st->n_graph_rows_host = R->n_graph_rows_host;
+        st->t_device_ms += R->t_device_ms; st->t_host_ms += R->t_host_ms;
+        for (int k = 0; k < 4; ++k) st->t_kernel_sr_ms[k] = R->t_kernel_ms[k];
+        st->t_kernel_graph_ms = R->t_kernel_graph_ms;
+    }
+    p->drop_cv();
+    *out = R;
+    return HS_OK;
 }
 
 int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_t amplicon) {

@@ -325,6 +325,29 @@ int hs_sr_run_cv(const hs_cv_batch* b, const hs_cv_result* cv, float error_rate,
                  int32_t low_memory, int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size,
                  hs_sr_result** out);
 /* separate_reads.cpp:1466-1498: window size from the read limits of all contigs of the .col */
+/* ------------------------------------------------------------------------------------------------
+ * Both stages over one resident batch with the contigs processed as n_groups consecutive ranges on persistent host threads
+ * (one HIP stream and one worker pool each): hs_cv_select once, then hs_cv_run_range per range in parallel
+ * (hs_pipeline_cv); the caller forms the error rate from mean_distance (job-wide, contig order,
+ * call_variants.cpp:1312-1315,1377 -- across processes if the job is sharded); then hs_sr_run_cv_range per range in parallel
+ * (hs_pipeline_sr), results concatenated in contig order. Equivalent to hs_cv_run + hs_sr_run_cv on the whole batch.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hs_pipeline hs_pipeline;
+typedef struct hs_pipeline_stats {
+    int64_t n_snps, n_cw_instances, n_graph_rows_host;
+    double t_device_ms, t_host_ms;      /* summed over the groups */
+    float t_kernel_cv_ms[4];            /* k_pileup, k_column_stats, k_gather_columns (+top3), k_cigar_scan */
+    float t_kernel_k4_ms;
+    float t_kernel_sr_ms[4];            /* k_simdiff and the three k_chinese_whispers waves */
+    float t_kernel_graph_ms;
+} hs_pipeline_stats;
+int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out);
+int hs_pipeline_cv(hs_pipeline* p, float automatic_snp_threshold, int32_t n_threads, float* mean_distance /* [C] out */,
+                   hs_pipeline_stats* stats);
+int hs_pipeline_sr(hs_pipeline* p, float error_rate, float rarest_strain_abundance, int32_t low_memory, int32_t amplicon,
+                   uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out, hs_pipeline_stats* stats);
+void hs_pipeline_destroy(hs_pipeline* p);
+
 int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_t amplicon);
 
 /* File-level entry points == main() of the two reference executables (same argv, same exit codes).
