@@ -178,14 +178,15 @@ struct ColumnBits {
         words = (n_reads + 63) >> 6;
         nslots = 0;
         any.assign((size_t)words, 0ull);
-        bits.clear();
+        if (bits.size() < (size_t)8 * words) bits.resize((size_t)8 * words);
         for (int i = 0; i < n; ++i) {
             int k = 0;
             while (k < nslots && code_of[k] != code[i]) ++k;
             if (k == nslots) {
                 if (nslots == 128) continue;   // cannot happen: 125 pileup codes
                 code_of[nslots++] = code[i];
-                bits.resize((size_t)nslots * words, 0ull);
+                if (bits.size() < (size_t)nslots * words) bits.resize((size_t)nslots * 2 * words);
+                std::fill(bits.begin() + (size_t)k * words, bits.begin() + (size_t)(k + 1) * words, 0ull);
             }
             const uint64_t b = 1ull << (idx[i] & 63);
             bits[(size_t)k * words + ((size_t)idx[i] >> 6)] |= b;
@@ -267,41 +268,43 @@ static void augment(DensePartition& p, const int32_t* idx, const uint8_t* code, 
         if (pos > p.right) p.right = pos;
     }
     if (!d.comparable || n == 0) return;      // empty partition_to_augment (:251-253)
+    // recoded column: +1 where the read carries the column's reference code ('A'), -1 for its second code ('a'), 0 otherwise
+    int8_t cls_stack[512];
+    std::vector<int8_t> cls_heap;
+    int8_t* cls = cls_stack;
+    if (n > 512) { cls_heap.resize((size_t)n); cls = cls_heap.data(); }
     int nA = 0, na = 0;
-    for (int i = 0; i < n; ++i) { if (code[i] == d.most) nA++; else if (code[i] == d.second) na++; }
-    // two most frequent characters over 0..254 except ' ', lowest character wins ties (:261-280)
-    int mostc, secondc;
-    if (nA == 0 && na == 0) { mostc = 0; secondc = 1; }
-    else if (nA >= na) { mostc = 'A'; secondc = na > 0 ? 'a' : 0; }
-    else { mostc = 'a'; secondc = nA > 0 ? 'A' : 0; }
-    auto recode = [&](uint8_t c) -> int { return c == d.most ? 'A' : (c == d.second ? 'a' : ' '); };
-    int swapped = 0;                           // phase vote over shared reads (:284-314)
+    for (int i = 0; i < n; ++i) {
+        const int isA = code[i] == d.most, isa = (code[i] == d.second) & !isA;
+        nA += isA; na += isa;
+        cls[i] = (int8_t)(isA - isa);
+    }
+    // two most frequent characters over 0..254 except ' ', lowest character wins ties (:261-280): 'A' < 'a'.
+    // vA / va = the sign an 'A' / 'a' entry votes with: +1 if it is the most frequent character, -1 if the second, 0 if neither
+    int vA, va;
+    if (nA == 0 && na == 0) { vA = 0; va = 0; }                       // mostc = 0, secondc = 1: no entry matches either
+    else if (nA >= na) { vA = 1; va = na > 0 ? -1 : 0; }
+    else { va = 1; vA = nA > 0 ? -1 : 0; }
+    int swapped = 0;                           // phase vote over shared reads (:284-314): sum of vote x partition state
     for (int i = 0; i < n; ++i) {
         const int8_t s = p.state[idx[i]];
-        if (s == ABSENT) continue;
-        const int ch = recode(code[i]);
-        if (ch == mostc && s == 1) swapped += 1;
-        else if (ch == mostc && s == -1) swapped -= 1;
-        else if (ch == secondc && s == -1) swapped += 1;
-        else if (ch == secondc && s == 1) swapped -= 1;
+        const int v = cls[i] > 0 ? vA : (cls[i] < 0 ? va : 0);
+        swapped += s == ABSENT ? 0 : v * s;
     }
-    if (swapped < 0) std::swap(mostc, secondc);
+    if (swapped < 0) { vA = -vA; va = -va; }   // std::swap(mostc, secondc)
     for (int i = 0; i < n; ++i) {              // element-wise form of the sorted merge (:322-390)
         const int r = idx[i];
-        const int ch = recode(code[i]);
-        int s = 0;
-        if (ch == secondc) s = -1;
-        if (ch == mostc) s = 1;
+        const int s = cls[i] > 0 ? vA : (cls[i] < 0 ? va : 0);
         int8_t& st = p.state[r];
         if (st == ABSENT) { st = (int8_t)s; p.more[r] = std::abs(s); p.less[r] = 0; }
-        else if (s == 0) { /* nothing new */ }
+        else if (s == 0) { continue; /* nothing new */ }
         else if (st == 0) { st = (int8_t)s; p.more[r] = 1; p.less[r] = 0; }
-        else if (s == st) { p.more[r] += 1; }
+        else if (s == st) { p.more[r] += 1; continue; }
         else {                                 // s == -st
             if (p.less[r] + 1 > p.more[r]) { st = (int8_t)-st; p.more[r] += 1; }
-            else p.less[r] += 1;
+            else { p.less[r] += 1; continue; }
         }
-        p.sync_bits(r);
+        p.sync_bits(r);                        // only when the state changed
     }
     if (n) { if (p.hi < p.lo) { p.lo = idx[0]; p.hi = idx[n - 1]; } else { p.lo = std::min(p.lo, idx[0]); p.hi = std::max(p.hi, idx[n - 1]); } }
     p.n_occ += 1;
@@ -477,6 +480,7 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
     auto nowus = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a0 = tim ? nowus() : 0;
     long n_cmp = 0, n_aug = 0;
+    double t_build = 0, t_aug = 0;
     // ---- loop A (:590-638) ----
     std::vector<DensePartition> parts;
     ColumnBits colbits;
@@ -487,7 +491,9 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
         const int32_t* idx = col_idx(ci); const uint8_t* code = col_code(ci); const int n = col_n(ci);
         bool found = false;
         int n_corr = 0;
+        const double tb0 = tim ? nowus() : 0;
         if (!parts.empty()) colbits.build(idx, code, n, n_reads);
+        if (tim) t_build += nowus() - tb0;
         for (size_t p = 0; p < parts.size(); ++p) {
             if (std::abs(pos - parts[p].right) > 50000) continue;
             const Contingency d = column_vs_partition_bits(parts[p], colbits, cs.k0[ci]);
@@ -509,7 +515,9 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
             if ((d.n01 <= std::max(0.1 * (d.n00 + d.n01), 1.0) && d.n10 < std::max(0.1 * (d.n11 + d.n10), 1.0) && enough)
                 || (d.n00 <= std::max(0.1 * (d.n00 + d.n01), 1.0) && d.n11 < std::max(0.1 * (d.n11 + d.n10), 1.0) && enough)) {
                 found = true; n_aug++;
+                const double ta0 = tim ? nowus() : 0;
                 augment(parts[p], idx, code, n, d, pos);
+                if (tim) t_aug += nowus() - ta0;
                 break;
             }
         }
@@ -546,8 +554,8 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
         if (different) finals.push_back(parts[p1]);
     }
     out.n_final_partitions = (int)finals.size();
-    if (tim) std::fprintf(stderr, "[hs timing] phase_ab: %d candidates, %zu partitions, %ld comparisons, %ld augmentations, %zu finals; loop A %.0f us, loop B %.0f us\n",
-                          (int)cand.size(), parts.size(), n_cmp, n_aug, finals.size(), t_b0 - t_a0, nowus() - t_b0);
+    if (tim) std::fprintf(stderr, "[hs timing] phase_ab: %d candidates, %zu partitions, %ld comparisons, %ld augmentations, %zu finals; loop A %.0f us (build %.0f, augment %.0f), loop B %.0f us\n",
+                          (int)cand.size(), parts.size(), n_cmp, n_aug, finals.size(), t_b0 - t_a0, t_build, t_aug, nowus() - t_b0);
 }
 
 // Loops C (:721-738) and D (:745-764) run on the device (k_column_partition_test): the final partitions leave as dense
