@@ -21,7 +21,7 @@ SYMBOLS = [
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
     "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
-    "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_cv", "hs_pipeline_sr", "hs_pipeline_destroy", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
+    "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_cv", "hs_pipeline_sr", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
     "hs_separate_reads_main",
 ]
 
@@ -328,7 +328,7 @@ class PipelineGroups:
         md = np.zeros(max(Cn, 1), np.float32)
         st = PipelineStats()
         t_0 = time.perf_counter()
-        _check(lib.hs_pipeline_cv(self.handle, C.c_float(automatic_snp_threshold), C.c_int32(n_threads), _hp(md, C.c_float), C.byref(st)))
+        _check(lib.hs_pipeline_select(self.handle, _hp(md, C.c_float), C.byref(st)))
         t_1 = time.perf_counter()
         md = md[:Cn]
         # call_variants.cpp:1312-1315,1377: float sum in contig order / number of contigs with a positive distance
@@ -336,22 +336,21 @@ class PipelineGroups:
         for v in md:
             if v > 0:
                 tot = np.float32(tot + np.float32(v)); n_pos += 1
-        cv = {"mean_distance": md, "error_rate": float(np.float32(tot) / np.float32(n_pos)) if n_pos else float("nan"),
-              "n_snps": int(st.n_snps), "t_device_ms": float(st.t_device_ms), "t_host_ms": float(st.t_host_ms),
-              "t_kernel_ms": [float(x) for x in st.t_kernel_cv_ms], "t_kernel_k4_ms": float(st.t_kernel_k4_ms)}
+        cv = {"mean_distance": md, "error_rate": float(np.float32(tot) / np.float32(n_pos)) if n_pos else float("nan")}
         e = error_rate_fn(cv) if error_rate_fn is not None else min(float("%g" % cv["error_rate"]), 0.15)
         if window_size <= 0:
             window_size = self.window_size(amplicon)
         sres = C.POINTER(SrResult)()
-        st2 = PipelineStats()
         t_2 = time.perf_counter()
-        _check(lib.hs_pipeline_sr(self.handle, C.c_float(e), C.c_float(rarest_strain_abundance), C.c_int32(1 if low_memory else 0),
-                                  C.c_int32(1 if amplicon else 0), C.c_uint32(seed), C.c_int32(n_threads), C.c_int32(window_size),
-                                  C.byref(sres), C.byref(st2)))
+        _check(lib.hs_pipeline_run(self.handle, C.c_float(automatic_snp_threshold), C.c_float(e), C.c_float(rarest_strain_abundance),
+                                   C.c_int32(1 if low_memory else 0), C.c_int32(1 if amplicon else 0), C.c_uint32(seed), C.c_int32(n_threads),
+                                   C.c_int32(window_size), C.byref(sres), C.byref(st)))
         t_3 = time.perf_counter()
+        cv.update({"n_snps": int(st.n_snps), "t_device_ms": float(st.t_device_ms), "t_host_ms": float(st.t_host_ms),
+                   "t_kernel_ms": [float(x) for x in st.t_kernel_cv_ms], "t_kernel_k4_ms": float(st.t_kernel_k4_ms)})
         sr = _sr_result_to_dict(sres, Cn)
         lib.hs_sr_result_destroy(sres)
-        sr["wall_ms"] = {"cv": (t_1 - t_0) * 1e3, "between": (t_2 - t_1) * 1e3, "sr": (t_3 - t_2) * 1e3, "collect": (time.perf_counter() - t_3) * 1e3}
+        sr["wall_ms"] = {"select": (t_1 - t_0) * 1e3, "between": (t_2 - t_1) * 1e3, "groups": (t_3 - t_2) * 1e3, "collect": (time.perf_counter() - t_3) * 1e3}
         return cv, sr
 
     def window_size(self, amplicon=False):

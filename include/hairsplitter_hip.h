@@ -346,6 +346,13 @@ int hs_pipeline_cv(hs_pipeline* p, float automatic_snp_threshold, int32_t n_thre
                    hs_pipeline_stats* stats);
 int hs_pipeline_sr(hs_pipeline* p, float error_rate, float rarest_strain_abundance, int32_t low_memory, int32_t amplicon,
                    uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out, hs_pipeline_stats* stats);
+/* The error rate only needs K1's per-record counters, which exist as soon as the streaming pass is done: hs_pipeline_select
+ * runs hs_cv_select and returns the per-contig mean distances; hs_pipeline_run then takes every group through stage 3 AND
+ * stage 4 without a barrier between the stages (same results as hs_pipeline_cv + hs_pipeline_sr). */
+int hs_pipeline_select(hs_pipeline* p, float* mean_distance /* [C] out */, hs_pipeline_stats* stats);
+int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_rate, float rarest_strain_abundance, int32_t low_memory,
+                    int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out,
+                    hs_pipeline_stats* stats);
 void hs_pipeline_destroy(hs_pipeline* p);
 
 int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_t amplicon);
