@@ -93,8 +93,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--contigs", type=int, default=16, help="C2-shaped contigs per GPU in one batch")
-    ap.add_argument("--groups", type=int, default=4, help="concurrent sub-batches (host thread + HIP stream each) per GPU")
+    ap.add_argument("--contigs", type=int, default=64, help="C2-shaped contigs per GPU in one batch (64 ~ the per-GPU share of the 500-contig config on 8 GPUs)")
+    ap.add_argument("--groups", type=int, default=0, help="contig groups (host thread + HIP stream each) per GPU; 0 = min(8, host threads / 4)")
     ap.add_argument("--threads", type=int, default=0, help="host threads for the sequential glue (0 = all cores / ranks)")
     ap.add_argument("--cpu-contigs", type=int, default=8, help="size of the CPU-baseline sample (0 disables)")
     ap.add_argument("--seed", type=int, default=2)
@@ -132,7 +132,7 @@ def main():
     B = args.contigs
     my_ids = list(range(rank * B, (rank + 1) * B))
     contigs = [synth.make_contig(args.seed, i, 100_000, 2, 0.01, 50, "ont") for i in my_ids]
-    G = max(1, min(args.groups, B))
+    G = max(1, min(args.groups if args.groups > 0 else min(8, max(1, n_threads // 4)), B))
     batch = api.PipelineGroups(contigs, G)   # inputs now resident in HBM; the streaming kernels run once per step over all of them
     local_bp = batch.aligned_bp
 
@@ -222,7 +222,10 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(dom)
+                tj = json.load(open(tfile))
+                traffic = tj.get(dom)
+                if traffic is not None and tj.get("_aligned_bp"):
+                    traffic = traffic * local_bp / float(tj["_aligned_bp"])   # measured on a 16-contig batch; streaming kernels scale with bp
             except Exception:
                 traffic = None
         out = {

@@ -137,10 +137,29 @@ struct UploadPack {
     }
 };
 
+// Host waits do not spin (unless HS_SPIN_WAIT is set): several host threads drive the device at once and a spinning waiter
+// takes a core away from the worker threads of the other contig groups. A blocking event per calling thread.
+static bool spin_wait() { static const bool s = std::getenv("HS_SPIN_WAIT") != nullptr; return s; }
+static int stream_wait(hipStream_t s) {
+    if (spin_wait()) { HS_HIP(hipStreamSynchronize(s)); return HS_OK; }
+    static thread_local hipEvent_t ev = nullptr;
+    if (!ev) HS_HIP(hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming));
+    HS_HIP(hipEventRecord(ev, s));
+    HS_HIP(hipEventSynchronize(ev));
+    return HS_OK;
+}
+static int copy_d2h(void* h, const void* d, size_t n, hipStream_t s) {
+    if (n) HS_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
+    return stream_wait(s);
+}
+
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
     ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-    int init() { HS_HIP(hipEventCreate(&a)); HS_HIP(hipEventCreate(&b)); return HS_OK; }
+    int init() {
+        const unsigned flags = spin_wait() ? hipEventDefault : hipEventBlockingSync;
+        HS_HIP(hipEventCreateWithFlags(&a, flags)); HS_HIP(hipEventCreateWithFlags(&b, flags)); return HS_OK;
+    }
     int ms(float* out) { HS_HIP(hipEventSynchronize(b)); HS_HIP(hipEventElapsedTime(out, a, b)); return HS_OK; }
 };
 
@@ -295,7 +314,7 @@ static int column_stats_launch(const uint8_t* d_pile, const int64_t* d_pile_off,
     HS_HIP(hipGetLastError());
     if (d_sel_count) {
         if (int rc = sc.finish(d_sel_count, d_sel_gpos, d_sel_depth, sel_cap, (hipStream_t)stream)) return rc;
-        HS_HIP(hipStreamSynchronize((hipStream_t)stream));   // the scratch goes back to the pool with this scope
+        if (int rc_w = stream_wait((hipStream_t)stream)) return rc_w;   // the scratch goes back to the pool with this scope
     }
     return HS_OK;
 }
@@ -388,7 +407,7 @@ int hs_column_stats_tiled(const uint8_t* d_pile, const int64_t* d_tile_off, cons
     if (d_sel_count) { if (int rc = sc.prepare(total_len)) return rc; }
     if (int rc = column_stats_tiled_launch(d_pile, d_tile_off, d_tile_ent, total_len, d_stats, min_second, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap,
                                            max_depth, &sc, nullptr, (hipStream_t)stream)) return rc;
-    if (d_sel_count) HS_HIP(hipStreamSynchronize((hipStream_t)stream));   // the scratch goes back to the pool with this scope
+    if (d_sel_count) if (int rc_w = stream_wait((hipStream_t)stream)) return rc_w;   // the scratch goes back to the pool with this scope
     return HS_OK;
 }
 
@@ -480,7 +499,7 @@ int hs_simdiff(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_pl
     DBuf a, b, c;
     int rc = simdiff_launch(d_alt, d_ref, d_plane_off, d_n_reads, d_words, d_out_off, h_n, d_sim, d_diff, stream, a, b, c);
     if (rc) return rc;
-    HS_HIP(hipStreamSynchronize((hipStream_t)stream));   // the tile lists die with this frame
+    if (int rc_w = stream_wait((hipStream_t)stream)) return rc_w;   // the tile lists die with this frame
     return HS_OK;
 }
 
@@ -539,7 +558,7 @@ int hs_edit_distance(const uint8_t* d_query, const int64_t* d_query_off, const u
     hipLaunchKernelGGL(hsdev::k_myers, dim3((unsigned)n_pairs), dim3(64), 0, (hipStream_t)stream, d_query, d_query_off, d_target,
                        d_target_off, n_pairs, mode, scratch.as<int8_t>(), soff.as<int64_t>(), d_dist, d_end);
     HS_HIP(hipGetLastError());
-    HS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (int rc_w = stream_wait((hipStream_t)stream)) return rc_w;
     return HS_OK;
 }
 
@@ -714,20 +733,20 @@ struct HipCvOps : hs::CvDeviceOps {
         HBuf h_a, h_b;
         if (!rec_stats.empty()) {
             if (int rc = h_a.alloc(rec_stats.size() * sizeof(int32_t))) return rc;
-            HS_HIP(hipMemcpy(h_a.p, b->rec_stats.p, rec_stats.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            if (int rc = copy_d2h(h_a.p, b->rec_stats.p, rec_stats.size() * sizeof(int32_t), stream)) return rc;
             std::memcpy(rec_stats.data(), h_a.p, rec_stats.size() * sizeof(int32_t));
         }
         const double t2 = now();
         int32_t n_sel = 0;
         if (int rc = h_b.alloc(64)) return rc;
-        HS_HIP(hipMemcpy(h_b.p, b->sel_count.p, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (int rc = copy_d2h(h_b.p, b->sel_count.p, sizeof(int32_t), stream)) return rc;
         n_sel = *(int32_t*)h_b.p;
         sel_gpos.resize((size_t)n_sel); sel_depth.resize((size_t)n_sel);
         if (n_sel) {
             if (int rc = h_a.alloc((size_t)n_sel * sizeof(int64_t))) return rc;
-            HS_HIP(hipMemcpy(h_a.p, b->sel_gpos.p, (size_t)n_sel * sizeof(int64_t), hipMemcpyDeviceToHost));
+            if (int rc = copy_d2h(h_a.p, b->sel_gpos.p, (size_t)n_sel * sizeof(int64_t), stream)) return rc;
             std::memcpy(sel_gpos.data(), h_a.p, (size_t)n_sel * sizeof(int64_t));
-            HS_HIP(hipMemcpy(h_a.p, b->sel_depth.p, (size_t)n_sel * sizeof(int32_t), hipMemcpyDeviceToHost));
+            if (int rc = copy_d2h(h_a.p, b->sel_depth.p, (size_t)n_sel * sizeof(int32_t), stream)) return rc;
             std::memcpy(sel_depth.data(), h_a.p, (size_t)n_sel * sizeof(int32_t));
         }
         const double t3 = now();
@@ -765,7 +784,11 @@ struct HipCvOps : hs::CvDeviceOps {
                                               d_ps.as<int8_t>(), d_keep.as<uint8_t>(), stream)) return rc;
         HS_HIP(hipEventRecord(e.b, stream));
         keep.resize((size_t)n);
-        if (n) HS_HIP(hipMemcpy(keep.data(), d_keep.p, (size_t)n, hipMemcpyDeviceToHost));
+        if (n) {
+            HBuf hk; if (int rc = hk.alloc((size_t)n)) return rc;
+            if (int rc = copy_d2h(hk.p, d_keep.p, (size_t)n, stream)) return rc;
+            std::memcpy(keep.data(), hk.p, (size_t)n);
+        }
         return e.ms(k_ms);
     }
     HBuf h_top;
@@ -800,7 +823,7 @@ struct HipCvOps : hs::CvDeviceOps {
             HS_HIP(hipMemcpyAsync(h_col_code.p, d_cc.p, total, hipMemcpyDeviceToHost, stream));
         }
         HS_HIP(hipMemcpyAsync(h_top.p, d_top.p, (size_t)n_sel * sizeof(hs_coltop), hipMemcpyDeviceToHost, stream));
-        HS_HIP(hipStreamSynchronize(stream));
+        if (int rc_w = stream_wait(stream)) return rc_w;
         return e.ms(k_ms);
     }
 };
@@ -855,11 +878,11 @@ static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const st
     HS_HIP(hipEventRecord(ev.b, stream));
     int32_t n_amb = 0;
     HS_HIP(hipMemcpyAsync(&n_amb, d_ac.p, 4, hipMemcpyDeviceToHost, stream));
-    HS_HIP(hipStreamSynchronize(stream));
+    if (int rc_w = stream_wait(stream)) return rc_w;
     if (n_amb > 0) {
         // rows where std::sort's arrangement of equal distances decides: fetch their sim/diff rows, do exactly what the reference does
         std::vector<int32_t> amb((size_t)n_amb);
-        HS_HIP(hipMemcpy(amb.data(), d_ar.p, (size_t)n_amb * 4, hipMemcpyDeviceToHost));
+        if (int rc = copy_d2h(amb.data(), d_ar.p, (size_t)n_amb * 4, stream)) return rc;
         std::sort(amb.begin(), amb.end());
         std::vector<int64_t> src((size_t)n_amb), dst((size_t)n_amb + 1, 0);
         std::vector<int32_t> len((size_t)n_amb);
@@ -882,7 +905,7 @@ static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const st
         std::vector<int32_t> hs_((size_t)dst.back()), hd_((size_t)dst.back());
         HS_HIP(hipMemcpyAsync(hs_.data(), d_os.p, hs_.size() * 4, hipMemcpyDeviceToHost, stream));
         HS_HIP(hipMemcpyAsync(hd_.data(), d_od.p, hd_.size() * 4, hipMemcpyDeviceToHost, stream));
-        HS_HIP(hipStreamSynchronize(stream));
+        if (int rc_w = stream_wait(stream)) return rc_w;
         std::vector<int64_t> pbase; std::vector<int32_t> pmw, pi, pj;
         std::vector<uint8_t> mask;
         std::vector<int> picked;
@@ -911,7 +934,7 @@ static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const st
             hipLaunchKernelGGL(hsdev::k_read_graph_patch, dim3((np + 255) / 256), dim3(256), 0, stream, d_pb.as<int64_t>(), d_pm.as<int32_t>(), d_pi.as<int32_t>(),
                                d_pj.as<int32_t>(), np, d_bits.as<unsigned long long>());
             HS_HIP(hipGetLastError());
-            HS_HIP(hipStreamSynchronize(stream));   // the patch arrays die with this scope
+            if (int rc_w = stream_wait(stream)) return rc_w;   // the patch arrays die with this scope
         }
         res.rows_resolved_on_host = n_amb;
     }
@@ -922,7 +945,7 @@ static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const st
     hipLaunchKernelGGL(hsdev::k_exclusive_scan_i32, dim3(1), dim3(1024), 0, stream, d_deg.as<int32_t>(), rows, d_no.as<int64_t>());
     HS_HIP(hipGetLastError());
     HS_HIP(hipMemcpyAsync(res.nbr_off.data(), d_no.p, ((size_t)rows + 1) * 8, hipMemcpyDeviceToHost, stream));
-    HS_HIP(hipStreamSynchronize(stream));
+    if (int rc_w = stream_wait(stream)) return rc_w;
     const int64_t total = res.nbr_off.back();
     res.nbr.resize((size_t)total);
     if (total > 0) {
@@ -932,7 +955,7 @@ static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const st
         HS_HIP(hipGetLastError());
         HBuf hb; if (int rc = hb.alloc((size_t)total * 4)) return rc;
         HS_HIP(hipMemcpyAsync(hb.p, d_nbr.p, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
-        HS_HIP(hipStreamSynchronize(stream));
+        if (int rc_w = stream_wait(stream)) return rc_w;
         std::memcpy(res.nbr.data(), hb.p, (size_t)total * 4);
     }
     float m = 0; if (int rc = ev.ms(&m)) return rc;
@@ -1087,7 +1110,7 @@ struct HipSrOps : hs::SrDeviceOps {
         {
             HBuf h;
             if (int rc = h.alloc((size_t)total_n * sizeof(int32_t))) return rc;
-            HS_HIP(hipMemcpy(h.p, d_lab3.p, (size_t)total_n * sizeof(int32_t), hipMemcpyDeviceToHost));
+            if (int rc = copy_d2h(h.p, d_lab3.p, (size_t)total_n * sizeof(int32_t), stream)) return rc;
             std::memcpy(labels.data(), h.p, (size_t)total_n * sizeof(int32_t));
         }
         float m = 0;
