@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <atomic>
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
@@ -147,6 +149,7 @@ void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool 
     st.windows.clear();
     st.graphs.clear();
     st.empty_graph = -1;
+    st.snp_pos_sorted = std::is_sorted(c.snp_pos, c.snp_pos + c.n_snps);
     if (c.n_snps == 0) return;
     int cur = 0, chunk = -1, upper;
     while ((long)(chunk + 1) * window_size + 100 <= L) {
@@ -214,8 +217,199 @@ void sr_build_window_graph(SrContigState& st, int window, float error_rate) {
     if (st.low_memory_now) build_graph_low_memory(st, w.mask.data(), error_rate, g);   // the matrix path is K6 (device)
 }
 
-// merge_close_clusters: cluster_graph.cpp:402-501
+// Per-thread scratch of the two cluster-merging steps: they run once per clustering window (tens of thousands of calls per
+// batch), so nothing in them allocates, and every table is indexed by cluster label (a handful) instead of by read.
+struct MergeScratch {
+    std::vector<int32_t> nc, order_masked, masked;
+    std::vector<int> initial, count, votes, touched;
+    std::vector<char> tested;
+    // merge_wrongly_split
+    std::vector<int> glist, gidx, index_of, slot_of, incompat, pos_last, nb_bases, majority, link_cnt, links_in, o2n, new_index;
+    std::vector<std::vector<int>> cnts;          // [slot][256], all zero between uses
+    std::vector<std::vector<uint8_t>> seen;
+    std::vector<std::pair<std::pair<int, int>, double>> sorted_links;
+};
+static MergeScratch& merge_scratch() { static thread_local MergeScratch s; return s; }
+
+// merge_close_clusters: cluster_graph.cpp:402-501. `n_labels`: cluster labels are 0 .. n_labels-1 (first-seen numbering).
 static void merge_close_clusters(const SrGraph& g, bool low_memory, std::vector<int32_t>& clusters, const uint8_t* mask,
+                                 const std::vector<int32_t>& order, int n_labels) {
+    MergeScratch& S = merge_scratch();
+    const int K = n_labels > 0 ? n_labels : 1;
+    S.order_masked.clear();                                          // S.masked: the window's reads, ascending (set by the caller)
+    for (int i : order) if (mask[i]) S.order_masked.push_back(i);   // the shuffled order restricted to the window's reads
+    S.initial.assign((size_t)K, 0); S.votes.assign((size_t)K, 0); S.tested.assign((size_t)K, 0);
+    for (int r : S.masked) if (clusters[r] >= 0) S.initial[(size_t)clusters[r]] += 1;   // reads outside the mask carry -2
+    S.nc.assign(clusters.begin(), clusters.end());
+    std::vector<int32_t>& nc = S.nc;
+    std::vector<int>& votes = S.votes;
+    std::vector<int>& touched = S.touched;
+    for (int node : S.masked) {
+        if (!(clusters[node] >= 0 && !S.tested[(size_t)clusters[node]])) continue;
+        const int target = clusters[node];
+        S.count = S.initial;
+        int changes = 3, iters = 0;
+        while (changes > 0 && iters < 10) {
+            changes = 0;
+            for (int i : S.order_masked) {
+                if (nc[i] != target) continue;
+                touched.clear();
+                const int o0 = g.off[i], o1 = g.off[i + 1];
+                if (low_memory) {   // :441-445 iterates j < degree and asks whether j itself is a neighbour (sic)
+                    for (int j = 0; j < o1 - o0; ++j)
+                        if (std::binary_search(g.adj.begin() + o0, g.adj.begin() + o1, j) && nc[j] >= 0) { if (votes[nc[j]]++ == 0) touched.push_back(nc[j]); }
+                } else {
+                    for (int o = o0; o < o1; ++o) { const int l = nc[g.adj[o]]; if (l >= 0) { if (votes[l]++ == 0) touched.push_back(l); } }
+                }
+                // largest and runner-up in ascending label order with strict '>' (:455-470)
+                std::sort(touched.begin(), touched.end());
+                int max_index = 0, max_value = 0, second_index = 0, second_value = 0;
+                for (int l : touched) {
+                    const int v = votes[l];
+                    if (v > max_value) { second_value = max_value; second_index = max_index; max_value = v; max_index = l; }
+                    else if (v > second_value) { second_value = v; second_index = l; }
+                }
+                for (int l : touched) votes[l] = 0;
+                if (max_value > 0 && max_index != target) { S.count[nc[i]]--; S.count[max_index]++; changes++; nc[i] = max_index; }
+                else if (max_value > 0 && max_value <= 2 * second_value) { S.count[nc[i]]--; S.count[second_index]++; nc[i] = second_index; changes++; }
+            }
+            iters++;
+        }
+        S.tested[(size_t)target] = 1;
+        if (S.count[(size_t)target] == 0) { for (int r : S.masked) clusters[r] = nc[r]; S.initial = S.count; }   // the cluster dissolved: keep
+        else for (int r : S.masked) nc[r] = clusters[r];                                                          // undo
+    }
+}
+
+// merge_wrongly_split_haplotypes: separate_reads.cpp:1007-1327. `n_labels` as above.
+static std::vector<int32_t> merge_wrongly_split(const SrContigState& st, const std::vector<int32_t>& clustered, const SrGraph& g,
+                                                bool low_memory, int posstart, int posend, int n_labels) {
+    MergeScratch& S = merge_scratch();
+    const hs_sr_contig& c = *st.c;
+    const int N = st.N;
+    const int K = n_labels > 0 ? n_labels : 1;
+    // clusters present, ascending (glist), and their first-seen rank over the reads (index_of), as the std::set / std::map give
+    S.index_of.assign((size_t)K, -1); S.slot_of.assign((size_t)K, -1);
+    int index = 0;
+    for (int r : S.masked) { const int cl = clustered[r]; if (cl > -1 && S.index_of[(size_t)cl] < 0) S.index_of[(size_t)cl] = index++; }   // reads outside the mask carry -2
+    S.glist.clear();
+    for (int l = 0; l < K; ++l) if (S.index_of[(size_t)l] >= 0) { S.slot_of[(size_t)l] = (int)S.glist.size(); S.glist.push_back(l); }
+    const int G = (int)S.glist.size();
+    if (G <= 1) {
+        std::vector<int32_t> one((size_t)N, 0);
+        for (int r = 0; r < N; ++r) if (clustered[r] == -2) one[r] = -2;
+        return one;
+    }
+    const std::vector<int>& glist = S.glist;
+    S.gidx.resize((size_t)G);
+    for (int i = 0; i < G; ++i) S.gidx[(size_t)i] = S.index_of[(size_t)glist[(size_t)i]];
+    S.incompat.assign((size_t)G * G, 0); S.pos_last.assign((size_t)G * G, -10);
+    if ((int)S.cnts.size() < G) { S.cnts.resize((size_t)G, std::vector<int>(256, 0)); S.seen.resize((size_t)G); }
+    S.nb_bases.assign((size_t)G, 0); S.majority.assign((size_t)G, 0);
+    std::vector<int>& incompat = S.incompat; std::vector<int>& pos_last = S.pos_last;
+    std::vector<int>& nb_bases = S.nb_bases; std::vector<int>& majority = S.majority;   // 0 == operator[] default for clusters absent at a SNP
+    // SNP positions ascend (call_variants writes them in position order; parse_col keeps file order): binary search if so
+    int s_first = 0, s_last = c.n_snps;
+    if (st.snp_pos_sorted) {
+        s_first = (int)(std::lower_bound(c.snp_pos, c.snp_pos + c.n_snps, posstart) - c.snp_pos);
+        s_last = (int)(std::lower_bound(c.snp_pos, c.snp_pos + c.n_snps, posend) - c.snp_pos);
+    }
+    for (int s = s_first; s < s_last; ++s) {
+        const int p = c.snp_pos[s];
+        if (!(p >= posstart && p < posend)) continue;
+        for (int i = 0; i < G; ++i) { nb_bases[i] = 0; majority[i] = 0; }
+        for (int64_t e = c.col_off[s]; e < c.col_off[s + 1]; ++e) {
+            const int cl = clustered[c.col_idx[e]];
+            if (cl > -1) {
+                const int sl = S.slot_of[(size_t)cl];
+                const uint8_t b = c.col_code[e];
+                if (S.cnts[(size_t)sl][b]++ == 0) S.seen[(size_t)sl].push_back(b);
+                nb_bases[sl]++;
+            }
+        }
+        // The reference walks the cluster's base counts in robin_hood order keeping (max, second max) with `>=` on the max
+        // (:1090-1099). The pair of values does not depend on the order, and neither does the verdict: a unique maximum names
+        // the base, a tied maximum gives second == max and is rejected by `second_max * 2 > max` just below.
+        int first_max = -1; bool several = false;
+        for (int i = 0; i < G; ++i) {
+            if (S.seen[(size_t)i].empty()) continue;
+            int second_max = 0, mx = 0;
+            int max_base = ' ';
+            for (uint8_t b : S.seen[(size_t)i]) {
+                const int v = S.cnts[(size_t)i][b];
+                if (v >= mx) { max_base = (int)(signed char)b; second_max = mx; mx = v; }
+                else if (v > second_max) second_max = v;
+                S.cnts[(size_t)i][b] = 0;
+            }
+            S.seen[(size_t)i].clear();
+            if (second_max * 2 > mx || nb_bases[i] * 0.5 > mx) max_base = ' ';
+            majority[i] = (int)(uint8_t)max_base;
+            if (max_base != ' ') { const int mb = (int)(uint8_t)max_base; if (first_max < 0) first_max = mb; else if (mb != first_max) several = true; }
+        }
+        if (!several) continue;
+        for (int a = 0; a < G; ++a)
+            for (int b = 0; b < G; ++b) {
+                if (majority[a] != ' ' && majority[b] != ' ' && glist[(size_t)a] > glist[(size_t)b]) {
+                    const int i1 = S.gidx[(size_t)a], i2 = S.gidx[(size_t)b];
+                    if (majority[a] != majority[b] && p - pos_last[(size_t)i1 * G + i2] > 10) {
+                        incompat[(size_t)i1 * G + i2] += 1; incompat[(size_t)i2 * G + i1] += 1;
+                        pos_last[(size_t)i1 * G + i2] = p; pos_last[(size_t)i2 * G + i1] = p;
+                    }
+                }
+            }
+    }
+    // link ratios (:1189-1250). The reference keys a std::map on (cluster1, cluster2), clusters -2 and -1 included; a
+    // dense (label + 2) x (label + 2) count matrix walked in ascending key order yields the same sequence.
+    const int M = K + 2;
+    S.link_cnt.assign((size_t)M * M, 0); S.links_in.assign((size_t)M, 0);
+    std::vector<int>& link_cnt = S.link_cnt; std::vector<int>& links_in = S.links_in;
+    auto count_link = [&](int r1, int r2) {
+        const int c1 = clustered[r1] + 2, c2 = clustered[r2] + 2;
+        if (c1 != c2) link_cnt[(size_t)c1 * M + c2] += 1;
+        links_in[(size_t)c1] += 1;
+    };
+    // only reads of the window have neighbours (the counts do not depend on the visiting order)
+    if (low_memory) {
+        for (int r1 : S.masked) for (int o = g.off[r1]; o < g.off[r1 + 1]; ++o) count_link(r1, g.adj[o]);
+    } else {
+        for (int k : S.masked) for (int o = g.off[k]; o < g.off[k + 1]; ++o) count_link(g.adj[o], k);
+    }
+    std::vector<std::pair<std::pair<int, int>, double>>& sorted_links = S.sorted_links;
+    sorted_links.clear();
+    for (int c1 = 0; c1 < M; ++c1)
+        for (int c2 = 0; c2 < M; ++c2)
+            if (link_cnt[(size_t)c1 * M + c2] > 0)
+                sorted_links.push_back(std::make_pair(std::make_pair(c1 - 2, c2 - 2), (double)link_cnt[(size_t)c1 * M + c2] / links_in[(size_t)c1]));
+    std::sort(sorted_links.begin(), sorted_links.end(),
+              [](const std::pair<std::pair<int, int>, double>& a, const std::pair<std::pair<int, int>, double>& b) { return a.second > b.second; });
+    // old label -> new label, keys -2 .. K-1 stored at [label + 2]
+    S.o2n.assign((size_t)M, 0);
+    std::vector<int>& o2n = S.o2n;
+    for (int gl : glist) o2n[(size_t)gl + 2] = gl;
+    o2n[1] = -1; o2n[0] = -2;
+    for (auto& pc : sorted_links) {
+        if (!(pc.second > 0.01)) continue;
+        const int c1 = pc.first.first, c2 = pc.first.second;
+        if (o2n[(size_t)c1 + 2] == o2n[(size_t)c2 + 2]) continue;
+        bool bad = false;
+        for (int g1 : glist) {
+            if (o2n[(size_t)g1 + 2] != o2n[(size_t)c1 + 2]) continue;
+            for (int g2 : glist) if (o2n[(size_t)g2 + 2] == o2n[(size_t)c2 + 2] && incompat[(size_t)S.index_of[(size_t)g1] * G + S.index_of[(size_t)g2]] > 1) bad = true;
+        }
+        if (!bad) { const int to = o2n[(size_t)c1 + 2], from = o2n[(size_t)c2 + 2]; for (int g2 : glist) if (o2n[(size_t)g2 + 2] == from) o2n[(size_t)g2 + 2] = to; }
+    }
+    S.new_index.assign((size_t)M, -1);   // keyed by the (possibly negative) merged label + 2
+    int ni = 0;
+    for (int gl : glist) { const int v = o2n[(size_t)gl + 2]; if (S.new_index[(size_t)v + 2] < 0) S.new_index[(size_t)v + 2] = ni++; }
+    for (int gl : glist) o2n[(size_t)gl + 2] = S.new_index[(size_t)o2n[(size_t)gl + 2] + 2];
+    std::vector<int32_t> out((size_t)N, -1);
+    for (int r = 0; r < N; ++r) out[r] = o2n[(size_t)clustered[r] + 2];
+    return out;
+}
+
+#ifdef HS_SELFCHECK   // the straightforward forms, kept as the cross-check in the test-harness build
+// merge_close_clusters: cluster_graph.cpp:402-501
+static void merge_close_clusters_ref(const SrGraph& g, bool low_memory, std::vector<int32_t>& clusters, const uint8_t* mask,
                                  const std::vector<int32_t>& order) {
     const int N = (int)clusters.size();
     std::set<int> tested;
@@ -263,7 +457,7 @@ static void merge_close_clusters(const SrGraph& g, bool low_memory, std::vector<
 }
 
 // merge_wrongly_split_haplotypes: separate_reads.cpp:1007-1327
-static std::vector<int32_t> merge_wrongly_split(const SrContigState& st, const std::vector<int32_t>& clustered, const SrGraph& g,
+static std::vector<int32_t> merge_wrongly_split_ref(const SrContigState& st, const std::vector<int32_t>& clustered, const SrGraph& g,
                                                 bool low_memory, int posstart, int posend) {
     const hs_sr_contig& c = *st.c;
     const int N = st.N;
@@ -383,6 +577,8 @@ static std::vector<int32_t> merge_wrongly_split(const SrContigState& st, const s
     return out;
 }
 
+#endif
+
 // finalize_clustering tail: separate_reads.cpp:973-993
 void sr_finish_window(const SrContigState& st, SrWindowPlan& w, const int32_t* reclustered, bool low_memory) {
     const int N = st.N;
@@ -398,8 +594,31 @@ void sr_finish_window(const SrContigState& st, SrWindowPlan& w, const int32_t* r
         else if (h >= 0) { if (to_index[(size_t)h] < 0) to_index[(size_t)h] = index_h++; hap[r] = to_index[(size_t)h]; }
     }
     const SrGraph& g = st.graphs[(size_t)w.graph_final];
-    merge_close_clusters(g, low_memory, hap, w.mask.data(), st.perm);
-    w.labels = merge_wrongly_split(st, hap, g, low_memory, w.final_lo, w.final_hi);
+    static const bool tim = std::getenv("HS_TIMING_FIN") != nullptr;
+    auto nowus = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = tim ? nowus() : 0;
+#ifdef HS_SELFCHECK
+    std::vector<int32_t> hap_ref = hap;
+    merge_close_clusters_ref(g, low_memory, hap_ref, w.mask.data(), st.perm);
+    const std::vector<int32_t> out_ref = merge_wrongly_split_ref(st, hap_ref, g, low_memory, w.final_lo, w.final_hi);
+#endif
+    {
+        MergeScratch& S = merge_scratch();
+        S.masked.clear();
+        for (int r = 0; r < N; ++r) if (w.mask[(size_t)r]) S.masked.push_back(r);
+    }
+    merge_close_clusters(g, low_memory, hap, w.mask.data(), st.perm, index_h);
+    const double t1 = tim ? nowus() : 0;
+    w.labels = merge_wrongly_split(st, hap, g, low_memory, w.final_lo, w.final_hi, index_h);
+#ifdef HS_SELFCHECK
+    if (hap_ref != hap || out_ref != w.labels) { std::fprintf(stderr, "HS_SELFCHECK: cluster merging differs from its reference form\n"); std::abort(); }
+#endif
+    if (tim) {
+        static std::atomic<long> a_mcc{0}, a_mws{0}, a_n{0};
+        a_mcc += (long)((t1 - t0) * 1000); a_mws += (long)((nowus() - t1) * 1000);
+        if (++a_n % 10 == 0) std::fprintf(stderr, "[hs timing] finish: %ld windows, merge_close_clusters %.1f us/window, merge_wrongly_split %.1f us/window\n",
+                                          a_n.load(), a_mcc.load() / 1000.0 / a_n.load(), a_mws.load() / 1000.0 / a_n.load());
+    }
 }
 
 // merge_haplotypes_to_fit_within_limit up to the re-clustering: separate_reads.cpp:1341-1383.

@@ -13,6 +13,7 @@ struct SrContigState {
     int N = 0;
     int words = 0;
     bool low_memory_now = false;
+    bool snp_pos_sorted = false;                    // SNP positions ascend (lets the per-window SNP range be a binary search)
     std::vector<SrGraph> graphs;
     int empty_graph = -1;
     std::vector<struct SrWindowPlan> windows;
