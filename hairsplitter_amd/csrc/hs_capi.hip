@@ -383,6 +383,11 @@ static int column_stats_tiled_launch(const uint8_t* d_pile, const int64_t* d_til
                                      hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth,
                                      int32_t sel_cap, int32_t max_depth, SelectionScratch* sc, hipEvent_t after_main, hipStream_t stream) {
     static_assert(sizeof(hs_tile_entry) == sizeof(int4), "hs_tile_entry is read as one 16-byte load");
+    if (total_len <= 0) {   // nothing to count: an empty selection
+        if (d_sel_count) HS_HIP(hipMemsetAsync(d_sel_count, 0, sizeof(int32_t), stream));
+        if (after_main) HS_HIP(hipEventRecord(after_main, stream));
+        return HS_OK;
+    }
     const int64_t grid = (total_len + 255) / 256;
     const bool full = d_stats != nullptr;
     const bool narrow = max_depth > 0 && max_depth <= 255;
@@ -722,7 +727,7 @@ struct HipCvOps : hs::CvDeviceOps {
                                    b->n_tasks, b->ev_per_task, b->pile.as<uint8_t>(), b->rec_stats.as<int32_t>(), stream)) return rc;
         HS_HIP(hipEventRecord(e1.b, stream));
         HS_HIP(hipEventRecord(e2.a, stream));
-        if (b->sel_scratch.n_tiles == 0) { if (int rc = b->sel_scratch.prepare(b->total_len)) return rc; }
+        if (b->sel_scratch.n_tiles == 0 && b->total_len > 0) { if (int rc = b->sel_scratch.prepare(b->total_len)) return rc; }
         if (int rc = column_stats_tiled_launch(b->pile.as<uint8_t>(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->total_len,
                                                nullptr, min_second, b->sel_count.as<int32_t>(), b->sel_gpos.as<int64_t>(),
                                                b->sel_depth.as<int32_t>(), (int32_t)std::min<int64_t>(b->total_len, 0x7fffffff), b->max_depth,

@@ -146,3 +146,28 @@ def test_pipeline_groups_equal_single_batch(built):
         assert np.array_equal(sr1["labels"], sr2["labels"])
         assert np.array_equal(sr1["win_start"], sr2["win_start"]) and np.array_equal(sr1["win_end"], sr2["win_end"])
     single.close(); groups.close()
+
+
+def test_degenerate_batches(built):
+    """empty and ragged inputs through the in-memory path: no contigs; a single contig spread over more groups than contigs;
+    a contig without reads and a contig without SNPs next to a normal one"""
+    from hairsplitter_amd import api, synth
+    empty = api.CvBatch(api.FlatBatch([]))
+    cv = empty.run(0.33, 4)
+    assert len(cv["mean_distance"]) == 0 and len(cv["snp_pos"]) == 0
+    empty.close()
+    one = [synth.make_contig(9, 0, 20_000, 2, 0.01, 40, "ont")]
+    ref_cv, ref_sr = api.CvBatch(api.FlatBatch(one)).run_pipeline(0.33, 4)
+    g = api.PipelineGroups(one, 8)
+    cv2, sr2 = g.run(0.33, 4)
+    assert np.array_equal(ref_sr["labels"], sr2["labels"]) and ref_cv["n_snps"] == cv2["n_snps"]
+    g.close()
+    ragged = [synth.make_contig(9, 1, 15_000, 1, 0.0, 0, "ont", name="noreads"), synth.make_contig(9, 2, 12_000, 1, 0.0, 30, "ont", name="nosnp"),
+              synth.make_contig(9, 3, 18_000, 3, 0.012, 45, "ont", name="tri")]
+    a_cv, a_sr = api.CvBatch(api.FlatBatch(ragged)).run_pipeline(0.33, 4)
+    g = api.PipelineGroups(ragged, 3)
+    b_cv, b_sr = g.run(0.33, 4)
+    assert np.array_equal(a_cv["mean_distance"], b_cv["mean_distance"]) and a_cv["mean_distance"][0] == 0
+    assert np.array_equal(a_sr["labels"], b_sr["labels"]) and np.array_equal(a_sr["win_off"], b_sr["win_off"])
+    assert a_sr["win_off"][1] == 0 and a_sr["win_off"][2] == 0        # contigs without SNPs produce no windows (separate_reads.cpp:1522-1524)
+    g.close()
