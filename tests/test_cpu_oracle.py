@@ -100,3 +100,24 @@ def test_probe_calls_of_the_orchestrator(built):
     assert subprocess.run([built["cv"], "--version"], stdout=subprocess.DEVNULL).returncode == 0
     assert subprocess.run([built["sr"], "--help"], stdout=subprocess.DEVNULL).returncode == 0
     assert subprocess.run([built["sr"], "a", "b"], stdout=subprocess.DEVNULL).returncode == 1
+
+
+@pytest.mark.parametrize("which", ["empty_sam", "empty_gfa"])
+def test_degenerate_files_match_reference_binary(built, which):
+    """inputs without alignments / without contigs: the product's host glue writes what the compiled reference writes"""
+    if not os.path.exists(built["ref_cv"]):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    from hairsplitter_amd import synth
+    with tempfile.TemporaryDirectory() as td:
+        f = synth.write_files([synth.make_contig(9, 0, 8000, 2, 0.01, 30, "ont")], td)
+        if which == "empty_sam":
+            open(f["sam"], "w").write("@HD\tVN:1.6\n")
+        else:
+            open(f["gfa"], "w").write("H\tVN:Z:1.0\n")
+        outs = {}
+        for tag, cmd in (("ref", [built["ref_cv"]]), ("hs", [built["harness"], "call_variants"])):
+            col, vcf, err = (os.path.join(td, tag + x) for x in (".col", ".vcf", ".err"))
+            r = subprocess.run(cmd + [f["gfa"], f["reads"], f["sam"], "1", td, err, "0", "0", col, vcf, "0.33"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            assert r.returncode == 0
+            outs[tag] = tuple(open(p, "rb").read() for p in (col, vcf, err))
+        assert outs["ref"] == outs["hs"]
