@@ -208,8 +208,9 @@ __global__ __launch_bounds__(256) void k_pileup(
                 const unsigned long long fm = __ballot(own != 0);
                 const int e = w0 + lane;
                 // flags strictly left of the lane (v_mbcnt) + its own + ops started before the window - 1
-                int rank = before - 1 + own + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-                rank = rank < 0 ? 0 : rank;
+                // (never negative for an event of the chunk: the op that owns it has started at or before it; lanes past the end of
+                // the chunk are masked below and may read any slot of the table, which holds 64 entries)
+                const int rank = (before - 1 + own + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))) & 63;
                 before += __popcll(fm);
                 const int4 od = s_op[wv][s_nzlane[wv][rank]];
                 const int off = e - od.x;
