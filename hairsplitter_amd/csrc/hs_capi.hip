@@ -1303,32 +1303,6 @@ void hs_pipeline_destroy(hs_pipeline* p) {
     delete p;
 }
 
-int hs_pipeline_cv(hs_pipeline* p, float automatic_snp_threshold, int32_t n_threads, float* mean_distance, hs_pipeline_stats* st) {
-    if (!p || !mean_distance) { set_error("hs_pipeline_cv: null argument"); return HS_EINVAL; }
-    p->drop_cv();
-    if (int rc = hs_cv_select(p->batch, &p->sel)) return rc;
-    const int G = (int)p->ranges.size();
-    const int per = n_threads > 0 ? std::max(1, n_threads / G) : 0;
-    if (int rc = p->run([&](int g) {
-            return hs_cv_run_range(p->batch, p->sel, p->ranges[(size_t)g].first, p->ranges[(size_t)g].second, automatic_snp_threshold, per, &p->cv[(size_t)g]);
-        })) return rc;
-    if (st) {
-        std::memset(st, 0, sizeof *st);
-        st->t_device_ms = p->sel->t_device_ms; st->t_host_ms = p->sel->t_host_ms;
-        st->t_kernel_cv_ms[0] = p->sel->t_kernel_ms[0]; st->t_kernel_cv_ms[1] = p->sel->t_kernel_ms[1]; st->t_kernel_cv_ms[3] = p->sel->t_kernel_ms[3];
-    }
-    for (int g = 0; g < G; ++g) {
-        const hs_cv_result* r = p->cv[(size_t)g];
-        std::memcpy(mean_distance + p->ranges[(size_t)g].first, r->mean_distance, (size_t)r->n_contigs * sizeof(float));
-        if (st) {
-            st->n_snps += r->snp_off[r->n_contigs];
-            st->t_device_ms += r->t_device_ms; st->t_host_ms += r->t_host_ms;
-            st->t_kernel_cv_ms[2] += r->t_kernel_ms[2]; st->t_kernel_k4_ms += r->t_kernel_k4_ms;
-        }
-    }
-    return HS_OK;
-}
-
 static hs_sr_result* concat_sr_parts(hs_pipeline* p, std::vector<hs_sr_result*>& parts, hs_pipeline_stats* st) {
     // concatenate in contig order
     hs_sr_result* R = (hs_sr_result*)std::calloc(1, sizeof(hs_sr_result));
@@ -1403,24 +1377,6 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
             st->t_kernel_cv_ms[2] += r->t_kernel_ms[2]; st->t_kernel_k4_ms += r->t_kernel_k4_ms;
         }
     }
-    hs_sr_result* R = concat_sr_parts(p, parts, st);
-    p->drop_cv();
-    *out = R;
-    return HS_OK;
-}
-
-int hs_pipeline_sr(hs_pipeline* p, float error_rate, float rarest_strain_abundance, int32_t low_memory, int32_t amplicon, uint32_t seed,
-                   int32_t n_threads, int32_t window_size, hs_sr_result** out, hs_pipeline_stats* st) {
-    if (!p || !out) { set_error("hs_pipeline_sr: null argument"); return HS_EINVAL; }
-    const int G = (int)p->ranges.size();
-    for (int g = 0; g < G; ++g) if (!p->cv[(size_t)g]) { set_error("hs_pipeline_sr: run hs_pipeline_cv first"); return HS_EINVAL; }
-    const int per = n_threads > 0 ? std::max(1, n_threads / G) : 0;
-    std::vector<hs_sr_result*> parts((size_t)G, nullptr);
-    const int rc = p->run([&](int g) {
-        return hs_sr_run_cv_range(p->batch, p->ranges[(size_t)g].first, p->ranges[(size_t)g].second, p->cv[(size_t)g], error_rate, rarest_strain_abundance,
-                                  low_memory, amplicon, seed, per, window_size, &parts[(size_t)g]);
-    });
-    if (rc) { for (hs_sr_result* r : parts) if (r) hs::free_sr_result(r); return rc; }
     hs_sr_result* R = concat_sr_parts(p, parts, st);
     p->drop_cv();
     *out = R;

@@ -327,10 +327,11 @@ int hs_sr_run_cv(const hs_cv_batch* b, const hs_cv_result* cv, float error_rate,
 /* separate_reads.cpp:1466-1498: window size from the read limits of all contigs of the .col */
 /* ------------------------------------------------------------------------------------------------
  * Both stages over one resident batch with the contigs processed as n_groups consecutive ranges on persistent host threads
- * (one HIP stream and one worker pool each): hs_cv_select once, then hs_cv_run_range per range in parallel
- * (hs_pipeline_cv); the caller forms the error rate from mean_distance (job-wide, contig order,
- * call_variants.cpp:1312-1315,1377 -- across processes if the job is sharded); then hs_sr_run_cv_range per range in parallel
- * (hs_pipeline_sr), results concatenated in contig order. Equivalent to hs_cv_run + hs_sr_run_cv on the whole batch.
+ * (one HIP stream and one worker pool each). hs_pipeline_select runs hs_cv_select (the streaming kernels, once over the whole
+ * batch) and returns the per-contig mean distances, which only need K1's per-record counters; the caller forms the error
+ * rate from them (job-wide, contig order, call_variants.cpp:1312-1315,1377 -- across processes if the job is sharded);
+ * hs_pipeline_run then takes every group through hs_cv_run_range and hs_sr_run_cv_range back to back, no barrier between the
+ * stages, and concatenates the results in contig order. Equivalent to hs_cv_run + hs_sr_run_cv on the whole batch.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct hs_pipeline hs_pipeline;
 typedef struct hs_pipeline_stats {
@@ -342,13 +343,6 @@ typedef struct hs_pipeline_stats {
     float t_kernel_graph_ms;
 } hs_pipeline_stats;
 int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out);
-int hs_pipeline_cv(hs_pipeline* p, float automatic_snp_threshold, int32_t n_threads, float* mean_distance /* [C] out */,
-                   hs_pipeline_stats* stats);
-int hs_pipeline_sr(hs_pipeline* p, float error_rate, float rarest_strain_abundance, int32_t low_memory, int32_t amplicon,
-                   uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out, hs_pipeline_stats* stats);
-/* The error rate only needs K1's per-record counters, which exist as soon as the streaming pass is done: hs_pipeline_select
- * runs hs_cv_select and returns the per-contig mean distances; hs_pipeline_run then takes every group through stage 3 AND
- * stage 4 without a barrier between the stages (same results as hs_pipeline_cv + hs_pipeline_sr). */
 int hs_pipeline_select(hs_pipeline* p, float* mean_distance /* [C] out */, hs_pipeline_stats* stats);
 int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_rate, float rarest_strain_abundance, int32_t low_memory,
                     int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out,
