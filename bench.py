@@ -153,9 +153,10 @@ def main():
         # (separate_reads.cpp:1466-1498) and all shards of this workload have the same read-length distribution
         cv, sr = batch.run(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=2000 if world > 1 else 0)
         t3 = time.perf_counter(); py_ms["pipeline_call"] += (t3 - t) * 1e3
-        if cap[0] is None:
-            cap[0] = hdist.gather_capacity(int(sr["labels"].size))   # first (warm-up) step only
-        gathered = hdist.gather_labels(sr["labels"], capacity=cap[0]) if not no_coll else None
+        if cap[0] is None:   # first (warm-up) step only: fix the size of the per-step collective, allocate its buffers
+            cap[0] = hdist.LabelGatherer(hdist.gather_capacity(int(sr["labels"].size)))
+        # the labels arrive on rank 0 (which would write the .gro); decoding them into arrays is the consumer's business
+        gathered = cap[0].gather(sr["labels"], decode=False) if not no_coll else None
         py_ms["gather"] += (time.perf_counter() - t3) * 1e3
         return cv, sr, gathered
 

@@ -31,6 +31,13 @@ def _worker(rank, world, port, q):
     er = hdist.global_error_rate(mine, md, len(weights))
     labels = np.concatenate([np.full(3 + i, i % 3 - 2, np.int32) for i in mine]) if mine else np.zeros(0, np.int32)
     g = hdist.gather_labels(labels)
+    # the preallocated form bench.py uses per step must deliver the same thing, step after step
+    lg = hdist.LabelGatherer(hdist.gather_capacity(int(labels.size)))
+    for _ in range(2):
+        g2 = lg.gather(labels)
+        assert (g is None) == (g2 is None)
+        if g is not None:
+            assert all(np.array_equal(a, b) for a, b in zip(g, g2))
     q.put((rank, mine, er, None if g is None else [x.tolist() for x in g]))
     dist.barrier()
     dist.destroy_process_group()
