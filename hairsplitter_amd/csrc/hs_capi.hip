@@ -2,6 +2,7 @@
 // stage drivers. There is no CPU fallback anywhere in this file: without a usable HIP device every entry
 // point fails with HS_ENODEVICE.
 #include <hip/hip_runtime.h>
+#include <malloc.h>
 #include <condition_variable>
 #include <functional>
 #include <thread>
@@ -583,6 +584,19 @@ struct hs_cv_batch {
     SelectionScratch sel_scratch;
 };
 
+// The stage drivers allocate and free multi-megabyte arrays on many threads every call; with glibc's defaults those go
+// through mmap/munmap and heap trimming, i.e. page faults and TLB shootdowns across all threads (20-ms stalls every few
+// steps). Keep the memory in the process instead.
+static void tune_allocator() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const int a = mallopt(M_MMAP_THRESHOLD, 32 << 20);      // the largest value glibc accepts
+        const int b = mallopt(M_TRIM_THRESHOLD, 1 << 30);
+        const int c = mallopt(M_TOP_PAD, 64 << 20);
+        if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] mallopt: mmap_threshold %d trim_threshold %d top_pad %d\n", a, b, c);
+    });
+}
+
 int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off, int32_t n_contigs,
                        const uint8_t* h_read_seq, const int64_t* h_read_off, int32_t n_reads,
                        const int32_t* h_rec_read, const int32_t* h_rec_pos, const uint8_t* h_rec_strand,
@@ -590,6 +604,7 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
                        hs_cv_batch** out) {
     if (int rc = require_device()) return rc;
     if (!out || n_contigs < 0) { set_error("hs_cv_batch_create: bad arguments"); return HS_EINVAL; }
+    tune_allocator();
     hs_cv_batch* b = new hs_cv_batch();
     b->n_contigs = n_contigs; b->n_reads = n_reads;
     b->contig_off.assign(h_contig_off, h_contig_off + n_contigs + 1);
@@ -1283,6 +1298,7 @@ struct hs_pipeline {
 int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out) {
     if (int rc = require_device()) return rc;
     if (!b || !out) { set_error("hs_pipeline_create: null argument"); return HS_EINVAL; }
+    tune_allocator();
     hs_pipeline* p = new hs_pipeline();
     p->batch = b;
     const int C = b->n_contigs;
