@@ -50,7 +50,7 @@ class SrResult(C.Structure):
     _fields_ = [("n_contigs", C.c_int32), ("win_off", C.POINTER(C.c_int64)), ("win_start", C.POINTER(C.c_int32)),
                 ("win_end", C.POINTER(C.c_int32)), ("label_off", C.POINTER(C.c_int64)), ("labels", C.POINTER(C.c_int32)),
                 ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("n_cw_instances", C.c_int64),
-                ("t_kernel_ms", C.c_float * 4), ("t_kernel_graph_ms", C.c_float), ("n_graph_rows_host", C.c_int64)]
+                ("t_kernel_ms", C.c_float * 4), ("t_kernel_graph_ms", C.c_float), ("n_graph_rows_host", C.c_int64), ("n_windows_finished_on_host", C.c_int64)]
 
 
 _lib = None
@@ -394,7 +394,7 @@ def _sr_result_to_dict(res, Cn):
         "labels": np.ctypeslib.as_array(r.labels, (max(NL, 1),))[:NL].copy(),
         "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "n_cw_instances": int(r.n_cw_instances),
         "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_graph_ms": float(r.t_kernel_graph_ms),
-        "n_graph_rows_host": int(r.n_graph_rows_host),
+        "n_graph_rows_host": int(r.n_graph_rows_host), "n_windows_finished_on_host": int(r.n_windows_finished_on_host),
     }
 
 
@@ -467,7 +467,7 @@ def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory:
         "labels": np.ctypeslib.as_array(r.labels, (max(NL, 1),))[:NL].copy(),
         "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "n_cw_instances": int(r.n_cw_instances),
         "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_graph_ms": float(r.t_kernel_graph_ms),
-        "n_graph_rows_host": int(r.n_graph_rows_host),
+        "n_graph_rows_host": int(r.n_graph_rows_host), "n_windows_finished_on_host": int(r.n_windows_finished_on_host),
     }
     lib.hs_sr_result_destroy(res)
     return out

@@ -23,6 +23,7 @@
 #include "hs_driver.h"
 #include "hs_kernels.hip"
 #include "hs_kernels_graph.hip"
+#include "hs_kernels_finish.hip"
 
 namespace hs {
 static thread_local std::string g_err;
@@ -1060,7 +1061,8 @@ struct HipSrOps : hs::SrDeviceOps {
         }
         return HS_OK;
     }
-    int cw_chain(const hs::CwChain& ch, std::vector<int32_t>& labels, float k_ms[3]) override {
+    int cw_chain(const hs::CwChain& ch, std::vector<int32_t>& labels, std::vector<int32_t>& final_labels, std::vector<uint8_t>& final_ok,
+                 float k_ms[3]) override {
         const int W = (int)ch.win_n.size();
         const int64_t n_inst = (int64_t)ch.seed_col.size();
         const int64_t total_n = ch.win_label_base.back();
@@ -1126,12 +1128,43 @@ struct HipSrOps : hs::SrDeviceOps {
                                d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), d_wgf.as<int32_t>(), d_wob.as<int64_t>(), W, max_n,
                                d_lab3.as<int32_t>(), nullptr, stream, nullptr, nullptr, nullptr, nullptr, d_visit.as<int32_t>(), d_visit_n.as<int32_t>())) return rc;
         HS_HIP(hipEventRecord(e3.b, stream));
+        // K8: first-seen renumbering + merge_close_clusters + merge_wrongly_split on the device, one wavefront per window
+        const size_t fin_lds = (size_t)max_n * 3 * sizeof(int32_t);
+        const bool finish = ch.finish_on_device && fin_lds <= 100 * 1024 && !std::getenv("HS_FINISH_ON_HOST");
+        DBuf d_final, d_ok, d_cpos, d_sf, d_sl, d_plo, d_phi;
+        UploadPack pk2;
+        if (finish) {
+            pk2.add(ch.col_pos, d_cpos); pk2.add(ch.win_snp_first, d_sf); pk2.add(ch.win_snp_last, d_sl); pk2.add(ch.win_pos_lo, d_plo); pk2.add(ch.win_pos_hi, d_phi);
+            if (int rc = pk2.commit(stream)) return rc;
+            if (int rc = d_final.alloc((size_t)total_n * sizeof(int32_t))) return rc;
+            if (int rc = d_ok.alloc((size_t)W)) return rc;
+            if (fin_lds > 32 * 1024)
+                HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_finish_window), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
+            hipLaunchKernelGGL(hsdev::k_finish_window, dim3((unsigned)W), dim3(64), fin_lds, stream, d_lab3.as<int32_t>(), d_wob.as<int64_t>(), d_wn.as<int32_t>(),
+                               d_wgf.as<int32_t>(), d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_mask.as<uint8_t>(),
+                               d_visit.as<int32_t>(), d_visit_n.as<int32_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(),
+                               d_cpos.as<int32_t>(), d_sf.as<int64_t>(), d_sl.as<int64_t>(), d_plo.as<int32_t>(), d_phi.as<int32_t>(), W, d_final.as<int32_t>(),
+                               d_ok.as<uint8_t>());
+            HS_HIP(hipGetLastError());
+        }
         labels.resize((size_t)total_n);
         {
-            HBuf h;
+            HBuf h, h2, h3;
             if (int rc = h.alloc((size_t)total_n * sizeof(int32_t))) return rc;
-            if (int rc = copy_d2h(h.p, d_lab3.p, (size_t)total_n * sizeof(int32_t), stream)) return rc;
+            HS_HIP(hipMemcpyAsync(h.p, d_lab3.p, (size_t)total_n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            if (finish) {
+                if (int rc = h2.alloc((size_t)total_n * sizeof(int32_t))) return rc;
+                if (int rc = h3.alloc((size_t)W)) return rc;
+                HS_HIP(hipMemcpyAsync(h2.p, d_final.p, (size_t)total_n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                HS_HIP(hipMemcpyAsync(h3.p, d_ok.p, (size_t)W, hipMemcpyDeviceToHost, stream));
+            }
+            if (int rc = stream_wait(stream)) return rc;
             std::memcpy(labels.data(), h.p, (size_t)total_n * sizeof(int32_t));
+            if (finish) {
+                final_labels.resize((size_t)total_n); final_ok.resize((size_t)W);
+                std::memcpy(final_labels.data(), h2.p, (size_t)total_n * sizeof(int32_t));
+                std::memcpy(final_ok.data(), h3.p, (size_t)W);
+            }
         }
         float m = 0;
         if (int rc = e1.ms(&m)) return rc; k_ms[0] += m;
@@ -1340,7 +1373,7 @@ static hs_sr_result* concat_sr_parts(hs_pipeline* p, std::vector<hs_sr_result*>&
         if (nl) std::memcpy(R->labels + l0, r->labels, (size_t)nl * sizeof(int32_t));
         R->t_device_ms += r->t_device_ms; R->t_host_ms += r->t_host_ms; R->n_cw_instances += r->n_cw_instances;
         for (int k = 0; k < 4; ++k) R->t_kernel_ms[k] += r->t_kernel_ms[k];
-        R->t_kernel_graph_ms += r->t_kernel_graph_ms; R->n_graph_rows_host += r->n_graph_rows_host;
+        R->t_kernel_graph_ms += r->t_kernel_graph_ms; R->n_graph_rows_host += r->n_graph_rows_host; R->n_windows_finished_on_host += r->n_windows_finished_on_host;
         w0 += w; l0 += nl; c0 += r->n_contigs;
         hs::free_sr_result(r);
     }

@@ -396,7 +396,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         sr_plan_windows(st[(size_t)c], window_size, error_rate, lowmem);
     });
     laps.lap("plan_windows");
-    int64_t rows_on_host = 0;
+    int64_t rows_on_host = 0, n_finish_host = 0;
     float k6_ms = 0;
     {   // K6: the graphs of all matrix-path windows in one device pass over the resident sim/diff matrices
         ReadGraphJob job;
@@ -492,6 +492,13 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     {
         ch.win_seed_begin.assign(1, 0);
         ch.win_label_base.assign(1, 0);
+        ch.finish_on_device = !lowmem;
+        for (int c = 0; c < C && ch.finish_on_device; ++c)
+            if (contigs[c].n_snps > 0 && (st[(size_t)c].low_memory_now || !st[(size_t)c].snp_pos_sorted)) ch.finish_on_device = false;
+        if (ch.finish_on_device) {
+            ch.col_pos.reserve(ch.col_off.size());
+            for (int c = 0; c < C; ++c) ch.col_pos.insert(ch.col_pos.end(), contigs[c].snp_pos, contigs[c].snp_pos + contigs[c].n_snps);
+        }
         for (size_t i = 0; i < wrefs.size(); ++i) {
             SrContigState& s = st[(size_t)wrefs[i].c];
             SrWindowPlan& w = s.windows[(size_t)wrefs[i].w];
@@ -503,16 +510,26 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
             for (int snp : w.local_snps) ch.seed_col.push_back(col_base_of_contig[(size_t)wrefs[i].c] + snp);
             ch.win_seed_begin.push_back((int64_t)ch.seed_col.size());
             ch.win_label_base.push_back(ch.win_label_base.back() + s.N);
+            if (ch.finish_on_device) {
+                const hs_sr_contig& hc = contigs[wrefs[i].c];
+                const int64_t base = col_base_of_contig[(size_t)wrefs[i].c];
+                ch.win_snp_first.push_back(base + (std::lower_bound(hc.snp_pos, hc.snp_pos + hc.n_snps, w.final_lo) - hc.snp_pos));
+                ch.win_snp_last.push_back(base + (std::lower_bound(hc.snp_pos, hc.snp_pos + hc.n_snps, w.final_hi) - hc.snp_pos));
+                ch.win_pos_lo.push_back(w.final_lo); ch.win_pos_hi.push_back(w.final_hi);
+            }
             n_cw += (int64_t)w.local_snps.size() + 2;
         }
     }
     laps.lap("chain_build");
-    std::vector<int32_t> chain_labels;
+    std::vector<int32_t> chain_labels, final_labels;
+    std::vector<uint8_t> final_ok;
     {
         const double t0 = now_ms();
-        if (!ch.win_n.empty()) { if (int rc = dev.cw_chain(ch, chain_labels, &k_ms[1])) return rc; }
+        if (!ch.win_n.empty()) { if (int rc = dev.cw_chain(ch, chain_labels, final_labels, final_ok, &k_ms[1])) return rc; }
         dev_ms += now_ms() - t0;
     }
+    std::vector<int64_t> chain_index(wrefs.size(), -1);   // position of the window in the chain
+    { int64_t k = 0; for (size_t i = 0; i < wrefs.size(); ++i) if (w2_base[i] >= 0) chain_index[i] = k++; }
 
     const double t_waves_done = now_ms();
     laps.lap("cw_chain");
@@ -523,8 +540,12 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         if (w2_base[(size_t)i] < 0) {
             w.labels.resize((size_t)s.N);
             for (int r = 0; r < s.N; ++r) w.labels[(size_t)r] = w.mask[(size_t)r] ? -1 : -2;
+        } else if (!final_ok.empty() && final_ok[(size_t)chain_index[(size_t)i]]) {
+            const int32_t* f = final_labels.data() + w2_base[(size_t)i];      // finished on the device (K8)
+            w.labels.assign(f, f + s.N);
         } else sr_finish_window(s, w, chain_labels.data() + w2_base[(size_t)i], lowmem);
     });
+    if (!final_ok.empty()) for (uint8_t ok : final_ok) n_finish_host += ok ? 0 : 1;
 
     const double t_finish_done = now_ms();
     laps.lap("finish");
@@ -567,12 +588,13 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     R->labels = dup_vec(labels);
     laps.lap("result");
     R->n_cw_instances = n_cw;
-    R->t_kernel_graph_ms = k6_ms; R->n_graph_rows_host = rows_on_host;
+    R->t_kernel_graph_ms = k6_ms; R->n_graph_rows_host = rows_on_host; R->n_windows_finished_on_host = final_ok.empty() ? (int64_t)ch.win_n.size() : n_finish_host;
     for (int k = 0; k < 4; ++k) R->t_kernel_ms[k] = k_ms[k];
     R->t_device_ms = dev_ms;
     R->t_host_ms = (now_ms() - t_start) - dev_ms;
     if (std::getenv("HS_TIMING"))
-        std::fprintf(stderr, "[hs timing] sr: graph rows resolved by std::sort on the host: %ld, k_read_graph_rows %.3f ms\n", (long)rows_on_host, k6_ms);
+        std::fprintf(stderr, "[hs timing] sr: graph rows resolved by std::sort on the host: %ld, k_read_graph_rows %.3f ms; windows finished on the host: %ld of %zu\n",
+                     (long)rows_on_host, k6_ms, (long)n_finish_host, ch.win_n.size());
     if (std::getenv("HS_TIMING"))
         std::fprintf(stderr, "[hs timing] sr: planes+simdiff %.2f ms, plan windows+graphs %.2f ms, graph upload + 3 CW waves (incl. label init) %.2f ms, finish %.2f ms, total %.2f ms (device %.2f)\n",
                      t_simdiff_done - t_start, t_plan_done - t_simdiff_done, t_waves_done - t_plan_done, t_finish_done - t_waves_done, now_ms() - t_start, dev_ms);

@@ -83,6 +83,13 @@ struct CwChain {
     std::vector<int64_t> win_seed_begin;   // [W+1] range of the window's seeding columns in seed_col
     std::vector<int64_t> seed_col;         // global column index of every per-SNP run
     std::vector<int64_t> win_label_base;   // [W+1] offset of the window's N output labels
+    // K8 (optional): the tail of finalize_clustering on the device. finish_on_device = every window of the chain may be
+    // finished there (matrix path, global low_memory off, SNP positions ascending); per window the range of its SNP columns
+    // (global column indices) and the position interval [pos_lo, pos_hi) that merge_wrongly_split looks at.
+    bool finish_on_device = false;
+    std::vector<int32_t> col_pos;          // [S] position of every SNP column
+    std::vector<int64_t> win_snp_first, win_snp_last;
+    std::vector<int32_t> win_pos_lo, win_pos_hi;
 };
 
 // K5 input: the SNP columns of every contig of the batch (concatenated in CwChain::col_*) with their two alleles
@@ -113,7 +120,10 @@ struct SrDeviceOps {
     virtual ~SrDeviceOps() {}
     // K6: create_read_graph_matrix for every window of the job
     virtual int read_graphs(const ReadGraphJob& job, ReadGraphResult& res, float* k_ms) = 0;
-    virtual int cw_chain(const CwChain& chain, std::vector<int32_t>& labels, float k_ms[3]) = 0;
+    // labels = what the third wave leaves (N per window). If the implementation also ran K8, final_labels holds the finished
+    // labels and final_ok[w] != 0 marks the windows it could finish (the others go through the host code); else both stay empty.
+    virtual int cw_chain(const CwChain& chain, std::vector<int32_t>& labels, std::vector<int32_t>& final_labels,
+                         std::vector<uint8_t>& final_ok, float k_ms[3]) = 0;
     // K5a + K5: bit-planes from the SNP columns, then sim / diff for every contig with n_reads[c] > 0. The columns (the same
     // object cw_chain() receives later) and the matrices stay with the implementation.
     virtual int simdiff_columns(const SimdiffJob& job, float* k_ms) = 0;

@@ -309,6 +309,7 @@ typedef struct hs_sr_result {
     float t_kernel_ms[4];      /* hipEvent time of k_simdiff and of the three k_chinese_whispers waves */
     float t_kernel_graph_ms;   /* hipEvent time of k_read_graph_rows */
     int64_t n_graph_rows_host; /* graph rows whose neighbour cut-off depended on std::sort's order of equal keys */
+    int64_t n_windows_finished_on_host;   /* clustering windows whose cluster merging (K8) fell back to the host code */
 } hs_sr_result;
 
 int hs_sr_run(const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,

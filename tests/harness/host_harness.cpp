@@ -214,7 +214,9 @@ struct OracleSrOps : hs::SrDeviceOps {
     const uint8_t* mask_of(int g) const { return gs.mask.data() + (size_t)(gs.graph_off_base[(size_t)g] - g); }
 
     // CPU statement of the device-resident chain (separate_reads.cpp:1674-1705, :840-885, :924-971)
-    int cw_chain(const hs::CwChain& ch, std::vector<int32_t>& labels, float k_ms[3]) override {
+    int cw_chain(const hs::CwChain& ch, std::vector<int32_t>& labels, std::vector<int32_t>& final_labels, std::vector<uint8_t>& final_ok,
+                 float k_ms[3]) override {
+        final_labels.clear(); final_ok.clear();   // the tail of finalize_clustering stays with the product's host code here
         (void)k_ms;
         const int W = (int)ch.win_n.size();
         labels.assign((size_t)ch.win_label_base.back(), 0);

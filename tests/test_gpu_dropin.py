@@ -171,3 +171,24 @@ def test_degenerate_batches(built):
     assert np.array_equal(a_sr["labels"], b_sr["labels"]) and np.array_equal(a_sr["win_off"], b_sr["win_off"])
     assert a_sr["win_off"][1] == 0 and a_sr["win_off"][2] == 0        # contigs without SNPs produce no windows (separate_reads.cpp:1522-1524)
     g.close()
+
+
+def test_cluster_merging_on_device_equals_host_code(built):
+    """K8 (first-seen renumbering + merge_close_clusters + merge_wrongly_split per window on the device) against the same
+    steps in the product's host code (HS_FINISH_ON_HOST=1 routes every window there), on polyploid contigs where clusters
+    do get merged; and the device path must be the one that ran."""
+    from hairsplitter_amd import api, synth
+    contigs = [synth.make_contig(31, i, 40_000, 2 + i, 0.012, 45, "ont") for i in range(4)]
+    b = api.CvBatch(api.FlatBatch(contigs))
+    cv, sr = b.run_pipeline(0.33, 8)
+    os.environ["HS_FINISH_ON_HOST"] = "1"
+    try:
+        cv_h, sr_h = b.run_pipeline(0.33, 8)
+    finally:
+        del os.environ["HS_FINISH_ON_HOST"]
+    b.close()
+    assert np.array_equal(sr["labels"], sr_h["labels"])
+    n_windows = int(sr["win_off"][-1])
+    assert sr_h["n_windows_finished_on_host"] > 0.5 * n_windows          # the switch works
+    assert sr["n_windows_finished_on_host"] < 0.1 * n_windows            # and the device is what normally runs
+    assert len(set(sr["labels"].tolist())) > 3                           # real clusterings, not all-zero windows
