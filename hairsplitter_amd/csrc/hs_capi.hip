@@ -155,13 +155,19 @@ static int copy_d2h(void* h, const void* d, size_t n, hipStream_t s) {
     return stream_wait(s);
 }
 
+// Timing events are recycled per host thread: creating and destroying a few hundred (interrupt-backed) events per step makes
+// the runtime stall for tens of milliseconds every few dozen steps.
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
-    ~EventPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-    int init() {
-        const unsigned flags = spin_wait() ? hipEventDefault : hipEventBlockingSync;
-        HS_HIP(hipEventCreateWithFlags(&a, flags)); HS_HIP(hipEventCreateWithFlags(&b, flags)); return HS_OK;
+    static std::vector<hipEvent_t>& cache() { static thread_local std::vector<hipEvent_t> c; return c; }
+    ~EventPair() { if (a) cache().push_back(a); if (b) cache().push_back(b); }
+    static int get(hipEvent_t* e) {
+        std::vector<hipEvent_t>& c = cache();
+        if (!c.empty()) { *e = c.back(); c.pop_back(); return HS_OK; }
+        HS_HIP(hipEventCreateWithFlags(e, spin_wait() ? hipEventDefault : hipEventBlockingSync));
+        return HS_OK;
     }
+    int init() { if (int rc = get(&a)) return rc; return get(&b); }
     int ms(float* out) { HS_HIP(hipEventSynchronize(b)); HS_HIP(hipEventElapsedTime(out, a, b)); return HS_OK; }
 };
 
