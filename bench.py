@@ -176,11 +176,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the synthetic inputs are a few hundred thousand Python / numpy objects that live for the whole run: park them in the
+    # permanent generation so that a full garbage collection in the middle of a step does not walk them (25-30 ms)
+    import gc
+    gc.collect()
+    gc.freeze()
     # set-up, not measurement: a few passes that size the device / pinned block pools, the per-thread scratch and the HIP
     # runtime's own pools (first use of every buffer size goes to hipMalloc / hipHostMalloc; the runtime stalls once for
     # ~30 ms around the eighth pass of a process), then the W warm-up steps of the contract
     for _ in range(8):
         step()
+    sync()
     for _ in range(args.warmup):
         step()
     sync()
@@ -202,7 +208,7 @@ def main():
             sys.stderr.write(f"outlier step {len(step_ms)}: {step_ms[-1]:.1f} ms {sr.get('wall_ms')}\n")
         k_cv += np.asarray(cv["t_kernel_ms"]); k_sr += np.asarray(sr["t_kernel_ms"]); k4 += cv.get("t_kernel_k4_ms", 0.0); k6 += sr.get("t_kernel_graph_ms", 0.0)
         t_dev += cv["t_device_ms"] + sr["t_device_ms"]; t_host += cv["t_host_ms"] + sr["t_host_ms"]
-        last = (cv, sr)
+        last = ({"n_snps": cv["n_snps"]}, {"n_cw_instances": sr["n_cw_instances"]})   # no references to the step's arrays: they die here, as in the warm-up
     sync()
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3
