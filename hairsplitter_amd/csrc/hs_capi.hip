@@ -157,6 +157,18 @@ static int copy_d2h(void* h, const void* d, size_t n, hipStream_t s) {
 
 // Timing events are recycled per host thread: creating and destroying a few hundred (interrupt-backed) events per step makes
 // the runtime stall for tens of milliseconds every few dozen steps.
+// Device -> host into pageable memory through a pooled pinned buffer. A direct copy makes the runtime pin the destination on
+// the fly (a "userptr" mapping); when that memory is later freed the kernel driver has to evict and restore the process's
+// GPU queues to drop the mapping -- tens of milliseconds during which nothing runs.
+static int d2h_pinned(void* dst, const void* d, size_t n, hipStream_t s) {
+    if (!n) return stream_wait(s);
+    HBuf h;
+    if (int rc = h.alloc(n)) return rc;
+    if (int rc = copy_d2h(h.p, d, n, s)) return rc;
+    std::memcpy(dst, h.p, n);
+    return HS_OK;
+}
+
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
     static std::vector<hipEvent_t>& cache() { static thread_local std::vector<hipEvent_t> c; return c; }
@@ -589,6 +601,7 @@ struct hs_cv_batch {
         d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, rec_chunk_off, chunk_scratch, task_rec, task_ev0,
         sel_count, sel_gpos, sel_depth, tile_off, tile_ent, tile_rec;
     SelectionScratch sel_scratch;
+    HBuf h_stage_a, h_stage_b, h_stage_c;   // pinned staging of the selection pass
 };
 
 // The stage drivers allocate and free multi-megabyte arrays on many threads every call; with glibc's defaults those go
@@ -757,24 +770,27 @@ struct HipCvOps : hs::CvDeviceOps {
         const double t1 = now();
         // downloads go through pooled pinned buffers: above a few hundred KB hipMemcpy into pageable memory pins the
         // destination on the fly, which costs tens of milliseconds
-        HBuf h_a, h_b;
+        // staging buffers owned by the batch (grown, never returned): a pool miss here means hipHostMalloc while the kernels
+        // of this very step are queued, which stalls the queue for tens of milliseconds
+        auto grow = [](HBuf& h, size_t need) -> int { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); };
         if (!rec_stats.empty()) {
-            if (int rc = h_a.alloc(rec_stats.size() * sizeof(int32_t))) return rc;
-            if (int rc = copy_d2h(h_a.p, b->rec_stats.p, rec_stats.size() * sizeof(int32_t), stream)) return rc;
-            std::memcpy(rec_stats.data(), h_a.p, rec_stats.size() * sizeof(int32_t));
+            if (int rc = grow(b->h_stage_a, rec_stats.size() * sizeof(int32_t))) return rc;
+            if (int rc = copy_d2h(b->h_stage_a.p, b->rec_stats.p, rec_stats.size() * sizeof(int32_t), stream)) return rc;
+            std::memcpy(rec_stats.data(), b->h_stage_a.p, rec_stats.size() * sizeof(int32_t));
         }
         const double t2 = now();
         int32_t n_sel = 0;
-        if (int rc = h_b.alloc(64)) return rc;
-        if (int rc = copy_d2h(h_b.p, b->sel_count.p, sizeof(int32_t), stream)) return rc;
-        n_sel = *(int32_t*)h_b.p;
+        if (int rc = grow(b->h_stage_c, 64)) return rc;
+        if (int rc = copy_d2h(b->h_stage_c.p, b->sel_count.p, sizeof(int32_t), stream)) return rc;
+        n_sel = *(int32_t*)b->h_stage_c.p;
         sel_gpos.resize((size_t)n_sel); sel_depth.resize((size_t)n_sel);
         if (n_sel) {
-            if (int rc = h_a.alloc((size_t)n_sel * sizeof(int64_t))) return rc;
-            if (int rc = copy_d2h(h_a.p, b->sel_gpos.p, (size_t)n_sel * sizeof(int64_t), stream)) return rc;
-            std::memcpy(sel_gpos.data(), h_a.p, (size_t)n_sel * sizeof(int64_t));
-            if (int rc = copy_d2h(h_a.p, b->sel_depth.p, (size_t)n_sel * sizeof(int32_t), stream)) return rc;
-            std::memcpy(sel_depth.data(), h_a.p, (size_t)n_sel * sizeof(int32_t));
+            if (int rc = grow(b->h_stage_b, (size_t)n_sel * 12)) return rc;
+            char* hg = (char*)b->h_stage_b.p; char* hd = hg + (size_t)n_sel * 8;
+            HS_HIP(hipMemcpyAsync(hg, b->sel_gpos.p, (size_t)n_sel * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+            if (int rc = copy_d2h(hd, b->sel_depth.p, (size_t)n_sel * sizeof(int32_t), stream)) return rc;
+            std::memcpy(sel_gpos.data(), hg, (size_t)n_sel * sizeof(int64_t));
+            std::memcpy(sel_depth.data(), hd, (size_t)n_sel * sizeof(int32_t));
         }
         const double t3 = now();
         if (int rc = e1.ms(&k_ms[0])) return rc;
@@ -904,12 +920,11 @@ static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const st
     HS_HIP(hipGetLastError());
     HS_HIP(hipEventRecord(ev.b, stream));
     int32_t n_amb = 0;
-    HS_HIP(hipMemcpyAsync(&n_amb, d_ac.p, 4, hipMemcpyDeviceToHost, stream));
-    if (int rc_w = stream_wait(stream)) return rc_w;
+    if (int rc = d2h_pinned(&n_amb, d_ac.p, 4, stream)) return rc;
     if (n_amb > 0) {
         // rows where std::sort's arrangement of equal distances decides: fetch their sim/diff rows, do exactly what the reference does
         std::vector<int32_t> amb((size_t)n_amb);
-        if (int rc = copy_d2h(amb.data(), d_ar.p, (size_t)n_amb * 4, stream)) return rc;
+        if (int rc = d2h_pinned(amb.data(), d_ar.p, (size_t)n_amb * 4, stream)) return rc;
         std::sort(amb.begin(), amb.end());
         std::vector<int64_t> src((size_t)n_amb), dst((size_t)n_amb + 1, 0);
         std::vector<int32_t> len((size_t)n_amb);
@@ -930,8 +945,8 @@ static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const st
                            d_dst.as<int64_t>(), d_os.as<int32_t>(), d_od.as<int32_t>());
         HS_HIP(hipGetLastError());
         std::vector<int32_t> hs_((size_t)dst.back()), hd_((size_t)dst.back());
-        HS_HIP(hipMemcpyAsync(hs_.data(), d_os.p, hs_.size() * 4, hipMemcpyDeviceToHost, stream));
-        HS_HIP(hipMemcpyAsync(hd_.data(), d_od.p, hd_.size() * 4, hipMemcpyDeviceToHost, stream));
+        if (int rc = d2h_pinned(hs_.data(), d_os.p, hs_.size() * 4, stream)) return rc;
+        if (int rc = d2h_pinned(hd_.data(), d_od.p, hd_.size() * 4, stream)) return rc;
         if (int rc_w = stream_wait(stream)) return rc_w;
         std::vector<int64_t> pbase; std::vector<int32_t> pmw, pi, pj;
         std::vector<uint8_t> mask;
@@ -971,7 +986,7 @@ static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const st
                        d_mo.as<int64_t>(), d_bo.as<int64_t>(), rows, d_deg.as<int32_t>());
     hipLaunchKernelGGL(hsdev::k_exclusive_scan_i32, dim3(1), dim3(1024), 0, stream, d_deg.as<int32_t>(), rows, d_no.as<int64_t>());
     HS_HIP(hipGetLastError());
-    HS_HIP(hipMemcpyAsync(res.nbr_off.data(), d_no.p, ((size_t)rows + 1) * 8, hipMemcpyDeviceToHost, stream));
+    if (int rc = d2h_pinned(res.nbr_off.data(), d_no.p, ((size_t)rows + 1) * 8, stream)) return rc;
     if (int rc_w = stream_wait(stream)) return rc_w;
     const int64_t total = res.nbr_off.back();
     res.nbr.resize((size_t)total);
