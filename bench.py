@@ -192,8 +192,9 @@ def main():
     sync()
     for k in py_ms:
         py_ms[k] = 0.0
-    thr0 = throttle_stats()
-    t0 = time.perf_counter(); cpu0 = time.process_time()
+    plain = bool(os.environ.get("HS_BENCH_PLAIN"))
+    thr0 = None if plain else throttle_stats()
+    t0 = time.perf_counter(); cpu0 = 0.0 if plain else time.process_time()
     k_cv = np.zeros(4); k_sr = np.zeros(4); t_dev = 0.0; t_host = 0.0; k4 = 0.0; k6 = 0.0
     last = None
     step_ms = []
