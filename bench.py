@@ -209,7 +209,8 @@ def main():
             sys.stderr.write(f"outlier step {len(step_ms)}: {step_ms[-1]:.1f} ms {sr.get('wall_ms')}\n")
         k_cv += np.asarray(cv["t_kernel_ms"]); k_sr += np.asarray(sr["t_kernel_ms"]); k4 += cv.get("t_kernel_k4_ms", 0.0); k6 += sr.get("t_kernel_graph_ms", 0.0)
         t_dev += cv["t_device_ms"] + sr["t_device_ms"]; t_host += cv["t_host_ms"] + sr["t_host_ms"]
-        last = ({"n_snps": cv["n_snps"]}, {"n_cw_instances": sr["n_cw_instances"]})   # no references to the step's arrays: they die here, as in the warm-up
+        last = ({"n_snps": cv["n_snps"]}, {"n_cw_instances": sr["n_cw_instances"]})
+        cv = sr = gathered = None   # no references to the step's arrays: they die here, as in the warm-up
     sync()
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3
