@@ -678,139 +678,4 @@ int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, int c0, int c1, const hs_c
 // ---------------------------------------------------------------------------------------------------
 // files
 // ---------------------------------------------------------------------------------------------------
-// parse_column_file: separate_reads.cpp:46-190 (integer- or character-encoded .col, decided by the first SNPS line)
-int parse_col(const std::string& path, float rsa, std::vector<ColFileContig>& cs) {
-    std::ifstream in(path);
-    std::string line;
-    bool numbers = false, first = true;
-    const int max_coverage = 1000000000;   // :1420-1426: uninitialised shadowed variable, observed "unlimited"
-    while (std::getline(in, line)) {
-        std::istringstream iss(line);
-        std::string type;
-        iss >> type;
-        if (type == "CONTIG") {
-            ColFileContig c;
-            c.contig_line = line;
-            std::string length; double cov = 0;
-            iss >> c.name >> length >> cov;
-            c.length = std::atoi(length.c_str());
-            cs.push_back(std::move(c));
-        } else if (type == "SNPS") {
-            if (cs.empty()) continue;
-            std::string pos, ref_s, sec_s, idx_s, content;
-            iss >> pos >> ref_s >> sec_s;
-            if (ref_s.empty() || sec_s.empty()) continue;
-            if (first && (!std::isalpha((unsigned char)ref_s[0]) && ref_s[0] != '-')) numbers = true;
-            first = false;
-            char ref_base, sec_base;
-            if (numbers) { ref_base = (char)std::atoi(ref_s.c_str()); sec_base = (char)std::atoi(sec_s.c_str()); }
-            else { ref_base = ref_s[0]; sec_base = sec_s[0]; }
-            iss >> idx_s >> content;
-            std::vector<char> codes;
-            std::string tok;
-            for (char ch : content) {
-                if (ch == ',') {
-                    if (tok == " ") codes.push_back(' ');
-                    else if (numbers) codes.push_back((char)(unsigned char)std::atoi(tok.c_str()));
-                    else for (char t : tok) codes.push_back(t);
-                    tok.clear();
-                } else tok += ch;
-            }
-            std::vector<int> ridx;
-            tok.clear();
-            for (char ch : idx_s) { if (ch == ',') { ridx.push_back(std::atoi(tok.c_str())); tok.clear(); } else tok += ch; }
-            ColFileContig& c = cs.back();
-            int cov_maj = 0, cov_sec = 0, cov = 0;
-            const size_t keep_from = c.col_idx.size();
-            for (size_t n = 0; n < codes.size() && n < ridx.size(); ++n) {
-                if (codes[n] != ' ' && cov < max_coverage) {
-                    c.col_code.push_back((uint8_t)codes[n]); c.col_idx.push_back(ridx[n]);
-                    if (codes[n] == ref_base) cov_maj++; else if (codes[n] == sec_base) cov_sec++;
-                }
-                if (codes[n] != ' ' && ridx[n] >= 0) cov++;
-            }
-            if ((float)cov_sec >= rsa * (float)(cov_maj + cov_sec)) {
-                c.snp_pos.push_back(std::atoi(pos.c_str())); c.snp_ref.push_back((uint8_t)ref_base); c.snp_alt.push_back((uint8_t)sec_base);
-                c.col_off.push_back((int64_t)c.col_idx.size());
-            } else { c.col_idx.resize(keep_from); c.col_code.resize(keep_from); }
-        } else if (type == "READ") {
-            if (cs.empty()) continue;
-            ColFileContig& c = cs.back();
-            c.read_lines.push_back(line);
-            std::string name, sR, eR, sC, eC;
-            iss >> name >> sR >> eR >> sC >> eC;
-            char* e1 = nullptr; char* e2 = nullptr;
-            long a = std::strtol(sC.c_str(), &e1, 10), b = std::strtol(eC.c_str(), &e2, 10);
-            if (e1 == sC.c_str() || e2 == eC.c_str()) {
-                std::cout << "error in parsing read limits" << std::endl << "line : " << line << std::endl;
-                return 1;
-            }
-            c.read_start.push_back((int32_t)a); c.read_end.push_back((int32_t)b);
-        }
-    }
-    return 0;
-}
-
-// output_files + error rate: call_variants.cpp:1174-1213,1310-1316,1377
-int write_cv_outputs(const CvFileInput& in, const hs_cv_result* res, const std::string& error_rate_out,
-                     const std::string& col_path, const std::string& vcf_path) {
-    const int C = (int)in.contig_names.size();
-    float total = 0; int n = 0;
-    for (int c = 0; c < C; ++c) {
-        if (in.contig_skip[(size_t)c]) continue;   // call_variants.cpp:1283
-        if (res->mean_distance[c] > 0) { total += res->mean_distance[c]; n += 1; }
-    }
-    {
-        std::ofstream er(error_rate_out);
-        std::cout << "total error rate : " << total << " number of contigs : " << n << std::endl;
-        er << total / n << std::endl;
-    }
-    // the VCF header of :1242-1247 is overwritten when output_files reopens the file (:1177): rows only
-    std::ofstream out(col_path), vcf(vcf_path);
-    std::string idxs, bases;
-    for (int c = 0; c < C; ++c) {
-        if (in.contig_skip[(size_t)c]) continue;
-        const int64_t L = in.contig_off[(size_t)c + 1] - in.contig_off[(size_t)c];
-        out << "CONTIG\t" << in.contig_names[(size_t)c] << "\t" << L << "\t" << res->depth[c] << "\n";
-        for (int r = in.contig_rec_off[(size_t)c]; r < in.contig_rec_off[(size_t)c + 1]; ++r) {
-            out << "READ\t" << in.read_names[(size_t)in.rec_read[(size_t)r]] << "\t" << in.rec_r0[(size_t)r] << "\t" << in.rec_r1[(size_t)r]
-                << "\t" << in.rec_c0[(size_t)r] << "\t" << in.rec_c1[(size_t)r] << "\t" << (in.rec_strand[(size_t)r] ? 1 : 0) << "\n";
-        }
-        for (int64_t s = res->snp_off[c]; s < res->snp_off[c + 1]; ++s) {
-            out << "SNPS\t" << res->snp_pos[s] << "\t" << (int)res->snp_ref[s] << "\t" << (int)res->snp_alt[s] << "\t";
-            idxs.clear(); bases.clear();
-            for (int64_t e = res->col_off[s]; e < res->col_off[s + 1]; ++e) {
-                idxs += std::to_string(res->col_idx[e]); idxs += ',';
-                bases += std::to_string((int)res->col_code[e]); bases += ',';
-            }
-            out << idxs << "\t" << bases << "\n";
-            vcf << in.contig_names[(size_t)c] << "\t" << res->snp_pos[s] << "\t.\t" << "ACGT-"[(res->snp_ref[s] - '!') % 5] << "\t"
-                << "ACGT-"[(res->snp_alt[s] - '!') % 5] << "\t.\t.\tDP=" << (res->col_off[s + 1] - res->col_off[s]) << "\n";
-        }
-        out << std::endl;
-        vcf << std::endl;
-    }
-    return 0;
-}
-
-// separate_reads.cpp:1754-1786
-int write_gro(const std::vector<ColFileContig>& cs, const hs_sr_result* res, const std::string& path) {
-    std::ofstream out(path, std::ios_base::app);
-    std::string a, b;
-    for (size_t i = 0; i < cs.size(); ++i) {
-        if (cs[i].snp_pos.empty()) continue;   // separate_reads.cpp:1522-1524
-        out << cs[i].contig_line << std::endl;
-        for (auto& r : cs[i].read_lines) out << r << "\n";
-        for (int64_t w = res->win_off[i]; w < res->win_off[i + 1]; ++w) {
-            out << "GROUP\t" << res->win_start[w] << "\t" << res->win_end[w] << "\t";
-            a.clear(); b.clear();
-            const int32_t* lab = res->labels + res->label_off[w];
-            const int64_t n = res->label_off[w + 1] - res->label_off[w];
-            for (int64_t h = 0; h < n; ++h) if (lab[h] != -2) { a += std::to_string(h); a += ','; b += std::to_string(lab[h]); b += ','; }
-            out << a << "\t" << b << "\n";
-        }
-    }
-    return 0;
-}
-
 }  // namespace hs

@@ -149,12 +149,12 @@ struct ColFileContig {
     std::vector<int32_t> col_idx;
     std::vector<uint8_t> col_code;
 };
-int parse_col(const std::string& path, float rarest_strain_abundance, std::vector<ColFileContig>& cs);
+int parse_col(const std::string& path, float rarest_strain_abundance, std::vector<ColFileContig>& cs, int n_threads = 1);
 
 // writers shared by the executables and the test harness
 int write_cv_outputs(const CvFileInput& in, const hs_cv_result* res, const std::string& error_rate_out,
-                     const std::string& col_path, const std::string& vcf_path);
-int write_gro(const std::vector<ColFileContig>& cs, const hs_sr_result* res, const std::string& path);
+                     const std::string& col_path, const std::string& vcf_path, int n_threads = 1);
+int write_gro(const std::vector<ColFileContig>& cs, const hs_sr_result* res, const std::string& path, int n_threads = 1);
 
 void free_cv_result(hs_cv_result* r);
 void free_sr_result(hs_sr_result* r);

@@ -4,8 +4,11 @@
 // :274-536 parse_SAM, :546-569 parse_reads_on_contig) and writers (call_variants.cpp:1174-1213,1377;
 // separate_reads.cpp:1754-1786); see SURVEY.md §8(b).
 #include "hs_host.h"
+#include "hs_driver.h"
 
 #include <algorithm>
+#include <cctype>
+#include <charconv>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -407,6 +410,210 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
         });
     }
     return HS_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// .col reader and the writers. Text formatting / parsing is per contig block and independent: blocks are handled on all
+// threads, the file itself is written with one write per block, in contig order.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+inline void put_int(std::string& s, long long v) {
+    char buf[24];
+    auto r = std::to_chars(buf, buf + sizeof buf, v);
+    s.append(buf, (size_t)(r.ptr - buf));
+}
+inline void put_float_g(std::string& s, double v) {   // what `ostream << float` prints: %g with 6 significant digits
+    char buf[48];
+    const int n = std::snprintf(buf, sizeof buf, "%g", v);
+    s.append(buf, (size_t)n);
+}
+
+struct Tok { const char* p; size_t n; };
+// whitespace-separated tokens of a line, as `istringstream >>` yields them
+inline bool next_tok(const char*& c, const char* e, Tok& t) {
+    while (c < e && (*c == ' ' || (*c >= '\t' && *c <= '\r'))) ++c;
+    if (c >= e) return false;
+    t.p = c;
+    while (c < e && !(*c == ' ' || (*c >= '\t' && *c <= '\r'))) ++c;
+    t.n = (size_t)(c - t.p);
+    return true;
+}
+
+}  // namespace
+
+// parse_column_file: separate_reads.cpp:46-190 (integer- or character-encoded .col, decided by the first SNPS line)
+int parse_col(const std::string& path, float rsa, std::vector<ColFileContig>& cs, int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    FileView txt;
+    if (!txt.open(path)) return 0;   // the reference's ifstream simply reads nothing
+    const std::vector<Line> lines = split_lines(txt.p, txt.n, n_threads);
+    const int max_coverage = 1000000000;   // :1420-1426: uninitialised shadowed variable, observed "unlimited"
+    // block boundaries (CONTIG lines) and the encoding, which the first complete SNPS line after a CONTIG decides (:93-95)
+    std::vector<size_t> starts;
+    bool numbers = false, decided = false;
+    for (size_t li = 0; li < lines.size(); ++li) {
+        const char* c = lines[li].p; const char* e = c + lines[li].n;
+        Tok t;
+        if (!next_tok(c, e, t)) continue;
+        if (t.n == 6 && std::memcmp(t.p, "CONTIG", 6) == 0) starts.push_back(li);
+        else if (!decided && !starts.empty() && t.n == 4 && std::memcmp(t.p, "SNPS", 4) == 0) {
+            Tok pos, r, s2;
+            if (next_tok(c, e, pos) && next_tok(c, e, r) && next_tok(c, e, s2)) {
+                numbers = !std::isalpha((unsigned char)r.p[0]) && r.p[0] != '-';
+                decided = true;
+            }
+        }
+    }
+    cs.assign(starts.size(), ColFileContig());
+    std::vector<int> rc_of(starts.size(), 0);
+    std::vector<std::string> err_of(starts.size());
+    hs_parallel_for((int)starts.size(), n_threads, [&](int b) {
+        ColFileContig& cc = cs[(size_t)b];
+        const size_t l0 = starts[(size_t)b], l1 = (size_t)b + 1 < starts.size() ? starts[(size_t)b + 1] : lines.size();
+        std::vector<char> codes;
+        std::vector<int> ridx;
+        for (size_t li = l0; li < l1 && !rc_of[(size_t)b]; ++li) {
+            const Line& L = lines[li];
+            const char* c = L.p; const char* e = c + L.n;
+            Tok type;
+            if (!next_tok(c, e, type)) continue;
+            if (li == l0) {   // the CONTIG line itself
+                cc.contig_line.assign(L.p, L.n);
+                Tok name, len;
+                if (next_tok(c, e, name)) cc.name.assign(name.p, name.n);
+                cc.length = next_tok(c, e, len) ? atoi_n(len.p, len.n) : 0;
+            } else if (type.n == 4 && std::memcmp(type.p, "SNPS", 4) == 0) {
+                Tok pos, ref_s, sec_s, idx_s, content;
+                if (!next_tok(c, e, pos)) continue;
+                if (!next_tok(c, e, ref_s) || !next_tok(c, e, sec_s)) continue;
+                char ref_base, sec_base;
+                if (numbers) { ref_base = (char)atoi_n(ref_s.p, ref_s.n); sec_base = (char)atoi_n(sec_s.p, sec_s.n); }
+                else { ref_base = ref_s.p[0]; sec_base = sec_s.p[0]; }
+                const bool has_idx = next_tok(c, e, idx_s), has_content = has_idx && next_tok(c, e, content);
+                codes.clear(); ridx.clear();
+                if (has_content) {   // comma-terminated tokens
+                    size_t t0 = 0;
+                    for (size_t k = 0; k < content.n; ++k)
+                        if (content.p[k] == ',') {
+                            const char* tp = content.p + t0; const size_t tn = k - t0;
+                            if (tn == 1 && tp[0] == ' ') codes.push_back(' ');
+                            else if (numbers) codes.push_back((char)(unsigned char)atoi_n(tp, tn));
+                            else for (size_t q = 0; q < tn; ++q) codes.push_back(tp[q]);
+                            t0 = k + 1;
+                        }
+                }
+                if (has_idx) {
+                    size_t t0 = 0;
+                    for (size_t k = 0; k < idx_s.n; ++k)
+                        if (idx_s.p[k] == ',') { ridx.push_back(atoi_n(idx_s.p + t0, k - t0)); t0 = k + 1; }
+                }
+                int cov_maj = 0, cov_sec = 0, cov = 0;
+                const size_t keep_from = cc.col_idx.size();
+                for (size_t n = 0; n < codes.size() && n < ridx.size(); ++n) {
+                    if (codes[n] != ' ' && cov < max_coverage) {
+                        cc.col_code.push_back((uint8_t)codes[n]); cc.col_idx.push_back(ridx[n]);
+                        if (codes[n] == ref_base) cov_maj++; else if (codes[n] == sec_base) cov_sec++;
+                    }
+                    if (codes[n] != ' ' && ridx[n] >= 0) cov++;
+                }
+                if ((float)cov_sec >= rsa * (float)(cov_maj + cov_sec)) {
+                    cc.snp_pos.push_back(atoi_n(pos.p, pos.n)); cc.snp_ref.push_back((uint8_t)ref_base); cc.snp_alt.push_back((uint8_t)sec_base);
+                    cc.col_off.push_back((int64_t)cc.col_idx.size());
+                } else { cc.col_idx.resize(keep_from); cc.col_code.resize(keep_from); }
+            } else if (type.n == 4 && std::memcmp(type.p, "READ", 4) == 0) {
+                cc.read_lines.emplace_back(L.p, L.n);
+                Tok name, sR, eR, sC, eC;
+                const bool ok = next_tok(c, e, name) && next_tok(c, e, sR) && next_tok(c, e, eR) && next_tok(c, e, sC) && next_tok(c, e, eC);
+                auto is_num = [](const Tok& t) {   // what strtol accepts at the start of the token
+                    size_t i = 0;
+                    if (i < t.n && (t.p[i] == '+' || t.p[i] == '-')) ++i;
+                    return i < t.n && t.p[i] >= '0' && t.p[i] <= '9';
+                };
+                if (!ok || !is_num(sC) || !is_num(eC)) { rc_of[(size_t)b] = 1; err_of[(size_t)b].assign(L.p, L.n); break; }
+                cc.read_start.push_back((int32_t)atoi_n(sC.p, sC.n)); cc.read_end.push_back((int32_t)atoi_n(eC.p, eC.n));
+            }
+        }
+    });
+    for (size_t b = 0; b < starts.size(); ++b)
+        if (rc_of[b]) { std::cout << "error in parsing read limits" << std::endl << "line : " << err_of[b] << std::endl; return 1; }
+    return 0;
+}
+
+int write_cv_outputs(const CvFileInput& in, const hs_cv_result* res, const std::string& error_rate_out, const std::string& col_path,
+                     const std::string& vcf_path, int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    const int C = (int)in.contig_names.size();
+    float total = 0; int n = 0;
+    for (int c = 0; c < C; ++c) {
+        if (in.contig_skip[(size_t)c]) continue;   // call_variants.cpp:1283
+        if (res->mean_distance[c] > 0) { total += res->mean_distance[c]; n += 1; }
+    }
+    {
+        std::ofstream er(error_rate_out);
+        std::cout << "total error rate : " << total << " number of contigs : " << n << std::endl;
+        er << total / n << std::endl;
+    }
+    // the VCF header of :1242-1247 is overwritten when output_files reopens the file (:1177): rows only
+    std::vector<std::string> col_block((size_t)C), vcf_block((size_t)C);
+    hs_parallel_for(C, n_threads, [&](int c) {
+        if (in.contig_skip[(size_t)c]) return;
+        std::string& out = col_block[(size_t)c];
+        std::string& vcf = vcf_block[(size_t)c];
+        const int64_t L = in.contig_off[(size_t)c + 1] - in.contig_off[(size_t)c];
+        const int64_t s0 = res->snp_off[c], s1 = res->snp_off[c + 1];
+        out.reserve((size_t)(res->col_off[s1] - res->col_off[s0]) * 7 + (size_t)(in.contig_rec_off[(size_t)c + 1] - in.contig_rec_off[(size_t)c]) * 48 + 256);
+        out += "CONTIG\t"; out += in.contig_names[(size_t)c]; out += '\t'; put_int(out, L); out += '\t'; put_float_g(out, res->depth[c]); out += '\n';
+        for (int r = in.contig_rec_off[(size_t)c]; r < in.contig_rec_off[(size_t)c + 1]; ++r) {
+            out += "READ\t"; out += in.read_names[(size_t)in.rec_read[(size_t)r]]; out += '\t';
+            put_int(out, in.rec_r0[(size_t)r]); out += '\t'; put_int(out, in.rec_r1[(size_t)r]); out += '\t';
+            put_int(out, in.rec_c0[(size_t)r]); out += '\t'; put_int(out, in.rec_c1[(size_t)r]); out += '\t';
+            out += in.rec_strand[(size_t)r] ? '1' : '0'; out += '\n';
+        }
+        for (int64_t s = s0; s < s1; ++s) {
+            out += "SNPS\t"; put_int(out, res->snp_pos[s]); out += '\t'; put_int(out, (int)res->snp_ref[s]); out += '\t'; put_int(out, (int)res->snp_alt[s]); out += '\t';
+            for (int64_t e = res->col_off[s]; e < res->col_off[s + 1]; ++e) { put_int(out, res->col_idx[e]); out += ','; }
+            out += '\t';
+            for (int64_t e = res->col_off[s]; e < res->col_off[s + 1]; ++e) { put_int(out, (int)res->col_code[e]); out += ','; }
+            out += '\n';
+            vcf += in.contig_names[(size_t)c]; vcf += '\t'; put_int(vcf, res->snp_pos[s]); vcf += "\t.\t"; vcf += "ACGT-"[(res->snp_ref[s] - '!') % 5];
+            vcf += '\t'; vcf += "ACGT-"[(res->snp_alt[s] - '!') % 5]; vcf += "\t.\t.\tDP="; put_int(vcf, res->col_off[s + 1] - res->col_off[s]); vcf += '\n';
+        }
+        out += '\n';
+        vcf += '\n';
+    });
+    std::ofstream out(col_path, std::ios::binary), vcf(vcf_path, std::ios::binary);
+    for (int c = 0; c < C; ++c) {
+        if (in.contig_skip[(size_t)c]) continue;
+        out.write(col_block[(size_t)c].data(), (std::streamsize)col_block[(size_t)c].size());
+        vcf.write(vcf_block[(size_t)c].data(), (std::streamsize)vcf_block[(size_t)c].size());
+    }
+    return 0;
+}
+
+int write_gro(const std::vector<ColFileContig>& cs, const hs_sr_result* res, const std::string& path, int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    std::vector<std::string> block(cs.size());
+    hs_parallel_for((int)cs.size(), n_threads, [&](int i) {
+        const ColFileContig& cc = cs[(size_t)i];
+        if (cc.snp_pos.empty()) return;   // separate_reads.cpp:1522-1524
+        std::string& out = block[(size_t)i];
+        out += cc.contig_line; out += '\n';
+        for (auto& r : cc.read_lines) { out += r; out += '\n'; }
+        std::string b;
+        for (int64_t w = res->win_off[i]; w < res->win_off[i + 1]; ++w) {
+            out += "GROUP\t"; put_int(out, res->win_start[w]); out += '\t'; put_int(out, res->win_end[w]); out += '\t';
+            b.clear();
+            const int32_t* lab = res->labels + res->label_off[w];
+            const int64_t n = res->label_off[w + 1] - res->label_off[w];
+            for (int64_t h = 0; h < n; ++h) if (lab[h] != -2) { put_int(out, h); out += ','; put_int(b, lab[h]); b += ','; }
+            out += '\t'; out += b; out += '\n';
+        }
+    });
+    std::ofstream out(path, std::ios_base::app | std::ios::binary);
+    for (const std::string& b : block) out.write(b.data(), (std::streamsize)b.size());
+    return 0;
 }
 
 }  // namespace hs

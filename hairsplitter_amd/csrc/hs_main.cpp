@@ -101,7 +101,7 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
         return EXIT_FAILURE;
     }
     clk.lap("hs_cv_run");
-    hs::write_cv_outputs(in, res, error_rate_out, file_out, vcf_file);
+    hs::write_cv_outputs(in, res, error_rate_out, file_out, vcf_file, num_threads);
     clk.lap("write .col/.vcf");
     hs_cv_result_destroy(res);
     hs_cv_batch_destroy(batch);
@@ -126,7 +126,7 @@ extern "C" int hs_separate_reads_main(int argc, char** argv) {
     int n_devices = 0;
     std::thread warm([&n_devices] { n_devices = hs_warmup(); });
     std::vector<hs::ColFileContig> cs;
-    const int parse_rc = hs::parse_col(columns_file, rsa, cs);
+    const int parse_rc = hs::parse_col(columns_file, rsa, cs, num_threads);
     clk.lap("parse .col");
     warm.join();
     clk.lap("wait for the device");
@@ -167,7 +167,7 @@ extern "C" int hs_separate_reads_main(int argc, char** argv) {
         return 1;
     }
     clk.lap("hs_sr_run");
-    hs::write_gro(cs, res, outfile);
+    hs::write_gro(cs, res, outfile, num_threads);
     clk.lap("write .gro");
     hs_sr_result_destroy(res);
     return 0;

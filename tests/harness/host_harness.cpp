@@ -300,7 +300,7 @@ int main(int argc, char** argv) {
         OracleCvOps ops(in);
         hs_cv_result* res = nullptr;
         if (int rc = hs::cv_run(ops, meta, std::strtof(a[11], nullptr), 1, &res)) return rc;
-        hs::write_cv_outputs(in, res, a[6], a[9], a[10]);
+        hs::write_cv_outputs(in, res, a[6], a[9], a[10], 4);
         hs::free_cv_result(res);
         return 0;
     }
@@ -308,7 +308,7 @@ int main(int argc, char** argv) {
         if (argc != 11) return 2;
         char** a = argv + 1;
         std::vector<hs::ColFileContig> cs;
-        if (int rc = hs::parse_col(a[1], (float)std::atof(a[6]), cs)) return rc;
+        if (int rc = hs::parse_col(a[1], (float)std::atof(a[6]), cs, 4)) return rc;
         std::map<std::string, int> ploidy_of; bool have = false;
         { std::ifstream pf(a[4]); if (pf) { have = true; std::string c; int p; while (pf >> c >> p) ploidy_of[c] = p; } }
         std::vector<hs_sr_contig> hc(cs.size());
@@ -324,7 +324,7 @@ int main(int argc, char** argv) {
         hs_sr_result* res = nullptr;
         if (int rc = hs::sr_run(ops, hc.data(), (int)hc.size(), w, (float)std::atof(a[3]), std::atoi(a[5]), 12345u, 1, &res)) return rc;
         { std::ofstream o(a[8]); }
-        hs::write_gro(cs, res, a[8]);
+        hs::write_gro(cs, res, a[8], 4);
         hs::free_sr_result(res);
         return 0;
     }
