@@ -4,6 +4,8 @@
 #pragma once
 #include <cstdint>
 #include <functional>
+#include <memory>
+#include <utility>
 #include <string>
 #include <vector>
 #include "../../include/hairsplitter_hip.h"
@@ -65,18 +67,30 @@ struct SrWindowPlan {
 };
 
 // ---- files -----------------------------------------------------------------------------------
+// std::allocator that default-initialises: resize() of a multi-gigabyte byte vector does not memset it first (every element
+// is written right afterwards, by many threads)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <class U, class... A> void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+
 struct CvFileInput {
     // flattened parse_reads / parse_assembly / parse_SAM result
     std::vector<std::string> contig_names;
-    std::vector<uint8_t> contig_seq;
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> contig_seq;
     std::vector<int64_t> contig_off;
     std::vector<std::string> read_names;
-    std::vector<uint8_t> read_seq;
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> read_seq;
     std::vector<int64_t> read_off;
     std::vector<int32_t> rec_read, rec_pos;
     std::vector<uint8_t> rec_strand;
     std::vector<int64_t> rec_cig_off;
-    std::vector<uint32_t> cigar;
+    std::vector<uint32_t, NoInitAlloc<uint32_t>> cigar;
     std::vector<int32_t> contig_rec_off;
     std::vector<int32_t> rec_r0, rec_r1, rec_c0, rec_c1;   // the four coordinates of the READ line
     std::vector<uint8_t> contig_skip;                      // call_variants.cpp:1283

@@ -7,6 +7,7 @@
 #include "hs_driver.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cctype>
 #include <charconv>
 #include <cstdio>
@@ -169,6 +170,7 @@ SamLineResult parse_sam_line(const Line& l, size_t line_no, long n_reads, long n
     }
     if (!(allgood && fieldnumber > 10 && seq2 != seq1)) return SAM_SKIP;
     r.cig.clear();
+    r.cig.reserve(cgn / 2 + 1);      // an op is at least two characters
     if (parse_cigar(cg, cgn, r.cig) != 0) { if (bad_cigar) bad_cigar->assign(cg, cgn); return SAM_BAD_CIGAR; }
     auto clip = [&](bool front, uint32_t what) -> int {
         if (r.cig.empty()) return 0;
@@ -208,6 +210,14 @@ SamLineResult parse_sam_line(const Line& l, size_t line_no, long n_reads, long n
 
 int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::string& sam, bool amplicon, CvFileInput& in, int n_threads) {
     if (n_threads < 1) n_threads = 1;
+    const bool tim = std::getenv("HS_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!tim) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[hs timing]   load: %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t_last).count());
+        t_last = n;
+    };
     // one name table for reads and contigs, as in the reference (reads first, contigs appended: input_output.cpp:134,241);
     // a later entry of the same name replaces the earlier one
     std::unordered_map<std::string_view, long> indices;
@@ -220,7 +230,9 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
     }
     char format = '@';
     if ((reads.size() > 6 && reads.substr(reads.size() - 6, 6) == ".fasta") || (reads.size() >= 3 && reads.substr(reads.size() - 3, 3) == ".fa")) format = '>';
+    lap("map reads");
     std::vector<Line> rl = split_lines(rtxt.p, rtxt.n, n_threads);
+    lap("split reads");
     std::vector<Line> seq_of_read;
     {
         std::vector<size_t> buffer;   // line indices
@@ -245,6 +257,7 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
         if (buffer.size() >= 2) flush();
     }
     const long n_reads = (long)in.read_names.size();
+    lap("index reads");
 
     // ---- contigs (input_output.cpp:120-264, S lines) ----
     FileView gtxt;
@@ -284,6 +297,7 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
         });
     }
     const long n_contigs = (long)in.contig_names.size();
+    lap("contigs");
 
     // ---- alignments (input_output.cpp:274-536): lines are independent once the names resolve, so they are parsed in
     // blocks on all threads. A name that is in neither file goes through the reference's operator[] (:325), which inserts
@@ -296,6 +310,7 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
         return HS_EIO;
     }
     std::vector<Line> sl = split_lines(stxt.p, stxt.n, n_threads);
+    lap("map + split sam");
     const int NB = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads * 4, sl.size() / 64 + 1));
     struct Block { std::vector<SamRec> recs; std::vector<size_t> deferred; size_t bad_line = (size_t)-1; std::string bad_cigar; };
     std::vector<Block> blocks((size_t)NB);
@@ -317,6 +332,7 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
             else if (k == SAM_BAD_CIGAR) { B.bad_line = li; break; }
         }
     });
+    lap("parse sam");
     for (const Block& B : blocks)
         if (B.bad_line != (size_t)-1) {
             std::cout << "ERROR : could not convert " << B.bad_cigar << " to int" << std::endl;
@@ -373,6 +389,7 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
             }
         });
     }
+    lap("code reads");
     size_t n_rec = 0;
     in.contig_rec_off.assign(1, 0);
     for (long c = 0; c < n_contigs; ++c) { n_rec += per_contig[(size_t)c].size(); in.contig_rec_off.push_back((int32_t)n_rec); }
@@ -409,6 +426,7 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
             }
         });
     }
+    lap("flatten");
     return HS_OK;
 }
 
