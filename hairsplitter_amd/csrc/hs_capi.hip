@@ -183,6 +183,19 @@ struct EventPair {
     int ms(float* out) { HS_HIP(hipEventSynchronize(b)); HS_HIP(hipEventElapsedTime(out, a, b)); return HS_OK; }
 };
 
+// threads for the host-side passes of the C entry points that take no thread count: the CPU quota of the cgroup if there is
+// one, else the hardware concurrency, at most 32
+int host_threads() {
+    static const int n = [] {
+        long q = 0, per = 0;
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) { char a[32]; if (std::fscanf(f, "%31s %ld", a, &per) == 2 && std::strcmp(a, "max") != 0) q = std::atol(a); std::fclose(f); }
+        int t = (int)std::thread::hardware_concurrency();
+        if (q > 0 && per > 0) t = std::min<int>(t, (int)((q + per - 1) / per));
+        return std::max(1, std::min(t, 32));
+    }();
+    return n;
+}
+
 int require_device() {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -274,12 +287,23 @@ int hs_pileup_plan(const int64_t* h_rec_cig_off, const uint32_t* h_cigar, int32_
     if (ev_per_task <= 0 || !h_rec_chunk_off || !n_tasks || !h_task_rec || !h_task_ev0) { set_error("hs_pileup_plan: bad arguments"); return HS_EINVAL; }
     std::vector<int32_t> tr, te;
     h_rec_chunk_off[0] = 0;
+    std::vector<int64_t> ev_of((size_t)std::max(n_rec, 0));
+    {   // events per record: one pass over all CIGAR ops, blocks of records on the host threads
+        const int nb = std::max(1, std::min(n_rec / 256 + 1, 256));
+        hs::hs_parallel_for(nb, host_threads(), [&](int b) {
+            const int r0 = (int)((int64_t)n_rec * b / nb), r1 = (int)((int64_t)n_rec * (b + 1) / nb);
+            for (int r = r0; r < r1; ++r) {
+                int64_t ev = 0;
+                for (int64_t o = h_rec_cig_off[r]; o < h_rec_cig_off[r + 1]; ++o) {
+                    const uint32_t op = h_cigar[o] & 15u;
+                    if (op == 0 || op == 1 || op == 2 || op == 7 || op == 8) ev += h_cigar[o] >> 4;
+                }
+                ev_of[(size_t)r] = ev;
+            }
+        });
+    }
     for (int r = 0; r < n_rec; ++r) {
-        int64_t ev = 0;
-        for (int64_t o = h_rec_cig_off[r]; o < h_rec_cig_off[r + 1]; ++o) {
-            const uint32_t op = h_cigar[o] & 15u;
-            if (op == 0 || op == 1 || op == 2 || op == 7 || op == 8) ev += h_cigar[o] >> 4;
-        }
+        const int64_t ev = ev_of[(size_t)r];
         if (ev > 0x7fffffff) { set_error("alignment with more than 2^31 events"); return HS_EINVAL; }
         h_rec_chunk_off[r + 1] = h_rec_chunk_off[r] + (h_rec_cig_off[r + 1] - h_rec_cig_off[r] + 63) / 64;
         for (int64_t e = 0; e < ev; e += ev_per_task) { tr.push_back(r); te.push_back((int32_t)e); }
@@ -637,6 +661,22 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
     b->rec_qend.resize((size_t)n_rec);
     b->rec_refspan.resize((size_t)n_rec);
     b->pile_off.assign((size_t)n_rec + 1, 0);
+    std::vector<int64_t> readspan_of((size_t)n_rec);
+    {   // reference / read span of every record: one pass over all CIGAR ops, blocks of records on the host threads
+        const int nb = std::max(1, std::min(n_rec / 256 + 1, 256));
+        hs::hs_parallel_for(nb, host_threads(), [&](int blk) {
+            const int r0 = (int)((int64_t)n_rec * blk / nb), r1 = (int)((int64_t)n_rec * (blk + 1) / nb);
+            for (int r = r0; r < r1; ++r) {
+                int64_t refspan = 0, readspan = 0;
+                for (int64_t o = h_rec_cig_off[r]; o < h_rec_cig_off[r + 1]; ++o) {
+                    const uint32_t op = h_cigar[o] & 15u; const int64_t len = h_cigar[o] >> 4;
+                    if (op == 0 || op == 2 || op == 7 || op == 8) refspan += len;
+                    if (op == 0 || op == 1 || op == 4 || op == 5 || op == 7 || op == 8) readspan += len;
+                }
+                b->rec_refspan[(size_t)r] = refspan; readspan_of[(size_t)r] = readspan;
+            }
+        });
+    }
     for (int c = 0; c < n_contigs; ++c) {
         const int64_t L = b->contig_off[(size_t)c + 1] - b->contig_off[(size_t)c];
         if (b->contig_rec_off[(size_t)c + 1] - b->contig_rec_off[(size_t)c] > 65535) {
@@ -645,12 +685,7 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
         }
         for (int r = b->contig_rec_off[(size_t)c]; r < b->contig_rec_off[(size_t)c + 1]; ++r) {
             b->rec_contig[(size_t)r] = c;
-            int64_t refspan = 0, readspan = 0;
-            for (int64_t o = h_rec_cig_off[r]; o < h_rec_cig_off[r + 1]; ++o) {
-                const uint32_t op = h_cigar[o] & 15u; const int64_t len = h_cigar[o] >> 4;
-                if (op == 0 || op == 2 || op == 7 || op == 8) refspan += len;
-                if (op == 0 || op == 1 || op == 4 || op == 5 || op == 7 || op == 8) readspan += len;
-            }
+            const int64_t refspan = b->rec_refspan[(size_t)r], readspan = readspan_of[(size_t)r];
             const int64_t rl = h_read_off[h_rec_read[r] + 1] - h_read_off[h_rec_read[r]];
             const int64_t pos = h_rec_pos[r];
             if (pos < 0) { set_error("negative alignment start"); delete b; return HS_EINVAL; }
@@ -658,7 +693,6 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
             // a CIGAR that runs past the read is only tolerated for the part that lies beyond the contig end
             if (readspan > rl && pos + refspan <= L) { set_error("CIGAR consumes more bases than the read has"); delete b; return HS_EINVAL; }
             b->rec_qend[(size_t)r] = (int32_t)qend;
-            b->rec_refspan[(size_t)r] = refspan;
             b->pile_off[(size_t)r + 1] = b->pile_off[(size_t)r] + (qend - pos);
         }
     }
