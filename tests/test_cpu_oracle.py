@@ -121,3 +121,23 @@ def test_degenerate_files_match_reference_binary(built, which):
             assert r.returncode == 0
             outs[tag] = tuple(open(p, "rb").read() for p in (col, vcf, err))
         assert outs["ref"] == outs["hs"]
+
+
+def test_host_glue_deep_coverage_equals_oracle(built):
+    """coverage > 1000 (low-memory graphs per contig, separate_reads.cpp:1515-1518; finalize on the never-filled matrix,
+    :1708): the product's host glue against the oracle restatement on the same files"""
+    from hairsplitter_amd import synth, canon
+    contigs = [synth.make_contig(77, 0, 4000, 2, 0.01, 1200, "ont", read_len_override=(1000, 2500))]
+    with tempfile.TemporaryDirectory() as td:
+        f = synth.write_files(contigs, td)
+        outs = {}
+        for tag, cv, sr in (("hs", [built["harness"], "call_variants"], [built["harness"], "separate_reads"]),
+                            ("orc", [built["oracle"], "call_variants"], [built["oracle"], "separate_reads"])):
+            col, vcf, err, gro = (os.path.join(td, tag + x) for x in (".col", ".vcf", ".err", ".gro"))
+            subprocess.run(cv + [f["gfa"], f["reads"], f["sam"], "2", td, err, "0", "0", col, vcf, "0.33"], check=True, stdout=subprocess.DEVNULL)
+            e = min(float(open(err).read().strip()), 0.15)
+            subprocess.run(sr + [col, "2", str(e), os.path.join(td, "no_ploidy"), "0", "0.01", "0", gro, "0"], check=True, stdout=subprocess.DEVNULL)
+            outs[tag] = (col, vcf, err, gro)
+        assert canon.split_blocks(outs["hs"][0]) == canon.split_blocks(outs["orc"][0])
+        assert open(outs["hs"][2]).read() == open(outs["orc"][2]).read()
+        assert canon.split_blocks(outs["hs"][3]) == canon.split_blocks(outs["orc"][3])

@@ -103,7 +103,7 @@ def test_fused_pipeline_equals_two_step_path(built):
         assert np.array_equal(sr[k], sr2[k]), k
 
 
-@pytest.mark.parametrize("shape", ["tetra100k", "hifi300k", "meta_ploidy1to8"])
+@pytest.mark.parametrize("shape", ["tetra100k", "hifi300k", "meta_ploidy1to8", "deep1200x"])
 def test_dropin_equals_oracle_at_larger_sizes(built, shape):
     """Beyond the committed fixtures: BASELINE-shaped contigs (tetraploid ONT as C3, a metagenome slice with ploidies 1..8 at
     30x total depth as C4, HiFi 300 kb chunk as C5) through the drop-in executables, against the oracle restatement run on
@@ -111,6 +111,10 @@ def test_dropin_equals_oracle_at_larger_sizes(built, shape):
     from hairsplitter_amd import synth, canon
     if shape == "tetra100k":
         contigs = [synth.make_contig(41, 0, 100_000, 4, 0.01, 40, "ont")]
+    elif shape == "deep1200x":
+        # coverage > 1000: 16-bit histogram counters in K2, the per-contig low-memory graph path (separate_reads.cpp:1515-1518),
+        # finalize_clustering on a graph that was never filled (:1708), 2700 reads per Chinese-Whispers instance, 500-bp windows
+        contigs = [synth.make_contig(77, 0, 4000, 2, 0.01, 1200, "ont", read_len_override=(1000, 2500))]
     elif shape == "meta_ploidy1to8":
         contigs = [synth.make_contig(43, i, 20_000 + 5_000 * i, 1 + i, 0.01 if i else 0.0, 30, "ont") for i in range(8)]
     else:
@@ -128,7 +132,7 @@ def test_dropin_equals_oracle_at_larger_sizes(built, shape):
         assert canon.vcf_blocks(outs["hip"][1]) == canon.vcf_blocks(outs["orc"][1])
         assert open(outs["hip"][2]).read() == open(outs["orc"][2]).read()
         assert canon.split_blocks(outs["hip"][3]) == canon.split_blocks(outs["orc"][3])
-        assert sum(1 for l in open(outs["hip"][3]) if l.startswith("GROUP")) > (20 if shape == "meta_ploidy1to8" else 40)
+        assert sum(1 for l in open(outs["hip"][3]) if l.startswith("GROUP")) > {"meta_ploidy1to8": 20, "deep1200x": 5}.get(shape, 40)
 
 
 def test_pipeline_groups_equal_single_batch(built):
