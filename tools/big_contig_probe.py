@@ -1,0 +1,22 @@
+import sys, os, subprocess, tempfile, time, json
+sys.path.insert(0, os.getcwd())
+from hairsplitter_amd import synth, canon
+import bench, __graft_entry__ as ge
+p = ge.paths()
+contigs = [synth.make_contig(88, 0, 2_000_000, 2, 0.001, 30, "hifi")]
+print("reads", len(contigs[0].reads), "bp", contigs[0].aligned_bp, flush=True)
+with tempfile.TemporaryDirectory() as td:
+    f = synth.write_files(contigs, td)
+    res = {}
+    for tag, cv, sr in (("hip", p["cv"], p["sr"]), ("ref", p["ref_cv"], p["ref_sr_seeded"])):
+        col, vcf, err, gro = (os.path.join(td, tag + x) for x in (".col", ".vcf", ".err", ".gro"))
+        t0 = time.time()
+        r = subprocess.run([cv, f["gfa"], f["reads"], f["sam"], "16", td, err, "0", "0", col, vcf, "0.33"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode: print(tag, "cv rc", r.returncode, r.stdout.decode()[-400:]); break
+        e = bench.py_error_rate(float(open(err).read().strip()))
+        r = subprocess.run([sr, col, "16", str(e), os.path.join(td, "nop"), "0", "0.01", "0", gro, "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode: print(tag, "sr rc", r.returncode, r.stdout.decode()[-400:]); break
+        res[tag] = (col, vcf, err, gro); print(tag, round(time.time() - t0, 2), "s", flush=True)
+    if len(res) == 2:
+        a, b = res["hip"], res["ref"]
+        print("col", canon.split_blocks(a[0]) == canon.split_blocks(b[0]), "gro", canon.split_blocks(a[3]) == canon.split_blocks(b[3]), "err", open(a[2]).read() == open(b[2]).read())
