@@ -125,7 +125,10 @@ __global__ __launch_bounds__(256) void k_pileup(
     // the ops that own events, and one "an op starts here" flag per event of the current 64-event window
     __shared__ int4 s_op[4][64];
     __shared__ uint8_t s_nzlane[4][64];
-    constexpr int PU = 4;
+#ifndef HS_K1_PU
+#define HS_K1_PU 4
+#endif
+    constexpr int PU = HS_K1_PU;
     __shared__ uint8_t s_flag[4][PU][64];
     const int lane = lane_id();
     const int wv = wave_id();
@@ -189,7 +192,8 @@ __global__ __launch_bounds__(256) void k_pileup(
         // popcounts of ballots), and the owner lookup shares one flag clear / one flag scatter between the four windows.
         uint8_t* const flags = &s_flag[wv][0][0];
         for (int eb = lo_el; eb < hi_el; eb += 64 * PU) {
-            reinterpret_cast<uint32_t*>(flags)[lane] = 0u;                    // 64 lanes x 4 B = the 256 flags of the iteration
+#pragma unroll
+            for (int z = 0; z < PU / 4; ++z) reinterpret_cast<uint32_t*>(flags)[lane + 64 * z] = 0u;   // 64 lanes x 4 B = 256 flags each
             wave_lds_sync();
             {
                 const int rel = ev_ex - eb;
