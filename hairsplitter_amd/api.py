@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_ROOT, "lib", "libhairsplitter_hip.so")
 SYMBOLS = [
     "hs_version", "hs_last_error", "hs_device_count", "hs_warmup", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
-    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
+    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
     "hs_separate_reads_main",
@@ -36,7 +36,8 @@ class CvResult(C.Structure):
                 ("snp_alt", C.POINTER(C.c_uint8)), ("snp_n_ref", C.POINTER(C.c_int32)), ("snp_n_alt", C.POINTER(C.c_int32)),
                 ("col_off", C.POINTER(C.c_int64)), ("col_idx", C.POINTER(C.c_int32)),
                 ("col_code", C.POINTER(C.c_uint8)), ("error_rate", C.c_float), ("n_contigs_with_error_rate", C.c_int32),
-                ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("t_kernel_ms", C.c_float * 4), ("t_kernel_k4_ms", C.c_float)]
+                ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("t_kernel_ms", C.c_float * 4), ("t_kernel_k4_ms", C.c_float),
+                ("n_columns_extracted", C.c_int64), ("n_columns_downloaded", C.c_int64), ("n_columns_downloaded_late", C.c_int64)]
 
 
 class SrContig(C.Structure):
@@ -226,6 +227,8 @@ class CvBatch:
             "error_rate": float(r.error_rate),
             "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms),
             "t_kernel_ms": [float(x) for x in r.t_kernel_ms],
+            "n_columns_extracted": int(r.n_columns_extracted), "n_columns_downloaded": int(r.n_columns_downloaded),
+            "n_columns_downloaded_late": int(r.n_columns_downloaded_late),
         }
         lib.hs_cv_result_destroy(res)
         return out
@@ -244,7 +247,9 @@ class CvBatch:
             Cn = r.n_contigs
             cv = {"mean_distance": np.ctypeslib.as_array(r.mean_distance, (max(Cn, 1),))[:Cn].copy(), "error_rate": float(r.error_rate),
                   "n_snps": int(np.ctypeslib.as_array(r.snp_off, (Cn + 1,))[-1]),
-                  "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_k4_ms": float(r.t_kernel_k4_ms)}
+                  "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_k4_ms": float(r.t_kernel_k4_ms),
+                  "n_columns_extracted": int(r.n_columns_extracted), "n_columns_downloaded": int(r.n_columns_downloaded),
+                  "n_columns_downloaded_late": int(r.n_columns_downloaded_late)}
             e = error_rate_fn(cv) if error_rate_fn is not None else min(float("%g" % cv["error_rate"]), 0.15)
             sres = C.POINTER(SrResult)()
             _check(lib.hs_sr_run_cv(self.handle, res, C.c_float(e), C.c_float(rarest_strain_abundance), C.c_int32(1 if low_memory else 0),
@@ -265,7 +270,9 @@ class CvBatch:
         Cn = r.n_contigs
         cv = {"mean_distance": np.ctypeslib.as_array(r.mean_distance, (max(Cn, 1),))[:Cn].copy(), "error_rate": float(r.error_rate),
               "n_snps": int(np.ctypeslib.as_array(r.snp_off, (Cn + 1,))[-1]),
-              "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_k4_ms": float(r.t_kernel_k4_ms)}
+              "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_k4_ms": float(r.t_kernel_k4_ms),
+                  "n_columns_extracted": int(r.n_columns_extracted), "n_columns_downloaded": int(r.n_columns_downloaded),
+                  "n_columns_downloaded_late": int(r.n_columns_downloaded_late)}
         return res, cv
 
     def _sr(self, res, e, n_threads, rarest_strain_abundance, low_memory, amplicon, seed, window_size):
@@ -301,7 +308,8 @@ class CvSelection(C.Structure):
 class PipelineStats(C.Structure):
     _fields_ = [("n_snps", C.c_int64), ("n_cw_instances", C.c_int64), ("n_graph_rows_host", C.c_int64),
                 ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("t_kernel_cv_ms", C.c_float * 4), ("t_kernel_k4_ms", C.c_float),
-                ("t_kernel_sr_ms", C.c_float * 4), ("t_kernel_graph_ms", C.c_float)]
+                ("t_kernel_sr_ms", C.c_float * 4), ("t_kernel_graph_ms", C.c_float),
+                ("n_columns_extracted", C.c_int64), ("n_columns_downloaded", C.c_int64), ("n_columns_downloaded_late", C.c_int64)]
 
 
 class PipelineGroups:
@@ -347,7 +355,9 @@ class PipelineGroups:
                                    C.c_int32(window_size), C.byref(sres), C.byref(st)))
         t_3 = time.perf_counter()
         cv.update({"n_snps": int(st.n_snps), "t_device_ms": float(st.t_device_ms), "t_host_ms": float(st.t_host_ms),
-                   "t_kernel_ms": [float(x) for x in st.t_kernel_cv_ms], "t_kernel_k4_ms": float(st.t_kernel_k4_ms)})
+                   "t_kernel_ms": [float(x) for x in st.t_kernel_cv_ms], "t_kernel_k4_ms": float(st.t_kernel_k4_ms),
+                   "n_columns_extracted": int(st.n_columns_extracted), "n_columns_downloaded": int(st.n_columns_downloaded),
+                   "n_columns_downloaded_late": int(st.n_columns_downloaded_late)})
         sr = _sr_result_to_dict(sres, Cn)
         lib.hs_sr_result_destroy(sres)
         sr["wall_ms"] = {"select": (t_1 - t_0) * 1e3, "between": (t_2 - t_1) * 1e3, "groups": (t_3 - t_2) * 1e3, "collect": (time.perf_counter() - t_3) * 1e3}
@@ -606,6 +616,28 @@ def column_top3(col_off, col_code):
     raw = out[:n].cpu().numpy()
     cnt = raw[:, :12].copy().view(np.int32).reshape(n, 3)
     return cnt[:, 0], cnt[:, 1], cnt[:, 2], raw[:, 12], raw[:, 13], raw[:, 14]
+
+
+def pack_columns(col_off, col_idx, col_code, ids):
+    """K3c on host arrays (uploaded here): the listed columns packed back to back; returns (packed_off, idx, code)"""
+    import torch
+    require_gpu()
+    dev = "cuda:0"
+    col_off = _np(col_off, np.int64); col_idx = _np(col_idx, np.int32); col_code = _np(col_code, np.uint8); ids = _np(ids, np.int32)
+    depth = (col_off[1:] - col_off[:-1])[ids] if len(ids) else np.zeros(0, np.int64)
+    packed_off = np.zeros(len(ids) + 1, np.int64)
+    np.cumsum(depth, out=packed_off[1:])
+    total = int(packed_off[-1])
+    d_off = torch.from_numpy(col_off).to(dev)
+    d_idx = torch.from_numpy(col_idx if col_idx.size else np.zeros(1, np.int32)).to(dev)
+    d_code = torch.from_numpy(col_code if col_code.size else np.zeros(1, np.uint8)).to(dev)
+    d_ids = torch.from_numpy(ids if ids.size else np.zeros(1, np.int32)).to(dev)
+    d_po = torch.from_numpy(packed_off).to(dev)
+    o_idx = torch.full((max(total, 1),), -1, dtype=torch.int32, device=dev)
+    o_code = torch.zeros(max(total, 1), dtype=torch.uint8, device=dev)
+    _check(load().hs_pack_columns(_p(d_off), _p(d_idx), _p(d_code), _p(d_ids), _p(d_po), C.c_int32(len(ids)), _p(o_idx), _p(o_code), C.c_void_p(0)))
+    torch.cuda.synchronize()
+    return packed_off, o_idx[:total].cpu().numpy(), o_code[:total].cpu().numpy()
 
 
 def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1, col_c1, col_is_cand, part_off, part_state_off, part_state):

@@ -495,6 +495,16 @@ int hs_column_top3(const int64_t* d_col_off, const uint8_t* d_col_code, int32_t 
     return HS_OK;
 }
 
+int hs_pack_columns(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code, const int32_t* d_ids,
+                    const int64_t* d_packed_off, int32_t n_ids, int32_t* d_out_idx, uint8_t* d_out_code, void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_ids <= 0) return HS_OK;
+    hipLaunchKernelGGL(hsdev::k_pack_columns, dim3((n_ids + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_col_off, d_col_idx, d_col_code, d_ids,
+                       d_packed_off, n_ids, d_out_idx, d_out_code);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
 int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code,
                              const int32_t* d_col_contig, const uint8_t* d_col_k0, const uint8_t* d_col_k1,
                              const int32_t* d_col_c1, const uint8_t* d_col_is_cand, int32_t n_cols,
@@ -835,7 +845,6 @@ struct HipCvOps : hs::CvDeviceOps {
         return HS_OK;
     }
 
-    HBuf h_col_idx, h_col_code;
     DBuf d_co, d_ci, d_cc;     // the extracted columns stay on the device for K4
     UploadPack gather_pack;
     int n_gathered = 0;
@@ -870,19 +879,17 @@ struct HipCvOps : hs::CvDeviceOps {
     }
     HBuf h_top;
     int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
-               const int32_t** col_idx, const uint8_t** col_code, const hs_coltop** top, float* k_ms) override {
+               const hs_coltop** top, float* k_ms) override {
         const int n_sel = (int)sel_pos.size();
         const size_t total = (size_t)col_off.back();
-        if (int rc = h_col_idx.alloc(total * sizeof(int32_t))) return rc;
-        if (int rc = h_col_code.alloc(total)) return rc;
         if (int rc = h_top.alloc((size_t)n_sel * sizeof(hs_coltop))) return rc;
-        *col_idx = (const int32_t*)h_col_idx.p; *col_code = (const uint8_t*)h_col_code.p; *top = (const hs_coltop*)h_top.p;
+        *top = (const hs_coltop*)h_top.p;
         n_gathered = n_sel;
         if (n_sel == 0) return HS_OK;
         DBuf d_sc, d_sp;
         gather_pack.add(sel_contig, d_sc);
         gather_pack.add(sel_pos, d_sp);
-        gather_pack.add(col_off, d_co);      // stays resident for K4 (member pack)
+        gather_pack.add(col_off, d_co);      // stays resident for K4 and fetch_columns (member pack)
         if (int rc = gather_pack.commit(stream)) return rc;
         if (int rc = d_ci.alloc(total * sizeof(int32_t))) return rc;
         if (int rc = d_cc.alloc(total)) return rc;
@@ -895,13 +902,31 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = d_top.alloc((size_t)n_sel * sizeof(hs_coltop))) return rc;
         if (int rc = hs_column_top3(d_co.as<int64_t>(), d_cc.as<uint8_t>(), n_sel, d_top.as<hs_coltop>(), stream)) return rc;
         HS_HIP(hipEventRecord(e.b, stream));
-        if (total) {
-            HS_HIP(hipMemcpyAsync(h_col_idx.p, d_ci.p, total * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-            HS_HIP(hipMemcpyAsync(h_col_code.p, d_cc.p, total, hipMemcpyDeviceToHost, stream));
-        }
         HS_HIP(hipMemcpyAsync(h_top.p, d_top.p, (size_t)n_sel * sizeof(hs_coltop), hipMemcpyDeviceToHost, stream));
         if (int rc_w = stream_wait(stream)) return rc_w;
         return e.ms(k_ms);
+    }
+    HBuf h_fetch_idx[2], h_fetch_code[2];
+    int fetch_columns(const std::vector<int32_t>& cols, const std::vector<int64_t>& packed_off, int slot, const int32_t** col_idx,
+                      const uint8_t** col_code) override {
+        if (slot < 0 || slot > 1 || packed_off.size() != cols.size() + 1) { set_error("fetch_columns: bad arguments"); return HS_EINVAL; }
+        const size_t total = (size_t)packed_off.back();
+        if (int rc = h_fetch_idx[slot].alloc(std::max<size_t>(total, 1) * sizeof(int32_t))) return rc;
+        if (int rc = h_fetch_code[slot].alloc(std::max<size_t>(total, 1))) return rc;
+        *col_idx = (const int32_t*)h_fetch_idx[slot].p; *col_code = (const uint8_t*)h_fetch_code[slot].p;
+        if (cols.empty() || total == 0) return HS_OK;
+        DBuf d_ids, d_po, d_pi, d_pc;
+        UploadPack pk;
+        pk.add(cols, d_ids);
+        pk.add(packed_off, d_po);
+        if (int rc = pk.commit(stream)) return rc;
+        if (int rc = d_pi.alloc(total * sizeof(int32_t))) return rc;
+        if (int rc = d_pc.alloc(total)) return rc;
+        if (int rc = hs_pack_columns(d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), d_ids.as<int32_t>(), d_po.as<int64_t>(), (int32_t)cols.size(),
+                                     d_pi.as<int32_t>(), d_pc.as<uint8_t>(), stream)) return rc;
+        HS_HIP(hipMemcpyAsync(h_fetch_idx[slot].p, d_pi.p, total * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HS_HIP(hipMemcpyAsync(h_fetch_code[slot].p, d_pc.p, total, hipMemcpyDeviceToHost, stream));
+        return stream_wait(stream);
     }
 };
 
@@ -1479,6 +1504,8 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
             st->n_snps += r->snp_off[r->n_contigs];
             st->t_device_ms += r->t_device_ms; st->t_host_ms += r->t_host_ms;
             st->t_kernel_cv_ms[2] += r->t_kernel_ms[2]; st->t_kernel_k4_ms += r->t_kernel_k4_ms;
+            st->n_columns_extracted += r->n_columns_extracted; st->n_columns_downloaded += r->n_columns_downloaded;
+            st->n_columns_downloaded_late += r->n_columns_downloaded_late;
         }
     }
     hs_sr_result* R = concat_sr_parts(p, parts, st);

@@ -190,10 +190,22 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
     for (int64_t i = g0; i < g1; ++i) col_off[(size_t)(i - g0) + 1] = col_off[(size_t)(i - g0)] + sel.sel_depth[(size_t)i];
     std::vector<int64_t> contig_sel_off((size_t)C + 1, 0);
     for (int c = 0; c <= C; ++c) contig_sel_off[(size_t)c] = sel.contig_sel_off[(size_t)(c0 + c)] - g0;
+    const hs_coltop* col_top = nullptr;
+    if (int rc = dev.gather(sel_contig, sel_pos, col_off, &col_top, &k_ms[2])) return rc;
+    // only the columns the host walks come back: the rest stays on the device for K4 (and for the late fetch below)
+    const size_t n_sel_range = sel_pos.size();
+    static const bool fetch_all = std::getenv("HS_FETCH_ALL_COLUMNS") != nullptr;   // diagnostic: download every extracted column
+    std::vector<int32_t> need_cols;
+    std::vector<int64_t> host_off(n_sel_range + 1, 0);       // offsets of every column in the packed download (empty if not fetched)
+    std::vector<int64_t> need_off(1, 0);
+    for (size_t i = 0; i < n_sel_range; ++i) {
+        int64_t n = 0;
+        if (fetch_all || cv_column_needed_on_host(col_top[i])) { need_cols.push_back((int32_t)i); n = col_off[i + 1] - col_off[i]; need_off.push_back(need_off.back() + n); }
+        host_off[i + 1] = host_off[i] + n;
+    }
     const int32_t* col_idx = nullptr;
     const uint8_t* col_code = nullptr;
-    const hs_coltop* col_top = nullptr;
-    if (int rc = dev.gather(sel_contig, sel_pos, col_off, &col_idx, &col_code, &col_top, &k_ms[2])) return rc;
+    if (int rc = dev.fetch_columns(need_cols, need_off, 0, &col_idx, &col_code)) return rc;
     const double t_dev_done = now_ms();
     Laps laps("cv glue");
 
@@ -206,9 +218,9 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         const int64_t s0 = contig_sel_off[(size_t)c], s1 = contig_sel_off[(size_t)c + 1];
         cs.pos.assign(sel_pos.begin() + s0, sel_pos.begin() + s1);
         cs.off.resize((size_t)(s1 - s0) + 1);
-        for (int64_t i = s0; i <= s1; ++i) cs.off[(size_t)(i - s0)] = col_off[(size_t)i] - col_off[(size_t)s0];
-        cs.idx = col_idx + col_off[(size_t)s0];
-        cs.code = col_code + col_off[(size_t)s0];
+        for (int64_t i = s0; i <= s1; ++i) cs.off[(size_t)(i - s0)] = host_off[(size_t)i] - host_off[(size_t)s0];
+        cs.idx = col_idx + host_off[(size_t)s0];
+        cs.code = col_code + host_off[(size_t)s0];
         cs.top = col_top + s0;
         const size_t n = cs.pos.size();
         cs.k0.resize(n); cs.k1.resize(n); cs.c0.resize(n); cs.c1.resize(n); cs.c2.resize(n);
@@ -274,10 +286,34 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         md[(size_t)c] = res[(size_t)c].mean_distance; dp[(size_t)c] = res[(size_t)c].depth;
         if (res[(size_t)c].mean_distance > 0) { total_error += res[(size_t)c].mean_distance; n_err_contigs++; }   // call_variants.cpp:1312-1315
         int64_t ent = 0;
-        for (int ci : res[(size_t)c].snp_col) ent += sets[(size_t)c].off[(size_t)ci + 1] - sets[(size_t)c].off[(size_t)ci];
+        const int64_t s0 = contig_sel_off[(size_t)c];
+        for (int ci : res[(size_t)c].snp_col) ent += col_off[(size_t)(s0 + ci) + 1] - col_off[(size_t)(s0 + ci)];
         snp_off[(size_t)c + 1] = snp_off[(size_t)c] + (int64_t)res[(size_t)c].snp_col.size();
         ent_off[(size_t)c + 1] = ent_off[(size_t)c] + ent;
     }
+    // output columns that were not downloaded above (rescued by loop D without having been candidates): second, small fetch
+    std::vector<int32_t> late_cols;
+    std::vector<int64_t> late_off(1, 0);
+    for (int c = 0; c < C; ++c) {
+        const int64_t s0 = contig_sel_off[(size_t)c];
+        for (int ci : res[(size_t)c].snp_col) {
+            const size_t g = (size_t)(s0 + ci);
+            if (host_off[g + 1] == host_off[g]) { late_cols.push_back((int32_t)g); late_off.push_back(late_off.back() + col_off[g + 1] - col_off[g]); }
+        }
+    }
+    const int32_t* late_idx = nullptr;
+    const uint8_t* late_code = nullptr;
+    if (!late_cols.empty()) { if (int rc = dev.fetch_columns(late_cols, late_off, 1, &late_idx, &late_code)) return rc; }
+    std::vector<int64_t> late_first((size_t)C + 1, 0);       // first late column of each contig (late_cols is contig-major)
+    {
+        size_t k = 0;
+        for (int c = 0; c < C; ++c) {
+            late_first[(size_t)c] = (int64_t)k;
+            while (k < late_cols.size() && late_cols[k] < contig_sel_off[(size_t)c + 1]) ++k;
+        }
+        late_first[(size_t)C] = (int64_t)k;
+    }
+    laps.lap("late fetch");
     const int64_t S = snp_off[(size_t)C], E = ent_off[(size_t)C];
     R->snp_pos = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t));
     R->snp_ref = (uint8_t*)std::malloc(std::max<int64_t>(1, S));
@@ -288,15 +324,26 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
     R->col_idx = (int32_t*)std::malloc(std::max<int64_t>(1, E) * sizeof(int32_t));
     R->col_code = (uint8_t*)std::malloc(std::max<int64_t>(1, E));
     R->col_off[0] = 0;
+    R->n_columns_extracted = (int64_t)n_sel_range;
+    R->n_columns_downloaded = (int64_t)need_cols.size();
+    R->n_columns_downloaded_late = (int64_t)late_cols.size();
     parallel_for(C, n_threads, [&](int c) {
         const ColumnSet& cs = sets[(size_t)c];
         int64_t s = snp_off[(size_t)c], e = ent_off[(size_t)c];
+        size_t late = (size_t)late_first[(size_t)c];
         for (int ci : res[(size_t)c].snp_col) {
-            const int64_t n = cs.off[(size_t)ci + 1] - cs.off[(size_t)ci];
+            int64_t n = cs.off[(size_t)ci + 1] - cs.off[(size_t)ci];
             R->snp_pos[s] = cs.pos[(size_t)ci]; R->snp_ref[s] = cs.k0[(size_t)ci]; R->snp_alt[s] = cs.k1[(size_t)ci];
             R->snp_n_ref[s] = cs.c0[(size_t)ci]; R->snp_n_alt[s] = cs.c1[(size_t)ci];
-            std::memcpy(R->col_idx + e, cs.idx + cs.off[(size_t)ci], (size_t)n * sizeof(int32_t));
-            std::memcpy(R->col_code + e, cs.code + cs.off[(size_t)ci], (size_t)n);
+            if (n > 0) {
+                std::memcpy(R->col_idx + e, cs.idx + cs.off[(size_t)ci], (size_t)n * sizeof(int32_t));
+                std::memcpy(R->col_code + e, cs.code + cs.off[(size_t)ci], (size_t)n);
+            } else {
+                n = late_off[late + 1] - late_off[late];
+                std::memcpy(R->col_idx + e, late_idx + late_off[late], (size_t)n * sizeof(int32_t));
+                std::memcpy(R->col_code + e, late_code + late_off[late], (size_t)n);
+                late++;
+            }
             e += n; s++;
             R->col_off[s] = e;
         }
@@ -309,8 +356,9 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
     R->t_device_ms = t_dev_done - t_start;
     R->t_host_ms = now_ms() - t_dev_done;
     if (std::getenv("HS_TIMING"))
-        std::fprintf(stderr, "[hs timing] cv range [%d,%d): gather %.2f ms, host glue %.2f ms (parallel part %.2f)\n",
-                     c0, c1, t_dev_done - t_start, R->t_host_ms, t_glue_done - t_dev_done);
+        std::fprintf(stderr, "[hs timing] cv range [%d,%d): gather %.2f ms, host glue %.2f ms (parallel part %.2f); columns: %lld extracted, %lld downloaded, %lld late\n",
+                     c0, c1, t_dev_done - t_start, R->t_host_ms, t_glue_done - t_dev_done, (long long)R->n_columns_extracted,
+                     (long long)R->n_columns_downloaded, (long long)R->n_columns_downloaded_late);
     *out = R;
     return HS_OK;
 }

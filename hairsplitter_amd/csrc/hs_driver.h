@@ -37,12 +37,15 @@ struct CvDeviceOps {
     // k_ms[3] = cigar scan alone (k_ms[0] then is the pileup kernel alone)
     virtual int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, std::vector<int64_t>& sel_gpos,
                                   std::vector<int32_t>& sel_depth, float k_ms[4]) = 0;
-    // K3: columns of the selected positions, and K3b: their top-3 (tie = 1: the host must resolve the column in the
-    // reference's tie order). The output arrays are owned by the implementation and stay valid until the next gather
-    // call or its destruction
+    // K3: columns of the selected positions (they stay on the device for K4 and fetch_columns), and K3b: their top-3
+    // (tie = 1: the host must resolve the column in the reference's tie order). `top` is owned by the implementation and
+    // stays valid until the next gather call or its destruction
     virtual int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos,
-                       const std::vector<int64_t>& col_off, const int32_t** col_idx, const uint8_t** col_code,
-                       const hs_coltop** top, float* k_ms) = 0;
+                       const std::vector<int64_t>& col_off, const hs_coltop** top, float* k_ms) = 0;
+    // K3c: the listed columns of the last gather() packed back to back on the host: column cols[k] at
+    // [packed_off[k], packed_off[k+1]). Two result slots (0, 1) that stay valid until the next gather / fetch of that slot
+    virtual int fetch_columns(const std::vector<int32_t>& cols, const std::vector<int64_t>& packed_off, int slot,
+                              const int32_t** col_idx, const uint8_t** col_code) = 0;
     // K4: loops C and D of keep_only_robust_variants on the columns of the last gather(); keep[i] for column i
     virtual int column_partition_test(const CvPartitionTest& t, std::vector<uint8_t>& keep, float* k_ms) = 0;
 };

@@ -18,8 +18,8 @@ void set_error(const std::string& msg);
 // Columns of the "interesting" positions of one contig (second-most frequent code seen >= 4 times), CSR.
 struct ColumnSet {
     std::vector<int32_t> pos;        // ascending
-    std::vector<int64_t> off;        // [n+1]
-    const int32_t* idx = nullptr;    // read indices (ascending inside a column), base pointer of the batch
+    std::vector<int64_t> off;        // [n+1] into idx / code; only the columns cv_column_needed_on_host() flags carry entries
+    const int32_t* idx = nullptr;    // read indices (ascending inside a column)
     const uint8_t* code = nullptr;
     const hs_coltop* top = nullptr;  // device top-3 of every column (K3b); tie = 1 -> resolved here in the reference's order
     // exact top-3 of call_variants.cpp:497-507 (reference tie order), filled by resolve_columns()
@@ -35,6 +35,9 @@ struct ContigCvResult {
     int n_candidates = 0, n_automatic = 0, n_partitions = 0, n_final_partitions = 0, n_filtered = 0;
 };
 
+// true if the host walks the entries of this column: its top-3 needs the reference's tie order, or it can become a
+// candidate SNP (the position-independent part of call_variants.cpp:525-536 with the smaller of the two read minima)
+bool cv_column_needed_on_host(const hs_coltop& t);
 void resolve_columns(ColumnSet& cs, int first, int last);   // columns [first, last); the k/c arrays must be sized
 struct CvContigState;   // per-contig state between the phases of the stage-3 glue (hs_host_cv.cpp)
 CvContigState* cv_state_new();

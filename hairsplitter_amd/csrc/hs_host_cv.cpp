@@ -438,6 +438,12 @@ static inline bool central_base_test(int k0, int k1) {
     return k0 % 5 != k1 % 5 && ((k1 - '!') % 5 != 4 || (k1 / 5 % 5 != k0 % 5 && k1 / 25 % 5 != k0 % 5));
 }
 
+bool cv_column_needed_on_host(const hs_coltop& t) {
+    if (t.tie) return true;                                  // exact_top3() reads the column
+    // min_reads is 3 or 5 (:463-466): every candidate of either setting passes this
+    return t.c1 > 3 && t.c1 > t.c2 * 5 && central_base_test(t.k0, t.k1);
+}
+
 // Stage-3 glue in three phases so that the embarrassingly parallel part (loops C and D: one independent decision per
 // extracted column) can be spread over all worker threads instead of one thread per contig.
 struct CvContigState {

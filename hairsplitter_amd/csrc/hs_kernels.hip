@@ -1254,6 +1254,21 @@ __global__ __launch_bounds__(256) void k_column_top3(const int64_t* __restrict__
     }
 }
 
+// K3c: copies the listed columns of the extracted CSR back to back (one wavefront per column), so that only the columns
+// the host really walks (candidate SNPs, columns whose top-3 needs the reference's tie order, rescued columns) cross PCIe.
+__global__ __launch_bounds__(256) void k_pack_columns(const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx,
+                                                      const uint8_t* __restrict__ col_code, const int32_t* __restrict__ ids,
+                                                      const int64_t* __restrict__ packed_off, int n_ids, int32_t* __restrict__ out_idx,
+                                                      uint8_t* __restrict__ out_code) {
+    const int lane = lane_id();
+    const int k = (int)blockIdx.x * 4 + wave_id();
+    if (k >= n_ids) return;                      // wave-uniform
+    const int col = ids[k];
+    const int64_t src = col_off[col], dst = packed_off[k];
+    const int n = (int)(packed_off[k + 1] - dst);
+    for (int j = lane; j < n; j += 64) { out_idx[dst + j] = col_idx[src + j]; out_code[dst + j] = col_code[src + j]; }
+}
+
 // small utility: apply host-resolved "swap top-2" decisions to the column statistics
 __global__ void k_swap_top2(hs_colstat_dev* __restrict__ stats, const int64_t* __restrict__ gpos, int n) {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);

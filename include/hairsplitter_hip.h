@@ -150,6 +150,13 @@ typedef struct hs_coltop {
 } hs_coltop;
 int hs_column_top3(const int64_t* d_col_off, const uint8_t* d_col_code, int32_t n_cols, hs_coltop* d_out, void* stream);
 
+/* K3c -- packs the listed columns (d_ids[k] = column index in the CSR of hs_gather_columns, any order) back to back:
+ * column d_ids[k] goes to [d_packed_off[k], d_packed_off[k+1]) of d_out_idx / d_out_code; the caller builds d_packed_off
+ * from the column depths. Only the columns the host walks (candidate SNPs of call_variants.cpp:525-536, columns whose
+ * top-3 depends on the reference's tie order, the output SNP columns) then need to be downloaded. */
+int hs_pack_columns(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code, const int32_t* d_ids,
+                    const int64_t* d_packed_off, int32_t n_ids, int32_t* d_out_idx, uint8_t* d_out_code, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K4 -- SNP column x partition correlation.  Replaces distance(Partition&, Column&) + computeChiSquare
  * (call_variants.cpp:778-967, :1135-1163) as used by loops C and D of keep_only_robust_variants (:721-764).
@@ -259,6 +266,9 @@ typedef struct hs_cv_result {
     double t_host_ms;          /* wall time of the host glue */
     float t_kernel_ms[4];      /* hipEvent time of k_pileup, k_column_stats, k_gather_columns, k_cigar_scan */
     float t_kernel_k4_ms;      /* hipEvent time of k_column_partition_test */
+    int64_t n_columns_extracted;        /* K3: columns of the selected positions (they stay on the device) */
+    int64_t n_columns_downloaded;       /* of those, walked by the host (candidate SNPs, tie-order columns) */
+    int64_t n_columns_downloaded_late;  /* output SNPs rescued by loop D that had not been downloaded before */
 } hs_cv_result;
 
 int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out);
@@ -342,6 +352,7 @@ typedef struct hs_pipeline_stats {
     float t_kernel_k4_ms;
     float t_kernel_sr_ms[4];            /* k_simdiff and the three k_chinese_whispers waves */
     float t_kernel_graph_ms;
+    int64_t n_columns_extracted, n_columns_downloaded, n_columns_downloaded_late;   /* see hs_cv_result */
 } hs_pipeline_stats;
 int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out);
 int hs_pipeline_select(hs_pipeline* p, float* mean_distance /* [C] out */, hs_pipeline_stats* stats);

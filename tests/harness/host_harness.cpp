@@ -5,6 +5,7 @@
 //   host_harness call_variants  <11 positional args of HS_call_variants>
 //   host_harness separate_reads <9 positional args of HS_separate_reads>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -77,18 +78,47 @@ struct OracleCvOps : hs::CvDeviceOps {
         return 0;
     }
     int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
-               const int32_t** col_idx_out, const uint8_t** col_code_out, const hs_coltop** top_out, float* k_ms) override {
+               const hs_coltop** top_out, float* k_ms) override {
         *k_ms = 0;
-        // every column is handed to the host's exact (reference order) resolution: the device's own top-3 is covered by the GPU tests
+        // HS_HARNESS_ALL_TIES: every column is handed to the host's exact (reference order) resolution; otherwise the
+        // top-3 is reported the way K3b does (tie = 1 only where the order of equal counts matters), which exercises the
+        // partial download and the late fetch of the stage driver
         tops.assign(sel_pos.size(), hs_coltop{0, 0, 0, 0, 0, 1, 0});
         *top_out = tops.data();
+        if (!std::getenv("HS_HARNESS_ALL_TIES")) {
+            for (size_t i = 0; i < sel_pos.size(); ++i) {
+                const hso::Column& col = cols[(size_t)sel_contig[i]][(size_t)sel_pos[i]];
+                int cnt[256] = {0};
+                bool odd = false;
+                for (unsigned char ch : col.content) { if (ch >= 33 && ch < 158) cnt[ch]++; else odd = true; }
+                std::vector<std::pair<int, int>> v;   // (-count, code)
+                for (int k = 33; k < 158; ++k) v.push_back(std::make_pair(-cnt[k], k));
+                std::sort(v.begin(), v.end());
+                hs_coltop t;
+                t.c0 = -v[0].first; t.c1 = -v[1].first; t.c2 = -v[2].first;
+                t.k0 = (uint8_t)v[0].second; t.k1 = (uint8_t)v[1].second;
+                t.tie = (odd || t.c0 == t.c1 || t.c1 == t.c2 || t.c1 == 0) ? 1 : 0; t.pad = 0;
+                tops[i] = t;
+            }
+        }
         last_sel_pos = sel_pos;
+        last_col_off = col_off;
         col_idx.assign((size_t)col_off.back(), 0); col_code.assign((size_t)col_off.back(), 0);
-        *col_idx_out = col_idx.data(); *col_code_out = col_code.data();
         for (size_t i = 0; i < sel_pos.size(); ++i) {
             const hso::Column& col = cols[(size_t)sel_contig[i]][(size_t)sel_pos[i]];
             for (size_t k = 0; k < col.content.size(); ++k) { col_idx[(size_t)col_off[i] + k] = (int32_t)col.readIdxs[k]; col_code[(size_t)col_off[i] + k] = col.content[k]; }
         }
+        return 0;
+    }
+    int fetch_columns(const std::vector<int32_t>& ids, const std::vector<int64_t>& packed_off, int slot, const int32_t** idx_out,
+                      const uint8_t** code_out) override {
+        std::vector<int32_t>& pi = packed_idx[slot]; std::vector<uint8_t>& pc = packed_code[slot];
+        pi.assign((size_t)packed_off.back() + 1, 0); pc.assign((size_t)packed_off.back() + 1, 0);
+        for (size_t k = 0; k < ids.size(); ++k) {
+            const int64_t src = last_col_off[(size_t)ids[k]], n = packed_off[k + 1] - packed_off[k];
+            for (int64_t j = 0; j < n; ++j) { pi[(size_t)(packed_off[k] + j)] = col_idx[(size_t)(src + j)]; pc[(size_t)(packed_off[k] + j)] = col_code[(size_t)(src + j)]; }
+        }
+        *idx_out = pi.data(); *code_out = pc.data();
         return 0;
     }
     // loops C and D of keep_only_robust_variants through the oracle's distance()/computeChiSquare()
@@ -143,6 +173,9 @@ struct OracleCvOps : hs::CvDeviceOps {
         return 0;
     }
     std::vector<int32_t> last_sel_pos;
+    std::vector<int64_t> last_col_off;
+    std::vector<int32_t> packed_idx[2];
+    std::vector<uint8_t> packed_code[2];
     std::vector<hs_coltop> tops;
 };
 

@@ -35,6 +35,19 @@ def test_host_glue_matches_reference_goldens(built, case):
         assert gu.compare(td, outs) == []
 
 
+@pytest.mark.parametrize("case", ["dip20k", "penta30k", "edge_ops"])
+def test_host_glue_with_every_column_resolved_on_host(built, case):
+    """Same, with the harness reporting every column as a tie: the exact (reference order) top-3 then runs on all
+    columns instead of only where K3b asks for it, and everything is downloaded up front (no late fetch)."""
+    if case not in gu.case_names():
+        pytest.skip("golden case not present")
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack(case, td)
+        env = dict(os.environ, HS_HARNESS_ALL_TIES="1")
+        outs = gu.run_stage_pair([built["harness"], "call_variants"], [built["harness"], "separate_reads"], td, meta, env=env)
+        assert gu.compare(td, outs) == []
+
+
 def test_robin_hood_order_vectors(built):
     vec = json.load(open(os.path.join(gu.GOLD, "robin_hood_order.json")))
     for v in vec:

@@ -59,6 +59,8 @@ def test_inmemory_pipeline_equals_oracle(built):
     b = api.CvBatch(flat)
     cv = b.run(0.33, 2)
     b.close()
+    # only the columns the host walks cross PCIe: candidates and tie-order columns up front, rescued SNPs afterwards
+    assert 0 < cv["n_columns_downloaded"] < cv["n_columns_extracted"] and cv["n_columns_downloaded_late"] > 0
     e = float("%g" % cv["error_rate"])
     sr = api.separate_reads(cv, flat, min(e, 0.15), rarest_strain_abundance=0.01, n_threads=2)
     with tempfile.TemporaryDirectory() as td:

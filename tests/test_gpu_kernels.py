@@ -152,6 +152,27 @@ def test_column_top3_of_extracted_columns(batch):
     assert n_checked > 0
 
 
+def test_pack_columns_copies_the_listed_columns(batch):
+    """K3c: any subset of the extracted columns, in any order (also none, also all), lands back to back and intact"""
+    from hairsplitter_amd import api
+    flat, t = batch
+    pile, _ = api.pileup(t, flat)
+    _, sel_g, sel_d = api.column_stats(t, flat, pile, min_second=2)
+    order = np.argsort(sel_g)
+    sel_g = sel_g[order]; sel_d = sel_d[order]
+    ctg = np.searchsorted(flat.contig_off, sel_g, side="right") - 1
+    pos = sel_g - flat.contig_off[ctg]
+    col_off, idx, code = api.gather_columns(t, flat, pile, ctg, pos, sel_d)
+    n = len(col_off) - 1
+    rng = np.random.default_rng(5)
+    for ids in (np.arange(n), np.zeros(0, np.int64), rng.permutation(n)[: max(1, n // 3)], np.array([n - 1, 0, n - 1])):
+        off, pidx, pcode = api.pack_columns(col_off, idx, code, ids)
+        assert off[-1] == sum(int(col_off[i + 1] - col_off[i]) for i in ids)
+        for k, i in enumerate(ids):
+            assert np.array_equal(pidx[off[k]:off[k + 1]], idx[col_off[i]:col_off[i + 1]])
+            assert np.array_equal(pcode[off[k]:off[k + 1]], code[col_off[i]:col_off[i + 1]])
+
+
 def test_stage3_result_equals_oracle_pipeline(batch, built):
     """hs_cv_run on the resident batch: SNP positions, ref/alt codes and columns equal the oracle's .col."""
     import subprocess, tempfile
