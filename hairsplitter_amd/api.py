@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_ROOT, "lib", "libhairsplitter_hip.so")
 SYMBOLS = [
     "hs_version", "hs_last_error", "hs_device_count", "hs_warmup", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
-    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
+    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
     "hs_separate_reads_main",
@@ -760,3 +760,26 @@ def edit_distance(queries: Sequence[np.ndarray], targets: Sequence[np.ndarray], 
     _check(load().hs_edit_distance(_p(d_q), _p(d_qo), _p(d_t), _p(d_to), C.c_int32(n), C.c_int32(m), _p(dist), _p(end), C.c_void_p(0)))
     torch.cuda.synchronize()
     return dist.cpu().numpy(), end.cpu().numpy()
+
+
+# ---- next stage: the .gro consumer (host code; needs no device) -----------------------------------------
+def gaf_from_files(gfa: str, reads: str, sam: str, gro: str, out_gaf: str, amplicon: bool = False, n_threads: int = 1) -> None:
+    """parse_split_file + merge_intervals + output_GAF of the reference's stage 5 (create_new_contigs.cpp:1582-1590)."""
+    _check(load().hs_gaf_from_files(gfa.encode(), reads.encode(), sam.encode(), gro.encode(), C.c_int32(1 if amplicon else 0),
+                                    out_gaf.encode(), C.c_int32(n_threads)))
+
+
+def gaf_from_labels(gfa: str, reads: str, sam: str, sr: Dict, out_gaf: str, contig_has_snps=None, amplicon: bool = False,
+                    n_threads: int = 1) -> None:
+    """Same, from a stage-4 result in memory (`sr` as returned by separate_reads / run_pipeline: win_off, win_start, win_end,
+    label_off, labels) instead of the .gro text; contig_has_snps[c] = False for contigs the .gro writer would skip (default:
+    the contigs without windows)."""
+    win_off = _np(sr["win_off"], np.int64); win_start = _np(sr["win_start"], np.int32); win_end = _np(sr["win_end"], np.int32)
+    label_off = _np(sr["label_off"], np.int64); labels = _np(sr["labels"], np.int32)
+    has = None if contig_has_snps is None else _np(np.asarray(contig_has_snps).astype(np.uint8), np.uint8)
+
+    def ptr(a):
+        return a.ctypes.data_as(C.c_void_p)
+    _check(load().hs_gaf_from_labels(gfa.encode(), reads.encode(), sam.encode(), C.c_int32(1 if amplicon else 0), C.c_int32(len(win_off) - 1),
+                                     ptr(win_off), ptr(win_start), ptr(win_end), ptr(label_off), ptr(labels), None if has is None else ptr(has),
+                                     out_gaf.encode(), C.c_int32(n_threads)))

@@ -100,6 +100,12 @@ struct CvFileInput {
 };
 int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::string& sam, bool amplicon,
                    CvFileInput& in, int n_threads = 1);
+// the .gro consumer of the next stage (hs_gaf.cpp)
+int gaf_from_files(const std::string& gfa, const std::string& reads, const std::string& sam, const std::string& gro, bool amplicon,
+                   const std::string& out_gaf, int n_threads);
+int gaf_from_labels(const std::string& gfa, const CvFileInput& in, int n_contigs, const int64_t* win_off, const int32_t* win_start,
+                    const int32_t* win_end, const int64_t* label_off, const int32_t* labels, const uint8_t* contig_has_snps,
+                    const std::string& out_gaf);
 
 // the calling thread's persistent worker pool (hs_driver.cpp)
 void hs_parallel_for(int n, int n_threads, const std::function<void(int)>& f);

@@ -183,8 +183,9 @@ def cigar_string(cigar: np.ndarray) -> str:
 
 
 def write_files(contigs: Sequence[ContigData], outdir: str, prefix: str = "",
-                sam_extra: Optional[List[str]] = None) -> dict:
-    """Writes assembly.gfa / reads.fasta / aln.sam. Returns the paths."""
+                sam_extra: Optional[List[str]] = None, gfa_extra: Optional[List[str]] = None) -> dict:
+    """Writes assembly.gfa / reads.fasta / aln.sam. Returns the paths. `sam_extra` / `gfa_extra`: verbatim lines appended
+    to the SAM / the GFA (e.g. supplementary records, 'L' lines)."""
     os.makedirs(outdir, exist_ok=True)
     gfa = os.path.join(outdir, prefix + "assembly.gfa")
     fa = os.path.join(outdir, prefix + "reads.fasta")
@@ -192,6 +193,8 @@ def write_files(contigs: Sequence[ContigData], outdir: str, prefix: str = "",
     with open(gfa, "w") as g:
         for c in contigs:
             g.write(f"S\t{c.name}\t{_ACGT[c.seq].tobytes().decode()}\n")
+        for line in (gfa_extra or []):
+            g.write(line.rstrip("\n") + "\n")
     with open(fa, "w") as f:
         for c in contigs:
             for nm, r in zip(c.read_names, c.reads):

@@ -368,6 +368,21 @@ int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_
 int hs_call_variants_main(int argc, char** argv);
 int hs_separate_reads_main(int argc, char** argv);
 
+/* ------------------------------------------------------------------------------------------------
+ * Next stage, consumer side of the .gro (host code, no device work): how every read threads through the contigs that the
+ * read separation implies, as a GAF.  Replaces parse_split_file + merge_intervals (+ stitch) + find_paths + output_GAF
+ * (create_new_contigs.cpp:41-175, :1427-1534, :833-903, :959-1112, :1128-1419) as called from its main (:1582-1590).
+ * hs_gaf_from_files reads the same four files the reference's HS_create_new_contigs reads; hs_gaf_from_labels takes the
+ * windows and labels of an hs_sr_result instead of the .gro text (contig_has_snps[c] = 0 for the contigs the .gro writer
+ * skips, separate_reads.cpp:1522-1524; NULL = the contigs without windows, which is what hs_sr_run leaves them with).  hs_gro_to_gaf_main: argv = <gfa> <reads> <sam> <gro> <amplicon> <out.gaf> [threads].
+ * ---------------------------------------------------------------------------------------------- */
+int hs_gaf_from_files(const char* gfa, const char* reads, const char* sam, const char* gro, int32_t amplicon, const char* out_gaf,
+                      int32_t n_threads);
+int hs_gaf_from_labels(const char* gfa, const char* reads, const char* sam, int32_t amplicon, int32_t n_contigs,
+                       const int64_t* win_off, const int32_t* win_start, const int32_t* win_end, const int64_t* label_off,
+                       const int32_t* labels, const uint8_t* contig_has_snps, const char* out_gaf, int32_t n_threads);
+int hs_gro_to_gaf_main(int argc, char** argv);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,8 @@ Run in the build container only (it needs oracle/_ref, i.e. /root/reference at b
 
 For every case it (1) generates build-owned synthetic inputs with hairsplitter_amd.synth (seeded),
 (2) runs the reference HS_call_variants (-t 1) and the seed-pinned HS_separate_reads exactly as
-hairsplitter.py:668-669,686-692,725-726 would, (3) stores inputs + reference outputs, gzip'ed, under
+hairsplitter.py:668-669,686-692,725-726 would, then the first half of the reference's HS_create_new_contigs on the
+resulting .gro (it writes the .gaf before it needs external tools), (3) stores inputs + reference outputs, gzip'ed, under
 tests/golden/<case>/. Nothing of the reference's source text is stored: fixtures are data only.
 
 Also written: robin_hood_order.json (iteration orders observed from the reference's vendored header),
@@ -55,14 +56,33 @@ def run_ref(workdir, files, low_memory=0, rsa="0.01", amplicon=0, ploidy_lines=N
             f.write("".join(ploidy_lines))
     subprocess.run([os.path.join(REF, "HS_separate_reads_seeded"), col, "1", earg, ploidy, str(low_memory), rsa,
                     str(amplicon), gro, "0"], check=True, stdout=subprocess.DEVNULL)
-    return {"col": col, "vcf": vcf, "err": err, "gro": gro, "error_rate_arg": earg,
+    gaf = run_ref_gaf(workdir, files, gro, amplicon, tag)
+    return {"col": col, "vcf": vcf, "err": err, "gro": gro, "gaf": gaf, "error_rate_arg": earg,
             "ploidy": ploidy if ploidy_lines is not None else None}
+
+
+def run_ref_gaf(workdir, files, gro, amplicon=0, tag=""):
+    """The .gro consumer of the reference's next stage (create_new_contigs.cpp:1582-1590: parse_split_file, merge_intervals,
+    output_GAF). HS_create_new_contigs writes the .gaf and only then shells out to minimap2 / racon / medaka, which do not
+    exist here: it is given paths that do not exist, fails there, and the .gaf it wrote before is what is kept."""
+    gaf = os.path.join(workdir, tag + "reads_haplo.gaf")
+    tmp = os.path.join(workdir, tag + "cnc_tmp")
+    os.makedirs(tmp, exist_ok=True)
+    if os.path.exists(gaf):
+        os.remove(gaf)
+    subprocess.run([os.path.join(REF, "HS_create_new_contigs"), files["gfa"], files["reads"], "0.05", gro, files["sam"], tmp + "/", "1",
+                    "ont", os.path.join(tmp, "out.gfa"), gaf, "racon", "0", str(amplicon), "/nonexistent/minimap2",
+                    "/nonexistent/racon", "/nonexistent/medaka", "/nonexistent/samtools", "/nonexistent/python", "0"],
+                   cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert os.path.exists(gaf), "the reference did not get as far as output_GAF"
+    shutil.rmtree(tmp, ignore_errors=True)
+    return gaf
 
 
 def store(case, files, outs, meta):
     d = os.path.join(GOLD, case)
     os.makedirs(d, exist_ok=True)
-    for k, p in list(files.items()) + [(k, v) for k, v in outs.items() if k in ("col", "vcf", "err", "gro", "ploidy") and v]:
+    for k, p in list(files.items()) + [(k, v) for k, v in outs.items() if k in ("col", "vcf", "err", "gro", "gaf", "ploidy") and v]:
         with open(p, "rb") as fi, gzip.GzipFile(os.path.join(d, os.path.basename(p) + ".gz"), "wb", mtime=0) as fo:
             shutil.copyfileobj(fi, fo)
     meta = dict(meta)
@@ -96,7 +116,61 @@ def cases():
                 {"ploidy_lines": ["ctg0\t2\n"]}))
     out.append(("dip12k_amplicon", [synth.make_contig(107, 0, 12_000, 2, 0.01, 60, "ont")], None, {"amplicon": 1}))
     out.append(("short_reads_w500", [synth.make_contig(108, 0, 15_000, 2, 0.01, 40, "ont")], None, {}))
+    out.append(linked_case())
     return out
+
+
+def linked_case():
+    """Five contigs joined by 'L' lines, with reads that continue from one contig onto another (supplementary records):
+    exercises the graph walk of the .gaf writer (find_paths: direct link, through a short contig, ambiguity, cycle, no
+    path), reverse-strand continuation, a contig without SNPs, a read with two records on the same contig."""
+    cs = [synth.make_contig(111, 0, 15_000, 2, 0.01, 40, "ont", name="ctgX"),
+          synth.make_contig(111, 1, 600, 1, 0.0, 0, "ont", name="ctgY_short"),
+          synth.make_contig(111, 2, 12_000, 2, 0.01, 40, "ont", name="ctgZ"),
+          synth.make_contig(111, 3, 9_000, 3, 0.015, 45, "ont", name="ctgW"),
+          synth.make_contig(111, 4, 6_000, 1, 0.0, 25, "ont", name="ctgV_noSNP")]
+    X, Y, Z, W, V = cs
+    links = ["L\tctgX\t+\tctgY_short\t+\t0M", "L\tctgY_short\t+\tctgZ\t+\t0M", "L\tctgX\t+\tctgW\t-\t0M",
+             "L\tctgZ\t+\tctgV_noSNP\t+\t0M", "L\tctgV_noSNP\t+\tctgX\t+\t0M", "L\tctgW\t+\tctgW\t+\t0M"]
+    extra = []
+
+    def supp(src, k, dst, pos, m_len, lead_h, trail_h, reverse=False):
+        """record k of contig `src` continues on `dst`: <lead_h>H <m_len>M <trail_h>H at 0-based `pos`"""
+        a = src.alns[k]
+        n = len(src.reads[a.read])
+        assert lead_h + m_len + trail_h == n
+        cig = (f"{lead_h}H" if lead_h else "") + f"{m_len}M" + (f"{trail_h}H" if trail_h else "")
+        extra.append(f"{src.read_names[a.read]}\t{2064 if reverse else 2048}\t{dst.name}\t{pos + 1}\t60\t{cig}\t*\t0\t0\t*\t*"
+                     f"\tNM:i:0\tLN:i:{n}")
+
+    def n_of(src, k):
+        return len(src.reads[src.alns[k].read])
+
+    fwd_x = [k for k, a in enumerate(X.alns) if a.strand][:14]
+    for k in fwd_x[0:5]:       # X -> (Y) -> Z
+        supp(X, k, Z, 0, 300, n_of(X, k) - 300, 0)
+    for k in fwd_x[5:8]:       # X -> Y
+        supp(X, k, Y, 0, 200, n_of(X, k) - 200, 0)
+    for k in fwd_x[8:11]:      # X -> W entered from its right end, read on the reverse strand of W
+        supp(X, k, W, len(W.seq) - 250, 250, 0, n_of(X, k) - 250, reverse=True)
+    k = fwd_x[11]              # X -> Z -> V, three records
+    supp(X, k, Z, 0, 500, n_of(X, k) - 900, 400)
+    supp(X, k, V, 0, 400, n_of(X, k) - 400, 0)
+    k = fwd_x[12]              # twice on X itself
+    supp(X, k, X, 100, 300, n_of(X, k) - 300, 0)
+    fwd_z = [k for k, a in enumerate(Z.alns) if a.strand][:4]
+    for k in fwd_z[0:2]:       # Z -> V (contig without SNPs)
+        supp(Z, k, V, 0, 400, n_of(Z, k) - 400, 0)
+    supp(Z, fwd_z[2], X, 0, 300, n_of(Z, fwd_z[2]) - 300, 0)   # Z -> X: only through V (6 kb: too long) -> not chained
+    fwd_v = [k for k, a in enumerate(V.alns) if a.strand][:2]
+    for k in fwd_v:            # V -> X closes the cycle
+        supp(V, k, X, 0, 300, n_of(V, k) - 300, 0)
+    rev_x = [k for k, a in enumerate(X.alns) if not a.strand][:2]
+    for k in rev_x:            # reverse-strand read of X whose beginning lies on Z: the chain runs Z -> Y -> X backwards
+        supp(X, k, Z, len(Z.seq) - 300, 300, 0, n_of(X, k) - 300, reverse=True)
+    fwd_w = [k for k, a in enumerate(W.alns) if a.strand][:1]
+    supp(W, fwd_w[0], Z, 50, 300, n_of(W, fwd_w[0]) - 300, 0)  # W -> Z: no link
+    return ("linked", cs, extra, {}, links)
 
 
 def gen_lib_vectors():
@@ -166,14 +240,16 @@ def main():
     if not args.only:
         gen_lib_vectors()
     from hairsplitter_amd import canon
-    for name, contigs, extra, kw in cases():
+    for case in cases():
+        name, contigs, extra, kw = case[:4]
+        gfa_extra = case[4] if len(case) > 4 else None
         if args.only and args.only != name:
             continue
         with tempfile.TemporaryDirectory() as td:
             if name == "short_reads_w500":
                 # force the 500-bp window branch (separate_reads.cpp:1489): cut every read alignment to <= 1.5 kb
                 contigs = [synth.make_contig(108, 0, 15_000, 2, 0.01, 40, "ont", read_len_override=(800, 1500))]
-            files = synth.write_files(contigs, td, sam_extra=extra)
+            files = synth.write_files(contigs, td, sam_extra=extra, gfa_extra=gfa_extra)
             outs = run_ref(td, files, **kw)
             meta = {"case": name, "kwargs": {k: v for k, v in kw.items()},
                     "aligned_bp": int(sum(c.aligned_bp for c in contigs)),

@@ -17,6 +17,33 @@ def test_dropin_binaries_match_reference_goldens(built, case):
         meta = gu.unpack(case, td)
         outs = gu.run_stage_pair([built["cv"]], [built["sr"]], td, meta)
         assert gu.compare(td, outs) == []
+        # ... and what the next stage makes of the .gro this build wrote: the .gaf the reference derives from its own .gro
+        gaf = os.path.join(td, "t_reads.gaf")
+        subprocess.run([built["gaf"], os.path.join(td, "assembly.gfa"), os.path.join(td, "reads.fasta"), os.path.join(td, "aln.sam"), outs["gro"],
+                        str(meta.get("kwargs", {}).get("amplicon", 0)), gaf], check=True, stdout=subprocess.DEVNULL)
+        assert open(gaf, "rb").read() == open(os.path.join(td, "reads_haplo.gaf"), "rb").read()
+
+
+def test_inmemory_labels_to_gaf(built):
+    """resident batch -> pipeline -> hs_gaf_from_labels, never touching .col / .gro text == drop-in executables -> hs_gro_to_gaf"""
+    from hairsplitter_amd import api, synth
+    contigs = [synth.make_contig(31, 0, 20_000, 3, 0.01, 40, "ont", name="a"), synth.make_contig(31, 1, 8_000, 1, 0.0, 30, "ont", name="b_noSNP"),
+               synth.make_contig(31, 2, 25_000, 2, 0.01, 35, "ont", name="c")]
+    with tempfile.TemporaryDirectory() as td:
+        f = synth.write_files(contigs, td)
+        col, vcf, err, gro = (os.path.join(td, x) for x in ("o.col", "o.vcf", "o.err", "o.gro"))
+        subprocess.run([built["cv"], f["gfa"], f["reads"], f["sam"], "2", td, err, "0", "0", col, vcf, "0.33"], check=True, stdout=subprocess.DEVNULL)
+        e = min(float(open(err).read()), 0.15)
+        subprocess.run([built["sr"], col, "2", str(e), os.path.join(td, "none"), "0", "0.01", "0", gro, "0"], check=True, stdout=subprocess.DEVNULL)
+        a, b_ = os.path.join(td, "files.gaf"), os.path.join(td, "mem.gaf")
+        api.gaf_from_files(f["gfa"], f["reads"], f["sam"], gro, a)
+        flat = api.FlatBatch(contigs)
+        b = api.CvBatch(flat)
+        cv, sr = b.run_pipeline(0.33, 2)
+        b.close()
+        assert int(sr["win_off"][2] - sr["win_off"][1]) == 0          # the contig without SNPs has no windows
+        api.gaf_from_labels(f["gfa"], f["reads"], f["sam"], sr, b_)
+        assert open(a, "rb").read() == open(b_, "rb").read() and os.path.getsize(a) > 0
 
 
 def test_native_library_is_what_ran(built):
