@@ -49,6 +49,22 @@ def main():
             out["reference"] = ref; out["reference"]["bp_per_s"] = bp / ref["total_s"]
             out["speedup"] = ref["total_s"] / ours["total_s"]
             out["col_identical"] = canon.digest(canon.split_blocks(col_a)) == canon.digest(canon.split_blocks(col_b))
+        # the consumer side of the .gro (next stage): hs_gro_to_gaf next to the reference's HS_create_new_contigs, which writes
+        # the .gaf and then stops at its first external tool (none exist here); its wall clock therefore also holds the set-up
+        # of modify_GFA for the first contig(s) -- an upper bound for parse + merge_intervals + output_GAF
+        gaf_a, gaf_b = os.path.join(td, "hip.gaf"), os.path.join(td, "ref.gaf")
+        t0 = time.perf_counter()
+        subprocess.run([p["gaf"], f["gfa"], f["reads"], f["sam"], gro_a, "0", gaf_a, str(threads)], check=True, stdout=subprocess.DEVNULL)
+        out["gro_to_gaf"] = {"hip_s": time.perf_counter() - t0, "lines": sum(1 for _ in open(gaf_a))}
+        if os.path.exists(p["ref_cnc"]):
+            tmp = os.path.join(td, "cnc_tmp")
+            os.makedirs(tmp, exist_ok=True)
+            t0 = time.perf_counter()
+            subprocess.run([p["ref_cnc"], f["gfa"], f["reads"], "0.05", gro_a, f["sam"], tmp + "/", str(threads), "ont", os.path.join(tmp, "o.gfa"),
+                            gaf_b, "racon", "0", "0", "/nonexistent/minimap2", "/nonexistent/racon", "/nonexistent/medaka",
+                            "/nonexistent/samtools", "/nonexistent/python", "0"], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            out["gro_to_gaf"]["reference_until_first_external_tool_s"] = time.perf_counter() - t0
+            out["gro_to_gaf"]["identical"] = os.path.exists(gaf_b) and open(gaf_a, "rb").read() == open(gaf_b, "rb").read()
     print(json.dumps(out))
 
 
