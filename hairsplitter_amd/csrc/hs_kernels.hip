@@ -693,6 +693,9 @@ __global__ __launch_bounds__(64) void k_cw_visit_lists(
     if (lane == 0) visit_n[g] = count;
 }
 
+#ifndef HS_CW_REG_LABELS
+#define HS_CW_REG_LABELS 8
+#endif
 __global__ __launch_bounds__(64) void k_chinese_whispers(
     const int32_t* __restrict__ adj_off, const int32_t* __restrict__ adj,
     const int64_t* __restrict__ graph_off_base, const int64_t* __restrict__ graph_adj_base,
@@ -750,23 +753,55 @@ __global__ __launch_bounds__(64) void k_chinese_whispers(
                 if (vis || msk[i_l]) { o0_l = aoff[i_l]; o1_l = aoff[i_l + 1]; }
             }
             unsigned long long act = __ballot(o1_l > o0_l);
+            // the neighbour ids of a node do not depend on the labels: they are loaded one visit ahead, so that the global
+            // load is off the dependent chain of a visit (LDS gather of the labels -> vote -> label update)
+            int nb_next = -1;
+            if (act) {
+                const int ln = __builtin_ctzll(act);
+                const int p0 = __builtin_amdgcn_readlane(o0_l, ln), p1 = __builtin_amdgcn_readlane(o1_l, ln);
+                nb_next = (p1 - p0 <= 64 && p0 + lane < p1) ? anb[p0 + lane] : -1;
+            }
             while (act) {
                 const int l = __builtin_ctzll(act);
                 act &= act - 1ull;
                 const int i = __builtin_amdgcn_readlane(i_l, l);
                 const int o0 = __builtin_amdgcn_readlane(o0_l, l), o1 = __builtin_amdgcn_readlane(o1_l, l);
+                const int nb = nb_next;
+                if (act) {
+                    const int ln = __builtin_ctzll(act);
+                    const int p0 = __builtin_amdgcn_readlane(o0_l, ln), p1 = __builtin_amdgcn_readlane(o1_l, ln);
+                    nb_next = (p1 - p0 <= 64 && p0 + lane < p1) ? anb[p0 + lane] : -1;
+                }
                 int best_cnt = 0, best_lab = -1;
                 if (o1 - o0 <= 64) {
-                    // the usual case: all neighbours in one step, their labels stay in registers for the three phases
-                    const int idx = o0 + lane;
-                    const int lb = idx < o1 ? lab[anb[idx]] : -1;
-                    if (lb >= 0) atomicAdd(&cnt[lb], 1);                       // votes
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    const int c = lb >= 0 ? cnt[lb] : 0;                       // totals
-                    best_cnt = wave_max_i32(c);
-                    best_lab = 0x7fffffff - wave_max_i32((lb >= 0 && c == best_cnt) ? 0x7fffffff - lb : 0);   // lowest label among the maxima
-                    if (lb >= 0) cnt[lb] = 0;                                  // reset the touched counters
+                    // the usual case: all neighbours in one step, one label per lane. The vote is taken in registers: one
+                    // ballot per distinct label (a handful once the seeding has grouped the reads); a node that sees more than
+                    // HS_CW_REG_LABELS distinct labels goes through the LDS counters instead
+                    const int lb = nb >= 0 ? lab[nb] : -1;
+                    unsigned long long rem = __ballot(lb >= 0);
+                    // key = count << 16 | (65535 - label): the largest key is the largest count, lowest label among equals
+                    // (labels are read indices: < 20 000, the limit the host enforces per contig)
+                    unsigned best_key = 0u;
+#pragma unroll
+                    for (int tries = 0; tries < HS_CW_REG_LABELS; ++tries) {
+                        if (!rem) break;
+                        const int v = __builtin_amdgcn_readlane(lb, __builtin_ctzll(rem));
+                        const unsigned long long m = __ballot(lb == v);
+                        const unsigned key = ((unsigned)__popcll(m) << 16) | (unsigned)(65535 - v);
+                        best_key = key > best_key ? key : best_key;
+                        rem &= ~m;
+                    }
+                    best_cnt = (int)(best_key >> 16);
+                    best_lab = best_cnt ? 65535 - (int)(best_key & 0xffffu) : -1;
+                    if (rem) {
+                        if (lb >= 0) atomicAdd(&cnt[lb], 1);                       // votes
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        const int c = lb >= 0 ? cnt[lb] : 0;                       // totals
+                        best_cnt = wave_max_i32(c);
+                        best_lab = 0x7fffffff - wave_max_i32((lb >= 0 && c == best_cnt) ? 0x7fffffff - lb : 0);
+                        if (lb >= 0) cnt[lb] = 0;                                  // reset the touched counters
+                    }
                 } else {
                     for (int o = o0; o < o1; o += 64) {
                         const int idx = o + lane;
