@@ -99,17 +99,38 @@ def cpu_baseline(n_contigs: int, seed: int):
                       + (f", -t {threads}; contig-level OpenMP only" if kind == "reference" else ", single thread")}
 
 
+def _make_contig(a):
+    from hairsplitter_amd import synth
+    return synth.make_contig(a[0], a[1], 100_000, 2, 0.01, 50, "ont")
+
+
+def make_contigs(seed, ids, workers):
+    """The synthetic C2-shaped contigs `ids` (deterministic per (seed, id)); forked workers when there are many"""
+    jobs = [(seed, i) for i in ids]
+    if workers <= 1 or len(jobs) < 16 or os.environ.get("HS_BENCH_SERIAL_SETUP"):
+        return [_make_contig(j) for j in jobs]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(_make_contig, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--contigs", type=int, default=64, help="C2-shaped contigs per GPU in one batch (64 ~ the per-GPU share of the 500-contig config on 8 GPUs)")
+    ap.add_argument("--contigs", type=int, default=256, help="C2-shaped contigs per GPU in one batch (256 ~ half of the 500-contig config; the step is a chain of short device calls and host sections per contig group, so small batches are latency-bound)")
     ap.add_argument("--groups", type=int, default=0, help="contig groups (host thread + HIP stream each) per GPU; 0 = min(8, host threads / 4)")
     ap.add_argument("--threads", type=int, default=0, help="host threads for the sequential glue (0 = all cores / ranks)")
     ap.add_argument("--cpu-contigs", type=int, default=8, help="size of the CPU-baseline sample (0 disables)")
     ap.add_argument("--seed", type=int, default=2)
     args = ap.parse_args()
+
+    # ---- this rank's shard: contigs [rank*B, (rank+1)*B) of the job (weak scaling). Generated first, on a few forked
+    # workers, while this process has not touched the GPU (or loaded torch) yet ----
+    rank_env, world_env = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    my_ids = list(range(rank_env * args.contigs, (rank_env + 1) * args.contigs))
+    contigs = make_contigs(args.seed, my_ids, max(1, min(8, effective_cores() // world_env)))
 
     import torch
     import torch.distributed as dist
@@ -139,10 +160,7 @@ def main():
     # box costs more than it buys (measured: 256 threads -> 15-60 ms steps, 64 threads -> 11.6 ms steps)
     n_threads = args.threads or max(1, min(64, (4 * effective_cores()) // world))
 
-    # ---- this rank's shard: contigs [rank*B, (rank+1)*B) of the job (weak scaling) ----
     B = args.contigs
-    my_ids = list(range(rank * B, (rank + 1) * B))
-    contigs = [synth.make_contig(args.seed, i, 100_000, 2, 0.01, 50, "ont") for i in my_ids]
     G = max(1, min(args.groups if args.groups > 0 else min(8, max(1, n_threads // 4)), B))
     batch = api.PipelineGroups(contigs, G)   # inputs now resident in HBM; the streaming kernels run once per step over all of them
     local_bp = batch.aligned_bp

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_ROOT, "lib", "libhairsplitter_hip.so")
 SYMBOLS = [
     "hs_version", "hs_last_error", "hs_device_count", "hs_warmup", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
-    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
+    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
     "hs_separate_reads_main",
@@ -616,6 +616,18 @@ def column_top3(col_off, col_code):
     raw = out[:n].cpu().numpy()
     cnt = raw[:, :12].copy().view(np.int32).reshape(n, 3)
     return cnt[:, 0], cnt[:, 1], cnt[:, 2], raw[:, 12], raw[:, 13], raw[:, 14]
+
+
+def exclusive_scan(values):
+    """n ints -> n + 1 offsets on the device (the scan behind the graph CSR and the selection list)"""
+    import torch
+    require_gpu()
+    v = _np(values, np.int32)
+    d_in = torch.from_numpy(v if v.size else np.zeros(1, np.int32)).to("cuda:0")
+    d_out = torch.full((len(v) + 1,), -1, dtype=torch.int64, device="cuda:0")
+    _check(load().hs_exclusive_scan_i32(_p(d_in), C.c_int32(len(v)), _p(d_out), C.c_void_p(0)))
+    torch.cuda.synchronize()
+    return d_out.cpu().numpy()
 
 
 def pack_columns(col_off, col_idx, col_code, ids):

@@ -316,10 +316,24 @@ int hs_pileup_plan(const int64_t* h_rec_cig_off, const uint32_t* h_cigar, int32_
 }
 void hs_free_host(void* p) { std::free(p); }
 
+// exclusive scan of n ints into n + 1 offsets (see hs_kernels_graph.hip); `scratch` must outlive the launches
+static int exclusive_scan_launch(const int32_t* d_in, int n, int64_t* d_out, DBuf& scratch, hipStream_t stream) {
+    const int n_tiles = (n + HS_SCAN_TILE - 1) / HS_SCAN_TILE;
+    if (n_tiles == 0) { HS_HIP(hipMemsetAsync(d_out, 0, sizeof(int64_t), stream)); return HS_OK; }
+    if (int rc = scratch.alloc((size_t)n_tiles * 16)) return rc;
+    long long* tile_sum = scratch.as<long long>();
+    long long* tile_off = tile_sum + n_tiles;
+    hipLaunchKernelGGL(hsdev::k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(256), 0, stream, d_in, n, tile_sum);
+    hipLaunchKernelGGL(hsdev::k_scan_tile_offsets, dim3(1), dim3(1024), 0, stream, tile_sum, n_tiles, tile_off, d_out + n);
+    hipLaunchKernelGGL(hsdev::k_scan_apply, dim3((unsigned)n_tiles), dim3(256), 0, stream, d_in, n, tile_off, d_out);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
 // K2's selection list: the kernels fill 256 scratch slots + one count per tile; scan + compact give the sorted list and its
 // length (see column_stats_tail in hs_kernels.hip)
 struct SelectionScratch {
-    DBuf tile_cnt, tile_base, gpos, depth;
+    DBuf tile_cnt, tile_base, gpos, depth, scan_scratch;
     int64_t n_tiles = 0;
     int prepare(int64_t total_len) {
         n_tiles = (total_len + 255) / 256;
@@ -330,7 +344,7 @@ struct SelectionScratch {
     }
     int finish(int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth, int32_t sel_cap, hipStream_t stream) {
         if (n_tiles > 0x7fffffff) { set_error("too many tiles"); return HS_EINVAL; }
-        hipLaunchKernelGGL(hsdev::k_exclusive_scan_i32, dim3(1), dim3(1024), 0, stream, tile_cnt.as<int32_t>(), (int)n_tiles, tile_base.as<int64_t>());
+        if (int rc = exclusive_scan_launch(tile_cnt.as<int32_t>(), (int)n_tiles, tile_base.as<int64_t>(), scan_scratch, stream)) return rc;
         hipLaunchKernelGGL(hsdev::k_selection_compact, dim3((unsigned)n_tiles), dim3(256), 0, stream, tile_cnt.as<int32_t>(), tile_base.as<int64_t>(),
                            gpos.as<int64_t>(), depth.as<int32_t>(), n_tiles, d_sel_count, d_sel_gpos, d_sel_depth, sel_cap);
         HS_HIP(hipGetLastError());
@@ -493,6 +507,14 @@ int hs_column_top3(const int64_t* d_col_off, const uint8_t* d_col_code, int32_t 
                        reinterpret_cast<hsdev::hs_coltop_dev*>(d_out));
     HS_HIP(hipGetLastError());
     return HS_OK;
+}
+
+int hs_exclusive_scan_i32(const int32_t* d_in, int32_t n, int64_t* d_out, void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n < 0) { set_error("hs_exclusive_scan_i32: negative length"); return HS_EINVAL; }
+    DBuf scratch;
+    if (int rc = exclusive_scan_launch(d_in, n, d_out, scratch, (hipStream_t)stream)) return rc;
+    return stream_wait((hipStream_t)stream);   // the scratch goes back to the pool with this scope
 }
 
 int hs_pack_columns(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code, const int32_t* d_ids,
@@ -1043,7 +1065,8 @@ static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const st
     if (int rc = d_no.alloc(((size_t)rows + 1) * 8)) return rc;
     hipLaunchKernelGGL(hsdev::k_read_graph_degrees, dim3((rows + 255) / 256), dim3(256), 0, stream, d_bits.as<unsigned long long>(), d_rw.as<int32_t>(),
                        d_mo.as<int64_t>(), d_bo.as<int64_t>(), rows, d_deg.as<int32_t>());
-    hipLaunchKernelGGL(hsdev::k_exclusive_scan_i32, dim3(1), dim3(1024), 0, stream, d_deg.as<int32_t>(), rows, d_no.as<int64_t>());
+    DBuf d_scan;
+    if (int rc = exclusive_scan_launch(d_deg.as<int32_t>(), rows, d_no.as<int64_t>(), d_scan, stream)) return rc;
     HS_HIP(hipGetLastError());
     if (int rc = d2h_pinned(res.nbr_off.data(), d_no.p, ((size_t)rows + 1) * 8, stream)) return rc;
     if (int rc_w = stream_wait(stream)) return rc_w;

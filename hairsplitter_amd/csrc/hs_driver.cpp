@@ -139,10 +139,22 @@ int cv_select(CvDeviceOps& dev, const CvMeta& b, CvSelection& sel) {
     // interesting positions: second count >= 4 (everything that can become a SNP, see hs_host_cv.cpp), ordered by position
     if (int rc = dev.pileup_and_select(sel.rec_stats, 4, sel_gpos, sel_depth, sel.k_ms)) return rc;
     const double t_k12_done = now_ms();
-    std::vector<size_t> order(sel_gpos.size());
-    if (std::is_sorted(sel_gpos.begin(), sel_gpos.end())) {   // the HIP implementation hands the list over sorted already
-        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    sel.contig_sel_off.assign((size_t)C + 1, 0);
+    if (std::is_sorted(sel_gpos.begin(), sel_gpos.end())) {
+        // the HIP implementation hands the list over sorted already: the contig boundaries by bisection, the three arrays
+        // filled per contig on the worker threads
+        sel.sel_contig.resize(sel_gpos.size()); sel.sel_pos.resize(sel_gpos.size());
+        sel.sel_depth.swap(sel_depth);
+        for (int c = 0; c <= C; ++c)
+            sel.contig_sel_off[(size_t)c] = (int64_t)(std::lower_bound(sel_gpos.begin(), sel_gpos.end(), b.contig_off[(size_t)c]) - sel_gpos.begin());
+        parallel_for(C, 8, [&](int c) {
+            const int64_t base = b.contig_off[(size_t)c];
+            for (int64_t i = sel.contig_sel_off[(size_t)c]; i < sel.contig_sel_off[(size_t)c + 1]; ++i) {
+                sel.sel_contig[(size_t)i] = c; sel.sel_pos[(size_t)i] = (int32_t)(sel_gpos[(size_t)i] - base);
+            }
+        });
     } else {   // bucket by 256-position tile, then order the few entries of each tile
+        std::vector<size_t> order(sel_gpos.size());
         const size_t n_tiles = (size_t)((b.total_len + 255) / 256);
         std::vector<uint32_t> start(n_tiles + 1, 0);
         for (int64_t g : sel_gpos) start[(size_t)(g >> 8) + 1]++;
@@ -152,10 +164,7 @@ int cv_select(CvDeviceOps& dev, const CvMeta& b, CvSelection& sel) {
         for (size_t t = 0; t < n_tiles; ++t)
             if (start[t + 1] - start[t] > 1)
                 std::sort(order.begin() + start[t], order.begin() + start[t + 1], [&](size_t x, size_t y) { return sel_gpos[x] < sel_gpos[y]; });
-    }
-    sel.sel_contig.resize(order.size()); sel.sel_pos.resize(order.size()); sel.sel_depth.resize(order.size());
-    sel.contig_sel_off.assign((size_t)C + 1, 0);
-    {
+        sel.sel_contig.resize(order.size()); sel.sel_pos.resize(order.size()); sel.sel_depth.resize(order.size());
         int c = 0;
         for (size_t i = 0; i < order.size(); ++i) {
             const int64_t g = sel_gpos[order[i]];

@@ -191,25 +191,63 @@ __global__ __launch_bounds__(256) void k_read_graph_degrees(const unsigned long 
     deg[row] = d;
 }
 
-// exclusive prefix sum of n ints by one workgroup (n is tens of thousands: rows of a batch); out has n + 1 entries
-__global__ __launch_bounds__(1024) void k_exclusive_scan_i32(const int32_t* __restrict__ in, int n, int64_t* __restrict__ out) {
+// exclusive prefix sum of n non-negative ints (degrees of graph rows, selection counts of tiles); out has n + 1 entries.
+// Three launches: per-tile sums (4096 ints per workgroup, coalesced), scan of the tile sums by one workgroup, and the scan
+// inside every tile on top of its offset. A tile sum fits 32 bits (4096 x at most 20 000); offsets are 64-bit.
+#define HS_SCAN_TILE 4096
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const int32_t* __restrict__ in, int n, long long* __restrict__ tile_sum) {
+    __shared__ int s_w[4];
+    const int t = (int)threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * HS_SCAN_TILE;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < HS_SCAN_TILE / 256; ++k) { const int64_t i = base + k * 256 + t; if (i < n) s += in[i]; }
+    s = wave_sum_i32(s);
+    if ((t & 63) == 0) s_w[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) tile_sum[blockIdx.x] = (long long)s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_tile_offsets(const long long* __restrict__ tile_sum, int n_tiles, long long* __restrict__ tile_off,
+                                                           int64_t* __restrict__ total_out) {
     __shared__ long long s_part[1024];
     const int t = (int)threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int b = t * per, e = (b + per) < n ? (b + per) : n;
-    long long s = 0;
-    for (int k = b; k < e; ++k) s += in[k];
-    s_part[t] = s;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        const long long v = t >= d ? s_part[t - d] : 0;
+    long long carry = 0;
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const long long v = base + t < n_tiles ? tile_sum[base + t] : 0;
+        s_part[t] = v;
         __syncthreads();
-        s_part[t] += v;
+        for (int d = 1; d < 1024; d <<= 1) {
+            const long long a = t >= d ? s_part[t - d] : 0;
+            __syncthreads();
+            s_part[t] += a;
+            __syncthreads();
+        }
+        if (base + t < n_tiles) tile_off[base + t] = carry + s_part[t] - v;
+        carry += s_part[1023];
         __syncthreads();
     }
-    long long run = t ? s_part[t - 1] : 0;
-    for (int k = b; k < e; ++k) { out[k] = run; run += in[k]; }
-    if (t == 1023) out[n] = s_part[1023];
+    if (t == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const int32_t* __restrict__ in, int n, const long long* __restrict__ tile_off,
+                                                    int64_t* __restrict__ out) {
+    __shared__ int s_w[2][4];
+    const int t = (int)threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t base = (int64_t)blockIdx.x * HS_SCAN_TILE;
+    long long run = tile_off[blockIdx.x];
+#pragma unroll 1
+    for (int k = 0; k < HS_SCAN_TILE / 256; ++k) {
+        const int64_t i = base + k * 256 + t;
+        const int v = i < n ? in[i] : 0;
+        const int incl = wave_scan_incl(v);
+        if (lane == 63) s_w[k & 1][wv] = incl;
+        __syncthreads();   // one barrier per chunk: the wave totals alternate between two slots
+        const int w0 = s_w[k & 1][0], w1 = s_w[k & 1][1], w2 = s_w[k & 1][2], w3 = s_w[k & 1][3];
+        const int before = (wv > 0 ? w0 : 0) + (wv > 1 ? w1 : 0) + (wv > 2 ? w2 : 0);
+        if (i < n) out[i] = run + before + incl - v;
+        run += (long long)w0 + w1 + w2 + w3;
+    }
 }
 
 // neighbour lists in ascending read id (the window's mask list is ascending)

@@ -150,6 +150,10 @@ typedef struct hs_coltop {
 } hs_coltop;
 int hs_column_top3(const int64_t* d_col_off, const uint8_t* d_col_code, int32_t n_cols, hs_coltop* d_out, void* stream);
 
+/* Exclusive prefix sum of n non-negative ints into n + 1 64-bit offsets (d_out[n] = total): the CSR offsets of the read
+ * graphs (K6) and of the selection list (K2) are built with it. Synchronous with respect to `stream`. */
+int hs_exclusive_scan_i32(const int32_t* d_in, int32_t n, int64_t* d_out, void* stream);
+
 /* K3c -- packs the listed columns (d_ids[k] = column index in the CSR of hs_gather_columns, any order) back to back:
  * column d_ids[k] goes to [d_packed_off[k], d_packed_off[k+1]) of d_out_idx / d_out_code; the caller builds d_packed_off
  * from the column depths. Only the columns the host walks (candidate SNPs of call_variants.cpp:525-536, columns whose

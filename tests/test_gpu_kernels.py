@@ -152,6 +152,20 @@ def test_column_top3_of_extracted_columns(batch):
     assert n_checked > 0
 
 
+@pytest.mark.parametrize("n", [0, 1, 63, 4095, 4096, 4097, 70_001, 1_000_000, 4_300_000])
+def test_exclusive_scan_sizes(n):
+    """one tile, tile boundaries, many tiles, more tiles than one pass of the tile-offset scan takes (> 1024 tiles)"""
+    from hairsplitter_amd import api
+    rng = np.random.default_rng(n)
+    v = rng.integers(0, 600, size=n, dtype=np.int32)
+    if n > 10:
+        v[rng.integers(0, n, size=n // 7)] = 0
+        v[3] = 20_000
+    exp = np.zeros(n + 1, np.int64)
+    np.cumsum(v, dtype=np.int64, out=exp[1:])
+    assert np.array_equal(api.exclusive_scan(v), exp)
+
+
 def test_pack_columns_copies_the_listed_columns(batch):
     """K3c: any subset of the extracted columns, in any order (also none, also all), lands back to back and intact"""
     from hairsplitter_amd import api

@@ -4,6 +4,7 @@
 # usage: tools/pmc.sh <tag> [bench args]
 tag=${1:-x}; shift
 cd /tmp && export TMPDIR=/tmp
+export HS_BENCH_SERIAL_SETUP=1   # no forked set-up workers under the profiler
 cd "$GRAFT_REPO_ROOT"
 groups=("FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES")
 i=0
