@@ -172,18 +172,22 @@ static Contingency column_vs_partition(const DensePartition& p, const int32_t* i
 struct ColumnBits {
     int words = 0, nslots = 0;
     uint8_t code_of[128];
+    uint8_t slot_of[256];         // code -> slot, 0xFF = none yet; reset for the used codes at the next build
     std::vector<uint64_t> bits;   // [nslots][words]
     std::vector<uint64_t> any;    // [words]
+    ColumnBits() { std::memset(slot_of, 0xFF, sizeof(slot_of)); }
     void build(const int32_t* idx, const uint8_t* code, int n, int n_reads) {
+        for (int k = 0; k < nslots; ++k) slot_of[code_of[k]] = 0xFF;
         words = (n_reads + 63) >> 6;
         nslots = 0;
         any.assign((size_t)words, 0ull);
         if (bits.size() < (size_t)8 * words) bits.resize((size_t)8 * words);
         for (int i = 0; i < n; ++i) {
-            int k = 0;
-            while (k < nslots && code_of[k] != code[i]) ++k;
-            if (k == nslots) {
+            int k = slot_of[code[i]];
+            if (k == 0xFF) {
                 if (nslots == 128) continue;   // cannot happen: 125 pileup codes
+                k = nslots;
+                slot_of[code[i]] = (uint8_t)k;
                 code_of[nslots++] = code[i];
                 if (bits.size() < (size_t)nslots * words) bits.resize((size_t)nslots * 2 * words);
                 std::fill(bits.begin() + (size_t)k * words, bits.begin() + (size_t)(k + 1) * words, 0ull);
@@ -204,20 +208,38 @@ static Contingency column_vs_partition_bits(const DensePartition& p, const Colum
     if (shared == 0) return r;
     r.comparable = true;
     r.most = ref;
-    // counts among the shared reads; first appearance among them = lowest shared read index (column entries are ascending)
-    uint8_t seen[128]; int cnt[128]; int first[128];
+    // counts among the shared reads
+    uint8_t seen[128]; int cnt[128]; int slot[128];
     int nseen = 0;
     for (int k = 0; k < cb.nslots; ++k) {
         const uint64_t* bk = cb.bits.data() + (size_t)k * W;
-        int c = 0, f = -1;
-        for (int w = 0; w < W; ++w) {
-            const uint64_t x = bk[w] & p.present[(size_t)w];
-            if (x) { if (f < 0) f = w * 64 + __builtin_ctzll(x); c += __builtin_popcountll(x); }
-        }
-        if (c) { seen[nseen] = cb.code_of[k]; cnt[nseen] = c; first[nseen] = f; nseen++; }
+        int c = 0;
+        for (int w = 0; w < W; ++w) c += __builtin_popcountll(bk[w] & p.present[(size_t)w]);
+        if (c) { seen[nseen] = cb.code_of[k]; cnt[nseen] = c; slot[nseen] = k; nseen++; }
     }
-    for (int i = 1; i < nseen; ++i)   // insertion sort by first shared appearance (a handful of codes)
-        for (int j = i; j > 0 && first[j] < first[j - 1]; --j) { std::swap(first[j], first[j - 1]); std::swap(seen[j], seen[j - 1]); std::swap(cnt[j], cnt[j - 1]); }
+    // second_from_seen() only looks at the order of `seen` when the best count is tied (the hash map is then filled in the
+    // order the codes first appear among the shared reads = lowest shared read index, column entries being ascending):
+    // that order is worked out only in that case
+    {
+        const bool ref_eligible = ref >= 128;
+        int best = -1, nbest = 0;
+        bool ref_seen = false;
+        for (int i = 0; i < nseen; ++i) {
+            if (seen[i] == ref) { ref_seen = true; if (!ref_eligible) continue; }
+            if (cnt[i] > best) { best = cnt[i]; nbest = 1; } else if (cnt[i] == best) nbest++;
+        }
+        if (ref_eligible && !ref_seen) { if (0 > best) { best = 0; nbest = 1; } else if (best == 0) nbest++; }
+        if (nbest > 1) {
+            int first[128];
+            for (int i = 0; i < nseen; ++i) {
+                const uint64_t* bk = cb.bits.data() + (size_t)slot[i] * W;
+                first[i] = -1;
+                for (int w = 0; w < W; ++w) { const uint64_t x = bk[w] & p.present[(size_t)w]; if (x) { first[i] = w * 64 + __builtin_ctzll(x); break; } }
+            }
+            for (int i = 1; i < nseen; ++i)   // insertion sort by first shared appearance (a handful of codes)
+                for (int j = i; j > 0 && first[j] < first[j - 1]; --j) { std::swap(first[j], first[j - 1]); std::swap(seen[j], seen[j - 1]); std::swap(cnt[j], cnt[j - 1]); }
+        }
+    }
     r.second = second_from_seen(seen, cnt, nseen, ref, true, true, ' ');
     const uint64_t* bm = nullptr; const uint64_t* bs = nullptr;
     for (int k = 0; k < cb.nslots; ++k) {
