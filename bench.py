@@ -68,6 +68,21 @@ def throttle_stats():
     return None
 
 
+def thread_cpu():
+    """{tid: (comm, utime + stime in seconds)} of this process's threads"""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    for t in os.listdir("/proc/self/task"):
+        try:
+            st = open(f"/proc/self/task/{t}/stat").read()
+            comm = st[st.index("(") + 1:st.rindex(")")]
+            f = st[st.rindex(")") + 2:].split()
+            out[int(t)] = (comm, (int(f[11]) + int(f[12])) / tick)
+        except Exception:
+            pass
+    return out
+
+
 def cpu_baseline(n_contigs: int, seed: int):
     """The compiled reference (oracle/_ref, built from /root/reference by oracle/Makefile) timed file-to-file on this
     box's host cores on a bounded sample of the same workload. Falls back to the oracle restatement ("port")."""
@@ -212,6 +227,7 @@ def main():
         py_ms[k] = 0.0
     plain = bool(os.environ.get("HS_BENCH_PLAIN"))
     thr0 = None if plain else throttle_stats()
+    tcpu0 = thread_cpu() if os.environ.get("HS_BENCH_THREADS") else None   # diagnostic: CPU time by thread over the timed steps
     t0 = time.perf_counter(); cpu0 = 0.0 if plain else time.process_time()
     k_cv = np.zeros(4); k_sr = np.zeros(4); t_dev = 0.0; t_host = 0.0; k4 = 0.0; k6 = 0.0
     last = None
@@ -232,6 +248,13 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3
+    if tcpu0 is not None:
+        tcpu1 = thread_cpu()
+        rows = sorted(((tcpu1[t][1] - tcpu0.get(t, (None, 0.0))[1], tcpu1[t][0], t) for t in tcpu1), reverse=True)
+        tot = sum(r[0] for r in rows)
+        sys.stderr.write(f"thread CPU over {args.steps} steps: {tot * 1e3 / args.steps:.1f} ms/step in {len(rows)} threads\n")
+        for d, comm, t in rows[:40]:
+            sys.stderr.write(f"  tid {t} {comm:16s} {d * 1e3 / args.steps:8.2f} ms/step\n")
     thr1 = throttle_stats()
     throttled = None if thr0 is None or thr1 is None else {"periods": thr1[0] - thr0[0], "usec": thr1[1] - thr0[1]}
     if use_dist:

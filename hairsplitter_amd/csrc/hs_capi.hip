@@ -139,9 +139,13 @@ struct UploadPack {
     }
 };
 
-// Host waits do not spin (unless HS_SPIN_WAIT is set): several host threads drive the device at once and a spinning waiter
-// takes a core away from the worker threads of the other contig groups. A blocking event per calling thread.
-static bool spin_wait() { static const bool s = std::getenv("HS_SPIN_WAIT") != nullptr; return s; }
+// Host waits. On this runtime a waiting host thread spins (100 % of a core for the whole wait) whether or not the event
+// carries hipEventBlockingSync; only the device-wide schedule flag makes hipEventSynchronize / hipStreamSynchronize sleep
+// (tools/probes/wait_probe.hip: 0.3 ms of CPU per 20-ms wait, woken 30-70 us late). Measured on the default bench, the
+// late wake-ups cost the contig-group chains more than the freed cores give back (41-44 vs 44-47 G aligned bp/s), so
+// spinning is the default and HS_BLOCKING_WAIT=1 selects the sleeping waits (for hosts that need the cores).
+static bool blocking_wait() { static const bool s = std::getenv("HS_BLOCKING_WAIT") != nullptr; return s; }
+static bool spin_wait() { return !blocking_wait(); }
 static int stream_wait(hipStream_t s) {
     if (spin_wait()) { HS_HIP(hipStreamSynchronize(s)); return HS_OK; }
     static thread_local hipEvent_t ev = nullptr;
@@ -196,6 +200,11 @@ int host_threads() {
     return n;
 }
 
+static void set_wait_policy() {   // see stream_wait
+    if (!blocking_wait()) return;
+    if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
+}
+
 int require_device() {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -203,6 +212,8 @@ int require_device() {
         set_error("no HIP device available: the HairSplitter MI355X path has no CPU fallback");
         return HS_ENODEVICE;
     }
+    static std::once_flag once;
+    std::call_once(once, set_wait_policy);
     return HS_OK;
 }
 
@@ -223,7 +234,7 @@ int hs_warmup(void) {
     (void)hipFree(p);
     return n;
 }
-int hs_set_device(int device) { HS_HIP(hipSetDevice(device)); return HS_OK; }
+int hs_set_device(int device) { HS_HIP(hipSetDevice(device)); set_wait_policy(); return HS_OK; }
 int hs_device_synchronize(void) { HS_HIP(hipDeviceSynchronize()); return HS_OK; }
 int hs_malloc(void** d_ptr, size_t bytes) { HS_HIP(hipMalloc(d_ptr, bytes ? bytes : 16)); return HS_OK; }
 int hs_free(void* d_ptr) { HS_HIP(hipFree(d_ptr)); return HS_OK; }

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -108,16 +109,20 @@ void free_sr_result(hs_sr_result* r) {
 }
 
 namespace {
-struct Laps {   // HS_TIMING: fine-grained wall clock of a stage driver
+struct Laps {   // HS_TIMING: fine-grained wall clock of a stage driver (HS_TIMING=cpu: wall/CPU time of the calling thread)
     bool on = std::getenv("HS_TIMING") != nullptr;
-    double t = now_ms();
+    bool cpu = on && std::string(std::getenv("HS_TIMING")) == "cpu";
+    double t = now_ms(), c = cpu_ms();
     std::string line;
     const char* tag;
     explicit Laps(const char* t_) : tag(t_) {}
+    static double cpu_ms() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
     void lap(const char* what) {
         if (!on) return;
         const double n = now_ms();
-        char buf[96]; std::snprintf(buf, sizeof buf, " %s %.2f", what, n - t);
+        char buf[96];
+        if (cpu) { const double cn = cpu_ms(); std::snprintf(buf, sizeof buf, " %s %.2f/%.2f", what, n - t, cn - c); c = cn; }
+        else std::snprintf(buf, sizeof buf, " %s %.2f", what, n - t);
         line += buf; t = n;
     }
     ~Laps() { if (on) std::fprintf(stderr, "[hs timing] %s laps (ms):%s\n", tag, line.c_str()); }
