@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O2 -o tools/probes/wait_probe tools/probes/wait_probe.hip ; run: tools/probes/wait_probe <0 stream sync / 1 blocking event / 2 device blocking schedule>
 // How much CPU does a host thread burn while it waits for the device? (diagnostic, not part of the product)
 #include <hip/hip_runtime.h>
 #include <cstdio>
