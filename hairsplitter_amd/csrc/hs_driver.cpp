@@ -472,7 +472,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
                 if (st[(size_t)c].low_memory_now) { lowmem_tasks.push_back(std::make_pair(c, (int)w)); continue; }
                 who.push_back(std::make_pair(c, (int)w));
                 job.win_contig.push_back(c);
-                for (int r = 0; r < st[(size_t)c].N; ++r) if (wp.mask[(size_t)r]) job.mask_ids.push_back(r);
+                job.mask_ids.insert(job.mask_ids.end(), wp.mask_ids.begin(), wp.mask_ids.end());
                 job.win_mask_off.push_back((int64_t)job.mask_ids.size());
             }
         laps.lap("graph_job");
@@ -505,25 +505,39 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         gs.perm.insert(gs.perm.end(), s.perm.begin(), s.perm.end());
         graph_id[(size_t)c].assign(s.graphs.size(), -1);
     }
-    for (int c = 0; c < C; ++c) {
-        SrContigState& s = st[(size_t)c];
-        for (auto& w : s.windows) {
-            if (!w.has_snps) continue;
-            for (int which = 0; which < 2; ++which) {
-                const int lg = which == 0 ? w.graph_now : w.graph_final;
-                if (graph_id[(size_t)c][(size_t)lg] >= 0) continue;
-                const SrGraph& g = s.graphs[(size_t)lg];
-                graph_id[(size_t)c][(size_t)lg] = (int)gs.graph_n.size();
-                gs.graph_off_base.push_back((int64_t)gs.adj_off.size());
-                gs.graph_adj_base.push_back((int64_t)gs.adj.size());
-                gs.graph_n.push_back(s.N);
-                gs.perm_base_of_graph.push_back(perm_base_of_contig[(size_t)c]);
-                gs.adj_off.insert(gs.adj_off.end(), g.off.begin(), g.off.end());
-                gs.adj.insert(gs.adj.end(), g.adj.begin(), g.adj.end());
-                gs.mask.insert(gs.mask.end(), w.mask.begin(), w.mask.end());
-                gs.max_n = std::max(gs.max_n, s.N);
+    // first the layout (serial: a few integers per graph), then the copies on the worker threads
+    struct GraphSlot { int c, lg; const SrWindowPlan* w; int64_t off_base, adj_base, mask_base; };
+    std::vector<GraphSlot> slots;
+    {
+        int64_t off_total = 0, adj_total = 0, mask_total = 0;
+        for (int c = 0; c < C; ++c) {
+            SrContigState& s = st[(size_t)c];
+            for (auto& w : s.windows) {
+                if (!w.has_snps) continue;
+                for (int which = 0; which < 2; ++which) {
+                    const int lg = which == 0 ? w.graph_now : w.graph_final;
+                    if (graph_id[(size_t)c][(size_t)lg] >= 0) continue;
+                    const SrGraph& g = s.graphs[(size_t)lg];
+                    graph_id[(size_t)c][(size_t)lg] = (int)slots.size();
+                    slots.push_back(GraphSlot{c, lg, &w, off_total, adj_total, mask_total});
+                    off_total += (int64_t)g.off.size(); adj_total += (int64_t)g.adj.size(); mask_total += (int64_t)w.mask.size();
+                    gs.max_n = std::max(gs.max_n, s.N);
+                }
             }
         }
+        const size_t G = slots.size();
+        gs.graph_off_base.resize(G); gs.graph_adj_base.resize(G); gs.graph_n.resize(G); gs.perm_base_of_graph.resize(G);
+        gs.adj_off.resize((size_t)off_total); gs.adj.resize((size_t)adj_total); gs.mask.resize((size_t)mask_total);
+        parallel_for((int)G, n_threads, [&](int i) {
+            const GraphSlot& sl = slots[(size_t)i];
+            const SrContigState& s = st[(size_t)sl.c];
+            const SrGraph& g = s.graphs[(size_t)sl.lg];
+            gs.graph_off_base[(size_t)i] = sl.off_base; gs.graph_adj_base[(size_t)i] = sl.adj_base;
+            gs.graph_n[(size_t)i] = s.N; gs.perm_base_of_graph[(size_t)i] = perm_base_of_contig[(size_t)sl.c];
+            std::copy(g.off.begin(), g.off.end(), gs.adj_off.begin() + sl.off_base);
+            std::copy(g.adj.begin(), g.adj.end(), gs.adj.begin() + sl.adj_base);
+            std::copy(sl.w->mask.begin(), sl.w->mask.end(), gs.mask.begin() + sl.mask_base);
+        });
     }
     laps.lap("graphset_build");
     {

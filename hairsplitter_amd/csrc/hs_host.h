@@ -62,6 +62,7 @@ struct SrWindowPlan {
     int start = 0, end = 0;
     bool has_snps = false;
     std::vector<uint8_t> mask;       // [N]
+    std::vector<int32_t> mask_ids;   // the reads of the mask, ascending
     std::vector<int32_t> labels;     // final labels [N]
     int graph_now = -1;              // graph built for this window (adjacency or neighbour list)
     int graph_final = -1;            // graph finalize_clustering sees (separate_reads.cpp:1708 quirk)

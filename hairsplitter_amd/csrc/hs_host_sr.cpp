@@ -188,6 +188,7 @@ void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool 
             idxmask++;
         }
         cur++;
+        for (int r = 0; r < N; ++r) if (w.mask[(size_t)r]) w.mask_ids.push_back(r);
         // graph slot for this window (filled by sr_build_window_graph, one independent task per window)
         st.graphs.emplace_back();
         st.graphs.back().off.assign((size_t)N + 1, 0);
