@@ -1,5 +1,5 @@
 """Parity at BASELINE's full configurations: the drop-in executables against the compiled reference (oracle/_ref, with the
-pinned random_device for stage 4) on the same synthetic files; per-contig comparison of .col / .vcf / error_rate / .gro.
+pinned random_device for stage 4) on the same synthetic files; per-contig comparison of .col / .vcf / error_rate / .gro, and the .gaf of the next stage.
 Usage: python tools/parity_full.py C3|C4|C5 [n_contigs]       (prints one JSON line; needs a GPU and oracle/_ref)"""
 import json
 import os
@@ -48,6 +48,21 @@ def main():
             out["gro_diff"] = canon.diff_blocks(ga, gb)[:3]
         out["n_snps"] = sum(1 for l in open(a[0]) if l.startswith("SNPS"))
         out["n_groups"] = sum(1 for l in open(a[3]) if l.startswith("GROUP"))
+        # next stage: the .gaf derived from each side's own .gro (hs_gro_to_gaf vs the reference's HS_create_new_contigs, which
+        # writes the .gaf and then stops at its first external tool)
+        if os.path.exists(p.get("ref_cnc", "")):
+            gaf_a, gaf_b, tmp = os.path.join(td, "hip.gaf"), os.path.join(td, "ref.gaf"), os.path.join(td, "cnc_tmp")
+            os.makedirs(tmp, exist_ok=True)
+            t0 = time.perf_counter()
+            subprocess.run([p["gaf"], f["gfa"], f["reads"], f["sam"], a[3], "0", gaf_a, str(threads)], check=True, stdout=subprocess.DEVNULL)
+            t1 = time.perf_counter()
+            subprocess.run([p["ref_cnc"], f["gfa"], f["reads"], "0.05", b[3], f["sam"], tmp + "/", str(threads), "ont", os.path.join(tmp, "o.gfa"), gaf_b,
+                            "racon", "0", "0", "/nonexistent/minimap2", "/nonexistent/racon", "/nonexistent/medaka", "/nonexistent/samtools",
+                            "/nonexistent/python", "0"], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            t2 = time.perf_counter()
+            out["gaf"] = {"hip_s": round(t1 - t0, 2), "ref_until_first_external_tool_s": round(t2 - t1, 2),
+                          "identical": os.path.exists(gaf_b) and open(gaf_a, "rb").read() == open(gaf_b, "rb").read(),
+                          "lines": sum(1 for _ in open(gaf_a))}
         out["speedup_file_to_file"] = round((out["ref"]["call_variants_s"] + out["ref"]["separate_reads_s"]) / (out["hip"]["call_variants_s"] + out["hip"]["separate_reads_s"]), 2)
     print(json.dumps(out))
 
