@@ -263,17 +263,31 @@ static int cigar_scan_launch(const int64_t* d_contig_off, const int32_t* d_rec_c
     return HS_OK;
 }
 
+// K1: the packed form over the task list, then the few records it leaves out (K0 flagged them) in the per-event form.
+// HS_K1_PER_EVENT=1: the per-event form for everything (the kernel of rounds r01_a .. r01_j).
 static int pileup_launch(const uint8_t* d_contig_seq, const int64_t* d_contig_off, const uint8_t* d_read_seq,
                          const int64_t* d_read_off, const int32_t* d_rec_read, const int32_t* d_rec_contig,
                          const int32_t* d_rec_pos, const uint8_t* d_rec_strand, const int64_t* d_rec_cig_off,
                          const uint32_t* d_cigar, const int64_t* d_pile_off, const int64_t* d_rec_chunk_off,
                          int32_t* d_chunk_scratch, const int32_t* d_task_rec, const int32_t* d_task_ev0, int32_t n_tasks,
-                         int32_t ev_per_task, uint8_t* d_pile, int32_t* d_rec_stats, void* stream) {
+                         int32_t ev_per_task, uint8_t* d_pile, int32_t* d_rec_stats, int32_t n_rec, void* stream) {
     if (n_tasks <= 0) return HS_OK;
-    hipLaunchKernelGGL(hsdev::k_pileup, dim3((n_tasks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_contig_seq, d_contig_off,
-                       d_read_seq, d_read_off, d_rec_read, d_rec_contig, d_rec_pos, d_rec_strand, d_rec_cig_off, d_cigar,
-                       d_pile_off, d_rec_chunk_off, d_chunk_scratch, d_task_rec, d_task_ev0, n_tasks, ev_per_task, d_pile,
-                       d_rec_stats);
+    static const bool per_event = std::getenv("HS_K1_PER_EVENT") != nullptr;
+    if (per_event) {
+        hipLaunchKernelGGL(hsdev::k_pileup, dim3((n_tasks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_contig_seq, d_contig_off,
+                           d_read_seq, d_read_off, d_rec_read, d_rec_contig, d_rec_pos, d_rec_strand, d_rec_cig_off, d_cigar,
+                           d_pile_off, d_rec_chunk_off, d_chunk_scratch, d_task_rec, d_task_ev0, n_tasks, ev_per_task, d_pile,
+                           d_rec_stats);
+    } else {
+        hipLaunchKernelGGL(hsdev::k_pileup_packed, dim3((n_tasks + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_contig_seq, d_contig_off,
+                           d_read_seq, d_read_off, d_rec_read, d_rec_contig, d_rec_pos, d_rec_strand, d_rec_cig_off, d_cigar,
+                           d_pile_off, d_rec_chunk_off, d_chunk_scratch, d_task_rec, d_task_ev0, n_tasks, ev_per_task, d_pile,
+                           d_rec_stats);
+        const int blocks = std::max(1, std::min(256, (n_rec + 255) / 256));
+        hipLaunchKernelGGL(hsdev::k_pileup_flagged_records, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_contig_seq, d_contig_off,
+                           d_read_seq, d_read_off, d_rec_read, d_rec_contig, d_rec_pos, d_rec_strand, d_rec_cig_off, d_cigar,
+                           d_pile_off, d_rec_chunk_off, d_chunk_scratch, n_rec, ev_per_task, d_pile, d_rec_stats);
+    }
     HS_HIP(hipGetLastError());
     return HS_OK;
 }
@@ -290,7 +304,7 @@ int hs_pileup(const uint8_t* d_contig_seq, const int64_t* d_contig_off, const ui
                                    d_rec_stats, stream)) return rc;
     return pileup_launch(d_contig_seq, d_contig_off, d_read_seq, d_read_off, d_rec_read, d_rec_contig, d_rec_pos, d_rec_strand,
                          d_rec_cig_off, d_cigar, d_pile_off, d_rec_chunk_off, d_chunk_scratch, d_task_rec, d_task_ev0, n_tasks,
-                         ev_per_task, d_pile, d_rec_stats, stream);
+                         ev_per_task, d_pile, d_rec_stats, n_rec, stream);
 }
 
 int hs_pileup_plan(const int64_t* h_rec_cig_off, const uint32_t* h_cigar, int32_t n_rec, int32_t ev_per_task,
@@ -836,7 +850,7 @@ struct HipCvOps : hs::CvDeviceOps {
                                    b->rec_read.as<int32_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(), b->rec_strand.as<uint8_t>(),
                                    b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->d_pile_off.as<int64_t>(),
                                    b->rec_chunk_off.as<int64_t>(), b->chunk_scratch.as<int32_t>(), b->task_rec.as<int32_t>(), b->task_ev0.as<int32_t>(),
-                                   b->n_tasks, b->ev_per_task, b->pile.as<uint8_t>(), b->rec_stats.as<int32_t>(), stream)) return rc;
+                                   b->n_tasks, b->ev_per_task, b->pile.as<uint8_t>(), b->rec_stats.as<int32_t>(), b->n_rec, stream)) return rc;
         HS_HIP(hipEventRecord(e1.b, stream));
         HS_HIP(hipEventRecord(e2.a, stream));
         if (b->sel_scratch.n_tiles == 0 && b->total_len > 0) { if (int rc = b->sel_scratch.prepare(b->total_len)) return rc; }

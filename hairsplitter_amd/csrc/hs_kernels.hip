@@ -88,13 +88,25 @@ __global__ __launch_bounds__(256) void k_cigar_scan(
     const int pos = rec_pos[r];
     int ev_cur = 0, t_cur = 0, q_cur = pos;
     int k = 0;
+    // smallest number of events that precede an op which moves a cursor without owning events (S, H, N) and has events before
+    // it: if events also follow it, the record is not one run of M/I/D events (see k_pileup_packed)
+    int first_gap = 0x7fffffff;
     for (int64_t ob = cig0; ob < cig1; ob += 64, ++k) {
         const int64_t oi = ob + lane;
         const OpAdv a = op_advances(oi < cig1 ? cigar[oi] : 0u, oi < cig1);
-        const int ev = wave_sum_i32(a.ev), rd = wave_sum_i32(a.rd), rf = wave_sum_i32(a.rf);
+        const int ev_incl = wave_scan_incl(a.ev);
+        const int ev = __builtin_amdgcn_readlane(ev_incl, 63), rd = wave_sum_i32(a.rd), rf = wave_sum_i32(a.rf);
+        const bool gap = a.ev == 0 && (a.rd > 0 || a.rf > 0);
+        if (__ballot(gap)) {   // wave-uniform; clips sit in the first and last chunk of a record
+            const int before = ev_cur + ev_incl - a.ev;
+            const int cand = (gap && before > 0) ? before : 0x7fffffff;
+            const int m = -wave_max_i32(-cand);
+            first_gap = m < first_gap ? m : first_gap;
+        }
         if (lane == 0) { cs[4 * k + 0] = ev_cur; cs[4 * k + 1] = t_cur; cs[4 * k + 2] = q_cur; cs[4 * k + 3] = 0; }
         ev_cur += ev; t_cur += rd; q_cur += rf;
     }
+    if (lane == 0 && k > 0) cs[3] = first_gap < ev_cur ? 1 : 0;   // 4th slot of the record's first chunk entry
     if (lane == 0) {
         const int ctg = rec_contig[r];
         const int L = (int)(contig_off[ctg + 1] - contig_off[ctg]);
@@ -112,30 +124,28 @@ __global__ __launch_bounds__(256) void k_cigar_scan(
 // wave-uniform carry; a task warms the carry up by replaying the two events before its range without
 // committing them. Pileup writes are contiguous per run of M/D events (coalesced).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pileup(
+#ifndef HS_K1_PU
+#define HS_K1_PU 4
+#endif
+// per-wave LDS of the per-event form: the 64 ops of the current chunk (first event, read offset, reference offset, op code),
+// the lanes of the ops that own events, and one "an op starts here" flag per event of the current 64-event window
+struct PileupLds {
+    int4 op[4][64];
+    uint8_t nzlane[4][64];
+    uint8_t flag[4][HS_K1_PU][64];
+};
+
+static __device__ __forceinline__ void pileup_task_per_event(
+    PileupLds& lds, const int lane, const int wv, const int r, const int e0, const int ev_per_task,
     const uint8_t* __restrict__ contig_seq, const int64_t* __restrict__ contig_off,
     const uint8_t* __restrict__ read_seq, const int64_t* __restrict__ read_off,
     const int32_t* __restrict__ rec_read, const int32_t* __restrict__ rec_contig,
     const int32_t* __restrict__ rec_pos, const uint8_t* __restrict__ rec_strand,
     const int64_t* __restrict__ rec_cig_off, const uint32_t* __restrict__ cigar,
     const int64_t* __restrict__ pile_off, const int64_t* __restrict__ rec_chunk_off,
-    const int32_t* __restrict__ chunk_start, const int32_t* __restrict__ task_rec, const int32_t* __restrict__ task_ev0,
-    int n_tasks, int ev_per_task, uint8_t* __restrict__ pile, int32_t* __restrict__ rec_stats) {
-    // per-wave LDS: the 64 ops of the current chunk (first event, read offset, reference offset, op code), the lanes of
-    // the ops that own events, and one "an op starts here" flag per event of the current 64-event window
-    __shared__ int4 s_op[4][64];
-    __shared__ uint8_t s_nzlane[4][64];
-#ifndef HS_K1_PU
-#define HS_K1_PU 4
-#endif
+    const int32_t* __restrict__ chunk_start, uint8_t* __restrict__ pile, int32_t* __restrict__ rec_stats) {
     constexpr int PU = HS_K1_PU;
-    __shared__ uint8_t s_flag[4][PU][64];
-    const int lane = lane_id();
-    const int wv = wave_id();
-    const int task = (int)blockIdx.x * 4 + wv;
-    if (task >= n_tasks) return;   // wave-uniform
-    const int r = task_rec[task];
-    const int e0 = task_ev0[task];
+    auto& s_op = lds.op; auto& s_nzlane = lds.nzlane; auto& s_flag = lds.flag;
     const int e1 = e0 + ev_per_task;
     const int e_first = e0 >= 2 ? e0 - 2 : 0;
 
@@ -252,6 +262,255 @@ __global__ __launch_bounds__(256) void k_pileup(
     if (lane == 0 && nlen > 0) {   // nlen / nerr are wave-uniform (scalar popcounts)
         atomicAdd(&rec_stats[4 * r + 1], nerr);
         atomicAdd(&rec_stats[4 * r + 2], nlen);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1, packed form: the same walk (generate_msa, call_variants.cpp:189-354) with FOUR consecutive alignment events per lane,
+// 256 per step, for records that are one uninterrupted run of M / I / D events (every record without a clip or skip
+// between aligned bases; K0 flags the others, k_pileup_flagged_records does those per event). In such a run the read
+// cursor advances on every event that is not a deletion and the reference cursor on every event that is not an insertion,
+// so no owner lookup is needed: the ops of the chunk mark the I and D events in a byte map (one byte per event), and
+//   t(e) = t(window) + (e - window) - #D before e,   q(e) = q(window) + (e - window) - #I before e
+// come from one packed wave prefix sum of the per-lane counts plus byte-wise prefixes inside the lane. Lanes whose four
+// events hold no deletion (no insertion) read their four read (reference) bytes with one unaligned dword load; the 3-mer
+// codes of four events are computed with packed byte arithmetic (all intermediate bytes stay below 256) and, when the
+// four events are consecutive columns, written with one dword store. Mismatch / length counters are byte sums per lane,
+// reduced once per task.
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+static __device__ __forceinline__ uint32_t byte_sum(uint32_t x, uint32_t acc) { return __builtin_amdgcn_sad_u8(x, 0u, acc); }
+// bytes 0 .. n-1 set (n in 0..4)
+static __device__ __forceinline__ uint32_t low_bytes(int n) { return n >= 4 ? 0xffffffffu : ((1u << (8 * n)) - 1u); }
+
+__global__ __launch_bounds__(256) void k_pileup_packed(
+    const uint8_t* __restrict__ contig_seq, const int64_t* __restrict__ contig_off,
+    const uint8_t* __restrict__ read_seq, const int64_t* __restrict__ read_off,
+    const int32_t* __restrict__ rec_read, const int32_t* __restrict__ rec_contig,
+    const int32_t* __restrict__ rec_pos, const uint8_t* __restrict__ rec_strand,
+    const int64_t* __restrict__ rec_cig_off, const uint32_t* __restrict__ cigar,
+    const int64_t* __restrict__ pile_off, const int64_t* __restrict__ rec_chunk_off,
+    const int32_t* __restrict__ chunk_start, const int32_t* __restrict__ task_rec, const int32_t* __restrict__ task_ev0,
+    int n_tasks, int ev_per_task, uint8_t* __restrict__ pile, int32_t* __restrict__ rec_stats) {
+#ifndef HS_K1_WINDOWS
+#define HS_K1_WINDOWS 4
+#endif
+    constexpr int NW = HS_K1_WINDOWS;
+    __shared__ uint32_t s_type[4][64 * NW];   // per wave: 256 x NW event types (0 = M, 1 = I, 2 = D)
+    const int lane = lane_id();
+    const int wv = wave_id();
+    const int task = (int)blockIdx.x * 4 + wv;
+    if (task >= n_tasks) return;   // wave-uniform
+    const int r = task_rec[task];
+    const int32_t* __restrict__ cs = chunk_start + 4 * rec_chunk_off[r];
+    if (cs[3] != 0) return;        // not one run of events: left to k_pileup_flagged_records
+    const int e0 = task_ev0[task];
+    const int e1 = e0 + ev_per_task;
+    const int e_first = e0 >= 2 ? e0 - 2 : 0;
+
+    const int ctg = rec_contig[r];
+    const int64_t coff = contig_off[ctg];
+    const int L = (int)(contig_off[ctg + 1] - coff);
+    const int rd = rec_read[r];
+    const int64_t roff = read_off[rd];
+    const int rlen = (int)(read_off[rd + 1] - roff);
+    const int pos = rec_pos[r];
+    const bool fwd = rec_strand[r] != 0;
+    const int64_t cig0 = rec_cig_off[r], cig1 = rec_cig_off[r + 1];
+    const int n_chunks = (int)((cig1 - cig0 + 63) >> 6);
+    uint8_t* __restrict__ out = pile + pile_off[r];
+    const uint8_t* __restrict__ ctgp = contig_seq + coff;
+    const uint8_t* __restrict__ rdp = read_seq + roff;
+    // reverse-strand records read the reverse complement: the four bytes of a load are mirrored and complemented
+    const uint32_t strand_sel = fwd ? 0x03020100u : 0x00010203u, strand_xor = fwd ? 0u : 0x03030303u;
+    uint8_t* const types = reinterpret_cast<uint8_t*>(&s_type[wv][0]);
+
+    int klo = 0, khi = n_chunks - 1;
+    while (klo < khi) { const int mid = (klo + khi + 1) >> 1; if (cs[4 * mid] <= e_first) klo = mid; else khi = mid - 1; }
+
+    int p1 = 2, p2 = 1;                  // previous char 'G', the one before 'C' (call_variants.cpp:212-214 after one shift)
+    uint32_t nerr_l = 0, nlen_l = 0;     // per-lane counters, reduced at the end
+    for (int k = klo; k < n_chunks; ++k) {
+        const int ev_base = cs[4 * k + 0];
+        if (ev_base >= e1) break;
+        const int t_cur = cs[4 * k + 1], q_cur = cs[4 * k + 2];
+        const int64_t oi = cig0 + ((int64_t)k << 6) + lane;
+        const bool in_range = oi < cig1;
+        const uint32_t op = in_range ? cigar[oi] : 0xFu;
+        const int code = in_range ? (int)(op & 15u) : 15;
+        const OpAdv a = op_advances(op, in_range);
+        const int ev_inc = wave_scan_incl(a.ev), rd_inc = wave_scan_incl(a.rd), rf_inc = wave_scan_incl(a.rf);
+        const int ev_ex = ev_inc - a.ev;
+        const int chunk_ev = __builtin_amdgcn_readlane(ev_inc, 63);
+        const unsigned long long nzmask = __ballot(a.ev > 0);
+        if (nzmask == 0ull) continue;                                        // a chunk of clips only
+        // cursors at the first event of the chunk (leading clips of the record are in front of it)
+        const int first_op = __builtin_ctzll(nzmask);
+        const int t0 = __builtin_amdgcn_readlane(t_cur + rd_inc - a.rd, first_op);
+        const int q0 = __builtin_amdgcn_readlane(q_cur + rf_inc - a.rf, first_op);
+        const int type = code == 1 ? 1 : (code == 2 ? 2 : 0);
+        const bool marks = a.ev > 0 && type != 0;                             // this op's events are I or D
+        const int lo_el = e_first > ev_base ? e_first - ev_base : 0;
+        const int hi_el = (e1 - ev_base) < chunk_ev ? (e1 - ev_base) : chunk_ev;
+        const int lo_commit = e0 - ev_base;                                   // events before it only warm the 3-mer context up
+        int tW = t0 + lo_el, qW = q0 + lo_el;                                 // cursors at the first event of the window
+        if (lo_el > 0) {                                                      // the task starts inside the chunk
+            int before = lo_el - ev_ex; before = before < 0 ? 0 : (before > a.ev ? a.ev : before);
+            tW -= wave_sum_i32(marks && type == 2 ? before : 0);
+            qW -= wave_sum_i32(marks && type == 1 ? before : 0);
+        }
+        // HS_K1_WINDOWS windows of 256 events per iteration: one type map for all of them, and the loads of every window issued
+        // before the first one is consumed (the packed form is short on instructions, so memory latency is what is left to hide)
+        for (int eb = lo_el; eb < hi_el; eb += 256 * NW) {
+            wave_lds_sync();                                                  // the previous iteration's readers are done
+#pragma unroll
+            for (int u = 0; u < NW; ++u) s_type[wv][u * 64 + lane] = 0u;
+            wave_lds_sync();
+            {   // the I / D ops mark their events of this iteration
+                int k0 = eb - ev_ex; k0 = k0 < 0 ? 0 : k0;
+                int k1 = eb + 256 * NW - ev_ex; k1 = k1 > a.ev ? a.ev : k1;
+                if (!marks) k1 = k0;
+                for (int kk = k0; __ballot(kk < k1) != 0ull; ++kk) if (kk < k1) types[ev_ex + kk - eb] = (uint8_t)type;
+            }
+            wave_lds_sync();
+            uint32_t isI_[NW], isD_[NW], ipre_[NW], rb_[NW], ref_[NW], inl_[NW], commit_[NW];
+            int qL_[NW], nI_[NW];
+#pragma unroll
+            for (int u = 0; u < NW; ++u) {
+                const int w0 = eb + 256 * u;                                  // wave-uniform; windows past hi_el hold no valid lane
+                const uint32_t f = s_type[wv][u * 64 + lane];
+                const uint32_t isI = f & 0x01010101u, isD = (f >> 1) & 0x01010101u;
+                const int nI = (int)byte_sum(isI, 0u), nD = (int)byte_sum(isD, 0u);
+                const int cnt = nD | (nI << 16);
+                const int cnt_incl = wave_scan_incl(cnt);
+                const int cnt_tot = __builtin_amdgcn_readlane(cnt_incl, 63);
+                const int cnt_ex = cnt_incl - cnt;
+                const int e_l = w0 + 4 * lane;                                // first event of the lane (relative to the chunk)
+                const int tL = tW + 4 * lane - (cnt_ex & 0xffff);
+                const int qL = qW + 4 * lane - (cnt_ex >> 16);
+                tW += 256 - (cnt_tot & 0xffff); qW += 256 - (cnt_tot >> 16);  // cursors at the next window
+                // byte b = number of D (I) among the lane's events before b (shift-adds: a 32-bit multiply is quarter rate)
+                const uint32_t d01 = isD + (isD << 8), i01 = isI + (isI << 8);
+                const uint32_t dpre = (d01 + (isD << 16)) << 8, ipre = (i01 + (isI << 16)) << 8;
+                int nv = hi_el - e_l; nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);     // events of the lane inside the chunk / task
+                int ns = lo_commit - e_l; ns = ns < 0 ? 0 : (ns > 4 ? 4 : ns); // leading events that only warm the context up
+                commit_[u] = low_bytes(nv) & ~low_bytes(ns);
+                // ---- the four read characters: the lane's non-D events consume consecutive read bases from tL on, so one
+                // dword holds them all; event b takes byte (b - #D before b) of it (+ d when the load was moved back to stay
+                // inside the read). Reverse strand: the dword is mirrored and complemented first. Unconditional: the address
+                // is clamped into the read, lanes without events read something they never use ----
+                uint32_t rb;
+                {
+                    int A, d;     // first byte of the dword in the stored read; how far the wanted bytes sit from byte 0
+                    if (fwd) { A = tL < rlen - 4 ? tL : rlen - 4; A = A < 0 ? 0 : A; d = tL - A; }
+                    else { A = rlen - 4 - tL; d = A < 0 ? -A : 0; A = A < 0 ? 0 : (A > rlen - 4 ? (rlen > 4 ? rlen - 4 : 0) : A); }
+                    const uint32_t w = __builtin_amdgcn_perm(0u, *reinterpret_cast<const u32_unaligned*>(rdp + A), strand_sel) ^ strand_xor;
+                    rb = __builtin_amdgcn_perm(w, w, (0x03020100u - dpre) + __builtin_amdgcn_perm(0u, (uint32_t)d, 0u)) & 0x03030303u;
+                }
+                // ---- the four reference characters (consecutive from qL on for the non-I events) and "on the contig" ----
+                uint32_t ref4, in_l = 0xffffffffu;
+                {
+                    const uint32_t off4 = 0x03020100u - ipre;                  // byte b = q of event b minus qL
+                    int A = qL < L - 4 ? qL : L - 4;
+                    A = A < 0 ? 0 : A;                                         // (contigs shorter than 4 bases: bytes past the end are masked by in_l)
+                    const uint32_t w = *reinterpret_cast<const u32_unaligned*>(ctgp + A);
+                    ref4 = __builtin_amdgcn_perm(w, w, off4 + __builtin_amdgcn_perm(0u, (uint32_t)((qL - A) & 3), 0u)) & 0x03030303u;
+                    const int room = L - qL;                                   // events whose q offset is below it are on the contig
+                    if (__ballot(room < 4) != 0ull) {                          // wave-uniform: only where a record runs to the contig end
+                        in_l = 0u;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) in_l |= ((int)((off4 >> (8 * b)) & 0xffu) < room ? 0xffu : 0u) << (8 * b);
+                    }
+                }
+                isI_[u] = isI; isD_[u] = isD; ipre_[u] = ipre; rb_[u] = rb; ref_[u] = ref4; inl_[u] = in_l; qL_[u] = qL; nI_[u] = nI;
+            }
+#pragma unroll
+            for (int u = 0; u < NW; ++u) {
+                const int w0 = eb + 256 * u;
+                if (w0 >= hi_el) break;                                       // wave-uniform
+                const uint32_t isI = isI_[u], isD = isD_[u];
+                const uint32_t c4 = (rb_[u] & ~(isD * 255u)) | (isD << 2);     // 4 == '-'
+                const uint32_t act = commit_[u] & inl_[u];                     // committed and on the contig (call_variants.cpp:217)
+                // ---- 3-mer codes: 33 + 25 c + c(-1) + 5 c(-2), four at a time ----
+                const uint32_t cprev = (uint32_t)wave_shr1((int)c4, (p1 << 24) | (p2 << 16));
+                const uint32_t cu1 = __builtin_amdgcn_alignbyte(c4, cprev, 3); // characters of the previous event
+                const uint32_t cu2 = __builtin_amdgcn_alignbyte(c4, cprev, 2); // and of the one before
+                const uint32_t code4 = 0x21212121u + (c4 << 4) + (c4 << 3) + c4 + cu1 + (cu2 << 2) + cu2;
+                // ---- counters: M: call_variants.cpp:238-240,254-256; D: :287-290; I: :337 ----
+                const uint32_t x = c4 ^ ref_[u];
+                const uint32_t neq = (x | (x >> 1) | (x >> 2)) & 0x01010101u;
+                const uint32_t act1 = act & 0x01010101u;
+                nlen_l = byte_sum(act1, nlen_l);
+                nerr_l = byte_sum(act1 & (isI | isD | neq), nerr_l);
+                // ---- pileup bytes of the M and D events ----
+                const uint32_t wr = act & ~(isI * 255u);
+                if (wr == 0xffffffffu && nI_[u] == 0) *reinterpret_cast<u32_unaligned*>(out + (unsigned)(qL_[u] - pos)) = code4;
+                else if (wr != 0u) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if ((wr >> (8 * b)) & 1u) out[(unsigned)(qL_[u] + b - (int)((ipre_[u] >> (8 * b)) & 0xffu) - pos)] = (uint8_t)(code4 >> (8 * b));
+                }
+                // ---- carry: the last two characters of the window ----
+                const int nw = (hi_el - w0) < 256 ? (hi_el - w0) : 256;
+                const int last = (int)((uint32_t)__builtin_amdgcn_readlane((int)c4, (nw - 1) >> 2) >> (8 * ((nw - 1) & 3))) & 0xff;
+                const int last2 = nw >= 2 ? (int)((uint32_t)__builtin_amdgcn_readlane((int)c4, (nw - 2) >> 2) >> (8 * ((nw - 2) & 3))) & 0xff : p1;
+                p2 = last2; p1 = last;
+            }
+        }
+    }
+    const int nlen = wave_sum_i32((int)nlen_l), nerr = wave_sum_i32((int)nerr_l);
+    if (lane == 0 && nlen > 0) {
+        atomicAdd(&rec_stats[4 * r + 1], nerr);
+        atomicAdd(&rec_stats[4 * r + 2], nlen);
+    }
+}
+
+// per-event form over a task list (every record; used when the packed form is switched off, and by the kernel entry of the C ABI)
+__global__ __launch_bounds__(256) void k_pileup(
+    const uint8_t* __restrict__ contig_seq, const int64_t* __restrict__ contig_off,
+    const uint8_t* __restrict__ read_seq, const int64_t* __restrict__ read_off,
+    const int32_t* __restrict__ rec_read, const int32_t* __restrict__ rec_contig,
+    const int32_t* __restrict__ rec_pos, const uint8_t* __restrict__ rec_strand,
+    const int64_t* __restrict__ rec_cig_off, const uint32_t* __restrict__ cigar,
+    const int64_t* __restrict__ pile_off, const int64_t* __restrict__ rec_chunk_off,
+    const int32_t* __restrict__ chunk_start, const int32_t* __restrict__ task_rec, const int32_t* __restrict__ task_ev0,
+    int n_tasks, int ev_per_task, uint8_t* __restrict__ pile, int32_t* __restrict__ rec_stats) {
+    __shared__ PileupLds lds;
+    const int lane = lane_id();
+    const int wv = wave_id();
+    const int task = (int)blockIdx.x * 4 + wv;
+    if (task >= n_tasks) return;   // wave-uniform
+    pileup_task_per_event(lds, lane, wv, task_rec[task], task_ev0[task], ev_per_task, contig_seq, contig_off, read_seq, read_off, rec_read, rec_contig,
+                          rec_pos, rec_strand, rec_cig_off, cigar, pile_off, rec_chunk_off, chunk_start, pile, rec_stats);
+}
+
+// the records k_pileup_packed leaves out (K0 flagged them: a clip or a skip between aligned bases), in the per-event form.
+// A small persistent grid: every wave checks 64 records per step and walks the tasks of the flagged ones.
+__global__ __launch_bounds__(256) void k_pileup_flagged_records(
+    const uint8_t* __restrict__ contig_seq, const int64_t* __restrict__ contig_off,
+    const uint8_t* __restrict__ read_seq, const int64_t* __restrict__ read_off,
+    const int32_t* __restrict__ rec_read, const int32_t* __restrict__ rec_contig,
+    const int32_t* __restrict__ rec_pos, const uint8_t* __restrict__ rec_strand,
+    const int64_t* __restrict__ rec_cig_off, const uint32_t* __restrict__ cigar,
+    const int64_t* __restrict__ pile_off, const int64_t* __restrict__ rec_chunk_off,
+    const int32_t* __restrict__ chunk_start, int n_rec, int ev_per_task, uint8_t* __restrict__ pile, int32_t* __restrict__ rec_stats) {
+    __shared__ PileupLds lds;
+    const int lane = lane_id();
+    const int wv = wave_id();
+    const int n_waves = (int)gridDim.x * 4;
+    for (int base = ((int)blockIdx.x * 4 + wv) * 64; base < n_rec; base += n_waves * 64) {
+        const int rr = base + lane;
+        bool flagged = false;
+        if (rr < n_rec && rec_chunk_off[rr + 1] > rec_chunk_off[rr]) flagged = chunk_start[4 * rec_chunk_off[rr] + 3] != 0;
+        unsigned long long m = __ballot(flagged);
+        while (m) {
+            const int r = base + __builtin_ctzll(m);
+            m &= m - 1ull;
+            const int n_ev = rec_stats[4 * r + 3];
+            for (int e0 = 0; e0 < n_ev; e0 += ev_per_task)
+                pileup_task_per_event(lds, lane, wv, r, e0, ev_per_task, contig_seq, contig_off, read_seq, read_off, rec_read, rec_contig, rec_pos,
+                                      rec_strand, rec_cig_off, cigar, pile_off, rec_chunk_off, chunk_start, pile, rec_stats);
+        }
     }
 }
 

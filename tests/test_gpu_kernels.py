@@ -52,6 +52,39 @@ def test_pileup_bytes_and_counters(batch):
         assert np.array_equal(s2.cpu().numpy()[:, :3], o_stats[:, :3]), ev
 
 
+def test_pileup_records_with_a_clip_between_aligned_bases(built):
+    """Records whose CIGAR holds an S / H run BETWEEN aligned bases (the reference just steps over the read bases,
+    call_variants.cpp:269-273) are not one run of M/I/D events: K0 flags them and the per-event form handles them, next to
+    the packed form for all other records. Also a clip longer than a task, and clips at several places of one record."""
+    from hairsplitter_amd import api, synth
+    rng = np.random.default_rng(11)
+    c = synth.make_contig(41, 0, 20_000, 2, 0.01, 30, "ont", clip_prob=0.3)
+    n_mod = 0
+    for ai, a in enumerate(c.alns):
+        if ai % 3 != 0 or len(a.cigar) < 12:
+            continue
+        for rep in range(1 + (ai % 2)):
+            k = int(rng.integers(2, len(a.cigar) - 2))
+            ops, lens = a.cigar & 0xF, (a.cigar >> 4).astype(np.int64)
+            t = int(lens[:k][np.isin(ops[:k], (synth.OP_M, synth.OP_I, synth.OP_S, synth.OP_H, synth.OP_EQ, synth.OP_X))].sum())
+            n = int(rng.integers(1, 40)) if ai % 9 else 5000
+            junk = rng.integers(0, 4, size=n).astype(np.uint8)
+            read = c.reads[a.read]
+            at = t if a.strand else len(read) - t            # reads are stored as sequenced
+            c.reads[a.read] = np.concatenate((read[:at], junk, read[at:]))
+            tok = np.array([(n << 4) | (synth.OP_S if rep == 0 else synth.OP_H)], dtype=np.uint32)
+            a.cigar = np.concatenate((a.cigar[:k], tok, a.cigar[k:]))
+        n_mod += 1
+    assert n_mod > 20
+    flat = api.FlatBatch([c, synth.make_contig(41, 1, 8_000, 2, 0.01, 25, "ont")])
+    t = api.device_tensors(flat)
+    o_pile, o_stats, _ = ol.pileup(flat)
+    for ev in (4096, 64, 1 << 30):
+        pile, stats = api.pileup(t, flat, ev_per_task=ev)
+        assert np.array_equal(pile.cpu().numpy(), o_pile), ev
+        assert np.array_equal(stats.cpu().numpy()[:, :3], o_stats[:, :3]), ev
+
+
 def test_column_stats_counts(batch):
     """K2 == histogram of call_variants.cpp:477-501: sorted counts, depth; keys wherever they are unambiguous."""
     from hairsplitter_amd import api
