@@ -279,6 +279,11 @@ static __device__ __forceinline__ void pileup_task_per_event(
 // reduced once per task.
 // ------------------------------------------------------------------------------------------------
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
+// keeps the compiler from folding a chain of shifts and adds back into a 32-bit multiply (quarter rate on the VALU)
+static __device__ __forceinline__ uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }
+// 0x01 bytes -> 0xff bytes
+static __device__ __forceinline__ uint32_t bytes_ff(uint32_t x01) { return opaque(x01 << 8) - x01; }
 static __device__ __forceinline__ uint32_t byte_sum(uint32_t x, uint32_t acc) { return __builtin_amdgcn_sad_u8(x, 0u, acc); }
 // bytes 0 .. n-1 set (n in 0..4)
 static __device__ __forceinline__ uint32_t low_bytes(int n) { return n >= 4 ? 0xffffffffu : ((1u << (8 * n)) - 1u); }
@@ -390,8 +395,8 @@ __global__ __launch_bounds__(256) void k_pileup_packed(
                 const int qL = qW + 4 * lane - (cnt_ex >> 16);
                 tW += 256 - (cnt_tot & 0xffff); qW += 256 - (cnt_tot >> 16);  // cursors at the next window
                 // byte b = number of D (I) among the lane's events before b (shift-adds: a 32-bit multiply is quarter rate)
-                const uint32_t d01 = isD + (isD << 8), i01 = isI + (isI << 8);
-                const uint32_t dpre = (d01 + (isD << 16)) << 8, ipre = (i01 + (isI << 16)) << 8;
+                const uint32_t d01 = opaque(isD + (isD << 8)), i01 = opaque(isI + (isI << 8));
+                const uint32_t dpre = opaque(d01 + (isD << 16)) << 8, ipre = opaque(i01 + (isI << 16)) << 8;
                 int nv = hi_el - e_l; nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);     // events of the lane inside the chunk / task
                 int ns = lo_commit - e_l; ns = ns < 0 ? 0 : (ns > 4 ? 4 : ns); // leading events that only warm the context up
                 commit_[u] = low_bytes(nv) & ~low_bytes(ns);
@@ -429,23 +434,37 @@ __global__ __launch_bounds__(256) void k_pileup_packed(
                 const int w0 = eb + 256 * u;
                 if (w0 >= hi_el) break;                                       // wave-uniform
                 const uint32_t isI = isI_[u], isD = isD_[u];
-                const uint32_t c4 = (rb_[u] & ~(isD * 255u)) | (isD << 2);     // 4 == '-'
+                const uint32_t c4 = (rb_[u] & ~bytes_ff(isD)) | (isD << 2);    // 4 == '-'
                 const uint32_t act = commit_[u] & inl_[u];                     // committed and on the contig (call_variants.cpp:217)
                 // ---- 3-mer codes: 33 + 25 c + c(-1) + 5 c(-2), four at a time ----
                 const uint32_t cprev = (uint32_t)wave_shr1((int)c4, (p1 << 24) | (p2 << 16));
                 const uint32_t cu1 = __builtin_amdgcn_alignbyte(c4, cprev, 3); // characters of the previous event
                 const uint32_t cu2 = __builtin_amdgcn_alignbyte(c4, cprev, 2); // and of the one before
-                const uint32_t code4 = 0x21212121u + (c4 << 4) + (c4 << 3) + c4 + cu1 + (cu2 << 2) + cu2;
+                const uint32_t code4 = 0x21212121u + opaque((c4 << 4) + c4) + opaque(c4 << 3) + cu1 + opaque((cu2 << 2) + cu2);
                 // ---- counters: M: call_variants.cpp:238-240,254-256; D: :287-290; I: :337 ----
                 const uint32_t x = c4 ^ ref_[u];
                 const uint32_t neq = (x | (x >> 1) | (x >> 2)) & 0x01010101u;
                 const uint32_t act1 = act & 0x01010101u;
                 nlen_l = byte_sum(act1, nlen_l);
                 nerr_l = byte_sum(act1 & (isI | isD | neq), nerr_l);
-                // ---- pileup bytes of the M and D events ----
-                const uint32_t wr = act & ~(isI * 255u);
-                if (wr == 0xffffffffu && nI_[u] == 0) *reinterpret_cast<u32_unaligned*>(out + (unsigned)(qL_[u] - pos)) = code4;
-                else if (wr != 0u) {
+                // ---- pileup bytes of the M and D events. The usual lane commits its first n events (all four, or fewer at the
+                // end of a chunk or task) on the contig: their M / D events are consecutive columns from qL on. With at most one
+                // insertion among them its code byte is squeezed out and the n bytes leave as one dword / short / byte store.
+                // Other lanes (first lane of a task, contig end, two insertions in one lane) store byte by byte ----
+                const uint32_t wi = isI & act;                                 // committed insertions
+                const int n_i = (int)byte_sum(wi, 0u);
+                if ((act & (act + 1u)) == 0u && n_i <= 1) {
+                    const int n = (int)byte_sum(act1, 0u) - n_i;
+                    const uint32_t below = wi - 1u;                            // bytes below the insertion (all of them if there is none)
+                    const uint32_t comp = (code4 & below) | ((code4 >> 8) & ~below);
+                    uint8_t* const o = out + (unsigned)(qL_[u] - pos);
+                    if (n == 4) *reinterpret_cast<u32_unaligned*>(o) = comp;
+                    else {
+                        if (n & 2) *reinterpret_cast<u16_unaligned*>(o) = (uint16_t)comp;
+                        if (n & 1) o[n & 2] = (uint8_t)(comp >> (8 * (n & 2)));
+                    }
+                } else {
+                    const uint32_t wr = act & ~bytes_ff(isI);
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
                         if ((wr >> (8 * b)) & 1u) out[(unsigned)(qL_[u] + b - (int)((ipre_[u] >> (8 * b)) & 0xffu) - pos)] = (uint8_t)(code4 >> (8 * b));
