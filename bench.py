@@ -310,7 +310,7 @@ def main():
                                    f"{B} such contigs per GPU per step, inputs resident in HBM",
                        "contigs_per_gpu": B, "aligned_bp_per_gpu": local_bp, "parallelism": f"contig-sharded x{world}", "groups_per_gpu": G,
                        "host_threads_per_rank": n_threads, "snps_rank0": int(cv["n_snps"]), "cw_instances_rank0": sr["n_cw_instances"]},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("k_pileup_packed" if dom == "k_pileup" and not os.environ.get("HS_K1_PER_EVENT") else dom), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kernels[dom],
                          "algorithmic_bytes_per_launch": alg_bytes[dom]},
             "kernel_ms_per_step": kernels, "step_ms": [round(x, 2) for x in step_ms],

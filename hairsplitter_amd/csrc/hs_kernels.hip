@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void k_pileup_packed(
             tW -= wave_sum_i32(marks && type == 2 ? before : 0);
             qW -= wave_sum_i32(marks && type == 1 ? before : 0);
         }
-        // HS_K1_WINDOWS windows of 256 events per iteration (measured: 1 -> 1.76 ms, 2 -> 1.64, 3 -> 1.64, 4 -> 1.80, 8 -> 3.0 per
+        // HS_K1_WINDOWS windows of 256 events per iteration (measured: 1 -> 1.76 ms, 2 -> 1.61, 3 -> 1.63, 4 -> 1.62, 8 -> 3.0 per
         // 1.28 G events): one type map for all of them, and the loads of every window issued
         // before the first one is consumed (the packed form is short on instructions, so memory latency is what is left to hide)
         for (int eb = lo_el; eb < hi_el; eb += 256 * NW) {
@@ -383,7 +383,8 @@ __global__ __launch_bounds__(256) void k_pileup_packed(
             int qL_[NW], nI_[NW];
 #pragma unroll
             for (int u = 0; u < NW; ++u) {
-                const int w0 = eb + 256 * u;                                  // wave-uniform; windows past hi_el hold no valid lane
+                const int w0 = eb + 256 * u;
+                if (w0 >= hi_el) break;                                       // wave-uniform: a chunk is ~2.5 windows of events
                 const uint32_t f = s_type[wv][u * 64 + lane];
                 const uint32_t isI = f & 0x01010101u, isD = (f >> 1) & 0x01010101u;
                 const int nI = (int)byte_sum(isI, 0u), nD = (int)byte_sum(isD, 0u);
