@@ -59,7 +59,9 @@ int hs_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchron
 
 /* ------------------------------------------------------------------------------------------------
  * K1 -- pileup.  Replaces generate_msa (call_variants.cpp:50-437) + convert_cigar (tools.cpp:27-57).
- * One wavefront per record. For record r with reference start pos[r]:
+ * One wavefront per task (a range of alignment events of one record). Launches K0 (CIGAR scan: fills d_chunk_scratch with the
+ * cursors at every 64-op chunk and flags the records that hold a clip between aligned bases), the packed pileup kernel (four
+ * events per lane) over the task list and the per-event kernel over the flagged records. For record r with reference start pos[r]:
  *   d_pile[pile_off[r] + (q - pos[r])] = 33 + 5*i(c-2) + i(c-1) + 25*i(c0)   for every M/=/X/D event at q < L
  * (i() = index in "ACGT-", previous chars initialised C,G as call_variants.cpp:212-214 leave them).
  * d_rec_stats[r] = {q_end, n_err, n_len, n_events}: final reference cursor (call_variants.cpp:354) and the number
