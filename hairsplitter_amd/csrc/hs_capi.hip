@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1120,9 +1121,30 @@ struct HipSrOps : hs::SrDeviceOps {
     std::vector<int32_t> sd_n;
     int max_n = 1;
 
+    // K5 runs on while the host plans the windows: its temporaries and its timing events are parked here until the next
+    // call that waits for the stream anyway
+    struct SimdiffInFlight {
+        DBuf d_alt, d_ref, d_sr, d_sa, d_sc, d_cb, d_po, d_n, d_w, d_oo, t_c, t_i, t_j;
+        UploadPack pk;
+        EventPair ev;
+        float* k_ms = nullptr;
+    };
+    std::unique_ptr<SimdiffInFlight> sd_flight;
+    int settle_simdiff(bool account = true) {   // waits for K5 if it is still running, accounts its time, releases its temporaries
+        if (!sd_flight) return HS_OK;
+        float m = 0;
+        const int rc = sd_flight->ev.ms(&m);
+        if (!rc && account && sd_flight->k_ms) *sd_flight->k_ms += m;
+        sd_flight.reset();
+        return rc;
+    }
+    ~HipSrOps() override { (void)settle_simdiff(false); }   // the caller's counter may be gone by now
+
     int read_graphs(const hs::ReadGraphJob& job, hs::ReadGraphResult& res, float* k_ms) override {
         if (!d_sim.p) { set_error("read_graphs before simdiff"); return HS_EINVAL; }
-        return read_graphs_run(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, job, res, stream, k_ms);
+        const int rc = read_graphs_run(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, job, res, stream, k_ms);
+        const int rc2 = settle_simdiff();   // K6 came after K5 on the stream and has been waited for
+        return rc ? rc : rc2;
     }
 
     DBuf d_col_off, d_col_idx, d_col_code;    // SNP columns of the batch: uploaded once, read by K5a and the seeded CW wave
@@ -1136,35 +1158,35 @@ struct HipSrOps : hs::SrDeviceOps {
         resident_cols = job.cols;
         sd_out_off = job.out_off; sd_n = job.n_reads;
         if (job.out_total <= 0) return HS_OK;
-        DBuf d_alt, d_ref, d_sr, d_sa, d_sc, d_cb, d_po, d_n, d_w, d_oo, t_c, t_i, t_j;
-        UploadPack pk;
-        pk.add(job.snp_ref, d_sr);
-        pk.add(job.snp_alt, d_sa);
-        pk.add(job.snp_contig, d_sc);
-        pk.add(job.contig_snp_base, d_cb);
-        pk.add(job.plane_off, d_po);
-        pk.add(job.n_reads, d_n);
-        pk.add(job.words, d_w);
-        pk.add(job.out_off, d_oo);
-        if (int rc = pk.commit(stream)) return rc;
+        if (int rc = settle_simdiff()) return rc;
+        sd_flight.reset(new SimdiffInFlight());
+        SimdiffInFlight& f = *sd_flight;
+        f.k_ms = k_ms;
+        f.pk.add(job.snp_ref, f.d_sr);
+        f.pk.add(job.snp_alt, f.d_sa);
+        f.pk.add(job.snp_contig, f.d_sc);
+        f.pk.add(job.contig_snp_base, f.d_cb);
+        f.pk.add(job.plane_off, f.d_po);
+        f.pk.add(job.n_reads, f.d_n);
+        f.pk.add(job.words, f.d_w);
+        f.pk.add(job.out_off, f.d_oo);
+        if (int rc = f.pk.commit(stream)) return rc;
         const size_t pbytes = (size_t)job.plane_total * sizeof(uint64_t);
-        if (int rc = d_alt.alloc(pbytes)) return rc;
-        if (int rc = d_ref.alloc(pbytes)) return rc;
+        if (int rc = f.d_alt.alloc(pbytes)) return rc;
+        if (int rc = f.d_ref.alloc(pbytes)) return rc;
         if (int rc = d_sim.alloc((size_t)job.out_total * sizeof(int32_t))) return rc;
         if (int rc = d_diff.alloc((size_t)job.out_total * sizeof(int32_t))) return rc;
-        HS_HIP(hipMemsetAsync(d_alt.p, 0, pbytes ? pbytes : 8, stream));
-        HS_HIP(hipMemsetAsync(d_ref.p, 0, pbytes ? pbytes : 8, stream));
-        if (int rc = hs_snp_planes(d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(), d_sr.as<uint8_t>(), d_sa.as<uint8_t>(),
-                                   d_sc.as<int32_t>(), d_cb.as<int64_t>(), d_po.as<int64_t>(), d_w.as<int32_t>(), (int32_t)job.snp_ref.size(),
-                                   d_alt.as<uint64_t>(), d_ref.as<uint64_t>(), stream)) return rc;
-        EventPair ev; if (int rc = ev.init()) return rc;
-        HS_HIP(hipEventRecord(ev.a, stream));
-        if (int rc = simdiff_launch(d_alt.as<uint64_t>(), d_ref.as<uint64_t>(), d_po.as<int64_t>(), d_n.as<int32_t>(), d_w.as<int32_t>(),
-                                    d_oo.as<int64_t>(), job.n_reads, d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, t_c, t_i, t_j)) return rc;
-        HS_HIP(hipEventRecord(ev.b, stream));
-        float m = 0; if (int rc = ev.ms(&m)) return rc;   // also keeps the temporaries alive until the kernels are done
-        if (k_ms) *k_ms += m;
-        return HS_OK;
+        HS_HIP(hipMemsetAsync(f.d_alt.p, 0, pbytes ? pbytes : 8, stream));
+        HS_HIP(hipMemsetAsync(f.d_ref.p, 0, pbytes ? pbytes : 8, stream));
+        if (int rc = hs_snp_planes(d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(), f.d_sr.as<uint8_t>(), f.d_sa.as<uint8_t>(),
+                                   f.d_sc.as<int32_t>(), f.d_cb.as<int64_t>(), f.d_po.as<int64_t>(), f.d_w.as<int32_t>(), (int32_t)job.snp_ref.size(),
+                                   f.d_alt.as<uint64_t>(), f.d_ref.as<uint64_t>(), stream)) return rc;
+        if (int rc = f.ev.init()) return rc;
+        HS_HIP(hipEventRecord(f.ev.a, stream));
+        if (int rc = simdiff_launch(f.d_alt.as<uint64_t>(), f.d_ref.as<uint64_t>(), f.d_po.as<int64_t>(), f.d_n.as<int32_t>(), f.d_w.as<int32_t>(),
+                                    f.d_oo.as<int64_t>(), job.n_reads, d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, f.t_c, f.t_i, f.t_j)) return rc;
+        HS_HIP(hipEventRecord(f.ev.b, stream));
+        return HS_OK;   // not waited for: the stream orders K6 behind it, the host goes on planning the windows
     }
     int set_graphs(const hs::CwGraphSet& g) override {
         max_n = g.max_n;
@@ -1191,6 +1213,7 @@ struct HipSrOps : hs::SrDeviceOps {
     }
     int cw_chain(const hs::CwChain& ch, std::vector<int32_t>& labels, std::vector<int32_t>& final_labels, std::vector<uint8_t>& final_ok,
                  float k_ms[3]) override {
+        if (int rc = settle_simdiff()) return rc;   // (a batch without graph windows never called read_graphs)
         const int W = (int)ch.win_n.size();
         const int64_t n_inst = (int64_t)ch.seed_col.size();
         const int64_t total_n = ch.win_label_base.back();
