@@ -340,11 +340,8 @@ class PipelineGroups:
         t_1 = time.perf_counter()
         md = md[:Cn]
         # call_variants.cpp:1312-1315,1377: float sum in contig order / number of contigs with a positive distance
-        tot = np.float32(0); n_pos = 0
-        for v in md:
-            if v > 0:
-                tot = np.float32(tot + np.float32(v)); n_pos += 1
-        cv = {"mean_distance": md, "error_rate": float(np.float32(tot) / np.float32(n_pos)) if n_pos else float("nan")}
+        from .dist import mean_of_positive_f32
+        cv = {"mean_distance": md, "error_rate": mean_of_positive_f32(md)}
         e = error_rate_fn(cv) if error_rate_fn is not None else min(float("%g" % cv["error_rate"]), 0.15)
         if window_size <= 0:
             window_size = self.window_size(amplicon)

@@ -70,9 +70,9 @@ static void exact_top3(const uint8_t* code, int n, uint8_t& k0, uint8_t& k1, int
     rh.insert(0); rh.insert(1); rh.insert(2);
     uint8_t ord[260];
     const int m = rh.order(ord);
-    std::vector<std::pair<uint8_t, int>> v(m);
+    std::pair<uint8_t, int> v[260];   // (same std::sort call on the same sequence as the reference's vector: same arrangement of equal counts)
     for (int i = 0; i < m; ++i) v[i] = std::make_pair(ord[i], cnt[ord[i]]);
-    std::sort(v.begin(), v.end(), [](const std::pair<uint8_t, int>& a, const std::pair<uint8_t, int>& b) { return a.second > b.second; });
+    std::sort(v, v + m, [](const std::pair<uint8_t, int>& a, const std::pair<uint8_t, int>& b) { return a.second > b.second; });
     k0 = v[0].first; k1 = v[1].first; c0 = v[0].second; c1 = v[1].second; c2 = v[2].second;
 }
 

@@ -38,13 +38,17 @@ def global_error_rate(local_ids: Sequence[int], local_mean_distance: np.ndarray,
         full = full.to(dev)
         dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)   # every contig is owned by exactly one rank: exact
         full = full.cpu()
-    total = np.float32(0.0)
-    n = 0
-    for v in full.numpy():
-        if v > 0:
-            total = np.float32(total + v)
-            n += 1
-    return float(np.float32(total / np.float32(n))) if n else float("nan")
+    return mean_of_positive_f32(full.numpy())
+
+
+def mean_of_positive_f32(values) -> float:
+    """call_variants.cpp:1312-1315,1377: float32 running sum of the positive entries in index order / their count.
+    np.cumsum accumulates left to right in the array's dtype, i.e. exactly that running sum."""
+    v = np.asarray(values, dtype=np.float32)
+    v = v[v > 0]
+    if v.size == 0:
+        return float("nan")
+    return float(np.float32(np.cumsum(v, dtype=np.float32)[-1] / np.float32(v.size)))
 
 
 def gather_capacity(local_n: int, group=None) -> int:
