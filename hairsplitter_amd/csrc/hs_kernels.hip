@@ -344,15 +344,16 @@ __global__ __launch_bounds__(256) void k_pileup_packed(
         const uint32_t op = in_range ? cigar[oi] : 0xFu;
         const int code = in_range ? (int)(op & 15u) : 15;
         const OpAdv a = op_advances(op, in_range);
-        const int ev_inc = wave_scan_incl(a.ev), rd_inc = wave_scan_incl(a.rd), rf_inc = wave_scan_incl(a.rf);
+        const int ev_inc = wave_scan_incl(a.ev);
         const int ev_ex = ev_inc - a.ev;
         const int chunk_ev = __builtin_amdgcn_readlane(ev_inc, 63);
         const unsigned long long nzmask = __ballot(a.ev > 0);
         if (nzmask == 0ull) continue;                                        // a chunk of clips only
-        // cursors at the first event of the chunk (leading clips of the record are in front of it)
+        // cursors at the first event of the chunk: the chunk's own, plus what ops without events in front of the first
+        // event-owning op consume (the leading clips of a record; nothing in every other chunk)
         const int first_op = __builtin_ctzll(nzmask);
-        const int t0 = __builtin_amdgcn_readlane(t_cur + rd_inc - a.rd, first_op);
-        const int q0 = __builtin_amdgcn_readlane(q_cur + rf_inc - a.rf, first_op);
+        int t0 = t_cur, q0 = q_cur;
+        if (first_op > 0) { t0 += wave_sum_i32(lane < first_op ? a.rd : 0); q0 += wave_sum_i32(lane < first_op ? a.rf : 0); }
         const int type = code == 1 ? 1 : (code == 2 ? 2 : 0);
         const bool marks = a.ev > 0 && type != 0;                             // this op's events are I or D
         const int lo_el = e_first > ev_base ? e_first - ev_base : 0;
@@ -399,9 +400,12 @@ __global__ __launch_bounds__(256) void k_pileup_packed(
                 // byte b = number of D (I) among the lane's events before b (shift-adds: a 32-bit multiply is quarter rate)
                 const uint32_t d01 = opaque(isD + (isD << 8)), i01 = opaque(isI + (isI << 8));
                 const uint32_t dpre = opaque(d01 + (isD << 16)) << 8, ipre = opaque(i01 + (isI << 16)) << 8;
-                int nv = hi_el - e_l; nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);     // events of the lane inside the chunk / task
-                int ns = lo_commit - e_l; ns = ns < 0 ? 0 : (ns > 4 ? 4 : ns); // leading events that only warm the context up
-                commit_[u] = low_bytes(nv) & ~low_bytes(ns);
+                if (w0 + 256 <= hi_el && w0 >= lo_commit) commit_[u] = 0xffffffffu;   // wave-uniform: every event of the window is committed
+                else {
+                    int nv = hi_el - e_l; nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);     // events of the lane inside the chunk / task
+                    int ns = lo_commit - e_l; ns = ns < 0 ? 0 : (ns > 4 ? 4 : ns); // leading events that only warm the context up
+                    commit_[u] = low_bytes(nv) & ~low_bytes(ns);
+                }
                 // ---- the four read characters: the lane's non-D events consume consecutive read bases from tL on, so one
                 // dword holds them all; event b takes byte (b - #D before b) of it (+ d when the load was moved back to stay
                 // inside the read). Reverse strand: the dword is mirrored and complemented first. Unconditional: the address
