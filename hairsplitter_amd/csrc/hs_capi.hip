@@ -830,7 +830,7 @@ struct HipCvOps : hs::CvDeviceOps {
     hipStream_t stream = nullptr;
     explicit HipCvOps(hs_cv_batch* batch) : b(batch) {}
 
-    int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, std::vector<int64_t>& sel_gpos, std::vector<int32_t>& sel_depth,
+    int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, const int64_t** sel_gpos, const int32_t** sel_depth, size_t* n_sel_out,
                           float k_ms[4]) override {
         const bool tim = std::getenv("HS_TIMING") != nullptr;
         auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -875,15 +875,13 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = grow(b->h_stage_c, 64)) return rc;
         if (int rc = copy_d2h(b->h_stage_c.p, b->sel_count.p, sizeof(int32_t), stream)) return rc;
         n_sel = *(int32_t*)b->h_stage_c.p;
-        sel_gpos.resize((size_t)n_sel); sel_depth.resize((size_t)n_sel);
+        if (int rc = grow(b->h_stage_b, std::max<size_t>((size_t)n_sel, 1) * 12)) return rc;
+        char* hg = (char*)b->h_stage_b.p; char* hd = hg + (size_t)n_sel * 8;
         if (n_sel) {
-            if (int rc = grow(b->h_stage_b, (size_t)n_sel * 12)) return rc;
-            char* hg = (char*)b->h_stage_b.p; char* hd = hg + (size_t)n_sel * 8;
             HS_HIP(hipMemcpyAsync(hg, b->sel_gpos.p, (size_t)n_sel * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
             if (int rc = copy_d2h(hd, b->sel_depth.p, (size_t)n_sel * sizeof(int32_t), stream)) return rc;
-            std::memcpy(sel_gpos.data(), hg, (size_t)n_sel * sizeof(int64_t));
-            std::memcpy(sel_depth.data(), hd, (size_t)n_sel * sizeof(int32_t));
         }
+        *sel_gpos = (const int64_t*)hg; *sel_depth = (const int32_t*)hd; *n_sel_out = (size_t)n_sel;   // read in place by the caller
         const double t3 = now();
         if (int rc = e1.ms(&k_ms[0])) return rc;
         if (int rc = e2.ms(&k_ms[1])) return rc;

@@ -139,33 +139,34 @@ int cv_select(CvDeviceOps& dev, const CvMeta& b, CvSelection& sel) {
     const double t_start = now_ms();
     for (int k = 0; k < 4; ++k) sel.k_ms[k] = 0;   // pileup, column_stats, (gather_columns), cigar_scan
     sel.rec_stats.assign((size_t)NR * 4, 0);
-    std::vector<int64_t> sel_gpos;
-    std::vector<int32_t> sel_depth;
+    const int64_t* sel_gpos = nullptr;
+    const int32_t* sel_depth = nullptr;
+    size_t n_sel = 0;
     // interesting positions: second count >= 4 (everything that can become a SNP, see hs_host_cv.cpp), ordered by position
-    if (int rc = dev.pileup_and_select(sel.rec_stats, 4, sel_gpos, sel_depth, sel.k_ms)) return rc;
+    if (int rc = dev.pileup_and_select(sel.rec_stats, 4, &sel_gpos, &sel_depth, &n_sel, sel.k_ms)) return rc;
     const double t_k12_done = now_ms();
     sel.contig_sel_off.assign((size_t)C + 1, 0);
-    if (std::is_sorted(sel_gpos.begin(), sel_gpos.end())) {
+    if (std::is_sorted(sel_gpos, sel_gpos + n_sel)) {
         // the HIP implementation hands the list over sorted already: the contig boundaries by bisection, the three arrays
-        // filled per contig on the worker threads
-        sel.sel_contig.resize(sel_gpos.size()); sel.sel_pos.resize(sel_gpos.size());
-        sel.sel_depth.swap(sel_depth);
+        // filled per contig on the worker threads (straight from the staging buffer of the download)
+        sel.sel_contig.resize(n_sel); sel.sel_pos.resize(n_sel); sel.sel_depth.resize(n_sel);
         for (int c = 0; c <= C; ++c)
-            sel.contig_sel_off[(size_t)c] = (int64_t)(std::lower_bound(sel_gpos.begin(), sel_gpos.end(), b.contig_off[(size_t)c]) - sel_gpos.begin());
+            sel.contig_sel_off[(size_t)c] = (int64_t)(std::lower_bound(sel_gpos, sel_gpos + n_sel, b.contig_off[(size_t)c]) - sel_gpos);
         parallel_for(C, 8, [&](int c) {
             const int64_t base = b.contig_off[(size_t)c];
             for (int64_t i = sel.contig_sel_off[(size_t)c]; i < sel.contig_sel_off[(size_t)c + 1]; ++i) {
                 sel.sel_contig[(size_t)i] = c; sel.sel_pos[(size_t)i] = (int32_t)(sel_gpos[(size_t)i] - base);
+                sel.sel_depth[(size_t)i] = sel_depth[(size_t)i];
             }
         });
     } else {   // bucket by 256-position tile, then order the few entries of each tile
-        std::vector<size_t> order(sel_gpos.size());
+        std::vector<size_t> order(n_sel);
         const size_t n_tiles = (size_t)((b.total_len + 255) / 256);
         std::vector<uint32_t> start(n_tiles + 1, 0);
-        for (int64_t g : sel_gpos) start[(size_t)(g >> 8) + 1]++;
+        for (size_t i = 0; i < n_sel; ++i) start[(size_t)(sel_gpos[i] >> 8) + 1]++;
         for (size_t t = 0; t < n_tiles; ++t) start[t + 1] += start[t];
         std::vector<uint32_t> fill(start.begin(), start.end() - 1);
-        for (size_t i = 0; i < sel_gpos.size(); ++i) order[fill[(size_t)(sel_gpos[i] >> 8)]++] = i;
+        for (size_t i = 0; i < n_sel; ++i) order[fill[(size_t)(sel_gpos[i] >> 8)]++] = i;
         for (size_t t = 0; t < n_tiles; ++t)
             if (start[t + 1] - start[t] > 1)
                 std::sort(order.begin() + start[t], order.begin() + start[t + 1], [&](size_t x, size_t y) { return sel_gpos[x] < sel_gpos[y]; });

@@ -35,8 +35,9 @@ struct CvDeviceOps {
     // K0+K1 + K2: per-record {q_end, n_err, n_len, n_events}; the global positions (unordered) whose second count c1 is
     // > min_second, or == min_second with a zero third count, with their depth; k_ms = {cigar scan + pileup, column_stats}
     // k_ms[3] = cigar scan alone (k_ms[0] then is the pileup kernel alone)
-    virtual int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, std::vector<int64_t>& sel_gpos,
-                                  std::vector<int32_t>& sel_depth, float k_ms[4]) = 0;
+    // The selection arrays are owned by the implementation (pinned staging of the download) and stay valid until the next call.
+    virtual int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, const int64_t** sel_gpos,
+                                  const int32_t** sel_depth, size_t* n_sel, float k_ms[4]) = 0;
     // K3: columns of the selected positions (they stay on the device for K4 and fetch_columns), and K3b: their top-3
     // (tie = 1: the host must resolve the column in the reference's tie order). `top` is owned by the implementation and
     // stays valid until the next gather call or its destruction

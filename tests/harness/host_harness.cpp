@@ -31,8 +31,10 @@ struct OracleCvOps : hs::CvDeviceOps {
     std::vector<uint8_t> col_code;
     explicit OracleCvOps(const hs::CvFileInput& i) : in(i) {}
 
-    int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, std::vector<int64_t>& sel_gpos, std::vector<int32_t>& sel_depth,
-                          float k_ms[4]) override {
+    std::vector<int64_t> sel_gpos;
+    std::vector<int32_t> sel_depth;
+    int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, const int64_t** sel_gpos_out, const int32_t** sel_depth_out,
+                          size_t* n_sel_out, float k_ms[4]) override {
         k_ms[0] = k_ms[1] = k_ms[3] = 0;
         sel_gpos.clear(); sel_depth.clear();
         const int C = (int)in.contig_names.size();
@@ -75,6 +77,7 @@ struct OracleCvOps : hs::CvDeviceOps {
             }
             cols[(size_t)c] = std::move(m.cols);
         }
+        *sel_gpos_out = sel_gpos.data(); *sel_depth_out = sel_depth.data(); *n_sel_out = sel_gpos.size();
         return 0;
     }
     int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
