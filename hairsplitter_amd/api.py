@@ -355,8 +355,7 @@ class PipelineGroups:
                    "t_kernel_ms": [float(x) for x in st.t_kernel_cv_ms], "t_kernel_k4_ms": float(st.t_kernel_k4_ms),
                    "n_columns_extracted": int(st.n_columns_extracted), "n_columns_downloaded": int(st.n_columns_downloaded),
                    "n_columns_downloaded_late": int(st.n_columns_downloaded_late)})
-        sr = _sr_result_to_dict(sres, Cn)
-        lib.hs_sr_result_destroy(sres)
+        sr = _sr_result_to_dict(sres, Cn, take_ownership=True)   # the labels stay where the library put them
         sr["wall_ms"] = {"select": (t_1 - t_0) * 1e3, "between": (t_2 - t_1) * 1e3, "groups": (t_3 - t_2) * 1e3, "collect": (time.perf_counter() - t_3) * 1e3}
         return cv, sr
 
@@ -387,7 +386,22 @@ class PipelineGroups:
         self.batch.close()
 
 
-def _sr_result_to_dict(res, Cn):
+class _SrResultOwner:
+    """Frees an hs_sr_result when the last array that views its memory is gone"""
+
+    def __init__(self, res):
+        self.res = res
+
+    def __del__(self):
+        try:
+            load().hs_sr_result_destroy(self.res)
+        except Exception:
+            pass
+
+
+def _sr_result_to_dict(res, Cn, take_ownership=False):
+    """take_ownership: the labels (tens of MB per batch) are returned as a view of the C result instead of a copy; the
+    result is destroyed when that array (and every view of it) is gone, and the caller must not destroy it."""
     r = res.contents
     win_off = np.ctypeslib.as_array(r.win_off, (Cn + 1,)).copy()
     W = int(win_off[-1])
@@ -398,11 +412,17 @@ def _sr_result_to_dict(res, Cn):
         "win_start": np.ctypeslib.as_array(r.win_start, (max(W, 1),))[:W].copy(),
         "win_end": np.ctypeslib.as_array(r.win_end, (max(W, 1),))[:W].copy(),
         "label_off": label_off,
-        "labels": np.ctypeslib.as_array(r.labels, (max(NL, 1),))[:NL].copy(),
+        "labels": _owned_view_i32(res, r.labels, NL) if take_ownership else np.ctypeslib.as_array(r.labels, (max(NL, 1),))[:NL].copy(),
         "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "n_cw_instances": int(r.n_cw_instances),
         "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_graph_ms": float(r.t_kernel_graph_ms),
         "n_graph_rows_host": int(r.n_graph_rows_host), "n_windows_finished_on_host": int(r.n_windows_finished_on_host),
     }
+
+
+def _owned_view_i32(res, ptr, n):
+    buf = (C.c_int32 * max(n, 1)).from_address(C.addressof(ptr.contents))
+    buf._hs_owner = _SrResultOwner(res)      # the ndarray's base is this ctypes array, which keeps the owner alive
+    return np.ctypeslib.as_array(buf)[:n]
 
 
 def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory: bool = False, amplicon: bool = False,
