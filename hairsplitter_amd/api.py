@@ -343,9 +343,7 @@ class PipelineGroups:
         from .dist import mean_of_positive_f32
         cv = {"mean_distance": md, "error_rate": mean_of_positive_f32(md)}
         e = error_rate_fn(cv) if error_rate_fn is not None else min(float("%g" % cv["error_rate"]), 0.15)
-        if window_size <= 0:
-            window_size = self.window_size(amplicon)
-        sres = C.POINTER(SrResult)()
+        sres = C.POINTER(SrResult)()   # window_size <= 0: hs_pipeline_run chooses it over the whole batch (same rule as self.window_size())
         t_2 = time.perf_counter()
         _check(lib.hs_pipeline_run(self.handle, C.c_float(automatic_snp_threshold), C.c_float(e), C.c_float(rarest_strain_abundance),
                                    C.c_int32(1 if low_memory else 0), C.c_int32(1 if amplicon else 0), C.c_uint32(seed), C.c_int32(n_threads),

@@ -1559,6 +1559,20 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
     if (!p || !out || !p->sel) { set_error("hs_pipeline_run: run hs_pipeline_select first"); return HS_EINVAL; }
     const int G = (int)p->ranges.size();
     const int per = n_threads > 0 ? std::max(1, n_threads / G) : 0;
+    if (window_size <= 0) {
+        // choose the window size over the WHOLE batch (separate_reads.cpp:1466-1498 looks at every read of every contig): READ
+        // limits are (POS-1, POS + reference span) (input_output.cpp:503-511), `int sumLength` wraps
+        const hs_cv_batch* b = p->batch;
+        if (amplicon) { window_size = 0; for (int c = 0; c < b->n_contigs; ++c) window_size = std::max<int32_t>(window_size, (int32_t)(b->contig_off[(size_t)c + 1] - b->contig_off[(size_t)c])); }
+        else {
+            uint32_t sum = 0; int above = 0;
+            for (int64_t v : b->rec_refspan) { const int len = (int)v + 2; sum += (uint32_t)len; above += len > 4000; }
+            const double mean = b->rec_refspan.empty() ? 4000.0 : (int32_t)sum / double(b->rec_refspan.size());
+            window_size = 2000;
+            if (above < 20 && mean < 4000 && mean > 2000) window_size = 1000;
+            else if (above < 20 && mean < 2000) window_size = 500;
+        }
+    }
     std::vector<hs_sr_result*> parts((size_t)G, nullptr);
     const int rc = p->run([&](int g) {
         const int c0 = p->ranges[(size_t)g].first, c1 = p->ranges[(size_t)g].second;

@@ -362,6 +362,7 @@ typedef struct hs_pipeline_stats {
 } hs_pipeline_stats;
 int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out);
 int hs_pipeline_select(hs_pipeline* p, float* mean_distance /* [C] out */, hs_pipeline_stats* stats);
+/* window_size <= 0: chosen over the whole batch as separate_reads.cpp:1466-1498 does over the whole .col file */
 int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_rate, float rarest_strain_abundance, int32_t low_memory,
                     int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out,
                     hs_pipeline_stats* stats);
