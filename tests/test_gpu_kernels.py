@@ -85,6 +85,42 @@ def test_pileup_records_with_a_clip_between_aligned_bases(built):
         assert np.array_equal(stats.cpu().numpy()[:, :3], o_stats[:, :3]), ev
 
 
+def test_pileup_tiny_reads_and_contigs(built):
+    """Reads and contigs shorter than the four bytes a lane of the packed form loads at once (the loads are moved back into
+    the sequence, never past its first byte), single-event records, records that start at the last base of the contig"""
+    from hairsplitter_amd import api, synth
+    rng = np.random.default_rng(3)
+    M, I, D, S = synth.OP_M, synth.OP_I, synth.OP_D, synth.OP_S
+
+    def cig(*ops):
+        return np.array([(n << 4) | o for n, o in ops], dtype=np.uint32)
+
+    def contig(name, L, recs):
+        seq = rng.integers(0, 4, size=L).astype(np.uint8)
+        reads, names, alns = [], [], []
+        for k, (pos, strand, ops) in enumerate(recs):
+            c = cig(*ops)
+            rl = int(sum(n for n, o in ops if o in (M, I, S)))
+            reads.append(rng.integers(0, 4, size=max(rl, 1)).astype(np.uint8)[:rl] if rl else np.zeros(0, np.uint8))
+            names.append(f"{name}_r{k}")
+            alns.append(synth.Alignment(k, pos, strand, c, 0))
+        return synth.ContigData(name, seq, reads, names, alns, np.zeros(len(recs), np.int32))
+
+    cs = [contig("t3", 3, [(0, True, [(3, M)]), (1, False, [(2, M)]), (2, True, [(1, M)]), (0, True, [(1, M), (1, I), (1, M)]),
+                           (0, False, [(1, M), (1, D), (1, M)]), (2, True, [(1, M), (2, M)]), (0, True, [(1, S), (2, M)])]),
+          contig("t1", 1, [(0, True, [(1, M)]), (0, False, [(1, M)]), (0, True, [(1, I), (1, M)])]),
+          contig("t9", 9, [(0, True, [(2, M), (3, D), (2, M)]), (5, False, [(1, M), (2, I), (3, M)]), (8, True, [(1, M)]),
+                           (7, False, [(3, M)]), (0, True, [(9, M)]), (3, False, [(1, M), (1, I), (1, D), (1, M), (1, I), (1, M)])]),
+          synth.make_contig(43, 3, 3_000, 2, 0.01, 20, "ont")]
+    flat = api.FlatBatch(cs)
+    t = api.device_tensors(flat)
+    o_pile, o_stats, _ = ol.pileup(flat)
+    for ev in (4096, 64, 1 << 30):
+        pile, stats = api.pileup(t, flat, ev_per_task=ev)
+        assert np.array_equal(pile.cpu().numpy(), o_pile), ev
+        assert np.array_equal(stats.cpu().numpy()[:, :3], o_stats[:, :3]), ev
+
+
 def test_column_stats_counts(batch):
     """K2 == histogram of call_variants.cpp:477-501: sorted counts, depth; keys wherever they are unambiguous."""
     from hairsplitter_amd import api
