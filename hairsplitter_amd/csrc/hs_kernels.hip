@@ -335,35 +335,42 @@ __global__ __launch_bounds__(256) void k_pileup_packed(
 
     int p1 = 2, p2 = 1;                  // previous char 'G', the one before 'C' (call_variants.cpp:212-214 after one shift)
     uint32_t nerr_l = 0, nlen_l = 0;     // per-lane counters, reduced at the end
-    for (int k = klo; k < n_chunks; ++k) {
+    // Two 64-op chunks of K0's table per step (ops A = lane, B = lane + 64): a chunk of ONT ops is only ~2.5 windows of events,
+    // so pairing them halves the per-chunk prologue and the half-empty window at the end of each
+    for (int k = klo & ~1; k < n_chunks; k += 2) {
         const int ev_base = cs[4 * k + 0];
         if (ev_base >= e1) break;
         const int t_cur = cs[4 * k + 1], q_cur = cs[4 * k + 2];
-        const int64_t oi = cig0 + ((int64_t)k << 6) + lane;
-        const bool in_range = oi < cig1;
-        const uint32_t op = in_range ? cigar[oi] : 0xFu;
-        const int code = in_range ? (int)(op & 15u) : 15;
-        const OpAdv a = op_advances(op, in_range);
-        const int ev_inc = wave_scan_incl(a.ev);
-        const int ev_ex = ev_inc - a.ev;
-        const int chunk_ev = __builtin_amdgcn_readlane(ev_inc, 63);
-        const unsigned long long nzmask = __ballot(a.ev > 0);
-        if (nzmask == 0ull) continue;                                        // a chunk of clips only
-        // cursors at the first event of the chunk: the chunk's own, plus what ops without events in front of the first
-        // event-owning op consume (the leading clips of a record; nothing in every other chunk)
-        const int first_op = __builtin_ctzll(nzmask);
+        const int64_t oiA = cig0 + ((int64_t)k << 6) + lane, oiB = oiA + 64;
+        const bool inA = oiA < cig1, inB = oiB < cig1;
+        const uint32_t opA = inA ? cigar[oiA] : 0xFu, opB = inB ? cigar[oiB] : 0xFu;
+        const int codeA = inA ? (int)(opA & 15u) : 15, codeB = inB ? (int)(opB & 15u) : 15;
+        const OpAdv aA = op_advances(opA, inA), aB = op_advances(opB, inB);
+        const int evA_inc = wave_scan_incl(aA.ev);
+        const int evB_inc = wave_scan_incl(aB.ev) + __builtin_amdgcn_readlane(evA_inc, 63);
+        const int evA_ex = evA_inc - aA.ev, evB_ex = evB_inc - aB.ev;
+        const int chunk_ev = __builtin_amdgcn_readlane(evB_inc, 63);
+        const unsigned long long nzA = __ballot(aA.ev > 0), nzB = __ballot(aB.ev > 0);
+        if ((nzA | nzB) == 0ull) continue;                                    // clips only
+        // cursors at the first event of the step: the table's, plus what ops without events in front of the first
+        // event-owning op consume (the leading clips of a record; nothing anywhere else)
+        const int leadA = nzA ? __builtin_ctzll(nzA) : 64, leadB = nzA ? 0 : __builtin_ctzll(nzB);
         int t0 = t_cur, q0 = q_cur;
-        if (first_op > 0) { t0 += wave_sum_i32(lane < first_op ? a.rd : 0); q0 += wave_sum_i32(lane < first_op ? a.rf : 0); }
-        const int type = code == 1 ? 1 : (code == 2 ? 2 : 0);
-        const bool marks = a.ev > 0 && type != 0;                             // this op's events are I or D
+        if (leadA > 0 || leadB > 0) {
+            t0 += wave_sum_i32((lane < leadA ? aA.rd : 0) + (lane < leadB ? aB.rd : 0));
+            q0 += wave_sum_i32((lane < leadA ? aA.rf : 0) + (lane < leadB ? aB.rf : 0));
+        }
+        const int typeA = codeA == 1 ? 1 : (codeA == 2 ? 2 : 0), typeB = codeB == 1 ? 1 : (codeB == 2 ? 2 : 0);
+        const bool marksA = aA.ev > 0 && typeA != 0, marksB = aB.ev > 0 && typeB != 0;   // the op's events are I or D
         const int lo_el = e_first > ev_base ? e_first - ev_base : 0;
         const int hi_el = (e1 - ev_base) < chunk_ev ? (e1 - ev_base) : chunk_ev;
         const int lo_commit = e0 - ev_base;                                   // events before it only warm the 3-mer context up
         int tW = t0 + lo_el, qW = q0 + lo_el;                                 // cursors at the first event of the window
-        if (lo_el > 0) {                                                      // the task starts inside the chunk
-            int before = lo_el - ev_ex; before = before < 0 ? 0 : (before > a.ev ? a.ev : before);
-            tW -= wave_sum_i32(marks && type == 2 ? before : 0);
-            qW -= wave_sum_i32(marks && type == 1 ? before : 0);
+        if (lo_el > 0) {                                                      // the task starts inside the step
+            int bA = lo_el - evA_ex; bA = bA < 0 ? 0 : (bA > aA.ev ? aA.ev : bA);
+            int bB = lo_el - evB_ex; bB = bB < 0 ? 0 : (bB > aB.ev ? aB.ev : bB);
+            tW -= wave_sum_i32((marksA && typeA == 2 ? bA : 0) + (marksB && typeB == 2 ? bB : 0));
+            qW -= wave_sum_i32((marksA && typeA == 1 ? bA : 0) + (marksB && typeB == 1 ? bB : 0));
         }
         // HS_K1_WINDOWS windows of 256 events per iteration (measured: 1 -> 1.76 ms, 2 -> 1.61, 3 -> 1.63, 4 -> 1.62, 8 -> 3.0 per
         // 1.28 G events): one type map for all of them, and the loads of every window issued
@@ -374,10 +381,16 @@ __global__ __launch_bounds__(256) void k_pileup_packed(
             for (int u = 0; u < NW; ++u) s_type[wv][u * 64 + lane] = 0u;
             wave_lds_sync();
             {   // the I / D ops mark their events of this iteration
-                int k0 = eb - ev_ex; k0 = k0 < 0 ? 0 : k0;
-                int k1 = eb + 256 * NW - ev_ex; k1 = k1 > a.ev ? a.ev : k1;
-                if (!marks) k1 = k0;
-                for (int kk = k0; __ballot(kk < k1) != 0ull; ++kk) if (kk < k1) types[ev_ex + kk - eb] = (uint8_t)type;
+                int a0 = eb - evA_ex; a0 = a0 < 0 ? 0 : a0;
+                int a1 = eb + 256 * NW - evA_ex; a1 = a1 > aA.ev ? aA.ev : a1;
+                if (!marksA) a1 = a0;
+                int b0 = eb - evB_ex; b0 = b0 < 0 ? 0 : b0;
+                int b1 = eb + 256 * NW - evB_ex; b1 = b1 > aB.ev ? aB.ev : b1;
+                if (!marksB) b1 = b0;
+                for (; __ballot(a0 < a1 || b0 < b1) != 0ull; ++a0, ++b0) {
+                    if (a0 < a1) types[evA_ex + a0 - eb] = (uint8_t)typeA;
+                    if (b0 < b1) types[evB_ex + b0 - eb] = (uint8_t)typeB;
+                }
             }
             wave_lds_sync();
             uint32_t isI_[NW], isD_[NW], ipre_[NW], rb_[NW], ref_[NW], inl_[NW], commit_[NW];
