@@ -152,7 +152,7 @@ int cv_select(CvDeviceOps& dev, const CvMeta& b, CvSelection& sel) {
         sel.sel_contig.resize(n_sel); sel.sel_pos.resize(n_sel); sel.sel_depth.resize(n_sel);
         for (int c = 0; c <= C; ++c)
             sel.contig_sel_off[(size_t)c] = (int64_t)(std::lower_bound(sel_gpos, sel_gpos + n_sel, b.contig_off[(size_t)c]) - sel_gpos);
-        parallel_for(C, 8, [&](int c) {
+        parallel_for(C, 16, [&](int c) {   // (the host is idle while the streaming pass runs)
             const int64_t base = b.contig_off[(size_t)c];
             for (int64_t i = sel.contig_sel_off[(size_t)c]; i < sel.contig_sel_off[(size_t)c + 1]; ++i) {
                 sel.sel_contig[(size_t)i] = c; sel.sel_pos[(size_t)i] = (int32_t)(sel_gpos[(size_t)i] - base);

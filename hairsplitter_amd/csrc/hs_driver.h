@@ -54,7 +54,7 @@ struct CvDeviceOps {
 // result of the whole-batch streaming pass (K0-K2): per-record counters and the interesting positions by (contig, position)
 struct CvSelection {
     std::vector<int32_t> rec_stats;
-    std::vector<int32_t> sel_contig, sel_pos, sel_depth;
+    std::vector<int32_t, NoInitAlloc<int32_t>> sel_contig, sel_pos, sel_depth;   // every element is written right after the resize
     std::vector<int64_t> contig_sel_off;   // [C+1]
     float k_ms[4] = {0, 0, 0, 0};          // pileup, column_stats, -, cigar_scan
     double t_device_ms = 0, t_host_ms = 0;
