@@ -1296,24 +1296,28 @@ struct HipSrOps : hs::SrDeviceOps {
                                d_ok.as<uint8_t>());
             HS_HIP(hipGetLastError());
         }
-        labels.resize((size_t)total_n);
         {
+            // With K8 on the device the finished labels and the per-window verdict come back first; the labels of the third wave
+            // are only fetched when some window has to be finished by the host code (few or none)
             HBuf h, h2, h3;
-            if (int rc = h.alloc((size_t)total_n * sizeof(int32_t))) return rc;
-            HS_HIP(hipMemcpyAsync(h.p, d_lab3.p, (size_t)total_n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            bool need_chain_labels = !finish;
             if (finish) {
                 if (int rc = h2.alloc((size_t)total_n * sizeof(int32_t))) return rc;
                 if (int rc = h3.alloc((size_t)W)) return rc;
                 HS_HIP(hipMemcpyAsync(h2.p, d_final.p, (size_t)total_n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
                 HS_HIP(hipMemcpyAsync(h3.p, d_ok.p, (size_t)W, hipMemcpyDeviceToHost, stream));
-            }
-            if (int rc = stream_wait(stream)) return rc;
-            std::memcpy(labels.data(), h.p, (size_t)total_n * sizeof(int32_t));
-            if (finish) {
+                if (int rc = stream_wait(stream)) return rc;
                 final_labels.resize((size_t)total_n); final_ok.resize((size_t)W);
                 std::memcpy(final_labels.data(), h2.p, (size_t)total_n * sizeof(int32_t));
                 std::memcpy(final_ok.data(), h3.p, (size_t)W);
+                for (uint8_t ok : final_ok) if (!ok) { need_chain_labels = true; break; }
             }
+            if (need_chain_labels) {
+                labels.resize((size_t)total_n);
+                if (int rc = h.alloc((size_t)total_n * sizeof(int32_t))) return rc;
+                if (int rc = copy_d2h(h.p, d_lab3.p, (size_t)total_n * sizeof(int32_t), stream)) return rc;
+                std::memcpy(labels.data(), h.p, (size_t)total_n * sizeof(int32_t));
+            } else labels.clear();
         }
         float m = 0;
         if (int rc = e1.ms(&m)) return rc; k_ms[0] += m;

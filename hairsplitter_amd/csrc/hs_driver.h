@@ -126,6 +126,7 @@ struct SrDeviceOps {
     virtual int read_graphs(const ReadGraphJob& job, ReadGraphResult& res, float* k_ms) = 0;
     // labels = what the third wave leaves (N per window). If the implementation also ran K8, final_labels holds the finished
     // labels and final_ok[w] != 0 marks the windows it could finish (the others go through the host code); else both stay empty.
+    // An implementation that finished EVERY window may leave `labels` empty (nobody reads them then).
     virtual int cw_chain(const CwChain& chain, std::vector<int32_t>& labels, std::vector<int32_t>& final_labels,
                          std::vector<uint8_t>& final_ok, float k_ms[3]) = 0;
     // K5a + K5: bit-planes from the SNP columns, then sim / diff for every contig with n_reads[c] > 0. The columns (the same
