@@ -978,11 +978,14 @@ struct HipCvOps : hs::CvDeviceOps {
 
 // HIP implementation of the stage-4 device interface
 // K6 driver: rows on the device, the few std::sort-dependent rows on the host, CSR on the device (see hs_kernels_graph.hip)
+// keep_dev / keep_host (both or neither): the caller takes over the neighbour array on the device and its pinned host copy;
+// the result then points at the latter (nbr_view) instead of holding another copy
 static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const std::vector<int64_t>& ctg_out_off, const std::vector<int32_t>& ctg_n,
-                           const hs::ReadGraphJob& job, hs::ReadGraphResult& res, hipStream_t stream, float* k_ms) {
+                           const hs::ReadGraphJob& job, hs::ReadGraphResult& res, hipStream_t stream, float* k_ms,
+                           DBuf* keep_dev = nullptr, HBuf* keep_host = nullptr) {
     const int W = (int)job.win_contig.size();
     const int64_t rows64 = job.win_mask_off.empty() ? 0 : job.win_mask_off.back();
-    res.nbr_off.assign((size_t)rows64 + 1, 0); res.nbr.clear(); res.rows_resolved_on_host = 0;
+    res.nbr_off.assign((size_t)rows64 + 1, 0); res.nbr.clear(); res.nbr_view = nullptr; res.rows_resolved_on_host = 0;
     if (rows64 == 0) return HS_OK;
     if (rows64 > 0x7fffffff) { set_error("read_graphs: too many rows"); return HS_EINVAL; }
     const int rows = (int)rows64;
@@ -1095,7 +1098,8 @@ static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const st
     if (int rc = d2h_pinned(res.nbr_off.data(), d_no.p, ((size_t)rows + 1) * 8, stream)) return rc;
     if (int rc_w = stream_wait(stream)) return rc_w;
     const int64_t total = res.nbr_off.back();
-    res.nbr.resize((size_t)total);
+    const bool keep = keep_dev && keep_host;
+    if (!keep) res.nbr.resize((size_t)total);
     if (total > 0) {
         if (int rc = d_nbr.alloc((size_t)total * 4)) return rc;
         hipLaunchKernelGGL(hsdev::k_read_graph_fill, dim3((rows + 255) / 256), dim3(256), 0, stream, d_bits.as<unsigned long long>(), d_rw.as<int32_t>(),
@@ -1104,7 +1108,11 @@ static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const st
         HBuf hb; if (int rc = hb.alloc((size_t)total * 4)) return rc;
         HS_HIP(hipMemcpyAsync(hb.p, d_nbr.p, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
         if (int rc_w = stream_wait(stream)) return rc_w;
-        std::memcpy(res.nbr.data(), hb.p, (size_t)total * 4);
+        if (keep) {
+            std::swap(keep_dev->p, d_nbr.p); std::swap(keep_dev->cap, d_nbr.cap); std::swap(keep_dev->bytes, d_nbr.bytes); std::swap(keep_dev->view, d_nbr.view);
+            std::swap(keep_host->p, hb.p); std::swap(keep_host->cap, hb.cap);
+            res.nbr_view = (const int32_t*)keep_host->p;
+        } else std::memcpy(res.nbr.data(), hb.p, (size_t)total * 4);
     }
     float m = 0; if (int rc = ev.ms(&m)) return rc;
     if (k_ms) *k_ms += m;
@@ -1140,7 +1148,7 @@ struct HipSrOps : hs::SrDeviceOps {
 
     int read_graphs(const hs::ReadGraphJob& job, hs::ReadGraphResult& res, float* k_ms) override {
         if (!d_sim.p) { set_error("read_graphs before simdiff"); return HS_EINVAL; }
-        const int rc = read_graphs_run(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, job, res, stream, k_ms);
+        const int rc = read_graphs_run(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, job, res, stream, k_ms, &d_rows_nbr, &h_rows_nbr);
         const int rc2 = settle_simdiff();   // K6 came after K5 on the stream and has been waited for
         return rc ? rc : rc2;
     }
@@ -1186,10 +1194,18 @@ struct HipSrOps : hs::SrDeviceOps {
         HS_HIP(hipEventRecord(f.ev.b, stream));
         return HS_OK;   // not waited for: the stream orders K6 behind it, the host goes on planning the windows
     }
+    DBuf d_rows_nbr;                          // neighbour array of the last K6 pass (the graph set may be slices of it)
+    HBuf h_rows_nbr;                          // and its pinned host copy (what ReadGraphResult::nbr_view points at)
+    bool keeps_graph_rows() const override { return true; }
     int set_graphs(const hs::CwGraphSet& g) override {
         max_n = g.max_n;
         graph_pack.add(g.adj_off, d_adj_off);
-        graph_pack.add(g.adj, d_adj);
+        if (g.adj_is_graph_rows) {
+            if (d_adj.p && !d_adj.view) pool().put(false, d_adj.p, d_adj.cap);
+            d_adj.p = d_rows_nbr.p; d_adj.bytes = d_rows_nbr.bytes; d_adj.cap = 0; d_adj.view = true;   // a view: d_rows_nbr owns the memory
+        } else graph_pack.add(g.adj, d_adj);
+        if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] sr graph set: %zu graphs, adjacency %s\n", g.graph_n.size(),
+                                                   g.adj_is_graph_rows ? "= slices of the K6 neighbour array on the device" : "uploaded");
         graph_pack.add(g.graph_off_base, d_gob);
         graph_pack.add(g.graph_adj_base, d_gab);
         graph_pack.add(g.graph_n, d_gn);

@@ -487,7 +487,8 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
             parallel_for((int)who.size(), n_threads, [&](int i) {
                 const int64_t m0 = job.win_mask_off[(size_t)i], m1 = job.win_mask_off[(size_t)i + 1];
                 sr_set_window_graph(st[(size_t)who[(size_t)i].first], who[(size_t)i].second, job.mask_ids.data() + m0, (int)(m1 - m0),
-                                    res.nbr_off.data() + m0, res.nbr.data());
+                                    res.nbr_off.data() + m0, res.nbr_data());
+                st[(size_t)who[(size_t)i].first].windows[(size_t)who[(size_t)i].second].rows_adj_base = res.nbr_off[(size_t)m0];
             });
         }
         // create_read_graph_low_memory (-l, or coverage > 1000): O(N^2 S) per window on the host, one task per window
@@ -506,9 +507,16 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         gs.perm.insert(gs.perm.end(), s.perm.begin(), s.perm.end());
         graph_id[(size_t)c].assign(s.graphs.size(), -1);
     }
-    // first the layout (serial: a few integers per graph), then the copies on the worker threads
+    // first the layout (serial: a few integers per graph), then the copies on the worker threads. When every graph came out
+    // of the device pass and the implementation still holds that pass's neighbour array, the adjacency is not copied at all:
+    // a graph's lists are a slice of that array
     struct GraphSlot { int c, lg; const SrWindowPlan* w; int64_t off_base, adj_base, mask_base; };
     std::vector<GraphSlot> slots;
+    bool alias_rows = dev.keeps_graph_rows();
+    for (int c = 0; c < C && alias_rows; ++c)
+        for (auto& w : st[(size_t)c].windows)
+            if (w.has_snps && (w.rows_adj_base < 0 || w.graph_final != w.graph_now)) { alias_rows = false; break; }
+    gs.adj_is_graph_rows = alias_rows;
     {
         int64_t off_total = 0, adj_total = 0, mask_total = 0;
         for (int c = 0; c < C; ++c) {
@@ -520,8 +528,8 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
                     if (graph_id[(size_t)c][(size_t)lg] >= 0) continue;
                     const SrGraph& g = s.graphs[(size_t)lg];
                     graph_id[(size_t)c][(size_t)lg] = (int)slots.size();
-                    slots.push_back(GraphSlot{c, lg, &w, off_total, adj_total, mask_total});
-                    off_total += (int64_t)g.off.size(); adj_total += (int64_t)g.adj.size(); mask_total += (int64_t)w.mask.size();
+                    slots.push_back(GraphSlot{c, lg, &w, off_total, alias_rows ? w.rows_adj_base : adj_total, mask_total});
+                    off_total += (int64_t)g.off.size(); adj_total += alias_rows ? 0 : (int64_t)g.adj.size(); mask_total += (int64_t)w.mask.size();
                     gs.max_n = std::max(gs.max_n, s.N);
                 }
             }
@@ -536,7 +544,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
             gs.graph_off_base[(size_t)i] = sl.off_base; gs.graph_adj_base[(size_t)i] = sl.adj_base;
             gs.graph_n[(size_t)i] = s.N; gs.perm_base_of_graph[(size_t)i] = perm_base_of_contig[(size_t)sl.c];
             std::copy(g.off.begin(), g.off.end(), gs.adj_off.begin() + sl.off_base);
-            std::copy(g.adj.begin(), g.adj.end(), gs.adj.begin() + sl.adj_base);
+            if (!alias_rows) std::copy(g.adj.begin(), g.adj.end(), gs.adj.begin() + sl.adj_base);
             std::copy(sl.w->mask.begin(), sl.w->mask.end(), gs.mask.begin() + sl.mask_base);
         });
     }

@@ -69,6 +69,9 @@ struct CwGraphSet {                   // every window graph of the batch, flatte
     std::vector<int64_t> graph_off_base, graph_adj_base, perm_base_of_graph;
     std::vector<uint8_t> mask;
     int max_n = 1;
+    // true: `adj` is left empty and graph_adj_base indexes the neighbour array of the last read_graphs() call, which the
+    // implementation still holds on the device (only offered to implementations whose keeps_graph_rows() is true)
+    bool adj_is_graph_rows = false;
 };
 struct CwWave {                       // one batched launch of the Chinese-Whispers kernel
     std::vector<int32_t> inst_graph;
@@ -117,6 +120,8 @@ struct ReadGraphJob {
 struct ReadGraphResult {                 // neighbour lists (ascending read ids) of every masked read, window after window
     std::vector<int64_t> nbr_off;        // [rows+1], row = position in mask_ids
     std::vector<int32_t> nbr;
+    const int32_t* nbr_view = nullptr;   // set instead of `nbr` by an implementation that keeps the array itself (until its next call)
+    const int32_t* nbr_data() const { return nbr_view ? nbr_view : nbr.data(); }
     int64_t rows_resolved_on_host = 0;   // rows whose cut-off fell inside a run of equal distances (std::sort order decides)
 };
 
@@ -124,6 +129,8 @@ struct SrDeviceOps {
     virtual ~SrDeviceOps() {}
     // K6: create_read_graph_matrix for every window of the job
     virtual int read_graphs(const ReadGraphJob& job, ReadGraphResult& res, float* k_ms) = 0;
+    // whether the neighbour array of the last read_graphs() stays available to set_graphs() (CwGraphSet::adj_is_graph_rows)
+    virtual bool keeps_graph_rows() const { return false; }
     // labels = what the third wave leaves (N per window). If the implementation also ran K8, final_labels holds the finished
     // labels and final_ok[w] != 0 marks the windows it could finish (the others go through the host code); else both stay empty.
     // An implementation that finished EVERY window may leave `labels` empty (nobody reads them then).

@@ -65,6 +65,7 @@ struct SrWindowPlan {
     std::vector<int32_t> mask_ids;   // the reads of the mask, ascending
     std::vector<int32_t> labels;     // final labels [N]
     int graph_now = -1;              // graph built for this window (adjacency or neighbour list)
+    int64_t rows_adj_base = -1;      // where the window's neighbour lists start in the device pass's array (-1: built on the host)
     int graph_final = -1;            // graph finalize_clustering sees (separate_reads.cpp:1708 quirk)
     std::vector<int32_t> local_snps; // SNP indices whose allele seeds a local Chinese-Whispers run
     int final_lo = 0, final_hi = 0;  // [posstart, posend) handed to merge_wrongly_split_haplotypes
