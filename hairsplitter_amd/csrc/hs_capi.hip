@@ -1534,18 +1534,30 @@ static hs_sr_result* concat_sr_parts(hs_pipeline* p, std::vector<hs_sr_result*>&
     R->labels = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, NL) * sizeof(int32_t));
     int64_t w0 = 0, l0 = 0; int c0 = 0;
     R->win_off[0] = 0; R->label_off[0] = 0;
-    for (hs_sr_result* r : parts) {
+    std::vector<int64_t> part_l0(parts.size(), 0);
+    for (size_t pi = 0; pi < parts.size(); ++pi) {
+        hs_sr_result* r = parts[pi];
         const int64_t w = r->win_off[r->n_contigs], nl = r->label_off[w];
         for (int c = 0; c < r->n_contigs; ++c) R->win_off[c0 + c + 1] = w0 + r->win_off[c + 1];
         if (w) { std::memcpy(R->win_start + w0, r->win_start, (size_t)w * sizeof(int32_t)); std::memcpy(R->win_end + w0, r->win_end, (size_t)w * sizeof(int32_t)); }
         for (int64_t k = 0; k < w; ++k) R->label_off[w0 + k + 1] = l0 + r->label_off[k + 1];
-        if (nl) std::memcpy(R->labels + l0, r->labels, (size_t)nl * sizeof(int32_t));
+        part_l0[pi] = l0;
         R->t_device_ms += r->t_device_ms; R->t_host_ms += r->t_host_ms; R->n_cw_instances += r->n_cw_instances;
         for (int k = 0; k < 4; ++k) R->t_kernel_ms[k] += r->t_kernel_ms[k];
         R->t_kernel_graph_ms += r->t_kernel_graph_ms; R->n_graph_rows_host += r->n_graph_rows_host; R->n_windows_finished_on_host += r->n_windows_finished_on_host;
         w0 += w; l0 += nl; c0 += r->n_contigs;
-        hs::free_sr_result(r);
     }
+    // the labels (tens of MB per batch): every part in a few pieces, on the caller's worker threads
+    {
+        const int pieces = 4;
+        hs::hs_parallel_for((int)parts.size() * pieces, host_threads(), [&](int i) {
+            const hs_sr_result* r = parts[(size_t)(i / pieces)];
+            const int64_t nl = r->label_off[r->win_off[r->n_contigs]];
+            const int64_t a = nl * (i % pieces) / pieces, b = nl * (i % pieces + 1) / pieces;
+            if (b > a) std::memcpy(R->labels + part_l0[(size_t)(i / pieces)] + a, r->labels + a, (size_t)(b - a) * sizeof(int32_t));
+        });
+    }
+    for (hs_sr_result* r : parts) hs::free_sr_result(r);
     if (st) {
         st->n_cw_instances = R->n_cw_instances; st->n_graph_rows_host = R->n_graph_rows_host;
         st->t_device_ms += R->t_device_ms; st->t_host_ms += R->t_host_ms;

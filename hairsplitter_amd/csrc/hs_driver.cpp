@@ -660,17 +660,21 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     hs_sr_result* R = (hs_sr_result*)std::calloc(1, sizeof(hs_sr_result));
     R->n_contigs = C;
     std::vector<int64_t> win_off((size_t)C + 1, 0), label_off(1, 0);
-    std::vector<int32_t> ws, we, labels;
+    std::vector<int32_t> ws, we;
+    std::vector<const std::vector<int32_t>*> wl;
     for (int c = 0; c < C; ++c) {
         for (auto& w : st[(size_t)c].windows) {
             ws.push_back(w.start); we.push_back(w.end);
-            labels.insert(labels.end(), w.labels.begin(), w.labels.end());
-            label_off.push_back((int64_t)labels.size());
+            wl.push_back(&w.labels);
+            label_off.push_back(label_off.back() + (int64_t)w.labels.size());
         }
         win_off[(size_t)c + 1] = (int64_t)ws.size();
     }
     R->win_off = dup_vec(win_off); R->win_start = dup_vec(ws); R->win_end = dup_vec(we); R->label_off = dup_vec(label_off);
-    R->labels = dup_vec(labels);
+    R->labels = (int32_t*)std::malloc(std::max<size_t>(1, (size_t)label_off.back()) * sizeof(int32_t));
+    parallel_for((int)wl.size(), n_threads, [&](int i) {   // the windows' labels straight into the result array
+        if (!wl[(size_t)i]->empty()) std::memcpy(R->labels + label_off[(size_t)i], wl[(size_t)i]->data(), wl[(size_t)i]->size() * sizeof(int32_t));
+    });
     laps.lap("result");
     R->n_cw_instances = n_cw;
     R->t_kernel_graph_ms = k6_ms; R->n_graph_rows_host = rows_on_host; R->n_windows_finished_on_host = final_ok.empty() ? (int64_t)ch.win_n.size() : n_finish_host;
