@@ -425,26 +425,37 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         ch.col_off.assign(1, 0);
         int64_t n_ent = 0, n_col = 0;
         for (int c = 0; c < C; ++c) { n_col += contigs[c].n_snps; if (contigs[c].n_snps) n_ent += contigs[c].col_off[contigs[c].n_snps] - contigs[c].col_off[0]; }
-        ch.col_off.reserve((size_t)n_col + 1); ch.col_idx.reserve((size_t)n_ent); ch.col_code.reserve((size_t)n_ent);
-        job.snp_ref.reserve((size_t)n_col); job.snp_alt.reserve((size_t)n_col); job.snp_contig.reserve((size_t)n_col);
-        for (int c = 0; c < C; ++c) {
-            col_base_of_contig[(size_t)c] = (int64_t)ch.col_off.size() - 1;
-            job.contig_snp_base[(size_t)c] = col_base_of_contig[(size_t)c];
-            const hs_sr_contig& hc = contigs[c];
-            if (hc.n_snps == 0) continue;
-            const int64_t e_base = (int64_t)ch.col_idx.size(), o0 = hc.col_off[0];   // col_off need not start at 0
-            for (int s = 0; s < hc.n_snps; ++s) ch.col_off.push_back(e_base + hc.col_off[s + 1] - o0);
-            ch.col_idx.insert(ch.col_idx.end(), hc.col_idx + o0, hc.col_idx + hc.col_off[hc.n_snps]);
-            ch.col_code.insert(ch.col_code.end(), hc.col_code + o0, hc.col_code + hc.col_off[hc.n_snps]);
-            job.snp_ref.insert(job.snp_ref.end(), hc.snp_ref, hc.snp_ref + hc.n_snps);
-            job.snp_alt.insert(job.snp_alt.end(), hc.snp_alt, hc.snp_alt + hc.n_snps);
-            job.snp_contig.insert(job.snp_contig.end(), (size_t)hc.n_snps, c);
-            if (st[(size_t)c].low_memory_now) continue;
-            job.plane_off[(size_t)c] = job.plane_total; job.out_off[(size_t)c] = job.out_total;
-            job.n_reads[(size_t)c] = st[(size_t)c].N; job.words[(size_t)c] = st[(size_t)c].words;
-            job.plane_total += (int64_t)st[(size_t)c].N * st[(size_t)c].words;
-            job.out_total += (int64_t)st[(size_t)c].N * st[(size_t)c].N;
+        // layout first (a few integers per contig), then the copies on the worker threads
+        ch.col_off.resize((size_t)n_col + 1); ch.col_idx.resize((size_t)n_ent); ch.col_code.resize((size_t)n_ent);
+        job.snp_ref.resize((size_t)n_col); job.snp_alt.resize((size_t)n_col); job.snp_contig.resize((size_t)n_col);
+        std::vector<int64_t> ent_base_of_contig((size_t)C, 0);
+        {
+            int64_t cb = 0, eb = 0;
+            for (int c = 0; c < C; ++c) {
+                col_base_of_contig[(size_t)c] = cb; ent_base_of_contig[(size_t)c] = eb;
+                job.contig_snp_base[(size_t)c] = cb;
+                const hs_sr_contig& hc = contigs[c];
+                if (hc.n_snps == 0) continue;
+                cb += hc.n_snps; eb += hc.col_off[hc.n_snps] - hc.col_off[0];
+                if (st[(size_t)c].low_memory_now) continue;
+                job.plane_off[(size_t)c] = job.plane_total; job.out_off[(size_t)c] = job.out_total;
+                job.n_reads[(size_t)c] = st[(size_t)c].N; job.words[(size_t)c] = st[(size_t)c].words;
+                job.plane_total += (int64_t)st[(size_t)c].N * st[(size_t)c].words;
+                job.out_total += (int64_t)st[(size_t)c].N * st[(size_t)c].N;
+            }
         }
+        parallel_for(C, n_threads, [&](int c) {
+            const hs_sr_contig& hc = contigs[c];
+            if (hc.n_snps == 0) return;
+            const int64_t cb = col_base_of_contig[(size_t)c], e_base = ent_base_of_contig[(size_t)c], o0 = hc.col_off[0];   // col_off need not start at 0
+            for (int s = 0; s < hc.n_snps; ++s) ch.col_off[(size_t)(cb + s) + 1] = e_base + hc.col_off[s + 1] - o0;
+            const int64_t n = hc.col_off[hc.n_snps] - o0;
+            std::memcpy(ch.col_idx.data() + e_base, hc.col_idx + o0, (size_t)n * sizeof(int32_t));
+            std::memcpy(ch.col_code.data() + e_base, hc.col_code + o0, (size_t)n);
+            std::memcpy(job.snp_ref.data() + cb, hc.snp_ref, (size_t)hc.n_snps);
+            std::memcpy(job.snp_alt.data() + cb, hc.snp_alt, (size_t)hc.n_snps);
+            std::fill(job.snp_contig.begin() + cb, job.snp_contig.begin() + cb + hc.n_snps, c);
+        });
         laps.lap("columns");
         const double t0 = now_ms();
         if (int rc = dev.simdiff_columns(job, &k_ms[0])) return rc;
