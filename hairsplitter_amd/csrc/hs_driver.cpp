@@ -273,13 +273,11 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         for (size_t i = 0; i < n_sel; ++i) t.col_contig[i] = sel_contig[i] - c0;   // index into part_off
         t.col_c1.resize(n_sel); t.col_k0.resize(n_sel); t.col_k1.resize(n_sel); t.col_is_cand.resize(n_sel);
         t.part_off.assign((size_t)C + 1, 0);
-        parallel_for(C, n_threads, [&](int c) {
+        for (int c = 0; c < C; ++c) {
             const ColumnSet& cs = sets[(size_t)c];
             const size_t s0 = (size_t)contig_sel_off[(size_t)c];
             for (size_t i = 0; i < cs.pos.size(); ++i) { t.col_c1[s0 + i] = cs.c1[i]; t.col_k0[s0 + i] = cs.k0[i]; t.col_k1[s0 + i] = cs.k1[i]; }
             cv_export_candidates(*cst[(size_t)c], t.col_is_cand.data() + s0);
-        });
-        for (int c = 0; c < C; ++c) {   // the partitions append to shared arrays: in contig order
             cv_export_partitions(*cst[(size_t)c], t.part_state, t.part_state_off);
             t.part_off[(size_t)c + 1] = (int32_t)t.part_state_off.size();
         }
@@ -290,7 +288,7 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         for (int c = 0; c < C; ++c) cv_import_keep(*cst[(size_t)c], keep.data() + contig_sel_off[(size_t)c]);
     }
     // ... and the final merge
-    parallel_for(C, n_threads, [&](int c) { cv_phase_merge(*cst[(size_t)c], sets[(size_t)c], res[(size_t)c]); cv_state_free(cst[(size_t)c]); });
+    for (int c = 0; c < C; ++c) { cv_phase_merge(*cst[(size_t)c], sets[(size_t)c], res[(size_t)c]); cv_state_free(cst[(size_t)c]); }
     const double t_glue_done = now_ms();
     laps.lap("merge");
 
