@@ -1,5 +1,5 @@
 """File-to-file wall clock of the two drop-in executables next to the compiled reference (metric ii).
-Usage: python tools/file_to_file.py [--contigs 16] [--threads T]      (prints one JSON line)"""
+Usage: python tests/tools/file_to_file.py [--contigs 16] [--threads T]      (prints one JSON line)"""
 import argparse
 import json
 import os
@@ -8,7 +8,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -1,6 +1,6 @@
 """Parity at BASELINE's full configurations: the drop-in executables against the compiled reference (oracle/_ref, with the
 pinned random_device for stage 4) on the same synthetic files; per-contig comparison of .col / .vcf / error_rate / .gro, and the .gaf of the next stage.
-Usage: python tools/parity_full.py C3|C4|C5 [n_contigs]       (prints one JSON line; needs a GPU and oracle/_ref)"""
+Usage: python tests/tools/parity_full.py C3|C4|C5 [n_contigs]       (prints one JSON line; needs a GPU and oracle/_ref)"""
 import json
 import os
 import subprocess
@@ -8,7 +8,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 
