@@ -865,22 +865,25 @@ struct HipCvOps : hs::CvDeviceOps {
         // staging buffers owned by the batch (grown, never returned): a pool miss here means hipHostMalloc while the kernels
         // of this very step are queued, which stalls the queue for tens of milliseconds
         auto grow = [](HBuf& h, size_t need) -> int { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); };
+        // the per-record counters and the length of the selection in one wait; the counters are unpacked while the selection
+        // itself is on its way
         if (!rec_stats.empty()) {
             if (int rc = grow(b->h_stage_a, rec_stats.size() * sizeof(int32_t))) return rc;
-            if (int rc = copy_d2h(b->h_stage_a.p, b->rec_stats.p, rec_stats.size() * sizeof(int32_t), stream)) return rc;
-            std::memcpy(rec_stats.data(), b->h_stage_a.p, rec_stats.size() * sizeof(int32_t));
+            HS_HIP(hipMemcpyAsync(b->h_stage_a.p, b->rec_stats.p, rec_stats.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         }
-        const double t2 = now();
         int32_t n_sel = 0;
         if (int rc = grow(b->h_stage_c, 64)) return rc;
         if (int rc = copy_d2h(b->h_stage_c.p, b->sel_count.p, sizeof(int32_t), stream)) return rc;
+        const double t2 = now();
         n_sel = *(int32_t*)b->h_stage_c.p;
         if (int rc = grow(b->h_stage_b, std::max<size_t>((size_t)n_sel, 1) * 12)) return rc;
         char* hg = (char*)b->h_stage_b.p; char* hd = hg + (size_t)n_sel * 8;
         if (n_sel) {
             HS_HIP(hipMemcpyAsync(hg, b->sel_gpos.p, (size_t)n_sel * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-            if (int rc = copy_d2h(hd, b->sel_depth.p, (size_t)n_sel * sizeof(int32_t), stream)) return rc;
+            HS_HIP(hipMemcpyAsync(hd, b->sel_depth.p, (size_t)n_sel * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         }
+        if (!rec_stats.empty()) std::memcpy(rec_stats.data(), b->h_stage_a.p, rec_stats.size() * sizeof(int32_t));
+        if (n_sel) { if (int rc = stream_wait(stream)) return rc; }
         *sel_gpos = (const int64_t*)hg; *sel_depth = (const int32_t*)hd; *n_sel_out = (size_t)n_sel;   // read in place by the caller
         const double t3 = now();
         if (int rc = e1.ms(&k_ms[0])) return rc;
