@@ -82,3 +82,17 @@ def test_lpt_shards_deterministic():
     assert a == b and sorted(sum(a, [])) == list(range(50))
     loads = [sum(w[i] for i in s) for s in a]
     assert max(loads) - min(loads) <= max(w)
+
+
+def test_bench_inputs_are_the_same_from_forked_workers():
+    """bench.py generates its synthetic contigs on forked workers before it touches the GPU: same contigs as one by one"""
+    import numpy as np
+    import bench
+    from hairsplitter_amd import synth
+    ids = list(range(3, 19))
+    pooled = bench.make_contigs(2, ids, 2)
+    for i, c in zip(ids, pooled):
+        d = synth.make_contig(2, i, 100_000, 2, 0.01, 50, "ont")
+        assert c.name == d.name and np.array_equal(c.seq, d.seq) and len(c.reads) == len(d.reads)
+        assert all(np.array_equal(a, b) for a, b in zip(c.reads, d.reads))
+        assert all(x.pos == y.pos and x.strand == y.strand and np.array_equal(x.cigar, y.cigar) for x, y in zip(c.alns, d.alns))
