@@ -108,22 +108,31 @@ def make_contig(seed: int, index: int, length: int, n_hap: int, div: float, dept
                 hap_weights: Optional[Sequence[float]] = None,
                 read_len_override: Optional[Sequence[int]] = None,
                 clip_prob: float = 0.0, eqx: bool = False, overhang_prob: float = 0.0,
-                inert_ops_prob: float = 0.0) -> ContigData:
-    """eqx: write matches/mismatches as '=' / 'X' instead of 'M'. overhang_prob: with this probability a read near the
+                inert_ops_prob: float = 0.0, haplotypes: Optional[Sequence[np.ndarray]] = None,
+                contig_seq: Optional[np.ndarray] = None) -> ContigData:
+    """haplotypes / contig_seq: see below. eqx: write matches/mismatches as '=' / 'X' instead of 'M'. overhang_prob: with this probability a read near the
     contig end is given a CIGAR that runs past the end of the contig (the reference stops at `indexQuery < L`,
     call_variants.cpp:217)."""
     rng = np.random.default_rng([seed, index])
     if err is None:
         err = 0.05 if tech == "ont" else 0.002
-    hap0 = rng.integers(0, 4, size=length).astype(np.uint8)
-    haps = [hap0]
-    for _ in range(1, n_hap):
-        h = hap0.copy()
-        m = rng.random(length) < div
-        k = int(m.sum())
-        if k:
-            h[m] = (h[m] + rng.integers(1, 4, size=k).astype(np.uint8)) & 3
-        haps.append(h)
+    if haplotypes is not None:
+        # given haplotypes (same coordinates as the contig, substitutions only) and a given contig sequence, e.g. a consensus
+        # assembly of them: reads are sampled from the haplotypes, the truth alignment is expressed on the contig
+        haps = [np.ascontiguousarray(h, dtype=np.uint8) for h in haplotypes]
+        hap0 = np.ascontiguousarray(contig_seq if contig_seq is not None else haps[0], dtype=np.uint8)
+        n_hap, length = len(haps), len(hap0)
+        assert all(len(h) == length for h in haps)
+    else:
+        hap0 = rng.integers(0, 4, size=length).astype(np.uint8)
+        haps = [hap0]
+        for _ in range(1, n_hap):
+            h = hap0.copy()
+            m = rng.random(length) < div
+            k = int(m.sum())
+            if k:
+                h[m] = (h[m] + rng.integers(1, 4, size=k).astype(np.uint8)) & 3
+            haps.append(h)
     reads, names, alns, truth = [], [], [], []
     target_bp = depth * length
     tot = 0
@@ -183,12 +192,12 @@ def cigar_string(cigar: np.ndarray) -> str:
 
 
 def write_files(contigs: Sequence[ContigData], outdir: str, prefix: str = "",
-                sam_extra: Optional[List[str]] = None, gfa_extra: Optional[List[str]] = None) -> dict:
+                sam_extra: Optional[List[str]] = None, gfa_extra: Optional[List[str]] = None, fastq: bool = False) -> dict:
     """Writes assembly.gfa / reads.fasta / aln.sam. Returns the paths. `sam_extra` / `gfa_extra`: verbatim lines appended
     to the SAM / the GFA (e.g. supplementary records, 'L' lines)."""
     os.makedirs(outdir, exist_ok=True)
     gfa = os.path.join(outdir, prefix + "assembly.gfa")
-    fa = os.path.join(outdir, prefix + "reads.fasta")
+    fa = os.path.join(outdir, prefix + ("reads.fastq" if fastq else "reads.fasta"))   # anything but .fasta / .fa is read as FASTQ (input_output.cpp:41-44)
     sam = os.path.join(outdir, prefix + "aln.sam")
     with open(gfa, "w") as g:
         for c in contigs:
@@ -198,7 +207,12 @@ def write_files(contigs: Sequence[ContigData], outdir: str, prefix: str = "",
     with open(fa, "w") as f:
         for c in contigs:
             for nm, r in zip(c.read_names, c.reads):
-                f.write(f">{nm}\n{_ACGT[r].tobytes().decode()}\n")
+                if fastq:
+                    # quality strings that begin with '@' or '+' exercise the record test of input_output.cpp:64
+                    q = ("@" if len(r) % 3 == 0 else "+" if len(r) % 3 == 1 else "I") + "I" * (len(r) - 1)
+                    f.write(f"@{nm} some description\n{_ACGT[r].tobytes().decode()}\n+\n{q}\n")
+                else:
+                    f.write(f">{nm}\n{_ACGT[r].tobytes().decode()}\n")
     with open(sam, "w") as s:
         s.write("@HD\tVN:1.6\tSO:unsorted\n")
         for c in contigs:
@@ -246,4 +260,28 @@ def config_contigs(cfg: str, seed: Optional[int] = None, first: int = 0, count: 
             L = 300_000 if i < 33 else 100_000
             out.append(make_contig(seed, i, int(L * scale), 2, 0.001, 30, "hifi"))
         return out
+    if cfg == "C5U":   # the uncut stress variant of C5: one 10 Mb contig, about 20 000 HiFi reads
+        seed = 5 if seed is None else seed
+        return [make_contig(seed, 100 + first, int(10_000_000 * scale), 2, 0.001, 30, "hifi", name="c5uncut")]
     raise ValueError(f"unknown config {cfg}")
+
+
+def _config_chunk(a):
+    cfg, seed, first, count, scale = a
+    return config_contigs(cfg, seed=seed, first=first, count=count, scale=scale)
+
+
+def config_contigs_parallel(cfg: str, seed: Optional[int] = None, count: Optional[int] = None, scale: float = 1.0,
+                            workers: Optional[int] = None) -> List[ContigData]:
+    """config_contigs on forked workers (a contig's data depends only on (seed, index), so the result is the same list).
+    Only call it from a process that has not initialised the GPU."""
+    n = {"C2": 1, "C3": 50, "C4": 500, "C5": 34, "C5U": 1}[cfg.upper()] if count is None else count
+    workers = max(1, min(workers or (os.cpu_count() or 1), n // 4))
+    if workers <= 1:
+        return config_contigs(cfg, seed=seed, count=count, scale=scale)
+    import multiprocessing as mp
+    step = max(1, n // (4 * workers))
+    jobs = [(cfg, seed, i, min(step, n - i), scale) for i in range(0, n, step)]
+    with mp.get_context("fork").Pool(workers) as pool:
+        parts = pool.map(_config_chunk, jobs)
+    return [c for part in parts for c in part]

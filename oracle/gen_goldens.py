@@ -41,7 +41,7 @@ def py_error_rate_arg(path):
     return str(e)
 
 
-def run_ref(workdir, files, low_memory=0, rsa="0.01", amplicon=0, ploidy_lines=None, thr="0.33", tag=""):
+def run_ref(workdir, files, low_memory=0, rsa="0.01", amplicon=0, ploidy_lines=None, thr="0.33", tag="", seed=None, fastq=False):
     col = os.path.join(workdir, tag + "variants.col")
     vcf = os.path.join(workdir, tag + "variants.vcf")
     err = os.path.join(workdir, tag + "error_rate.txt")
@@ -54,7 +54,8 @@ def run_ref(workdir, files, low_memory=0, rsa="0.01", amplicon=0, ploidy_lines=N
         ploidy = os.path.join(workdir, tag + "ploidy.txt")
         with open(ploidy, "w") as f:
             f.write("".join(ploidy_lines))
-    subprocess.run([os.path.join(REF, "HS_separate_reads_seeded"), col, "1", earg, ploidy, str(low_memory), rsa,
+    # seed: a second build of the reference with another constant behind std::random_device (oracle/Makefile)
+    subprocess.run([os.path.join(REF, "HS_separate_reads_seeded" + (f"_{seed}" if seed else "")), col, "1", earg, ploidy, str(low_memory), rsa,
                     str(amplicon), gro, "0"], check=True, stdout=subprocess.DEVNULL)
     gaf = run_ref_gaf(workdir, files, gro, amplicon, tag)
     return {"col": col, "vcf": vcf, "err": err, "gro": gro, "gaf": gaf, "error_rate_arg": earg,
@@ -117,7 +118,48 @@ def cases():
     out.append(("dip12k_amplicon", [synth.make_contig(107, 0, 12_000, 2, 0.01, 60, "ont")], None, {"amplicon": 1}))
     out.append(("short_reads_w500", [synth.make_contig(108, 0, 15_000, 2, 0.01, 40, "ont")], None, {}))
     out.append(linked_case())
+    # the same inputs as dip20k / penta30k against a reference whose random_device returns 777 (the product takes HS_SEED=777)
+    out.append(("penta30k_seed777", [synth.make_contig(102, 0, 30_000, 5, 0.01, 60, "ont")], None, {"seed": 777}))
+    # reads as FASTQ (input_output.cpp:41-44,64: everything that is not .fasta / .fa; '@' and '+' may start a quality line)
+    out.append(("dip10k_fastq", [synth.make_contig(112, 0, 10_000, 2, 0.01, 40, "ont")], None, {"fastq": True}))
+    out.append(simple_mock_case())
     return out
+
+
+def simple_mock_case():
+    """BASELINE config C1: the reference's own test/simple_mock/assembly.gfa (a data file of the reference's test, stored as
+    is) with reads simulated at 30x ONT from the three haplotypes of test/simple_mock/mock_reference.fasta (the
+    mock_reads.fasta the README names is not in the repository). The assembly's contigs are substitution-only consensus
+    pieces of the haplotypes (consensus@0 = [0, 100000), consensus@1 = [100000, 190000), consensus@2 = [189999, 199999);
+    consensus_2 matches nothing and gets no reads), so the truth alignment of a read is known without an aligner."""
+    import numpy as np
+    mock = os.path.join(os.environ.get("HS_REFERENCE", "/root/reference"), "test", "simple_mock")
+    code = np.full(256, 3, dtype=np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    haps, name = [], None
+    for line in open(os.path.join(mock, "mock_reference.fasta")):
+        if not line.startswith(">"):
+            haps.append(code[np.frombuffer(line.strip().encode(), dtype=np.uint8)])
+    seqs, links = {}, []
+    order = []
+    for line in open(os.path.join(mock, "assembly.gfa")):
+        f = line.rstrip("\n").split("\t")
+        if f[0] == "S":
+            seqs[f[1]] = code[np.frombuffer(f[2].encode(), dtype=np.uint8)]
+            order.append(f[1])
+        else:
+            links.append(line.rstrip("\n"))
+    place = {"consensus@0": 0, "consensus@1": 100000, "consensus@2": 189999}
+    cs = []
+    for i, nm in enumerate(order):
+        s = seqs[nm]
+        if nm in place:
+            a = place[nm]
+            cs.append(synth.make_contig(113, i, len(s), 3, 0.0, 30, "ont", name=nm, haplotypes=[h[a:a + len(s)] for h in haps], contig_seq=s))
+        else:
+            cs.append(synth.ContigData(nm, s, [], [], [], np.zeros(0, dtype=np.int32)))
+    return ("simple_mock", cs, None, {}, links)
 
 
 def linked_case():
@@ -249,7 +291,9 @@ def main():
             if name == "short_reads_w500":
                 # force the 500-bp window branch (separate_reads.cpp:1489): cut every read alignment to <= 1.5 kb
                 contigs = [synth.make_contig(108, 0, 15_000, 2, 0.01, 40, "ont", read_len_override=(800, 1500))]
-            files = synth.write_files(contigs, td, sam_extra=extra, gfa_extra=gfa_extra)
+            files = synth.write_files(contigs, td, sam_extra=extra, gfa_extra=gfa_extra, fastq=bool(kw.get("fastq")))
+            if name == "simple_mock":   # the reference's data file as it is (its S lines carry DP:f: tags and a trailing tab)
+                shutil.copyfile("/root/reference/test/simple_mock/assembly.gfa", files["gfa"])
             outs = run_ref(td, files, **kw)
             meta = {"case": name, "kwargs": {k: v for k, v in kw.items()},
                     "aligned_bp": int(sum(c.aligned_bp for c in contigs)),
@@ -264,7 +308,8 @@ def main():
                                 str(kw.get("amplicon", 0)), "0", ocol, ovcf, "0.33"], check=True, stdout=subprocess.DEVNULL)
                 subprocess.run([orc, "separate_reads", outs["col"], "1", outs["error_rate_arg"],
                                 outs["ploidy"] or os.path.join(td, "absent"), str(kw.get("low_memory", 0)), "0.01",
-                                str(kw.get("amplicon", 0)), ogro, "0"], check=True, stdout=subprocess.DEVNULL)
+                                str(kw.get("amplicon", 0)), ogro, "0"], check=True, stdout=subprocess.DEVNULL,
+                               env=dict(os.environ, HS_ORACLE_SEED=str(kw["seed"])) if kw.get("seed") else None)
                 ok_col = canon.split_blocks(ocol) == canon.split_blocks(outs["col"])
                 ok_vcf = canon.vcf_blocks(ovcf) == canon.vcf_blocks(outs["vcf"])
                 ok_err = open(oerr).read() == open(outs["err"]).read()

@@ -1,0 +1,88 @@
+"""BASELINE.json's configurations at FULL size: synthetic inputs (hairsplitter_amd.synth), the drop-in
+executables next to the compiled reference (oracle/_ref, std::random_device pinned for stage 4) on the same files, every
+output compared per contig. Used by tests/test_gpu_full_configs.py (-m gpu) and tests/tools/parity_full.py (CLI).
+Test infrastructure: runs binaries under oracle/."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def generate_files(cfg, outdir, count=None, workers=None):
+    """Writes assembly.gfa / reads.fasta / aln.sam of a configuration in a CHILD process (forked generator workers must not
+    inherit an initialised HIP runtime; the pytest process may have one). Returns (paths, aligned_bp, n_contigs, seconds)."""
+    t = time.perf_counter()
+    code = ("import sys, json; sys.path.insert(0, %r)\n"
+            "from hairsplitter_amd import synth\n"
+            "cs = synth.config_contigs_parallel(%r, count=%r, workers=%r)\n"
+            "f = synth.write_files(cs, %r)\n"
+            "print(json.dumps({'files': f, 'bp': int(sum(c.aligned_bp for c in cs)), 'n': len(cs)}))\n") % (ROOT, cfg, count, workers, outdir)
+    r = subprocess.run([sys.executable, "-c", code], check=True, stdout=subprocess.PIPE)
+    j = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    return j["files"], j["bp"], j["n"], time.perf_counter() - t
+
+
+def py_error_rate(er32):
+    """hairsplitter.py:686-692,725: the float stage 3 printed (6 significant digits), capped at 0.15"""
+    return min(float("%g" % er32), 0.15)
+
+
+def run_pair(cv, sr, f, td, tag, threads, env=None):
+    col, vcf, err, gro = (os.path.join(td, tag + x) for x in (".col", ".vcf", ".err", ".gro"))
+    t0 = time.perf_counter()
+    subprocess.run([cv, f["gfa"], f["reads"], f["sam"], str(threads), td, err, "0", "0", col, vcf, "0.33"], check=True, stdout=subprocess.DEVNULL, env=env)
+    t1 = time.perf_counter()
+    e = py_error_rate(float(open(err).read().strip()))
+    subprocess.run([sr, col, str(threads), str(e), os.path.join(td, "no_ploidy"), "0", "0.01", "0", gro, "0"], check=True, stdout=subprocess.DEVNULL, env=env)
+    t2 = time.perf_counter()
+    return (col, vcf, err, gro), {"call_variants_s": round(t1 - t0, 2), "separate_reads_s": round(t2 - t1, 2)}
+
+
+def compare_outputs(a, b, out):
+    from hairsplitter_amd import canon
+    out["col_identical"] = canon.split_blocks(a[0]) == canon.split_blocks(b[0])
+    out["vcf_identical"] = canon.vcf_blocks(a[1]) == canon.vcf_blocks(b[1])
+    out["error_rate_identical"] = open(a[2]).read() == open(b[2]).read()
+    ga, gb = canon.split_blocks(a[3]), canon.split_blocks(b[3])
+    out["gro_identical"] = ga == gb
+    if ga != gb:
+        out["gro_diff"] = canon.diff_blocks(ga, gb)[:3]
+    if not out["col_identical"]:
+        out["col_diff"] = canon.diff_blocks(canon.split_blocks(a[0]), canon.split_blocks(b[0]))[:3]
+    out["n_snps"] = sum(1 for l in open(a[0]) if l.startswith("SNPS"))
+    out["n_groups"] = sum(1 for l in open(a[3]) if l.startswith("GROUP"))
+
+
+def run_config(cfg, td, count=None, threads=None, with_gaf=True):
+    """Returns a dict with the verdicts (col/vcf/error_rate/gro[/gaf]_identical) and the wall clocks."""
+    import __graft_entry__ as ge
+    import bench
+    p = ge.paths()
+    threads = threads or bench.effective_cores()
+    f, bp, n, t_gen = generate_files(cfg, td, count, workers=min(8, threads))
+    out = {"config": cfg, "contigs": n, "aligned_bp": bp, "threads": threads, "generation_s": round(t_gen, 1)}
+    a, out["hip"] = run_pair(p["cv"], p["sr"], f, td, "hip", threads)
+    b, out["ref"] = run_pair(p["ref_cv"], p["ref_sr_seeded"], f, td, "ref", threads)
+    compare_outputs(a, b, out)
+    if with_gaf and os.path.exists(p.get("ref_cnc", "")):
+        # next stage: the .gaf derived from each side's own .gro (hs_gro_to_gaf vs the reference's HS_create_new_contigs, which
+        # writes the .gaf and then stops at its first external tool)
+        gaf_a, gaf_b, tmp = os.path.join(td, "hip.gaf"), os.path.join(td, "ref.gaf"), os.path.join(td, "cnc_tmp")
+        os.makedirs(tmp, exist_ok=True)
+        t0 = time.perf_counter()
+        subprocess.run([p["gaf"], f["gfa"], f["reads"], f["sam"], a[3], "0", gaf_a, str(threads)], check=True, stdout=subprocess.DEVNULL)
+        t1 = time.perf_counter()
+        subprocess.run([p["ref_cnc"], f["gfa"], f["reads"], "0.05", b[3], f["sam"], tmp + "/", str(threads), "ont", os.path.join(tmp, "o.gfa"), gaf_b,
+                        "racon", "0", "0", "/nonexistent/minimap2", "/nonexistent/racon", "/nonexistent/medaka", "/nonexistent/samtools",
+                        "/nonexistent/python", "0"], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t2 = time.perf_counter()
+        out["gaf"] = {"hip_s": round(t1 - t0, 2), "ref_until_first_external_tool_s": round(t2 - t1, 2),
+                      "identical": os.path.exists(gaf_b) and open(gaf_a, "rb").read() == open(gaf_b, "rb").read(),
+                      "lines": sum(1 for _ in open(gaf_a))}
+    out["speedup_file_to_file"] = round((out["ref"]["call_variants_s"] + out["ref"]["separate_reads_s"]) /
+                                        max(1e-9, out["hip"]["call_variants_s"] + out["hip"]["separate_reads_s"]), 2)
+    return out

@@ -356,9 +356,11 @@ int main(int argc, char** argv) {
             h.ploidy = (have && ploidy_of.count(c.name)) ? ploidy_of[c.name] : 0;
         }
         const int w = hs::sr_window_size(hc.data(), (int)hc.size(), std::atoi(a[7]) != 0);
-        OracleSrOps ops(12345u);
+        uint32_t seed = 12345u;   // as hs_main.cpp: the pinned std::random_device of the reference, HS_SEED overrides
+        if (const char* e = std::getenv("HS_SEED")) seed = (uint32_t)std::strtoul(e, nullptr, 10);
+        OracleSrOps ops(seed);
         hs_sr_result* res = nullptr;
-        if (int rc = hs::sr_run(ops, hc.data(), (int)hc.size(), w, (float)std::atof(a[3]), std::atoi(a[5]), 12345u, 1, &res)) return rc;
+        if (int rc = hs::sr_run(ops, hc.data(), (int)hc.size(), w, (float)std::atof(a[3]), std::atoi(a[5]), seed, 1, &res)) return rc;
         { std::ofstream o(a[8]); }
         hs::write_gro(cs, res, a[8], 4);
         hs::free_sr_result(res);

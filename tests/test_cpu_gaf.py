@@ -25,7 +25,7 @@ def test_gaf_tool_matches_reference_goldens(built, case):
         meta = gu.unpack(case, td)
         amp = str(meta.get("kwargs", {}).get("amplicon", 0))
         out = os.path.join(td, "mine.gaf")
-        r = subprocess.run([built["gaf"], os.path.join(td, "assembly.gfa"), os.path.join(td, "reads.fasta"), os.path.join(td, "aln.sam"),
+        r = subprocess.run([built["gaf"], os.path.join(td, "assembly.gfa"), gu.reads_path(td, meta), os.path.join(td, "aln.sam"),
                             os.path.join(td, "reads_haplo.gro"), amp, out, "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         assert r.returncode == 0, r.stdout.decode()[-2000:]
         assert _read(out) == _read(os.path.join(td, "reads_haplo.gaf"))

@@ -19,7 +19,7 @@ def test_dropin_binaries_match_reference_goldens(built, case):
         assert gu.compare(td, outs) == []
         # ... and what the next stage makes of the .gro this build wrote: the .gaf the reference derives from its own .gro
         gaf = os.path.join(td, "t_reads.gaf")
-        subprocess.run([built["gaf"], os.path.join(td, "assembly.gfa"), os.path.join(td, "reads.fasta"), os.path.join(td, "aln.sam"), outs["gro"],
+        subprocess.run([built["gaf"], os.path.join(td, "assembly.gfa"), gu.reads_path(td, meta), os.path.join(td, "aln.sam"), outs["gro"],
                         str(meta.get("kwargs", {}).get("amplicon", 0)), gaf], check=True, stdout=subprocess.DEVNULL)
         assert open(gaf, "rb").read() == open(os.path.join(td, "reads_haplo.gaf"), "rb").read()
 

@@ -1,0 +1,59 @@
+"""GPU parity at BASELINE.json's FULL configurations: the drop-in executables against the compiled reference (oracle/_ref,
+built from /root/reference by oracle/Makefile and shipped to the GPU box as binaries) on the same synthetic files. Per-contig
+comparison of .col / .vcf / error_rate / .gro and of the .gaf the next stage derives.  match: call_variants.cpp:1215-1385,
+separate_reads.cpp:1398-1790."""
+import json
+import os
+import tempfile
+
+import pytest
+
+import full_configs as fc
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check(built, cfg, count=None, with_gaf=True):
+    if not (os.path.exists(built["ref_cv"]) and os.path.exists(built["ref_sr_seeded"])):
+        pytest.fail("oracle/_ref binaries are missing: run `make -C oracle ref` where /root/reference exists (they travel with the snapshot)")
+    with tempfile.TemporaryDirectory() as td:
+        out = fc.run_config(cfg, td, count, with_gaf=with_gaf)
+    try:   # a record of the run next to the profiles of the round (scratch on the GPU box, merged back by gpurun)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_full_configs.jsonl"), "a") as f:
+            f.write(json.dumps(out) + "\n")
+    except OSError:
+        pass
+    assert out["col_identical"], out.get("col_diff")
+    assert out["vcf_identical"]
+    assert out["error_rate_identical"]
+    assert out["gro_identical"], out.get("gro_diff")
+    if "gaf" in out:
+        assert out["gaf"]["identical"]
+    return out
+
+
+def test_c2_x16_full_size_equals_reference(built):
+    """C2: 100 kb contig, 2 haplotypes @1 %, 50x ONT (16 independent contigs of that shape)"""
+    out = _check(built, "C2", 16)
+    assert out["n_snps"] > 10_000
+
+
+def test_c3_full_size_equals_reference(built):
+    """C3: 50 contigs x 200 kb, tetraploid, 40x ONT (400 M aligned bp)"""
+    out = _check(built, "C3")
+    assert out["contigs"] == 50 and out["aligned_bp"] > 3.9e8
+
+
+def test_c4_full_size_equals_reference(built):
+    """C4: the 500-contig metagenome, ploidy 1-8, 30x ONT (1.7 G aligned bp) -- the configuration the headline metric is quoted on"""
+    out = _check(built, "C4")
+    assert out["contigs"] == 500 and out["aligned_bp"] > 1.6e9
+
+
+def test_c5_chunks_full_size_equals_reference(built):
+    """C5 in its pipeline-faithful form: the 10 Mb contig cut in 34 chunks of <= 300 kb, diploid @0.1 %, 30x HiFi"""
+    out = _check(built, "C5")
+    assert out["contigs"] == 34 and out["aligned_bp"] > 2.9e8

@@ -256,8 +256,10 @@ def test_pack_columns_copies_the_listed_columns(batch):
             assert np.array_equal(pcode[off[k]:off[k + 1]], code[col_off[i]:col_off[i + 1]])
 
 
-def test_stage3_result_equals_oracle_pipeline(batch, built):
-    """hs_cv_run on the resident batch: SNP positions, ref/alt codes and columns equal the oracle's .col."""
+def test_stage3_result_equals_oracle_pipeline(request, batch, built):
+    """hs_cv_run on the resident batch (no files on the product side): SNP positions, ref / alt codes, read indices, codes,
+    depth and mean distance of every contig equal what the oracle restatement writes into its .col / error_rate for the
+    same contigs."""
     import subprocess, tempfile
     from hairsplitter_amd import api, synth, canon
     flat, _ = batch
@@ -265,14 +267,32 @@ def test_stage3_result_equals_oracle_pipeline(batch, built):
     assert b.aligned_bp == flat.aligned_bp
     out = b.run(0.33)
     b.close()
-    # size-independent properties
-    assert np.all(np.diff(out["snp_off"]) >= 0)
-    for c in range(flat.n_contigs):
-        pos = out["snp_pos"][out["snp_off"][c]:out["snp_off"][c + 1]]
-        assert np.all(np.diff(pos) > 0)
-    for s in range(len(out["snp_pos"])):
-        idx = out["col_idx"][out["col_off"][s]:out["col_off"][s + 1]]
-        assert np.all(np.diff(idx) > 0)
+    contigs = _contigs(request.node.callspec.params["batch"])
+    with tempfile.TemporaryDirectory() as td:
+        f = synth.write_files(contigs, td)
+        col, vcf, err = (os.path.join(td, x) for x in ("o.col", "o.vcf", "o.err"))
+        subprocess.run([built["oracle"], "call_variants", f["gfa"], f["reads"], f["sam"], "1", td, err, "0", "0", col, vcf, "0.33"],
+                       check=True, stdout=subprocess.DEVNULL)
+        blocks = canon.split_blocks(col)
+        o_err = open(err).read()
+    assert "%g" % np.float32(out["error_rate"]) == o_err.strip()      # default ostream precision (call_variants.cpp:1377)
+    n_checked = 0
+    for c, cd in enumerate(contigs):
+        lines = blocks[cd.name]
+        head = lines[0].split("\t")
+        assert int(head[2]) == len(cd.seq)
+        assert "%g" % np.float32(out["depth"][c]) == head[3]
+        snps = [l.split("\t") for l in lines if l.startswith("SNPS")]
+        s0, s1 = int(out["snp_off"][c]), int(out["snp_off"][c + 1])
+        assert s1 - s0 == len(snps)
+        for k, fld in enumerate(snps):
+            s = s0 + k
+            assert int(fld[1]) == int(out["snp_pos"][s]) and int(fld[2]) == int(out["snp_ref"][s]) and int(fld[3]) == int(out["snp_alt"][s])
+            e0, e1 = int(out["col_off"][s]), int(out["col_off"][s + 1])
+            assert [int(x) for x in fld[4].split(",") if x] == out["col_idx"][e0:e1].tolist()
+            assert [int(x) for x in fld[5].split(",") if x] == out["col_code"][e0:e1].tolist()
+            n_checked += 1
+    assert n_checked == len(out["snp_pos"])
 
 
 def _partition_test_case(rng, n_contigs, cols_per_contig, mode):
