@@ -51,7 +51,8 @@ class SrResult(C.Structure):
     _fields_ = [("n_contigs", C.c_int32), ("win_off", C.POINTER(C.c_int64)), ("win_start", C.POINTER(C.c_int32)),
                 ("win_end", C.POINTER(C.c_int32)), ("label_off", C.POINTER(C.c_int64)), ("labels", C.POINTER(C.c_int32)),
                 ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("n_cw_instances", C.c_int64),
-                ("t_kernel_ms", C.c_float * 4), ("t_kernel_graph_ms", C.c_float), ("n_graph_rows_host", C.c_int64), ("n_windows_finished_on_host", C.c_int64)]
+                ("t_kernel_ms", C.c_float * 4), ("t_kernel_graph_ms", C.c_float), ("n_graph_rows_host", C.c_int64), ("n_windows_finished_on_host", C.c_int64),
+                ("n_cw_sweeps", C.c_int64), ("cw_bytes", C.c_int64), ("graph_nnz", C.c_int64), ("n_graph_rows", C.c_int64), ("simdiff_bytes", C.c_int64)]
 
 
 _lib = None
@@ -309,7 +310,8 @@ class PipelineStats(C.Structure):
     _fields_ = [("n_snps", C.c_int64), ("n_cw_instances", C.c_int64), ("n_graph_rows_host", C.c_int64),
                 ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("t_kernel_cv_ms", C.c_float * 4), ("t_kernel_k4_ms", C.c_float),
                 ("t_kernel_sr_ms", C.c_float * 4), ("t_kernel_graph_ms", C.c_float),
-                ("n_columns_extracted", C.c_int64), ("n_columns_downloaded", C.c_int64), ("n_columns_downloaded_late", C.c_int64)]
+                ("n_columns_extracted", C.c_int64), ("n_columns_downloaded", C.c_int64), ("n_columns_downloaded_late", C.c_int64),
+                ("n_cw_sweeps", C.c_int64), ("cw_bytes", C.c_int64), ("graph_nnz", C.c_int64), ("n_graph_rows", C.c_int64), ("simdiff_bytes", C.c_int64)]
 
 
 class PipelineGroups:
@@ -414,6 +416,8 @@ def _sr_result_to_dict(res, Cn, take_ownership=False):
         "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "n_cw_instances": int(r.n_cw_instances),
         "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_graph_ms": float(r.t_kernel_graph_ms),
         "n_graph_rows_host": int(r.n_graph_rows_host), "n_windows_finished_on_host": int(r.n_windows_finished_on_host),
+        "n_cw_sweeps": int(r.n_cw_sweeps), "cw_bytes": int(r.cw_bytes), "graph_nnz": int(r.graph_nnz), "n_graph_rows": int(r.n_graph_rows),
+        "simdiff_bytes": int(r.simdiff_bytes),
     }
 
 
@@ -493,6 +497,8 @@ def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory:
         "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "n_cw_instances": int(r.n_cw_instances),
         "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_graph_ms": float(r.t_kernel_graph_ms),
         "n_graph_rows_host": int(r.n_graph_rows_host), "n_windows_finished_on_host": int(r.n_windows_finished_on_host),
+        "n_cw_sweeps": int(r.n_cw_sweeps), "cw_bytes": int(r.cw_bytes), "graph_nnz": int(r.graph_nnz), "n_graph_rows": int(r.n_graph_rows),
+        "simdiff_bytes": int(r.simdiff_bytes),
     }
     lib.hs_sr_result_destroy(res)
     return out

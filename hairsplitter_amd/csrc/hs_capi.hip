@@ -24,7 +24,7 @@
 #include "hs_driver.h"
 #include "hs_kernels.hip"
 #include "hs_kernels_graph.hip"
-#include "hs_kernels_finish.hip"
+#include "hs_kernels_cw.hip"
 
 namespace hs {
 static thread_local std::string g_err;
@@ -613,18 +613,20 @@ int hs_simdiff(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_pl
 static int cw_launch(const int32_t* d_adj_off, const int32_t* d_adj, const int64_t* d_graph_off_base,
                      const int64_t* d_graph_adj_base, const int32_t* d_graph_n, const int32_t* d_perm, const int64_t* d_perm_base,
                      const uint8_t* d_mask, const int32_t* d_inst_graph, const int64_t* d_inst_label_base, int32_t n_inst,
-                     int32_t max_n, int32_t* d_labels, int32_t* d_sweeps, void* stream, const int64_t* d_inst_seed_col = nullptr,
-                     const int64_t* d_col_off = nullptr, const int32_t* d_col_idx = nullptr, const uint8_t* d_col_code = nullptr,
-                     const int32_t* d_visit = nullptr, const int32_t* d_visit_n = nullptr) {
+                     int32_t max_n, int32_t* d_labels, int32_t* d_sweeps, void* stream) {
     if (n_inst <= 0) return HS_OK;
-    const size_t lds = (size_t)max_n * 8 + 1024;
-    if (lds > 160 * 1024) { set_error("Chinese Whispers: more than 20000 reads on one contig is not supported"); return HS_EINVAL; }
+    size_t lds = (size_t)max_n * 8 + 1024;
+    DBuf scratch;     // graphs whose labels + counters do not fit LDS keep them in global memory (2 * max_n ints per instance)
+    const bool in_global = lds > 96 * 1024;
+    if (in_global) { if (int rc = scratch.alloc((size_t)n_inst * 2 * (size_t)max_n * 4)) return rc; lds = 1024; }
     if (lds > 48 * 1024)
         HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_chinese_whispers), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(hsdev::k_chinese_whispers, dim3((unsigned)n_inst), dim3(64), lds, (hipStream_t)stream, d_adj_off, d_adj,
                        d_graph_off_base, d_graph_adj_base, d_graph_n, d_perm, d_perm_base, d_mask, d_inst_graph,
-                       d_inst_label_base, n_inst, d_labels, d_sweeps, d_inst_seed_col, d_col_off, d_col_idx, d_col_code, d_visit, d_visit_n);
+                       d_inst_label_base, n_inst, d_labels, d_sweeps, (const int64_t*)nullptr, (const int64_t*)nullptr, (const int32_t*)nullptr,
+                       (const uint8_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, in_global ? scratch.as<int32_t>() : (int32_t*)nullptr, max_n);
     HS_HIP(hipGetLastError());
+    if (in_global) { if (int rc = stream_wait((hipStream_t)stream)) return rc; }   // the scratch goes back to the pool with this scope
     return HS_OK;
 }
 
@@ -737,10 +739,6 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
     }
     for (int c = 0; c < n_contigs; ++c) {
         const int64_t L = b->contig_off[(size_t)c + 1] - b->contig_off[(size_t)c];
-        if (b->contig_rec_off[(size_t)c + 1] - b->contig_rec_off[(size_t)c] > 65535) {
-            set_error("more than 65535 alignment records on one contig (the reference's depth loop counter is a short)");
-            delete b; return HS_EINVAL;
-        }
         for (int r = b->contig_rec_off[(size_t)c]; r < b->contig_rec_off[(size_t)c + 1]; ++r) {
             b->rec_contig[(size_t)r] = c;
             const int64_t refspan = b->rec_refspan[(size_t)r], readspan = readspan_of[(size_t)r];
@@ -765,6 +763,9 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
             int d = 0;
             for (auto& e : ev) { d += e.second; b->max_depth = std::max(b->max_depth, d); }
         }
+        // what the kernels need is a bound on the depth of ONE position (K2 counts in 16-bit lanes; the reference's own loop
+        // over a column's reads is a `short`, call_variants.cpp:479); the number of records on a contig is unbounded
+        if (b->max_depth > 65535) { set_error("a position is covered by more than 65535 alignment records"); delete b; return HS_EINVAL; }
     }
     int rc = 0;
     auto up = [&](DBuf& d, const void* src, size_t bytes) {
@@ -979,156 +980,197 @@ struct HipCvOps : hs::CvDeviceOps {
     }
 };
 
-// HIP implementation of the stage-4 device interface
-// K6 driver: rows on the device, the few std::sort-dependent rows on the host, CSR on the device (see hs_kernels_graph.hip)
-// keep_dev / keep_host (both or neither): the caller takes over the neighbour array on the device and its pinned host copy;
-// the result then points at the latter (nbr_view) instead of holding another copy
-static int read_graphs_run(const int32_t* d_sim, const int32_t* d_diff, const std::vector<int64_t>& ctg_out_off, const std::vector<int32_t>& ctg_n,
-                           const hs::ReadGraphJob& job, hs::ReadGraphResult& res, hipStream_t stream, float* k_ms,
-                           DBuf* keep_dev = nullptr, HBuf* keep_host = nullptr) {
-    const int W = (int)job.win_contig.size();
-    const int64_t rows64 = job.win_mask_off.empty() ? 0 : job.win_mask_off.back();
-    res.nbr_off.assign((size_t)rows64 + 1, 0); res.nbr.clear(); res.nbr_view = nullptr; res.rows_resolved_on_host = 0;
-    if (rows64 == 0) return HS_OK;
-    if (rows64 > 0x7fffffff) { set_error("read_graphs: too many rows"); return HS_EINVAL; }
-    const int rows = (int)rows64;
-    std::vector<int32_t> row_win((size_t)rows);
-    std::vector<int64_t> win_bits_off((size_t)W + 1, 0);
-    int max_m = 1;
+// ---------------------------------------------------------------------------------------------------
+// stage 4 on the device: every clustering window in its local index space (hs_driver.h: SrWindowSet)
+// ---------------------------------------------------------------------------------------------------
+// The read graphs of a call: ONE CSR over the rows (window, masked read) with local neighbour ids, the visiting order of
+// every window, and the window tables the clustering kernels index. Built by K6 from the resident sim / diff matrices (the
+// few rows whose result depends on std::sort's arrangement of equal distances are resolved on the host and patched in) plus
+// the rows a caller brings for windows on the low-memory path.
+struct GraphRows {
+    DBuf d_oo, d_n, d_wc, d_row0, d_ids, d_rw, d_bo, d_fe, d_rank, d_rank_off;   // views into `pack`
+    UploadPack pack;
+    DBuf d_off, d_nbr, d_visit, d_visit_n;
+    int64_t rows = 0, rows_dev = 0, total = 0;
+    int W = 0, max_m = 1;
+    std::vector<int32_t> win_m;    // [W]
+};
+
+static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const std::vector<int64_t>& ctg_out_off, const std::vector<int32_t>& ctg_n,
+                            const hs::SrWindowSet& ws, GraphRows& G, hipStream_t stream, int64_t* rows_on_host, float* k_ms) {
+    const int W = (int)ws.win_contig.size();
+    G.W = W; G.rows = ws.rows(); G.total = 0; G.max_m = 1;
+    if (rows_on_host) *rows_on_host = 0;
+    if (G.rows > 0x7fffffff) { set_error("read graphs: too many rows"); return HS_EINVAL; }
+    const int rows = (int)G.rows;
+    const int Wd = ws.n_dev_windows;
+    const int rows_dev = (int)ws.win_row0[(size_t)Wd];
+    G.rows_dev = rows_dev;
+    if ((int64_t)ws.host_off.size() != (int64_t)(rows - rows_dev) + 1 && rows != rows_dev) { set_error("read graphs: host rows do not match the window set"); return HS_EINVAL; }
+    std::vector<int32_t> row_win((size_t)rows_dev);
+    std::vector<int64_t> win_bits_off((size_t)Wd + 1, 0);
+    G.win_m.resize((size_t)W);
+    int max_m_dev = 1;
     for (int w = 0; w < W; ++w) {
-        const int64_t m0 = job.win_mask_off[(size_t)w], m = job.win_mask_off[(size_t)w + 1] - m0;
-        for (int64_t r = 0; r < m; ++r) row_win[(size_t)(m0 + r)] = w;
-        win_bits_off[(size_t)w + 1] = win_bits_off[(size_t)w] + m * ((m + 63) >> 6);
-        max_m = std::max(max_m, (int)m);
+        const int64_t m0 = ws.win_row0[(size_t)w], m = ws.win_row0[(size_t)w + 1] - m0;
+        G.win_m[(size_t)w] = (int32_t)m;
+        G.max_m = std::max(G.max_m, (int)m);
+        if (w < Wd) {
+            for (int64_t r = 0; r < m; ++r) row_win[(size_t)(m0 + r)] = w;
+            win_bits_off[(size_t)w + 1] = win_bits_off[(size_t)w] + m * ((m + 63) >> 6);
+            max_m_dev = std::max(max_m_dev, (int)m);
+        }
     }
-    DBuf d_oo, d_n, d_wc, d_mo, d_ids, d_rw, d_bo, d_bits, d_ac, d_ar, d_deg, d_no, d_nbr;
-    UploadPack pk;
-    pk.add(ctg_out_off, d_oo);
-    pk.add(ctg_n, d_n);
-    pk.add(job.win_contig, d_wc);
-    pk.add(job.win_mask_off, d_mo);
-    pk.add(job.mask_ids, d_ids);
-    pk.add(row_win, d_rw);
-    pk.add(win_bits_off, d_bo);
-    if (int rc = pk.commit(stream)) return rc;
-    const size_t bits_bytes = (size_t)win_bits_off.back() * 8;
-    if (int rc = d_bits.alloc(bits_bytes)) return rc;
-    if (int rc = d_ac.alloc(4)) return rc;
-    if (int rc = d_ar.alloc((size_t)rows * 4)) return rc;
-    HS_HIP(hipMemsetAsync(d_bits.p, 0, bits_bytes ? bits_bytes : 8, stream));
-    HS_HIP(hipMemsetAsync(d_ac.p, 0, 4, stream));
-    // per-wave LDS: cap distances + cap totals. Four waves per workgroup while they fit, else one; windows wider than that
-    // (m > 7168 masked reads) send their rows to the host
-    int cap = ((max_m + 63) / 64) * 64, waves = 4;
-    if ((size_t)cap * 8 * 4 > 57344) waves = 1;
-    if ((size_t)cap * 8 > 57344) cap = 7168;
-    const float below = 1 - job.error_rate * 2;   // :778
-    EventPair ev; if (int rc = ev.init()) return rc;
-    HS_HIP(hipEventRecord(ev.a, stream));
-    hipLaunchKernelGGL(hsdev::k_read_graph_rows, dim3((rows + waves - 1) / waves), dim3(64 * waves), (size_t)cap * 8 * waves, stream, d_sim, d_diff,
-                       d_oo.as<int64_t>(), d_n.as<int32_t>(), d_wc.as<int32_t>(), d_mo.as<int64_t>(), d_ids.as<int32_t>(), d_rw.as<int32_t>(),
-                       d_bo.as<int64_t>(), rows, below, cap, d_bits.as<unsigned long long>(), d_ac.as<int32_t>(), d_ar.as<int32_t>(), rows);
-    HS_HIP(hipGetLastError());
-    HS_HIP(hipEventRecord(ev.b, stream));
-    int32_t n_amb = 0;
-    if (int rc = d2h_pinned(&n_amb, d_ac.p, 4, stream)) return rc;
-    if (n_amb > 0) {
-        // rows where std::sort's arrangement of equal distances decides: fetch their sim/diff rows, do exactly what the reference does
-        std::vector<int32_t> amb((size_t)n_amb);
-        if (int rc = d2h_pinned(amb.data(), d_ar.p, (size_t)n_amb * 4, stream)) return rc;
-        std::sort(amb.begin(), amb.end());
-        std::vector<int64_t> src((size_t)n_amb), dst((size_t)n_amb + 1, 0);
-        std::vector<int32_t> len((size_t)n_amb);
-        for (int k = 0; k < n_amb; ++k) {
-            const int w = row_win[(size_t)amb[(size_t)k]];
-            const int c = job.win_contig[(size_t)w];
-            const int N = ctg_n[(size_t)c];
-            const int r1 = job.mask_ids[(size_t)amb[(size_t)k]];
-            src[(size_t)k] = ctg_out_off[(size_t)c] + (int64_t)r1 * N; len[(size_t)k] = N; dst[(size_t)k + 1] = dst[(size_t)k] + N;
-        }
-        DBuf d_src, d_len, d_dst, d_os, d_od;
-        if (int rc = d_src.upload(src)) return rc;
-        if (int rc = d_len.upload(len)) return rc;
-        if (int rc = d_dst.upload(dst)) return rc;
-        if (int rc = d_os.alloc((size_t)dst.back() * 4)) return rc;
-        if (int rc = d_od.alloc((size_t)dst.back() * 4)) return rc;
-        hipLaunchKernelGGL(hsdev::k_read_graph_fetch_rows, dim3(n_amb), dim3(256), 0, stream, d_sim, d_diff, d_src.as<int64_t>(), d_len.as<int32_t>(),
-                           d_dst.as<int64_t>(), d_os.as<int32_t>(), d_od.as<int32_t>());
-        HS_HIP(hipGetLastError());
-        std::vector<int32_t> hs_((size_t)dst.back()), hd_((size_t)dst.back());
-        if (int rc = d2h_pinned(hs_.data(), d_os.p, hs_.size() * 4, stream)) return rc;
-        if (int rc = d2h_pinned(hd_.data(), d_od.p, hd_.size() * 4, stream)) return rc;
-        if (int rc_w = stream_wait(stream)) return rc_w;
-        std::vector<int64_t> pbase; std::vector<int32_t> pmw, pi, pj;
-        std::vector<uint8_t> mask;
-        std::vector<int> picked;
-        for (int k = 0; k < n_amb; ++k) {
-            const int row = amb[(size_t)k];
-            const int w = row_win[(size_t)row];
-            const int64_t m0 = job.win_mask_off[(size_t)w];
-            const int m = (int)(job.win_mask_off[(size_t)w + 1] - m0);
-            const int32_t* ids = job.mask_ids.data() + m0;
-            const int N = len[(size_t)k];
-            mask.assign((size_t)N, 0);
-            for (int j = 0; j < m; ++j) mask[(size_t)ids[j]] = 1;
-            hs::sr_pick_row_sorted(hs_.data() + dst[(size_t)k], hd_.data() + dst[(size_t)k], N, ids[row - m0], mask.data(), job.error_rate, picked);
-            for (int nb : picked) {
-                const int j = (int)(std::lower_bound(ids, ids + m, nb) - ids);
-                pbase.push_back(win_bits_off[(size_t)w]); pmw.push_back((m + 63) >> 6); pi.push_back((int32_t)(row - m0)); pj.push_back(j);
-            }
-        }
-        if (!pi.empty()) {
-            DBuf d_pb, d_pm, d_pi, d_pj;
-            if (int rc = d_pb.upload(pbase)) return rc;
-            if (int rc = d_pm.upload(pmw)) return rc;
-            if (int rc = d_pi.upload(pi)) return rc;
-            if (int rc = d_pj.upload(pj)) return rc;
-            const int np = (int)pi.size();
-            hipLaunchKernelGGL(hsdev::k_read_graph_patch, dim3((np + 255) / 256), dim3(256), 0, stream, d_pb.as<int64_t>(), d_pm.as<int32_t>(), d_pi.as<int32_t>(),
-                               d_pj.as<int32_t>(), np, d_bits.as<unsigned long long>());
-            HS_HIP(hipGetLastError());
-            if (int rc_w = stream_wait(stream)) return rc_w;   // the patch arrays die with this scope
-        }
-        res.rows_resolved_on_host = n_amb;
-    }
+    G.pack.add(ctg_out_off, G.d_oo);
+    G.pack.add(ctg_n, G.d_n);
+    G.pack.add(ws.win_contig, G.d_wc);
+    G.pack.add(ws.win_row0, G.d_row0);
+    G.pack.add(ws.mask_ids, G.d_ids);
+    G.pack.add(row_win, G.d_rw);
+    G.pack.add(win_bits_off, G.d_bo);
+    G.pack.add(ws.win_final_empty, G.d_fe);
+    G.pack.add(ws.rank, G.d_rank);
+    G.pack.add(ws.ctg_rank_off, G.d_rank_off);
+    if (int rc = G.pack.commit(stream)) return rc;
+    if (int rc = G.d_off.alloc(((size_t)rows + 1) * 8)) return rc;
+    if (int rc = G.d_visit.alloc(std::max<size_t>((size_t)rows, 1) * 4)) return rc;
+    if (int rc = G.d_visit_n.alloc(std::max<size_t>((size_t)W, 1) * 4)) return rc;
+    if (rows == 0) { HS_HIP(hipMemsetAsync(G.d_off.p, 0, 8, stream)); return HS_OK; }
+    DBuf d_bits, d_ac, d_ar, d_deg, d_scan;
     if (int rc = d_deg.alloc((size_t)rows * 4)) return rc;
-    if (int rc = d_no.alloc(((size_t)rows + 1) * 8)) return rc;
-    hipLaunchKernelGGL(hsdev::k_read_graph_degrees, dim3((rows + 255) / 256), dim3(256), 0, stream, d_bits.as<unsigned long long>(), d_rw.as<int32_t>(),
-                       d_mo.as<int64_t>(), d_bo.as<int64_t>(), rows, d_deg.as<int32_t>());
-    DBuf d_scan;
-    if (int rc = exclusive_scan_launch(d_deg.as<int32_t>(), rows, d_no.as<int64_t>(), d_scan, stream)) return rc;
-    HS_HIP(hipGetLastError());
-    if (int rc = d2h_pinned(res.nbr_off.data(), d_no.p, ((size_t)rows + 1) * 8, stream)) return rc;
-    if (int rc_w = stream_wait(stream)) return rc_w;
-    const int64_t total = res.nbr_off.back();
-    const bool keep = keep_dev && keep_host;
-    if (!keep) res.nbr.resize((size_t)total);
-    if (total > 0) {
-        if (int rc = d_nbr.alloc((size_t)total * 4)) return rc;
-        hipLaunchKernelGGL(hsdev::k_read_graph_fill, dim3((rows + 255) / 256), dim3(256), 0, stream, d_bits.as<unsigned long long>(), d_rw.as<int32_t>(),
-                           d_mo.as<int64_t>(), d_bo.as<int64_t>(), d_ids.as<int32_t>(), d_no.as<int64_t>(), rows, d_nbr.as<int32_t>());
+    EventPair ev; if (int rc = ev.init()) return rc;
+    bool timed = false;
+    if (rows_dev > 0) {
+        if (!d_sim) { set_error("read graphs before simdiff"); return HS_EINVAL; }
+        const size_t bits_bytes = (size_t)win_bits_off.back() * 8;
+        if (int rc = d_bits.alloc(bits_bytes)) return rc;
+        if (int rc = d_ac.alloc(4)) return rc;
+        if (int rc = d_ar.alloc((size_t)rows_dev * 4)) return rc;
+        HS_HIP(hipMemsetAsync(d_bits.p, 0, bits_bytes ? bits_bytes : 8, stream));
+        HS_HIP(hipMemsetAsync(d_ac.p, 0, 4, stream));
+        // per-wave LDS: cap distances + cap totals. Four waves per workgroup while they fit, else one; windows wider than that
+        // (m > 7168 masked reads) send their rows to the host
+        int cap = ((max_m_dev + 63) / 64) * 64, waves = 4;
+        if ((size_t)cap * 8 * 4 > 57344) waves = 1;
+        if ((size_t)cap * 8 > 57344) cap = 7168;
+        const float below = 1 - ws.error_rate * 2;   // :778
+        HS_HIP(hipEventRecord(ev.a, stream));
+        hipLaunchKernelGGL(hsdev::k_read_graph_rows, dim3((rows_dev + waves - 1) / waves), dim3(64 * waves), (size_t)cap * 8 * waves, stream, d_sim, d_diff,
+                           G.d_oo.as<int64_t>(), G.d_n.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_rw.as<int32_t>(),
+                           G.d_bo.as<int64_t>(), rows_dev, below, cap, d_bits.as<unsigned long long>(), d_ac.as<int32_t>(), d_ar.as<int32_t>(), rows_dev);
         HS_HIP(hipGetLastError());
-        HBuf hb; if (int rc = hb.alloc((size_t)total * 4)) return rc;
-        HS_HIP(hipMemcpyAsync(hb.p, d_nbr.p, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
-        if (int rc_w = stream_wait(stream)) return rc_w;
-        if (keep) {
-            std::swap(keep_dev->p, d_nbr.p); std::swap(keep_dev->cap, d_nbr.cap); std::swap(keep_dev->bytes, d_nbr.bytes); std::swap(keep_dev->view, d_nbr.view);
-            std::swap(keep_host->p, hb.p); std::swap(keep_host->cap, hb.cap);
-            res.nbr_view = (const int32_t*)keep_host->p;
-        } else std::memcpy(res.nbr.data(), hb.p, (size_t)total * 4);
+        HS_HIP(hipEventRecord(ev.b, stream));
+        timed = true;
+        int32_t n_amb = 0;
+        if (int rc = d2h_pinned(&n_amb, d_ac.p, 4, stream)) return rc;
+        if (n_amb > 0) {
+            // rows where std::sort's arrangement of equal distances decides: fetch their sim/diff rows, do exactly what the reference does
+            std::vector<int32_t> amb((size_t)n_amb);
+            if (int rc = d2h_pinned(amb.data(), d_ar.p, (size_t)n_amb * 4, stream)) return rc;
+            std::sort(amb.begin(), amb.end());
+            std::vector<int64_t> src((size_t)n_amb), dst((size_t)n_amb + 1, 0);
+            std::vector<int32_t> len((size_t)n_amb);
+            for (int k = 0; k < n_amb; ++k) {
+                const int w = row_win[(size_t)amb[(size_t)k]];
+                const int c = ws.win_contig[(size_t)w];
+                const int N = ctg_n[(size_t)c];
+                const int r1 = ws.mask_ids[(size_t)amb[(size_t)k]];
+                src[(size_t)k] = ctg_out_off[(size_t)c] + (int64_t)r1 * N; len[(size_t)k] = N; dst[(size_t)k + 1] = dst[(size_t)k] + N;
+            }
+            DBuf d_src, d_len, d_dst, d_os, d_od;
+            if (int rc = d_src.upload(src)) return rc;
+            if (int rc = d_len.upload(len)) return rc;
+            if (int rc = d_dst.upload(dst)) return rc;
+            if (int rc = d_os.alloc((size_t)dst.back() * 4)) return rc;
+            if (int rc = d_od.alloc((size_t)dst.back() * 4)) return rc;
+            hipLaunchKernelGGL(hsdev::k_read_graph_fetch_rows, dim3(n_amb), dim3(256), 0, stream, d_sim, d_diff, d_src.as<int64_t>(), d_len.as<int32_t>(),
+                               d_dst.as<int64_t>(), d_os.as<int32_t>(), d_od.as<int32_t>());
+            HS_HIP(hipGetLastError());
+            std::vector<int32_t> hs_((size_t)dst.back()), hd_((size_t)dst.back());
+            if (int rc = d2h_pinned(hs_.data(), d_os.p, hs_.size() * 4, stream)) return rc;
+            if (int rc = d2h_pinned(hd_.data(), d_od.p, hd_.size() * 4, stream)) return rc;
+            if (int rc_w = stream_wait(stream)) return rc_w;
+            std::vector<int64_t> pbase; std::vector<int32_t> pmw, pi, pj;
+            std::vector<uint8_t> mask;
+            std::vector<int> picked;
+            for (int k = 0; k < n_amb; ++k) {
+                const int row = amb[(size_t)k];
+                const int w = row_win[(size_t)row];
+                const int64_t m0 = ws.win_row0[(size_t)w];
+                const int m = (int)(ws.win_row0[(size_t)w + 1] - m0);
+                const int32_t* ids = ws.mask_ids.data() + m0;
+                const int N = len[(size_t)k];
+                mask.assign((size_t)N, 0);
+                for (int j = 0; j < m; ++j) mask[(size_t)ids[j]] = 1;
+                hs::sr_pick_row_sorted(hs_.data() + dst[(size_t)k], hd_.data() + dst[(size_t)k], N, ids[row - m0], mask.data(), ws.error_rate, picked);
+                for (int nb : picked) {
+                    const int j = (int)(std::lower_bound(ids, ids + m, nb) - ids);
+                    pbase.push_back(win_bits_off[(size_t)w]); pmw.push_back((m + 63) >> 6); pi.push_back((int32_t)(row - m0)); pj.push_back(j);
+                }
+            }
+            if (!pi.empty()) {
+                DBuf d_pb, d_pm, d_pi, d_pj;
+                if (int rc = d_pb.upload(pbase)) return rc;
+                if (int rc = d_pm.upload(pmw)) return rc;
+                if (int rc = d_pi.upload(pi)) return rc;
+                if (int rc = d_pj.upload(pj)) return rc;
+                const int np = (int)pi.size();
+                hipLaunchKernelGGL(hsdev::k_read_graph_patch, dim3((np + 255) / 256), dim3(256), 0, stream, d_pb.as<int64_t>(), d_pm.as<int32_t>(), d_pi.as<int32_t>(),
+                                   d_pj.as<int32_t>(), np, d_bits.as<unsigned long long>());
+                HS_HIP(hipGetLastError());
+                if (int rc_w = stream_wait(stream)) return rc_w;   // the patch arrays die with this scope
+            }
+            if (rows_on_host) *rows_on_host = n_amb;
+        }
+        hipLaunchKernelGGL(hsdev::k_read_graph_degrees, dim3((rows_dev + 255) / 256), dim3(256), 0, stream, d_bits.as<unsigned long long>(), G.d_rw.as<int32_t>(),
+                           G.d_row0.as<int64_t>(), G.d_bo.as<int64_t>(), rows_dev, d_deg.as<int32_t>());
+        HS_HIP(hipGetLastError());
     }
-    float m = 0; if (int rc = ev.ms(&m)) return rc;
-    if (k_ms) *k_ms += m;
+    HBuf h_deg;   // degrees of the rows the host brings
+    if (rows > rows_dev) {
+        const size_t nh = (size_t)(rows - rows_dev);
+        if (int rc = h_deg.alloc(nh * 4)) return rc;
+        int32_t* hd = (int32_t*)h_deg.p;
+        for (size_t r = 0; r < nh; ++r) hd[r] = (int32_t)(ws.host_off[r + 1] - ws.host_off[r]);
+        HS_HIP(hipMemcpyAsync(d_deg.as<int32_t>() + rows_dev, hd, nh * 4, hipMemcpyHostToDevice, stream));
+    }
+    if (int rc = exclusive_scan_launch(d_deg.as<int32_t>(), rows, G.d_off.as<int64_t>(), d_scan, stream)) return rc;
+    int64_t total = 0;
+    if (int rc = d2h_pinned(&total, G.d_off.as<int64_t>() + rows, 8, stream)) return rc;
+    G.total = total;
+    if (int rc = G.d_nbr.alloc(std::max<size_t>((size_t)total, 1) * 4)) return rc;
+    HBuf h_nbr;
+    if (total > 0) {
+        if (rows_dev > 0) {
+            hipLaunchKernelGGL(hsdev::k_read_graph_fill, dim3((rows_dev + 255) / 256), dim3(256), 0, stream, d_bits.as<unsigned long long>(), G.d_rw.as<int32_t>(),
+                               G.d_row0.as<int64_t>(), G.d_bo.as<int64_t>(), G.d_off.as<int64_t>(), rows_dev, G.d_nbr.as<int32_t>());
+            HS_HIP(hipGetLastError());
+        }
+        if (!ws.host_nbr.empty()) {   // the host rows sit behind the device rows: their lists start at total - |host_nbr|
+            const size_t nb = ws.host_nbr.size() * 4;
+            if (int rc = h_nbr.alloc(nb)) return rc;
+            std::memcpy(h_nbr.p, ws.host_nbr.data(), nb);
+            HS_HIP(hipMemcpyAsync(G.d_nbr.as<int32_t>() + (total - (int64_t)ws.host_nbr.size()), h_nbr.p, nb, hipMemcpyHostToDevice, stream));
+        }
+    }
+    {   // visiting order of every window (hs_kernels_cw.hip)
+        const int cap = std::min(((G.max_m + 63) / 64) * 64, 8192);
+        hipLaunchKernelGGL(hsdev::k_cw_visit_lists, dim3((unsigned)W), dim3(256), (size_t)cap * 4, stream, G.d_off.as<int64_t>(), G.d_row0.as<int64_t>(),
+                           G.d_ids.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_rank_off.as<int64_t>(), G.d_rank.as<int32_t>(), W, cap, G.d_visit.as<int32_t>(),
+                           G.d_visit_n.as<int32_t>());
+        HS_HIP(hipGetLastError());
+    }
+    if (int rc_w = stream_wait(stream)) return rc_w;     // the temporaries (bit matrices, degrees, staging) die with this scope
+    if (timed) { float m = 0; if (int rc = ev.ms(&m)) return rc; if (k_ms) *k_ms += m; }
     return HS_OK;
 }
 
 struct HipSrOps : hs::SrDeviceOps {
     hipStream_t stream = nullptr;
-    DBuf d_adj_off, d_adj, d_gob, d_gab, d_gn, d_perm, d_pb, d_mask;
     DBuf d_sim, d_diff;                       // K5 results stay in HBM for K6
     std::vector<int64_t> sd_out_off;
     std::vector<int32_t> sd_n;
-    int max_n = 1;
+    GraphRows G;
 
     // K5 runs on while the host plans the windows: its temporaries and its timing events are parked here until the next
     // call that waits for the stream anyway
@@ -1149,16 +1191,8 @@ struct HipSrOps : hs::SrDeviceOps {
     }
     ~HipSrOps() override { (void)settle_simdiff(false); }   // the caller's counter may be gone by now
 
-    int read_graphs(const hs::ReadGraphJob& job, hs::ReadGraphResult& res, float* k_ms) override {
-        if (!d_sim.p) { set_error("read_graphs before simdiff"); return HS_EINVAL; }
-        const int rc = read_graphs_run(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, job, res, stream, k_ms, &d_rows_nbr, &h_rows_nbr);
-        const int rc2 = settle_simdiff();   // K6 came after K5 on the stream and has been waited for
-        return rc ? rc : rc2;
-    }
-
-    DBuf d_col_off, d_col_idx, d_col_code;    // SNP columns of the batch: uploaded once, read by K5a and the seeded CW wave
-    UploadPack col_pack, graph_pack;          // their storage, and the storage of the graph set
-    DBuf d_visit, d_visit_n;                  // per-graph visiting lists of the Chinese-Whispers kernel
+    DBuf d_col_off, d_col_idx, d_col_code;    // SNP columns of the batch: uploaded once, read by K5a and the seeded CW runs
+    UploadPack col_pack;
     const hs::CwChain* resident_cols = nullptr;
     int simdiff_columns(const hs::SimdiffJob& job, float* k_ms) override {
         const hs::CwChain& ch = *job.cols;
@@ -1197,167 +1231,181 @@ struct HipSrOps : hs::SrDeviceOps {
         HS_HIP(hipEventRecord(f.ev.b, stream));
         return HS_OK;   // not waited for: the stream orders K6 behind it, the host goes on planning the windows
     }
-    DBuf d_rows_nbr;                          // neighbour array of the last K6 pass (the graph set may be slices of it)
-    HBuf h_rows_nbr;                          // and its pinned host copy (what ReadGraphResult::nbr_view points at)
-    bool keeps_graph_rows() const override { return true; }
-    int set_graphs(const hs::CwGraphSet& g) override {
-        max_n = g.max_n;
-        graph_pack.add(g.adj_off, d_adj_off);
-        if (g.adj_is_graph_rows) {
-            if (d_adj.p && !d_adj.view) pool().put(false, d_adj.p, d_adj.cap);
-            d_adj.p = d_rows_nbr.p; d_adj.bytes = d_rows_nbr.bytes; d_adj.cap = 0; d_adj.view = true;   // a view: d_rows_nbr owns the memory
-        } else graph_pack.add(g.adj, d_adj);
-        if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] sr graph set: %zu graphs, adjacency %s\n", g.graph_n.size(),
-                                                   g.adj_is_graph_rows ? "= slices of the K6 neighbour array on the device" : "uploaded");
-        graph_pack.add(g.graph_off_base, d_gob);
-        graph_pack.add(g.graph_adj_base, d_gab);
-        graph_pack.add(g.graph_n, d_gn);
-        graph_pack.add(g.perm, d_perm);
-        graph_pack.add(g.perm_base_of_graph, d_pb);
-        graph_pack.add(g.mask, d_mask);
-        if (int rc = graph_pack.commit(stream)) return rc;
-        // visiting lists (masked nodes with neighbours, in permutation order), once per graph
-        const int n_graphs = (int)g.graph_n.size();
-        if (int rc = d_visit.alloc(g.mask.size() * sizeof(int32_t))) return rc;
-        if (int rc = d_visit_n.alloc((size_t)n_graphs * sizeof(int32_t))) return rc;
-        if (n_graphs > 0) {
-            hipLaunchKernelGGL(hsdev::k_cw_visit_lists, dim3((unsigned)n_graphs), dim3(64), 0, stream, d_adj_off.as<int32_t>(), d_gob.as<int64_t>(),
-                               d_gn.as<int32_t>(), d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), n_graphs, d_visit.as<int32_t>(),
-                               d_visit_n.as<int32_t>());
-            HS_HIP(hipGetLastError());
-        }
+
+    int build_graphs(const hs::SrWindowSet& ws, int64_t* rows_on_host, float* k_ms) override {
+        const int rc = graph_rows_build(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, ws, G, stream, rows_on_host, k_ms);
+        const int rc2 = settle_simdiff();   // K6 came after K5 on the stream and has been waited for
+        return rc ? rc : rc2;
+    }
+    int fetch_graphs(std::vector<int64_t>& off, std::vector<int32_t>& nbr) override {
+        off.assign((size_t)G.rows + 1, 0); nbr.assign((size_t)G.total, 0);
+        if (int rc = d2h_pinned(off.data(), G.d_off.p, off.size() * 8, stream)) return rc;
+        if (G.total > 0) { if (int rc = d2h_pinned(nbr.data(), G.d_nbr.p, nbr.size() * 4, stream)) return rc; }
         return HS_OK;
     }
+
+    // dynamic LDS of the one-wavefront-per-instance kernels: nodes kept in LDS (wider windows use global scratch)
+    static int lds_nodes(int max_m, int ints_per_node, int limit_bytes) {
+        const int cap = ((std::max(max_m, 1) + 63) / 64) * 64;
+        return std::min(cap, (limit_bytes / (ints_per_node * 4)) / 64 * 64);
+    }
+
     int cw_chain(const hs::CwChain& ch, std::vector<int32_t>& labels, std::vector<int32_t>& final_labels, std::vector<uint8_t>& final_ok,
-                 float k_ms[3]) override {
-        if (int rc = settle_simdiff()) return rc;   // (a batch without graph windows never called read_graphs)
-        const int W = (int)ch.win_n.size();
+                 float k_ms[3], hs::SrChainStats* stats) override {
+        if (int rc = settle_simdiff()) return rc;   // (a batch without graph windows never built graphs)
+        const int Wc = (int)ch.win.size();
         const int64_t n_inst = (int64_t)ch.seed_col.size();
-        const int64_t total_n = ch.win_label_base.back();
-        // per-SNP instances: graph, label base inside the local-label slab (instances of a window are contiguous)
-        std::vector<int32_t> ig((size_t)n_inst), win_k((size_t)W);
-        std::vector<int64_t> ilb((size_t)n_inst), win_local_base((size_t)W);
-        int64_t slab = 0;
-        for (int w = 0; w < W; ++w) {
-            win_local_base[(size_t)w] = slab;
-            win_k[(size_t)w] = (int32_t)(ch.win_seed_begin[(size_t)w + 1] - ch.win_seed_begin[(size_t)w]);
-            for (int64_t i = ch.win_seed_begin[(size_t)w]; i < ch.win_seed_begin[(size_t)w + 1]; ++i) {
-                ig[(size_t)i] = ch.win_graph_now[(size_t)w]; ilb[(size_t)i] = slab; slab += ch.win_n[(size_t)w];
+        const int64_t total_m = ch.chain_row0.back();
+        if (n_inst > 0x7fffffff) { set_error("Chinese Whispers: too many runs in one call"); return HS_EINVAL; }
+        // per-SNP runs: window, slab offset (the runs of a window are contiguous: K * m labels); small windows go to the
+        // row-packed kernel, the others to the one-wavefront-per-run kernel
+        std::vector<int32_t> inst_win((size_t)n_inst), list_small, list_big;
+        std::vector<int64_t> inst_slab((size_t)n_inst), chain_slab0((size_t)Wc), big_scr, tail_scr((size_t)Wc, 0);
+        int64_t slab = 0, big_scr_total = 0, tail_scr_total = 0;
+        int max_m_big = 1, max_m_chain = 1;
+        for (int k = 0; k < Wc; ++k) {
+            const int w = ch.win[(size_t)k];
+            const int m = G.win_m[(size_t)w];
+            chain_slab0[(size_t)k] = slab;
+            max_m_chain = std::max(max_m_chain, m);
+            for (int64_t i = ch.win_seed_begin[(size_t)k]; i < ch.win_seed_begin[(size_t)k + 1]; ++i) {
+                inst_win[(size_t)i] = w; inst_slab[(size_t)i] = slab; slab += m;
+                if (m <= HS_CWR_CAP) list_small.push_back((int32_t)i);
+                else { list_big.push_back((int32_t)i); max_m_big = std::max(max_m_big, m); }
             }
         }
-        std::vector<int64_t> wbase(ch.win_label_base.begin(), ch.win_label_base.end() - 1);
-        DBuf d_ig, d_ilb, d_seed, d_local, d_wk, d_wn, d_wgn, d_wgf, d_wlb, d_wob, d_lab2, d_lab3, d_agg,
-            d_s1, d_s2, d_s3;
+        const int cap_big = lds_nodes(max_m_big, 2, 96 * 1024);
+        for (int32_t i : list_big) {
+            const int m = G.win_m[(size_t)inst_win[(size_t)i]];
+            big_scr.push_back(big_scr_total);
+            if (m > cap_big) big_scr_total += 2 * (int64_t)m;
+        }
+        const int cap_tail = lds_nodes(max_m_chain, 7, 56 * 1024);
+        for (int k = 0; k < Wc; ++k) {
+            const int m = G.win_m[(size_t)ch.win[(size_t)k]];
+            tail_scr[(size_t)k] = tail_scr_total;
+            if (m > cap_tail) tail_scr_total += 7 * (int64_t)m + (m & 1);      // keeps the next window's doubles 8-byte aligned
+        }
+        DBuf d_iw, d_is, d_seed, d_ls, d_lb, d_bs, d_cw, d_cr0, d_csb, d_cs0, d_ts, d_slab, d_gs, d_l3, d_final, d_ok, d_stat,
+            d_cpos, d_sf, d_sl, d_plo, d_phi;
         if (resident_cols != &ch) {   // normally uploaded by simdiff_columns already
             col_pack.add(ch.col_off, d_col_off); col_pack.add(ch.col_idx, d_col_idx); col_pack.add(ch.col_code, d_col_code);
             if (int rc = col_pack.commit(stream)) return rc;
             resident_cols = &ch;
         }
+        const bool finish = ch.finish_on_device && !std::getenv("HS_FINISH_ON_HOST");
         UploadPack pk;
-        pk.add(ig, d_ig); pk.add(ilb, d_ilb); pk.add(ch.seed_col, d_seed);
-        if (int rc = d_local.alloc((size_t)slab * sizeof(int32_t))) return rc;
-        pk.add(win_k, d_wk); pk.add(ch.win_n, d_wn); pk.add(ch.win_graph_now, d_wgn); pk.add(ch.win_graph_final, d_wgf);
-        pk.add(win_local_base, d_wlb); pk.add(wbase, d_wob);
+        pk.add(inst_win, d_iw); pk.add(inst_slab, d_is); pk.add(ch.seed_col, d_seed); pk.add(list_small, d_ls); pk.add(list_big, d_lb);
+        pk.add(big_scr, d_bs); pk.add(ch.win, d_cw); pk.add(ch.chain_row0, d_cr0); pk.add(ch.win_seed_begin, d_csb); pk.add(chain_slab0, d_cs0);
+        pk.add(tail_scr, d_ts);
+        if (finish) { pk.add(ch.col_pos, d_cpos); pk.add(ch.win_snp_first, d_sf); pk.add(ch.win_snp_last, d_sl); pk.add(ch.win_pos_lo, d_plo); pk.add(ch.win_pos_hi, d_phi); }
         if (int rc = pk.commit(stream)) return rc;
-        if (int rc = d_lab2.alloc((size_t)total_n * sizeof(int32_t))) return rc;
-        if (int rc = d_lab3.alloc((size_t)total_n * sizeof(int32_t))) return rc;
-        if (int rc = d_agg.alloc((size_t)total_n * sizeof(double))) return rc;
-        if (int rc = d_s1.alloc((size_t)total_n * sizeof(int32_t))) return rc;
-        if (int rc = d_s2.alloc((size_t)total_n * sizeof(int32_t))) return rc;
-        if (int rc = d_s3.alloc((size_t)total_n * sizeof(int32_t))) return rc;
-        EventPair e1, e2, e3;
+        if (int rc = d_slab.alloc(std::max<size_t>((size_t)slab, 1) * 4)) return rc;
+        if (int rc = d_gs.alloc(std::max<size_t>((size_t)std::max(big_scr_total, tail_scr_total), 2) * 4)) return rc;
+        if (int rc = d_l3.alloc(std::max<size_t>((size_t)total_m, 1) * 4)) return rc;
+        if (int rc = d_final.alloc(std::max<size_t>((size_t)total_m, 1) * 4)) return rc;
+        if (int rc = d_ok.alloc(std::max<size_t>((size_t)Wc, 1))) return rc;
+        if (int rc = d_stat.alloc(16)) return rc;
+        HS_HIP(hipMemsetAsync(d_stat.p, 0, 16, stream));
+        EventPair e1, e2;
         if (int rc = e1.init()) return rc;
         if (int rc = e2.init()) return rc;
-        if (int rc = e3.init()) return rc;
-        // wave 1: per-SNP runs, seeded on the device from the SNP columns
+        // ---- per-SNP runs, seeded on the device from the SNP columns ----
         HS_HIP(hipEventRecord(e1.a, stream));
-        if (int rc = cw_launch(d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_gn.as<int32_t>(),
-                               d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), d_ig.as<int32_t>(), d_ilb.as<int64_t>(), (int32_t)n_inst,
-                               max_n, d_local.as<int32_t>(), nullptr, stream, d_seed.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
-                               d_col_code.as<uint8_t>(), d_visit.as<int32_t>(), d_visit_n.as<int32_t>())) return rc;
-        HS_HIP(hipEventRecord(e1.b, stream));
-        // merged ids -> wave 2 on the finalize graph
-        HS_HIP(hipEventRecord(e2.a, stream));
-        hipLaunchKernelGGL(hsdev::k_cw_merge_ids, dim3((unsigned)W), dim3(256), 0, stream, d_local.as<int32_t>(), d_wlb.as<int64_t>(), d_wk.as<int32_t>(),
-                           d_wn.as<int32_t>(), d_wgf.as<int32_t>(), d_gob.as<int64_t>(), d_mask.as<uint8_t>(), d_wob.as<int64_t>(), d_agg.as<double>(),
-                           d_s1.as<int32_t>(), d_s2.as<int32_t>(), d_lab2.as<int32_t>());
-        HS_HIP(hipGetLastError());
-        if (int rc = cw_launch(d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_gn.as<int32_t>(),
-                               d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), d_wgf.as<int32_t>(), d_wob.as<int64_t>(), W, max_n,
-                               d_lab2.as<int32_t>(), nullptr, stream, nullptr, nullptr, nullptr, nullptr, d_visit.as<int32_t>(), d_visit_n.as<int32_t>())) return rc;
-        HS_HIP(hipEventRecord(e2.b, stream));
-        // small clusters dropped, renumbered -> wave 3
-        HS_HIP(hipEventRecord(e3.a, stream));
-        hipLaunchKernelGGL(hsdev::k_cw_drop_small, dim3((unsigned)W), dim3(256), 0, stream, d_lab2.as<int32_t>(), d_wn.as<int32_t>(), d_wgf.as<int32_t>(),
-                           d_gob.as<int64_t>(), d_mask.as<uint8_t>(), d_wob.as<int64_t>(), d_s1.as<int32_t>(), d_s2.as<int32_t>(), d_s3.as<int32_t>(),
-                           d_lab3.as<int32_t>());
-        HS_HIP(hipGetLastError());
-        if (int rc = cw_launch(d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_gn.as<int32_t>(),
-                               d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), d_wgf.as<int32_t>(), d_wob.as<int64_t>(), W, max_n,
-                               d_lab3.as<int32_t>(), nullptr, stream, nullptr, nullptr, nullptr, nullptr, d_visit.as<int32_t>(), d_visit_n.as<int32_t>())) return rc;
-        HS_HIP(hipEventRecord(e3.b, stream));
-        // K8: first-seen renumbering + merge_close_clusters + merge_wrongly_split on the device, one wavefront per window
-        const size_t fin_lds = (size_t)max_n * 3 * sizeof(int32_t);
-        const bool finish = ch.finish_on_device && fin_lds <= 100 * 1024 && !std::getenv("HS_FINISH_ON_HOST");
-        DBuf d_final, d_ok, d_cpos, d_sf, d_sl, d_plo, d_phi;
-        UploadPack pk2;
-        if (finish) {
-            pk2.add(ch.col_pos, d_cpos); pk2.add(ch.win_snp_first, d_sf); pk2.add(ch.win_snp_last, d_sl); pk2.add(ch.win_pos_lo, d_plo); pk2.add(ch.win_pos_hi, d_phi);
-            if (int rc = pk2.commit(stream)) return rc;
-            if (int rc = d_final.alloc((size_t)total_n * sizeof(int32_t))) return rc;
-            if (int rc = d_ok.alloc((size_t)W)) return rc;
-            if (fin_lds > 32 * 1024)
-                HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_finish_window), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds));
-            hipLaunchKernelGGL(hsdev::k_finish_window, dim3((unsigned)W), dim3(64), fin_lds, stream, d_lab3.as<int32_t>(), d_wob.as<int64_t>(), d_wn.as<int32_t>(),
-                               d_wgf.as<int32_t>(), d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_mask.as<uint8_t>(),
-                               d_visit.as<int32_t>(), d_visit_n.as<int32_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(),
-                               d_cpos.as<int32_t>(), d_sf.as<int64_t>(), d_sl.as<int64_t>(), d_plo.as<int32_t>(), d_phi.as<int32_t>(), W, d_final.as<int32_t>(),
-                               d_ok.as<uint8_t>());
+        if (!list_small.empty()) {
+            const int n = (int)list_small.size();
+            hipLaunchKernelGGL(hsdev::k_cw_seeded_rows, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(),
+                               G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), d_ls.as<int32_t>(), n,
+                               d_iw.as<int32_t>(), d_seed.as<int64_t>(), d_is.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
+                               d_col_code.as<uint8_t>(), d_slab.as<int32_t>(), d_stat.as<unsigned long long>());
             HS_HIP(hipGetLastError());
         }
+        if (!list_big.empty()) {
+            const int n = (int)list_big.size();
+            const size_t lds = (size_t)cap_big * 8;
+            if (lds > 48 * 1024)
+                HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_cw_seeded_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(hsdev::k_cw_seeded_wave, dim3((unsigned)n), dim3(64), lds, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(),
+                               G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), d_lb.as<int32_t>(), n,
+                               d_iw.as<int32_t>(), d_seed.as<int64_t>(), d_is.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
+                               d_col_code.as<uint8_t>(), cap_big, d_gs.as<int32_t>(), d_bs.as<int64_t>(), d_slab.as<int32_t>(), d_stat.as<unsigned long long>());
+            HS_HIP(hipGetLastError());
+        }
+        HS_HIP(hipEventRecord(e1.b, stream));
+        // ---- the rest of the window's chain, labels in LDS from here to the finished clusters ----
+        HS_HIP(hipEventRecord(e2.a, stream));
+        if (Wc > 0) {
+            const size_t lds = (size_t)cap_tail * 7 * 4;
+            if (lds > 32 * 1024)
+                HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_window_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(hsdev::k_window_tail, dim3((unsigned)Wc), dim3(64), lds, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(), G.d_row0.as<int64_t>(),
+                               G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), G.d_fe.as<uint8_t>(), d_cw.as<int32_t>(), d_cr0.as<int64_t>(),
+                               d_csb.as<int64_t>(), d_cs0.as<int64_t>(), d_slab.as<int32_t>(), Wc, d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
+                               d_col_code.as<uint8_t>(), d_cpos.as<int32_t>(), d_sf.as<int64_t>(), d_sl.as<int64_t>(), d_plo.as<int32_t>(), d_phi.as<int32_t>(),
+                               finish ? 1 : 0, cap_tail, d_gs.as<int32_t>(), d_ts.as<int64_t>(), d_l3.as<int32_t>(), d_final.as<int32_t>(), d_ok.as<uint8_t>(),
+                               d_stat.as<unsigned long long>());
+            HS_HIP(hipGetLastError());
+        }
+        HS_HIP(hipEventRecord(e2.b, stream));
         {
-            // With K8 on the device the finished labels and the per-window verdict come back first; the labels of the third wave
-            // are only fetched when some window has to be finished by the host code (few or none)
-            HBuf h, h2, h3;
+            // the finished labels and the per-window verdict come back first; the labels of the third run are only fetched
+            // when some window has to be finished by the host code (few or none)
+            HBuf h, h2, h3, h4;
+            if (int rc = h4.alloc(16)) return rc;
+            HS_HIP(hipMemcpyAsync(h4.p, d_stat.p, 16, hipMemcpyDeviceToHost, stream));
             bool need_chain_labels = !finish;
             if (finish) {
-                if (int rc = h2.alloc((size_t)total_n * sizeof(int32_t))) return rc;
-                if (int rc = h3.alloc((size_t)W)) return rc;
-                HS_HIP(hipMemcpyAsync(h2.p, d_final.p, (size_t)total_n * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-                HS_HIP(hipMemcpyAsync(h3.p, d_ok.p, (size_t)W, hipMemcpyDeviceToHost, stream));
+                if (int rc = h2.alloc(std::max<size_t>((size_t)total_m, 1) * sizeof(int32_t))) return rc;
+                if (int rc = h3.alloc(std::max<size_t>((size_t)Wc, 1))) return rc;
+                HS_HIP(hipMemcpyAsync(h2.p, d_final.p, (size_t)total_m * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                HS_HIP(hipMemcpyAsync(h3.p, d_ok.p, (size_t)Wc, hipMemcpyDeviceToHost, stream));
                 if (int rc = stream_wait(stream)) return rc;
-                final_labels.resize((size_t)total_n); final_ok.resize((size_t)W);
-                std::memcpy(final_labels.data(), h2.p, (size_t)total_n * sizeof(int32_t));
-                std::memcpy(final_ok.data(), h3.p, (size_t)W);
+                final_labels.resize((size_t)total_m); final_ok.resize((size_t)Wc);
+                std::memcpy(final_labels.data(), h2.p, (size_t)total_m * sizeof(int32_t));
+                std::memcpy(final_ok.data(), h3.p, (size_t)Wc);
                 for (uint8_t ok : final_ok) if (!ok) { need_chain_labels = true; break; }
             }
             if (need_chain_labels) {
-                labels.resize((size_t)total_n);
-                if (int rc = h.alloc((size_t)total_n * sizeof(int32_t))) return rc;
-                if (int rc = copy_d2h(h.p, d_lab3.p, (size_t)total_n * sizeof(int32_t), stream)) return rc;
-                std::memcpy(labels.data(), h.p, (size_t)total_n * sizeof(int32_t));
+                labels.resize((size_t)total_m);
+                if (int rc = h.alloc(std::max<size_t>((size_t)total_m, 1) * sizeof(int32_t))) return rc;
+                if (int rc = copy_d2h(h.p, d_l3.p, (size_t)total_m * sizeof(int32_t), stream)) return rc;
+                std::memcpy(labels.data(), h.p, (size_t)total_m * sizeof(int32_t));
             } else labels.clear();
+            if (stats) {
+                const unsigned long long* st = (const unsigned long long*)h4.p;
+                stats->n_instances = n_inst + 2 * (int64_t)Wc; stats->sweeps = (int64_t)st[0]; stats->bytes = (int64_t)st[1]; stats->graph_nnz = G.total;
+            }
         }
         float m = 0;
         if (int rc = e1.ms(&m)) return rc; k_ms[0] += m;
         if (int rc = e2.ms(&m)) return rc; k_ms[1] += m;
-        if (int rc = e3.ms(&m)) return rc; k_ms[2] += m;
         return HS_OK;
     }
     int cw(hs::CwWave& wv, float* k_ms) override {
-        const int n_inst = (int)wv.inst_graph.size();
+        const int n_inst = (int)wv.inst_win.size();
         if (n_inst == 0) return HS_OK;
-        DBuf d_ig, d_lb, d_lab;
-        if (int rc = d_ig.upload(wv.inst_graph)) return rc;
-        if (int rc = d_lb.upload(wv.inst_label_base)) return rc;
-        if (int rc = d_lab.upload(wv.labels)) return rc;
+        int max_m = 1;
+        for (int w : wv.inst_win) max_m = std::max(max_m, G.win_m[(size_t)w]);
+        const int cap = lds_nodes(max_m, 2, 96 * 1024);
+        std::vector<int64_t> scr((size_t)n_inst, 0);
+        int64_t scr_total = 0;
+        for (int k = 0; k < n_inst; ++k) { const int m = G.win_m[(size_t)wv.inst_win[(size_t)k]]; scr[(size_t)k] = scr_total; if (m > cap) scr_total += 2 * (int64_t)m; }
+        DBuf d_iw, d_lo, d_lab, d_scr, d_gs;
+        UploadPack pk;
+        pk.add(wv.inst_win, d_iw); pk.add(wv.inst_label_off, d_lo); pk.add(wv.labels, d_lab); pk.add(scr, d_scr);
+        if (int rc = pk.commit(stream)) return rc;
+        if (int rc = d_gs.alloc(std::max<size_t>((size_t)scr_total, 2) * 4)) return rc;
         EventPair ev; if (int rc = ev.init()) return rc;
         HS_HIP(hipEventRecord(ev.a, stream));
-        if (int rc = cw_launch(d_adj_off.as<int32_t>(), d_adj.as<int32_t>(), d_gob.as<int64_t>(), d_gab.as<int64_t>(), d_gn.as<int32_t>(),
-                               d_perm.as<int32_t>(), d_pb.as<int64_t>(), d_mask.as<uint8_t>(), d_ig.as<int32_t>(), d_lb.as<int64_t>(), n_inst,
-                               max_n, d_lab.as<int32_t>(), nullptr, stream, nullptr, nullptr, nullptr, nullptr, d_visit.as<int32_t>(), d_visit_n.as<int32_t>())) return rc;
+        const size_t lds = (size_t)cap * 8;
+        if (lds > 48 * 1024)
+            HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_cw_local), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(hsdev::k_cw_local, dim3((unsigned)n_inst), dim3(64), lds, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(), G.d_row0.as<int64_t>(),
+                           G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), G.d_fe.as<uint8_t>(), d_iw.as<int32_t>(), d_lo.as<int64_t>(), n_inst, cap,
+                           d_gs.as<int32_t>(), d_scr.as<int64_t>(), d_lab.as<int32_t>());
+        HS_HIP(hipGetLastError());
         HS_HIP(hipEventRecord(ev.b, stream));
-        HS_HIP(hipMemcpy(wv.labels.data(), d_lab.p, wv.labels.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (int rc = d2h_pinned(wv.labels.data(), d_lab.p, wv.labels.size() * sizeof(int32_t), stream)) return rc;
         float m = 0; if (int rc = ev.ms(&m)) return rc;
         if (k_ms) *k_ms += m;
         return HS_OK;
@@ -1386,22 +1434,32 @@ int hs_read_graphs(const int32_t* d_sim, const int32_t* d_diff, const int64_t* c
                    int32_t n_windows, float error_rate, int64_t** nbr_off, int32_t** nbr, int64_t* n_rows_host, void* stream) {
     if (int rc = require_device()) return rc;
     if (!nbr_off || !nbr || n_windows < 0 || n_contigs < 0) { set_error("hs_read_graphs: bad arguments"); return HS_EINVAL; }
-    hs::ReadGraphJob job;
-    job.error_rate = error_rate;
-    job.win_contig.assign(win_contig, win_contig + n_windows);
-    job.win_mask_off.assign(win_mask_off, win_mask_off + n_windows + 1);
-    job.mask_ids.assign(mask_ids, mask_ids + win_mask_off[n_windows]);
+    hs::SrWindowSet ws;
+    ws.error_rate = error_rate;
+    ws.win_contig.assign(win_contig, win_contig + n_windows);
+    ws.win_row0.assign(win_mask_off, win_mask_off + n_windows + 1);
+    ws.mask_ids.assign(mask_ids, mask_ids + win_mask_off[n_windows]);
+    ws.n_dev_windows = n_windows;
+    ws.win_final_empty.assign((size_t)n_windows, 0);
+    ws.ctg_rank_off.assign((size_t)n_contigs, 0);
+    int64_t ro = 0;
+    for (int c = 0; c < n_contigs; ++c) { ws.ctg_rank_off[(size_t)c] = ro; ro += ctg_n_reads[c]; }
+    ws.rank.assign((size_t)ro, 0);      // the visiting order is of no interest here
     for (int w = 0; w < n_windows; ++w) if (win_contig[w] < 0 || win_contig[w] >= n_contigs) { set_error("hs_read_graphs: window contig out of range"); return HS_EINVAL; }
-    hs::ReadGraphResult res;
+    GraphRows G;
     float ms = 0;
-    if (int rc = read_graphs_run(d_sim, d_diff, std::vector<int64_t>(ctg_out_off, ctg_out_off + n_contigs), std::vector<int32_t>(ctg_n_reads, ctg_n_reads + n_contigs),
-                                 job, res, (hipStream_t)stream, &ms)) return rc;
-    *nbr_off = (int64_t*)std::malloc(res.nbr_off.size() * sizeof(int64_t));
-    *nbr = (int32_t*)std::malloc((res.nbr.size() + 1) * sizeof(int32_t));
+    int64_t on_host = 0;
+    if (int rc = graph_rows_build(d_sim, d_diff, std::vector<int64_t>(ctg_out_off, ctg_out_off + n_contigs), std::vector<int32_t>(ctg_n_reads, ctg_n_reads + n_contigs),
+                                  ws, G, (hipStream_t)stream, &on_host, &ms)) return rc;
+    *nbr_off = (int64_t*)std::malloc(((size_t)G.rows + 1) * sizeof(int64_t));
+    *nbr = (int32_t*)std::malloc(((size_t)G.total + 1) * sizeof(int32_t));
     if (!*nbr_off || !*nbr) { set_error("hs_read_graphs: out of memory"); return HS_EINVAL; }
-    std::memcpy(*nbr_off, res.nbr_off.data(), res.nbr_off.size() * sizeof(int64_t));
-    if (!res.nbr.empty()) std::memcpy(*nbr, res.nbr.data(), res.nbr.size() * sizeof(int32_t));
-    if (n_rows_host) *n_rows_host = res.rows_resolved_on_host;
+    if (int rc = d2h_pinned(*nbr_off, G.d_off.p, ((size_t)G.rows + 1) * 8, (hipStream_t)stream)) return rc;
+    if (G.total > 0) { if (int rc = d2h_pinned(*nbr, G.d_nbr.p, (size_t)G.total * 4, (hipStream_t)stream)) return rc; }
+    // the device keeps neighbours as window-local indices; this entry point reports read ids
+    for (int w = 0; w < n_windows; ++w)
+        for (int64_t e = (*nbr_off)[win_mask_off[w]]; e < (*nbr_off)[win_mask_off[w + 1]]; ++e) (*nbr)[e] = mask_ids[win_mask_off[w] + (*nbr)[e]];
+    if (n_rows_host) *n_rows_host = on_host;
     return HS_OK;
 }
 
@@ -1548,6 +1606,7 @@ static hs_sr_result* concat_sr_parts(hs_pipeline* p, std::vector<hs_sr_result*>&
         R->t_device_ms += r->t_device_ms; R->t_host_ms += r->t_host_ms; R->n_cw_instances += r->n_cw_instances;
         for (int k = 0; k < 4; ++k) R->t_kernel_ms[k] += r->t_kernel_ms[k];
         R->t_kernel_graph_ms += r->t_kernel_graph_ms; R->n_graph_rows_host += r->n_graph_rows_host; R->n_windows_finished_on_host += r->n_windows_finished_on_host;
+        R->n_cw_sweeps += r->n_cw_sweeps; R->cw_bytes += r->cw_bytes; R->graph_nnz += r->graph_nnz; R->n_graph_rows += r->n_graph_rows; R->simdiff_bytes += r->simdiff_bytes;
         w0 += w; l0 += nl; c0 += r->n_contigs;
     }
     // the labels (tens of MB per batch): every part in a few pieces, on the caller's worker threads
@@ -1566,6 +1625,7 @@ static hs_sr_result* concat_sr_parts(hs_pipeline* p, std::vector<hs_sr_result*>&
         st->t_device_ms += R->t_device_ms; st->t_host_ms += R->t_host_ms;
         for (int k = 0; k < 4; ++k) st->t_kernel_sr_ms[k] = R->t_kernel_ms[k];
         st->t_kernel_graph_ms = R->t_kernel_graph_ms;
+        st->n_cw_sweeps = R->n_cw_sweeps; st->cw_bytes = R->cw_bytes; st->graph_nnz = R->graph_nnz; st->n_graph_rows = R->n_graph_rows; st->simdiff_bytes = R->simdiff_bytes;
     }
     return R;
 }

@@ -411,6 +411,8 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         if (contigs[c].n_snps == 0) return;                                 // :1522-1524
         s.words = (contigs[c].n_snps + 63) / 64;
         s.perm = shuffled_order(s.N, seed);
+        s.rank.resize((size_t)s.N);
+        for (int k = 0; k < s.N; ++k) s.rank[(size_t)s.perm[(size_t)k]] = k;
     });
 
     laps.lap("perm");
@@ -464,133 +466,78 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
 
     const double t_simdiff_done = now_ms();
     laps.lap("simdiff");
-    // ---- window plans + graphs (host) ----
+    // ---- window plans (host) ----
     parallel_for(C, n_threads, [&](int c) {
         if (contigs[c].n_snps == 0) return;
         sr_plan_windows(st[(size_t)c], window_size, error_rate, lowmem);
     });
     laps.lap("plan_windows");
-    int64_t rows_on_host = 0, n_finish_host = 0;
-    float k6_ms = 0;
-    {   // K6: the graphs of all matrix-path windows in one device pass over the resident sim/diff matrices
-        ReadGraphJob job;
-        job.error_rate = error_rate;
-        job.win_mask_off.assign(1, 0);
-        std::vector<std::pair<int, int>> who, lowmem_tasks;
+    // ---- the window set of the call: matrix-path windows first (their graphs come from K6), then the low-memory ones ----
+    struct WRef { int c, w; };
+    std::vector<WRef> wrefs;            // index = window index in the set
+    SrWindowSet ws;
+    ws.error_rate = error_rate;
+    {
+        std::vector<WRef> host_w;
         for (int c = 0; c < C; ++c)
             for (size_t w = 0; w < st[(size_t)c].windows.size(); ++w) {
-                const SrWindowPlan& wp = st[(size_t)c].windows[w];
-                if (!wp.has_snps) continue;
-                if (st[(size_t)c].low_memory_now) { lowmem_tasks.push_back(std::make_pair(c, (int)w)); continue; }
-                who.push_back(std::make_pair(c, (int)w));
-                job.win_contig.push_back(c);
-                job.mask_ids.insert(job.mask_ids.end(), wp.mask_ids.begin(), wp.mask_ids.end());
-                job.win_mask_off.push_back((int64_t)job.mask_ids.size());
+                if (!st[(size_t)c].windows[w].has_snps) continue;
+                (st[(size_t)c].low_memory_now ? host_w : wrefs).push_back(WRef{c, (int)w});
             }
-        laps.lap("graph_job");
-        if (!who.empty()) {
-            ReadGraphResult res;
-            const double t0 = now_ms();
-            if (int rc = dev.read_graphs(job, res, &k6_ms)) return rc;
-            dev_ms += now_ms() - t0;
-            rows_on_host = res.rows_resolved_on_host;
-            laps.lap("read_graphs");
-            parallel_for((int)who.size(), n_threads, [&](int i) {
-                const int64_t m0 = job.win_mask_off[(size_t)i], m1 = job.win_mask_off[(size_t)i + 1];
-                sr_set_window_graph(st[(size_t)who[(size_t)i].first], who[(size_t)i].second, job.mask_ids.data() + m0, (int)(m1 - m0),
-                                    res.nbr_off.data() + m0, res.nbr_data());
-                st[(size_t)who[(size_t)i].first].windows[(size_t)who[(size_t)i].second].rows_adj_base = res.nbr_off[(size_t)m0];
-            });
+        ws.n_dev_windows = (int32_t)wrefs.size();
+        wrefs.insert(wrefs.end(), host_w.begin(), host_w.end());
+        const size_t W = wrefs.size();
+        ws.win_contig.resize(W); ws.win_row0.assign(W + 1, 0); ws.win_final_empty.resize(W);
+        for (size_t i = 0; i < W; ++i) {
+            SrWindowPlan& wp = st[(size_t)wrefs[i].c].windows[(size_t)wrefs[i].w];
+            wp.row0 = ws.win_row0[i];
+            ws.win_contig[i] = wrefs[i].c;
+            ws.win_final_empty[i] = wp.final_graph_empty ? 1 : 0;
+            ws.win_row0[i + 1] = ws.win_row0[i] + (int64_t)wp.ids.size();
         }
-        // create_read_graph_low_memory (-l, or coverage > 1000): O(N^2 S) per window on the host, one task per window
-        parallel_for((int)lowmem_tasks.size(), n_threads, [&](int i) { sr_build_window_graph(st[(size_t)lowmem_tasks[(size_t)i].first], lowmem_tasks[(size_t)i].second, error_rate); });
-    }
-
-    const double t_plan_done = now_ms();
-    laps.lap("set_window_graphs");
-    // ---- all graphs of the batch, uploaded once; a graph belongs to exactly one window (its mask) ----
-    CwGraphSet gs;
-    std::vector<int64_t> perm_base_of_contig((size_t)C, 0);
-    std::vector<std::vector<int>> graph_id((size_t)C);
-    for (int c = 0; c < C; ++c) {
-        SrContigState& s = st[(size_t)c];
-        perm_base_of_contig[(size_t)c] = (int64_t)gs.perm.size();
-        gs.perm.insert(gs.perm.end(), s.perm.begin(), s.perm.end());
-        graph_id[(size_t)c].assign(s.graphs.size(), -1);
-    }
-    // first the layout (serial: a few integers per graph), then the copies on the worker threads. When every graph came out
-    // of the device pass and the implementation still holds that pass's neighbour array, the adjacency is not copied at all:
-    // a graph's lists are a slice of that array
-    struct GraphSlot { int c, lg; const SrWindowPlan* w; int64_t off_base, adj_base, mask_base; };
-    std::vector<GraphSlot> slots;
-    bool alias_rows = dev.keeps_graph_rows();
-    for (int c = 0; c < C && alias_rows; ++c)
-        for (auto& w : st[(size_t)c].windows)
-            if (w.has_snps && (w.rows_adj_base < 0 || w.graph_final != w.graph_now)) { alias_rows = false; break; }
-    gs.adj_is_graph_rows = alias_rows;
-    {
-        int64_t off_total = 0, adj_total = 0, mask_total = 0;
-        for (int c = 0; c < C; ++c) {
-            SrContigState& s = st[(size_t)c];
-            for (auto& w : s.windows) {
-                if (!w.has_snps) continue;
-                for (int which = 0; which < 2; ++which) {
-                    const int lg = which == 0 ? w.graph_now : w.graph_final;
-                    if (graph_id[(size_t)c][(size_t)lg] >= 0) continue;
-                    const SrGraph& g = s.graphs[(size_t)lg];
-                    graph_id[(size_t)c][(size_t)lg] = (int)slots.size();
-                    slots.push_back(GraphSlot{c, lg, &w, off_total, alias_rows ? w.rows_adj_base : adj_total, mask_total});
-                    off_total += (int64_t)g.off.size(); adj_total += alias_rows ? 0 : (int64_t)g.adj.size(); mask_total += (int64_t)w.mask.size();
-                    gs.max_n = std::max(gs.max_n, s.N);
-                }
-            }
-        }
-        const size_t G = slots.size();
-        gs.graph_off_base.resize(G); gs.graph_adj_base.resize(G); gs.graph_n.resize(G); gs.perm_base_of_graph.resize(G);
-        gs.adj_off.resize((size_t)off_total); gs.adj.resize((size_t)adj_total); gs.mask.resize((size_t)mask_total);
-        parallel_for((int)G, n_threads, [&](int i) {
-            const GraphSlot& sl = slots[(size_t)i];
-            const SrContigState& s = st[(size_t)sl.c];
-            const SrGraph& g = s.graphs[(size_t)sl.lg];
-            gs.graph_off_base[(size_t)i] = sl.off_base; gs.graph_adj_base[(size_t)i] = sl.adj_base;
-            gs.graph_n[(size_t)i] = s.N; gs.perm_base_of_graph[(size_t)i] = perm_base_of_contig[(size_t)sl.c];
-            std::copy(g.off.begin(), g.off.end(), gs.adj_off.begin() + sl.off_base);
-            if (!alias_rows) std::copy(g.adj.begin(), g.adj.end(), gs.adj.begin() + sl.adj_base);
-            std::copy(sl.w->mask.begin(), sl.w->mask.end(), gs.mask.begin() + sl.mask_base);
+        ws.mask_ids.resize((size_t)ws.win_row0[W]);
+        parallel_for((int)W, n_threads, [&](int i) {
+            const SrWindowPlan& wp = st[(size_t)wrefs[(size_t)i].c].windows[(size_t)wrefs[(size_t)i].w];
+            std::copy(wp.ids.begin(), wp.ids.end(), ws.mask_ids.begin() + ws.win_row0[(size_t)i]);
         });
+        ws.ctg_rank_off.assign((size_t)C, 0);
+        int64_t ro = 0;
+        for (int c = 0; c < C; ++c) { ws.ctg_rank_off[(size_t)c] = ro; ro += (int64_t)st[(size_t)c].rank.size(); }
+        ws.rank.resize((size_t)ro);
+        parallel_for(C, n_threads, [&](int c) { std::copy(st[(size_t)c].rank.begin(), st[(size_t)c].rank.end(), ws.rank.begin() + ws.ctg_rank_off[(size_t)c]); });
+        // create_read_graph_low_memory (-l, or coverage > 1000): O(m^2 S) per window on the host, one task per window
+        const int n_host = (int)host_w.size();
+        if (n_host > 0) {
+            std::vector<std::vector<std::vector<int32_t>>> lists((size_t)n_host);
+            parallel_for(n_host, n_threads, [&](int i) {
+                const WRef& r = wrefs[(size_t)ws.n_dev_windows + (size_t)i];
+                sr_build_window_graph_low_memory(st[(size_t)r.c], st[(size_t)r.c].windows[(size_t)r.w], error_rate, lists[(size_t)i]);
+            });
+            ws.host_off.assign(1, 0);
+            for (auto& wl : lists)
+                for (auto& row : wl) { ws.host_nbr.insert(ws.host_nbr.end(), row.begin(), row.end()); ws.host_off.push_back((int64_t)ws.host_nbr.size()); }
+        }
     }
-    laps.lap("graphset_build");
-    {
+    laps.lap("window_set");
+    int64_t rows_on_host = 0, n_finish_host = 0;
+    float k6_ms = 0;
+    if (!wrefs.empty()) {
         const double t0 = now_ms();
-        if (int rc = dev.set_graphs(gs)) return rc;
+        if (int rc = dev.build_graphs(ws, &rows_on_host, &k6_ms)) return rc;
         dev_ms += now_ms() - t0;
     }
-    laps.lap("set_graphs");
+    const double t_plan_done = now_ms();
+    laps.lap("build_graphs");
 
+    // ---- the dependent Chinese-Whispers runs, device resident (see CwChain) ----
     int64_t n_cw = 0;
-    auto run_wave = [&](CwWave& wv, float* ms) -> int {
-        if (wv.inst_graph.empty()) return HS_OK;
-        const double t0 = now_ms();
-        if (int rc = dev.cw(wv, ms)) return rc;
-        n_cw += (int64_t)wv.inst_graph.size();
-        dev_ms += now_ms() - t0;
-        return HS_OK;
-    };
-
-    struct WRef { int c, w; int64_t local_base; };
-    std::vector<WRef> wrefs;
-    for (int c = 0; c < C; ++c)
-        for (size_t w = 0; w < st[(size_t)c].windows.size(); ++w)
-            if (st[(size_t)c].windows[w].has_snps) wrefs.push_back(WRef{c, (int)w, 0});
-
-    // ---- the three dependent Chinese-Whispers waves, device resident (see CwChain) ----
-    std::vector<int64_t> w2_base(wrefs.size(), -1);
+    std::vector<int64_t> chain_index(wrefs.size(), -1);   // position of the window in the chain
     {
         ch.win_seed_begin.assign(1, 0);
-        ch.win_label_base.assign(1, 0);
+        ch.chain_row0.assign(1, 0);
         ch.finish_on_device = !lowmem;
         for (int c = 0; c < C && ch.finish_on_device; ++c)
-            if (contigs[c].n_snps > 0 && (st[(size_t)c].low_memory_now || !st[(size_t)c].snp_pos_sorted)) ch.finish_on_device = false;
+            if (contigs[c].n_snps > 0 && !st[(size_t)c].snp_pos_sorted) ch.finish_on_device = false;
         if (ch.finish_on_device) {
             ch.col_pos.reserve(ch.col_off.size());
             for (int c = 0; c < C; ++c) ch.col_pos.insert(ch.col_pos.end(), contigs[c].snp_pos, contigs[c].snp_pos + contigs[c].n_snps);
@@ -599,13 +546,11 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
             SrContigState& s = st[(size_t)wrefs[i].c];
             SrWindowPlan& w = s.windows[(size_t)wrefs[i].w];
             if (w.local_snps.empty()) continue;          // finalize_clustering :909-919
-            w2_base[i] = ch.win_label_base.back();
-            ch.win_graph_now.push_back(graph_id[(size_t)wrefs[i].c][(size_t)w.graph_now]);
-            ch.win_graph_final.push_back(graph_id[(size_t)wrefs[i].c][(size_t)w.graph_final]);
-            ch.win_n.push_back(s.N);
+            chain_index[i] = (int64_t)ch.win.size();
+            ch.win.push_back((int32_t)i);
             for (int snp : w.local_snps) ch.seed_col.push_back(col_base_of_contig[(size_t)wrefs[i].c] + snp);
             ch.win_seed_begin.push_back((int64_t)ch.seed_col.size());
-            ch.win_label_base.push_back(ch.win_label_base.back() + s.N);
+            ch.chain_row0.push_back(ch.chain_row0.back() + (int64_t)w.ids.size());
             if (ch.finish_on_device) {
                 const hs_sr_contig& hc = contigs[wrefs[i].c];
                 const int64_t base = col_base_of_contig[(size_t)wrefs[i].c];
@@ -619,29 +564,47 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     laps.lap("chain_build");
     std::vector<int32_t> chain_labels, final_labels;
     std::vector<uint8_t> final_ok;
+    SrChainStats cst;
     {
         const double t0 = now_ms();
-        if (!ch.win_n.empty()) { if (int rc = dev.cw_chain(ch, chain_labels, final_labels, final_ok, &k_ms[1])) return rc; }
+        if (!ch.win.empty()) { if (int rc = dev.cw_chain(ch, chain_labels, final_labels, final_ok, &k_ms[1], &cst)) return rc; }
         dev_ms += now_ms() - t0;
     }
-    std::vector<int64_t> chain_index(wrefs.size(), -1);   // position of the window in the chain
-    { int64_t k = 0; for (size_t i = 0; i < wrefs.size(); ++i) if (w2_base[i] >= 0) chain_index[i] = k++; }
 
     const double t_waves_done = now_ms();
     laps.lap("cw_chain");
-    // ---- tail of finalize_clustering on the host ----
+    // ---- tail of finalize_clustering on the host for the windows the device left: needs the graphs here ----
+    std::vector<int64_t> g_off; std::vector<int32_t> g_nbr;
+    bool graphs_here = false;
+    auto need_graphs = [&]() -> int {
+        if (graphs_here) return HS_OK;
+        const double t0 = now_ms();
+        if (int rc = dev.fetch_graphs(g_off, g_nbr)) return rc;
+        dev_ms += now_ms() - t0;
+        graphs_here = true;
+        return HS_OK;
+    };
+    {
+        bool any_host = false;
+        for (size_t i = 0; i < wrefs.size() && !any_host; ++i)
+            if (chain_index[i] >= 0 && (final_ok.empty() || !final_ok[(size_t)chain_index[i]])) any_host = true;
+        if (any_host) { if (int rc = need_graphs()) return rc; }
+    }
     parallel_for((int)wrefs.size(), n_threads, [&](int i) {
         SrContigState& s = st[(size_t)wrefs[(size_t)i].c];
         SrWindowPlan& w = s.windows[(size_t)wrefs[(size_t)i].w];
-        if (w2_base[(size_t)i] < 0) {
-            w.labels.resize((size_t)s.N);
-            for (int r = 0; r < s.N; ++r) w.labels[(size_t)r] = w.mask[(size_t)r] ? -1 : -2;
-        } else if (!final_ok.empty() && final_ok[(size_t)chain_index[(size_t)i]]) {
-            const int32_t* f = final_labels.data() + w2_base[(size_t)i];      // finished on the device (K8)
-            w.labels.assign(f, f + s.N);
-        } else sr_finish_window(s, w, chain_labels.data() + w2_base[(size_t)i], lowmem);
+        const int64_t k = chain_index[(size_t)i];
+        if (k < 0) w.labels.assign(w.ids.size(), -1);                    // no seeding SNP: every read of the window unclustered
+        else if (!final_ok.empty() && final_ok[(size_t)k]) {
+            const int32_t* f = final_labels.data() + ch.chain_row0[(size_t)k];      // finished on the device (K8)
+            w.labels.assign(f, f + w.ids.size());
+        } else {
+            SrLocalGraph g; g.off = g_off.data() + w.row0; g.nbr = g_nbr.data();
+            sr_finish_window(s, w, chain_labels.data() + ch.chain_row0[(size_t)k], g, lowmem);
+        }
     });
-    if (!final_ok.empty()) for (uint8_t ok : final_ok) n_finish_host += ok ? 0 : 1;
+    for (size_t i = 0; i < wrefs.size(); ++i)
+        if (chain_index[i] >= 0 && (final_ok.empty() || !final_ok[(size_t)chain_index[i]])) n_finish_host++;
 
     const double t_finish_done = now_ms();
     laps.lap("finish");
@@ -653,50 +616,63 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
             SrContigState& s = st[(size_t)wrefs[i].c];
             SrWindowPlan& w = s.windows[(size_t)wrefs[i].w];
             if (contigs[wrefs[i].c].ploidy <= 0) continue;
-            std::vector<int32_t> init((size_t)s.N);
-            if (!sr_ploidy_init_labels(s, w, contigs[wrefs[i].c].ploidy, init.data())) continue;
+            std::vector<int32_t> init(w.ids.size());
+            if (!sr_ploidy_init_labels(w, contigs[wrefs[i].c].ploidy, init.data())) continue;
             who.push_back(i);
-            w4.inst_graph.push_back(graph_id[(size_t)wrefs[i].c][(size_t)w.graph_final]);
-            w4.inst_label_base.push_back((int64_t)w4.labels.size());
+            w4.inst_win.push_back((int32_t)i);
+            w4.inst_label_off.push_back((int64_t)w4.labels.size());
             w4.labels.insert(w4.labels.end(), init.begin(), init.end());
         }
-        if (int rc = run_wave(w4, &k_ms[3])) return rc;
+        if (!w4.inst_win.empty()) {
+            const double t0 = now_ms();
+            if (int rc = dev.cw(w4, &k_ms[3])) return rc;
+            n_cw += (int64_t)w4.inst_win.size();
+            dev_ms += now_ms() - t0;
+        }
         for (size_t k = 0; k < who.size(); ++k) {
-            SrContigState& s = st[(size_t)wrefs[who[k]].c];
-            SrWindowPlan& w = s.windows[(size_t)wrefs[who[k]].w];
-            w.labels.assign(w4.labels.begin() + w4.inst_label_base[k], w4.labels.begin() + w4.inst_label_base[k] + s.N);
+            SrWindowPlan& w = st[(size_t)wrefs[who[k]].c].windows[(size_t)wrefs[who[k]].w];
+            w.labels.assign(w4.labels.begin() + w4.inst_label_off[k], w4.labels.begin() + w4.inst_label_off[k] + (int64_t)w.ids.size());
         }
     }
 
+    // ---- result: N labels per window (-2 for the reads the window does not hold) ----
     hs_sr_result* R = (hs_sr_result*)std::calloc(1, sizeof(hs_sr_result));
     R->n_contigs = C;
     std::vector<int64_t> win_off((size_t)C + 1, 0), label_off(1, 0);
-    std::vector<int32_t> ws, we;
-    std::vector<const std::vector<int32_t>*> wl;
+    std::vector<int32_t> ws_, we_;
+    std::vector<const SrWindowPlan*> wl;
     for (int c = 0; c < C; ++c) {
         for (auto& w : st[(size_t)c].windows) {
-            ws.push_back(w.start); we.push_back(w.end);
-            wl.push_back(&w.labels);
-            label_off.push_back(label_off.back() + (int64_t)w.labels.size());
+            ws_.push_back(w.start); we_.push_back(w.end);
+            wl.push_back(&w);
+            label_off.push_back(label_off.back() + (int64_t)st[(size_t)c].N);
         }
-        win_off[(size_t)c + 1] = (int64_t)ws.size();
+        win_off[(size_t)c + 1] = (int64_t)ws_.size();
     }
-    R->win_off = dup_vec(win_off); R->win_start = dup_vec(ws); R->win_end = dup_vec(we); R->label_off = dup_vec(label_off);
+    R->win_off = dup_vec(win_off); R->win_start = dup_vec(ws_); R->win_end = dup_vec(we_); R->label_off = dup_vec(label_off);
     R->labels = (int32_t*)std::malloc(std::max<size_t>(1, (size_t)label_off.back()) * sizeof(int32_t));
-    parallel_for((int)wl.size(), n_threads, [&](int i) {   // the windows' labels straight into the result array
-        if (!wl[(size_t)i]->empty()) std::memcpy(R->labels + label_off[(size_t)i], wl[(size_t)i]->data(), wl[(size_t)i]->size() * sizeof(int32_t));
+    parallel_for((int)wl.size(), n_threads, [&](int i) {
+        int32_t* o = R->labels + label_off[(size_t)i];
+        const int64_t n = label_off[(size_t)i + 1] - label_off[(size_t)i];
+        std::fill(o, o + n, -2);
+        const SrWindowPlan& w = *wl[(size_t)i];
+        for (size_t j = 0; j < w.ids.size(); ++j) o[w.ids[j]] = w.labels[j];
     });
     laps.lap("result");
     R->n_cw_instances = n_cw;
-    R->t_kernel_graph_ms = k6_ms; R->n_graph_rows_host = rows_on_host; R->n_windows_finished_on_host = final_ok.empty() ? (int64_t)ch.win_n.size() : n_finish_host;
+    R->t_kernel_graph_ms = k6_ms; R->n_graph_rows_host = rows_on_host; R->n_windows_finished_on_host = n_finish_host;
+    R->n_cw_sweeps = cst.sweeps; R->cw_bytes = cst.bytes; R->graph_nnz = cst.graph_nnz; R->n_graph_rows = ws.rows();
+    for (int c = 0; c < C; ++c)
+        if (contigs[c].n_snps > 0 && !st[(size_t)c].low_memory_now)
+            R->simdiff_bytes += (int64_t)st[(size_t)c].N * contigs[c].n_snps / 4 + 16 * (int64_t)st[(size_t)c].N * st[(size_t)c].N;
     for (int k = 0; k < 4; ++k) R->t_kernel_ms[k] = k_ms[k];
     R->t_device_ms = dev_ms;
     R->t_host_ms = (now_ms() - t_start) - dev_ms;
     if (std::getenv("HS_TIMING"))
         std::fprintf(stderr, "[hs timing] sr: graph rows resolved by std::sort on the host: %ld, k_read_graph_rows %.3f ms; windows finished on the host: %ld of %zu\n",
-                     (long)rows_on_host, k6_ms, (long)n_finish_host, ch.win_n.size());
+                     (long)rows_on_host, k6_ms, (long)n_finish_host, ch.win.size());
     if (std::getenv("HS_TIMING"))
-        std::fprintf(stderr, "[hs timing] sr: planes+simdiff %.2f ms, plan windows+graphs %.2f ms, graph upload + 3 CW waves (incl. label init) %.2f ms, finish %.2f ms, total %.2f ms (device %.2f)\n",
+        std::fprintf(stderr, "[hs timing] sr: planes+simdiff %.2f ms, plan windows+graphs %.2f ms, clustering chain %.2f ms, finish %.2f ms, total %.2f ms (device %.2f)\n",
                      t_simdiff_done - t_start, t_plan_done - t_simdiff_done, t_waves_done - t_plan_done, t_finish_done - t_waves_done, now_ms() - t_start, dev_ms);
     *out = R;
     return HS_OK;

@@ -64,39 +64,49 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& meta, const CvSelection& sel, i
                  hs_cv_result** out);
 int cv_run(CvDeviceOps& dev, const CvMeta& meta, float automatic_snp_threshold, int n_threads, hs_cv_result** out);
 
-struct CwGraphSet {                   // every window graph of the batch, flattened
-    std::vector<int32_t> adj_off, adj, graph_n, perm;
-    std::vector<int64_t> graph_off_base, graph_adj_base, perm_base_of_graph;
-    std::vector<uint8_t> mask;
-    int max_n = 1;
-    // true: `adj` is left empty and graph_adj_base indexes the neighbour array of the last read_graphs() call, which the
-    // implementation still holds on the device (only offered to implementations whose keeps_graph_rows() is true)
-    bool adj_is_graph_rows = false;
-};
-struct CwWave {                       // one batched launch of the Chinese-Whispers kernel
-    std::vector<int32_t> inst_graph;
-    std::vector<int64_t> inst_label_base;
-    std::vector<int32_t> labels;      // in: initial labels, out: result
+// Every clustering window of a stage-4 call, each in its own LOCAL index space: node j of window w is the read
+// mask_ids[win_row0[w] + j] (ascending inside a window). "Row" = (window, node); the read graphs of the call are ONE CSR
+// over the rows whose neighbours are local ids. Windows [0, n_dev_windows) take their graph from the sim / diff matrices of
+// the last simdiff_columns() call (K6); the others (contigs on the low-memory path) bring theirs in host_off / host_nbr.
+struct SrWindowSet {
+    std::vector<int32_t> win_contig;       // [W] contig index as passed to simdiff_columns
+    std::vector<int64_t> win_row0;         // [W+1]
+    std::vector<int32_t> mask_ids;         // [rows]
+    int32_t n_dev_windows = 0;
+    std::vector<int64_t> host_off;         // [host rows + 1], starts at 0
+    std::vector<int32_t> host_nbr;
+    std::vector<uint8_t> win_final_empty;  // [W] finalize_clustering sees an empty graph for this window (separate_reads.cpp:1708)
+    std::vector<int32_t> rank;             // position of every read in its contig's shuffled visiting order, contigs concatenated
+    std::vector<int64_t> ctg_rank_off;     // [C] first entry of each contig in `rank`
+    float error_rate = 0;
+    int64_t rows() const { return win_row0.empty() ? 0 : win_row0.back(); }
 };
 
-// The three dependent Chinese-Whispers waves of every clustering window, kept on the device end to end:
+// The dependent Chinese-Whispers runs of every clustering window that has seeding SNPs, kept on the device end to end:
 // per-SNP runs seeded from the SNP columns (separate_reads.cpp:1674-1705) -> merged ids (:840-874) -> run on the
-// finalize graph (:881) -> small clusters dropped + renumbered (:924-955) -> run (:970). Only the last labels return.
+// finalize graph (:881) -> small clusters dropped + renumbered (:924-955) -> run (:970) [-> K8: the tail of
+// finalize_clustering]. Labels are local: m per window, chain window k at chain_row0[k].
 struct CwChain {
     std::vector<int64_t> col_off;          // SNP columns of all contigs, concatenated CSR [S+1]
     std::vector<int32_t> col_idx;
     std::vector<uint8_t> col_code;
-    std::vector<int32_t> win_graph_now, win_graph_final, win_n;   // per clustering window (global graph ids of CwGraphSet)
-    std::vector<int64_t> win_seed_begin;   // [W+1] range of the window's seeding columns in seed_col
+    std::vector<int32_t> win;              // [Wc] window index in the SrWindowSet
+    std::vector<int64_t> chain_row0;       // [Wc+1] offset of the window's m labels
+    std::vector<int64_t> win_seed_begin;   // [Wc+1] range of the window's per-SNP runs in seed_col
     std::vector<int64_t> seed_col;         // global column index of every per-SNP run
-    std::vector<int64_t> win_label_base;   // [W+1] offset of the window's N output labels
     // K8 (optional): the tail of finalize_clustering on the device. finish_on_device = every window of the chain may be
-    // finished there (matrix path, global low_memory off, SNP positions ascending); per window the range of its SNP columns
-    // (global column indices) and the position interval [pos_lo, pos_hi) that merge_wrongly_split looks at.
+    // finished there (global low_memory off, SNP positions ascending); per window the range of its SNP columns (global
+    // column indices) and the position interval [pos_lo, pos_hi) that merge_wrongly_split looks at.
     bool finish_on_device = false;
     std::vector<int32_t> col_pos;          // [S] position of every SNP column
     std::vector<int64_t> win_snp_first, win_snp_last;
     std::vector<int32_t> win_pos_lo, win_pos_hi;
+};
+
+struct CwWave {                       // one batched launch of single runs on the finalize graphs: (window, m initial labels)
+    std::vector<int32_t> inst_win;
+    std::vector<int64_t> inst_label_off;
+    std::vector<int32_t> labels;      // in: initial labels, out: result
 };
 
 // K5 input: the SNP columns of every contig of the batch (concatenated in CwChain::col_*) with their two alleles
@@ -110,36 +120,29 @@ struct SimdiffJob {
     int64_t plane_total = 0, out_total = 0;
 };
 
-// K6 input: the clustering windows whose graph comes from the sim/diff matrices of the last simdiff() call
-struct ReadGraphJob {
-    std::vector<int32_t> win_contig;     // contig index (as passed to simdiff) of every window
-    std::vector<int64_t> win_mask_off;   // [W+1] range of the window's masked reads in mask_ids
-    std::vector<int32_t> mask_ids;       // ascending read ids
-    float error_rate = 0;
-};
-struct ReadGraphResult {                 // neighbour lists (ascending read ids) of every masked read, window after window
-    std::vector<int64_t> nbr_off;        // [rows+1], row = position in mask_ids
-    std::vector<int32_t> nbr;
-    const int32_t* nbr_view = nullptr;   // set instead of `nbr` by an implementation that keeps the array itself (until its next call)
-    const int32_t* nbr_data() const { return nbr_view ? nbr_view : nbr.data(); }
-    int64_t rows_resolved_on_host = 0;   // rows whose cut-off fell inside a run of equal distances (std::sort order decides)
+struct SrChainStats {                 // what the clustering chain did (bench.py's whole-path roofline)
+    int64_t n_instances = 0;          // Chinese-Whispers runs
+    int64_t sweeps = 0;               // sweeps over all runs
+    int64_t bytes = 0;                // sum over runs of sweeps * (4 * nnz + 8 * m)
+    int64_t graph_nnz = 0;            // neighbour entries of all window graphs
 };
 
 struct SrDeviceOps {
     virtual ~SrDeviceOps() {}
-    // K6: create_read_graph_matrix for every window of the job
-    virtual int read_graphs(const ReadGraphJob& job, ReadGraphResult& res, float* k_ms) = 0;
-    // whether the neighbour array of the last read_graphs() stays available to set_graphs() (CwGraphSet::adj_is_graph_rows)
-    virtual bool keeps_graph_rows() const { return false; }
-    // labels = what the third wave leaves (N per window). If the implementation also ran K8, final_labels holds the finished
-    // labels and final_ok[w] != 0 marks the windows it could finish (the others go through the host code); else both stay empty.
-    // An implementation that finished EVERY window may leave `labels` empty (nobody reads them then).
-    virtual int cw_chain(const CwChain& chain, std::vector<int32_t>& labels, std::vector<int32_t>& final_labels,
-                         std::vector<uint8_t>& final_ok, float k_ms[3]) = 0;
     // K5a + K5: bit-planes from the SNP columns, then sim / diff for every contig with n_reads[c] > 0. The columns (the same
     // object cw_chain() receives later) and the matrices stay with the implementation.
     virtual int simdiff_columns(const SimdiffJob& job, float* k_ms) = 0;
-    virtual int set_graphs(const CwGraphSet& g) = 0;
+    // K6 (create_read_graph_matrix) for the device windows + the rows the host brings, one CSR, and the visiting order of
+    // every window; all of it stays with the implementation. rows_on_host: rows whose cut-off fell inside a run of equal
+    // distances (std::sort's order decides: resolved with std::sort itself)
+    virtual int build_graphs(const SrWindowSet& ws, int64_t* rows_on_host, float* k_ms) = 0;
+    // host copy of the CSR of the last build_graphs(): off[rows + 1] absolute, nbr local ids
+    virtual int fetch_graphs(std::vector<int64_t>& off, std::vector<int32_t>& nbr) = 0;
+    // labels = what the third run leaves (m per chain window). If the implementation also ran K8, final_labels holds the
+    // finished labels and final_ok[k] != 0 marks the windows it could finish (the others go through the host code); else
+    // both stay empty. An implementation that finished EVERY window may leave `labels` empty (nobody reads them then).
+    virtual int cw_chain(const CwChain& chain, std::vector<int32_t>& labels, std::vector<int32_t>& final_labels,
+                         std::vector<uint8_t>& final_ok, float k_ms[3], SrChainStats* stats) = 0;
     virtual int cw(CwWave& wave, float* k_ms) = 0;
 };
 

@@ -53,22 +53,18 @@ void cv_phase_merge(CvContigState& st, const ColumnSet& cs, ContigCvResult& out)
 float mean_distance_from_counts(int64_t n_err, int64_t n_len);
 
 // ---- stage 4 ---------------------------------------------------------------------------------
-struct SrGraph {                     // one window's read graph, CSR over the contig's reads
-    std::vector<int32_t> off;        // [N+1]
-    std::vector<int32_t> adj;
-};
-
+// A clustering window lives in its own LOCAL index space: node j = its j-th masked read (ascending read id). Everything the
+// reference does with a window only ever touches those reads (see hs_kernels_cw.hip), so graphs, labels and every table are
+// m-sized (m = masked reads of the window) instead of N-sized (N = reads of the contig).
 struct SrWindowPlan {
     int start = 0, end = 0;
     bool has_snps = false;
-    std::vector<uint8_t> mask;       // [N]
-    std::vector<int32_t> mask_ids;   // the reads of the mask, ascending
-    std::vector<int32_t> labels;     // final labels [N]
-    int graph_now = -1;              // graph built for this window (adjacency or neighbour list)
-    int64_t rows_adj_base = -1;      // where the window's neighbour lists start in the device pass's array (-1: built on the host)
-    int graph_final = -1;            // graph finalize_clustering sees (separate_reads.cpp:1708 quirk)
+    std::vector<int32_t> ids;        // reads the window reports (ascending): its masked reads, or, for a window without SNPs, the reads over its midpoint
+    std::vector<int32_t> labels;     // final label of every entry of `ids` (every other read of the contig is -2)
     std::vector<int32_t> local_snps; // SNP indices whose allele seeds a local Chinese-Whispers run
     int final_lo = 0, final_hi = 0;  // [posstart, posend) handed to merge_wrongly_split_haplotypes
+    int64_t row0 = -1;               // first row of the window in the graph set of the call (window-local CSR rows)
+    bool final_graph_empty = false;  // finalize_clustering sees a graph that was never filled (separate_reads.cpp:1708 quirk)
 };
 
 // ---- files -----------------------------------------------------------------------------------

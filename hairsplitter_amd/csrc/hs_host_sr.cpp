@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <numeric>
 #include <random>
@@ -52,19 +53,6 @@ static void pick_neighbors_sorted(std::vector<std::pair<int, float>>& smallest, 
     }
 }
 
-static void to_csr(std::vector<std::vector<int>>& lists, SrGraph& g) {
-    const int N = (int)lists.size();
-    g.off.assign((size_t)N + 1, 0);
-    g.adj.clear();
-    for (int i = 0; i < N; ++i) {
-        auto& v = lists[i];
-        std::sort(v.begin(), v.end());
-        v.erase(std::unique(v.begin(), v.end()), v.end());
-        g.off[i + 1] = g.off[i] + (int)v.size();
-        g.adj.insert(g.adj.end(), v.begin(), v.end());
-    }
-}
-
 // One row of create_read_graph_matrix (separate_reads.cpp:745-815) exactly as the reference does it. The device (K6) builds
 // the graphs; it hands back the rare rows where fewer than five neighbours qualify by value and the run of equal distances
 // at the cut-off is only partly taken, i.e. where std::sort's arrangement of equal keys decides.
@@ -85,70 +73,69 @@ void sr_pick_row_sorted(const int32_t* srow, const int32_t* drow, int N, int r1,
     pick_neighbors_sorted(smallest, mask, error_rate, picked);
 }
 
-void sr_set_window_graph(SrContigState& st, int window, const int32_t* ids, int m, const int64_t* nbr_off, const int32_t* nbr) {
-    SrWindowPlan& w = st.windows[(size_t)window];
-    SrGraph& g = st.graphs[(size_t)w.graph_now];
-    g.off.assign((size_t)st.N + 1, 0);
-    g.adj.assign(nbr + nbr_off[0], nbr + nbr_off[m]);
-    int j = 0;
-    for (int r = 0; r < st.N; ++r) {
-        g.off[(size_t)r] = (int)(j < m ? nbr_off[j] - nbr_off[0] : nbr_off[m] - nbr_off[0]);
-        if (j < m && ids[j] == r) j++;
-    }
-    g.off[(size_t)st.N] = (int)(nbr_off[m] - nbr_off[0]);
+// position of read r in the ascending list ids, or -1
+static inline int local_index(const std::vector<int32_t>& ids, int r) {
+    const auto it = std::lower_bound(ids.begin(), ids.end(), r);
+    return (it != ids.end() && *it == r) ? (int)(it - ids.begin()) : -1;
 }
 
-// create_read_graph_low_memory: separate_reads.cpp:538-693
-static void build_graph_low_memory(const SrContigState& st, const uint8_t* mask, float error_rate, SrGraph& g) {
+// create_read_graph_low_memory: separate_reads.cpp:538-693. Only reads of the mask take part (ext = mask && present at a SNP,
+// :582-586) and only they are linked, so the graph is built over the window's local indices; the neighbour selection runs
+// on the reference's N-entry array (entries of the other reads are zero), because std::sort sees all of them.
+void sr_build_window_graph_low_memory(const SrContigState& st, const SrWindowPlan& w, float error_rate, std::vector<std::vector<int32_t>>& lists) {
     const hs_sr_contig& c = *st.c;
     const int N = st.N;
-    std::vector<int> first((size_t)N, -1);
+    const int m = (int)w.ids.size();
+    std::vector<int> first((size_t)N, -1);          // per-read SNP vectors of the contig (:545-575)
     std::vector<std::vector<uint8_t>> val((size_t)N);
     for (int s = 0; s < c.n_snps; ++s)
         for (int64_t e = c.col_off[s]; e < c.col_off[s + 1]; ++e) {
             const int r = c.col_idx[e];
-            if (first[r] == -1) first[r] = s;
-            val[r].push_back(c.col_code[e] == c.snp_ref[s] ? 1 : (c.col_code[e] == c.snp_alt[s] ? 2 : 0));
+            if (first[(size_t)r] == -1) first[(size_t)r] = s;
+            val[(size_t)r].push_back(c.col_code[e] == c.snp_ref[s] ? 1 : (c.col_code[e] == c.snp_alt[s] ? 2 : 0));
         }
-    std::vector<uint8_t> ext((size_t)N, 0);
-    for (int r = 0; r < N; ++r) ext[r] = mask[r] && first[r] != -1;
-    std::vector<std::vector<int>> lists((size_t)N);
+    std::vector<uint8_t> mask((size_t)N, 0);
+    for (int r : w.ids) mask[(size_t)r] = 1;
+    lists.assign((size_t)m, std::vector<int32_t>());
     std::vector<std::pair<int, float>> smallest((size_t)N);
     std::vector<int> simv((size_t)N), difv((size_t)N), picked;
-    for (int r1 = 0; r1 < N; ++r1) {
-        if (!ext[r1]) continue;
+    for (int j1 = 0; j1 < m; ++j1) {
+        const int r1 = w.ids[(size_t)j1];
+        if (first[(size_t)r1] == -1) continue;
         int max_compat = 0;
-        for (int r = 0; r < N; ++r) { smallest[r] = std::make_pair(r, 0.0f); simv[r] = 0; difv[r] = 0; }
-        for (int r2 = 0; r2 < N; ++r2) {
-            if (!(ext[r2] && r1 != r2)) continue;
+        for (int r = 0; r < N; ++r) { smallest[(size_t)r] = std::make_pair(r, 0.0f); simv[(size_t)r] = 0; difv[(size_t)r] = 0; }
+        for (int j2 = 0; j2 < m; ++j2) {
+            const int r2 = w.ids[(size_t)j2];
+            if (first[(size_t)r2] == -1 || r1 == r2) continue;
             int nsim = 0, ndif = 0;
-            const long a = std::max(first[r1], first[r2]);
-            const long b = std::min((long)val[r1].size() + first[r1] - 1, (long)val[r2].size() + first[r2] - 1);
+            const long a = std::max(first[(size_t)r1], first[(size_t)r2]);
+            const long b = std::min((long)val[(size_t)r1].size() + first[(size_t)r1] - 1, (long)val[(size_t)r2].size() + first[(size_t)r2] - 1);
             for (long p = a; p <= b; ++p) {
-                const int v1 = val[r1][p - first[r1]], v2 = val[r2][p - first[r2]];
+                const int v1 = val[(size_t)r1][(size_t)(p - first[(size_t)r1])], v2 = val[(size_t)r2][(size_t)(p - first[(size_t)r2])];
                 if (v1 == 2 && v2 == 2) nsim += 3; else if (v1 == 1 && v2 == 1) nsim++; else if (v1 != 0 && v2 != 0) ndif++;
             }
-            smallest[r2].second = 1 - std::max(0, ndif - 1) / float(ndif + nsim);
+            smallest[(size_t)r2].second = 1 - std::max(0, ndif - 1) / float(ndif + nsim);
             if (nsim > max_compat) max_compat = nsim;
-            simv[r2] = nsim; difv[r2] = ndif;
+            simv[(size_t)r2] = nsim; difv[(size_t)r2] = ndif;
         }
-        for (int r = 0; r < N; ++r)
-            if (mask[r] && r != r1 && simv[r] + difv[r] < 0.7 * max_compat) smallest[r].second = 0;
-        pick_neighbors_sorted(smallest, mask, error_rate, picked);   // 0/0 distances (NaN) exist on this path
-        for (int nb : picked) { lists[r1].push_back(nb); lists[nb].push_back(r1); }
+        for (int r : w.ids)
+            if (r != r1 && simv[(size_t)r] + difv[(size_t)r] < 0.7 * max_compat) smallest[(size_t)r].second = 0;
+        pick_neighbors_sorted(smallest, mask.data(), error_rate, picked);   // 0/0 distances (NaN) exist on this path
+        for (int nb : picked) { const int j2 = local_index(w.ids, nb); lists[(size_t)j1].push_back(j2); lists[(size_t)j2].push_back(j1); }
     }
-    to_csr(lists, g);
+    for (auto& v : lists) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
 }
 
-// Window / mask planning: separate_reads.cpp:1545-1622 (the running SNP cursor is carried across windows)
+// Window / mask planning: separate_reads.cpp:1545-1622 (the running SNP cursor is carried across windows). The mask of a
+// window is never materialised over the N reads of the contig: it is the reads of the window's first SNP column that are
+// also in its last one -- or lie beyond that column's last read, which the reference's clearing loop (:1612-1619) never
+// reaches --, i.e. a merge of two ascending lists.
 void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool low_memory) {
     (void)error_rate;
     const hs_sr_contig& c = *st.c;
     const int N = st.N;
     const long L = c.length;
     st.windows.clear();
-    st.graphs.clear();
-    st.empty_graph = -1;
     st.snp_pos_sorted = std::is_sorted(c.snp_pos, c.snp_pos + c.n_snps);
     if (c.n_snps == 0) return;
     int cur = 0, chunk = -1, upper;
@@ -162,47 +149,56 @@ void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool 
         w.end = std::min(upper - 1, (int)L);
         if (cur >= c.n_snps || c.snp_pos[cur] > upper - 1) {          // :1565-1587
             w.has_snps = false;
-            w.labels.assign((size_t)N, -2);
             int mid = (w.start + std::min(upper - 1, (int)L)) / 2;
             if (mid < 500) mid = std::min(500, (int)(L / 2));
             if (mid > (int)L - 500) mid = std::max((int)(L / 2), (int)L - 500);
-            for (int r = 0; r < N; ++r) if (c.read_start[r] <= mid && c.read_end[r] >= mid) w.labels[r] = 0;
+            for (int r = 0; r < N; ++r) if (c.read_start[r] <= mid && c.read_end[r] >= mid) w.ids.push_back(r);
+            w.labels.assign(w.ids.size(), 0);
             st.windows.push_back(std::move(w));
             continue;
         }
         w.has_snps = true;
-        w.mask.assign((size_t)N, 0);
         if (chunk == 0) {
             while (cur < c.n_snps - 1 && c.snp_pos[cur] < chunk * window_size + 0.2 * window_size
                    && c.snp_pos[cur + 1] < chunk * window_size + 0.4 * window_size) cur++;
         }
-        for (int64_t e = c.col_off[cur]; e < c.col_off[cur + 1]; ++e) w.mask[c.col_idx[e]] = 1;
+        const int col_a = cur;
         while (cur < c.n_snps && c.snp_pos[cur] < upper - 1) cur++;
         if (cur > 0) cur--;
         if (last) {
             while (cur > 0 && c.snp_pos[cur] > upper - 1 - 0.2 * window_size && c.snp_pos[cur - 1] > upper - 1 - 0.4 * window_size) cur--;
         }
-        int idxmask = 0;
-        for (int64_t e = c.col_off[cur]; e < c.col_off[cur + 1]; ++e) {
-            while (idxmask < c.col_idx[e]) { w.mask[idxmask] = 0; idxmask++; }
-            idxmask++;
+        {
+            const int32_t* a = c.col_idx + c.col_off[col_a]; const int32_t* a1 = c.col_idx + c.col_off[col_a + 1];
+            const int32_t* b = c.col_idx + c.col_off[cur]; const int32_t* b1 = c.col_idx + c.col_off[cur + 1];
+            auto strictly_ascending = [](const int32_t* x, const int32_t* x1) { return std::adjacent_find(x, x1, std::greater_equal<int32_t>()) == x1; };
+            if (strictly_ascending(a, a1) && strictly_ascending(b, b1)) {
+                const int32_t b_last = b1 > b ? b1[-1] : -1;          // an empty last column clears nothing
+                for (; a < a1; ++a) {
+                    if (*a > b_last) { w.ids.push_back(*a); continue; }
+                    while (b < b1 && *b < *a) ++b;
+                    if (b < b1 && *b == *a) w.ids.push_back(*a);
+                }
+            } else {   // a .col whose read indices do not ascend: the reference's two loops as they are, on a dense mask
+                std::vector<uint8_t> mask((size_t)N, 0);
+                for (; a < a1; ++a) mask[(size_t)*a] = 1;
+                int idxmask = 0;
+                for (; b < b1; ++b) { while (idxmask < *b) { mask[(size_t)idxmask] = 0; idxmask++; } idxmask++; }
+                for (int r = 0; r < N; ++r) if (mask[(size_t)r]) w.ids.push_back(r);
+            }
         }
         cur++;
-        for (int r = 0; r < N; ++r) if (w.mask[(size_t)r]) w.mask_ids.push_back(r);
-        // graph slot for this window (filled by sr_build_window_graph, one independent task per window)
-        st.graphs.emplace_back();
-        st.graphs.back().off.assign((size_t)N + 1, 0);
-        w.graph_now = (int)st.graphs.size() - 1;
         // finalize_clustering is handed the *global* low_memory flag (:1708): with low_memory_now && !low_memory it
         // sees an Eigen matrix that was never filled
-        if (st.low_memory_now && !low_memory) {
-            st.graphs.emplace_back();
-            st.graphs.back().off.assign((size_t)N + 1, 0);
-            w.graph_final = (int)st.graphs.size() - 1;
-        } else w.graph_final = w.graph_now;
+        w.final_graph_empty = st.low_memory_now && !low_memory;
         // SNPs seeding a local run (:1673-1676): inside [start, start+window) and more than 10 bp apart
         int lastpos = -10;
-        for (int s = 0; s < c.n_snps; ++s) {
+        int s_lo = 0, s_hi = c.n_snps;
+        if (st.snp_pos_sorted) {
+            s_lo = (int)(std::lower_bound(c.snp_pos, c.snp_pos + c.n_snps, chunk * window_size) - c.snp_pos);
+            s_hi = (int)(std::lower_bound(c.snp_pos, c.snp_pos + c.n_snps, chunk * window_size + window_size) - c.snp_pos);
+        }
+        for (int s = s_lo; s < s_hi; ++s) {
             const int p = c.snp_pos[s];
             if (p >= chunk * window_size && p < chunk * window_size + window_size && p > lastpos + 10) { lastpos = p; w.local_snps.push_back(s); }
         }
@@ -211,17 +207,10 @@ void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool 
     }
 }
 
-void sr_build_window_graph(SrContigState& st, int window, float error_rate) {
-    SrWindowPlan& w = st.windows[(size_t)window];
-    if (!w.has_snps) return;
-    SrGraph& g = st.graphs[(size_t)w.graph_now];
-    if (st.low_memory_now) build_graph_low_memory(st, w.mask.data(), error_rate, g);   // the matrix path is K6 (device)
-}
-
-// Per-thread scratch of the two cluster-merging steps: they run once per clustering window (tens of thousands of calls per
-// batch), so nothing in them allocates, and every table is indexed by cluster label (a handful) instead of by read.
+// Per-thread scratch of the two cluster-merging steps: they run once per clustering window the device did not finish, so
+// nothing in them allocates, and every table is indexed by cluster label (a handful) or by local node.
 struct MergeScratch {
-    std::vector<int32_t> nc, order_masked, masked;
+    std::vector<int32_t> nc, order;
     std::vector<int> initial, count, votes, touched;
     std::vector<char> tested;
     // merge_wrongly_split
@@ -232,75 +221,74 @@ struct MergeScratch {
 };
 static MergeScratch& merge_scratch() { static thread_local MergeScratch s; return s; }
 
-// merge_close_clusters: cluster_graph.cpp:402-501. `n_labels`: cluster labels are 0 .. n_labels-1 (first-seen numbering).
-static void merge_close_clusters(const SrGraph& g, bool low_memory, std::vector<int32_t>& clusters, const uint8_t* mask,
-                                 const std::vector<int32_t>& order, int n_labels) {
+// merge_close_clusters: cluster_graph.cpp:402-501, on the window's local nodes (`clusters`: m labels, first-seen numbering
+// 0 .. n_labels-1 or -1; `ids`: the read of every node; S.order: the nodes in the order of the shuffled permutation).
+static void merge_close_clusters(const SrLocalGraph& g, bool low_memory, std::vector<int32_t>& clusters, const std::vector<int32_t>& ids, int n_labels) {
     MergeScratch& S = merge_scratch();
+    const int m = (int)clusters.size();
     const int K = n_labels > 0 ? n_labels : 1;
-    S.order_masked.clear();                                          // S.masked: the window's reads, ascending (set by the caller)
-    for (int i : order) if (mask[i]) S.order_masked.push_back(i);   // the shuffled order restricted to the window's reads
     S.initial.assign((size_t)K, 0); S.votes.assign((size_t)K, 0); S.tested.assign((size_t)K, 0);
-    for (int r : S.masked) if (clusters[r] >= 0) S.initial[(size_t)clusters[r]] += 1;   // reads outside the mask carry -2
+    for (int j = 0; j < m; ++j) if (clusters[(size_t)j] >= 0) S.initial[(size_t)clusters[(size_t)j]] += 1;
     S.nc.assign(clusters.begin(), clusters.end());
     std::vector<int32_t>& nc = S.nc;
     std::vector<int>& votes = S.votes;
     std::vector<int>& touched = S.touched;
-    for (int node : S.masked) {
-        if (!(clusters[node] >= 0 && !S.tested[(size_t)clusters[node]])) continue;
-        const int target = clusters[node];
+    for (int node = 0; node < m; ++node) {
+        if (!(clusters[(size_t)node] >= 0 && !S.tested[(size_t)clusters[(size_t)node]])) continue;
+        const int target = clusters[(size_t)node];
         S.count = S.initial;
         int changes = 3, iters = 0;
         while (changes > 0 && iters < 10) {
             changes = 0;
-            for (int i : S.order_masked) {
-                if (nc[i] != target) continue;
+            for (int i : S.order) {
+                if (nc[(size_t)i] != target) continue;
                 touched.clear();
-                const int o0 = g.off[i], o1 = g.off[i + 1];
-                if (low_memory) {   // :441-445 iterates j < degree and asks whether j itself is a neighbour (sic)
-                    for (int j = 0; j < o1 - o0; ++j)
-                        if (std::binary_search(g.adj.begin() + o0, g.adj.begin() + o1, j) && nc[j] >= 0) { if (votes[nc[j]]++ == 0) touched.push_back(nc[j]); }
+                const int64_t o0 = g.begin(i), o1 = g.end(i);
+                if (low_memory) {
+                    // :441-445 iterates j < degree and asks whether READ j itself is a neighbour (sic): reads outside the window
+                    // carry -2 and never vote
+                    for (int r = 0; r < (int)(o1 - o0); ++r) {
+                        const int j = local_index(ids, r);
+                        if (j >= 0 && std::binary_search(g.nbr + o0, g.nbr + o1, j) && nc[(size_t)j] >= 0) { if (votes[(size_t)nc[(size_t)j]]++ == 0) touched.push_back(nc[(size_t)j]); }
+                    }
                 } else {
-                    for (int o = o0; o < o1; ++o) { const int l = nc[g.adj[o]]; if (l >= 0) { if (votes[l]++ == 0) touched.push_back(l); } }
+                    for (int64_t o = o0; o < o1; ++o) { const int l = nc[(size_t)g.nbr[o]]; if (l >= 0) { if (votes[(size_t)l]++ == 0) touched.push_back(l); } }
                 }
                 // largest and runner-up in ascending label order with strict '>' (:455-470)
                 std::sort(touched.begin(), touched.end());
                 int max_index = 0, max_value = 0, second_index = 0, second_value = 0;
                 for (int l : touched) {
-                    const int v = votes[l];
+                    const int v = votes[(size_t)l];
                     if (v > max_value) { second_value = max_value; second_index = max_index; max_value = v; max_index = l; }
                     else if (v > second_value) { second_value = v; second_index = l; }
                 }
-                for (int l : touched) votes[l] = 0;
-                if (max_value > 0 && max_index != target) { S.count[nc[i]]--; S.count[max_index]++; changes++; nc[i] = max_index; }
-                else if (max_value > 0 && max_value <= 2 * second_value) { S.count[nc[i]]--; S.count[second_index]++; nc[i] = second_index; changes++; }
+                for (int l : touched) votes[(size_t)l] = 0;
+                if (max_value > 0 && max_index != target) { S.count[(size_t)nc[(size_t)i]]--; S.count[(size_t)max_index]++; changes++; nc[(size_t)i] = max_index; }
+                else if (max_value > 0 && max_value <= 2 * second_value) { S.count[(size_t)nc[(size_t)i]]--; S.count[(size_t)second_index]++; nc[(size_t)i] = second_index; changes++; }
             }
             iters++;
         }
         S.tested[(size_t)target] = 1;
-        if (S.count[(size_t)target] == 0) { for (int r : S.masked) clusters[r] = nc[r]; S.initial = S.count; }   // the cluster dissolved: keep
-        else for (int r : S.masked) nc[r] = clusters[r];                                                          // undo
+        if (S.count[(size_t)target] == 0) { clusters.assign(nc.begin(), nc.end()); S.initial = S.count; }   // the cluster dissolved: keep
+        else nc.assign(clusters.begin(), clusters.end());                                                  // undo
     }
 }
 
-// merge_wrongly_split_haplotypes: separate_reads.cpp:1007-1327. `n_labels` as above.
-static std::vector<int32_t> merge_wrongly_split(const SrContigState& st, const std::vector<int32_t>& clustered, const SrGraph& g,
-                                                bool low_memory, int posstart, int posend, int n_labels) {
+// merge_wrongly_split_haplotypes: separate_reads.cpp:1007-1327, on the window's local nodes. `n_labels` as above.
+static std::vector<int32_t> merge_wrongly_split(const SrContigState& st, const std::vector<int32_t>& clustered, const std::vector<int32_t>& ids,
+                                                const SrLocalGraph& g, bool low_memory, int posstart, int posend, int n_labels) {
     MergeScratch& S = merge_scratch();
     const hs_sr_contig& c = *st.c;
-    const int N = st.N;
+    const int m = (int)clustered.size();
     const int K = n_labels > 0 ? n_labels : 1;
     // clusters present, ascending (glist), and their first-seen rank over the reads (index_of), as the std::set / std::map give
     S.index_of.assign((size_t)K, -1); S.slot_of.assign((size_t)K, -1);
     int index = 0;
-    for (int r : S.masked) { const int cl = clustered[r]; if (cl > -1 && S.index_of[(size_t)cl] < 0) S.index_of[(size_t)cl] = index++; }   // reads outside the mask carry -2
+    for (int j = 0; j < m; ++j) { const int cl = clustered[(size_t)j]; if (cl > -1 && S.index_of[(size_t)cl] < 0) S.index_of[(size_t)cl] = index++; }
     S.glist.clear();
     for (int l = 0; l < K; ++l) if (S.index_of[(size_t)l] >= 0) { S.slot_of[(size_t)l] = (int)S.glist.size(); S.glist.push_back(l); }
     const int G = (int)S.glist.size();
-    if (G <= 1) {
-        std::vector<int32_t> one((size_t)N, 0);
-        for (int r = 0; r < N; ++r) if (clustered[r] == -2) one[r] = -2;
-        return one;
-    }
+    if (G <= 1) return std::vector<int32_t>((size_t)m, 0);      // (every node of the window is a masked read)
     const std::vector<int>& glist = S.glist;
     S.gidx.resize((size_t)G);
     for (int i = 0; i < G; ++i) S.gidx[(size_t)i] = S.index_of[(size_t)glist[(size_t)i]];
@@ -318,14 +306,15 @@ static std::vector<int32_t> merge_wrongly_split(const SrContigState& st, const s
     for (int s = s_first; s < s_last; ++s) {
         const int p = c.snp_pos[s];
         if (!(p >= posstart && p < posend)) continue;
-        for (int i = 0; i < G; ++i) { nb_bases[i] = 0; majority[i] = 0; }
+        for (int i = 0; i < G; ++i) { nb_bases[(size_t)i] = 0; majority[(size_t)i] = 0; }
         for (int64_t e = c.col_off[s]; e < c.col_off[s + 1]; ++e) {
-            const int cl = clustered[c.col_idx[e]];
+            const int j = local_index(ids, c.col_idx[e]);      // reads outside the window carry -2
+            const int cl = j >= 0 ? clustered[(size_t)j] : -2;
             if (cl > -1) {
                 const int sl = S.slot_of[(size_t)cl];
                 const uint8_t b = c.col_code[e];
                 if (S.cnts[(size_t)sl][b]++ == 0) S.seen[(size_t)sl].push_back(b);
-                nb_bases[sl]++;
+                nb_bases[(size_t)sl]++;
             }
         }
         // The reference walks the cluster's base counts in robin_hood order keeping (max, second max) with `>=` on the max
@@ -343,16 +332,16 @@ static std::vector<int32_t> merge_wrongly_split(const SrContigState& st, const s
                 S.cnts[(size_t)i][b] = 0;
             }
             S.seen[(size_t)i].clear();
-            if (second_max * 2 > mx || nb_bases[i] * 0.5 > mx) max_base = ' ';
-            majority[i] = (int)(uint8_t)max_base;
+            if (second_max * 2 > mx || nb_bases[(size_t)i] * 0.5 > mx) max_base = ' ';
+            majority[(size_t)i] = (int)(uint8_t)max_base;
             if (max_base != ' ') { const int mb = (int)(uint8_t)max_base; if (first_max < 0) first_max = mb; else if (mb != first_max) several = true; }
         }
         if (!several) continue;
         for (int a = 0; a < G; ++a)
             for (int b = 0; b < G; ++b) {
-                if (majority[a] != ' ' && majority[b] != ' ' && glist[(size_t)a] > glist[(size_t)b]) {
+                if (majority[(size_t)a] != ' ' && majority[(size_t)b] != ' ' && glist[(size_t)a] > glist[(size_t)b]) {
                     const int i1 = S.gidx[(size_t)a], i2 = S.gidx[(size_t)b];
-                    if (majority[a] != majority[b] && p - pos_last[(size_t)i1 * G + i2] > 10) {
+                    if (majority[(size_t)a] != majority[(size_t)b] && p - pos_last[(size_t)i1 * G + i2] > 10) {
                         incompat[(size_t)i1 * G + i2] += 1; incompat[(size_t)i2 * G + i1] += 1;
                         pos_last[(size_t)i1 * G + i2] = p; pos_last[(size_t)i2 * G + i1] = p;
                     }
@@ -364,16 +353,16 @@ static std::vector<int32_t> merge_wrongly_split(const SrContigState& st, const s
     const int M = K + 2;
     S.link_cnt.assign((size_t)M * M, 0); S.links_in.assign((size_t)M, 0);
     std::vector<int>& link_cnt = S.link_cnt; std::vector<int>& links_in = S.links_in;
-    auto count_link = [&](int r1, int r2) {
-        const int c1 = clustered[r1] + 2, c2 = clustered[r2] + 2;
+    auto count_link = [&](int j1, int j2) {
+        const int c1 = clustered[(size_t)j1] + 2, c2 = clustered[(size_t)j2] + 2;
         if (c1 != c2) link_cnt[(size_t)c1 * M + c2] += 1;
         links_in[(size_t)c1] += 1;
     };
     // only reads of the window have neighbours (the counts do not depend on the visiting order)
     if (low_memory) {
-        for (int r1 : S.masked) for (int o = g.off[r1]; o < g.off[r1 + 1]; ++o) count_link(r1, g.adj[o]);
+        for (int j1 = 0; j1 < m; ++j1) for (int64_t o = g.begin(j1); o < g.end(j1); ++o) count_link(j1, g.nbr[o]);
     } else {
-        for (int k : S.masked) for (int o = g.off[k]; o < g.off[k + 1]; ++o) count_link(g.adj[o], k);
+        for (int k = 0; k < m; ++k) for (int64_t o = g.begin(k); o < g.end(k); ++o) count_link(g.nbr[o], k);
     }
     std::vector<std::pair<std::pair<int, int>, double>>& sorted_links = S.sorted_links;
     sorted_links.clear();
@@ -403,228 +392,44 @@ static std::vector<int32_t> merge_wrongly_split(const SrContigState& st, const s
     int ni = 0;
     for (int gl : glist) { const int v = o2n[(size_t)gl + 2]; if (S.new_index[(size_t)v + 2] < 0) S.new_index[(size_t)v + 2] = ni++; }
     for (int gl : glist) o2n[(size_t)gl + 2] = S.new_index[(size_t)o2n[(size_t)gl + 2] + 2];
-    std::vector<int32_t> out((size_t)N, -1);
-    for (int r = 0; r < N; ++r) out[r] = o2n[(size_t)clustered[r] + 2];
+    std::vector<int32_t> out((size_t)m, -1);
+    for (int j = 0; j < m; ++j) out[(size_t)j] = o2n[(size_t)clustered[(size_t)j] + 2];
     return out;
 }
-
-#ifdef HS_SELFCHECK   // the straightforward forms, kept as the cross-check in the test-harness build
-// merge_close_clusters: cluster_graph.cpp:402-501
-static void merge_close_clusters_ref(const SrGraph& g, bool low_memory, std::vector<int32_t>& clusters, const uint8_t* mask,
-                                 const std::vector<int32_t>& order) {
-    const int N = (int)clusters.size();
-    std::set<int> tested;
-    std::vector<int> initial((size_t)N, 0);
-    for (int v : clusters) if (v >= 0 && v < N) initial[v] += 1;
-    std::vector<int> votes((size_t)N, 0), touched;
-    std::vector<int32_t> nc;
-    std::vector<int> count;
-    std::vector<int32_t> order_masked;   // the shuffled order restricted to the window's reads (the others are skipped anyway)
-    for (int i : order) if (mask[i]) order_masked.push_back(i);
-    for (int node = 0; node < N; ++node) {
-        if (!(clusters[node] >= 0 && tested.find(clusters[node]) == tested.end())) continue;
-        const int target = clusters[node];
-        nc = clusters; count = initial;
-        int changes = 3, iters = 0;
-        while (changes > 0 && iters < 10) {
-            changes = 0;
-            for (int i : order_masked) {
-                if (nc[i] != target) continue;
-                touched.clear();
-                const int o0 = g.off[i], o1 = g.off[i + 1];
-                if (low_memory) {   // :441-445 iterates j < degree and asks whether j itself is a neighbour (sic)
-                    for (int j = 0; j < o1 - o0; ++j)
-                        if (std::binary_search(g.adj.begin() + o0, g.adj.begin() + o1, j) && nc[j] >= 0) { if (votes[nc[j]]++ == 0) touched.push_back(nc[j]); }
-                } else {
-                    for (int o = o0; o < o1; ++o) { const int l = nc[g.adj[o]]; if (l >= 0) { if (votes[l]++ == 0) touched.push_back(l); } }
-                }
-                // largest and runner-up in ascending label order with strict '>' (:455-470)
-                std::sort(touched.begin(), touched.end());
-                int max_index = 0, max_value = 0, second_index = 0, second_value = 0;
-                for (int l : touched) {
-                    const int v = votes[l];
-                    if (v > max_value) { second_value = max_value; second_index = max_index; max_value = v; max_index = l; }
-                    else if (v > second_value) { second_value = v; second_index = l; }
-                }
-                for (int l : touched) votes[l] = 0;
-                if (max_value > 0 && max_index != target) { count[nc[i]]--; count[max_index]++; changes++; nc[i] = max_index; }
-                else if (max_value > 0 && max_value <= 2 * second_value) { count[nc[i]]--; count[second_index]++; nc[i] = second_index; changes++; }
-            }
-            iters++;
-        }
-        tested.insert(target);
-        if (count[target] == 0) { clusters = nc; initial = count; }
-    }
-}
-
-// merge_wrongly_split_haplotypes: separate_reads.cpp:1007-1327
-static std::vector<int32_t> merge_wrongly_split_ref(const SrContigState& st, const std::vector<int32_t>& clustered, const SrGraph& g,
-                                                bool low_memory, int posstart, int posend) {
-    const hs_sr_contig& c = *st.c;
-    const int N = st.N;
-    std::set<int> groups;
-    std::map<int, int> index_of;
-    int index = 0;
-    for (int r = 0; r < N; ++r)
-        if (clustered[r] > -1) { groups.insert(clustered[r]); if (index_of.find(clustered[r]) == index_of.end()) index_of[clustered[r]] = index++; }
-    const int G = (int)groups.size();
-    if (G <= 1) {
-        std::vector<int32_t> one((size_t)N, 0);
-        for (int r = 0; r < N; ++r) if (clustered[r] == -2) one[r] = -2;
-        return one;
-    }
-    std::vector<int> incompat((size_t)G * G, 0), pos_last((size_t)G * G, -10);
-    std::vector<int> glist(groups.begin(), groups.end());
-    std::vector<int> gidx(glist.size());
-    for (size_t i = 0; i < glist.size(); ++i) gidx[i] = index_of[glist[i]];
-    // per-SNP majority base of every cluster (:1056-1112); the inner map's iteration order decides ties (>=)
-    std::vector<int> slot_of_group;   // group label -> dense slot
-    {
-        int mx = 0; for (int gl : glist) mx = std::max(mx, gl);
-        slot_of_group.assign((size_t)mx + 1, -1);
-        for (size_t i = 0; i < glist.size(); ++i) slot_of_group[glist[i]] = (int)i;
-    }
-    std::vector<std::vector<uint8_t>> seen((size_t)G);
-    std::vector<std::vector<int>> cnts((size_t)G, std::vector<int>(256, 0));
-    std::vector<int> nb_bases((size_t)G);
-    std::vector<int> majority((size_t)G);   // 0 == the operator[] default for clusters absent at this SNP
-    for (int s = 0; s < c.n_snps; ++s) {
-        const int p = c.snp_pos[s];
-        if (!(p >= posstart && p < posend)) continue;
-        for (int i = 0; i < G; ++i) { nb_bases[i] = 0; majority[i] = 0; }
-        for (int64_t e = c.col_off[s]; e < c.col_off[s + 1]; ++e) {
-            const int cl = clustered[c.col_idx[e]];
-            if (cl > -1) {
-                const int sl = slot_of_group[cl];
-                const uint8_t b = c.col_code[e];
-                if (cnts[sl][b]++ == 0) seen[sl].push_back(b);
-                nb_bases[sl]++;
-            }
-        }
-        // The reference walks the cluster's base counts in robin_hood order keeping (max, second max) with `>=` on the max
-        // (:1090-1099). The pair of values does not depend on the order, and neither does the verdict: a unique maximum names
-        // the base, a tied maximum gives second == max and is rejected by `second_max * 2 > max` just below.
-        int first_max = -1; bool several = false;
-        for (int i = 0; i < G; ++i) {
-            if (seen[i].empty()) continue;
-            int second_max = 0, mx = 0;
-            int max_base = ' ';
-            for (uint8_t b : seen[i]) {
-                const int v = cnts[i][b];
-                if (v >= mx) { max_base = (int)(signed char)b; second_max = mx; mx = v; }
-                else if (v > second_max) second_max = v;
-                cnts[i][b] = 0;
-            }
-            seen[i].clear();
-            if (second_max * 2 > mx || nb_bases[i] * 0.5 > mx) max_base = ' ';
-            majority[i] = (int)(uint8_t)max_base;
-            if (max_base != ' ') { const int mb = (int)(uint8_t)max_base; if (first_max < 0) first_max = mb; else if (mb != first_max) several = true; }
-        }
-        if (!several) continue;
-        for (int a = 0; a < G; ++a)
-            for (int b = 0; b < G; ++b) {
-                if (majority[a] != ' ' && majority[b] != ' ' && glist[a] > glist[b]) {
-                    const int i1 = gidx[a], i2 = gidx[b];
-                    if (majority[a] != majority[b] && p - pos_last[(size_t)i1 * G + i2] > 10) {
-                        incompat[(size_t)i1 * G + i2] += 1; incompat[(size_t)i2 * G + i1] += 1;
-                        pos_last[(size_t)i1 * G + i2] = p; pos_last[(size_t)i2 * G + i1] = p;
-                    }
-                }
-            }
-    }
-    // link ratios (:1189-1250). The reference keys a std::map on (cluster1, cluster2), clusters -2 and -1 included; a
-    // dense (label + 2) x (label + 2) count matrix walked in ascending key order yields the same sequence.
-    int max_label = -2;
-    for (int r = 0; r < N; ++r) max_label = std::max(max_label, clustered[r]);
-    const int M = max_label + 3;
-    std::vector<int> link_cnt((size_t)M * M, 0), links_in((size_t)M, 0);
-    auto count_link = [&](int r1, int r2) {
-        const int c1 = clustered[r1] + 2, c2 = clustered[r2] + 2;
-        if (c1 != c2) link_cnt[(size_t)c1 * M + c2] += 1;
-        links_in[(size_t)c1] += 1;
-    };
-    if (low_memory) {
-        for (int r1 = 0; r1 < N; ++r1) for (int o = g.off[r1]; o < g.off[r1 + 1]; ++o) count_link(r1, g.adj[o]);
-    } else {
-        for (int k = 0; k < N; ++k) for (int o = g.off[k]; o < g.off[k + 1]; ++o) count_link(g.adj[o], k);
-    }
-    std::vector<std::pair<std::pair<int, int>, double>> sorted_links;
-    for (int c1 = 0; c1 < M; ++c1)
-        for (int c2 = 0; c2 < M; ++c2)
-            if (link_cnt[(size_t)c1 * M + c2] > 0)
-                sorted_links.push_back(std::make_pair(std::make_pair(c1 - 2, c2 - 2), (double)link_cnt[(size_t)c1 * M + c2] / links_in[(size_t)c1]));
-    std::sort(sorted_links.begin(), sorted_links.end(),
-              [](const std::pair<std::pair<int, int>, double>& a, const std::pair<std::pair<int, int>, double>& b) { return a.second > b.second; });
-    std::map<int, int> o2n;
-    for (int gl : glist) o2n[gl] = gl;
-    o2n[-1] = -1; o2n[-2] = -2;
-    for (auto& pc : sorted_links) {
-        if (!(pc.second > 0.01)) continue;
-        const int c1 = pc.first.first, c2 = pc.first.second;
-        if (o2n[c1] == o2n[c2]) continue;
-        bool bad = false;
-        for (int g1 : glist) {
-            if (o2n[g1] != o2n[c1]) continue;
-            for (int g2 : glist) if (o2n[g2] == o2n[c2] && incompat[(size_t)index_of[g1] * G + index_of[g2]] > 1) bad = true;
-        }
-        if (!bad) for (int g2 : glist) if (o2n[g2] == o2n[c2]) o2n[g2] = o2n[c1];
-    }
-    std::map<int, int> new_index;
-    int ni = 0;
-    for (int gl : glist) if (new_index.find(o2n[gl]) == new_index.end()) new_index[o2n[gl]] = ni++;
-    for (int gl : glist) o2n[gl] = new_index[o2n[gl]];
-    std::vector<int32_t> out((size_t)N, -1);
-    for (int r = 0; r < N; ++r) out[r] = o2n[clustered[r]];
-    return out;
-}
-
-#endif
 
 // finalize_clustering tail: separate_reads.cpp:973-993
-void sr_finish_window(const SrContigState& st, SrWindowPlan& w, const int32_t* reclustered, bool low_memory) {
-    const int N = st.N;
-    std::vector<int32_t> hap(reclustered, reclustered + N);
-    // first-seen renumbering of the non-negative labels (:973-984); -1 and -2 keep their meaning
+void sr_finish_window(const SrContigState& st, SrWindowPlan& w, const int32_t* reclustered, const SrLocalGraph& g, bool low_memory) {
+    const int m = (int)w.ids.size();
+    std::vector<int32_t> hap(reclustered, reclustered + m);
+    // first-seen renumbering of the non-negative labels (:973-984); -1 keeps its meaning (a window of the chain has SNPs)
     int max_label = -1;
     for (int h : hap) max_label = std::max(max_label, h);
     std::vector<int> to_index((size_t)max_label + 1, -1);
     int index_h = 0;
-    for (int r = 0; r < N; ++r) {
-        const int h = hap[r];
-        if (h == -1) hap[r] = st.c->n_snps == 0 ? 0 : -1;
-        else if (h >= 0) { if (to_index[(size_t)h] < 0) to_index[(size_t)h] = index_h++; hap[r] = to_index[(size_t)h]; }
+    for (int j = 0; j < m; ++j) {
+        const int h = hap[(size_t)j];
+        if (h == -1) hap[(size_t)j] = st.c->n_snps == 0 ? 0 : -1;
+        else if (h >= 0) { if (to_index[(size_t)h] < 0) to_index[(size_t)h] = index_h++; hap[(size_t)j] = to_index[(size_t)h]; }
     }
-    const SrGraph& g = st.graphs[(size_t)w.graph_final];
-    static const bool tim = std::getenv("HS_TIMING_FIN") != nullptr;
-    auto nowus = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = tim ? nowus() : 0;
-#ifdef HS_SELFCHECK
-    std::vector<int32_t> hap_ref = hap;
-    merge_close_clusters_ref(g, low_memory, hap_ref, w.mask.data(), st.perm);
-    const std::vector<int32_t> out_ref = merge_wrongly_split_ref(st, hap_ref, g, low_memory, w.final_lo, w.final_hi);
-#endif
-    {
+    {   // the shuffled order restricted to the window's reads (the others are skipped anyway)
         MergeScratch& S = merge_scratch();
-        S.masked.clear();
-        for (int r = 0; r < N; ++r) if (w.mask[(size_t)r]) S.masked.push_back(r);
+        S.order.clear();
+        static thread_local std::vector<std::pair<int32_t, int32_t>> byrank;
+        byrank.clear();
+        for (int j = 0; j < m; ++j) byrank.push_back(std::make_pair(st.rank[(size_t)w.ids[(size_t)j]], j));
+        std::sort(byrank.begin(), byrank.end());
+        for (auto& pr : byrank) S.order.push_back(pr.second);
     }
-    merge_close_clusters(g, low_memory, hap, w.mask.data(), st.perm, index_h);
-    const double t1 = tim ? nowus() : 0;
-    w.labels = merge_wrongly_split(st, hap, g, low_memory, w.final_lo, w.final_hi, index_h);
-#ifdef HS_SELFCHECK
-    if (hap_ref != hap || out_ref != w.labels) { std::fprintf(stderr, "HS_SELFCHECK: cluster merging differs from its reference form\n"); std::abort(); }
-#endif
-    if (tim) {
-        static std::atomic<long> a_mcc{0}, a_mws{0}, a_n{0};
-        a_mcc += (long)((t1 - t0) * 1000); a_mws += (long)((nowus() - t1) * 1000);
-        if (++a_n % 10 == 0) std::fprintf(stderr, "[hs timing] finish: %ld windows, merge_close_clusters %.1f us/window, merge_wrongly_split %.1f us/window\n",
-                                          a_n.load(), a_mcc.load() / 1000.0 / a_n.load(), a_mws.load() / 1000.0 / a_n.load());
-    }
+    SrLocalGraph gf = g;
+    std::vector<int64_t> empty_off;
+    if (w.final_graph_empty) { empty_off.assign((size_t)m + 1, 0); gf.off = empty_off.data(); gf.nbr = nullptr; }
+    merge_close_clusters(gf, low_memory, hap, w.ids, index_h);
+    w.labels = merge_wrongly_split(st, hap, w.ids, gf, low_memory, w.final_lo, w.final_hi, index_h);
 }
 
 // merge_haplotypes_to_fit_within_limit up to the re-clustering: separate_reads.cpp:1341-1383.
 // Returns false when the limit is already met (labels untouched).
-bool sr_ploidy_init_labels(const SrContigState& st, const SrWindowPlan& w, int max_haplotypes, int32_t* out) {
+bool sr_ploidy_init_labels(const SrWindowPlan& w, int max_haplotypes, int32_t* out) {
     std::map<int, int> count;
     for (int v : w.labels) if (v >= 0) count[v] += 1;
     if ((int)count.size() <= max_haplotypes) return false;
@@ -632,8 +437,8 @@ bool sr_ploidy_init_labels(const SrContigState& st, const SrWindowPlan& w, int m
     for (auto& c : count) v.push_back(std::make_pair(c.second, c.first));
     std::sort(v.begin(), v.end(), std::greater<std::pair<int, int>>());
     std::set<int> kept;
-    for (int i = 0; i < max_haplotypes; ++i) kept.insert(v[i].second);
-    for (int r = 0; r < st.N; ++r) out[r] = (w.labels[r] >= 0 && kept.find(w.labels[r]) == kept.end()) ? -1 : w.labels[r];
+    for (int i = 0; i < max_haplotypes; ++i) kept.insert(v[(size_t)i].second);
+    for (size_t j = 0; j < w.labels.size(); ++j) out[j] = (w.labels[j] >= 0 && kept.find(w.labels[j]) == kept.end()) ? -1 : w.labels[j];
     return true;
 }
 

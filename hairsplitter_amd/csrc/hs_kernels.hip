@@ -963,33 +963,6 @@ __global__ __launch_bounds__(256) void k_simdiff(
 // most frequent label with the LOWEST id on ties (:272-279). Masked-out nodes keep voting with their initial
 // label and are set to -2 at the end. Stops after 15 sweeps or when a sweep changes <= 2 nodes (:167).
 // ------------------------------------------------------------------------------------------------
-// Visiting list of a graph: its masked nodes with at least one neighbour, in the order of the permutation. The order is the
-// same in every sweep of every instance on the graph, so it is built once per graph instead of re-scanning the N-entry
-// permutation (N ~ 10 x the masked reads of a window) in every sweep.
-__global__ __launch_bounds__(64) void k_cw_visit_lists(
-    const int32_t* __restrict__ adj_off, const int64_t* __restrict__ graph_off_base, const int32_t* __restrict__ graph_n,
-    const int32_t* __restrict__ perm, const int64_t* __restrict__ perm_base, const uint8_t* __restrict__ mask, int n_graphs,
-    int32_t* __restrict__ visit, int32_t* __restrict__ visit_n) {
-    const int lane = lane_id();
-    const int g = (int)blockIdx.x;
-    if (g >= n_graphs) return;
-    const int N = graph_n[g];
-    const int32_t* __restrict__ aoff = adj_off + graph_off_base[g];
-    const int32_t* __restrict__ prm = perm + perm_base[g];
-    const uint8_t* __restrict__ msk = mask + graph_off_base[g] - g;
-    int32_t* __restrict__ out = visit + graph_off_base[g] - g;
-    int count = 0;
-    for (int k0 = 0; k0 < N; k0 += 64) {
-        const int kk = k0 + lane;
-        int i = 0; bool ok = false;
-        if (kk < N) { i = prm[kk]; ok = msk[i] && aoff[i + 1] > aoff[i]; }
-        const unsigned long long m = __ballot(ok);
-        if (ok) out[count + __popcll(m & ((1ull << lane) - 1ull))] = i;
-        count += __popcll(m);
-    }
-    if (lane == 0) visit_n[g] = count;
-}
-
 #ifndef HS_CW_REG_LABELS
 #define HS_CW_REG_LABELS 8
 #endif
@@ -1004,7 +977,9 @@ __global__ __launch_bounds__(64) void k_chinese_whispers(
     const int64_t* __restrict__ inst_seed_col, const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx,
     const uint8_t* __restrict__ col_code,
     // optional visiting lists (k_cw_visit_lists); nullptr: the permutation is scanned in every sweep
-    const int32_t* __restrict__ visit, const int32_t* __restrict__ visit_n) {
+    const int32_t* __restrict__ visit, const int32_t* __restrict__ visit_n,
+    // labels + vote counters of graphs too large for LDS: 2 * max_n ints per instance (nullptr: they live in LDS)
+    int32_t* __restrict__ gscratch, int max_n) {
     extern __shared__ int32_t cw_lds[];
     const int lane = lane_id();
     const int inst = (int)blockIdx.x;
@@ -1018,9 +993,9 @@ __global__ __launch_bounds__(64) void k_chinese_whispers(
     const int32_t* __restrict__ vis = visit ? visit + graph_off_base[g] - g : nullptr;
     const int n_visit = visit ? visit_n[g] : N;
     int32_t* __restrict__ lab_g = labels_io + inst_label_base[inst];
-    int32_t* lab = cw_lds;          // [N]
-    int32_t* cnt = cw_lds + N;      // [N]
-    int32_t* first = cw_lds + 2 * N;   // [256] first masked read carrying each code (seeding only)
+    int32_t* lab = gscratch ? gscratch + (int64_t)inst * 2 * max_n : cw_lds;   // [N]
+    int32_t* cnt = lab + N;                                                      // [N]
+    int32_t* first = gscratch ? cw_lds : cw_lds + 2 * N;   // [256] first masked read carrying each code (seeding only)
     if (inst_seed_col) {
         // every read starts alone; masked reads of the seeding column start in the cluster of the first masked read
         // that carries the same code
@@ -1077,11 +1052,11 @@ __global__ __launch_bounds__(64) void k_chinese_whispers(
                     const int lb = nb >= 0 ? lab[nb] : -1;
                     unsigned long long rem = __ballot(lb >= 0);
                     // key = count << 16 | (65535 - label): the largest key is the largest count, lowest label among equals
-                    // (labels are read indices: < 20 000, the limit the host enforces per contig)
+                    // (only when every label fits 16 bits: N <= 65535; larger graphs always take the counter path)
                     unsigned best_key = 0u;
 #pragma unroll
                     for (int tries = 0; tries < HS_CW_REG_LABELS; ++tries) {
-                        if (!rem) break;
+                        if (!rem || N > 65535) break;
                         const int v = __builtin_amdgcn_readlane(lb, __builtin_ctzll(rem));
                         const unsigned long long m = __ballot(lb == v);
                         const unsigned key = ((unsigned)__popcll(m) << 16) | (unsigned)(65535 - v);
@@ -1238,109 +1213,6 @@ __global__ __launch_bounds__(64) void k_myers(
         if (mode == 0) { dist[pr] = fs; endloc[pr] = tn - 1; }
         else { dist[pr] = fb; endloc[pr] = fj; }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// First-appearance renumbering shared by the two bookkeeping kernels below: given first[j] (index of the first
-// element equal to element j, or -1 for "no label"), id[j] = number of distinct first-appearances before first[j].
-// One workgroup; `flag` and `pre` are N-int scratch arrays in global memory.
-// ------------------------------------------------------------------------------------------------
-static __device__ void first_seen_ids(const int32_t* first, int N, int32_t* pre, int32_t* out_id) {
-    __shared__ int s_carry;
-    __shared__ int s_wsum[4];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < N; b0 += 256) {
-        const int j = b0 + tid;
-        const int f = (j < N && first[j] == j) ? 1 : 0;
-        int incl = f;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int x = __shfl_up(incl, d, 64); if (lane >= d) incl += x; }
-        if (lane == 63) s_wsum[wv] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < wv; ++k) woff += s_wsum[k];
-        if (j < N) pre[j] = s_carry + woff + incl - f;     // exclusive count of first-appearances before j
-        __syncthreads();
-        if (tid == 0) s_carry += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-        __syncthreads();
-    }
-    for (int j = tid; j < N; j += 256) { const int f = first[j]; out_id[j] = f >= 0 ? pre[f] : -1; }
-}
-
-// merge_clusterings, separate_reads.cpp:840-874: reads that were never separated by any per-SNP clustering share
-// an id. The reference keys a hash map on sum_i label_i[j] * 2^i accumulated in double; the same double is built
-// here in the same order, ids are handed out in order of first appearance, non-masked reads get -2.
-__global__ __launch_bounds__(256) void k_cw_merge_ids(
-    const int32_t* __restrict__ local_labels, const int64_t* __restrict__ win_local_base, const int32_t* __restrict__ win_k,
-    const int32_t* __restrict__ win_n, const int32_t* __restrict__ win_graph, const int64_t* __restrict__ graph_off_base,
-    const uint8_t* __restrict__ mask, const int64_t* __restrict__ win_out_base, double* __restrict__ agg_scratch,
-    int32_t* __restrict__ first_scratch, int32_t* __restrict__ pre_scratch, int32_t* __restrict__ out_labels) {
-    const int w = (int)blockIdx.x;
-    const int N = win_n[w], K = win_k[w];
-    const int32_t* __restrict__ loc = local_labels + win_local_base[w];
-    const int g = win_graph[w];
-    const uint8_t* __restrict__ msk = mask + graph_off_base[g] - g;
-    double* agg = agg_scratch + win_out_base[w];
-    int32_t* first = first_scratch + win_out_base[w];
-    int32_t* pre = pre_scratch + win_out_base[w];
-    int32_t* out = out_labels + win_out_base[w];
-    const int tid = (int)threadIdx.x;
-    for (int j = tid; j < N; j += 256) {
-        double a = 0.0, f = 1.0;
-        for (int i = 0; i < K; ++i) { a += (double)loc[(int64_t)i * N + j] * f; f *= 2.0; }   // exact powers of two
-        agg[j] = a;
-    }
-    __syncthreads();
-    for (int j = tid; j < N; j += 256) {
-        const double a = agg[j];
-        int k = 0;
-        while (agg[k] != a) ++k;      // terminates at k == j at the latest
-        first[j] = k;
-    }
-    __syncthreads();
-    first_seen_ids(first, N, pre, out);
-    __syncthreads();
-    for (int j = tid; j < N; j += 256) if (!msk[j]) out[j] = -2;
-}
-
-// finalize_clustering, separate_reads.cpp:924-955: clusters with fewer than 5 masked reads become -1, the others are
-// renumbered in order of first appearance; non-masked reads are -2.
-__global__ __launch_bounds__(256) void k_cw_drop_small(
-    const int32_t* __restrict__ in_labels, const int32_t* __restrict__ win_n, const int32_t* __restrict__ win_graph,
-    const int64_t* __restrict__ graph_off_base, const uint8_t* __restrict__ mask, const int64_t* __restrict__ win_base,
-    int32_t* __restrict__ size_scratch, int32_t* __restrict__ first_scratch, int32_t* __restrict__ pre_scratch,
-    int32_t* __restrict__ out_labels) {
-    const int w = (int)blockIdx.x;
-    const int N = win_n[w];
-    const int g = win_graph[w];
-    const uint8_t* __restrict__ msk = mask + graph_off_base[g] - g;
-    const int32_t* __restrict__ in = in_labels + win_base[w];
-    int32_t* size = size_scratch + win_base[w];      // per label
-    int32_t* fpos = first_scratch + win_base[w];     // reused: first position of a label, then first[] per read
-    int32_t* pre = pre_scratch + win_base[w];
-    int32_t* out = out_labels + win_base[w];
-    const int tid = (int)threadIdx.x;
-    for (int j = tid; j < N; j += 256) { size[j] = 0; pre[j] = 0x7fffffff; }
-    __syncthreads();
-    for (int j = tid; j < N; j += 256) { const int l = msk[j] ? in[j] : -2; if (l >= 0 && l < N) atomicAdd(&size[l], 1); }
-    __syncthreads();
-    // labels surviving the size filter; first position of each surviving label (in pre[], per label)
-    for (int j = tid; j < N; j += 256) {
-        int l = msk[j] ? in[j] : -2;
-        if (l != -2 && (l < 0 || l >= N || size[l] < 5)) l = -1;      // a label outside [0,N) has map-default size 0
-        out[j] = l;
-        if (l >= 0) atomicMin(&pre[l], j);
-    }
-    __syncthreads();
-    for (int j = tid; j < N; j += 256) fpos[j] = out[j] >= 0 ? pre[out[j]] : -1;
-    __syncthreads();
-    // keep -2 / -1 where they are, renumber the rest
-    int32_t* ids = size;   // size[] is dead now
-    first_seen_ids(fpos, N, pre, ids);
-    __syncthreads();
-    for (int j = tid; j < N; j += 256) if (out[j] >= 0) out[j] = ids[j];
 }
 
 // ------------------------------------------------------------------------------------------------

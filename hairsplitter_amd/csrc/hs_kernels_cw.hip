@@ -1,0 +1,688 @@
+// hs_kernels_cw.hip -- the clustering chain of a window in the window's LOCAL index space.
+//
+// A clustering window only ever touches its masked reads (the reads present at its first and last SNP,
+// separate_reads.cpp:1590-1622): create_read_graph_matrix links masked reads only (:806-815), Chinese Whispers only
+// updates masked nodes and a masked node only has masked neighbours (cluster_graph.cpp:240-310), every later step
+// (:840-994, :1007-1327) skips the label -2 the other reads carry. Node j of a window is therefore the j-th masked read
+// (ascending read id, so "lowest label wins" and "first appearance" mean the same as on read ids); a graph is the window's
+// row range of the K6 CSR; labels, vote counters and every table are m-sized (m ~ 40 of the N ~ 500..20 000 reads of a
+// contig). The one place where the VALUE of a label matters is merge_clusterings' double key (:848-853): it is formed from
+// the read ids (mask_ids[label]).
+//
+//   k_cw_visit_lists      per window: nodes with neighbours in the order of the contig's shuffled permutation
+//   k_cw_seeded_rows      per-SNP runs (:1674-1705), FOUR instances per wavefront: one 16-lane DPP row per instance
+//                         (mean degree ~ 16), windows with m <= 256
+//   k_cw_seeded_wave      the same for any m, one wavefront per instance (labels in LDS, or in global scratch beyond its size)
+//   k_window_tail         one wavefront per window: merge_clusterings ids -> CW -> small clusters dropped -> CW
+//                         (finalize_clustering :897-971) -> first-seen renumbering, merge_close_clusters
+//                         (cluster_graph.cpp:402-501), merge_wrongly_split_haplotypes (:1007-1327); labels never leave LDS
+//   k_cw_local            one wavefront per (window, initial labels): the optional ploidy cap (:1341-1396)
+// Included by hs_capi.hip after hs_kernels.hip.
+#pragma once
+
+namespace hsdev {
+
+#define HS_FIN_KCAP 16      // cluster labels entering merge_close_clusters
+#define HS_FIN_GCAP 8       // clusters entering merge_wrongly_split
+#define HS_FIN_LCAP 16      // cluster links (std::sort is a plain insertion sort up to 16 elements)
+#define HS_FIN_MCAP (HS_FIN_KCAP + 2)
+#define HS_CWR_CAP 256      // nodes per instance in the row-packed kernel
+#ifndef HS_CW_REG_LABELS
+#define HS_CW_REG_LABELS 8
+#endif
+
+static __device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// position of read id r in the ascending list ids[0..m), or -1
+static __device__ __forceinline__ int local_index(const int32_t* __restrict__ ids, int m, int r) {
+    int lo = 0, hi = m;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (ids[mid] < r) lo = mid + 1; else hi = mid; }
+    return (lo < m && ids[lo] == r) ? lo : -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Visiting order of a window: its nodes with at least one neighbour, in the order of the contig's permutation
+// (std::shuffle(mt19937(seed)) of 0..N-1 on the host: cluster_graph.cpp:254-258; with the pinned seed the same order in
+// every sweep). rank[r] = position of read r in that permutation; the nodes are sorted by rank by counting, per node, the
+// nodes that come before it (m ~ 40: one pass of the wave over an LDS copy of the ranks).
+// One workgroup (256 threads) per window.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cw_visit_lists(
+    const int64_t* __restrict__ off, const int64_t* __restrict__ win_row0, const int32_t* __restrict__ mask_ids,
+    const int32_t* __restrict__ win_contig, const int64_t* __restrict__ ctg_rank_off, const int32_t* __restrict__ rank,
+    int n_windows, int cap, int32_t* __restrict__ visit, int32_t* __restrict__ visit_n) {
+    extern __shared__ int32_t s_rank[];   // [cap] rank of every node with neighbours, -1 otherwise
+    const int w = (int)blockIdx.x;
+    if (w >= n_windows) return;
+    const int tid = (int)threadIdx.x;
+    const int64_t r0 = win_row0[w];
+    const int m = (int)(win_row0[w + 1] - r0);
+    const int32_t* __restrict__ rk = rank + ctg_rank_off[win_contig[w]];
+    int32_t* __restrict__ out = visit + r0;
+    __shared__ int s_total;
+    if (tid == 0) s_total = 0;
+    __syncthreads();
+    // windows wider than the LDS copy are processed against global memory (rank gathers straight from `rank`)
+    const bool in_lds = m <= cap;
+    int mine = 0;
+    for (int j = tid; j < m; j += 256) {
+        const bool has = off[r0 + j + 1] > off[r0 + j];
+        const int v = has ? rk[mask_ids[r0 + j]] : -1;
+        if (in_lds) s_rank[j] = v;
+        mine += has ? 1 : 0;
+    }
+    atomicAdd(&s_total, mine);
+    __syncthreads();
+    for (int j = tid; j < m; j += 256) {
+        const int v = in_lds ? s_rank[j] : (off[r0 + j + 1] > off[r0 + j] ? rk[mask_ids[r0 + j]] : -1);
+        if (v < 0) continue;
+        int before = 0;
+        if (in_lds) { for (int k = 0; k < m; ++k) { const int u = s_rank[k]; before += (u >= 0 && u < v) ? 1 : 0; } }
+        else { for (int k = 0; k < m; ++k) { if (off[r0 + k + 1] > off[r0 + k]) before += rk[mask_ids[r0 + k]] < v ? 1 : 0; } }
+        out[before] = j;
+    }
+    if (tid == 0) visit_n[w] = s_total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One Chinese-Whispers run by one wavefront on a local graph (cluster_graph.cpp:240-310): nodes sequential in the visiting
+// order, the neighbours of the current node across the lanes; <= 15 sweeps, stop when a sweep changes <= 2 nodes (:167).
+// Vote: lowest label among the most frequent ones (:272-279), labels < 0 do not vote. With at most 64 neighbours the vote is
+// taken in registers (one ballot per distinct label; nodes that see more than HS_CW_REG_LABELS distinct labels go through
+// the counters `cnt`, which are all zero between visits); the neighbour ids of the next node are loaded one visit ahead.
+// `lab` / `cnt`: m ints each, LDS or global. Returns the number of sweeps.
+// ------------------------------------------------------------------------------------------------
+static __device__ int cw_local_wave(const int64_t* __restrict__ off_w /* at the window's first row */, const int32_t* __restrict__ nbr,
+                                    const int32_t* __restrict__ vis, int n_visit, int m, int32_t* lab, int32_t* cnt, int lane) {
+    const int64_t base = off_w[0];
+    const int32_t* __restrict__ anb = nbr + base;
+    const bool small_labels = m <= 65535;
+    int changes = 3, iters = 0;
+    while (changes > 2 && iters < 15) {
+        changes = 0;
+        for (int k0 = 0; k0 < n_visit; k0 += 64) {
+            const int kk = k0 + lane;
+            int i_l = -1, o0_l = 0, o1_l = 0;
+            if (kk < n_visit) { i_l = vis[kk]; o0_l = (int)(off_w[i_l] - base); o1_l = (int)(off_w[i_l + 1] - base); }
+            unsigned long long act = __ballot(o1_l > o0_l);
+            int nb_next = -1;
+            if (act) {
+                const int ln = __builtin_ctzll(act);
+                const int p0 = __builtin_amdgcn_readlane(o0_l, ln), p1 = __builtin_amdgcn_readlane(o1_l, ln);
+                nb_next = (p1 - p0 <= 64 && p0 + lane < p1) ? anb[p0 + lane] : -1;
+            }
+            while (act) {
+                const int l = __builtin_ctzll(act);
+                act &= act - 1ull;
+                const int i = __builtin_amdgcn_readlane(i_l, l);
+                const int o0 = __builtin_amdgcn_readlane(o0_l, l), o1 = __builtin_amdgcn_readlane(o1_l, l);
+                const int nb = nb_next;
+                if (act) {
+                    const int ln = __builtin_ctzll(act);
+                    const int p0 = __builtin_amdgcn_readlane(o0_l, ln), p1 = __builtin_amdgcn_readlane(o1_l, ln);
+                    nb_next = (p1 - p0 <= 64 && p0 + lane < p1) ? anb[p0 + lane] : -1;
+                }
+                int best_cnt = 0, best_lab = -1;
+                if (o1 - o0 <= 64) {
+                    const int lb = nb >= 0 ? lab[nb] : -1;
+                    unsigned long long rem = __ballot(lb >= 0);
+                    unsigned best_key = 0u;   // count << 16 | (65535 - label): largest count, lowest label among equals
+                    if (small_labels) {
+#pragma unroll
+                        for (int tries = 0; tries < HS_CW_REG_LABELS; ++tries) {
+                            if (!rem) break;
+                            const int v = __builtin_amdgcn_readlane(lb, __builtin_ctzll(rem));
+                            const unsigned long long mm = __ballot(lb == v);
+                            const unsigned key = ((unsigned)__popcll(mm) << 16) | (unsigned)(65535 - v);
+                            best_key = key > best_key ? key : best_key;
+                            rem &= ~mm;
+                        }
+                    }
+                    best_cnt = (int)(best_key >> 16);
+                    best_lab = best_cnt ? 65535 - (int)(best_key & 0xffffu) : -1;
+                    if (rem) {
+                        if (lb >= 0) atomicAdd(&cnt[lb], 1);
+                        wave_sync_lds();
+                        const int c = lb >= 0 ? cnt[lb] : 0;
+                        best_cnt = wave_max_i32(c);
+                        best_lab = 0x7fffffff - wave_max_i32((lb >= 0 && c == best_cnt) ? 0x7fffffff - lb : 0);
+                        wave_sync_lds();
+                        if (lb >= 0) cnt[lb] = 0;
+                    }
+                } else {
+                    for (int o = o0 + lane; o < o1; o += 64) { const int lb = lab[anb[o]]; if (lb >= 0) atomicAdd(&cnt[lb], 1); }
+                    wave_sync_lds();
+                    unsigned long long best = 0ull;
+                    for (int o = o0 + lane; o < o1; o += 64) {
+                        const int lb = lab[anb[o]];
+                        if (lb >= 0) {
+                            const unsigned long long key = ((unsigned long long)(unsigned)cnt[lb] << 32) | (unsigned)(0x7fffffff - lb);
+                            best = key > best ? key : best;
+                        }
+                    }
+                    best = wave_max_u64(best);
+                    wave_sync_lds();
+                    for (int o = o0 + lane; o < o1; o += 64) { const int lb = lab[anb[o]]; if (lb >= 0) cnt[lb] = 0; }
+                    best_cnt = (int)(best >> 32);
+                    best_lab = 0x7fffffff - (int)(best & 0xffffffffull);
+                }
+                if (best_cnt > 0) {
+                    if (lab[i] != best_lab) changes++;
+                    wave_sync_lds();
+                    if (lane == 0) lab[i] = best_lab;
+                }
+                wave_sync_lds();
+            }
+        }
+        iters++;
+    }
+    return iters;
+}
+
+// Seeding of a per-SNP run (separate_reads.cpp:1678-1691): every node starts alone; the nodes that carry the same code at
+// the seeding SNP start in the cluster of the first node (lowest read id) carrying it. `first`: 256 ints of scratch.
+template <int LANES>
+static __device__ __forceinline__ void cw_seed_labels(const int32_t* __restrict__ ids, int m, int64_t c0, int64_t c1,
+                                                      const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
+                                                      int32_t* first, int l) {
+    for (int64_t e = c0 + l; e < c1; e += LANES) {
+        const int j = local_index(ids, m, col_idx[e]);
+        if (j >= 0) atomicMin(&first[col_code[e]], j);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-SNP runs, row-packed: a workgroup of 256 threads = 16 DPP rows = 16 instances, each with its own slice of LDS
+// (labels u16 + vote counters). The lanes of a row hold the neighbours of the row's current node (mean degree ~ 16):
+// LDS atomic votes, every lane reads its label's total, the row maximum of (count << 16 | 65535 - label) comes from four
+// row_ror DPP steps. Rows of a wavefront run in lock step on different instances (EXEC masks off the finished ones).
+// Windows with m > HS_CWR_CAP are left to k_cw_seeded_wave (inst_list holds the instances of this launch).
+// Output: slab[inst_slab_off + j] = label (local) of node j.
+// ------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ unsigned row_max_u32(unsigned v) {
+    unsigned o;
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false); v = o > v ? o : v;   // row_ror:8
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false); v = o > v ? o : v;   // row_ror:4
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false); v = o > v ? o : v;   // row_ror:2
+    o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false); v = o > v ? o : v;   // row_ror:1
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_cw_seeded_rows(
+    const int64_t* __restrict__ off, const int32_t* __restrict__ nbr, const int64_t* __restrict__ win_row0,
+    const int32_t* __restrict__ mask_ids, const int32_t* __restrict__ visit, const int32_t* __restrict__ visit_n,
+    const int32_t* __restrict__ inst_list, int n_list, const int32_t* __restrict__ inst_win, const int64_t* __restrict__ inst_seed_col,
+    const int64_t* __restrict__ inst_slab_off, const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx,
+    const uint8_t* __restrict__ col_code, int32_t* __restrict__ slab, unsigned long long* __restrict__ stat /* [2]: sweeps, bytes */) {
+    __shared__ int32_t s_cnt[16][HS_CWR_CAP];      // vote counters; the first-node-per-code table while seeding
+    __shared__ uint16_t s_lab[16][HS_CWR_CAP];
+    const int tid = (int)threadIdx.x, row = tid >> 4, l = tid & 15;
+    const int k = (int)blockIdx.x * 16 + row;
+    const bool live = k < n_list;
+    const int inst = live ? inst_list[k] : 0;
+    const int w = live ? inst_win[inst] : 0;
+    const int64_t r0 = win_row0[w];
+    const int m = live ? (int)(win_row0[w + 1] - r0) : 0;
+    const int32_t* __restrict__ ids = mask_ids + r0;
+    const int32_t* __restrict__ vis = visit + r0;
+    const int n_visit = live ? visit_n[w] : 0;
+    const int64_t* __restrict__ off_w = off + r0;
+    const int64_t base = off_w[0];
+    const int32_t* __restrict__ anb = nbr + base;
+    int32_t* cnt = s_cnt[row];
+    uint16_t* lab = s_lab[row];
+    for (int j = l; j < HS_CWR_CAP; j += 16) { cnt[j] = 0x7fffffff; lab[j] = (uint16_t)j; }
+    wave_sync_lds();
+    if (live) {
+        const int64_t s = inst_seed_col[inst];
+        cw_seed_labels<16>(ids, m, col_off[s], col_off[s + 1], col_idx, col_code, cnt, l);
+    }
+    wave_sync_lds();
+    if (live) {
+        const int64_t s = inst_seed_col[inst];
+        for (int64_t e = col_off[s] + l; e < col_off[s + 1]; e += 16) {
+            const int j = local_index(ids, m, col_idx[e]);
+            if (j >= 0) lab[j] = (uint16_t)cnt[col_code[e]];
+        }
+    }
+    wave_sync_lds();
+    for (int j = l; j < HS_CWR_CAP; j += 16) cnt[j] = 0;
+    wave_sync_lds();
+
+    int changes = 3, iters = 0;
+    while (live && changes > 2 && iters < 15) {
+        changes = 0;
+        for (int v = 0; v < n_visit; ++v) {
+            const int i = vis[v];
+            const int o0 = (int)(off_w[i] - base), o1 = (int)(off_w[i + 1] - base);
+            unsigned best = 0u;
+            if (o1 - o0 <= 16) {          // the usual case: one neighbour per lane, its label stays in a register
+                const bool has = o0 + l < o1;
+                const int lb = has ? (int)lab[anb[o0 + l]] : 0;
+                if (has) atomicAdd(&cnt[lb], 1);
+                wave_sync_lds();
+                if (has) best = ((unsigned)cnt[lb] << 16) | (unsigned)(65535 - lb);
+                best = row_max_u32(best);
+                wave_sync_lds();
+                if (has) cnt[lb] = 0;
+            } else {
+                for (int o = o0 + l; o < o1; o += 16) atomicAdd(&cnt[lab[anb[o]]], 1);
+                wave_sync_lds();
+                for (int o = o0 + l; o < o1; o += 16) { const int lb = lab[anb[o]]; const unsigned key = ((unsigned)cnt[lb] << 16) | (unsigned)(65535 - lb); best = key > best ? key : best; }
+                best = row_max_u32(best);
+                wave_sync_lds();
+                for (int o = o0 + l; o < o1; o += 16) cnt[lab[anb[o]]] = 0;
+            }
+            const int best_lab = 65535 - (int)(best & 0xffffu);      // a visited node has neighbours: the count is > 0
+            if ((int)lab[i] != best_lab) changes++;
+            wave_sync_lds();
+            if (l == 0) lab[i] = (uint16_t)best_lab;
+            wave_sync_lds();
+        }
+        iters++;
+    }
+    if (live) {
+        int32_t* __restrict__ out = slab + inst_slab_off[inst];
+        for (int j = l; j < m; j += 16) out[j] = (int32_t)lab[j];
+        if (l == 0 && stat) {
+            atomicAdd(&stat[0], (unsigned long long)iters);
+            atomicAdd(&stat[1], (unsigned long long)iters * (4ull * (unsigned long long)(off_w[m] - base) + 8ull * (unsigned long long)m));
+        }
+    }
+}
+
+// The same for any window: one wavefront per instance. lds_cap = nodes whose labels + counters fit the dynamic LDS of the
+// launch; wider windows keep them in `gscratch` (2 * m ints per instance at gscratch_off[k]).
+__global__ __launch_bounds__(64) void k_cw_seeded_wave(
+    const int64_t* __restrict__ off, const int32_t* __restrict__ nbr, const int64_t* __restrict__ win_row0,
+    const int32_t* __restrict__ mask_ids, const int32_t* __restrict__ visit, const int32_t* __restrict__ visit_n,
+    const int32_t* __restrict__ inst_list, int n_list, const int32_t* __restrict__ inst_win, const int64_t* __restrict__ inst_seed_col,
+    const int64_t* __restrict__ inst_slab_off, const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx,
+    const uint8_t* __restrict__ col_code, int lds_cap, int32_t* __restrict__ gscratch, const int64_t* __restrict__ gscratch_off,
+    int32_t* __restrict__ slab, unsigned long long* __restrict__ stat) {
+    extern __shared__ int32_t cw_dyn[];     // [2 * lds_cap]
+    __shared__ int32_t s_first[256];
+    const int lane = lane_id();
+    const int k = (int)blockIdx.x;
+    if (k >= n_list) return;
+    const int inst = inst_list[k];
+    const int w = inst_win[inst];
+    const int64_t r0 = win_row0[w];
+    const int m = (int)(win_row0[w + 1] - r0);
+    const int32_t* __restrict__ ids = mask_ids + r0;
+    int32_t* lab = m <= lds_cap ? cw_dyn : gscratch + gscratch_off[k];
+    int32_t* cnt = lab + (m <= lds_cap ? lds_cap : m);
+    for (int j = lane; j < m; j += 64) { lab[j] = j; cnt[j] = 0; }
+    for (int j = lane; j < 256; j += 64) s_first[j] = 0x7fffffff;
+    wave_sync_lds();
+    const int64_t s = inst_seed_col[inst];
+    cw_seed_labels<64>(ids, m, col_off[s], col_off[s + 1], col_idx, col_code, s_first, lane);
+    wave_sync_lds();
+    for (int64_t e = col_off[s] + lane; e < col_off[s + 1]; e += 64) {
+        const int j = local_index(ids, m, col_idx[e]);
+        if (j >= 0) lab[j] = s_first[col_code[e]];
+    }
+    wave_sync_lds();
+    const int iters = cw_local_wave(off + r0, nbr, visit + r0, visit_n[w], m, lab, cnt, lane);
+    int32_t* __restrict__ out = slab + inst_slab_off[inst];
+    for (int j = lane; j < m; j += 64) out[j] = lab[j];
+    if (lane == 0 && stat) {
+        atomicAdd(&stat[0], (unsigned long long)iters);
+        atomicAdd(&stat[1], (unsigned long long)iters * (4ull * (unsigned long long)(off[r0 + m] - off[r0]) + 8ull * (unsigned long long)m));
+    }
+}
+
+// One run per (window, initial local labels): labels_io[inst_label_off[i] .. + m). Used by the optional ploidy cap.
+__global__ __launch_bounds__(64) void k_cw_local(
+    const int64_t* __restrict__ off, const int32_t* __restrict__ nbr, const int64_t* __restrict__ win_row0,
+    const int32_t* __restrict__ visit, const int32_t* __restrict__ visit_n, const uint8_t* __restrict__ win_final_empty,
+    const int32_t* __restrict__ inst_win, const int64_t* __restrict__ inst_label_off, int n_inst, int lds_cap,
+    int32_t* __restrict__ gscratch, const int64_t* __restrict__ gscratch_off, int32_t* __restrict__ labels_io) {
+    extern __shared__ int32_t cw_dyn[];
+    const int lane = lane_id();
+    const int k = (int)blockIdx.x;
+    if (k >= n_inst) return;
+    const int w = inst_win[k];
+    const int64_t r0 = win_row0[w];
+    const int m = (int)(win_row0[w + 1] - r0);
+    int32_t* lab = m <= lds_cap ? cw_dyn : gscratch + gscratch_off[k];
+    int32_t* cnt = lab + (m <= lds_cap ? lds_cap : m);
+    int32_t* __restrict__ io = labels_io + inst_label_off[k];
+    for (int j = lane; j < m; j += 64) { lab[j] = io[j]; cnt[j] = 0; }
+    wave_sync_lds();
+    cw_local_wave(off + r0, nbr, visit + r0, win_final_empty[w] ? 0 : visit_n[w], m, lab, cnt, lane);
+    for (int j = lane; j < m; j += 64) io[j] = lab[j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// id[j] = number of distinct first appearances before first[j], where first[j] = index of the first element equal to
+// element j (or -1: no label). One wavefront, chunks of 64 with a ballot prefix; `pre` is m ints of scratch.
+// ------------------------------------------------------------------------------------------------
+static __device__ void first_seen_ids_wave(const int32_t* first, int m, int32_t* pre, int32_t* out_id, int lane) {
+    int carry = 0;
+    for (int b0 = 0; b0 < m; b0 += 64) {
+        const int j = b0 + lane;
+        const bool f = j < m && first[j] == j;
+        const unsigned long long b = __ballot(f);
+        if (j < m) pre[j] = carry + __popcll(b & ((1ull << lane) - 1ull));
+        carry += __popcll(b);
+    }
+    wave_sync_lds();
+    for (int j = lane; j < m; j += 64) { const int f = first[j]; out_id[j] = f >= 0 ? pre[f] : -1; }
+    wave_sync_lds();
+}
+
+// ------------------------------------------------------------------------------------------------
+// The tail of a clustering window, one wavefront per window of the chain (see the file header). Arrays of m ints in LDS
+// (or in global scratch for windows wider than lds_cap): lab, nc, cnt, t0, t1 and m doubles agg.
+// labels3_out: what the third Chinese-Whispers run leaves (for the windows the host has to finish: ok_out = 0 when the
+// window exceeds the fixed tables of the cluster-merging steps or finish_on_device is off); final_out: finished labels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_window_tail(
+    const int64_t* __restrict__ off, const int32_t* __restrict__ nbr, const int64_t* __restrict__ win_row0,
+    const int32_t* __restrict__ mask_ids, const int32_t* __restrict__ visit, const int32_t* __restrict__ visit_n,
+    const uint8_t* __restrict__ win_final_empty,
+    const int32_t* __restrict__ chain_win, const int64_t* __restrict__ chain_row0, const int64_t* __restrict__ chain_seed_begin,
+    const int64_t* __restrict__ chain_slab0, const int32_t* __restrict__ slab, int n_chain,
+    const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
+    const int32_t* __restrict__ col_pos, const int64_t* __restrict__ win_snp_first, const int64_t* __restrict__ win_snp_last,
+    const int32_t* __restrict__ win_pos_lo, const int32_t* __restrict__ win_pos_hi, int finish_on_device,
+    int lds_cap, int32_t* __restrict__ gscratch, const int64_t* __restrict__ gscratch_off,
+    int32_t* __restrict__ labels3_out, int32_t* __restrict__ final_out, uint8_t* __restrict__ ok_out, unsigned long long* __restrict__ stat) {
+    extern __shared__ int32_t tail_dyn[];    // [7 * lds_cap] (the doubles first: 8-byte aligned)
+    __shared__ int s_votes[HS_FIN_KCAP], s_count[HS_FIN_KCAP], s_initial[HS_FIN_KCAP], s_tested[HS_FIN_KCAP];
+    __shared__ int s_index_of[HS_FIN_KCAP], s_slot_of[HS_FIN_KCAP];
+    __shared__ int s_cnts[HS_FIN_GCAP][256];
+    __shared__ int s_nb[HS_FIN_GCAP], s_major[HS_FIN_GCAP], s_glist[HS_FIN_GCAP], s_gidx[HS_FIN_GCAP];
+    __shared__ int s_incompat[HS_FIN_GCAP * HS_FIN_GCAP], s_pos_last[HS_FIN_GCAP * HS_FIN_GCAP];
+    __shared__ int s_link_cnt[HS_FIN_MCAP * HS_FIN_MCAP], s_links_in[HS_FIN_MCAP], s_o2n[HS_FIN_MCAP], s_new_index[HS_FIN_MCAP];
+    __shared__ int s_scalar[8];
+    const int lane = lane_id();
+    const int c = (int)blockIdx.x;
+    if (c >= n_chain) return;
+    const int w = chain_win[c];
+    const int64_t r0 = win_row0[w];
+    const int m = (int)(win_row0[w + 1] - r0);
+    const int32_t* __restrict__ ids = mask_ids + r0;
+    const int64_t* __restrict__ off_w = off + r0;
+    const int64_t abase = off_w[0];
+    const int32_t* __restrict__ anb = nbr + abase;
+    const int32_t* __restrict__ vis = visit + r0;
+    const int n_visit = win_final_empty[w] ? 0 : visit_n[w];   // finalize_clustering may be handed an empty graph (:1708)
+    const int K = (int)(chain_seed_begin[c + 1] - chain_seed_begin[c]);
+    const int32_t* __restrict__ sl = slab + chain_slab0[c];
+    const bool in_lds = m <= lds_cap;
+    const int stride = in_lds ? lds_cap : m;
+    int32_t* basep = in_lds ? tail_dyn : gscratch + gscratch_off[c];
+    double* agg = reinterpret_cast<double*>(basep);          // [stride]
+    int32_t* lab = basep + 2 * stride;
+    int32_t* nc = lab + stride;
+    int32_t* cnt = nc + stride;
+    int32_t* t0 = cnt + stride;
+    int32_t* t1 = t0 + stride;
+    int32_t* __restrict__ l3 = labels3_out + chain_row0[c];
+    int32_t* __restrict__ lout = final_out + chain_row0[c];
+    auto bail = [&]() { if (lane == 0) ok_out[c] = 0; };
+    unsigned long long sweeps = 0;
+
+    // ---- merge_clusterings ids (:840-874): the reference's double key sum_i label_i * 2^i, labels = read ids ----
+    for (int j = lane; j < m; j += 64) {
+        double a = 0.0, f = 1.0;
+        for (int i = 0; i < K; ++i) { a += (double)ids[sl[(int64_t)i * m + j]] * f; f *= 2.0; }   // exact powers of two
+        agg[j] = a; cnt[j] = 0;
+    }
+    wave_sync_lds();
+    for (int j = lane; j < m; j += 64) {
+        const double a = agg[j];
+        int k = 0;
+        while (agg[k] != a) ++k;      // terminates at k == j at the latest
+        t0[j] = k;
+    }
+    wave_sync_lds();
+    first_seen_ids_wave(t0, m, t1, lab, lane);
+    // ---- run on the finalize graph (:881) ----
+    sweeps += (unsigned long long)cw_local_wave(off_w, nbr, vis, n_visit, m, lab, cnt, lane);
+    // ---- clusters with fewer than 5 reads become -1, the others are renumbered by first appearance (:924-955) ----
+    for (int j = lane; j < m; j += 64) { nc[j] = 0; t1[j] = 0x7fffffff; }
+    wave_sync_lds();
+    for (int j = lane; j < m; j += 64) { const int l = lab[j]; if (l >= 0 && l < m) atomicAdd(&nc[l], 1); }
+    wave_sync_lds();
+    for (int j = lane; j < m; j += 64) {
+        int l = lab[j];
+        if (l < 0 || l >= m || nc[l] < 5) l = -1;
+        t0[j] = l;
+        if (l >= 0) atomicMin(&t1[l], j);
+    }
+    wave_sync_lds();
+    for (int j = lane; j < m; j += 64) nc[j] = t0[j] >= 0 ? t1[t0[j]] : -1;     // first position of the node's label
+    wave_sync_lds();
+    first_seen_ids_wave(nc, m, t1, lab, lane);
+    // ---- run (:970) ----
+    sweeps += (unsigned long long)cw_local_wave(off_w, nbr, vis, n_visit, m, lab, cnt, lane);
+    for (int j = lane; j < m; j += 64) l3[j] = lab[j];
+    if (lane == 0 && stat) {
+        atomicAdd(&stat[0], sweeps);
+        atomicAdd(&stat[1], sweeps * (4ull * (unsigned long long)(off_w[m] - abase) + 8ull * (unsigned long long)m));
+    }
+    if (!finish_on_device) { bail(); return; }
+
+    // ---- first-seen renumbering (:973-984) ----
+    for (int j = lane; j < m; j += 64) nc[j] = -1;
+    wave_sync_lds();
+    if (lane == 0) {
+        int Kc = 0;
+        bool bad = false;
+        for (int j = 0; j < m; ++j) {
+            const int l = lab[j];
+            if (l >= 0) {
+                if (l >= m) { bad = true; break; }
+                if (nc[l] < 0) nc[l] = Kc++;      // nc doubles as the old -> new map here
+                lab[j] = nc[l];
+            }
+        }
+        s_scalar[0] = Kc; s_scalar[1] = bad ? 1 : 0;
+    }
+    wave_sync_lds();
+    const int Kc = s_scalar[0];
+    if (s_scalar[1] || Kc > HS_FIN_KCAP) { bail(); return; }
+
+    // ---- merge_close_clusters (cluster_graph.cpp:402-501) ----
+    if (lane < HS_FIN_KCAP) { s_initial[lane] = 0; s_votes[lane] = 0; s_tested[lane] = 0; }
+    wave_sync_lds();
+    for (int j = lane; j < m; j += 64) { const int l = lab[j]; if (l >= 0) atomicAdd(&s_initial[l], 1); nc[j] = l; }
+    wave_sync_lds();
+    for (int j = 0; j < m; ++j) {
+        const int target = lab[j];                      // uniform
+        if (target < 0 || s_tested[target]) continue;
+        if (lane < Kc) s_count[lane] = s_initial[lane];
+        wave_sync_lds();
+        int changes = 3, iters = 0;
+        while (changes > 0 && iters < 10) {
+            changes = 0;
+            for (int k0 = 0; k0 < n_visit; k0 += 64) {
+                const int kk = k0 + lane;
+                int i_l = 0, o0_l = 0, o1_l = 0;
+                if (kk < n_visit) { i_l = vis[kk]; o0_l = (int)(off_w[i_l] - abase); o1_l = (int)(off_w[i_l + 1] - abase); }
+                unsigned long long act = __ballot(kk < n_visit && nc[i_l] == target);
+                while (act) {
+                    const int l = __builtin_ctzll(act);
+                    act &= act - 1ull;
+                    const int i = __builtin_amdgcn_readlane(i_l, l);
+                    const int o0 = __builtin_amdgcn_readlane(o0_l, l), o1 = __builtin_amdgcn_readlane(o1_l, l);
+                    for (int o = o0 + lane; o < o1; o += 64) { const int lb = nc[anb[o]]; if (lb >= 0) atomicAdd(&s_votes[lb], 1); }
+                    wave_sync_lds();
+                    // largest and runner-up in ascending label order with strict '>' (:455-470): (count desc, label asc)
+                    const int v = lane < Kc ? s_votes[lane] : 0;
+                    const int key = v > 0 ? ((v << 8) | (255 - lane)) : 0;
+                    const int best = wave_max_i32(key);
+                    const int max_value = best >> 8, max_index = best ? 255 - (best & 255) : 0;
+                    const int best2 = wave_max_i32((best && lane == max_index) ? 0 : key);
+                    const int second_value = best2 >> 8, second_index = best2 ? 255 - (best2 & 255) : 0;
+                    wave_sync_lds();
+                    if (lane < Kc) s_votes[lane] = 0;
+                    if (max_value > 0 && max_index != target) {
+                        if (lane == 0) { s_count[target]--; s_count[max_index]++; nc[i] = max_index; }
+                        changes++;
+                    } else if (max_value > 0 && max_value <= 2 * second_value) {
+                        if (lane == 0) { s_count[target]--; s_count[second_index]++; nc[i] = second_index; }
+                        changes++;
+                    }
+                    wave_sync_lds();
+                }
+            }
+            iters++;
+        }
+        const bool dissolved = s_count[target] == 0;
+        wave_sync_lds();
+        if (lane == 0) s_tested[target] = 1;
+        if (dissolved) {
+            for (int q = lane; q < m; q += 64) lab[q] = nc[q];
+            if (lane < Kc) s_initial[lane] = s_count[lane];
+        } else {
+            for (int q = lane; q < m; q += 64) nc[q] = lab[q];
+        }
+        wave_sync_lds();
+    }
+
+    // ---- merge_wrongly_split_haplotypes (separate_reads.cpp:1007-1327) ----
+    if (lane < HS_FIN_KCAP) { s_index_of[lane] = -1; s_slot_of[lane] = -1; }
+    wave_sync_lds();
+    if (lane == 0) {
+        int index = 0;
+        for (int j = 0; j < m; ++j) { const int cl = lab[j]; if (cl > -1 && s_index_of[cl] < 0) s_index_of[cl] = index++; }
+        int G = 0;
+        for (int l = 0; l < Kc; ++l) if (s_index_of[l] >= 0) { if (G < HS_FIN_GCAP) { s_slot_of[l] = G; s_glist[G] = l; s_gidx[G] = s_index_of[l]; } G++; }
+        s_scalar[2] = G;
+    }
+    wave_sync_lds();
+    const int G = s_scalar[2];
+    if (G <= 1) {
+        for (int j = lane; j < m; j += 64) lout[j] = 0;
+        if (lane == 0) ok_out[c] = 1;
+        return;
+    }
+    if (G > HS_FIN_GCAP) { bail(); return; }
+    for (int x = lane; x < G * 256; x += 64) (&s_cnts[0][0])[x] = 0;
+    for (int x = lane; x < G * G; x += 64) { s_incompat[x] = 0; s_pos_last[x] = -10; }
+    wave_sync_lds();
+    const int pos_lo = win_pos_lo[c], pos_hi = win_pos_hi[c];
+    for (int64_t s = win_snp_first[c]; s < win_snp_last[c]; ++s) {
+        const int p = col_pos[s];
+        if (!(p >= pos_lo && p < pos_hi)) continue;
+        if (lane < G) { s_nb[lane] = 0; s_major[lane] = 0; }   // 0 == the operator[] default for clusters absent at this SNP
+        wave_sync_lds();
+        for (int64_t e = col_off[s] + lane; e < col_off[s + 1]; e += 64) {
+            const int j = local_index(ids, m, col_idx[e]);
+            const int cl = j >= 0 ? lab[j] : -2;
+            if (cl > -1) { const int slt = s_slot_of[cl]; atomicAdd(&s_cnts[slt][col_code[e]], 1); atomicAdd(&s_nb[slt], 1); }
+        }
+        wave_sync_lds();
+        for (int i = 0; i < G; ++i) {
+            // (largest count, runner-up count) of the cluster's bases; a tied maximum yields runner-up == maximum (:1090-1099)
+            int t1v = 0, c1 = -1, t2v = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int code = lane + 64 * q;
+                const int v = s_cnts[i][code];
+                if (v > t1v) { t2v = t1v; t1v = v; c1 = code; } else if (v > t2v) t2v = v;
+                s_cnts[i][code] = 0;
+            }
+            const int mx = wave_max_i32(t1v);
+            if (mx == 0) continue;                              // cluster absent at this SNP: majority stays 0
+            const int n_at = wave_sum_i32((t1v == mx ? 1 : 0) + (t2v == mx ? 1 : 0));
+            const int below = wave_max_i32(t1v == mx ? t2v : t1v);  // best count strictly below the maximum when it is unique
+            const int second_max = n_at >= 2 ? mx : below;
+            int max_base = wave_max_i32(t1v == mx ? c1 : -1);
+            if (second_max * 2 > mx || s_nb[i] * 0.5 > mx) max_base = ' ';
+            if (lane == 0) s_major[i] = max_base & 255;
+        }
+        wave_sync_lds();
+        int first_max = -1; bool several = false;
+        for (int i = 0; i < G; ++i) {
+            const int mb = s_major[i];
+            if (mb == 0 || mb == ' ') continue;
+            if (first_max < 0) first_max = mb; else if (mb != first_max) several = true;
+        }
+        // clusters absent at the SNP keep majority 0, which is not ' ': they take part in the comparison below (sic), but they
+        // do not count as a "max base" for the `several` test (:1100-1112 only inserts bases of clusters that carry reads)
+        if (several && lane < G * G) {
+            const int a = lane / G, b = lane % G;
+            const int ma = s_major[a], mb = s_major[b];
+            if (ma != ' ' && mb != ' ' && s_glist[a] > s_glist[b]) {
+                const int i1 = s_gidx[a], i2 = s_gidx[b];
+                if (ma != mb && p - s_pos_last[i1 * G + i2] > 10) {
+                    s_incompat[i1 * G + i2] += 1; s_incompat[i2 * G + i1] += 1;
+                    s_pos_last[i1 * G + i2] = p; s_pos_last[i2 * G + i1] = p;
+                }
+            }
+        }
+        wave_sync_lds();
+    }
+    // link ratios (:1189-1250): a dense (label + 2) x (label + 2) count matrix walked in ascending key order
+    const int M = Kc + 2;
+    for (int x = lane; x < M * M; x += 64) s_link_cnt[x] = 0;
+    if (lane < M) s_links_in[lane] = 0;
+    wave_sync_lds();
+    if (n_visit > 0) {   // (an empty finalize graph has no links)
+        for (int q = lane; q < m; q += 64) {
+            const int c2 = lab[q] + 2;
+            for (int64_t o = off_w[q]; o < off_w[q + 1]; ++o) {
+                const int c1 = lab[nbr[o]] + 2;
+                if (c1 != c2) atomicAdd(&s_link_cnt[c1 * M + c2], 1);
+                atomicAdd(&s_links_in[c1], 1);
+            }
+        }
+    }
+    wave_sync_lds();
+    if (lane == 0) {
+        int lc1[HS_FIN_LCAP], lc2[HS_FIN_LCAP];
+        double lr[HS_FIN_LCAP];
+        int nl = 0;
+        bool over = false;
+        for (int c1 = 0; c1 < M && !over; ++c1)
+            for (int c2 = 0; c2 < M; ++c2)
+                if (s_link_cnt[c1 * M + c2] > 0) {
+                    if (nl == HS_FIN_LCAP) { over = true; break; }
+                    lc1[nl] = c1 - 2; lc2[nl] = c2 - 2; lr[nl] = (double)s_link_cnt[c1 * M + c2] / s_links_in[c1]; nl++;
+                }
+        if (over) { s_scalar[3] = 1; }
+        else {
+            s_scalar[3] = 0;
+            // std::sort with `a.second > b.second` on <= 16 elements == libstdc++'s insertion sort (stl_algo.h __insertion_sort)
+            for (int i = 1; i < nl; ++i) {
+                const int a1 = lc1[i], a2 = lc2[i]; const double ar = lr[i];
+                int j = i;
+                while (j > 0 && ar > lr[j - 1]) { lc1[j] = lc1[j - 1]; lc2[j] = lc2[j - 1]; lr[j] = lr[j - 1]; --j; }
+                lc1[j] = a1; lc2[j] = a2; lr[j] = ar;
+            }
+            for (int x = 0; x < M; ++x) s_o2n[x] = 0;
+            for (int i = 0; i < G; ++i) s_o2n[s_glist[i] + 2] = s_glist[i];
+            s_o2n[1] = -1; s_o2n[0] = -2;
+            for (int q = 0; q < nl; ++q) {
+                if (!(lr[q] > 0.01)) continue;
+                const int c1 = lc1[q], c2 = lc2[q];
+                if (s_o2n[c1 + 2] == s_o2n[c2 + 2]) continue;
+                bool bad = false;
+                for (int i = 0; i < G; ++i) {
+                    if (s_o2n[s_glist[i] + 2] != s_o2n[c1 + 2]) continue;
+                    for (int k = 0; k < G; ++k)
+                        if (s_o2n[s_glist[k] + 2] == s_o2n[c2 + 2] && s_incompat[s_gidx[i] * G + s_gidx[k]] > 1) bad = true;
+                }
+                if (!bad) { const int to = s_o2n[c1 + 2], from = s_o2n[c2 + 2]; for (int k = 0; k < G; ++k) if (s_o2n[s_glist[k] + 2] == from) s_o2n[s_glist[k] + 2] = to; }
+            }
+            for (int x = 0; x < M; ++x) s_new_index[x] = -1;
+            int ni = 0;
+            for (int i = 0; i < G; ++i) { const int v = s_o2n[s_glist[i] + 2]; if (s_new_index[v + 2] < 0) s_new_index[v + 2] = ni++; }
+            for (int i = 0; i < G; ++i) s_o2n[s_glist[i] + 2] = s_new_index[s_o2n[s_glist[i] + 2] + 2];
+        }
+    }
+    wave_sync_lds();
+    if (s_scalar[3]) { bail(); return; }
+    for (int j = lane; j < m; j += 64) lout[j] = s_o2n[lab[j] + 2];
+    if (lane == 0) ok_out[c] = 1;
+}
+
+}  // namespace hsdev

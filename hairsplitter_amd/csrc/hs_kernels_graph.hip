@@ -250,11 +250,10 @@ __global__ __launch_bounds__(256) void k_scan_apply(const int32_t* __restrict__ 
     }
 }
 
-// neighbour lists in ascending read id (the window's mask list is ascending)
+// neighbour lists as window-local indices, ascending (= ascending read id: the window's mask list is ascending)
 __global__ __launch_bounds__(256) void k_read_graph_fill(const unsigned long long* __restrict__ bits, const int32_t* __restrict__ row_win,
                                                         const int64_t* __restrict__ win_mask_off, const int64_t* __restrict__ win_bits_off,
-                                                        const int32_t* __restrict__ mask_ids, const int64_t* __restrict__ nbr_off, int n_rows,
-                                                        int32_t* __restrict__ nbr) {
+                                                        const int64_t* __restrict__ nbr_off, int n_rows, int32_t* __restrict__ nbr) {
     const int row = (int)(blockIdx.x * 256 + threadIdx.x);
     if (row >= n_rows) return;
     const int w = row_win[row];
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(256) void k_read_graph_fill(const unsigned long lon
     int32_t* o = nbr + nbr_off[row];
     for (int k = 0; k < mw64; ++k) {
         unsigned long long x = p[k];
-        while (x) { const int b = __builtin_ctzll(x); x &= x - 1; *o++ = mask_ids[m0 + (k << 6) + b]; }
+        while (x) { const int b = __builtin_ctzll(x); x &= x - 1; *o++ = (k << 6) + b; }
     }
 }
 

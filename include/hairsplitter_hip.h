@@ -326,6 +326,12 @@ typedef struct hs_sr_result {
     float t_kernel_graph_ms;   /* hipEvent time of k_read_graph_rows */
     int64_t n_graph_rows_host; /* graph rows whose neighbour cut-off depended on std::sort's order of equal keys */
     int64_t n_windows_finished_on_host;   /* clustering windows whose cluster merging (K8) fell back to the host code */
+    /* counts behind the whole-path roofline of SURVEY.md 8(d): emitted by the kernels / the driver, not estimated */
+    int64_t n_cw_sweeps;       /* Chinese-Whispers sweeps, summed over every run */
+    int64_t cw_bytes;          /* sum over runs of sweeps * (4 * nnz + 8 * m), nnz / m = neighbour entries / nodes of the run's window graph */
+    int64_t graph_nnz;         /* neighbour entries of all window graphs */
+    int64_t n_graph_rows;      /* rows (window, masked read) of all window graphs */
+    int64_t simdiff_bytes;     /* sum over matrix-path contigs of N * S / 4 + 16 * N * N */
 } hs_sr_result;
 
 int hs_sr_run(const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
@@ -359,6 +365,7 @@ typedef struct hs_pipeline_stats {
     float t_kernel_sr_ms[4];            /* k_simdiff and the three k_chinese_whispers waves */
     float t_kernel_graph_ms;
     int64_t n_columns_extracted, n_columns_downloaded, n_columns_downloaded_late;   /* see hs_cv_result */
+    int64_t n_cw_sweeps, cw_bytes, graph_nnz, n_graph_rows, simdiff_bytes;          /* see hs_sr_result */
 } hs_pipeline_stats;
 int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out);
 int hs_pipeline_select(hs_pipeline* p, float* mean_distance /* [C] out */, hs_pipeline_stats* stats);

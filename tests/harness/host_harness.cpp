@@ -183,7 +183,9 @@ struct OracleCvOps : hs::CvDeviceOps {
 };
 
 struct OracleSrOps : hs::SrDeviceOps {
-    hs::CwGraphSet gs;
+    hs::SrWindowSet ws;
+    std::vector<int64_t> g_off;      // CSR over the rows of the window set, neighbours = local ids
+    std::vector<int32_t> g_nbr;
     std::vector<int32_t> sim, diff;
     uint32_t seed;
     explicit OracleSrOps(uint32_t s) : seed(s) {}
@@ -214,97 +216,112 @@ struct OracleSrOps : hs::SrDeviceOps {
         return 0;
     }
     std::vector<int64_t> sd_off; std::vector<int32_t> sd_n;
-    // K6 through the oracle's create_read_graph_matrix
-    int read_graphs(const hs::ReadGraphJob& job, hs::ReadGraphResult& res, float* k_ms) override {
+    int n_reads_of_contig(int c) const { return (int)((c + 1 < (int)ws.ctg_rank_off.size() ? ws.ctg_rank_off[(size_t)c + 1] : (int64_t)ws.rank.size()) - ws.ctg_rank_off[(size_t)c]); }
+    // K6 through the oracle's create_read_graph_matrix (N-space), stored in the windows' local index space
+    int build_graphs(const hs::SrWindowSet& w_in, int64_t* rows_on_host, float* k_ms) override {
         (void)k_ms;
-        res.nbr_off.assign(1, 0); res.nbr.clear(); res.rows_resolved_on_host = 0;
-        for (size_t w = 0; w < job.win_contig.size(); ++w) {
-            const int c = job.win_contig[w];
+        ws = w_in;
+        if (rows_on_host) *rows_on_host = 0;
+        g_off.assign(1, 0); g_nbr.clear();
+        for (int w = 0; w < ws.n_dev_windows; ++w) {
+            const int c = ws.win_contig[(size_t)w];
             const int N = sd_n[(size_t)c];
+            const int64_t m0 = ws.win_row0[(size_t)w], m1 = ws.win_row0[(size_t)w + 1];
             std::vector<bool> mask((size_t)N, false);
-            for (int64_t k = job.win_mask_off[w]; k < job.win_mask_off[w + 1]; ++k) mask[(size_t)job.mask_ids[(size_t)k]] = true;
+            std::vector<int> local((size_t)N, -1);
+            for (int64_t k = m0; k < m1; ++k) { mask[(size_t)ws.mask_ids[(size_t)k]] = true; local[(size_t)ws.mask_ids[(size_t)k]] = (int)(k - m0); }
             std::vector<int> S(sim.begin() + sd_off[(size_t)c], sim.begin() + sd_off[(size_t)c] + (size_t)N * N);
             std::vector<int> D(diff.begin() + sd_off[(size_t)c], diff.begin() + sd_off[(size_t)c] + (size_t)N * N);
             std::vector<std::vector<int>> adj;
-            hso::create_read_graph_matrix(mask, S, D, N, job.error_rate, adj);
-            for (int64_t k = job.win_mask_off[w]; k < job.win_mask_off[w + 1]; ++k) {
-                const std::vector<int>& a = adj[(size_t)job.mask_ids[(size_t)k]];
-                res.nbr.insert(res.nbr.end(), a.begin(), a.end());
-                res.nbr_off.push_back((int64_t)res.nbr.size());
+            hso::create_read_graph_matrix(mask, S, D, N, ws.error_rate, adj);
+            for (int r = 0; r < N; ++r) if (!mask[(size_t)r] && !adj[(size_t)r].empty()) { std::cerr << "harness: a read outside the mask has neighbours\n"; return 3; }
+            for (int64_t k = m0; k < m1; ++k) {
+                for (int nb : adj[(size_t)ws.mask_ids[(size_t)k]]) {
+                    if (local[(size_t)nb] < 0) { std::cerr << "harness: a neighbour outside the mask\n"; return 3; }
+                    g_nbr.push_back(local[(size_t)nb]);
+                }
+                g_off.push_back((int64_t)g_nbr.size());
             }
         }
+        const int64_t base = (int64_t)g_nbr.size();
+        for (size_t r = 1; r < ws.host_off.size(); ++r) g_off.push_back(base + ws.host_off[r]);
+        g_nbr.insert(g_nbr.end(), ws.host_nbr.begin(), ws.host_nbr.end());
+        if ((int64_t)g_off.size() != ws.rows() + 1) { std::cerr << "harness: rows of the window set do not add up\n"; return 3; }
         return 0;
     }
-    int set_graphs(const hs::CwGraphSet& g) override { gs = g; return 0; }
+    int fetch_graphs(std::vector<int64_t>& off, std::vector<int32_t>& nbr) override { off = g_off; nbr = g_nbr; return 0; }
 
-    std::vector<int> run_cw(int g, const std::vector<int>& init) {
-        const int N = gs.graph_n[(size_t)g];
+    // one run of the oracle's Chinese Whispers on window w: the local graph expanded to the contig's N reads, so that the
+    // visiting order is the oracle's own shuffle of 0..N-1 (the product's kernels work on the local nodes)
+    std::vector<int> run_cw(int w, const std::vector<int>& init_n, bool empty_graph) {
+        const int N = n_reads_of_contig(ws.win_contig[(size_t)w]);
+        const int64_t m0 = ws.win_row0[(size_t)w], m1 = ws.win_row0[(size_t)w + 1];
         std::vector<std::vector<int>> adj((size_t)N);
-        const int32_t* off = gs.adj_off.data() + gs.graph_off_base[(size_t)g];
-        const int32_t* nb = gs.adj.data() + gs.graph_adj_base[(size_t)g];
-        for (int r = 0; r < N; ++r) adj[(size_t)r].assign(nb + off[r], nb + off[r + 1]);
-        std::vector<bool> mask((size_t)N);
-        for (int r = 0; r < N; ++r) mask[(size_t)r] = gs.mask[(size_t)(gs.graph_off_base[(size_t)g] - g) + (size_t)r] != 0;
-        return hso::chinese_whispers(adj, init, mask, seed);
+        std::vector<bool> mask((size_t)N, false);
+        for (int64_t k = m0; k < m1; ++k) {
+            const int r = ws.mask_ids[(size_t)k];
+            mask[(size_t)r] = true;
+            if (!empty_graph) for (int64_t e = g_off[(size_t)k]; e < g_off[(size_t)k + 1]; ++e) adj[(size_t)r].push_back(ws.mask_ids[(size_t)(m0 + g_nbr[(size_t)e])]);
+        }
+        return hso::chinese_whispers(adj, init_n, mask, seed);
     }
-    const uint8_t* mask_of(int g) const { return gs.mask.data() + (size_t)(gs.graph_off_base[(size_t)g] - g); }
 
     // CPU statement of the device-resident chain (separate_reads.cpp:1674-1705, :840-885, :924-971)
     int cw_chain(const hs::CwChain& ch, std::vector<int32_t>& labels, std::vector<int32_t>& final_labels, std::vector<uint8_t>& final_ok,
-                 float k_ms[3]) override {
+                 float k_ms[3], hs::SrChainStats* stats) override {
         final_labels.clear(); final_ok.clear();   // the tail of finalize_clustering stays with the product's host code here
-        (void)k_ms;
-        const int W = (int)ch.win_n.size();
-        labels.assign((size_t)ch.win_label_base.back(), 0);
-        for (int w = 0; w < W; ++w) {
-            const int N = ch.win_n[(size_t)w];
-            const uint8_t* mask = mask_of(ch.win_graph_now[(size_t)w]);
+        (void)k_ms; (void)stats;
+        const int Wc = (int)ch.win.size();
+        labels.assign((size_t)ch.chain_row0.back(), 0);
+        for (int k = 0; k < Wc; ++k) {
+            const int w = ch.win[(size_t)k];
+            const int N = n_reads_of_contig(ws.win_contig[(size_t)w]);
+            const int64_t m0 = ws.win_row0[(size_t)w], m1 = ws.win_row0[(size_t)w + 1];
+            std::vector<bool> mask((size_t)N, false);
+            for (int64_t q = m0; q < m1; ++q) mask[(size_t)ws.mask_ids[(size_t)q]] = true;
+            const bool fe = ws.win_final_empty[(size_t)w] != 0;
             std::vector<std::vector<int>> local;
-            for (int64_t i = ch.win_seed_begin[(size_t)w]; i < ch.win_seed_begin[(size_t)w + 1]; ++i) {
+            for (int64_t i = ch.win_seed_begin[(size_t)k]; i < ch.win_seed_begin[(size_t)k + 1]; ++i) {
                 const int64_t s = ch.seed_col[(size_t)i];
                 std::vector<int> start((size_t)N);
                 for (int r = 0; r < N; ++r) start[(size_t)r] = r;
                 std::map<unsigned char, int> first;
                 for (int64_t e = ch.col_off[(size_t)s]; e < ch.col_off[(size_t)s + 1]; ++e) {
                     const int r = ch.col_idx[(size_t)e];
-                    if (!mask[r]) continue;
+                    if (!mask[(size_t)r]) continue;
                     if (!first.count(ch.col_code[(size_t)e])) first[ch.col_code[(size_t)e]] = r;
                     start[(size_t)r] = first[ch.col_code[(size_t)e]];
                 }
-                local.push_back(run_cw(ch.win_graph_now[(size_t)w], start));
+                local.push_back(run_cw(w, start, false));
             }
             // merge_clusterings :840-874
             std::vector<double> agg((size_t)N, 0.0);
             for (size_t i = 0; i < local.size(); ++i) for (int j = 0; j < N; ++j) agg[(size_t)j] += local[i][(size_t)j] * std::pow(2.0, (double)i);
             std::unordered_map<double, int> ids; std::vector<int> merged((size_t)N); int index = 0;
             for (int j = 0; j < N; ++j) { auto it = ids.find(agg[(size_t)j]); if (it == ids.end()) { ids[agg[(size_t)j]] = index; merged[(size_t)j] = index++; } else merged[(size_t)j] = it->second; }
-            for (int j = 0; j < N; ++j) if (!mask[j]) merged[(size_t)j] = -2;
-            std::vector<int> c2 = run_cw(ch.win_graph_final[(size_t)w], merged);
+            for (int j = 0; j < N; ++j) if (!mask[(size_t)j]) merged[(size_t)j] = -2;
+            std::vector<int> c2 = run_cw(w, merged, fe);
             // finalize_clustering :924-955
             std::map<int, int> sizes;
-            for (int r = 0; r < N; ++r) { if (!mask[r]) c2[(size_t)r] = -2; else sizes[c2[(size_t)r]] += 1; }
+            for (int r = 0; r < N; ++r) { if (!mask[(size_t)r]) c2[(size_t)r] = -2; else sizes[c2[(size_t)r]] += 1; }
             for (int r = 0; r < N; ++r) if (c2[(size_t)r] != -2 && sizes[c2[(size_t)r]] < 5) c2[(size_t)r] = -1;
             std::map<int, int> to_hap; int hap = 0;
             for (int r = 0; r < N; ++r) if (c2[(size_t)r] > -1) { if (!to_hap.count(c2[(size_t)r])) to_hap[c2[(size_t)r]] = hap++; c2[(size_t)r] = to_hap[c2[(size_t)r]]; }
-            std::vector<int> c3 = run_cw(ch.win_graph_final[(size_t)w], c2);
-            std::copy(c3.begin(), c3.end(), labels.begin() + ch.win_label_base[(size_t)w]);
+            std::vector<int> c3 = run_cw(w, c2, fe);
+            for (int64_t q = m0; q < m1; ++q) labels[(size_t)(ch.chain_row0[(size_t)k] + (q - m0))] = c3[(size_t)ws.mask_ids[(size_t)q]];
         }
         return 0;
     }
     int cw(hs::CwWave& wv, float* k_ms) override {
         (void)k_ms;
-        for (size_t i = 0; i < wv.inst_graph.size(); ++i) {
-            const int g = wv.inst_graph[i];
-            const int N = gs.graph_n[(size_t)g];
-            std::vector<std::vector<int>> adj((size_t)N);
-            const int32_t* off = gs.adj_off.data() + gs.graph_off_base[(size_t)g];
-            const int32_t* nb = gs.adj.data() + gs.graph_adj_base[(size_t)g];
-            for (int r = 0; r < N; ++r) adj[(size_t)r].assign(nb + off[r], nb + off[r + 1]);
-            std::vector<bool> mask((size_t)N);
-            for (int r = 0; r < N; ++r) mask[(size_t)r] = gs.mask[(size_t)(gs.graph_off_base[(size_t)g] - g) + (size_t)r] != 0;
-            std::vector<int> init(wv.labels.begin() + wv.inst_label_base[i], wv.labels.begin() + wv.inst_label_base[i] + N);
-            std::vector<int> res = hso::chinese_whispers(adj, init, mask, seed);
-            std::copy(res.begin(), res.end(), wv.labels.begin() + wv.inst_label_base[i]);
+        for (size_t i = 0; i < wv.inst_win.size(); ++i) {
+            const int w = wv.inst_win[i];
+            const int N = n_reads_of_contig(ws.win_contig[(size_t)w]);
+            const int64_t m0 = ws.win_row0[(size_t)w], m1 = ws.win_row0[(size_t)w + 1];
+            std::vector<int> init((size_t)N, -2);
+            for (int64_t q = m0; q < m1; ++q) init[(size_t)ws.mask_ids[(size_t)q]] = wv.labels[(size_t)(wv.inst_label_off[i] + (q - m0))];
+            std::vector<int> res = run_cw(w, init, ws.win_final_empty[(size_t)w] != 0);
+            for (int64_t q = m0; q < m1; ++q) wv.labels[(size_t)(wv.inst_label_off[i] + (q - m0))] = res[(size_t)ws.mask_ids[(size_t)q]];
         }
         return 0;
     }
