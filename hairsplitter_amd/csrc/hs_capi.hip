@@ -188,6 +188,58 @@ struct EventPair {
     int ms(float* out) { HS_HIP(hipEventSynchronize(b)); HS_HIP(hipEventElapsedTime(out, a, b)); return HS_OK; }
 };
 
+// Per-kernel accounting (include/hairsplitter_hip.h: hs_kernel_stats). A KernelClock belongs to one host thread / stream;
+// begin() / end() bracket a launch (or a short run of launches of one family) with events, flush() -- called once the stream
+// has been waited for -- turns them into durations and adds them to the process-wide table.
+struct KernelTable {
+    std::mutex mu;
+    hs_kernel_stats st;
+    KernelTable() { std::memset(&st, 0, sizeof st); }
+};
+KernelTable& kernel_table() { static KernelTable* t = new KernelTable(); return *t; }
+struct KernelClock {
+    struct Item { int k; hipEvent_t a, b; int64_t bytes; };
+    std::vector<Item> items;
+    hipEvent_t open_a = nullptr;
+    int open_k = -1;
+    int begin(int k, hipStream_t s) {
+        if (int rc = EventPair::get(&open_a)) return rc;
+        open_k = k;
+        HS_HIP(hipEventRecord(open_a, s));
+        return HS_OK;
+    }
+    int end(int64_t bytes, hipStream_t s) {
+        hipEvent_t b = nullptr;
+        if (int rc = EventPair::get(&b)) return rc;
+        HS_HIP(hipEventRecord(b, s));
+        items.push_back(Item{open_k, open_a, b, bytes});
+        open_a = nullptr; open_k = -1;
+        return HS_OK;
+    }
+    // for launches whose closing event is recorded by the callee: the item is queued, *b is recorded by the caller's callee
+    int end_prepare(int64_t bytes, hipEvent_t* b) {
+        if (int rc = EventPair::get(b)) return rc;
+        items.push_back(Item{open_k, open_a, *b, bytes});
+        open_a = nullptr; open_k = -1;
+        return HS_OK;
+    }
+    static void add_bytes(int k, int64_t bytes) { KernelTable& t = kernel_table(); std::lock_guard<std::mutex> g(t.mu); t.st.bytes[k] += bytes; }
+    void flush() {
+        if (items.empty()) return;
+        KernelTable& t = kernel_table();
+        std::lock_guard<std::mutex> g(t.mu);
+        for (Item& it : items) {
+            float ms = 0;
+            if (hipEventSynchronize(it.b) == hipSuccess && hipEventElapsedTime(&ms, it.a, it.b) == hipSuccess) {
+                t.st.ms[it.k] += ms; t.st.launches[it.k] += 1; t.st.bytes[it.k] += it.bytes;
+            } else (void)hipGetLastError();
+            EventPair::cache().push_back(it.a); EventPair::cache().push_back(it.b);
+        }
+        items.clear();
+    }
+    ~KernelClock() { flush(); if (open_a) EventPair::cache().push_back(open_a); }
+};
+
 // threads for the host-side passes of the C entry points that take no thread count: the CPU quota of the cgroup if there is
 // one, else the hardware concurrency, at most 32
 int host_threads() {
@@ -222,7 +274,15 @@ int require_device() {
 
 extern "C" {
 
-const char* hs_version(void) { return "hairsplitter_amd 0.1 (gfx950)"; }
+const char* hs_version(void) { return "hairsplitter_amd 0.2 (gfx950)"; }
+const char* hs_kernel_name(int k) {
+    static const char* names[HS_NKERNELS] = {"k_cigar_scan", "k_pileup_packed", "k_column_stats_tiled", "k_gather_columns_tiled", "k_column_top3", "k_pack_columns",
+                                             "k_column_partition_test", "k_snp_planes", "k_simdiff", "k_read_graph_rows", "k_read_graph_fill", "k_cw_visit_lists",
+                                             "k_cw_seeded_rows", "k_window_tail", "k_cw_local", "other"};
+    return k >= 0 && k < HS_NKERNELS ? names[k] : "?";
+}
+void hs_kernel_stats_reset(void) { KernelTable& t = kernel_table(); std::lock_guard<std::mutex> g(t.mu); std::memset(&t.st, 0, sizeof t.st); }
+void hs_kernel_stats_get(hs_kernel_stats* out) { if (!out) return; KernelTable& t = kernel_table(); std::lock_guard<std::mutex> g(t.mu); *out = t.st; }
 const char* hs_last_error(void) { return hs::g_err.c_str(); }
 int hs_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 int hs_warmup(void) {
@@ -465,11 +525,13 @@ int hs_tile_plan(const int64_t* h_contig_off, int32_t n_contigs, const int32_t* 
 // kernel so that its duration can be told apart from the two small selection kernels
 static int column_stats_tiled_launch(const uint8_t* d_pile, const int64_t* d_tile_off, const hs_tile_entry* d_tile_ent, int64_t total_len,
                                      hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth,
-                                     int32_t sel_cap, int32_t max_depth, SelectionScratch* sc, hipEvent_t after_main, hipStream_t stream) {
+                                     int32_t sel_cap, int32_t max_depth, SelectionScratch* sc, hipEvent_t after_main, hipStream_t stream,
+                                     hipEvent_t after_main2 = nullptr) {
     static_assert(sizeof(hs_tile_entry) == sizeof(int4), "hs_tile_entry is read as one 16-byte load");
     if (total_len <= 0) {   // nothing to count: an empty selection
         if (d_sel_count) HS_HIP(hipMemsetAsync(d_sel_count, 0, sizeof(int32_t), stream));
         if (after_main) HS_HIP(hipEventRecord(after_main, stream));
+        if (after_main2) HS_HIP(hipEventRecord(after_main2, stream));
         return HS_OK;
     }
     const int64_t grid = (total_len + 255) / 256;
@@ -483,6 +545,7 @@ static int column_stats_tiled_launch(const uint8_t* d_pile, const int64_t* d_til
                        d_sel_count ? sc->gpos.as<int64_t>() : nullptr, d_sel_count ? sc->depth.as<int32_t>() : nullptr, sel_cap);
     HS_HIP(hipGetLastError());
     if (after_main) HS_HIP(hipEventRecord(after_main, stream));
+    if (after_main2) HS_HIP(hipEventRecord(after_main2, stream));
     if (d_sel_count) return sc->finish(d_sel_count, d_sel_gpos, d_sel_depth, sel_cap, stream);
     return HS_OK;
 }
@@ -830,6 +893,7 @@ struct HipCvOps : hs::CvDeviceOps {
     hs_cv_batch* b;
     hipStream_t stream = nullptr;
     explicit HipCvOps(hs_cv_batch* batch) : b(batch) {}
+    KernelClock kc;
 
     int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, const int64_t** sel_gpos, const int32_t** sel_depth, size_t* n_sel_out,
                           float k_ms[4]) override {
@@ -843,23 +907,30 @@ struct HipCvOps : hs::CvDeviceOps {
         EventPair e0;
         if (int rc = e0.init()) return rc;
         HS_HIP(hipEventRecord(e0.a, stream));
+        if (int rc = kc.begin(HS_K_CIGAR_SCAN, stream)) return rc;
         if (int rc = cigar_scan_launch(b->d_contig_off.as<int64_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(),
                                        b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->rec_chunk_off.as<int64_t>(), b->n_rec,
                                        b->chunk_scratch.as<int32_t>(), b->rec_stats.as<int32_t>(), stream)) return rc;
+        if (int rc = kc.end((int64_t)b->cigar.bytes + (int64_t)b->chunk_scratch.bytes + 16 * (int64_t)b->n_rec, stream)) return rc;   // ops in, chunk table + counters out
         HS_HIP(hipEventRecord(e0.b, stream));
         HS_HIP(hipEventRecord(e1.a, stream));
+        if (int rc = kc.begin(HS_K_PILEUP, stream)) return rc;
         if (int rc = pileup_launch(b->contig_seq.as<uint8_t>(), b->d_contig_off.as<int64_t>(), b->read_seq.as<uint8_t>(), b->read_off.as<int64_t>(),
                                    b->rec_read.as<int32_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(), b->rec_strand.as<uint8_t>(),
                                    b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->d_pile_off.as<int64_t>(),
                                    b->rec_chunk_off.as<int64_t>(), b->chunk_scratch.as<int32_t>(), b->task_rec.as<int32_t>(), b->task_ev0.as<int32_t>(),
                                    b->n_tasks, b->ev_per_task, b->pile.as<uint8_t>(), b->rec_stats.as<int32_t>(), b->n_rec, stream)) return rc;
+        if (int rc = kc.end(2 * b->total_pile, stream)) return rc;      // one read base in + one code out per aligned bp
         HS_HIP(hipEventRecord(e1.b, stream));
         HS_HIP(hipEventRecord(e2.a, stream));
+        if (int rc = kc.begin(HS_K_COLUMN_STATS, stream)) return rc;
+        hipEvent_t k2_done = nullptr;
+        if (int rc = kc.end_prepare(b->total_pile, &k2_done)) return rc;   // one code in per aligned bp; recorded right after the histogram kernel
         if (b->sel_scratch.n_tiles == 0 && b->total_len > 0) { if (int rc = b->sel_scratch.prepare(b->total_len)) return rc; }
         if (int rc = column_stats_tiled_launch(b->pile.as<uint8_t>(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->total_len,
                                                nullptr, min_second, b->sel_count.as<int32_t>(), b->sel_gpos.as<int64_t>(),
                                                b->sel_depth.as<int32_t>(), (int32_t)std::min<int64_t>(b->total_len, 0x7fffffff), b->max_depth,
-                                               &b->sel_scratch, e2.b, stream)) return rc;
+                                               &b->sel_scratch, e2.b, stream, k2_done)) return rc;
         const double t1 = now();
         // downloads go through pooled pinned buffers: above a few hundred KB hipMemcpy into pageable memory pins the
         // destination on the fly, which costs tens of milliseconds
@@ -890,6 +961,7 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = e1.ms(&k_ms[0])) return rc;
         if (int rc = e2.ms(&k_ms[1])) return rc;
         if (int rc = e0.ms(&k_ms[3])) return rc;
+        kc.flush();
         if (tim) std::fprintf(stderr, "[hs timing]   pileup_and_select: launches %.2f ms, first D2H (waits for kernels) %.2f ms, selection D2H %.2f ms (%d positions), events %.2f ms\n",
                               t1 - t0, t2 - t1, t3 - t2, n_sel, now() - t3);
         return HS_OK;
@@ -898,6 +970,7 @@ struct HipCvOps : hs::CvDeviceOps {
     DBuf d_co, d_ci, d_cc;     // the extracted columns stay on the device for K4
     UploadPack gather_pack;
     int n_gathered = 0;
+    int64_t gathered_entries = 0;
     int column_partition_test(const hs::CvPartitionTest& t, std::vector<uint8_t>& keep, float* k_ms) override {
         const int n = (int)t.col_contig.size();
         if (n != n_gathered) { set_error("column_partition_test: column count differs from the last gather"); return HS_EINVAL; }
@@ -915,9 +988,11 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = d_keep.alloc((size_t)n)) return rc;
         EventPair e; if (int rc = e.init()) return rc;
         HS_HIP(hipEventRecord(e.a, stream));
+        if (int rc = kc.begin(HS_K_PARTITION_TEST, stream)) return rc;
         if (int rc = hs_column_partition_test(d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), d_ctg.as<int32_t>(), d_k0.as<uint8_t>(),
                                               d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), n, d_po.as<int32_t>(), d_pso.as<int64_t>(),
                                               d_ps.as<int8_t>(), d_keep.as<uint8_t>(), stream)) return rc;
+        if (int rc = kc.end(5 * gathered_entries + (int64_t)t.part_state.size(), stream)) return rc;   // the columns (idx + code) and the partition states
         HS_HIP(hipEventRecord(e.b, stream));
         keep.resize((size_t)n);
         if (n) {
@@ -925,6 +1000,7 @@ struct HipCvOps : hs::CvDeviceOps {
             if (int rc = copy_d2h(hk.p, d_keep.p, (size_t)n, stream)) return rc;
             std::memcpy(keep.data(), hk.p, (size_t)n);
         }
+        kc.flush();
         return e.ms(k_ms);
     }
     HBuf h_top;
@@ -934,7 +1010,7 @@ struct HipCvOps : hs::CvDeviceOps {
         const size_t total = (size_t)col_off.back();
         if (int rc = h_top.alloc((size_t)n_sel * sizeof(hs_coltop))) return rc;
         *top = (const hs_coltop*)h_top.p;
-        n_gathered = n_sel;
+        n_gathered = n_sel; gathered_entries = (int64_t)total;
         if (n_sel == 0) return HS_OK;
         DBuf d_sc, d_sp;
         gather_pack.add(sel_contig, d_sc);
@@ -945,15 +1021,20 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = d_cc.alloc(total)) return rc;
         EventPair e; if (int rc = e.init()) return rc;
         HS_HIP(hipEventRecord(e.a, stream));
+        if (int rc = kc.begin(HS_K_GATHER_COLUMNS, stream)) return rc;
         if (int rc = hs_gather_columns_tiled(b->pile.as<uint8_t>(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->tile_rec.as<int32_t>(),
                                              b->d_contig_off.as<int64_t>(), b->d_contig_rec_off.as<int32_t>(), d_sc.as<int32_t>(), d_sp.as<int32_t>(),
                                              d_co.as<int64_t>(), n_sel, d_ci.as<int32_t>(), d_cc.as<uint8_t>(), stream)) return rc;
+        if (int rc = kc.end(6 * (int64_t)total, stream)) return rc;     // per column entry: one pileup byte in, read index + code out
         DBuf d_top;
         if (int rc = d_top.alloc((size_t)n_sel * sizeof(hs_coltop))) return rc;
+        if (int rc = kc.begin(HS_K_COLUMN_TOP3, stream)) return rc;
         if (int rc = hs_column_top3(d_co.as<int64_t>(), d_cc.as<uint8_t>(), n_sel, d_top.as<hs_coltop>(), stream)) return rc;
+        if (int rc = kc.end((int64_t)total + 16 * (int64_t)n_sel, stream)) return rc;
         HS_HIP(hipEventRecord(e.b, stream));
         HS_HIP(hipMemcpyAsync(h_top.p, d_top.p, (size_t)n_sel * sizeof(hs_coltop), hipMemcpyDeviceToHost, stream));
         if (int rc_w = stream_wait(stream)) return rc_w;
+        kc.flush();
         return e.ms(k_ms);
     }
     HBuf h_fetch_idx[2], h_fetch_code[2];
@@ -972,11 +1053,15 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = pk.commit(stream)) return rc;
         if (int rc = d_pi.alloc(total * sizeof(int32_t))) return rc;
         if (int rc = d_pc.alloc(total)) return rc;
+        if (int rc = kc.begin(HS_K_PACK_COLUMNS, stream)) return rc;
         if (int rc = hs_pack_columns(d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), d_ids.as<int32_t>(), d_po.as<int64_t>(), (int32_t)cols.size(),
                                      d_pi.as<int32_t>(), d_pc.as<uint8_t>(), stream)) return rc;
+        if (int rc = kc.end(10 * (int64_t)total, stream)) return rc;
         HS_HIP(hipMemcpyAsync(h_fetch_idx[slot].p, d_pi.p, total * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         HS_HIP(hipMemcpyAsync(h_fetch_code[slot].p, d_pc.p, total, hipMemcpyDeviceToHost, stream));
-        return stream_wait(stream);
+        if (int rc = stream_wait(stream)) return rc;
+        kc.flush();
+        return HS_OK;
     }
 };
 
@@ -997,7 +1082,7 @@ struct GraphRows {
 };
 
 static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const std::vector<int64_t>& ctg_out_off, const std::vector<int32_t>& ctg_n,
-                            const hs::SrWindowSet& ws, GraphRows& G, hipStream_t stream, int64_t* rows_on_host, float* k_ms) {
+                            const hs::SrWindowSet& ws, GraphRows& G, hipStream_t stream, int64_t* rows_on_host, float* k_ms, KernelClock* kc = nullptr) {
     const int W = (int)ws.win_contig.size();
     G.W = W; G.rows = ws.rows(); G.total = 0; G.max_m = 1;
     if (rows_on_host) *rows_on_host = 0;
@@ -1055,10 +1140,16 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
         if ((size_t)cap * 8 > 57344) cap = 7168;
         const float below = 1 - ws.error_rate * 2;   // :778
         HS_HIP(hipEventRecord(ev.a, stream));
+        if (kc) { if (int rc = kc->begin(HS_K_GRAPH_ROWS, stream)) return rc; }
         hipLaunchKernelGGL(hsdev::k_read_graph_rows, dim3((rows_dev + waves - 1) / waves), dim3(64 * waves), (size_t)cap * 8 * waves, stream, d_sim, d_diff,
                            G.d_oo.as<int64_t>(), G.d_n.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_rw.as<int32_t>(),
                            G.d_bo.as<int64_t>(), rows_dev, below, cap, d_bits.as<unsigned long long>(), d_ac.as<int32_t>(), d_ar.as<int32_t>(), rows_dev);
         HS_HIP(hipGetLastError());
+        if (kc) {   // per row: the sim and diff entries of the window's m reads in, m link bits out
+            int64_t by = 0;
+            for (int w = 0; w < Wd; ++w) { const int64_t m = G.win_m[(size_t)w]; by += m * (8 * m + (m + 7) / 8); }
+            if (int rc = kc->end(by, stream)) return rc;
+        }
         HS_HIP(hipEventRecord(ev.b, stream));
         timed = true;
         int32_t n_amb = 0;
@@ -1122,9 +1213,11 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
             }
             if (rows_on_host) *rows_on_host = n_amb;
         }
+        if (kc) { if (int rc = kc->begin(HS_K_GRAPH_CSR, stream)) return rc; }
         hipLaunchKernelGGL(hsdev::k_read_graph_degrees, dim3((rows_dev + 255) / 256), dim3(256), 0, stream, d_bits.as<unsigned long long>(), G.d_rw.as<int32_t>(),
                            G.d_row0.as<int64_t>(), G.d_bo.as<int64_t>(), rows_dev, d_deg.as<int32_t>());
         HS_HIP(hipGetLastError());
+        if (kc) { if (int rc = kc->end((int64_t)win_bits_off.back() * 8 + 4 * (int64_t)rows_dev, stream)) return rc; }
     }
     HBuf h_deg;   // degrees of the rows the host brings
     if (rows > rows_dev) {
@@ -1142,9 +1235,11 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
     HBuf h_nbr;
     if (total > 0) {
         if (rows_dev > 0) {
+            if (kc) { if (int rc = kc->begin(HS_K_GRAPH_CSR, stream)) return rc; }
             hipLaunchKernelGGL(hsdev::k_read_graph_fill, dim3((rows_dev + 255) / 256), dim3(256), 0, stream, d_bits.as<unsigned long long>(), G.d_rw.as<int32_t>(),
                                G.d_row0.as<int64_t>(), G.d_bo.as<int64_t>(), G.d_off.as<int64_t>(), rows_dev, G.d_nbr.as<int32_t>());
             HS_HIP(hipGetLastError());
+            if (kc) { if (int rc = kc->end((int64_t)win_bits_off.back() * 8 + 4 * total, stream)) return rc; }
         }
         if (!ws.host_nbr.empty()) {   // the host rows sit behind the device rows: their lists start at total - |host_nbr|
             const size_t nb = ws.host_nbr.size() * 4;
@@ -1155,12 +1250,15 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
     }
     {   // visiting order of every window (hs_kernels_cw.hip)
         const int cap = std::min(((G.max_m + 63) / 64) * 64, 8192);
+        if (kc) { if (int rc = kc->begin(HS_K_VISIT_LISTS, stream)) return rc; }
         hipLaunchKernelGGL(hsdev::k_cw_visit_lists, dim3((unsigned)W), dim3(256), (size_t)cap * 4, stream, G.d_off.as<int64_t>(), G.d_row0.as<int64_t>(),
                            G.d_ids.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_rank_off.as<int64_t>(), G.d_rank.as<int32_t>(), W, cap, G.d_visit.as<int32_t>(),
                            G.d_visit_n.as<int32_t>());
         HS_HIP(hipGetLastError());
+        if (kc) { if (int rc = kc->end(20 * (int64_t)rows, stream)) return rc; }   // row offsets + read id + rank in, visiting slot out
     }
     if (int rc_w = stream_wait(stream)) return rc_w;     // the temporaries (bit matrices, degrees, staging) die with this scope
+    if (kc) kc->flush();
     if (timed) { float m = 0; if (int rc = ev.ms(&m)) return rc; if (k_ms) *k_ms += m; }
     return HS_OK;
 }
@@ -1171,6 +1269,7 @@ struct HipSrOps : hs::SrDeviceOps {
     std::vector<int64_t> sd_out_off;
     std::vector<int32_t> sd_n;
     GraphRows G;
+    KernelClock kc;
 
     // K5 runs on while the host plans the windows: its temporaries and its timing events are parked here until the next
     // call that waits for the stream anyway
@@ -1221,19 +1320,23 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = d_diff.alloc((size_t)job.out_total * sizeof(int32_t))) return rc;
         HS_HIP(hipMemsetAsync(f.d_alt.p, 0, pbytes ? pbytes : 8, stream));
         HS_HIP(hipMemsetAsync(f.d_ref.p, 0, pbytes ? pbytes : 8, stream));
+        if (int rc = kc.begin(HS_K_SNP_PLANES, stream)) return rc;
         if (int rc = hs_snp_planes(d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(), f.d_sr.as<uint8_t>(), f.d_sa.as<uint8_t>(),
                                    f.d_sc.as<int32_t>(), f.d_cb.as<int64_t>(), f.d_po.as<int64_t>(), f.d_w.as<int32_t>(), (int32_t)job.snp_ref.size(),
                                    f.d_alt.as<uint64_t>(), f.d_ref.as<uint64_t>(), stream)) return rc;
+        if (int rc = kc.end(5 * (int64_t)ch.col_idx.size() + 2 * (int64_t)pbytes, stream)) return rc;
         if (int rc = f.ev.init()) return rc;
         HS_HIP(hipEventRecord(f.ev.a, stream));
+        if (int rc = kc.begin(HS_K_SIMDIFF, stream)) return rc;
         if (int rc = simdiff_launch(f.d_alt.as<uint64_t>(), f.d_ref.as<uint64_t>(), f.d_po.as<int64_t>(), f.d_n.as<int32_t>(), f.d_w.as<int32_t>(),
                                     f.d_oo.as<int64_t>(), job.n_reads, d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, f.t_c, f.t_i, f.t_j)) return rc;
+        if (int rc = kc.end(2 * (int64_t)pbytes + 8 * job.out_total, stream)) return rc;   // the two bit-planes in, sim + diff out
         HS_HIP(hipEventRecord(f.ev.b, stream));
         return HS_OK;   // not waited for: the stream orders K6 behind it, the host goes on planning the windows
     }
 
     int build_graphs(const hs::SrWindowSet& ws, int64_t* rows_on_host, float* k_ms) override {
-        const int rc = graph_rows_build(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, ws, G, stream, rows_on_host, k_ms);
+        const int rc = graph_rows_build(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, ws, G, stream, rows_on_host, k_ms, &kc);
         const int rc2 = settle_simdiff();   // K6 came after K5 on the stream and has been waited for
         return rc ? rc : rc2;
     }
@@ -1305,13 +1408,14 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = d_l3.alloc(std::max<size_t>((size_t)total_m, 1) * 4)) return rc;
         if (int rc = d_final.alloc(std::max<size_t>((size_t)total_m, 1) * 4)) return rc;
         if (int rc = d_ok.alloc(std::max<size_t>((size_t)Wc, 1))) return rc;
-        if (int rc = d_stat.alloc(16)) return rc;
-        HS_HIP(hipMemsetAsync(d_stat.p, 0, 16, stream));
+        if (int rc = d_stat.alloc(32)) return rc;     // {sweeps, bytes} of the per-SNP runs, {sweeps, bytes} of the window tails
+        HS_HIP(hipMemsetAsync(d_stat.p, 0, 32, stream));
         EventPair e1, e2;
         if (int rc = e1.init()) return rc;
         if (int rc = e2.init()) return rc;
         // ---- per-SNP runs, seeded on the device from the SNP columns ----
         HS_HIP(hipEventRecord(e1.a, stream));
+        if (int rc = kc.begin(HS_K_CW_SEEDED, stream)) return rc;
         if (!list_small.empty()) {
             const int n = (int)list_small.size();
             hipLaunchKernelGGL(hsdev::k_cw_seeded_rows, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(),
@@ -1331,9 +1435,11 @@ struct HipSrOps : hs::SrDeviceOps {
                                d_col_code.as<uint8_t>(), cap_big, d_gs.as<int32_t>(), d_bs.as<int64_t>(), d_slab.as<int32_t>(), d_stat.as<unsigned long long>());
             HS_HIP(hipGetLastError());
         }
+        if (int rc = kc.end(4 * slab, stream)) return rc;      // + sweeps * (4 nnz + 8 m) per run, counted by the kernel itself (below)
         HS_HIP(hipEventRecord(e1.b, stream));
         // ---- the rest of the window's chain, labels in LDS from here to the finished clusters ----
         HS_HIP(hipEventRecord(e2.a, stream));
+        if (int rc = kc.begin(HS_K_WINDOW_TAIL, stream)) return rc;
         if (Wc > 0) {
             const size_t lds = (size_t)cap_tail * 7 * 4;
             if (lds > 32 * 1024)
@@ -1343,16 +1449,17 @@ struct HipSrOps : hs::SrDeviceOps {
                                d_csb.as<int64_t>(), d_cs0.as<int64_t>(), d_slab.as<int32_t>(), Wc, d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
                                d_col_code.as<uint8_t>(), d_cpos.as<int32_t>(), d_sf.as<int64_t>(), d_sl.as<int64_t>(), d_plo.as<int32_t>(), d_phi.as<int32_t>(),
                                finish ? 1 : 0, cap_tail, d_gs.as<int32_t>(), d_ts.as<int64_t>(), d_l3.as<int32_t>(), d_final.as<int32_t>(), d_ok.as<uint8_t>(),
-                               d_stat.as<unsigned long long>());
+                               d_stat.as<unsigned long long>() + 2);
             HS_HIP(hipGetLastError());
         }
+        if (int rc = kc.end(4 * slab + 8 * total_m, stream)) return rc;   // the runs' labels in, the two label arrays out (+ its two runs, below)
         HS_HIP(hipEventRecord(e2.b, stream));
         {
             // the finished labels and the per-window verdict come back first; the labels of the third run are only fetched
             // when some window has to be finished by the host code (few or none)
             HBuf h, h2, h3, h4;
-            if (int rc = h4.alloc(16)) return rc;
-            HS_HIP(hipMemcpyAsync(h4.p, d_stat.p, 16, hipMemcpyDeviceToHost, stream));
+            if (int rc = h4.alloc(32)) return rc;
+            HS_HIP(hipMemcpyAsync(h4.p, d_stat.p, 32, hipMemcpyDeviceToHost, stream));
             bool need_chain_labels = !finish;
             if (finish) {
                 if (int rc = h2.alloc(std::max<size_t>((size_t)total_m, 1) * sizeof(int32_t))) return rc;
@@ -1371,10 +1478,12 @@ struct HipSrOps : hs::SrDeviceOps {
                 if (int rc = copy_d2h(h.p, d_l3.p, (size_t)total_m * sizeof(int32_t), stream)) return rc;
                 std::memcpy(labels.data(), h.p, (size_t)total_m * sizeof(int32_t));
             } else labels.clear();
-            if (stats) {
-                const unsigned long long* st = (const unsigned long long*)h4.p;
-                stats->n_instances = n_inst + 2 * (int64_t)Wc; stats->sweeps = (int64_t)st[0]; stats->bytes = (int64_t)st[1]; stats->graph_nnz = G.total;
-            }
+            if (!finish && !need_chain_labels) { if (int rc = stream_wait(stream)) return rc; }
+            const unsigned long long* st = (const unsigned long long*)h4.p;
+            if (stats) { stats->n_instances = n_inst + 2 * (int64_t)Wc; stats->sweeps = (int64_t)(st[0] + st[2]); stats->bytes = (int64_t)(st[1] + st[3]); stats->graph_nnz = G.total; }
+            KernelClock::add_bytes(HS_K_CW_SEEDED, (int64_t)st[1]);
+            KernelClock::add_bytes(HS_K_WINDOW_TAIL, (int64_t)st[3]);
+            kc.flush();
         }
         float m = 0;
         if (int rc = e1.ms(&m)) return rc; k_ms[0] += m;
@@ -1397,6 +1506,7 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = d_gs.alloc(std::max<size_t>((size_t)scr_total, 2) * 4)) return rc;
         EventPair ev; if (int rc = ev.init()) return rc;
         HS_HIP(hipEventRecord(ev.a, stream));
+        if (int rc = kc.begin(HS_K_CW_LOCAL, stream)) return rc;
         const size_t lds = (size_t)cap * 8;
         if (lds > 48 * 1024)
             HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_cw_local), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1404,6 +1514,7 @@ struct HipSrOps : hs::SrDeviceOps {
                            G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), G.d_fe.as<uint8_t>(), d_iw.as<int32_t>(), d_lo.as<int64_t>(), n_inst, cap,
                            d_gs.as<int32_t>(), d_scr.as<int64_t>(), d_lab.as<int32_t>());
         HS_HIP(hipGetLastError());
+        if (int rc = kc.end(8 * (int64_t)wv.labels.size(), stream)) return rc;
         HS_HIP(hipEventRecord(ev.b, stream));
         if (int rc = d2h_pinned(wv.labels.data(), d_lab.p, wv.labels.size() * sizeof(int32_t), stream)) return rc;
         float m = 0; if (int rc = ev.ms(&m)) return rc;

@@ -58,6 +58,26 @@ int hs_event_record(void* ev, void* stream);
 int hs_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
 
 /* ------------------------------------------------------------------------------------------------
+ * Per-kernel accounting of everything the stage drivers launch (bench.py's roofline leg): every launch is bracketed by HIP
+ * events on the stream it runs on; the elapsed times, the number of launches and the ALGORITHMIC bytes of each launch
+ *  are accumulated per kernel family, process-wide, until hs_kernel_stats_reset().
+ * ---------------------------------------------------------------------------------------------- */
+#define HS_NKERNELS 16
+enum {
+    HS_K_CIGAR_SCAN = 0, HS_K_PILEUP, HS_K_COLUMN_STATS, HS_K_GATHER_COLUMNS, HS_K_COLUMN_TOP3, HS_K_PACK_COLUMNS, HS_K_PARTITION_TEST,
+    HS_K_SNP_PLANES, HS_K_SIMDIFF, HS_K_GRAPH_ROWS, HS_K_GRAPH_CSR, HS_K_VISIT_LISTS, HS_K_CW_SEEDED, HS_K_WINDOW_TAIL, HS_K_CW_LOCAL,
+    HS_K_OTHER
+};
+typedef struct hs_kernel_stats {
+    double ms[HS_NKERNELS];        /* sum of the launch durations (hipEventElapsedTime) */
+    int64_t launches[HS_NKERNELS];
+    int64_t bytes[HS_NKERNELS];    /* sum of the algorithmic bytes of the launches */
+} hs_kernel_stats;
+const char* hs_kernel_name(int k);          /* name of the (dominant) kernel of family k as rocprofv3 prints it */
+void hs_kernel_stats_reset(void);
+void hs_kernel_stats_get(hs_kernel_stats* out);
+
+/* ------------------------------------------------------------------------------------------------
  * K1 -- pileup.  Replaces generate_msa (call_variants.cpp:50-437) + convert_cigar (tools.cpp:27-57).
  * One wavefront per task (a range of alignment events of one record). Launches K0 (CIGAR scan: fills d_chunk_scratch with the
  * cursors at every 64-op chunk and flags the records that hold a clip between aligned bases), the packed pileup kernel (four

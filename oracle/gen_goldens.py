@@ -273,11 +273,47 @@ def gen_lib_vectors():
     # the .gro goldens. The libstdc++ permutations below come from the oracle binary (system library, not reference code).
 
 
+def gen_c5u():
+    """The uncut stress variant of BASELINE C5: the reference needs about 12 minutes for it (one contig = one
+    thread), so its OUTPUTS are stored (tests/golden_big/c5u, ~1.2 MB) and the inputs are regenerated from the seed by the
+    test (tests/test_gpu_full_configs.py::test_c5_uncut_10mb_equals_reference_outputs), checked by their sha256."""
+    import hashlib
+    import time
+    d = os.path.join(ROOT, "tests", "golden_big", "c5u")
+    os.makedirs(d, exist_ok=True)
+    with tempfile.TemporaryDirectory() as td:
+        files = synth.write_files(synth.config_contigs("C5U"), td)
+        t0 = time.time()
+        col, vcf, err, gro = (os.path.join(td, x) for x in ("variants.col", "variants.vcf", "error_rate.txt", "reads_haplo.gro"))
+        subprocess.run([os.path.join(REF, "HS_call_variants"), files["gfa"], files["reads"], files["sam"], "1", td, err, "0", "0", col, vcf, "0.33"],
+                       check=True, stdout=subprocess.DEVNULL)
+        t1 = time.time()
+        earg = py_error_rate_arg(err)
+        subprocess.run([os.path.join(REF, "HS_separate_reads_seeded"), col, "1", earg, os.path.join(td, "absent"), "0", "0.01", "0", gro, "0"],
+                       check=True, stdout=subprocess.DEVNULL)
+        t2 = time.time()
+        for p in (col, vcf, gro):
+            with open(p, "rb") as fi, gzip.GzipFile(os.path.join(d, os.path.basename(p) + ".gz"), "wb", mtime=0) as fo:
+                shutil.copyfileobj(fi, fo)
+        shutil.copyfile(err, os.path.join(d, "error_rate.txt"))
+        meta = {"case": "c5u", "error_rate_arg": earg, "n_snps": sum(1 for l in open(col) if l.startswith("SNPS")),
+                "n_groups": sum(1 for l in open(gro) if l.startswith("GROUP")),
+                "input_sha256": {os.path.basename(p): hashlib.sha256(open(p, "rb").read()).hexdigest() for p in files.values()},
+                "reference_wall_s": {"HS_call_variants": round(t1 - t0, 1), "HS_separate_reads_seeded": round(t2 - t1, 1)},
+                "generated_by": "python oracle/gen_goldens.py --c5u"}
+        with open(os.path.join(d, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+    print("c5u:", meta["n_snps"], "SNPs,", meta["n_groups"], "windows")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check-oracle", action="store_true", help="also run oracle/_build/hs_oracle and report parity")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--c5u", action="store_true", help="only the uncut 10 Mb variant of C5: outputs into tests/golden_big/c5u (12 minutes of the reference)")
     args = ap.parse_args()
+    if args.c5u:
+        return gen_c5u()
     os.makedirs(GOLD, exist_ok=True)
     if not args.only:
         gen_lib_vectors()

@@ -57,3 +57,38 @@ def test_c5_chunks_full_size_equals_reference(built):
     """C5 in its pipeline-faithful form: the 10 Mb contig cut in 34 chunks of <= 300 kb, diploid @0.1 %, 30x HiFi"""
     out = _check(built, "C5")
     assert out["contigs"] == 34 and out["aligned_bp"] > 2.9e8
+
+
+def test_c5_uncut_10mb_equals_reference_outputs(built):
+    """C5 uncut: ONE 10 Mb contig with 20 010 HiFi reads -- more reads than the former per-contig limit of the
+    Chinese-Whispers kernels. The reference takes 12 minutes for it (one contig = one thread), so its outputs are a stored
+    fixture (tests/golden_big/c5u, written by `oracle/gen_goldens.py --c5u`); the inputs are regenerated from the seed here
+    and checked by their sha256."""
+    import gzip
+    import hashlib
+    import shutil
+    from hairsplitter_amd import canon
+    gold = os.path.join(ROOT, "tests", "golden_big", "c5u")
+    meta = json.load(open(os.path.join(gold, "meta.json")))
+    with tempfile.TemporaryDirectory() as td:
+        f, bp, n, _ = fc.generate_files("C5U", td)
+        for k in ("gfa", "reads", "sam"):
+            name = os.path.basename(f[k])
+            assert hashlib.sha256(open(f[k], "rb").read()).hexdigest() == meta["input_sha256"][name], "regenerated input differs: " + name
+        a, wall = fc.run_pair(built["cv"], built["sr"], f, td, "hip", 16)
+        exp = {}
+        for name in ("variants.col", "variants.vcf", "reads_haplo.gro"):
+            exp[name] = os.path.join(td, "exp_" + name)
+            with gzip.open(os.path.join(gold, name + ".gz"), "rb") as fi, open(exp[name], "wb") as fo:
+                shutil.copyfileobj(fi, fo)
+        assert canon.split_blocks(a[0]) == canon.split_blocks(exp["variants.col"])
+        assert canon.vcf_blocks(a[1]) == canon.vcf_blocks(exp["variants.vcf"])
+        assert open(a[2]).read() == open(os.path.join(gold, "error_rate.txt")).read()
+        ga, gb = canon.split_blocks(a[3]), canon.split_blocks(exp["reads_haplo.gro"])
+        assert ga == gb, canon.diff_blocks(ga, gb)[:3]
+    try:
+        with open(os.path.join(ROOT, "gpurun_out", "parity_full_configs.jsonl"), "a") as fo:
+            fo.write(json.dumps({"config": "C5U", "aligned_bp": bp, "hip": wall, "identical_to_stored_reference_outputs": True,
+                                 "reference_wall_s": meta.get("reference_wall_s")}) + "\n")
+    except OSError:
+        pass
