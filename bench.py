@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- aligned read-bp/s through call_variants + separate_reads on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the whole hot path (stage 3 + stage 4, device kernels and host glue) over one batch of
-synthetic contigs whose inputs are already resident in HBM. Workload at any N: BASELINE.json configs[1] (C2:
-100 kb contig, 2 haplotypes @1 %, 50x ONT-error reads), `--contigs` independent contigs of that shape per GPU
-(weak scaling: per-GPU work is fixed as N grows; contigs are sharded by index over the ranks, the only
-collectives are the tiny error-rate exchange and ONE gather of the partition labels to rank 0 per step).
+One "step" = one pass of the whole hot path (stage 3 + stage 4, device kernels and host glue) over the job's synthetic
+contigs, inputs already resident in HBM. Default job = BASELINE.json configs[3] (C4): the 500-contig synthetic metagenome
+(lengths lognormal around 100 kb, ploidy 1-8, 30x ONT), the configuration the headline metric and the >= 20x target are
+quoted on; it fits one GPU (1.7 G aligned bp). `--config C2|C3|C5` select the other configurations (C2: `--contigs` copies
+of the 100 kb diploid contig). With N ranks the SAME job is sharded by contig (longest-processing-time on the contig
+lengths), one process per GPU: strong scaling. The only collectives are the per-contig error-rate exchange and ONE gather
+of the partition labels to rank 0 per step (RCCL).
 
 Launched by the driver as
     python bench.py --gpus 1 --steps K --warmup W
@@ -15,6 +17,8 @@ Rank 0 prints one JSON line.
 import argparse
 import json
 import os
+import shutil
+import statistics
 import subprocess
 import sys
 import tempfile
@@ -26,6 +30,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+SETUP_STEPS = 8         # untimed passes before the W warm-up steps: they size the block pools of the library and the runtime
+
+WORKLOADS = {
+    "C2": "C2 (BASELINE.json configs[1]): 100 kb contig, 2 haplotypes @1% divergence, 50x ONT-error reads; {n} such contigs",
+    "C3": "C3 (BASELINE.json configs[2]): {n} contigs x 200 kb, tetraploid (4 haplotypes @1%), 40x ONT-error reads",
+    "C4": "C4 (BASELINE.json configs[3]): {n}-contig synthetic metagenome, lengths lognormal(median 100 kb) in [20 kb, 300 kb], ploidy 1-8 @1%, 30x ONT-error reads",
+    "C5": "C5 (BASELINE.json configs[4], pipeline-faithful form): 10 Mb diploid @0.1%, 30x HiFi, cut in {n} chunks of <= 300 kb",
+}
 
 
 def effective_cores() -> int:
@@ -68,65 +80,71 @@ def throttle_stats():
     return None
 
 
-def thread_cpu():
-    """{tid: (comm, utime + stime in seconds)} of this process's threads"""
-    out = {}
-    tick = os.sysconf("SC_CLK_TCK")
-    for t in os.listdir("/proc/self/task"):
-        try:
-            st = open(f"/proc/self/task/{t}/stat").read()
-            comm = st[st.index("(") + 1:st.rindex(")")]
-            f = st[st.rindex(")") + 2:].split()
-            out[int(t)] = (comm, (int(f[11]) + int(f[12])) / tick)
-        except Exception:
-            pass
-    return out
+def run_stage_pair(cv, sr, files, td, tag, threads, env=None):
+    """The two executables as hairsplitter.py:668-669,725-726 runs them; returns (seconds stage 3, seconds stage 4)"""
+    col, vcf, err, gro = (os.path.join(td, f"{tag}.{x}") for x in ("col", "vcf", "err", "gro"))
+    t0 = time.perf_counter()
+    subprocess.run(cv + [files["gfa"], files["reads"], files["sam"], str(threads), td, err, "0", "0", col, vcf, "0.33"], check=True,
+                   stdout=subprocess.DEVNULL, env=env)
+    t1 = time.perf_counter()
+    e = py_error_rate(float(open(err).read().strip()))
+    subprocess.run(sr + [col, str(threads), str(e), os.path.join(td, "no_ploidy"), "0", "0.01", "0", gro, "0"], check=True,
+                   stdout=subprocess.DEVNULL, env=env)
+    t2 = time.perf_counter()
+    return t1 - t0, t2 - t1
 
 
-def cpu_baseline(n_contigs: int, seed: int):
-    """The compiled reference (oracle/_ref, built from /root/reference by oracle/Makefile) timed file-to-file on this
-    box's host cores on a bounded sample of the same workload. Falls back to the oracle restatement ("port")."""
+def file_to_file(cfg, n_job, sample_ids, job_files, seed, reps, reference_on_full_job):
+    """SURVEY.md 8(d) metric (ii): wall clock of the two drop-in executables next to the compiled reference (oracle/_ref,
+    built from /root/reference by oracle/Makefile) on the SAME files, `reps` runs each, median. The reference runs on a
+    bounded sample of the job (the first contigs of the configuration) so that the default bench stays within minutes; the
+    drop-ins additionally run on the files of the whole job. Also the `cpu_baseline` of the bench line."""
     from hairsplitter_amd import synth
     import __graft_entry__ as ge
     p = ge.paths()
     cores = effective_cores()
-    kind = "reference" if os.path.exists(p["ref_cv"]) and os.path.exists(p["ref_sr"]) else "port"
-    if kind == "port" and not os.path.exists(p["oracle"]):
-        return None
-    contigs = [synth.make_contig(seed, 10_000 + i, 100_000, 2, 0.01, 50, "ont") for i in range(n_contigs)]
-    bp = sum(c.aligned_bp for c in contigs)
+    have_ref = os.path.exists(p["ref_cv"]) and os.path.exists(p["ref_sr"])
+    if not have_ref and not os.path.exists(p["oracle"]):
+        return None, None
+    out = {"threads": cores, "runs": reps}
     with tempfile.TemporaryDirectory() as td:
-        f = synth.write_files(contigs, td)
-        col, vcf, err, gro = (os.path.join(td, x) for x in ("v.col", "v.vcf", "e.txt", "r.gro"))
-        if kind == "reference":
-            cv, sr, threads = [p["ref_cv"]], [p["ref_sr"]], cores
+        contigs, f = synth.generate_job(cfg, sample_ids, seed=seed, workers=min(8, cores), outdir=td)
+        bp = int(sum(c.aligned_bp for c in contigs))
+        del contigs
+        ours = [run_stage_pair([p["cv"]], [p["sr"]], f, td, "hip", cores) for _ in range(reps)]
+        if have_ref:
+            ref = [run_stage_pair([p["ref_cv"]], [p["ref_sr"]], f, td, "ref", cores) for _ in range(reps)]
+            kind, threads = "reference", cores
         else:
-            cv, sr, threads = [p["oracle"], "call_variants"], [p["oracle"], "separate_reads"], 1
-        t0 = time.perf_counter()
-        subprocess.run(cv + [f["gfa"], f["reads"], f["sam"], str(threads), td, err, "0", "0", col, vcf, "0.33"], check=True,
-                       stdout=subprocess.DEVNULL)
-        e = py_error_rate(float(open(err).read().strip()))
-        subprocess.run(sr + [col, str(threads), str(e), os.path.join(td, "no_ploidy"), "0", "0.01", "0", gro, "0"], check=True,
-                       stdout=subprocess.DEVNULL)
-        dt = time.perf_counter() - t0
-    return {"value": bp / dt, "unit": "aligned read-bp/s", "cores": threads if kind == "reference" else 1, "kind": kind,
-            "sample": f"{n_contigs} contigs of the C2 shape ({bp} aligned bp), stage 3+4 file-to-file, {dt:.2f} s wall"
-                      + (f", -t {threads}; contig-level OpenMP only" if kind == "reference" else ", single thread")}
-
-
-def _make_contig(a):
-    from hairsplitter_amd import synth
-    return synth.make_contig(a[0], a[1], 100_000, 2, 0.01, 50, "ont")
-
-
-def make_contigs(seed, ids, workers):
-    """The synthetic C2-shaped contigs `ids` (deterministic per (seed, id)); forked workers when there are many"""
-    jobs = [(seed, i) for i in ids]
-    if workers <= 1 or len(jobs) < 16 or os.environ.get("HS_BENCH_SERIAL_SETUP"):
-        return [_make_contig(j) for j in jobs]
-    import multiprocessing as mp
-    with mp.get_context("fork").Pool(workers) as pool:
-        return pool.map(_make_contig, jobs, chunksize=max(1, len(jobs) // (4 * workers)))
+            ref = [run_stage_pair([p["oracle"], "call_variants"], [p["oracle"], "separate_reads"], f, td, "ref", 1)]
+            kind, threads = "port", 1
+        med = lambda v: statistics.median(v)
+        o_t, r_t = med([a + b for a, b in ours]), med([a + b for a, b in ref])
+        out["sample"] = {"contigs": len(sample_ids), "aligned_bp": bp,
+                         "dropin_s": {"call_variants": med([a for a, _ in ours]), "separate_reads": med([b for _, b in ours]), "total": o_t},
+                         "reference_s": {"call_variants": med([a for a, _ in ref]), "separate_reads": med([b for _, b in ref]), "total": r_t},
+                         "speedup": r_t / o_t, "reference_kind": kind}
+        base = {"value": bp / r_t, "unit": "aligned read-bp/s", "cores": threads, "kind": kind,
+                "sample": f"the first {len(sample_ids)} of the {n_job} contigs of {cfg} ({bp} aligned bp), stage 3+4 file to file, median of {len(ref)} runs: {r_t:.2f} s wall"
+                          + (f", -t {threads} (contig-level OpenMP only)" if kind == "reference" else ", single thread")}
+    if job_files is not None:
+        with tempfile.TemporaryDirectory() as td:
+            env = dict(os.environ, HS_TIMING="1")
+            runs = []
+            for _ in range(reps):
+                runs.append(run_stage_pair([p["cv"]], [p["sr"]], job_files, td, "hip", cores))
+            o_t = statistics.median([a + b for a, b in runs])
+            out["job"] = {"contigs": n_job, "aligned_bp": job_files["aligned_bp"],
+                          "dropin_s": {"call_variants": statistics.median([a for a, _ in runs]), "separate_reads": statistics.median([b for _, b in runs]), "total": o_t},
+                          "dropin_bp_per_s": job_files["aligned_bp"] / o_t}
+            if reference_on_full_job and have_ref:
+                a, b = run_stage_pair([p["ref_cv"]], [p["ref_sr"]], job_files, td, "ref", cores)
+                out["job"]["reference_s"] = {"call_variants": a, "separate_reads": b, "total": a + b}
+                out["job"]["speedup"] = (a + b) / o_t
+            else:   # ~40 s per run on C4 with 16 threads: measured with --f2f-reference-full (profiles/), not in the default run
+                out["job"]["reference_s"] = None
+            del env
+    return out, base
 
 
 def main():
@@ -134,22 +152,37 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--contigs", type=int, default=256, help="C2-shaped contigs per GPU in one batch (256 ~ half of the 500-contig config; the step is a chain of short device calls and host sections per contig group, so small batches are latency-bound)")
+    ap.add_argument("--config", default="C4", choices=sorted(WORKLOADS))
+    ap.add_argument("--contigs", type=int, default=0, help="number of contigs of the configuration (0 = its own: C2 256, C3 50, C4 500, C5 34)")
     ap.add_argument("--groups", type=int, default=0, help="contig groups (host thread + HIP stream each) per GPU; 0 = min(8, host threads / 4)")
     ap.add_argument("--threads", type=int, default=0, help="host threads for the sequential glue (0 = all cores / ranks)")
-    ap.add_argument("--cpu-contigs", type=int, default=8, help="size of the CPU-baseline sample (0 disables)")
-    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--cpu-contigs", type=int, default=-1, help="contigs of the CPU-baseline / file-to-file sample (0 disables both; -1 = about 80 M aligned bp)")
+    ap.add_argument("--no-f2f-job", action="store_true", help="skip the file-to-file run of the drop-ins on the whole job")
+    ap.add_argument("--f2f-reference-full", action="store_true", help="also time the reference on the files of the whole job (C4: ~40 s per run)")
+    ap.add_argument("--f2f-runs", type=int, default=3)
+    ap.add_argument("--seed", type=int, default=None)
     args = ap.parse_args()
 
-    # ---- this rank's shard: contigs [rank*B, (rank+1)*B) of the job (weak scaling). Generated first, on a few forked
-    # workers, while this process has not touched the GPU (or loaded torch) yet ----
     rank_env, world_env = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    my_ids = list(range(rank_env * args.contigs, (rank_env + 1) * args.contigs))
-    contigs = make_contigs(args.seed, my_ids, max(1, min(8, effective_cores() // world_env)))
+    cfg = args.config
+    n_job = args.contigs or {"C2": 256, "C3": 50, "C4": 500, "C5": 34}[cfg]
+    from hairsplitter_amd import synth, dist as hdist
+    shapes = synth.config_shapes(cfg, seed=args.seed, count=n_job)
+    # ---- this rank's shard of the job: longest-processing-time over the contig lengths (depth is constant inside a
+    # configuration, so length ~ aligned bp; a scheduler knows the lengths from the assembly). Generated first, on forked
+    # workers, while this process has not touched the GPU (or loaded torch) yet; rank 0 of a single-GPU run also writes the
+    # job's three input files for the file-to-file leg ----
+    shards = hdist.lpt_shards([float(s[0] * s[2]) for s in shapes], world_env)
+    my_ids = shards[rank_env]
+    want_f2f = world_env == 1 and args.cpu_contigs != 0
+    job_dir = tempfile.mkdtemp(prefix="hs_bench_job_") if (want_f2f and not args.no_f2f_job) else None
+    t_gen = time.perf_counter()
+    contigs, job_files = synth.generate_job(cfg, my_ids, seed=args.seed, workers=max(1, min(8, effective_cores() // world_env)), outdir=job_dir)
+    t_gen = time.perf_counter() - t_gen
 
     import torch
     import torch.distributed as dist
-    from hairsplitter_amd import api, synth, dist as hdist
+    from hairsplitter_amd import api
     # PyTorch is only the allocator / collective layer here: keep its CPU thread pools out of the way of the host glue
     torch.set_num_threads(1)
     try:
@@ -167,7 +200,7 @@ def main():
     else:
         local_rank = 0
         torch.cuda.set_device(0)
-    # tiny host-side exchanges (error rate) go over gloo; RCCL is used for the one gather of labels per step
+    # tiny host-side exchanges (error rate, window size) go over gloo; RCCL is used for the one gather of labels per step
     cpu_group = dist.new_group(backend="gloo") if use_dist else None
     api.require_gpu()
     api.load().hs_set_device(local_rank)
@@ -175,10 +208,15 @@ def main():
     # box costs more than it buys (measured: 256 threads -> 15-60 ms steps, 64 threads -> 11.6 ms steps)
     n_threads = args.threads or max(1, min(64, (4 * effective_cores()) // world))
 
-    B = args.contigs
-    G = max(1, min(args.groups if args.groups > 0 else min(8, max(1, n_threads // 4)), B))
+    B = len(contigs)
+    G = max(1, min(args.groups if args.groups > 0 else min(8, max(1, n_threads // 4)), max(B, 1)))
     batch = api.PipelineGroups(contigs, G)   # inputs now resident in HBM; the streaming kernels run once per step over all of them
     local_bp = batch.aligned_bp
+    if job_files is not None:
+        job_files["aligned_bp"] = int(local_bp)
+    # window size of stage 4: chosen over the reads of the WHOLE job (separate_reads.cpp:1466-1498), i.e. across the ranks
+    window_size = hdist.global_window_size(batch.flat.rec_refspan, group=cpu_group) if use_dist else 0
+    contigs = None
 
     py_ms = {"pipeline_call": 0.0, "error_rate": 0.0, "gather": 0.0}
     no_coll = bool(os.environ.get("HS_BENCH_NO_COLLECTIVES"))   # diagnostic only
@@ -187,17 +225,15 @@ def main():
     def error_rate_fn(cv):
         # the one cross-contig quantity of the path: mean of the per-contig distances over the WHOLE job, in contig order
         t = time.perf_counter()
-        er = hdist.global_error_rate(my_ids, cv["mean_distance"], world * B, group=cpu_group) if not no_coll else float(cv["error_rate"])
+        er = hdist.global_error_rate(my_ids, cv["mean_distance"], n_job, group=cpu_group) if not no_coll else float(cv["error_rate"])
         py_ms["error_rate"] += (time.perf_counter() - t) * 1e3
         return py_error_rate(er)
 
     def step():
         t = time.perf_counter()
-        # window size 2000 for every rank when sharded: it depends on the read lengths of the whole job
-        # (separate_reads.cpp:1466-1498) and all shards of this workload have the same read-length distribution
-        cv, sr = batch.run(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=2000 if world > 1 else 0)
+        cv, sr = batch.run(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=window_size)
         t3 = time.perf_counter(); py_ms["pipeline_call"] += (t3 - t) * 1e3
-        if cap[0] is None:   # first (warm-up) step only: fix the size of the per-step collective, allocate its buffers
+        if cap[0] is None:   # first (set-up) step only: fix the size of the per-step collective, allocate its buffers
             cap[0] = hdist.LabelGatherer(hdist.gather_capacity(int(sr["labels"].size)))
         # the labels arrive on rank 0 (which would write the .gro); decoding them into arrays is the consumer's business
         gathered = cap[0].gather(sr["labels"], decode=False) if not no_coll else None
@@ -214,10 +250,10 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    # set-up, not measurement: a few passes that size the device / pinned block pools, the per-thread scratch and the HIP
-    # runtime's own pools (first use of every buffer size goes to hipMalloc / hipHostMalloc; the runtime stalls once for
-    # ~30 ms around the eighth pass of a process), then the W warm-up steps of the contract
-    for _ in range(8):
+    # set-up, not measurement (reported as setup_steps): a few passes that size the device / pinned block pools, the
+    # per-thread scratch and the HIP runtime's own pools (first use of every buffer size goes to hipMalloc / hipHostMalloc),
+    # then the W warm-up steps of the contract
+    for _ in range(SETUP_STEPS):
         step()
     sync()
     for _ in range(args.warmup):
@@ -225,11 +261,10 @@ def main():
     sync()
     for k in py_ms:
         py_ms[k] = 0.0
-    plain = bool(os.environ.get("HS_BENCH_PLAIN"))
-    thr0 = None if plain else throttle_stats()
-    tcpu0 = thread_cpu() if os.environ.get("HS_BENCH_THREADS") else None   # diagnostic: CPU time by thread over the timed steps
-    t0 = time.perf_counter(); cpu0 = 0.0 if plain else time.process_time()
-    k_cv = np.zeros(4); k_sr = np.zeros(4); t_dev = 0.0; t_host = 0.0; k4 = 0.0; k6 = 0.0
+    thr0 = throttle_stats()
+    api.kernel_stats_reset()
+    t0 = time.perf_counter(); cpu0 = time.process_time()
+    t_dev = 0.0; t_host = 0.0
     last = None
     step_ms = []
     wall = {}
@@ -239,22 +274,15 @@ def main():
         step_ms.append((time.perf_counter() - ts) * 1e3)
         for kk, vv in sr.get("wall_ms", {}).items():
             wall[kk] = wall.get(kk, 0.0) + vv
-        if os.environ.get("HS_BENCH_OUTLIERS") and step_ms[-1] > 15:
-            sys.stderr.write(f"outlier step {len(step_ms)}: {step_ms[-1]:.1f} ms {sr.get('wall_ms')}\n")
-        k_cv += np.asarray(cv["t_kernel_ms"]); k_sr += np.asarray(sr["t_kernel_ms"]); k4 += cv.get("t_kernel_k4_ms", 0.0); k6 += sr.get("t_kernel_graph_ms", 0.0)
         t_dev += cv["t_device_ms"] + sr["t_device_ms"]; t_host += cv["t_host_ms"] + sr["t_host_ms"]
-        last = ({"n_snps": cv["n_snps"]}, {"n_cw_instances": sr["n_cw_instances"]})
+        last = {k: sr[k] for k in ("n_cw_instances", "n_cw_sweeps", "cw_bytes", "graph_nnz", "n_graph_rows", "simdiff_bytes", "n_graph_rows_host",
+                                   "n_windows_finished_on_host")}
+        last["n_snps"] = cv["n_snps"]; last["n_windows"] = int(sr["win_off"][-1])
         cv = sr = gathered = None   # no references to the step's arrays: they die here, as in the warm-up
     sync()
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3
-    if tcpu0 is not None:
-        tcpu1 = thread_cpu()
-        rows = sorted(((tcpu1[t][1] - tcpu0.get(t, (None, 0.0))[1], tcpu1[t][0], t) for t in tcpu1), reverse=True)
-        tot = sum(r[0] for r in rows)
-        sys.stderr.write(f"thread CPU over {args.steps} steps: {tot * 1e3 / args.steps:.1f} ms/step in {len(rows)} threads\n")
-        for d, comm, t in rows[:40]:
-            sys.stderr.write(f"  tid {t} {comm:16s} {d * 1e3 / args.steps:8.2f} ms/step\n")
+    kstats = api.kernel_stats()
     thr1 = throttle_stats()
     throttled = None if thr0 is None or thr1 is None else {"periods": thr1[0] - thr0[0], "usec": thr1[1] - thr0[1]}
     if use_dist:
@@ -267,63 +295,78 @@ def main():
     else:
         total_bp = local_bp
 
-    if rank == 0 and os.environ.get("HS_BENCH_THREAD_CPU"):   # diagnostic: CPU seconds per thread of this process
-        rows = []
-        for t in os.listdir("/proc/self/task"):
-            try:
-                f = open(f"/proc/self/task/{t}/stat").read()
-                comm = f[f.index("(") + 1:f.rindex(")")]
-                rest = f[f.rindex(")") + 2:].split()
-                rows.append(((int(rest[11]) + int(rest[12])) / os.sysconf("SC_CLK_TCK"), comm, t))
-            except Exception:
-                pass
-        rows.sort(reverse=True)
-        sys.stderr.write("thread cpu_s: " + ", ".join(f"{c}:{u:.2f}" for u, c, t in rows[:30]) + f" (threads={len(rows)})\n")
     if rank == 0:
         K = args.steps
-        cv, sr = last
-        kernels = {"k_cigar_scan": k_cv[3] / K, "k_pileup": k_cv[0] / K, "k_column_stats": k_cv[1] / K, "k_gather_columns": k_cv[2] / K, "k_column_partition_test": k4 / K,
-                   "k_simdiff": k_sr[0] / K, "k_read_graph_rows": k6 / K, "k_chinese_whispers": (k_sr[1] + k_sr[2] + k_sr[3]) / K}
-        # algorithmic bytes per launch: pileup = read base in + code out = 2 B / aligned bp;
-        # column_stats = 1 B / aligned bp in + 16 B / position out; chinese_whispers: see DESIGN.md
-        alg_bytes = {"k_pileup": 2.0 * local_bp, "k_column_stats": 1.0 * local_bp + 16.0 * float(batch.total_len)}
-        dom = max(("k_pileup", "k_column_stats"), key=lambda k: kernels[k])
-        achieved = alg_bytes[dom] / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
+        # ---- roofline of the kernel family with the largest time per step (all kernels of the path compete) ----
+        per_step = {k: {"ms_per_step": v["ms"] / K, "launches_per_step": v["launches"] / K, "avg_launch_ms": v["ms"] / max(1, v["launches"]),
+                        "algorithmic_bytes_per_launch": v["bytes"] / max(1, v["launches"]),
+                        "achieved_GBs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else 0.0} for k, v in kstats.items()}
+        dom = max(per_step, key=lambda k: per_step[k]["ms_per_step"])
+        d = per_step[dom]
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                traffic = tj.get(dom)
-                if traffic is not None and tj.get("_aligned_bp"):
-                    traffic = traffic * local_bp / float(tj["_aligned_bp"])   # measured on a 16-contig batch; streaming kernels scale with bp
+                if tj.get("_config") == cfg and tj.get("_contigs") == n_job and world == 1:
+                    traffic = tj.get(dom)      # HBM bytes per launch from the PMC passes at THIS size (tools/pmc.sh)
             except Exception:
                 traffic = None
+        # ---- whole path by SURVEY.md 8(d)'s formula with the counts the run itself emitted ----
+        t_kernels_ms = sum(v["ms_per_step"] for v in per_step.values())
+        whole_bytes = 4.0 * local_bp + float(last["simdiff_bytes"]) + float(last["cw_bytes"])
+        whole = {"formula": "4 B x aligned bp + sum_contigs(N*S/4 + 16*N^2) + sum_CW-runs sweeps*(4*nnz + 8*m)",
+                 "bytes_per_step": whole_bytes, "terms": {"4_bytes_per_aligned_bp": 4.0 * local_bp, "simdiff": float(last["simdiff_bytes"]), "chinese_whispers": float(last["cw_bytes"])},
+                 "counts": {"aligned_bp": int(local_bp), "cw_runs": int(last["n_cw_instances"]), "cw_sweeps": int(last["n_cw_sweeps"]), "graph_nnz": int(last["graph_nnz"]),
+                            "graph_rows": int(last["n_graph_rows"]), "windows": int(last["n_windows"]), "snps": int(last["n_snps"])},
+                 "sum_of_kernel_ms_per_step": t_kernels_ms,
+                 "frac_vs_kernel_time": whole_bytes / (t_kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if t_kernels_ms > 0 else None,
+                 "frac_vs_step_time": whole_bytes / (dt / K) / 1e9 / HBM_PEAK_GBS,
+                 "note": "rank 0's shard; m = masked reads of the window (the kernels work in the window's local index space), not the N reads of the contig"}
         out = {
             "metric": "aligned read-bp/sec through call_variants+separate_reads",
-            "value": total_bp * K / dt, "unit": "aligned read-bp/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "value": total_bp * K / dt, "unit": "aligned read-bp/s", "n_gpus": world, "steps": K, "warmup": args.warmup, "setup_steps": SETUP_STEPS,
+            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "host": {"cpus_online": os.cpu_count(), "cpus_effective": effective_cores(), "process_cpu_ms_per_step": cpu_ms_per_step,
-                     "cfs_throttled_during_timed_steps": throttled},
-            "config": {"workload": f"C2 (BASELINE.json configs[1]): 100 kb contig, 2 haplotypes @1% divergence, 50x ONT-error reads; "
-                                   f"{B} such contigs per GPU per step, inputs resident in HBM",
-                       "contigs_per_gpu": B, "aligned_bp_per_gpu": local_bp, "parallelism": f"contig-sharded x{world}", "groups_per_gpu": G,
-                       "host_threads_per_rank": n_threads, "snps_rank0": int(cv["n_snps"]), "cw_instances_rank0": sr["n_cw_instances"]},
-            "roofline": {"bound": "hbm", "kernel": ("k_pileup_packed" if dom == "k_pileup" and not os.environ.get("HS_K1_PER_EVENT") else dom), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": kernels[dom],
-                         "algorithmic_bytes_per_launch": alg_bytes[dom]},
-            "kernel_ms_per_step": kernels, "step_ms": [round(x, 2) for x in step_ms],
+                     "cfs_throttled_during_timed_steps": throttled, "input_generation_s": t_gen},
+            "config": {"workload": WORKLOADS[cfg].format(n=n_job) + "; the whole job per step, inputs resident in HBM",
+                       "config": cfg, "contigs": n_job, "aligned_bp": total_bp, "contigs_rank0": B, "aligned_bp_rank0": int(local_bp),
+                       "parallelism": f"contigs sharded over {world} GPU(s) by LPT on contig length", "groups_per_gpu": G,
+                       "host_threads_per_rank": n_threads},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": d["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": d["avg_launch_ms"],
+                         "launches_per_step": d["launches_per_step"], "ms_per_step": d["ms_per_step"],
+                         "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                         "selection": "largest summed launch time per step among all kernels of the path (HIP events on each launch stream)",
+                         "whole_path": whole},
+            "kernels": {k: {kk: (round(vv, 6) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+            "step_ms": [round(x, 2) for x in step_ms],
             "pipeline_wall_ms_per_step": {k: v / K for k, v in wall.items()},
-            "phase_ms_per_step": {"device_phases": t_dev / K, "host_glue": t_host / K, **{"py_" + k: v / K for k, v in py_ms.items()}},
+            "phase_ms_per_step": {"device_phases_summed_over_groups": t_dev / K, "host_glue_summed_over_groups": t_host / K, **{"py_" + k: v / K for k, v in py_ms.items()}},
         }
-        if world == 1 and args.cpu_contigs > 0:
+        batch.close()
+        batch = None
+        if want_f2f:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_contigs, args.seed)
+                if args.cpu_contigs > 0:
+                    n_s = min(args.cpu_contigs, n_job)
+                else:   # about 80 M aligned bp: ~2-4 s of the reference on 16 cores
+                    n_s, acc = 0, 0.0
+                    while n_s < n_job and acc < 80e6:
+                        acc += shapes[n_s][0] * shapes[n_s][2]; n_s += 1
+                    n_s = max(n_s, min(n_job, effective_cores()))
+                f2f, base = file_to_file(cfg, n_job, list(range(n_s)), job_files, args.seed, max(1, args.f2f_runs), args.f2f_reference_full)
+                if f2f is not None:
+                    out["file_to_file"] = f2f
+                    out["cpu_baseline"] = base
             except Exception as e:  # the baseline is informational; never fail the bench on it
-                out["cpu_baseline"] = {"error": str(e)}
+                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    batch.close()
+    if batch is not None:
+        batch.close()
+    if job_dir is not None:
+        shutil.rmtree(job_dir, ignore_errors=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

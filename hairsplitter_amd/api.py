@@ -22,8 +22,10 @@ SYMBOLS = [
     "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
-    "hs_separate_reads_main",
+    "hs_separate_reads_main", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get",
 ]
+
+HS_NKERNELS = 16
 
 
 class HsError(RuntimeError):
@@ -38,6 +40,10 @@ class CvResult(C.Structure):
                 ("col_code", C.POINTER(C.c_uint8)), ("error_rate", C.c_float), ("n_contigs_with_error_rate", C.c_int32),
                 ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("t_kernel_ms", C.c_float * 4), ("t_kernel_k4_ms", C.c_float),
                 ("n_columns_extracted", C.c_int64), ("n_columns_downloaded", C.c_int64), ("n_columns_downloaded_late", C.c_int64)]
+
+
+class KernelStats(C.Structure):
+    _fields_ = [("ms", C.c_double * HS_NKERNELS), ("launches", C.c_int64 * HS_NKERNELS), ("bytes", C.c_int64 * HS_NKERNELS)]
 
 
 class SrContig(C.Structure):
@@ -101,8 +107,30 @@ def load() -> C.CDLL:
     lib.hs_event_elapsed_ms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     lib.hs_event_record.argtypes = [C.c_void_p, C.c_void_p]
     lib.hs_event_destroy.argtypes = [C.c_void_p]
+    lib.hs_kernel_name.restype = C.c_char_p
+    lib.hs_kernel_name.argtypes = [C.c_int]
+    lib.hs_kernel_stats_reset.restype = None
+    lib.hs_kernel_stats_get.restype = None
+    lib.hs_kernel_stats_get.argtypes = [C.POINTER(KernelStats)]
     _lib = lib
     return lib
+
+
+def kernel_stats_reset():
+    load().hs_kernel_stats_reset()
+
+
+def kernel_stats():
+    """{kernel name: {"ms": summed launch durations (HIP events on the launch stream), "launches": n, "bytes": summed algorithmic bytes}}
+    of everything the stage drivers launched since kernel_stats_reset()"""
+    lib = load()
+    st = KernelStats()
+    lib.hs_kernel_stats_get(C.byref(st))
+    out = {}
+    for k in range(HS_NKERNELS):
+        if st.launches[k]:
+            out[lib.hs_kernel_name(k).decode()] = {"ms": float(st.ms[k]), "launches": int(st.launches[k]), "bytes": int(st.bytes[k])}
+    return out
 
 
 def _check(rc: int):

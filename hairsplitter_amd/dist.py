@@ -41,6 +41,37 @@ def global_error_rate(local_ids: Sequence[int], local_mean_distance: np.ndarray,
     return mean_of_positive_f32(full.numpy())
 
 
+def global_window_size(local_rec_refspan: np.ndarray, amplicon: bool = False, longest_contig: int = 0, group=None) -> int:
+    """choose_window_size over the WHOLE job (separate_reads.cpp:1466-1498): it looks at every read of every contig, so the
+    ranks exchange (sum of lengths, reads, reads above 4 kb [, longest contig]) -- one tiny all-reduce, once per job. READ
+    limits are (POS-1, POS + reference span) (input_output.cpp:503-511); the reference's `int sumLength` wraps."""
+    import torch
+    import torch.distributed as dist
+    lens = np.asarray(local_rec_refspan, dtype=np.int64) + 2
+    v = torch.tensor([int(lens.sum()), int(lens.size), int((lens > 4000).sum())], dtype=torch.int64)
+    mx = torch.tensor([int(longest_contig)], dtype=torch.int64)
+    if dist.is_available() and dist.is_initialized():
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        v = v.to(dev); mx = mx.to(dev)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+        v = v.cpu(); mx = mx.cpu()
+    if amplicon:
+        return int(mx.item())
+    total, n, above = int(v[0]), int(v[1]), int(v[2])
+    if n == 0:
+        return 2000
+    total &= 0xFFFFFFFF
+    if total >= 1 << 31:
+        total -= 1 << 32
+    mean = total / float(n)
+    if above < 20 and 2000 < mean < 4000:
+        return 1000
+    if above < 20 and mean < 2000:
+        return 500
+    return 2000
+
+
 def mean_of_positive_f32(values) -> float:
     """call_variants.cpp:1312-1315,1377: float32 running sum of the positive entries in index order / their count.
     np.cumsum accumulates left to right in the array's dtype, i.e. exactly that running sum."""
@@ -120,18 +151,27 @@ class LabelGatherer:
         self.np16 = self.host16.numpy()
         self.dev_buf = torch.empty((self.capacity + 2) * 2, dtype=torch.uint8, device=self.dev)
         self.out = [torch.empty_like(self.dev_buf) for _ in range(self.world)] if self.rank == dst else None
+        self.copied = torch.cuda.Event() if self.dev == "cuda" else None   # the staging buffer is rewritten by the next step
 
     def gather(self, labels: np.ndarray, decode: bool = True):
         """Returns the per-rank label arrays on `dst` (raw device byte buffers if decode=False), None elsewhere."""
         import torch.distributed as dist
         if not self.active:
             return [labels]
+        import torch
         n = int(labels.size)
         assert n <= self.capacity
+        if n != getattr(self, "checked_n", None):    # int16 on the wire: checked on the first gather and whenever the job changes
+            assert n == 0 or (int(labels.min()) >= -2 and int(labels.max()) < 32767)
+            self.checked_n = n
+        if self.copied is not None:
+            self.copied.synchronize()      # the previous step's host-to-device copy has read the staging buffer
         self.np16[0] = n & 0x7fff
         self.np16[1] = n >> 15
         np.copyto(self.np16[2:2 + n], labels, casting="unsafe")      # labels are -2, -1 or a group id < 32767
-        self.dev_buf.copy_(self.host16.view(dtype=__import__("torch").uint8), non_blocking=True)
+        self.dev_buf.copy_(self.host16.view(dtype=torch.uint8), non_blocking=True)
+        if self.copied is not None:
+            self.copied.record()
         dist.gather(self.dev_buf, self.out, dst=self.dst, group=self.group)
         if self.rank != self.dst:
             return None

@@ -192,7 +192,8 @@ def cigar_string(cigar: np.ndarray) -> str:
 
 
 def write_files(contigs: Sequence[ContigData], outdir: str, prefix: str = "",
-                sam_extra: Optional[List[str]] = None, gfa_extra: Optional[List[str]] = None, fastq: bool = False) -> dict:
+                sam_extra: Optional[List[str]] = None, gfa_extra: Optional[List[str]] = None, fastq: bool = False,
+                sam_header: bool = True) -> dict:
     """Writes assembly.gfa / reads.fasta / aln.sam. Returns the paths. `sam_extra` / `gfa_extra`: verbatim lines appended
     to the SAM / the GFA (e.g. supplementary records, 'L' lines)."""
     os.makedirs(outdir, exist_ok=True)
@@ -214,9 +215,10 @@ def write_files(contigs: Sequence[ContigData], outdir: str, prefix: str = "",
                 else:
                     f.write(f">{nm}\n{_ACGT[r].tobytes().decode()}\n")
     with open(sam, "w") as s:
-        s.write("@HD\tVN:1.6\tSO:unsorted\n")
-        for c in contigs:
-            s.write(f"@SQ\tSN:{c.name}\tLN:{len(c.seq)}\n")
+        if sam_header:
+            s.write("@HD\tVN:1.6\tSO:unsorted\n")
+            for c in contigs:
+                s.write(f"@SQ\tSN:{c.name}\tLN:{len(c.seq)}\n")
         for c in contigs:
             for a in c.alns:
                 flag = 0 if a.strand else 16
@@ -285,3 +287,71 @@ def config_contigs_parallel(cfg: str, seed: Optional[int] = None, count: Optiona
     with mp.get_context("fork").Pool(workers) as pool:
         parts = pool.map(_config_chunk, jobs)
     return [c for part in parts for c in part]
+
+
+def config_shapes(cfg: str, seed: Optional[int] = None, count: Optional[int] = None):
+    """(length, ploidy, depth) of every contig of a configuration WITHOUT generating it: what a scheduler knows up front
+    (contig lengths come with the assembly; aligned bp ~ depth x length). Used to shard a job over ranks."""
+    cfg = cfg.upper()
+    if cfg == "C2":
+        return [(100_000, 2, 50)] * (1 if count is None else count)
+    if cfg == "C3":
+        return [(200_000, 4, 40)] * (50 if count is None else count)
+    if cfg == "C4":
+        seed = 4 if seed is None else seed
+        out = []
+        for i in range(500 if count is None else count):
+            r = np.random.default_rng([seed, 1_000_000 + i])
+            L = int(np.clip(np.exp(r.normal(np.log(100_000.0), 0.5)), 20_000, 300_000))
+            out.append((L, int(r.integers(1, 9)), 30))
+        return out
+    if cfg == "C5":
+        n = 34 if count is None else count
+        return [(300_000 if i < 33 else 100_000, 2, 30) for i in range(n)]
+    if cfg == "C5U":
+        return [(10_000_000, 2, 30)]
+    raise ValueError(f"unknown config {cfg}")
+
+
+def _gen_ids_chunk(a):
+    cfg, seed, ids, outdir, part = a
+    cs = [config_contigs(cfg, seed=seed, first=i, count=1)[0] for i in ids]
+    if outdir is not None:
+        write_files(cs, outdir, prefix=f"part{part:05d}_", sam_header=False)
+    return cs
+
+
+def generate_job(cfg: str, ids: Sequence[int], seed: Optional[int] = None, workers: int = 1, outdir: Optional[str] = None):
+    """The contigs `ids` of a configuration on forked workers (a contig depends only on (seed, id)); with `outdir` the three
+    input files of the job are written too (every worker writes its part, the parts are concatenated). Only call it from a
+    process that has not initialised the GPU. Returns (contigs, paths or None)."""
+    ids = list(ids)
+    workers = max(1, min(workers, (len(ids) + 3) // 4))
+    step = max(1, (len(ids) + 4 * workers - 1) // (4 * workers))
+    jobs = [(cfg, seed, ids[i:i + step], outdir, k) for k, i in enumerate(range(0, len(ids), step))]
+    if workers <= 1:
+        parts = [_gen_ids_chunk(j) for j in jobs]
+    else:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            parts = pool.map(_gen_ids_chunk, jobs)
+    contigs = [c for p in parts for c in p]
+    files = None
+    if outdir is not None:
+        import shutil
+        files = {"gfa": os.path.join(outdir, "assembly.gfa"), "reads": os.path.join(outdir, "reads.fasta"), "sam": os.path.join(outdir, "aln.sam")}
+        with open(files["sam"], "wb") as s:
+            s.write(b"@HD\tVN:1.6\tSO:unsorted\n")
+            for c in contigs:
+                s.write(f"@SQ\tSN:{c.name}\tLN:{len(c.seq)}\n".encode())
+            for k in range(len(jobs)):
+                with open(os.path.join(outdir, f"part{k:05d}_aln.sam"), "rb") as f:
+                    shutil.copyfileobj(f, s, 16 << 20)
+                os.remove(os.path.join(outdir, f"part{k:05d}_aln.sam"))
+        for key, name in (("gfa", "assembly.gfa"), ("reads", "reads.fasta")):
+            with open(files[key], "wb") as o:
+                for k in range(len(jobs)):
+                    with open(os.path.join(outdir, f"part{k:05d}_{name}"), "rb") as f:
+                        shutil.copyfileobj(f, o, 16 << 20)
+                    os.remove(os.path.join(outdir, f"part{k:05d}_{name}"))
+    return contigs, files

@@ -38,7 +38,10 @@ def _worker(rank, world, port, q):
         assert (g is None) == (g2 is None)
         if g is not None:
             assert all(np.array_equal(a, b) for a, b in zip(g, g2))
-    q.put((rank, mine, er, None if g is None else [x.tolist() for x in g]))
+    # window size of stage 4: every rank derives the job-wide choice from its own reads + one all-reduce
+    spans = np.array([1500, 2500, 3500], np.int64) if rank == 0 else np.array([2600] * 5, np.int64)
+    ws = hdist.global_window_size(spans)
+    q.put((rank, mine, er, None if g is None else [x.tolist() for x in g], ws))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,6 +71,8 @@ def test_sharded_exchange_gloo_world2():
         tot = np.float32(tot + v)
     exp = float(np.float32(tot / np.float32(len(vals))))
     assert res[0][2] == exp and res[1][2] == exp
+    # mean READ length of the whole job = (sum + 2 per read) / 8 reads in (2000, 4000), fewer than 20 reads above 4 kb -> 1000
+    assert res[0][4] == 1000 and res[1][4] == 1000
     # rank 0 received every rank's labels unchanged; rank 1 nothing
     assert res[1][3] is None
     for r in range(world):
@@ -85,14 +90,32 @@ def test_lpt_shards_deterministic():
 
 
 def test_bench_inputs_are_the_same_from_forked_workers():
-    """bench.py generates its synthetic contigs on forked workers before it touches the GPU: same contigs as one by one"""
-    import numpy as np
-    import bench
+    """bench.py generates its shard of the job on forked workers before it touches the GPU (and writes the job's files from
+    the workers' parts): same contigs, same files as one by one"""
+    import tempfile
     from hairsplitter_amd import synth
-    ids = list(range(3, 19))
-    pooled = bench.make_contigs(2, ids, 2)
-    for i, c in zip(ids, pooled):
-        d = synth.make_contig(2, i, 100_000, 2, 0.01, 50, "ont")
-        assert c.name == d.name and np.array_equal(c.seq, d.seq) and len(c.reads) == len(d.reads)
-        assert all(np.array_equal(a, b) for a, b in zip(c.reads, d.reads))
-        assert all(x.pos == y.pos and x.strand == y.strand and np.array_equal(x.cigar, y.cigar) for x, y in zip(c.alns, d.alns))
+    ids = [3, 4, 7, 8, 9, 15, 16, 20, 21]
+    with tempfile.TemporaryDirectory() as a, tempfile.TemporaryDirectory() as b:
+        pooled, files = synth.generate_job("C4", ids, workers=3, outdir=a)
+        serial = [synth.config_contigs("C4", first=i, count=1)[0] for i in ids]
+        for c, d in zip(pooled, serial):
+            assert c.name == d.name and np.array_equal(c.seq, d.seq) and len(c.reads) == len(d.reads)
+            assert all(np.array_equal(x, y) for x, y in zip(c.reads, d.reads))
+            assert all(x.pos == y.pos and x.strand == y.strand and np.array_equal(x.cigar, y.cigar) for x, y in zip(c.alns, d.alns))
+        f2 = synth.write_files(serial, b)
+        for k in f2:
+            assert open(files[k], "rb").read() == open(f2[k], "rb").read()
+    # what the sharding knows up front (lengths) is what the generator produces
+    shapes = synth.config_shapes("C4", count=22)
+    assert [shapes[i][0] for i in ids] == [len(c.seq) for c in serial]
+
+
+def test_strong_scaling_shards_cover_the_job():
+    """bench.py --gpus N: the SAME job, contigs assigned by LPT on (length x depth)"""
+    from hairsplitter_amd import synth
+    shapes = synth.config_shapes("C4")
+    for world in (1, 2, 4, 8):
+        shards = hdist.lpt_shards([float(s[0] * s[2]) for s in shapes], world)
+        assert sorted(sum(shards, [])) == list(range(500))
+        loads = [sum(shapes[i][0] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= 300_000

@@ -15,7 +15,8 @@ def main():
     parts = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 12
     import bench
-    contigs = bench.make_contigs(2, list(range(n)), 8)
+    from hairsplitter_amd import synth
+    contigs = synth.generate_job("C2", list(range(n)), seed=2, workers=8)[0]
     import torch
     from hairsplitter_amd import api
     torch.cuda.set_device(0)
