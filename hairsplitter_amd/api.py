@@ -701,7 +701,7 @@ def pack_columns(col_off, col_idx, col_code, ids):
     return packed_off, o_idx[:total].cpu().numpy(), o_code[:total].cpu().numpy()
 
 
-def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1, col_c1, col_is_cand, part_off, part_state_off, part_state):
+def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1, col_c1, col_is_cand, part_off, part_state_off, part_state, n_reads):
     """K4: loops C/D of keep_only_robust_variants (call_variants.cpp:721-764); returns keep uint8 [n_cols]."""
     import torch
     require_gpu()
@@ -714,7 +714,8 @@ def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1
          up(col_c1, np.int32), up(col_is_cand, np.uint8)]
     q = [up(part_off, np.int32), up(part_state_off, np.int64), up(part_state, np.int8)]
     keep = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
-    _check(load().hs_column_partition_test(*[_p(x) for x in d], C.c_int32(n), *[_p(x) for x in q], _p(keep), C.c_void_p(0)))
+    nr = _np(n_reads, np.int32)
+    _check(load().hs_column_partition_test(*[_p(x) for x in d], C.c_int32(n), *[_p(x) for x in q], _hp(nr, C.c_int32), C.c_int32(len(nr)), _p(keep), C.c_void_p(0)))
     torch.cuda.synchronize()
     return keep[:n].cpu().numpy()
 

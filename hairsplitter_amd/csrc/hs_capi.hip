@@ -616,18 +616,62 @@ int hs_pack_columns(const int64_t* d_col_off, const int32_t* d_col_idx, const ui
     return HS_OK;
 }
 
+// K4 in two steps: the lanes-as-partitions kernel on a per-contig [read][partition] table (built on the device from the
+// dense state arrays), then the exact one-partition-at-a-time kernel on the few columns the first one leaves undecided
+static int partition_test_launch(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code, const int32_t* d_col_contig,
+                                 const uint8_t* d_col_k0, const uint8_t* d_col_k1, const int32_t* d_col_c1, const uint8_t* d_col_is_cand, int32_t n_cols,
+                                 const int32_t* d_part_off, const int64_t* d_part_state_off, const int8_t* d_part_state,
+                                 const int32_t* h_part_off, const int32_t* h_contig_n_reads, int32_t n_contigs, uint8_t* d_keep, hipStream_t stream,
+                                 DBuf& d_tab, DBuf& d_tab_off, DBuf& d_ctg_n, DBuf& d_list, UploadPack& pk) {
+    std::vector<int64_t> tab_off((size_t)n_contigs + 1, 0);
+    std::vector<int32_t> ctg_n(h_contig_n_reads, h_contig_n_reads + n_contigs);
+    int64_t max_cells = 1;
+    for (int c = 0; c < n_contigs; ++c) {
+        const int P = h_part_off[c + 1] - h_part_off[c];
+        const int64_t cells = (int64_t)ctg_n[(size_t)c] * ((P + 63) & ~63);
+        tab_off[(size_t)c + 1] = tab_off[(size_t)c] + cells;
+        max_cells = std::max(max_cells, cells);
+    }
+    pk.add(tab_off, d_tab_off); pk.add(ctg_n, d_ctg_n);
+    if (int rc = pk.commit(stream)) return rc;
+    if (int rc = d_tab.alloc(std::max<size_t>((size_t)tab_off.back(), 64))) return rc;
+    if (tab_off.back() > 0) {
+        const unsigned gx = (unsigned)std::min<int64_t>((max_cells + 255) / 256, 64);
+        hipLaunchKernelGGL(hsdev::k_partition_transpose, dim3(gx, (unsigned)n_contigs), dim3(256), 0, stream, d_part_off, d_part_state_off, d_part_state,
+                           d_ctg_n.as<int32_t>(), d_tab_off.as<int64_t>(), n_contigs, d_tab.as<uint8_t>());
+    }
+    if (int rc = d_list.alloc(((size_t)n_cols + 1) * 4)) return rc;     // [0] = number of undecided columns, then their indices
+    HS_HIP(hipMemsetAsync(d_list.p, 0, 4, stream));
+    hipLaunchKernelGGL(hsdev::k_column_partition_lanes, dim3((n_cols + 3) / 4), dim3(256), 0, stream, d_col_off, d_col_idx, d_col_code, d_col_contig,
+                       d_col_k0, d_col_k1, d_col_c1, d_col_is_cand, n_cols, d_part_off, d_tab_off.as<int64_t>(), d_tab.as<uint8_t>(), d_keep,
+                       d_list.as<int32_t>() + 1, d_list.as<int32_t>());
+    if (std::getenv("HS_K4_DEBUG")) {   // diagnostic: how many columns the first kernel leaves to the exact one
+        int32_t nu = 0;
+        if (int rc = d2h_pinned(&nu, d_list.p, 4, stream)) return rc;
+        std::fprintf(stderr, "[hs k4] %d columns, %d undecided after the lanes kernel\n", n_cols, nu);
+    }
+    hipLaunchKernelGGL(hsdev::k_column_partition_test, dim3((unsigned)std::min(n_cols, 2048)), dim3(1024), 0, stream, d_col_off, d_col_idx,
+                       d_col_code, d_col_contig, d_col_k0, d_col_k1, d_col_c1, d_col_is_cand, n_cols, d_part_off, d_part_state_off,
+                       d_part_state, d_keep, d_list.as<int32_t>() + 1, d_list.as<int32_t>());
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
 int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code,
                              const int32_t* d_col_contig, const uint8_t* d_col_k0, const uint8_t* d_col_k1,
                              const int32_t* d_col_c1, const uint8_t* d_col_is_cand, int32_t n_cols,
                              const int32_t* d_part_off, const int64_t* d_part_state_off, const int8_t* d_part_state,
-                             uint8_t* d_keep, void* stream) {
+                             const int32_t* h_contig_n_reads, int32_t n_contigs, uint8_t* d_keep, void* stream) {
     if (int rc = require_device()) return rc;
     if (n_cols <= 0) return HS_OK;
-    hipLaunchKernelGGL(hsdev::k_column_partition_test, dim3((n_cols + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_col_off, d_col_idx,
-                       d_col_code, d_col_contig, d_col_k0, d_col_k1, d_col_c1, d_col_is_cand, n_cols, d_part_off, d_part_state_off,
-                       d_part_state, d_keep);
-    HS_HIP(hipGetLastError());
-    return HS_OK;
+    if (!h_contig_n_reads || n_contigs <= 0) { set_error("hs_column_partition_test: the number of reads of every contig is needed"); return HS_EINVAL; }
+    std::vector<int32_t> h_po((size_t)n_contigs + 1);
+    if (int rc = d2h_pinned(h_po.data(), d_part_off, h_po.size() * 4, (hipStream_t)stream)) return rc;
+    DBuf tab, tab_off, ctg_n, list;
+    UploadPack pk;
+    if (int rc = partition_test_launch(d_col_off, d_col_idx, d_col_code, d_col_contig, d_col_k0, d_col_k1, d_col_c1, d_col_is_cand, n_cols, d_part_off,
+                                       d_part_state_off, d_part_state, h_po.data(), h_contig_n_reads, n_contigs, d_keep, (hipStream_t)stream, tab, tab_off, ctg_n, list, pk)) return rc;
+    return stream_wait((hipStream_t)stream);   // the table goes back to the pool with this scope
 }
 
 int hs_snp_planes(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code, const uint8_t* d_snp_ref,
@@ -989,9 +1033,12 @@ struct HipCvOps : hs::CvDeviceOps {
         EventPair e; if (int rc = e.init()) return rc;
         HS_HIP(hipEventRecord(e.a, stream));
         if (int rc = kc.begin(HS_K_PARTITION_TEST, stream)) return rc;
-        if (int rc = hs_column_partition_test(d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), d_ctg.as<int32_t>(), d_k0.as<uint8_t>(),
-                                              d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), n, d_po.as<int32_t>(), d_pso.as<int64_t>(),
-                                              d_ps.as<int8_t>(), d_keep.as<uint8_t>(), stream)) return rc;
+        DBuf d_tab, d_tab_off, d_ctg_n, d_list;
+        UploadPack pk_tab;
+        if (int rc = partition_test_launch(d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), d_ctg.as<int32_t>(), d_k0.as<uint8_t>(),
+                                           d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), n, d_po.as<int32_t>(), d_pso.as<int64_t>(),
+                                           d_ps.as<int8_t>(), t.part_off.data(), t.contig_n_reads.data(), (int32_t)t.contig_n_reads.size(), d_keep.as<uint8_t>(),
+                                           stream, d_tab, d_tab_off, d_ctg_n, d_list, pk_tab)) return rc;
         if (int rc = kc.end(5 * gathered_entries + (int64_t)t.part_state.size(), stream)) return rc;   // the columns (idx + code) and the partition states
         HS_HIP(hipEventRecord(e.b, stream));
         keep.resize((size_t)n);
@@ -1362,7 +1409,8 @@ struct HipSrOps : hs::SrDeviceOps {
         if (n_inst > 0x7fffffff) { set_error("Chinese Whispers: too many runs in one call"); return HS_EINVAL; }
         // per-SNP runs: window, slab offset (the runs of a window are contiguous: K * m labels); small windows go to the
         // row-packed kernel, the others to the one-wavefront-per-run kernel
-        std::vector<int32_t> inst_win((size_t)n_inst), list_small, list_big;
+        std::vector<int32_t> inst_win((size_t)n_inst), list_big, unit_win, unit_inst0, unit_n;
+        int max_m_small = 1;
         std::vector<int64_t> inst_slab((size_t)n_inst), chain_slab0((size_t)Wc), big_scr, tail_scr((size_t)Wc, 0);
         int64_t slab = 0, big_scr_total = 0, tail_scr_total = 0;
         int max_m_big = 1, max_m_chain = 1;
@@ -1373,8 +1421,14 @@ struct HipSrOps : hs::SrDeviceOps {
             max_m_chain = std::max(max_m_chain, m);
             for (int64_t i = ch.win_seed_begin[(size_t)k]; i < ch.win_seed_begin[(size_t)k + 1]; ++i) {
                 inst_win[(size_t)i] = w; inst_slab[(size_t)i] = slab; slab += m;
-                if (m <= HS_CWR_CAP) list_small.push_back((int32_t)i);
-                else { list_big.push_back((int32_t)i); max_m_big = std::max(max_m_big, m); }
+                if (m > HS_CWR_CAP) { list_big.push_back((int32_t)i); max_m_big = std::max(max_m_big, m); }
+            }
+            if (m <= HS_CWR_CAP) {      // units of up to eight runs of this window for the row-packed kernel
+                max_m_small = std::max(max_m_small, m);
+                for (int64_t i = ch.win_seed_begin[(size_t)k]; i < ch.win_seed_begin[(size_t)k + 1]; i += 8) {
+                    unit_win.push_back(w); unit_inst0.push_back((int32_t)i);
+                    unit_n.push_back((int32_t)std::min<int64_t>(8, ch.win_seed_begin[(size_t)k + 1] - i));
+                }
             }
         }
         const int cap_big = lds_nodes(max_m_big, 2, 96 * 1024);
@@ -1389,7 +1443,7 @@ struct HipSrOps : hs::SrDeviceOps {
             tail_scr[(size_t)k] = tail_scr_total;
             if (m > cap_tail) tail_scr_total += 7 * (int64_t)m + (m & 1);      // keeps the next window's doubles 8-byte aligned
         }
-        DBuf d_iw, d_is, d_seed, d_ls, d_lb, d_bs, d_cw, d_cr0, d_csb, d_cs0, d_ts, d_slab, d_gs, d_l3, d_final, d_ok, d_stat,
+        DBuf d_iw, d_is, d_seed, d_uw, d_ui, d_un, d_lb, d_bs, d_cw, d_cr0, d_csb, d_cs0, d_ts, d_slab, d_gs, d_l3, d_final, d_ok, d_stat,
             d_cpos, d_sf, d_sl, d_plo, d_phi;
         if (resident_cols != &ch) {   // normally uploaded by simdiff_columns already
             col_pack.add(ch.col_off, d_col_off); col_pack.add(ch.col_idx, d_col_idx); col_pack.add(ch.col_code, d_col_code);
@@ -1398,7 +1452,7 @@ struct HipSrOps : hs::SrDeviceOps {
         }
         const bool finish = ch.finish_on_device && !std::getenv("HS_FINISH_ON_HOST");
         UploadPack pk;
-        pk.add(inst_win, d_iw); pk.add(inst_slab, d_is); pk.add(ch.seed_col, d_seed); pk.add(list_small, d_ls); pk.add(list_big, d_lb);
+        pk.add(inst_win, d_iw); pk.add(inst_slab, d_is); pk.add(ch.seed_col, d_seed); pk.add(unit_win, d_uw); pk.add(unit_inst0, d_ui); pk.add(unit_n, d_un); pk.add(list_big, d_lb);
         pk.add(big_scr, d_bs); pk.add(ch.win, d_cw); pk.add(ch.chain_row0, d_cr0); pk.add(ch.win_seed_begin, d_csb); pk.add(chain_slab0, d_cs0);
         pk.add(tail_scr, d_ts);
         if (finish) { pk.add(ch.col_pos, d_cpos); pk.add(ch.win_snp_first, d_sf); pk.add(ch.win_snp_last, d_sl); pk.add(ch.win_pos_lo, d_plo); pk.add(ch.win_pos_hi, d_phi); }
@@ -1416,12 +1470,18 @@ struct HipSrOps : hs::SrDeviceOps {
         // ---- per-SNP runs, seeded on the device from the SNP columns ----
         HS_HIP(hipEventRecord(e1.a, stream));
         if (int rc = kc.begin(HS_K_CW_SEEDED, stream)) return rc;
-        if (!list_small.empty()) {
-            const int n = (int)list_small.size();
-            hipLaunchKernelGGL(hsdev::k_cw_seeded_rows, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(),
-                               G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), d_ls.as<int32_t>(), n,
-                               d_iw.as<int32_t>(), d_seed.as<int64_t>(), d_is.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
-                               d_col_code.as<uint8_t>(), d_slab.as<int32_t>(), d_stat.as<unsigned long long>());
+        if (!unit_win.empty()) {
+            const int n = (int)unit_win.size();
+            const int m_cap = std::max(16, (max_m_small + 15) & ~15);
+            const int cnt_cap = std::max(m_cap, 256);
+            const int prog_cap = std::max(2048, m_cap * 32);
+            const size_t lds = (size_t)2 * m_cap * 4 + (size_t)8 * cnt_cap * 4 + (size_t)prog_cap + (size_t)8 * m_cap;
+            if (lds > 48 * 1024)
+                HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_cw_seeded_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(hsdev::k_cw_seeded_rows, dim3((unsigned)n), dim3(128), lds, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(),
+                               G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), d_uw.as<int32_t>(),
+                               d_ui.as<int32_t>(), d_un.as<int32_t>(), n, d_seed.as<int64_t>(), d_is.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
+                               d_col_code.as<uint8_t>(), m_cap, prog_cap, d_slab.as<int32_t>(), d_stat.as<unsigned long long>());
             HS_HIP(hipGetLastError());
         }
         if (!list_big.empty()) {

@@ -273,7 +273,9 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         for (size_t i = 0; i < n_sel; ++i) t.col_contig[i] = sel_contig[i] - c0;   // index into part_off
         t.col_c1.resize(n_sel); t.col_k0.resize(n_sel); t.col_k1.resize(n_sel); t.col_is_cand.resize(n_sel);
         t.part_off.assign((size_t)C + 1, 0);
+        t.contig_n_reads.resize((size_t)C);
         for (int c = 0; c < C; ++c) {
+            t.contig_n_reads[(size_t)c] = b.contig_rec_off[(size_t)(c0 + c) + 1] - b.contig_rec_off[(size_t)(c0 + c)];
             const ColumnSet& cs = sets[(size_t)c];
             const size_t s0 = (size_t)contig_sel_off[(size_t)c];
             for (size_t i = 0; i < cs.pos.size(); ++i) { t.col_c1[s0 + i] = cs.c1[i]; t.col_k0[s0 + i] = cs.k0[i]; t.col_k1[s0 + i] = cs.k1[i]; }

@@ -25,6 +25,7 @@ struct CvMeta {                       // host-side description of a stage-3 batc
 struct CvPartitionTest {
     std::vector<int32_t> col_contig, col_c1;
     std::vector<uint8_t> col_k0, col_k1, col_is_cand;
+    std::vector<int32_t> contig_n_reads;    // [C]
     std::vector<int32_t> part_off;          // [C+1] range of partitions of each contig
     std::vector<int64_t> part_state_off;    // [sum F] offset of each partition's state array
     std::vector<int8_t> part_state;

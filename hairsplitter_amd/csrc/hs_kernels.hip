@@ -1343,41 +1343,170 @@ static __device__ Table2x2 column_vs_partition_dev(const int32_t* __restrict__ i
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_column_partition_test(
+// One workgroup of 16 wavefronts per listed column (the columns k_column_partition_lanes left undecided, or every column when
+// `list` is null): wavefront w takes the partitions w, w + 16, ... of the column's contig, the verdict is the OR.
+__global__ __launch_bounds__(1024) void k_column_partition_test(
     const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
     const int32_t* __restrict__ col_contig, const uint8_t* __restrict__ col_k0, const uint8_t* __restrict__ col_k1,
     const int32_t* __restrict__ col_c1, const uint8_t* __restrict__ col_is_cand, int n_cols,
     const int32_t* __restrict__ part_off /* [C+1] */, const int64_t* __restrict__ part_state_off /* [sum F] */,
-    const int8_t* __restrict__ part_state, uint8_t* __restrict__ keep) {
-    __shared__ uint8_t s_seen[4][128];
-    __shared__ uint8_t s_ord[4][264];
-    __shared__ int s_ord_n[4];
+    const int8_t* __restrict__ part_state, uint8_t* __restrict__ keep, const int32_t* __restrict__ list, const int32_t* __restrict__ n_list) {
+    __shared__ uint8_t s_seen[16][128];
+    __shared__ uint8_t s_ord[16][264];
+    __shared__ int s_ord_n[16];
+    __shared__ int s_kept;
     const int lane = lane_id();
     const int wv = wave_id();
-    const int col = (int)blockIdx.x * 4 + wv;
+    const int total = list ? *n_list : n_cols;
+    for (int f = (int)blockIdx.x; f < total; f += (int)gridDim.x) {
+        const int col = list ? list[f] : f;
+        if (threadIdx.x == 0) s_kept = 0;
+        __syncthreads();
+        const int c = col_contig[col];
+        const int p0 = part_off[c], p1 = part_off[c + 1];
+        const int64_t e0 = col_off[col];
+        const int n = (int)(col_off[col + 1] - e0);
+        const int32_t* __restrict__ idx = col_idx + e0;
+        const uint8_t* __restrict__ code = col_code + e0;
+        const int k0 = col_k0[col], k1 = col_k1[col];
+        const bool loop_c = col_is_cand[col] != 0;                                   // loop C (:721-738)
+        const bool loop_d = col_c1[col] >= 5 && central_base_test_dev(k0, k1);     // loop D (:745-764) on the columns that can be rescued
+        bool kept = false;
+        if (loop_c || loop_d) {
+            for (int p = p0 + wv; p < p1 && !kept; p += 16) {
+                const Table2x2 d = column_vs_partition_dev(idx, code, n, part_state + part_state_off[p], k0, s_seen[wv], s_ord[wv], &s_ord_n[wv]);
+                const float chi = chi_square_dev(d);
+                if (loop_c && (double)(d.n00 + d.n01 + d.n10 + d.n11) > 0.5 * (double)n && chi > 15) kept = true;
+                if (loop_d && (double)chi > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) kept = true;
+            }
+        }
+        if (kept && lane == 0) atomicOr(&s_kept, 1);
+        __syncthreads();
+        if (threadIdx.x == 0) keep[col] = s_kept ? 1 : 0;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4, fast form: one wavefront per extracted column, LANES = PARTITIONS of the column's contig (blocks of 64).
+// The partition states are read from a per-contig table transposed to [read][partition] (k_partition_transpose), one
+// byte per (read, partition) holding 8 x {0 absent, 1 present with state 0, 2 state +1, 3 state -1}: for a column entry
+// (read r, code c) every lane loads the byte of ITS partition -- 64 consecutive bytes per entry instead of one scattered
+// byte per (entry, partition) -- and adds 1 << byte to an accumulator whose four byte fields count absent / zero / plus /
+// minus reads. Entries are visited code by code (leader loop over ballots), so that after a code's entries each lane knows
+// how many shared reads carry it on either side of its partition: reference code -> n11 / n01, most frequent other code ->
+// n10 / n00 (call_variants.cpp:832-936). The table, chi-square and the verdicts of loops C and D (:721-764) are then formed
+// per lane, i.e. for 64 partitions at once; keep = any lane.
+// Not decided here (keep = 2, re-done by the exact kernel above): a column whose verdict hinges on a partition where the
+// second allele is tied among the shared reads (the reference breaks the tie by hash-map order), reference codes >= 128
+// (signed-char quirk), columns deeper than 255.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_partition_transpose(
+    const int32_t* __restrict__ part_off, const int64_t* __restrict__ part_state_off, const int8_t* __restrict__ part_state,
+    const int32_t* __restrict__ ctg_n, const int64_t* __restrict__ tab_off, int n_contigs, uint8_t* __restrict__ tab) {
+    const int c = (int)blockIdx.y;
+    if (c >= n_contigs) return;
+    const int p0 = part_off[c], P = part_off[c + 1] - p0;
+    const int N = ctg_n[c];
+    const int ppad = (P + 63) & ~63;
+    const int64_t total = (int64_t)N * ppad;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / ppad), p = (int)(i % ppad);
+        uint8_t e = 0;
+        if (p < P) { const int s = part_state[part_state_off[p0 + p] + r]; e = s == 2 ? 0 : (s == 0 ? 8 : (s == 1 ? 16 : 24)); }
+        tab[tab_off[c] + i] = e;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_column_partition_lanes(
+    const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
+    const int32_t* __restrict__ col_contig, const uint8_t* __restrict__ col_k0, const uint8_t* __restrict__ col_k1,
+    const int32_t* __restrict__ col_c1, const uint8_t* __restrict__ col_is_cand, int n_cols,
+    const int32_t* __restrict__ part_off, const int64_t* __restrict__ tab_off, const uint8_t* __restrict__ tab,
+    uint8_t* __restrict__ keep, int32_t* __restrict__ undecided_list, int32_t* __restrict__ n_undecided) {
+    const int lane = lane_id();
+    const int col = (int)blockIdx.x * 4 + wave_id();
     if (col >= n_cols) return;
     const int c = col_contig[col];
-    const int p0 = part_off[c], p1 = part_off[c + 1];
+    const int P = part_off[c + 1] - part_off[c];
     const int64_t e0 = col_off[col];
     const int n = (int)(col_off[col + 1] - e0);
-    const int32_t* __restrict__ idx = col_idx + e0;
-    const uint8_t* __restrict__ code = col_code + e0;
     const int k0 = col_k0[col], k1 = col_k1[col];
-    bool kept = false;
-    if (col_is_cand[col]) {                                   // loop C (:721-738)
-        for (int p = p0; p < p1 && !kept; ++p) {
-            const Table2x2 d = column_vs_partition_dev(idx, code, n, part_state + part_state_off[p], k0, s_seen[wv], s_ord[wv], &s_ord_n[wv]);
-            const float chi = chi_square_dev(d);
-            if ((double)(d.n00 + d.n01 + d.n10 + d.n11) > 0.5 * (double)n && chi > 15) kept = true;
-        }
+    const bool is_cand = col_is_cand[col] != 0;
+    const bool loop_d = col_c1[col] >= 5 && central_base_test_dev(k0, k1);
+    if (P == 0 || (!is_cand && !loop_d)) { if (lane == 0) keep[col] = 0; return; }
+    if (n > 255 || k0 >= 128) {   // (the byte fields of the accumulator hold up to 255 entries)
+        if (lane == 0) { keep[col] = 2; undecided_list[atomicAdd(n_undecided, 1)] = col; }
+        return;
     }
-    if (!kept && col_c1[col] >= 5 && central_base_test_dev(k0, k1)) {   // loop D (:745-764) on the columns that can be rescued
-        for (int p = p0; p < p1 && !kept; ++p) {
-            const Table2x2 d = column_vs_partition_dev(idx, code, n, part_state + part_state_off[p], k0, s_seen[wv], s_ord[wv], &s_ord_n[wv]);
-            if ((double)chi_square_dev(d) > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) kept = true;
-        }
+    const int ppad = (P + 63) & ~63;
+    const uint8_t* __restrict__ tb = tab + tab_off[c];
+    // the column: up to four chunks of 64 entries, one entry per lane
+    int r_i[4], c_i[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = k * 64 + lane;
+        r_i[k] = e < n ? col_idx[e0 + e] : 0;
+        c_i[k] = e < n ? (int)col_code[e0 + e] : -1;
     }
-    if (lane == 0) keep[col] = kept ? 1 : 0;
+    bool kept = false, undecided = false;
+    for (int pb = 0; pb < ppad && !kept; pb += 64) {
+        const uint8_t* __restrict__ tl = tb + pb + lane;
+        unsigned long long rem[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rem[k] = __ballot(c_i[k] >= 0);
+        int n11 = 0, n01 = 0, n10 = 0, n00 = 0, best = -1;
+        bool tie = false;
+        for (;;) {
+            int code = -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (code < 0 && rem[k]) code = __builtin_amdgcn_readlane(c_i[k], __builtin_ctzll(rem[k]));
+            if (code < 0) break;
+            unsigned acc = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                unsigned long long m = __ballot(c_i[k] == code);
+                rem[k] &= ~m;
+                while (m) {      // two entries per step: both loads in flight before the adds
+                    const int ea = __builtin_ctzll(m); m &= m - 1ull;
+                    const int ra = __builtin_amdgcn_readlane(r_i[k], ea);
+                    int rb = -1;
+                    if (m) { const int eb = __builtin_ctzll(m); m &= m - 1ull; rb = __builtin_amdgcn_readlane(r_i[k], eb); }
+                    const unsigned sa = tl[(int64_t)ra * ppad];
+                    const unsigned sb = rb >= 0 ? (unsigned)tl[(int64_t)rb * ppad] : 0u;
+                    acc += 1u << sa;
+                    if (rb >= 0) acc += 1u << sb;
+                }
+            }
+            const int plus = (int)((acc >> 16) & 255u), minus = (int)(acc >> 24);
+            const int take = (int)((acc >> 8) & 255u) + plus + minus;
+            if (code == k0) { n11 = plus; n01 = minus; }
+            else if (take > 0) {
+                if (take > best) { best = take; n10 = plus; n00 = minus; tie = false; }
+                else if (take == best) tie = true;
+            }
+        }
+        if (pb + lane < P) {
+            Table2x2 d; d.n00 = n00; d.n01 = n01; d.n10 = n10; d.n11 = n11;
+            // a tie among the second alleles only matters where the verdict could depend on which one is taken: loop C needs more
+            // than half of the column's reads in the table (at most n11 + n01 + best of them are), loop D five reads on the
+            // second allele (at most best)
+            const bool tie_matters = tie && ((is_cand && (double)(n11 + n01 + best) > 0.5 * (double)n) || (loop_d && best >= 5));
+            bool ok = false;
+            if (!tie_matters) {
+                const float chi = chi_square_dev(d);
+                if (is_cand && (double)(d.n00 + d.n01 + d.n10 + d.n11) > 0.5 * (double)n && chi > 15) ok = true;                 // loop C (:721-738)
+                if (loop_d && (double)chi > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) ok = true;                           // loop D (:745-764)
+            }
+            kept = ok; undecided = undecided || tie_matters;
+        } else kept = false;
+        kept = __ballot(kept) != 0ull;
+    }
+    undecided = __ballot(undecided) != 0ull;
+    if (lane == 0) {
+        keep[col] = kept ? 1 : (undecided ? 2 : 0);
+        if (!kept && undecided) undecided_list[atomicAdd(n_undecided, 1)] = col;
+    }
 }
 
 // K3 with the tile plan: only the records of the position's tile are tested (one 64-record step for 50x data instead of

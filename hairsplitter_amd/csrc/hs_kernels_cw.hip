@@ -26,7 +26,7 @@ namespace hsdev {
 #define HS_FIN_GCAP 8       // clusters entering merge_wrongly_split
 #define HS_FIN_LCAP 16      // cluster links (std::sort is a plain insertion sort up to 16 elements)
 #define HS_FIN_MCAP (HS_FIN_KCAP + 2)
-#define HS_CWR_CAP 256      // nodes per instance in the row-packed kernel
+#define HS_CWR_CAP 255      // nodes per run in the row-packed kernel (local ids and labels are bytes, 255 = none)
 #ifndef HS_CW_REG_LABELS
 #define HS_CW_REG_LABELS 8
 #endif
@@ -195,11 +195,11 @@ static __device__ __forceinline__ void cw_seed_labels(const int32_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// Per-SNP runs, row-packed: a workgroup of 256 threads = 16 DPP rows = 16 instances, each with its own slice of LDS
-// (labels u16 + vote counters). The lanes of a row hold the neighbours of the row's current node (mean degree ~ 16):
-// LDS atomic votes, every lane reads its label's total, the row maximum of (count << 16 | 65535 - label) comes from four
-// row_ror DPP steps. Rows of a wavefront run in lock step on different instances (EXEC masks off the finished ones).
-// Windows with m > HS_CWR_CAP are left to k_cw_seeded_wave (inst_list holds the instances of this launch).
+// Per-SNP runs, row-packed: FOUR runs per wavefront, one 16-lane DPP row each, with its own slice of LDS (labels as
+// bytes + vote counters). The lanes of a row hold the neighbours of the row's current node (mean degree ~ 16): LDS atomic
+// votes, every lane reads its label's total, the row maximum of (count << 16 | 65535 - label) comes from four row_ror DPP
+// steps. Rows of a wavefront run in lock step on different runs (EXEC masks off the finished ones).
+// Windows with m > HS_CWR_CAP are left to k_cw_seeded_wave.
 // Output: slab[inst_slab_off + j] = label (local) of node j.
 // ------------------------------------------------------------------------------------------------
 static __device__ __forceinline__ unsigned row_max_u32(unsigned v) {
@@ -211,78 +211,195 @@ static __device__ __forceinline__ unsigned row_max_u32(unsigned v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_cw_seeded_rows(
+// One workgroup (128 threads = 8 DPP rows) per UNIT = up to eight consecutive per-SNP runs of ONE window, so that the
+// window's graph is staged once in LDS and shared by the rows: a "visit program" -- per visited node (in visiting order) its
+// neighbour list cut in chunks of 16 bytes (local ids fit a byte: m <= 256), one dword of info per visit {node, chunks,
+// first chunk}. Inside the sweeps nothing but LDS is touched: per visit one read of the info dword (prefetched a visit
+// ahead), the neighbour bytes, the label gather, the atomic votes and the read-back, i.e. four LDS round trips on the
+// dependent chain whatever the degree (up to 64 neighbours; beyond, a loop). A window whose program does not fit
+// `prog_cap` runs the same sweeps against global memory.
+__global__ __launch_bounds__(128) void k_cw_seeded_rows(
     const int64_t* __restrict__ off, const int32_t* __restrict__ nbr, const int64_t* __restrict__ win_row0,
     const int32_t* __restrict__ mask_ids, const int32_t* __restrict__ visit, const int32_t* __restrict__ visit_n,
-    const int32_t* __restrict__ inst_list, int n_list, const int32_t* __restrict__ inst_win, const int64_t* __restrict__ inst_seed_col,
-    const int64_t* __restrict__ inst_slab_off, const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx,
-    const uint8_t* __restrict__ col_code, int32_t* __restrict__ slab, unsigned long long* __restrict__ stat /* [2]: sweeps, bytes */) {
-    __shared__ int32_t s_cnt[16][HS_CWR_CAP];      // vote counters; the first-node-per-code table while seeding
-    __shared__ uint16_t s_lab[16][HS_CWR_CAP];
+    const int32_t* __restrict__ unit_win, const int32_t* __restrict__ unit_inst0, const int32_t* __restrict__ unit_n, int n_units,
+    const int64_t* __restrict__ inst_seed_col, const int64_t* __restrict__ inst_slab_off, const int64_t* __restrict__ col_off,
+    const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code, int m_cap, int prog_cap,
+    int32_t* __restrict__ slab, unsigned long long* __restrict__ stat /* [2]: sweeps, bytes */) {
+    extern __shared__ int32_t cwr_dyn[];
+    __shared__ int s_steps;
     const int tid = (int)threadIdx.x, row = tid >> 4, l = tid & 15;
-    const int k = (int)blockIdx.x * 16 + row;
-    const bool live = k < n_list;
-    const int inst = live ? inst_list[k] : 0;
-    const int w = live ? inst_win[inst] : 0;
+    const int u = (int)blockIdx.x;
+    if (u >= n_units) return;
+    const int w = unit_win[u];
     const int64_t r0 = win_row0[w];
-    const int m = live ? (int)(win_row0[w + 1] - r0) : 0;
+    const int m = (int)(win_row0[w + 1] - r0);
+    const int n_visit = visit_n[w];
     const int32_t* __restrict__ ids = mask_ids + r0;
     const int32_t* __restrict__ vis = visit + r0;
-    const int n_visit = live ? visit_n[w] : 0;
     const int64_t* __restrict__ off_w = off + r0;
     const int64_t base = off_w[0];
     const int32_t* __restrict__ anb = nbr + base;
-    int32_t* cnt = s_cnt[row];
-    uint16_t* lab = s_lab[row];
-    for (int j = l; j < HS_CWR_CAP; j += 16) { cnt[j] = 0x7fffffff; lab[j] = (uint16_t)j; }
-    wave_sync_lds();
+    // LDS: info[m_cap] | ids[m_cap] | per row cnt[cnt_cap] x 8 | prog bytes[prog_cap] | per row labels bytes[m_cap] x 8
+    // (cnt_cap >= 256: the counters double as the first-node-per-code table while seeding)
+    const int cnt_cap = m_cap > 256 ? m_cap : 256;
+    uint32_t* s_info = reinterpret_cast<uint32_t*>(cwr_dyn);
+    int32_t* s_ids = cwr_dyn + m_cap;
+    int32_t* cnt = cwr_dyn + 2 * m_cap + row * cnt_cap;
+    uint8_t* s_prog = reinterpret_cast<uint8_t*>(cwr_dyn + 2 * m_cap + 8 * cnt_cap);
+    uint8_t* lab = s_prog + prog_cap + row * m_cap;
+    // ---- the visit program: chunks per visited node (all threads), their exclusive prefix (first wavefront) ----
+    for (int v = tid; v < n_visit; v += 128) {
+        const int i = vis[v];
+        const int nc = ((int)(off_w[i + 1] - off_w[i]) + 15) >> 4;       // m <= 255: at most 16 chunks
+        s_info[v] = (uint32_t)i | ((uint32_t)nc << 8);
+    }
+    for (int j = tid; j < m; j += 128) s_ids[j] = ids[j];
+    __syncthreads();
+    if (tid < 64) {
+        int carry = 0;
+        for (int b0 = 0; b0 < n_visit; b0 += 64) {
+            const int v = b0 + tid;
+            const int nc = v < n_visit ? (int)((s_info[v] >> 8) & 255u) : 0;
+            const int incl = wave_scan_incl(nc);
+            const int first = carry + incl - nc;
+            if (v < n_visit) s_info[v] |= (uint32_t)(first > 65535 ? 65535 : first) << 16;
+            carry += __builtin_amdgcn_readlane(incl, 63);
+        }
+        if (tid == 0) s_steps = carry;
+    }
+    __syncthreads();
+    const bool staged = s_steps * 16 <= prog_cap && s_steps < 65535;
+    if (staged) {
+        for (int v = tid; v < n_visit; v += 128) {
+            const uint32_t inf = s_info[v];
+            const int i = (int)(inf & 255u), s0 = (int)(inf >> 16);
+            const int o0 = (int)(off_w[i] - base), o1 = (int)(off_w[i + 1] - base);
+            for (int o = o0; o < ((o1 - o0 + 15) & ~15) + o0; ++o) s_prog[s0 * 16 + (o - o0)] = o < o1 ? (uint8_t)anb[o] : (uint8_t)255;
+        }
+    }
+    // ---- seeding (:1678-1691) ----
+    const bool live = row < unit_n[u];
+    const int inst = unit_inst0[u] + row;
+    for (int j = l; j < cnt_cap; j += 16) cnt[j] = 0x7fffffff;
+    for (int j = l; j < m_cap; j += 16) lab[j] = (uint8_t)j;
+    __syncthreads();
     if (live) {
         const int64_t s = inst_seed_col[inst];
-        cw_seed_labels<16>(ids, m, col_off[s], col_off[s + 1], col_idx, col_code, cnt, l);
+        for (int64_t e = col_off[s] + l; e < col_off[s + 1]; e += 16) {
+            const int j = local_index(s_ids, m, col_idx[e]);
+            if (j >= 0) atomicMin(&cnt[col_code[e]], j);
+        }
     }
     wave_sync_lds();
     if (live) {
         const int64_t s = inst_seed_col[inst];
         for (int64_t e = col_off[s] + l; e < col_off[s + 1]; e += 16) {
-            const int j = local_index(ids, m, col_idx[e]);
-            if (j >= 0) lab[j] = (uint16_t)cnt[col_code[e]];
+            const int j = local_index(s_ids, m, col_idx[e]);
+            if (j >= 0) lab[j] = (uint8_t)cnt[col_code[e]];
         }
     }
     wave_sync_lds();
-    for (int j = l; j < HS_CWR_CAP; j += 16) cnt[j] = 0;
+    for (int j = l; j < cnt_cap; j += 16) cnt[j] = 0;
     wave_sync_lds();
 
     int changes = 3, iters = 0;
-    while (live && changes > 2 && iters < 15) {
-        changes = 0;
-        for (int v = 0; v < n_visit; ++v) {
-            const int i = vis[v];
-            const int o0 = (int)(off_w[i] - base), o1 = (int)(off_w[i + 1] - base);
-            unsigned best = 0u;
-            if (o1 - o0 <= 16) {          // the usual case: one neighbour per lane, its label stays in a register
-                const bool has = o0 + l < o1;
-                const int lb = has ? (int)lab[anb[o0 + l]] : 0;
-                if (has) atomicAdd(&cnt[lb], 1);
+    if (staged) {
+        while (live && changes > 2 && iters < 15) {
+            changes = 0;
+            uint32_t inf = n_visit > 0 ? s_info[0] : 0u;
+            for (int v = 0; v < n_visit; ++v) {
+                const uint32_t inf_next = v + 1 < n_visit ? s_info[v + 1] : 0u;      // off the dependent chain
+                const int i = (int)(inf & 255u), nc = (int)((inf >> 8) & 255u);
+                const uint8_t* pg = s_prog + (inf >> 16) * 16 + l;
+                unsigned best = 0u;
+                if (nc <= 4) {
+                    // up to 64 neighbours: every lane keeps its (up to four) labels in registers and the vote is taken there,
+                    // one round per distinct label of the row: X = label of the row's first lane that still holds an uncounted
+                    // one (row maximum of a (position, label) key), its count = set bits of the row's 16-bit slice of the
+                    // ballots "label == X". A handful of labels per node is the rule (the seeding groups the reads by allele);
+                    // a row that sees more than HS_CW_REG_LABELS goes through the LDS counters for this visit.
+                    const int n0 = pg[0], n1 = nc > 1 ? pg[16] : 255, n2 = nc > 2 ? pg[32] : 255, n3 = nc > 3 ? pg[48] : 255;
+                    int lb0 = -1, lb1 = -1, lb2 = -1, lb3 = -1;
+                    if (n0 != 255) lb0 = lab[n0];
+                    if (n1 != 255) lb1 = lab[n1];
+                    if (n2 != 255) lb2 = lab[n2];
+                    if (n3 != 255) lb3 = lab[n3];
+                    const int sh = (tid & 48);                 // first lane of this row inside the wavefront
+                    bool done = false;
+                    for (int round = 0; round < HS_CW_REG_LABELS; ++round) {
+                        // some label of the row that has not been counted yet (the order of the rounds does not matter)
+                        const int mine = lb0 >= 0 ? lb0 : (lb1 >= 0 ? lb1 : (lb2 >= 0 ? lb2 : lb3));
+                        const unsigned key = row_max_u32((unsigned)(mine + 1));
+                        if (key == 0u) { done = true; break; }          // (row-uniform: the rows of a wavefront leave separately)
+                        const int X = (int)key - 1;
+                        const unsigned long long b0 = __ballot(lb0 == X), b1 = __ballot(lb1 == X), b2 = __ballot(lb2 == X), b3 = __ballot(lb3 == X);
+                        const int c = __popc((unsigned)(b0 >> sh) & 0xffffu) + __popc((unsigned)(b1 >> sh) & 0xffffu) + __popc((unsigned)(b2 >> sh) & 0xffffu)
+                                    + __popc((unsigned)(b3 >> sh) & 0xffffu);
+                        const unsigned k = ((unsigned)c << 16) | (unsigned)(65535 - X);
+                        best = k > best ? k : best;
+                        if (lb0 == X) lb0 = -1;
+                        if (lb1 == X) lb1 = -1;
+                        if (lb2 == X) lb2 = -1;
+                        if (lb3 == X) lb3 = -1;
+                    }
+                    if (!done) {
+                        // more distinct labels than rounds: recount everything through the LDS counters
+                        const int m0 = n0 != 255 ? (int)lab[n0] : -1, m1 = n1 != 255 ? (int)lab[n1] : -1, m2 = n2 != 255 ? (int)lab[n2] : -1, m3 = n3 != 255 ? (int)lab[n3] : -1;
+                        best = 0u;
+                        if (m0 >= 0) atomicAdd(&cnt[m0], 1);
+                        if (m1 >= 0) atomicAdd(&cnt[m1], 1);
+                        if (m2 >= 0) atomicAdd(&cnt[m2], 1);
+                        if (m3 >= 0) atomicAdd(&cnt[m3], 1);
+                        wave_sync_lds();
+                        if (m0 >= 0) { const unsigned k = ((unsigned)cnt[m0] << 16) | (unsigned)(65535 - m0); best = k > best ? k : best; }
+                        if (m1 >= 0) { const unsigned k = ((unsigned)cnt[m1] << 16) | (unsigned)(65535 - m1); best = k > best ? k : best; }
+                        if (m2 >= 0) { const unsigned k = ((unsigned)cnt[m2] << 16) | (unsigned)(65535 - m2); best = k > best ? k : best; }
+                        if (m3 >= 0) { const unsigned k = ((unsigned)cnt[m3] << 16) | (unsigned)(65535 - m3); best = k > best ? k : best; }
+                        best = row_max_u32(best);
+                        wave_sync_lds();
+                        if (m0 >= 0) cnt[m0] = 0;
+                        if (m1 >= 0) cnt[m1] = 0;
+                        if (m2 >= 0) cnt[m2] = 0;
+                        if (m3 >= 0) cnt[m3] = 0;
+                    }
+                } else {
+                    for (int c = 0; c < nc; ++c) { const int nb = pg[c * 16]; if (nb != 255) atomicAdd(&cnt[lab[nb]], 1); }
+                    wave_sync_lds();
+                    for (int c = 0; c < nc; ++c) { const int nb = pg[c * 16]; if (nb != 255) { const int lb = lab[nb]; const unsigned k = ((unsigned)cnt[lb] << 16) | (unsigned)(65535 - lb); best = k > best ? k : best; } }
+                    best = row_max_u32(best);
+                    wave_sync_lds();
+                    for (int c = 0; c < nc; ++c) { const int nb = pg[c * 16]; if (nb != 255) cnt[lab[nb]] = 0; }
+                }
+                const int best_lab = 65535 - (int)(best & 0xffffu);      // a visited node has neighbours: the count is > 0
+                if ((int)lab[i] != best_lab) changes++;
                 wave_sync_lds();
-                if (has) best = ((unsigned)cnt[lb] << 16) | (unsigned)(65535 - lb);
-                best = row_max_u32(best);
+                if (l == 0) lab[i] = (uint8_t)best_lab;
                 wave_sync_lds();
-                if (has) cnt[lb] = 0;
-            } else {
+                inf = inf_next;
+            }
+            iters++;
+        }
+    } else {
+        while (live && changes > 2 && iters < 15) {
+            changes = 0;
+            for (int v = 0; v < n_visit; ++v) {
+                const int i = vis[v];
+                const int o0 = (int)(off_w[i] - base), o1 = (int)(off_w[i + 1] - base);
+                unsigned best = 0u;
                 for (int o = o0 + l; o < o1; o += 16) atomicAdd(&cnt[lab[anb[o]]], 1);
                 wave_sync_lds();
                 for (int o = o0 + l; o < o1; o += 16) { const int lb = lab[anb[o]]; const unsigned key = ((unsigned)cnt[lb] << 16) | (unsigned)(65535 - lb); best = key > best ? key : best; }
                 best = row_max_u32(best);
                 wave_sync_lds();
                 for (int o = o0 + l; o < o1; o += 16) cnt[lab[anb[o]]] = 0;
+                const int best_lab = 65535 - (int)(best & 0xffffu);
+                if ((int)lab[i] != best_lab) changes++;
+                wave_sync_lds();
+                if (l == 0) lab[i] = (uint8_t)best_lab;
+                wave_sync_lds();
             }
-            const int best_lab = 65535 - (int)(best & 0xffffu);      // a visited node has neighbours: the count is > 0
-            if ((int)lab[i] != best_lab) changes++;
-            wave_sync_lds();
-            if (l == 0) lab[i] = (uint16_t)best_lab;
-            wave_sync_lds();
+            iters++;
         }
-        iters++;
     }
     if (live) {
         int32_t* __restrict__ out = slab + inst_slab_off[inst];

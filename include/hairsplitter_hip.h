@@ -189,6 +189,8 @@ int hs_pack_columns(const int64_t* d_col_off, const int32_t* d_col_idx, const ui
  * Columns are the CSR produced by hs_gather_columns; col_k0 / col_k1 their two most frequent codes in the reference's
  * tie order; col_c1 the second count; col_is_cand marks candidate SNPs (loop C). Partitions are dense int8 state
  * arrays over the contig's reads (1, -1, 0, or 2 = read absent); contig c owns partitions [part_off[c], part_off[c+1]).
+ * Two kernels: lanes = partitions on a [read][partition] table built on the device (64 partitions per step), then the
+ * one-partition-at-a-time form for the few columns whose verdict hinges on the reference's order of tied second alleles.
  * d_keep[i] = 1 if column i is kept by loop C (chi2 > 15 on more than half of its reads) or rescued by loop D
  * (chi2 > 20, both alleles carried by more than four partition reads).
  * ---------------------------------------------------------------------------------------------- */
@@ -196,6 +198,7 @@ int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx,
                              const int32_t* d_col_contig, const uint8_t* d_col_k0, const uint8_t* d_col_k1,
                              const int32_t* d_col_c1, const uint8_t* d_col_is_cand, int32_t n_cols,
                              const int32_t* d_part_off, const int64_t* d_part_state_off, const int8_t* d_part_state,
+                             const int32_t* h_contig_n_reads /* HOST, [C]: reads of every contig (length of its state arrays) */, int32_t n_contigs,
                              uint8_t* d_keep, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

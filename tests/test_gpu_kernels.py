@@ -297,14 +297,15 @@ def test_stage3_result_equals_oracle_pipeline(request, batch, built):
 
 def _partition_test_case(rng, n_contigs, cols_per_contig, mode):
     """random columns x partitions; mode picks the regime: 'snp' = correlated two-allele columns, 'ties' = many codes with equal counts
-    (exercises the robin_hood order of the second allele), 'high' = codes >= 128 as most frequent (signed-char quirk)"""
+    (exercises the robin_hood order of the second allele), 'high' = codes >= 128 as most frequent (signed-char quirk), 'many' = like
+    'snp' with up to 150 partitions per contig (more than one block of 64 lanes) and columns deeper than 255 reads"""
     col_off = [0]; col_idx = []; col_code = []; col_contig = []; k0s = []; k1s = []; c1s = []; cand = []
     part_off = [0]; pso = []; states = []; nreads = []
     tot_state = 0
     for c in range(n_contigs):
-        N = int(rng.integers(6, 180))
+        N = int(rng.integers(6, 180)) if mode != "many" else int(rng.integers(200, 700))
         nreads.append(N)
-        F = int(rng.integers(0, 4))
+        F = int(rng.integers(0, 4)) if mode != "many" else int(rng.choice([1, 63, 64, 65, 150]))
         hap = rng.integers(0, 2, N)
         for f in range(F):
             st = np.where(hap == 1, 1, -1).astype(np.int8)
@@ -316,8 +317,11 @@ def _partition_test_case(rng, n_contigs, cols_per_contig, mode):
         part_off.append(len(pso))
         for _ in range(cols_per_contig):
             n = int(rng.integers(1, N + 1))
+            if mode == "many":
+                n = int(rng.choice([rng.integers(5, 70), 255, 256, rng.integers(257, max(N, 258) + 1)]))
+                n = min(n, N)
             idx = np.sort(rng.choice(N, n, replace=False)).astype(np.int32)
-            if mode == "snp":
+            if mode in ("snp", "many"):
                 a, b = rng.choice(np.arange(33, 158), 2, replace=False)
                 code = np.where(hap[idx] == 1, a, b)
                 noise = rng.random(n) < 0.08
@@ -347,13 +351,13 @@ def _partition_test_case(rng, n_contigs, cols_per_contig, mode):
                 part_state_off=np.array(pso, np.int64), part_state=cat(states, np.int8)), nreads
 
 
-@pytest.mark.parametrize("mode", ["snp", "ties", "high"])
+@pytest.mark.parametrize("mode", ["snp", "ties", "high", "many"])
 def test_column_partition_test_matches_oracle(built, mode):
     from hairsplitter_amd import api
-    rng = np.random.default_rng({"snp": 11, "ties": 12, "high": 13}[mode])
-    case, nreads = _partition_test_case(rng, 24, 60, mode)
+    rng = np.random.default_rng({"snp": 11, "ties": 12, "high": 13, "many": 14}[mode])
+    case, nreads = _partition_test_case(rng, 24 if mode != "many" else 10, 60 if mode != "many" else 40, mode)
     want, _, _ = ol.column_partition_test(n_reads_of_contig=nreads, **case)
-    got = api.column_partition_test(**case)
+    got = api.column_partition_test(n_reads=nreads, **case)
     assert np.array_equal(got, want)
     assert 0 < int(want.sum()) < len(want)          # both verdicts occur
 
