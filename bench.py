@@ -262,6 +262,8 @@ def main():
     for k in py_ms:
         py_ms[k] = 0.0
     thr0 = throttle_stats()
+    if os.environ.get("HS_CPU_PROFILE"):      # diagnostic: sampling profile of the host side over the timed steps (tools/cpuprof_report.py)
+        api.load().hs_cpuprof_start(os.environ["HS_CPU_PROFILE"].encode())
     api.kernel_stats_reset()
     t0 = time.perf_counter(); cpu0 = time.process_time()
     t_dev = 0.0; t_host = 0.0
@@ -282,6 +284,8 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3
+    if os.environ.get("HS_CPU_PROFILE"):
+        api.load().hs_cpuprof_stop()
     kstats = api.kernel_stats()
     thr1 = throttle_stats()
     throttled = None if thr0 is None or thr1 is None else {"periods": thr1[0] - thr0[0], "usec": thr1[1] - thr0[1]}
@@ -301,6 +305,8 @@ def main():
         per_step = {k: {"ms_per_step": v["ms"] / K, "launches_per_step": v["launches"] / K, "avg_launch_ms": v["ms"] / max(1, v["launches"]),
                         "algorithmic_bytes_per_launch": v["bytes"] / max(1, v["launches"]),
                         "achieved_GBs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else 0.0} for k, v in kstats.items()}
+        if not per_step:       # HS_NO_KERNEL_STATS=1 (diagnostic): no roofline leg
+            per_step = {"none": {"ms_per_step": 0.0, "launches_per_step": 0.0, "avg_launch_ms": 0.0, "algorithmic_bytes_per_launch": 0.0, "achieved_GBs": 0.0}}
         dom = max(per_step, key=lambda k: per_step[k]["ms_per_step"])
         d = per_step[dom]
         traffic = None

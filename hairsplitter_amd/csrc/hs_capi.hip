@@ -67,7 +67,22 @@ struct BlockPool {
         (host ? free_host : free_dev).push_back(std::make_pair(cap, p));
     }
 };
-BlockPool& pool() { static BlockPool* p = new BlockPool(); return *p; }
+// one pool per device: a block belongs to the device (and, for pinned host blocks, is mapped for the device) that was current
+// when it was allocated; the host threads of a shard stay on one device (hs_set_device / the sharded stage calls below)
+BlockPool& pool() {
+    static BlockPool* pools[64] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    dev &= 63;
+    BlockPool* p = __atomic_load_n(&pools[dev], __ATOMIC_ACQUIRE);
+    if (!p) {
+        std::lock_guard<std::mutex> g(mu);
+        if (!pools[dev]) __atomic_store_n(&pools[dev], new BlockPool(), __ATOMIC_RELEASE);
+        p = pools[dev];
+    }
+    return *p;
+}
 
 // RAII device buffer (pooled)
 struct DBuf {
@@ -202,13 +217,16 @@ struct KernelClock {
     std::vector<Item> items;
     hipEvent_t open_a = nullptr;
     int open_k = -1;
+    static bool enabled() { static const bool on = std::getenv("HS_NO_KERNEL_STATS") == nullptr; return on; }
     int begin(int k, hipStream_t s) {
+        if (!enabled()) return HS_OK;
         if (int rc = EventPair::get(&open_a)) return rc;
         open_k = k;
         HS_HIP(hipEventRecord(open_a, s));
         return HS_OK;
     }
     int end(int64_t bytes, hipStream_t s) {
+        if (!enabled()) return HS_OK;
         hipEvent_t b = nullptr;
         if (int rc = EventPair::get(&b)) return rc;
         HS_HIP(hipEventRecord(b, s));
@@ -218,6 +236,7 @@ struct KernelClock {
     }
     // for launches whose closing event is recorded by the callee: the item is queued, *b is recorded by the caller's callee
     int end_prepare(int64_t bytes, hipEvent_t* b) {
+        if (!enabled()) { *b = nullptr; return HS_OK; }
         if (int rc = EventPair::get(b)) return rc;
         items.push_back(Item{open_k, open_a, *b, bytes});
         open_a = nullptr; open_k = -1;
@@ -285,14 +304,28 @@ void hs_kernel_stats_reset(void) { KernelTable& t = kernel_table(); std::lock_gu
 void hs_kernel_stats_get(hs_kernel_stats* out) { if (!out) return; KernelTable& t = kernel_table(); std::lock_guard<std::mutex> g(t.mu); *out = t.st; }
 const char* hs_last_error(void) { return hs::g_err.c_str(); }
 int hs_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+static std::vector<int> device_list();
 int hs_warmup(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
-    void* p = nullptr;
-    if (hipMalloc(&p, 256) != hipSuccess) return 0;
-    hipLaunchKernelGGL(hsdev::k_swap_top2, dim3(1), dim3(64), 0, 0, (hsdev::hs_colstat_dev*)p, (const int64_t*)p, 0);   // loads the code object
-    (void)hipDeviceSynchronize();
-    (void)hipFree(p);
+    // every device the stage calls will use (HS_DEVICES / all visible), side by side: context + code object of each
+    std::vector<int> devs = device_list();
+    std::sort(devs.begin(), devs.end());
+    devs.erase(std::unique(devs.begin(), devs.end()), devs.end());
+    if (devs.empty()) devs.push_back(0);
+    auto warm_one = [](int dev) {
+        if (hipSetDevice(dev) != hipSuccess) return;
+        void* p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess) return;
+        hipLaunchKernelGGL(hsdev::k_swap_top2, dim3(1), dim3(64), 0, 0, (hsdev::hs_colstat_dev*)p, (const int64_t*)p, 0);   // loads the code object
+        (void)hipDeviceSynchronize();
+        (void)hipFree(p);
+    };
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < devs.size(); ++i) th.emplace_back(warm_one, devs[i]);
+    warm_one(devs[0]);
+    for (auto& t : th) t.join();
+    (void)hipSetDevice(devs[0]);
     return n;
 }
 int hs_set_device(int device) { HS_HIP(hipSetDevice(device)); set_wait_policy(); return HS_OK; }
@@ -1867,12 +1900,242 @@ int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_
     return hs::sr_window_size(contigs, n_contigs, amplicon != 0);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Several GPUs in one process: contigs are independent in both stages (call_variants.cpp:1276-1280, separate_reads.cpp:
+// 1506-1508), so the stage-level calls shard them over the devices of hs_devices() -- longest-processing-time on a weight
+// per contig -- one host thread (with its worker pool and HIP stream) per device; the per-shard results come back over each
+// device's own PCIe link and are merged in contig order. HS_DEVICES="0,1,.." picks the devices (default: every visible
+// one); a device may be listed more than once (two shards on one GPU: how the path is exercised on a single-GPU box).
+// ---------------------------------------------------------------------------------------------------
+static std::vector<int> device_list() {   // (extern "C" linkage block: plain static function)
+    std::vector<int> d;
+    if (const char* e = std::getenv("HS_DEVICES")) {
+        for (const char* p = e; *p;) { char* end = nullptr; const long v = std::strtol(p, &end, 10); if (end == p) break; d.push_back((int)v); p = *end == ',' ? end + 1 : end; }
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    if (d.empty()) for (int i = 0; i < n; ++i) d.push_back(i);
+    for (int& v : d) if (v < 0 || v >= n) v = 0;
+    return d;
+}
+int hs_devices(int32_t* out, int32_t cap) {
+    const std::vector<int> d = device_list();
+    for (size_t i = 0; i < d.size() && (int32_t)i < cap; ++i) out[i] = d[i];
+    return (int)d.size();
+}
+// longest-processing-time assignment, deterministic (ties by index); shards hold ascending contig ids
+static std::vector<std::vector<int>> lpt_shards(const std::vector<double>& w, int parts) {
+    std::vector<int> order(w.size());
+    for (size_t i = 0; i < w.size(); ++i) order[i] = (int)i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return w[(size_t)a] != w[(size_t)b] ? w[(size_t)a] > w[(size_t)b] : a < b; });
+    std::vector<double> load((size_t)parts, 0.0);
+    std::vector<std::vector<int>> sh((size_t)parts);
+    for (int i : order) {
+        int best = 0;
+        for (int k = 1; k < parts; ++k) if (load[(size_t)k] < load[(size_t)best]) best = k;
+        sh[(size_t)best].push_back(i); load[(size_t)best] += w[(size_t)i];
+    }
+    for (auto& v : sh) std::sort(v.begin(), v.end());
+    return sh;
+}
+// f(shard) on one host thread per shard, each bound to its device; first failure wins
+static int run_on_devices(const std::vector<int>& devs, const std::function<int(int)>& f) {
+    const int D = (int)devs.size();
+    std::vector<int> rcs((size_t)D, 0);
+    std::vector<std::string> errs((size_t)D);
+    std::vector<std::thread> th;
+    for (int k = 0; k < D; ++k)
+        th.emplace_back([&, k] {
+            if (hipSetDevice(devs[(size_t)k]) != hipSuccess) { rcs[(size_t)k] = HS_EHIP; errs[(size_t)k] = "hipSetDevice failed"; return; }
+            set_wait_policy();
+            rcs[(size_t)k] = f(k);
+            if (rcs[(size_t)k]) errs[(size_t)k] = hs_last_error();
+        });
+    for (auto& t : th) t.join();
+    for (int k = 0; k < D; ++k) if (rcs[(size_t)k]) { set_error(errs[(size_t)k]); return rcs[(size_t)k]; }
+    return HS_OK;
+}
+
 int hs_sr_run(const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate, int32_t low_memory,
               uint32_t seed, int32_t n_threads, hs_sr_result** out) {
     if (int rc = require_device()) return rc;
     if (!out || n_contigs < 0) { set_error("hs_sr_run: bad arguments"); return HS_EINVAL; }
-    HipSrOps ops;
-    return hs::sr_run(ops, contigs, n_contigs, window_size, error_rate, low_memory, seed, n_threads, out);
+    const std::vector<int> devs = device_list();
+    if (devs.size() <= 1 || n_contigs < 2) {
+        HipSrOps ops;
+        return hs::sr_run(ops, contigs, n_contigs, window_size, error_rate, low_memory, seed, n_threads, out);
+    }
+    // weight of a contig in stage 4: its sim / diff matrices (N^2) and its windows (~ length x depth)
+    std::vector<double> w((size_t)n_contigs);
+    for (int c = 0; c < n_contigs; ++c) w[(size_t)c] = 16.0 * contigs[c].n_reads * (double)contigs[c].n_reads + (double)contigs[c].n_snps * contigs[c].n_reads + 1.0;
+    const int D = (int)std::min<size_t>(devs.size(), (size_t)n_contigs);
+    const std::vector<std::vector<int>> shards = lpt_shards(w, D);
+    std::vector<hs_sr_result*> parts((size_t)D, nullptr);
+    const int per = n_threads > 0 ? std::max(1, n_threads / D) : 0;
+    const int rc = run_on_devices(std::vector<int>(devs.begin(), devs.begin() + D), [&](int k) {
+        std::vector<hs_sr_contig> sub;
+        for (int c : shards[(size_t)k]) sub.push_back(contigs[c]);
+        HipSrOps ops;
+        return hs::sr_run(ops, sub.data(), (int32_t)sub.size(), window_size, error_rate, low_memory, seed, per, &parts[(size_t)k]);
+    });
+    if (rc) { for (hs_sr_result* r : parts) if (r) hs::free_sr_result(r); return rc; }
+    // merge in contig order
+    std::vector<std::pair<int, int>> where((size_t)n_contigs);   // contig -> (shard, index in shard)
+    for (int k = 0; k < D; ++k) for (size_t i = 0; i < shards[(size_t)k].size(); ++i) where[(size_t)shards[(size_t)k][i]] = std::make_pair(k, (int)i);
+    hs_sr_result* R = (hs_sr_result*)std::calloc(1, sizeof(hs_sr_result));
+    int64_t W = 0, NL = 0;
+    for (hs_sr_result* r : parts) { W += r->win_off[r->n_contigs]; NL += r->label_off[r->win_off[r->n_contigs]]; }
+    R->n_contigs = n_contigs;
+    R->win_off = (int64_t*)std::malloc(((size_t)n_contigs + 1) * sizeof(int64_t));
+    R->win_start = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, W) * sizeof(int32_t));
+    R->win_end = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, W) * sizeof(int32_t));
+    R->label_off = (int64_t*)std::malloc(((size_t)W + 1) * sizeof(int64_t));
+    R->labels = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, NL) * sizeof(int32_t));
+    R->win_off[0] = 0; R->label_off[0] = 0;
+    int64_t w0 = 0;
+    for (int c = 0; c < n_contigs; ++c) {
+        const hs_sr_result* r = parts[(size_t)where[(size_t)c].first];
+        const int i = where[(size_t)c].second;
+        for (int64_t q = r->win_off[i]; q < r->win_off[i + 1]; ++q) {
+            R->win_start[w0] = r->win_start[q]; R->win_end[w0] = r->win_end[q];
+            const int64_t n = r->label_off[q + 1] - r->label_off[q];
+            std::memcpy(R->labels + R->label_off[w0], r->labels + r->label_off[q], (size_t)n * sizeof(int32_t));
+            R->label_off[w0 + 1] = R->label_off[w0] + n;
+            w0++;
+        }
+        R->win_off[c + 1] = w0;
+    }
+    for (hs_sr_result* r : parts) {
+        R->t_device_ms += r->t_device_ms; R->t_host_ms += r->t_host_ms; R->n_cw_instances += r->n_cw_instances;
+        for (int k = 0; k < 4; ++k) R->t_kernel_ms[k] += r->t_kernel_ms[k];
+        R->t_kernel_graph_ms += r->t_kernel_graph_ms; R->n_graph_rows_host += r->n_graph_rows_host; R->n_windows_finished_on_host += r->n_windows_finished_on_host;
+        R->n_cw_sweeps += r->n_cw_sweeps; R->cw_bytes += r->cw_bytes; R->graph_nnz += r->graph_nnz; R->n_graph_rows += r->n_graph_rows; R->simdiff_bytes += r->simdiff_bytes;
+        hs::free_sr_result(r);
+    }
+    *out = R;
+    return HS_OK;
+}
+
+// Stage 3 from host buffers (what parse_reads / parse_assembly / parse_SAM produce, flattened as for hs_cv_batch_create),
+// sharded over hs_devices(): every shard uploads its contigs, the reads its records refer to and their CIGARs to its device,
+// runs hs_cv_run there and the results are merged in contig order (error rate over the whole job, call_variants.cpp:1312-1315).
+int hs_cv_run_host(const uint8_t* h_contig_seq, const int64_t* h_contig_off, int32_t n_contigs, const uint8_t* h_read_seq, const int64_t* h_read_off,
+                   int32_t n_reads, const int32_t* h_rec_read, const int32_t* h_rec_pos, const uint8_t* h_rec_strand, const int64_t* h_rec_cig_off,
+                   const uint32_t* h_cigar, const int32_t* h_contig_rec_off, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out) {
+    if (int rc = require_device()) return rc;
+    if (!out || n_contigs < 0) { set_error("hs_cv_run_host: bad arguments"); return HS_EINVAL; }
+    const std::vector<int> devs = device_list();
+    if (devs.size() <= 1 || n_contigs < 2) {
+        hs_cv_batch* b = nullptr;
+        if (int rc = hs_cv_batch_create(h_contig_seq, h_contig_off, n_contigs, h_read_seq, h_read_off, n_reads, h_rec_read, h_rec_pos, h_rec_strand,
+                                        h_rec_cig_off, h_cigar, h_contig_rec_off, &b)) return rc;
+        const int rc = hs_cv_run(b, automatic_snp_threshold, n_threads, out);
+        hs_cv_batch_destroy(b);
+        return rc;
+    }
+    // weight of a contig in stage 3 ~ its aligned bp ~ the bases of the reads aligned to it
+    std::vector<double> w((size_t)n_contigs, 1.0);
+    for (int c = 0; c < n_contigs; ++c)
+        for (int r = h_contig_rec_off[c]; r < h_contig_rec_off[c + 1]; ++r) w[(size_t)c] += (double)(h_read_off[h_rec_read[r] + 1] - h_read_off[h_rec_read[r]]);
+    const int D = (int)std::min<size_t>(devs.size(), (size_t)n_contigs);
+    const std::vector<std::vector<int>> shards = lpt_shards(w, D);
+    std::vector<hs_cv_result*> parts((size_t)D, nullptr);
+    const int per = n_threads > 0 ? std::max(1, n_threads / D) : 0;
+    const int rc = run_on_devices(std::vector<int>(devs.begin(), devs.begin() + D), [&](int k) {
+        // the shard's own flat arrays: contigs, the reads its records use (first-use order), records, CIGARs
+        const std::vector<int>& ids = shards[(size_t)k];
+        std::vector<int64_t> c_off(1, 0), r_off(1, 0), cig_off(1, 0);
+        std::vector<int32_t> rec_off(1, 0), rec_read, rec_pos;
+        std::vector<uint8_t> rec_strand;
+        std::vector<uint8_t, hs::NoInitAlloc<uint8_t>> c_seq, r_seq;
+        std::vector<uint32_t, hs::NoInitAlloc<uint32_t>> cig;
+        std::vector<int32_t> new_id((size_t)n_reads, -1);
+        int n_sub_reads = 0;
+        int64_t c_total = 0, r_total = 0, cig_total = 0, rec_total = 0;
+        for (int c : ids) {
+            c_total += h_contig_off[c + 1] - h_contig_off[c];
+            for (int r = h_contig_rec_off[c]; r < h_contig_rec_off[c + 1]; ++r) {
+                rec_total++; cig_total += h_rec_cig_off[r + 1] - h_rec_cig_off[r];
+                if (new_id[(size_t)h_rec_read[r]] < 0) { new_id[(size_t)h_rec_read[r]] = n_sub_reads++; r_total += h_read_off[h_rec_read[r] + 1] - h_read_off[h_rec_read[r]]; }
+            }
+        }
+        c_seq.resize((size_t)c_total); r_seq.resize((size_t)r_total); cig.resize((size_t)cig_total);
+        rec_read.reserve((size_t)rec_total); rec_pos.reserve((size_t)rec_total); rec_strand.reserve((size_t)rec_total);
+        r_off.assign((size_t)n_sub_reads + 1, 0);
+        std::fill(new_id.begin(), new_id.end(), -1);
+        n_sub_reads = 0;
+        int64_t cw = 0, rw = 0, gw = 0;
+        for (int c : ids) {
+            const int64_t L = h_contig_off[c + 1] - h_contig_off[c];
+            std::memcpy(c_seq.data() + cw, h_contig_seq + h_contig_off[c], (size_t)L); cw += L; c_off.push_back(cw);
+            for (int r = h_contig_rec_off[c]; r < h_contig_rec_off[c + 1]; ++r) {
+                const int g = h_rec_read[r];
+                if (new_id[(size_t)g] < 0) {
+                    new_id[(size_t)g] = n_sub_reads;
+                    const int64_t n = h_read_off[g + 1] - h_read_off[g];
+                    std::memcpy(r_seq.data() + rw, h_read_seq + h_read_off[g], (size_t)n); rw += n;
+                    r_off[(size_t)++n_sub_reads] = rw;
+                }
+                rec_read.push_back(new_id[(size_t)g]); rec_pos.push_back(h_rec_pos[r]); rec_strand.push_back(h_rec_strand[r]);
+                const int64_t n = h_rec_cig_off[r + 1] - h_rec_cig_off[r];
+                std::memcpy(cig.data() + gw, h_cigar + h_rec_cig_off[r], (size_t)n * sizeof(uint32_t)); gw += n; cig_off.push_back(gw);
+            }
+            rec_off.push_back((int32_t)rec_read.size());
+        }
+        hs_cv_batch* b = nullptr;
+        if (int rc2 = hs_cv_batch_create(c_seq.data(), c_off.data(), (int32_t)ids.size(), r_seq.data(), r_off.data(), n_sub_reads, rec_read.data(), rec_pos.data(),
+                                         rec_strand.data(), cig_off.data(), cig.data(), rec_off.data(), &b)) return rc2;
+        const int rc2 = hs_cv_run(b, automatic_snp_threshold, per, &parts[(size_t)k]);
+        hs_cv_batch_destroy(b);
+        return rc2;
+    });
+    if (rc) { for (hs_cv_result* r : parts) if (r) hs::free_cv_result(r); return rc; }
+    std::vector<std::pair<int, int>> where((size_t)n_contigs);
+    for (int k = 0; k < D; ++k) for (size_t i = 0; i < shards[(size_t)k].size(); ++i) where[(size_t)shards[(size_t)k][i]] = std::make_pair(k, (int)i);
+    hs_cv_result* R = (hs_cv_result*)std::calloc(1, sizeof(hs_cv_result));
+    int64_t S = 0, E = 0;
+    for (hs_cv_result* r : parts) { S += r->snp_off[r->n_contigs]; E += r->col_off[r->snp_off[r->n_contigs]]; }
+    R->n_contigs = n_contigs;
+    R->mean_distance = (float*)std::malloc(std::max<size_t>(1, (size_t)n_contigs) * sizeof(float));
+    R->depth = (float*)std::malloc(std::max<size_t>(1, (size_t)n_contigs) * sizeof(float));
+    R->snp_off = (int64_t*)std::malloc(((size_t)n_contigs + 1) * sizeof(int64_t));
+    R->snp_pos = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t));
+    R->snp_ref = (uint8_t*)std::malloc(std::max<int64_t>(1, S));
+    R->snp_alt = (uint8_t*)std::malloc(std::max<int64_t>(1, S));
+    R->snp_n_ref = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t));
+    R->snp_n_alt = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t));
+    R->col_off = (int64_t*)std::malloc(((size_t)S + 1) * sizeof(int64_t));
+    R->col_idx = (int32_t*)std::malloc(std::max<int64_t>(1, E) * sizeof(int32_t));
+    R->col_code = (uint8_t*)std::malloc(std::max<int64_t>(1, E));
+    R->snp_off[0] = 0; R->col_off[0] = 0;
+    int64_t s0 = 0;
+    float total_error = 0; int n_err = 0;
+    for (int c = 0; c < n_contigs; ++c) {
+        const hs_cv_result* r = parts[(size_t)where[(size_t)c].first];
+        const int i = where[(size_t)c].second;
+        R->mean_distance[c] = r->mean_distance[i]; R->depth[c] = r->depth[i];
+        if (r->mean_distance[i] > 0) { total_error += r->mean_distance[i]; n_err++; }      // call_variants.cpp:1312-1315, contig order
+        for (int64_t q = r->snp_off[i]; q < r->snp_off[i + 1]; ++q) {
+            R->snp_pos[s0] = r->snp_pos[q]; R->snp_ref[s0] = r->snp_ref[q]; R->snp_alt[s0] = r->snp_alt[q];
+            R->snp_n_ref[s0] = r->snp_n_ref[q]; R->snp_n_alt[s0] = r->snp_n_alt[q];
+            const int64_t n = r->col_off[q + 1] - r->col_off[q];
+            std::memcpy(R->col_idx + R->col_off[s0], r->col_idx + r->col_off[q], (size_t)n * sizeof(int32_t));
+            std::memcpy(R->col_code + R->col_off[s0], r->col_code + r->col_off[q], (size_t)n);
+            R->col_off[s0 + 1] = R->col_off[s0] + n;
+            s0++;
+        }
+        R->snp_off[c + 1] = s0;
+    }
+    R->error_rate = total_error / n_err; R->n_contigs_with_error_rate = n_err;
+    for (hs_cv_result* r : parts) {
+        R->t_device_ms += r->t_device_ms; R->t_host_ms += r->t_host_ms;
+        for (int k = 0; k < 4; ++k) R->t_kernel_ms[k] += r->t_kernel_ms[k];
+        R->t_kernel_k4_ms += r->t_kernel_k4_ms;
+        R->n_columns_extracted += r->n_columns_extracted; R->n_columns_downloaded += r->n_columns_downloaded; R->n_columns_downloaded_late += r->n_columns_downloaded_late;
+        hs::free_cv_result(r);
+    }
+    *out = R;
+    return HS_OK;
 }
 
 }  // extern "C"

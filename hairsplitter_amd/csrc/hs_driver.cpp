@@ -261,8 +261,11 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         const int64_t L = b.contig_off[(size_t)gc + 1] - b.contig_off[(size_t)gc];
         const int64_t entries = b.pile_off[(size_t)b.contig_rec_off[(size_t)gc + 1]] - b.pile_off[(size_t)b.contig_rec_off[(size_t)gc]];
         o.depth = (float)((double)entries / (double)L);   // call_variants.cpp:565
-        const int n_reads_c = b.contig_rec_off[(size_t)gc + 1] - b.contig_rec_off[(size_t)gc];
-        cv_phase_ab(*cst[(size_t)c], n_reads_c, cs, o.mean_distance, automatic_snp_threshold, o);
+        const int r0 = b.contig_rec_off[(size_t)gc];
+        const int n_reads_c = b.contig_rec_off[(size_t)gc + 1] - r0;
+        std::vector<int32_t> rend((size_t)n_reads_c);
+        for (int r = 0; r < n_reads_c; ++r) rend[(size_t)r] = (int32_t)std::min<int64_t>(b.rec_pos[(size_t)(r0 + r)] + b.rec_refspan[(size_t)(r0 + r)], 0x7fffffff);
+        cv_phase_ab(*cst[(size_t)c], n_reads_c, cs, o.mean_distance, automatic_snp_threshold, o, b.rec_pos.data() + r0, rend.data());
     });
     laps.lap("phase_ab");
     // ... loops C and D on the device: one wavefront per extracted column against the contig's final partitions ...

@@ -42,7 +42,9 @@ void resolve_columns(ColumnSet& cs, int first, int last);   // columns [first, l
 struct CvContigState;   // per-contig state between the phases of the stage-3 glue (hs_host_cv.cpp)
 CvContigState* cv_state_new();
 void cv_state_free(CvContigState* st);
-void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out);
+// read_start / read_end: [n_reads] reference interval [start, end) of every record of the contig (POS-1, POS-1 + reference span)
+void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out,
+                 const int32_t* read_start, const int32_t* read_end);
 // exports the final partitions / candidate flags for the device test (K4) and imports its verdict
 void cv_export_partitions(const CvContigState& st, std::vector<int8_t>& state, std::vector<int64_t>& state_off);
 void cv_export_candidates(const CvContigState& st, uint8_t* is_cand);

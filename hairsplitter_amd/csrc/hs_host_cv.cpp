@@ -36,13 +36,20 @@ struct DensePartition {
     std::vector<int8_t> state;     // ABSENT, or mostFrequentBases in {-1,0,1}
     std::vector<int32_t> more, less;
     // the same states as bit sets over the reads (loop A compares every candidate column with every live partition:
-    // popcounts of ANDs instead of a walk over the column entries); maintained by partition_from_column() and augment()
+    // popcounts of ANDs instead of a walk over the column entries); maintained by partition_from_column() and augment().
+    // Bit k = the read of RANK k in the order of the reads' start positions: the reads of a column (all of them cover its
+    // position) and of a partition (they cover SNPs a few kb apart) then sit in a few neighbouring words, [wlo, whi], whatever
+    // the order of the records in the SAM file; only those words are looked at.
     std::vector<uint64_t> present, plus, minus;
+    const int32_t* rank_of = nullptr;
+    int wlo = 0, whi = -1;         // words that hold present reads
+    int reach = -1;                // largest (exclusive) end position of a present read: no read of the partition covers a position >= reach
     void sync_bits(int r) {
-        const uint64_t b = 1ull << (r & 63);
-        const size_t w = (size_t)r >> 6;
+        const int k = rank_of[r];
+        const uint64_t b = 1ull << (k & 63);
+        const size_t w = (size_t)k >> 6;
         const int8_t s = state[(size_t)r];
-        if (s == 2) present[w] &= ~b; else present[w] |= b;
+        if (s == 2) present[w] &= ~b; else { present[w] |= b; if (whi < wlo) { wlo = whi = (int)w; } else { if ((int)w < wlo) wlo = (int)w; if ((int)w > whi) whi = (int)w; } }
         if (s == 1) plus[w] |= b; else plus[w] &= ~b;
         if (s == -1) minus[w] |= b; else minus[w] &= ~b;
     }
@@ -175,11 +182,13 @@ struct ColumnBits {
     uint8_t slot_of[256];         // code -> slot, 0xFF = none yet; reset for the used codes at the next build
     std::vector<uint64_t> bits;   // [nslots][words]
     std::vector<uint64_t> any;    // [words]
+    int wlo = 0, whi = -1;        // words that hold reads of the column (bit = rank of the read by start position)
     ColumnBits() { std::memset(slot_of, 0xFF, sizeof(slot_of)); }
-    void build(const int32_t* idx, const uint8_t* code, int n, int n_reads) {
+    void build(const int32_t* idx, const uint8_t* code, int n, int n_reads, const int32_t* rank_of) {
         for (int k = 0; k < nslots; ++k) slot_of[code_of[k]] = 0xFF;
         words = (n_reads + 63) >> 6;
         nslots = 0;
+        wlo = words; whi = -1;
         any.assign((size_t)words, 0ull);
         if (bits.size() < (size_t)8 * words) bits.resize((size_t)8 * words);
         for (int i = 0; i < n; ++i) {
@@ -192,19 +201,25 @@ struct ColumnBits {
                 if (bits.size() < (size_t)nslots * words) bits.resize((size_t)nslots * 2 * words);
                 std::fill(bits.begin() + (size_t)k * words, bits.begin() + (size_t)(k + 1) * words, 0ull);
             }
-            const uint64_t b = 1ull << (idx[i] & 63);
-            bits[(size_t)k * words + ((size_t)idx[i] >> 6)] |= b;
-            any[(size_t)idx[i] >> 6] |= b;
+            const int rk = rank_of[idx[i]];
+            const uint64_t b = 1ull << (rk & 63);
+            bits[(size_t)k * words + ((size_t)rk >> 6)] |= b;
+            any[(size_t)rk >> 6] |= b;
+            if ((rk >> 6) < wlo) wlo = rk >> 6;
+            if ((rk >> 6) > whi) whi = rk >> 6;
         }
     }
 };
 
-// column_vs_partition() on bit sets: same result, popcounts of ANDs instead of a walk over the column entries
-static Contingency column_vs_partition_bits(const DensePartition& p, const ColumnBits& cb, uint8_t ref) {
+// column_vs_partition() on bit sets: same result, popcounts of ANDs instead of a walk over the column entries; only the
+// words both the column and the partition occupy are visited. `orig_of`: rank -> read index (the order in which the
+// reference's hash map meets the codes is the order of the READ INDICES, needed when the best count is tied)
+static Contingency column_vs_partition_bits(const DensePartition& p, const ColumnBits& cb, uint8_t ref, const int32_t* orig_of) {
     Contingency r;
     const int W = cb.words;
+    const int w0 = std::max(cb.wlo, p.wlo), w1 = std::min(cb.whi, p.whi);
     int shared = 0;
-    for (int w = 0; w < W; ++w) shared += __builtin_popcountll(cb.any[(size_t)w] & p.present[(size_t)w]);
+    for (int w = w0; w <= w1; ++w) shared += __builtin_popcountll(cb.any[(size_t)w] & p.present[(size_t)w]);
     if (shared == 0) return r;
     r.comparable = true;
     r.most = ref;
@@ -214,7 +229,7 @@ static Contingency column_vs_partition_bits(const DensePartition& p, const Colum
     for (int k = 0; k < cb.nslots; ++k) {
         const uint64_t* bk = cb.bits.data() + (size_t)k * W;
         int c = 0;
-        for (int w = 0; w < W; ++w) c += __builtin_popcountll(bk[w] & p.present[(size_t)w]);
+        for (int w = w0; w <= w1; ++w) c += __builtin_popcountll(bk[w] & p.present[(size_t)w]);
         if (c) { seen[nseen] = cb.code_of[k]; cnt[nseen] = c; slot[nseen] = k; nseen++; }
     }
     // second_from_seen() only looks at the order of `seen` when the best count is tied (the hash map is then filled in the
@@ -233,8 +248,11 @@ static Contingency column_vs_partition_bits(const DensePartition& p, const Colum
             int first[128];
             for (int i = 0; i < nseen; ++i) {
                 const uint64_t* bk = cb.bits.data() + (size_t)slot[i] * W;
-                first[i] = -1;
-                for (int w = 0; w < W; ++w) { const uint64_t x = bk[w] & p.present[(size_t)w]; if (x) { first[i] = w * 64 + __builtin_ctzll(x); break; } }
+                first[i] = 0x7fffffff;
+                for (int w = w0; w <= w1; ++w) {
+                    uint64_t x = bk[w] & p.present[(size_t)w];
+                    while (x) { const int o = orig_of[w * 64 + __builtin_ctzll(x)]; if (o < first[i]) first[i] = o; x &= x - 1; }
+                }
             }
             for (int i = 1; i < nseen; ++i)   // insertion sort by first shared appearance (a handful of codes)
                 for (int j = i; j > 0 && first[j] < first[j - 1]; --j) { std::swap(first[j], first[j - 1]); std::swap(seen[j], seen[j - 1]); std::swap(cnt[j], cnt[j - 1]); }
@@ -246,8 +264,8 @@ static Contingency column_vs_partition_bits(const DensePartition& p, const Colum
         if (cb.code_of[k] == r.most) bm = cb.bits.data() + (size_t)k * W;
         if (cb.code_of[k] == r.second) bs = cb.bits.data() + (size_t)k * W;
     }
-    if (bm) for (int w = 0; w < W; ++w) { r.n11 += __builtin_popcountll(bm[w] & p.plus[(size_t)w]); r.n01 += __builtin_popcountll(bm[w] & p.minus[(size_t)w]); }
-    if (bs && r.second != r.most) for (int w = 0; w < W; ++w) { r.n10 += __builtin_popcountll(bs[w] & p.plus[(size_t)w]); r.n00 += __builtin_popcountll(bs[w] & p.minus[(size_t)w]); }
+    if (bm) for (int w = w0; w <= w1; ++w) { r.n11 += __builtin_popcountll(bm[w] & p.plus[(size_t)w]); r.n01 += __builtin_popcountll(bm[w] & p.minus[(size_t)w]); }
+    if (bs && r.second != r.most) for (int w = w0; w <= w1; ++w) { r.n10 += __builtin_popcountll(bs[w] & p.plus[(size_t)w]); r.n00 += __builtin_popcountll(bs[w] & p.minus[(size_t)w]); }
     return r;
 }
 
@@ -267,8 +285,11 @@ static float chi_square(const Contingency& d) {
 }
 
 // Partition::Partition(Column&, pos, ref_base): Partition.cpp:32-83
-static void partition_from_column(DensePartition& p, int n_reads, const int32_t* idx, const uint8_t* code, int n, int pos, uint8_t ref) {
+static void partition_from_column(DensePartition& p, int n_reads, const int32_t* idx, const uint8_t* code, int n, int pos, uint8_t ref,
+                                  const int32_t* rank_of, const int32_t* read_end) {
     p.left = p.right = pos; p.n_occ = 1; p.n_corr = 0;
+    p.rank_of = rank_of; p.wlo = 0; p.whi = -1; p.reach = -1;
+    for (int i = 0; i < n; ++i) p.reach = std::max(p.reach, read_end[idx[i]]);
     p.state.assign(n_reads, ABSENT); p.more.assign(n_reads, 0); p.less.assign(n_reads, 0);
     const uint8_t second = second_most_frequent(code, n, nullptr, ref, false, false, 0);
     for (int i = 0; i < n; ++i) {
@@ -284,7 +305,7 @@ static void partition_from_column(DensePartition& p, int n_reads, const int32_t*
 
 // Partition::augmentPartition with the 'A'/'a'/' ' recoding of distance() folded in:
 // Partition.cpp:243-397 + call_variants.cpp:856-872
-static void augment(DensePartition& p, const int32_t* idx, const uint8_t* code, int n, const Contingency& d, int pos) {
+static void augment(DensePartition& p, const int32_t* idx, const uint8_t* code, int n, const Contingency& d, int pos, const int32_t* read_end) {
     if (pos != -1) {
         if (pos < p.left || p.left == -1) p.left = pos;
         if (pos > p.right) p.right = pos;
@@ -318,7 +339,7 @@ static void augment(DensePartition& p, const int32_t* idx, const uint8_t* code, 
         const int r = idx[i];
         const int s = cls[i] > 0 ? vA : (cls[i] < 0 ? va : 0);
         int8_t& st = p.state[r];
-        if (st == ABSENT) { st = (int8_t)s; p.more[r] = std::abs(s); p.less[r] = 0; }
+        if (st == ABSENT) { st = (int8_t)s; p.more[r] = std::abs(s); p.less[r] = 0; if (read_end[r] > p.reach) p.reach = read_end[r]; }
         else if (s == 0) { continue; /* nothing new */ }
         else if (st == 0) { st = (int8_t)s; p.more[r] = 1; p.less[r] = 0; }
         else if (s == st) { p.more[r] += 1; continue; }
@@ -452,6 +473,8 @@ static void merge_partitions(DensePartition& a, const DensePartition& b, short p
         }
     }
     if (b.hi >= b.lo) { if (a.hi < a.lo) { a.lo = b.lo; a.hi = b.hi; } else { a.lo = std::min(a.lo, b.lo); a.hi = std::max(a.hi, b.hi); } }
+    for (int r = b.lo; r <= b.hi; ++r) if (b.state[r] != ABSENT) a.sync_bits(r);   // the bit sets follow (loop B asks them whether two partitions share a read)
+    a.reach = std::max(a.reach, b.reach);
     a.n_occ += b.n_occ;
 }
 
@@ -481,7 +504,8 @@ CvContigState* cv_state_new() { return new CvContigState(); }
 void cv_state_free(CvContigState* st) { delete st; }
 
 // V1 scan + loops A and B (sequential per contig): call_variants.cpp:525-536, :590-708
-void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out) {
+void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out,
+                 const int32_t* read_start, const int32_t* read_end) {
     st.n_reads = n_reads; st.mean_distance = mean_distance; st.threshold = automatic_snp_threshold;
     const int n_cols = (int)cs.pos.size();
     const int min_reads = mean_distance < 0.015 ? 3 : 5;                       // :463-466
@@ -512,6 +536,14 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
     // ---- loop A (:590-638) ----
     std::vector<DensePartition> parts;
     ColumnBits colbits;
+    // reads ranked by start position (ties by index): the bit order of the partitions' and columns' bit sets
+    std::vector<int32_t> rank_of((size_t)n_reads), orig_of((size_t)((n_reads + 63) / 64) * 64, 0);
+    {
+        std::vector<int32_t> order((size_t)n_reads);
+        for (int r = 0; r < n_reads; ++r) order[(size_t)r] = r;
+        std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return read_start[a] != read_start[b] ? read_start[a] < read_start[b] : a < b; });
+        for (int k = 0; k < n_reads; ++k) { rank_of[(size_t)order[(size_t)k]] = k; orig_of[(size_t)k] = order[(size_t)k]; }
+    }
     int last_position = -5;
     for (int ci : cand) {
         const int pos = cs.pos[ci];
@@ -520,11 +552,14 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
         bool found = false;
         int n_corr = 0;
         const double tb0 = tim ? nowus() : 0;
-        if (!parts.empty()) colbits.build(idx, code, n, n_reads);
+        if (!parts.empty()) colbits.build(idx, code, n, n_reads, rank_of.data());
         if (tim) t_build += nowus() - tb0;
         for (size_t p = 0; p < parts.size(); ++p) {
             if (std::abs(pos - parts[p].right) > 50000) continue;
-            const Contingency d = column_vs_partition_bits(parts[p], colbits, cs.k0[ci]);
+            // no read of the partition reaches this position: nothing is shared, the comparison yields "not comparable", which
+            // neither correlates nor matches (:817-828) -- skipped without looking at the bit sets
+            if (pos >= parts[p].reach) continue;
+            const Contingency d = column_vs_partition_bits(parts[p], colbits, cs.k0[ci], orig_of.data());
             n_cmp++;
 #ifdef HS_SELFCHECK
             {
@@ -544,14 +579,14 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
                 || (d.n00 <= std::max(0.1 * (d.n00 + d.n01), 1.0) && d.n11 < std::max(0.1 * (d.n11 + d.n10), 1.0) && enough)) {
                 found = true; n_aug++;
                 const double ta0 = tim ? nowus() : 0;
-                augment(parts[p], idx, code, n, d, pos);
+                augment(parts[p], idx, code, n, d, pos, read_end);
                 if (tim) t_aug += nowus() - ta0;
                 break;
             }
         }
         if (!found) {
             parts.emplace_back();
-            partition_from_column(parts.back(), n_reads, idx, code, n, pos, cs.k0[ci]);
+            partition_from_column(parts.back(), n_reads, idx, code, n, pos, cs.k0[ci], rank_of.data(), read_end);
             parts.back().n_corr = n_corr;
         } else last_position = pos;
     }
@@ -567,6 +602,13 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
         if (!((p_value < 0.001 || parts[p1].n_corr > 1) && is_informative(parts[p1], mean_distance))) continue;
         bool different = true;
         for (size_t p2 = 0; p2 < finals.size(); ++p2) {
+            {   // partitions without a common read are "not comparable" (comparable == 0 -> augmented = false, :1107-1111): one AND
+                // over the few words both occupy instead of a walk over all reads of the contig
+                const DensePartition& fa = finals[p2]; const DensePartition& fb = parts[p1];
+                bool any = false;
+                for (int w = std::max(fa.wlo, fb.wlo); w <= std::min(fa.whi, fb.whi) && !any; ++w) any = (fa.present[(size_t)w] & fb.present[(size_t)w]) != 0;
+                if (!any) continue;
+            }
             const PartPartDistance d = partition_vs_partition(finals[p2], parts[p1], 2);
             if (d.augmented && (d.n00 + d.n11 > 5 * (d.n01 + d.n10) || d.n10 + d.n01 > 5 * (d.n00 + d.n11))
                 && d.n10 < std::max(2, 2 * d.n01) && d.n01 < std::max(2, 2 * d.n10)) {

@@ -85,26 +85,18 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
         return load_rc == HS_EIO ? 1 : EXIT_FAILURE;
     }
     std::cout << " - Calling variants on each contig\n";
-    hs_cv_batch* batch = nullptr;
     const int C = (int)in.contig_names.size();
-    if (int rc = hs_cv_batch_create(in.contig_seq.data(), in.contig_off.data(), C, in.read_seq.data(), in.read_off.data(),
-                                    (int)in.read_names.size(), in.rec_read.data(), in.rec_pos.data(), in.rec_strand.data(),
-                                    in.rec_cig_off.data(), in.cigar.data(), in.contig_rec_off.data(), &batch)) {
+    hs_cv_result* res = nullptr;   // upload + stage 3, sharded over the visible devices (HS_DEVICES) when there are several
+    if (int rc = hs_cv_run_host(in.contig_seq.data(), in.contig_off.data(), C, in.read_seq.data(), in.read_off.data(),
+                                (int)in.read_names.size(), in.rec_read.data(), in.rec_pos.data(), in.rec_strand.data(),
+                                in.rec_cig_off.data(), in.cigar.data(), in.contig_rec_off.data(), automatic_snp_threshold, num_threads, &res)) {
         std::cout << "ERROR: " << hs_last_error() << " (" << rc << ")" << std::endl;
         return EXIT_FAILURE;
     }
-    clk.lap("batch create (H2D)");
-    hs_cv_result* res = nullptr;
-    if (int rc = hs_cv_run(batch, automatic_snp_threshold, num_threads, &res)) {
-        std::cout << "ERROR: " << hs_last_error() << " (" << rc << ")" << std::endl;
-        hs_cv_batch_destroy(batch);
-        return EXIT_FAILURE;
-    }
-    clk.lap("hs_cv_run");
+    clk.lap("hs_cv_run_host (H2D + stage 3)");
     hs::write_cv_outputs(in, res, error_rate_out, file_out, vcf_file, num_threads);
     clk.lap("write .col/.vcf");
     hs_cv_result_destroy(res);
-    hs_cv_batch_destroy(batch);
     return 0;
 }
 

@@ -302,6 +302,19 @@ typedef struct hs_cv_result {
 
 int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out);
 
+/* Several GPUs in one process. Contigs are the independent units of both stages (call_variants.cpp:1276-1280,
+ * separate_reads.cpp:1506-1508): hs_cv_run_host and hs_sr_run shard them over the devices of hs_devices() by
+ * longest-processing-time (stage 3: bases of the reads aligned to the contig; stage 4: N^2 + N * S), one host thread and one
+ * device per shard, results merged in contig order (the error rate over the whole job). hs_devices: the device list =
+ * HS_DEVICES="0,1,.." or every visible device; a device may be listed more than once (two shards on one GPU).
+ * hs_cv_run_host = hs_cv_batch_create + hs_cv_run + destroy per shard (host buffers as for hs_cv_batch_create). */
+int hs_devices(int32_t* out, int32_t cap);       /* returns the number of devices of the list */
+int hs_cv_run_host(const uint8_t* h_contig_seq, const int64_t* h_contig_off, int32_t n_contigs,
+                   const uint8_t* h_read_seq, const int64_t* h_read_off, int32_t n_reads,
+                   const int32_t* h_rec_read, const int32_t* h_rec_pos, const uint8_t* h_rec_strand,
+                   const int64_t* h_rec_cig_off, const uint32_t* h_cigar, const int32_t* h_contig_rec_off,
+                   float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out);
+
 /* hs_cv_run in two steps, for hosts that overlap the sequential glue of several contig groups:
  * hs_cv_select = the streaming pass over the WHOLE batch (K0 CIGAR scan, K1 pileup, K2 column statistics; one launch each),
  * hs_cv_run_range = everything after it (K3, partitions, K4, merge) for the contigs [c0, c1) of the batch. Contigs are

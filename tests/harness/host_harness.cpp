@@ -340,12 +340,14 @@ int main(int argc, char** argv) {
         meta.n_contigs = (int)in.contig_names.size(); meta.n_rec = (int)in.rec_read.size();
         meta.contig_off = in.contig_off; meta.contig_rec_off = in.contig_rec_off; meta.total_len = in.contig_off.back();
         meta.pile_off.assign((size_t)meta.n_rec + 1, 0);
+        meta.rec_pos = in.rec_pos; meta.rec_refspan.assign((size_t)meta.n_rec, 0);
         for (int c = 0; c < meta.n_contigs; ++c) {
             const int64_t L = in.contig_off[(size_t)c + 1] - in.contig_off[(size_t)c];
             for (int r = in.contig_rec_off[(size_t)c]; r < in.contig_rec_off[(size_t)c + 1]; ++r) {
                 int64_t span = 0;
                 for (int64_t o = in.rec_cig_off[(size_t)r]; o < in.rec_cig_off[(size_t)r + 1]; ++o) { uint32_t k = in.cigar[(size_t)o] & 15u; if (k == 0 || k == 2 || k == 7 || k == 8) span += in.cigar[(size_t)o] >> 4; }
                 const int64_t pos = in.rec_pos[(size_t)r];
+                meta.rec_refspan[(size_t)r] = span;
                 const int64_t qend = pos >= L ? pos : std::min(pos + span, L);
                 meta.pile_off[(size_t)r + 1] = meta.pile_off[(size_t)r] + (qend - pos);
             }

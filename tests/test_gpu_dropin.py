@@ -35,6 +35,35 @@ def test_dropin_binaries_with_the_alternative_paths(built, case, switch):
         assert gu.compare(td, outs) == []
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0,0"])
+@pytest.mark.parametrize("case", ["multi", "linked", "simple_mock", "tetra25k_ploidy2"])
+def test_dropin_binaries_sharded_over_devices(built, case, devices):
+    """Several GPUs in one process (hs_cv_run_host / hs_sr_run shard the contigs over hs_devices() by LPT, one host thread per
+    device, results merged in contig order). HS_DEVICES may list a device more than once: on this single-GPU box every shard
+    runs on device 0, which exercises the sharding, the per-shard batches with remapped reads and the merge -- the outputs
+    must still be the reference's."""
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack(case, td)
+        outs = gu.run_stage_pair([built["cv"]], [built["sr"]], td, meta, env=dict(os.environ, HS_DEVICES=devices))
+        assert gu.compare(td, outs) == []
+
+
+def test_device_list_follows_the_environment(built):
+    import ctypes
+    from hairsplitter_amd import api
+    lib = api.load()
+    buf = (ctypes.c_int32 * 16)()
+    old = os.environ.get("HS_DEVICES")
+    try:
+        os.environ["HS_DEVICES"] = "0,0,0"
+        assert lib.hs_devices(buf, 16) == 3 and list(buf[:3]) == [0, 0, 0]
+        os.environ.pop("HS_DEVICES")
+        assert lib.hs_devices(buf, 16) == lib.hs_device_count()
+    finally:
+        if old is not None:
+            os.environ["HS_DEVICES"] = old
+
+
 def test_inmemory_labels_to_gaf(built):
     """resident batch -> pipeline -> hs_gaf_from_labels, never touching .col / .gro text == drop-in executables -> hs_gro_to_gaf"""
     from hairsplitter_amd import api, synth
