@@ -433,6 +433,17 @@ int hs_gaf_from_labels(const char* gfa, const char* reads, const char* sam, int3
                        const int32_t* labels, const uint8_t* contig_has_snps, const char* out_gaf, int32_t n_threads);
 int hs_gro_to_gaf_main(int argc, char** argv);
 
+/* ------------------------------------------------------------------------------------------------
+ * Upstream feeders of stage 3 that are plain text transforms (host code): the 300 kb cutter the orchestrator runs before the
+ * reads are aligned (src/cut_gfa.py:33-66, hairsplitter.py:583) and the GFA -> FASTA converter (src/gfa2fa.cpp).
+ * hs_cut_gfa_main: argv of cut_gfa.py (--assembly/-a, --length/-l, --output/-o); hs_gfa2fa_main: argv[1] = gfa, FASTA on
+ * standard output. Byte-identical to the reference's outputs (tests/golden/gfa_tools).
+ * ---------------------------------------------------------------------------------------------- */
+int hs_cut_gfa(const char* gfa_in, int64_t length, const char* gfa_out);
+int hs_gfa_to_fasta(const char* gfa_in, const char* fasta_out /* NULL or "-": standard output */);
+int hs_cut_gfa_main(int argc, char** argv);
+int hs_gfa2fa_main(int argc, char** argv);
+
 #ifdef __cplusplus
 }
 #endif
