@@ -22,7 +22,7 @@ SYMBOLS = [
     "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
-    "hs_separate_reads_main", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_devices", "hs_cv_run_host", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
+    "hs_separate_reads_main", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
 ]
 
 HS_NKERNELS = 16
@@ -845,3 +845,32 @@ def gaf_from_labels(gfa: str, reads: str, sam: str, sr: Dict, out_gaf: str, cont
     _check(load().hs_gaf_from_labels(gfa.encode(), reads.encode(), sam.encode(), C.c_int32(1 if amplicon else 0), C.c_int32(len(win_off) - 1),
                                      ptr(win_off), ptr(win_start), ptr(win_end), ptr(label_off), ptr(labels), None if has is None else ptr(has),
                                      out_gaf.encode(), C.c_int32(n_threads)))
+
+
+def edlib_hw_align(pairs, path=True):
+    """A1 as stage 5 uses edlib (HW, k = -1, TASK_PATH): list of (query, target) strings over ACGT -> list of dicts
+    {distance, start, end, ops (numpy uint8 of edlib move codes) or None}"""
+    import torch
+    require_gpu()
+    dev = "cuda:0"
+    code = np.full(256, 3, np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    enc = lambda x: code[np.frombuffer(x.encode(), dtype=np.uint8)] if x else np.zeros(0, np.uint8)
+    qs = [enc(q) for q, _ in pairs]; ts = [enc(t) for _, t in pairs]
+    n = len(pairs)
+    qo = np.zeros(n + 1, np.int64); to = np.zeros(n + 1, np.int64); oo = np.zeros(n + 1, np.int64)
+    np.cumsum([len(x) for x in qs], out=qo[1:]); np.cumsum([len(x) for x in ts], out=to[1:]); np.cumsum([len(a) + len(b) for a, b in zip(qs, ts)], out=oo[1:])
+    cat = lambda xs: np.concatenate(xs) if xs and sum(len(x) for x in xs) else np.zeros(1, np.uint8)
+    dq = torch.from_numpy(cat(qs)).to(dev); dt = torch.from_numpy(cat(ts)).to(dev)
+    dd = torch.zeros(max(n, 1), dtype=torch.int32, device=dev); ds = torch.zeros_like(dd); de = torch.zeros_like(dd); dl = torch.zeros_like(dd)
+    dops = torch.zeros(max(int(oo[-1]), 1), dtype=torch.uint8, device=dev)
+    _check(load().hs_edlib_hw_align(_p(dq), _hp(qo, C.c_int64), _p(dt), _hp(to, C.c_int64), C.c_int32(n), _p(dd), _p(ds), _p(de),
+                                    _p(dops) if path else C.c_void_p(0), _hp(oo, C.c_int64), _p(dl), C.c_void_p(0)))
+    torch.cuda.synchronize()
+    dd, ds, de, dl, ops = dd.cpu().numpy(), ds.cpu().numpy(), de.cpu().numpy(), dl.cpu().numpy(), dops.cpu().numpy()
+    out = []
+    for i in range(n):
+        out.append({"distance": int(dd[i]), "start": int(ds[i]), "end": int(de[i]),
+                    "ops": ops[oo[i]:oo[i] + dl[i]].copy() if path and dl[i] >= 0 else None})
+    return out

@@ -25,6 +25,7 @@
 #include "hs_kernels.hip"
 #include "hs_kernels_graph.hip"
 #include "hs_kernels_cw.hip"
+#include "hs_kernels_myers.hip"
 
 namespace hs {
 static thread_local std::string g_err;
@@ -809,6 +810,38 @@ int hs_edit_distance(const uint8_t* d_query, const int64_t* d_query_off, const u
     HS_HIP(hipGetLastError());
     if (int rc_w = stream_wait((hipStream_t)stream)) return rc_w;
     return HS_OK;
+}
+
+// A1 as the stage-5 call sites use edlib: HW mode, k = -1, TASK_PATH (see hs_kernels_myers.hip). Host offsets; the device
+// buffers of the sequences and results are the caller's. d_ops may be NULL (locations only: edlib's TASK_LOC).
+int hs_edlib_hw_align(const uint8_t* d_query, const int64_t* h_query_off, const uint8_t* d_target, const int64_t* h_target_off, int32_t n_pairs,
+                      int32_t* d_dist, int32_t* d_start, int32_t* d_end, uint8_t* d_ops, const int64_t* h_ops_off, int32_t* d_ops_len, void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_pairs <= 0) return HS_OK;
+    if (!h_query_off || !h_target_off || !d_dist || !d_start || !d_end || (d_ops && (!h_ops_off || !d_ops_len))) { set_error("hs_edlib_hw_align: bad arguments"); return HS_EINVAL; }
+    const bool path = d_ops != nullptr;
+    std::vector<int64_t> hs_off((size_t)n_pairs + 1, 0), st_off((size_t)n_pairs + 1, 0), qo(h_query_off, h_query_off + n_pairs + 1), to(h_target_off, h_target_off + n_pairs + 1),
+        oo;
+    for (int i = 0; i < n_pairs; ++i) {
+        const int64_t qn = qo[(size_t)i + 1] - qo[(size_t)i], tn = to[(size_t)i + 1] - to[(size_t)i];
+        hs_off[(size_t)i + 1] = hs_off[(size_t)i] + tn + 64;
+        const int64_t nb = (qn + 63) / 64;
+        st_off[(size_t)i + 1] = st_off[(size_t)i] + (path && nb <= 64 ? tn * nb * 3 : 0);
+        if (path && h_ops_off[i + 1] - h_ops_off[i] < qn + tn) { set_error("hs_edlib_hw_align: an alignment needs room for query + target operations"); return HS_EINVAL; }
+    }
+    if (path) oo.assign(h_ops_off, h_ops_off + n_pairs + 1);
+    DBuf d_qo, d_to, d_ho, d_so, d_oo, d_hs, d_st;
+    UploadPack pk;
+    pk.add(qo, d_qo); pk.add(to, d_to); pk.add(hs_off, d_ho); pk.add(st_off, d_so);
+    if (path) pk.add(oo, d_oo);
+    if (int rc = pk.commit((hipStream_t)stream)) return rc;
+    if (int rc = d_hs.alloc((size_t)hs_off.back())) return rc;
+    if (int rc = d_st.alloc(std::max<size_t>((size_t)st_off.back(), 1) * 8)) return rc;
+    hipLaunchKernelGGL(hsdev::k_myers_hw_path, dim3((unsigned)n_pairs), dim3(64), 0, (hipStream_t)stream, d_query, d_qo.as<int64_t>(), d_target, d_to.as<int64_t>(),
+                       n_pairs, d_hs.as<int8_t>(), d_ho.as<int64_t>(), d_st.as<unsigned long long>(), d_so.as<int64_t>(), path ? 1 : 0, d_dist, d_start, d_end,
+                       d_ops, path ? d_oo.as<int64_t>() : nullptr, d_ops_len);
+    HS_HIP(hipGetLastError());
+    return stream_wait((hipStream_t)stream);   // the scratch goes back to the pool with this scope
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,187 @@
+// hs_kernels_myers.hip -- A1 for the stage-5 call sites: what the reference asks of its bundled edlib
+// there is edlibAlign(query, target, k = -1, EDLIB_MODE_HW, EDLIB_TASK_PATH) (create_new_contigs.cpp:558-629,
+// tools.cpp:515-534) -- edit distance, first end location, its start location and one optimal alignment -- for a 200-300 bp
+// query against a target of a few hundred to a few thousand bases. One wavefront per pair, three Myers sweeps (lane b owns
+// query block b, anti-diagonal schedule as in k_myers):
+//   1. HW (infix): minimum of the bottom row, FIRST column that attains it            (edlib.cpp:560-700; the k-doubling of
+//      edlibAlign :194-214 only bounds the band of the reference's own search: the optimum it returns is the exact one)
+//   2. SHW of the reversed query on the reversed target prefix that ends there, LAST best column = the start location
+//      (:226-258: "taking last location as start ensures that alignment will not start with insertions")
+//   3. NW on target[start .. end] with the vertical delta words (P, M) and the bottom score of every (column, block) kept
+//      (:737-930 with findAlignment), then the traceback of :947-1130 by lane 0: up (insertion) before left (deletion) before
+//      the diagonal, on exact cell scores recomputed from the stored words.
+// Alignment ops as edlib's: 0 match, 1 insertion (query base without target base), 2 deletion, 3 mismatch.
+// Sequences are 2-bit base codes (A C G T), as everywhere on this path. Included by hs_capi.hip after hs_kernels.hip.
+#pragma once
+
+namespace hsdev {
+
+struct MyersSeq {              // a sequence seen forwards or backwards
+    const uint8_t* p; int n; bool rev;
+    __device__ __forceinline__ int at(int i) const { return (int)(p[rev ? n - 1 - i : i] & 3); }
+};
+
+// One sweep. mode 0 NW, 1 SHW, 2 HW. Outputs through references (valid in every lane): final bottom-row score of the
+// last column, best bottom-row score over the columns, first and last column attaining it (-1: before the target).
+// store != nullptr (single pass only: <= 64 blocks): P, M, bottom score of every (column, block) at store[(col * nblocks + blk) * 3 ...]
+// as three 64-bit words {P, M, score}.
+static __device__ void myers_sweep(const MyersSeq& q, const MyersSeq& t, int mode, int8_t* __restrict__ hb, uint8_t* tbuf /* LDS [MY_TCHUNK + 64] */,
+                                   unsigned long long* __restrict__ store, int& out_score, int& out_best, int& out_first, int& out_last) {
+    const int lane = lane_id();
+    const int qn = q.n, tn = t.n;
+    const int nblocks = (qn + 63) >> 6;
+    const int last_row = (qn - 1) & 63;
+    int score = qn, best = qn, best_first = -1, best_last = -1;
+    for (int pb = 0; pb < nblocks; pb += 64) {
+        const int blk = pb + lane;
+        const bool bvalid = blk < nblocks;
+        const bool is_last_blk = blk == nblocks - 1;
+        const int nb_pass = (nblocks - pb) < 64 ? (nblocks - pb) : 64;
+        uint64_t peq[4] = {0, 0, 0, 0};
+        if (bvalid) {
+            const int rbase = blk << 6;
+            for (int k = 0; k < 64; ++k) {
+                const int row = rbase + k;
+                if (row < qn) peq[q.at(row)] |= 1ull << k;
+            }
+        }
+        uint64_t Pv = ~0ull, Mv = 0ull;
+        int hout_prev = 0;
+        int bottom = (blk + 1) << 6;          // D[64 blk + 63][-1]
+        const int nsteps = tn + nb_pass - 1;
+        for (int s0 = 0; s0 < nsteps; s0 += MY_TCHUNK) {
+            __builtin_amdgcn_wave_barrier();
+            for (int x = lane; x < MY_TCHUNK + 64; x += 64) {
+                const int col = s0 - 63 + x;
+                tbuf[x] = (col >= 0 && col < tn) ? (uint8_t)t.at(col) : (uint8_t)0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int s_end = (s0 + MY_TCHUNK) < nsteps ? (s0 + MY_TCHUNK) : nsteps;
+            for (int s = s0; s < s_end; ++s) {
+                const int j = s - lane;
+                const int hin_up = __shfl_up(hout_prev, 1, 64);
+                const bool work = bvalid && j >= 0 && j < tn;
+                int hin;
+                if (lane == 0) hin = pb == 0 ? (mode == 2 ? 0 : 1) : (work ? (int)hb[j] : 0);
+                else hin = hin_up;
+                if (work) {
+                    const int sym = tbuf[(s - s0) + 63 - lane] & 3;
+                    uint64_t Eq = peq[sym];
+                    const uint64_t Xv = Eq | Mv;
+                    if (hin < 0) Eq |= 1ull;
+                    const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                    uint64_t Ph = Mv | ~(Xh | Pv);
+                    uint64_t Mh = Pv & Xh;
+                    int hout = 0;
+                    if (Ph >> 63) hout = 1; else if (Mh >> 63) hout = -1;
+                    bottom += hout;
+                    if (is_last_blk) {
+                        score += (int)((Ph >> last_row) & 1ull) - (int)((Mh >> last_row) & 1ull);
+                        if (mode != 0) {
+                            if (score < best) { best = score; best_first = j; best_last = j; }
+                            else if (score == best) best_last = j;
+                        }
+                    }
+                    Ph <<= 1; Mh <<= 1;
+                    if (hin < 0) Mh |= 1ull; else if (hin > 0) Ph |= 1ull;
+                    Pv = Mh | ~(Xv | Ph);
+                    Mv = Ph & Xv;
+                    hout_prev = hout;
+                    if (lane == nb_pass - 1 && !is_last_blk) hb[j] = (int8_t)hout;
+                    if (store) {
+                        unsigned long long* o = store + ((int64_t)j * nblocks + blk) * 3;
+                        o[0] = Pv; o[1] = Mv; o[2] = (unsigned long long)(long long)bottom;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int owner = (nblocks - 1) & 63;
+    out_score = __shfl(score, owner, 64); out_best = __shfl(best, owner, 64);
+    out_first = __shfl(best_first, owner, 64); out_last = __shfl(best_last, owner, 64);
+}
+
+// exact score of cell (row, col) of the NW matrix from the stored words; boundaries as edlib's (:980-984)
+static __device__ __forceinline__ int myers_cell(const unsigned long long* __restrict__ store, int nblocks, int row, int col) {
+    if (row < 0) return col + 1;
+    if (col < 0) return row + 1;
+    const unsigned long long* o = store + ((int64_t)col * nblocks + (row >> 6)) * 3;
+    const int k = row & 63;
+    const unsigned long long above = k == 63 ? 0ull : (~0ull << (k + 1));      // the rows of the block below this one
+    return (int)(long long)o[2] - __popcll(o[0] & above) + __popcll(o[1] & above);
+}
+
+__global__ __launch_bounds__(64) void k_myers_hw_path(
+    const uint8_t* __restrict__ query, const int64_t* __restrict__ query_off, const uint8_t* __restrict__ target,
+    const int64_t* __restrict__ target_off, int n_pairs, int8_t* __restrict__ hscratch, const int64_t* __restrict__ hscratch_off,
+    unsigned long long* __restrict__ store, const int64_t* __restrict__ store_off, int want_path,
+    int32_t* __restrict__ dist, int32_t* __restrict__ start_loc, int32_t* __restrict__ end_loc,
+    uint8_t* __restrict__ ops, const int64_t* __restrict__ ops_off, int32_t* __restrict__ ops_len) {
+    __shared__ uint8_t tbuf[MY_TCHUNK + 64];
+    const int lane = lane_id();
+    const int pr = (int)blockIdx.x;
+    if (pr >= n_pairs) return;
+    const uint8_t* qp = query + query_off[pr];
+    const int qn = (int)(query_off[pr + 1] - query_off[pr]);
+    const uint8_t* tp = target + target_off[pr];
+    const int tn = (int)(target_off[pr + 1] - target_off[pr]);
+    int8_t* hb = hscratch + hscratch_off[pr];
+    uint8_t* op = ops ? ops + ops_off[pr] : nullptr;
+    if (qn == 0 || tn == 0) {      // edlib.cpp:174-191: distance = query length, end location -1, no start location / path
+        if (lane == 0) { dist[pr] = qn; end_loc[pr] = -1; start_loc[pr] = -1; if (ops_len) ops_len[pr] = 0; }
+        return;
+    }
+    int sc, best, first, last;
+    // 1. HW: distance and first end location
+    myers_sweep(MyersSeq{qp, qn, false}, MyersSeq{tp, tn, false}, 2, hb, tbuf, nullptr, sc, best, first, last);
+    const int d = best, e = first;
+    if (e < 0) {   // the whole query before the target (:233-246): start location 0, the alignment over an empty target is all insertions (:1171-1178)
+        if (lane == 0) {
+            dist[pr] = d; end_loc[pr] = -1; start_loc[pr] = 0;
+            if (want_path && op) { for (int i = 0; i < qn; ++i) op[i] = 1; ops_len[pr] = qn; }
+        }
+        return;
+    }
+    // 2. start location: reversed query against the reversed target prefix [0, e], last best column
+    myers_sweep(MyersSeq{qp, qn, true}, MyersSeq{tp, e + 1, true}, 1, hb, tbuf, nullptr, sc, best, first, last);
+    const int st = e - last;
+    if (lane == 0) { dist[pr] = d; end_loc[pr] = e; start_loc[pr] = st; }
+    if (!want_path || !ops) return;
+    // 3. NW on target[st .. e] with the columns kept, traceback
+    const int an = e - st + 1;
+    const int nblocks = (qn + 63) >> 6;
+    if (nblocks > 64) { if (lane == 0) ops_len[pr] = -1; return; }          // (queries beyond 4096 bases: distance and locations only)
+    unsigned long long* sto = store + store_off[pr];
+    myers_sweep(MyersSeq{qp, qn, false}, MyersSeq{tp + st, an, false}, 0, hb, tbuf, sto, sc, best, first, last);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        int row = qn - 1, col = an - 1, cur = sc, n = 0;
+        while (true) {
+            const int u = myers_cell(sto, nblocks, row - 1, col);
+            if (u + 1 == cur) {                                   // up: insertion (:1022-1055)
+                op[n++] = 1; cur = u; row--;
+                if (row < 0) { for (int i = 0; i < col + 1; ++i) op[n++] = 2; break; }
+                continue;
+            }
+            const int l = myers_cell(sto, nblocks, row, col - 1);
+            if (l + 1 == cur) {                                   // left: deletion (:1057-1087)
+                op[n++] = 2; cur = l; col--;
+                if (col < 0) { for (int i = 0; i < row + 1; ++i) op[n++] = 1; break; }
+                continue;
+            }
+            const int ul = (row == 0 && col == 0) ? 0 : myers_cell(sto, nblocks, row - 1, col - 1);
+            op[n++] = ul == cur ? 0 : 3;                          // diagonal: match / mismatch (:1089-1134)
+            cur = ul; row--; col--;
+            if (col < 0) { for (int i = 0; i < row + 1; ++i) op[n++] = 1; break; }
+            if (row < 0) { for (int i = 0; i < col + 1; ++i) op[n++] = 2; break; }
+        }
+        for (int i = 0; i < n / 2; ++i) { const uint8_t x = op[i]; op[i] = op[n - 1 - i]; op[n - 1 - i] = x; }
+        ops_len[pr] = n;
+    }
+}
+
+}  // namespace hsdev

@@ -259,6 +259,17 @@ int hs_edit_distance(const uint8_t* d_query, const int64_t* d_query_off, const u
                      const int64_t* d_target_off, int32_t n_pairs, int32_t mode, int32_t* d_dist,
                      int32_t* d_end, void* stream);
 
+/* A1 as the stage-5 call sites of the reference use their bundled edlib (create_new_contigs.cpp:558-629, tools.cpp:515-534):
+ * edlibAlign(query, target, edlibNewAlignConfig(-1, EDLIB_MODE_HW, EDLIB_TASK_PATH, NULL, 0)), batched, one wavefront per
+ * pair. d_dist = editDistance, d_end = endLocations[0], d_start = startLocations[0] (edlib.cpp:226-258), d_ops[h_ops_off[i] ..
+ * + d_ops_len[i]) = alignment of pair i in edlib's move codes (0 '=', 1 insertion, 2 deletion, 3 mismatch; every pair needs
+ * room for query + target operations). d_ops == NULL: locations only (EDLIB_TASK_LOC). d_ops_len[i] = -1 where edlib
+ * itself has no alignment to offer (end location -1) or the query has more than 4096 bases. Offsets are HOST arrays [n+1];
+ * sequences are base codes 0..3. Synchronous with respect to `stream`. */
+int hs_edlib_hw_align(const uint8_t* d_query, const int64_t* h_query_off, const uint8_t* d_target, const int64_t* h_target_off,
+                      int32_t n_pairs, int32_t* d_dist, int32_t* d_start, int32_t* d_end, uint8_t* d_ops, const int64_t* h_ops_off,
+                      int32_t* d_ops_len, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Stage level (host buffers in, host buffers out). These run the whole stage exactly as the drop-in
  * executables do: device kernels for pileup / histogram / extraction / sim-diff / Chinese Whispers, host code

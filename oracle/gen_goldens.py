@@ -273,6 +273,65 @@ def gen_lib_vectors():
     # the .gro goldens. The libstdc++ permutations below come from the oracle binary (system library, not reference code).
 
 
+def gen_edlib_path_vectors():
+    """HW + PATH vectors from the reference's bundled edlib at the shapes of its stage-5 call sites (create_new_contigs.cpp:558-629,
+    tools.cpp:515-534: a 200-300 bp query inside a target of a few hundred to a few thousand bases) plus edge cases: written to
+    tests/golden/edlib_path_vectors.json"""
+    rnd = random.Random(23)
+    rs = lambda n: "".join(rnd.choice("ACGT") for _ in range(n))
+
+    def mutate(s, rate):
+        out = []
+        for c in s:
+            u = rnd.random()
+            if u < rate / 3:
+                out.append(rnd.choice("ACGT"))
+            elif u < 2 * rate / 3:
+                continue
+            elif u < rate:
+                out.append(c); out.append(rnd.choice("ACGT"))
+            else:
+                out.append(c)
+        return "".join(out)
+
+    pairs = []
+    for _ in range(120):      # stage-5 shapes: the end of a contig inside its polished version
+        q = rs(rnd.choice([200, 250, 300, 300, 300]))
+        t = rs(rnd.randint(0, 2500)) + mutate(q, rnd.choice([0.0, 0.02, 0.05, 0.12, 0.3])) + rs(rnd.randint(0, 800))
+        pairs.append((q, t))
+    for _ in range(40):       # tools.cpp:515-534: 200 bp of the consensus inside 300 bp of the backbone
+        t = rs(300)
+        a = rnd.randint(0, 100)
+        pairs.append((mutate(t[a:a + 200], rnd.choice([0.0, 0.03, 0.1])), t))
+    for _ in range(60):       # small and odd cases
+        qn = rnd.choice([1, 2, 5, 17, 63, 64, 65, 127, 128, 129, 200])
+        q = rs(qn)
+        kind = rnd.randint(0, 5)
+        if kind == 0:
+            t = rs(rnd.randint(1, 90))                       # unrelated
+        elif kind == 1:
+            t = q                                            # identical
+        elif kind == 2:
+            t = q[:max(1, qn // 2)]                          # target shorter than the query
+        elif kind == 3:
+            t = rs(rnd.randint(0, 30)) + q + rs(rnd.randint(0, 30))
+        elif kind == 4:
+            t = (q * 3)[:rnd.randint(qn, 3 * qn)]            # repeats: several optimal placements
+        else:
+            t = mutate(q, 0.4) or "A"
+        pairs.append((q, t))
+    pairs += [("CCTT", "AAGG"), ("A", "C"), ("ACGT", "ACGT"), ("AAAA", "AAAAAAAAAAAA"), ("ACGTACGT", "TTTTACGTACGTTTTT"), ("G", "G"), ("-", "ACGT"), ("ACGT", "-")]
+    lines = ["HWPATH -1 %s %s" % (q, t) for q, t in pairs]
+    res = subprocess.run([os.path.join(REF, "edlib_driver")], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.splitlines()
+    vec = []
+    for (q, t), r in zip(pairs, res):
+        d, st, en, cig = r.split()
+        vec.append({"query": "" if q == "-" else q, "target": "" if t == "-" else t, "distance": int(d), "start": int(st), "end": int(en), "cigar": cig})
+    with open(os.path.join(GOLD, "edlib_path_vectors.json"), "w") as f:
+        json.dump(vec, f)
+    print("edlib path vectors:", len(vec))
+
+
 def gen_c5u():
     """The uncut stress variant of BASELINE C5: the reference needs about 12 minutes for it (one contig = one
     thread), so its OUTPUTS are stored (tests/golden_big/c5u, ~1.2 MB) and the inputs are regenerated from the seed by the
@@ -310,10 +369,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check-oracle", action="store_true", help="also run oracle/_build/hs_oracle and report parity")
     ap.add_argument("--only", default=None)
+    ap.add_argument("--edlib-path", action="store_true", help="only tests/golden/edlib_path_vectors.json")
     ap.add_argument("--c5u", action="store_true", help="only the uncut 10 Mb variant of C5: outputs into tests/golden_big/c5u (12 minutes of the reference)")
     args = ap.parse_args()
     if args.c5u:
         return gen_c5u()
+    if args.edlib_path:
+        return gen_edlib_path_vectors()
     os.makedirs(GOLD, exist_ok=True)
     if not args.only:
         gen_lib_vectors()

@@ -484,3 +484,33 @@ def test_myers_matches_edlib_vectors_and_oracle(built):
         for k in range(len(qs)):
             od, oe = ol.edit_distance(qs[k], ts[k], mi)
             assert d[k] == od and e[k] == oe, (mode, k, d[k], od, e[k], oe)
+
+
+def test_edlib_hw_path_matches_the_reference_edlib(built):
+    """A1 as the stage-5 call sites use the reference's bundled edlib (HW, k = -1, TASK_PATH; create_new_contigs.cpp:558-629,
+    tools.cpp:515-534): edit distance, first end location, its start location and the alignment itself, move by move."""
+    from hairsplitter_amd import api
+    vec = json.load(open(os.path.join(gu.GOLD, "edlib_path_vectors.json")))
+    got = api.edlib_hw_align([(v["query"], v["target"]) for v in vec])
+    sym = "=IDX"
+    n_paths = 0
+    for v, g in zip(vec, got):
+        assert g["distance"] == v["distance"], (v["query"][:30], v["target"][:30])
+        assert g["end"] == v["end"]
+        if v["end"] >= 0:
+            assert g["start"] == v["start"]
+        if v["cigar"] != "*":
+            ops = g["ops"]
+            assert ops is not None
+            runs = []
+            for o in ops.tolist():
+                if runs and runs[-1][1] == sym[o]:
+                    runs[-1][0] += 1
+                else:
+                    runs.append([1, sym[o]])
+            assert "".join("%d%s" % (c, s) for c, s in runs) == v["cigar"]
+            n_paths += 1
+    assert n_paths > 200
+    # locations only (edlib's TASK_LOC): same numbers without the path
+    loc = api.edlib_hw_align([(v["query"], v["target"]) for v in vec[:50]], path=False)
+    assert [(g["distance"], g["end"]) for g in loc] == [(v["distance"], v["end"]) for v in vec[:50]]
