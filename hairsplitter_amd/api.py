@@ -22,7 +22,7 @@ SYMBOLS = [
     "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
-    "hs_separate_reads_main", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
+    "hs_separate_reads_main", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
 ]
 
 HS_NKERNELS = 16
@@ -874,3 +874,29 @@ def edlib_hw_align(pairs, path=True):
         out.append({"distance": int(dd[i]), "start": int(ds[i]), "end": int(de[i]),
                     "ops": ops[oo[i]:oo[i] + dl[i]].copy() if path and dl[i] >= 0 else None})
     return out
+
+
+def _string_batch(fn, lists, ints=()):
+    lib = load()
+    require_gpu()
+    n = len(lists[0])
+    arrs = [(C.c_char_p * max(n, 1))(*[x.encode() for x in l]) for l in lists]
+    iarrs = [np.ascontiguousarray(v, np.int32) for v in ints]
+    out = C.POINTER(C.c_char_p)()
+    fn.argtypes = [C.POINTER(C.c_char_p)] * len(arrs) + [C.POINTER(C.c_int32)] * len(iarrs) + [C.c_int32, C.POINTER(C.POINTER(C.c_char_p))]
+    _check(fn(*arrs, *[_hp(v, C.c_int32) for v in iarrs], C.c_int32(n), C.byref(out)))
+    res = [out[i].decode() for i in range(n)]
+    lib.hs_free_strings.argtypes = [C.POINTER(C.c_char_p), C.c_int32]
+    lib.hs_free_strings.restype = None
+    lib.hs_free_strings(out, C.c_int32(n))
+    return res
+
+
+def reattach_ends(backbones, consensuses):
+    """tools.cpp:505-536, batched"""
+    return _string_batch(load().hs_reattach_ends, [backbones, consensuses])
+
+
+def trim_polished(to_polish, newcontigs, overhang_left, overhang_right):
+    """create_new_contigs.cpp:556-629, batched"""
+    return _string_batch(load().hs_trim_polished, [to_polish, newcontigs], [overhang_left, overhang_right])

@@ -270,6 +270,16 @@ int hs_edlib_hw_align(const uint8_t* d_query, const int64_t* h_query_off, const 
                       int32_t n_pairs, int32_t* d_dist, int32_t* d_start, int32_t* d_end, uint8_t* d_ops, const int64_t* h_ops_off,
                       int32_t* d_ops_len, void* stream);
 
+/* The two stage-5 computations that sit on those edlib calls, batched (two alignments per item in ONE hs_edlib_hw_align call):
+ * hs_reattach_ends == tools.cpp:505-536 (the ends of the backbone that racon dropped are attached to the consensus again),
+ * hs_trim_polished == create_new_contigs.cpp:556-629 (the overhangs the piece was polished with are cut off the polished
+ * sequence through the alignment path of the piece's ends). Strings are NUL-terminated ACGT; *out = n malloc'ed strings,
+ * released with hs_free_strings. */
+int hs_reattach_ends(const char* const* backbone, const char* const* consensus, int32_t n, char*** out);
+int hs_trim_polished(const char* const* to_polish, const char* const* newcontig, const int32_t* overhang_left, const int32_t* overhang_right,
+                     int32_t n, char*** out);
+void hs_free_strings(char** s, int32_t n);
+
 /* ------------------------------------------------------------------------------------------------
  * Stage level (host buffers in, host buffers out). These run the whole stage exactly as the drop-in
  * executables do: device kernels for pileup / histogram / extraction / sim-diff / Chinese Whispers, host code

@@ -330,6 +330,27 @@ def gen_edlib_path_vectors():
     with open(os.path.join(GOLD, "edlib_path_vectors.json"), "w") as f:
         json.dump(vec, f)
     print("edlib path vectors:", len(vec))
+    # the two stage-5 computations around those calls (oracle/edlib_driver.cpp restates them on the reference's edlib)
+    lines, cases = [], []
+    for _ in range(40):      # tools.cpp:505-536: racon dropped some bases at both ends of the backbone
+        b = rs(rnd.randint(250, 2500))
+        cut_l, cut_r = rnd.randint(0, 60), rnd.randint(0, 60)
+        c = mutate(b[cut_l:len(b) - cut_r], rnd.choice([0.0, 0.01, 0.04]))
+        if len(c) < 10:
+            continue
+        lines.append("REATTACH 0 %s %s" % (b, c)); cases.append({"kind": "reattach", "backbone": b, "consensus": c})
+    for _ in range(40):      # create_new_contigs.cpp:556-629: the piece was polished together with its overhangs
+        ol, orr = rnd.choice([0, 50, 150, 400]), rnd.choice([0, 50, 150, 400])
+        core = rs(rnd.randint(400, 2500))
+        tp = rs(ol) + core + rs(orr)
+        nc = mutate(tp, rnd.choice([0.0, 0.01, 0.04])) if rnd.random() < 0.85 else rs(len(tp))      # sometimes "reassembled": aligns badly
+        lines.append("TRIM %d,%d %s %s" % (ol, orr, tp, nc)); cases.append({"kind": "trim", "to_polish": tp, "newcontig": nc, "overhang_left": ol, "overhang_right": orr})
+    res = subprocess.run([os.path.join(REF, "edlib_driver")], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.split("\n")
+    for c, r in zip(cases, res):
+        c["expected"] = r
+    with open(os.path.join(GOLD, "stage5_edlib_cases.json"), "w") as f:
+        json.dump(cases, f)
+    print("stage-5 call-site cases:", len(cases))
 
 
 def gen_c5u():

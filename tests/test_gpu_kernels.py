@@ -514,3 +514,19 @@ def test_edlib_hw_path_matches_the_reference_edlib(built):
     # locations only (edlib's TASK_LOC): same numbers without the path
     loc = api.edlib_hw_align([(v["query"], v["target"]) for v in vec[:50]], path=False)
     assert [(g["distance"], g["end"]) for g in loc] == [(v["distance"], v["end"]) for v in vec[:50]]
+
+
+def test_stage5_edlib_call_sites(built):
+    """The two stage-5 computations that sit on the reference's edlib calls, batched on the A1 kernel: the ends racon dropped are
+    attached again (tools.cpp:505-536) and the overhangs are cut off the polished piece (create_new_contigs.cpp:556-629).
+    Expected sequences: those lines restated around the reference's own edlib (oracle/edlib_driver.cpp)."""
+    from hairsplitter_amd import api
+    cases = json.load(open(os.path.join(gu.GOLD, "stage5_edlib_cases.json")))
+    re_ = [c for c in cases if c["kind"] == "reattach"]
+    tr = [c for c in cases if c["kind"] == "trim"]
+    assert len(re_) > 30 and len(tr) > 30
+    got = api.reattach_ends([c["backbone"] for c in re_], [c["consensus"] for c in re_])
+    assert got == [c["expected"] for c in re_]
+    got = api.trim_polished([c["to_polish"] for c in tr], [c["newcontig"] for c in tr], [c["overhang_left"] for c in tr], [c["overhang_right"] for c in tr])
+    assert got == [c["expected"] for c in tr]
+    assert any(len(c["expected"]) < len(c["newcontig"]) for c in tr)
