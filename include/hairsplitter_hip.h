@@ -438,6 +438,8 @@ int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_
  * call_variants.cpp:1215-1385 and separate_reads.cpp:1398-1790. */
 int hs_call_variants_main(int argc, char** argv);
 int hs_separate_reads_main(int argc, char** argv);
+/* for executables that _exit right after one of the two: nothing is torn down at the end (parsed inputs, results, device state) */
+void hs_main_process_exits(int yes);
 
 /* ------------------------------------------------------------------------------------------------
  * Next stage, consumer side of the .gro (host code, no device work): how every read threads through the contigs that the
