@@ -142,6 +142,10 @@ struct UploadPack {
         items.push_back(Item{v.data(), v.size() * sizeof(T), total, &dst});
         total = (total + v.size() * sizeof(T) + 255) & ~(size_t)255;
     }
+    template <class T> void add(const hs::ArrayView<T>& v, DBuf& dst) {
+        items.push_back(Item{v.data(), v.size() * sizeof(T), total, &dst});
+        total = (total + v.size() * sizeof(T) + 255) & ~(size_t)255;
+    }
     int commit(hipStream_t stream) {
         if (int rc = dev.alloc(total ? total : 256)) return rc;
         if (int rc = host.alloc(total ? total : 256)) return rc;

@@ -429,11 +429,30 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         job.cols = &ch;
         job.contig_snp_base.assign((size_t)C, 0); job.plane_off.assign((size_t)C, 0); job.out_off.assign((size_t)C, 0);
         job.n_reads.assign((size_t)C, 0); job.words.assign((size_t)C, 0);
-        ch.col_off.assign(1, 0);
         int64_t n_ent = 0, n_col = 0;
         for (int c = 0; c < C; ++c) { n_col += contigs[c].n_snps; if (contigs[c].n_snps) n_ent += contigs[c].col_off[contigs[c].n_snps] - contigs[c].col_off[0]; }
-        // layout first (a few integers per contig), then the copies on the worker threads
-        ch.col_off.resize((size_t)n_col + 1); ch.col_idx.resize((size_t)n_ent); ch.col_code.resize((size_t)n_ent);
+        // The columns of the call as ONE CSR in contig order. When the caller's arrays already are that (stage 3 hands its result
+        // over in memory: one offset array starting at 0, entries back to back) they are used where they lie.
+        bool contiguous = n_col > 0;
+        {
+            const int64_t* off_next = nullptr; const int32_t* idx0 = nullptr; const uint8_t* code0 = nullptr;
+            for (int c = 0; c < C && contiguous; ++c) {
+                const hs_sr_contig& hc = contigs[c];
+                if (hc.n_snps == 0) continue;
+                if (!idx0) { idx0 = hc.col_idx; code0 = hc.col_code; if (hc.col_off[0] != 0) contiguous = false; }
+                else if (hc.col_idx != idx0 || hc.col_code != code0 || hc.col_off != off_next) contiguous = false;
+                off_next = hc.col_off + hc.n_snps;
+            }
+        }
+        int64_t* own_off = nullptr; int32_t* own_idx = nullptr; uint8_t* own_code = nullptr;
+        if (contiguous) {
+            const hs_sr_contig* first = nullptr;
+            for (int c = 0; c < C && !first; ++c) if (contigs[c].n_snps) first = &contigs[c];
+            ch.col_off.view(first->col_off, (size_t)n_col + 1); ch.col_idx.view(first->col_idx, (size_t)n_ent); ch.col_code.view(first->col_code, (size_t)n_ent);
+        } else {
+            own_off = ch.col_off.alloc((size_t)n_col + 1); own_idx = ch.col_idx.alloc((size_t)n_ent); own_code = ch.col_code.alloc((size_t)n_ent);
+            own_off[0] = 0;
+        }
         job.snp_ref.resize((size_t)n_col); job.snp_alt.resize((size_t)n_col); job.snp_contig.resize((size_t)n_col);
         std::vector<int64_t> ent_base_of_contig((size_t)C, 0);
         {
@@ -455,10 +474,12 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
             const hs_sr_contig& hc = contigs[c];
             if (hc.n_snps == 0) return;
             const int64_t cb = col_base_of_contig[(size_t)c], e_base = ent_base_of_contig[(size_t)c], o0 = hc.col_off[0];   // col_off need not start at 0
-            for (int s = 0; s < hc.n_snps; ++s) ch.col_off[(size_t)(cb + s) + 1] = e_base + hc.col_off[s + 1] - o0;
-            const int64_t n = hc.col_off[hc.n_snps] - o0;
-            std::memcpy(ch.col_idx.data() + e_base, hc.col_idx + o0, (size_t)n * sizeof(int32_t));
-            std::memcpy(ch.col_code.data() + e_base, hc.col_code + o0, (size_t)n);
+            if (!contiguous) {
+                for (int s = 0; s < hc.n_snps; ++s) own_off[(size_t)(cb + s) + 1] = e_base + hc.col_off[s + 1] - o0;
+                const int64_t n = hc.col_off[hc.n_snps] - o0;
+                std::memcpy(own_idx + e_base, hc.col_idx + o0, (size_t)n * sizeof(int32_t));
+                std::memcpy(own_code + e_base, hc.col_code + o0, (size_t)n);
+            }
             std::memcpy(job.snp_ref.data() + cb, hc.snp_ref, (size_t)hc.n_snps);
             std::memcpy(job.snp_alt.data() + cb, hc.snp_alt, (size_t)hc.n_snps);
             std::fill(job.snp_contig.begin() + cb, job.snp_contig.begin() + cb + hc.n_snps, c);

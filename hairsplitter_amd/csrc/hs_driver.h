@@ -87,10 +87,23 @@ struct SrWindowSet {
 // per-SNP runs seeded from the SNP columns (separate_reads.cpp:1674-1705) -> merged ids (:840-874) -> run on the
 // finalize graph (:881) -> small clusters dropped + renumbered (:924-955) -> run (:970) [-> K8: the tail of
 // finalize_clustering]. Labels are local: m per window, chain window k at chain_row0[k].
+// a read-only array that either views memory of the caller (the SNP columns stage 3 just produced, already contiguous in
+// contig order) or owns a copy: no second copy of a hundred megabytes of columns per call when the first case applies
+template <class T> struct ArrayView {
+    const T* p = nullptr;
+    size_t n = 0;
+    std::vector<T> own;
+    void view(const T* ptr, size_t count) { own.clear(); p = ptr; n = count; }
+    T* alloc(size_t count) { own.resize(count); p = own.data(); n = count; return own.data(); }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
+
 struct CwChain {
-    std::vector<int64_t> col_off;          // SNP columns of all contigs, concatenated CSR [S+1]
-    std::vector<int32_t> col_idx;
-    std::vector<uint8_t> col_code;
+    ArrayView<int64_t> col_off;            // SNP columns of all contigs, concatenated CSR [S+1]
+    ArrayView<int32_t> col_idx;
+    ArrayView<uint8_t> col_code;
     std::vector<int32_t> win;              // [Wc] window index in the SrWindowSet
     std::vector<int64_t> chain_row0;       // [Wc+1] offset of the window's m labels
     std::vector<int64_t> win_seed_begin;   // [Wc+1] range of the window's per-SNP runs in seed_col
