@@ -1,0 +1,26 @@
+"""traffic.json from the summary of tools/pmc_traffic.sh: HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024 per kernel.
+usage: python tools/pmc_traffic_json.py gpurun_out/pmc_<tag>  > profiles/traffic_latest.json"""
+import collections
+import csv
+import json
+import os
+import sys
+
+root = sys.argv[1]
+rows = list(csv.DictReader(open(os.path.join(root, "summary.csv"))))
+by = collections.defaultdict(dict)
+for r in rows:
+    by[r["kernel"].strip()][r["counter"]] = (float(r["mean_per_dispatch"]), int(r["dispatches"]))
+j = json.load(open(os.path.join(root, "g0", "bench.json")))
+out = {"_note": "HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024, mean over the dispatches of "
+                "'python bench.py --steps 2 --warmup 0 --cpu-contigs 0' (the DEFAULT workload and group count), separate rocprofv3 --pmc "
+                "passes (tools/pmc_traffic.sh). Accesses of these kernels are 1-4 B per lane: the gfx950 half-counting of 16-B/lane "
+                "streaming reads (MI355X_MICROARCH.md, HBM) is not applied; Infinity-Cache hits are counted.",
+       "_config": j["config"]["config"], "_contigs": j["config"]["contigs"], "_aligned_bp": j["config"]["aligned_bp"],
+       "_groups_per_gpu": j["config"]["groups_per_gpu"], "_dispatches": {}}
+for k, v in sorted(by.items()):
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        name = k.split("<")[0]
+        out[name] = (v["FETCH_SIZE"][0] + v["WRITE_SIZE"][0]) * 1024.0
+        out["_dispatches"][name] = v["FETCH_SIZE"][1]
+print(json.dumps(out, indent=1))
