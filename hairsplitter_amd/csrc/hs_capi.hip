@@ -1192,7 +1192,7 @@ struct HipCvOps : hs::CvDeviceOps {
 struct GraphRows {
     DBuf d_oo, d_n, d_wc, d_row0, d_ids, d_rw, d_bo, d_fe, d_rank, d_rank_off;   // views into `pack`
     UploadPack pack;
-    DBuf d_off, d_nbr, d_visit, d_visit_n;
+    DBuf d_off, d_nbr, d_visit, d_visit_n, d_prog_info, d_prog_bytes, d_prog_steps;
     int64_t rows = 0, rows_dev = 0, total = 0;
     int W = 0, max_m = 1;
     std::vector<int32_t> win_m;    // [W]
@@ -1367,10 +1367,15 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
     }
     {   // visiting order of every window (hs_kernels_cw.hip)
         const int cap = std::min(((G.max_m + 63) / 64) * 64, 8192);
+        // the visit programs of the row-packed Chinese-Whispers kernel (windows with m <= 255): nnz + 15 m bytes per window
+        if (int rc = G.d_prog_info.alloc(std::max<size_t>((size_t)rows, 1) * 4)) return rc;
+        if (int rc = G.d_prog_bytes.alloc((size_t)total + 15 * (size_t)rows + 64)) return rc;
+        if (int rc = G.d_prog_steps.alloc(std::max<size_t>((size_t)W, 1) * 4)) return rc;
+        HS_HIP(hipMemsetAsync(G.d_prog_steps.p, 0, std::max<size_t>((size_t)W, 1) * 4, stream));
         if (kc) { if (int rc = kc->begin(HS_K_VISIT_LISTS, stream)) return rc; }
-        hipLaunchKernelGGL(hsdev::k_cw_visit_lists, dim3((unsigned)W), dim3(256), (size_t)cap * 4, stream, G.d_off.as<int64_t>(), G.d_row0.as<int64_t>(),
+        hipLaunchKernelGGL(hsdev::k_cw_visit_lists, dim3((unsigned)W), dim3(256), (size_t)cap * 4, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(), G.d_row0.as<int64_t>(),
                            G.d_ids.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_rank_off.as<int64_t>(), G.d_rank.as<int32_t>(), W, cap, G.d_visit.as<int32_t>(),
-                           G.d_visit_n.as<int32_t>());
+                           G.d_visit_n.as<int32_t>(), G.d_prog_info.as<uint32_t>(), G.d_prog_bytes.as<uint8_t>(), G.d_prog_steps.as<int32_t>());
         HS_HIP(hipGetLastError());
         if (kc) { if (int rc = kc->end(20 * (int64_t)rows, stream)) return rc; }   // row offsets + read id + rank in, visiting slot out
     }
@@ -1532,8 +1537,8 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = d_l3.alloc(std::max<size_t>((size_t)total_m, 1) * 4)) return rc;
         if (int rc = d_final.alloc(std::max<size_t>((size_t)total_m, 1) * 4)) return rc;
         if (int rc = d_ok.alloc(std::max<size_t>((size_t)Wc, 1))) return rc;
-        if (int rc = d_stat.alloc(32)) return rc;     // {sweeps, bytes} of the per-SNP runs, {sweeps, bytes} of the window tails
-        HS_HIP(hipMemsetAsync(d_stat.p, 0, 32, stream));
+        if (int rc = d_stat.alloc(160)) return rc;    // {sweeps, bytes} of the per-SNP runs, {sweeps, bytes} of the window tails, histogram of sweeps per run [16]
+        HS_HIP(hipMemsetAsync(d_stat.p, 0, 160, stream));
         EventPair e1, e2;
         if (int rc = e1.init()) return rc;
         if (int rc = e2.init()) return rc;
@@ -1549,8 +1554,8 @@ struct HipSrOps : hs::SrDeviceOps {
             if (lds > 48 * 1024)
                 HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_cw_seeded_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(hsdev::k_cw_seeded_rows, dim3((unsigned)n), dim3(128), lds, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(),
-                               G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), d_uw.as<int32_t>(),
-                               d_ui.as<int32_t>(), d_un.as<int32_t>(), n, d_seed.as<int64_t>(), d_is.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
+                               G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), G.d_prog_info.as<uint32_t>(),
+                               G.d_prog_bytes.as<uint8_t>(), G.d_prog_steps.as<int32_t>(), d_uw.as<int32_t>(), d_ui.as<int32_t>(), d_un.as<int32_t>(), n, d_seed.as<int64_t>(), d_is.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
                                d_col_code.as<uint8_t>(), m_cap, prog_cap, d_slab.as<int32_t>(), d_stat.as<unsigned long long>());
             HS_HIP(hipGetLastError());
         }
@@ -1588,8 +1593,8 @@ struct HipSrOps : hs::SrDeviceOps {
             // the finished labels and the per-window verdict come back first; the labels of the third run are only fetched
             // when some window has to be finished by the host code (few or none)
             HBuf h, h2, h3, h4;
-            if (int rc = h4.alloc(32)) return rc;
-            HS_HIP(hipMemcpyAsync(h4.p, d_stat.p, 32, hipMemcpyDeviceToHost, stream));
+            if (int rc = h4.alloc(160)) return rc;
+            HS_HIP(hipMemcpyAsync(h4.p, d_stat.p, 160, hipMemcpyDeviceToHost, stream));
             bool need_chain_labels = !finish;
             if (finish) {
                 if (int rc = h2.alloc(std::max<size_t>((size_t)total_m, 1) * sizeof(int32_t))) return rc;
@@ -1611,6 +1616,11 @@ struct HipSrOps : hs::SrDeviceOps {
             if (!finish && !need_chain_labels) { if (int rc = stream_wait(stream)) return rc; }
             const unsigned long long* st = (const unsigned long long*)h4.p;
             if (stats) { stats->n_instances = n_inst + 2 * (int64_t)Wc; stats->sweeps = (int64_t)(st[0] + st[2]); stats->bytes = (int64_t)(st[1] + st[3]); stats->graph_nnz = G.total; }
+            if (std::getenv("HS_TIMING")) {
+                std::string h;
+                for (int k = 0; k < 16; ++k) h += " " + std::to_string((unsigned long long)st[4 + k]);
+                std::fprintf(stderr, "[hs timing] sr: per-SNP Chinese-Whispers runs by number of sweeps (0..15+):%s\n", h.c_str());
+            }
             KernelClock::add_bytes(HS_K_CW_SEEDED, (int64_t)st[1]);
             KernelClock::add_bytes(HS_K_WINDOW_TAIL, (int64_t)st[3]);
             kc.flush();
@@ -1685,7 +1695,8 @@ int hs_read_graphs(const int32_t* d_sim, const int32_t* d_diff, const int64_t* c
     ws.ctg_rank_off.assign((size_t)n_contigs, 0);
     int64_t ro = 0;
     for (int c = 0; c < n_contigs; ++c) { ws.ctg_rank_off[(size_t)c] = ro; ro += ctg_n_reads[c]; }
-    ws.rank.assign((size_t)ro, 0);      // the visiting order is of no interest here
+    ws.rank.resize((size_t)ro);         // the visiting order is of no interest here: the identity permutation per contig
+    for (int c = 0; c < n_contigs; ++c) for (int32_t r = 0; r < ctg_n_reads[c]; ++r) ws.rank[(size_t)(ws.ctg_rank_off[(size_t)c] + r)] = r;
     for (int w = 0; w < n_windows; ++w) if (win_contig[w] < 0 || win_contig[w] >= n_contigs) { set_error("hs_read_graphs: window contig out of range"); return HS_EINVAL; }
     GraphRows G;
     float ms = 0;

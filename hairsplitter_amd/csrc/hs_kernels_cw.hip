@@ -51,9 +51,13 @@ static __device__ __forceinline__ int local_index(const int32_t* __restrict__ id
 // One workgroup (256 threads) per window.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cw_visit_lists(
-    const int64_t* __restrict__ off, const int64_t* __restrict__ win_row0, const int32_t* __restrict__ mask_ids,
+    const int64_t* __restrict__ off, const int32_t* __restrict__ nbr, const int64_t* __restrict__ win_row0, const int32_t* __restrict__ mask_ids,
     const int32_t* __restrict__ win_contig, const int64_t* __restrict__ ctg_rank_off, const int32_t* __restrict__ rank,
-    int n_windows, int cap, int32_t* __restrict__ visit, int32_t* __restrict__ visit_n) {
+    int n_windows, int cap, int32_t* __restrict__ visit, int32_t* __restrict__ visit_n,
+    // the "visit program" of windows with m <= HS_CWR_CAP for k_cw_seeded_rows (nullptr: not wanted): per visit one dword
+    // {node, chunks << 8, first chunk << 16} at prog_info[row0 + v]; the neighbour lists cut in 16-byte chunks of local ids
+    // (255 = none) at prog_bytes[off[row0] + 15 * row0 ...] (room for nnz + 15 m bytes per window); chunks in all at prog_steps[w]
+    uint32_t* __restrict__ prog_info, uint8_t* __restrict__ prog_bytes, int32_t* __restrict__ prog_steps) {
     extern __shared__ int32_t s_rank[];   // [cap] rank of every node with neighbours, -1 otherwise
     const int w = (int)blockIdx.x;
     if (w >= n_windows) return;
@@ -63,6 +67,7 @@ __global__ __launch_bounds__(256) void k_cw_visit_lists(
     const int32_t* __restrict__ rk = rank + ctg_rank_off[win_contig[w]];
     int32_t* __restrict__ out = visit + r0;
     __shared__ int s_total;
+    __shared__ int s_scan[256];
     if (tid == 0) s_total = 0;
     __syncthreads();
     // windows wider than the LDS copy are processed against global memory (rank gathers straight from `rank`)
@@ -85,6 +90,29 @@ __global__ __launch_bounds__(256) void k_cw_visit_lists(
         out[before] = j;
     }
     if (tid == 0) visit_n[w] = s_total;
+    if (!prog_info || m > HS_CWR_CAP) return;              // (block-uniform)
+    __threadfence_block();
+    __syncthreads();
+    const int n_visit = s_total;                           // <= 255
+    const int64_t base = off[r0];
+    int i = 0, deg = 0, nc = 0;
+    if (tid < n_visit) { i = out[tid]; deg = (int)(off[r0 + i + 1] - off[r0 + i]); nc = (deg + 15) >> 4; }
+    s_scan[tid] = nc;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {                    // inclusive scan of the chunk counts
+        const int a = tid >= d ? s_scan[tid - d] : 0;
+        __syncthreads();
+        s_scan[tid] += a;
+        __syncthreads();
+    }
+    const int first = s_scan[tid] - nc;
+    if (tid == 255) prog_steps[w] = s_scan[255];
+    if (tid < n_visit) {
+        prog_info[r0 + tid] = (uint32_t)i | ((uint32_t)nc << 8) | ((uint32_t)first << 16);
+        uint8_t* pb = prog_bytes + base + 15 * r0 + (int64_t)first * 16;
+        const int32_t* an = nbr + off[r0 + i];
+        for (int k = 0; k < nc * 16; ++k) pb[k] = k < deg ? (uint8_t)an[k] : (uint8_t)255;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -221,24 +249,33 @@ static __device__ __forceinline__ unsigned row_max_u32(unsigned v) {
 __global__ __launch_bounds__(128) void k_cw_seeded_rows(
     const int64_t* __restrict__ off, const int32_t* __restrict__ nbr, const int64_t* __restrict__ win_row0,
     const int32_t* __restrict__ mask_ids, const int32_t* __restrict__ visit, const int32_t* __restrict__ visit_n,
+    const uint32_t* __restrict__ prog_info, const uint8_t* __restrict__ prog_bytes, const int32_t* __restrict__ prog_steps,
     const int32_t* __restrict__ unit_win, const int32_t* __restrict__ unit_inst0, const int32_t* __restrict__ unit_n, int n_units,
     const int64_t* __restrict__ inst_seed_col, const int64_t* __restrict__ inst_slab_off, const int64_t* __restrict__ col_off,
     const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code, int m_cap, int prog_cap,
     int32_t* __restrict__ slab, unsigned long long* __restrict__ stat /* [2]: sweeps, bytes */) {
     extern __shared__ int32_t cwr_dyn[];
-    __shared__ int s_steps;
     const int tid = (int)threadIdx.x, row = tid >> 4, l = tid & 15;
     const int u = (int)blockIdx.x;
     if (u >= n_units) return;
     const int w = unit_win[u];
+    const bool live = row < unit_n[u];
+    const int inst = unit_inst0[u] + (live ? row : 0);
+    const int64_t seed = inst_seed_col[inst];              // the seeding column: issued first, needed last
     const int64_t r0 = win_row0[w];
     const int m = (int)(win_row0[w + 1] - r0);
     const int n_visit = visit_n[w];
+    const int steps = prog_steps[w];
+    const int64_t c0 = col_off[seed], c1 = col_off[seed + 1];
     const int32_t* __restrict__ ids = mask_ids + r0;
     const int32_t* __restrict__ vis = visit + r0;
     const int64_t* __restrict__ off_w = off + r0;
     const int64_t base = off_w[0];
     const int32_t* __restrict__ anb = nbr + base;
+    // up to four entries of the seeding column per lane (columns deeper than 64 reads re-read the rest below)
+    int e_r[4]; int e_c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int64_t e = c0 + l + 16 * k; e_r[k] = e < c1 ? col_idx[e] : -1; e_c[k] = e < c1 ? (int)col_code[e] : 0; }
     // LDS: info[m_cap] | ids[m_cap] | per row cnt[cnt_cap] x 8 | prog bytes[prog_cap] | per row labels bytes[m_cap] x 8
     // (cnt_cap >= 256: the counters double as the first-node-per-code table while seeding)
     const int cnt_cap = m_cap > 256 ? m_cap : 256;
@@ -247,104 +284,82 @@ __global__ __launch_bounds__(128) void k_cw_seeded_rows(
     int32_t* cnt = cwr_dyn + 2 * m_cap + row * cnt_cap;
     uint8_t* s_prog = reinterpret_cast<uint8_t*>(cwr_dyn + 2 * m_cap + 8 * cnt_cap);
     uint8_t* lab = s_prog + prog_cap + row * m_cap;
-    // ---- the visit program: chunks per visited node (all threads), their exclusive prefix (first wavefront) ----
-    for (int v = tid; v < n_visit; v += 128) {
-        const int i = vis[v];
-        const int nc = ((int)(off_w[i + 1] - off_w[i]) + 15) >> 4;       // m <= 255: at most 16 chunks
-        s_info[v] = (uint32_t)i | ((uint32_t)nc << 8);
-    }
+    // ---- the window's visit program (built once per window by k_cw_visit_lists) and read ids: three coalesced copies ----
+    const bool staged = steps * 16 <= prog_cap;
+    for (int v = tid; v < n_visit; v += 128) s_info[v] = prog_info[r0 + v];
     for (int j = tid; j < m; j += 128) s_ids[j] = ids[j];
-    __syncthreads();
-    if (tid < 64) {
-        int carry = 0;
-        for (int b0 = 0; b0 < n_visit; b0 += 64) {
-            const int v = b0 + tid;
-            const int nc = v < n_visit ? (int)((s_info[v] >> 8) & 255u) : 0;
-            const int incl = wave_scan_incl(nc);
-            const int first = carry + incl - nc;
-            if (v < n_visit) s_info[v] |= (uint32_t)(first > 65535 ? 65535 : first) << 16;
-            carry += __builtin_amdgcn_readlane(incl, 63);
-        }
-        if (tid == 0) s_steps = carry;
-    }
-    __syncthreads();
-    const bool staged = s_steps * 16 <= prog_cap && s_steps < 65535;
     if (staged) {
-        for (int v = tid; v < n_visit; v += 128) {
-            const uint32_t inf = s_info[v];
-            const int i = (int)(inf & 255u), s0 = (int)(inf >> 16);
-            const int o0 = (int)(off_w[i] - base), o1 = (int)(off_w[i + 1] - base);
-            for (int o = o0; o < ((o1 - o0 + 15) & ~15) + o0; ++o) s_prog[s0 * 16 + (o - o0)] = o < o1 ? (uint8_t)anb[o] : (uint8_t)255;
-        }
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(prog_bytes + base + 15 * r0);      // (16-byte chunks; the base may be unaligned: byte-wise below if so)
+        if ((((uintptr_t)src) & 3u) == 0) { for (int x = tid; x < steps * 4; x += 128) reinterpret_cast<uint32_t*>(s_prog)[x] = src[x]; }
+        else { const uint8_t* sb = prog_bytes + base + 15 * r0; for (int x = tid; x < steps * 16; x += 128) s_prog[x] = sb[x]; }
     }
     // ---- seeding (:1678-1691) ----
-    const bool live = row < unit_n[u];
-    const int inst = unit_inst0[u] + row;
     for (int j = l; j < cnt_cap; j += 16) cnt[j] = 0x7fffffff;
     for (int j = l; j < m_cap; j += 16) lab[j] = (uint8_t)j;
     __syncthreads();
-    if (live) {
-        const int64_t s = inst_seed_col[inst];
-        for (int64_t e = col_off[s] + l; e < col_off[s + 1]; e += 16) {
-            const int j = local_index(s_ids, m, col_idx[e]);
-            if (j >= 0) atomicMin(&cnt[col_code[e]], j);
-        }
-    }
+    int e_j[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { e_j[k] = (live && e_r[k] >= 0) ? local_index(s_ids, m, e_r[k]) : -1; if (e_j[k] >= 0) atomicMin(&cnt[e_c[k]], e_j[k]); }
+    if (live) for (int64_t e = c0 + 64 + l; e < c1; e += 16) { const int j = local_index(s_ids, m, col_idx[e]); if (j >= 0) atomicMin(&cnt[col_code[e]], j); }
     wave_sync_lds();
-    if (live) {
-        const int64_t s = inst_seed_col[inst];
-        for (int64_t e = col_off[s] + l; e < col_off[s + 1]; e += 16) {
-            const int j = local_index(s_ids, m, col_idx[e]);
-            if (j >= 0) lab[j] = (uint8_t)cnt[col_code[e]];
-        }
-    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (e_j[k] >= 0) lab[e_j[k]] = (uint8_t)cnt[e_c[k]];
+    if (live) for (int64_t e = c0 + 64 + l; e < c1; e += 16) { const int j = local_index(s_ids, m, col_idx[e]); if (j >= 0) lab[j] = (uint8_t)cnt[col_code[e]]; }
     wave_sync_lds();
     for (int j = l; j < cnt_cap; j += 16) cnt[j] = 0;
     wave_sync_lds();
 
-    int changes = 3, iters = 0;
+    // ---- the sweeps. The rows of a workgroup run the same window, so the visits, the node and its chunk count are the same
+    // for all of them: control flow is wave-uniform (scalar branches, no EXEC juggling), a row that has converged just stops
+    // storing. ----
+    int iters = 0;
+    bool active = live;
     if (staged) {
-        while (live && changes > 2 && iters < 15) {
-            changes = 0;
+        while (__ballot(active) != 0ull) {
+            int changes = 0;
             uint32_t inf = n_visit > 0 ? s_info[0] : 0u;
             for (int v = 0; v < n_visit; ++v) {
-                const uint32_t inf_next = v + 1 < n_visit ? s_info[v + 1] : 0u;      // off the dependent chain
-                const int i = (int)(inf & 255u), nc = (int)((inf >> 8) & 255u);
+                const uint32_t inf_next = s_info[v + 1 < n_visit ? v + 1 : v];        // off the dependent chain
+                const int i = (int)(inf & 255u);
+                const int nc = __builtin_amdgcn_readfirstlane((int)((inf >> 8) & 255u));
                 const uint8_t* pg = s_prog + (inf >> 16) * 16 + l;
                 unsigned best = 0u;
-                if (nc <= 4) {
-                    // up to 64 neighbours: every lane keeps its (up to four) labels in registers and the vote is taken there,
-                    // one round per distinct label of the row: X = label of the row's first lane that still holds an uncounted
-                    // one (row maximum of a (position, label) key), its count = set bits of the row's 16-bit slice of the
-                    // ballots "label == X". A handful of labels per node is the rule (the seeding groups the reads by allele);
-                    // a row that sees more than HS_CW_REG_LABELS goes through the LDS counters for this visit.
-                    const int n0 = pg[0], n1 = nc > 1 ? pg[16] : 255, n2 = nc > 2 ? pg[32] : 255, n3 = nc > 3 ? pg[48] : 255;
-                    int lb0 = -1, lb1 = -1, lb2 = -1, lb3 = -1;
-                    if (n0 != 255) lb0 = lab[n0];
-                    if (n1 != 255) lb1 = lab[n1];
-                    if (n2 != 255) lb2 = lab[n2];
-                    if (n3 != 255) lb3 = lab[n3];
-                    const int sh = (tid & 48);                 // first lane of this row inside the wavefront
-                    bool done = false;
+                const int old = (int)lab[i];
+                if (nc == 1) {
+                    // up to 16 neighbours, one per lane: how many lanes of the row hold the same label = 15 row rotations
+                    const int n0 = pg[0];
+                    const int lb = n0 != 255 ? (int)lab[n0] : -1;
+                    int cnt = 1;
+#define HS_ROT(K) { const int o = __builtin_amdgcn_update_dpp(-2, lb, 0x120 + (K), 0xf, 0xf, false); cnt += o == lb ? 1 : 0; }
+                    HS_ROT(1) HS_ROT(2) HS_ROT(3) HS_ROT(4) HS_ROT(5) HS_ROT(6) HS_ROT(7) HS_ROT(8)
+                    HS_ROT(9) HS_ROT(10) HS_ROT(11) HS_ROT(12) HS_ROT(13) HS_ROT(14) HS_ROT(15)
+#undef HS_ROT
+                    best = row_max_u32(lb >= 0 ? (((unsigned)cnt << 16) | (unsigned)(65535 - lb)) : 0u);
+                } else if (nc <= 4) {
+                    // up to 64 neighbours, up to four labels per lane in registers; one round per distinct label of the row:
+                    // the row maximum picks an uncounted label X, its count = set bits of the row's 16-bit slice of the
+                    // ballots "label == X"
+                    const int n0 = pg[0], n1 = pg[16], n2 = nc > 2 ? pg[32] : 255, n3 = nc > 3 ? pg[48] : 255;
+                    int lb0 = n0 != 255 ? (int)lab[n0] : -1, lb1 = n1 != 255 ? (int)lab[n1] : -1;
+                    int lb2 = n2 != 255 ? (int)lab[n2 & 255] : -1, lb3 = n3 != 255 ? (int)lab[n3 & 255] : -1;
+                    const int sh = tid & 48;                  // first lane of this row inside the wavefront
+                    bool left = true;
                     for (int round = 0; round < HS_CW_REG_LABELS; ++round) {
-                        // some label of the row that has not been counted yet (the order of the rounds does not matter)
                         const int mine = lb0 >= 0 ? lb0 : (lb1 >= 0 ? lb1 : (lb2 >= 0 ? lb2 : lb3));
                         const unsigned key = row_max_u32((unsigned)(mine + 1));
-                        if (key == 0u) { done = true; break; }          // (row-uniform: the rows of a wavefront leave separately)
-                        const int X = (int)key - 1;
-                        const unsigned long long b0 = __ballot(lb0 == X), b1 = __ballot(lb1 == X), b2 = __ballot(lb2 == X), b3 = __ballot(lb3 == X);
+                        if (__ballot(key != 0u) == 0ull) { left = false; break; }       // every row of the wavefront is done
+                        const int X = (int)key - 1;                                      // -1 in a row that is done: matches nothing below
+                        const unsigned long long b0 = __ballot(lb0 == X && X >= 0), b1 = __ballot(lb1 == X && X >= 0);
+                        const unsigned long long b2 = __ballot(lb2 == X && X >= 0), b3 = __ballot(lb3 == X && X >= 0);
                         const int c = __popc((unsigned)(b0 >> sh) & 0xffffu) + __popc((unsigned)(b1 >> sh) & 0xffffu) + __popc((unsigned)(b2 >> sh) & 0xffffu)
                                     + __popc((unsigned)(b3 >> sh) & 0xffffu);
-                        const unsigned k = ((unsigned)c << 16) | (unsigned)(65535 - X);
+                        const unsigned k = X >= 0 ? (((unsigned)c << 16) | (unsigned)(65535 - X)) : 0u;
                         best = k > best ? k : best;
-                        if (lb0 == X) lb0 = -1;
-                        if (lb1 == X) lb1 = -1;
-                        if (lb2 == X) lb2 = -1;
-                        if (lb3 == X) lb3 = -1;
+                        lb0 = lb0 == X ? -1 : lb0; lb1 = lb1 == X ? -1 : lb1; lb2 = lb2 == X ? -1 : lb2; lb3 = lb3 == X ? -1 : lb3;
                     }
-                    if (!done) {
-                        // more distinct labels than rounds: recount everything through the LDS counters
-                        const int m0 = n0 != 255 ? (int)lab[n0] : -1, m1 = n1 != 255 ? (int)lab[n1] : -1, m2 = n2 != 255 ? (int)lab[n2] : -1, m3 = n3 != 255 ? (int)lab[n3] : -1;
+                    if (left && __ballot((lb0 & lb1 & lb2 & lb3) >= 0 || lb0 >= 0 || lb1 >= 0 || lb2 >= 0 || lb3 >= 0) != 0ull) {
+                        // some row saw more distinct labels than rounds: everything of this visit again through the LDS counters
+                        const int m0 = n0 != 255 ? (int)lab[n0] : -1, m1 = n1 != 255 ? (int)lab[n1] : -1, m2 = n2 != 255 ? (int)lab[n2 & 255] : -1, m3 = n3 != 255 ? (int)lab[n3 & 255] : -1;
                         best = 0u;
                         if (m0 >= 0) atomicAdd(&cnt[m0], 1);
                         if (m1 >= 0) atomicAdd(&cnt[m1], 1);
@@ -371,15 +386,16 @@ __global__ __launch_bounds__(128) void k_cw_seeded_rows(
                     for (int c = 0; c < nc; ++c) { const int nb = pg[c * 16]; if (nb != 255) cnt[lab[nb]] = 0; }
                 }
                 const int best_lab = 65535 - (int)(best & 0xffffu);      // a visited node has neighbours: the count is > 0
-                if ((int)lab[i] != best_lab) changes++;
+                changes += old != best_lab ? 1 : 0;
                 wave_sync_lds();
-                if (l == 0) lab[i] = (uint8_t)best_lab;
+                if (l == 0 && active) lab[i] = (uint8_t)best_lab;
                 wave_sync_lds();
                 inf = inf_next;
             }
-            iters++;
+            if (active) { iters++; active = changes > 2 && iters < 15; }
         }
     } else {
+        int changes = 3;
         while (live && changes > 2 && iters < 15) {
             changes = 0;
             for (int v = 0; v < n_visit; ++v) {
@@ -407,6 +423,7 @@ __global__ __launch_bounds__(128) void k_cw_seeded_rows(
         if (l == 0 && stat) {
             atomicAdd(&stat[0], (unsigned long long)iters);
             atomicAdd(&stat[1], (unsigned long long)iters * (4ull * (unsigned long long)(off_w[m] - base) + 8ull * (unsigned long long)m));
+            atomicAdd(&stat[4 + (iters > 15 ? 15 : iters)], 1ull);      // histogram of the sweeps per run (diagnostic, HS_TIMING)
         }
     }
 }
