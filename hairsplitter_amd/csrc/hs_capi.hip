@@ -1192,7 +1192,7 @@ struct HipCvOps : hs::CvDeviceOps {
 struct GraphRows {
     DBuf d_oo, d_n, d_wc, d_row0, d_ids, d_rw, d_bo, d_fe, d_rank, d_rank_off;   // views into `pack`
     UploadPack pack;
-    DBuf d_off, d_nbr, d_visit, d_visit_n, d_prog_info, d_prog_bytes, d_prog_steps;
+    DBuf d_off, d_nbr, d_visit, d_visit_n, d_prog_info, d_prog_bytes, d_prog_steps, d_prog_adj;
     int64_t rows = 0, rows_dev = 0, total = 0;
     int W = 0, max_m = 1;
     std::vector<int32_t> win_m;    // [W]
@@ -1371,11 +1371,13 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
         if (int rc = G.d_prog_info.alloc(std::max<size_t>((size_t)rows, 1) * 4)) return rc;
         if (int rc = G.d_prog_bytes.alloc((size_t)total + 15 * (size_t)rows + 64)) return rc;
         if (int rc = G.d_prog_steps.alloc(std::max<size_t>((size_t)W, 1) * 4)) return rc;
+        if (int rc = G.d_prog_adj.alloc(std::max<size_t>((size_t)rows, 1) * 8)) return rc;
         HS_HIP(hipMemsetAsync(G.d_prog_steps.p, 0, std::max<size_t>((size_t)W, 1) * 4, stream));
         if (kc) { if (int rc = kc->begin(HS_K_VISIT_LISTS, stream)) return rc; }
         hipLaunchKernelGGL(hsdev::k_cw_visit_lists, dim3((unsigned)W), dim3(256), (size_t)cap * 4, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(), G.d_row0.as<int64_t>(),
                            G.d_ids.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_rank_off.as<int64_t>(), G.d_rank.as<int32_t>(), W, cap, G.d_visit.as<int32_t>(),
-                           G.d_visit_n.as<int32_t>(), G.d_prog_info.as<uint32_t>(), G.d_prog_bytes.as<uint8_t>(), G.d_prog_steps.as<int32_t>());
+                           G.d_visit_n.as<int32_t>(), G.d_prog_info.as<uint32_t>(), G.d_prog_bytes.as<uint8_t>(), G.d_prog_steps.as<int32_t>(),
+                           G.d_prog_adj.as<unsigned long long>());
         HS_HIP(hipGetLastError());
         if (kc) { if (int rc = kc->end(20 * (int64_t)rows, stream)) return rc; }   // row offsets + read id + rank in, visiting slot out
     }
@@ -1484,7 +1486,8 @@ struct HipSrOps : hs::SrDeviceOps {
         if (n_inst > 0x7fffffff) { set_error("Chinese Whispers: too many runs in one call"); return HS_EINVAL; }
         // per-SNP runs: window, slab offset (the runs of a window are contiguous: K * m labels); small windows go to the
         // row-packed kernel, the others to the one-wavefront-per-run kernel
-        std::vector<int32_t> inst_win((size_t)n_inst), list_big, unit_win, unit_inst0, unit_n;
+        std::vector<int32_t> inst_win((size_t)n_inst), list_big, list_lanes, unit_win, unit_inst0, unit_n;
+        const int lanes_cap = std::getenv("HS_CW_NO_LANES") ? 0 : 64;     // windows up to 64 reads: one run per lane (k_cw_seeded_lanes)
         int max_m_small = 1;
         std::vector<int64_t> inst_slab((size_t)n_inst), chain_slab0((size_t)Wc), big_scr, tail_scr((size_t)Wc, 0);
         int64_t slab = 0, big_scr_total = 0, tail_scr_total = 0;
@@ -1497,8 +1500,9 @@ struct HipSrOps : hs::SrDeviceOps {
             for (int64_t i = ch.win_seed_begin[(size_t)k]; i < ch.win_seed_begin[(size_t)k + 1]; ++i) {
                 inst_win[(size_t)i] = w; inst_slab[(size_t)i] = slab; slab += m;
                 if (m > HS_CWR_CAP) { list_big.push_back((int32_t)i); max_m_big = std::max(max_m_big, m); }
+                else if (m <= lanes_cap) list_lanes.push_back((int32_t)i);
             }
-            if (m <= HS_CWR_CAP) {      // units of up to eight runs of this window for the row-packed kernel
+            if (m <= HS_CWR_CAP && m > lanes_cap) {      // units of up to eight runs of this window for the row-packed kernel
                 max_m_small = std::max(max_m_small, m);
                 for (int64_t i = ch.win_seed_begin[(size_t)k]; i < ch.win_seed_begin[(size_t)k + 1]; i += 8) {
                     unit_win.push_back(w); unit_inst0.push_back((int32_t)i);
@@ -1518,7 +1522,7 @@ struct HipSrOps : hs::SrDeviceOps {
             tail_scr[(size_t)k] = tail_scr_total;
             if (m > cap_tail) tail_scr_total += 7 * (int64_t)m + (m & 1);      // keeps the next window's doubles 8-byte aligned
         }
-        DBuf d_iw, d_is, d_seed, d_uw, d_ui, d_un, d_lb, d_bs, d_cw, d_cr0, d_csb, d_cs0, d_ts, d_slab, d_gs, d_l3, d_final, d_ok, d_stat,
+        DBuf d_ll, d_sets, d_names, d_slots, d_alive, d_ovf, d_ovf_n, d_iw, d_is, d_seed, d_uw, d_ui, d_un, d_lb, d_bs, d_cw, d_cr0, d_csb, d_cs0, d_ts, d_slab, d_gs, d_l3, d_final, d_ok, d_stat,
             d_cpos, d_sf, d_sl, d_plo, d_phi;
         if (resident_cols != &ch) {   // normally uploaded by simdiff_columns already
             col_pack.add(ch.col_off, d_col_off); col_pack.add(ch.col_idx, d_col_idx); col_pack.add(ch.col_code, d_col_code);
@@ -1527,7 +1531,7 @@ struct HipSrOps : hs::SrDeviceOps {
         }
         const bool finish = ch.finish_on_device && !std::getenv("HS_FINISH_ON_HOST");
         UploadPack pk;
-        pk.add(inst_win, d_iw); pk.add(inst_slab, d_is); pk.add(ch.seed_col, d_seed); pk.add(unit_win, d_uw); pk.add(unit_inst0, d_ui); pk.add(unit_n, d_un); pk.add(list_big, d_lb);
+        pk.add(inst_win, d_iw); pk.add(inst_slab, d_is); pk.add(ch.seed_col, d_seed); pk.add(unit_win, d_uw); pk.add(unit_inst0, d_ui); pk.add(unit_n, d_un); pk.add(list_big, d_lb); pk.add(list_lanes, d_ll);
         pk.add(big_scr, d_bs); pk.add(ch.win, d_cw); pk.add(ch.chain_row0, d_cr0); pk.add(ch.win_seed_begin, d_csb); pk.add(chain_slab0, d_cs0);
         pk.add(tail_scr, d_ts);
         if (finish) { pk.add(ch.col_pos, d_cpos); pk.add(ch.win_snp_first, d_sf); pk.add(ch.win_snp_last, d_sl); pk.add(ch.win_pos_lo, d_plo); pk.add(ch.win_pos_hi, d_phi); }
@@ -1537,14 +1541,39 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = d_l3.alloc(std::max<size_t>((size_t)total_m, 1) * 4)) return rc;
         if (int rc = d_final.alloc(std::max<size_t>((size_t)total_m, 1) * 4)) return rc;
         if (int rc = d_ok.alloc(std::max<size_t>((size_t)Wc, 1))) return rc;
-        if (int rc = d_stat.alloc(160)) return rc;    // {sweeps, bytes} of the per-SNP runs, {sweeps, bytes} of the window tails, histogram of sweeps per run [16]
-        HS_HIP(hipMemsetAsync(d_stat.p, 0, 160, stream));
+        if (int rc = d_stat.alloc(416)) return rc;    // {sweeps, bytes} of the per-SNP runs, {sweeps, bytes} of the window tails, histogram of sweeps per run [16]
+        HS_HIP(hipMemsetAsync(d_stat.p, 0, 416, stream));
         EventPair e1, e2;
         if (int rc = e1.init()) return rc;
         if (int rc = e2.init()) return rc;
         // ---- per-SNP runs, seeded on the device from the SNP columns ----
         HS_HIP(hipEventRecord(e1.a, stream));
         if (int rc = kc.begin(HS_K_CW_SEEDED, stream)) return rc;
+        if (!list_lanes.empty()) {
+            const int n = (int)list_lanes.size();
+            const size_t npad = ((size_t)n + 63) & ~(size_t)63;
+            if (int rc = d_sets.alloc(npad * 128)) return rc;
+            if (int rc = d_names.alloc(npad * 16)) return rc;
+            if (int rc = d_slots.alloc(npad * 64)) return rc;
+            if (int rc = d_alive.alloc(npad)) return rc;
+            if (int rc = d_ovf.alloc((size_t)n * 4)) return rc;
+            if (int rc = d_ovf_n.alloc(4)) return rc;
+            HS_HIP(hipMemsetAsync(d_ovf_n.p, 0, 4, stream));
+            hipLaunchKernelGGL(hsdev::k_cw_seed_sets, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), d_ll.as<int32_t>(), n,
+                               d_iw.as<int32_t>(), d_seed.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(),
+                               d_sets.as<unsigned long long>(), d_names.as<uint8_t>(), d_slots.as<uint8_t>(), d_alive.as<uint8_t>(), d_ovf.as<int32_t>(), d_ovf_n.as<int32_t>());
+            HS_HIP(hipGetLastError());
+            hipLaunchKernelGGL(hsdev::k_cw_seeded_lanes, dim3((unsigned)(npad / 64)), dim3(64), 0, stream, G.d_off.as<int64_t>(), G.d_row0.as<int64_t>(), G.d_visit_n.as<int32_t>(),
+                               G.d_prog_info.as<uint32_t>(), G.d_prog_adj.as<unsigned long long>(), d_ll.as<int32_t>(), n, d_iw.as<int32_t>(), d_is.as<int64_t>(),
+                               d_sets.as<unsigned long long>(), d_names.as<uint8_t>(), d_slots.as<uint8_t>(), d_alive.as<uint8_t>(), d_slab.as<int32_t>(), d_stat.as<unsigned long long>());
+            HS_HIP(hipGetLastError());
+            // the few runs with more labels alive than slots: one wavefront each, the list and its length are on the device
+            hipLaunchKernelGGL(hsdev::k_cw_seeded_wave, dim3((unsigned)std::min(n, 1024)), dim3(64), (size_t)64 * 8, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(),
+                               G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), d_ovf.as<int32_t>(), 0, d_ovf_n.as<int32_t>(),
+                               d_iw.as<int32_t>(), d_seed.as<int64_t>(), d_is.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
+                               d_col_code.as<uint8_t>(), 64, (int32_t*)nullptr, (const int64_t*)nullptr, d_slab.as<int32_t>(), d_stat.as<unsigned long long>());
+            HS_HIP(hipGetLastError());
+        }
         if (!unit_win.empty()) {
             const int n = (int)unit_win.size();
             const int m_cap = std::max(16, (max_m_small + 15) & ~15);
@@ -1565,7 +1594,7 @@ struct HipSrOps : hs::SrDeviceOps {
             if (lds > 48 * 1024)
                 HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_cw_seeded_wave), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(hsdev::k_cw_seeded_wave, dim3((unsigned)n), dim3(64), lds, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(),
-                               G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), d_lb.as<int32_t>(), n,
+                               G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), d_lb.as<int32_t>(), n, (const int32_t*)nullptr,
                                d_iw.as<int32_t>(), d_seed.as<int64_t>(), d_is.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
                                d_col_code.as<uint8_t>(), cap_big, d_gs.as<int32_t>(), d_bs.as<int64_t>(), d_slab.as<int32_t>(), d_stat.as<unsigned long long>());
             HS_HIP(hipGetLastError());
@@ -1593,8 +1622,8 @@ struct HipSrOps : hs::SrDeviceOps {
             // the finished labels and the per-window verdict come back first; the labels of the third run are only fetched
             // when some window has to be finished by the host code (few or none)
             HBuf h, h2, h3, h4;
-            if (int rc = h4.alloc(160)) return rc;
-            HS_HIP(hipMemcpyAsync(h4.p, d_stat.p, 160, hipMemcpyDeviceToHost, stream));
+            if (int rc = h4.alloc(416)) return rc;
+            HS_HIP(hipMemcpyAsync(h4.p, d_stat.p, 416, hipMemcpyDeviceToHost, stream));
             bool need_chain_labels = !finish;
             if (finish) {
                 if (int rc = h2.alloc(std::max<size_t>((size_t)total_m, 1) * sizeof(int32_t))) return rc;
@@ -1620,6 +1649,12 @@ struct HipSrOps : hs::SrDeviceOps {
                 std::string h;
                 for (int k = 0; k < 16; ++k) h += " " + std::to_string((unsigned long long)st[4 + k]);
                 std::fprintf(stderr, "[hs timing] sr: per-SNP Chinese-Whispers runs by number of sweeps (0..15+):%s\n", h.c_str());
+#ifdef HS_CW_DIAG
+                h.clear(); for (int k = 0; k < 16; ++k) h += " " + std::to_string((unsigned long long)st[20 + k]);
+                std::fprintf(stderr, "[hs timing] sr: runs by labels alive after seeding (0..15+):%s\n", h.c_str());
+                h.clear(); for (int k = 0; k < 16; ++k) h += " " + std::to_string((unsigned long long)st[36 + k]);
+                std::fprintf(stderr, "[hs timing] sr: runs by m/16:%s\n", h.c_str());
+#endif
             }
             KernelClock::add_bytes(HS_K_CW_SEEDED, (int64_t)st[1]);
             KernelClock::add_bytes(HS_K_WINDOW_TAIL, (int64_t)st[3]);

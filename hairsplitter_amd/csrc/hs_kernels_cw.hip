@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void k_cw_visit_lists(
     // the "visit program" of windows with m <= HS_CWR_CAP for k_cw_seeded_rows (nullptr: not wanted): per visit one dword
     // {node, chunks << 8, first chunk << 16} at prog_info[row0 + v]; the neighbour lists cut in 16-byte chunks of local ids
     // (255 = none) at prog_bytes[off[row0] + 15 * row0 ...] (room for nnz + 15 m bytes per window); chunks in all at prog_steps[w]
-    uint32_t* __restrict__ prog_info, uint8_t* __restrict__ prog_bytes, int32_t* __restrict__ prog_steps) {
+    uint32_t* __restrict__ prog_info, uint8_t* __restrict__ prog_bytes, int32_t* __restrict__ prog_steps,
+    // windows with m <= 64 (k_cw_seeded_lanes): the neighbours of the v-th visited node as one bit mask over local ids
+    unsigned long long* __restrict__ prog_adj) {
     extern __shared__ int32_t s_rank[];   // [cap] rank of every node with neighbours, -1 otherwise
     const int w = (int)blockIdx.x;
     if (w >= n_windows) return;
@@ -112,6 +114,11 @@ __global__ __launch_bounds__(256) void k_cw_visit_lists(
         uint8_t* pb = prog_bytes + base + 15 * r0 + (int64_t)first * 16;
         const int32_t* an = nbr + off[r0 + i];
         for (int k = 0; k < nc * 16; ++k) pb[k] = k < deg ? (uint8_t)an[k] : (uint8_t)255;
+        if (prog_adj && m <= 64) {
+            unsigned long long a = 0ull;
+            for (int k = 0; k < deg; ++k) a |= 1ull << an[k];
+            prog_adj[r0 + tid] = a;
+        }
     }
 }
 
@@ -308,6 +315,9 @@ __global__ __launch_bounds__(128) void k_cw_seeded_rows(
     wave_sync_lds();
     for (int j = l; j < cnt_cap; j += 16) cnt[j] = 0;
     wave_sync_lds();
+#ifdef HS_CW_DIAG
+    if (live && l == 0) { int alive = 0; for (int j = 0; j < m; ++j) alive += lab[j] == j ? 1 : 0; atomicAdd(&stat[20 + (alive > 15 ? 15 : alive)], 1ull); atomicAdd(&stat[36 + (m >> 4 > 15 ? 15 : m >> 4)], 1ull); }
+#endif
 
     // ---- the sweeps. The rows of a workgroup run the same window, so the visits, the node and its chunk count are the same
     // for all of them: control flow is wave-uniform (scalar branches, no EXEC juggling), a row that has converged just stops
@@ -433,15 +443,17 @@ __global__ __launch_bounds__(128) void k_cw_seeded_rows(
 __global__ __launch_bounds__(64) void k_cw_seeded_wave(
     const int64_t* __restrict__ off, const int32_t* __restrict__ nbr, const int64_t* __restrict__ win_row0,
     const int32_t* __restrict__ mask_ids, const int32_t* __restrict__ visit, const int32_t* __restrict__ visit_n,
-    const int32_t* __restrict__ inst_list, int n_list, const int32_t* __restrict__ inst_win, const int64_t* __restrict__ inst_seed_col,
+    const int32_t* __restrict__ inst_list, int n_list, const int32_t* __restrict__ n_list_dev /* when the list was made on the device */,
+    const int32_t* __restrict__ inst_win, const int64_t* __restrict__ inst_seed_col,
     const int64_t* __restrict__ inst_slab_off, const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx,
     const uint8_t* __restrict__ col_code, int lds_cap, int32_t* __restrict__ gscratch, const int64_t* __restrict__ gscratch_off,
     int32_t* __restrict__ slab, unsigned long long* __restrict__ stat) {
     extern __shared__ int32_t cw_dyn[];     // [2 * lds_cap]
     __shared__ int32_t s_first[256];
     const int lane = lane_id();
-    const int k = (int)blockIdx.x;
-    if (k >= n_list) return;
+    const int n_runs = n_list_dev ? *n_list_dev : n_list;
+    for (int k = (int)blockIdx.x; k < n_runs; k += (int)gridDim.x) {
+    wave_sync_lds();
     const int inst = inst_list[k];
     const int w = inst_win[inst];
     const int64_t r0 = win_row0[w];
@@ -466,6 +478,192 @@ __global__ __launch_bounds__(64) void k_cw_seeded_wave(
     if (lane == 0 && stat) {
         atomicAdd(&stat[0], (unsigned long long)iters);
         atomicAdd(&stat[1], (unsigned long long)iters * (4ull * (unsigned long long)(off[r0 + m] - off[r0]) + 8ull * (unsigned long long)m));
+        atomicAdd(&stat[4 + (iters > 15 ? 15 : iters)], 1ull);
+    }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-SNP runs of windows with m <= 64, ONE RUN PER LANE. The labels of a run are kept as sets: at most HS_CWL_SLOTS labels
+// are alive after seeding (one per base seen in the column plus one per read that does not cover it; 4-5 typically), slot s
+// = the s-th lowest label, set[s] = the nodes that carry it as a 64-bit mask in two VGPRs. A visit is then
+//     votes of label s = popcount(neighbours(i) & set[s]),  winner = max over s of (votes << 8 | 255 - s)
+// -- the lowest label among the most frequent ones (cluster_graph.cpp:272-279) -- with no memory on the dependent chain
+// but one LDS byte (the slot node i is in now, to count the change). The neighbour masks come from k_cw_visit_lists, in
+// visiting order, and are fetched one visit ahead.
+//   k_cw_seed_sets     one wavefront per run: labels from the seeding column (:1678-1691) -> slot of every node, the sets,
+//                      the label each slot stands for; runs with more labels alive than slots go to `ovf_list`
+//   k_cw_seeded_lanes  64 runs per wavefront
+// ------------------------------------------------------------------------------------------------
+#define HS_CWL_SLOTS 16
+
+__global__ __launch_bounds__(256) void k_cw_seed_sets(
+    const int64_t* __restrict__ win_row0, const int32_t* __restrict__ mask_ids, const int32_t* __restrict__ inst_list, int n_list,
+    const int32_t* __restrict__ inst_win, const int64_t* __restrict__ inst_seed_col, const int64_t* __restrict__ col_off,
+    const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
+    unsigned long long* __restrict__ seed_sets /* [n_list][16] */, uint8_t* __restrict__ seed_names /* [n_list][16] */,
+    uint8_t* __restrict__ seed_slots /* [n_list][64] */, uint8_t* __restrict__ seed_n /* [n_list]: labels alive, 255 = too many */,
+    int32_t* __restrict__ ovf_list, int32_t* __restrict__ ovf_n) {
+    __shared__ int32_t s_ids[4][64];
+    __shared__ int32_t s_lab[4][64];
+    __shared__ int32_t s_first[4][256];
+    const int lane = (int)threadIdx.x & 63, wv = (int)threadIdx.x >> 6;
+    const int q = (int)blockIdx.x * 4 + wv;
+    if (q >= n_list) return;                      // (no workgroup barrier below: the wavefronts are independent)
+    int32_t* ids = s_ids[wv]; int32_t* lab = s_lab[wv]; int32_t* first = s_first[wv];
+    const int inst = inst_list[q];
+    const int w = inst_win[inst];
+    const int64_t seed = inst_seed_col[inst];
+    const int64_t r0 = win_row0[w];
+    const int m = (int)(win_row0[w + 1] - r0);    // <= 64
+    const int64_t c0 = col_off[seed], c1 = col_off[seed + 1];
+    const int64_t e0 = c0 + lane;
+    const int R0 = e0 < c1 ? col_idx[e0] : -1;
+    const int code0 = e0 < c1 ? (int)col_code[e0] : 0;
+    ids[lane] = lane < m ? mask_ids[r0 + lane] : 0x7fffffff;
+    lab[lane] = lane;
+    for (int c = lane; c < 256; c += 64) first[c] = 0x7fffffff;
+    wave_sync_lds();
+    const int j0 = R0 >= 0 ? local_index(ids, m, R0) : -1;
+    if (j0 >= 0) atomicMin(&first[code0], j0);
+    for (int64_t e = e0 + 64; e < c1; e += 64) { const int j = local_index(ids, m, col_idx[e]); if (j >= 0) atomicMin(&first[col_code[e]], j); }
+    wave_sync_lds();
+    if (j0 >= 0) lab[j0] = first[code0];
+    for (int64_t e = e0 + 64; e < c1; e += 64) { const int j = local_index(ids, m, col_idx[e]); if (j >= 0) lab[j] = first[col_code[e]]; }
+    wave_sync_lds();
+    const int L = lab[lane];                                            // < 64
+    const bool node = lane < m;
+    const unsigned long long leaders = __ballot(node && L == lane);
+    const int alive = __popcll(leaders);
+    const int slot = __popcll(leaders & ((1ull << L) - 1ull));         // labels in ascending order
+    seed_slots[(int64_t)q * 64 + lane] = (uint8_t)(node ? slot : 0);
+    if (alive > HS_CWL_SLOTS) {
+        if (lane == 0) { seed_n[q] = 255; ovf_list[atomicAdd(ovf_n, 1)] = inst; }
+        return;
+    }
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int k = 0; k < HS_CWL_SLOTS; ++k) { const unsigned long long S = __ballot(node && slot == k); if (lane == k) mine = S; }
+    if (lane < HS_CWL_SLOTS) seed_sets[(int64_t)q * HS_CWL_SLOTS + lane] = mine;
+    if (node && L == lane) ids[slot] = lane;                            // (the read ids are not needed any more)
+    wave_sync_lds();
+    if (lane < HS_CWL_SLOTS) seed_names[(int64_t)q * HS_CWL_SLOTS + lane] = (uint8_t)(lane < alive ? ids[lane] : 0);
+    if (lane == 0) seed_n[q] = (uint8_t)alive;
+}
+
+// The sweeps of 64 runs, one per lane, with NS slots in use (the slots above stay empty). Returns the lane's number of sweeps.
+template <int NS>
+static __device__ __forceinline__ int cwl_sweeps(unsigned (&set_lo)[HS_CWL_SLOTS], unsigned (&set_hi)[HS_CWL_SLOTS], uint8_t* my_slot,
+                                                 const unsigned long long* __restrict__ adj_w, const uint32_t* __restrict__ inf_w, int nv, bool ok) {
+    int iters = 0;
+    bool active = ok;
+    while (__ballot(active) != 0ull) {
+        int changes = 0;
+        unsigned long long adj_n = (active && nv > 0) ? adj_w[0] : 0ull;
+        uint32_t inf_n = (active && nv > 0) ? inf_w[0] : 0u;
+        for (int v = 0;; ++v) {
+            const bool on = active && v < nv;
+            if (__ballot(on) == 0ull) break;
+            const unsigned long long adj = adj_n;
+            const int i = (int)(inf_n & 255u);
+            if (active && v + 1 < nv) { adj_n = adj_w[v + 1]; inf_n = inf_w[v + 1]; }
+            const int old = (int)my_slot[i];
+            const unsigned lo = (unsigned)adj, hi = (unsigned)(adj >> 32);
+            unsigned best = 0u;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const unsigned c = (unsigned)__popc(lo & set_lo[s]) + (unsigned)__popc(hi & set_hi[s]);
+                const unsigned key = (c << 8) | (unsigned)(255 - s);
+                best = key > best ? key : best;
+            }
+            const int b = 255 - (int)(best & 255u);
+            const bool chg = on && b != old;
+            changes += chg ? 1 : 0;
+            if (__ballot(chg) != 0ull) {
+                const unsigned long long bit = chg ? 1ull << i : 0ull;
+                const unsigned bl = (unsigned)bit, bh = (unsigned)(bit >> 32);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    set_lo[s] = (set_lo[s] & ~bl) | (s == b ? bl : 0u);
+                    set_hi[s] = (set_hi[s] & ~bh) | (s == b ? bh : 0u);
+                }
+                if (chg) my_slot[i] = (uint8_t)b;
+            }
+        }
+        if (active) { iters++; active = changes > 2 && iters < 15; }
+    }
+    return iters;
+}
+
+__global__ __launch_bounds__(64) void k_cw_seeded_lanes(
+    const int64_t* __restrict__ off, const int64_t* __restrict__ win_row0, const int32_t* __restrict__ visit_n,
+    const uint32_t* __restrict__ prog_info, const unsigned long long* __restrict__ prog_adj,
+    const int32_t* __restrict__ inst_list, int n_list, const int32_t* __restrict__ inst_win, const int64_t* __restrict__ inst_slab_off,
+    const unsigned long long* __restrict__ seed_sets, const uint8_t* __restrict__ seed_names, const uint8_t* __restrict__ seed_slots /* padded to 64 runs */,
+    const uint8_t* __restrict__ seed_n, int32_t* __restrict__ slab, unsigned long long* __restrict__ stat) {
+    __shared__ uint32_t s_slot[64 * 17];           // [run][68 bytes]: slot of every node (17 dwords apart: no bank conflicts)
+    __shared__ uint32_t s_name[64 * 4];            // [run][16 bytes]: the label a slot stands for
+    __shared__ unsigned int s_hist[16];
+    const int lane = (int)threadIdx.x;
+    const int q0 = (int)blockIdx.x * 64, q = q0 + lane;
+    const bool valid = q < n_list;
+    const int inst = valid ? inst_list[q] : 0;
+    const int na = valid ? (int)seed_n[q] : 255;
+    const bool ok = valid && na != 255;
+    const int w = ok ? inst_win[inst] : 0;
+    const int64_t r0 = ok ? win_row0[w] : 0;
+    const int m = ok ? (int)(win_row0[w + 1] - r0) : 0;
+    const int nv = ok ? visit_n[w] : 0;
+    const int64_t out0 = ok ? inst_slab_off[inst] : 0;
+    unsigned set_lo[HS_CWL_SLOTS], set_hi[HS_CWL_SLOTS];
+    {
+        const ulonglong2* p = reinterpret_cast<const ulonglong2*>(seed_sets + (int64_t)(valid ? q : 0) * HS_CWL_SLOTS);
+#pragma unroll
+        for (int k = 0; k < HS_CWL_SLOTS / 2; ++k) {
+            const ulonglong2 v = p[k];
+            set_lo[2 * k] = ok ? (unsigned)v.x : 0u; set_hi[2 * k] = ok ? (unsigned)(v.x >> 32) : 0u;
+            set_lo[2 * k + 1] = ok ? (unsigned)v.y : 0u; set_hi[2 * k + 1] = ok ? (unsigned)(v.y >> 32) : 0u;
+        }
+        const uint4 nm = reinterpret_cast<const uint4*>(seed_names)[valid ? q : 0];
+        s_name[lane * 4 + 0] = nm.x; s_name[lane * 4 + 1] = nm.y; s_name[lane * 4 + 2] = nm.z; s_name[lane * 4 + 3] = nm.w;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(seed_slots + (int64_t)q0 * 64);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int x = lane + 64 * k; s_slot[(x >> 4) * 17 + (x & 15)] = src[x]; }
+        if (lane < 16) s_hist[lane] = 0u;
+    }
+    wave_sync_lds();
+    int nmax = 0;                                  // slots in use by any run of this wavefront
+#pragma unroll
+    for (int k = 1; k <= HS_CWL_SLOTS; ++k) if (__ballot(ok && na >= k) != 0ull) nmax = k;
+    uint8_t* my_slot = reinterpret_cast<uint8_t*>(s_slot) + lane * 68;
+    int iters;
+    if (nmax <= 4) iters = cwl_sweeps<4>(set_lo, set_hi, my_slot, prog_adj + r0, prog_info + r0, nv, ok);
+    else if (nmax <= 6) iters = cwl_sweeps<6>(set_lo, set_hi, my_slot, prog_adj + r0, prog_info + r0, nv, ok);
+    else if (nmax <= 8) iters = cwl_sweeps<8>(set_lo, set_hi, my_slot, prog_adj + r0, prog_info + r0, nv, ok);
+    else if (nmax <= 10) iters = cwl_sweeps<10>(set_lo, set_hi, my_slot, prog_adj + r0, prog_info + r0, nv, ok);
+    else if (nmax <= 12) iters = cwl_sweeps<12>(set_lo, set_hi, my_slot, prog_adj + r0, prog_info + r0, nv, ok);
+    else iters = cwl_sweeps<HS_CWL_SLOTS>(set_lo, set_hi, my_slot, prog_adj + r0, prog_info + r0, nv, ok);
+    wave_sync_lds();
+    // labels out, run by run: lane j writes node j (coalesced)
+    const unsigned long long okm = __ballot(ok);
+    const uint8_t* names = reinterpret_cast<const uint8_t*>(s_name);
+    const uint8_t* slots = reinterpret_cast<const uint8_t*>(s_slot);
+    const int out_lo = (int)(unsigned)out0, out_hi = (int)(out0 >> 32);
+    for (int r = 0; r < 64; ++r) {
+        if (!((okm >> r) & 1ull)) continue;
+        const int m_r = __builtin_amdgcn_readlane(m, r);
+        const int64_t o_r = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(out_hi, r) << 32) | (unsigned)__builtin_amdgcn_readlane(out_lo, r));
+        if (lane < m_r) slab[o_r + lane] = (int32_t)names[r * 16 + slots[r * 68 + lane]];
+    }
+    if (stat) {
+        unsigned long long sw = ok ? (unsigned long long)iters : 0ull;
+        unsigned long long by = ok ? (unsigned long long)iters * (4ull * (unsigned long long)(off[r0 + m] - off[r0]) + 8ull * (unsigned long long)m) : 0ull;
+        if (ok) atomicAdd(&s_hist[iters > 15 ? 15 : iters], 1u);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { sw += __shfl_xor(sw, d, 64); by += __shfl_xor(by, d, 64); }
+        wave_sync_lds();
+        if (lane == 0) { atomicAdd(&stat[0], sw); atomicAdd(&stat[1], by); }
+        if (lane < 16 && s_hist[lane]) atomicAdd(&stat[4 + lane], (unsigned long long)s_hist[lane]);
     }
 }
 
