@@ -26,6 +26,7 @@
 #include "hs_kernels_graph.hip"
 #include "hs_kernels_cw.hip"
 #include "hs_kernels_myers.hip"
+#include "hs_kernels_parts.hip"
 
 namespace hs {
 static thread_local std::string g_err;
@@ -167,7 +168,17 @@ struct UploadPack {
 // spinning is the default and HS_BLOCKING_WAIT=1 selects the sleeping waits (for hosts that need the cores).
 static bool blocking_wait() { static const bool s = std::getenv("HS_BLOCKING_WAIT") != nullptr; return s; }
 static bool spin_wait() { return !blocking_wait(); }
+static std::atomic<long> g_waits{0}, g_wait_us{0};     // HS_TIMING: host waits and the wall time spent in them
+static int stream_wait_impl(hipStream_t s);
 static int stream_wait(hipStream_t s) {
+    static const bool timed = std::getenv("HS_TIMING") != nullptr;
+    if (!timed) return stream_wait_impl(s);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = stream_wait_impl(s);
+    g_waits.fetch_add(1); g_wait_us.fetch_add((long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    return rc;
+}
+static int stream_wait_impl(hipStream_t s) {
     if (spin_wait()) { HS_HIP(hipStreamSynchronize(s)); return HS_OK; }
     static thread_local hipEvent_t ev = nullptr;
     if (!ev) HS_HIP(hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming));
@@ -302,7 +313,7 @@ const char* hs_version(void) { return "hairsplitter_amd 0.2 (gfx950)"; }
 const char* hs_kernel_name(int k) {
     static const char* names[HS_NKERNELS] = {"k_cigar_scan", "k_pileup_packed", "k_column_stats_tiled", "k_gather_columns_tiled", "k_column_top3", "k_pack_columns",
                                              "k_column_partition_test", "k_snp_planes", "k_simdiff", "k_read_graph_rows", "k_read_graph_fill", "k_cw_visit_lists",
-                                             "k_cw_seeded_rows", "k_window_tail", "k_cw_local", "other"};
+                                             "k_cw_seeded_lanes", "k_window_tail", "k_cw_local", "k_robust_partitions", "other"};
     return k >= 0 && k < HS_NKERNELS ? names[k] : "?";
 }
 void hs_kernel_stats_reset(void) { KernelTable& t = kernel_table(); std::lock_guard<std::mutex> g(t.mu); std::memset(&t.st, 0, sizeof t.st); }
@@ -1154,6 +1165,97 @@ struct HipCvOps : hs::CvDeviceOps {
         kc.flush();
         return e.ms(k_ms);
     }
+    // ---- loop A on the device (hs_kernels_parts.hip) ----
+    bool has_robust_partitions() const override { return true; }
+    HBuf h_la_rec, h_la_state, h_la_more, h_la_less;
+    int robust_partitions(const hs::CvLoopA& in, hs::CvLoopAResult& out, float* k_ms) override {
+        static_assert(sizeof(hs::CvPartRecord) == sizeof(hsdev::PartitionRecord), "partition record layouts differ");
+        const int C = (int)in.contig_n_reads.size();
+        const int64_t n_cand = in.cand_off.back();
+        out.part_base.assign((size_t)C + 1, 0); out.failed.assign((size_t)C, 0);
+        out.rec = nullptr; out.state = nullptr; out.more = nullptr; out.less = nullptr;
+        if (k_ms) *k_ms = 0;
+        if (C == 0 || n_cand == 0) return HS_OK;
+        if (in.cand_col.size() != (size_t)n_cand) { set_error("robust_partitions: bad arguments"); return HS_EINVAL; }
+        for (int32_t col : in.cand_col) if (col < 0 || col >= n_gathered) { set_error("robust_partitions: column outside the last gather"); return HS_EINVAL; }
+        // the pool: a contig cannot make more partitions than it has candidates, N elements each. HS_LOOP_A_POOL_ELEMS caps it
+        // (a contig that does not fit is left to the host)
+        long long pool_cap = 0;
+        std::vector<std::pair<double, int>> weight((size_t)C);
+        for (int c = 0; c < C; ++c) {
+            const long long k = in.cand_off[(size_t)c + 1] - in.cand_off[(size_t)c];
+            pool_cap += k * (long long)in.contig_n_reads[(size_t)c];
+            weight[(size_t)c] = std::make_pair(-(double)k * (double)std::max(in.contig_n_reads[(size_t)c], 64), c);
+        }
+        static const long long pool_limit = []() { const char* e = std::getenv("HS_LOOP_A_POOL_ELEMS"); return e ? std::atoll(e) : (1ll << 31); }();
+        pool_cap = std::max<long long>(1, std::min(pool_cap, pool_limit));
+        std::sort(weight.begin(), weight.end());
+        std::vector<int32_t> order((size_t)C);
+        for (int c = 0; c < C; ++c) order[(size_t)c] = weight[(size_t)c].second;
+        DBuf d_co_, d_cc_, d_cp, d_cr, d_n, d_ro, d_re, d_ord, d_state, d_more, d_less, d_scal, d_np, d_fail, d_used, d_base, d_rec;
+        UploadPack pk;
+        pk.add(in.cand_off, d_co_); pk.add(in.cand_col, d_cc_); pk.add(in.cand_pos, d_cp); pk.add(in.cand_ref, d_cr); pk.add(in.contig_n_reads, d_n);
+        pk.add(in.read_off, d_ro); pk.add(in.read_end, d_re); pk.add(order, d_ord);
+        if (int rc = pk.commit(stream)) return rc;
+        if (int rc = d_state.alloc((size_t)pool_cap)) return rc;
+        if (int rc = d_more.alloc((size_t)pool_cap * 4)) return rc;
+        if (int rc = d_less.alloc((size_t)pool_cap * 4)) return rc;
+        if (int rc = d_scal.alloc((size_t)n_cand * 36 + 64)) return rc;
+        if (int rc = d_np.alloc((size_t)C * 4)) return rc;
+        if (int rc = d_fail.alloc((size_t)C * 4)) return rc;
+        if (int rc = d_used.alloc(8)) return rc;
+        if (int rc = d_base.alloc(((size_t)C + 1) * 8)) return rc;
+        if (int rc = d_rec.alloc((size_t)n_cand * sizeof(hsdev::PartitionRecord))) return rc;
+        HS_HIP(hipMemsetAsync(d_used.p, 0, 8, stream));
+        hsdev::PartitionScalars ps;
+        {
+            char* base = (char*)d_scal.p;
+            ps.elem = (long long*)base; base += (size_t)n_cand * 8;      // (8-byte aligned first)
+            ps.left = (int32_t*)base; base += (size_t)n_cand * 4; ps.right = (int32_t*)base; base += (size_t)n_cand * 4;
+            ps.n_occ = (int32_t*)base; base += (size_t)n_cand * 4; ps.n_corr = (int32_t*)base; base += (size_t)n_cand * 4;
+            ps.lo = (int32_t*)base; base += (size_t)n_cand * 4; ps.hi = (int32_t*)base; base += (size_t)n_cand * 4;
+            ps.reach = (int32_t*)base;
+        }
+        EventPair e; if (int rc = e.init()) return rc;
+        HS_HIP(hipEventRecord(e.a, stream));
+        if (int rc = kc.begin(HS_K_ROBUST_PARTITIONS, stream)) return rc;
+        hipLaunchKernelGGL(hsdev::k_robust_partitions, dim3((unsigned)C), dim3(256), 0, stream, d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(),
+                           d_co_.as<int64_t>(), d_cc_.as<int32_t>(), d_cp.as<int32_t>(), d_cr.as<uint8_t>(), d_n.as<int32_t>(), d_ro.as<int64_t>(),
+                           d_re.as<int32_t>(), d_ord.as<int32_t>(), C, d_state.as<int8_t>(), d_more.as<int32_t>(), d_less.as<int32_t>(), pool_cap,
+                           d_used.as<unsigned long long>(), ps, d_np.as<int32_t>(), d_fail.as<int32_t>());
+        HS_HIP(hipGetLastError());
+        hipLaunchKernelGGL(hsdev::k_partitions_pack, dim3(1), dim3(256), 0, stream, d_co_.as<int64_t>(), d_np.as<int32_t>(), C, ps, d_base.as<int64_t>(),
+                           d_rec.as<hsdev::PartitionRecord>());
+        HS_HIP(hipGetLastError());
+        // the candidates' entries (idx + code) once: their share of the gathered entries (the ops do not keep the column lengths on the host)
+        if (int rc = kc.end(5 * (gathered_entries * n_cand / std::max(1, n_gathered)), stream)) return rc;
+        HS_HIP(hipEventRecord(e.b, stream));
+        // first the sizes, then the partitions themselves
+        HBuf h1; if (int rc = h1.alloc(8 + ((size_t)C + 1) * 8 + (size_t)C * 4)) return rc;
+        HS_HIP(hipMemcpyAsync(h1.p, d_used.p, 8, hipMemcpyDeviceToHost, stream));
+        HS_HIP(hipMemcpyAsync((char*)h1.p + 8, d_base.p, ((size_t)C + 1) * 8, hipMemcpyDeviceToHost, stream));
+        HS_HIP(hipMemcpyAsync((char*)h1.p + 8 + ((size_t)C + 1) * 8, d_fail.p, (size_t)C * 4, hipMemcpyDeviceToHost, stream));
+        if (int rc = stream_wait(stream)) return rc;
+        const long long used = std::min<long long>((long long)*(unsigned long long*)h1.p, pool_cap);
+        std::memcpy(out.part_base.data(), (char*)h1.p + 8, ((size_t)C + 1) * 8);
+        std::memcpy(out.failed.data(), (char*)h1.p + 8 + ((size_t)C + 1) * 8, (size_t)C * 4);
+        const int64_t n_parts = out.part_base[(size_t)C];
+        auto grow = [](HBuf& h, size_t need) -> int { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); };
+        if (int rc = grow(h_la_rec, std::max<size_t>(1, (size_t)n_parts) * sizeof(hs::CvPartRecord))) return rc;
+        if (int rc = grow(h_la_state, std::max<size_t>(1, (size_t)used))) return rc;
+        if (int rc = grow(h_la_more, std::max<size_t>(1, (size_t)used) * 4)) return rc;
+        if (int rc = grow(h_la_less, std::max<size_t>(1, (size_t)used) * 4)) return rc;
+        if (n_parts) HS_HIP(hipMemcpyAsync(h_la_rec.p, d_rec.p, (size_t)n_parts * sizeof(hs::CvPartRecord), hipMemcpyDeviceToHost, stream));
+        if (used) {
+            HS_HIP(hipMemcpyAsync(h_la_state.p, d_state.p, (size_t)used, hipMemcpyDeviceToHost, stream));
+            HS_HIP(hipMemcpyAsync(h_la_more.p, d_more.p, (size_t)used * 4, hipMemcpyDeviceToHost, stream));
+            HS_HIP(hipMemcpyAsync(h_la_less.p, d_less.p, (size_t)used * 4, hipMemcpyDeviceToHost, stream));
+        }
+        if (int rc = stream_wait(stream)) return rc;
+        out.rec = (const hs::CvPartRecord*)h_la_rec.p; out.state = (const int8_t*)h_la_state.p; out.more = (const int32_t*)h_la_more.p; out.less = (const int32_t*)h_la_less.p;
+        kc.flush();
+        return e.ms(k_ms);
+    }
     HBuf h_fetch_idx[2], h_fetch_code[2];
     int fetch_columns(const std::vector<int32_t>& cols, const std::vector<int64_t>& packed_off, int slot, const int32_t** col_idx,
                       const uint8_t** col_code) override {
@@ -1869,7 +1971,7 @@ void hs_pipeline_destroy(hs_pipeline* p) {
     delete p;
 }
 
-static hs_sr_result* concat_sr_parts(hs_pipeline* p, std::vector<hs_sr_result*>& parts, hs_pipeline_stats* st) {
+static hs_sr_result* concat_sr_parts(hs_pipeline* p, std::vector<hs_sr_result*>& parts, const std::vector<hs::SrSparseLabels>& sparse, hs_pipeline_stats* st) {
     // concatenate in contig order
     hs_sr_result* R = (hs_sr_result*)std::calloc(1, sizeof(hs_sr_result));
     int64_t W = 0, NL = 0;
@@ -1879,7 +1981,7 @@ static hs_sr_result* concat_sr_parts(hs_pipeline* p, std::vector<hs_sr_result*>&
     R->win_start = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, W) * sizeof(int32_t));
     R->win_end = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, W) * sizeof(int32_t));
     R->label_off = (int64_t*)std::malloc(((size_t)W + 1) * sizeof(int64_t));
-    R->labels = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, NL) * sizeof(int32_t));
+    R->labels = hs::sr_labels_alloc((size_t)NL);
     int64_t w0 = 0, l0 = 0; int c0 = 0;
     R->win_off[0] = 0; R->label_off[0] = 0;
     std::vector<int64_t> part_l0(parts.size(), 0);
@@ -1896,14 +1998,19 @@ static hs_sr_result* concat_sr_parts(hs_pipeline* p, std::vector<hs_sr_result*>&
         R->n_cw_sweeps += r->n_cw_sweeps; R->cw_bytes += r->cw_bytes; R->graph_nnz += r->graph_nnz; R->n_graph_rows += r->n_graph_rows; R->simdiff_bytes += r->simdiff_bytes;
         w0 += w; l0 += nl; c0 += r->n_contigs;
     }
-    // the labels (tens of MB per batch): every part in a few pieces, on the caller's worker threads
+    // the labels (tens of MB per batch) are spread over the reads of every window here, once, in their final place: blocks of
+    // windows on the caller's worker threads
     {
-        const int pieces = 4;
-        hs::hs_parallel_for((int)parts.size() * pieces, host_threads(), [&](int i) {
-            const hs_sr_result* r = parts[(size_t)(i / pieces)];
-            const int64_t nl = r->label_off[r->win_off[r->n_contigs]];
-            const int64_t a = nl * (i % pieces) / pieces, b = nl * (i % pieces + 1) / pieces;
-            if (b > a) std::memcpy(R->labels + part_l0[(size_t)(i / pieces)] + a, r->labels + a, (size_t)(b - a) * sizeof(int32_t));
+        struct Blk { int part; int64_t w0, w1; };
+        std::vector<Blk> blks;
+        for (size_t pi = 0; pi < parts.size(); ++pi) {
+            const int64_t w = parts[pi]->win_off[parts[pi]->n_contigs];
+            for (int64_t a = 0; a < w; a += 64) blks.push_back(Blk{(int)pi, a, std::min<int64_t>(w, a + 64)});
+        }
+        hs::hs_parallel_for((int)blks.size(), host_threads(), [&](int i) {
+            const Blk& b = blks[(size_t)i];
+            const hs_sr_result* r = parts[(size_t)b.part];
+            hs::sr_expand_labels(sparse[(size_t)b.part], r->label_off, b.w0, b.w1, R->labels + part_l0[(size_t)b.part]);
         });
     }
     for (hs_sr_result* r : parts) hs::free_sr_result(r);
@@ -1956,11 +2063,14 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
         }
     }
     std::vector<hs_sr_result*> parts((size_t)G, nullptr);
+    std::vector<hs::SrSparseLabels> sparse((size_t)G);      // the groups leave their labels per window; concat_sr_parts spreads them
     const int rc = p->run([&](int g) {
         const int c0 = p->ranges[(size_t)g].first, c1 = p->ranges[(size_t)g].second;
         if (int r = hs_cv_run_range(p->batch, p->sel, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g])) return r;
-        return hs_sr_run_cv_range(p->batch, c0, c1, p->cv[(size_t)g], error_rate, rarest_strain_abundance, low_memory, amplicon, seed, per, window_size,
-                                  &parts[(size_t)g]);
+        hs::CvMeta meta; fill_meta(p->batch, meta);
+        HipSrOps ops;
+        return hs::sr_run_from_cv(ops, meta, c0, c1, p->cv[(size_t)g], error_rate, rarest_strain_abundance, low_memory, amplicon, seed, per, window_size,
+                                  &parts[(size_t)g], &sparse[(size_t)g]);
     });
     if (rc) { for (hs_sr_result* r : parts) if (r) hs::free_sr_result(r); return rc; }
     if (st) {
@@ -1973,7 +2083,8 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
             st->n_columns_downloaded_late += r->n_columns_downloaded_late;
         }
     }
-    hs_sr_result* R = concat_sr_parts(p, parts, st);
+    if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] host waits so far: %ld, %.1f ms in them\n", g_waits.load(), g_wait_us.load() / 1e3);
+    hs_sr_result* R = concat_sr_parts(p, parts, sparse, st);
     p->drop_cv();
     *out = R;
     return HS_OK;
@@ -2073,7 +2184,7 @@ int hs_sr_run(const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_siz
     R->win_start = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, W) * sizeof(int32_t));
     R->win_end = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, W) * sizeof(int32_t));
     R->label_off = (int64_t*)std::malloc(((size_t)W + 1) * sizeof(int64_t));
-    R->labels = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, NL) * sizeof(int32_t));
+    R->labels = hs::sr_labels_alloc((size_t)NL);
     R->win_off[0] = 0; R->label_off[0] = 0;
     int64_t w0 = 0;
     for (int c = 0; c < n_contigs; ++c) {

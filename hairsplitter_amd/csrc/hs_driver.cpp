@@ -102,9 +102,47 @@ void free_cv_result(hs_cv_result* r) {
     std::free(r->snp_alt); std::free(r->snp_n_ref); std::free(r->snp_n_alt); std::free(r->col_off); std::free(r->col_idx); std::free(r->col_code);
     std::free(r);
 }
+// The dense label array of a result is tens of megabytes, above the largest mmap threshold glibc accepts: malloc'ed, every
+// call would map it, fault it in page by page on all threads and unmap it again (15 % of the host's CPU time on the
+// 500-contig bench). A few big blocks are therefore kept and handed out again; a 64-byte header carries the capacity.
+namespace {
+struct LabelBlockHeader { uint64_t magic; size_t cap; char pad[48]; };
+constexpr uint64_t kLabelMagic = 0x48534c4142454c53ull;
+constexpr size_t kLabelKeepMin = 8u << 20, kLabelKeepBlocks = 4;
+std::mutex g_label_mu;
+std::vector<LabelBlockHeader*> g_label_free;
+}  // namespace
+
+int32_t* sr_labels_alloc(size_t n_labels) {
+    const size_t need = std::max<size_t>(1, n_labels) * sizeof(int32_t);
+    {
+        std::lock_guard<std::mutex> g(g_label_mu);
+        for (size_t i = 0; i < g_label_free.size(); ++i) {
+            LabelBlockHeader* h = g_label_free[i];
+            if (h->cap >= need && h->cap / 2 <= need) { g_label_free.erase(g_label_free.begin() + (long)i); return (int32_t*)(h + 1); }
+        }
+    }
+    const size_t cap = need >= kLabelKeepMin ? need + need / 8 : need;      // room for the next batch to be a little bigger
+    LabelBlockHeader* h = (LabelBlockHeader*)std::malloc(sizeof(LabelBlockHeader) + cap);
+    if (!h) return nullptr;
+    h->magic = kLabelMagic; h->cap = cap;
+    return (int32_t*)(h + 1);
+}
+
+void sr_labels_free(int32_t* labels) {
+    if (!labels) return;
+    LabelBlockHeader* h = (LabelBlockHeader*)labels - 1;
+    if (h->magic != kLabelMagic) { std::free(labels); return; }      // (not ours: a plain malloc)
+    if (h->cap >= kLabelKeepMin) {
+        std::lock_guard<std::mutex> g(g_label_mu);
+        if (g_label_free.size() < kLabelKeepBlocks) { g_label_free.push_back(h); return; }
+    }
+    std::free(h);
+}
+
 void free_sr_result(hs_sr_result* r) {
     if (!r) return;
-    std::free(r->win_off); std::free(r->win_start); std::free(r->win_end); std::free(r->label_off); std::free(r->labels);
+    std::free(r->win_off); std::free(r->win_start); std::free(r->win_end); std::free(r->label_off); sr_labels_free(r->labels);
     std::free(r);
 }
 
@@ -248,9 +286,11 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         resolve_columns(cs, f, std::min<int>(f + 256, (int)cs.pos.size()));
     });
     laps.lap("resolve_columns");
-    // ... then the sequential partition logic (V1 scan, loops A and B), one contig per thread ...
+    // ... then the partition logic: the V1 scan names the candidates, loop A runs on the device (contig by contig, one
+    // workgroup each) or, without that kernel, on the host; loop B on the host, one contig per thread ...
     std::vector<CvContigState*> cst((size_t)C, nullptr);
     for (int c = 0; c < C; ++c) cst[(size_t)c] = cv_state_new();
+    std::vector<std::vector<int32_t>> rend((size_t)C);
     parallel_for(C, n_threads, [&](int c) {
         ColumnSet& cs = sets[(size_t)c];
         int64_t nerr = 0, nlen = 0;
@@ -263,10 +303,49 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         o.depth = (float)((double)entries / (double)L);   // call_variants.cpp:565
         const int r0 = b.contig_rec_off[(size_t)gc];
         const int n_reads_c = b.contig_rec_off[(size_t)gc + 1] - r0;
-        std::vector<int32_t> rend((size_t)n_reads_c);
-        for (int r = 0; r < n_reads_c; ++r) rend[(size_t)r] = (int32_t)std::min<int64_t>(b.rec_pos[(size_t)(r0 + r)] + b.rec_refspan[(size_t)(r0 + r)], 0x7fffffff);
-        cv_phase_ab(*cst[(size_t)c], n_reads_c, cs, o.mean_distance, automatic_snp_threshold, o, b.rec_pos.data() + r0, rend.data());
+        rend[(size_t)c].resize((size_t)n_reads_c);
+        for (int r = 0; r < n_reads_c; ++r) rend[(size_t)c][(size_t)r] = (int32_t)std::min<int64_t>(b.rec_pos[(size_t)(r0 + r)] + b.rec_refspan[(size_t)(r0 + r)], 0x7fffffff);
+        cv_phase_v1(*cst[(size_t)c], n_reads_c, cs, o.mean_distance, automatic_snp_threshold, o);
     });
+    laps.lap("v1");
+    static const bool loop_a_on_host = std::getenv("HS_LOOP_A_ON_DEVICE") == nullptr;      // (first device form: correct, not yet faster than the host's)
+    const bool on_device = dev.has_robust_partitions() && !loop_a_on_host;
+    CvLoopAResult la;
+    float k_ms_a = 0;
+    if (on_device) {
+        CvLoopA in;
+        in.cand_off.assign((size_t)C + 1, 0); in.read_off.assign((size_t)C + 1, 0); in.contig_n_reads.resize((size_t)C);
+        for (int c = 0; c < C; ++c) {
+            in.cand_off[(size_t)c + 1] = in.cand_off[(size_t)c] + (int64_t)cv_candidates(*cst[(size_t)c]).size();
+            in.contig_n_reads[(size_t)c] = (int32_t)rend[(size_t)c].size();
+            in.read_off[(size_t)c + 1] = in.read_off[(size_t)c] + (int64_t)rend[(size_t)c].size();
+        }
+        in.cand_col.resize((size_t)in.cand_off.back()); in.cand_pos.resize((size_t)in.cand_off.back()); in.cand_ref.resize((size_t)in.cand_off.back());
+        in.read_end.resize((size_t)in.read_off.back());
+        parallel_for(C, n_threads, [&](int c) {
+            const ColumnSet& cs = sets[(size_t)c];
+            const std::vector<int>& cand = cv_candidates(*cst[(size_t)c]);
+            const int64_t k0 = in.cand_off[(size_t)c], s0 = contig_sel_off[(size_t)c];
+            for (size_t i = 0; i < cand.size(); ++i) {
+                in.cand_col[(size_t)k0 + i] = (int32_t)(s0 + cand[i]); in.cand_pos[(size_t)k0 + i] = cs.pos[(size_t)cand[i]];
+                in.cand_ref[(size_t)k0 + i] = cs.k0[(size_t)cand[i]];
+            }
+            std::copy(rend[(size_t)c].begin(), rend[(size_t)c].end(), in.read_end.begin() + in.read_off[(size_t)c]);
+        });
+        laps.lap("loop_a_prep");
+        if (int rc = dev.robust_partitions(in, la, &k_ms_a)) return rc;
+        laps.lap("loop_a");
+    }
+    std::atomic<int> n_host_a{0};
+    parallel_for(C, n_threads, [&](int c) {
+        const int r0 = b.contig_rec_off[(size_t)(c0 + c)];
+        if (on_device && !la.failed[(size_t)c])
+            cv_phase_a_import(*cst[(size_t)c], b.rec_pos.data() + r0, (int)(la.part_base[(size_t)c + 1] - la.part_base[(size_t)c]), la.rec + la.part_base[(size_t)c],
+                              la.state, la.more, la.less);
+        else { cv_phase_a_host(*cst[(size_t)c], sets[(size_t)c], b.rec_pos.data() + r0, rend[(size_t)c].data()); n_host_a++; }
+        cv_phase_b(*cst[(size_t)c], res[(size_t)c]);
+    });
+    if (std::getenv("HS_TIMING") && on_device) std::fprintf(stderr, "[hs timing] cv loop A on the device: %.3f ms of kernels, %d of %d contigs redone on the host\n", k_ms_a, n_host_a.load(), C);
     laps.lap("phase_ab");
     // ... loops C and D on the device: one wavefront per extracted column against the contig's final partitions ...
     {
@@ -398,7 +477,7 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
 // stage 4
 // ---------------------------------------------------------------------------------------------------
 int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
-           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out) {
+           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out, SrSparseLabels* sparse) {
     Laps laps("sr");
     if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
     const int C = n_contigs;
@@ -676,14 +755,26 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         win_off[(size_t)c + 1] = (int64_t)ws_.size();
     }
     R->win_off = dup_vec(win_off); R->win_start = dup_vec(ws_); R->win_end = dup_vec(we_); R->label_off = dup_vec(label_off);
-    R->labels = (int32_t*)std::malloc(std::max<size_t>(1, (size_t)label_off.back()) * sizeof(int32_t));
-    parallel_for((int)wl.size(), n_threads, [&](int i) {
-        int32_t* o = R->labels + label_off[(size_t)i];
-        const int64_t n = label_off[(size_t)i + 1] - label_off[(size_t)i];
-        std::fill(o, o + n, -2);
-        const SrWindowPlan& w = *wl[(size_t)i];
-        for (size_t j = 0; j < w.ids.size(); ++j) o[w.ids[j]] = w.labels[j];
-    });
+    if (sparse) {      // the caller spreads the labels itself (sr_expand_labels)
+        sparse->off.assign(wl.size() + 1, 0);
+        for (size_t i = 0; i < wl.size(); ++i) sparse->off[i + 1] = sparse->off[i] + (int64_t)wl[i]->ids.size();
+        sparse->ids.resize((size_t)sparse->off.back()); sparse->labels.resize((size_t)sparse->off.back());
+        parallel_for((int)wl.size(), n_threads, [&](int i) {
+            const SrWindowPlan& w = *wl[(size_t)i];
+            std::copy(w.ids.begin(), w.ids.end(), sparse->ids.begin() + sparse->off[(size_t)i]);
+            std::copy(w.labels.begin(), w.labels.end(), sparse->labels.begin() + sparse->off[(size_t)i]);
+        });
+        R->labels = nullptr;
+    } else {
+        R->labels = sr_labels_alloc((size_t)label_off.back());
+        parallel_for((int)wl.size(), n_threads, [&](int i) {
+            int32_t* o = R->labels + label_off[(size_t)i];
+            const int64_t n = label_off[(size_t)i + 1] - label_off[(size_t)i];
+            std::fill(o, o + n, -2);
+            const SrWindowPlan& w = *wl[(size_t)i];
+            for (size_t j = 0; j < w.ids.size(); ++j) o[w.ids[j]] = w.labels[j];
+        });
+    }
     laps.lap("result");
     R->n_cw_instances = n_cw;
     R->t_kernel_graph_ms = k6_ms; R->n_graph_rows_host = rows_on_host; R->n_windows_finished_on_host = n_finish_host;
@@ -704,11 +795,19 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     return HS_OK;
 }
 
+void sr_expand_labels(const SrSparseLabels& sp, const int64_t* label_off, int64_t w0, int64_t w1, int32_t* dense) {
+    for (int64_t w = w0; w < w1; ++w) {
+        int32_t* o = dense + (label_off[w] - label_off[0]);
+        std::fill(o, o + (label_off[w + 1] - label_off[w]), -2);
+        for (int64_t e = sp.off[(size_t)w]; e < sp.off[(size_t)w + 1]; ++e) o[sp.ids[(size_t)e]] = sp.labels[(size_t)e];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // stage 3 -> stage 4 hand-over without the .col text round trip
 // ---------------------------------------------------------------------------------------------------
 int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, int c0, int c1, const hs_cv_result* cv, float error_rate, float rsa, int32_t low_memory,
-                   int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out) {
+                   int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out, SrSparseLabels* sparse) {
     if (c0 < 0 || c1 > b.n_contigs || c0 > c1 || cv->n_contigs != c1 - c0) { set_error("sr_run_from_cv: contig range does not match the stage-3 result"); return HS_EINVAL; }
     const int C = c1 - c0;
     const double t_prep0 = now_ms();
@@ -774,7 +873,7 @@ int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, int c0, int c1, const hs_c
     }
     if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] sr hand-over from stage 3: %.2f ms\n", now_ms() - t_prep0);
     const int32_t w = window_size > 0 ? window_size : sr_window_size(hc.data(), C, amplicon != 0);
-    return sr_run(dev, hc.data(), C, w, error_rate, low_memory, seed, n_threads, out);
+    return sr_run(dev, hc.data(), C, w, error_rate, low_memory, seed, n_threads, out, sparse);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -31,6 +31,23 @@ struct CvPartitionTest {
     std::vector<int8_t> part_state;
 };
 
+struct CvLoopA {
+    std::vector<int64_t> cand_off;             // [C+1] candidates per contig
+    std::vector<int32_t> cand_col, cand_pos;   // column (index in the last gather) and position of every candidate, position order
+    std::vector<uint8_t> cand_ref;             // its reference code (k0)
+    std::vector<int32_t> contig_n_reads;       // [C]
+    std::vector<int64_t> read_off;             // [C+1] into read_end
+    std::vector<int32_t> read_end;             // exclusive end position of every read
+};
+struct CvLoopAResult {
+    std::vector<int64_t> part_base;            // [C+1] partitions per contig
+    std::vector<int32_t> failed;               // [C] != 0: the device gave up on this contig (pool exhausted), the host does it
+    const CvPartRecord* rec = nullptr;         // [part_base[C]]
+    const int8_t* state = nullptr;             // pool: rec.elem is the first of the N elements of a partition
+    const int32_t* more = nullptr;
+    const int32_t* less = nullptr;
+};
+
 struct CvDeviceOps {
     virtual ~CvDeviceOps() {}
     // K0+K1 + K2: per-record {q_end, n_err, n_len, n_events}; the global positions (unordered) whose second count c1 is
@@ -50,6 +67,11 @@ struct CvDeviceOps {
                               const int32_t** col_idx, const uint8_t** col_code) = 0;
     // K4: loops C and D of keep_only_robust_variants on the columns of the last gather(); keep[i] for column i
     virtual int column_partition_test(const CvPartitionTest& t, std::vector<uint8_t>& keep, float* k_ms) = 0;
+    // Loop A of keep_only_robust_variants (call_variants.cpp:590-638) on the columns of the last gather(), contig by contig.
+    // Optional: an implementation without it leaves the loop to the host (cv_phase_a_host). The result arrays are owned by
+    // the implementation and stay valid until the next call.
+    virtual bool has_robust_partitions() const { return false; }
+    virtual int robust_partitions(const CvLoopA& in, CvLoopAResult& out, float* k_ms) { (void)in; (void)out; (void)k_ms; return -1; }
 };
 
 // result of the whole-batch streaming pass (K0-K2): per-record counters and the interesting positions by (contig, position)
@@ -160,11 +182,26 @@ struct SrDeviceOps {
     virtual int cw(CwWave& wave, float* k_ms) = 0;
 };
 
+// The labels of a result before they are spread over the N reads of each window: per window the reads it holds (ascending
+// ids) and their labels. A caller that merges several partial results (contig groups, device shards) asks for this form
+// and writes the dense array once, in its final place (sr_expand_labels), instead of building it per part and copying it.
+struct SrSparseLabels {
+    std::vector<int64_t> off;           // [W+1]
+    std::vector<int32_t> ids, labels;
+};
+// sparse != nullptr: filled, and out->labels stays nullptr (label_off is filled as usual)
 int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
-           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out);
+           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out, SrSparseLabels* sparse = nullptr);
 
 int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& meta, int c0, int c1, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance,
-                   int32_t low_memory, int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out);
+                   int32_t low_memory, int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out,
+                   SrSparseLabels* sparse = nullptr);
+
+// the dense label array of an hs_sr_result (recycled big blocks; free_sr_result returns it)
+int32_t* sr_labels_alloc(size_t n_labels);
+void sr_labels_free(int32_t* labels);
+// windows [w0, w1) of `sp` into dense[label_off[w] - label_off[0] ...]: -2 for the reads a window does not hold
+void sr_expand_labels(const SrSparseLabels& sp, const int64_t* label_off, int64_t w0, int64_t w1, int32_t* dense);
 
 // .col reader of HS_separate_reads (separate_reads.cpp:46-190)
 struct ColFileContig {

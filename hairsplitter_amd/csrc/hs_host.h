@@ -45,6 +45,15 @@ void cv_state_free(CvContigState* st);
 // read_start / read_end: [n_reads] reference interval [start, end) of every record of the contig (POS-1, POS-1 + reference span)
 void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out,
                  const int32_t* read_start, const int32_t* read_end);
+// The same in steps, for the driver that runs loop A on the device (k_robust_partitions):
+//   cv_phase_v1 (candidates) -> [device loop A -> cv_phase_a_import] or cv_phase_a_host -> cv_phase_b
+struct CvPartRecord { int32_t left, right, n_occ, n_corr, lo, hi, reach, pad; int64_t elem; };   // what k_partitions_pack writes per partition
+void cv_phase_v1(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out);
+const std::vector<int>& cv_candidates(const CvContigState& st);   // candidate columns (indices into the ColumnSet), ascending position
+void cv_phase_a_host(CvContigState& st, ColumnSet& cs, const int32_t* read_start, const int32_t* read_end);
+void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const int8_t* pool_state,
+                       const int32_t* pool_more, const int32_t* pool_less);
+void cv_phase_b(CvContigState& st, ContigCvResult& out);
 // exports the final partitions / candidate flags for the device test (K4) and imports its verdict
 void cv_export_partitions(const CvContigState& st, std::vector<int8_t>& state, std::vector<int64_t>& state_off);
 void cv_export_candidates(const CvContigState& st, uint8_t* is_cand);

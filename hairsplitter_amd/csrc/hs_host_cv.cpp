@@ -495,6 +495,8 @@ struct CvContigState {
     int n_reads = 0;
     float mean_distance = 0, threshold = 0;
     std::vector<int> cand, automatic;
+    std::vector<DensePartition> parts;   // what loop A leaves (host loop or imported from the device)
+    std::vector<int32_t> rank_of, orig_of;   // reads ranked by start position (ties by index): the bit order of the bit sets
     std::vector<DensePartition> finals;
     std::vector<char> is_cand, keep;     // per extracted column
     bool have_partitions = false;
@@ -503,18 +505,14 @@ struct CvContigState {
 CvContigState* cv_state_new() { return new CvContigState(); }
 void cv_state_free(CvContigState* st) { delete st; }
 
-// V1 scan + loops A and B (sequential per contig): call_variants.cpp:525-536, :590-708
-void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out,
-                 const int32_t* read_start, const int32_t* read_end) {
+// V1 scan (call_variants.cpp:525-536): the candidate and the "automatic" columns of a contig
+void cv_phase_v1(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out) {
     st.n_reads = n_reads; st.mean_distance = mean_distance; st.threshold = automatic_snp_threshold;
     const int n_cols = (int)cs.pos.size();
     const int min_reads = mean_distance < 0.015 ? 3 : 5;                       // :463-466
-    auto col_idx = [&](int i) { return cs.idx + cs.off[i]; };
-    auto col_code = [&](int i) { return cs.code + cs.off[i]; };
-    auto col_n = [&](int i) { return (int)(cs.off[i + 1] - cs.off[i]); };
     st.is_cand.assign((size_t)n_cols, 0); st.keep.assign((size_t)n_cols, 0);
-
     std::vector<int>& cand = st.cand; std::vector<int>& automatic = st.automatic;
+    cand.clear(); automatic.clear();
     int pos_of_last = -5;
     for (int i = 0; i < n_cols; ++i) {
         const int k0 = cs.k0[i], k1 = cs.k1[i];
@@ -527,23 +525,35 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
     }
     out.n_candidates = (int)cand.size();
     out.n_automatic = (int)automatic.size();
+}
+const std::vector<int>& cv_candidates(const CvContigState& st) { return st.cand; }
 
+static void rank_reads(CvContigState& st, const int32_t* read_start) {
+    const int n_reads = st.n_reads;
+    st.rank_of.assign((size_t)n_reads, 0); st.orig_of.assign((size_t)((n_reads + 63) / 64) * 64, 0);
+    std::vector<int32_t> order((size_t)n_reads);
+    for (int r = 0; r < n_reads; ++r) order[(size_t)r] = r;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return read_start[a] != read_start[b] ? read_start[a] < read_start[b] : a < b; });
+    for (int k = 0; k < n_reads; ++k) { st.rank_of[(size_t)order[(size_t)k]] = k; st.orig_of[(size_t)k] = order[(size_t)k]; }
+}
+
+// loop A (:590-638) on the host: sequential over the candidate columns of the contig
+void cv_phase_a_host(CvContigState& st, ColumnSet& cs, const int32_t* read_start, const int32_t* read_end) {
+    const int n_reads = st.n_reads;
+    auto col_idx = [&](int i) { return cs.idx + cs.off[i]; };
+    auto col_code = [&](int i) { return cs.code + cs.off[i]; };
+    auto col_n = [&](int i) { return (int)(cs.off[i + 1] - cs.off[i]); };
+    const std::vector<int>& cand = st.cand;
     const bool tim = std::getenv("HS_TIMING_AB") != nullptr;
     auto nowus = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a0 = tim ? nowus() : 0;
     long n_cmp = 0, n_aug = 0;
     double t_build = 0, t_aug = 0;
-    // ---- loop A (:590-638) ----
-    std::vector<DensePartition> parts;
+    std::vector<DensePartition>& parts = st.parts;
+    parts.clear();
     ColumnBits colbits;
-    // reads ranked by start position (ties by index): the bit order of the partitions' and columns' bit sets
-    std::vector<int32_t> rank_of((size_t)n_reads), orig_of((size_t)((n_reads + 63) / 64) * 64, 0);
-    {
-        std::vector<int32_t> order((size_t)n_reads);
-        for (int r = 0; r < n_reads; ++r) order[(size_t)r] = r;
-        std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return read_start[a] != read_start[b] ? read_start[a] < read_start[b] : a < b; });
-        for (int k = 0; k < n_reads; ++k) { rank_of[(size_t)order[(size_t)k]] = k; orig_of[(size_t)k] = order[(size_t)k]; }
-    }
+    rank_reads(st, read_start);
+    const std::vector<int32_t>& rank_of = st.rank_of; const std::vector<int32_t>& orig_of = st.orig_of;
     int last_position = -5;
     for (int ci : cand) {
         const int pos = cs.pos[ci];
@@ -590,15 +600,46 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
             parts.back().n_corr = n_corr;
         } else last_position = pos;
     }
+    if (tim) std::fprintf(stderr, "[hs timing] loop A: %d candidates, %zu partitions, %ld comparisons, %ld augmentations; %.0f us (build %.0f, augment %.0f)\n",
+                          (int)cand.size(), parts.size(), n_cmp, n_aug, nowus() - t_a0, t_build, t_aug);
+}
+
+// loop A ran on the device (k_robust_partitions): its partitions become the host's dense form
+void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const int8_t* pool_state,
+                       const int32_t* pool_more, const int32_t* pool_less) {
+    const int N = st.n_reads;
+    rank_reads(st, read_start);
+    std::vector<DensePartition>& parts = st.parts;
+    parts.clear();
+    parts.resize((size_t)n_parts);
+    const size_t words = ((size_t)N + 63) >> 6;
+    for (int p = 0; p < n_parts; ++p) {
+        DensePartition& d = parts[(size_t)p];
+        const CvPartRecord& r = rec[p];
+        d.left = r.left; d.right = r.right; d.n_occ = r.n_occ; d.n_corr = r.n_corr; d.lo = r.lo; d.hi = r.hi; d.reach = r.reach;
+        d.rank_of = st.rank_of.data(); d.wlo = 0; d.whi = -1;
+        const int8_t* s = pool_state + r.elem; const int32_t* mo = pool_more + r.elem; const int32_t* le = pool_less + r.elem;
+        d.state.assign(s, s + N);
+        d.more.assign((size_t)N, 0); d.less.assign((size_t)N, 0);
+        d.present.assign(words, 0ull); d.plus.assign(words, 0ull); d.minus.assign(words, 0ull);
+        for (int q = d.lo; q <= d.hi; ++q) {
+            if (s[q] == ABSENT) continue;
+            d.more[(size_t)q] = mo[q]; d.less[(size_t)q] = le[q];
+            d.sync_bits(q);
+        }
+    }
+}
+
+// loop B (:646-708)
+void cv_phase_b(CvContigState& st, ContigCvResult& out) {
+    std::vector<DensePartition>& parts = st.parts;
+    const float mean_distance = st.mean_distance;
     out.n_partitions = (int)parts.size();
     st.have_partitions = !parts.empty();
     if (parts.empty()) return;
-
-    const double t_b0 = tim ? nowus() : 0;
-    // ---- loop B (:646-708) ----
     std::vector<DensePartition>& finals = st.finals;
     for (size_t p1 = 0; p1 < parts.size(); ++p1) {
-        const double p_value = significance(parts[p1], (int)cand.size());
+        const double p_value = significance(parts[p1], (int)st.cand.size());
         if (!((p_value < 0.001 || parts[p1].n_corr > 1) && is_informative(parts[p1], mean_distance))) continue;
         bool different = true;
         for (size_t p2 = 0; p2 < finals.size(); ++p2) {
@@ -624,8 +665,15 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
         if (different) finals.push_back(parts[p1]);
     }
     out.n_final_partitions = (int)finals.size();
-    if (tim) std::fprintf(stderr, "[hs timing] phase_ab: %d candidates, %zu partitions, %ld comparisons, %ld augmentations, %zu finals; loop A %.0f us (build %.0f, augment %.0f), loop B %.0f us\n",
-                          (int)cand.size(), parts.size(), n_cmp, n_aug, finals.size(), t_b0 - t_a0, t_build, t_aug, nowus() - t_b0);
+    std::vector<DensePartition>().swap(parts);
+}
+
+// V1 scan + loops A and B on the host (sequential per contig): call_variants.cpp:525-536, :590-708
+void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out,
+                 const int32_t* read_start, const int32_t* read_end) {
+    cv_phase_v1(st, n_reads, cs, mean_distance, automatic_snp_threshold, out);
+    cv_phase_a_host(st, cs, read_start, read_end);
+    cv_phase_b(st, out);
 }
 
 // Loops C (:721-738) and D (:745-764) run on the device (k_column_partition_test): the final partitions leave as dense

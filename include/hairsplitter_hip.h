@@ -62,11 +62,11 @@ int hs_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchron
  * events on the stream it runs on; the elapsed times, the number of launches and the ALGORITHMIC bytes of each launch
  *  are accumulated per kernel family, process-wide, until hs_kernel_stats_reset().
  * ---------------------------------------------------------------------------------------------- */
-#define HS_NKERNELS 16
+#define HS_NKERNELS 17
 enum {
     HS_K_CIGAR_SCAN = 0, HS_K_PILEUP, HS_K_COLUMN_STATS, HS_K_GATHER_COLUMNS, HS_K_COLUMN_TOP3, HS_K_PACK_COLUMNS, HS_K_PARTITION_TEST,
     HS_K_SNP_PLANES, HS_K_SIMDIFF, HS_K_GRAPH_ROWS, HS_K_GRAPH_CSR, HS_K_VISIT_LISTS, HS_K_CW_SEEDED, HS_K_WINDOW_TAIL, HS_K_CW_LOCAL,
-    HS_K_OTHER
+    HS_K_ROBUST_PARTITIONS, HS_K_OTHER
 };
 typedef struct hs_kernel_stats {
     double ms[HS_NKERNELS];        /* sum of the launch durations (hipEventElapsedTime) */
