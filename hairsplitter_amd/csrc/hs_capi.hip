@@ -1178,68 +1178,80 @@ struct HipCvOps : hs::CvDeviceOps {
         if (C == 0 || n_cand == 0) return HS_OK;
         if (in.cand_col.size() != (size_t)n_cand) { set_error("robust_partitions: bad arguments"); return HS_EINVAL; }
         for (int32_t col : in.cand_col) if (col < 0 || col >= n_gathered) { set_error("robust_partitions: column outside the last gather"); return HS_EINVAL; }
-        // the pool: a contig cannot make more partitions than it has candidates, N elements each. HS_LOOP_A_POOL_ELEMS caps it
-        // (a contig that does not fit is left to the host)
-        long long pool_cap = 0;
-        std::vector<std::pair<double, int>> weight((size_t)C);
+        // state tables: a contig cannot make more partitions than it has candidates -> ceil(candidates / 64) blocks of N x 64.
+        // HS_LOOP_A_TABLE_ELEMS caps the whole (a contig that does not fit is left to the host: failed = 1)
+        static const long long table_limit = []() { const char* e = std::getenv("HS_LOOP_A_TABLE_ELEMS"); return e ? std::atoll(e) : (1ll << 31); }();
+        std::vector<int64_t> tab_off((size_t)C + 1, 0);
+        std::vector<std::pair<double, int>> weight;
+        int max_n = 1;
         for (int c = 0; c < C; ++c) {
             const long long k = in.cand_off[(size_t)c + 1] - in.cand_off[(size_t)c];
-            pool_cap += k * (long long)in.contig_n_reads[(size_t)c];
-            weight[(size_t)c] = std::make_pair(-(double)k * (double)std::max(in.contig_n_reads[(size_t)c], 64), c);
+            const long long need = ((k + 63) / 64) * 64 * (long long)in.contig_n_reads[(size_t)c];
+            const bool fits = tab_off[(size_t)c] + need <= table_limit;
+            tab_off[(size_t)c + 1] = tab_off[(size_t)c] + (fits ? need : 0);
+            if (!fits) out.failed[(size_t)c] = 1;
+            else if (k > 0) { weight.push_back(std::make_pair(-(double)k, c)); max_n = std::max(max_n, in.contig_n_reads[(size_t)c]); }
         }
-        static const long long pool_limit = []() { const char* e = std::getenv("HS_LOOP_A_POOL_ELEMS"); return e ? std::atoll(e) : (1ll << 31); }();
-        pool_cap = std::max<long long>(1, std::min(pool_cap, pool_limit));
+        const int n_dev = (int)weight.size();
+        if (n_dev == 0) return HS_OK;
         std::sort(weight.begin(), weight.end());
-        std::vector<int32_t> order((size_t)C);
-        for (int c = 0; c < C; ++c) order[(size_t)c] = weight[(size_t)c].second;
-        DBuf d_co_, d_cc_, d_cp, d_cr, d_n, d_ro, d_re, d_ord, d_state, d_more, d_less, d_scal, d_np, d_fail, d_used, d_base, d_rec;
+        std::vector<int32_t> order((size_t)n_dev);
+        for (int i = 0; i < n_dev; ++i) order[(size_t)i] = weight[(size_t)i].second;
+        const long long tab_total = std::max<long long>(1, tab_off[(size_t)C]);
+        DBuf d_co_, d_cc_, d_cp, d_cr, d_n, d_ro, d_re, d_ord, d_to, d_tab, d_more, d_less, d_scal, d_np, d_pb, d_eb, d_rec, d_state, d_mo, d_le;
         UploadPack pk;
         pk.add(in.cand_off, d_co_); pk.add(in.cand_col, d_cc_); pk.add(in.cand_pos, d_cp); pk.add(in.cand_ref, d_cr); pk.add(in.contig_n_reads, d_n);
-        pk.add(in.read_off, d_ro); pk.add(in.read_end, d_re); pk.add(order, d_ord);
+        pk.add(in.read_off, d_ro); pk.add(in.read_end, d_re); pk.add(order, d_ord); pk.add(tab_off, d_to);
         if (int rc = pk.commit(stream)) return rc;
-        if (int rc = d_state.alloc((size_t)pool_cap)) return rc;
-        if (int rc = d_more.alloc((size_t)pool_cap * 4)) return rc;
-        if (int rc = d_less.alloc((size_t)pool_cap * 4)) return rc;
-        if (int rc = d_scal.alloc((size_t)n_cand * 36 + 64)) return rc;
+        if (int rc = d_tab.alloc((size_t)tab_total)) return rc;
+        if (int rc = d_more.alloc((size_t)tab_total * 4)) return rc;
+        if (int rc = d_less.alloc((size_t)tab_total * 4)) return rc;
+        if (int rc = d_scal.alloc((size_t)n_cand * 28 + 64)) return rc;
         if (int rc = d_np.alloc((size_t)C * 4)) return rc;
-        if (int rc = d_fail.alloc((size_t)C * 4)) return rc;
-        if (int rc = d_used.alloc(8)) return rc;
-        if (int rc = d_base.alloc(((size_t)C + 1) * 8)) return rc;
-        if (int rc = d_rec.alloc((size_t)n_cand * sizeof(hsdev::PartitionRecord))) return rc;
-        HS_HIP(hipMemsetAsync(d_used.p, 0, 8, stream));
+        if (int rc = d_pb.alloc(((size_t)C + 1) * 8)) return rc;
+        if (int rc = d_eb.alloc(((size_t)C + 1) * 8)) return rc;
+        HS_HIP(hipMemsetAsync(d_tab.p, 0, (size_t)tab_total, stream));
+        HS_HIP(hipMemsetAsync(d_np.p, 0, (size_t)C * 4, stream));
         hsdev::PartitionScalars ps;
         {
-            char* base = (char*)d_scal.p;
-            ps.elem = (long long*)base; base += (size_t)n_cand * 8;      // (8-byte aligned first)
-            ps.left = (int32_t*)base; base += (size_t)n_cand * 4; ps.right = (int32_t*)base; base += (size_t)n_cand * 4;
-            ps.n_occ = (int32_t*)base; base += (size_t)n_cand * 4; ps.n_corr = (int32_t*)base; base += (size_t)n_cand * 4;
-            ps.lo = (int32_t*)base; base += (size_t)n_cand * 4; ps.hi = (int32_t*)base; base += (size_t)n_cand * 4;
-            ps.reach = (int32_t*)base;
+            int32_t* base = (int32_t*)d_scal.p;
+            ps.left = base; ps.right = base + n_cand; ps.n_occ = base + 2 * n_cand; ps.n_corr = base + 3 * n_cand; ps.lo = base + 4 * n_cand;
+            ps.hi = base + 5 * n_cand; ps.reach = base + 6 * n_cand;
         }
+        // LDS: the two scalar arrays + as many table blocks of the widest contig as fit (at least one if it can)
+        static const int lds_budget = []() { const char* e = std::getenv("HS_LOOP_A_LDS"); return e ? std::atoi(e) : 64 * 1024; }();
+        const int lds_bytes = std::max(2 * 1024 * 4 + 64, std::min(160 * 1024 - 1024, std::max(lds_budget, 2 * 1024 * 4 + std::min(max_n, 2000) * 64)));
+        if (lds_bytes > 48 * 1024)
+            HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_robust_partitions), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         EventPair e; if (int rc = e.init()) return rc;
         HS_HIP(hipEventRecord(e.a, stream));
         if (int rc = kc.begin(HS_K_ROBUST_PARTITIONS, stream)) return rc;
-        hipLaunchKernelGGL(hsdev::k_robust_partitions, dim3((unsigned)C), dim3(256), 0, stream, d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(),
+        hipLaunchKernelGGL(hsdev::k_robust_partitions, dim3((unsigned)n_dev), dim3(64), (size_t)lds_bytes, stream, d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(),
                            d_co_.as<int64_t>(), d_cc_.as<int32_t>(), d_cp.as<int32_t>(), d_cr.as<uint8_t>(), d_n.as<int32_t>(), d_ro.as<int64_t>(),
-                           d_re.as<int32_t>(), d_ord.as<int32_t>(), C, d_state.as<int8_t>(), d_more.as<int32_t>(), d_less.as<int32_t>(), pool_cap,
-                           d_used.as<unsigned long long>(), ps, d_np.as<int32_t>(), d_fail.as<int32_t>());
-        HS_HIP(hipGetLastError());
-        hipLaunchKernelGGL(hsdev::k_partitions_pack, dim3(1), dim3(256), 0, stream, d_co_.as<int64_t>(), d_np.as<int32_t>(), C, ps, d_base.as<int64_t>(),
-                           d_rec.as<hsdev::PartitionRecord>());
+                           d_re.as<int32_t>(), d_ord.as<int32_t>(), n_dev, d_to.as<int64_t>(), d_tab.as<uint8_t>(), d_more.as<int32_t>(), d_less.as<int32_t>(),
+                           ps, d_np.as<int32_t>(), lds_bytes);
         HS_HIP(hipGetLastError());
         // the candidates' entries (idx + code) once: their share of the gathered entries (the ops do not keep the column lengths on the host)
         if (int rc = kc.end(5 * (gathered_entries * n_cand / std::max(1, n_gathered)), stream)) return rc;
+        hipLaunchKernelGGL(hsdev::k_partitions_scan, dim3(1), dim3(64), 0, stream, d_np.as<int32_t>(), d_n.as<int32_t>(), C, d_pb.as<int64_t>(), d_eb.as<int64_t>());
+        HS_HIP(hipGetLastError());
         HS_HIP(hipEventRecord(e.b, stream));
         // first the sizes, then the partitions themselves
-        HBuf h1; if (int rc = h1.alloc(8 + ((size_t)C + 1) * 8 + (size_t)C * 4)) return rc;
-        HS_HIP(hipMemcpyAsync(h1.p, d_used.p, 8, hipMemcpyDeviceToHost, stream));
-        HS_HIP(hipMemcpyAsync((char*)h1.p + 8, d_base.p, ((size_t)C + 1) * 8, hipMemcpyDeviceToHost, stream));
-        HS_HIP(hipMemcpyAsync((char*)h1.p + 8 + ((size_t)C + 1) * 8, d_fail.p, (size_t)C * 4, hipMemcpyDeviceToHost, stream));
+        HBuf h1; if (int rc = h1.alloc(((size_t)C + 1) * 16)) return rc;
+        HS_HIP(hipMemcpyAsync(h1.p, d_pb.p, ((size_t)C + 1) * 8, hipMemcpyDeviceToHost, stream));
+        HS_HIP(hipMemcpyAsync((char*)h1.p + ((size_t)C + 1) * 8, d_eb.p, ((size_t)C + 1) * 8, hipMemcpyDeviceToHost, stream));
         if (int rc = stream_wait(stream)) return rc;
-        const long long used = std::min<long long>((long long)*(unsigned long long*)h1.p, pool_cap);
-        std::memcpy(out.part_base.data(), (char*)h1.p + 8, ((size_t)C + 1) * 8);
-        std::memcpy(out.failed.data(), (char*)h1.p + 8 + ((size_t)C + 1) * 8, (size_t)C * 4);
+        std::memcpy(out.part_base.data(), h1.p, ((size_t)C + 1) * 8);
         const int64_t n_parts = out.part_base[(size_t)C];
+        const int64_t used = ((const int64_t*)((char*)h1.p + ((size_t)C + 1) * 8))[C];
+        if (int rc = d_rec.alloc(std::max<size_t>(1, (size_t)n_parts) * sizeof(hsdev::PartitionRecord))) return rc;
+        if (int rc = d_state.alloc(std::max<size_t>(1, (size_t)used))) return rc;
+        if (int rc = d_mo.alloc(std::max<size_t>(1, (size_t)used) * 4)) return rc;
+        if (int rc = d_le.alloc(std::max<size_t>(1, (size_t)used) * 4)) return rc;
+        hipLaunchKernelGGL(hsdev::k_partitions_unpack, dim3((unsigned)C), dim3(256), 0, stream, d_co_.as<int64_t>(), d_np.as<int32_t>(), d_n.as<int32_t>(), d_to.as<int64_t>(),
+                           d_tab.as<uint8_t>(), d_more.as<int32_t>(), d_less.as<int32_t>(), ps, d_pb.as<int64_t>(), d_eb.as<int64_t>(), d_rec.as<hsdev::PartitionRecord>(),
+                           d_state.as<int8_t>(), d_mo.as<int32_t>(), d_le.as<int32_t>());
+        HS_HIP(hipGetLastError());
         auto grow = [](HBuf& h, size_t need) -> int { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); };
         if (int rc = grow(h_la_rec, std::max<size_t>(1, (size_t)n_parts) * sizeof(hs::CvPartRecord))) return rc;
         if (int rc = grow(h_la_state, std::max<size_t>(1, (size_t)used))) return rc;
@@ -1248,8 +1260,8 @@ struct HipCvOps : hs::CvDeviceOps {
         if (n_parts) HS_HIP(hipMemcpyAsync(h_la_rec.p, d_rec.p, (size_t)n_parts * sizeof(hs::CvPartRecord), hipMemcpyDeviceToHost, stream));
         if (used) {
             HS_HIP(hipMemcpyAsync(h_la_state.p, d_state.p, (size_t)used, hipMemcpyDeviceToHost, stream));
-            HS_HIP(hipMemcpyAsync(h_la_more.p, d_more.p, (size_t)used * 4, hipMemcpyDeviceToHost, stream));
-            HS_HIP(hipMemcpyAsync(h_la_less.p, d_less.p, (size_t)used * 4, hipMemcpyDeviceToHost, stream));
+            HS_HIP(hipMemcpyAsync(h_la_more.p, d_mo.p, (size_t)used * 4, hipMemcpyDeviceToHost, stream));
+            HS_HIP(hipMemcpyAsync(h_la_less.p, d_le.p, (size_t)used * 4, hipMemcpyDeviceToHost, stream));
         }
         if (int rc = stream_wait(stream)) return rc;
         out.rec = (const hs::CvPartRecord*)h_la_rec.p; out.state = (const int8_t*)h_la_state.p; out.more = (const int32_t*)h_la_more.p; out.less = (const int32_t*)h_la_less.p;

@@ -62,6 +62,15 @@ def test_robin_hood_order_vectors(built):
         assert list(map(int, o.split())) == v["order"]
 
 
+def test_rh8_static_order(built):
+    """The closed form k_robust_partitions uses for the iteration order of small hash maps (hs_kernels_parts.hip) against the
+    emulator, on two million random key sets"""
+    exe = os.path.join(ROOT, "tests", "harness", "_build", "rh8_static_order")
+    r = subprocess.run([exe, "2000000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert " bad 0 " in r.stdout
+
+
 def test_shuffle_permutations_pinned(built):
     """libstdc++ mt19937(12345) + std::shuffle (SURVEY.md appendix B known answers)."""
     assert ol.shuffled_order(5).tolist() == [0, 1, 4, 3, 2]
