@@ -206,7 +206,7 @@ def main():
     api.load().hs_set_device(local_rank)
     # host threads for the sequential glue: the parallel sections are short, and waking hundreds of workers on a busy
     # box costs more than it buys (measured: 256 threads -> 15-60 ms steps, 64 threads -> 11.6 ms steps)
-    n_threads = args.threads or max(1, min(64, (4 * effective_cores()) // world))
+    n_threads = args.threads or max(1, min(64, (3 * effective_cores()) // world))      # (16 usable cores: 32 threads 46 ms per step, 48: 44, 64: 47, 128: 51)
 
     B = len(contigs)
     G = max(1, min(args.groups if args.groups > 0 else min(8, max(1, n_threads // 4)), max(B, 1)))

@@ -96,6 +96,19 @@ template <class T> T* dup_vec(const std::vector<T>& v) {
 
 void hs_parallel_for(int n, int n_threads, const std::function<void(int)>& f) { WorkerPool::get().run(n, n_threads, f); }
 
+// Worker threads for host-side passes when the caller names no count: the cores this process may actually use -- the cgroup
+// CPU quota when there is one (a container limited to 16 of 256 CPUs must not start 255 workers) -- and never more than 32
+int host_threads() {
+    static const int n = [] {
+        long q = -1, per = 100000;
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) { char a[32]; if (std::fscanf(f, "%31s %ld", a, &per) == 2 && std::strcmp(a, "max") != 0) q = std::atol(a); std::fclose(f); }
+        int t = (int)std::thread::hardware_concurrency();
+        if (q > 0 && per > 0) t = std::min<int>(t, (int)((q + per - 1) / per));
+        return std::max(1, std::min(t, 32));
+    }();
+    return n;
+}
+
 void free_cv_result(hs_cv_result* r) {
     if (!r) return;
     std::free(r->mean_distance); std::free(r->depth); std::free(r->snp_off); std::free(r->snp_pos); std::free(r->snp_ref);
@@ -229,7 +242,7 @@ int cv_select(CvDeviceOps& dev, const CvMeta& b, CvSelection& sel) {
 // threads, each with its own device interface (stream).
 int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int c0, int c1, float automatic_snp_threshold, int n_threads,
                  hs_cv_result** out) {
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads <= 0) n_threads = host_threads();
     if (c0 < 0 || c1 > b.n_contigs || c0 > c1) { set_error("cv_run_range: bad contig range"); return HS_EINVAL; }
     const int C = c1 - c0;
     const double t_start = now_ms();
@@ -479,7 +492,7 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
 int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
            int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out, SrSparseLabels* sparse) {
     Laps laps("sr");
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads <= 0) n_threads = host_threads();
     const int C = n_contigs;
     const bool lowmem = low_memory != 0;
     const double t_start = now_ms();
@@ -815,7 +828,7 @@ int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, int c0, int c1, const hs_c
     std::vector<std::vector<int32_t>> rs((size_t)C), re((size_t)C), spos((size_t)C);
     std::vector<std::vector<uint8_t>> sref((size_t)C), salt((size_t)C);
     std::vector<std::vector<int64_t>> coff((size_t)C);
-    if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (n_threads <= 0) n_threads = host_threads();
     parallel_for(C, n_threads, [&](int c) {
         const int gc = c0 + c;   // index in the batch
         const int r0 = b.contig_rec_off[(size_t)gc], r1 = b.contig_rec_off[(size_t)gc + 1];

@@ -182,6 +182,8 @@ struct SrDeviceOps {
     virtual int cw(CwWave& wave, float* k_ms) = 0;
 };
 
+int host_threads();      // default number of host worker threads: usable cores (cgroup quota), at most 32
+
 // The labels of a result before they are spread over the N reads of each window: per window the reads it holds (ascending
 // ids) and their labels. A caller that merges several partial results (contig groups, device shards) asks for this form
 // and writes the dense array once, in its final place (sr_expand_labels), instead of building it per part and copying it.
