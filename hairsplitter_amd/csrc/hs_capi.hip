@@ -872,7 +872,7 @@ static void tune_allocator() {
     static std::once_flag once;
     std::call_once(once, [] {
         const int a = mallopt(M_MMAP_THRESHOLD, 32 << 20);      // the largest value glibc accepts
-        const int b = mallopt(M_TRIM_THRESHOLD, 1 << 30);
+        const int b = mallopt(M_TRIM_THRESHOLD, 0x7fffffff);      // (never give freed memory back: the next call takes it again)
         const int c = mallopt(M_TOP_PAD, 64 << 20);
         if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] mallopt: mmap_threshold %d trim_threshold %d top_pad %d\n", a, b, c);
     });
@@ -1670,6 +1670,12 @@ struct HipSrOps : hs::SrDeviceOps {
                                G.d_prog_info.as<uint32_t>(), G.d_prog_adj.as<unsigned long long>(), d_ll.as<int32_t>(), n, d_iw.as<int32_t>(), d_is.as<int64_t>(),
                                d_sets.as<unsigned long long>(), d_names.as<uint8_t>(), d_slots.as<uint8_t>(), d_alive.as<uint8_t>(), d_slab.as<int32_t>(), d_stat.as<unsigned long long>());
             HS_HIP(hipGetLastError());
+            if (std::getenv("HS_TIMING")) {
+                int32_t n_ovf = 0;
+                if (int rc = d2h_pinned(&n_ovf, d_ovf_n.p, 4, stream)) return rc;
+                std::fprintf(stderr, "[hs timing] sr: %d per-SNP runs one per lane, %d of them with more than 16 labels alive (-> one wavefront each); %zu runs in units of 8, %zu one wavefront each\n",
+                             n, n_ovf, unit_win.size() * 8, list_big.size());
+            }
             // the few runs with more labels alive than slots: one wavefront each, the list and its length are on the device
             hipLaunchKernelGGL(hsdev::k_cw_seeded_wave, dim3((unsigned)std::min(n, 1024)), dim3(64), (size_t)64 * 8, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(),
                                G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), d_ovf.as<int32_t>(), 0, d_ovf_n.as<int32_t>(),

@@ -265,3 +265,40 @@ def test_cluster_merging_on_device_equals_host_code(built):
     assert sr_h["n_windows_finished_on_host"] > 0.5 * n_windows          # the switch works
     assert sr["n_windows_finished_on_host"] < 0.1 * n_windows            # and the device is what normally runs
     assert len(set(sr["labels"].tolist())) > 3                           # real clusterings, not all-zero windows
+
+
+@pytest.mark.gpu
+def test_separate_reads_with_many_alleles_per_column(built):
+    """Stage 4 on a hand-made .col whose SNP columns carry up to two dozen different codes, on contigs of 40 .. 300 reads that all
+    span the contig: the per-SNP Chinese-Whispers runs then start from more labels than the one-run-per-lane kernel keeps in
+    registers (-> its overflow list), windows of exactly 64 and of 65 reads sit on either side of that kernel's limit, and the
+    300-read contig takes the one-wavefront-per-run kernel. Byte-equal .gro against the oracle."""
+    import numpy as np
+    rng = np.random.default_rng(77)
+    L = 6300
+    lines = []
+    for ci, N in enumerate([40, 64, 65, 130, 300]):
+        lines.append(f"CONTIG\tc{ci}\t{L}\t{N}.0")
+        for r in range(N):
+            lines.append(f"READ\tc{ci}_r{r}\t0\t{L}\t0\t{L}\t1")
+        hap = rng.integers(0, 3, N)
+        for pos in range(150, L - 150, 45):
+            ref, alt = (int(x) for x in rng.choice(np.arange(40, 64), 2, replace=False))
+            allele = rng.integers(0, 2, 3)
+            if allele.min() == allele.max():
+                allele[0] ^= 1
+            codes = np.where(allele[hap] == 0, ref, alt)
+            noisy = rng.random(N) < (0.5 if pos % 2 else 0.1)
+            codes = np.where(noisy, rng.integers(70, 94, N), codes)
+            covered = np.flatnonzero(rng.random(N) < 0.97)
+            lines.append(f"SNPS\t{pos}\t{ref}\t{alt}\t" + "".join(f"{i}," for i in covered) + "\t" + "".join(f"{int(codes[i])}," for i in covered))
+    with tempfile.TemporaryDirectory() as td:
+        col = os.path.join(td, "many.col")
+        open(col, "w").write("\n".join(lines) + "\n")
+        outs = []
+        for exe, tag in ((built["sr"], "hip"), (built["oracle"], "oracle")):
+            gro = os.path.join(td, tag + ".gro")
+            cmd = ([exe] if tag == "hip" else [exe, "separate_reads"]) + [col, "2", "0.05", os.path.join(td, "none"), "0", "0", "0", gro, "0"]
+            subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+            outs.append(open(gro, "rb").read())
+        assert len(outs[0]) > 1000 and outs[0] == outs[1]
