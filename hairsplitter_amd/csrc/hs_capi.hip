@@ -729,7 +729,7 @@ static int simdiff_launch(const uint64_t* d_alt, const uint64_t* d_ref, const in
     std::vector<int32_t> tc, ti, tj;
     for (size_t c = 0; c < h_n_reads.size(); ++c) {
         const int nt = (h_n_reads[c] + 63) / 64;
-        for (int i = 0; i < nt; ++i) for (int j = 0; j < nt; ++j) { tc.push_back((int32_t)c); ti.push_back(i); tj.push_back(j); }
+        for (int i = 0; i < nt; ++i) for (int j = i; j < nt; ++j) { tc.push_back((int32_t)c); ti.push_back(i); tj.push_back(j); }      // the upper triangle: the kernel mirrors
     }
     if (tc.empty()) return HS_OK;
     if (int rc = t_c.upload(tc)) return rc;

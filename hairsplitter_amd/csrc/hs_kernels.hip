@@ -897,7 +897,9 @@ __global__ __launch_bounds__(256) void k_simdiff(
     const int32_t* __restrict__ n_reads, const int32_t* __restrict__ words, const int64_t* __restrict__ out_off,
     const int32_t* __restrict__ tile_contig, const int32_t* __restrict__ tile_i, const int32_t* __restrict__ tile_j,
     int32_t* __restrict__ sim, int32_t* __restrict__ diff) {
-    __shared__ uint64_t sAi[64][SD_KW + 1], sRi[64][SD_KW + 1], sAj[64][SD_KW + 1], sRj[64][SD_KW + 1];
+    __shared__ uint64_t s_planes[4][64][SD_KW + 1];      // one array: the mirrored store below reuses it as a 64 x 65 int tile
+    uint64_t (*sAi)[SD_KW + 1] = s_planes[0]; uint64_t (*sRi)[SD_KW + 1] = s_planes[1];
+    uint64_t (*sAj)[SD_KW + 1] = s_planes[2]; uint64_t (*sRj)[SD_KW + 1] = s_planes[3];
     const int tid = (int)threadIdx.x;
     const int c = tile_contig[blockIdx.x];
     const int i0 = tile_i[blockIdx.x] * 64, j0 = tile_j[blockIdx.x] * 64;
@@ -953,6 +955,26 @@ __global__ __launch_bounds__(256) void k_simdiff(
                 D[(int64_t)gi * N + gj] = dg ? 0 : d_acc[a][b];
             }
         }
+    // Both matrices are symmetric (sim = 3 A A^T + R R^T, diff = A R^T + R A^T): only the tiles on and above the diagonal are
+    // computed, the mirror image of an off-diagonal tile goes out through LDS so that its rows are written contiguously too
+    if (i0 != j0) {
+        int32_t* tile = reinterpret_cast<int32_t*>(&s_planes[0][0][0]);      // 64 x 65 ints (16.6 KB of the 34.8 KB staging area; the loop above is done with it)
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) tile[(tj + 16 * b) * 65 + (ti + 16 * a)] = which == 0 ? s_acc[a][b] : d_acc[a][b];
+            __syncthreads();
+            int32_t* __restrict__ O = which == 0 ? S : D;
+            for (int x = tid; x < 64 * 64; x += 256) {
+                const int rj = x >> 6, ci = x & 63;              // row of the mirrored tile = a read of the j side
+                const int gj = j0 + rj, gi = i0 + ci;
+                if (gj < N && gi < N) O[(int64_t)gj * N + gi] = tile[rj * 65 + ci];
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -17,5 +17,5 @@ for g in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_
   i=$((i+1))
 done
 python3 tools/pmc_summary.py gpurun_out/pmc_diag > gpurun_out/pmc_diag/summary.csv
-grep -E "k_cw_seeded_rows|k_window_tail|k_column_partition_lanes|k_simdiff" gpurun_out/pmc_diag/summary.csv
+grep -E "k_cw_seeded_lanes|k_cw_seed_sets|k_window_tail|k_column_partition_lanes|k_simdiff" gpurun_out/pmc_diag/summary.csv
 find gpurun_out/pmc_diag -name "*.csv" -size +5M -delete
