@@ -177,7 +177,10 @@ def main():
     want_f2f = world_env == 1 and args.cpu_contigs != 0
     job_dir = tempfile.mkdtemp(prefix="hs_bench_job_") if (want_f2f and not args.no_f2f_job) else None
     t_gen = time.perf_counter()
-    contigs, job_files = synth.generate_job(cfg, my_ids, seed=args.seed, workers=max(1, min(8, effective_cores() // world_env)), outdir=job_dir)
+    # HS_BENCH_SERIAL_SETUP=1: no forked workers (under `rocprofv3 --pmc` the profiler has initialised the GPU before this program
+    # starts, and a fork from such a process hangs on this pool: tools/pmc_traffic.sh sets it)
+    gen_workers = 1 if os.environ.get("HS_BENCH_SERIAL_SETUP") else max(1, min(8, effective_cores() // world_env))
+    contigs, job_files = synth.generate_job(cfg, my_ids, seed=args.seed, workers=gen_workers, outdir=job_dir)
     t_gen = time.perf_counter() - t_gen
 
     import torch

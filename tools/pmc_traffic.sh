@@ -11,7 +11,7 @@ i=0
 for g in "FETCH_SIZE" "WRITE_SIZE"; do
   out=gpurun_out/pmc_${tag}/g$i
   mkdir -p $out
-  rocprofv3 --kernel-trace --pmc $g --output-format csv -d $out -- python3 bench.py --steps 2 --warmup 0 --cpu-contigs 0 > $out/bench.json 2> $out/err.log
+  timeout 900 rocprofv3 --kernel-trace --pmc $g --output-format csv -d $out -- python3 bench.py --steps 2 --warmup 0 --cpu-contigs 0 > $out/bench.json 2> $out/err.log
   i=$((i+1))
 done
 python3 tools/pmc_summary.py gpurun_out/pmc_${tag} > gpurun_out/pmc_${tag}/summary.csv
