@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_ROOT, "lib", "libhairsplitter_hip.so")
 
 # every symbol declared in include/hairsplitter_hip.h
 SYMBOLS = [
-    "hs_version", "hs_last_error", "hs_device_count", "hs_warmup", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
+    "hs_cv_batch_set_ploidy", "hs_version", "hs_last_error", "hs_device_count", "hs_warmup", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
     "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
@@ -231,6 +231,16 @@ class CvBatch:
     @property
     def aligned_bp(self) -> int:
         return int(load().hs_cv_batch_aligned_bp(self.handle))
+
+    def set_ploidy(self, ploidy: Optional[Sequence[int]]):
+        """Ploidy of every contig (0 = none) for the in-memory stage 3 -> 4 paths (run_pipeline, PipelineGroups.run): what the
+        <ploidy_of_contigs> file is to HS_separate_reads. None clears it."""
+        if ploidy is None:
+            _check(load().hs_cv_batch_set_ploidy(self.handle, None))
+            return
+        p = np.ascontiguousarray(ploidy, dtype=np.int32)
+        assert p.size == self.flat.n_contigs
+        _check(load().hs_cv_batch_set_ploidy(self.handle, _hp(p, C.c_int32)))
 
     def run(self, automatic_snp_threshold: float = 0.33, n_threads: int = 0) -> Dict:
         """Stage 3 on the resident batch == HS_call_variants without the file I/O (call_variants.cpp:1276-1381)."""

@@ -856,6 +856,7 @@ struct hs_cv_batch {
     std::vector<int64_t> contig_off, pile_off;
     std::vector<int32_t> contig_rec_off, rec_pos, rec_qend, rec_contig;
     std::vector<int64_t> rec_refspan;
+    std::vector<int32_t> ploidy;      // hs_cv_batch_set_ploidy
     int64_t total_len = 0, total_pile = 0;
     int32_t n_tasks = 0, ev_per_task = 4096, max_depth = 0;
     DBuf contig_seq, d_contig_off, read_seq, read_off, rec_read, d_rec_contig, d_rec_pos, rec_strand, rec_cig_off, cigar,
@@ -1813,7 +1814,13 @@ extern "C" {
 
 static void fill_meta(const hs_cv_batch* b, hs::CvMeta& meta) {
     meta.n_contigs = b->n_contigs; meta.n_rec = b->n_rec; meta.contig_off = b->contig_off; meta.contig_rec_off = b->contig_rec_off;
-    meta.pile_off = b->pile_off; meta.total_len = b->total_len; meta.rec_pos = b->rec_pos; meta.rec_refspan = b->rec_refspan;
+    meta.pile_off = b->pile_off; meta.total_len = b->total_len; meta.rec_pos = b->rec_pos; meta.rec_refspan = b->rec_refspan; meta.ploidy = b->ploidy;
+}
+
+int hs_cv_batch_set_ploidy(hs_cv_batch* b, const int32_t* ploidy) {
+    if (!b) { set_error("hs_cv_batch_set_ploidy: null batch"); return HS_EINVAL; }
+    if (ploidy) b->ploidy.assign(ploidy, ploidy + b->n_contigs); else b->ploidy.clear();
+    return HS_OK;
 }
 
 int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out) {

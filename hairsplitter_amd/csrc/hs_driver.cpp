@@ -852,7 +852,7 @@ int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, int c0, int c1, const hs_c
         hs_sr_contig& h = hc[(size_t)c];
         h.length = b.contig_off[(size_t)gc + 1] - b.contig_off[(size_t)gc];
         h.n_reads = r1 - r0; h.read_start = rs[(size_t)c].data(); h.read_end = re[(size_t)c].data();
-        h.col_idx = cv->col_idx; h.col_code = cv->col_code; h.ploidy = 0;
+        h.col_idx = cv->col_idx; h.col_code = cv->col_code; h.ploidy = b.ploidy.empty() ? 0 : b.ploidy[(size_t)gc];
         if (all_kept) {
             h.n_snps = (int32_t)(s1 - s0); h.snp_pos = cv->snp_pos + s0; h.snp_ref = cv->snp_ref + s0; h.snp_alt = cv->snp_alt + s0;
             h.col_off = cv->col_off + s0;

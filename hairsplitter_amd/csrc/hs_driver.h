@@ -18,6 +18,7 @@ struct CvMeta {                       // host-side description of a stage-3 batc
     std::vector<int32_t> rec_pos;         // [NREC] POS-1
     std::vector<int64_t> rec_refspan;     // [NREC] reference bases consumed by the CIGAR (unclipped)
     int64_t total_len = 0;
+    std::vector<int32_t> ploidy;          // [C] or empty: ploidy of the contigs for the stage 3 -> 4 hand-over (0 = none)
 };
 
 // K4 input: the extracted columns (still resident on the device after gather()) with their exact top-2 codes, and the

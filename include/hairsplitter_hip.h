@@ -294,6 +294,10 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
                        const int64_t* h_rec_cig_off, const uint32_t* h_cigar,
                        const int32_t* h_contig_rec_off, hs_cv_batch** out);
 void hs_cv_batch_destroy(hs_cv_batch* b);
+/* Optional ploidy of every contig (0 = none), the in-memory counterpart of the <ploidy_of_contigs> file of HS_separate_reads
+ * (separate_reads.cpp:1444-1463, used at :1711-1715): the stage-3 -> stage-4 entry points below (hs_sr_run_cv, hs_sr_run_cv_range,
+ * hs_pipeline_run) apply it. ploidy == NULL clears it. */
+int hs_cv_batch_set_ploidy(hs_cv_batch* b, const int32_t* ploidy /* [n_contigs] or NULL */);
 int64_t hs_cv_batch_aligned_bp(const hs_cv_batch* b);   /* number of pileup entries (the metric's unit) */
 
 /* Per-contig result of stage 3 == what output_files (call_variants.cpp:1174-1213) prints. */

@@ -172,6 +172,30 @@ def test_fused_pipeline_equals_two_step_path(built):
         assert np.array_equal(sr[k], sr2[k]), k
 
 
+def test_fused_pipeline_takes_the_ploidy_of_the_contigs(built):
+    """hs_cv_batch_set_ploidy: the in-memory hand-over caps the clusters per window as HS_separate_reads does with a ploidy file
+    (separate_reads.cpp:1711-1715); equal to the two-step path that is handed the same ploidies."""
+    import numpy as np
+    from hairsplitter_amd import api, synth
+    contigs = [synth.make_contig(23, i, 25_000, 4, 0.01, 40, "ont") for i in range(3)]
+    flat = api.FlatBatch(contigs)
+    b = api.CvBatch(flat)
+    cv = b.run(0.33, 2)
+    e = min(float("%g" % cv["error_rate"]), 0.15)
+    ploidy = [2, 0, 3]
+    want = api.separate_reads(cv, flat, e, rarest_strain_abundance=0.01, n_threads=2, ploidy=ploidy)
+    free = api.separate_reads(cv, flat, e, rarest_strain_abundance=0.01, n_threads=2)
+    b.set_ploidy(ploidy)
+    _, got = b.run_pipeline(0.33, 2)
+    b.set_ploidy(None)
+    _, got_free = b.run_pipeline(0.33, 2)
+    b.close()
+    assert not np.array_equal(want["labels"], free["labels"])      # the cap does something on these tetraploid contigs
+    for k in ("win_off", "win_start", "win_end", "label_off", "labels"):
+        assert np.array_equal(want[k], got[k]), k
+        assert np.array_equal(free[k], got_free[k]), k
+
+
 @pytest.mark.parametrize("shape", ["tetra100k", "hifi300k", "meta_ploidy1to8", "deep1200x"])
 def test_dropin_equals_oracle_at_larger_sizes(built, shape):
     """Beyond the committed fixtures: BASELINE-shaped contigs (tetraploid ONT as C3, a metagenome slice with ploidies 1..8 at
