@@ -369,15 +369,22 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         t.col_c1.resize(n_sel); t.col_k0.resize(n_sel); t.col_k1.resize(n_sel); t.col_is_cand.resize(n_sel);
         t.part_off.assign((size_t)C + 1, 0);
         t.contig_n_reads.resize((size_t)C);
+        // offsets first (partitions and state bytes per contig), then every contig writes its own slices
+        std::vector<int64_t> st_base((size_t)C + 1, 0);
         for (int c = 0; c < C; ++c) {
             t.contig_n_reads[(size_t)c] = b.contig_rec_off[(size_t)(c0 + c) + 1] - b.contig_rec_off[(size_t)(c0 + c)];
+            const int nf = cv_final_partitions(*cst[(size_t)c]);
+            t.part_off[(size_t)c + 1] = t.part_off[(size_t)c] + nf;
+            st_base[(size_t)c + 1] = st_base[(size_t)c] + (int64_t)nf * t.contig_n_reads[(size_t)c];
+        }
+        t.part_state.resize((size_t)st_base[(size_t)C]); t.part_state_off.resize((size_t)t.part_off[(size_t)C]);
+        parallel_for(C, n_threads, [&](int c) {
             const ColumnSet& cs = sets[(size_t)c];
             const size_t s0 = (size_t)contig_sel_off[(size_t)c];
             for (size_t i = 0; i < cs.pos.size(); ++i) { t.col_c1[s0 + i] = cs.c1[i]; t.col_k0[s0 + i] = cs.k0[i]; t.col_k1[s0 + i] = cs.k1[i]; }
             cv_export_candidates(*cst[(size_t)c], t.col_is_cand.data() + s0);
-            cv_export_partitions(*cst[(size_t)c], t.part_state, t.part_state_off);
-            t.part_off[(size_t)c + 1] = (int32_t)t.part_state_off.size();
-        }
+            cv_export_partitions(*cst[(size_t)c], t.part_state.data() + st_base[(size_t)c], st_base[(size_t)c], t.part_state_off.data() + t.part_off[(size_t)c]);
+        });
         std::vector<uint8_t> keep(n_sel, 0);
         laps.lap("k4_prep");
         if (n_sel) { if (int rc = dev.column_partition_test(t, keep, &k_ms_k4)) return rc; }
@@ -385,7 +392,7 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         for (int c = 0; c < C; ++c) cv_import_keep(*cst[(size_t)c], keep.data() + contig_sel_off[(size_t)c]);
     }
     // ... and the final merge
-    for (int c = 0; c < C; ++c) { cv_phase_merge(*cst[(size_t)c], sets[(size_t)c], res[(size_t)c]); cv_state_free(cst[(size_t)c]); }
+    parallel_for(C, n_threads, [&](int c) { cv_phase_merge(*cst[(size_t)c], sets[(size_t)c], res[(size_t)c]); cv_state_free(cst[(size_t)c]); });
     const double t_glue_done = now_ms();
     laps.lap("merge");
 

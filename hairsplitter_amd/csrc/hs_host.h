@@ -55,7 +55,9 @@ void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts
                        const int32_t* pool_more, const int32_t* pool_less);
 void cv_phase_b(CvContigState& st, ContigCvResult& out);
 // exports the final partitions / candidate flags for the device test (K4) and imports its verdict
-void cv_export_partitions(const CvContigState& st, std::vector<int8_t>& state, std::vector<int64_t>& state_off);
+int cv_final_partitions(const CvContigState& st);
+// the final partitions' dense state arrays (n_reads bytes each) written at `state`, their offsets (state_base + ...) at state_off
+void cv_export_partitions(const CvContigState& st, int8_t* state, int64_t state_base, int64_t* state_off);
 void cv_export_candidates(const CvContigState& st, uint8_t* is_cand);
 void cv_import_keep(CvContigState& st, const uint8_t* keep);
 void cv_phase_merge(CvContigState& st, const ColumnSet& cs, ContigCvResult& out);

@@ -678,10 +678,14 @@ void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_dista
 
 // Loops C (:721-738) and D (:745-764) run on the device (k_column_partition_test): the final partitions leave as dense
 // state arrays, the verdict per extracted column comes back.
-void cv_export_partitions(const CvContigState& st, std::vector<int8_t>& state, std::vector<int64_t>& state_off) {
-    for (const DensePartition& p : st.finals) {
-        state_off.push_back((int64_t)state.size());
-        state.insert(state.end(), p.state.begin(), p.state.end());
+int cv_final_partitions(const CvContigState& st) { return (int)st.finals.size(); }
+void cv_export_partitions(const CvContigState& st, int8_t* state, int64_t state_base, int64_t* state_off) {
+    int64_t o = 0;
+    for (size_t k = 0; k < st.finals.size(); ++k) {
+        const DensePartition& p = st.finals[k];
+        state_off[k] = state_base + o;
+        std::copy(p.state.begin(), p.state.end(), state + o);
+        o += (int64_t)p.state.size();
     }
 }
 void cv_export_candidates(const CvContigState& st, uint8_t* is_cand) {
