@@ -163,10 +163,16 @@ struct UploadPack {
 
 // Host waits. On this runtime a waiting host thread spins (100 % of a core for the whole wait) whether or not the event
 // carries hipEventBlockingSync; only the device-wide schedule flag makes hipEventSynchronize / hipStreamSynchronize sleep
-// (tools/probes/wait_probe.hip: 0.3 ms of CPU per 20-ms wait, woken 30-70 us late). Measured on the default bench, the
-// late wake-ups cost the contig-group chains more than the freed cores give back (41-44 vs 44-47 G aligned bp/s), so
-// spinning is the default and HS_BLOCKING_WAIT=1 selects the sleeping waits (for hosts that need the cores).
-static bool blocking_wait() { static const bool s = std::getenv("HS_BLOCKING_WAIT") != nullptr; return s; }
+// (tools/probes/wait_probe.hip: 0.3 ms of CPU per 20-ms wait, woken 30-70 us late). Which is better depends on whether the
+// host has cores to spare: on the 16-core box 256 x C2 (14.5 cores busy) runs 5 % faster spinning, the 500-contig job (it
+// wants 17-18 cores: the cgroup throttles it) 4 % faster sleeping. So the pipeline starts spinning and looks at its own CPU
+// load after every run (adapt_wait_policy); HS_BLOCKING_WAIT=1 / HS_SPIN_WAIT=1 pin the choice.
+static std::atomic<int> g_block_waits{0};
+static int forced_wait_policy() {
+    static const int f = std::getenv("HS_BLOCKING_WAIT") ? 1 : (std::getenv("HS_SPIN_WAIT") ? 0 : -1);
+    return f;
+}
+static bool blocking_wait() { const int f = forced_wait_policy(); return f >= 0 ? f == 1 : g_block_waits.load(std::memory_order_relaxed) == 1; }
 static bool spin_wait() { return !blocking_wait(); }
 static std::atomic<long> g_waits{0}, g_wait_us{0};     // HS_TIMING: host waits and the wall time spent in them
 static int stream_wait_impl(hipStream_t s);
@@ -280,6 +286,18 @@ static int host_threads() { return hs::host_threads(); }      // usable cores (h
 static void set_wait_policy() {   // see stream_wait
     if (!blocking_wait()) return;
     if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
+}
+// after a pipeline run: process CPU time over (wall time x usable cores). Above 0.97 the host is the limit and the cores the
+// waiting threads burn are missed elsewhere -> sleeping waits from the next run on; below 0.85 back to spinning.
+static void adapt_wait_policy(double cpu_s, double wall_s) {
+    if (forced_wait_policy() >= 0 || wall_s <= 0) return;
+    const double load = cpu_s / (wall_s * host_threads());
+    const int cur = g_block_waits.load(std::memory_order_relaxed);
+    const int next = load > 0.97 ? 1 : (load < 0.85 ? 0 : cur);
+    if (next == cur) return;
+    g_block_waits.store(next, std::memory_order_relaxed);
+    if (hipSetDeviceFlags(next ? hipDeviceScheduleBlockingSync : hipDeviceScheduleSpin) != hipSuccess) (void)hipGetLastError();
+    if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] host waits now %s (process CPU load %.2f of %d cores)\n", next ? "sleep" : "spin", load, host_threads());
 }
 
 int require_device() {
@@ -2080,6 +2098,8 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
             else if (above < 20 && mean < 2000) window_size = 500;
         }
     }
+    struct timespec cpu0; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &cpu0);
+    const auto wall0 = std::chrono::steady_clock::now();
     std::vector<hs_sr_result*> parts((size_t)G, nullptr);
     std::vector<hs::SrSparseLabels> sparse((size_t)G);      // the groups leave their labels per window; concat_sr_parts spreads them
     const int rc = p->run([&](int g) {
@@ -2105,6 +2125,11 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
     hs_sr_result* R = concat_sr_parts(p, parts, sparse, st);
     p->drop_cv();
     *out = R;
+    {
+        struct timespec cpu1; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &cpu1);
+        adapt_wait_policy((double)(cpu1.tv_sec - cpu0.tv_sec) + 1e-9 * (double)(cpu1.tv_nsec - cpu0.tv_nsec),
+                          std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count());
+    }
     return HS_OK;
 }
 
