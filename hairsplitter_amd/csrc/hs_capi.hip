@@ -582,7 +582,7 @@ int hs_tile_plan(const int64_t* h_contig_off, int32_t n_contigs, const int32_t* 
 static int column_stats_tiled_launch(const uint8_t* d_pile, const int64_t* d_tile_off, const hs_tile_entry* d_tile_ent, int64_t total_len,
                                      hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth,
                                      int32_t sel_cap, int32_t max_depth, SelectionScratch* sc, hipEvent_t after_main, hipStream_t stream,
-                                     hipEvent_t after_main2 = nullptr) {
+                                     hipEvent_t after_main2 = nullptr, int64_t tile0 = 0, int64_t tile1 = -1 /* tiles [tile0, tile1) only */) {
     static_assert(sizeof(hs_tile_entry) == sizeof(int4), "hs_tile_entry is read as one 16-byte load");
     if (total_len <= 0) {   // nothing to count: an empty selection
         if (d_sel_count) HS_HIP(hipMemsetAsync(d_sel_count, 0, sizeof(int32_t), stream));
@@ -590,15 +590,15 @@ static int column_stats_tiled_launch(const uint8_t* d_pile, const int64_t* d_til
         if (after_main2) HS_HIP(hipEventRecord(after_main2, stream));
         return HS_OK;
     }
-    const int64_t grid = (total_len + 255) / 256;
+    const int64_t grid = tile1 >= 0 ? tile1 - tile0 : (total_len + 255) / 256;
     const bool full = d_stats != nullptr;
     const bool narrow = max_depth > 0 && max_depth <= 255;
-    using KernelT = void (*)(const uint8_t*, const int64_t*, const int4*, int64_t, hsdev::hs_colstat_dev*, int, int32_t*, int64_t*, int32_t*, int);
+    using KernelT = void (*)(const uint8_t*, const int64_t*, const int4*, int64_t, hsdev::hs_colstat_dev*, int, int32_t*, int64_t*, int32_t*, int, int64_t);
     KernelT kernel = narrow ? (full ? (KernelT)hsdev::k_column_stats_tiled<1, true> : (KernelT)hsdev::k_column_stats_tiled<1, false>)
                             : (full ? (KernelT)hsdev::k_column_stats_tiled<2, true> : (KernelT)hsdev::k_column_stats_tiled<2, false>);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), 0, stream, d_pile, d_tile_off, reinterpret_cast<const int4*>(d_tile_ent),
                        total_len, reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second, d_sel_count ? sc->tile_cnt.as<int32_t>() : nullptr,
-                       d_sel_count ? sc->gpos.as<int64_t>() : nullptr, d_sel_count ? sc->depth.as<int32_t>() : nullptr, sel_cap);
+                       d_sel_count ? sc->gpos.as<int64_t>() : nullptr, d_sel_count ? sc->depth.as<int32_t>() : nullptr, sel_cap, tile0);
     HS_HIP(hipGetLastError());
     if (after_main) HS_HIP(hipEventRecord(after_main, stream));
     if (after_main2) HS_HIP(hipEventRecord(after_main2, stream));
@@ -1027,6 +1027,80 @@ struct HipCvOps : hs::CvDeviceOps {
     hipStream_t stream = nullptr;
     explicit HipCvOps(hs_cv_batch* batch) : b(batch) {}
     KernelClock kc;
+
+    // ---- the streaming pass in two parts (contig groups): K0 + K1 over the whole batch, K2 + selection per range of contigs ----
+    bool has_select_range() const override { return true; }
+    int pileup(std::vector<int32_t>& rec_stats, float k_ms[4]) override {
+        EventPair e0, e1;
+        if (int rc = e0.init()) return rc;
+        if (int rc = e1.init()) return rc;
+        HS_HIP(hipEventRecord(e0.a, stream));
+        if (int rc = kc.begin(HS_K_CIGAR_SCAN, stream)) return rc;
+        if (int rc = cigar_scan_launch(b->d_contig_off.as<int64_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(),
+                                       b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->rec_chunk_off.as<int64_t>(), b->n_rec,
+                                       b->chunk_scratch.as<int32_t>(), b->rec_stats.as<int32_t>(), stream)) return rc;
+        if (int rc = kc.end((int64_t)b->cigar.bytes + (int64_t)b->chunk_scratch.bytes + 16 * (int64_t)b->n_rec, stream)) return rc;
+        HS_HIP(hipEventRecord(e0.b, stream));
+        HS_HIP(hipEventRecord(e1.a, stream));
+        if (int rc = kc.begin(HS_K_PILEUP, stream)) return rc;
+        if (int rc = pileup_launch(b->contig_seq.as<uint8_t>(), b->d_contig_off.as<int64_t>(), b->read_seq.as<uint8_t>(), b->read_off.as<int64_t>(),
+                                   b->rec_read.as<int32_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(), b->rec_strand.as<uint8_t>(),
+                                   b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->d_pile_off.as<int64_t>(),
+                                   b->rec_chunk_off.as<int64_t>(), b->chunk_scratch.as<int32_t>(), b->task_rec.as<int32_t>(), b->task_ev0.as<int32_t>(),
+                                   b->n_tasks, b->ev_per_task, b->pile.as<uint8_t>(), b->rec_stats.as<int32_t>(), b->n_rec, stream)) return rc;
+        if (int rc = kc.end(2 * b->total_pile, stream)) return rc;
+        HS_HIP(hipEventRecord(e1.b, stream));
+        auto grow = [](HBuf& h, size_t need) -> int { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); };
+        if (!rec_stats.empty()) {
+            if (int rc = grow(b->h_stage_a, rec_stats.size() * sizeof(int32_t))) return rc;
+            HS_HIP(hipMemcpyAsync(b->h_stage_a.p, b->rec_stats.p, rec_stats.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        }
+        if (int rc = stream_wait(stream)) return rc;
+        if (!rec_stats.empty()) std::memcpy(rec_stats.data(), b->h_stage_a.p, rec_stats.size() * sizeof(int32_t));
+        if (int rc = e1.ms(&k_ms[0])) return rc;
+        if (int rc = e0.ms(&k_ms[3])) return rc;
+        kc.flush();
+        return HS_OK;
+    }
+    SelectionScratch range_scratch;
+    DBuf d_rsel_count, d_rsel_gpos, d_rsel_depth;
+    HBuf h_rsel, h_rsel_n;
+    // K2 over the tiles that hold the global positions [g0, g1) (the pileup must be complete); the list comes back sorted and may
+    // hold positions of the neighbouring ranges from the two boundary tiles
+    int select_range(int64_t g0, int64_t g1, int min_second, const int64_t** sel_gpos, const int32_t** sel_depth, size_t* n_sel_out, float* k_ms) override {
+        *sel_gpos = nullptr; *sel_depth = nullptr; *n_sel_out = 0;
+        if (k_ms) *k_ms = 0;
+        if (g1 <= g0) return HS_OK;
+        const int64_t t0 = g0 >> 8, t1 = (g1 + 255) >> 8;
+        const int64_t cap = (t1 - t0) * 256;
+        if (int rc = range_scratch.prepare(cap)) return rc;
+        if (int rc = d_rsel_count.alloc(8)) return rc;
+        if (int rc = d_rsel_gpos.alloc((size_t)cap * 8)) return rc;
+        if (int rc = d_rsel_depth.alloc((size_t)cap * 4)) return rc;
+        EventPair e; if (int rc = e.init()) return rc;
+        HS_HIP(hipEventRecord(e.a, stream));
+        if (int rc = kc.begin(HS_K_COLUMN_STATS, stream)) return rc;
+        hipEvent_t k2_done = nullptr;
+        int64_t range_pile = b->total_len > 0 ? (int64_t)((double)b->total_pile * (double)(g1 - g0) / (double)b->total_len) : 0;      // one code in per aligned bp of the range (its share of the batch)
+        if (int rc = kc.end_prepare(range_pile, &k2_done)) return rc;
+        if (int rc = column_stats_tiled_launch(b->pile.as<uint8_t>(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->total_len,
+                                               nullptr, min_second, d_rsel_count.as<int32_t>(), d_rsel_gpos.as<int64_t>(), d_rsel_depth.as<int32_t>(),
+                                               (int32_t)std::min<int64_t>(cap, 0x7fffffff), b->max_depth, &range_scratch, e.b, stream, k2_done, t0, t1)) return rc;
+        auto grow = [](HBuf& h, size_t need) -> int { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); };
+        if (int rc = grow(h_rsel_n, 64)) return rc;
+        if (int rc = copy_d2h(h_rsel_n.p, d_rsel_count.p, sizeof(int32_t), stream)) return rc;
+        const int32_t n_sel = *(int32_t*)h_rsel_n.p;
+        if (int rc = grow(h_rsel, std::max<size_t>((size_t)n_sel, 1) * 12)) return rc;
+        char* hg = (char*)h_rsel.p; char* hd = hg + (size_t)n_sel * 8;
+        if (n_sel) {
+            HS_HIP(hipMemcpyAsync(hg, d_rsel_gpos.p, (size_t)n_sel * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+            HS_HIP(hipMemcpyAsync(hd, d_rsel_depth.p, (size_t)n_sel * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            if (int rc = stream_wait(stream)) return rc;
+        }
+        *sel_gpos = (const int64_t*)hg; *sel_depth = (const int32_t*)hd; *n_sel_out = (size_t)n_sel;
+        kc.flush();
+        return e.ms(k_ms);
+    }
 
     int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, const int64_t** sel_gpos, const int32_t** sel_depth, size_t* n_sel_out,
                           float k_ms[4]) override {
@@ -2056,10 +2130,25 @@ static hs_sr_result* concat_sr_parts(hs_pipeline* p, std::vector<hs_sr_result*>&
     return R;
 }
 
+// K2 and the selection run per contig group, inside the group's chain (HS_SELECT_WHOLE=1: once over the whole batch, before the
+// groups start, as hs_cv_select does): the groups then start after K0 + K1 and the host works while K2 of the later groups runs
+static bool select_per_group() { static const bool whole = std::getenv("HS_SELECT_WHOLE") != nullptr; return !whole; }
+
 int hs_pipeline_select(hs_pipeline* p, float* mean_distance, hs_pipeline_stats* st) {
     if (!p || !mean_distance) { set_error("hs_pipeline_select: null argument"); return HS_EINVAL; }
     p->drop_cv();
-    if (int rc = hs_cv_select(p->batch, &p->sel)) return rc;
+    if (select_per_group()) {
+        if (int rc = require_device()) return rc;
+        hs::CvMeta meta; fill_meta(p->batch, meta);
+        HipCvOps ops(p->batch);
+        hs::CvSelection* sel = new hs::CvSelection();
+        if (int rc = hs::cv_pileup(ops, meta, *sel)) { delete sel; return rc; }
+        hs_cv_selection* o = (hs_cv_selection*)std::calloc(1, sizeof(hs_cv_selection));
+        for (int k = 0; k < 4; ++k) o->t_kernel_ms[k] = sel->k_ms[k];
+        o->t_device_ms = sel->t_device_ms; o->t_host_ms = sel->t_host_ms;
+        o->impl = sel;
+        p->sel = o;
+    } else if (int rc = hs_cv_select(p->batch, &p->sel)) return rc;
     const hs::CvSelection& sel = *(const hs::CvSelection*)p->sel->impl;
     const hs_cv_batch* b = p->batch;
     for (int c = 0; c < b->n_contigs; ++c) {   // call_variants.cpp:434 per contig, from the integer counters of K1
@@ -2101,11 +2190,22 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
     struct timespec cpu0; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &cpu0);
     const auto wall0 = std::chrono::steady_clock::now();
     std::vector<hs_sr_result*> parts((size_t)G, nullptr);
+    std::vector<float> group_k2_ms((size_t)G, 0.f);
+    std::vector<int64_t> group_sel((size_t)G, 0);
+    std::vector<double> group_sel_dev_ms((size_t)G, 0.0), group_sel_host_ms((size_t)G, 0.0);
     std::vector<hs::SrSparseLabels> sparse((size_t)G);      // the groups leave their labels per window; concat_sr_parts spreads them
     const int rc = p->run([&](int g) {
         const int c0 = p->ranges[(size_t)g].first, c1 = p->ranges[(size_t)g].second;
-        if (int r = hs_cv_run_range(p->batch, p->sel, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g])) return r;
         hs::CvMeta meta; fill_meta(p->batch, meta);
+        if (select_per_group()) {
+            HipCvOps cv_ops(p->batch);
+            hs::CvSelection gsel;
+            if (int r = hs::cv_select_range(cv_ops, meta, c0, c1, gsel)) return r;
+            group_k2_ms[(size_t)g] = gsel.k_ms[1]; group_sel[(size_t)g] = (int64_t)gsel.sel_pos.size();
+            group_sel_dev_ms[(size_t)g] = gsel.t_device_ms; group_sel_host_ms[(size_t)g] = gsel.t_host_ms;
+            if (int r = hs::cv_run_range(cv_ops, meta, gsel, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g],
+                                         &((const hs::CvSelection*)p->sel->impl)->rec_stats)) return r;
+        } else if (int r = hs_cv_run_range(p->batch, p->sel, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g])) return r;
         HipSrOps ops;
         return hs::sr_run_from_cv(ops, meta, c0, c1, p->cv[(size_t)g], error_rate, rarest_strain_abundance, low_memory, amplicon, seed, per, window_size,
                                   &parts[(size_t)g], &sparse[(size_t)g]);
@@ -2119,6 +2219,8 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
             st->t_kernel_cv_ms[2] += r->t_kernel_ms[2]; st->t_kernel_k4_ms += r->t_kernel_k4_ms;
             st->n_columns_extracted += r->n_columns_extracted; st->n_columns_downloaded += r->n_columns_downloaded;
             st->n_columns_downloaded_late += r->n_columns_downloaded_late;
+            st->t_kernel_cv_ms[1] += group_k2_ms[(size_t)g];      // (zero unless K2 ran per group)
+            st->t_device_ms += group_sel_dev_ms[(size_t)g]; st->t_host_ms += group_sel_host_ms[(size_t)g];
         }
     }
     if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] host waits so far: %ld, %.1f ms in them\n", g_waits.load(), g_wait_us.load() / 1e3);

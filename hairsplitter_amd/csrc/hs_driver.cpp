@@ -240,15 +240,51 @@ int cv_select(CvDeviceOps& dev, const CvMeta& b, CvSelection& sel) {
 // Stage 3 for the contigs [c0, c1) of the batch on top of a selection: column extraction (K3), the host partition logic,
 // the column x partition test (K4) and the merge. Ranges are independent: several may run concurrently from different host
 // threads, each with its own device interface (stream).
+int cv_pileup(CvDeviceOps& dev, const CvMeta& b, CvSelection& sel) {
+    const double t_start = now_ms();
+    for (int k = 0; k < 4; ++k) sel.k_ms[k] = 0;
+    sel.rec_stats.assign((size_t)b.n_rec * 4, 0);
+    if (int rc = dev.pileup(sel.rec_stats, sel.k_ms)) return rc;
+    sel.contig_sel_off.assign((size_t)b.n_contigs + 1, 0);
+    sel.t_device_ms = now_ms() - t_start; sel.t_host_ms = 0;
+    return HS_OK;
+}
+
+int cv_select_range(CvDeviceOps& dev, const CvMeta& b, int c0, int c1, CvSelection& sel) {
+    const int C = b.n_contigs;
+    if (c0 < 0 || c1 > C || c0 > c1) { set_error("cv_select_range: bad contig range"); return HS_EINVAL; }
+    const double t_start = now_ms();
+    const int64_t g0 = b.contig_off[(size_t)c0], g1 = b.contig_off[(size_t)c1];
+    const int64_t* gp = nullptr; const int32_t* dp = nullptr; size_t n = 0;
+    if (int rc = dev.select_range(g0, g1, 4, &gp, &dp, &n, &sel.k_ms[1])) return rc;
+    const double t_dev = now_ms();
+    // the list is sorted; the boundary tiles may bring positions of the neighbouring ranges
+    const int64_t* lo = std::lower_bound(gp, gp + n, g0);
+    const int64_t* hi = std::lower_bound(gp, gp + n, g1);
+    const size_t first = (size_t)(lo - gp), m = (size_t)(hi - lo);
+    sel.contig_sel_off.assign((size_t)C + 1, 0);
+    for (int c = c0; c <= c1; ++c) sel.contig_sel_off[(size_t)c] = (int64_t)(std::lower_bound(lo, hi, b.contig_off[(size_t)c]) - lo);
+    for (int c = c1 + 1; c <= C; ++c) sel.contig_sel_off[(size_t)c] = (int64_t)m;
+    sel.sel_contig.resize(m); sel.sel_pos.resize(m); sel.sel_depth.resize(m);
+    int c = c0;
+    for (size_t i = 0; i < m; ++i) {
+        const int64_t g = lo[i];
+        while (g >= b.contig_off[(size_t)c + 1]) ++c;
+        sel.sel_contig[i] = c; sel.sel_pos[i] = (int32_t)(g - b.contig_off[(size_t)c]); sel.sel_depth[i] = dp[first + i];
+    }
+    sel.t_device_ms = t_dev - t_start; sel.t_host_ms = now_ms() - t_dev;
+    return HS_OK;
+}
+
 int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int c0, int c1, float automatic_snp_threshold, int n_threads,
-                 hs_cv_result** out) {
+                 hs_cv_result** out, const std::vector<int32_t>* rec_stats_ext) {
     if (n_threads <= 0) n_threads = host_threads();
     if (c0 < 0 || c1 > b.n_contigs || c0 > c1) { set_error("cv_run_range: bad contig range"); return HS_EINVAL; }
     const int C = c1 - c0;
     const double t_start = now_ms();
     float k_ms[4] = {0, 0, 0, 0};
     float k_ms_k4 = 0;              // column x partition test
-    const std::vector<int32_t>& rec_stats = sel.rec_stats;
+    const std::vector<int32_t>& rec_stats = rec_stats_ext ? *rec_stats_ext : sel.rec_stats;
     const int64_t g0 = sel.contig_sel_off[(size_t)c0], g1 = sel.contig_sel_off[(size_t)c1];
     std::vector<int32_t> sel_contig(sel.sel_contig.begin() + g0, sel.sel_contig.begin() + g1);   // batch-global contig ids (K3 wants those)
     std::vector<int32_t> sel_pos(sel.sel_pos.begin() + g0, sel.sel_pos.begin() + g1);

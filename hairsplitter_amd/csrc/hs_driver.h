@@ -68,6 +68,14 @@ struct CvDeviceOps {
                               const int32_t** col_idx, const uint8_t** col_code) = 0;
     // K4: loops C and D of keep_only_robust_variants on the columns of the last gather(); keep[i] for column i
     virtual int column_partition_test(const CvPartitionTest& t, std::vector<uint8_t>& keep, float* k_ms) = 0;
+    // The streaming pass in two parts, for callers that work through the batch in ranges of contigs: pileup() = K0 + K1 over
+    // the whole batch (per-record counters back), select_range() = K2 + selection for the global positions [g0, g1) only
+    // (sorted; positions of the neighbouring ranges from the boundary tiles may be included). Optional.
+    virtual bool has_select_range() const { return false; }
+    virtual int pileup(std::vector<int32_t>& rec_stats, float k_ms[4]) { (void)rec_stats; (void)k_ms; return -1; }
+    virtual int select_range(int64_t g0, int64_t g1, int min_second, const int64_t** sel_gpos, const int32_t** sel_depth, size_t* n_sel, float* k_ms) {
+        (void)g0; (void)g1; (void)min_second; (void)sel_gpos; (void)sel_depth; (void)n_sel; (void)k_ms; return -1;
+    }
     // Loop A of keep_only_robust_variants (call_variants.cpp:590-638) on the columns of the last gather(), contig by contig.
     // Optional: an implementation without it leaves the loop to the host (cv_phase_a_host). The result arrays are owned by
     // the implementation and stay valid until the next call.
@@ -84,8 +92,13 @@ struct CvSelection {
     double t_device_ms = 0, t_host_ms = 0;
 };
 int cv_select(CvDeviceOps& dev, const CvMeta& meta, CvSelection& sel);
+// the same in two parts: cv_pileup fills sel.rec_stats (K0 + K1 of the whole batch), cv_select_range the selection of the contigs
+// [c0, c1) alone (contig_sel_off is [C+1] as always, zero-based at c0; the arrays hold that range only)
+int cv_pileup(CvDeviceOps& dev, const CvMeta& meta, CvSelection& sel);
+int cv_select_range(CvDeviceOps& dev, const CvMeta& meta, int c0, int c1, CvSelection& sel);
+// rec_stats: the per-record counters of the batch when `sel` does not carry them (a range selection)
 int cv_run_range(CvDeviceOps& dev, const CvMeta& meta, const CvSelection& sel, int c0, int c1, float automatic_snp_threshold, int n_threads,
-                 hs_cv_result** out);
+                 hs_cv_result** out, const std::vector<int32_t>* rec_stats = nullptr);
 int cv_run(CvDeviceOps& dev, const CvMeta& meta, float automatic_snp_threshold, int n_threads, hs_cv_result** out);
 
 // Every clustering window of a stage-4 call, each in its own LOCAL index space: node j of window w is the read

@@ -785,13 +785,14 @@ template <int CB, bool FULL>
 __global__ __launch_bounds__(256) void k_column_stats_tiled(
     const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, int64_t total,
     hs_colstat_dev* __restrict__ stats, int min_second, int32_t* __restrict__ sel_count, int64_t* __restrict__ sel_gpos,
-    int32_t* __restrict__ sel_depth, int sel_cap) {
+    int32_t* __restrict__ sel_depth, int sel_cap, int64_t tile0 /* first tile of the launch: the selection scratch is indexed from it */) {
     constexpr int PER_WORD = 4 / CB;
     constexpr int NWORDS = (HS_NBINS + PER_WORD - 1) / PER_WORD;
     __shared__ uint32_t hw[NWORDS * 256];
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
-    const int64_t g = (int64_t)blockIdx.x * 256 + tid;
+    const int64_t tile = tile0 + (int64_t)blockIdx.x;
+    const int64_t g = tile * 256 + tid;
 #pragma unroll
     for (int w = 0; w < NWORDS; ++w) hw[w * 256 + tid] = 0u;
     auto bump = [&](unsigned code, bool valid) {
@@ -799,7 +800,7 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled(
         const unsigned inc = valid ? (1u << ((cc & (PER_WORD - 1)) * (8 * CB))) : 0u;
         __hip_atomic_fetch_add(&hw[(cc / PER_WORD) * 256 + tid], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    const int64_t e0 = tile_off[blockIdx.x], e1 = tile_off[blockIdx.x + 1];
+    const int64_t e0 = tile_off[tile], e1 = tile_off[tile + 1];
     for (int64_t i0 = e0; i0 < e1; i0 += 64) {
         const int nrec = (e1 - i0) < 64 ? (int)(e1 - i0) : 64;
         const int4 held = tile_ent[i0 + (lane < nrec ? lane : nrec - 1)];   // lane j keeps record i0 + j
