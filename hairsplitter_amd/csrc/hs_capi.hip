@@ -283,6 +283,18 @@ struct KernelClock {
 
 static int host_threads() { return hs::host_threads(); }      // usable cores (hs_driver.cpp)
 
+// K2 of one contig group at a time: the kernel fills the device on its own; eight of them side by side only slow each other
+// down (0.29 ms alone, 1.0 ms each among eight) and every group would get its selection at the same late moment, whereas one
+// after the other the groups' chains start 0.3 ms apart and their host work spreads out (44.5 -> 39.7 ms per C4 step). Taking
+// turns for EVERY device phase of the groups was tried too: 52 ms per step -- the later phases are short, the lock then mostly
+// adds its own queueing. HS_DEVICE_TURNS=0: no turns.
+struct DeviceTurn {
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static bool on() { static const bool v = []() { const char* e = std::getenv("HS_DEVICE_TURNS"); return !(e && e[0] == '0'); }(); return v; }
+    std::unique_lock<std::mutex> lk;
+    DeviceTurn() { if (on()) lk = std::unique_lock<std::mutex>(mu()); }
+};
+
 static void set_wait_policy() {   // see stream_wait
     if (!blocking_wait()) return;
     if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
@@ -1073,6 +1085,7 @@ struct HipCvOps : hs::CvDeviceOps {
         if (g1 <= g0) return HS_OK;
         const int64_t t0 = g0 >> 8, t1 = (g1 + 255) >> 8;
         const int64_t cap = (t1 - t0) * 256;
+        DeviceTurn turn;
         if (int rc = range_scratch.prepare(cap)) return rc;
         if (int rc = d_rsel_count.alloc(8)) return rc;
         if (int rc = d_rsel_gpos.alloc((size_t)cap * 8)) return rc;
