@@ -1824,7 +1824,8 @@ struct HipSrOps : hs::SrDeviceOps {
             if (lds > 32 * 1024)
                 HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_window_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(hsdev::k_window_tail, dim3((unsigned)Wc), dim3(64), lds, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(), G.d_row0.as<int64_t>(),
-                               G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), G.d_fe.as<uint8_t>(), d_cw.as<int32_t>(), d_cr0.as<int64_t>(),
+                               G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), G.d_fe.as<uint8_t>(), G.d_prog_info.as<uint32_t>(),
+                               G.d_prog_adj.as<unsigned long long>(), d_cw.as<int32_t>(), d_cr0.as<int64_t>(),
                                d_csb.as<int64_t>(), d_cs0.as<int64_t>(), d_slab.as<int32_t>(), Wc, d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
                                d_col_code.as<uint8_t>(), d_cpos.as<int32_t>(), d_sf.as<int64_t>(), d_sl.as<int64_t>(), d_plo.as<int32_t>(), d_phi.as<int32_t>(),
                                finish ? 1 : 0, cap_tail, d_gs.as<int32_t>(), d_ts.as<int64_t>(), d_l3.as<int32_t>(), d_final.as<int32_t>(), d_ok.as<uint8_t>(),

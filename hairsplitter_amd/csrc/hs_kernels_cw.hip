@@ -217,6 +217,42 @@ static __device__ int cw_local_wave(const int64_t* __restrict__ off_w /* at the 
     return iters;
 }
 
+// The same run for a window of at most 64 nodes, without memory on the way: lane j holds the label of node j, the neighbours of
+// the visited node are ONE 64-bit mask (k_cw_visit_lists), the vote is a leader loop over the distinct labels of the lanes in
+// that mask (ballot + popcount each), the new label goes to its lane. `lab` (m ints) is read at the start and written at the end.
+static __device__ int cw_local_wave_masks(const unsigned long long* __restrict__ adj_w, const uint32_t* __restrict__ info_w, int n_visit, int m,
+                                          int32_t* lab, int lane) {
+    int L = lane < m ? lab[lane] : -1;
+    int changes = 3, iters = 0;
+    while (changes > 2 && iters < 15) {
+        changes = 0;
+        unsigned long long adj_n = n_visit > 0 ? adj_w[0] : 0ull;
+        uint32_t inf_n = n_visit > 0 ? info_w[0] : 0u;
+        for (int v = 0; v < n_visit; ++v) {
+            const unsigned long long adj = adj_n;
+            const int i = (int)(inf_n & 255u);
+            if (v + 1 < n_visit) { adj_n = adj_w[v + 1]; inf_n = info_w[v + 1]; }
+            unsigned long long rem = adj & __ballot(L >= 0);      // labels < 0 do not vote
+            int best_cnt = 0, best_lab = -1;
+            while (rem) {
+                const int X = __builtin_amdgcn_readlane(L, __builtin_ctzll(rem));
+                const unsigned long long mX = __ballot(L == X) & adj;
+                rem &= ~mX;
+                const int c = __popcll(mX);
+                if (c > best_cnt || (c == best_cnt && X < best_lab)) { best_cnt = c; best_lab = X; }      // lowest label among the most frequent (:272-279)
+            }
+            if (best_cnt > 0) {
+                const int old = __builtin_amdgcn_readlane(L, i);
+                if (old != best_lab) { changes++; if (lane == i) L = best_lab; }
+            }
+        }
+        iters++;
+    }
+    if (lane < m) lab[lane] = L;
+    wave_sync_lds();
+    return iters;
+}
+
 // Seeding of a per-SNP run (separate_reads.cpp:1678-1691): every node starts alone; the nodes that carry the same code at
 // the seeding SNP start in the cluster of the first node (lowest read id) carrying it. `first`: 256 ints of scratch.
 template <int LANES>
@@ -716,7 +752,7 @@ static __device__ void first_seen_ids_wave(const int32_t* first, int m, int32_t*
 __global__ __launch_bounds__(64) void k_window_tail(
     const int64_t* __restrict__ off, const int32_t* __restrict__ nbr, const int64_t* __restrict__ win_row0,
     const int32_t* __restrict__ mask_ids, const int32_t* __restrict__ visit, const int32_t* __restrict__ visit_n,
-    const uint8_t* __restrict__ win_final_empty,
+    const uint8_t* __restrict__ win_final_empty, const uint32_t* __restrict__ prog_info, const unsigned long long* __restrict__ prog_adj,
     const int32_t* __restrict__ chain_win, const int64_t* __restrict__ chain_row0, const int64_t* __restrict__ chain_seed_begin,
     const int64_t* __restrict__ chain_slab0, const int32_t* __restrict__ slab, int n_chain,
     const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
@@ -776,7 +812,10 @@ __global__ __launch_bounds__(64) void k_window_tail(
     wave_sync_lds();
     first_seen_ids_wave(t0, m, t1, lab, lane);
     // ---- run on the finalize graph (:881) ----
-    sweeps += (unsigned long long)cw_local_wave(off_w, nbr, vis, n_visit, m, lab, cnt, lane);
+    const bool masks = m <= 64 && prog_adj != nullptr;      // the window's neighbour masks exist (k_cw_visit_lists)
+    wave_sync_lds();
+    sweeps += (unsigned long long)(masks ? cw_local_wave_masks(prog_adj + r0, prog_info + r0, n_visit, m, lab, lane)
+                                         : cw_local_wave(off_w, nbr, vis, n_visit, m, lab, cnt, lane));
     // ---- clusters with fewer than 5 reads become -1, the others are renumbered by first appearance (:924-955) ----
     for (int j = lane; j < m; j += 64) { nc[j] = 0; t1[j] = 0x7fffffff; }
     wave_sync_lds();
@@ -793,7 +832,9 @@ __global__ __launch_bounds__(64) void k_window_tail(
     wave_sync_lds();
     first_seen_ids_wave(nc, m, t1, lab, lane);
     // ---- run (:970) ----
-    sweeps += (unsigned long long)cw_local_wave(off_w, nbr, vis, n_visit, m, lab, cnt, lane);
+    wave_sync_lds();
+    sweeps += (unsigned long long)(masks ? cw_local_wave_masks(prog_adj + r0, prog_info + r0, n_visit, m, lab, lane)
+                                         : cw_local_wave(off_w, nbr, vis, n_visit, m, lab, cnt, lane));
     for (int j = lane; j < m; j += 64) l3[j] = lab[j];
     if (lane == 0 && stat) {
         atomicAdd(&stat[0], sweeps);
