@@ -796,6 +796,12 @@ __global__ __launch_bounds__(64) void k_window_tail(
     auto bail = [&]() { if (lane == 0) ok_out[c] = 0; };
     unsigned long long sweeps = 0;
 
+#ifdef HS_TAIL_DIAG
+    unsigned long long tq0 = __builtin_readcyclecounter();
+#define HS_TQ(k) { const unsigned long long tq1 = __builtin_readcyclecounter(); if (lane == 0 && stat) atomicAdd(&stat[18 + (k)], tq1 - tq0); tq0 = tq1; }
+#else
+#define HS_TQ(k)
+#endif
     // ---- merge_clusterings ids (:840-874): the reference's double key sum_i label_i * 2^i, labels = read ids ----
     for (int j = lane; j < m; j += 64) {
         double a = 0.0, f = 1.0;
@@ -811,6 +817,7 @@ __global__ __launch_bounds__(64) void k_window_tail(
     }
     wave_sync_lds();
     first_seen_ids_wave(t0, m, t1, lab, lane);
+    HS_TQ(0)
     // ---- run on the finalize graph (:881) ----
     const bool masks = m <= 64 && prog_adj != nullptr;      // the window's neighbour masks exist (k_cw_visit_lists)
     wave_sync_lds();
@@ -842,6 +849,7 @@ __global__ __launch_bounds__(64) void k_window_tail(
     }
     if (!finish_on_device) { bail(); return; }
 
+    HS_TQ(1)
     // ---- first-seen renumbering (:973-984) ----
     for (int j = lane; j < m; j += 64) nc[j] = -1;
     wave_sync_lds();
@@ -862,6 +870,7 @@ __global__ __launch_bounds__(64) void k_window_tail(
     const int Kc = s_scalar[0];
     if (s_scalar[1] || Kc > HS_FIN_KCAP) { bail(); return; }
 
+    HS_TQ(2)
     // ---- merge_close_clusters (cluster_graph.cpp:402-501) ----
     if (lane < HS_FIN_KCAP) { s_initial[lane] = 0; s_votes[lane] = 0; s_tested[lane] = 0; }
     wave_sync_lds();
@@ -920,6 +929,7 @@ __global__ __launch_bounds__(64) void k_window_tail(
         wave_sync_lds();
     }
 
+    HS_TQ(3)
     // ---- merge_wrongly_split_haplotypes (separate_reads.cpp:1007-1327) ----
     if (lane < HS_FIN_KCAP) { s_index_of[lane] = -1; s_slot_of[lane] = -1; }
     wave_sync_lds();
@@ -942,13 +952,16 @@ __global__ __launch_bounds__(64) void k_window_tail(
     for (int x = lane; x < G * G; x += 64) { s_incompat[x] = 0; s_pos_last[x] = -10; }
     wave_sync_lds();
     const int pos_lo = win_pos_lo[c], pos_hi = win_pos_hi[c];
+    for (int j = lane; j < m; j += 64) t0[j] = ids[j];          // the read ids next to the labels: the look-ups below stay off global memory
+    wave_sync_lds();
+    const int32_t* ids_l = t0;
     for (int64_t s = win_snp_first[c]; s < win_snp_last[c]; ++s) {
         const int p = col_pos[s];
         if (!(p >= pos_lo && p < pos_hi)) continue;
         if (lane < G) { s_nb[lane] = 0; s_major[lane] = 0; }   // 0 == the operator[] default for clusters absent at this SNP
         wave_sync_lds();
         for (int64_t e = col_off[s] + lane; e < col_off[s + 1]; e += 64) {
-            const int j = local_index(ids, m, col_idx[e]);
+            const int j = local_index(ids_l, m, col_idx[e]);
             const int cl = j >= 0 ? lab[j] : -2;
             if (cl > -1) { const int slt = s_slot_of[cl]; atomicAdd(&s_cnts[slt][col_code[e]], 1); atomicAdd(&s_nb[slt], 1); }
         }
@@ -963,12 +976,14 @@ __global__ __launch_bounds__(64) void k_window_tail(
                 if (v > t1v) { t2v = t1v; t1v = v; c1 = code; } else if (v > t2v) t2v = v;
                 s_cnts[i][code] = 0;
             }
-            const int mx = wave_max_i32(t1v);
+            // one reduction gives the maximum and, among the lanes that hold it, the largest of their codes (counts < 2^23)
+            const int top = wave_max_i32((t1v << 8) | (c1 & 255));
+            const int mx = top >> 8;
             if (mx == 0) continue;                              // cluster absent at this SNP: majority stays 0
-            const int n_at = wave_sum_i32((t1v == mx ? 1 : 0) + (t2v == mx ? 1 : 0));
+            const int n_at = __popcll(__ballot(t1v == mx)) + __popcll(__ballot(t2v == mx));
             const int below = wave_max_i32(t1v == mx ? t2v : t1v);  // best count strictly below the maximum when it is unique
             const int second_max = n_at >= 2 ? mx : below;
-            int max_base = wave_max_i32(t1v == mx ? c1 : -1);
+            int max_base = top & 255;
             if (second_max * 2 > mx || s_nb[i] * 0.5 > mx) max_base = ' ';
             if (lane == 0) s_major[i] = max_base & 255;
         }
@@ -1056,6 +1071,7 @@ __global__ __launch_bounds__(64) void k_window_tail(
     if (s_scalar[3]) { bail(); return; }
     for (int j = lane; j < m; j += 64) lout[j] = s_o2n[lab[j] + 2];
     if (lane == 0) ok_out[c] = 1;
+    HS_TQ(4)
 }
 
 }  // namespace hsdev
