@@ -177,7 +177,7 @@ static Contingency column_vs_partition(const DensePartition& p, const int32_t* i
 
 // A candidate column as one bit set per distinct code (the reads that carry it), in first-appearance order.
 struct ColumnBits {
-    int words = 0, nslots = 0;
+    int words = 0, nslots = 0, n_entries = 0;
     uint8_t code_of[128];
     uint8_t slot_of[256];         // code -> slot, 0xFF = none yet; reset for the used codes at the next build
     std::vector<uint64_t> bits;   // [nslots][words]
@@ -187,7 +187,7 @@ struct ColumnBits {
     void build(const int32_t* idx, const uint8_t* code, int n, int n_reads, const int32_t* rank_of) {
         for (int k = 0; k < nslots; ++k) slot_of[code_of[k]] = 0xFF;
         words = (n_reads + 63) >> 6;
-        nslots = 0;
+        nslots = 0; n_entries = n;
         wlo = words; whi = -1;
         any.assign((size_t)words, 0ull);
         if (bits.size() < (size_t)8 * words) bits.resize((size_t)8 * words);
@@ -223,6 +223,10 @@ static Contingency column_vs_partition_bits(const DensePartition& p, const Colum
     if (shared == 0) return r;
     r.comparable = true;
     r.most = ref;
+    // Few shared reads: the table holds at most `shared` reads, the column can only fit the partition with at least half of its
+    // own reads in the table (:624-627) and only correlate with chi-square > 15, which a 2x2 table of N reads cannot exceed N
+    // for (14 leaves room for the float rounding) -- neither can happen, the counts are of no consequence
+    if (shared <= 14 && (size_t)shared < (size_t)cb.n_entries / 2) return r;
     // counts among the shared reads
     uint8_t seen[128]; int cnt[128]; int slot[128];
     int nseen = 0;
@@ -575,7 +579,15 @@ void cv_phase_a_host(CvContigState& st, ColumnSet& cs, const int32_t* read_start
             {
                 const Contingency e = column_vs_partition(parts[p], idx, code, n, cs.k0[ci]);
                 if (e.n00 != d.n00 || e.n01 != d.n01 || e.n10 != d.n10 || e.n11 != d.n11 || e.comparable != d.comparable || e.second != d.second) {
-                    std::fprintf(stderr, "HS_SELFCHECK: bit-set column_vs_partition differs\n"); std::abort();
+                    // the bit-set form leaves the counts at zero where they cannot matter (few shared reads): the entry walk must
+                    // then say "no correlation, no fit" as well
+                    const int ec = e.n00 + e.n11 + e.n01 + e.n10;
+                    const bool e_corr = e.n00 + e.n01 > 0.1 * ec && e.n00 + e.n01 < 0.9 * ec && e.n01 + e.n11 > 0.1 * ec && e.n01 + e.n11 < 0.9 * ec && chi_square(e) > 15;
+                    const bool e_enough = (size_t)ec >= (size_t)n / 2;
+                    const bool e_fit = (e.n01 <= std::max(0.1 * (e.n00 + e.n01), 1.0) && e.n10 < std::max(0.1 * (e.n11 + e.n10), 1.0) && e_enough)
+                                       || (e.n00 <= std::max(0.1 * (e.n00 + e.n01), 1.0) && e.n11 < std::max(0.1 * (e.n11 + e.n10), 1.0) && e_enough);
+                    const bool skipped = d.comparable && d.n00 + d.n01 + d.n10 + d.n11 == 0 && e.comparable;
+                    if (!skipped || e_corr || e_fit) { std::fprintf(stderr, "HS_SELFCHECK: bit-set column_vs_partition differs\n"); std::abort(); }
                 }
             }
 #endif
