@@ -357,6 +357,17 @@ static void augment(DensePartition& p, const int32_t* idx, const uint8_t* code, 
     p.n_occ += 1;
 }
 
+// 0.5 n + 3 sqrt(n 0.5 (1 - 0.5)) as the reference forms it (double arithmetic, then float): Partition.cpp:154, call_variants.cpp:
+// 1033-1034. A function of the integer n alone: tabulated once for the small n that occur (the same expression, the same bits).
+static inline float three_sigma_threshold(int n) {
+    static const std::vector<float> table = [] {
+        std::vector<float> t(4096);
+        for (int k = 0; k < 4096; ++k) t[(size_t)k] = (float)(0.5 * k + 3 * std::sqrt(k * 0.5 * (1 - 0.5)));
+        return t;
+    }();
+    return n >= 0 && n < 4096 ? table[(size_t)n] : (float)(0.5 * n + 3 * std::sqrt(n * 0.5 * (1 - 0.5)));
+}
+
 // Partition::isInformative(false, meanError): Partition.cpp:141-179
 static bool is_informative(const DensePartition& p, float mean_error) {
     int suspicious[2] = {0, 0};
@@ -364,7 +375,7 @@ static bool is_informative(const DensePartition& p, float mean_error) {
     for (int r = p.lo; r <= p.hi; ++r) {
         if (p.state[r] == ABSENT) continue;
         const int read_number = p.more[r] + p.less[r];
-        float threshold = (float)(0.5 * read_number + 3 * std::sqrt(read_number * 0.5 * (1 - 0.5)));
+        float threshold = three_sigma_threshold(read_number);
         threshold = std::min(threshold, float(read_number) - 1);
         if ((float)p.more[r] > threshold) {
             if (p.state[r] == -1) { suspicious[0]++; number_of_reads++; }
@@ -422,8 +433,8 @@ static PartPartDistance partition_vs_partition(const DensePartition& a, const De
         if (a.state[r] == ABSENT || b.state[r] == ABSENT) continue;
         if (!(a.more[r] > 1 && b.more[r] > 1)) continue;
         comparable++;
-        const float t1 = (float)(0.5 * (a.more[r] + a.less[r]) + 3 * std::sqrt((a.more[r] + a.less[r]) * 0.5 * (1 - 0.5)));
-        const float t2 = (float)(0.5 * (b.more[r] + b.less[r]) + 3 * std::sqrt((b.more[r] + b.less[r]) * 0.5 * (1 - 0.5)));
+        const float t1 = three_sigma_threshold(a.more[r] + a.less[r]);
+        const float t2 = three_sigma_threshold(b.more[r] + b.less[r]);
         const bool both = (float)a.more[r] > t1 && (float)b.more[r] > t2;
         const bool either = (float)a.more[r] > t1 || (float)b.more[r] > t2;
         const int s1 = a.state[r], s2 = b.state[r];
