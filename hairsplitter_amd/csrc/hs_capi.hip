@@ -161,12 +161,13 @@ struct UploadPack {
     }
 };
 
-// Host waits. On this runtime a waiting host thread spins (100 % of a core for the whole wait) whether or not the event
-// carries hipEventBlockingSync; only the device-wide schedule flag makes hipEventSynchronize / hipStreamSynchronize sleep
-// (tools/probes/wait_probe.hip: 0.3 ms of CPU per 20-ms wait, woken 30-70 us late). Which is better depends on whether the
-// host has cores to spare: on the 16-core box 256 x C2 (14.5 cores busy) runs 5 % faster spinning, the 500-contig job (it
-// wants 17-18 cores: the cgroup throttles it) 4 % faster sleeping. So the pipeline starts spinning and looks at its own CPU
-// load after every run (adapt_wait_policy); HS_BLOCKING_WAIT=1 / HS_SPIN_WAIT=1 pin the choice.
+// Host waits = polling hipStreamQuery: back to back ("spin") or with a 25-us sleep between two looks ("sleep": about 1 % of a
+// core instead of 100 %, the host learns of the end of the work 30-80 us late). No events, no interrupts, no device-wide
+// scheduling flag: the mode is a plain variable and can change between two waits; a wait that sees no progress for five
+// minutes returns an error instead of hanging the caller. Which mode is better depends on whether the host has cores to
+// spare: on the 16-core box 256 x C2 (14.5 cores busy) runs 3-5 % faster spinning, the 500-contig job (it wants 17-18 cores:
+// the cgroup throttles it) 4 % faster sleeping. So the pipeline starts spinning and looks at its own CPU load after every run
+// (adapt_wait_policy); HS_BLOCKING_WAIT=1 / HS_SPIN_WAIT=1 pin the choice.
 static std::atomic<int> g_block_waits{0};
 static int forced_wait_policy() {
     static const int f = std::getenv("HS_BLOCKING_WAIT") ? 1 : (std::getenv("HS_SPIN_WAIT") ? 0 : -1);
@@ -185,12 +186,19 @@ static int stream_wait(hipStream_t s) {
     return rc;
 }
 static int stream_wait_impl(hipStream_t s) {
-    if (spin_wait()) { HS_HIP(hipStreamSynchronize(s)); return HS_OK; }
-    static thread_local hipEvent_t ev = nullptr;
-    if (!ev) HS_HIP(hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming));
-    HS_HIP(hipEventRecord(ev, s));
-    HS_HIP(hipEventSynchronize(ev));
-    return HS_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long looks = 1;; ++looks) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return HS_OK;
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); set_error(std::string("hipStreamQuery: ") + hipGetErrorString(e)); return HS_EHIP; }
+        (void)hipGetLastError();      // (hipErrorNotReady is sticky otherwise)
+        if (blocking_wait()) { struct timespec ts = {0, 25000}; nanosleep(&ts, nullptr); }
+        else { for (int i = 0; i < 16; ++i) __builtin_ia32_pause(); }
+        if ((looks & 4095ul) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) {
+            set_error("the device did not finish the queued work within 300 s");
+            return HS_EHIP;
+        }
+    }
 }
 static int copy_d2h(void* h, const void* d, size_t n, hipStream_t s) {
     if (n) HS_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
@@ -218,7 +226,7 @@ struct EventPair {
     static int get(hipEvent_t* e) {
         std::vector<hipEvent_t>& c = cache();
         if (!c.empty()) { *e = c.back(); c.pop_back(); return HS_OK; }
-        HS_HIP(hipEventCreateWithFlags(e, spin_wait() ? hipEventDefault : hipEventBlockingSync));
+        HS_HIP(hipEventCreateWithFlags(e, hipEventDefault));
         return HS_OK;
     }
     int init() { if (int rc = get(&a)) return rc; return get(&b); }
@@ -295,10 +303,7 @@ struct DeviceTurn {
     DeviceTurn() { if (on()) lk = std::unique_lock<std::mutex>(mu()); }
 };
 
-static void set_wait_policy() {   // see stream_wait
-    if (!blocking_wait()) return;
-    if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
-}
+static void set_wait_policy() {}   // (the wait mode is no device state any more: see stream_wait)
 // after a pipeline run: process CPU time over (wall time x usable cores). Above 0.97 the host is the limit and the cores the
 // waiting threads burn are missed elsewhere -> sleeping waits from the next run on; below 0.85 back to spinning.
 static void adapt_wait_policy(double cpu_s, double wall_s) {
@@ -308,7 +313,6 @@ static void adapt_wait_policy(double cpu_s, double wall_s) {
     const int next = load > 0.97 ? 1 : (load < 0.85 ? 0 : cur);
     if (next == cur) return;
     g_block_waits.store(next, std::memory_order_relaxed);
-    if (hipSetDeviceFlags(next ? hipDeviceScheduleBlockingSync : hipDeviceScheduleSpin) != hipSuccess) (void)hipGetLastError();
     if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] host waits now %s (process CPU load %.2f of %d cores)\n", next ? "sleep" : "spin", load, host_threads());
 }
 

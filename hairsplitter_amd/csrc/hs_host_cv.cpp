@@ -226,7 +226,13 @@ static Contingency column_vs_partition_bits(const DensePartition& p, const Colum
     // Few shared reads: the table holds at most `shared` reads, the column can only fit the partition with at least half of its
     // own reads in the table (:624-627) and only correlate with chi-square > 15, which a 2x2 table of N reads cannot exceed N
     // for (14 leaves room for the float rounding) -- neither can happen, the counts are of no consequence
-    if (shared <= 14 && (size_t)shared < (size_t)cb.n_entries / 2) return r;
+    static const bool no_skip = std::getenv("HS_LOOP_A_NO_SKIP") != nullptr;      // (diagnostic: form every table)
+    if (!no_skip && shared <= 14 && (size_t)shared < (size_t)cb.n_entries / 2) return r;
+    if (!no_skip) {   // the same with the shared reads the partition has an opinion on (state +1 / -1): only those enter the table
+        int decided = 0;
+        for (int w = w0; w <= w1; ++w) decided += __builtin_popcountll(cb.any[(size_t)w] & (p.plus[(size_t)w] | p.minus[(size_t)w]));
+        if (decided <= 14 && (size_t)decided < (size_t)cb.n_entries / 2) return r;
+    }
     // counts among the shared reads
     uint8_t seen[128]; int cnt[128]; int slot[128];
     int nseen = 0;
