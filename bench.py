@@ -148,6 +148,16 @@ def file_to_file(cfg, n_job, sample_ids, job_files, seed, reps, reference_on_ful
 
 
 def main():
+    # a run that stops making progress leaves the stacks of its threads on stderr (SIGUSR1 at any time; on its own after
+    # HS_BENCH_WATCHDOG_S seconds, default 1500, and exits) instead of sitting there until somebody's timeout
+    import faulthandler
+    import signal
+    faulthandler.enable()
+    try:
+        faulthandler.register(signal.SIGUSR1, all_threads=True)
+    except (AttributeError, ValueError):
+        pass
+    faulthandler.dump_traceback_later(float(os.environ.get("HS_BENCH_WATCHDOG_S", "1500")), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
