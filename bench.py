@@ -85,16 +85,16 @@ def run_stage_pair(cv, sr, files, td, tag, threads, env=None):
     col, vcf, err, gro = (os.path.join(td, f"{tag}.{x}") for x in ("col", "vcf", "err", "gro"))
     t0 = time.perf_counter()
     subprocess.run(cv + [files["gfa"], files["reads"], files["sam"], str(threads), td, err, "0", "0", col, vcf, "0.33"], check=True,
-                   stdout=subprocess.DEVNULL, env=env)
+                   stdout=subprocess.DEVNULL, env=env, timeout=900)
     t1 = time.perf_counter()
     e = py_error_rate(float(open(err).read().strip()))
     subprocess.run(sr + [col, str(threads), str(e), os.path.join(td, "no_ploidy"), "0", "0.01", "0", gro, "0"], check=True,
-                   stdout=subprocess.DEVNULL, env=env)
+                   stdout=subprocess.DEVNULL, env=env, timeout=900)
     t2 = time.perf_counter()
     return t1 - t0, t2 - t1
 
 
-def file_to_file(cfg, n_job, sample_ids, job_files, seed, reps, reference_on_full_job):
+def file_to_file(cfg, n_job, sample_ids, sample_files, job_files, reps, reference_on_full_job):
     """SURVEY.md 8(d) metric (ii): wall clock of the two drop-in executables next to the compiled reference (oracle/_ref,
     built from /root/reference by oracle/Makefile) on the SAME files, `reps` runs each, median. The reference runs on a
     bounded sample of the job (the first contigs of the configuration) so that the default bench stays within minutes; the
@@ -108,9 +108,8 @@ def file_to_file(cfg, n_job, sample_ids, job_files, seed, reps, reference_on_ful
         return None, None
     out = {"threads": cores, "runs": reps}
     with tempfile.TemporaryDirectory() as td:
-        contigs, f = synth.generate_job(cfg, sample_ids, seed=seed, workers=min(8, cores), outdir=td)
-        bp = int(sum(c.aligned_bp for c in contigs))
-        del contigs
+        f = sample_files                      # written before the GPU was touched (main)
+        bp = int(sample_files["aligned_bp"])
         ours = [run_stage_pair([p["cv"]], [p["sr"]], f, td, "hip", cores) for _ in range(reps)]
         if have_ref:
             ref = [run_stage_pair([p["ref_cv"]], [p["ref_sr"]], f, td, "ref", cores) for _ in range(reps)]
@@ -192,6 +191,21 @@ def main():
     gen_workers = 1 if os.environ.get("HS_BENCH_SERIAL_SETUP") else max(1, min(8, effective_cores() // world_env))
     contigs, job_files = synth.generate_job(cfg, my_ids, seed=args.seed, workers=gen_workers, outdir=job_dir)
     t_gen = time.perf_counter() - t_gen
+    # the files of the file-to-file sample too, NOW: forking workers from a process that has initialised the GPU (runtime threads,
+    # their locks copied mid-flight into the child) hangs now and then
+    sample_dir, sample_files, n_sample = None, None, 0
+    if want_f2f:
+        if args.cpu_contigs > 0:
+            n_sample = min(args.cpu_contigs, n_job)
+        else:   # about 80 M aligned bp: ~2-4 s of the reference on 16 cores
+            acc = 0.0
+            while n_sample < n_job and acc < 80e6:
+                acc += shapes[n_sample][0] * shapes[n_sample][2]; n_sample += 1
+            n_sample = max(n_sample, min(n_job, effective_cores()))
+        sample_dir = tempfile.mkdtemp(prefix="hs_bench_sample_")
+        sample_contigs, sample_files = synth.generate_job(cfg, list(range(n_sample)), seed=args.seed, workers=gen_workers, outdir=sample_dir)
+        sample_files["aligned_bp"] = int(sum(c.aligned_bp for c in sample_contigs))
+        del sample_contigs
 
     import torch
     import torch.distributed as dist
@@ -368,14 +382,7 @@ def main():
         batch = None
         if want_f2f:
             try:
-                if args.cpu_contigs > 0:
-                    n_s = min(args.cpu_contigs, n_job)
-                else:   # about 80 M aligned bp: ~2-4 s of the reference on 16 cores
-                    n_s, acc = 0, 0.0
-                    while n_s < n_job and acc < 80e6:
-                        acc += shapes[n_s][0] * shapes[n_s][2]; n_s += 1
-                    n_s = max(n_s, min(n_job, effective_cores()))
-                f2f, base = file_to_file(cfg, n_job, list(range(n_s)), job_files, args.seed, max(1, args.f2f_runs), args.f2f_reference_full)
+                f2f, base = file_to_file(cfg, n_job, list(range(n_sample)), sample_files, job_files, max(1, args.f2f_runs), args.f2f_reference_full)
                 if f2f is not None:
                     out["file_to_file"] = f2f
                     out["cpu_baseline"] = base
@@ -386,6 +393,8 @@ def main():
         batch.close()
     if job_dir is not None:
         shutil.rmtree(job_dir, ignore_errors=True)
+    if sample_dir is not None:
+        shutil.rmtree(sample_dir, ignore_errors=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
