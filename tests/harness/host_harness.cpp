@@ -329,8 +329,77 @@ struct OracleSrOps : hs::SrDeviceOps {
 
 }  // namespace
 
+// `selftest`: host-side pieces of the drivers that need no device and no input files
+struct RangeOnlyOps : hs::CvDeviceOps {
+    std::vector<int64_t> gpos; std::vector<int32_t> depth;
+    int pileup_and_select(std::vector<int32_t>&, int, const int64_t**, const int32_t**, size_t*, float*) override { return -1; }
+    int gather(const std::vector<int32_t>&, const std::vector<int32_t>&, const std::vector<int64_t>&, const hs_coltop**, float*) override { return -1; }
+    int fetch_columns(const std::vector<int32_t>&, const std::vector<int64_t>&, int, const int32_t**, const uint8_t**) override { return -1; }
+    int column_partition_test(const hs::CvPartitionTest&, std::vector<uint8_t>&, float*) override { return -1; }
+    bool has_select_range() const override { return true; }
+    int select_range(int64_t g0, int64_t g1, int, const int64_t** sg, const int32_t** sd, size_t* n, float* k_ms) override {
+        // like the device: everything of the 256-position tiles that hold [g0, g1), i.e. also positions of the neighbours
+        static std::vector<int64_t> og; static std::vector<int32_t> od;
+        og.clear(); od.clear();
+        const int64_t t0 = (g0 >> 8) << 8, t1 = ((g1 + 255) >> 8) << 8;
+        for (size_t i = 0; i < gpos.size(); ++i) if (gpos[i] >= t0 && gpos[i] < t1) { og.push_back(gpos[i]); od.push_back(depth[i]); }
+        *sg = og.data(); *sd = od.data(); *n = og.size(); if (k_ms) *k_ms = 0;
+        return 0;
+    }
+};
+
+static int selftest() {
+    int bad = 0;
+    auto expect = [&](bool ok, const char* what) { if (!ok) { std::fprintf(stderr, "selftest FAILED: %s\n", what); bad++; } };
+    {   // sr_expand_labels: -2 where a window does not hold the read
+        hs::SrSparseLabels sp;
+        sp.off = {0, 2, 2, 5}; sp.ids = {1, 3, 0, 2, 4}; sp.labels = {7, -1, 0, 1, 0};
+        const int64_t label_off[4] = {0, 5, 10, 15};
+        std::vector<int32_t> dense(15, 99);
+        hs::sr_expand_labels(sp, label_off, 0, 3, dense.data());
+        const int32_t want[15] = {-2, 7, -2, -1, -2,  -2, -2, -2, -2, -2,  0, -2, 1, -2, 0};
+        expect(std::equal(dense.begin(), dense.end(), want), "sr_expand_labels");
+        std::vector<int32_t> part(15, 99);     // windows [1, 3) alone: the first five stay as they are
+        hs::sr_expand_labels(sp, label_off, 1, 3, part.data());
+        const int32_t want2[15] = {99, 99, 99, 99, 99,  -2, -2, -2, -2, -2,  0, -2, 1, -2, 0};
+        expect(std::equal(part.begin(), part.end(), want2), "sr_expand_labels on a range of windows");
+    }
+    {   // the dense label block is recycled between calls
+        int32_t* a = hs::sr_labels_alloc(5u << 20);
+        a[0] = 1; a[(5u << 20) - 1] = 2;
+        hs::sr_labels_free(a);
+        int32_t* b = hs::sr_labels_alloc((5u << 20) - 1000);
+        expect(a == b, "a freed label block of 20 MB is handed out again");
+        hs::sr_labels_free(b);
+        int32_t* c = hs::sr_labels_alloc(16);
+        hs::sr_labels_free(c);
+        int32_t* plain = (int32_t*)std::malloc(64);
+        std::memset(plain, 0, 64);
+        hs::sr_labels_free(nullptr);      // (accepted)
+        std::free(plain);
+    }
+    {   // cv_select_range: positions of the neighbouring ranges from the boundary tiles are dropped, offsets start at c0
+        hs::CvMeta m;
+        m.n_contigs = 4; m.contig_off = {0, 300, 700, 1000, 1300}; m.total_len = 1300;
+        RangeOnlyOps ops;
+        ops.gpos = {10, 290, 310, 500, 699, 700, 705, 999, 1001, 1200};
+        ops.depth = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10};
+        hs::CvSelection sel;
+        expect(hs::cv_select_range(ops, m, 1, 3, sel) == 0, "cv_select_range runs");
+        const std::vector<int32_t> wc = {1, 1, 1, 2, 2, 2}, wp = {10, 200, 399, 0, 5, 299}, wd = {3, 4, 5, 6, 7, 8};
+        expect(std::vector<int32_t>(sel.sel_contig.begin(), sel.sel_contig.end()) == wc, "cv_select_range contigs");
+        expect(std::vector<int32_t>(sel.sel_pos.begin(), sel.sel_pos.end()) == wp, "cv_select_range positions");
+        expect(std::vector<int32_t>(sel.sel_depth.begin(), sel.sel_depth.end()) == wd, "cv_select_range depths");
+        const std::vector<int64_t> wo = {0, 0, 3, 6, 6};
+        expect(sel.contig_sel_off == wo, "cv_select_range offsets");
+    }
+    std::printf("selftest %s\n", bad ? "FAILED" : "ok");
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
+    if (!std::strcmp(argv[1], "selftest")) return selftest();
     if (!std::strcmp(argv[1], "call_variants")) {
         if (argc < 13) return 2;
         char** a = argv + 1;

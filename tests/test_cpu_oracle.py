@@ -62,6 +62,14 @@ def test_robin_hood_order_vectors(built):
         assert list(map(int, o.split())) == v["order"]
 
 
+def test_host_driver_selftest(built):
+    """Pieces of the stage drivers that need neither a device nor input files (tests/harness/host_harness.cpp `selftest`): the
+    labels of the contig groups spread into the dense result (sr_expand_labels), the recycled result block, and the per-range
+    selection of the contig groups (cv_select_range: boundary tiles bring positions of the neighbouring ranges)"""
+    r = subprocess.run([built["harness"], "selftest"], capture_output=True, text=True)
+    assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_rh8_static_order(built):
     """The closed form k_robust_partitions uses for the iteration order of small hash maps (hs_kernels_parts.hip) against the
     emulator, on two million random key sets"""
