@@ -691,7 +691,7 @@ void cv_phase_b(CvContigState& st, ContigCvResult& out) {
                 if (do_merge) { merge_partitions(finals[p2], parts[p1], d.phased); different = false; break; }
             }
         }
-        if (different) finals.push_back(parts[p1]);
+        if (different) finals.push_back(std::move(parts[p1]));      // (a partition of loop A is looked at once)
     }
     out.n_final_partitions = (int)finals.size();
     std::vector<DensePartition>().swap(parts);
