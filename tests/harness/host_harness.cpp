@@ -80,6 +80,24 @@ struct OracleCvOps : hs::CvDeviceOps {
         *sel_gpos_out = sel_gpos.data(); *sel_depth_out = sel_depth.data(); *n_sel_out = sel_gpos.size();
         return 0;
     }
+    // the two-part form of the streaming pass (contig groups): pileup = the per-record counters, select_range = the selection
+    // of the 256-position tiles that hold [g0, g1), SORTED (as the device hands it over), neighbours' positions included
+    std::vector<int64_t> rng_gpos; std::vector<int32_t> rng_depth;
+    bool has_select_range() const override { return true; }
+    int pileup(std::vector<int32_t>& rec_stats, float k_ms[4]) override {
+        const int64_t* g; const int32_t* d; size_t n;
+        return pileup_and_select(rec_stats, 4, &g, &d, &n, k_ms);      // (the selection of the whole batch is kept for select_range)
+    }
+    int select_range(int64_t g0, int64_t g1, int, const int64_t** sg, const int32_t** sd, size_t* n, float* k_ms) override {
+        std::vector<std::pair<int64_t, int32_t>> v;
+        const int64_t t0 = (g0 >> 8) << 8, t1 = ((g1 + 255) >> 8) << 8;
+        for (size_t i = 0; i < sel_gpos.size(); ++i) if (sel_gpos[i] >= t0 && sel_gpos[i] < t1) v.push_back(std::make_pair(sel_gpos[i], sel_depth[i]));
+        std::sort(v.begin(), v.end());
+        rng_gpos.clear(); rng_depth.clear();
+        for (auto& kv : v) { rng_gpos.push_back(kv.first); rng_depth.push_back(kv.second); }
+        *sg = rng_gpos.data(); *sd = rng_depth.data(); *n = rng_gpos.size(); if (k_ms) *k_ms = 0;
+        return 0;
+    }
     int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
                const hs_coltop** top_out, float* k_ms) override {
         *k_ms = 0;
@@ -423,6 +441,12 @@ int main(int argc, char** argv) {
         }
         OracleCvOps ops(in);
         hs_cv_result* res = nullptr;
+        if (std::getenv("HS_HARNESS_RANGE_SELECT")) {   // the way a contig group goes: pileup, then selection + stage 3 of a range (here: all contigs)
+            hs::CvSelection whole, range;
+            if (int rc = hs::cv_pileup(ops, meta, whole)) return rc;
+            if (int rc = hs::cv_select_range(ops, meta, 0, meta.n_contigs, range)) return rc;
+            if (int rc = hs::cv_run_range(ops, meta, range, 0, meta.n_contigs, std::strtof(a[11], nullptr), 1, &res, &whole.rec_stats)) return rc;
+        } else
         if (int rc = hs::cv_run(ops, meta, std::strtof(a[11], nullptr), 1, &res)) return rc;
         hs::write_cv_outputs(in, res, a[6], a[9], a[10], 4);
         hs::free_cv_result(res);

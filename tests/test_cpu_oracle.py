@@ -48,6 +48,20 @@ def test_host_glue_with_every_column_resolved_on_host(built, case):
         assert gu.compare(td, outs) == []
 
 
+@pytest.mark.parametrize("case", ["multi", "penta30k", "edge_ops"])
+def test_host_glue_through_the_per_range_selection(built, case):
+    """Same, the way a contig group goes through stage 3: pileup of the batch (cv_pileup), then the selection of a range of contigs
+    (cv_select_range: sorted list of the range's tiles, neighbours' positions dropped) and cv_run_range with the batch's
+    per-record counters handed in separately"""
+    if case not in gu.case_names():
+        pytest.skip("golden case not present")
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack(case, td)
+        env = dict(os.environ, HS_HARNESS_RANGE_SELECT="1")
+        outs = gu.run_stage_pair([built["harness"], "call_variants"], [built["harness"], "separate_reads"], td, meta, env=env)
+        assert gu.compare(td, outs) == []
+
+
 def test_robin_hood_order_vectors(built):
     vec = json.load(open(os.path.join(gu.GOLD, "robin_hood_order.json")))
     for v in vec:
