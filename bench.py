@@ -159,8 +159,8 @@ def main():
     faulthandler.dump_traceback_later(float(os.environ.get("HS_BENCH_WATCHDOG_S", "1500")), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--contigs", type=int, default=0, help="number of contigs of the configuration (0 = its own: C2 256, C3 50, C4 500, C5 34)")
     ap.add_argument("--groups", type=int, default=0, help="contig groups (host thread + HIP stream each) per GPU; 0 = min(8, host threads / 4)")
