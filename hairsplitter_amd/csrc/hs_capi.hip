@@ -48,6 +48,9 @@ namespace {
 
 // Size-class pool of device / pinned-host blocks: the stage drivers allocate dozens of temporaries per call and
 // hipMalloc/hipFree (which synchronises) would dominate small batches. Blocks are kept for the life of the process.
+// set when a host wait gave up on the device (stream_wait_impl): kernels may still be writing the blocks of the failed call, so
+// from then on nothing is handed back to the pools (the blocks leak; the process is expected to report the error and end)
+static std::atomic<bool> g_device_lost{false};
 struct BlockPool {
     std::mutex mu;
     std::vector<std::pair<size_t, void*>> free_dev, free_host;
@@ -65,6 +68,7 @@ struct BlockPool {
         return HS_OK;
     }
     void put(bool host, void* p, size_t cap) {
+        if (g_device_lost.load(std::memory_order_relaxed)) return;
         std::lock_guard<std::mutex> g(mu);
         (host ? free_host : free_dev).push_back(std::make_pair(cap, p));
     }
@@ -86,17 +90,20 @@ BlockPool& pool() {
     return *p;
 }
 
-// RAII device buffer (pooled)
+// RAII device buffer (pooled). A block goes back to the pool it came from (`owner`), whatever device is current on the thread
+// that releases it.
 struct DBuf {
     void* p = nullptr;
     size_t bytes = 0, cap = 0;
     bool view = false;             // points into an UploadPack: not owned
-    ~DBuf() { if (p && !view) pool().put(false, p, cap); }
+    BlockPool* owner = nullptr;
+    ~DBuf() { release(); }
+    void release() { if (p && !view && owner) owner->put(false, p, cap); p = nullptr; view = false; }
     int alloc(size_t n) {
-        if (p && !view) pool().put(false, p, cap);
-        p = nullptr; view = false;
+        release();
         bytes = n;
-        return pool().get(false, n ? n : 16, &p, &cap);
+        owner = &pool();
+        return owner->get(false, n ? n : 16, &p, &cap);
     }
     template <class T> int upload(const std::vector<T>& v);
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
@@ -106,10 +113,13 @@ struct DBuf {
 struct HBuf {
     void* p = nullptr;
     size_t cap = 0;
-    ~HBuf() { if (p) pool().put(true, p, cap); }
+    BlockPool* owner = nullptr;
+    ~HBuf() { release(); }
+    void release() { if (p && owner) owner->put(true, p, cap); p = nullptr; }
     int alloc(size_t n) {
-        if (p) { pool().put(true, p, cap); p = nullptr; }
-        return pool().get(true, n ? n : 16, &p, &cap);
+        release();
+        owner = &pool();
+        return owner->get(true, n ? n : 16, &p, &cap);
     }
 };
 
@@ -152,7 +162,7 @@ struct UploadPack {
         if (int rc = host.alloc(total ? total : 256)) return rc;
         for (const Item& it : items) {
             if (it.bytes) std::memcpy((char*)host.p + it.off, it.src, it.bytes);
-            if (it.dst->p && !it.dst->view) pool().put(false, it.dst->p, it.dst->cap);
+            it.dst->release();
             it.dst->p = (char*)dev.p + it.off; it.dst->bytes = it.bytes; it.dst->cap = 0; it.dst->view = true;
         }
         if (total) HS_HIP(hipMemcpyAsync(dev.p, host.p, total, hipMemcpyHostToDevice, stream));
@@ -163,8 +173,9 @@ struct UploadPack {
 
 // Host waits = polling hipStreamQuery: back to back ("spin") or with a 25-us sleep between two looks ("sleep": about 1 % of a
 // core instead of 100 %, the host learns of the end of the work 30-80 us late). No events, no interrupts, no device-wide
-// scheduling flag: the mode is a plain variable and can change between two waits; a wait that sees no progress for five
-// minutes returns an error instead of hanging the caller. Which mode is better depends on whether the host has cores to
+// scheduling flag: the mode is a plain variable and can change between two waits. A wait that has lasted HS_WAIT_TIMEOUT_S
+// seconds (default 1800, 0 = no limit) returns an error instead of hanging the caller for ever; the blocks of that call are
+// then leaked, not recycled (g_device_lost), because the device may still be writing them. Which mode is better depends on whether the host has cores to
 // spare: on the 16-core box 256 x C2 (14.5 cores busy) runs 3-5 % faster spinning, the 500-contig job (it wants 17-18 cores:
 // the cgroup throttles it) 4 % faster sleeping. So the pipeline starts spinning and looks at its own CPU load after every run
 // (adapt_wait_policy); HS_BLOCKING_WAIT=1 / HS_SPIN_WAIT=1 pin the choice.
@@ -185,8 +196,13 @@ static int stream_wait(hipStream_t s) {
     g_waits.fetch_add(1); g_wait_us.fetch_add((long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     return rc;
 }
+static long wait_timeout_s() {
+    static const long v = []() { const char* e = std::getenv("HS_WAIT_TIMEOUT_S"); return e ? std::atol(e) : 1800l; }();
+    return v;
+}
 static int stream_wait_impl(hipStream_t s) {
     const auto t0 = std::chrono::steady_clock::now();
+    const long limit = wait_timeout_s();
     for (unsigned long looks = 1;; ++looks) {
         const hipError_t e = hipStreamQuery(s);
         if (e == hipSuccess) return HS_OK;
@@ -194,8 +210,9 @@ static int stream_wait_impl(hipStream_t s) {
         (void)hipGetLastError();      // (hipErrorNotReady is sticky otherwise)
         if (blocking_wait()) { struct timespec ts = {0, 25000}; nanosleep(&ts, nullptr); }
         else { for (int i = 0; i < 16; ++i) __builtin_ia32_pause(); }
-        if ((looks & 4095ul) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) {
-            set_error("the device did not finish the queued work within 300 s");
+        if (limit > 0 && (looks & 4095ul) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(limit)) {
+            g_device_lost.store(true);
+            set_error("the device did not finish the queued work within " + std::to_string(limit) + " s (HS_WAIT_TIMEOUT_S)");
             return HS_EHIP;
         }
     }
@@ -325,6 +342,15 @@ int require_device() {
     }
     static std::once_flag once;
     std::call_once(once, set_wait_policy);
+    return HS_OK;
+}
+
+// The HIP current device is a per-thread setting (0 on a new thread): every thread that works on a batch -- the caller's, the
+// contig-group threads of a pipeline -- binds itself to the batch's device first
+static int bind_device(int device) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur == device) return HS_OK;
+    HS_HIP(hipSetDevice(device));
     return HS_OK;
 }
 
@@ -893,6 +919,7 @@ struct hs_cv_batch {
     std::vector<int32_t> ploidy;      // hs_cv_batch_set_ploidy
     int64_t total_len = 0, total_pile = 0;
     int32_t n_tasks = 0, ev_per_task = 4096, max_depth = 0;
+    int device = 0;                   // the device that was current when the batch was created: every buffer below lives there
     DBuf contig_seq, d_contig_off, read_seq, read_off, rec_read, d_rec_contig, d_rec_pos, rec_strand, rec_cig_off, cigar,
         d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, rec_chunk_off, chunk_scratch, task_rec, task_ev0,
         sel_count, sel_gpos, sel_depth, tile_off, tile_ent, tile_rec;
@@ -922,6 +949,7 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
     if (!out || n_contigs < 0) { set_error("hs_cv_batch_create: bad arguments"); return HS_EINVAL; }
     tune_allocator();
     hs_cv_batch* b = new hs_cv_batch();
+    HS_HIP(hipGetDevice(&b->device));
     b->n_contigs = n_contigs; b->n_reads = n_reads;
     b->contig_off.assign(h_contig_off, h_contig_off + n_contigs + 1);
     b->contig_rec_off.assign(h_contig_rec_off, h_contig_rec_off + n_contigs + 1);
@@ -1940,6 +1968,7 @@ int hs_cv_batch_set_ploidy(hs_cv_batch* b, const int32_t* ploidy) {
 int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out) {
     if (int rc = require_device()) return rc;
     if (!b || !out) { set_error("hs_cv_run: null argument"); return HS_EINVAL; }
+    if (int rc = bind_device(b->device)) return rc;
     hs::CvMeta meta; fill_meta(b, meta);
     HipCvOps ops(b);
     return hs::cv_run(ops, meta, automatic_snp_threshold, n_threads, out);
@@ -1983,6 +2012,7 @@ int hs_read_graphs(const int32_t* d_sim, const int32_t* d_diff, const int64_t* c
 int hs_cv_select(hs_cv_batch* b, hs_cv_selection** out) {
     if (int rc = require_device()) return rc;
     if (!b || !out) { set_error("hs_cv_select: null argument"); return HS_EINVAL; }
+    if (int rc = bind_device(b->device)) return rc;
     hs::CvMeta meta; fill_meta(b, meta);
     HipCvOps ops(b);
     hs::CvSelection* sel = new hs::CvSelection();
@@ -2004,6 +2034,7 @@ int hs_cv_run_range(hs_cv_batch* b, const hs_cv_selection* sel, int32_t c0, int3
                     hs_cv_result** out) {
     if (int rc = require_device()) return rc;
     if (!b || !sel || !sel->impl || !out) { set_error("hs_cv_run_range: null argument"); return HS_EINVAL; }
+    if (int rc = bind_device(b->device)) return rc;
     hs::CvMeta meta; fill_meta(b, meta);
     HipCvOps ops(b);
     return hs::cv_run_range(ops, meta, *(const hs::CvSelection*)sel->impl, c0, c1, automatic_snp_threshold, n_threads, out);
@@ -2013,6 +2044,7 @@ int hs_sr_run_cv_range(const hs_cv_batch* b, int32_t c0, int32_t c1, const hs_cv
                        int32_t low_memory, int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out) {
     if (int rc = require_device()) return rc;
     if (!b || !cv || !out) { set_error("hs_sr_run_cv_range: null argument"); return HS_EINVAL; }
+    if (int rc = bind_device(b->device)) return rc;
     hs::CvMeta meta; fill_meta(b, meta);
     HipSrOps ops;
     return hs::sr_run_from_cv(ops, meta, c0, c1, cv, error_rate, rarest_strain_abundance, low_memory, amplicon, seed, n_threads, window_size, out);
@@ -2039,8 +2071,12 @@ struct hs_pipeline {
     hs_cv_selection* sel = nullptr;
     std::vector<hs_cv_result*> cv;
 
+    int device = 0;        // = batch->device: the group threads bind themselves to it (a new thread starts on device 0)
+    std::vector<int> thread_device;   // what every group thread found current after binding (hs_pipeline_thread_devices)
     void worker(int g) {
         uint64_t seen = 0;
+        const bool bound = hipSetDevice(device) == hipSuccess;
+        { int cur = -1; if (!bound || hipGetDevice(&cur) != hipSuccess) cur = -1; std::lock_guard<std::mutex> lk(mu); thread_device[(size_t)g] = cur; }
         for (;;) {
             std::function<int(int)> f;
             {
@@ -2049,7 +2085,9 @@ struct hs_pipeline {
                 if (quit) return;
                 seen = gen; f = job;
             }
-            const int rc = f(g);
+            int rc;
+            if (!bound) { set_error("a contig-group thread could not bind to the device of its batch"); rc = HS_EHIP; }
+            else rc = f(g);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 rcs[(size_t)g] = rc;
@@ -2085,9 +2123,21 @@ int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out) {
     const int G = std::max(1, std::min<int>(n_groups, std::max(C, 1)));
     for (int g = 0; g < G; ++g) p->ranges.push_back(std::make_pair((int)((int64_t)C * g / G), (int)((int64_t)C * (g + 1) / G)));
     p->rcs.assign((size_t)G, 0); p->errs.assign((size_t)G, std::string()); p->cv.assign((size_t)G, nullptr);
+    p->device = b->device; p->thread_device.assign((size_t)G, -1);
     for (int g = 0; g < G; ++g) p->threads.emplace_back([p, g] { p->worker(g); });
     *out = p;
     return HS_OK;
+}
+
+int hs_cv_batch_device(const hs_cv_batch* b) { return b ? b->device : -1; }
+// the device every contig-group thread is bound to (-1: not bound yet / failed); returns the number of groups
+int hs_pipeline_thread_devices(hs_pipeline* p, int32_t* out, int32_t cap) {
+    if (!p) return 0;
+    // the threads bind themselves when they start: an empty job makes sure every one of them has got that far
+    (void)p->run([](int) { return HS_OK; });
+    std::lock_guard<std::mutex> lk(p->mu);
+    for (size_t g = 0; g < p->thread_device.size() && (int32_t)g < cap; ++g) out[g] = p->thread_device[g];
+    return (int)p->thread_device.size();
 }
 
 void hs_pipeline_destroy(hs_pipeline* p) {
@@ -2158,6 +2208,7 @@ static bool select_per_group() { static const bool whole = std::getenv("HS_SELEC
 
 int hs_pipeline_select(hs_pipeline* p, float* mean_distance, hs_pipeline_stats* st) {
     if (!p || !mean_distance) { set_error("hs_pipeline_select: null argument"); return HS_EINVAL; }
+    if (int rc = bind_device(p->batch->device)) return rc;
     p->drop_cv();
     if (select_per_group()) {
         if (int rc = require_device()) return rc;
@@ -2189,6 +2240,7 @@ int hs_pipeline_select(hs_pipeline* p, float* mean_distance, hs_pipeline_stats* 
 int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_rate, float rarest_strain_abundance, int32_t low_memory,
                     int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out, hs_pipeline_stats* st) {
     if (!p || !out || !p->sel) { set_error("hs_pipeline_run: run hs_pipeline_select first"); return HS_EINVAL; }
+    if (int rc = bind_device(p->batch->device)) return rc;
     const int G = (int)p->ranges.size();
     // n_threads <= 0: three workers per usable core over all groups -- a group is on the host for part of its chain only (the
     // rest it waits for the device), so that many threads keep the cores busy without queueing behind each other (500-contig

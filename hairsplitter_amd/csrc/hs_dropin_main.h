@@ -1,0 +1,78 @@
+/* hs_dropin_main.h -- how the two drop-in executables start and end (shared by HS_call_variants.c and HS_separate_reads.c).
+ *
+ * Destroying the parsed inputs and results, the HIP runtime, and -- on the kernel side, after _exit -- a 4 GB address space with
+ * pinned staging buffers and the device state takes 0.4-0.6 s on the 500-contig job: a quarter of the stage. None of it is of
+ * interest to the caller, who waits for the exit status (hairsplitter.py:670-679). So: (1) nothing is destroyed in user space
+ * (hs_main_process_exits), (2) the work runs in a child forked BEFORE anything touches the GPU; when its output files are
+ * complete it reports its status through a pipe and the parent exits with it at once, while the child's teardown finishes in
+ * the background. A child that dies without reporting is waited for and its status passed on.
+ *   - Until it has reported, the child dies with its parent (PR_SET_PDEATHSIG) and the parent passes SIGTERM / SIGINT / SIGHUP /
+ *     SIGQUIT on to it: a caller that kills the process it started (a timeout) leaves nothing behind that still holds the GPU
+ *     or writes the output files. After the report only the teardown is left and the tie is cut.
+ *   - HS_NO_DETACH=1 runs everything in the process that was started. The same happens by itself when a tool is preloaded into
+ *     the process (LD_PRELOAD, ROCP_TOOL_LIBRARIES, HSA_TOOLS_LIB: rocprofv3 and friends initialise the GPU before main(), and
+ *     a fork after that is not safe): profile the drop-ins as they are, no switch needed. */
+#ifndef HS_DROPIN_MAIN_H
+#define HS_DROPIN_MAIN_H
+#include <signal.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+#include <unistd.h>
+#include <sys/prctl.h>
+#include <sys/types.h>
+#include <sys/wait.h>
+#include "../../include/hairsplitter_hip.h"
+
+static double hs_dropin_now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static int (*hs_dropin_stage)(int, char**);
+static int hs_dropin_run(int argc, char** argv) {
+    const double t0 = hs_dropin_now_ms();
+    hs_main_process_exits(1);
+    const int rc = hs_dropin_stage(argc, argv);
+    fflush(NULL);
+    if (getenv("HS_TIMING")) fprintf(stderr, "[hs timing] main: entry to exit %.1f ms\n", hs_dropin_now_ms() - t0);
+    return rc;
+}
+static volatile pid_t hs_dropin_child = 0;
+static void hs_dropin_forward(int sig) { if (hs_dropin_child > 0) kill(hs_dropin_child, sig); }
+static int hs_dropin_tool_preloaded(void) {
+    const char* names[] = {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD"};
+    for (unsigned i = 0; i < sizeof names / sizeof names[0]; ++i) { const char* v = getenv(names[i]); if (v && v[0]) return 1; }
+    return 0;
+}
+static int hs_dropin_main(int (*stage)(int, char**), int argc, char** argv) {
+    int pfd[2];
+    hs_dropin_stage = stage;
+    if (getenv("HS_NO_DETACH") || hs_dropin_tool_preloaded() || pipe(pfd) != 0) _exit(hs_dropin_run(argc, argv));
+    const pid_t parent = getpid();
+    const pid_t pid = fork();
+    if (pid < 0) _exit(hs_dropin_run(argc, argv));
+    if (pid == 0) {
+        close(pfd[0]);
+        prctl(PR_SET_PDEATHSIG, SIGKILL);
+        if (getppid() != parent) _exit(1);      /* the parent went away between fork and prctl */
+        const int rc = hs_dropin_run(argc, argv);
+        prctl(PR_SET_PDEATHSIG, 0);             /* the outputs are complete: the parent is about to leave, the teardown goes on */
+        if (write(pfd[1], &rc, sizeof rc) != (ssize_t)sizeof rc) _exit(rc ? rc : 1);
+        close(pfd[1]);
+        close(0); close(1); close(2);           /* whoever reads this program's output sees its end now */
+        _exit(rc);
+    }
+    close(pfd[1]);
+    hs_dropin_child = pid;
+    {
+        struct sigaction sa;
+        sa.sa_handler = hs_dropin_forward; sigemptyset(&sa.sa_mask); sa.sa_flags = SA_RESTART;
+        sigaction(SIGTERM, &sa, NULL); sigaction(SIGINT, &sa, NULL); sigaction(SIGHUP, &sa, NULL); sigaction(SIGQUIT, &sa, NULL);
+    }
+    int rc = 1;
+    if (read(pfd[0], &rc, sizeof rc) == (ssize_t)sizeof rc) _exit(rc);
+    int st = 0;
+    if (waitpid(pid, &st, 0) == pid) {
+        if (WIFEXITED(st)) _exit(WEXITSTATUS(st));
+        if (WIFSIGNALED(st)) { signal(WTERMSIG(st), SIG_DFL); kill(getpid(), WTERMSIG(st)); }      /* end the way the child ended */
+    }
+    _exit(1);
+}
+#endif

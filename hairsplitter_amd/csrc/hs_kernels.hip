@@ -1167,8 +1167,9 @@ __global__ __launch_bounds__(64) void k_myers(
     }
     const int nblocks = (qn + 63) >> 6;
     const int last_row = (qn - 1) & 63;
-    int score = qn, best = qn, best_j = -1;   // D[qn][0] = qn; column -1 == "before the target"
-    if (mode != 0) { best = qn; best_j = -1; }
+    // D[qn][0] = qn; column -1 == "before the target": it takes part (and wins ties) only when the reference's edlib pads the
+    // query (qn not a multiple of 64, edlib.cpp:664-690: the score of column c is read off column c + padding)
+    int score = qn, best = (qn & 63) == 0 ? qn + 1 : qn, best_j = -1;
     for (int pb = 0; pb < nblocks; pb += 64) {
         const int blk = pb + lane;
         const bool bvalid = blk < nblocks;

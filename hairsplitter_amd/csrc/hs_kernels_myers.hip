@@ -31,7 +31,11 @@ static __device__ void myers_sweep(const MyersSeq& q, const MyersSeq& t, int mod
     const int qn = q.n, tn = t.n;
     const int nblocks = (qn + 63) >> 6;
     const int last_row = (qn - 1) & 63;
-    int score = qn, best = qn, best_first = -1, best_last = -1;
+    // The reference's edlib pads the query to a multiple of 64 rows and reads the score of column c off column c + W (W = padding
+    // rows, edlib.cpp:664-690): with W > 0 the columns "before the target" (score = query length) take part and win ties, which is
+    // what best = qn, first = -1 reproduces; with W == 0 there are none, and the first real column that reaches the best score --
+    // query length included -- is the answer (64 x 'A' in 'CCC...': end location 0, path 1X63I).
+    int score = qn, best = (qn & 63) == 0 ? qn + 1 : qn, best_first = -1, best_last = -1;
     for (int pb = 0; pb < nblocks; pb += 64) {
         const int blk = pb + lane;
         const bool bvalid = blk < nblocks;

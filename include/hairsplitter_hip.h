@@ -299,6 +299,9 @@ void hs_cv_batch_destroy(hs_cv_batch* b);
  * hs_pipeline_run) apply it. ploidy == NULL clears it. */
 int hs_cv_batch_set_ploidy(hs_cv_batch* b, const int32_t* ploidy /* [n_contigs] or NULL */);
 int64_t hs_cv_batch_aligned_bp(const hs_cv_batch* b);   /* number of pileup entries (the metric's unit) */
+/* The device the batch lives on (the one that was current on the creating thread). Every entry point that takes a batch binds
+ * the calling thread -- and every thread the library starts for it -- to that device first. */
+int hs_cv_batch_device(const hs_cv_batch* b);
 
 /* Per-contig result of stage 3 == what output_files (call_variants.cpp:1174-1213) prints. */
 typedef struct hs_cv_result {
@@ -434,6 +437,9 @@ int hs_pipeline_select(hs_pipeline* p, float* mean_distance /* [C] out */, hs_pi
 int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_rate, float rarest_strain_abundance, int32_t low_memory,
                     int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out,
                     hs_pipeline_stats* stats);
+/* the HIP device each contig-group thread of the pipeline is bound to (== hs_cv_batch_device of its batch); returns the number
+ * of groups, fills at most cap entries */
+int hs_pipeline_thread_devices(hs_pipeline* p, int32_t* out, int32_t cap);
 void hs_pipeline_destroy(hs_pipeline* p);
 
 int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_t amplicon);

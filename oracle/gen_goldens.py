@@ -273,6 +273,29 @@ def gen_lib_vectors():
     # the .gro goldens. The libstdc++ permutations below come from the oracle binary (system library, not reference code).
 
 
+def gen_edlib_edge_vectors():
+    """Distance + first end location where no column of the target beats the all-insertions score, for queries with and without
+    padding rows in edlib's last block (multiples of 64 behave differently): tests/golden/edlib_edge_vectors.json"""
+    rnd = random.Random(41)
+    rs = lambda n, al="ACGT": "".join(rnd.choice(al) for _ in range(n))
+    pairs = [("A" * 64, "C" * 100), ("A" * 128, "C" * 10), ("A" * 65, "C" * 100), ("AC" * 32, "G"), ("ACGT" * 16, "ACGT" * 16 + "T"), ("A" * 64, "A" * 10),
+             ("A" * 63, "C" * 9), ("A" * 192, "CGT" * 50), ("A" * 256, "C"), ("AAAA", "CCCC"), ("A" * 64, "C" * 63 + "A")]
+    for qn in (64, 128, 192, 63, 65, 127):
+        for _ in range(4):
+            pairs.append((rs(qn, "AC"), rs(rnd.randint(1, 150), "GT")))      # disjoint alphabets: nothing matches
+            pairs.append((rs(qn), rs(rnd.randint(1, 40))))                   # target much shorter than the query
+    lines = ["%s -1 %s %s" % (m, q, t) for q, t in pairs for m in ("NW", "SHW", "HW")]
+    res = subprocess.run([os.path.join(REF, "edlib_driver")], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.splitlines()
+    vec = []
+    for l, r in zip(lines, res):
+        mode, k, q, t = l.split()
+        d, nloc, sloc, eloc = map(int, r.split())
+        vec.append({"mode": mode, "query": q, "target": t, "distance": d, "end": eloc})
+    with open(os.path.join(GOLD, "edlib_edge_vectors.json"), "w") as f:
+        json.dump(vec, f)
+    print("edlib edge vectors:", len(vec))
+
+
 def gen_edlib_path_vectors():
     """HW + PATH vectors from the reference's bundled edlib at the shapes of its stage-5 call sites (create_new_contigs.cpp:558-629,
     tools.cpp:515-534: a 200-300 bp query inside a target of a few hundred to a few thousand bases) plus edge cases: written to
@@ -320,6 +343,9 @@ def gen_edlib_path_vectors():
         else:
             t = mutate(q, 0.4) or "A"
         pairs.append((q, t))
+    # no column beats the all-insertions score: with a query of k * 64 bases (no padding rows in edlib's last block) the first
+    # column is the end location, otherwise the location "before the target" (-1)
+    pairs += [("A" * 64, "C" * 100), ("A" * 128, "C" * 10), ("A" * 65, "C" * 100), ("A" * 63, "C" * 7), ("AC" * 32, "G"), ("A" * 192, "CCGT" * 90)]
     pairs += [("CCTT", "AAGG"), ("A", "C"), ("ACGT", "ACGT"), ("AAAA", "AAAAAAAAAAAA"), ("ACGTACGT", "TTTTACGTACGTTTTT"), ("G", "G"), ("-", "ACGT"), ("ACGT", "-")]
     lines = ["HWPATH -1 %s %s" % (q, t) for q, t in pairs]
     res = subprocess.run([os.path.join(REF, "edlib_driver")], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.splitlines()
@@ -391,12 +417,15 @@ def main():
     ap.add_argument("--check-oracle", action="store_true", help="also run oracle/_build/hs_oracle and report parity")
     ap.add_argument("--only", default=None)
     ap.add_argument("--edlib-path", action="store_true", help="only tests/golden/edlib_path_vectors.json")
+    ap.add_argument("--edlib-edge", action="store_true", help="only tests/golden/edlib_edge_vectors.json")
     ap.add_argument("--c5u", action="store_true", help="only the uncut 10 Mb variant of C5: outputs into tests/golden_big/c5u (12 minutes of the reference)")
     args = ap.parse_args()
     if args.c5u:
         return gen_c5u()
     if args.edlib_path:
         return gen_edlib_path_vectors()
+    if args.edlib_edge:
+        return gen_edlib_edge_vectors()
     os.makedirs(GOLD, exist_ok=True)
     if not args.only:
         gen_lib_vectors()

@@ -663,7 +663,11 @@ int edit_distance(const unsigned char* q, int qn, const unsigned char* t, int tn
         std::swap(prev, cur);
     }
     if (mode == 0) { if (end_loc) *end_loc = tn - 1; return prev[tn]; }
+    // The reference's edlib pads the query to a multiple of 64 rows and reads the score of column c off column c + W (W = padding
+    // rows, edlib.cpp:664-690): with W > 0 the columns "before the target" (score = query length) take part and win ties; with
+    // W == 0 (and a non-empty query) there are none and the first real column that reaches the minimum is reported.
     int best = prev[0], bj = 0;
+    if (qn > 0 && qn % 64 == 0 && tn > 0) { best = prev[1]; bj = 1; }
     for (int j = 1; j <= tn; j++) if (prev[j] < best) { best = prev[j]; bj = j; }
     if (end_loc) *end_loc = bj - 1;   // first (leftmost) end location, 0-based inclusive, as edlib reports endLocations[0]
     return best;

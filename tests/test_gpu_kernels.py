@@ -460,7 +460,7 @@ def test_chinese_whispers_matches_oracle(built):
 def test_myers_matches_edlib_vectors_and_oracle(built):
     """A1 == edlibAlign distance / first end location (golden vectors from the reference's bundled edlib)."""
     from hairsplitter_amd import api
-    vec = json.load(open(os.path.join(gu.GOLD, "edlib_vectors.json")))
+    vec = json.load(open(os.path.join(gu.GOLD, "edlib_vectors.json"))) + json.load(open(os.path.join(gu.GOLD, "edlib_edge_vectors.json")))
     code = {"A": 0, "C": 1, "G": 2, "T": 3}
     for mode in ("NW", "HW", "SHW"):
         vs = [v for v in vec if v["mode"] == mode]
