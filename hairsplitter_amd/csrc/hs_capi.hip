@@ -27,6 +27,7 @@
 #include "hs_kernels_cw.hip"
 #include "hs_kernels_myers.hip"
 #include "hs_kernels_parts.hip"
+#include "hs_kernels_cols.hip"
 
 namespace hs {
 static thread_local std::string g_err;
@@ -624,7 +625,8 @@ int hs_tile_plan(const int64_t* h_contig_off, int32_t n_contigs, const int32_t* 
 static int column_stats_tiled_launch(const uint8_t* d_pile, const int64_t* d_tile_off, const hs_tile_entry* d_tile_ent, int64_t total_len,
                                      hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth,
                                      int32_t sel_cap, int32_t max_depth, SelectionScratch* sc, hipEvent_t after_main, hipStream_t stream,
-                                     hipEvent_t after_main2 = nullptr, int64_t tile0 = 0, int64_t tile1 = -1 /* tiles [tile0, tile1) only */) {
+                                     hipEvent_t after_main2 = nullptr, int64_t tile0 = 0, int64_t tile1 = -1 /* tiles [tile0, tile1) only */,
+                                     int64_t g_lo = 0, int64_t g_hi = 0x7fffffffffffffffll, int32_t* d_tile_ent_sum = nullptr, bool compact = true) {
     static_assert(sizeof(hs_tile_entry) == sizeof(int4), "hs_tile_entry is read as one 16-byte load");
     if (total_len <= 0) {   // nothing to count: an empty selection
         if (d_sel_count) HS_HIP(hipMemsetAsync(d_sel_count, 0, sizeof(int32_t), stream));
@@ -635,16 +637,18 @@ static int column_stats_tiled_launch(const uint8_t* d_pile, const int64_t* d_til
     const int64_t grid = tile1 >= 0 ? tile1 - tile0 : (total_len + 255) / 256;
     const bool full = d_stats != nullptr;
     const bool narrow = max_depth > 0 && max_depth <= 255;
-    using KernelT = void (*)(const uint8_t*, const int64_t*, const int4*, int64_t, hsdev::hs_colstat_dev*, int, int32_t*, int64_t*, int32_t*, int, int64_t);
+    using KernelT = void (*)(const uint8_t*, const int64_t*, const int4*, int64_t, hsdev::hs_colstat_dev*, int, int32_t*, int64_t*, int32_t*, int, int64_t,
+                             int64_t, int64_t, int32_t*);
     KernelT kernel = narrow ? (full ? (KernelT)hsdev::k_column_stats_tiled<1, true> : (KernelT)hsdev::k_column_stats_tiled<1, false>)
                             : (full ? (KernelT)hsdev::k_column_stats_tiled<2, true> : (KernelT)hsdev::k_column_stats_tiled<2, false>);
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), 0, stream, d_pile, d_tile_off, reinterpret_cast<const int4*>(d_tile_ent),
                        total_len, reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second, d_sel_count ? sc->tile_cnt.as<int32_t>() : nullptr,
-                       d_sel_count ? sc->gpos.as<int64_t>() : nullptr, d_sel_count ? sc->depth.as<int32_t>() : nullptr, sel_cap, tile0);
+                       d_sel_count ? sc->gpos.as<int64_t>() : nullptr, d_sel_count ? sc->depth.as<int32_t>() : nullptr, sel_cap, tile0, g_lo, g_hi,
+                       d_tile_ent_sum);
     HS_HIP(hipGetLastError());
     if (after_main) HS_HIP(hipEventRecord(after_main, stream));
     if (after_main2) HS_HIP(hipEventRecord(after_main2, stream));
-    if (d_sel_count) return sc->finish(d_sel_count, d_sel_gpos, d_sel_depth, sel_cap, stream);
+    if (d_sel_count && compact) return sc->finish(d_sel_count, d_sel_gpos, d_sel_depth, sel_cap, stream);
     return HS_OK;
 }
 
@@ -922,9 +926,11 @@ struct hs_cv_batch {
     int device = 0;                   // the device that was current when the batch was created: every buffer below lives there
     DBuf contig_seq, d_contig_off, read_seq, read_off, rec_read, d_rec_contig, d_rec_pos, rec_strand, rec_cig_off, cigar,
         d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, rec_chunk_off, chunk_scratch, task_rec, task_ev0,
-        sel_count, sel_gpos, sel_depth, tile_off, tile_ent, tile_rec;
-    SelectionScratch sel_scratch;
-    HBuf h_stage_a, h_stage_b, h_stage_c;   // pinned staging of the selection pass
+        tile_off, tile_ent, tile_lrec;
+    HBuf h_stage_a;   // pinned staging of the per-record counters
+    // the pileup is padded by 256 bytes on both sides: k_gather_tiles loads the 256 bytes a record lays over a tile whole, also
+    // where the record covers part of the tile only
+    uint8_t* pile_ptr() const { return pile.as<uint8_t>() + 256; }
 };
 
 // The stage drivers allocate and free multi-megabyte arrays on many threads every call; with glibc's defaults those go
@@ -1029,7 +1035,8 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
         build_tile_plan(b->contig_off.data(), n_contigs, b->contig_rec_off.data(), b->rec_pos.data(), b->rec_qend.data(), b->pile_off.data(), to, en, rc_);
         up(b->tile_off, to.data(), sizeof(int64_t) * to.size());
         up(b->tile_ent, en.data(), sizeof(hs_tile_entry) * en.size());
-        up(b->tile_rec, rc_.data(), sizeof(int32_t) * rc_.size());
+        for (size_t k = 0; k < rc_.size(); ++k) rc_[k] -= b->contig_rec_off[(size_t)b->rec_contig[(size_t)rc_[k]]];      // the read's index on its contig: what a column lists
+        up(b->tile_lrec, rc_.data(), sizeof(int32_t) * rc_.size());
     }
     up(b->d_contig_rec_off, b->contig_rec_off.data(), sizeof(int32_t) * b->contig_rec_off.size());
     up(b->d_rec_qend, b->rec_qend.data(), sizeof(int32_t) * (size_t)n_rec);
@@ -1045,10 +1052,7 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
         }
         std::free(tr); std::free(te);
     }
-    if (!rc) rc = b->sel_count.alloc(sizeof(int32_t));
-    if (!rc) rc = b->sel_gpos.alloc(sizeof(int64_t) * (size_t)b->total_len);
-    if (!rc) rc = b->sel_depth.alloc(sizeof(int32_t) * (size_t)b->total_len);
-    if (!rc) rc = b->pile.alloc((size_t)b->total_pile);
+    if (!rc) rc = b->pile.alloc((size_t)b->total_pile + 512);
     if (!rc) rc = b->rec_stats.alloc(sizeof(int32_t) * 4 * (size_t)n_rec);
     if (rc) { delete b; return rc; }
     *out = b;
@@ -1065,99 +1069,19 @@ void hs_sr_result_destroy(hs_sr_result* r) { hs::free_sr_result(r); }
 
 namespace {
 
-// HIP implementation of the stage-3 device interface (the only one the product has)
+// HIP implementation of the stage-3 device interface (the only one the product has). The columns of a contig range live in
+// this object from extract_candidates() to finish_columns(); the SNP columns it leaves (snp_*) are what stage 4 reads.
 struct HipCvOps : hs::CvDeviceOps {
     hs_cv_batch* b;
     hipStream_t stream = nullptr;
     explicit HipCvOps(hs_cv_batch* batch) : b(batch) {}
     KernelClock kc;
 
-    // ---- the streaming pass in two parts (contig groups): K0 + K1 over the whole batch, K2 + selection per range of contigs ----
-    bool has_select_range() const override { return true; }
+    // ---- K0 + K1 over the whole batch ----
     int pileup(std::vector<int32_t>& rec_stats, float k_ms[4]) override {
         EventPair e0, e1;
         if (int rc = e0.init()) return rc;
         if (int rc = e1.init()) return rc;
-        HS_HIP(hipEventRecord(e0.a, stream));
-        if (int rc = kc.begin(HS_K_CIGAR_SCAN, stream)) return rc;
-        if (int rc = cigar_scan_launch(b->d_contig_off.as<int64_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(),
-                                       b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->rec_chunk_off.as<int64_t>(), b->n_rec,
-                                       b->chunk_scratch.as<int32_t>(), b->rec_stats.as<int32_t>(), stream)) return rc;
-        if (int rc = kc.end((int64_t)b->cigar.bytes + (int64_t)b->chunk_scratch.bytes + 16 * (int64_t)b->n_rec, stream)) return rc;
-        HS_HIP(hipEventRecord(e0.b, stream));
-        HS_HIP(hipEventRecord(e1.a, stream));
-        if (int rc = kc.begin(HS_K_PILEUP, stream)) return rc;
-        if (int rc = pileup_launch(b->contig_seq.as<uint8_t>(), b->d_contig_off.as<int64_t>(), b->read_seq.as<uint8_t>(), b->read_off.as<int64_t>(),
-                                   b->rec_read.as<int32_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(), b->rec_strand.as<uint8_t>(),
-                                   b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->d_pile_off.as<int64_t>(),
-                                   b->rec_chunk_off.as<int64_t>(), b->chunk_scratch.as<int32_t>(), b->task_rec.as<int32_t>(), b->task_ev0.as<int32_t>(),
-                                   b->n_tasks, b->ev_per_task, b->pile.as<uint8_t>(), b->rec_stats.as<int32_t>(), b->n_rec, stream)) return rc;
-        if (int rc = kc.end(2 * b->total_pile, stream)) return rc;
-        HS_HIP(hipEventRecord(e1.b, stream));
-        auto grow = [](HBuf& h, size_t need) -> int { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); };
-        if (!rec_stats.empty()) {
-            if (int rc = grow(b->h_stage_a, rec_stats.size() * sizeof(int32_t))) return rc;
-            HS_HIP(hipMemcpyAsync(b->h_stage_a.p, b->rec_stats.p, rec_stats.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        }
-        if (int rc = stream_wait(stream)) return rc;
-        if (!rec_stats.empty()) std::memcpy(rec_stats.data(), b->h_stage_a.p, rec_stats.size() * sizeof(int32_t));
-        if (int rc = e1.ms(&k_ms[0])) return rc;
-        if (int rc = e0.ms(&k_ms[3])) return rc;
-        kc.flush();
-        return HS_OK;
-    }
-    SelectionScratch range_scratch;
-    DBuf d_rsel_count, d_rsel_gpos, d_rsel_depth;
-    HBuf h_rsel, h_rsel_n;
-    // K2 over the tiles that hold the global positions [g0, g1) (the pileup must be complete); the list comes back sorted and may
-    // hold positions of the neighbouring ranges from the two boundary tiles
-    int select_range(int64_t g0, int64_t g1, int min_second, const int64_t** sel_gpos, const int32_t** sel_depth, size_t* n_sel_out, float* k_ms) override {
-        *sel_gpos = nullptr; *sel_depth = nullptr; *n_sel_out = 0;
-        if (k_ms) *k_ms = 0;
-        if (g1 <= g0) return HS_OK;
-        const int64_t t0 = g0 >> 8, t1 = (g1 + 255) >> 8;
-        const int64_t cap = (t1 - t0) * 256;
-        DeviceTurn turn;
-        if (int rc = range_scratch.prepare(cap)) return rc;
-        if (int rc = d_rsel_count.alloc(8)) return rc;
-        if (int rc = d_rsel_gpos.alloc((size_t)cap * 8)) return rc;
-        if (int rc = d_rsel_depth.alloc((size_t)cap * 4)) return rc;
-        EventPair e; if (int rc = e.init()) return rc;
-        HS_HIP(hipEventRecord(e.a, stream));
-        if (int rc = kc.begin(HS_K_COLUMN_STATS, stream)) return rc;
-        hipEvent_t k2_done = nullptr;
-        int64_t range_pile = b->total_len > 0 ? (int64_t)((double)b->total_pile * (double)(g1 - g0) / (double)b->total_len) : 0;      // one code in per aligned bp of the range (its share of the batch)
-        if (int rc = kc.end_prepare(range_pile, &k2_done)) return rc;
-        if (int rc = column_stats_tiled_launch(b->pile.as<uint8_t>(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->total_len,
-                                               nullptr, min_second, d_rsel_count.as<int32_t>(), d_rsel_gpos.as<int64_t>(), d_rsel_depth.as<int32_t>(),
-                                               (int32_t)std::min<int64_t>(cap, 0x7fffffff), b->max_depth, &range_scratch, e.b, stream, k2_done, t0, t1)) return rc;
-        auto grow = [](HBuf& h, size_t need) -> int { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); };
-        if (int rc = grow(h_rsel_n, 64)) return rc;
-        if (int rc = copy_d2h(h_rsel_n.p, d_rsel_count.p, sizeof(int32_t), stream)) return rc;
-        const int32_t n_sel = *(int32_t*)h_rsel_n.p;
-        if (int rc = grow(h_rsel, std::max<size_t>((size_t)n_sel, 1) * 12)) return rc;
-        char* hg = (char*)h_rsel.p; char* hd = hg + (size_t)n_sel * 8;
-        if (n_sel) {
-            HS_HIP(hipMemcpyAsync(hg, d_rsel_gpos.p, (size_t)n_sel * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-            HS_HIP(hipMemcpyAsync(hd, d_rsel_depth.p, (size_t)n_sel * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-            if (int rc = stream_wait(stream)) return rc;
-        }
-        *sel_gpos = (const int64_t*)hg; *sel_depth = (const int32_t*)hd; *n_sel_out = (size_t)n_sel;
-        kc.flush();
-        return e.ms(k_ms);
-    }
-
-    int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, const int64_t** sel_gpos, const int32_t** sel_depth, size_t* n_sel_out,
-                          float k_ms[4]) override {
-        const bool tim = std::getenv("HS_TIMING") != nullptr;
-        auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        const double t0 = now();
-        EventPair e1, e2;
-        if (int rc = e1.init()) return rc;
-        if (int rc = e2.init()) return rc;
-        HS_HIP(hipMemsetAsync(b->sel_count.p, 0, sizeof(int32_t), stream));
-        EventPair e0;
-        if (int rc = e0.init()) return rc;
         HS_HIP(hipEventRecord(e0.a, stream));
         if (int rc = kc.begin(HS_K_CIGAR_SCAN, stream)) return rc;
         if (int rc = cigar_scan_launch(b->d_contig_off.as<int64_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(),
@@ -1171,126 +1095,243 @@ struct HipCvOps : hs::CvDeviceOps {
                                    b->rec_read.as<int32_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(), b->rec_strand.as<uint8_t>(),
                                    b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->d_pile_off.as<int64_t>(),
                                    b->rec_chunk_off.as<int64_t>(), b->chunk_scratch.as<int32_t>(), b->task_rec.as<int32_t>(), b->task_ev0.as<int32_t>(),
-                                   b->n_tasks, b->ev_per_task, b->pile.as<uint8_t>(), b->rec_stats.as<int32_t>(), b->n_rec, stream)) return rc;
+                                   b->n_tasks, b->ev_per_task, b->pile_ptr(), b->rec_stats.as<int32_t>(), b->n_rec, stream)) return rc;
         if (int rc = kc.end(2 * b->total_pile, stream)) return rc;      // one read base in + one code out per aligned bp
         HS_HIP(hipEventRecord(e1.b, stream));
-        HS_HIP(hipEventRecord(e2.a, stream));
-        if (int rc = kc.begin(HS_K_COLUMN_STATS, stream)) return rc;
-        hipEvent_t k2_done = nullptr;
-        if (int rc = kc.end_prepare(b->total_pile, &k2_done)) return rc;   // one code in per aligned bp; recorded right after the histogram kernel
-        if (b->sel_scratch.n_tiles == 0 && b->total_len > 0) { if (int rc = b->sel_scratch.prepare(b->total_len)) return rc; }
-        if (int rc = column_stats_tiled_launch(b->pile.as<uint8_t>(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->total_len,
-                                               nullptr, min_second, b->sel_count.as<int32_t>(), b->sel_gpos.as<int64_t>(),
-                                               b->sel_depth.as<int32_t>(), (int32_t)std::min<int64_t>(b->total_len, 0x7fffffff), b->max_depth,
-                                               &b->sel_scratch, e2.b, stream, k2_done)) return rc;
-        const double t1 = now();
-        // downloads go through pooled pinned buffers: above a few hundred KB hipMemcpy into pageable memory pins the
-        // destination on the fly, which costs tens of milliseconds
-        // staging buffers owned by the batch (grown, never returned): a pool miss here means hipHostMalloc while the kernels
-        // of this very step are queued, which stalls the queue for tens of milliseconds
         auto grow = [](HBuf& h, size_t need) -> int { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); };
-        // the per-record counters and the length of the selection in one wait; the counters are unpacked while the selection
-        // itself is on its way
         if (!rec_stats.empty()) {
             if (int rc = grow(b->h_stage_a, rec_stats.size() * sizeof(int32_t))) return rc;
             HS_HIP(hipMemcpyAsync(b->h_stage_a.p, b->rec_stats.p, rec_stats.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         }
-        int32_t n_sel = 0;
-        if (int rc = grow(b->h_stage_c, 64)) return rc;
-        if (int rc = copy_d2h(b->h_stage_c.p, b->sel_count.p, sizeof(int32_t), stream)) return rc;
-        const double t2 = now();
-        n_sel = *(int32_t*)b->h_stage_c.p;
-        if (int rc = grow(b->h_stage_b, std::max<size_t>((size_t)n_sel, 1) * 12)) return rc;
-        char* hg = (char*)b->h_stage_b.p; char* hd = hg + (size_t)n_sel * 8;
-        if (n_sel) {
-            HS_HIP(hipMemcpyAsync(hg, b->sel_gpos.p, (size_t)n_sel * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-            HS_HIP(hipMemcpyAsync(hd, b->sel_depth.p, (size_t)n_sel * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        }
+        if (int rc = stream_wait(stream)) return rc;
         if (!rec_stats.empty()) std::memcpy(rec_stats.data(), b->h_stage_a.p, rec_stats.size() * sizeof(int32_t));
-        if (n_sel) { if (int rc = stream_wait(stream)) return rc; }
-        *sel_gpos = (const int64_t*)hg; *sel_depth = (const int32_t*)hd; *n_sel_out = (size_t)n_sel;   // read in place by the caller
-        const double t3 = now();
         if (int rc = e1.ms(&k_ms[0])) return rc;
-        if (int rc = e2.ms(&k_ms[1])) return rc;
         if (int rc = e0.ms(&k_ms[3])) return rc;
         kc.flush();
-        if (tim) std::fprintf(stderr, "[hs timing]   pileup_and_select: launches %.2f ms, first D2H (waits for kernels) %.2f ms, selection D2H %.2f ms (%d positions), events %.2f ms\n",
-                              t1 - t0, t2 - t1, t3 - t2, n_sel, now() - t3);
         return HS_OK;
     }
 
-    DBuf d_co, d_ci, d_cc;     // the extracted columns stay on the device for K4
-    UploadPack gather_pack;
-    int n_gathered = 0;
+    // ---- the columns of the current contig range ----
+    int range_c0 = 0, range_c1 = 0;
+    int64_t n_cols = 0, n_entries = 0;            // extracted columns / their entries
+    SelectionScratch range_scratch;               // K2's per-tile slots
+    DBuf d_tile_ent_sum, d_tile_ebase, d_scan2;
+    DBuf d_header, d_col_gpos, d_col_rec, d_co, d_col_len, d_ci, d_cc;      // d_co / d_ci / d_cc: the CSR of the columns (also read by k_robust_partitions)
+    DBuf d_col_ctg, d_k0, d_k1, d_c1, d_cand, d_ctg_col_off, d_ctg_n, d_min_reads, d_blk_cnt, d_blk_ent, d_tie;
+    DBuf d_pk_rec, d_pk_col, d_pk_off, d_pk_idx, d_pk_code;                 // packed candidates, then packed SNPs
+    HBuf h_header, h_pk_rec, h_pk_col, h_pk_off, h_pk_idx, h_pk_code, h_ctg_n;
+    UploadPack range_pack;
+    int n_gathered = 0;                           // (k_robust_partitions checks its column indices against it)
     int64_t gathered_entries = 0;
-    int column_partition_test(const hs::CvPartitionTest& t, std::vector<uint8_t>& keep, float* k_ms) override {
-        const int n = (int)t.col_contig.size();
-        if (n != n_gathered) { set_error("column_partition_test: column count differs from the last gather"); return HS_EINVAL; }
-        DBuf d_ctg, d_k0, d_k1, d_c1, d_cand, d_po, d_pso, d_ps, d_keep;
+    static int grow(HBuf& h, size_t need) { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); }
+    static int grow(DBuf& d, size_t need) { if (d.cap >= need && d.p && !d.view) { d.bytes = need; return HS_OK; } return d.alloc(need + need / 4); }
+
+    // header of the range from the device (one 64-byte download + wait)
+    int fetch_header(hsdev::ColumnsHeader& h) {
+        if (int rc = grow(h_header, sizeof(hsdev::ColumnsHeader))) return rc;
+        if (int rc = copy_d2h(h_header.p, d_header.p, sizeof(hsdev::ColumnsHeader), stream)) return rc;
+        std::memcpy(&h, h_header.p, sizeof h);
+        return HS_OK;
+    }
+    // the columns carrying `flag` packed on the device (d_pk_*) and, with their entries if asked for, on the host (h_pk_*)
+    int pack_flagged(int flag, bool want_entries, int64_t* n_out, int64_t* e_out) {
+        const int n_blocks = (int)((n_cols + HS_FP_BLOCK - 1) / HS_FP_BLOCK);
+        *n_out = 0; *e_out = 0;
+        if (n_blocks == 0) return HS_OK;
+        if (int rc = grow(d_blk_cnt, (size_t)n_blocks * 8)) return rc;
+        if (int rc = grow(d_blk_ent, (size_t)n_blocks * 8)) return rc;
+        if (int rc = kc.begin(HS_K_PACK_COLUMNS, stream)) return rc;
+        hipLaunchKernelGGL(hsdev::k_flag_block_sums, dim3((unsigned)n_blocks), dim3(256), 0, stream, d_col_rec.as<hsdev::hs_colrec_dev>(), d_col_len.as<int32_t>(),
+                           d_header.as<hsdev::ColumnsHeader>(), flag, d_blk_cnt.as<long long>(), d_blk_ent.as<long long>());
+        hipLaunchKernelGGL(hsdev::k_flag_block_offsets, dim3(1), dim3(1024), 0, stream, d_blk_cnt.as<long long>(), d_blk_ent.as<long long>(), n_blocks,
+                           d_header.as<hsdev::ColumnsHeader>());
+        HS_HIP(hipGetLastError());
+        if (int rc = kc.end(20 * n_cols, stream)) return rc;      // record + length of every column in
+        hsdev::ColumnsHeader h;
+        if (int rc = fetch_header(h)) return rc;
+        const int64_t nf = h.n_flagged, ne = h.n_flagged_entries;
+        *n_out = nf; *e_out = ne;
+        if (int rc = grow(d_pk_rec, std::max<size_t>(1, (size_t)nf) * sizeof(hs_colrec))) return rc;
+        if (int rc = grow(d_pk_col, std::max<size_t>(1, (size_t)nf) * 4)) return rc;
+        if (int rc = grow(d_pk_off, ((size_t)nf + 1) * 8)) return rc;
+        if (int rc = grow(d_pk_idx, std::max<size_t>(1, (size_t)ne) * 4)) return rc;
+        if (int rc = grow(d_pk_code, std::max<size_t>(1, (size_t)ne))) return rc;
+        if (nf == 0) { HS_HIP(hipMemsetAsync(d_pk_off.p, 0, 8, stream)); }
+        if (int rc = kc.begin(HS_K_PACK_COLUMNS, stream)) return rc;
+        hipLaunchKernelGGL(hsdev::k_pack_flagged, dim3((unsigned)n_blocks), dim3(256), 0, stream, d_col_rec.as<hsdev::hs_colrec_dev>(), d_co.as<int64_t>(),
+                           d_col_len.as<int32_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), d_header.as<hsdev::ColumnsHeader>(), flag, d_blk_cnt.as<long long>(),
+                           d_blk_ent.as<long long>(), d_pk_rec.as<hsdev::hs_colrec_dev>(), d_pk_col.as<int32_t>(), d_pk_off.as<int64_t>(), d_pk_idx.as<int32_t>(),
+                           d_pk_code.as<uint8_t>(), nf, ne);
+        HS_HIP(hipGetLastError());
+        if (int rc = kc.end(10 * ne + 60 * nf, stream)) return rc;      // the flagged columns' entries in and out, their records
+        if (int rc = grow(h_pk_rec, std::max<size_t>(1, (size_t)nf) * sizeof(hs_colrec))) return rc;
+        if (int rc = grow(h_pk_col, std::max<size_t>(1, (size_t)nf) * 4)) return rc;
+        if (int rc = grow(h_pk_off, ((size_t)nf + 1) * 8)) return rc;
+        if (nf) {
+            HS_HIP(hipMemcpyAsync(h_pk_rec.p, d_pk_rec.p, (size_t)nf * sizeof(hs_colrec), hipMemcpyDeviceToHost, stream));
+            HS_HIP(hipMemcpyAsync(h_pk_col.p, d_pk_col.p, (size_t)nf * 4, hipMemcpyDeviceToHost, stream));
+        }
+        HS_HIP(hipMemcpyAsync(h_pk_off.p, d_pk_off.p, ((size_t)nf + 1) * 8, hipMemcpyDeviceToHost, stream));
+        if (want_entries && ne) {
+            if (int rc = grow(h_pk_idx, (size_t)ne * 4)) return rc;
+            if (int rc = grow(h_pk_code, (size_t)ne)) return rc;
+            HS_HIP(hipMemcpyAsync(h_pk_idx.p, d_pk_idx.p, (size_t)ne * 4, hipMemcpyDeviceToHost, stream));
+            HS_HIP(hipMemcpyAsync(h_pk_code.p, d_pk_code.p, (size_t)ne, hipMemcpyDeviceToHost, stream));
+        }
+        return HS_OK;
+    }
+
+    int extract_candidates(int c0, int c1, const std::vector<int32_t>& min_reads, float thr, hs::CvCandidates& out, float k_ms[3]) override {
+        static_assert(sizeof(hs_colrec) == sizeof(hsdev::hs_colrec_dev), "hs_colrec layout");
+        const int C = c1 - c0;
+        range_c0 = c0; range_c1 = c1; n_cols = 0; n_entries = 0; n_gathered = 0; gathered_entries = 0;
+        out = hs::CvCandidates();
+        out.contig_n_cand.assign((size_t)C, 0);
+        k_ms[0] = k_ms[1] = k_ms[2] = 0;
+        const int64_t g0 = b->contig_off[(size_t)c0], g1 = b->contig_off[(size_t)c1];
+        if (g1 <= g0 || C <= 0) return HS_OK;
+        const int64_t t0 = g0 >> 8, t1 = (g1 + 255) >> 8, nt = t1 - t0;
+        if (nt > 0x7fffffff) { set_error("too many tiles in one contig range"); return HS_EINVAL; }
+        EventPair e_k2, e_k3, e_k3b;
+        if (int rc = e_k2.init()) return rc;
+        if (int rc = e_k3.init()) return rc;
+        if (int rc = e_k3b.init()) return rc;
+        {   // ---- K2 over the tiles of the range: per tile its selected positions (second count >= 4), their depths and the sum of those ----
+            DeviceTurn turn;
+            if (int rc = range_scratch.prepare(nt * 256)) return rc;
+            if (int rc = grow(d_tile_ent_sum, (size_t)nt * 4)) return rc;
+            if (int rc = grow(d_tile_ebase, ((size_t)nt + 1) * 8)) return rc;
+            if (int rc = grow(d_header, sizeof(hsdev::ColumnsHeader))) return rc;
+            if (int rc = grow(d_tie, 16)) return rc;
+            HS_HIP(hipMemsetAsync(d_header.p, 0, sizeof(hsdev::ColumnsHeader), stream));
+            HS_HIP(hipMemsetAsync(d_tie.p, 0, 16, stream));
+            HS_HIP(hipEventRecord(e_k2.a, stream));
+            if (int rc = kc.begin(HS_K_COLUMN_STATS, stream)) return rc;
+            hipEvent_t k2_done = nullptr;
+            const int64_t range_pile = b->total_len > 0 ? (int64_t)((double)b->total_pile * (double)(g1 - g0) / (double)b->total_len) : 0;      // one code in per aligned bp of the range (its share of the batch)
+            if (int rc = kc.end_prepare(range_pile, &k2_done)) return rc;
+            if (int rc = column_stats_tiled_launch(b->pile_ptr(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->total_len, nullptr, 4,
+                                                   range_scratch.tile_cnt.as<int32_t>() /* (only "selection wanted") */, nullptr, nullptr, 0, b->max_depth, &range_scratch,
+                                                   e_k2.b, stream, k2_done, t0, t1, g0, g1, d_tile_ent_sum.as<int32_t>(), false)) return rc;
+            if (int rc = exclusive_scan_launch(range_scratch.tile_cnt.as<int32_t>(), (int)nt, range_scratch.tile_base.as<int64_t>(), range_scratch.scan_scratch, stream)) return rc;
+            if (int rc = exclusive_scan_launch(d_tile_ent_sum.as<int32_t>(), (int)nt, d_tile_ebase.as<int64_t>(), d_scan2, stream)) return rc;
+            // the two totals (the last elements of the scans) -> sizes of the column arrays
+            if (int rc = grow(h_header, sizeof(hsdev::ColumnsHeader))) return rc;
+            HS_HIP(hipMemcpyAsync(h_header.p, range_scratch.tile_base.as<int64_t>() + nt, 8, hipMemcpyDeviceToHost, stream));
+            HS_HIP(hipMemcpyAsync((char*)h_header.p + 8, d_tile_ebase.as<int64_t>() + nt, 8, hipMemcpyDeviceToHost, stream));
+            if (int rc = stream_wait(stream)) return rc;
+        }
+        n_cols = ((const int64_t*)h_header.p)[0]; n_entries = ((const int64_t*)h_header.p)[1];
+        out.n_columns = n_cols; out.n_entries = n_entries;
+        if (n_cols > 0x7fffffff) { set_error("more than 2^31 columns in one contig range"); return HS_EINVAL; }
+        n_gathered = (int)n_cols; gathered_entries = n_entries;
+        if (int rc = grow(d_col_gpos, std::max<size_t>(1, (size_t)n_cols) * 8)) return rc;
+        if (int rc = grow(d_col_rec, std::max<size_t>(1, (size_t)n_cols) * sizeof(hs_colrec))) return rc;
+        if (int rc = grow(d_co, ((size_t)n_cols + 1) * 8)) return rc;
+        if (int rc = grow(d_col_len, std::max<size_t>(1, (size_t)n_cols) * 4)) return rc;
+        if (int rc = grow(d_ci, std::max<size_t>(1, (size_t)n_entries) * 4)) return rc;
+        if (int rc = grow(d_cc, std::max<size_t>(1, (size_t)n_entries))) return rc;
+        if (int rc = grow(d_col_ctg, std::max<size_t>(1, (size_t)n_cols) * 4)) return rc;
+        if (int rc = grow(d_k0, std::max<size_t>(1, (size_t)n_cols))) return rc;
+        if (int rc = grow(d_k1, std::max<size_t>(1, (size_t)n_cols))) return rc;
+        if (int rc = grow(d_c1, std::max<size_t>(1, (size_t)n_cols) * 4)) return rc;
+        if (int rc = grow(d_cand, std::max<size_t>(1, (size_t)n_cols))) return rc;
+        if (int rc = grow(d_ctg_col_off, ((size_t)C + 1) * 8)) return rc;
+        if (int rc = grow(d_ctg_n, (size_t)C * 4)) return rc;
+        range_pack.add(min_reads, d_min_reads);
+        if (int rc = range_pack.commit(stream)) return rc;
+        // ---- the column list with its CSR offsets, K3 (tile-cooperative gather), K3b (leading codes, reference order), V1 ----
+        hipLaunchKernelGGL(hsdev::k_columns_compact, dim3((unsigned)nt), dim3(256), 0, stream, range_scratch.tile_cnt.as<int32_t>(), range_scratch.tile_base.as<int64_t>(),
+                           d_tile_ebase.as<int64_t>(), range_scratch.gpos.as<int64_t>(), range_scratch.depth.as<int32_t>(), nt, b->d_contig_off.as<int64_t>(), b->n_contigs,
+                           d_col_gpos.as<int64_t>(), d_col_rec.as<hsdev::hs_colrec_dev>(), d_co.as<int64_t>(), d_col_len.as<int32_t>(), d_header.as<hsdev::ColumnsHeader>(), n_cols);
+        HS_HIP(hipGetLastError());
+        HS_HIP(hipEventRecord(e_k3.a, stream));
+        if (n_cols > 0) {
+            if (int rc = kc.begin(HS_K_GATHER_COLUMNS, stream)) return rc;
+            hipLaunchKernelGGL(hsdev::k_gather_tiles, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, stream, b->pile_ptr(), b->tile_off.as<int64_t>(),
+                               reinterpret_cast<const int4*>(b->tile_ent.as<hs_tile_entry>()), b->tile_lrec.as<int32_t>(), t0, nt, range_scratch.tile_cnt.as<int32_t>(),
+                               range_scratch.tile_base.as<int64_t>(), d_col_gpos.as<int64_t>(), d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>());
+            HS_HIP(hipGetLastError());
+            // the pileup bytes of the range's tiles in (every one of them once), read index + code out per column entry
+            const int64_t range_pile = b->total_len > 0 ? (int64_t)((double)b->total_pile * (double)(g1 - g0) / (double)b->total_len) : 0;
+            if (int rc = kc.end(range_pile + 5 * n_entries, stream)) return rc;
+        }
+        HS_HIP(hipEventRecord(e_k3.b, stream));
+        HS_HIP(hipEventRecord(e_k3b.a, stream));
+        if (n_cols > 0) {
+            if (int rc = kc.begin(HS_K_COLUMN_TOP3, stream)) return rc;
+            const unsigned grid = (unsigned)std::min<int64_t>((n_cols + 3) / 4, 16384);
+            hipLaunchKernelGGL(hsdev::k_column_top3_exact, dim3(grid), dim3(256), 0, stream, d_co.as<int64_t>(), d_col_len.as<int32_t>(), d_cc.as<uint8_t>(),
+                               d_header.as<hsdev::ColumnsHeader>(), d_col_rec.as<hsdev::hs_colrec_dev>(), d_tie.as<unsigned long long>());
+            HS_HIP(hipGetLastError());
+            if (int rc = kc.end(n_entries + 16 * n_cols, stream)) return rc;
+        }
+        hipLaunchKernelGGL(hsdev::k_candidates_scan, dim3((unsigned)C), dim3(64), 0, stream, d_col_gpos.as<int64_t>(), d_header.as<hsdev::ColumnsHeader>(),
+                           b->d_contig_off.as<int64_t>(), c0, C, d_min_reads.as<int32_t>(), thr, d_col_rec.as<hsdev::hs_colrec_dev>(), d_col_ctg.as<int32_t>(),
+                           d_k0.as<uint8_t>(), d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), d_ctg_col_off.as<int64_t>(), d_ctg_n.as<int32_t>());
+        HS_HIP(hipGetLastError());
+        HS_HIP(hipEventRecord(e_k3b.b, stream));
+        // ---- the candidates, packed, to the host ----
+        int64_t n_cand = 0, e_cand = 0;
+        if (int rc = pack_flagged(HS_COL_CAND, true, &n_cand, &e_cand)) return rc;
+        if (int rc = grow(h_ctg_n, (size_t)C * 4 + 16)) return rc;
+        HS_HIP(hipMemcpyAsync(h_ctg_n.p, d_ctg_n.p, (size_t)C * 4, hipMemcpyDeviceToHost, stream));
+        HS_HIP(hipMemcpyAsync((char*)h_ctg_n.p + (size_t)C * 4, d_tie.p, 16, hipMemcpyDeviceToHost, stream));
+        if (int rc = stream_wait(stream)) return rc;
+        out.n_cand = n_cand;
+        out.rec = (const hs_colrec*)h_pk_rec.p; out.col = (const int32_t*)h_pk_col.p; out.off = (const int64_t*)h_pk_off.p;
+        out.idx = (const int32_t*)h_pk_idx.p; out.code = (const uint8_t*)h_pk_code.p;
+        std::memcpy(out.contig_n_cand.data(), h_ctg_n.p, (size_t)C * 4);
+        { unsigned long long t2[2]; std::memcpy(t2, (char*)h_ctg_n.p + (size_t)C * 4, 16); out.n_tie = (int64_t)t2[0]; out.n_tie_big = (int64_t)t2[1]; }
+        kc.flush();
+        if (int rc = e_k2.ms(&k_ms[0])) return rc;
+        if (int rc = e_k3.ms(&k_ms[1])) return rc;
+        return e_k3b.ms(&k_ms[2]);
+    }
+
+    // ---- K4 + the merge of the SNP lists + the SNP columns packed (they stay in d_pk_* for stage 4) ----
+    DBuf d_keep;
+    std::vector<int32_t> snp_contig_n;
+    int finish_columns(const hs::CvPartitionTest& t, bool want_entries, hs::CvSnpSet& out, float* k_ms) override {
+        const int C = range_c1 - range_c0;
+        out = hs::CvSnpSet();
+        out.contig_n_snp.assign((size_t)C, 0);
+        if (k_ms) *k_ms = 0;
+        if ((int)t.contig_n_reads.size() != C) { set_error("finish_columns: partitions of another contig range"); return HS_EINVAL; }
+        if (n_cols == 0 || C == 0) { if (int rc = grow(h_pk_off, 8)) return rc; *(int64_t*)h_pk_off.p = 0; out.off = (const int64_t*)h_pk_off.p; return HS_OK; }
+        const int n = (int)n_cols;
+        DBuf d_po, d_pso, d_ps;
         UploadPack pk;
-        pk.add(t.col_contig, d_ctg);
-        pk.add(t.col_k0, d_k0);
-        pk.add(t.col_k1, d_k1);
-        pk.add(t.col_c1, d_c1);
-        pk.add(t.col_is_cand, d_cand);
         pk.add(t.part_off, d_po);
         pk.add(t.part_state_off, d_pso);
         pk.add(t.part_state, d_ps);
         if (int rc = pk.commit(stream)) return rc;
-        if (int rc = d_keep.alloc((size_t)n)) return rc;
+        if (int rc = grow(d_keep, (size_t)n)) return rc;
         EventPair e; if (int rc = e.init()) return rc;
         HS_HIP(hipEventRecord(e.a, stream));
         if (int rc = kc.begin(HS_K_PARTITION_TEST, stream)) return rc;
-        DBuf d_tab, d_tab_off, d_ctg_n, d_list;
+        DBuf d_tab, d_tab_off, d_ctg_nr, d_list;
         UploadPack pk_tab;
-        if (int rc = partition_test_launch(d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), d_ctg.as<int32_t>(), d_k0.as<uint8_t>(),
+        if (int rc = partition_test_launch(d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), d_col_ctg.as<int32_t>(), d_k0.as<uint8_t>(),
                                            d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), n, d_po.as<int32_t>(), d_pso.as<int64_t>(),
-                                           d_ps.as<int8_t>(), t.part_off.data(), t.contig_n_reads.data(), (int32_t)t.contig_n_reads.size(), d_keep.as<uint8_t>(),
-                                           stream, d_tab, d_tab_off, d_ctg_n, d_list, pk_tab)) return rc;
+                                           d_ps.as<int8_t>(), t.part_off.data(), t.contig_n_reads.data(), C, d_keep.as<uint8_t>(),
+                                           stream, d_tab, d_tab_off, d_ctg_nr, d_list, pk_tab)) return rc;
         if (int rc = kc.end(5 * gathered_entries + (int64_t)t.part_state.size(), stream)) return rc;   // the columns (idx + code) and the partition states
         HS_HIP(hipEventRecord(e.b, stream));
-        keep.resize((size_t)n);
-        if (n) {
-            HBuf hk; if (int rc = hk.alloc((size_t)n)) return rc;
-            if (int rc = copy_d2h(hk.p, d_keep.p, (size_t)n, stream)) return rc;
-            std::memcpy(keep.data(), hk.p, (size_t)n);
-        }
+        hipLaunchKernelGGL(hsdev::k_snp_select, dim3((unsigned)C), dim3(64), 0, stream, d_ctg_col_off.as<int64_t>(), C, d_keep.as<uint8_t>(),
+                           d_col_rec.as<hsdev::hs_colrec_dev>(), d_ctg_n.as<int32_t>());
+        HS_HIP(hipGetLastError());
+        int64_t n_snp = 0, e_snp = 0;
+        if (int rc = pack_flagged(HS_COL_SNP, want_entries, &n_snp, &e_snp)) return rc;
+        if (int rc = grow(h_ctg_n, (size_t)C * 4 + 16)) return rc;
+        HS_HIP(hipMemcpyAsync(h_ctg_n.p, d_ctg_n.p, (size_t)C * 4, hipMemcpyDeviceToHost, stream));
+        if (int rc = stream_wait(stream)) return rc;       // (the partition tables, uploads and lists of this scope are done with)
+        out.n_snp = n_snp; out.n_entries = e_snp;
+        out.rec = (const hs_colrec*)h_pk_rec.p; out.off = (const int64_t*)h_pk_off.p;
+        if (want_entries) { out.idx = (const int32_t*)h_pk_idx.p; out.code = (const uint8_t*)h_pk_code.p; }
+        std::memcpy(out.contig_n_snp.data(), h_ctg_n.p, (size_t)C * 4);
         kc.flush();
-        return e.ms(k_ms);
-    }
-    HBuf h_top;
-    int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
-               const hs_coltop** top, float* k_ms) override {
-        const int n_sel = (int)sel_pos.size();
-        const size_t total = (size_t)col_off.back();
-        if (int rc = h_top.alloc((size_t)n_sel * sizeof(hs_coltop))) return rc;
-        *top = (const hs_coltop*)h_top.p;
-        n_gathered = n_sel; gathered_entries = (int64_t)total;
-        if (n_sel == 0) return HS_OK;
-        DBuf d_sc, d_sp;
-        gather_pack.add(sel_contig, d_sc);
-        gather_pack.add(sel_pos, d_sp);
-        gather_pack.add(col_off, d_co);      // stays resident for K4 and fetch_columns (member pack)
-        if (int rc = gather_pack.commit(stream)) return rc;
-        if (int rc = d_ci.alloc(total * sizeof(int32_t))) return rc;
-        if (int rc = d_cc.alloc(total)) return rc;
-        EventPair e; if (int rc = e.init()) return rc;
-        HS_HIP(hipEventRecord(e.a, stream));
-        if (int rc = kc.begin(HS_K_GATHER_COLUMNS, stream)) return rc;
-        if (int rc = hs_gather_columns_tiled(b->pile.as<uint8_t>(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->tile_rec.as<int32_t>(),
-                                             b->d_contig_off.as<int64_t>(), b->d_contig_rec_off.as<int32_t>(), d_sc.as<int32_t>(), d_sp.as<int32_t>(),
-                                             d_co.as<int64_t>(), n_sel, d_ci.as<int32_t>(), d_cc.as<uint8_t>(), stream)) return rc;
-        if (int rc = kc.end(6 * (int64_t)total, stream)) return rc;     // per column entry: one pileup byte in, read index + code out
-        DBuf d_top;
-        if (int rc = d_top.alloc((size_t)n_sel * sizeof(hs_coltop))) return rc;
-        if (int rc = kc.begin(HS_K_COLUMN_TOP3, stream)) return rc;
-        if (int rc = hs_column_top3(d_co.as<int64_t>(), d_cc.as<uint8_t>(), n_sel, d_top.as<hs_coltop>(), stream)) return rc;
-        if (int rc = kc.end((int64_t)total + 16 * (int64_t)n_sel, stream)) return rc;
-        HS_HIP(hipEventRecord(e.b, stream));
-        HS_HIP(hipMemcpyAsync(h_top.p, d_top.p, (size_t)n_sel * sizeof(hs_coltop), hipMemcpyDeviceToHost, stream));
-        if (int rc_w = stream_wait(stream)) return rc_w;
-        kc.flush();
-        return e.ms(k_ms);
+        return k_ms ? e.ms(k_ms) : HS_OK;
     }
     // ---- loop A on the device (hs_kernels_parts.hip) ----
     bool has_robust_partitions() const override { return true; }
@@ -1394,32 +1435,6 @@ struct HipCvOps : hs::CvDeviceOps {
         out.rec = (const hs::CvPartRecord*)h_la_rec.p; out.state = (const int8_t*)h_la_state.p; out.more = (const int32_t*)h_la_more.p; out.less = (const int32_t*)h_la_less.p;
         kc.flush();
         return e.ms(k_ms);
-    }
-    HBuf h_fetch_idx[2], h_fetch_code[2];
-    int fetch_columns(const std::vector<int32_t>& cols, const std::vector<int64_t>& packed_off, int slot, const int32_t** col_idx,
-                      const uint8_t** col_code) override {
-        if (slot < 0 || slot > 1 || packed_off.size() != cols.size() + 1) { set_error("fetch_columns: bad arguments"); return HS_EINVAL; }
-        const size_t total = (size_t)packed_off.back();
-        if (int rc = h_fetch_idx[slot].alloc(std::max<size_t>(total, 1) * sizeof(int32_t))) return rc;
-        if (int rc = h_fetch_code[slot].alloc(std::max<size_t>(total, 1))) return rc;
-        *col_idx = (const int32_t*)h_fetch_idx[slot].p; *col_code = (const uint8_t*)h_fetch_code[slot].p;
-        if (cols.empty() || total == 0) return HS_OK;
-        DBuf d_ids, d_po, d_pi, d_pc;
-        UploadPack pk;
-        pk.add(cols, d_ids);
-        pk.add(packed_off, d_po);
-        if (int rc = pk.commit(stream)) return rc;
-        if (int rc = d_pi.alloc(total * sizeof(int32_t))) return rc;
-        if (int rc = d_pc.alloc(total)) return rc;
-        if (int rc = kc.begin(HS_K_PACK_COLUMNS, stream)) return rc;
-        if (int rc = hs_pack_columns(d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), d_ids.as<int32_t>(), d_po.as<int64_t>(), (int32_t)cols.size(),
-                                     d_pi.as<int32_t>(), d_pc.as<uint8_t>(), stream)) return rc;
-        if (int rc = kc.end(10 * (int64_t)total, stream)) return rc;
-        HS_HIP(hipMemcpyAsync(h_fetch_idx[slot].p, d_pi.p, total * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        HS_HIP(hipMemcpyAsync(h_fetch_code[slot].p, d_pc.p, total, hipMemcpyDeviceToHost, stream));
-        if (int rc = stream_wait(stream)) return rc;
-        kc.flush();
-        return HS_OK;
     }
 };
 
@@ -2016,9 +2031,9 @@ int hs_cv_select(hs_cv_batch* b, hs_cv_selection** out) {
     hs::CvMeta meta; fill_meta(b, meta);
     HipCvOps ops(b);
     hs::CvSelection* sel = new hs::CvSelection();
-    if (int rc = hs::cv_select(ops, meta, *sel)) { delete sel; return rc; }
+    if (int rc = hs::cv_pileup(ops, meta, *sel)) { delete sel; return rc; }
     hs_cv_selection* o = (hs_cv_selection*)std::calloc(1, sizeof(hs_cv_selection));
-    o->n_selected = (int64_t)sel->sel_pos.size();
+    o->n_selected = 0;
     for (int k = 0; k < 4; ++k) o->t_kernel_ms[k] = sel->k_ms[k];
     o->t_device_ms = sel->t_device_ms; o->t_host_ms = sel->t_host_ms;
     o->impl = sel;
@@ -2037,7 +2052,7 @@ int hs_cv_run_range(hs_cv_batch* b, const hs_cv_selection* sel, int32_t c0, int3
     if (int rc = bind_device(b->device)) return rc;
     hs::CvMeta meta; fill_meta(b, meta);
     HipCvOps ops(b);
-    return hs::cv_run_range(ops, meta, *(const hs::CvSelection*)sel->impl, c0, c1, automatic_snp_threshold, n_threads, out);
+    return hs::cv_run_range(ops, meta, ((const hs::CvSelection*)sel->impl)->rec_stats, c0, c1, automatic_snp_threshold, n_threads, out);
 }
 
 int hs_sr_run_cv_range(const hs_cv_batch* b, int32_t c0, int32_t c1, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance,
@@ -2202,26 +2217,11 @@ static hs_sr_result* concat_sr_parts(hs_pipeline* p, std::vector<hs_sr_result*>&
     return R;
 }
 
-// K2 and the selection run per contig group, inside the group's chain (HS_SELECT_WHOLE=1: once over the whole batch, before the
-// groups start, as hs_cv_select does): the groups then start after K0 + K1 and the host works while K2 of the later groups runs
-static bool select_per_group() { static const bool whole = std::getenv("HS_SELECT_WHOLE") != nullptr; return !whole; }
-
 int hs_pipeline_select(hs_pipeline* p, float* mean_distance, hs_pipeline_stats* st) {
     if (!p || !mean_distance) { set_error("hs_pipeline_select: null argument"); return HS_EINVAL; }
     if (int rc = bind_device(p->batch->device)) return rc;
     p->drop_cv();
-    if (select_per_group()) {
-        if (int rc = require_device()) return rc;
-        hs::CvMeta meta; fill_meta(p->batch, meta);
-        HipCvOps ops(p->batch);
-        hs::CvSelection* sel = new hs::CvSelection();
-        if (int rc = hs::cv_pileup(ops, meta, *sel)) { delete sel; return rc; }
-        hs_cv_selection* o = (hs_cv_selection*)std::calloc(1, sizeof(hs_cv_selection));
-        for (int k = 0; k < 4; ++k) o->t_kernel_ms[k] = sel->k_ms[k];
-        o->t_device_ms = sel->t_device_ms; o->t_host_ms = sel->t_host_ms;
-        o->impl = sel;
-        p->sel = o;
-    } else if (int rc = hs_cv_select(p->batch, &p->sel)) return rc;
+    if (int rc = hs_cv_select(p->batch, &p->sel)) return rc;
     const hs::CvSelection& sel = *(const hs::CvSelection*)p->sel->impl;
     const hs_cv_batch* b = p->batch;
     for (int c = 0; c < b->n_contigs; ++c) {   // call_variants.cpp:434 per contig, from the integer counters of K1
@@ -2232,7 +2232,7 @@ int hs_pipeline_select(hs_pipeline* p, float* mean_distance, hs_pipeline_stats* 
     if (st) {
         std::memset(st, 0, sizeof *st);
         st->t_device_ms = p->sel->t_device_ms; st->t_host_ms = p->sel->t_host_ms;
-        st->t_kernel_cv_ms[0] = p->sel->t_kernel_ms[0]; st->t_kernel_cv_ms[1] = p->sel->t_kernel_ms[1]; st->t_kernel_cv_ms[3] = p->sel->t_kernel_ms[3];
+        st->t_kernel_cv_ms[0] = p->sel->t_kernel_ms[0]; st->t_kernel_cv_ms[3] = p->sel->t_kernel_ms[3];
     }
     return HS_OK;
 }
@@ -2264,22 +2264,12 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
     struct timespec cpu0; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &cpu0);
     const auto wall0 = std::chrono::steady_clock::now();
     std::vector<hs_sr_result*> parts((size_t)G, nullptr);
-    std::vector<float> group_k2_ms((size_t)G, 0.f);
-    std::vector<int64_t> group_sel((size_t)G, 0);
-    std::vector<double> group_sel_dev_ms((size_t)G, 0.0), group_sel_host_ms((size_t)G, 0.0);
     std::vector<hs::SrSparseLabels> sparse((size_t)G);      // the groups leave their labels per window; concat_sr_parts spreads them
     const int rc = p->run([&](int g) {
         const int c0 = p->ranges[(size_t)g].first, c1 = p->ranges[(size_t)g].second;
         hs::CvMeta meta; fill_meta(p->batch, meta);
-        if (select_per_group()) {
-            HipCvOps cv_ops(p->batch);
-            hs::CvSelection gsel;
-            if (int r = hs::cv_select_range(cv_ops, meta, c0, c1, gsel)) return r;
-            group_k2_ms[(size_t)g] = gsel.k_ms[1]; group_sel[(size_t)g] = (int64_t)gsel.sel_pos.size();
-            group_sel_dev_ms[(size_t)g] = gsel.t_device_ms; group_sel_host_ms[(size_t)g] = gsel.t_host_ms;
-            if (int r = hs::cv_run_range(cv_ops, meta, gsel, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g],
-                                         &((const hs::CvSelection*)p->sel->impl)->rec_stats)) return r;
-        } else if (int r = hs_cv_run_range(p->batch, p->sel, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g])) return r;
+        HipCvOps cv_ops(p->batch);
+        if (int r = hs::cv_run_range(cv_ops, meta, ((const hs::CvSelection*)p->sel->impl)->rec_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g])) return r;
         HipSrOps ops;
         return hs::sr_run_from_cv(ops, meta, c0, c1, p->cv[(size_t)g], error_rate, rarest_strain_abundance, low_memory, amplicon, seed, per, window_size,
                                   &parts[(size_t)g], &sparse[(size_t)g]);
@@ -2293,8 +2283,7 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
             st->t_kernel_cv_ms[2] += r->t_kernel_ms[2]; st->t_kernel_k4_ms += r->t_kernel_k4_ms;
             st->n_columns_extracted += r->n_columns_extracted; st->n_columns_downloaded += r->n_columns_downloaded;
             st->n_columns_downloaded_late += r->n_columns_downloaded_late;
-            st->t_kernel_cv_ms[1] += group_k2_ms[(size_t)g];      // (zero unless K2 ran per group)
-            st->t_device_ms += group_sel_dev_ms[(size_t)g]; st->t_host_ms += group_sel_host_ms[(size_t)g];
+            st->t_kernel_cv_ms[1] += r->t_kernel_ms[1];
         }
     }
     if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] host waits so far: %ld, %.1f ms in them\n", g_waits.load(), g_wait_us.load() / 1e3);

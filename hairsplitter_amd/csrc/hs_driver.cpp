@@ -183,204 +183,87 @@ struct Laps {   // HS_TIMING: fine-grained wall clock of a stage driver (HS_TIMI
 // ---------------------------------------------------------------------------------------------------
 // stage 3
 // ---------------------------------------------------------------------------------------------------
-// The whole-batch streaming pass (K0 CIGAR scan, K1 pileup, K2 column statistics + selection): one launch each over every
-// contig of the batch, then the (small) list of interesting positions ordered by (contig, position).
-int cv_select(CvDeviceOps& dev, const CvMeta& b, CvSelection& sel) {
-    const int C = b.n_contigs, NR = b.n_rec;
-    const double t_start = now_ms();
-    for (int k = 0; k < 4; ++k) sel.k_ms[k] = 0;   // pileup, column_stats, (gather_columns), cigar_scan
-    sel.rec_stats.assign((size_t)NR * 4, 0);
-    const int64_t* sel_gpos = nullptr;
-    const int32_t* sel_depth = nullptr;
-    size_t n_sel = 0;
-    // interesting positions: second count >= 4 (everything that can become a SNP, see hs_host_cv.cpp), ordered by position
-    if (int rc = dev.pileup_and_select(sel.rec_stats, 4, &sel_gpos, &sel_depth, &n_sel, sel.k_ms)) return rc;
-    const double t_k12_done = now_ms();
-    sel.contig_sel_off.assign((size_t)C + 1, 0);
-    if (std::is_sorted(sel_gpos, sel_gpos + n_sel)) {
-        // the HIP implementation hands the list over sorted already: the contig boundaries by bisection, the three arrays
-        // filled per contig on the worker threads (straight from the staging buffer of the download)
-        sel.sel_contig.resize(n_sel); sel.sel_pos.resize(n_sel); sel.sel_depth.resize(n_sel);
-        for (int c = 0; c <= C; ++c)
-            sel.contig_sel_off[(size_t)c] = (int64_t)(std::lower_bound(sel_gpos, sel_gpos + n_sel, b.contig_off[(size_t)c]) - sel_gpos);
-        parallel_for(C, 16, [&](int c) {   // (the host is idle while the streaming pass runs)
-            const int64_t base = b.contig_off[(size_t)c];
-            for (int64_t i = sel.contig_sel_off[(size_t)c]; i < sel.contig_sel_off[(size_t)c + 1]; ++i) {
-                sel.sel_contig[(size_t)i] = c; sel.sel_pos[(size_t)i] = (int32_t)(sel_gpos[(size_t)i] - base);
-                sel.sel_depth[(size_t)i] = sel_depth[(size_t)i];
-            }
-        });
-    } else {   // bucket by 256-position tile, then order the few entries of each tile
-        std::vector<size_t> order(n_sel);
-        const size_t n_tiles = (size_t)((b.total_len + 255) / 256);
-        std::vector<uint32_t> start(n_tiles + 1, 0);
-        for (size_t i = 0; i < n_sel; ++i) start[(size_t)(sel_gpos[i] >> 8) + 1]++;
-        for (size_t t = 0; t < n_tiles; ++t) start[t + 1] += start[t];
-        std::vector<uint32_t> fill(start.begin(), start.end() - 1);
-        for (size_t i = 0; i < n_sel; ++i) order[fill[(size_t)(sel_gpos[i] >> 8)]++] = i;
-        for (size_t t = 0; t < n_tiles; ++t)
-            if (start[t + 1] - start[t] > 1)
-                std::sort(order.begin() + start[t], order.begin() + start[t + 1], [&](size_t x, size_t y) { return sel_gpos[x] < sel_gpos[y]; });
-        sel.sel_contig.resize(order.size()); sel.sel_pos.resize(order.size()); sel.sel_depth.resize(order.size());
-        int c = 0;
-        for (size_t i = 0; i < order.size(); ++i) {
-            const int64_t g = sel_gpos[order[i]];
-            while (g >= b.contig_off[(size_t)c + 1]) { c++; sel.contig_sel_off[(size_t)c] = (int64_t)i; }
-            sel.sel_contig[i] = c; sel.sel_pos[i] = (int32_t)(g - b.contig_off[(size_t)c]);
-            sel.sel_depth[i] = sel_depth[order[i]];
-        }
-        for (int k = c + 1; k <= C; ++k) sel.contig_sel_off[(size_t)k] = (int64_t)order.size();
-    }
-    sel.t_device_ms = t_k12_done - t_start;
-    sel.t_host_ms = now_ms() - t_k12_done;
-    if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] cv select: k0+k1+k2+d2h %.2f ms, ordering %.2f ms\n", sel.t_device_ms, sel.t_host_ms);
-    return HS_OK;
-}
-
-// Stage 3 for the contigs [c0, c1) of the batch on top of a selection: column extraction (K3), the host partition logic,
-// the column x partition test (K4) and the merge. Ranges are independent: several may run concurrently from different host
-// threads, each with its own device interface (stream).
+// The whole-batch streaming pass (K0 CIGAR scan, K1 pileup): one launch each over every contig of the batch; the per-record
+// counters come back (error rate of every contig, call_variants.cpp:434).
 int cv_pileup(CvDeviceOps& dev, const CvMeta& b, CvSelection& sel) {
     const double t_start = now_ms();
     for (int k = 0; k < 4; ++k) sel.k_ms[k] = 0;
     sel.rec_stats.assign((size_t)b.n_rec * 4, 0);
     if (int rc = dev.pileup(sel.rec_stats, sel.k_ms)) return rc;
-    sel.contig_sel_off.assign((size_t)b.n_contigs + 1, 0);
     sel.t_device_ms = now_ms() - t_start; sel.t_host_ms = 0;
     return HS_OK;
 }
 
-int cv_select_range(CvDeviceOps& dev, const CvMeta& b, int c0, int c1, CvSelection& sel) {
-    const int C = b.n_contigs;
-    if (c0 < 0 || c1 > C || c0 > c1) { set_error("cv_select_range: bad contig range"); return HS_EINVAL; }
-    const double t_start = now_ms();
-    const int64_t g0 = b.contig_off[(size_t)c0], g1 = b.contig_off[(size_t)c1];
-    const int64_t* gp = nullptr; const int32_t* dp = nullptr; size_t n = 0;
-    if (int rc = dev.select_range(g0, g1, 4, &gp, &dp, &n, &sel.k_ms[1])) return rc;
-    const double t_dev = now_ms();
-    // the list is sorted; the boundary tiles may bring positions of the neighbouring ranges
-    const int64_t* lo = std::lower_bound(gp, gp + n, g0);
-    const int64_t* hi = std::lower_bound(gp, gp + n, g1);
-    const size_t first = (size_t)(lo - gp), m = (size_t)(hi - lo);
-    sel.contig_sel_off.assign((size_t)C + 1, 0);
-    for (int c = c0; c <= c1; ++c) sel.contig_sel_off[(size_t)c] = (int64_t)(std::lower_bound(lo, hi, b.contig_off[(size_t)c]) - lo);
-    for (int c = c1 + 1; c <= C; ++c) sel.contig_sel_off[(size_t)c] = (int64_t)m;
-    sel.sel_contig.resize(m); sel.sel_pos.resize(m); sel.sel_depth.resize(m);
-    int c = c0;
-    for (size_t i = 0; i < m; ++i) {
-        const int64_t g = lo[i];
-        while (g >= b.contig_off[(size_t)c + 1]) ++c;
-        sel.sel_contig[i] = c; sel.sel_pos[i] = (int32_t)(g - b.contig_off[(size_t)c]); sel.sel_depth[i] = dp[first + i];
-    }
-    sel.t_device_ms = t_dev - t_start; sel.t_host_ms = now_ms() - t_dev;
-    return HS_OK;
-}
-
-int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int c0, int c1, float automatic_snp_threshold, int n_threads,
-                 hs_cv_result** out, const std::vector<int32_t>* rec_stats_ext) {
+// Stage 3 for the contigs [c0, c1) of the batch on top of the pileup. The columns never leave the device: it extracts them,
+// names their leading codes, picks the candidates (K2, K3, K3b, V1) and hands the candidates over; the partition logic
+// (loops A and B: sequential per contig, libm inside) runs here; the final partitions go back for loops C / D and the merge
+// of the SNP lists, and the SNPs come out. Ranges are independent: several may run concurrently from different host threads,
+// each with its own device interface (stream).
+int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& rec_stats, int c0, int c1, float automatic_snp_threshold, int n_threads,
+                 hs_cv_result** out, bool resident) {
     if (n_threads <= 0) n_threads = host_threads();
     if (c0 < 0 || c1 > b.n_contigs || c0 > c1) { set_error("cv_run_range: bad contig range"); return HS_EINVAL; }
     const int C = c1 - c0;
     const double t_start = now_ms();
     float k_ms[4] = {0, 0, 0, 0};
     float k_ms_k4 = 0;              // column x partition test
-    const std::vector<int32_t>& rec_stats = rec_stats_ext ? *rec_stats_ext : sel.rec_stats;
-    const int64_t g0 = sel.contig_sel_off[(size_t)c0], g1 = sel.contig_sel_off[(size_t)c1];
-    std::vector<int32_t> sel_contig(sel.sel_contig.begin() + g0, sel.sel_contig.begin() + g1);   // batch-global contig ids (K3 wants those)
-    std::vector<int32_t> sel_pos(sel.sel_pos.begin() + g0, sel.sel_pos.begin() + g1);
-    std::vector<int64_t> col_off((size_t)(g1 - g0) + 1, 0);
-    for (int64_t i = g0; i < g1; ++i) col_off[(size_t)(i - g0) + 1] = col_off[(size_t)(i - g0)] + sel.sel_depth[(size_t)i];
-    std::vector<int64_t> contig_sel_off((size_t)C + 1, 0);
-    for (int c = 0; c <= C; ++c) contig_sel_off[(size_t)c] = sel.contig_sel_off[(size_t)(c0 + c)] - g0;
-    const hs_coltop* col_top = nullptr;
-    if (int rc = dev.gather(sel_contig, sel_pos, col_off, &col_top, &k_ms[2])) return rc;
-    // only the columns the host walks come back: the rest stays on the device for K4 (and for the late fetch below)
-    const size_t n_sel_range = sel_pos.size();
-    static const bool fetch_all = std::getenv("HS_FETCH_ALL_COLUMNS") != nullptr;   // diagnostic: download every extracted column
-    std::vector<int32_t> need_cols;
-    std::vector<int64_t> host_off(n_sel_range + 1, 0);       // offsets of every column in the packed download (empty if not fetched)
-    std::vector<int64_t> need_off(1, 0);
-    for (size_t i = 0; i < n_sel_range; ++i) {
-        int64_t n = 0;
-        if (fetch_all || cv_column_needed_on_host(col_top[i])) { need_cols.push_back((int32_t)i); n = col_off[i + 1] - col_off[i]; need_off.push_back(need_off.back() + n); }
-        host_off[i + 1] = host_off[i] + n;
-    }
-    const int32_t* col_idx = nullptr;
-    const uint8_t* col_code = nullptr;
-    if (int rc = dev.fetch_columns(need_cols, need_off, 0, &col_idx, &col_code)) return rc;
-    const double t_dev_done = now_ms();
-    Laps laps("cv glue");
-
-    // host glue: exact tie order of the extracted columns (independent per column: chunked over all threads) ...
-    std::vector<ColumnSet> sets((size_t)C);
     std::vector<ContigCvResult> res((size_t)C);
-    std::vector<std::pair<int, int>> chunks;   // (contig, first column)
-    for (int c = 0; c < C; ++c) {
-        ColumnSet& cs = sets[(size_t)c];
-        const int64_t s0 = contig_sel_off[(size_t)c], s1 = contig_sel_off[(size_t)c + 1];
-        cs.pos.assign(sel_pos.begin() + s0, sel_pos.begin() + s1);
-        cs.off.resize((size_t)(s1 - s0) + 1);
-        for (int64_t i = s0; i <= s1; ++i) cs.off[(size_t)(i - s0)] = host_off[(size_t)i] - host_off[(size_t)s0];
-        cs.idx = col_idx + host_off[(size_t)s0];
-        cs.code = col_code + host_off[(size_t)s0];
-        cs.top = col_top + s0;
-        const size_t n = cs.pos.size();
-        cs.k0.resize(n); cs.k1.resize(n); cs.c0.resize(n); cs.c1.resize(n); cs.c2.resize(n);
-        for (int64_t f = 0; f < s1 - s0; f += 256) chunks.push_back(std::make_pair(c, (int)f));
-    }
-    laps.lap("sets");
-    parallel_for((int)chunks.size(), n_threads, [&](int i) {
-        ColumnSet& cs = sets[(size_t)chunks[(size_t)i].first];
-        const int f = chunks[(size_t)i].second;
-        resolve_columns(cs, f, std::min<int>(f + 256, (int)cs.pos.size()));
-    });
-    laps.lap("resolve_columns");
-    // ... then the partition logic: the V1 scan names the candidates, loop A runs on the device (contig by contig, one
-    // workgroup each) or, without that kernel, on the host; loop B on the host, one contig per thread ...
-    std::vector<CvContigState*> cst((size_t)C, nullptr);
-    for (int c = 0; c < C; ++c) cst[(size_t)c] = cv_state_new();
-    std::vector<std::vector<int32_t>> rend((size_t)C);
-    parallel_for(C, n_threads, [&](int c) {
-        ColumnSet& cs = sets[(size_t)c];
+    std::vector<int32_t> min_reads((size_t)C, 5);
+    for (int c = 0; c < C; ++c) {   // call_variants.cpp:434 and :463-466 from the integer counters of K1; :565
+        const int gc = c0 + c;
         int64_t nerr = 0, nlen = 0;
-        const int gc = c0 + c;   // index in the batch
         for (int r = b.contig_rec_off[(size_t)gc]; r < b.contig_rec_off[(size_t)gc + 1]; ++r) { nerr += rec_stats[(size_t)r * 4 + 1]; nlen += rec_stats[(size_t)r * 4 + 2]; }
         ContigCvResult& o = res[(size_t)c];
         o.mean_distance = mean_distance_from_counts(nerr, nlen);
+        min_reads[(size_t)c] = o.mean_distance < 0.015 ? 3 : 5;
         const int64_t L = b.contig_off[(size_t)gc + 1] - b.contig_off[(size_t)gc];
         const int64_t entries = b.pile_off[(size_t)b.contig_rec_off[(size_t)gc + 1]] - b.pile_off[(size_t)b.contig_rec_off[(size_t)gc]];
-        o.depth = (float)((double)entries / (double)L);   // call_variants.cpp:565
+        o.depth = (float)((double)entries / (double)L);
+    }
+    CvCandidates cand;
+    float k_ms_x[3] = {0, 0, 0};
+    if (int rc = dev.extract_candidates(c0, c1, min_reads, automatic_snp_threshold, cand, k_ms_x)) return rc;
+    k_ms[1] = k_ms_x[0]; k_ms[2] = k_ms_x[1] + k_ms_x[2];
+    const double t_dev_done = now_ms();
+    Laps laps("cv glue");
+    std::vector<int64_t> cand_base((size_t)C + 1, 0);
+    for (int c = 0; c < C; ++c) cand_base[(size_t)c + 1] = cand_base[(size_t)c] + cand.contig_n_cand[(size_t)c];
+    if (cand_base[(size_t)C] != cand.n_cand) { set_error("cv_run_range: candidate counts do not add up"); return HS_EINVAL; }
+
+    // ---- the partition logic: loop A on the host (or, with that kernel, contig by contig on the device), loop B on the host ----
+    std::vector<CvContigState*> cst((size_t)C, nullptr);
+    for (int c = 0; c < C; ++c) cst[(size_t)c] = cv_state_new();
+    std::vector<std::vector<int32_t>> rend((size_t)C);
+    auto candidates_of = [&](int c) {
+        CandidateSet cs;
+        cs.n = cand.contig_n_cand[(size_t)c];
+        cs.rec = cand.rec + cand_base[(size_t)c]; cs.off = cand.off + cand_base[(size_t)c]; cs.idx = cand.idx; cs.code = cand.code;
+        return cs;
+    };
+    parallel_for(C, n_threads, [&](int c) {
+        const int gc = c0 + c;   // index in the batch
         const int r0 = b.contig_rec_off[(size_t)gc];
         const int n_reads_c = b.contig_rec_off[(size_t)gc + 1] - r0;
         rend[(size_t)c].resize((size_t)n_reads_c);
         for (int r = 0; r < n_reads_c; ++r) rend[(size_t)c][(size_t)r] = (int32_t)std::min<int64_t>(b.rec_pos[(size_t)(r0 + r)] + b.rec_refspan[(size_t)(r0 + r)], 0x7fffffff);
-        cv_phase_v1(*cst[(size_t)c], n_reads_c, cs, o.mean_distance, automatic_snp_threshold, o);
+        cv_phase_begin(*cst[(size_t)c], n_reads_c, cand.contig_n_cand[(size_t)c], res[(size_t)c].mean_distance, res[(size_t)c]);
     });
-    laps.lap("v1");
-    static const bool loop_a_on_host = std::getenv("HS_LOOP_A_ON_DEVICE") == nullptr;      // (first device form: correct, not yet faster than the host's)
+    laps.lap("begin");
+    static const bool loop_a_on_host = std::getenv("HS_LOOP_A_ON_DEVICE") == nullptr;      // (the device form is exact but slower than the host's)
     const bool on_device = dev.has_robust_partitions() && !loop_a_on_host;
     CvLoopAResult la;
     float k_ms_a = 0;
     if (on_device) {
         CvLoopA in;
-        in.cand_off.assign((size_t)C + 1, 0); in.read_off.assign((size_t)C + 1, 0); in.contig_n_reads.resize((size_t)C);
+        in.cand_off = cand_base; in.read_off.assign((size_t)C + 1, 0); in.contig_n_reads.resize((size_t)C);
         for (int c = 0; c < C; ++c) {
-            in.cand_off[(size_t)c + 1] = in.cand_off[(size_t)c] + (int64_t)cv_candidates(*cst[(size_t)c]).size();
             in.contig_n_reads[(size_t)c] = (int32_t)rend[(size_t)c].size();
             in.read_off[(size_t)c + 1] = in.read_off[(size_t)c] + (int64_t)rend[(size_t)c].size();
         }
-        in.cand_col.resize((size_t)in.cand_off.back()); in.cand_pos.resize((size_t)in.cand_off.back()); in.cand_ref.resize((size_t)in.cand_off.back());
+        in.cand_col.assign(cand.col, cand.col + cand.n_cand); in.cand_pos.resize((size_t)cand.n_cand); in.cand_ref.resize((size_t)cand.n_cand);
+        for (int64_t k = 0; k < cand.n_cand; ++k) { in.cand_pos[(size_t)k] = cand.rec[k].pos; in.cand_ref[(size_t)k] = cand.rec[k].k0; }
         in.read_end.resize((size_t)in.read_off.back());
-        parallel_for(C, n_threads, [&](int c) {
-            const ColumnSet& cs = sets[(size_t)c];
-            const std::vector<int>& cand = cv_candidates(*cst[(size_t)c]);
-            const int64_t k0 = in.cand_off[(size_t)c], s0 = contig_sel_off[(size_t)c];
-            for (size_t i = 0; i < cand.size(); ++i) {
-                in.cand_col[(size_t)k0 + i] = (int32_t)(s0 + cand[i]); in.cand_pos[(size_t)k0 + i] = cs.pos[(size_t)cand[i]];
-                in.cand_ref[(size_t)k0 + i] = cs.k0[(size_t)cand[i]];
-            }
-            std::copy(rend[(size_t)c].begin(), rend[(size_t)c].end(), in.read_end.begin() + in.read_off[(size_t)c]);
-        });
+        for (int c = 0; c < C; ++c) std::copy(rend[(size_t)c].begin(), rend[(size_t)c].end(), in.read_end.begin() + in.read_off[(size_t)c]);
         laps.lap("loop_a_prep");
         if (int rc = dev.robust_partitions(in, la, &k_ms_a)) return rc;
         laps.lap("loop_a");
@@ -391,21 +274,17 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         if (on_device && !la.failed[(size_t)c])
             cv_phase_a_import(*cst[(size_t)c], b.rec_pos.data() + r0, (int)(la.part_base[(size_t)c + 1] - la.part_base[(size_t)c]), la.rec + la.part_base[(size_t)c],
                               la.state, la.more, la.less);
-        else { cv_phase_a_host(*cst[(size_t)c], sets[(size_t)c], b.rec_pos.data() + r0, rend[(size_t)c].data()); n_host_a++; }
+        else { cv_phase_a_host(*cst[(size_t)c], candidates_of(c), b.rec_pos.data() + r0, rend[(size_t)c].data()); n_host_a++; }
         cv_phase_b(*cst[(size_t)c], res[(size_t)c]);
     });
     if (std::getenv("HS_TIMING") && on_device) std::fprintf(stderr, "[hs timing] cv loop A on the device: %.3f ms of kernels, %d of %d contigs redone on the host\n", k_ms_a, n_host_a.load(), C);
     laps.lap("phase_ab");
-    // ... loops C and D on the device: one wavefront per extracted column against the contig's final partitions ...
+    // ---- loops C and D and the merge of the SNP lists on the device, against the final partitions ----
+    CvSnpSet snps;
     {
         CvPartitionTest t;
-        const size_t n_sel = sel_pos.size();
-        t.col_contig.resize(n_sel);
-        for (size_t i = 0; i < n_sel; ++i) t.col_contig[i] = sel_contig[i] - c0;   // index into part_off
-        t.col_c1.resize(n_sel); t.col_k0.resize(n_sel); t.col_k1.resize(n_sel); t.col_is_cand.resize(n_sel);
         t.part_off.assign((size_t)C + 1, 0);
         t.contig_n_reads.resize((size_t)C);
-        // offsets first (partitions and state bytes per contig), then every contig writes its own slices
         std::vector<int64_t> st_base((size_t)C + 1, 0);
         for (int c = 0; c < C; ++c) {
             t.contig_n_reads[(size_t)c] = b.contig_rec_off[(size_t)(c0 + c) + 1] - b.contig_rec_off[(size_t)(c0 + c)];
@@ -415,94 +294,57 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
         }
         t.part_state.resize((size_t)st_base[(size_t)C]); t.part_state_off.resize((size_t)t.part_off[(size_t)C]);
         parallel_for(C, n_threads, [&](int c) {
-            const ColumnSet& cs = sets[(size_t)c];
-            const size_t s0 = (size_t)contig_sel_off[(size_t)c];
-            for (size_t i = 0; i < cs.pos.size(); ++i) { t.col_c1[s0 + i] = cs.c1[i]; t.col_k0[s0 + i] = cs.k0[i]; t.col_k1[s0 + i] = cs.k1[i]; }
-            cv_export_candidates(*cst[(size_t)c], t.col_is_cand.data() + s0);
             cv_export_partitions(*cst[(size_t)c], t.part_state.data() + st_base[(size_t)c], st_base[(size_t)c], t.part_state_off.data() + t.part_off[(size_t)c]);
+            cv_state_free(cst[(size_t)c]);
         });
-        std::vector<uint8_t> keep(n_sel, 0);
         laps.lap("k4_prep");
-        if (n_sel) { if (int rc = dev.column_partition_test(t, keep, &k_ms_k4)) return rc; }
-        laps.lap("k4");
-        for (int c = 0; c < C; ++c) cv_import_keep(*cst[(size_t)c], keep.data() + contig_sel_off[(size_t)c]);
+        if (int rc = dev.finish_columns(t, !resident, snps, &k_ms_k4)) return rc;
+        laps.lap("k4+snps");
     }
-    // ... and the final merge
-    parallel_for(C, n_threads, [&](int c) { cv_phase_merge(*cst[(size_t)c], sets[(size_t)c], res[(size_t)c]); cv_state_free(cst[(size_t)c]); });
     const double t_glue_done = now_ms();
-    laps.lap("merge");
 
     hs_cv_result* R = (hs_cv_result*)std::calloc(1, sizeof(hs_cv_result));
     R->n_contigs = C;
     std::vector<float> md((size_t)C), dp((size_t)C);
-    std::vector<int64_t> snp_off((size_t)C + 1, 0), ent_off((size_t)C + 1, 0);
+    std::vector<int64_t> snp_off((size_t)C + 1, 0);
     float total_error = 0; int n_err_contigs = 0;
     for (int c = 0; c < C; ++c) {
         md[(size_t)c] = res[(size_t)c].mean_distance; dp[(size_t)c] = res[(size_t)c].depth;
         if (res[(size_t)c].mean_distance > 0) { total_error += res[(size_t)c].mean_distance; n_err_contigs++; }   // call_variants.cpp:1312-1315
-        int64_t ent = 0;
-        const int64_t s0 = contig_sel_off[(size_t)c];
-        for (int ci : res[(size_t)c].snp_col) ent += col_off[(size_t)(s0 + ci) + 1] - col_off[(size_t)(s0 + ci)];
-        snp_off[(size_t)c + 1] = snp_off[(size_t)c] + (int64_t)res[(size_t)c].snp_col.size();
-        ent_off[(size_t)c + 1] = ent_off[(size_t)c] + ent;
+        snp_off[(size_t)c + 1] = snp_off[(size_t)c] + snps.contig_n_snp[(size_t)c];
     }
-    // output columns that were not downloaded above (rescued by loop D without having been candidates): second, small fetch
-    std::vector<int32_t> late_cols;
-    std::vector<int64_t> late_off(1, 0);
-    for (int c = 0; c < C; ++c) {
-        const int64_t s0 = contig_sel_off[(size_t)c];
-        for (int ci : res[(size_t)c].snp_col) {
-            const size_t g = (size_t)(s0 + ci);
-            if (host_off[g + 1] == host_off[g]) { late_cols.push_back((int32_t)g); late_off.push_back(late_off.back() + col_off[g + 1] - col_off[g]); }
-        }
-    }
-    const int32_t* late_idx = nullptr;
-    const uint8_t* late_code = nullptr;
-    if (!late_cols.empty()) { if (int rc = dev.fetch_columns(late_cols, late_off, 1, &late_idx, &late_code)) return rc; }
-    std::vector<int64_t> late_first((size_t)C + 1, 0);       // first late column of each contig (late_cols is contig-major)
-    {
-        size_t k = 0;
-        for (int c = 0; c < C; ++c) {
-            late_first[(size_t)c] = (int64_t)k;
-            while (k < late_cols.size() && late_cols[k] < contig_sel_off[(size_t)c + 1]) ++k;
-        }
-        late_first[(size_t)C] = (int64_t)k;
-    }
-    laps.lap("late fetch");
-    const int64_t S = snp_off[(size_t)C], E = ent_off[(size_t)C];
+    const int64_t S = snps.n_snp, E = snps.n_entries;
+    if (snp_off[(size_t)C] != S) { set_error("cv_run_range: SNP counts do not add up"); return HS_EINVAL; }
     R->snp_pos = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t));
     R->snp_ref = (uint8_t*)std::malloc(std::max<int64_t>(1, S));
     R->snp_alt = (uint8_t*)std::malloc(std::max<int64_t>(1, S));
     R->snp_n_ref = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t));
     R->snp_n_alt = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t));
     R->col_off = (int64_t*)std::malloc((S + 1) * sizeof(int64_t));
-    R->col_idx = (int32_t*)std::malloc(std::max<int64_t>(1, E) * sizeof(int32_t));
-    R->col_code = (uint8_t*)std::malloc(std::max<int64_t>(1, E));
-    R->col_off[0] = 0;
-    R->n_columns_extracted = (int64_t)n_sel_range;
-    R->n_columns_downloaded = (int64_t)need_cols.size();
-    R->n_columns_downloaded_late = (int64_t)late_cols.size();
-    parallel_for(C, n_threads, [&](int c) {
-        const ColumnSet& cs = sets[(size_t)c];
-        int64_t s = snp_off[(size_t)c], e = ent_off[(size_t)c];
-        size_t late = (size_t)late_first[(size_t)c];
-        for (int ci : res[(size_t)c].snp_col) {
-            int64_t n = cs.off[(size_t)ci + 1] - cs.off[(size_t)ci];
-            R->snp_pos[s] = cs.pos[(size_t)ci]; R->snp_ref[s] = cs.k0[(size_t)ci]; R->snp_alt[s] = cs.k1[(size_t)ci];
-            R->snp_n_ref[s] = cs.c0[(size_t)ci]; R->snp_n_alt[s] = cs.c1[(size_t)ci];
-            if (n > 0) {
-                std::memcpy(R->col_idx + e, cs.idx + cs.off[(size_t)ci], (size_t)n * sizeof(int32_t));
-                std::memcpy(R->col_code + e, cs.code + cs.off[(size_t)ci], (size_t)n);
-            } else {
-                n = late_off[late + 1] - late_off[late];
-                std::memcpy(R->col_idx + e, late_idx + late_off[late], (size_t)n * sizeof(int32_t));
-                std::memcpy(R->col_code + e, late_code + late_off[late], (size_t)n);
-                late++;
+    const bool with_entries = snps.idx != nullptr || E == 0;
+    R->col_idx = with_entries ? (int32_t*)std::malloc(std::max<int64_t>(1, E) * sizeof(int32_t)) : nullptr;
+    R->col_code = with_entries ? (uint8_t*)std::malloc(std::max<int64_t>(1, E)) : nullptr;
+    R->n_columns_extracted = cand.n_columns;
+    R->n_columns_downloaded = cand.n_cand;
+    R->n_columns_downloaded_late = cand.n_tie;
+    {
+        const int nb = (int)std::min<int64_t>(std::max<int64_t>(1, S / 4096), 4 * (int64_t)n_threads);
+        parallel_for(nb, n_threads, [&](int blk) {
+            const int64_t a = S * blk / nb, e = S * (blk + 1) / nb;
+            for (int64_t s = a; s < e; ++s) {
+                const hs_colrec& r = snps.rec[s];
+                R->snp_pos[s] = r.pos; R->snp_ref[s] = r.k0; R->snp_alt[s] = r.k1; R->snp_n_ref[s] = r.c0; R->snp_n_alt[s] = r.c1;
             }
-            e += n; s++;
-            R->col_off[s] = e;
-        }
-    });
+            if (S) std::memcpy(R->col_off + a, snps.off + a, (size_t)(e - a) * sizeof(int64_t));
+            if (with_entries && e > a) {
+                const int64_t ea = snps.off[a], ee = snps.off[e];
+                std::memcpy(R->col_idx + ea, snps.idx + ea, (size_t)(ee - ea) * sizeof(int32_t));
+                std::memcpy(R->col_code + ea, snps.code + ea, (size_t)(ee - ea));
+            }
+        });
+        R->col_off[S] = E;
+        if (S == 0) R->col_off[0] = 0;
+    }
     laps.lap("result");
     R->mean_distance = dup_vec(md); R->depth = dup_vec(dp); R->snp_off = dup_vec(snp_off);
     R->error_rate = total_error / n_err_contigs;      // call_variants.cpp:1377 (float / int)
@@ -511,20 +353,63 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const CvSelection& sel, int 
     R->t_device_ms = t_dev_done - t_start;
     R->t_host_ms = now_ms() - t_dev_done;
     if (std::getenv("HS_TIMING"))
-        std::fprintf(stderr, "[hs timing] cv range [%d,%d): gather %.2f ms, host glue %.2f ms (parallel part %.2f); columns: %lld extracted, %lld downloaded, %lld late\n",
-                     c0, c1, t_dev_done - t_start, R->t_host_ms, t_glue_done - t_dev_done, (long long)R->n_columns_extracted,
-                     (long long)R->n_columns_downloaded, (long long)R->n_columns_downloaded_late);
+        std::fprintf(stderr, "[hs timing] cv range [%d,%d): columns + candidates %.2f ms, host glue %.2f ms (up to the SNPs %.2f); columns: %lld extracted, %lld candidates, %lld with tied counts (%lld beyond 16 keys), %lld SNPs\n",
+                     c0, c1, t_dev_done - t_start, R->t_host_ms, t_glue_done - t_dev_done, (long long)cand.n_columns,
+                     (long long)cand.n_cand, (long long)cand.n_tie, (long long)cand.n_tie_big, (long long)S);
     *out = R;
     return HS_OK;
 }
 
 
+// results of two consecutive contig ranges put together (both are consumed); the error rate over all contigs, in contig order
+// (call_variants.cpp:1312-1315,1377)
+hs_cv_result* cv_concat_results(hs_cv_result* a, hs_cv_result* b) {
+    hs_cv_result* R = (hs_cv_result*)std::calloc(1, sizeof(hs_cv_result));
+    const int Ca = a->n_contigs, Cb = b->n_contigs, C = Ca + Cb;
+    const int64_t Sa = a->snp_off[Ca], Sb = b->snp_off[Cb], S = Sa + Sb;
+    const int64_t Ea = a->col_off[Sa], Eb = b->col_off[Sb], E = Ea + Eb;
+    R->n_contigs = C;
+    R->mean_distance = (float*)std::malloc(std::max(1, C) * sizeof(float)); R->depth = (float*)std::malloc(std::max(1, C) * sizeof(float));
+    R->snp_off = (int64_t*)std::malloc(((size_t)C + 1) * sizeof(int64_t));
+    R->snp_pos = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t));
+    R->snp_ref = (uint8_t*)std::malloc(std::max<int64_t>(1, S)); R->snp_alt = (uint8_t*)std::malloc(std::max<int64_t>(1, S));
+    R->snp_n_ref = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t)); R->snp_n_alt = (int32_t*)std::malloc(std::max<int64_t>(1, S) * sizeof(int32_t));
+    R->col_off = (int64_t*)std::malloc(((size_t)S + 1) * sizeof(int64_t));
+    const bool with_entries = (a->col_idx || Ea == 0) && (b->col_idx || Eb == 0);
+    R->col_idx = with_entries ? (int32_t*)std::malloc(std::max<int64_t>(1, E) * sizeof(int32_t)) : nullptr;
+    R->col_code = with_entries ? (uint8_t*)std::malloc(std::max<int64_t>(1, E)) : nullptr;
+    float total_error = 0; int n_err = 0;
+    auto put = [&](const hs_cv_result* r, int cbase, int64_t sbase, int64_t ebase) {
+        const int Cr = r->n_contigs; const int64_t Sr = r->snp_off[Cr], Er = r->col_off[Sr];
+        for (int c = 0; c < Cr; ++c) {
+            R->mean_distance[cbase + c] = r->mean_distance[c]; R->depth[cbase + c] = r->depth[c];
+            if (r->mean_distance[c] > 0) { total_error += r->mean_distance[c]; n_err++; }
+            R->snp_off[cbase + c] = sbase + r->snp_off[c];
+        }
+        if (Sr) {
+            std::memcpy(R->snp_pos + sbase, r->snp_pos, (size_t)Sr * sizeof(int32_t)); std::memcpy(R->snp_ref + sbase, r->snp_ref, (size_t)Sr); std::memcpy(R->snp_alt + sbase, r->snp_alt, (size_t)Sr);
+            std::memcpy(R->snp_n_ref + sbase, r->snp_n_ref, (size_t)Sr * sizeof(int32_t)); std::memcpy(R->snp_n_alt + sbase, r->snp_n_alt, (size_t)Sr * sizeof(int32_t));
+        }
+        for (int64_t q = 0; q < Sr; ++q) R->col_off[sbase + q] = ebase + r->col_off[q];
+        if (with_entries && Er) { std::memcpy(R->col_idx + ebase, r->col_idx, (size_t)Er * sizeof(int32_t)); std::memcpy(R->col_code + ebase, r->col_code, (size_t)Er); }
+        R->t_device_ms += r->t_device_ms; R->t_host_ms += r->t_host_ms;
+        for (int k = 0; k < 4; ++k) R->t_kernel_ms[k] += r->t_kernel_ms[k];
+        R->t_kernel_k4_ms += r->t_kernel_k4_ms;
+        R->n_columns_extracted += r->n_columns_extracted; R->n_columns_downloaded += r->n_columns_downloaded; R->n_columns_downloaded_late += r->n_columns_downloaded_late;
+    };
+    put(a, 0, 0, 0); put(b, Ca, Sa, Ea);
+    R->snp_off[C] = S; R->col_off[S] = E;
+    R->error_rate = total_error / n_err; R->n_contigs_with_error_rate = n_err;
+    free_cv_result(a); free_cv_result(b);
+    return R;
+}
+
 int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int n_threads, hs_cv_result** out) {
     CvSelection sel;
-    if (int rc = cv_select(dev, b, sel)) return rc;
-    if (int rc = cv_run_range(dev, b, sel, 0, b.n_contigs, automatic_snp_threshold, n_threads, out)) return rc;
+    if (int rc = cv_pileup(dev, b, sel)) return rc;
+    if (int rc = cv_run_range(dev, b, sel.rec_stats, 0, b.n_contigs, automatic_snp_threshold, n_threads, out)) return rc;
     hs_cv_result* R = *out;
-    R->t_kernel_ms[0] = sel.k_ms[0]; R->t_kernel_ms[1] = sel.k_ms[1]; R->t_kernel_ms[3] = sel.k_ms[3];
+    R->t_kernel_ms[0] = sel.k_ms[0]; R->t_kernel_ms[3] = sel.k_ms[3];
     R->t_device_ms += sel.t_device_ms; R->t_host_ms += sel.t_host_ms;
     return HS_OK;
 }

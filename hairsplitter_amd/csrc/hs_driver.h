@@ -21,20 +21,40 @@ struct CvMeta {                       // host-side description of a stage-3 batc
     std::vector<int32_t> ploidy;          // [C] or empty: ploidy of the contigs for the stage 3 -> 4 hand-over (0 = none)
 };
 
-// K4 input: the extracted columns (still resident on the device after gather()) with their exact top-2 codes, and the
-// final partitions of every contig as dense per-read state arrays (2 = read not in the partition)
+// K4 input: the final partitions of every contig of a range as dense per-read state arrays (2 = read not in the partition)
 struct CvPartitionTest {
-    std::vector<int32_t> col_contig, col_c1;
-    std::vector<uint8_t> col_k0, col_k1, col_is_cand;
     std::vector<int32_t> contig_n_reads;    // [C]
     std::vector<int32_t> part_off;          // [C+1] range of partitions of each contig
     std::vector<int64_t> part_state_off;    // [sum F] offset of each partition's state array
     std::vector<int8_t> part_state;
 };
 
+// What the device hands to the host in the middle of stage 3: the candidate columns of a contig range (call_variants.cpp:525-536),
+// contig by contig, position order inside a contig. The arrays belong to the implementation and stay valid until its next call.
+struct CvCandidates {
+    int64_t n_columns = 0, n_entries = 0;    // columns extracted for the range (second count >= 4: everything that can become a SNP) -- they stay with the implementation
+    int64_t n_tie = 0, n_tie_big = 0;        // of those, columns whose two leading codes needed the reference's order of equal counts / std::sort beyond 16 keys
+    std::vector<int32_t> contig_n_cand;      // [C]
+    int64_t n_cand = 0;
+    const hs_colrec* rec = nullptr;          // [n_cand]
+    const int32_t* col = nullptr;            // [n_cand] index of the candidate in the implementation's column list
+    const int64_t* off = nullptr;            // [n_cand + 1]
+    const int32_t* idx = nullptr;            // read indices (ascending inside a column)
+    const uint8_t* code = nullptr;
+};
+// ... and at its end: the SNPs (call_variants.cpp:1335-1352), same layout; idx / code only when they were asked for
+struct CvSnpSet {
+    std::vector<int32_t> contig_n_snp;       // [C]
+    int64_t n_snp = 0, n_entries = 0;
+    const hs_colrec* rec = nullptr;
+    const int64_t* off = nullptr;            // [n_snp + 1]
+    const int32_t* idx = nullptr;
+    const uint8_t* code = nullptr;
+};
+
 struct CvLoopA {
     std::vector<int64_t> cand_off;             // [C+1] candidates per contig
-    std::vector<int32_t> cand_col, cand_pos;   // column (index in the last gather) and position of every candidate, position order
+    std::vector<int32_t> cand_col, cand_pos;   // column (index in the implementation's column list) and position of every candidate, position order
     std::vector<uint8_t> cand_ref;             // its reference code (k0)
     std::vector<int32_t> contig_n_reads;       // [C]
     std::vector<int64_t> read_off;             // [C+1] into read_end
@@ -49,57 +69,41 @@ struct CvLoopAResult {
     const int32_t* less = nullptr;
 };
 
+// The device side of stage 3. One object serves one range of contigs at a time: pileup() once per batch, then per range
+// extract_candidates() -> [robust_partitions()] -> finish_columns().
 struct CvDeviceOps {
     virtual ~CvDeviceOps() {}
-    // K0+K1 + K2: per-record {q_end, n_err, n_len, n_events}; the global positions (unordered) whose second count c1 is
-    // > min_second, or == min_second with a zero third count, with their depth; k_ms = {cigar scan + pileup, column_stats}
-    // k_ms[3] = cigar scan alone (k_ms[0] then is the pileup kernel alone)
-    // The selection arrays are owned by the implementation (pinned staging of the download) and stay valid until the next call.
-    virtual int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, const int64_t** sel_gpos,
-                                  const int32_t** sel_depth, size_t* n_sel, float k_ms[4]) = 0;
-    // K3: columns of the selected positions (they stay on the device for K4 and fetch_columns), and K3b: their top-3
-    // (tie = 1: the host must resolve the column in the reference's tie order). `top` is owned by the implementation and
-    // stays valid until the next gather call or its destruction
-    virtual int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos,
-                       const std::vector<int64_t>& col_off, const hs_coltop** top, float* k_ms) = 0;
-    // K3c: the listed columns of the last gather() packed back to back on the host: column cols[k] at
-    // [packed_off[k], packed_off[k+1]). Two result slots (0, 1) that stay valid until the next gather / fetch of that slot
-    virtual int fetch_columns(const std::vector<int32_t>& cols, const std::vector<int64_t>& packed_off, int slot,
-                              const int32_t** col_idx, const uint8_t** col_code) = 0;
-    // K4: loops C and D of keep_only_robust_variants on the columns of the last gather(); keep[i] for column i
-    virtual int column_partition_test(const CvPartitionTest& t, std::vector<uint8_t>& keep, float* k_ms) = 0;
-    // The streaming pass in two parts, for callers that work through the batch in ranges of contigs: pileup() = K0 + K1 over
-    // the whole batch (per-record counters back), select_range() = K2 + selection for the global positions [g0, g1) only
-    // (sorted; positions of the neighbouring ranges from the boundary tiles may be included). Optional.
-    virtual bool has_select_range() const { return false; }
-    virtual int pileup(std::vector<int32_t>& rec_stats, float k_ms[4]) { (void)rec_stats; (void)k_ms; return -1; }
-    virtual int select_range(int64_t g0, int64_t g1, int min_second, const int64_t** sel_gpos, const int32_t** sel_depth, size_t* n_sel, float* k_ms) {
-        (void)g0; (void)g1; (void)min_second; (void)sel_gpos; (void)sel_depth; (void)n_sel; (void)k_ms; return -1;
-    }
-    // Loop A of keep_only_robust_variants (call_variants.cpp:590-638) on the columns of the last gather(), contig by contig.
+    // K0 + K1 over the whole batch: per-record {q_end, n_err, n_len, n_events}; k_ms = {pileup, -, -, cigar scan}
+    virtual int pileup(std::vector<int32_t>& rec_stats, float k_ms[4]) = 0;
+    // K2 -> K3 -> K3b -> V1 for the contigs [c0, c1): every position whose second count is >= 4 becomes a column (it stays with the
+    // implementation), its two leading codes are named in the reference's order, the candidates are chosen (min_reads[c - c0] = 3 or 5,
+    // call_variants.cpp:463-466) and packed for the host. k_ms = {column statistics, gather, top-3 + candidates}
+    virtual int extract_candidates(int c0, int c1, const std::vector<int32_t>& min_reads, float automatic_snp_threshold, CvCandidates& out,
+                                   float k_ms[3]) = 0;
+    // K4 (loops C and D of keep_only_robust_variants on the extracted columns against the final partitions) and the merge of the
+    // automatic and the filtered SNPs; want_entries = false leaves idx / code of the result null (the SNP columns stay with the
+    // implementation for stage 4: take_snp_columns)
+    virtual int finish_columns(const CvPartitionTest& t, bool want_entries, CvSnpSet& out, float* k_ms) = 0;
+    // Loop A of keep_only_robust_variants (call_variants.cpp:590-638) on the candidate columns, contig by contig.
     // Optional: an implementation without it leaves the loop to the host (cv_phase_a_host). The result arrays are owned by
     // the implementation and stay valid until the next call.
     virtual bool has_robust_partitions() const { return false; }
     virtual int robust_partitions(const CvLoopA& in, CvLoopAResult& out, float* k_ms) { (void)in; (void)out; (void)k_ms; return -1; }
 };
 
-// result of the whole-batch streaming pass (K0-K2): per-record counters and the interesting positions by (contig, position)
+// result of the whole-batch streaming pass (K0 + K1): the per-record counters
 struct CvSelection {
     std::vector<int32_t> rec_stats;
-    std::vector<int32_t, NoInitAlloc<int32_t>> sel_contig, sel_pos, sel_depth;   // every element is written right after the resize
-    std::vector<int64_t> contig_sel_off;   // [C+1]
-    float k_ms[4] = {0, 0, 0, 0};          // pileup, column_stats, -, cigar_scan
+    float k_ms[4] = {0, 0, 0, 0};          // pileup, -, -, cigar_scan
     double t_device_ms = 0, t_host_ms = 0;
 };
-int cv_select(CvDeviceOps& dev, const CvMeta& meta, CvSelection& sel);
-// the same in two parts: cv_pileup fills sel.rec_stats (K0 + K1 of the whole batch), cv_select_range the selection of the contigs
-// [c0, c1) alone (contig_sel_off is [C+1] as always, zero-based at c0; the arrays hold that range only)
 int cv_pileup(CvDeviceOps& dev, const CvMeta& meta, CvSelection& sel);
-int cv_select_range(CvDeviceOps& dev, const CvMeta& meta, int c0, int c1, CvSelection& sel);
-// rec_stats: the per-record counters of the batch when `sel` does not carry them (a range selection)
-int cv_run_range(CvDeviceOps& dev, const CvMeta& meta, const CvSelection& sel, int c0, int c1, float automatic_snp_threshold, int n_threads,
-                 hs_cv_result** out, const std::vector<int32_t>* rec_stats = nullptr);
+// stage 3 for the contigs [c0, c1) on top of the pileup; `resident` (optional): the SNP columns are not downloaded into the result
+// (col_idx / col_code stay null) because the caller hands them to stage 4 on the device
+int cv_run_range(CvDeviceOps& dev, const CvMeta& meta, const std::vector<int32_t>& rec_stats, int c0, int c1, float automatic_snp_threshold, int n_threads,
+                 hs_cv_result** out, bool resident = false);
 int cv_run(CvDeviceOps& dev, const CvMeta& meta, float automatic_snp_threshold, int n_threads, hs_cv_result** out);
+hs_cv_result* cv_concat_results(hs_cv_result* a, hs_cv_result* b);   // two consecutive contig ranges (both consumed)
 
 // Every clustering window of a stage-4 call, each in its own LOCAL index space: node j of window w is the read
 // mask_ids[win_row0[w] + j] (ascending inside a window). "Row" = (window, node); the read graphs of the call are ONE CSR

@@ -15,52 +15,38 @@ namespace hs {
 void set_error(const std::string& msg);
 
 // ---- stage 3 ---------------------------------------------------------------------------------
-// Columns of the "interesting" positions of one contig (second-most frequent code seen >= 4 times), CSR.
-struct ColumnSet {
-    std::vector<int32_t> pos;        // ascending
-    std::vector<int64_t> off;        // [n+1] into idx / code; only the columns cv_column_needed_on_host() flags carry entries
+// The candidate columns of one contig (call_variants.cpp:525-536), position order: views into what the device handed over
+// (the device extracts the columns, names their two leading codes in the reference's order and runs the spacing scan).
+struct CandidateSet {
+    int n = 0;
+    const hs_colrec* rec = nullptr;  // [n] position, codes k0 / k1, counts
+    const int64_t* off = nullptr;    // [n+1] into idx / code
     const int32_t* idx = nullptr;    // read indices (ascending inside a column)
     const uint8_t* code = nullptr;
-    const hs_coltop* top = nullptr;  // device top-3 of every column (K3b); tie = 1 -> resolved here in the reference's order
-    // exact top-3 of call_variants.cpp:497-507 (reference tie order), filled by resolve_columns()
-    std::vector<uint8_t> k0, k1;
-    std::vector<int32_t> c0, c1, c2;
 };
 
 struct ContigCvResult {
     float mean_distance = 0;
     float depth = 0;
-    std::vector<int32_t> snp_col;    // indices into ColumnSet (merged output, ascending position)
     // diagnostics
-    int n_candidates = 0, n_automatic = 0, n_partitions = 0, n_final_partitions = 0, n_filtered = 0;
+    int n_candidates = 0, n_partitions = 0, n_final_partitions = 0;
 };
 
-// true if the host walks the entries of this column: its top-3 needs the reference's tie order, or it can become a
-// candidate SNP (the position-independent part of call_variants.cpp:525-536 with the smaller of the two read minima)
-bool cv_column_needed_on_host(const hs_coltop& t);
-void resolve_columns(ColumnSet& cs, int first, int last);   // columns [first, last); the k/c arrays must be sized
 struct CvContigState;   // per-contig state between the phases of the stage-3 glue (hs_host_cv.cpp)
 CvContigState* cv_state_new();
 void cv_state_free(CvContigState* st);
+// The host part of keep_only_robust_variants in steps: loop A on the host (cv_phase_a_host) or imported from the device
+// (k_robust_partitions -> cv_phase_a_import), then loop B (cv_phase_b); the final partitions leave for loops C / D on the device.
 // read_start / read_end: [n_reads] reference interval [start, end) of every record of the contig (POS-1, POS-1 + reference span)
-void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out,
-                 const int32_t* read_start, const int32_t* read_end);
-// The same in steps, for the driver that runs loop A on the device (k_robust_partitions):
-//   cv_phase_v1 (candidates) -> [device loop A -> cv_phase_a_import] or cv_phase_a_host -> cv_phase_b
 struct CvPartRecord { int32_t left, right, n_occ, n_corr, lo, hi, reach, pad; int64_t elem; };   // what k_partitions_pack writes per partition
-void cv_phase_v1(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out);
-const std::vector<int>& cv_candidates(const CvContigState& st);   // candidate columns (indices into the ColumnSet), ascending position
-void cv_phase_a_host(CvContigState& st, ColumnSet& cs, const int32_t* read_start, const int32_t* read_end);
+void cv_phase_begin(CvContigState& st, int n_reads, int n_candidates, float mean_distance, ContigCvResult& out);
+void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* read_start, const int32_t* read_end);
 void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const int8_t* pool_state,
                        const int32_t* pool_more, const int32_t* pool_less);
 void cv_phase_b(CvContigState& st, ContigCvResult& out);
-// exports the final partitions / candidate flags for the device test (K4) and imports its verdict
 int cv_final_partitions(const CvContigState& st);
 // the final partitions' dense state arrays (n_reads bytes each) written at `state`, their offsets (state_base + ...) at state_off
 void cv_export_partitions(const CvContigState& st, int8_t* state, int64_t state_base, int64_t* state_off);
-void cv_export_candidates(const CvContigState& st, uint8_t* is_cand);
-void cv_import_keep(CvContigState& st, const uint8_t* keep);
-void cv_phase_merge(CvContigState& st, const ColumnSet& cs, ContigCvResult& out);
 
 // generate_msa's return value from the integer event counts of the pileup kernel (call_variants.cpp:67-68,434)
 float mean_distance_from_counts(int64_t n_err, int64_t n_len);

@@ -1,9 +1,10 @@
 // hs_host_cv.cpp -- sequential glue of stage 3 (HS_call_variants) over dense per-read arrays.
 //
-// The device produces the pileup, the per-position code statistics and the columns of the few positions
-// that can matter (second allele seen >= 4 times). What is left is the reference's inherently sequential
-// logic: the greedy spacing scan (call_variants.cpp:525-536), the evolving set of partitions of
-// keep_only_robust_variants (:577-768) and the final two-pointer merge (:1335-1352).
+// The device produces the pileup, the per-position code statistics, the columns of the few positions that can matter
+// (second allele seen >= 4 times) with their leading codes in the reference's order, the candidate SNPs (the greedy spacing
+// scan of call_variants.cpp:525-536), and at the end loops C / D and the merge of the SNP lists (:721-764, :1335-1352).
+// What is left here is the reference's inherently sequential logic in between: the evolving set of partitions of
+// keep_only_robust_variants (loops A and B, :577-708), whose decisions go through libm (lgamma / exp / log).
 //
 // Representation: a partition is three dense arrays over the contig's N reads (state, more, less) instead of
 // the reference's sorted sparse lists, so comparing a column with a partition costs O(column depth) instead of
@@ -66,33 +67,6 @@ float mean_distance_from_counts(int64_t n_err, int64_t n_len) {
     float total_distance = n_err > 16777216 ? 16777216.0f : (float)n_err;
     double total_length = 1.0 + (double)n_len;
     return (float)(total_distance / total_length);
-}
-
-// ---- exact (reference tie order) top-3 of a column: call_variants.cpp:477-507 -------------------------
-static void exact_top3(const uint8_t* code, int n, uint8_t& k0, uint8_t& k1, int& c0, int& c1, int& c2) {
-    int cnt[256];
-    std::memset(cnt, 0, sizeof(cnt));
-    Rh8 rh; rh.clear();
-    for (int i = 0; i < n; ++i) { rh.insert(code[i]); if (code[i] != ' ') cnt[code[i]]++; }
-    rh.insert(0); rh.insert(1); rh.insert(2);
-    uint8_t ord[260];
-    const int m = rh.order(ord);
-    std::pair<uint8_t, int> v[260];   // (same std::sort call on the same sequence as the reference's vector: same arrangement of equal counts)
-    for (int i = 0; i < m; ++i) v[i] = std::make_pair(ord[i], cnt[ord[i]]);
-    std::sort(v, v + m, [](const std::pair<uint8_t, int>& a, const std::pair<uint8_t, int>& b) { return a.second > b.second; });
-    k0 = v[0].first; k1 = v[1].first; c0 = v[0].second; c1 = v[1].second; c2 = v[2].second;
-}
-
-void resolve_columns(ColumnSet& cs, int first, int last) {
-    for (int i = first; i < last; ++i) {
-        if (cs.top && !cs.top[i].tie) {   // all three counts distinct: no order of equal keys involved
-            cs.k0[(size_t)i] = cs.top[i].k0; cs.k1[(size_t)i] = cs.top[i].k1;
-            cs.c0[(size_t)i] = cs.top[i].c0; cs.c1[(size_t)i] = cs.top[i].c1; cs.c2[(size_t)i] = cs.top[i].c2;
-            continue;
-        }
-        exact_top3(cs.code + cs.off[(size_t)i], (int)(cs.off[(size_t)i + 1] - cs.off[(size_t)i]), cs.k0[(size_t)i], cs.k1[(size_t)i],
-                   cs.c0[(size_t)i], cs.c1[(size_t)i], cs.c2[(size_t)i]);
-    }
 }
 
 // most frequent non-reference code among `codes` restricted to the entries flagged in `take`
@@ -499,55 +473,22 @@ static void merge_partitions(DensePartition& a, const DensePartition& b, short p
     a.n_occ += b.n_occ;
 }
 
-static inline bool central_base_test(int k0, int k1) {
-    // call_variants.cpp:527-528 and :751-752 (same predicate on raw code bytes)
-    return k0 % 5 != k1 % 5 && ((k1 - '!') % 5 != 4 || (k1 / 5 % 5 != k0 % 5 && k1 / 25 % 5 != k0 % 5));
-}
-
-bool cv_column_needed_on_host(const hs_coltop& t) {
-    if (t.tie) return true;                                  // exact_top3() reads the column
-    // min_reads is 3 or 5 (:463-466): every candidate of either setting passes this
-    return t.c1 > 3 && t.c1 > t.c2 * 5 && central_base_test(t.k0, t.k1);
-}
-
-// Stage-3 glue in three phases so that the embarrassingly parallel part (loops C and D: one independent decision per
-// extracted column) can be spread over all worker threads instead of one thread per contig.
+// Per-contig state of the stage-3 glue between its steps (loop A -> loop B -> export of the final partitions)
 struct CvContigState {
-    int n_reads = 0;
-    float mean_distance = 0, threshold = 0;
-    std::vector<int> cand, automatic;
+    int n_reads = 0, n_candidates = 0;
+    float mean_distance = 0;
     std::vector<DensePartition> parts;   // what loop A leaves (host loop or imported from the device)
     std::vector<int32_t> rank_of, orig_of;   // reads ranked by start position (ties by index): the bit order of the bit sets
     std::vector<DensePartition> finals;
-    std::vector<char> is_cand, keep;     // per extracted column
-    bool have_partitions = false;
 };
 
 CvContigState* cv_state_new() { return new CvContigState(); }
 void cv_state_free(CvContigState* st) { delete st; }
 
-// V1 scan (call_variants.cpp:525-536): the candidate and the "automatic" columns of a contig
-void cv_phase_v1(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out) {
-    st.n_reads = n_reads; st.mean_distance = mean_distance; st.threshold = automatic_snp_threshold;
-    const int n_cols = (int)cs.pos.size();
-    const int min_reads = mean_distance < 0.015 ? 3 : 5;                       // :463-466
-    st.is_cand.assign((size_t)n_cols, 0); st.keep.assign((size_t)n_cols, 0);
-    std::vector<int>& cand = st.cand; std::vector<int>& automatic = st.automatic;
-    cand.clear(); automatic.clear();
-    int pos_of_last = -5;
-    for (int i = 0; i < n_cols; ++i) {
-        const int k0 = cs.k0[i], k1 = cs.k1[i];
-        if (cs.c1[i] > min_reads && cs.c1[i] > cs.c2[i] * 5 && central_base_test(k0, k1) && cs.pos[i] - pos_of_last > 5) {
-            if ((float)cs.c1[i] > automatic_snp_threshold * (float)cs.c0[i]) automatic.push_back(i);
-            pos_of_last = cs.pos[i];
-            cand.push_back(i);
-            st.is_cand[(size_t)i] = 1;
-        }
-    }
-    out.n_candidates = (int)cand.size();
-    out.n_automatic = (int)automatic.size();
+void cv_phase_begin(CvContigState& st, int n_reads, int n_candidates, float mean_distance, ContigCvResult& out) {
+    st.n_reads = n_reads; st.n_candidates = n_candidates; st.mean_distance = mean_distance;
+    out.n_candidates = n_candidates;
 }
-const std::vector<int>& cv_candidates(const CvContigState& st) { return st.cand; }
 
 static void rank_reads(CvContigState& st, const int32_t* read_start) {
     const int n_reads = st.n_reads;
@@ -559,12 +500,11 @@ static void rank_reads(CvContigState& st, const int32_t* read_start) {
 }
 
 // loop A (:590-638) on the host: sequential over the candidate columns of the contig
-void cv_phase_a_host(CvContigState& st, ColumnSet& cs, const int32_t* read_start, const int32_t* read_end) {
+void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* read_start, const int32_t* read_end) {
     const int n_reads = st.n_reads;
     auto col_idx = [&](int i) { return cs.idx + cs.off[i]; };
     auto col_code = [&](int i) { return cs.code + cs.off[i]; };
     auto col_n = [&](int i) { return (int)(cs.off[i + 1] - cs.off[i]); };
-    const std::vector<int>& cand = st.cand;
     const bool tim = std::getenv("HS_TIMING_AB") != nullptr;
     auto nowus = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a0 = tim ? nowus() : 0;
@@ -576,8 +516,9 @@ void cv_phase_a_host(CvContigState& st, ColumnSet& cs, const int32_t* read_start
     rank_reads(st, read_start);
     const std::vector<int32_t>& rank_of = st.rank_of; const std::vector<int32_t>& orig_of = st.orig_of;
     int last_position = -5;
-    for (int ci : cand) {
-        const int pos = cs.pos[ci];
+    for (int ci = 0; ci < cs.n; ++ci) {
+        const int pos = cs.rec[ci].pos;
+        const uint8_t k0 = cs.rec[ci].k0;
         if (pos - last_position <= 5) continue;
         const int32_t* idx = col_idx(ci); const uint8_t* code = col_code(ci); const int n = col_n(ci);
         bool found = false;
@@ -590,11 +531,11 @@ void cv_phase_a_host(CvContigState& st, ColumnSet& cs, const int32_t* read_start
             // no read of the partition reaches this position: nothing is shared, the comparison yields "not comparable", which
             // neither correlates nor matches (:817-828) -- skipped without looking at the bit sets
             if (pos >= parts[p].reach) continue;
-            const Contingency d = column_vs_partition_bits(parts[p], colbits, cs.k0[ci], orig_of.data());
+            const Contingency d = column_vs_partition_bits(parts[p], colbits, k0, orig_of.data());
             n_cmp++;
 #ifdef HS_SELFCHECK
             {
-                const Contingency e = column_vs_partition(parts[p], idx, code, n, cs.k0[ci]);
+                const Contingency e = column_vs_partition(parts[p], idx, code, n, k0);
                 if (e.n00 != d.n00 || e.n01 != d.n01 || e.n10 != d.n10 || e.n11 != d.n11 || e.comparable != d.comparable || e.second != d.second) {
                     // the bit-set form leaves the counts at zero where they cannot matter (few shared reads): the entry walk must
                     // then say "no correlation, no fit" as well
@@ -625,12 +566,12 @@ void cv_phase_a_host(CvContigState& st, ColumnSet& cs, const int32_t* read_start
         }
         if (!found) {
             parts.emplace_back();
-            partition_from_column(parts.back(), n_reads, idx, code, n, pos, cs.k0[ci], rank_of.data(), read_end);
+            partition_from_column(parts.back(), n_reads, idx, code, n, pos, k0, rank_of.data(), read_end);
             parts.back().n_corr = n_corr;
         } else last_position = pos;
     }
     if (tim) std::fprintf(stderr, "[hs timing] loop A: %d candidates, %zu partitions, %ld comparisons, %ld augmentations; %.0f us (build %.0f, augment %.0f)\n",
-                          (int)cand.size(), parts.size(), n_cmp, n_aug, nowus() - t_a0, t_build, t_aug);
+                          cs.n, parts.size(), n_cmp, n_aug, nowus() - t_a0, t_build, t_aug);
 }
 
 // loop A ran on the device (k_robust_partitions): its partitions become the host's dense form
@@ -664,11 +605,10 @@ void cv_phase_b(CvContigState& st, ContigCvResult& out) {
     std::vector<DensePartition>& parts = st.parts;
     const float mean_distance = st.mean_distance;
     out.n_partitions = (int)parts.size();
-    st.have_partitions = !parts.empty();
     if (parts.empty()) return;
     std::vector<DensePartition>& finals = st.finals;
     for (size_t p1 = 0; p1 < parts.size(); ++p1) {
-        const double p_value = significance(parts[p1], (int)st.cand.size());
+        const double p_value = significance(parts[p1], st.n_candidates);
         if (!((p_value < 0.001 || parts[p1].n_corr > 1) && is_informative(parts[p1], mean_distance))) continue;
         bool different = true;
         for (size_t p2 = 0; p2 < finals.size(); ++p2) {
@@ -697,16 +637,8 @@ void cv_phase_b(CvContigState& st, ContigCvResult& out) {
     std::vector<DensePartition>().swap(parts);
 }
 
-// V1 scan + loops A and B on the host (sequential per contig): call_variants.cpp:525-536, :590-708
-void cv_phase_ab(CvContigState& st, int n_reads, ColumnSet& cs, float mean_distance, float automatic_snp_threshold, ContigCvResult& out,
-                 const int32_t* read_start, const int32_t* read_end) {
-    cv_phase_v1(st, n_reads, cs, mean_distance, automatic_snp_threshold, out);
-    cv_phase_a_host(st, cs, read_start, read_end);
-    cv_phase_b(st, out);
-}
-
-// Loops C (:721-738) and D (:745-764) run on the device (k_column_partition_test): the final partitions leave as dense
-// state arrays, the verdict per extracted column comes back.
+// Loops C (:721-738) and D (:745-764) and the merge of the two SNP lists (:1335-1352) run on the device: the final partitions
+// leave as dense state arrays.
 int cv_final_partitions(const CvContigState& st) { return (int)st.finals.size(); }
 void cv_export_partitions(const CvContigState& st, int8_t* state, int64_t state_base, int64_t* state_off) {
     int64_t o = 0;
@@ -717,27 +649,4 @@ void cv_export_partitions(const CvContigState& st, int8_t* state, int64_t state_
         o += (int64_t)p.state.size();
     }
 }
-void cv_export_candidates(const CvContigState& st, uint8_t* is_cand) {
-    for (size_t i = 0; i < st.is_cand.size(); ++i) is_cand[i] = (uint8_t)st.is_cand[i];
-}
-void cv_import_keep(CvContigState& st, const uint8_t* keep) {
-    for (size_t i = 0; i < st.keep.size(); ++i) st.keep[i] = (st.have_partitions && keep[i]) ? 1 : 0;
-}
-
-// two-pointer union of automatic and filtered SNPs that stops when either list ends (:1335-1352)
-void cv_phase_merge(CvContigState& st, const ColumnSet& cs, ContigCvResult& out) {
-    std::vector<int> filtered;
-    for (int i = 0; i < (int)st.keep.size(); ++i) if (st.keep[(size_t)i]) filtered.push_back(i);
-    out.n_filtered = (int)filtered.size();
-    const std::vector<int>& automatic = st.automatic;
-    size_t ia = 0, ifi = 0;
-    out.snp_col.clear();
-    while (ia < automatic.size() && ifi < filtered.size()) {
-        const int pa = cs.pos[automatic[ia]], pf = cs.pos[filtered[ifi]];
-        if (pa < pf) { out.snp_col.push_back(automatic[ia]); ia++; }
-        else if (pa > pf) { out.snp_col.push_back(filtered[ifi]); ifi++; }
-        else { out.snp_col.push_back(automatic[ia]); ia++; ifi++; }
-    }
-}
-
 }  // namespace hs

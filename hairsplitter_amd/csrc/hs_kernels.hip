@@ -577,7 +577,8 @@ __global__ __launch_bounds__(256) void k_pileup_flagged_records(
 template <int CB, bool FULL>
 static __device__ __forceinline__ void column_stats_tail(const uint32_t* __restrict__ hw, int tid, int lane, int64_t g, int64_t total,
                                                          hs_colstat_dev* __restrict__ stats, int min_second, int32_t* __restrict__ sel_count,
-                                                         int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int sel_cap) {
+                                                         int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int sel_cap,
+                                                         int64_t g_lo = 0, int64_t g_hi = 0x7fffffffffffffffll, int32_t* __restrict__ sel_ent = nullptr) {
     constexpr int PER_WORD = 4 / CB;
     constexpr int NWORDS = (HS_NBINS + PER_WORD - 1) / PER_WORD;
     int k0 = 0, k1 = 0, k2 = 0, k3 = 0;
@@ -655,11 +656,14 @@ static __device__ __forceinline__ void column_stats_tail(const uint32_t* __restr
         // hold there). Every tile owns 256 slots of a scratch list and writes its selected positions there in lane order with
         // its count (no global atomic: ten thousand returning atomics on one counter cost more than the histogram itself);
         // k_selection_compact then packs the tiles in order, so the list comes out sorted by position.
-        __shared__ int s_wc[4];
-        const bool sel = g < total && (c1 > min_second || (c1 == min_second && c2 == 0));
+        // [g_lo, g_hi): the positions of the caller's contig range (a boundary tile also holds positions of its neighbours);
+        // sel_ent (optional): entries of the tile's selected columns = sum of their depths
+        __shared__ int s_wc[4], s_we[4];
+        const bool sel = g < total && g >= g_lo && g < g_hi && (c1 > min_second || (c1 == min_second && c2 == 0));
         const unsigned long long m = __ballot(sel);
         const int wv = tid >> 6;
         if (lane == 0) s_wc[wv] = __popcll(m);
+        if (sel_ent) { const int we = wave_sum_i32(sel ? depth : 0); if (lane == 0) s_we[wv] = we; }
         __syncthreads();
         int base = 0;
         for (int w = 0; w < wv; ++w) base += s_wc[w];
@@ -668,7 +672,7 @@ static __device__ __forceinline__ void column_stats_tail(const uint32_t* __restr
             const int64_t slot = tile0 + base + __popcll(m & ((1ull << lane) - 1ull));
             sel_gpos[slot] = g; sel_depth[slot] = depth;
         }
-        if (tid == 0) sel_count[blockIdx.x] = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+        if (tid == 0) { sel_count[blockIdx.x] = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3]; if (sel_ent) sel_ent[blockIdx.x] = s_we[0] + s_we[1] + s_we[2] + s_we[3]; }
     }
 }
 
@@ -785,7 +789,8 @@ template <int CB, bool FULL>
 __global__ __launch_bounds__(256) void k_column_stats_tiled(
     const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, int64_t total,
     hs_colstat_dev* __restrict__ stats, int min_second, int32_t* __restrict__ sel_count, int64_t* __restrict__ sel_gpos,
-    int32_t* __restrict__ sel_depth, int sel_cap, int64_t tile0 /* first tile of the launch: the selection scratch is indexed from it */) {
+    int32_t* __restrict__ sel_depth, int sel_cap, int64_t tile0 /* first tile of the launch: the selection scratch is indexed from it */,
+    int64_t g_lo, int64_t g_hi, int32_t* __restrict__ sel_ent) {
     constexpr int PER_WORD = 4 / CB;
     constexpr int NWORDS = (HS_NBINS + PER_WORD - 1) / PER_WORD;
     __shared__ uint32_t hw[NWORDS * 256];
@@ -823,7 +828,7 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled(
             for (int u = 0; u < HS_K2_INFLIGHT; ++u) bump(code[u], in_[u] && code[u] < (unsigned)HS_NBINS);
         }
     }
-    column_stats_tail<CB, FULL>(hw, tid, lane, g, total, stats, min_second, sel_count, sel_gpos, sel_depth, sel_cap);
+    column_stats_tail<CB, FULL>(hw, tid, lane, g, total, stats, min_second, sel_count, sel_gpos, sel_depth, sel_cap, g_lo, g_hi, sel_ent);
 }
 
 // ------------------------------------------------------------------------------------------------

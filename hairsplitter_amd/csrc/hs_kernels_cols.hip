@@ -1,0 +1,437 @@
+// hs_kernels_cols.hip -- the column pass of stage 3 kept on the device from the pileup to the candidate SNPs and from the
+// final partitions to the SNP columns stage 4 reads (call_variants.cpp:471-536 and :721-764, :1335-1352). The host sees two
+// things only: the candidate columns (loops A and B of keep_only_robust_variants are sequential per contig and go through
+// libm, hs_host_cv.cpp) and the SNPs that come out.
+//
+//   k_columns_compact     K2's per-tile selections -> the sorted column list of a contig range with its CSR offsets
+//   k_gather_tiles        K3: one wavefront per 256-position tile; the tile's pileup bytes are staged in LDS row by row
+//                         (one coalesced 256-byte row per record) and every selected position reads its column out of
+//                         LDS (lane = record): each pileup byte of the tile is fetched once, where the per-position form
+//                         (k_gather_columns_tiled) touched one 64-byte line per entry
+//   k_column_top3_exact   K3b: the two most frequent codes of every column in the reference's order of equal counts --
+//                         robin_hood iteration order (hs::Rh8View) + libstdc++'s std::sort (hs::CountSort), replayed by
+//                         one lane on LDS tables for the columns where counts tie; nothing goes to the host
+//   k_candidates_scan     V1: the greedy spacing scan of call_variants.cpp:525-536 per contig (lanes = columns, the
+//                         dependency only runs along the few columns that pass the predicate)
+//   k_flag_prefix / k_pack_flagged   the flagged columns (candidates, later the SNPs) packed back to back with their records
+//   k_snp_select          the two-pointer merge of automatic and filtered SNPs (:1335-1352) as a per-contig bound
+// Included by hs_capi.hip after hs_kernels.hip.
+#pragma once
+
+namespace hsdev {
+
+// per-column record the device keeps (== hs_colrec of include/hairsplitter_hip.h)
+struct alignas(16) hs_colrec_dev {
+    int32_t pos;            // position on its contig
+    int32_t contig;         // contig index in the batch
+    uint16_t c0, c1;        // counts of the two most frequent codes (saturate at 65535: the depth limit of the path)
+    uint8_t k0, k1;         // the codes, reference order of equal counts
+    uint8_t flags;          // HS_COL_*
+    uint8_t c2_zero;        // third count is zero
+};
+static_assert(sizeof(hs_colrec_dev) == 16, "hs_colrec must be 16 bytes");
+#define HS_COL_CAND 1
+#define HS_COL_AUTO 2
+#define HS_COL_LOOPD 4      // can be rescued by loop D (second count >= 5 + byte predicate)
+#define HS_COL_KEEP 8       // kept by loop C or D
+#define HS_COL_SNP 16       // in the output
+#define HS_COL_TIE 32       // its top-3 needed the reference's order of equal counts
+#define HS_COL_C1GT5C2 64   // second count > 5 x third count (call_variants.cpp:526; the third count itself is not kept)
+
+struct ColumnsHeader {      // what the host reads between the phases (one small download)
+    int64_t n_cols, n_entries;          // extracted columns / their entries
+    int64_t n_flagged, n_flagged_entries;   // candidates (after k_candidates_scan + k_flag_prefix) or SNPs (after k_snp_select + ...)
+    int64_t n_tie, n_tie_big;           // columns whose order went through the emulator / through std::sort's non-stable part
+    int64_t pad[2];
+};
+
+// ------------------------------------------------------------------------------------------------
+// K2's selection of the tiles [tile0, tile0 + n_tiles) packed into the column list, in position order. One workgroup per tile.
+// tile_base / tile_ebase: exclusive scans of the tiles' column counts / entry counts.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_columns_compact(
+    const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_base, const int64_t* __restrict__ tile_ebase,
+    const int64_t* __restrict__ scratch_gpos, const int32_t* __restrict__ scratch_depth, int64_t n_tiles,
+    const int64_t* __restrict__ contig_off, int n_contigs, int64_t* __restrict__ col_gpos, hs_colrec_dev* __restrict__ col_rec,
+    int64_t* __restrict__ col_off, int32_t* __restrict__ col_len, ColumnsHeader* __restrict__ header, int64_t cap_cols) {
+    __shared__ int s_wsum[4];
+    const int64_t t = blockIdx.x;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cnt = tile_cnt[t];
+    const bool mine = tid < cnt;
+    const int depth = mine ? scratch_depth[t * 256 + tid] : 0;
+    const int incl = wave_scan_incl(depth);
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wv; ++w) before += s_wsum[w];
+    if (t == n_tiles - 1 && tid == 0) {
+        header->n_cols = tile_base[n_tiles]; header->n_entries = tile_ebase[n_tiles];
+        if (tile_base[n_tiles] <= cap_cols) col_off[tile_base[n_tiles]] = tile_ebase[n_tiles];
+    }
+    if (!mine) return;
+    const int64_t k = tile_base[t] + tid;
+    if (k >= cap_cols) return;
+    const int64_t g = scratch_gpos[t * 256 + tid];
+    int lo = 0, hi = n_contigs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (contig_off[mid] <= g) lo = mid; else hi = mid - 1; }
+    col_gpos[k] = g;
+    col_off[k] = tile_ebase[t] + before + incl - depth;
+    col_len[k] = depth;
+    hs_colrec_dev r;
+    r.pos = (int32_t)(g - contig_off[lo]); r.contig = lo; r.c0 = 0; r.c1 = 0; r.k0 = 0; r.k1 = 0; r.flags = 0; r.c2_zero = 0;
+    col_rec[k] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3, tile-cooperative. One wavefront per tile that has selected positions. RC records at a time: lane j keeps plan entry j
+// (first position in the tile, length, pileup address of tile position 0); the RC x 256 bytes the records lay over the tile
+// go to LDS with one dword load per lane and record (rows of 260 bytes: a column read -- lane = record, fixed position -- then
+// hits 64 different banks). For every selected position the covering records are a ballot; rank = prefix popcount, so the
+// read indices of a column come out ascending (the plan lists a tile's records in ascending order) and a column's entries are
+// written with one coalesced store of indices and one of codes per RC records.
+// The pileup buffer is padded by 256 bytes on both sides: a row is loaded whole, also where the record covers part of the tile.
+// ------------------------------------------------------------------------------------------------
+#define HS_GT_RC 32
+#define HS_GT_ROW 260
+__global__ __launch_bounds__(256) void k_gather_tiles(
+    const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, const int32_t* __restrict__ tile_lrec,
+    int64_t tile0, int64_t n_tiles, const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_base,
+    const int64_t* __restrict__ col_gpos, const int64_t* __restrict__ col_off, int32_t* __restrict__ col_idx, uint8_t* __restrict__ col_code) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_rows[4][HS_GT_RC * HS_GT_ROW];
+    const int lane = lane_id();
+    const int wv = wave_id();
+    const int64_t tl = (int64_t)blockIdx.x * 4 + wv;      // tile index in the launch
+    if (tl >= n_tiles) return;
+    const int cnt = tile_cnt[tl];
+    if (cnt == 0) return;
+    uint8_t* __restrict__ rows = s_rows[wv];
+    const int64_t kbase = tile_base[tl];
+    const int64_t e0 = tile_off[tile0 + tl], e1 = tile_off[tile0 + tl + 1];
+    for (int sc = 0; sc < cnt; sc += 64) {      // (a tile rarely selects more than 64 of its 256 positions)
+        const int ns = (cnt - sc) < 64 ? (cnt - sc) : 64;
+        int my_x = 0;
+        int64_t my_w = 0;
+        if (lane < ns) { my_x = (int)(col_gpos[kbase + sc + lane] & 255); my_w = col_off[kbase + sc + lane]; }
+        for (int64_t rb = e0; rb < e1; rb += HS_GT_RC) {
+            const int nrec = (e1 - rb) < HS_GT_RC ? (int)(e1 - rb) : HS_GT_RC;
+            int4 en = make_int4(0, 0, 0, 0);
+            int lrec = 0;
+            if (lane < nrec) { en = tile_ent[rb + lane]; lrec = tile_lrec[rb + lane]; }
+            __builtin_amdgcn_wave_barrier();
+            // stage the rows: record j -> bytes of tile positions 4 * lane .. 4 * lane + 3
+#pragma unroll 4
+            for (int j = 0; j < nrec; ++j) {
+                const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane(en.z, j), phi = (uint32_t)__builtin_amdgcn_readlane(en.w, j);
+                const uint8_t* __restrict__ base = pile + (int64_t)(((uint64_t)phi << 32) | plo);
+                const uint32_t v = *reinterpret_cast<const u32_unaligned*>(base + 4 * lane);      // one (unaligned) dword per lane: the row
+                *reinterpret_cast<uint32_t*>(rows + j * HS_GT_ROW + 4 * lane) = v;
+            }
+            wave_lds_sync();
+            for (int s = 0; s < ns; ++s) {
+                const int x = __builtin_amdgcn_readlane(my_x, s);
+                const bool cov = lane < nrec && (unsigned)(x - en.x) < (unsigned)en.y;
+                const unsigned long long m = __ballot(cov);
+                if (m == 0ull) continue;
+                const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_w & 0xffffffffll), s);
+                const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)my_w >> 32), s);
+                const int64_t w = (int64_t)(((uint64_t)whi << 32) | wlo);
+                if (cov) {
+                    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+                    col_idx[w + rank] = lrec;
+                    col_code[w + rank] = rows[lane * HS_GT_ROW + x];
+                }
+                if (lane == s) my_w += __popcll(m);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3b, exact: top-3 of every extracted column as call_variants.cpp:477-507 forms it -- the counts of the column's codes go
+// into a robin_hood map (keys in the order the reads bring them, then the zero-count fillers 0, 1, 2), the map is walked into
+// a vector and std::sort orders it by count. Where the three largest counts differ from each other and from the fourth, no
+// order of equal keys is involved: histogram in LDS, three wave arg-max rounds. Else one lane replays the reference: the codes
+// in first-appearance order into hs::Rh8View (tables in LDS), its iteration order into hs::CountSort (std::sort's own
+// sequence of moves). Writes counts and codes into the column record.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_len,
+                                                           const uint8_t* __restrict__ col_code, const ColumnsHeader* __restrict__ header,
+                                                           hs_colrec_dev* __restrict__ col_rec, unsigned long long* __restrict__ n_tie /* [2] */) {
+    __shared__ int s_hist[4][128];
+    __shared__ uint8_t s_info[4][512], s_key[4][512], s_tmp[4][512];
+    __shared__ uint32_t s_sort[4][136];
+    __shared__ int s_stack[4][120];
+    __shared__ uint8_t s_first[4][128];
+    const int lane = lane_id();
+    const int wv = wave_id();
+    const int64_t n_cols = header->n_cols;
+    int* __restrict__ h = s_hist[wv];
+    for (int64_t col = (int64_t)blockIdx.x * 4 + wv; col < n_cols; col += (int64_t)gridDim.x * 4) {
+        h[lane] = 0; h[lane + 64] = 0;
+        wave_lds_sync();
+        const int64_t b = col_off[col];
+        const int n = col_len[col];
+        for (int j = lane; j < n; j += 64) {
+            const int c = (int)col_code[b + j] - 33;
+            if (c >= 0 && c < HS_NBINS) atomicAdd(&h[c], 1);
+        }
+        wave_lds_sync();
+        int k_a = (h[lane] << 8) | (255 - lane), k_b = (h[lane + 64] << 8) | (255 - (lane + 64));
+        int top[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mine = k_a > k_b ? k_a : k_b;
+            const int best = wave_max_i32(mine);
+            top[r] = best;
+            if (k_a == best) k_a = -1;
+            if (k_b == best) k_b = -1;
+        }
+        int c0 = top[0] >> 8, c1 = top[1] >> 8, c2 = top[2] >> 8;
+        const int c3 = top[3] >> 8;
+        int k0 = 33 + 255 - (top[0] & 255), k1 = 33 + 255 - (top[1] & 255);
+        // which keys take places 0 and 1 is open when c0 == c1 or c1 == c2 (c2 == c3 only permutes places 2.. -- the third COUNT
+        // is all the path uses); a second count of zero means the fillers take part
+        const bool tie = c0 == c1 || c1 == c2 || c1 == 0;
+        (void)c3;
+        if (tie) {
+            if (lane == 0) {
+                // codes in first-appearance order
+                int nd = 0;
+                uint8_t* first = s_first[wv];
+                for (int j = 0; j < n; ++j) {
+                    const int c = (int)col_code[b + j];
+                    const int bin = c - 33;
+                    if (bin < 0 || bin >= HS_NBINS) continue;
+                    if (h[bin] > 0) { first[nd++] = (uint8_t)c; h[bin] = -h[bin]; }      // negative = listed
+                }
+                hs::Rh8View rh; rh.init(s_info[wv], s_key[wv], s_tmp[wv], 512);
+                for (int i = 0; i < nd; ++i) rh.insert(first[i]);
+                rh.insert(0); rh.insert(1); rh.insert(2);
+                const int m = rh.order(s_tmp[wv]);
+                uint32_t* v = s_sort[wv];
+                for (int i = 0; i < m; ++i) {
+                    const int key = s_tmp[wv][i];
+                    const int bin = key - 33;
+                    const int cnt = (bin >= 0 && bin < HS_NBINS) ? -h[bin] : 0;
+                    v[i] = ((uint32_t)cnt << 8) | (uint32_t)key;
+                }
+                hs::CountSort::sort_with_stack(v, m, s_stack[wv]);
+                s_sort[wv][132] = v[0]; s_sort[wv][133] = v[1]; s_sort[wv][134] = v[2]; s_sort[wv][135] = (uint32_t)m;
+            }
+            wave_lds_sync();
+            const uint32_t v0 = s_sort[wv][132], v1 = s_sort[wv][133], v2 = s_sort[wv][134];
+            const int m = (int)s_sort[wv][135];
+            k0 = (int)(v0 & 255u); k1 = (int)(v1 & 255u); c0 = (int)(v0 >> 8); c1 = (int)(v1 >> 8); c2 = (int)(v2 >> 8);
+            if (lane == 0) { atomicAdd(&n_tie[0], 1ull); if (m > 16) atomicAdd(&n_tie[1], 1ull); }
+            wave_lds_sync();
+        }
+        if (lane == 0) {
+            hs_colrec_dev r = col_rec[col];
+            r.c0 = (uint16_t)(c0 > 65535 ? 65535 : c0); r.c1 = (uint16_t)(c1 > 65535 ? 65535 : c1);
+            r.k0 = (uint8_t)k0; r.k1 = (uint8_t)k1; r.c2_zero = c2 == 0 ? 1 : 0;
+            r.flags = tie ? HS_COL_TIE : 0;
+            // c1 > c2 * 5 is all the path asks of the third count (call_variants.cpp:526): kept as a bit next to c2 == 0
+            if (c1 > c2 * 5) r.flags |= HS_COL_C1GT5C2;
+            col_rec[col] = r;
+        }
+    }
+}
+
+static __device__ __forceinline__ bool central_base_test_cols(int k0, int k1) {
+    // call_variants.cpp:527-528 and :751-752 (same predicate on raw code bytes)
+    return k0 % 5 != k1 % 5 && ((k1 - '!') % 5 != 4 || (k1 / 5 % 5 != k0 % 5 && k1 / 25 % 5 != k0 % 5));
+}
+
+// ------------------------------------------------------------------------------------------------
+// V1: the candidate and the "automatic" columns of every contig of the range (call_variants.cpp:525-536). One wavefront per
+// contig; 64 columns per step, lanes test the position-independent part, the greedy "more than five positions after the last
+// candidate" runs along the lanes that pass (a handful per step). Also splits the record into the arrays K4 reads.
+// min_reads[c] = 3 or 5 (:463-466, from the contig's mean distance); thr = automatic_snp_threshold.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_candidates_scan(
+    const int64_t* __restrict__ col_gpos, const ColumnsHeader* __restrict__ header, const int64_t* __restrict__ contig_off, int c_first, int c_count,
+    const int32_t* __restrict__ min_reads /* [c_count] */, float thr, hs_colrec_dev* __restrict__ col_rec,
+    int32_t* __restrict__ col_contig_local, uint8_t* __restrict__ col_k0, uint8_t* __restrict__ col_k1, int32_t* __restrict__ col_c1, uint8_t* __restrict__ col_is_cand,
+    int64_t* __restrict__ contig_col_off /* [c_count + 1] */, int32_t* __restrict__ contig_n_cand /* [c_count] */) {
+    const int lane = lane_id();
+    const int ci = (int)blockIdx.x;
+    if (ci >= c_count) return;
+    const int64_t n_cols = header->n_cols;
+    // the contig's columns: [s0, s1) by bisection of its global position range in the sorted list
+    auto lower = [&](int64_t g) { int64_t lo = 0, hi = n_cols; while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (col_gpos[mid] < g) lo = mid + 1; else hi = mid; } return lo; };
+    const int64_t s0 = lower(contig_off[c_first + ci]), s1 = lower(contig_off[c_first + ci + 1]);
+    if (lane == 0) { contig_col_off[ci] = s0; if (ci == c_count - 1) contig_col_off[c_count] = s1; }
+    const int mr = min_reads[ci];
+    int pos_of_last = -5, n_cand = 0;
+    for (int64_t sb = s0; sb < s1; sb += 64) {
+        const int64_t k = sb + lane;
+        hs_colrec_dev r;
+        bool pass = false;
+        if (k < s1) {
+            r = col_rec[k];
+            pass = (int)r.c1 > mr && (r.flags & HS_COL_C1GT5C2) && central_base_test_cols(r.k0, r.k1);
+        } else { r.pos = 0; r.contig = 0; r.c0 = r.c1 = 0; r.k0 = r.k1 = 0; r.flags = 0; r.c2_zero = 0; }
+        unsigned long long m = __ballot(pass);
+        unsigned long long accepted = 0ull;
+        while (m) {
+            const int l = __builtin_ctzll(m); m &= m - 1ull;
+            const int p = __builtin_amdgcn_readlane(r.pos, l);
+            if (p - pos_of_last > 5) { accepted |= 1ull << l; pos_of_last = p; }
+        }
+        if (k < s1) {
+            const bool cand = (accepted >> lane) & 1ull;
+            uint8_t f = r.flags & (HS_COL_TIE);
+            if (cand) { f |= HS_COL_CAND; if ((float)r.c1 > thr * (float)r.c0) f |= HS_COL_AUTO; }
+            if ((int)r.c1 >= 5 && central_base_test_cols(r.k0, r.k1)) f |= HS_COL_LOOPD;
+            r.flags = f;
+            col_rec[k] = r;
+            col_contig_local[k] = ci; col_k0[k] = r.k0; col_k1[k] = r.k1; col_c1[k] = r.c1; col_is_cand[k] = cand ? 1 : 0;
+        }
+        n_cand += __popcll(accepted);
+    }
+    if (lane == 0) contig_n_cand[ci] = n_cand;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Columns whose record carries `flag` packed back to back: exclusive prefix of (1, length) over the column list in two kernels
+// (per 1024-column block sums, then one workgroup orders the blocks), then one wavefront per flagged column copies its entries.
+// ------------------------------------------------------------------------------------------------
+#define HS_FP_BLOCK 1024
+__global__ __launch_bounds__(256) void k_flag_block_sums(const hs_colrec_dev* __restrict__ col_rec, const int32_t* __restrict__ col_len, const ColumnsHeader* __restrict__ header,
+                                                         int flag, long long* __restrict__ blk_cnt, long long* __restrict__ blk_ent) {
+    __shared__ long long s_c[4], s_e[4];
+    const int64_t n_cols = header->n_cols;
+    const int64_t base = (int64_t)blockIdx.x * HS_FP_BLOCK;
+    if (base >= n_cols) { if (threadIdx.x == 0) { blk_cnt[blockIdx.x] = 0; blk_ent[blockIdx.x] = 0; } return; }
+    int c = 0; long long e = 0;
+    for (int i = (int)threadIdx.x; i < HS_FP_BLOCK; i += 256) {
+        const int64_t k = base + i;
+        if (k < n_cols && (col_rec[k].flags & flag)) { c++; e += col_len[k]; }
+    }
+    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+    const int cs = wave_sum_i32(c);
+    long long es = e;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) es += __shfl_xor(es, d, 64);
+    if (lane == 0) { s_c[wv] = cs; s_e[wv] = es; }
+    __syncthreads();
+    if (threadIdx.x == 0) { blk_cnt[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3]; blk_ent[blockIdx.x] = s_e[0] + s_e[1] + s_e[2] + s_e[3]; }
+}
+__global__ __launch_bounds__(1024) void k_flag_block_offsets(long long* __restrict__ blk_cnt, long long* __restrict__ blk_ent, int n_blocks, ColumnsHeader* __restrict__ header) {
+    // serial over chunks of 1024 blocks, parallel inside (a range has a few hundred blocks)
+    __shared__ long long s_c[1024], s_e[1024];
+    __shared__ long long carry_c, carry_e;
+    if (threadIdx.x == 0) { carry_c = 0; carry_e = 0; }
+    __syncthreads();
+    for (int b0 = 0; b0 < n_blocks; b0 += 1024) {
+        const int i = b0 + (int)threadIdx.x;
+        const long long c = i < n_blocks ? blk_cnt[i] : 0, e = i < n_blocks ? blk_ent[i] : 0;
+        s_c[threadIdx.x] = c; s_e[threadIdx.x] = e;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            long long ac = 0, ae = 0;
+            if ((int)threadIdx.x >= d) { ac = s_c[threadIdx.x - d]; ae = s_e[threadIdx.x - d]; }
+            __syncthreads();
+            s_c[threadIdx.x] += ac; s_e[threadIdx.x] += ae;
+            __syncthreads();
+        }
+        if (i < n_blocks) { blk_cnt[i] = carry_c + s_c[threadIdx.x] - c; blk_ent[i] = carry_e + s_e[threadIdx.x] - e; }
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry_c += s_c[1023]; carry_e += s_e[1023]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { header->n_flagged = carry_c; header->n_flagged_entries = carry_e; }
+}
+// out_rec[f] = record of the f-th flagged column, out_col[f] = its index in the column list, out_off[f] = first entry in the
+// packed arrays (out_off[n_flagged] = total); entries copied by the wavefront that owns the column
+__global__ __launch_bounds__(256) void k_pack_flagged(
+    const hs_colrec_dev* __restrict__ col_rec, const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_len, const int32_t* __restrict__ col_idx,
+    const uint8_t* __restrict__ col_code, const ColumnsHeader* __restrict__ header, int flag, const long long* __restrict__ blk_cnt,
+    const long long* __restrict__ blk_ent, hs_colrec_dev* __restrict__ out_rec, int32_t* __restrict__ out_col, int64_t* __restrict__ out_off,
+    int32_t* __restrict__ out_idx, uint8_t* __restrict__ out_code, int64_t cap_flagged, int64_t cap_entries) {
+    // one workgroup per block of HS_FP_BLOCK columns: wave w walks columns w * 256 .. of the block 64 at a time
+    const int64_t n_cols = header->n_cols;
+    const int64_t base = (int64_t)blockIdx.x * HS_FP_BLOCK;
+    if (base >= n_cols) return;
+    __shared__ long long s_wc[4], s_we[4];
+    const int lane = lane_id(), wv = wave_id();
+    // counts of the four quarters first (the order inside the block is quarter by quarter)
+    {
+        int c = 0; long long e = 0;
+        for (int i = lane; i < 256; i += 64) {
+            const int64_t k = base + wv * 256 + i;
+            if (k < n_cols && (col_rec[k].flags & flag)) { c++; e += col_len[k]; }
+        }
+        const int cs = wave_sum_i32(c);
+        long long es = e;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) es += __shfl_xor(es, d, 64);
+        if (lane == 0) { s_wc[wv] = cs; s_we[wv] = es; }
+    }
+    __syncthreads();
+    long long f = blk_cnt[blockIdx.x], o = blk_ent[blockIdx.x];
+    for (int w = 0; w < wv; ++w) { f += s_wc[w]; o += s_we[w]; }
+    const bool last_block = base + HS_FP_BLOCK >= n_cols;
+    for (int i0 = 0; i0 < 256; i0 += 64) {
+        const int64_t k = base + wv * 256 + i0 + lane;
+        const bool on = k < n_cols && (col_rec[k].flags & flag);
+        const int len = on ? col_len[k] : 0;
+        const unsigned long long m = __ballot(on);
+        const int incl = wave_scan_incl(len);
+        const long long my_f = f + __popcll(m & ((1ull << lane) - 1ull));
+        const long long my_o = o + incl - len;
+        if (on && my_f < cap_flagged) { out_rec[my_f] = col_rec[k]; out_col[my_f] = (int32_t)k; out_off[my_f] = my_o; }
+        // the entries: the wave copies the flagged columns of this step one after the other
+        unsigned long long rem = m;
+        while (rem) {
+            const int l = __builtin_ctzll(rem); rem &= rem - 1ull;
+            const int n = __builtin_amdgcn_readlane(len, l);
+            const uint32_t olo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_o & 0xffffffffll), l), ohi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)my_o >> 32), l);
+            const int64_t dst = (int64_t)(((uint64_t)ohi << 32) | olo);
+            const int64_t kk = base + wv * 256 + i0 + l;
+            const int64_t src = col_off[kk];
+            if (dst + n <= cap_entries)
+                for (int j = lane; j < n; j += 64) { out_idx[dst + j] = col_idx[src + j]; out_code[dst + j] = col_code[src + j]; }
+        }
+        f += __popcll(m); o += __builtin_amdgcn_readlane(incl, 63);
+    }
+    if (last_block && wv == 3 && lane == 0 && f <= cap_flagged) out_off[f] = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The merge of the automatic and the filtered SNPs of a contig (call_variants.cpp:1335-1352) walks both lists in position
+// order and stops when either ends: what it emits is every column of either list up to min(last automatic, last filtered).
+// One wavefront per contig: the two maxima, then the SNP flag. keep[k]: verdict of loops C / D (K4).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_snp_select(const int64_t* __restrict__ contig_col_off, int c_count, const uint8_t* __restrict__ keep,
+                                                   hs_colrec_dev* __restrict__ col_rec, int32_t* __restrict__ contig_n_snp) {
+    const int lane = lane_id();
+    const int ci = (int)blockIdx.x;
+    if (ci >= c_count) return;
+    const int64_t s0 = contig_col_off[ci], s1 = contig_col_off[ci + 1];
+    int max_a = -1, max_f = -1;
+    for (int64_t k = s0 + lane; k < s1; k += 64) {
+        const hs_colrec_dev r = col_rec[k];
+        if (r.flags & HS_COL_AUTO) max_a = r.pos > max_a ? r.pos : max_a;
+        if (keep[k] == 1) max_f = r.pos > max_f ? r.pos : max_f;
+    }
+    max_a = wave_max_i32(max_a); max_f = wave_max_i32(max_f);
+    const int bound = (max_a < 0 || max_f < 0) ? -1 : (max_a < max_f ? max_a : max_f);
+    int n = 0;
+    for (int64_t k = s0 + lane; k < s1; k += 64) {
+        hs_colrec_dev r = col_rec[k];
+        const bool kept = keep[k] == 1;
+        const bool snp = ((r.flags & HS_COL_AUTO) || kept) && r.pos <= bound;
+        uint8_t f = r.flags & ~(HS_COL_KEEP | HS_COL_SNP);
+        if (kept) f |= HS_COL_KEEP;
+        if (snp) { f |= HS_COL_SNP; n++; }
+        r.flags = f;
+        col_rec[k] = r;
+    }
+    n = wave_sum_i32(n);
+    if (lane == 0) contig_n_snp[ci] = n;
+}
+
+}  // namespace hsdev

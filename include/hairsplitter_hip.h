@@ -303,6 +303,23 @@ int64_t hs_cv_batch_aligned_bp(const hs_cv_batch* b);   /* number of pileup entr
  * the calling thread -- and every thread the library starts for it -- to that device first. */
 int hs_cv_batch_device(const hs_cv_batch* b);
 
+/* A column of the pileup as the device keeps it between the kernels of stage 3 (16 bytes). */
+typedef struct hs_colrec {
+    int32_t pos;          /* position on its contig */
+    int32_t contig;       /* contig index in the batch */
+    uint16_t c0, c1;      /* reads carrying the two most frequent codes (call_variants.cpp:497-507) */
+    uint8_t k0, k1;       /* those codes, equal counts in the reference's order (robin_hood iteration order + std::sort) */
+    uint8_t flags;        /* HS_COL_* */
+    uint8_t c2_zero;      /* the third count is zero */
+} hs_colrec;
+#define HS_COL_CAND 1     /* candidate SNP of call_variants.cpp:525-536 */
+#define HS_COL_AUTO 2     /* ... that also passes the automatic threshold (:532) */
+#define HS_COL_LOOPD 4    /* may be rescued by loop D (:745-764) */
+#define HS_COL_KEEP 8     /* kept by loop C or D */
+#define HS_COL_SNP 16     /* in the output (:1335-1352) */
+#define HS_COL_TIE 32     /* equal counts among its leading codes */
+#define HS_COL_C1GT5C2 64 /* second count > 5 x third count (:526) */
+
 /* Per-contig result of stage 3 == what output_files (call_variants.cpp:1174-1213) prints. */
 typedef struct hs_cv_result {
     int32_t n_contigs;
@@ -324,8 +341,8 @@ typedef struct hs_cv_result {
     float t_kernel_ms[4];      /* hipEvent time of k_pileup, k_column_stats, k_gather_columns, k_cigar_scan */
     float t_kernel_k4_ms;      /* hipEvent time of k_column_partition_test */
     int64_t n_columns_extracted;        /* K3: columns of the selected positions (they stay on the device) */
-    int64_t n_columns_downloaded;       /* of those, walked by the host (candidate SNPs, tie-order columns) */
-    int64_t n_columns_downloaded_late;  /* output SNPs rescued by loop D that had not been downloaded before */
+    int64_t n_columns_downloaded;       /* of those, candidate SNPs: the columns the host walks (loops A / B) */
+    int64_t n_columns_downloaded_late;  /* columns whose leading codes had equal counts (ordered on the device as the reference orders them) */
 } hs_cv_result;
 
 int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out);

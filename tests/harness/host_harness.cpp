@@ -26,17 +26,12 @@ namespace {
 
 struct OracleCvOps : hs::CvDeviceOps {
     const hs::CvFileInput& in;
-    std::vector<std::vector<hso::Column>> cols;   // per contig
-    std::vector<int32_t> col_idx;
-    std::vector<uint8_t> col_code;
+    std::vector<hso::MsaResult> msa;              // per contig
     explicit OracleCvOps(const hs::CvFileInput& i) : in(i) {}
 
-    std::vector<int64_t> sel_gpos;
-    std::vector<int32_t> sel_depth;
-    int pileup_and_select(std::vector<int32_t>& rec_stats, int min_second, const int64_t** sel_gpos_out, const int32_t** sel_depth_out,
-                          size_t* n_sel_out, float k_ms[4]) override {
+    // K0 + K1 through the oracle's generate_msa
+    int pileup(std::vector<int32_t>& rec_stats, float k_ms[4]) override {
         k_ms[0] = k_ms[1] = k_ms[3] = 0;
-        sel_gpos.clear(); sel_depth.clear();
         const int C = (int)in.contig_names.size();
         std::vector<std::string> read_seq(in.read_names.size());
         for (size_t r = 0; r < read_seq.size(); ++r) {
@@ -44,7 +39,7 @@ struct OracleCvOps : hs::CvDeviceOps {
             for (int64_t k = in.read_off[r]; k < in.read_off[r + 1]; ++k) s += "ACGT"[in.read_seq[(size_t)k]];
             read_seq[r] = s;
         }
-        cols.resize((size_t)C);
+        msa.clear(); msa.resize((size_t)C);
         const char* opc = "MIDNSHP=X";
         for (int c = 0; c < C; ++c) {
             hso::Contig ctg;
@@ -62,102 +57,76 @@ struct OracleCvOps : hs::CvDeviceOps {
                 const size_t r = (size_t)in.contig_rec_off[(size_t)c] + k;
                 rec_stats[r * 4 + 0] = m.q_end[k]; rec_stats[r * 4 + 1] = (int32_t)m.n_err[k]; rec_stats[r * 4 + 2] = (int32_t)m.n_len[k];
             }
-            const int64_t base = in.contig_off[(size_t)c];
+            msa[(size_t)c] = std::move(m);
+        }
+        return 0;
+    }
+
+    // the columns of the current range: every position whose second count is >= 4 (what the device extracts), in position order
+    struct XCol { int contig, pos; hs_colrec rec; };
+    int r0 = 0, r1 = 0;
+    std::vector<XCol> xcols;
+    std::vector<hs_colrec> pk_rec; std::vector<int32_t> pk_col; std::vector<int64_t> pk_off; std::vector<int32_t> pk_idx; std::vector<uint8_t> pk_code;
+    void pack(int flag) {
+        pk_rec.clear(); pk_col.clear(); pk_off.assign(1, 0); pk_idx.clear(); pk_code.clear();
+        for (size_t k = 0; k < xcols.size(); ++k) {
+            if (!(xcols[k].rec.flags & flag)) continue;
+            const hso::Column& col = msa[(size_t)xcols[k].contig].cols[(size_t)xcols[k].pos];
+            pk_rec.push_back(xcols[k].rec); pk_col.push_back((int32_t)k);
+            for (size_t e = 0; e < col.content.size(); ++e) { pk_idx.push_back((int32_t)col.readIdxs[e]); pk_code.push_back(col.content[e]); }
+            pk_off.push_back((int64_t)pk_idx.size());
+        }
+        pk_idx.push_back(0); pk_code.push_back(0);      // (never null)
+    }
+    // K2 + K3 + K3b + V1 through the oracle's call_variants (call_variants.cpp:447-567): its per-position top-3 (the reference's
+    // order of equal counts) and its candidate / automatic lists
+    int extract_candidates(int c0, int c1, const std::vector<int32_t>& min_reads, float thr, hs::CvCandidates& out, float k_ms[3]) override {
+        k_ms[0] = k_ms[1] = k_ms[2] = 0;
+        r0 = c0; r1 = c1;
+        xcols.clear();
+        out = hs::CvCandidates();
+        out.contig_n_cand.assign((size_t)(c1 - c0), 0);
+        for (int c = c0; c < c1; ++c) {
+            hso::MsaResult& m = msa[(size_t)c];
+            if (((m.meanDistance < 0.015f) ? 3 : 5) != min_reads[(size_t)(c - c0)]) { std::cerr << "harness: the driver's read minimum differs from the oracle's\n"; return 3; }
+            hso::CallResult cr = hso::call_variants(m.cols, m.newref, m.meanDistance, thr);
+            std::vector<char> is_cand(m.cols.size(), 0), is_auto(m.cols.size(), 0);
+            for (const hso::Column& s : cr.suspicious) is_cand[(size_t)s.pos] = 1;
+            for (const hso::Column& s : cr.automatic) is_auto[(size_t)s.pos] = 1;
             for (size_t p = 0; p < m.cols.size(); ++p) {
-                int cnt[256] = {0};
-                for (unsigned char ch : m.cols[p].content) cnt[ch]++;
-                std::vector<std::pair<int, int>> v;   // (-count, code)
-                for (int k = 33; k < 158; ++k) if (cnt[k]) v.push_back(std::make_pair(-cnt[k], k));
-                std::sort(v.begin(), v.end());
-                const int c1v = v.size() >= 2 ? -v[1].first : 0, c2v = v.size() >= 3 ? -v[2].first : 0;
-                if (c1v > min_second || (c1v == min_second && c2v == 0)) {   // reversed on purpose: the device list is unordered
-                    sel_gpos.insert(sel_gpos.begin(), base + (int64_t)p);
-                    sel_depth.insert(sel_depth.begin(), (int32_t)m.cols[p].content.size());
-                }
-            }
-            cols[(size_t)c] = std::move(m.cols);
-        }
-        *sel_gpos_out = sel_gpos.data(); *sel_depth_out = sel_depth.data(); *n_sel_out = sel_gpos.size();
-        return 0;
-    }
-    // the two-part form of the streaming pass (contig groups): pileup = the per-record counters, select_range = the selection
-    // of the 256-position tiles that hold [g0, g1), SORTED (as the device hands it over), neighbours' positions included
-    std::vector<int64_t> rng_gpos; std::vector<int32_t> rng_depth;
-    bool has_select_range() const override { return true; }
-    int pileup(std::vector<int32_t>& rec_stats, float k_ms[4]) override {
-        const int64_t* g; const int32_t* d; size_t n;
-        return pileup_and_select(rec_stats, 4, &g, &d, &n, k_ms);      // (the selection of the whole batch is kept for select_range)
-    }
-    int select_range(int64_t g0, int64_t g1, int, const int64_t** sg, const int32_t** sd, size_t* n, float* k_ms) override {
-        std::vector<std::pair<int64_t, int32_t>> v;
-        const int64_t t0 = (g0 >> 8) << 8, t1 = ((g1 + 255) >> 8) << 8;
-        for (size_t i = 0; i < sel_gpos.size(); ++i) if (sel_gpos[i] >= t0 && sel_gpos[i] < t1) v.push_back(std::make_pair(sel_gpos[i], sel_depth[i]));
-        std::sort(v.begin(), v.end());
-        rng_gpos.clear(); rng_depth.clear();
-        for (auto& kv : v) { rng_gpos.push_back(kv.first); rng_depth.push_back(kv.second); }
-        *sg = rng_gpos.data(); *sd = rng_depth.data(); *n = rng_gpos.size(); if (k_ms) *k_ms = 0;
-        return 0;
-    }
-    int gather(const std::vector<int32_t>& sel_contig, const std::vector<int32_t>& sel_pos, const std::vector<int64_t>& col_off,
-               const hs_coltop** top_out, float* k_ms) override {
-        *k_ms = 0;
-        // HS_HARNESS_ALL_TIES: every column is handed to the host's exact (reference order) resolution; otherwise the
-        // top-3 is reported the way K3b does (tie = 1 only where the order of equal counts matters), which exercises the
-        // partial download and the late fetch of the stage driver
-        tops.assign(sel_pos.size(), hs_coltop{0, 0, 0, 0, 0, 1, 0});
-        *top_out = tops.data();
-        if (!std::getenv("HS_HARNESS_ALL_TIES")) {
-            for (size_t i = 0; i < sel_pos.size(); ++i) {
-                const hso::Column& col = cols[(size_t)sel_contig[i]][(size_t)sel_pos[i]];
-                int cnt[256] = {0};
-                bool odd = false;
-                for (unsigned char ch : col.content) { if (ch >= 33 && ch < 158) cnt[ch]++; else odd = true; }
-                std::vector<std::pair<int, int>> v;   // (-count, code)
-                for (int k = 33; k < 158; ++k) v.push_back(std::make_pair(-cnt[k], k));
-                std::sort(v.begin(), v.end());
-                hs_coltop t;
-                t.c0 = -v[0].first; t.c1 = -v[1].first; t.c2 = -v[2].first;
-                t.k0 = (uint8_t)v[0].second; t.k1 = (uint8_t)v[1].second;
-                t.tie = (odd || t.c0 == t.c1 || t.c1 == t.c2 || t.c1 == 0) ? 1 : 0; t.pad = 0;
-                tops[i] = t;
+                const int c1v = cr.c1[p], c2v = cr.c2[p];
+                if (!(c1v > 4 || (c1v == 4 && c2v == 0))) { if (is_cand[p]) { std::cerr << "harness: a candidate outside the extracted columns\n"; return 3; } continue; }
+                XCol x; x.contig = c; x.pos = (int)p;
+                hs_colrec& r = x.rec;
+                r.pos = (int32_t)p; r.contig = c; r.c0 = (uint16_t)cr.c0[p]; r.c1 = (uint16_t)c1v; r.k0 = cr.k0[p]; r.k1 = cr.k1[p]; r.c2_zero = c2v == 0;
+                r.flags = 0;
+                if (c1v > 5 * c2v) r.flags |= HS_COL_C1GT5C2;
+                if (is_cand[p]) r.flags |= HS_COL_CAND;
+                if (is_auto[p]) r.flags |= HS_COL_AUTO;
+                const int rb = r.k0, sb = r.k1;
+                if (c1v >= 5 && rb % 5 != sb % 5 && ((sb - '!') % 5 != 4 || (sb / 5 % 5 != rb % 5 && sb / 25 % 5 != rb % 5))) r.flags |= HS_COL_LOOPD;
+                out.n_entries += (int64_t)m.cols[p].content.size();
+                if (is_cand[p]) out.contig_n_cand[(size_t)(c - c0)]++;
+                xcols.push_back(x);
             }
         }
-        last_sel_pos = sel_pos;
-        last_col_off = col_off;
-        col_idx.assign((size_t)col_off.back(), 0); col_code.assign((size_t)col_off.back(), 0);
-        for (size_t i = 0; i < sel_pos.size(); ++i) {
-            const hso::Column& col = cols[(size_t)sel_contig[i]][(size_t)sel_pos[i]];
-            for (size_t k = 0; k < col.content.size(); ++k) { col_idx[(size_t)col_off[i] + k] = (int32_t)col.readIdxs[k]; col_code[(size_t)col_off[i] + k] = col.content[k]; }
-        }
+        out.n_columns = (int64_t)xcols.size();
+        pack(HS_COL_CAND);
+        out.n_cand = (int64_t)pk_rec.size();
+        out.rec = pk_rec.data(); out.col = pk_col.data(); out.off = pk_off.data(); out.idx = pk_idx.data(); out.code = pk_code.data();
         return 0;
     }
-    int fetch_columns(const std::vector<int32_t>& ids, const std::vector<int64_t>& packed_off, int slot, const int32_t** idx_out,
-                      const uint8_t** code_out) override {
-        std::vector<int32_t>& pi = packed_idx[slot]; std::vector<uint8_t>& pc = packed_code[slot];
-        pi.assign((size_t)packed_off.back() + 1, 0); pc.assign((size_t)packed_off.back() + 1, 0);
-        for (size_t k = 0; k < ids.size(); ++k) {
-            const int64_t src = last_col_off[(size_t)ids[k]], n = packed_off[k + 1] - packed_off[k];
-            for (int64_t j = 0; j < n; ++j) { pi[(size_t)(packed_off[k] + j)] = col_idx[(size_t)(src + j)]; pc[(size_t)(packed_off[k] + j)] = col_code[(size_t)(src + j)]; }
-        }
-        *idx_out = pi.data(); *code_out = pc.data();
-        return 0;
-    }
-    // loops C and D of keep_only_robust_variants through the oracle's distance()/computeChiSquare()
-    int column_partition_test(const hs::CvPartitionTest& t, std::vector<uint8_t>& keep, float* k_ms) override {
-        *k_ms = 0;
-        const size_t n = t.col_contig.size();
-        keep.assign(n, 0);
-        std::vector<int64_t> off(n + 1, 0);
-        // CSR offsets of the last gather: columns were stored back to back
-        {
-            size_t i = 0; int64_t o = 0;
-            for (; i < n; ++i) { off[i] = o; o += (int64_t)cols[(size_t)t.col_contig[i]][(size_t)last_sel_pos[i]].content.size(); }
-            off[n] = o;
-        }
-        const int C = (int)t.part_off.size() - 1;
+    // loops C and D of keep_only_robust_variants through the oracle's distance() / computeChiSquare(), then the reference's own
+    // two-pointer merge of the automatic and the filtered SNPs (call_variants.cpp:1335-1352)
+    int finish_columns(const hs::CvPartitionTest& t, bool want_entries, hs::CvSnpSet& out, float* k_ms) override {
+        if (k_ms) *k_ms = 0;
+        const int C = r1 - r0;
+        out = hs::CvSnpSet();
+        out.contig_n_snp.assign((size_t)C, 0);
         std::vector<std::vector<hso::Partition>> parts((size_t)C);
         for (int c = 0; c < C; ++c) {
-            const int nreads = in.contig_rec_off[(size_t)c + 1] - in.contig_rec_off[(size_t)c];
+            const int nreads = in.contig_rec_off[(size_t)(r0 + c) + 1] - in.contig_rec_off[(size_t)(r0 + c)];
+            if (nreads != t.contig_n_reads[(size_t)c]) { std::cerr << "harness: read counts of the partitions differ\n"; return 3; }
             for (int f = t.part_off[(size_t)c]; f < t.part_off[(size_t)c + 1]; ++f) {
                 hso::Partition P;
                 for (int r = 0; r < nreads; ++r) {
@@ -168,36 +137,47 @@ struct OracleCvOps : hs::CvDeviceOps {
                 parts[(size_t)c].push_back(P);
             }
         }
-        for (size_t i = 0; i < n; ++i) {
-            hso::Column col;
-            for (int64_t k = off[i]; k < off[i + 1]; ++k) { col.readIdxs.push_back((unsigned)col_idx[(size_t)k]); col.content.push_back(col_code[(size_t)k]); }
-            col.ref_base = t.col_k0[i]; col.second_base = t.col_k1[i];
-            const std::vector<hso::Partition>& fin = parts[(size_t)t.col_contig[i]];
+        std::vector<std::vector<size_t>> autos((size_t)C), filt((size_t)C);
+        for (size_t i = 0; i < xcols.size(); ++i) {
+            hs_colrec& r = xcols[i].rec;
+            const int c = xcols[i].contig - r0;
+            hso::Column col = msa[(size_t)xcols[i].contig].cols[(size_t)xcols[i].pos];
+            col.ref_base = r.k0; col.second_base = r.k1;
+            const std::vector<hso::Partition>& fin = parts[(size_t)c];
             bool kept = false;
-            if (t.col_is_cand[i]) {
+            if (r.flags & HS_COL_CAND) {
                 for (const hso::Partition& P : fin) {
                     hso::DistRes d = hso::distance(P, col, (char)col.ref_base);
                     if (d.n00 + d.n01 + d.n10 + d.n11 > 0.5 * col.content.size() && hso::computeChiSquare(d) > 15) { kept = true; break; }
                 }
             }
-            if (!kept && t.col_c1[i] >= 5) {
-                const int rb = col.ref_base, sb = col.second_base;
-                if (rb % 5 != sb % 5 && ((sb - '!') % 5 != 4 || (sb / 5 % 5 != rb % 5 && sb / 25 % 5 != rb % 5))) {
-                    for (const hso::Partition& P : fin) {
-                        hso::DistRes d = hso::distance(P, col, (char)col.ref_base);
-                        if (hso::computeChiSquare(d) > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) { kept = true; break; }
-                    }
+            if (!kept && (r.flags & HS_COL_LOOPD)) {
+                for (const hso::Partition& P : fin) {
+                    hso::DistRes d = hso::distance(P, col, (char)col.ref_base);
+                    if (hso::computeChiSquare(d) > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) { kept = true; break; }
                 }
             }
-            keep[i] = kept ? 1 : 0;
+            r.flags &= ~(HS_COL_KEEP | HS_COL_SNP);
+            if (kept) { r.flags |= HS_COL_KEEP; filt[(size_t)c].push_back(i); }
+            if (r.flags & HS_COL_AUTO) autos[(size_t)c].push_back(i);
         }
+        for (int c = 0; c < C; ++c) {
+            size_t ia = 0, ifi = 0;
+            const std::vector<size_t>& A = autos[(size_t)c]; const std::vector<size_t>& F = filt[(size_t)c];
+            while (ia < A.size() && ifi < F.size()) {
+                const int pa = xcols[A[ia]].pos, pf = xcols[F[ifi]].pos;
+                if (pa < pf) { xcols[A[ia]].rec.flags |= HS_COL_SNP; ia++; }
+                else if (pa > pf) { xcols[F[ifi]].rec.flags |= HS_COL_SNP; ifi++; }
+                else { xcols[A[ia]].rec.flags |= HS_COL_SNP; ia++; ifi++; }
+                out.contig_n_snp[(size_t)c]++;
+            }
+        }
+        pack(HS_COL_SNP);
+        out.n_snp = (int64_t)pk_rec.size(); out.n_entries = pk_off.back();
+        out.rec = pk_rec.data(); out.off = pk_off.data();
+        if (want_entries) { out.idx = pk_idx.data(); out.code = pk_code.data(); }
         return 0;
     }
-    std::vector<int32_t> last_sel_pos;
-    std::vector<int64_t> last_col_off;
-    std::vector<int32_t> packed_idx[2];
-    std::vector<uint8_t> packed_code[2];
-    std::vector<hs_coltop> tops;
 };
 
 struct OracleSrOps : hs::SrDeviceOps {
@@ -348,24 +328,6 @@ struct OracleSrOps : hs::SrDeviceOps {
 }  // namespace
 
 // `selftest`: host-side pieces of the drivers that need no device and no input files
-struct RangeOnlyOps : hs::CvDeviceOps {
-    std::vector<int64_t> gpos; std::vector<int32_t> depth;
-    int pileup_and_select(std::vector<int32_t>&, int, const int64_t**, const int32_t**, size_t*, float*) override { return -1; }
-    int gather(const std::vector<int32_t>&, const std::vector<int32_t>&, const std::vector<int64_t>&, const hs_coltop**, float*) override { return -1; }
-    int fetch_columns(const std::vector<int32_t>&, const std::vector<int64_t>&, int, const int32_t**, const uint8_t**) override { return -1; }
-    int column_partition_test(const hs::CvPartitionTest&, std::vector<uint8_t>&, float*) override { return -1; }
-    bool has_select_range() const override { return true; }
-    int select_range(int64_t g0, int64_t g1, int, const int64_t** sg, const int32_t** sd, size_t* n, float* k_ms) override {
-        // like the device: everything of the 256-position tiles that hold [g0, g1), i.e. also positions of the neighbours
-        static std::vector<int64_t> og; static std::vector<int32_t> od;
-        og.clear(); od.clear();
-        const int64_t t0 = (g0 >> 8) << 8, t1 = ((g1 + 255) >> 8) << 8;
-        for (size_t i = 0; i < gpos.size(); ++i) if (gpos[i] >= t0 && gpos[i] < t1) { og.push_back(gpos[i]); od.push_back(depth[i]); }
-        *sg = og.data(); *sd = od.data(); *n = og.size(); if (k_ms) *k_ms = 0;
-        return 0;
-    }
-};
-
 static int selftest() {
     int bad = 0;
     auto expect = [&](bool ok, const char* what) { if (!ok) { std::fprintf(stderr, "selftest FAILED: %s\n", what); bad++; } };
@@ -395,21 +357,6 @@ static int selftest() {
         std::memset(plain, 0, 64);
         hs::sr_labels_free(nullptr);      // (accepted)
         std::free(plain);
-    }
-    {   // cv_select_range: positions of the neighbouring ranges from the boundary tiles are dropped, offsets start at c0
-        hs::CvMeta m;
-        m.n_contigs = 4; m.contig_off = {0, 300, 700, 1000, 1300}; m.total_len = 1300;
-        RangeOnlyOps ops;
-        ops.gpos = {10, 290, 310, 500, 699, 700, 705, 999, 1001, 1200};
-        ops.depth = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10};
-        hs::CvSelection sel;
-        expect(hs::cv_select_range(ops, m, 1, 3, sel) == 0, "cv_select_range runs");
-        const std::vector<int32_t> wc = {1, 1, 1, 2, 2, 2}, wp = {10, 200, 399, 0, 5, 299}, wd = {3, 4, 5, 6, 7, 8};
-        expect(std::vector<int32_t>(sel.sel_contig.begin(), sel.sel_contig.end()) == wc, "cv_select_range contigs");
-        expect(std::vector<int32_t>(sel.sel_pos.begin(), sel.sel_pos.end()) == wp, "cv_select_range positions");
-        expect(std::vector<int32_t>(sel.sel_depth.begin(), sel.sel_depth.end()) == wd, "cv_select_range depths");
-        const std::vector<int64_t> wo = {0, 0, 3, 6, 6};
-        expect(sel.contig_sel_off == wo, "cv_select_range offsets");
     }
     std::printf("selftest %s\n", bad ? "FAILED" : "ok");
     return bad ? 1 : 0;
@@ -441,11 +388,14 @@ int main(int argc, char** argv) {
         }
         OracleCvOps ops(in);
         hs_cv_result* res = nullptr;
-        if (std::getenv("HS_HARNESS_RANGE_SELECT")) {   // the way a contig group goes: pileup, then selection + stage 3 of a range (here: all contigs)
-            hs::CvSelection whole, range;
+        if (std::getenv("HS_HARNESS_RANGE_SELECT")) {   // the way the contig groups go: the pileup of the batch, then stage 3 range by range, results put together
+            hs::CvSelection whole;
             if (int rc = hs::cv_pileup(ops, meta, whole)) return rc;
-            if (int rc = hs::cv_select_range(ops, meta, 0, meta.n_contigs, range)) return rc;
-            if (int rc = hs::cv_run_range(ops, meta, range, 0, meta.n_contigs, std::strtof(a[11], nullptr), 1, &res, &whole.rec_stats)) return rc;
+            const int mid = meta.n_contigs / 2;
+            hs_cv_result* ra = nullptr; hs_cv_result* rb = nullptr;
+            if (int rc = hs::cv_run_range(ops, meta, whole.rec_stats, 0, mid, std::strtof(a[11], nullptr), 1, &ra)) return rc;
+            if (int rc = hs::cv_run_range(ops, meta, whole.rec_stats, mid, meta.n_contigs, std::strtof(a[11], nullptr), 1, &rb)) return rc;
+            res = hs::cv_concat_results(ra, rb);
         } else
         if (int rc = hs::cv_run(ops, meta, std::strtof(a[11], nullptr), 1, &res)) return rc;
         hs::write_cv_outputs(in, res, a[6], a[9], a[10], 4);

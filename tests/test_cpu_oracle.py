@@ -35,24 +35,10 @@ def test_host_glue_matches_reference_goldens(built, case):
         assert gu.compare(td, outs) == []
 
 
-@pytest.mark.parametrize("case", ["dip20k", "penta30k", "edge_ops"])
-def test_host_glue_with_every_column_resolved_on_host(built, case):
-    """Same, with the harness reporting every column as a tie: the exact (reference order) top-3 then runs on all
-    columns instead of only where K3b asks for it, and everything is downloaded up front (no late fetch)."""
-    if case not in gu.case_names():
-        pytest.skip("golden case not present")
-    with tempfile.TemporaryDirectory() as td:
-        meta = gu.unpack(case, td)
-        env = dict(os.environ, HS_HARNESS_ALL_TIES="1")
-        outs = gu.run_stage_pair([built["harness"], "call_variants"], [built["harness"], "separate_reads"], td, meta, env=env)
-        assert gu.compare(td, outs) == []
-
-
 @pytest.mark.parametrize("case", ["multi", "penta30k", "edge_ops"])
 def test_host_glue_through_the_per_range_selection(built, case):
-    """Same, the way a contig group goes through stage 3: pileup of the batch (cv_pileup), then the selection of a range of contigs
-    (cv_select_range: sorted list of the range's tiles, neighbours' positions dropped) and cv_run_range with the batch's
-    per-record counters handed in separately"""
+    """Same, the way the contig groups go through stage 3: pileup of the batch (cv_pileup), then cv_run_range on two consecutive
+    ranges of contigs with the batch's per-record counters, the two results put together (cv_concat_results)"""
     if case not in gu.case_names():
         pytest.skip("golden case not present")
     with tempfile.TemporaryDirectory() as td:
@@ -82,6 +68,16 @@ def test_host_driver_selftest(built):
     selection of the contig groups (cv_select_range: boundary tiles bring positions of the neighbouring ranges)"""
     r = subprocess.run([built["harness"], "selftest"], capture_output=True, text=True)
     assert r.returncode == 0 and "selftest ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_hash_map_view_and_std_sort_restatements(built):
+    """What the device uses to order equal counts exactly as the reference does (k_column_top3_exact): hs::Rh8View against the
+    pinned emulator, hs::CountSort against std::sort of this libstdc++ -- random, tie-heavy and adversarial (heap-sort branch) inputs"""
+    exe = os.path.join(ROOT, "tests", "harness", "_build", "sort_selftest")
+    r = subprocess.run([exe, "200000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert " bad 0;" in r.stdout and r.stdout.strip().split(" bad ")[2].startswith("0 ")
+    assert int(r.stdout.split("heap-paths")[1]) > 50
 
 
 def test_rh8_static_order(built):

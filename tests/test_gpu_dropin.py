@@ -326,3 +326,57 @@ def test_separate_reads_with_many_alleles_per_column(built):
             subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
             outs.append(open(gro, "rb").read())
         assert len(outs[0]) > 1000 and outs[0] == outs[1]
+
+
+def test_pipeline_group_threads_run_on_the_device_of_their_batch(built):
+    """The HIP current device is a per-thread setting that starts at 0: every contig-group thread of a pipeline must bind itself
+    to the device its batch was created on (with one visible device that is device 0 -- the binding itself is what is checked:
+    a thread that failed to bind reports -1)."""
+    import ctypes
+    from hairsplitter_amd import api, synth
+    lib = api.load()
+    contigs = [synth.make_contig(3, k, 6000, 2, 0.01, 20, "ont") for k in range(4)]
+    pg = api.PipelineGroups(contigs, 3)
+    try:
+        dev = lib.hs_cv_batch_device(pg.batch.handle)
+        assert dev == 0
+        buf = (ctypes.c_int32 * 8)(*([-7] * 8))
+        n = lib.hs_pipeline_thread_devices(pg.handle, buf, 8)
+        assert n == 3 and list(buf[:3]) == [dev] * 3
+        cv, sr = pg.run()          # ... and the pipeline works from a thread that was never bound by the caller
+        assert cv["n_snps"] > 0
+    finally:
+        pg.close()
+
+
+def test_killing_the_dropin_leaves_no_worker_behind(built):
+    """The executables do their work in a forked child (hs_dropin_main.h). A caller that kills the process it started must not
+    leave that child holding the GPU and writing the outputs: SIGTERM is passed on, and the child dies with its parent."""
+    import signal
+    import time
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack("penta30k", td)
+        args = [os.path.join(td, "assembly.gfa"), gu.reads_path(td, meta), os.path.join(td, "aln.sam"), "2", td, os.path.join(td, "err.txt"),
+                "0", "0", os.path.join(td, "o.col"), os.path.join(td, "o.vcf"), "0.33"]
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            p = subprocess.Popen([built["cv"]] + args, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            kids = []
+            for _ in range(200):      # the child appears within milliseconds
+                try:
+                    kids = [int(x) for x in open(f"/proc/{p.pid}/task/{p.pid}/children").read().split()]
+                except OSError:
+                    kids = []
+                if kids or p.poll() is not None:
+                    break
+                time.sleep(0.005)
+            if p.poll() is not None:
+                continue      # finished before it could be killed: nothing to check
+            assert kids, "the drop-in did not fork its worker"
+            p.send_signal(sig)
+            p.wait(timeout=30)
+            deadline = time.time() + 20
+            while time.time() < deadline and any(os.path.exists(f"/proc/{k}") and "Z" not in open(f"/proc/{k}/stat").read().split(")")[-1][:3] for k in kids):
+                time.sleep(0.05)
+            for k in kids:
+                alive = os.path.exists(f"/proc/{k}") and "Z" not in open(f"/proc/{k}/stat").read().split(")")[-1][:3]
+                assert not alive, f"worker {k} survived its parent being killed with signal {int(sig)}"
