@@ -1291,14 +1291,21 @@ struct HipCvOps : hs::CvDeviceOps {
 
     // ---- K4 + the merge of the SNP lists + the SNP columns packed (they stay in d_pk_* for stage 4) ----
     DBuf d_keep;
-    std::vector<int32_t> snp_contig_n;
+    int64_t snp_count = 0, snp_entries = 0;       // what d_pk_off / d_pk_idx / d_pk_code hold after finish_columns (HipSrOps::adopt_columns)
     int finish_columns(const hs::CvPartitionTest& t, bool want_entries, hs::CvSnpSet& out, float* k_ms) override {
         const int C = range_c1 - range_c0;
         out = hs::CvSnpSet();
         out.contig_n_snp.assign((size_t)C, 0);
         if (k_ms) *k_ms = 0;
         if ((int)t.contig_n_reads.size() != C) { set_error("finish_columns: partitions of another contig range"); return HS_EINVAL; }
-        if (n_cols == 0 || C == 0) { if (int rc = grow(h_pk_off, 8)) return rc; *(int64_t*)h_pk_off.p = 0; out.off = (const int64_t*)h_pk_off.p; return HS_OK; }
+        snp_count = 0; snp_entries = 0;
+        if (n_cols == 0 || C == 0) {
+            if (int rc = grow(h_pk_off, 8)) return rc;
+            if (int rc = grow(d_pk_off, 8)) return rc;
+            HS_HIP(hipMemsetAsync(d_pk_off.p, 0, 8, stream));
+            *(int64_t*)h_pk_off.p = 0; out.off = (const int64_t*)h_pk_off.p;
+            return stream_wait(stream);
+        }
         const int n = (int)n_cols;
         DBuf d_po, d_pso, d_ps;
         UploadPack pk;
@@ -1327,6 +1334,7 @@ struct HipCvOps : hs::CvDeviceOps {
         HS_HIP(hipMemcpyAsync(h_ctg_n.p, d_ctg_n.p, (size_t)C * 4, hipMemcpyDeviceToHost, stream));
         if (int rc = stream_wait(stream)) return rc;       // (the partition tables, uploads and lists of this scope are done with)
         out.n_snp = n_snp; out.n_entries = e_snp;
+        snp_count = n_snp; snp_entries = e_snp;
         out.rec = (const hs_colrec*)h_pk_rec.p; out.off = (const int64_t*)h_pk_off.p;
         if (want_entries) { out.idx = (const int32_t*)h_pk_idx.p; out.code = (const uint8_t*)h_pk_code.p; }
         std::memcpy(out.contig_n_snp.data(), h_ctg_n.p, (size_t)C * 4);
@@ -1670,13 +1678,61 @@ struct HipSrOps : hs::SrDeviceOps {
     }
     ~HipSrOps() override { (void)settle_simdiff(false); }   // the caller's counter may be gone by now
 
-    DBuf d_col_off, d_col_idx, d_col_code;    // SNP columns of the batch: uploaded once, read by K5a and the seeded CW runs
+    DBuf d_col_off, d_col_idx, d_col_code;    // SNP columns of the batch: uploaded once (or taken over from stage 3), read by K5a and the seeded CW runs
     UploadPack col_pack;
     const hs::CwChain* resident_cols = nullptr;
+    // stage 3 -> 4 on the device: the packed SNP columns HipCvOps::finish_columns left (offsets, read indices, codes) become this
+    // object's columns; nothing is uploaded
+    bool adopted = false;
+    int64_t adopted_cols = 0, adopted_entries = 0;
+    void adopt_columns(HipCvOps& cv) {
+        std::swap(d_col_off, cv.d_pk_off); std::swap(d_col_idx, cv.d_pk_idx); std::swap(d_col_code, cv.d_pk_code);
+        adopted = true; adopted_cols = cv.snp_count; adopted_entries = cv.snp_entries;
+    }
+    bool columns_resident() const override { return adopted; }
+    void drop_resident_columns() override { adopted = false; resident_cols = nullptr; }
+    int fetch_columns(std::vector<int32_t>& idx, std::vector<uint8_t>& code) override {
+        if (!adopted) { set_error("fetch_columns: no resident columns"); return HS_EINVAL; }
+        idx.resize((size_t)adopted_entries); code.resize((size_t)adopted_entries);
+        if (adopted_entries == 0) return HS_OK;
+        if (int rc = d2h_pinned(idx.data(), d_col_idx.p, (size_t)adopted_entries * 4, stream)) return rc;
+        return d2h_pinned(code.data(), d_col_code.p, (size_t)adopted_entries, stream);
+    }
+    int window_masks(const std::vector<int64_t>& col_a, const std::vector<int64_t>& col_b, const std::vector<int64_t>& slot_off,
+                     std::vector<int32_t>& ids, std::vector<int32_t>& win_m) override {
+        if (!adopted) { set_error("window_masks: no resident columns"); return HS_EINVAL; }
+        const int W = (int)col_a.size();
+        const int64_t total = slot_off.back();
+        ids.resize((size_t)total); win_m.assign((size_t)W, 0);
+        if (W == 0) return HS_OK;
+        DBuf d_a, d_b, d_so, d_ids, d_m;
+        UploadPack pk;
+        pk.add(col_a, d_a); pk.add(col_b, d_b); pk.add(slot_off, d_so);
+        if (int rc = pk.commit(stream)) return rc;
+        if (int rc = d_ids.alloc(std::max<size_t>(1, (size_t)total) * 4)) return rc;
+        if (int rc = d_m.alloc((size_t)W * 4)) return rc;
+        if (int rc = kc.begin(HS_K_OTHER, stream)) return rc;
+        hipLaunchKernelGGL(hsdev::k_window_masks, dim3((unsigned)((W + 3) / 4)), dim3(256), 0, stream, d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_a.as<int64_t>(),
+                           d_b.as<int64_t>(), d_so.as<int64_t>(), W, d_ids.as<int32_t>(), d_m.as<int32_t>());
+        HS_HIP(hipGetLastError());
+        if (int rc = kc.end(8 * total + 4 * (int64_t)W, stream)) return rc;
+        HBuf h_ids, h_m;
+        if (int rc = h_ids.alloc(std::max<size_t>(1, (size_t)total) * 4)) return rc;
+        if (int rc = h_m.alloc((size_t)W * 4)) return rc;
+        if (total) HS_HIP(hipMemcpyAsync(h_ids.p, d_ids.p, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
+        HS_HIP(hipMemcpyAsync(h_m.p, d_m.p, (size_t)W * 4, hipMemcpyDeviceToHost, stream));
+        if (int rc = stream_wait(stream)) return rc;
+        if (total) std::memcpy(ids.data(), h_ids.p, (size_t)total * 4);
+        std::memcpy(win_m.data(), h_m.p, (size_t)W * 4);
+        kc.flush();
+        return HS_OK;
+    }
     int simdiff_columns(const hs::SimdiffJob& job, float* k_ms) override {
         const hs::CwChain& ch = *job.cols;
-        col_pack.add(ch.col_off, d_col_off); col_pack.add(ch.col_idx, d_col_idx); col_pack.add(ch.col_code, d_col_code);
-        if (int rc = col_pack.commit(stream)) return rc;
+        if (!adopted) {
+            col_pack.add(ch.col_off, d_col_off); col_pack.add(ch.col_idx, d_col_idx); col_pack.add(ch.col_code, d_col_code);
+            if (int rc = col_pack.commit(stream)) return rc;
+        } else if ((int64_t)ch.col_off.size() != adopted_cols + 1) { set_error("simdiff_columns: the resident columns are not those of this call"); return HS_EINVAL; }
         resident_cols = job.cols;
         sd_out_off = job.out_off; sd_n = job.n_reads;
         if (job.out_total <= 0) return HS_OK;
@@ -1704,7 +1760,7 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = hs_snp_planes(d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(), f.d_sr.as<uint8_t>(), f.d_sa.as<uint8_t>(),
                                    f.d_sc.as<int32_t>(), f.d_cb.as<int64_t>(), f.d_po.as<int64_t>(), f.d_w.as<int32_t>(), (int32_t)job.snp_ref.size(),
                                    f.d_alt.as<uint64_t>(), f.d_ref.as<uint64_t>(), stream)) return rc;
-        if (int rc = kc.end(5 * (int64_t)ch.col_idx.size() + 2 * (int64_t)pbytes, stream)) return rc;
+        if (int rc = kc.end(5 * (adopted ? adopted_entries : (int64_t)ch.col_idx.size()) + 2 * (int64_t)pbytes, stream)) return rc;
         if (int rc = f.ev.init()) return rc;
         HS_HIP(hipEventRecord(f.ev.a, stream));
         if (int rc = kc.begin(HS_K_SIMDIFF, stream)) return rc;
@@ -1780,7 +1836,7 @@ struct HipSrOps : hs::SrDeviceOps {
         }
         DBuf d_ll, d_sets, d_names, d_slots, d_alive, d_ovf, d_ovf_n, d_iw, d_is, d_seed, d_uw, d_ui, d_un, d_lb, d_bs, d_cw, d_cr0, d_csb, d_cs0, d_ts, d_slab, d_gs, d_l3, d_final, d_ok, d_stat,
             d_cpos, d_sf, d_sl, d_plo, d_phi;
-        if (resident_cols != &ch) {   // normally uploaded by simdiff_columns already
+        if (resident_cols != &ch && !adopted) {   // normally uploaded by simdiff_columns already
             col_pack.add(ch.col_off, d_col_off); col_pack.add(ch.col_idx, d_col_idx); col_pack.add(ch.col_code, d_col_code);
             if (int rc = col_pack.commit(stream)) return rc;
             resident_cols = &ch;
@@ -2269,8 +2325,11 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
         const int c0 = p->ranges[(size_t)g].first, c1 = p->ranges[(size_t)g].second;
         hs::CvMeta meta; fill_meta(p->batch, meta);
         HipCvOps cv_ops(p->batch);
-        if (int r = hs::cv_run_range(cv_ops, meta, ((const hs::CvSelection*)p->sel->impl)->rec_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g])) return r;
+        // the SNP columns stay on the device: stage 4 takes them over where stage 3 packed them (HS_COLUMNS_VIA_HOST=1: down and up again)
+        static const bool via_host = std::getenv("HS_COLUMNS_VIA_HOST") != nullptr;
+        if (int r = hs::cv_run_range(cv_ops, meta, ((const hs::CvSelection*)p->sel->impl)->rec_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host)) return r;
         HipSrOps ops;
+        if (!via_host) ops.adopt_columns(cv_ops);
         return hs::sr_run_from_cv(ops, meta, c0, c1, p->cv[(size_t)g], error_rate, rarest_strain_abundance, low_memory, amplicon, seed, per, window_size,
                                   &parts[(size_t)g], &sparse[(size_t)g]);
     });

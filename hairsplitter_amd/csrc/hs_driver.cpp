@@ -427,10 +427,14 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     double dev_ms = 0;
     float k_ms[4] = {0, 0, 0, 0};
 
+    // the SNP columns may be with the device already (stage 3 left them there): the host then only has their offsets, until
+    // something needs to walk them here (need_columns)
+    const bool resident = dev.columns_resident();
+    std::vector<hs_sr_contig> cs_local(contigs, contigs + C);      // (the column pointers are filled in if the columns are fetched)
     std::vector<SrContigState> st((size_t)C);
     parallel_for(C, n_threads, [&](int c) {
         SrContigState& s = st[(size_t)c];
-        s.c = &contigs[c];
+        s.c = &cs_local[(size_t)c];
         s.N = contigs[c].n_reads;
         s.low_memory_now = lowmem || sr_coverage_above_1000(contigs[c]);   // separate_reads.cpp:1515-1518
         if (contigs[c].n_snps == 0) return;                                 // :1522-1524
@@ -456,19 +460,22 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         bool contiguous = n_col > 0;
         {
             const int64_t* off_next = nullptr; const int32_t* idx0 = nullptr; const uint8_t* code0 = nullptr;
+            bool first = true;
             for (int c = 0; c < C && contiguous; ++c) {
                 const hs_sr_contig& hc = contigs[c];
                 if (hc.n_snps == 0) continue;
-                if (!idx0) { idx0 = hc.col_idx; code0 = hc.col_code; if (hc.col_off[0] != 0) contiguous = false; }
+                if (first) { first = false; idx0 = hc.col_idx; code0 = hc.col_code; if (hc.col_off[0] != 0) contiguous = false; }
                 else if (hc.col_idx != idx0 || hc.col_code != code0 || hc.col_off != off_next) contiguous = false;
                 off_next = hc.col_off + hc.n_snps;
             }
         }
+        if (resident && n_col > 0 && !contiguous) { set_error("sr_run: resident columns need one offset array in contig order"); return HS_EINVAL; }
         int64_t* own_off = nullptr; int32_t* own_idx = nullptr; uint8_t* own_code = nullptr;
         if (contiguous) {
             const hs_sr_contig* first = nullptr;
             for (int c = 0; c < C && !first; ++c) if (contigs[c].n_snps) first = &contigs[c];
-            ch.col_off.view(first->col_off, (size_t)n_col + 1); ch.col_idx.view(first->col_idx, (size_t)n_ent); ch.col_code.view(first->col_code, (size_t)n_ent);
+            ch.col_off.view(first->col_off, (size_t)n_col + 1);
+            if (!resident) { ch.col_idx.view(first->col_idx, (size_t)n_ent); ch.col_code.view(first->col_code, (size_t)n_ent); }
         } else {
             own_off = ch.col_off.alloc((size_t)n_col + 1); own_idx = ch.col_idx.alloc((size_t)n_ent); own_code = ch.col_code.alloc((size_t)n_ent);
             own_off[0] = 0;
@@ -512,12 +519,49 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
 
     const double t_simdiff_done = now_ms();
     laps.lap("simdiff");
+    // the columns on the host, for the few things that walk them here (resident case: fetched once, on demand)
+    std::vector<int32_t> fetched_idx; std::vector<uint8_t> fetched_code;
+    bool columns_here = !resident;
+    auto need_columns = [&]() -> int {
+        if (columns_here) return HS_OK;
+        const double t0 = now_ms();
+        if (int rc = dev.fetch_columns(fetched_idx, fetched_code)) return rc;
+        dev_ms += now_ms() - t0;
+        for (int c = 0; c < C; ++c) { cs_local[(size_t)c].col_idx = fetched_idx.data(); cs_local[(size_t)c].col_code = fetched_code.data(); }
+        ch.col_idx.view(fetched_idx.data(), fetched_idx.size()); ch.col_code.view(fetched_code.data(), fetched_code.size());
+        columns_here = true;
+        return HS_OK;
+    };
     // ---- window plans (host) ----
     parallel_for(C, n_threads, [&](int c) {
         if (contigs[c].n_snps == 0) return;
-        sr_plan_windows(st[(size_t)c], window_size, error_rate, lowmem);
+        sr_plan_windows(st[(size_t)c], window_size, error_rate, lowmem, !resident);
     });
     laps.lap("plan_windows");
+    if (resident) {   // the reads of every window from the device: those present at its first and its last SNP column
+        struct WR { int c, w; };
+        std::vector<WR> wr;
+        for (int c = 0; c < C; ++c)
+            for (size_t w = 0; w < st[(size_t)c].windows.size(); ++w) if (st[(size_t)c].windows[w].has_snps) wr.push_back(WR{c, (int)w});
+        const size_t W = wr.size();
+        std::vector<int64_t> col_a(W), col_b(W), slot_off(W + 1, 0);
+        for (size_t i = 0; i < W; ++i) {
+            const SrWindowPlan& wp = st[(size_t)wr[i].c].windows[(size_t)wr[i].w];
+            col_a[i] = col_base_of_contig[(size_t)wr[i].c] + wp.col_a; col_b[i] = col_base_of_contig[(size_t)wr[i].c] + wp.col_b;
+            slot_off[i + 1] = slot_off[i] + (ch.col_off[(size_t)col_a[i] + 1] - ch.col_off[(size_t)col_a[i]]);
+        }
+        std::vector<int32_t> ids, win_m;
+        if (W) {
+            const double t0 = now_ms();
+            if (int rc = dev.window_masks(col_a, col_b, slot_off, ids, win_m)) return rc;
+            dev_ms += now_ms() - t0;
+        }
+        parallel_for((int)W, n_threads, [&](int i) {
+            SrWindowPlan& wp = st[(size_t)wr[(size_t)i].c].windows[(size_t)wr[(size_t)i].w];
+            wp.ids.assign(ids.begin() + slot_off[(size_t)i], ids.begin() + slot_off[(size_t)i] + win_m[(size_t)i]);
+        });
+        laps.lap("window_masks");
+    }
     // ---- the window set of the call: matrix-path windows first (their graphs come from K6), then the low-memory ones ----
     struct WRef { int c, w; };
     std::vector<WRef> wrefs;            // index = window index in the set
@@ -554,6 +598,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         // create_read_graph_low_memory (-l, or coverage > 1000): O(m^2 S) per window on the host, one task per window
         const int n_host = (int)host_w.size();
         if (n_host > 0) {
+            if (int rc = need_columns()) return rc;
             std::vector<std::vector<std::vector<int32_t>>> lists((size_t)n_host);
             parallel_for(n_host, n_threads, [&](int i) {
                 const WRef& r = wrefs[(size_t)ws.n_dev_windows + (size_t)i];
@@ -634,7 +679,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         bool any_host = false;
         for (size_t i = 0; i < wrefs.size() && !any_host; ++i)
             if (chain_index[i] >= 0 && (final_ok.empty() || !final_ok[(size_t)chain_index[i]])) any_host = true;
-        if (any_host) { if (int rc = need_graphs()) return rc; }
+        if (any_host) { if (int rc = need_graphs()) return rc; if (int rc = need_columns()) return rc; }
     }
     parallel_for((int)wrefs.size(), n_threads, [&](int i) {
         SrContigState& s = st[(size_t)wrefs[(size_t)i].c];
@@ -752,6 +797,22 @@ int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, int c0, int c1, const hs_c
     if (c0 < 0 || c1 > b.n_contigs || c0 > c1 || cv->n_contigs != c1 - c0) { set_error("sr_run_from_cv: contig range does not match the stage-3 result"); return HS_EINVAL; }
     const int C = c1 - c0;
     const double t_prep0 = now_ms();
+    // SNP columns that stayed on the device (stage 3 ran with `resident`): the result carries their offsets only. If SNPs have to
+    // be dropped below, the columns are needed here after all: fetched, and stage 4 uploads what is left
+    std::vector<int32_t> fetched_idx; std::vector<uint8_t> fetched_code;
+    const int32_t* cv_idx = cv->col_idx; const uint8_t* cv_code = cv->col_code;
+    const bool resident_in = cv->col_idx == nullptr && cv->snp_off[C] > 0 && cv->col_off[cv->snp_off[C]] > 0;
+    if (resident_in && !dev.columns_resident()) { set_error("sr_run_from_cv: the stage-3 result has no columns and the device has none either"); return HS_EINVAL; }
+    if (resident_in) {
+        bool all = true;
+        for (int64_t s = 0; s < cv->snp_off[C] && all; ++s)
+            if (!((float)cv->snp_n_alt[s] >= rsa * (float)(cv->snp_n_ref[s] + cv->snp_n_alt[s]))) all = false;
+        if (!all) {
+            if (int rc = dev.fetch_columns(fetched_idx, fetched_code)) return rc;
+            dev.drop_resident_columns();
+            cv_idx = fetched_idx.data(); cv_code = fetched_code.data();
+        }
+    } else if (dev.columns_resident()) dev.drop_resident_columns();
     std::vector<hs_sr_contig> hc((size_t)C);
     std::vector<std::vector<int32_t>> rs((size_t)C), re((size_t)C), spos((size_t)C);
     std::vector<std::vector<uint8_t>> sref((size_t)C), salt((size_t)C);
@@ -774,13 +835,13 @@ int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, int c0, int c1, const hs_c
         for (int64_t s = s0; s < s1; ++s) {
             int maj = 0, sec = 0;
             if (cv->snp_n_ref && cv->snp_n_alt) { maj = cv->snp_n_ref[s]; sec = cv->snp_n_alt[s]; }   // counted by stage 3 already
-            else for (int64_t e = cv->col_off[s]; e < cv->col_off[s + 1]; ++e) { if (cv->col_code[e] == cv->snp_ref[s]) maj++; else if (cv->col_code[e] == cv->snp_alt[s]) sec++; }
+            else for (int64_t e = cv->col_off[s]; e < cv->col_off[s + 1]; ++e) { if (cv_code[e] == cv->snp_ref[s]) maj++; else if (cv_code[e] == cv->snp_alt[s]) sec++; }
             if (!((float)sec >= rsa * (float)(maj + sec))) { keep[(size_t)(s - s0)] = 0; all_kept = false; }
         }
         hs_sr_contig& h = hc[(size_t)c];
         h.length = b.contig_off[(size_t)gc + 1] - b.contig_off[(size_t)gc];
         h.n_reads = r1 - r0; h.read_start = rs[(size_t)c].data(); h.read_end = re[(size_t)c].data();
-        h.col_idx = cv->col_idx; h.col_code = cv->col_code; h.ploidy = b.ploidy.empty() ? 0 : b.ploidy[(size_t)gc];
+        h.col_idx = cv_idx; h.col_code = cv_code; h.ploidy = b.ploidy.empty() ? 0 : b.ploidy[(size_t)gc];
         if (all_kept) {
             h.n_snps = (int32_t)(s1 - s0); h.snp_pos = cv->snp_pos + s0; h.snp_ref = cv->snp_ref + s0; h.snp_alt = cv->snp_alt + s0;
             h.col_off = cv->col_off + s0;
@@ -803,8 +864,8 @@ int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, int c0, int c1, const hs_c
         size_t k = 0;
         for (int64_t s = cv->snp_off[c]; s < cv->snp_off[c + 1]; ++s) {
             if (k < spos[(size_t)c].size() && cv->snp_pos[s] == spos[(size_t)c][k]) {
-                cidx[(size_t)c].insert(cidx[(size_t)c].end(), cv->col_idx + cv->col_off[s], cv->col_idx + cv->col_off[s + 1]);
-                ccode[(size_t)c].insert(ccode[(size_t)c].end(), cv->col_code + cv->col_off[s], cv->col_code + cv->col_off[s + 1]);
+                cidx[(size_t)c].insert(cidx[(size_t)c].end(), cv_idx + cv->col_off[s], cv_idx + cv->col_off[s + 1]);
+                ccode[(size_t)c].insert(ccode[(size_t)c].end(), cv_code + cv->col_off[s], cv_code + cv->col_off[s + 1]);
                 coff[(size_t)c].push_back((int64_t)cidx[(size_t)c].size());
                 k++;
             }

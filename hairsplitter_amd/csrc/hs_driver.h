@@ -198,6 +198,18 @@ struct SrDeviceOps {
     virtual int cw_chain(const CwChain& chain, std::vector<int32_t>& labels, std::vector<int32_t>& final_labels,
                          std::vector<uint8_t>& final_ok, float k_ms[3], SrChainStats* stats) = 0;
     virtual int cw(CwWave& wave, float* k_ms) = 0;
+    // The SNP columns of the call may be with the implementation already (stage 3 left them on the device, in the order and with
+    // the offsets of CwChain::col_off): then CwChain's col_idx / col_code stay empty and ...
+    virtual bool columns_resident() const { return false; }
+    virtual void drop_resident_columns() {}
+    // ... the reads of every clustering window -- those present at its first AND its last SNP column (separate_reads.cpp:1590-1622),
+    // global column indices col_a / col_b -- come from there: the reads of window w at ids[slot_off[w] ...], win_m[w] of them
+    // (slot_off: room for the whole first column of every window) ...
+    virtual int window_masks(const std::vector<int64_t>& col_a, const std::vector<int64_t>& col_b, const std::vector<int64_t>& slot_off,
+                             std::vector<int32_t>& ids, std::vector<int32_t>& win_m) { (void)col_a; (void)col_b; (void)slot_off; (void)ids; (void)win_m; return -1; }
+    // ... and the columns themselves can be fetched for the few places that walk them on the host (low-memory graphs, windows the
+    // device did not finish)
+    virtual int fetch_columns(std::vector<int32_t>& idx, std::vector<uint8_t>& code) { (void)idx; (void)code; return -1; }
 };
 
 int host_threads();      // default number of host worker threads: usable cores (cgroup quota), at most 32

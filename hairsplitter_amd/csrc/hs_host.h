@@ -64,6 +64,7 @@ struct SrWindowPlan {
     int final_lo = 0, final_hi = 0;  // [posstart, posend) handed to merge_wrongly_split_haplotypes
     int64_t row0 = -1;               // first row of the window in the graph set of the call (window-local CSR rows)
     bool final_graph_empty = false;  // finalize_clustering sees a graph that was never filled (separate_reads.cpp:1708 quirk)
+    int col_a = -1, col_b = -1;      // first and last SNP column of the window (indices on the contig): its reads are those present at both
 };
 
 // ---- files -----------------------------------------------------------------------------------

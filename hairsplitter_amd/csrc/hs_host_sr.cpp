@@ -130,7 +130,7 @@ void sr_build_window_graph_low_memory(const SrContigState& st, const SrWindowPla
 // window is never materialised over the N reads of the contig: it is the reads of the window's first SNP column that are
 // also in its last one -- or lie beyond that column's last read, which the reference's clearing loop (:1612-1619) never
 // reaches --, i.e. a merge of two ascending lists.
-void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool low_memory) {
+void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool low_memory, bool with_reads) {
     (void)error_rate;
     const hs_sr_contig& c = *st.c;
     const int N = st.N;
@@ -168,7 +168,8 @@ void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool 
         if (last) {
             while (cur > 0 && c.snp_pos[cur] > upper - 1 - 0.2 * window_size && c.snp_pos[cur - 1] > upper - 1 - 0.4 * window_size) cur--;
         }
-        {
+        w.col_a = col_a; w.col_b = cur;
+        if (with_reads) {
             const int32_t* a = c.col_idx + c.col_off[col_a]; const int32_t* a1 = c.col_idx + c.col_off[col_a + 1];
             const int32_t* b = c.col_idx + c.col_off[cur]; const int32_t* b1 = c.col_idx + c.col_off[cur + 1];
             auto strictly_ascending = [](const int32_t* x, const int32_t* x1) { return std::adjacent_find(x, x1, std::greater_equal<int32_t>()) == x1; };

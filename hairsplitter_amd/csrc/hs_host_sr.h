@@ -26,7 +26,8 @@ struct SrLocalGraph {
 };
 
 std::vector<int32_t> shuffled_order(int n, uint32_t seed);
-void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool low_memory);
+// with_reads = false: the windows' read lists (ids) are left empty -- the columns are not here; col_a / col_b say which two make them
+void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool low_memory, bool with_reads = true);
 // create_read_graph_low_memory (separate_reads.cpp:538-693) for one window, in local index space: deg/nbr lists per node
 void sr_build_window_graph_low_memory(const SrContigState& st, const SrWindowPlan& w, float error_rate, std::vector<std::vector<int32_t>>& lists);
 // one row of create_read_graph_matrix in the reference's own way (std::sort + walk, separate_reads.cpp:745-815): used for

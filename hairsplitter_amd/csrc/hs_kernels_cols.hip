@@ -434,4 +434,43 @@ __global__ __launch_bounds__(64) void k_snp_select(const int64_t* __restrict__ c
     if (lane == 0) contig_n_snp[ci] = n;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The reads of a clustering window = the reads present at its first AND its last SNP (separate_reads.cpp:1590-1622: the mask
+// is set from the first column, then cleared up to the last read of the last column wherever that column lacks the read --
+// reads beyond its last read keep their bit). One wavefront per window; both columns are ascending read lists of the SNP CSR,
+// lanes take the reads of the first column and bisect the second. Window w writes its reads at slot_off[w] (room for the
+// whole first column) and their number to win_m[w].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_window_masks(const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const int64_t* __restrict__ win_col_a,
+                                                      const int64_t* __restrict__ win_col_b, const int64_t* __restrict__ slot_off, int n_windows,
+                                                      int32_t* __restrict__ ids, int32_t* __restrict__ win_m) {
+    const int lane = lane_id();
+    const int w = (int)blockIdx.x * 4 + wave_id();
+    if (w >= n_windows) return;
+    const int64_t a0 = col_off[win_col_a[w]], a1 = col_off[win_col_a[w] + 1];
+    const int64_t b0 = col_off[win_col_b[w]], b1 = col_off[win_col_b[w] + 1];
+    const int b_last = b1 > b0 ? col_idx[b1 - 1] : -1;      // an empty last column clears nothing
+    int32_t* __restrict__ out = ids + slot_off[w];
+    int cnt = 0;
+    for (int64_t base = a0; base < a1; base += 64) {
+        const int64_t e = base + lane;
+        bool keep = false;
+        int x = 0;
+        if (e < a1) {
+            x = col_idx[e];
+            if (x > b_last) keep = true;
+            else {
+                int64_t lo = b0, hi = b1;
+                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (col_idx[mid] < x) lo = mid + 1; else hi = mid; }
+                keep = lo < b1 && col_idx[lo] == x;
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) out[cnt + __popcll(m & ((1ull << lane) - 1ull))] = x;
+        cnt += __popcll(m);
+    }
+    if (lane == 0) win_m[w] = cnt;
+}
+
 }  // namespace hsdev
