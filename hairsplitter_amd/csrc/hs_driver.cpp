@@ -39,9 +39,13 @@ public:
         {
             std::lock_guard<std::mutex> g(mu_);
             job_ = &f; n_ = n; next_.store(0); active_ = std::min((int)workers_.size(), std::min(n_threads, n) - 1); pending_ = active_; gen_++;
+            // indices are handed out in runs: with thousands of tiny items (one per clustering window) a shared counter bumped
+            // once per item costs more than the items
+            grain_ = std::max(1, n / (8 * (active_ + 1)));
         }
         cv_.notify_all();
-        for (;;) { const int i = next_.fetch_add(1); if (i >= n) break; f(i); }
+        const int grain = grain_;
+        for (;;) { const int i = next_.fetch_add(grain); if (i >= n) break; for (int k = i; k < std::min(n, i + grain); ++k) f(k); }
         std::unique_lock<std::mutex> g(mu_);
         done_cv_.wait(g, [&] { return pending_ == 0; });
         job_ = nullptr;
@@ -58,13 +62,13 @@ private:
     void loop(int id) {
         uint64_t seen = 0;
         for (;;) {
-            const std::function<void(int)>* job; int n;
+            const std::function<void(int)>* job; int n, grain;
             {
                 std::unique_lock<std::mutex> g(mu_);
                 cv_.wait(g, [&] { return gen_ != seen && id < active_; });
-                seen = gen_; job = job_; n = n_;
+                seen = gen_; job = job_; n = n_; grain = grain_;
             }
-            for (;;) { const int i = next_.fetch_add(1); if (i >= n) break; (*job)(i); }
+            for (;;) { const int i = next_.fetch_add(grain); if (i >= n) break; for (int k = i; k < std::min(n, i + grain); ++k) (*job)(k); }
             {
                 std::lock_guard<std::mutex> g(mu_);
                 if (--pending_ == 0) done_cv_.notify_one();
@@ -76,7 +80,7 @@ private:
     std::vector<std::thread> workers_;
     const std::function<void(int)>* job_ = nullptr;
     std::atomic<int> next_{0};
-    int n_ = 0, active_ = 0, pending_ = 0;
+    int n_ = 0, active_ = 0, pending_ = 0, grain_ = 1;
     uint64_t gen_ = 0;
 };
 

@@ -24,27 +24,81 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace hs {
 
 static constexpr int8_t ABSENT = 2;
+
+// Storage of the partitions of a contig: every partition is nine bytes per read of the contig plus its bit sets, a few
+// thousand partitions are made and dropped per contig group and step -- as individual std::vectors that was a seventh of
+// the host's CPU time in malloc / free / memset. Partitions are bump-allocated from 1-MiB blocks instead; the blocks come
+// from and go back to a process-wide cache when the contig's state dies.
+namespace {
+constexpr size_t kArenaBlock = 1u << 20;
+struct BlockCache {
+    std::mutex mu;
+    std::vector<char*> free_blocks;
+    char* get() {
+        { std::lock_guard<std::mutex> g(mu); if (!free_blocks.empty()) { char* p = free_blocks.back(); free_blocks.pop_back(); return p; } }
+        return (char*)std::malloc(kArenaBlock);
+    }
+    void put(char* p) { std::lock_guard<std::mutex> g(mu); if (free_blocks.size() < 4096) free_blocks.push_back(p); else std::free(p); }
+};
+BlockCache& block_cache() { static BlockCache* c = new BlockCache(); return *c; }
+}  // namespace
+struct PartitionArena {
+    std::vector<char*> blocks, big;
+    size_t used = kArenaBlock;
+    void* alloc(size_t n) {
+        n = (n + 63) & ~(size_t)63;
+        if (n > kArenaBlock) { char* p = (char*)std::malloc(n); big.push_back(p); return p; }
+        if (used + n > kArenaBlock) { blocks.push_back(block_cache().get()); used = 0; }
+        void* p = blocks.back() + used;
+        used += n;
+        return p;
+    }
+    ~PartitionArena() { for (char* b : blocks) block_cache().put(b); for (char* b : big) std::free(b); }
+};
 
 struct DensePartition {
     int left = -1, right = -1;
     int n_occ = 0;                 // numberOfOccurences
     int n_corr = 0;                // number_of_correlating_snps
     int lo = 0, hi = -1;           // present reads lie in [lo, hi]
-    std::vector<int8_t> state;     // ABSENT, or mostFrequentBases in {-1,0,1}
-    std::vector<int32_t> more, less;
+    int8_t* state = nullptr;       // [n_reads] ABSENT, or mostFrequentBases in {-1,0,1}
+    int32_t* more = nullptr;       // [n_reads]
+    int32_t* less = nullptr;
+    int n_reads = 0, words = 0;
     // the same states as bit sets over the reads (loop A compares every candidate column with every live partition:
     // popcounts of ANDs instead of a walk over the column entries); maintained by partition_from_column() and augment().
     // Bit k = the read of RANK k in the order of the reads' start positions: the reads of a column (all of them cover its
     // position) and of a partition (they cover SNPs a few kb apart) then sit in a few neighbouring words, [wlo, whi], whatever
     // the order of the records in the SAM file; only those words are looked at.
-    std::vector<uint64_t> present, plus, minus;
+    uint64_t* present = nullptr;   // [words] each
+    uint64_t* plus = nullptr;
+    uint64_t* minus = nullptr;
     const int32_t* rank_of = nullptr;
+    const int32_t* orig_of = nullptr;   // rank -> read
     int wlo = 0, whi = -1;         // words that hold present reads
     int reach = -1;                // largest (exclusive) end position of a present read: no read of the partition covers a position >= reach
+    // storage from the contig's arena: every read absent, counters and bit sets zero
+    void allocate(PartitionArena& arena, int n) {
+        n_reads = n; words = (n + 63) >> 6;
+        const size_t counters = ((size_t)n * 4 + 63) & ~(size_t)63, states = ((size_t)n + 63) & ~(size_t)63, bits = (size_t)words * 8;
+        char* p = (char*)arena.alloc(2 * counters + states + 3 * bits);
+        std::memset(p, 0, 2 * counters + states + 3 * bits);
+        more = (int32_t*)p; less = (int32_t*)(p + counters); state = (int8_t*)(p + 2 * counters);
+        present = (uint64_t*)(p + 2 * counters + states); plus = present + words; minus = plus + words;
+        std::memset(state, ABSENT, (size_t)n);
+    }
+    void copy_from(const DensePartition& o) {      // same contig: same sizes (this partition's own storage is kept)
+        int8_t* s = state; int32_t* mo = more; int32_t* le = less; uint64_t* pr = present; uint64_t* pl = plus; uint64_t* mi = minus;
+        *this = o;
+        state = s; more = mo; less = le; present = pr; plus = pl; minus = mi;
+        std::memcpy(state, o.state, (size_t)n_reads); std::memcpy(more, o.more, (size_t)n_reads * 4); std::memcpy(less, o.less, (size_t)n_reads * 4);
+        std::memcpy(present, o.present, (size_t)words * 8); std::memcpy(plus, o.plus, (size_t)words * 8); std::memcpy(minus, o.minus, (size_t)words * 8);
+    }
     void sync_bits(int r) {
         const int k = rank_of[r];
         const uint64_t b = 1ull << (k & 63);
@@ -269,20 +323,18 @@ static float chi_square(const Contingency& d) {
 }
 
 // Partition::Partition(Column&, pos, ref_base): Partition.cpp:32-83
-static void partition_from_column(DensePartition& p, int n_reads, const int32_t* idx, const uint8_t* code, int n, int pos, uint8_t ref,
-                                  const int32_t* rank_of, const int32_t* read_end) {
+static void partition_from_column(DensePartition& p, PartitionArena& arena, int n_reads, const int32_t* idx, const uint8_t* code, int n, int pos, uint8_t ref,
+                                  const int32_t* rank_of, const int32_t* orig_of, const int32_t* read_end) {
     p.left = p.right = pos; p.n_occ = 1; p.n_corr = 0;
-    p.rank_of = rank_of; p.wlo = 0; p.whi = -1; p.reach = -1;
+    p.rank_of = rank_of; p.orig_of = orig_of; p.wlo = 0; p.whi = -1; p.reach = -1;
     for (int i = 0; i < n; ++i) p.reach = std::max(p.reach, read_end[idx[i]]);
-    p.state.assign(n_reads, ABSENT); p.more.assign(n_reads, 0); p.less.assign(n_reads, 0);
+    p.allocate(arena, n_reads);
     const uint8_t second = second_most_frequent(code, n, nullptr, ref, false, false, 0);
     for (int i = 0; i < n; ++i) {
         const int r = idx[i];
         p.state[r] = code[i] == ref ? 1 : (code[i] == second ? -1 : 0);
         p.more[r] = 1; p.less[r] = 0;
     }
-    const size_t words = ((size_t)n_reads + 63) >> 6;
-    p.present.assign(words, 0ull); p.plus.assign(words, 0ull); p.minus.assign(words, 0ull);
     for (int i = 0; i < n; ++i) p.sync_bits(idx[i]);
     p.lo = n ? idx[0] : 0; p.hi = n ? idx[n - 1] : -1;
 }
@@ -408,9 +460,12 @@ static PartPartDistance partition_vs_partition(const DensePartition& a, const De
     int scores[2] = {0, 0};
     short ndiv[2] = {0, 0}, nunsure[2] = {0, 0};
     int m00[2] = {0, 0}, m01[2] = {0, 0}, m10[2] = {0, 0}, m11[2] = {0, 0};
-    const int lo = std::max(a.lo, b.lo), hi = std::min(a.hi, b.hi);
-    for (int r = lo; r <= hi; ++r) {
-        if (a.state[r] == ABSENT || b.state[r] == ABSENT) continue;
+    // every count below is a sum over the reads both partitions hold: those are the common bits of the two `present` sets (any
+    // order), not a walk over all reads between the partitions' first and last
+    const int32_t* orig_of = a.orig_of;
+    for (int w = std::max(a.wlo, b.wlo); w <= std::min(a.whi, b.whi); ++w)
+    for (uint64_t x = a.present[(size_t)w] & b.present[(size_t)w]; x; x &= x - 1) {
+        const int r = orig_of[w * 64 + __builtin_ctzll(x)];
         if (!(a.more[r] > 1 && b.more[r] > 1)) continue;
         comparable++;
         const float t1 = three_sigma_threshold(a.more[r] + a.less[r]);
@@ -477,6 +532,7 @@ static void merge_partitions(DensePartition& a, const DensePartition& b, short p
 struct CvContigState {
     int n_reads = 0, n_candidates = 0;
     float mean_distance = 0;
+    PartitionArena arena;                // storage of every partition below
     std::vector<DensePartition> parts;   // what loop A leaves (host loop or imported from the device)
     std::vector<int32_t> rank_of, orig_of;   // reads ranked by start position (ties by index): the bit order of the bit sets
     std::vector<DensePartition> finals;
@@ -566,7 +622,7 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
         }
         if (!found) {
             parts.emplace_back();
-            partition_from_column(parts.back(), n_reads, idx, code, n, pos, k0, rank_of.data(), read_end);
+            partition_from_column(parts.back(), st.arena, n_reads, idx, code, n, pos, k0, rank_of.data(), orig_of.data(), read_end);
             parts.back().n_corr = n_corr;
         } else last_position = pos;
     }
@@ -582,16 +638,14 @@ void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts
     std::vector<DensePartition>& parts = st.parts;
     parts.clear();
     parts.resize((size_t)n_parts);
-    const size_t words = ((size_t)N + 63) >> 6;
     for (int p = 0; p < n_parts; ++p) {
         DensePartition& d = parts[(size_t)p];
         const CvPartRecord& r = rec[p];
         d.left = r.left; d.right = r.right; d.n_occ = r.n_occ; d.n_corr = r.n_corr; d.lo = r.lo; d.hi = r.hi; d.reach = r.reach;
-        d.rank_of = st.rank_of.data(); d.wlo = 0; d.whi = -1;
+        d.rank_of = st.rank_of.data(); d.orig_of = st.orig_of.data(); d.wlo = 0; d.whi = -1;
         const int8_t* s = pool_state + r.elem; const int32_t* mo = pool_more + r.elem; const int32_t* le = pool_less + r.elem;
-        d.state.assign(s, s + N);
-        d.more.assign((size_t)N, 0); d.less.assign((size_t)N, 0);
-        d.present.assign(words, 0ull); d.plus.assign(words, 0ull); d.minus.assign(words, 0ull);
+        d.allocate(st.arena, N);
+        std::memcpy(d.state, s, (size_t)N);
         for (int q = d.lo; q <= d.hi; ++q) {
             if (s[q] == ABSENT) continue;
             d.more[(size_t)q] = mo[q]; d.less[(size_t)q] = le[q];
@@ -607,6 +661,7 @@ void cv_phase_b(CvContigState& st, ContigCvResult& out) {
     out.n_partitions = (int)parts.size();
     if (parts.empty()) return;
     std::vector<DensePartition>& finals = st.finals;
+    DensePartition scratch;
     for (size_t p1 = 0; p1 < parts.size(); ++p1) {
         const double p_value = significance(parts[p1], st.n_candidates);
         if (!((p_value < 0.001 || parts[p1].n_corr > 1) && is_informative(parts[p1], mean_distance))) continue;
@@ -624,14 +679,16 @@ void cv_phase_b(CvContigState& st, ContigCvResult& out) {
                 && d.n10 < std::max(2, 2 * d.n01) && d.n01 < std::max(2, 2 * d.n10)) {
                 bool do_merge = d.n01 + d.n10 < 0.1 * (d.n00 + d.n11);
                 if (!do_merge) {
-                    DensePartition merged = finals[p2];
+                    if (!scratch.state) scratch.allocate(st.arena, st.n_reads);      // one trial copy per contig, reused
+                    DensePartition& merged = scratch;
+                    merged.copy_from(finals[p2]);
                     merge_partitions(merged, parts[p1], d.phased);
                     do_merge = confidence_score(merged) > confidence_score(finals[p2]);
                 }
                 if (do_merge) { merge_partitions(finals[p2], parts[p1], d.phased); different = false; break; }
             }
         }
-        if (different) finals.push_back(std::move(parts[p1]));      // (a partition of loop A is looked at once)
+        if (different) finals.push_back(parts[p1]);      // (a partition of loop A is looked at once: its storage goes along)
     }
     out.n_final_partitions = (int)finals.size();
     std::vector<DensePartition>().swap(parts);
@@ -645,8 +702,8 @@ void cv_export_partitions(const CvContigState& st, int8_t* state, int64_t state_
     for (size_t k = 0; k < st.finals.size(); ++k) {
         const DensePartition& p = st.finals[k];
         state_off[k] = state_base + o;
-        std::copy(p.state.begin(), p.state.end(), state + o);
-        o += (int64_t)p.state.size();
+        std::memcpy(state + o, p.state, (size_t)p.n_reads);
+        o += (int64_t)p.n_reads;
     }
 }
 }  // namespace hs
