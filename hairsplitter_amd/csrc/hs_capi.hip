@@ -798,16 +798,15 @@ int hs_snp_planes(const int64_t* d_col_off, const int32_t* d_col_idx, const uint
 
 static int simdiff_launch(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_plane_off, const int32_t* d_n_reads,
                           const int32_t* d_words, const int64_t* d_out_off, const std::vector<int32_t>& h_n_reads,
-                          int32_t* d_sim, int32_t* d_diff, void* stream, DBuf& t_c, DBuf& t_i, DBuf& t_j) {
+                          int32_t* d_sim, int32_t* d_diff, void* stream, DBuf& t_c, DBuf& t_i, DBuf& t_j, UploadPack& tiles) {
     std::vector<int32_t> tc, ti, tj;
     for (size_t c = 0; c < h_n_reads.size(); ++c) {
         const int nt = (h_n_reads[c] + 63) / 64;
         for (int i = 0; i < nt; ++i) for (int j = i; j < nt; ++j) { tc.push_back((int32_t)c); ti.push_back(i); tj.push_back(j); }      // the upper triangle: the kernel mirrors
     }
     if (tc.empty()) return HS_OK;
-    if (int rc = t_c.upload(tc)) return rc;
-    if (int rc = t_i.upload(ti)) return rc;
-    if (int rc = t_j.upload(tj)) return rc;
+    tiles.add(tc, t_c); tiles.add(ti, t_i); tiles.add(tj, t_j);      // one asynchronous copy (staged in pinned memory: the vectors may die)
+    if (int rc = tiles.commit((hipStream_t)stream)) return rc;
     hipLaunchKernelGGL(hsdev::k_simdiff, dim3((unsigned)tc.size()), dim3(256), 0, (hipStream_t)stream, d_alt, d_ref, d_plane_off,
                        d_n_reads, d_words, d_out_off, t_c.as<int32_t>(), t_i.as<int32_t>(), t_j.as<int32_t>(), d_sim, d_diff);
     HS_HIP(hipGetLastError());
@@ -822,7 +821,8 @@ int hs_simdiff(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_pl
     std::vector<int32_t> h_n((size_t)n_contigs);
     HS_HIP(hipMemcpy(h_n.data(), d_n_reads, sizeof(int32_t) * (size_t)n_contigs, hipMemcpyDeviceToHost));
     DBuf a, b, c;
-    int rc = simdiff_launch(d_alt, d_ref, d_plane_off, d_n_reads, d_words, d_out_off, h_n, d_sim, d_diff, stream, a, b, c);
+    UploadPack tiles;
+    int rc = simdiff_launch(d_alt, d_ref, d_plane_off, d_n_reads, d_words, d_out_off, h_n, d_sim, d_diff, stream, a, b, c, tiles);
     if (rc) return rc;
     if (int rc_w = stream_wait((hipStream_t)stream)) return rc_w;   // the tile lists die with this frame
     return HS_OK;
@@ -1125,73 +1125,75 @@ struct HipCvOps : hs::CvDeviceOps {
     int64_t n_cols = 0, n_entries = 0;            // extracted columns / their entries
     SelectionScratch range_scratch;               // K2's per-tile slots
     DBuf d_tile_ent_sum, d_tile_ebase, d_scan2;
-    DBuf d_header, d_col_gpos, d_col_rec, d_co, d_col_len, d_ci, d_cc;      // d_co / d_ci / d_cc: the CSR of the columns (also read by k_robust_partitions)
-    DBuf d_col_ctg, d_k0, d_k1, d_c1, d_cand, d_ctg_col_off, d_ctg_n, d_min_reads, d_blk_cnt, d_blk_ent, d_tie;
-    DBuf d_pk_rec, d_pk_col, d_pk_off, d_pk_idx, d_pk_code;                 // packed candidates, then packed SNPs
-    HBuf h_header, h_pk_rec, h_pk_col, h_pk_off, h_pk_idx, h_pk_code, h_ctg_n;
+    DBuf d_col_gpos, d_col_rec, d_co, d_col_len, d_ci, d_cc;      // d_co / d_ci / d_cc: the CSR of the columns (also read by k_robust_partitions)
+    DBuf d_col_ctg, d_k0, d_k1, d_c1, d_cand, d_ctg_col_off, d_min_reads, d_blk_cnt, d_blk_ent;
+    // what the host reads between the phases, one small block = one download: [ColumnsHeader 64 B][tie counters 16 B][pad][per-contig counts 4 C]
+    DBuf d_info; HBuf h_info;
+    hsdev::ColumnsHeader* dev_header() const { return d_info.as<hsdev::ColumnsHeader>(); }
+    unsigned long long* dev_tie() const { return (unsigned long long*)((char*)d_info.p + 64); }
+    int32_t* dev_ctg_n() const { return (int32_t*)((char*)d_info.p + 128); }
+    const hsdev::ColumnsHeader& host_header() const { return *(const hsdev::ColumnsHeader*)h_info.p; }
+    const int32_t* host_ctg_n() const { return (const int32_t*)((const char*)h_info.p + 128); }
+    // the flagged columns (candidates, later the SNPs) packed into ONE block = one download: [records 16 nf][column index 4 nf][offsets 8 (nf + 1)]
+    // [read indices 4 ne][codes ne], every part 256-byte aligned; the SNP block is what stage 4 takes over (HipSrOps::adopt_columns)
+    DBuf d_pk; HBuf h_pk;
+    struct PackLayout { size_t rec, col, off, idx, code, total, head; };
+    static PackLayout pack_layout(int64_t nf, int64_t ne) {
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        PackLayout L;
+        L.rec = 0; L.col = up((size_t)nf * 16); L.off = L.col + up((size_t)nf * 4); L.idx = L.off + up(((size_t)nf + 1) * 8);
+        L.head = L.idx; L.code = L.idx + up((size_t)ne * 4); L.total = L.code + up((size_t)ne + 1);
+        return L;
+    }
+    PackLayout pk_layout{};
     UploadPack range_pack;
     int n_gathered = 0;                           // (k_robust_partitions checks its column indices against it)
     int64_t gathered_entries = 0;
     static int grow(HBuf& h, size_t need) { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); }
     static int grow(DBuf& d, size_t need) { if (d.cap >= need && d.p && !d.view) { d.bytes = need; return HS_OK; } return d.alloc(need + need / 4); }
 
-    // header of the range from the device (one 64-byte download + wait)
-    int fetch_header(hsdev::ColumnsHeader& h) {
-        if (int rc = grow(h_header, sizeof(hsdev::ColumnsHeader))) return rc;
-        if (int rc = copy_d2h(h_header.p, d_header.p, sizeof(hsdev::ColumnsHeader), stream)) return rc;
-        std::memcpy(&h, h_header.p, sizeof h);
-        return HS_OK;
+    int fetch_info() {      // the info block from the device (one download + wait)
+        const size_t bytes = 128 + (size_t)(range_c1 - range_c0) * 4;
+        if (int rc = grow(h_info, bytes)) return rc;
+        return copy_d2h(h_info.p, d_info.p, bytes, stream);
     }
-    // the columns carrying `flag` packed on the device (d_pk_*) and, with their entries if asked for, on the host (h_pk_*)
+    // the columns carrying `flag` packed on the device (d_pk) and, with their entries if asked for, on the host (h_pk)
     int pack_flagged(int flag, bool want_entries, int64_t* n_out, int64_t* e_out) {
         const int n_blocks = (int)((n_cols + HS_FP_BLOCK - 1) / HS_FP_BLOCK);
         *n_out = 0; *e_out = 0;
-        if (n_blocks == 0) return HS_OK;
+        if (n_blocks == 0) return fetch_info();
         if (int rc = grow(d_blk_cnt, (size_t)n_blocks * 8)) return rc;
         if (int rc = grow(d_blk_ent, (size_t)n_blocks * 8)) return rc;
         if (int rc = kc.begin(HS_K_PACK_COLUMNS, stream)) return rc;
         hipLaunchKernelGGL(hsdev::k_flag_block_sums, dim3((unsigned)n_blocks), dim3(256), 0, stream, d_col_rec.as<hsdev::hs_colrec_dev>(), d_col_len.as<int32_t>(),
-                           d_header.as<hsdev::ColumnsHeader>(), flag, d_blk_cnt.as<long long>(), d_blk_ent.as<long long>());
-        hipLaunchKernelGGL(hsdev::k_flag_block_offsets, dim3(1), dim3(1024), 0, stream, d_blk_cnt.as<long long>(), d_blk_ent.as<long long>(), n_blocks,
-                           d_header.as<hsdev::ColumnsHeader>());
+                           dev_header(), flag, d_blk_cnt.as<long long>(), d_blk_ent.as<long long>());
+        hipLaunchKernelGGL(hsdev::k_flag_block_offsets, dim3(1), dim3(1024), 0, stream, d_blk_cnt.as<long long>(), d_blk_ent.as<long long>(), n_blocks, dev_header());
         HS_HIP(hipGetLastError());
         if (int rc = kc.end(20 * n_cols, stream)) return rc;      // record + length of every column in
-        hsdev::ColumnsHeader h;
-        if (int rc = fetch_header(h)) return rc;
-        const int64_t nf = h.n_flagged, ne = h.n_flagged_entries;
+        if (int rc = fetch_info()) return rc;
+        const int64_t nf = host_header().n_flagged, ne = host_header().n_flagged_entries;
         *n_out = nf; *e_out = ne;
-        if (int rc = grow(d_pk_rec, std::max<size_t>(1, (size_t)nf) * sizeof(hs_colrec))) return rc;
-        if (int rc = grow(d_pk_col, std::max<size_t>(1, (size_t)nf) * 4)) return rc;
-        if (int rc = grow(d_pk_off, ((size_t)nf + 1) * 8)) return rc;
-        if (int rc = grow(d_pk_idx, std::max<size_t>(1, (size_t)ne) * 4)) return rc;
-        if (int rc = grow(d_pk_code, std::max<size_t>(1, (size_t)ne))) return rc;
-        if (nf == 0) { HS_HIP(hipMemsetAsync(d_pk_off.p, 0, 8, stream)); }
+        pk_layout = pack_layout(nf, ne);
+        const PackLayout& L = pk_layout;
+        if (int rc = grow(d_pk, L.total)) return rc;
+        char* base = (char*)d_pk.p;
+        if (nf == 0) { HS_HIP(hipMemsetAsync(base + L.off, 0, 8, stream)); }
         if (int rc = kc.begin(HS_K_PACK_COLUMNS, stream)) return rc;
         hipLaunchKernelGGL(hsdev::k_pack_flagged, dim3((unsigned)n_blocks), dim3(256), 0, stream, d_col_rec.as<hsdev::hs_colrec_dev>(), d_co.as<int64_t>(),
-                           d_col_len.as<int32_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), d_header.as<hsdev::ColumnsHeader>(), flag, d_blk_cnt.as<long long>(),
-                           d_blk_ent.as<long long>(), d_pk_rec.as<hsdev::hs_colrec_dev>(), d_pk_col.as<int32_t>(), d_pk_off.as<int64_t>(), d_pk_idx.as<int32_t>(),
-                           d_pk_code.as<uint8_t>(), nf, ne);
+                           d_col_len.as<int32_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), dev_header(), flag, d_blk_cnt.as<long long>(),
+                           d_blk_ent.as<long long>(), (hsdev::hs_colrec_dev*)(base + L.rec), (int32_t*)(base + L.col), (int64_t*)(base + L.off), (int32_t*)(base + L.idx),
+                           (uint8_t*)(base + L.code), nf, ne);
         HS_HIP(hipGetLastError());
         if (int rc = kc.end(10 * ne + 60 * nf, stream)) return rc;      // the flagged columns' entries in and out, their records
-        if (int rc = grow(h_pk_rec, std::max<size_t>(1, (size_t)nf) * sizeof(hs_colrec))) return rc;
-        if (int rc = grow(h_pk_col, std::max<size_t>(1, (size_t)nf) * 4)) return rc;
-        if (int rc = grow(h_pk_off, ((size_t)nf + 1) * 8)) return rc;
-        if (nf) {
-            HS_HIP(hipMemcpyAsync(h_pk_rec.p, d_pk_rec.p, (size_t)nf * sizeof(hs_colrec), hipMemcpyDeviceToHost, stream));
-            HS_HIP(hipMemcpyAsync(h_pk_col.p, d_pk_col.p, (size_t)nf * 4, hipMemcpyDeviceToHost, stream));
-        }
-        HS_HIP(hipMemcpyAsync(h_pk_off.p, d_pk_off.p, ((size_t)nf + 1) * 8, hipMemcpyDeviceToHost, stream));
-        if (want_entries && ne) {
-            if (int rc = grow(h_pk_idx, (size_t)ne * 4)) return rc;
-            if (int rc = grow(h_pk_code, (size_t)ne)) return rc;
-            HS_HIP(hipMemcpyAsync(h_pk_idx.p, d_pk_idx.p, (size_t)ne * 4, hipMemcpyDeviceToHost, stream));
-            HS_HIP(hipMemcpyAsync(h_pk_code.p, d_pk_code.p, (size_t)ne, hipMemcpyDeviceToHost, stream));
-        }
+        const size_t bytes = want_entries ? L.total : L.head;
+        if (int rc = grow(h_pk, std::max<size_t>(bytes, 256))) return rc;
+        HS_HIP(hipMemcpyAsync(h_pk.p, d_pk.p, bytes, hipMemcpyDeviceToHost, stream));
         return HS_OK;
     }
 
     int extract_candidates(int c0, int c1, const std::vector<int32_t>& min_reads, float thr, hs::CvCandidates& out, float k_ms[3]) override {
         static_assert(sizeof(hs_colrec) == sizeof(hsdev::hs_colrec_dev), "hs_colrec layout");
+        static_assert(sizeof(hsdev::ColumnsHeader) == 64, "info block layout");
         const int C = c1 - c0;
         range_c0 = c0; range_c1 = c1; n_cols = 0; n_entries = 0; n_gathered = 0; gathered_entries = 0;
         out = hs::CvCandidates();
@@ -1205,15 +1207,13 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = e_k2.init()) return rc;
         if (int rc = e_k3.init()) return rc;
         if (int rc = e_k3b.init()) return rc;
+        if (int rc = grow(d_info, 128 + (size_t)C * 4)) return rc;
         {   // ---- K2 over the tiles of the range: per tile its selected positions (second count >= 4), their depths and the sum of those ----
             DeviceTurn turn;
             if (int rc = range_scratch.prepare(nt * 256)) return rc;
             if (int rc = grow(d_tile_ent_sum, (size_t)nt * 4)) return rc;
             if (int rc = grow(d_tile_ebase, ((size_t)nt + 1) * 8)) return rc;
-            if (int rc = grow(d_header, sizeof(hsdev::ColumnsHeader))) return rc;
-            if (int rc = grow(d_tie, 16)) return rc;
-            HS_HIP(hipMemsetAsync(d_header.p, 0, sizeof(hsdev::ColumnsHeader), stream));
-            HS_HIP(hipMemsetAsync(d_tie.p, 0, 16, stream));
+            HS_HIP(hipMemsetAsync(d_info.p, 0, 128, stream));
             HS_HIP(hipEventRecord(e_k2.a, stream));
             if (int rc = kc.begin(HS_K_COLUMN_STATS, stream)) return rc;
             hipEvent_t k2_done = nullptr;
@@ -1225,12 +1225,11 @@ struct HipCvOps : hs::CvDeviceOps {
             if (int rc = exclusive_scan_launch(range_scratch.tile_cnt.as<int32_t>(), (int)nt, range_scratch.tile_base.as<int64_t>(), range_scratch.scan_scratch, stream)) return rc;
             if (int rc = exclusive_scan_launch(d_tile_ent_sum.as<int32_t>(), (int)nt, d_tile_ebase.as<int64_t>(), d_scan2, stream)) return rc;
             // the two totals (the last elements of the scans) -> sizes of the column arrays
-            if (int rc = grow(h_header, sizeof(hsdev::ColumnsHeader))) return rc;
-            HS_HIP(hipMemcpyAsync(h_header.p, range_scratch.tile_base.as<int64_t>() + nt, 8, hipMemcpyDeviceToHost, stream));
-            HS_HIP(hipMemcpyAsync((char*)h_header.p + 8, d_tile_ebase.as<int64_t>() + nt, 8, hipMemcpyDeviceToHost, stream));
-            if (int rc = stream_wait(stream)) return rc;
+            hipLaunchKernelGGL(hsdev::k_columns_totals, dim3(1), dim3(64), 0, stream, range_scratch.tile_base.as<int64_t>() + nt, d_tile_ebase.as<int64_t>() + nt, dev_header());
+            HS_HIP(hipGetLastError());
+            if (int rc = fetch_info()) return rc;
         }
-        n_cols = ((const int64_t*)h_header.p)[0]; n_entries = ((const int64_t*)h_header.p)[1];
+        n_cols = host_header().n_cols; n_entries = host_header().n_entries;
         out.n_columns = n_cols; out.n_entries = n_entries;
         if (n_cols > 0x7fffffff) { set_error("more than 2^31 columns in one contig range"); return HS_EINVAL; }
         n_gathered = (int)n_cols; gathered_entries = n_entries;
@@ -1246,13 +1245,12 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = grow(d_c1, std::max<size_t>(1, (size_t)n_cols) * 4)) return rc;
         if (int rc = grow(d_cand, std::max<size_t>(1, (size_t)n_cols))) return rc;
         if (int rc = grow(d_ctg_col_off, ((size_t)C + 1) * 8)) return rc;
-        if (int rc = grow(d_ctg_n, (size_t)C * 4)) return rc;
         range_pack.add(min_reads, d_min_reads);
         if (int rc = range_pack.commit(stream)) return rc;
         // ---- the column list with its CSR offsets, K3 (tile-cooperative gather), K3b (leading codes, reference order), V1 ----
         hipLaunchKernelGGL(hsdev::k_columns_compact, dim3((unsigned)nt), dim3(256), 0, stream, range_scratch.tile_cnt.as<int32_t>(), range_scratch.tile_base.as<int64_t>(),
                            d_tile_ebase.as<int64_t>(), range_scratch.gpos.as<int64_t>(), range_scratch.depth.as<int32_t>(), nt, b->d_contig_off.as<int64_t>(), b->n_contigs,
-                           d_col_gpos.as<int64_t>(), d_col_rec.as<hsdev::hs_colrec_dev>(), d_co.as<int64_t>(), d_col_len.as<int32_t>(), d_header.as<hsdev::ColumnsHeader>(), n_cols);
+                           d_col_gpos.as<int64_t>(), d_col_rec.as<hsdev::hs_colrec_dev>(), d_co.as<int64_t>(), d_col_len.as<int32_t>(), dev_header(), n_cols);
         HS_HIP(hipGetLastError());
         HS_HIP(hipEventRecord(e_k3.a, stream));
         if (n_cols > 0) {
@@ -1271,36 +1269,36 @@ struct HipCvOps : hs::CvDeviceOps {
             if (int rc = kc.begin(HS_K_COLUMN_TOP3, stream)) return rc;
             const unsigned grid = (unsigned)std::min<int64_t>((n_cols + 3) / 4, 16384);
             hipLaunchKernelGGL(hsdev::k_column_top3_exact, dim3(grid), dim3(256), 0, stream, d_co.as<int64_t>(), d_col_len.as<int32_t>(), d_cc.as<uint8_t>(),
-                               d_header.as<hsdev::ColumnsHeader>(), d_col_rec.as<hsdev::hs_colrec_dev>(), d_tie.as<unsigned long long>());
+                               dev_header(), d_col_rec.as<hsdev::hs_colrec_dev>(), dev_tie());
             HS_HIP(hipGetLastError());
             if (int rc = kc.end(n_entries + 16 * n_cols, stream)) return rc;
         }
-        hipLaunchKernelGGL(hsdev::k_candidates_scan, dim3((unsigned)C), dim3(64), 0, stream, d_col_gpos.as<int64_t>(), d_header.as<hsdev::ColumnsHeader>(),
+        hipLaunchKernelGGL(hsdev::k_candidates_scan, dim3((unsigned)C), dim3(64), 0, stream, d_col_gpos.as<int64_t>(), dev_header(),
                            b->d_contig_off.as<int64_t>(), c0, C, d_min_reads.as<int32_t>(), thr, d_col_rec.as<hsdev::hs_colrec_dev>(), d_col_ctg.as<int32_t>(),
-                           d_k0.as<uint8_t>(), d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), d_ctg_col_off.as<int64_t>(), d_ctg_n.as<int32_t>());
+                           d_k0.as<uint8_t>(), d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), d_ctg_col_off.as<int64_t>(), dev_ctg_n());
         HS_HIP(hipGetLastError());
         HS_HIP(hipEventRecord(e_k3b.b, stream));
         // ---- the candidates, packed, to the host ----
         int64_t n_cand = 0, e_cand = 0;
-        if (int rc = pack_flagged(HS_COL_CAND, true, &n_cand, &e_cand)) return rc;
-        if (int rc = grow(h_ctg_n, (size_t)C * 4 + 16)) return rc;
-        HS_HIP(hipMemcpyAsync(h_ctg_n.p, d_ctg_n.p, (size_t)C * 4, hipMemcpyDeviceToHost, stream));
-        HS_HIP(hipMemcpyAsync((char*)h_ctg_n.p + (size_t)C * 4, d_tie.p, 16, hipMemcpyDeviceToHost, stream));
+        if (int rc = pack_flagged(HS_COL_CAND, true, &n_cand, &e_cand)) return rc;      // (its info download carries the per-contig counts and the tie counters)
+        std::memcpy(out.contig_n_cand.data(), host_ctg_n(), (size_t)C * 4);
+        { unsigned long long t2[2]; std::memcpy(t2, (const char*)h_info.p + 64, 16); out.n_tie = (int64_t)t2[0]; out.n_tie_big = (int64_t)t2[1]; }
         if (int rc = stream_wait(stream)) return rc;
         out.n_cand = n_cand;
-        out.rec = (const hs_colrec*)h_pk_rec.p; out.col = (const int32_t*)h_pk_col.p; out.off = (const int64_t*)h_pk_off.p;
-        out.idx = (const int32_t*)h_pk_idx.p; out.code = (const uint8_t*)h_pk_code.p;
-        std::memcpy(out.contig_n_cand.data(), h_ctg_n.p, (size_t)C * 4);
-        { unsigned long long t2[2]; std::memcpy(t2, (char*)h_ctg_n.p + (size_t)C * 4, 16); out.n_tie = (int64_t)t2[0]; out.n_tie_big = (int64_t)t2[1]; }
+        if (n_cand > 0) {
+            const char* hb = (const char*)h_pk.p;
+            out.rec = (const hs_colrec*)(hb + pk_layout.rec); out.col = (const int32_t*)(hb + pk_layout.col); out.off = (const int64_t*)(hb + pk_layout.off);
+            out.idx = (const int32_t*)(hb + pk_layout.idx); out.code = (const uint8_t*)(hb + pk_layout.code);
+        } else { static const int64_t zero_off[1] = {0}; out.off = zero_off; }
         kc.flush();
         if (int rc = e_k2.ms(&k_ms[0])) return rc;
         if (int rc = e_k3.ms(&k_ms[1])) return rc;
         return e_k3b.ms(&k_ms[2]);
     }
 
-    // ---- K4 + the merge of the SNP lists + the SNP columns packed (they stay in d_pk_* for stage 4) ----
+    // ---- K4 + the merge of the SNP lists + the SNP columns packed (they stay in d_pk for stage 4) ----
     DBuf d_keep;
-    int64_t snp_count = 0, snp_entries = 0;       // what d_pk_off / d_pk_idx / d_pk_code hold after finish_columns (HipSrOps::adopt_columns)
+    int64_t snp_count = 0, snp_entries = 0;       // what d_pk holds after finish_columns (HipSrOps::adopt_columns)
     int finish_columns(const hs::CvPartitionTest& t, bool want_entries, hs::CvSnpSet& out, float* k_ms) override {
         const int C = range_c1 - range_c0;
         out = hs::CvSnpSet();
@@ -1308,11 +1306,12 @@ struct HipCvOps : hs::CvDeviceOps {
         if (k_ms) *k_ms = 0;
         if ((int)t.contig_n_reads.size() != C) { set_error("finish_columns: partitions of another contig range"); return HS_EINVAL; }
         snp_count = 0; snp_entries = 0;
+        static const int64_t zero_off[1] = {0};
         if (n_cols == 0 || C == 0) {
-            if (int rc = grow(h_pk_off, 8)) return rc;
-            if (int rc = grow(d_pk_off, 8)) return rc;
-            HS_HIP(hipMemsetAsync(d_pk_off.p, 0, 8, stream));
-            *(int64_t*)h_pk_off.p = 0; out.off = (const int64_t*)h_pk_off.p;
+            pk_layout = pack_layout(0, 0);
+            if (int rc = grow(d_pk, pk_layout.total)) return rc;
+            HS_HIP(hipMemsetAsync((char*)d_pk.p + pk_layout.off, 0, 8, stream));
+            out.off = zero_off;
             return stream_wait(stream);
         }
         const int n = (int)n_cols;
@@ -1335,18 +1334,19 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = kc.end(5 * gathered_entries + (int64_t)t.part_state.size(), stream)) return rc;   // the columns (idx + code) and the partition states
         HS_HIP(hipEventRecord(e.b, stream));
         hipLaunchKernelGGL(hsdev::k_snp_select, dim3((unsigned)C), dim3(64), 0, stream, d_ctg_col_off.as<int64_t>(), C, d_keep.as<uint8_t>(),
-                           d_col_rec.as<hsdev::hs_colrec_dev>(), d_ctg_n.as<int32_t>());
+                           d_col_rec.as<hsdev::hs_colrec_dev>(), dev_ctg_n());
         HS_HIP(hipGetLastError());
         int64_t n_snp = 0, e_snp = 0;
-        if (int rc = pack_flagged(HS_COL_SNP, want_entries, &n_snp, &e_snp)) return rc;
-        if (int rc = grow(h_ctg_n, (size_t)C * 4 + 16)) return rc;
-        HS_HIP(hipMemcpyAsync(h_ctg_n.p, d_ctg_n.p, (size_t)C * 4, hipMemcpyDeviceToHost, stream));
-        if (int rc = stream_wait(stream)) return rc;       // (the partition tables, uploads and lists of this scope are done with)
+        if (int rc = pack_flagged(HS_COL_SNP, want_entries, &n_snp, &e_snp)) return rc;      // (the partition tables, uploads and lists of this scope are done with: it waits)
+        std::memcpy(out.contig_n_snp.data(), host_ctg_n(), (size_t)C * 4);
+        if (int rc = stream_wait(stream)) return rc;
         out.n_snp = n_snp; out.n_entries = e_snp;
         snp_count = n_snp; snp_entries = e_snp;
-        out.rec = (const hs_colrec*)h_pk_rec.p; out.off = (const int64_t*)h_pk_off.p;
-        if (want_entries) { out.idx = (const int32_t*)h_pk_idx.p; out.code = (const uint8_t*)h_pk_code.p; }
-        std::memcpy(out.contig_n_snp.data(), h_ctg_n.p, (size_t)C * 4);
+        if (n_snp > 0) {
+            const char* hb = (const char*)h_pk.p;
+            out.rec = (const hs_colrec*)(hb + pk_layout.rec); out.off = (const int64_t*)(hb + pk_layout.off);
+            if (want_entries) { out.idx = (const int32_t*)(hb + pk_layout.idx); out.code = (const uint8_t*)(hb + pk_layout.code); }
+        } else out.off = zero_off;
         kc.flush();
         return k_ms ? e.ms(k_ms) : HS_OK;
     }
@@ -1512,6 +1512,8 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
     if (int rc = G.d_visit_n.alloc(std::max<size_t>((size_t)W, 1) * 4)) return rc;
     if (rows == 0) { HS_HIP(hipMemsetAsync(G.d_off.p, 0, 8, stream)); return HS_OK; }
     DBuf d_bits, d_ac, d_ar, d_deg, d_scan;
+    DBuf d_src, d_len, d_dst, d_os, d_od, d_pb, d_pm, d_pi, d_pj;      // rows resolved on the host (below); released after the final wait
+    UploadPack pk_amb, pk_patch;
     if (int rc = d_deg.alloc((size_t)rows * 4)) return rc;
     EventPair ev; if (int rc = ev.init()) return rc;
     bool timed = false;
@@ -1519,10 +1521,9 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
         if (!d_sim) { set_error("read graphs before simdiff"); return HS_EINVAL; }
         const size_t bits_bytes = (size_t)win_bits_off.back() * 8;
         if (int rc = d_bits.alloc(bits_bytes)) return rc;
-        if (int rc = d_ac.alloc(4)) return rc;
-        if (int rc = d_ar.alloc((size_t)rows_dev * 4)) return rc;
+        if (int rc = d_ar.alloc(((size_t)rows_dev + 1) * 4)) return rc;      // [0] = number of rows left to the host, then the rows
         HS_HIP(hipMemsetAsync(d_bits.p, 0, bits_bytes ? bits_bytes : 8, stream));
-        HS_HIP(hipMemsetAsync(d_ac.p, 0, 4, stream));
+        HS_HIP(hipMemsetAsync(d_ar.p, 0, 4, stream));
         // per-wave LDS: cap distances + cap totals. Four waves per workgroup while they fit, else one; windows wider than that
         // (m > 7168 masked reads) send their rows to the host
         int cap = ((max_m_dev + 63) / 64) * 64, waves = 4;
@@ -1533,7 +1534,7 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
         if (kc) { if (int rc = kc->begin(HS_K_GRAPH_ROWS, stream)) return rc; }
         hipLaunchKernelGGL(hsdev::k_read_graph_rows, dim3((rows_dev + waves - 1) / waves), dim3(64 * waves), (size_t)cap * 8 * waves, stream, d_sim, d_diff,
                            G.d_oo.as<int64_t>(), G.d_n.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_rw.as<int32_t>(),
-                           G.d_bo.as<int64_t>(), rows_dev, below, cap, d_bits.as<unsigned long long>(), d_ac.as<int32_t>(), d_ar.as<int32_t>(), rows_dev);
+                           G.d_bo.as<int64_t>(), rows_dev, below, cap, d_bits.as<unsigned long long>(), d_ar.as<int32_t>(), d_ar.as<int32_t>() + 1, rows_dev);
         HS_HIP(hipGetLastError());
         if (kc) {   // per row: the sim and diff entries of the window's m reads in, m link bits out
             int64_t by = 0;
@@ -1542,12 +1543,17 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
         }
         HS_HIP(hipEventRecord(ev.b, stream));
         timed = true;
-        int32_t n_amb = 0;
-        if (int rc = d2h_pinned(&n_amb, d_ac.p, 4, stream)) return rc;
+        // the count and (normally all of) the list in one download
+        const size_t first_rows = std::min<size_t>((size_t)rows_dev, 2048);
+        HBuf h_amb;
+        if (int rc = h_amb.alloc((first_rows + 1) * 4)) return rc;
+        if (int rc = copy_d2h(h_amb.p, d_ar.p, (first_rows + 1) * 4, stream)) return rc;
+        const int32_t n_amb = *(const int32_t*)h_amb.p;
         if (n_amb > 0) {
             // rows where std::sort's arrangement of equal distances decides: fetch their sim/diff rows, do exactly what the reference does
             std::vector<int32_t> amb((size_t)n_amb);
-            if (int rc = d2h_pinned(amb.data(), d_ar.p, (size_t)n_amb * 4, stream)) return rc;
+            std::memcpy(amb.data(), (const int32_t*)h_amb.p + 1, std::min<size_t>((size_t)n_amb, first_rows) * 4);
+            if ((size_t)n_amb > first_rows) { if (int rc = d2h_pinned(amb.data() + first_rows, d_ar.as<int32_t>() + 1 + first_rows, ((size_t)n_amb - first_rows) * 4, stream)) return rc; }
             std::sort(amb.begin(), amb.end());
             std::vector<int64_t> src((size_t)n_amb), dst((size_t)n_amb + 1, 0);
             std::vector<int32_t> len((size_t)n_amb);
@@ -1558,19 +1564,23 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
                 const int r1 = ws.mask_ids[(size_t)amb[(size_t)k]];
                 src[(size_t)k] = ctg_out_off[(size_t)c] + (int64_t)r1 * N; len[(size_t)k] = N; dst[(size_t)k + 1] = dst[(size_t)k] + N;
             }
-            DBuf d_src, d_len, d_dst, d_os, d_od;
-            if (int rc = d_src.upload(src)) return rc;
-            if (int rc = d_len.upload(len)) return rc;
-            if (int rc = d_dst.upload(dst)) return rc;
+            pk_amb.add(src, d_src); pk_amb.add(len, d_len); pk_amb.add(dst, d_dst);
+            if (int rc = pk_amb.commit(stream)) return rc;
             if (int rc = d_os.alloc((size_t)dst.back() * 4)) return rc;
             if (int rc = d_od.alloc((size_t)dst.back() * 4)) return rc;
             hipLaunchKernelGGL(hsdev::k_read_graph_fetch_rows, dim3(n_amb), dim3(256), 0, stream, d_sim, d_diff, d_src.as<int64_t>(), d_len.as<int32_t>(),
                                d_dst.as<int64_t>(), d_os.as<int32_t>(), d_od.as<int32_t>());
             HS_HIP(hipGetLastError());
-            std::vector<int32_t> hs_((size_t)dst.back()), hd_((size_t)dst.back());
-            if (int rc = d2h_pinned(hs_.data(), d_os.p, hs_.size() * 4, stream)) return rc;
-            if (int rc = d2h_pinned(hd_.data(), d_od.p, hd_.size() * 4, stream)) return rc;
+            // both row sets with one wait, read where they land
+            HBuf h_rows;
+            const size_t row_bytes = (size_t)dst.back() * 4;
+            if (int rc = h_rows.alloc(2 * row_bytes + 16)) return rc;
+            if (row_bytes) {
+                HS_HIP(hipMemcpyAsync(h_rows.p, d_os.p, row_bytes, hipMemcpyDeviceToHost, stream));
+                HS_HIP(hipMemcpyAsync((char*)h_rows.p + row_bytes, d_od.p, row_bytes, hipMemcpyDeviceToHost, stream));
+            }
             if (int rc_w = stream_wait(stream)) return rc_w;
+            const int32_t* hs_ = (const int32_t*)h_rows.p; const int32_t* hd_ = (const int32_t*)((const char*)h_rows.p + row_bytes);
             std::vector<int64_t> pbase; std::vector<int32_t> pmw, pi, pj;
             std::vector<uint8_t> mask;
             std::vector<int> picked;
@@ -1583,23 +1593,19 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
                 const int N = len[(size_t)k];
                 mask.assign((size_t)N, 0);
                 for (int j = 0; j < m; ++j) mask[(size_t)ids[j]] = 1;
-                hs::sr_pick_row_sorted(hs_.data() + dst[(size_t)k], hd_.data() + dst[(size_t)k], N, ids[row - m0], mask.data(), ws.error_rate, picked);
+                hs::sr_pick_row_sorted(hs_ + dst[(size_t)k], hd_ + dst[(size_t)k], N, ids[row - m0], mask.data(), ws.error_rate, picked);
                 for (int nb : picked) {
                     const int j = (int)(std::lower_bound(ids, ids + m, nb) - ids);
                     pbase.push_back(win_bits_off[(size_t)w]); pmw.push_back((m + 63) >> 6); pi.push_back((int32_t)(row - m0)); pj.push_back(j);
                 }
             }
             if (!pi.empty()) {
-                DBuf d_pb, d_pm, d_pi, d_pj;
-                if (int rc = d_pb.upload(pbase)) return rc;
-                if (int rc = d_pm.upload(pmw)) return rc;
-                if (int rc = d_pi.upload(pi)) return rc;
-                if (int rc = d_pj.upload(pj)) return rc;
+                pk_patch.add(pbase, d_pb); pk_patch.add(pmw, d_pm); pk_patch.add(pi, d_pi); pk_patch.add(pj, d_pj);
+                if (int rc = pk_patch.commit(stream)) return rc;
                 const int np = (int)pi.size();
                 hipLaunchKernelGGL(hsdev::k_read_graph_patch, dim3((np + 255) / 256), dim3(256), 0, stream, d_pb.as<int64_t>(), d_pm.as<int32_t>(), d_pi.as<int32_t>(),
                                    d_pj.as<int32_t>(), np, d_bits.as<unsigned long long>());
-                HS_HIP(hipGetLastError());
-                if (int rc_w = stream_wait(stream)) return rc_w;   // the patch arrays die with this scope
+                HS_HIP(hipGetLastError());      // (the patch arrays live until the wait at the end of this function)
             }
             if (rows_on_host) *rows_on_host = n_amb;
         }
@@ -1672,7 +1678,7 @@ struct HipSrOps : hs::SrDeviceOps {
     // call that waits for the stream anyway
     struct SimdiffInFlight {
         DBuf d_alt, d_ref, d_sr, d_sa, d_sc, d_cb, d_po, d_n, d_w, d_oo, t_c, t_i, t_j;
-        UploadPack pk;
+        UploadPack pk, tiles;
         EventPair ev;
         float* k_ms = nullptr;
     };
@@ -1694,8 +1700,14 @@ struct HipSrOps : hs::SrDeviceOps {
     // object's columns; nothing is uploaded
     bool adopted = false;
     int64_t adopted_cols = 0, adopted_entries = 0;
+    DBuf cols_block;      // (adopted: the packed SNP block of stage 3; d_col_off / d_col_idx / d_col_code are views into it)
     void adopt_columns(HipCvOps& cv) {
-        std::swap(d_col_off, cv.d_pk_off); std::swap(d_col_idx, cv.d_pk_idx); std::swap(d_col_code, cv.d_pk_code);
+        std::swap(cols_block, cv.d_pk);
+        char* base = (char*)cols_block.p;
+        auto view = [&](DBuf& d, size_t off, size_t bytes) { d.release(); d.p = base + off; d.bytes = bytes; d.cap = 0; d.view = true; };
+        view(d_col_off, cv.pk_layout.off, ((size_t)cv.snp_count + 1) * 8);
+        view(d_col_idx, cv.pk_layout.idx, (size_t)cv.snp_entries * 4);
+        view(d_col_code, cv.pk_layout.code, (size_t)cv.snp_entries);
         adopted = true; adopted_cols = cv.snp_count; adopted_entries = cv.snp_entries;
     }
     bool columns_resident() const override { return adopted; }
@@ -1774,7 +1786,7 @@ struct HipSrOps : hs::SrDeviceOps {
         HS_HIP(hipEventRecord(f.ev.a, stream));
         if (int rc = kc.begin(HS_K_SIMDIFF, stream)) return rc;
         if (int rc = simdiff_launch(f.d_alt.as<uint64_t>(), f.d_ref.as<uint64_t>(), f.d_po.as<int64_t>(), f.d_n.as<int32_t>(), f.d_w.as<int32_t>(),
-                                    f.d_oo.as<int64_t>(), job.n_reads, d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, f.t_c, f.t_i, f.t_j)) return rc;
+                                    f.d_oo.as<int64_t>(), job.n_reads, d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, f.t_c, f.t_i, f.t_j, f.tiles)) return rc;
         if (int rc = kc.end(2 * (int64_t)pbytes + 8 * job.out_total, stream)) return rc;   // the two bit-planes in, sim + diff out
         HS_HIP(hipEventRecord(f.ev.b, stream));
         return HS_OK;   // not waited for: the stream orders K6 behind it, the host goes on planning the windows

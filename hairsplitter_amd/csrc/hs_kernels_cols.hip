@@ -45,6 +45,11 @@ struct ColumnsHeader {      // what the host reads between the phases (one small
     int64_t pad[2];
 };
 
+// the totals of the two tile scans into the header the host reads before it sizes the column arrays
+__global__ void k_columns_totals(const int64_t* __restrict__ n_cols, const int64_t* __restrict__ n_entries, ColumnsHeader* __restrict__ header) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { header->n_cols = *n_cols; header->n_entries = *n_entries; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K2's selection of the tiles [tile0, tile0 + n_tiles) packed into the column list, in position order. One workgroup per tile.
 // tile_base / tile_ebase: exclusive scans of the tiles' column counts / entry counts.
