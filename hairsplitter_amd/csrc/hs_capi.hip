@@ -172,20 +172,13 @@ struct UploadPack {
     }
 };
 
-// Host waits = polling hipStreamQuery: back to back ("spin") or with a 25-us sleep between two looks ("sleep": about 1 % of a
-// core instead of 100 %, the host learns of the end of the work 30-80 us late). No events, no interrupts, no device-wide
-// scheduling flag: the mode is a plain variable and can change between two waits. A wait that has lasted HS_WAIT_TIMEOUT_S
+// Host waits = polling hipStreamQuery with a 25-us sleep between two looks: about 1 % of a core instead of 100 %, the host learns
+// of the end of the work 30-80 us late -- which the other contig groups cover. No events, no interrupts, no device-wide
+// scheduling flag. HS_SPIN_WAIT=1 polls back to back instead (measured on the 16-core box, 500-contig job: the same step time,
+// 60-80 CPU-ms more per step; it only pays when a single chain owns the device). A wait that has lasted HS_WAIT_TIMEOUT_S
 // seconds (default 1800, 0 = no limit) returns an error instead of hanging the caller for ever; the blocks of that call are
-// then leaked, not recycled (g_device_lost), because the device may still be writing them. Which mode is better depends on whether the host has cores to
-// spare: on the 16-core box 256 x C2 (14.5 cores busy) runs 3-5 % faster spinning, the 500-contig job (it wants 17-18 cores:
-// the cgroup throttles it) 4 % faster sleeping. So the pipeline starts spinning and looks at its own CPU load after every run
-// (adapt_wait_policy); HS_BLOCKING_WAIT=1 / HS_SPIN_WAIT=1 pin the choice.
-static std::atomic<int> g_block_waits{0};
-static int forced_wait_policy() {
-    static const int f = std::getenv("HS_BLOCKING_WAIT") ? 1 : (std::getenv("HS_SPIN_WAIT") ? 0 : -1);
-    return f;
-}
-static bool blocking_wait() { const int f = forced_wait_policy(); return f >= 0 ? f == 1 : g_block_waits.load(std::memory_order_relaxed) == 1; }
+// then leaked, not recycled (g_device_lost), because the device may still be writing them.
+static bool blocking_wait() { static const bool spin = std::getenv("HS_SPIN_WAIT") != nullptr && std::getenv("HS_BLOCKING_WAIT") == nullptr; return !spin; }
 static bool spin_wait() { return !blocking_wait(); }
 static std::atomic<long> g_waits{0}, g_wait_us{0};     // HS_TIMING: host waits and the wall time spent in them
 static int stream_wait_impl(hipStream_t s);
@@ -330,18 +323,7 @@ struct DeviceTurn {
     DeviceTurn() { if (on()) lk = std::unique_lock<std::mutex>(mu()); }
 };
 
-static void set_wait_policy() {}   // (the wait mode is no device state any more: see stream_wait)
-// after a pipeline run: process CPU time over (wall time x usable cores). Above 0.97 the host is the limit and the cores the
-// waiting threads burn are missed elsewhere -> sleeping waits from the next run on; below 0.85 back to spinning.
-static void adapt_wait_policy(double cpu_s, double wall_s) {
-    if (forced_wait_policy() >= 0 || wall_s <= 0) return;
-    const double load = cpu_s / (wall_s * host_threads());
-    const int cur = g_block_waits.load(std::memory_order_relaxed);
-    const int next = load > 0.97 ? 1 : (load < 0.85 ? 0 : cur);
-    if (next == cur) return;
-    g_block_waits.store(next, std::memory_order_relaxed);
-    if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] host waits now %s (process CPU load %.2f of %d cores)\n", next ? "sleep" : "spin", load, host_threads());
-}
+static void set_wait_policy() {}   // (the wait mode is no device state: see stream_wait)
 
 int require_device() {
     int n = 0;
@@ -2162,6 +2144,7 @@ struct hs_pipeline {
     std::vector<std::string> errs;
     hs_cv_selection* sel = nullptr;
     std::vector<hs_cv_result*> cv;
+    std::vector<hs::SrWorkspace> sr_keep;      // per group: the stage-4 plans and visiting orders live from step to step
 
     int device = 0;        // = batch->device: the group threads bind themselves to it (a new thread starts on device 0)
     std::vector<int> thread_device;   // what every group thread found current after binding (hs_pipeline_thread_devices)
@@ -2216,6 +2199,7 @@ int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out) {
     for (int g = 0; g < G; ++g) p->ranges.push_back(std::make_pair((int)((int64_t)C * g / G), (int)((int64_t)C * (g + 1) / G)));
     p->rcs.assign((size_t)G, 0); p->errs.assign((size_t)G, std::string()); p->cv.assign((size_t)G, nullptr);
     p->device = b->device; p->thread_device.assign((size_t)G, -1);
+    p->sr_keep.resize((size_t)G);
     for (int g = 0; g < G; ++g) p->threads.emplace_back([p, g] { p->worker(g); });
     *out = p;
     return HS_OK;
@@ -2338,8 +2322,6 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
             else if (above < 20 && mean < 2000) window_size = 500;
         }
     }
-    struct timespec cpu0; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &cpu0);
-    const auto wall0 = std::chrono::steady_clock::now();
     std::vector<hs_sr_result*> parts((size_t)G, nullptr);
     std::vector<hs::SrSparseLabels> sparse((size_t)G);      // the groups leave their labels per window; concat_sr_parts spreads them
     const int rc = p->run([&](int g) {
@@ -2352,7 +2334,7 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
         HipSrOps ops;
         if (!via_host) ops.adopt_columns(cv_ops);
         return hs::sr_run_from_cv(ops, meta, c0, c1, p->cv[(size_t)g], error_rate, rarest_strain_abundance, low_memory, amplicon, seed, per, window_size,
-                                  &parts[(size_t)g], &sparse[(size_t)g]);
+                                  &parts[(size_t)g], &sparse[(size_t)g], &p->sr_keep[(size_t)g]);
     });
     if (rc) { for (hs_sr_result* r : parts) if (r) hs::free_sr_result(r); return rc; }
     if (st) {
@@ -2370,11 +2352,6 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
     hs_sr_result* R = concat_sr_parts(p, parts, sparse, st);
     p->drop_cv();
     *out = R;
-    {
-        struct timespec cpu1; clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &cpu1);
-        adapt_wait_policy((double)(cpu1.tv_sec - cpu0.tv_sec) + 1e-9 * (double)(cpu1.tv_nsec - cpu0.tv_nsec),
-                          std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count());
-    }
     return HS_OK;
 }
 

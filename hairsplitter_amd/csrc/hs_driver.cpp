@@ -422,7 +422,7 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
 // stage 4
 // ---------------------------------------------------------------------------------------------------
 int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
-           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out, SrSparseLabels* sparse) {
+           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out, SrSparseLabels* sparse, SrWorkspace* keep) {
     Laps laps("sr");
     if (n_threads <= 0) n_threads = host_threads();
     const int C = n_contigs;
@@ -435,17 +435,22 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     // something needs to walk them here (need_columns)
     const bool resident = dev.columns_resident();
     std::vector<hs_sr_contig> cs_local(contigs, contigs + C);      // (the column pointers are filled in if the columns are fetched)
-    std::vector<SrContigState> st((size_t)C);
+    std::vector<SrContigState> st_local;
+    if (keep) keep->st.resize((size_t)C); else st_local.resize((size_t)C);
+    std::vector<SrContigState>& st = keep ? keep->st : st_local;
     parallel_for(C, n_threads, [&](int c) {
         SrContigState& s = st[(size_t)c];
         s.c = &cs_local[(size_t)c];
         s.N = contigs[c].n_reads;
         s.low_memory_now = lowmem || sr_coverage_above_1000(contigs[c]);   // separate_reads.cpp:1515-1518
-        if (contigs[c].n_snps == 0) return;                                 // :1522-1524
+        if (contigs[c].n_snps == 0) { for (SrWindowPlan& old : s.windows) s.spare.push_back(std::move(old)); s.windows.clear(); return; }   // :1522-1524
         s.words = (contigs[c].n_snps + 63) / 64;
-        s.perm = shuffled_order(s.N, seed);
-        s.rank.resize((size_t)s.N);
-        for (int k = 0; k < s.N; ++k) s.rank[(size_t)s.perm[(size_t)k]] = k;
+        if (s.perm_n != s.N || s.perm_seed != seed) {      // (a kept state has the order of these N reads already)
+            s.perm = shuffled_order(s.N, seed);
+            s.rank.resize((size_t)s.N);
+            for (int k = 0; k < s.N; ++k) s.rank[(size_t)s.perm[(size_t)k]] = k;
+            s.perm_n = s.N; s.perm_seed = seed;
+        }
     });
 
     laps.lap("perm");
@@ -797,7 +802,7 @@ void sr_expand_labels(const SrSparseLabels& sp, const int64_t* label_off, int64_
 // stage 3 -> stage 4 hand-over without the .col text round trip
 // ---------------------------------------------------------------------------------------------------
 int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, int c0, int c1, const hs_cv_result* cv, float error_rate, float rsa, int32_t low_memory,
-                   int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out, SrSparseLabels* sparse) {
+                   int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out, SrSparseLabels* sparse, SrWorkspace* keep) {
     if (c0 < 0 || c1 > b.n_contigs || c0 > c1 || cv->n_contigs != c1 - c0) { set_error("sr_run_from_cv: contig range does not match the stage-3 result"); return HS_EINVAL; }
     const int C = c1 - c0;
     const double t_prep0 = now_ms();
@@ -879,7 +884,7 @@ int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, int c0, int c1, const hs_c
     }
     if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] sr hand-over from stage 3: %.2f ms\n", now_ms() - t_prep0);
     const int32_t w = window_size > 0 ? window_size : sr_window_size(hc.data(), C, amplicon != 0);
-    return sr_run(dev, hc.data(), C, w, error_rate, low_memory, seed, n_threads, out, sparse);
+    return sr_run(dev, hc.data(), C, w, error_rate, low_memory, seed, n_threads, out, sparse, keep);
 }
 
 // ---------------------------------------------------------------------------------------------------

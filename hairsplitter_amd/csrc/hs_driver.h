@@ -222,12 +222,15 @@ struct SrSparseLabels {
     std::vector<int32_t> ids, labels;
 };
 // sparse != nullptr: filled, and out->labels stays nullptr (label_off is filled as usual)
+// state of a stage-4 call that is worth keeping for the next one on the same contigs (a pipeline group runs the same contigs step
+// after step): the per-contig plans with their storage, the shuffled visiting orders
+struct SrWorkspace { std::vector<SrContigState> st; };
 int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
-           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out, SrSparseLabels* sparse = nullptr);
+           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out, SrSparseLabels* sparse = nullptr, SrWorkspace* keep = nullptr);
 
 int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& meta, int c0, int c1, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance,
                    int32_t low_memory, int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out,
-                   SrSparseLabels* sparse = nullptr);
+                   SrSparseLabels* sparse = nullptr, SrWorkspace* keep = nullptr);
 
 // the dense label array of an hs_sr_result (recycled big blocks; free_sr_result returns it)
 int32_t* sr_labels_alloc(size_t n_labels);

@@ -216,9 +216,17 @@ struct ColumnBits {
         for (int k = 0; k < nslots; ++k) slot_of[code_of[k]] = 0xFF;
         words = (n_reads + 63) >> 6;
         nslots = 0; n_entries = n;
-        wlo = words; whi = -1;
-        any.assign((size_t)words, 0ull);
+        // the reads of a column sit in a few neighbouring words (bit = rank by start position): only those words are kept valid
+        int32_t rk_stack[512];
+        std::vector<int32_t> rk_heap;
+        int32_t* rk = rk_stack;
+        if (n > 512) { rk_heap.resize((size_t)n); rk = rk_heap.data(); }
+        int lo = words, hi = -1;
+        for (int i = 0; i < n; ++i) { const int r = rank_of[idx[i]]; rk[i] = r; const int w = r >> 6; if (w < lo) lo = w; if (w > hi) hi = w; }
+        wlo = lo; whi = hi;
+        if (any.size() < (size_t)words) any.resize((size_t)words);
         if (bits.size() < (size_t)8 * words) bits.resize((size_t)8 * words);
+        for (int w = lo; w <= hi; ++w) any[(size_t)w] = 0ull;
         for (int i = 0; i < n; ++i) {
             int k = slot_of[code[i]];
             if (k == 0xFF) {
@@ -227,14 +235,12 @@ struct ColumnBits {
                 slot_of[code[i]] = (uint8_t)k;
                 code_of[nslots++] = code[i];
                 if (bits.size() < (size_t)nslots * words) bits.resize((size_t)nslots * 2 * words);
-                std::fill(bits.begin() + (size_t)k * words, bits.begin() + (size_t)(k + 1) * words, 0ull);
+                for (int w = lo; w <= hi; ++w) bits[(size_t)k * words + (size_t)w] = 0ull;
             }
-            const int rk = rank_of[idx[i]];
-            const uint64_t b = 1ull << (rk & 63);
-            bits[(size_t)k * words + ((size_t)rk >> 6)] |= b;
-            any[(size_t)rk >> 6] |= b;
-            if ((rk >> 6) < wlo) wlo = rk >> 6;
-            if ((rk >> 6) > whi) whi = rk >> 6;
+            const int r = rk[i];
+            const uint64_t b = 1ull << (r & 63);
+            bits[(size_t)k * words + ((size_t)r >> 6)] |= b;
+            any[(size_t)r >> 6] |= b;
         }
     }
 };
@@ -260,6 +266,33 @@ static Contingency column_vs_partition_bits(const DensePartition& p, const Colum
         int decided = 0;
         for (int w = w0; w <= w1; ++w) decided += __builtin_popcountll(cb.any[(size_t)w] & (p.plus[(size_t)w] | p.minus[(size_t)w]));
         if (decided <= 14 && (size_t)decided < (size_t)cb.n_entries / 2) return r;
+    }
+    if (ref < 128) {
+        // the usual case in one pass: the counts of the column's codes among the shared reads, the largest among the codes other
+        // than the reference code; a tie of that largest count (the reference then takes the first of the tied codes in the
+        // iteration order of its hash map) goes through the general form below
+        int best = -1, nbest = 0, best_slot = -1;
+        const int ref_slot = cb.slot_of[ref] == 0xFF ? -1 : (int)cb.slot_of[ref];
+        for (int k = 0; k < cb.nslots; ++k) {
+            if (k == ref_slot) continue;
+            const uint64_t* bk = cb.bits.data() + (size_t)k * W;
+            int c = 0;
+            for (int w = w0; w <= w1; ++w) c += __builtin_popcountll(bk[w] & p.present[(size_t)w]);
+            if (c == 0) continue;
+            if (c > best) { best = c; nbest = 1; best_slot = k; } else if (c == best) nbest++;
+        }
+        if (nbest <= 1) {
+            r.second = best_slot >= 0 ? cb.code_of[best_slot] : (uint8_t)' ';
+            if (ref_slot >= 0) {
+                const uint64_t* bm = cb.bits.data() + (size_t)ref_slot * W;
+                for (int w = w0; w <= w1; ++w) { r.n11 += __builtin_popcountll(bm[w] & p.plus[(size_t)w]); r.n01 += __builtin_popcountll(bm[w] & p.minus[(size_t)w]); }
+            }
+            if (best_slot >= 0) {
+                const uint64_t* bs = cb.bits.data() + (size_t)best_slot * W;
+                for (int w = w0; w <= w1; ++w) { r.n10 += __builtin_popcountll(bs[w] & p.plus[(size_t)w]); r.n00 += __builtin_popcountll(bs[w] & p.minus[(size_t)w]); }
+            }
+            return r;
+        }
     }
     // counts among the shared reads
     uint8_t seen[128]; int cnt[128]; int slot[128];
@@ -572,6 +605,10 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
     rank_reads(st, read_start);
     const std::vector<int32_t>& rank_of = st.rank_of; const std::vector<int32_t>& orig_of = st.orig_of;
     int last_position = -5;
+    // the partitions a column can still meet, in creation order: one that is more than 50 kb behind (:595) or none of whose reads
+    // reaches the position stays so for every later column (positions ascend; `right` and `reach` only move when the partition
+    // is augmented, which takes a comparison), so it leaves the list for good
+    std::vector<int> active;
     for (int ci = 0; ci < cs.n; ++ci) {
         const int pos = cs.rec[ci].pos;
         const uint8_t k0 = cs.rec[ci].k0;
@@ -582,11 +619,15 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
         const double tb0 = tim ? nowus() : 0;
         if (!parts.empty()) colbits.build(idx, code, n, n_reads, rank_of.data());
         if (tim) t_build += nowus() - tb0;
-        for (size_t p = 0; p < parts.size(); ++p) {
+        size_t kept = 0;
+        for (size_t a = 0; a < active.size(); ++a) {
+            const size_t p = (size_t)active[a];
+            if (found) { active[kept++] = (int)p; continue; }      // (behind the partition that took the column: not looked at, :630)
             if (std::abs(pos - parts[p].right) > 50000) continue;
             // no read of the partition reaches this position: nothing is shared, the comparison yields "not comparable", which
             // neither correlates nor matches (:817-828) -- skipped without looking at the bit sets
             if (pos >= parts[p].reach) continue;
+            active[kept++] = (int)p;
             const Contingency d = column_vs_partition_bits(parts[p], colbits, k0, orig_of.data());
             n_cmp++;
 #ifdef HS_SELFCHECK
@@ -617,10 +658,11 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
                 const double ta0 = tim ? nowus() : 0;
                 augment(parts[p], idx, code, n, d, pos, read_end);
                 if (tim) t_aug += nowus() - ta0;
-                break;
             }
         }
+        active.resize(kept);
         if (!found) {
+            active.push_back((int)parts.size());
             parts.emplace_back();
             partition_from_column(parts.back(), st.arena, n_reads, idx, code, n, pos, k0, rank_of.data(), orig_of.data(), read_end);
             parts.back().n_corr = n_corr;

@@ -130,11 +130,23 @@ void sr_build_window_graph_low_memory(const SrContigState& st, const SrWindowPla
 // window is never materialised over the N reads of the contig: it is the reads of the window's first SNP column that are
 // also in its last one -- or lie beyond that column's last read, which the reference's clearing loop (:1612-1619) never
 // reaches --, i.e. a merge of two ascending lists.
+// The plans of a contig are a few dozen small vectors each; a state that lives from call to call (SrWorkspace) hands their
+// storage round instead of freeing and allocating it every time.
+SrWindowPlan SrContigState::take_window() {
+    if (spare.empty()) return SrWindowPlan();
+    SrWindowPlan w = std::move(spare.back());
+    spare.pop_back();
+    w.ids.clear(); w.labels.clear(); w.local_snps.clear();
+    w.start = w.end = 0; w.has_snps = false; w.final_lo = w.final_hi = 0; w.row0 = -1; w.final_graph_empty = false; w.col_a = w.col_b = -1;
+    return w;
+}
+
 void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool low_memory, bool with_reads) {
     (void)error_rate;
     const hs_sr_contig& c = *st.c;
     const int N = st.N;
     const long L = c.length;
+    for (SrWindowPlan& old : st.windows) st.spare.push_back(std::move(old));
     st.windows.clear();
     st.snp_pos_sorted = std::is_sorted(c.snp_pos, c.snp_pos + c.n_snps);
     if (c.n_snps == 0) return;
@@ -144,7 +156,7 @@ void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool 
         upper = (chunk + 1) * window_size;
         const bool last = (long)(chunk + 1) * window_size + 100 > L;
         if (last) upper = (int)L + 1;
-        SrWindowPlan w;
+        SrWindowPlan w = st.take_window();
         w.start = chunk * window_size;
         w.end = std::min(upper - 1, (int)L);
         if (cur >= c.n_snps || c.snp_pos[cur] > upper - 1) {          // :1565-1587

@@ -15,6 +15,9 @@ struct SrContigState {
     std::vector<struct SrWindowPlan> windows;
     std::vector<int32_t> perm;                      // std::shuffle(mt19937(seed)) of 0..N-1
     std::vector<int32_t> rank;                      // rank[perm[k]] = k
+    uint32_t perm_seed = 0; int perm_n = -1;        // what perm / rank were made for (a state kept from call to call skips the shuffle)
+    std::vector<struct SrWindowPlan> spare;         // window plans of the previous call: their vectors' storage is used again
+    struct SrWindowPlan take_window();              // an empty plan, recycled if one is there
 };
 
 // a window's read graph in its local index space: CSR rows [0, m), neighbours = local ids (ascending)
