@@ -96,10 +96,11 @@ def run_stage_pair(cv, sr, files, td, tag, threads, env=None):
 
 def file_to_file(cfg, n_job, sample_ids, sample_files, job_files, reps, reference_on_full_job):
     """SURVEY.md 8(d) metric (ii): wall clock of the two drop-in executables next to the compiled reference (oracle/_ref,
-    built from /root/reference by oracle/Makefile) on the SAME files, `reps` runs each, median. The reference runs on a
-    bounded sample of the job (the first contigs of the configuration) so that the default bench stays within minutes; the
-    drop-ins additionally run on the files of the whole job. Also the `cpu_baseline` of the bench line."""
-    from hairsplitter_amd import synth
+    built from /root/reference by oracle/Makefile) on the SAME files. The drop-ins are timed both ways: as a caller sees them
+    (the started process exits when the outputs are complete, the worker's teardown goes on in the background: hs_dropin_main.h)
+    and with HS_NO_DETACH=1 (one process, timed to its full exit) -- speed-ups are quoted from the second, conservative number.
+    The reference runs ONCE on the files of the whole job (C4: about 40 s with 16 threads) -- that run is the `cpu_baseline` of
+    the bench line; without the job's files (or with --no-f2f-reference-full) it runs on a bounded sample instead."""
     import __graft_entry__ as ge
     p = ge.paths()
     cores = effective_cores()
@@ -107,42 +108,43 @@ def file_to_file(cfg, n_job, sample_ids, sample_files, job_files, reps, referenc
     if not have_ref and not os.path.exists(p["oracle"]):
         return None, None
     out = {"threads": cores, "runs": reps}
-    with tempfile.TemporaryDirectory() as td:
-        f = sample_files                      # written before the GPU was touched (main)
-        bp = int(sample_files["aligned_bp"])
-        ours = [run_stage_pair([p["cv"]], [p["sr"]], f, td, "hip", cores) for _ in range(reps)]
-        if have_ref:
-            ref = [run_stage_pair([p["ref_cv"]], [p["ref_sr"]], f, td, "ref", cores) for _ in range(reps)]
-            kind, threads = "reference", cores
-        else:
-            ref = [run_stage_pair([p["oracle"], "call_variants"], [p["oracle"], "separate_reads"], f, td, "ref", 1)]
-            kind, threads = "port", 1
-        med = lambda v: statistics.median(v)
-        o_t, r_t = med([a + b for a, b in ours]), med([a + b for a, b in ref])
-        out["sample"] = {"contigs": len(sample_ids), "aligned_bp": bp,
-                         "dropin_s": {"call_variants": med([a for a, _ in ours]), "separate_reads": med([b for _, b in ours]), "total": o_t},
-                         "reference_s": {"call_variants": med([a for a, _ in ref]), "separate_reads": med([b for _, b in ref]), "total": r_t},
-                         "speedup": r_t / o_t, "reference_kind": kind}
-        base = {"value": bp / r_t, "unit": "aligned read-bp/s", "cores": threads, "kind": kind,
-                "sample": f"the first {len(sample_ids)} of the {n_job} contigs of {cfg} ({bp} aligned bp), stage 3+4 file to file, median of {len(ref)} runs: {r_t:.2f} s wall"
-                          + (f", -t {threads} (contig-level OpenMP only)" if kind == "reference" else ", single thread")}
-    if job_files is not None:
+    med = lambda v: statistics.median(v)
+    no_detach = dict(os.environ, HS_NO_DETACH="1")
+
+    def leg(files, n_contigs, with_reference, tag):
+        bp = int(files["aligned_bp"])
         with tempfile.TemporaryDirectory() as td:
-            env = dict(os.environ, HS_TIMING="1")
-            runs = []
-            for _ in range(reps):
-                runs.append(run_stage_pair([p["cv"]], [p["sr"]], job_files, td, "hip", cores))
-            o_t = statistics.median([a + b for a, b in runs])
-            out["job"] = {"contigs": n_job, "aligned_bp": job_files["aligned_bp"],
-                          "dropin_s": {"call_variants": statistics.median([a for a, _ in runs]), "separate_reads": statistics.median([b for _, b in runs]), "total": o_t},
-                          "dropin_bp_per_s": job_files["aligned_bp"] / o_t}
-            if reference_on_full_job and have_ref:
-                a, b = run_stage_pair([p["ref_cv"]], [p["ref_sr"]], job_files, td, "ref", cores)
-                out["job"]["reference_s"] = {"call_variants": a, "separate_reads": b, "total": a + b}
-                out["job"]["speedup"] = (a + b) / o_t
-            else:   # ~40 s per run on C4 with 16 threads: measured with --f2f-reference-full (profiles/), not in the default run
-                out["job"]["reference_s"] = None
-            del env
+            det = [run_stage_pair([p["cv"]], [p["sr"]], files, td, "hip", cores) for _ in range(reps)]
+            one = [run_stage_pair([p["cv"]], [p["sr"]], files, td, "hip1", cores, env=no_detach) for _ in range(reps)]
+            d = {"contigs": n_contigs, "aligned_bp": bp,
+                 "dropin_s": {"call_variants": med([a for a, _ in one]), "separate_reads": med([b for _, b in one]), "total": med([a + b for a, b in one]),
+                              "note": "HS_NO_DETACH=1: one process per stage, timed to its exit"},
+                 "dropin_detached_s": {"call_variants": med([a for a, _ in det]), "separate_reads": med([b for _, b in det]), "total": med([a + b for a, b in det]),
+                                       "note": "as started by hairsplitter.py: the process exits when the outputs are complete, teardown in the background"}}
+            d["dropin_bp_per_s"] = bp / d["dropin_s"]["total"]
+            base = None
+            if with_reference:
+                if have_ref:
+                    a, b = run_stage_pair([p["ref_cv"]], [p["ref_sr"]], files, td, "ref", cores)
+                    kind, threads = "reference", cores
+                else:
+                    a, b = run_stage_pair([p["oracle"], "call_variants"], [p["oracle"], "separate_reads"], files, td, "ref", 1)
+                    kind, threads = "port", 1
+                d["reference_s"] = {"call_variants": a, "separate_reads": b, "total": a + b}
+                d["speedup"] = (a + b) / d["dropin_s"]["total"]
+                d["speedup_detached"] = (a + b) / d["dropin_detached_s"]["total"]
+                d["reference_kind"] = kind
+                base = {"value": bp / (a + b), "unit": "aligned read-bp/s", "cores": threads, "kind": kind,
+                        "sample": f"{tag} ({bp} aligned bp), stage 3+4 file to file, one run: {a + b:.2f} s wall"
+                                  + (f", -t {threads} (contig-level OpenMP only)" if kind == "reference" else ", single thread"),
+                        "note": "file to file (parsing 2 GB of text included): compare with file_to_file.*.dropin_bp_per_s, NOT with `value` (HBM-resident steps)"}
+            return d, base
+
+    base = None
+    if job_files is not None:
+        out["job"], base = leg(job_files, n_job, reference_on_full_job, f"the whole job: the {n_job} contigs of {cfg}")
+    if base is None and sample_files is not None:
+        out["sample"], base = leg(sample_files, len(sample_ids), True, f"the first {len(sample_ids)} of the {n_job} contigs of {cfg}")
     return out, base
 
 
@@ -156,7 +158,12 @@ def main():
         faulthandler.register(signal.SIGUSR1, all_threads=True)
     except (AttributeError, ValueError):
         pass
-    faulthandler.dump_traceback_later(float(os.environ.get("HS_BENCH_WATCHDOG_S", "1500")), exit=True)
+    # re-armed at every step and phase (a slow but progressing run -- a bigger configuration, the reference on the whole job -- is not killed)
+    watchdog_s = float(os.environ.get("HS_BENCH_WATCHDOG_S", "900"))
+    def pet():
+        faulthandler.cancel_dump_traceback_later()
+        faulthandler.dump_traceback_later(watchdog_s, exit=True)
+    pet()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -167,8 +174,8 @@ def main():
     ap.add_argument("--threads", type=int, default=0, help="host threads for the sequential glue (0 = all cores / ranks)")
     ap.add_argument("--cpu-contigs", type=int, default=-1, help="contigs of the CPU-baseline / file-to-file sample (0 disables both; -1 = about 80 M aligned bp)")
     ap.add_argument("--no-f2f-job", action="store_true", help="skip the file-to-file run of the drop-ins on the whole job")
-    ap.add_argument("--f2f-reference-full", action="store_true", help="also time the reference on the files of the whole job (C4: ~40 s per run)")
-    ap.add_argument("--f2f-runs", type=int, default=3)
+    ap.add_argument("--no-f2f-reference-full", action="store_true", help="do not time the reference on the files of the whole job (C4: ~40 s); a sample of the job instead")
+    ap.add_argument("--f2f-runs", type=int, default=2)
     ap.add_argument("--seed", type=int, default=None)
     args = ap.parse_args()
 
@@ -194,7 +201,7 @@ def main():
     # the files of the file-to-file sample too, NOW: forking workers from a process that has initialised the GPU (runtime threads,
     # their locks copied mid-flight into the child) hangs now and then
     sample_dir, sample_files, n_sample = None, None, 0
-    if want_f2f:
+    if want_f2f and (args.no_f2f_reference_full or job_dir is None):
         if args.cpu_contigs > 0:
             n_sample = min(args.cpu_contigs, n_job)
         else:   # about 80 M aligned bp: ~2-4 s of the reference on 16 cores
@@ -237,7 +244,11 @@ def main():
 
     B = len(contigs)
     G = max(1, min(args.groups if args.groups > 0 else min(8, max(1, n_threads // 4)), max(B, 1)))
+    pet()
+    t_up = time.perf_counter()
     batch = api.PipelineGroups(contigs, G)   # inputs now resident in HBM; the streaming kernels run once per step over all of them
+    t_upload = batch.batch.create_s           # hs_cv_batch_create: H2D of the job's flat arrays + the launch plans (CIGAR spans, tile plan, pileup tasks), once per job
+    t_flatten = time.perf_counter() - t_up - t_upload   # (Python: the synthetic contigs flattened into those arrays -- not part of the path)
     local_bp = batch.aligned_bp
     if job_files is not None:
         job_files["aligned_bp"] = int(local_bp)
@@ -281,10 +292,10 @@ def main():
     # per-thread scratch and the HIP runtime's own pools (first use of every buffer size goes to hipMalloc / hipHostMalloc),
     # then the W warm-up steps of the contract
     for _ in range(SETUP_STEPS):
-        step()
+        pet(); step()
     sync()
     for _ in range(args.warmup):
-        step()
+        pet(); step()
     sync()
     for k in py_ms:
         py_ms[k] = 0.0
@@ -292,12 +303,14 @@ def main():
     if os.environ.get("HS_CPU_PROFILE"):      # diagnostic: sampling profile of the host side over the timed steps (tools/cpuprof_report.py)
         api.load().hs_cpuprof_start(os.environ["HS_CPU_PROFILE"].encode())
     api.kernel_stats_reset()
+    waits0 = api.host_waits()
     t0 = time.perf_counter(); cpu0 = time.process_time()
     t_dev = 0.0; t_host = 0.0
     last = None
     step_ms = []
     wall = {}
     for _ in range(args.steps):
+        pet()
         ts = time.perf_counter()
         cv, sr, gathered = step()
         step_ms.append((time.perf_counter() - ts) * 1e3)
@@ -311,6 +324,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3
+    waits_per_step = (api.host_waits() - waits0) / args.steps
     if os.environ.get("HS_CPU_PROFILE"):
         api.load().hs_cpuprof_stop()
     kstats = api.kernel_stats()
@@ -362,7 +376,13 @@ def main():
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "host": {"cpus_online": os.cpu_count(), "cpus_effective": effective_cores(), "process_cpu_ms_per_step": cpu_ms_per_step,
-                     "cfs_throttled_during_timed_steps": throttled, "input_generation_s": t_gen},
+                     "cfs_throttled_during_timed_steps": throttled, "input_generation_s": t_gen, "waits_per_step": waits_per_step,
+                     "note": "waits = host round trips to the device summed over the contig groups"},
+            "host_fallbacks_per_step": {"windows_finished_on_host": int(last["n_windows_finished_on_host"]), "of_windows": int(last["n_windows"]),
+                                        "graph_rows_resolved_by_std_sort_on_host": int(last["n_graph_rows_host"]), "of_graph_rows": int(last["n_graph_rows"])},
+            "with_h2d_and_plans": {"h2d_plus_launch_plans_s": t_upload, "python_flattening_s_not_counted": t_flatten,
+                                   "bp_per_s_one_job_from_host_buffers": total_bp / (t_upload + dt / K) if world == 1 else None,
+                                   "note": "host buffers in (hs_cv_batch_create: PCIe upload + launch plans, once per job) + one step; never `value`"},
             "config": {"workload": WORKLOADS[cfg].format(n=n_job) + "; the whole job per step, inputs resident in HBM",
                        "config": cfg, "contigs": n_job, "aligned_bp": total_bp, "contigs_rank0": B, "aligned_bp_rank0": int(local_bp),
                        "parallelism": f"contigs sharded over {world} GPU(s) by LPT on contig length", "groups_per_gpu": G,
@@ -371,7 +391,7 @@ def main():
                          "frac": d["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": d["avg_launch_ms"],
                          "launches_per_step": d["launches_per_step"], "ms_per_step": d["ms_per_step"],
                          "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
-                         "selection": "largest summed launch time per step among all kernels of the path (HIP events on each launch stream)",
+                         "selection": "the kernel with the largest summed launch time per step among all kernels of the path (one slot per kernel, HIP events on each launch stream)",
                          "whole_path": whole},
             "kernels": {k: {kk: (round(vv, 6) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]["ms_per_step"])},
             "step_ms": [round(x, 2) for x in step_ms],
@@ -382,7 +402,9 @@ def main():
         batch = None
         if want_f2f:
             try:
-                f2f, base = file_to_file(cfg, n_job, list(range(n_sample)), sample_files, job_files, max(1, args.f2f_runs), args.f2f_reference_full)
+                pet()
+                faulthandler.cancel_dump_traceback_later()      # (the reference on the whole job takes its time; every subprocess has its own limit)
+                f2f, base = file_to_file(cfg, n_job, list(range(n_sample)), sample_files, job_files, max(1, args.f2f_runs), not args.no_f2f_reference_full)
                 if f2f is not None:
                     out["file_to_file"] = f2f
                     out["cpu_baseline"] = base

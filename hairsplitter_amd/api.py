@@ -22,10 +22,10 @@ SYMBOLS = [
     "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_pipeline_thread_devices", "hs_cv_batch_device", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
-    "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
+    "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_host_wait_stats", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
 ]
 
-HS_NKERNELS = 17
+HS_NKERNELS = 25
 
 
 class HsError(RuntimeError):
@@ -114,6 +114,15 @@ def load() -> C.CDLL:
     lib.hs_kernel_stats_get.argtypes = [C.POINTER(KernelStats)]
     _lib = lib
     return lib
+
+
+def host_waits():
+    """number of host waits for the device since the library was loaded"""
+    n = C.c_int64(0); ms = C.c_double(0)
+    lib = load()
+    lib.hs_host_wait_stats.restype = None
+    lib.hs_host_wait_stats(C.byref(n), C.byref(ms))
+    return int(n.value)
 
 
 def kernel_stats_reset():
@@ -221,11 +230,14 @@ class CvBatch:
         lib = load()
         self.flat = flat
         h = C.c_void_p()
+        import time
+        t0 = time.perf_counter()
         _check(lib.hs_cv_batch_create(_hp(flat.contig_seq, C.c_uint8), _hp(flat.contig_off, C.c_int64), C.c_int32(flat.n_contigs),
                                       _hp(flat.read_seq, C.c_uint8), _hp(flat.read_off, C.c_int64), C.c_int32(flat.n_reads),
                                       _hp(flat.rec_read, C.c_int32), _hp(flat.rec_pos, C.c_int32), _hp(flat.rec_strand, C.c_uint8),
                                       _hp(flat.rec_cig_off, C.c_int64), _hp(flat.cigar, C.c_uint32),
                                       _hp(flat.contig_rec_off, C.c_int32), C.byref(h)))
+        self.create_s = time.perf_counter() - t0      # host buffers -> HBM + the launch plans (CIGAR spans, tile plan, pileup tasks)
         self.handle = h
 
     @property

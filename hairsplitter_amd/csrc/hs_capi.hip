@@ -184,7 +184,7 @@ static std::atomic<long> g_waits{0}, g_wait_us{0};     // HS_TIMING: host waits 
 static int stream_wait_impl(hipStream_t s);
 static int stream_wait(hipStream_t s) {
     static const bool timed = std::getenv("HS_TIMING") != nullptr;
-    if (!timed) return stream_wait_impl(s);
+    if (!timed) { g_waits.fetch_add(1, std::memory_order_relaxed); return stream_wait_impl(s); }
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = stream_wait_impl(s);
     g_waits.fetch_add(1); g_wait_us.fetch_add((long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
@@ -352,14 +352,18 @@ extern "C" {
 
 const char* hs_version(void) { return "hairsplitter_amd 0.2 (gfx950)"; }
 const char* hs_kernel_name(int k) {
-    static const char* names[HS_NKERNELS] = {"k_cigar_scan", "k_pileup_packed", "k_column_stats_tiled", "k_gather_columns_tiled", "k_column_top3", "k_pack_columns",
-                                             "k_column_partition_test", "k_snp_planes", "k_simdiff", "k_read_graph_rows", "k_read_graph_fill", "k_cw_visit_lists",
-                                             "k_cw_seeded_lanes", "k_window_tail", "k_cw_local", "k_robust_partitions", "other"};
+    static const char* names[HS_NKERNELS] = {"k_cigar_scan", "k_pileup_packed", "k_column_stats_tiled", "k_columns_compact", "k_gather_tiles", "k_column_top3_exact",
+                                             "k_candidates_scan", "k_pack_flagged", "k_partition_transpose", "k_column_partition_lanes", "k_column_partition_test",
+                                             "k_snp_flags", "k_window_masks", "k_snp_planes", "k_simdiff", "k_read_graph_rows", "k_read_graph_fill", "k_cw_visit_lists",
+                                             "k_cw_seed_sets", "k_cw_seeded_lanes", "k_cw_seeded_rows", "k_window_tail", "k_cw_local", "k_robust_partitions", "other"};
     return k >= 0 && k < HS_NKERNELS ? names[k] : "?";
 }
 void hs_kernel_stats_reset(void) { KernelTable& t = kernel_table(); std::lock_guard<std::mutex> g(t.mu); std::memset(&t.st, 0, sizeof t.st); }
 void hs_kernel_stats_get(hs_kernel_stats* out) { if (!out) return; KernelTable& t = kernel_table(); std::lock_guard<std::mutex> g(t.mu); *out = t.st; }
 const char* hs_last_error(void) { return hs::g_err.c_str(); }
+// host waits for the device since the library was loaded (every one is a round trip of a contig group's chain); the wall time
+// spent in them is only kept under HS_TIMING
+void hs_host_wait_stats(int64_t* n_waits, double* ms_in_waits) { if (n_waits) *n_waits = g_waits.load(); if (ms_in_waits) *ms_in_waits = g_wait_us.load() / 1e3; }
 int hs_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 static std::vector<int> device_list();
 int hs_warmup(void) {
@@ -715,7 +719,8 @@ static int partition_test_launch(const int64_t* d_col_off, const int32_t* d_col_
                                  const uint8_t* d_col_k0, const uint8_t* d_col_k1, const int32_t* d_col_c1, const uint8_t* d_col_is_cand, int32_t n_cols,
                                  const int32_t* d_part_off, const int64_t* d_part_state_off, const int8_t* d_part_state,
                                  const int32_t* h_part_off, const int32_t* h_contig_n_reads, int32_t n_contigs, uint8_t* d_keep, hipStream_t stream,
-                                 DBuf& d_tab, DBuf& d_tab_off, DBuf& d_ctg_n, DBuf& d_list, UploadPack& pk) {
+                                 DBuf& d_tab, DBuf& d_tab_off, DBuf& d_ctg_n, DBuf& d_list, UploadPack& pk, KernelClock* kc = nullptr,
+                                 int64_t col_entries = 0, int64_t state_bytes = 0) {
     std::vector<int64_t> tab_off((size_t)n_contigs + 1, 0);
     std::vector<int32_t> ctg_n(h_contig_n_reads, h_contig_n_reads + n_contigs);
     int64_t max_cells = 1;
@@ -730,23 +735,29 @@ static int partition_test_launch(const int64_t* d_col_off, const int32_t* d_col_
     if (int rc = d_tab.alloc(std::max<size_t>((size_t)tab_off.back(), 64))) return rc;
     if (tab_off.back() > 0) {
         const unsigned gx = (unsigned)std::min<int64_t>((max_cells + 255) / 256, 64);
+        if (kc) { if (int rc = kc->begin(HS_K_PARTITION_TRANSPOSE, stream)) return rc; }
         hipLaunchKernelGGL(hsdev::k_partition_transpose, dim3(gx, (unsigned)n_contigs), dim3(256), 0, stream, d_part_off, d_part_state_off, d_part_state,
                            d_ctg_n.as<int32_t>(), d_tab_off.as<int64_t>(), n_contigs, d_tab.as<uint8_t>());
+        if (kc) { if (int rc = kc->end(state_bytes + (int64_t)tab_off.back(), stream)) return rc; }      // the dense states in, the [read][partition] table out
     }
     if (int rc = d_list.alloc(((size_t)n_cols + 1) * 4)) return rc;     // [0] = number of undecided columns, then their indices
     HS_HIP(hipMemsetAsync(d_list.p, 0, 4, stream));
+    if (kc) { if (int rc = kc->begin(HS_K_PARTITION_LANES, stream)) return rc; }
     hipLaunchKernelGGL(hsdev::k_column_partition_lanes, dim3((n_cols + 3) / 4), dim3(256), 0, stream, d_col_off, d_col_idx, d_col_code, d_col_contig,
                        d_col_k0, d_col_k1, d_col_c1, d_col_is_cand, n_cols, d_part_off, d_tab_off.as<int64_t>(), d_tab.as<uint8_t>(), d_keep,
                        d_list.as<int32_t>() + 1, d_list.as<int32_t>());
+    if (kc) { if (int rc = kc->end(5 * col_entries + (int64_t)tab_off.back(), stream)) return rc; }      // the columns (idx + code) and the table, once each
     if (std::getenv("HS_K4_DEBUG")) {   // diagnostic: how many columns the first kernel leaves to the exact one
         int32_t nu = 0;
         if (int rc = d2h_pinned(&nu, d_list.p, 4, stream)) return rc;
         std::fprintf(stderr, "[hs k4] %d columns, %d undecided after the lanes kernel\n", n_cols, nu);
     }
+    if (kc) { if (int rc = kc->begin(HS_K_PARTITION_TEST, stream)) return rc; }
     hipLaunchKernelGGL(hsdev::k_column_partition_test, dim3((unsigned)std::min(n_cols, 2048)), dim3(1024), 0, stream, d_col_off, d_col_idx,
                        d_col_code, d_col_contig, d_col_k0, d_col_k1, d_col_c1, d_col_is_cand, n_cols, d_part_off, d_part_state_off,
                        d_part_state, d_keep, d_list.as<int32_t>() + 1, d_list.as<int32_t>());
     HS_HIP(hipGetLastError());
+    if (kc) { if (int rc = kc->end(state_bytes, stream)) return rc; }      // (the undecided columns against the dense states: a small share of them)
     return HS_OK;
 }
 
@@ -1230,10 +1241,12 @@ struct HipCvOps : hs::CvDeviceOps {
         range_pack.add(min_reads, d_min_reads);
         if (int rc = range_pack.commit(stream)) return rc;
         // ---- the column list with its CSR offsets, K3 (tile-cooperative gather), K3b (leading codes, reference order), V1 ----
+        if (int rc = kc.begin(HS_K_COLUMNS_COMPACT, stream)) return rc;
         hipLaunchKernelGGL(hsdev::k_columns_compact, dim3((unsigned)nt), dim3(256), 0, stream, range_scratch.tile_cnt.as<int32_t>(), range_scratch.tile_base.as<int64_t>(),
                            d_tile_ebase.as<int64_t>(), range_scratch.gpos.as<int64_t>(), range_scratch.depth.as<int32_t>(), nt, b->d_contig_off.as<int64_t>(), b->n_contigs,
                            d_col_gpos.as<int64_t>(), d_col_rec.as<hsdev::hs_colrec_dev>(), d_co.as<int64_t>(), d_col_len.as<int32_t>(), dev_header(), n_cols);
         HS_HIP(hipGetLastError());
+        if (int rc = kc.end(20 * nt + 48 * n_cols, stream)) return rc;      // tile counts and bases in; slot in, position + record + offset + length out per column
         HS_HIP(hipEventRecord(e_k3.a, stream));
         if (n_cols > 0) {
             if (int rc = kc.begin(HS_K_GATHER_COLUMNS, stream)) return rc;
@@ -1255,10 +1268,12 @@ struct HipCvOps : hs::CvDeviceOps {
             HS_HIP(hipGetLastError());
             if (int rc = kc.end(n_entries + 16 * n_cols, stream)) return rc;
         }
+        if (int rc = kc.begin(HS_K_CANDIDATES_SCAN, stream)) return rc;
         hipLaunchKernelGGL(hsdev::k_candidates_scan, dim3((unsigned)C), dim3(64), 0, stream, d_col_gpos.as<int64_t>(), dev_header(),
                            b->d_contig_off.as<int64_t>(), c0, C, d_min_reads.as<int32_t>(), thr, d_col_rec.as<hsdev::hs_colrec_dev>(), d_col_ctg.as<int32_t>(),
                            d_k0.as<uint8_t>(), d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), d_ctg_col_off.as<int64_t>(), dev_ctg_n());
         HS_HIP(hipGetLastError());
+        if (int rc = kc.end(43 * n_cols, stream)) return rc;      // record in and out, the four arrays K4 reads out
         HS_HIP(hipEventRecord(e_k3b.b, stream));
         // ---- the candidates, packed, to the host ----
         int64_t n_cand = 0, e_cand = 0;
@@ -1279,7 +1294,7 @@ struct HipCvOps : hs::CvDeviceOps {
     }
 
     // ---- K4 + the merge of the SNP lists + the SNP columns packed (they stay in d_pk for stage 4) ----
-    DBuf d_keep;
+    DBuf d_keep, d_snp_bounds;
     int64_t snp_count = 0, snp_entries = 0;       // what d_pk holds after finish_columns (HipSrOps::adopt_columns)
     int finish_columns(const hs::CvPartitionTest& t, bool want_entries, hs::CvSnpSet& out, float* k_ms) override {
         const int C = range_c1 - range_c0;
@@ -1306,18 +1321,23 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = grow(d_keep, (size_t)n)) return rc;
         EventPair e; if (int rc = e.init()) return rc;
         HS_HIP(hipEventRecord(e.a, stream));
-        if (int rc = kc.begin(HS_K_PARTITION_TEST, stream)) return rc;
         DBuf d_tab, d_tab_off, d_ctg_nr, d_list;
         UploadPack pk_tab;
         if (int rc = partition_test_launch(d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), d_col_ctg.as<int32_t>(), d_k0.as<uint8_t>(),
                                            d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), n, d_po.as<int32_t>(), d_pso.as<int64_t>(),
                                            d_ps.as<int8_t>(), t.part_off.data(), t.contig_n_reads.data(), C, d_keep.as<uint8_t>(),
-                                           stream, d_tab, d_tab_off, d_ctg_nr, d_list, pk_tab)) return rc;
-        if (int rc = kc.end(5 * gathered_entries + (int64_t)t.part_state.size(), stream)) return rc;   // the columns (idx + code) and the partition states
+                                           stream, d_tab, d_tab_off, d_ctg_nr, d_list, pk_tab, &kc, gathered_entries, (int64_t)t.part_state.size())) return rc;
         HS_HIP(hipEventRecord(e.b, stream));
-        hipLaunchKernelGGL(hsdev::k_snp_select, dim3((unsigned)C), dim3(64), 0, stream, d_ctg_col_off.as<int64_t>(), C, d_keep.as<uint8_t>(),
-                           d_col_rec.as<hsdev::hs_colrec_dev>(), dev_ctg_n());
+        if (int rc = grow(d_snp_bounds, (size_t)C * 8)) return rc;
+        HS_HIP(hipMemsetAsync(d_snp_bounds.p, 0, (size_t)C * 8, stream));
+        HS_HIP(hipMemsetAsync(dev_ctg_n(), 0, (size_t)C * 4, stream));
+        if (int rc = kc.begin(HS_K_SNP_SELECT, stream)) return rc;
+        hipLaunchKernelGGL(hsdev::k_snp_bounds, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, stream, d_col_rec.as<hsdev::hs_colrec_dev>(), d_col_ctg.as<int32_t>(),
+                           d_keep.as<uint8_t>(), n_cols, C, d_snp_bounds.as<int32_t>());
+        hipLaunchKernelGGL(hsdev::k_snp_flags, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, stream, d_col_rec.as<hsdev::hs_colrec_dev>(), d_col_ctg.as<int32_t>(),
+                           d_keep.as<uint8_t>(), n_cols, C, d_snp_bounds.as<int32_t>(), dev_ctg_n());
         HS_HIP(hipGetLastError());
+        if (int rc = kc.end(33 * n_cols, stream)) return rc;      // records in (twice) and out, the verdicts in
         int64_t n_snp = 0, e_snp = 0;
         if (int rc = pack_flagged(HS_COL_SNP, want_entries, &n_snp, &e_snp)) return rc;      // (the partition tables, uploads and lists of this scope are done with: it waits)
         std::memcpy(out.contig_n_snp.data(), host_ctg_n(), (size_t)C * 4);
@@ -1714,7 +1734,7 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = pk.commit(stream)) return rc;
         if (int rc = d_ids.alloc(std::max<size_t>(1, (size_t)total) * 4)) return rc;
         if (int rc = d_m.alloc((size_t)W * 4)) return rc;
-        if (int rc = kc.begin(HS_K_OTHER, stream)) return rc;
+        if (int rc = kc.begin(HS_K_WINDOW_MASKS, stream)) return rc;
         hipLaunchKernelGGL(hsdev::k_window_masks, dim3((unsigned)((W + 3) / 4)), dim3(256), 0, stream, d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_a.as<int64_t>(),
                            d_b.as<int64_t>(), d_so.as<int64_t>(), W, d_ids.as<int32_t>(), d_m.as<int32_t>());
         HS_HIP(hipGetLastError());
@@ -1863,7 +1883,6 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = e2.init()) return rc;
         // ---- per-SNP runs, seeded on the device from the SNP columns ----
         HS_HIP(hipEventRecord(e1.a, stream));
-        if (int rc = kc.begin(HS_K_CW_SEEDED, stream)) return rc;
         if (!list_lanes.empty()) {
             const int n = (int)list_lanes.size();
             const size_t npad = ((size_t)n + 63) & ~(size_t)63;
@@ -1874,14 +1893,18 @@ struct HipSrOps : hs::SrDeviceOps {
             if (int rc = d_ovf.alloc((size_t)n * 4)) return rc;
             if (int rc = d_ovf_n.alloc(4)) return rc;
             HS_HIP(hipMemsetAsync(d_ovf_n.p, 0, 4, stream));
+            if (int rc = kc.begin(HS_K_CW_SEED_SETS, stream)) return rc;
             hipLaunchKernelGGL(hsdev::k_cw_seed_sets, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), d_ll.as<int32_t>(), n,
                                d_iw.as<int32_t>(), d_seed.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(),
                                d_sets.as<unsigned long long>(), d_names.as<uint8_t>(), d_slots.as<uint8_t>(), d_alive.as<uint8_t>(), d_ovf.as<int32_t>(), d_ovf_n.as<int32_t>());
             HS_HIP(hipGetLastError());
+            if (int rc = kc.end((int64_t)npad * 209 + 5 * (int64_t)n * 40, stream)) return rc;      // sets, names, slots, alive out per run; the seeding column (about 40 entries) in
+            if (int rc = kc.begin(HS_K_CW_SEEDED, stream)) return rc;
             hipLaunchKernelGGL(hsdev::k_cw_seeded_lanes, dim3((unsigned)(npad / 64)), dim3(64), 0, stream, G.d_off.as<int64_t>(), G.d_row0.as<int64_t>(), G.d_visit_n.as<int32_t>(),
                                G.d_prog_info.as<uint32_t>(), G.d_prog_adj.as<unsigned long long>(), d_ll.as<int32_t>(), n, d_iw.as<int32_t>(), d_is.as<int64_t>(),
                                d_sets.as<unsigned long long>(), d_names.as<uint8_t>(), d_slots.as<uint8_t>(), d_alive.as<uint8_t>(), d_slab.as<int32_t>(), d_stat.as<unsigned long long>());
             HS_HIP(hipGetLastError());
+            if (int rc = kc.end((int64_t)npad * 209, stream)) return rc;      // + sweeps * (4 nnz + 8 m) per run, counted by the kernel itself (added below)
             if (std::getenv("HS_TIMING")) {
                 int32_t n_ovf = 0;
                 if (int rc = d2h_pinned(&n_ovf, d_ovf_n.p, 4, stream)) return rc;
@@ -1889,12 +1912,15 @@ struct HipSrOps : hs::SrDeviceOps {
                              n, n_ovf, unit_win.size() * 8, list_big.size());
             }
             // the few runs with more labels alive than slots: one wavefront each, the list and its length are on the device
+            if (int rc = kc.begin(HS_K_CW_SEEDED_WIDE, stream)) return rc;
             hipLaunchKernelGGL(hsdev::k_cw_seeded_wave, dim3((unsigned)std::min(n, 1024)), dim3(64), (size_t)64 * 8, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(),
                                G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_visit.as<int32_t>(), G.d_visit_n.as<int32_t>(), d_ovf.as<int32_t>(), 0, d_ovf_n.as<int32_t>(),
                                d_iw.as<int32_t>(), d_seed.as<int64_t>(), d_is.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(),
                                d_col_code.as<uint8_t>(), 64, (int32_t*)nullptr, (const int64_t*)nullptr, d_slab.as<int32_t>(), d_stat.as<unsigned long long>());
             HS_HIP(hipGetLastError());
+            if (int rc = kc.end(0, stream)) return rc;
         }
+        if (!unit_win.empty() || !list_big.empty()) { if (int rc = kc.begin(HS_K_CW_SEEDED_WIDE, stream)) return rc; }
         if (!unit_win.empty()) {
             const int n = (int)unit_win.size();
             const int m_cap = std::max(16, (max_m_small + 15) & ~15);
@@ -1920,7 +1946,7 @@ struct HipSrOps : hs::SrDeviceOps {
                                d_col_code.as<uint8_t>(), cap_big, d_gs.as<int32_t>(), d_bs.as<int64_t>(), d_slab.as<int32_t>(), d_stat.as<unsigned long long>());
             HS_HIP(hipGetLastError());
         }
-        if (int rc = kc.end(4 * slab, stream)) return rc;      // + sweeps * (4 nnz + 8 m) per run, counted by the kernel itself (below)
+        if (!unit_win.empty() || !list_big.empty()) { if (int rc = kc.end(0, stream)) return rc; }
         HS_HIP(hipEventRecord(e1.b, stream));
         // ---- the rest of the window's chain, labels in LDS from here to the finished clusters ----
         HS_HIP(hipEventRecord(e2.a, stream));

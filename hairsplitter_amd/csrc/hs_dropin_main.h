@@ -10,13 +10,15 @@
  *     SIGQUIT on to it: a caller that kills the process it started (a timeout) leaves nothing behind that still holds the GPU
  *     or writes the output files. After the report only the teardown is left and the tie is cut.
  *   - HS_NO_DETACH=1 runs everything in the process that was started. The same happens by itself when a tool is preloaded into
- *     the process (LD_PRELOAD, ROCP_TOOL_LIBRARIES, HSA_TOOLS_LIB: rocprofv3 and friends initialise the GPU before main(), and
- *     a fork after that is not safe): profile the drop-ins as they are, no switch needed. */
+ *     the process (ROCP_TOOL_LIBRARIES, HSA_TOOLS_LIB, an LD_PRELOAD that names rocprof / roctracer / the HSA or HIP runtime:
+ *     rocprofv3 and friends initialise the GPU before main(), and a fork after that is not safe): profile the drop-ins as they
+ *     are, no switch needed. */
 #ifndef HS_DROPIN_MAIN_H
 #define HS_DROPIN_MAIN_H
 #include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
 #include <unistd.h>
 #include <sys/prctl.h>
@@ -25,6 +27,11 @@
 #include "../../include/hairsplitter_hip.h"
 
 static double hs_dropin_now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static void hs_dropin_stamp(const char* what) {      /* HS_TIMING: wall-clock stamps of the process (epoch ms), to be set against the caller's own */
+    if (!getenv("HS_TIMING")) return;
+    struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+    fprintf(stderr, "[hs timing] stamp %s pid %d at %.1f ms\n", what, (int)getpid(), ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6);
+}
 static int (*hs_dropin_stage)(int, char**);
 static int hs_dropin_run(int argc, char** argv) {
     const double t0 = hs_dropin_now_ms();
@@ -36,14 +43,17 @@ static int hs_dropin_run(int argc, char** argv) {
 }
 static volatile pid_t hs_dropin_child = 0;
 static void hs_dropin_forward(int sig) { if (hs_dropin_child > 0) kill(hs_dropin_child, sig); }
-static int hs_dropin_tool_preloaded(void) {
-    const char* names[] = {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD"};
+static int hs_dropin_tool_preloaded(void) {      /* a profiler / tracer of the ROCm stack in the process (they initialise the GPU before main()) */
+    const char* names[] = {"ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCTRACER_DOMAIN"};
     for (unsigned i = 0; i < sizeof names / sizeof names[0]; ++i) { const char* v = getenv(names[i]); if (v && v[0]) return 1; }
+    const char* pre = getenv("LD_PRELOAD");      /* (other preloads -- sanitizers, exec guards -- do not touch the GPU) */
+    if (pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "rocprofiler") || strstr(pre, "libhsa") || strstr(pre, "amdhip"))) return 1;
     return 0;
 }
 static int hs_dropin_main(int (*stage)(int, char**), int argc, char** argv) {
     int pfd[2];
     hs_dropin_stage = stage;
+    hs_dropin_stamp("main entered");
     if (getenv("HS_NO_DETACH") || hs_dropin_tool_preloaded() || pipe(pfd) != 0) _exit(hs_dropin_run(argc, argv));
     const pid_t parent = getpid();
     const pid_t pid = fork();
@@ -52,7 +62,9 @@ static int hs_dropin_main(int (*stage)(int, char**), int argc, char** argv) {
         close(pfd[0]);
         prctl(PR_SET_PDEATHSIG, SIGKILL);
         if (getppid() != parent) _exit(1);      /* the parent went away between fork and prctl */
+        hs_dropin_stamp("worker started");
         const int rc = hs_dropin_run(argc, argv);
+        hs_dropin_stamp("worker done");
         prctl(PR_SET_PDEATHSIG, 0);             /* the outputs are complete: the parent is about to leave, the teardown goes on */
         if (write(pfd[1], &rc, sizeof rc) != (ssize_t)sizeof rc) _exit(rc ? rc : 1);
         close(pfd[1]);
@@ -67,7 +79,7 @@ static int hs_dropin_main(int (*stage)(int, char**), int argc, char** argv) {
         sigaction(SIGTERM, &sa, NULL); sigaction(SIGINT, &sa, NULL); sigaction(SIGHUP, &sa, NULL); sigaction(SIGQUIT, &sa, NULL);
     }
     int rc = 1;
-    if (read(pfd[0], &rc, sizeof rc) == (ssize_t)sizeof rc) _exit(rc);
+    if (read(pfd[0], &rc, sizeof rc) == (ssize_t)sizeof rc) { hs_dropin_stamp("status received"); _exit(rc); }
     int st = 0;
     if (waitpid(pid, &st, 0) == pid) {
         if (WIFEXITED(st)) _exit(WEXITSTATUS(st));

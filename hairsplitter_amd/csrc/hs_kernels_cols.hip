@@ -270,14 +270,15 @@ __global__ __launch_bounds__(64) void k_candidates_scan(
     if (lane == 0) { contig_col_off[ci] = s0; if (ci == c_count - 1) contig_col_off[c_count] = s1; }
     const int mr = min_reads[ci];
     int pos_of_last = -5, n_cand = 0;
+    hs_colrec_dev r_next;      // the next 64 records are on their way while these 64 are decided
+    r_next.pos = 0; r_next.contig = 0; r_next.c0 = r_next.c1 = 0; r_next.k0 = r_next.k1 = 0; r_next.flags = 0; r_next.c2_zero = 0;
+    if (s0 + lane < s1) r_next = col_rec[s0 + lane];
     for (int64_t sb = s0; sb < s1; sb += 64) {
         const int64_t k = sb + lane;
-        hs_colrec_dev r;
+        hs_colrec_dev r = r_next;
+        if (k + 64 < s1) r_next = col_rec[k + 64];
         bool pass = false;
-        if (k < s1) {
-            r = col_rec[k];
-            pass = (int)r.c1 > mr && (r.flags & HS_COL_C1GT5C2) && central_base_test_cols(r.k0, r.k1);
-        } else { r.pos = 0; r.contig = 0; r.c0 = r.c1 = 0; r.k0 = r.k1 = 0; r.flags = 0; r.c2_zero = 0; }
+        if (k < s1) pass = (int)r.c1 > mr && (r.flags & HS_COL_C1GT5C2) && central_base_test_cols(r.k0, r.k1);
         unsigned long long m = __ballot(pass);
         unsigned long long accepted = 0ull;
         while (m) {
@@ -408,37 +409,56 @@ __global__ __launch_bounds__(256) void k_pack_flagged(
 // ------------------------------------------------------------------------------------------------
 // The merge of the automatic and the filtered SNPs of a contig (call_variants.cpp:1335-1352) walks both lists in position
 // order and stops when either ends: what it emits is every column of either list up to min(last automatic, last filtered).
-// One wavefront per contig: the two maxima, then the SNP flag. keep[k]: verdict of loops C / D (K4).
+// Two passes over the column list, lanes = columns: the two maxima per contig (position + 1; 0 = the list is empty; `bounds`
+// = [2][C] zeroed by the caller, as is contig_n_snp), then the SNP flag and the count per contig. keep[k]: verdict of loops
+// C / D (K4). A wavefront's 64 columns nearly always belong to one contig: one atomic per wavefront then.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_snp_select(const int64_t* __restrict__ contig_col_off, int c_count, const uint8_t* __restrict__ keep,
-                                                   hs_colrec_dev* __restrict__ col_rec, int32_t* __restrict__ contig_n_snp) {
+__global__ __launch_bounds__(256) void k_snp_bounds(const hs_colrec_dev* __restrict__ col_rec, const int32_t* __restrict__ col_contig_local,
+                                                    const uint8_t* __restrict__ keep, int64_t n_cols, int c_count, int32_t* __restrict__ bounds) {
     const int lane = lane_id();
-    const int ci = (int)blockIdx.x;
-    if (ci >= c_count) return;
-    const int64_t s0 = contig_col_off[ci], s1 = contig_col_off[ci + 1];
-    int max_a = -1, max_f = -1;
-    for (int64_t k = s0 + lane; k < s1; k += 64) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int ci = -1, pa = 0, pf = 0;
+    if (k < n_cols) {
         const hs_colrec_dev r = col_rec[k];
-        if (r.flags & HS_COL_AUTO) max_a = r.pos > max_a ? r.pos : max_a;
-        if (keep[k] == 1) max_f = r.pos > max_f ? r.pos : max_f;
+        ci = col_contig_local[k];
+        if (r.flags & HS_COL_AUTO) pa = r.pos + 1;
+        if (keep[k] == 1) pf = r.pos + 1;
     }
-    max_a = wave_max_i32(max_a); max_f = wave_max_i32(max_f);
-    const int bound = (max_a < 0 || max_f < 0) ? -1 : (max_a < max_f ? max_a : max_f);
-    int n = 0;
-    for (int64_t k = s0 + lane; k < s1; k += 64) {
+    const int c_first = __builtin_amdgcn_readfirstlane(ci);
+    if (__ballot(ci != c_first && ci >= 0) == 0ull && c_first >= 0) {
+        const int ma = wave_max_i32(pa), mf = wave_max_i32(pf);
+        if (lane == 0) { if (ma) atomicMax(&bounds[c_first], ma); if (mf) atomicMax(&bounds[c_count + c_first], mf); }
+    } else if (ci >= 0) {
+        if (pa) atomicMax(&bounds[ci], pa);
+        if (pf) atomicMax(&bounds[c_count + ci], pf);
+    }
+}
+__global__ __launch_bounds__(256) void k_snp_flags(hs_colrec_dev* __restrict__ col_rec, const int32_t* __restrict__ col_contig_local,
+                                                   const uint8_t* __restrict__ keep, int64_t n_cols, int c_count, const int32_t* __restrict__ bounds,
+                                                   int32_t* __restrict__ contig_n_snp) {
+    const int lane = lane_id();
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int ci = -1;
+    bool snp = false;
+    if (k < n_cols) {
         hs_colrec_dev r = col_rec[k];
+        ci = col_contig_local[k];
+        const int ma = bounds[ci], mf = bounds[c_count + ci];
+        const int bound = (ma == 0 || mf == 0) ? -1 : (ma < mf ? ma : mf) - 1;
         const bool kept = keep[k] == 1;
-        const bool snp = ((r.flags & HS_COL_AUTO) || kept) && r.pos <= bound;
+        snp = ((r.flags & HS_COL_AUTO) || kept) && r.pos <= bound;
         uint8_t f = r.flags & ~(HS_COL_KEEP | HS_COL_SNP);
         if (kept) f |= HS_COL_KEEP;
-        if (snp) { f |= HS_COL_SNP; n++; }
+        if (snp) f |= HS_COL_SNP;
         r.flags = f;
         col_rec[k] = r;
     }
-    n = wave_sum_i32(n);
-    if (lane == 0) contig_n_snp[ci] = n;
+    const int c_first = __builtin_amdgcn_readfirstlane(ci);
+    if (__ballot(ci != c_first && ci >= 0) == 0ull && c_first >= 0) {
+        const int n = __popcll(__ballot(snp));
+        if (lane == 0 && n) atomicAdd(&contig_n_snp[c_first], n);
+    } else if (snp) atomicAdd(&contig_n_snp[ci], 1);
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // The reads of a clustering window = the reads present at its first AND its last SNP (separate_reads.cpp:1590-1622: the mask
