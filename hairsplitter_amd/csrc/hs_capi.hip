@@ -26,8 +26,8 @@
 #include "hs_kernels_graph.hip"
 #include "hs_kernels_cw.hip"
 #include "hs_kernels_myers.hip"
-#include "hs_kernels_parts.hip"
 #include "hs_kernels_cols.hip"
+#include "hs_kernels_loopa.hip"
 
 namespace hs {
 static thread_local std::string g_err;
@@ -355,7 +355,7 @@ const char* hs_kernel_name(int k) {
     static const char* names[HS_NKERNELS] = {"k_cigar_scan", "k_pileup_packed", "k_column_stats_tiled", "k_columns_compact", "k_gather_tiles", "k_column_top3_exact",
                                              "k_candidates_scan", "k_pack_flagged", "k_partition_transpose", "k_column_partition_lanes", "k_column_partition_test",
                                              "k_snp_flags", "k_window_masks", "k_snp_planes", "k_simdiff", "k_read_graph_rows", "k_read_graph_fill", "k_cw_visit_lists",
-                                             "k_cw_seed_sets", "k_cw_seeded_lanes", "k_cw_seeded_rows", "k_window_tail", "k_cw_local", "k_robust_partitions", "other"};
+                                             "k_cw_seed_sets", "k_cw_seeded_lanes", "k_cw_seeded_rows", "k_window_tail", "k_cw_local", "k_loop_a", "other"};
     return k >= 0 && k < HS_NKERNELS ? names[k] : "?";
 }
 void hs_kernel_stats_reset(void) { KernelTable& t = kernel_table(); std::lock_guard<std::mutex> g(t.mu); std::memset(&t.st, 0, sizeof t.st); }
@@ -928,7 +928,7 @@ struct hs_cv_batch {
     int device = 0;                   // the device that was current when the batch was created: every buffer below lives there
     DBuf contig_seq, d_contig_off, read_seq, read_off, rec_read, d_rec_contig, d_rec_pos, rec_strand, rec_cig_off, cigar,
         d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, rec_chunk_off, chunk_scratch, task_rec, task_ev0,
-        tile_off, tile_ent, tile_lrec;
+        tile_off, tile_ent, tile_lrec, d_rank_of, d_orig_of, d_read_end;
     HBuf h_stage_a;   // pinned staging of the per-record counters
     // the pileup is padded by 256 bytes on both sides: k_gather_tiles loads the 256 bytes a record lays over a tile whole, also
     // where the record covers part of the tile only
@@ -1041,6 +1041,21 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
         up(b->tile_lrec, rc_.data(), sizeof(int32_t) * rc_.size());
     }
     up(b->d_contig_rec_off, b->contig_rec_off.data(), sizeof(int32_t) * b->contig_rec_off.size());
+    {   // what loop A on the device (k_loop_a) needs of the reads: their rank by start position on the contig (ties by index: the
+        // bit order of the partition bit sets, as rank_reads() of the host glue), the inverse, the end of their alignment
+        std::vector<int32_t> rank_of((size_t)n_rec), orig_of((size_t)n_rec), read_end((size_t)n_rec);
+        hs::hs_parallel_for(n_contigs, host_threads(), [&](int c) {
+            const int r0 = b->contig_rec_off[(size_t)c], n = b->contig_rec_off[(size_t)c + 1] - r0;
+            std::vector<int32_t> order((size_t)n);
+            for (int r = 0; r < n; ++r) order[(size_t)r] = r;
+            std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return h_rec_pos[r0 + x] != h_rec_pos[r0 + y] ? h_rec_pos[r0 + x] < h_rec_pos[r0 + y] : x < y; });
+            for (int k = 0; k < n; ++k) { rank_of[(size_t)(r0 + order[(size_t)k])] = k; orig_of[(size_t)(r0 + k)] = order[(size_t)k]; }
+            for (int r = 0; r < n; ++r) read_end[(size_t)(r0 + r)] = (int32_t)std::min<int64_t>((int64_t)h_rec_pos[r0 + r] + b->rec_refspan[(size_t)(r0 + r)], 0x7fffffff);
+        });
+        up(b->d_rank_of, rank_of.data(), sizeof(int32_t) * (size_t)n_rec);
+        up(b->d_orig_of, orig_of.data(), sizeof(int32_t) * (size_t)n_rec);
+        up(b->d_read_end, read_end.data(), sizeof(int32_t) * (size_t)n_rec);
+    }
     up(b->d_rec_qend, b->rec_qend.data(), sizeof(int32_t) * (size_t)n_rec);
     if (!rc) {   // launch plan of the pileup kernel
         std::vector<int64_t> chunk_off((size_t)n_rec + 1);
@@ -1151,7 +1166,8 @@ struct HipCvOps : hs::CvDeviceOps {
         return copy_d2h(h_info.p, d_info.p, bytes, stream);
     }
     // the columns carrying `flag` packed on the device (d_pk) and, with their entries if asked for, on the host (h_pk)
-    int pack_flagged(int flag, bool want_entries, int64_t* n_out, int64_t* e_out) {
+    // download: 0 nothing (the packed block stays on the device), 1 records + offsets, 2 the entries too
+    int pack_flagged(int flag, int download, int64_t* n_out, int64_t* e_out) {
         const int n_blocks = (int)((n_cols + HS_FP_BLOCK - 1) / HS_FP_BLOCK);
         *n_out = 0; *e_out = 0;
         if (n_blocks == 0) return fetch_info();
@@ -1178,13 +1194,28 @@ struct HipCvOps : hs::CvDeviceOps {
                            (uint8_t*)(base + L.code), nf, ne);
         HS_HIP(hipGetLastError());
         if (int rc = kc.end(10 * ne + 60 * nf, stream)) return rc;      // the flagged columns' entries in and out, their records
-        const size_t bytes = want_entries ? L.total : L.head;
-        if (int rc = grow(h_pk, std::max<size_t>(bytes, 256))) return rc;
-        HS_HIP(hipMemcpyAsync(h_pk.p, d_pk.p, bytes, hipMemcpyDeviceToHost, stream));
+        if (download) {
+            const size_t bytes = download == 2 ? L.total : L.head;
+            if (int rc = grow(h_pk, std::max<size_t>(bytes, 256))) return rc;
+            HS_HIP(hipMemcpyAsync(h_pk.p, d_pk.p, bytes, hipMemcpyDeviceToHost, stream));
+        }
         return HS_OK;
     }
 
-    int extract_candidates(int c0, int c1, const std::vector<int32_t>& min_reads, float thr, hs::CvCandidates& out, float k_ms[3]) override {
+    int fetch_candidates(hs::CvCandidates& out) override {      // the packed candidates of the last extract_candidates(), after all
+        if (cand_count == 0) return HS_OK;
+        if (int rc = grow(h_pk, std::max<size_t>(cand_layout.total, 256))) return rc;
+        if (int rc = copy_d2h(h_pk.p, d_cand_pk.p, cand_layout.total, stream)) return rc;
+        const char* hb = (const char*)h_pk.p;
+        out.rec = (const hs_colrec*)(hb + cand_layout.rec); out.col = (const int32_t*)(hb + cand_layout.col); out.off = (const int64_t*)(hb + cand_layout.off);
+        out.idx = (const int32_t*)(hb + cand_layout.idx); out.code = (const uint8_t*)(hb + cand_layout.code);
+        return HS_OK;
+    }
+    DBuf d_cand_pk;                   // the packed candidates (kept beside d_pk, which the SNPs take later): k_loop_a reads them
+    PackLayout cand_layout{};
+    int64_t cand_count = 0, cand_entries = 0;
+    std::vector<int32_t> cand_per_contig;
+    int extract_candidates(int c0, int c1, const std::vector<int32_t>& min_reads, float thr, hs::CvCandidates& out, float k_ms[3], bool want_entries) override {
         static_assert(sizeof(hs_colrec) == sizeof(hsdev::hs_colrec_dev), "hs_colrec layout");
         static_assert(sizeof(hsdev::ColumnsHeader) == 64, "info block layout");
         const int C = c1 - c0;
@@ -1277,12 +1308,14 @@ struct HipCvOps : hs::CvDeviceOps {
         HS_HIP(hipEventRecord(e_k3b.b, stream));
         // ---- the candidates, packed, to the host ----
         int64_t n_cand = 0, e_cand = 0;
-        if (int rc = pack_flagged(HS_COL_CAND, true, &n_cand, &e_cand)) return rc;      // (its info download carries the per-contig counts and the tie counters)
+        if (int rc = pack_flagged(HS_COL_CAND, want_entries ? 2 : 0, &n_cand, &e_cand)) return rc;      // (its info download carries the per-contig counts and the tie counters)
         std::memcpy(out.contig_n_cand.data(), host_ctg_n(), (size_t)C * 4);
+        cand_per_contig = out.contig_n_cand; cand_count = n_cand; cand_entries = e_cand; cand_layout = pk_layout;
+        std::swap(d_cand_pk, d_pk);      // (d_pk is packed again for the SNPs)
         { unsigned long long t2[2]; std::memcpy(t2, (const char*)h_info.p + 64, 16); out.n_tie = (int64_t)t2[0]; out.n_tie_big = (int64_t)t2[1]; }
         if (int rc = stream_wait(stream)) return rc;
         out.n_cand = n_cand;
-        if (n_cand > 0) {
+        if (n_cand > 0 && want_entries) {
             const char* hb = (const char*)h_pk.p;
             out.rec = (const hs_colrec*)(hb + pk_layout.rec); out.col = (const int32_t*)(hb + pk_layout.col); out.off = (const int64_t*)(hb + pk_layout.off);
             out.idx = (const int32_t*)(hb + pk_layout.idx); out.code = (const uint8_t*)(hb + pk_layout.code);
@@ -1339,7 +1372,7 @@ struct HipCvOps : hs::CvDeviceOps {
         HS_HIP(hipGetLastError());
         if (int rc = kc.end(33 * n_cols, stream)) return rc;      // records in (twice) and out, the verdicts in
         int64_t n_snp = 0, e_snp = 0;
-        if (int rc = pack_flagged(HS_COL_SNP, want_entries, &n_snp, &e_snp)) return rc;      // (the partition tables, uploads and lists of this scope are done with: it waits)
+        if (int rc = pack_flagged(HS_COL_SNP, want_entries ? 2 : 1, &n_snp, &e_snp)) return rc;      // (the partition tables, uploads and lists of this scope are done with: it waits)
         std::memcpy(out.contig_n_snp.data(), host_ctg_n(), (size_t)C * 4);
         if (int rc = stream_wait(stream)) return rc;
         out.n_snp = n_snp; out.n_entries = e_snp;
@@ -1352,108 +1385,114 @@ struct HipCvOps : hs::CvDeviceOps {
         kc.flush();
         return k_ms ? e.ms(k_ms) : HS_OK;
     }
-    // ---- loop A on the device (hs_kernels_parts.hip) ----
+    // ---- loop A on the device (hs_kernels_loopa.hip) on the candidates of the last extract_candidates() ----
     bool has_robust_partitions() const override { return true; }
-    HBuf h_la_rec, h_la_state, h_la_more, h_la_less;
-    int robust_partitions(const hs::CvLoopA& in, hs::CvLoopAResult& out, float* k_ms) override {
-        static_assert(sizeof(hs::CvPartRecord) == sizeof(hsdev::PartitionRecord), "partition record layouts differ");
-        const int C = (int)in.contig_n_reads.size();
-        const int64_t n_cand = in.cand_off.back();
-        out.part_base.assign((size_t)C + 1, 0); out.failed.assign((size_t)C, 0);
-        out.rec = nullptr; out.state = nullptr; out.more = nullptr; out.less = nullptr;
+    DBuf d_la_parts, d_la_bits, d_la_cnt, d_la_np, d_la_pb, d_la_out_rec, d_la_out_bits, d_la_out_cnt, d_la_diag;
+    HBuf h_la_np, h_la_rec, h_la_bits, h_la_cnt;
+    int robust_partitions(const std::vector<int32_t>& contig_n_reads, hs::CvLoopAResult& out, float* k_ms) override {
+        static_assert(sizeof(hs::CvPartRecord) == sizeof(hsdev::LoopAPartition), "partition record layouts differ");
+        const int C = (int)contig_n_reads.size();
+        out = hs::CvLoopAResult();
+        out.part_base.assign((size_t)C + 1, 0); out.failed.assign((size_t)C, 0); out.bits_base.assign((size_t)C, 0); out.cnt_base.assign((size_t)C, 0);
         if (k_ms) *k_ms = 0;
-        if (C == 0 || n_cand == 0) return HS_OK;
-        if (in.cand_col.size() != (size_t)n_cand) { set_error("robust_partitions: bad arguments"); return HS_EINVAL; }
-        for (int32_t col : in.cand_col) if (col < 0 || col >= n_gathered) { set_error("robust_partitions: column outside the last gather"); return HS_EINVAL; }
-        // state tables: a contig cannot make more partitions than it has candidates -> ceil(candidates / 64) blocks of N x 64.
-        // HS_LOOP_A_TABLE_ELEMS caps the whole (a contig that does not fit is left to the host: failed = 1)
-        static const long long table_limit = []() { const char* e = std::getenv("HS_LOOP_A_TABLE_ELEMS"); return e ? std::atoll(e) : (1ll << 31); }();
-        std::vector<int64_t> tab_off((size_t)C + 1, 0);
-        std::vector<std::pair<double, int>> weight;
-        int max_n = 1;
+        if (C == 0 || cand_count == 0) return HS_OK;
+        if (C != range_c1 - range_c0 || (int)cand_per_contig.size() != C) { set_error("robust_partitions: contigs of another range"); return HS_EINVAL; }
+        // pools: a contig gets room for a share of its candidates as partitions (most candidates join a partition; one that needs
+        // more is done by the host). HS_LOOP_A_POOL_DIV sets the share (default: candidates / 6 + 48)
+        static const int pool_div = []() { const char* e = std::getenv("HS_LOOP_A_POOL_DIV"); return e && std::atoi(e) > 0 ? std::atoi(e) : 6; }();
+        std::vector<int64_t> cand_off((size_t)C + 1, 0), cap_off((size_t)C + 1, 0), bits_off((size_t)C + 1, 0), cnt_off((size_t)C + 1, 0);
+        std::vector<std::pair<int64_t, int>> weight;
+        int w_max = 1;
         for (int c = 0; c < C; ++c) {
-            const long long k = in.cand_off[(size_t)c + 1] - in.cand_off[(size_t)c];
-            const long long need = ((k + 63) / 64) * 64 * (long long)in.contig_n_reads[(size_t)c];
-            const bool fits = tab_off[(size_t)c] + need <= table_limit;
-            tab_off[(size_t)c + 1] = tab_off[(size_t)c] + (fits ? need : 0);
-            if (!fits) out.failed[(size_t)c] = 1;
-            else if (k > 0) { weight.push_back(std::make_pair(-(double)k, c)); max_n = std::max(max_n, in.contig_n_reads[(size_t)c]); }
+            const int64_t k = cand_per_contig[(size_t)c];
+            const int N = contig_n_reads[(size_t)c];
+            const int W = (N + 63) >> 6;
+            const bool fits = W <= HS_LA_MAXW;
+            const int64_t cap = (k == 0 || !fits) ? 0 : std::min<int64_t>(k, k / pool_div + 48);
+            cand_off[(size_t)c + 1] = cand_off[(size_t)c] + k;
+            cap_off[(size_t)c + 1] = cap_off[(size_t)c] + cap;
+            bits_off[(size_t)c + 1] = bits_off[(size_t)c] + cap * 3 * W;
+            cnt_off[(size_t)c + 1] = cnt_off[(size_t)c] + cap * N;
+            if (fits) w_max = std::max(w_max, W);
+            weight.push_back(std::make_pair(-k, c));
         }
-        const int n_dev = (int)weight.size();
-        if (n_dev == 0) return HS_OK;
         std::sort(weight.begin(), weight.end());
-        std::vector<int32_t> order((size_t)n_dev);
-        for (int i = 0; i < n_dev; ++i) order[(size_t)i] = weight[(size_t)i].second;
-        const long long tab_total = std::max<long long>(1, tab_off[(size_t)C]);
-        DBuf d_co_, d_cc_, d_cp, d_cr, d_n, d_ro, d_re, d_ord, d_to, d_tab, d_more, d_less, d_scal, d_np, d_pb, d_eb, d_rec, d_state, d_mo, d_le;
+        std::vector<int32_t> order((size_t)C);
+        for (int i = 0; i < C; ++i) order[(size_t)i] = weight[(size_t)i].second;
+        DBuf d_co_, d_cap, d_bo, d_cno, d_ord;
         UploadPack pk;
-        pk.add(in.cand_off, d_co_); pk.add(in.cand_col, d_cc_); pk.add(in.cand_pos, d_cp); pk.add(in.cand_ref, d_cr); pk.add(in.contig_n_reads, d_n);
-        pk.add(in.read_off, d_ro); pk.add(in.read_end, d_re); pk.add(order, d_ord); pk.add(tab_off, d_to);
+        pk.add(cand_off, d_co_); pk.add(cap_off, d_cap); pk.add(bits_off, d_bo); pk.add(cnt_off, d_cno); pk.add(order, d_ord);
         if (int rc = pk.commit(stream)) return rc;
-        if (int rc = d_tab.alloc((size_t)tab_total)) return rc;
-        if (int rc = d_more.alloc((size_t)tab_total * 4)) return rc;
-        if (int rc = d_less.alloc((size_t)tab_total * 4)) return rc;
-        if (int rc = d_scal.alloc((size_t)n_cand * 28 + 64)) return rc;
-        if (int rc = d_np.alloc((size_t)C * 4)) return rc;
-        if (int rc = d_pb.alloc(((size_t)C + 1) * 8)) return rc;
-        if (int rc = d_eb.alloc(((size_t)C + 1) * 8)) return rc;
-        HS_HIP(hipMemsetAsync(d_tab.p, 0, (size_t)tab_total, stream));
-        HS_HIP(hipMemsetAsync(d_np.p, 0, (size_t)C * 4, stream));
-        hsdev::PartitionScalars ps;
-        {
-            int32_t* base = (int32_t*)d_scal.p;
-            ps.left = base; ps.right = base + n_cand; ps.n_occ = base + 2 * n_cand; ps.n_corr = base + 3 * n_cand; ps.lo = base + 4 * n_cand;
-            ps.hi = base + 5 * n_cand; ps.reach = base + 6 * n_cand;
-        }
-        // LDS: the two scalar arrays + as many table blocks of the widest contig as fit (at least one if it can)
-        static const int lds_budget = []() { const char* e = std::getenv("HS_LOOP_A_LDS"); return e ? std::atoi(e) : 64 * 1024; }();
-        const int lds_bytes = std::max(2 * 1024 * 4 + 64, std::min(160 * 1024 - 1024, std::max(lds_budget, 2 * 1024 * 4 + std::min(max_n, 2000) * 64)));
-        if (lds_bytes > 48 * 1024)
-            HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_robust_partitions), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        if (int rc = grow(d_la_parts, std::max<size_t>(1, (size_t)cap_off.back()) * sizeof(hsdev::LoopAPartition))) return rc;
+        if (int rc = grow(d_la_bits, std::max<size_t>(1, (size_t)bits_off.back()) * 8)) return rc;
+        if (int rc = grow(d_la_cnt, std::max<size_t>(1, (size_t)cnt_off.back()) * 4)) return rc;
+        if (int rc = grow(d_la_np, (size_t)C * 8)) return rc;      // [C] partitions, [C] failed
+        if (int rc = grow(d_la_pb, ((size_t)C + 1) * 8)) return rc;
+        const char* cb = (const char*)d_cand_pk.p;
+        if (int rc = grow(d_la_diag, 128)) return rc;
+        HS_HIP(hipMemsetAsync(d_la_diag.p, 0, 128, stream));
+        const size_t lds = (size_t)3 * w_max * HS_LA_SLOTS * 8;
+        if (lds > 32 * 1024)
+            HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_loop_a), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         EventPair e; if (int rc = e.init()) return rc;
         HS_HIP(hipEventRecord(e.a, stream));
         if (int rc = kc.begin(HS_K_ROBUST_PARTITIONS, stream)) return rc;
-        hipLaunchKernelGGL(hsdev::k_robust_partitions, dim3((unsigned)n_dev), dim3(64), (size_t)lds_bytes, stream, d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(),
-                           d_co_.as<int64_t>(), d_cc_.as<int32_t>(), d_cp.as<int32_t>(), d_cr.as<uint8_t>(), d_n.as<int32_t>(), d_ro.as<int64_t>(),
-                           d_re.as<int32_t>(), d_ord.as<int32_t>(), n_dev, d_to.as<int64_t>(), d_tab.as<uint8_t>(), d_more.as<int32_t>(), d_less.as<int32_t>(),
-                           ps, d_np.as<int32_t>(), lds_bytes);
+        hipLaunchKernelGGL(hsdev::k_loop_a, dim3((unsigned)C), dim3(64), lds, stream, (const hsdev::hs_colrec_dev*)(cb + cand_layout.rec), (const int64_t*)(cb + cand_layout.off),
+                           (const int32_t*)(cb + cand_layout.idx), (const uint8_t*)(cb + cand_layout.code), d_co_.as<int64_t>(), range_c0, C, b->d_contig_rec_off.as<int32_t>(),
+                           b->d_rank_of.as<int32_t>(), b->d_orig_of.as<int32_t>(), b->d_read_end.as<int32_t>(), d_ord.as<int32_t>(), d_cap.as<int64_t>(), d_bo.as<int64_t>(),
+                           d_cno.as<int64_t>(), d_la_parts.as<hsdev::LoopAPartition>(), d_la_bits.as<unsigned long long>(), d_la_cnt.as<int32_t>(), d_la_np.as<int32_t>(),
+                           d_la_np.as<int32_t>() + C, w_max, d_la_diag.as<unsigned long long>());
         HS_HIP(hipGetLastError());
-        // the candidates' entries (idx + code) once: their share of the gathered entries (the ops do not keep the column lengths on the host)
-        if (int rc = kc.end(5 * (gathered_entries * n_cand / std::max(1, n_gathered)), stream)) return rc;
-        hipLaunchKernelGGL(hsdev::k_partitions_scan, dim3(1), dim3(64), 0, stream, d_np.as<int32_t>(), d_n.as<int32_t>(), C, d_pb.as<int64_t>(), d_eb.as<int64_t>());
+        if (int rc = kc.end(5 * cand_entries + 16 * cand_count, stream)) return rc;      // the candidates' entries (idx + code) and records once
+        hipLaunchKernelGGL(hsdev::k_loop_a_scan, dim3(1), dim3(64), 0, stream, d_la_np.as<int32_t>(), C, d_la_pb.as<int64_t>());
         HS_HIP(hipGetLastError());
         HS_HIP(hipEventRecord(e.b, stream));
-        // first the sizes, then the partitions themselves
-        HBuf h1; if (int rc = h1.alloc(((size_t)C + 1) * 16)) return rc;
-        HS_HIP(hipMemcpyAsync(h1.p, d_pb.p, ((size_t)C + 1) * 8, hipMemcpyDeviceToHost, stream));
-        HS_HIP(hipMemcpyAsync((char*)h1.p + ((size_t)C + 1) * 8, d_eb.p, ((size_t)C + 1) * 8, hipMemcpyDeviceToHost, stream));
+        // the counts first, then the partitions themselves, packed
+        if (int rc = grow(h_la_np, (size_t)C * 8 + ((size_t)C + 1) * 8)) return rc;
+        HS_HIP(hipMemcpyAsync(h_la_np.p, d_la_np.p, (size_t)C * 8, hipMemcpyDeviceToHost, stream));
+        HS_HIP(hipMemcpyAsync((char*)h_la_np.p + (size_t)C * 8, d_la_pb.p, ((size_t)C + 1) * 8, hipMemcpyDeviceToHost, stream));
         if (int rc = stream_wait(stream)) return rc;
-        std::memcpy(out.part_base.data(), h1.p, ((size_t)C + 1) * 8);
+        const int32_t* h_np = (const int32_t*)h_la_np.p;
+        std::memcpy(out.failed.data(), h_np + C, (size_t)C * 4);
+        std::memcpy(out.part_base.data(), (const char*)h_la_np.p + (size_t)C * 8, ((size_t)C + 1) * 8);
         const int64_t n_parts = out.part_base[(size_t)C];
-        const int64_t used = ((const int64_t*)((char*)h1.p + ((size_t)C + 1) * 8))[C];
-        if (int rc = d_rec.alloc(std::max<size_t>(1, (size_t)n_parts) * sizeof(hsdev::PartitionRecord))) return rc;
-        if (int rc = d_state.alloc(std::max<size_t>(1, (size_t)used))) return rc;
-        if (int rc = d_mo.alloc(std::max<size_t>(1, (size_t)used) * 4)) return rc;
-        if (int rc = d_le.alloc(std::max<size_t>(1, (size_t)used) * 4)) return rc;
-        hipLaunchKernelGGL(hsdev::k_partitions_unpack, dim3((unsigned)C), dim3(256), 0, stream, d_co_.as<int64_t>(), d_np.as<int32_t>(), d_n.as<int32_t>(), d_to.as<int64_t>(),
-                           d_tab.as<uint8_t>(), d_more.as<int32_t>(), d_less.as<int32_t>(), ps, d_pb.as<int64_t>(), d_eb.as<int64_t>(), d_rec.as<hsdev::PartitionRecord>(),
-                           d_state.as<int8_t>(), d_mo.as<int32_t>(), d_le.as<int32_t>());
-        HS_HIP(hipGetLastError());
-        auto grow = [](HBuf& h, size_t need) -> int { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); };
-        if (int rc = grow(h_la_rec, std::max<size_t>(1, (size_t)n_parts) * sizeof(hs::CvPartRecord))) return rc;
-        if (int rc = grow(h_la_state, std::max<size_t>(1, (size_t)used))) return rc;
-        if (int rc = grow(h_la_more, std::max<size_t>(1, (size_t)used) * 4)) return rc;
-        if (int rc = grow(h_la_less, std::max<size_t>(1, (size_t)used) * 4)) return rc;
-        if (n_parts) HS_HIP(hipMemcpyAsync(h_la_rec.p, d_rec.p, (size_t)n_parts * sizeof(hs::CvPartRecord), hipMemcpyDeviceToHost, stream));
-        if (used) {
-            HS_HIP(hipMemcpyAsync(h_la_state.p, d_state.p, (size_t)used, hipMemcpyDeviceToHost, stream));
-            HS_HIP(hipMemcpyAsync(h_la_more.p, d_mo.p, (size_t)used * 4, hipMemcpyDeviceToHost, stream));
-            HS_HIP(hipMemcpyAsync(h_la_less.p, d_le.p, (size_t)used * 4, hipMemcpyDeviceToHost, stream));
+        int64_t tb = 0, tc = 0;
+        for (int c = 0; c < C; ++c) {
+            const int64_t P = h_np[c];
+            const int N = contig_n_reads[(size_t)c];
+            out.bits_base[(size_t)c] = tb; out.cnt_base[(size_t)c] = tc;
+            tb += P * 3 * ((N + 63) >> 6); tc += P * N;
         }
-        if (int rc = stream_wait(stream)) return rc;
-        out.rec = (const hs::CvPartRecord*)h_la_rec.p; out.state = (const int8_t*)h_la_state.p; out.more = (const int32_t*)h_la_more.p; out.less = (const int32_t*)h_la_less.p;
+        if (int rc = grow(d_la_out_rec, std::max<size_t>(1, (size_t)n_parts) * sizeof(hsdev::LoopAPartition))) return rc;
+        if (int rc = grow(d_la_out_bits, std::max<size_t>(1, (size_t)tb) * 8)) return rc;
+        if (int rc = grow(d_la_out_cnt, std::max<size_t>(1, (size_t)tc) * 4)) return rc;
+        DBuf d_bb, d_cb2;
+        UploadPack pk2;
+        pk2.add(out.bits_base, d_bb); pk2.add(out.cnt_base, d_cb2);
+        if (int rc = pk2.commit(stream)) return rc;
+        hipLaunchKernelGGL(hsdev::k_loop_a_pack, dim3((unsigned)C), dim3(256), 0, stream, d_la_np.as<int32_t>(), range_c0, b->d_contig_rec_off.as<int32_t>(), d_cap.as<int64_t>(),
+                           d_bo.as<int64_t>(), d_cno.as<int64_t>(), d_la_parts.as<hsdev::LoopAPartition>(), d_la_bits.as<unsigned long long>(), d_la_cnt.as<int32_t>(),
+                           d_la_pb.as<int64_t>(), d_bb.as<int64_t>(), d_cb2.as<int64_t>(), d_la_out_rec.as<hsdev::LoopAPartition>(), d_la_out_bits.as<unsigned long long>(),
+                           d_la_out_cnt.as<int32_t>());
+        HS_HIP(hipGetLastError());
+        if (int rc = grow(h_la_rec, std::max<size_t>(1, (size_t)n_parts) * sizeof(hs::CvPartRecord))) return rc;
+        if (int rc = grow(h_la_bits, std::max<size_t>(1, (size_t)tb) * 8)) return rc;
+        if (int rc = grow(h_la_cnt, std::max<size_t>(1, (size_t)tc) * 4)) return rc;
+        if (n_parts) HS_HIP(hipMemcpyAsync(h_la_rec.p, d_la_out_rec.p, (size_t)n_parts * sizeof(hs::CvPartRecord), hipMemcpyDeviceToHost, stream));
+        if (tb) HS_HIP(hipMemcpyAsync(h_la_bits.p, d_la_out_bits.p, (size_t)tb * 8, hipMemcpyDeviceToHost, stream));
+        if (tc) HS_HIP(hipMemcpyAsync(h_la_cnt.p, d_la_out_cnt.p, (size_t)tc * 4, hipMemcpyDeviceToHost, stream));
+        if (int rc = stream_wait(stream)) return rc;      // (the offset tables of this scope are done with)
+        out.rec = (const hs::CvPartRecord*)h_la_rec.p; out.bits = (const uint64_t*)h_la_bits.p; out.cnt = (const int32_t*)h_la_cnt.p;
+#ifdef HS_LA_DIAG
+        {
+            unsigned long long dg[10];
+            if (int rc = d2h_pinned(dg, d_la_diag.p, sizeof dg, stream)) return rc;
+            std::fprintf(stderr, "[hs la] cycles: loads+window %llu, build %llu, compare %llu, exact %llu, verdict+evict %llu, augment %llu, create %llu, end %llu; candidates %llu, exact lanes %llu\n",
+                         dg[0], dg[1], dg[2], dg[3], dg[4], dg[5], dg[6], dg[7], dg[8], dg[9]);
+        }
+#endif
         kc.flush();
-        return e.ms(k_ms);
+        return k_ms ? e.ms(k_ms) : HS_OK;
     }
 };
 

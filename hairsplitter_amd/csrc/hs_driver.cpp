@@ -224,9 +224,13 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
         const int64_t entries = b.pile_off[(size_t)b.contig_rec_off[(size_t)gc + 1]] - b.pile_off[(size_t)b.contig_rec_off[(size_t)gc]];
         o.depth = (float)((double)entries / (double)L);
     }
+    // loop A of keep_only_robust_variants runs on the device when the implementation has it (HS_LOOP_A_ON_HOST=1: on the host): the
+    // candidates then stay there, and only the contigs the kernel's tables cannot hold are walked here
+    static const bool loop_a_on_host = []() { const char* e = std::getenv("HS_LOOP_A_ON_HOST"); return e && e[0] != '0'; }();
+    const bool on_device = dev.has_robust_partitions() && !loop_a_on_host;
     CvCandidates cand;
     float k_ms_x[3] = {0, 0, 0};
-    if (int rc = dev.extract_candidates(c0, c1, min_reads, automatic_snp_threshold, cand, k_ms_x)) return rc;
+    if (int rc = dev.extract_candidates(c0, c1, min_reads, automatic_snp_threshold, cand, k_ms_x, !on_device)) return rc;
     k_ms[1] = k_ms_x[0]; k_ms[2] = k_ms_x[1] + k_ms_x[2];
     const double t_dev_done = now_ms();
     Laps laps("cv glue");
@@ -234,54 +238,53 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
     for (int c = 0; c < C; ++c) cand_base[(size_t)c + 1] = cand_base[(size_t)c] + cand.contig_n_cand[(size_t)c];
     if (cand_base[(size_t)C] != cand.n_cand) { set_error("cv_run_range: candidate counts do not add up"); return HS_EINVAL; }
 
-    // ---- the partition logic: loop A on the host (or, with that kernel, contig by contig on the device), loop B on the host ----
+    // ---- the partition logic: loop A (device, or host), loop B on the host ----
     std::vector<CvContigState*> cst((size_t)C, nullptr);
     for (int c = 0; c < C; ++c) cst[(size_t)c] = cv_state_new();
     std::vector<std::vector<int32_t>> rend((size_t)C);
+    std::vector<int32_t> n_reads_of((size_t)C);
+    parallel_for(C, n_threads, [&](int c) {
+        const int gc = c0 + c;   // index in the batch
+        const int r0 = b.contig_rec_off[(size_t)gc];
+        const int n_reads_c = b.contig_rec_off[(size_t)gc + 1] - r0;
+        n_reads_of[(size_t)c] = n_reads_c;
+        cv_phase_begin(*cst[(size_t)c], n_reads_c, cand.contig_n_cand[(size_t)c], res[(size_t)c].mean_distance, res[(size_t)c]);
+    });
+    laps.lap("begin");
+    CvLoopAResult la;
+    float k_ms_a = 0;
+    bool some_on_host = !on_device;
+    if (on_device) {
+        if (int rc = dev.robust_partitions(n_reads_of, la, &k_ms_a)) return rc;
+        for (int c = 0; c < C; ++c) if (la.failed[(size_t)c]) some_on_host = true;
+        if (some_on_host) { if (int rc = dev.fetch_candidates(cand)) return rc; }      // (rare: the tables of the kernel did not hold a contig)
+        laps.lap("loop_a");
+    }
+    if (some_on_host)
+        parallel_for(C, n_threads, [&](int c) {
+            if (on_device && !la.failed[(size_t)c]) return;
+            const int r0 = b.contig_rec_off[(size_t)(c0 + c)];
+            rend[(size_t)c].resize((size_t)n_reads_of[(size_t)c]);
+            for (int r = 0; r < n_reads_of[(size_t)c]; ++r) rend[(size_t)c][(size_t)r] = (int32_t)std::min<int64_t>(b.rec_pos[(size_t)(r0 + r)] + b.rec_refspan[(size_t)(r0 + r)], 0x7fffffff);
+        });
     auto candidates_of = [&](int c) {
         CandidateSet cs;
         cs.n = cand.contig_n_cand[(size_t)c];
         cs.rec = cand.rec + cand_base[(size_t)c]; cs.off = cand.off + cand_base[(size_t)c]; cs.idx = cand.idx; cs.code = cand.code;
         return cs;
     };
-    parallel_for(C, n_threads, [&](int c) {
-        const int gc = c0 + c;   // index in the batch
-        const int r0 = b.contig_rec_off[(size_t)gc];
-        const int n_reads_c = b.contig_rec_off[(size_t)gc + 1] - r0;
-        rend[(size_t)c].resize((size_t)n_reads_c);
-        for (int r = 0; r < n_reads_c; ++r) rend[(size_t)c][(size_t)r] = (int32_t)std::min<int64_t>(b.rec_pos[(size_t)(r0 + r)] + b.rec_refspan[(size_t)(r0 + r)], 0x7fffffff);
-        cv_phase_begin(*cst[(size_t)c], n_reads_c, cand.contig_n_cand[(size_t)c], res[(size_t)c].mean_distance, res[(size_t)c]);
-    });
-    laps.lap("begin");
-    static const bool loop_a_on_host = std::getenv("HS_LOOP_A_ON_DEVICE") == nullptr;      // (the device form is exact but slower than the host's)
-    const bool on_device = dev.has_robust_partitions() && !loop_a_on_host;
-    CvLoopAResult la;
-    float k_ms_a = 0;
-    if (on_device) {
-        CvLoopA in;
-        in.cand_off = cand_base; in.read_off.assign((size_t)C + 1, 0); in.contig_n_reads.resize((size_t)C);
-        for (int c = 0; c < C; ++c) {
-            in.contig_n_reads[(size_t)c] = (int32_t)rend[(size_t)c].size();
-            in.read_off[(size_t)c + 1] = in.read_off[(size_t)c] + (int64_t)rend[(size_t)c].size();
-        }
-        in.cand_col.assign(cand.col, cand.col + cand.n_cand); in.cand_pos.resize((size_t)cand.n_cand); in.cand_ref.resize((size_t)cand.n_cand);
-        for (int64_t k = 0; k < cand.n_cand; ++k) { in.cand_pos[(size_t)k] = cand.rec[k].pos; in.cand_ref[(size_t)k] = cand.rec[k].k0; }
-        in.read_end.resize((size_t)in.read_off.back());
-        for (int c = 0; c < C; ++c) std::copy(rend[(size_t)c].begin(), rend[(size_t)c].end(), in.read_end.begin() + in.read_off[(size_t)c]);
-        laps.lap("loop_a_prep");
-        if (int rc = dev.robust_partitions(in, la, &k_ms_a)) return rc;
-        laps.lap("loop_a");
-    }
     std::atomic<int> n_host_a{0};
     parallel_for(C, n_threads, [&](int c) {
         const int r0 = b.contig_rec_off[(size_t)(c0 + c)];
-        if (on_device && !la.failed[(size_t)c])
+        if (on_device && !la.failed[(size_t)c]) {
+            const int N = n_reads_of[(size_t)c];
             cv_phase_a_import(*cst[(size_t)c], b.rec_pos.data() + r0, (int)(la.part_base[(size_t)c + 1] - la.part_base[(size_t)c]), la.rec + la.part_base[(size_t)c],
-                              la.state, la.more, la.less);
-        else { cv_phase_a_host(*cst[(size_t)c], candidates_of(c), b.rec_pos.data() + r0, rend[(size_t)c].data()); n_host_a++; }
+                              la.bits + la.bits_base[(size_t)c], la.cnt + la.cnt_base[(size_t)c]);
+            (void)N;
+        } else { cv_phase_a_host(*cst[(size_t)c], candidates_of(c), b.rec_pos.data() + r0, rend[(size_t)c].data()); n_host_a++; }
         cv_phase_b(*cst[(size_t)c], res[(size_t)c]);
     });
-    if (std::getenv("HS_TIMING") && on_device) std::fprintf(stderr, "[hs timing] cv loop A on the device: %.3f ms of kernels, %d of %d contigs redone on the host\n", k_ms_a, n_host_a.load(), C);
+    if (std::getenv("HS_TIMING") && on_device) std::fprintf(stderr, "[hs timing] cv loop A on the device: %.3f ms of kernels, %d of %d contigs done on the host\n", k_ms_a, n_host_a.load(), C);
     laps.lap("phase_ab");
     // ---- loops C and D and the merge of the SNP lists on the device, against the final partitions ----
     CvSnpSet snps;

@@ -52,21 +52,17 @@ struct CvSnpSet {
     const uint8_t* code = nullptr;
 };
 
-struct CvLoopA {
-    std::vector<int64_t> cand_off;             // [C+1] candidates per contig
-    std::vector<int32_t> cand_col, cand_pos;   // column (index in the implementation's column list) and position of every candidate, position order
-    std::vector<uint8_t> cand_ref;             // its reference code (k0)
-    std::vector<int32_t> contig_n_reads;       // [C]
-    std::vector<int64_t> read_off;             // [C+1] into read_end
-    std::vector<int32_t> read_end;             // exclusive end position of every read
-};
+// Loop A of keep_only_robust_variants on the device: input = the candidates of the last extract_candidates() (they are with the
+// implementation) + the per-contig read counts; output = the partitions of every contig as the device keeps them: a record, three
+// bit sets over the reads ranked by start position (present / state +1 / state -1, W = ceil(N / 64) words each) and one counter
+// per read (more | less << 16)
 struct CvLoopAResult {
     std::vector<int64_t> part_base;            // [C+1] partitions per contig
-    std::vector<int32_t> failed;               // [C] != 0: the device gave up on this contig (pool exhausted), the host does it
+    std::vector<int32_t> failed;               // [C] != 0: the device gave up on this contig (its tables do not hold it), the host does it
+    std::vector<int64_t> bits_base, cnt_base;  // [C] first word / counter of the contig's partitions in `bits` / `cnt`
     const CvPartRecord* rec = nullptr;         // [part_base[C]]
-    const int8_t* state = nullptr;             // pool: rec.elem is the first of the N elements of a partition
-    const int32_t* more = nullptr;
-    const int32_t* less = nullptr;
+    const uint64_t* bits = nullptr;            // partition p of contig c: words bits_base[c] + p * 3 W ...
+    const int32_t* cnt = nullptr;              // ... counters cnt_base[c] + p * N ...
 };
 
 // The device side of stage 3. One object serves one range of contigs at a time: pileup() once per batch, then per range
@@ -78,8 +74,11 @@ struct CvDeviceOps {
     // K2 -> K3 -> K3b -> V1 for the contigs [c0, c1): every position whose second count is >= 4 becomes a column (it stays with the
     // implementation), its two leading codes are named in the reference's order, the candidates are chosen (min_reads[c - c0] = 3 or 5,
     // call_variants.cpp:463-466) and packed for the host. k_ms = {column statistics, gather, top-3 + candidates}
+    // want_entries = false: only the counts come back (n_columns, contig_n_cand, n_cand ...); the candidates stay with the
+    // implementation for robust_partitions() and can still be fetched (fetch_candidates) if the host has to walk some after all
     virtual int extract_candidates(int c0, int c1, const std::vector<int32_t>& min_reads, float automatic_snp_threshold, CvCandidates& out,
-                                   float k_ms[3]) = 0;
+                                   float k_ms[3], bool want_entries = true) = 0;
+    virtual int fetch_candidates(CvCandidates& out) { (void)out; return -1; }
     // K4 (loops C and D of keep_only_robust_variants on the extracted columns against the final partitions) and the merge of the
     // automatic and the filtered SNPs; want_entries = false leaves idx / code of the result null (the SNP columns stay with the
     // implementation for stage 4: take_snp_columns)
@@ -88,7 +87,7 @@ struct CvDeviceOps {
     // Optional: an implementation without it leaves the loop to the host (cv_phase_a_host). The result arrays are owned by
     // the implementation and stay valid until the next call.
     virtual bool has_robust_partitions() const { return false; }
-    virtual int robust_partitions(const CvLoopA& in, CvLoopAResult& out, float* k_ms) { (void)in; (void)out; (void)k_ms; return -1; }
+    virtual int robust_partitions(const std::vector<int32_t>& contig_n_reads, CvLoopAResult& out, float* k_ms) { (void)contig_n_reads; (void)out; (void)k_ms; return -1; }
 };
 
 // result of the whole-batch streaming pass (K0 + K1): the per-record counters

@@ -38,11 +38,12 @@ void cv_state_free(CvContigState* st);
 // The host part of keep_only_robust_variants in steps: loop A on the host (cv_phase_a_host) or imported from the device
 // (k_robust_partitions -> cv_phase_a_import), then loop B (cv_phase_b); the final partitions leave for loops C / D on the device.
 // read_start / read_end: [n_reads] reference interval [start, end) of every record of the contig (POS-1, POS-1 + reference span)
-struct CvPartRecord { int32_t left, right, n_occ, n_corr, lo, hi, reach, pad; int64_t elem; };   // what k_partitions_pack writes per partition
+struct CvPartRecord { int32_t left, right, n_occ, n_corr, lo, hi, reach, pad; int64_t elem; };   // what k_loop_a_pack writes per partition
 void cv_phase_begin(CvContigState& st, int n_reads, int n_candidates, float mean_distance, ContigCvResult& out);
 void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* read_start, const int32_t* read_end);
-void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const int8_t* pool_state,
-                       const int32_t* pool_more, const int32_t* pool_less);
+// bits: the contig's partitions, 3 W words each (present, plus, minus over the reads ranked by start position); cnt: N counters each
+// (more | less << 16); rec[p].elem is not used here
+void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const uint64_t* bits, const int32_t* cnt);
 void cv_phase_b(CvContigState& st, ContigCvResult& out);
 int cv_final_partitions(const CvContigState& st);
 // the final partitions' dense state arrays (n_reads bytes each) written at `state`, their offsets (state_base + ...) at state_off

@@ -672,10 +672,11 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
                           cs.n, parts.size(), n_cmp, n_aug, nowus() - t_a0, t_build, t_aug);
 }
 
-// loop A ran on the device (k_robust_partitions): its partitions become the host's dense form
-void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const int8_t* pool_state,
-                       const int32_t* pool_more, const int32_t* pool_less) {
+// loop A ran on the device (k_loop_a): its partitions become the host's dense form. The device ranks the reads exactly as
+// rank_reads() does (the batch carries that order), so its bit sets are taken as they are.
+void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const uint64_t* bits, const int32_t* cnt) {
     const int N = st.n_reads;
+    const int W = (N + 63) >> 6;
     rank_reads(st, read_start);
     std::vector<DensePartition>& parts = st.parts;
     parts.clear();
@@ -684,15 +685,24 @@ void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts
         DensePartition& d = parts[(size_t)p];
         const CvPartRecord& r = rec[p];
         d.left = r.left; d.right = r.right; d.n_occ = r.n_occ; d.n_corr = r.n_corr; d.lo = r.lo; d.hi = r.hi; d.reach = r.reach;
-        d.rank_of = st.rank_of.data(); d.orig_of = st.orig_of.data(); d.wlo = 0; d.whi = -1;
-        const int8_t* s = pool_state + r.elem; const int32_t* mo = pool_more + r.elem; const int32_t* le = pool_less + r.elem;
+        d.rank_of = st.rank_of.data(); d.orig_of = st.orig_of.data(); d.wlo = W; d.whi = -1;
         d.allocate(st.arena, N);
-        std::memcpy(d.state, s, (size_t)N);
-        for (int q = d.lo; q <= d.hi; ++q) {
-            if (s[q] == ABSENT) continue;
-            d.more[(size_t)q] = mo[q]; d.less[(size_t)q] = le[q];
-            d.sync_bits(q);
+        const uint64_t* pb = bits + (size_t)p * 3 * W;
+        const int32_t* pc = cnt + (size_t)p * N;
+        std::memcpy(d.present, pb, (size_t)W * 8); std::memcpy(d.plus, pb + W, (size_t)W * 8); std::memcpy(d.minus, pb + 2 * W, (size_t)W * 8);
+        for (int w = 0; w < W; ++w) {
+            if (!d.present[w]) continue;
+            if (w < d.wlo) d.wlo = w;
+            if (w > d.whi) d.whi = w;
+            for (uint64_t x = d.present[w]; x; x &= x - 1) {
+                const int k = w * 64 + __builtin_ctzll(x);
+                const int q = st.orig_of[(size_t)k];
+                const uint64_t b = 1ull << (k & 63);
+                d.state[q] = (d.plus[w] & b) ? 1 : ((d.minus[w] & b) ? -1 : 0);
+                d.more[q] = pc[q] & 0xffff; d.less[q] = (pc[q] >> 16) & 0xffff;
+            }
         }
+        if (d.whi < d.wlo) d.wlo = 0;
     }
 }
 

@@ -80,7 +80,7 @@ struct OracleCvOps : hs::CvDeviceOps {
     }
     // K2 + K3 + K3b + V1 through the oracle's call_variants (call_variants.cpp:447-567): its per-position top-3 (the reference's
     // order of equal counts) and its candidate / automatic lists
-    int extract_candidates(int c0, int c1, const std::vector<int32_t>& min_reads, float thr, hs::CvCandidates& out, float k_ms[3]) override {
+    int extract_candidates(int c0, int c1, const std::vector<int32_t>& min_reads, float thr, hs::CvCandidates& out, float k_ms[3], bool) override {
         k_ms[0] = k_ms[1] = k_ms[2] = 0;
         r0 = c0; r1 = c1;
         xcols.clear();

@@ -24,7 +24,7 @@ def test_dropin_binaries_match_reference_goldens(built, case):
         assert open(gaf, "rb").read() == open(os.path.join(td, "reads_haplo.gaf"), "rb").read()
 
 
-@pytest.mark.parametrize("switch", ["HS_K1_PER_EVENT", "HS_SPIN_WAIT", "HS_FINISH_ON_HOST", "HS_LOOP_A_ON_DEVICE"])
+@pytest.mark.parametrize("switch", ["HS_K1_PER_EVENT", "HS_SPIN_WAIT", "HS_FINISH_ON_HOST", "HS_LOOP_A_ON_HOST"])
 @pytest.mark.parametrize("case", ["penta30k", "edge_ops"])
 def test_dropin_binaries_with_the_alternative_paths(built, case, switch):
     """The opt-in switches select other ways to the same result (event-per-lane pileup, sleeping waits, full column download,
