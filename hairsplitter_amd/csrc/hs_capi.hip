@@ -1050,7 +1050,10 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
             for (int r = 0; r < n; ++r) order[(size_t)r] = r;
             std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return h_rec_pos[r0 + x] != h_rec_pos[r0 + y] ? h_rec_pos[r0 + x] < h_rec_pos[r0 + y] : x < y; });
             for (int k = 0; k < n; ++k) { rank_of[(size_t)(r0 + order[(size_t)k])] = k; orig_of[(size_t)(r0 + k)] = order[(size_t)k]; }
-            for (int r = 0; r < n; ++r) read_end[(size_t)(r0 + r)] = (int32_t)std::min<int64_t>((int64_t)h_rec_pos[r0 + r] + b->rec_refspan[(size_t)(r0 + r)], 0x7fffffff);
+            for (int k = 0; k < n; ++k) {      // (in rank order: the kernel indexes everything per read by rank)
+                const int r = order[(size_t)k];
+                read_end[(size_t)(r0 + k)] = (int32_t)std::min<int64_t>((int64_t)h_rec_pos[r0 + r] + b->rec_refspan[(size_t)(r0 + r)], 0x7fffffff);
+            }
         });
         up(b->d_rank_of, rank_of.data(), sizeof(int32_t) * (size_t)n_rec);
         up(b->d_orig_of, orig_of.data(), sizeof(int32_t) * (size_t)n_rec);
@@ -1387,7 +1390,7 @@ struct HipCvOps : hs::CvDeviceOps {
     }
     // ---- loop A on the device (hs_kernels_loopa.hip) on the candidates of the last extract_candidates() ----
     bool has_robust_partitions() const override { return true; }
-    DBuf d_la_parts, d_la_bits, d_la_cnt, d_la_np, d_la_pb, d_la_out_rec, d_la_out_bits, d_la_out_cnt, d_la_diag;
+    DBuf d_la_parts, d_la_bits, d_la_cnt, d_la_np, d_la_pb, d_la_out_rec, d_la_out_bits, d_la_out_cnt, d_la_diag, d_la_rc, d_la_hdr, d_la_words, d_la_ends;
     HBuf h_la_np, h_la_rec, h_la_bits, h_la_cnt;
     int robust_partitions(const std::vector<int32_t>& contig_n_reads, hs::CvLoopAResult& out, float* k_ms) override {
         static_assert(sizeof(hs::CvPartRecord) == sizeof(hsdev::LoopAPartition), "partition record layouts differ");
@@ -1431,15 +1434,24 @@ struct HipCvOps : hs::CvDeviceOps {
         const char* cb = (const char*)d_cand_pk.p;
         if (int rc = grow(d_la_diag, 128)) return rc;
         HS_HIP(hipMemsetAsync(d_la_diag.p, 0, 128, stream));
+        if (int rc = grow(d_la_rc, std::max<size_t>(1, (size_t)cand_count) * 512)) return rc;      // a row of 128 (rank << 8 | code) per candidate
+        if (int rc = grow(d_la_ends, std::max<size_t>(1, (size_t)cand_count) * 8)) return rc;
+        if (int rc = grow(d_la_hdr, std::max<size_t>(1, (size_t)cand_count) * sizeof(hsdev::LoopAColumn))) return rc;
+        if (int rc = grow(d_la_words, std::max<size_t>(1, (size_t)cand_count) * 512)) return rc;
         const size_t lds = (size_t)3 * w_max * HS_LA_SLOTS * 8;
         if (lds > 32 * 1024)
             HS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hsdev::k_loop_a), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         EventPair e; if (int rc = e.init()) return rc;
         HS_HIP(hipEventRecord(e.a, stream));
         if (int rc = kc.begin(HS_K_ROBUST_PARTITIONS, stream)) return rc;
-        hipLaunchKernelGGL(hsdev::k_loop_a, dim3((unsigned)C), dim3(64), lds, stream, (const hsdev::hs_colrec_dev*)(cb + cand_layout.rec), (const int64_t*)(cb + cand_layout.off),
-                           (const int32_t*)(cb + cand_layout.idx), (const uint8_t*)(cb + cand_layout.code), d_co_.as<int64_t>(), range_c0, C, b->d_contig_rec_off.as<int32_t>(),
-                           b->d_rank_of.as<int32_t>(), b->d_orig_of.as<int32_t>(), b->d_read_end.as<int32_t>(), d_ord.as<int32_t>(), d_cap.as<int64_t>(), d_bo.as<int64_t>(),
+        hipLaunchKernelGGL(hsdev::k_loop_a_prepare, dim3((unsigned)((cand_count + 3) / 4)), dim3(256), 0, stream, (const hsdev::hs_colrec_dev*)(cb + cand_layout.rec),
+                           (const int64_t*)(cb + cand_layout.off), (const int32_t*)(cb + cand_layout.idx), (const uint8_t*)(cb + cand_layout.code), cand_count,
+                           b->d_contig_rec_off.as<int32_t>(), b->d_rank_of.as<int32_t>(), d_la_rc.as<int32_t>(), d_la_hdr.as<hsdev::LoopAColumn>(), d_la_words.as<unsigned long long>(),
+                           d_la_ends.as<int32_t>());
+        hipLaunchKernelGGL(hsdev::k_loop_a, dim3((unsigned)C), dim3(64), lds, stream, (const hsdev::hs_colrec_dev*)(cb + cand_layout.rec), d_la_rc.as<int32_t>(),
+                           d_la_ends.as<int32_t>(), d_la_hdr.as<hsdev::LoopAColumn>(), d_la_words.as<unsigned long long>(),
+                           d_co_.as<int64_t>(), range_c0, C, b->d_contig_rec_off.as<int32_t>(),
+                           b->d_orig_of.as<int32_t>(), b->d_read_end.as<int32_t>(), d_ord.as<int32_t>(), d_cap.as<int64_t>(), d_bo.as<int64_t>(),
                            d_cno.as<int64_t>(), d_la_parts.as<hsdev::LoopAPartition>(), d_la_bits.as<unsigned long long>(), d_la_cnt.as<int32_t>(), d_la_np.as<int32_t>(),
                            d_la_np.as<int32_t>() + C, w_max, d_la_diag.as<unsigned long long>());
         HS_HIP(hipGetLastError());

@@ -224,10 +224,12 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
         const int64_t entries = b.pile_off[(size_t)b.contig_rec_off[(size_t)gc + 1]] - b.pile_off[(size_t)b.contig_rec_off[(size_t)gc]];
         o.depth = (float)((double)entries / (double)L);
     }
-    // loop A of keep_only_robust_variants runs on the device when the implementation has it (HS_LOOP_A_ON_HOST=1: on the host): the
-    // candidates then stay there, and only the contigs the kernel's tables cannot hold are walked here
-    static const bool loop_a_on_host = []() { const char* e = std::getenv("HS_LOOP_A_ON_HOST"); return e && e[0] != '0'; }();
-    const bool on_device = dev.has_robust_partitions() && !loop_a_on_host;
+    // loop A of keep_only_robust_variants runs on the host threads by default. HS_LOOP_A_ON_DEVICE=1 runs it as k_loop_a (exact, one
+    // wave per contig): the candidates then stay on the device and only the contigs the kernel's tables cannot hold are walked here.
+    // Measured ("loop A on the device"): a lone wave needs about 5 us per candidate against 0.25 us on a host core, and
+    // the longest contig's chain bounds the launch, so the kernel is the experiment and the host walk the product path.
+    static const bool loop_a_on_device = []() { const char* e = std::getenv("HS_LOOP_A_ON_DEVICE"); return e && e[0] != '0'; }();
+    const bool on_device = dev.has_robust_partitions() && loop_a_on_device;
     CvCandidates cand;
     float k_ms_x[3] = {0, 0, 0};
     if (int rc = dev.extract_candidates(c0, c1, min_reads, automatic_snp_threshold, cand, k_ms_x, !on_device)) return rc;

@@ -699,7 +699,7 @@ void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts
                 const int q = st.orig_of[(size_t)k];
                 const uint64_t b = 1ull << (k & 63);
                 d.state[q] = (d.plus[w] & b) ? 1 : ((d.minus[w] & b) ? -1 : 0);
-                d.more[q] = pc[q] & 0xffff; d.less[q] = (pc[q] >> 16) & 0xffff;
+                d.more[q] = pc[k] & 0xffff; d.less[q] = (pc[k] >> 16) & 0xffff;      // (the device keeps the counters by rank)
             }
         }
         if (d.whi < d.wlo) d.wlo = 0;

@@ -28,6 +28,7 @@ namespace hsdev {
 #define HS_LA_MAXW 32          // words per bit set: contigs of up to 2048 reads
 #define HS_LA_CODES 16         // distinct codes of a column
 #define HS_LA_WIN 16           // words a column may spread over
+#define HS_LA_FAST_W 4         // ... and the usual case, with the bit sets of its codes made ahead (k_loop_a_prepare)
 
 struct LoopAPartition {        // == hs::CvPartRecord (what the host imports per partition)
     int32_t left, right, n_occ, n_corr, lo, hi, reach, pad;
@@ -49,9 +50,18 @@ struct LoopAShared {           // fixed-size part of the LDS of a wavefront
     int x_seen[HS_LA_CODES], x_cnt[HS_LA_CODES], x_first[HS_LA_CODES];
 };
 
-static __device__ __forceinline__ float chi_square_la(int n00, int n01, int n10, int n11) {      // computeChiSquare, call_variants.cpp:1135-1163
+// computeChiSquare(...) > 15 (call_variants.cpp:1135-1163). The reference's own sequence of float / double operations (chi_square_dev)
+// decides only where a single-precision form of the same statistic, n (ad - bc)^2 / (row and column sums), comes within 2 of
+// the threshold; its relative error is a few 1e-7 on tables of at most a few hundred reads, the margin is 13 %
+static __device__ __forceinline__ bool chi_square_gt15(int n00, int n01, int n10, int n11) {
+    const int r0 = n00 + n01, r1 = n10 + n11, c0 = n00 + n10, c1 = n01 + n11;
+    if (r0 == 0 || r1 == 0 || c0 == 0 || c1 == 0) return false;      // (the reference returns 0 or -1 for a degenerate table)
+    const float det = (float)(n00 * n11 - n01 * n10);
+    const float est = (float)(r0 + r1) * det * det / ((float)r0 * (float)r1 * (float)c0 * (float)c1);
+    if (est < 13.0f) return false;
+    if (est > 17.0f) return true;
     Table2x2 t; t.n00 = n00; t.n01 = n01; t.n10 = n10; t.n11 = n11;
-    return chi_square_dev(t);
+    return chi_square_dev(t) > 15;
 }
 
 // second_from_seen() of the host (hs_host_cv.cpp): the most frequent eligible code among `seen` (first-appearance order) with
@@ -83,12 +93,104 @@ static __device__ int second_from_seen_dev(LoopAShared& S, int nseen, int ref, b
     return bestk;
 }
 
+// Everything about a candidate column that does not depend on the partitions, made for all candidates at once (one wavefront
+// per column) before the sequential kernel walks them:
+//   cand_rc[e]   = rank of the entry's read by start position on its contig << 8 | its code
+//   header       = first word the column's reads lie in, number of words, its distinct codes in first-appearance order with
+//                  their counts, the slot of the reference code
+//   64 words     = the bit sets of the codes over the column's words, when it has at most 15 codes in at most 4 words (nearly
+//                  always): word w of `any` at [w], of code slot q at [4 (q + 1) + w] -- the sequential kernel keeps them one
+//                  per lane and reads them with v_readlane
+struct LoopAColumn {           // 64 bytes
+    int32_t wlo;
+    int16_t ww, nslots, ref_slot, fast;      // fast: the 64 words hold the bit sets; else the sequential kernel builds them (or gives up: ww = -1)
+    uint8_t codes[HS_LA_CODES];
+    uint16_t cnts[HS_LA_CODES];
+    int16_t n, pad;                          // entries of the column (its first 128 sit in the column's row of cand_row)
+};
+static_assert(sizeof(LoopAColumn) == 64, "LoopAColumn layout");
+
+__global__ __launch_bounds__(256) void k_loop_a_prepare(const hs_colrec_dev* __restrict__ cand_rec, const int64_t* __restrict__ cand_ent_off, const int32_t* __restrict__ cand_idx,
+                                                        const uint8_t* __restrict__ cand_code, int64_t n_cand, const int32_t* __restrict__ contig_rec_off,
+                                                        const int32_t* __restrict__ rank_of, int32_t* __restrict__ cand_row /* [n_cand][128] */, LoopAColumn* __restrict__ col_hdr,
+                                                        unsigned long long* __restrict__ col_words, int32_t* __restrict__ col_ends /* [n_cand][2]: first and last read */) {
+    __shared__ unsigned long long s_cb[4][HS_LA_CODES + 1][HS_LA_FAST_W];
+    const int lane = lane_id();
+    const int wv = wave_id();
+    const int64_t k = (int64_t)blockIdx.x * 4 + wv;
+    if (k >= n_cand) return;
+    const hs_colrec_dev rec = cand_rec[k];
+    const int r0 = contig_rec_off[rec.contig];
+    const int ref = (int)rec.k0;
+    const int64_t e0 = cand_ent_off[k];
+    const int n = (int)(cand_ent_off[k + 1] - e0);
+    int rc[2];      // (a column deeper than 128 reads goes to the host)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int e = c * 64 + lane;
+        rc[c] = e < n ? ((rank_of[r0 + cand_idx[e0 + e]] << 8) | (int)cand_code[e0 + e]) : -1;
+        cand_row[k * 128 + e] = rc[c];
+    }
+    if (lane == 0) { col_ends[2 * k] = n > 0 ? cand_idx[e0] : 0; col_ends[2 * k + 1] = n > 0 ? cand_idx[e0 + n - 1] : -1; }
+    int wlo, whi;
+    {
+        const int w0 = rc[0] >= 0 ? (rc[0] >> 14) : -1, w1 = rc[1] >= 0 ? (rc[1] >> 14) : -1;
+        const int hi_l = w0 > w1 ? w0 : w1;
+        const int lo0 = rc[0] >= 0 ? w0 : 0x7fffffff, lo1 = rc[1] >= 0 ? w1 : 0x7fffffff;
+        const int lo_l = lo0 < lo1 ? lo0 : lo1;
+        whi = wave_max_i32(hi_l); wlo = -wave_max_i32(-lo_l);
+    }
+    const int ww = n > 0 ? whi - wlo + 1 : 0;
+    const bool narrow = ww <= HS_LA_FAST_W && n > 0 && n <= 128;
+    for (int x = lane; x < (HS_LA_CODES + 1) * HS_LA_FAST_W; x += 64) (&s_cb[wv][0][0])[x] = 0ull;
+    wave_lds_sync();
+    int slot_code = -1, slot_cnt = 0, nslots = 0, ref_slot = -1;
+    bool many = false;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int cd = rc[c] >= 0 ? (rc[c] & 255) : -1;
+        const int rk = rc[c] >> 8;
+        unsigned long long rem = __ballot(rc[c] >= 0);
+        while (rem) {
+            const int X = __builtin_amdgcn_readlane(cd, __builtin_ctzll(rem));
+            const unsigned long long mX = __ballot(cd == X);
+            rem &= ~mX;
+            const unsigned long long hit = __ballot(slot_code == X);
+            int ks;
+            if (hit) ks = __builtin_ctzll(hit);
+            else {
+                if (nslots == HS_LA_CODES) { many = true; break; }
+                ks = nslots++;
+                if (lane == ks) { slot_code = X; slot_cnt = 0; }
+                if (X == ref) ref_slot = ks;
+            }
+            if (lane == ks) slot_cnt += __popcll(mX);
+            if (cd == X && narrow) {
+                const unsigned long long bit = 1ull << (rk & 63);
+                atomicOr(&s_cb[wv][ks + 1][(rk >> 6) - wlo], bit);
+                atomicOr(&s_cb[wv][0][(rk >> 6) - wlo], bit);
+            }
+        }
+    }
+    wave_lds_sync();
+    const bool fast = narrow && !many && nslots <= HS_LA_CODES - 1;
+    LoopAColumn* h = col_hdr + k;
+    if (lane == 0) { h->wlo = wlo; h->ww = (int16_t)((many || n == 0 || n > 128) ? -1 : ww); h->nslots = (int16_t)nslots; h->ref_slot = (int16_t)ref_slot; h->fast = fast ? 1 : 0; h->n = (int16_t)(n > 32767 ? 32767 : n); h->pad = 0; }
+    if (lane < HS_LA_CODES) { h->codes[lane] = (uint8_t)(slot_code < 0 ? 0 : slot_code); h->cnts[lane] = (uint16_t)slot_cnt; }
+    col_words[k * 64 + lane] = fast ? (&s_cb[wv][0][0])[lane] : 0ull;
+}
+
 // One wavefront per contig of the range. Dynamic LDS: the slot tables [3][W][64] u64 (present, plus, minus).
+// The column in flight sits in registers (two chunks of 64 entries: rank << 8 | code per lane; a deeper column sends the contig to
+// the host), the next one is loaded while this one is decided. Columns that lie in at most HS_LA_FAST words (nearly all) are
+// compared with the table words of the lanes' partitions in registers.
+#define HS_LA_FAST HS_LA_FAST_W
 __global__ __launch_bounds__(64) void k_loop_a(
-    const hs_colrec_dev* __restrict__ cand_rec, const int64_t* __restrict__ cand_ent_off, const int32_t* __restrict__ cand_idx, const uint8_t* __restrict__ cand_code,
+    const hs_colrec_dev* __restrict__ cand_rec, const int32_t* __restrict__ cand_row, const int32_t* __restrict__ col_ends,
+    const LoopAColumn* __restrict__ col_hdr, const unsigned long long* __restrict__ col_words,
     const int64_t* __restrict__ cand_off /* [C+1] */, int c_first, int c_count, const int32_t* __restrict__ contig_rec_off,
-    const int32_t* __restrict__ rank_of /* per record of the batch */, const int32_t* __restrict__ orig_of /* per record: rank -> read of its contig */,
-    const int32_t* __restrict__ read_end /* per record */, const int32_t* __restrict__ ctg_order /* heaviest contig first */,
+    const int32_t* __restrict__ orig_of /* per record: rank -> read of its contig */, const int32_t* __restrict__ read_end_by_rank /* per record, rank order */,
+    const int32_t* __restrict__ ctg_order /* heaviest contig first */,
     const int64_t* __restrict__ part_cap_off /* [C+1] partitions the pool holds per contig */, const int64_t* __restrict__ bits_off /* [C+1] words */,
     const int64_t* __restrict__ cnt_off /* [C+1] counters */, LoopAPartition* __restrict__ parts, unsigned long long* __restrict__ g_bits, int32_t* g_cnt,
     int32_t* __restrict__ n_parts /* [C] */, int32_t* __restrict__ failed /* [C] */, int w_cap, unsigned long long* __restrict__ diag) {
@@ -104,13 +206,11 @@ __global__ __launch_bounds__(64) void k_loop_a(
     const long long p_base = part_cap_off[ci];
     const int p_cap = (int)(part_cap_off[ci + 1] - p_base);
     unsigned long long* __restrict__ gb = g_bits + bits_off[ci];      // partition p: words [p * 3 W, (p + 1) * 3 W)
-    int32_t* gc = g_cnt + cnt_off[ci];                                 // partition p: counters [p * N, (p + 1) * N)
-    const int32_t* __restrict__ rk_of = rank_of + r0;
+    int32_t* gc = g_cnt + cnt_off[ci];                                 // partition p: counters [p * N, (p + 1) * N), indexed by RANK
     const int32_t* __restrict__ og_of = orig_of + r0;
-    const int32_t* __restrict__ rend = read_end + r0;
+    const int32_t* __restrict__ rend = read_end_by_rank + r0;
     auto tab = [&](int t, int w, int slot) -> unsigned long long& { return la_tab[((size_t)t * w_cap + w) * HS_LA_SLOTS + slot]; };
     if (W > w_cap || W > HS_LA_MAXW) { if (lane == 0) { failed[ci] = 1; n_parts[ci] = 0; } return; }
-    // slots: all free
     int slot_pid = -1;                 // lane = slot: the partition it holds (-1: free)
     S.birth[lane] = 0x7fffffff;
     wave_lds_sync();
@@ -131,61 +231,72 @@ __global__ __launch_bounds__(64) void k_loop_a(
             S.birth[s] = 0x7fffffff;
         }
     };
+    // the column in flight and the next one (loaded one column ahead)
+    // Everything of a column comes in with VECTOR loads (lane-dependent addresses) one column ahead: scalar loads share their
+    // counter with the LDS, and the first LDS access after them would wait for the whole prefetch.
+    struct Col { int recw, hdrw, endw, rc0, rc1; unsigned long long dw; };
+    auto load_col = [&](long long k) {
+        Col c;
+        c.recw = reinterpret_cast<const int*>(cand_rec)[k * 4 + (lane & 3)];      // lane 0: position, lane 3: k0 | k1 << 8 | ...
+        c.hdrw = reinterpret_cast<const int*>(col_hdr)[k * 16 + (lane & 15)];    // the 16 words of the LoopAColumn
+        c.endw = col_ends[2 * k + (lane & 1)];
+        c.rc0 = cand_row[k * 128 + lane];
+        c.rc1 = cand_row[k * 128 + 64 + lane];
+        c.dw = col_words[k * 64 + lane];
+        return c;
+    };
+    int last_pid = -1;         // the partition that took the previous column: its counters for this column's reads are fetched ahead
+    Col nxt;
+    nxt.recw = 0; nxt.hdrw = 0; nxt.endw = 0; nxt.rc0 = -1; nxt.rc1 = -1; nxt.dw = 0ull;
+    if (k0c < k1c) nxt = load_col(k0c);
     for (long long k = k0c; k < k1c && !fail; ++k) {
-        const hs_colrec_dev rec = cand_rec[k];
-        const int pos = rec.pos;
+        const Col cur = nxt;
+        if (k + 1 < k1c) nxt = load_col(k + 1);
+        const int pos = __builtin_amdgcn_readlane(cur.recw, 0);
         if (pos - last_position <= 5) continue;                  // (:592)
-        const int ref = (int)rec.k0;
-        const long long e0 = cand_ent_off[k];
-        const int n = (int)(cand_ent_off[k + 1] - e0);
-        const int32_t* __restrict__ idx = cand_idx + e0;
-        const uint8_t* __restrict__ code = cand_code + e0;
+        const int ref = __builtin_amdgcn_readlane(cur.recw, 3) & 255;
+        const int n = __builtin_amdgcn_readlane(cur.hdrw, 15) & 0xffff;
+        const int cur_i0 = __builtin_amdgcn_readlane(cur.endw, 0), cur_i1 = __builtin_amdgcn_readlane(cur.endw, 1);
+        if (n == 0 || n > 128) { fail = true; break; }
+        const int rc[2] = {cur.rc0, cur.rc1};
 #ifdef HS_LA_DIAG
         if (lane == 0) la_acc[8] += 1;
 #endif
-        // ---- the column's words and codes ----
-        int wlo = 0x7fffffff, whi = -1;
-        for (int base = 0; base < n; base += 64) {
-            const int e = base + lane;
-            const int w = e < n ? (rk_of[idx[e]] >> 6) : -1;
-            const int mn = -wave_max_i32(e < n ? -w : -0x7fffffff), mx = wave_max_i32(w);
-            wlo = mn < wlo ? mn : wlo; whi = mx > whi ? mx : whi;
+        int spec[2] = {0, 0};      // counters of `last_pid` for this column's reads: nearly always the partition that takes this column too
+        if (last_pid >= 0) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) if (rc[c] >= 0) spec[c] = __hip_atomic_load(gc + (long long)last_pid * N + (rc[c] >> 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const int ww = whi - wlo + 1;
+        // ---- the column's words and codes: made ahead by k_loop_a_prepare ----
+        const int wlo = __builtin_amdgcn_readlane(cur.hdrw, 0);
+        const int h1 = __builtin_amdgcn_readlane(cur.hdrw, 1), h2 = __builtin_amdgcn_readlane(cur.hdrw, 2);
+        const int ww = (int)(short)(h1 & 0xffff), nslots = (int)(short)(h1 >> 16), ref_slot = (int)(short)(h2 & 0xffff);
+        const bool fast_col = (h2 >> 16) != 0;
+        const unsigned long long dw = cur.dw;      // fast column: word w of `any` in lane w, of code slot q in lane 4 (q + 1) + w
+        // lane q: the code of slot q (first-appearance order) and its count, out of the header words 3..6 / 7..14
+        const int codes_w = __shfl(cur.hdrw, 3 + ((lane & 15) >> 2), 64), cnts_w = __shfl(cur.hdrw, 7 + ((lane & 15) >> 1), 64);
+        const int cur_scode = (codes_w >> (8 * (lane & 3))) & 255, cur_scnt = (cnts_w >> (16 * (lane & 1))) & 0xffff;
+        const int slot_code = lane < nslots ? cur_scode : -1;
         HS_LA_T(0);
-        if (n == 0 || ww > HS_LA_WIN) { fail = true; break; }
-        for (int x = lane; x < HS_LA_CODES * HS_LA_WIN; x += 64) (&S.cb[0][0])[x] = 0ull;
-        if (lane < HS_LA_WIN) S.any[lane] = 0ull;
-        wave_lds_sync();
-        int nslots = 0, ref_slot = -1;
-        for (int base = 0; base < n && !fail; base += 64) {
-            const int e = base + lane;
-            const bool valid = e < n;
-            const int cd = valid ? (int)code[e] : -1;
-            const int rk = valid ? rk_of[idx[e]] : 0;
-            unsigned long long rem = __ballot(valid);
-            while (rem) {
-                const int X = __builtin_amdgcn_readlane(cd, __builtin_ctzll(rem));
-                const unsigned long long mX = __ballot(cd == X);
-                rem &= ~mX;
-                int ks = -1;
-                for (int q = 0; q < nslots; ++q) if (S.code_of[q] == X) ks = q;      // (uniform: a handful of codes)
-                if (ks < 0) {
-                    if (nslots == HS_LA_CODES) { fail = true; break; }
-                    ks = nslots++;
-                    if (lane == 0) { S.code_of[ks] = X; S.cnt_of[ks] = 0; }
-                    if (X == ref) ref_slot = ks;
-                }
-                if (lane == 0) S.cnt_of[ks] += __popcll(mX);
-                if (cd == X) {
+        if (ww < 0 || ww > HS_LA_WIN) { fail = true; break; }     // (too many codes / too deep / spread too wide: the host's)
+        if (lane < HS_LA_CODES) { S.code_of[lane] = slot_code; S.cnt_of[lane] = cur_scnt; }
+        if (!fast_col) {
+            // the unusual column (more than four words): its bit sets into LDS here
+            for (int x = lane; x < HS_LA_CODES * HS_LA_WIN; x += 64) (&S.cb[0][0])[x] = 0ull;
+            if (lane < HS_LA_WIN) S.any[lane] = 0ull;
+            wave_lds_sync();
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (rc[c] >= 0) {
+                    const int cd = rc[c] & 255, rk = rc[c] >> 8;
+                    int ks = -1;
+                    for (int q = 0; q < nslots; ++q) if (__builtin_amdgcn_readlane(cur_scode, q) == cd) ks = q;
                     const unsigned long long bit = 1ull << (rk & 63);
                     atomicOr(&S.cb[ks][(rk >> 6) - wlo], bit);
                     atomicOr(&S.any[(rk >> 6) - wlo], bit);
                 }
-                wave_lds_sync();
             }
         }
-        if (fail) break;
         wave_lds_sync();
         HS_LA_T(1);
         // ---- the live partitions against the column: lanes = slots ----
@@ -199,7 +310,59 @@ __global__ __launch_bounds__(64) void k_loop_a(
         int n00 = 0, n01 = 0, n10 = 0, n11 = 0;
         bool need_exact = false;
         int best = -1, nbest = 0, best_slot = -1, shared = 0;
-        if (elig) {
+        auto rl64 = [&](unsigned long long v, int l) -> unsigned long long {      // v_readlane of a 64-bit value (l wave-uniform)
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), l);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+            return ((unsigned long long)hi << 32) | lo;
+        };
+        if (fast_col) {
+            // the usual column: its (at most four) words of the lane's partition in registers, the words of the column's codes out of
+            // the lanes of `dw` as scalars: every count is ANDs and popcounts on registers
+            unsigned long long pr[HS_LA_FAST], pl[HS_LA_FAST], mi[HS_LA_FAST], an[HS_LA_FAST];
+#pragma unroll
+            for (int w = 0; w < HS_LA_FAST; ++w) {
+                const bool in = w < ww && elig;
+                const int ws = in ? wlo + w : 0;
+                pr[w] = tab(0, ws, lane); pl[w] = tab(1, ws, lane); mi[w] = tab(2, ws, lane); an[w] = rl64(dw, w);
+                if (!in) { pr[w] = 0ull; pl[w] = 0ull; mi[w] = 0ull; }
+            }
+            int decided = 0;
+#pragma unroll
+            for (int w = 0; w < HS_LA_FAST; ++w) { shared += __popcll(an[w] & pr[w]); decided += __popcll(an[w] & (pl[w] | mi[w])); }
+            const bool skip = !elig || shared == 0 || (shared <= 14 && (unsigned)shared < (unsigned)n / 2u) || (decided <= 14 && (unsigned)decided < (unsigned)n / 2u);
+            if (__ballot(!skip) != 0ull) {
+                for (int q = 0; q < nslots; ++q) {
+                    if (q == ref_slot) continue;
+                    int c = 0;
+#pragma unroll
+                    for (int w = 0; w < HS_LA_FAST; ++w) c += __popcll(rl64(dw, 4 * (q + 1) + w) & pr[w]);
+                    if (c > 0) { if (c > best) { best = c; nbest = 1; best_slot = q; } else if (c == best) nbest++; }
+                }
+                if (skip) { best_slot = -1; nbest = 0; }
+                else if (ref >= 128 || nbest > 1) need_exact = true;
+                else {
+                    if (ref_slot >= 0) {
+#pragma unroll
+                        for (int w = 0; w < HS_LA_FAST; ++w) { const unsigned long long x = rl64(dw, 4 * (ref_slot + 1) + w); n11 += __popcll(x & pl[w]); n01 += __popcll(x & mi[w]); }
+                    }
+                }
+                // the words of the lane's own second allele: a gather across the lanes of `dw`
+                const bool want = !skip && !need_exact && best_slot >= 0;
+#pragma unroll
+                for (int w = 0; w < HS_LA_FAST; ++w) {
+                    const int src = want ? 4 * (best_slot + 1) + w : 0;
+                    const unsigned lo = (unsigned)__shfl((int)(unsigned)(dw & 0xffffffffull), src, 64), hi = (unsigned)__shfl((int)(unsigned)(dw >> 32), src, 64);
+                    const unsigned long long x = want ? (((unsigned long long)hi << 32) | lo) : 0ull;
+                    n10 += __popcll(x & pl[w]); n00 += __popcll(x & mi[w]);
+                }
+            }
+            if (__ballot(need_exact) != 0ull) {      // the tie order needs the column's bit sets where the general form reads them
+                S.any[lane & 15] = 0ull;
+                if (lane < 4) S.any[lane] = dw;
+                else (&S.cb[0][0])[((lane >> 2) - 1) * HS_LA_WIN + (lane & 3)] = dw;
+                wave_lds_sync();
+            }
+        } else if (elig) {
             int decided = 0;
             for (int w = 0; w < ww; ++w) {
                 const unsigned long long a = S.any[w];
@@ -284,7 +447,7 @@ __global__ __launch_bounds__(64) void k_loop_a(
         const double dc = (double)comparable;
         bool corr = false;
         if (elig && (double)(n00 + n01) > 0.1 * dc && (double)(n00 + n01) < 0.9 * dc && (double)(n01 + n11) > 0.1 * dc && (double)(n01 + n11) < 0.9 * dc)
-            corr = chi_square_la(n00, n01, n10, n11) > 15;
+            corr = chi_square_gt15(n00, n01, n10, n11);
         const bool enough = (unsigned long long)comparable >= (unsigned long long)n / 2ull;
         const double m0 = 0.1 * (double)(n00 + n01), m1 = 0.1 * (double)(n11 + n10);
         const double t0 = m0 > 1.0 ? m0 : 1.0, t1 = m1 > 1.0 ? m1 : 1.0;      // std::max(x, 1.0)
@@ -297,8 +460,7 @@ __global__ __launch_bounds__(64) void k_loop_a(
         if (counts) S.n_corr[lane] += 1;
         const int n_corr_col = __popcll(__ballot(counts));
         const unsigned long long Fm = __ballot(fit && my_birth == fit_birth);
-        // the dead slots go to the pool now (they are complete) -- only when room is needed or at the end would do as well, but a
-        // freed slot is one comparison less for every later column
+        // the dead slots go to the pool now (they are complete): a freed slot is one comparison less for every later column
         unsigned long long D = __ballot(dead);
         while (D) { const int s = __builtin_ctzll(D); D &= D - 1ull; const int pid = __builtin_amdgcn_readlane(slot_pid, s); evict(s, pid); if (lane == s) slot_pid = -1; }
         wave_lds_sync();
@@ -313,58 +475,53 @@ __global__ __launch_bounds__(64) void k_loop_a(
             if (lane == 0) { if (pos < S.left[f] || S.left[f] == -1) S.left[f] = pos; if (pos > S.right[f]) S.right[f] = pos; }
             if (f_shared != 0) {
                 int nA = 0, na = 0;
-                for (int base = 0; base < n; base += 64) {
-                    const int e = base + lane;
-                    const int cd = e < n ? (int)code[e] : -1;
-                    const bool isA = e < n && cd == ref, isa = e < n && cd == second && !isA;
-                    nA += __popcll(__ballot(isA)); na += __popcll(__ballot(isa));
+                bool isA[2], isa[2], pr_[2];
+                int st_[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const bool v = rc[c] >= 0;
+                    const int cd = rc[c] & 255, rk = rc[c] >> 8;
+                    isA[c] = v && cd == ref; isa[c] = v && cd == second && !isA[c];
+                    nA += __popcll(__ballot(isA[c])); na += __popcll(__ballot(isa[c]));
+                    const int w = v ? rk >> 6 : 0;
+                    const unsigned long long bit = 1ull << (rk & 63);
+                    pr_[c] = v && (tab(0, w, f) & bit) != 0ull;
+                    st_[c] = (tab(1, w, f) & bit) ? 1 : ((tab(2, w, f) & bit) ? -1 : 0);
                 }
                 int vA, va;                                   // the two most frequent characters of the recoded column, the lowest wins ties (:261-280)
                 if (nA == 0 && na == 0) { vA = 0; va = 0; }
                 else if (nA >= na) { vA = 1; va = na > 0 ? -1 : 0; }
                 else { va = 1; vA = nA > 0 ? -1 : 0; }
                 int swapped = 0;                              // phase vote over the shared reads (:284-314)
-                for (int base = 0; base < n; base += 64) {
-                    const int e = base + lane;
-                    int t = 0;
-                    if (e < n) {
-                        const int cd = (int)code[e];
-                        const bool isA = cd == ref, isa = cd == second && !isA;
-                        const int rk = rk_of[idx[e]];
-                        const unsigned long long bit = 1ull << (rk & 63);
-                        const bool pr = (tab(0, rk >> 6, f) & bit) != 0ull;
-                        const int st = (tab(1, rk >> 6, f) & bit) ? 1 : ((tab(2, rk >> 6, f) & bit) ? -1 : 0);
-                        const int v = isA ? vA : (isa ? va : 0);
-                        t = pr ? v * st : 0;
-                    }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int v = isA[c] ? vA : (isa[c] ? va : 0);
+                    const int t = pr_[c] ? v * st_[c] : 0;
                     swapped += __popcll(__ballot(t == 1)) - __popcll(__ballot(t == -1));
                 }
                 if (swapped < 0) { vA = -vA; va = -va; }
                 int reach_l = -1;
-                for (int base = 0; base < n; base += 64) {   // element-wise form of the sorted merge (:322-390)
-                    const int e = base + lane;
-                    if (e < n) {
-                        const int r = idx[e];
-                        const int cd = (int)code[e];
-                        const bool isA = cd == ref, isa = cd == second && !isA;
-                        const int s = isA ? vA : (isa ? va : 0);
-                        const int rk = rk_of[r];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {                 // element-wise form of the sorted merge (:322-390)
+                    if (rc[c] >= 0) {
+                        const int s = isA[c] ? vA : (isa[c] ? va : 0);
+                        const int rk = rc[c] >> 8;
                         const int w = rk >> 6;
                         const unsigned long long bit = 1ull << (rk & 63);
-                        const bool pr = (tab(0, w, f) & bit) != 0ull;
-                        const int st = (tab(1, w, f) & bit) ? 1 : ((tab(2, w, f) & bit) ? -1 : 0);
-                        int32_t* cp = gc + (long long)pid * N + r;      // (agent-scope accesses: served by L2, another lane's earlier store is seen)
+                        const bool pr = pr_[c];
+                        const int st = st_[c];
+                        int32_t* cp = gc + (long long)pid * N + rk;      // (agent-scope accesses: served by L2, another lane's earlier store is seen)
                         int new_st = st;
                         bool change = false;
                         if (!pr) {
                             new_st = s; change = true;
                             __hip_atomic_store(cp, s < 0 ? -s : s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // more = |s|, less = 0
-                            reach_l = rend[r] > reach_l ? rend[r] : reach_l;
+                            reach_l = rend[rk] > reach_l ? rend[rk] : reach_l;
                         } else if (s == 0) {
                         } else if (st == 0) { new_st = s; change = true; __hip_atomic_store(cp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                         else if (s == st) { atomicAdd(cp, 1); }
                         else {
-                            const int v = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const int v = pid == last_pid ? spec[c] : __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             const int mo = v & 0xffff, le = (v >> 16) & 0xffff;
                             if (le + 1 > mo) { new_st = -st; change = true; __hip_atomic_store(cp, (mo + 1) | (le << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                             else __hip_atomic_store(cp, mo | ((le + 1) << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -380,13 +537,13 @@ __global__ __launch_bounds__(64) void k_loop_a(
                 reach_l = wave_max_i32(reach_l);
                 if (lane == 0) {
                     if (reach_l > S.reach[f]) S.reach[f] = reach_l;
-                    const int i0 = idx[0], i1 = idx[n - 1];
-                    if (S.hi[f] < S.lo[f]) { S.lo[f] = i0; S.hi[f] = i1; } else { if (i0 < S.lo[f]) S.lo[f] = i0; if (i1 > S.hi[f]) S.hi[f] = i1; }
+                    if (S.hi[f] < S.lo[f]) { S.lo[f] = cur_i0; S.hi[f] = cur_i1; } else { if (cur_i0 < S.lo[f]) S.lo[f] = cur_i0; if (cur_i1 > S.hi[f]) S.hi[f] = cur_i1; }
                     S.n_occ[f] += 1;
                     if (S.n_occ[f] >= 65535) S.n_occ[f] = -1;      // (the 16-bit counters would wrap: reported below)
                 }
             }
             last_position = pos;
+            last_pid = pid;
             wave_lds_sync();
             HS_LA_T(5);
             if (S.n_occ[f] < 0) { fail = true; break; }
@@ -420,26 +577,25 @@ __global__ __launch_bounds__(64) void k_loop_a(
             for (long long x = lane; x < N; x += 64) __hip_atomic_store(gc + (long long)pid * N + x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             wave_lds_sync();
             int reach_l = -1;
-            for (int base = 0; base < n; base += 64) {
-                const int e = base + lane;
-                if (e < n) {
-                    const int r = idx[e];
-                    const int cd = (int)code[e];
-                    const int rk = rk_of[r];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (rc[c] >= 0) {
+                    const int cd = rc[c] & 255, rk = rc[c] >> 8;
                     const unsigned long long bit = 1ull << (rk & 63);
                     atomicOr(&tab(0, rk >> 6, s), bit);
                     if (cd == ref) atomicOr(&tab(1, rk >> 6, s), bit);
                     else if (cd == second) atomicOr(&tab(2, rk >> 6, s), bit);
-                    __hip_atomic_store(gc + (long long)pid * N + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    reach_l = rend[r] > reach_l ? rend[r] : reach_l;
+                    __hip_atomic_store(gc + (long long)pid * N + rk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    reach_l = rend[rk] > reach_l ? rend[rk] : reach_l;
                 }
             }
             reach_l = wave_max_i32(reach_l);
             if (lane == 0) {
                 S.left[s] = pos; S.right[s] = pos; S.n_occ[s] = 1; S.n_corr[s] = n_corr_col; S.reach[s] = reach_l;
-                S.lo[s] = idx[0]; S.hi[s] = idx[n - 1]; S.birth[s] = pid;
+                S.lo[s] = cur_i0; S.hi[s] = cur_i1; S.birth[s] = pid;
             }
             if (lane == s) slot_pid = pid;
+            last_pid = pid;
             wave_lds_sync();
             HS_LA_T(6);
         }
@@ -456,7 +612,6 @@ __global__ __launch_bounds__(64) void k_loop_a(
     (void)diag;
 #endif
 }
-
 
 // part_base[c] = partitions of the contigs before c (contig order)
 __global__ __launch_bounds__(64) void k_loop_a_scan(const int32_t* __restrict__ n_parts, int c_count, int64_t* __restrict__ part_base /* [C+1] */) {
