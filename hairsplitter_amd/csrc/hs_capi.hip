@@ -2527,20 +2527,27 @@ int hs_sr_run(const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_siz
     R->win_end = (int32_t*)std::malloc((size_t)std::max<int64_t>(1, W) * sizeof(int32_t));
     R->label_off = (int64_t*)std::malloc(((size_t)W + 1) * sizeof(int64_t));
     R->labels = hs::sr_labels_alloc((size_t)NL);
+    // contig order: where every contig's windows and labels go (prefix sums over the contigs), then the copies on all host threads
     R->win_off[0] = 0; R->label_off[0] = 0;
-    int64_t w0 = 0;
+    std::vector<int64_t> lab0((size_t)n_contigs + 1, 0);
     for (int c = 0; c < n_contigs; ++c) {
         const hs_sr_result* r = parts[(size_t)where[(size_t)c].first];
         const int i = where[(size_t)c].second;
-        for (int64_t q = r->win_off[i]; q < r->win_off[i + 1]; ++q) {
-            R->win_start[w0] = r->win_start[q]; R->win_end[w0] = r->win_end[q];
-            const int64_t n = r->label_off[q + 1] - r->label_off[q];
-            std::memcpy(R->labels + R->label_off[w0], r->labels + r->label_off[q], (size_t)n * sizeof(int32_t));
-            R->label_off[w0 + 1] = R->label_off[w0] + n;
-            w0++;
-        }
-        R->win_off[c + 1] = w0;
+        R->win_off[c + 1] = R->win_off[c] + (r->win_off[i + 1] - r->win_off[i]);
+        lab0[(size_t)c + 1] = lab0[(size_t)c] + (r->label_off[r->win_off[i + 1]] - r->label_off[r->win_off[i]]);
     }
+    R->label_off[W] = NL;
+    hs::hs_parallel_for(n_contigs, host_threads(), [&](int c) {
+        const hs_sr_result* r = parts[(size_t)where[(size_t)c].first];
+        const int i = where[(size_t)c].second;
+        const int64_t q0 = r->win_off[i], nq = r->win_off[i + 1] - q0, w0 = R->win_off[c];
+        if (nq == 0) return;
+        std::memcpy(R->win_start + w0, r->win_start + q0, (size_t)nq * sizeof(int32_t));
+        std::memcpy(R->win_end + w0, r->win_end + q0, (size_t)nq * sizeof(int32_t));
+        const int64_t shift = lab0[(size_t)c] - r->label_off[q0];
+        for (int64_t q = 0; q < nq; ++q) R->label_off[w0 + q] = r->label_off[q0 + q] + shift;
+        std::memcpy(R->labels + lab0[(size_t)c], r->labels + r->label_off[q0], (size_t)(r->label_off[q0 + nq] - r->label_off[q0]) * sizeof(int32_t));
+    });
     for (hs_sr_result* r : parts) {
         R->t_device_ms += r->t_device_ms; R->t_host_ms += r->t_host_ms; R->n_cw_instances += r->n_cw_instances;
         for (int k = 0; k < 4; ++k) R->t_kernel_ms[k] += r->t_kernel_ms[k];
@@ -2643,25 +2650,35 @@ int hs_cv_run_host(const uint8_t* h_contig_seq, const int64_t* h_contig_off, int
     R->col_off = (int64_t*)std::malloc(((size_t)S + 1) * sizeof(int64_t));
     R->col_idx = (int32_t*)std::malloc(std::max<int64_t>(1, E) * sizeof(int32_t));
     R->col_code = (uint8_t*)std::malloc(std::max<int64_t>(1, E));
+    // contig order: where every contig's SNPs and column entries go (prefix sums over the contigs), then the copies on all host threads
     R->snp_off[0] = 0; R->col_off[0] = 0;
-    int64_t s0 = 0;
+    std::vector<int64_t> ent0((size_t)n_contigs + 1, 0);
     float total_error = 0; int n_err = 0;
     for (int c = 0; c < n_contigs; ++c) {
         const hs_cv_result* r = parts[(size_t)where[(size_t)c].first];
         const int i = where[(size_t)c].second;
         R->mean_distance[c] = r->mean_distance[i]; R->depth[c] = r->depth[i];
         if (r->mean_distance[i] > 0) { total_error += r->mean_distance[i]; n_err++; }      // call_variants.cpp:1312-1315, contig order
-        for (int64_t q = r->snp_off[i]; q < r->snp_off[i + 1]; ++q) {
-            R->snp_pos[s0] = r->snp_pos[q]; R->snp_ref[s0] = r->snp_ref[q]; R->snp_alt[s0] = r->snp_alt[q];
-            R->snp_n_ref[s0] = r->snp_n_ref[q]; R->snp_n_alt[s0] = r->snp_n_alt[q];
-            const int64_t n = r->col_off[q + 1] - r->col_off[q];
-            std::memcpy(R->col_idx + R->col_off[s0], r->col_idx + r->col_off[q], (size_t)n * sizeof(int32_t));
-            std::memcpy(R->col_code + R->col_off[s0], r->col_code + r->col_off[q], (size_t)n);
-            R->col_off[s0 + 1] = R->col_off[s0] + n;
-            s0++;
-        }
-        R->snp_off[c + 1] = s0;
+        R->snp_off[c + 1] = R->snp_off[c] + (r->snp_off[i + 1] - r->snp_off[i]);
+        ent0[(size_t)c + 1] = ent0[(size_t)c] + (r->col_off[r->snp_off[i + 1]] - r->col_off[r->snp_off[i]]);
     }
+    R->col_off[S] = E;
+    hs::hs_parallel_for(n_contigs, host_threads(), [&](int c) {
+        const hs_cv_result* r = parts[(size_t)where[(size_t)c].first];
+        const int i = where[(size_t)c].second;
+        const int64_t q0 = r->snp_off[i], nq = r->snp_off[i + 1] - q0, s0 = R->snp_off[c];
+        if (nq == 0) return;
+        std::memcpy(R->snp_pos + s0, r->snp_pos + q0, (size_t)nq * sizeof(int32_t));
+        std::memcpy(R->snp_ref + s0, r->snp_ref + q0, (size_t)nq);
+        std::memcpy(R->snp_alt + s0, r->snp_alt + q0, (size_t)nq);
+        std::memcpy(R->snp_n_ref + s0, r->snp_n_ref + q0, (size_t)nq * sizeof(int32_t));
+        std::memcpy(R->snp_n_alt + s0, r->snp_n_alt + q0, (size_t)nq * sizeof(int32_t));
+        const int64_t shift = ent0[(size_t)c] - r->col_off[q0];
+        for (int64_t q = 0; q < nq; ++q) R->col_off[s0 + q] = r->col_off[q0 + q] + shift;
+        const int64_t ne = r->col_off[q0 + nq] - r->col_off[q0];
+        std::memcpy(R->col_idx + ent0[(size_t)c], r->col_idx + r->col_off[q0], (size_t)ne * sizeof(int32_t));
+        std::memcpy(R->col_code + ent0[(size_t)c], r->col_code + r->col_off[q0], (size_t)ne);
+    });
     R->error_rate = total_error / n_err; R->n_contigs_with_error_rate = n_err;
     for (hs_cv_result* r : parts) {
         R->t_device_ms += r->t_device_ms; R->t_host_ms += r->t_host_ms;
