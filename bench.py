@@ -177,9 +177,17 @@ def main():
     ap.add_argument("--no-f2f-reference-full", action="store_true", help="do not time the reference on the files of the whole job (C4: ~40 s); a sample of the job instead")
     ap.add_argument("--f2f-runs", type=int, default=2)
     ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--as-rank-of", type=int, default=0, help="readiness check without a node: run rank 0's LPT shard of an N-rank job on this one GPU with the "
+                    "host threads / groups a rank of N gets (the line says so in config.emulated_rank_of; `value` is this ONE rank's rate)")
+    ap.add_argument("--cores", type=int, default=0, help="pin the process to this many CPUs before anything starts (with --as-rank-of: the share of the host one rank has)")
     args = ap.parse_args()
 
     rank_env, world_env = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if args.cores > 0:
+        os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:args.cores])
+    emulated = args.as_rank_of if (args.as_rank_of > 1 and world_env == 1) else 0
+    if emulated:
+        world_env = emulated      # shard, threads and groups as rank 0 of that many; one process, no collective
     cfg = args.config
     n_job = args.contigs or {"C2": 256, "C3": 50, "C4": 500, "C5": 34}[cfg]
     from hairsplitter_amd import synth, dist as hdist
@@ -190,12 +198,12 @@ def main():
     # job's three input files for the file-to-file leg ----
     shards = hdist.lpt_shards([float(s[0] * s[2]) for s in shapes], world_env)
     my_ids = shards[rank_env]
-    want_f2f = world_env == 1 and args.cpu_contigs != 0
+    want_f2f = world_env == 1 and args.cpu_contigs != 0      # (never for an emulated rank)
     job_dir = tempfile.mkdtemp(prefix="hs_bench_job_") if (want_f2f and not args.no_f2f_job) else None
     t_gen = time.perf_counter()
     # HS_BENCH_SERIAL_SETUP=1: no forked workers (under `rocprofv3 --pmc` the profiler has initialised the GPU before this program
     # starts, and a fork from such a process hangs on this pool: tools/pmc_traffic.sh sets it)
-    gen_workers = 1 if os.environ.get("HS_BENCH_SERIAL_SETUP") else max(1, min(8, effective_cores() // world_env))
+    gen_workers = 1 if os.environ.get("HS_BENCH_SERIAL_SETUP") else max(1, min(8, effective_cores() // (1 if emulated else world_env)))
     contigs, job_files = synth.generate_job(cfg, my_ids, seed=args.seed, workers=gen_workers, outdir=job_dir)
     t_gen = time.perf_counter() - t_gen
     # the files of the file-to-file sample too, NOW: forking workers from a process that has initialised the GPU (runtime threads,
@@ -226,7 +234,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = emulated or int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # launched by torch.distributed.run
     if use_dist:
         torch.cuda.set_device(local_rank)
@@ -240,7 +248,7 @@ def main():
     api.load().hs_set_device(local_rank)
     # host threads for the sequential glue: the parallel sections are short, and waking hundreds of workers on a busy
     # box costs more than it buys (measured: 256 threads -> 15-60 ms steps, 64 threads -> 11.6 ms steps)
-    n_threads = args.threads or max(1, min(64, (3 * effective_cores()) // world))      # (16 usable cores: 32 threads 46 ms per step, 48: 44, 64: 47, 128: 51)
+    n_threads = args.threads or max(1, min(64, (3 * effective_cores()) // (1 if args.cores > 0 else world)))      # (16 usable cores: 32 threads 46 ms per step, 48: 44, 64: 47, 128: 51)
 
     B = len(contigs)
     G = max(1, min(args.groups if args.groups > 0 else min(8, max(1, n_threads // 4)), max(B, 1)))
@@ -372,7 +380,7 @@ def main():
                  "note": "rank 0's shard; m = masked reads of the window (the kernels work in the window's local index space), not the N reads of the contig"}
         out = {
             "metric": "aligned read-bp/sec through call_variants+separate_reads",
-            "value": total_bp * K / dt, "unit": "aligned read-bp/s", "n_gpus": world, "steps": K, "warmup": args.warmup, "setup_steps": SETUP_STEPS,
+            "value": total_bp * K / dt, "unit": "aligned read-bp/s", "n_gpus": 1 if emulated else world, "steps": K, "warmup": args.warmup, "setup_steps": SETUP_STEPS,
             "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "host": {"cpus_online": os.cpu_count(), "cpus_effective": effective_cores(), "process_cpu_ms_per_step": cpu_ms_per_step,
@@ -386,6 +394,8 @@ def main():
             "config": {"workload": WORKLOADS[cfg].format(n=n_job) + "; the whole job per step, inputs resident in HBM",
                        "config": cfg, "contigs": n_job, "aligned_bp": total_bp, "contigs_rank0": B, "aligned_bp_rank0": int(local_bp),
                        "parallelism": f"contigs sharded over {world} GPU(s) by LPT on contig length", "groups_per_gpu": G,
+                       **({"emulated_rank_of": emulated, "cores_pinned": args.cores or None,
+                           "note": "ONE rank of an %d-rank job on one GPU (its LPT shard, its threads and groups): a readiness check, not a scaling measurement" % emulated} if emulated else {}),
                        "host_threads_per_rank": n_threads},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": d["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": d["avg_launch_ms"],

@@ -1240,7 +1240,7 @@ struct HipCvOps : hs::CvDeviceOps {
             if (int rc = range_scratch.prepare(nt * 256)) return rc;
             if (int rc = grow(d_tile_ent_sum, (size_t)nt * 4)) return rc;
             if (int rc = grow(d_tile_ebase, ((size_t)nt + 1) * 8)) return rc;
-            HS_HIP(hipMemsetAsync(d_info.p, 0, 128, stream));
+            HS_HIP(hipMemsetAsync(d_info.p, 0, 128 + (size_t)C * 4, stream));      // (header, tie counters, candidates per contig)
             HS_HIP(hipEventRecord(e_k2.a, stream));
             if (int rc = kc.begin(HS_K_COLUMN_STATS, stream)) return rc;
             hipEvent_t k2_done = nullptr;
@@ -1303,7 +1303,7 @@ struct HipCvOps : hs::CvDeviceOps {
             if (int rc = kc.end(n_entries + 16 * n_cols, stream)) return rc;
         }
         if (int rc = kc.begin(HS_K_CANDIDATES_SCAN, stream)) return rc;
-        hipLaunchKernelGGL(hsdev::k_candidates_scan, dim3((unsigned)C), dim3(64), 0, stream, d_col_gpos.as<int64_t>(), dev_header(),
+        hipLaunchKernelGGL(hsdev::k_candidates_scan, dim3((unsigned)((std::max<int64_t>(n_cols, C) + 255) / 256)), dim3(256), 0, stream, d_col_gpos.as<int64_t>(), dev_header(),
                            b->d_contig_off.as<int64_t>(), c0, C, d_min_reads.as<int32_t>(), thr, d_col_rec.as<hsdev::hs_colrec_dev>(), d_col_ctg.as<int32_t>(),
                            d_k0.as<uint8_t>(), d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), d_ctg_col_off.as<int64_t>(), dev_ctg_n());
         HS_HIP(hipGetLastError());

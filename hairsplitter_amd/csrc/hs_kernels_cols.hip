@@ -250,54 +250,83 @@ static __device__ __forceinline__ bool central_base_test_cols(int k0, int k1) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// V1: the candidate and the "automatic" columns of every contig of the range (call_variants.cpp:525-536). One wavefront per
-// contig; 64 columns per step, lanes test the position-independent part, the greedy "more than five positions after the last
-// candidate" runs along the lanes that pass (a handful per step). Also splits the record into the arrays K4 reads.
+// V1: the candidate and the "automatic" columns of every contig of the range (call_variants.cpp:525-536). One thread per
+// column. The reference walks a contig's positions and takes a column that passes the predicate when it lies more than five
+// positions after the last one it took (posoflastvariant starts at -5, so position 0 is never taken). A passing column with no
+// passing column in the five positions before it is therefore always taken, whatever happened earlier: the dependency only
+// runs along a CHAIN of passing columns each within five positions of the one before. A thread whose column passes walks back
+// to the head of its chain (nearly always itself) and replays the greedy rule from there. Also splits the record into the
+// arrays K4 reads, finds every contig's first column (threads 0..c_count of the launch) and counts the candidates per contig
+// (contig_n_cand zeroed by the caller).
+// The record is rewritten in place while neighbours may read it: everything the predicate reads (counts, codes, the
+// HS_COL_C1GT5C2 bit, position, contig) is written back unchanged.
 // min_reads[c] = 3 or 5 (:463-466, from the contig's mean distance); thr = automatic_snp_threshold.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_candidates_scan(
+__global__ __launch_bounds__(256) void k_candidates_scan(
     const int64_t* __restrict__ col_gpos, const ColumnsHeader* __restrict__ header, const int64_t* __restrict__ contig_off, int c_first, int c_count,
-    const int32_t* __restrict__ min_reads /* [c_count] */, float thr, hs_colrec_dev* __restrict__ col_rec,
+    const int32_t* __restrict__ min_reads /* [c_count] */, float thr, hs_colrec_dev* col_rec,
     int32_t* __restrict__ col_contig_local, uint8_t* __restrict__ col_k0, uint8_t* __restrict__ col_k1, int32_t* __restrict__ col_c1, uint8_t* __restrict__ col_is_cand,
-    int64_t* __restrict__ contig_col_off /* [c_count + 1] */, int32_t* __restrict__ contig_n_cand /* [c_count] */) {
-    const int lane = lane_id();
-    const int ci = (int)blockIdx.x;
-    if (ci >= c_count) return;
+    int64_t* __restrict__ contig_col_off /* [c_count + 1] */, int32_t* contig_n_cand /* [c_count], zeroed */) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t n_cols = header->n_cols;
-    // the contig's columns: [s0, s1) by bisection of its global position range in the sorted list
-    auto lower = [&](int64_t g) { int64_t lo = 0, hi = n_cols; while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (col_gpos[mid] < g) lo = mid + 1; else hi = mid; } return lo; };
-    const int64_t s0 = lower(contig_off[c_first + ci]), s1 = lower(contig_off[c_first + ci + 1]);
-    if (lane == 0) { contig_col_off[ci] = s0; if (ci == c_count - 1) contig_col_off[c_count] = s1; }
-    const int mr = min_reads[ci];
-    int pos_of_last = -5, n_cand = 0;
-    hs_colrec_dev r_next;      // the next 64 records are on their way while these 64 are decided
-    r_next.pos = 0; r_next.contig = 0; r_next.c0 = r_next.c1 = 0; r_next.k0 = r_next.k1 = 0; r_next.flags = 0; r_next.c2_zero = 0;
-    if (s0 + lane < s1) r_next = col_rec[s0 + lane];
-    for (int64_t sb = s0; sb < s1; sb += 64) {
-        const int64_t k = sb + lane;
-        hs_colrec_dev r = r_next;
-        if (k + 64 < s1) r_next = col_rec[k + 64];
-        bool pass = false;
-        if (k < s1) pass = (int)r.c1 > mr && (r.flags & HS_COL_C1GT5C2) && central_base_test_cols(r.k0, r.k1);
-        unsigned long long m = __ballot(pass);
-        unsigned long long accepted = 0ull;
-        while (m) {
-            const int l = __builtin_ctzll(m); m &= m - 1ull;
-            const int p = __builtin_amdgcn_readlane(r.pos, l);
-            if (p - pos_of_last > 5) { accepted |= 1ull << l; pos_of_last = p; }
-        }
-        if (k < s1) {
-            const bool cand = (accepted >> lane) & 1ull;
-            uint8_t f = r.flags & (HS_COL_TIE);
-            if (cand) { f |= HS_COL_CAND; if ((float)r.c1 > thr * (float)r.c0) f |= HS_COL_AUTO; }
-            if ((int)r.c1 >= 5 && central_base_test_cols(r.k0, r.k1)) f |= HS_COL_LOOPD;
-            r.flags = f;
-            col_rec[k] = r;
-            col_contig_local[k] = ci; col_k0[k] = r.k0; col_k1[k] = r.k1; col_c1[k] = r.c1; col_is_cand[k] = cand ? 1 : 0;
-        }
-        n_cand += __popcll(accepted);
+    if (k < c_count) {
+        // the contig's columns start at the first one at or after its global offset in the sorted list
+        auto lower = [&](int64_t g) { int64_t lo = 0, hi = n_cols; while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (col_gpos[mid] < g) lo = mid + 1; else hi = mid; } return lo; };
+        contig_col_off[k] = lower(contig_off[c_first + k]);
+        if (k == c_count - 1) contig_col_off[c_count] = lower(contig_off[c_first + c_count]);
     }
-    if (lane == 0) contig_n_cand[ci] = n_cand;
+    bool cand = false;
+    int ci = -1;
+    if (k < n_cols) {
+        const int4* recs = reinterpret_cast<const int4*>(col_rec);
+        auto unpack = [](const int4 v) { hs_colrec_dev r; __builtin_memcpy(&r, &v, 16); return r; };
+        hs_colrec_dev r = unpack(recs[k]);
+        ci = r.contig - c_first;
+        const int mr = min_reads[ci];
+        auto passes = [&](const hs_colrec_dev& q) {
+            return q.pos > 0 && (int)q.c1 > mr && (q.flags & HS_COL_C1GT5C2) && central_base_test_cols(q.k0, q.k1);
+        };
+        if (passes(r)) {
+            // back to the head of the chain
+            int64_t h = k;
+            int pos_h = r.pos;
+            for (;;) {
+                int64_t q = h - 1;
+                bool linked = false;
+                while (q >= 0) {
+                    const hs_colrec_dev rq = unpack(recs[q]);
+                    if (rq.contig != r.contig || pos_h - rq.pos > 5) break;
+                    if (passes(rq)) { h = q; pos_h = rq.pos; linked = true; break; }
+                    --q;
+                }
+                if (!linked) break;
+            }
+            if (h == k) cand = true;
+            else {
+                int last = pos_h;      // the head is taken
+                for (int64_t q = h + 1; q <= k; ++q) {
+                    const hs_colrec_dev rq = unpack(recs[q]);
+                    if (passes(rq) && rq.pos - last > 5) { last = rq.pos; cand = q == k; }
+                }
+            }
+        }
+        uint8_t f = r.flags & (HS_COL_TIE | HS_COL_C1GT5C2);
+        if (cand) { f |= HS_COL_CAND; if ((float)r.c1 > thr * (float)r.c0) f |= HS_COL_AUTO; }
+        if ((int)r.c1 >= 5 && central_base_test_cols(r.k0, r.k1)) f |= HS_COL_LOOPD;
+        r.flags = f;
+        int4 w; __builtin_memcpy(&w, &r, 16);
+        reinterpret_cast<int4*>(col_rec)[k] = w;
+        col_contig_local[k] = ci; col_k0[k] = r.k0; col_k1[k] = r.k1; col_c1[k] = r.c1; col_is_cand[k] = cand ? 1 : 0;
+    }
+    // candidates per contig: one atomic per contig and wavefront (a wavefront's columns nearly always lie in one contig)
+    unsigned long long m = __ballot(cand);
+    while (m) {
+        const int l = __builtin_ctzll(m);
+        const int c_l = __builtin_amdgcn_readlane(ci, l);
+        const unsigned long long same = __ballot(cand && ci == c_l);
+        if ((int)lane_id() == l) atomicAdd(&contig_n_cand[c_l], __popcll(same));
+        m &= ~same;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
