@@ -726,7 +726,7 @@ static int partition_test_launch(const int64_t* d_col_off, const int32_t* d_col_
     int64_t max_cells = 1;
     for (int c = 0; c < n_contigs; ++c) {
         const int P = h_part_off[c + 1] - h_part_off[c];
-        const int64_t cells = (int64_t)ctg_n[(size_t)c] * ((P + 63) & ~63);
+        const int64_t cells = (int64_t)ctg_n[(size_t)c] * ((P + 15) & ~15);
         tab_off[(size_t)c + 1] = tab_off[(size_t)c] + cells;
         max_cells = std::max(max_cells, cells);
     }
@@ -743,7 +743,7 @@ static int partition_test_launch(const int64_t* d_col_off, const int32_t* d_col_
     if (int rc = d_list.alloc(((size_t)n_cols + 1) * 4)) return rc;     // [0] = number of undecided columns, then their indices
     HS_HIP(hipMemsetAsync(d_list.p, 0, 4, stream));
     if (kc) { if (int rc = kc->begin(HS_K_PARTITION_LANES, stream)) return rc; }
-    hipLaunchKernelGGL(hsdev::k_column_partition_lanes, dim3((n_cols + 3) / 4), dim3(256), 0, stream, d_col_off, d_col_idx, d_col_code, d_col_contig,
+    hipLaunchKernelGGL(hsdev::k_column_partition_lanes, dim3((n_cols + 63) / 64), dim3(256), 0, stream, d_col_off, d_col_idx, d_col_code, d_col_contig,
                        d_col_k0, d_col_k1, d_col_c1, d_col_is_cand, n_cols, d_part_off, d_tab_off.as<int64_t>(), d_tab.as<uint8_t>(), d_keep,
                        d_list.as<int32_t>() + 1, d_list.as<int32_t>());
     if (kc) { if (int rc = kc->end(5 * col_entries + (int64_t)tab_off.back(), stream)) return rc; }      // the columns (idx + code) and the table, once each

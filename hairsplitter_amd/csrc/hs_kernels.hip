@@ -1283,7 +1283,7 @@ static __device__ __forceinline__ bool central_base_test_dev(int k0, int k1) {
 // the 2x2 table of one column against one partition; wave-uniform result
 static __device__ Table2x2 column_vs_partition_dev(const int32_t* __restrict__ idx, const uint8_t* __restrict__ code, int n,
                                                    const int8_t* __restrict__ state, int ref, uint8_t* s_seen /* [128] */,
-                                                   uint8_t* s_ord /* [260] */, int* s_ord_n /* [1] */) {
+                                                   uint8_t* s_ord /* [260] */, int* s_ord_n /* [1] */, uint8_t* s_map /* [3 * 512]: the hash map's tables */) {
     const int lane = lane_id();
     // slot j of the distinct-code table lives in lane j (codes 33..157: at most 125 distinct -> two slots per lane)
     int sc[2] = {-1, -1}, st_tot[2] = {0, 0}, st_pos[2] = {0, 0}, st_neg[2] = {0, 0};
@@ -1344,7 +1344,7 @@ static __device__ Table2x2 column_vs_partition_dev(const int32_t* __restrict__ i
             if (lane + 64 < nseen) s_seen[lane + 64] = (uint8_t)sc[1];
             wave_lds_sync();
             if (lane == 0) {
-                hs::Rh8 rh; rh.clear();
+                hs::Rh8View rh; rh.init(s_map, s_map + 512, s_map + 1024, 512);      // (cap 512: every set of byte keys fits, no overflow)
                 for (int i = 0; i < nseen; ++i) rh.insert(s_seen[i]);
                 rh.insert((uint8_t)ref);
                 s_ord_n[0] = rh.order(s_ord);
@@ -1382,6 +1382,7 @@ __global__ __launch_bounds__(1024) void k_column_partition_test(
     const int8_t* __restrict__ part_state, uint8_t* __restrict__ keep, const int32_t* __restrict__ list, const int32_t* __restrict__ n_list) {
     __shared__ uint8_t s_seen[16][128];
     __shared__ uint8_t s_ord[16][264];
+    __shared__ uint8_t s_map[16][3 * 512];
     __shared__ int s_ord_n[16];
     __shared__ int s_kept;
     const int lane = lane_id();
@@ -1403,7 +1404,7 @@ __global__ __launch_bounds__(1024) void k_column_partition_test(
         bool kept = false;
         if (loop_c || loop_d) {
             for (int p = p0 + wv; p < p1 && !kept; p += 16) {
-                const Table2x2 d = column_vs_partition_dev(idx, code, n, part_state + part_state_off[p], k0, s_seen[wv], s_ord[wv], &s_ord_n[wv]);
+                const Table2x2 d = column_vs_partition_dev(idx, code, n, part_state + part_state_off[p], k0, s_seen[wv], s_ord[wv], &s_ord_n[wv], s_map[wv]);
                 const float chi = chi_square_dev(d);
                 if (loop_c && (double)(d.n00 + d.n01 + d.n10 + d.n11) > 0.5 * (double)n && chi > 15) kept = true;
                 if (loop_d && (double)chi > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) kept = true;
@@ -1437,7 +1438,7 @@ __global__ __launch_bounds__(256) void k_partition_transpose(
     if (c >= n_contigs) return;
     const int p0 = part_off[c], P = part_off[c + 1] - p0;
     const int N = ctg_n[c];
-    const int ppad = (P + 63) & ~63;
+    const int ppad = (P + 15) & ~15;
     const int64_t total = (int64_t)N * ppad;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int r = (int)(i / ppad), p = (int)(i % ppad);
@@ -1447,94 +1448,167 @@ __global__ __launch_bounds__(256) void k_partition_transpose(
     }
 }
 
+// 16 lanes per column, four columns per wavefront at a time (a contig rarely ends with more than 16 partitions; more are walked
+// 16 at a time). A wavefront owns 16 consecutive columns: lanes 0..15 read their headers and decide which are tested at all, the
+// tested ones are then taken four per round. Per round and column the wavefront groups the entries by code (ballots; every lane
+// scatters its read index to LDS behind the entries of the codes found before) and the four 16-lane groups then walk their own
+// column: per code one accumulator over that code's entries -- LDS broadcast of the read index, one table byte, one add.
+#define HS_K4_GROUPS 4
+#define HS_K4_MAXCODES 32
 __global__ __launch_bounds__(256) void k_column_partition_lanes(
     const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
     const int32_t* __restrict__ col_contig, const uint8_t* __restrict__ col_k0, const uint8_t* __restrict__ col_k1,
     const int32_t* __restrict__ col_c1, const uint8_t* __restrict__ col_is_cand, int n_cols,
     const int32_t* __restrict__ part_off, const int64_t* __restrict__ tab_off, const uint8_t* __restrict__ tab,
     uint8_t* __restrict__ keep, int32_t* __restrict__ undecided_list, int32_t* __restrict__ n_undecided) {
+    __shared__ int32_t s_idx[4][HS_K4_GROUPS][256];
+    __shared__ int16_t s_cstart[4][HS_K4_GROUPS][HS_K4_MAXCODES + 2];
+    __shared__ uint8_t s_ccode[4][HS_K4_GROUPS][HS_K4_MAXCODES];
     const int lane = lane_id();
-    const int col = (int)blockIdx.x * 4 + wave_id();
-    if (col >= n_cols) return;
-    const int c = col_contig[col];
-    const int P = part_off[c + 1] - part_off[c];
-    const int64_t e0 = col_off[col];
-    const int n = (int)(col_off[col + 1] - e0);
-    const int k0 = col_k0[col], k1 = col_k1[col];
-    const bool is_cand = col_is_cand[col] != 0;
-    const bool loop_d = col_c1[col] >= 5 && central_base_test_dev(k0, k1);
-    if (P == 0 || (!is_cand && !loop_d)) { if (lane == 0) keep[col] = 0; return; }
-    if (n > 255 || k0 >= 128) {   // (the byte fields of the accumulator hold up to 255 entries)
-        if (lane == 0) { keep[col] = 2; undecided_list[atomicAdd(n_undecided, 1)] = col; }
-        return;
+    const int wv = wave_id();
+    const int col_base = ((int)blockIdx.x * 4 + wv) * 16;
+    if (col_base >= n_cols) return;
+    // ---- the 16 column headers: lane l < 16 holds column col_base + l ----
+    const int hc = col_base + (lane & 15);
+    const bool hvalid = lane < 16 && hc < n_cols;
+    int h_c = 0, h_P = 0, h_n = 0, h_k0 = 0, h_flags = 0;      // flags: 1 candidate, 2 loop D
+    int64_t h_e0 = 0;
+    bool tested = false;
+    if (hvalid) {
+        h_c = col_contig[hc];
+        h_P = part_off[h_c + 1] - part_off[h_c];
+        h_e0 = col_off[hc];
+        h_n = (int)(col_off[hc + 1] - h_e0);
+        h_k0 = col_k0[hc];
+        const int k1 = col_k1[hc];
+        const bool is_cand = col_is_cand[hc] != 0;
+        const bool loop_d = col_c1[hc] >= 5 && central_base_test_dev(h_k0, k1);
+        h_flags = (is_cand ? 1 : 0) | (loop_d ? 2 : 0);
+        if (h_P == 0 || h_flags == 0) keep[hc] = 0;
+        else if (h_n > 255 || h_k0 >= 128) {      // (the byte fields of the accumulator hold up to 255 entries)
+            keep[hc] = 2; undecided_list[atomicAdd(n_undecided, 1)] = hc;
+        } else tested = true;
     }
-    const int ppad = (P + 63) & ~63;
-    const uint8_t* __restrict__ tb = tab + tab_off[c];
-    // the column: up to four chunks of 64 entries, one entry per lane
-    int r_i[4], c_i[4];
+    unsigned todo = (unsigned)(__ballot(tested) & 0xffffull);
+    const int grp = lane >> 4, pl = lane & 15;
+    while (todo) {
+        // ---- this round's (up to) four columns: group g takes the g-th of the remaining ones ----
+        int src[HS_K4_GROUPS];
+        unsigned t = todo;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int e = k * 64 + lane;
-        r_i[k] = e < n ? col_idx[e0 + e] : 0;
-        c_i[k] = e < n ? (int)col_code[e0 + e] : -1;
-    }
-    bool kept = false, undecided = false;
-    for (int pb = 0; pb < ppad && !kept; pb += 64) {
-        const uint8_t* __restrict__ tl = tb + pb + lane;
-        unsigned long long rem[4];
+        for (int g = 0; g < HS_K4_GROUPS; ++g) { if (t) { src[g] = __builtin_ctz(t); t &= t - 1u; } else src[g] = -1; }
+        todo = t;
+        // ---- entries grouped by code into LDS, one column after the other, all lanes (the loads of all four columns first) ----
+        bool too_many_codes = false;      // per group, valid in the lanes of that group after the loop
+        int r_all[HS_K4_GROUPS][4], c_all[HS_K4_GROUPS][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) rem[k] = __ballot(c_i[k] >= 0);
-        int n11 = 0, n01 = 0, n10 = 0, n00 = 0, best = -1;
-        bool tie = false;
-        for (;;) {
-            int code = -1;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (code < 0 && rem[k]) code = __builtin_amdgcn_readlane(c_i[k], __builtin_ctzll(rem[k]));
-            if (code < 0) break;
-            unsigned acc = 0u;
+        for (int g = 0; g < HS_K4_GROUPS; ++g) {
+            const int sg = src[g] < 0 ? 0 : src[g];
+            const int64_t e0 = ((int64_t)(unsigned)__builtin_amdgcn_readlane((int)(h_e0 >> 32), sg) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(h_e0 & 0xffffffffll), sg);
+            const int n = src[g] < 0 ? 0 : __builtin_amdgcn_readlane(h_n, sg);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                unsigned long long m = __ballot(c_i[k] == code);
-                rem[k] &= ~m;
-                while (m) {      // two entries per step: both loads in flight before the adds
-                    const int ea = __builtin_ctzll(m); m &= m - 1ull;
-                    const int ra = __builtin_amdgcn_readlane(r_i[k], ea);
-                    int rb = -1;
-                    if (m) { const int eb = __builtin_ctzll(m); m &= m - 1ull; rb = __builtin_amdgcn_readlane(r_i[k], eb); }
-                    const unsigned sa = tl[(int64_t)ra * ppad];
-                    const unsigned sb = rb >= 0 ? (unsigned)tl[(int64_t)rb * ppad] : 0u;
-                    acc += 1u << sa;
-                    if (rb >= 0) acc += 1u << sb;
-                }
-            }
-            const int plus = (int)((acc >> 16) & 255u), minus = (int)(acc >> 24);
-            const int take = (int)((acc >> 8) & 255u) + plus + minus;
-            if (code == k0) { n11 = plus; n01 = minus; }
-            else if (take > 0) {
-                if (take > best) { best = take; n10 = plus; n00 = minus; tie = false; }
-                else if (take == best) tie = true;
+                const int e = k * 64 + lane;
+                r_all[g][k] = e < n ? col_idx[e0 + e] : 0;
+                c_all[g][k] = e < n ? (int)col_code[e0 + e] : -1;
             }
         }
-        if (pb + lane < P) {
-            Table2x2 d; d.n00 = n00; d.n01 = n01; d.n10 = n10; d.n11 = n11;
-            // a tie among the second alleles only matters where the verdict could depend on which one is taken: loop C needs more
-            // than half of the column's reads in the table (at most n11 + n01 + best of them are), loop D five reads on the
-            // second allele (at most best)
-            const bool tie_matters = tie && ((is_cand && (double)(n11 + n01 + best) > 0.5 * (double)n) || (loop_d && best >= 5));
-            bool ok = false;
-            if (!tie_matters) {
-                const float chi = chi_square_dev(d);
-                if (is_cand && (double)(d.n00 + d.n01 + d.n10 + d.n11) > 0.5 * (double)n && chi > 15) ok = true;                 // loop C (:721-738)
-                if (loop_d && (double)chi > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) ok = true;                           // loop D (:745-764)
+#pragma unroll
+        for (int g = 0; g < HS_K4_GROUPS; ++g) {
+            if (src[g] < 0) continue;      // (wave-uniform)
+            int r_i[4], c_i[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { r_i[k] = r_all[g][k]; c_i[k] = c_all[g][k]; }
+            unsigned long long rem[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rem[k] = __ballot(c_i[k] >= 0);
+            int ncodes = 0, filled = 0;
+            for (;;) {
+                int code = -1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (code < 0 && rem[k]) code = __builtin_amdgcn_readlane(c_i[k], __builtin_ctzll(rem[k]));
+                if (code < 0) break;
+                if (ncodes == HS_K4_MAXCODES) { ncodes++; break; }
+                if (lane == 0) { s_cstart[wv][g][ncodes] = (int16_t)filled; s_ccode[wv][g][ncodes] = (uint8_t)code; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned long long m = __ballot(c_i[k] == code);
+                    rem[k] &= ~m;
+                    if (c_i[k] == code) s_idx[wv][g][filled + __popcll(m & ((1ull << lane) - 1ull))] = r_i[k];
+                    filled += __popcll(m);
+                }
+                ncodes++;
             }
-            kept = ok; undecided = undecided || tie_matters;
-        } else kept = false;
-        kept = __ballot(kept) != 0ull;
-    }
-    undecided = __ballot(undecided) != 0ull;
-    if (lane == 0) {
-        keep[col] = kept ? 1 : (undecided ? 2 : 0);
-        if (!kept && undecided) undecided_list[atomicAdd(n_undecided, 1)] = col;
+            if (lane == 0) { s_cstart[wv][g][ncodes <= HS_K4_MAXCODES ? ncodes : HS_K4_MAXCODES] = (int16_t)filled; s_cstart[wv][g][HS_K4_MAXCODES + 1] = (int16_t)ncodes; }
+            if (grp == g) too_many_codes = ncodes > HS_K4_MAXCODES;
+        }
+        wave_lds_sync();
+        // ---- the four groups, each on its own column: lanes = partitions ----
+        int my_src = src[0];
+#pragma unroll
+        for (int g = 1; g < HS_K4_GROUPS; ++g) if (grp == g) my_src = src[g];
+        const bool active = my_src >= 0;
+        const int sl = active ? my_src : 0;
+        const int col = col_base + sl;
+        const int c = __shfl(h_c, sl, 64), P = __shfl(h_P, sl, 64), n = __shfl(h_n, sl, 64), k0 = __shfl(h_k0, sl, 64), fl = __shfl(h_flags, sl, 64);
+        const bool is_cand = (fl & 1) != 0, loop_d = (fl & 2) != 0;
+        bool kept = false, undecided = false;
+        if (active && too_many_codes) undecided = true;
+        else if (active) {
+            const int ppad = (P + 15) & ~15;
+            const uint8_t* __restrict__ tb = tab + tab_off[c];
+            const int ncodes = s_cstart[wv][grp][HS_K4_MAXCODES + 1];
+            const int32_t* __restrict__ ix = s_idx[wv][grp];
+            const unsigned gmask_shift = 16u * (unsigned)grp;
+            for (int pb = 0; pb < ppad && !kept; pb += 16) {
+                const uint8_t* __restrict__ tl = tb + pb + pl;
+                int n11 = 0, n01 = 0, n10 = 0, n00 = 0, best = -1;
+                bool tie = false;
+                for (int j = 0; j < ncodes; ++j) {
+                    const int code = s_ccode[wv][grp][j];
+                    int e = s_cstart[wv][grp][j];
+                    const int e1 = s_cstart[wv][grp][j + 1];
+                    unsigned acc = 0u;
+                    for (; e + 4 <= e1; e += 4) {      // four loads in flight before the adds
+                        const int ra = ix[e], rb = ix[e + 1], rc = ix[e + 2], rd = ix[e + 3];
+                        const unsigned sa = tl[(int64_t)ra * ppad], sb = tl[(int64_t)rb * ppad], sc = tl[(int64_t)rc * ppad], sd = tl[(int64_t)rd * ppad];
+                        acc += (1u << sa) + (1u << sb) + (1u << sc) + (1u << sd);
+                    }
+                    for (; e < e1; ++e) acc += 1u << (unsigned)tl[(int64_t)ix[e] * ppad];
+                    const int plus = (int)((acc >> 16) & 255u), minus = (int)(acc >> 24);
+                    const int take = (int)((acc >> 8) & 255u) + plus + minus;
+                    if (code == k0) { n11 = plus; n01 = minus; }
+                    else if (take > 0) {
+                        if (take > best) { best = take; n10 = plus; n00 = minus; tie = false; }
+                        else if (take == best) tie = true;
+                    }
+                }
+                bool ok = false;
+                if (pb + pl < P) {
+                    Table2x2 d; d.n00 = n00; d.n01 = n01; d.n10 = n10; d.n11 = n11;
+                    // a tie among the second alleles only matters where the verdict could depend on which one is taken: loop C needs more
+                    // than half of the column's reads in the table (at most n11 + n01 + best of them are), loop D five reads on the
+                    // second allele (at most best)
+                    const bool tie_matters = tie && ((is_cand && (double)(n11 + n01 + best) > 0.5 * (double)n) || (loop_d && best >= 5));
+                    if (!tie_matters) {
+                        const float chi = chi_square_dev(d);
+                        if (is_cand && (double)(d.n00 + d.n01 + d.n10 + d.n11) > 0.5 * (double)n && chi > 15) ok = true;                 // loop C (:721-738)
+                        if (loop_d && (double)chi > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) ok = true;                           // loop D (:745-764)
+                    }
+                    undecided = undecided || tie_matters;
+                }
+                kept = ((__ballot(ok) >> gmask_shift) & 0xffffull) != 0ull;      // (the 16 lanes of a group run in step)
+            }
+        }
+        {
+            const unsigned long long um = __ballot(undecided);
+            undecided = ((um >> (16u * (unsigned)grp)) & 0xffffull) != 0ull;
+        }
+        if (active && pl == 0) {
+            keep[col] = kept ? 1 : (undecided ? 2 : 0);
+            if (!kept && undecided) undecided_list[atomicAdd(n_undecided, 1)] = col;
+        }
+        wave_lds_sync();
     }
 }
 
