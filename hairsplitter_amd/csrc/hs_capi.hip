@@ -2049,8 +2049,9 @@ struct HipSrOps : hs::SrDeviceOps {
                 for (int k = 0; k < 16; ++k) h += " " + std::to_string((unsigned long long)st[4 + k]);
                 std::fprintf(stderr, "[hs timing] sr: per-SNP Chinese-Whispers runs by number of sweeps (0..15+):%s\n", h.c_str());
 #ifdef HS_TAIL_DIAG      // (build with -DHS_TAIL_DIAG: shader cycles of the sections of k_window_tail, summed over the windows)
-                std::fprintf(stderr, "[hs timing] sr: k_window_tail cycles: merged ids %llu, two runs + small clusters %llu, renumbering %llu, merge_close_clusters %llu, merge_wrongly_split_haplotypes %llu\n",
-                             (unsigned long long)st[20], (unsigned long long)st[21], (unsigned long long)st[22], (unsigned long long)st[23], (unsigned long long)st[24]);
+                std::fprintf(stderr, "[hs timing] sr: k_window_tail cycles: merged ids %llu, two runs + small clusters %llu, renumbering %llu, merge_close_clusters %llu, merge_wrongly_split_haplotypes: slots + map %llu, SNPs %llu, link counts %llu, links + output %llu; SNPs fast %llu slow %llu, keys %llu, windows with map %llu, clusters %llu\n",
+                             (unsigned long long)st[20], (unsigned long long)st[21], (unsigned long long)st[22], (unsigned long long)st[23], (unsigned long long)st[25], (unsigned long long)st[26],
+                             (unsigned long long)st[27], (unsigned long long)st[24], (unsigned long long)st[28], (unsigned long long)st[29], (unsigned long long)st[30], (unsigned long long)st[31], (unsigned long long)st[32]);
 #endif
 #ifdef HS_CW_DIAG
                 h.clear(); for (int k = 0; k < 16; ++k) h += " " + std::to_string((unsigned long long)st[20 + k]);

@@ -26,6 +26,7 @@ namespace hsdev {
 #define HS_FIN_GCAP 8       // clusters entering merge_wrongly_split
 #define HS_FIN_LCAP 16      // cluster links (std::sort is a plain insertion sort up to 16 elements)
 #define HS_FIN_MCAP (HS_FIN_KCAP + 2)
+#define HS_TAIL_BATCH 8     // SNP columns of a window in flight at once in merge_wrongly_split
 #define HS_CWR_CAP 255      // nodes per run in the row-packed kernel (local ids and labels are bytes, 255 = none)
 #ifndef HS_CW_REG_LABELS
 #define HS_CW_REG_LABELS 8
@@ -763,9 +764,9 @@ __global__ __launch_bounds__(64) void k_window_tail(
     extern __shared__ int32_t tail_dyn[];    // [7 * lds_cap] (the doubles first: 8-byte aligned)
     __shared__ int s_votes[HS_FIN_KCAP], s_count[HS_FIN_KCAP], s_initial[HS_FIN_KCAP], s_tested[HS_FIN_KCAP];
     __shared__ int s_index_of[HS_FIN_KCAP], s_slot_of[HS_FIN_KCAP];
-    __shared__ int s_cnts[HS_FIN_GCAP][256];
-    __shared__ int s_nb[HS_FIN_GCAP], s_major[HS_FIN_GCAP], s_glist[HS_FIN_GCAP], s_gidx[HS_FIN_GCAP];
-    __shared__ int s_incompat[HS_FIN_GCAP * HS_FIN_GCAP], s_pos_last[HS_FIN_GCAP * HS_FIN_GCAP];
+    __shared__ int s_cnts[256];
+    __shared__ int s_glist[HS_FIN_GCAP], s_gidx[HS_FIN_GCAP];
+    __shared__ int s_incompat[HS_FIN_GCAP * HS_FIN_GCAP];
     __shared__ int s_link_cnt[HS_FIN_MCAP * HS_FIN_MCAP], s_links_in[HS_FIN_MCAP], s_o2n[HS_FIN_MCAP], s_new_index[HS_FIN_MCAP];
     __shared__ int s_scalar[8];
     const int lane = lane_id();
@@ -803,19 +804,46 @@ __global__ __launch_bounds__(64) void k_window_tail(
 #define HS_TQ(k)
 #endif
     // ---- merge_clusterings ids (:840-874): the reference's double key sum_i label_i * 2^i, labels = read ids ----
+    for (int j = lane; j < m; j += 64) t1[j] = ids[j];      // (the read ids out of LDS: the labels of the runs index them)
+    wave_sync_lds();
     for (int j = lane; j < m; j += 64) {
         double a = 0.0, f = 1.0;
-        for (int i = 0; i < K; ++i) { a += (double)ids[sl[(int64_t)i * m + j]] * f; f *= 2.0; }   // exact powers of two
+        int i = 0;
+        for (; i + 4 <= K; i += 4) {      // four labels in flight, added in the reference's order
+            const int l0 = sl[(int64_t)i * m + j], l1 = sl[(int64_t)(i + 1) * m + j], l2 = sl[(int64_t)(i + 2) * m + j], l3v = sl[(int64_t)(i + 3) * m + j];
+            a += (double)t1[l0] * f; f *= 2.0; a += (double)t1[l1] * f; f *= 2.0; a += (double)t1[l2] * f; f *= 2.0; a += (double)t1[l3v] * f; f *= 2.0;      // exact powers of two
+        }
+        for (; i < K; ++i) { a += (double)t1[sl[(int64_t)i * m + j]] * f; f *= 2.0; }
         agg[j] = a; cnt[j] = 0;
     }
     wave_sync_lds();
-    for (int j = lane; j < m; j += 64) {
-        const double a = agg[j];
-        int k = 0;
-        while (agg[k] != a) ++k;      // terminates at k == j at the latest
-        t0[j] = k;
+    {
+        // t0[j] = the first node with node j's key: an open-addressing table over nc|cnt (2 * stride ints) holds, per distinct key, the
+        // smallest index seen so far -- any index in a slot carries the slot's key, so a probe compares against whichever is there
+        int T = 1;
+        while (T <= m) T <<= 1;      // m < T <= 2 m: an empty slot always exists
+        int32_t* tab = nc;
+        for (int x = lane; x < T; x += 64) tab[x] = -1;
+        wave_sync_lds();
+        for (int j = lane; j < m; j += 64) {
+            const double a = agg[j];
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(a);
+            unsigned h = ((unsigned)(bits >> 32) * 0x9E3779B1u ^ (unsigned)bits * 0x85EBCA6Bu);
+            h = (h ^ (h >> 15)) & (unsigned)(T - 1);
+            for (;;) {
+                const int cur = atomicCAS(&tab[h], -1, j);
+                if (cur == -1) break;
+                if (agg[cur] == a) { atomicMin(&tab[h], j); break; }
+                h = (h + 1u) & (unsigned)(T - 1);
+            }
+            t0[j] = (int)h;
+        }
+        wave_sync_lds();
+        for (int j = lane; j < m; j += 64) t0[j] = tab[t0[j]];
+        wave_sync_lds();
+        for (int j = lane; j < m; j += 64) cnt[j] = 0;
+        wave_sync_lds();
     }
-    wave_sync_lds();
     first_seen_ids_wave(t0, m, t1, lab, lane);
     HS_TQ(0)
     // ---- run on the finalize graph (:881) ----
@@ -850,25 +878,23 @@ __global__ __launch_bounds__(64) void k_window_tail(
     if (!finish_on_device) { bail(); return; }
 
     HS_TQ(1)
-    // ---- first-seen renumbering (:973-984) ----
-    for (int j = lane; j < m; j += 64) nc[j] = -1;
+    // ---- first-seen renumbering (:973-984): a label's new number = how many labels appear for the first time before it does ----
+    for (int j = lane; j < m; j += 64) t1[j] = 0x7fffffff;
     wave_sync_lds();
-    if (lane == 0) {
-        int Kc = 0;
-        bool bad = false;
-        for (int j = 0; j < m; ++j) {
-            const int l = lab[j];
-            if (l >= 0) {
-                if (l >= m) { bad = true; break; }
-                if (nc[l] < 0) nc[l] = Kc++;      // nc doubles as the old -> new map here
-                lab[j] = nc[l];
-            }
-        }
-        s_scalar[0] = Kc; s_scalar[1] = bad ? 1 : 0;
+    bool bad_l = false;
+    for (int j = lane; j < m; j += 64) { const int l = lab[j]; if (l >= 0) { if (l >= m) bad_l = true; else atomicMin(&t1[l], j); } }
+    wave_sync_lds();
+    if (__ballot(bad_l) != 0ull) { bail(); return; }
+    int Kc = 0;
+    for (int b0 = 0; b0 < m; b0 += 64) {
+        const int j = b0 + lane;
+        int f = -1;
+        if (j < m) { const int l = lab[j]; f = l >= 0 ? t1[l] : -1; nc[j] = f; }
+        Kc += __popcll(__ballot(j < m && f == j));
     }
     wave_sync_lds();
-    const int Kc = s_scalar[0];
-    if (s_scalar[1] || Kc > HS_FIN_KCAP) { bail(); return; }
+    first_seen_ids_wave(nc, m, t1, lab, lane);
+    if (Kc > HS_FIN_KCAP) { bail(); return; }
 
     HS_TQ(2)
     // ---- merge_close_clusters (cluster_graph.cpp:402-501) ----
@@ -948,34 +974,105 @@ __global__ __launch_bounds__(64) void k_window_tail(
         return;
     }
     if (G > HS_FIN_GCAP) { bail(); return; }
-    for (int x = lane; x < G * 256; x += 64) (&s_cnts[0][0])[x] = 0;
-    for (int x = lane; x < G * G; x += 64) { s_incompat[x] = 0; s_pos_last[x] = -10; }
+    for (int x = lane; x < G * G; x += 64) s_incompat[x] = 0;
     wave_sync_lds();
     const int pos_lo = win_pos_lo[c], pos_hi = win_pos_hi[c];
     for (int j = lane; j < m; j += 64) t0[j] = ids[j];          // the read ids next to the labels: the look-ups below stay off global memory
     wave_sync_lds();
     const int32_t* ids_l = t0;
-    for (int64_t s = win_snp_first[c]; s < win_snp_last[c]; ++s) {
-        const int p = col_pos[s];
-        if (!(p >= pos_lo && p < pos_hi)) continue;
-        if (lane < G) { s_nb[lane] = 0; s_major[lane] = 0; }   // 0 == the operator[] default for clusters absent at this SNP
+    // read id -> cluster slot as a byte map over the window's id range (the `agg` doubles are free by now), when the range fits:
+    // one LDS byte per column entry instead of a bisection of the id list
+    const int id_lo = m > 0 ? ids_l[0] : 0;
+    const long long id_range = m > 0 ? (long long)ids_l[m - 1] - id_lo + 1 : 0;
+    const bool use_map = in_lds && id_range <= 8ll * stride;
+    uint8_t* smap = reinterpret_cast<uint8_t*>(agg);
+    if (use_map) {
+        for (int x = lane; x < (int)id_range; x += 64) smap[x] = 0xff;
         wave_sync_lds();
-        for (int64_t e = col_off[s] + lane; e < col_off[s + 1]; e += 64) {
-            const int j = local_index(ids_l, m, col_idx[e]);
-            const int cl = j >= 0 ? lab[j] : -2;
-            if (cl > -1) { const int slt = s_slot_of[cl]; atomicAdd(&s_cnts[slt][col_code[e]], 1); atomicAdd(&s_nb[slt], 1); }
+        for (int j = lane; j < m; j += 64) { const int cl = lab[j]; if (cl > -1) smap[ids_l[j] - id_lo] = (uint8_t)s_slot_of[cl]; }
+        wave_sync_lds();
+    }
+    HS_TQ(5)
+    // lane a * G + b keeps the pair of clusters (a, b) with label(a) > label(b): its count of incompatible SNPs and the position of
+    // the last one (both entries of the symmetric tables of :1113-1135 always move together)
+    const int pa = lane < G * G ? lane / G : 0, pb = lane < G * G ? lane % G : 0;
+    const bool pair_owner = lane < G * G && s_glist[pa] > s_glist[pb];
+    int pair_inc = 0, pair_last = -10;
+#ifdef HS_TAIL_DIAG
+    unsigned long long dq_fast = 0, dq_slow = 0, dq_keys = 0;
+#endif
+    // what the majority bases of a SNP at position p do to the pairs (:1100-1135). Clusters absent at the SNP keep majority 0, which is
+    // not ' ': they take part in the comparison (sic), but they do not count as a "max base" for the `several` test (:1100-1112 only
+    // inserts bases of clusters that carry reads)
+    auto pairs_update = [&](int p, int major) {
+        const bool counts_l = lane < G && major != 0 && major != ' ';
+        const unsigned long long cm = __ballot(counts_l);
+        bool several = false;
+        if (cm) { const int first_max = __builtin_amdgcn_readlane(major, __builtin_ctzll(cm)); several = __ballot(counts_l && major != first_max) != 0ull; }
+        if (several) {
+            const int ma = __shfl(major, pa, 64), mb = __shfl(major, pb, 64);
+            if (pair_owner && ma != ' ' && mb != ' ' && ma != mb && p - pair_last > 10) { pair_inc += 1; pair_last = p; }
         }
-        wave_sync_lds();
+    };
+    // a column of at most 64 entries, lane = entry: (largest count, runner-up count, total) of every cluster's bases from ballots, key =
+    // (slot, code); lane i keeps cluster slot i's three numbers. A tied maximum yields runner-up == maximum (:1090-1099).
+    auto snp_fast = [&](int p, int n, int idx, int code) {
+        int slot = 0xff;
+        if (lane < n) {
+            if (use_map) { const long long d = (long long)idx - id_lo; slot = (d >= 0 && d < id_range) ? (int)smap[d] : 0xff; }
+            else { const int j = local_index(ids_l, m, idx); const int cl = j >= 0 ? lab[j] : -2; slot = cl > -1 ? s_slot_of[cl] : 0xff; }
+        }
+        const int key = slot != 0xff ? ((slot << 8) | code) : -1;
+        unsigned long long rem = __ballot(key >= 0);
+        int t1v = 0, t2v = 0, c1 = -1, nbv = 0;
+#ifdef HS_TAIL_DIAG
+        dq_fast++;
+#endif
+        while (rem) {
+#ifdef HS_TAIL_DIAG
+            dq_keys++;
+#endif
+            const int k = __builtin_amdgcn_readlane(key, __builtin_ctzll(rem));
+            const unsigned long long msk = __ballot(key == k);
+            rem &= ~msk;
+            const int v = __popcll(msk);
+            if (lane == (k >> 8)) { nbv += v; if (v > t1v) { t2v = t1v; t1v = v; c1 = k & 255; } else if (v > t2v) t2v = v; }
+        }
+        int major = 0;      // lane i < G: the majority base of cluster slot i at this SNP (0: absent, ' ': none)
+        if (lane < G && t1v > 0) { major = c1; if (t2v * 2 > t1v || nbv * 0.5 > t1v) major = ' '; }
+        pairs_update(p, major);
+    };
+    // a column deeper than a wavefront (rare): one cluster at a time over a 256-bin LDS histogram, the column read once per cluster
+    auto snp_deep = [&](int p, int64_t e0, int n) {
+#ifdef HS_TAIL_DIAG
+        dq_slow++;
+#endif
+        int major = 0;
         for (int i = 0; i < G; ++i) {
-            // (largest count, runner-up count) of the cluster's bases; a tied maximum yields runner-up == maximum (:1090-1099)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_cnts[lane + 64 * q] = 0;
+            wave_sync_lds();
+            int nb_i = 0;
+            for (int64_t eb = e0; eb < e0 + n; eb += 64) {
+                const int64_t e = eb + lane;
+                bool mine = false;
+                if (e < e0 + n) {
+                    const int j = local_index(ids_l, m, col_idx[e]);
+                    const int cl = j >= 0 ? lab[j] : -2;
+                    mine = cl > -1 && s_slot_of[cl] == i;
+                    if (mine) atomicAdd(&s_cnts[col_code[e]], 1);
+                }
+                nb_i += __popcll(__ballot(mine));
+            }
+            wave_sync_lds();
             int t1v = 0, c1 = -1, t2v = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int code = lane + 64 * q;
-                const int v = s_cnts[i][code];
-                if (v > t1v) { t2v = t1v; t1v = v; c1 = code; } else if (v > t2v) t2v = v;
-                s_cnts[i][code] = 0;
+                const int cd = lane + 64 * q;
+                const int v = s_cnts[cd];
+                if (v > t1v) { t2v = t1v; t1v = v; c1 = cd; } else if (v > t2v) t2v = v;
             }
+            wave_sync_lds();
             // one reduction gives the maximum and, among the lanes that hold it, the largest of their codes (counts < 2^23)
             const int top = wave_max_i32((t1v << 8) | (c1 & 255));
             const int mx = top >> 8;
@@ -984,31 +1081,63 @@ __global__ __launch_bounds__(64) void k_window_tail(
             const int below = wave_max_i32(t1v == mx ? t2v : t1v);  // best count strictly below the maximum when it is unique
             const int second_max = n_at >= 2 ? mx : below;
             int max_base = top & 255;
-            if (second_max * 2 > mx || s_nb[i] * 0.5 > mx) max_base = ' ';
-            if (lane == 0) s_major[i] = max_base & 255;
+            if (second_max * 2 > mx || nb_i * 0.5 > mx) max_base = ' ';
+            if (lane == i) major = max_base & 255;
         }
-        wave_sync_lds();
-        int first_max = -1; bool several = false;
-        for (int i = 0; i < G; ++i) {
-            const int mb = s_major[i];
-            if (mb == 0 || mb == ' ') continue;
-            if (first_max < 0) first_max = mb; else if (mb != first_max) several = true;
-        }
-        // clusters absent at the SNP keep majority 0, which is not ' ': they take part in the comparison below (sic), but they
-        // do not count as a "max base" for the `several` test (:1100-1112 only inserts bases of clusters that carry reads)
-        if (several && lane < G * G) {
-            const int a = lane / G, b = lane % G;
-            const int ma = s_major[a], mb = s_major[b];
-            if (ma != ' ' && mb != ' ' && s_glist[a] > s_glist[b]) {
-                const int i1 = s_gidx[a], i2 = s_gidx[b];
-                if (ma != mb && p - s_pos_last[i1 * G + i2] > 10) {
-                    s_incompat[i1 * G + i2] += 1; s_incompat[i2 * G + i1] += 1;
-                    s_pos_last[i1 * G + i2] = p; s_pos_last[i2 * G + i1] = p;
+        pairs_update(p, major);
+    };
+    for (int64_t sb = win_snp_first[c]; sb < win_snp_last[c]; sb += 64) {
+        // 64 SNPs' position, first entry and depth at once; then eight SNPs per round: their entries are all requested before the first
+        // of them is counted (one memory round trip per eight columns)
+        const int64_t s_l = sb + lane;
+        const bool s_valid = s_l < win_snp_last[c];
+        const int p_l = s_valid ? col_pos[s_l] : 0;
+        const int64_t e0_l = s_valid ? col_off[s_l] : 0;
+        const int n_l = s_valid ? (int)(col_off[s_l + 1] - e0_l) : 0;
+        unsigned long long todo = __ballot(s_valid && p_l >= pos_lo && p_l < pos_hi);
+        auto rl_e0 = [&](int l) { return ((int64_t)(unsigned)__builtin_amdgcn_readlane((int)(e0_l >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(e0_l & 0xffffffffll), l); };
+        while (todo) {
+            int aq[HS_TAIL_BATCH], idx_b[HS_TAIL_BATCH], code_b[HS_TAIL_BATCH];
+            bool any_deep = false;
+            const unsigned long long batch_todo = todo;
+#pragma unroll
+            for (int q = 0; q < HS_TAIL_BATCH; ++q) {
+                aq[q] = -1; idx_b[q] = -1; code_b[q] = 0;
+                if (todo) {
+                    aq[q] = __builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    const int64_t e0 = rl_e0(aq[q]);
+                    const int n = __builtin_amdgcn_readlane(n_l, aq[q]);
+                    any_deep = any_deep || n > 64;
+                    if (lane < n) { idx_b[q] = col_idx[e0 + lane]; code_b[q] = col_code[e0 + lane]; }
+                }
+            }
+            if (!any_deep) {
+#pragma unroll
+                for (int q = 0; q < HS_TAIL_BATCH; ++q) {
+                    if (aq[q] < 0) break;
+                    snp_fast(__builtin_amdgcn_readlane(p_l, aq[q]), __builtin_amdgcn_readlane(n_l, aq[q]), idx_b[q], code_b[q]);
+                }
+            } else {
+                // (a batch with a deep column: one SNP after the other, in position order)
+                unsigned long long bt = batch_todo & ~todo;
+                while (bt) {
+                    const int a = __builtin_ctzll(bt);
+                    bt &= bt - 1ull;
+                    const int p = __builtin_amdgcn_readlane(p_l, a), n = __builtin_amdgcn_readlane(n_l, a);
+                    const int64_t e0 = rl_e0(a);
+                    if (n <= 64) { int idx = -1, code = 0; if (lane < n) { idx = col_idx[e0 + lane]; code = col_code[e0 + lane]; } snp_fast(p, n, idx, code); }
+                    else snp_deep(p, e0, n);
                 }
             }
         }
-        wave_sync_lds();
     }
+#ifdef HS_TAIL_DIAG
+    if (lane == 0 && stat) { atomicAdd(&stat[18 + 8], dq_fast); atomicAdd(&stat[18 + 9], dq_slow); atomicAdd(&stat[18 + 10], dq_keys); atomicAdd(&stat[18 + 11], use_map ? 1ull : 0ull); atomicAdd(&stat[18 + 12], (unsigned long long)G); }
+#endif
+    if (pair_owner) { const int i1 = s_gidx[pa], i2 = s_gidx[pb]; s_incompat[i1 * G + i2] = pair_inc; s_incompat[i2 * G + i1] = pair_inc; }
+    wave_sync_lds();
+    HS_TQ(6)
     // link ratios (:1189-1250): a dense (label + 2) x (label + 2) count matrix walked in ascending key order
     const int M = Kc + 2;
     for (int x = lane; x < M * M; x += 64) s_link_cnt[x] = 0;
@@ -1025,6 +1154,7 @@ __global__ __launch_bounds__(64) void k_window_tail(
         }
     }
     wave_sync_lds();
+    HS_TQ(7)
     if (lane == 0) {
         int lc1[HS_FIN_LCAP], lc2[HS_FIN_LCAP];
         double lr[HS_FIN_LCAP];
