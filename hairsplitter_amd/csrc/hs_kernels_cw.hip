@@ -762,13 +762,15 @@ __global__ __launch_bounds__(64) void k_window_tail(
     int lds_cap, int32_t* __restrict__ gscratch, const int64_t* __restrict__ gscratch_off,
     int32_t* __restrict__ labels3_out, int32_t* __restrict__ final_out, uint8_t* __restrict__ ok_out, unsigned long long* __restrict__ stat) {
     extern __shared__ int32_t tail_dyn[];    // [7 * lds_cap] (the doubles first: 8-byte aligned)
-    __shared__ int s_votes[HS_FIN_KCAP], s_count[HS_FIN_KCAP], s_initial[HS_FIN_KCAP], s_tested[HS_FIN_KCAP];
+    __shared__ int s_count[HS_FIN_KCAP], s_initial[HS_FIN_KCAP], s_tested[HS_FIN_KCAP];
     __shared__ int s_index_of[HS_FIN_KCAP], s_slot_of[HS_FIN_KCAP];
     __shared__ int s_cnts[256];
     __shared__ int s_glist[HS_FIN_GCAP], s_gidx[HS_FIN_GCAP];
     __shared__ int s_incompat[HS_FIN_GCAP * HS_FIN_GCAP];
     __shared__ int s_link_cnt[HS_FIN_MCAP * HS_FIN_MCAP], s_links_in[HS_FIN_MCAP], s_o2n[HS_FIN_MCAP], s_new_index[HS_FIN_MCAP];
     __shared__ int s_scalar[8];
+    __shared__ int s_lc1[HS_FIN_LCAP], s_lc2[HS_FIN_LCAP];
+    __shared__ double s_lr[HS_FIN_LCAP];
     const int lane = lane_id();
     const int c = (int)blockIdx.x;
     if (c >= n_chain) return;
@@ -898,7 +900,7 @@ __global__ __launch_bounds__(64) void k_window_tail(
 
     HS_TQ(2)
     // ---- merge_close_clusters (cluster_graph.cpp:402-501) ----
-    if (lane < HS_FIN_KCAP) { s_initial[lane] = 0; s_votes[lane] = 0; s_tested[lane] = 0; }
+    if (lane < HS_FIN_KCAP) { s_initial[lane] = 0; s_tested[lane] = 0; }
     wave_sync_lds();
     for (int j = lane; j < m; j += 64) { const int l = lab[j]; if (l >= 0) atomicAdd(&s_initial[l], 1); nc[j] = l; }
     wave_sync_lds();
@@ -915,22 +917,44 @@ __global__ __launch_bounds__(64) void k_window_tail(
                 int i_l = 0, o0_l = 0, o1_l = 0;
                 if (kk < n_visit) { i_l = vis[kk]; o0_l = (int)(off_w[i_l] - abase); o1_l = (int)(off_w[i_l + 1] - abase); }
                 unsigned long long act = __ballot(kk < n_visit && nc[i_l] == target);
+                int nb_next = -1;      // the first 64 neighbours of the next node of the cluster: on their way while this one votes
+                if (act) {
+                    const int ln = __builtin_ctzll(act);
+                    const int q0 = __builtin_amdgcn_readlane(o0_l, ln), q1 = __builtin_amdgcn_readlane(o1_l, ln);
+                    if (q0 + lane < q1) nb_next = anb[q0 + lane];
+                }
                 while (act) {
                     const int l = __builtin_ctzll(act);
                     act &= act - 1ull;
                     const int i = __builtin_amdgcn_readlane(i_l, l);
                     const int o0 = __builtin_amdgcn_readlane(o0_l, l), o1 = __builtin_amdgcn_readlane(o1_l, l);
-                    for (int o = o0 + lane; o < o1; o += 64) { const int lb = nc[anb[o]]; if (lb >= 0) atomicAdd(&s_votes[lb], 1); }
-                    wave_sync_lds();
+                    const int nb0 = nb_next;
+                    nb_next = -1;
+                    if (act) {
+                        const int ln = __builtin_ctzll(act);
+                        const int q0 = __builtin_amdgcn_readlane(o0_l, ln), q1 = __builtin_amdgcn_readlane(o1_l, ln);
+                        if (q0 + lane < q1) nb_next = anb[q0 + lane];
+                    }
+                    // the votes of the neighbours' labels from ballots: lane L keeps the count of label L (Kc <= 16 labels)
+                    int v = 0;
+                    for (int ob = o0; ob < o1; ob += 64) {
+                        int lb = -1;
+                        if (ob == o0) { if (nb0 >= 0) lb = nc[nb0]; }
+                        else if (ob + lane < o1) lb = nc[anb[ob + lane]];
+                        unsigned long long rem = __ballot(lb >= 0);
+                        while (rem) {
+                            const int L = __builtin_amdgcn_readlane(lb, __builtin_ctzll(rem));
+                            const unsigned long long msk = __ballot(lb == L);
+                            rem &= ~msk;
+                            if (lane == L) v += __popcll(msk);
+                        }
+                    }
                     // largest and runner-up in ascending label order with strict '>' (:455-470): (count desc, label asc)
-                    const int v = lane < Kc ? s_votes[lane] : 0;
                     const int key = v > 0 ? ((v << 8) | (255 - lane)) : 0;
                     const int best = wave_max_i32(key);
                     const int max_value = best >> 8, max_index = best ? 255 - (best & 255) : 0;
                     const int best2 = wave_max_i32((best && lane == max_index) ? 0 : key);
                     const int second_value = best2 >> 8, second_index = best2 ? 255 - (best2 & 255) : 0;
-                    wave_sync_lds();
-                    if (lane < Kc) s_votes[lane] = 0;
                     if (max_value > 0 && max_index != target) {
                         if (lane == 0) { s_count[target]--; s_count[max_index]++; nc[i] = max_index; }
                         changes++;
@@ -1155,17 +1179,24 @@ __global__ __launch_bounds__(64) void k_window_tail(
     }
     wave_sync_lds();
     HS_TQ(7)
+    // the links in ascending (c1, c2) order: the non-zero cells of the count matrix, ranked by a ballot prefix
+    {
+        int nl_all = 0;
+        for (int x0 = 0; x0 < M * M; x0 += 64) {
+            const int x = x0 + lane;
+            const int cv = x < M * M ? s_link_cnt[x] : 0;
+            const unsigned long long nz = __ballot(cv > 0);
+            const int rank = nl_all + __popcll(nz & ((1ull << lane) - 1ull));
+            if (cv > 0 && rank < HS_FIN_LCAP) { const int c1 = x / M, c2 = x % M; s_lc1[rank] = c1 - 2; s_lc2[rank] = c2 - 2; s_lr[rank] = (double)cv / s_links_in[c1]; }
+            nl_all += __popcll(nz);
+        }
+        if (lane == 0) s_scalar[4] = nl_all;
+    }
+    wave_sync_lds();
     if (lane == 0) {
-        int lc1[HS_FIN_LCAP], lc2[HS_FIN_LCAP];
-        double lr[HS_FIN_LCAP];
-        int nl = 0;
-        bool over = false;
-        for (int c1 = 0; c1 < M && !over; ++c1)
-            for (int c2 = 0; c2 < M; ++c2)
-                if (s_link_cnt[c1 * M + c2] > 0) {
-                    if (nl == HS_FIN_LCAP) { over = true; break; }
-                    lc1[nl] = c1 - 2; lc2[nl] = c2 - 2; lr[nl] = (double)s_link_cnt[c1 * M + c2] / s_links_in[c1]; nl++;
-                }
+        int* lc1 = s_lc1; int* lc2 = s_lc2; double* lr = s_lr;      // (indexed at run time: LDS, not registers)
+        const int nl = s_scalar[4] > HS_FIN_LCAP ? HS_FIN_LCAP : s_scalar[4];
+        const bool over = s_scalar[4] > HS_FIN_LCAP;
         if (over) { s_scalar[3] = 1; }
         else {
             s_scalar[3] = 0;
