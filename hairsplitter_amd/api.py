@@ -752,8 +752,10 @@ def snp_planes(n_reads, snp_ref, snp_alt, col_off, col_idx, col_code):
     up = lambda a, dt: torch.from_numpy(_np(a, dt) if len(a) else np.zeros(1, dt)).to(dev)
     d = [up(col_off, np.int64), up(col_idx, np.int32), up(col_code, np.uint8), up(snp_ref, np.uint8), up(snp_alt, np.uint8),
          up(np.zeros(S, np.int32), np.int32), up(np.zeros(1, np.int64), np.int64), up(np.zeros(1, np.int64), np.int64), up(np.array([W], np.int32), np.int32)]
-    alt = torch.zeros((n_reads, max(W, 1)), dtype=torch.int64, device=dev); ref = torch.zeros_like(alt)
-    _check(load().hs_snp_planes(*[_p(x) for x in d], C.c_int32(S), _p(alt), _p(ref), C.c_void_p(0)))
+    # (not zeroed on purpose: the kernel writes every word of the rows)
+    alt = torch.full((n_reads, max(W, 1)), -1, dtype=torch.int64, device=dev); ref = torch.full_like(alt, -1)
+    hw = np.array([W], np.int32)
+    _check(load().hs_snp_planes(*[_p(x) for x in d], _p(up(np.array([n_reads], np.int32), np.int32)), _hp(hw, C.c_int32), C.c_int32(1), C.c_int32(S), _p(alt), _p(ref), C.c_void_p(0)))
     torch.cuda.synchronize()
     return alt.cpu().numpy().view(np.uint64)[:, :W], ref.cpu().numpy().view(np.uint64)[:, :W]
 

@@ -778,30 +778,55 @@ int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx,
     return stream_wait((hipStream_t)stream);   // the table goes back to the pool with this scope
 }
 
-int hs_snp_planes(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code, const uint8_t* d_snp_ref,
-                  const uint8_t* d_snp_alt, const int32_t* d_snp_contig, const int64_t* d_contig_snp_base,
-                  const int64_t* d_plane_off, const int32_t* d_words, int32_t n_snps, uint64_t* d_alt, uint64_t* d_ref, void* stream) {
-    if (int rc = require_device()) return rc;
-    if (n_snps <= 0) return HS_OK;
-    hipLaunchKernelGGL(hsdev::k_snp_planes, dim3((n_snps + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_col_off, d_col_idx, d_col_code, d_snp_ref,
-                       d_snp_alt, d_snp_contig, d_contig_snp_base, d_plane_off, d_words, n_snps, (unsigned long long*)d_alt, (unsigned long long*)d_ref);
+// K5a: one workgroup per (contig, 4 words of its bit rows); the list of workgroups is made from the host copy of words[]
+static void snp_planes_blocks(const int32_t* h_words, int n_contigs, std::vector<int32_t>& blk_c, std::vector<int32_t>& blk_w) {
+    blk_c.clear(); blk_w.clear();
+    for (int c = 0; c < n_contigs; ++c)
+        for (int w0 = 0; w0 < h_words[c]; w0 += 4) { blk_c.push_back(c); blk_w.push_back(w0); }
+}
+static int snp_planes_launch(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code, const uint8_t* d_snp_ref,
+                             const uint8_t* d_snp_alt, const int32_t* d_snp_contig, const int64_t* d_contig_snp_base, const int64_t* d_plane_off,
+                             const int32_t* d_words, const int32_t* d_n_reads, const int32_t* d_blk_c, const int32_t* d_blk_w, size_t n_blocks,
+                             int32_t n_snps, uint64_t* d_alt, uint64_t* d_ref, hipStream_t stream) {
+    if (n_blocks == 0 || n_snps <= 0) return HS_OK;
+    hipLaunchKernelGGL(hsdev::k_snp_planes, dim3((unsigned)n_blocks), dim3(256), 0, stream, d_col_off, d_col_idx, d_col_code, d_snp_ref, d_snp_alt,
+                       d_snp_contig, d_contig_snp_base, d_plane_off, d_words, d_n_reads, d_blk_c, d_blk_w, n_snps, (unsigned long long*)d_alt,
+                       (unsigned long long*)d_ref);
     HS_HIP(hipGetLastError());
     return HS_OK;
 }
+int hs_snp_planes(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code, const uint8_t* d_snp_ref,
+                  const uint8_t* d_snp_alt, const int32_t* d_snp_contig, const int64_t* d_contig_snp_base,
+                  const int64_t* d_plane_off, const int32_t* d_words, const int32_t* d_n_reads, const int32_t* h_words, int32_t n_contigs,
+                  int32_t n_snps, uint64_t* d_alt, uint64_t* d_ref, void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_snps <= 0 || n_contigs <= 0) return HS_OK;
+    if (!h_words) { set_error("hs_snp_planes: the host copy of words[] is needed"); return HS_EINVAL; }
+    std::vector<int32_t> blk_c, blk_w;
+    snp_planes_blocks(h_words, n_contigs, blk_c, blk_w);
+    DBuf d_bc, d_bw;
+    UploadPack pk;
+    pk.add(blk_c, d_bc); pk.add(blk_w, d_bw);
+    if (int rc = pk.commit((hipStream_t)stream)) return rc;
+    if (int rc = snp_planes_launch(d_col_off, d_col_idx, d_col_code, d_snp_ref, d_snp_alt, d_snp_contig, d_contig_snp_base, d_plane_off, d_words, d_n_reads,
+                                   d_bc.as<int32_t>(), d_bw.as<int32_t>(), blk_c.size(), n_snps, d_alt, d_ref, (hipStream_t)stream)) return rc;
+    return stream_wait((hipStream_t)stream);   // the list goes back to the pool with this scope
+}
 
-static int simdiff_launch(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_plane_off, const int32_t* d_n_reads,
-                          const int32_t* d_words, const int64_t* d_out_off, const std::vector<int32_t>& h_n_reads,
-                          int32_t* d_sim, int32_t* d_diff, void* stream, DBuf& t_c, DBuf& t_i, DBuf& t_j, UploadPack& tiles) {
-    std::vector<int32_t> tc, ti, tj;
+// the upper-triangle 64 x 64 tiles of every contig's sim / diff matrices (the kernel mirrors)
+static void simdiff_tiles(const std::vector<int32_t>& h_n_reads, std::vector<int32_t>& tc, std::vector<int32_t>& ti, std::vector<int32_t>& tj) {
+    tc.clear(); ti.clear(); tj.clear();
     for (size_t c = 0; c < h_n_reads.size(); ++c) {
         const int nt = (h_n_reads[c] + 63) / 64;
-        for (int i = 0; i < nt; ++i) for (int j = i; j < nt; ++j) { tc.push_back((int32_t)c); ti.push_back(i); tj.push_back(j); }      // the upper triangle: the kernel mirrors
+        for (int i = 0; i < nt; ++i) for (int j = i; j < nt; ++j) { tc.push_back((int32_t)c); ti.push_back(i); tj.push_back(j); }
     }
-    if (tc.empty()) return HS_OK;
-    tiles.add(tc, t_c); tiles.add(ti, t_i); tiles.add(tj, t_j);      // one asynchronous copy (staged in pinned memory: the vectors may die)
-    if (int rc = tiles.commit((hipStream_t)stream)) return rc;
-    hipLaunchKernelGGL(hsdev::k_simdiff, dim3((unsigned)tc.size()), dim3(256), 0, (hipStream_t)stream, d_alt, d_ref, d_plane_off,
-                       d_n_reads, d_words, d_out_off, t_c.as<int32_t>(), t_i.as<int32_t>(), t_j.as<int32_t>(), d_sim, d_diff);
+}
+static int simdiff_launch(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_plane_off, const int32_t* d_n_reads,
+                          const int32_t* d_words, const int64_t* d_out_off, int32_t* d_sim, int32_t* d_diff, void* stream,
+                          const int32_t* d_tc, const int32_t* d_ti, const int32_t* d_tj, size_t n_tiles) {
+    if (n_tiles == 0) return HS_OK;
+    hipLaunchKernelGGL(hsdev::k_simdiff, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, d_alt, d_ref, d_plane_off,
+                       d_n_reads, d_words, d_out_off, d_tc, d_ti, d_tj, d_sim, d_diff);
     HS_HIP(hipGetLastError());
     return HS_OK;
 }
@@ -813,10 +838,13 @@ int hs_simdiff(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_pl
     if (n_contigs <= 0) return HS_OK;
     std::vector<int32_t> h_n((size_t)n_contigs);
     HS_HIP(hipMemcpy(h_n.data(), d_n_reads, sizeof(int32_t) * (size_t)n_contigs, hipMemcpyDeviceToHost));
+    std::vector<int32_t> tc, ti, tj;
+    simdiff_tiles(h_n, tc, ti, tj);
     DBuf a, b, c;
     UploadPack tiles;
-    int rc = simdiff_launch(d_alt, d_ref, d_plane_off, d_n_reads, d_words, d_out_off, h_n, d_sim, d_diff, stream, a, b, c, tiles);
-    if (rc) return rc;
+    tiles.add(tc, a); tiles.add(ti, b); tiles.add(tj, c);
+    if (int rc = tiles.commit((hipStream_t)stream)) return rc;
+    if (int rc = simdiff_launch(d_alt, d_ref, d_plane_off, d_n_reads, d_words, d_out_off, d_sim, d_diff, stream, a.as<int32_t>(), b.as<int32_t>(), c.as<int32_t>(), tc.size())) return rc;
     if (int rc_w = stream_wait((hipStream_t)stream)) return rc_w;   // the tile lists die with this frame
     return HS_OK;
 }
@@ -1730,8 +1758,9 @@ struct HipSrOps : hs::SrDeviceOps {
     // K5 runs on while the host plans the windows: its temporaries and its timing events are parked here until the next
     // call that waits for the stream anyway
     struct SimdiffInFlight {
-        DBuf d_alt, d_ref, d_sr, d_sa, d_sc, d_cb, d_po, d_n, d_w, d_oo, t_c, t_i, t_j;
-        UploadPack pk, tiles;
+        DBuf d_alt, d_ref, d_sr, d_sa, d_sc, d_cb, d_po, d_n, d_w, d_oo, t_c, t_i, t_j, d_bc, d_bw;
+        std::vector<int32_t> tc, ti, tj, blk_c, blk_w;      // (the lists ride in the one upload of the call)
+        UploadPack pk;
         EventPair ev;
         float* k_ms = nullptr;
     };
@@ -1822,24 +1851,25 @@ struct HipSrOps : hs::SrDeviceOps {
         f.pk.add(job.n_reads, f.d_n);
         f.pk.add(job.words, f.d_w);
         f.pk.add(job.out_off, f.d_oo);
+        snp_planes_blocks(job.words.data(), (int)job.words.size(), f.blk_c, f.blk_w);
+        simdiff_tiles(job.n_reads, f.tc, f.ti, f.tj);
+        f.pk.add(f.blk_c, f.d_bc); f.pk.add(f.blk_w, f.d_bw); f.pk.add(f.tc, f.t_c); f.pk.add(f.ti, f.t_i); f.pk.add(f.tj, f.t_j);
         if (int rc = f.pk.commit(stream)) return rc;
         const size_t pbytes = (size_t)job.plane_total * sizeof(uint64_t);
         if (int rc = f.d_alt.alloc(pbytes)) return rc;
         if (int rc = f.d_ref.alloc(pbytes)) return rc;
         if (int rc = d_sim.alloc((size_t)job.out_total * sizeof(int32_t))) return rc;
         if (int rc = d_diff.alloc((size_t)job.out_total * sizeof(int32_t))) return rc;
-        HS_HIP(hipMemsetAsync(f.d_alt.p, 0, pbytes ? pbytes : 8, stream));
-        HS_HIP(hipMemsetAsync(f.d_ref.p, 0, pbytes ? pbytes : 8, stream));
         if (int rc = kc.begin(HS_K_SNP_PLANES, stream)) return rc;
-        if (int rc = hs_snp_planes(d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(), f.d_sr.as<uint8_t>(), f.d_sa.as<uint8_t>(),
-                                   f.d_sc.as<int32_t>(), f.d_cb.as<int64_t>(), f.d_po.as<int64_t>(), f.d_w.as<int32_t>(), (int32_t)job.snp_ref.size(),
-                                   f.d_alt.as<uint64_t>(), f.d_ref.as<uint64_t>(), stream)) return rc;
+        if (int rc = snp_planes_launch(d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(), f.d_sr.as<uint8_t>(), f.d_sa.as<uint8_t>(),
+                                       f.d_sc.as<int32_t>(), f.d_cb.as<int64_t>(), f.d_po.as<int64_t>(), f.d_w.as<int32_t>(), f.d_n.as<int32_t>(), f.d_bc.as<int32_t>(),
+                                       f.d_bw.as<int32_t>(), f.blk_c.size(), (int32_t)job.snp_ref.size(), f.d_alt.as<uint64_t>(), f.d_ref.as<uint64_t>(), stream)) return rc;
         if (int rc = kc.end(5 * (adopted ? adopted_entries : (int64_t)ch.col_idx.size()) + 2 * (int64_t)pbytes, stream)) return rc;
         if (int rc = f.ev.init()) return rc;
         HS_HIP(hipEventRecord(f.ev.a, stream));
         if (int rc = kc.begin(HS_K_SIMDIFF, stream)) return rc;
         if (int rc = simdiff_launch(f.d_alt.as<uint64_t>(), f.d_ref.as<uint64_t>(), f.d_po.as<int64_t>(), f.d_n.as<int32_t>(), f.d_w.as<int32_t>(),
-                                    f.d_oo.as<int64_t>(), job.n_reads, d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, f.t_c, f.t_i, f.t_j, f.tiles)) return rc;
+                                    f.d_oo.as<int64_t>(), d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, f.t_c.as<int32_t>(), f.t_i.as<int32_t>(), f.t_j.as<int32_t>(), f.tc.size())) return rc;
         if (int rc = kc.end(2 * (int64_t)pbytes + 8 * job.out_total, stream)) return rc;   // the two bit-planes in, sim + diff out
         HS_HIP(hipEventRecord(f.ev.b, stream));
         return HS_OK;   // not waited for: the stream orders K6 behind it, the host goes on planning the windows

@@ -866,30 +866,57 @@ __global__ __launch_bounds__(256) void k_gather_columns(
 // ------------------------------------------------------------------------------------------------
 // K5a SNP bit-planes: the 0/1 matrices A (read carries second_base) and R (read carries ref_base) of
 // list_similarities_and_differences_between_reads3 (separate_reads.cpp:386-405) as bit rows, built from the SNP columns that
-// are resident for the Chinese-Whispers seeding anyway. One wavefront per SNP column, one atomic OR per entry; the planes
-// must be zero on entry. Contigs with words[c] == 0 (low-memory path, no SNPs) are skipped.
+// are resident for the Chinese-Whispers seeding anyway. One workgroup per (contig, HS_SP_WORDS consecutive words = 256 SNP
+// columns): the bits of HS_SP_READS reads at a time are ORed together in LDS (one ds_or_b64 per column entry) and every word of
+// those rows is then stored once, 32 contiguous bytes per read and plane -- zero words included, so the planes need no clearing.
+// blk_contig / blk_word0: the launch's list of (contig, first word); contigs with words[c] == 0 (low-memory path, no SNPs) have
+// no workgroup.
 // ------------------------------------------------------------------------------------------------
+#define HS_SP_WORDS 4
+#define HS_SP_READS 512
 __global__ __launch_bounds__(256) void k_snp_planes(
     const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
     const uint8_t* __restrict__ snp_ref, const uint8_t* __restrict__ snp_alt, const int32_t* __restrict__ snp_contig,
-    const int64_t* __restrict__ contig_snp_base, const int64_t* __restrict__ plane_off, const int32_t* __restrict__ words, int n_snps,
+    const int64_t* __restrict__ contig_snp_base, const int64_t* __restrict__ plane_off, const int32_t* __restrict__ words,
+    const int32_t* __restrict__ n_reads, const int32_t* __restrict__ blk_contig, const int32_t* __restrict__ blk_word0, int n_snps,
     unsigned long long* __restrict__ alt, unsigned long long* __restrict__ ref) {
-    const int lane = lane_id();
-    const int s = (int)blockIdx.x * 4 + wave_id();
-    if (s >= n_snps) return;
-    const int c = snp_contig[s];
-    const int W = words[c];
-    if (W == 0) return;
-    const int sl = (int)(s - contig_snp_base[c]);
-    const unsigned long long bit = 1ull << (sl & 63);
-    const int64_t base = plane_off[c] + (sl >> 6);
-    const int rb = snp_ref[s], ab = snp_alt[s];
-    const int64_t e0 = col_off[s], e1 = col_off[s + 1];
-    for (int64_t e = e0 + lane; e < e1; e += 64) {
-        const int code = col_code[e];
-        const int64_t at = base + (int64_t)col_idx[e] * W;
-        if (code == rb) atomicOr(&ref[at], bit);
-        else if (code == ab) atomicOr(&alt[at], bit);
+    __shared__ unsigned long long s_a[HS_SP_READS][HS_SP_WORDS], s_r[HS_SP_READS][HS_SP_WORDS];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c = blk_contig[blockIdx.x];
+    const int w0 = blk_word0[blockIdx.x];
+    const int W = words[c], N = n_reads[c];
+    const int nw = W - w0 < HS_SP_WORDS ? W - w0 : HS_SP_WORDS;
+    const int64_t s0 = contig_snp_base[c] + 64ll * w0;      // first column of the workgroup
+    unsigned long long* __restrict__ A = alt + plane_off[c];
+    unsigned long long* __restrict__ R = ref + plane_off[c];
+    for (int rb = 0; rb < N; rb += HS_SP_READS) {
+        for (int x = tid; x < HS_SP_READS * HS_SP_WORDS; x += 256) { (&s_a[0][0])[x] = 0ull; (&s_r[0][0])[x] = 0ull; }
+        __syncthreads();
+        for (int q = wv; q < 64 * nw; q += 4) {      // a wavefront per column, lanes = its entries (ascending read indices)
+            const int64_t s = s0 + q;
+            if (s >= n_snps || snp_contig[s] != c) break;      // (the contig's last word is partly filled)
+            const int rbv = snp_ref[s], abv = snp_alt[s];
+            const unsigned long long bit = 1ull << (q & 63);
+            const int wq = q >> 6;
+            const int64_t e0 = col_off[s], e1 = col_off[s + 1];
+            for (int64_t e = e0 + lane; e < e1; e += 64) {
+                const int r = col_idx[e] - rb;
+                if (r < 0 || r >= HS_SP_READS) continue;
+                const int code = col_code[e];
+                if (code == rbv) atomicOr(&s_r[r][wq], bit);
+                else if (code == abv) atomicOr(&s_a[r][wq], bit);
+            }
+        }
+        __syncthreads();
+        const int nr = N - rb < HS_SP_READS ? N - rb : HS_SP_READS;
+        for (int x = tid; x < nr * HS_SP_WORDS; x += 256) {      // (consecutive threads: consecutive words of a row)
+            const int r = x / HS_SP_WORDS, wq = x % HS_SP_WORDS;
+            if (wq < nw) {
+                const int64_t at = (int64_t)(rb + r) * W + w0 + wq;
+                A[at] = s_a[r][wq]; R[at] = s_r[r][wq];
+            }
+        }
+        __syncthreads();
     }
 }
 

@@ -208,12 +208,14 @@ int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx,
 /* ------------------------------------------------------------------------------------------------
  * K5a -- SNP bit-planes for K5 from the SNP columns (separate_reads.cpp:386-405): bit s of row r of d_ref / d_alt = read r
  * carries snp_ref[s] / snp_alt[s]. Columns of all contigs concatenated (CSR); snp_contig[s] = contig of column s,
- * contig_snp_base[c] = first column of contig c; plane_off / words as for hs_simdiff (words[c] == 0 skips the contig).
- * The planes must be zeroed by the caller.
+ * contig_snp_base[c] = first column of contig c; plane_off / words / n_reads as for hs_simdiff (words[c] == 0 skips the contig).
+ * Every word of the rows of a contig with words[c] > 0 is written (the planes need no clearing). h_words: the HOST copy of
+ * words[] (the launch has one workgroup per contig and four words).
  * ---------------------------------------------------------------------------------------------- */
 int hs_snp_planes(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code, const uint8_t* d_snp_ref,
                   const uint8_t* d_snp_alt, const int32_t* d_snp_contig, const int64_t* d_contig_snp_base,
-                  const int64_t* d_plane_off, const int32_t* d_words, int32_t n_snps, uint64_t* d_alt, uint64_t* d_ref, void* stream);
+                  const int64_t* d_plane_off, const int32_t* d_words, const int32_t* d_n_reads, const int32_t* h_words /* HOST, [C] */,
+                  int32_t n_contigs, int32_t n_snps, uint64_t* d_alt, uint64_t* d_ref, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K5 -- read x read similarity / difference.  Replaces list_similarities_and_differences_between_reads3
