@@ -621,7 +621,8 @@ static int column_stats_tiled_launch(const uint8_t* d_pile, const int64_t* d_til
                                      hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth,
                                      int32_t sel_cap, int32_t max_depth, SelectionScratch* sc, hipEvent_t after_main, hipStream_t stream,
                                      hipEvent_t after_main2 = nullptr, int64_t tile0 = 0, int64_t tile1 = -1 /* tiles [tile0, tile1) only */,
-                                     int64_t g_lo = 0, int64_t g_hi = 0x7fffffffffffffffll, int32_t* d_tile_ent_sum = nullptr, bool compact = true) {
+                                     int64_t g_lo = 0, int64_t g_hi = 0x7fffffffffffffffll, int32_t* d_tile_ent_sum = nullptr, bool compact = true,
+                                     bool padded = false /* 256 readable bytes on both sides of the pileup */) {
     static_assert(sizeof(hs_tile_entry) == sizeof(int4), "hs_tile_entry is read as one 16-byte load");
     if (total_len <= 0) {   // nothing to count: an empty selection
         if (d_sel_count) HS_HIP(hipMemsetAsync(d_sel_count, 0, sizeof(int32_t), stream));
@@ -634,8 +635,10 @@ static int column_stats_tiled_launch(const uint8_t* d_pile, const int64_t* d_til
     const bool narrow = max_depth > 0 && max_depth <= 255;
     using KernelT = void (*)(const uint8_t*, const int64_t*, const int4*, int64_t, hsdev::hs_colstat_dev*, int, int32_t*, int64_t*, int32_t*, int, int64_t,
                              int64_t, int64_t, int32_t*);
-    KernelT kernel = narrow ? (full ? (KernelT)hsdev::k_column_stats_tiled<1, true> : (KernelT)hsdev::k_column_stats_tiled<1, false>)
-                            : (full ? (KernelT)hsdev::k_column_stats_tiled<2, true> : (KernelT)hsdev::k_column_stats_tiled<2, false>);
+    KernelT kernel = padded ? (narrow ? (full ? (KernelT)hsdev::k_column_stats_tiled<1, true, true> : (KernelT)hsdev::k_column_stats_tiled<1, false, true>)
+                                      : (full ? (KernelT)hsdev::k_column_stats_tiled<2, true, true> : (KernelT)hsdev::k_column_stats_tiled<2, false, true>))
+                            : (narrow ? (full ? (KernelT)hsdev::k_column_stats_tiled<1, true, false> : (KernelT)hsdev::k_column_stats_tiled<1, false, false>)
+                                      : (full ? (KernelT)hsdev::k_column_stats_tiled<2, true, false> : (KernelT)hsdev::k_column_stats_tiled<2, false, false>));
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), 0, stream, d_pile, d_tile_off, reinterpret_cast<const int4*>(d_tile_ent),
                        total_len, reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second, d_sel_count ? sc->tile_cnt.as<int32_t>() : nullptr,
                        d_sel_count ? sc->gpos.as<int64_t>() : nullptr, d_sel_count ? sc->depth.as<int32_t>() : nullptr, sel_cap, tile0, g_lo, g_hi,
@@ -1276,7 +1279,7 @@ struct HipCvOps : hs::CvDeviceOps {
             if (int rc = kc.end_prepare(range_pile, &k2_done)) return rc;
             if (int rc = column_stats_tiled_launch(b->pile_ptr(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->total_len, nullptr, 4,
                                                    range_scratch.tile_cnt.as<int32_t>() /* (only "selection wanted") */, nullptr, nullptr, 0, b->max_depth, &range_scratch,
-                                                   e_k2.b, stream, k2_done, t0, t1, g0, g1, d_tile_ent_sum.as<int32_t>(), false)) return rc;
+                                                   e_k2.b, stream, k2_done, t0, t1, g0, g1, d_tile_ent_sum.as<int32_t>(), false, true)) return rc;
             if (int rc = exclusive_scan_launch(range_scratch.tile_cnt.as<int32_t>(), (int)nt, range_scratch.tile_base.as<int64_t>(), range_scratch.scan_scratch, stream)) return rc;
             if (int rc = exclusive_scan_launch(d_tile_ent_sum.as<int32_t>(), (int)nt, d_tile_ebase.as<int64_t>(), d_scan2, stream)) return rc;
             // the two totals (the last elements of the scans) -> sizes of the column arrays

@@ -585,7 +585,6 @@ static __device__ __forceinline__ void column_stats_tail(const uint32_t* __restr
     int c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
     int depth = 0;
     if (!FULL) {
-        int nzb = 0;   // number of non-empty bins
         if (g < total) {
             // two largest counters over all bins with packed 16-bit maxima: the bytes of a word are split over two registers of
             // two 16-bit fields; every field keeps its own (largest, runner-up); the four pairs are merged at the end
@@ -597,12 +596,10 @@ static __device__ __forceinline__ void column_stats_tail(const uint32_t* __restr
                 us2 va, vb;
                 if (CB == 1) {
                     depth = (int)__builtin_amdgcn_sad_u8(word, 0u, (uint32_t)depth);      // sum of the four byte counters
-                    nzb += __popc((((word & 0x7f7f7f7fu) + 0x7f7f7f7fu) | word) & 0x80808080u);
                     va = __builtin_bit_cast(us2, word & 0x00ff00ffu);
                     vb = __builtin_bit_cast(us2, (word >> 8) & 0x00ff00ffu);
                 } else {
                     depth += (int)(word & 0xffffu) + (int)(word >> 16);
-                    nzb += ((word & 0xffffu) != 0) + ((word >> 16) != 0);
                     va = __builtin_bit_cast(us2, word);
                     vb = us2{0, 0};
                 }
@@ -624,7 +621,7 @@ static __device__ __forceinline__ void column_stats_tail(const uint32_t* __restr
                 c0 = c0 > v ? c0 : v;
             }
         }
-        c2 = nzb > 2 ? 1 : 0;   // only "is there a third allele" is needed
+        c2 = depth > c0 + c1 ? 1 : 0;   // only "is there a third allele" is needed: a third non-empty bin <=> reads beyond the two largest counts
     } else if (g < total) {
         for (int w = 0; w < NWORDS; ++w) {
             const uint32_t word = hw[w * 256 + tid];
@@ -785,7 +782,9 @@ __global__ __launch_bounds__(256) void k_column_stats(
 // K2 with a tile plan (hs_tile_plan): the records overlapping each 256-position tile are listed by the host once per batch
 // ({first lane, length, pileup address of lane 0} per record and tile), so a wavefront goes straight from one coalesced 16-B
 // load per lane to the pileup bytes: no list compaction, no workgroup barrier, the four waves of a workgroup are independent.
-template <int CB, bool FULL>
+// PAD: the pileup buffer has 256 bytes before and after it (the batch's own: hs_cv_batch), so every lane loads the byte of ITS
+// position whether the record covers it or not -- one address for all records (the tile's base + the lane) instead of a select.
+template <int CB, bool FULL, bool PAD>
 __global__ __launch_bounds__(256) void k_column_stats_tiled(
     const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, int64_t total,
     hs_colstat_dev* __restrict__ stats, int min_second, int32_t* __restrict__ sel_count, int64_t* __restrict__ sel_gpos,
@@ -793,40 +792,57 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled(
     int64_t g_lo, int64_t g_hi, int32_t* __restrict__ sel_ent) {
     constexpr int PER_WORD = 4 / CB;
     constexpr int NWORDS = (HS_NBINS + PER_WORD - 1) / PER_WORD;
-    __shared__ uint32_t hw[NWORDS * 256];
+    __shared__ __attribute__((aligned(16))) uint32_t hw[NWORDS * 256];
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     const int64_t tile = tile0 + (int64_t)blockIdx.x;
     const int64_t g = tile * 256 + tid;
+    // a wavefront clears the counters of its own 64 positions, four words per store instruction (no workgroup barrier anywhere)
 #pragma unroll
-    for (int w = 0; w < NWORDS; ++w) hw[w * 256 + tid] = 0u;
+    for (int w4 = 0; w4 < NWORDS; w4 += 4) {
+        const int w = w4 + (lane >> 4);
+        if (w < NWORDS) *reinterpret_cast<uint4*>(&hw[w * 256 + (tid & ~63) + (lane & 15) * 4]) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    char* const my_col = reinterpret_cast<char*>(hw) + tid * 4;      // counter word w of this position: my_col + 1024 w
     auto bump = [&](unsigned code, bool valid) {
-        const unsigned cc = valid ? code : 0u;
-        const unsigned inc = valid ? (1u << ((cc & (PER_WORD - 1)) * (8 * CB))) : 0u;
-        __hip_atomic_fetch_add(&hw[(cc / PER_WORD) * 256 + tid], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // bytes (or halves) of a word = consecutive codes: word code / PER_WORD, field code % PER_WORD
+        if (valid) {
+            const unsigned inc = 1u << ((code & (unsigned)(PER_WORD - 1)) * (unsigned)(8 * CB));
+            uint32_t* at = reinterpret_cast<uint32_t*>(my_col + ((code & ~(unsigned)(PER_WORD - 1)) << (CB == 1 ? 8 : 9)));
+            __hip_atomic_fetch_add(at, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     };
     const int64_t e0 = tile_off[tile], e1 = tile_off[tile + 1];
     for (int64_t i0 = e0; i0 < e1; i0 += 64) {
         const int nrec = (e1 - i0) < 64 ? (int)(e1 - i0) : 64;
         const int4 held = tile_ent[i0 + (lane < nrec ? lane : nrec - 1)];   // lane j keeps record i0 + j
         // HS_K2_INFLIGHT records per step: K2 waits on the pileup bytes (two thirds of its wave cycles are s_waitcnt), so the
-        // more byte loads are in flight per wait, the fewer waits a tile costs
-        for (int i = 0; i < nrec; i += HS_K2_INFLIGHT) {
-            unsigned code[HS_K2_INFLIGHT]; bool in_[HS_K2_INFLIGHT];
+        // more byte loads are in flight per wait, the fewer waits a tile costs; what is left of the list goes four, then one at a time
+        // (no loads of records that are not there)
+        auto step = [&](int i, auto n_const) {
+            constexpr int NU = decltype(n_const)::value;
+            unsigned code[NU]; bool in_[NU];
 #pragma unroll
-            for (int u = 0; u < HS_K2_INFLIGHT; ++u) {
-                const int j = (i + u) < nrec ? (i + u) : (nrec - 1);
+            for (int u = 0; u < NU; ++u) {
+                const int j = i + u;
                 const int first = __builtin_amdgcn_readlane(held.x, j), len = __builtin_amdgcn_readlane(held.y, j);
                 const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane(held.z, j), phi = (uint32_t)__builtin_amdgcn_readlane(held.w, j);
                 const uint8_t* __restrict__ base = pile + (int64_t)(((uint64_t)phi << 32) | plo);   // pileup byte of lane 0 of the tile
-                const bool in = (i + u) < nrec && (unsigned)(tid - first) < (unsigned)len;
-                const unsigned off = (unsigned)(in ? tid : (first < 0 ? 0 : first));   // lanes outside the record re-read one of its bytes
-                code[u] = (unsigned)base[off] - 33u;
+                const bool in = (unsigned)(tid - first) < (unsigned)len;
+                if (PAD) code[u] = (unsigned)base[tid] - 33u;
+                else {
+                    const unsigned off = (unsigned)(in ? tid : (first < 0 ? 0 : first));   // lanes outside the record re-read one of its bytes
+                    code[u] = (unsigned)base[off] - 33u;
+                }
                 in_[u] = in;
             }
 #pragma unroll
-            for (int u = 0; u < HS_K2_INFLIGHT; ++u) bump(code[u], in_[u] && code[u] < (unsigned)HS_NBINS);
-        }
+            for (int u = 0; u < NU; ++u) bump(code[u], in_[u] && code[u] < (unsigned)HS_NBINS);
+        };
+        int i = 0;
+        for (; i + HS_K2_INFLIGHT <= nrec; i += HS_K2_INFLIGHT) step(i, std::integral_constant<int, HS_K2_INFLIGHT>());
+        for (; i + 4 <= nrec; i += 4) step(i, std::integral_constant<int, 4>());
+        for (; i < nrec; ++i) step(i, std::integral_constant<int, 1>());
     }
     column_stats_tail<CB, FULL>(hw, tid, lane, g, total, stats, min_second, sel_count, sel_gpos, sel_depth, sel_cap, g_lo, g_hi, sel_ent);
 }
@@ -892,19 +908,48 @@ __global__ __launch_bounds__(256) void k_snp_planes(
     for (int rb = 0; rb < N; rb += HS_SP_READS) {
         for (int x = tid; x < HS_SP_READS * HS_SP_WORDS; x += 256) { (&s_a[0][0])[x] = 0ull; (&s_r[0][0])[x] = 0ull; }
         __syncthreads();
-        for (int q = wv; q < 64 * nw; q += 4) {      // a wavefront per column, lanes = its entries (ascending read indices)
-            const int64_t s = s0 + q;
-            if (s >= n_snps || snp_contig[s] != c) break;      // (the contig's last word is partly filled)
-            const int rbv = snp_ref[s], abv = snp_alt[s];
-            const unsigned long long bit = 1ull << (q & 63);
-            const int wq = q >> 6;
-            const int64_t e0 = col_off[s], e1 = col_off[s + 1];
-            for (int64_t e = e0 + lane; e < e1; e += 64) {
-                const int r = col_idx[e] - rb;
-                if (r < 0 || r >= HS_SP_READS) continue;
-                const int code = col_code[e];
-                if (code == rbv) atomicOr(&s_r[r][wq], bit);
-                else if (code == abv) atomicOr(&s_a[r][wq], bit);
+        {
+            // a wavefront takes every fourth column of the workgroup: lane t first reads what column wv + 4 t needs (one round trip for
+            // all of them), then the columns go by one after the other, lanes = entries, the next column's entries already on their way
+            const int q_l = wv + 4 * lane;
+            const int64_t s_l = s0 + q_l;
+            const bool v_l = q_l < 64 * nw && s_l < n_snps && snp_contig[s_l] == c;      // (the contig's last word is partly filled)
+            const int64_t e0_l = v_l ? col_off[s_l] : 0;
+            const int n_l = v_l ? (int)(col_off[s_l + 1] - e0_l) : 0;
+            const int al_l = v_l ? ((int)snp_ref[s_l] | ((int)snp_alt[s_l] << 8)) : 0;
+            unsigned long long todo = __ballot(v_l);
+            auto rl_e0 = [&](int l) { return ((int64_t)(unsigned)__builtin_amdgcn_readlane((int)(e0_l >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(e0_l & 0xffffffffll), l); };
+            int idx_n = 0, code_n = -1;
+            if (todo) {
+                const int l = __builtin_ctzll(todo);
+                const int64_t e0 = rl_e0(l); const int n = __builtin_amdgcn_readlane(n_l, l);
+                if (lane < n) { idx_n = col_idx[e0 + lane]; code_n = col_code[e0 + lane]; }
+            }
+            while (todo) {
+                const int t = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const int q = wv + 4 * t;
+                const int64_t e0 = rl_e0(t);
+                const int n = __builtin_amdgcn_readlane(n_l, t);
+                const int al = __builtin_amdgcn_readlane(al_l, t);
+                const int rbv = al & 255, abv = al >> 8;
+                int idx = idx_n, code = code_n;
+                idx_n = 0; code_n = -1;
+                if (todo) {
+                    const int l = __builtin_ctzll(todo);
+                    const int64_t e0n = rl_e0(l); const int nn = __builtin_amdgcn_readlane(n_l, l);
+                    if (lane < nn) { idx_n = col_idx[e0n + lane]; code_n = col_code[e0n + lane]; }
+                }
+                const unsigned long long bit = 1ull << (q & 63);
+                const int wq = q >> 6;
+                for (int eb = 0; eb < n; eb += 64) {
+                    if (eb > 0) { idx = 0; code = -1; if (eb + lane < n) { idx = col_idx[e0 + eb + lane]; code = col_code[e0 + eb + lane]; } }
+                    const int r = idx - rb;
+                    if (code >= 0 && r >= 0 && r < HS_SP_READS) {
+                        if (code == rbv) atomicOr(&s_r[r][wq], bit);
+                        else if (code == abv) atomicOr(&s_a[r][wq], bit);
+                    }
+                }
             }
         }
         __syncthreads();
