@@ -144,6 +144,15 @@ template <class T> int DBuf::upload(const std::vector<T>& v) {
 // pageable array costs 10-20 us of latency on the calling thread (a blit kernel each); a stage call used to issue a dozen.
 // The DBufs handed to add() become views into the pack's device block; the pack (and its pinned buffer) must outlive the copy:
 // keep it in the scope that ends with a synchronising call, or as a member.
+// HS_COPY_STATS=1: how often every hipMemcpyAsync call site ran, printed when the library is unloaded (diagnostic for the copy count)
+static std::atomic<long> g_copy_sites[4096];
+static const bool g_copy_stats = [] {
+    const bool on = std::getenv("HS_COPY_STATS") != nullptr;
+    if (on) std::atexit([] { for (int i = 0; i < 4096; ++i) { const long n = g_copy_sites[i].load(); if (n) std::fprintf(stderr, "[hs copies] hs_capi.hip:%d %ld\n", i, n); } });
+    return on;
+}();
+#define HS_COPY_ASYNC(...) ((g_copy_stats ? (void)g_copy_sites[__LINE__ & 4095].fetch_add(1, std::memory_order_relaxed) : (void)0), hipMemcpyAsync(__VA_ARGS__))
+
 struct UploadPack {
     struct Item { const void* src; size_t bytes, off; DBuf* dst; };
     std::vector<Item> items;
@@ -166,7 +175,7 @@ struct UploadPack {
             it.dst->release();
             it.dst->p = (char*)dev.p + it.off; it.dst->bytes = it.bytes; it.dst->cap = 0; it.dst->view = true;
         }
-        if (total) HS_HIP(hipMemcpyAsync(dev.p, host.p, total, hipMemcpyHostToDevice, stream));
+        if (total) HS_HIP(HS_COPY_ASYNC(dev.p, host.p, total, hipMemcpyHostToDevice, stream));
         items.clear(); total = 0;
         return HS_OK;
     }
@@ -212,7 +221,7 @@ static int stream_wait_impl(hipStream_t s) {
     }
 }
 static int copy_d2h(void* h, const void* d, size_t n, hipStream_t s) {
-    if (n) HS_HIP(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
+    if (n) HS_HIP(HS_COPY_ASYNC(h, d, n, hipMemcpyDeviceToHost, s));
     return stream_wait(s);
 }
 
@@ -1152,7 +1161,7 @@ struct HipCvOps : hs::CvDeviceOps {
         auto grow = [](HBuf& h, size_t need) -> int { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); };
         if (!rec_stats.empty()) {
             if (int rc = grow(b->h_stage_a, rec_stats.size() * sizeof(int32_t))) return rc;
-            HS_HIP(hipMemcpyAsync(b->h_stage_a.p, b->rec_stats.p, rec_stats.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            HS_HIP(HS_COPY_ASYNC(b->h_stage_a.p, b->rec_stats.p, rec_stats.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         }
         if (int rc = stream_wait(stream)) return rc;
         if (!rec_stats.empty()) std::memcpy(rec_stats.data(), b->h_stage_a.p, rec_stats.size() * sizeof(int32_t));
@@ -1173,9 +1182,13 @@ struct HipCvOps : hs::CvDeviceOps {
     DBuf d_info; HBuf h_info;
     hsdev::ColumnsHeader* dev_header() const { return d_info.as<hsdev::ColumnsHeader>(); }
     unsigned long long* dev_tie() const { return (unsigned long long*)((char*)d_info.p + 64); }
+    // behind the two counters: per contig of the range the candidates [C], the SNPs [C] and the SNP bounds [2 C], cleared with the header
     int32_t* dev_ctg_n() const { return (int32_t*)((char*)d_info.p + 128); }
+    int32_t* dev_ctg_snp() const { return dev_ctg_n() + (range_c1 - range_c0); }
+    int32_t* dev_snp_bounds() const { return dev_ctg_n() + 2 * (range_c1 - range_c0); }
     const hsdev::ColumnsHeader& host_header() const { return *(const hsdev::ColumnsHeader*)h_info.p; }
     const int32_t* host_ctg_n() const { return (const int32_t*)((const char*)h_info.p + 128); }
+    const int32_t* host_ctg_snp() const { return host_ctg_n() + (range_c1 - range_c0); }
     // the flagged columns (candidates, later the SNPs) packed into ONE block = one download: [records 16 nf][column index 4 nf][offsets 8 (nf + 1)]
     // [read indices 4 ne][codes ne], every part 256-byte aligned; the SNP block is what stage 4 takes over (HipSrOps::adopt_columns)
     DBuf d_pk; HBuf h_pk;
@@ -1195,7 +1208,7 @@ struct HipCvOps : hs::CvDeviceOps {
     static int grow(DBuf& d, size_t need) { if (d.cap >= need && d.p && !d.view) { d.bytes = need; return HS_OK; } return d.alloc(need + need / 4); }
 
     int fetch_info() {      // the info block from the device (one download + wait)
-        const size_t bytes = 128 + (size_t)(range_c1 - range_c0) * 4;
+        const size_t bytes = 128 + (size_t)(range_c1 - range_c0) * 8;
         if (int rc = grow(h_info, bytes)) return rc;
         return copy_d2h(h_info.p, d_info.p, bytes, stream);
     }
@@ -1231,7 +1244,7 @@ struct HipCvOps : hs::CvDeviceOps {
         if (download) {
             const size_t bytes = download == 2 ? L.total : L.head;
             if (int rc = grow(h_pk, std::max<size_t>(bytes, 256))) return rc;
-            HS_HIP(hipMemcpyAsync(h_pk.p, d_pk.p, bytes, hipMemcpyDeviceToHost, stream));
+            HS_HIP(HS_COPY_ASYNC(h_pk.p, d_pk.p, bytes, hipMemcpyDeviceToHost, stream));
         }
         return HS_OK;
     }
@@ -1265,13 +1278,13 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = e_k2.init()) return rc;
         if (int rc = e_k3.init()) return rc;
         if (int rc = e_k3b.init()) return rc;
-        if (int rc = grow(d_info, 128 + (size_t)C * 4)) return rc;
+        if (int rc = grow(d_info, 128 + (size_t)C * 16)) return rc;
         {   // ---- K2 over the tiles of the range: per tile its selected positions (second count >= 4), their depths and the sum of those ----
             DeviceTurn turn;
             if (int rc = range_scratch.prepare(nt * 256)) return rc;
             if (int rc = grow(d_tile_ent_sum, (size_t)nt * 4)) return rc;
             if (int rc = grow(d_tile_ebase, ((size_t)nt + 1) * 8)) return rc;
-            HS_HIP(hipMemsetAsync(d_info.p, 0, 128 + (size_t)C * 4, stream));      // (header, tie counters, candidates per contig)
+            HS_HIP(hipMemsetAsync(d_info.p, 0, 128 + (size_t)C * 16, stream));      // (header, tie counters, candidates / SNPs / SNP bounds per contig)
             HS_HIP(hipEventRecord(e_k2.a, stream));
             if (int rc = kc.begin(HS_K_COLUMN_STATS, stream)) return rc;
             hipEvent_t k2_done = nullptr;
@@ -1361,7 +1374,7 @@ struct HipCvOps : hs::CvDeviceOps {
     }
 
     // ---- K4 + the merge of the SNP lists + the SNP columns packed (they stay in d_pk for stage 4) ----
-    DBuf d_keep, d_snp_bounds;
+    DBuf d_keep;
     int64_t snp_count = 0, snp_entries = 0;       // what d_pk holds after finish_columns (HipSrOps::adopt_columns)
     int finish_columns(const hs::CvPartitionTest& t, bool want_entries, hs::CvSnpSet& out, float* k_ms) override {
         const int C = range_c1 - range_c0;
@@ -1395,19 +1408,16 @@ struct HipCvOps : hs::CvDeviceOps {
                                            d_ps.as<int8_t>(), t.part_off.data(), t.contig_n_reads.data(), C, d_keep.as<uint8_t>(),
                                            stream, d_tab, d_tab_off, d_ctg_nr, d_list, pk_tab, &kc, gathered_entries, (int64_t)t.part_state.size())) return rc;
         HS_HIP(hipEventRecord(e.b, stream));
-        if (int rc = grow(d_snp_bounds, (size_t)C * 8)) return rc;
-        HS_HIP(hipMemsetAsync(d_snp_bounds.p, 0, (size_t)C * 8, stream));
-        HS_HIP(hipMemsetAsync(dev_ctg_n(), 0, (size_t)C * 4, stream));
         if (int rc = kc.begin(HS_K_SNP_SELECT, stream)) return rc;
         hipLaunchKernelGGL(hsdev::k_snp_bounds, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, stream, d_col_rec.as<hsdev::hs_colrec_dev>(), d_col_ctg.as<int32_t>(),
-                           d_keep.as<uint8_t>(), n_cols, C, d_snp_bounds.as<int32_t>());
+                           d_keep.as<uint8_t>(), n_cols, C, dev_snp_bounds());
         hipLaunchKernelGGL(hsdev::k_snp_flags, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, stream, d_col_rec.as<hsdev::hs_colrec_dev>(), d_col_ctg.as<int32_t>(),
-                           d_keep.as<uint8_t>(), n_cols, C, d_snp_bounds.as<int32_t>(), dev_ctg_n());
+                           d_keep.as<uint8_t>(), n_cols, C, dev_snp_bounds(), dev_ctg_snp());
         HS_HIP(hipGetLastError());
         if (int rc = kc.end(33 * n_cols, stream)) return rc;      // records in (twice) and out, the verdicts in
         int64_t n_snp = 0, e_snp = 0;
         if (int rc = pack_flagged(HS_COL_SNP, want_entries ? 2 : 1, &n_snp, &e_snp)) return rc;      // (the partition tables, uploads and lists of this scope are done with: it waits)
-        std::memcpy(out.contig_n_snp.data(), host_ctg_n(), (size_t)C * 4);
+        std::memcpy(out.contig_n_snp.data(), host_ctg_snp(), (size_t)C * 4);
         if (int rc = stream_wait(stream)) return rc;
         out.n_snp = n_snp; out.n_entries = e_snp;
         snp_count = n_snp; snp_entries = e_snp;
@@ -1492,8 +1502,8 @@ struct HipCvOps : hs::CvDeviceOps {
         HS_HIP(hipEventRecord(e.b, stream));
         // the counts first, then the partitions themselves, packed
         if (int rc = grow(h_la_np, (size_t)C * 8 + ((size_t)C + 1) * 8)) return rc;
-        HS_HIP(hipMemcpyAsync(h_la_np.p, d_la_np.p, (size_t)C * 8, hipMemcpyDeviceToHost, stream));
-        HS_HIP(hipMemcpyAsync((char*)h_la_np.p + (size_t)C * 8, d_la_pb.p, ((size_t)C + 1) * 8, hipMemcpyDeviceToHost, stream));
+        HS_HIP(HS_COPY_ASYNC(h_la_np.p, d_la_np.p, (size_t)C * 8, hipMemcpyDeviceToHost, stream));
+        HS_HIP(HS_COPY_ASYNC((char*)h_la_np.p + (size_t)C * 8, d_la_pb.p, ((size_t)C + 1) * 8, hipMemcpyDeviceToHost, stream));
         if (int rc = stream_wait(stream)) return rc;
         const int32_t* h_np = (const int32_t*)h_la_np.p;
         std::memcpy(out.failed.data(), h_np + C, (size_t)C * 4);
@@ -1521,9 +1531,9 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = grow(h_la_rec, std::max<size_t>(1, (size_t)n_parts) * sizeof(hs::CvPartRecord))) return rc;
         if (int rc = grow(h_la_bits, std::max<size_t>(1, (size_t)tb) * 8)) return rc;
         if (int rc = grow(h_la_cnt, std::max<size_t>(1, (size_t)tc) * 4)) return rc;
-        if (n_parts) HS_HIP(hipMemcpyAsync(h_la_rec.p, d_la_out_rec.p, (size_t)n_parts * sizeof(hs::CvPartRecord), hipMemcpyDeviceToHost, stream));
-        if (tb) HS_HIP(hipMemcpyAsync(h_la_bits.p, d_la_out_bits.p, (size_t)tb * 8, hipMemcpyDeviceToHost, stream));
-        if (tc) HS_HIP(hipMemcpyAsync(h_la_cnt.p, d_la_out_cnt.p, (size_t)tc * 4, hipMemcpyDeviceToHost, stream));
+        if (n_parts) HS_HIP(HS_COPY_ASYNC(h_la_rec.p, d_la_out_rec.p, (size_t)n_parts * sizeof(hs::CvPartRecord), hipMemcpyDeviceToHost, stream));
+        if (tb) HS_HIP(HS_COPY_ASYNC(h_la_bits.p, d_la_out_bits.p, (size_t)tb * 8, hipMemcpyDeviceToHost, stream));
+        if (tc) HS_HIP(HS_COPY_ASYNC(h_la_cnt.p, d_la_out_cnt.p, (size_t)tc * 4, hipMemcpyDeviceToHost, stream));
         if (int rc = stream_wait(stream)) return rc;      // (the offset tables of this scope are done with)
         out.rec = (const hs::CvPartRecord*)h_la_rec.p; out.bits = (const uint64_t*)h_la_bits.p; out.cnt = (const int32_t*)h_la_cnt.p;
 #ifdef HS_LA_DIAG
@@ -1660,8 +1670,8 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
             const size_t row_bytes = (size_t)dst.back() * 4;
             if (int rc = h_rows.alloc(2 * row_bytes + 16)) return rc;
             if (row_bytes) {
-                HS_HIP(hipMemcpyAsync(h_rows.p, d_os.p, row_bytes, hipMemcpyDeviceToHost, stream));
-                HS_HIP(hipMemcpyAsync((char*)h_rows.p + row_bytes, d_od.p, row_bytes, hipMemcpyDeviceToHost, stream));
+                HS_HIP(HS_COPY_ASYNC(h_rows.p, d_os.p, row_bytes, hipMemcpyDeviceToHost, stream));
+                HS_HIP(HS_COPY_ASYNC((char*)h_rows.p + row_bytes, d_od.p, row_bytes, hipMemcpyDeviceToHost, stream));
             }
             if (int rc_w = stream_wait(stream)) return rc_w;
             const int32_t* hs_ = (const int32_t*)h_rows.p; const int32_t* hd_ = (const int32_t*)((const char*)h_rows.p + row_bytes);
@@ -1705,7 +1715,7 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
         if (int rc = h_deg.alloc(nh * 4)) return rc;
         int32_t* hd = (int32_t*)h_deg.p;
         for (size_t r = 0; r < nh; ++r) hd[r] = (int32_t)(ws.host_off[r + 1] - ws.host_off[r]);
-        HS_HIP(hipMemcpyAsync(d_deg.as<int32_t>() + rows_dev, hd, nh * 4, hipMemcpyHostToDevice, stream));
+        HS_HIP(HS_COPY_ASYNC(d_deg.as<int32_t>() + rows_dev, hd, nh * 4, hipMemcpyHostToDevice, stream));
     }
     if (int rc = exclusive_scan_launch(d_deg.as<int32_t>(), rows, G.d_off.as<int64_t>(), d_scan, stream)) return rc;
     int64_t total = 0;
@@ -1725,7 +1735,7 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
             const size_t nb = ws.host_nbr.size() * 4;
             if (int rc = h_nbr.alloc(nb)) return rc;
             std::memcpy(h_nbr.p, ws.host_nbr.data(), nb);
-            HS_HIP(hipMemcpyAsync(G.d_nbr.as<int32_t>() + (total - (int64_t)ws.host_nbr.size()), h_nbr.p, nb, hipMemcpyHostToDevice, stream));
+            HS_HIP(HS_COPY_ASYNC(G.d_nbr.as<int32_t>() + (total - (int64_t)ws.host_nbr.size()), h_nbr.p, nb, hipMemcpyHostToDevice, stream));
         }
     }
     {   // visiting order of every window (hs_kernels_cw.hip)
@@ -1811,25 +1821,24 @@ struct HipSrOps : hs::SrDeviceOps {
         const int64_t total = slot_off.back();
         ids.resize((size_t)total); win_m.assign((size_t)W, 0);
         if (W == 0) return HS_OK;
-        DBuf d_a, d_b, d_so, d_ids, d_m;
+        DBuf d_a, d_b, d_so, d_ids;
         UploadPack pk;
         pk.add(col_a, d_a); pk.add(col_b, d_b); pk.add(slot_off, d_so);
         if (int rc = pk.commit(stream)) return rc;
-        if (int rc = d_ids.alloc(std::max<size_t>(1, (size_t)total) * 4)) return rc;
-        if (int rc = d_m.alloc((size_t)W * 4)) return rc;
+        // the ids and the per-window counts in one block: one copy back
+        const size_t ids_bytes = ((size_t)total * 4 + 255) & ~(size_t)255;
+        if (int rc = d_ids.alloc(ids_bytes + (size_t)W * 4)) return rc;
+        int32_t* const dm = reinterpret_cast<int32_t*>((char*)d_ids.p + ids_bytes);
         if (int rc = kc.begin(HS_K_WINDOW_MASKS, stream)) return rc;
         hipLaunchKernelGGL(hsdev::k_window_masks, dim3((unsigned)((W + 3) / 4)), dim3(256), 0, stream, d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_a.as<int64_t>(),
-                           d_b.as<int64_t>(), d_so.as<int64_t>(), W, d_ids.as<int32_t>(), d_m.as<int32_t>());
+                           d_b.as<int64_t>(), d_so.as<int64_t>(), W, d_ids.as<int32_t>(), dm);
         HS_HIP(hipGetLastError());
         if (int rc = kc.end(8 * total + 4 * (int64_t)W, stream)) return rc;
-        HBuf h_ids, h_m;
-        if (int rc = h_ids.alloc(std::max<size_t>(1, (size_t)total) * 4)) return rc;
-        if (int rc = h_m.alloc((size_t)W * 4)) return rc;
-        if (total) HS_HIP(hipMemcpyAsync(h_ids.p, d_ids.p, (size_t)total * 4, hipMemcpyDeviceToHost, stream));
-        HS_HIP(hipMemcpyAsync(h_m.p, d_m.p, (size_t)W * 4, hipMemcpyDeviceToHost, stream));
-        if (int rc = stream_wait(stream)) return rc;
+        HBuf h_ids;
+        if (int rc = h_ids.alloc(ids_bytes + (size_t)W * 4)) return rc;
+        if (int rc = copy_d2h(h_ids.p, d_ids.p, ids_bytes + (size_t)W * 4, stream)) return rc;
         if (total) std::memcpy(ids.data(), h_ids.p, (size_t)total * 4);
-        std::memcpy(win_m.data(), h_m.p, (size_t)W * 4);
+        std::memcpy(win_m.data(), (const char*)h_ids.p + ids_bytes, (size_t)W * 4);
         kc.flush();
         return HS_OK;
     }
@@ -2055,13 +2064,13 @@ struct HipSrOps : hs::SrDeviceOps {
             // when some window has to be finished by the host code (few or none)
             HBuf h, h2, h3, h4;
             if (int rc = h4.alloc(416)) return rc;
-            HS_HIP(hipMemcpyAsync(h4.p, d_stat.p, 416, hipMemcpyDeviceToHost, stream));
+            HS_HIP(HS_COPY_ASYNC(h4.p, d_stat.p, 416, hipMemcpyDeviceToHost, stream));
             bool need_chain_labels = !finish;
             if (finish) {
                 if (int rc = h2.alloc(std::max<size_t>((size_t)total_m, 1) * sizeof(int32_t))) return rc;
                 if (int rc = h3.alloc(std::max<size_t>((size_t)Wc, 1))) return rc;
-                HS_HIP(hipMemcpyAsync(h2.p, d_final.p, (size_t)total_m * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-                HS_HIP(hipMemcpyAsync(h3.p, d_ok.p, (size_t)Wc, hipMemcpyDeviceToHost, stream));
+                HS_HIP(HS_COPY_ASYNC(h2.p, d_final.p, (size_t)total_m * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                HS_HIP(HS_COPY_ASYNC(h3.p, d_ok.p, (size_t)Wc, hipMemcpyDeviceToHost, stream));
                 if (int rc = stream_wait(stream)) return rc;
                 final_labels.resize((size_t)total_m); final_ok.resize((size_t)Wc);
                 std::memcpy(final_labels.data(), h2.p, (size_t)total_m * sizeof(int32_t));
