@@ -170,7 +170,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C4", choices=sorted(WORKLOADS))
     ap.add_argument("--contigs", type=int, default=0, help="number of contigs of the configuration (0 = its own: C2 256, C3 50, C4 500, C5 34)")
-    ap.add_argument("--groups", type=int, default=0, help="contig groups (host thread + HIP stream each) per GPU; 0 = min(8, host threads / 4)")
+    ap.add_argument("--groups", type=int, default=0, help="contig groups (host thread + HIP stream each) per GPU; 0 = min(8, host threads / 3)")
     ap.add_argument("--threads", type=int, default=0, help="host threads for the sequential glue (0 = all cores / ranks)")
     ap.add_argument("--cpu-contigs", type=int, default=-1, help="contigs of the CPU-baseline / file-to-file sample (0 disables both; -1 = about 80 M aligned bp)")
     ap.add_argument("--no-f2f-job", action="store_true", help="skip the file-to-file run of the drop-ins on the whole job")
@@ -251,7 +251,7 @@ def main():
     n_threads = args.threads or max(1, min(64, (3 * effective_cores()) // (1 if args.cores > 0 else world)))      # (16 usable cores: 32 threads 46 ms per step, 48: 44, 64: 47, 128: 51)
 
     B = len(contigs)
-    G = max(1, min(args.groups if args.groups > 0 else min(8, max(1, n_threads // 4)), max(B, 1)))
+    G = max(1, min(args.groups if args.groups > 0 else min(8, max(1, n_threads // 3)), max(B, 1)))      # (a rank of 8 with 6 threads: 2 groups, 7.0 ms per step on its shard against 10.3 with one)
     pet()
     t_up = time.perf_counter()
     batch = api.PipelineGroups(contigs, G)   # inputs now resident in HBM; the streaming kernels run once per step over all of them
