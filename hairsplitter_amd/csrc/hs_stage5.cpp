@@ -5,8 +5,11 @@
 //                      after that placement is attached again
 //   hs_trim_polished   create_new_contigs.cpp:556-629  the polished sequence was built from the backbone piece plus overhangs:
 //                      the overhangs are located on it through the alignment PATH of the piece's ends and cut off
-// Host code around ONE batched call of hs_edlib_hw_align (two alignments per item). Sequences: ACGT (anything else is read
-// as T, as everywhere on this path; the reference's edlib would tell other letters apart).
+// Host code around ONE batched call of hs_edlib_hw_align (two alignments per item). Alphabet: edlib compares BYTES (its default
+// equality: 'N' only matches 'N', 'a' is not 'A'), the kernel compares codes 0..3; distance and path only depend on which
+// positions are equal, so every pair gets its own bijection from the bytes it contains to the codes -- exact for any pair with at
+// most four distinct bytes (ACGT in either case, ACG + N, ...). A pair with more than four (ACGT + N) is an error (HS_EFORMAT),
+// not an approximation.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -25,7 +28,21 @@ struct Dev {                     // device buffers through the raw-memory entry 
 
 struct Aln { int32_t dist = 0, start = 0, end = 0; std::vector<uint8_t> ops; };
 
-uint8_t code_of(char c) { return c == 'A' || c == 'a' ? 0 : (c == 'C' || c == 'c' ? 1 : (c == 'G' || c == 'g' ? 2 : 3)); }
+// the pair's bytes -> codes 0..3 in order of first appearance; false when the pair has more than four distinct bytes
+bool encode_pair(const std::string& q, const std::string& t, uint8_t* cq, uint8_t* ct) {
+    int code[256];
+    for (int i = 0; i < 256; ++i) code[i] = -1;
+    int n = 0;
+    auto enc = [&](const std::string& s, uint8_t* out) {
+        for (size_t k = 0; k < s.size(); ++k) {
+            const unsigned char b = (unsigned char)s[k];
+            if (code[b] < 0) { if (n == 4) return false; code[b] = n++; }
+            out[k] = (uint8_t)code[b];
+        }
+        return true;
+    };
+    return enc(q, cq) && enc(t, ct);
+}
 
 // edlibAlign(query, target, HW, k = -1, TASK_PATH) for every pair
 int align_all(const std::vector<std::string>& q, const std::vector<std::string>& t, bool path, std::vector<Aln>& out) {
@@ -35,10 +52,11 @@ int align_all(const std::vector<std::string>& q, const std::vector<std::string>&
     std::vector<int64_t> qo((size_t)n + 1, 0), to((size_t)n + 1, 0), oo((size_t)n + 1, 0);
     for (int i = 0; i < n; ++i) { qo[(size_t)i + 1] = qo[(size_t)i] + (int64_t)q[(size_t)i].size(); to[(size_t)i + 1] = to[(size_t)i] + (int64_t)t[(size_t)i].size(); oo[(size_t)i + 1] = oo[(size_t)i] + (int64_t)(q[(size_t)i].size() + t[(size_t)i].size()); }
     std::vector<uint8_t> hq((size_t)qo.back() + 1), ht((size_t)to.back() + 1);
-    for (int i = 0; i < n; ++i) {
-        for (size_t k = 0; k < q[(size_t)i].size(); ++k) hq[(size_t)qo[(size_t)i] + k] = code_of(q[(size_t)i][k]);
-        for (size_t k = 0; k < t[(size_t)i].size(); ++k) ht[(size_t)to[(size_t)i] + k] = code_of(t[(size_t)i][k]);
-    }
+    for (int i = 0; i < n; ++i)
+        if (!encode_pair(q[(size_t)i], t[(size_t)i], hq.data() + qo[(size_t)i], ht.data() + to[(size_t)i])) {
+            hs::set_error("stage 5 alignment " + std::to_string(i) + ": more than four distinct bytes in one query / target pair (edlib compares bytes; this path has four codes)");
+            return HS_EFORMAT;
+        }
     Dev dev;
     void *dq, *dt, *dd, *ds, *de, *dl, *dops = nullptr;
     if (int rc = dev.alloc(&dq, hq.size())) return rc;

@@ -296,6 +296,50 @@ def gen_edlib_edge_vectors():
     print("edlib edge vectors:", len(vec))
 
 
+def gen_stage5_alphabet_cases():
+    """Stage-5 call-site cases over other alphabets than ACGT (edlib compares bytes: lower case differs from upper case, N only
+    matches N): tests/golden/stage5_alphabet_cases.json. Every query / target pair has at most four distinct bytes -- what the
+    four-code kernel can represent exactly -- except the last case, which the library must refuse."""
+    rnd = random.Random(31)
+
+    def rs(n, alpha):
+        return "".join(rnd.choice(alpha) for _ in range(n))
+
+    def mutate(s, rate, alpha):
+        out = []
+        for c in s:
+            u = rnd.random()
+            if u < rate / 3:
+                out.append(rnd.choice(alpha))
+            elif u < 2 * rate / 3:
+                continue
+            elif u < rate:
+                out.append(c); out.append(rnd.choice(alpha))
+            else:
+                out.append(c)
+        return "".join(out)
+
+    lines, cases = [], []
+    for alpha in ("acgt", "ACGN", "ANTG", "Acgt", "AaCc", "NT", "ACG"):
+        for _ in range(6):
+            b = rs(rnd.randint(250, 1500), alpha)
+            cut_l, cut_r = rnd.randint(0, 60), rnd.randint(0, 60)
+            c = mutate(b[cut_l:len(b) - cut_r], rnd.choice([0.0, 0.02, 0.05]), alpha)
+            lines.append("REATTACH 0 %s %s" % (b, c)); cases.append({"kind": "reattach", "backbone": b, "consensus": c})
+        for _ in range(6):
+            ol, orr = rnd.choice([0, 50, 150]), rnd.choice([0, 50, 150])
+            tp = rs(ol, alpha) + rs(rnd.randint(400, 1500), alpha) + rs(orr, alpha)
+            nc = mutate(tp, rnd.choice([0.0, 0.02, 0.05]), alpha)
+            lines.append("TRIM %d,%d %s %s" % (ol, orr, tp, nc)); cases.append({"kind": "trim", "to_polish": tp, "newcontig": nc, "overhang_left": ol, "overhang_right": orr})
+    res = subprocess.run([os.path.join(REF, "edlib_driver")], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.split("\n")
+    for c, r in zip(cases, res):
+        c["expected"] = r
+    cases.append({"kind": "refused", "backbone": "NACGT" * 80, "consensus": "NACGT" * 76})      # five distinct bytes in one pair
+    with open(os.path.join(GOLD, "stage5_alphabet_cases.json"), "w") as f:
+        json.dump(cases, f)
+    print("stage-5 alphabet cases:", len(cases))
+
+
 def gen_edlib_path_vectors():
     """HW + PATH vectors from the reference's bundled edlib at the shapes of its stage-5 call sites (create_new_contigs.cpp:558-629,
     tools.cpp:515-534: a 200-300 bp query inside a target of a few hundred to a few thousand bases) plus edge cases: written to
@@ -418,12 +462,15 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--edlib-path", action="store_true", help="only tests/golden/edlib_path_vectors.json")
     ap.add_argument("--edlib-edge", action="store_true", help="only tests/golden/edlib_edge_vectors.json")
+    ap.add_argument("--stage5-alphabet", action="store_true", help="only tests/golden/stage5_alphabet_cases.json")
     ap.add_argument("--c5u", action="store_true", help="only the uncut 10 Mb variant of C5: outputs into tests/golden_big/c5u (12 minutes of the reference)")
     args = ap.parse_args()
     if args.c5u:
         return gen_c5u()
     if args.edlib_path:
         return gen_edlib_path_vectors()
+    if args.stage5_alphabet:
+        return gen_stage5_alphabet_cases()
     if args.edlib_edge:
         return gen_edlib_edge_vectors()
     os.makedirs(GOLD, exist_ok=True)

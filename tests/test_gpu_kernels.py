@@ -530,3 +530,20 @@ def test_stage5_edlib_call_sites(built):
     got = api.trim_polished([c["to_polish"] for c in tr], [c["newcontig"] for c in tr], [c["overhang_left"] for c in tr], [c["overhang_right"] for c in tr])
     assert got == [c["expected"] for c in tr]
     assert any(len(c["expected"]) < len(c["newcontig"]) for c in tr)
+
+
+def test_stage5_call_sites_compare_bytes_like_edlib(built):
+    """edlib's default equality compares bytes: lower case is not upper case, N only matches N. The kernel has four codes, so every
+    query / target pair gets its own bijection bytes -> codes (distance and path only depend on which positions are equal): cases
+    over acgt, ACGN, mixed case ... against the reference's edlib; a pair with five distinct bytes is refused, not approximated."""
+    from hairsplitter_amd import api
+    cases = json.load(open(os.path.join(gu.GOLD, "stage5_alphabet_cases.json")))
+    re_ = [c for c in cases if c["kind"] == "reattach"]
+    tr = [c for c in cases if c["kind"] == "trim"]
+    assert len(re_) >= 40 and len(tr) >= 40
+    assert api.reattach_ends([c["backbone"] for c in re_], [c["consensus"] for c in re_]) == [c["expected"] for c in re_]
+    assert api.trim_polished([c["to_polish"] for c in tr], [c["newcontig"] for c in tr], [c["overhang_left"] for c in tr], [c["overhang_right"] for c in tr]) == [c["expected"] for c in tr]
+    bad = [c for c in cases if c["kind"] == "refused"]
+    assert bad
+    with pytest.raises(Exception, match="distinct bytes"):
+        api.reattach_ends([bad[0]["backbone"]], [bad[0]["consensus"]])
