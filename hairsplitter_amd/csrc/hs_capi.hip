@@ -1565,16 +1565,24 @@ struct GraphRows {
     std::vector<int32_t> win_m;    // [W]
 };
 
-static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const std::vector<int64_t>& ctg_out_off, const std::vector<int32_t>& ctg_n,
-                            const hs::SrWindowSet& ws, GraphRows& G, hipStream_t stream, int64_t* rows_on_host, float* k_ms, KernelClock* kc = nullptr) {
+// the bit rows of the call (K5a), for the windows of the low-memory path
+struct PlaneRows { const uint64_t* d_alt = nullptr; const uint64_t* d_ref = nullptr; const int64_t* d_plane_off = nullptr; const int32_t* d_words = nullptr; };
+
+static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const std::vector<int64_t>& ctg_out_off, const std::vector<int32_t>& ctg_n_matrix,
+                            const hs::SrWindowSet& ws, GraphRows& G, hipStream_t stream, int64_t* rows_on_host, float* k_ms, KernelClock* kc = nullptr,
+                            const PlaneRows* planes = nullptr) {
+    const std::vector<int32_t>& ctg_n = ws.ctg_reads.empty() ? ctg_n_matrix : ws.ctg_reads;      // reads of every contig (the matrix list has 0 for low-memory contigs)
     const int W = (int)ws.win_contig.size();
     G.W = W; G.rows = ws.rows(); G.total = 0; G.max_m = 1;
     if (rows_on_host) *rows_on_host = 0;
     if (G.rows > 0x7fffffff) { set_error("read graphs: too many rows"); return HS_EINVAL; }
     const int rows = (int)G.rows;
     const int Wd = ws.n_dev_windows;
+    const int Wmx = ws.ctg_reads.empty() ? Wd : ws.n_matrix_windows;      // [0, Wmx): sim / diff of the contig; [Wmx, Wd): window-local matrices (low-memory path)
     const int rows_dev = (int)ws.win_row0[(size_t)Wd];
+    const int rows_mx = (int)ws.win_row0[(size_t)Wmx];
     G.rows_dev = rows_dev;
+    if (Wmx < Wd && (!planes || !planes->d_alt)) { set_error("read graphs: low-memory windows without bit rows"); return HS_EINVAL; }
     if ((int64_t)ws.host_off.size() != (int64_t)(rows - rows_dev) + 1 && rows != rows_dev) { set_error("read graphs: host rows do not match the window set"); return HS_EINVAL; }
     std::vector<int32_t> row_win((size_t)rows_dev);
     std::vector<int64_t> win_bits_off((size_t)Wd + 1, 0);
@@ -1590,6 +1598,17 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
             max_m_dev = std::max(max_m_dev, (int)m);
         }
     }
+    // low-memory windows: an m x m sim / diff per window, every 64 x 64 tile of it one workgroup
+    std::vector<int64_t> win_mat_off((size_t)Wd + 1, 0);
+    std::vector<int32_t> lt_w, lt_i, lt_j;
+    for (int w = 0; w < Wd; ++w) {
+        const int64_t m = w >= Wmx ? G.win_m[(size_t)w] : 0;
+        win_mat_off[(size_t)w + 1] = win_mat_off[(size_t)w] + m * m;
+        const int nt = (int)((m + 63) / 64);
+        for (int i = 0; i < nt; ++i) for (int j = 0; j < nt; ++j) { lt_w.push_back(w); lt_i.push_back(i); lt_j.push_back(j); }
+    }
+    DBuf d_wmo, d_ltw, d_lti, d_ltj, d_wsim, d_wdiff;
+    if (Wmx < Wd) { G.pack.add(win_mat_off, d_wmo); G.pack.add(lt_w, d_ltw); G.pack.add(lt_i, d_lti); G.pack.add(lt_j, d_ltj); }
     G.pack.add(ctg_out_off, G.d_oo);
     G.pack.add(ctg_n, G.d_n);
     G.pack.add(ws.win_contig, G.d_wc);
@@ -1612,7 +1631,7 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
     EventPair ev; if (int rc = ev.init()) return rc;
     bool timed = false;
     if (rows_dev > 0) {
-        if (!d_sim) { set_error("read graphs before simdiff"); return HS_EINVAL; }
+        if (rows_mx > 0 && !d_sim) { set_error("read graphs before simdiff"); return HS_EINVAL; }
         const size_t bits_bytes = (size_t)win_bits_off.back() * 8;
         if (int rc = d_bits.alloc(bits_bytes)) return rc;
         if (int rc = d_ar.alloc(((size_t)rows_dev + 1) * 4)) return rc;      // [0] = number of rows left to the host, then the rows
@@ -1625,15 +1644,38 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
         if ((size_t)cap * 8 > 57344) cap = 7168;
         const float below = 1 - ws.error_rate * 2;   // :778
         HS_HIP(hipEventRecord(ev.a, stream));
-        if (kc) { if (int rc = kc->begin(HS_K_GRAPH_ROWS, stream)) return rc; }
-        hipLaunchKernelGGL(hsdev::k_read_graph_rows, dim3((rows_dev + waves - 1) / waves), dim3(64 * waves), (size_t)cap * 8 * waves, stream, d_sim, d_diff,
-                           G.d_oo.as<int64_t>(), G.d_n.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_rw.as<int32_t>(),
-                           G.d_bo.as<int64_t>(), rows_dev, below, cap, d_bits.as<unsigned long long>(), d_ar.as<int32_t>(), d_ar.as<int32_t>() + 1, rows_dev);
-        HS_HIP(hipGetLastError());
-        if (kc) {   // per row: the sim and diff entries of the window's m reads in, m link bits out
-            int64_t by = 0;
-            for (int w = 0; w < Wd; ++w) { const int64_t m = G.win_m[(size_t)w]; by += m * (8 * m + (m + 7) / 8); }
-            if (int rc = kc->end(by, stream)) return rc;
+        if (rows_mx > 0) {
+            if (kc) { if (int rc = kc->begin(HS_K_GRAPH_ROWS, stream)) return rc; }
+            hipLaunchKernelGGL(hsdev::k_read_graph_rows<false>, dim3((rows_mx + waves - 1) / waves), dim3(64 * waves), (size_t)cap * 8 * waves, stream, d_sim, d_diff,
+                               G.d_oo.as<int64_t>(), G.d_n.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_rw.as<int32_t>(),
+                               G.d_bo.as<int64_t>(), 0, rows_mx, below, cap, d_bits.as<unsigned long long>(), d_ar.as<int32_t>(), d_ar.as<int32_t>() + 1, rows_dev,
+                               (const int64_t*)nullptr);
+            HS_HIP(hipGetLastError());
+            if (kc) {   // per row: the sim and diff entries of the window's m reads in, m link bits out
+                int64_t by = 0;
+                for (int w = 0; w < Wmx; ++w) { const int64_t m = G.win_m[(size_t)w]; by += m * (8 * m + (m + 7) / 8); }
+                if (int rc = kc->end(by, stream)) return rc;
+            }
+        }
+        if (rows_dev > rows_mx) {
+            // create_read_graph_low_memory: the window-local matrices from the bit rows, then the same row kernel with that path's distance
+            const size_t mat = (size_t)win_mat_off.back();
+            if (int rc = d_wsim.alloc(std::max<size_t>(mat, 1) * 4)) return rc;
+            if (int rc = d_wdiff.alloc(std::max<size_t>(mat, 1) * 4)) return rc;
+            if (kc) { if (int rc = kc->begin(HS_K_SIMDIFF, stream)) return rc; }
+            hipLaunchKernelGGL(hsdev::k_simdiff_windows, dim3((unsigned)lt_w.size()), dim3(256), 0, stream, planes->d_alt, planes->d_ref, planes->d_plane_off, planes->d_words,
+                               G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), d_wmo.as<int64_t>(), d_ltw.as<int32_t>(), d_lti.as<int32_t>(),
+                               d_ltj.as<int32_t>(), d_wsim.as<int32_t>(), d_wdiff.as<int32_t>());
+            HS_HIP(hipGetLastError());
+            if (kc) { if (int rc = kc->end(8 * (int64_t)mat, stream)) return rc; }
+            if (kc) { if (int rc = kc->begin(HS_K_GRAPH_ROWS, stream)) return rc; }
+            const int n_lm = rows_dev - rows_mx;
+            hipLaunchKernelGGL(hsdev::k_read_graph_rows<true>, dim3((n_lm + waves - 1) / waves), dim3(64 * waves), (size_t)cap * 8 * waves, stream, d_wsim.as<int32_t>(),
+                               d_wdiff.as<int32_t>(), G.d_oo.as<int64_t>(), G.d_n.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(),
+                               G.d_rw.as<int32_t>(), G.d_bo.as<int64_t>(), rows_mx, n_lm, below, cap, d_bits.as<unsigned long long>(), d_ar.as<int32_t>(),
+                               d_ar.as<int32_t>() + 1, rows_dev, d_wmo.as<int64_t>());
+            HS_HIP(hipGetLastError());
+            if (kc) { if (int rc = kc->end(8 * (int64_t)mat, stream)) return rc; }
         }
         HS_HIP(hipEventRecord(ev.b, stream));
         timed = true;
@@ -1656,14 +1698,24 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
                 const int c = ws.win_contig[(size_t)w];
                 const int N = ctg_n[(size_t)c];
                 const int r1 = ws.mask_ids[(size_t)amb[(size_t)k]];
-                src[(size_t)k] = ctg_out_off[(size_t)c] + (int64_t)r1 * N; len[(size_t)k] = N; dst[(size_t)k + 1] = dst[(size_t)k] + N;
+                if (amb[(size_t)k] < rows_mx) { src[(size_t)k] = ctg_out_off[(size_t)c] + (int64_t)r1 * N; len[(size_t)k] = N; }
+                else {      // a row of a window-local matrix: its m entries
+                    const int64_t m = G.win_m[(size_t)w];
+                    src[(size_t)k] = win_mat_off[(size_t)w] + (int64_t)(amb[(size_t)k] - ws.win_row0[(size_t)w]) * m; len[(size_t)k] = (int32_t)m;
+                }
+                dst[(size_t)k + 1] = dst[(size_t)k] + len[(size_t)k];
             }
+            const int n_amb_mx = (int)(std::lower_bound(amb.begin(), amb.end(), rows_mx) - amb.begin());      // (sorted: the matrix rows come first)
             pk_amb.add(src, d_src); pk_amb.add(len, d_len); pk_amb.add(dst, d_dst);
             if (int rc = pk_amb.commit(stream)) return rc;
             if (int rc = d_os.alloc((size_t)dst.back() * 4)) return rc;
             if (int rc = d_od.alloc((size_t)dst.back() * 4)) return rc;
-            hipLaunchKernelGGL(hsdev::k_read_graph_fetch_rows, dim3(n_amb), dim3(256), 0, stream, d_sim, d_diff, d_src.as<int64_t>(), d_len.as<int32_t>(),
-                               d_dst.as<int64_t>(), d_os.as<int32_t>(), d_od.as<int32_t>());
+            if (n_amb_mx > 0)
+                hipLaunchKernelGGL(hsdev::k_read_graph_fetch_rows, dim3(n_amb_mx), dim3(256), 0, stream, d_sim, d_diff, d_src.as<int64_t>(), d_len.as<int32_t>(),
+                                   d_dst.as<int64_t>(), d_os.as<int32_t>(), d_od.as<int32_t>());
+            if (n_amb > n_amb_mx)
+                hipLaunchKernelGGL(hsdev::k_read_graph_fetch_rows, dim3(n_amb - n_amb_mx), dim3(256), 0, stream, d_wsim.as<int32_t>(), d_wdiff.as<int32_t>(),
+                                   d_src.as<int64_t>() + n_amb_mx, d_len.as<int32_t>() + n_amb_mx, d_dst.as<int64_t>() + n_amb_mx, d_os.as<int32_t>(), d_od.as<int32_t>());
             HS_HIP(hipGetLastError());
             // both row sets with one wait, read where they land
             HBuf h_rows;
@@ -1684,10 +1736,11 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
                 const int64_t m0 = ws.win_row0[(size_t)w];
                 const int m = (int)(ws.win_row0[(size_t)w + 1] - m0);
                 const int32_t* ids = ws.mask_ids.data() + m0;
-                const int N = len[(size_t)k];
+                const int N = ctg_n[(size_t)ws.win_contig[(size_t)w]];
                 mask.assign((size_t)N, 0);
                 for (int j = 0; j < m; ++j) mask[(size_t)ids[j]] = 1;
-                hs::sr_pick_row_sorted(hs_ + dst[(size_t)k], hd_ + dst[(size_t)k], N, ids[row - m0], mask.data(), ws.error_rate, picked);
+                if (row < rows_mx) hs::sr_pick_row_sorted(hs_ + dst[(size_t)k], hd_ + dst[(size_t)k], N, ids[row - m0], mask.data(), ws.error_rate, picked);
+                else hs::sr_pick_row_sorted_low_memory(hs_ + dst[(size_t)k], hd_ + dst[(size_t)k], ids, m, (int)(row - m0), N, mask.data(), ws.error_rate, picked);
                 for (int nb : picked) {
                     const int j = (int)(std::lower_bound(ids, ids + m, nb) - ids);
                     pbase.push_back(win_bits_off[(size_t)w]); pmw.push_back((m + 63) >> 6); pi.push_back((int32_t)(row - m0)); pj.push_back(j);
@@ -1702,7 +1755,11 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
                 HS_HIP(hipGetLastError());      // (the patch arrays live until the wait at the end of this function)
             }
             if (rows_on_host) *rows_on_host = n_amb;
-        }
+            if (std::getenv("HS_TIMING") && Wmx < Wd)
+                std::fprintf(stderr, "[hs timing] sr: low-memory path on the device: %d windows, %d rows, %d of them resolved on the host (NaN distances / std::sort ties)\n",
+                             Wd - Wmx, rows_dev - rows_mx, n_amb - n_amb_mx);
+        } else if (std::getenv("HS_TIMING") && Wmx < Wd)
+            std::fprintf(stderr, "[hs timing] sr: low-memory path on the device: %d windows, %d rows, none resolved on the host\n", Wd - Wmx, rows_dev - rows_mx);
         if (kc) { if (int rc = kc->begin(HS_K_GRAPH_CSR, stream)) return rc; }
         hipLaunchKernelGGL(hsdev::k_read_graph_degrees, dim3((rows_dev + 255) / 256), dim3(256), 0, stream, d_bits.as<unsigned long long>(), G.d_rw.as<int32_t>(),
                            G.d_row0.as<int64_t>(), G.d_bo.as<int64_t>(), rows_dev, d_deg.as<int32_t>());
@@ -1771,7 +1828,7 @@ struct HipSrOps : hs::SrDeviceOps {
     // K5 runs on while the host plans the windows: its temporaries and its timing events are parked here until the next
     // call that waits for the stream anyway
     struct SimdiffInFlight {
-        DBuf d_alt, d_ref, d_sr, d_sa, d_sc, d_cb, d_po, d_n, d_w, d_oo, t_c, t_i, t_j, d_bc, d_bw;
+        DBuf d_alt, d_ref, d_sr, d_sa, d_sc, d_cb, d_po, d_n, d_pn, d_w, d_oo, t_c, t_i, t_j, d_bc, d_bw;
         std::vector<int32_t> tc, ti, tj, blk_c, blk_w;      // (the lists ride in the one upload of the call)
         UploadPack pk;
         EventPair ev;
@@ -1806,6 +1863,8 @@ struct HipSrOps : hs::SrDeviceOps {
         adopted = true; adopted_cols = cv.snp_count; adopted_entries = cv.snp_entries;
     }
     bool columns_resident() const override { return adopted; }
+    // (HS_LOW_MEMORY_GRAPHS_ON_HOST=1: the windows of the low-memory path keep the host builder)
+    bool low_memory_graphs() const override { static const bool host = std::getenv("HS_LOW_MEMORY_GRAPHS_ON_HOST") != nullptr; return !host; }
     void drop_resident_columns() override { adopted = false; resident_cols = nullptr; }
     int fetch_columns(std::vector<int32_t>& idx, std::vector<uint8_t>& code) override {
         if (!adopted) { set_error("fetch_columns: no resident columns"); return HS_EINVAL; }
@@ -1850,7 +1909,7 @@ struct HipSrOps : hs::SrDeviceOps {
         } else if ((int64_t)ch.col_off.size() != adopted_cols + 1) { set_error("simdiff_columns: the resident columns are not those of this call"); return HS_EINVAL; }
         resident_cols = job.cols;
         sd_out_off = job.out_off; sd_n = job.n_reads;
-        if (job.out_total <= 0) return HS_OK;
+        if (job.out_total <= 0 && job.plane_total <= 0) return HS_OK;
         if (int rc = settle_simdiff()) return rc;
         sd_flight.reset(new SimdiffInFlight());
         SimdiffInFlight& f = *sd_flight;
@@ -1861,6 +1920,7 @@ struct HipSrOps : hs::SrDeviceOps {
         f.pk.add(job.contig_snp_base, f.d_cb);
         f.pk.add(job.plane_off, f.d_po);
         f.pk.add(job.n_reads, f.d_n);
+        f.pk.add(job.plane_n, f.d_pn);
         f.pk.add(job.words, f.d_w);
         f.pk.add(job.out_off, f.d_oo);
         snp_planes_blocks(job.words.data(), (int)job.words.size(), f.blk_c, f.blk_w);
@@ -1870,11 +1930,11 @@ struct HipSrOps : hs::SrDeviceOps {
         const size_t pbytes = (size_t)job.plane_total * sizeof(uint64_t);
         if (int rc = f.d_alt.alloc(pbytes)) return rc;
         if (int rc = f.d_ref.alloc(pbytes)) return rc;
-        if (int rc = d_sim.alloc((size_t)job.out_total * sizeof(int32_t))) return rc;
-        if (int rc = d_diff.alloc((size_t)job.out_total * sizeof(int32_t))) return rc;
+        if (int rc = d_sim.alloc(std::max<size_t>((size_t)job.out_total, 1) * sizeof(int32_t))) return rc;
+        if (int rc = d_diff.alloc(std::max<size_t>((size_t)job.out_total, 1) * sizeof(int32_t))) return rc;
         if (int rc = kc.begin(HS_K_SNP_PLANES, stream)) return rc;
         if (int rc = snp_planes_launch(d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(), f.d_sr.as<uint8_t>(), f.d_sa.as<uint8_t>(),
-                                       f.d_sc.as<int32_t>(), f.d_cb.as<int64_t>(), f.d_po.as<int64_t>(), f.d_w.as<int32_t>(), f.d_n.as<int32_t>(), f.d_bc.as<int32_t>(),
+                                       f.d_sc.as<int32_t>(), f.d_cb.as<int64_t>(), f.d_po.as<int64_t>(), f.d_w.as<int32_t>(), f.d_pn.as<int32_t>(), f.d_bc.as<int32_t>(),
                                        f.d_bw.as<int32_t>(), f.blk_c.size(), (int32_t)job.snp_ref.size(), f.d_alt.as<uint64_t>(), f.d_ref.as<uint64_t>(), stream)) return rc;
         if (int rc = kc.end(5 * (adopted ? adopted_entries : (int64_t)ch.col_idx.size()) + 2 * (int64_t)pbytes, stream)) return rc;
         if (int rc = f.ev.init()) return rc;
@@ -1888,7 +1948,9 @@ struct HipSrOps : hs::SrDeviceOps {
     }
 
     int build_graphs(const hs::SrWindowSet& ws, int64_t* rows_on_host, float* k_ms) override {
-        const int rc = graph_rows_build(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, ws, G, stream, rows_on_host, k_ms, &kc);
+        PlaneRows pr;
+        if (sd_flight) { pr.d_alt = sd_flight->d_alt.as<uint64_t>(); pr.d_ref = sd_flight->d_ref.as<uint64_t>(); pr.d_plane_off = sd_flight->d_po.as<int64_t>(); pr.d_words = sd_flight->d_w.as<int32_t>(); }
+        const int rc = graph_rows_build(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, ws, G, stream, rows_on_host, k_ms, &kc, &pr);
         const int rc2 = settle_simdiff();   // K6 came after K5 on the stream and has been waited for
         return rc ? rc : rc2;
     }

@@ -459,6 +459,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     });
 
     laps.lap("perm");
+    const bool lm_on_device = dev.low_memory_graphs();
     // ---- the SNP columns of the batch, concatenated once: K5a/K5 (sim / diff) now, Chinese-Whispers seeding later ----
     CwChain ch;
     std::vector<int64_t> col_base_of_contig((size_t)C, 0);
@@ -466,7 +467,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         SimdiffJob job;
         job.cols = &ch;
         job.contig_snp_base.assign((size_t)C, 0); job.plane_off.assign((size_t)C, 0); job.out_off.assign((size_t)C, 0);
-        job.n_reads.assign((size_t)C, 0); job.words.assign((size_t)C, 0);
+        job.n_reads.assign((size_t)C, 0); job.words.assign((size_t)C, 0); job.plane_n.assign((size_t)C, 0);
         int64_t n_ent = 0, n_col = 0;
         for (int c = 0; c < C; ++c) { n_col += contigs[c].n_snps; if (contigs[c].n_snps) n_ent += contigs[c].col_off[contigs[c].n_snps] - contigs[c].col_off[0]; }
         // The columns of the call as ONE CSR in contig order. When the caller's arrays already are that (stage 3 hands its result
@@ -504,10 +505,13 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
                 const hs_sr_contig& hc = contigs[c];
                 if (hc.n_snps == 0) continue;
                 cb += hc.n_snps; eb += hc.col_off[hc.n_snps] - hc.col_off[0];
-                if (st[(size_t)c].low_memory_now) continue;
-                job.plane_off[(size_t)c] = job.plane_total; job.out_off[(size_t)c] = job.out_total;
-                job.n_reads[(size_t)c] = st[(size_t)c].N; job.words[(size_t)c] = st[(size_t)c].words;
+                if (st[(size_t)c].low_memory_now && !lm_on_device) continue;
+                // bit rows for the matrix path and for the low-memory path (whose windows compare their own reads only: no N x N)
+                job.plane_off[(size_t)c] = job.plane_total; job.words[(size_t)c] = st[(size_t)c].words; job.plane_n[(size_t)c] = st[(size_t)c].N;
                 job.plane_total += (int64_t)st[(size_t)c].N * st[(size_t)c].words;
+                if (st[(size_t)c].low_memory_now) continue;
+                job.out_off[(size_t)c] = job.out_total;
+                job.n_reads[(size_t)c] = st[(size_t)c].N;
                 job.out_total += (int64_t)st[(size_t)c].N * st[(size_t)c].N;
             }
         }
@@ -582,14 +586,47 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     SrWindowSet ws;
     ws.error_rate = error_rate;
     {
-        std::vector<WRef> host_w;
+        // Low-memory contigs on the device: the reference indexes a read's 0/1/2 vector by the ORDER of its appearances (:545-575),
+        // the bit rows by SNP; the two agree when every read is present at every SNP between its first and its last one (always so
+        // for columns that stage 3 wrote: a column lists every record that covers the position). Checked here; a contig where it
+        // does not hold keeps the host builder.
+        std::vector<uint8_t> lm_dev((size_t)C, 0);
+        bool any_lm = false;
+        for (int c = 0; c < C; ++c) if (contigs[c].n_snps > 0 && st[(size_t)c].low_memory_now) any_lm = true;
+        if (any_lm && lm_on_device) {
+            if (int rc = need_columns()) return rc;
+            parallel_for(C, n_threads, [&](int c) {
+                const hs_sr_contig& hc = cs_local[(size_t)c];
+                if (hc.n_snps == 0 || !st[(size_t)c].low_memory_now) return;
+                std::vector<int32_t> first((size_t)st[(size_t)c].N, -1), last((size_t)st[(size_t)c].N, -1), cnt((size_t)st[(size_t)c].N, 0);
+                for (int s = 0; s < hc.n_snps; ++s)
+                    for (int64_t e = hc.col_off[s]; e < hc.col_off[s + 1]; ++e) {
+                        const int r = hc.col_idx[e];
+                        if (first[(size_t)r] < 0) first[(size_t)r] = s;
+                        last[(size_t)r] = s; cnt[(size_t)r]++;
+                    }
+                bool ok = true;
+                for (int r = 0; r < st[(size_t)c].N && ok; ++r) if (cnt[(size_t)r] > 0 && cnt[(size_t)r] != last[(size_t)r] - first[(size_t)r] + 1) ok = false;
+                lm_dev[(size_t)c] = ok ? 1 : 0;
+            });
+        }
+        if (any_lm && std::getenv("HS_TIMING")) {
+            int n_lm = 0, n_ok = 0;
+            for (int c = 0; c < C; ++c) if (contigs[c].n_snps > 0 && st[(size_t)c].low_memory_now) { n_lm++; n_ok += lm_dev[(size_t)c]; }
+            std::fprintf(stderr, "[hs timing] sr: %d contigs on the low-memory path, %d of them with graphs from the device\n", n_lm, n_ok);
+        }
+        std::vector<WRef> lm_w, host_w;
         for (int c = 0; c < C; ++c)
             for (size_t w = 0; w < st[(size_t)c].windows.size(); ++w) {
                 if (!st[(size_t)c].windows[w].has_snps) continue;
-                (st[(size_t)c].low_memory_now ? host_w : wrefs).push_back(WRef{c, (int)w});
+                (!st[(size_t)c].low_memory_now ? wrefs : (lm_dev[(size_t)c] ? lm_w : host_w)).push_back(WRef{c, (int)w});
             }
+        ws.n_matrix_windows = (int32_t)wrefs.size();
+        wrefs.insert(wrefs.end(), lm_w.begin(), lm_w.end());
         ws.n_dev_windows = (int32_t)wrefs.size();
         wrefs.insert(wrefs.end(), host_w.begin(), host_w.end());
+        ws.ctg_reads.resize((size_t)C);
+        for (int c = 0; c < C; ++c) ws.ctg_reads[(size_t)c] = st[(size_t)c].N;
         const size_t W = wrefs.size();
         ws.win_contig.resize(W); ws.win_row0.assign(W + 1, 0); ws.win_final_empty.resize(W);
         for (size_t i = 0; i < W; ++i) {

@@ -112,7 +112,9 @@ struct SrWindowSet {
     std::vector<int32_t> win_contig;       // [W] contig index as passed to simdiff_columns
     std::vector<int64_t> win_row0;         // [W+1]
     std::vector<int32_t> mask_ids;         // [rows]
-    int32_t n_dev_windows = 0;
+    int32_t n_dev_windows = 0;             // windows whose graphs the device builds: the first n_matrix_windows from the contig's sim / diff
+    int32_t n_matrix_windows = 0;          // matrices, the others (low-memory path) from window-local matrices; behind them the host's
+    std::vector<int32_t> ctg_reads;        // [C] reads of every contig
     std::vector<int64_t> host_off;         // [host rows + 1], starts at 0
     std::vector<int32_t> host_nbr;
     std::vector<uint8_t> win_final_empty;  // [W] finalize_clustering sees an empty graph for this window (separate_reads.cpp:1708)
@@ -170,6 +172,7 @@ struct SimdiffJob {
     std::vector<int64_t> contig_snp_base;        // [C] first column of each contig
     std::vector<int64_t> plane_off, out_off;     // [C] offsets of the contig's bit rows (uint64 words) / matrices (int32)
     std::vector<int32_t> n_reads, words;         // [C]; n_reads == 0: contig not on the matrix path
+    std::vector<int32_t> plane_n;                // [C] reads of every contig that has bit rows (words > 0): the matrix path AND the low-memory path
     int64_t plane_total = 0, out_total = 0;
 };
 
@@ -199,6 +202,8 @@ struct SrDeviceOps {
     virtual int cw(CwWave& wave, float* k_ms) = 0;
     // The SNP columns of the call may be with the implementation already (stage 3 left them on the device, in the order and with
     // the offsets of CwChain::col_off): then CwChain's col_idx / col_code stay empty and ...
+    // create_read_graph_low_memory on the device (window-local sim / diff from the bit rows); false: the caller builds those rows
+    virtual bool low_memory_graphs() const { return false; }
     virtual bool columns_resident() const { return false; }
     virtual void drop_resident_columns() {}
     // ... the reads of every clustering window -- those present at its first AND its last SNP column (separate_reads.cpp:1590-1622),

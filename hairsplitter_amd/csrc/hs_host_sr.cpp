@@ -73,6 +73,25 @@ void sr_pick_row_sorted(const int32_t* srow, const int32_t* drow, int N, int r1,
     pick_neighbors_sorted(smallest, mask, error_rate, picked);
 }
 
+// One row of create_read_graph_low_memory (separate_reads.cpp:590-670) from the counts of the window's own reads: srow / drow hold
+// nsim / ndif of masked read `i` against the m masked reads (local order); every other read of the contig keeps distance 0. No
+// `sim > 0` guard on this path (:618): 0 / 0 is NaN and std::sort sees it, as in the reference.
+void sr_pick_row_sorted_low_memory(const int32_t* srow, const int32_t* drow, const int32_t* ids, int m, int i, int N, const uint8_t* mask, float error_rate,
+                                   std::vector<int>& picked) {
+    std::vector<std::pair<int, float>> smallest((size_t)N);
+    for (int r = 0; r < N; ++r) smallest[(size_t)r] = std::make_pair(r, 0.0f);
+    int max_compat = 0;
+    for (int j = 0; j < m; ++j) {
+        if (j == i) continue;
+        const int nsim = srow[j], ndif = drow[j];
+        smallest[(size_t)ids[j]].second = 1 - std::max(0, ndif - 1) / float(ndif + nsim);
+        if (nsim > max_compat) max_compat = nsim;
+    }
+    for (int j = 0; j < m; ++j)
+        if (j != i && srow[j] + drow[j] < 0.7 * max_compat) smallest[(size_t)ids[j]].second = 0;
+    pick_neighbors_sorted(smallest, mask, error_rate, picked);
+}
+
 // position of read r in the ascending list ids, or -1
 static inline int local_index(const std::vector<int32_t>& ids, int r) {
     const auto it = std::lower_bound(ids.begin(), ids.end(), r);

@@ -31,6 +31,10 @@ struct SrLocalGraph {
 std::vector<int32_t> shuffled_order(int n, uint32_t seed);
 // with_reads = false: the windows' read lists (ids) are left empty -- the columns are not here; col_a / col_b say which two make them
 void sr_plan_windows(SrContigState& st, int window_size, float error_rate, bool low_memory, bool with_reads = true);
+// one row of that builder from the window-local counts the device formed (the rows it hands back: a NaN distance, or a run of equal
+// distances at the cut-off)
+void sr_pick_row_sorted_low_memory(const int32_t* srow, const int32_t* drow, const int32_t* ids, int m, int i, int N, const uint8_t* mask, float error_rate,
+                                   std::vector<int>& picked);
 // create_read_graph_low_memory (separate_reads.cpp:538-693) for one window, in local index space: deg/nbr lists per node
 void sr_build_window_graph_low_memory(const SrContigState& st, const SrWindowPlan& w, float error_rate, std::vector<std::vector<int32_t>>& lists);
 // one row of create_read_graph_matrix in the reference's own way (std::sort + walk, separate_reads.cpp:745-815): used for

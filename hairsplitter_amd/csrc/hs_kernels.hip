@@ -1056,6 +1056,77 @@ __global__ __launch_bounds__(256) void k_simdiff(
 }
 
 // ------------------------------------------------------------------------------------------------
+// K5 for the low-memory path (create_read_graph_low_memory, separate_reads.cpp:538-693): the reference compares every pair of
+// masked reads of a WINDOW over the SNPs both reads cover and never forms the N x N matrices. With the 0/1/2 vectors as bit rows
+// that comparison is the same popcount as k_simdiff (2 & 2 -> +3, 1 & 1 -> +1, 1 & 2 or 2 & 1 -> difference; a read has no bits
+// outside its span, so all words of the contig can be walked), restricted to the window's m masked reads: an m x m matrix per
+// window. One workgroup per 64 x 64 tile of a window, every tile (no mirroring), rows gathered through the window's read list.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_simdiff_windows(
+    const uint64_t* __restrict__ alt, const uint64_t* __restrict__ ref, const int64_t* __restrict__ plane_off, const int32_t* __restrict__ words,
+    const int32_t* __restrict__ win_contig, const int64_t* __restrict__ win_mask_off, const int32_t* __restrict__ mask_ids,
+    const int64_t* __restrict__ win_mat_off, const int32_t* __restrict__ tile_win, const int32_t* __restrict__ tile_i, const int32_t* __restrict__ tile_j,
+    int32_t* __restrict__ wsim, int32_t* __restrict__ wdiff) {
+    __shared__ uint64_t s_planes[4][64][SD_KW + 1];
+    uint64_t (*sAi)[SD_KW + 1] = s_planes[0]; uint64_t (*sRi)[SD_KW + 1] = s_planes[1];
+    uint64_t (*sAj)[SD_KW + 1] = s_planes[2]; uint64_t (*sRj)[SD_KW + 1] = s_planes[3];
+    const int tid = (int)threadIdx.x;
+    const int w = tile_win[blockIdx.x];
+    const int c = win_contig[w];
+    const int i0 = tile_i[blockIdx.x] * 64, j0 = tile_j[blockIdx.x] * 64;
+    const int64_t m0 = win_mask_off[w];
+    const int m = (int)(win_mask_off[w + 1] - m0);
+    const int32_t* __restrict__ ids = mask_ids + m0;
+    const int W = words[c];
+    const uint64_t* __restrict__ A = alt + plane_off[c];
+    const uint64_t* __restrict__ R = ref + plane_off[c];
+    const int ti = tid >> 4, tj = tid & 15;
+    int s_acc[4][4], d_acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { s_acc[a][b] = 0; d_acc[a][b] = 0; }
+    for (int w0 = 0; w0 < W; w0 += SD_KW) {
+        for (int x = tid; x < 64 * SD_KW; x += 256) {
+            const int row = x / SD_KW, ww = x % SD_KW;
+            const int gw = w0 + ww;
+            const bool wi = i0 + row < m && gw < W, wj = j0 + row < m && gw < W;
+            const int64_t ri = wi ? ids[i0 + row] : 0, rj = wj ? ids[j0 + row] : 0;
+            sAi[row][ww] = wi ? A[ri * W + gw] : 0ull;
+            sRi[row][ww] = wi ? R[ri * W + gw] : 0ull;
+            sAj[row][ww] = wj ? A[rj * W + gw] : 0ull;
+            sRj[row][ww] = wj ? R[rj * W + gw] : 0ull;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int ww = 0; ww < SD_KW; ++ww) {
+            uint64_t ai[4], ri[4], aj[4], rj[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { ai[a] = sAi[ti + 16 * a][ww]; ri[a] = sRi[ti + 16 * a][ww]; }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { aj[b] = sAj[tj + 16 * b][ww]; rj[b] = sRj[tj + 16 * b][ww]; }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    s_acc[a][b] += 3 * __popcll(ai[a] & aj[b]) + __popcll(ri[a] & rj[b]);
+                    d_acc[a][b] += __popcll(ai[a] & rj[b]) + __popcll(ri[a] & aj[b]);
+                }
+        }
+        __syncthreads();
+    }
+    int32_t* __restrict__ S = wsim + win_mat_off[w];
+    int32_t* __restrict__ D = wdiff + win_mat_off[w];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int gi = i0 + ti + 16 * a, gj = j0 + tj + 16 * b;
+            if (gi < m && gj < m) { S[(int64_t)gi * m + gj] = s_acc[a][b]; D[(int64_t)gi * m + gj] = d_acc[a][b]; }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K7 Chinese Whispers: cluster_graph.cpp:240-310 (and :152-230). One wavefront (one 64-thread workgroup)
 // per instance; labels and the per-label vote counters live in LDS. Nodes are visited sequentially in the
 // supplied permutation; the neighbours of the current node are spread over the lanes: LDS atomic add of one

@@ -45,17 +45,22 @@ static __device__ __forceinline__ void next_level(const float* __restrict__ dv, 
     *v_out = vv; *c_out = c;
 }
 
+// LM: the low-memory path (create_read_graph_low_memory, separate_reads.cpp:538-693). sim / diff are then the window-local m x m
+// matrices of k_simdiff_windows (window w at win_mat_off[w], indexed by local ids), and the distance is that path's own: every
+// other masked read takes part whether the two share a similar SNP or not (no `sim > 0` guard, :618), so 0 / 0 occurs; a row with
+// a NaN goes to the host (std::sort with NaNs is the reference's behaviour, not ours to restate with order statistics).
+template <bool LM>
 __global__ __launch_bounds__(256) void k_read_graph_rows(
     const int32_t* __restrict__ sim, const int32_t* __restrict__ diff, const int64_t* __restrict__ ctg_out_off,
     const int32_t* __restrict__ ctg_n, const int32_t* __restrict__ win_contig, const int64_t* __restrict__ win_mask_off,
     const int32_t* __restrict__ mask_ids, const int32_t* __restrict__ row_win, const int64_t* __restrict__ win_bits_off,
-    int n_rows, float below, int cap, unsigned long long* __restrict__ bits, int32_t* __restrict__ amb_count,
-    int32_t* __restrict__ amb_rows, int amb_cap) {
+    int row_base, int n_rows, float below, int cap, unsigned long long* __restrict__ bits, int32_t* __restrict__ amb_count,
+    int32_t* __restrict__ amb_rows, int amb_cap, const int64_t* __restrict__ win_mat_off) {
     extern __shared__ unsigned char s_dyn[];
     const int lane = lane_id();
     const int wv = wave_id(), waves = (int)(blockDim.x >> 6);
-    const int row = (int)blockIdx.x * waves + wv;
-    if (row >= n_rows) return;                    // wave-uniform
+    const int row = row_base + (int)blockIdx.x * waves + wv;
+    if (row >= row_base + n_rows) return;         // wave-uniform
     float* __restrict__ dv = reinterpret_cast<float*>(s_dyn) + (size_t)wv * 2 * cap;
     int* __restrict__ tv = reinterpret_cast<int*>(dv + cap);
     const int w = row_win[row];
@@ -70,16 +75,23 @@ __global__ __launch_bounds__(256) void k_read_graph_rows(
         if (lane == 0) { const int k = atomicAdd(amb_count, 1); if (k < amb_cap) amb_rows[k] = row; }
     };
     if (m > cap || N < 2 || !(below >= 0.f)) { give_up(); return; }
-    const int32_t* __restrict__ srow = sim + ctg_out_off[c] + (int64_t)r1 * N;
-    const int32_t* __restrict__ drow = diff + ctg_out_off[c] + (int64_t)r1 * N;
+    const int32_t* __restrict__ srow = LM ? sim + win_mat_off[w] + (int64_t)i * m : sim + ctg_out_off[c] + (int64_t)r1 * N;
+    const int32_t* __restrict__ drow = LM ? diff + win_mat_off[w] + (int64_t)i * m : diff + ctg_out_off[c] + (int64_t)r1 * N;
 
-    // distances of the masked reads (:752-759); every other read of the contig has distance 0
+    // distances of the masked reads (:752-759 / :611-624); every other read of the contig has distance 0
     int max_compat = 0;
+    bool nan_l = false;
     for (int j = lane; j < m; j += 64) {
         const int r = ids[j];
-        const int s = srow[r], dd = drow[r];
+        const int s = LM ? srow[j] : srow[r], dd = LM ? drow[j] : drow[r];
         float d = 0.f;
-        if (r != r1 && s > 0) {
+        if (LM) {
+            if (r != r1) {
+                const float df = (float)(dd - 1 > 0 ? dd - 1 : 0);
+                d = 1.f - df / (float)(s + dd);
+                if (s > max_compat) max_compat = s;
+            }
+        } else if (r != r1 && s > 0) {
             const float df = (float)(dd - 1 > 0 ? dd - 1 : 0);
             d = 1.f - df / (float)(s + dd);
             if (s > max_compat) max_compat = s;
@@ -88,9 +100,12 @@ __global__ __launch_bounds__(256) void k_read_graph_rows(
     }
     max_compat = wave_max_i32(max_compat);
     const double thr = 0.7 * (double)max_compat;   // :762-766
-    for (int j = lane; j < m; j += 64)
+    for (int j = lane; j < m; j += 64) {
         if ((double)tv[j] < thr) dv[j] = 0.f;
+        if (LM && dv[j] != dv[j]) nan_l = true;
+    }
     wave_lds_sync();
+    if (LM && __ballot(nan_l) != 0ull) { give_up(); return; }
 
     const int extra_zeros = N - m;
     // two largest values with multiplicity, number of exact ones

@@ -35,6 +35,16 @@ def test_dropin_binaries_with_the_alternative_paths(built, case, switch):
         assert gu.compare(td, outs) == []
 
 
+@pytest.mark.parametrize("case", [c for c in gu.case_names() if "lowmem" in c or "deep" in c])
+def test_dropin_binaries_with_low_memory_graphs_on_the_host(built, case):
+    """create_read_graph_low_memory runs on the device by default (window-local sim / diff from the bit rows, the row kernel with
+    that path's distance, rows with a NaN resolved on the host); HS_LOW_MEMORY_GRAPHS_ON_HOST=1 keeps the host builder: same files"""
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack(case, td)
+        outs = gu.run_stage_pair([built["cv"]], [built["sr"]], td, meta, env=dict(os.environ, HS_LOW_MEMORY_GRAPHS_ON_HOST="1"))
+        assert gu.compare(td, outs) == []
+
+
 @pytest.mark.parametrize("case", gu.case_names())
 def test_dropin_binaries_with_loop_a_on_the_device(built, case):
     """k_loop_a (loop A of keep_only_robust_variants as one wave per contig over bit sets in LDS, opt-in) against every golden case"""
