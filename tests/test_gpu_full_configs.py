@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _check(built, cfg, count=None, with_gaf=True):
+def _check(built, cfg, count=None, with_gaf=True, low_memory=0):
     if not (os.path.exists(built["ref_cv"]) and os.path.exists(built["ref_sr_seeded"])):
         pytest.fail("oracle/_ref binaries are missing: run `make -C oracle ref` where /root/reference exists (they travel with the snapshot)")
     with tempfile.TemporaryDirectory() as td:
-        out = fc.run_config(cfg, td, count, with_gaf=with_gaf)
+        out = fc.run_config(cfg, td, count, with_gaf=with_gaf, low_memory=low_memory)
     try:   # a record of the run next to the profiles of the round (scratch on the GPU box, merged back by gpurun)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "parity_full_configs.jsonl"), "a") as f:
@@ -39,6 +39,13 @@ def test_c2_x16_full_size_equals_reference(built):
     """C2: 100 kb contig, 2 haplotypes @1 %, 50x ONT (16 independent contigs of that shape)"""
     out = _check(built, "C2", 16)
     assert out["n_snps"] > 10_000
+
+
+def test_c2_x16_low_memory_flag_equals_reference(built):
+    """C2 x 16 with `-l` (create_read_graph_low_memory for every window, separate_reads.cpp:538-693): the graphs come from the
+    window-local sim / diff on the device, the reference builds them pair by pair on its cores"""
+    out = _check(built, "C2", 16, with_gaf=False, low_memory=1)
+    assert out["n_groups"] > 100
 
 
 def test_c3_full_size_equals_reference(built):
