@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_ROOT, "lib", "libhairsplitter_hip.so")
 SYMBOLS = [
     "hs_cv_batch_set_ploidy", "hs_version", "hs_last_error", "hs_device_count", "hs_warmup", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
-    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
+    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_partition_pair_distance", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_pipeline_thread_devices", "hs_cv_batch_device", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
     "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_host_wait_stats", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
@@ -740,6 +740,22 @@ def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1
     _check(load().hs_column_partition_test(*[_p(x) for x in d], C.c_int32(n), *[_p(x) for x in q], _hp(nr, C.c_int32), C.c_int32(len(nr)), _p(keep), C.c_void_p(0)))
     torch.cuda.synchronize()
     return keep[:n].cpu().numpy()
+
+
+def partition_pair_distance(state, more, less, part_off, part_n, pair_a, pair_b, threshold_p=2):
+    """V5 for a list of partition pairs (dense arrays, state 2 = absent): [n_pairs, 8] = n00, n01, n10, n11, phased, augmented, valid, comparable"""
+    import torch
+    require_gpu()
+    dev = "cuda:0"
+    n = len(pair_a)
+    up = lambda a, dt: torch.from_numpy(_np(a, dt) if len(a) else np.zeros(1, dt)).to(dev)
+    sigma3 = np.array([np.float32(0.5 * k + 3 * np.sqrt(k * 0.5 * (1 - 0.5))) for k in range(4096)], np.float32)
+    d = [up(state, np.int8), up(more, np.int32), up(less, np.int32), up(part_off, np.int64), up(part_n, np.int32), up(pair_a, np.int32), up(pair_b, np.int32)]
+    sg = up(sigma3, np.float32)
+    out = torch.zeros((max(n, 1), 8), dtype=torch.int32, device=dev)
+    _check(load().hs_partition_pair_distance(*[_p(x) for x in d], C.c_int32(n), C.c_int32(threshold_p), _p(sg), _p(out), C.c_void_p(0)))
+    torch.cuda.synchronize()
+    return out[:n].cpu().numpy()
 
 
 def snp_planes(n_reads, snp_ref, snp_alt, col_off, col_idx, col_code):

@@ -773,6 +773,17 @@ static int partition_test_launch(const int64_t* d_col_off, const int32_t* d_col_
     return HS_OK;
 }
 
+int hs_partition_pair_distance(const int8_t* d_state, const int32_t* d_more, const int32_t* d_less, const int64_t* d_part_off, const int32_t* d_part_n,
+                               const int32_t* d_pair_a, const int32_t* d_pair_b, int32_t n_pairs, int32_t threshold_p, const float* d_sigma3, int32_t* d_out,
+                               void* stream) {
+    if (int rc = require_device()) return rc;
+    if (n_pairs <= 0) return HS_OK;
+    hipLaunchKernelGGL(hsdev::k_partition_pair_distance, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_state, d_more, d_less, d_part_off,
+                       d_part_n, d_pair_a, d_pair_b, n_pairs, threshold_p, d_sigma3, d_out);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
+
 int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code,
                              const int32_t* d_col_contig, const uint8_t* d_col_k0, const uint8_t* d_col_k1,
                              const int32_t* d_col_c1, const uint8_t* d_col_is_cand, int32_t n_cols,
@@ -1430,6 +1441,22 @@ struct HipCvOps : hs::CvDeviceOps {
         return k_ms ? e.ms(k_ms) : HS_OK;
     }
     // ---- loop A on the device (hs_kernels_loopa.hip) on the candidates of the last extract_candidates() ----
+    bool has_partition_pairs() const override { return true; }
+    int partition_pairs(const std::vector<int8_t>& state, const std::vector<int32_t>& more, const std::vector<int32_t>& less, const std::vector<int64_t>& part_off,
+                        const std::vector<int32_t>& part_n, const std::vector<int32_t>& pair_a, const std::vector<int32_t>& pair_b, const std::vector<float>& sigma3,
+                        std::vector<int32_t>& out) override {
+        const int n_pairs = (int)pair_a.size();
+        out.assign((size_t)n_pairs * 8, 0);
+        if (n_pairs == 0) return HS_OK;
+        DBuf d_st, d_mo, d_le, d_po, d_pn, d_pa, d_pb, d_sg, d_out;
+        UploadPack pk;
+        pk.add(state, d_st); pk.add(more, d_mo); pk.add(less, d_le); pk.add(part_off, d_po); pk.add(part_n, d_pn); pk.add(pair_a, d_pa); pk.add(pair_b, d_pb); pk.add(sigma3, d_sg);
+        if (int rc = pk.commit(stream)) return rc;
+        if (int rc = d_out.alloc((size_t)n_pairs * 32)) return rc;
+        if (int rc = hs_partition_pair_distance(d_st.as<int8_t>(), d_mo.as<int32_t>(), d_le.as<int32_t>(), d_po.as<int64_t>(), d_pn.as<int32_t>(), d_pa.as<int32_t>(),
+                                                d_pb.as<int32_t>(), n_pairs, 2, d_sg.as<float>(), d_out.as<int32_t>(), stream)) return rc;
+        return d2h_pinned(out.data(), d_out.p, (size_t)n_pairs * 32, stream);
+    }
     bool has_robust_partitions() const override { return true; }
     DBuf d_la_parts, d_la_bits, d_la_cnt, d_la_np, d_la_pb, d_la_out_rec, d_la_out_bits, d_la_out_cnt, d_la_diag, d_la_rc, d_la_hdr, d_la_words, d_la_ends;
     HBuf h_la_np, h_la_rec, h_la_bits, h_la_cnt;

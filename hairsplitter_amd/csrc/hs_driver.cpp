@@ -275,6 +275,8 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
         cs.rec = cand.rec + cand_base[(size_t)c]; cs.off = cand.off + cand_base[(size_t)c]; cs.idx = cand.idx; cs.code = cand.code;
         return cs;
     };
+    static const bool loop_b_pairs = []() { const char* e = std::getenv("HS_LOOP_B_PAIRS_ON_DEVICE"); return e && e[0] != '0'; }();
+    const bool pairs_on_device = loop_b_pairs && dev.has_partition_pairs();
     std::atomic<int> n_host_a{0};
     parallel_for(C, n_threads, [&](int c) {
         const int r0 = b.contig_rec_off[(size_t)(c0 + c)];
@@ -284,8 +286,36 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
                               la.bits + la.bits_base[(size_t)c], la.cnt + la.cnt_base[(size_t)c]);
             (void)N;
         } else { cv_phase_a_host(*cst[(size_t)c], candidates_of(c), b.rec_pos.data() + r0, rend[(size_t)c].data()); n_host_a++; }
-        cv_phase_b(*cst[(size_t)c], res[(size_t)c]);
+        if (!pairs_on_device) cv_phase_b(*cst[(size_t)c], res[(size_t)c]);
     });
+    if (pairs_on_device) {
+        // loop B with distance(Partition, Partition) from the device (HS_LOOP_B_PAIRS_ON_DEVICE=1): every pair of the partitions that
+        // pass loop B's gate, in one launch for the range; the host walks loop B with the table and only recomputes a pair whose
+        // final partition has been merged into meanwhile
+        std::vector<int32_t> n_surv((size_t)C, 0);
+        parallel_for(C, n_threads, [&](int c) { n_surv[(size_t)c] = cv_loop_b_survivors(*cst[(size_t)c]); });
+        std::vector<int64_t> part_first((size_t)C + 1, 0), elem_first((size_t)C + 1, 0), pair_first((size_t)C + 1, 0);
+        for (int c = 0; c < C; ++c) {
+            part_first[(size_t)c + 1] = part_first[(size_t)c] + n_surv[(size_t)c];
+            elem_first[(size_t)c + 1] = elem_first[(size_t)c] + (int64_t)n_surv[(size_t)c] * n_reads_of[(size_t)c];
+            pair_first[(size_t)c + 1] = pair_first[(size_t)c] + (int64_t)n_surv[(size_t)c] * (n_surv[(size_t)c] - 1) / 2;
+        }
+        std::vector<int8_t> pstate((size_t)elem_first[(size_t)C]);
+        std::vector<int32_t> pmore((size_t)elem_first[(size_t)C]), pless((size_t)elem_first[(size_t)C]), part_n((size_t)part_first[(size_t)C]);
+        std::vector<int64_t> part_off((size_t)part_first[(size_t)C]);
+        std::vector<int32_t> pair_a((size_t)pair_first[(size_t)C]), pair_b((size_t)pair_first[(size_t)C]);
+        parallel_for(C, n_threads, [&](int c) {
+            const int S = n_surv[(size_t)c], N = n_reads_of[(size_t)c];
+            cv_export_survivors(*cst[(size_t)c], pstate.data() + elem_first[(size_t)c], pmore.data() + elem_first[(size_t)c], pless.data() + elem_first[(size_t)c]);
+            for (int k = 0; k < S; ++k) { part_off[(size_t)part_first[(size_t)c] + k] = elem_first[(size_t)c] + (int64_t)k * N; part_n[(size_t)part_first[(size_t)c] + k] = N; }
+            int64_t q = pair_first[(size_t)c];
+            for (int j = 1; j < S; ++j) for (int i = 0; i < j; ++i, ++q) { pair_a[(size_t)q] = (int32_t)(part_first[(size_t)c] + i); pair_b[(size_t)q] = (int32_t)(part_first[(size_t)c] + j); }
+        });
+        std::vector<int32_t> table;
+        if (int rc = dev.partition_pairs(pstate, pmore, pless, part_off, part_n, pair_a, pair_b, cv_three_sigma_table(), table)) return rc;
+        parallel_for(C, n_threads, [&](int c) { cv_phase_b(*cst[(size_t)c], res[(size_t)c], table.data() + 8 * pair_first[(size_t)c]); });
+        if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] cv loop B: %ld partition pairs of %ld gated partitions from the device\n", (long)pair_first[(size_t)C], (long)part_first[(size_t)C]);
+    }
     if (std::getenv("HS_TIMING") && on_device) std::fprintf(stderr, "[hs timing] cv loop A on the device: %.3f ms of kernels, %d of %d contigs done on the host\n", k_ms_a, n_host_a.load(), C);
     laps.lap("phase_ab");
     // ---- loops C and D and the merge of the SNP lists on the device, against the final partitions ----

@@ -86,6 +86,12 @@ struct CvDeviceOps {
     // Loop A of keep_only_robust_variants (call_variants.cpp:590-638) on the candidate columns, contig by contig.
     // Optional: an implementation without it leaves the loop to the host (cv_phase_a_host). The result arrays are owned by
     // the implementation and stay valid until the next call.
+    // V5 distance(Partition, Partition, 2) for a list of pairs (loop B, opt-in): dense arrays of the partitions one after the other
+    // (state 2 = absent), part_off / part_n per partition, out = 8 ints per pair {n00, n01, n10, n11, phased, augmented, valid, comparable}
+    virtual bool has_partition_pairs() const { return false; }
+    virtual int partition_pairs(const std::vector<int8_t>& state, const std::vector<int32_t>& more, const std::vector<int32_t>& less, const std::vector<int64_t>& part_off,
+                                const std::vector<int32_t>& part_n, const std::vector<int32_t>& pair_a, const std::vector<int32_t>& pair_b, const std::vector<float>& sigma3,
+                                std::vector<int32_t>& out) { (void)state; (void)more; (void)less; (void)part_off; (void)part_n; (void)pair_a; (void)pair_b; (void)sigma3; (void)out; return -1; }
     virtual bool has_robust_partitions() const { return false; }
     virtual int robust_partitions(const std::vector<int32_t>& contig_n_reads, CvLoopAResult& out, float* k_ms) { (void)contig_n_reads; (void)out; (void)k_ms; return -1; }
 };

@@ -44,7 +44,12 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
 // bits: the contig's partitions, 3 W words each (present, plus, minus over the reads ranked by start position); cnt: N counters each
 // (more | less << 16); rec[p].elem is not used here
 void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const uint64_t* bits, const int32_t* cnt);
-void cv_phase_b(CvContigState& st, ContigCvResult& out);
+void cv_phase_b(CvContigState& st, ContigCvResult& out, const int32_t* pair_table = nullptr);
+// loop B with the pair distances from the device (k_partition_pair_distance): the partitions that pass loop B's gate, their dense
+// arrays, the host's table of 3-sigma thresholds
+int cv_loop_b_survivors(CvContigState& st);
+void cv_export_survivors(const CvContigState& st, int8_t* state, int32_t* more, int32_t* less);
+const std::vector<float>& cv_three_sigma_table();
 int cv_final_partitions(const CvContigState& st);
 // the final partitions' dense state arrays (n_reads bytes each) written at `state`, their offsets (state_base + ...) at state_off
 void cv_export_partitions(const CvContigState& st, int8_t* state, int64_t state_base, int64_t* state_off);

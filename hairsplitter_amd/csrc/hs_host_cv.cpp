@@ -81,6 +81,8 @@ struct DensePartition {
     const int32_t* rank_of = nullptr;
     const int32_t* orig_of = nullptr;   // rank -> read
     int wlo = 0, whi = -1;         // words that hold present reads
+    int survivor = -1;             // loop B with pair distances from the device: ordinal among the partitions that pass its gate,
+    bool pristine = true;          // and whether this (final) partition still is what was uploaded (no merge into it yet)
     int reach = -1;                // largest (exclusive) end position of a present read: no read of the partition covers a position >= reach
     // storage from the contig's arena: every read absent, counters and bit sets zero
     void allocate(PartitionArena& arena, int n) {
@@ -569,6 +571,7 @@ struct CvContigState {
     std::vector<DensePartition> parts;   // what loop A leaves (host loop or imported from the device)
     std::vector<int32_t> rank_of, orig_of;   // reads ranked by start position (ties by index): the bit order of the bit sets
     std::vector<DensePartition> finals;
+    std::vector<int32_t> survivors;      // (cv_loop_b_survivors) indices in `parts` of the partitions that pass loop B's gate
 };
 
 CvContigState* cv_state_new() { return new CvContigState(); }
@@ -706,8 +709,34 @@ void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts
     }
 }
 
-// loop B (:646-708)
-void cv_phase_b(CvContigState& st, ContigCvResult& out) {
+// loop B's gate (:650-653) for every partition of loop A: it depends on the partition alone, not on the finals
+int cv_loop_b_survivors(CvContigState& st) {
+    st.survivors.clear();
+    for (size_t p1 = 0; p1 < st.parts.size(); ++p1) {
+        const double p_value = significance(st.parts[p1], st.n_candidates);
+        if ((p_value < 0.001 || st.parts[p1].n_corr > 1) && is_informative(st.parts[p1], st.mean_distance)) {
+            st.parts[p1].survivor = (int)st.survivors.size();
+            st.survivors.push_back((int32_t)p1);
+        }
+    }
+    return (int)st.survivors.size();
+}
+// the survivors' dense arrays (n_reads entries each, one after the other) for k_partition_pair_distance
+void cv_export_survivors(const CvContigState& st, int8_t* state, int32_t* more, int32_t* less) {
+    const size_t N = (size_t)st.n_reads;
+    for (size_t k = 0; k < st.survivors.size(); ++k) {
+        const DensePartition& p = st.parts[(size_t)st.survivors[k]];
+        std::memcpy(state + k * N, p.state, N); std::memcpy(more + k * N, p.more, N * 4); std::memcpy(less + k * N, p.less, N * 4);
+    }
+}
+const std::vector<float>& cv_three_sigma_table() {
+    static const std::vector<float> t = [] { std::vector<float> v(4096); for (int k = 0; k < 4096; ++k) v[(size_t)k] = three_sigma_threshold(k); return v; }();
+    return t;
+}
+
+// loop B (:646-708). pair_table (optional): distance(survivor i, survivor j, 2) for i < j at 8 * (j (j - 1) / 2 + i), as
+// k_partition_pair_distance leaves it: used while the final partition still is survivor i as uploaded (no merge into it yet)
+void cv_phase_b(CvContigState& st, ContigCvResult& out, const int32_t* pair_table) {
     std::vector<DensePartition>& parts = st.parts;
     const float mean_distance = st.mean_distance;
     out.n_partitions = (int)parts.size();
@@ -715,18 +744,33 @@ void cv_phase_b(CvContigState& st, ContigCvResult& out) {
     std::vector<DensePartition>& finals = st.finals;
     DensePartition scratch;
     for (size_t p1 = 0; p1 < parts.size(); ++p1) {
-        const double p_value = significance(parts[p1], st.n_candidates);
-        if (!((p_value < 0.001 || parts[p1].n_corr > 1) && is_informative(parts[p1], mean_distance))) continue;
+        if (pair_table) { if (parts[p1].survivor < 0) continue; }
+        else {
+            const double p_value = significance(parts[p1], st.n_candidates);
+            if (!((p_value < 0.001 || parts[p1].n_corr > 1) && is_informative(parts[p1], mean_distance))) continue;
+        }
         bool different = true;
         for (size_t p2 = 0; p2 < finals.size(); ++p2) {
-            {   // partitions without a common read are "not comparable" (comparable == 0 -> augmented = false, :1107-1111): one AND
-                // over the few words both occupy instead of a walk over all reads of the contig
-                const DensePartition& fa = finals[p2]; const DensePartition& fb = parts[p1];
-                bool any = false;
-                for (int w = std::max(fa.wlo, fb.wlo); w <= std::min(fa.whi, fb.whi) && !any; ++w) any = (fa.present[(size_t)w] & fb.present[(size_t)w]) != 0;
-                if (!any) continue;
+            PartPartDistance d;
+            const int32_t* row = nullptr;
+            if (pair_table && finals[p2].pristine && finals[p2].survivor >= 0) {
+                const int64_t i = finals[p2].survivor, j = parts[p1].survivor;
+                row = pair_table + 8 * (j * (j - 1) / 2 + i);
+                if (!row[6]) row = nullptr;      // (a vote count beyond the threshold table: the host's own walk)
             }
-            const PartPartDistance d = partition_vs_partition(finals[p2], parts[p1], 2);
+            if (row) {
+                if (row[7] == 0) continue;       // no comparable read: augmented = false
+                d.n00 = row[0]; d.n01 = row[1]; d.n10 = row[2]; d.n11 = row[3]; d.phased = (short)row[4]; d.augmented = row[5] != 0;
+            } else {
+                {   // partitions without a common read are "not comparable" (comparable == 0 -> augmented = false, :1107-1111): one AND
+                    // over the few words both occupy instead of a walk over all reads of the contig
+                    const DensePartition& fa = finals[p2]; const DensePartition& fb = parts[p1];
+                    bool any = false;
+                    for (int w = std::max(fa.wlo, fb.wlo); w <= std::min(fa.whi, fb.whi) && !any; ++w) any = (fa.present[(size_t)w] & fb.present[(size_t)w]) != 0;
+                    if (!any) continue;
+                }
+                d = partition_vs_partition(finals[p2], parts[p1], 2);
+            }
             if (d.augmented && (d.n00 + d.n11 > 5 * (d.n01 + d.n10) || d.n10 + d.n01 > 5 * (d.n00 + d.n11))
                 && d.n10 < std::max(2, 2 * d.n01) && d.n01 < std::max(2, 2 * d.n10)) {
                 bool do_merge = d.n01 + d.n10 < 0.1 * (d.n00 + d.n11);
@@ -737,7 +781,7 @@ void cv_phase_b(CvContigState& st, ContigCvResult& out) {
                     merge_partitions(merged, parts[p1], d.phased);
                     do_merge = confidence_score(merged) > confidence_score(finals[p2]);
                 }
-                if (do_merge) { merge_partitions(finals[p2], parts[p1], d.phased); different = false; break; }
+                if (do_merge) { merge_partitions(finals[p2], parts[p1], d.phased); finals[p2].pristine = false; different = false; break; }
             }
         }
         if (different) finals.push_back(parts[p1]);      // (a partition of loop A is looked at once: its storage goes along)

@@ -1591,6 +1591,68 @@ __global__ __launch_bounds__(256) void k_partition_transpose(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// V5 distance(Partition&, Partition&, threshold_p) of loop B (call_variants.cpp:977-1127) for a list of partition pairs of the same
+// contig: one wavefront per pair, lanes = reads. A read counts when both partitions hold it with more than one vote; the two
+// phasings' tables are mirror images (same-sign reads are n11 / n00 of phasing 0 and n10 / n01 of phasing 1, opposite-sign reads
+// the other way round), so nine per-lane counters and their wave sums give everything: the four counts of the better phasing, the
+// phasing, and `augmented` (fewer than threshold_p surely divergent reads on either side ...). The 3-sigma threshold of a read
+// (0.5 n + 3 sqrt(0.25 n), double then float) comes from the host's table for n < 4096; a pair with a larger vote count is marked
+// not valid and left to the host. out[k] = {n00, n01, n10, n11, phased, augmented, valid, comparable}.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_partition_pair_distance(
+    const int8_t* __restrict__ state, const int32_t* __restrict__ more, const int32_t* __restrict__ less, const int64_t* __restrict__ part_off,
+    const int32_t* __restrict__ part_n, const int32_t* __restrict__ pair_a, const int32_t* __restrict__ pair_b, int n_pairs, int threshold_p,
+    const float* __restrict__ sigma3 /* [4096] */, int32_t* __restrict__ out) {
+    const int lane = lane_id();
+    const int k = (int)blockIdx.x * 4 + wave_id();
+    if (k >= n_pairs) return;
+    const int a = pair_a[k], b = pair_b[k];
+    const int N = part_n[a];
+    const int8_t* __restrict__ sa = state + part_off[a]; const int8_t* __restrict__ sb = state + part_off[b];
+    const int32_t* __restrict__ ma = more + part_off[a]; const int32_t* __restrict__ mb = more + part_off[b];
+    const int32_t* __restrict__ la = less + part_off[a]; const int32_t* __restrict__ lb = less + part_off[b];
+    int comparable = 0, n_pp = 0, n_mm = 0, n_pm = 0, n_mp = 0;      // (state of b, state of a): ++, --, +-, -+
+    int div_same = 0, div_opp = 0, uns_same = 0, uns_opp = 0;
+    bool big = false;
+    for (int r = lane; r < N; r += 64) {
+        const int s1 = sa[r], s2 = sb[r];
+        if (s1 == 2 || s2 == 2) continue;                              // absent from one of them
+        const int m1 = ma[r], m2 = mb[r];
+        if (!(m1 > 1 && m2 > 1)) continue;
+        comparable++;
+        const int t1n = m1 + la[r], t2n = m2 + lb[r];
+        if (t1n >= 4096 || t2n >= 4096) { big = true; continue; }
+        const float t1 = sigma3[t1n], t2 = sigma3[t2n];
+        const bool c1 = (float)m1 > t1, c2 = (float)m2 > t2;
+        const bool both = c1 && c2, either = c1 || c2;
+        if (s2 == 1) {
+            if (s1 == 1) { n_pp++; div_same += both; uns_same += either; }
+            else if (s1 == -1) { n_pm++; div_opp += both; uns_opp += either; }
+        } else if (s2 == -1) {
+            if (s1 == 1) { n_mp++; div_opp += both; uns_opp += either; }
+            else if (s1 == -1) { n_mm++; div_same += both; uns_same += either; }
+        }
+    }
+    comparable = wave_sum_i32(comparable);
+    n_pp = wave_sum_i32(n_pp); n_mm = wave_sum_i32(n_mm); n_pm = wave_sum_i32(n_pm); n_mp = wave_sum_i32(n_mp);
+    div_same = wave_sum_i32(div_same); div_opp = wave_sum_i32(div_opp); uns_same = wave_sum_i32(uns_same); uns_opp = wave_sum_i32(uns_opp);
+    const bool any_big = __ballot(big) != 0ull;
+    if (lane == 0) {
+        // phasing 0: n11 = ++, n01 = +- (b plus, a minus), n10 = -+, n00 = --; phasing 1: n10 = ++, n00 = +-, n11 = -+, n01 = --
+        const int score0 = (n_pp + n_mm) - (n_pm + n_mp);
+        const int kk = -score0 > score0 ? 1 : 0;
+        const short ndiv0 = (short)div_opp, ndiv1 = (short)div_same, nuns0 = (short)uns_opp, nuns1 = (short)uns_same;      // (the reference counts in shorts)
+        const bool augmented = !((ndiv0 >= threshold_p && ndiv1 >= threshold_p) || (nuns0 >= 5 && nuns1 >= 5) || comparable == 0);
+        int32_t* o = out + (int64_t)k * 8;
+        o[0] = kk ? n_pm : n_mm;      // n00
+        o[1] = kk ? n_mm : n_pm;      // n01
+        o[2] = kk ? n_pp : n_mp;      // n10
+        o[3] = kk ? n_mp : n_pp;      // n11
+        o[4] = -2 * kk + 1; o[5] = augmented ? 1 : 0; o[6] = any_big ? 0 : 1; o[7] = comparable;
+    }
+}
+
 // 16 lanes per column, four columns per wavefront at a time (a contig rarely ends with more than 16 partitions; more are walked
 // 16 at a time). A wavefront owns 16 consecutive columns: lanes 0..15 read their headers and decide which are tested at all, the
 // tested ones are then taken four per round. Per round and column the wavefront groups the entries by code (ballots; every lane

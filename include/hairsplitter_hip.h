@@ -206,6 +206,18 @@ int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx,
                              uint8_t* d_keep, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * V5 -- distance(Partition&, Partition&, threshold_p) of loop B (call_variants.cpp:977-1127) for a list of partition pairs.
+ * Partitions as dense arrays one after the other: partition p occupies [part_off[p], part_off[p] + part_n[p]) of d_state
+ * (mostFrequentBases in {-1, 0, 1}, 2 = read absent), d_more / d_less (moreFrequence / lessFrequence); the two partitions of a
+ * pair belong to the same contig (same part_n). d_sigma3[n], n < 4096 = (float)(0.5 n + 3 sqrt(0.25 n)) as the host forms it.
+ * d_out: 8 ints per pair {n00, n01, n10, n11, phased, augmented, valid, comparable}; valid = 0 when a read's vote count is
+ * beyond the table (the caller's own walk decides). pair_a = par1, pair_b = par2 of the reference's call.
+ * ---------------------------------------------------------------------------------------------- */
+int hs_partition_pair_distance(const int8_t* d_state, const int32_t* d_more, const int32_t* d_less, const int64_t* d_part_off, const int32_t* d_part_n,
+                               const int32_t* d_pair_a, const int32_t* d_pair_b, int32_t n_pairs, int32_t threshold_p, const float* d_sigma3, int32_t* d_out,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K5a -- SNP bit-planes for K5 from the SNP columns (separate_reads.cpp:386-405): bit s of row r of d_ref / d_alt = read r
  * carries snp_ref[s] / snp_alt[s]. Columns of all contigs concatenated (CSR); snp_contig[s] = contig of column s,
  * contig_snp_base[c] = first column of contig c; plane_off / words / n_reads as for hs_simdiff (words[c] == 0 skips the contig).

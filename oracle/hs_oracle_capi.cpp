@@ -94,6 +94,27 @@ int hso_column_partition_test(const int64_t* col_off, const int32_t* col_idx, co
     return 0;
 }
 
+// V5 oracle: distance(Partition&, Partition&, threshold_p) (call_variants.cpp:977-1127) for pairs of partitions given as dense arrays
+// (state 2 = read absent); out = 6 ints per pair {n00, n01, n10, n11, phased, augmented}
+int hso_partition_pair_distance(const int8_t* state, const int32_t* more, const int32_t* less, const int64_t* part_off, const int32_t* part_n,
+                                const int32_t* pair_a, const int32_t* pair_b, int32_t n_pairs, int32_t threshold_p, int32_t* out) {
+    auto make = [&](int p) {
+        hso::Partition P;
+        for (int r = 0; r < part_n[p]; ++r) {
+            const int8_t st = state[part_off[p] + r];
+            if (st == 2) continue;
+            P.readIdx.push_back(r); P.mostFrequentBases.push_back(st); P.moreFrequence.push_back(more[part_off[p] + r]); P.lessFrequence.push_back(less[part_off[p] + r]);
+        }
+        return P;
+    };
+    for (int k = 0; k < n_pairs; ++k) {
+        const hso::Partition A = make(pair_a[k]), B = make(pair_b[k]);
+        const hso::DistRes d = hso::distance(A, B, threshold_p);
+        out[6 * k] = d.n00; out[6 * k + 1] = d.n01; out[6 * k + 2] = d.n10; out[6 * k + 3] = d.n11; out[6 * k + 4] = d.phased; out[6 * k + 5] = d.augmented ? 1 : 0;
+    }
+    return 0;
+}
+
 // exact (reference tie order) top-3 of every position: call_variants.cpp:477-507 on a read-major pileup
 int hso_column_top3(const uint8_t* pile, const int64_t* pile_off, const int32_t* rec_pos, const int32_t* rec_qend,
                     int32_t r0, int32_t r1, int64_t L, uint8_t* k0, uint8_t* k1, int32_t* c0, int32_t* c1, int32_t* c2,

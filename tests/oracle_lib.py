@@ -59,6 +59,18 @@ def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1
     return keep[:n], chi[:n], tab[:n]
 
 
+def partition_pair_distance(state, more, less, part_off, part_n, pair_a, pair_b, threshold_p=2):
+    """distance(Partition, Partition, threshold_p) of the oracle for every pair: [n_pairs, 6] = n00, n01, n10, n11, phased, augmented"""
+    n = len(pair_a)
+    a = lambda x, dt: np.ascontiguousarray(x if len(x) else np.zeros(1), dt)
+    state = a(state, np.int8); more = a(more, np.int32); less = a(less, np.int32); part_off = a(part_off, np.int64); part_n = a(part_n, np.int32)
+    pair_a = a(pair_a, np.int32); pair_b = a(pair_b, np.int32)
+    out = np.zeros((max(n, 1), 6), np.int32)
+    lib().hso_partition_pair_distance(_hp(state, C.c_int8), _hp(more, C.c_int32), _hp(less, C.c_int32), _hp(part_off, C.c_int64), _hp(part_n, C.c_int32),
+                                      _hp(pair_a, C.c_int32), _hp(pair_b, C.c_int32), C.c_int32(n), C.c_int32(threshold_p), _hp(out, C.c_int32))
+    return out[:n]
+
+
 def simdiff(n_reads, snp_ref, snp_alt, col_off, col_idx, col_code):
     sim = np.zeros((n_reads, n_reads), np.int32); diff = np.zeros((n_reads, n_reads), np.int32)
     snp_ref = np.ascontiguousarray(snp_ref, np.uint8); snp_alt = np.ascontiguousarray(snp_alt, np.uint8)

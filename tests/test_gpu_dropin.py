@@ -24,7 +24,7 @@ def test_dropin_binaries_match_reference_goldens(built, case):
         assert open(gaf, "rb").read() == open(os.path.join(td, "reads_haplo.gaf"), "rb").read()
 
 
-@pytest.mark.parametrize("switch", ["HS_K1_PER_EVENT", "HS_SPIN_WAIT", "HS_FINISH_ON_HOST", "HS_LOOP_A_ON_DEVICE"])
+@pytest.mark.parametrize("switch", ["HS_K1_PER_EVENT", "HS_SPIN_WAIT", "HS_FINISH_ON_HOST", "HS_LOOP_A_ON_DEVICE", "HS_LOOP_B_PAIRS_ON_DEVICE"])
 @pytest.mark.parametrize("case", ["penta30k", "edge_ops"])
 def test_dropin_binaries_with_the_alternative_paths(built, case, switch):
     """The opt-in switches select other ways to the same result (event-per-lane pileup, sleeping waits, full column download,
@@ -42,6 +42,15 @@ def test_dropin_binaries_with_low_memory_graphs_on_the_host(built, case):
     with tempfile.TemporaryDirectory() as td:
         meta = gu.unpack(case, td)
         outs = gu.run_stage_pair([built["cv"]], [built["sr"]], td, meta, env=dict(os.environ, HS_LOW_MEMORY_GRAPHS_ON_HOST="1"))
+        assert gu.compare(td, outs) == []
+
+
+@pytest.mark.parametrize("case", gu.case_names())
+def test_dropin_binaries_with_loop_b_pair_distances_from_the_device(built, case):
+    """distance(Partition, Partition) of loop B from k_partition_pair_distance (opt-in) against every golden case"""
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack(case, td)
+        outs = gu.run_stage_pair([built["cv"]], [built["sr"]], td, meta, env=dict(os.environ, HS_LOOP_B_PAIRS_ON_DEVICE="1"))
         assert gu.compare(td, outs) == []
 
 

@@ -547,3 +547,38 @@ def test_stage5_call_sites_compare_bytes_like_edlib(built):
     assert bad
     with pytest.raises(Exception, match="distinct bytes"):
         api.reattach_ends([bad[0]["backbone"]], [bad[0]["consensus"]])
+
+
+def test_partition_pair_distance_matches_oracle(built):
+    """V5 distance(Partition, Partition, 2) (call_variants.cpp:977-1127), one wavefront per pair, against the oracle on random
+    partitions: overlapping and disjoint read sets, zero states, vote counts around the 3-sigma thresholds, both phasings"""
+    from hairsplitter_amd import api
+    import oracle_lib as ol
+    rng = np.random.default_rng(11)
+    state, more, less, part_off, part_n, pa, pb = [], [], [], [], [], [], []
+    off = 0
+    for N in (1, 63, 64, 65, 200, 1000, 3000):
+        first = len(part_n)
+        base = rng.choice([-1, 1], N)
+        for p in range(8):
+            lo = int(rng.integers(0, max(1, N // 2))); hi = int(rng.integers(lo, N)) + 1
+            st = np.full(N, 2, np.int8)
+            phase = 1 if p % 2 == 0 else -1
+            flip = rng.random(N) < (0.05 if p < 6 else 0.5)
+            vals = np.where(flip, -base, base) * phase
+            vals = np.where(rng.random(N) < 0.1, 0, vals)
+            st[lo:hi] = vals[lo:hi]
+            st[rng.random(N) < 0.15] = 2
+            mo = rng.integers(0, 12, N).astype(np.int32); le = rng.integers(0, 6, N).astype(np.int32)
+            mo[rng.random(N) < 0.05] += 40
+            state.append(st); more.append(mo); less.append(le); part_off.append(off); part_n.append(N); off += N
+        for i in range(8):
+            for j in range(8):
+                if i != j:
+                    pa.append(first + i); pb.append(first + j)
+    state = np.concatenate(state); more = np.concatenate(more); less = np.concatenate(less)
+    got = api.partition_pair_distance(state, more, less, part_off, part_n, pa, pb)
+    want = ol.partition_pair_distance(state, more, less, part_off, part_n, pa, pb)
+    assert got[:, 6].all()
+    assert (got[:, :6] == want).all(), np.nonzero((got[:, :6] != want).any(axis=1))[0][:10]
+    assert (want[:, 5] == 1).any() and (want[:, 5] == 0).any() and (want[:, 4] == -1).any() and (want[:, 4] == 1).any()
