@@ -985,11 +985,11 @@ __global__ __launch_bounds__(256) void k_simdiff(
     const uint64_t* __restrict__ A = alt + plane_off[c];
     const uint64_t* __restrict__ R = ref + plane_off[c];
     const int ti = tid >> 4, tj = tid & 15;
-    int s_acc[4][4], d_acc[4][4];
+    int s_acc[4][4], d_acc[4][4], u_acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) { s_acc[a][b] = 0; d_acc[a][b] = 0; }
+        for (int b = 0; b < 4; ++b) { s_acc[a][b] = 0; d_acc[a][b] = 0; u_acc[a][b] = 0; }
 
     for (int w0 = 0; w0 < W; w0 += SD_KW) {
         // stage 64 rows x SD_KW words of both planes for both sides (coalesced along words)
@@ -1010,16 +1010,29 @@ __global__ __launch_bounds__(256) void k_simdiff(
             for (int a = 0; a < 4; ++a) { ai[a] = sAi[ti + 16 * a][w]; ri[a] = sRi[ti + 16 * a][w]; }
 #pragma unroll
             for (int b = 0; b < 4; ++b) { aj[b] = sAj[tj + 16 * b][w]; rj[b] = sRj[tj + 16 * b][w]; }
+            // a read carries at most one of the two alleles at a SNP (the planes are disjoint), so with U = A | R:
+            // pop(Ui & Uj) = pop(Ai & Aj) + pop(Ri & Rj) + [pop(Ai & Rj) + pop(Ri & Aj)] -- three popcounts per pair instead of four
+            uint64_t ui[4], uj[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { ui[a] = ai[a] | ri[a]; uj[a] = aj[a] | rj[a]; }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    s_acc[a][b] += 3 * __popcll(ai[a] & aj[b]) + __popcll(ri[a] & rj[b]);
-                    d_acc[a][b] += __popcll(ai[a] & rj[b]) + __popcll(ri[a] & aj[b]);
+                    s_acc[a][b] += __popcll(ai[a] & aj[b]);      // (pop(A A), pop(R R), pop(U U): combined after the loop)
+                    d_acc[a][b] += __popcll(ri[a] & rj[b]);
+                    u_acc[a][b] += __popcll(ui[a] & uj[b]);
                 }
         }
         __syncthreads();
     }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int paa = s_acc[a][b], prr = d_acc[a][b], puu = u_acc[a][b];
+            s_acc[a][b] = 3 * paa + prr; d_acc[a][b] = puu - paa - prr;
+        }
     int32_t* __restrict__ S = sim + out_off[c];
     int32_t* __restrict__ D = diff + out_off[c];
 #pragma unroll
@@ -1081,11 +1094,11 @@ __global__ __launch_bounds__(256) void k_simdiff_windows(
     const uint64_t* __restrict__ A = alt + plane_off[c];
     const uint64_t* __restrict__ R = ref + plane_off[c];
     const int ti = tid >> 4, tj = tid & 15;
-    int s_acc[4][4], d_acc[4][4];
+    int s_acc[4][4], d_acc[4][4], u_acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) { s_acc[a][b] = 0; d_acc[a][b] = 0; }
+        for (int b = 0; b < 4; ++b) { s_acc[a][b] = 0; d_acc[a][b] = 0; u_acc[a][b] = 0; }
     for (int w0 = 0; w0 < W; w0 += SD_KW) {
         for (int x = tid; x < 64 * SD_KW; x += 256) {
             const int row = x / SD_KW, ww = x % SD_KW;
@@ -1105,16 +1118,29 @@ __global__ __launch_bounds__(256) void k_simdiff_windows(
             for (int a = 0; a < 4; ++a) { ai[a] = sAi[ti + 16 * a][ww]; ri[a] = sRi[ti + 16 * a][ww]; }
 #pragma unroll
             for (int b = 0; b < 4; ++b) { aj[b] = sAj[tj + 16 * b][ww]; rj[b] = sRj[tj + 16 * b][ww]; }
+            // a read carries at most one of the two alleles at a SNP (the planes are disjoint), so with U = A | R:
+            // pop(Ui & Uj) = pop(Ai & Aj) + pop(Ri & Rj) + [pop(Ai & Rj) + pop(Ri & Aj)] -- three popcounts per pair instead of four
+            uint64_t ui[4], uj[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { ui[a] = ai[a] | ri[a]; uj[a] = aj[a] | rj[a]; }
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    s_acc[a][b] += 3 * __popcll(ai[a] & aj[b]) + __popcll(ri[a] & rj[b]);
-                    d_acc[a][b] += __popcll(ai[a] & rj[b]) + __popcll(ri[a] & aj[b]);
+                    s_acc[a][b] += __popcll(ai[a] & aj[b]);      // (pop(A A), pop(R R), pop(U U): combined after the loop)
+                    d_acc[a][b] += __popcll(ri[a] & rj[b]);
+                    u_acc[a][b] += __popcll(ui[a] & uj[b]);
                 }
         }
         __syncthreads();
     }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int paa = s_acc[a][b], prr = d_acc[a][b], puu = u_acc[a][b];
+            s_acc[a][b] = 3 * paa + prr; d_acc[a][b] = puu - paa - prr;
+        }
     int32_t* __restrict__ S = wsim + win_mat_off[w];
     int32_t* __restrict__ D = wdiff + win_mat_off[w];
 #pragma unroll

@@ -233,7 +233,8 @@ int hs_snp_planes(const int64_t* d_col_off, const int32_t* d_col_idx, const uint
  * K5 -- read x read similarity / difference.  Replaces list_similarities_and_differences_between_reads3
  * (separate_reads.cpp:374-433): sim = 3*A*At + R*Rt, diff = A*Rt + R*At with zero diagonals, as popcounts of
  * bit-planes. d_alt / d_ref: N rows of `words` uint64 (bit s of row r = read r carries second_base / ref_base
- * at SNP s). Batched over contigs: plane_off[c] (in uint64 words), out_off[c] (in int32 elements).
+ * at SNP s; a read carries at most one of the two at a SNP: the planes are disjoint, which the kernel relies on). Batched over
+ * contigs: plane_off[c] (in uint64 words), out_off[c] (in int32 elements).
  * ---------------------------------------------------------------------------------------------- */
 int hs_simdiff(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_plane_off,
                const int32_t* d_n_reads, const int32_t* d_words, const int64_t* d_out_off, int32_t n_contigs,
