@@ -264,6 +264,10 @@ def main():
     window_size = hdist.global_window_size(batch.flat.rec_refspan, group=cpu_group) if use_dist else 0
     contigs = None
 
+    # HS_BENCH_FUSED=1: a job in ONE process through hs_pipeline_run_fused (the groups bring up their own share of the pileup, the
+    # error rate is formed inside: 22.4 ms per C4 step against 22.1 with the two calls -- the last group's chain ends at the same
+    # time either way); with several ranks the per-contig distances cross the processes between the two calls anyway
+    fused = (not use_dist) and not emulated and bool(os.environ.get("HS_BENCH_FUSED"))
     py_ms = {"pipeline_call": 0.0, "error_rate": 0.0, "gather": 0.0}
     no_coll = bool(os.environ.get("HS_BENCH_NO_COLLECTIVES"))   # diagnostic only
     cap = [None]
@@ -277,7 +281,10 @@ def main():
 
     def step():
         t = time.perf_counter()
-        cv, sr = batch.run(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=window_size)
+        if fused:      # one process = the whole job: pileup per contig group, the error rate formed inside the library
+            cv, sr = batch.run_fused(0.33, n_threads, rarest_strain_abundance=0.01, window_size=window_size)
+        else:
+            cv, sr = batch.run(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=window_size)
         t3 = time.perf_counter(); py_ms["pipeline_call"] += (t3 - t) * 1e3
         if cap[0] is None:   # first (set-up) step only: fix the size of the per-step collective, allocate its buffers
             cap[0] = hdist.LabelGatherer(hdist.gather_capacity(int(sr["labels"].size)))
@@ -396,7 +403,7 @@ def main():
                        "parallelism": f"contigs sharded over {world} GPU(s) by LPT on contig length", "groups_per_gpu": G,
                        **({"emulated_rank_of": emulated, "cores_pinned": args.cores or None,
                            "note": "ONE rank of an %d-rank job on one GPU (its LPT shard, its threads and groups): a readiness check, not a scaling measurement" % emulated} if emulated else {}),
-                       "host_threads_per_rank": n_threads},
+                       "host_threads_per_rank": n_threads, "pipeline": "hs_pipeline_run_fused" if fused else "hs_pipeline_select + hs_pipeline_run"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": d["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": d["avg_launch_ms"],
                          "launches_per_step": d["launches_per_step"], "ms_per_step": d["ms_per_step"],

@@ -22,7 +22,7 @@ SYMBOLS = [
     "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_partition_pair_distance", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_pipeline_thread_devices", "hs_cv_batch_device", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
-    "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_host_wait_stats", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
+    "hs_pipeline_run_fused", "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_host_wait_stats", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
 ]
 
 HS_NKERNELS = 25
@@ -407,6 +407,29 @@ class PipelineGroups:
                    "n_columns_downloaded_late": int(st.n_columns_downloaded_late)})
         sr = _sr_result_to_dict(sres, Cn, take_ownership=True)   # the labels stay where the library put them
         sr["wall_ms"] = {"select": (t_1 - t_0) * 1e3, "between": (t_2 - t_1) * 1e3, "groups": (t_3 - t_2) * 1e3, "collect": (time.perf_counter() - t_3) * 1e3}
+        return cv, sr
+
+    def run_fused(self, automatic_snp_threshold=0.33, n_threads=0, rarest_strain_abundance=0.01, low_memory=False, amplicon=False, seed=12345,
+                  window_size=0):
+        """hs_pipeline_run_fused: the same job in one library call (single process: the error rate is formed inside)"""
+        import time
+        lib = load()
+        Cn = self.flat.n_contigs
+        md = np.zeros(max(Cn, 1), np.float32)
+        st = PipelineStats()
+        er = C.c_float(0)
+        sres = C.POINTER(SrResult)()
+        t_0 = time.perf_counter()
+        _check(lib.hs_pipeline_run_fused(self.handle, C.c_float(automatic_snp_threshold), C.c_float(rarest_strain_abundance), C.c_int32(1 if low_memory else 0),
+                                         C.c_int32(1 if amplicon else 0), C.c_uint32(seed), C.c_int32(n_threads), C.c_int32(window_size), _hp(md, C.c_float),
+                                         C.byref(er), C.byref(sres), C.byref(st)))
+        t_1 = time.perf_counter()
+        cv = {"mean_distance": md[:Cn], "error_rate": float(er.value), "error_rate_is_final": True, "n_snps": int(st.n_snps), "t_device_ms": float(st.t_device_ms),
+              "t_host_ms": float(st.t_host_ms), "t_kernel_ms": [float(x) for x in st.t_kernel_cv_ms], "t_kernel_k4_ms": float(st.t_kernel_k4_ms),
+              "n_columns_extracted": int(st.n_columns_extracted), "n_columns_downloaded": int(st.n_columns_downloaded),
+              "n_columns_downloaded_late": int(st.n_columns_downloaded_late)}
+        sr = _sr_result_to_dict(sres, Cn, take_ownership=True)
+        sr["wall_ms"] = {"select": 0.0, "between": 0.0, "groups": (t_1 - t_0) * 1e3, "collect": (time.perf_counter() - t_1) * 1e3}
         return cv, sr
 
     def window_size(self, amplicon=False):

@@ -8,6 +8,7 @@
 #include <thread>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -976,6 +977,7 @@ struct hs_cv_batch {
     std::vector<int32_t> ploidy;      // hs_cv_batch_set_ploidy
     int64_t total_len = 0, total_pile = 0;
     int32_t n_tasks = 0, ev_per_task = 4096, max_depth = 0;
+    std::vector<int32_t> rec_task_off;      // [n_rec + 1] first pileup task of every record (tasks are listed record by record)
     int device = 0;                   // the device that was current when the batch was created: every buffer below lives there
     DBuf contig_seq, d_contig_off, read_seq, read_off, rec_read, d_rec_contig, d_rec_pos, rec_strand, rec_cig_off, cigar,
         d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, rec_chunk_off, chunk_scratch, task_rec, task_ev0,
@@ -1119,6 +1121,9 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
             up(b->rec_chunk_off, chunk_off.data(), sizeof(int64_t) * chunk_off.size());
             up(b->task_rec, tr, sizeof(int32_t) * (size_t)b->n_tasks);
             up(b->task_ev0, te, sizeof(int32_t) * (size_t)b->n_tasks);
+            b->rec_task_off.assign((size_t)n_rec + 1, 0);
+            for (int32_t t = 0; t < b->n_tasks; ++t) b->rec_task_off[(size_t)tr[t] + 1]++;
+            for (int r = 0; r < n_rec; ++r) b->rec_task_off[(size_t)r + 1] += b->rec_task_off[(size_t)r];
             if (!rc) rc = b->chunk_scratch.alloc(sizeof(int32_t) * 4 * (size_t)chunk_off[(size_t)n_rec]);
         }
         std::free(tr); std::free(te);
@@ -1181,6 +1186,72 @@ struct HipCvOps : hs::CvDeviceOps {
         kc.flush();
         return HS_OK;
     }
+
+    // K0 + K1 for the records of the contigs [c0, c1) only (the fused pipeline: every contig group brings up its own share of the
+    // pileup, one group at a time, so that the first group's host work starts a quarter of a millisecond into the step instead
+    // of after the whole batch); rec_stats: the batch-wide array, this range's slice is filled in
+    int pileup_range(int c0, int c1, std::vector<int32_t>& rec_stats, float k_ms[4]) {
+        const int r0 = b->contig_rec_off[(size_t)c0], r1 = b->contig_rec_off[(size_t)c1];
+        const int nr = r1 - r0;
+        if (nr <= 0) return HS_OK;
+        if ((int)b->rec_task_off.size() != b->n_rec + 1) { set_error("pileup_range: the batch has no task index"); return HS_EINVAL; }
+        const int t0 = b->rec_task_off[(size_t)r0], t1 = b->rec_task_off[(size_t)r1];
+        EventPair e0, e1;
+        if (int rc = e0.init()) return rc;
+        if (int rc = e1.init()) return rc;
+        {
+            DeviceTurn turn;
+            HS_HIP(hipEventRecord(e0.a, stream));
+            if (int rc = kc.begin(HS_K_CIGAR_SCAN, stream)) return rc;
+            if (int rc = cigar_scan_launch(b->d_contig_off.as<int64_t>(), b->d_rec_contig.as<int32_t>() + r0, b->d_rec_pos.as<int32_t>() + r0,
+                                           b->rec_cig_off.as<int64_t>() + r0, b->cigar.as<uint32_t>(), b->rec_chunk_off.as<int64_t>() + r0, nr,
+                                           b->chunk_scratch.as<int32_t>(), b->rec_stats.as<int32_t>() + 4 * (size_t)r0, stream)) return rc;
+            const double share = b->n_rec > 0 ? (double)nr / (double)b->n_rec : 0.0;
+            if (int rc = kc.end((int64_t)(share * ((double)b->cigar.bytes + (double)b->chunk_scratch.bytes)) + 16 * (int64_t)nr, stream)) return rc;
+            HS_HIP(hipEventRecord(e0.b, stream));
+            HS_HIP(hipEventRecord(e1.a, stream));
+            if (int rc = kc.begin(HS_K_PILEUP, stream)) return rc;
+            static const bool per_event = std::getenv("HS_K1_PER_EVENT") != nullptr;
+            int64_t range_pile = 0;
+            if (t1 > t0) {
+                if (per_event)
+                    hipLaunchKernelGGL(hsdev::k_pileup, dim3((t1 - t0 + 3) / 4), dim3(256), 0, stream, b->contig_seq.as<uint8_t>(), b->d_contig_off.as<int64_t>(),
+                                       b->read_seq.as<uint8_t>(), b->read_off.as<int64_t>(), b->rec_read.as<int32_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(),
+                                       b->rec_strand.as<uint8_t>(), b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->d_pile_off.as<int64_t>(), b->rec_chunk_off.as<int64_t>(),
+                                       b->chunk_scratch.as<int32_t>(), b->task_rec.as<int32_t>() + t0, b->task_ev0.as<int32_t>() + t0, t1 - t0, b->ev_per_task, b->pile_ptr(),
+                                       b->rec_stats.as<int32_t>());
+                else {
+                    hipLaunchKernelGGL(hsdev::k_pileup_packed, dim3((t1 - t0 + 3) / 4), dim3(256), 0, stream, b->contig_seq.as<uint8_t>(), b->d_contig_off.as<int64_t>(),
+                                       b->read_seq.as<uint8_t>(), b->read_off.as<int64_t>(), b->rec_read.as<int32_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(),
+                                       b->rec_strand.as<uint8_t>(), b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->d_pile_off.as<int64_t>(), b->rec_chunk_off.as<int64_t>(),
+                                       b->chunk_scratch.as<int32_t>(), b->task_rec.as<int32_t>() + t0, b->task_ev0.as<int32_t>() + t0, t1 - t0, b->ev_per_task, b->pile_ptr(),
+                                       b->rec_stats.as<int32_t>());
+                    const int blocks = std::max(1, std::min(256, (nr + 255) / 256));
+                    hipLaunchKernelGGL(hsdev::k_pileup_flagged_records, dim3(blocks), dim3(256), 0, stream, b->contig_seq.as<uint8_t>(), b->d_contig_off.as<int64_t>(),
+                                       b->read_seq.as<uint8_t>(), b->read_off.as<int64_t>(), b->rec_read.as<int32_t>() + r0, b->d_rec_contig.as<int32_t>() + r0,
+                                       b->d_rec_pos.as<int32_t>() + r0, b->rec_strand.as<uint8_t>() + r0, b->rec_cig_off.as<int64_t>() + r0, b->cigar.as<uint32_t>(),
+                                       b->d_pile_off.as<int64_t>() + r0, b->rec_chunk_off.as<int64_t>() + r0, b->chunk_scratch.as<int32_t>(), nr, b->ev_per_task, b->pile_ptr(),
+                                       b->rec_stats.as<int32_t>() + 4 * (size_t)r0);
+                }
+                HS_HIP(hipGetLastError());
+                range_pile = b->pile_off[(size_t)r1] - b->pile_off[(size_t)r0];
+            }
+            if (int rc = kc.end(2 * range_pile, stream)) return rc;      // one read base in + one code out per aligned bp
+            HS_HIP(hipEventRecord(e1.b, stream));
+            const size_t bytes = (size_t)nr * 4 * sizeof(int32_t);
+            if (int rc = h_info_grow(h_rec_stats, bytes)) return rc;
+            HS_HIP(HS_COPY_ASYNC(h_rec_stats.p, b->rec_stats.as<int32_t>() + 4 * (size_t)r0, bytes, hipMemcpyDeviceToHost, stream));
+            if (int rc = stream_wait(stream)) return rc;      // (inside the turn: the next group's share starts when this one is through)
+            std::memcpy(rec_stats.data() + 4 * (size_t)r0, h_rec_stats.p, bytes);
+        }
+        float m = 0;
+        if (int rc = e1.ms(&m)) return rc; k_ms[0] += m;
+        if (int rc = e0.ms(&m)) return rc; k_ms[3] += m;
+        kc.flush();
+        return HS_OK;
+    }
+    HBuf h_rec_stats;
+    static int h_info_grow(HBuf& h, size_t need) { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); }
 
     // ---- the columns of the current contig range ----
     int range_c0 = 0, range_c1 = 0;
@@ -2558,6 +2629,107 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
         }
     }
     if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] host waits so far: %ld, %.1f ms in them\n", g_waits.load(), g_wait_us.load() / 1e3);
+    hs_sr_result* R = concat_sr_parts(p, parts, sparse, st);
+    p->drop_cv();
+    *out = R;
+    return HS_OK;
+}
+
+// hs_pipeline_select + the error rate + hs_pipeline_run in ONE call for a job that lives in one process: every contig group brings
+// up its own share of the pileup (one group at a time on the device), so its host work starts a quarter of a millisecond into the
+// step instead of after the pileup of the whole batch; the job-wide error rate (call_variants.cpp:1312-1315: float sum of the
+// positive per-contig mean distances in contig order, then what hairsplitter.py makes of the printed value: %g, capped at 0.15,
+// hairsplitter.py:686-692,725) is formed when the last group has its counters, which is long before the first one needs it for
+// stage 4. mean_distance [n_contigs] and error_rate_out (optional) receive what hs_pipeline_select would have returned / what
+// the caller would have computed.
+int hs_pipeline_run_fused(hs_pipeline* p, float automatic_snp_threshold, float rarest_strain_abundance, int32_t low_memory, int32_t amplicon, uint32_t seed,
+                          int32_t n_threads, int32_t window_size, float* mean_distance, float* error_rate_out, hs_sr_result** out, hs_pipeline_stats* st) {
+    if (!p || !out) { set_error("hs_pipeline_run_fused: null argument"); return HS_EINVAL; }
+    if (int rc = bind_device(p->batch->device)) return rc;
+    hs_cv_batch* b = p->batch;
+    const int G = (int)p->ranges.size();
+    const int C = b->n_contigs;
+    if (n_threads <= 0) n_threads = 3 * host_threads();
+    const int per = std::max(1, n_threads / G);
+    if (window_size <= 0) {
+        if (amplicon) { window_size = 0; for (int c = 0; c < C; ++c) window_size = std::max<int32_t>(window_size, (int32_t)(b->contig_off[(size_t)c + 1] - b->contig_off[(size_t)c])); }
+        else {
+            uint32_t sum = 0; int above = 0;
+            for (int64_t v : b->rec_refspan) { const int len = (int)v + 2; sum += (uint32_t)len; above += len > 4000; }
+            const double mean = b->rec_refspan.empty() ? 4000.0 : (int32_t)sum / double(b->rec_refspan.size());
+            window_size = 2000;
+            if (above < 20 && mean < 4000 && mean > 2000) window_size = 1000;
+            else if (above < 20 && mean < 2000) window_size = 500;
+        }
+    }
+    p->drop_cv();
+    hs::CvSelection* sel = new hs::CvSelection();
+    sel->rec_stats.assign((size_t)b->n_rec * 4, 0);
+    for (int k = 0; k < 4; ++k) sel->k_ms[k] = 0;
+    p->sel = (hs_cv_selection*)std::calloc(1, sizeof(hs_cv_selection));
+    p->sel->impl = sel;
+    std::vector<float> md((size_t)std::max(C, 1), 0.f);
+    std::vector<std::array<float, 4>> k_ms_g((size_t)G, std::array<float, 4>{0, 0, 0, 0});
+    // the meeting point of the groups before stage 4
+    std::mutex bm; std::condition_variable bcv;
+    int arrived = 0; bool aborted = false;
+    float error_rate = 0;
+    std::vector<hs_sr_result*> parts((size_t)G, nullptr);
+    std::vector<hs::SrSparseLabels> sparse((size_t)G);
+    const int rc = p->run([&](int g) {
+        const int c0 = p->ranges[(size_t)g].first, c1 = p->ranges[(size_t)g].second;
+        hs::CvMeta meta; fill_meta(b, meta);
+        HipCvOps cv_ops(b);
+        auto fail = [&](int r) { { std::lock_guard<std::mutex> lk(bm); aborted = true; } bcv.notify_all(); return r; };
+        if (int r = cv_ops.pileup_range(c0, c1, sel->rec_stats, k_ms_g[(size_t)g].data())) return fail(r);
+        for (int c = c0; c < c1; ++c) {   // call_variants.cpp:434 per contig, from the integer counters of K1
+            int64_t nerr = 0, nlen = 0;
+            for (int r = b->contig_rec_off[(size_t)c]; r < b->contig_rec_off[(size_t)c + 1]; ++r) { nerr += sel->rec_stats[(size_t)r * 4 + 1]; nlen += sel->rec_stats[(size_t)r * 4 + 2]; }
+            md[(size_t)c] = hs::mean_distance_from_counts(nerr, nlen);
+        }
+        {
+            std::lock_guard<std::mutex> lk(bm);
+            if (++arrived == G) {
+                float total = 0; int n = 0;
+                for (int c = 0; c < C; ++c) if (md[(size_t)c] > 0) { total += md[(size_t)c]; n++; }      // :1312-1315, contig order
+                const float er32 = total / n;
+                char buf[64];
+                std::snprintf(buf, sizeof buf, "%g", (double)er32);      // what stage 3 prints and hairsplitter.py reads back
+                double e = std::strtod(buf, nullptr);
+                if (e > 0.15) e = 0.15;
+                error_rate = (float)e;
+                bcv.notify_all();
+            }
+        }
+        static const bool via_host = std::getenv("HS_COLUMNS_VIA_HOST") != nullptr;
+        if (int r = hs::cv_run_range(cv_ops, meta, sel->rec_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host)) return fail(r);
+        {
+            std::unique_lock<std::mutex> lk(bm);
+            bcv.wait(lk, [&] { return arrived == G || aborted; });
+            if (aborted) { set_error("hs_pipeline_run_fused: another contig group failed"); return HS_EINVAL; }
+        }
+        HipSrOps ops;
+        if (!via_host) ops.adopt_columns(cv_ops);
+        const int r = hs::sr_run_from_cv(ops, meta, c0, c1, p->cv[(size_t)g], error_rate, rarest_strain_abundance, low_memory, amplicon, seed, per, window_size,
+                                         &parts[(size_t)g], &sparse[(size_t)g], &p->sr_keep[(size_t)g]);
+        return r ? fail(r) : r;
+    });
+    if (rc) { for (hs_sr_result* r : parts) if (r) hs::free_sr_result(r); return rc; }
+    if (mean_distance) std::memcpy(mean_distance, md.data(), (size_t)C * sizeof(float));
+    if (error_rate_out) *error_rate_out = error_rate;
+    if (st) {
+        std::memset(st, 0, sizeof *st);
+        for (int g = 0; g < G; ++g) {
+            st->t_kernel_cv_ms[0] += k_ms_g[(size_t)g][0]; st->t_kernel_cv_ms[3] += k_ms_g[(size_t)g][3];
+            const hs_cv_result* r = p->cv[(size_t)g];
+            st->n_snps += r->snp_off[r->n_contigs];
+            st->t_device_ms += r->t_device_ms; st->t_host_ms += r->t_host_ms;
+            st->t_kernel_cv_ms[2] += r->t_kernel_ms[2]; st->t_kernel_k4_ms += r->t_kernel_k4_ms;
+            st->n_columns_extracted += r->n_columns_extracted; st->n_columns_downloaded += r->n_columns_downloaded;
+            st->n_columns_downloaded_late += r->n_columns_downloaded_late;
+            st->t_kernel_cv_ms[1] += r->t_kernel_ms[1];
+        }
+    }
     hs_sr_result* R = concat_sr_parts(p, parts, sparse, st);
     p->drop_cv();
     *out = R;

@@ -473,6 +473,13 @@ int hs_pipeline_select(hs_pipeline* p, float* mean_distance /* [C] out */, hs_pi
 int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_rate, float rarest_strain_abundance, int32_t low_memory,
                     int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out,
                     hs_pipeline_stats* stats);
+/* hs_pipeline_select + the job-wide error rate + hs_pipeline_run in one call, for a job that lives in ONE process: every contig
+ * group brings up its own share of the pileup (one group at a time), the error rate (call_variants.cpp:1312-1315, then %g and
+ * the 0.15 cap of hairsplitter.py:686-692,725) is formed inside when the last group has its counters. mean_distance
+ * [n_contigs] and error_rate_out are optional outputs. Same results as the two calls. */
+int hs_pipeline_run_fused(hs_pipeline* p, float automatic_snp_threshold, float rarest_strain_abundance, int32_t low_memory, int32_t amplicon,
+                          uint32_t seed, int32_t n_threads, int32_t window_size, float* mean_distance, float* error_rate_out, hs_sr_result** out,
+                          hs_pipeline_stats* st);
 /* the HIP device each contig-group thread of the pipeline is bound to (== hs_cv_batch_device of its batch); returns the number
  * of groups, fills at most cap entries */
 int hs_pipeline_thread_devices(hs_pipeline* p, int32_t* out, int32_t cap);

@@ -270,6 +270,14 @@ def test_pipeline_groups_equal_single_batch(built):
         assert cv1["n_snps"] == cv2["n_snps"]
         assert np.array_equal(sr1["labels"], sr2["labels"])
         assert np.array_equal(sr1["win_start"], sr2["win_start"]) and np.array_equal(sr1["win_end"], sr2["win_end"])
+    # the same job in ONE library call (hs_pipeline_run_fused: pileup per group, the error rate formed inside)
+    for _ in range(2):
+        cv3, sr3 = groups.run_fused(0.33, 8)
+        assert np.array_equal(cv1["mean_distance"], cv3["mean_distance"])
+        assert np.float32(min(float("%g" % cv1["error_rate"]), 0.15)) == np.float32(cv3["error_rate"])
+        assert cv1["n_snps"] == cv3["n_snps"]
+        assert np.array_equal(sr1["labels"], sr3["labels"])
+        assert np.array_equal(sr1["win_start"], sr3["win_start"]) and np.array_equal(sr1["win_end"], sr3["win_end"])
     single.close(); groups.close()
 
 
@@ -294,6 +302,9 @@ def test_degenerate_batches(built):
     b_cv, b_sr = g.run(0.33, 4)
     assert np.array_equal(a_cv["mean_distance"], b_cv["mean_distance"]) and a_cv["mean_distance"][0] == 0
     assert np.array_equal(a_sr["labels"], b_sr["labels"]) and np.array_equal(a_sr["win_off"], b_sr["win_off"])
+    c_cv, c_sr = g.run_fused(0.33, 4)
+    assert np.array_equal(a_cv["mean_distance"], c_cv["mean_distance"])
+    assert np.array_equal(a_sr["labels"], c_sr["labels"]) and np.array_equal(a_sr["win_off"], c_sr["win_off"])
     assert a_sr["win_off"][1] == 0 and a_sr["win_off"][2] == 0        # contigs without SNPs produce no windows (separate_reads.cpp:1522-1524)
     g.close()
 
