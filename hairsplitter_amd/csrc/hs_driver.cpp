@@ -278,7 +278,13 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
     static const bool loop_b_pairs = []() { const char* e = std::getenv("HS_LOOP_B_PAIRS_ON_DEVICE"); return e && e[0] != '0'; }();
     const bool pairs_on_device = loop_b_pairs && dev.has_partition_pairs();
     std::atomic<int> n_host_a{0};
-    parallel_for(C, n_threads, [&](int c) {
+    // the contigs with the most candidates first: the walk is sequential per contig, and a large contig that starts last is what the
+    // other threads of the group then wait for
+    std::vector<int> by_work((size_t)C);
+    for (int c = 0; c < C; ++c) by_work[(size_t)c] = c;
+    std::stable_sort(by_work.begin(), by_work.end(), [&](int x, int y) { return cand.contig_n_cand[(size_t)x] > cand.contig_n_cand[(size_t)y]; });
+    parallel_for(C, n_threads, [&](int k) {
+        const int c = by_work[(size_t)k];
         const int r0 = b.contig_rec_off[(size_t)(c0 + c)];
         if (on_device && !la.failed[(size_t)c]) {
             const int N = n_reads_of[(size_t)c];
