@@ -2476,7 +2476,31 @@ int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out) {
     p->batch = b;
     const int C = b->n_contigs;
     const int G = std::max(1, std::min<int>(n_groups, std::max(C, 1)));
-    for (int g = 0; g < G; ++g) p->ranges.push_back(std::make_pair((int)((int64_t)C * g / G), (int)((int64_t)C * (g + 1) / G)));
+    {
+        // consecutive contigs per group, cut where the aligned bases (= pileup bytes) reach g / G of the batch: the groups' chains are
+        // as long as their data, and the longest one ends the step
+        std::vector<int> cut((size_t)G + 1, 0);
+        cut[(size_t)G] = C;
+        const int64_t total = b->pile_off.empty() ? 0 : b->pile_off.back();
+        if (total > 0 && (int)b->contig_rec_off.size() == C + 1) {
+            int c = 0;
+            for (int g = 1; g < G; ++g) {
+                const int64_t want = total / G * g;
+                while (c < C && b->pile_off[(size_t)b->contig_rec_off[(size_t)c + 1]] <= want) ++c;
+                // the contig that crosses the mark goes to the side it lies more on
+                if (c < C) {
+                    const int64_t lo = b->pile_off[(size_t)b->contig_rec_off[(size_t)c]], hi = b->pile_off[(size_t)b->contig_rec_off[(size_t)c + 1]];
+                    if (hi - want < want - lo) ++c;
+                }
+                cut[(size_t)g] = std::max(cut[(size_t)g - 1], std::min(c, C));
+            }
+        } else for (int g = 1; g < G; ++g) cut[(size_t)g] = (int)((int64_t)C * g / G);
+        // every group keeps at least one contig while there are enough of them
+        for (int g = 1; g < G; ++g) cut[(size_t)g] = std::max(cut[(size_t)g], std::min(g, C));
+        for (int g = G - 1; g >= 1; --g) cut[(size_t)g] = std::min(cut[(size_t)g], C - (G - g));
+        for (int g = 1; g < G; ++g) cut[(size_t)g] = std::max(cut[(size_t)g], cut[(size_t)g - 1]);
+        for (int g = 0; g < G; ++g) p->ranges.push_back(std::make_pair(cut[(size_t)g], cut[(size_t)g + 1]));
+    }
     p->rcs.assign((size_t)G, 0); p->errs.assign((size_t)G, std::string()); p->cv.assign((size_t)G, nullptr);
     p->device = b->device; p->thread_device.assign((size_t)G, -1);
     p->sr_keep.resize((size_t)G);
