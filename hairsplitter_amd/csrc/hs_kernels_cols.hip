@@ -125,7 +125,6 @@ __global__ __launch_bounds__(256) void k_gather_tiles(
             if (lane < nrec) { en = tile_ent[rb + lane]; lrec = tile_lrec[rb + lane]; }
             __builtin_amdgcn_wave_barrier();
             // stage the rows: record j -> bytes of tile positions 4 * lane .. 4 * lane + 3
-#pragma unroll 4
             for (int j = 0; j < nrec; ++j) {
                 const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane(en.z, j), phi = (uint32_t)__builtin_amdgcn_readlane(en.w, j);
                 const uint8_t* __restrict__ base = pile + (int64_t)(((uint64_t)phi << 32) | plo);
