@@ -1740,8 +1740,8 @@ __global__ __launch_bounds__(256) void k_column_partition_lanes(
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int e = k * 64 + lane;
-                r_all[g][k] = e < n ? col_idx[e0 + e] : 0;
-                c_all[g][k] = e < n ? (int)col_code[e0 + e] : -1;
+                r_all[g][k] = 0; c_all[g][k] = -1;
+                if (k * 64 < n && e < n) { r_all[g][k] = col_idx[e0 + e]; c_all[g][k] = (int)col_code[e0 + e]; }      // (k * 64 < n: wave-uniform, most columns are one chunk)
             }
         }
 #pragma unroll
@@ -1750,9 +1750,17 @@ __global__ __launch_bounds__(256) void k_column_partition_lanes(
             int r_i[4], c_i[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { r_i[k] = r_all[g][k]; c_i[k] = c_all[g][k]; }
+            const int nch = (__builtin_amdgcn_readlane(h_n, src[g]) + 63) >> 6;      // chunks of 64 entries the column has (wave-uniform; nearly always one)
+            // what goes to LDS is the entry's ROW OFFSET in the table (read x row length): formed once here instead of by each of the
+            // sixteen lanes that walk the column
+            const int ppad_g = (__builtin_amdgcn_readlane(h_P, src[g]) + 15) & ~15;
+            bool wide = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const long long pr = (long long)r_i[k] * ppad_g; wide = wide || pr > 0x7fffffffll; r_i[k] = (int)pr; }
+            const bool any_wide = __ballot(wide) != 0ull;
             unsigned long long rem[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rem[k] = __ballot(c_i[k] >= 0);
+            for (int k = 0; k < 4; ++k) rem[k] = k < nch ? __ballot(c_i[k] >= 0) : 0ull;
             int ncodes = 0, filled = 0;
             for (;;) {
                 int code = -1;
@@ -1763,6 +1771,7 @@ __global__ __launch_bounds__(256) void k_column_partition_lanes(
                 if (lane == 0) { s_cstart[wv][g][ncodes] = (int16_t)filled; s_ccode[wv][g][ncodes] = (uint8_t)code; }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
+                    if (k >= nch) break;
                     const unsigned long long m = __ballot(c_i[k] == code);
                     rem[k] &= ~m;
                     if (c_i[k] == code) s_idx[wv][g][filled + __popcll(m & ((1ull << lane) - 1ull))] = r_i[k];
@@ -1771,7 +1780,7 @@ __global__ __launch_bounds__(256) void k_column_partition_lanes(
                 ncodes++;
             }
             if (lane == 0) { s_cstart[wv][g][ncodes <= HS_K4_MAXCODES ? ncodes : HS_K4_MAXCODES] = (int16_t)filled; s_cstart[wv][g][HS_K4_MAXCODES + 1] = (int16_t)ncodes; }
-            if (grp == g) too_many_codes = ncodes > HS_K4_MAXCODES;
+            if (grp == g) too_many_codes = ncodes > HS_K4_MAXCODES || any_wide;      // (a table beyond 2 GB: the exact kernel)
         }
         wave_lds_sync();
         // ---- the four groups, each on its own column: lanes = partitions ----
@@ -1802,10 +1811,10 @@ __global__ __launch_bounds__(256) void k_column_partition_lanes(
                     unsigned acc = 0u;
                     for (; e + 4 <= e1; e += 4) {      // four loads in flight before the adds
                         const int ra = ix[e], rb = ix[e + 1], rc = ix[e + 2], rd = ix[e + 3];
-                        const unsigned sa = tl[(int64_t)ra * ppad], sb = tl[(int64_t)rb * ppad], sc = tl[(int64_t)rc * ppad], sd = tl[(int64_t)rd * ppad];
+                        const unsigned sa = tl[ra], sb = tl[rb], sc = tl[rc], sd = tl[rd];
                         acc += (1u << sa) + (1u << sb) + (1u << sc) + (1u << sd);
                     }
-                    for (; e < e1; ++e) acc += 1u << (unsigned)tl[(int64_t)ix[e] * ppad];
+                    for (; e < e1; ++e) acc += 1u << (unsigned)tl[ix[e]];
                     const int plus = (int)((acc >> 16) & 255u), minus = (int)(acc >> 24);
                     const int take = (int)((acc >> 8) & 255u) + plus + minus;
                     if (code == k0) { n11 = plus; n01 = minus; }
