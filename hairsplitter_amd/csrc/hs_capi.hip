@@ -649,6 +649,11 @@ static int column_stats_tiled_launch(const uint8_t* d_pile, const int64_t* d_til
                                       : (full ? (KernelT)hsdev::k_column_stats_tiled<2, true, true> : (KernelT)hsdev::k_column_stats_tiled<2, false, true>))
                             : (narrow ? (full ? (KernelT)hsdev::k_column_stats_tiled<1, true, false> : (KernelT)hsdev::k_column_stats_tiled<1, false, false>)
                                       : (full ? (KernelT)hsdev::k_column_stats_tiled<2, true, false> : (KernelT)hsdev::k_column_stats_tiled<2, false, false>));
+    static const bool no_dw = std::getenv("HS_K2_BYTE_LOADS") != nullptr;      // (diagnostic: the one-byte-per-lane form for every launch)
+    if (padded && narrow && !full && d_sel_count && !no_dw)      // the stage driver's launch: four positions per lane
+        hipLaunchKernelGGL(hsdev::k_column_stats_tiled_dw, dim3((unsigned)grid), dim3(256), 0, stream, d_pile, d_tile_off, reinterpret_cast<const int4*>(d_tile_ent),
+                           total_len, min_second, sc->tile_cnt.as<int32_t>(), sc->gpos.as<int64_t>(), sc->depth.as<int32_t>(), tile0, g_lo, g_hi, d_tile_ent_sum);
+    else
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), 0, stream, d_pile, d_tile_off, reinterpret_cast<const int4*>(d_tile_ent),
                        total_len, reinterpret_cast<hsdev::hs_colstat_dev*>(d_stats), min_second, d_sel_count ? sc->tile_cnt.as<int32_t>() : nullptr,
                        d_sel_count ? sc->gpos.as<int64_t>() : nullptr, d_sel_count ? sc->depth.as<int32_t>() : nullptr, sel_cap, tile0, g_lo, g_hi,

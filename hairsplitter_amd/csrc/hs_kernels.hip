@@ -847,6 +847,123 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled(
     column_stats_tail<CB, FULL>(hw, tid, lane, g, total, stats, min_second, sel_count, sel_gpos, sel_depth, sel_cap, g_lo, g_hi, sel_ent);
 }
 
+// K2 on a tile plan, four positions per lane (the form the stage driver runs: byte counters, padded pileup, only the selection):
+// a record's 256 bytes over the tile are ONE dword load per lane of one wavefront (lane l: positions 4 l .. 4 l + 3) instead of
+// four byte loads in four wavefronts, and the wavefronts of the workgroup take the tile's records in turn (record j goes to wave
+// j mod 4), all four counting into the same histogram columns with LDS atomics. A record that covers the whole tile -- 19 of 20
+// at 30x with 10-kb reads -- needs no range test at all (wave-uniform branch). Counter word w of position p lives at
+// [w][p % 4][p / 4]: for a fixed byte of the dword the 64 lanes hit 64 different banks. The final scan gives every thread one
+// column (thread t: position 4 (t % 64) + t / 64); the selection is written in position order through the four ballots.
+__global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
+    const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, int64_t total, int min_second,
+    int32_t* __restrict__ sel_count, int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int64_t tile0, int64_t g_lo, int64_t g_hi,
+    int32_t* __restrict__ sel_ent) {
+    constexpr int NWORDS = (HS_NBINS + 3) / 4;
+    // exactly 32 KB of LDS (five workgroups per CU): the ballots of the selection reuse the histogram's first bytes once every
+    // thread has read its column
+    __shared__ __attribute__((aligned(16))) uint32_t hw[NWORDS * 256];
+    unsigned long long* const s_b = reinterpret_cast<unsigned long long*>(hw);
+    int* const s_e = reinterpret_cast<int*>(hw) + 8;
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63, wv = wave_id();
+    const int64_t tile = tile0 + (int64_t)blockIdx.x;
+#pragma unroll
+    for (int x = 0; x < NWORDS * 256 / (256 * 4); ++x) reinterpret_cast<uint4*>(hw)[x * 256 + tid] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    char* const my_cols = reinterpret_cast<char*>(hw) + lane * 4;      // byte k of this lane's dword: column k * 64 + lane, i.e. + 256 k bytes
+    auto bump = [&](unsigned code, bool valid, int k) {
+        if (valid) {
+            const unsigned inc = 1u << ((code & 3u) * 8u);
+            uint32_t* at = reinterpret_cast<uint32_t*>(my_cols + 256 * k + ((code & ~3u) << 8));
+            __hip_atomic_fetch_add(at, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    const int64_t e0 = tile_off[tile], e1 = tile_off[tile + 1];
+    for (int64_t i0 = e0; i0 < e1; i0 += 64) {
+        const int nrec = (e1 - i0) < 64 ? (int)(e1 - i0) : 64;
+        const int4 held = tile_ent[i0 + (lane < nrec ? lane : nrec - 1)];   // lane j keeps record i0 + j
+        auto step = [&](int j, auto n_const) {      // records j, j + 4, ... (this wavefront's), NU of them with their loads in flight together
+            constexpr int NU = decltype(n_const)::value;
+            uint32_t v[NU]; int first[NU], len[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int jj = j + 4 * u;
+                first[u] = __builtin_amdgcn_readlane(held.x, jj); len[u] = __builtin_amdgcn_readlane(held.y, jj);
+                const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane(held.z, jj), phi = (uint32_t)__builtin_amdgcn_readlane(held.w, jj);
+                const uint8_t* __restrict__ base = pile + (int64_t)(((uint64_t)phi << 32) | plo);   // pileup byte of position 0 of the tile
+                v[u] = *reinterpret_cast<const u32_unaligned*>(base + 4 * lane);      // (the buffer is padded: positions the record does not cover are readable)
+            }
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if (first[u] == 0 && len[u] == 256) {      // the record covers the tile (wave-uniform)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { const unsigned code = ((v[u] >> (8 * k)) & 255u) - 33u; bump(code, code < (unsigned)HS_NBINS, k); }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned code = ((v[u] >> (8 * k)) & 255u) - 33u;
+                        bump(code, (unsigned)(4 * lane + k - first[u]) < (unsigned)len[u] && code < (unsigned)HS_NBINS, k);
+                    }
+                }
+            }
+        };
+        int j = wv;
+        for (; j + 4 * 7 < nrec; j += 4 * 8) step(j, std::integral_constant<int, 8>());
+        for (; j + 4 * 1 < nrec; j += 4 * 2) step(j, std::integral_constant<int, 2>());
+        for (; j < nrec; j += 4) step(j, std::integral_constant<int, 1>());
+    }
+    __syncthreads();
+    // ---- thread t scans column t = the counters of position 4 (t % 64) + t / 64 ----
+    const int64_t g = tile * 256 + 4 * lane + wv;
+    int c0 = 0, c1 = 0, depth = 0;
+    if (g < total) {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        us2 m0a = {0, 0}, m1a = {0, 0}, m0b = {0, 0}, m1b = {0, 0};
+#pragma unroll 4
+        for (int w = 0; w < NWORDS; ++w) {
+            const uint32_t word = hw[w * 256 + tid];
+            depth = (int)__builtin_amdgcn_sad_u8(word, 0u, (uint32_t)depth);      // sum of the four byte counters
+            const us2 va = __builtin_bit_cast(us2, word & 0x00ff00ffu);
+            const us2 vb = __builtin_bit_cast(us2, (word >> 8) & 0x00ff00ffu);
+            const us2 la = __builtin_elementwise_min(va, m0a);
+            m1a = __builtin_elementwise_max(m1a, la);
+            m0a = __builtin_elementwise_max(m0a, va);
+            const us2 lb = __builtin_elementwise_min(vb, m0b);
+            m1b = __builtin_elementwise_max(m1b, lb);
+            m0b = __builtin_elementwise_max(m0b, vb);
+        }
+        const int tops[8] = {m0a.x, m1a.x, m0a.y, m1a.y, m0b.x, m1b.x, m0b.y, m1b.y};
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const int v = tops[f];
+            const int lo2 = v < c0 ? v : c0;     // branch-free two largest
+            c1 = c1 > lo2 ? c1 : lo2;
+            c0 = c0 > v ? c0 : v;
+        }
+    }
+    const bool third = depth > c0 + c1;      // a third non-empty bin <=> reads beyond the two largest counts
+    // selection in position order: second count above the floor, or exactly at it with no third allele (see column_stats_tail)
+    const bool sel = g < total && g >= g_lo && g < g_hi && (c1 > min_second || (c1 == min_second && !third));
+    const unsigned long long mine = __ballot(sel);
+    const int we = wave_sum_i32(sel ? depth : 0);
+    __syncthreads();      // (every column has been read)
+    if (lane == 0) { s_b[wv] = mine; s_e[wv] = we; }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int rank = 0, n_sel = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long bk = s_b[k];
+        rank += __popcll(bk & below) + ((k < wv) ? (int)((bk >> lane) & 1ull) : 0);
+        n_sel += __popcll(bk);
+    }
+    if (sel) {
+        const int64_t slot = (int64_t)blockIdx.x * 256 + rank;
+        sel_gpos[slot] = g; sel_depth[slot] = depth;
+    }
+    if (tid == 0) { sel_count[blockIdx.x] = n_sel; if (sel_ent) sel_ent[blockIdx.x] = s_e[0] + s_e[1] + s_e[2] + s_e[3]; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3 column extraction: builds the reference's Column (Partition.h:8-14) for selected positions.
 // One wavefront per selected position; 64 records per step, ballot + prefix popcount give every covering
