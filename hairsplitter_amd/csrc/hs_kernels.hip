@@ -597,7 +597,7 @@ static __device__ __forceinline__ void column_stats_tail(const uint32_t* __restr
                 if (CB == 1) {
                     depth = (int)__builtin_amdgcn_sad_u8(word, 0u, (uint32_t)depth);      // sum of the four byte counters
                     va = __builtin_bit_cast(us2, word & 0x00ff00ffu);
-                    vb = __builtin_bit_cast(us2, (word >> 8) & 0x00ff00ffu);
+                    vb = __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, word, 0x0c030c01u));      // bytes 1 and 3, zero-extended: one v_perm
                 } else {
                     depth += (int)(word & 0xffffu) + (int)(word >> 16);
                     va = __builtin_bit_cast(us2, word);
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
             const uint32_t word = hw[w * 256 + tid];
             depth = (int)__builtin_amdgcn_sad_u8(word, 0u, (uint32_t)depth);      // sum of the four byte counters
             const us2 va = __builtin_bit_cast(us2, word & 0x00ff00ffu);
-            const us2 vb = __builtin_bit_cast(us2, (word >> 8) & 0x00ff00ffu);
+            const us2 vb = __builtin_bit_cast(us2, __builtin_amdgcn_perm(0u, word, 0x0c030c01u));      // bytes 1 and 3, zero-extended: one v_perm
             const us2 la = __builtin_elementwise_min(va, m0a);
             m1a = __builtin_elementwise_max(m1a, la);
             m0a = __builtin_elementwise_max(m0a, va);
