@@ -92,6 +92,23 @@ BlockPool& pool() {
     return *p;
 }
 
+// HS_EXIT_PROBE=1 (diagnostic, called by the drop-in executables before they leave): gives the pooled blocks back and resets the
+// device, timing every step -- what the process would otherwise leave to the kernel's teardown after _exit
+extern "C" void hs_teardown_probe(void) {
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    BlockPool& p = pool();
+    size_t db = 0, hb = 0, dn = 0, hn = 0;
+    const double t0 = now();
+    for (auto& b : p.free_dev) { db += b.first; dn++; (void)hipFree(b.second); }
+    const double t1 = now();
+    for (auto& b : p.free_host) { hb += b.first; hn++; (void)hipHostFree(b.second); }
+    const double t2 = now();
+    (void)hipDeviceReset();
+    const double t3 = now();
+    std::fprintf(stderr, "[hs exit probe] pooled device blocks: %zu, %.1f MB, hipFree %.1f ms; pooled pinned blocks: %zu, %.1f MB, hipHostFree %.1f ms; hipDeviceReset %.1f ms\n",
+                 dn, db / 1e6, t1 - t0, hn, hb / 1e6, t2 - t1, t3 - t2);
+}
+
 // RAII device buffer (pooled). A block goes back to the pool it came from (`owner`), whatever device is current on the thread
 // that releases it.
 struct DBuf {
