@@ -25,7 +25,9 @@
 #include <sys/types.h>
 #include <sys/wait.h>
 #include "../../include/hairsplitter_hip.h"
-void hs_teardown_probe(void);      /* (diagnostic, not part of the C ABI header) */
+void hs_teardown_probe(void);      /* (diagnostics, not part of the C ABI header) */
+void hs_cpuprof_start(const char* out_file);
+void hs_cpuprof_stop(void);
 
 static double hs_dropin_now_ms(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 static void hs_dropin_stamp(const char* what) {      /* HS_TIMING: wall-clock stamps of the process (epoch ms), to be set against the caller's own */
@@ -37,7 +39,9 @@ static int (*hs_dropin_stage)(int, char**);
 static int hs_dropin_run(int argc, char** argv) {
     const double t0 = hs_dropin_now_ms();
     hs_main_process_exits(1);
+    if (getenv("HS_CPU_PROFILE")) hs_cpuprof_start(getenv("HS_CPU_PROFILE"));      /* sampling profile of the host side (tools/cpuprof_report.py) */
     const int rc = hs_dropin_stage(argc, argv);
+    if (getenv("HS_CPU_PROFILE")) hs_cpuprof_stop();
     fflush(NULL);
     if (getenv("HS_EXIT_PROBE")) { const double tp = hs_dropin_now_ms(); hs_teardown_probe(); fprintf(stderr, "[hs exit probe] explicit teardown %.1f ms\n", hs_dropin_now_ms() - tp); }
     if (getenv("HS_TIMING")) fprintf(stderr, "[hs timing] main: entry to exit %.1f ms\n", hs_dropin_now_ms() - t0);

@@ -104,7 +104,8 @@ static int atoi_n(const char* p, size_t n) {        // std::atoi on a field that
     return (int)(neg ? -v : v);
 }
 
-static int parse_cigar(const char* cg, size_t n, std::vector<uint32_t>& ops) {
+template <class Ops>
+static int parse_cigar(const char* cg, size_t n, Ops& ops) {
     // tools.cpp:27-57 semantics: digits accumulate, any other byte closes a run of that operation.
     if (n == 1 && cg[0] == '*') return 0;
     long num = -1;
@@ -127,13 +128,17 @@ static int parse_cigar(const char* cg, size_t n, std::vector<uint32_t>& ops) {
 }
 
 namespace {
-struct SamRec { size_t line; int32_t contig; int32_t read, pos; uint8_t strand; int32_t r0, r1, c0, c1; int64_t need; std::vector<uint32_t> cig; };
+// the CIGAR ops of a record are [cig_off, cig_off + cig_n) of the buffer its block (or the replay pass) parses into: one growing
+// array per block instead of one heap allocation per record (171 k allocations of 16 KB on 16 threads: a quarter of the stage's CPU
+// time went into glibc growing its per-thread arenas, mprotect by mprotect)
+using CigarBuf = std::vector<uint32_t, NoInitAlloc<uint32_t>>;
+struct SamRec { size_t line; int32_t contig; int32_t read, pos; uint8_t strand; int32_t r0, r1, c0, c1; int64_t need; size_t cig_off, cig_n; const CigarBuf* buf; };
 enum SamLineResult { SAM_SKIP = 0, SAM_REC = 1, SAM_DEFER = 2, SAM_BAD_CIGAR = 3 };
 
 // One alignment line (input_output.cpp:300-528). `lookup(name, is_query, &found)` resolves a name to its index in the
 // reference's single name table (reads first, then contigs); the parallel pass defers lines with unknown names.
 template <class Lookup>
-SamLineResult parse_sam_line(const Line& l, size_t line_no, long n_reads, long n_contigs, bool amplicon, Lookup&& lookup, SamRec& r, std::string* bad_cigar) {
+SamLineResult parse_sam_line(const Line& l, size_t line_no, long n_reads, long n_contigs, bool amplicon, Lookup&& lookup, SamRec& r, std::string* bad_cigar, CigarBuf& ops) {
     const char* cg = nullptr; size_t cgn = 0;
     long seq1 = -1, seq2 = -2;
     int length1 = 0, pos2_1 = -1, flag = 0, nonmatching = 0;
@@ -141,8 +146,9 @@ SamLineResult parse_sam_line(const Line& l, size_t line_no, long n_reads, long n
     int fieldnumber = 0;
     size_t a = 0;
     while (true) {
-        size_t b = a;
-        while (b < l.n && l.p[b] != '\t') b++;
+        // (the sequence and quality fields of a long read are tens of kilobytes: memchr, not a byte loop)
+        const char* tab = a < l.n ? (const char*)std::memchr(l.p + a, '\t', l.n - a) : nullptr;
+        const size_t b = tab ? (size_t)(tab - l.p) : l.n;
         const char* f = l.p + a; const size_t fn = b - a;
         if (fieldnumber == 0) {
             bool found = true, defer = false;
@@ -169,40 +175,43 @@ SamLineResult parse_sam_line(const Line& l, size_t line_no, long n_reads, long n
         a = b + 1;
     }
     if (!(allgood && fieldnumber > 10 && seq2 != seq1)) return SAM_SKIP;
-    r.cig.clear();
-    r.cig.reserve(cgn / 2 + 1);      // an op is at least two characters
-    if (parse_cigar(cg, cgn, r.cig) != 0) { if (bad_cigar) bad_cigar->assign(cg, cgn); return SAM_BAD_CIGAR; }
+    const size_t cig0 = ops.size();
+    auto drop = [&](SamLineResult k) { ops.resize(cig0); return k; };      // (a line that yields no record leaves nothing behind)
+    if (parse_cigar(cg, cgn, ops) != 0) { if (bad_cigar) bad_cigar->assign(cg, cgn); return drop(SAM_BAD_CIGAR); }
+    const uint32_t* cig = ops.data() + cig0;
+    const size_t ncig = ops.size() - cig0;
     auto clip = [&](bool front, uint32_t what) -> int {
-        if (r.cig.empty()) return 0;
-        uint32_t op = front ? r.cig.front() : r.cig.back();
+        if (ncig == 0) return 0;
+        uint32_t op = front ? cig[0] : cig[ncig - 1];
         return (op & 15u) == what ? (int)(op >> 4) : 0;
     };
     int nbH_start = clip(true, 5), nbH_end = clip(false, 5);
     int nbS_start = clip(true, 4), nbS_end = clip(false, 4);
-    if (r.cig.size() == 1) {   // single-op CIGAR: the reference's backward scan sees the same run from both ends
+    if (ncig == 1) {   // single-op CIGAR: the reference's backward scan sees the same run from both ends
         nbH_end = nbH_start; nbS_end = nbS_start;
     }
     if (!positive) { std::swap(nbH_start, nbH_end); std::swap(nbS_start, nbS_end); }
     if (nbH_start + nbH_end > 0.2 * length1 && flag < 2048) allgood = false;
     else if (flag % 512 >= 256) allgood = false;
     if (amplicon && nonmatching > 0.2 * length1) allgood = false;
-    if (!allgood) return SAM_SKIP;
+    if (!allgood) return drop(SAM_SKIP);
     int length_read = 0, length_contig = 0;
     int64_t need = 0;
-    for (uint32_t op : r.cig) {
+    for (size_t q = 0; q < ncig; ++q) {
+        const uint32_t op = cig[q];
         const uint32_t c = op & 15u; const int len = (int)(op >> 4);
         if (c == 0 || c == 7 || c == 8) { length_read += len; length_contig += len; }
         else if (c == 1) length_read += len;
         else if (c == 2) length_contig += len;
         if (c == 0 || c == 1 || c == 4 || c == 5 || c == 7 || c == 8) need += len;
     }
-    r.line = line_no; r.need = need;
+    r.line = line_no; r.need = need; r.cig_off = cig0; r.cig_n = ncig; r.buf = &ops;
     r.read = (int32_t)seq1; r.pos = pos2_1 - 1; r.strand = positive ? 1 : 0;
     r.r0 = nbS_start + nbH_start; r.r1 = nbS_start + nbH_start + length_read;
     r.c0 = pos2_1 - 1; r.c1 = pos2_1 + length_contig;
     const long ci = seq2 - n_reads;
-    if (ci < 0 || ci >= n_contigs) return SAM_SKIP;   // target is not a contig of the GFA
-    if (seq1 >= n_reads) return SAM_SKIP;             // contig-on-contig records are outside this path's contract
+    if (ci < 0 || ci >= n_contigs) return drop(SAM_SKIP);   // target is not a contig of the GFA
+    if (seq1 >= n_reads) return drop(SAM_SKIP);             // contig-on-contig records are outside this path's contract
     r.contig = (int32_t)ci;
     return SAM_REC;
 }
@@ -274,8 +283,8 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
             // fields are tab separated: S <name> <sequence> ...
             size_t a = 0; int field = 0; std::string_view name;
             while (a <= l.n) {
-                size_t b = a;
-                while (b < l.n && l.p[b] != '\t') b++;
+                const char* tab = a < l.n ? (const char*)std::memchr(l.p + a, '\t', l.n - a) : nullptr;
+                const size_t b = tab ? (size_t)(tab - l.p) : l.n;
                 if (field == 1) name = first_token(l.p + a, b - a);
                 else if (field == 2) {
                     seqs.push_back(Line{l.p + a, b - a});
@@ -312,7 +321,7 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
     std::vector<Line> sl = split_lines(stxt.p, stxt.n, n_threads);
     lap("map + split sam");
     const int NB = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads * 4, sl.size() / 64 + 1));
-    struct Block { std::vector<SamRec> recs; std::vector<size_t> deferred; size_t bad_line = (size_t)-1; std::string bad_cigar; };
+    struct Block { std::vector<SamRec> recs; CigarBuf ops; std::vector<size_t> deferred; size_t bad_line = (size_t)-1; std::string bad_cigar; };
     std::vector<Block> blocks((size_t)NB);
     hs_parallel_for(NB, n_threads, [&](int bi) {
         Block& B = blocks[(size_t)bi];
@@ -323,11 +332,16 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
             return it->second;
         };
         SamRec r;
+        {   // room for the block's ops up front: a CIGAR op is at least two characters and the CIGAR a fraction of its line
+            size_t bytes = 0;
+            for (size_t li = l0; li < l1; ++li) bytes += sl[li].n;
+            B.ops.reserve(bytes / 6 + 1024);
+        }
         for (size_t li = l0; li < l1; ++li) {
             const Line& l = sl[li];
             if (l.n == 0 || l.p[0] == '@') continue;
-            const SamLineResult k = parse_sam_line(l, li, n_reads, n_contigs, amplicon, lookup, r, &B.bad_cigar);
-            if (k == SAM_REC) B.recs.push_back(std::move(r));
+            const SamLineResult k = parse_sam_line(l, li, n_reads, n_contigs, amplicon, lookup, r, &B.bad_cigar, B.ops);
+            if (k == SAM_REC) B.recs.push_back(r);
             else if (k == SAM_DEFER) B.deferred.push_back(li);
             else if (k == SAM_BAD_CIGAR) { B.bad_line = li; break; }
         }
@@ -340,6 +354,7 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
             return HS_EFORMAT;
         }
     std::vector<SamRec> replayed;
+    CigarBuf replayed_ops;
     {
         std::unordered_map<std::string, long> inserted;   // names operator[] would have added, all with index 0
         std::string bad;
@@ -354,8 +369,8 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
                     return 0;
                 };
                 SamRec r;
-                const SamLineResult k = parse_sam_line(sl[li], li, n_reads, n_contigs, amplicon, lookup, r, &bad);
-                if (k == SAM_REC) replayed.push_back(std::move(r));
+                const SamLineResult k = parse_sam_line(sl[li], li, n_reads, n_contigs, amplicon, lookup, r, &bad, replayed_ops);
+                if (k == SAM_REC) replayed.push_back(r);
                 else if (k == SAM_BAD_CIGAR) {
                     std::cout << "ERROR : could not convert " << bad << " to int" << std::endl;
                     set_error("malformed CIGAR " + bad);
@@ -409,7 +424,7 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
                     return HS_EFORMAT;
                 }
                 flat[k] = r;
-                in.rec_cig_off[k + 1] = in.rec_cig_off[k] + (int64_t)r->cig.size();
+                in.rec_cig_off[k + 1] = in.rec_cig_off[k] + (int64_t)r->cig_n;
                 k++;
             }
     }
@@ -422,7 +437,7 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
                 const SamRec* r = flat[k];
                 in.rec_read[k] = r->read; in.rec_pos[k] = r->pos; in.rec_strand[k] = r->strand;
                 in.rec_r0[k] = r->r0; in.rec_r1[k] = r->r1; in.rec_c0[k] = r->c0; in.rec_c1[k] = r->c1;
-                if (!r->cig.empty()) std::memcpy(in.cigar.data() + in.rec_cig_off[k], r->cig.data(), r->cig.size() * sizeof(uint32_t));
+                if (r->cig_n) std::memcpy(in.cigar.data() + in.rec_cig_off[k], r->buf->data() + r->cig_off, r->cig_n * sizeof(uint32_t));
             }
         });
     }
