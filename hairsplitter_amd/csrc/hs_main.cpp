@@ -106,6 +106,11 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
     clk.lap("hs_cv_run_host (H2D + stage 3)");
     hs::write_cv_outputs(in, res, error_rate_out, file_out, vcf_file, num_threads);
     clk.lap("write .col/.vcf");
+    if (std::getenv("HS_EXIT_PROBE")) {      // (diagnostic: what destroying the parsed input and the result costs here instead of at exit)
+        hs_cv_result_destroy(res); clk.lap("destroy the result");
+        delete in_p; in_guard.p = nullptr; clk.lap("destroy the parsed input");
+        return 0;
+    }
     if (!g_leak_at_exit) hs_cv_result_destroy(res);
     return 0;
 }
