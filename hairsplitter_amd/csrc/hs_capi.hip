@@ -1091,10 +1091,39 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
         if (b->max_depth > 65535) { set_error("a position is covered by more than 65535 alignment records"); delete b; return HS_EINVAL; }
     }
     int rc = 0;
+    // Large pageable arrays (read bases, CIGAR ops: gigabytes) go up through two pinned 32-MB buffers: a chunk is copied into one on
+    // several host threads while the other is on its way (a plain hipMemcpy from pageable memory stages through the runtime's own
+    // buffers with one copying thread: 12-15 GB/s)
+    HBuf stage[2];
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
+    auto up_big = [&](void* dst, const char* src, size_t bytes) -> int {
+        const size_t CH = (size_t)32 << 20;
+        for (int k = 0; k < 2; ++k) {
+            if (!stage[k].p) { if (int r = stage[k].alloc(CH)) return r; }
+            if (!stage_done[k]) HS_HIP(hipEventCreateWithFlags(&stage_done[k], hipEventDisableTiming));
+        }
+        int k = 0;
+        for (size_t off = 0; off < bytes; off += CH, k ^= 1) {
+            const size_t n = std::min(CH, bytes - off);
+            HS_HIP(hipEventSynchronize(stage_done[k]));      // (the copy that last used this buffer; returns at once the first time)
+            const int parts = 8;
+            hs::hs_parallel_for(parts, std::min(parts, host_threads()), [&](int q) {
+                const size_t a = n * (size_t)q / parts, e = n * ((size_t)q + 1) / parts;
+                std::memcpy((char*)stage[k].p + a, src + off + a, e - a);
+            });
+            HS_HIP(hipMemcpyAsync((char*)dst + off, stage[k].p, n, hipMemcpyHostToDevice, nullptr));
+            HS_HIP(hipEventRecord(stage_done[k], nullptr));
+        }
+        HS_HIP(hipStreamSynchronize(nullptr));
+        return HS_OK;
+    };
     auto up = [&](DBuf& d, const void* src, size_t bytes) {
         if (rc) return;
         rc = d.alloc(bytes);
-        if (!rc && bytes) { hipError_t e = hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice); if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = HS_EHIP; } }
+        if (rc || !bytes) return;
+        if (bytes >= ((size_t)64 << 20)) { rc = up_big(d.p, (const char*)src, bytes); return; }
+        hipError_t e = hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { set_error(hipGetErrorString(e)); rc = HS_EHIP; }
     };
     up(b->contig_seq, h_contig_seq, (size_t)b->total_len);
     up(b->d_contig_off, b->contig_off.data(), sizeof(int64_t) * b->contig_off.size());
@@ -1152,6 +1181,7 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
     }
     if (!rc) rc = b->pile.alloc((size_t)b->total_pile + 512);
     if (!rc) rc = b->rec_stats.alloc(sizeof(int32_t) * 4 * (size_t)n_rec);
+    for (int k = 0; k < 2; ++k) if (stage_done[k]) (void)hipEventDestroy(stage_done[k]);
     if (rc) { delete b; return rc; }
     *out = b;
     return HS_OK;
