@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
     __shared__ uint32_t s_sort[4][136];
     __shared__ int s_stack[4][120];
     __shared__ uint8_t s_first[4][128];
+    __shared__ int s_fpos[4][128];
     const int lane = lane_id();
     const int wv = wave_id();
     const int64_t n_cols = header->n_cols;
@@ -200,16 +201,32 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
         const bool tie = c0 == c1 || c1 == c2 || c1 == 0;
         (void)c3;
         if (tie) {
-            if (lane == 0) {
-                // codes in first-appearance order
-                int nd = 0;
+            // the column's codes in the order in which its reads bring them: the first position of every code by LDS atomic minima
+            // over a coalesced pass (instead of one lane walking the column byte by byte out of global memory), the rank of a code =
+            // how many codes appear before it
+            int* __restrict__ fp = s_fpos[wv];
+            fp[lane] = 0x7fffffff; fp[lane + 64] = 0x7fffffff;
+            wave_lds_sync();
+            for (int j = lane; j < n; j += 64) {
+                const int bin = (int)col_code[b + j] - 33;
+                if (bin >= 0 && bin < HS_NBINS) atomicMin(&fp[bin], j);
+            }
+            wave_lds_sync();
+            {
+                const int p_a = fp[lane], p_b = fp[lane + 64];      // (0x7fffffff: the code does not occur)
+                const unsigned long long m_a = __ballot(p_a != 0x7fffffff), m_b = __ballot(p_b != 0x7fffffff);
+                int r_a = 0, r_b = 0;
+                for (unsigned long long m = m_a; m; m &= m - 1ull) { const int pq = __builtin_amdgcn_readlane(p_a, __builtin_ctzll(m)); r_a += pq < p_a; r_b += pq < p_b; }
+                for (unsigned long long m = m_b; m; m &= m - 1ull) { const int pq = __builtin_amdgcn_readlane(p_b, __builtin_ctzll(m)); r_a += pq < p_a; r_b += pq < p_b; }
                 uint8_t* first = s_first[wv];
-                for (int j = 0; j < n; ++j) {
-                    const int c = (int)col_code[b + j];
-                    const int bin = c - 33;
-                    if (bin < 0 || bin >= HS_NBINS) continue;
-                    if (h[bin] > 0) { first[nd++] = (uint8_t)c; h[bin] = -h[bin]; }      // negative = listed
-                }
+                if (p_a != 0x7fffffff) { first[r_a] = (uint8_t)(lane + 33); h[lane] = -h[lane]; }      // negative = listed
+                if (p_b != 0x7fffffff) { first[r_b] = (uint8_t)(lane + 64 + 33); h[lane + 64] = -h[lane + 64]; }
+                if (lane == 0) s_sort[wv][131] = (uint32_t)(__popcll(m_a) + __popcll(m_b));
+            }
+            wave_lds_sync();
+            if (lane == 0) {
+                const int nd = (int)s_sort[wv][131];
+                const uint8_t* first = s_first[wv];
                 hs::Rh8View rh; rh.init(s_info[wv], s_key[wv], s_tmp[wv], 512);
                 for (int i = 0; i < nd; ++i) rh.insert(first[i]);
                 rh.insert(0); rh.insert(1); rh.insert(2);
