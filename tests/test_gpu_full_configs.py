@@ -59,10 +59,11 @@ def test_c4_full_size_equals_reference(built):
     out = _check(built, "C4")
     assert out["contigs"] == 500 and out["aligned_bp"] > 1.6e9
     # BASELINE.json's target is >= 20x the reference's call_variants + separate_reads wall clock at 8 GPUs. On ONE GPU, file to file
-    # (2 GB of text parsed by both sides), as the orchestrator sees the two stages (hairsplitter.py:668-679,725-726), next to the
-    # reference with all cores, runs on this pool give 19.5x - 24x (the value is recorded in gpurun_out/parity_full_configs.jsonl and
-    # in bench.py's file_to_file.job.speedup); the assertion is the floor below that spread, so that a regression fails the suite
-    assert out["speedup_file_to_file"] >= 16, (out["hip"], out["ref"])
+    # (3.6 GB of text parsed by both sides), as the orchestrator sees the two stages (hairsplitter.py:668-679,725-726), next to the
+    # reference with all cores, runs on this pool give 38x - 44x (23x - 27x timed to the full exit of the processes: recorded as
+    # speedup_file_to_file_no_detach in gpurun_out/parity_full_configs.jsonl and in bench.py's file_to_file.job.speedup); the
+    # assertion is the target itself, half of what is measured, so that a regression fails the suite
+    assert out["speedup_file_to_file"] >= 20, (out["hip"], out.get("hip_runs_s"), out["ref"])
 
 
 def test_c5_chunks_full_size_equals_reference(built):
