@@ -1310,7 +1310,7 @@ struct HipCvOps : hs::CvDeviceOps {
     int64_t n_cols = 0, n_entries = 0;            // extracted columns / their entries
     SelectionScratch range_scratch;               // K2's per-tile slots
     DBuf d_tile_ent_sum, d_tile_ebase, d_scan2;
-    DBuf d_col_gpos, d_col_rec, d_co, d_col_len, d_ci, d_cc;      // d_co / d_ci / d_cc: the CSR of the columns (also read by k_robust_partitions)
+    DBuf d_col_gpos, d_col_rec, d_co, d_col_len, d_ci, d_cc;      // d_co / d_ci / d_cc: the CSR of the columns (also read by k_loop_a_prepare)
     DBuf d_col_ctg, d_k0, d_k1, d_c1, d_cand, d_ctg_col_off, d_min_reads, d_blk_cnt, d_blk_ent;
     // what the host reads between the phases, one small block = one download: [ColumnsHeader 64 B][tie counters 16 B][pad][per-contig counts 4 C]
     DBuf d_info; HBuf h_info;
@@ -1336,7 +1336,7 @@ struct HipCvOps : hs::CvDeviceOps {
     }
     PackLayout pk_layout{};
     UploadPack range_pack;
-    int n_gathered = 0;                           // (k_robust_partitions checks its column indices against it)
+    int n_gathered = 0;                           // (k_loop_a_prepare checks its column indices against it)
     int64_t gathered_entries = 0;
     static int grow(HBuf& h, size_t need) { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); }
     static int grow(DBuf& d, size_t need) { if (d.cap >= need && d.p && !d.view) { d.bytes = need; return HS_OK; } return d.alloc(need + need / 4); }

@@ -36,7 +36,7 @@ struct CvContigState;   // per-contig state between the phases of the stage-3 gl
 CvContigState* cv_state_new();
 void cv_state_free(CvContigState* st);
 // The host part of keep_only_robust_variants in steps: loop A on the host (cv_phase_a_host) or imported from the device
-// (k_robust_partitions -> cv_phase_a_import), then loop B (cv_phase_b); the final partitions leave for loops C / D on the device.
+// (k_loop_a -> cv_phase_a_import), then loop B (cv_phase_b); the final partitions leave for loops C / D on the device.
 // read_start / read_end: [n_reads] reference interval [start, end) of every record of the contig (POS-1, POS-1 + reference span)
 struct CvPartRecord { int32_t left, right, n_occ, n_corr, lo, hi, reach, pad; int64_t elem; };   // what k_loop_a_pack writes per partition
 void cv_phase_begin(CvContigState& st, int n_reads, int n_candidates, float mean_distance, ContigCvResult& out);

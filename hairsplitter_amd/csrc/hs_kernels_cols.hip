@@ -13,8 +13,8 @@
 //                         one lane on LDS tables for the columns where counts tie; nothing goes to the host
 //   k_candidates_scan     V1: the greedy spacing scan of call_variants.cpp:525-536 per contig (lanes = columns, the
 //                         dependency only runs along the few columns that pass the predicate)
-//   k_flag_prefix / k_pack_flagged   the flagged columns (candidates, later the SNPs) packed back to back with their records
-//   k_snp_select          the two-pointer merge of automatic and filtered SNPs (:1335-1352) as a per-contig bound
+//   k_flag_block_sums / k_flag_block_offsets / k_pack_flagged   the flagged columns (candidates, later the SNPs) packed back to back with their records
+//   k_snp_bounds / k_snp_flags   the two-pointer merge of automatic and filtered SNPs (:1335-1352) as a per-contig bound
 // Included by hs_capi.hip after hs_kernels.hip.
 #pragma once
 
@@ -40,7 +40,7 @@ static_assert(sizeof(hs_colrec_dev) == 16, "hs_colrec must be 16 bytes");
 
 struct ColumnsHeader {      // what the host reads between the phases (one small download)
     int64_t n_cols, n_entries;          // extracted columns / their entries
-    int64_t n_flagged, n_flagged_entries;   // candidates (after k_candidates_scan + k_flag_prefix) or SNPs (after k_snp_select + ...)
+    int64_t n_flagged, n_flagged_entries;   // candidates (after k_candidates_scan + k_flag_block_sums/_offsets) or SNPs (after k_snp_flags + ...)
     int64_t n_tie, n_tie_big;           // columns whose order went through the emulator / through std::sort's non-stable part
     int64_t pad[2];
 };
