@@ -970,19 +970,20 @@ int hs_edlib_hw_align(const uint8_t* d_query, const int64_t* h_query_off, const 
         const int64_t qn = qo[(size_t)i + 1] - qo[(size_t)i], tn = to[(size_t)i + 1] - to[(size_t)i];
         hs_off[(size_t)i + 1] = hs_off[(size_t)i] + tn + 64;
         const int64_t nb = (qn + 63) / 64;
-        st_off[(size_t)i + 1] = st_off[(size_t)i] + (path && nb <= 64 ? tn * nb * 3 : 0);
+        st_off[(size_t)i + 1] = st_off[(size_t)i] + (path ? std::min<int64_t>(tn * nb, MY_LEAF_CELLS) * 3 : 0);      // one leaf matrix (edlib's 1-MB rule)
         if (path && h_ops_off[i + 1] - h_ops_off[i] < qn + tn) { set_error("hs_edlib_hw_align: an alignment needs room for query + target operations"); return HS_EINVAL; }
     }
     if (path) oo.assign(h_ops_off, h_ops_off + n_pairs + 1);
-    DBuf d_qo, d_to, d_ho, d_so, d_oo, d_hs, d_st;
+    DBuf d_qo, d_to, d_ho, d_so, d_oo, d_hs, d_st, d_cols;
     UploadPack pk;
     pk.add(qo, d_qo); pk.add(to, d_to); pk.add(hs_off, d_ho); pk.add(st_off, d_so);
     if (path) pk.add(oo, d_oo);
     if (int rc = pk.commit((hipStream_t)stream)) return rc;
     if (int rc = d_hs.alloc((size_t)hs_off.back())) return rc;
     if (int rc = d_st.alloc(std::max<size_t>((size_t)st_off.back(), 1) * 8)) return rc;
+    if (int rc = d_cols.alloc(std::max<size_t>(path ? (size_t)(qo.back() - qo.front()) * 2 : 0, 1) * sizeof(int32_t))) return rc;      // Hirschberg's two columns
     hipLaunchKernelGGL(hsdev::k_myers_hw_path, dim3((unsigned)n_pairs), dim3(64), 0, (hipStream_t)stream, d_query, d_qo.as<int64_t>(), d_target, d_to.as<int64_t>(),
-                       n_pairs, d_hs.as<int8_t>(), d_ho.as<int64_t>(), d_st.as<unsigned long long>(), d_so.as<int64_t>(), path ? 1 : 0, d_dist, d_start, d_end,
+                       n_pairs, d_hs.as<int8_t>(), d_ho.as<int64_t>(), d_st.as<unsigned long long>(), d_so.as<int64_t>(), d_cols.as<int32_t>(), path ? 1 : 0, d_dist, d_start, d_end,
                        d_ops, path ? d_oo.as<int64_t>() : nullptr, d_ops_len);
     HS_HIP(hipGetLastError());
     return stream_wait((hipStream_t)stream);   // the scratch goes back to the pool with this scope

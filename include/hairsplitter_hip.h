@@ -283,7 +283,8 @@ int hs_edit_distance(const uint8_t* d_query, const int64_t* d_query_off, const u
  * pair. d_dist = editDistance, d_end = endLocations[0], d_start = startLocations[0] (edlib.cpp:226-258), d_ops[h_ops_off[i] ..
  * + d_ops_len[i]) = alignment of pair i in edlib's move codes (0 '=', 1 insertion, 2 deletion, 3 mismatch; every pair needs
  * room for query + target operations). d_ops == NULL: locations only (EDLIB_TASK_LOC). d_ops_len[i] = -1 where edlib
- * itself has no alignment to offer (end location -1) or the query has more than 4096 bases. Offsets are HOST arrays [n+1];
+ * itself has no alignment to offer (end location -1) or the query has more than 2^20 bases. Long pairs are cut in halves the way
+ * edlib cuts them (Hirschberg, edlib.cpp:1166-1404), so the alignment is edlib's at any length. Offsets are HOST arrays [n+1];
  * sequences are base codes 0..3. Synchronous with respect to `stream`. */
 int hs_edlib_hw_align(const uint8_t* d_query, const int64_t* h_query_off, const uint8_t* d_target, const int64_t* h_target_off,
                       int32_t n_pairs, int32_t* d_dist, int32_t* d_start, int32_t* d_end, uint8_t* d_ops, const int64_t* h_ops_off,

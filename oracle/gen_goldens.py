@@ -456,11 +456,69 @@ def gen_c5u():
     print("c5u:", meta["n_snps"], "SNPs,", meta["n_groups"], "windows")
 
 
+def gen_edlib_long_path_vectors():
+    """HW + PATH vectors from the reference's bundled edlib for queries of 1.5-60 kb: beyond 1 MB of its own bookkeeping edlib cuts
+    the alignment in halves (Hirschberg, edlib.cpp:1166-1404), and which of the equally good alignments it returns depends on the
+    cuts. Read-like errors, long insertions and deletions (a half that is all deletions: the boundary rows of :1335-1353),
+    repeats (many optimal alignments), unrelated sequences: tests/golden/edlib_long_path_vectors.json.gz"""
+    import gzip
+    rnd = random.Random(31)
+    rs = lambda n: "".join(rnd.choice("ACGT") for _ in range(n))
+
+    def mutate(s, rate):
+        out = []
+        for c in s:
+            u = rnd.random()
+            if u < rate / 3:
+                out.append(rnd.choice("ACGT"))
+            elif u < 2 * rate / 3:
+                continue
+            elif u < rate:
+                out.append(c); out.append(rnd.choice("ACGT"))
+            else:
+                out.append(c)
+        return "".join(out)
+
+    pairs = []
+    for qn in (1500, 1830, 1900, 2047, 2048, 3000, 4096, 4097, 5000, 8200, 12000):
+        q = rs(qn)
+        pairs.append((q, rs(rnd.randint(0, 1500)) + mutate(q, rnd.choice([0.0, 0.03, 0.12])) + rs(rnd.randint(0, 800))))
+    for qn in (2500, 4500, 7000):
+        q = rs(qn)
+        pairs.append((q, mutate(q, 0.3)))                                        # a wide band
+        unit = rs(rnd.randint(1, 7))
+        r = (unit * (qn // len(unit) + 1))[:qn]
+        pairs.append((r, mutate(r, 0.05) + rs(100)))                             # a repeat: many optimal alignments
+        pairs.append((rs(qn), rs(qn // 3)))                                      # unrelated, target shorter than the query
+        q = rs(qn); pairs.append((q, q[:qn // 2] + q[qn // 2 + 700:]))           # 700 query bases without a partner
+        q = rs(qn); pairs.append((q, q[:qn // 3] + rs(900) + q[qn // 3:]))       # 900 target bases without a partner
+    for _ in range(8):                                                           # several long gaps anywhere
+        q = rs(rnd.randint(2000, 7000))
+        t = q
+        for _ in range(rnd.randint(1, 3)):
+            p = rnd.randint(0, len(t))
+            t = t[:p] + rs(rnd.randint(500, 5000)) + t[p:] if rnd.random() < 0.5 else t[:p] + t[p + rnd.randint(500, 3000):]
+        pairs.append((q, t or "A"))
+    q = rs(300); pairs.append((q, rs(4000) + mutate(q, 0.05) + rs(8000)))        # the stage-5 shape on a long target (no cut: 300 rows)
+    q = rs(30000); pairs.append((q, rs(500) + mutate(q, 0.08) + rs(500)))
+    q = rs(60000); pairs.append((q, mutate(q, 0.05)))
+    lines = ["HWPATH -1 %s %s" % (q, t) for q, t in pairs]
+    res = subprocess.run([os.path.join(REF, "edlib_driver")], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.splitlines()
+    vec = []
+    for (q, t), r in zip(pairs, res):
+        d, st, en, cig = r.split()
+        vec.append({"query": q, "target": t, "distance": int(d), "start": int(st), "end": int(en), "cigar": cig})
+    with gzip.GzipFile(os.path.join(GOLD, "edlib_long_path_vectors.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(vec).encode())
+    print("edlib long path vectors:", len(vec), "longest query", max(len(v["query"]) for v in vec))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check-oracle", action="store_true", help="also run oracle/_build/hs_oracle and report parity")
     ap.add_argument("--only", default=None)
     ap.add_argument("--edlib-path", action="store_true", help="only tests/golden/edlib_path_vectors.json")
+    ap.add_argument("--edlib-long", action="store_true", help="only tests/golden/edlib_long_path_vectors.json.gz")
     ap.add_argument("--edlib-edge", action="store_true", help="only tests/golden/edlib_edge_vectors.json")
     ap.add_argument("--stage5-alphabet", action="store_true", help="only tests/golden/stage5_alphabet_cases.json")
     ap.add_argument("--c5u", action="store_true", help="only the uncut 10 Mb variant of C5: outputs into tests/golden_big/c5u (12 minutes of the reference)")
@@ -469,6 +527,8 @@ def main():
         return gen_c5u()
     if args.edlib_path:
         return gen_edlib_path_vectors()
+    if args.edlib_long:
+        return gen_edlib_long_path_vectors()
     if args.stage5_alphabet:
         return gen_stage5_alphabet_cases()
     if args.edlib_edge:

@@ -109,6 +109,27 @@ def test_edit_distance_oracle_matches_edlib_vectors(built):
         assert e == v["end"], (v["mode"], d, e, v["end"])
 
 
+def test_alignment_path_oracle_matches_edlib_vectors():
+    """oracle/edlib_path_oracle.py (distance, locations and the alignment move by move, Hirschberg cuts included) against the
+    reference's own edlib: the stage-5 shapes and, for queries up to 5 kb, the long vectors (the GPU test takes all of them)."""
+    import gzip
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import edlib_path_oracle as eo
+    short = json.load(open(os.path.join(gu.GOLD, "edlib_path_vectors.json")))
+    long_ = [v for v in json.loads(gzip.open(os.path.join(gu.GOLD, "edlib_long_path_vectors.json.gz")).read()) if len(v["query"]) <= 5000]
+    assert len(long_) >= 20
+    stats = {}
+    for v in short[::3] + long_:
+        g = eo.hw_align(v["query"], v["target"], stats=stats)
+        assert (g["distance"], g["end"]) == (v["distance"], v["end"])
+        if v["end"] >= 0:
+            assert g["start"] == v["start"]
+        if v["cigar"] != "*":
+            assert eo.cigar(g["ops"]) == v["cigar"], (len(v["query"]), len(v["target"]))
+    assert stats["splits"] > 20 and stats["leaves"] > 40      # both of obtainAlignment's branches were taken
+
+
 def test_c_abi_exports_every_declared_symbol(built):
     from hairsplitter_amd import api
     hdr = open(os.path.join(ROOT, "include", "hairsplitter_hip.h")).read()

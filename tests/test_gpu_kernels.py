@@ -516,6 +516,26 @@ def test_edlib_hw_path_matches_the_reference_edlib(built):
     assert [(g["distance"], g["end"]) for g in loc] == [(v["distance"], v["end"]) for v in vec[:50]]
 
 
+def test_edlib_hw_path_beyond_one_leaf_matches_reference_edlib(built):
+    """Queries of 1.5-60 kb: above 1 MB of its own bookkeeping edlib cuts the alignment in halves (Hirschberg, edlib.cpp:1166-1404) and
+    the cuts decide which optimal alignment comes out -- k_myers_hw_path makes the same cuts. Vectors: the reference's edlib
+    (oracle/gen_goldens.py --edlib-long)."""
+    import gzip
+    from hairsplitter_amd import api
+    vec = json.loads(gzip.open(os.path.join(gu.GOLD, "edlib_long_path_vectors.json.gz")).read())
+    got = api.edlib_hw_align([(v["query"], v["target"]) for v in vec])
+    sym = "=IDX"
+    for v, g in zip(vec, got):
+        assert (g["distance"], g["start"], g["end"]) == (v["distance"], v["start"], v["end"]), (len(v["query"]), len(v["target"]))
+        ops = g["ops"]
+        assert ops is not None, (len(v["query"]), len(v["target"]))
+        cut = np.flatnonzero(np.diff(ops)) + 1
+        runs = np.diff(np.concatenate(([0], cut, [len(ops)])))
+        heads = ops[np.concatenate(([0], cut))]
+        assert "".join("%d%s" % (c, sym[o]) for c, o in zip(runs.tolist(), heads.tolist())) == v["cigar"], (len(v["query"]), len(v["target"]))
+    assert max(len(v["query"]) for v in vec) >= 60000
+
+
 def test_stage5_edlib_call_sites(built):
     """The two stage-5 computations that sit on the reference's edlib calls, batched on the A1 kernel: the ends racon dropped are
     attached again (tools.cpp:505-536) and the overhangs are cut off the polished piece (create_new_contigs.cpp:556-629).
