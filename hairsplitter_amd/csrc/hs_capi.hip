@@ -968,7 +968,7 @@ int hs_edlib_hw_align(const uint8_t* d_query, const int64_t* h_query_off, const 
         oo;
     for (int i = 0; i < n_pairs; ++i) {
         const int64_t qn = qo[(size_t)i + 1] - qo[(size_t)i], tn = to[(size_t)i + 1] - to[(size_t)i];
-        hs_off[(size_t)i + 1] = hs_off[(size_t)i] + tn + 64;
+        hs_off[(size_t)i + 1] = hs_off[(size_t)i] + ((tn + 64 + 3) & ~(int64_t)3) + 4 * (tn + 64);      // deltas (bytes) and bottoms (ints) between two passes
         const int64_t nb = (qn + 63) / 64;
         st_off[(size_t)i + 1] = st_off[(size_t)i] + (path ? std::min<int64_t>(tn * nb, MY_LEAF_CELLS) * 3 : 0);      // one leaf matrix (edlib's 1-MB rule)
         if (path && h_ops_off[i + 1] - h_ops_off[i] < qn + tn) { set_error("hs_edlib_hw_align: an alignment needs room for query + target operations"); return HS_EINVAL; }

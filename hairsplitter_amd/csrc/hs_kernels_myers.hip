@@ -28,15 +28,73 @@ namespace hsdev {
 struct MyersSeq {              // a sequence seen forwards or backwards
     const uint8_t* p; int n; bool rev;
     __device__ __forceinline__ int at(int i) const { return (int)(p[rev ? n - 1 - i : i] & 3); }
+    // rows r0 .. r0 + 63 (those below n) as two bit planes: bit k of m0 / m1 = bit 0 / 1 of the code of row r0 + k. Sixteen
+    // (unaligned) dword loads in flight; bit b of the four bytes of a dword lands in one nibble through a multiplication whose
+    // partial products do not meet (byte i, bit b -> bit 28 + i forwards, 31 - i backwards).
+    __device__ __forceinline__ void planes(int r0, uint64_t& m0, uint64_t& m1, uint64_t& valid) const {
+        const int nrow = (n - r0) < 64 ? (n - r0) : 64;
+        valid = nrow >= 64 ? ~0ull : ((1ull << nrow) - 1ull);
+        uint32_t x[16];
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int r = r0 + 4 * w;
+            x[w] = 0u;
+            if (r + 3 < n) x[w] = rev ? *reinterpret_cast<const u32_unaligned*>(p + (n - 4 - r)) : *reinterpret_cast<const u32_unaligned*>(p + r);
+            else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (r + b < n) x[w] |= (uint32_t)p[rev ? n - 1 - (r + b) : r + b] << (rev ? 8 * (3 - b) : 8 * b);
+            }
+        }
+        const uint32_t mul = rev ? ((1u << 31) | (1u << 22) | (1u << 13) | (1u << 4)) : ((1u << 28) | (1u << 21) | (1u << 14) | (1u << 7));
+        uint32_t lo0 = 0, lo1 = 0, hi0 = 0, hi1 = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t n0 = ((x[w] & 0x01010101u) * mul) >> 28, n1 = (((x[w] >> 1) & 0x01010101u) * mul) >> 28;
+            if (w < 8) { lo0 |= n0 << (4 * w); lo1 |= n1 << (4 * w); } else { hi0 |= n0 << (4 * (w - 8)); hi1 |= n1 << (4 * (w - 8)); }
+        }
+        m0 = ((uint64_t)hi0 << 32) | lo0; m1 = ((uint64_t)hi1 << 32) | lo1;
+    }
 };
+// lane i takes the value of lane i - 1 (lane 0: zero): one DPP move across the whole wavefront
+static __device__ __forceinline__ int wave_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+
+// The band of a sweep: block b (query rows 64 b .. 64 b + 63) is computed for the columns 64 b + lo .. 64 b + 63 + hi only
+// (Ukkonen: a cell on an alignment of at most k errors lies within k diagonals of where the alignment starts and of where it
+// ends). A block that is not computed hands +1 per column to the block below it and a block that enters the band starts from
+// +1 per row -- what edlib assumes at the edges of its own band (edlib.cpp:773-817): every score inside the band is then an upper
+// bound, and exact on every cell an alignment of at most k errors passes through; those are the only ones the results read.
+struct MyersBand {
+    int lo, hi;
+    static __device__ __forceinline__ MyersBand whole() { return MyersBand{-(1 << 29), 1 << 29}; }
+    // start and end fixed (NW, also a half of Hirschberg's cut of a qn x tn problem of score k): diagonals [-k, k] and [D - k, D + k]
+    static __device__ __forceinline__ MyersBand global(int qn, int tn, int k) {
+        const int D = tn - qn;
+        MyersBand b{max(-k, D - k), min(k, D + k)};
+        if (b.lo > 0) b.lo = 0;
+        if (b.hi < b.lo + 1) b.hi = b.lo + 1;
+        return b;
+    }
+    static __device__ __forceinline__ MyersBand prefix(int k) { return MyersBand{-k, k < 1 ? 1 : k}; }                 // SHW: start fixed, any end column
+    static __device__ __forceinline__ MyersBand infix(int qn, int tn, int k) {                                        // HW: any start column, any end column
+        MyersBand b{-k, tn - qn + k};
+        if (b.hi < b.lo + 1) b.hi = b.lo + 1;
+        return b;
+    }
+    __device__ __forceinline__ bool holds(int blk, int col) const { return col >= (blk << 6) + lo && col <= (blk << 6) + 63 + hi; }
+};
+#define MY_INF (1 << 28)
 
 // One sweep. mode 0 NW, 1 SHW, 2 HW. Outputs through references (valid in every lane): final bottom-row score of the
 // last column, best bottom-row score over the columns, first and last column attaining it (-1: before the target).
-// store != nullptr: P, M, bottom score of every (column, block) at store[(col * nblocks + blk) * 3 ...] as three 64-bit words
-// {P, M, score}. col_scores != nullptr: the scores of the LAST column, one int per query row (what Hirschberg's split reads).
-static __device__ void myers_sweep(const MyersSeq& q, const MyersSeq& t, int mode, int8_t* __restrict__ hb, uint8_t* tbuf /* LDS [MY_TCHUNK + 64] */,
-                                   unsigned long long* __restrict__ store, int32_t* __restrict__ col_scores, int& out_score, int& out_best, int& out_first,
-                                   int& out_last) {
+// hb: [tn] the horizontal deltas of a pass's last block for the next pass, hbot: [tn] its bottom scores (a block of the next pass
+// that enters the band starts from them).
+// store != nullptr: P, M, bottom score of every (column, block) of the band at store[(col * nblocks + blk) * 3 ...] as three
+// 64-bit words {P, M, score}. col_scores != nullptr: the scores of the LAST column, one int per query row (what Hirschberg's
+// split reads), MY_INF outside the band.
+static __device__ void myers_sweep(const MyersSeq& q, const MyersSeq& t, int mode, MyersBand band, int8_t* __restrict__ hb, int32_t* __restrict__ hbot,
+                                   uint8_t* tbuf /* LDS [MY_TCHUNK + 64] */, unsigned long long* __restrict__ store, int32_t* __restrict__ col_scores,
+                                   int& out_score, int& out_best, int& out_first, int& out_last) {
     const int lane = lane_id();
     const int qn = q.n, tn = t.n;
     const int nblocks = (qn + 63) >> 6;
@@ -46,24 +104,32 @@ static __device__ void myers_sweep(const MyersSeq& q, const MyersSeq& t, int mod
     // what best = qn, first = -1 reproduces; with W == 0 there are none, and the first real column that reaches the best score --
     // query length included -- is the answer (64 x 'A' in 'CCC...': end location 0, path 1X63I).
     int score = qn, best = (qn & 63) == 0 ? qn + 1 : qn, best_first = -1, best_last = -1;
+    bool reached_end = false;
     for (int pb = 0; pb < nblocks; pb += 64) {
         const int blk = pb + lane;
         const bool bvalid = blk < nblocks;
         const bool is_last_blk = blk == nblocks - 1;
         const int nb_pass = (nblocks - pb) < 64 ? (nblocks - pb) : 64;
+        // this block's columns, the block above's last column
+        const int jlo_u = (blk << 6) + band.lo, jhi_u = (blk << 6) + 63 + band.hi;
+        const int jlo = jlo_u > 0 ? jlo_u : 0, jhi = jhi_u < tn - 1 ? jhi_u : tn - 1;
+        const int jhi_up = (jhi_u - 64) < tn - 1 ? (jhi_u - 64) : tn - 1;
+        const bool some = bvalid && jlo <= jhi;
+        int s_begin = some ? jlo + lane : 0x7fffffff, s_last = some ? jhi + lane : -1;
+        for (int o = 32; o > 0; o >>= 1) { s_begin = min(s_begin, __shfl_xor(s_begin, o, 64)); s_last = max(s_last, __shfl_xor(s_last, o, 64)); }
         uint64_t peq[4] = {0, 0, 0, 0};
-        if (bvalid) {
-            const int rbase = blk << 6;
-            for (int k = 0; k < 64; ++k) {
-                const int row = rbase + k;
-                if (row < qn) peq[q.at(row)] |= 1ull << k;
-            }
+        if (some) {
+            uint64_t m0, m1, valid;
+            q.planes(blk << 6, m0, m1, valid);
+            peq[0] = ~m1 & ~m0 & valid; peq[1] = ~m1 & m0 & valid; peq[2] = m1 & ~m0 & valid; peq[3] = m1 & m0 & valid;
         }
         uint64_t Pv = ~0ull, Mv = 0ull;
-        int hout_prev = 0;
+        int h_prev = 0;                       // horizontal delta out of the last column done: bit 0 = +1, bit 1 = -1
         int bottom = (blk + 1) << 6;          // D[64 blk + 63][-1]
-        const int nsteps = tn + nb_pass - 1;
-        for (int s0 = 0; s0 < nsteps; s0 += MY_TCHUNK) {
+        const int s_lo = jlo + lane, s_hi = some ? jhi + lane : -1, s_up = jhi_up + lane;
+        const bool top = lane == 0 && pb == 0;
+        const bool feeds = lane == nb_pass - 1 && !is_last_blk;
+        for (int s0 = s_begin; s0 <= s_last; s0 += MY_TCHUNK) {
             __builtin_amdgcn_wave_barrier();
             for (int x = lane; x < MY_TCHUNK + 64; x += 64) {
                 const int col = s0 - 63 + x;
@@ -71,38 +137,47 @@ static __device__ void myers_sweep(const MyersSeq& q, const MyersSeq& t, int mod
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            const int s_end = (s0 + MY_TCHUNK) < nsteps ? (s0 + MY_TCHUNK) : nsteps;
+            const int s_end = (s0 + MY_TCHUNK) <= s_last ? (s0 + MY_TCHUNK) : s_last + 1;
+            const uint8_t* trow = tbuf + 63 - lane - s0;
             for (int s = s0; s < s_end; ++s) {
-                const int j = s - lane;
-                const int hin_up = __shfl_up(hout_prev, 1, 64);
-                const bool work = bvalid && j >= 0 && j < tn;
-                int hin;
-                if (lane == 0) hin = pb == 0 ? (mode == 2 ? 0 : 1) : (work ? (int)hb[j] : 0);
-                else hin = hin_up;
-                if (work) {
-                    const int sym = tbuf[(s - s0) + 63 - lane] & 3;
+                int h_up = wave_shr1(h_prev);
+                int bot_up = wave_shr1(bottom);
+                if (s >= s_lo && s <= s_hi) {
+                    const int j = s - lane;
+                    const bool up_in = s <= s_up;      // the block above was computed in this column (it never starts later than this one)
+                    if (lane == 0) {
+                        if (pb == 0) h_up = mode == 2 ? 0 : 1;
+                        else if (up_in) { h_up = (int)hb[j]; bot_up = hbot[j]; }
+                    }
+                    const int h = (up_in || top) ? h_up : 1;
+                    if (s == s_lo && jlo_u > 0) {          // the block enters the band: +1 per row below the block above's bottom of the column before
+                        Pv = ~0ull; Mv = 0ull;
+                        bottom = bot_up - (h_up & 1) + (h_up >> 1) + 64;
+                        if (is_last_blk) score = bottom - (63 - last_row);
+                    }
+                    const int sym = trow[s] & 3;
                     uint64_t Eq = peq[sym];
                     const uint64_t Xv = Eq | Mv;
-                    if (hin < 0) Eq |= 1ull;
+                    Eq |= (uint64_t)(uint32_t)(h >> 1);
                     const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
                     uint64_t Ph = Mv | ~(Xh | Pv);
                     uint64_t Mh = Pv & Xh;
-                    int hout = 0;
-                    if (Ph >> 63) hout = 1; else if (Mh >> 63) hout = -1;
-                    bottom += hout;
+                    const int hout = (int)(Ph >> 63) | ((int)(Mh >> 62) & 2);
+                    bottom += (hout & 1) - (hout >> 1);
                     if (is_last_blk) {
                         score += (int)((Ph >> last_row) & 1ull) - (int)((Mh >> last_row) & 1ull);
                         if (mode != 0) {
                             if (score < best) { best = score; best_first = j; best_last = j; }
                             else if (score == best) best_last = j;
                         }
+                        if (j == tn - 1) reached_end = true;
                     }
-                    Ph <<= 1; Mh <<= 1;
-                    if (hin < 0) Mh |= 1ull; else if (hin > 0) Ph |= 1ull;
+                    Ph = (Ph << 1) | (uint64_t)(uint32_t)(h & 1);
+                    Mh = (Mh << 1) | (uint64_t)(uint32_t)(h >> 1);
                     Pv = Mh | ~(Xv | Ph);
                     Mv = Ph & Xv;
-                    hout_prev = hout;
-                    if (lane == nb_pass - 1 && !is_last_blk) hb[j] = (int8_t)hout;
+                    h_prev = hout;
+                    if (feeds) { hb[j] = (int8_t)hout; hbot[j] = bottom; }
                     if (store) {
                         unsigned long long* o = store + ((int64_t)j * nblocks + blk) * 3;
                         o[0] = Pv; o[1] = Mv; o[2] = (unsigned long long)(long long)bottom;
@@ -111,10 +186,11 @@ static __device__ void myers_sweep(const MyersSeq& q, const MyersSeq& t, int mod
             }
         }
         if (col_scores && bvalid) {      // rows 64 blk + 63 .. 64 blk of the last column, downwards differences undone
+            const bool at_end = some && jhi == tn - 1;
             int sc_row = bottom;
             const int rbase = blk << 6;
             for (int k = 63; k >= 0; --k) {
-                if (rbase + k < qn) col_scores[rbase + k] = sc_row;
+                if (rbase + k < qn) col_scores[rbase + k] = at_end ? sc_row : MY_INF;
                 sc_row += (int)((Mv >> k) & 1ull) - (int)((Pv >> k) & 1ull);
             }
         }
@@ -122,14 +198,15 @@ static __device__ void myers_sweep(const MyersSeq& q, const MyersSeq& t, int mod
         __builtin_amdgcn_wave_barrier();
     }
     const int owner = (nblocks - 1) & 63;
-    out_score = __shfl(score, owner, 64); out_best = __shfl(best, owner, 64);
+    out_score = __shfl(reached_end ? score : MY_INF, owner, 64); out_best = __shfl(best, owner, 64);
     out_first = __shfl(best_first, owner, 64); out_last = __shfl(best_last, owner, 64);
 }
 
 // exact score of cell (row, col) of the NW matrix from the stored words; boundaries as edlib's (:980-984)
-static __device__ __forceinline__ int myers_cell(const unsigned long long* __restrict__ store, int nblocks, int row, int col) {
+static __device__ __forceinline__ int myers_cell(const unsigned long long* __restrict__ store, int nblocks, MyersBand band, int row, int col) {
     if (row < 0) return col + 1;
     if (col < 0) return row + 1;
+    if (!band.holds(row >> 6, col)) return MY_INF;      // (not computed: no alignment of the score asked for passes here)
     const unsigned long long* o = store + ((int64_t)col * nblocks + (row >> 6)) * 3;
     const int k = row & 63;
     const unsigned long long above = k == 63 ? 0ull : (~0ull << (k + 1));      // the rows of the block below this one
@@ -138,12 +215,12 @@ static __device__ __forceinline__ int myers_cell(const unsigned long long* __res
 
 // lane 0: the traceback of edlib.cpp:947-1140 over the stored words of one NW matrix (query rows x an columns, final score sc):
 // up (insertion) before left (deletion) before the diagonal, on exact cell scores; the moves are written in alignment order.
-static __device__ int myers_traceback(const unsigned long long* __restrict__ sto, int nblocks, int qn, int an, int sc, uint8_t* __restrict__ op) {
+static __device__ int myers_traceback(const unsigned long long* __restrict__ sto, int nblocks, MyersBand band, int qn, int an, int sc, uint8_t* __restrict__ op) {
     int row = qn - 1, col = an - 1, cur = sc, n = 0;
     while (true) {
-        const int u = myers_cell(sto, nblocks, row - 1, col);           // (the three neighbours are requested together)
-        const int l = myers_cell(sto, nblocks, row, col - 1);
-        const int ul = (row == 0 && col == 0) ? 0 : myers_cell(sto, nblocks, row - 1, col - 1);
+        const int u = myers_cell(sto, nblocks, band, row - 1, col);           // (the three neighbours are requested together)
+        const int l = myers_cell(sto, nblocks, band, row, col - 1);
+        const int ul = (row == 0 && col == 0) ? 0 : myers_cell(sto, nblocks, band, row - 1, col - 1);
         if (u + 1 == cur) {                                   // up: insertion (:1022-1055)
             op[n++] = 1; cur = u; row--;
             if (row < 0) { for (int i = 0; i < col + 1; ++i) op[n++] = 2; break; }
@@ -187,15 +264,23 @@ __global__ __launch_bounds__(64) void k_myers_hw_path(
     const int qn = (int)(query_off[pr + 1] - query_off[pr]);
     const uint8_t* tp = target + target_off[pr];
     const int tn = (int)(target_off[pr + 1] - target_off[pr]);
-    int8_t* hb = hscratch + hscratch_off[pr];
+    int8_t* hb = hscratch + hscratch_off[pr];                                   // [tn + 64] bytes, then [tn + 64] ints
+    int32_t* hbot = reinterpret_cast<int32_t*>(hb + ((tn + 64 + 3) & ~3));
     uint8_t* op = ops ? ops + ops_off[pr] : nullptr;
     if (qn == 0 || tn == 0) {      // edlib.cpp:174-191: distance = query length, end location -1, no start location / path
         if (lane == 0) { dist[pr] = qn; end_loc[pr] = -1; start_loc[pr] = -1; if (ops_len) ops_len[pr] = 0; }
         return;
     }
     int sc, best, first, last;
-    // 1. HW: distance and first end location
-    myers_sweep(MyersSeq{qp, qn, false}, MyersSeq{tp, tn, false}, 2, hb, tbuf, nullptr, nullptr, sc, best, first, last);
+    // 1. HW: distance and first end location. The band needs a bound on the distance: tried from 1/16 of the query length
+    //    upwards, doubled until the distance found is within it (edlibAlign does the same from 64, :194-214; the answer does
+    //    not depend on the bounds tried: the first one that holds the optimum returns it exactly).
+    for (int k = max(64, qn >> 4);; k *= 2) {
+        const bool all = k >= qn;
+        myers_sweep(MyersSeq{qp, qn, false}, MyersSeq{tp, tn, false}, 2, all ? MyersBand::whole() : MyersBand::infix(qn, tn, k), hb, hbot, tbuf, nullptr, nullptr,
+                    sc, best, first, last);
+        if (all || best <= k) break;
+    }
     const int d = best, e = first;
     if (e < 0) {   // the whole query before the target (:233-246): start location 0, the alignment over an empty target is all insertions (:1171-1178)
         if (lane == 0) { dist[pr] = d; end_loc[pr] = -1; start_loc[pr] = 0; }
@@ -203,7 +288,7 @@ __global__ __launch_bounds__(64) void k_myers_hw_path(
         return;
     }
     // 2. start location: reversed query against the reversed target prefix [0, e], last best column
-    myers_sweep(MyersSeq{qp, qn, true}, MyersSeq{tp, e + 1, true}, 1, hb, tbuf, nullptr, nullptr, sc, best, first, last);
+    myers_sweep(MyersSeq{qp, qn, true}, MyersSeq{tp, e + 1, true}, 1, MyersBand::prefix(d), hb, hbot, tbuf, nullptr, nullptr, sc, best, first, last);
     const int st = e - last;
     if (lane == 0) { dist[pr] = d; end_loc[pr] = e; start_loc[pr] = st; }
     if (!want_path || !ops) return;
@@ -230,19 +315,21 @@ __global__ __launch_bounds__(64) void k_myers_hw_path(
         }
         if (myers_leaf(fqn, ftn)) {                            // :1196-1209: the whole matrix and the traceback
             const int nblocks = (fqn + 63) >> 6;
-            myers_sweep(MyersSeq{qp + fqa, fqn, false}, MyersSeq{tp + fta, ftn, false}, 0, hb, tbuf, sto, nullptr, sc, best, first, last);
+            const MyersBand band = MyersBand::global(fqn, ftn, fbest);
+            myers_sweep(MyersSeq{qp + fqa, fqn, false}, MyersSeq{tp + fta, ftn, false}, 0, band, hb, hbot, tbuf, sto, nullptr, sc, best, first, last);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
             __builtin_amdgcn_wave_barrier();
             int n = 0;
-            if (lane == 0) n = myers_traceback(sto, nblocks, fqn, ftn, sc, op + n_out);
+            if (lane == 0) n = myers_traceback(sto, nblocks, band, fqn, ftn, sc, op + n_out);
             n_out += __shfl(n, 0, 64);
             continue;
         }
         // :1236-1404 Hirschberg: the target in halves, the left one forwards and the right one backwards up to the cut, then the
         // FIRST query row whose two scores add up to the optimum (:1322-1333), the two boundary rows after it (:1335-1353)
         const int lw = ftn / 2, rw = ftn - lw;
-        myers_sweep(MyersSeq{qp + fqa, fqn, false}, MyersSeq{tp + fta, lw, false}, 0, hb, tbuf, nullptr, left, sc, best, first, last);
-        myers_sweep(MyersSeq{qp + fqa, fqn, true}, MyersSeq{tp + fta + lw, rw, true}, 0, hb, tbuf, nullptr, right_rev, sc, best, first, last);
+        const MyersBand band = MyersBand::global(fqn, ftn, fbest);      // (of the whole frame: both halves see the same diagonals, the right one mirrored)
+        myers_sweep(MyersSeq{qp + fqa, fqn, false}, MyersSeq{tp + fta, lw, false}, 0, band, hb, hbot, tbuf, nullptr, left, sc, best, first, last);
+        myers_sweep(MyersSeq{qp + fqa, fqn, true}, MyersSeq{tp + fta + lw, rw, true}, 0, band, hb, hbot, tbuf, nullptr, right_rev, sc, best, first, last);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
         __builtin_amdgcn_wave_barrier();
         // left[i]: query[0..i] against the left half; right[i] = right_rev[fqn - 1 - i]: query[i..] against the right half
