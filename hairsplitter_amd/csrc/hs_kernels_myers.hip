@@ -251,15 +251,16 @@ static __device__ __forceinline__ bool myers_leaf(int qn, int tn) {
 
 __global__ __launch_bounds__(64) void k_myers_hw_path(
     const uint8_t* __restrict__ query, const int64_t* __restrict__ query_off, const uint8_t* __restrict__ target,
-    const int64_t* __restrict__ target_off, int n_pairs, int8_t* __restrict__ hscratch, const int64_t* __restrict__ hscratch_off,
-    unsigned long long* __restrict__ store, const int64_t* __restrict__ store_off, int32_t* __restrict__ col_scratch, int want_path,
+    const int64_t* __restrict__ target_off, const int32_t* __restrict__ pair_ids, int n_list, int8_t* __restrict__ hscratch,
+    const int64_t* __restrict__ hscratch_off, unsigned long long* __restrict__ store, const int64_t* __restrict__ store_off,
+    int32_t* __restrict__ col_scratch, int want_path,
     int32_t* __restrict__ dist, int32_t* __restrict__ start_loc, int32_t* __restrict__ end_loc,
     uint8_t* __restrict__ ops, const int64_t* __restrict__ ops_off, int32_t* __restrict__ ops_len) {
     __shared__ uint8_t tbuf[MY_TCHUNK + 64];
     __shared__ int s_stack[40][5];
     const int lane = lane_id();
-    const int pr = (int)blockIdx.x;
-    if (pr >= n_pairs) return;
+    if ((int)blockIdx.x >= n_list) return;
+    const int pr = pair_ids[blockIdx.x];      // (the pairs the grouped kernel below does not take)
     const uint8_t* qp = query + query_off[pr];
     const int qn = (int)(query_off[pr + 1] - query_off[pr]);
     const uint8_t* tp = target + target_off[pr];
@@ -361,5 +362,163 @@ __global__ __launch_bounds__(64) void k_myers_hw_path(
     }
     if (lane == 0) ops_len[pr] = n_out;
 }
+
+// ---- short queries: G lanes per pair, 64 / G pairs per wavefront ----------------------------------------------------------
+// The stage-5 call sites align 200-300 bases (five 64-row blocks): with a wavefront per pair five lanes of 64 work. Here a pair
+// takes G = 8 / 16 / 32 lanes (queries up to 64 G bases whose matrix edlib keeps whole: one pass, one leaf, no cuts), every
+// per-pair quantity lives in the lanes of its group, the loops run to the longest pair of the wavefront and a group that is
+// done idles under the exec mask. Same sweeps, same band, same traceback as above.
+#define MY_GCHUNK 1024
+template <int G>
+static __device__ void myers_sweep_grouped(bool active, const MyersSeq& q, const MyersSeq& t, int mode, MyersBand band, uint8_t* __restrict__ tb /* this group's LDS [MY_GCHUNK + 64] */,
+                                           unsigned long long* __restrict__ store, int& out_score, int& out_best, int& out_first, int& out_last) {
+    const int lane = lane_id(), gl = lane & (G - 1);
+    const int qn = q.n, tn = t.n;
+    const int nblocks = (qn + 63) >> 6;
+    const int last_row = (qn - 1) & 63;
+    int score = qn, best = (qn & 63) == 0 ? qn + 1 : qn, best_first = -1, best_last = -1;
+    bool reached_end = false;
+    const int blk = gl;
+    const bool is_last_blk = blk == nblocks - 1;
+    const int jlo_u = (blk << 6) + band.lo, jhi_u = (blk << 6) + 63 + band.hi;
+    const int jlo = jlo_u > 0 ? jlo_u : 0, jhi = jhi_u < tn - 1 ? jhi_u : tn - 1;
+    const int jhi_up = (jhi_u - 64) < tn - 1 ? (jhi_u - 64) : tn - 1;
+    const bool some = active && blk < nblocks && jlo <= jhi;
+    const int s_lo = jlo + gl, s_hi = some ? jhi + gl : -1, s_up = jhi_up + gl;
+    int s_begin = some ? s_lo : 0x3fffffff, s_last = s_hi;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) { s_begin = min(s_begin, __shfl_xor(s_begin, o, 64)); s_last = max(s_last, __shfl_xor(s_last, o, 64)); }
+    int n_steps = s_last - s_begin + 1;          // of this group; the loop runs to the longest of the wavefront
+    if (n_steps < 0) n_steps = 0;
+    int n_max = n_steps;
+#pragma unroll
+    for (int o = 32; o >= G; o >>= 1) n_max = max(n_max, __shfl_xor(n_max, o, 64));
+    uint64_t peq[4] = {0, 0, 0, 0};
+    if (some) {
+        uint64_t m0, m1, valid;
+        q.planes(blk << 6, m0, m1, valid);
+        peq[0] = ~m1 & ~m0 & valid; peq[1] = ~m1 & m0 & valid; peq[2] = m1 & ~m0 & valid; peq[3] = m1 & m0 & valid;
+    }
+    uint64_t Pv = ~0ull, Mv = 0ull;
+    int h_prev = 0, bottom = (blk + 1) << 6;
+    const bool top = gl == 0;
+    for (int i0 = 0; i0 < n_max; i0 += MY_GCHUNK) {
+        __builtin_amdgcn_wave_barrier();
+        // columns s_begin + i0 - (G - 1) ... of this group's target, four per lane and load
+        if (n_steps > i0) {
+            const int c0 = s_begin + i0 - (G - 1);
+            for (int x = 4 * gl; x < MY_GCHUNK + G; x += 4 * G) {
+                const int c = c0 + x;
+                uint32_t w = 0u;
+                if (c >= 0 && c + 3 < tn) {
+                    w = t.rev ? __builtin_bswap32(*reinterpret_cast<const u32_unaligned*>(t.p + (tn - 4 - c))) : *reinterpret_cast<const u32_unaligned*>(t.p + c);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) if (c + b >= 0 && c + b < tn) w |= (uint32_t)t.at(c + b) << (8 * b);
+                }
+                *reinterpret_cast<uint32_t*>(tb + x) = w;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int i_end = (i0 + MY_GCHUNK) < n_max ? (i0 + MY_GCHUNK) : n_max;
+        const uint8_t* trow = tb + (G - 1) - gl - i0;
+        for (int i = i0; i < i_end; ++i) {
+            const int s = s_begin + i;
+            int h_up = wave_shr1(h_prev);
+            const int bot_up = wave_shr1(bottom);
+            if (s >= s_lo && s <= s_hi) {
+                const int j = s - gl;
+                const bool up_in = s <= s_up;
+                if (top) h_up = mode == 2 ? 0 : 1;
+                const int h = (up_in || top) ? h_up : 1;
+                if (s == s_lo && jlo_u > 0) {
+                    Pv = ~0ull; Mv = 0ull;
+                    bottom = bot_up - (h_up & 1) + (h_up >> 1) + 64;
+                    if (is_last_blk) score = bottom - (63 - last_row);
+                }
+                const int sym = trow[i] & 3;
+                uint64_t Eq = peq[sym];
+                const uint64_t Xv = Eq | Mv;
+                Eq |= (uint64_t)(uint32_t)(h >> 1);
+                const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                uint64_t Ph = Mv | ~(Xh | Pv);
+                uint64_t Mh = Pv & Xh;
+                const int hout = (int)(Ph >> 63) | ((int)(Mh >> 62) & 2);
+                bottom += (hout & 1) - (hout >> 1);
+                if (is_last_blk) {
+                    score += (int)((Ph >> last_row) & 1ull) - (int)((Mh >> last_row) & 1ull);
+                    if (mode != 0) {
+                        if (score < best) { best = score; best_first = j; best_last = j; }
+                        else if (score == best) best_last = j;
+                    }
+                    if (j == tn - 1) reached_end = true;
+                }
+                Ph = (Ph << 1) | (uint64_t)(uint32_t)(h & 1);
+                Mh = (Mh << 1) | (uint64_t)(uint32_t)(h >> 1);
+                Pv = Mh | ~(Xv | Ph);
+                Mv = Ph & Xv;
+                h_prev = hout;
+                if (store) {
+                    unsigned long long* o = store + ((int64_t)j * nblocks + blk) * 3;
+                    o[0] = Pv; o[1] = Mv; o[2] = (unsigned long long)(long long)bottom;
+                }
+            }
+        }
+    }
+    const int owner = (lane & ~(G - 1)) + ((nblocks - 1) & (G - 1));
+    out_score = __shfl(reached_end ? score : MY_INF, owner, 64); out_best = __shfl(best, owner, 64);
+    out_first = __shfl(best_first, owner, 64); out_last = __shfl(best_last, owner, 64);
+}
+
+template <int G>
+__global__ __launch_bounds__(64) void k_myers_hw_path_grouped(
+    const uint8_t* __restrict__ query, const int64_t* __restrict__ query_off, const uint8_t* __restrict__ target,
+    const int64_t* __restrict__ target_off, const int32_t* __restrict__ pair_ids, int n_list,
+    unsigned long long* __restrict__ store, const int64_t* __restrict__ store_off, int want_path,
+    int32_t* __restrict__ dist, int32_t* __restrict__ start_loc, int32_t* __restrict__ end_loc,
+    uint8_t* __restrict__ ops, const int64_t* __restrict__ ops_off, int32_t* __restrict__ ops_len) {
+    constexpr int NG = 64 / G;
+    __shared__ __attribute__((aligned(16))) uint8_t tbuf[NG][MY_GCHUNK + 64];
+    const int lane = lane_id(), gl = lane & (G - 1), grp = lane / G;
+    const int slot = (int)blockIdx.x * NG + grp;
+    const bool live = slot < n_list;
+    const int pr = live ? pair_ids[slot] : 0;
+    const uint8_t* qp = query; const uint8_t* tp = target;
+    int qn = 0, tn = 0;
+    if (live) { qp += query_off[pr]; qn = (int)(query_off[pr + 1] - query_off[pr]); tp += target_off[pr]; tn = (int)(target_off[pr + 1] - target_off[pr]); }
+    uint8_t* op = (ops && live) ? ops + ops_off[pr] : nullptr;
+    uint8_t* tb = tbuf[grp];
+    bool act = live && qn > 0 && tn > 0;
+    if (live && !act && gl == 0) { dist[pr] = qn; end_loc[pr] = -1; start_loc[pr] = -1; if (ops_len) ops_len[pr] = 0; }      // edlib.cpp:174-191
+    int sc, best, first, last;
+    // 1. HW with a doubled bound (every group at its own)
+    int k = max(64, qn >> 4), d = 0, e = -1;
+    bool pending = act;
+    while (__ballot(pending) != 0ull) {
+        const bool all = k >= qn;
+        myers_sweep_grouped<G>(pending, MyersSeq{qp, qn, false}, MyersSeq{tp, tn, false}, 2, all ? MyersBand::whole() : MyersBand::infix(qn, tn, k), tb, nullptr, sc, best, first, last);
+        if (pending) { if (all || best <= k) { pending = false; d = best; e = first; } else k *= 2; }
+    }
+    if (act && e < 0) {      // the whole query before the target (:233-246)
+        if (gl == 0) { dist[pr] = d; end_loc[pr] = -1; start_loc[pr] = 0; }
+        if (want_path && op) { for (int i = gl; i < qn; i += G) op[i] = 1; if (gl == 0) ops_len[pr] = qn; }
+        act = false;
+    }
+    // 2. start location
+    myers_sweep_grouped<G>(act, MyersSeq{qp, qn, true}, MyersSeq{tp, e + 1, true}, 1, MyersBand::prefix(d), tb, nullptr, sc, best, first, last);
+    const int st = e - last;
+    if (act && gl == 0) { dist[pr] = d; end_loc[pr] = e; start_loc[pr] = st; }
+    if (!want_path || !ops) return;
+    // 3. one leaf: the matrix whole, the traceback by the group's first lane
+    const int an = e - st + 1;
+    const MyersBand band = MyersBand::global(qn, an, d);
+    unsigned long long* sto = store + (live ? store_off[pr] : 0);
+    myers_sweep_grouped<G>(act, MyersSeq{qp, qn, false}, MyersSeq{tp + st, an, false}, 0, band, tb, sto, sc, best, first, last);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+    __builtin_amdgcn_wave_barrier();
+    if (act && gl == 0) ops_len[pr] = myers_traceback(sto, (qn + 63) >> 6, band, qn, an, sc, op);
+}
+
 
 }  // namespace hsdev

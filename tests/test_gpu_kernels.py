@@ -514,6 +514,15 @@ def test_edlib_hw_path_matches_the_reference_edlib(built):
     # locations only (edlib's TASK_LOC): same numbers without the path
     loc = api.edlib_hw_align([(v["query"], v["target"]) for v in vec[:50]], path=False)
     assert [(g["distance"], g["end"]) for g in loc] == [(v["distance"], v["end"]) for v in vec[:50]]
+    # short queries share a wavefront (8 lanes per pair here); a wavefront per pair gives the same
+    os.environ["HS_MYERS_NO_GROUPS"] = "1"
+    try:
+        alone = api.edlib_hw_align([(v["query"], v["target"]) for v in vec])
+    finally:
+        del os.environ["HS_MYERS_NO_GROUPS"]
+    for g, a in zip(got, alone):
+        assert (g["distance"], g["start"], g["end"]) == (a["distance"], a["start"], a["end"])
+        assert (g["ops"] is None) == (a["ops"] is None) and (g["ops"] is None or np.array_equal(g["ops"], a["ops"]))
 
 
 def test_edlib_hw_path_beyond_one_leaf_matches_reference_edlib(built):
