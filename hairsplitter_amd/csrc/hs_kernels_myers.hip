@@ -273,14 +273,17 @@ __global__ __launch_bounds__(64) void k_myers_hw_path(
         return;
     }
     int sc, best, first, last;
-    // 1. HW: distance and first end location. The band needs a bound on the distance: tried from 1/16 of the query length
-    //    upwards, doubled until the distance found is within it (edlibAlign does the same from 64, :194-214; the answer does
-    //    not depend on the bounds tried: the first one that holds the optimum returns it exactly).
-    for (int k = max(64, qn >> 4);; k *= 2) {
+    // 1. HW: distance and first end location. The band needs a bound on the distance: 1/16 of the query length first; when the
+    //    best score found lies above the bound it is the score of an alignment that exists (every score in the band is one), so
+    //    the optimum is at most that and the second sweep, with that bound, holds it (edlibAlign doubles its bound from 64
+    //    instead, :194-214; the answer does not depend on the bounds tried: the first one that holds the optimum returns it
+    //    exactly).
+    for (int k = max(64, qn >> 4);;) {
         const bool all = k >= qn;
         myers_sweep(MyersSeq{qp, qn, false}, MyersSeq{tp, tn, false}, 2, all ? MyersBand::whole() : MyersBand::infix(qn, tn, k), hb, hbot, tbuf, nullptr, nullptr,
                     sc, best, first, last);
         if (all || best <= k) break;
+        k = best;
     }
     const int d = best, e = first;
     if (e < 0) {   // the whole query before the target (:233-246): start location 0, the alignment over an empty target is all insertions (:1171-1178)
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(64) void k_myers_hw_path_grouped(
     while (__ballot(pending) != 0ull) {
         const bool all = k >= qn;
         myers_sweep_grouped<G>(pending, MyersSeq{qp, qn, false}, MyersSeq{tp, tn, false}, 2, all ? MyersBand::whole() : MyersBand::infix(qn, tn, k), tb, nullptr, sc, best, first, last);
-        if (pending) { if (all || best <= k) { pending = false; d = best; e = first; } else k *= 2; }
+        if (pending) { if (all || best <= k) { pending = false; d = best; e = first; } else k = best; }      // (see k_myers_hw_path)
     }
     if (act && e < 0) {      // the whole query before the target (:233-246)
         if (gl == 0) { dist[pr] = d; end_loc[pr] = -1; start_loc[pr] = 0; }
