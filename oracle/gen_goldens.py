@@ -513,12 +513,62 @@ def gen_edlib_long_path_vectors():
     print("edlib long path vectors:", len(vec), "longest query", max(len(v["query"]) for v in vec))
 
 
+def gen_edlib_mid_path_vectors():
+    """HW + PATH vectors for queries of 330-2048 bases whose matrix edlib keeps whole (one leaf): the sizes at which
+    k_myers_hw_path_grouped takes 8, 16 or 32 lanes per pair, mixed so that one call holds every class:
+    tests/golden/edlib_mid_path_vectors.json.gz"""
+    import gzip
+    rnd = random.Random(47)
+    rs = lambda n: "".join(rnd.choice("ACGT") for _ in range(n))
+
+    def mutate(s, rate):
+        out = []
+        for c in s:
+            u = rnd.random()
+            if u < rate / 3:
+                out.append(rnd.choice("ACGT"))
+            elif u < 2 * rate / 3:
+                continue
+            elif u < rate:
+                out.append(c); out.append(rnd.choice("ACGT"))
+            else:
+                out.append(c)
+        return "".join(out)
+
+    pairs = []
+    for qn in (330, 448, 511, 512, 513, 600, 777, 1000, 1023, 1024, 1025, 1300, 1536, 1800, 2047, 2048):
+        nb = (qn + 63) // 64
+        tmax = (1024 * 1024 - 1) // (20 * nb + 8)          # edlib.cpp:1192-1196
+        for kind in range(4):
+            q = rs(qn)
+            body = mutate(q, [0.0, 0.04, 0.15, 0.4][kind])
+            room = max(0, tmax - len(body) - 1)
+            left = rnd.randint(0, room) if kind != 2 else 0
+            t = (rs(left) + body + rs(rnd.randint(0, room - left)))[:tmax] or "A"
+            pairs.append((q, t))
+        pairs.append((rs(qn), rs(rnd.randint(1, min(tmax, qn // 2)))))       # unrelated, target shorter than the query
+        unit = rs(rnd.randint(1, 5))
+        r = (unit * (qn // len(unit) + 1))[:qn]
+        pairs.append((r, (mutate(r, 0.05) + rs(50))[:tmax]))                  # repeats
+    rnd.shuffle(pairs)
+    lines = ["HWPATH -1 %s %s" % (q, t) for q, t in pairs]
+    res = subprocess.run([os.path.join(REF, "edlib_driver")], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.splitlines()
+    vec = []
+    for (q, t), r in zip(pairs, res):
+        d, st, en, cig = r.split()
+        vec.append({"query": q, "target": t, "distance": int(d), "start": int(st), "end": int(en), "cigar": cig})
+    with gzip.GzipFile(os.path.join(GOLD, "edlib_mid_path_vectors.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(vec).encode())
+    print("edlib mid path vectors:", len(vec))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check-oracle", action="store_true", help="also run oracle/_build/hs_oracle and report parity")
     ap.add_argument("--only", default=None)
     ap.add_argument("--edlib-path", action="store_true", help="only tests/golden/edlib_path_vectors.json")
     ap.add_argument("--edlib-long", action="store_true", help="only tests/golden/edlib_long_path_vectors.json.gz")
+    ap.add_argument("--edlib-mid", action="store_true", help="only tests/golden/edlib_mid_path_vectors.json.gz")
     ap.add_argument("--edlib-edge", action="store_true", help="only tests/golden/edlib_edge_vectors.json")
     ap.add_argument("--stage5-alphabet", action="store_true", help="only tests/golden/stage5_alphabet_cases.json")
     ap.add_argument("--c5u", action="store_true", help="only the uncut 10 Mb variant of C5: outputs into tests/golden_big/c5u (12 minutes of the reference)")
@@ -529,6 +579,8 @@ def main():
         return gen_edlib_path_vectors()
     if args.edlib_long:
         return gen_edlib_long_path_vectors()
+    if args.edlib_mid:
+        return gen_edlib_mid_path_vectors()
     if args.stage5_alphabet:
         return gen_stage5_alphabet_cases()
     if args.edlib_edge:

@@ -119,6 +119,7 @@ def test_alignment_path_oracle_matches_edlib_vectors():
     short = json.load(open(os.path.join(gu.GOLD, "edlib_path_vectors.json")))
     long_ = [v for v in json.loads(gzip.open(os.path.join(gu.GOLD, "edlib_long_path_vectors.json.gz")).read()) if len(v["query"]) <= 5000]
     assert len(long_) >= 20
+    long_ += json.loads(gzip.open(os.path.join(gu.GOLD, "edlib_mid_path_vectors.json.gz")).read())[::2]
     stats = {}
     for v in short[::3] + long_:
         g = eo.hw_align(v["query"], v["target"], stats=stats)

@@ -545,6 +545,48 @@ def test_edlib_hw_path_beyond_one_leaf_matches_reference_edlib(built):
     assert max(len(v["query"]) for v in vec) >= 60000
 
 
+def _check_paths_against_vectors(vec, got):
+    sym = "=IDX"
+    for v, g in zip(vec, got):
+        assert (g["distance"], g["end"]) == (v["distance"], v["end"]), (len(v["query"]), len(v["target"]))
+        if v["end"] >= 0:
+            assert g["start"] == v["start"]
+        if v["cigar"] == "*":
+            continue
+        ops = g["ops"]
+        assert ops is not None, (len(v["query"]), len(v["target"]))
+        cut = np.flatnonzero(np.diff(ops)) + 1
+        runs = np.diff(np.concatenate(([0], cut, [len(ops)])))
+        heads = ops[np.concatenate(([0], cut))]
+        assert "".join("%d%s" % (c, sym[o]) for c, o in zip(runs.tolist(), heads.tolist())) == v["cigar"], (len(v["query"]), len(v["target"]))
+
+
+def test_edlib_hw_path_every_lane_grouping_in_one_call(built):
+    """Queries of 330-2048 bases whose matrix edlib keeps whole take 8, 16 or 32 lanes of a wavefront (k_myers_hw_path_grouped);
+    here one call holds all of those classes, stage-5-sized pairs and pairs that need a wavefront and Hirschberg's cuts. Vectors:
+    the reference's edlib (oracle/gen_goldens.py --edlib-mid / --edlib-path / --edlib-long)."""
+    import gzip
+    from hairsplitter_amd import api
+    mid = json.loads(gzip.open(os.path.join(gu.GOLD, "edlib_mid_path_vectors.json.gz")).read())
+    short = json.load(open(os.path.join(gu.GOLD, "edlib_path_vectors.json")))[:40]
+    long_ = [v for v in json.loads(gzip.open(os.path.join(gu.GOLD, "edlib_long_path_vectors.json.gz")).read()) if len(v["query"]) <= 5000][:8]
+    vec = []
+    for i in range(max(len(mid), len(short), len(long_))):      # interleaved: neighbours in the call are of different classes
+        vec += [x[i] for x in (mid, short, long_) if i < len(x)]
+    nb = [(len(v["query"]) + 63) // 64 for v in mid]
+    assert any(b <= 8 for b in nb) and any(8 < b <= 16 for b in nb) and any(16 < b <= 32 for b in nb)
+    got = api.edlib_hw_align([(v["query"], v["target"]) for v in vec])
+    _check_paths_against_vectors(vec, got)
+    loc = api.edlib_hw_align([(v["query"], v["target"]) for v in vec], path=False)
+    assert [(g["distance"], g["end"]) for g in loc] == [(v["distance"], v["end"]) for v in vec]
+    os.environ["HS_MYERS_NO_GROUPS"] = "1"
+    try:
+        alone = api.edlib_hw_align([(v["query"], v["target"]) for v in vec])
+    finally:
+        del os.environ["HS_MYERS_NO_GROUPS"]
+    _check_paths_against_vectors(vec, alone)
+
+
 def test_stage5_edlib_call_sites(built):
     """The two stage-5 computations that sit on the reference's edlib calls, batched on the A1 kernel: the ends racon dropped are
     attached again (tools.cpp:505-536) and the overhangs are cut off the polished piece (create_new_contigs.cpp:556-629).
