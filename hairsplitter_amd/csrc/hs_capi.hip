@@ -941,16 +941,41 @@ int hs_edit_distance(const uint8_t* d_query, const int64_t* d_query_off, const u
     if (int rc = require_device()) return rc;
     if (n_pairs <= 0) return HS_OK;
     if (mode < 0 || mode > 2) { set_error("hs_edit_distance: mode must be 0 (NW), 1 (SHW) or 2 (HW)"); return HS_EINVAL; }
-    // scratch row for the bottom carries of every 64-block pass: one byte per target column
-    std::vector<int64_t> toff((size_t)n_pairs + 1);
+    // the offsets come back once: short queries share a wavefront (8 / 16 / 32 lanes per pair), the others take one each with the
+    // hand-over row between two passes of 64 blocks as scratch (see hs_kernels_myers.hip)
+    std::vector<int64_t> toff((size_t)n_pairs + 1), qoff((size_t)n_pairs + 1);
     HS_HIP(hipMemcpy(toff.data(), d_target_off, sizeof(int64_t) * toff.size(), hipMemcpyDeviceToHost));
-    DBuf scratch, soff;
-    if (int rc = scratch.alloc((size_t)(toff[(size_t)n_pairs] - toff[0]) + 64)) return rc;
-    std::vector<int64_t> so((size_t)n_pairs + 1);
-    for (size_t i = 0; i < so.size(); ++i) so[i] = toff[i] - toff[0];
-    if (int rc = soff.upload(so)) return rc;
-    hipLaunchKernelGGL(hsdev::k_myers, dim3((unsigned)n_pairs), dim3(64), 0, (hipStream_t)stream, d_query, d_query_off, d_target,
-                       d_target_off, n_pairs, mode, scratch.as<int8_t>(), soff.as<int64_t>(), d_dist, d_end);
+    HS_HIP(hipMemcpy(qoff.data(), d_query_off, sizeof(int64_t) * qoff.size(), hipMemcpyDeviceToHost));
+    std::vector<int32_t> cls[4];
+    std::vector<int64_t> hs_off((size_t)n_pairs + 1, 0);
+    const bool no_groups = std::getenv("HS_MYERS_NO_GROUPS") != nullptr;
+    for (int i = 0; i < n_pairs; ++i) {
+        const int64_t qn = qoff[(size_t)i + 1] - qoff[(size_t)i], tn = toff[(size_t)i + 1] - toff[(size_t)i];
+        const int64_t nb = (qn + 63) / 64;
+        const int c = (no_groups || nb > 32) ? 3 : nb <= 8 ? 0 : nb <= 16 ? 1 : 2;
+        cls[c].push_back(i);
+        hs_off[(size_t)i + 1] = hs_off[(size_t)i] + (c == 3 ? ((tn + 64 + 3) & ~(int64_t)3) + 4 * (tn + 64) : 0);
+    }
+    std::vector<int32_t> ids;
+    size_t cls_off[5] = {0, 0, 0, 0, 0};
+    for (int c = 0; c < 4; ++c) { ids.insert(ids.end(), cls[c].begin(), cls[c].end()); cls_off[c + 1] = ids.size(); }
+    DBuf scratch, d_ho, d_ids;
+    UploadPack pk;
+    pk.add(hs_off, d_ho); pk.add(ids, d_ids);
+    if (int rc = pk.commit((hipStream_t)stream)) return rc;
+    if (int rc = scratch.alloc(std::max<size_t>((size_t)hs_off.back(), 1))) return rc;
+    const int32_t* idp = d_ids.as<int32_t>();
+#define HS_MYERS_DIST_GROUPED(G, c)                                                                                                                       \
+    if (!cls[c].empty())                                                                                                                                  \
+        hipLaunchKernelGGL(hsdev::k_myers_distance_grouped<G>, dim3((unsigned)((cls[c].size() + 64 / G - 1) / (64 / G))), dim3(64), 0, (hipStream_t)stream, d_query, \
+                           d_query_off, d_target, d_target_off, idp + cls_off[c], (int)cls[c].size(), mode, d_dist, d_end);
+    HS_MYERS_DIST_GROUPED(8, 0)
+    HS_MYERS_DIST_GROUPED(16, 1)
+    HS_MYERS_DIST_GROUPED(32, 2)
+#undef HS_MYERS_DIST_GROUPED
+    if (!cls[3].empty())
+        hipLaunchKernelGGL(hsdev::k_myers_distance, dim3((unsigned)cls[3].size()), dim3(64), 0, (hipStream_t)stream, d_query, d_query_off, d_target, d_target_off,
+                           idp + cls_off[3], (int)cls[3].size(), mode, scratch.as<int8_t>(), d_ho.as<int64_t>(), d_dist, d_end);
     HS_HIP(hipGetLastError());
     if (int rc_w = stream_wait((hipStream_t)stream)) return rc_w;
     return HS_OK;

@@ -1430,107 +1430,7 @@ __global__ __launch_bounds__(64) void k_chinese_whispers(
     if (sweeps_out && lane == 0) sweeps_out[inst] = iters;
 }
 
-// ------------------------------------------------------------------------------------------------
-// A1 Myers bit-vector edit distance (Myers 1999 / Hyyro block formulation; oracle = the reference's bundled
-// edlib, edlib.h:242-246). One wavefront per (query,target) pair. Lane b owns query block b (64 rows: Peq for
-// the 4 symbols, Pv, Mv in registers); the wave sweeps anti-diagonals so that at step s lane b is at target
-// column s-b and receives the horizontal carry of the block above through a lane shift. Queries longer than
-// 4096 rows run in passes of 64 blocks; the bottom carries of a pass are kept in a scratch row (one byte per
-// column). The target is staged through LDS in 2 KiB pieces (all lanes read consecutive bytes).
-// mode 0 NW, 1 SHW, 2 HW.
-// ------------------------------------------------------------------------------------------------
-#define MY_TCHUNK 2048
-__global__ __launch_bounds__(64) void k_myers(
-    const uint8_t* __restrict__ query, const int64_t* __restrict__ query_off,
-    const uint8_t* __restrict__ target, const int64_t* __restrict__ target_off, int n_pairs, int mode,
-    int8_t* __restrict__ hscratch, const int64_t* __restrict__ hscratch_off,
-    int32_t* __restrict__ dist, int32_t* __restrict__ endloc) {
-    __shared__ uint8_t tbuf[MY_TCHUNK + 64];
-    const int lane = lane_id();
-    const int pr = (int)blockIdx.x;
-    if (pr >= n_pairs) return;
-    const uint8_t* __restrict__ q = query + query_off[pr];
-    const int qn = (int)(query_off[pr + 1] - query_off[pr]);
-    const uint8_t* __restrict__ t = target + target_off[pr];
-    const int tn = (int)(target_off[pr + 1] - target_off[pr]);
-    int8_t* __restrict__ hb = hscratch + hscratch_off[pr];
-    if (qn == 0) {   // degenerate: distance is tn for NW, 0 otherwise
-        if (lane == 0) { dist[pr] = mode == 0 ? tn : 0; endloc[pr] = mode == 0 ? tn - 1 : -1; }
-        return;
-    }
-    const int nblocks = (qn + 63) >> 6;
-    const int last_row = (qn - 1) & 63;
-    // D[qn][0] = qn; column -1 == "before the target": it takes part (and wins ties) only when the reference's edlib pads the
-    // query (qn not a multiple of 64, edlib.cpp:664-690: the score of column c is read off column c + padding)
-    int score = qn, best = (qn & 63) == 0 ? qn + 1 : qn, best_j = -1;
-    for (int pb = 0; pb < nblocks; pb += 64) {
-        const int blk = pb + lane;
-        const bool bvalid = blk < nblocks;
-        const bool is_last_blk = blk == nblocks - 1;
-        const int nb_pass = (nblocks - pb) < 64 ? (nblocks - pb) : 64;
-        uint64_t peq[4] = {0, 0, 0, 0};
-        if (bvalid) {
-            const int rbase = blk << 6;
-            for (int k = 0; k < 64; ++k) {
-                const int row = rbase + k;
-                if (row < qn) peq[q[row] & 3] |= 1ull << k;
-            }
-        }
-        uint64_t Pv = ~0ull, Mv = 0ull;
-        int hout_prev = 0;
-        const int nsteps = tn + nb_pass - 1;
-        for (int s0 = 0; s0 < nsteps; s0 += MY_TCHUNK) {
-            // stage target bytes [s0-63, s0+MY_TCHUNK) so that column s-b is tbuf[(s - s0) + 63 - b]
-            __builtin_amdgcn_wave_barrier();
-            for (int x = lane; x < MY_TCHUNK + 64; x += 64) {
-                const int col = s0 - 63 + x - 1 + 1;
-                tbuf[x] = (col >= 0 && col < tn) ? t[col] : 0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            const int s_end = (s0 + MY_TCHUNK) < nsteps ? (s0 + MY_TCHUNK) : nsteps;
-            for (int s = s0; s < s_end; ++s) {
-                const int j = s - lane;
-                int hin_up = __shfl_up(hout_prev, 1, 64);
-                const bool work = bvalid && j >= 0 && j < tn;
-                int hin;
-                if (lane == 0) hin = pb == 0 ? (mode == 2 ? 0 : 1) : (work ? (int)hb[j] : 0);
-                else hin = hin_up;
-                if (work) {
-                    const int sym = tbuf[(s - s0) + 63 - lane] & 3;
-                    uint64_t Eq = peq[sym];
-                    const uint64_t Xv = Eq | Mv;
-                    if (hin < 0) Eq |= 1ull;
-                    const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-                    uint64_t Ph = Mv | ~(Xh | Pv);
-                    uint64_t Mh = Pv & Xh;
-                    int hout = 0;
-                    if (Ph >> 63) hout = 1; else if (Mh >> 63) hout = -1;
-                    if (is_last_blk) {
-                        score += (int)((Ph >> last_row) & 1ull) - (int)((Mh >> last_row) & 1ull);
-                        if (mode != 0 && score < best) { best = score; best_j = j; }
-                    }
-                    Ph <<= 1; Mh <<= 1;
-                    if (hin < 0) Mh |= 1ull; else if (hin > 0) Ph |= 1ull;
-                    Pv = Mh | ~(Xv | Ph);
-                    Mv = Ph & Xv;
-                    hout_prev = hout;
-                    if (lane == nb_pass - 1 && !is_last_blk) hb[j] = (int8_t)hout;
-                }
-            }
-        }
-        // make the pass's bottom carries visible to lane 0 of the next pass
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-        __builtin_amdgcn_wave_barrier();
-    }
-    // the lane that owns the last block holds the answer
-    const int owner = (nblocks - 1) & 63;
-    const int fs = __shfl(score, owner, 64), fb = __shfl(best, owner, 64), fj = __shfl(best_j, owner, 64);
-    if (lane == 0) {
-        if (mode == 0) { dist[pr] = fs; endloc[pr] = tn - 1; }
-        else { dist[pr] = fb; endloc[pr] = fj; }
-    }
-}
+// (A1, the Myers bit-vector alignment kernels: hs_kernels_myers.hip)
 
 // ------------------------------------------------------------------------------------------------
 // K4 SNP column x partition correlation: distance(Partition&, Column&) + computeChiSquare

@@ -2,7 +2,8 @@
 // there is edlibAlign(query, target, k = -1, EDLIB_MODE_HW, EDLIB_TASK_PATH) (create_new_contigs.cpp:558-629,
 // tools.cpp:515-534) -- edit distance, first end location, its start location and one optimal alignment -- for a 200-300 bp
 // query against a target of a few hundred to a few thousand bases there; any query up to 2^20 bases here. One wavefront per
-// pair, Myers sweeps (lane b owns query block b, 64 blocks per pass, anti-diagonal schedule as in k_myers):
+// pair, Myers sweeps (lane b owns query block b, 64 blocks per pass; at step s lane b is at target column s - b and takes the
+// horizontal carry of the block above from the lane before it; the bottom row of a pass is handed to the next through memory):
 //   1. HW (infix): minimum of the bottom row, FIRST column that attains it            (edlib.cpp:560-700; the k-doubling of
 //      edlibAlign :194-214 only bounds the band of the reference's own search: the optimum it returns is the exact one)
 //   2. SHW of the reversed query on the reversed target prefix that ends there, LAST best column = the start location
@@ -22,6 +23,7 @@
 // Alignment ops as edlib's: 0 match, 1 insertion (query base without target base), 2 deletion, 3 mismatch.
 // Sequences are 2-bit base codes (A C G T), as everywhere on this path. Included by hs_capi.hip after hs_kernels.hip.
 #pragma once
+#define MY_TCHUNK 2048      /* target columns staged in LDS at a time */
 
 namespace hsdev {
 
@@ -521,6 +523,87 @@ __global__ __launch_bounds__(64) void k_myers_hw_path_grouped(
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
     __builtin_amdgcn_wave_barrier();
     if (act && gl == 0) ops_len[pr] = myers_traceback(sto, (qn + 63) >> 6, band, qn, an, sc, op);
+}
+
+
+// ---- distance and end location only (hs_edit_distance: edlib's TASK_DISTANCE / TASK_LOC end, modes NW / SHW / HW) ------------
+// The same banded sweeps. The bound: 1/16 of the query length (+ the length difference for NW) first; a score above the bound
+// is the score of an alignment that exists, so the sweep with that score as its bound holds the optimum.
+static __device__ __forceinline__ MyersBand myers_mode_band(int mode, int qn, int tn, int k, bool all) {
+    if (all) return MyersBand::whole();
+    return mode == 0 ? MyersBand::global(qn, tn, k) : mode == 1 ? MyersBand::prefix(k) : MyersBand::infix(qn, tn, k);
+}
+static __device__ __forceinline__ int myers_first_bound(int mode, int qn, int tn) {
+    const int D = tn > qn ? tn - qn : qn - tn;
+    return max(64, qn >> 4) + (mode == 0 ? D : 0);
+}
+
+__global__ __launch_bounds__(64) void k_myers_distance(
+    const uint8_t* __restrict__ query, const int64_t* __restrict__ query_off, const uint8_t* __restrict__ target,
+    const int64_t* __restrict__ target_off, const int32_t* __restrict__ pair_ids, int n_list, int mode, int8_t* __restrict__ hscratch,
+    const int64_t* __restrict__ hscratch_off, int32_t* __restrict__ dist, int32_t* __restrict__ end_loc) {
+    __shared__ uint8_t tbuf[MY_TCHUNK + 64];
+    const int lane = lane_id();
+    if ((int)blockIdx.x >= n_list) return;
+    const int pr = pair_ids[blockIdx.x];
+    const uint8_t* qp = query + query_off[pr];
+    const int qn = (int)(query_off[pr + 1] - query_off[pr]);
+    const uint8_t* tp = target + target_off[pr];
+    const int tn = (int)(target_off[pr + 1] - target_off[pr]);
+    if (qn == 0 || tn == 0) {      // nothing to sweep: all deletions / all insertions (NW), an empty placement otherwise
+        if (lane == 0) { dist[pr] = mode == 0 ? (qn ? qn : tn) : qn; end_loc[pr] = (mode == 0 && qn == 0) ? tn - 1 : -1; }
+        return;
+    }
+    int8_t* hb = hscratch + hscratch_off[pr];
+    int32_t* hbot = reinterpret_cast<int32_t*>(hb + ((tn + 64 + 3) & ~3));
+    const int kmax = mode == 0 ? max(qn, tn) : qn;
+    int sc, best, first, last;
+    for (int k = myers_first_bound(mode, qn, tn);;) {
+        const bool all = k >= kmax;
+        myers_sweep(MyersSeq{qp, qn, false}, MyersSeq{tp, tn, false}, mode, myers_mode_band(mode, qn, tn, k, all), hb, hbot, tbuf, nullptr, nullptr, sc, best, first, last);
+        const int got = mode == 0 ? sc : best;
+        if (all || got <= k) break;
+        k = got >= MY_INF ? 2 * k : got;
+    }
+    if (lane == 0) {
+        if (mode == 0) { dist[pr] = sc; end_loc[pr] = tn - 1; }
+        else { dist[pr] = best; end_loc[pr] = first; }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(64) void k_myers_distance_grouped(
+    const uint8_t* __restrict__ query, const int64_t* __restrict__ query_off, const uint8_t* __restrict__ target,
+    const int64_t* __restrict__ target_off, const int32_t* __restrict__ pair_ids, int n_list, int mode,
+    int32_t* __restrict__ dist, int32_t* __restrict__ end_loc) {
+    constexpr int NG = 64 / G;
+    __shared__ __attribute__((aligned(16))) uint8_t tbuf[NG][MY_GCHUNK + 64];
+    const int lane = lane_id(), gl = lane & (G - 1), grp = lane / G;
+    const int slot = (int)blockIdx.x * NG + grp;
+    const bool live = slot < n_list;
+    const int pr = live ? pair_ids[slot] : 0;
+    const uint8_t* qp = query; const uint8_t* tp = target;
+    int qn = 0, tn = 0;
+    if (live) { qp += query_off[pr]; qn = (int)(query_off[pr + 1] - query_off[pr]); tp += target_off[pr]; tn = (int)(target_off[pr + 1] - target_off[pr]); }
+    const bool act = live && qn > 0 && tn > 0;
+    if (live && !act && gl == 0) { dist[pr] = mode == 0 ? (qn ? qn : tn) : qn; end_loc[pr] = (mode == 0 && qn == 0) ? tn - 1 : -1; }
+    const int kmax = mode == 0 ? max(qn, tn) : qn;
+    int sc = 0, best = 0, first = -1, last = -1, r_sc = 0, r_best = 0, r_first = -1;
+    int k = myers_first_bound(mode, qn, tn);
+    bool pending = act;
+    while (__ballot(pending) != 0ull) {
+        const bool all = k >= kmax;
+        myers_sweep_grouped<G>(pending, MyersSeq{qp, qn, false}, MyersSeq{tp, tn, false}, mode, myers_mode_band(mode, qn, tn, k, all), tbuf[grp], nullptr, sc, best, first, last);
+        if (pending) {
+            const int got = mode == 0 ? sc : best;
+            if (all || got <= k) { pending = false; r_sc = sc; r_best = best; r_first = first; }
+            else k = got >= MY_INF ? 2 * k : got;
+        }
+    }
+    if (act && gl == 0) {
+        if (mode == 0) { dist[pr] = r_sc; end_loc[pr] = tn - 1; }
+        else { dist[pr] = r_best; end_loc[pr] = r_first; }
+    }
 }
 
 

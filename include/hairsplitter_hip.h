@@ -268,8 +268,9 @@ int hs_chinese_whispers(const int32_t* d_adj_off, const int32_t* d_adj, const in
                         int32_t* d_sweeps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * A1 -- Myers bit-vector edit distance, batched (one wavefront per pair; 64 query rows per lane-block,
- * carries passed between lanes). The reference's hot path takes base-level alignments from the SAM CIGAR;
+ * A1 -- Myers bit-vector edit distance, batched and banded (64 query rows per lane, carries passed between lanes;
+ * a wavefront per pair, queries up to 2048 bases 8 / 16 / 32 lanes per pair; the band's bound is found on the way, as
+ * edlib's k = -1 does). The reference's hot path takes base-level alignments from the SAM CIGAR;
  * its bundled edlib (edlib.h:242-246, modes edlib.h:36-62) is the behavioural oracle for this kernel.
  * mode: 0 = NW (global), 1 = SHW (prefix), 2 = HW (infix). Outputs: edit distance and the first end location
  * on the target (0-based, inclusive), like edlibAlign's editDistance / endLocations[0].

@@ -562,12 +562,35 @@ def gen_edlib_mid_path_vectors():
     print("edlib mid path vectors:", len(vec))
 
 
+def gen_edlib_long_dist_vectors():
+    """NW / SHW / HW distance + first end location from the reference's bundled edlib for the pairs of edlib_long_path_vectors and
+    edlib_mid_path_vectors (0.3-60 kb): what hs_edit_distance returns. Stored by pair index: tests/golden/edlib_long_dist_vectors.json"""
+    import gzip
+    out = {}
+    for name in ("edlib_long_path_vectors", "edlib_mid_path_vectors"):
+        vec = json.loads(gzip.open(os.path.join(GOLD, name + ".json.gz")).read())
+        lines = ["%s -1 %s %s" % (mode, v["query"], v["target"]) for v in vec for mode in ("NW", "SHW", "HW")]
+        res = subprocess.run([os.path.join(REF, "edlib_driver")], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.splitlines()
+        rows = []
+        for i in range(len(vec)):
+            row = {}
+            for m, mode in enumerate(("NW", "SHW", "HW")):
+                d, nloc, st, en = res[3 * i + m].split()
+                row[mode] = [int(d), int(en)]
+            rows.append(row)
+        out[name] = rows
+    with open(os.path.join(GOLD, "edlib_long_dist_vectors.json"), "w") as f:
+        json.dump(out, f)
+    print("edlib long distance vectors:", {k: len(v) for k, v in out.items()})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check-oracle", action="store_true", help="also run oracle/_build/hs_oracle and report parity")
     ap.add_argument("--only", default=None)
     ap.add_argument("--edlib-path", action="store_true", help="only tests/golden/edlib_path_vectors.json")
     ap.add_argument("--edlib-long", action="store_true", help="only tests/golden/edlib_long_path_vectors.json.gz")
+    ap.add_argument("--edlib-long-dist", action="store_true", help="only tests/golden/edlib_long_dist_vectors.json")
     ap.add_argument("--edlib-mid", action="store_true", help="only tests/golden/edlib_mid_path_vectors.json.gz")
     ap.add_argument("--edlib-edge", action="store_true", help="only tests/golden/edlib_edge_vectors.json")
     ap.add_argument("--stage5-alphabet", action="store_true", help="only tests/golden/stage5_alphabet_cases.json")
@@ -581,6 +604,8 @@ def main():
         return gen_edlib_long_path_vectors()
     if args.edlib_mid:
         return gen_edlib_mid_path_vectors()
+    if args.edlib_long_dist:
+        return gen_edlib_long_dist_vectors()
     if args.stage5_alphabet:
         return gen_stage5_alphabet_cases()
     if args.edlib_edge:

@@ -587,6 +587,32 @@ def test_edlib_hw_path_every_lane_grouping_in_one_call(built):
     _check_paths_against_vectors(vec, alone)
 
 
+def test_edit_distance_long_and_mixed_pairs_match_reference_edlib(built):
+    """hs_edit_distance (NW / SHW / HW distance + first end location) on pairs of 0.3-60 kb, every lane grouping and the
+    wavefront-per-pair kernel in one call: the banded sweeps with their bound found on the way. Expected: the reference's edlib
+    (oracle/gen_goldens.py --edlib-long-dist)."""
+    import gzip
+    from hairsplitter_amd import api
+    exp = json.load(open(os.path.join(gu.GOLD, "edlib_long_dist_vectors.json")))
+    code = np.full(256, 3, np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    enc = lambda x: code[np.frombuffer(x.encode(), dtype=np.uint8)]
+    pairs, want = [], {"NW": [], "SHW": [], "HW": []}
+    for name in ("edlib_mid_path_vectors", "edlib_long_path_vectors"):
+        vec = json.loads(gzip.open(os.path.join(gu.GOLD, name + ".json.gz")).read())
+        for v, e in zip(vec, exp[name]):
+            pairs.append((enc(v["query"]), enc(v["target"])))
+            for m in want:
+                want[m].append(e[m])
+    assert max(len(q) for q, _ in pairs) >= 60000
+    for mode in ("NW", "SHW", "HW"):
+        d, e = api.edit_distance([q for q, _ in pairs], [t for _, t in pairs], mode)
+        w = np.array(want[mode])
+        bad = np.flatnonzero((d != w[:, 0]) | (e != w[:, 1]))
+        assert len(bad) == 0, (mode, [(int(i), len(pairs[i][0]), len(pairs[i][1]), int(d[i]), int(e[i]), w[i].tolist()) for i in bad[:5]])
+
+
 def test_stage5_edlib_call_sites(built):
     """The two stage-5 computations that sit on the reference's edlib calls, batched on the A1 kernel: the ends racon dropped are
     attached again (tools.cpp:505-536) and the overhangs are cut off the polished piece (create_new_contigs.cpp:556-629).
