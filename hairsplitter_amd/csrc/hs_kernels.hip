@@ -859,9 +859,9 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
     int32_t* __restrict__ sel_count, int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int64_t tile0, int64_t g_lo, int64_t g_hi,
     int32_t* __restrict__ sel_ent) {
     constexpr int NWORDS = (HS_NBINS + 3) / 4;
-    // 33 KB of LDS: the ballots of the selection reuse the histogram's first bytes once every thread has read its column
+    // exactly 32 KB of LDS (five workgroups per CU): the ballots of the selection reuse the histogram's first bytes once every
+    // thread has read its column
     __shared__ __attribute__((aligned(16))) uint32_t hw[NWORDS * 256];
-    __shared__ uint32_t wmask[256];      // [k][l]: the counter words position 4 l + k has counted in (the final scan reads only those)
     unsigned long long* const s_b = reinterpret_cast<unsigned long long*>(hw);
     int* const s_e = reinterpret_cast<int*>(hw) + 8;
     const int tid = (int)threadIdx.x;
@@ -869,7 +869,6 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
     const int64_t tile = tile0 + (int64_t)blockIdx.x;
 #pragma unroll
     for (int x = 0; x < NWORDS * 256 / (256 * 4); ++x) reinterpret_cast<uint4*>(hw)[x * 256 + tid] = make_uint4(0u, 0u, 0u, 0u);
-    wmask[tid] = 0u;
     __syncthreads();
     char* const my_cols = reinterpret_cast<char*>(hw) + lane * 4;      // byte k of this lane's dword: column k * 64 + lane, i.e. + 256 k bytes
     auto bump = [&](unsigned code, bool valid, int k) {
@@ -877,7 +876,6 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
             const unsigned inc = 1u << ((code & 3u) * 8u);
             uint32_t* at = reinterpret_cast<uint32_t*>(my_cols + 256 * k + ((code & ~3u) << 8));
             __hip_atomic_fetch_add(at, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_or(&wmask[64 * k + lane], 1u << (code >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     };
     const int64_t e0 = tile_off[tile], e1 = tile_off[tile + 1];
@@ -921,8 +919,8 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
     if (g < total) {
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
         us2 m0a = {0, 0}, m1a = {0, 0}, m0b = {0, 0}, m1b = {0, 0};
-        for (uint32_t m = wmask[tid]; m != 0u; m &= m - 1u) {      // (thread t = 64 wv + lane scans position 4 lane + wv: mask [wv][lane])
-            const int w = __builtin_ctz(m);
+#pragma unroll 4
+        for (int w = 0; w < NWORDS; ++w) {
             const uint32_t word = hw[w * 256 + tid];
             depth = (int)__builtin_amdgcn_sad_u8(word, 0u, (uint32_t)depth);      // sum of the four byte counters
             const us2 va = __builtin_bit_cast(us2, word & 0x00ff00ffu);
