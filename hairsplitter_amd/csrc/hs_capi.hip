@@ -869,10 +869,10 @@ static void simdiff_tiles(const std::vector<int32_t>& h_n_reads, std::vector<int
 }
 static int simdiff_launch(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_plane_off, const int32_t* d_n_reads,
                           const int32_t* d_words, const int64_t* d_out_off, int32_t* d_sim, int32_t* d_diff, void* stream,
-                          const int32_t* d_tc, const int32_t* d_ti, const int32_t* d_tj, size_t n_tiles) {
+                          const int32_t* d_tc, const int32_t* d_ti, const int32_t* d_tj, size_t n_tiles, int es = 1 /* 2: (sim, diff) pairs, d_diff = d_sim + 1 */) {
     if (n_tiles == 0) return HS_OK;
     hipLaunchKernelGGL(hsdev::k_simdiff, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, d_alt, d_ref, d_plane_off,
-                       d_n_reads, d_words, d_out_off, d_tc, d_ti, d_tj, d_sim, d_diff);
+                       d_n_reads, d_words, d_out_off, d_tc, d_ti, d_tj, d_sim, d_diff, es);
     HS_HIP(hipGetLastError());
     return HS_OK;
 }
@@ -1768,7 +1768,7 @@ struct PlaneRows { const uint64_t* d_alt = nullptr; const uint64_t* d_ref = null
 
 static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const std::vector<int64_t>& ctg_out_off, const std::vector<int32_t>& ctg_n_matrix,
                             const hs::SrWindowSet& ws, GraphRows& G, hipStream_t stream, int64_t* rows_on_host, float* k_ms, KernelClock* kc = nullptr,
-                            const PlaneRows* planes = nullptr) {
+                            const PlaneRows* planes = nullptr, int es = 1 /* element stride of d_sim / d_diff (2: pairs in one array) */) {
     const std::vector<int32_t>& ctg_n = ws.ctg_reads.empty() ? ctg_n_matrix : ws.ctg_reads;      // reads of every contig (the matrix list has 0 for low-memory contigs)
     const int W = (int)ws.win_contig.size();
     G.W = W; G.rows = ws.rows(); G.total = 0; G.max_m = 1;
@@ -1847,7 +1847,7 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
             hipLaunchKernelGGL(hsdev::k_read_graph_rows<false>, dim3((rows_mx + waves - 1) / waves), dim3(64 * waves), (size_t)cap * 8 * waves, stream, d_sim, d_diff,
                                G.d_oo.as<int64_t>(), G.d_n.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_rw.as<int32_t>(),
                                G.d_bo.as<int64_t>(), 0, rows_mx, below, cap, d_bits.as<unsigned long long>(), d_ar.as<int32_t>(), d_ar.as<int32_t>() + 1, rows_dev,
-                               (const int64_t*)nullptr);
+                               (const int64_t*)nullptr, es);
             HS_HIP(hipGetLastError());
             if (kc) {   // per row: the sim and diff entries of the window's m reads in, m link bits out
                 int64_t by = 0;
@@ -1858,12 +1858,12 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
         if (rows_dev > rows_mx) {
             // create_read_graph_low_memory: the window-local matrices from the bit rows, then the same row kernel with that path's distance
             const size_t mat = (size_t)win_mat_off.back();
-            if (int rc = d_wsim.alloc(std::max<size_t>(mat, 1) * 4)) return rc;
-            if (int rc = d_wdiff.alloc(std::max<size_t>(mat, 1) * 4)) return rc;
+            if (int rc = d_wsim.alloc(std::max<size_t>(mat, 1) * 8)) return rc;      // (sim, diff) pairs: a row kernel's two reads of a pair share a line
+            d_wdiff.p = (char*)d_wsim.p + 4; d_wdiff.bytes = 0; d_wdiff.cap = 0; d_wdiff.view = true;
             if (kc) { if (int rc = kc->begin(HS_K_SIMDIFF, stream)) return rc; }
             hipLaunchKernelGGL(hsdev::k_simdiff_windows, dim3((unsigned)lt_w.size()), dim3(256), 0, stream, planes->d_alt, planes->d_ref, planes->d_plane_off, planes->d_words,
                                G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), d_wmo.as<int64_t>(), d_ltw.as<int32_t>(), d_lti.as<int32_t>(),
-                               d_ltj.as<int32_t>(), d_wsim.as<int32_t>(), d_wdiff.as<int32_t>());
+                               d_ltj.as<int32_t>(), d_wsim.as<int32_t>(), d_wdiff.as<int32_t>(), 2);
             HS_HIP(hipGetLastError());
             if (kc) { if (int rc = kc->end(8 * (int64_t)mat, stream)) return rc; }
             if (kc) { if (int rc = kc->begin(HS_K_GRAPH_ROWS, stream)) return rc; }
@@ -1871,7 +1871,7 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
             hipLaunchKernelGGL(hsdev::k_read_graph_rows<true>, dim3((n_lm + waves - 1) / waves), dim3(64 * waves), (size_t)cap * 8 * waves, stream, d_wsim.as<int32_t>(),
                                d_wdiff.as<int32_t>(), G.d_oo.as<int64_t>(), G.d_n.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(),
                                G.d_rw.as<int32_t>(), G.d_bo.as<int64_t>(), rows_mx, n_lm, below, cap, d_bits.as<unsigned long long>(), d_ar.as<int32_t>(),
-                               d_ar.as<int32_t>() + 1, rows_dev, d_wmo.as<int64_t>());
+                               d_ar.as<int32_t>() + 1, rows_dev, d_wmo.as<int64_t>(), 2);
             HS_HIP(hipGetLastError());
             if (kc) { if (int rc = kc->end(8 * (int64_t)mat, stream)) return rc; }
         }
@@ -1910,10 +1910,10 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
             if (int rc = d_od.alloc((size_t)dst.back() * 4)) return rc;
             if (n_amb_mx > 0)
                 hipLaunchKernelGGL(hsdev::k_read_graph_fetch_rows, dim3(n_amb_mx), dim3(256), 0, stream, d_sim, d_diff, d_src.as<int64_t>(), d_len.as<int32_t>(),
-                                   d_dst.as<int64_t>(), d_os.as<int32_t>(), d_od.as<int32_t>());
+                                   d_dst.as<int64_t>(), d_os.as<int32_t>(), d_od.as<int32_t>(), es);
             if (n_amb > n_amb_mx)
                 hipLaunchKernelGGL(hsdev::k_read_graph_fetch_rows, dim3(n_amb - n_amb_mx), dim3(256), 0, stream, d_wsim.as<int32_t>(), d_wdiff.as<int32_t>(),
-                                   d_src.as<int64_t>() + n_amb_mx, d_len.as<int32_t>() + n_amb_mx, d_dst.as<int64_t>() + n_amb_mx, d_os.as<int32_t>(), d_od.as<int32_t>());
+                                   d_src.as<int64_t>() + n_amb_mx, d_len.as<int32_t>() + n_amb_mx, d_dst.as<int64_t>() + n_amb_mx, d_os.as<int32_t>(), d_od.as<int32_t>(), 2);
             HS_HIP(hipGetLastError());
             // both row sets with one wait, read where they land
             HBuf h_rows;
@@ -2128,8 +2128,9 @@ struct HipSrOps : hs::SrDeviceOps {
         const size_t pbytes = (size_t)job.plane_total * sizeof(uint64_t);
         if (int rc = f.d_alt.alloc(pbytes)) return rc;
         if (int rc = f.d_ref.alloc(pbytes)) return rc;
-        if (int rc = d_sim.alloc(std::max<size_t>((size_t)job.out_total, 1) * sizeof(int32_t))) return rc;
-        if (int rc = d_diff.alloc(std::max<size_t>((size_t)job.out_total, 1) * sizeof(int32_t))) return rc;
+        // (sim, diff) of a read pair side by side: K6 reads both for every masked read of a row, one 64-byte line instead of two
+        if (int rc = d_sim.alloc(std::max<size_t>((size_t)job.out_total, 1) * 2 * sizeof(int32_t))) return rc;
+        d_diff.release(); d_diff.p = (char*)d_sim.p + sizeof(int32_t); d_diff.bytes = 0; d_diff.cap = 0; d_diff.view = true;
         if (int rc = kc.begin(HS_K_SNP_PLANES, stream)) return rc;
         if (int rc = snp_planes_launch(d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(), f.d_sr.as<uint8_t>(), f.d_sa.as<uint8_t>(),
                                        f.d_sc.as<int32_t>(), f.d_cb.as<int64_t>(), f.d_po.as<int64_t>(), f.d_w.as<int32_t>(), f.d_pn.as<int32_t>(), f.d_bc.as<int32_t>(),
@@ -2139,7 +2140,7 @@ struct HipSrOps : hs::SrDeviceOps {
         HS_HIP(hipEventRecord(f.ev.a, stream));
         if (int rc = kc.begin(HS_K_SIMDIFF, stream)) return rc;
         if (int rc = simdiff_launch(f.d_alt.as<uint64_t>(), f.d_ref.as<uint64_t>(), f.d_po.as<int64_t>(), f.d_n.as<int32_t>(), f.d_w.as<int32_t>(),
-                                    f.d_oo.as<int64_t>(), d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, f.t_c.as<int32_t>(), f.t_i.as<int32_t>(), f.t_j.as<int32_t>(), f.tc.size())) return rc;
+                                    f.d_oo.as<int64_t>(), d_sim.as<int32_t>(), d_diff.as<int32_t>(), stream, f.t_c.as<int32_t>(), f.t_i.as<int32_t>(), f.t_j.as<int32_t>(), f.tc.size(), 2)) return rc;
         if (int rc = kc.end(2 * (int64_t)pbytes + 8 * job.out_total, stream)) return rc;   // the two bit-planes in, sim + diff out
         HS_HIP(hipEventRecord(f.ev.b, stream));
         return HS_OK;   // not waited for: the stream orders K6 behind it, the host goes on planning the windows
@@ -2148,7 +2149,7 @@ struct HipSrOps : hs::SrDeviceOps {
     int build_graphs(const hs::SrWindowSet& ws, int64_t* rows_on_host, float* k_ms) override {
         PlaneRows pr;
         if (sd_flight) { pr.d_alt = sd_flight->d_alt.as<uint64_t>(); pr.d_ref = sd_flight->d_ref.as<uint64_t>(); pr.d_plane_off = sd_flight->d_po.as<int64_t>(); pr.d_words = sd_flight->d_w.as<int32_t>(); }
-        const int rc = graph_rows_build(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, ws, G, stream, rows_on_host, k_ms, &kc, &pr);
+        const int rc = graph_rows_build(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, ws, G, stream, rows_on_host, k_ms, &kc, &pr, 2);
         const int rc2 = settle_simdiff();   // K6 came after K5 on the stream and has been waited for
         return rc ? rc : rc2;
     }

@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(256) void k_simdiff(
     const uint64_t* __restrict__ alt, const uint64_t* __restrict__ ref, const int64_t* __restrict__ plane_off,
     const int32_t* __restrict__ n_reads, const int32_t* __restrict__ words, const int64_t* __restrict__ out_off,
     const int32_t* __restrict__ tile_contig, const int32_t* __restrict__ tile_i, const int32_t* __restrict__ tile_j,
-    int32_t* __restrict__ sim, int32_t* __restrict__ diff) {
+    int32_t* __restrict__ sim, int32_t* __restrict__ diff, int es /* element stride: 1 = two arrays, 2 = (sim, diff) pairs in one (diff = sim + 1) */) {
     __shared__ uint64_t s_planes[4][64][SD_KW + 1];      // one array: the mirrored store below reuses it as a 64 x 65 int tile
     uint64_t (*sAi)[SD_KW + 1] = s_planes[0]; uint64_t (*sRi)[SD_KW + 1] = s_planes[1];
     uint64_t (*sAj)[SD_KW + 1] = s_planes[2]; uint64_t (*sRj)[SD_KW + 1] = s_planes[3];
@@ -1150,8 +1150,8 @@ __global__ __launch_bounds__(256) void k_simdiff(
             const int paa = s_acc[a][b], prr = d_acc[a][b], puu = u_acc[a][b];
             s_acc[a][b] = 3 * paa + prr; d_acc[a][b] = puu - paa - prr;
         }
-    int32_t* __restrict__ S = sim + out_off[c];
-    int32_t* __restrict__ D = diff + out_off[c];
+    int32_t* __restrict__ S = sim + out_off[c] * es;
+    int32_t* __restrict__ D = diff + out_off[c] * es;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -1159,8 +1159,8 @@ __global__ __launch_bounds__(256) void k_simdiff(
             const int gi = i0 + ti + 16 * a, gj = j0 + tj + 16 * b;
             if (gi < N && gj < N) {
                 const bool dg = gi == gj;
-                S[(int64_t)gi * N + gj] = dg ? 0 : s_acc[a][b];
-                D[(int64_t)gi * N + gj] = dg ? 0 : d_acc[a][b];
+                S[((int64_t)gi * N + gj) * es] = dg ? 0 : s_acc[a][b];
+                D[((int64_t)gi * N + gj) * es] = dg ? 0 : d_acc[a][b];
             }
         }
     // Both matrices are symmetric (sim = 3 A A^T + R R^T, diff = A R^T + R A^T): only the tiles on and above the diagonal are
@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(256) void k_simdiff(
             for (int x = tid; x < 64 * 64; x += 256) {
                 const int rj = x >> 6, ci = x & 63;              // row of the mirrored tile = a read of the j side
                 const int gj = j0 + rj, gi = i0 + ci;
-                if (gj < N && gi < N) O[(int64_t)gj * N + gi] = tile[rj * 65 + ci];
+                if (gj < N && gi < N) O[((int64_t)gj * N + gi) * es] = tile[rj * 65 + ci];
             }
         }
     }
@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(256) void k_simdiff_windows(
     const uint64_t* __restrict__ alt, const uint64_t* __restrict__ ref, const int64_t* __restrict__ plane_off, const int32_t* __restrict__ words,
     const int32_t* __restrict__ win_contig, const int64_t* __restrict__ win_mask_off, const int32_t* __restrict__ mask_ids,
     const int64_t* __restrict__ win_mat_off, const int32_t* __restrict__ tile_win, const int32_t* __restrict__ tile_i, const int32_t* __restrict__ tile_j,
-    int32_t* __restrict__ wsim, int32_t* __restrict__ wdiff) {
+    int32_t* __restrict__ wsim, int32_t* __restrict__ wdiff, int es) {
     __shared__ uint64_t s_planes[4][64][SD_KW + 1];
     uint64_t (*sAi)[SD_KW + 1] = s_planes[0]; uint64_t (*sRi)[SD_KW + 1] = s_planes[1];
     uint64_t (*sAj)[SD_KW + 1] = s_planes[2]; uint64_t (*sRj)[SD_KW + 1] = s_planes[3];
@@ -1258,14 +1258,14 @@ __global__ __launch_bounds__(256) void k_simdiff_windows(
             const int paa = s_acc[a][b], prr = d_acc[a][b], puu = u_acc[a][b];
             s_acc[a][b] = 3 * paa + prr; d_acc[a][b] = puu - paa - prr;
         }
-    int32_t* __restrict__ S = wsim + win_mat_off[w];
-    int32_t* __restrict__ D = wdiff + win_mat_off[w];
+    int32_t* __restrict__ S = wsim + win_mat_off[w] * es;
+    int32_t* __restrict__ D = wdiff + win_mat_off[w] * es;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int gi = i0 + ti + 16 * a, gj = j0 + tj + 16 * b;
-            if (gi < m && gj < m) { S[(int64_t)gi * m + gj] = s_acc[a][b]; D[(int64_t)gi * m + gj] = d_acc[a][b]; }
+            if (gi < m && gj < m) { S[((int64_t)gi * m + gj) * es] = s_acc[a][b]; D[((int64_t)gi * m + gj) * es] = d_acc[a][b]; }
         }
 }
 

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_read_graph_rows(
     const int32_t* __restrict__ ctg_n, const int32_t* __restrict__ win_contig, const int64_t* __restrict__ win_mask_off,
     const int32_t* __restrict__ mask_ids, const int32_t* __restrict__ row_win, const int64_t* __restrict__ win_bits_off,
     int row_base, int n_rows, float below, int cap, unsigned long long* __restrict__ bits, int32_t* __restrict__ amb_count,
-    int32_t* __restrict__ amb_rows, int amb_cap, const int64_t* __restrict__ win_mat_off) {
+    int32_t* __restrict__ amb_rows, int amb_cap, const int64_t* __restrict__ win_mat_off, int es /* element stride of sim / diff: 2 = (sim, diff) pairs */) {
     extern __shared__ unsigned char s_dyn[];
     const int lane = lane_id();
     const int wv = wave_id(), waves = (int)(blockDim.x >> 6);
@@ -75,15 +75,15 @@ __global__ __launch_bounds__(256) void k_read_graph_rows(
         if (lane == 0) { const int k = atomicAdd(amb_count, 1); if (k < amb_cap) amb_rows[k] = row; }
     };
     if (m > cap || N < 2 || !(below >= 0.f)) { give_up(); return; }
-    const int32_t* __restrict__ srow = LM ? sim + win_mat_off[w] + (int64_t)i * m : sim + ctg_out_off[c] + (int64_t)r1 * N;
-    const int32_t* __restrict__ drow = LM ? diff + win_mat_off[w] + (int64_t)i * m : diff + ctg_out_off[c] + (int64_t)r1 * N;
+    const int32_t* __restrict__ srow = LM ? sim + (win_mat_off[w] + (int64_t)i * m) * es : sim + (ctg_out_off[c] + (int64_t)r1 * N) * es;
+    const int32_t* __restrict__ drow = LM ? diff + (win_mat_off[w] + (int64_t)i * m) * es : diff + (ctg_out_off[c] + (int64_t)r1 * N) * es;
 
     // distances of the masked reads (:752-759 / :611-624); every other read of the contig has distance 0
     int max_compat = 0;
     bool nan_l = false;
     for (int j = lane; j < m; j += 64) {
         const int r = ids[j];
-        const int s = LM ? srow[j] : srow[r], dd = LM ? drow[j] : drow[r];
+        const int s = LM ? srow[(int64_t)j * es] : srow[(int64_t)r * es], dd = LM ? drow[(int64_t)j * es] : drow[(int64_t)r * es];
         float d = 0.f;
         if (LM) {
             if (r != r1) {
@@ -174,10 +174,10 @@ __global__ __launch_bounds__(256) void k_read_graph_rows(
 // rows the device could not decide: their sim / diff rows, compacted for one copy to the host
 __global__ __launch_bounds__(256) void k_read_graph_fetch_rows(
     const int32_t* __restrict__ sim, const int32_t* __restrict__ diff, const int64_t* __restrict__ src_off,
-    const int32_t* __restrict__ len, const int64_t* __restrict__ dst_off, int32_t* __restrict__ out_sim, int32_t* __restrict__ out_diff) {
+    const int32_t* __restrict__ len, const int64_t* __restrict__ dst_off, int32_t* __restrict__ out_sim, int32_t* __restrict__ out_diff, int es) {
     const int k = (int)blockIdx.x;
     const int n = len[k];
-    for (int j = (int)threadIdx.x; j < n; j += 256) { out_sim[dst_off[k] + j] = sim[src_off[k] + j]; out_diff[dst_off[k] + j] = diff[src_off[k] + j]; }
+    for (int j = (int)threadIdx.x; j < n; j += 256) { out_sim[dst_off[k] + j] = sim[(src_off[k] + j) * es]; out_diff[dst_off[k] + j] = diff[(src_off[k] + j) * es]; }
 }
 
 // links decided on the host: (window-local row, window-local column) pairs with the bit-matrix base of their window
