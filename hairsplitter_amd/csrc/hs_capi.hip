@@ -3,6 +3,7 @@
 // point fails with HS_ENODEVICE.
 #include <hip/hip_runtime.h>
 #include <malloc.h>
+#include <sys/prctl.h>
 #include <condition_variable>
 #include <functional>
 #include <thread>
@@ -199,8 +200,9 @@ struct UploadPack {
     }
 };
 
-// Host waits = polling hipStreamQuery with a 25-us sleep between two looks: about 1 % of a core instead of 100 %, the host learns
-// of the end of the work 30-80 us late -- which the other contig groups cover. No events, no interrupts, no device-wide
+// Host waits = polling hipStreamQuery with a 25-us sleep between two looks (HS_WAIT_SLEEP_US; the polling thread's timer slack set
+// to 1 us, HS_TIMER_SLACK_NS, so that 25 us are 25 us and not 75): about 1 % of a core instead of 100 %, the host learns of the
+// end of the work 30 us late -- which the other contig groups cover. No events, no interrupts, no device-wide
 // scheduling flag. HS_SPIN_WAIT=1 polls back to back instead (measured on the 16-core box, 500-contig job: the same step time,
 // 60-80 CPU-ms more per step; it only pays when a single chain owns the device). A wait that has lasted HS_WAIT_TIMEOUT_S
 // seconds (default 1800, 0 = no limit) returns an error instead of hanging the caller for ever; the blocks of that call are
@@ -229,7 +231,14 @@ static int stream_wait_impl(hipStream_t s) {
         if (e == hipSuccess) return HS_OK;
         if (e != hipErrorNotReady) { (void)hipGetLastError(); set_error(std::string("hipStreamQuery: ") + hipGetErrorString(e)); return HS_EHIP; }
         (void)hipGetLastError();      // (hipErrorNotReady is sticky otherwise)
-        if (blocking_wait()) { struct timespec ts = {0, 25000}; nanosleep(&ts, nullptr); }
+        if (blocking_wait()) {
+            static const long sleep_ns = []() { const char* e = std::getenv("HS_WAIT_SLEEP_US"); return e ? std::atol(e) * 1000l : 25000l; }();
+            // the kernel's default timer slack adds up to 50 us to every sleep: a polling thread asks for 1 us (its own setting only)
+            static const long slack_ns = []() { const char* e = std::getenv("HS_TIMER_SLACK_NS"); return e ? std::atol(e) : 1000l; }();
+            static thread_local bool slack_set = false;
+            if (slack_ns > 0 && !slack_set) { prctl(PR_SET_TIMERSLACK, (unsigned long)slack_ns); slack_set = true; }
+            struct timespec ts = {0, sleep_ns}; nanosleep(&ts, nullptr);
+        }
         else { for (int i = 0; i < 16; ++i) __builtin_ia32_pause(); }
         if (limit > 0 && (looks & 4095ul) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(limit)) {
             g_device_lost.store(true);
