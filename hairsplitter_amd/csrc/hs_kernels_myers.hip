@@ -1,5 +1,5 @@
-// hs_kernels_myers.hip -- A1 for the stage-5 call sites: what the reference asks of its bundled edlib
-// there is edlibAlign(query, target, k = -1, EDLIB_MODE_HW, EDLIB_TASK_PATH) (create_new_contigs.cpp:558-629,
+// hs_kernels_myers.hip -- A1: banded Myers bit-vector alignment with the results of the reference's
+// bundled edlib. What stage 5 asks of it is edlibAlign(query, target, k = -1, EDLIB_MODE_HW, EDLIB_TASK_PATH) (create_new_contigs.cpp:558-629,
 // tools.cpp:515-534) -- edit distance, first end location, its start location and one optimal alignment -- for a 200-300 bp
 // query against a target of a few hundred to a few thousand bases there; any query up to 2^20 bases here. One wavefront per
 // pair, Myers sweeps (lane b owns query block b, 64 blocks per pass; at step s lane b is at target column s - b and takes the
@@ -17,9 +17,12 @@
 //      lower-right part -- which of the equally good alignments comes out depends on these cuts, so they are edlib's. The
 //      recursion is a stack of frames in LDS, walked depth first (upper left first: the moves come out in order); the
 //      scratch of a pair is one leaf matrix (<= 1.26 MB) + two columns of ints, whatever the lengths.
-//      edlib computes these matrices inside a band around the diagonal; every score it reads there is the exact one, so
-//      whole exact columns give the same decisions (oracle/edlib_path_oracle.py makes the same argument on numpy columns and
-//      is pinned against the reference's edlib up to 60 kb).
+//      edlib computes these matrices inside a band around the diagonal; every score it READS there is the exact one, so any
+//      computation that is exact on the cells of alignments within the bound gives the same decisions: whole columns
+//      (oracle/edlib_path_oracle.py, numpy, pinned against the reference's edlib up to 60 kb) or the static band of the sweeps
+//      here (MyersBand below).
+// Kernels: k_myers_hw_path (a wavefront per pair, any length), k_myers_hw_path_grouped<8|16|32> (short queries, 64 / G pairs per
+// wavefront), k_myers_distance / k_myers_distance_grouped<G> (hs_edit_distance: NW / SHW / HW distance + first end location).
 // Alignment ops as edlib's: 0 match, 1 insertion (query base without target base), 2 deletion, 3 mismatch.
 // Sequences are 2-bit base codes (A C G T), as everywhere on this path. Included by hs_capi.hip after hs_kernels.hip.
 #pragma once
