@@ -613,6 +613,58 @@ def test_edit_distance_long_and_mixed_pairs_match_reference_edlib(built):
         assert len(bad) == 0, (mode, [(int(i), len(pairs[i][0]), len(pairs[i][1]), int(d[i]), int(e[i]), w[i].tolist()) for i in bad[:5]])
 
 
+def test_edlib_hw_path_random_pairs_against_the_numpy_restatement(built):
+    """Seeded random pairs of 1-2600 bases (substitutions, insertions, deletions at 0-35 %, unrelated pairs, repeats) through
+    hs_edlib_hw_align, against oracle/edlib_path_oracle.py -- the numpy restatement that the CPU suite pins on the reference's
+    edlib vectors. Covers sizes and error rates between the committed vectors."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import edlib_path_oracle as eo
+    from hairsplitter_amd import api
+    rng = np.random.default_rng(20261002)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rs = lambda n: acgt[rng.integers(0, 4, size=n)].tobytes().decode()
+
+    def mutate(q, rate):
+        out = []
+        for ch in q:
+            u = rng.random()
+            if u < rate / 3:
+                out.append("ACGT"[rng.integers(0, 4)])
+            elif u < 2 * rate / 3:
+                continue
+            elif u < rate:
+                out.append(ch); out.append("ACGT"[rng.integers(0, 4)])
+            else:
+                out.append(ch)
+        return "".join(out)
+    pairs = []
+    for i in range(64):
+        qn = int(rng.choice([1, 7, 63, 64, 65, 130, 300, 511, 513, 900, 1024, 1500, 2048, 2600]))
+        q = rs(qn)
+        kind = i % 4
+        if kind == 0:
+            t = rs(int(rng.integers(0, 400))) + mutate(q, float(rng.choice([0.0, 0.02, 0.1, 0.35]))) + rs(int(rng.integers(0, 400)))
+        elif kind == 1:
+            t = rs(int(rng.integers(1, 2 * qn + 2)))
+        elif kind == 2:
+            unit = rs(int(rng.integers(1, 6)))
+            q = (unit * (qn // len(unit) + 1))[:qn]
+            t = mutate(q, 0.08) + unit * 3
+        else:
+            t = mutate(q, 0.05)[: max(1, qn // 2)]
+        pairs.append((q, t or "A"))
+    got = api.edlib_hw_align(pairs)
+    for (q, t), g in zip(pairs, got):
+        e = eo.hw_align(q, t)
+        assert (g["distance"], g["end"]) == (e["distance"], e["end"]), (len(q), len(t))
+        if e["end"] >= 0:
+            assert g["start"] == e["start"], (len(q), len(t))
+        assert (g["ops"] is None) == (e["ops"] is None)
+        if e["ops"] is not None:
+            assert g["ops"].tolist() == e["ops"], (len(q), len(t))
+
+
 def test_stage5_edlib_call_sites(built):
     """The two stage-5 computations that sit on the reference's edlib calls, batched on the A1 kernel: the ends racon dropped are
     attached again (tools.cpp:505-536) and the overhangs are cut off the polished piece (create_new_contigs.cpp:556-629).
