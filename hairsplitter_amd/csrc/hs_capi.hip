@@ -1004,43 +1004,66 @@ int hs_edlib_hw_align(const uint8_t* d_query, const int64_t* h_query_off, const 
     // others take a wavefront each
     std::vector<int32_t> cls[4];      // 0: 8 lanes, 1: 16, 2: 32, 3: a wavefront
     const bool no_groups = std::getenv("HS_MYERS_NO_GROUPS") != nullptr;      // (diagnostic, read at every call: every pair on a wavefront of its own)
+    std::vector<int64_t> need_st((size_t)n_pairs, 0), need_hs((size_t)n_pairs, 0);
     for (int i = 0; i < n_pairs; ++i) {
         const int64_t qn = qo[(size_t)i + 1] - qo[(size_t)i], tn = to[(size_t)i + 1] - to[(size_t)i];
         const int64_t nb = (qn + 63) / 64;
         const bool one_leaf = 20 * nb * tn + 8 * tn < 1024 * 1024;      // edlib.cpp:1192-1196 on the whole target: on any part of it as well
         const int c = (no_groups || nb > 32 || (path && !one_leaf)) ? 3 : nb <= 8 ? 0 : nb <= 16 ? 1 : 2;
         cls[c].push_back(i);
-        hs_off[(size_t)i + 1] = hs_off[(size_t)i] + (c == 3 ? ((tn + 64 + 3) & ~(int64_t)3) + 4 * (tn + 64) : 0);      // deltas (bytes) and bottoms (ints) between two passes
-        st_off[(size_t)i + 1] = st_off[(size_t)i] + (path ? std::min<int64_t>(tn * nb, MY_LEAF_CELLS) * 3 : 0);      // one leaf matrix (edlib's 1-MB rule)
+        need_hs[(size_t)i] = c == 3 ? ((tn + 64 + 3) & ~(int64_t)3) + 4 * (tn + 64) : 0;      // deltas (bytes) and bottoms (ints) between two passes
+        need_st[(size_t)i] = path ? std::min<int64_t>(tn * nb, MY_LEAF_CELLS) * 3 : 0;      // one leaf matrix (edlib's 1-MB rule), in 8-byte words
         if (path && h_ops_off[i + 1] - h_ops_off[i] < qn + tn) { set_error("hs_edlib_hw_align: an alignment needs room for query + target operations"); return HS_EINVAL; }
     }
     if (path) oo.assign(h_ops_off, h_ops_off + n_pairs + 1);
+    // The pairs go out class by class, in chunks whose scratch (a leaf matrix per pair: up to 1.26 MB) stays within a budget: the
+    // launches of a stream run one after the other, so the next chunk takes the same scratch again (HS_MYERS_SCRATCH_MB, default 16384:
+    // 68 000 stage-5-sized pairs or 13 000 long ones at a time).
+    const char* bud = std::getenv("HS_MYERS_SCRATCH_MB");
+    const int64_t budget = std::max<int64_t>(2, bud ? std::atoll(bud) : 16384) * (1 << 20);
+    struct Slice { int cls; size_t begin, end; };
+    std::vector<Slice> slices;
     std::vector<int32_t> ids;
-    size_t cls_off[5] = {0, 0, 0, 0, 0};
-    for (int c = 0; c < 4; ++c) { ids.insert(ids.end(), cls[c].begin(), cls[c].end()); cls_off[c + 1] = ids.size(); }
+    int64_t cur_st = 0, cur_hs = 0, max_st = 0, max_hs = 0;
+    for (int c = 0; c < 4; ++c) {
+        size_t begin = ids.size();
+        for (int32_t i : cls[c]) {
+            if (cur_st > 0 && (cur_st + need_st[(size_t)i]) * 8 + cur_hs + need_hs[(size_t)i] > budget) {      // the chunk is full: what came before goes out, the scratch starts over
+                if (ids.size() > begin) slices.push_back(Slice{c, begin, ids.size()});
+                begin = ids.size(); cur_st = 0; cur_hs = 0;
+            }
+            st_off[(size_t)i] = cur_st; hs_off[(size_t)i] = cur_hs;
+            cur_st += need_st[(size_t)i]; cur_hs += need_hs[(size_t)i];
+            max_st = std::max(max_st, cur_st); max_hs = std::max(max_hs, cur_hs);
+            ids.push_back(i);
+        }
+        if (ids.size() > begin) slices.push_back(Slice{c, begin, ids.size()});
+    }
     DBuf d_qo, d_to, d_ho, d_so, d_oo, d_hs, d_st, d_cols, d_ids;
     UploadPack pk;
     pk.add(qo, d_qo); pk.add(to, d_to); pk.add(hs_off, d_ho); pk.add(st_off, d_so); pk.add(ids, d_ids);
     if (path) pk.add(oo, d_oo);
     if (int rc = pk.commit((hipStream_t)stream)) return rc;
-    if (int rc = d_hs.alloc(std::max<size_t>((size_t)hs_off.back(), 1))) return rc;
-    if (int rc = d_st.alloc(std::max<size_t>((size_t)st_off.back(), 1) * 8)) return rc;
+    if (int rc = d_hs.alloc(std::max<size_t>((size_t)max_hs, 1))) return rc;
+    if (int rc = d_st.alloc(std::max<size_t>((size_t)max_st, 1) * 8)) return rc;
     if (int rc = d_cols.alloc(std::max<size_t>(path && !cls[3].empty() ? (size_t)(qo.back() - qo.front()) * 2 : 0, 1) * sizeof(int32_t))) return rc;      // Hirschberg's two columns
     const int32_t* idp = d_ids.as<int32_t>();
     const int64_t* oop = path ? d_oo.as<int64_t>() : nullptr;
-#define HS_MYERS_GROUPED(G, c)                                                                                                                              \
-    if (!cls[c].empty())                                                                                                                                    \
-        hipLaunchKernelGGL(hsdev::k_myers_hw_path_grouped<G>, dim3((unsigned)((cls[c].size() + 64 / G - 1) / (64 / G))), dim3(64), 0, (hipStream_t)stream, d_query,    \
-                           d_qo.as<int64_t>(), d_target, d_to.as<int64_t>(), idp + cls_off[c], (int)cls[c].size(), d_st.as<unsigned long long>(), d_so.as<int64_t>(), \
-                           path ? 1 : 0, d_dist, d_start, d_end, d_ops, oop, d_ops_len);
-    HS_MYERS_GROUPED(8, 0)
-    HS_MYERS_GROUPED(16, 1)
-    HS_MYERS_GROUPED(32, 2)
+    for (const Slice& sl : slices) {
+        const int n = (int)(sl.end - sl.begin);
+#define HS_MYERS_GROUPED(G)                                                                                                                               \
+        hipLaunchKernelGGL(hsdev::k_myers_hw_path_grouped<G>, dim3((unsigned)((n + 64 / G - 1) / (64 / G))), dim3(64), 0, (hipStream_t)stream, d_query,        \
+                           d_qo.as<int64_t>(), d_target, d_to.as<int64_t>(), idp + sl.begin, n, d_st.as<unsigned long long>(), d_so.as<int64_t>(),        \
+                           path ? 1 : 0, d_dist, d_start, d_end, d_ops, oop, d_ops_len)
+        if (sl.cls == 0) HS_MYERS_GROUPED(8);
+        else if (sl.cls == 1) HS_MYERS_GROUPED(16);
+        else if (sl.cls == 2) HS_MYERS_GROUPED(32);
+        else
+            hipLaunchKernelGGL(hsdev::k_myers_hw_path, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_query, d_qo.as<int64_t>(), d_target, d_to.as<int64_t>(),
+                               idp + sl.begin, n, d_hs.as<int8_t>(), d_ho.as<int64_t>(), d_st.as<unsigned long long>(), d_so.as<int64_t>(), d_cols.as<int32_t>(),
+                               path ? 1 : 0, d_dist, d_start, d_end, d_ops, oop, d_ops_len);
 #undef HS_MYERS_GROUPED
-    if (!cls[3].empty())
-        hipLaunchKernelGGL(hsdev::k_myers_hw_path, dim3((unsigned)cls[3].size()), dim3(64), 0, (hipStream_t)stream, d_query, d_qo.as<int64_t>(), d_target, d_to.as<int64_t>(),
-                           idp + cls_off[3], (int)cls[3].size(), d_hs.as<int8_t>(), d_ho.as<int64_t>(), d_st.as<unsigned long long>(), d_so.as<int64_t>(), d_cols.as<int32_t>(),
-                           path ? 1 : 0, d_dist, d_start, d_end, d_ops, oop, d_ops_len);
+    }
     HS_HIP(hipGetLastError());
     return stream_wait((hipStream_t)stream);   // the scratch goes back to the pool with this scope
 }

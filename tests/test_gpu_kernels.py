@@ -585,6 +585,13 @@ def test_edlib_hw_path_every_lane_grouping_in_one_call(built):
     finally:
         del os.environ["HS_MYERS_NO_GROUPS"]
     _check_paths_against_vectors(vec, alone)
+    # the scratch of a call is bounded: with 2 MB of it the pairs go out in many chunks that take the same scratch in turn
+    os.environ["HS_MYERS_SCRATCH_MB"] = "2"
+    try:
+        chunked = api.edlib_hw_align([(v["query"], v["target"]) for v in vec])
+    finally:
+        del os.environ["HS_MYERS_SCRATCH_MB"]
+    _check_paths_against_vectors(vec, chunked)
 
 
 def test_edit_distance_long_and_mixed_pairs_match_reference_edlib(built):
