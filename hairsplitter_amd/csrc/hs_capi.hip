@@ -1028,7 +1028,7 @@ int hs_edlib_hw_align(const uint8_t* d_query, const int64_t* h_query_off, const 
     for (int c = 0; c < 4; ++c) {
         size_t begin = ids.size();
         for (int32_t i : cls[c]) {
-            if (cur_st > 0 && (cur_st + need_st[(size_t)i]) * 8 + cur_hs + need_hs[(size_t)i] > budget) {      // the chunk is full: what came before goes out, the scratch starts over
+            if ((cur_st > 0 || cur_hs > 0) && (cur_st + need_st[(size_t)i]) * 8 + cur_hs + need_hs[(size_t)i] > budget) {      // the chunk is full: what came before goes out, the scratch starts over
                 if (ids.size() > begin) slices.push_back(Slice{c, begin, ids.size()});
                 begin = ids.size(); cur_st = 0; cur_hs = 0;
             }
