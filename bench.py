@@ -344,6 +344,27 @@ def main():
         api.load().hs_cpuprof_stop()
     kstats = api.kernel_stats()
     thr1 = throttle_stats()
+    # After the timed region: the same job with ONE contig group (every kernel alone on the GPU), a few steps, to put the kernels' own
+    # durations next to the ones above -- with G groups a launch shares the GPU with the other groups' kernels and lasts longer.
+    kstats_alone = None
+    PROBE_STEPS = 3
+    if G > 1 and not use_dist and not fused and not os.environ.get("HS_BENCH_NO_PROBE"):
+        try:
+            probe = batch.sibling(1)
+            def probe_step():
+                pet()
+                cv1, sr1 = probe.run(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=window_size)
+                cv1 = sr1 = None
+            probe_step(); sync()
+            api.kernel_stats_reset()
+            for _ in range(PROBE_STEPS):
+                probe_step()
+            sync()
+            kstats_alone = api.kernel_stats()
+            api.load().hs_pipeline_destroy(probe.handle); probe.handle = None
+        except Exception as e:      # (a diagnostic leg: the line goes out without it)
+            kstats_alone = None
+            sys.stderr.write("one-group probe failed: %r\n" % (e,))
     throttled = None if thr0 is None or thr1 is None else {"periods": thr1[0] - thr0[0], "usec": thr1[1] - thr0[1]}
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -385,6 +406,15 @@ def main():
                  "frac_vs_kernel_time": whole_bytes / (t_kernels_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if t_kernels_ms > 0 else None,
                  "frac_vs_step_time": whole_bytes / (dt / K) / 1e9 / HBM_PEAK_GBS,
                  "note": "rank 0's shard; m = masked reads of the window (the kernels work in the window's local index space), not the N reads of the contig"}
+        alone = None
+        if kstats_alone and dom in kstats_alone and kstats_alone[dom]["ms"] > 0:
+            a = kstats_alone[dom]
+            a_gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+            alone = {"groups": 1, "steps": PROBE_STEPS, "launches_per_step": a["launches"] / PROBE_STEPS, "avg_launch_ms": a["ms"] / max(1, a["launches"]),
+                     "ms_per_step": a["ms"] / PROBE_STEPS, "achieved": a_gbs, "frac": a_gbs / HBM_PEAK_GBS,
+                     "kernels_ms_per_step": {k: round(v["ms"] / PROBE_STEPS, 4) for k, v in sorted(kstats_alone.items(), key=lambda kv: -kv[1]["ms"])[:12]},
+                     "note": "the same kernel, same job, ONE contig group: no other kernel of the path shares the GPU with a launch. Measured after the timed "
+                             "region (HIP events, %d steps); `frac` above is the per-launch average of the timed region, where %d groups overlap" % (PROBE_STEPS, G)}
         out = {
             "metric": "aligned read-bp/sec through call_variants+separate_reads",
             "value": total_bp * K / dt, "unit": "aligned read-bp/s", "n_gpus": 1 if emulated else world, "steps": K, "warmup": args.warmup, "setup_steps": SETUP_STEPS,
@@ -409,6 +439,7 @@ def main():
                          "launches_per_step": d["launches_per_step"], "ms_per_step": d["ms_per_step"],
                          "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                          "selection": "the kernel with the largest summed launch time per step among all kernels of the path (one slot per kernel, HIP events on each launch stream)",
+                         "alone": alone,
                          "whole_path": whole},
             "kernels": {k: {kk: (round(vv, 6) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]["ms_per_step"])},
             "step_ms": [round(x, 2) for x in step_ms],

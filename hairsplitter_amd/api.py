@@ -380,6 +380,15 @@ class PipelineGroups:
         self.aligned_bp = self.flat.aligned_bp
         self.total_len = int(self.flat.contig_off[-1])
 
+    def sibling(self, n_groups):
+        """Another pipeline over the SAME resident batch with its own number of contig groups (bench.py: one group, where every
+        kernel runs alone, to read the kernels' own durations next to those of the default run)."""
+        o = object.__new__(PipelineGroups)
+        o.flat, o.batch, o.aligned_bp, o.total_len = self.flat, self.batch, self.aligned_bp, self.total_len
+        o.handle = C.c_void_p()
+        _check(load().hs_pipeline_create(self.batch.handle, C.c_int32(n_groups), C.byref(o.handle)))
+        return o
+
     def run(self, automatic_snp_threshold=0.33, n_threads=0, error_rate_fn=None, rarest_strain_abundance=0.01, low_memory=False,
             amplicon=False, seed=12345, window_size=0):
         import time
