@@ -348,7 +348,9 @@ def main():
     # durations next to the ones above -- with G groups a launch shares the GPU with the other groups' kernels and lasts longer.
     kstats_alone = None
     PROBE_STEPS = 3
-    if G > 1 and not use_dist and not fused and not os.environ.get("HS_BENCH_NO_PROBE"):
+    # (not under a profiler: rocprofv3's per-kernel averages of this command stay those of the timed configuration)
+    profiled = any(os.environ.get(k) for k in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD")) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if G > 1 and not use_dist and not fused and not profiled and not os.environ.get("HS_BENCH_NO_PROBE"):
         try:
             probe = batch.sibling(1)
             def probe_step():
