@@ -568,9 +568,17 @@ int parse_col(const std::string& path, float rsa, std::vector<ColFileContig>& cs
                 cc.read_start.push_back((int32_t)atoi_n(sC.p, sC.n)); cc.read_end.push_back((int32_t)atoi_n(eC.p, eC.n));
             }
         }
+        // a SNPS line names reads by their place among the contig's READ lines: an index outside them (a damaged file) would be read
+        // as it stands by the reference (out of bounds there) and by the kernels here -- refused instead
+        if (!rc_of[(size_t)b]) {
+            const int32_t nr = (int32_t)cc.read_start.size();
+            for (int32_t v : cc.col_idx) if (v < 0 || v >= nr) { rc_of[(size_t)b] = 2; err_of[(size_t)b] = cc.contig_line; break; }
+        }
     });
-    for (size_t b = 0; b < starts.size(); ++b)
-        if (rc_of[b]) { std::cout << "error in parsing read limits" << std::endl << "line : " << err_of[b] << std::endl; return 1; }
+    for (size_t b = 0; b < starts.size(); ++b) {
+        if (rc_of[b] == 1) { std::cout << "error in parsing read limits" << std::endl << "line : " << err_of[b] << std::endl; return 1; }
+        if (rc_of[b] == 2) { std::cout << "error in parsing SNPS: a read index outside the contig's READ lines" << std::endl << "contig : " << err_of[b] << std::endl; return 1; }
+    }
     return 0;
 }
 

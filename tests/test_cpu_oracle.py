@@ -131,6 +131,26 @@ def test_alignment_path_oracle_matches_edlib_vectors():
     assert stats["splits"] > 20 and stats["leaves"] > 40      # both of obtainAlignment's branches were taken
 
 
+def test_col_file_with_a_read_index_outside_the_read_list_is_refused(built):
+    """A damaged .col whose SNPS line names a read beyond the contig's READ lines: the reference indexes out of bounds, the kernels
+    would too -- hs::parse_col refuses the file (found by running mutated inputs through the AddressSanitizer build of the harness,
+    tools/host_asan.py)."""
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack("simple_mock", td)
+        p = os.path.join(td, "variants.col")
+        lines = open(p).read().split("\n")
+        k = next(i for i, l in enumerate(lines) if l.startswith("SNPS"))
+        f = lines[k].split("\t")
+        idx = f[4].split(",")
+        idx[0] = "999999"
+        f[4] = ",".join(idx)
+        lines[k] = "\t".join(f)
+        open(p, "w").write("\n".join(lines))
+        r = subprocess.run([built["harness"], "separate_reads", p, "1", meta["error_rate_arg"], os.path.join(td, "absent_ploidy.txt"), "0", "0.01", "0",
+                            os.path.join(td, "o.gro"), "0"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        assert r.returncode != 0 and b"read index outside" in r.stdout, r.stdout[-500:]
+
+
 def test_c_abi_exports_every_declared_symbol(built):
     from hairsplitter_amd import api
     hdr = open(os.path.join(ROOT, "include", "hairsplitter_hip.h")).read()
