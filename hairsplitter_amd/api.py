@@ -25,7 +25,7 @@ SYMBOLS = [
     "hs_pipeline_run_fused", "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_host_wait_stats", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
 ]
 
-HS_NKERNELS = 25
+HS_NKERNELS = 27
 
 
 class HsError(RuntimeError):

@@ -266,6 +266,29 @@ static int d2h_pinned(void* dst, const void* d, size_t n, hipStream_t s) {
     return HS_OK;
 }
 
+// a transfer queued as a kernel (hsdev::k_ship: pinned host memory is mapped into the device's address space); segments whose length
+// is a count on the device take it from there when the kernel runs
+struct Shipment {
+    hsdev::ShipList L;
+    Shipment() { L.n = 0; }
+    void add(void* dst, const void* src, size_t bytes) {
+        if (!bytes) return;
+        hsdev::ShipSeg& g = L.seg[L.n++];
+        g.src = src; g.dst = dst; g.bytes = (long long)bytes; g.count = nullptr; g.stride = 0; g.cap = 0; g.extra = 0;
+    }
+    void add_counted(void* dst, const void* src, const long long* d_count, size_t stride, long long cap, size_t extra = 0) {
+        hsdev::ShipSeg& g = L.seg[L.n++];
+        g.src = src; g.dst = dst; g.bytes = 0; g.count = d_count; g.stride = (long long)stride; g.cap = cap; g.extra = (long long)extra;
+    }
+    int launch(hipStream_t s, int blocks = 256) {
+        if (L.n == 0) return HS_OK;
+        hipLaunchKernelGGL(hsdev::k_ship, dim3((unsigned)blocks), dim3(256), 0, s, L);
+        HS_HIP(hipGetLastError());
+        L.n = 0;
+        return HS_OK;
+    }
+};
+
 struct EventPair {
     hipEvent_t a = nullptr, b = nullptr;
     static std::vector<hipEvent_t>& cache() { static thread_local std::vector<hipEvent_t> c; return c; }
@@ -391,7 +414,7 @@ const char* hs_kernel_name(int k) {
     static const char* names[HS_NKERNELS] = {"k_cigar_scan", "k_pileup_packed", "k_column_stats_tiled", "k_columns_compact", "k_gather_tiles", "k_column_top3_exact",
                                              "k_candidates_scan", "k_pack_flagged", "k_partition_transpose", "k_column_partition_lanes", "k_column_partition_test",
                                              "k_snp_flags", "k_window_masks", "k_snp_planes", "k_simdiff", "k_read_graph_rows", "k_read_graph_fill", "k_cw_visit_lists",
-                                             "k_cw_seed_sets", "k_cw_seeded_lanes", "k_cw_seeded_rows", "k_window_tail", "k_cw_local", "k_loop_a", "other"};
+                                             "k_cw_seed_sets", "k_cw_seeded_lanes", "k_cw_seeded_rows", "k_window_tail", "k_cw_local", "k_loop_a", "other", "k_cand_bits", "k_ship"};
     return k >= 0 && k < HS_NKERNELS ? names[k] : "?";
 }
 void hs_kernel_stats_reset(void) { KernelTable& t = kernel_table(); std::lock_guard<std::mutex> g(t.mu); std::memset(&t.st, 0, sizeof t.st); }
@@ -1463,14 +1486,53 @@ struct HipCvOps : hs::CvDeviceOps {
         return HS_OK;
     }
 
-    int fetch_candidates(hs::CvCandidates& out) override {      // the packed candidates of the last extract_candidates(), after all
+    // The packed candidates as bit sets (k_cand_bits) straight into pinned host memory, with their records: what loop A reads.
+    // The word blocks are bump-allocated on the device; a capacity that does not suffice doubles and the kernel runs again.
+    DBuf d_cb_bits, d_cb_words, d_cb_counter;
+    HBuf h_cb;
+    int64_t cb_words_hint = 0;        // words the blocks took last time (kept by the caller from step to step: HipCvKeep)
+    int ship_cand_bits(hs::CvCandidates& out) {
+        out.bits = nullptr; out.words = nullptr;
         if (cand_count == 0) return HS_OK;
-        if (int rc = grow(h_pk, std::max<size_t>(cand_layout.total, 256))) return rc;
-        if (int rc = copy_d2h(h_pk.p, d_cand_pk.p, cand_layout.total, stream)) return rc;
-        const char* hb = (const char*)h_pk.p;
-        out.rec = (const hs_colrec*)(hb + cand_layout.rec); out.col = (const int32_t*)(hb + cand_layout.col); out.off = (const int64_t*)(hb + cand_layout.off);
-        out.idx = (const int32_t*)(hb + cand_layout.idx); out.code = (const uint8_t*)(hb + cand_layout.code);
-        return HS_OK;
+        static_assert(sizeof(hs::CandBits) == sizeof(hsdev::CandBitsDev), "CandBits layout");
+        const char* cb = (const char*)d_cand_pk.p;
+        int64_t cap_words = std::max<int64_t>(cb_words_hint + cb_words_hint / 8, 16 * cand_count + cand_entries / 4) + 64;
+        for (int attempt = 0;; ++attempt) {
+            if (int rc = grow(d_cb_bits, (size_t)cand_count * 32)) return rc;
+            if (int rc = grow(d_cb_words, (size_t)cap_words * 8)) return rc;
+            if (int rc = grow(d_cb_counter, 256)) return rc;
+            const size_t o_rec = 256, o_bits = o_rec + (((size_t)cand_count * 16 + 255) & ~(size_t)255), o_words = o_bits + (((size_t)cand_count * 32 + 255) & ~(size_t)255);
+            if (int rc = grow(h_cb, o_words + (size_t)cap_words * 8 + 256)) return rc;
+            hipLaunchKernelGGL(hsdev::k_fill16, dim3(1), dim3(64), 0, stream, d_cb_counter.as<uint4>(), 16ll, 0u);
+            if (int rc = kc.begin(HS_K_CAND_BITS, stream)) return rc;
+            hipLaunchKernelGGL(hsdev::k_cand_bits, dim3((unsigned)((cand_count + HS_CB_WAVES - 1) / HS_CB_WAVES)), dim3(64 * HS_CB_WAVES), 0, stream, (const hsdev::hs_colrec_dev*)(cb + cand_layout.rec),
+                               (const int64_t*)(cb + cand_layout.off), (const int32_t*)(cb + cand_layout.idx), (const uint8_t*)(cb + cand_layout.code), dev_header(),
+                               (long long)cand_count, b->d_contig_rec_off.as<int32_t>(), b->d_rank_of.as<int32_t>(), b->d_read_end.as<int32_t>(),
+                               d_cb_bits.as<hsdev::CandBitsDev>(), d_cb_words.as<unsigned long long>(), (long long)cap_words, d_cb_counter.as<unsigned long long>());
+            HS_HIP(hipGetLastError());
+            if (int rc = kc.end(5 * cand_entries + 48 * cand_count, stream)) return rc;      // the candidates' entries in; record, header and block out
+            Shipment sh;
+            sh.add(h_cb.p, d_cb_counter.p, 16);
+            sh.add((char*)h_cb.p + o_rec, cb + cand_layout.rec, (size_t)cand_count * 16);
+            sh.add((char*)h_cb.p + o_bits, d_cb_bits.p, (size_t)cand_count * 32);
+            sh.add_counted((char*)h_cb.p + o_words, d_cb_words.p, d_cb_counter.as<long long>(), 8, cap_words);
+            if (int rc = sh.launch(stream)) return rc;
+            if (int rc = stream_wait(stream)) return rc;
+            const unsigned long long* cnt = (const unsigned long long*)h_cb.p;
+            if (cnt[1] == 0) {
+                cb_words_hint = (int64_t)cnt[0];
+                out.rec = (const hs_colrec*)((const char*)h_cb.p + o_rec);
+                out.bits = (const hs::CandBits*)((const char*)h_cb.p + o_bits);
+                out.words = (const uint64_t*)((const char*)h_cb.p + o_words);
+                return HS_OK;
+            }
+            if (attempt >= 8 || (int64_t)cnt[0] <= cap_words) { set_error("candidate bit sets: a column spans more than 65535 words of reads"); return HS_EINVAL; }
+            cap_words = (int64_t)cnt[0] + 64;      // (the counter ran on past the capacity: it is the exact need)
+        }
+    }
+    int fetch_candidates(hs::CvCandidates& out) override {      // the candidates of the last extract_candidates() for the host's loop A, after all
+        if (cand_count == 0) return HS_OK;
+        return ship_cand_bits(out);
     }
     DBuf d_cand_pk;                   // the packed candidates (kept beside d_pk, which the SNPs take later): k_loop_a reads them
     PackLayout cand_layout{};
@@ -1567,20 +1629,17 @@ struct HipCvOps : hs::CvDeviceOps {
         HS_HIP(hipGetLastError());
         if (int rc = kc.end(43 * n_cols, stream)) return rc;      // record in and out, the four arrays K4 reads out
         HS_HIP(hipEventRecord(e_k3b.b, stream));
-        // ---- the candidates, packed, to the host ----
+        // ---- the candidates, packed (they stay on the device); the host's loop A gets them as bit sets ----
         int64_t n_cand = 0, e_cand = 0;
-        if (int rc = pack_flagged(HS_COL_CAND, want_entries ? 2 : 0, &n_cand, &e_cand)) return rc;      // (its info download carries the per-contig counts and the tie counters)
+        if (int rc = pack_flagged(HS_COL_CAND, 0, &n_cand, &e_cand)) return rc;      // (its info download carries the per-contig counts and the tie counters)
         std::memcpy(out.contig_n_cand.data(), host_ctg_n(), (size_t)C * 4);
         cand_per_contig = out.contig_n_cand; cand_count = n_cand; cand_entries = e_cand; cand_layout = pk_layout;
         std::swap(d_cand_pk, d_pk);      // (d_pk is packed again for the SNPs)
         { unsigned long long t2[2]; std::memcpy(t2, (const char*)h_info.p + 64, 16); out.n_tie = (int64_t)t2[0]; out.n_tie_big = (int64_t)t2[1]; }
-        if (int rc = stream_wait(stream)) return rc;
         out.n_cand = n_cand;
-        if (n_cand > 0 && want_entries) {
-            const char* hb = (const char*)h_pk.p;
-            out.rec = (const hs_colrec*)(hb + pk_layout.rec); out.col = (const int32_t*)(hb + pk_layout.col); out.off = (const int64_t*)(hb + pk_layout.off);
-            out.idx = (const int32_t*)(hb + pk_layout.idx); out.code = (const uint8_t*)(hb + pk_layout.code);
-        } else { static const int64_t zero_off[1] = {0}; out.off = zero_off; }
+        { static const int64_t zero_off[1] = {0}; out.off = zero_off; }
+        if (n_cand > 0 && want_entries) { if (int rc = ship_cand_bits(out)) return rc; }
+        else if (int rc = stream_wait(stream)) return rc;
         kc.flush();
         if (int rc = e_k2.ms(&k_ms[0])) return rc;
         if (int rc = e_k3.ms(&k_ms[1])) return rc;

@@ -243,7 +243,6 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
     // ---- the partition logic: loop A (device, or host), loop B on the host ----
     std::vector<CvContigState*> cst((size_t)C, nullptr);
     for (int c = 0; c < C; ++c) cst[(size_t)c] = cv_state_new();
-    std::vector<std::vector<int32_t>> rend((size_t)C);
     std::vector<int32_t> n_reads_of((size_t)C);
     parallel_for(C, n_threads, [&](int c) {
         const int gc = c0 + c;   // index in the batch
@@ -262,17 +261,12 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
         if (some_on_host) { if (int rc = dev.fetch_candidates(cand)) return rc; }      // (rare: the tables of the kernel did not hold a contig)
         laps.lap("loop_a");
     }
-    if (some_on_host)
-        parallel_for(C, n_threads, [&](int c) {
-            if (on_device && !la.failed[(size_t)c]) return;
-            const int r0 = b.contig_rec_off[(size_t)(c0 + c)];
-            rend[(size_t)c].resize((size_t)n_reads_of[(size_t)c]);
-            for (int r = 0; r < n_reads_of[(size_t)c]; ++r) rend[(size_t)c][(size_t)r] = (int32_t)std::min<int64_t>(b.rec_pos[(size_t)(r0 + r)] + b.rec_refspan[(size_t)(r0 + r)], 0x7fffffff);
-        });
+    if (some_on_host && cand.n_cand > 0 && !cand.bits) { set_error("cv_run_range: the device interface handed no bit sets of the candidate columns"); return HS_EINVAL; }
     auto candidates_of = [&](int c) {
         CandidateSet cs;
         cs.n = cand.contig_n_cand[(size_t)c];
-        cs.rec = cand.rec + cand_base[(size_t)c]; cs.off = cand.off + cand_base[(size_t)c]; cs.idx = cand.idx; cs.code = cand.code;
+        cs.rec = cand.rec + cand_base[(size_t)c]; cs.bits = cand.bits + cand_base[(size_t)c]; cs.words = cand.words;
+        if (cand.idx) { cs.off = cand.off + cand_base[(size_t)c]; cs.idx = cand.idx; cs.code = cand.code; }      // (raw entries: the harness's cross-check only)
         return cs;
     };
     static const bool loop_b_pairs = []() { const char* e = std::getenv("HS_LOOP_B_PAIRS_ON_DEVICE"); return e && e[0] != '0'; }();
@@ -291,7 +285,7 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
             cv_phase_a_import(*cst[(size_t)c], b.rec_pos.data() + r0, (int)(la.part_base[(size_t)c + 1] - la.part_base[(size_t)c]), la.rec + la.part_base[(size_t)c],
                               la.bits + la.bits_base[(size_t)c], la.cnt + la.cnt_base[(size_t)c]);
             (void)N;
-        } else { cv_phase_a_host(*cst[(size_t)c], candidates_of(c), b.rec_pos.data() + r0, rend[(size_t)c].data()); n_host_a++; }
+        } else { cv_phase_a_host(*cst[(size_t)c], candidates_of(c), b.rec_pos.data() + r0); n_host_a++; }
         if (!pairs_on_device) cv_phase_b(*cst[(size_t)c], res[(size_t)c]);
     });
     if (pairs_on_device) {

@@ -39,8 +39,12 @@ struct CvCandidates {
     const hs_colrec* rec = nullptr;          // [n_cand]
     const int32_t* col = nullptr;            // [n_cand] index of the candidate in the implementation's column list
     const int64_t* off = nullptr;            // [n_cand + 1]
-    const int32_t* idx = nullptr;            // read indices (ascending inside a column)
+    const int32_t* idx = nullptr;            // read indices (ascending inside a column); idx / code may be null when `bits` is given
     const uint8_t* code = nullptr;
+    // the same columns as bit sets over the reads ranked by start position (hs::CandBits, hs_host.h): what loop A reads.
+    // word_off counts from `words`; bits[k] belongs to rec[k]
+    const CandBits* bits = nullptr;          // [n_cand]
+    const uint64_t* words = nullptr;
 };
 // ... and at its end: the SNPs (call_variants.cpp:1335-1352), same layout; idx / code only when they were asked for
 struct CvSnpSet {

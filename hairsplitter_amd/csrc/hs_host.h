@@ -15,15 +15,41 @@ namespace hs {
 void set_error(const std::string& msg);
 
 // ---- stage 3 ---------------------------------------------------------------------------------
+// A candidate column as loop A reads it: the reads of the column as one bit set per distinct code, bit k = the read of RANK k in
+// the order of the reads' start positions on the contig (ties by read index). The reads of a column all cover its position, so
+// they sit in a few neighbouring 64-read words whatever the order of the records in the SAM file. Built on the device
+// (k_cand_bits) from the packed candidate columns; 32 bytes + a block of 64-bit words per column.
+struct CandBits {
+    int32_t wlo;                // first word the column's reads lie in
+    uint16_t n_words;           // words it spans (0: a column without entries)
+    uint16_t n_slots;           // distinct codes, in the order their first read (ascending read index) brings them
+    int32_t idx_min, idx_max;   // first / last read index of the column
+    int32_t reach;              // largest (exclusive) end position of its reads
+    int32_t n_entries;
+    int64_t word_off;           // its block in the word array: any[n_words], slot bits [n_slots][n_words], the slots' codes 8 per word
+};
+static_assert(sizeof(CandBits) == 32, "CandBits layout");
+inline int64_t cand_bits_block_words(int n_words, int n_slots) { return (int64_t)n_words * (n_slots + 1) + (n_slots + 7) / 8; }
+
 // The candidate columns of one contig (call_variants.cpp:525-536), position order: views into what the device handed over
-// (the device extracts the columns, names their two leading codes in the reference's order and runs the spacing scan).
+// (the device extracts the columns, names their two leading codes in the reference's order, runs the spacing scan and turns
+// every candidate into bit sets). off / idx / code (the raw entries) are optional: only the cross-check of the test harness walks them.
 struct CandidateSet {
     int n = 0;
     const hs_colrec* rec = nullptr;  // [n] position, codes k0 / k1, counts
+    const CandBits* bits = nullptr;  // [n]
+    const uint64_t* words = nullptr; // the blocks (CandBits::word_off)
     const int64_t* off = nullptr;    // [n+1] into idx / code
     const int32_t* idx = nullptr;    // read indices (ascending inside a column)
     const uint8_t* code = nullptr;
 };
+// The same from raw entries on the host: what k_cand_bits computes, restated (the test harness's device interface and the kernel's
+// unit test use it; the product gets the bit sets from the device). rank_of: read -> rank, read_end: read -> exclusive end position.
+// Appends the blocks to `words`, fills bits[0..n).
+void cv_build_cand_bits(int n, const int64_t* off, const int32_t* idx, const uint8_t* code, const int32_t* rank_of, const int32_t* read_end,
+                        CandBits* bits, std::vector<uint64_t>& words);
+// reads of a contig ranked by start position (ties by index): rank_of[read] and orig_of[rank] (padded to a multiple of 64)
+void cv_rank_reads(int n_reads, const int32_t* read_start, std::vector<int32_t>& rank_of, std::vector<int32_t>& orig_of);
 
 struct ContigCvResult {
     float mean_distance = 0;
@@ -37,10 +63,10 @@ CvContigState* cv_state_new();
 void cv_state_free(CvContigState* st);
 // The host part of keep_only_robust_variants in steps: loop A on the host (cv_phase_a_host) or imported from the device
 // (k_loop_a -> cv_phase_a_import), then loop B (cv_phase_b); the final partitions leave for loops C / D on the device.
-// read_start / read_end: [n_reads] reference interval [start, end) of every record of the contig (POS-1, POS-1 + reference span)
+// read_start: [n_reads] POS-1 of every record of the contig (the bit order of every bit set: ranks by start position)
 struct CvPartRecord { int32_t left, right, n_occ, n_corr, lo, hi, reach, pad; int64_t elem; };   // what k_loop_a_pack writes per partition
 void cv_phase_begin(CvContigState& st, int n_reads, int n_candidates, float mean_distance, ContigCvResult& out);
-void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* read_start, const int32_t* read_end);
+void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* read_start);
 // bits: the contig's partitions, 3 W words each (present, plus, minus over the reads ranked by start position); cnt: N counters each
 // (more | less << 16); rec[p].elem is not used here
 void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const uint64_t* bits, const int32_t* cnt);

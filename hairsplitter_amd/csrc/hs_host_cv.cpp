@@ -6,11 +6,13 @@
 // What is left here is the reference's inherently sequential logic in between: the evolving set of partitions of
 // keep_only_robust_variants (loops A and B, :577-708), whose decisions go through libm (lgamma / exp / log).
 //
-// Representation: a partition is three dense arrays over the contig's N reads (state, more, less) instead of
-// the reference's sorted sparse lists, so comparing a column with a partition costs O(column depth) instead of
-// O(|partition| + depth), and augmenting is element-wise. Results are identical because every rule of
-// Partition.cpp is per shared read; only loops whose floating-point accumulation order is observable
-// (compute_conf) are run in ascending read order.
+// Representation (round 4: everything in RANK space): the reads of a contig are ranked by start position; a partition is three
+// bit sets over the ranks (present / state +1 / state -1) plus two counters per rank (more, less) instead of the reference's
+// sorted sparse lists, a candidate column arrives from the device as one bit set per distinct code (hs::CandBits). Comparing a
+// column with a partition is popcounts of ANDs over the one or two words both occupy; augmenting is word-wise set algebra plus a
+// counter bump per read of the column; no per-entry walk, no per-read state array. Results are identical because every rule
+// of Partition.cpp is per shared read; only loops whose floating-point accumulation order is observable (compute_conf) are
+// run in ascending read order.
 //
 // Loop D of the reference (:745-764) evaluates every position of the contig against every final partition; a
 // rescue needs n10+n00 > 4 (:756), i.e. some non-reference code carried by >= 5 reads, so only positions whose
@@ -30,7 +32,7 @@ namespace hs {
 
 static constexpr int8_t ABSENT = 2;
 
-// Storage of the partitions of a contig: every partition is nine bytes per read of the contig plus its bit sets, a few
+// Storage of the partitions of a contig: every partition is eight bytes per read of the contig plus its bit sets, a few
 // thousand partitions are made and dropped per contig group and step -- as individual std::vectors that was a seventh of
 // the host's CPU time in malloc / free / memset. Partitions are bump-allocated from 1-MiB blocks instead; the blocks come
 // from and go back to a process-wide cache when the contig's state dies.
@@ -61,54 +63,56 @@ struct PartitionArena {
     ~PartitionArena() { for (char* b : blocks) block_cache().put(b); for (char* b : big) std::free(b); }
 };
 
-struct DensePartition {
+
+// A partition in rank space. State of rank k: absent (present bit clear), +1 (plus), -1 (minus), 0 (present only).
+// more / less are only meaningful where the present bit is set (never cleared beforehand: a partition is 8 bytes per read of
+// the contig and a few thousand are made per contig group and step).
+struct RankPartition {
     int left = -1, right = -1;
     int n_occ = 0;                 // numberOfOccurences
     int n_corr = 0;                // number_of_correlating_snps
-    int lo = 0, hi = -1;           // present reads lie in [lo, hi]
-    int8_t* state = nullptr;       // [n_reads] ABSENT, or mostFrequentBases in {-1,0,1}
-    int32_t* more = nullptr;       // [n_reads]
-    int32_t* less = nullptr;
+    int lo = 0, hi = -1;           // present reads lie in [lo, hi] (read indices)
     int n_reads = 0, words = 0;
-    // the same states as bit sets over the reads (loop A compares every candidate column with every live partition:
-    // popcounts of ANDs instead of a walk over the column entries); maintained by partition_from_column() and augment().
-    // Bit k = the read of RANK k in the order of the reads' start positions: the reads of a column (all of them cover its
-    // position) and of a partition (they cover SNPs a few kb apart) then sit in a few neighbouring words, [wlo, whi], whatever
-    // the order of the records in the SAM file; only those words are looked at.
     uint64_t* present = nullptr;   // [words] each
     uint64_t* plus = nullptr;
     uint64_t* minus = nullptr;
+    int32_t* more = nullptr;       // [words * 64] by rank
+    int32_t* less = nullptr;
     const int32_t* rank_of = nullptr;
     const int32_t* orig_of = nullptr;   // rank -> read
     int wlo = 0, whi = -1;         // words that hold present reads
     int survivor = -1;             // loop B with pair distances from the device: ordinal among the partitions that pass its gate,
     bool pristine = true;          // and whether this (final) partition still is what was uploaded (no merge into it yet)
     int reach = -1;                // largest (exclusive) end position of a present read: no read of the partition covers a position >= reach
-    // storage from the contig's arena: every read absent, counters and bit sets zero
     void allocate(PartitionArena& arena, int n) {
         n_reads = n; words = (n + 63) >> 6;
-        const size_t counters = ((size_t)n * 4 + 63) & ~(size_t)63, states = ((size_t)n + 63) & ~(size_t)63, bits = (size_t)words * 8;
-        char* p = (char*)arena.alloc(2 * counters + states + 3 * bits);
-        std::memset(p, 0, 2 * counters + states + 3 * bits);
-        more = (int32_t*)p; less = (int32_t*)(p + counters); state = (int8_t*)(p + 2 * counters);
-        present = (uint64_t*)(p + 2 * counters + states); plus = present + words; minus = plus + words;
-        std::memset(state, ABSENT, (size_t)n);
+        const size_t counters = (size_t)words * 64 * 4, bits = (size_t)words * 8;
+        char* p = (char*)arena.alloc(3 * bits + 2 * counters);
+        std::memset(p, 0, 3 * bits);
+        present = (uint64_t*)p; plus = present + words; minus = plus + words;
+        more = (int32_t*)(p + 3 * bits); less = more + (size_t)words * 64;
     }
-    void copy_from(const DensePartition& o) {      // same contig: same sizes (this partition's own storage is kept)
-        int8_t* s = state; int32_t* mo = more; int32_t* le = less; uint64_t* pr = present; uint64_t* pl = plus; uint64_t* mi = minus;
+    void copy_from(const RankPartition& o) {      // same contig: same sizes (this partition's own storage is kept)
+        uint64_t* pr = present; int32_t* mo = more; int32_t* le = less;
         *this = o;
-        state = s; more = mo; less = le; present = pr; plus = pl; minus = mi;
-        std::memcpy(state, o.state, (size_t)n_reads); std::memcpy(more, o.more, (size_t)n_reads * 4); std::memcpy(less, o.less, (size_t)n_reads * 4);
-        std::memcpy(present, o.present, (size_t)words * 8); std::memcpy(plus, o.plus, (size_t)words * 8); std::memcpy(minus, o.minus, (size_t)words * 8);
+        present = pr; plus = pr + words; minus = plus + words; more = mo; less = le;
+        std::memcpy(present, o.present, (size_t)words * 24);
+        if (o.whi >= o.wlo) {
+            const size_t a = (size_t)o.wlo * 64, n = (size_t)(o.whi - o.wlo + 1) * 64;
+            std::memcpy(more + a, o.more + a, n * 4); std::memcpy(less + a, o.less + a, n * 4);
+        }
     }
-    void sync_bits(int r) {
-        const int k = rank_of[r];
-        const uint64_t b = 1ull << (k & 63);
-        const size_t w = (size_t)k >> 6;
-        const int8_t s = state[(size_t)r];
-        if (s == 2) present[w] &= ~b; else { present[w] |= b; if (whi < wlo) { wlo = whi = (int)w; } else { if ((int)w < wlo) wlo = (int)w; if ((int)w > whi) whi = (int)w; } }
-        if (s == 1) plus[w] |= b; else plus[w] &= ~b;
-        if (s == -1) minus[w] |= b; else minus[w] &= ~b;
+    void touch_word(int w) { if (whi < wlo) { wlo = whi = w; } else { if (w < wlo) wlo = w; if (w > whi) whi = w; } }
+    int state_at(int k) const {      // 2 = absent
+        const uint64_t b = 1ull << (k & 63); const size_t w = (size_t)k >> 6;
+        if (!(present[w] & b)) return ABSENT;
+        return (plus[w] & b) ? 1 : ((minus[w] & b) ? -1 : 0);
+    }
+    void set_state(int k, int s) {   // s in {-1, 0, 1}: present with that state
+        const uint64_t b = 1ull << (k & 63); const size_t w = (size_t)k >> 6;
+        present[w] |= b;
+        if (s == 1) { plus[w] |= b; minus[w] &= ~b; } else if (s == -1) { minus[w] |= b; plus[w] &= ~b; } else { plus[w] &= ~b; minus[w] &= ~b; }
+        touch_word((int)w);
     }
 };
 
@@ -124,6 +128,7 @@ float mean_distance_from_counts(int64_t n_err, int64_t n_len) {
     double total_length = 1.0 + (double)n_len;
     return (float)(total_distance / total_length);
 }
+
 
 // most frequent non-reference code among `codes` restricted to the entries flagged in `take`
 // (first in robin_hood iteration order on ties: call_variants.cpp:837-844, Partition.cpp:59-66).
@@ -181,23 +186,74 @@ static uint8_t second_most_frequent(const uint8_t* code, int n, const uint8_t* t
     return second_from_seen(seen, cnt, nseen, ref, signed_ref_quirk, insert_ref_last, dflt);
 }
 
+
+// A candidate column as loop A sees it: views into the device's block (hs::CandBits)
+struct ColView {
+    int wlo = 0, whi = -1, W = 0, nslots = 0, n_entries = 0;
+    const uint64_t* any = nullptr;     // [W]
+    const uint64_t* slots = nullptr;   // [nslots][W]
+    const uint8_t* codes = nullptr;    // [nslots]
+    int idx_min = 0, idx_max = -1, reach = -1;
+    ColView(const CandBits& h, const uint64_t* words) {
+        wlo = h.wlo; W = h.n_words; whi = h.wlo + (int)h.n_words - 1; nslots = h.n_slots; n_entries = h.n_entries;
+        any = words + h.word_off; slots = any + W; codes = reinterpret_cast<const uint8_t*>(slots + (size_t)nslots * W);
+        idx_min = h.idx_min; idx_max = h.idx_max; reach = h.reach;
+    }
+    int slot_of(uint8_t code) const { for (int k = 0; k < nslots; ++k) if (codes[k] == code) return k; return -1; }
+    const uint64_t* slot(int k) const { return slots + (size_t)k * W; }
+};
+
+void cv_rank_reads(int n_reads, const int32_t* read_start, std::vector<int32_t>& rank_of, std::vector<int32_t>& orig_of) {
+    rank_of.assign((size_t)n_reads, 0); orig_of.assign((size_t)((n_reads + 63) / 64) * 64, 0);
+    std::vector<int32_t> order((size_t)n_reads);
+    for (int r = 0; r < n_reads; ++r) order[(size_t)r] = r;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return read_start[a] != read_start[b] ? read_start[a] < read_start[b] : a < b; });
+    for (int k = 0; k < n_reads; ++k) { rank_of[(size_t)order[(size_t)k]] = k; orig_of[(size_t)k] = order[(size_t)k]; }
+}
+
+// what k_cand_bits computes, restated on the host (see hs_host.h)
+void cv_build_cand_bits(int n_cols, const int64_t* off, const int32_t* idx, const uint8_t* code, const int32_t* rank_of, const int32_t* read_end,
+                        CandBits* bits, std::vector<uint64_t>& words) {
+    for (int c = 0; c < n_cols; ++c) {
+        const int32_t* ci = idx + off[c]; const uint8_t* cc = code + off[c];
+        const int n = (int)(off[c + 1] - off[c]);
+        CandBits& h = bits[c];
+        h.n_entries = n; h.word_off = (int64_t)words.size();
+        if (n == 0) { h.wlo = 0; h.n_words = 0; h.n_slots = 0; h.idx_min = 0; h.idx_max = -1; h.reach = -1; continue; }
+        int lo = 0x7fffffff, hi = -1, reach = -1;
+        for (int i = 0; i < n; ++i) { const int w = rank_of[ci[i]] >> 6; lo = std::min(lo, w); hi = std::max(hi, w); reach = std::max(reach, read_end[ci[i]]); }
+        const int W = hi - lo + 1;
+        uint8_t codes[256]; int slot_of[256]; int nslots = 0;
+        std::fill(slot_of, slot_of + 256, -1);
+        for (int i = 0; i < n; ++i) if (slot_of[cc[i]] < 0) { slot_of[cc[i]] = nslots; codes[nslots++] = cc[i]; }
+        h.wlo = lo; h.n_words = (uint16_t)W; h.n_slots = (uint16_t)nslots; h.idx_min = ci[0]; h.idx_max = ci[n - 1]; h.reach = reach;
+        const size_t base = words.size();
+        words.resize(base + (size_t)cand_bits_block_words(W, nslots), 0ull);
+        uint64_t* any = words.data() + base; uint64_t* sl = any + W;
+        for (int i = 0; i < n; ++i) {
+            const int k = rank_of[ci[i]];
+            const uint64_t b = 1ull << (k & 63);
+            any[(k >> 6) - lo] |= b;
+            sl[(size_t)slot_of[cc[i]] * W + ((k >> 6) - lo)] |= b;
+        }
+        std::memcpy(reinterpret_cast<uint8_t*>(sl + (size_t)nslots * W), codes, (size_t)nslots);
+    }
+}
+
 #ifdef HS_SELFCHECK   // entry-walk form, kept as the cross-check of the bit-set form in the test harness build
 // distance(Partition&, Column&, char): call_variants.cpp:778-967
-static Contingency column_vs_partition(const DensePartition& p, const int32_t* idx, const uint8_t* code, int n, uint8_t ref) {
+static Contingency column_vs_partition(const RankPartition& p, const int32_t* idx, const uint8_t* code, int n, uint8_t ref) {
     Contingency r;
-    uint8_t take_stack[512];
-    std::vector<uint8_t> take_heap;
-    uint8_t* take = take_stack;
-    if (n > 512) { take_heap.resize(n); take = take_heap.data(); }
+    std::vector<uint8_t> take((size_t)std::max(n, 1));
     int shared = 0;
-    for (int i = 0; i < n; ++i) { take[i] = p.state[idx[i]] != ABSENT; shared += take[i]; }
+    for (int i = 0; i < n; ++i) { take[i] = p.state_at(p.rank_of[idx[i]]) != ABSENT; shared += take[i]; }
     if (shared == 0) return r;
     r.comparable = true;
     r.most = ref;
-    r.second = second_most_frequent(code, n, take, ref, true, true, ' ');
+    r.second = second_most_frequent(code, n, take.data(), ref, true, true, ' ');
     for (int i = 0; i < n; ++i) {
         if (!take[i]) continue;
-        const int8_t s = p.state[idx[i]];
+        const int s = p.state_at(p.rank_of[idx[i]]);
         if (code[i] == r.most) { if (s == 1) r.n11++; else if (s == -1) r.n01++; }
         else if (code[i] == r.second) { if (s == 1) r.n10++; else if (s == -1) r.n00++; }
     }
@@ -205,57 +261,17 @@ static Contingency column_vs_partition(const DensePartition& p, const int32_t* i
 }
 #endif
 
-// A candidate column as one bit set per distinct code (the reads that carry it), in first-appearance order.
-struct ColumnBits {
-    int words = 0, nslots = 0, n_entries = 0;
-    uint8_t code_of[128];
-    uint8_t slot_of[256];         // code -> slot, 0xFF = none yet; reset for the used codes at the next build
-    std::vector<uint64_t> bits;   // [nslots][words]
-    std::vector<uint64_t> any;    // [words]
-    int wlo = 0, whi = -1;        // words that hold reads of the column (bit = rank of the read by start position)
-    ColumnBits() { std::memset(slot_of, 0xFF, sizeof(slot_of)); }
-    void build(const int32_t* idx, const uint8_t* code, int n, int n_reads, const int32_t* rank_of) {
-        for (int k = 0; k < nslots; ++k) slot_of[code_of[k]] = 0xFF;
-        words = (n_reads + 63) >> 6;
-        nslots = 0; n_entries = n;
-        // the reads of a column sit in a few neighbouring words (bit = rank by start position): only those words are kept valid
-        int32_t rk_stack[512];
-        std::vector<int32_t> rk_heap;
-        int32_t* rk = rk_stack;
-        if (n > 512) { rk_heap.resize((size_t)n); rk = rk_heap.data(); }
-        int lo = words, hi = -1;
-        for (int i = 0; i < n; ++i) { const int r = rank_of[idx[i]]; rk[i] = r; const int w = r >> 6; if (w < lo) lo = w; if (w > hi) hi = w; }
-        wlo = lo; whi = hi;
-        if (any.size() < (size_t)words) any.resize((size_t)words);
-        if (bits.size() < (size_t)8 * words) bits.resize((size_t)8 * words);
-        for (int w = lo; w <= hi; ++w) any[(size_t)w] = 0ull;
-        for (int i = 0; i < n; ++i) {
-            int k = slot_of[code[i]];
-            if (k == 0xFF) {
-                if (nslots == 128) continue;   // cannot happen: 125 pileup codes
-                k = nslots;
-                slot_of[code[i]] = (uint8_t)k;
-                code_of[nslots++] = code[i];
-                if (bits.size() < (size_t)nslots * words) bits.resize((size_t)nslots * 2 * words);
-                for (int w = lo; w <= hi; ++w) bits[(size_t)k * words + (size_t)w] = 0ull;
-            }
-            const int r = rk[i];
-            const uint64_t b = 1ull << (r & 63);
-            bits[(size_t)k * words + ((size_t)r >> 6)] |= b;
-            any[(size_t)r >> 6] |= b;
-        }
-    }
-};
-
-// column_vs_partition() on bit sets: same result, popcounts of ANDs instead of a walk over the column entries; only the
-// words both the column and the partition occupy are visited. `orig_of`: rank -> read index (the order in which the
-// reference's hash map meets the codes is the order of the READ INDICES, needed when the best count is tied)
-static Contingency column_vs_partition_bits(const DensePartition& p, const ColumnBits& cb, uint8_t ref, const int32_t* orig_of) {
+// distance(Partition&, Column&, char) (call_variants.cpp:778-967) on bit sets: popcounts of ANDs over the words both the column
+// and the partition occupy. `orig_of`: rank -> read index (the order in which the reference's hash map meets the codes is the
+// order of the READ INDICES, needed when the best count is tied)
+static Contingency column_vs_partition_bits(const RankPartition& p, const ColView& cb, uint8_t ref, const int32_t* orig_of) {
     Contingency r;
-    const int W = cb.words;
+    const int W = cb.W;
     const int w0 = std::max(cb.wlo, p.wlo), w1 = std::min(cb.whi, p.whi);
+    if (w0 > w1) return r;
+    const uint64_t* any = cb.any - cb.wlo;      // (indexed by absolute word below)
     int shared = 0;
-    for (int w = w0; w <= w1; ++w) shared += __builtin_popcountll(cb.any[(size_t)w] & p.present[(size_t)w]);
+    for (int w = w0; w <= w1; ++w) shared += __builtin_popcountll(any[w] & p.present[(size_t)w]);
     if (shared == 0) return r;
     r.comparable = true;
     r.most = ref;
@@ -266,31 +282,32 @@ static Contingency column_vs_partition_bits(const DensePartition& p, const Colum
     if (!no_skip && shared <= 14 && (size_t)shared < (size_t)cb.n_entries / 2) return r;
     if (!no_skip) {   // the same with the shared reads the partition has an opinion on (state +1 / -1): only those enter the table
         int decided = 0;
-        for (int w = w0; w <= w1; ++w) decided += __builtin_popcountll(cb.any[(size_t)w] & (p.plus[(size_t)w] | p.minus[(size_t)w]));
+        for (int w = w0; w <= w1; ++w) decided += __builtin_popcountll(any[w] & (p.plus[(size_t)w] | p.minus[(size_t)w]));
         if (decided <= 14 && (size_t)decided < (size_t)cb.n_entries / 2) return r;
     }
+    auto slot_abs = [&](int k) { return cb.slots + (size_t)k * W - cb.wlo; };
     if (ref < 128) {
         // the usual case in one pass: the counts of the column's codes among the shared reads, the largest among the codes other
         // than the reference code; a tie of that largest count (the reference then takes the first of the tied codes in the
         // iteration order of its hash map) goes through the general form below
         int best = -1, nbest = 0, best_slot = -1;
-        const int ref_slot = cb.slot_of[ref] == 0xFF ? -1 : (int)cb.slot_of[ref];
+        const int ref_slot = cb.slot_of(ref);
         for (int k = 0; k < cb.nslots; ++k) {
             if (k == ref_slot) continue;
-            const uint64_t* bk = cb.bits.data() + (size_t)k * W;
+            const uint64_t* bk = slot_abs(k);
             int c = 0;
             for (int w = w0; w <= w1; ++w) c += __builtin_popcountll(bk[w] & p.present[(size_t)w]);
             if (c == 0) continue;
             if (c > best) { best = c; nbest = 1; best_slot = k; } else if (c == best) nbest++;
         }
         if (nbest <= 1) {
-            r.second = best_slot >= 0 ? cb.code_of[best_slot] : (uint8_t)' ';
+            r.second = best_slot >= 0 ? cb.codes[best_slot] : (uint8_t)' ';
             if (ref_slot >= 0) {
-                const uint64_t* bm = cb.bits.data() + (size_t)ref_slot * W;
+                const uint64_t* bm = slot_abs(ref_slot);
                 for (int w = w0; w <= w1; ++w) { r.n11 += __builtin_popcountll(bm[w] & p.plus[(size_t)w]); r.n01 += __builtin_popcountll(bm[w] & p.minus[(size_t)w]); }
             }
             if (best_slot >= 0) {
-                const uint64_t* bs = cb.bits.data() + (size_t)best_slot * W;
+                const uint64_t* bs = slot_abs(best_slot);
                 for (int w = w0; w <= w1; ++w) { r.n10 += __builtin_popcountll(bs[w] & p.plus[(size_t)w]); r.n00 += __builtin_popcountll(bs[w] & p.minus[(size_t)w]); }
             }
             return r;
@@ -299,11 +316,11 @@ static Contingency column_vs_partition_bits(const DensePartition& p, const Colum
     // counts among the shared reads
     uint8_t seen[128]; int cnt[128]; int slot[128];
     int nseen = 0;
-    for (int k = 0; k < cb.nslots; ++k) {
-        const uint64_t* bk = cb.bits.data() + (size_t)k * W;
+    for (int k = 0; k < cb.nslots && k < 128; ++k) {
+        const uint64_t* bk = slot_abs(k);
         int c = 0;
         for (int w = w0; w <= w1; ++w) c += __builtin_popcountll(bk[w] & p.present[(size_t)w]);
-        if (c) { seen[nseen] = cb.code_of[k]; cnt[nseen] = c; slot[nseen] = k; nseen++; }
+        if (c) { seen[nseen] = cb.codes[k]; cnt[nseen] = c; slot[nseen] = k; nseen++; }
     }
     // second_from_seen() only looks at the order of `seen` when the best count is tied (the hash map is then filled in the
     // order the codes first appear among the shared reads = lowest shared read index, column entries being ascending):
@@ -320,7 +337,7 @@ static Contingency column_vs_partition_bits(const DensePartition& p, const Colum
         if (nbest > 1) {
             int first[128];
             for (int i = 0; i < nseen; ++i) {
-                const uint64_t* bk = cb.bits.data() + (size_t)slot[i] * W;
+                const uint64_t* bk = slot_abs(slot[i]);
                 first[i] = 0x7fffffff;
                 for (int w = w0; w <= w1; ++w) {
                     uint64_t x = bk[w] & p.present[(size_t)w];
@@ -332,13 +349,9 @@ static Contingency column_vs_partition_bits(const DensePartition& p, const Colum
         }
     }
     r.second = second_from_seen(seen, cnt, nseen, ref, true, true, ' ');
-    const uint64_t* bm = nullptr; const uint64_t* bs = nullptr;
-    for (int k = 0; k < cb.nslots; ++k) {
-        if (cb.code_of[k] == r.most) bm = cb.bits.data() + (size_t)k * W;
-        if (cb.code_of[k] == r.second) bs = cb.bits.data() + (size_t)k * W;
-    }
-    if (bm) for (int w = w0; w <= w1; ++w) { r.n11 += __builtin_popcountll(bm[w] & p.plus[(size_t)w]); r.n01 += __builtin_popcountll(bm[w] & p.minus[(size_t)w]); }
-    if (bs && r.second != r.most) for (int w = w0; w <= w1; ++w) { r.n10 += __builtin_popcountll(bs[w] & p.plus[(size_t)w]); r.n00 += __builtin_popcountll(bs[w] & p.minus[(size_t)w]); }
+    const int sm = cb.slot_of(r.most), ss = cb.slot_of(r.second);
+    if (sm >= 0) { const uint64_t* bm = slot_abs(sm); for (int w = w0; w <= w1; ++w) { r.n11 += __builtin_popcountll(bm[w] & p.plus[(size_t)w]); r.n01 += __builtin_popcountll(bm[w] & p.minus[(size_t)w]); } }
+    if (ss >= 0 && r.second != r.most) { const uint64_t* bs = slot_abs(ss); for (int w = w0; w <= w1; ++w) { r.n10 += __builtin_popcountll(bs[w] & p.plus[(size_t)w]); r.n00 += __builtin_popcountll(bs[w] & p.minus[(size_t)w]); } }
     return r;
 }
 
@@ -357,42 +370,51 @@ static float chi_square(const Contingency& d) {
     return (float)(d00 * d00 / (double)e00 + d01 * d01 / (double)e01 + d10 * d10 / (double)e10 + d11 * d11 / (double)e11);
 }
 
+
 // Partition::Partition(Column&, pos, ref_base): Partition.cpp:32-83
-static void partition_from_column(DensePartition& p, PartitionArena& arena, int n_reads, const int32_t* idx, const uint8_t* code, int n, int pos, uint8_t ref,
-                                  const int32_t* rank_of, const int32_t* orig_of, const int32_t* read_end) {
+static void partition_from_column(RankPartition& p, PartitionArena& arena, int n_reads, const ColView& cb, int pos, uint8_t ref,
+                                  const int32_t* rank_of, const int32_t* orig_of) {
     p.left = p.right = pos; p.n_occ = 1; p.n_corr = 0;
-    p.rank_of = rank_of; p.orig_of = orig_of; p.wlo = 0; p.whi = -1; p.reach = -1;
-    for (int i = 0; i < n; ++i) p.reach = std::max(p.reach, read_end[idx[i]]);
+    p.rank_of = rank_of; p.orig_of = orig_of; p.wlo = 0; p.whi = -1; p.reach = cb.reach;
     p.allocate(arena, n_reads);
-    const uint8_t second = second_most_frequent(code, n, nullptr, ref, false, false, 0);
-    for (int i = 0; i < n; ++i) {
-        const int r = idx[i];
-        p.state[r] = code[i] == ref ? 1 : (code[i] == second ? -1 : 0);
-        p.more[r] = 1; p.less[r] = 0;
+    // the most frequent code other than the reference code (first in the hash map's order on ties; the map meets the codes in
+    // the order of the column's entries = the order of the slots)
+    int cnt[128];
+    const int ns = std::min(cb.nslots, 128);
+    for (int k = 0; k < ns; ++k) { int c = 0; const uint64_t* bk = cb.slot(k); for (int j = 0; j < cb.W; ++j) c += __builtin_popcountll(bk[j]); cnt[k] = c; }
+    const uint8_t second = second_from_seen(cb.codes, cnt, ns, ref, false, false, 0);
+    const int sr = cb.slot_of(ref), ss = second != ref ? cb.slot_of(second) : -1;
+    for (int j = 0; j < cb.W; ++j) {
+        const size_t w = (size_t)(cb.wlo + j);
+        const uint64_t a = cb.any[j];
+        if (!a) continue;
+        p.present[w] = a;
+        p.plus[w] = sr >= 0 ? cb.slot(sr)[j] : 0ull;
+        p.minus[w] = ss >= 0 ? cb.slot(ss)[j] : 0ull;
+        p.touch_word((int)w);
+        for (uint64_t x = a; x; x &= x - 1) { const size_t k = w * 64 + (size_t)__builtin_ctzll(x); p.more[k] = 1; p.less[k] = 0; }
     }
-    for (int i = 0; i < n; ++i) p.sync_bits(idx[i]);
-    p.lo = n ? idx[0] : 0; p.hi = n ? idx[n - 1] : -1;
+    p.lo = cb.n_entries ? cb.idx_min : 0; p.hi = cb.n_entries ? cb.idx_max : -1;
 }
 
 // Partition::augmentPartition with the 'A'/'a'/' ' recoding of distance() folded in:
 // Partition.cpp:243-397 + call_variants.cpp:856-872
-static void augment(DensePartition& p, const int32_t* idx, const uint8_t* code, int n, const Contingency& d, int pos, const int32_t* read_end) {
+static void augment(RankPartition& p, const ColView& cb, const Contingency& d, int pos) {
     if (pos != -1) {
         if (pos < p.left || p.left == -1) p.left = pos;
         if (pos > p.right) p.right = pos;
     }
-    if (!d.comparable || n == 0) return;      // empty partition_to_augment (:251-253)
-    // recoded column: +1 where the read carries the column's reference code ('A'), -1 for its second code ('a'), 0 otherwise
-    int8_t cls_stack[512];
-    std::vector<int8_t> cls_heap;
-    int8_t* cls = cls_stack;
-    if (n > 512) { cls_heap.resize((size_t)n); cls = cls_heap.data(); }
+    if (!d.comparable || cb.n_entries == 0) return;      // empty partition_to_augment (:251-253)
+    // recoded column: 'A' where the read carries the column's reference code, 'a' for its second code, ' ' otherwise
+    static const uint64_t zero_words[4] = {0, 0, 0, 0};
+    std::vector<uint64_t> zheap;
+    const uint64_t* zeros = zero_words;
+    if (cb.W > 4) { zheap.assign((size_t)cb.W, 0ull); zeros = zheap.data(); }
+    const int sA = cb.slot_of(d.most), sa_ = d.second != d.most ? cb.slot_of(d.second) : -1;
+    const uint64_t* A = sA >= 0 ? cb.slot(sA) : zeros;
+    const uint64_t* a = sa_ >= 0 ? cb.slot(sa_) : zeros;
     int nA = 0, na = 0;
-    for (int i = 0; i < n; ++i) {
-        const int isA = code[i] == d.most, isa = (code[i] == d.second) & !isA;
-        nA += isA; na += isa;
-        cls[i] = (int8_t)(isA - isa);
-    }
+    for (int j = 0; j < cb.W; ++j) { nA += __builtin_popcountll(A[j]); na += __builtin_popcountll(a[j]); }
     // two most frequent characters over 0..254 except ' ', lowest character wins ties (:261-280): 'A' < 'a'.
     // vA / va = the sign an 'A' / 'a' entry votes with: +1 if it is the most frequent character, -1 if the second, 0 if neither
     int vA, va;
@@ -400,27 +422,38 @@ static void augment(DensePartition& p, const int32_t* idx, const uint8_t* code, 
     else if (nA >= na) { vA = 1; va = na > 0 ? -1 : 0; }
     else { va = 1; vA = nA > 0 ? -1 : 0; }
     int swapped = 0;                           // phase vote over shared reads (:284-314): sum of vote x partition state
-    for (int i = 0; i < n; ++i) {
-        const int8_t s = p.state[idx[i]];
-        const int v = cls[i] > 0 ? vA : (cls[i] < 0 ? va : 0);
-        swapped += s == ABSENT ? 0 : v * s;
+    for (int j = 0; j < cb.W; ++j) {
+        const size_t w = (size_t)(cb.wlo + j);
+        const uint64_t pl = p.plus[w], mi = p.minus[w];
+        swapped += vA * (__builtin_popcountll(A[j] & pl) - __builtin_popcountll(A[j] & mi)) + va * (__builtin_popcountll(a[j] & pl) - __builtin_popcountll(a[j] & mi));
     }
     if (swapped < 0) { vA = -vA; va = -va; }   // std::swap(mostc, secondc)
-    for (int i = 0; i < n; ++i) {              // element-wise form of the sorted merge (:322-390)
-        const int r = idx[i];
-        const int s = cls[i] > 0 ? vA : (cls[i] < 0 ? va : 0);
-        int8_t& st = p.state[r];
-        if (st == ABSENT) { st = (int8_t)s; p.more[r] = std::abs(s); p.less[r] = 0; if (read_end[r] > p.reach) p.reach = read_end[r]; }
-        else if (s == 0) { continue; /* nothing new */ }
-        else if (st == 0) { st = (int8_t)s; p.more[r] = 1; p.less[r] = 0; }
-        else if (s == st) { p.more[r] += 1; continue; }
-        else {                                 // s == -st
-            if (p.less[r] + 1 > p.more[r]) { st = (int8_t)-st; p.more[r] += 1; }
-            else { p.less[r] += 1; continue; }
+    for (int j = 0; j < cb.W; ++j) {           // word-wise form of the sorted merge (:322-390)
+        const size_t w = (size_t)(cb.wlo + j);
+        const uint64_t any = cb.any[j];
+        if (!any) continue;
+        const uint64_t s_plus = (vA == 1 ? A[j] : 0ull) | (va == 1 ? a[j] : 0ull), s_minus = (vA == -1 ? A[j] : 0ull) | (va == -1 ? a[j] : 0ull);
+        const uint64_t voting = s_plus | s_minus;
+        const uint64_t P = p.present[w], PL = p.plus[w], MI = p.minus[w];
+        const uint64_t fresh = any & ~P;                               // not in the partition yet: takes the vote as it is
+        const uint64_t undecided = any & P & ~PL & ~MI & voting;       // state 0 meets a vote: takes it, counters restart
+        const uint64_t agree = any & ((PL & s_plus) | (MI & s_minus));
+        const uint64_t against = any & ((PL & s_minus) | (MI & s_plus));
+        uint64_t npl = PL | ((fresh | undecided) & s_plus), nmi = MI | ((fresh | undecided) & s_minus);
+        int32_t* more = p.more + w * 64; int32_t* less = p.less + w * 64;
+        for (uint64_t x = fresh; x; x &= x - 1) { const int b = __builtin_ctzll(x); more[b] = (voting >> b) & 1; less[b] = 0; }
+        for (uint64_t x = undecided; x; x &= x - 1) { const int b = __builtin_ctzll(x); more[b] = 1; less[b] = 0; }
+        for (uint64_t x = agree; x; x &= x - 1) more[__builtin_ctzll(x)] += 1;
+        for (uint64_t x = against; x; x &= x - 1) {
+            const int b = __builtin_ctzll(x);
+            if (less[b] + 1 > more[b]) { more[b] += 1; const uint64_t bit = 1ull << b; if (PL & bit) { npl &= ~bit; nmi |= bit; } else { nmi &= ~bit; npl |= bit; } }
+            else less[b] += 1;
         }
-        p.sync_bits(r);                        // only when the state changed
+        p.present[w] = P | any; p.plus[w] = npl; p.minus[w] = nmi;
+        if (fresh) p.touch_word((int)w);
     }
-    if (n) { if (p.hi < p.lo) { p.lo = idx[0]; p.hi = idx[n - 1]; } else { p.lo = std::min(p.lo, idx[0]); p.hi = std::max(p.hi, idx[n - 1]); } }
+    if (cb.reach > p.reach) p.reach = cb.reach;      // (a read that was present already ends at or before the old reach)
+    if (p.hi < p.lo) { p.lo = cb.idx_min; p.hi = cb.idx_max; } else { p.lo = std::min(p.lo, cb.idx_min); p.hi = std::max(p.hi, cb.idx_max); }
     p.n_occ += 1;
 }
 
@@ -435,49 +468,58 @@ static inline float three_sigma_threshold(int n) {
     return n >= 0 && n < 4096 ? table[(size_t)n] : (float)(0.5 * n + 3 * std::sqrt(n * 0.5 * (1 - 0.5)));
 }
 
-// Partition::isInformative(false, meanError): Partition.cpp:141-179
-static bool is_informative(const DensePartition& p, float mean_error) {
+
+// Partition::isInformative(false, meanError): Partition.cpp:141-179 (counts: any order of the reads)
+static bool is_informative(const RankPartition& p, float mean_error) {
     int suspicious[2] = {0, 0};
     int number_of_reads = 0;
-    for (int r = p.lo; r <= p.hi; ++r) {
-        if (p.state[r] == ABSENT) continue;
-        const int read_number = p.more[r] + p.less[r];
-        float threshold = three_sigma_threshold(read_number);
-        threshold = std::min(threshold, float(read_number) - 1);
-        if ((float)p.more[r] > threshold) {
-            if (p.state[r] == -1) { suspicious[0]++; number_of_reads++; }
-            else if (p.state[r] == 1) { suspicious[1]++; number_of_reads++; }
+    for (int w = p.wlo; w <= p.whi; ++w)
+        for (uint64_t x = p.plus[(size_t)w] | p.minus[(size_t)w]; x; x &= x - 1) {
+            const int b = __builtin_ctzll(x);
+            const size_t k = (size_t)w * 64 + (size_t)b;
+            const int read_number = p.more[k] + p.less[k];
+            float threshold = three_sigma_threshold(read_number);
+            threshold = std::min(threshold, float(read_number) - 1);
+            if ((float)p.more[k] > threshold) { suspicious[(p.plus[(size_t)w] >> b) & 1]++; number_of_reads++; }
         }
-    }
     const float min_reads = mean_error * number_of_reads / 2;
     return !(suspicious[0] < min_reads || suspicious[1] < min_reads);
 }
 
 static double lchoose(double n, double k) { return std::lgamma(n + 1) - std::lgamma(k + 1) - std::lgamma(n - k + 1); }
 
-// Partition::isSignificant: Partition.cpp:197-233 (the "p != 0" test is on the ordinal of the read, :209)
-static float significance(const DensePartition& p, int total_columns) {
-    int mutated = 0, reads = 0, columns = 0, ordinal = 0;
-    for (int r = p.lo; r <= p.hi; ++r) {
-        if (p.state[r] == ABSENT) continue;
-        if (p.state[r] == -1 && p.more[r] > 1 && p.less[r] == 0) { mutated++; if (p.more[r] > columns) columns = p.more[r]; }
-        if (ordinal != 0 && p.more[r] > 1 && p.less[r] == 0) reads++;
-        ordinal++;
-    }
+// Partition::isSignificant: Partition.cpp:197-233 (the "p != 0" test is on the ordinal of the read, :209: the partition's
+// first read -- lowest read index -- is not counted in `reads`)
+static float significance(const RankPartition& p, int total_columns) {
+    int mutated = 0, reads = 0, columns = 0;
+    int first_read = 0x7fffffff; bool first_counts = false;
+    for (int w = p.wlo; w <= p.whi; ++w)
+        for (uint64_t x = p.present[(size_t)w]; x; x &= x - 1) {
+            const int b = __builtin_ctzll(x);
+            const size_t k = (size_t)w * 64 + (size_t)b;
+            const bool solid = p.more[k] > 1 && p.less[k] == 0;
+            if (solid && ((p.minus[(size_t)w] >> b) & 1)) { mutated++; if (p.more[k] > columns) columns = p.more[k]; }
+            if (solid) reads++;
+            const int o = p.orig_of[k];
+            if (o < first_read) { first_read = o; first_counts = solid; }
+        }
+    if (first_counts) reads--;
     const double pv = std::exp(::log((double)(float(mutated) / reads)) * columns * mutated + lchoose(reads, mutated) + lchoose(total_columns, columns));
     return (float)std::max(0.0, pv);
 }
 
 // Partition::compute_conf: Partition.cpp:716-732 with getConfidence :811-827 (ascending read order matters)
-static float confidence_score(const DensePartition& p) {
+static float confidence_score(const RankPartition& p) {
     double conf = 1;
     int n = 0;
     for (int r = p.lo; r <= p.hi; ++r) {
-        if (p.state[r] == ABSENT) continue;
-        if (p.more[r] > 1) {
+        const size_t k = (size_t)p.rank_of[r];
+        const int s = p.state_at((int)k);
+        if (s == ABSENT) continue;
+        if (p.more[k] > 1) {
             float c;
-            if (p.state[r] == 0) c = 0.5f;
-            else if (p.more[r] + p.less[r] > 0) c = float(p.more[r]) / (p.more[r] + p.less[r]);
+            if (s == 0) c = 0.5f;
+            else if (p.more[k] + p.less[k] > 0) c = float(p.more[k]) / (p.more[k] + p.less[k]);
             else c = 1;
             conf *= c; n++;
         }
@@ -490,24 +532,25 @@ static float confidence_score(const DensePartition& p) {
 struct PartPartDistance { int n00 = 0, n01 = 0, n10 = 0, n11 = 0; short phased = 1; bool augmented = true; };
 
 // distance(Partition&, Partition&, 2): call_variants.cpp:977-1127
-static PartPartDistance partition_vs_partition(const DensePartition& a, const DensePartition& b, int threshold_p) {
+static PartPartDistance partition_vs_partition(const RankPartition& a, const RankPartition& b, int threshold_p) {
     int comparable = 0;
     int scores[2] = {0, 0};
     short ndiv[2] = {0, 0}, nunsure[2] = {0, 0};
     int m00[2] = {0, 0}, m01[2] = {0, 0}, m10[2] = {0, 0}, m11[2] = {0, 0};
     // every count below is a sum over the reads both partitions hold: those are the common bits of the two `present` sets (any
     // order), not a walk over all reads between the partitions' first and last
-    const int32_t* orig_of = a.orig_of;
     for (int w = std::max(a.wlo, b.wlo); w <= std::min(a.whi, b.whi); ++w)
     for (uint64_t x = a.present[(size_t)w] & b.present[(size_t)w]; x; x &= x - 1) {
-        const int r = orig_of[w * 64 + __builtin_ctzll(x)];
+        const int bit = __builtin_ctzll(x);
+        const size_t r = (size_t)w * 64 + (size_t)bit;
         if (!(a.more[r] > 1 && b.more[r] > 1)) continue;
         comparable++;
         const float t1 = three_sigma_threshold(a.more[r] + a.less[r]);
         const float t2 = three_sigma_threshold(b.more[r] + b.less[r]);
         const bool both = (float)a.more[r] > t1 && (float)b.more[r] > t2;
         const bool either = (float)a.more[r] > t1 || (float)b.more[r] > t2;
-        const int s1 = a.state[r], s2 = b.state[r];
+        const int s1 = (int)((a.plus[(size_t)w] >> bit) & 1) - (int)((a.minus[(size_t)w] >> bit) & 1);
+        const int s2 = (int)((b.plus[(size_t)w] >> bit) & 1) - (int)((b.minus[(size_t)w] >> bit) & 1);
         if (s2 == 1) {
             if (s1 == 1) { scores[0]++; scores[1]--; m11[0]++; m10[1]++; if (both) ndiv[1]++; if (either) nunsure[1]++; }
             else if (s1 == -1) { scores[0]--; scores[1]++; m01[0]++; m00[1]++; if (both) ndiv[0]++; if (either) nunsure[0]++; }
@@ -524,15 +567,17 @@ static PartPartDistance partition_vs_partition(const DensePartition& a, const De
     return d;
 }
 
-// Partition::mergePartition(p, phased): Partition.cpp:401-537, element-wise
-static void merge_partitions(DensePartition& a, const DensePartition& b, short phased) {
+// Partition::mergePartition(p, phased): Partition.cpp:401-537, per read of b (every rule is per read)
+static void merge_partitions(RankPartition& a, const RankPartition& b, short phased) {
     a.left = std::min(a.left, b.left);
     a.right = std::max(a.right, b.right);
-    for (int r = b.lo; r <= b.hi; ++r) {
-        const int8_t ob = b.state[r];
-        if (ob == ABSENT) continue;
-        int8_t& sa = a.state[r];
-        if (sa == ABSENT || sa == 0) { sa = (int8_t)(ob * phased); a.more[r] = b.more[r]; a.less[r] = b.less[r]; }
+    for (int w = b.wlo; w <= b.whi; ++w)
+    for (uint64_t x = b.present[(size_t)w]; x; x &= x - 1) {
+        const int bit = __builtin_ctzll(x);
+        const size_t r = (size_t)w * 64 + (size_t)bit;
+        const int ob = (int)((b.plus[(size_t)w] >> bit) & 1) - (int)((b.minus[(size_t)w] >> bit) & 1);
+        const int sa = a.state_at((int)r);
+        if (sa == ABSENT || sa == 0) { a.set_state((int)r, ob * phased); a.more[r] = b.more[r]; a.less[r] = b.less[r]; }
         else if (ob == 0) { /* keep a */ }
         else if (phased * ob == sa) {
             int which = 0;
@@ -553,12 +598,11 @@ static void merge_partitions(DensePartition& a, const DensePartition& b, short p
             int nm = 0, nl = 0;
             if (which != 1) { nm += a.more[r]; nl += a.less[r]; }
             if (which != 2) { nm += b.less[r]; nl += b.more[r]; }
-            if (nl > nm) { sa = (int8_t)-sa; std::swap(nm, nl); }
+            if (nl > nm) { a.set_state((int)r, -sa); std::swap(nm, nl); }
             a.more[r] = nm; a.less[r] = nl;
         }
     }
     if (b.hi >= b.lo) { if (a.hi < a.lo) { a.lo = b.lo; a.hi = b.hi; } else { a.lo = std::min(a.lo, b.lo); a.hi = std::max(a.hi, b.hi); } }
-    for (int r = b.lo; r <= b.hi; ++r) if (b.state[r] != ABSENT) a.sync_bits(r);   // the bit sets follow (loop B asks them whether two partitions share a read)
     a.reach = std::max(a.reach, b.reach);
     a.n_occ += b.n_occ;
 }
@@ -568,9 +612,9 @@ struct CvContigState {
     int n_reads = 0, n_candidates = 0;
     float mean_distance = 0;
     PartitionArena arena;                // storage of every partition below
-    std::vector<DensePartition> parts;   // what loop A leaves (host loop or imported from the device)
+    std::vector<RankPartition> parts;    // what loop A leaves (host loop or imported from the device)
     std::vector<int32_t> rank_of, orig_of;   // reads ranked by start position (ties by index): the bit order of the bit sets
-    std::vector<DensePartition> finals;
+    std::vector<RankPartition> finals;
     std::vector<int32_t> survivors;      // (cv_loop_b_survivors) indices in `parts` of the partitions that pass loop B's gate
 };
 
@@ -582,30 +626,17 @@ void cv_phase_begin(CvContigState& st, int n_reads, int n_candidates, float mean
     out.n_candidates = n_candidates;
 }
 
-static void rank_reads(CvContigState& st, const int32_t* read_start) {
-    const int n_reads = st.n_reads;
-    st.rank_of.assign((size_t)n_reads, 0); st.orig_of.assign((size_t)((n_reads + 63) / 64) * 64, 0);
-    std::vector<int32_t> order((size_t)n_reads);
-    for (int r = 0; r < n_reads; ++r) order[(size_t)r] = r;
-    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return read_start[a] != read_start[b] ? read_start[a] < read_start[b] : a < b; });
-    for (int k = 0; k < n_reads; ++k) { st.rank_of[(size_t)order[(size_t)k]] = k; st.orig_of[(size_t)k] = order[(size_t)k]; }
-}
-
 // loop A (:590-638) on the host: sequential over the candidate columns of the contig
-void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* read_start, const int32_t* read_end) {
+void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* read_start) {
     const int n_reads = st.n_reads;
-    auto col_idx = [&](int i) { return cs.idx + cs.off[i]; };
-    auto col_code = [&](int i) { return cs.code + cs.off[i]; };
-    auto col_n = [&](int i) { return (int)(cs.off[i + 1] - cs.off[i]); };
     const bool tim = std::getenv("HS_TIMING_AB") != nullptr;
     auto nowus = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a0 = tim ? nowus() : 0;
     long n_cmp = 0, n_aug = 0;
-    double t_build = 0, t_aug = 0;
-    std::vector<DensePartition>& parts = st.parts;
+    double t_aug = 0;
+    std::vector<RankPartition>& parts = st.parts;
     parts.clear();
-    ColumnBits colbits;
-    rank_reads(st, read_start);
+    cv_rank_reads(n_reads, read_start, st.rank_of, st.orig_of);
     const std::vector<int32_t>& rank_of = st.rank_of; const std::vector<int32_t>& orig_of = st.orig_of;
     int last_position = -5;
     // the partitions a column can still meet, in creation order: one that is more than 50 kb behind (:595) or none of whose reads
@@ -616,12 +647,10 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
         const int pos = cs.rec[ci].pos;
         const uint8_t k0 = cs.rec[ci].k0;
         if (pos - last_position <= 5) continue;
-        const int32_t* idx = col_idx(ci); const uint8_t* code = col_code(ci); const int n = col_n(ci);
+        const ColView colbits(cs.bits[ci], cs.words);
+        const int n = colbits.n_entries;
         bool found = false;
         int n_corr = 0;
-        const double tb0 = tim ? nowus() : 0;
-        if (!parts.empty()) colbits.build(idx, code, n, n_reads, rank_of.data());
-        if (tim) t_build += nowus() - tb0;
         size_t kept = 0;
         for (size_t a = 0; a < active.size(); ++a) {
             const size_t p = (size_t)active[a];
@@ -634,7 +663,9 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
             const Contingency d = column_vs_partition_bits(parts[p], colbits, k0, orig_of.data());
             n_cmp++;
 #ifdef HS_SELFCHECK
-            {
+            if (cs.idx) {
+                const int32_t* idx = cs.idx + cs.off[ci]; const uint8_t* code = cs.code + cs.off[ci];
+                if ((int)(cs.off[ci + 1] - cs.off[ci]) != n) { std::fprintf(stderr, "HS_SELFCHECK: bit sets of another column\n"); std::abort(); }
                 const Contingency e = column_vs_partition(parts[p], idx, code, n, k0);
                 if (e.n00 != d.n00 || e.n01 != d.n01 || e.n10 != d.n10 || e.n11 != d.n11 || e.comparable != d.comparable || e.second != d.second) {
                     // the bit-set form leaves the counts at zero where they cannot matter (few shared reads): the entry walk must
@@ -659,7 +690,46 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
                 || (d.n00 <= std::max(0.1 * (d.n00 + d.n01), 1.0) && d.n11 < std::max(0.1 * (d.n11 + d.n10), 1.0) && enough)) {
                 found = true; n_aug++;
                 const double ta0 = tim ? nowus() : 0;
-                augment(parts[p], idx, code, n, d, pos, read_end);
+#ifdef HS_SELFCHECK
+                std::vector<int> before, want;
+                if (cs.idx) {      // the entry-wise augmentPartition on a copy of the states, compared below
+                    const int32_t* idx = cs.idx + cs.off[ci]; const uint8_t* code = cs.code + cs.off[ci];
+                    int nA = 0, na = 0;
+                    for (int i = 0; i < n; ++i) { const int isA = code[i] == d.most, isa = (code[i] == d.second) & !isA; nA += isA; na += isa; }
+                    int vA, va;
+                    if (nA == 0 && na == 0) { vA = 0; va = 0; } else if (nA >= na) { vA = 1; va = na > 0 ? -1 : 0; } else { va = 1; vA = nA > 0 ? -1 : 0; }
+                    int swapped = 0;
+                    for (int i = 0; i < n; ++i) {
+                        const int s = parts[p].state_at(rank_of[(size_t)idx[i]]);
+                        const int v = code[i] == d.most ? vA : (code[i] == d.second ? va : 0);
+                        swapped += s == ABSENT ? 0 : v * s;
+                    }
+                    if (swapped < 0) { vA = -vA; va = -va; }
+                    for (int i = 0; i < n; ++i) {      // (state, more, less) after the element-wise merge of the reference
+                        const int k = rank_of[(size_t)idx[i]];
+                        int st_ = parts[p].state_at(k), mo = st_ == ABSENT ? 0 : parts[p].more[k], le = st_ == ABSENT ? 0 : parts[p].less[k];
+                        const int s = code[i] == d.most ? vA : (code[i] == d.second ? va : 0);
+                        if (st_ == ABSENT) { st_ = s; mo = std::abs(s); le = 0; }
+                        else if (s == 0) {}
+                        else if (st_ == 0) { st_ = s; mo = 1; le = 0; }
+                        else if (s == st_) mo += 1;
+                        else { if (le + 1 > mo) { st_ = -st_; mo += 1; } else le += 1; }
+                        want.push_back(st_); want.push_back(mo); want.push_back(le);
+                    }
+                }
+#endif
+                augment(parts[p], colbits, d, pos);
+#ifdef HS_SELFCHECK
+                if (cs.idx) {
+                    const int32_t* idx = cs.idx + cs.off[ci];
+                    for (int i = 0; i < n; ++i) {
+                        const int k = rank_of[(size_t)idx[i]];
+                        if (parts[p].state_at(k) != want[(size_t)3 * i] || parts[p].more[k] != want[(size_t)3 * i + 1] || parts[p].less[k] != want[(size_t)3 * i + 2]) {
+                            std::fprintf(stderr, "HS_SELFCHECK: word-wise augmentPartition differs from the entry walk\n"); std::abort();
+                        }
+                    }
+                }
+#endif
                 if (tim) t_aug += nowus() - ta0;
             }
         }
@@ -667,25 +737,25 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
         if (!found) {
             active.push_back((int)parts.size());
             parts.emplace_back();
-            partition_from_column(parts.back(), st.arena, n_reads, idx, code, n, pos, k0, rank_of.data(), orig_of.data(), read_end);
+            partition_from_column(parts.back(), st.arena, n_reads, colbits, pos, k0, rank_of.data(), orig_of.data());
             parts.back().n_corr = n_corr;
         } else last_position = pos;
     }
-    if (tim) std::fprintf(stderr, "[hs timing] loop A: %d candidates, %zu partitions, %ld comparisons, %ld augmentations; %.0f us (build %.0f, augment %.0f)\n",
-                          cs.n, parts.size(), n_cmp, n_aug, nowus() - t_a0, t_build, t_aug);
+    if (tim) std::fprintf(stderr, "[hs timing] loop A: %d candidates, %zu partitions, %ld comparisons, %ld augmentations; %.0f us (augment %.0f)\n",
+                          cs.n, parts.size(), n_cmp, n_aug, nowus() - t_a0, t_aug);
 }
 
-// loop A ran on the device (k_loop_a): its partitions become the host's dense form. The device ranks the reads exactly as
-// rank_reads() does (the batch carries that order), so its bit sets are taken as they are.
+// loop A ran on the device (k_loop_a): its partitions become the host's. The device ranks the reads exactly as
+// cv_rank_reads() does (the batch carries that order), so its bit sets and per-rank counters are taken as they are.
 void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const uint64_t* bits, const int32_t* cnt) {
     const int N = st.n_reads;
     const int W = (N + 63) >> 6;
-    rank_reads(st, read_start);
-    std::vector<DensePartition>& parts = st.parts;
+    cv_rank_reads(N, read_start, st.rank_of, st.orig_of);
+    std::vector<RankPartition>& parts = st.parts;
     parts.clear();
     parts.resize((size_t)n_parts);
     for (int p = 0; p < n_parts; ++p) {
-        DensePartition& d = parts[(size_t)p];
+        RankPartition& d = parts[(size_t)p];
         const CvPartRecord& r = rec[p];
         d.left = r.left; d.right = r.right; d.n_occ = r.n_occ; d.n_corr = r.n_corr; d.lo = r.lo; d.hi = r.hi; d.reach = r.reach;
         d.rank_of = st.rank_of.data(); d.orig_of = st.orig_of.data(); d.wlo = W; d.whi = -1;
@@ -699,10 +769,7 @@ void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts
             if (w > d.whi) d.whi = w;
             for (uint64_t x = d.present[w]; x; x &= x - 1) {
                 const int k = w * 64 + __builtin_ctzll(x);
-                const int q = st.orig_of[(size_t)k];
-                const uint64_t b = 1ull << (k & 63);
-                d.state[q] = (d.plus[w] & b) ? 1 : ((d.minus[w] & b) ? -1 : 0);
-                d.more[q] = pc[k] & 0xffff; d.less[q] = (pc[k] >> 16) & 0xffff;      // (the device keeps the counters by rank)
+                d.more[k] = pc[k] & 0xffff; d.less[k] = (pc[k] >> 16) & 0xffff;      // (the device keeps the counters by rank too)
             }
         }
         if (d.whi < d.wlo) d.wlo = 0;
@@ -721,13 +788,24 @@ int cv_loop_b_survivors(CvContigState& st) {
     }
     return (int)st.survivors.size();
 }
+// a partition as dense arrays over the READ INDICES (what the device kernels index): state 2 = absent
+static void export_dense(const RankPartition& p, int8_t* state, int32_t* more, int32_t* less) {
+    const size_t N = (size_t)p.n_reads;
+    std::memset(state, ABSENT, N);
+    if (more) { std::memset(more, 0, N * 4); std::memset(less, 0, N * 4); }
+    for (int w = p.wlo; w <= p.whi; ++w)
+        for (uint64_t x = p.present[(size_t)w]; x; x &= x - 1) {
+            const int bit = __builtin_ctzll(x);
+            const size_t k = (size_t)w * 64 + (size_t)bit;
+            const size_t r = (size_t)p.orig_of[k];
+            state[r] = (int8_t)((int)((p.plus[(size_t)w] >> bit) & 1) - (int)((p.minus[(size_t)w] >> bit) & 1));
+            if (more) { more[r] = p.more[k]; less[r] = p.less[k]; }
+        }
+}
 // the survivors' dense arrays (n_reads entries each, one after the other) for k_partition_pair_distance
 void cv_export_survivors(const CvContigState& st, int8_t* state, int32_t* more, int32_t* less) {
     const size_t N = (size_t)st.n_reads;
-    for (size_t k = 0; k < st.survivors.size(); ++k) {
-        const DensePartition& p = st.parts[(size_t)st.survivors[k]];
-        std::memcpy(state + k * N, p.state, N); std::memcpy(more + k * N, p.more, N * 4); std::memcpy(less + k * N, p.less, N * 4);
-    }
+    for (size_t k = 0; k < st.survivors.size(); ++k) export_dense(st.parts[(size_t)st.survivors[k]], state + k * N, more + k * N, less + k * N);
 }
 const std::vector<float>& cv_three_sigma_table() {
     static const std::vector<float> t = [] { std::vector<float> v(4096); for (int k = 0; k < 4096; ++k) v[(size_t)k] = three_sigma_threshold(k); return v; }();
@@ -737,12 +815,12 @@ const std::vector<float>& cv_three_sigma_table() {
 // loop B (:646-708). pair_table (optional): distance(survivor i, survivor j, 2) for i < j at 8 * (j (j - 1) / 2 + i), as
 // k_partition_pair_distance leaves it: used while the final partition still is survivor i as uploaded (no merge into it yet)
 void cv_phase_b(CvContigState& st, ContigCvResult& out, const int32_t* pair_table) {
-    std::vector<DensePartition>& parts = st.parts;
+    std::vector<RankPartition>& parts = st.parts;
     const float mean_distance = st.mean_distance;
     out.n_partitions = (int)parts.size();
     if (parts.empty()) return;
-    std::vector<DensePartition>& finals = st.finals;
-    DensePartition scratch;
+    std::vector<RankPartition>& finals = st.finals;
+    RankPartition scratch;
     for (size_t p1 = 0; p1 < parts.size(); ++p1) {
         if (pair_table) { if (parts[p1].survivor < 0) continue; }
         else {
@@ -764,7 +842,7 @@ void cv_phase_b(CvContigState& st, ContigCvResult& out, const int32_t* pair_tabl
             } else {
                 {   // partitions without a common read are "not comparable" (comparable == 0 -> augmented = false, :1107-1111): one AND
                     // over the few words both occupy instead of a walk over all reads of the contig
-                    const DensePartition& fa = finals[p2]; const DensePartition& fb = parts[p1];
+                    const RankPartition& fa = finals[p2]; const RankPartition& fb = parts[p1];
                     bool any = false;
                     for (int w = std::max(fa.wlo, fb.wlo); w <= std::min(fa.whi, fb.whi) && !any; ++w) any = (fa.present[(size_t)w] & fb.present[(size_t)w]) != 0;
                     if (!any) continue;
@@ -775,8 +853,8 @@ void cv_phase_b(CvContigState& st, ContigCvResult& out, const int32_t* pair_tabl
                 && d.n10 < std::max(2, 2 * d.n01) && d.n01 < std::max(2, 2 * d.n10)) {
                 bool do_merge = d.n01 + d.n10 < 0.1 * (d.n00 + d.n11);
                 if (!do_merge) {
-                    if (!scratch.state) scratch.allocate(st.arena, st.n_reads);      // one trial copy per contig, reused
-                    DensePartition& merged = scratch;
+                    if (!scratch.present) scratch.allocate(st.arena, st.n_reads);      // one trial copy per contig, reused
+                    RankPartition& merged = scratch;
                     merged.copy_from(finals[p2]);
                     merge_partitions(merged, parts[p1], d.phased);
                     do_merge = confidence_score(merged) > confidence_score(finals[p2]);
@@ -787,18 +865,18 @@ void cv_phase_b(CvContigState& st, ContigCvResult& out, const int32_t* pair_tabl
         if (different) finals.push_back(parts[p1]);      // (a partition of loop A is looked at once: its storage goes along)
     }
     out.n_final_partitions = (int)finals.size();
-    std::vector<DensePartition>().swap(parts);
+    std::vector<RankPartition>().swap(parts);
 }
 
 // Loops C (:721-738) and D (:745-764) and the merge of the two SNP lists (:1335-1352) run on the device: the final partitions
-// leave as dense state arrays.
+// leave as dense state arrays over the read indices.
 int cv_final_partitions(const CvContigState& st) { return (int)st.finals.size(); }
 void cv_export_partitions(const CvContigState& st, int8_t* state, int64_t state_base, int64_t* state_off) {
     int64_t o = 0;
     for (size_t k = 0; k < st.finals.size(); ++k) {
-        const DensePartition& p = st.finals[k];
+        const RankPartition& p = st.finals[k];
         state_off[k] = state_base + o;
-        std::memcpy(state + o, p.state, (size_t)p.n_reads);
+        export_dense(p, state + o, nullptr, nullptr);
         o += (int64_t)p.n_reads;
     }
 }

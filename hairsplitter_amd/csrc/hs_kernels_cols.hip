@@ -14,6 +14,8 @@
 //   k_candidates_scan     V1: the greedy spacing scan of call_variants.cpp:525-536 per contig (lanes = columns, the
 //                         dependency only runs along the few columns that pass the predicate)
 //   k_flag_block_sums / k_flag_block_offsets / k_pack_flagged   the flagged columns (candidates, later the SNPs) packed back to back with their records
+//   k_cand_bits           the packed candidate columns as bit sets over the reads ranked by start position (what loop A reads)
+//   k_ship / k_fill16     transfers and fills as kernels (pinned host memory is mapped into the device's address space)
 //   k_snp_bounds / k_snp_flags   the two-pointer merge of automatic and filtered SNPs (:1335-1352) as a per-contig bound
 // Included by hs_capi.hip after hs_kernels.hip.
 #pragma once
@@ -266,6 +268,155 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
             if (c1 > c2 * 5) r.flags |= HS_COL_C1GT5C2;
             col_rec[col] = r;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host <-> device transfers as kernels over pinned host memory (hipHostMalloc'ed blocks are mapped into the device's address
+// space): a launch costs the host a few microseconds where hipMemcpyAsync costs 50 and an interrupt-driven completion signal,
+// and -- what matters more -- the number of bytes may be a value that only exists on the device when the kernel is queued
+// (a count a previous kernel of the stream produced), so that a chain of kernels ends in ONE host wait instead of "wait for the
+// count, then queue the copy, then wait again". Up to 8 segments per launch; a segment's length is `bytes`, or, with `count`,
+// min(*count, cap) * stride (+ extra) bytes, rounded up to 16 (every block of the pools is 256-byte aligned and padded).
+// ------------------------------------------------------------------------------------------------
+struct ShipSeg { const void* src; void* dst; long long bytes; const long long* count; long long stride, cap, extra; };
+struct ShipList { ShipSeg seg[8]; int n; };
+__global__ __launch_bounds__(256) void k_ship(const ShipList L) {
+    for (int s = 0; s < L.n; ++s) {
+        const ShipSeg& g = L.seg[s];
+        long long bytes = g.bytes;
+        if (g.count) { long long c = *g.count; if (c > g.cap) c = g.cap; if (c < 0) c = 0; bytes = c * g.stride + g.extra; }
+        const long long n16 = (bytes + 15) >> 4;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(g.src);
+        uint4* __restrict__ dst = reinterpret_cast<uint4*>(g.dst);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) dst[i] = src[i];
+    }
+}
+// (fills: the same reasoning for hipMemsetAsync)
+__global__ __launch_bounds__(256) void k_fill16(uint4* __restrict__ dst, long long n16, unsigned v) {
+    const uint4 x = make_uint4(v, v, v, v);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) dst[i] = x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The candidate columns as bit sets over the reads ranked by start position: what loop A of keep_only_robust_variants reads on
+// the host (hs::CandBits in hs_host.h; hs::cv_build_cand_bits is the same on the host, for the tests). One wavefront per packed
+// candidate column: lanes = entries. The distinct codes in the order their first entry brings them (LDS minima over the entry
+// index, then one wave minimum per code), the words the reads' ranks span, the largest alignment end, and the block
+// [any][slot bits][codes] -- built in LDS when it has at most HS_CB_LDS_WORDS words (nearly always: two words x five codes),
+// else in place with global atomics. Blocks are bump-allocated from `out_words` (counter[0] = words used; counter[1] != 0: the
+// capacity did not suffice or a column spans more than 65535 words -- the caller sizes up and runs the kernel again).
+// ------------------------------------------------------------------------------------------------
+struct alignas(16) CandBitsDev { int32_t wlo; uint16_t n_words, n_slots; int32_t idx_min, idx_max, reach, n_entries; long long word_off; };
+static_assert(sizeof(CandBitsDev) == 32, "CandBitsDev must be 32 bytes");
+#define HS_CB_LDS_WORDS 96
+#define HS_CB_WAVES 16      // columns per workgroup: ONE allocation atomic per workgroup (one per column: 60 k atomics on one address per launch, 0.8 ms)
+__global__ __launch_bounds__(64 * HS_CB_WAVES) void k_cand_bits(
+    const hs_colrec_dev* __restrict__ cand_rec, const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_idx, const uint8_t* __restrict__ cand_code,
+    const ColumnsHeader* __restrict__ header, long long cap_cand, const int32_t* __restrict__ contig_rec_off, const int32_t* __restrict__ rank_of,
+    const int32_t* __restrict__ read_end_by_rank, CandBitsDev* __restrict__ out_bits, unsigned long long* out_words, long long cap_words,
+    unsigned long long* counter) {
+    __shared__ int s_fp[HS_CB_WAVES][256];
+    __shared__ uint8_t s_slot[HS_CB_WAVES][256];
+    __shared__ uint8_t s_codes[HS_CB_WAVES][128];
+    __shared__ unsigned long long s_blk[HS_CB_WAVES][HS_CB_LDS_WORDS];
+    __shared__ int s_size[HS_CB_WAVES];
+    __shared__ long long s_base;
+    const int lane = lane_id();
+    const int wv = wave_id();
+    long long n_cand = header->n_flagged;
+    if (n_cand > cap_cand) n_cand = cap_cand;
+    const long long k = (long long)blockIdx.x * HS_CB_WAVES + wv;
+    const bool live = k < n_cand;      // (a wave without a column still meets the others at the barriers)
+    const hs_colrec_dev rec = cand_rec[live ? k : 0];
+    const int r0 = live ? contig_rec_off[rec.contig] : 0;
+    const int64_t e0 = live ? cand_off[k] : 0;
+    const int n = live ? (int)(cand_off[k + 1] - e0) : 0;
+    int* __restrict__ fp = s_fp[wv];
+    uint8_t* __restrict__ slot_of = s_slot[wv];
+    uint8_t* __restrict__ codes = s_codes[wv];
+    unsigned long long* __restrict__ blk = s_blk[wv];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fp[lane + 64 * i] = 0x7fffffff;
+    wave_lds_sync();
+    int lo = 0x7fffffff, hi = -1, reach = -1;
+    for (int j0 = 0; j0 < n; j0 += 64) {
+        const int j = j0 + lane;
+        if (j < n) {
+            const int rk = rank_of[r0 + cand_idx[e0 + j]];
+            const int w = rk >> 6;
+            lo = w < lo ? w : lo; hi = w > hi ? w : hi;
+            const int re = read_end_by_rank[r0 + rk];
+            reach = re > reach ? re : reach;
+            atomicMin(&fp[cand_code[e0 + j]], j);
+        }
+    }
+    wave_lds_sync();
+    lo = -wave_max_i32(-lo); hi = wave_max_i32(hi); reach = wave_max_i32(reach);
+    // the slots: the codes by first appearance
+    int nslots = 0;
+    {
+        int f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = fp[lane + 64 * i];
+        for (;;) {
+            int m = f[0];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) m = f[i] < m ? f[i] : m;
+            const int best = -wave_max_i32(-m);
+            if (best == 0x7fffffff || nslots == 128) break;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (f[i] == best) { f[i] = 0x7fffffff; slot_of[lane + 64 * i] = (uint8_t)nslots; codes[nslots] = (uint8_t)(lane + 64 * i); }
+            nslots++;
+        }
+    }
+    const int W = n > 0 ? hi - lo + 1 : 0;
+    if (n == 0) { lo = 0; nslots = 0; }
+    const int cells = W * (nslots + 1);
+    const int size = live ? cells + (nslots + 7) / 8 : 0;
+    if (lane == 0) s_size[wv] = size;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int w = 0; w < HS_CB_WAVES; ++w) total += s_size[w];
+        s_base = total ? (long long)atomicAdd(counter, (unsigned long long)total) : 0ll;
+    }
+    __syncthreads();      // (also: slot_of / codes are written)
+    if (!live) return;
+    long long off = s_base;
+    for (int w = 0; w < wv; ++w) off += s_size[w];
+    if (off + size > cap_words || W > 65535) { if (lane == 0) atomicOr(counter + 1, 1ull); off = -1; }
+    if (off >= 0 && n > 0) {
+        unsigned long long* __restrict__ out = out_words + off;
+        const bool in_lds = cells <= HS_CB_LDS_WORDS;
+        if (in_lds) { for (int x = lane; x < cells; x += 64) blk[x] = 0ull; }
+        else { for (int x = lane; x < cells; x += 64) out[x] = 0ull; __threadfence(); }
+        wave_lds_sync();
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const int j = j0 + lane;
+            if (j < n) {
+                const int rk = rank_of[r0 + cand_idx[e0 + j]];
+                const int w = (rk >> 6) - lo;
+                const unsigned long long bit = 1ull << (rk & 63);
+                const int sl = slot_of[cand_code[e0 + j]];
+                if (in_lds) { atomicOr(&blk[w], bit); atomicOr(&blk[(sl + 1) * W + w], bit); }
+                else { atomicOr(&out[w], bit); atomicOr(&out[(long long)(sl + 1) * W + w], bit); }
+            }
+        }
+        wave_lds_sync();
+        if (in_lds) for (int x = lane; x < cells; x += 64) out[x] = blk[x];
+        if (lane < (nslots + 7) / 8) {
+            unsigned long long cw = 0;
+            for (int q = 0; q < 8; ++q) if (8 * lane + q < nslots) cw |= (unsigned long long)codes[8 * lane + q] << (8 * q);
+            out[cells + lane] = cw;
+        }
+        if (nslots > 64 * 8) { /* unreachable: at most 128 slots */ }
+    }
+    if (lane == 0) {
+        CandBitsDev h;
+        h.wlo = lo; h.n_words = (uint16_t)(W > 65535 ? 65535 : W); h.n_slots = (uint16_t)nslots;
+        h.idx_min = n > 0 ? cand_idx[e0] : 0; h.idx_max = n > 0 ? cand_idx[e0 + n - 1] : -1; h.reach = reach; h.n_entries = n; h.word_off = off;
+        out_bits[k] = h;
     }
 }
 

@@ -62,12 +62,12 @@ int hs_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchron
  * events on the stream it runs on; the elapsed times, the number of launches and the ALGORITHMIC bytes of each launch
  *  are accumulated per kernel family, process-wide, until hs_kernel_stats_reset().
  * ---------------------------------------------------------------------------------------------- */
-#define HS_NKERNELS 25
+#define HS_NKERNELS 27
 enum {   /* one slot per kernel of the path (a slot's helper launches -- prefix scans, block sums -- are counted with it) */
     HS_K_CIGAR_SCAN = 0, HS_K_PILEUP, HS_K_COLUMN_STATS, HS_K_COLUMNS_COMPACT, HS_K_GATHER_COLUMNS, HS_K_COLUMN_TOP3, HS_K_CANDIDATES_SCAN,
     HS_K_PACK_COLUMNS, HS_K_PARTITION_TRANSPOSE, HS_K_PARTITION_LANES, HS_K_PARTITION_TEST, HS_K_SNP_SELECT, HS_K_WINDOW_MASKS,
     HS_K_SNP_PLANES, HS_K_SIMDIFF, HS_K_GRAPH_ROWS, HS_K_GRAPH_CSR, HS_K_VISIT_LISTS, HS_K_CW_SEED_SETS, HS_K_CW_SEEDED, HS_K_CW_SEEDED_WIDE,
-    HS_K_WINDOW_TAIL, HS_K_CW_LOCAL, HS_K_ROBUST_PARTITIONS, HS_K_OTHER
+    HS_K_WINDOW_TAIL, HS_K_CW_LOCAL, HS_K_ROBUST_PARTITIONS, HS_K_OTHER, HS_K_CAND_BITS, HS_K_SHIP
 };
 typedef struct hs_kernel_stats {
     double ms[HS_NKERNELS];        /* sum of the launch durations (hipEventElapsedTime) */

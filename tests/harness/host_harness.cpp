@@ -114,8 +114,33 @@ struct OracleCvOps : hs::CvDeviceOps {
         pack(HS_COL_CAND);
         out.n_cand = (int64_t)pk_rec.size();
         out.rec = pk_rec.data(); out.col = pk_col.data(); out.off = pk_off.data(); out.idx = pk_idx.data(); out.code = pk_code.data();
+        // the candidates as bit sets over the reads ranked by start position (what the device's k_cand_bits hands to loop A),
+        // contig by contig with the product's own restatement of that kernel; word offsets count from the start of cb_words
+        cb_bits.assign(pk_rec.size(), hs::CandBits()); cb_words.clear();
+        {
+            size_t k = 0;
+            for (int c = c0; c < c1; ++c) {
+                const int n = out.contig_n_cand[(size_t)(c - c0)];
+                const int rr0 = in.contig_rec_off[(size_t)c], nr = in.contig_rec_off[(size_t)c + 1] - rr0;
+                std::vector<int32_t> rank_of, orig_of, read_end((size_t)nr);
+                hs::cv_rank_reads(nr, in.rec_pos.data() + rr0, rank_of, orig_of);
+                for (int r = 0; r < nr; ++r) {
+                    int64_t span = 0;
+                    for (int64_t o = in.rec_cig_off[(size_t)(rr0 + r)]; o < in.rec_cig_off[(size_t)(rr0 + r) + 1]; ++o) {
+                        const uint32_t op = in.cigar[(size_t)o] & 15u;
+                        if (op == 0 || op == 2 || op == 7 || op == 8) span += in.cigar[(size_t)o] >> 4;
+                    }
+                    read_end[(size_t)r] = (int32_t)std::min<int64_t>((int64_t)in.rec_pos[(size_t)(rr0 + r)] + span, 0x7fffffff);
+                }
+                hs::cv_build_cand_bits(n, pk_off.data() + k, pk_idx.data(), pk_code.data(), rank_of.data(), read_end.data(), cb_bits.data() + k, cb_words);
+                k += (size_t)n;
+            }
+        }
+        cb_words.push_back(0);
+        out.bits = cb_bits.data(); out.words = cb_words.data();
         return 0;
     }
+    std::vector<hs::CandBits> cb_bits; std::vector<uint64_t> cb_words;
     // loops C and D of keep_only_robust_variants through the oracle's distance() / computeChiSquare(), then the reference's own
     // two-pointer merge of the automatic and the filtered SNPs (call_variants.cpp:1335-1352)
     int finish_columns(const hs::CvPartitionTest& t, bool want_entries, hs::CvSnpSet& out, float* k_ms) override {
