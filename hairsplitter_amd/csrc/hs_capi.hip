@@ -172,6 +172,7 @@ static const bool g_copy_stats = [] {
 }();
 #define HS_COPY_ASYNC(...) ((g_copy_stats ? (void)g_copy_sites[__LINE__ & 4095].fetch_add(1, std::memory_order_relaxed) : (void)0), hipMemcpyAsync(__VA_ARGS__))
 
+static int ship_kernel(void* dst, const void* src, size_t bytes, hipStream_t stream);      // (hsdev::k_ship, below the kernels)
 struct UploadPack {
     struct Item { const void* src; size_t bytes, off; DBuf* dst; };
     std::vector<Item> items;
@@ -194,7 +195,7 @@ struct UploadPack {
             it.dst->release();
             it.dst->p = (char*)dev.p + it.off; it.dst->bytes = it.bytes; it.dst->cap = 0; it.dst->view = true;
         }
-        if (total) HS_HIP(HS_COPY_ASYNC(dev.p, host.p, total, hipMemcpyHostToDevice, stream));
+        if (total) { if (int rc = ship_kernel(dev.p, host.p, total, stream)) return rc; }
         items.clear(); total = 0;
         return HS_OK;
     }
@@ -266,6 +267,13 @@ static int d2h_pinned(void* dst, const void* d, size_t n, hipStream_t s) {
     return HS_OK;
 }
 
+static int ship_kernel(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    hsdev::ShipList L; L.n = 1;
+    L.seg[0].src = src; L.seg[0].dst = dst; L.seg[0].bytes = (long long)bytes; L.seg[0].count = nullptr; L.seg[0].stride = 0; L.seg[0].cap = 0; L.seg[0].extra = 0;
+    hipLaunchKernelGGL(hsdev::k_ship, dim3((unsigned)std::max<size_t>(1, std::min<size_t>(256, bytes / 4096 + 1))), dim3(256), 0, stream, L);
+    HS_HIP(hipGetLastError());
+    return HS_OK;
+}
 // a transfer queued as a kernel (hsdev::k_ship: pinned host memory is mapped into the device's address space); segments whose length
 // is a count on the device take it from there when the kernel runs
 struct Shipment {
@@ -784,7 +792,7 @@ int hs_pack_columns(const int64_t* d_col_off, const int32_t* d_col_idx, const ui
 // dense state arrays), then the exact one-partition-at-a-time kernel on the few columns the first one leaves undecided
 static int partition_test_launch(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code, const int32_t* d_col_contig,
                                  const uint8_t* d_col_k0, const uint8_t* d_col_k1, const int32_t* d_col_c1, const uint8_t* d_col_is_cand, int32_t n_cols,
-                                 const int32_t* d_part_off, const int64_t* d_part_state_off, const int8_t* d_part_state,
+                                 DBuf& b_part_off, DBuf& b_part_state_off, DBuf& b_part_state /* (filled by pk.commit below) */,
                                  const int32_t* h_part_off, const int32_t* h_contig_n_reads, int32_t n_contigs, uint8_t* d_keep, hipStream_t stream,
                                  DBuf& d_tab, DBuf& d_tab_off, DBuf& d_ctg_n, DBuf& d_list, UploadPack& pk, KernelClock* kc = nullptr,
                                  int64_t col_entries = 0, int64_t state_bytes = 0) {
@@ -799,6 +807,7 @@ static int partition_test_launch(const int64_t* d_col_off, const int32_t* d_col_
     }
     pk.add(tab_off, d_tab_off); pk.add(ctg_n, d_ctg_n);
     if (int rc = pk.commit(stream)) return rc;
+    const int32_t* d_part_off = b_part_off.as<int32_t>(); const int64_t* d_part_state_off = b_part_state_off.as<int64_t>(); const int8_t* d_part_state = b_part_state.as<int8_t>();
     if (int rc = d_tab.alloc(std::max<size_t>((size_t)tab_off.back(), 64))) return rc;
     if (tab_off.back() > 0) {
         const unsigned gx = (unsigned)std::min<int64_t>((max_cells + 255) / 256, 64);
@@ -808,7 +817,7 @@ static int partition_test_launch(const int64_t* d_col_off, const int32_t* d_col_
         if (kc) { if (int rc = kc->end(state_bytes + (int64_t)tab_off.back(), stream)) return rc; }      // the dense states in, the [read][partition] table out
     }
     if (int rc = d_list.alloc(((size_t)n_cols + 1) * 4)) return rc;     // [0] = number of undecided columns, then their indices
-    HS_HIP(hipMemsetAsync(d_list.p, 0, 4, stream));
+    hipLaunchKernelGGL(hsdev::k_fill16, dim3(1), dim3(64), 0, stream, d_list.as<uint4>(), 1ll, 0u);
     if (kc) { if (int rc = kc->begin(HS_K_PARTITION_LANES, stream)) return rc; }
     hipLaunchKernelGGL(hsdev::k_column_partition_lanes, dim3((n_cols + 63) / 64), dim3(256), 0, stream, d_col_off, d_col_idx, d_col_code, d_col_contig,
                        d_col_k0, d_col_k1, d_col_c1, d_col_is_cand, n_cols, d_part_off, d_tab_off.as<int64_t>(), d_tab.as<uint8_t>(), d_keep,
@@ -849,10 +858,11 @@ int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx,
     if (!h_contig_n_reads || n_contigs <= 0) { set_error("hs_column_partition_test: the number of reads of every contig is needed"); return HS_EINVAL; }
     std::vector<int32_t> h_po((size_t)n_contigs + 1);
     if (int rc = d2h_pinned(h_po.data(), d_part_off, h_po.size() * 4, (hipStream_t)stream)) return rc;
-    DBuf tab, tab_off, ctg_n, list;
+    DBuf tab, tab_off, ctg_n, list, v_po, v_pso, v_ps;      // (the caller's device arrays as views)
+    v_po.p = const_cast<int32_t*>(d_part_off); v_po.view = true; v_pso.p = const_cast<int64_t*>(d_part_state_off); v_pso.view = true; v_ps.p = const_cast<int8_t*>(d_part_state); v_ps.view = true;
     UploadPack pk;
-    if (int rc = partition_test_launch(d_col_off, d_col_idx, d_col_code, d_col_contig, d_col_k0, d_col_k1, d_col_c1, d_col_is_cand, n_cols, d_part_off,
-                                       d_part_state_off, d_part_state, h_po.data(), h_contig_n_reads, n_contigs, d_keep, (hipStream_t)stream, tab, tab_off, ctg_n, list, pk)) return rc;
+    if (int rc = partition_test_launch(d_col_off, d_col_idx, d_col_code, d_col_contig, d_col_k0, d_col_k1, d_col_c1, d_col_is_cand, n_cols, v_po,
+                                       v_pso, v_ps, h_po.data(), h_contig_n_reads, n_contigs, d_keep, (hipStream_t)stream, tab, tab_off, ctg_n, list, pk)) return rc;
     return stream_wait((hipStream_t)stream);   // the table goes back to the pool with this scope
 }
 
@@ -1444,105 +1454,138 @@ struct HipCvOps : hs::CvDeviceOps {
     static int grow(HBuf& h, size_t need) { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); }
     static int grow(DBuf& d, size_t need) { if (d.cap >= need && d.p && !d.view) { d.bytes = need; return HS_OK; } return d.alloc(need + need / 4); }
 
-    int fetch_info() {      // the info block from the device (one download + wait)
-        const size_t bytes = 128 + (size_t)(range_c1 - range_c0) * 8;
+    // What a call learnt about the sizes of this contig range, kept by the caller from step to step (a pipeline group runs the same
+    // contigs again and again; a service runs batches of the same shape): with it the arrays are sized ahead and the whole column
+    // pass, K2 to the candidates' bit sets, is queued without a host round trip; every kernel checks the capacities it was given and
+    // a pass whose numbers did not fit (the header says so) is run again the careful way, sizes first.
+    struct Keep {
+        bool valid = false;
+        int64_t cols = 0, entries = 0, cand = 0, cand_entries = 0, cb_words = 0, snp = 0, snp_entries = 0;
+        hipEvent_t k2_done = nullptr;      // K2 of the groups one after the other on the device (DeviceTurn without the host in it)
+        ~Keep() { if (k2_done) (void)hipEventDestroy(k2_done); }
+    };
+    struct K2Order { std::mutex mu; hipEvent_t last = nullptr; };      // per pipeline: the event behind which the next group's K2 queues
+    Keep* keep = nullptr;
+    K2Order* k2_order = nullptr;
+    static int64_t with_margin(int64_t v) { return v + v / 8 + 1024; }
+    static bool hints_on() { static const bool off = std::getenv("HS_NO_SIZE_HINTS") != nullptr; return !off; }
+
+    int fetch_info() {      // the info block from the device (one transfer + wait)
+        const size_t bytes = 128 + (size_t)(range_c1 - range_c0) * 16;
         if (int rc = grow(h_info, bytes)) return rc;
-        return copy_d2h(h_info.p, d_info.p, bytes, stream);
+        Shipment sh; sh.add(h_info.p, d_info.p, bytes);
+        if (int rc = sh.launch(stream, 1)) return rc;
+        return stream_wait(stream);
     }
-    // the columns carrying `flag` packed on the device (d_pk) and, with their entries if asked for, on the host (h_pk)
-    // download: 0 nothing (the packed block stays on the device), 1 records + offsets, 2 the entries too
-    int pack_flagged(int flag, int download, int64_t* n_out, int64_t* e_out) {
-        const int n_blocks = (int)((n_cols + HS_FP_BLOCK - 1) / HS_FP_BLOCK);
-        *n_out = 0; *e_out = 0;
-        if (n_blocks == 0) return fetch_info();
-        if (int rc = grow(d_blk_cnt, (size_t)n_blocks * 8)) return rc;
-        if (int rc = grow(d_blk_ent, (size_t)n_blocks * 8)) return rc;
+    // the columns carrying `flag`: block sums + offsets (the header then holds their number and their entries) ...
+    int flag_sums_launch(int flag, int64_t cols_cap) {
+        const int n_blocks = (int)((cols_cap + HS_FP_BLOCK - 1) / HS_FP_BLOCK);
+        if (int rc = grow(d_blk_cnt, std::max<size_t>(1, (size_t)n_blocks) * 8)) return rc;
+        if (int rc = grow(d_blk_ent, std::max<size_t>(1, (size_t)n_blocks) * 8)) return rc;
         if (int rc = kc.begin(HS_K_PACK_COLUMNS, stream)) return rc;
-        hipLaunchKernelGGL(hsdev::k_flag_block_sums, dim3((unsigned)n_blocks), dim3(256), 0, stream, d_col_rec.as<hsdev::hs_colrec_dev>(), d_col_len.as<int32_t>(),
-                           dev_header(), flag, d_blk_cnt.as<long long>(), d_blk_ent.as<long long>());
+        if (n_blocks > 0)
+            hipLaunchKernelGGL(hsdev::k_flag_block_sums, dim3((unsigned)n_blocks), dim3(256), 0, stream, d_col_rec.as<hsdev::hs_colrec_dev>(), d_col_len.as<int32_t>(),
+                               dev_header(), flag, d_blk_cnt.as<long long>(), d_blk_ent.as<long long>());
         hipLaunchKernelGGL(hsdev::k_flag_block_offsets, dim3(1), dim3(1024), 0, stream, d_blk_cnt.as<long long>(), d_blk_ent.as<long long>(), n_blocks, dev_header());
         HS_HIP(hipGetLastError());
-        if (int rc = kc.end(20 * n_cols, stream)) return rc;      // record + length of every column in
-        if (int rc = fetch_info()) return rc;
-        const int64_t nf = host_header().n_flagged, ne = host_header().n_flagged_entries;
-        *n_out = nf; *e_out = ne;
-        pk_layout = pack_layout(nf, ne);
+        return kc.end(20 * cols_cap, stream);      // record + length of every column in
+    }
+    // ... and packed on the device (d_pk, laid out for the capacities cap_f columns / cap_e entries)
+    int pack_launch(int flag, int64_t cols_cap, int64_t cap_f, int64_t cap_e) {
+        const int n_blocks = (int)((cols_cap + HS_FP_BLOCK - 1) / HS_FP_BLOCK);
+        pk_layout = pack_layout(cap_f, cap_e);
         const PackLayout& L = pk_layout;
         if (int rc = grow(d_pk, L.total)) return rc;
         char* base = (char*)d_pk.p;
-        if (nf == 0) { HS_HIP(hipMemsetAsync(base + L.off, 0, 8, stream)); }
+        hipLaunchKernelGGL(hsdev::k_fill16, dim3(1), dim3(64), 0, stream, reinterpret_cast<uint4*>(base + L.off), 1ll, 0u);      // (no flagged column: offsets[0] = 0)
+        if (n_blocks == 0) { HS_HIP(hipGetLastError()); return HS_OK; }
         if (int rc = kc.begin(HS_K_PACK_COLUMNS, stream)) return rc;
         hipLaunchKernelGGL(hsdev::k_pack_flagged, dim3((unsigned)n_blocks), dim3(256), 0, stream, d_col_rec.as<hsdev::hs_colrec_dev>(), d_co.as<int64_t>(),
                            d_col_len.as<int32_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), dev_header(), flag, d_blk_cnt.as<long long>(),
                            d_blk_ent.as<long long>(), (hsdev::hs_colrec_dev*)(base + L.rec), (int32_t*)(base + L.col), (int64_t*)(base + L.off), (int32_t*)(base + L.idx),
-                           (uint8_t*)(base + L.code), nf, ne);
+                           (uint8_t*)(base + L.code), cap_f, cap_e);
         HS_HIP(hipGetLastError());
-        if (int rc = kc.end(10 * ne + 60 * nf, stream)) return rc;      // the flagged columns' entries in and out, their records
-        if (download) {
-            const size_t bytes = download == 2 ? L.total : L.head;
-            if (int rc = grow(h_pk, std::max<size_t>(bytes, 256))) return rc;
-            HS_HIP(HS_COPY_ASYNC(h_pk.p, d_pk.p, bytes, hipMemcpyDeviceToHost, stream));
-        }
-        return HS_OK;
+        return kc.end(10 * cap_e + 60 * cap_f, stream);      // the flagged columns' entries in and out, their records
     }
 
-    // The packed candidates as bit sets (k_cand_bits) straight into pinned host memory, with their records: what loop A reads.
-    // The word blocks are bump-allocated on the device; a capacity that does not suffice doubles and the kernel runs again.
+    // The packed candidates as bit sets (k_cand_bits) straight into pinned host memory, with their records and the info block: what
+    // loop A reads. The word blocks are bump-allocated on the device (cap_words).
     DBuf d_cb_bits, d_cb_words, d_cb_counter;
     HBuf h_cb;
-    int64_t cb_words_hint = 0;        // words the blocks took last time (kept by the caller from step to step: HipCvKeep)
-    int ship_cand_bits(hs::CvCandidates& out) {
-        out.bits = nullptr; out.words = nullptr;
-        if (cand_count == 0) return HS_OK;
+    struct CbLayout { size_t rec, bits, words, total; int64_t cap_cand, cap_words; } cbl{};
+    int cand_bits_launch(int64_t cap_cand, int64_t cap_cand_entries, int64_t cap_words) {
         static_assert(sizeof(hs::CandBits) == sizeof(hsdev::CandBitsDev), "CandBits layout");
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        cbl.cap_cand = cap_cand; cbl.cap_words = cap_words;
+        cbl.rec = 256; cbl.bits = cbl.rec + up((size_t)cap_cand * 16); cbl.words = cbl.bits + up((size_t)cap_cand * 32); cbl.total = cbl.words + up((size_t)cap_words * 8);
+        if (int rc = grow(d_cb_bits, std::max<size_t>(1, (size_t)cap_cand) * 32)) return rc;
+        if (int rc = grow(d_cb_words, std::max<size_t>(1, (size_t)cap_words) * 8)) return rc;
+        if (int rc = grow(d_cb_counter, 256)) return rc;
+        if (int rc = grow(h_cb, cbl.total)) return rc;
         const char* cb = (const char*)d_cand_pk.p;
-        int64_t cap_words = std::max<int64_t>(cb_words_hint + cb_words_hint / 8, 16 * cand_count + cand_entries / 4) + 64;
-        for (int attempt = 0;; ++attempt) {
-            if (int rc = grow(d_cb_bits, (size_t)cand_count * 32)) return rc;
-            if (int rc = grow(d_cb_words, (size_t)cap_words * 8)) return rc;
-            if (int rc = grow(d_cb_counter, 256)) return rc;
-            const size_t o_rec = 256, o_bits = o_rec + (((size_t)cand_count * 16 + 255) & ~(size_t)255), o_words = o_bits + (((size_t)cand_count * 32 + 255) & ~(size_t)255);
-            if (int rc = grow(h_cb, o_words + (size_t)cap_words * 8 + 256)) return rc;
-            hipLaunchKernelGGL(hsdev::k_fill16, dim3(1), dim3(64), 0, stream, d_cb_counter.as<uint4>(), 16ll, 0u);
+        hipLaunchKernelGGL(hsdev::k_fill16, dim3(1), dim3(64), 0, stream, d_cb_counter.as<uint4>(), 16ll, 0u);
+        if (cap_cand > 0) {
             if (int rc = kc.begin(HS_K_CAND_BITS, stream)) return rc;
-            hipLaunchKernelGGL(hsdev::k_cand_bits, dim3((unsigned)((cand_count + HS_CB_WAVES - 1) / HS_CB_WAVES)), dim3(64 * HS_CB_WAVES), 0, stream, (const hsdev::hs_colrec_dev*)(cb + cand_layout.rec),
-                               (const int64_t*)(cb + cand_layout.off), (const int32_t*)(cb + cand_layout.idx), (const uint8_t*)(cb + cand_layout.code), dev_header(),
-                               (long long)cand_count, b->d_contig_rec_off.as<int32_t>(), b->d_rank_of.as<int32_t>(), b->d_read_end.as<int32_t>(),
-                               d_cb_bits.as<hsdev::CandBitsDev>(), d_cb_words.as<unsigned long long>(), (long long)cap_words, d_cb_counter.as<unsigned long long>());
+            hipLaunchKernelGGL(hsdev::k_cand_bits, dim3((unsigned)((cap_cand + HS_CB_WAVES - 1) / HS_CB_WAVES)), dim3(64 * HS_CB_WAVES), 0, stream,
+                               (const hsdev::hs_colrec_dev*)(cb + cand_layout.rec), (const int64_t*)(cb + cand_layout.off), (const int32_t*)(cb + cand_layout.idx),
+                               (const uint8_t*)(cb + cand_layout.code), dev_header(), (long long)cap_cand, b->d_contig_rec_off.as<int32_t>(), b->d_rank_of.as<int32_t>(),
+                               b->d_read_end.as<int32_t>(), d_cb_bits.as<hsdev::CandBitsDev>(), d_cb_words.as<unsigned long long>(), (long long)cap_words,
+                               d_cb_counter.as<unsigned long long>(), (long long)cap_cand_entries);
             HS_HIP(hipGetLastError());
-            if (int rc = kc.end(5 * cand_entries + 48 * cand_count, stream)) return rc;      // the candidates' entries in; record, header and block out
-            Shipment sh;
-            sh.add(h_cb.p, d_cb_counter.p, 16);
-            sh.add((char*)h_cb.p + o_rec, cb + cand_layout.rec, (size_t)cand_count * 16);
-            sh.add((char*)h_cb.p + o_bits, d_cb_bits.p, (size_t)cand_count * 32);
-            sh.add_counted((char*)h_cb.p + o_words, d_cb_words.p, d_cb_counter.as<long long>(), 8, cap_words);
-            if (int rc = sh.launch(stream)) return rc;
-            if (int rc = stream_wait(stream)) return rc;
-            const unsigned long long* cnt = (const unsigned long long*)h_cb.p;
-            if (cnt[1] == 0) {
-                cb_words_hint = (int64_t)cnt[0];
-                out.rec = (const hs_colrec*)((const char*)h_cb.p + o_rec);
-                out.bits = (const hs::CandBits*)((const char*)h_cb.p + o_bits);
-                out.words = (const uint64_t*)((const char*)h_cb.p + o_words);
-                return HS_OK;
-            }
-            if (attempt >= 8 || (int64_t)cnt[0] <= cap_words) { set_error("candidate bit sets: a column spans more than 65535 words of reads"); return HS_EINVAL; }
-            cap_words = (int64_t)cnt[0] + 64;      // (the counter ran on past the capacity: it is the exact need)
+            if (int rc = kc.end(5 * cap_cand_entries + 48 * cap_cand, stream)) return rc;      // the candidates' entries in; record, header and block out
         }
+        Shipment sh;
+        sh.add(h_cb.p, d_cb_counter.p, 16);
+        const long long* n_flagged = reinterpret_cast<const long long*>((const char*)d_info.p + offsetof(hsdev::ColumnsHeader, n_flagged));
+        sh.add_counted((char*)h_cb.p + cbl.rec, cb + cand_layout.rec, n_flagged, 16, cap_cand);
+        sh.add_counted((char*)h_cb.p + cbl.bits, d_cb_bits.p, n_flagged, 32, cap_cand);
+        sh.add_counted((char*)h_cb.p + cbl.words, d_cb_words.p, d_cb_counter.as<long long>(), 8, cap_words);
+        if (int rc = grow(h_info, 128 + (size_t)(range_c1 - range_c0) * 16)) return rc;
+        sh.add(h_info.p, d_info.p, 128 + (size_t)(range_c1 - range_c0) * 16);
+        if (int rc = kc.begin(HS_K_SHIP, stream)) return rc;
+        if (int rc = sh.launch(stream)) return rc;
+        return kc.end(0, stream);
+    }
+    // after the wait: did the capacities hold?
+    bool cand_bits_fit() const { const unsigned long long* cnt = (const unsigned long long*)h_cb.p; return cnt[1] == 0; }
+    int64_t cand_bits_words() const { return (int64_t)((const unsigned long long*)h_cb.p)[0]; }
+    void cand_bits_result(hs::CvCandidates& out) const {
+        out.rec = (const hs_colrec*)((const char*)h_cb.p + cbl.rec);
+        out.bits = (const hs::CandBits*)((const char*)h_cb.p + cbl.bits);
+        out.words = (const uint64_t*)((const char*)h_cb.p + cbl.words);
     }
     int fetch_candidates(hs::CvCandidates& out) override {      // the candidates of the last extract_candidates() for the host's loop A, after all
+        out.bits = nullptr; out.words = nullptr;
         if (cand_count == 0) return HS_OK;
-        return ship_cand_bits(out);
+        int64_t cap_words = std::max<int64_t>(with_margin(keep ? keep->cb_words : 0), 16 * cand_count + cand_entries / 4 + 64);
+        for (int attempt = 0;; ++attempt) {
+            if (int rc = cand_bits_launch(cand_count, cand_entries, cap_words)) return rc;
+            if (int rc = stream_wait(stream)) return rc;
+            if (cand_bits_fit()) { if (keep) keep->cb_words = cand_bits_words(); cand_bits_result(out); return HS_OK; }
+            if (attempt >= 4 || cand_bits_words() <= cap_words) { set_error("candidate bit sets: the blocks do not fit (a column over more than 65535 words of reads?)"); return HS_EINVAL; }
+            cap_words = cand_bits_words() + 64;      // (the counter ran on past the capacity: it is the exact need)
+        }
     }
-    DBuf d_cand_pk;                   // the packed candidates (kept beside d_pk, which the SNPs take later): k_loop_a reads them
+    DBuf d_cand_pk;                   // the packed candidates (kept beside d_pk, which the SNPs take later): k_cand_bits and k_loop_a read them
     PackLayout cand_layout{};
     int64_t cand_count = 0, cand_entries = 0;
     std::vector<int32_t> cand_per_contig;
     int extract_candidates(int c0, int c1, const std::vector<int32_t>& min_reads, float thr, hs::CvCandidates& out, float k_ms[3], bool want_entries) override {
+        const bool hinted = keep && keep->valid && want_entries && hints_on();
+        if (hinted) {
+            const int rc = extract_candidates_impl(c0, c1, min_reads, thr, out, k_ms, want_entries, true);
+            if (rc != HS_EAGAIN_SIZES) return rc;
+            keep->valid = false;      // (the sizes of this range have changed: the careful way, which also takes the new ones)
+        }
+        return extract_candidates_impl(c0, c1, min_reads, thr, out, k_ms, want_entries, false);
+    }
+    static constexpr int HS_EAGAIN_SIZES = -1000;      // (internal: a capacity did not hold)
+    int extract_candidates_impl(int c0, int c1, const std::vector<int32_t>& min_reads, float thr, hs::CvCandidates& out, float k_ms[3], bool want_entries, bool hinted) {
         static_assert(sizeof(hs_colrec) == sizeof(hsdev::hs_colrec_dev), "hs_colrec layout");
         static_assert(sizeof(hsdev::ColumnsHeader) == 64, "info block layout");
         const int C = c1 - c0;
         range_c0 = c0; range_c1 = c1; n_cols = 0; n_entries = 0; n_gathered = 0; gathered_entries = 0;
+        cand_count = 0; cand_entries = 0;
         out = hs::CvCandidates();
         out.contig_n_cand.assign((size_t)C, 0);
         k_ms[0] = k_ms[1] = k_ms[2] = 0;
@@ -1554,43 +1597,58 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = e_k2.init()) return rc;
         if (int rc = e_k3.init()) return rc;
         if (int rc = e_k3b.init()) return rc;
-        if (int rc = grow(d_info, 128 + (size_t)C * 16)) return rc;
-        {   // ---- K2 over the tiles of the range: per tile its selected positions (second count >= 4), their depths and the sum of those ----
-            DeviceTurn turn;
-            if (int rc = range_scratch.prepare(nt * 256)) return rc;
-            if (int rc = grow(d_tile_ent_sum, (size_t)nt * 4)) return rc;
-            if (int rc = grow(d_tile_ebase, ((size_t)nt + 1) * 8)) return rc;
-            HS_HIP(hipMemsetAsync(d_info.p, 0, 128 + (size_t)C * 16, stream));      // (header, tie counters, candidates / SNPs / SNP bounds per contig)
+        const size_t info_bytes = 128 + (size_t)C * 16;
+        if (int rc = grow(d_info, info_bytes)) return rc;
+        if (int rc = range_scratch.prepare(nt * 256)) return rc;
+        if (int rc = grow(d_tile_ent_sum, (size_t)nt * 4)) return rc;
+        if (int rc = grow(d_tile_ebase, ((size_t)nt + 1) * 8)) return rc;
+        const int64_t range_pile = b->total_len > 0 ? (int64_t)((double)b->total_pile * (double)(g1 - g0) / (double)b->total_len) : 0;      // one code in per aligned bp of the range (its share of the batch)
+        auto k2_launch = [&]() -> int {   // ---- K2 over the tiles of the range: per tile its selected positions (second count >= 4), their depths and the sum of those ----
+            hipLaunchKernelGGL(hsdev::k_fill16, dim3(1), dim3(256), 0, stream, d_info.as<uint4>(), (long long)(info_bytes / 16), 0u);      // (header, tie counters, candidates / SNPs / SNP bounds per contig)
             HS_HIP(hipEventRecord(e_k2.a, stream));
             if (int rc = kc.begin(HS_K_COLUMN_STATS, stream)) return rc;
             hipEvent_t k2_done = nullptr;
-            const int64_t range_pile = b->total_len > 0 ? (int64_t)((double)b->total_pile * (double)(g1 - g0) / (double)b->total_len) : 0;      // one code in per aligned bp of the range (its share of the batch)
             if (int rc = kc.end_prepare(range_pile, &k2_done)) return rc;
             if (int rc = column_stats_tiled_launch(b->pile_ptr(), b->tile_off.as<int64_t>(), b->tile_ent.as<hs_tile_entry>(), b->total_len, nullptr, 4,
                                                    range_scratch.tile_cnt.as<int32_t>() /* (only "selection wanted") */, nullptr, nullptr, 0, b->max_depth, &range_scratch,
                                                    e_k2.b, stream, k2_done, t0, t1, g0, g1, d_tile_ent_sum.as<int32_t>(), false, true)) return rc;
             if (int rc = exclusive_scan_launch(range_scratch.tile_cnt.as<int32_t>(), (int)nt, range_scratch.tile_base.as<int64_t>(), range_scratch.scan_scratch, stream)) return rc;
-            if (int rc = exclusive_scan_launch(d_tile_ent_sum.as<int32_t>(), (int)nt, d_tile_ebase.as<int64_t>(), d_scan2, stream)) return rc;
+            return exclusive_scan_launch(d_tile_ent_sum.as<int32_t>(), (int)nt, d_tile_ebase.as<int64_t>(), d_scan2, stream);
+        };
+        int64_t cap_cols = 0, cap_entries = 0;
+        if (!hinted) {
+            DeviceTurn turn;
+            if (int rc = k2_launch()) return rc;
             // the two totals (the last elements of the scans) -> sizes of the column arrays
             hipLaunchKernelGGL(hsdev::k_columns_totals, dim3(1), dim3(64), 0, stream, range_scratch.tile_base.as<int64_t>() + nt, d_tile_ebase.as<int64_t>() + nt, dev_header());
             HS_HIP(hipGetLastError());
             if (int rc = fetch_info()) return rc;
+            cap_cols = host_header().n_cols; cap_entries = host_header().n_entries;
+        } else {
+            // the groups' K2 launches one after the other ON THE DEVICE (each fills it on its own, see DeviceTurn): this group's
+            // launch queues behind the event of the group that came before it, no host thread waits for anything
+            if (k2_order && DeviceTurn::on()) {
+                std::lock_guard<std::mutex> lk(k2_order->mu);
+                if (!keep->k2_done) HS_HIP(hipEventCreateWithFlags(&keep->k2_done, hipEventDisableTiming));
+                if (k2_order->last && k2_order->last != keep->k2_done) HS_HIP(hipStreamWaitEvent(stream, k2_order->last, 0));
+                if (int rc = k2_launch()) return rc;
+                HS_HIP(hipEventRecord(keep->k2_done, stream));
+                k2_order->last = keep->k2_done;
+            } else if (int rc = k2_launch()) return rc;
+            cap_cols = with_margin(keep->cols); cap_entries = with_margin(keep->entries);
         }
-        n_cols = host_header().n_cols; n_entries = host_header().n_entries;
-        out.n_columns = n_cols; out.n_entries = n_entries;
-        if (n_cols > 0x7fffffff) { set_error("more than 2^31 columns in one contig range"); return HS_EINVAL; }
-        n_gathered = (int)n_cols; gathered_entries = n_entries;
-        if (int rc = grow(d_col_gpos, std::max<size_t>(1, (size_t)n_cols) * 8)) return rc;
-        if (int rc = grow(d_col_rec, std::max<size_t>(1, (size_t)n_cols) * sizeof(hs_colrec))) return rc;
-        if (int rc = grow(d_co, ((size_t)n_cols + 1) * 8)) return rc;
-        if (int rc = grow(d_col_len, std::max<size_t>(1, (size_t)n_cols) * 4)) return rc;
-        if (int rc = grow(d_ci, std::max<size_t>(1, (size_t)n_entries) * 4)) return rc;
-        if (int rc = grow(d_cc, std::max<size_t>(1, (size_t)n_entries))) return rc;
-        if (int rc = grow(d_col_ctg, std::max<size_t>(1, (size_t)n_cols) * 4)) return rc;
-        if (int rc = grow(d_k0, std::max<size_t>(1, (size_t)n_cols))) return rc;
-        if (int rc = grow(d_k1, std::max<size_t>(1, (size_t)n_cols))) return rc;
-        if (int rc = grow(d_c1, std::max<size_t>(1, (size_t)n_cols) * 4)) return rc;
-        if (int rc = grow(d_cand, std::max<size_t>(1, (size_t)n_cols))) return rc;
+        if (cap_cols > 0x7fffffff) { set_error("more than 2^31 columns in one contig range"); return HS_EINVAL; }
+        if (int rc = grow(d_col_gpos, std::max<size_t>(1, (size_t)cap_cols) * 8)) return rc;
+        if (int rc = grow(d_col_rec, std::max<size_t>(1, (size_t)cap_cols) * sizeof(hs_colrec))) return rc;
+        if (int rc = grow(d_co, ((size_t)cap_cols + 1) * 8)) return rc;
+        if (int rc = grow(d_col_len, std::max<size_t>(1, (size_t)cap_cols) * 4)) return rc;
+        if (int rc = grow(d_ci, std::max<size_t>(1, (size_t)cap_entries) * 4)) return rc;
+        if (int rc = grow(d_cc, std::max<size_t>(1, (size_t)cap_entries))) return rc;
+        if (int rc = grow(d_col_ctg, std::max<size_t>(1, (size_t)cap_cols) * 4)) return rc;
+        if (int rc = grow(d_k0, std::max<size_t>(1, (size_t)cap_cols))) return rc;
+        if (int rc = grow(d_k1, std::max<size_t>(1, (size_t)cap_cols))) return rc;
+        if (int rc = grow(d_c1, std::max<size_t>(1, (size_t)cap_cols) * 4)) return rc;
+        if (int rc = grow(d_cand, std::max<size_t>(1, (size_t)cap_cols))) return rc;
         if (int rc = grow(d_ctg_col_off, ((size_t)C + 1) * 8)) return rc;
         range_pack.add(min_reads, d_min_reads);
         if (int rc = range_pack.commit(stream)) return rc;
@@ -1598,48 +1656,73 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = kc.begin(HS_K_COLUMNS_COMPACT, stream)) return rc;
         hipLaunchKernelGGL(hsdev::k_columns_compact, dim3((unsigned)nt), dim3(256), 0, stream, range_scratch.tile_cnt.as<int32_t>(), range_scratch.tile_base.as<int64_t>(),
                            d_tile_ebase.as<int64_t>(), range_scratch.gpos.as<int64_t>(), range_scratch.depth.as<int32_t>(), nt, b->d_contig_off.as<int64_t>(), b->n_contigs,
-                           d_col_gpos.as<int64_t>(), d_col_rec.as<hsdev::hs_colrec_dev>(), d_co.as<int64_t>(), d_col_len.as<int32_t>(), dev_header(), n_cols);
+                           d_col_gpos.as<int64_t>(), d_col_rec.as<hsdev::hs_colrec_dev>(), d_co.as<int64_t>(), d_col_len.as<int32_t>(), dev_header(), cap_cols, cap_entries);
         HS_HIP(hipGetLastError());
-        if (int rc = kc.end(20 * nt + 48 * n_cols, stream)) return rc;      // tile counts and bases in; slot in, position + record + offset + length out per column
+        if (int rc = kc.end(20 * nt + 48 * cap_cols, stream)) return rc;      // tile counts and bases in; slot in, position + record + offset + length out per column
         HS_HIP(hipEventRecord(e_k3.a, stream));
-        if (n_cols > 0) {
+        if (cap_cols > 0) {
             if (int rc = kc.begin(HS_K_GATHER_COLUMNS, stream)) return rc;
             hipLaunchKernelGGL(hsdev::k_gather_tiles, dim3((unsigned)((nt + 3) / 4)), dim3(256), 0, stream, b->pile_ptr(), b->tile_off.as<int64_t>(),
                                reinterpret_cast<const int4*>(b->tile_ent.as<hs_tile_entry>()), b->tile_lrec.as<int32_t>(), t0, nt, range_scratch.tile_cnt.as<int32_t>(),
-                               range_scratch.tile_base.as<int64_t>(), d_col_gpos.as<int64_t>(), d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>());
+                               range_scratch.tile_base.as<int64_t>(), d_col_gpos.as<int64_t>(), d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), dev_header());
             HS_HIP(hipGetLastError());
             // the pileup bytes of the range's tiles in (every one of them once), read index + code out per column entry
-            const int64_t range_pile = b->total_len > 0 ? (int64_t)((double)b->total_pile * (double)(g1 - g0) / (double)b->total_len) : 0;
-            if (int rc = kc.end(range_pile + 5 * n_entries, stream)) return rc;
+            if (int rc = kc.end(range_pile + 5 * (hinted ? keep->entries : cap_entries), stream)) return rc;
         }
         HS_HIP(hipEventRecord(e_k3.b, stream));
         HS_HIP(hipEventRecord(e_k3b.a, stream));
-        if (n_cols > 0) {
+        if (cap_cols > 0) {
             if (int rc = kc.begin(HS_K_COLUMN_TOP3, stream)) return rc;
-            const unsigned grid = (unsigned)std::min<int64_t>((n_cols + 3) / 4, 16384);
+            const unsigned grid = (unsigned)std::min<int64_t>((cap_cols + 3) / 4, 16384);
             hipLaunchKernelGGL(hsdev::k_column_top3_exact, dim3(grid), dim3(256), 0, stream, d_co.as<int64_t>(), d_col_len.as<int32_t>(), d_cc.as<uint8_t>(),
                                dev_header(), d_col_rec.as<hsdev::hs_colrec_dev>(), dev_tie());
             HS_HIP(hipGetLastError());
-            if (int rc = kc.end(n_entries + 16 * n_cols, stream)) return rc;
+            if (int rc = kc.end((hinted ? keep->entries : cap_entries) + 16 * (hinted ? keep->cols : cap_cols), stream)) return rc;
         }
         if (int rc = kc.begin(HS_K_CANDIDATES_SCAN, stream)) return rc;
-        hipLaunchKernelGGL(hsdev::k_candidates_scan, dim3((unsigned)((std::max<int64_t>(n_cols, C) + 255) / 256)), dim3(256), 0, stream, d_col_gpos.as<int64_t>(), dev_header(),
+        hipLaunchKernelGGL(hsdev::k_candidates_scan, dim3((unsigned)((std::max<int64_t>(cap_cols, C) + 255) / 256)), dim3(256), 0, stream, d_col_gpos.as<int64_t>(), dev_header(),
                            b->d_contig_off.as<int64_t>(), c0, C, d_min_reads.as<int32_t>(), thr, d_col_rec.as<hsdev::hs_colrec_dev>(), d_col_ctg.as<int32_t>(),
                            d_k0.as<uint8_t>(), d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), d_ctg_col_off.as<int64_t>(), dev_ctg_n());
         HS_HIP(hipGetLastError());
-        if (int rc = kc.end(43 * n_cols, stream)) return rc;      // record in and out, the four arrays K4 reads out
+        if (int rc = kc.end(43 * (hinted ? keep->cols : cap_cols), stream)) return rc;      // record in and out, the four arrays K4 reads out
         HS_HIP(hipEventRecord(e_k3b.b, stream));
         // ---- the candidates, packed (they stay on the device); the host's loop A gets them as bit sets ----
-        int64_t n_cand = 0, e_cand = 0;
-        if (int rc = pack_flagged(HS_COL_CAND, 0, &n_cand, &e_cand)) return rc;      // (its info download carries the per-contig counts and the tie counters)
-        std::memcpy(out.contig_n_cand.data(), host_ctg_n(), (size_t)C * 4);
-        cand_per_contig = out.contig_n_cand; cand_count = n_cand; cand_entries = e_cand; cand_layout = pk_layout;
+        if (int rc = flag_sums_launch(HS_COL_CAND, cap_cols)) return rc;
+        int64_t cap_cand = 0, cap_cand_entries = 0, cap_words = 0;
+        if (!hinted) {
+            if (int rc = fetch_info()) return rc;      // (carries the per-contig counts and the tie counters too)
+            cap_cand = host_header().n_flagged; cap_cand_entries = host_header().n_flagged_entries;
+            cap_words = std::max<int64_t>(with_margin(keep ? keep->cb_words : 0), 16 * cap_cand + cap_cand_entries / 4 + 64);
+        } else { cap_cand = with_margin(keep->cand); cap_cand_entries = with_margin(keep->cand_entries); cap_words = with_margin(keep->cb_words); }
+        if (int rc = pack_launch(HS_COL_CAND, cap_cols, cap_cand, cap_cand_entries)) return rc;
+        cand_layout = pk_layout;
         std::swap(d_cand_pk, d_pk);      // (d_pk is packed again for the SNPs)
+        if (want_entries) {
+            for (int attempt = 0;; ++attempt) {
+                if (int rc = cand_bits_launch(cap_cand, cap_cand_entries, cap_words)) return rc;
+                if (int rc = stream_wait(stream)) return rc;
+                if (cand_bits_fit()) break;
+                if (hinted) return HS_EAGAIN_SIZES;
+                if (attempt >= 4 || cand_bits_words() <= cap_words) { set_error("candidate bit sets: the blocks do not fit (a column over more than 65535 words of reads?)"); return HS_EINVAL; }
+                cap_words = cand_bits_words() + 64;      // (the counter ran on past the capacity: it is the exact need)
+            }
+        } else if (int rc = fetch_info()) return rc;
+        const hsdev::ColumnsHeader& H = host_header();
+        if (hinted && (!H.ok || H.n_cols > cap_cols || H.n_entries > cap_entries || H.n_flagged > cap_cand || H.n_flagged_entries > cap_cand_entries)) return HS_EAGAIN_SIZES;
+        n_cols = H.n_cols; n_entries = H.n_entries;
+        out.n_columns = n_cols; out.n_entries = n_entries;
+        n_gathered = (int)n_cols; gathered_entries = n_entries;
+        std::memcpy(out.contig_n_cand.data(), host_ctg_n(), (size_t)C * 4);
+        cand_per_contig = out.contig_n_cand; cand_count = H.n_flagged; cand_entries = H.n_flagged_entries;
         { unsigned long long t2[2]; std::memcpy(t2, (const char*)h_info.p + 64, 16); out.n_tie = (int64_t)t2[0]; out.n_tie_big = (int64_t)t2[1]; }
-        out.n_cand = n_cand;
+        out.n_cand = cand_count;
         { static const int64_t zero_off[1] = {0}; out.off = zero_off; }
-        if (n_cand > 0 && want_entries) { if (int rc = ship_cand_bits(out)) return rc; }
-        else if (int rc = stream_wait(stream)) return rc;
+        if (want_entries && cand_count > 0) cand_bits_result(out);
+        if (keep) {
+            keep->cols = n_cols; keep->entries = n_entries; keep->cand = cand_count; keep->cand_entries = cand_entries;
+            if (want_entries) keep->cb_words = cand_bits_words();
+            keep->valid = want_entries;
+        }
         kc.flush();
         if (int rc = e_k2.ms(&k_ms[0])) return rc;
         if (int rc = e_k3.ms(&k_ms[1])) return rc;
@@ -1660,25 +1743,23 @@ struct HipCvOps : hs::CvDeviceOps {
         if (n_cols == 0 || C == 0) {
             pk_layout = pack_layout(0, 0);
             if (int rc = grow(d_pk, pk_layout.total)) return rc;
-            HS_HIP(hipMemsetAsync((char*)d_pk.p + pk_layout.off, 0, 8, stream));
+            hipLaunchKernelGGL(hsdev::k_fill16, dim3(1), dim3(64), 0, stream, reinterpret_cast<uint4*>((char*)d_pk.p + pk_layout.off), 1ll, 0u);
             out.off = zero_off;
             return stream_wait(stream);
         }
         const int n = (int)n_cols;
         DBuf d_po, d_pso, d_ps;
-        UploadPack pk;
-        pk.add(t.part_off, d_po);
-        pk.add(t.part_state_off, d_pso);
-        pk.add(t.part_state, d_ps);
-        if (int rc = pk.commit(stream)) return rc;
+        DBuf d_tab, d_tab_off, d_ctg_nr, d_list;
+        UploadPack pk_tab;      // one upload: the partitions and the table offsets (partition_test_launch adds its arrays and commits)
+        pk_tab.add(t.part_off, d_po);
+        pk_tab.add(t.part_state_off, d_pso);
+        pk_tab.add(t.part_state, d_ps);
         if (int rc = grow(d_keep, (size_t)n)) return rc;
         EventPair e; if (int rc = e.init()) return rc;
         HS_HIP(hipEventRecord(e.a, stream));
-        DBuf d_tab, d_tab_off, d_ctg_nr, d_list;
-        UploadPack pk_tab;
         if (int rc = partition_test_launch(d_co.as<int64_t>(), d_ci.as<int32_t>(), d_cc.as<uint8_t>(), d_col_ctg.as<int32_t>(), d_k0.as<uint8_t>(),
-                                           d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), n, d_po.as<int32_t>(), d_pso.as<int64_t>(),
-                                           d_ps.as<int8_t>(), t.part_off.data(), t.contig_n_reads.data(), C, d_keep.as<uint8_t>(),
+                                           d_k1.as<uint8_t>(), d_c1.as<int32_t>(), d_cand.as<uint8_t>(), n, d_po, d_pso,
+                                           d_ps, t.part_off.data(), t.contig_n_reads.data(), C, d_keep.as<uint8_t>(),
                                            stream, d_tab, d_tab_off, d_ctg_nr, d_list, pk_tab, &kc, gathered_entries, (int64_t)t.part_state.size())) return rc;
         HS_HIP(hipEventRecord(e.b, stream));
         if (int rc = kc.begin(HS_K_SNP_SELECT, stream)) return rc;
@@ -1688,12 +1769,43 @@ struct HipCvOps : hs::CvDeviceOps {
                            d_keep.as<uint8_t>(), n_cols, C, dev_snp_bounds(), dev_ctg_snp());
         HS_HIP(hipGetLastError());
         if (int rc = kc.end(33 * n_cols, stream)) return rc;      // records in (twice) and out, the verdicts in
-        int64_t n_snp = 0, e_snp = 0;
-        if (int rc = pack_flagged(HS_COL_SNP, want_entries ? 2 : 1, &n_snp, &e_snp)) return rc;      // (the partition tables, uploads and lists of this scope are done with: it waits)
+        if (int rc = flag_sums_launch(HS_COL_SNP, n_cols)) return rc;
+        bool hinted = keep && keep->valid && keep->snp > 0 && hints_on();
+        for (;;) {
+            int64_t cap_snp, cap_snp_entries;
+            if (!hinted) {
+                if (int rc = fetch_info()) return rc;      // (the partition tables, uploads and lists of this scope are done with: it waits)
+                cap_snp = host_header().n_flagged; cap_snp_entries = host_header().n_flagged_entries;
+            } else { cap_snp = with_margin(keep->snp); cap_snp_entries = with_margin(keep->snp_entries); }
+            if (int rc = pack_launch(HS_COL_SNP, n_cols, cap_snp, cap_snp_entries)) return rc;
+            // the SNPs' records and offsets (and, for a caller that writes the .col file, their entries) into pinned memory, with the info block
+            const PackLayout& L = pk_layout;
+            if (int rc = grow(h_pk, std::max<size_t>(want_entries ? L.total : L.head, 256))) return rc;
+            if (int rc = grow(h_info, 128 + (size_t)C * 16)) return rc;
+            const long long* n_flagged = reinterpret_cast<const long long*>((const char*)d_info.p + offsetof(hsdev::ColumnsHeader, n_flagged));
+            const long long* n_flagged_e = reinterpret_cast<const long long*>((const char*)d_info.p + offsetof(hsdev::ColumnsHeader, n_flagged_entries));
+            Shipment sh;
+            const char* base = (const char*)d_pk.p;
+            sh.add_counted((char*)h_pk.p + L.rec, base + L.rec, n_flagged, 16, cap_snp);
+            sh.add_counted((char*)h_pk.p + L.off, base + L.off, n_flagged, 8, cap_snp, 8);
+            if (want_entries) {
+                sh.add_counted((char*)h_pk.p + L.idx, base + L.idx, n_flagged_e, 4, cap_snp_entries);
+                sh.add_counted((char*)h_pk.p + L.code, base + L.code, n_flagged_e, 1, cap_snp_entries);
+            }
+            sh.add(h_info.p, d_info.p, 128 + (size_t)C * 16);
+            if (int rc = kc.begin(HS_K_SHIP, stream)) return rc;
+            if (int rc = sh.launch(stream)) return rc;
+            if (int rc = kc.end(0, stream)) return rc;
+            if (int rc = stream_wait(stream)) return rc;
+            if (host_header().n_flagged <= cap_snp && host_header().n_flagged_entries <= cap_snp_entries) break;
+            if (!hinted) { set_error("finish_columns: the packed SNP block does not hold the SNPs"); return HS_EINVAL; }
+            hinted = false;      // (more SNPs than last time: once more with the counts known)
+        }
+        const int64_t n_snp = host_header().n_flagged, e_snp = host_header().n_flagged_entries;
         std::memcpy(out.contig_n_snp.data(), host_ctg_snp(), (size_t)C * 4);
-        if (int rc = stream_wait(stream)) return rc;
         out.n_snp = n_snp; out.n_entries = e_snp;
         snp_count = n_snp; snp_entries = e_snp;
+        if (keep) { keep->snp = n_snp; keep->snp_entries = e_snp; }
         if (n_snp > 0) {
             const char* hb = (const char*)h_pk.p;
             out.rec = (const hs_colrec*)(hb + pk_layout.rec); out.off = (const int64_t*)(hb + pk_layout.off);
@@ -2617,6 +2729,8 @@ struct hs_pipeline {
     hs_cv_selection* sel = nullptr;
     std::vector<hs_cv_result*> cv;
     std::vector<hs::SrWorkspace> sr_keep;      // per group: the stage-4 plans and visiting orders live from step to step
+    std::vector<std::unique_ptr<HipCvOps::Keep>> cv_keep;      // per group: the sizes of its column pass (the next step queues it without asking)
+    HipCvOps::K2Order k2_order;
 
     int device = 0;        // = batch->device: the group threads bind themselves to it (a new thread starts on device 0)
     std::vector<int> thread_device;   // what every group thread found current after binding (hs_pipeline_thread_devices)
@@ -2696,6 +2810,7 @@ int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out) {
     p->rcs.assign((size_t)G, 0); p->errs.assign((size_t)G, std::string()); p->cv.assign((size_t)G, nullptr);
     p->device = b->device; p->thread_device.assign((size_t)G, -1);
     p->sr_keep.resize((size_t)G);
+    for (int g = 0; g < G; ++g) p->cv_keep.emplace_back(new HipCvOps::Keep());
     for (int g = 0; g < G; ++g) p->threads.emplace_back([p, g] { p->worker(g); });
     *out = p;
     return HS_OK;
@@ -2824,6 +2939,7 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
         const int c0 = p->ranges[(size_t)g].first, c1 = p->ranges[(size_t)g].second;
         hs::CvMeta meta; fill_meta(p->batch, meta);
         HipCvOps cv_ops(p->batch);
+        cv_ops.keep = p->cv_keep[(size_t)g].get(); cv_ops.k2_order = &p->k2_order;
         // the SNP columns stay on the device: stage 4 takes them over where stage 3 packed them (HS_COLUMNS_VIA_HOST=1: down and up again)
         static const bool via_host = std::getenv("HS_COLUMNS_VIA_HOST") != nullptr;
         if (int r = hs::cv_run_range(cv_ops, meta, ((const hs::CvSelection*)p->sel->impl)->rec_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host)) return r;
@@ -2896,6 +3012,7 @@ int hs_pipeline_run_fused(hs_pipeline* p, float automatic_snp_threshold, float r
         const int c0 = p->ranges[(size_t)g].first, c1 = p->ranges[(size_t)g].second;
         hs::CvMeta meta; fill_meta(b, meta);
         HipCvOps cv_ops(b);
+        cv_ops.keep = p->cv_keep[(size_t)g].get(); cv_ops.k2_order = &p->k2_order;
         auto fail = [&](int r) { { std::lock_guard<std::mutex> lk(bm); aborted = true; } bcv.notify_all(); return r; };
         if (int r = cv_ops.pileup_range(c0, c1, sel->rec_stats, k_ms_g[(size_t)g].data())) return fail(r);
         for (int c = c0; c < c1; ++c) {   // call_variants.cpp:434 per contig, from the integer counters of K1

@@ -44,8 +44,10 @@ struct ColumnsHeader {      // what the host reads between the phases (one small
     int64_t n_cols, n_entries;          // extracted columns / their entries
     int64_t n_flagged, n_flagged_entries;   // candidates (after k_candidates_scan + k_flag_block_sums/_offsets) or SNPs (after k_snp_flags + ...)
     int64_t n_tie, n_tie_big;           // columns whose order went through the emulator / through std::sort's non-stable part
-    int64_t pad[2];
+    int64_t ok;                         // the column arrays' capacities hold n_cols / n_entries (k_columns_compact): 0 makes every later kernel of the pass a no-op
+    int64_t pad;
 };
+static __device__ __forceinline__ int64_t header_cols(const ColumnsHeader* __restrict__ h) { return h->ok ? h->n_cols : 0; }
 
 // the totals of the two tile scans into the header the host reads before it sizes the column arrays
 __global__ void k_columns_totals(const int64_t* __restrict__ n_cols, const int64_t* __restrict__ n_entries, ColumnsHeader* __restrict__ header) {
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void k_columns_compact(
     const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_base, const int64_t* __restrict__ tile_ebase,
     const int64_t* __restrict__ scratch_gpos, const int32_t* __restrict__ scratch_depth, int64_t n_tiles,
     const int64_t* __restrict__ contig_off, int n_contigs, int64_t* __restrict__ col_gpos, hs_colrec_dev* __restrict__ col_rec,
-    int64_t* __restrict__ col_off, int32_t* __restrict__ col_len, ColumnsHeader* __restrict__ header, int64_t cap_cols) {
+    int64_t* __restrict__ col_off, int32_t* __restrict__ col_len, ColumnsHeader* __restrict__ header, int64_t cap_cols, int64_t cap_entries) {
     __shared__ int s_wsum[4];
     const int64_t t = blockIdx.x;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -74,6 +76,7 @@ __global__ __launch_bounds__(256) void k_columns_compact(
     for (int w = 0; w < wv; ++w) before += s_wsum[w];
     if (t == n_tiles - 1 && tid == 0) {
         header->n_cols = tile_base[n_tiles]; header->n_entries = tile_ebase[n_tiles];
+        header->ok = (tile_base[n_tiles] <= cap_cols && tile_ebase[n_tiles] <= cap_entries) ? 1 : 0;
         if (tile_base[n_tiles] <= cap_cols) col_off[tile_base[n_tiles]] = tile_ebase[n_tiles];
     }
     if (!mine) return;
@@ -104,8 +107,10 @@ __global__ __launch_bounds__(256) void k_columns_compact(
 __global__ __launch_bounds__(256) void k_gather_tiles(
     const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, const int32_t* __restrict__ tile_lrec,
     int64_t tile0, int64_t n_tiles, const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_base,
-    const int64_t* __restrict__ col_gpos, const int64_t* __restrict__ col_off, int32_t* __restrict__ col_idx, uint8_t* __restrict__ col_code) {
+    const int64_t* __restrict__ col_gpos, const int64_t* __restrict__ col_off, int32_t* __restrict__ col_idx, uint8_t* __restrict__ col_code,
+    const ColumnsHeader* __restrict__ header) {
     __shared__ __attribute__((aligned(16))) uint8_t s_rows[4][HS_GT_RC * HS_GT_ROW];
+    if (!header->ok) return;      // (the column arrays are too small for this range: the caller sizes up and runs the pass again)
     const int lane = lane_id();
     const int wv = wave_id();
     const int64_t tl = (int64_t)blockIdx.x * 4 + wv;      // tile index in the launch
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
     __shared__ int s_fpos[4][128];
     const int lane = lane_id();
     const int wv = wave_id();
-    const int64_t n_cols = header->n_cols;
+    const int64_t n_cols = header_cols(header);
     int* __restrict__ h = s_hist[wv];
     for (int64_t col = (int64_t)blockIdx.x * 4 + wv; col < n_cols; col += (int64_t)gridDim.x * 4) {
         h[lane] = 0; h[lane + 64] = 0;
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(64 * HS_CB_WAVES) void k_cand_bits(
     const hs_colrec_dev* __restrict__ cand_rec, const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_idx, const uint8_t* __restrict__ cand_code,
     const ColumnsHeader* __restrict__ header, long long cap_cand, const int32_t* __restrict__ contig_rec_off, const int32_t* __restrict__ rank_of,
     const int32_t* __restrict__ read_end_by_rank, CandBitsDev* __restrict__ out_bits, unsigned long long* out_words, long long cap_words,
-    unsigned long long* counter) {
+    unsigned long long* counter, long long cap_entries) {
     __shared__ int s_fp[HS_CB_WAVES][256];
     __shared__ uint8_t s_slot[HS_CB_WAVES][256];
     __shared__ uint8_t s_codes[HS_CB_WAVES][128];
@@ -325,7 +330,10 @@ __global__ __launch_bounds__(64 * HS_CB_WAVES) void k_cand_bits(
     const int lane = lane_id();
     const int wv = wave_id();
     long long n_cand = header->n_flagged;
-    if (n_cand > cap_cand) n_cand = cap_cand;
+    if (n_cand > cap_cand || header->n_flagged_entries > cap_entries) {      // the packed block did not hold the candidates: nothing to read
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(counter + 1, 2ull);
+        return;
+    }
     const long long k = (long long)blockIdx.x * HS_CB_WAVES + wv;
     const bool live = k < n_cand;      // (a wave without a column still meets the others at the barriers)
     const hs_colrec_dev rec = cand_rec[live ? k : 0];
@@ -444,7 +452,7 @@ __global__ __launch_bounds__(256) void k_candidates_scan(
     int32_t* __restrict__ col_contig_local, uint8_t* __restrict__ col_k0, uint8_t* __restrict__ col_k1, int32_t* __restrict__ col_c1, uint8_t* __restrict__ col_is_cand,
     int64_t* __restrict__ contig_col_off /* [c_count + 1] */, int32_t* contig_n_cand /* [c_count], zeroed */) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t n_cols = header->n_cols;
+    const int64_t n_cols = header_cols(header);
     if (k < c_count) {
         // the contig's columns start at the first one at or after its global offset in the sorted list
         auto lower = [&](int64_t g) { int64_t lo = 0, hi = n_cols; while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (col_gpos[mid] < g) lo = mid + 1; else hi = mid; } return lo; };
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(256) void k_candidates_scan(
 __global__ __launch_bounds__(256) void k_flag_block_sums(const hs_colrec_dev* __restrict__ col_rec, const int32_t* __restrict__ col_len, const ColumnsHeader* __restrict__ header,
                                                          int flag, long long* __restrict__ blk_cnt, long long* __restrict__ blk_ent) {
     __shared__ long long s_c[4], s_e[4];
-    const int64_t n_cols = header->n_cols;
+    const int64_t n_cols = header_cols(header);
     const int64_t base = (int64_t)blockIdx.x * HS_FP_BLOCK;
     if (base >= n_cols) { if (threadIdx.x == 0) { blk_cnt[blockIdx.x] = 0; blk_ent[blockIdx.x] = 0; } return; }
     int c = 0; long long e = 0;
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(256) void k_pack_flagged(
     const long long* __restrict__ blk_ent, hs_colrec_dev* __restrict__ out_rec, int32_t* __restrict__ out_col, int64_t* __restrict__ out_off,
     int32_t* __restrict__ out_idx, uint8_t* __restrict__ out_code, int64_t cap_flagged, int64_t cap_entries) {
     // one workgroup per block of HS_FP_BLOCK columns: wave w walks columns w * 256 .. of the block 64 at a time
-    const int64_t n_cols = header->n_cols;
+    const int64_t n_cols = header_cols(header);
     const int64_t base = (int64_t)blockIdx.x * HS_FP_BLOCK;
     if (base >= n_cols) return;
     __shared__ long long s_wc[4], s_we[4];
