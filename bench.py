@@ -264,10 +264,11 @@ def main():
     window_size = hdist.global_window_size(batch.flat.rec_refspan, group=cpu_group) if use_dist else 0
     contigs = None
 
-    # HS_BENCH_FUSED=1: a job in ONE process through hs_pipeline_run_fused (the groups bring up their own share of the pileup, the
-    # error rate is formed inside: 22.4 ms per C4 step against 22.1 with the two calls -- the last group's chain ends at the same
-    # time either way); with several ranks the per-contig distances cross the processes between the two calls anyway
-    fused = (not use_dist) and not emulated and bool(os.environ.get("HS_BENCH_FUSED"))
+    # A job that lives in ONE process goes through hs_pipeline_run_fused: every contig group brings up its own share of the pileup at
+    # the head of its chain on the device and the job's error rate is formed inside the library (round 4, no host wait before the
+    # candidates: 18.5 ms per C4 step against 21.0 with the two calls on the same box). With several ranks the per-contig distances
+    # cross the processes between hs_pipeline_select and hs_pipeline_run. HS_BENCH_TWO_CALLS=1: the two calls in one process too.
+    fused = (not use_dist) and not emulated and not os.environ.get("HS_BENCH_TWO_CALLS")
     py_ms = {"pipeline_call": 0.0, "error_rate": 0.0, "gather": 0.0}
     no_coll = bool(os.environ.get("HS_BENCH_NO_COLLECTIVES"))   # diagnostic only
     cap = [None]

@@ -1116,7 +1116,7 @@ struct hs_cv_batch {
     int device = 0;                   // the device that was current when the batch was created: every buffer below lives there
     DBuf contig_seq, d_contig_off, read_seq, read_off, rec_read, d_rec_contig, d_rec_pos, rec_strand, rec_cig_off, cigar,
         d_pile_off, d_contig_rec_off, d_rec_qend, pile, rec_stats, rec_chunk_off, chunk_scratch, task_rec, task_ev0,
-        tile_off, tile_ent, tile_lrec, d_rank_of, d_orig_of, d_read_end;
+        tile_off, tile_ent, tile_lrec, d_rank_of, d_orig_of, d_read_end, d_rank_end;
     HBuf h_stage_a;   // pinned staging of the per-record counters
     // the pileup is padded by 256 bytes on both sides: k_gather_tiles loads the 256 bytes a record lays over a tile whole, also
     // where the record covers part of the tile only
@@ -1275,6 +1275,11 @@ int hs_cv_batch_create(const uint8_t* h_contig_seq, const int64_t* h_contig_off,
         up(b->d_rank_of, rank_of.data(), sizeof(int32_t) * (size_t)n_rec);
         up(b->d_orig_of, orig_of.data(), sizeof(int32_t) * (size_t)n_rec);
         up(b->d_read_end, read_end.data(), sizeof(int32_t) * (size_t)n_rec);
+        {   // per READ of a contig: {its rank, the end of its alignment} (k_cand_bits: one gather per column entry)
+            std::vector<int32_t> rank_end((size_t)n_rec * 2);
+            for (int r = 0; r < n_rec; ++r) { rank_end[(size_t)r * 2] = rank_of[(size_t)r]; rank_end[(size_t)r * 2 + 1] = (int32_t)std::min<int64_t>((int64_t)h_rec_pos[r] + b->rec_refspan[(size_t)r], 0x7fffffff); }
+            up(b->d_rank_end, rank_end.data(), sizeof(int32_t) * 2 * (size_t)n_rec);
+        }
     }
     up(b->d_rec_qend, b->rec_qend.data(), sizeof(int32_t) * (size_t)n_rec);
     if (!rc) {   // launch plan of the pileup kernel
@@ -1416,6 +1421,46 @@ struct HipCvOps : hs::CvDeviceOps {
         return HS_OK;
     }
     HBuf h_rec_stats;
+    // K0 + K1 of the contigs [c0, c1) queued on the stream, nothing waited for, and the contigs' mean distances formed on the device
+    // (k_contig_error: call_variants.cpp:434 from K1's integer counters, and the read minimum of :463-466 that follows from it) into the
+    // info block / d_min_reads: the fused pipeline's column pass starts from its own share of the pileup without the host in between
+    bool own_pileup = false;
+    int pileup_range_launch(int c0, int c1, float* d_mean_distance, int32_t* d_min_reads_out) {
+        const int r0 = b->contig_rec_off[(size_t)c0], r1 = b->contig_rec_off[(size_t)c1];
+        const int nr = r1 - r0;
+        if ((int)b->rec_task_off.size() != b->n_rec + 1) { set_error("pileup_range: the batch has no task index"); return HS_EINVAL; }
+        if (nr > 0) {
+            const int t0 = b->rec_task_off[(size_t)r0], t1 = b->rec_task_off[(size_t)r1];
+            if (int rc = kc.begin(HS_K_CIGAR_SCAN, stream)) return rc;
+            if (int rc = cigar_scan_launch(b->d_contig_off.as<int64_t>(), b->d_rec_contig.as<int32_t>() + r0, b->d_rec_pos.as<int32_t>() + r0,
+                                           b->rec_cig_off.as<int64_t>() + r0, b->cigar.as<uint32_t>(), b->rec_chunk_off.as<int64_t>() + r0, nr,
+                                           b->chunk_scratch.as<int32_t>(), b->rec_stats.as<int32_t>() + 4 * (size_t)r0, stream)) return rc;
+            const double share = b->n_rec > 0 ? (double)nr / (double)b->n_rec : 0.0;
+            if (int rc = kc.end((int64_t)(share * ((double)b->cigar.bytes + (double)b->chunk_scratch.bytes)) + 16 * (int64_t)nr, stream)) return rc;
+            if (int rc = kc.begin(HS_K_PILEUP, stream)) return rc;
+            int64_t range_pile = 0;
+            if (t1 > t0) {
+                hipLaunchKernelGGL(hsdev::k_pileup_packed, dim3((t1 - t0 + 3) / 4), dim3(256), 0, stream, b->contig_seq.as<uint8_t>(), b->d_contig_off.as<int64_t>(),
+                                   b->read_seq.as<uint8_t>(), b->read_off.as<int64_t>(), b->rec_read.as<int32_t>(), b->d_rec_contig.as<int32_t>(), b->d_rec_pos.as<int32_t>(),
+                                   b->rec_strand.as<uint8_t>(), b->rec_cig_off.as<int64_t>(), b->cigar.as<uint32_t>(), b->d_pile_off.as<int64_t>(), b->rec_chunk_off.as<int64_t>(),
+                                   b->chunk_scratch.as<int32_t>(), b->task_rec.as<int32_t>() + t0, b->task_ev0.as<int32_t>() + t0, t1 - t0, b->ev_per_task, b->pile_ptr(),
+                                   b->rec_stats.as<int32_t>());
+                const int blocks = std::max(1, std::min(256, (nr + 255) / 256));
+                hipLaunchKernelGGL(hsdev::k_pileup_flagged_records, dim3(blocks), dim3(256), 0, stream, b->contig_seq.as<uint8_t>(), b->d_contig_off.as<int64_t>(),
+                                   b->read_seq.as<uint8_t>(), b->read_off.as<int64_t>(), b->rec_read.as<int32_t>() + r0, b->d_rec_contig.as<int32_t>() + r0,
+                                   b->d_rec_pos.as<int32_t>() + r0, b->rec_strand.as<uint8_t>() + r0, b->rec_cig_off.as<int64_t>() + r0, b->cigar.as<uint32_t>(),
+                                   b->d_pile_off.as<int64_t>() + r0, b->rec_chunk_off.as<int64_t>() + r0, b->chunk_scratch.as<int32_t>(), nr, b->ev_per_task, b->pile_ptr(),
+                                   b->rec_stats.as<int32_t>() + 4 * (size_t)r0);
+                HS_HIP(hipGetLastError());
+                range_pile = b->pile_off[(size_t)r1] - b->pile_off[(size_t)r0];
+            }
+            if (int rc = kc.end(2 * range_pile, stream)) return rc;      // one read base in + one code out per aligned bp
+        }
+        hipLaunchKernelGGL(hsdev::k_contig_error, dim3((unsigned)((c1 - c0 + 3) / 4)), dim3(256), 0, stream, b->rec_stats.as<int32_t>(), b->d_contig_rec_off.as<int32_t>(), c0, c1 - c0,
+                           d_mean_distance, d_min_reads_out);
+        HS_HIP(hipGetLastError());
+        return HS_OK;
+    }
     static int h_info_grow(HBuf& h, size_t need) { if (h.cap >= need && h.p) return HS_OK; return h.alloc(need + need / 4); }
 
     // ---- the columns of the current contig range ----
@@ -1436,6 +1481,10 @@ struct HipCvOps : hs::CvDeviceOps {
     const hsdev::ColumnsHeader& host_header() const { return *(const hsdev::ColumnsHeader*)h_info.p; }
     const int32_t* host_ctg_n() const { return (const int32_t*)((const char*)h_info.p + 128); }
     const int32_t* host_ctg_snp() const { return host_ctg_n() + (range_c1 - range_c0); }
+    // ... and, for a range that brought up its own pileup, the contigs' mean distances [C floats]
+    static size_t info_bytes(int C) { return (128 + (size_t)C * 20 + 15) & ~(size_t)15; }
+    float* dev_ctg_md() const { return (float*)(dev_ctg_n() + 4 * (range_c1 - range_c0)); }
+    const float* host_ctg_md() const { return (const float*)(host_ctg_n() + 4 * (range_c1 - range_c0)); }
     // the flagged columns (candidates, later the SNPs) packed into ONE block = one download: [records 16 nf][column index 4 nf][offsets 8 (nf + 1)]
     // [read indices 4 ne][codes ne], every part 256-byte aligned; the SNP block is what stage 4 takes over (HipSrOps::adopt_columns)
     DBuf d_pk; HBuf h_pk;
@@ -1464,14 +1513,33 @@ struct HipCvOps : hs::CvDeviceOps {
         hipEvent_t k2_done = nullptr;      // K2 of the groups one after the other on the device (DeviceTurn without the host in it)
         ~Keep() { if (k2_done) (void)hipEventDestroy(k2_done); }
     };
-    struct K2Order { std::mutex mu; hipEvent_t last = nullptr; };      // per pipeline: the event behind which the next group's K2 queues
+    // per pipeline: the groups queue their K2 in group order (group 0 first: the groups are cut so that the early ones are the big ones),
+    // each behind the event of the one before
+    struct K2Order {
+        std::mutex mu; std::condition_variable cv; hipEvent_t last = nullptr; int next = 0;
+        void reset() { std::lock_guard<std::mutex> lk(mu); next = 0; }
+        void abort() { { std::lock_guard<std::mutex> lk(mu); next = 1 << 30; } cv.notify_all(); }      // (a group failed: nobody waits for its turn)
+    };
+    struct K2Turn {      // holds the order's lock from this group's turn on; passes the turn on when it goes out of scope at the latest
+        K2Order* o = nullptr; std::unique_lock<std::mutex> lk; bool passed = true;
+        void take(K2Order* order, int ticket) {
+            o = order; lk = std::unique_lock<std::mutex>(o->mu);
+            if (ticket >= 0) o->cv.wait(lk, [&] { return o->next >= ticket; });
+            passed = false;
+        }
+        void pass() { if (!passed) { passed = true; o->next++; lk.unlock(); o->cv.notify_all(); } }
+        bool held() const { return !passed; }
+        ~K2Turn() { pass(); }
+    };
+    int order_ticket = -1;             // this group's place in the order (-1: whoever comes first)
     Keep* keep = nullptr;
     K2Order* k2_order = nullptr;
     static int64_t with_margin(int64_t v) { return v + v / 8 + 1024; }
+    static bool order_phase1() { static const bool k2_only = []() { const char* e = std::getenv("HS_ORDER_SCOPE"); return e && std::string(e) == "k2"; }(); return !k2_only; }
     static bool hints_on() { static const bool off = std::getenv("HS_NO_SIZE_HINTS") != nullptr; return !off; }
 
     int fetch_info() {      // the info block from the device (one transfer + wait)
-        const size_t bytes = 128 + (size_t)(range_c1 - range_c0) * 16;
+        const size_t bytes = info_bytes(range_c1 - range_c0);
         if (int rc = grow(h_info, bytes)) return rc;
         Shipment sh; sh.add(h_info.p, d_info.p, bytes);
         if (int rc = sh.launch(stream, 1)) return rc;
@@ -1528,8 +1596,8 @@ struct HipCvOps : hs::CvDeviceOps {
             if (int rc = kc.begin(HS_K_CAND_BITS, stream)) return rc;
             hipLaunchKernelGGL(hsdev::k_cand_bits, dim3((unsigned)((cap_cand + HS_CB_WAVES - 1) / HS_CB_WAVES)), dim3(64 * HS_CB_WAVES), 0, stream,
                                (const hsdev::hs_colrec_dev*)(cb + cand_layout.rec), (const int64_t*)(cb + cand_layout.off), (const int32_t*)(cb + cand_layout.idx),
-                               (const uint8_t*)(cb + cand_layout.code), dev_header(), (long long)cap_cand, b->d_contig_rec_off.as<int32_t>(), b->d_rank_of.as<int32_t>(),
-                               b->d_read_end.as<int32_t>(), d_cb_bits.as<hsdev::CandBitsDev>(), d_cb_words.as<unsigned long long>(), (long long)cap_words,
+                               (const uint8_t*)(cb + cand_layout.code), dev_header(), (long long)cap_cand, b->d_contig_rec_off.as<int32_t>(), b->d_rank_end.as<int2>(),
+                               d_cb_bits.as<hsdev::CandBitsDev>(), d_cb_words.as<unsigned long long>(), (long long)cap_words,
                                d_cb_counter.as<unsigned long long>(), (long long)cap_cand_entries);
             HS_HIP(hipGetLastError());
             if (int rc = kc.end(5 * cap_cand_entries + 48 * cap_cand, stream)) return rc;      // the candidates' entries in; record, header and block out
@@ -1540,8 +1608,8 @@ struct HipCvOps : hs::CvDeviceOps {
         sh.add_counted((char*)h_cb.p + cbl.rec, cb + cand_layout.rec, n_flagged, 16, cap_cand);
         sh.add_counted((char*)h_cb.p + cbl.bits, d_cb_bits.p, n_flagged, 32, cap_cand);
         sh.add_counted((char*)h_cb.p + cbl.words, d_cb_words.p, d_cb_counter.as<long long>(), 8, cap_words);
-        if (int rc = grow(h_info, 128 + (size_t)(range_c1 - range_c0) * 16)) return rc;
-        sh.add(h_info.p, d_info.p, 128 + (size_t)(range_c1 - range_c0) * 16);
+        if (int rc = grow(h_info, info_bytes(range_c1 - range_c0))) return rc;
+        sh.add(h_info.p, d_info.p, info_bytes(range_c1 - range_c0));
         if (int rc = kc.begin(HS_K_SHIP, stream)) return rc;
         if (int rc = sh.launch(stream)) return rc;
         return kc.end(0, stream);
@@ -1597,14 +1665,16 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = e_k2.init()) return rc;
         if (int rc = e_k3.init()) return rc;
         if (int rc = e_k3b.init()) return rc;
-        const size_t info_bytes = 128 + (size_t)C * 16;
-        if (int rc = grow(d_info, info_bytes)) return rc;
+        const size_t info_b = info_bytes(C);
+        if (int rc = grow(d_info, info_b)) return rc;
+        if (own_pileup) { if (int rc = grow(d_min_reads, std::max<size_t>(1, (size_t)C) * 4)) return rc; }
         if (int rc = range_scratch.prepare(nt * 256)) return rc;
         if (int rc = grow(d_tile_ent_sum, (size_t)nt * 4)) return rc;
         if (int rc = grow(d_tile_ebase, ((size_t)nt + 1) * 8)) return rc;
         const int64_t range_pile = b->total_len > 0 ? (int64_t)((double)b->total_pile * (double)(g1 - g0) / (double)b->total_len) : 0;      // one code in per aligned bp of the range (its share of the batch)
         auto k2_launch = [&]() -> int {   // ---- K2 over the tiles of the range: per tile its selected positions (second count >= 4), their depths and the sum of those ----
-            hipLaunchKernelGGL(hsdev::k_fill16, dim3(1), dim3(256), 0, stream, d_info.as<uint4>(), (long long)(info_bytes / 16), 0u);      // (header, tie counters, candidates / SNPs / SNP bounds per contig)
+            hipLaunchKernelGGL(hsdev::k_fill16, dim3(1), dim3(256), 0, stream, d_info.as<uint4>(), (long long)(info_b / 16), 0u);      // (header, tie counters, candidates / SNPs / SNP bounds per contig)
+            if (own_pileup) { if (int rc = pileup_range_launch(c0, c1, dev_ctg_md(), d_min_reads.as<int32_t>())) return rc; }
             HS_HIP(hipEventRecord(e_k2.a, stream));
             if (int rc = kc.begin(HS_K_COLUMN_STATS, stream)) return rc;
             hipEvent_t k2_done = nullptr;
@@ -1616,6 +1686,7 @@ struct HipCvOps : hs::CvDeviceOps {
             return exclusive_scan_launch(d_tile_ent_sum.as<int32_t>(), (int)nt, d_tile_ebase.as<int64_t>(), d_scan2, stream);
         };
         int64_t cap_cols = 0, cap_entries = 0;
+        K2Turn order_lock;
         if (!hinted) {
             DeviceTurn turn;
             if (int rc = k2_launch()) return rc;
@@ -1627,13 +1698,15 @@ struct HipCvOps : hs::CvDeviceOps {
         } else {
             // the groups' K2 launches one after the other ON THE DEVICE (each fills it on its own, see DeviceTurn): this group's
             // launch queues behind the event of the group that came before it, no host thread waits for anything
+            // HS_ORDER_SCOPE=phase1 (default): not only K2 but the group's whole chain up to the shipment of the candidates runs behind the
+            // previous group's -- the groups then reach the host one after the other (candidates every ~0.8 ms) instead of all at the same
+            // late moment, and loops A / B of one group run while the device works on the next one's columns. HS_ORDER_SCOPE=k2: K2 only.
             if (k2_order && DeviceTurn::on()) {
-                std::lock_guard<std::mutex> lk(k2_order->mu);
+                order_lock.take(k2_order, order_ticket);
                 if (!keep->k2_done) HS_HIP(hipEventCreateWithFlags(&keep->k2_done, hipEventDisableTiming));
                 if (k2_order->last && k2_order->last != keep->k2_done) HS_HIP(hipStreamWaitEvent(stream, k2_order->last, 0));
                 if (int rc = k2_launch()) return rc;
-                HS_HIP(hipEventRecord(keep->k2_done, stream));
-                k2_order->last = keep->k2_done;
+                if (!order_phase1()) { HS_HIP(hipEventRecord(keep->k2_done, stream)); k2_order->last = keep->k2_done; order_lock.pass(); }
             } else if (int rc = k2_launch()) return rc;
             cap_cols = with_margin(keep->cols); cap_entries = with_margin(keep->entries);
         }
@@ -1650,8 +1723,7 @@ struct HipCvOps : hs::CvDeviceOps {
         if (int rc = grow(d_c1, std::max<size_t>(1, (size_t)cap_cols) * 4)) return rc;
         if (int rc = grow(d_cand, std::max<size_t>(1, (size_t)cap_cols))) return rc;
         if (int rc = grow(d_ctg_col_off, ((size_t)C + 1) * 8)) return rc;
-        range_pack.add(min_reads, d_min_reads);
-        if (int rc = range_pack.commit(stream)) return rc;
+        if (!own_pileup) { range_pack.add(min_reads, d_min_reads); if (int rc = range_pack.commit(stream)) return rc; }
         // ---- the column list with its CSR offsets, K3 (tile-cooperative gather), K3b (leading codes, reference order), V1 ----
         if (int rc = kc.begin(HS_K_COLUMNS_COMPACT, stream)) return rc;
         hipLaunchKernelGGL(hsdev::k_columns_compact, dim3((unsigned)nt), dim3(256), 0, stream, range_scratch.tile_cnt.as<int32_t>(), range_scratch.tile_base.as<int64_t>(),
@@ -1700,6 +1772,7 @@ struct HipCvOps : hs::CvDeviceOps {
         if (want_entries) {
             for (int attempt = 0;; ++attempt) {
                 if (int rc = cand_bits_launch(cap_cand, cap_cand_entries, cap_words)) return rc;
+                if (order_lock.held()) { HS_HIP(hipEventRecord(keep->k2_done, stream)); k2_order->last = keep->k2_done; order_lock.pass(); }
                 if (int rc = stream_wait(stream)) return rc;
                 if (cand_bits_fit()) break;
                 if (hinted) return HS_EAGAIN_SIZES;
@@ -1713,6 +1786,7 @@ struct HipCvOps : hs::CvDeviceOps {
         out.n_columns = n_cols; out.n_entries = n_entries;
         n_gathered = (int)n_cols; gathered_entries = n_entries;
         std::memcpy(out.contig_n_cand.data(), host_ctg_n(), (size_t)C * 4);
+        if (own_pileup) out.contig_mean_distance.assign(host_ctg_md(), host_ctg_md() + C);
         cand_per_contig = out.contig_n_cand; cand_count = H.n_flagged; cand_entries = H.n_flagged_entries;
         { unsigned long long t2[2]; std::memcpy(t2, (const char*)h_info.p + 64, 16); out.n_tie = (int64_t)t2[0]; out.n_tie_big = (int64_t)t2[1]; }
         out.n_cand = cand_count;
@@ -1781,7 +1855,7 @@ struct HipCvOps : hs::CvDeviceOps {
             // the SNPs' records and offsets (and, for a caller that writes the .col file, their entries) into pinned memory, with the info block
             const PackLayout& L = pk_layout;
             if (int rc = grow(h_pk, std::max<size_t>(want_entries ? L.total : L.head, 256))) return rc;
-            if (int rc = grow(h_info, 128 + (size_t)C * 16)) return rc;
+            if (int rc = grow(h_info, info_bytes(C))) return rc;
             const long long* n_flagged = reinterpret_cast<const long long*>((const char*)d_info.p + offsetof(hsdev::ColumnsHeader, n_flagged));
             const long long* n_flagged_e = reinterpret_cast<const long long*>((const char*)d_info.p + offsetof(hsdev::ColumnsHeader, n_flagged_entries));
             Shipment sh;
@@ -1792,7 +1866,7 @@ struct HipCvOps : hs::CvDeviceOps {
                 sh.add_counted((char*)h_pk.p + L.idx, base + L.idx, n_flagged_e, 4, cap_snp_entries);
                 sh.add_counted((char*)h_pk.p + L.code, base + L.code, n_flagged_e, 1, cap_snp_entries);
             }
-            sh.add(h_info.p, d_info.p, 128 + (size_t)C * 16);
+            sh.add(h_info.p, d_info.p, info_bytes(C));
             if (int rc = kc.begin(HS_K_SHIP, stream)) return rc;
             if (int rc = sh.launch(stream)) return rc;
             if (int rc = kc.end(0, stream)) return rc;
@@ -2721,6 +2795,7 @@ struct hs_pipeline {
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
     std::function<int(int)> job;
+    std::function<void()> on_fail;      // called by a group thread whose job failed (or that never bound to the device): releases whoever waits for that group
     uint64_t gen = 0;
     int pending = 0;
     bool quit = false;
@@ -2749,6 +2824,7 @@ struct hs_pipeline {
             int rc;
             if (!bound) { set_error("a contig-group thread could not bind to the device of its batch"); rc = HS_EHIP; }
             else rc = f(g);
+            if (rc) { k2_order.abort(); std::function<void()> h; { std::lock_guard<std::mutex> lk(mu); h = on_fail; } if (h) h(); }      // (nobody waits for a group that is gone: its turn, its share of the error rate)
             {
                 std::lock_guard<std::mutex> lk(mu);
                 rcs[(size_t)g] = rc;
@@ -2789,9 +2865,16 @@ int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out) {
         cut[(size_t)G] = C;
         const int64_t total = b->pile_off.empty() ? 0 : b->pile_off.back();
         if (total > 0 && (int)b->contig_rec_off.size() == C + 1) {
+            // The groups reach the host one after the other (the device hands out their candidate columns about 0.8 ms apart, K2 by K2),
+            // and the step ends when the LAST group's chain -- loops A / B, K4, all of stage 4 -- is through: the later a group starts,
+            // the smaller it is made, so that the chains end together. HS_GROUP_TAPER = share of the last group relative to the first
+            // (default 0.35; 1 = equal groups), linear in between.
+            static const double taper = []() { const char* e = std::getenv("HS_GROUP_TAPER"); const double v = e ? std::atof(e) : 0.35; return v > 0 && v <= 1 ? v : 1.0; }();
+            std::vector<double> upto((size_t)G + 1, 0.0);
+            for (int g = 0; g < G; ++g) upto[(size_t)g + 1] = upto[(size_t)g] + (G > 1 ? 1.0 + (taper - 1.0) * g / (G - 1) : 1.0);
             int c = 0;
             for (int g = 1; g < G; ++g) {
-                const int64_t want = total / G * g;
+                const int64_t want = (int64_t)((double)total * upto[(size_t)g] / upto[(size_t)G]);
                 while (c < C && b->pile_off[(size_t)b->contig_rec_off[(size_t)c + 1]] <= want) ++c;
                 // the contig that crosses the mark goes to the side it lies more on
                 if (c < C) {
@@ -2935,11 +3018,13 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
     }
     std::vector<hs_sr_result*> parts((size_t)G, nullptr);
     std::vector<hs::SrSparseLabels> sparse((size_t)G);      // the groups leave their labels per window; concat_sr_parts spreads them
+    hs::set_trace_origin();
+    p->k2_order.reset();
     const int rc = p->run([&](int g) {
         const int c0 = p->ranges[(size_t)g].first, c1 = p->ranges[(size_t)g].second;
         hs::CvMeta meta; fill_meta(p->batch, meta);
         HipCvOps cv_ops(p->batch);
-        cv_ops.keep = p->cv_keep[(size_t)g].get(); cv_ops.k2_order = &p->k2_order;
+        cv_ops.keep = p->cv_keep[(size_t)g].get(); cv_ops.k2_order = &p->k2_order; cv_ops.order_ticket = g;
         // the SNP columns stay on the device: stage 4 takes them over where stage 3 packed them (HS_COLUMNS_VIA_HOST=1: down and up again)
         static const bool via_host = std::getenv("HS_COLUMNS_VIA_HOST") != nullptr;
         if (int r = hs::cv_run_range(cv_ops, meta, ((const hs::CvSelection*)p->sel->impl)->rec_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host)) return r;
@@ -3008,19 +3093,22 @@ int hs_pipeline_run_fused(hs_pipeline* p, float automatic_snp_threshold, float r
     float error_rate = 0;
     std::vector<hs_sr_result*> parts((size_t)G, nullptr);
     std::vector<hs::SrSparseLabels> sparse((size_t)G);
+    hs::set_trace_origin();
+    p->k2_order.reset();
+    // HS_FUSED_HOST_PILEUP=1: the round-3 form (every group waits for its share of the pileup and forms the distances on the host)
+    static const bool host_pileup = std::getenv("HS_FUSED_HOST_PILEUP") != nullptr;
+    const std::vector<int32_t> no_stats;
+    { std::lock_guard<std::mutex> lk(p->mu); p->on_fail = [&] { { std::lock_guard<std::mutex> lk2(bm); aborted = true; } bcv.notify_all(); }; }
     const int rc = p->run([&](int g) {
         const int c0 = p->ranges[(size_t)g].first, c1 = p->ranges[(size_t)g].second;
         hs::CvMeta meta; fill_meta(b, meta);
         HipCvOps cv_ops(b);
-        cv_ops.keep = p->cv_keep[(size_t)g].get(); cv_ops.k2_order = &p->k2_order;
+        cv_ops.keep = p->cv_keep[(size_t)g].get(); cv_ops.k2_order = &p->k2_order; cv_ops.order_ticket = g;
         auto fail = [&](int r) { { std::lock_guard<std::mutex> lk(bm); aborted = true; } bcv.notify_all(); return r; };
-        if (int r = cv_ops.pileup_range(c0, c1, sel->rec_stats, k_ms_g[(size_t)g].data())) return fail(r);
-        for (int c = c0; c < c1; ++c) {   // call_variants.cpp:434 per contig, from the integer counters of K1
-            int64_t nerr = 0, nlen = 0;
-            for (int r = b->contig_rec_off[(size_t)c]; r < b->contig_rec_off[(size_t)c + 1]; ++r) { nerr += sel->rec_stats[(size_t)r * 4 + 1]; nlen += sel->rec_stats[(size_t)r * 4 + 2]; }
-            md[(size_t)c] = hs::mean_distance_from_counts(nerr, nlen);
-        }
-        {
+        // the group's mean distances are known (from the host's sums, or with its candidate columns from the device): the last group
+        // to get here forms the job's error rate
+        auto arrive = [&](const float* md_g) {
+            std::memcpy(md.data() + c0, md_g, (size_t)(c1 - c0) * sizeof(float));
             std::lock_guard<std::mutex> lk(bm);
             if (++arrived == G) {
                 float total = 0; int n = 0;
@@ -3033,9 +3121,25 @@ int hs_pipeline_run_fused(hs_pipeline* p, float automatic_snp_threshold, float r
                 error_rate = (float)e;
                 bcv.notify_all();
             }
-        }
+        };
         static const bool via_host = std::getenv("HS_COLUMNS_VIA_HOST") != nullptr;
-        if (int r = hs::cv_run_range(cv_ops, meta, sel->rec_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host)) return fail(r);
+        if (host_pileup) {
+            if (int r = cv_ops.pileup_range(c0, c1, sel->rec_stats, k_ms_g[(size_t)g].data())) return fail(r);
+            std::vector<float> md_g((size_t)(c1 - c0));
+            for (int c = c0; c < c1; ++c) {   // call_variants.cpp:434 per contig, from the integer counters of K1
+                int64_t nerr = 0, nlen = 0;
+                for (int r = b->contig_rec_off[(size_t)c]; r < b->contig_rec_off[(size_t)c + 1]; ++r) { nerr += sel->rec_stats[(size_t)r * 4 + 1]; nlen += sel->rec_stats[(size_t)r * 4 + 2]; }
+                md_g[(size_t)(c - c0)] = hs::mean_distance_from_counts(nerr, nlen);
+            }
+            arrive(md_g.data());
+            if (int r = hs::cv_run_range(cv_ops, meta, sel->rec_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host)) return fail(r);
+        } else {
+            // the group's share of the pileup is the head of its column pass on the device (K0, K1, the contigs' distances, K2 ...): one chain,
+            // queued behind the previous group's, no host wait before the candidates
+            cv_ops.own_pileup = true;
+            const std::function<void(const float*)> on_md = arrive;
+            if (int r = hs::cv_run_range(cv_ops, meta, no_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host, &on_md)) return fail(r);
+        }
         {
             std::unique_lock<std::mutex> lk(bm);
             bcv.wait(lk, [&] { return arrived == G || aborted; });
@@ -3047,6 +3151,7 @@ int hs_pipeline_run_fused(hs_pipeline* p, float automatic_snp_threshold, float r
                                          &parts[(size_t)g], &sparse[(size_t)g], &p->sr_keep[(size_t)g]);
         return r ? fail(r) : r;
     });
+    { std::lock_guard<std::mutex> lk(p->mu); p->on_fail = nullptr; }
     if (rc) { for (hs_sr_result* r : parts) if (r) hs::free_sr_result(r); return rc; }
     if (mean_distance) std::memcpy(mean_distance, md.data(), (size_t)C * sizeof(float));
     if (error_rate_out) *error_rate_out = error_rate;

@@ -19,6 +19,8 @@
 
 namespace hs {
 
+int host_threads();
+
 namespace {
 
 double now_ms() {
@@ -84,10 +86,66 @@ private:
     uint64_t gen_ = 0;
 };
 
+// One pool for the whole process (default; HS_SHARED_POOL=0: a private pool per calling thread, as before). The contig groups of a
+// pipeline are on the host at different moments -- the device hands them their candidate columns one after the other -- and the
+// step ends with the LAST group's chain: with a private pool of n_threads / groups workers each, that group walks its contigs on six
+// threads while the cores the other groups have left stand idle. Here every parallel section is a job in one list; the
+// workers (as many as the process has usable cores) take chunks of the oldest job that has any left, the caller works on its own
+// job too. No oversubscription when all groups are on the host at once, all cores for a group that is there alone.
+class SharedPool {
+public:
+    static SharedPool& get() { static SharedPool* p = new SharedPool(); return *p; }
+    static bool on() { static const bool v = []() { const char* e = std::getenv("HS_SHARED_POOL"); return !(e && e[0] == '0'); }(); return v; }
+    void run(int n, int n_threads, const std::function<void(int)>& f) {
+        if (n <= 0) return;
+        if (n_threads <= 1 || n == 1) { for (int i = 0; i < n; ++i) f(i); return; }
+        Job job;
+        job.f = &f; job.n = n;
+        job.grain = std::max(1, n / (8 * (std::min(n_threads, (int)workers_.size() + 1))));
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            ensure();
+            jobs_.push_back(&job);
+        }
+        cv_.notify_all();
+        for (;;) { const int i = job.next.fetch_add(job.grain); if (i >= n) break; const int e = std::min(n, i + job.grain); for (int k = i; k < e; ++k) f(k); job.done.fetch_add(e - i); }
+        std::unique_lock<std::mutex> g(mu_);
+        jobs_.erase(std::find(jobs_.begin(), jobs_.end(), &job));      // (nothing left to hand out; chunks in flight finish below)
+        done_cv_.wait(g, [&] { return job.done.load() >= n; });
+    }
+private:
+    struct Job { const std::function<void(int)>* f = nullptr; int n = 0, grain = 1; std::atomic<int> next{0}, done{0}; };
+    void ensure() {
+        static const int want = []() { const char* e = std::getenv("HS_POOL_THREADS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : host_threads(); }();
+        while ((int)workers_.size() < want) { workers_.emplace_back([this] { loop(); }); workers_.back().detach(); }
+    }
+    void loop() {
+        std::unique_lock<std::mutex> g(mu_);
+        for (;;) {
+            Job* job = nullptr;
+            for (Job* j : jobs_) if (j->next.load(std::memory_order_relaxed) < j->n) { job = j; break; }
+            if (!job) { cv_.wait(g); continue; }
+            const int i = job->next.fetch_add(job->grain);
+            if (i >= job->n) continue;
+            const int n = job->n, e = std::min(n, i + job->grain);
+            const std::function<void(int)>* f = job->f;
+            g.unlock();
+            for (int k = i; k < e; ++k) (*f)(k);
+            const bool last = job->done.fetch_add(e - i) + (e - i) >= n;      // (the job may be gone after this line)
+            g.lock();
+            if (last) done_cv_.notify_all();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> workers_;
+    std::vector<Job*> jobs_;
+};
+
 template <class F>
 void parallel_for(int n, int n_threads, F f) {
     std::function<void(int)> fn = f;
-    WorkerPool::get().run(n, n_threads, fn);
+    if (SharedPool::on()) SharedPool::get().run(n, n_threads, fn); else WorkerPool::get().run(n, n_threads, fn);
 }
 
 template <class T> T* dup_vec(const std::vector<T>& v) {
@@ -98,7 +156,7 @@ template <class T> T* dup_vec(const std::vector<T>& v) {
 
 }  // namespace
 
-void hs_parallel_for(int n, int n_threads, const std::function<void(int)>& f) { WorkerPool::get().run(n, n_threads, f); }
+void hs_parallel_for(int n, int n_threads, const std::function<void(int)>& f) { if (SharedPool::on()) SharedPool::get().run(n, n_threads, f); else WorkerPool::get().run(n, n_threads, f); }
 
 // Worker threads for host-side passes when the caller names no count: the cores this process may actually use -- the cgroup
 // CPU quota when there is one (a container limited to 16 of 256 CPUs must not start 255 workers) -- and never more than 32
@@ -163,10 +221,14 @@ void free_sr_result(hs_sr_result* r) {
     std::free(r);
 }
 
+static std::atomic<double> g_trace_origin{0.0};
+void set_trace_origin() { g_trace_origin.store(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count()); }
 namespace {
-struct Laps {   // HS_TIMING: fine-grained wall clock of a stage driver (HS_TIMING=cpu: wall/CPU time of the calling thread)
+struct Laps {   // HS_TIMING: fine-grained wall clock of a stage driver (HS_TIMING=cpu: wall/CPU time of the calling thread; HS_TIMING=abs: the
+                // end of every lap in ms since the start of the pipeline call, so that the chains of the contig groups can be laid side by side)
     bool on = std::getenv("HS_TIMING") != nullptr;
     bool cpu = on && std::string(std::getenv("HS_TIMING")) == "cpu";
+    bool abs_ = on && std::string(std::getenv("HS_TIMING")) == "abs";
     double t = now_ms(), c = cpu_ms();
     std::string line;
     const char* tag;
@@ -176,11 +238,12 @@ struct Laps {   // HS_TIMING: fine-grained wall clock of a stage driver (HS_TIMI
         if (!on) return;
         const double n = now_ms();
         char buf[96];
-        if (cpu) { const double cn = cpu_ms(); std::snprintf(buf, sizeof buf, " %s %.2f/%.2f", what, n - t, cn - c); c = cn; }
+        if (abs_) std::snprintf(buf, sizeof buf, " %s @%.2f", what, n - g_trace_origin.load());
+        else if (cpu) { const double cn = cpu_ms(); std::snprintf(buf, sizeof buf, " %s %.2f/%.2f", what, n - t, cn - c); c = cn; }
         else std::snprintf(buf, sizeof buf, " %s %.2f", what, n - t);
         line += buf; t = n;
     }
-    ~Laps() { if (on) std::fprintf(stderr, "[hs timing] %s laps (ms):%s\n", tag, line.c_str()); }
+    ~Laps() { if (on) std::fprintf(stderr, "[hs timing] %s laps (ms) thread %zu:%s\n", tag, std::hash<std::thread::id>()(std::this_thread::get_id()) % 1000, line.c_str()); }
 };
 }  // namespace
 
@@ -204,7 +267,7 @@ int cv_pileup(CvDeviceOps& dev, const CvMeta& b, CvSelection& sel) {
 // of the SNP lists, and the SNPs come out. Ranges are independent: several may run concurrently from different host threads,
 // each with its own device interface (stream).
 int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& rec_stats, int c0, int c1, float automatic_snp_threshold, int n_threads,
-                 hs_cv_result** out, bool resident) {
+                 hs_cv_result** out, bool resident, const std::function<void(const float*)>* on_mean_distance) {
     if (n_threads <= 0) n_threads = host_threads();
     if (c0 < 0 || c1 > b.n_contigs || c0 > c1) { set_error("cv_run_range: bad contig range"); return HS_EINVAL; }
     const int C = c1 - c0;
@@ -212,14 +275,17 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
     float k_ms[4] = {0, 0, 0, 0};
     float k_ms_k4 = 0;              // column x partition test
     std::vector<ContigCvResult> res((size_t)C);
-    std::vector<int32_t> min_reads((size_t)C, 5);
+    const bool derive = rec_stats.empty() && b.n_rec > 0;      // the device forms the mean distances (and the read minima) from its own counters
+    std::vector<int32_t> min_reads((size_t)(derive ? 0 : C), 5);
     for (int c = 0; c < C; ++c) {   // call_variants.cpp:434 and :463-466 from the integer counters of K1; :565
         const int gc = c0 + c;
-        int64_t nerr = 0, nlen = 0;
-        for (int r = b.contig_rec_off[(size_t)gc]; r < b.contig_rec_off[(size_t)gc + 1]; ++r) { nerr += rec_stats[(size_t)r * 4 + 1]; nlen += rec_stats[(size_t)r * 4 + 2]; }
         ContigCvResult& o = res[(size_t)c];
-        o.mean_distance = mean_distance_from_counts(nerr, nlen);
-        min_reads[(size_t)c] = o.mean_distance < 0.015 ? 3 : 5;
+        if (!derive) {
+            int64_t nerr = 0, nlen = 0;
+            for (int r = b.contig_rec_off[(size_t)gc]; r < b.contig_rec_off[(size_t)gc + 1]; ++r) { nerr += rec_stats[(size_t)r * 4 + 1]; nlen += rec_stats[(size_t)r * 4 + 2]; }
+            o.mean_distance = mean_distance_from_counts(nerr, nlen);
+            min_reads[(size_t)c] = o.mean_distance < 0.015 ? 3 : 5;
+        }
         const int64_t L = b.contig_off[(size_t)gc + 1] - b.contig_off[(size_t)gc];
         const int64_t entries = b.pile_off[(size_t)b.contig_rec_off[(size_t)gc + 1]] - b.pile_off[(size_t)b.contig_rec_off[(size_t)gc]];
         o.depth = (float)((double)entries / (double)L);
@@ -234,6 +300,11 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
     float k_ms_x[3] = {0, 0, 0};
     if (int rc = dev.extract_candidates(c0, c1, min_reads, automatic_snp_threshold, cand, k_ms_x, !on_device)) return rc;
     k_ms[1] = k_ms_x[0]; k_ms[2] = k_ms_x[1] + k_ms_x[2];
+    if (derive) {
+        if ((int)cand.contig_mean_distance.size() != C) { set_error("cv_run_range: the device interface did not report the contigs' mean distances"); return HS_EINVAL; }
+        for (int c = 0; c < C; ++c) res[(size_t)c].mean_distance = cand.contig_mean_distance[(size_t)c];
+    }
+    if (on_mean_distance) { std::vector<float> md((size_t)C); for (int c = 0; c < C; ++c) md[(size_t)c] = res[(size_t)c].mean_distance; (*on_mean_distance)(md.data()); }
     const double t_dev_done = now_ms();
     Laps laps("cv glue");
     std::vector<int64_t> cand_base((size_t)C + 1, 0);

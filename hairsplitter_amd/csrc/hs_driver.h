@@ -4,6 +4,7 @@
 // checked on a machine without a GPU (that harness is test infrastructure and never ships).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
 #include "hs_host.h"
 #include "hs_host_sr.h"
@@ -35,6 +36,7 @@ struct CvCandidates {
     int64_t n_columns = 0, n_entries = 0;    // columns extracted for the range (second count >= 4: everything that can become a SNP) -- they stay with the implementation
     int64_t n_tie = 0, n_tie_big = 0;        // of those, columns whose two leading codes needed the reference's order of equal counts / std::sort beyond 16 keys
     std::vector<int32_t> contig_n_cand;      // [C]
+    std::vector<float> contig_mean_distance; // [C] when the implementation brought up the range's pileup itself (min_reads passed empty), else empty
     int64_t n_cand = 0;
     const hs_colrec* rec = nullptr;          // [n_cand]
     const int32_t* col = nullptr;            // [n_cand] index of the candidate in the implementation's column list
@@ -109,8 +111,10 @@ struct CvSelection {
 int cv_pileup(CvDeviceOps& dev, const CvMeta& meta, CvSelection& sel);
 // stage 3 for the contigs [c0, c1) on top of the pileup; `resident` (optional): the SNP columns are not downloaded into the result
 // (col_idx / col_code stay null) because the caller hands them to stage 4 on the device
+// rec_stats empty: the device interface brings up the range's share of the pileup itself and reports the contigs' mean distances with
+// the candidates (CvCandidates::contig_mean_distance); on_mean_distance (optional) is called with them [c1 - c0] as soon as they are known
 int cv_run_range(CvDeviceOps& dev, const CvMeta& meta, const std::vector<int32_t>& rec_stats, int c0, int c1, float automatic_snp_threshold, int n_threads,
-                 hs_cv_result** out, bool resident = false);
+                 hs_cv_result** out, bool resident = false, const std::function<void(const float*)>* on_mean_distance = nullptr);
 int cv_run(CvDeviceOps& dev, const CvMeta& meta, float automatic_snp_threshold, int n_threads, hs_cv_result** out);
 hs_cv_result* cv_concat_results(hs_cv_result* a, hs_cv_result* b);   // two consecutive contig ranges (both consumed)
 
@@ -226,6 +230,7 @@ struct SrDeviceOps {
     virtual int fetch_columns(std::vector<int32_t>& idx, std::vector<uint8_t>& code) { (void)idx; (void)code; return -1; }
 };
 
+void set_trace_origin();   // HS_TIMING=abs: laps are printed relative to this moment
 int host_threads();      // default number of host worker threads: usable cores (cgroup quota), at most 32
 
 // The labels of a result before they are spread over the N reads of each window: per window the reads it holds (ascending

@@ -277,6 +277,30 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// generate_msa's return value per contig (call_variants.cpp:434) from the integer counters of K1 -- totalDistance is a float that
+// is incremented by one (saturates at 2^24), totalLength a double starting at 1 (:67-68) -- and the read minimum that follows from
+// it (:463-466). One wavefront per contig of the range; rec_stats = {q_end, errors, events, -} per record.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_contig_error(const int32_t* __restrict__ rec_stats, const int32_t* __restrict__ contig_rec_off, int c_first, int c_count,
+                                                      float* __restrict__ mean_distance, int32_t* __restrict__ min_reads) {
+    const int lane = lane_id();
+    const int c = (int)blockIdx.x * 4 + wave_id();
+    if (c >= c_count) return;
+    const int r0 = contig_rec_off[c_first + c], r1 = contig_rec_off[c_first + c + 1];
+    long long nerr = 0, nlen = 0;
+    for (int r = r0 + lane; r < r1; r += 64) { nerr += rec_stats[(size_t)r * 4 + 1]; nlen += rec_stats[(size_t)r * 4 + 2]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { nerr += __shfl_xor(nerr, d, 64); nlen += __shfl_xor(nlen, d, 64); }
+    if (lane == 0) {
+        const float total_distance = nerr > 16777216 ? 16777216.0f : (float)nerr;
+        const double total_length = 1.0 + (double)nlen;
+        const float md = (float)((double)total_distance / total_length);
+        mean_distance[c] = md;
+        min_reads[c] = (double)md < 0.015 ? 3 : 5;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Host <-> device transfers as kernels over pinned host memory (hipHostMalloc'ed blocks are mapped into the device's address
 // space): a launch costs the host a few microseconds where hipMemcpyAsync costs 50 and an interrupt-driven completion signal,
 // and -- what matters more -- the number of bytes may be a value that only exists on the device when the kernel is queued
@@ -318,8 +342,8 @@ static_assert(sizeof(CandBitsDev) == 32, "CandBitsDev must be 32 bytes");
 #define HS_CB_WAVES 16      // columns per workgroup: ONE allocation atomic per workgroup (one per column: 60 k atomics on one address per launch, 0.8 ms)
 __global__ __launch_bounds__(64 * HS_CB_WAVES) void k_cand_bits(
     const hs_colrec_dev* __restrict__ cand_rec, const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_idx, const uint8_t* __restrict__ cand_code,
-    const ColumnsHeader* __restrict__ header, long long cap_cand, const int32_t* __restrict__ contig_rec_off, const int32_t* __restrict__ rank_of,
-    const int32_t* __restrict__ read_end_by_rank, CandBitsDev* __restrict__ out_bits, unsigned long long* out_words, long long cap_words,
+    const ColumnsHeader* __restrict__ header, long long cap_cand, const int32_t* __restrict__ contig_rec_off, const int2* __restrict__ rank_end /* per record: {rank on its contig, alignment end} */,
+    CandBitsDev* __restrict__ out_bits, unsigned long long* out_words, long long cap_words,
     unsigned long long* counter, long long cap_entries) {
     __shared__ int s_fp[HS_CB_WAVES][256];
     __shared__ uint8_t s_slot[HS_CB_WAVES][256];
@@ -348,15 +372,17 @@ __global__ __launch_bounds__(64 * HS_CB_WAVES) void k_cand_bits(
     for (int i = 0; i < 4; ++i) fp[lane + 64 * i] = 0x7fffffff;
     wave_lds_sync();
     int lo = 0x7fffffff, hi = -1, reach = -1;
+    int rc0 = -1;      // the first 64 entries stay in registers (rank << 8 | code): nearly every column is that shallow
     for (int j0 = 0; j0 < n; j0 += 64) {
         const int j = j0 + lane;
         if (j < n) {
-            const int rk = rank_of[r0 + cand_idx[e0 + j]];
-            const int w = rk >> 6;
+            const int2 re = rank_end[r0 + cand_idx[e0 + j]];
+            const int cd = cand_code[e0 + j];
+            const int w = re.x >> 6;
             lo = w < lo ? w : lo; hi = w > hi ? w : hi;
-            const int re = read_end_by_rank[r0 + rk];
-            reach = re > reach ? re : reach;
-            atomicMin(&fp[cand_code[e0 + j]], j);
+            reach = re.y > reach ? re.y : reach;
+            atomicMin(&fp[cd], j);
+            if (j0 == 0) rc0 = (re.x << 8) | cd;
         }
     }
     wave_lds_sync();
@@ -403,10 +429,12 @@ __global__ __launch_bounds__(64 * HS_CB_WAVES) void k_cand_bits(
         for (int j0 = 0; j0 < n; j0 += 64) {
             const int j = j0 + lane;
             if (j < n) {
-                const int rk = rank_of[r0 + cand_idx[e0 + j]];
+                int rk, cd;
+                if (j0 == 0) { rk = rc0 >> 8; cd = rc0 & 255; }
+                else { rk = rank_end[r0 + cand_idx[e0 + j]].x; cd = cand_code[e0 + j]; }
                 const int w = (rk >> 6) - lo;
                 const unsigned long long bit = 1ull << (rk & 63);
-                const int sl = slot_of[cand_code[e0 + j]];
+                const int sl = slot_of[cd];
                 if (in_lds) { atomicOr(&blk[w], bit); atomicOr(&blk[(sl + 1) * W + w], bit); }
                 else { atomicOr(&out[w], bit); atomicOr(&out[(long long)(sl + 1) * W + w], bit); }
             }

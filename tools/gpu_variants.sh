@@ -9,12 +9,12 @@ try:
 except Exception as e: print('$tag failed', e)
 P
 }
-run base HS_X=1
+export HS_ORDER_SCOPE=k2 HS_GROUP_TAPER=1 HS_SHARED_POOL=0
+timeout 900 python -m pytest tests/test_gpu_dropin.py -x -q 2>&1 | tail -2
+run twocalls HS_X=1
 run fused HS_BENCH_FUSED=1
-EXTRA="--groups 12" run g12 HS_X=1
-EXTRA="--groups 16" run g16 HS_X=1
-EXTRA="--groups 12" run g12fused HS_BENCH_FUSED=1
-EXTRA="--groups 16" run g16fused HS_BENCH_FUSED=1
-EXTRA="--groups 6" run g6 HS_X=1
-EXTRA="--threads 32" run t32 HS_X=1
-EXTRA="--threads 64" run t64 HS_X=1
+run fused_hostpile HS_BENCH_FUSED=1 HS_FUSED_HOST_PILEUP=1
+run fused_t05 HS_BENCH_FUSED=1 HS_GROUP_TAPER=0.5
+run fused_shared HS_BENCH_FUSED=1 HS_SHARED_POOL=1
+EXTRA="--groups 10" run fused_g10 HS_BENCH_FUSED=1
+run fused_phase1 HS_BENCH_FUSED=1 HS_ORDER_SCOPE=phase1
