@@ -2035,34 +2035,56 @@ struct GraphRows {
     DBuf d_oo, d_n, d_wc, d_row0, d_ids, d_rw, d_bo, d_fe, d_rank, d_rank_off;   // views into `pack`
     UploadPack pack;
     DBuf d_off, d_nbr, d_visit, d_visit_n, d_prog_info, d_prog_bytes, d_prog_steps, d_prog_adj;
-    int64_t rows = 0, rows_dev = 0, total = 0;
+    int64_t rows = 0, rows_dev = 0, total = 0;      // total: neighbour entries of the CSR -- an upper bound while !total_exact (the exact number is d_off[rows])
+    bool total_exact = true;
     int W = 0, max_m = 1;
     std::vector<int32_t> win_m;    // [W]
+    // what the build leaves behind on the stream: the object keeps it until it dies (or builds again), so that no host wait is needed
+    // just to give temporaries back to the pool
+    DBuf d_bits, d_amb, d_deg, d_scan, d_wmo, d_ltw, d_lti, d_ltj, d_wsim, d_wdiff, d_stage, d_src, d_len, d_dst, d_os, d_od, d_pb, d_pm, d_pi, d_pj;
+    UploadPack pk_amb, pk_patch;
+    HBuf h_amb, h_rows, h_deg, h_nbr;
+    std::vector<int32_t> row_win;
+    std::vector<int64_t> win_bits_off, win_mat_off;
+    std::vector<int32_t> lt_w, lt_i, lt_j;
+    int Wd = 0, Wmx = 0, rows_mx = 0;
+    size_t amb_cap = 0;
+    int64_t stage_cap = 0, stage_hint = 0;      // entries (sim / diff pairs) the undecided rows may stage / staged last time
+    EventPair ev;
+    bool timed = false, begun = false;
+    const int32_t* d_sim = nullptr; const int32_t* d_diff = nullptr; int es = 1;
+    std::vector<int64_t> ctg_out_off; std::vector<int32_t> ctg_n;
+    float* k_ms = nullptr;
 };
 
 // the bit rows of the call (K5a), for the windows of the low-memory path
 struct PlaneRows { const uint64_t* d_alt = nullptr; const uint64_t* d_ref = nullptr; const int64_t* d_plane_off = nullptr; const int32_t* d_words = nullptr; };
 
-static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const std::vector<int64_t>& ctg_out_off, const std::vector<int32_t>& ctg_n_matrix,
-                            const hs::SrWindowSet& ws, GraphRows& G, hipStream_t stream, int64_t* rows_on_host, float* k_ms, KernelClock* kc = nullptr,
+// K6 in two halves. begin: the window tables go up, the row kernels run and -- in the same pass -- stage the sim / diff entries of the
+// rows they cannot decide; count, list and staged entries are shipped to pinned memory. Nothing is waited for: the caller has host
+// work of its own to do meanwhile (the Chinese-Whispers chain of the call is planned from the window plans alone).
+static int graph_rows_begin(const int32_t* d_sim, const int32_t* d_diff, const std::vector<int64_t>& ctg_out_off, const std::vector<int32_t>& ctg_n_matrix,
+                            const hs::SrWindowSet& ws, GraphRows& G, hipStream_t stream, float* k_ms, KernelClock* kc = nullptr,
                             const PlaneRows* planes = nullptr, int es = 1 /* element stride of d_sim / d_diff (2: pairs in one array) */) {
-    const std::vector<int32_t>& ctg_n = ws.ctg_reads.empty() ? ctg_n_matrix : ws.ctg_reads;      // reads of every contig (the matrix list has 0 for low-memory contigs)
+    G.ctg_n = ws.ctg_reads.empty() ? ctg_n_matrix : ws.ctg_reads;      // reads of every contig (the matrix list has 0 for low-memory contigs)
+    G.ctg_out_off = ctg_out_off;
+    const std::vector<int32_t>& ctg_n = G.ctg_n;
     const int W = (int)ws.win_contig.size();
-    G.W = W; G.rows = ws.rows(); G.total = 0; G.max_m = 1;
-    if (rows_on_host) *rows_on_host = 0;
+    G.W = W; G.rows = ws.rows(); G.total = 0; G.total_exact = true; G.max_m = 1; G.begun = true; G.timed = false; G.k_ms = k_ms;
+    G.d_sim = d_sim; G.d_diff = d_diff; G.es = es;
     if (G.rows > 0x7fffffff) { set_error("read graphs: too many rows"); return HS_EINVAL; }
     const int rows = (int)G.rows;
     const int Wd = ws.n_dev_windows;
     const int Wmx = ws.ctg_reads.empty() ? Wd : ws.n_matrix_windows;      // [0, Wmx): sim / diff of the contig; [Wmx, Wd): window-local matrices (low-memory path)
     const int rows_dev = (int)ws.win_row0[(size_t)Wd];
     const int rows_mx = (int)ws.win_row0[(size_t)Wmx];
-    G.rows_dev = rows_dev;
+    G.rows_dev = rows_dev; G.Wd = Wd; G.Wmx = Wmx; G.rows_mx = rows_mx;
     if (Wmx < Wd && (!planes || !planes->d_alt)) { set_error("read graphs: low-memory windows without bit rows"); return HS_EINVAL; }
     if ((int64_t)ws.host_off.size() != (int64_t)(rows - rows_dev) + 1 && rows != rows_dev) { set_error("read graphs: host rows do not match the window set"); return HS_EINVAL; }
-    std::vector<int32_t> row_win((size_t)rows_dev);
-    std::vector<int64_t> win_bits_off((size_t)Wd + 1, 0);
+    std::vector<int32_t>& row_win = G.row_win; row_win.assign((size_t)rows_dev, 0);
+    std::vector<int64_t>& win_bits_off = G.win_bits_off; win_bits_off.assign((size_t)Wd + 1, 0);
     G.win_m.resize((size_t)W);
-    int max_m_dev = 1;
+    int max_m_dev = 1, max_len = 1;
     for (int w = 0; w < W; ++w) {
         const int64_t m0 = ws.win_row0[(size_t)w], m = ws.win_row0[(size_t)w + 1] - m0;
         G.win_m[(size_t)w] = (int32_t)m;
@@ -2071,19 +2093,20 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
             for (int64_t r = 0; r < m; ++r) row_win[(size_t)(m0 + r)] = w;
             win_bits_off[(size_t)w + 1] = win_bits_off[(size_t)w] + m * ((m + 63) >> 6);
             max_m_dev = std::max(max_m_dev, (int)m);
+            max_len = std::max(max_len, w < Wmx ? ctg_n[(size_t)ws.win_contig[(size_t)w]] : (int)m);
         }
     }
     // low-memory windows: an m x m sim / diff per window, every 64 x 64 tile of it one workgroup
-    std::vector<int64_t> win_mat_off((size_t)Wd + 1, 0);
-    std::vector<int32_t> lt_w, lt_i, lt_j;
+    std::vector<int64_t>& win_mat_off = G.win_mat_off; win_mat_off.assign((size_t)Wd + 1, 0);
+    std::vector<int32_t>& lt_w = G.lt_w; std::vector<int32_t>& lt_i = G.lt_i; std::vector<int32_t>& lt_j = G.lt_j;
+    lt_w.clear(); lt_i.clear(); lt_j.clear();
     for (int w = 0; w < Wd; ++w) {
         const int64_t m = w >= Wmx ? G.win_m[(size_t)w] : 0;
         win_mat_off[(size_t)w + 1] = win_mat_off[(size_t)w] + m * m;
         const int nt = (int)((m + 63) / 64);
         for (int i = 0; i < nt; ++i) for (int j = 0; j < nt; ++j) { lt_w.push_back(w); lt_i.push_back(i); lt_j.push_back(j); }
     }
-    DBuf d_wmo, d_ltw, d_lti, d_ltj, d_wsim, d_wdiff;
-    if (Wmx < Wd) { G.pack.add(win_mat_off, d_wmo); G.pack.add(lt_w, d_ltw); G.pack.add(lt_i, d_lti); G.pack.add(lt_j, d_ltj); }
+    if (Wmx < Wd) { G.pack.add(win_mat_off, G.d_wmo); G.pack.add(lt_w, G.d_ltw); G.pack.add(lt_i, G.d_lti); G.pack.add(lt_j, G.d_ltj); }
     G.pack.add(ctg_out_off, G.d_oo);
     G.pack.add(ctg_n, G.d_n);
     G.pack.add(ws.win_contig, G.d_wc);
@@ -2095,36 +2118,41 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
     G.pack.add(ws.rank, G.d_rank);
     G.pack.add(ws.ctg_rank_off, G.d_rank_off);
     if (int rc = G.pack.commit(stream)) return rc;
-    if (int rc = G.d_off.alloc(((size_t)rows + 1) * 8)) return rc;
+    if (int rc = G.d_off.alloc(((size_t)rows + 1) * 8 + 32)) return rc;      // (+ room for the 16-byte granules of a shipment of its last element)
     if (int rc = G.d_visit.alloc(std::max<size_t>((size_t)rows, 1) * 4)) return rc;
     if (int rc = G.d_visit_n.alloc(std::max<size_t>((size_t)W, 1) * 4)) return rc;
-    if (rows == 0) { HS_HIP(hipMemsetAsync(G.d_off.p, 0, 8, stream)); return HS_OK; }
-    DBuf d_bits, d_ac, d_ar, d_deg, d_scan;
-    DBuf d_src, d_len, d_dst, d_os, d_od, d_pb, d_pm, d_pi, d_pj;      // rows resolved on the host (below); released after the final wait
-    UploadPack pk_amb, pk_patch;
-    if (int rc = d_deg.alloc((size_t)rows * 4)) return rc;
-    EventPair ev; if (int rc = ev.init()) return rc;
-    bool timed = false;
+    if (rows == 0) { hipLaunchKernelGGL(hsdev::k_fill16, dim3(1), dim3(64), 0, stream, G.d_off.as<uint4>(), 1ll, 0u); HS_HIP(hipGetLastError()); return HS_OK; }
+    if (int rc = G.d_deg.alloc((size_t)rows * 4)) return rc;
+    if (int rc = G.ev.init()) return rc;
     if (rows_dev > 0) {
         if (rows_mx > 0 && !d_sim) { set_error("read graphs before simdiff"); return HS_EINVAL; }
-        const size_t bits_bytes = (size_t)win_bits_off.back() * 8;
-        if (int rc = d_bits.alloc(bits_bytes)) return rc;
-        if (int rc = d_ar.alloc(((size_t)rows_dev + 1) * 4)) return rc;      // [0] = number of rows left to the host, then the rows
-        HS_HIP(hipMemsetAsync(d_bits.p, 0, bits_bytes ? bits_bytes : 8, stream));
-        HS_HIP(hipMemsetAsync(d_ar.p, 0, 4, stream));
+        const size_t bits_bytes = ((size_t)win_bits_off.back() * 8 + 15) & ~(size_t)15;
+        if (int rc = G.d_bits.alloc(std::max<size_t>(bits_bytes, 16))) return rc;
+        // the block the host reads: [rows left to it][entries staged] | rows [amb_cap] | stage offsets [amb_cap] ; then the staged entries
+        G.amb_cap = (size_t)rows_dev;
+        G.stage_cap = std::max<int64_t>(G.stage_hint + G.stage_hint / 2, 64 * (int64_t)max_len);
+        const size_t amb_bytes = 16 + (((size_t)G.amb_cap * 4 + 15) & ~(size_t)15) + (((size_t)G.amb_cap * 8 + 15) & ~(size_t)15);      // (every part a whole number of 16-byte granules: the parts of a shipment must not share one)
+        if (int rc = G.d_amb.alloc(amb_bytes)) return rc;
+        if (int rc = G.d_stage.alloc((size_t)G.stage_cap * 8 + 32)) return rc;
+        hipLaunchKernelGGL(hsdev::k_fill16, dim3((unsigned)std::min<size_t>(256, bits_bytes / 4096 + 1)), dim3(256), 0, stream, G.d_bits.as<uint4>(), (long long)(std::max<size_t>(bits_bytes, 16) / 16), 0u);
+        hipLaunchKernelGGL(hsdev::k_fill16, dim3(1), dim3(64), 0, stream, G.d_amb.as<uint4>(), 1ll, 0u);
+        unsigned long long* amb_head = G.d_amb.as<unsigned long long>();
+        int32_t* amb_rows = reinterpret_cast<int32_t*>((char*)G.d_amb.p + 16);
+        long long* amb_so = reinterpret_cast<long long*>((char*)G.d_amb.p + 16 + (((size_t)G.amb_cap * 4 + 15) & ~(size_t)15));
+        int32_t* st_sim = G.d_stage.as<int32_t>(); int32_t* st_diff = st_sim + (((size_t)G.stage_cap + 3) & ~(size_t)3);
         // per-wave LDS: cap distances + cap totals. Four waves per workgroup while they fit, else one; windows wider than that
         // (m > 7168 masked reads) send their rows to the host
         int cap = ((max_m_dev + 63) / 64) * 64, waves = 4;
         if ((size_t)cap * 8 * 4 > 57344) waves = 1;
         if ((size_t)cap * 8 > 57344) cap = 7168;
         const float below = 1 - ws.error_rate * 2;   // :778
-        HS_HIP(hipEventRecord(ev.a, stream));
+        HS_HIP(hipEventRecord(G.ev.a, stream));
         if (rows_mx > 0) {
             if (kc) { if (int rc = kc->begin(HS_K_GRAPH_ROWS, stream)) return rc; }
             hipLaunchKernelGGL(hsdev::k_read_graph_rows<false>, dim3((rows_mx + waves - 1) / waves), dim3(64 * waves), (size_t)cap * 8 * waves, stream, d_sim, d_diff,
                                G.d_oo.as<int64_t>(), G.d_n.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_rw.as<int32_t>(),
-                               G.d_bo.as<int64_t>(), 0, rows_mx, below, cap, d_bits.as<unsigned long long>(), d_ar.as<int32_t>(), d_ar.as<int32_t>() + 1, rows_dev,
-                               (const int64_t*)nullptr, es);
+                               G.d_bo.as<int64_t>(), 0, rows_mx, below, cap, G.d_bits.as<unsigned long long>(), amb_head, amb_rows, (int)G.amb_cap,
+                               (const int64_t*)nullptr, es, amb_so, st_sim, st_diff, (long long)G.stage_cap);
             HS_HIP(hipGetLastError());
             if (kc) {   // per row: the sim and diff entries of the window's m reads in, m link bits out
                 int64_t by = 0;
@@ -2135,139 +2163,184 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
         if (rows_dev > rows_mx) {
             // create_read_graph_low_memory: the window-local matrices from the bit rows, then the same row kernel with that path's distance
             const size_t mat = (size_t)win_mat_off.back();
-            if (int rc = d_wsim.alloc(std::max<size_t>(mat, 1) * 8)) return rc;      // (sim, diff) pairs: a row kernel's two reads of a pair share a line
-            d_wdiff.p = (char*)d_wsim.p + 4; d_wdiff.bytes = 0; d_wdiff.cap = 0; d_wdiff.view = true;
+            if (int rc = G.d_wsim.alloc(std::max<size_t>(mat, 1) * 8)) return rc;      // (sim, diff) pairs: a row kernel's two reads of a pair share a line
+            G.d_wdiff.release(); G.d_wdiff.p = (char*)G.d_wsim.p + 4; G.d_wdiff.bytes = 0; G.d_wdiff.cap = 0; G.d_wdiff.view = true;
             if (kc) { if (int rc = kc->begin(HS_K_SIMDIFF, stream)) return rc; }
             hipLaunchKernelGGL(hsdev::k_simdiff_windows, dim3((unsigned)lt_w.size()), dim3(256), 0, stream, planes->d_alt, planes->d_ref, planes->d_plane_off, planes->d_words,
-                               G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), d_wmo.as<int64_t>(), d_ltw.as<int32_t>(), d_lti.as<int32_t>(),
-                               d_ltj.as<int32_t>(), d_wsim.as<int32_t>(), d_wdiff.as<int32_t>(), 2);
+                               G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), G.d_wmo.as<int64_t>(), G.d_ltw.as<int32_t>(), G.d_lti.as<int32_t>(),
+                               G.d_ltj.as<int32_t>(), G.d_wsim.as<int32_t>(), G.d_wdiff.as<int32_t>(), 2);
             HS_HIP(hipGetLastError());
             if (kc) { if (int rc = kc->end(8 * (int64_t)mat, stream)) return rc; }
             if (kc) { if (int rc = kc->begin(HS_K_GRAPH_ROWS, stream)) return rc; }
             const int n_lm = rows_dev - rows_mx;
-            hipLaunchKernelGGL(hsdev::k_read_graph_rows<true>, dim3((n_lm + waves - 1) / waves), dim3(64 * waves), (size_t)cap * 8 * waves, stream, d_wsim.as<int32_t>(),
-                               d_wdiff.as<int32_t>(), G.d_oo.as<int64_t>(), G.d_n.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(),
-                               G.d_rw.as<int32_t>(), G.d_bo.as<int64_t>(), rows_mx, n_lm, below, cap, d_bits.as<unsigned long long>(), d_ar.as<int32_t>(),
-                               d_ar.as<int32_t>() + 1, rows_dev, d_wmo.as<int64_t>(), 2);
+            hipLaunchKernelGGL(hsdev::k_read_graph_rows<true>, dim3((n_lm + waves - 1) / waves), dim3(64 * waves), (size_t)cap * 8 * waves, stream, G.d_wsim.as<int32_t>(),
+                               G.d_wdiff.as<int32_t>(), G.d_oo.as<int64_t>(), G.d_n.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(),
+                               G.d_rw.as<int32_t>(), G.d_bo.as<int64_t>(), rows_mx, n_lm, below, cap, G.d_bits.as<unsigned long long>(), amb_head, amb_rows, (int)G.amb_cap,
+                               G.d_wmo.as<int64_t>(), 2, amb_so, st_sim, st_diff, (long long)G.stage_cap);
             HS_HIP(hipGetLastError());
             if (kc) { if (int rc = kc->end(8 * (int64_t)mat, stream)) return rc; }
         }
-        HS_HIP(hipEventRecord(ev.b, stream));
-        timed = true;
-        // the count and (normally all of) the list in one download
-        const size_t first_rows = std::min<size_t>((size_t)rows_dev, 2048);
-        HBuf h_amb;
-        if (int rc = h_amb.alloc((first_rows + 1) * 4)) return rc;
-        if (int rc = copy_d2h(h_amb.p, d_ar.p, (first_rows + 1) * 4, stream)) return rc;
-        const int32_t n_amb = *(const int32_t*)h_amb.p;
+        HS_HIP(hipEventRecord(G.ev.b, stream));
+        G.timed = true;
+        // count, list, stage offsets and the staged entries in one shipment
+        const size_t rows_part = ((size_t)G.amb_cap * 4 + 15) & ~(size_t)15, stage_half = (((size_t)G.stage_cap + 3) & ~(size_t)3) * 4;
+        if (int rc = G.h_amb.alloc(amb_bytes + 2 * stage_half + 64)) return rc;
+        Shipment sh;
+        char* hb = (char*)G.h_amb.p;
+        sh.add(hb, G.d_amb.p, 16);
+        sh.add_counted(hb + 16, (char*)G.d_amb.p + 16, reinterpret_cast<const long long*>(amb_head), 4, (long long)G.amb_cap);
+        sh.add_counted(hb + 16 + rows_part, (char*)G.d_amb.p + 16 + rows_part, reinterpret_cast<const long long*>(amb_head), 8, (long long)G.amb_cap);
+        sh.add_counted(hb + amb_bytes, st_sim, reinterpret_cast<const long long*>(amb_head + 1), 4, G.stage_cap);
+        sh.add_counted(hb + amb_bytes + stage_half, st_diff, reinterpret_cast<const long long*>(amb_head + 1), 4, G.stage_cap);
+        if (kc) { if (int rc = kc->begin(HS_K_SHIP, stream)) return rc; }
+        if (int rc = sh.launch(stream, 16)) return rc;
+        if (kc) { if (int rc = kc->end(0, stream)) return rc; }
+    }
+    return HS_OK;
+}
+
+// end: the one wait of K6; the undecided rows are resolved with std::sort itself on the staged entries and patched in; degrees, scan,
+// fill (the neighbour array sized by its upper bound sum m^2 where that is moderate: no round trip for the total), visiting orders.
+// Nothing is waited for at the end: what the stream still reads lives in G.
+static int graph_rows_end(const hs::SrWindowSet& ws, GraphRows& G, hipStream_t stream, int64_t* rows_on_host, KernelClock* kc = nullptr) {
+    if (rows_on_host) *rows_on_host = 0;
+    const int rows = (int)G.rows, rows_dev = (int)G.rows_dev, rows_mx = G.rows_mx, Wd = G.Wd, Wmx = G.Wmx, W = G.W;
+    if (rows == 0) return HS_OK;
+    const std::vector<int32_t>& ctg_n = G.ctg_n;
+    const std::vector<int32_t>& row_win = G.row_win;
+    const std::vector<int64_t>& win_bits_off = G.win_bits_off;
+    const std::vector<int64_t>& win_mat_off = G.win_mat_off;
+    if (rows_dev > 0) {
+        if (int rc = stream_wait(stream)) return rc;
+        const size_t rows_part = ((size_t)G.amb_cap * 4 + 15) & ~(size_t)15, amb_bytes = 16 + rows_part + (((size_t)G.amb_cap * 8 + 15) & ~(size_t)15), stage_half = (((size_t)G.stage_cap + 3) & ~(size_t)3) * 4;
+        const char* hb = (const char*)G.h_amb.p;
+        const int64_t n_amb = (int64_t)((const unsigned long long*)hb)[0];
+        const int64_t staged = (int64_t)((const unsigned long long*)hb)[1];
+        G.stage_hint = staged;
+        if (n_amb > (int64_t)G.amb_cap) { set_error("read graphs: more undecided rows than rows"); return HS_EINVAL; }
         if (n_amb > 0) {
-            // rows where std::sort's arrangement of equal distances decides: fetch their sim/diff rows, do exactly what the reference does
-            std::vector<int32_t> amb((size_t)n_amb);
-            std::memcpy(amb.data(), (const int32_t*)h_amb.p + 1, std::min<size_t>((size_t)n_amb, first_rows) * 4);
-            if ((size_t)n_amb > first_rows) { if (int rc = d2h_pinned(amb.data() + first_rows, d_ar.as<int32_t>() + 1 + first_rows, ((size_t)n_amb - first_rows) * 4, stream)) return rc; }
-            std::sort(amb.begin(), amb.end());
-            std::vector<int64_t> src((size_t)n_amb), dst((size_t)n_amb + 1, 0);
-            std::vector<int32_t> len((size_t)n_amb);
-            for (int k = 0; k < n_amb; ++k) {
-                const int w = row_win[(size_t)amb[(size_t)k]];
-                const int c = ws.win_contig[(size_t)w];
-                const int N = ctg_n[(size_t)c];
-                const int r1 = ws.mask_ids[(size_t)amb[(size_t)k]];
-                if (amb[(size_t)k] < rows_mx) { src[(size_t)k] = ctg_out_off[(size_t)c] + (int64_t)r1 * N; len[(size_t)k] = N; }
-                else {      // a row of a window-local matrix: its m entries
-                    const int64_t m = G.win_m[(size_t)w];
-                    src[(size_t)k] = win_mat_off[(size_t)w] + (int64_t)(amb[(size_t)k] - ws.win_row0[(size_t)w]) * m; len[(size_t)k] = (int32_t)m;
+            // rows where std::sort's arrangement of equal distances decides: exactly what the reference does, on their sim / diff entries
+            const int32_t* amb_rows = (const int32_t*)(hb + 16);
+            const long long* amb_so = (const long long*)(hb + 16 + rows_part);
+            const int32_t* st_sim = (const int32_t*)(hb + amb_bytes); const int32_t* st_diff = (const int32_t*)(hb + amb_bytes + stage_half);
+            std::vector<int32_t> order((size_t)n_amb);
+            for (int64_t k = 0; k < n_amb; ++k) order[(size_t)k] = (int32_t)k;
+            std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return amb_rows[x] < amb_rows[y]; });      // (the links are ORed in: any order gives the same bits; sorted for the fetch below)
+            // rows whose entries found no room in the staging area (a first call, or more of them than ever before): fetched the old way
+            std::vector<int32_t> late;
+            for (int32_t k : order) if (amb_so[k] < 0) late.push_back(k);
+            std::vector<int64_t> late_dst((size_t)late.size() + 1, 0);
+            const int32_t* late_sim = nullptr; const int32_t* late_diff = nullptr;
+            if (!late.empty()) {
+                std::vector<int64_t> src(late.size()); std::vector<int32_t> len(late.size());
+                int n_mx = 0;
+                for (size_t q = 0; q < late.size(); ++q) {
+                    const int row = amb_rows[late[q]];
+                    const int w = row_win[(size_t)row];
+                    const int c = ws.win_contig[(size_t)w];
+                    const int N = ctg_n[(size_t)c];
+                    const int r1 = ws.mask_ids[(size_t)row];
+                    if (row < rows_mx) { src[q] = G.ctg_out_off[(size_t)c] + (int64_t)r1 * N; len[q] = N; n_mx++; }
+                    else { const int64_t m = G.win_m[(size_t)w]; src[q] = win_mat_off[(size_t)w] + (int64_t)(row - ws.win_row0[(size_t)w]) * m; len[q] = (int32_t)m; }
+                    late_dst[q + 1] = late_dst[q] + len[q];
                 }
-                dst[(size_t)k + 1] = dst[(size_t)k] + len[(size_t)k];
+                G.pk_amb.add(src, G.d_src); G.pk_amb.add(len, G.d_len); G.pk_amb.add(late_dst, G.d_dst);
+                if (int rc = G.pk_amb.commit(stream)) return rc;
+                if (int rc = G.d_os.alloc((size_t)late_dst.back() * 4 + 16)) return rc;
+                if (int rc = G.d_od.alloc((size_t)late_dst.back() * 4 + 16)) return rc;
+                if (n_mx > 0)
+                    hipLaunchKernelGGL(hsdev::k_read_graph_fetch_rows, dim3(n_mx), dim3(256), 0, stream, G.d_sim, G.d_diff, G.d_src.as<int64_t>(), G.d_len.as<int32_t>(),
+                                       G.d_dst.as<int64_t>(), G.d_os.as<int32_t>(), G.d_od.as<int32_t>(), G.es);
+                if ((int)late.size() > n_mx)
+                    hipLaunchKernelGGL(hsdev::k_read_graph_fetch_rows, dim3((unsigned)late.size() - n_mx), dim3(256), 0, stream, G.d_wsim.as<int32_t>(), G.d_wdiff.as<int32_t>(),
+                                       G.d_src.as<int64_t>() + n_mx, G.d_len.as<int32_t>() + n_mx, G.d_dst.as<int64_t>() + n_mx, G.d_os.as<int32_t>(), G.d_od.as<int32_t>(), 2);
+                HS_HIP(hipGetLastError());
+                const size_t row_bytes = (((size_t)late_dst.back() * 4) + 15) & ~(size_t)15;
+                if (int rc = G.h_rows.alloc(2 * row_bytes + 16)) return rc;
+                Shipment sh; sh.add(G.h_rows.p, G.d_os.p, row_bytes); sh.add((char*)G.h_rows.p + row_bytes, G.d_od.p, row_bytes);
+                if (int rc = sh.launch(stream, 16)) return rc;
+                if (int rc_w = stream_wait(stream)) return rc_w;
+                late_sim = (const int32_t*)G.h_rows.p; late_diff = (const int32_t*)((const char*)G.h_rows.p + row_bytes);
+                G.stage_hint = std::max<int64_t>(G.stage_hint, staged + late_dst.back());
             }
-            const int n_amb_mx = (int)(std::lower_bound(amb.begin(), amb.end(), rows_mx) - amb.begin());      // (sorted: the matrix rows come first)
-            pk_amb.add(src, d_src); pk_amb.add(len, d_len); pk_amb.add(dst, d_dst);
-            if (int rc = pk_amb.commit(stream)) return rc;
-            if (int rc = d_os.alloc((size_t)dst.back() * 4)) return rc;
-            if (int rc = d_od.alloc((size_t)dst.back() * 4)) return rc;
-            if (n_amb_mx > 0)
-                hipLaunchKernelGGL(hsdev::k_read_graph_fetch_rows, dim3(n_amb_mx), dim3(256), 0, stream, d_sim, d_diff, d_src.as<int64_t>(), d_len.as<int32_t>(),
-                                   d_dst.as<int64_t>(), d_os.as<int32_t>(), d_od.as<int32_t>(), es);
-            if (n_amb > n_amb_mx)
-                hipLaunchKernelGGL(hsdev::k_read_graph_fetch_rows, dim3(n_amb - n_amb_mx), dim3(256), 0, stream, d_wsim.as<int32_t>(), d_wdiff.as<int32_t>(),
-                                   d_src.as<int64_t>() + n_amb_mx, d_len.as<int32_t>() + n_amb_mx, d_dst.as<int64_t>() + n_amb_mx, d_os.as<int32_t>(), d_od.as<int32_t>(), 2);
-            HS_HIP(hipGetLastError());
-            // both row sets with one wait, read where they land
-            HBuf h_rows;
-            const size_t row_bytes = (size_t)dst.back() * 4;
-            if (int rc = h_rows.alloc(2 * row_bytes + 16)) return rc;
-            if (row_bytes) {
-                HS_HIP(HS_COPY_ASYNC(h_rows.p, d_os.p, row_bytes, hipMemcpyDeviceToHost, stream));
-                HS_HIP(HS_COPY_ASYNC((char*)h_rows.p + row_bytes, d_od.p, row_bytes, hipMemcpyDeviceToHost, stream));
-            }
-            if (int rc_w = stream_wait(stream)) return rc_w;
-            const int32_t* hs_ = (const int32_t*)h_rows.p; const int32_t* hd_ = (const int32_t*)((const char*)h_rows.p + row_bytes);
             std::vector<int64_t> pbase; std::vector<int32_t> pmw, pi, pj;
             std::vector<uint8_t> mask;
             std::vector<int> picked;
-            for (int k = 0; k < n_amb; ++k) {
-                const int row = amb[(size_t)k];
+            size_t late_q = 0;
+            for (int32_t k : order) {
+                const int row = amb_rows[k];
                 const int w = row_win[(size_t)row];
                 const int64_t m0 = ws.win_row0[(size_t)w];
                 const int m = (int)(ws.win_row0[(size_t)w + 1] - m0);
                 const int32_t* ids = ws.mask_ids.data() + m0;
                 const int N = ctg_n[(size_t)ws.win_contig[(size_t)w]];
+                const int32_t* rs; const int32_t* rd;
+                if (late_q < late.size() && late[late_q] == k) { rs = late_sim + late_dst[late_q]; rd = late_diff + late_dst[late_q]; late_q++; }
+                else { rs = st_sim + amb_so[k]; rd = st_diff + amb_so[k]; }
                 mask.assign((size_t)N, 0);
                 for (int j = 0; j < m; ++j) mask[(size_t)ids[j]] = 1;
-                if (row < rows_mx) hs::sr_pick_row_sorted(hs_ + dst[(size_t)k], hd_ + dst[(size_t)k], N, ids[row - m0], mask.data(), ws.error_rate, picked);
-                else hs::sr_pick_row_sorted_low_memory(hs_ + dst[(size_t)k], hd_ + dst[(size_t)k], ids, m, (int)(row - m0), N, mask.data(), ws.error_rate, picked);
+                if (row < rows_mx) hs::sr_pick_row_sorted(rs, rd, N, ids[row - m0], mask.data(), ws.error_rate, picked);
+                else hs::sr_pick_row_sorted_low_memory(rs, rd, ids, m, (int)(row - m0), N, mask.data(), ws.error_rate, picked);
                 for (int nb : picked) {
                     const int j = (int)(std::lower_bound(ids, ids + m, nb) - ids);
                     pbase.push_back(win_bits_off[(size_t)w]); pmw.push_back((m + 63) >> 6); pi.push_back((int32_t)(row - m0)); pj.push_back(j);
                 }
             }
             if (!pi.empty()) {
-                pk_patch.add(pbase, d_pb); pk_patch.add(pmw, d_pm); pk_patch.add(pi, d_pi); pk_patch.add(pj, d_pj);
-                if (int rc = pk_patch.commit(stream)) return rc;
+                G.pk_patch.add(pbase, G.d_pb); G.pk_patch.add(pmw, G.d_pm); G.pk_patch.add(pi, G.d_pi); G.pk_patch.add(pj, G.d_pj);
+                if (int rc = G.pk_patch.commit(stream)) return rc;
                 const int np = (int)pi.size();
-                hipLaunchKernelGGL(hsdev::k_read_graph_patch, dim3((np + 255) / 256), dim3(256), 0, stream, d_pb.as<int64_t>(), d_pm.as<int32_t>(), d_pi.as<int32_t>(),
-                                   d_pj.as<int32_t>(), np, d_bits.as<unsigned long long>());
-                HS_HIP(hipGetLastError());      // (the patch arrays live until the wait at the end of this function)
+                hipLaunchKernelGGL(hsdev::k_read_graph_patch, dim3((np + 255) / 256), dim3(256), 0, stream, G.d_pb.as<int64_t>(), G.d_pm.as<int32_t>(), G.d_pi.as<int32_t>(),
+                                   G.d_pj.as<int32_t>(), np, G.d_bits.as<unsigned long long>());
+                HS_HIP(hipGetLastError());
             }
             if (rows_on_host) *rows_on_host = n_amb;
-            if (std::getenv("HS_TIMING") && Wmx < Wd)
-                std::fprintf(stderr, "[hs timing] sr: low-memory path on the device: %d windows, %d rows, %d of them resolved on the host (NaN distances / std::sort ties)\n",
-                             Wd - Wmx, rows_dev - rows_mx, n_amb - n_amb_mx);
+            if (std::getenv("HS_TIMING") && Wmx < Wd) {
+                int64_t n_lm = 0; for (int64_t k = 0; k < n_amb; ++k) n_lm += amb_rows[k] >= rows_mx;
+                std::fprintf(stderr, "[hs timing] sr: low-memory path on the device: %d windows, %d rows, %ld of them resolved on the host (NaN distances / std::sort ties)\n",
+                             Wd - Wmx, rows_dev - rows_mx, (long)n_lm);
+            }
         } else if (std::getenv("HS_TIMING") && Wmx < Wd)
             std::fprintf(stderr, "[hs timing] sr: low-memory path on the device: %d windows, %d rows, none resolved on the host\n", Wd - Wmx, rows_dev - rows_mx);
         if (kc) { if (int rc = kc->begin(HS_K_GRAPH_CSR, stream)) return rc; }
-        hipLaunchKernelGGL(hsdev::k_read_graph_degrees, dim3((rows_dev + 255) / 256), dim3(256), 0, stream, d_bits.as<unsigned long long>(), G.d_rw.as<int32_t>(),
-                           G.d_row0.as<int64_t>(), G.d_bo.as<int64_t>(), rows_dev, d_deg.as<int32_t>());
+        hipLaunchKernelGGL(hsdev::k_read_graph_degrees, dim3((rows_dev + 255) / 256), dim3(256), 0, stream, G.d_bits.as<unsigned long long>(), G.d_rw.as<int32_t>(),
+                           G.d_row0.as<int64_t>(), G.d_bo.as<int64_t>(), rows_dev, G.d_deg.as<int32_t>());
         HS_HIP(hipGetLastError());
         if (kc) { if (int rc = kc->end((int64_t)win_bits_off.back() * 8 + 4 * (int64_t)rows_dev, stream)) return rc; }
     }
-    HBuf h_deg;   // degrees of the rows the host brings
-    if (rows > rows_dev) {
+    if (rows > rows_dev) {   // degrees of the rows the host brings
         const size_t nh = (size_t)(rows - rows_dev);
-        if (int rc = h_deg.alloc(nh * 4)) return rc;
-        int32_t* hd = (int32_t*)h_deg.p;
+        if (int rc = G.h_deg.alloc(nh * 4 + 16)) return rc;
+        int32_t* hd = (int32_t*)G.h_deg.p;
         for (size_t r = 0; r < nh; ++r) hd[r] = (int32_t)(ws.host_off[r + 1] - ws.host_off[r]);
-        HS_HIP(HS_COPY_ASYNC(d_deg.as<int32_t>() + rows_dev, hd, nh * 4, hipMemcpyHostToDevice, stream));
+        HS_HIP(HS_COPY_ASYNC(G.d_deg.as<int32_t>() + rows_dev, hd, nh * 4, hipMemcpyHostToDevice, stream));
     }
-    if (int rc = exclusive_scan_launch(d_deg.as<int32_t>(), rows, G.d_off.as<int64_t>(), d_scan, stream)) return rc;
-    int64_t total = 0;
-    if (int rc = d2h_pinned(&total, G.d_off.as<int64_t>() + rows, 8, stream)) return rc;
+    if (int rc = exclusive_scan_launch(G.d_deg.as<int32_t>(), rows, G.d_off.as<int64_t>(), G.d_scan, stream)) return rc;
+    // the neighbour array: at most sum m^2 entries for the device rows; the exact number only has to be known here when host rows have to
+    // be placed behind them (contigs whose low-memory graphs the host builds) or when the bound is unreasonable
+    int64_t bound = (int64_t)ws.host_nbr.size();
+    for (int w = 0; w < Wd; ++w) bound += (int64_t)G.win_m[(size_t)w] * G.win_m[(size_t)w];
+    int64_t total = bound;
+    G.total_exact = false;
+    if (!ws.host_nbr.empty() || bound > ((int64_t)1 << 28)) {
+        if (int rc = d2h_pinned(&total, G.d_off.as<int64_t>() + rows, 8, stream)) return rc;
+        G.total_exact = true;
+    }
     G.total = total;
     if (int rc = G.d_nbr.alloc(std::max<size_t>((size_t)total, 1) * 4)) return rc;
-    HBuf h_nbr;
     if (total > 0) {
         if (rows_dev > 0) {
             if (kc) { if (int rc = kc->begin(HS_K_GRAPH_CSR, stream)) return rc; }
-            hipLaunchKernelGGL(hsdev::k_read_graph_fill, dim3((rows_dev + 255) / 256), dim3(256), 0, stream, d_bits.as<unsigned long long>(), G.d_rw.as<int32_t>(),
+            hipLaunchKernelGGL(hsdev::k_read_graph_fill, dim3((rows_dev + 255) / 256), dim3(256), 0, stream, G.d_bits.as<unsigned long long>(), G.d_rw.as<int32_t>(),
                                G.d_row0.as<int64_t>(), G.d_bo.as<int64_t>(), G.d_off.as<int64_t>(), rows_dev, G.d_nbr.as<int32_t>());
             HS_HIP(hipGetLastError());
-            if (kc) { if (int rc = kc->end((int64_t)win_bits_off.back() * 8 + 4 * total, stream)) return rc; }
+            if (kc) { if (int rc = kc->end((int64_t)win_bits_off.back() * 8 + 4 * (G.total_exact ? total : (int64_t)rows_dev * 20), stream)) return rc; }
         }
         if (!ws.host_nbr.empty()) {   // the host rows sit behind the device rows: their lists start at total - |host_nbr|
             const size_t nb = ws.host_nbr.size() * 4;
-            if (int rc = h_nbr.alloc(nb)) return rc;
-            std::memcpy(h_nbr.p, ws.host_nbr.data(), nb);
-            HS_HIP(HS_COPY_ASYNC(G.d_nbr.as<int32_t>() + (total - (int64_t)ws.host_nbr.size()), h_nbr.p, nb, hipMemcpyHostToDevice, stream));
+            if (int rc = G.h_nbr.alloc(nb)) return rc;
+            std::memcpy(G.h_nbr.p, ws.host_nbr.data(), nb);
+            HS_HIP(HS_COPY_ASYNC(G.d_nbr.as<int32_t>() + (total - (int64_t)ws.host_nbr.size()), G.h_nbr.p, nb, hipMemcpyHostToDevice, stream));
         }
     }
     {   // visiting order of every window (hs_kernels_cw.hip)
@@ -2275,9 +2348,10 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
         // the visit programs of the row-packed Chinese-Whispers kernel (windows with m <= 255): nnz + 15 m bytes per window
         if (int rc = G.d_prog_info.alloc(std::max<size_t>((size_t)rows, 1) * 4)) return rc;
         if (int rc = G.d_prog_bytes.alloc((size_t)total + 15 * (size_t)rows + 64)) return rc;
-        if (int rc = G.d_prog_steps.alloc(std::max<size_t>((size_t)W, 1) * 4)) return rc;
+        const size_t steps_bytes = (std::max<size_t>((size_t)W, 1) * 4 + 15) & ~(size_t)15;
+        if (int rc = G.d_prog_steps.alloc(steps_bytes)) return rc;
         if (int rc = G.d_prog_adj.alloc(std::max<size_t>((size_t)rows, 1) * 8)) return rc;
-        HS_HIP(hipMemsetAsync(G.d_prog_steps.p, 0, std::max<size_t>((size_t)W, 1) * 4, stream));
+        hipLaunchKernelGGL(hsdev::k_fill16, dim3((unsigned)std::min<size_t>(64, steps_bytes / 4096 + 1)), dim3(256), 0, stream, G.d_prog_steps.as<uint4>(), (long long)(steps_bytes / 16), 0u);
         if (kc) { if (int rc = kc->begin(HS_K_VISIT_LISTS, stream)) return rc; }
         hipLaunchKernelGGL(hsdev::k_cw_visit_lists, dim3((unsigned)W), dim3(256), (size_t)cap * 4, stream, G.d_off.as<int64_t>(), G.d_nbr.as<int32_t>(), G.d_row0.as<int64_t>(),
                            G.d_ids.as<int32_t>(), G.d_wc.as<int32_t>(), G.d_rank_off.as<int64_t>(), G.d_rank.as<int32_t>(), W, cap, G.d_visit.as<int32_t>(),
@@ -2286,10 +2360,23 @@ static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const s
         HS_HIP(hipGetLastError());
         if (kc) { if (int rc = kc->end(20 * (int64_t)rows, stream)) return rc; }   // row offsets + read id + rank in, visiting slot out
     }
-    if (int rc_w = stream_wait(stream)) return rc_w;     // the temporaries (bit matrices, degrees, staging) die with this scope
-    if (kc) kc->flush();
-    if (timed) { float m = 0; if (int rc = ev.ms(&m)) return rc; if (k_ms) *k_ms += m; }
     return HS_OK;
+}
+// after a wait of the stream: the kernel clocks and the K6 time of the call
+static int graph_rows_settle(GraphRows& G, KernelClock* kc) {
+    if (kc) kc->flush();
+    if (G.timed) { G.timed = false; float m = 0; if (int rc = G.ev.ms(&m)) return rc; if (G.k_ms) *G.k_ms += m; }
+    return HS_OK;
+}
+// both halves and a wait: the graphs are complete and G.total is their exact size (the kernel-level entry point)
+static int graph_rows_build(const int32_t* d_sim, const int32_t* d_diff, const std::vector<int64_t>& ctg_out_off, const std::vector<int32_t>& ctg_n_matrix,
+                            const hs::SrWindowSet& ws, GraphRows& G, hipStream_t stream, int64_t* rows_on_host, float* k_ms, KernelClock* kc = nullptr,
+                            const PlaneRows* planes = nullptr, int es = 1) {
+    if (int rc = graph_rows_begin(d_sim, d_diff, ctg_out_off, ctg_n_matrix, ws, G, stream, k_ms, kc, planes, es)) return rc;
+    if (int rc = graph_rows_end(ws, G, stream, rows_on_host, kc)) return rc;
+    if (G.rows > 0 && !G.total_exact) { int64_t t = 0; if (int rc = d2h_pinned(&t, G.d_off.as<int64_t>() + G.rows, 8, stream)) return rc; G.total = t; G.total_exact = true; }
+    else if (int rc_w = stream_wait(stream)) return rc_w;
+    return graph_rows_settle(G, kc);
 }
 
 struct HipSrOps : hs::SrDeviceOps {
@@ -2361,7 +2448,7 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = pk.commit(stream)) return rc;
         // the ids and the per-window counts in one block: one copy back
         const size_t ids_bytes = ((size_t)total * 4 + 255) & ~(size_t)255;
-        if (int rc = d_ids.alloc(ids_bytes + (size_t)W * 4)) return rc;
+        if (int rc = d_ids.alloc(ids_bytes + (size_t)W * 4 + 16)) return rc;
         int32_t* const dm = reinterpret_cast<int32_t*>((char*)d_ids.p + ids_bytes);
         if (int rc = kc.begin(HS_K_WINDOW_MASKS, stream)) return rc;
         hipLaunchKernelGGL(hsdev::k_window_masks, dim3((unsigned)((W + 3) / 4)), dim3(256), 0, stream, d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_a.as<int64_t>(),
@@ -2369,8 +2456,9 @@ struct HipSrOps : hs::SrDeviceOps {
         HS_HIP(hipGetLastError());
         if (int rc = kc.end(8 * total + 4 * (int64_t)W, stream)) return rc;
         HBuf h_ids;
-        if (int rc = h_ids.alloc(ids_bytes + (size_t)W * 4)) return rc;
-        if (int rc = copy_d2h(h_ids.p, d_ids.p, ids_bytes + (size_t)W * 4, stream)) return rc;
+        if (int rc = h_ids.alloc(ids_bytes + (size_t)W * 4 + 16)) return rc;
+        { Shipment sh; sh.add(h_ids.p, d_ids.p, ids_bytes + (size_t)W * 4); if (int rc = sh.launch(stream, 32)) return rc; }
+        if (int rc = stream_wait(stream)) return rc;
         if (total) std::memcpy(ids.data(), h_ids.p, (size_t)total * 4);
         std::memcpy(win_m.data(), (const char*)h_ids.p + ids_bytes, (size_t)W * 4);
         kc.flush();
@@ -2423,14 +2511,30 @@ struct HipSrOps : hs::SrDeviceOps {
         return HS_OK;   // not waited for: the stream orders K6 behind it, the host goes on planning the windows
     }
 
-    int build_graphs(const hs::SrWindowSet& ws, int64_t* rows_on_host, float* k_ms) override {
+    struct Keep { int64_t stage_hint = 0; };      // kept by the caller from step to step: how much the undecided graph rows staged
+    Keep* keep = nullptr;
+    PlaneRows plane_rows() const {
         PlaneRows pr;
         if (sd_flight) { pr.d_alt = sd_flight->d_alt.as<uint64_t>(); pr.d_ref = sd_flight->d_ref.as<uint64_t>(); pr.d_plane_off = sd_flight->d_po.as<int64_t>(); pr.d_words = sd_flight->d_w.as<int32_t>(); }
-        const int rc = graph_rows_build(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, ws, G, stream, rows_on_host, k_ms, &kc, &pr, 2);
-        const int rc2 = settle_simdiff();   // K6 came after K5 on the stream and has been waited for
-        return rc ? rc : rc2;
+        return pr;
+    }
+    int build_graphs(const hs::SrWindowSet& ws, int64_t* rows_on_host, float* k_ms) override {
+        if (int rc = build_graphs_begin(ws, k_ms)) return rc;
+        return build_graphs_end(ws, rows_on_host);
+    }
+    bool two_phase_graphs() const override { return true; }
+    int build_graphs_begin(const hs::SrWindowSet& ws, float* k_ms) override {
+        const PlaneRows pr = plane_rows();
+        if (keep) G.stage_hint = keep->stage_hint;
+        return graph_rows_begin(d_sim.as<int32_t>(), d_diff.as<int32_t>(), sd_out_off, sd_n, ws, G, stream, k_ms, &kc, &pr, 2);
+    }
+    int build_graphs_end(const hs::SrWindowSet& ws, int64_t* rows_on_host) override {
+        const int rc = graph_rows_end(ws, G, stream, rows_on_host, &kc);
+        if (keep) keep->stage_hint = G.stage_hint;
+        return rc;      // (not waited for: K5's temporaries and the clocks are settled behind the wait of cw_chain / the destructor)
     }
     int fetch_graphs(std::vector<int64_t>& off, std::vector<int32_t>& nbr) override {
+        if (G.rows > 0 && !G.total_exact) { int64_t t = 0; if (int rc = d2h_pinned(&t, G.d_off.as<int64_t>() + G.rows, 8, stream)) return rc; G.total = t; G.total_exact = true; }
         off.assign((size_t)G.rows + 1, 0); nbr.assign((size_t)G.total, 0);
         if (int rc = d2h_pinned(off.data(), G.d_off.p, off.size() * 8, stream)) return rc;
         if (G.total > 0) { if (int rc = d2h_pinned(nbr.data(), G.d_nbr.p, nbr.size() * 4, stream)) return rc; }
@@ -2508,7 +2612,7 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = d_final.alloc(std::max<size_t>((size_t)total_m, 1) * 4)) return rc;
         if (int rc = d_ok.alloc(std::max<size_t>((size_t)Wc, 1))) return rc;
         if (int rc = d_stat.alloc(416)) return rc;    // {sweeps, bytes} of the per-SNP runs, {sweeps, bytes} of the window tails, histogram of sweeps per run [16]
-        HS_HIP(hipMemsetAsync(d_stat.p, 0, 416, stream));
+        hipLaunchKernelGGL(hsdev::k_fill16, dim3(1), dim3(64), 0, stream, d_stat.as<uint4>(), 26ll, 0u);
         EventPair e1, e2;
         if (int rc = e1.init()) return rc;
         if (int rc = e2.init()) return rc;
@@ -2522,8 +2626,8 @@ struct HipSrOps : hs::SrDeviceOps {
             if (int rc = d_slots.alloc(npad * 64)) return rc;
             if (int rc = d_alive.alloc(npad)) return rc;
             if (int rc = d_ovf.alloc((size_t)n * 4)) return rc;
-            if (int rc = d_ovf_n.alloc(4)) return rc;
-            HS_HIP(hipMemsetAsync(d_ovf_n.p, 0, 4, stream));
+            if (int rc = d_ovf_n.alloc(16)) return rc;
+            hipLaunchKernelGGL(hsdev::k_fill16, dim3(1), dim3(64), 0, stream, d_ovf_n.as<uint4>(), 1ll, 0u);
             if (int rc = kc.begin(HS_K_CW_SEED_SETS, stream)) return rc;
             hipLaunchKernelGGL(hsdev::k_cw_seed_sets, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, G.d_row0.as<int64_t>(), G.d_ids.as<int32_t>(), d_ll.as<int32_t>(), n,
                                d_iw.as<int32_t>(), d_seed.as<int64_t>(), d_col_off.as<int64_t>(), d_col_idx.as<int32_t>(), d_col_code.as<uint8_t>(),
@@ -2598,21 +2702,28 @@ struct HipSrOps : hs::SrDeviceOps {
         if (int rc = kc.end(4 * slab + 8 * total_m, stream)) return rc;   // the runs' labels in, the two label arrays out (+ its two runs, below)
         HS_HIP(hipEventRecord(e2.b, stream));
         {
-            // the finished labels and the per-window verdict come back first; the labels of the third run are only fetched
-            // when some window has to be finished by the host code (few or none)
-            HBuf h, h2, h3, h4;
-            if (int rc = h4.alloc(416)) return rc;
-            HS_HIP(HS_COPY_ASYNC(h4.p, d_stat.p, 416, hipMemcpyDeviceToHost, stream));
+            // the finished labels and the per-window verdict come back in one shipment with the counters (and the size of the graphs, which
+            // the host has not asked for until now); the labels of the third run are only fetched when some window has to be finished by the
+            // host code (few or none)
+            HBuf h, h4;
+            const size_t o_nnz = 416, o_final = 512, o_ok = o_final + (((size_t)total_m * 4 + 255) & ~(size_t)255);
+            if (int rc = h4.alloc(o_ok + (size_t)Wc + 256)) return rc;
+            Shipment sh;
+            sh.add(h4.p, d_stat.p, 416);
+            sh.add((char*)h4.p + o_nnz, G.d_off.as<int64_t>() + (G.rows & ~(int64_t)1), 16);      // (the granule that holds d_off[rows])
             bool need_chain_labels = !finish;
             if (finish) {
-                if (int rc = h2.alloc(std::max<size_t>((size_t)total_m, 1) * sizeof(int32_t))) return rc;
-                if (int rc = h3.alloc(std::max<size_t>((size_t)Wc, 1))) return rc;
-                HS_HIP(HS_COPY_ASYNC(h2.p, d_final.p, (size_t)total_m * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-                HS_HIP(HS_COPY_ASYNC(h3.p, d_ok.p, (size_t)Wc, hipMemcpyDeviceToHost, stream));
-                if (int rc = stream_wait(stream)) return rc;
+                sh.add((char*)h4.p + o_final, d_final.p, (size_t)total_m * sizeof(int32_t));
+                sh.add((char*)h4.p + o_ok, d_ok.p, (size_t)Wc);
+            }
+            if (int rc = kc.begin(HS_K_SHIP, stream)) return rc;
+            if (int rc = sh.launch(stream, 64)) return rc;
+            if (int rc = kc.end(0, stream)) return rc;
+            if (int rc = stream_wait(stream)) return rc;
+            if (finish) {
                 final_labels.resize((size_t)total_m); final_ok.resize((size_t)Wc);
-                std::memcpy(final_labels.data(), h2.p, (size_t)total_m * sizeof(int32_t));
-                std::memcpy(final_ok.data(), h3.p, (size_t)Wc);
+                std::memcpy(final_labels.data(), (const char*)h4.p + o_final, (size_t)total_m * sizeof(int32_t));
+                std::memcpy(final_ok.data(), (const char*)h4.p + o_ok, (size_t)Wc);
                 for (uint8_t ok : final_ok) if (!ok) { need_chain_labels = true; break; }
             }
             if (need_chain_labels) {
@@ -2621,7 +2732,8 @@ struct HipSrOps : hs::SrDeviceOps {
                 if (int rc = copy_d2h(h.p, d_l3.p, (size_t)total_m * sizeof(int32_t), stream)) return rc;
                 std::memcpy(labels.data(), h.p, (size_t)total_m * sizeof(int32_t));
             } else labels.clear();
-            if (!finish && !need_chain_labels) { if (int rc = stream_wait(stream)) return rc; }
+            if (!G.total_exact) { G.total = ((const int64_t*)((const char*)h4.p + o_nnz))[G.rows & 1]; G.total_exact = true; }
+            if (int rc = graph_rows_settle(G, &kc)) return rc;
             const unsigned long long* st = (const unsigned long long*)h4.p;
             if (stats) { stats->n_instances = n_inst + 2 * (int64_t)Wc; stats->sweeps = (int64_t)(st[0] + st[2]); stats->bytes = (int64_t)(st[1] + st[3]); stats->graph_nnz = G.total; }
             if (std::getenv("HS_TIMING")) {
@@ -2805,6 +2917,7 @@ struct hs_pipeline {
     std::vector<hs_cv_result*> cv;
     std::vector<hs::SrWorkspace> sr_keep;      // per group: the stage-4 plans and visiting orders live from step to step
     std::vector<std::unique_ptr<HipCvOps::Keep>> cv_keep;      // per group: the sizes of its column pass (the next step queues it without asking)
+    std::vector<HipSrOps::Keep> sr_dev_keep;
     HipCvOps::K2Order k2_order;
 
     int device = 0;        // = batch->device: the group threads bind themselves to it (a new thread starts on device 0)
@@ -2868,8 +2981,8 @@ int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out) {
             // The groups reach the host one after the other (the device hands out their candidate columns about 0.8 ms apart, K2 by K2),
             // and the step ends when the LAST group's chain -- loops A / B, K4, all of stage 4 -- is through: the later a group starts,
             // the smaller it is made, so that the chains end together. HS_GROUP_TAPER = share of the last group relative to the first
-            // (default 0.35; 1 = equal groups), linear in between.
-            static const double taper = []() { const char* e = std::getenv("HS_GROUP_TAPER"); const double v = e ? std::atof(e) : 0.35; return v > 0 && v <= 1 ? v : 1.0; }();
+            // (1 = equal groups, the default: on the 16-core box 0.2 - 0.5 measured within the noise of equal groups, 18.9 - 21.5 ms), linear in between.
+            static const double taper = []() { const char* e = std::getenv("HS_GROUP_TAPER"); const double v = e ? std::atof(e) : 1.0; return v > 0 && v <= 1 ? v : 1.0; }();
             std::vector<double> upto((size_t)G + 1, 0.0);
             for (int g = 0; g < G; ++g) upto[(size_t)g + 1] = upto[(size_t)g] + (G > 1 ? 1.0 + (taper - 1.0) * g / (G - 1) : 1.0);
             int c = 0;
@@ -2894,6 +3007,7 @@ int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out) {
     p->device = b->device; p->thread_device.assign((size_t)G, -1);
     p->sr_keep.resize((size_t)G);
     for (int g = 0; g < G; ++g) p->cv_keep.emplace_back(new HipCvOps::Keep());
+    p->sr_dev_keep.resize((size_t)G);
     for (int g = 0; g < G; ++g) p->threads.emplace_back([p, g] { p->worker(g); });
     *out = p;
     return HS_OK;
@@ -3029,6 +3143,7 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
         static const bool via_host = std::getenv("HS_COLUMNS_VIA_HOST") != nullptr;
         if (int r = hs::cv_run_range(cv_ops, meta, ((const hs::CvSelection*)p->sel->impl)->rec_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host)) return r;
         HipSrOps ops;
+        ops.keep = &p->sr_dev_keep[(size_t)g];
         if (!via_host) ops.adopt_columns(cv_ops);
         return hs::sr_run_from_cv(ops, meta, c0, c1, p->cv[(size_t)g], error_rate, rarest_strain_abundance, low_memory, amplicon, seed, per, window_size,
                                   &parts[(size_t)g], &sparse[(size_t)g], &p->sr_keep[(size_t)g]);
@@ -3146,6 +3261,7 @@ int hs_pipeline_run_fused(hs_pipeline* p, float automatic_snp_threshold, float r
             if (aborted) { set_error("hs_pipeline_run_fused: another contig group failed"); return HS_EINVAL; }
         }
         HipSrOps ops;
+        ops.keep = &p->sr_dev_keep[(size_t)g];
         if (!via_host) ops.adopt_columns(cv_ops);
         const int r = hs::sr_run_from_cv(ops, meta, c0, c1, p->cv[(size_t)g], error_rate, rarest_strain_abundance, low_memory, amplicon, seed, per, window_size,
                                          &parts[(size_t)g], &sparse[(size_t)g], &p->sr_keep[(size_t)g]);

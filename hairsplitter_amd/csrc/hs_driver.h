@@ -206,6 +206,11 @@ struct SrDeviceOps {
     // every window; all of it stays with the implementation. rows_on_host: rows whose cut-off fell inside a run of equal
     // distances (std::sort's order decides: resolved with std::sort itself)
     virtual int build_graphs(const SrWindowSet& ws, int64_t* rows_on_host, float* k_ms) = 0;
+    // the same in two halves, for an implementation that can leave the device working on the rows while the caller plans the
+    // Chinese-Whispers chain of the call (which needs the window plans only): begin queues, end resolves what the host has to resolve
+    virtual bool two_phase_graphs() const { return false; }
+    virtual int build_graphs_begin(const SrWindowSet& ws, float* k_ms) { (void)ws; (void)k_ms; return -1; }
+    virtual int build_graphs_end(const SrWindowSet& ws, int64_t* rows_on_host) { (void)ws; (void)rows_on_host; return -1; }
     // host copy of the CSR of the last build_graphs(): off[rows + 1] absolute, nbr local ids
     virtual int fetch_graphs(std::vector<int64_t>& off, std::vector<int32_t>& nbr) = 0;
     // labels = what the third run leaves (m per chain window). If the implementation also ran K8, final_labels holds the

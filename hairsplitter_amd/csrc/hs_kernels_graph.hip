@@ -54,8 +54,10 @@ __global__ __launch_bounds__(256) void k_read_graph_rows(
     const int32_t* __restrict__ sim, const int32_t* __restrict__ diff, const int64_t* __restrict__ ctg_out_off,
     const int32_t* __restrict__ ctg_n, const int32_t* __restrict__ win_contig, const int64_t* __restrict__ win_mask_off,
     const int32_t* __restrict__ mask_ids, const int32_t* __restrict__ row_win, const int64_t* __restrict__ win_bits_off,
-    int row_base, int n_rows, float below, int cap, unsigned long long* __restrict__ bits, int32_t* __restrict__ amb_count,
-    int32_t* __restrict__ amb_rows, int amb_cap, const int64_t* __restrict__ win_mat_off, int es /* element stride of sim / diff: 2 = (sim, diff) pairs */) {
+    int row_base, int n_rows, float below, int cap, unsigned long long* __restrict__ bits, unsigned long long* __restrict__ amb_head /* [0] rows left to the host, [1] staged entries */,
+    int32_t* __restrict__ amb_rows, int amb_cap, const int64_t* __restrict__ win_mat_off, int es /* element stride of sim / diff: 2 = (sim, diff) pairs */,
+    long long* __restrict__ amb_stage_off /* [amb_cap] where the row's entries were staged, -1: no room */, int32_t* __restrict__ stage_sim, int32_t* __restrict__ stage_diff,
+    long long stage_cap) {
     extern __shared__ unsigned char s_dyn[];
     const int lane = lane_id();
     const int wv = wave_id(), waves = (int)(blockDim.x >> 6);
@@ -71,12 +73,26 @@ __global__ __launch_bounds__(256) void k_read_graph_rows(
     const int N = ctg_n[c];
     const int32_t* __restrict__ ids = mask_ids + m0;
     const int r1 = ids[i];
-    auto give_up = [&]() {
-        if (lane == 0) { const int k = atomicAdd(amb_count, 1); if (k < amb_cap) amb_rows[k] = row; }
-    };
-    if (m > cap || N < 2 || !(below >= 0.f)) { give_up(); return; }
     const int32_t* __restrict__ srow = LM ? sim + (win_mat_off[w] + (int64_t)i * m) * es : sim + (ctg_out_off[c] + (int64_t)r1 * N) * es;
     const int32_t* __restrict__ drow = LM ? diff + (win_mat_off[w] + (int64_t)i * m) * es : diff + (ctg_out_off[c] + (int64_t)r1 * N) * es;
+    // a row the order statistics cannot decide goes to the host -- with its sim / diff entries (the N of the contig, or the m of a
+    // window-local matrix) staged here, so that the host needs ONE transfer to resolve every such row of the call
+    auto give_up = [&]() {
+        const int len = LM ? m : N;
+        long long so = -1;
+        if (lane == 0) {
+            const long long k = (long long)atomicAdd(&amb_head[0], 1ull);
+            if (k < amb_cap) {
+                amb_rows[k] = row;
+                if (stage_sim) { so = (long long)atomicAdd(&amb_head[1], (unsigned long long)len); if (so + len > stage_cap) so = -1; }
+                amb_stage_off[k] = so;
+            }
+        }
+        so = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(so & 0xffffffffll), 0)) |
+                         ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)so >> 32), 0) << 32));
+        if (so >= 0) for (int j = lane; j < len; j += 64) { stage_sim[so + j] = srow[(int64_t)j * es]; stage_diff[so + j] = drow[(int64_t)j * es]; }
+    };
+    if (m > cap || N < 2 || !(below >= 0.f)) { give_up(); return; }
 
     // distances of the masked reads (:752-759 / :611-624); every other read of the contig has distance 0
     int max_compat = 0;
