@@ -351,23 +351,50 @@ def main():
     PROBE_STEPS = 3
     # (not under a profiler: rocprofv3's per-kernel averages of this command stay those of the timed configuration)
     profiled = any(os.environ.get(k) for k in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD")) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-    if G > 1 and not use_dist and not fused and not profiled and not os.environ.get("HS_BENCH_NO_PROBE"):
+
+    def any_step(pl):
+        pet()
+        if fused:
+            cv1, sr1 = pl.run_fused(0.33, n_threads, rarest_strain_abundance=0.01, window_size=window_size)
+        else:
+            cv1, sr1 = pl.run(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=window_size)
+        cv1 = sr1 = None
+
+    if G > 1 and not use_dist and not profiled and not os.environ.get("HS_BENCH_NO_PROBE"):
+        probe = None
         try:
             probe = batch.sibling(1)
-            def probe_step():
-                pet()
-                cv1, sr1 = probe.run(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=window_size)
-                cv1 = sr1 = None
-            probe_step(); sync()
+            any_step(probe); any_step(probe); sync()      # (its first pass sizes its arrays the careful way)
             api.kernel_stats_reset()
             for _ in range(PROBE_STEPS):
-                probe_step()
+                any_step(probe)
             sync()
             kstats_alone = api.kernel_stats()
-            api.load().hs_pipeline_destroy(probe.handle); probe.handle = None
         except Exception as e:      # (a diagnostic leg: the line goes out without it)
             kstats_alone = None
             sys.stderr.write("one-group probe failed: %r\n" % (e,))
+        finally:
+            if probe is not None:
+                probe.close()      # (a sibling leaves the batch alone)
+    # After the timed region too: the same steps with .col's payload (the entries of every SNP column) brought to the host inside
+    # the call -- the timed steps hand stage 3 -> 4 over on the device and return the SNPs' positions, alleles and counts only
+    ms_with_col = None
+    if not use_dist and not profiled and not os.environ.get("HS_BENCH_NO_PROBE"):
+        try:
+            batch.keep_columns(True)
+            any_step(batch); any_step(batch); sync()
+            tc0 = time.perf_counter()
+            for _ in range(5):
+                any_step(batch)
+            sync()
+            ms_with_col = (time.perf_counter() - tc0) / 5 * 1e3
+        except Exception as e:
+            sys.stderr.write("column-download leg failed: %r\n" % (e,))
+        finally:
+            try:
+                batch.keep_columns(False)
+            except Exception:
+                pass
     throttled = None if thr0 is None or thr1 is None else {"periods": thr1[0] - thr0[0], "usec": thr1[1] - thr0[1]}
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -387,15 +414,22 @@ def main():
                         "achieved_GBs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else 0.0} for k, v in kstats.items()}
         if not per_step:       # HS_NO_KERNEL_STATS=1 (diagnostic): no roofline leg
             per_step = {"none": {"ms_per_step": 0.0, "launches_per_step": 0.0, "avg_launch_ms": 0.0, "algorithmic_bytes_per_launch": 0.0, "achieved_GBs": 0.0}}
-        dom = max(per_step, key=lambda k: per_step[k]["ms_per_step"])
-        d = per_step[dom]
+        # the dominant kernel = the one with the largest time per step when every kernel runs ALONE on the GPU (the one-group leg after the
+        # timed region); in the timed region the contig groups' kernels share the GPU and a launch lasts longer for reasons that are not its own
+        alone_ms = {k: v["ms"] / PROBE_STEPS for k, v in (kstats_alone or {}).items() if k not in ("k_ship", "other")}
+        timed_ms = {k: v["ms_per_step"] for k, v in per_step.items() if k not in ("k_ship", "other")}
+        dom = max(alone_ms, key=alone_ms.get) if alone_ms else max(timed_ms or {"none": 0.0}, key=(timed_ms or {"none": 0.0}).get)
+        d = per_step.get(dom, {"ms_per_step": 0.0, "launches_per_step": 0.0, "avg_launch_ms": 0.0, "algorithmic_bytes_per_launch": 0.0, "achieved_GBs": 0.0})
         traffic = None
+        traffic_src = None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
                 if tj.get("_config") == cfg and tj.get("_contigs") == n_job and world == 1:
-                    traffic = tj.get(dom)      # HBM bytes per launch from the PMC passes at THIS size (tools/pmc.sh)
+                    traffic = tj.get(dom)      # HBM bytes per launch from the PMC passes at THIS size (tools/pmc_traffic.sh)
+                    traffic_src = {"file": "profiles/traffic_latest.json", "measured_at_commit": tj.get("_commit"), "groups": tj.get("_groups"),
+                                   "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command (tools/pmc_traffic.sh), stored, not measured in this run"}
             except Exception:
                 traffic = None
         # ---- whole path by SURVEY.md 8(d)'s formula with the counts the run itself emitted ----
@@ -414,14 +448,12 @@ def main():
             a = kstats_alone[dom]
             a_gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9
             alone = {"groups": 1, "steps": PROBE_STEPS, "launches_per_step": a["launches"] / PROBE_STEPS, "avg_launch_ms": a["ms"] / max(1, a["launches"]),
-                     "ms_per_step": a["ms"] / PROBE_STEPS, "achieved": a_gbs, "frac": a_gbs / HBM_PEAK_GBS,
-                     "kernels_ms_per_step": {k: round(v["ms"] / PROBE_STEPS, 4) for k, v in sorted(kstats_alone.items(), key=lambda kv: -kv[1]["ms"])[:12]},
-                     "note": "the same kernel, same job, ONE contig group: no other kernel of the path shares the GPU with a launch. Measured after the timed "
-                             "region (HIP events, %d steps); `frac` above is the per-launch average of the timed region, where %d groups overlap" % (PROBE_STEPS, G)}
+                     "ms_per_step": a["ms"] / PROBE_STEPS, "algorithmic_bytes_per_launch": a["bytes"] / max(1, a["launches"]), "achieved": a_gbs, "frac": a_gbs / HBM_PEAK_GBS,
+                     "kernels_ms_per_step": {k: round(v["ms"] / PROBE_STEPS, 4) for k, v in sorted(kstats_alone.items(), key=lambda kv: -kv[1]["ms"])[:14]}}
         out = {
             "metric": "aligned read-bp/sec through call_variants+separate_reads",
             "value": total_bp * K / dt, "unit": "aligned read-bp/s", "n_gpus": 1 if emulated else world, "steps": K, "warmup": args.warmup, "setup_steps": SETUP_STEPS,
-            "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+            "ms_per_step": dt / K * 1e3, "ms_per_step_with_col_download": ms_with_col, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "host": {"cpus_online": os.cpu_count(), "cpus_effective": effective_cores(), "process_cpu_ms_per_step": cpu_ms_per_step,
                      "cfs_throttled_during_timed_steps": throttled, "input_generation_s": t_gen, "waits_per_step": waits_per_step,
@@ -436,12 +468,26 @@ def main():
                        "parallelism": f"contigs sharded over {world} GPU(s) by LPT on contig length", "groups_per_gpu": G,
                        **({"emulated_rank_of": emulated, "cores_pinned": args.cores or None,
                            "note": "ONE rank of an %d-rank job on one GPU (its LPT shard, its threads and groups): a readiness check, not a scaling measurement" % emulated} if emulated else {}),
-                       "host_threads_per_rank": n_threads, "pipeline": "hs_pipeline_run_fused" if fused else "hs_pipeline_select + hs_pipeline_run"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": d["achieved_GBs"] / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": d["avg_launch_ms"],
-                         "launches_per_step": d["launches_per_step"], "ms_per_step": d["ms_per_step"],
-                         "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
-                         "selection": "the kernel with the largest summed launch time per step among all kernels of the path (one slot per kernel, HIP events on each launch stream)",
+                       "host_threads_per_rank": n_threads, "pipeline": "hs_pipeline_run_fused" if fused else "hs_pipeline_select + hs_pipeline_run",
+                       "outputs": "per step, on the host: for every clustering window its reads and their partition labels (hs_sr_result: window bounds + one int32 per read "
+                                  "and window, -2 = read not in the window; the GROUP lines of the .gro), per contig the mean distance (error_rate.txt) and the SNPs' positions, "
+                                  "alleles and read counts. NOT in the timed steps: the per-read entries of the SNP columns (.col's payload) -- stage 3 hands them to stage 4 on "
+                                  "the device; `ms_per_step_with_col_download` is the same step with them brought to the host as well"},
+            "roofline": {"bound": "hbm", "kernel": dom,
+                         # the kernel on its own (one contig group, nothing else on the GPU): what the kernel itself achieves
+                         "achieved": alone["achieved"] if alone else d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (alone["achieved"] if alone else d["achieved_GBs"]) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_launch_ms": alone["avg_launch_ms"] if alone else d["avg_launch_ms"],
+                         "launches_per_step": alone["launches_per_step"] if alone else d["launches_per_step"],
+                         "algorithmic_bytes_per_launch": alone["algorithmic_bytes_per_launch"] if alone else d["algorithmic_bytes_per_launch"],
+                         "measured": ("HIP events on the launch stream, %d steps of the same resident job through a ONE-group pipeline right after the timed region: every kernel "
+                                      "alone on the GPU (reproducible from profiles/*_groups1.csv)" % PROBE_STEPS) if alone else "HIP events on the launch streams over the timed region",
+                         "selection": "the kernel with the largest time per step when it runs alone (all kernels of the path compete; transfers excluded)",
+                         # the same kernel inside the timed region, where the contig groups' kernels share the GPU
+                         "timed_region": {"achieved": d["achieved_GBs"], "frac": d["achieved_GBs"] / HBM_PEAK_GBS, "avg_launch_ms": d["avg_launch_ms"],
+                                          "launches_per_step": d["launches_per_step"], "ms_per_step": d["ms_per_step"],
+                                          "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                                          "note": "HIP events on each launch stream over the K timed steps; %d contig groups overlap, a launch shares the GPU with the other groups' kernels" % G},
                          "alone": alone,
                          "whole_path": whole},
             "kernels": {k: {kk: (round(vv, 6) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]["ms_per_step"])},

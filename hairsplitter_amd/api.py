@@ -22,7 +22,7 @@ SYMBOLS = [
     "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_partition_pair_distance", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_pipeline_thread_devices", "hs_cv_batch_device", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
-    "hs_pipeline_run_fused", "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_host_wait_stats", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
+    "hs_pipeline_run_fused", "hs_pipeline_set_option", "hs_pipeline_groups", "hs_pipeline_group_range", "hs_pipeline_group_cv", "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_host_wait_stats", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
 ]
 
 HS_NKERNELS = 27
@@ -91,6 +91,7 @@ def load() -> C.CDLL:
     lib.hs_cv_result_destroy.argtypes = [C.c_void_p]
     lib.hs_cv_result_destroy.restype = None
     lib.hs_pipeline_destroy.argtypes = [C.c_void_p]
+    lib.hs_pipeline_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
     lib.hs_pipeline_destroy.restype = None
     lib.hs_cv_selection_destroy.argtypes = [C.c_void_p]
     lib.hs_cv_selection_destroy.restype = None
@@ -379,6 +380,11 @@ class PipelineGroups:
         _check(load().hs_pipeline_create(self.batch.handle, C.c_int32(n_groups), C.byref(self.handle)))
         self.aligned_bp = self.flat.aligned_bp
         self.total_len = int(self.flat.contig_off[-1])
+        self._owns_batch = True
+
+    def keep_columns(self, on=True):
+        """HS_PIPELINE_KEEP_COLUMNS: the entries of the SNP columns (.col's payload) are brought to the host inside every call too"""
+        _check(load().hs_pipeline_set_option(self.handle, C.c_int32(1), C.c_int64(1 if on else 0)))
 
     def sibling(self, n_groups):
         """Another pipeline over the SAME resident batch with its own number of contig groups (bench.py: one group, where every
@@ -386,6 +392,7 @@ class PipelineGroups:
         o = object.__new__(PipelineGroups)
         o.flat, o.batch, o.aligned_bp, o.total_len = self.flat, self.batch, self.aligned_bp, self.total_len
         o.handle = C.c_void_p()
+        o._owns_batch = False      # (the batch belongs to the pipeline it was made from: close() of the sibling leaves it alone)
         _check(load().hs_pipeline_create(self.batch.handle, C.c_int32(n_groups), C.byref(o.handle)))
         return o
 
@@ -465,7 +472,8 @@ class PipelineGroups:
         if self.handle:
             load().hs_pipeline_destroy(self.handle)
             self.handle = None
-        self.batch.close()
+        if getattr(self, "_owns_batch", True):
+            self.batch.close()
 
 
 class _SrResultOwner:

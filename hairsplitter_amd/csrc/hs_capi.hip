@@ -2919,6 +2919,7 @@ struct hs_pipeline {
     std::vector<std::unique_ptr<HipCvOps::Keep>> cv_keep;      // per group: the sizes of its column pass (the next step queues it without asking)
     std::vector<HipSrOps::Keep> sr_dev_keep;
     HipCvOps::K2Order k2_order;
+    bool keep_columns = false;      // HS_PIPELINE_KEEP_COLUMNS
 
     int device = 0;        // = batch->device: the group threads bind themselves to it (a new thread starts on device 0)
     std::vector<int> thread_device;   // what every group thread found current after binding (hs_pipeline_thread_devices)
@@ -3014,6 +3015,18 @@ int hs_pipeline_create(hs_cv_batch* b, int32_t n_groups, hs_pipeline** out) {
 }
 
 int hs_cv_batch_device(const hs_cv_batch* b) { return b ? b->device : -1; }
+int hs_pipeline_set_option(hs_pipeline* p, int32_t option, int64_t value) {
+    if (!p) { set_error("hs_pipeline_set_option: null pipeline"); return HS_EINVAL; }
+    if (option == HS_PIPELINE_KEEP_COLUMNS) { p->keep_columns = value != 0; return HS_OK; }
+    set_error("hs_pipeline_set_option: unknown option"); return HS_EINVAL;
+}
+int hs_pipeline_groups(const hs_pipeline* p) { return p ? (int)p->ranges.size() : 0; }
+int hs_pipeline_group_range(const hs_pipeline* p, int32_t g, int32_t* c0, int32_t* c1) {
+    if (!p || g < 0 || g >= (int32_t)p->ranges.size()) { set_error("hs_pipeline_group_range: no such group"); return HS_EINVAL; }
+    if (c0) *c0 = p->ranges[(size_t)g].first; if (c1) *c1 = p->ranges[(size_t)g].second;
+    return HS_OK;
+}
+const hs_cv_result* hs_pipeline_group_cv(const hs_pipeline* p, int32_t g) { return (p && g >= 0 && g < (int32_t)p->cv.size()) ? p->cv[(size_t)g] : nullptr; }
 // the device every contig-group thread is bound to (-1: not bound yet / failed); returns the number of groups
 int hs_pipeline_thread_devices(hs_pipeline* p, int32_t* out, int32_t cap) {
     if (!p) return 0;
@@ -3141,7 +3154,8 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
         cv_ops.keep = p->cv_keep[(size_t)g].get(); cv_ops.k2_order = &p->k2_order; cv_ops.order_ticket = g;
         // the SNP columns stay on the device: stage 4 takes them over where stage 3 packed them (HS_COLUMNS_VIA_HOST=1: down and up again)
         static const bool via_host = std::getenv("HS_COLUMNS_VIA_HOST") != nullptr;
-        if (int r = hs::cv_run_range(cv_ops, meta, ((const hs::CvSelection*)p->sel->impl)->rec_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host)) return r;
+        if (p->cv[(size_t)g]) { hs::free_cv_result(p->cv[(size_t)g]); p->cv[(size_t)g] = nullptr; }
+        if (int r = hs::cv_run_range(cv_ops, meta, ((const hs::CvSelection*)p->sel->impl)->rec_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host && !p->keep_columns)) return r;
         HipSrOps ops;
         ops.keep = &p->sr_dev_keep[(size_t)g];
         if (!via_host) ops.adopt_columns(cv_ops);
@@ -3162,8 +3176,7 @@ int hs_pipeline_run(hs_pipeline* p, float automatic_snp_threshold, float error_r
     }
     if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] host waits so far: %ld, %.1f ms in them\n", g_waits.load(), g_wait_us.load() / 1e3);
     hs_sr_result* R = concat_sr_parts(p, parts, sparse, st);
-    p->drop_cv();
-    *out = R;
+    *out = R;      // (the groups' stage-3 results stay until the next call: hs_pipeline_group_cv)
     return HS_OK;
 }
 
@@ -3247,13 +3260,13 @@ int hs_pipeline_run_fused(hs_pipeline* p, float automatic_snp_threshold, float r
                 md_g[(size_t)(c - c0)] = hs::mean_distance_from_counts(nerr, nlen);
             }
             arrive(md_g.data());
-            if (int r = hs::cv_run_range(cv_ops, meta, sel->rec_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host)) return fail(r);
+            if (int r = hs::cv_run_range(cv_ops, meta, sel->rec_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host && !p->keep_columns)) return fail(r);
         } else {
             // the group's share of the pileup is the head of its column pass on the device (K0, K1, the contigs' distances, K2 ...): one chain,
             // queued behind the previous group's, no host wait before the candidates
             cv_ops.own_pileup = true;
             const std::function<void(const float*)> on_md = arrive;
-            if (int r = hs::cv_run_range(cv_ops, meta, no_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host, &on_md)) return fail(r);
+            if (int r = hs::cv_run_range(cv_ops, meta, no_stats, c0, c1, automatic_snp_threshold, per, &p->cv[(size_t)g], !via_host && !p->keep_columns, &on_md)) return fail(r);
         }
         {
             std::unique_lock<std::mutex> lk(bm);
@@ -3285,7 +3298,6 @@ int hs_pipeline_run_fused(hs_pipeline* p, float automatic_snp_threshold, float r
         }
     }
     hs_sr_result* R = concat_sr_parts(p, parts, sparse, st);
-    p->drop_cv();
     *out = R;
     return HS_OK;
 }

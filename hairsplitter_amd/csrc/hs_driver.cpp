@@ -962,7 +962,10 @@ int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& b, int c0, int c1, const hs_c
     // be dropped below, the columns are needed here after all: fetched, and stage 4 uploads what is left
     std::vector<int32_t> fetched_idx; std::vector<uint8_t> fetched_code;
     const int32_t* cv_idx = cv->col_idx; const uint8_t* cv_code = cv->col_code;
-    const bool resident_in = cv->col_idx == nullptr && cv->snp_off[C] > 0 && cv->col_off[cv->snp_off[C]] > 0;
+    // (a device interface that holds the columns is used whether or not the result ALSO carries their entries: a caller that keeps
+    // .col's payload on the host still hands stage 3 -> 4 over on the device)
+    const bool have_snps = cv->snp_off[C] > 0 && cv->col_off[cv->snp_off[C]] > 0;
+    const bool resident_in = have_snps && (cv->col_idx == nullptr || dev.columns_resident());
     if (resident_in && !dev.columns_resident()) { set_error("sr_run_from_cv: the stage-3 result has no columns and the device has none either"); return HS_EINVAL; }
     if (resident_in) {
         bool all = true;

@@ -485,6 +485,16 @@ int hs_pipeline_run_fused(hs_pipeline* p, float automatic_snp_threshold, float r
 /* the HIP device each contig-group thread of the pipeline is bound to (== hs_cv_batch_device of its batch); returns the number
  * of groups, fills at most cap entries */
 int hs_pipeline_thread_devices(hs_pipeline* p, int32_t* out, int32_t cap);
+/* What a pipeline call leaves with the host besides the labels. Stage 3's SNP columns are handed to stage 4 on the device; with
+ * HS_PIPELINE_KEEP_COLUMNS != 0 their entries (.col's payload: read indices and codes of every SNP column, the SNPS lines of
+ * call_variants.cpp:1184-1204) are ALSO brought to the host inside the call, and the groups' stage-3 results stay available through
+ * hs_pipeline_group_cv until the next call on the pipeline (they are dropped when it starts). Default 0: positions, alleles and
+ * counts of the SNPs only. */
+#define HS_PIPELINE_KEEP_COLUMNS 1
+int hs_pipeline_set_option(hs_pipeline* p, int32_t option, int64_t value);
+int hs_pipeline_groups(const hs_pipeline* p);                                  /* number of contig groups */
+int hs_pipeline_group_range(const hs_pipeline* p, int32_t g, int32_t* c0, int32_t* c1);   /* contigs [c0, c1) of group g */
+const hs_cv_result* hs_pipeline_group_cv(const hs_pipeline* p, int32_t g);    /* stage-3 result of group g from the last call (NULL before the first) */
 void hs_pipeline_destroy(hs_pipeline* p);
 
 int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_t amplicon);
