@@ -275,6 +275,9 @@ struct ColFileContig {
     std::vector<uint8_t> col_code;
 };
 int parse_col(const std::string& path, float rarest_strain_abundance, std::vector<ColFileContig>& cs, int n_threads = 1);
+// the binary companion HS_call_variants leaves next to the .col (<col>.hsbin, hs_io.cpp): 1 = cs filled from it (it matched the .col
+// block by block), 0 = no usable companion, parse the text
+int read_col_sidecar(const std::string& col_path, float rarest_strain_abundance, std::vector<ColFileContig>& cs, int n_threads = 1);
 
 // writers shared by the executables and the test harness
 int write_cv_outputs(const CvFileInput& in, const hs_cv_result* res, const std::string& error_rate_out,

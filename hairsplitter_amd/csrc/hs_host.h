@@ -130,6 +130,18 @@ struct CvFileInput {
 };
 int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::string& sam, bool amplicon,
                    CvFileInput& in, int n_threads = 1);
+// every read and every contig of a job, coded 0..3, with their names (the PAF ingest aligns read segments against contig windows)
+struct SeqSet {
+    std::vector<std::string> read_names, contig_names;
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> read_seq, contig_seq;
+    std::vector<int64_t> read_off, contig_off;
+};
+int load_sequences(const std::string& gfa, const std::string& reads, SeqSet& out, int n_threads = 1);
+// CIGAR-less input (hs_realign.cpp): a PAF file becomes the SAM the path reads, every read segment aligned against its contig window
+// on the device with edlib's HW path (A1)
+struct RealignStats { int64_t n_lines = 0, n_aligned = 0, query_bases = 0; double ms_device = 0, ms_total = 0; };
+int realign_paf_to_sam(const std::string& gfa, const std::string& reads, const std::string& paf, const std::string& out_sam, int n_threads, RealignStats* stats = nullptr);
+int host_threads();
 // the .gro consumer of the next stage (hs_gaf.cpp)
 int gaf_from_files(const std::string& gfa, const std::string& reads, const std::string& sam, const std::string& gro, bool amplicon,
                    const std::string& out_gaf, int n_threads);

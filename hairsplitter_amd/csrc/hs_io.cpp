@@ -217,6 +217,73 @@ SamLineResult parse_sam_line(const Line& l, size_t line_no, long n_reads, long n
 }
 }  // namespace
 
+// every read (FASTA / FASTQ, records as input_output.cpp:39-109 cuts them) and every contig (S lines) of a job, coded
+int load_sequences(const std::string& gfa, const std::string& reads, SeqSet& out, int n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    FileView rtxt;
+    if (!rtxt.open(reads)) { std::cout << "problem reading files in index_reads, while trying to read " << reads << std::endl; set_error("Input file could not be read: " + reads); return HS_EIO; }
+    char format = '@';
+    if ((reads.size() > 6 && reads.substr(reads.size() - 6, 6) == ".fasta") || (reads.size() >= 3 && reads.substr(reads.size() - 3, 3) == ".fa")) format = '>';
+    std::vector<Line> rl = split_lines(rtxt.p, rtxt.n, n_threads);
+    std::vector<Line> seq_of_read;
+    {
+        std::vector<size_t> buffer;
+        char lastlinestart = '+';
+        auto flush = [&]() {
+            const Line& h = rl[buffer[0]];
+            out.read_names.emplace_back(first_token(h.p + (h.n ? 1 : 0), h.n ? h.n - 1 : 0));
+            seq_of_read.push_back(rl[buffer[1]]);
+        };
+        for (size_t li = 0; li < rl.size(); ++li) {
+            const Line& l = rl[li];
+            const char first = l.n ? l.p[0] : '\0';
+            if (first == format && buffer.size() >= 2 && (((lastlinestart != '+' || buffer.size() == 4) && format == '@') || format == '>')) { flush(); buffer.clear(); buffer.push_back(li); }
+            else buffer.push_back(li);
+            if (l.n > 0) lastlinestart = l.p[0];
+        }
+        if (buffer.size() >= 2) flush();
+    }
+    const long n_reads = (long)out.read_names.size();
+    out.read_off.assign((size_t)n_reads + 1, 0);
+    for (long i = 0; i < n_reads; ++i) out.read_off[(size_t)i + 1] = out.read_off[(size_t)i] + (int64_t)seq_of_read[(size_t)i].n;
+    out.read_seq.resize((size_t)out.read_off.back());
+    {
+        const int RB = (int)std::max<long>(1, std::min<long>((long)n_threads * 8, std::max<long>(n_reads, 1)));
+        hs_parallel_for(RB, n_threads, [&](int bi) {
+            const long i0 = n_reads * bi / RB, i1 = n_reads * (bi + 1) / RB;
+            for (long i = i0; i < i1; ++i) {
+                const Line& s = seq_of_read[(size_t)i];
+                uint8_t* o = out.read_seq.data() + out.read_off[(size_t)i];
+                for (size_t k = 0; k < s.n; ++k) o[k] = g_lut.t[(unsigned char)s.p[k]];
+            }
+        });
+    }
+    FileView gtxt;
+    if (!gtxt.open(gfa)) { std::cout << "problem reading files in index_reads, while trying to read " << gfa << std::endl; set_error("Input file could not be read: " + gfa); return HS_EIO; }
+    out.contig_off.assign(1, 0);
+    std::vector<Line> seqs;
+    for (const Line& l : split_lines(gtxt.p, gtxt.n, n_threads)) {
+        if (!l.n || l.p[0] != 'S') continue;
+        size_t a = 0; int field = 0; std::string_view name;
+        while (a <= l.n) {
+            const char* tab = a < l.n ? (const char*)std::memchr(l.p + a, '\t', l.n - a) : nullptr;
+            const size_t b = tab ? (size_t)(tab - l.p) : l.n;
+            if (field == 1) name = first_token(l.p + a, b - a);
+            else if (field == 2) { seqs.push_back(Line{l.p + a, b - a}); out.contig_off.push_back(out.contig_off.back() + (int64_t)(b - a)); out.contig_names.emplace_back(name); }
+            field++;
+            if (b >= l.n) break;
+            a = b + 1;
+        }
+    }
+    out.contig_seq.resize((size_t)out.contig_off.back());
+    hs_parallel_for((int)seqs.size(), n_threads, [&](int c) {
+        uint8_t* o = out.contig_seq.data() + out.contig_off[(size_t)c];
+        const Line& s = seqs[(size_t)c];
+        for (size_t k = 0; k < s.n; ++k) o[k] = g_lut.t[(unsigned char)s.p[k]];
+    });
+    return HS_OK;
+}
+
 int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::string& sam, bool amplicon, CvFileInput& in, int n_threads) {
     if (n_threads < 1) n_threads = 1;
     const bool tim = std::getenv("HS_TIMING") != nullptr;
@@ -582,6 +649,7 @@ int parse_col(const std::string& path, float rsa, std::vector<ColFileContig>& cs
     return 0;
 }
 
+int write_col_sidecar(const CvFileInput& in, const hs_cv_result* res, const std::vector<std::string>& col_block, const std::string& col_path, int n_threads);
 int write_cv_outputs(const CvFileInput& in, const hs_cv_result* res, const std::string& error_rate_out, const std::string& col_path,
                      const std::string& vcf_path, int n_threads) {
     if (n_threads < 1) n_threads = 1;
@@ -624,13 +692,207 @@ int write_cv_outputs(const CvFileInput& in, const hs_cv_result* res, const std::
         out += '\n';
         vcf += '\n';
     });
-    std::ofstream out(col_path, std::ios::binary), vcf(vcf_path, std::ios::binary);
-    for (int c = 0; c < C; ++c) {
-        if (in.contig_skip[(size_t)c]) continue;
-        out.write(col_block[(size_t)c].data(), (std::streamsize)col_block[(size_t)c].size());
-        vcf.write(vcf_block[(size_t)c].data(), (std::streamsize)vcf_block[(size_t)c].size());
+    {
+        std::ofstream out(col_path, std::ios::binary), vcf(vcf_path, std::ios::binary);
+        for (int c = 0; c < C; ++c) {
+            if (in.contig_skip[(size_t)c]) continue;
+            out.write(col_block[(size_t)c].data(), (std::streamsize)col_block[(size_t)c].size());
+            vcf.write(vcf_block[(size_t)c].data(), (std::streamsize)vcf_block[(size_t)c].size());
+        }
     }
+    // the text file first (what --resume and every other reader go by), then its binary companion for HS_separate_reads
+    if (res->col_idx || res->col_off[res->snp_off[C]] == 0) write_col_sidecar(in, res, col_block, col_path, n_threads);
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// <out.col>.hsbin -- the binary side-channel between the two executables. The reference hands stage 3's result to
+// stage 4 as text (call_variants.cpp:1197-1204 writes, separate_reads.cpp:84-170 parses it back): 300 MB of decimal numbers for the
+// 500-contig job, and parsing them is most of what HS_separate_reads does before the GPU gets anything. The .col file stays what
+// it is (written first, complete, the file every other tool and --resume read); next to it HS_call_variants leaves the same
+// content as flat arrays -- per contig: where its block lies in the .col, a hash of that block, the READ limits, the SNPs with
+// their counts, the columns as CSR. HS_separate_reads takes the arrays only if the .col it was given still IS that file (size and
+// every block's hash), applies the rarest-strain filter of :151-167 from the counts, and points at the READ lines of the .col
+// itself for the .gro; anything else -- no companion, another size, one differing block -- and it parses the text as before.
+// HS_NO_SIDECAR=1: neither written nor read.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+constexpr uint64_t kSidecarMagic = 0x0001004e49425348ull;      // "HSBIN\0\1\0"
+constexpr uint64_t kSidecarVersion = 1;
+struct SidecarHeader { uint64_t magic, version, col_size, n_contigs, table_off, file_size, pad[2]; };
+struct SidecarEntry { uint64_t col_off, col_bytes, hash, header_len, n_reads, n_snps, n_entries, length, name_len, data_off, data_bytes, pad; };
+// 64-bit block hash: four interleaved multiply-xorshift lanes over 8-byte words (speed of memory; not cryptographic -- it guards
+// against a .col that was edited or replaced, not against an adversary)
+uint64_t block_hash(const char* p, size_t n) {
+    uint64_t h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32)
+        for (int k = 0; k < 4; ++k) { uint64_t w; std::memcpy(&w, p + i + 8 * k, 8); h[k] = (h[k] ^ w) * 0x9FB21C651E98DF25ull; h[k] ^= h[k] >> 29; }
+    uint64_t tail = 0x2545F4914F6CDD1Dull;
+    for (; i < n; ++i) tail = (tail ^ (unsigned char)p[i]) * 0x100000001B3ull;
+    uint64_t r = (uint64_t)n * 0xD6E8FEB86659FD93ull;
+    for (int k = 0; k < 4; ++k) { r = (r ^ h[k]) * 0x9FB21C651E98DF25ull; r ^= r >> 32; }
+    return (r ^ tail) * 0x9E3779B97F4A7C15ull;
+}
+bool sidecar_off() { static const bool off = std::getenv("HS_NO_SIDECAR") != nullptr; return off; }
+template <class T> void put_arr(std::string& o, const T* p, size_t n) { o.append(reinterpret_cast<const char*>(p), n * sizeof(T)); while (o.size() & 7) o += '\0'; }
+}  // namespace
+
+int write_col_sidecar(const CvFileInput& in, const hs_cv_result* res, const std::vector<std::string>& col_block, const std::string& col_path, int n_threads) {
+    if (sidecar_off()) return 0;
+    const int C = (int)in.contig_names.size();
+    std::vector<int> order;
+    for (int c = 0; c < C; ++c) if (!in.contig_skip[(size_t)c]) order.push_back(c);
+    const size_t K = order.size();
+    std::vector<SidecarEntry> tab(K);
+    std::vector<std::string> data(K);
+    uint64_t off = 0;
+    for (size_t k = 0; k < K; ++k) { tab[k] = SidecarEntry(); tab[k].col_off = off; tab[k].col_bytes = col_block[(size_t)order[k]].size(); off += tab[k].col_bytes; }
+    const uint64_t col_size = off;
+    hs_parallel_for((int)K, n_threads, [&](int k) {
+        const int c = order[(size_t)k];
+        const std::string& blk = col_block[(size_t)c];
+        SidecarEntry& e = tab[(size_t)k];
+        e.hash = block_hash(blk.data(), blk.size());
+        const int r0 = in.contig_rec_off[(size_t)c], nr = in.contig_rec_off[(size_t)c + 1] - r0;
+        const int64_t s0 = res->snp_off[c], s1 = res->snp_off[c + 1], S = s1 - s0;
+        const int64_t e0 = res->col_off[s0], E = res->col_off[s1] - e0;
+        e.n_reads = (uint64_t)nr; e.n_snps = (uint64_t)S; e.n_entries = (uint64_t)E;
+        e.length = (uint64_t)(in.contig_off[(size_t)c + 1] - in.contig_off[(size_t)c]);
+        e.name_len = 0;      // (what parse_column_file takes for the name: the CONTIG line's second token)
+        while (e.name_len < in.contig_names[(size_t)c].size() && !std::isspace((unsigned char)in.contig_names[(size_t)c][(size_t)e.name_len])) e.name_len++;
+        // the lines of the block: CONTIG, then the READ lines (their offsets in the block), then SNPS
+        std::vector<int32_t> line_off((size_t)nr + 1);
+        size_t pos = blk.find('\n');
+        e.header_len = pos == std::string::npos ? blk.size() : pos;
+        pos = pos == std::string::npos ? blk.size() : pos + 1;
+        for (int r = 0; r < nr; ++r) { line_off[(size_t)r] = (int32_t)pos; const size_t nl = blk.find('\n', pos); pos = nl == std::string::npos ? blk.size() : nl + 1; }
+        line_off[(size_t)nr] = (int32_t)pos;
+        std::vector<int32_t> n_ref((size_t)S), n_alt((size_t)S);
+        std::vector<int64_t> coff((size_t)S + 1);
+        for (int64_t q = 0; q < S; ++q) {      // what parse_column_file recounts (separate_reads.cpp:151-167)
+            int a = 0, b2 = 0;
+            const uint8_t rb = res->snp_ref[s0 + q], sb = res->snp_alt[s0 + q];
+            for (int64_t x = res->col_off[s0 + q]; x < res->col_off[s0 + q + 1]; ++x) { if (res->col_code[x] == rb) a++; else if (res->col_code[x] == sb) b2++; }
+            n_ref[(size_t)q] = a; n_alt[(size_t)q] = b2; coff[(size_t)q] = res->col_off[s0 + q] - e0;
+        }
+        coff[(size_t)S] = E;
+        std::string& o = data[(size_t)k];
+        o.reserve((size_t)nr * 12 + (size_t)S * 30 + (size_t)E * 5 + 256);
+        put_arr(o, line_off.data(), line_off.size());
+        put_arr(o, in.rec_c0.data() + r0, (size_t)nr);
+        put_arr(o, in.rec_c1.data() + r0, (size_t)nr);
+        put_arr(o, res->snp_pos + s0, (size_t)S);
+        put_arr(o, n_ref.data(), (size_t)S);
+        put_arr(o, n_alt.data(), (size_t)S);
+        put_arr(o, coff.data(), coff.size());
+        put_arr(o, res->col_idx ? res->col_idx + e0 : nullptr, (size_t)E);
+        put_arr(o, res->snp_ref + s0, (size_t)S);
+        put_arr(o, res->snp_alt + s0, (size_t)S);
+        put_arr(o, res->col_code ? res->col_code + e0 : nullptr, (size_t)E);
+        put_arr(o, in.contig_names[(size_t)c].data(), (size_t)e.name_len);
+        e.data_bytes = o.size();
+    });
+    SidecarHeader h; std::memset(&h, 0, sizeof h);
+    h.magic = kSidecarMagic; h.version = kSidecarVersion; h.col_size = col_size; h.n_contigs = K; h.table_off = sizeof h;
+    uint64_t doff = sizeof h + K * sizeof(SidecarEntry);
+    for (size_t k = 0; k < K; ++k) { tab[k].data_off = doff; doff += tab[k].data_bytes; }
+    h.file_size = doff;
+    const std::string tmp = col_path + ".hsbin.tmp", fin = col_path + ".hsbin";
+    {
+        std::ofstream out(tmp, std::ios::binary);
+        if (!out) return 1;
+        out.write(reinterpret_cast<const char*>(&h), sizeof h);
+        out.write(reinterpret_cast<const char*>(tab.data()), (std::streamsize)(K * sizeof(SidecarEntry)));
+        for (size_t k = 0; k < K; ++k) out.write(data[k].data(), (std::streamsize)data[k].size());
+        if (!out) { std::remove(tmp.c_str()); return 1; }
+    }
+    if (std::rename(tmp.c_str(), fin.c_str()) != 0) { std::remove(tmp.c_str()); return 1; }      // (complete or absent, never half a file)
+    return 0;
+}
+
+// 1: the contigs were taken from the companion of `col_path` (cs filled as parse_col would have filled it); 0: no usable companion
+int read_col_sidecar(const std::string& col_path, float rsa, std::vector<ColFileContig>& cs, int n_threads) {
+    if (sidecar_off()) return 0;
+    FileView bin;
+    { struct stat st; if (::stat((col_path + ".hsbin").c_str(), &st) != 0) return 0; }
+    if (!bin.open(col_path + ".hsbin") || bin.n < sizeof(SidecarHeader)) return 0;
+    SidecarHeader h; std::memcpy(&h, bin.p, sizeof h);
+    if (h.magic != kSidecarMagic || h.version != kSidecarVersion || h.file_size != bin.n || h.table_off != sizeof h) return 0;
+    if (h.n_contigs > (bin.n - sizeof h) / sizeof(SidecarEntry)) return 0;
+    FileView txt;
+    if (!txt.open(col_path) || txt.n != h.col_size) return 0;
+    const size_t K = (size_t)h.n_contigs;
+    const SidecarEntry* tab = reinterpret_cast<const SidecarEntry*>(bin.p + h.table_off);
+    std::vector<char> bad(K, 0);
+    if (n_threads < 1) n_threads = 1;
+    // the .col must still be the file these arrays were written beside: every block in its place with its hash, the arrays inside the companion
+    hs_parallel_for((int)K, n_threads, [&](int k) {
+        const SidecarEntry& e = tab[k];
+        const uint64_t R = e.n_reads, S = e.n_snps, E = e.n_entries;
+        auto a8 = [](uint64_t x) { return (x + 7) & ~(uint64_t)7; };
+        const uint64_t need = a8((R + 1) * 4) + 2 * a8(R * 4) + 3 * a8(S * 4) + a8((S + 1) * 8) + a8(E * 4) + 2 * a8(S) + a8(E) + a8(e.name_len);
+        if (e.col_off > txt.n || e.col_bytes > txt.n - e.col_off || e.data_off > bin.n || e.data_bytes > bin.n - e.data_off || need != e.data_bytes || e.header_len > e.col_bytes
+            || R > 0x7fffffff || S > 0x7fffffff) { bad[(size_t)k] = 1; return; }
+        if (block_hash(txt.p + e.col_off, (size_t)e.col_bytes) != e.hash) bad[(size_t)k] = 1;
+    });
+    for (size_t k = 0; k < K; ++k) if (bad[k]) return 0;
+    cs.assign(K, ColFileContig());
+    hs_parallel_for((int)K, n_threads, [&](int k) {
+        const SidecarEntry& e = tab[k];
+        ColFileContig& cc = cs[(size_t)k];
+        const size_t R = (size_t)e.n_reads, S = (size_t)e.n_snps, E = (size_t)e.n_entries;
+        auto a8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+        const char* d = bin.p + e.data_off;
+        const int32_t* line_off = reinterpret_cast<const int32_t*>(d); d += a8((R + 1) * 4);
+        const int32_t* c0 = reinterpret_cast<const int32_t*>(d); d += a8(R * 4);
+        const int32_t* c1 = reinterpret_cast<const int32_t*>(d); d += a8(R * 4);
+        const int32_t* spos = reinterpret_cast<const int32_t*>(d); d += a8(S * 4);
+        const int32_t* n_ref = reinterpret_cast<const int32_t*>(d); d += a8(S * 4);
+        const int32_t* n_alt = reinterpret_cast<const int32_t*>(d); d += a8(S * 4);
+        const int64_t* coff = reinterpret_cast<const int64_t*>(d); d += a8((S + 1) * 8);
+        const int32_t* cidx = reinterpret_cast<const int32_t*>(d); d += a8(E * 4);
+        const uint8_t* sref = reinterpret_cast<const uint8_t*>(d); d += a8(S);
+        const uint8_t* salt = reinterpret_cast<const uint8_t*>(d); d += a8(S);
+        const uint8_t* ccode = reinterpret_cast<const uint8_t*>(d); d += a8(E);
+        const char* blk = txt.p + e.col_off;
+        cc.contig_line.assign(blk, (size_t)e.header_len);
+        cc.name.assign(d, (size_t)e.name_len);
+        cc.length = (long)e.length;
+        cc.read_lines.resize(R);
+        bool ok = true;
+        for (size_t r = 0; r < R && ok; ++r) {
+            const int64_t a = line_off[r], b2 = line_off[r + 1];
+            if (a < 0 || b2 <= a || (uint64_t)b2 > e.col_bytes) { ok = false; break; }
+            cc.read_lines[r].assign(blk + a, (size_t)(b2 - a - 1));      // (without the newline)
+        }
+        if (!ok) { bad[(size_t)k] = 1; return; }
+        cc.read_start.assign(c0, c0 + R); cc.read_end.assign(c1, c1 + R);
+        // parse_column_file keeps a SNP iff its second allele is frequent enough among the reads that carry one of the two (:151-167)
+        cc.col_off.assign(1, 0);
+        bool all = true;
+        for (size_t q = 0; q < S && all; ++q) if (!((float)n_alt[q] >= rsa * (float)(n_ref[q] + n_alt[q]))) all = false;
+        if (coff[0] != 0 || (uint64_t)coff[S] != E) { bad[(size_t)k] = 1; return; }
+        if (all) {
+            cc.snp_pos.assign(spos, spos + S); cc.snp_ref.assign(sref, sref + S); cc.snp_alt.assign(salt, salt + S);
+            cc.col_off.assign(coff, coff + S + 1); cc.col_idx.assign(cidx, cidx + E); cc.col_code.assign(ccode, ccode + E);
+        } else {
+            for (size_t q = 0; q < S; ++q) {
+                if (!((float)n_alt[q] >= rsa * (float)(n_ref[q] + n_alt[q]))) continue;
+                if (coff[q] < 0 || coff[q + 1] < coff[q] || (uint64_t)coff[q + 1] > E) { bad[(size_t)k] = 1; return; }
+                cc.snp_pos.push_back(spos[q]); cc.snp_ref.push_back(sref[q]); cc.snp_alt.push_back(salt[q]);
+                cc.col_idx.insert(cc.col_idx.end(), cidx + coff[q], cidx + coff[q + 1]);
+                cc.col_code.insert(cc.col_code.end(), ccode + coff[q], ccode + coff[q + 1]);
+                cc.col_off.push_back((int64_t)cc.col_idx.size());
+            }
+        }
+        for (size_t q = 0; q + 1 < cc.col_off.size(); ++q) if (cc.col_off[q + 1] < cc.col_off[q]) { bad[(size_t)k] = 1; return; }
+        const int32_t nr = (int32_t)R;
+        for (int32_t v : cc.col_idx) if (v < 0 || v >= nr) { bad[(size_t)k] = 1; return; }
+    });
+    for (size_t k = 0; k < K; ++k) if (bad[k]) { cs.clear(); return 0; }
+    if (std::getenv("HS_SIDECAR_REPORT")) std::fprintf(stderr, "[hs] %s: %zu contigs from the binary companion\n", col_path.c_str(), K);
+    return 1;
 }
 
 int write_gro(const std::vector<ColFileContig>& cs, const hs_sr_result* res, const std::string& path, int n_threads) {

@@ -67,11 +67,28 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
     StageClock clk;
     { std::ofstream o(file_out); }   // truncate (call_variants.cpp:1239-1240)
     clk.lap("truncate the output");
+    std::string realigned_sam;
     if (has_suffix(sam_file, ".paf")) {
-        std::cout << "ERROR: please provide a .sam file as input for the alignments of the reads on the contigs." << std::endl;
-        return EXIT_FAILURE;
+        // the reference refuses a .paf (call_variants.cpp:1256-1259) and so does this executable -- unless HS_REALIGN=1 asks for the
+        // read segments to be aligned against their contig windows on the device (hs_realign.cpp): the SAM it makes is read instead
+        const char* e = std::getenv("HS_REALIGN");
+        if (!(e && e[0] == '1')) {
+            std::cout << "ERROR: please provide a .sam file as input for the alignments of the reads on the contigs." << std::endl;
+            return EXIT_FAILURE;
+        }
+        realigned_sam = std::string(argv[5]) + "/hs_realigned.sam";
+        std::cout << " - Aligning the read segments of " << sam_file << " against their contig windows on the device\n";
+        hs::RealignStats rs;
+        if (int rc = hs::realign_paf_to_sam(gfafile, reads_file, sam_file, realigned_sam, num_threads, &rs)) {
+            std::cout << "ERROR: " << hs_last_error() << " (" << rc << ")" << std::endl;
+            return EXIT_FAILURE;
+        }
+        if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] realign: %ld of %ld PAF lines aligned, %.1f M read bases, device %.1f ms, total %.1f ms\n", (long)rs.n_aligned,
+                                                   (long)rs.n_lines, rs.query_bases / 1e6, rs.ms_device, rs.ms_total);
+        clk.lap("realign the PAF records");
     }
-    if (!has_suffix(sam_file, ".sam")) {
+    const std::string& aln_file = realigned_sam.empty() ? sam_file : realigned_sam;
+    if (!has_suffix(aln_file, ".sam")) {
         std::cout << "ERROR: the file containing the alignments on the assembly should be .sam" << std::endl;
         return EXIT_FAILURE;
     }
@@ -82,7 +99,7 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
     hs::CvFileInput* in_p = new hs::CvFileInput();
     struct InGuard { hs::CvFileInput* p; ~InGuard() { if (!g_leak_at_exit) delete p; } } in_guard{in_p};
     hs::CvFileInput& in = *in_p;
-    const int load_rc = hs::load_cv_inputs(gfafile, reads_file, sam_file, amplicon_i != 0, in, num_threads);
+    const int load_rc = hs::load_cv_inputs(gfafile, reads_file, aln_file, amplicon_i != 0, in, num_threads);
     clk.lap("load gfa + reads + sam");
     warm.join();
     clk.lap("wait for the device");
@@ -135,8 +152,10 @@ extern "C" int hs_separate_reads_main(int argc, char** argv) {
     std::vector<hs::ColFileContig>* cs_p = new std::vector<hs::ColFileContig>();
     struct CsGuard { std::vector<hs::ColFileContig>* p; ~CsGuard() { if (!g_leak_at_exit) delete p; } } cs_guard{cs_p};
     std::vector<hs::ColFileContig>& cs = *cs_p;
-    const int parse_rc = hs::parse_col(columns_file, rsa, cs, num_threads);
-    clk.lap("parse .col");
+    // the arrays HS_call_variants left beside the .col, if this .col still is the file they describe; else the text
+    const bool from_sidecar = hs::read_col_sidecar(columns_file, rsa, cs, num_threads) == 1;
+    const int parse_rc = from_sidecar ? 0 : hs::parse_col(columns_file, rsa, cs, num_threads);
+    clk.lap(from_sidecar ? "read .col.hsbin" : "parse .col");
     warm.join();
     clk.lap("wait for the device");
     if (n_devices <= 0) {

@@ -291,6 +291,16 @@ int hs_edlib_hw_align(const uint8_t* d_query, const int64_t* h_query_off, const 
                       int32_t n_pairs, int32_t* d_dist, int32_t* d_start, int32_t* d_end, uint8_t* d_ops, const int64_t* h_ops_off,
                       int32_t* d_ops_len, void* stream);
 
+/* A1 on the path: a CIGAR-less input. The reference reads the base-level alignments from the CIGARs of a SAM file and
+ * refuses a .paf (call_variants.cpp:1256-1267; CIGAR required at input_output.cpp:357-368). hs_realign_paf turns a PAF file (read
+ * interval, strand, contig interval per line) into that SAM: every read segment is aligned against its contig window (the PAF
+ * interval + HS_REALIGN_PAD = 100 bases on both sides) on the device exactly as edlibAlign(segment, window, k = -1, EDLIB_MODE_HW,
+ * EDLIB_TASK_PATH) of the reference's bundled edlib aligns it; POS = window start + start location + 1, CIGAR = clips (S) + the
+ * path as M / I / D runs, NM:i: = the edit distance, LN:i: = the read length. HS_call_variants takes a .paf this way when
+ * HS_REALIGN=1 is set (the SAM goes to <tmpDir>/hs_realigned.sam); without it the reference's refusal stands. */
+typedef struct hs_realign_stats { int64_t n_lines, n_aligned, query_bases; double ms_device, ms_total; } hs_realign_stats;
+int hs_realign_paf(const char* gfa, const char* reads, const char* paf, const char* out_sam, int32_t n_threads, hs_realign_stats* stats /* may be NULL */);
+
 /* The two stage-5 computations that sit on those edlib calls, batched (two alignments per item in ONE hs_edlib_hw_align call):
  * hs_reattach_ends == tools.cpp:505-536 (the ends of the backbone that racon dropped are attached to the consensus again),
  * hs_trim_polished == create_new_contigs.cpp:556-629 (the overhangs the piece was polished with are cut off the polished

@@ -431,7 +431,8 @@ int main(int argc, char** argv) {
         if (argc != 11) return 2;
         char** a = argv + 1;
         std::vector<hs::ColFileContig> cs;
-        if (int rc = hs::parse_col(a[1], (float)std::atof(a[6]), cs, 4)) return rc;
+        // as the product's HS_separate_reads: the binary companion of the .col if it still describes this file, else the text
+        if (hs::read_col_sidecar(a[1], (float)std::atof(a[6]), cs, 4) != 1) { if (int rc = hs::parse_col(a[1], (float)std::atof(a[6]), cs, 4)) return rc; }
         std::map<std::string, int> ploidy_of; bool have = false;
         { std::ifstream pf(a[4]); if (pf) { have = true; std::string c; int p; while (pf >> c >> p) ploidy_of[c] = p; } }
         std::vector<hs_sr_contig> hc(cs.size());

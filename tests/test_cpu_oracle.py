@@ -224,3 +224,57 @@ def test_host_glue_deep_coverage_equals_oracle(built):
         assert canon.split_blocks(outs["hs"][0]) == canon.split_blocks(outs["orc"][0])
         assert open(outs["hs"][2]).read() == open(outs["orc"][2]).read()
         assert canon.split_blocks(outs["hs"][3]) == canon.split_blocks(outs["orc"][3])
+
+
+def _sr_through_harness(built, td, meta, col, gro, env):
+    kw = meta.get("kwargs", {})
+    ploidy = os.path.join(td, "ploidy.txt") if "ploidy_lines" in kw else os.path.join(td, "absent_ploidy.txt")
+    r = subprocess.run([built["harness"], "separate_reads", col, "1", meta["error_rate_arg"], ploidy, str(kw.get("low_memory", 0)), "0.01",
+                        str(kw.get("amplicon", 0)), gro, "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    return r.stderr.decode()
+
+
+@pytest.mark.parametrize("case", ["multi", "penta30k", "clips"])
+def test_binary_companion_of_the_col_file(built, case):
+    """<out.col>.hsbin: stage 3 leaves the .col's content as flat arrays next to it; stage 4 takes them only
+    while the .col still is that file, and the .gro is the same either way. (Host code: checked through the harness; the drop-in
+    executables go through the same reader / writer.)"""
+    if case not in gu.case_names():
+        pytest.skip("golden case not present")
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack(case, td)
+        outs = gu.run_stage_pair([built["harness"], "call_variants"], [built["harness"], "separate_reads"], td, meta)
+        assert gu.compare(td, outs) == []
+        col = outs["col"]
+        assert os.path.exists(col + ".hsbin") and not os.path.exists(col + ".hsbin.tmp")
+        rep = dict(os.environ, HS_SIDECAR_REPORT="1")
+        g_bin, g_txt = os.path.join(td, "bin.gro"), os.path.join(td, "txt.gro")
+        assert "from the binary companion" in _sr_through_harness(built, td, meta, col, g_bin, rep)
+        assert "from the binary companion" not in _sr_through_harness(built, td, meta, col, g_txt, dict(rep, HS_NO_SIDECAR="1"))
+        assert open(g_bin).read() == open(g_txt).read() == open(outs["gro"]).read()
+        # the rarest-strain filter (separate_reads.cpp:151-167) from the companion's counts == from the text
+        r1 = subprocess.run([built["harness"], "separate_reads", col, "1", meta["error_rate_arg"], os.path.join(td, "absent"), "0", "0.3", "0", g_bin + "2", "0"],
+                            env=rep, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        r2 = subprocess.run([built["harness"], "separate_reads", col, "1", meta["error_rate_arg"], os.path.join(td, "absent"), "0", "0.3", "0", g_txt + "2", "0"],
+                            env=dict(rep, HS_NO_SIDECAR="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r1.returncode == 0 and r2.returncode == 0 and b"from the binary companion" in r1.stderr
+        assert open(g_bin + "2").read() == open(g_txt + "2").read()
+        # an edited .col (one SNPS line gone: another size; one digit changed: the same size, another block hash) is parsed as text
+        lines = open(col).read().split("\n")
+        k = next(i for i, l in enumerate(lines) if l.startswith("SNPS"))
+        edited = os.path.join(td, "edited.col")
+        open(edited, "w").write("\n".join(lines[:k] + lines[k + 1:]))
+        os.replace(col + ".hsbin", edited + ".hsbin")
+        g_e1, g_e2 = os.path.join(td, "e1.gro"), os.path.join(td, "e2.gro")
+        assert "from the binary companion" not in _sr_through_harness(built, td, meta, edited, g_e1, rep)
+        _sr_through_harness(built, td, meta, edited, g_e2, dict(rep, HS_NO_SIDECAR="1"))
+        assert open(g_e1).read() == open(g_e2).read()
+        txt = open(col).read()
+        pos = txt.index("SNPS\t") + 5
+        flipped = txt[:pos] + ("1" if txt[pos] != "1" else "2") + txt[pos + 1:]
+        same_size = os.path.join(td, "same_size.col")
+        open(same_size, "w").write(flipped)
+        assert len(flipped) == len(txt)
+        os.replace(edited + ".hsbin", same_size + ".hsbin")
+        assert "from the binary companion" not in _sr_through_harness(built, td, meta, same_size, os.path.join(td, "s.gro"), rep)
