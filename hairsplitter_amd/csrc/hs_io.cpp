@@ -17,6 +17,7 @@
 #include <iostream>
 #include <sstream>
 #include <string_view>
+#include <thread>
 #include <unordered_map>
 
 #include <fcntl.h>
@@ -692,6 +693,11 @@ int write_cv_outputs(const CvFileInput& in, const hs_cv_result* res, const std::
         out += '\n';
         vcf += '\n';
     });
+    // the binary companion for HS_separate_reads is formed and written on a thread of its own while this one writes the text (the
+    // companion is only ever used next to a .col of exactly the size and the block hashes it records: whichever file is complete first,
+    // a process that dies in between leaves nothing a reader would take)
+    std::thread side;
+    if (res->col_idx || res->col_off[res->snp_off[C]] == 0) side = std::thread([&] { write_col_sidecar(in, res, col_block, col_path, std::max(1, n_threads / 2)); });
     {
         std::ofstream out(col_path, std::ios::binary), vcf(vcf_path, std::ios::binary);
         for (int c = 0; c < C; ++c) {
@@ -700,8 +706,7 @@ int write_cv_outputs(const CvFileInput& in, const hs_cv_result* res, const std::
             vcf.write(vcf_block[(size_t)c].data(), (std::streamsize)vcf_block[(size_t)c].size());
         }
     }
-    // the text file first (what --resume and every other reader go by), then its binary companion for HS_separate_reads
-    if (res->col_idx || res->col_off[res->snp_off[C]] == 0) write_col_sidecar(in, res, col_block, col_path, n_threads);
+    if (side.joinable()) side.join();
     return 0;
 }
 
