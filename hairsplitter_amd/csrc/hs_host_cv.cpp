@@ -41,11 +41,17 @@ constexpr size_t kArenaBlock = 1u << 20;
 struct BlockCache {
     std::mutex mu;
     std::vector<char*> free_blocks;
+    // blocks kept for the next contig: at most HS_ARENA_CACHE_MB (default 512) of them; what is freed beyond that goes back to malloc
+    static size_t keep_max() { static const size_t v = []() { const char* e = std::getenv("HS_ARENA_CACHE_MB"); const long m = e ? std::atol(e) : 512; return (size_t)(m > 0 ? m : 0); }(); return v; }
+    static char* must(void* p, size_t n) {
+        if (!p) { std::fprintf(stderr, "hairsplitter: out of memory (a partition block of %zu bytes)\n", n); std::abort(); }
+        return (char*)p;
+    }
     char* get() {
         { std::lock_guard<std::mutex> g(mu); if (!free_blocks.empty()) { char* p = free_blocks.back(); free_blocks.pop_back(); return p; } }
-        return (char*)std::malloc(kArenaBlock);
+        return must(std::malloc(kArenaBlock), kArenaBlock);
     }
-    void put(char* p) { std::lock_guard<std::mutex> g(mu); if (free_blocks.size() < 4096) free_blocks.push_back(p); else std::free(p); }
+    void put(char* p) { std::lock_guard<std::mutex> g(mu); if (free_blocks.size() < keep_max()) free_blocks.push_back(p); else std::free(p); }
 };
 BlockCache& block_cache() { static BlockCache* c = new BlockCache(); return *c; }
 }  // namespace
@@ -54,7 +60,7 @@ struct PartitionArena {
     size_t used = kArenaBlock;
     void* alloc(size_t n) {
         n = (n + 63) & ~(size_t)63;
-        if (n > kArenaBlock) { char* p = (char*)std::malloc(n); big.push_back(p); return p; }
+        if (n > kArenaBlock) { char* p = BlockCache::must(std::malloc(n), n); big.push_back(p); return p; }
         if (used + n > kArenaBlock) { blocks.push_back(block_cache().get()); used = 0; }
         void* p = blocks.back() + used;
         used += n;

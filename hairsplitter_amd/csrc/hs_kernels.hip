@@ -1533,6 +1533,7 @@ static __device__ Table2x2 column_vs_partition_dev(const int32_t* __restrict__ i
                 hs::Rh8View rh; rh.init(s_map, s_map + 512, s_map + 1024, 512);      // (cap 512: every set of byte keys fits, no overflow)
                 for (int i = 0; i < nseen; ++i) rh.insert(s_seen[i]);
                 rh.insert((uint8_t)ref);
+                if (rh.overflow) __builtin_trap();      // (never silently another order)
                 s_ord_n[0] = rh.order(s_ord);
             }
             wave_lds_sync();

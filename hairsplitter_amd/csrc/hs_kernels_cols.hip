@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
                 hs::Rh8View rh; rh.init(s_info[wv], s_key[wv], s_tmp[wv], 512);
                 for (int i = 0; i < nd; ++i) rh.insert(first[i]);
                 rh.insert(0); rh.insert(1); rh.insert(2);
+                if (rh.overflow) __builtin_trap();      // (cap 512 holds every set of byte keys: tests/harness/rh8_selftest worstcase; never silently another order)
                 const int m = rh.order(s_tmp[wv]);
                 uint32_t* v = s_sort[wv];
                 for (int i = 0; i < m; ++i) {

@@ -110,7 +110,8 @@ struct Rh8 {
 
 
 // The same map over storage the caller provides (LDS on the device): info / key / tmp hold `cap` bytes each; a map that would
-// need more slots than that sets `overflow` and stops growing (the caller falls back to Rh8). cap 128 holds 64 buckets (51 keys),
+// need more slots than that sets `overflow` and stops growing (the kernels give it cap 512, which holds every key set of the path, and trap on
+// the flag rather than go on with another order: tests/harness/rh8_selftest worstcase). cap 128 holds 64 buckets (51 keys),
 // cap 512 holds 256 buckets (every set of byte keys the path can produce: 125 pileup codes + 3).
 struct Rh8View {
     uint8_t* info; uint8_t* key; uint8_t* tmp;

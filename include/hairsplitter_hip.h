@@ -78,7 +78,9 @@ const char* hs_kernel_name(int k);          /* name of the (dominant) kernel of 
 void hs_kernel_stats_reset(void);
 void hs_kernel_stats_get(hs_kernel_stats* out);
 /* Host waits for the device since the library was loaded: each is one round trip in the chain of a contig group (bench.py reports
- * them per step). The time spent in them is only accumulated under HS_TIMING. */
+ * them per step). The time spent in them is only accumulated under HS_TIMING. A wait polls hipStreamQuery and sleeps 25 us between two
+ * looks; for the duration of the wait the calling thread's timer slack is set to 1 us (prctl PR_SET_TIMERSLACK; HS_TIMER_SLACK_NS=0: not
+ * touched) and the thread's own value is put back before the call returns. */
 void hs_host_wait_stats(int64_t* n_waits, double* ms_in_waits);
 
 /* ------------------------------------------------------------------------------------------------

@@ -80,6 +80,14 @@ def test_hash_map_view_and_std_sort_restatements(built):
     assert int(r.stdout.split("heap-paths")[1]) > 50
 
 
+def test_hash_map_view_holds_every_key_set_of_the_path(built):
+    """hs::Rh8View at the capacity the kernels give it (512 bytes per table in LDS): 128 distinct byte keys never set its overflow flag and
+    iterate like the unbounded emulator (the kernels trap on the flag instead of going on with another order)"""
+    exe = os.path.join(os.path.dirname(built["harness"]), "rh8_selftest")
+    r = subprocess.run([exe, "worstcase"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout
+
+
 def test_rh8_static_order(built):
     """The closed form k_robust_partitions uses for the iteration order of small hash maps (hs_kernels_parts.hip) against the
     emulator, on two million random key sets"""
