@@ -287,10 +287,12 @@ def main():
         else:
             cv, sr = batch.run(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=window_size)
         t3 = time.perf_counter(); py_ms["pipeline_call"] += (t3 - t) * 1e3
-        if cap[0] is None:   # first (set-up) step only: fix the size of the per-step collective, allocate its buffers
-            cap[0] = hdist.LabelGatherer(hdist.gather_capacity(int(sr["labels"].size)))
-        # the labels arrive on rank 0 (which would write the .gro); decoding them into arrays is the consumer's business
-        gathered = cap[0].gather(sr["labels"], decode=False) if not no_coll else None
+        # the labels arrive on rank 0 (which would write the .gro) as the lists its GROUP lines are made of: per window the reads it holds
+        # and their labels; decoding them into arrays is the consumer's business. cap[0] is made during set-up (below), not here.
+        gathered = None
+        if cap[0] is not None and not no_coll:
+            off, ids, lab = sr["sparse"]
+            gathered = cap[0].gather(off, ids, lab, decode=False)
         py_ms["gather"] += (time.perf_counter() - t3) * 1e3
         return cv, sr, gathered
 
@@ -307,7 +309,13 @@ def main():
     # set-up, not measurement (reported as setup_steps): a few passes that size the device / pinned block pools, the
     # per-thread scratch and the HIP runtime's own pools (first use of every buffer size goes to hipMalloc / hipHostMalloc),
     # then the W warm-up steps of the contract
-    for _ in range(SETUP_STEPS):
+    batch.sparse_labels(True)      # a step returns what the .gro lists: per window its reads and their labels (config.outputs)
+    pet()
+    _cv0, _sr0, _ = step()      # set-up: the first pass sizes the library's pools -- and the per-step collective (largest payload of any rank, once)
+    if use_dist:      # (one rank: its lists are the job's, nothing to gather)
+        cap[0] = hdist.SparseLabelGatherer(hdist.SparseLabelGatherer.job_capacity(hdist.sparse_payload_bytes(int(_sr0["sparse"][0].size) - 1, int(_sr0["sparse"][1].size))))
+    _cv0 = _sr0 = None
+    for _ in range(SETUP_STEPS - 1):
         pet(); step()
     sync()
     for _ in range(args.warmup):
@@ -469,8 +477,8 @@ def main():
                        **({"emulated_rank_of": emulated, "cores_pinned": args.cores or None,
                            "note": "ONE rank of an %d-rank job on one GPU (its LPT shard, its threads and groups): a readiness check, not a scaling measurement" % emulated} if emulated else {}),
                        "host_threads_per_rank": n_threads, "pipeline": "hs_pipeline_run_fused" if fused else "hs_pipeline_select + hs_pipeline_run",
-                       "outputs": "per step, on the host: for every clustering window its reads and their partition labels (hs_sr_result: window bounds + one int32 per read "
-                                  "and window, -2 = read not in the window; the GROUP lines of the .gro), per contig the mean distance (error_rate.txt) and the SNPs' positions, "
+                       "outputs": "per step, on the host: for every clustering window its bounds, the reads it holds and their partition labels (hs_pipeline_sparse_labels: the "
+                                  "content of the GROUP lines of the .gro; every other read of the contig has the label -2), per contig the mean distance (error_rate.txt) and the SNPs' positions, "
                                   "alleles and read counts. NOT in the timed steps: the per-read entries of the SNP columns (.col's payload) -- stage 3 hands them to stage 4 on "
                                   "the device; `ms_per_step_with_col_download` is the same step with them brought to the host as well"},
             "roofline": {"bound": "hbm", "kernel": dom,

@@ -22,7 +22,7 @@ SYMBOLS = [
     "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_partition_pair_distance", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_pipeline_thread_devices", "hs_cv_batch_device", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main",
-    "hs_pipeline_run_fused", "hs_realign_paf", "hs_pipeline_set_option", "hs_pipeline_groups", "hs_pipeline_group_range", "hs_pipeline_group_cv", "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_host_wait_stats", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
+    "hs_pipeline_run_fused", "hs_realign_paf", "hs_pipeline_set_option", "hs_pipeline_groups", "hs_pipeline_group_range", "hs_pipeline_group_cv", "hs_pipeline_sparse_labels", "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_host_wait_stats", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
 ]
 
 HS_NKERNELS = 27
@@ -386,6 +386,23 @@ class PipelineGroups:
         """HS_PIPELINE_KEEP_COLUMNS: the entries of the SNP columns (.col's payload) are brought to the host inside every call too"""
         _check(load().hs_pipeline_set_option(self.handle, C.c_int32(1), C.c_int64(1 if on else 0)))
 
+    def sparse_labels(self, on=True):
+        """HS_PIPELINE_SPARSE_LABELS: results carry sr["sparse"] = (win_row_off, ids, labels) -- per window the reads it holds and their
+        labels, what the .gro lists -- instead of the dense array sr["labels"] (None then). The arrays view the pipeline's memory and
+        stay valid until its next call."""
+        _check(load().hs_pipeline_set_option(self.handle, C.c_int32(2), C.c_int64(1 if on else 0)))
+        self._sparse = bool(on)
+
+    def _attach_sparse(self, sr):
+        if not getattr(self, "_sparse", False):
+            return sr
+        off, ids, lab = C.POINTER(C.c_int64)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)()
+        nw, nr = C.c_int64(0), C.c_int64(0)
+        _check(load().hs_pipeline_sparse_labels(self.handle, C.byref(off), C.byref(ids), C.byref(lab), C.byref(nw), C.byref(nr)))
+        W, R = int(nw.value), int(nr.value)
+        sr["sparse"] = (np.ctypeslib.as_array(off, (W + 1,)), np.ctypeslib.as_array(ids, (max(R, 1),))[:R], np.ctypeslib.as_array(lab, (max(R, 1),))[:R])
+        return sr
+
     def sibling(self, n_groups):
         """Another pipeline over the SAME resident batch with its own number of contig groups (bench.py: one group, where every
         kernel runs alone, to read the kernels' own durations next to those of the default run)."""
@@ -421,7 +438,7 @@ class PipelineGroups:
                    "t_kernel_ms": [float(x) for x in st.t_kernel_cv_ms], "t_kernel_k4_ms": float(st.t_kernel_k4_ms),
                    "n_columns_extracted": int(st.n_columns_extracted), "n_columns_downloaded": int(st.n_columns_downloaded),
                    "n_columns_downloaded_late": int(st.n_columns_downloaded_late)})
-        sr = _sr_result_to_dict(sres, Cn, take_ownership=True)   # the labels stay where the library put them
+        sr = self._attach_sparse(_sr_result_to_dict(sres, Cn, take_ownership=True))   # the labels stay where the library put them
         sr["wall_ms"] = {"select": (t_1 - t_0) * 1e3, "between": (t_2 - t_1) * 1e3, "groups": (t_3 - t_2) * 1e3, "collect": (time.perf_counter() - t_3) * 1e3}
         return cv, sr
 
@@ -444,7 +461,7 @@ class PipelineGroups:
               "t_host_ms": float(st.t_host_ms), "t_kernel_ms": [float(x) for x in st.t_kernel_cv_ms], "t_kernel_k4_ms": float(st.t_kernel_k4_ms),
               "n_columns_extracted": int(st.n_columns_extracted), "n_columns_downloaded": int(st.n_columns_downloaded),
               "n_columns_downloaded_late": int(st.n_columns_downloaded_late)}
-        sr = _sr_result_to_dict(sres, Cn, take_ownership=True)
+        sr = self._attach_sparse(_sr_result_to_dict(sres, Cn, take_ownership=True))
         sr["wall_ms"] = {"select": 0.0, "between": 0.0, "groups": (t_1 - t_0) * 1e3, "collect": (time.perf_counter() - t_1) * 1e3}
         return cv, sr
 
@@ -502,7 +519,8 @@ def _sr_result_to_dict(res, Cn, take_ownership=False):
         "win_start": np.ctypeslib.as_array(r.win_start, (max(W, 1),))[:W].copy(),
         "win_end": np.ctypeslib.as_array(r.win_end, (max(W, 1),))[:W].copy(),
         "label_off": label_off,
-        "labels": _owned_view_i32(res, r.labels, NL) if take_ownership else np.ctypeslib.as_array(r.labels, (max(NL, 1),))[:NL].copy(),
+        "labels": (None if not r.labels else (_owned_view_i32(res, r.labels, NL) if take_ownership else np.ctypeslib.as_array(r.labels, (max(NL, 1),))[:NL].copy())),
+        "_owner": (_SrResultOwner(res) if (take_ownership and not r.labels) else None),      # (no label array to carry the ownership: the dict does)
         "t_device_ms": float(r.t_device_ms), "t_host_ms": float(r.t_host_ms), "n_cw_instances": int(r.n_cw_instances),
         "t_kernel_ms": [float(x) for x in r.t_kernel_ms], "t_kernel_graph_ms": float(r.t_kernel_graph_ms),
         "n_graph_rows_host": int(r.n_graph_rows_host), "n_windows_finished_on_host": int(r.n_windows_finished_on_host),

@@ -183,3 +183,87 @@ class LabelGatherer:
             k = int(v[0]) | (int(v[1]) << 15)
             res.append(v[2:2 + k].astype(np.int32))
         return res
+
+
+# ---------------------------------------------------------------------------------------------
+# The gather of a step in the form the .gro needs (separate_reads.cpp:1756-1784): per window the reads it holds and their
+# labels. The final labels of a window come from three places (the device's cluster chains, windows without a seeding SNP:
+# every read -1, windows without SNPs: the reads over the midpoint), so they are put together on the host; what crosses to
+# the device for the collective is that list -- 6 bytes per (window, read) pair, an eighth of the dense [window][N reads of the
+# contig] array of the round before -- staged in ONE pinned buffer that is allocated with the gatherer, copied once, gathered once.
+# Payload (bytes): int64 n_windows, int64 n_rows | int32 row_off[n_windows + 1] | int32 ids[n_rows] | int16 labels[n_rows]
+# ---------------------------------------------------------------------------------------------
+def sparse_payload_bytes(n_windows: int, n_rows: int) -> int:
+    return 16 + 4 * (n_windows + 1) + 4 * n_rows + 2 * n_rows + 8
+
+
+def encode_sparse(win_row_off: np.ndarray, ids: np.ndarray, labels: np.ndarray, out: np.ndarray) -> int:
+    """Writes the payload into the uint8 array `out`; returns its length in bytes"""
+    W, R = int(win_row_off.size) - 1, int(ids.size)
+    n = sparse_payload_bytes(W, R)
+    assert out.size >= n and R < (1 << 31)
+    out[:16].view(np.int64)[:] = (W, R)
+    o = 16
+    np.copyto(out[o:o + 4 * (W + 1)].view(np.int32), win_row_off, casting="unsafe"); o += 4 * (W + 1)
+    np.copyto(out[o:o + 4 * R].view(np.int32), ids, casting="unsafe"); o += 4 * R
+    np.copyto(out[o:o + 2 * R].view(np.int16), labels, casting="unsafe")      # labels are -2, -1 or a group id < 32767
+    return n
+
+
+def decode_sparse(buf: np.ndarray):
+    """(win_row_off int64, ids int32, labels int32) of one rank's payload"""
+    W, R = (int(x) for x in buf[:16].view(np.int64))
+    o = 16
+    off = buf[o:o + 4 * (W + 1)].view(np.int32).astype(np.int64); o += 4 * (W + 1)
+    ids = buf[o:o + 4 * R].view(np.int32).copy(); o += 4 * R
+    lab = buf[o:o + 2 * R].view(np.int16).astype(np.int32)
+    return off, ids, lab
+
+
+class SparseLabelGatherer:
+    """ONE gather per step of the ranks' (window, read, label) lists to `dst`. Everything is allocated here, once, for `capacity`
+    bytes per rank (the largest payload of any rank: exchanged when the job is set up, not per step): the pinned staging buffer,
+    the device buffer the collective sends, the receive buffers on `dst`."""
+
+    def __init__(self, capacity_bytes: int, group=None, dst: int = 0):
+        import torch
+        import torch.distributed as dist
+        self.capacity = (int(capacity_bytes) + 15) & ~15
+        self.group, self.dst = group, dst
+        self.active = dist.is_available() and dist.is_initialized()
+        self.host = torch.zeros(self.capacity, dtype=torch.uint8)
+        if not self.active:
+            self.np = self.host.numpy()
+            return
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        if self.dev == "cuda":
+            self.host = self.host.pin_memory()
+        self.np = self.host.numpy()
+        self.dev_buf = torch.empty(self.capacity, dtype=torch.uint8, device=self.dev)
+        self.out = [torch.empty_like(self.dev_buf) for _ in range(self.world)] if self.rank == dst else None
+        self.copied = torch.cuda.Event() if self.dev == "cuda" else None   # the staging buffer is rewritten by the next step
+
+    @staticmethod
+    def job_capacity(local_bytes: int, group=None) -> int:
+        """set-up: the largest payload over the ranks (+ 1/8: the lists of a job vary little from step to step, none at all for the same input)"""
+        return gather_capacity(int(local_bytes) + int(local_bytes) // 8 + 64, group)
+
+    def gather(self, win_row_off: np.ndarray, ids: np.ndarray, labels: np.ndarray, decode: bool = True):
+        """Per-rank (win_row_off, ids, labels) on `dst` (raw byte tensors if decode=False), None elsewhere"""
+        import torch.distributed as dist
+        if self.active and self.copied is not None:
+            self.copied.synchronize()      # the previous step's host-to-device copy has read the staging buffer
+        n = encode_sparse(win_row_off, ids, labels, self.np)
+        if not self.active:
+            return [decode_sparse(self.np[:n])] if decode else [self.host]
+        self.dev_buf.copy_(self.host, non_blocking=True)
+        if self.copied is not None:
+            self.copied.record()
+        dist.gather(self.dev_buf, self.out, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        if not decode:
+            return self.out
+        return [decode_sparse(o.cpu().numpy()) for o in self.out]

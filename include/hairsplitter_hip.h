@@ -503,9 +503,15 @@ int hs_pipeline_thread_devices(hs_pipeline* p, int32_t* out, int32_t cap);
  * hs_pipeline_group_cv until the next call on the pipeline (they are dropped when it starts). Default 0: positions, alleles and
  * counts of the SNPs only. */
 #define HS_PIPELINE_KEEP_COLUMNS 1
+/* HS_PIPELINE_SPARSE_LABELS != 0: the labels come back per window as the reads the window holds and their labels -- what the GROUP lines
+ * of the .gro list (separate_reads.cpp:1756-1784), nothing else: hs_sr_result::labels is NULL (label_off still describes the dense
+ * form) and hs_pipeline_sparse_labels returns, valid until the next call on the pipeline, win_row_off [W+1], ids [rows] (ascending
+ * read indices inside a window) and labels [rows]; every read a window does not list has the label -2. */
+#define HS_PIPELINE_SPARSE_LABELS 2
 int hs_pipeline_set_option(hs_pipeline* p, int32_t option, int64_t value);
 int hs_pipeline_groups(const hs_pipeline* p);                                  /* number of contig groups */
 int hs_pipeline_group_range(const hs_pipeline* p, int32_t g, int32_t* c0, int32_t* c1);   /* contigs [c0, c1) of group g */
+int hs_pipeline_sparse_labels(const hs_pipeline* p, const int64_t** win_row_off, const int32_t** ids, const int32_t** labels, int64_t* n_windows, int64_t* n_rows);
 const hs_cv_result* hs_pipeline_group_cv(const hs_pipeline* p, int32_t g);    /* stage-3 result of group g from the last call (NULL before the first) */
 void hs_pipeline_destroy(hs_pipeline* p);
 

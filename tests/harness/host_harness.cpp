@@ -424,6 +424,10 @@ int main(int argc, char** argv) {
         } else
         if (int rc = hs::cv_run(ops, meta, std::strtof(a[11], nullptr), 1, &res)) return rc;
         hs::write_cv_outputs(in, res, a[6], a[9], a[10], 4);
+        if (const char* e = std::getenv("HS_HARNESS_DUMP_MD")) {      // the contigs' mean distances, exactly (what the ranks of a sharded job exchange)
+            std::ofstream o(e);
+            for (int c = 0; c < res->n_contigs; ++c) { char buf[64]; std::snprintf(buf, sizeof buf, "%a\n", (double)res->mean_distance[c]); o << buf; }
+        }
         hs::free_cv_result(res);
         return 0;
     }
@@ -443,7 +447,8 @@ int main(int argc, char** argv) {
             h.col_off = c.col_off.data(); h.col_idx = c.col_idx.data(); h.col_code = c.col_code.data();
             h.ploidy = (have && ploidy_of.count(c.name)) ? ploidy_of[c.name] : 0;
         }
-        const int w = hs::sr_window_size(hc.data(), (int)hc.size(), std::atoi(a[7]) != 0);
+        int w = hs::sr_window_size(hc.data(), (int)hc.size(), std::atoi(a[7]) != 0);
+        if (const char* e = std::getenv("HS_HARNESS_WINDOW_SIZE")) w = std::atoi(e);      // (a shard of a job: the window size is chosen over the whole job)
         uint32_t seed = 12345u;   // as hs_main.cpp: the pinned std::random_device of the reference, HS_SEED overrides
         if (const char* e = std::getenv("HS_SEED")) seed = (uint32_t)std::strtoul(e, nullptr, 10);
         OracleSrOps ops(seed);

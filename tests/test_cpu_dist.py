@@ -119,3 +119,104 @@ def test_strong_scaling_shards_cover_the_job():
         assert sorted(sum(shards, [])) == list(range(500))
         loads = [sum(shapes[i][0] for i in s) for s in shards]
         assert max(loads) - min(loads) <= 300_000
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py's step logic across two ranks, on the CPU: the job's contigs sharded by LPT, every rank runs both stages on ITS contigs
+# (the product's host glue with the oracle-backed device interface: tests/harness), the per-contig distances cross the ranks for
+# the job's error rate, the windows' (read, label) lists are gathered to rank 0 in ONE collective -- and what rank 0 then holds is
+# what a single process computes for the whole job.
+# ---------------------------------------------------------------------------------------------
+def _gro_lists(path):
+    """per contig name: [(start, end, ids, labels)] of its GROUP lines"""
+    out, name = {}, None
+    for l in open(path):
+        t = l.rstrip("\n").split("\t")
+        if t[0] == "CONTIG":
+            name = t[1]; out[name] = []
+        elif t[0] == "GROUP":
+            ids = [int(x) for x in t[3].split(",") if x != ""]
+            lab = [int(x) for x in t[4].split(",") if x != ""]
+            out[name].append((int(t[1]), int(t[2]), ids, lab))
+    return out
+
+
+def _rank_job(rank, world, port, td, names, q):
+    import subprocess
+    import __graft_entry__ as ge
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = ge.paths()
+    mine = names[rank]
+    d = os.path.join(td, "rank%d" % rank)
+    # stage 3 on this rank's contigs; its per-contig distances are what crosses the ranks
+    col, vcf, err, gro = (os.path.join(d, x) for x in ("o.col", "o.vcf", "o.err", "o.gro"))
+    subprocess.run([p["harness"], "call_variants", os.path.join(d, "assembly.gfa"), os.path.join(d, "reads.fasta"), os.path.join(d, "aln.sam"), "1", d, err, "0", "0", col, vcf, "0.33"],
+                   check=True, stdout=subprocess.DEVNULL, env=dict(os.environ, HS_HARNESS_DUMP_MD=os.path.join(d, "md.txt")))
+    md = np.array([float.fromhex(x) for x in open(os.path.join(d, "md.txt")).read().split()], np.float32)
+    er = hdist.global_error_rate(mine["ids"], md, mine["n_total"])
+    e = min(float("%g" % er), 0.15)
+    ws = hdist.global_window_size(np.array(mine["refspans"], np.int64))
+    env = dict(os.environ, HS_HARNESS_WINDOW_SIZE=str(ws))
+    subprocess.run([p["harness"], "separate_reads", col, "1", str(e), os.path.join(d, "none"), "0", "0.01", "0", gro, "0"], check=True, stdout=subprocess.DEVNULL, env=env)
+    lists = _gro_lists(gro)
+    off, ids, lab = [0], [], []
+    order = []
+    for name in sorted(lists):
+        for (a, b, i, l) in lists[name]:
+            order.append((name, a, b)); ids += i; lab += l; off.append(len(ids))
+    off, ids, lab = np.array(off, np.int64), np.array(ids, np.int32), np.array(lab, np.int32)
+    g = hdist.SparseLabelGatherer(hdist.SparseLabelGatherer.job_capacity(hdist.sparse_payload_bytes(off.size - 1, ids.size)))
+    got = None
+    for _ in range(2):      # (step after step through the same buffers)
+        got = g.gather(off, ids, lab)
+    all_orders = [None] * world
+    dist.all_gather_object(all_orders, order)
+    if rank == 0:
+        merged = {}
+        for r in range(world):
+            o, i, l = got[r]
+            for w, (name, a, b) in enumerate(all_orders[r]):
+                merged.setdefault(name, []).append((a, b, i[o[w]:o[w + 1]].tolist(), l[o[w]:o[w + 1]].tolist()))
+        q.put((e, ws, merged))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gather_what_one_process_computes():
+    import subprocess
+    import tempfile
+    import __graft_entry__ as ge
+    from hairsplitter_amd import synth
+    ge.build()
+    p = ge.paths()
+    contigs = [synth.make_contig(77, i, L, h, 0.012, 28, "ont") for i, (L, h) in enumerate([(9000, 2), (7000, 3), (6000, 1), (8000, 2), (5000, 2)])]
+    world = 2
+    shards = hdist.lpt_shards([float(len(c.seq)) for c in contigs], world)
+    with tempfile.TemporaryDirectory() as td:
+        full = synth.write_files(contigs, os.path.join(td, "full"))
+        col, vcf, err, gro = (os.path.join(td, "full", x) for x in ("o.col", "o.vcf", "o.err", "o.gro"))
+        subprocess.run([p["harness"], "call_variants", full["gfa"], full["reads"], full["sam"], "1", td, err, "0", "0", col, vcf, "0.33"], check=True, stdout=subprocess.DEVNULL)
+        e_full = min(float("%g" % float(open(err).read().strip())), 0.15)
+        subprocess.run([p["harness"], "separate_reads", col, "1", str(e_full), os.path.join(td, "none"), "0", "0.01", "0", gro, "0"], check=True, stdout=subprocess.DEVNULL)
+        want = _gro_lists(gro)
+        names = []
+        for r in range(world):
+            d = os.path.join(td, "rank%d" % r)
+            mine = [contigs[i] for i in shards[r]]
+            synth.write_files(mine, d)
+            spans = [int(sum(int(x) >> 4 for x in a.cigar if (int(x) & 15) in (0, 2, 7, 8))) for c in mine for a in c.alns]
+            names.append({"ids": shards[r], "n_total": len(contigs), "refspans": spans})
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_rank_job, args=(r, world, port, td, names, q)) for r in range(world)]
+        for pr in procs:
+            pr.start()
+        e, ws, merged = q.get(timeout=300)
+        for pr in procs:
+            pr.join(120)
+            assert pr.exitcode == 0
+        assert e == e_full                     # the job's error rate from the ranks' distances == the single process's
+        assert merged == want                  # and every window's reads and labels as one process computes them
