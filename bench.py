@@ -309,10 +309,11 @@ def main():
     # set-up, not measurement (reported as setup_steps): a few passes that size the device / pinned block pools, the
     # per-thread scratch and the HIP runtime's own pools (first use of every buffer size goes to hipMalloc / hipHostMalloc),
     # then the W warm-up steps of the contract
-    batch.sparse_labels(True)      # a step returns what the .gro lists: per window its reads and their labels (config.outputs)
+    if not os.environ.get("HS_BENCH_DENSE_LABELS"):      # (diagnostic switch: the dense [window][reads of the contig] array of the C result instead)
+        batch.sparse_labels(True)      # a step returns what the .gro lists: per window its reads and their labels (config.outputs)
     pet()
     _cv0, _sr0, _ = step()      # set-up: the first pass sizes the library's pools -- and the per-step collective (largest payload of any rank, once)
-    if use_dist:      # (one rank: its lists are the job's, nothing to gather)
+    if use_dist and "sparse" in _sr0:      # (one rank: its lists are the job's, nothing to gather)
         cap[0] = hdist.SparseLabelGatherer(hdist.SparseLabelGatherer.job_capacity(hdist.sparse_payload_bytes(int(_sr0["sparse"][0].size) - 1, int(_sr0["sparse"][1].size))))
     _cv0 = _sr0 = None
     for _ in range(SETUP_STEPS - 1):

@@ -9,12 +9,13 @@ try:
 except Exception as e: print('$tag failed', e)
 P
 }
-export HS_ORDER_SCOPE=k2 HS_GROUP_TAPER=1 HS_SHARED_POOL=0
-timeout 900 python -m pytest tests/test_gpu_dropin.py -x -q 2>&1 | tail -2
-run twocalls HS_X=1
-run fused HS_BENCH_FUSED=1
-run fused_hostpile HS_BENCH_FUSED=1 HS_FUSED_HOST_PILEUP=1
-run fused_t05 HS_BENCH_FUSED=1 HS_GROUP_TAPER=0.5
-run fused_shared HS_BENCH_FUSED=1 HS_SHARED_POOL=1
-EXTRA="--groups 10" run fused_g10 HS_BENCH_FUSED=1
-run fused_phase1 HS_BENCH_FUSED=1 HS_ORDER_SCOPE=phase1
+export HS_BENCH_NO_PROBE=1
+run sparse1 HS_X=1
+run dense1 HS_BENCH_DENSE_LABELS=1
+run sparse2 HS_X=1
+run dense2 HS_BENCH_DENSE_LABELS=1
+run twocalls HS_BENCH_TWO_CALLS=1
+run phase1 HS_ORDER_SCOPE=phase1
+run k2 HS_ORDER_SCOPE=k2
+EXTRA="--groups 10" run g10 HS_X=1
+EXTRA="--groups 6" run g6 HS_X=1
