@@ -552,6 +552,14 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         s.low_memory_now = lowmem || sr_coverage_above_1000(contigs[c]);   // separate_reads.cpp:1515-1518
         if (contigs[c].n_snps == 0) { for (SrWindowPlan& old : s.windows) s.spare.push_back(std::move(old)); s.windows.clear(); return; }   // :1522-1524
         s.words = (contigs[c].n_snps + 63) / 64;
+        if (!s.low_memory_now && ((int)s.pos_key.size() != s.N || std::memcmp(s.pos_key.data(), contigs[c].read_start, (size_t)s.N * 4) != 0)) {
+            s.pos_key.assign(contigs[c].read_start, contigs[c].read_start + s.N);
+            s.pos_orig.resize((size_t)s.N); s.pos_rank.resize((size_t)s.N);
+            for (int k = 0; k < s.N; ++k) s.pos_orig[(size_t)k] = k;
+            const int32_t* st0 = contigs[c].read_start;
+            std::sort(s.pos_orig.begin(), s.pos_orig.end(), [st0](int32_t a, int32_t b2) { return st0[a] != st0[b2] ? st0[a] < st0[b2] : a < b2; });
+            for (int k = 0; k < s.N; ++k) s.pos_rank[(size_t)s.pos_orig[(size_t)k]] = k;
+        }
         if (s.perm_n != s.N || s.perm_seed != seed) {      // (a kept state has the order of these N reads already)
             s.perm = shuffled_order(s.N, seed);
             s.rank.resize((size_t)s.N);
@@ -562,6 +570,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
 
     laps.lap("perm");
     const bool lm_on_device = dev.low_memory_graphs();
+    bool matrices_by_position = false;
     // ---- the SNP columns of the batch, concatenated once: K5a/K5 (sim / diff) now, Chinese-Whispers seeding later ----
     CwChain ch;
     std::vector<int64_t> col_base_of_contig((size_t)C, 0);
@@ -569,7 +578,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         SimdiffJob job;
         job.cols = &ch;
         job.contig_snp_base.assign((size_t)C, 0); job.plane_off.assign((size_t)C, 0); job.out_off.assign((size_t)C, 0);
-        job.n_reads.assign((size_t)C, 0); job.words.assign((size_t)C, 0); job.plane_n.assign((size_t)C, 0);
+        job.n_reads.assign((size_t)C, 0); job.words.assign((size_t)C, 0); job.plane_n.assign((size_t)C, 0); job.read_base.assign((size_t)C, 0);
         int64_t n_ent = 0, n_col = 0;
         for (int c = 0; c < C; ++c) { n_col += contigs[c].n_snps; if (contigs[c].n_snps) n_ent += contigs[c].col_off[contigs[c].n_snps] - contigs[c].col_off[0]; }
         // The columns of the call as ONE CSR in contig order. When the caller's arrays already are that (stage 3 hands its result
@@ -600,7 +609,7 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         job.snp_ref.resize((size_t)n_col); job.snp_alt.resize((size_t)n_col); job.snp_contig.resize((size_t)n_col);
         std::vector<int64_t> ent_base_of_contig((size_t)C, 0);
         {
-            int64_t cb = 0, eb = 0;
+            int64_t cb = 0, eb = 0, rows_total = 0;
             for (int c = 0; c < C; ++c) {
                 col_base_of_contig[(size_t)c] = cb; ent_base_of_contig[(size_t)c] = eb;
                 job.contig_snp_base[(size_t)c] = cb;
@@ -611,11 +620,20 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
                 // bit rows for the matrix path and for the low-memory path (whose windows compare their own reads only: no N x N)
                 job.plane_off[(size_t)c] = job.plane_total; job.words[(size_t)c] = st[(size_t)c].words; job.plane_n[(size_t)c] = st[(size_t)c].N;
                 job.plane_total += (int64_t)st[(size_t)c].N * st[(size_t)c].words;
+                job.read_base[(size_t)c] = rows_total; rows_total += st[(size_t)c].N;
                 if (st[(size_t)c].low_memory_now) continue;
                 job.out_off[(size_t)c] = job.out_total;
                 job.n_reads[(size_t)c] = st[(size_t)c].N;
                 job.out_total += (int64_t)st[(size_t)c].N * st[(size_t)c].N;
             }
+        }
+        {   // the matrices' rows in the order of the reads' start positions (HS_SIMDIFF_READ_ORDER=1: in read order, every tile computed)
+            static const bool read_order = std::getenv("HS_SIMDIFF_READ_ORDER") != nullptr;
+            int64_t rows_all = 0;
+            for (int c = 0; c < C; ++c) rows_all = std::max<int64_t>(rows_all, job.read_base[(size_t)c] + job.plane_n[(size_t)c]);
+            if (!read_order) job.pos_orig.assign((size_t)rows_all, 0);
+            if (!read_order) for (int c = 0; c < C; ++c) if (job.plane_n[(size_t)c] > 0 && job.n_reads[(size_t)c] == 0)      // (bit rows only: the low-memory path keeps read order)
+                for (int k = 0; k < job.plane_n[(size_t)c]; ++k) job.pos_orig[(size_t)(job.read_base[(size_t)c] + k)] = k;
         }
         parallel_for(C, n_threads, [&](int c) {
             const hs_sr_contig& hc = contigs[c];
@@ -627,11 +645,16 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
                 std::memcpy(own_idx + e_base, hc.col_idx + o0, (size_t)n * sizeof(int32_t));
                 std::memcpy(own_code + e_base, hc.col_code + o0, (size_t)n);
             }
+            if (!job.pos_orig.empty() && job.n_reads[(size_t)c] > 0) {
+                if ((int)st[(size_t)c].pos_orig.size() == st[(size_t)c].N) std::memcpy(job.pos_orig.data() + job.read_base[(size_t)c], st[(size_t)c].pos_orig.data(), (size_t)st[(size_t)c].N * 4);
+                else for (int k = 0; k < st[(size_t)c].N; ++k) job.pos_orig[(size_t)(job.read_base[(size_t)c] + k)] = k;
+            }
             std::memcpy(job.snp_ref.data() + cb, hc.snp_ref, (size_t)hc.n_snps);
             std::memcpy(job.snp_alt.data() + cb, hc.snp_alt, (size_t)hc.n_snps);
             std::fill(job.snp_contig.begin() + cb, job.snp_contig.begin() + cb + hc.n_snps, c);
         });
         laps.lap("columns");
+        matrices_by_position = !job.pos_orig.empty();
         const double t0 = now_ms();
         if (int rc = dev.simdiff_columns(job, &k_ms[0])) return rc;
         dev_ms += now_ms() - t0;
@@ -748,6 +771,16 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
         for (int c = 0; c < C; ++c) { ws.ctg_rank_off[(size_t)c] = ro; ro += (int64_t)st[(size_t)c].rank.size(); }
         ws.rank.resize((size_t)ro);
         parallel_for(C, n_threads, [&](int c) { std::copy(st[(size_t)c].rank.begin(), st[(size_t)c].rank.end(), ws.rank.begin() + ws.ctg_rank_off[(size_t)c]); });
+        if (matrices_by_position) {      // (the same layout: rank.size() == N for every contig with SNPs)
+            ws.pos_rank.assign((size_t)ro, 0);
+            parallel_for(C, n_threads, [&](int c) {
+                const SrContigState& s = st[(size_t)c];
+                if (s.rank.empty()) return;
+                int32_t* o = ws.pos_rank.data() + ws.ctg_rank_off[(size_t)c];
+                if (!s.low_memory_now && (int)s.pos_rank.size() == s.N) std::copy(s.pos_rank.begin(), s.pos_rank.end(), o);
+                else for (int k = 0; k < (int)s.rank.size(); ++k) o[k] = k;
+            });
+        }
         // create_read_graph_low_memory (-l, or coverage > 1000): O(m^2 S) per window on the host, one task per window
         const int n_host = (int)host_w.size();
         if (n_host > 0) {

@@ -133,6 +133,7 @@ struct SrWindowSet {
     std::vector<int32_t> host_nbr;
     std::vector<uint8_t> win_final_empty;  // [W] finalize_clustering sees an empty graph for this window (separate_reads.cpp:1708)
     std::vector<int32_t> rank;             // position of every read in its contig's shuffled visiting order, contigs concatenated
+    std::vector<int32_t> pos_rank;         // row of every read in its contig's sim / diff matrices (SimdiffJob::pos_orig inverted), same layout as `rank`; empty: the read index
     std::vector<int64_t> ctg_rank_off;     // [C] first entry of each contig in `rank`
     float error_rate = 0;
     int64_t rows() const { return win_row0.empty() ? 0 : win_row0.back(); }
@@ -188,6 +189,10 @@ struct SimdiffJob {
     std::vector<int32_t> n_reads, words;         // [C]; n_reads == 0: contig not on the matrix path
     std::vector<int32_t> plane_n;                // [C] reads of every contig that has bit rows (words > 0): the matrix path AND the low-memory path
     int64_t plane_total = 0, out_total = 0;
+    // row order of the matrices: row k of contig c is the read pos_orig[read_base[c] + k] (reads by start position); read_base[c] = first
+    // read of the contig among the reads of all contigs with bit rows. Empty pos_orig: rows = read indices.
+    std::vector<int32_t> pos_orig;
+    std::vector<int64_t> read_base;              // [C]
 };
 
 struct SrChainStats {                 // what the clustering chain did (bench.py's whole-path roofline)

@@ -16,6 +16,9 @@ struct SrContigState {
     std::vector<int32_t> perm;                      // std::shuffle(mt19937(seed)) of 0..N-1
     std::vector<int32_t> rank;                      // rank[perm[k]] = k
     uint32_t perm_seed = 0; int perm_n = -1;        // what perm / rank were made for (a state kept from call to call skips the shuffle)
+    // the reads ranked by start position (ties by index): the row order of the contig's sim / diff matrices (K5 then only computes the
+    // blocks of reads that lie next to each other); kept from call to call while the starts are the same
+    std::vector<int32_t> pos_rank, pos_orig, pos_key;
     std::vector<struct SrWindowPlan> spare;         // window plans of the previous call: their vectors' storage is used again
     struct SrWindowPlan take_window();              // an empty plan, recycled if one is there
 };

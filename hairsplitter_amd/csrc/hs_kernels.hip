@@ -1012,8 +1012,12 @@ __global__ __launch_bounds__(256) void k_snp_planes(
     const uint8_t* __restrict__ snp_ref, const uint8_t* __restrict__ snp_alt, const int32_t* __restrict__ snp_contig,
     const int64_t* __restrict__ contig_snp_base, const int64_t* __restrict__ plane_off, const int32_t* __restrict__ words,
     const int32_t* __restrict__ n_reads, const int32_t* __restrict__ blk_contig, const int32_t* __restrict__ blk_word0, int n_snps,
-    unsigned long long* __restrict__ alt, unsigned long long* __restrict__ ref) {
+    unsigned long long* __restrict__ alt, unsigned long long* __restrict__ ref,
+    const int64_t* __restrict__ read_base /* [C] first row of the contig in rng_lo / rng_hi, or NULL */, int32_t* __restrict__ rng_lo, int32_t* __restrict__ rng_hi) {
     __shared__ unsigned long long s_a[HS_SP_READS][HS_SP_WORDS], s_r[HS_SP_READS][HS_SP_WORDS];
+    // which of the workgroup's words a read is PRESENT in (any code, also a third allele that sets no bit in either plane): K5 only
+    // compares two reads over the words both are present in, and skips pairs of read blocks that share none
+    __shared__ unsigned int s_p[HS_SP_READS];
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = blk_contig[blockIdx.x];
     const int w0 = blk_word0[blockIdx.x];
@@ -1024,6 +1028,7 @@ __global__ __launch_bounds__(256) void k_snp_planes(
     unsigned long long* __restrict__ R = ref + plane_off[c];
     for (int rb = 0; rb < N; rb += HS_SP_READS) {
         for (int x = tid; x < HS_SP_READS * HS_SP_WORDS; x += 256) { (&s_a[0][0])[x] = 0ull; (&s_r[0][0])[x] = 0ull; }
+        if (read_base) for (int x = tid; x < HS_SP_READS; x += 256) s_p[x] = 0u;
         __syncthreads();
         {
             // a wavefront takes every fourth column of the workgroup: lane t first reads what column wv + 4 t needs (one round trip for
@@ -1065,6 +1070,7 @@ __global__ __launch_bounds__(256) void k_snp_planes(
                     if (code >= 0 && r >= 0 && r < HS_SP_READS) {
                         if (code == rbv) atomicOr(&s_r[r][wq], bit);
                         else if (code == abv) atomicOr(&s_a[r][wq], bit);
+                        if (read_base && !(s_p[r] & (1u << wq))) atomicOr(&s_p[r], 1u << wq);
                     }
                 }
             }
@@ -1078,6 +1084,15 @@ __global__ __launch_bounds__(256) void k_snp_planes(
                 A[at] = s_a[r][wq]; R[at] = s_r[r][wq];
             }
         }
+        if (read_base)
+            for (int r = tid; r < nr; r += 256) {
+                const unsigned int pm = s_p[r];
+                if (pm) {
+                    const int64_t at = read_base[c] + rb + r;
+                    atomicMin(&rng_lo[at], w0 + __builtin_ctz(pm));
+                    atomicMax(&rng_hi[at], w0 + 31 - __builtin_clz(pm));
+                }
+            }
         __syncthreads();
     }
 }
@@ -1091,8 +1106,16 @@ __global__ __launch_bounds__(256) void k_simdiff(
     const uint64_t* __restrict__ alt, const uint64_t* __restrict__ ref, const int64_t* __restrict__ plane_off,
     const int32_t* __restrict__ n_reads, const int32_t* __restrict__ words, const int64_t* __restrict__ out_off,
     const int32_t* __restrict__ tile_contig, const int32_t* __restrict__ tile_i, const int32_t* __restrict__ tile_j,
-    int32_t* __restrict__ sim, int32_t* __restrict__ diff, int es /* element stride: 1 = two arrays, 2 = (sim, diff) pairs in one (diff = sim + 1) */) {
+    int32_t* __restrict__ sim, int32_t* __restrict__ diff, int es /* element stride: 1 = two arrays, 2 = (sim, diff) pairs in one (diff = sim + 1) */,
+    const int64_t* __restrict__ read_base /* [C] or NULL */, const int32_t* __restrict__ orig_of /* row of the matrices -> read, per contig at read_base[c] */,
+    const int32_t* __restrict__ rng_lo, const int32_t* __restrict__ rng_hi) {
+    // With orig_of the rows / columns of the matrices are the reads in the order of their START POSITIONS (row k = read orig_of[k]): the
+    // reads of a 64-row block then lie next to each other on the contig, a tile of two blocks far apart has no read pair that shares a SNP
+    // -- it is not computed and not written (nobody reads it: a window only ever asks for pairs of reads that are both present at its
+    // first and its last SNP) -- and a tile that is computed only walks the words both blocks are present in.
     __shared__ uint64_t s_planes[4][64][SD_KW + 1];      // one array: the mirrored store below reuses it as a 64 x 65 int tile
+    __shared__ int s_rows[2][64];
+    __shared__ int s_rng[4];
     uint64_t (*sAi)[SD_KW + 1] = s_planes[0]; uint64_t (*sRi)[SD_KW + 1] = s_planes[1];
     uint64_t (*sAj)[SD_KW + 1] = s_planes[2]; uint64_t (*sRj)[SD_KW + 1] = s_planes[3];
     const int tid = (int)threadIdx.x;
@@ -1101,6 +1124,25 @@ __global__ __launch_bounds__(256) void k_simdiff(
     const int N = n_reads[c], W = words[c];
     const uint64_t* __restrict__ A = alt + plane_off[c];
     const uint64_t* __restrict__ R = ref + plane_off[c];
+    int w_begin = 0, w_end = W;
+    if (orig_of) {
+        const int64_t rb = read_base[c];
+        if (tid < 128) {      // wave 0: the i rows, wave 1: the j rows -- the read of every row and the words it is present in
+            const int side = tid >> 6, k = (side ? j0 : i0) + (tid & 63);
+            int lo = 0x7fffffff, hi = -1, rd = -1;
+            if (k < N) { rd = orig_of[rb + k]; lo = rng_lo[rb + rd]; hi = rng_hi[rb + rd]; }
+            s_rows[side][tid & 63] = rd;
+            lo = -wave_max_i32(-lo); hi = wave_max_i32(hi);
+            if ((tid & 63) == 0) { s_rng[2 * side] = lo; s_rng[2 * side + 1] = hi; }
+        }
+        __syncthreads();
+        w_begin = s_rng[0] > s_rng[2] ? s_rng[0] : s_rng[2];
+        const int e = s_rng[1] < s_rng[3] ? s_rng[1] : s_rng[3];
+        w_end = e + 1;
+        if (w_begin >= w_end) return;      // no word in common: every pair of the tile is (0, 0), and nobody asks
+        w_begin &= ~(SD_KW - 1);
+        if (w_end > W) w_end = W;
+    }
     const int ti = tid >> 4, tj = tid & 15;
     int s_acc[4][4], d_acc[4][4], u_acc[4][4];
 #pragma unroll
@@ -1108,12 +1150,13 @@ __global__ __launch_bounds__(256) void k_simdiff(
 #pragma unroll
         for (int b = 0; b < 4; ++b) { s_acc[a][b] = 0; d_acc[a][b] = 0; u_acc[a][b] = 0; }
 
-    for (int w0 = 0; w0 < W; w0 += SD_KW) {
+    for (int w0 = w_begin; w0 < w_end; w0 += SD_KW) {
         // stage 64 rows x SD_KW words of both planes for both sides (coalesced along words)
         for (int x = tid; x < 64 * SD_KW; x += 256) {
             const int row = x / SD_KW, w = x % SD_KW;
-            const int gi = i0 + row, gj = j0 + row, gw = w0 + w;
-            const bool wi = gi < N && gw < W, wj = gj < N && gw < W;
+            const int gw = w0 + w;
+            const int gi = orig_of ? s_rows[0][row] : (i0 + row < N ? i0 + row : -1), gj = orig_of ? s_rows[1][row] : (j0 + row < N ? j0 + row : -1);
+            const bool wi = gi >= 0 && gw < W, wj = gj >= 0 && gw < W;
             sAi[row][w] = wi ? A[(int64_t)gi * W + gw] : 0ull;
             sRi[row][w] = wi ? R[(int64_t)gi * W + gw] : 0ull;
             sAj[row][w] = wj ? A[(int64_t)gj * W + gw] : 0ull;

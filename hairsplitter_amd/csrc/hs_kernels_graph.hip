@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void k_read_graph_rows(
     int row_base, int n_rows, float below, int cap, unsigned long long* __restrict__ bits, unsigned long long* __restrict__ amb_head /* [0] rows left to the host, [1] staged entries */,
     int32_t* __restrict__ amb_rows, int amb_cap, const int64_t* __restrict__ win_mat_off, int es /* element stride of sim / diff: 2 = (sim, diff) pairs */,
     long long* __restrict__ amb_stage_off /* [amb_cap] where the row's entries were staged, -1: no room */, int32_t* __restrict__ stage_sim, int32_t* __restrict__ stage_diff,
-    long long stage_cap) {
+    long long stage_cap, const int32_t* __restrict__ pos_rank /* row / column of the contig's matrices that holds a read (the matrices are in the order of
+    the reads' start positions: k_simdiff), per contig at rank_off[c]; NULL: the read index itself */, const int64_t* __restrict__ rank_off) {
     extern __shared__ unsigned char s_dyn[];
     const int lane = lane_id();
     const int wv = wave_id(), waves = (int)(blockDim.x >> 6);
@@ -73,8 +74,10 @@ __global__ __launch_bounds__(256) void k_read_graph_rows(
     const int N = ctg_n[c];
     const int32_t* __restrict__ ids = mask_ids + m0;
     const int r1 = ids[i];
-    const int32_t* __restrict__ srow = LM ? sim + (win_mat_off[w] + (int64_t)i * m) * es : sim + (ctg_out_off[c] + (int64_t)r1 * N) * es;
-    const int32_t* __restrict__ drow = LM ? diff + (win_mat_off[w] + (int64_t)i * m) * es : diff + (ctg_out_off[c] + (int64_t)r1 * N) * es;
+    const int32_t* __restrict__ prk = (!LM && pos_rank) ? pos_rank + rank_off[c] : nullptr;
+    const int r1k = prk ? prk[r1] : r1;
+    const int32_t* __restrict__ srow = LM ? sim + (win_mat_off[w] + (int64_t)i * m) * es : sim + (ctg_out_off[c] + (int64_t)r1k * N) * es;
+    const int32_t* __restrict__ drow = LM ? diff + (win_mat_off[w] + (int64_t)i * m) * es : diff + (ctg_out_off[c] + (int64_t)r1k * N) * es;
     // a row the order statistics cannot decide goes to the host -- with its sim / diff entries (the N of the contig, or the m of a
     // window-local matrix) staged here, so that the host needs ONE transfer to resolve every such row of the call
     auto give_up = [&]() {
@@ -90,7 +93,8 @@ __global__ __launch_bounds__(256) void k_read_graph_rows(
         }
         so = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(so & 0xffffffffll), 0)) |
                          ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)so >> 32), 0) << 32));
-        if (so >= 0) for (int j = lane; j < len; j += 64) { stage_sim[so + j] = srow[(int64_t)j * es]; stage_diff[so + j] = drow[(int64_t)j * es]; }
+        // (staged in the order of the READ indices, whatever the order of the matrix: the host walks the row by read)
+        if (so >= 0) for (int j = lane; j < len; j += 64) { const int64_t at = (int64_t)(prk ? prk[j] : j) * es; stage_sim[so + j] = srow[at]; stage_diff[so + j] = drow[at]; }
     };
     if (m > cap || N < 2 || !(below >= 0.f)) { give_up(); return; }
 
@@ -99,7 +103,8 @@ __global__ __launch_bounds__(256) void k_read_graph_rows(
     bool nan_l = false;
     for (int j = lane; j < m; j += 64) {
         const int r = ids[j];
-        const int s = LM ? srow[(int64_t)j * es] : srow[(int64_t)r * es], dd = LM ? drow[(int64_t)j * es] : drow[(int64_t)r * es];
+        const int64_t at = (int64_t)(LM ? j : (prk ? prk[r] : r)) * es;
+        const int s = srow[at], dd = drow[at];
         float d = 0.f;
         if (LM) {
             if (r != r1) {
