@@ -10,12 +10,12 @@ except Exception as e: print('$tag failed', e)
 P
 }
 export HS_BENCH_NO_PROBE=1
-run sparse1 HS_X=1
-run dense1 HS_BENCH_DENSE_LABELS=1
-run sparse2 HS_X=1
-run dense2 HS_BENCH_DENSE_LABELS=1
-run twocalls HS_BENCH_TWO_CALLS=1
-run phase1 HS_ORDER_SCOPE=phase1
-run k2 HS_ORDER_SCOPE=k2
-EXTRA="--groups 10" run g10 HS_X=1
-EXTRA="--groups 6" run g6 HS_X=1
+timeout 600 python -m pytest tests/test_gpu_dropin.py -x -q -k "goldens or groups" 2>&1 | tail -2
+run prio1 HS_X=1
+run noprio1 HS_STREAM_PRIORITIES=0
+run prio2 HS_X=1
+run noprio2 HS_STREAM_PRIORITIES=0
+EXTRA="--groups 10" run prio_g10 HS_X=1
+EXTRA="--groups 12" run prio_g12 HS_X=1
+EXTRA="--groups 6" run prio_g6 HS_X=1
+run prio_shared HS_SHARED_POOL=1
