@@ -281,6 +281,50 @@ def test_pipeline_groups_equal_single_batch(built):
     single.close(); groups.close()
 
 
+
+def test_pipeline_options_sparse_labels_and_kept_columns(built):
+    """HS_PIPELINE_SPARSE_LABELS: per window the reads it holds and their labels == the non -2 entries of the dense array;
+    HS_PIPELINE_KEEP_COLUMNS: the groups' stage-3 results then carry the SNP columns' entries (.col's payload), equal to what the
+    single-batch call returns; neither option changes the labels; step after step (the second step runs on the sizes the first left)"""
+    import ctypes as C
+    from hairsplitter_amd import api, synth
+    contigs = [synth.make_contig(11, i, 24_000, 2 + (i % 3), 0.012, 36, "ont") for i in range(5)]
+    single = api.CvBatch(api.FlatBatch(contigs))
+    cv1, sr1 = single.run_pipeline(0.33, 8)
+    full = single.run(0.33, 8)      # stage 3 alone, entries on the host
+    pg = api.PipelineGroups(contigs, 3)
+    lib = api.load()
+    try:
+        dense = pg.run_fused(0.33, 8)[1]["labels"].copy()
+        assert np.array_equal(dense, sr1["labels"])
+        pg.sparse_labels(True)
+        pg.keep_columns(True)
+        for _ in range(3):
+            cv2, sr2 = pg.run_fused(0.33, 8)
+            assert sr2["labels"] is None
+            off, ids, lab = sr2["sparse"]
+            lo = sr2["label_off"]
+            rebuilt = np.full(int(lo[-1]), -2, np.int32)
+            for w in range(len(off) - 1):
+                rebuilt[lo[w] + ids[off[w]:off[w + 1]]] = lab[off[w]:off[w + 1]]
+            assert np.array_equal(rebuilt, sr1["labels"])
+            assert np.all(lab != -2)
+            # the groups' stage-3 results, concatenated in contig order, are the single call's
+            lib.hs_pipeline_group_cv.restype = C.POINTER(api.CvResult)
+            pos, idx, code = [], [], []
+            for g in range(lib.hs_pipeline_groups(pg.handle)):
+                r = lib.hs_pipeline_group_cv(pg.handle, C.c_int32(g)).contents
+                S = int(r.snp_off[r.n_contigs]); E = int(r.col_off[S])
+                assert bool(r.col_idx) and bool(r.col_code)
+                pos.append(np.ctypeslib.as_array(r.snp_pos, (max(S, 1),))[:S].copy())
+                idx.append(np.ctypeslib.as_array(r.col_idx, (max(E, 1),))[:E].copy())
+                code.append(np.ctypeslib.as_array(r.col_code, (max(E, 1),))[:E].copy())
+            assert np.array_equal(np.concatenate(pos), full["snp_pos"])
+            assert np.array_equal(np.concatenate(idx), full["col_idx"]) and np.array_equal(np.concatenate(code), full["col_code"])
+    finally:
+        pg.close(); single.close()
+
+
 def test_degenerate_batches(built):
     """empty and ragged inputs through the in-memory path: no contigs; a single contig spread over more groups than contigs;
     a contig without reads and a contig without SNPs next to a normal one"""
