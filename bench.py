@@ -435,7 +435,7 @@ def main():
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if tj.get("_config") == cfg and tj.get("_contigs") == n_job and world == 1:
+                if tj.get("_config") == cfg and tj.get("_contigs") == n_job and world == 1 and tj.get("_groups", tj.get("_groups_per_gpu")) == 1:      # (per launch of the whole job, like `achieved`)
                     traffic = tj.get(dom)      # HBM bytes per launch from the PMC passes at THIS size (tools/pmc_traffic.sh)
                     traffic_src = {"file": "profiles/traffic_latest.json", "measured_at_commit": tj.get("_commit"), "groups": tj.get("_groups"),
                                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this command (tools/pmc_traffic.sh), stored, not measured in this run"}

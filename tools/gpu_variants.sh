@@ -10,12 +10,12 @@ except Exception as e: print('$tag failed', e)
 P
 }
 export HS_BENCH_NO_PROBE=1
-timeout 600 python -m pytest tests/test_gpu_dropin.py -x -q -k "goldens or groups" 2>&1 | tail -2
-run prio1 HS_X=1
-run noprio1 HS_STREAM_PRIORITIES=0
-run prio2 HS_X=1
-run noprio2 HS_STREAM_PRIORITIES=0
-EXTRA="--groups 10" run prio_g10 HS_X=1
-EXTRA="--groups 12" run prio_g12 HS_X=1
-EXTRA="--groups 6" run prio_g6 HS_X=1
-run prio_shared HS_SHARED_POOL=1
+run base1 HS_X=1
+EXTRA="--threads 64" run t64 HS_X=1
+EXTRA="--threads 96" run t96 HS_X=1
+EXTRA="--threads 32" run t32 HS_X=1
+run shared HS_SHARED_POOL=1
+run shared24 HS_SHARED_POOL=1 HS_POOL_THREADS=24
+run taper05 HS_GROUP_TAPER=0.5
+run taper03 HS_GROUP_TAPER=0.3
+run base2 HS_X=1
