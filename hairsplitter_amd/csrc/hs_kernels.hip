@@ -857,13 +857,14 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled(
 __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
     const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, int64_t total, int min_second,
     int32_t* __restrict__ sel_count, int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int64_t tile0, int64_t g_lo, int64_t g_hi,
-    int32_t* __restrict__ sel_ent) {
+    int32_t* __restrict__ sel_ent, uint2* __restrict__ sel_info /* NULL: the plain selection, no leading codes */) {
     constexpr int NWORDS = (HS_NBINS + 3) / 4;
-    // exactly 32 KB of LDS (five workgroups per CU): the ballots of the selection reuse the histogram's first bytes once every
-    // thread has read its column
+    static_assert(NWORDS == 32, "the second pass splits 32 counter words over four wavefronts");
     __shared__ __attribute__((aligned(16))) uint32_t hw[NWORDS * 256];
-    unsigned long long* const s_b = reinterpret_cast<unsigned long long*>(hw);
-    int* const s_e = reinterpret_cast<int*>(hw) + 8;
+    __shared__ unsigned long long s_b[4];
+    __shared__ int s_e[4];
+    __shared__ uint32_t s_item[256];          // the selected positions in position order: scanning thread | c0 << 8 | c1 << 16 | depth << 24
+    __shared__ uint32_t s_part[4][3][64];     // per wavefront and item of the round: the three largest (count << 8 | code) of its eight counter words, two per dword
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wv = wave_id();
     const int64_t tile = tile0 + (int64_t)blockIdx.x;
@@ -946,7 +947,6 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
     const bool sel = g < total && g >= g_lo && g < g_hi && (c1 > min_second || (c1 == min_second && !third));
     const unsigned long long mine = __ballot(sel);
     const int we = wave_sum_i32(sel ? depth : 0);
-    __syncthreads();      // (every column has been read)
     if (lane == 0) { s_b[wv] = mine; s_e[wv] = we; }
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -957,11 +957,88 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
         rank += __popcll(bk & below) + ((k < wv) ? (int)((bk >> lane) & 1ull) : 0);
         n_sel += __popcll(bk);
     }
-    if (sel) {
-        const int64_t slot = (int64_t)blockIdx.x * 256 + rank;
-        sel_gpos[slot] = g; sel_depth[slot] = depth;
+    if (!sel_info) {
+        if (sel) {
+            const int64_t slot = (int64_t)blockIdx.x * 256 + rank;
+            sel_gpos[slot] = g; sel_depth[slot] = depth;
+        }
+        if (tid == 0) { sel_count[blockIdx.x] = n_sel; if (sel_ent) sel_ent[blockIdx.x] = s_e[0] + s_e[1] + s_e[2] + s_e[3]; }
+        return;
     }
-    if (tid == 0) { sel_count[blockIdx.x] = n_sel; if (sel_ent) sel_ent[blockIdx.x] = s_e[0] + s_e[1] + s_e[2] + s_e[3]; }
+    // ---- the leading codes of the selected positions, from the counters that are still in LDS (call_variants.cpp:477-507: the three
+    // largest counts and the codes of the first two), and only the positions the path can use go on: a position whose three
+    // counts are distinct has ONE order of its leading codes, the predicate of :527-528 (also loop D's, :751-752) can be asked here;
+    // what fails it, or has neither five reads of the second code nor more than five times the third count, is read by nobody
+    // (k_candidates_scan, K4). Positions with equal leading counts go on undecided (flag HS_COL_TIE): k_column_top3_exact orders
+    // them as the reference does once their reads are gathered. Items = selected positions in position order, lane = item, the 32
+    // counter words of an item's column split over the four wavefronts; keys (count << 8 | code) as packed 16-bit pairs. ----
+    if (n_sel == 0) { if (tid == 0) { sel_count[blockIdx.x] = 0; if (sel_ent) sel_ent[blockIdx.x] = 0; } return; }
+    if (sel) s_item[rank] = (uint32_t)tid | ((uint32_t)c0 << 8) | ((uint32_t)c1 << 16) | ((uint32_t)depth << 24);      // (byte counters: depth <= 255)
+    __syncthreads();
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    auto pk = [](uint32_t x) { return __builtin_bit_cast(us2, x); };
+    auto insert3 = [](us2& t0, us2& t1, us2& t2, const us2 v) {
+        const us2 lo0 = __builtin_elementwise_min(v, t0); t0 = __builtin_elementwise_max(v, t0);
+        const us2 lo1 = __builtin_elementwise_min(lo0, t1); t1 = __builtin_elementwise_max(lo0, t1);
+        t2 = __builtin_elementwise_max(lo1, t2);
+    };
+    auto merge3 = [](us2& a0, us2& a1, us2& a2, const us2 b0, const us2 b1, const us2 b2) {      // two descending triples -> the three largest of the six
+        const us2 m = __builtin_elementwise_min(a0, b0), x = __builtin_elementwise_max(a1, b1), y = __builtin_elementwise_min(a1, b1);
+        a0 = __builtin_elementwise_max(a0, b0);
+        a1 = __builtin_elementwise_max(m, x);
+        a2 = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_min(m, x), y), __builtin_elementwise_max(a2, b2));
+    };
+    int n_kept = 0, e_kept = 0;      // (wavefront 0's)
+    for (int r0 = 0; r0 < n_sel; r0 += 64) {
+        const int item = r0 + lane;
+        const uint32_t inf = s_item[item < n_sel ? item : 0];
+        {
+            const uint32_t* __restrict__ col = hw + (inf & 255u) + (unsigned)(8 * wv) * 256u;
+            us2 a0 = {0, 0}, a1 = {0, 0}, a2 = {0, 0}, b0 = {0, 0}, b1 = {0, 0}, b2 = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t word = col[j * 256];
+                const uint32_t idw = (uint32_t)(4 * (8 * wv + j)) * 0x00010001u;      // (wave-uniform)
+                // bytes 0 and 2 -> codes 4 w, 4 w + 2; bytes 1 and 3 -> codes 4 w + 1, 4 w + 3
+                insert3(a0, a1, a2, pk(((word & 0x00ff00ffu) << 8) | (idw | 0x00020000u)));
+                insert3(b0, b1, b2, pk((word & 0xff00ff00u) | (idw | 0x00030001u)));
+            }
+            merge3(a0, a1, a2, b0, b1, b2);
+            s_part[wv][0][lane] = __builtin_bit_cast(uint32_t, a0); s_part[wv][1][lane] = __builtin_bit_cast(uint32_t, a1); s_part[wv][2][lane] = __builtin_bit_cast(uint32_t, a2);
+        }
+        __syncthreads();
+        if (wv == 0) {
+            us2 a0 = pk(s_part[0][0][lane]), a1 = pk(s_part[0][1][lane]), a2 = pk(s_part[0][2][lane]);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) merge3(a0, a1, a2, pk(s_part[w][0][lane]), pk(s_part[w][1][lane]), pk(s_part[w][2][lane]));
+            // the two halves of the packed triple -> one triple of 32-bit keys
+            const uint32_t l0 = a0.x, l1 = a1.x, l2 = a2.x, h0 = a0.y, h1 = a1.y, h2 = a2.y;
+            const uint32_t m = l0 < h0 ? l0 : h0, x = l1 > h1 ? l1 : h1, y = l1 < h1 ? l1 : h1;
+            const uint32_t K0 = l0 > h0 ? l0 : h0, K1 = m > x ? m : x;
+            uint32_t K2 = m < x ? m : x; K2 = K2 > y ? K2 : y; K2 = K2 > l2 ? K2 : l2; K2 = K2 > h2 ? K2 : h2;
+            const int n0 = (int)(K0 >> 8), n1 = (int)(K1 >> 8), n2 = (int)(K2 >> 8);
+            const int k0 = 33 + (int)(K0 & 255u), k1 = 33 + (int)(K1 & 255u);
+            const bool tie = n0 == n1 || n1 == n2 || n1 == 0;
+            const bool gt5 = n1 > 5 * n2;
+            // call_variants.cpp:527-528 / :751-752 on the raw code bytes
+            const bool central = k0 % 5 != k1 % 5 && ((k1 - 33) % 5 != 4 || (k1 / 5 % 5 != k0 % 5 && k1 / 25 % 5 != k0 % 5));
+            const bool keep = item < n_sel && (tie || (central && (n1 >= 5 || gt5)));
+            const unsigned long long km = __ballot(keep);
+            const int d = (int)(inf >> 24);
+            if (keep) {
+                const int64_t slot = (int64_t)blockIdx.x * 256 + n_kept + __popcll(km & below);
+                const int t_scan = (int)(inf & 255u);
+                sel_gpos[slot] = tile * 256 + 4 * (t_scan & 63) + (t_scan >> 6);
+                sel_depth[slot] = d;
+                sel_info[slot] = make_uint2((uint32_t)n0 | ((uint32_t)n1 << 16),
+                                            (uint32_t)k0 | ((uint32_t)k1 << 8) | ((tie ? 32u /* HS_COL_TIE */ : 0u) | (gt5 ? 64u /* HS_COL_C1GT5C2 */ : 0u)) << 16 | (n2 == 0 ? 1u : 0u) << 24 | 0x80000000u);
+            }
+            n_kept += __popcll(km);
+            e_kept += wave_sum_i32(keep ? d : 0);
+        }
+        if (r0 + 64 < n_sel) __syncthreads();      // (s_part is written again)
+    }
+    if (tid == 0) { sel_count[blockIdx.x] = n_kept; if (sel_ent) sel_ent[blockIdx.x] = e_kept; }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -45,7 +45,7 @@ struct ColumnsHeader {      // what the host reads between the phases (one small
     int64_t n_flagged, n_flagged_entries;   // candidates (after k_candidates_scan + k_flag_block_sums/_offsets) or SNPs (after k_snp_flags + ...)
     int64_t n_tie, n_tie_big;           // columns whose order went through the emulator / through std::sort's non-stable part
     int64_t ok;                         // the column arrays' capacities hold n_cols / n_entries (k_columns_compact): 0 makes every later kernel of the pass a no-op
-    int64_t pad;
+    int64_t n_undecided;                // columns K2 left to k_column_top3_exact (equal leading counts; every column when K2 ran without its second pass)
 };
 static __device__ __forceinline__ int64_t header_cols(const ColumnsHeader* __restrict__ h) { return h->ok ? h->n_cols : 0; }
 
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void k_columns_compact(
     const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_base, const int64_t* __restrict__ tile_ebase,
     const int64_t* __restrict__ scratch_gpos, const int32_t* __restrict__ scratch_depth, int64_t n_tiles,
     const int64_t* __restrict__ contig_off, int n_contigs, int64_t* __restrict__ col_gpos, hs_colrec_dev* __restrict__ col_rec,
-    int64_t* __restrict__ col_off, int32_t* __restrict__ col_len, ColumnsHeader* __restrict__ header, int64_t cap_cols, int64_t cap_entries) {
+    int64_t* __restrict__ col_off, int32_t* __restrict__ col_len, ColumnsHeader* __restrict__ header, int64_t cap_cols, int64_t cap_entries,
+    const uint2* __restrict__ scratch_info /* K2's leading codes per slot, or NULL */, int32_t* __restrict__ undecided /* [cap_cols] */) {
     __shared__ int s_wsum[4];
     const int64_t t = blockIdx.x;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -79,18 +80,37 @@ __global__ __launch_bounds__(256) void k_columns_compact(
         header->ok = (tile_base[n_tiles] <= cap_cols && tile_ebase[n_tiles] <= cap_entries) ? 1 : 0;
         if (tile_base[n_tiles] <= cap_cols) col_off[tile_base[n_tiles]] = tile_ebase[n_tiles];
     }
-    if (!mine) return;
     const int64_t k = tile_base[t] + tid;
-    if (k >= cap_cols) return;
-    const int64_t g = scratch_gpos[t * 256 + tid];
-    int lo = 0, hi = n_contigs - 1;
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (contig_off[mid] <= g) lo = mid; else hi = mid - 1; }
-    col_gpos[k] = g;
-    col_off[k] = tile_ebase[t] + before + incl - depth;
-    col_len[k] = depth;
-    hs_colrec_dev r;
-    r.pos = (int32_t)(g - contig_off[lo]); r.contig = lo; r.c0 = 0; r.c1 = 0; r.k0 = 0; r.k1 = 0; r.flags = 0; r.c2_zero = 0;
-    col_rec[k] = r;
+    const bool live = mine && k < cap_cols;
+    bool open = false;
+    if (live) {
+        const int64_t g = scratch_gpos[t * 256 + tid];
+        int lo = 0, hi = n_contigs - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (contig_off[mid] <= g) lo = mid; else hi = mid - 1; }
+        col_gpos[k] = g;
+        col_off[k] = tile_ebase[t] + before + incl - depth;
+        col_len[k] = depth;
+        hs_colrec_dev r;
+        r.pos = (int32_t)(g - contig_off[lo]); r.contig = lo; r.c0 = 0; r.c1 = 0; r.k0 = 0; r.k1 = 0; r.flags = 0; r.c2_zero = 0;
+        open = true;
+        if (scratch_info) {
+            const uint2 inf = scratch_info[t * 256 + tid];
+            if (inf.y & 0x80000000u) {
+                r.c0 = (uint16_t)(inf.x & 0xffffu); r.c1 = (uint16_t)(inf.x >> 16);
+                r.k0 = (uint8_t)(inf.y & 255u); r.k1 = (uint8_t)((inf.y >> 8) & 255u); r.flags = (uint8_t)((inf.y >> 16) & 255u); r.c2_zero = (uint8_t)((inf.y >> 24) & 1u);
+                open = (r.flags & HS_COL_TIE) != 0;
+            }
+        }
+        col_rec[k] = r;
+    }
+    // the columns whose leading codes are still open: one list, one atomic per wavefront
+    const unsigned long long om = __ballot(open);
+    if (om) {
+        long long base = 0;
+        if (lane == 0) base = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(&header->n_undecided), (unsigned long long)__popcll(om));
+        base = ((long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffll));
+        if (open) undecided[base + __popcll(om & ((1ull << lane) - 1ull))] = (int32_t)k;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -178,7 +198,8 @@ __global__ __launch_bounds__(256) void k_gather_tiles(
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_len,
                                                            const uint8_t* __restrict__ col_code, const ColumnsHeader* __restrict__ header,
-                                                           hs_colrec_dev* __restrict__ col_rec, unsigned long long* __restrict__ n_tie /* [2] */) {
+                                                           hs_colrec_dev* __restrict__ col_rec, unsigned long long* __restrict__ n_tie /* [2] */,
+                                                           const int32_t* __restrict__ list /* the columns to do (header->n_undecided of them), or NULL: all */) {
     __shared__ int s_hist[4][128];
     __shared__ uint8_t s_info[4][512], s_key[4][512], s_tmp[4][512];
     __shared__ uint32_t s_sort[4][136];
@@ -187,9 +208,10 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
     __shared__ int s_fpos[4][128];
     const int lane = lane_id();
     const int wv = wave_id();
-    const int64_t n_cols = header_cols(header);
+    const int64_t n_cols = list ? (header->ok ? header->n_undecided : 0) : header_cols(header);
     int* __restrict__ h = s_hist[wv];
-    for (int64_t col = (int64_t)blockIdx.x * 4 + wv; col < n_cols; col += (int64_t)gridDim.x * 4) {
+    for (int64_t f = (int64_t)blockIdx.x * 4 + wv; f < n_cols; f += (int64_t)gridDim.x * 4) {
+        const int64_t col = list ? (int64_t)list[f] : f;
         h[lane] = 0; h[lane + 64] = 0;
         wave_lds_sync();
         const int64_t b = col_off[col];
