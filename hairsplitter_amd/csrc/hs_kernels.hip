@@ -854,17 +854,18 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled(
 // at 30x with 10-kb reads -- needs no range test at all (wave-uniform branch). Counter word w of position p lives at
 // [w][p % 4][p / 4]: for a fixed byte of the dword the 64 lanes hit 64 different banks. The final scan gives every thread one
 // column (thread t: position 4 (t % 64) + t / 64); the selection is written in position order through the four ballots.
-__global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
+template <bool TOP /* the leading codes of the selection from the counters, only the positions the path reads go on */>
+static __device__ __forceinline__ void column_stats_tiled_dw_body(
     const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, int64_t total, int min_second,
     int32_t* __restrict__ sel_count, int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int64_t tile0, int64_t g_lo, int64_t g_hi,
-    int32_t* __restrict__ sel_ent, uint2* __restrict__ sel_info /* NULL: the plain selection, no leading codes */) {
+    int32_t* __restrict__ sel_ent, uint2* __restrict__ sel_info) {
     constexpr int NWORDS = (HS_NBINS + 3) / 4;
     static_assert(NWORDS == 32, "the second pass splits 32 counter words over four wavefronts");
     __shared__ __attribute__((aligned(16))) uint32_t hw[NWORDS * 256];
     __shared__ unsigned long long s_b[4];
     __shared__ int s_e[4];
-    __shared__ uint32_t s_item[256];          // the selected positions in position order: scanning thread | c0 << 8 | c1 << 16 | depth << 24
-    __shared__ uint32_t s_part[4][3][64];     // per wavefront and item of the round: the three largest (count << 8 | code) of its eight counter words, two per dword
+    __shared__ uint8_t s_item[TOP ? 256 : 4];       // TOP: the scanning threads of the positions that go to the second pass, in position order
+    __shared__ uint32_t s_part[TOP ? 4 : 1][4][64];  // per wavefront and item of the round: the three largest (count << 8 | code) of its eight counter words, two per dword; their sum
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63, wv = wave_id();
     const int64_t tile = tile0 + (int64_t)blockIdx.x;
@@ -917,6 +918,22 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
     // ---- thread t scans column t = the counters of position 4 (t % 64) + t / 64 ----
     const int64_t g = tile * 256 + 4 * lane + wv;
     int c0 = 0, c1 = 0, depth = 0;
+    bool sel;
+    if (TOP) {
+        // Only "can the second count reach the floor": at least two counters >= min_second (4: the bits above the low two). Exactly what
+        // is selected is decided in the second pass, which has the three largest counts -- this scan is 5 instructions per counter
+        // word instead of 9 (it was 55 % of the kernel's instructions).
+        int small = 0;      // counters below 4 (of the 128 bytes of the column)
+        if (g < total) {
+#pragma unroll 8
+            for (int w = 0; w < NWORDS; ++w) {
+                const uint32_t word = hw[w * 256 + tid];
+                const uint32_t q = (word >> 2) & 0x3f3f3f3fu;                       // count / 4 per byte
+                small += __builtin_popcount((0x80808080u - q) & 0x80808080u);      // 0x80 - q keeps bit 7 only for q == 0 (no borrow: q <= 63)
+            }
+        }
+        sel = g < total && g >= g_lo && g < g_hi && ((128 - small) >= 2 || min_second < 4);      // (a floor below 4: every position to the second pass)
+    } else {
     if (g < total) {
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
         us2 m0a = {0, 0}, m1a = {0, 0}, m0b = {0, 0}, m1b = {0, 0};
@@ -944,7 +961,8 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
     }
     const bool third = depth > c0 + c1;      // a third non-empty bin <=> reads beyond the two largest counts
     // selection in position order: second count above the floor, or exactly at it with no third allele (see column_stats_tail)
-    const bool sel = g < total && g >= g_lo && g < g_hi && (c1 > min_second || (c1 == min_second && !third));
+    sel = g < total && g >= g_lo && g < g_hi && (c1 > min_second || (c1 == min_second && !third));
+    }
     const unsigned long long mine = __ballot(sel);
     const int we = wave_sum_i32(sel ? depth : 0);
     if (lane == 0) { s_b[wv] = mine; s_e[wv] = we; }
@@ -957,7 +975,7 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
         rank += __popcll(bk & below) + ((k < wv) ? (int)((bk >> lane) & 1ull) : 0);
         n_sel += __popcll(bk);
     }
-    if (!sel_info) {
+    if (!TOP) {
         if (sel) {
             const int64_t slot = (int64_t)blockIdx.x * 256 + rank;
             sel_gpos[slot] = g; sel_depth[slot] = depth;
@@ -973,7 +991,7 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
     // them as the reference does once their reads are gathered. Items = selected positions in position order, lane = item, the 32
     // counter words of an item's column split over the four wavefronts; keys (count << 8 | code) as packed 16-bit pairs. ----
     if (n_sel == 0) { if (tid == 0) { sel_count[blockIdx.x] = 0; if (sel_ent) sel_ent[blockIdx.x] = 0; } return; }
-    if (sel) s_item[rank] = (uint32_t)tid | ((uint32_t)c0 << 8) | ((uint32_t)c1 << 16) | ((uint32_t)depth << 24);      // (byte counters: depth <= 255)
+    if (sel) s_item[rank] = (uint8_t)tid;
     __syncthreads();
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     auto pk = [](uint32_t x) { return __builtin_bit_cast(us2, x); };
@@ -991,13 +1009,15 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
     int n_kept = 0, e_kept = 0;      // (wavefront 0's)
     for (int r0 = 0; r0 < n_sel; r0 += 64) {
         const int item = r0 + lane;
-        const uint32_t inf = s_item[item < n_sel ? item : 0];
+        const uint32_t t_scan = s_item[item < n_sel ? item : 0];
         {
-            const uint32_t* __restrict__ col = hw + (inf & 255u) + (unsigned)(8 * wv) * 256u;
+            const uint32_t* __restrict__ col = hw + t_scan + (unsigned)(8 * wv) * 256u;
             us2 a0 = {0, 0}, a1 = {0, 0}, a2 = {0, 0}, b0 = {0, 0}, b1 = {0, 0}, b2 = {0, 0};
+            uint32_t dsum = 0;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const uint32_t word = col[j * 256];
+                dsum = __builtin_amdgcn_sad_u8(word, 0u, dsum);
                 const uint32_t idw = (uint32_t)(4 * (8 * wv + j)) * 0x00010001u;      // (wave-uniform)
                 // bytes 0 and 2 -> codes 4 w, 4 w + 2; bytes 1 and 3 -> codes 4 w + 1, 4 w + 3
                 insert3(a0, a1, a2, pk(((word & 0x00ff00ffu) << 8) | (idw | 0x00020000u)));
@@ -1005,6 +1025,7 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
             }
             merge3(a0, a1, a2, b0, b1, b2);
             s_part[wv][0][lane] = __builtin_bit_cast(uint32_t, a0); s_part[wv][1][lane] = __builtin_bit_cast(uint32_t, a1); s_part[wv][2][lane] = __builtin_bit_cast(uint32_t, a2);
+            s_part[wv][3][lane] = dsum;
         }
         __syncthreads();
         if (wv == 0) {
@@ -1022,13 +1043,14 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
             const bool gt5 = n1 > 5 * n2;
             // call_variants.cpp:527-528 / :751-752 on the raw code bytes
             const bool central = k0 % 5 != k1 % 5 && ((k1 - 33) % 5 != 4 || (k1 / 5 % 5 != k0 % 5 && k1 / 25 % 5 != k0 % 5));
-            const bool keep = item < n_sel && (tie || (central && (n1 >= 5 || gt5)));
+            // the selection itself (second count above the floor, or exactly at it with no third allele: column_stats_tail), then what the path reads
+            const bool chosen = n1 > min_second || (n1 == min_second && n2 == 0);
+            const bool keep = item < n_sel && chosen && (tie || (central && (n1 >= 5 || gt5)));
             const unsigned long long km = __ballot(keep);
-            const int d = (int)(inf >> 24);
+            const int d = (int)(s_part[0][3][lane] + s_part[1][3][lane] + s_part[2][3][lane] + s_part[3][3][lane]);
             if (keep) {
                 const int64_t slot = (int64_t)blockIdx.x * 256 + n_kept + __popcll(km & below);
-                const int t_scan = (int)(inf & 255u);
-                sel_gpos[slot] = tile * 256 + 4 * (t_scan & 63) + (t_scan >> 6);
+                sel_gpos[slot] = tile * 256 + 4 * (int)(t_scan & 63u) + (int)(t_scan >> 6);
                 sel_depth[slot] = d;
                 sel_info[slot] = make_uint2((uint32_t)n0 | ((uint32_t)n1 << 16),
                                             (uint32_t)k0 | ((uint32_t)k1 << 8) | ((tie ? 32u /* HS_COL_TIE */ : 0u) | (gt5 ? 64u /* HS_COL_C1GT5C2 */ : 0u)) << 16 | (n2 == 0 ? 1u : 0u) << 24 | 0x80000000u);
@@ -1039,6 +1061,19 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
         if (r0 + 64 < n_sel) __syncthreads();      // (s_part is written again)
     }
     if (tid == 0) { sel_count[blockIdx.x] = n_kept; if (sel_ent) sel_ent[blockIdx.x] = e_kept; }
+}
+__global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
+    const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, int64_t total, int min_second,
+    int32_t* __restrict__ sel_count, int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int64_t tile0, int64_t g_lo, int64_t g_hi,
+    int32_t* __restrict__ sel_ent, uint2* __restrict__ sel_info) {
+    column_stats_tiled_dw_body<true>(pile, tile_off, tile_ent, total, min_second, sel_count, sel_gpos, sel_depth, tile0, g_lo, g_hi, sel_ent, sel_info);
+}
+// (the selection alone: HS_K2_PLAIN, and where the leading codes are not wanted)
+__global__ __launch_bounds__(256) void k_column_stats_tiled_dw_plain(
+    const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, int64_t total, int min_second,
+    int32_t* __restrict__ sel_count, int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int64_t tile0, int64_t g_lo, int64_t g_hi,
+    int32_t* __restrict__ sel_ent) {
+    column_stats_tiled_dw_body<false>(pile, tile_off, tile_ent, total, min_second, sel_count, sel_gpos, sel_depth, tile0, g_lo, g_hi, sel_ent, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -2,7 +2,6 @@
 R=/root/repo
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
-rm -rf $R/gpurun_out/ktrace
 HS_ORDER_SCOPE=${HS_ORDER_SCOPE:-k2} HS_NO_KERNEL_STATS=1 HS_BENCH_NO_PROBE=1 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/ktrace -o kt -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-contigs 0 > $R/gpurun_out/ktrace.json 2> $R/gpurun_out/ktrace.err
 f=$(find $R/gpurun_out/ktrace -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'P'
@@ -86,4 +85,10 @@ for s_, e_, n, q in l:
     print('  %-34s start %7.3f dur %6.3f gap-before %6.3f' % (n[:34], (s_ - t0) / 1e6, (e_ - s_) / 1e6, gap))
     prev_end = max(prev_end, e_) if prev_end is not None else e_
 P
+python3 - "$f" > $R/gpurun_out/ktrace_rows.tsv <<'P'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    print('\t'.join([r['Start_Timestamp'], r['End_Timestamp'], r['Thread_Id'], r['Queue_Id'], r['Kernel_Name'].split('(')[0].replace('void ','').replace('hsdev::','')[:40], r['Grid_Size_X'], r['Workgroup_Size_X']]))
+P
+gzip -f $R/gpurun_out/ktrace_rows.tsv
 rm -rf $R/gpurun_out/ktrace
