@@ -224,6 +224,7 @@ void free_sr_result(hs_sr_result* r) {
 
 static std::atomic<double> g_trace_origin{0.0};
 void set_trace_origin() { g_trace_origin.store(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count()); }
+double trace_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - g_trace_origin.load(); }
 namespace {
 struct Laps {   // HS_TIMING: fine-grained wall clock of a stage driver (HS_TIMING=cpu: wall/CPU time of the calling thread; HS_TIMING=abs: the
                 // end of every lap in ms since the start of the pipeline call, so that the chains of the contig groups can be laid side by side)

@@ -241,6 +241,7 @@ struct SrDeviceOps {
 };
 
 void set_trace_origin();   // HS_TIMING=abs: laps are printed relative to this moment
+double trace_ms();         // milliseconds since then
 int host_threads();      // default number of host worker threads: usable cores (cgroup quota), at most 32
 
 // The labels of a result before they are spread over the N reads of each window: per window the reads it holds (ascending
