@@ -10,6 +10,9 @@
 #include <hip/hip_runtime.h>
 #include <malloc.h>
 #include <sys/prctl.h>
+#include <sys/resource.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <condition_variable>
 #include <functional>
 #include <thread>
