@@ -10,9 +10,6 @@
 #include <hip/hip_runtime.h>
 #include <malloc.h>
 #include <sys/prctl.h>
-#include <sys/resource.h>
-#include <sys/syscall.h>
-#include <unistd.h>
 #include <condition_variable>
 #include <functional>
 #include <thread>
