@@ -39,13 +39,14 @@ static_assert(sizeof(hs_colrec_dev) == 16, "hs_colrec must be 16 bytes");
 #define HS_COL_SNP 16       // in the output
 #define HS_COL_TIE 32       // its top-3 needed the reference's order of equal counts
 #define HS_COL_C1GT5C2 64   // second count > 5 x third count (call_variants.cpp:526; the third count itself is not kept)
+#define HS_COL_OPEN 128     // between k_columns_compact and k_column_top3_exact: the leading codes are not decided yet (equal counts, or K2 ran without its second pass)
 
 struct ColumnsHeader {      // what the host reads between the phases (one small download)
     int64_t n_cols, n_entries;          // extracted columns / their entries
     int64_t n_flagged, n_flagged_entries;   // candidates (after k_candidates_scan + k_flag_block_sums/_offsets) or SNPs (after k_snp_flags + ...)
     int64_t n_tie, n_tie_big;           // columns whose order went through the emulator / through std::sort's non-stable part
     int64_t ok;                         // the column arrays' capacities hold n_cols / n_entries (k_columns_compact): 0 makes every later kernel of the pass a no-op
-    int64_t n_undecided;                // columns K2 left to k_column_top3_exact (equal leading counts; every column when K2 ran without its second pass)
+    int64_t pad;
 };
 static __device__ __forceinline__ int64_t header_cols(const ColumnsHeader* __restrict__ h) { return h->ok ? h->n_cols : 0; }
 
@@ -63,53 +64,47 @@ __global__ __launch_bounds__(256) void k_columns_compact(
     const int64_t* __restrict__ scratch_gpos, const int32_t* __restrict__ scratch_depth, int64_t n_tiles,
     const int64_t* __restrict__ contig_off, int n_contigs, int64_t* __restrict__ col_gpos, hs_colrec_dev* __restrict__ col_rec,
     int64_t* __restrict__ col_off, int32_t* __restrict__ col_len, ColumnsHeader* __restrict__ header, int64_t cap_cols, int64_t cap_entries,
-    const uint2* __restrict__ scratch_info /* K2's leading codes per slot, or NULL */, int32_t* __restrict__ undecided /* [cap_cols] */) {
-    __shared__ int s_wsum[4];
-    const int64_t t = blockIdx.x;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int cnt = tile_cnt[t];
-    const bool mine = tid < cnt;
-    const int depth = mine ? scratch_depth[t * 256 + tid] : 0;
-    const int incl = wave_scan_incl(depth);
-    if (lane == 63) s_wsum[wv] = incl;
-    __syncthreads();
-    int before = 0;
-    for (int w = 0; w < wv; ++w) before += s_wsum[w];
-    if (t == n_tiles - 1 && tid == 0) {
+    const uint2* __restrict__ scratch_info /* K2's leading codes per slot, or NULL */) {
+    // one wavefront per tile (a tile keeps a handful of its 256 positions since K2 drops what nobody reads), 64 slots at a time
+    const int lane = lane_id();
+    const int64_t t = (int64_t)blockIdx.x * 4 + wave_id();
+    if (t >= n_tiles) return;
+    if (t == n_tiles - 1 && lane == 0) {
         header->n_cols = tile_base[n_tiles]; header->n_entries = tile_ebase[n_tiles];
         header->ok = (tile_base[n_tiles] <= cap_cols && tile_ebase[n_tiles] <= cap_entries) ? 1 : 0;
         if (tile_base[n_tiles] <= cap_cols) col_off[tile_base[n_tiles]] = tile_ebase[n_tiles];
     }
-    const int64_t k = tile_base[t] + tid;
-    const bool live = mine && k < cap_cols;
-    bool open = false;
-    if (live) {
-        const int64_t g = scratch_gpos[t * 256 + tid];
-        int lo = 0, hi = n_contigs - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (contig_off[mid] <= g) lo = mid; else hi = mid - 1; }
-        col_gpos[k] = g;
-        col_off[k] = tile_ebase[t] + before + incl - depth;
-        col_len[k] = depth;
-        hs_colrec_dev r;
-        r.pos = (int32_t)(g - contig_off[lo]); r.contig = lo; r.c0 = 0; r.c1 = 0; r.k0 = 0; r.k1 = 0; r.flags = 0; r.c2_zero = 0;
-        open = true;
-        if (scratch_info) {
-            const uint2 inf = scratch_info[t * 256 + tid];
-            if (inf.y & 0x80000000u) {
-                r.c0 = (uint16_t)(inf.x & 0xffffu); r.c1 = (uint16_t)(inf.x >> 16);
-                r.k0 = (uint8_t)(inf.y & 255u); r.k1 = (uint8_t)((inf.y >> 8) & 255u); r.flags = (uint8_t)((inf.y >> 16) & 255u); r.c2_zero = (uint8_t)((inf.y >> 24) & 1u);
-                open = (r.flags & HS_COL_TIE) != 0;
+    const int cnt = tile_cnt[t];
+    if (cnt == 0) return;
+    const int64_t k0 = tile_base[t], e0 = tile_ebase[t];
+    int before = 0;
+    for (int s0 = 0; s0 < cnt; s0 += 64) {
+        const int slot = s0 + lane;
+        const bool mine = slot < cnt;
+        const int depth = mine ? scratch_depth[t * 256 + slot] : 0;
+        const int incl = wave_scan_incl(depth);
+        const int64_t k = k0 + slot;
+        const bool live = mine && k < cap_cols;
+        if (live) {
+            const int64_t g = scratch_gpos[t * 256 + slot];
+            int lo = 0, hi = n_contigs - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (contig_off[mid] <= g) lo = mid; else hi = mid - 1; }
+            col_gpos[k] = g;
+            col_off[k] = e0 + before + incl - depth;
+            col_len[k] = depth;
+            hs_colrec_dev r;
+            r.pos = (int32_t)(g - contig_off[lo]); r.contig = lo; r.c0 = 0; r.c1 = 0; r.k0 = 0; r.k1 = 0; r.flags = HS_COL_OPEN; r.c2_zero = 0;
+            if (scratch_info) {
+                const uint2 inf = scratch_info[t * 256 + slot];
+                if (inf.y & 0x80000000u) {
+                    r.c0 = (uint16_t)(inf.x & 0xffffu); r.c1 = (uint16_t)(inf.x >> 16);
+                    r.k0 = (uint8_t)(inf.y & 255u); r.k1 = (uint8_t)((inf.y >> 8) & 255u); r.flags = (uint8_t)((inf.y >> 16) & 255u); r.c2_zero = (uint8_t)((inf.y >> 24) & 1u);
+                    if (r.flags & HS_COL_TIE) r.flags |= HS_COL_OPEN;      // (k_column_top3_exact orders it as the reference does)
+                }
             }
+            col_rec[k] = r;
         }
-        col_rec[k] = r;
-    }
-    // the columns whose leading codes are still open: one list, one atomic per wavefront
-    const unsigned long long om = __ballot(open);
-    if (om) {
-        long long base = 0;
-        if (lane == 0) base = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(&header->n_undecided), (unsigned long long)__popcll(om));
-        base = ((long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffll));
-        if (open) undecided[base + __popcll(om & ((1ull << lane) - 1ull))] = (int32_t)k;
+        before += __builtin_amdgcn_readlane(incl, 63);
     }
 }
 
@@ -198,8 +193,7 @@ __global__ __launch_bounds__(256) void k_gather_tiles(
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_len,
                                                            const uint8_t* __restrict__ col_code, const ColumnsHeader* __restrict__ header,
-                                                           hs_colrec_dev* __restrict__ col_rec, unsigned long long* __restrict__ n_tie /* [2] */,
-                                                           const int32_t* __restrict__ list /* the columns to do (header->n_undecided of them), or NULL: all */) {
+                                                           hs_colrec_dev* __restrict__ col_rec, unsigned long long* __restrict__ n_tie /* [4][2]: {ties, of them sorted beyond 16 keys}, four slots the host adds up */) {
     __shared__ int s_hist[4][128];
     __shared__ uint8_t s_info[4][512], s_key[4][512], s_tmp[4][512];
     __shared__ uint32_t s_sort[4][136];
@@ -208,10 +202,18 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
     __shared__ int s_fpos[4][128];
     const int lane = lane_id();
     const int wv = wave_id();
-    const int64_t n_cols = list ? (header->ok ? header->n_undecided : 0) : header_cols(header);
+    const int64_t n_cols = header_cols(header);
     int* __restrict__ h = s_hist[wv];
-    for (int64_t f = (int64_t)blockIdx.x * 4 + wv; f < n_cols; f += (int64_t)gridDim.x * 4) {
-        const int64_t col = list ? (int64_t)list[f] : f;
+    __shared__ int s_ties[2];
+    if (threadIdx.x < 2) s_ties[threadIdx.x] = 0;
+    __syncthreads();
+    int my_ties = 0, my_big = 0;
+    // a wavefront looks at 64 column records at a time and does the ones k_columns_compact left open (since K2 forms the leading codes itself:
+    // the columns with equal counts, about one in 35), one after the other, all lanes on one column
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + wv) * 64; base < n_cols; base += (int64_t)gridDim.x * 256) {
+      unsigned long long todo = __ballot(base + lane < n_cols && (col_rec[base + lane < n_cols ? base + lane : 0].flags & HS_COL_OPEN) != 0);
+      for (; todo; todo &= todo - 1ull) {
+        const int64_t col = base + __builtin_ctzll(todo);
         h[lane] = 0; h[lane + 64] = 0;
         wave_lds_sync();
         const int64_t b = col_off[col];
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
             const uint32_t v0 = s_sort[wv][132], v1 = s_sort[wv][133], v2 = s_sort[wv][134];
             const int m = (int)s_sort[wv][135];
             k0 = (int)(v0 & 255u); k1 = (int)(v1 & 255u); c0 = (int)(v0 >> 8); c1 = (int)(v1 >> 8); c2 = (int)(v2 >> 8);
-            if (lane == 0) { atomicAdd(&n_tie[0], 1ull); if (m > 16) atomicAdd(&n_tie[1], 1ull); }
+            my_ties++; if (m > 16) my_big++;
             wave_lds_sync();
         }
         if (lane == 0) {
@@ -296,7 +298,12 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
             if (c1 > c2 * 5) r.flags |= HS_COL_C1GT5C2;
             col_rec[col] = r;
         }
+      }
     }
+    // one atomic per workgroup and counter, over four slots (39 k atomics on one address took 0.47 ms: 12 ns each, one after the other)
+    if (lane == 0 && my_ties) { atomicAdd(&s_ties[0], my_ties); if (my_big) atomicAdd(&s_ties[1], my_big); }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_ties[threadIdx.x]) atomicAdd(&n_tie[2 * (blockIdx.x & 3) + threadIdx.x], (unsigned long long)s_ties[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
