@@ -358,7 +358,11 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
             cv_phase_a_import(*cst[(size_t)c], b.rec_pos.data() + r0, (int)(la.part_base[(size_t)c + 1] - la.part_base[(size_t)c]), la.rec + la.part_base[(size_t)c],
                               la.bits + la.bits_base[(size_t)c], la.cnt + la.cnt_base[(size_t)c]);
             (void)N;
-        } else { cv_phase_a_host(*cst[(size_t)c], candidates_of(c), b.rec_pos.data() + r0); n_host_a++; }
+        } else {
+            const bool ranked = (int)b.rank_of.size() == b.n_rec && (int)b.orig_of.size() == b.n_rec;
+            cv_phase_a_host(*cst[(size_t)c], candidates_of(c), b.rec_pos.data() + r0, ranked ? b.rank_of.data() + r0 : nullptr, ranked ? b.orig_of.data() + r0 : nullptr);
+            n_host_a++;
+        }
         if (!pairs_on_device) cv_phase_b(*cst[(size_t)c], res[(size_t)c]);
     });
     if (pairs_on_device) {

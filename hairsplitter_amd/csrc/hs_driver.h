@@ -20,6 +20,9 @@ struct CvMeta {                       // host-side description of a stage-3 batc
     std::vector<int64_t> rec_refspan;     // [NREC] reference bases consumed by the CIGAR (unclipped)
     int64_t total_len = 0;
     std::vector<int32_t> ploidy;          // [C] or empty: ploidy of the contigs for the stage 3 -> 4 hand-over (0 = none)
+    // optional, [NREC] each: the reads of every contig ranked by start position (ties by index) -- rank of a read on its contig, and the
+    // read at a rank -- when the batch has them already (it ranks the reads once for the device); empty: loop A sorts per call
+    std::vector<int32_t> rank_of, orig_of;
 };
 
 // K4 input: the final partitions of every contig of a range as dense per-read state arrays (2 = read not in the partition)

@@ -66,7 +66,7 @@ void cv_state_free(CvContigState* st);
 // read_start: [n_reads] POS-1 of every record of the contig (the bit order of every bit set: ranks by start position)
 struct CvPartRecord { int32_t left, right, n_occ, n_corr, lo, hi, reach, pad; int64_t elem; };   // what k_loop_a_pack writes per partition
 void cv_phase_begin(CvContigState& st, int n_reads, int n_candidates, float mean_distance, ContigCvResult& out);
-void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* read_start);
+void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* read_start, const int32_t* rank_of = nullptr, const int32_t* orig_of = nullptr /* the contig's reads ranked already (cv_rank_reads' result), or NULL */);
 // bits: the contig's partitions, 3 W words each (present, plus, minus over the reads ranked by start position); cnt: N counters each
 // (more | less << 16); rec[p].elem is not used here
 void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const uint64_t* bits, const int32_t* cnt);

@@ -633,7 +633,7 @@ void cv_phase_begin(CvContigState& st, int n_reads, int n_candidates, float mean
 }
 
 // loop A (:590-638) on the host: sequential over the candidate columns of the contig
-void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* read_start) {
+void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* read_start, const int32_t* rank_pre, const int32_t* orig_pre) {
     const int n_reads = st.n_reads;
     const bool tim = std::getenv("HS_TIMING_AB") != nullptr;
     auto nowus = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -642,7 +642,11 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
     double t_aug = 0;
     std::vector<RankPartition>& parts = st.parts;
     parts.clear();
-    cv_rank_reads(n_reads, read_start, st.rank_of, st.orig_of);
+    if (rank_pre && orig_pre) {      // (the batch ranked the reads when it was created: no sort per step)
+        st.rank_of.assign(rank_pre, rank_pre + n_reads);
+        st.orig_of.assign((size_t)((n_reads + 63) / 64) * 64, 0);
+        std::copy(orig_pre, orig_pre + n_reads, st.orig_of.begin());
+    } else cv_rank_reads(n_reads, read_start, st.rank_of, st.orig_of);
     const std::vector<int32_t>& rank_of = st.rank_of; const std::vector<int32_t>& orig_of = st.orig_of;
     int last_position = -5;
     // the partitions a column can still meet, in creation order: one that is more than 50 kb behind (:595) or none of whose reads
