@@ -14,6 +14,8 @@ import numpy as np
 
 _ROOT = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_ROOT, "lib", "libhairsplitter_hip.so")
+if os.environ.get("HS_LIB_AB"):      # (tools/gpu_ab_lib.sh: another build of the same library, for A/B timing of a code change on one box)
+    LIB_PATH = os.environ["HS_LIB_AB"]
 
 # every symbol declared in include/hairsplitter_hip.h
 SYMBOLS = [
