@@ -302,6 +302,14 @@ __global__ __launch_bounds__(256) void k_pileup_packed(
 #endif
     constexpr int NW = HS_K1_WINDOWS;
     __shared__ uint32_t s_type[4][64 * NW];   // per wave: 256 x NW event types (0 = M, 1 = I, 2 = D)
+    // v_perm selectors that pack the bytes of a lane's WRITTEN events (bit b of the index: event b writes a column) to the low end
+    __shared__ uint32_t s_squeeze[16];
+    if (threadIdx.x < 16) {
+        uint32_t sel = 0x0c0c0c0cu; int j = 0;
+        for (int b = 0; b < 4; ++b) if ((threadIdx.x >> b) & 1u) { sel = (sel & ~(0xffu << (8 * j))) | ((uint32_t)b << (8 * j)); ++j; }
+        s_squeeze[threadIdx.x] = sel;
+    }
+    __syncthreads();
     const int lane = lane_id();
     const int wv = wave_id();
     const int task = (int)blockIdx.x * 4 + wv;
@@ -466,27 +474,24 @@ __global__ __launch_bounds__(256) void k_pileup_packed(
                 const uint32_t act1 = act & 0x01010101u;
                 nlen_l = byte_sum(act1, nlen_l);
                 nerr_l = byte_sum(act1 & (isI | isD | neq), nerr_l);
-                // ---- pileup bytes of the M and D events. The usual lane commits its first n events (all four, or fewer at the
-                // end of a chunk or task) on the contig: their M / D events are consecutive columns from qL on. With at most one
-                // insertion among them its code byte is squeezed out and the n bytes leave as one dword / short / byte store.
-                // Other lanes (first lane of a task, contig end, two insertions in one lane) store byte by byte ----
-                const uint32_t wi = isI & act;                                 // committed insertions
-                const int n_i = (int)byte_sum(wi, 0u);
-                if ((act & (act + 1u)) == 0u && n_i <= 1) {
-                    const int n = (int)byte_sum(act1, 0u) - n_i;
-                    const uint32_t below = wi - 1u;                            // bytes below the insertion (all of them if there is none)
-                    const uint32_t comp = (code4 & below) | ((code4 >> 8) & ~below);
-                    uint8_t* const o = out + (unsigned)(qL_[u] - pos);
+                // ---- pileup bytes of the M and D events. The events of a lane that write a column -- committed, on the contig, not an
+                // insertion -- are a run of the lane's events minus its insertions, so their columns are consecutive from the column of
+                // the first of them: the code bytes of the written events are packed to the low end with ONE v_perm (selector from a
+                // 16-entry table in LDS, indexed by the 4-bit "writes" mask) and leave as one dword / short / byte store. No lane takes
+                // another path (round 4: the byte-by-byte form ran for the whole wavefront whenever one of its lanes had two
+                // insertions, started a task or ended a chunk -- about every second window) ----
+                const uint32_t wr1 = act & ~bytes_ff(isI) & 0x01010101u;
+                const uint32_t m4 = (wr1 | (wr1 >> 7) | (wr1 >> 14) | (wr1 >> 21)) & 15u;
+                if (m4) {
+                    const uint32_t comp = __builtin_amdgcn_perm(0u, code4, s_squeeze[m4]);
+                    const int n = __builtin_popcount(m4);
+                    const int first = __builtin_ctz(m4);
+                    uint8_t* const o = out + (unsigned)(qL_[u] + first - (int)((ipre_[u] >> (8 * first)) & 0xffu) - pos);
                     if (n == 4) *reinterpret_cast<u32_unaligned*>(o) = comp;
                     else {
                         if (n & 2) *reinterpret_cast<u16_unaligned*>(o) = (uint16_t)comp;
                         if (n & 1) o[n & 2] = (uint8_t)(comp >> (8 * (n & 2)));
                     }
-                } else {
-                    const uint32_t wr = act & ~bytes_ff(isI);
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        if ((wr >> (8 * b)) & 1u) out[(unsigned)(qL_[u] + b - (int)((ipre_[u] >> (8 * b)) & 0xffu) - pos)] = (uint8_t)(code4 >> (8 * b));
                 }
                 // ---- carry: the last two characters of the window ----
                 const int nw = (hi_el - w0) < 256 ? (hi_el - w0) : 256;
