@@ -24,11 +24,12 @@ def test_dropin_binaries_match_reference_goldens(built, case):
         assert open(gaf, "rb").read() == open(os.path.join(td, "reads_haplo.gaf"), "rb").read()
 
 
-@pytest.mark.parametrize("switch", ["HS_K1_PER_EVENT", "HS_SPIN_WAIT", "HS_FINISH_ON_HOST", "HS_LOOP_A_ON_DEVICE", "HS_LOOP_B_PAIRS_ON_DEVICE"])
+@pytest.mark.parametrize("switch", ["HS_K1_PER_EVENT", "HS_SPIN_WAIT", "HS_FINISH_ON_HOST", "HS_LOOP_A_ON_DEVICE", "HS_LOOP_B_PAIRS_ON_DEVICE", "HS_K2_PLAIN"])
 @pytest.mark.parametrize("case", ["penta30k", "edge_ops"])
 def test_dropin_binaries_with_the_alternative_paths(built, case, switch):
     """The opt-in switches select other ways to the same result (event-per-lane pileup, sleeping waits, full column download,
-    cluster merging on the host, loop A of keep_only_robust_variants on the device): the executables must still reproduce the reference goldens"""
+    cluster merging on the host, loop A of keep_only_robust_variants on the device, K2 without its second pass -- every column's leading
+    codes from k_column_top3_exact): the executables must still reproduce the reference goldens"""
     with tempfile.TemporaryDirectory() as td:
         meta = gu.unpack(case, td)
         outs = gu.run_stage_pair([built["cv"]], [built["sr"]], td, meta, env=dict(os.environ, **{switch: "1"}))
@@ -224,7 +225,7 @@ def test_fused_pipeline_takes_the_ploidy_of_the_contigs(built):
         assert np.array_equal(free[k], got_free[k]), k
 
 
-@pytest.mark.parametrize("shape", ["tetra100k", "hifi300k", "meta_ploidy1to8", "deep1200x"])
+@pytest.mark.parametrize("shape", ["tetra100k", "hifi300k", "meta_ploidy1to8", "deep1200x", "shallow14x_ploidy3", "shallow10x_ploidy2"])
 def test_dropin_equals_oracle_at_larger_sizes(built, shape):
     """Beyond the committed fixtures: BASELINE-shaped contigs (tetraploid ONT as C3, a metagenome slice with ploidies 1..8 at
     30x total depth as C4, HiFi 300 kb chunk as C5) through the drop-in executables, against the oracle restatement run on
@@ -236,6 +237,12 @@ def test_dropin_equals_oracle_at_larger_sizes(built, shape):
         # coverage > 1000: 16-bit histogram counters in K2, the per-contig low-memory graph path (separate_reads.cpp:1515-1518),
         # finalize_clustering on a graph that was never filled (:1708), 2700 reads per Chinese-Whispers instance, 500-bp windows
         contigs = [synth.make_contig(77, 0, 4000, 2, 0.01, 1200, "ont", read_len_override=(1000, 2500))]
+    elif shape == "shallow14x_ploidy3":
+        # fourteen reads over three haplotypes: leading counts tie all the time (5 : 5 : 4, 4 : 4 ...), so K2's second pass hands those
+        # positions to k_column_top3_exact, and the floor of the selection (second count 4 with no third allele) decides many columns
+        contigs = [synth.make_contig(44, 0, 60_000, 3, 0.02, 14, "ont")]
+    elif shape == "shallow10x_ploidy2":
+        contigs = [synth.make_contig(44, 0, 60_000, 2, 0.02, 10, "ont")]
     elif shape == "meta_ploidy1to8":
         contigs = [synth.make_contig(43, i, 20_000 + 5_000 * i, 1 + i, 0.01 if i else 0.0, 30, "ont") for i in range(8)]
     else:
@@ -253,7 +260,7 @@ def test_dropin_equals_oracle_at_larger_sizes(built, shape):
         assert canon.vcf_blocks(outs["hip"][1]) == canon.vcf_blocks(outs["orc"][1])
         assert open(outs["hip"][2]).read() == open(outs["orc"][2]).read()
         assert canon.split_blocks(outs["hip"][3]) == canon.split_blocks(outs["orc"][3])
-        assert sum(1 for l in open(outs["hip"][3]) if l.startswith("GROUP")) > {"meta_ploidy1to8": 20, "deep1200x": 5}.get(shape, 40)
+        assert sum(1 for l in open(outs["hip"][3]) if l.startswith("GROUP")) > {"meta_ploidy1to8": 20, "deep1200x": 5, "shallow14x_ploidy3": 20, "shallow10x_ploidy2": 20}.get(shape, 40)
 
 
 def test_pipeline_groups_equal_single_batch(built):
