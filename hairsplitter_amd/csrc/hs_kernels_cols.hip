@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void k_columns_compact(
 // ------------------------------------------------------------------------------------------------
 #define HS_GT_RC 32
 #define HS_GT_ROW 260
+#define HS_GT_DIRECT 16      // tiles with at most this many kept positions fetch their bytes directly
 __global__ __launch_bounds__(256) void k_gather_tiles(
     const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, const int32_t* __restrict__ tile_lrec,
     int64_t tile0, int64_t n_tiles, const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_base,
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256) void k_gather_tiles(
     uint8_t* __restrict__ rows = s_rows[wv];
     const int64_t kbase = tile_base[tl];
     const int64_t e0 = tile_off[tile0 + tl], e1 = tile_off[tile0 + tl + 1];
+    if (cnt <= HS_GT_DIRECT) return;      // (k_gather_tiles_direct does those)
     for (int sc = 0; sc < cnt; sc += 64) {      // (a tile rarely selects more than 64 of its 256 positions)
         const int ns = (cnt - sc) < 64 ? (cnt - sc) : 64;
         int my_x = 0;
@@ -179,6 +181,61 @@ __global__ __launch_bounds__(256) void k_gather_tiles(
                 if (lane == s) my_w += __popcll(m);
             }
             __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// K3 for the tiles that keep few positions (nearly all of them since K2 drops what nobody reads): no LDS, so a CU holds eight times the
+// wavefronts of the staging form -- the kernel is a latency chain of plan entry -> byte loads -> stores per tile.
+__global__ __launch_bounds__(256) void k_gather_tiles_direct(
+    const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, const int32_t* __restrict__ tile_lrec,
+    int64_t tile0, int64_t n_tiles, const int32_t* __restrict__ tile_cnt, const int64_t* __restrict__ tile_base,
+    const int64_t* __restrict__ col_gpos, const int64_t* __restrict__ col_off, int32_t* __restrict__ col_idx, uint8_t* __restrict__ col_code,
+    const ColumnsHeader* __restrict__ header) {
+    if (!header->ok) return;
+    const int lane = lane_id();
+    const int64_t tl = (int64_t)blockIdx.x * 4 + wave_id();
+    if (tl >= n_tiles) return;
+    const int cnt = tile_cnt[tl];
+    if (cnt == 0 || cnt > HS_GT_DIRECT) return;
+    const int64_t kbase = tile_base[tl];
+    const int64_t e0 = tile_off[tile0 + tl], e1 = tile_off[tile0 + tl + 1];
+    // Round 4: K2 keeps a handful of positions per tile (5.5 on average), so the bytes a column needs are fetched directly -- lane =
+    // record, one byte load per kept position, all of a chunk's loads in flight together -- instead of staging 32 x 256 bytes of rows
+    // in LDS for them. Same ranks (ballot + prefix popcount over the records in plan order), same stores.
+    int my_x = 0;
+    int64_t my_w = 0;
+    if (lane < cnt) { my_x = (int)(col_gpos[kbase + lane] & 255); my_w = col_off[kbase + lane]; }
+    for (int64_t rb = e0; rb < e1; rb += 64) {
+        const int nrec = (e1 - rb) < 64 ? (int)(e1 - rb) : 64;
+        int4 en = make_int4(0, 0, 0, 0);
+        int lrec = 0;
+        if (lane < nrec) { en = tile_ent[rb + lane]; lrec = tile_lrec[rb + lane]; }
+        const uint8_t* __restrict__ base = pile + (int64_t)(((uint64_t)(uint32_t)en.w << 32) | (uint32_t)en.z);
+        for (int s0 = 0; s0 < cnt; s0 += 8) {
+            uint8_t code[8]; bool cov[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int x = __builtin_amdgcn_readlane(my_x, (s0 + u) & 63);
+                cov[u] = s0 + u < cnt && lane < nrec && (unsigned)(x - en.x) < (unsigned)en.y;
+                code[u] = cov[u] ? base[x] : (uint8_t)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (s0 + u >= cnt) break;      // wave-uniform
+                const unsigned long long m = __ballot(cov[u]);
+                if (m == 0ull) continue;
+                const int s = s0 + u;
+                const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_w & 0xffffffffll), s);
+                const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)my_w >> 32), s);
+                const int64_t w = (int64_t)(((uint64_t)whi << 32) | wlo);
+                if (cov[u]) {
+                    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+                    col_idx[w + rank] = lrec;
+                    col_code[w + rank] = code[u];
+                }
+                if (lane == s) my_w += __popcll(m);
+            }
         }
     }
 }

@@ -12,7 +12,7 @@ traffic = json.load(open(sys.argv[5])) if len(sys.argv) > 5 else {}
 g1 = json.load(open(g1_json))
 df = json.load(open(def_json))
 steps_g1 = g1["steps"] + g1["warmup"] + g1.get("setup_steps", 0)
-ALIAS = {"k_column_stats_tiled_dw": "k_column_stats_tiled", "k_column_stats_tiled_dw_plain": "k_column_stats_tiled", "k_read_graph_rows<false>": "k_read_graph_rows", "k_read_graph_rows<true>": "k_read_graph_rows"}
+ALIAS = {"k_column_stats_tiled_dw": "k_column_stats_tiled", "k_column_stats_tiled_dw_plain": "k_column_stats_tiled", "k_gather_tiles_direct": "k_gather_tiles", "k_read_graph_rows<false>": "k_read_graph_rows", "k_read_graph_rows<true>": "k_read_graph_rows"}
 own = {}
 for r in csv.DictReader(open(stats_csv)):
     name = r["Name"].split("(")[0].replace("void ", "").replace("hsdev::", "").strip()

@@ -20,7 +20,7 @@ out = {"_note": "HBM bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024, mean o
        "_groups_per_gpu": j["config"]["groups_per_gpu"], "_groups": j["config"]["groups_per_gpu"], "_steps": j["steps"] + j["warmup"] + j.get("setup_steps", 0),
        "_commit": os.environ.get("HS_COMMIT"), "_dispatches": {}}
 # the stat slot of bench.py is named after the kernel family: the four-positions-per-lane form of K2 reports under k_column_stats_tiled
-ALIAS = {"k_column_stats_tiled_dw": "k_column_stats_tiled", "k_column_stats_tiled_dw_plain": "k_column_stats_tiled"}
+ALIAS = {"k_column_stats_tiled_dw": "k_column_stats_tiled", "k_column_stats_tiled_dw_plain": "k_column_stats_tiled", "k_gather_tiles_direct": "k_gather_tiles"}
 for k, v in sorted(by.items()):
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         name = k.split("<")[0]
