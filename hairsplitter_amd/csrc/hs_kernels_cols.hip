@@ -431,7 +431,8 @@ __global__ __launch_bounds__(64 * HS_CB_WAVES) void k_cand_bits(
     const hs_colrec_dev* __restrict__ cand_rec, const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_idx, const uint8_t* __restrict__ cand_code,
     const ColumnsHeader* __restrict__ header, long long cap_cand, const int32_t* __restrict__ contig_rec_off, const int2* __restrict__ rank_end /* per record: {rank on its contig, alignment end} */,
     CandBitsDev* __restrict__ out_bits, unsigned long long* out_words, long long cap_words,
-    unsigned long long* counter, long long cap_entries) {
+    unsigned long long* counter, long long cap_entries, const int32_t* __restrict__ cand_len /* non-NULL: cand_off[k] is column k's place in cand_idx / cand_code (the
+    range's own column arrays) and cand_len[k] its length; NULL: the packed arrays, lengths from consecutive offsets */) {
     __shared__ int s_fp[HS_CB_WAVES][256];
     __shared__ uint8_t s_slot[HS_CB_WAVES][256];
     __shared__ uint8_t s_codes[HS_CB_WAVES][128];
@@ -441,7 +442,7 @@ __global__ __launch_bounds__(64 * HS_CB_WAVES) void k_cand_bits(
     const int lane = lane_id();
     const int wv = wave_id();
     long long n_cand = header->n_flagged;
-    if (n_cand > cap_cand || header->n_flagged_entries > cap_entries) {      // the packed block did not hold the candidates: nothing to read
+    if (n_cand > cap_cand || (!cand_len && header->n_flagged_entries > cap_entries)) {      // the packed block did not hold the candidates: nothing to read
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(counter + 1, 2ull);
         return;
     }
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(64 * HS_CB_WAVES) void k_cand_bits(
     const hs_colrec_dev rec = cand_rec[live ? k : 0];
     const int r0 = live ? contig_rec_off[rec.contig] : 0;
     const int64_t e0 = live ? cand_off[k] : 0;
-    const int n = live ? (int)(cand_off[k + 1] - e0) : 0;
+    const int n = live ? (cand_len ? cand_len[k] : (int)(cand_off[k + 1] - e0)) : 0;
     int* __restrict__ fp = s_fp[wv];
     uint8_t* __restrict__ slot_of = s_slot[wv];
     uint8_t* __restrict__ codes = s_codes[wv];
@@ -684,7 +685,8 @@ __global__ __launch_bounds__(256) void k_pack_flagged(
     const hs_colrec_dev* __restrict__ col_rec, const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_len, const int32_t* __restrict__ col_idx,
     const uint8_t* __restrict__ col_code, const ColumnsHeader* __restrict__ header, int flag, const long long* __restrict__ blk_cnt,
     const long long* __restrict__ blk_ent, hs_colrec_dev* __restrict__ out_rec, int32_t* __restrict__ out_col, int64_t* __restrict__ out_off,
-    int32_t* __restrict__ out_idx, uint8_t* __restrict__ out_code, int64_t cap_flagged, int64_t cap_entries) {
+    int32_t* __restrict__ out_idx, uint8_t* __restrict__ out_code, int64_t cap_flagged, int64_t cap_entries,
+    int32_t* __restrict__ out_len /* non-NULL: the LIGHT form -- no entry is copied, out_off[f] is the column's place in col_idx / col_code and out_len[f] its length */) {
     // one workgroup per block of HS_FP_BLOCK columns: wave w walks columns w * 256 .. of the block 64 at a time
     const int64_t n_cols = header_cols(header);
     const int64_t base = (int64_t)blockIdx.x * HS_FP_BLOCK;
@@ -717,6 +719,11 @@ __global__ __launch_bounds__(256) void k_pack_flagged(
         const int incl = wave_scan_incl(len);
         const long long my_f = f + __popcll(m & ((1ull << lane) - 1ull));
         const long long my_o = o + incl - len;
+        if (out_len) {      // (the candidates: k_cand_bits reads their entries where they lie)
+            if (on && my_f < cap_flagged) { out_rec[my_f] = col_rec[k]; out_col[my_f] = (int32_t)k; out_off[my_f] = my_src; out_len[my_f] = len; }
+            f += __popcll(m); o += __builtin_amdgcn_readlane(incl, 63);
+            continue;
+        }
         if (on && my_f < cap_flagged) { out_rec[my_f] = col_rec[k]; out_col[my_f] = (int32_t)k; out_off[my_f] = my_o; }
         // the entries: the wave copies the flagged columns of this step one after the other (four at a time with their loads in
         // flight together: 0.45 ms per step against 0.36)
