@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256) void k_gather_tiles_direct(
 // in first-appearance order into hs::Rh8View (tables in LDS), its iteration order into hs::CountSort (std::sort's own
 // sequence of moves). Writes counts and codes into the column record.
 // ------------------------------------------------------------------------------------------------
+#define HS_T3_CHUNK 16
 __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_len,
                                                            const uint8_t* __restrict__ col_code, const ColumnsHeader* __restrict__ header,
                                                            hs_colrec_dev* __restrict__ col_rec, unsigned long long* __restrict__ n_tie /* [4][2]: {ties, of them sorted beyond 16 keys}, four slots the host adds up */) {
@@ -267,8 +268,10 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
     int my_ties = 0, my_big = 0;
     // a wavefront looks at 64 column records at a time and does the ones k_columns_compact left open (since K2 forms the leading codes itself:
     // the columns with equal counts, about one in 35), one after the other, all lanes on one column
-    for (int64_t base = ((int64_t)blockIdx.x * 4 + wv) * 64; base < n_cols; base += (int64_t)gridDim.x * 256) {
-      unsigned long long todo = __ballot(base + lane < n_cols && (col_rec[base + lane < n_cols ? base + lane : 0].flags & HS_COL_OPEN) != 0);
+    // (HS_T3_CHUNK records per wavefront and round: the kernel is as long as the wavefront with the most tied columns -- a tie takes 14 us of
+    // one lane's dependent LDS accesses -- and ties come in runs; 64 records per wavefront: 0.49 ms for the C4 job, 16: see DESIGN 4.3)
+    for (int64_t base = ((int64_t)blockIdx.x * 4 + wv) * HS_T3_CHUNK; base < n_cols; base += (int64_t)gridDim.x * 4 * HS_T3_CHUNK) {
+      unsigned long long todo = __ballot(lane < HS_T3_CHUNK && base + lane < n_cols && (col_rec[base + lane < n_cols ? base + lane : 0].flags & HS_COL_OPEN) != 0);
       for (; todo; todo &= todo - 1ull) {
         const int64_t col = base + __builtin_ctzll(todo);
         h[lane] = 0; h[lane + 64] = 0;
