@@ -928,16 +928,18 @@ static __device__ __forceinline__ void column_stats_tiled_dw_body(
         // Only "can the second count reach the floor": at least two counters >= min_second (4: the bits above the low two). Exactly what
         // is selected is decided in the second pass, which has the three largest counts -- this scan is 5 instructions per counter
         // word instead of 9 (it was 55 % of the kernel's instructions).
-        int small = 0;      // counters below 4 (of the 128 bytes of the column)
+        uint32_t big = 0;      // counters of 4 and more (of the 128 bytes of the column)
         if (g < total) {
 #pragma unroll 8
             for (int w = 0; w < NWORDS; ++w) {
                 const uint32_t word = hw[w * 256 + tid];
-                const uint32_t q = (word >> 2) & 0x3f3f3f3fu;                       // count / 4 per byte
-                small += __builtin_popcount((0x80808080u - q) & 0x80808080u);      // 0x80 - q keeps bit 7 only for q == 0 (no borrow: q <= 63)
+                const uint32_t t = word & 0xfcfcfcfcu;                              // the bits above the low two: non-zero <=> the counter is >= 4
+                // v_msad_u8: sum of |a - b| over the bytes whose REFERENCE byte (second operand) is not zero -- with a = t | 1 that is
+                // one per non-zero byte of t: three instructions per counter word
+                big = __builtin_amdgcn_msad_u8(t | 0x01010101u, t, big);
             }
         }
-        sel = g < total && g >= g_lo && g < g_hi && ((128 - small) >= 2 || min_second < 4);      // (a floor below 4: every position to the second pass)
+        sel = g < total && g >= g_lo && g < g_hi && (big >= 2u || min_second < 4);      // (a floor below 4: every position to the second pass)
     } else {
     if (g < total) {
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
