@@ -225,7 +225,7 @@ def test_fused_pipeline_takes_the_ploidy_of_the_contigs(built):
         assert np.array_equal(free[k], got_free[k]), k
 
 
-@pytest.mark.parametrize("shape", ["tetra100k", "hifi300k", "meta_ploidy1to8", "deep1200x", "shallow14x_ploidy3", "shallow10x_ploidy2"])
+@pytest.mark.parametrize("shape", ["tetra100k", "hifi300k", "meta_ploidy1to8", "deep1200x", "shallow14x_ploidy3", "shallow10x_ploidy2", "dense60x_ploidy8", "dense120x_ploidy6"])
 def test_dropin_equals_oracle_at_larger_sizes(built, shape):
     """Beyond the committed fixtures: BASELINE-shaped contigs (tetraploid ONT as C3, a metagenome slice with ploidies 1..8 at
     30x total depth as C4, HiFi 300 kb chunk as C5) through the drop-in executables, against the oracle restatement run on
@@ -243,6 +243,12 @@ def test_dropin_equals_oracle_at_larger_sizes(built, shape):
         contigs = [synth.make_contig(44, 0, 60_000, 3, 0.02, 14, "ont")]
     elif shape == "shallow10x_ploidy2":
         contigs = [synth.make_contig(44, 0, 60_000, 2, 0.02, 10, "ont")]
+    elif shape == "dense60x_ploidy8":
+        # 5 % divergence over eight haplotypes at 60x: a 256-position tile holds more positions with two counters of four reads than
+        # a wavefront has lanes (K2's second pass in several rounds), SNPs every few bases (V1's chains of passing columns)
+        contigs = [synth.make_contig(46, 0, 40_000, 8, 0.05, 60, "ont")]
+    elif shape == "dense120x_ploidy6":
+        contigs = [synth.make_contig(46, 0, 30_000, 6, 0.08, 120, "ont")]
     elif shape == "meta_ploidy1to8":
         contigs = [synth.make_contig(43, i, 20_000 + 5_000 * i, 1 + i, 0.01 if i else 0.0, 30, "ont") for i in range(8)]
     else:
@@ -260,7 +266,7 @@ def test_dropin_equals_oracle_at_larger_sizes(built, shape):
         assert canon.vcf_blocks(outs["hip"][1]) == canon.vcf_blocks(outs["orc"][1])
         assert open(outs["hip"][2]).read() == open(outs["orc"][2]).read()
         assert canon.split_blocks(outs["hip"][3]) == canon.split_blocks(outs["orc"][3])
-        assert sum(1 for l in open(outs["hip"][3]) if l.startswith("GROUP")) > {"meta_ploidy1to8": 20, "deep1200x": 5, "shallow14x_ploidy3": 20, "shallow10x_ploidy2": 20}.get(shape, 40)
+        assert sum(1 for l in open(outs["hip"][3]) if l.startswith("GROUP")) > {"meta_ploidy1to8": 20, "deep1200x": 5, "shallow14x_ploidy3": 20, "shallow10x_ploidy2": 20, "dense60x_ploidy8": 10, "dense120x_ploidy6": 10}.get(shape, 40)
 
 
 def test_pipeline_groups_equal_single_batch(built):
