@@ -92,3 +92,5 @@ for r in csv.DictReader(open(sys.argv[1])):
 P
 gzip -f $R/gpurun_out/ktrace_rows.tsv
 rm -rf $R/gpurun_out/ktrace
+python3 $R/tools/ktrace_timeline.py 7 > $R/gpurun_out/ktrace_timeline.txt 2>&1
+head -14 $R/gpurun_out/ktrace_timeline.txt
