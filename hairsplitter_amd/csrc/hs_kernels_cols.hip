@@ -429,18 +429,23 @@ __global__ __launch_bounds__(256) void k_fill16(uint4* __restrict__ dst, long lo
 struct alignas(16) CandBitsDev { int32_t wlo; uint16_t n_words, n_slots; int32_t idx_min, idx_max, reach, n_entries; long long word_off; };
 static_assert(sizeof(CandBitsDev) == 32, "CandBitsDev must be 32 bytes");
 #define HS_CB_LDS_WORDS 96
-#define HS_CB_WAVES 16      // columns per workgroup: ONE allocation atomic per workgroup (one per column: 60 k atomics on one address per launch, 0.8 ms)
+#define HS_CB_WAVES 4       // wavefronts per workgroup
+#define HS_CB_PER_WAVE 4    // columns per wavefront, one after the other with their loads in flight together: 16 columns and ONE allocation atomic per
+                            // workgroup (one per column: 60 k atomics on one address per launch, 0.8 ms). Round 4, first form: one column per wavefront, 16
+                            // wavefronts per workgroup -- 0.47 ms, a latency chain per column at full occupancy, and 1024-thread workgroups find room late
+                            // on a device that other contig groups' kernels share.
 __global__ __launch_bounds__(64 * HS_CB_WAVES) void k_cand_bits(
     const hs_colrec_dev* __restrict__ cand_rec, const int64_t* __restrict__ cand_off, const int32_t* __restrict__ cand_idx, const uint8_t* __restrict__ cand_code,
     const ColumnsHeader* __restrict__ header, long long cap_cand, const int32_t* __restrict__ contig_rec_off, const int2* __restrict__ rank_end /* per record: {rank on its contig, alignment end} */,
     CandBitsDev* __restrict__ out_bits, unsigned long long* out_words, long long cap_words,
     unsigned long long* counter, long long cap_entries, const int32_t* __restrict__ cand_len /* non-NULL: cand_off[k] is column k's place in cand_idx / cand_code (the
     range's own column arrays) and cand_len[k] its length; NULL: the packed arrays, lengths from consecutive offsets */) {
-    __shared__ int s_fp[HS_CB_WAVES][256];
-    __shared__ uint8_t s_slot[HS_CB_WAVES][256];
-    __shared__ uint8_t s_codes[HS_CB_WAVES][128];
+    constexpr int PW = HS_CB_PER_WAVE;
+    __shared__ int s_fp[HS_CB_WAVES][PW][256];
+    __shared__ uint8_t s_slot[HS_CB_WAVES][PW][256];
+    __shared__ uint8_t s_codes[HS_CB_WAVES][PW][128];
     __shared__ unsigned long long s_blk[HS_CB_WAVES][HS_CB_LDS_WORDS];
-    __shared__ int s_size[HS_CB_WAVES];
+    __shared__ int s_size[HS_CB_WAVES * PW];
     __shared__ long long s_base;
     const int lane = lane_id();
     const int wv = wave_id();
@@ -449,101 +454,189 @@ __global__ __launch_bounds__(64 * HS_CB_WAVES) void k_cand_bits(
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(counter + 1, 2ull);
         return;
     }
-    const long long k = (long long)blockIdx.x * HS_CB_WAVES + wv;
-    const bool live = k < n_cand;      // (a wave without a column still meets the others at the barriers)
-    const hs_colrec_dev rec = cand_rec[live ? k : 0];
-    const int r0 = live ? contig_rec_off[rec.contig] : 0;
-    const int64_t e0 = live ? cand_off[k] : 0;
-    const int n = live ? (cand_len ? cand_len[k] : (int)(cand_off[k + 1] - e0)) : 0;
-    int* __restrict__ fp = s_fp[wv];
-    uint8_t* __restrict__ slot_of = s_slot[wv];
-    uint8_t* __restrict__ codes = s_codes[wv];
-    unsigned long long* __restrict__ blk = s_blk[wv];
+    const long long k0 = ((long long)blockIdx.x * HS_CB_WAVES + wv) * PW;
+    // ---- phase 1: per column the codes in first-appearance order, the words its reads' ranks span, the largest alignment end -> its size ----
+    bool live[PW]; int r0[PW], n[PW]; int64_t e0[PW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fp[lane + 64 * i] = 0x7fffffff;
-    wave_lds_sync();
-    int lo = 0x7fffffff, hi = -1, reach = -1;
-    int rc0 = -1;      // the first 64 entries stay in registers (rank << 8 | code): nearly every column is that shallow
-    for (int j0 = 0; j0 < n; j0 += 64) {
-        const int j = j0 + lane;
-        if (j < n) {
-            const int2 re = rank_end[r0 + cand_idx[e0 + j]];
-            const int cd = cand_code[e0 + j];
-            const int w = re.x >> 6;
-            lo = w < lo ? w : lo; hi = w > hi ? w : hi;
-            reach = re.y > reach ? re.y : reach;
-            atomicMin(&fp[cd], j);
-            if (j0 == 0) rc0 = (re.x << 8) | cd;
-        }
+    for (int c = 0; c < PW; ++c) {
+        const long long k = k0 + c;
+        live[c] = k < n_cand;      // (a wavefront without a column still meets the others at the barriers)
+        const hs_colrec_dev rec = cand_rec[live[c] ? k : 0];
+        r0[c] = live[c] ? contig_rec_off[rec.contig] : 0;
+        e0[c] = live[c] ? cand_off[k] : 0;
+        n[c] = live[c] ? (cand_len ? cand_len[k] : (int)(cand_off[k + 1] - e0[c])) : 0;
+    }
+    int rc0[PW];      // the first 64 entries of every column stay in registers (rank << 8 | code): nearly every column is that shallow
+    int2 re0[PW]; int cd0[PW];
+#pragma unroll
+    for (int c = 0; c < PW; ++c) {      // (the four columns' gathers in flight together)
+        re0[c] = make_int2(0, -1); cd0[c] = 0;
+        if (lane < n[c]) { re0[c] = rank_end[r0[c] + cand_idx[e0[c] + lane]]; cd0[c] = cand_code[e0[c] + lane]; }
+    }
+    // A column of up to 64 entries (nearly all) needs no table: its distinct codes in first-appearance order come from ballots -- the lowest
+    // remaining lane's code is the next one -- and every lane keeps the slot of its code in a register. Deeper columns: the first position
+    // of every code by LDS minima, then one wave minimum per code.
+#pragma unroll
+    for (int c = 0; c < PW; ++c) {
+        if (n[c] <= 64) continue;      // (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s_fp[wv][c][lane + 64 * i] = 0x7fffffff;
     }
     wave_lds_sync();
-    lo = -wave_max_i32(-lo); hi = wave_max_i32(hi); reach = wave_max_i32(reach);
-    // the slots: the codes by first appearance
-    int nslots = 0;
-    {
-        int f[4];
+    int lo[PW], hi[PW], reach[PW], nslots[PW], W[PW], cells[PW], size[PW], my_slot[PW];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = fp[lane + 64 * i];
-        for (;;) {
-            int m = f[0];
-#pragma unroll
-            for (int i = 1; i < 4; ++i) m = f[i] < m ? f[i] : m;
-            const int best = -wave_max_i32(-m);
-            if (best == 0x7fffffff || nslots == 128) break;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) if (f[i] == best) { f[i] = 0x7fffffff; slot_of[lane + 64 * i] = (uint8_t)nslots; codes[nslots] = (uint8_t)(lane + 64 * i); }
-            nslots++;
+    for (int c = 0; c < PW; ++c) {
+        int* __restrict__ fp = s_fp[wv][c];
+        int l_lo = 0x7fffffff, l_hi = -1, l_reach = -1;
+        rc0[c] = -1; my_slot[c] = -1; nslots[c] = 0;
+        if (lane < n[c]) {
+            const int w = re0[c].x >> 6;
+            l_lo = w; l_hi = w; l_reach = re0[c].y;
+            if (n[c] > 64) atomicMin(&fp[cd0[c]], lane);
+            rc0[c] = (re0[c].x << 8) | cd0[c];
         }
+        if (n[c] <= 64) {
+            const bool valid = lane < n[c];
+            unsigned long long rem = __ballot(valid);
+            int ns = 0;
+            while (rem) {
+                const int code = __builtin_amdgcn_readlane(cd0[c], __builtin_ctzll(rem));
+                const bool mine = valid && cd0[c] == code;
+                if (mine) my_slot[c] = ns;
+                if (lane == 0) s_codes[wv][c][ns] = (uint8_t)code;
+                rem &= ~__ballot(mine);
+                ns++;
+            }
+            nslots[c] = ns;
+        }
+        for (int j0 = 64; j0 < n[c]; j0 += 64) {      // (deep columns)
+            const int j = j0 + lane;
+            if (j < n[c]) {
+                const int2 re = rank_end[r0[c] + cand_idx[e0[c] + j]];
+                const int cd = cand_code[e0[c] + j];
+                const int w = re.x >> 6;
+                l_lo = w < l_lo ? w : l_lo; l_hi = w > l_hi ? w : l_hi;
+                l_reach = re.y > l_reach ? re.y : l_reach;
+                atomicMin(&fp[cd], j);
+            }
+        }
+        lo[c] = -wave_max_i32(-l_lo); hi[c] = wave_max_i32(l_hi); reach[c] = wave_max_i32(l_reach);
     }
-    const int W = n > 0 ? hi - lo + 1 : 0;
-    if (n == 0) { lo = 0; nslots = 0; }
-    const int cells = W * (nslots + 1);
-    const int size = live ? cells + (nslots + 7) / 8 : 0;
-    if (lane == 0) s_size[wv] = size;
+    wave_lds_sync();
+#pragma unroll
+    for (int c = 0; c < PW; ++c) {
+        // the slots: the codes by first appearance
+        int ns = nslots[c];
+        if (n[c] > 64) {
+            int f[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[i] = s_fp[wv][c][lane + 64 * i];
+            for (;;) {
+                int m = f[0];
+#pragma unroll
+                for (int i = 1; i < 4; ++i) m = f[i] < m ? f[i] : m;
+                const int best = -wave_max_i32(-m);
+                if (best == 0x7fffffff || ns == 128) break;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (f[i] == best) { f[i] = 0x7fffffff; s_slot[wv][c][lane + 64 * i] = (uint8_t)ns; s_codes[wv][c][ns] = (uint8_t)(lane + 64 * i); }
+                ns++;
+            }
+        }
+        W[c] = n[c] > 0 ? hi[c] - lo[c] + 1 : 0;
+        if (n[c] == 0) { lo[c] = 0; ns = 0; }
+        nslots[c] = ns;
+        cells[c] = W[c] * (ns + 1);
+        size[c] = live[c] ? cells[c] + (ns + 7) / 8 : 0;
+        if (lane == 0) s_size[wv * PW + c] = size[c];
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         int total = 0;
-        for (int w = 0; w < HS_CB_WAVES; ++w) total += s_size[w];
+        for (int w = 0; w < HS_CB_WAVES * PW; ++w) total += s_size[w];
         s_base = total ? (long long)atomicAdd(counter, (unsigned long long)total) : 0ll;
     }
-    __syncthreads();      // (also: slot_of / codes are written)
-    if (!live) return;
-    long long off = s_base;
-    for (int w = 0; w < wv; ++w) off += s_size[w];
-    if (off + size > cap_words || W > 65535) { if (lane == 0) atomicOr(counter + 1, 1ull); off = -1; }
-    if (off >= 0 && n > 0) {
-        unsigned long long* __restrict__ out = out_words + off;
-        const bool in_lds = cells <= HS_CB_LDS_WORDS;
-        if (in_lds) { for (int x = lane; x < cells; x += 64) blk[x] = 0ull; }
-        else { for (int x = lane; x < cells; x += 64) out[x] = 0ull; __threadfence(); }
-        wave_lds_sync();
-        for (int j0 = 0; j0 < n; j0 += 64) {
-            const int j = j0 + lane;
-            if (j < n) {
-                int rk, cd;
-                if (j0 == 0) { rk = rc0 >> 8; cd = rc0 & 255; }
-                else { rk = rank_end[r0 + cand_idx[e0 + j]].x; cd = cand_code[e0 + j]; }
-                const int w = (rk >> 6) - lo;
-                const unsigned long long bit = 1ull << (rk & 63);
-                const int sl = slot_of[cd];
-                if (in_lds) { atomicOr(&blk[w], bit); atomicOr(&blk[(sl + 1) * W + w], bit); }
-                else { atomicOr(&out[w], bit); atomicOr(&out[(long long)(sl + 1) * W + w], bit); }
+    __syncthreads();      // (also: the slots and codes are written)
+    // ---- phase 2: the blocks [any][slot bits][codes], built in LDS when they have at most HS_CB_LDS_WORDS words, else in place ----
+    long long off_w = s_base;
+    for (int w = 0; w < wv * PW; ++w) off_w += s_size[w];
+    unsigned long long* __restrict__ blk = s_blk[wv];
+#pragma unroll
+    for (int c = 0; c < PW; ++c) {
+        if (!live[c]) continue;      // (wave-uniform)
+        const long long k = k0 + c;
+        long long off = off_w;
+        off_w += size[c];
+        if (off + size[c] > cap_words || W[c] > 65535) { if (lane == 0) atomicOr(counter + 1, 1ull); off = -1; }
+        const uint8_t* __restrict__ slot_of = s_slot[wv][c];
+        const uint8_t* __restrict__ codes = s_codes[wv][c];
+        if (off >= 0 && n[c] > 0 && n[c] <= 64 && W[c] <= 4) {
+            // every entry is another read, so (word, bit) is another cell for each: a byte per cell holding the entry's slot + 1, written without a
+            // conflict, and the rows of the block are ballots over those bytes -- no atomic, no word that 30 lanes OR into at once
+            unsigned long long* __restrict__ out = out_words + off;
+            uint8_t* __restrict__ cellb = reinterpret_cast<uint8_t*>(blk);
+            reinterpret_cast<uint32_t*>(cellb)[lane] = 0u;      // 256 bytes: four words of 64 cells
+            wave_lds_sync();
+            if (lane < n[c]) { const int rk = rc0[c] >> 8; cellb[(((rk >> 6) - lo[c]) << 6) + (rk & 63)] = (uint8_t)(my_slot[c] + 1); }
+            wave_lds_sync();
+            unsigned long long mine_w = 0ull;      // lane x keeps word x of the block
+            for (int w = 0; w < W[c]; ++w) {
+                const int v = cellb[(w << 6) + lane];
+                const unsigned long long any = __ballot(v != 0);
+                if (lane == w) mine_w = any;
+                for (int q = 0; q < nslots[c]; ++q) {
+                    const unsigned long long row = __ballot(v == q + 1);
+                    if (lane == (q + 1) * W[c] + w) mine_w = row;
+                }
             }
+            if (cells[c] <= 64) { if (lane < cells[c]) out[lane] = mine_w; }
+            else {      // (more than 64 words: 16 and more codes over four words -- the rows once more, one word at a time)
+                for (int w = 0; w < W[c]; ++w) {
+                    const int v = cellb[(w << 6) + lane];
+                    const unsigned long long any = __ballot(v != 0);
+                    if (lane == 0) out[w] = any;
+                    for (int q = 0; q < nslots[c]; ++q) { const unsigned long long row = __ballot(v == q + 1); if (lane == 0) out[(long long)(q + 1) * W[c] + w] = row; }
+                }
+            }
+            if (lane < (nslots[c] + 7) / 8) {
+                unsigned long long cw = 0;
+                for (int q = 0; q < 8; ++q) if (8 * lane + q < nslots[c]) cw |= (unsigned long long)codes[8 * lane + q] << (8 * q);
+                out[cells[c] + lane] = cw;
+            }
+            wave_lds_sync();      // (blk is the next column's)
+        } else if (off >= 0 && n[c] > 0) {
+            unsigned long long* __restrict__ out = out_words + off;
+            const bool in_lds = cells[c] <= HS_CB_LDS_WORDS;
+            if (in_lds) { for (int x = lane; x < cells[c]; x += 64) blk[x] = 0ull; }
+            else { for (int x = lane; x < cells[c]; x += 64) out[x] = 0ull; __threadfence(); }
+            wave_lds_sync();
+            for (int j0 = 0; j0 < n[c]; j0 += 64) {
+                const int j = j0 + lane;
+                if (j < n[c]) {
+                    int rk, cd;
+                    if (j0 == 0) { rk = rc0[c] >> 8; cd = rc0[c] & 255; }
+                    else { rk = rank_end[r0[c] + cand_idx[e0[c] + j]].x; cd = cand_code[e0[c] + j]; }
+                    const int w = (rk >> 6) - lo[c];
+                    const unsigned long long bit = 1ull << (rk & 63);
+                    const int sl = n[c] <= 64 ? my_slot[c] : (int)slot_of[cd];
+                    if (in_lds) { atomicOr(&blk[w], bit); atomicOr(&blk[(sl + 1) * W[c] + w], bit); }
+                    else { atomicOr(&out[w], bit); atomicOr(&out[(long long)(sl + 1) * W[c] + w], bit); }
+                }
+            }
+            wave_lds_sync();
+            if (in_lds) for (int x = lane; x < cells[c]; x += 64) out[x] = blk[x];
+            if (lane < (nslots[c] + 7) / 8) {
+                unsigned long long cw = 0;
+                for (int q = 0; q < 8; ++q) if (8 * lane + q < nslots[c]) cw |= (unsigned long long)codes[8 * lane + q] << (8 * q);
+                out[cells[c] + lane] = cw;
+            }
+            wave_lds_sync();      // (blk is the next column's)
         }
-        wave_lds_sync();
-        if (in_lds) for (int x = lane; x < cells; x += 64) out[x] = blk[x];
-        if (lane < (nslots + 7) / 8) {
-            unsigned long long cw = 0;
-            for (int q = 0; q < 8; ++q) if (8 * lane + q < nslots) cw |= (unsigned long long)codes[8 * lane + q] << (8 * q);
-            out[cells + lane] = cw;
+        if (lane == 0) {
+            CandBitsDev h;
+            h.wlo = lo[c]; h.n_words = (uint16_t)(W[c] > 65535 ? 65535 : W[c]); h.n_slots = (uint16_t)nslots[c];
+            h.idx_min = n[c] > 0 ? cand_idx[e0[c]] : 0; h.idx_max = n[c] > 0 ? cand_idx[e0[c] + n[c] - 1] : -1; h.reach = reach[c]; h.n_entries = n[c]; h.word_off = off;
+            out_bits[k] = h;
         }
-        if (nslots > 64 * 8) { /* unreachable: at most 128 slots */ }
-    }
-    if (lane == 0) {
-        CandBitsDev h;
-        h.wlo = lo; h.n_words = (uint16_t)(W > 65535 ? 65535 : W); h.n_slots = (uint16_t)nslots;
-        h.idx_min = n > 0 ? cand_idx[e0] : 0; h.idx_max = n > 0 ? cand_idx[e0 + n - 1] : -1; h.reach = reach; h.n_entries = n; h.word_off = off;
-        out_bits[k] = h;
     }
 }
 
