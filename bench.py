@@ -327,10 +327,11 @@ def main():
     thr0 = throttle_stats()
     if os.environ.get("HS_CPU_PROFILE"):      # diagnostic: sampling profile of the host side over the timed steps (tools/cpuprof_report.py)
         api.load().hs_cpuprof_start(os.environ["HS_CPU_PROFILE"].encode())
-    # The library's timing events (two per kernel launch) are recorded on every STATS_EVERY-th step of the timed region: ~1200 event records
+    # The library's timing events (two per kernel launch) are recorded on every STATS_EVERY-th step of the timed region (default: every tenth, at
+    # least two steps): ~1200 event records
     # per C4 step cost the step 1.3 ms when every step is instrumented (alternating runs on one box: 15.6 against 16.9 ms per step). The
     # per-kernel rows below are averages over the instrumented steps; `value` is the mean over ALL timed steps, instrumented or not.
-    STATS_EVERY = max(1, int(os.environ.get("HS_BENCH_STATS_EVERY", "4")))
+    STATS_EVERY = max(1, int(os.environ.get("HS_BENCH_STATS_EVERY", str(max(1, min(10, args.steps // 2))))))      # (two instrumented steps of the default twenty)
     api.kernel_stats_every(STATS_EVERY)
     K_TIMED = (args.steps + STATS_EVERY - 1) // STATS_EVERY
     api.kernel_stats_reset()
