@@ -94,24 +94,39 @@ def run_stage_pair(cv, sr, files, td, tag, threads, env=None):
     return t1 - t0, t2 - t1
 
 
-def file_to_file(cfg, n_job, sample_ids, sample_files, job_files, reps, reference_on_full_job):
+def run_stage4_on(sr, col, err_file, td, tag, threads):
+    """stage 4 alone on an existing .col (the second half of run_stage_pair); returns (seconds, .gro path)"""
+    gro = os.path.join(td, f"{tag}.gro")
+    e = py_error_rate(float(open(err_file).read().strip()))
+    t0 = time.perf_counter()
+    subprocess.run(sr + [col, str(threads), str(e), os.path.join(td, "no_ploidy"), "0", "0.01", "0", gro, "0"], check=True, stdout=subprocess.DEVNULL, timeout=900)
+    return time.perf_counter() - t0, gro
+
+
+def file_to_file(cfg, n_job, sample_ids, sample_files, job_files, reps, reference_on_full_job, parity_fn=None):
     """SURVEY.md 8(d) metric (ii): wall clock of the two drop-in executables next to the compiled reference (oracle/_ref,
     built from /root/reference by oracle/Makefile) on the SAME files. The drop-ins are timed both ways: as a caller sees them
     (the started process exits when the outputs are complete, the worker's teardown goes on in the background: hs_dropin_main.h)
     and with HS_NO_DETACH=1 (one process, timed to its full exit) -- speed-ups are quoted from the second, conservative number.
     The reference runs ONCE on the files of the whole job (C4: about 40 s with 16 threads) -- that run is the `cpu_baseline` of
-    the bench line; without the job's files (or with --no-f2f-reference-full) it runs on a bounded sample instead."""
+    the bench line; without the job's files (or with --no-f2f-reference-full) it runs on a bounded sample instead.
+    PARITY GATE: `parity_fn(col, gro, err, against, subset)` is called while the reference's output files exist -- the .col / error rate
+    of the reference's HS_call_variants and the .gro of its HS_separate_reads built with std::random_device pinned (oracle/_ref/
+    HS_separate_reads_seeded: the stock binary re-seeds from the hardware at every Chinese-Whispers sweep, its labels are not reproducible,
+    cluster_graph.cpp:175-177) on the SAME files -- and compares them with what the timed steps of this run returned."""
     import __graft_entry__ as ge
     p = ge.paths()
     cores = effective_cores()
     have_ref = os.path.exists(p["ref_cv"]) and os.path.exists(p["ref_sr"])
+    have_seeded = have_ref and os.path.exists(p["ref_sr_seeded"])
+    parity = [None]
     if not have_ref and not os.path.exists(p["oracle"]):
         return None, None
     out = {"threads": cores, "runs": reps}
     med = lambda v: statistics.median(v)
     no_detach = dict(os.environ, HS_NO_DETACH="1")
 
-    def leg(files, n_contigs, with_reference, tag):
+    def leg(files, n_contigs, with_reference, tag, subset):
         bp = int(files["aligned_bp"])
         with tempfile.TemporaryDirectory() as td:
             det = [run_stage_pair([p["cv"]], [p["sr"]], files, td, "hip", cores) for _ in range(reps)]
@@ -134,18 +149,29 @@ def file_to_file(cfg, n_job, sample_ids, sample_files, job_files, reps, referenc
                 d["speedup"] = (a + b) / d["dropin_s"]["total"]
                 d["speedup_detached"] = (a + b) / d["dropin_detached_s"]["total"]
                 d["reference_kind"] = kind
+                gro_ref, against = os.path.join(td, "ref.gro"), "oracle restatement (oracle/_build/hs_oracle), seed 12345"
+                if kind == "reference":
+                    gro_ref, against = None, "reference HS_call_variants (.col, error rate); no seeded HS_separate_reads on this box: .gro not compared"
+                    if have_seeded:      # the reference's stage 4 with std::random_device pinned, on the reference's own .col: what the labels are compared with
+                        b_seeded, gro_ref = run_stage4_on([p["ref_sr_seeded"]], os.path.join(td, "ref.col"), os.path.join(td, "ref.err"), td, "refseed", cores)
+                        against = "reference binaries built from /root/reference (oracle/_ref): HS_call_variants + HS_separate_reads_seeded (std::random_device pinned to 12345)"
+                        d["reference_seeded_s"] = {"call_variants": a, "separate_reads": b_seeded, "total": a + b_seeded,
+                                                   "note": "the same reference with std::random_device pinned (no entropy read per Chinese-Whispers sweep): the deterministic build the parity gate compares with"}
+                        d["speedup_vs_seeded_reference"] = (a + b_seeded) / d["dropin_s"]["total"]
+                if parity_fn is not None and parity[0] is None:
+                    parity[0] = parity_fn(os.path.join(td, "ref.col"), None if subset else gro_ref, os.path.join(td, "ref.err"), against, subset)
                 base = {"value": bp / (a + b), "unit": "aligned read-bp/s", "cores": threads, "kind": kind,
                         "sample": f"{tag} ({bp} aligned bp), stage 3+4 file to file, one run: {a + b:.2f} s wall"
-                                  + (f", -t {threads} (contig-level OpenMP only)" if kind == "reference" else ", single thread"),
+                                  + (f", -t {threads} (contig-level OpenMP only)" if kind == "reference" else ", single thread") + "; ONE run, not a median",
                         "note": "file to file (parsing 2 GB of text included): compare with file_to_file.*.dropin_bp_per_s, NOT with `value` (HBM-resident steps)"}
             return d, base
 
     base = None
     if job_files is not None:
-        out["job"], base = leg(job_files, n_job, reference_on_full_job, f"the whole job: the {n_job} contigs of {cfg}")
+        out["job"], base = leg(job_files, n_job, reference_on_full_job, f"the whole job: the {n_job} contigs of {cfg}", False)
     if base is None and sample_files is not None:
-        out["sample"], base = leg(sample_files, len(sample_ids), True, f"the first {len(sample_ids)} of the {n_job} contigs of {cfg}")
-    return out, base
+        out["sample"], base = leg(sample_files, len(sample_ids), True, f"the first {len(sample_ids)} of the {n_job} contigs of {cfg}", True)
+    return out, base, parity[0]
 
 
 def main():
@@ -251,6 +277,7 @@ def main():
     n_threads = args.threads or max(1, min(64, (3 * effective_cores()) // (1 if args.cores > 0 else world)))      # (16 usable cores: 32 threads 46 ms per step, 48: 44, 64: 47, 128: 51)
 
     B = len(contigs)
+    contig_names = [c.name for c in contigs]
     G = max(1, min(args.groups if args.groups > 0 else min(8, max(1, n_threads // 3)), max(B, 1)))      # (a rank of 8 with 6 threads: 2 groups, 7.0 ms per step on its shard against 10.3 with one)
     pet()
     t_up = time.perf_counter()
@@ -341,11 +368,14 @@ def main():
     last = None
     step_ms = []
     wall = {}
-    for _ in range(args.steps):
+    last_results = None
+    for it in range(args.steps):
         pet()
         ts = time.perf_counter()
         cv, sr, gathered = step()
         step_ms.append((time.perf_counter() - ts) * 1e3)
+        if it == args.steps - 1:
+            last_results = (cv, sr)      # the LAST TIMED STEP's results: what the parity gate compares with the reference (after the clock stops)
         for kk, vv in sr.get("wall_ms", {}).items():
             wall[kk] = wall.get(kk, 0.0) + vv
         t_dev += cv["t_device_ms"] + sr["t_device_ms"]; t_host += cv["t_host_ms"] + sr["t_host_ms"]
@@ -356,6 +386,14 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3
+    # ---- parity gate, part 1: copies of what the last timed step left with the host (its arrays belong to the pipeline and die with the
+    # next call). Compared with the reference's files in the file-to-file leg below; one rank = the whole job only ----
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    snap_timed = snap_col = None
+    if rank == 0 and world == 1 and not emulated and last_results is not None:
+        import ref_outputs
+        snap_timed = ref_outputs.pipeline_snapshot(batch, last_results[0], last_results[1], contig_names)
+    last_results = None
     waits_per_step = (api.host_waits() - waits0) / args.steps
     if os.environ.get("HS_CPU_PROFILE"):
         api.load().hs_cpuprof_stop()
@@ -375,7 +413,7 @@ def main():
             cv1, sr1 = pl.run_fused(0.33, n_threads, rarest_strain_abundance=0.01, window_size=window_size)
         else:
             cv1, sr1 = pl.run(0.33, n_threads, error_rate_fn, rarest_strain_abundance=0.01, window_size=window_size)
-        cv1 = sr1 = None
+        return cv1, sr1
 
     if G > 1 and not use_dist and not profiled and not os.environ.get("HS_BENCH_NO_PROBE"):
         probe = None
@@ -402,9 +440,12 @@ def main():
             any_step(batch); any_step(batch); sync()
             tc0 = time.perf_counter()
             for _ in range(5):
-                any_step(batch)
+                res_col = any_step(batch)
             sync()
             ms_with_col = (time.perf_counter() - tc0) / 5 * 1e3
+            if snap_timed is not None:      # (with the SNP columns' entries: the .col's SNPS lines are compared whole)
+                snap_col = ref_outputs.pipeline_snapshot(batch, res_col[0], res_col[1], contig_names)
+            res_col = None
         except Exception as e:
             sys.stderr.write("column-download leg failed: %r\n" % (e,))
         finally:
@@ -423,6 +464,7 @@ def main():
     else:
         total_bp = local_bp
 
+    parity_failed = False
     if rank == 0:
         K = args.steps
         # ---- roofline of the kernel family with the largest time per step (all kernels of the path compete) ----
@@ -470,7 +512,10 @@ def main():
         out = {
             "metric": "aligned read-bp/sec through call_variants+separate_reads",
             "value": total_bp * K / dt, "unit": "aligned read-bp/s", "n_gpus": 1 if emulated else world, "steps": K, "warmup": args.warmup, "setup_steps": SETUP_STEPS,
-            "ms_per_step": dt / K * 1e3, "ms_per_step_with_col_download": ms_with_col, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
+            "ms_per_step": dt / K * 1e3, "ms_per_step_with_col_download": ms_with_col,
+            "value_with_col_download": (total_bp / (ms_with_col * 1e-3)) if ms_with_col else None,
+            "value_excludes_col_payload": True,      # the timed steps hand the SNP columns' entries (.col's payload) from stage 3 to stage 4 ON THE DEVICE (config.outputs)
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "host": {"cpus_online": os.cpu_count(), "cpus_effective": effective_cores(), "process_cpu_ms_per_step": cpu_ms_per_step,
                      "cfs_throttled_during_timed_steps": throttled, "input_generation_s": t_gen, "waits_per_step": waits_per_step,
@@ -491,21 +536,19 @@ def main():
                                   "alleles and read counts. NOT in the timed steps: the per-read entries of the SNP columns (.col's payload) -- stage 3 hands them to stage 4 on "
                                   "the device; `ms_per_step_with_col_download` is the same step with them brought to the host as well"},
             "roofline": {"bound": "hbm", "kernel": dom,
-                         # the kernel on its own (one contig group, nothing else on the GPU): what the kernel itself achieves
-                         "achieved": alone["achieved"] if alone else d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (alone["achieved"] if alone else d["achieved_GBs"]) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": alone["avg_launch_ms"] if alone else d["avg_launch_ms"],
-                         "launches_per_step": alone["launches_per_step"] if alone else d["launches_per_step"],
-                         "algorithmic_bytes_per_launch": alone["algorithmic_bytes_per_launch"] if alone else d["algorithmic_bytes_per_launch"],
-                         "measured": ("HIP events on the launch stream, %d steps of the same resident job through a ONE-group pipeline right after the timed region: every kernel "
-                                      "alone on the GPU (reproducible from profiles/*_groups1.csv)" % PROBE_STEPS) if alone else "HIP events on the launch streams over the timed region",
-                         "selection": "the kernel with the largest time per step when it runs alone (all kernels of the path compete; transfers excluded)",
-                         # the same kernel inside the timed region, where the contig groups' kernels share the GPU
-                         "timed_region": {"achieved": d["achieved_GBs"], "frac": d["achieved_GBs"] / HBM_PEAK_GBS, "avg_launch_ms": d["avg_launch_ms"],
-                                          "launches_per_step": d["launches_per_step"], "ms_per_step": d["ms_per_step"],
-                                          "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
-                                          "note": "HIP events on each launch stream over the K timed steps; %d contig groups overlap, a launch shares the GPU with the other groups' kernels" % G},
-                         "alone": alone,
+                         # PRIMARY: the dominant kernel INSIDE THE TIMED REGION -- HIP events on each launch stream over the instrumented timed steps; the
+                         # contig groups overlap there, so a launch shares the GPU with the other groups' kernels (the kernel on its own: `probe_one_group`)
+                         "achieved": d["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["achieved_GBs"] / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"], "ms_per_step": d["ms_per_step"],
+                         "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+                         "measured": "HIP events on the launch streams over the instrumented steps of the timed region (%d contig groups overlap)" % G,
+                         "selection": "the kernel with the largest time per step when it runs alone (one-group probe; all kernels of the path compete; transfers excluded)"
+                                      if alone else "the kernel with the largest time per step in the timed region (transfers excluded)",
+                         # PROBE (not the timed region): the same resident job through a ONE-group pipeline right after the timed region, every kernel alone
+                         # on the GPU, one launch per step over the whole job -- the kernel's own rate, reproducible from profiles/*_groups1.csv
+                         "frac_probe_one_group": alone["frac"] if alone else None,
+                         "probe_one_group": alone,
                          "whole_path": whole},
             "kernel_timing": {"events_on_every_nth_step": STATS_EVERY, "instrumented_steps": K_TIMED, "of_steps": args.steps,
                               "note": "per-kernel rows and roofline.timed_region: HIP events on the launch streams over the instrumented steps of the timed region; `value` and ms_per_step: all timed steps"},
@@ -520,13 +563,37 @@ def main():
             try:
                 pet()
                 faulthandler.cancel_dump_traceback_later()      # (the reference on the whole job takes its time; every subprocess has its own limit)
-                f2f, base = file_to_file(cfg, n_job, list(range(n_sample)), sample_files, job_files, max(1, args.f2f_runs), not args.no_f2f_reference_full)
+                def parity_fn(col, gro, err, against, subset):
+                    if snap_timed is None:
+                        return None
+                    t_p = time.perf_counter()
+                    r = ref_outputs.compare_with_reference(snap_timed, col, gro, err, subset=subset)
+                    r["against"] = against
+                    r["what"] = "the results of the LAST TIMED STEP (%s, %d contig groups, sparse labels, size hints of the step before)" % ("hs_pipeline_run_fused" if fused else "hs_pipeline_select + hs_pipeline_run", G)
+                    if snap_col is not None:      # the same job one leg later, with the SNP columns' entries on the host: the SNPS lines whole
+                        rc_ = ref_outputs.compare_with_reference(snap_col, col, gro, err, subset=subset)
+                        r["col_entries_identical"] = rc_["col_entries_identical"]
+                        r["col_download_step_identical"] = rc_["identical"]
+                        if not rc_["identical"]:
+                            r["identical"] = False
+                            r.setdefault("diffs", []).extend(rc_.get("diffs", []))
+                    r["seconds"] = round(time.perf_counter() - t_p, 2)
+                    return r
+                f2f, base, par = file_to_file(cfg, n_job, list(range(n_sample)), sample_files, job_files, max(1, args.f2f_runs), not args.no_f2f_reference_full, parity_fn)
                 if f2f is not None:
                     out["file_to_file"] = f2f
                     out["cpu_baseline"] = base
+                if par is not None:
+                    out["parity"] = par
             except Exception as e:  # the baseline is informational; never fail the bench on it
                 out["cpu_baseline"] = {"error": repr(e)}
+        if "parity" not in out:
+            out["parity"] = {"checked": False, "why": "several ranks (each holds a shard; the full-job comparison runs at --gpus 1)" if (use_dist or emulated) else
+                             ("no file-to-file leg in this run (--cpu-contigs 0) or no reference / oracle binaries on this box" if "error" not in (out.get("cpu_baseline") or {}) else "the file-to-file leg failed")}
         print(json.dumps(out), flush=True)
+        if out["parity"].get("checked") and not out["parity"].get("identical"):
+            sys.stderr.write("PARITY GATE FAILED: the timed path's results differ from the reference's: %r\n" % (out["parity"].get("diffs"),))
+            parity_failed = True
     if batch is not None:
         batch.close()
     if job_dir is not None:
@@ -536,6 +603,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

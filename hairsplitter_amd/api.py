@@ -230,6 +230,26 @@ class FlatBatch:
         self.aligned_bp = int(self.pile_off[-1])
 
 
+    _ARRAYS = ("contig_seq", "contig_off", "read_seq", "read_off", "rec_read", "rec_pos", "rec_strand", "rec_cig_off", "cigar", "contig_rec_off",
+               "rec_contig", "rec_refspan", "rec_qend", "pile_off")
+
+    def save(self, path: str):
+        """the flat arrays as one .npz (a job generated in one process, run in another)"""
+        np.savez(path, **{k: getattr(self, k) for k in self._ARRAYS})
+
+    @classmethod
+    def load(cls, path: str) -> "FlatBatch":
+        o = object.__new__(cls)
+        with np.load(path) as z:
+            for k in cls._ARRAYS:
+                setattr(o, k, np.ascontiguousarray(z[k]))
+        o.n_contigs = len(o.contig_off) - 1
+        o.n_reads = len(o.read_off) - 1
+        o.n_rec = len(o.rec_read)
+        o.aligned_bp = int(o.pile_off[-1])
+        return o
+
+
 class CvBatch:
     """hs_cv_batch: a FlatBatch resident in HBM."""
 
@@ -381,7 +401,7 @@ class PipelineGroups:
     for a single call."""
 
     def __init__(self, contigs, n_groups):
-        self.flat = FlatBatch(contigs)
+        self.flat = contigs if isinstance(contigs, FlatBatch) else FlatBatch(contigs)
         self.batch = CvBatch(self.flat)
         self.handle = C.c_void_p()
         _check(load().hs_pipeline_create(self.batch.handle, C.c_int32(n_groups), C.byref(self.handle)))

@@ -1,5 +1,8 @@
 // ORACLE (test infrastructure, CPU only): flat-array C entry points so that the parity tests can compare the
 // HIP kernels with the CPU restatement buffer by buffer (ctypes). Never linked into the product.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -197,6 +200,127 @@ int hso_rh_order_int(const int32_t* keys, int32_t n, int32_t* out) {
     int k = 0;
     m.for_each([&](int key, int) { out[k++] = key; });
     return k;
+}
+
+}  // extern "C"
+
+// ---- reading the reference's OUTPUT files into flat arrays (checker side of bench.py's parity gate and of the tests that compare the
+// in-memory pipeline with the reference at full size). The formats are the writers' of call_variants.cpp:1184-1211 (.col) and
+// separate_reads.cpp:1756-1784 (.gro): CONTIG <name> <fields...> / READ ... / <tag> a b [c] idx,idx,..., val,val,...,
+struct hso_blocks {
+    int32_t n_contigs;
+    int64_t names_len;      // '\n'-separated contig names, in file order
+    char* names;
+    int64_t extra_len;      // '\n'-separated rest of every CONTIG line (after the name: "L\tdepth")
+    char* extra;
+    int32_t* n_read_lines;  // [C] READ lines of the contig
+    int64_t* rec_off;       // [C+1] records (SNPS / GROUP lines) of the contig
+    int64_t n_records;
+    int32_t *a, *b, *c;     // [R] the two or three numbers after the tag (.col: pos, ref, second; .gro: start, end, 0)
+    int64_t* ent_off;       // [R+1]
+    int32_t *idx, *val;     // the two comma lists (they must have the same length: otherwise the call fails)
+};
+
+static bool hso_read_file(const char* path, std::string& s) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END);
+    long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    s.resize((size_t)n);
+    size_t got = n ? std::fread(&s[0], 1, (size_t)n, f) : 0;
+    std::fclose(f);
+    return got == (size_t)n;
+}
+
+template <class T> static T* hso_dup(const std::vector<T>& v) {
+    T* p = (T*)std::malloc(std::max<size_t>(1, v.size()) * sizeof(T));
+    if (!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+extern "C" {
+
+void hso_blocks_free(hso_blocks* b) {
+    if (!b) return;
+    std::free(b->names); std::free(b->extra); std::free(b->n_read_lines); std::free(b->rec_off); std::free(b->a); std::free(b->b); std::free(b->c);
+    std::free(b->ent_off); std::free(b->idx); std::free(b->val);
+    delete b;
+}
+
+// n_fixed = 3 for "SNPS" (.col), 2 for "GROUP" (.gro). Returns 0, or a negative code (-1 unreadable, -2 malformed line).
+int hso_parse_blocks(const char* path, const char* tag, int32_t n_fixed, hso_blocks** out) {
+    std::string s;
+    if (!hso_read_file(path, s)) return -1;
+    const size_t tl = std::strlen(tag);
+    std::string names, extra;
+    std::vector<int32_t> nread, a, b, c, idx, val;
+    std::vector<int64_t> rec_off, ent_off;
+    ent_off.push_back(0);
+    const char* p = s.data();
+    const char* end = p + s.size();
+    auto number = [&](const char*& q, const char* e, int32_t& v) -> bool {
+        bool neg = false;
+        if (q < e && *q == '-') { neg = true; ++q; }
+        if (q >= e || *q < '0' || *q > '9') return false;
+        int64_t x = 0;
+        while (q < e && *q >= '0' && *q <= '9') { x = x * 10 + (*q - '0'); ++q; }
+        v = (int32_t)(neg ? -x : x);
+        return true;
+    };
+    while (p < end) {
+        const char* e = (const char*)std::memchr(p, '\n', (size_t)(end - p));
+        if (!e) e = end;
+        if (e - p >= 7 && std::memcmp(p, "CONTIG\t", 7) == 0) {
+            const char* q = p + 7;
+            const char* t = (const char*)std::memchr(q, '\t', (size_t)(e - q));
+            if (!t) t = e;
+            names.append(q, t); names.push_back('\n');
+            if (t < e) extra.append(t + 1, e);
+            extra.push_back('\n');
+            nread.push_back(0);
+            rec_off.push_back((int64_t)a.size());
+        } else if (e - p >= 5 && std::memcmp(p, "READ\t", 5) == 0) {
+            if (nread.empty()) return -2;
+            nread.back() += 1;
+        } else if ((size_t)(e - p) > tl && std::memcmp(p, tag, tl) == 0 && p[tl] == '\t') {
+            if (nread.empty()) return -2;
+            const char* q = p + tl + 1;
+            int32_t v[3] = {0, 0, 0};
+            for (int k = 0; k < n_fixed; ++k) {
+                if (!number(q, e, v[k])) return -2;
+                if (q < e && *q == '\t') ++q;
+            }
+            a.push_back(v[0]); b.push_back(v[1]); c.push_back(v[2]);
+            size_t n0 = idx.size();
+            while (q < e && *q != '\t') {
+                int32_t x;
+                if (!number(q, e, x)) return -2;
+                idx.push_back(x);
+                if (q < e && *q == ',') ++q;
+            }
+            if (q < e && *q == '\t') ++q;
+            while (q < e && *q != '\t') {
+                int32_t x;
+                if (!number(q, e, x)) return -2;
+                val.push_back(x);
+                if (q < e && *q == ',') ++q;
+            }
+            if (val.size() != idx.size()) return -2;
+            (void)n0;
+            ent_off.push_back((int64_t)idx.size());
+        }
+        p = e + 1;
+    }
+    rec_off.push_back((int64_t)a.size());
+    hso_blocks* B = new hso_blocks();
+    B->n_contigs = (int32_t)nread.size();
+    B->names_len = (int64_t)names.size(); B->names = (char*)std::malloc(names.size() + 1); std::memcpy(B->names, names.c_str(), names.size() + 1);
+    B->extra_len = (int64_t)extra.size(); B->extra = (char*)std::malloc(extra.size() + 1); std::memcpy(B->extra, extra.c_str(), extra.size() + 1);
+    B->n_read_lines = hso_dup(nread); B->rec_off = hso_dup(rec_off); B->n_records = (int64_t)a.size();
+    B->a = hso_dup(a); B->b = hso_dup(b); B->c = hso_dup(c); B->ent_off = hso_dup(ent_off); B->idx = hso_dup(idx); B->val = hso_dup(val);
+    *out = B;
+    return 0;
 }
 
 }  // extern "C"

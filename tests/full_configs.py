@@ -12,15 +12,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def generate_files(cfg, outdir, count=None, workers=None):
+def generate_files(cfg, outdir, count=None, workers=None, with_flat=False):
     """Writes assembly.gfa / reads.fasta / aln.sam of a configuration in a CHILD process (forked generator workers must not
-    inherit an initialised HIP runtime; the pytest process may have one). Returns (paths, aligned_bp, n_contigs, seconds)."""
+    inherit an initialised HIP runtime; the pytest process may have one). Returns (paths, aligned_bp, n_contigs, seconds).
+    `with_flat`: the same contigs also as the flat arrays of the C ABI (paths['flat'], an .npz of api.FlatBatch) and paths['names']:
+    what bench.py builds its resident batch from."""
     t = time.perf_counter()
-    code = ("import sys, json; sys.path.insert(0, %r)\n"
+    code = ("import sys, json, os; sys.path.insert(0, %r)\n"
             "from hairsplitter_amd import synth\n"
             "cs = synth.config_contigs_parallel(%r, count=%r, workers=%r)\n"
             "f = synth.write_files(cs, %r)\n"
-            "print(json.dumps({'files': f, 'bp': int(sum(c.aligned_bp for c in cs)), 'n': len(cs)}))\n") % (ROOT, cfg, count, workers, outdir)
+            "if %r:\n"
+            "    from hairsplitter_amd import api\n"
+            "    f['flat'] = os.path.join(%r, 'flat.npz'); api.FlatBatch(cs).save(f['flat']); f['names'] = [c.name for c in cs]\n"
+            "print(json.dumps({'files': f, 'bp': int(sum(c.aligned_bp for c in cs)), 'n': len(cs)}))\n") % (ROOT, cfg, count, workers, outdir, bool(with_flat), outdir)
     r = subprocess.run([sys.executable, "-c", code], check=True, stdout=subprocess.PIPE)
     j = json.loads(r.stdout.decode().strip().splitlines()[-1])
     return j["files"], j["bp"], j["n"], time.perf_counter() - t
@@ -57,13 +62,48 @@ def compare_outputs(a, b, out):
     out["n_groups"] = sum(1 for l in open(a[3]) if l.startswith("GROUP"))
 
 
-def run_config(cfg, td, count=None, threads=None, with_gaf=True, low_memory=0):
-    """Returns a dict with the verdicts (col/vcf/error_rate/gro[/gaf]_identical) and the wall clocks."""
+def bench_path_check(flat_npz, names, ref_col, ref_gro, ref_err, n_groups=8, n_threads=0):
+    """THE PATH bench.py TIMES, against the reference's files of the same job: the job resident in HBM as api.PipelineGroups with
+    `n_groups` contig groups, hs_pipeline_run_fused with sparse labels (what bench.py's step() calls), two consecutive steps -- the
+    second runs on the size hints the first left -- then two more with HS_PIPELINE_KEEP_COLUMNS (the SNP columns' entries on the host
+    too). Every step's results are compared per contig with the reference's .col / error_rate / seeded .gro (oracle/ref_outputs.py).
+    match: separate_reads.cpp:1754-1786, call_variants.cpp:1184-1211,1310-1316."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bench
+    import ref_outputs as ro
+    from hairsplitter_amd import api
+    n_threads = n_threads or max(1, min(64, 3 * bench.effective_cores()))
+    flat = api.FlatBatch.load(flat_npz)
+    pg = api.PipelineGroups(flat, n_groups)
+    out = {"groups": n_groups, "threads": n_threads, "steps": []}
+    try:
+        pg.sparse_labels(True)
+        for keep in (False, True):
+            pg.keep_columns(keep)
+            for k in range(2):
+                t0 = time.perf_counter()
+                cv, sr = pg.run_fused(0.33, n_threads, rarest_strain_abundance=0.01)
+                ms = (time.perf_counter() - t0) * 1e3
+                snap = ro.pipeline_snapshot(pg, cv, sr, names)
+                cv = sr = None
+                r = ro.compare_with_reference(snap, ref_col, ref_gro, ref_err)
+                r["keep_columns"], r["step"], r["ms"] = keep, k, round(ms, 2)
+                out["steps"].append(r)
+    finally:
+        pg.close()
+    out["identical"] = all(r["identical"] for r in out["steps"])
+    out["col_entries_identical"] = all(r["col_entries_identical"] for r in out["steps"] if r["keep_columns"])
+    return out
+
+
+def run_config(cfg, td, count=None, threads=None, with_gaf=True, low_memory=0, bench_path_groups=0):
+    """Returns a dict with the verdicts (col/vcf/error_rate/gro[/gaf]_identical) and the wall clocks.
+    `bench_path_groups` > 0: also bench_path_check() on the same job against the same reference files (out["bench_path"])."""
     import __graft_entry__ as ge
     import bench
     p = ge.paths()
     threads = threads or bench.effective_cores()
-    f, bp, n, t_gen = generate_files(cfg, td, count, workers=min(8, threads))
+    f, bp, n, t_gen = generate_files(cfg, td, count, workers=min(8, threads), with_flat=bench_path_groups > 0)
     out = {"config": cfg, "contigs": n, "aligned_bp": bp, "threads": threads, "generation_s": round(t_gen, 1)}
     if low_memory:
         out["low_memory"] = 1
@@ -80,6 +120,8 @@ def run_config(cfg, td, count=None, threads=None, with_gaf=True, low_memory=0):
         _, out["hip_no_detach"] = run_pair(p["cv"], p["sr"], f, td, "hip1", threads, env=dict(os.environ, HS_NO_DETACH="1"))
     b, out["ref"] = run_pair(p["ref_cv"], p["ref_sr_seeded"], f, td, "ref", threads, low_memory=low_memory)
     compare_outputs(a, b, out)
+    if bench_path_groups > 0:
+        out["bench_path"] = bench_path_check(f["flat"], f["names"], b[0], b[3], b[2], n_groups=bench_path_groups)
     if with_gaf and os.path.exists(p.get("ref_cnc", "")):
         # next stage: the .gaf derived from each side's own .gro (hs_gro_to_gaf vs the reference's HS_create_new_contigs, which
         # writes the .gaf and then stops at its first external tool)

@@ -286,3 +286,37 @@ def test_binary_companion_of_the_col_file(built, case):
         assert len(flipped) == len(txt)
         os.replace(edited + ".hsbin", same_size + ".hsbin")
         assert "from the binary companion" not in _sr_through_harness(built, td, meta, same_size, os.path.join(td, "s.gro"), rep)
+
+
+@pytest.mark.parametrize("case", ["multi", "penta30k", "linked"])
+def test_checker_reads_the_reference_files_as_a_line_parser_does(built, case):
+    """oracle/ref_outputs.read_blocks (the reader behind bench.py's parity gate and the full-size pipeline tests) against a plain
+    line-by-line parse of the goldens' .col and .gro"""
+    import sys
+    sys.path.insert(0, os.path.join(gu.ROOT, "oracle"))
+    import ref_outputs as ro
+    with tempfile.TemporaryDirectory() as td:
+        gu.unpack(case, td)
+        for fname, tag, nfix in (("variants.col", "SNPS", 3), ("reads_haplo.gro", "GROUP", 2)):
+            path = os.path.join(td, fname)
+            b = ro.read_blocks(path, tag)
+            names, extra, nread, recs = [], [], [], []
+            for line in open(path):
+                f = line.rstrip("\n").split("\t")
+                if f[0] == "CONTIG":
+                    names.append(f[1]); extra.append("\t".join(f[2:])); nread.append(0); recs.append([])
+                elif f[0] == "READ":
+                    nread[-1] += 1
+                elif f[0] == tag:
+                    nums = [int(x) for x in f[1:1 + nfix]] + [0] * (3 - nfix)
+                    recs[-1].append((nums, [int(x) for x in f[1 + nfix].split(",") if x], [int(x) for x in f[2 + nfix].split(",") if x]))
+            assert b["names"] == names and b["extra"] == extra and b["n_read_lines"].tolist() == nread
+            assert b["rec_off"].tolist() == np.concatenate(([0], np.cumsum([len(r) for r in recs]))).tolist()
+            k = 0
+            for rs in recs:
+                for nums, idx, val in rs:
+                    assert [int(b["a"][k]), int(b["b"][k]), int(b["c"][k])] == nums
+                    e0, e1 = int(b["ent_off"][k]), int(b["ent_off"][k + 1])
+                    assert b["idx"][e0:e1].tolist() == idx and b["val"][e0:e1].tolist() == val
+                    k += 1
+            assert k == len(b["a"]) and k > 0

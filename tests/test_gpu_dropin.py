@@ -146,8 +146,11 @@ def _parse_gro(path):
 
 
 def test_inmemory_pipeline_equals_oracle(built):
-    """The path bench.py times (hs_cv_batch resident in HBM -> hs_cv_run -> hs_sr_run, no files) gives the same SNP
-    columns and partition labels as the oracle run file-to-file on the same synthetic contigs."""
+    """The single-batch in-memory calls (hs_cv_batch resident in HBM -> hs_cv_run -> hs_sr_run, no files) give the same SNP
+    columns and partition labels as the oracle run file-to-file on the same synthetic contigs. (What bench.py times is the grouped,
+    fused call -- api.PipelineGroups.run_fused -- compared with the reference itself at full size in
+    tests/test_gpu_full_configs.py::test_bench_path_equals_reference_c3 / _c4 and with this single-batch form in
+    test_pipeline_groups_equal_single_batch.)"""
     import numpy as np
     from hairsplitter_amd import api, synth
     contigs = [synth.make_contig(21, i, 30_000, 2 + i, 0.01, 40, "ont") for i in range(3)]
@@ -185,7 +188,7 @@ def test_inmemory_pipeline_equals_oracle(built):
 
 
 def test_fused_pipeline_equals_two_step_path(built):
-    """hs_cv_run -> hs_sr_run_cv (what bench.py times) == hs_cv_run -> Python hand-over -> hs_sr_run."""
+    """hs_cv_run -> hs_sr_run_cv (stage 3 -> 4 handed over inside the library) == hs_cv_run -> Python hand-over -> hs_sr_run."""
     import numpy as np
     from hairsplitter_amd import api, synth
     contigs = [synth.make_contig(22, i, 25_000, 2 + (i % 3), 0.01, 40, "ont") for i in range(4)]

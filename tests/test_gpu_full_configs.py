@@ -15,17 +15,24 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _check(built, cfg, count=None, with_gaf=True, low_memory=0):
-    if not (os.path.exists(built["ref_cv"]) and os.path.exists(built["ref_sr_seeded"])):
-        pytest.fail("oracle/_ref binaries are missing: run `make -C oracle ref` where /root/reference exists (they travel with the snapshot)")
-    with tempfile.TemporaryDirectory() as td:
-        out = fc.run_config(cfg, td, count, with_gaf=with_gaf, low_memory=low_memory)
-    try:   # a record of the run next to the profiles of the round (scratch on the GPU box, merged back by gpurun)
-        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", "parity_full_configs.jsonl"), "a") as f:
-            f.write(json.dumps(out) + "\n")
-    except OSError:
-        pass
+_RUNS = {}      # one generation + one run of the reference per configuration, shared by the tests that look at it
+
+
+def _check(built, cfg, count=None, with_gaf=True, low_memory=0, bench_path_groups=0):
+    key = (cfg, count, with_gaf, low_memory, bench_path_groups)
+    if key not in _RUNS:
+        if not (os.path.exists(built["ref_cv"]) and os.path.exists(built["ref_sr_seeded"])):
+            pytest.fail("oracle/_ref binaries are missing: run `make -C oracle ref` where /root/reference exists (they travel with the snapshot)")
+        with tempfile.TemporaryDirectory() as td:
+            out = fc.run_config(cfg, td, count, with_gaf=with_gaf, low_memory=low_memory, bench_path_groups=bench_path_groups)
+        _RUNS[key] = out
+        try:   # a record of the run next to the profiles of the round (scratch on the GPU box, merged back by gpurun)
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "parity_full_configs.jsonl"), "a") as f:
+                f.write(json.dumps(out) + "\n")
+        except OSError:
+            pass
+    out = _RUNS[key]
     assert out["col_identical"], out.get("col_diff")
     assert out["vcf_identical"]
     assert out["error_rate_identical"]
@@ -50,20 +57,51 @@ def test_c2_x16_low_memory_flag_equals_reference(built):
 
 def test_c3_full_size_equals_reference(built):
     """C3: 50 contigs x 200 kb, tetraploid, 40x ONT (400 M aligned bp)"""
-    out = _check(built, "C3")
+    out = _check(built, "C3", bench_path_groups=8)
     assert out["contigs"] == 50 and out["aligned_bp"] > 3.9e8
 
 
 def test_c4_full_size_equals_reference(built):
-    """C4: the 500-contig metagenome, ploidy 1-8, 30x ONT (1.7 G aligned bp) -- the configuration the headline metric is quoted on"""
-    out = _check(built, "C4")
+    """C4: the 500-contig metagenome, ploidy 1-8, 30x ONT (1.7 G aligned bp) -- the configuration the headline metric is quoted on.
+    Parity only: the file-to-file speed-up of the same run is recorded (gpurun_out/parity_full_configs.jsonl, bench.py's
+    file_to_file.job) and asserted in test_c4_file_to_file_speedup_no_detach, not here."""
+    out = _check(built, "C4", bench_path_groups=8)
     assert out["contigs"] == 500 and out["aligned_bp"] > 1.6e9
-    # BASELINE.json's target is >= 20x the reference's call_variants + separate_reads wall clock at 8 GPUs. On ONE GPU, file to file
-    # (3.6 GB of text parsed by both sides), as the orchestrator sees the two stages (hairsplitter.py:668-679,725-726), next to the
-    # reference with all cores, runs on this pool give 38x - 44x (23x - 27x timed to the full exit of the processes: recorded as
-    # speedup_file_to_file_no_detach in gpurun_out/parity_full_configs.jsonl and in bench.py's file_to_file.job.speedup); the
-    # assertion is the target itself, half of what is measured, so that a regression fails the suite
-    assert out["speedup_file_to_file"] >= 20, (out["hip"], out.get("hip_runs_s"), out["ref"])
+
+
+def _bench_path(out):
+    bp = out["bench_path"]
+    bad = [r for r in bp["steps"] if not r["identical"]]
+    assert not bad, bad[:2]
+    assert len(bp["steps"]) == 4 and bp["col_entries_identical"]
+    for r in bp["steps"]:
+        assert r["gro_identical"] and r["col_snps_identical"] and r["error_rate_identical"]
+        assert (r["col_entries_identical"] is True) == r["keep_columns"]
+    return bp
+
+
+def test_bench_path_equals_reference_c3(built):
+    """What bench.py times -- api.PipelineGroups(job, 8).run_fused with sparse labels, step after step on the size hints of the step
+    before, with and without HS_PIPELINE_KEEP_COLUMNS -- against the compiled reference on the same C3 job: per contig the GROUP lines
+    (bounds, reads, labels), the SNPS lines (positions, alleles, counts; entries when kept), depth and the error rate.
+    match: separate_reads.cpp:1754-1786, call_variants.cpp:1184-1211,1310-1316."""
+    bp = _bench_path(_check(built, "C3", bench_path_groups=8))
+    assert bp["steps"][0]["gro_group_lines"] > 4000 and bp["steps"][0]["col_snps_lines"] > 200_000
+
+
+def test_bench_path_equals_reference_c4(built):
+    """the same at C4 (500 contigs, 1.7 G aligned bp): the job and the driver (8 tapered contig groups, one fused call) of the headline number"""
+    bp = _bench_path(_check(built, "C4", bench_path_groups=8))
+    assert bp["steps"][0]["gro_group_lines"] > 20_000 and bp["steps"][0]["col_snps_lines"] > 800_000
+
+
+def test_c4_file_to_file_speedup_no_detach(built):
+    """BASELINE.json's target (>= 20x the reference's call_variants + separate_reads wall clock, quoted at 8 GPUs) on ONE GPU, file to
+    file (3.6 GB of text parsed by both sides), the drop-ins timed to the FULL EXIT of their processes (HS_NO_DETACH=1) against one run
+    of the reference with all cores on the same box. A performance assertion, kept apart from the parity tests: a noisy box fails this
+    test and no other. Measured on this pool: 23x - 28x."""
+    out = _check(built, "C4", bench_path_groups=8)
+    assert out["speedup_file_to_file_no_detach"] >= 20, (out["hip_no_detach"], out["ref"])
 
 
 def test_c5_chunks_full_size_equals_reference(built):
