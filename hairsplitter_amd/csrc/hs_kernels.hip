@@ -91,9 +91,13 @@ __global__ __launch_bounds__(256) void k_cigar_scan(
     // smallest number of events that precede an op which moves a cursor without owning events (S, H, N) and has events before
     // it: if events also follow it, the record is not one run of M/I/D events (see k_pileup_packed)
     int first_gap = 0x7fffffff;
+    // what the two events before the chunk were (k_pileup_runs forms the 3-mer context of an op's first events from it):
+    // 0 = an event that consumed a read base (M / I), 1 = a deletion, 2 / 3 = none yet: the initial 'G' / 'C' of call_variants.cpp:212-214
+    int ctx1 = 2, ctx2 = 3;
     for (int64_t ob = cig0; ob < cig1; ob += 64, ++k) {
         const int64_t oi = ob + lane;
-        const OpAdv a = op_advances(oi < cig1 ? cigar[oi] : 0u, oi < cig1);
+        const uint32_t opw = oi < cig1 ? cigar[oi] : 0u;
+        const OpAdv a = op_advances(opw, oi < cig1);
         const int ev_incl = wave_scan_incl(a.ev);
         const int ev = __builtin_amdgcn_readlane(ev_incl, 63), rd = wave_sum_i32(a.rd), rf = wave_sum_i32(a.rf);
         const bool gap = a.ev == 0 && (a.rd > 0 || a.rf > 0);
@@ -103,10 +107,24 @@ __global__ __launch_bounds__(256) void k_cigar_scan(
             const int m = -wave_max_i32(-cand);
             first_gap = m < first_gap ? m : first_gap;
         }
-        if (lane == 0) { cs[4 * k + 0] = ev_cur; cs[4 * k + 1] = t_cur; cs[4 * k + 2] = q_cur; cs[4 * k + 3] = 0; }
+        // bit 0 of the 4th slot of the record's FIRST chunk: the record is not one run of events (set below); bits 4..7: ctx1 | ctx2 << 2
+        if (lane == 0) { cs[4 * k + 0] = ev_cur; cs[4 * k + 1] = t_cur; cs[4 * k + 2] = q_cur; cs[4 * k + 3] = (ctx1 | (ctx2 << 2)) << 4; }
         ev_cur += ev; t_cur += rd; q_cur += rf;
+        {   // the last two events of the chunk (wave-uniform: three ballots)
+            const unsigned long long nz = __ballot(a.ev > 0), dm = __ballot(a.ev > 0 && (opw & 15u) == 2u), lg = __ballot(a.ev > 1);
+            if (nz) {
+                const int l1 = 63 - __builtin_clzll(nz);
+                const int t1 = (int)((dm >> l1) & 1ull);
+                if ((lg >> l1) & 1ull) { ctx1 = t1; ctx2 = t1; }
+                else {
+                    const unsigned long long below = nz & ((1ull << l1) - 1ull);
+                    ctx2 = below ? (int)((dm >> (63 - __builtin_clzll(below))) & 1ull) : ctx1;
+                    ctx1 = t1;
+                }
+            }
+        }
     }
-    if (lane == 0 && k > 0) cs[3] = first_gap < ev_cur ? 1 : 0;   // 4th slot of the record's first chunk entry
+    if (lane == 0 && k > 0 && first_gap < ev_cur) cs[3] |= 1;   // 4th slot of the record's first chunk entry
     if (lane == 0) {
         const int ctg = rec_contig[r];
         const int L = (int)(contig_off[ctg + 1] - contig_off[ctg]);
@@ -280,6 +298,7 @@ static __device__ __forceinline__ void pileup_task_per_event(
 // ------------------------------------------------------------------------------------------------
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
 // keeps the compiler from folding a chain of shifts and adds back into a 32-bit multiply (quarter rate on the VALU)
 static __device__ __forceinline__ uint32_t opaque(uint32_t x) { asm("" : "+v"(x)); return x; }
 // 0x01 bytes -> 0xff bytes
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(256) void k_pileup_packed(
     if (task >= n_tasks) return;   // wave-uniform
     const int r = task_rec[task];
     const int32_t* __restrict__ cs = chunk_start + 4 * rec_chunk_off[r];
-    if (cs[3] != 0) return;        // not one run of events: left to k_pileup_flagged_records
+    if ((cs[3] & 1) != 0) return;  // not one run of events: left to k_pileup_flagged_records
     const int e0 = task_ev0[task];
     const int e1 = e0 + ev_per_task;
     const int e_first = e0 >= 2 ? e0 - 2 : 0;
@@ -544,7 +563,7 @@ __global__ __launch_bounds__(256) void k_pileup_flagged_records(
     for (int base = ((int)blockIdx.x * 4 + wv) * 64; base < n_rec; base += n_waves * 64) {
         const int rr = base + lane;
         bool flagged = false;
-        if (rr < n_rec && rec_chunk_off[rr + 1] > rec_chunk_off[rr]) flagged = chunk_start[4 * rec_chunk_off[rr] + 3] != 0;
+        if (rr < n_rec && rec_chunk_off[rr + 1] > rec_chunk_off[rr]) flagged = (chunk_start[4 * rec_chunk_off[rr] + 3] & 1) != 0;
         unsigned long long m = __ballot(flagged);
         while (m) {
             const int r = base + __builtin_ctzll(m);
