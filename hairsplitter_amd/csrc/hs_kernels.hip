@@ -527,6 +527,8 @@ __global__ __launch_bounds__(256) void k_pileup_packed(
     }
 }
 
+#include "hs_kernels_runs.inc"      // K1, run form (round 5): lanes = 16-event pieces of one CIGAR op
+
 // per-event form over a task list (every record; used when the packed form is switched off, and by the kernel entry of the C ABI)
 __global__ __launch_bounds__(256) void k_pileup(
     const uint8_t* __restrict__ contig_seq, const int64_t* __restrict__ contig_off,
