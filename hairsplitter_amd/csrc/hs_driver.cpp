@@ -477,6 +477,23 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
 }
 
 
+int cv_attach_entries(CvDeviceOps& dev, hs_cv_result* R, int n_threads) {
+    if (!R || R->col_idx) return HS_OK;      // (nothing deferred: the entries came with the result, or there are none)
+    const int64_t S = R->snp_off[R->n_contigs], E = R->col_off[S];
+    CvSnpSet snps;
+    if (int rc = dev.late_entries(snps)) return rc;
+    if (E > 0 && (!snps.idx || !snps.code)) return HS_OK;      // (the implementation kept them on the device only)
+    R->col_idx = (int32_t*)std::malloc(std::max<int64_t>(1, E) * sizeof(int32_t));
+    R->col_code = (uint8_t*)std::malloc(std::max<int64_t>(1, E));
+    if (n_threads <= 0) n_threads = host_threads();
+    const int nb = (int)std::min<int64_t>(std::max<int64_t>(1, E >> 20), 4 * (int64_t)n_threads);
+    parallel_for(nb, n_threads, [&](int blk) {
+        const int64_t a = E * blk / nb, e = E * (blk + 1) / nb;
+        if (e > a) { std::memcpy(R->col_idx + a, snps.idx + a, (size_t)(e - a) * sizeof(int32_t)); std::memcpy(R->col_code + a, snps.code + a, (size_t)(e - a)); }
+    });
+    return HS_OK;
+}
+
 // results of two consecutive contig ranges put together (both are consumed); the error rate over all contigs, in contig order
 // (call_variants.cpp:1312-1315,1377)
 hs_cv_result* cv_concat_results(hs_cv_result* a, hs_cv_result* b) {

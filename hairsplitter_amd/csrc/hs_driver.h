@@ -92,6 +92,10 @@ struct CvDeviceOps {
     // automatic and the filtered SNPs; want_entries = false leaves idx / code of the result null (the SNP columns stay with the
     // implementation for stage 4: take_snp_columns)
     virtual int finish_columns(const CvPartitionTest& t, bool want_entries, CvSnpSet& out, float* k_ms) = 0;
+    // An implementation may bring the entries of the SNP columns (want_entries) to the host BEHIND the call -- idx / code of the result
+    // null, the transfer on its way beside whatever the caller does next (stage 4 reads the columns on the device) -- and hand them over
+    // here: waits for the transfer, fills idx / code (valid while the implementation lives). Default: nothing was deferred.
+    virtual int late_entries(CvSnpSet& out) { (void)out; return 0; }
     // Loop A of keep_only_robust_variants (call_variants.cpp:590-638) on the candidate columns, contig by contig.
     // Optional: an implementation without it leaves the loop to the host (cv_phase_a_host). The result arrays are owned by
     // the implementation and stay valid until the next call.
@@ -120,6 +124,8 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& meta, const std::vector<int32_t
                  hs_cv_result** out, bool resident = false, const std::function<void(const float*)>* on_mean_distance = nullptr);
 int cv_run(CvDeviceOps& dev, const CvMeta& meta, float automatic_snp_threshold, int n_threads, hs_cv_result** out);
 hs_cv_result* cv_concat_results(hs_cv_result* a, hs_cv_result* b);   // two consecutive contig ranges (both consumed)
+// the entries of the SNP columns of a result whose device interface deferred them (CvDeviceOps::late_entries): col_idx / col_code filled in
+int cv_attach_entries(CvDeviceOps& dev, hs_cv_result* r, int n_threads);
 
 // Every clustering window of a stage-4 call, each in its own LOCAL index space: node j of window w is the read
 // mask_ids[win_row0[w] + j] (ascending inside a window). "Row" = (window, node); the read graphs of the call are ONE CSR
