@@ -427,7 +427,10 @@ class PipelineGroups:
         nw, nr = C.c_int64(0), C.c_int64(0)
         _check(load().hs_pipeline_sparse_labels(self.handle, C.byref(off), C.byref(ids), C.byref(lab), C.byref(nw), C.byref(nr)))
         W, R = int(nw.value), int(nr.value)
-        sr["sparse"] = (np.ctypeslib.as_array(off, (W + 1,)), np.ctypeslib.as_array(ids, (max(R, 1),))[:R], np.ctypeslib.as_array(lab, (max(R, 1),))[:R])
+        if R == 0:      # (an empty std::vector's data() may be NULL)
+            sr["sparse"] = (np.ctypeslib.as_array(off, (W + 1,)), np.zeros(0, np.int32), np.zeros(0, np.int32))
+            return sr
+        sr["sparse"] = (np.ctypeslib.as_array(off, (W + 1,)), np.ctypeslib.as_array(ids, (R,)), np.ctypeslib.as_array(lab, (R,)))
         return sr
 
     def sibling(self, n_groups):

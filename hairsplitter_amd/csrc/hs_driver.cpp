@@ -102,10 +102,10 @@ public:
         if (n_threads <= 1 || n == 1) { for (int i = 0; i < n; ++i) f(i); return; }
         Job job;
         job.f = &f; job.n = n;
-        job.grain = std::max(1, n / (8 * (std::min(n_threads, (int)workers_.size() + 1))));
         {
             std::lock_guard<std::mutex> g(mu_);
             ensure();
+            job.grain = std::max(1, n / (8 * (std::min(n_threads, (int)workers_.size() + 1))));      // (workers_ is read under the lock: ensure() may grow it)
             jobs_.push_back(&job);
         }
         cv_.notify_all();

@@ -697,7 +697,14 @@ int write_cv_outputs(const CvFileInput& in, const hs_cv_result* res, const std::
     // companion is only ever used next to a .col of exactly the size and the block hashes it records: whichever file is complete first,
     // a process that dies in between leaves nothing a reader would take)
     std::thread side;
-    if (res->col_idx || res->col_off[res->snp_off[C]] == 0) side = std::thread([&] { write_col_sidecar(in, res, col_block, col_path, std::max(1, n_threads / 2)); });
+    const std::string side_path = col_path + ".hsbin";
+    std::remove(side_path.c_str());      // (a companion of an earlier .col of this name must not outlive it)
+    if (res->col_idx || res->col_off[res->snp_off[C]] == 0) side = std::thread([&] {
+        // the companion is an optimisation: whatever goes wrong with it (memory, the disk) must leave the .col / .vcf alone and no half-written companion behind
+        try { write_col_sidecar(in, res, col_block, col_path, std::max(1, n_threads / 2)); }
+        catch (const std::exception& e) { std::fprintf(stderr, "hairsplitter: the binary companion of %s was not written (%s)\n", col_path.c_str(), e.what()); std::remove(side_path.c_str()); }
+        catch (...) { std::fprintf(stderr, "hairsplitter: the binary companion of %s was not written\n", col_path.c_str()); std::remove(side_path.c_str()); }
+    });
     {
         std::ofstream out(col_path, std::ios::binary), vcf(vcf_path, std::ios::binary);
         for (int c = 0; c < C; ++c) {
@@ -835,6 +842,7 @@ int read_col_sidecar(const std::string& col_path, float rsa, std::vector<ColFile
     hs_parallel_for((int)K, n_threads, [&](int k) {
         const SidecarEntry& e = tab[k];
         const uint64_t R = e.n_reads, S = e.n_snps, E = e.n_entries;
+        if (R > bin.n || S > bin.n || E > bin.n || e.name_len > bin.n) return 0;      // (counts no file of this size can hold: the sums below stay far from 2^64)
         auto a8 = [](uint64_t x) { return (x + 7) & ~(uint64_t)7; };
         const uint64_t need = a8((R + 1) * 4) + 2 * a8(R * 4) + 3 * a8(S * 4) + a8((S + 1) * 8) + a8(E * 4) + 2 * a8(S) + a8(E) + a8(e.name_len);
         if (e.col_off > txt.n || e.col_bytes > txt.n - e.col_off || e.data_off > bin.n || e.data_bytes > bin.n - e.data_off || need != e.data_bytes || e.header_len > e.col_bytes

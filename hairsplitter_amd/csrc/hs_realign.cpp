@@ -49,6 +49,7 @@ int realign_paf_to_sam(const std::string& gfa, const std::string& reads, const s
     for (size_t i = 0; i < seqs.contig_names.size(); ++i) contig_of[seqs.contig_names[i]] = (long)i;
     // ---- the PAF lines: qname qlen qstart qend strand tname tlen tstart tend ... ----
     std::vector<PafRec> recs;
+    long n_unknown = 0;      // PAF lines that name a read or a contig of neither input file
     {
         std::ifstream f(paf);
         if (!f) { set_error("Input file '" + paf + "' could not be read"); std::cout << "problem reading PAF file " << paf << std::endl; return HS_EIO; }
@@ -59,7 +60,7 @@ int realign_paf_to_sam(const std::string& gfa, const std::string& reads, const s
             PafRec r; long tlen = 0;
             if (!(ss >> qn >> r.qlen >> r.qs >> r.qe >> strand >> tn >> tlen >> r.ts >> r.te)) continue;
             auto iq = read_of.find(qn); auto it = contig_of.find(tn);
-            if (iq == read_of.end() || it == contig_of.end()) continue;      // (a name of neither file: no record)
+            if (iq == read_of.end() || it == contig_of.end()) { n_unknown++; continue; }      // (a name of neither file: no record; counted, reported below)
             r.read = iq->second; r.contig = it->second; r.minus = strand == "-";
             const long rl = (long)(seqs.read_off[(size_t)r.read + 1] - seqs.read_off[(size_t)r.read]);
             const long cl = (long)(seqs.contig_off[(size_t)r.contig + 1] - seqs.contig_off[(size_t)r.contig]);
@@ -158,6 +159,10 @@ int realign_paf_to_sam(const std::string& gfa, const std::string& reads, const s
         out.write(hdr.data(), (std::streamsize)hdr.size());
         for (const std::string& s : sam_line) if (!s.empty()) out.write(s.data(), (std::streamsize)s.size());
     }
+    if (n_unknown) std::fprintf(stderr, "hairsplitter: realign: %ld PAF lines name a read or a contig that is in neither input file and were left out\n", n_unknown);
+    if (n_aligned != (int64_t)n)      // (never silent: these records are missing from the SAM the stage goes on with)
+        std::fprintf(stderr, "hairsplitter: realign: %ld of %ld PAF records have no alignment (the device aligner found none, or the read segment is longer than 2^20 bases) and were left out\n",
+                     (long)((int64_t)n - n_aligned), (long)n);
     if (stats) {
         stats->n_lines = (int64_t)n; stats->n_aligned = n_aligned; stats->ms_device = ms_device;
         stats->ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();

@@ -160,9 +160,11 @@ class LabelGatherer:
             return [labels]
         import torch
         n = int(labels.size)
-        assert n <= self.capacity
+        if n > self.capacity:
+            raise ValueError(f"{n} labels do not fit the gather buffer of {self.capacity}")
         if n != getattr(self, "checked_n", None):    # int16 on the wire: checked on the first gather and whenever the job changes
-            assert n == 0 or (int(labels.min()) >= -2 and int(labels.max()) < 32767)
+            if n and not (int(labels.min()) >= -2 and int(labels.max()) < 32767):
+                raise ValueError("a partition label does not fit the 16 bits it travels in")
             self.checked_n = n
         if self.copied is not None:
             self.copied.synchronize()      # the previous step's host-to-device copy has read the staging buffer
@@ -201,7 +203,12 @@ def encode_sparse(win_row_off: np.ndarray, ids: np.ndarray, labels: np.ndarray, 
     """Writes the payload into the uint8 array `out`; returns its length in bytes"""
     W, R = int(win_row_off.size) - 1, int(ids.size)
     n = sparse_payload_bytes(W, R)
-    assert out.size >= n and R < (1 << 31)
+    if out.size < n:
+        raise ValueError(f"label payload of {n} bytes does not fit the gather buffer of {out.size} (the job's lists grew: size the SparseLabelGatherer again)")
+    if R >= (1 << 31):
+        raise ValueError("more than 2^31 (window, read) pairs in one rank's list")
+    if R and (int(labels.min()) < -32768 or int(labels.max()) > 32767):
+        raise ValueError("a partition label does not fit the 16 bits it travels in")
     out[:16].view(np.int64)[:] = (W, R)
     o = 16
     np.copyto(out[o:o + 4 * (W + 1)].view(np.int32), win_row_off, casting="unsafe"); o += 4 * (W + 1)
