@@ -842,7 +842,7 @@ int read_col_sidecar(const std::string& col_path, float rsa, std::vector<ColFile
     hs_parallel_for((int)K, n_threads, [&](int k) {
         const SidecarEntry& e = tab[k];
         const uint64_t R = e.n_reads, S = e.n_snps, E = e.n_entries;
-        if (R > bin.n || S > bin.n || E > bin.n || e.name_len > bin.n) return 0;      // (counts no file of this size can hold: the sums below stay far from 2^64)
+        if (R > bin.n || S > bin.n || E > bin.n || e.name_len > bin.n) { bad[(size_t)k] = 1; return; }      // (counts no file of this size can hold: the sums below stay far from 2^64)
         auto a8 = [](uint64_t x) { return (x + 7) & ~(uint64_t)7; };
         const uint64_t need = a8((R + 1) * 4) + 2 * a8(R * 4) + 3 * a8(S * 4) + a8((S + 1) * 8) + a8(E * 4) + 2 * a8(S) + a8(E) + a8(e.name_len);
         if (e.col_off > txt.n || e.col_bytes > txt.n - e.col_off || e.data_off > bin.n || e.data_bytes > bin.n - e.data_off || need != e.data_bytes || e.header_len > e.col_bytes
