@@ -434,7 +434,7 @@ def main():
     # After the timed region too: the same steps with .col's payload (the entries of every SNP column) brought to the host inside
     # the call -- the timed steps hand stage 3 -> 4 over on the device and return the SNPs' positions, alleles and counts only
     ms_with_col = None
-    if not use_dist and not profiled and not os.environ.get("HS_BENCH_NO_PROBE"):
+    if (not use_dist or world == 1) and not profiled and not os.environ.get("HS_BENCH_NO_PROBE"):
         try:
             batch.keep_columns(True)
             any_step(batch); any_step(batch); sync()

@@ -1,0 +1,55 @@
+"""bench.py itself under the launchers the driver uses, on a small job: the single-process line (hs_pipeline_run_fused) and one rank under
+torch.distributed.run with the nccl (= RCCL) backend -- the two-call pipeline, the gloo exchanges of the error rate / window size and the
+RCCL gather of the labels all execute, with one rank. Both lines must carry the parity gate's verdict against the compiled reference."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _line(out):
+    lines = [l for l in out.decode().splitlines() if l.startswith("{")]
+    assert lines, out.decode()[-2000:]
+    return json.loads(lines[-1])
+
+
+def _check(d, pipeline):
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0
+    assert d["config"]["pipeline"] == pipeline
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    p = d["parity"]
+    assert p["checked"] and p["identical"], p
+    assert p["gro_identical"] and p["col_snps_identical"] and p["error_rate_identical"] and p["col_entries_identical"]
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["value"] > 0
+
+
+def test_bench_single_process_line_with_parity_gate(built):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--config", "C2", "--contigs", "6", "--f2f-runs", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    _check(_line(r.stdout), "hs_pipeline_run_fused")
+
+
+def test_bench_one_rank_under_torch_distributed_run_with_rccl(built):
+    """world size 1, backend nccl: what the driver launches for N > 1, with one rank (this box has one GPU)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--config", "C2", "--contigs", "6", "--f2f-runs", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = _line(r.stdout)
+    _check(d, "hs_pipeline_select + hs_pipeline_run")
+    assert d["phase_ms_per_step"]["py_gather"] > 0      # the collective ran
