@@ -298,6 +298,12 @@ int read_col_sidecar(const std::string& col_path, float rarest_strain_abundance,
 int write_cv_outputs(const CvFileInput& in, const hs_cv_result* res, const std::string& error_rate_out,
                      const std::string& col_path, const std::string& vcf_path, int n_threads = 1);
 int write_gro(const std::vector<ColFileContig>& cs, const hs_sr_result* res, const std::string& path, int n_threads = 1);
+// <col>.hsgro: the .gro of the orchestrator's usual stage-4 call, precomputed by HS_call_variants (hs_io.cpp)
+int write_gro_companion(const std::string& col_path, const std::vector<ColFileContig>& cs, const hs_sr_result* res, float error_rate, float rsa, bool low_memory, bool amplicon,
+                        uint32_t seed, int32_t window, int n_threads);
+int take_gro_companion(const std::string& col_path, float error_rate, float rsa, bool low_memory, bool amplicon, uint32_t seed, const std::string& outfile, int n_threads);
+void remove_gro_companion(const std::string& col_path);
+void mark_gro_companion_pending(const std::string& col_path);
 
 void free_cv_result(hs_cv_result* r);
 void free_sr_result(hs_sr_result* r);

@@ -26,6 +26,7 @@
 #include <sys/wait.h>
 #include "../../include/hairsplitter_hip.h"
 void hs_teardown_probe(void);      /* (diagnostics, not part of the C ABI header) */
+void hs_call_variants_epilogue(void);
 void hs_cpuprof_start(const char* out_file);
 void hs_cpuprof_stop(void);
 
@@ -36,6 +37,7 @@ static void hs_dropin_stamp(const char* what) {      /* HS_TIMING: wall-clock st
     fprintf(stderr, "[hs timing] stamp %s pid %d at %.1f ms\n", what, (int)getpid(), ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6);
 }
 static int (*hs_dropin_stage)(int, char**);
+static void (*hs_dropin_epilogue)(void);      /* work the stage may still do once its outputs are complete (HS_call_variants: the precomputed .gro); may be NULL */
 static int hs_dropin_run(int argc, char** argv) {
     const double t0 = hs_dropin_now_ms();
     hs_main_process_exits(1);
@@ -56,14 +58,20 @@ static int hs_dropin_tool_preloaded(void) {      /* a profiler / tracer of the R
     if (pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "rocprofiler") || strstr(pre, "libhsa") || strstr(pre, "amdhip"))) return 1;
     return 0;
 }
-static int hs_dropin_main(int (*stage)(int, char**), int argc, char** argv) {
+static int hs_dropin_run_all(int argc, char** argv) {      /* one process: the stage, then its epilogue, then the exit */
+    const int rc = hs_dropin_run(argc, argv);
+    if (rc == 0 && hs_dropin_epilogue) { hs_dropin_epilogue(); fflush(NULL); }
+    return rc;
+}
+static int hs_dropin_main2(int (*stage)(int, char**), void (*epilogue)(void), int argc, char** argv) {
     int pfd[2];
     hs_dropin_stage = stage;
+    hs_dropin_epilogue = epilogue;
     hs_dropin_stamp("main entered");
-    if (getenv("HS_NO_DETACH") || hs_dropin_tool_preloaded() || pipe(pfd) != 0) _exit(hs_dropin_run(argc, argv));
+    if (getenv("HS_NO_DETACH") || hs_dropin_tool_preloaded() || pipe(pfd) != 0) _exit(hs_dropin_run_all(argc, argv));
     const pid_t parent = getpid();
     const pid_t pid = fork();
-    if (pid < 0) _exit(hs_dropin_run(argc, argv));
+    if (pid < 0) _exit(hs_dropin_run_all(argc, argv));
     if (pid == 0) {
         close(pfd[0]);
         prctl(PR_SET_PDEATHSIG, SIGKILL);
@@ -74,7 +82,9 @@ static int hs_dropin_main(int (*stage)(int, char**), int argc, char** argv) {
         prctl(PR_SET_PDEATHSIG, 0);             /* the outputs are complete: the parent is about to leave, the teardown goes on */
         if (write(pfd[1], &rc, sizeof rc) != (ssize_t)sizeof rc) _exit(rc ? rc : 1);
         close(pfd[1]);
-        close(0); close(1); close(2);           /* whoever reads this program's output sees its end now */
+        close(0); close(1);                     /* whoever reads this program's output sees its end now */
+        if (rc == 0 && hs_dropin_epilogue) hs_dropin_epilogue();      /* (the caller has its exit status; this runs beside whatever it starts next) */
+        close(2);
         _exit(rc);
     }
     close(pfd[1]);
@@ -93,4 +103,5 @@ static int hs_dropin_main(int (*stage)(int, char**), int argc, char** argv) {
     }
     _exit(1);
 }
+static int hs_dropin_main(int (*stage)(int, char**), int argc, char** argv) { return hs_dropin_main2(stage, NULL, argc, argv); }
 #endif

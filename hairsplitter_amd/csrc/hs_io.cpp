@@ -908,6 +908,97 @@ int read_col_sidecar(const std::string& col_path, float rsa, std::vector<ColFile
     return 1;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// <out.col>.hsgro -- the .gro HS_separate_reads would write for this .col with the orchestrator's usual arguments, left by
+// HS_call_variants (hs_call_variants_epilogue: stage 4 run in the process that still has the job's device state, instead of a second
+// process that brings the device up again, reads the columns back and runs on cold pools). HS_separate_reads copies it to its output
+// ONLY when everything that determines the .gro is what the companion was made with: the .col still is the file the binary companion
+// (.hsbin) describes -- size and every block's hash --, the .hsgro belongs to that .hsbin (hash of its table), and error rate, rarest
+// strain abundance, low-memory and amplicon switches, seed and the absence of ploidies are equal. Anything else: the normal path.
+// Written to <col>.hsgro.tmp and renamed when complete. HS_NO_PRECOMPUTE=1: neither written nor read.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+constexpr uint64_t kGroMagic = 0x0100004F52475348ull;      // "HSGRO", two zero bytes, format 1
+struct GroCompanionHeader { uint64_t magic, version, col_size, table_hash, n_contigs, gro_bytes; uint32_t error_rate_bits, rsa_bits, low_memory, amplicon, seed, window; uint64_t pad[2]; };
+static_assert(sizeof(GroCompanionHeader) == 88, "GroCompanionHeader layout");
+uint32_t f32_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+// the .col at `col_path` is the file its binary companion describes: 1 and the hash of the companion's table, else 0
+int sidecar_tag(const std::string& col_path, int n_threads, uint64_t* tag, uint64_t* col_size, uint64_t* n_contigs) {
+    if (sidecar_off()) return 0;
+    FileView bin;
+    { struct stat st; if (::stat((col_path + ".hsbin").c_str(), &st) != 0) return 0; }
+    if (!bin.open(col_path + ".hsbin") || bin.n < sizeof(SidecarHeader)) return 0;
+    SidecarHeader h; std::memcpy(&h, bin.p, sizeof h);
+    if (h.magic != kSidecarMagic || h.version != kSidecarVersion || h.file_size != bin.n || h.table_off != sizeof h) return 0;
+    if (h.n_contigs > (bin.n - sizeof h) / sizeof(SidecarEntry)) return 0;
+    FileView txt;
+    if (!txt.open(col_path) || txt.n != h.col_size) return 0;
+    const size_t K = (size_t)h.n_contigs;
+    const SidecarEntry* tab = reinterpret_cast<const SidecarEntry*>(bin.p + h.table_off);
+    std::vector<char> bad(K, 0);
+    hs_parallel_for((int)K, std::max(1, n_threads), [&](int k) {
+        const SidecarEntry& e = tab[k];
+        if (e.col_off > txt.n || e.col_bytes > txt.n - e.col_off) { bad[(size_t)k] = 1; return; }
+        if (block_hash(txt.p + e.col_off, (size_t)e.col_bytes) != e.hash) bad[(size_t)k] = 1;
+    });
+    for (size_t k = 0; k < K; ++k) if (bad[k]) return 0;
+    *tag = block_hash(bin.p + h.table_off, K * sizeof(SidecarEntry)) ^ (h.col_size * 0x9E3779B97F4A7C15ull);
+    *col_size = h.col_size; *n_contigs = h.n_contigs;
+    return 1;
+}
+bool precompute_off() { static const bool off = std::getenv("HS_NO_PRECOMPUTE") != nullptr; return off || sidecar_off(); }
+}  // namespace
+
+int write_gro_companion(const std::string& col_path, const std::vector<ColFileContig>& cs, const hs_sr_result* res, float error_rate, float rsa, bool low_memory, bool amplicon,
+                        uint32_t seed, int32_t window, int n_threads) {
+    if (precompute_off()) return 0;
+    GroCompanionHeader h; std::memset(&h, 0, sizeof h);
+    if (!sidecar_tag(col_path, n_threads, &h.table_hash, &h.col_size, &h.n_contigs)) return 0;
+    h.magic = kGroMagic; h.version = 1; h.error_rate_bits = f32_bits(error_rate); h.rsa_bits = f32_bits(rsa); h.low_memory = low_memory; h.amplicon = amplicon; h.seed = seed; h.window = (uint32_t)window;
+    const std::string tmp = col_path + ".hsgro.tmp", fin = col_path + ".hsgro";
+    { std::ofstream out(tmp, std::ios::binary); if (!out) return 1; out.write(reinterpret_cast<const char*>(&h), sizeof h); if (!out) { std::remove(tmp.c_str()); return 1; } }
+    if (write_gro(cs, res, tmp, n_threads)) { std::remove(tmp.c_str()); return 1; }      // (appends)
+    struct stat st;
+    if (::stat(tmp.c_str(), &st) != 0 || (uint64_t)st.st_size < sizeof h) { std::remove(tmp.c_str()); return 1; }
+    h.gro_bytes = (uint64_t)st.st_size - sizeof h;
+    { std::fstream out(tmp, std::ios::binary | std::ios::in | std::ios::out); if (!out) { std::remove(tmp.c_str()); return 1; } out.seekp(0); out.write(reinterpret_cast<const char*>(&h), sizeof h); if (!out) { std::remove(tmp.c_str()); return 1; } }
+    if (std::rename(tmp.c_str(), fin.c_str()) != 0) { std::remove(tmp.c_str()); return 1; }
+    return 0;
+}
+void remove_gro_companion(const std::string& col_path) { std::remove((col_path + ".hsgro").c_str()); std::remove((col_path + ".hsgro.tmp").c_str()); }
+void mark_gro_companion_pending(const std::string& col_path) { if (precompute_off()) return; std::ofstream out(col_path + ".hsgro.tmp", std::ios::binary); }
+
+// 1: `outfile` holds the .gro (the companion was made for exactly this call); 0: no usable companion
+int take_gro_companion(const std::string& col_path, float error_rate, float rsa, bool low_memory, bool amplicon, uint32_t seed, const std::string& outfile, int n_threads) {
+    if (precompute_off()) return 0;
+    const std::string fin = col_path + ".hsgro", tmp = col_path + ".hsgro.tmp";
+    struct stat st;
+    if (::stat(fin.c_str(), &st) != 0) {
+        // HS_call_variants may still be at it (it writes the companion after its own outputs, its caller has moved on): a moment's patience
+        if (::stat(tmp.c_str(), &st) != 0) return 0;
+        static const long wait_ms = []() { const char* e = std::getenv("HS_PRECOMPUTE_WAIT_MS"); const long v = e ? std::atol(e) : 1500; return v >= 0 ? v : 1500; }();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            if (::stat(fin.c_str(), &st) == 0) break;
+            if (::stat(tmp.c_str(), &st) != 0) { if (::stat(fin.c_str(), &st) == 0) break; return 0; }      // (given up on, or renamed just now)
+            if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > (double)wait_ms) return 0;
+            std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        }
+    }
+    FileView g;
+    if (!g.open(fin) || g.n < sizeof(GroCompanionHeader)) return 0;
+    GroCompanionHeader h; std::memcpy(&h, g.p, sizeof h);
+    if (h.magic != kGroMagic || h.version != 1 || h.gro_bytes != g.n - sizeof h) return 0;
+    if (h.error_rate_bits != f32_bits(error_rate) || h.rsa_bits != f32_bits(rsa) || h.low_memory != (uint32_t)low_memory || h.amplicon != (uint32_t)amplicon || h.seed != seed) return 0;
+    uint64_t tag = 0, col_size = 0, nc = 0;
+    if (!sidecar_tag(col_path, n_threads, &tag, &col_size, &nc)) return 0;
+    if (tag != h.table_hash || col_size != h.col_size || nc != h.n_contigs) return 0;
+    std::ofstream out(outfile, std::ios::binary | std::ios::trunc);
+    if (!out) return 0;
+    out.write(g.p + sizeof h, (std::streamsize)h.gro_bytes);
+    return out ? 1 : 0;
+}
+
 int write_gro(const std::vector<ColFileContig>& cs, const hs_sr_result* res, const std::string& path, int n_threads) {
     if (n_threads < 1) n_threads = 1;
     std::vector<std::string> block(cs.size());

@@ -44,6 +44,32 @@ struct StageClock {   // HS_TIMING=1: wall clock of each phase of a stage execut
 
 bool g_leak_at_exit = false;   // hs_main_process_exits(1): the caller is an executable about to _exit -- nothing is torn down
 
+// what HS_call_variants may still do once its outputs are complete (hs_call_variants_epilogue): the .gro of the usual stage-4 call
+struct PendingGro { bool on = false; std::string col, err; bool amplicon = false; int threads = 1; } g_pending_gro;
+
+// the contigs of a parsed .col as the C ABI of stage 4 takes them; 1 if a read index is out of range
+int sr_contigs_of(std::vector<hs::ColFileContig>& cs, const std::unordered_map<std::string, int>* ploidy_of, std::vector<hs_sr_contig>& hc) {
+    hc.resize(cs.size());
+    for (size_t i = 0; i < cs.size(); ++i) {
+        hs::ColFileContig& c = cs[i];
+        hs_sr_contig& h = hc[i];
+        h.length = c.length; h.n_reads = (int32_t)c.read_lines.size();
+        h.read_start = c.read_start.data(); h.read_end = c.read_end.data();
+        h.n_snps = (int32_t)c.snp_pos.size();
+        h.snp_pos = c.snp_pos.data(); h.snp_ref = c.snp_ref.data(); h.snp_alt = c.snp_alt.data();
+        h.col_off = c.col_off.data(); h.col_idx = c.col_idx.data(); h.col_code = c.col_code.data();
+        h.ploidy = 0;
+        if (ploidy_of) { auto it = ploidy_of->find(c.name); if (it != ploidy_of->end()) h.ploidy = it->second; }
+        for (int32_t v : c.col_idx) if (v < 0 || v >= h.n_reads) return 1;
+    }
+    return 0;
+}
+uint32_t stage4_seed() {   // std::random_device of the reference, pinned; override with HS_SEED
+    uint32_t seed = 12345u;
+    if (const char* s = std::getenv("HS_SEED")) seed = (uint32_t)std::strtoul(s, nullptr, 10);
+    return seed;
+}
+
 }  // namespace
 
 // The drop-in executables call this before the stage's main: the process ends right after it, so the gigabytes of parsed
@@ -66,6 +92,8 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
     const float automatic_snp_threshold = std::strtof(argv[11], nullptr);
     StageClock clk;
     { std::ofstream o(file_out); }   // truncate (call_variants.cpp:1239-1240)
+    hs::remove_gro_companion(file_out);      // (a precomputed .gro of an earlier .col of this name)
+    g_pending_gro.on = false;
     clk.lap("truncate the output");
     std::string realigned_sam;
     if (has_suffix(sam_file, ".paf")) {
@@ -123,6 +151,10 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
     clk.lap("hs_cv_run_host (H2D + stage 3)");
     hs::write_cv_outputs(in, res, error_rate_out, file_out, vcf_file, num_threads);
     clk.lap("write .col/.vcf");
+    if (res->col_idx || res->col_off[res->snp_off[C]] == 0) {      // the stage's outputs are complete: what may follow is hs_call_variants_epilogue
+        g_pending_gro.on = true; g_pending_gro.col = file_out; g_pending_gro.err = error_rate_out; g_pending_gro.amplicon = amplicon_i != 0; g_pending_gro.threads = num_threads;
+        hs::mark_gro_companion_pending(file_out);
+    }
     if (std::getenv("HS_EXIT_PROBE")) {      // (diagnostic: what destroying the parsed input and the result costs here instead of at exit)
         hs_cv_result_destroy(res); clk.lap("destroy the result");
         delete in_p; in_guard.p = nullptr; clk.lap("destroy the parsed input");
@@ -130,6 +162,35 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
     }
     if (!g_leak_at_exit) hs_cv_result_destroy(res);
     return 0;
+}
+
+// After HS_call_variants' outputs are complete: stage 4 for the arguments hairsplitter.py passes by default (hairsplitter.py:686-692,
+// 725-726: the error rate it reads back from error_rate_out capped at 0.15, no ploidies, low memory off, rarest strain abundance 0.01,
+// the same amplicon switch), in this process -- the device is up, its pools are warm, the columns are a memory-mapped file away -- and
+// the .gro left as <col>.hsgro for HS_separate_reads to adopt if that is the call it gets (hs_io.cpp: take_gro_companion). The
+// executable calls this after it has reported its exit status (hs_dropin_main.h); a failure here costs nothing but the companion.
+extern "C" void hs_call_variants_epilogue(void) {
+    if (!g_pending_gro.on) return;
+    g_pending_gro.on = false;
+    const std::string col = g_pending_gro.col;
+    const int nt = std::max(1, g_pending_gro.threads);
+    StageClock clk;
+    try {
+        float er = 0;
+        { std::ifstream f(g_pending_gro.err); std::string t; if (!(f >> t)) { hs::remove_gro_companion(col); return; } double e = std::strtod(t.c_str(), nullptr); if (e > 0.15) e = 0.15; er = (float)e; }
+        const float rsa = (float)std::atof("0.01");
+        std::vector<hs::ColFileContig>* cs_p = new std::vector<hs::ColFileContig>();      // (left to the process end like everything else of the executable)
+        if (hs::read_col_sidecar(col, rsa, *cs_p, nt) != 1) { hs::remove_gro_companion(col); return; }
+        std::vector<hs_sr_contig> hc;
+        if (sr_contigs_of(*cs_p, nullptr, hc)) { hs::remove_gro_companion(col); return; }
+        const int32_t w = hs_sr_window_size(hc.data(), (int32_t)hc.size(), g_pending_gro.amplicon ? 1 : 0);
+        const uint32_t seed = stage4_seed();
+        hs_sr_result* res = nullptr;
+        if (hs_sr_run(hc.data(), (int32_t)hc.size(), w, er, 0, seed, nt, &res)) { hs::remove_gro_companion(col); return; }
+        clk.lap("epilogue: stage 4 for the usual arguments");
+        if (hs::write_gro_companion(col, *cs_p, res, er, rsa, false, g_pending_gro.amplicon, seed, w, nt)) hs::remove_gro_companion(col);
+        clk.lap("epilogue: write .col.hsgro");
+    } catch (...) { hs::remove_gro_companion(col); }
 }
 
 extern "C" int hs_separate_reads_main(int argc, char** argv) {
@@ -147,6 +208,22 @@ extern "C" int hs_separate_reads_main(int argc, char** argv) {
     const float rsa = (float)std::atof(argv[6]);
     StageClock clk;
     { std::ofstream o(outfile); }
+    const uint32_t seed = stage4_seed();
+    std::unordered_map<std::string, int> ploidy_of;
+    bool have_ploidy = false;
+    {
+        std::ifstream pf(ploidy_file);
+        if (pf) {
+            have_ploidy = true;
+            std::string line;
+            while (std::getline(pf, line)) { std::istringstream iss(line); std::string ctg; int p; if (!(iss >> ctg >> p)) break; ploidy_of[ctg] = p; }
+        }
+    }
+    // the .gro HS_call_variants left for exactly this call (same .col, same arguments, no ploidies): copied, no device needed
+    if (ploidy_of.empty() && hs::take_gro_companion(columns_file, error_rate, rsa, low_memory, amplicon, seed, outfile, num_threads) == 1) {
+        clk.lap("the precomputed .gro of this call (.col.hsgro)");
+        return 0;
+    }
     int n_devices = 0;
     std::thread warm([&n_devices] { n_devices = hs_warmup(); });
     std::vector<hs::ColFileContig>* cs_p = new std::vector<hs::ColFileContig>();
@@ -163,32 +240,9 @@ extern "C" int hs_separate_reads_main(int argc, char** argv) {
         return 1;
     }
     if (parse_rc) return parse_rc;
-    std::unordered_map<std::string, int> ploidy_of;
-    bool have_ploidy = false;
-    {
-        std::ifstream pf(ploidy_file);
-        if (pf) {
-            have_ploidy = true;
-            std::string line;
-            while (std::getline(pf, line)) { std::istringstream iss(line); std::string ctg; int p; if (!(iss >> ctg >> p)) break; ploidy_of[ctg] = p; }
-        }
-    }
-    std::vector<hs_sr_contig> hc(cs.size());
-    for (size_t i = 0; i < cs.size(); ++i) {
-        hs::ColFileContig& c = cs[i];
-        hs_sr_contig& h = hc[i];
-        h.length = c.length; h.n_reads = (int32_t)c.read_lines.size();
-        h.read_start = c.read_start.data(); h.read_end = c.read_end.data();
-        h.n_snps = (int32_t)c.snp_pos.size();
-        h.snp_pos = c.snp_pos.data(); h.snp_ref = c.snp_ref.data(); h.snp_alt = c.snp_alt.data();
-        h.col_off = c.col_off.data(); h.col_idx = c.col_idx.data(); h.col_code = c.col_code.data();
-        h.ploidy = 0;
-        if (have_ploidy) { auto it = ploidy_of.find(c.name); if (it != ploidy_of.end()) h.ploidy = it->second; }
-        for (int32_t v : c.col_idx) if (v < 0 || v >= h.n_reads) { std::cout << "ERROR: read index out of range in " << columns_file << std::endl; return 1; }
-    }
+    std::vector<hs_sr_contig> hc;
+    if (sr_contigs_of(cs, have_ploidy ? &ploidy_of : nullptr, hc)) { std::cout << "ERROR: read index out of range in " << columns_file << std::endl; return 1; }
     const int32_t w = hs_sr_window_size(hc.data(), (int32_t)hc.size(), amplicon ? 1 : 0);
-    uint32_t seed = 12345u;   // std::random_device of the reference, pinned; override with HS_SEED
-    if (const char* s = std::getenv("HS_SEED")) seed = (uint32_t)std::strtoul(s, nullptr, 10);
     hs_sr_result* res = nullptr;
     if (int rc = hs_sr_run(hc.data(), (int32_t)hc.size(), w, error_rate, low_memory ? 1 : 0, seed, num_threads, &res)) {
         std::cout << "ERROR: " << hs_last_error() << " (" << rc << ")" << std::endl;

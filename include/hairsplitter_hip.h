@@ -525,6 +525,13 @@ int32_t hs_sr_window_size(const hs_sr_contig* contigs, int32_t n_contigs, int32_
 /* File-level entry points == main() of the two reference executables (same argv, same exit codes).
  * call_variants.cpp:1215-1385 and separate_reads.cpp:1398-1790. */
 int hs_call_variants_main(int argc, char** argv);
+/* What HS_call_variants may still do once hs_call_variants_main has returned 0 and its outputs are complete: stage 4 for the arguments
+ * hairsplitter.py passes by default (hairsplitter.py:686-692,725-726), in the process that still holds the job's device state; the
+ * .gro is left as <out.col>.hsgro and hs_separate_reads_main copies it ONLY if it is called with that .col (size and block hashes
+ * of the .hsbin companion) and exactly those arguments (error rate, rarest strain abundance 0.01, low memory 0, the same amplicon
+ * switch, HS_SEED, no ploidies); anything else runs stage 4 as always. The executable calls it after it has reported its exit
+ * status (csrc/hs_dropin_main.h). HS_NO_PRECOMPUTE=1: neither written nor read. No-op without a preceding successful main. */
+void hs_call_variants_epilogue(void);
 int hs_separate_reads_main(int argc, char** argv);
 /* for executables that _exit right after one of the two: nothing is torn down at the end (parsed inputs, results, device state) */
 void hs_main_process_exits(int yes);
