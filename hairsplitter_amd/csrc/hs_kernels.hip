@@ -903,7 +903,11 @@ static __device__ __forceinline__ void column_stats_tiled_dw_body(
         if (valid) {
             const unsigned inc = 1u << ((code & 3u) * 8u);
             uint32_t* at = reinterpret_cast<uint32_t*>(my_cols + 256 * k + ((code & ~3u) << 8));
+#if defined(HS_K2_ABL) && HS_K2_ABL == 1      /* (timing experiment, wrong results: the counting without its LDS atomics) */
+            asm volatile("" :: "v"(at), "v"(inc));
+#else
             __hip_atomic_fetch_add(at, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
         }
     };
     const int64_t e0 = tile_off[tile], e1 = tile_off[tile + 1];
@@ -919,7 +923,11 @@ static __device__ __forceinline__ void column_stats_tiled_dw_body(
                 first[u] = __builtin_amdgcn_readlane(held.x, jj); len[u] = __builtin_amdgcn_readlane(held.y, jj);
                 const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane(held.z, jj), phi = (uint32_t)__builtin_amdgcn_readlane(held.w, jj);
                 const uint8_t* __restrict__ base = pile + (int64_t)(((uint64_t)phi << 32) | plo);   // pileup byte of position 0 of the tile
+#if defined(HS_K2_ABL) && HS_K2_ABL == 2      /* (timing experiment, wrong results: the counting without its loads of the pileup) */
+                v[u] = 0x41424344u + (uint32_t)lane + (uint32_t)(reinterpret_cast<uintptr_t>(base) & 3u);
+#else
                 v[u] = *reinterpret_cast<const u32_unaligned*>(base + 4 * lane);      // (the buffer is padded: positions the record does not cover are readable)
+#endif
             }
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
