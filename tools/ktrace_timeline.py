@@ -15,7 +15,7 @@ print('step span %.2f ms'%((max(e[1] for e in seg)-t0)/1e6), len(seg),'dispatche
 by=collections.defaultdict(list)
 for e in seg: by[e[2]].append(e)
 order=sorted(by, key=lambda k: by[k][0][0])
-names=['k_cigar_scan','k_pileup_packed','k_column_stats_tiled_dw','k_gather_tiles','k_cand_bits','k_column_partition_lanes','k_snp_planes','k_simdiff','k_read_graph_rows','k_cw_seeded_lanes','k_window_tail']
+names=['k_cigar_scan','k_pileup_runs','k_column_stats_tiled_dw','k_gather_tiles','k_cand_bits','k_column_partition_lanes','k_snp_planes','k_simdiff','k_read_graph_rows','k_cw_seeded_lanes','k_window_tail']
 print('thread      '+' '.join('%9s'%n[2:11] for n in names)+'   lastend  sumdur')
 for t in order:
     l=by[t]

@@ -18,5 +18,5 @@ for g in "FETCH_SIZE" "WRITE_SIZE"; do
 done
 python3 tools/pmc_summary.py gpurun_out/pmc_${tag} > gpurun_out/pmc_${tag}/summary.csv
 python3 tools/pmc_traffic_json.py gpurun_out/pmc_${tag} > gpurun_out/pmc_${tag}/traffic.json
-grep -E "k_pileup_packed|k_column_stats_tiled|k_simdiff|k_cw_seeded_lanes|k_cw_seed_sets|k_window_tail|k_column_partition_lanes" gpurun_out/pmc_${tag}/traffic.json
+grep -E "k_pileup_runs|k_pileup_packed|k_column_stats_tiled|k_simdiff|k_cw_seeded_lanes|k_cw_seed_sets|k_window_tail|k_column_partition_lanes" gpurun_out/pmc_${tag}/traffic.json
 find gpurun_out/pmc_${tag} -name "*.csv" -size +5M -delete
