@@ -479,3 +479,86 @@ def test_killing_the_dropin_leaves_no_worker_behind(built):
             for k in kids:
                 alive = os.path.exists(f"/proc/{k}") and "Z" not in open(f"/proc/{k}/stat").read().split(")")[-1][:3]
                 assert not alive, f"worker {k} survived its parent being killed with signal {int(sig)}"
+
+
+# ---- the precomputed .gro (<col>.hsgro): HS_call_variants' epilogue, adopted by HS_separate_reads only for exactly the call it was made for
+
+def _stage3(built, td, meta, env):
+    col, vcf, err = (os.path.join(td, "t_" + n) for n in ("variants.col", "variants.vcf", "error_rate.txt"))
+    amplicon = str(meta.get("kwargs", {}).get("amplicon", 0))
+    r = subprocess.run([built["cv"], os.path.join(td, "assembly.gfa"), gu.reads_path(td, meta), os.path.join(td, "aln.sam"), "1", td, err,
+                        amplicon, "0", col, vcf, "0.33"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    return col
+
+
+def _stage4(built, td, col, out, env, error_rate, ploidy="absent_ploidy.txt", low_memory="0", rsa="0.01", amplicon="0"):
+    r = subprocess.run([built["sr"], col, "1", error_rate, os.path.join(td, ploidy), low_memory, rsa, amplicon, os.path.join(td, out), "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(env, HS_TIMING="1"))
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    return "precomputed .gro" in r.stdout.decode(), open(os.path.join(td, out), "rb").read()
+
+
+def test_precomputed_gro_is_adopted_for_the_default_call_only(built):
+    """HS_call_variants leaves <col>.hsgro (stage 4 for the arguments hairsplitter.py passes by default, hairsplitter.py:686-692,725-726);
+    HS_separate_reads copies it when its own call is that one, and computes -- to the same file as with HS_NO_PRECOMPUTE=1 -- whenever an
+    argument, the seed, the ploidies or the .col differ"""
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack("penta30k", td)
+        env = dict(os.environ, HS_NO_DETACH="1")
+        col = _stage3(built, td, meta, env)
+        assert os.path.exists(col + ".hsgro") and not os.path.exists(col + ".hsgro.tmp")
+        er = meta["error_rate_arg"]
+        off = dict(env, HS_NO_PRECOMPUTE="1")
+        took, gro = _stage4(built, td, col, "a.gro", env, er)
+        assert took, "the default call must find its companion"
+        took_off, gro_off = _stage4(built, td, col, "b.gro", off, er)
+        assert not took_off and gro == gro_off
+        from hairsplitter_amd import canon
+        assert canon.split_blocks(os.path.join(td, "a.gro")) == canon.split_blocks(os.path.join(td, "reads_haplo.gro"))
+        open(os.path.join(td, "ploidy.txt"), "w").write("ctg0\t3\n")
+        other = [dict(error_rate="0.031"), dict(error_rate=er, low_memory="1"), dict(error_rate=er, rsa="0.05"), dict(error_rate=er, amplicon="1"),
+                 dict(error_rate=er, ploidy="ploidy.txt")]
+        for k, kw in enumerate(other):
+            took, a = _stage4(built, td, col, "c%d.gro" % k, env, **kw)
+            took_off, b = _stage4(built, td, col, "d%d.gro" % k, off, **kw)
+            assert not took and not took_off and a == b, kw
+        took, a = _stage4(built, td, col, "e.gro", dict(env, HS_SEED="777"), er)
+        _, b = _stage4(built, td, col, "f.gro", dict(off, HS_SEED="777"), er)
+        assert not took and a == b
+        # the .col edited after stage 3 (one allele of one SNPS line, same size): neither the arrays beside it nor the .gro describe it any more
+        text = open(col, "rb").read()
+        at = text.index(b"SNPS\t")
+        line_end = text.index(b"\n", at)
+        fields = text[at:line_end].split(b"\t")
+        fields[2] = b"A" if fields[2] != b"A" else b"C"
+        open(col, "wb").write(text[:at] + b"\t".join(fields) + text[line_end:])
+        took, a = _stage4(built, td, col, "g.gro", env, er)
+        _, b = _stage4(built, td, col, "h.gro", off, er)
+        assert not took and a == b
+
+
+def test_precomputed_gro_that_never_arrives_is_not_waited_for_long(built):
+    """A marker without a companion (HS_call_variants died in its epilogue): HS_separate_reads waits HS_PRECOMPUTE_WAIT_MS at most, then computes"""
+    import time
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack("dip20k", td)
+        env = dict(os.environ, HS_NO_DETACH="1")
+        col = _stage3(built, td, meta, env)
+        os.rename(col + ".hsgro", col + ".hsgro.tmp")
+        t0 = time.time()
+        took, a = _stage4(built, td, col, "a.gro", dict(env, HS_PRECOMPUTE_WAIT_MS="100"), meta["error_rate_arg"])
+        assert not took and time.time() - t0 < 30
+        os.remove(col + ".hsgro.tmp")
+        _, b = _stage4(built, td, col, "b.gro", dict(env, HS_NO_PRECOMPUTE="1"), meta["error_rate_arg"])
+        assert a == b
+
+
+@pytest.mark.parametrize("case", ["multi", "linked", "simple_mock"])
+def test_stage_4_right_behind_a_detached_stage_3(built, case):
+    """As hairsplitter.py runs them: HS_separate_reads started the moment HS_call_variants' exit status is in, while its worker is still
+    writing the companion -- whichever way stage 4 goes (adopts, waits and adopts, computes), the .gro is the reference's"""
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack(case, td)
+        outs = gu.run_stage_pair([built["cv"]], [built["sr"]], td, meta, env={k: v for k, v in os.environ.items() if k != "HS_NO_DETACH"})
+        assert gu.compare(td, outs) == []
