@@ -23,6 +23,8 @@
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <signal.h>
+#include <cerrno>
 #include <unistd.h>
 
 namespace hs {
@@ -966,7 +968,14 @@ int write_gro_companion(const std::string& col_path, const std::vector<ColFileCo
     return 0;
 }
 void remove_gro_companion(const std::string& col_path) { std::remove((col_path + ".hsgro").c_str()); std::remove((col_path + ".hsgro.tmp").c_str()); }
-void mark_gro_companion_pending(const std::string& col_path) { if (precompute_off()) return; std::ofstream out(col_path + ".hsgro.tmp", std::ios::binary); }
+// the marker "a companion is being made": holds the process id of its maker, so that a reader can tell a maker at work from one that died
+void mark_gro_companion_pending(const std::string& col_path) { if (precompute_off()) return; std::ofstream out(col_path + ".hsgro.tmp", std::ios::binary); out << (long)::getpid() << "\n"; }
+static bool companion_maker_gone(const std::string& tmp) {
+    std::ifstream in(tmp, std::ios::binary);
+    long pid = 0;
+    if (!(in >> pid) || pid <= 0) return false;      // (no process id in it: the companion itself, about to be renamed -- or somebody else's file: patience decides)
+    return ::kill((pid_t)pid, 0) != 0 && errno == ESRCH;
+}
 
 // 1: `outfile` holds the .gro (the companion was made for exactly this call); 0: no usable companion
 int take_gro_companion(const std::string& col_path, float error_rate, float rsa, bool low_memory, bool amplicon, uint32_t seed, const std::string& outfile, int n_threads) {
@@ -976,12 +985,14 @@ int take_gro_companion(const std::string& col_path, float error_rate, float rsa,
     if (::stat(fin.c_str(), &st) != 0) {
         // HS_call_variants may still be at it (it writes the companion after its own outputs, its caller has moved on): a moment's patience
         if (::stat(tmp.c_str(), &st) != 0) return 0;
+        if (companion_maker_gone(tmp)) { std::remove(tmp.c_str()); return 0; }      // (it died in its epilogue: nothing will come)
         static const long wait_ms = []() { const char* e = std::getenv("HS_PRECOMPUTE_WAIT_MS"); const long v = e ? std::atol(e) : 1500; return v >= 0 ? v : 1500; }();
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
             if (::stat(fin.c_str(), &st) == 0) break;
             if (::stat(tmp.c_str(), &st) != 0) { if (::stat(fin.c_str(), &st) == 0) break; return 0; }      // (given up on, or renamed just now)
             if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > (double)wait_ms) return 0;
+            if (companion_maker_gone(tmp)) { if (::stat(fin.c_str(), &st) == 0) break; std::remove(tmp.c_str()); return 0; }
             std::this_thread::sleep_for(std::chrono::milliseconds(2));
         }
     }

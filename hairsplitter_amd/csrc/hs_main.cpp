@@ -173,6 +173,7 @@ extern "C" void hs_call_variants_epilogue(void) {
     if (!g_pending_gro.on) return;
     g_pending_gro.on = false;
     const std::string col = g_pending_gro.col;
+    if (std::getenv("HS_EXIT_PROBE")) { hs::remove_gro_companion(col); return; }      // (the diagnostic has torn the device down already)
     const int nt = std::max(1, g_pending_gro.threads);
     StageClock clk;
     try {

@@ -554,6 +554,23 @@ def test_precomputed_gro_that_never_arrives_is_not_waited_for_long(built):
         assert a == b
 
 
+def test_marker_of_a_maker_that_died_is_not_waited_for(built):
+    """The marker holds the process id of its maker: one that no longer exists (HS_call_variants killed in its epilogue) means nothing will come"""
+    import time
+    with tempfile.TemporaryDirectory() as td:
+        meta = gu.unpack("dip20k", td)
+        env = dict(os.environ, HS_NO_DETACH="1")
+        col = _stage3(built, td, meta, env)
+        os.remove(col + ".hsgro")
+        gone = subprocess.Popen(["true"]); gone.wait()
+        open(col + ".hsgro.tmp", "w").write("%d\n" % gone.pid)
+        t0 = time.time()
+        took, a = _stage4(built, td, col, "a.gro", dict(env, HS_PRECOMPUTE_WAIT_MS="60000"), meta["error_rate_arg"])
+        assert not took and time.time() - t0 < 20 and not os.path.exists(col + ".hsgro.tmp")
+        _, b = _stage4(built, td, col, "b.gro", dict(env, HS_NO_PRECOMPUTE="1"), meta["error_rate_arg"])
+        assert a == b
+
+
 @pytest.mark.parametrize("case", ["multi", "linked", "simple_mock"])
 def test_stage_4_right_behind_a_detached_stage_3(built, case):
     """As hairsplitter.py runs them: HS_separate_reads started the moment HS_call_variants' exit status is in, while its worker is still
