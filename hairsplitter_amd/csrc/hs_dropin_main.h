@@ -69,8 +69,8 @@ static int hs_dropin_run_all(int argc, char** argv) {      /* one process: the s
  * a million pages to give back on the way out (0.15 s of the 500-contig job's 1.35 s). glibc (>= 2.35) asks for transparent huge pages for what malloc maps
  * when it is STARTED with GLIBC_TUNABLES=glibc.malloc.hugetlb=1 -- so the executable starts itself again with that setting, once, before anything of it
  * has touched the GPU (not when a profiler's library is in the process: that one has; not when the caller set GLIBC_TUNABLES itself). HS_NO_REEXEC=1: never. */
-static void hs_dropin_with_huge_pages(char** argv) {
-    if (getenv("HS_NO_REEXEC") || getenv("GLIBC_TUNABLES") || hs_dropin_tool_preloaded()) return;
+static void hs_dropin_with_huge_pages(char** argv, int wanted) {
+    if (!wanted || getenv("HS_NO_REEXEC") || getenv("GLIBC_TUNABLES") || hs_dropin_tool_preloaded()) return;
     setenv("HS_NO_REEXEC", "1", 1);
     setenv("GLIBC_TUNABLES", "glibc.malloc.hugetlb=1", 1);
     execv("/proc/self/exe", argv);
@@ -80,7 +80,7 @@ static int hs_dropin_main2(int (*stage)(int, char**), void (*epilogue)(void), in
     int pfd[2];
     hs_dropin_stage = stage;
     hs_dropin_epilogue = epilogue;
-    hs_dropin_with_huge_pages(argv);
+    hs_dropin_with_huge_pages(argv, epilogue != NULL);      /* (HS_call_variants: the stage that parses the job's text; HS_separate_reads maps the arrays it left: the restart would only cost it 30 ms) */
     hs_dropin_stamp("main entered");
     if (getenv("HS_NO_DETACH") || hs_dropin_tool_preloaded() || pipe(pfd) != 0) _exit(hs_dropin_run_all(argc, argv));
     const pid_t parent = getpid();
