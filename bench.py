@@ -271,7 +271,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = emulated or int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # launched by torch.distributed.run
-    if use_dist:
+    # HS_BENCH_SHARE_DEVICE=1 (a test of the N > 1 path on a box with ONE GPU): every rank on device 0, every exchange over gloo -- RCCL
+    # does not take two ranks on one device; sharding, per-rank pipelines, the exchanges and rank 0's line are what a node runs
+    share_device = use_dist and os.environ.get("HS_BENCH_SHARE_DEVICE") == "1"
+    if share_device:
+        local_rank = 0
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="gloo")
+    elif use_dist:
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
     else:
@@ -378,6 +385,7 @@ def main():
     step_ms = []
     wall = {}
     last_results = None
+    last_gathered = None
     for it in range(args.steps):
         pet()
         ts = time.perf_counter()
@@ -385,6 +393,7 @@ def main():
         step_ms.append((time.perf_counter() - ts) * 1e3)
         if it == args.steps - 1:
             last_results = (cv, sr)      # the LAST TIMED STEP's results: what the parity gate compares with the reference (after the clock stops)
+            last_gathered = gathered
         for kk, vv in sr.get("wall_ms", {}).items():
             wall[kk] = wall.get(kk, 0.0) + vv
         t_dev += cv["t_device_ms"] + sr["t_device_ms"]; t_host += cv["t_host_ms"] + sr["t_host_ms"]
@@ -402,7 +411,18 @@ def main():
     if rank == 0 and world == 1 and not emulated and last_results is not None:
         import ref_outputs
         snap_timed = ref_outputs.pipeline_snapshot(batch, last_results[0], last_results[1], contig_names)
+    # what rank 0 holds of the WHOLE job after the last timed step, as an order-independent digest: one process and N ranks must agree on it
+    labels_digest = None
+    try:
+        if rank == 0 and last_results is not None:
+            if use_dist and last_gathered is not None:
+                labels_digest = dict(hdist.sparse_digest([hdist.decode_sparse(o.cpu().numpy()) for o in last_gathered]), ranks=len(last_gathered))
+            elif not use_dist and "sparse" in last_results[1]:
+                labels_digest = dict(hdist.sparse_digest([tuple(np.array(x) for x in last_results[1]["sparse"])]), ranks=1)
+    except Exception as e:
+        sys.stderr.write("labels digest failed: %r\n" % (e,))
     last_results = None
+    last_gathered = None
     waits_per_step = (api.host_waits() - waits0) / args.steps
     if os.environ.get("HS_CPU_PROFILE"):
         api.load().hs_cpuprof_stop()
@@ -464,10 +484,11 @@ def main():
                 pass
     throttled = None if thr0 is None or thr1 is None else {"periods": thr1[0] - thr0[0], "usec": thr1[1] - thr0[1]}
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        red_dev = "cpu" if share_device else "cuda"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        tot = torch.tensor([local_bp], dtype=torch.int64, device="cuda")
+        tot = torch.tensor([local_bp], dtype=torch.int64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_bp = int(tot.item())
     else:
@@ -530,6 +551,7 @@ def main():
             "value": total_bp * K / dt, "unit": "aligned read-bp/s", "n_gpus": 1 if emulated else world, "steps": K, "warmup": args.warmup, "setup_steps": SETUP_STEPS,
             "ms_per_step": dt / K * 1e3, "ms_per_step_with_col_download": ms_with_col,
             "value_with_col_download": (total_bp / (ms_with_col * 1e-3)) if ms_with_col else None,
+            "labels_digest": labels_digest,      # windows / entries / sum of per-window CRC-32 of (reads, labels) rank 0 holds for the whole job
             "value_excludes_col_payload": True,      # the timed steps hand the SNP columns' entries (.col's payload) from stage 3 to stage 4 ON THE DEVICE (config.outputs)
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",

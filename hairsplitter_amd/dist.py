@@ -227,6 +227,22 @@ def decode_sparse(buf: np.ndarray):
     return off, ids, lab
 
 
+def sparse_digest(payloads):
+    """Order-independent digest of per-window (reads, labels) lists, one (win_row_off, ids, labels) triple per rank: the number of windows
+    and entries and the sum of the windows' CRC-32 -- the same job gives the same digest however its contigs were sharded over the ranks
+    (a window's reads are indices within its contig)."""
+    import zlib
+    W = R = 0
+    acc = 0
+    for off, ids, lab in payloads:
+        off = np.asarray(off, dtype=np.int64); ids = np.ascontiguousarray(ids, dtype=np.int32); lab = np.ascontiguousarray(lab, dtype=np.int32)
+        W += len(off) - 1; R += int(off[-1]) if len(off) else 0
+        for w in range(len(off) - 1):
+            a, b = int(off[w]), int(off[w + 1])
+            acc = (acc + zlib.crc32(lab[a:b].tobytes(), zlib.crc32(ids[a:b].tobytes()))) & 0xFFFFFFFFFFFFFFFF
+    return {"windows": int(W), "entries": int(R), "sum_crc32": int(acc)}
+
+
 class SparseLabelGatherer:
     """ONE gather per step of the ranks' (window, read, label) lists to `dst`. Everything is allocated here, once, for `capacity`
     bytes per rank (the largest payload of any rank: exchanged when the job is set up, not per step): the pinned staging buffer,

@@ -53,3 +53,24 @@ def test_bench_one_rank_under_torch_distributed_run_with_rccl(built):
     d = _line(r.stdout)
     _check(d, "hs_pipeline_select + hs_pipeline_run")
     assert d["phase_ms_per_step"]["py_gather"] > 0      # the collective ran
+
+
+def test_bench_two_ranks_hold_what_one_process_holds(built):
+    """N = 2 as the driver launches it (torch.distributed.run, one rank per GPU) on a box with one GPU: HS_BENCH_SHARE_DEVICE=1 puts both
+    ranks on device 0 and every exchange on gloo. The job is sharded by LPT, each rank runs its own pipeline, the error rate and window
+    size are formed across the ranks, rank 0 gathers the labels: its digest of the whole job's windows equals the single process's."""
+    common = ["--steps", "2", "--warmup", "1", "--config", "C2", "--contigs", "6", "--cpu-contigs", "0"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=900)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    d1 = _line(one.stdout)
+    env = dict(os.environ, HS_BENCH_SHARE_DEVICE="1")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr.decode()[-3000:]
+    d2 = _line(two.stdout)
+    assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["value"] > 0
+    g1, g2 = d1["labels_digest"], d2["labels_digest"]
+    assert g1["ranks"] == 1 and g2["ranks"] == 2
+    assert g1["windows"] > 0 and g1["entries"] > 0
+    assert {k: g1[k] for k in ("windows", "entries", "sum_crc32")} == {k: g2[k] for k in ("windows", "entries", "sum_crc32")}
+    assert d2["parity"]["checked"] is False      # (the reference comparison is the single process's)
