@@ -9,6 +9,7 @@
 // point fails with HS_ENODEVICE.
 #include <hip/hip_runtime.h>
 #include <malloc.h>
+#include <sys/mman.h>
 #include <sys/prctl.h>
 #include <condition_variable>
 #include <functional>
