@@ -35,14 +35,30 @@ struct FileView {
     size_t n = 0;
     void* map = nullptr;
     std::string fallback;
-    bool open(const std::string& path) {
+    // n_threads > 1: the page tables of a large mapping are filled on the host threads (MADV_POPULATE_READ per slice: one thread needs
+    // 25 ms per gigabyte of cached file for it), else by the mmap call itself
+    bool open(const std::string& path, int n_threads = 1) {
         const int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) return false;
         struct stat st;
         if (::fstat(fd, &st) != 0) { ::close(fd); return false; }
         if (S_ISREG(st.st_mode) && st.st_size > 0) {
-            void* m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
-            if (m != MAP_FAILED) { map = m; p = (const char*)m; n = (size_t)st.st_size; ::close(fd); return true; }
+            const size_t len = (size_t)st.st_size, SL = (size_t)32 << 20;
+            const bool par = n_threads > 1 && len >= 2 * SL;
+            void* m = ::mmap(nullptr, len, PROT_READ, MAP_PRIVATE | (par ? 0 : MAP_POPULATE), fd, 0);
+            if (m != MAP_FAILED) {
+                map = m; p = (const char*)m; n = len; ::close(fd);
+#ifdef MADV_POPULATE_READ
+                if (par) {
+                    const int slices = (int)((len + SL - 1) / SL);
+                    hs_parallel_for(slices, n_threads, [&](int k) {
+                        const size_t a = (size_t)k * SL, e = std::min(len, a + SL);
+                        (void)::madvise((char*)m + a, e - a, MADV_POPULATE_READ);      // (refused by an older kernel: the pages come in as they are touched)
+                    });
+                }
+#endif
+                return true;
+            }
         }
         char buf[1 << 16];
         ssize_t k;
@@ -302,7 +318,7 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
     std::unordered_map<std::string_view, long> indices;
     // ---- reads: names, lengths, sequence line of each record (input_output.cpp:39-109) ----
     FileView rtxt;
-    if (!rtxt.open(reads)) {
+    if (!rtxt.open(reads, n_threads)) {
         std::cout << "problem reading files in index_reads, while trying to read " << reads << std::endl;
         set_error("Input file could not be read: " + reads);
         return HS_EIO;
@@ -383,7 +399,7 @@ int load_cv_inputs(const std::string& gfa, const std::string& reads, const std::
     // it with index 0: its first appearance as a query is refused, later ones are taken as read 0. Lines with such names are
     // set aside and replayed in file order afterwards. ----
     FileView stxt;
-    if (!stxt.open(sam)) {
+    if (!stxt.open(sam, n_threads)) {
         std::cout << "problem reading SAM file " << sam << std::endl;
         set_error("Input file '" + sam + "' could not be read");
         return HS_EIO;

@@ -91,10 +91,14 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
     const std::string error_rate_out = argv[6], file_out = argv[9], vcf_file = argv[10];
     const float automatic_snp_threshold = std::strtof(argv[11], nullptr);
     StageClock clk;
-    { std::ofstream o(file_out); }   // truncate (call_variants.cpp:1239-1240)
-    hs::remove_gro_companion(file_out);      // (a precomputed .gro of an earlier .col of this name)
+    // truncate (call_variants.cpp:1239-1240) -- on a thread of its own: giving back the pages of an earlier run's 300-MB .col and its companions takes
+    // 25 ms, and nothing needs the empty file before the outputs are written (every way out of this function waits for it)
+    struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } truncation;
+    truncation.t = std::thread([file_out] {
+        { std::ofstream o(file_out); }
+        hs::remove_gro_companion(file_out);      // (a precomputed .gro of an earlier .col of this name)
+    });
     g_pending_gro.on = false;
-    clk.lap("truncate the output");
     std::string realigned_sam;
     if (has_suffix(sam_file, ".paf")) {
         // the reference refuses a .paf (call_variants.cpp:1256-1259) and so does this executable -- unless HS_REALIGN=1 asks for the
@@ -149,6 +153,7 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
         return EXIT_FAILURE;
     }
     clk.lap("hs_cv_run_host (H2D + stage 3)");
+    if (truncation.t.joinable()) truncation.t.join();
     hs::write_cv_outputs(in, res, error_rate_out, file_out, vcf_file, num_threads);
     clk.lap("write .col/.vcf");
     if (res->col_idx || res->col_off[res->snp_off[C]] == 0) {      // the stage's outputs are complete: what may follow is hs_call_variants_epilogue
