@@ -27,6 +27,7 @@
 #include "../../include/hairsplitter_hip.h"
 void hs_teardown_probe(void);      /* (diagnostics, not part of the C ABI header) */
 void hs_exit_reset(void);
+void hs_dropin_finish(void);
 void hs_call_variants_epilogue(void);
 void hs_cpuprof_start(const char* out_file);
 void hs_cpuprof_stop(void);
@@ -62,6 +63,8 @@ static int hs_dropin_tool_preloaded(void) {      /* a profiler / tracer of the R
 static int hs_dropin_run_all(int argc, char** argv) {      /* one process: the stage, then its epilogue, then the exit */
     const int rc = hs_dropin_run(argc, argv);
     if (rc == 0 && hs_dropin_epilogue) { hs_dropin_epilogue(); fflush(NULL); }
+    hs_dropin_finish();
+    hs_dropin_stamp("leaving");
     if (getenv("HS_EXIT_RESET")) { const double tp = hs_dropin_now_ms(); hs_exit_reset(); if (getenv("HS_TIMING")) fprintf(stderr, "[hs timing] hipDeviceReset before the exit %.1f ms\n", hs_dropin_now_ms() - tp); }
     return rc;
 }
@@ -98,6 +101,7 @@ static int hs_dropin_main2(int (*stage)(int, char**), void (*epilogue)(void), in
         close(pfd[1]);
         close(0); close(1);                     /* whoever reads this program's output sees its end now */
         if (rc == 0 && hs_dropin_epilogue) hs_dropin_epilogue();      /* (the caller has its exit status; this runs beside whatever it starts next) */
+        hs_dropin_finish();
         close(2);
         _exit(rc);
     }

@@ -76,6 +76,7 @@ uint32_t stage4_seed() {   // std::random_device of the reference, pinned (SURVE
 // input, the results and the device state are left to the operating system instead of being destroyed piece by piece
 // (0.2 s on the 500-contig job). In-process hosts do not call it.
 extern "C" void hs_main_process_exits(int yes) { g_leak_at_exit = yes != 0; }
+static std::thread g_destroyer;
 
 extern "C" int hs_call_variants_main(int argc, char** argv) {
     if (argc < 12) {   // also how `HS_call_variants --version` is answered (hairsplitter.py:229-252 expects exit 0)
@@ -165,8 +166,26 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
         delete in_p; in_guard.p = nullptr; clk.lap("destroy the parsed input");
         return 0;
     }
+    // The executable is about to leave (hs_main_process_exits): the gigabytes of parsed input and the result go back on a thread of their own
+    // while the epilogue runs, hs_dropin_finish() waits for it and gives the device's blocks back -- 0.09 s less than leaving all of it to the
+    // kernel's teardown after _exit (alternating blocks of runs, 500-contig job: 1.02 s against 0.93). HS_EXIT_LEAK=1: nothing is destroyed.
+    if (g_leak_at_exit && !std::getenv("HS_EXIT_LEAK")) {
+        hs::CvFileInput* gone = in_p; in_guard.p = nullptr;
+        g_destroyer = std::thread([gone, res] { hs_cv_result_destroy(res); delete gone; });
+        return 0;
+    }
     if (!g_leak_at_exit) hs_cv_result_destroy(res);
     return 0;
+}
+extern "C" void hs_teardown_probe(void);
+extern "C" void hs_dropin_finish(void) {      // (the drop-in executables, after the stage and its epilogue)
+    if (std::getenv("HS_EXIT_LEAK") || std::getenv("HS_EXIT_PROBE")) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (g_destroyer.joinable()) g_destroyer.join();
+    const auto t1 = std::chrono::steady_clock::now();
+    hs_teardown_probe();
+    if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] exit: waited %.1f ms for the destruction of the inputs, device blocks given back in %.1f ms\n",
+                                               std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
 }
 
 // After HS_call_variants' outputs are complete: stage 4 for the arguments hairsplitter.py passes by default (hairsplitter.py:686-692,
