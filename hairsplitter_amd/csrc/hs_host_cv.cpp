@@ -21,6 +21,7 @@
 #include "hs_rh8.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -270,26 +271,33 @@ static Contingency column_vs_partition(const RankPartition& p, const int32_t* id
 // distance(Partition&, Column&, char) (call_variants.cpp:778-967) on bit sets: popcounts of ANDs over the words both the column
 // and the partition occupy. `orig_of`: rank -> read index (the order in which the reference's hash map meets the codes is the
 // order of the READ INDICES, needed when the best count is tied)
+#ifdef HS_LOOPA_STATS
+static std::atomic<long> g_la_stat[8];
+#define LA_STAT(i) g_la_stat[i].fetch_add(1, std::memory_order_relaxed)
+#else
+#define LA_STAT(i)
+#endif
 static Contingency column_vs_partition_bits(const RankPartition& p, const ColView& cb, uint8_t ref, const int32_t* orig_of) {
     Contingency r;
     const int W = cb.W;
     const int w0 = std::max(cb.wlo, p.wlo), w1 = std::min(cb.whi, p.whi);
-    if (w0 > w1) return r;
+    LA_STAT(0);
+    if (w0 > w1) { LA_STAT(1); return r; }
     const uint64_t* any = cb.any - cb.wlo;      // (indexed by absolute word below)
     int shared = 0;
     for (int w = w0; w <= w1; ++w) shared += __builtin_popcountll(any[w] & p.present[(size_t)w]);
-    if (shared == 0) return r;
+    if (shared == 0) { LA_STAT(2); return r; }
     r.comparable = true;
     r.most = ref;
     // Few shared reads: the table holds at most `shared` reads, the column can only fit the partition with at least half of its
     // own reads in the table (:624-627) and only correlate with chi-square > 15, which a 2x2 table of N reads cannot exceed N
     // for (14 leaves room for the float rounding) -- neither can happen, the counts are of no consequence
     static const bool no_skip = std::getenv("HS_LOOP_A_NO_SKIP") != nullptr;      // (diagnostic: form every table)
-    if (!no_skip && shared <= 14 && (size_t)shared < (size_t)cb.n_entries / 2) return r;
+    if (!no_skip && shared <= 14 && (size_t)shared < (size_t)cb.n_entries / 2) { LA_STAT(3); return r; }
     if (!no_skip) {   // the same with the shared reads the partition has an opinion on (state +1 / -1): only those enter the table
         int decided = 0;
         for (int w = w0; w <= w1; ++w) decided += __builtin_popcountll(any[w] & (p.plus[(size_t)w] | p.minus[(size_t)w]));
-        if (decided <= 14 && (size_t)decided < (size_t)cb.n_entries / 2) return r;
+        if (decided <= 14 && (size_t)decided < (size_t)cb.n_entries / 2) { LA_STAT(4); return r; }
     }
     auto slot_abs = [&](int k) { return cb.slots + (size_t)k * W - cb.wlo; };
     if (ref < 128) {
@@ -307,6 +315,7 @@ static Contingency column_vs_partition_bits(const RankPartition& p, const ColVie
             if (c > best) { best = c; nbest = 1; best_slot = k; } else if (c == best) nbest++;
         }
         if (nbest <= 1) {
+            LA_STAT(5);
             r.second = best_slot >= 0 ? cb.codes[best_slot] : (uint8_t)' ';
             if (ref_slot >= 0) {
                 const uint64_t* bm = slot_abs(ref_slot);
@@ -751,6 +760,9 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
             parts.back().n_corr = n_corr;
         } else last_position = pos;
     }
+#ifdef HS_LOOPA_STATS
+    if (tim) std::fprintf(stderr, "[hs loopa stats] calls %ld no-common-words %ld shared0 %ld few-shared %ld few-decided %ld fast-table %ld\n", g_la_stat[0].load(), g_la_stat[1].load(), g_la_stat[2].load(), g_la_stat[3].load(), g_la_stat[4].load(), g_la_stat[5].load());
+#endif
     if (tim) std::fprintf(stderr, "[hs timing] loop A: %d candidates, %zu partitions, %ld comparisons, %ld augmentations; %.0f us (augment %.0f)\n",
                           cs.n, parts.size(), n_cmp, n_aug, nowus() - t_a0, t_aug);
 }
