@@ -379,6 +379,17 @@ def main():
     K_TIMED = (args.steps + STATS_EVERY - 1) // STATS_EVERY
     api.kernel_stats_reset()
     waits0 = api.host_waits()
+    def thread_cpu():      # HS_BENCH_THREAD_CPU=1: CPU time per thread NAME over the timed region (the library names its own threads; the rest is Python + the ROCm runtime)
+        acc = {}
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                name = open("/proc/self/task/%s/comm" % tid).read().strip()
+                f = open("/proc/self/task/%s/stat" % tid).read().rsplit(")", 1)[1].split()
+                acc.setdefault(name, [0, 0, 0]); acc[name][0] += int(f[11]); acc[name][1] += int(f[12]); acc[name][2] += 1
+            except Exception:
+                pass
+        return acc
+    tcpu0 = thread_cpu() if os.environ.get("HS_BENCH_THREAD_CPU") else None
     t0 = time.perf_counter(); cpu0 = time.process_time()
     t_dev = 0.0; t_host = 0.0
     last = None
@@ -404,6 +415,10 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     cpu_ms_per_step = (time.process_time() - cpu0) / args.steps * 1e3
+    if tcpu0 is not None:
+        tcpu1 = thread_cpu(); tick = 1e3 / os.sysconf("SC_CLK_TCK")
+        rows = sorted(((n, (v[0] - tcpu0.get(n, [0, 0, 0])[0]) * tick / args.steps, (v[1] - tcpu0.get(n, [0, 0, 0])[1]) * tick / args.steps, v[2]) for n, v in tcpu1.items()), key=lambda r: -(r[1] + r[2]))
+        sys.stderr.write("[thread cpu] per step, by thread name: " + "; ".join("%s x%d user %.1f sys %.1f ms" % (n, k, u, sy) for n, u, sy, k in rows if u + sy > 0.05) + "\n")
     # ---- parity gate, part 1: copies of what the last timed step left with the host (its arrays belong to the pipeline and die with the
     # next call). Compared with the reference's files in the file-to-file leg below; one rank = the whole job only ----
     sys.path.insert(0, os.path.join(ROOT, "oracle"))

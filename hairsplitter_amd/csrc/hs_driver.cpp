@@ -2,6 +2,7 @@
 // HS_separate_reads, independent of how the device interface is implemented (see hs_driver.h).
 #include "hs_driver.h"
 
+#include <sys/prctl.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -57,7 +58,7 @@ private:
         want = std::min(want, 255);
         while ((int)workers_.size() < want) {
             const int id = (int)workers_.size();
-            workers_.emplace_back([this, id] { loop(id); });
+            workers_.emplace_back([this, id] { ::prctl(PR_SET_NAME, "hs-pool", 0, 0, 0); loop(id); });      // (named: per-thread CPU accounting, bench.py HS_BENCH_THREAD_CPU=1)
             workers_.back().detach();
         }
     }
@@ -118,7 +119,7 @@ private:
     struct Job { const std::function<void(int)>* f = nullptr; int n = 0, grain = 1; std::atomic<int> next{0}, done{0}; };
     void ensure() {
         static const int want = []() { const char* e = std::getenv("HS_POOL_THREADS"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : host_threads(); }();
-        while ((int)workers_.size() < want) { workers_.emplace_back([this] { loop(); }); workers_.back().detach(); }
+        while ((int)workers_.size() < want) { workers_.emplace_back([this] { ::prctl(PR_SET_NAME, "hs-spool", 0, 0, 0); loop(); }); workers_.back().detach(); }
     }
     void loop() {
         std::unique_lock<std::mutex> g(mu_);

@@ -254,7 +254,10 @@ static __device__ __forceinline__ bool myers_leaf(int qn, int tn) {
 #define MY_LEAF_CELLS 52428      /* blocks x columns of the largest matrix that passes myers_leaf */
 #define MY_MAX_QUERY (1 << 20)   /* (a matrix that does not pass has >= 4 columns up to this query length) */
 
-__global__ __launch_bounds__(64) void k_myers_hw_path(
+#ifndef MY_WAVES_PER_EU
+#define MY_WAVES_PER_EU 1
+#endif
+__global__ __launch_bounds__(64, MY_WAVES_PER_EU) void k_myers_hw_path(
     const uint8_t* __restrict__ query, const int64_t* __restrict__ query_off, const uint8_t* __restrict__ target,
     const int64_t* __restrict__ target_off, const int32_t* __restrict__ pair_ids, int n_list, int8_t* __restrict__ hscratch,
     const int64_t* __restrict__ hscratch_off, unsigned long long* __restrict__ store, const int64_t* __restrict__ store_off,
