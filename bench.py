@@ -640,6 +640,22 @@ def main():
                     out["parity"] = par
             except Exception as e:  # the baseline is informational; never fail the bench on it
                 out["cpu_baseline"] = {"error": repr(e)}
+        # a run that could not put the reference beside itself (several ranks, --cpu-contigs 0) still has a known answer for the jobs listed in
+        # tests/golden/bench_labels_digest.json: the digest of the labels a single process held when ITS reference gate said "identical"
+        # (tools/make_bench_digests.py). Only the default seed, and only when rank 0 holds the whole job's labels.
+        if "parity" not in out and labels_digest is not None and args.seed is None and not emulated:
+            try:
+                known = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_labels_digest.json"))).get("%s:%d:default" % (cfg, n_job))
+            except Exception:
+                known = None
+            if known:
+                same = all(labels_digest[k] == known[k] for k in ("windows", "entries", "sum_crc32"))
+                out["parity"] = {"checked": True, "kind": "labels digest", "identical": bool(same), "gro_identical": bool(same),
+                                 "against": "tests/golden/bench_labels_digest.json: windows / entries / sum of per-window CRC-32 of (reads, labels) of the single-process run of this job whose "
+                                            "reference gate passed (" + known.get("verified", "")[:120] + ")",
+                                 "what": "the labels rank 0 holds for the whole job after the LAST TIMED STEP (%d rank(s))" % labels_digest.get("ranks", 1),
+                                 "not_compared": ".col SNPS lines and the error rate (the reference gate of a --gpus 1 run with the file-to-file leg compares them)",
+                                 "diffs": None if same else {"got": labels_digest, "expected": {k: known[k] for k in ("windows", "entries", "sum_crc32")}}}
         if "parity" not in out:
             out["parity"] = {"checked": False, "why": "several ranks (each holds a shard; the full-job comparison runs at --gpus 1)" if (use_dist or emulated) else
                              ("no file-to-file leg in this run (--cpu-contigs 0) or no reference / oracle binaries on this box" if "error" not in (out.get("cpu_baseline") or {}) else "the file-to-file leg failed")}

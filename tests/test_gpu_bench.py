@@ -73,4 +73,16 @@ def test_bench_two_ranks_hold_what_one_process_holds(built):
     assert g1["ranks"] == 1 and g2["ranks"] == 2
     assert g1["windows"] > 0 and g1["entries"] > 0
     assert {k: g1[k] for k in ("windows", "entries", "sum_crc32")} == {k: g2[k] for k in ("windows", "entries", "sum_crc32")}
-    assert d2["parity"]["checked"] is False      # (the reference comparison is the single process's)
+    # neither run had the reference beside it (--cpu-contigs 0): both are checked against the known answer of this job (tests/golden/bench_labels_digest.json,
+    # the digest of a single-process run whose reference gate passed: tools/make_bench_digests.py)
+    for d in (d1, d2):
+        assert d["parity"]["checked"] and d["parity"]["kind"] == "labels digest" and d["parity"]["identical"], d["parity"]
+
+
+def test_bench_default_job_against_its_known_answer(built):
+    """The default job (C4) without the file-to-file leg: the labels of the timed path against the digest kept from the run that passed the reference gate"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-contigs", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = _line(r.stdout)
+    assert d["config"]["contigs"] == 500 and d["labels_digest"]["windows"] == 25594
+    assert d["parity"]["checked"] and d["parity"]["kind"] == "labels digest" and d["parity"]["identical"], d["parity"]
