@@ -523,6 +523,10 @@ def main():
         alone_ms = {k: v["ms"] / PROBE_STEPS for k, v in (kstats_alone or {}).items() if k not in ("k_ship", "other")}
         timed_ms = {k: v["ms_per_step"] for k, v in per_step.items() if k not in ("k_ship", "other")}
         dom = max(alone_ms, key=alone_ms.get) if alone_ms else max(timed_ms or {"none": 0.0}, key=(timed_ms or {"none": 0.0}).get)
+        if alone_ms:      # K1 and K2 are within a per cent of each other: kernels within 3 % of the longest count as tied, and a tie goes to the one that
+            top = alone_ms[dom]      # moves more algorithmic bytes per launch -- the line then names the same kernel run after run; the other one is `runner_up`
+            tied = [k for k, v in alone_ms.items() if v >= 0.97 * top]
+            dom = max(tied, key=lambda k: (kstats_alone[k]["bytes"] / max(1, kstats_alone[k]["launches"]), alone_ms[k]))
         d = per_step.get(dom, {"ms_per_step": 0.0, "launches_per_step": 0.0, "avg_launch_ms": 0.0, "algorithmic_bytes_per_launch": 0.0, "achieved_GBs": 0.0})
         traffic = None
         traffic_src = None
@@ -596,7 +600,7 @@ def main():
                          "avg_launch_ms": d["avg_launch_ms"], "launches_per_step": d["launches_per_step"], "ms_per_step": d["ms_per_step"],
                          "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                          "measured": "HIP events on the launch streams over the instrumented steps of the timed region (%d contig groups overlap)" % G,
-                         "selection": "the kernel with the largest time per step when it runs alone (one-group probe; all kernels of the path compete; transfers excluded)"
+                         "selection": "the kernel with the largest time per step when it runs alone (one-group probe; all kernels of the path compete; transfers excluded; kernels within 3 % of the longest are tied and the tie goes to the one with more algorithmic bytes per launch: see probe_one_group.runner_up)"
                                       if alone else "the kernel with the largest time per step in the timed region (transfers excluded)",
                          # PROBE (not the timed region): the same resident job through a ONE-group pipeline right after the timed region, every kernel alone
                          # on the GPU, one launch per step over the whole job -- the kernel's own rate, reproducible from profiles/*_groups1.csv
