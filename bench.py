@@ -294,7 +294,12 @@ def main():
 
     B = len(contigs)
     contig_names = [c.name for c in contigs]
-    G = max(1, min(args.groups if args.groups > 0 else min(8, max(1, n_threads // 3)), max(B, 1)))      # (a rank of 8 with 6 threads: 2 groups, 7.0 ms per step on its shard against 10.3 with one)
+    # contig groups of this process's pipeline: as many as its threads feed (three per group) and as its share of the job is worth -- a group's
+    # chain has a fixed part (five waits, ~60 launches), so a 1/8 shard wants 3 groups, a 1/4 shard 4, the whole 500-contig job 8 (measured
+    # with 16-48 threads: rank of 8 3.7-4.0 ms at 3 groups against 4.1-4.9 at 4-8; rank of 4 6.6 ms at 4 against 7.1-7.4 at 6-8): sqrt(aligned bp / 24 M)
+    shard_bp = float(sum(shapes[i][0] * shapes[i][2] for i in my_ids))      # (length x depth of the shard's contigs: what a scheduler knows before anything is parsed)
+    G_size = max(2, min(8, int(round((shard_bp / 24e6) ** 0.5))))
+    G = max(1, min(args.groups if args.groups > 0 else min(G_size, max(1, n_threads // 3)), max(B, 1)))      # (a rank of 8 with 6 threads: 2 groups, 7.0 ms per step on its shard against 10.3 with one)
     pet()
     t_up = time.perf_counter()
     batch = api.PipelineGroups(contigs, G)   # inputs now resident in HBM; the streaming kernels run once per step over all of them

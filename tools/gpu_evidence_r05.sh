@@ -19,6 +19,7 @@ HS_CPU_PROFILE=$R/gpurun_out/${TAG}_cpu_prof.txt timeout 600 python bench.py --s
 python tools/cpuprof_report.py gpurun_out/${TAG}_cpu_prof.txt 60 > gpurun_out/${TAG}_cpu_profile_top.txt 2>&1
 rm -f gpurun_out/${TAG}_cpu_prof.txt
 timeout 400 python bench.py --as-rank-of 8 --cpu-contigs 0 > gpurun_out/${TAG}_rank_of_8.json 2> gpurun_out/${TAG}_rank_of_8.err
+timeout 400 python bench.py --as-rank-of 8 --threads 16 --cpu-contigs 0 --steps 60 > gpurun_out/${TAG}_rank_of_8_16threads.json 2>> gpurun_out/${TAG}_rank_of_8.err
 timeout 400 python bench.py --as-rank-of 8 --cores 2 --cpu-contigs 0 > gpurun_out/${TAG}_rank_of_8_2cores.json 2>> gpurun_out/${TAG}_rank_of_8.err
 # the file-to-file job on one device and on eight shards of it (HS_DEVICES=0 x 8: the same sharding, batches and merge as eight GPUs)
 python - > gpurun_out/${TAG}_f2f_devices.txt 2>&1 <<P
