@@ -220,3 +220,39 @@ def test_two_ranks_gather_what_one_process_computes():
             assert pr.exitcode == 0
         assert e == e_full                     # the job's error rate from the ranks' distances == the single process's
         assert merged == want                  # and every window's reads and labels as one process computes them
+
+
+def test_sparse_digest_does_not_depend_on_how_the_windows_are_sharded():
+    """hdist.sparse_digest: the same windows give the same digest in one payload, split over ranks in any order, and a changed label changes it"""
+    import numpy as np
+    from hairsplitter_amd import dist as hdist
+    rng = np.random.default_rng(3)
+    wins = []
+    for _ in range(200):
+        n = int(rng.integers(0, 40))
+        wins.append((np.sort(rng.choice(500, size=n, replace=False)).astype(np.int32), rng.integers(-1, 6, size=n).astype(np.int32)))
+
+    def payload(ws):
+        off = np.zeros(len(ws) + 1, np.int64)
+        off[1:] = np.cumsum([len(w[0]) for w in ws])
+        ids = np.concatenate([w[0] for w in ws]) if ws else np.zeros(0, np.int32)
+        lab = np.concatenate([w[1] for w in ws]) if ws else np.zeros(0, np.int32)
+        return off, ids, lab
+
+    one = hdist.sparse_digest([payload(wins)])
+    order = rng.permutation(len(wins))
+    parts = [[wins[i] for i in order[k::3]] for k in range(3)]
+    three = hdist.sparse_digest([payload(p) for p in parts])
+    assert one == three and one["windows"] == 200 and one["entries"] == sum(len(w[0]) for w in wins)
+    # round trip through the gather's encoding (labels travel as int16)
+    enc = []
+    for p in parts:
+        off, ids, lab = payload(p)
+        buf = np.zeros(hdist.sparse_payload_bytes(len(off) - 1, len(ids)) + 64, np.uint8)
+        n = hdist.encode_sparse(off, ids, lab, buf)
+        enc.append(hdist.decode_sparse(buf[:n]))
+    assert hdist.sparse_digest(enc) == one
+    changed = [(w[0], w[1].copy()) for w in wins]
+    k = next(i for i, w in enumerate(changed) if len(w[0]))
+    changed[k][1][0] += 1
+    assert hdist.sparse_digest([payload(changed)]) != one
