@@ -293,15 +293,12 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
         const int64_t entries = b.pile_off[(size_t)b.contig_rec_off[(size_t)gc + 1]] - b.pile_off[(size_t)b.contig_rec_off[(size_t)gc]];
         o.depth = (float)((double)entries / (double)L);
     }
-    // loop A of keep_only_robust_variants runs on the host threads by default. HS_LOOP_A_ON_DEVICE=1 runs it as k_loop_a (exact, one
-    // wave per contig): the candidates then stay on the device and only the contigs the kernel's tables cannot hold are walked here.
-    // Measured ("loop A on the device"): a lone wave needs about 5 us per candidate against 0.25 us on a host core, and
-    // the longest contig's chain bounds the launch, so the kernel is the experiment and the host walk the product path.
-    static const bool loop_a_on_device = []() { const char* e = std::getenv("HS_LOOP_A_ON_DEVICE"); return e && e[0] != '0'; }();
-    const bool on_device = dev.has_robust_partitions() && loop_a_on_device;
+    // loop A of keep_only_robust_variants: the device interface may keep the contigs its kernel (k_loop_a) holds for itself -- it queues
+    // their walk inside extract_candidates() and marks them in contig_on_device; the others' candidates arrive as bit sets and are walked
+    // here meanwhile, then the device's partitions are collected and every contig goes through loop B (libm) on the host threads.
     CvCandidates cand;
     float k_ms_x[3] = {0, 0, 0};
-    if (int rc = dev.extract_candidates(c0, c1, min_reads, automatic_snp_threshold, cand, k_ms_x, !on_device)) return rc;
+    if (int rc = dev.extract_candidates(c0, c1, min_reads, automatic_snp_threshold, cand, k_ms_x, true)) return rc;
     k_ms[1] = k_ms_x[0]; k_ms[2] = k_ms_x[1] + k_ms_x[2];
     if (derive) {
         if ((int)cand.contig_mean_distance.size() != C) { set_error("cv_run_range: the device interface did not report the contigs' mean distances"); return HS_EINVAL; }
@@ -326,16 +323,9 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
         cv_phase_begin(*cst[(size_t)c], n_reads_c, cand.contig_n_cand[(size_t)c], res[(size_t)c].mean_distance, res[(size_t)c]);
     });
     laps.lap("begin");
-    CvLoopAResult la;
-    float k_ms_a = 0;
-    bool some_on_host = !on_device;
-    if (on_device) {
-        if (int rc = dev.robust_partitions(n_reads_of, la, &k_ms_a)) return rc;
-        for (int c = 0; c < C; ++c) if (la.failed[(size_t)c]) some_on_host = true;
-        if (some_on_host) { if (int rc = dev.fetch_candidates(cand)) return rc; }      // (rare: the tables of the kernel did not hold a contig)
-        laps.lap("loop_a");
-    }
-    if (some_on_host && cand.n_cand > 0 && !cand.bits) { set_error("cv_run_range: the device interface handed no bit sets of the candidate columns"); return HS_EINVAL; }
+    const bool some_on_device = (int)cand.contig_on_device.size() == C;
+    auto on_device = [&](int c) { return some_on_device && cand.contig_on_device[(size_t)c] != 0; };
+    bool host_has_bits = cand.bits != nullptr || cand.n_cand == 0;
     auto candidates_of = [&](int c) {
         CandidateSet cs;
         cs.n = cand.contig_n_cand[(size_t)c];
@@ -345,27 +335,43 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
     };
     static const bool loop_b_pairs = []() { const char* e = std::getenv("HS_LOOP_B_PAIRS_ON_DEVICE"); return e && e[0] != '0'; }();
     const bool pairs_on_device = loop_b_pairs && dev.has_partition_pairs();
-    std::atomic<int> n_host_a{0};
-    // the contigs with the most candidates first: the walk is sequential per contig, and a large contig that starts last is what the
-    // other threads of the group then wait for
-    std::vector<int> by_work((size_t)C);
-    for (int c = 0; c < C; ++c) by_work[(size_t)c] = c;
-    std::stable_sort(by_work.begin(), by_work.end(), [&](int x, int y) { return cand.contig_n_cand[(size_t)x] > cand.contig_n_cand[(size_t)y]; });
-    parallel_for(C, n_threads, [&](int k) {
-        const int c = by_work[(size_t)k];
+    const bool ranked = (int)b.rank_of.size() == b.n_rec && (int)b.orig_of.size() == b.n_rec;
+    auto walk_on_host = [&](int c) {
         const int r0 = b.contig_rec_off[(size_t)(c0 + c)];
-        if (on_device && !la.failed[(size_t)c]) {
-            const int N = n_reads_of[(size_t)c];
-            cv_phase_a_import(*cst[(size_t)c], b.rec_pos.data() + r0, (int)(la.part_base[(size_t)c + 1] - la.part_base[(size_t)c]), la.rec + la.part_base[(size_t)c],
-                              la.bits + la.bits_base[(size_t)c], la.cnt + la.cnt_base[(size_t)c]);
-            (void)N;
-        } else {
-            const bool ranked = (int)b.rank_of.size() == b.n_rec && (int)b.orig_of.size() == b.n_rec;
-            cv_phase_a_host(*cst[(size_t)c], candidates_of(c), b.rec_pos.data() + r0, ranked ? b.rank_of.data() + r0 : nullptr, ranked ? b.orig_of.data() + r0 : nullptr);
-            n_host_a++;
-        }
+        cv_phase_a_host(*cst[(size_t)c], candidates_of(c), b.rec_pos.data() + r0, ranked ? b.rank_of.data() + r0 : nullptr, ranked ? b.orig_of.data() + r0 : nullptr);
         if (!pairs_on_device) cv_phase_b(*cst[(size_t)c], res[(size_t)c]);
-    });
+    };
+    // the host's contigs, those with the most candidates first: the walk is sequential per contig, and a large contig that starts last is
+    // what the other threads of the group then wait for
+    std::vector<int> host_list, dev_list;
+    for (int c = 0; c < C; ++c) (on_device(c) ? dev_list : host_list).push_back(c);
+    std::stable_sort(host_list.begin(), host_list.end(), [&](int x, int y) { return cand.contig_n_cand[(size_t)x] > cand.contig_n_cand[(size_t)y]; });
+    if (!host_list.empty() && !host_has_bits) { set_error("cv_run_range: the device interface handed no bit sets of the candidate columns"); return HS_EINVAL; }
+    parallel_for((int)host_list.size(), n_threads, [&](int k) { walk_on_host(host_list[(size_t)k]); });
+    laps.lap("loop_a_host");
+    int n_dev_failed = 0;
+    if (!dev_list.empty()) {
+        CvLoopAResult la;
+        if (int rc = dev.collect_partitions(la)) return rc;
+        if ((int)la.failed.size() != C || (int)la.part_base.size() != C + 1) { set_error("cv_run_range: the device interface did not hand over the partitions of its contigs"); return HS_EINVAL; }
+        laps.lap("loop_a_device");
+        std::vector<int> redo;
+        for (int c : dev_list) if (la.failed[(size_t)c]) redo.push_back(c);
+        n_dev_failed = (int)redo.size();
+        if (!redo.empty()) {      // (rare: a contig the kernel's tables did not hold after all -- its candidates as bit sets, walked here)
+            if (int rc = dev.fetch_candidates(cand)) return rc;
+            if (cand.n_cand > 0 && !cand.bits) { set_error("cv_run_range: the device interface handed no bit sets of the candidate columns"); return HS_EINVAL; }
+        }
+        std::stable_sort(dev_list.begin(), dev_list.end(), [&](int x, int y) { return cand.contig_n_cand[(size_t)x] > cand.contig_n_cand[(size_t)y]; });
+        parallel_for((int)dev_list.size(), n_threads, [&](int k) {
+            const int c = dev_list[(size_t)k];
+            if (la.failed[(size_t)c]) { walk_on_host(c); return; }
+            const int r0 = b.contig_rec_off[(size_t)(c0 + c)];
+            cv_phase_a_import(*cst[(size_t)c], b.rec_pos.data() + r0, (int)(la.part_base[(size_t)c + 1] - la.part_base[(size_t)c]), la.rec + la.part_base[(size_t)c], la.bits, la.cnt,
+                              ranked ? b.rank_of.data() + r0 : nullptr, ranked ? b.orig_of.data() + r0 : nullptr);
+            if (!pairs_on_device) cv_phase_b(*cst[(size_t)c], res[(size_t)c]);
+        });
+    }
     if (pairs_on_device) {
         // loop B with distance(Partition, Partition) from the device (HS_LOOP_B_PAIRS_ON_DEVICE=1): every pair of the partitions that
         // pass loop B's gate, in one launch for the range; the host walks loop B with the table and only recomputes a pair whose
@@ -394,7 +400,7 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
         parallel_for(C, n_threads, [&](int c) { cv_phase_b(*cst[(size_t)c], res[(size_t)c], table.data() + 8 * pair_first[(size_t)c]); });
         if (std::getenv("HS_TIMING")) std::fprintf(stderr, "[hs timing] cv loop B: %ld partition pairs of %ld gated partitions from the device\n", (long)pair_first[(size_t)C], (long)part_first[(size_t)C]);
     }
-    if (std::getenv("HS_TIMING") && on_device) std::fprintf(stderr, "[hs timing] cv loop A on the device: %.3f ms of kernels, %d of %d contigs done on the host\n", k_ms_a, n_host_a.load(), C);
+    if (std::getenv("HS_TIMING") && !dev_list.empty()) std::fprintf(stderr, "[hs timing] cv loop A: %zu of %d contigs on the device (%d handed back), %zu on the host\n", dev_list.size(), C, n_dev_failed, host_list.size());
     laps.lap("phase_ab");
     // ---- loops C and D and the merge of the SNP lists on the device, against the final partitions ----
     CvSnpSet snps;

@@ -50,6 +50,7 @@ struct CvCandidates {
     // word_off counts from `words`; bits[k] belongs to rec[k]
     const CandBits* bits = nullptr;          // [n_cand]
     const uint64_t* words = nullptr;
+    std::vector<uint8_t> contig_on_device;   // [C] != 0: loop A of this contig runs on the device (collect_partitions); empty: none does
 };
 // ... and at its end: the SNPs (call_variants.cpp:1335-1352), same layout; idx / code only when they were asked for
 struct CvSnpSet {
@@ -61,21 +62,21 @@ struct CvSnpSet {
     const uint8_t* code = nullptr;
 };
 
-// Loop A of keep_only_robust_variants on the device: input = the candidates of the last extract_candidates() (they are with the
-// implementation) + the per-contig read counts; output = the partitions of every contig as the device keeps them: a record, three
-// bit sets over the reads ranked by start position (present / state +1 / state -1, W = ceil(N / 64) words each) and one counter
-// per read (more | less << 16)
+// Loop A of keep_only_robust_variants on the device (k_loop_a), for the contigs of the range its tables hold: the partitions of every
+// such contig as the host imports them (cv_phase_a_import) -- a record, and for the words [w0, w1] of the contig's reads (ranked by
+// start position) that the partition's reads lie in: present / state +1 / state -1 (3 x span words at 3 x word_off of `bits`) and one
+// counter per read of those words (more | less << 16; 64 x span at 64 x word_off of `cnt`)
 struct CvLoopAResult {
-    std::vector<int64_t> part_base;            // [C+1] partitions per contig
+    std::vector<uint8_t> on_device;            // [C] != 0: the contig was the device's (empty: none was)
     std::vector<int32_t> failed;               // [C] != 0: the device gave up on this contig (its tables do not hold it), the host does it
-    std::vector<int64_t> bits_base, cnt_base;  // [C] first word / counter of the contig's partitions in `bits` / `cnt`
-    const CvPartRecord* rec = nullptr;         // [part_base[C]]
-    const uint64_t* bits = nullptr;            // partition p of contig c: words bits_base[c] + p * 3 W ...
-    const int32_t* cnt = nullptr;              // ... counters cnt_base[c] + p * N ...
+    std::vector<int64_t> part_base;            // [C+1] first partition of every contig in `rec`
+    const CvPartRecord* rec = nullptr;
+    const uint64_t* bits = nullptr;
+    const int32_t* cnt = nullptr;
 };
 
 // The device side of stage 3. One object serves one range of contigs at a time: pileup() once per batch, then per range
-// extract_candidates() -> [robust_partitions()] -> finish_columns().
+// extract_candidates() -> [collect_partitions()] -> finish_columns().
 struct CvDeviceOps {
     virtual ~CvDeviceOps() {}
     // K0 + K1 over the whole batch: per-record {q_end, n_err, n_len, n_events}; k_ms = {pileup, -, -, cigar scan}
@@ -105,8 +106,10 @@ struct CvDeviceOps {
     virtual int partition_pairs(const std::vector<int8_t>& state, const std::vector<int32_t>& more, const std::vector<int32_t>& less, const std::vector<int64_t>& part_off,
                                 const std::vector<int32_t>& part_n, const std::vector<int32_t>& pair_a, const std::vector<int32_t>& pair_b, const std::vector<float>& sigma3,
                                 std::vector<int32_t>& out) { (void)state; (void)more; (void)less; (void)part_off; (void)part_n; (void)pair_a; (void)pair_b; (void)sigma3; (void)out; return -1; }
-    virtual bool has_robust_partitions() const { return false; }
-    virtual int robust_partitions(const std::vector<int32_t>& contig_n_reads, CvLoopAResult& out, float* k_ms) { (void)contig_n_reads; (void)out; (void)k_ms; return -1; }
+    // loop A on the device: an implementation that has it queues it inside extract_candidates() for the contigs it marks in
+    // CvCandidates::contig_on_device (their candidates come without bit sets) and hands the partitions over here, once the host has
+    // walked the other contigs; fetch_candidates() brings the bit sets of every candidate after all (a contig the device gave up on)
+    virtual int collect_partitions(CvLoopAResult& out) { out = CvLoopAResult(); return 0; }
 };
 
 // result of the whole-batch streaming pass (K0 + K1): the per-record counters

@@ -64,12 +64,12 @@ void cv_state_free(CvContigState* st);
 // The host part of keep_only_robust_variants in steps: loop A on the host (cv_phase_a_host) or imported from the device
 // (k_loop_a -> cv_phase_a_import), then loop B (cv_phase_b); the final partitions leave for loops C / D on the device.
 // read_start: [n_reads] POS-1 of every record of the contig (the bit order of every bit set: ranks by start position)
-struct CvPartRecord { int32_t left, right, n_occ, n_corr, lo, hi, reach, pad; int64_t elem; };   // what k_loop_a_pack writes per partition
+struct CvPartRecord { int32_t left, right, n_occ, n_corr, lo, hi, reach, w0, w1, pad; int64_t word_off; };   // what k_loop_a_pack writes per partition (w0..w1: the words of the contig's ranked reads its reads lie in)
 void cv_phase_begin(CvContigState& st, int n_reads, int n_candidates, float mean_distance, ContigCvResult& out);
 void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* read_start, const int32_t* rank_of = nullptr, const int32_t* orig_of = nullptr /* the contig's reads ranked already (cv_rank_reads' result), or NULL */);
 // bits: the contig's partitions, 3 W words each (present, plus, minus over the reads ranked by start position); cnt: N counters each
 // (more | less << 16); rec[p].elem is not used here
-void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const uint64_t* bits, const int32_t* cnt);
+void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const uint64_t* bits, const int32_t* cnt, const int32_t* rank_of = nullptr, const int32_t* orig_of = nullptr);
 void cv_phase_b(CvContigState& st, ContigCvResult& out, const int32_t* pair_table = nullptr);
 // loop B with the pair distances from the device (k_partition_pair_distance): the partitions that pass loop B's gate, their dense
 // arrays, the host's table of 3-sigma thresholds

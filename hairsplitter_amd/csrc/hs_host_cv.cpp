@@ -30,6 +30,9 @@
 #include <mutex>
 
 namespace hs {
+#ifdef HS_LOOPA_STATS2
+long g_s2[64];
+#endif
 
 static constexpr int8_t ABSENT = 2;
 
@@ -314,6 +317,9 @@ static Contingency column_vs_partition_bits(const RankPartition& p, const ColVie
             if (c == 0) continue;
             if (c > best) { best = c; nbest = 1; best_slot = k; } else if (c == best) nbest++;
         }
+#ifdef HS_LOOPA_STATS2
+        { extern long g_s2[64]; g_s2[31]++; if (nbest > 1) g_s2[32]++; }
+#endif
         if (nbest <= 1) {
             LA_STAT(5);
             r.second = best_slot >= 0 ? cb.codes[best_slot] : (uint8_t)' ';
@@ -668,6 +674,10 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
         if (pos - last_position <= 5) continue;
         const ColView colbits(cs.bits[ci], cs.words);
         const int n = colbits.n_entries;
+#ifdef HS_LOOPA_STATS2
+        { extern long g_s2[64]; g_s2[0]++; g_s2[1 + std::min(colbits.W, 8)]++; g_s2[10 + std::min(colbits.nslots, 15)]++; if (n > 128) g_s2[26]++; if (k0 >= 128) g_s2[27]++;
+          if ((long)active.size() > g_s2[28]) g_s2[28] = (long)active.size(); g_s2[29] += (long)active.size(); if (n > g_s2[30]) g_s2[30] = n; }
+#endif
         bool found = false;
         int n_corr = 0;
         size_t kept = 0;
@@ -763,16 +773,26 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
 #ifdef HS_LOOPA_STATS
     if (tim) std::fprintf(stderr, "[hs loopa stats] calls %ld no-common-words %ld shared0 %ld few-shared %ld few-decided %ld fast-table %ld\n", g_la_stat[0].load(), g_la_stat[1].load(), g_la_stat[2].load(), g_la_stat[3].load(), g_la_stat[4].load(), g_la_stat[5].load());
 #endif
+#ifdef HS_LOOPA_STATS2
+    { extern long g_s2[64]; long live = 0; for (int p : active) { (void)p; live++; } std::fprintf(stderr, "[s2] cands %ld W:", g_s2[0]); for (int i = 1; i < 10; ++i) std::fprintf(stderr, " %ld", g_s2[i]);
+      std::fprintf(stderr, " nslots:"); for (int i = 10; i < 26; ++i) std::fprintf(stderr, " %ld", g_s2[i]);
+      std::fprintf(stderr, " n>128 %ld ref>=128 %ld maxactive %ld sumactive %ld maxn %ld tables %ld tied %ld parts %zu\n", g_s2[26], g_s2[27], g_s2[28], g_s2[29], g_s2[30], g_s2[31], g_s2[32], parts.size()); }
+#endif
     if (tim) std::fprintf(stderr, "[hs timing] loop A: %d candidates, %zu partitions, %ld comparisons, %ld augmentations; %.0f us (augment %.0f)\n",
                           cs.n, parts.size(), n_cmp, n_aug, nowus() - t_a0, t_aug);
 }
 
 // loop A ran on the device (k_loop_a): its partitions become the host's. The device ranks the reads exactly as
-// cv_rank_reads() does (the batch carries that order), so its bit sets and per-rank counters are taken as they are.
-void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const uint64_t* bits, const int32_t* cnt) {
+// cv_rank_reads() does (the batch carries that order), so its bit sets and per-rank counters are taken as they are -- the
+// words [w0, w1] of every partition, which hold all of its reads.
+void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts, const CvPartRecord* rec, const uint64_t* bits, const int32_t* cnt,
+                       const int32_t* rank_pre, const int32_t* orig_pre) {
     const int N = st.n_reads;
-    const int W = (N + 63) >> 6;
-    cv_rank_reads(N, read_start, st.rank_of, st.orig_of);
+    if (rank_pre && orig_pre) {
+        st.rank_of.assign(rank_pre, rank_pre + N);
+        st.orig_of.assign((size_t)((N + 63) / 64) * 64, 0);
+        std::copy(orig_pre, orig_pre + N, st.orig_of.begin());
+    } else cv_rank_reads(N, read_start, st.rank_of, st.orig_of);
     std::vector<RankPartition>& parts = st.parts;
     parts.clear();
     parts.resize((size_t)n_parts);
@@ -780,21 +800,23 @@ void cv_phase_a_import(CvContigState& st, const int32_t* read_start, int n_parts
         RankPartition& d = parts[(size_t)p];
         const CvPartRecord& r = rec[p];
         d.left = r.left; d.right = r.right; d.n_occ = r.n_occ; d.n_corr = r.n_corr; d.lo = r.lo; d.hi = r.hi; d.reach = r.reach;
-        d.rank_of = st.rank_of.data(); d.orig_of = st.orig_of.data(); d.wlo = W; d.whi = -1;
+        d.rank_of = st.rank_of.data(); d.orig_of = st.orig_of.data(); d.wlo = 0; d.whi = -1;
         d.allocate(st.arena, N);
-        const uint64_t* pb = bits + (size_t)p * 3 * W;
-        const int32_t* pc = cnt + (size_t)p * N;
-        std::memcpy(d.present, pb, (size_t)W * 8); std::memcpy(d.plus, pb + W, (size_t)W * 8); std::memcpy(d.minus, pb + 2 * W, (size_t)W * 8);
-        for (int w = 0; w < W; ++w) {
-            if (!d.present[w]) continue;
-            if (w < d.wlo) d.wlo = w;
-            if (w > d.whi) d.whi = w;
-            for (uint64_t x = d.present[w]; x; x &= x - 1) {
-                const int k = w * 64 + __builtin_ctzll(x);
-                d.more[k] = pc[k] & 0xffff; d.less[k] = (pc[k] >> 16) & 0xffff;      // (the device keeps the counters by rank too)
+        const int span = r.w1 - r.w0 + 1;
+        const uint64_t* pb = bits + 3 * r.word_off;
+        const int32_t* pc = cnt + 64 * r.word_off;
+        for (int j = 0; j < span; ++j) {
+            const size_t w = (size_t)(r.w0 + j);
+            const uint64_t pres = pb[j];
+            if (!pres) continue;
+            d.present[w] = pres; d.plus[w] = pb[span + j]; d.minus[w] = pb[2 * span + j];
+            d.touch_word((int)w);
+            for (uint64_t x = pres; x; x &= x - 1) {
+                const int bit = __builtin_ctzll(x);
+                const int32_t v = pc[j * 64 + bit];
+                d.more[w * 64 + (size_t)bit] = v & 0xffff; d.less[w * 64 + (size_t)bit] = (v >> 16) & 0xffff;
             }
         }
-        if (d.whi < d.wlo) d.wlo = 0;
     }
 }
 

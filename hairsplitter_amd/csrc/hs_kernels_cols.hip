@@ -439,7 +439,8 @@ __global__ __launch_bounds__(64 * HS_CB_WAVES) void k_cand_bits(
     const ColumnsHeader* __restrict__ header, long long cap_cand, const int32_t* __restrict__ contig_rec_off, const int2* __restrict__ rank_end /* per record: {rank on its contig, alignment end} */,
     CandBitsDev* __restrict__ out_bits, unsigned long long* out_words, long long cap_words,
     unsigned long long* counter, long long cap_entries, const int32_t* __restrict__ cand_len /* non-NULL: cand_off[k] is column k's place in cand_idx / cand_code (the
-    range's own column arrays) and cand_len[k] its length; NULL: the packed arrays, lengths from consecutive offsets */) {
+    range's own column arrays) and cand_len[k] its length; NULL: the packed arrays, lengths from consecutive offsets */,
+    const uint8_t* __restrict__ skip_contig /* non-NULL: [contig - c_first] != 0 -- loop A of that contig runs on the device (k_loop_a): its columns get an empty header and no block */, int c_first) {
     constexpr int PW = HS_CB_PER_WAVE;
     __shared__ int s_fp[HS_CB_WAVES][PW][256];
     __shared__ uint8_t s_slot[HS_CB_WAVES][PW][256];
@@ -462,6 +463,10 @@ __global__ __launch_bounds__(64 * HS_CB_WAVES) void k_cand_bits(
         const long long k = k0 + c;
         live[c] = k < n_cand;      // (a wavefront without a column still meets the others at the barriers)
         const hs_colrec_dev rec = cand_rec[live[c] ? k : 0];
+        if (live[c] && skip_contig && skip_contig[rec.contig - c_first]) {
+            live[c] = false;
+            if (lane == 0) { CandBitsDev h; h.wlo = 0; h.n_words = 0; h.n_slots = 0; h.idx_min = 0; h.idx_max = -1; h.reach = -1; h.n_entries = 0; h.word_off = 0; out_bits[k] = h; }
+        }
         r0[c] = live[c] ? contig_rec_off[rec.contig] : 0;
         e0[c] = live[c] ? cand_off[k] : 0;
         n[c] = live[c] ? (cand_len ? cand_len[k] : (int)(cand_off[k + 1] - e0[c])) : 0;

@@ -86,3 +86,14 @@ def test_bench_default_job_against_its_known_answer(built):
     d = _line(r.stdout)
     assert d["config"]["contigs"] == 500 and d["labels_digest"]["windows"] == 25594
     assert d["parity"]["checked"] and d["parity"]["kind"] == "labels digest" and d["parity"]["identical"], d["parity"]
+
+
+def test_bench_default_job_with_loop_a_on_the_device(built):
+    """The same job with loop A of keep_only_robust_variants walked by k_loop_a for every contig (HS_LOOP_A_ON_DEVICE=1: 500 chains of up to
+    3 300 candidate columns, one wavefront each; the host imports the partitions for loop B): the timed path's labels against the same digest"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-contigs", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT,
+                       env=dict(os.environ, HS_LOOP_A_ON_DEVICE="1"), timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = _line(r.stdout)
+    assert d["kernels"]["k_loop_a"]["launches_per_step"] > 0
+    assert d["parity"]["checked"] and d["parity"]["kind"] == "labels digest" and d["parity"]["identical"], d["parity"]
