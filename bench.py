@@ -321,6 +321,8 @@ def main():
     no_coll = bool(os.environ.get("HS_BENCH_NO_COLLECTIVES"))   # diagnostic only
     cap = [None]
 
+    my_ids_np = np.asarray(my_ids, dtype=np.int32)
+
     def error_rate_fn(cv):
         # the one cross-contig quantity of the path: mean of the per-contig distances over the WHOLE job, in contig order
         t = time.perf_counter()
@@ -339,8 +341,10 @@ def main():
         # and their labels; decoding them into arrays is the consumer's business. cap[0] is made during set-up (below), not here.
         gathered = None
         if cap[0] is not None and not no_coll:
+            # ... and END THE STEP ON RANK 0'S HOST, as the single process's step does: the gathered payloads are copied into one pinned block and
+            # that copy is waited for inside the step (to_host). Every window carries the contig of the JOB it belongs to.
             off, ids, lab = sr["sparse"]
-            gathered = cap[0].gather(off, ids, lab, decode=False)
+            gathered = cap[0].gather(off, ids, lab, decode=False, win_contig=np.repeat(my_ids_np, np.diff(sr["win_off"])), to_host=True)
         py_ms["gather"] += (time.perf_counter() - t3) * 1e3
         return cv, sr, gathered
 
@@ -362,7 +366,7 @@ def main():
     pet()
     _cv0, _sr0, _ = step()      # set-up: the first pass sizes the library's pools -- and the per-step collective (largest payload of any rank, once)
     if use_dist and "sparse" in _sr0:      # (one rank: its lists are the job's, nothing to gather)
-        cap[0] = hdist.SparseLabelGatherer(hdist.SparseLabelGatherer.job_capacity(hdist.sparse_payload_bytes(int(_sr0["sparse"][0].size) - 1, int(_sr0["sparse"][1].size))))
+        cap[0] = hdist.SparseLabelGatherer(hdist.SparseLabelGatherer.job_capacity(hdist.sparse_payload_bytes(int(_sr0["sparse"][0].size) - 1, int(_sr0["sparse"][1].size), with_contigs=True)))
     _cv0 = _sr0 = None
     for _ in range(SETUP_STEPS - 1):
         pet(); step()
@@ -436,11 +440,27 @@ def main():
     try:
         if rank == 0 and last_results is not None:
             if use_dist and last_gathered is not None:
-                labels_digest = dict(hdist.sparse_digest([hdist.decode_sparse(o.cpu().numpy()) for o in last_gathered]), ranks=len(last_gathered))
+                labels_digest = dict(hdist.sparse_digest([hdist.decode_sparse(np.asarray(o)) for o in last_gathered]), ranks=len(last_gathered))
             elif not use_dist and "sparse" in last_results[1]:
-                labels_digest = dict(hdist.sparse_digest([tuple(np.array(x) for x in last_results[1]["sparse"])]), ranks=1)
+                labels_digest = dict(hdist.sparse_digest([tuple(np.array(x) for x in last_results[1]["sparse"]) + (np.repeat(my_ids_np, np.diff(last_results[1]["win_off"])),)]), ranks=1)
     except Exception as e:
         sys.stderr.write("labels digest failed: %r\n" % (e,))
+    # ... and what stage 3 leaves beside the labels: the job's SNP count, the contigs' mean distances (error_rate.txt is their mean) -- summed
+    # / put together over the ranks after the clock has stopped (two tiny host-side exchanges every rank takes part in)
+    try:
+        if last_results is not None and not emulated:
+            import zlib
+            md_full = np.zeros(n_job, np.float32); md_full[my_ids_np] = np.asarray(last_results[0]["mean_distance"], np.float32)[:len(my_ids)]
+            snps = np.array([int(last_results[0].get("n_snps", 0))], np.int64)
+            if use_dist:
+                t_md = torch.from_numpy(md_full); t_sn = torch.from_numpy(snps)
+                dist.all_reduce(t_md, op=dist.ReduceOp.SUM, group=cpu_group); dist.all_reduce(t_sn, op=dist.ReduceOp.SUM, group=cpu_group)
+            if labels_digest is not None:
+                labels_digest["n_snps"] = int(snps[0])
+                labels_digest["mean_distance_crc32"] = int(zlib.crc32(md_full.tobytes()))
+                labels_digest["error_rate"] = "%g" % hdist.mean_of_positive_f32(md_full)
+    except Exception as e:
+        sys.stderr.write("digest of the stage-3 results failed: %r\n" % (e,))
     last_results = None
     last_gathered = None
     waits_per_step = (api.host_waits() - waits0) / args.steps
@@ -658,13 +678,16 @@ def main():
             except Exception:
                 known = None
             if known:
-                same = all(labels_digest[k] == known[k] for k in ("windows", "entries", "sum_crc32"))
-                out["parity"] = {"checked": True, "kind": "labels digest", "identical": bool(same), "gro_identical": bool(same),
-                                 "against": "tests/golden/bench_labels_digest.json: windows / entries / sum of per-window CRC-32 of (reads, labels) of the single-process run of this job whose "
-                                            "reference gate passed (" + known.get("verified", "")[:120] + ")",
-                                 "what": "the labels rank 0 holds for the whole job after the LAST TIMED STEP (%d rank(s))" % labels_digest.get("ranks", 1),
-                                 "not_compared": ".col SNPS lines and the error rate (the reference gate of a --gpus 1 run with the file-to-file leg compares them)",
-                                 "diffs": None if same else {"got": labels_digest, "expected": {k: known[k] for k in ("windows", "entries", "sum_crc32")}}}
+                keys = [k for k in ("windows", "entries", "sum_crc32", "n_snps", "mean_distance_crc32", "error_rate") if k in known]
+                same = all(labels_digest.get(k) == known[k] for k in keys)
+                # (a digest, not the reference's files beside the run: `identical` says so through its scope; the file-level flags stay null)
+                out["parity"] = {"checked": True, "kind": "labels digest", "identical": bool(same), "identical_scope": "digest of " + ", ".join(keys),
+                                 "gro_identical": None, "col_snps_identical": None, "error_rate_identical": None,
+                                 "against": "tests/golden/bench_labels_digest.json: windows / entries / sum of per-window CRC-32 of (contig, reads, labels), the job's SNP count, CRC-32 of the "
+                                            "contigs' mean distances and the error rate of the single-process run of this job whose reference gate passed (" + known.get("verified", "")[:120] + ")",
+                                 "what": "what rank 0 holds for the whole job after the LAST TIMED STEP (%d rank(s))" % labels_digest.get("ranks", 1),
+                                 "not_compared": "the SNPS lines of the .col (positions, alleles, entries): the reference gate of a --gpus 1 run with the file-to-file leg compares them",
+                                 "diffs": None if same else {"got": {k: labels_digest.get(k) for k in keys}, "expected": {k: known[k] for k in keys}}}
         if "parity" not in out:
             out["parity"] = {"checked": False, "why": "several ranks (each holds a shard; the full-job comparison runs at --gpus 1)" if (use_dist or emulated) else
                              ("no file-to-file leg in this run (--cpu-contigs 0) or no reference / oracle binaries on this box" if "error" not in (out.get("cpu_baseline") or {}) else "the file-to-file leg failed")}

@@ -306,7 +306,7 @@ int write_gro_companion(const std::string& col_path, const std::vector<ColFileCo
                         uint32_t seed, int32_t window, int n_threads);
 int take_gro_companion(const std::string& col_path, float error_rate, float rsa, bool low_memory, bool amplicon, uint32_t seed, const std::string& outfile, int n_threads);
 void remove_gro_companion(const std::string& col_path);
-void mark_gro_companion_pending(const std::string& col_path);
+bool mark_gro_companion_pending(const std::string& col_path, float error_rate, float rsa, bool low_memory, bool amplicon, uint32_t seed);
 
 void free_cv_result(hs_cv_result* r);
 void free_sr_result(hs_sr_result* r);

@@ -9,12 +9,15 @@
  *   - Until it has reported, the child dies with its parent (PR_SET_PDEATHSIG) and the parent passes SIGTERM / SIGINT / SIGHUP /
  *     SIGQUIT on to it: a caller that kills the process it started (a timeout) leaves nothing behind that still holds the GPU
  *     or writes the output files. After the report only the teardown is left and the tie is cut.
- *   - HS_NO_DETACH=1 runs everything in the process that was started. The same happens by itself when a tool is preloaded into
- *     the process (ROCP_TOOL_LIBRARIES, HSA_TOOLS_LIB, an LD_PRELOAD that names rocprof / roctracer / the HSA or HIP runtime:
- *     rocprofv3 and friends initialise the GPU before main(), and a fork after that is not safe): profile the drop-ins as they
- *     are, no switch needed. */
+ *   - HS_NO_DETACH=1 runs everything in the process that was started. The same happens by itself when the process holds a descriptor
+ *     of the GPU when main() begins (/dev/kfd or a render node among /proc/self/fd: somebody -- rocprofv3 and friends, under whatever
+ *     name -- has initialised the GPU before main(), and neither a fork nor an exec after that is safe), and, as a second line, when a
+ *     known tool is named in the environment (ROCP_TOOL_LIBRARIES, HSA_TOOLS_LIB, an LD_PRELOAD with rocprof / roctracer / the HSA or
+ *     HIP runtime): profile the drop-ins as they are, no switch needed. */
 #ifndef HS_DROPIN_MAIN_H
 #define HS_DROPIN_MAIN_H
+#include <dirent.h>
+#include <fcntl.h>
 #include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -53,12 +56,32 @@ static int hs_dropin_run(int argc, char** argv) {
 }
 static volatile pid_t hs_dropin_child = 0;
 static void hs_dropin_forward(int sig) { if (hs_dropin_child > 0) kill(hs_dropin_child, sig); }
-static int hs_dropin_tool_preloaded(void) {      /* a profiler / tracer of the ROCm stack in the process (they initialise the GPU before main()) */
+static int hs_dropin_tool_preloaded(void) {      // a profiler / tracer of the ROCm stack in the process (they initialise the GPU before main())
     const char* names[] = {"ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCTRACER_DOMAIN"};
     for (unsigned i = 0; i < sizeof names / sizeof names[0]; ++i) { const char* v = getenv(names[i]); if (v && v[0]) return 1; }
-    const char* pre = getenv("LD_PRELOAD");      /* (other preloads -- sanitizers, exec guards -- do not touch the GPU) */
+    const char* pre = getenv("LD_PRELOAD");      // (other preloads -- sanitizers, exec guards -- do not touch the GPU)
     if (pre && (strstr(pre, "rocprof") || strstr(pre, "roctracer") || strstr(pre, "rocprofiler") || strstr(pre, "libhsa") || strstr(pre, "amdhip"))) return 1;
     return 0;
+}
+/* The positive test: does this process hold a descriptor of the GPU (the compute node /dev/kfd or a render node /dev/dri/renderD*)? Whoever
+ * initialised the GPU before main() -- under whatever name -- has opened them. 1: yes, or it cannot be told (no /proc/self/fd): no fork and
+ * no exec then; 0: none. */
+static int hs_dropin_gpu_is_open(void) {
+    DIR* d = opendir("/proc/self/fd");
+    if (!d) return 1;
+    int found = 0;
+    struct dirent* e;
+    while (!found && (e = readdir(d)) != NULL) {
+        if (e->d_name[0] == '.') continue;
+        char path[64], target[256];
+        snprintf(path, sizeof path, "/proc/self/fd/%s", e->d_name);
+        const ssize_t n = readlink(path, target, sizeof target - 1);
+        if (n <= 0) continue;
+        target[n] = 0;
+        if (strncmp(target, "/dev/kfd", 8) == 0 || strncmp(target, "/dev/dri/", 9) == 0) found = 1;
+    }
+    closedir(d);
+    return found;
 }
 static int hs_dropin_run_all(int argc, char** argv) {      /* one process: the stage, then its epilogue, then the exit */
     const int rc = hs_dropin_run(argc, argv);
@@ -71,9 +94,9 @@ static int hs_dropin_run_all(int argc, char** argv) {      /* one process: the s
 /* The stage parses gigabytes into freshly mapped memory and leaves them to the process end: with 4-KB pages that is a million page faults on the way in and
  * a million pages to give back on the way out (0.15 s of the 500-contig job's 1.35 s). glibc (>= 2.35) asks for transparent huge pages for what malloc maps
  * when it is STARTED with GLIBC_TUNABLES=glibc.malloc.hugetlb=1 -- so the executable starts itself again with that setting, once, before anything of it
- * has touched the GPU (not when a profiler's library is in the process: that one has; not when the caller set GLIBC_TUNABLES itself). HS_NO_REEXEC=1: never. */
+ * has touched the GPU (checked, not assumed: hs_dropin_gpu_is_open; not when the caller set GLIBC_TUNABLES itself). HS_NO_REEXEC=1: never. This call stays above every hs_* call. */
 static void hs_dropin_with_huge_pages(char** argv, int wanted) {
-    if (!wanted || getenv("HS_NO_REEXEC") || getenv("GLIBC_TUNABLES") || hs_dropin_tool_preloaded()) return;
+    if (!wanted || getenv("HS_NO_REEXEC") || getenv("GLIBC_TUNABLES") || hs_dropin_tool_preloaded() || hs_dropin_gpu_is_open()) return;
     setenv("HS_NO_REEXEC", "1", 1);
     setenv("GLIBC_TUNABLES", "glibc.malloc.hugetlb=1", 1);
     execv("/proc/self/exe", argv);
@@ -85,7 +108,7 @@ static int hs_dropin_main2(int (*stage)(int, char**), void (*epilogue)(void), in
     hs_dropin_epilogue = epilogue;
     hs_dropin_with_huge_pages(argv, epilogue != NULL);      /* (HS_call_variants: the stage that parses the job's text; HS_separate_reads maps the arrays it left: the restart would only cost it 30 ms) */
     hs_dropin_stamp("main entered");
-    if (getenv("HS_NO_DETACH") || hs_dropin_tool_preloaded() || pipe(pfd) != 0) _exit(hs_dropin_run_all(argc, argv));
+    if (getenv("HS_NO_DETACH") || hs_dropin_tool_preloaded() || hs_dropin_gpu_is_open() || pipe(pfd) != 0) _exit(hs_dropin_run_all(argc, argv));
     const pid_t parent = getpid();
     const pid_t pid = fork();
     if (pid < 0) _exit(hs_dropin_run_all(argc, argv));
@@ -99,10 +122,14 @@ static int hs_dropin_main2(int (*stage)(int, char**), void (*epilogue)(void), in
         prctl(PR_SET_PDEATHSIG, 0);             /* the outputs are complete: the parent is about to leave, the teardown goes on */
         if (write(pfd[1], &rc, sizeof rc) != (ssize_t)sizeof rc) _exit(rc ? rc : 1);
         close(pfd[1]);
-        close(0); close(1);                     /* whoever reads this program's output sees its end now */
+        {   /* whoever reads this program's output sees its end now; the descriptors stay taken (by /dev/null), so that nothing the epilogue
+             * opens -- the companion file, a mapping, a device node -- becomes "standard output" */
+            const int nul = open("/dev/null", O_RDWR);
+            if (nul >= 0) { dup2(nul, 0); dup2(nul, 1); if (nul > 2) close(nul); } else { close(0); close(1); }
+        }
         if (rc == 0 && hs_dropin_epilogue) hs_dropin_epilogue();      /* (the caller has its exit status; this runs beside whatever it starts next) */
         hs_dropin_finish();
-        close(2);
+        { const int nul = open("/dev/null", O_RDWR); if (nul >= 0) { dup2(nul, 2); if (nul > 2) close(nul); } else close(2); }
         _exit(rc);
     }
     close(pfd[1]);

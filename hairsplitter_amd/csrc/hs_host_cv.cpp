@@ -30,9 +30,6 @@
 #include <mutex>
 
 namespace hs {
-#ifdef HS_LOOPA_STATS2
-long g_s2[64];
-#endif
 
 static constexpr int8_t ABSENT = 2;
 
@@ -317,9 +314,6 @@ static Contingency column_vs_partition_bits(const RankPartition& p, const ColVie
             if (c == 0) continue;
             if (c > best) { best = c; nbest = 1; best_slot = k; } else if (c == best) nbest++;
         }
-#ifdef HS_LOOPA_STATS2
-        { extern long g_s2[64]; g_s2[31]++; if (nbest > 1) g_s2[32]++; }
-#endif
         if (nbest <= 1) {
             LA_STAT(5);
             r.second = best_slot >= 0 ? cb.codes[best_slot] : (uint8_t)' ';
@@ -674,10 +668,6 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
         if (pos - last_position <= 5) continue;
         const ColView colbits(cs.bits[ci], cs.words);
         const int n = colbits.n_entries;
-#ifdef HS_LOOPA_STATS2
-        { extern long g_s2[64]; g_s2[0]++; g_s2[1 + std::min(colbits.W, 8)]++; g_s2[10 + std::min(colbits.nslots, 15)]++; if (n > 128) g_s2[26]++; if (k0 >= 128) g_s2[27]++;
-          if ((long)active.size() > g_s2[28]) g_s2[28] = (long)active.size(); g_s2[29] += (long)active.size(); if (n > g_s2[30]) g_s2[30] = n; }
-#endif
         bool found = false;
         int n_corr = 0;
         size_t kept = 0;
@@ -772,11 +762,6 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
     }
 #ifdef HS_LOOPA_STATS
     if (tim) std::fprintf(stderr, "[hs loopa stats] calls %ld no-common-words %ld shared0 %ld few-shared %ld few-decided %ld fast-table %ld\n", g_la_stat[0].load(), g_la_stat[1].load(), g_la_stat[2].load(), g_la_stat[3].load(), g_la_stat[4].load(), g_la_stat[5].load());
-#endif
-#ifdef HS_LOOPA_STATS2
-    { extern long g_s2[64]; long live = 0; for (int p : active) { (void)p; live++; } std::fprintf(stderr, "[s2] cands %ld W:", g_s2[0]); for (int i = 1; i < 10; ++i) std::fprintf(stderr, " %ld", g_s2[i]);
-      std::fprintf(stderr, " nslots:"); for (int i = 10; i < 26; ++i) std::fprintf(stderr, " %ld", g_s2[i]);
-      std::fprintf(stderr, " n>128 %ld ref>=128 %ld maxactive %ld sumactive %ld maxn %ld tables %ld tied %ld parts %zu\n", g_s2[26], g_s2[27], g_s2[28], g_s2[29], g_s2[30], g_s2[31], g_s2[32], parts.size()); }
 #endif
     if (tim) std::fprintf(stderr, "[hs timing] loop A: %d candidates, %zu partitions, %ld comparisons, %ld augmentations; %.0f us (augment %.0f)\n",
                           cs.n, parts.size(), n_cmp, n_aug, nowus() - t_a0, t_aug);

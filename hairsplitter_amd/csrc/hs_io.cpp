@@ -1004,7 +1004,22 @@ int write_gro_companion(const std::string& col_path, const std::vector<ColFileCo
 }
 void remove_gro_companion(const std::string& col_path) { std::remove((col_path + ".hsgro").c_str()); std::remove((col_path + ".hsgro.tmp").c_str()); }
 // the marker "a companion is being made": holds the process id of its maker, so that a reader can tell a maker at work from one that died
-void mark_gro_companion_pending(const std::string& col_path) { if (precompute_off()) return; std::ofstream out(col_path + ".hsgro.tmp", std::ios::binary); out << (long)::getpid() << "\n"; }
+// ... and the arguments the companion is being made for, so that a reader with other arguments does not wait for it. Returns false when
+// no companion is to be made (HS_NO_PRECOMPUTE / no sidecar): the caller then skips the epilogue's stage 4 altogether
+bool mark_gro_companion_pending(const std::string& col_path, float error_rate, float rsa, bool low_memory, bool amplicon, uint32_t seed) {
+    if (precompute_off()) return false;
+    std::ofstream out(col_path + ".hsgro.tmp", std::ios::binary);
+    out << (long)::getpid() << "\n" << f32_bits(error_rate) << " " << f32_bits(rsa) << " " << (low_memory ? 1 : 0) << " " << (amplicon ? 1 : 0) << " " << seed << "\n";
+    return (bool)out;
+}
+// 1: the marker names other arguments than these (nothing usable will come of it); 0: the same, or a marker without arguments
+static int companion_marker_mismatch(const std::string& tmp, float error_rate, float rsa, bool low_memory, bool amplicon, uint32_t seed) {
+    std::ifstream in(tmp, std::ios::binary);
+    long pid = 0; unsigned long er = 0, rs = 0, lm = 0, am = 0, sd = 0;
+    if (!(in >> pid) || pid <= 0) return 0;
+    if (!(in >> er >> rs >> lm >> am >> sd)) return 0;
+    return (er != f32_bits(error_rate) || rs != f32_bits(rsa) || lm != (unsigned long)(low_memory ? 1 : 0) || am != (unsigned long)(amplicon ? 1 : 0) || sd != (unsigned long)seed) ? 1 : 0;
+}
 static bool companion_maker_gone(const std::string& tmp) {
     std::ifstream in(tmp, std::ios::binary);
     long pid = 0;
@@ -1021,6 +1036,7 @@ int take_gro_companion(const std::string& col_path, float error_rate, float rsa,
         // HS_call_variants may still be at it (it writes the companion after its own outputs, its caller has moved on): a moment's patience
         if (::stat(tmp.c_str(), &st) != 0) return 0;
         if (companion_maker_gone(tmp)) { std::remove(tmp.c_str()); return 0; }      // (it died in its epilogue: nothing will come)
+        if (companion_marker_mismatch(tmp, error_rate, rsa, low_memory, amplicon, seed)) return 0;      // (it is being made for another call)
         static const long wait_ms = []() { const char* e = std::getenv("HS_PRECOMPUTE_WAIT_MS"); const long v = e ? std::atol(e) : 1500; return v >= 0 ? v : 1500; }();
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {

@@ -158,8 +158,11 @@ extern "C" int hs_call_variants_main(int argc, char** argv) {
     hs::write_cv_outputs(in, res, error_rate_out, file_out, vcf_file, num_threads);
     clk.lap("write .col/.vcf");
     if (res->col_idx || res->col_off[res->snp_off[C]] == 0) {      // the stage's outputs are complete: what may follow is hs_call_variants_epilogue
-        g_pending_gro.on = true; g_pending_gro.col = file_out; g_pending_gro.err = error_rate_out; g_pending_gro.amplicon = amplicon_i != 0; g_pending_gro.threads = num_threads;
-        hs::mark_gro_companion_pending(file_out);
+        // (HS_NO_PRECOMPUTE, or no sidecar: no companion, and no stage 4 behind this stage's back either)
+        float er = 0; bool er_ok = false;
+        { std::ifstream f(error_rate_out); std::string t; if (f >> t) { double e = std::strtod(t.c_str(), nullptr); if (e > 0.15) e = 0.15; er = (float)e; er_ok = true; } }
+        g_pending_gro.col = file_out; g_pending_gro.err = error_rate_out; g_pending_gro.amplicon = amplicon_i != 0; g_pending_gro.threads = num_threads;
+        g_pending_gro.on = er_ok && hs::mark_gro_companion_pending(file_out, er, (float)std::atof("0.01"), false, amplicon_i != 0, stage4_seed());
     }
     if (std::getenv("HS_EXIT_PROBE")) {      // (diagnostic: what destroying the parsed input and the result costs here instead of at exit)
         hs_cv_result_destroy(res); clk.lap("destroy the result");

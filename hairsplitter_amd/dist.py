@@ -5,7 +5,7 @@ partition labels to rank 0, which writes the .gro. `torch.distributed` backend "
 same code runs on "gloo" for the CPU tests."""
 from __future__ import annotations
 
-from typing import List, Sequence
+from typing import Optional, List, Sequence
 
 import numpy as np
 
@@ -193,53 +193,72 @@ class LabelGatherer:
 # every read -1, windows without SNPs: the reads over the midpoint), so they are put together on the host; what crosses to
 # the device for the collective is that list -- 6 bytes per (window, read) pair, an eighth of the dense [window][N reads of the
 # contig] array of the round before -- staged in ONE pinned buffer that is allocated with the gatherer, copied once, gathered once.
-# Payload (bytes): int64 n_windows, int64 n_rows | int32 row_off[n_windows + 1] | int32 ids[n_rows] | int16 labels[n_rows]
+# Payload (bytes): int64 n_windows, int64 n_rows (bit 62 set: with contigs) | int32 row_off[n_windows + 1] | [int32 win_contig[n_windows]] |
+#                  int32 ids[n_rows] | int16 labels[n_rows]
+# win_contig (optional): the contig of the JOB every window belongs to -- what whoever writes the .gro needs to put a rank's GROUP lines
+# under the right CONTIG line, and what makes the digest below notice two windows that changed places.
 # ---------------------------------------------------------------------------------------------
-def sparse_payload_bytes(n_windows: int, n_rows: int) -> int:
-    return 16 + 4 * (n_windows + 1) + 4 * n_rows + 2 * n_rows + 8
+_WITH_CONTIGS = 1 << 62
 
 
-def encode_sparse(win_row_off: np.ndarray, ids: np.ndarray, labels: np.ndarray, out: np.ndarray) -> int:
+def sparse_payload_bytes(n_windows: int, n_rows: int, with_contigs: bool = False) -> int:
+    return 16 + 4 * (n_windows + 1) + (4 * n_windows if with_contigs else 0) + 4 * n_rows + 2 * n_rows + 8
+
+
+def encode_sparse(win_row_off: np.ndarray, ids: np.ndarray, labels: np.ndarray, out: np.ndarray, win_contig: Optional[np.ndarray] = None) -> int:
     """Writes the payload into the uint8 array `out`; returns its length in bytes"""
     W, R = int(win_row_off.size) - 1, int(ids.size)
-    n = sparse_payload_bytes(W, R)
+    n = sparse_payload_bytes(W, R, win_contig is not None)
     if out.size < n:
         raise ValueError(f"label payload of {n} bytes does not fit the gather buffer of {out.size} (the job's lists grew: size the SparseLabelGatherer again)")
     if R >= (1 << 31):
         raise ValueError("more than 2^31 (window, read) pairs in one rank's list")
     if R and (int(labels.min()) < -32768 or int(labels.max()) > 32767):
         raise ValueError("a partition label does not fit the 16 bits it travels in")
-    out[:16].view(np.int64)[:] = (W, R)
+    if win_contig is not None and int(win_contig.size) != W:
+        raise ValueError("one contig per window")
+    out[:16].view(np.int64)[:] = (W, R | (_WITH_CONTIGS if win_contig is not None else 0))
     o = 16
     np.copyto(out[o:o + 4 * (W + 1)].view(np.int32), win_row_off, casting="unsafe"); o += 4 * (W + 1)
+    if win_contig is not None:
+        np.copyto(out[o:o + 4 * W].view(np.int32), win_contig, casting="unsafe"); o += 4 * W
     np.copyto(out[o:o + 4 * R].view(np.int32), ids, casting="unsafe"); o += 4 * R
     np.copyto(out[o:o + 2 * R].view(np.int16), labels, casting="unsafe")      # labels are -2, -1 or a group id < 32767
     return n
 
 
 def decode_sparse(buf: np.ndarray):
-    """(win_row_off int64, ids int32, labels int32) of one rank's payload"""
+    """(win_row_off int64, ids int32, labels int32[, win_contig int32]) of one rank's payload"""
     W, R = (int(x) for x in buf[:16].view(np.int64))
+    with_contigs = bool(R & _WITH_CONTIGS)
+    R &= ~_WITH_CONTIGS
     o = 16
     off = buf[o:o + 4 * (W + 1)].view(np.int32).astype(np.int64); o += 4 * (W + 1)
+    wc = None
+    if with_contigs:
+        wc = buf[o:o + 4 * W].view(np.int32).copy(); o += 4 * W
     ids = buf[o:o + 4 * R].view(np.int32).copy(); o += 4 * R
     lab = buf[o:o + 2 * R].view(np.int16).astype(np.int32)
-    return off, ids, lab
+    return (off, ids, lab) if wc is None else (off, ids, lab, wc)
 
 
 def sparse_digest(payloads):
-    """Order-independent digest of per-window (reads, labels) lists, one (win_row_off, ids, labels) triple per rank: the number of windows
-    and entries and the sum of the windows' CRC-32 -- the same job gives the same digest however its contigs were sharded over the ranks
-    (a window's reads are indices within its contig)."""
+    """Order-independent digest of per-window (reads, labels) lists, one (win_row_off, ids, labels[, win_contig]) tuple per rank: the number
+    of windows and entries and the sum of the windows' CRC-32 -- over the window's contig (when the payload names it), its reads and their
+    labels: the same job gives the same digest however its contigs were sharded over the ranks (a window's reads are indices within its
+    contig), and two windows that changed places between contigs do not."""
     import zlib
     W = R = 0
     acc = 0
-    for off, ids, lab in payloads:
+    for pay in payloads:
+        off, ids, lab = pay[0], pay[1], pay[2]
+        wc = np.ascontiguousarray(pay[3], dtype=np.int32) if len(pay) > 3 and pay[3] is not None else None
         off = np.asarray(off, dtype=np.int64); ids = np.ascontiguousarray(ids, dtype=np.int32); lab = np.ascontiguousarray(lab, dtype=np.int32)
         W += len(off) - 1; R += int(off[-1]) if len(off) else 0
         for w in range(len(off) - 1):
             a, b = int(off[w]), int(off[w + 1])
-            acc = (acc + zlib.crc32(lab[a:b].tobytes(), zlib.crc32(ids[a:b].tobytes()))) & 0xFFFFFFFFFFFFFFFF
+            seed = zlib.crc32(wc[w:w + 1].tobytes()) if wc is not None else 0
+            acc = (acc + zlib.crc32(lab[a:b].tobytes(), zlib.crc32(ids[a:b].tobytes(), seed))) & 0xFFFFFFFFFFFFFFFF
     return {"windows": int(W), "entries": int(R), "sum_crc32": int(acc)}
 
 
@@ -273,12 +292,15 @@ class SparseLabelGatherer:
         """set-up: the largest payload over the ranks (+ 1/8: the lists of a job vary little from step to step, none at all for the same input)"""
         return gather_capacity(int(local_bytes) + int(local_bytes) // 8 + 64, group)
 
-    def gather(self, win_row_off: np.ndarray, ids: np.ndarray, labels: np.ndarray, decode: bool = True):
-        """Per-rank (win_row_off, ids, labels) on `dst` (raw byte tensors if decode=False), None elsewhere"""
+    def gather(self, win_row_off: np.ndarray, ids: np.ndarray, labels: np.ndarray, decode: bool = True, win_contig: Optional[np.ndarray] = None,
+               to_host: bool = False):
+        """Per-rank (win_row_off, ids, labels[, win_contig]) on `dst`, None elsewhere. decode=False: the raw payloads -- the collective's own
+        receive buffers, or, with to_host, uint8 arrays over ONE pinned host block the payloads have been copied into when the call
+        returns (what a single process ends its step with: the lists on the host)"""
         import torch.distributed as dist
         if self.active and self.copied is not None:
             self.copied.synchronize()      # the previous step's host-to-device copy has read the staging buffer
-        n = encode_sparse(win_row_off, ids, labels, self.np)
+        n = encode_sparse(win_row_off, ids, labels, self.np, win_contig)
         if not self.active:
             return [decode_sparse(self.np[:n])] if decode else [self.host]
         self.dev_buf.copy_(self.host, non_blocking=True)
@@ -287,6 +309,18 @@ class SparseLabelGatherer:
         dist.gather(self.dev_buf, self.out, dst=self.dst, group=self.group)
         if self.rank != self.dst:
             return None
-        if not decode:
-            return self.out
-        return [decode_sparse(o.cpu().numpy()) for o in self.out]
+        if to_host or decode:
+            import torch
+            if self.dev == "cuda":
+                if getattr(self, "host_out", None) is None:
+                    self.host_out = torch.empty((self.world, self.capacity), dtype=torch.uint8).pin_memory()
+                    self.landed = torch.cuda.Event()
+                for k, o in enumerate(self.out):
+                    self.host_out[k].copy_(o, non_blocking=True)
+                self.landed.record()
+                self.landed.synchronize()
+                arrs = [self.host_out[k].numpy() for k in range(self.world)]
+            else:
+                arrs = [o.numpy() for o in self.out]
+            return [decode_sparse(a) for a in arrs] if decode else arrs
+        return self.out

@@ -231,7 +231,13 @@ def compare_with_reference(snap: Dict, col_path: str, gro_path: Optional[str], e
         out["error_rate_identical"] = bool(got == want)
         if got != want:
             diffs.append(f"error rate: {got} here, {want} in the reference's file")
-    out["identical"] = bool(out["gro_identical"] is not False and out["col_snps_identical"] and out.get("error_rate_identical", True) and out["col_entries_identical"] is not False)
+    # `identical` covers what was compared, and says what that was: a part that was not compared (the .gro and the error rate of a sample of
+    # the job, the entries of a step that left them on the device) is named in identical_scope, never counted as equal
+    compared = [k for k in ("gro_identical", "col_snps_identical", "col_entries_identical", "error_rate_identical") if out.get(k) is not None]
+    out["identical"] = bool(compared and all(out[k] for k in compared))
+    out["identical_scope"] = "compared: " + ", ".join(k[:-len("_identical")] for k in compared) + \
+        ("; NOT compared: " + ", ".join(k[:-len("_identical")] for k in ("gro_identical", "col_snps_identical", "col_entries_identical", "error_rate_identical") if out.get(k) is None)
+         if len(compared) < 4 else "")
     if diffs:
         out["diffs"] = diffs[:max_diffs + 2]
     return out

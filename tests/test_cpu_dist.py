@@ -256,3 +256,40 @@ def test_sparse_digest_does_not_depend_on_how_the_windows_are_sharded():
     k = next(i for i, w in enumerate(changed) if len(w[0]))
     changed[k][1][0] += 1
     assert hdist.sparse_digest([payload(changed)]) != one
+
+
+def test_sparse_digest_with_contigs_notices_windows_that_changed_places():
+    """With the contig of every window in the payload (what bench.py gathers) the digest still does not depend on the sharding, survives the
+    gather's encoding, and two windows of different contigs that swap their contents change it (the plain sum of CRCs would not)"""
+    import numpy as np
+    from hairsplitter_amd import dist as hdist
+    rng = np.random.default_rng(5)
+    wins = []
+    for k in range(120):
+        n = int(rng.integers(1, 30))
+        wins.append((np.sort(rng.choice(300, size=n, replace=False)).astype(np.int32), rng.integers(-1, 5, size=n).astype(np.int32), k // 4))
+
+    def payload(ws):
+        off = np.zeros(len(ws) + 1, np.int64)
+        off[1:] = np.cumsum([len(w[0]) for w in ws])
+        return off, np.concatenate([w[0] for w in ws]), np.concatenate([w[1] for w in ws]), np.array([w[2] for w in ws], np.int32)
+
+    one = hdist.sparse_digest([payload(wins)])
+    order = rng.permutation(len(wins))
+    parts = [[wins[i] for i in order[k::2]] for k in range(2)]
+    assert hdist.sparse_digest([payload(p) for p in parts]) == one
+    enc = []
+    for p in parts:
+        off, ids, lab, wc = payload(p)
+        buf = np.zeros(hdist.sparse_payload_bytes(len(off) - 1, len(ids), with_contigs=True) + 64, np.uint8)
+        n = hdist.encode_sparse(off, ids, lab, buf, wc)
+        assert n == hdist.sparse_payload_bytes(len(off) - 1, len(ids), with_contigs=True)
+        dec = hdist.decode_sparse(buf[:n])
+        assert len(dec) == 4 and (dec[3] == wc).all()
+        enc.append(dec)
+    assert hdist.sparse_digest(enc) == one
+    swapped = list(wins)
+    a, b = 0, 117      # windows of contig 0 and contig 29
+    swapped[a], swapped[b] = (wins[b][0], wins[b][1], wins[a][2]), (wins[a][0], wins[a][1], wins[b][2])
+    assert hdist.sparse_digest([payload(swapped)]) != one
+    assert hdist.sparse_digest([payload(swapped)[:3]]) == hdist.sparse_digest([payload(wins)[:3]])      # (without the contigs the swap goes unnoticed)

@@ -21,6 +21,6 @@ for cfg, contigs, extra in JOBS:
     if not (p.get("checked") and p.get("identical") and p.get("kind", "reference") == "reference" and g):
         sys.stderr.write("%s: no reference verdict in this run: %r\n" % (cfg, p)); continue
     key = "%s:%d:%s" % (cfg, d["config"]["contigs"] if "contigs" in d["config"] else contigs, "default")
-    out[key] = {"windows": g["windows"], "entries": g["entries"], "sum_crc32": g["sum_crc32"],
+    out[key] = {"windows": g["windows"], "entries": g["entries"], "sum_crc32": g["sum_crc32"], "n_snps": g["n_snps"], "mean_distance_crc32": g["mean_distance_crc32"], "error_rate": g["error_rate"],
                 "verified": "bench.py --gpus 1 on this job, reference gate: " + p.get("against", "")[:160]}
 print(json.dumps(out, indent=1))
