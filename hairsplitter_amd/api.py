@@ -21,7 +21,7 @@ if os.environ.get("HS_LIB_AB"):      # (tools/gpu_ab_lib.sh: another build of th
 SYMBOLS = [
     "hs_cv_batch_set_ploidy", "hs_version", "hs_last_error", "hs_device_count", "hs_warmup", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
-    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_column_stats", "hs_gather_columns", "hs_tile_plan", "hs_column_stats_tiled", "hs_gather_columns_tiled", "hs_column_top3", "hs_pack_columns", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_partition_pair_distance", "hs_snp_planes", "hs_simdiff", "hs_read_graphs", "hs_chinese_whispers",
+    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_tile_plan", "hs_column_stats_tiled", "hs_cv_column_pass_taps", "hs_cv_taps_destroy", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_partition_pair_distance", "hs_snp_planes", "hs_simdiff", "hs_read_graphs",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_pipeline_thread_devices", "hs_cv_batch_device", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main", "hs_call_variants_epilogue",
     "hs_pipeline_run_fused", "hs_realign_paf", "hs_pipeline_set_option", "hs_pipeline_groups", "hs_pipeline_group_range", "hs_pipeline_group_cv", "hs_pipeline_sparse_labels", "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_kernel_stats_every", "hs_host_wait_stats", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
@@ -708,13 +708,15 @@ def tile_plan(flat: FlatBatch, device="cuda:0"):
 
 
 def column_stats(t, flat: FlatBatch, pile, min_second: int = 0, max_depth: int = 0, plan=None):
-    """K2; returns a numpy structured view: key u8[4], cnt u16[5], depth u16 per position (and, when min_second > 0,
-    the compact selection -- second count > min_second, or == min_second with no third allele -- as sorted global
-    positions + depths)."""
+    """K2 in its full-statistics form on the tile plan (hs_column_stats_tiled); returns a numpy structured view: key u8[4], cnt u16[5],
+    depth u16 per position (and, when min_second > 0, the compact selection -- second count > min_second, or == min_second with no
+    third allele -- as sorted global positions + depths)."""
     import torch
     require_gpu()
     total = int(flat.contig_off[-1])
     dev = pile.device
+    if plan is None:
+        plan = tile_plan(flat, dev)
     out = torch.zeros((max(total, 1), 16), dtype=torch.uint8, device=dev)
     if min_second > 0:
         cnt = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -723,11 +725,7 @@ def column_stats(t, flat: FlatBatch, pile, min_second: int = 0, max_depth: int =
         args = (C.c_int32(min_second), _p(cnt), _p(gpos), _p(dep), C.c_int32(total))
     else:
         args = (C.c_int32(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_int32(0))
-    if plan is not None:
-        _check(load().hs_column_stats_tiled(_p(pile), _p(plan["off"]), _p(plan["ent"]), C.c_int64(total), _p(out), *args, C.c_int32(max_depth), C.c_void_p(0)))
-    else:
-        _check(load().hs_column_stats(_p(pile), _p(t["pile_off"]), _p(t["rec_pos"]), _p(t["rec_qend"]), _p(t["contig_rec_off"]),
-                                      _p(t["contig_off"]), C.c_int32(flat.n_contigs), _p(out), *args, C.c_int32(max_depth), C.c_void_p(0)))
+    _check(load().hs_column_stats_tiled(_p(pile), _p(plan["off"]), _p(plan["ent"]), C.c_int64(total), _p(out), *args, C.c_int32(max_depth), C.c_void_p(0)))
     torch.cuda.synchronize()
     dt = np.dtype([("key", np.uint8, 4), ("cnt", np.uint16, 5), ("depth", np.uint16)])
     st = out[:total].cpu().numpy().view(dt).reshape(-1)
@@ -739,42 +737,48 @@ def column_stats(t, flat: FlatBatch, pile, min_second: int = 0, max_depth: int =
     return st
 
 
-def gather_columns(t, flat: FlatBatch, pile, sel_contig, sel_pos, depths, plan=None):
-    import torch
-    require_gpu()
-    dev = pile.device
-    sel_contig = _np(sel_contig, np.int32); sel_pos = _np(sel_pos, np.int32)
-    col_off = _np(np.concatenate(([0], np.cumsum(depths))), np.int64)
-    n = len(sel_pos)
-    tot = int(col_off[-1])
-    idx = torch.zeros(max(tot, 1), dtype=torch.int32, device=dev)
-    code = torch.zeros(max(tot, 1), dtype=torch.uint8, device=dev)
-    d_sc = torch.from_numpy(sel_contig).to(dev); d_sp = torch.from_numpy(sel_pos).to(dev); d_co = torch.from_numpy(col_off).to(dev)
-    if plan is not None:
-        _check(load().hs_gather_columns_tiled(_p(pile), _p(plan["off"]), _p(plan["ent"]), _p(plan["rec"]), _p(t["contig_off"]), _p(t["contig_rec_off"]),
-                                              _p(d_sc), _p(d_sp), _p(d_co), C.c_int32(n), _p(idx), _p(code), C.c_void_p(0)))
-    else:
-        _check(load().hs_gather_columns(_p(pile), _p(t["pile_off"]), _p(t["rec_pos"]), _p(t["rec_qend"]), _p(t["contig_rec_off"]),
-                                        _p(d_sc), _p(d_sp), _p(d_co), C.c_int32(n), _p(idx), _p(code), C.c_void_p(0)))
-    torch.cuda.synchronize()
-    return col_off, idx[:tot].cpu().numpy(), code[:tot].cpu().numpy()
+class _CandBits(C.Structure):
+    _fields_ = [("wlo", C.c_int32), ("n_words", C.c_uint16), ("n_slots", C.c_uint16), ("idx_min", C.c_int32), ("idx_max", C.c_int32), ("reach", C.c_int32),
+                ("n_entries", C.c_int32), ("word_off", C.c_int64)]
 
 
-def column_top3(col_off, col_code):
-    """K3b on host arrays (uploaded here): returns (c0, c1, c2, k0, k1, tie) per column"""
-    import torch
-    require_gpu()
-    dev = "cuda:0"
-    col_off = _np(col_off, np.int64); col_code = _np(col_code, np.uint8)
-    n = len(col_off) - 1
-    d_off = torch.from_numpy(col_off).to(dev)
-    d_code = torch.from_numpy(col_code if col_code.size else np.zeros(1, np.uint8)).to(dev)
-    out = torch.zeros((max(n, 1), 16), dtype=torch.uint8, device=dev)
-    _check(load().hs_column_top3(_p(d_off), _p(d_code), C.c_int32(n), _p(out), C.c_void_p(0)))
-    torch.cuda.synchronize()
-    raw = out[:n].cpu().numpy()
-    cnt = raw[:, :12].copy().view(np.int32).reshape(n, 3)
-    return cnt[:, 0], cnt[:, 1], cnt[:, 2], raw[:, 12], raw[:, 13], raw[:, 14]
+class _CvTaps(C.Structure):
+    _fields_ = [("n_contigs", C.c_int32), ("n_cols", C.c_int64), ("n_entries", C.c_int64), ("col_gpos", C.POINTER(C.c_int64)), ("col_rec", C.c_void_p),
+                ("col_off", C.POINTER(C.c_int64)), ("col_idx", C.POINTER(C.c_int32)), ("col_code", C.POINTER(C.c_uint8)), ("n_cand", C.c_int64),
+                ("cand_rec", C.c_void_p), ("cand_col", C.POINTER(C.c_int32)), ("cand_bits", C.POINTER(_CandBits)), ("cand_words", C.POINTER(C.c_uint64)),
+                ("n_cand_words", C.c_int64), ("contig_n_cand", C.POINTER(C.c_int32)), ("contig_mean_distance", C.POINTER(C.c_float))]
+
+
+COLREC_DTYPE = np.dtype([("pos", np.int32), ("contig", np.int32), ("c0", np.uint16), ("c1", np.uint16), ("k0", np.uint8), ("k1", np.uint8), ("flags", np.uint8), ("c2_zero", np.uint8)])
+CANDBITS_DTYPE = np.dtype([("wlo", np.int32), ("n_words", np.uint16), ("n_slots", np.uint16), ("idx_min", np.int32), ("idx_max", np.int32), ("reach", np.int32),
+                           ("n_entries", np.int32), ("word_off", np.int64)])
+
+
+def cv_column_pass_taps(batch: "CvBatch", c0: int, c1: int, automatic_snp_threshold: float = 0.33) -> Dict:
+    """The column pass of stage 3 as the pipeline queues it (hs_cv_column_pass_taps), with what its kernels left on the device: the extracted
+    columns (positions, records, CSR), the packed candidates, their bit sets, the contigs' candidate counts and mean distances."""
+    lib = load()
+    lib.hs_cv_column_pass_taps.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.POINTER(C.POINTER(_CvTaps))]
+    lib.hs_cv_taps_destroy.argtypes = [C.POINTER(_CvTaps)]
+    lib.hs_cv_taps_destroy.restype = None
+    tp = C.POINTER(_CvTaps)()
+    _check(lib.hs_cv_column_pass_taps(batch.handle, C.c_int32(c0), C.c_int32(c1), C.c_float(automatic_snp_threshold), C.byref(tp)))
+    t = tp.contents
+    n, e, nc, Cn = int(t.n_cols), int(t.n_entries), int(t.n_cand), int(t.n_contigs)
+
+    def arr(ptr, count, dtype):
+        if count == 0:
+            return np.zeros(0, dtype)
+        return np.frombuffer(C.string_at(ptr, count * np.dtype(dtype).itemsize), dtype=dtype).copy()
+    out = {
+        "col_gpos": arr(t.col_gpos, n, np.int64), "col_rec": arr(t.col_rec, n, COLREC_DTYPE), "col_off": arr(t.col_off, n + 1, np.int64),
+        "col_idx": arr(t.col_idx, e, np.int32), "col_code": arr(t.col_code, e, np.uint8),
+        "cand_rec": arr(t.cand_rec, nc, COLREC_DTYPE), "cand_col": arr(t.cand_col, nc, np.int32), "cand_bits": arr(t.cand_bits, nc, CANDBITS_DTYPE),
+        "cand_words": arr(t.cand_words, int(t.n_cand_words), np.uint64),
+        "contig_n_cand": arr(t.contig_n_cand, Cn, np.int32), "contig_mean_distance": arr(t.contig_mean_distance, Cn, np.float32),
+    }
+    lib.hs_cv_taps_destroy(tp)
+    return out
 
 
 def exclusive_scan(values):
@@ -787,28 +791,6 @@ def exclusive_scan(values):
     _check(load().hs_exclusive_scan_i32(_p(d_in), C.c_int32(len(v)), _p(d_out), C.c_void_p(0)))
     torch.cuda.synchronize()
     return d_out.cpu().numpy()
-
-
-def pack_columns(col_off, col_idx, col_code, ids):
-    """K3c on host arrays (uploaded here): the listed columns packed back to back; returns (packed_off, idx, code)"""
-    import torch
-    require_gpu()
-    dev = "cuda:0"
-    col_off = _np(col_off, np.int64); col_idx = _np(col_idx, np.int32); col_code = _np(col_code, np.uint8); ids = _np(ids, np.int32)
-    depth = (col_off[1:] - col_off[:-1])[ids] if len(ids) else np.zeros(0, np.int64)
-    packed_off = np.zeros(len(ids) + 1, np.int64)
-    np.cumsum(depth, out=packed_off[1:])
-    total = int(packed_off[-1])
-    d_off = torch.from_numpy(col_off).to(dev)
-    d_idx = torch.from_numpy(col_idx if col_idx.size else np.zeros(1, np.int32)).to(dev)
-    d_code = torch.from_numpy(col_code if col_code.size else np.zeros(1, np.uint8)).to(dev)
-    d_ids = torch.from_numpy(ids if ids.size else np.zeros(1, np.int32)).to(dev)
-    d_po = torch.from_numpy(packed_off).to(dev)
-    o_idx = torch.full((max(total, 1),), -1, dtype=torch.int32, device=dev)
-    o_code = torch.zeros(max(total, 1), dtype=torch.uint8, device=dev)
-    _check(load().hs_pack_columns(_p(d_off), _p(d_idx), _p(d_code), _p(d_ids), _p(d_po), C.c_int32(len(ids)), _p(o_idx), _p(o_code), C.c_void_p(0)))
-    torch.cuda.synchronize()
-    return packed_off, o_idx[:total].cpu().numpy(), o_code[:total].cpu().numpy()
 
 
 def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1, col_c1, col_is_cand, part_off, part_state_off, part_state, n_reads):
@@ -906,31 +888,6 @@ def read_graphs(sim_list, diff_list, windows, error_rate):
     for w in range(len(windows)):
         out.append({int(ids[r]): nbr[noff[r]:noff[r + 1]].tolist() for r in range(int(moff[w]), int(moff[w + 1]))})
     return out, int(n_host.value)
-
-
-def chinese_whispers(adj_lists: List[List[int]], perm: Sequence[int], mask: Sequence[int], inits: np.ndarray):
-    """K7 for one graph and several initial labelings (inits: [n_inst, N]); returns (labels, sweeps)."""
-    import torch
-    require_gpu()
-    dev = "cuda:0"
-    N = len(adj_lists)
-    off = np.zeros(N + 1, np.int32)
-    off[1:] = np.cumsum([len(a) for a in adj_lists])
-    adj = _np(np.concatenate([np.asarray(a, np.int32) for a in adj_lists]) if off[-1] else np.zeros(0), np.int32)
-    n_inst = inits.shape[0]
-    T = lambda a, dt: torch.from_numpy(_np(a, dt)).to(dev)
-    d_off, d_adj = T(off, np.int32), T(adj if len(adj) else np.zeros(1), np.int32)
-    d_gob, d_gab = T([0], np.int64), T([0], np.int64)
-    d_gn, d_perm, d_pb = T([N], np.int32), T(perm, np.int32), T([0], np.int64)
-    d_mask = T(mask, np.uint8)
-    d_ig = T(np.zeros(n_inst), np.int32)
-    d_lb = T(np.arange(n_inst) * N, np.int64)
-    d_lab = T(inits.reshape(-1), np.int32)
-    d_sw = torch.zeros(n_inst, dtype=torch.int32, device=dev)
-    _check(load().hs_chinese_whispers(_p(d_off), _p(d_adj), _p(d_gob), _p(d_gab), _p(d_gn), _p(d_perm), _p(d_pb), _p(d_mask),
-                                      _p(d_ig), _p(d_lb), C.c_int32(n_inst), _p(d_lab), _p(d_sw), C.c_void_p(0)))
-    torch.cuda.synchronize()
-    return d_lab.cpu().numpy().reshape(n_inst, N), d_sw.cpu().numpy()
 
 
 def edit_distance(queries: Sequence[np.ndarray], targets: Sequence[np.ndarray], mode: str = "NW"):

@@ -283,19 +283,7 @@ static __device__ __forceinline__ void pileup_task_per_event(
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K1, packed form: the same walk (generate_msa, call_variants.cpp:189-354) with FOUR consecutive alignment events per lane,
-// 256 per step, for records that are one uninterrupted run of M / I / D events (every record without a clip or skip
-// between aligned bases; K0 flags the others, k_pileup_flagged_records does those per event). In such a run the read
-// cursor advances on every event that is not a deletion and the reference cursor on every event that is not an insertion,
-// so no owner lookup is needed: the ops of the chunk mark the I and D events in a byte map (one byte per event), and
-//   t(e) = t(window) + (e - window) - #D before e,   q(e) = q(window) + (e - window) - #I before e
-// come from one packed wave prefix sum of the per-lane counts plus byte-wise prefixes inside the lane. Lanes whose four
-// events hold no deletion (no insertion) read their four read (reference) bytes with one unaligned dword load; the 3-mer
-// codes of four events are computed with packed byte arithmetic (all intermediate bytes stay below 256) and, when the
-// four events are consecutive columns, written with one dword store. Mismatch / length counters are byte sums per lane,
-// reduced once per task.
-// ------------------------------------------------------------------------------------------------
+// unaligned vector types and packed-byte helpers shared by K1 (run form) and K2
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
@@ -307,248 +295,9 @@ static __device__ __forceinline__ uint32_t byte_sum(uint32_t x, uint32_t acc) { 
 // bytes 0 .. n-1 set (n in 0..4)
 static __device__ __forceinline__ uint32_t low_bytes(int n) { return n >= 4 ? 0xffffffffu : ((1u << (8 * n)) - 1u); }
 
-__global__ __launch_bounds__(256) void k_pileup_packed(
-    const uint8_t* __restrict__ contig_seq, const int64_t* __restrict__ contig_off,
-    const uint8_t* __restrict__ read_seq, const int64_t* __restrict__ read_off,
-    const int32_t* __restrict__ rec_read, const int32_t* __restrict__ rec_contig,
-    const int32_t* __restrict__ rec_pos, const uint8_t* __restrict__ rec_strand,
-    const int64_t* __restrict__ rec_cig_off, const uint32_t* __restrict__ cigar,
-    const int64_t* __restrict__ pile_off, const int64_t* __restrict__ rec_chunk_off,
-    const int32_t* __restrict__ chunk_start, const int32_t* __restrict__ task_rec, const int32_t* __restrict__ task_ev0,
-    int n_tasks, int ev_per_task, uint8_t* __restrict__ pile, int32_t* __restrict__ rec_stats) {
-#ifndef HS_K1_WINDOWS
-#define HS_K1_WINDOWS 2
-#endif
-    constexpr int NW = HS_K1_WINDOWS;
-    __shared__ uint32_t s_type[4][64 * NW];   // per wave: 256 x NW event types (0 = M, 1 = I, 2 = D)
-    // v_perm selectors that pack the bytes of a lane's WRITTEN events (bit b of the index: event b writes a column) to the low end
-    __shared__ uint32_t s_squeeze[16];
-    if (threadIdx.x < 16) {
-        uint32_t sel = 0x0c0c0c0cu; int j = 0;
-        for (int b = 0; b < 4; ++b) if ((threadIdx.x >> b) & 1u) { sel = (sel & ~(0xffu << (8 * j))) | ((uint32_t)b << (8 * j)); ++j; }
-        s_squeeze[threadIdx.x] = sel;
-    }
-    __syncthreads();
-    const int lane = lane_id();
-    const int wv = wave_id();
-    const int task = (int)blockIdx.x * 4 + wv;
-    if (task >= n_tasks) return;   // wave-uniform
-    const int r = task_rec[task];
-    const int32_t* __restrict__ cs = chunk_start + 4 * rec_chunk_off[r];
-    if ((cs[3] & 1) != 0) return;  // not one run of events: left to k_pileup_flagged_records
-    const int e0 = task_ev0[task];
-    const int e1 = e0 + ev_per_task;
-    const int e_first = e0 >= 2 ? e0 - 2 : 0;
-
-    const int ctg = rec_contig[r];
-    const int64_t coff = contig_off[ctg];
-    const int L = (int)(contig_off[ctg + 1] - coff);
-    const int rd = rec_read[r];
-    const int64_t roff = read_off[rd];
-    const int rlen = (int)(read_off[rd + 1] - roff);
-    const int pos = rec_pos[r];
-    const bool fwd = rec_strand[r] != 0;
-    const int64_t cig0 = rec_cig_off[r], cig1 = rec_cig_off[r + 1];
-    const int n_chunks = (int)((cig1 - cig0 + 63) >> 6);
-    uint8_t* __restrict__ out = pile + pile_off[r];
-    const uint8_t* __restrict__ ctgp = contig_seq + coff;
-    const uint8_t* __restrict__ rdp = read_seq + roff;
-    // reverse-strand records read the reverse complement: the four bytes of a load are mirrored and complemented
-    const uint32_t strand_sel = fwd ? 0x03020100u : 0x00010203u, strand_xor = fwd ? 0u : 0x03030303u;
-    uint8_t* const types = reinterpret_cast<uint8_t*>(&s_type[wv][0]);
-
-    int klo = 0, khi = n_chunks - 1;
-    while (klo < khi) { const int mid = (klo + khi + 1) >> 1; if (cs[4 * mid] <= e_first) klo = mid; else khi = mid - 1; }
-
-    int p1 = 2, p2 = 1;                  // previous char 'G', the one before 'C' (call_variants.cpp:212-214 after one shift)
-    uint32_t nerr_l = 0, nlen_l = 0;     // per-lane counters, reduced at the end
-    // Two 64-op chunks of K0's table per step (ops A = lane, B = lane + 64): a chunk of ONT ops is only ~2.5 windows of events,
-    // so pairing them halves the per-chunk prologue and the half-empty window at the end of each
-    for (int k = klo & ~1; k < n_chunks; k += 2) {
-        const int ev_base = cs[4 * k + 0];
-        if (ev_base >= e1) break;
-        const int t_cur = cs[4 * k + 1], q_cur = cs[4 * k + 2];
-        const int64_t oiA = cig0 + ((int64_t)k << 6) + lane, oiB = oiA + 64;
-        const bool inA = oiA < cig1, inB = oiB < cig1;
-        const uint32_t opA = inA ? cigar[oiA] : 0xFu, opB = inB ? cigar[oiB] : 0xFu;
-        const int codeA = inA ? (int)(opA & 15u) : 15, codeB = inB ? (int)(opB & 15u) : 15;
-        const OpAdv aA = op_advances(opA, inA), aB = op_advances(opB, inB);
-        const int evA_inc = wave_scan_incl(aA.ev);
-        const int evB_inc = wave_scan_incl(aB.ev) + __builtin_amdgcn_readlane(evA_inc, 63);
-        const int evA_ex = evA_inc - aA.ev, evB_ex = evB_inc - aB.ev;
-        const int chunk_ev = __builtin_amdgcn_readlane(evB_inc, 63);
-        const unsigned long long nzA = __ballot(aA.ev > 0), nzB = __ballot(aB.ev > 0);
-        if ((nzA | nzB) == 0ull) continue;                                    // clips only
-        // cursors at the first event of the step: the table's, plus what ops without events in front of the first
-        // event-owning op consume (the leading clips of a record; nothing anywhere else)
-        const int leadA = nzA ? __builtin_ctzll(nzA) : 64, leadB = nzA ? 0 : __builtin_ctzll(nzB);
-        int t0 = t_cur, q0 = q_cur;
-        if (leadA > 0 || leadB > 0) {
-            t0 += wave_sum_i32((lane < leadA ? aA.rd : 0) + (lane < leadB ? aB.rd : 0));
-            q0 += wave_sum_i32((lane < leadA ? aA.rf : 0) + (lane < leadB ? aB.rf : 0));
-        }
-        const int typeA = codeA == 1 ? 1 : (codeA == 2 ? 2 : 0), typeB = codeB == 1 ? 1 : (codeB == 2 ? 2 : 0);
-        const bool marksA = aA.ev > 0 && typeA != 0, marksB = aB.ev > 0 && typeB != 0;   // the op's events are I or D
-        const int lo_el = e_first > ev_base ? e_first - ev_base : 0;
-        const int hi_el = (e1 - ev_base) < chunk_ev ? (e1 - ev_base) : chunk_ev;
-        const int lo_commit = e0 - ev_base;                                   // events before it only warm the 3-mer context up
-        int tW = t0 + lo_el, qW = q0 + lo_el;                                 // cursors at the first event of the window
-        if (lo_el > 0) {                                                      // the task starts inside the step
-            int bA = lo_el - evA_ex; bA = bA < 0 ? 0 : (bA > aA.ev ? aA.ev : bA);
-            int bB = lo_el - evB_ex; bB = bB < 0 ? 0 : (bB > aB.ev ? aB.ev : bB);
-            tW -= wave_sum_i32((marksA && typeA == 2 ? bA : 0) + (marksB && typeB == 2 ? bB : 0));
-            qW -= wave_sum_i32((marksA && typeA == 1 ? bA : 0) + (marksB && typeB == 1 ? bB : 0));
-        }
-        // HS_K1_WINDOWS windows of 256 events per iteration (measured: 1 -> 1.76 ms, 2 -> 1.61, 3 -> 1.63, 4 -> 1.62, 8 -> 3.0 per
-        // 1.28 G events): one type map for all of them, and the loads of every window issued
-        // before the first one is consumed (the packed form is short on instructions, so memory latency is what is left to hide)
-        for (int eb = lo_el; eb < hi_el; eb += 256 * NW) {
-            wave_lds_sync();                                                  // the previous iteration's readers are done
-#pragma unroll
-            for (int u = 0; u < NW; ++u) s_type[wv][u * 64 + lane] = 0u;
-            wave_lds_sync();
-            {   // the I / D ops mark their events of this iteration
-                int a0 = eb - evA_ex; a0 = a0 < 0 ? 0 : a0;
-                int a1 = eb + 256 * NW - evA_ex; a1 = a1 > aA.ev ? aA.ev : a1;
-                if (!marksA) a1 = a0;
-                int b0 = eb - evB_ex; b0 = b0 < 0 ? 0 : b0;
-                int b1 = eb + 256 * NW - evB_ex; b1 = b1 > aB.ev ? aB.ev : b1;
-                if (!marksB) b1 = b0;
-                for (; __ballot(a0 < a1 || b0 < b1) != 0ull; ++a0, ++b0) {
-                    if (a0 < a1) types[evA_ex + a0 - eb] = (uint8_t)typeA;
-                    if (b0 < b1) types[evB_ex + b0 - eb] = (uint8_t)typeB;
-                }
-            }
-            wave_lds_sync();
-            uint32_t isI_[NW], isD_[NW], ipre_[NW], rb_[NW], ref_[NW], inl_[NW], commit_[NW];
-            int qL_[NW], nI_[NW];
-#pragma unroll
-            for (int u = 0; u < NW; ++u) {
-                const int w0 = eb + 256 * u;
-                if (w0 >= hi_el) break;                                       // wave-uniform: a chunk is ~2.5 windows of events
-                const uint32_t f = s_type[wv][u * 64 + lane];
-                const uint32_t isI = f & 0x01010101u, isD = (f >> 1) & 0x01010101u;
-                const int nI = (int)byte_sum(isI, 0u), nD = (int)byte_sum(isD, 0u);
-                const int cnt = nD | (nI << 16);
-                const int cnt_incl = wave_scan_incl(cnt);
-                const int cnt_tot = __builtin_amdgcn_readlane(cnt_incl, 63);
-                const int cnt_ex = cnt_incl - cnt;
-                const int e_l = w0 + 4 * lane;                                // first event of the lane (relative to the chunk)
-                const int tL = tW + 4 * lane - (cnt_ex & 0xffff);
-                const int qL = qW + 4 * lane - (cnt_ex >> 16);
-                tW += 256 - (cnt_tot & 0xffff); qW += 256 - (cnt_tot >> 16);  // cursors at the next window
-                // byte b = number of D (I) among the lane's events before b (shift-adds: a 32-bit multiply is quarter rate)
-                const uint32_t d01 = opaque(isD + (isD << 8)), i01 = opaque(isI + (isI << 8));
-                const uint32_t dpre = opaque(d01 + (isD << 16)) << 8, ipre = opaque(i01 + (isI << 16)) << 8;
-                if (w0 + 256 <= hi_el && w0 >= lo_commit) commit_[u] = 0xffffffffu;   // wave-uniform: every event of the window is committed
-                else {
-                    int nv = hi_el - e_l; nv = nv < 0 ? 0 : (nv > 4 ? 4 : nv);     // events of the lane inside the chunk / task
-                    int ns = lo_commit - e_l; ns = ns < 0 ? 0 : (ns > 4 ? 4 : ns); // leading events that only warm the context up
-                    commit_[u] = low_bytes(nv) & ~low_bytes(ns);
-                }
-                // ---- the four read characters: the lane's non-D events consume consecutive read bases from tL on, so one
-                // dword holds them all; event b takes byte (b - #D before b) of it (+ d when the load was moved back to stay
-                // inside the read). Reverse strand: the dword is mirrored and complemented first. Unconditional: the address
-                // is clamped into the read, lanes without events read something they never use ----
-                uint32_t rb;
-                {
-                    int A, d;     // first byte of the dword in the stored read; how far the wanted bytes sit from byte 0
-                    if (fwd) { A = tL < rlen - 4 ? tL : rlen - 4; A = A < 0 ? 0 : A; d = tL - A; }
-                    else { A = rlen - 4 - tL; d = A < 0 ? -A : 0; A = A < 0 ? 0 : (A > rlen - 4 ? (rlen > 4 ? rlen - 4 : 0) : A); }
-                    const uint32_t w = __builtin_amdgcn_perm(0u, *reinterpret_cast<const u32_unaligned*>(rdp + A), strand_sel) ^ strand_xor;
-                    rb = __builtin_amdgcn_perm(w, w, (0x03020100u - dpre) + __builtin_amdgcn_perm(0u, (uint32_t)d, 0u)) & 0x03030303u;
-                }
-                // ---- the four reference characters (consecutive from qL on for the non-I events) and "on the contig" ----
-                uint32_t ref4, in_l = 0xffffffffu;
-                {
-                    const uint32_t off4 = 0x03020100u - ipre;                  // byte b = q of event b minus qL
-                    int A = qL < L - 4 ? qL : L - 4;
-                    A = A < 0 ? 0 : A;                                         // (contigs shorter than 4 bases: bytes past the end are masked by in_l)
-                    const uint32_t w = *reinterpret_cast<const u32_unaligned*>(ctgp + A);
-                    ref4 = __builtin_amdgcn_perm(w, w, off4 + __builtin_amdgcn_perm(0u, (uint32_t)((qL - A) & 3), 0u)) & 0x03030303u;
-                    const int room = L - qL;                                   // events whose q offset is below it are on the contig
-                    if (__ballot(room < 4) != 0ull) {                          // wave-uniform: only where a record runs to the contig end
-                        in_l = 0u;
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) in_l |= ((int)((off4 >> (8 * b)) & 0xffu) < room ? 0xffu : 0u) << (8 * b);
-                    }
-                }
-                isI_[u] = isI; isD_[u] = isD; ipre_[u] = ipre; rb_[u] = rb; ref_[u] = ref4; inl_[u] = in_l; qL_[u] = qL; nI_[u] = nI;
-            }
-#pragma unroll
-            for (int u = 0; u < NW; ++u) {
-                const int w0 = eb + 256 * u;
-                if (w0 >= hi_el) break;                                       // wave-uniform
-                const uint32_t isI = isI_[u], isD = isD_[u];
-                const uint32_t c4 = (rb_[u] & ~bytes_ff(isD)) | (isD << 2);    // 4 == '-'
-                const uint32_t act = commit_[u] & inl_[u];                     // committed and on the contig (call_variants.cpp:217)
-                // ---- 3-mer codes: 33 + 25 c + c(-1) + 5 c(-2), four at a time ----
-                const uint32_t cprev = (uint32_t)wave_shr1((int)c4, (p1 << 24) | (p2 << 16));
-                const uint32_t cu1 = __builtin_amdgcn_alignbyte(c4, cprev, 3); // characters of the previous event
-                const uint32_t cu2 = __builtin_amdgcn_alignbyte(c4, cprev, 2); // and of the one before
-                const uint32_t code4 = 0x21212121u + opaque((c4 << 4) + c4) + opaque(c4 << 3) + cu1 + opaque((cu2 << 2) + cu2);
-                // ---- counters: M: call_variants.cpp:238-240,254-256; D: :287-290; I: :337 ----
-                const uint32_t x = c4 ^ ref_[u];
-                const uint32_t neq = (x | (x >> 1) | (x >> 2)) & 0x01010101u;
-                const uint32_t act1 = act & 0x01010101u;
-                nlen_l = byte_sum(act1, nlen_l);
-                nerr_l = byte_sum(act1 & (isI | isD | neq), nerr_l);
-                // ---- pileup bytes of the M and D events. The events of a lane that write a column -- committed, on the contig, not an
-                // insertion -- are a run of the lane's events minus its insertions, so their columns are consecutive from the column of
-                // the first of them: the code bytes of the written events are packed to the low end with ONE v_perm (selector from a
-                // 16-entry table in LDS, indexed by the 4-bit "writes" mask) and leave as one dword / short / byte store. No lane takes
-                // another path (round 4: the byte-by-byte form ran for the whole wavefront whenever one of its lanes had two
-                // insertions, started a task or ended a chunk -- about every second window) ----
-                const uint32_t wr1 = act & ~bytes_ff(isI) & 0x01010101u;
-                const uint32_t m4 = (wr1 | (wr1 >> 7) | (wr1 >> 14) | (wr1 >> 21)) & 15u;
-                if (m4) {
-                    const uint32_t comp = __builtin_amdgcn_perm(0u, code4, s_squeeze[m4]);
-                    const int n = __builtin_popcount(m4);
-                    const int first = __builtin_ctz(m4);
-                    uint8_t* const o = out + (unsigned)(qL_[u] + first - (int)((ipre_[u] >> (8 * first)) & 0xffu) - pos);
-                    if (n == 4) *reinterpret_cast<u32_unaligned*>(o) = comp;
-                    else {
-                        if (n & 2) *reinterpret_cast<u16_unaligned*>(o) = (uint16_t)comp;
-                        if (n & 1) o[n & 2] = (uint8_t)(comp >> (8 * (n & 2)));
-                    }
-                }
-                // ---- carry: the last two characters of the window ----
-                const int nw = (hi_el - w0) < 256 ? (hi_el - w0) : 256;
-                const int last = (int)((uint32_t)__builtin_amdgcn_readlane((int)c4, (nw - 1) >> 2) >> (8 * ((nw - 1) & 3))) & 0xff;
-                const int last2 = nw >= 2 ? (int)((uint32_t)__builtin_amdgcn_readlane((int)c4, (nw - 2) >> 2) >> (8 * ((nw - 2) & 3))) & 0xff : p1;
-                p2 = last2; p1 = last;
-            }
-        }
-    }
-    const int nlen = wave_sum_i32((int)nlen_l), nerr = wave_sum_i32((int)nerr_l);
-    if (lane == 0 && nlen > 0) {
-        atomicAdd(&rec_stats[4 * r + 1], nerr);
-        atomicAdd(&rec_stats[4 * r + 2], nlen);
-    }
-}
-
 #include "hs_kernels_runs.inc"      // K1, run form (round 5): lanes = 16-event pieces of one CIGAR op
 
-// per-event form over a task list (every record; used when the packed form is switched off, and by the kernel entry of the C ABI)
-__global__ __launch_bounds__(256) void k_pileup(
-    const uint8_t* __restrict__ contig_seq, const int64_t* __restrict__ contig_off,
-    const uint8_t* __restrict__ read_seq, const int64_t* __restrict__ read_off,
-    const int32_t* __restrict__ rec_read, const int32_t* __restrict__ rec_contig,
-    const int32_t* __restrict__ rec_pos, const uint8_t* __restrict__ rec_strand,
-    const int64_t* __restrict__ rec_cig_off, const uint32_t* __restrict__ cigar,
-    const int64_t* __restrict__ pile_off, const int64_t* __restrict__ rec_chunk_off,
-    const int32_t* __restrict__ chunk_start, const int32_t* __restrict__ task_rec, const int32_t* __restrict__ task_ev0,
-    int n_tasks, int ev_per_task, uint8_t* __restrict__ pile, int32_t* __restrict__ rec_stats) {
-    __shared__ PileupLds lds;
-    const int lane = lane_id();
-    const int wv = wave_id();
-    const int task = (int)blockIdx.x * 4 + wv;
-    if (task >= n_tasks) return;   // wave-uniform
-    pileup_task_per_event(lds, lane, wv, task_rec[task], task_ev0[task], ev_per_task, contig_seq, contig_off, read_seq, read_off, rec_read, rec_contig,
-                          rec_pos, rec_strand, rec_cig_off, cigar, pile_off, rec_chunk_off, chunk_start, pile, rec_stats);
-}
-
-// the records k_pileup_packed leaves out (K0 flagged them: a clip or a skip between aligned bases), in the per-event form.
+// the records k_pileup_runs leaves out (K0 flagged them: a clip or a skip between aligned bases), in the per-event form.
 // A small persistent grid: every wave checks 64 records per step and walks the tasks of the flagged ones.
 __global__ __launch_bounds__(256) void k_pileup_flagged_records(
     const uint8_t* __restrict__ contig_seq, const int64_t* __restrict__ contig_off,
@@ -713,103 +462,6 @@ __global__ __launch_bounds__(256) void k_selection_compact(const int32_t* __rest
     }
 }
 
-template <int CB, bool FULL>
-__global__ __launch_bounds__(256) void k_column_stats(
-    const uint8_t* __restrict__ pile, const int64_t* __restrict__ pile_off,
-    const int32_t* __restrict__ rec_pos, const int32_t* __restrict__ rec_qend,
-    const int32_t* __restrict__ contig_rec_off, const int64_t* __restrict__ contig_off,
-    int n_contigs, hs_colstat_dev* __restrict__ stats, int min_second, int32_t* __restrict__ sel_count,
-    int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int sel_cap) {
-    constexpr int PER_WORD = 4 / CB;
-    constexpr int NWORDS = (HS_NBINS + PER_WORD - 1) / PER_WORD;
-    __shared__ uint32_t hw[NWORDS * 256];
-    __shared__ int4 s_rec[HS_LIST_CAP];   // records overlapping the tile: {first position, end position, pileup offset of position 0 (lo, hi)}
-    __shared__ int s_n;
-    const int tid = (int)threadIdx.x;
-    const int lane = tid & 63;
-    const int64_t total = contig_off[n_contigs];
-    const int64_t g0 = (int64_t)blockIdx.x * 256;
-    const int64_t g = g0 + tid;
-#pragma unroll
-    for (int w = 0; w < NWORDS; ++w) hw[w * 256 + tid] = 0u;
-    // one LDS add per (position, record): the counter of `code` lives in byte (or half) code % PER_WORD of the lane's word
-    // code / PER_WORD; lanes that are not covered add zero to word 0 (no divergence, no read-modify-write sequence)
-    auto bump = [&](unsigned code, bool valid) {
-        const unsigned cc = valid ? code : 0u;
-        const unsigned inc = valid ? (1u << ((cc & (PER_WORD - 1)) * (8 * CB))) : 0u;
-        __hip_atomic_fetch_add(&hw[(cc / PER_WORD) * 256 + tid], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    int c_first;
-    {
-        int lo = 0, hi = n_contigs - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (contig_off[mid] <= g0) lo = mid; else hi = mid - 1; }
-        c_first = lo;
-    }
-    const int64_t g_last = (g0 + 256 - 1 < total - 1) ? g0 + 256 - 1 : total - 1;
-    for (int c = c_first; c < n_contigs && contig_off[c] <= g_last; ++c) {
-        const int64_t cs = contig_off[c], ce = contig_off[c + 1];
-        if (ce <= g0) continue;
-        const bool mine = g >= cs && g < ce;
-        const int p = (int)(g - cs);
-        const int tile_lo = (int)((g0 > cs ? g0 : cs) - cs);
-        const int tile_hi = (int)(((g_last + 1) < ce ? (g_last + 1) : ce) - cs);   // exclusive
-        const int r0 = contig_rec_off[c], r1 = contig_rec_off[c + 1];
-        for (int rb = r0; rb < r1; rb += HS_LIST_CAP) {
-            const int rb_end = (rb + HS_LIST_CAP) < r1 ? (rb + HS_LIST_CAP) : r1;
-            __syncthreads();
-            if (tid == 0) s_n = 0;
-            __syncthreads();
-            for (int nb = rb; nb < rb_end; nb += 256) {
-                const int n = nb + tid;
-                int ps = 0, qe = 0;
-                bool ov = false;
-                if (n < rb_end) { ps = rec_pos[n]; qe = rec_qend[n]; ov = qe > tile_lo && ps < tile_hi; }
-                const unsigned long long m = __ballot(ov);
-                int base = 0;
-                if (lane == 0 && m) base = atomicAdd(&s_n, __popcll(m));
-                base = __shfl(base, 0, 64);
-                if (ov) {
-                    const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-                    const int64_t po = pile_off[n] - ps;
-                    s_rec[slot] = make_int4(ps, qe, (int)(uint32_t)(po & 0xffffffffll), (int)(po >> 32));
-                }
-            }
-            __syncthreads();
-            const int cnt = __builtin_amdgcn_readfirstlane(s_n);
-            // A record is wave-uniform. Lane j of a wave keeps record i0 + j of the list in registers; the fields of the record
-            // being processed come out with v_readlane (no LDS round trip, no wait), so a lane only pays a range compare, a
-            // select and a byte load with scalar base + 32-bit lane offset. Eight records per step, every load unconditional
-            // (lanes outside the record read its first byte and add zero), so that the eight loads are in flight together.
-            for (int i0 = 0; i0 < cnt; i0 += 64) {
-                const int nrec = (cnt - i0) < 64 ? (cnt - i0) : 64;
-                const int4 held = s_rec[i0 + (lane < nrec ? lane : nrec - 1)];
-                for (int i = 0; i < nrec; i += 8) {
-                    unsigned code[8]; bool in_[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int j = (i + u) < nrec ? (i + u) : (nrec - 1);
-                        const int ps = __builtin_amdgcn_readlane(held.x, j), qe = __builtin_amdgcn_readlane(held.y, j);
-                        const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane(held.z, j), phi = (uint32_t)__builtin_amdgcn_readlane(held.w, j);
-                        const uint8_t* __restrict__ base = pile + (int64_t)(((uint64_t)phi << 32) | plo);   // pileup byte of position 0
-                        const bool in = mine && (i + u) < nrec && (unsigned)(p - ps) < (unsigned)(qe - ps);
-                        const unsigned off = (unsigned)(in ? p : ps);
-                        code[u] = (unsigned)base[off] - 33u;
-                        in_[u] = in;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) bump(code[u], in_[u] && code[u] < (unsigned)HS_NBINS);
-                }
-            }
-        }
-    }
-    column_stats_tail<CB, FULL>(hw, tid, lane, g, total, stats, min_second, sel_count, sel_gpos, sel_depth, sel_cap);
-}
-
-// K2 with a tile plan (hs_tile_plan): the records overlapping each 256-position tile are listed by the host once per batch
-// ({first lane, length, pileup address of lane 0} per record and tile), so a wavefront goes straight from one coalesced 16-B
-// load per lane to the pileup bytes: no list compaction, no workgroup barrier, the four waves of a workgroup are independent.
-// PAD: the pileup buffer has 256 bytes before and after it (the batch's own: hs_cv_batch), so every lane loads the byte of ITS
-// position whether the record covers it or not -- one address for all records (the tile's base + the lane) instead of a select.
 template <int CB, bool FULL, bool PAD>
 __global__ __launch_bounds__(256) void k_column_stats_tiled(
     const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, int64_t total,
@@ -1103,45 +755,6 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
     int32_t* __restrict__ sel_count, int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int64_t tile0, int64_t g_lo, int64_t g_hi,
     int32_t* __restrict__ sel_ent, uint2* __restrict__ sel_info) {
     column_stats_tiled_dw_body<true>(pile, tile_off, tile_ent, total, min_second, sel_count, sel_gpos, sel_depth, tile0, g_lo, g_hi, sel_ent, sel_info);
-}
-// (the selection alone: HS_K2_PLAIN, and where the leading codes are not wanted)
-__global__ __launch_bounds__(256) void k_column_stats_tiled_dw_plain(
-    const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent, int64_t total, int min_second,
-    int32_t* __restrict__ sel_count, int64_t* __restrict__ sel_gpos, int32_t* __restrict__ sel_depth, int64_t tile0, int64_t g_lo, int64_t g_hi,
-    int32_t* __restrict__ sel_ent) {
-    column_stats_tiled_dw_body<false>(pile, tile_off, tile_ent, total, min_second, sel_count, sel_gpos, sel_depth, tile0, g_lo, g_hi, sel_ent, nullptr);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3 column extraction: builds the reference's Column (Partition.h:8-14) for selected positions.
-// One wavefront per selected position; 64 records per step, ballot + prefix popcount give every covering
-// record its slot, so read indices come out ascending and the writes of a step are contiguous.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gather_columns(
-    const uint8_t* __restrict__ pile, const int64_t* __restrict__ pile_off,
-    const int32_t* __restrict__ rec_pos, const int32_t* __restrict__ rec_qend,
-    const int32_t* __restrict__ contig_rec_off, const int32_t* __restrict__ sel_contig,
-    const int32_t* __restrict__ sel_pos, const int64_t* __restrict__ col_off, int n_sel,
-    int32_t* __restrict__ col_idx, uint8_t* __restrict__ col_code) {
-    const int lane = lane_id();
-    const int s = (int)blockIdx.x * 4 + wave_id();
-    if (s >= n_sel) return;
-    const int c = sel_contig[s], p = sel_pos[s];
-    const int r0 = contig_rec_off[c], r1 = contig_rec_off[c + 1];
-    int64_t w = col_off[s];
-    for (int nb = r0; nb < r1; nb += 64) {
-        const int n = nb + lane;
-        bool cov = false;
-        int ps = 0;
-        if (n < r1) { ps = rec_pos[n]; cov = p >= ps && p < rec_qend[n]; }
-        const unsigned long long m = __ballot(cov);
-        if (cov) {
-            const int rank = __popcll(m & ((1ull << lane) - 1ull));
-            col_idx[w + rank] = n - r0;
-            col_code[w + rank] = pile[pile_off[n] + (p - ps)];
-        }
-        w += __popcll(m);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1459,167 +1072,6 @@ __global__ __launch_bounds__(256) void k_simdiff_windows(
             if (gi < m && gj < m) { S[((int64_t)gi * m + gj) * es] = s_acc[a][b]; D[((int64_t)gi * m + gj) * es] = d_acc[a][b]; }
         }
 }
-
-// ------------------------------------------------------------------------------------------------
-// K7 Chinese Whispers: cluster_graph.cpp:240-310 (and :152-230). One wavefront (one 64-thread workgroup)
-// per instance; labels and the per-label vote counters live in LDS. Nodes are visited sequentially in the
-// supplied permutation; the neighbours of the current node are spread over the lanes: LDS atomic add of one
-// vote per lane, then every lane reads its label's total and a wave max-reduce on (count, -label) yields the
-// most frequent label with the LOWEST id on ties (:272-279). Masked-out nodes keep voting with their initial
-// label and are set to -2 at the end. Stops after 15 sweeps or when a sweep changes <= 2 nodes (:167).
-// ------------------------------------------------------------------------------------------------
-#ifndef HS_CW_REG_LABELS
-#define HS_CW_REG_LABELS 8
-#endif
-__global__ __launch_bounds__(64) void k_chinese_whispers(
-    const int32_t* __restrict__ adj_off, const int32_t* __restrict__ adj,
-    const int64_t* __restrict__ graph_off_base, const int64_t* __restrict__ graph_adj_base,
-    const int32_t* __restrict__ graph_n, const int32_t* __restrict__ perm, const int64_t* __restrict__ perm_base,
-    const uint8_t* __restrict__ mask, const int32_t* __restrict__ inst_graph,
-    const int64_t* __restrict__ inst_label_base, int n_inst, int32_t* __restrict__ labels_io,
-    int32_t* __restrict__ sweeps_out,
-    // optional seeding from a SNP column (separate_reads.cpp:1678-1691); inst_seed_col == nullptr: labels_io holds the start
-    const int64_t* __restrict__ inst_seed_col, const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx,
-    const uint8_t* __restrict__ col_code,
-    // optional visiting lists (k_cw_visit_lists); nullptr: the permutation is scanned in every sweep
-    const int32_t* __restrict__ visit, const int32_t* __restrict__ visit_n,
-    // labels + vote counters of graphs too large for LDS: 2 * max_n ints per instance (nullptr: they live in LDS)
-    int32_t* __restrict__ gscratch, int max_n) {
-    extern __shared__ int32_t cw_lds[];
-    const int lane = lane_id();
-    const int inst = (int)blockIdx.x;
-    if (inst >= n_inst) return;
-    const int g = inst_graph[inst];
-    const int N = graph_n[g];
-    const int32_t* __restrict__ aoff = adj_off + graph_off_base[g];     // N+1 entries, relative to the graph's adj slice
-    const int32_t* __restrict__ anb = adj + graph_adj_base[g];
-    const int32_t* __restrict__ prm = perm + perm_base[g];
-    const uint8_t* __restrict__ msk = mask + graph_off_base[g] - g;      // mask is N per graph: base = off_base - g
-    const int32_t* __restrict__ vis = visit ? visit + graph_off_base[g] - g : nullptr;
-    const int n_visit = visit ? visit_n[g] : N;
-    int32_t* __restrict__ lab_g = labels_io + inst_label_base[inst];
-    int32_t* lab = gscratch ? gscratch + (int64_t)inst * 2 * max_n : cw_lds;   // [N]
-    int32_t* cnt = lab + N;                                                      // [N]
-    int32_t* first = gscratch ? cw_lds : cw_lds + 2 * N;   // [256] first masked read carrying each code (seeding only)
-    if (inst_seed_col) {
-        // every read starts alone; masked reads of the seeding column start in the cluster of the first masked read
-        // that carries the same code
-        for (int i = lane; i < N; i += 64) { lab[i] = i; cnt[i] = 0; }
-        for (int i = lane; i < 256; i += 64) first[i] = 0x7fffffff;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        const int64_t c0 = col_off[inst_seed_col[inst]], c1 = col_off[inst_seed_col[inst] + 1];
-        for (int64_t e = c0 + lane; e < c1; e += 64) { const int r = col_idx[e]; if (msk[r]) atomicMin(&first[col_code[e]], r); }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        for (int64_t e = c0 + lane; e < c1; e += 64) { const int r = col_idx[e]; if (msk[r]) lab[r] = first[col_code[e]]; }
-    } else {
-        for (int i = lane; i < N; i += 64) { lab[i] = lab_g[i]; cnt[i] = 0; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-
-    int changes = 3, iters = 0;
-    while (changes > 2 && iters < 15) {
-        changes = 0;
-        for (int k0 = 0; k0 < n_visit; k0 += 64) {
-            const int kk = k0 + lane;
-            int i_l = -1, o0_l = 0, o1_l = 0;
-            if (kk < n_visit) {
-                i_l = vis ? vis[kk] : prm[kk];
-                if (vis || msk[i_l]) { o0_l = aoff[i_l]; o1_l = aoff[i_l + 1]; }
-            }
-            unsigned long long act = __ballot(o1_l > o0_l);
-            // the neighbour ids of a node do not depend on the labels: they are loaded one visit ahead, so that the global
-            // load is off the dependent chain of a visit (LDS gather of the labels -> vote -> label update)
-            int nb_next = -1;
-            if (act) {
-                const int ln = __builtin_ctzll(act);
-                const int p0 = __builtin_amdgcn_readlane(o0_l, ln), p1 = __builtin_amdgcn_readlane(o1_l, ln);
-                nb_next = (p1 - p0 <= 64 && p0 + lane < p1) ? anb[p0 + lane] : -1;
-            }
-            while (act) {
-                const int l = __builtin_ctzll(act);
-                act &= act - 1ull;
-                const int i = __builtin_amdgcn_readlane(i_l, l);
-                const int o0 = __builtin_amdgcn_readlane(o0_l, l), o1 = __builtin_amdgcn_readlane(o1_l, l);
-                const int nb = nb_next;
-                if (act) {
-                    const int ln = __builtin_ctzll(act);
-                    const int p0 = __builtin_amdgcn_readlane(o0_l, ln), p1 = __builtin_amdgcn_readlane(o1_l, ln);
-                    nb_next = (p1 - p0 <= 64 && p0 + lane < p1) ? anb[p0 + lane] : -1;
-                }
-                int best_cnt = 0, best_lab = -1;
-                if (o1 - o0 <= 64) {
-                    // the usual case: all neighbours in one step, one label per lane. The vote is taken in registers: one
-                    // ballot per distinct label (a handful once the seeding has grouped the reads); a node that sees more than
-                    // HS_CW_REG_LABELS distinct labels goes through the LDS counters instead
-                    const int lb = nb >= 0 ? lab[nb] : -1;
-                    unsigned long long rem = __ballot(lb >= 0);
-                    // key = count << 16 | (65535 - label): the largest key is the largest count, lowest label among equals
-                    // (only when every label fits 16 bits: N <= 65535; larger graphs always take the counter path)
-                    unsigned best_key = 0u;
-#pragma unroll
-                    for (int tries = 0; tries < HS_CW_REG_LABELS; ++tries) {
-                        if (!rem || N > 65535) break;
-                        const int v = __builtin_amdgcn_readlane(lb, __builtin_ctzll(rem));
-                        const unsigned long long m = __ballot(lb == v);
-                        const unsigned key = ((unsigned)__popcll(m) << 16) | (unsigned)(65535 - v);
-                        best_key = key > best_key ? key : best_key;
-                        rem &= ~m;
-                    }
-                    best_cnt = (int)(best_key >> 16);
-                    best_lab = best_cnt ? 65535 - (int)(best_key & 0xffffu) : -1;
-                    if (rem) {
-                        if (lb >= 0) atomicAdd(&cnt[lb], 1);                       // votes
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                        __builtin_amdgcn_wave_barrier();
-                        const int c = lb >= 0 ? cnt[lb] : 0;                       // totals
-                        best_cnt = wave_max_i32(c);
-                        best_lab = 0x7fffffff - wave_max_i32((lb >= 0 && c == best_cnt) ? 0x7fffffff - lb : 0);
-                        if (lb >= 0) cnt[lb] = 0;                                  // reset the touched counters
-                    }
-                } else {
-                    for (int o = o0; o < o1; o += 64) {
-                        const int idx = o + lane;
-                        if (idx < o1) { const int lb = lab[anb[idx]]; if (lb >= 0) atomicAdd(&cnt[lb], 1); }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    unsigned long long best = 0ull;
-                    for (int o = o0; o < o1; o += 64) {
-                        const int idx = o + lane;
-                        if (idx < o1) {
-                            const int lb = lab[anb[idx]];
-                            if (lb >= 0) {
-                                const unsigned long long key = ((unsigned long long)(unsigned)cnt[lb] << 32) | (unsigned)(0x7fffffff - lb);
-                                best = key > best ? key : best;
-                            }
-                        }
-                    }
-                    best = wave_max_u64(best);
-                    for (int o = o0; o < o1; o += 64) {
-                        const int idx = o + lane;
-                        if (idx < o1) { const int lb = lab[anb[idx]]; if (lb >= 0) cnt[lb] = 0; }
-                    }
-                    best_cnt = (int)(best >> 32);
-                    best_lab = 0x7fffffff - (int)(best & 0xffffffffull);
-                }
-                if (best_cnt > 0) {
-                    if (lab[i] != best_lab) changes++;
-                    if (lane == 0) lab[i] = best_lab;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        iters++;
-    }
-    for (int i = lane; i < N; i += 64) lab_g[i] = msk[i] ? lab[i] : -2;
-    if (sweeps_out && lane == 0) sweeps_out[inst] = iters;
-}
-
-// (A1, the Myers bit-vector alignment kernels: hs_kernels_myers.hip)
 
 // ------------------------------------------------------------------------------------------------
 // K4 SNP column x partition correlation: distance(Partition&, Column&) + computeChiSquare
@@ -2059,108 +1511,6 @@ __global__ __launch_bounds__(256) void k_column_partition_lanes(
         }
         wave_lds_sync();
     }
-}
-
-// K3 with the tile plan: only the records of the position's tile are tested (one 64-record step for 50x data instead of
-// ten); the plan lists them in ascending record order, so the read indices still come out ascending.
-__global__ __launch_bounds__(256) void k_gather_columns_tiled(
-    const uint8_t* __restrict__ pile, const int64_t* __restrict__ tile_off, const int4* __restrict__ tile_ent,
-    const int32_t* __restrict__ tile_rec, const int64_t* __restrict__ contig_off, const int32_t* __restrict__ contig_rec_off,
-    const int32_t* __restrict__ sel_contig, const int32_t* __restrict__ sel_pos, const int64_t* __restrict__ col_off, int n_sel,
-    int32_t* __restrict__ col_idx, uint8_t* __restrict__ col_code) {
-    const int lane = lane_id();
-    const int s = (int)blockIdx.x * 4 + wave_id();
-    if (s >= n_sel) return;
-    const int c = sel_contig[s];
-    const int64_t g = contig_off[c] + sel_pos[s];
-    const int64_t tile = g >> 8;
-    const int x = (int)(g & 255);
-    const int r0 = contig_rec_off[c];
-    int64_t w = col_off[s];
-    const int64_t e1 = tile_off[tile + 1];
-    for (int64_t eb = tile_off[tile]; eb < e1; eb += 64) {
-        const int64_t e = eb + lane;
-        bool cov = false;
-        int4 en = make_int4(0, 0, 0, 0);
-        if (e < e1) { en = tile_ent[e]; cov = (unsigned)(x - en.x) < (unsigned)en.y; }
-        const unsigned long long m = __ballot(cov);
-        if (cov) {
-            const int rank = __popcll(m & ((1ull << lane) - 1ull));
-            col_idx[w + rank] = tile_rec[e] - r0;
-            col_code[w + rank] = pile[(int64_t)(((uint64_t)(uint32_t)en.w << 32) | (uint32_t)en.z) + x];
-        }
-        w += __popcll(m);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3b top-3 of the extracted columns (call_variants.cpp:477-507 for the selected positions only): one wavefront per column,
-// histogram over the 125 codes in LDS, three wave arg-max rounds. The reference orders equal counts by robin_hood iteration
-// order + std::sort; the device reports such columns (tie = 1: two largest counts equal, second and third equal, no second
-// allele, or a byte outside 33..157) and the host resolves those exactly.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_column_top3(const int64_t* __restrict__ col_off, const uint8_t* __restrict__ col_code, int n_cols,
-                                                     hs_coltop_dev* __restrict__ out) {
-    __shared__ int s_hist[4][128];
-    const int lane = lane_id();
-    const int wv = wave_id();
-    const int col = (int)blockIdx.x * 4 + wv;
-    if (col >= n_cols) return;                   // wave-uniform
-    int* __restrict__ h = s_hist[wv];
-    h[lane] = 0; h[lane + 64] = 0;
-    wave_lds_sync();
-    const int64_t b = col_off[col];
-    const int n = (int)(col_off[col + 1] - b);
-    bool odd = false;
-    for (int j = lane; j < n; j += 64) {
-        const int c = (int)col_code[b + j] - 33;
-        if (c >= 0 && c < HS_NBINS) atomicAdd(&h[c], 1); else odd = true;
-    }
-    wave_lds_sync();
-    // key = count << 8 | (255 - bin): larger count first, then smaller code (only used when the counts differ)
-    int k_a = (h[lane] << 8) | (255 - lane), k_b = (h[lane + 64] << 8) | (255 - (lane + 64));
-    int top[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int mine = k_a > k_b ? k_a : k_b;
-        const int best = wave_max_i32(mine);
-        top[r] = best;
-        if (k_a == best) k_a = -1;
-        if (k_b == best) k_b = -1;
-    }
-    const bool any_odd = __ballot(odd) != 0ull;
-    if (lane == 0) {
-        hs_coltop_dev o;
-        o.c0 = top[0] >> 8; o.c1 = top[1] >> 8; o.c2 = top[2] >> 8;
-        o.k0 = (uint8_t)(33 + 255 - (top[0] & 255)); o.k1 = (uint8_t)(33 + 255 - (top[1] & 255));
-        o.tie = (uint8_t)((any_odd || o.c0 == o.c1 || o.c1 == o.c2 || o.c1 == 0) ? 1 : 0);
-        o.pad = 0;
-        out[col] = o;
-    }
-}
-
-// K3c: copies the listed columns of the extracted CSR back to back (one wavefront per column), so that only the columns
-// the host really walks (candidate SNPs, columns whose top-3 needs the reference's tie order, rescued columns) cross PCIe.
-__global__ __launch_bounds__(256) void k_pack_columns(const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx,
-                                                      const uint8_t* __restrict__ col_code, const int32_t* __restrict__ ids,
-                                                      const int64_t* __restrict__ packed_off, int n_ids, int32_t* __restrict__ out_idx,
-                                                      uint8_t* __restrict__ out_code) {
-    const int lane = lane_id();
-    const int k = (int)blockIdx.x * 4 + wave_id();
-    if (k >= n_ids) return;                      // wave-uniform
-    const int col = ids[k];
-    const int64_t src = col_off[col], dst = packed_off[k];
-    const int n = (int)(packed_off[k + 1] - dst);
-    for (int j = lane; j < n; j += 64) { out_idx[dst + j] = col_idx[src + j]; out_code[dst + j] = col_code[src + j]; }
-}
-
-// small utility: apply host-resolved "swap top-2" decisions to the column statistics
-__global__ void k_swap_top2(hs_colstat_dev* __restrict__ stats, const int64_t* __restrict__ gpos, int n) {
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= n) return;
-    hs_colstat_dev s = stats[gpos[i]];
-    uint8_t k = s.key[0]; s.key[0] = s.key[1]; s.key[1] = k;
-    stats[gpos[i]] = s;
 }
 
 }  // namespace hsdev

@@ -131,15 +131,6 @@ typedef struct hs_colstat {
     uint16_t depth;
 } hs_colstat;
 
-int hs_column_stats(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
-                    const int32_t* d_rec_qend, const int32_t* d_contig_rec_off, const int64_t* d_contig_off,
-                    int32_t n_contigs, hs_colstat* d_stats /* [sum L]; NULL = selection only (cheaper kernel, no per-position record) */,
-                    /* optional compact selection (all NULL / 0 to skip): global positions (index into the concatenated
-                     * contigs) whose second count is >= min_second, unordered, with their depth; *d_sel_count must be 0 */
-                    int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos, int32_t* d_sel_depth, int32_t sel_cap,
-                    /* upper bound on the depth of any position, if known (1..255 selects 8-bit LDS counters); 0 = unknown */
-                    int32_t max_depth, void* stream);
-
 /* ------------------------------------------------------------------------------------------------
  * Tile plan for K2 / K3: which records overlap each tile of 256 consecutive positions of the concatenated contigs, in
  * ascending record order. Built on the host from the same per-record aggregates as the pileup layout (one pass over the
@@ -152,52 +143,22 @@ typedef struct hs_tile_entry { int32_t first, len; int64_t base; } hs_tile_entry
 int hs_tile_plan(const int64_t* h_contig_off, int32_t n_contigs, const int32_t* h_contig_rec_off, const int32_t* h_rec_pos,
                  const int32_t* h_rec_qend, const int64_t* h_pile_off, int64_t** tile_off /* [n_tiles+1] */,
                  hs_tile_entry** tile_ent, int32_t** tile_rec, int64_t* n_tiles);
-/* K2 / K3 on a tile plan (same outputs as hs_column_stats / hs_gather_columns; total_len = contig_off[C]) */
+/* K2 on a tile plan in its full-statistics form (total_len = contig_off[C]): d_stats [sum L] or NULL = selection only; optional compact
+ * selection (all NULL / 0 to skip): global positions (index into the concatenated contigs) whose second count is >= min_second,
+ * unordered, with their depth; *d_sel_count must be 0; max_depth: upper bound on the depth of any position, if known (1..255
+ * selects 8-bit LDS counters), 0 = unknown. (The stage drivers run the selection-only form k_column_stats_tiled_dw: see
+ * hs_cv_column_pass_taps.) */
 int hs_column_stats_tiled(const uint8_t* d_pile, const int64_t* d_tile_off, const hs_tile_entry* d_tile_ent, int64_t total_len,
                           hs_colstat* d_stats, int32_t min_second, int32_t* d_sel_count, int64_t* d_sel_gpos,
                           int32_t* d_sel_depth, int32_t sel_cap, int32_t max_depth, void* stream);
-int hs_gather_columns_tiled(const uint8_t* d_pile, const int64_t* d_tile_off, const hs_tile_entry* d_tile_ent,
-                            const int32_t* d_tile_rec, const int64_t* d_contig_off, const int32_t* d_contig_rec_off,
-                            const int32_t* d_sel_contig, const int32_t* d_sel_pos, const int64_t* d_col_off, int32_t n_sel,
-                            int32_t* d_col_idx, uint8_t* d_col_code, void* stream);
-
-/* ------------------------------------------------------------------------------------------------
- * K3 -- column extraction (pileup transposition for selected positions, coalesced writes).
- * Produces the reference's `Column` (Partition.h:8-14): read indices ascending + one code per read, for the
- * positions in d_sel_pos (position inside contig d_sel_contig). d_col_off[k] is the output offset of
- * selected column k (exclusive prefix of hs_colstat.depth, computed by the caller).
- * ---------------------------------------------------------------------------------------------- */
-int hs_gather_columns(const uint8_t* d_pile, const int64_t* d_pile_off, const int32_t* d_rec_pos,
-                      const int32_t* d_rec_qend, const int32_t* d_contig_rec_off,
-                      const int32_t* d_sel_contig, const int32_t* d_sel_pos, const int64_t* d_col_off,
-                      int32_t n_sel, int32_t* d_col_idx, uint8_t* d_col_code, void* stream);
-
-/* ------------------------------------------------------------------------------------------------
- * K3b -- the two most frequent codes and the three largest counts of every extracted column (call_variants.cpp:477-507
- * restricted to the selected positions). tie = 1 where the reference's order of equal counts (robin_hood iteration order +
- * std::sort) matters or the column has no second allele: the caller resolves those columns on the host.
- * ---------------------------------------------------------------------------------------------- */
-typedef struct hs_coltop {
-    int32_t c0, c1, c2;
-    uint8_t k0, k1, tie, pad;
-} hs_coltop;
-int hs_column_top3(const int64_t* d_col_off, const uint8_t* d_col_code, int32_t n_cols, hs_coltop* d_out, void* stream);
-
 /* Exclusive prefix sum of n non-negative ints into n + 1 64-bit offsets (d_out[n] = total): the CSR offsets of the read
  * graphs (K6) and of the selection list (K2) are built with it. Synchronous with respect to `stream`. */
 int hs_exclusive_scan_i32(const int32_t* d_in, int32_t n, int64_t* d_out, void* stream);
 
-/* K3c -- packs the listed columns (d_ids[k] = column index in the CSR of hs_gather_columns, any order) back to back:
- * column d_ids[k] goes to [d_packed_off[k], d_packed_off[k+1]) of d_out_idx / d_out_code; the caller builds d_packed_off
- * from the column depths. Only the columns the host walks (candidate SNPs of call_variants.cpp:525-536, columns whose
- * top-3 depends on the reference's tie order, the output SNP columns) then need to be downloaded. */
-int hs_pack_columns(const int64_t* d_col_off, const int32_t* d_col_idx, const uint8_t* d_col_code, const int32_t* d_ids,
-                    const int64_t* d_packed_off, int32_t n_ids, int32_t* d_out_idx, uint8_t* d_out_code, void* stream);
-
 /* ------------------------------------------------------------------------------------------------
  * K4 -- SNP column x partition correlation.  Replaces distance(Partition&, Column&) + computeChiSquare
  * (call_variants.cpp:778-967, :1135-1163) as used by loops C and D of keep_only_robust_variants (:721-764).
- * Columns are the CSR produced by hs_gather_columns; col_k0 / col_k1 their two most frequent codes in the reference's
+ * Columns are a CSR as the column pass of stage 3 leaves it (hs_cv_taps); col_k0 / col_k1 their two most frequent codes in the reference's
  * tie order; col_c1 the second count; col_is_cand marks candidate SNPs (loop C). Partitions are dense int8 state
  * arrays over the contig's reads (1, -1, 0, or 2 = read absent); contig c owns partitions [part_off[c], part_off[c+1]).
  * Two kernels: lanes = partitions on a [read][partition] table built on the device (64 partitions per step), then the
@@ -259,20 +220,6 @@ int hs_simdiff(const uint64_t* d_alt, const uint64_t* d_ref, const int64_t* d_pl
 int hs_read_graphs(const int32_t* d_sim, const int32_t* d_diff, const int64_t* ctg_out_off, const int32_t* ctg_n_reads,
                    int32_t n_contigs, const int32_t* win_contig, const int64_t* win_mask_off, const int32_t* mask_ids,
                    int32_t n_windows, float error_rate, int64_t** nbr_off, int32_t** nbr, int64_t* n_rows_host, void* stream);
-
-/* ------------------------------------------------------------------------------------------------
- * K7 -- Chinese Whispers, batched.  Replaces chinese_whispers / chinese_whispers_high_memory
- * (cluster_graph.cpp:152-310). One wavefront per instance; an instance is (graph g, initial labels, mask).
- * Graph g is a CSR over n_nodes[g] nodes (adj_off relative to graph_adj_base[g]); perm[g] is the node visiting
- * order (the caller supplies std::shuffle(mt19937(seed)) of 0..N-1; with a pinned seed the reference uses the
- * same permutation in every sweep). Labels in/out: int32, -2 for masked-out nodes on output.
- * d_sweeps[i] (optional, may be NULL) receives the number of sweeps instance i ran.
- * ---------------------------------------------------------------------------------------------- */
-int hs_chinese_whispers(const int32_t* d_adj_off, const int32_t* d_adj, const int64_t* d_graph_off_base,
-                        const int64_t* d_graph_adj_base, const int32_t* d_graph_n, const int32_t* d_perm,
-                        const int64_t* d_perm_base, const uint8_t* d_mask, const int32_t* d_inst_graph,
-                        const int64_t* d_inst_label_base, int32_t n_inst, int32_t* d_labels,
-                        int32_t* d_sweeps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A1 -- Myers bit-vector edit distance, batched and banded (64 query rows per lane, carries passed between lanes;
@@ -384,6 +331,34 @@ typedef struct hs_cv_result {
 } hs_cv_result;
 
 int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out);
+
+/* Test taps of the column pass of stage 3 exactly as the pipeline queues it for the contigs [c0, c1) of a resident batch -- K0, K1, K2
+ * (k_column_stats_tiled_dw), k_columns_compact, k_gather_tiles_direct / k_gather_tiles, k_column_top3_exact, k_candidates_scan,
+ * k_flag_block_sums / _offsets, k_pack_flagged, k_cand_bits -- with what those kernels left on the device copied out, so that each of
+ * them can be held against the oracle on its own (tests/test_gpu_kernels.py). The reference has no counterpart: call_variants.cpp:
+ * 471-536 walks positions one by one. */
+typedef struct hs_cand_bits {        /* == hs::CandBits (hs_host.h): a candidate column as bit sets over the reads ranked by start position */
+    int32_t wlo; uint16_t n_words, n_slots; int32_t idx_min, idx_max, reach, n_entries; int64_t word_off;
+} hs_cand_bits;
+typedef struct hs_cv_taps {
+    int32_t n_contigs;               /* c1 - c0 */
+    int64_t n_cols, n_entries;       /* the extracted columns (K2's selection: every position that can still become a SNP) and their entries */
+    int64_t* col_gpos;               /* [n_cols] position in the concatenated contigs of the batch, ascending (k_columns_compact) */
+    hs_colrec* col_rec;              /* [n_cols] leading codes and counts (K2's second pass / k_column_top3_exact), flags (k_candidates_scan) */
+    int64_t* col_off;                /* [n_cols + 1] */
+    int32_t* col_idx;                /* [n_entries] read index on the contig, ascending inside a column (k_gather_tiles*) */
+    uint8_t* col_code;               /* [n_entries] pileup code */
+    int64_t n_cand;                  /* candidates (HS_COL_CAND) */
+    hs_colrec* cand_rec;             /* [n_cand] k_pack_flagged: their records ... */
+    int32_t* cand_col;               /* ... and their index among the columns */
+    hs_cand_bits* cand_bits;         /* [n_cand] k_cand_bits */
+    uint64_t* cand_words;            /* [n_cand_words] */
+    int64_t n_cand_words;
+    int32_t* contig_n_cand;          /* [n_contigs] */
+    float* contig_mean_distance;     /* [n_contigs] k_contig_error */
+} hs_cv_taps;
+int hs_cv_column_pass_taps(hs_cv_batch* b, int32_t c0, int32_t c1, float automatic_snp_threshold, hs_cv_taps** out);
+void hs_cv_taps_destroy(hs_cv_taps* t);
 
 /* Several GPUs in one process. Contigs are the independent units of both stages (call_variants.cpp:1276-1280,
  * separate_reads.cpp:1506-1508): hs_cv_run_host and hs_sr_run shard them over the devices of hs_devices() by

@@ -131,6 +131,21 @@ int hso_column_top3(const uint8_t* pile, const int64_t* pile_off, const int32_t*
     return 0;
 }
 
+// the candidate SNPs of a contig (call_variants.cpp:447-567: the predicate of :525-529 with the greedy spacing, the automatic ones of :531)
+// on a read-major pileup: flags[p] bit 0 = suspicious, bit 1 = automatic. Returns the number of candidates.
+int hso_call_variants_flags(const uint8_t* pile, const int64_t* pile_off, const int32_t* rec_pos, const int32_t* rec_qend,
+                            int32_t r0, int32_t r1, int64_t L, float mean_error, float automatic_snp_threshold, uint8_t* flags) {
+    std::vector<hso::Column> cols((size_t)L);
+    for (int r = r0; r < r1; ++r)
+        for (int q = rec_pos[r]; q < rec_qend[r]; ++q) { cols[(size_t)q].readIdxs.push_back((unsigned)(r - r0)); cols[(size_t)q].content.push_back(pile[pile_off[r] + (q - rec_pos[r])]); }
+    std::string ref((size_t)L, 'A');
+    hso::CallResult cr = hso::call_variants(cols, ref, mean_error, automatic_snp_threshold);
+    for (int64_t p = 0; p < L; ++p) flags[p] = 0;
+    for (const hso::Column& c : cr.suspicious) flags[c.pos] |= 1;
+    for (const hso::Column& c : cr.automatic) flags[c.pos] |= 2;
+    return (int)cr.suspicious.size();
+}
+
 // K5 oracle: separate_reads.cpp:374-433 from CSR SNP columns
 int hso_simdiff(int32_t n_reads, int32_t n_snps, const uint8_t* snp_ref, const uint8_t* snp_alt, const int64_t* col_off,
                 const int32_t* col_idx, const uint8_t* col_code, int32_t* sim, int32_t* diff) {

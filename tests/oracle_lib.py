@@ -43,6 +43,17 @@ def column_top3(flat, pile, c):
     return k0, k1, c0, c1, c2, d
 
 
+def call_variants_flags(flat, pile, c, mean_error, automatic_snp_threshold=0.33):
+    """per position of contig c: bit 0 = candidate SNP (call_variants.cpp:525-529 with the spacing rule), bit 1 = automatic (:531)"""
+    r0, r1 = int(flat.contig_rec_off[c]), int(flat.contig_rec_off[c + 1])
+    L = int(flat.contig_off[c + 1] - flat.contig_off[c])
+    flags = np.zeros(max(L, 1), np.uint8)
+    pile = np.ascontiguousarray(pile)
+    lib().hso_call_variants_flags(_hp(pile, C.c_uint8), _hp(flat.pile_off, C.c_int64), _hp(flat.rec_pos, C.c_int32), _hp(flat.rec_qend, C.c_int32),
+                                  C.c_int32(r0), C.c_int32(r1), C.c_int64(L), C.c_float(mean_error), C.c_float(automatic_snp_threshold), _hp(flags, C.c_uint8))
+    return flags[:L]
+
+
 def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1, col_c1, col_is_cand, part_off, part_state_off, part_state,
                           n_reads_of_contig):
     n = len(col_contig)

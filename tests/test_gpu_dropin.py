@@ -24,14 +24,13 @@ def test_dropin_binaries_match_reference_goldens(built, case):
         assert open(gaf, "rb").read() == open(os.path.join(td, "reads_haplo.gaf"), "rb").read()
 
 
-@pytest.mark.parametrize("switch", ["HS_K1_PER_EVENT", "HS_K1_PACKED", "HS_SPIN_WAIT", "HS_FINISH_ON_HOST", "HS_LOOP_A_ON_DEVICE", "HS_LOOP_B_PAIRS_ON_DEVICE", "HS_K2_PLAIN",
+@pytest.mark.parametrize("switch", ["HS_SPIN_WAIT", "HS_FINISH_ON_HOST", "HS_LOOP_A_ON_DEVICE", "HS_LOOP_B_PAIRS_ON_DEVICE",
                                     "HS_NO_REEXEC", "HS_EXIT_LEAK", "HS_PINNED_HOSTMALLOC", "HS_NO_DETACH"])
 @pytest.mark.parametrize("case", ["penta30k", "edge_ops"])
 def test_dropin_binaries_with_the_alternative_paths(built, case, switch):
-    """The opt-in switches select other ways to the same result (event-per-lane / packed pileup, no huge-page restart, nothing destroyed at the
-    exit, pinned blocks from hipHostMalloc, one process; sleeping waits, full column download,
-    cluster merging on the host, loop A of keep_only_robust_variants on the device, K2 without its second pass -- every column's leading
-    codes from k_column_top3_exact): the executables must still reproduce the reference goldens"""
+    """The switches select other ways to the same result (no huge-page restart, nothing destroyed at the exit, pinned blocks from hipHostMalloc,
+    one process; back-to-back polling waits, cluster merging on the host, loop A of keep_only_robust_variants on the device, loop B's pair distances
+    from the device): the executables must still reproduce the reference goldens"""
     with tempfile.TemporaryDirectory() as td:
         meta = gu.unpack(case, td)
         outs = gu.run_stage_pair([built["cv"]], [built["sr"]], td, meta, env=dict(os.environ, **{switch: "1"}))

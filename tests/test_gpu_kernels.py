@@ -149,76 +149,145 @@ def test_column_stats_counts(batch):
         assert np.all(np.diff(cnt, axis=1) <= 0) and np.all(cnt.sum(axis=1) <= depth)
 
 
-def test_tiled_variants_equal_planless(batch):
-    """K2 / K3 on the host-built tile plan (what the stage driver runs) == the plan-less kernels, byte for byte"""
+def test_tile_plan_lists_every_overlap_once_in_record_order(batch):
+    """the host-built tile plan of K2 / K3: every (tile, record) overlap once, ascending record ids per tile"""
     from hairsplitter_amd import api
     flat, t = batch
-    pile, _ = api.pileup(t, flat)
     plan = api.tile_plan(flat)
-    # the plan itself: every (tile, record) overlap once, ascending record ids per tile
+    n = 0
     for tl in range(len(plan["h_off"]) - 1):
         recs = plan["h_rec"][plan["h_off"][tl]:plan["h_off"][tl + 1]]
         assert np.all(np.diff(recs) > 0)
-    for md in (0, 255):
-        a = api.column_stats(t, flat, pile, min_second=4, max_depth=md)
-        b = api.column_stats(t, flat, pile, min_second=4, max_depth=md, plan=plan)
-        assert np.array_equal(a[0].view(np.uint8), b[0].view(np.uint8)) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-    st, sel_g, sel_d = a
-    ctg = np.searchsorted(flat.contig_off, sel_g, side="right") - 1
-    pos = sel_g - flat.contig_off[ctg]
-    x = api.gather_columns(t, flat, pile, ctg, pos, sel_d)
-    y = api.gather_columns(t, flat, pile, ctg, pos, sel_d, plan=plan)
-    assert all(np.array_equal(u, v) for u, v in zip(x, y))
+        n += len(recs)
+    exp = 0
+    for c in range(flat.n_contigs):
+        g0 = int(flat.contig_off[c])
+        for r in range(int(flat.contig_rec_off[c]), int(flat.contig_rec_off[c + 1])):
+            if flat.rec_qend[r] > flat.rec_pos[r]:
+                exp += ((g0 + int(flat.rec_qend[r]) - 1) >> 8) - ((g0 + int(flat.rec_pos[r])) >> 8) + 1
+    assert n == exp
 
 
-def test_gather_columns(batch):
-    """K3 == the reference's Column for selected positions: ascending read indices, matching codes."""
+@pytest.fixture(scope="module")
+def taps(batch):
+    """the column pass of stage 3 AS THE PIPELINE QUEUES IT over the whole batch (hs_cv_column_pass_taps: K0, K1, k_column_stats_tiled_dw,
+    k_columns_compact, k_gather_tiles_direct / k_gather_tiles, k_column_top3_exact, k_candidates_scan, k_flag_block_*, k_pack_flagged, k_cand_bits),
+    with what those kernels left on the device, + the oracle's pileup of the same batch"""
     from hairsplitter_amd import api
     flat, t = batch
-    pile, _ = api.pileup(t, flat)
-    st = api.column_stats(t, flat, pile)
-    rng = np.random.default_rng(5)
-    sel_c, sel_p, depths = [], [], []
+    b = api.CvBatch(flat)
+    tp = api.cv_column_pass_taps(b, 0, flat.n_contigs, 0.33)
+    b.close()
+    o_pile, _, _ = ol.pileup(flat)
+    return flat, tp, o_pile
+
+
+def test_column_pass_selection_and_gather(taps):
+    """K2's selection (k_column_stats_tiled_dw + k_columns_compact) and K3 (k_gather_tiles_direct / k_gather_tiles): the extracted columns
+    ascend by position, hold every position that can still become a SNP (second count >= 5, or a candidate of call_variants.cpp:525-529) and
+    nothing whose second count is below 4, and every column is the reference's Column (Partition.h:8-14) of its position: the reads covering
+    it in ascending index with their pileup codes."""
+    flat, tp, hp = taps
+    g = tp["col_gpos"]
+    assert np.all(np.diff(g) > 0)
+    ctg = np.searchsorted(flat.contig_off, g, side="right") - 1
+    pos = g - flat.contig_off[ctg]
+    assert np.array_equal(tp["col_rec"]["contig"], ctg.astype(np.int32)) and np.array_equal(tp["col_rec"]["pos"], pos.astype(np.int32))
+    off, idx, code = tp["col_off"], tp["col_idx"], tp["col_code"]
+    assert off[0] == 0 and off[-1] == len(idx) == len(code)
+    have = set(int(x) for x in g)
     for c in range(flat.n_contigs):
-        L = int(flat.contig_off[c + 1] - flat.contig_off[c])
-        for p in sorted(set([0, L - 1] + rng.integers(0, L, 40).tolist())):
-            sel_c.append(c); sel_p.append(p); depths.append(int(st[int(flat.contig_off[c]) + p]["depth"]))
-    col_off, idx, code = api.gather_columns(t, flat, pile, sel_c, sel_p, depths)
-    hp = pile.cpu().numpy()
-    for k, (c, p) in enumerate(zip(sel_c, sel_p)):
         r0, r1 = int(flat.contig_rec_off[c]), int(flat.contig_rec_off[c + 1])
-        exp_idx, exp_code = [], []
-        for r in range(r0, r1):
-            if flat.rec_pos[r] <= p < flat.rec_qend[r]:
-                exp_idx.append(r - r0); exp_code.append(hp[flat.pile_off[r] + p - flat.rec_pos[r]])
-        assert idx[col_off[k]:col_off[k + 1]].tolist() == exp_idx
-        assert code[col_off[k]:col_off[k + 1]].tolist() == exp_code
-
-
-def test_column_top3_of_extracted_columns(batch):
-    """K3b: where it reports no tie its result is the reference's (call_variants.cpp:477-507); ties are flagged, not guessed"""
-    from hairsplitter_amd import api
-    flat, t = batch
-    pile, _ = api.pileup(t, flat)
-    _, sel_g, sel_d = api.column_stats(t, flat, pile, min_second=2)
-    order = np.argsort(sel_g)
-    sel_g = sel_g[order]; sel_d = sel_d[order]
-    ctg = np.searchsorted(flat.contig_off, sel_g, side="right") - 1
-    pos = sel_g - flat.contig_off[ctg]
-    col_off, _, code = api.gather_columns(t, flat, pile, ctg, pos, sel_d)
-    c0, c1, c2, k0, k1, tie = api.column_top3(col_off, code)
-    pile_h = pile.cpu().numpy()
-    n_checked = 0
-    for c in range(flat.n_contigs):
-        ek0, ek1, ec0, ec1, ec2, _ = ol.column_top3(flat, pile_h, c)
+        g0 = int(flat.contig_off[c])
+        k0, k1, c0, c1, c2, depth = ol.column_top3(flat, hp, c)
+        md = float(tp["contig_mean_distance"][c])
+        fl = ol.call_variants_flags(flat, hp, c, md)
+        # (what K2 drops: positions nobody reads -- neither a candidate nor a column loop D could rescue, call_variants.cpp:751-756)
+        rescue = np.array([p for p in np.flatnonzero(c1 >= 5) if (int(k0[p]) % 5 != int(k1[p]) % 5 and ((int(k1[p]) - 33) % 5 != 4 or (int(k1[p]) // 5 % 5 != int(k0[p]) % 5 and int(k1[p]) // 25 % 5 != int(k0[p]) % 5)))], dtype=np.int64)
+        for p in list(np.flatnonzero((fl & 1).astype(bool))) + list(rescue):
+            assert g0 + int(p) in have, (c, int(p))
         for i in np.flatnonzero(ctg == c):
             p = int(pos[i])
-            assert (c0[i], c1[i], c2[i]) == (ec0[p], ec1[p], ec2[p])
-            distinct = ec0[p] != ec1[p] and ec1[p] != ec2[p] and ec1[p] != 0
-            assert bool(tie[i]) == (not distinct)
-            if not tie[i]:
-                assert (k0[i], k1[i]) == (ek0[p], ek1[p]); n_checked += 1
-    assert n_checked > 0
+            assert c1[p] >= 4
+            rs = np.arange(r0, r1)
+            cover = rs[(flat.rec_pos[r0:r1] <= p) & (p < flat.rec_qend[r0:r1])]
+            assert idx[off[i]:off[i + 1]].tolist() == (cover - r0).tolist()
+            assert code[off[i]:off[i + 1]].tolist() == [int(hp[flat.pile_off[r] + p - flat.rec_pos[r]]) for r in cover]
+
+
+def test_column_pass_leading_codes(taps):
+    """K2's second pass + k_column_top3_exact: the two leading codes and their counts of EVERY extracted column are the reference's
+    (call_variants.cpp:477-507), equal counts in the order of its hash map and its std::sort included"""
+    flat, tp, hp = taps
+    rec = tp["col_rec"]
+    n = 0
+    for c in range(flat.n_contigs):
+        k0, k1, c0, c1, c2, _ = ol.column_top3(flat, hp, c)
+        sel = np.flatnonzero(rec["contig"] == c)
+        p = rec["pos"][sel]
+        assert np.array_equal(rec["k0"][sel], k0[p]) and np.array_equal(rec["k1"][sel], k1[p])
+        assert np.array_equal(rec["c0"][sel].astype(np.int32), c0[p]) and np.array_equal(rec["c1"][sel].astype(np.int32), c1[p])
+        assert np.array_equal(rec["c2_zero"][sel] != 0, c2[p] == 0)
+        n += len(sel)
+    assert n == len(rec)
+
+
+def test_column_pass_candidates(taps):
+    """k_candidates_scan: the candidate SNPs (predicate + greedy spacing of call_variants.cpp:525-529, column-parallel on the device) and the
+    automatic ones (:531) of every contig, with the contig's own mean distance deciding the read minimum (:463-466); k_flag_block_* +
+    k_pack_flagged: the packed candidates are those columns, in order, records intact"""
+    from hairsplitter_amd import api  # noqa: F401
+    flat, tp, hp = taps
+    rec = tp["col_rec"]
+    HS_COL_CAND, HS_COL_AUTO = 1, 2
+    n_cand = 0
+    for c in range(flat.n_contigs):
+        fl = ol.call_variants_flags(flat, hp, c, float(tp["contig_mean_distance"][c]))
+        sel = np.flatnonzero(rec["contig"] == c)
+        p = rec["pos"][sel]
+        got_c = (rec["flags"][sel] & HS_COL_CAND) != 0
+        got_a = (rec["flags"][sel] & HS_COL_AUTO) != 0
+        assert np.array_equal(got_c, (fl[p] & 1) != 0)
+        assert np.array_equal(got_a, (fl[p] & 2) != 0)
+        assert int(tp["contig_n_cand"][c]) == int((fl & 1).sum()) == int(got_c.sum())      # (no candidate outside the extracted columns)
+        n_cand += int(got_c.sum())
+    cand_cols = np.flatnonzero((rec["flags"] & HS_COL_CAND) != 0)
+    assert len(tp["cand_rec"]) == n_cand and np.array_equal(tp["cand_col"], cand_cols.astype(np.int32))
+    assert np.array_equal(tp["cand_rec"].view(np.uint8), rec[cand_cols].view(np.uint8))
+
+
+def test_column_pass_candidate_bit_sets(taps):
+    """k_cand_bits: every candidate column as loop A reads it (hs::CandBits) -- one bit set per distinct code in the order the column's
+    entries bring them, bit k = the read of rank k by (start position, index) on its contig -- holds exactly the column's (read, code) pairs"""
+    flat, tp, hp = taps
+    off, idx, code = tp["col_off"], tp["col_idx"], tp["col_code"]
+    bits, words = tp["cand_bits"], tp["cand_words"]
+    rank_of = {}
+    for c in range(flat.n_contigs):
+        r0, r1 = int(flat.contig_rec_off[c]), int(flat.contig_rec_off[c + 1])
+        order = np.lexsort((np.arange(r1 - r0), flat.rec_pos[r0:r1]))
+        rk = np.zeros(r1 - r0, np.int64); rk[order] = np.arange(r1 - r0)
+        rank_of[c] = rk
+    ref_span_end = flat.rec_pos + np.asarray(flat.rec_refspan)
+    for k, col in enumerate(tp["cand_col"]):
+        h = bits[k]
+        c = int(tp["cand_rec"]["contig"][k])
+        r0 = int(flat.contig_rec_off[c])
+        ci, cc = idx[off[col]:off[col + 1]], code[off[col]:off[col + 1]]
+        assert int(h["n_entries"]) == len(ci) and int(h["idx_min"]) == int(ci[0]) and int(h["idx_max"]) == int(ci[-1])
+        rk = rank_of[c][ci]
+        assert int(h["wlo"]) == int(rk.min() >> 6) and int(h["n_words"]) == int(rk.max() >> 6) - int(rk.min() >> 6) + 1
+        assert int(h["reach"]) == int(ref_span_end[r0 + ci].max())
+        slots = list(dict.fromkeys(int(x) for x in cc))
+        assert int(h["n_slots"]) == len(slots)
+        W, o = int(h["n_words"]), int(h["word_off"])
+        blk = words[o:o + W * (len(slots) + 1) + (len(slots) + 7) // 8]
+        exp = np.zeros((len(slots) + 1, W), np.uint64)
+        for r, x in zip(rk, cc):
+            w, b = int(r >> 6) - int(h["wlo"]), np.uint64(1) << np.uint64(int(r) & 63)
+            exp[0, w] |= b; exp[1 + slots.index(int(x)), w] |= b
+        assert np.array_equal(blk[:W * (len(slots) + 1)].reshape(len(slots) + 1, W), exp)
+        assert blk[W * (len(slots) + 1):].view(np.uint8)[:len(slots)].tolist() == slots
 
 
 @pytest.mark.parametrize("n", [0, 1, 63, 4095, 4096, 4097, 70_001, 1_000_000, 4_300_000])
@@ -233,27 +302,6 @@ def test_exclusive_scan_sizes(n):
     exp = np.zeros(n + 1, np.int64)
     np.cumsum(v, dtype=np.int64, out=exp[1:])
     assert np.array_equal(api.exclusive_scan(v), exp)
-
-
-def test_pack_columns_copies_the_listed_columns(batch):
-    """K3c: any subset of the extracted columns, in any order (also none, also all), lands back to back and intact"""
-    from hairsplitter_amd import api
-    flat, t = batch
-    pile, _ = api.pileup(t, flat)
-    _, sel_g, sel_d = api.column_stats(t, flat, pile, min_second=2)
-    order = np.argsort(sel_g)
-    sel_g = sel_g[order]; sel_d = sel_d[order]
-    ctg = np.searchsorted(flat.contig_off, sel_g, side="right") - 1
-    pos = sel_g - flat.contig_off[ctg]
-    col_off, idx, code = api.gather_columns(t, flat, pile, ctg, pos, sel_d)
-    n = len(col_off) - 1
-    rng = np.random.default_rng(5)
-    for ids in (np.arange(n), np.zeros(0, np.int64), rng.permutation(n)[: max(1, n // 3)], np.array([n - 1, 0, n - 1])):
-        off, pidx, pcode = api.pack_columns(col_off, idx, code, ids)
-        assert off[-1] == sum(int(col_off[i + 1] - col_off[i]) for i in ids)
-        for k, i in enumerate(ids):
-            assert np.array_equal(pidx[off[k]:off[k + 1]], idx[col_off[i]:col_off[i + 1]])
-            assert np.array_equal(pcode[off[k]:off[k + 1]], code[col_off[i]:col_off[i + 1]])
 
 
 def test_stage3_result_equals_oracle_pipeline(request, batch, built):
@@ -431,30 +479,6 @@ def test_read_graphs_match_oracle(built, regime):
                 assert g.get(r, []) == want[r], (regime, err, c, r)
         if regime == "ties":
             assert n_host > 0
-
-
-def test_chinese_whispers_matches_oracle(built):
-    """K7 == chinese_whispers_high_memory (cluster_graph.cpp:240-310): labels and number of sweeps."""
-    from hairsplitter_amd import api
-    rng = np.random.default_rng(9)
-    for N, deg, nblocks in [(1, 0, 1), (8, 2, 2), (100, 6, 3), (333, 12, 4), (700, 70, 5)]:
-        block = rng.integers(0, nblocks, N)
-        adj = [set() for _ in range(N)]
-        for i in range(N):
-            for _ in range(deg):
-                j = int(rng.integers(0, N))
-                if j != i and (block[i] == block[j] or rng.random() < 0.15):
-                    adj[i].add(j); adj[j].add(i)
-        adj_l = [sorted(a) for a in adj]
-        mask = (rng.random(N) < 0.8).astype(np.uint8)
-        perm = ol.shuffled_order(N)
-        inits = np.stack([np.arange(N), rng.integers(0, max(1, N // 3), N), np.where(rng.random(N) < 0.2, -1, rng.integers(0, N, N))]).astype(np.int32)
-        got, sweeps = api.chinese_whispers(adj_l, perm, mask, inits)
-        for k in range(inits.shape[0]):
-            exp, sw = ol.chinese_whispers(adj_l, mask, inits[k])
-            assert np.array_equal(got[k], exp), (N, k)
-            assert sweeps[k] == sw
-            assert np.all(got[k][mask == 0] == -2)
 
 
 def test_myers_matches_edlib_vectors_and_oracle(built):
