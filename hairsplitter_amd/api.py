@@ -21,7 +21,7 @@ if os.environ.get("HS_LIB_AB"):      # (tools/gpu_ab_lib.sh: another build of th
 SYMBOLS = [
     "hs_cv_batch_set_ploidy", "hs_version", "hs_last_error", "hs_device_count", "hs_warmup", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
-    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_tile_plan", "hs_column_stats_tiled", "hs_cv_column_pass_taps", "hs_cv_taps_destroy", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_partition_pair_distance", "hs_snp_planes", "hs_simdiff", "hs_read_graphs",
+    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_tile_plan", "hs_column_stats_tiled", "hs_cv_column_pass_taps", "hs_cv_taps_destroy", "hs_sr_run_taps", "hs_sr_taps_destroy", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_partition_pair_distance", "hs_snp_planes", "hs_simdiff", "hs_read_graphs",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_pipeline_thread_devices", "hs_cv_batch_device", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main", "hs_call_variants_epilogue",
     "hs_pipeline_run_fused", "hs_realign_paf", "hs_pipeline_set_option", "hs_pipeline_groups", "hs_pipeline_group_range", "hs_pipeline_group_cv", "hs_pipeline_sparse_labels", "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_kernel_stats_every", "hs_host_wait_stats", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
@@ -536,6 +536,12 @@ class _SrResultOwner:
             pass
 
 
+class _SrTaps(C.Structure):
+    _fields_ = [("n_windows", C.c_int32), ("win_contig", C.POINTER(C.c_int32)), ("win_start", C.POINTER(C.c_int32)), ("win_row0", C.POINTER(C.c_int64)),
+                ("mask_ids", C.POINTER(C.c_int32)), ("run_begin", C.POINTER(C.c_int64)), ("run_snp", C.POINTER(C.c_int32)), ("run_off", C.POINTER(C.c_int64)),
+                ("run_labels", C.POINTER(C.c_int32)), ("third", C.POINTER(C.c_int32))]
+
+
 def _sr_result_to_dict(res, Cn, take_ownership=False):
     """take_ownership: the labels (tens of MB per batch) are returned as a view of the C result instead of a copy; the
     result is destroyed when that array (and every view of it) is gone, and the caller must not destroy it."""
@@ -567,8 +573,10 @@ def _owned_view_i32(res, ptr, n):
 
 def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory: bool = False, amplicon: bool = False,
                    seed: int = 12345, n_threads: int = 0, ploidy: Optional[Sequence[int]] = None,
-                   rarest_strain_abundance: float = 0.0, window_size: Optional[int] = None) -> Dict:
-    """Stage 4 on the in-memory result of stage 3 == HS_separate_reads without the .col round trip
+                   rarest_strain_abundance: float = 0.0, window_size: Optional[int] = None, taps: bool = False) -> Dict:
+    """(taps=True: through hs_sr_run_taps -- out["taps"] holds what the kernels of the clustering chain left, out["contigs"] the per-contig
+    inputs as numpy arrays, for the tests.)
+    Stage 4 on the in-memory result of stage 3 == HS_separate_reads without the .col round trip
     (separate_reads.cpp:1440-1739). READ limits are (position_2_1, position_2_2) of the records
     (call_variants.cpp:1186-1189 -> separate_reads.cpp:176-179)."""
     require_gpu()
@@ -576,6 +584,7 @@ def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory:
     Cn = flat.n_contigs
     arr = (SrContig * Cn)()
     keep = []   # keep numpy buffers alive
+    per_contig = []
     ops = flat.cigar & 0xF
     lens = (flat.cigar >> 4).astype(np.int64)
     refc = np.where((ops == 0) | (ops == 2) | (ops == 7) | (ops == 8), lens, 0)
@@ -609,6 +618,8 @@ def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory:
                 snp_pos, snp_ref, snp_alt = _np(snp_pos, np.int32), _np(snp_ref, np.uint8), _np(snp_alt, np.uint8)
                 s1 = s0 + len(snp_pos)
         keep += [rs, re, snp_pos, snp_ref, snp_alt, col_off, col_idx, col_code]
+        per_contig.append({"read_start": rs, "read_end": re, "snp_pos": snp_pos, "snp_ref": snp_ref, "snp_alt": snp_alt, "col_off": col_off, "col_idx": col_idx,
+                           "col_code": col_code, "length": int(flat.contig_off[c + 1] - flat.contig_off[c])})
         a = arr[c]
         a.length = int(flat.contig_off[c + 1] - flat.contig_off[c])
         a.n_reads = r1 - r0
@@ -619,8 +630,15 @@ def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory:
         a.ploidy = int(ploidy[c]) if ploidy is not None else 0
     w = lib.hs_sr_window_size(arr, C.c_int32(Cn), C.c_int32(1 if amplicon else 0)) if window_size is None else int(window_size)
     res = C.POINTER(SrResult)()
-    _check(lib.hs_sr_run(arr, C.c_int32(Cn), C.c_int32(w), C.c_float(error_rate), C.c_int32(1 if low_memory else 0),
-                         C.c_uint32(seed), C.c_int32(n_threads), C.byref(res)))
+    tp = C.POINTER(_SrTaps)()
+    if taps:
+        lib.hs_sr_run_taps.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint32, C.c_int32, C.POINTER(C.POINTER(SrResult)), C.POINTER(C.POINTER(_SrTaps))]
+        lib.hs_sr_taps_destroy.argtypes = [C.POINTER(_SrTaps)]; lib.hs_sr_taps_destroy.restype = None
+        _check(lib.hs_sr_run_taps(C.cast(arr, C.c_void_p), C.c_int32(Cn), C.c_int32(w), C.c_float(error_rate), C.c_int32(1 if low_memory else 0),
+                                  C.c_uint32(seed), C.c_int32(n_threads), C.byref(res), C.byref(tp)))
+    else:
+        _check(lib.hs_sr_run(arr, C.c_int32(Cn), C.c_int32(w), C.c_float(error_rate), C.c_int32(1 if low_memory else 0),
+                             C.c_uint32(seed), C.c_int32(n_threads), C.byref(res)))
     r = res.contents
     win_off = np.ctypeslib.as_array(r.win_off, (Cn + 1,)).copy()
     W = int(win_off[-1])
@@ -639,6 +657,17 @@ def separate_reads(cv_out: Dict, flat: FlatBatch, error_rate: float, low_memory:
         "simdiff_bytes": int(r.simdiff_bytes),
     }
     lib.hs_sr_result_destroy(res)
+    if taps:
+        t = tp.contents
+        Wc = int(t.n_windows)
+        a = lambda ptr, n, dt: np.ctypeslib.as_array(ptr, (max(n, 1),))[:n].astype(dt).copy()
+        row0 = a(t.win_row0, Wc + 1, np.int64); rb = a(t.run_begin, Wc + 1, np.int64)
+        n_runs = int(rb[-1]); ro = a(t.run_off, n_runs + 1, np.int64)
+        out["taps"] = {"win_contig": a(t.win_contig, Wc, np.int32), "win_start": a(t.win_start, Wc, np.int32), "win_row0": row0, "mask_ids": a(t.mask_ids, int(row0[-1]), np.int32),
+                       "run_begin": rb, "run_snp": a(t.run_snp, n_runs, np.int32), "run_off": ro, "run_labels": a(t.run_labels, int(ro[-1]), np.int32),
+                       "third": a(t.third, int(row0[-1]), np.int32)}
+        out["contigs"] = per_contig
+        lib.hs_sr_taps_destroy(tp)
     return out
 
 

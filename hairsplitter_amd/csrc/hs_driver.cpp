@@ -558,7 +558,7 @@ int cv_run(CvDeviceOps& dev, const CvMeta& b, float automatic_snp_threshold, int
 // stage 4
 // ---------------------------------------------------------------------------------------------------
 int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
-           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out, SrSparseLabels* sparse, SrWorkspace* keep) {
+           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out, SrSparseLabels* sparse, SrWorkspace* keep, SrTaps* taps) {
     Laps laps("sr");
     if (n_threads <= 0) n_threads = host_threads();
     const int C = n_contigs;
@@ -881,8 +881,23 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
     SrChainStats cst;
     {
         const double t0 = now_ms();
+        if (taps) dev.tap_chain(&taps->run_off, &taps->run_labels);
         if (!ch.win.empty()) { if (int rc = dev.cw_chain(ch, chain_labels, final_labels, final_ok, &k_ms[1], &cst)) return rc; }
         dev_ms += now_ms() - t0;
+    }
+    if (taps) {
+        dev.tap_chain(nullptr, nullptr);
+        taps->win_row0.assign(1, 0); taps->run_begin.assign(1, 0);
+        for (size_t k = 0; k < ch.win.size(); ++k) {
+            const WRef& wr = wrefs[(size_t)ch.win[k]];
+            const SrWindowPlan& w = st[(size_t)wr.c].windows[(size_t)wr.w];
+            taps->win_contig.push_back(wr.c); taps->win_start.push_back(w.start);
+            taps->mask_ids.insert(taps->mask_ids.end(), w.ids.begin(), w.ids.end());
+            taps->win_row0.push_back((int64_t)taps->mask_ids.size());
+            for (int snp : w.local_snps) taps->run_snp.push_back(snp);
+            taps->run_begin.push_back((int64_t)taps->run_snp.size());
+        }
+        taps->third = chain_labels;
     }
 
     const double t_waves_done = now_ms();

@@ -236,6 +236,8 @@ struct SrDeviceOps {
     virtual int cw_chain(const CwChain& chain, std::vector<int32_t>& labels, std::vector<int32_t>& final_labels,
                          std::vector<uint8_t>& final_ok, float k_ms[3], SrChainStats* stats) = 0;
     virtual int cw(CwWave& wave, float* k_ms) = 0;
+    // (test taps: the next cw_chain() also leaves the labels of its per-SNP runs -- run_off / run_labels -- and always fills `labels`)
+    virtual void tap_chain(std::vector<int64_t>* run_off, std::vector<int32_t>* run_labels) { (void)run_off; (void)run_labels; }
     // The SNP columns of the call may be with the implementation already (stage 3 left them on the device, in the order and with
     // the offsets of CwChain::col_off): then CwChain's col_idx / col_code stay empty and ...
     // create_read_graph_low_memory on the device (window-local sim / diff from the bit rows); false: the caller builds those rows
@@ -267,8 +269,20 @@ struct SrSparseLabels {
 // state of a stage-4 call that is worth keeping for the next one on the same contigs (a pipeline group runs the same contigs step
 // after step): the per-contig plans with their storage, the shuffled visiting orders
 struct SrWorkspace { std::vector<SrContigState> st; };
+// Test taps of the clustering chain of a stage-4 call (hs_sr_run_taps): the windows that have seeding SNPs, in chain order, with what the
+// kernels of the chain left -- the labels of every per-SNP Chinese-Whispers run (k_cw_seed_sets + k_cw_seeded_lanes / _rows / _wave) and
+// of the third run (inside k_window_tail), as window-local node ids / cluster indices
+struct SrTaps {
+    std::vector<int32_t> win_contig, win_start;   // contig index in the call, first position of the window
+    std::vector<int64_t> win_row0;                // [Wc + 1] into mask_ids
+    std::vector<int32_t> mask_ids;                // the window's reads (ascending)
+    std::vector<int64_t> run_begin;               // [Wc + 1] the window's per-SNP runs
+    std::vector<int32_t> run_snp;                 // SNP index on its contig of every run
+    std::vector<int64_t> run_off;                 // [runs + 1] into run_labels (m labels per run)
+    std::vector<int32_t> run_labels, third;       // third: [win_row0.back()] what the third run left
+};
 int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
-           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out, SrSparseLabels* sparse = nullptr, SrWorkspace* keep = nullptr);
+           int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out, SrSparseLabels* sparse = nullptr, SrWorkspace* keep = nullptr, SrTaps* taps = nullptr);
 
 int sr_run_from_cv(SrDeviceOps& dev, const CvMeta& meta, int c0, int c1, const hs_cv_result* cv, float error_rate, float rarest_strain_abundance,
                    int32_t low_memory, int32_t amplicon, uint32_t seed, int32_t n_threads, int32_t window_size, hs_sr_result** out,

@@ -430,6 +430,25 @@ typedef struct hs_sr_result {
 
 int hs_sr_run(const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate,
               int32_t low_memory, uint32_t seed, int32_t n_threads, hs_sr_result** out);
+
+/* Test taps of the clustering chain of stage 4 exactly as hs_sr_run queues it: for every window that has seeding SNPs (chain order) its
+ * contig, first position and reads, and what the kernels of the chain left -- the labels of every per-SNP Chinese-Whispers run
+ * (separate_reads.cpp:1674-1705: k_cw_seed_sets + k_cw_seeded_lanes / k_cw_seeded_rows / k_cw_seeded_wave) as READ indices, and the labels of
+ * the run behind finalize_clustering's small-cluster filter (:924-970, inside k_window_tail). The finished labels are in the result. */
+typedef struct hs_sr_taps {
+    int32_t n_windows;
+    int32_t* win_contig; int32_t* win_start;      /* [n_windows] */
+    int64_t* win_row0;                            /* [n_windows + 1] into mask_ids / third */
+    int32_t* mask_ids;                            /* the window's reads, ascending */
+    int64_t* run_begin;                           /* [n_windows + 1] the window's per-SNP runs */
+    int32_t* run_snp;                             /* SNP index on its contig of every run */
+    int64_t* run_off;                             /* [runs + 1] into run_labels: m labels per run, in the order of mask_ids */
+    int32_t* run_labels;                          /* label = the read index the label stands for */
+    int32_t* third;                               /* cluster index (-1: dropped with its small cluster) */
+} hs_sr_taps;
+int hs_sr_run_taps(const hs_sr_contig* contigs, int32_t n_contigs, int32_t window_size, float error_rate, int32_t low_memory, uint32_t seed,
+                   int32_t n_threads, hs_sr_result** out, hs_sr_taps** taps);
+void hs_sr_taps_destroy(hs_sr_taps* t);
 void hs_sr_result_destroy(hs_sr_result* r);
 /* Stage 4 directly on the result of hs_cv_run, without the .col text round trip (call_variants.cpp:1197-1204 <->
  * separate_reads.cpp:84-170). READ limits come from the records (input_output.cpp:503-511); SNPs whose second base is

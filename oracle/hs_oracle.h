@@ -138,6 +138,11 @@ std::vector<ColContig> parse_column_file(const std::string& file, int max_covera
                                          float rarest_strain_abundance);                // :46-190
 
 struct Window { int start, end; std::vector<int> labels; };
+// test taps (tests only): when g_window_taps is set, separate_reads_on_contig leaves, for every window that builds a read graph, its reads,
+// the labels of every per-SNP Chinese-Whispers run (separate_reads.cpp:1674-1705) and of the run behind finalize_clustering's small-cluster
+// filter (:924-970), both restricted to the window's reads
+struct WindowTap { int start = 0; std::vector<int> mask_ids; std::vector<int> run_snp; std::vector<std::vector<int>> runs; std::vector<int> third; };
+extern thread_local std::vector<WindowTap>* g_window_taps;
 
 // dense restatement of the two Eigen products (:374-433)
 void list_similarities_and_differences(const std::vector<Column>& snps, int N,

@@ -256,6 +256,53 @@ template <class T> static T* hso_dup(const std::vector<T>& v) {
 
 extern "C" {
 
+// One contig through separate_reads_on_contig (separate_reads.cpp:1508-1739) with the test taps on: the windows that build a read graph,
+// their reads, the labels of their per-SNP Chinese-Whispers runs, of the run behind the small-cluster filter, and the finished labels of
+// EVERY window of the contig. Arrays are malloc'ed (hso_sr_taps_free).
+struct hso_sr_taps {
+    int32_t n_tap; int32_t* tap_start; int64_t* tap_row0; int32_t* mask_ids; int64_t* run_begin; int32_t* run_snp; int32_t* run_labels /* runs x m, window after window */; int32_t* third;
+    int32_t n_windows; int32_t* win_start; int32_t* win_end; int32_t* win_labels /* n_windows x N */;
+};
+void hso_sr_taps_free(hso_sr_taps* t) {
+    if (!t) return;
+    std::free(t->tap_start); std::free(t->tap_row0); std::free(t->mask_ids); std::free(t->run_begin); std::free(t->run_snp); std::free(t->run_labels); std::free(t->third);
+    std::free(t->win_start); std::free(t->win_end); std::free(t->win_labels); std::free(t);
+}
+int hso_sr_contig_taps(int32_t n_reads, int64_t length, const int32_t* read_start, const int32_t* read_end, int32_t n_snps, const int32_t* snp_pos,
+                       const uint8_t* snp_ref, const uint8_t* snp_alt, const int64_t* col_off, const int32_t* col_idx, const uint8_t* col_code,
+                       int32_t window, float error_rate, int32_t low_memory, uint32_t seed, hso_sr_taps** out) {
+    hso::ColContig c;
+    c.length = (long)length;
+    c.read_lines.assign((size_t)n_reads, std::string());
+    for (int r = 0; r < n_reads; ++r) c.readLimits.push_back(std::make_pair((int)read_start[r], (int)read_end[r]));
+    for (int s = 0; s < n_snps; ++s) {
+        hso::Column col;
+        col.pos = snp_pos[s]; col.ref_base = snp_ref[s]; col.second_base = snp_alt[s];
+        for (int64_t e = col_off[s]; e < col_off[s + 1]; ++e) { col.readIdxs.push_back((unsigned)col_idx[e]); col.content.push_back(col_code[e]); }
+        c.snps.push_back(col);
+    }
+    std::vector<hso::WindowTap> taps;
+    hso::g_window_taps = &taps;
+    std::vector<hso::Window> ws = hso::separate_reads_on_contig(c, window, error_rate, low_memory != 0, low_memory != 0, 0, seed);
+    hso::g_window_taps = nullptr;
+    hso_sr_taps* t = (hso_sr_taps*)std::calloc(1, sizeof(hso_sr_taps));
+    std::vector<int32_t> start, mask, rsnp, rlab, third, wst, wen, wlab; std::vector<int64_t> row0(1, 0), rb(1, 0);
+    for (const hso::WindowTap& w : taps) {
+        start.push_back(w.start);
+        mask.insert(mask.end(), w.mask_ids.begin(), w.mask_ids.end()); row0.push_back((int64_t)mask.size());
+        for (size_t k = 0; k < w.runs.size(); ++k) { rsnp.push_back(w.run_snp[k]); rlab.insert(rlab.end(), w.runs[k].begin(), w.runs[k].end()); }
+        rb.push_back((int64_t)rsnp.size());
+        if (w.third.size() == w.mask_ids.size()) third.insert(third.end(), w.third.begin(), w.third.end());
+        else third.insert(third.end(), w.mask_ids.size(), -9);      // (a window without runs never gets there)
+    }
+    for (const hso::Window& w : ws) { wst.push_back(w.start); wen.push_back(w.end); wlab.insert(wlab.end(), w.labels.begin(), w.labels.end()); }
+    t->n_tap = (int32_t)taps.size(); t->tap_start = hso_dup(start); t->tap_row0 = hso_dup(row0); t->mask_ids = hso_dup(mask); t->run_begin = hso_dup(rb);
+    t->run_snp = hso_dup(rsnp); t->run_labels = hso_dup(rlab); t->third = hso_dup(third);
+    t->n_windows = (int32_t)ws.size(); t->win_start = hso_dup(wst); t->win_end = hso_dup(wen); t->win_labels = hso_dup(wlab);
+    *out = t;
+    return 0;
+}
+
 void hso_blocks_free(hso_blocks* b) {
     if (!b) return;
     std::free(b->names); std::free(b->extra); std::free(b->n_read_lines); std::free(b->rec_off); std::free(b->a); std::free(b->b); std::free(b->c);

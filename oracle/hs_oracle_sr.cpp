@@ -408,6 +408,8 @@ std::vector<int> merge_wrongly_split_haplotypes(const std::vector<int>& clustere
     return out;
 }
 
+thread_local std::vector<WindowTap>* g_window_taps = nullptr;
+
 // separate_reads.cpp:840-885
 static std::vector<int> merge_clusterings(const std::vector<std::vector<int>>& localClusters,
                                           const std::vector<std::vector<int>>& graph, const std::vector<bool>& mask,
@@ -456,6 +458,7 @@ static void finalize_clustering(const std::vector<Column>& snps, const std::vect
         }
     }
     haplotypes = chinese_whispers(graph, merged, mask, seed);
+    if (g_window_taps && !g_window_taps->empty()) { WindowTap& t = g_window_taps->back(); for (int r : t.mask_ids) t.third.push_back(haplotypes[(size_t)r]); }
     std::map<int, int> toIndex;
     toIndex[-1] = -1;
     if (snps.size() == 0) toIndex[-1] = 0;
@@ -568,7 +571,10 @@ std::vector<Window> separate_reads_on_contig(const ColContig& c, int sizeOfWindo
 
         std::vector<std::vector<int>> localClusters;                                            // :1673-1705
         int lastpos = -10;
+        if (g_window_taps) { g_window_taps->emplace_back(); g_window_taps->back().start = chunk * sizeOfWindow; for (int r = 0; r < N; ++r) if (mask[(size_t)r]) g_window_taps->back().mask_ids.push_back(r); }
+        int snp_index = -1;
         for (const Column& snp : snps) {
+            ++snp_index;
             if (snp.pos >= chunk * sizeOfWindow && snp.pos < chunk * sizeOfWindow + sizeOfWindow && snp.pos > lastpos + 10) {
                 lastpos = snp.pos;
                 std::map<unsigned char, int> charToIndex;
@@ -581,6 +587,7 @@ std::vector<Window> separate_reads_on_contig(const ColContig& c, int sizeOfWindo
                     }
                 }
                 localClusters.push_back(chinese_whispers(graph_now, start, mask, seed));
+                if (g_window_taps) { WindowTap& t = g_window_taps->back(); t.run_snp.push_back(snp_index); t.runs.emplace_back(); for (int r : t.mask_ids) t.runs.back().push_back(localClusters.back()[(size_t)r]); }
             }
         }
         std::vector<int> haplotypes(N, -2);

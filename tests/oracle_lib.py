@@ -54,6 +54,40 @@ def call_variants_flags(flat, pile, c, mean_error, automatic_snp_threshold=0.33)
     return flags[:L]
 
 
+class _SrTapsO(C.Structure):
+    _fields_ = [("n_tap", C.c_int32), ("tap_start", C.POINTER(C.c_int32)), ("tap_row0", C.POINTER(C.c_int64)), ("mask_ids", C.POINTER(C.c_int32)),
+                ("run_begin", C.POINTER(C.c_int64)), ("run_snp", C.POINTER(C.c_int32)), ("run_labels", C.POINTER(C.c_int32)), ("third", C.POINTER(C.c_int32)),
+                ("n_windows", C.c_int32), ("win_start", C.POINTER(C.c_int32)), ("win_end", C.POINTER(C.c_int32)), ("win_labels", C.POINTER(C.c_int32))]
+
+
+def sr_contig_taps(ctg, window, error_rate, low_memory=False, seed=12345):
+    """One contig (dict of numpy arrays as hairsplitter_amd.api.separate_reads(taps=True) leaves them in out["contigs"]) through the oracle's
+    separate_reads_on_contig with its test taps on: per graph window its start, reads, per-SNP run labels (read ids), the labels of the run behind the
+    small-cluster filter; and the finished labels of every window."""
+    L = lib()
+    L.hso_sr_contig_taps.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int32, C.c_float, C.c_int32, C.c_uint32, C.POINTER(C.POINTER(_SrTapsO))]
+    L.hso_sr_taps_free.argtypes = [C.POINTER(_SrTapsO)]; L.hso_sr_taps_free.restype = None
+    N, S = len(ctg["read_start"]), len(ctg["snp_pos"])
+    tp = C.POINTER(_SrTapsO)()
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    keep = [np.ascontiguousarray(ctg[k]) for k in ("read_start", "read_end", "snp_pos", "snp_ref", "snp_alt", "col_off", "col_idx", "col_code")]
+    rc = L.hso_sr_contig_taps(C.c_int32(N), C.c_int64(ctg["length"]), ptr(keep[0]), ptr(keep[1]), C.c_int32(S), ptr(keep[2]), ptr(keep[3]), ptr(keep[4]), ptr(keep[5]),
+                              ptr(keep[6]), ptr(keep[7]), C.c_int32(window), C.c_float(error_rate), C.c_int32(1 if low_memory else 0), C.c_uint32(seed), C.byref(tp))
+    assert rc == 0
+    t = tp.contents
+    a = lambda p, n, dt: np.ctypeslib.as_array(p, (max(n, 1),))[:n].astype(dt).copy()
+    nt, nw = int(t.n_tap), int(t.n_windows)
+    row0 = a(t.tap_row0, nt + 1, np.int64); rb = a(t.run_begin, nt + 1, np.int64)
+    m = np.diff(row0)
+    n_lab = int(sum(int(m[k]) * int(rb[k + 1] - rb[k]) for k in range(nt)))
+    out = {"tap_start": a(t.tap_start, nt, np.int32), "tap_row0": row0, "mask_ids": a(t.mask_ids, int(row0[-1]), np.int32), "run_begin": rb,
+           "run_snp": a(t.run_snp, int(rb[-1]), np.int32), "run_labels": a(t.run_labels, n_lab, np.int32), "third": a(t.third, int(row0[-1]), np.int32),
+           "win_start": a(t.win_start, nw, np.int32), "win_end": a(t.win_end, nw, np.int32), "win_labels": a(t.win_labels, nw * N, np.int32).reshape(nw, N) if nw else np.zeros((0, N), np.int32)}
+    L.hso_sr_taps_free(tp)
+    return out
+
+
 def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1, col_c1, col_is_cand, part_off, part_state_off, part_state,
                           n_reads_of_contig):
     n = len(col_contig)

@@ -481,6 +481,70 @@ def test_read_graphs_match_oracle(built, regime):
             assert n_host > 0
 
 
+@pytest.mark.parametrize("kind", ["dip", "multi", "penta"])
+def test_clustering_chain_kernels_match_oracle(built, kind):
+    """The clustering chain of stage 4 as hs_sr_run queues it, kernel by kernel against the oracle's separate_reads_on_contig (test taps on both
+    sides): for every window with seeding SNPs the same reads (k_window_masks), the labels of every per-SNP Chinese-Whispers run
+    (separate_reads.cpp:1674-1705, cluster_graph.cpp:240-310: k_cw_seed_sets + k_cw_seeded_lanes / _rows / _wave on the graphs of
+    k_read_graph_rows, visiting orders of k_cw_visit_lists), the labels of the run behind finalize_clustering's small-cluster filter (:897-970,
+    first half of k_window_tail) as a partition of the window's reads, and the finished labels of every window (:973-993, cluster_graph.cpp:402-501,
+    separate_reads.cpp:1007-1327: the rest of k_window_tail)."""
+    from hairsplitter_amd import api, synth
+    if kind == "penta":
+        contigs = [synth.make_contig(21, 0, 24_000, 5, 0.012, 60, "ont")]
+    else:
+        contigs = _contigs(kind)
+    flat = api.FlatBatch(contigs)
+    b = api.CvBatch(flat)
+    cv = b.run(0.33)
+    b.close()
+    er = min(float("%g" % np.float32(cv["error_rate"])), 0.15)
+    out = api.separate_reads(cv, flat, er, taps=True)
+    tp = out["taps"]
+    n_runs = n_win = 0
+    for c, ctg in enumerate(out["contigs"]):
+        o = ol.sr_contig_taps(ctg, out["window_size"], er)
+        N = len(ctg["read_start"])
+        # the finished labels of every window of the contig
+        w0, w1 = int(out["win_off"][c]), int(out["win_off"][c + 1])
+        assert w1 - w0 == len(o["win_start"])
+        for k in range(w1 - w0):
+            assert int(out["win_start"][w0 + k]) == int(o["win_start"][k]) and int(out["win_end"][w0 + k]) == int(o["win_end"][k])
+            got = out["labels"][int(out["label_off"][w0 + k]):int(out["label_off"][w0 + k + 1])]
+            assert np.array_equal(got, o["win_labels"][k]), (c, k)
+        # the chain's windows of this contig, in order: those of the oracle that have runs
+        mine = np.flatnonzero(tp["win_contig"] == c)
+        theirs = [k for k in range(len(o["tap_start"])) if o["run_begin"][k + 1] > o["run_begin"][k]]
+        assert [int(tp["win_start"][k]) for k in mine] == [int(o["tap_start"][k]) for k in theirs]
+        o_lab_off = 0
+        o_off = {}
+        for k in range(len(o["tap_start"])):
+            m = int(o["tap_row0"][k + 1] - o["tap_row0"][k])
+            o_off[k] = o_lab_off
+            o_lab_off += m * int(o["run_begin"][k + 1] - o["run_begin"][k])
+        for km, ko in zip(mine, theirs):
+            ids = tp["mask_ids"][int(tp["win_row0"][km]):int(tp["win_row0"][km + 1])]
+            oid = o["mask_ids"][int(o["tap_row0"][ko]):int(o["tap_row0"][ko + 1])]
+            assert np.array_equal(ids, oid)
+            m = len(ids)
+            r0, r1 = int(tp["run_begin"][km]), int(tp["run_begin"][km + 1])
+            assert np.array_equal(tp["run_snp"][r0:r1], o["run_snp"][int(o["run_begin"][ko]):int(o["run_begin"][ko + 1])])
+            for i in range(r0, r1):
+                got = tp["run_labels"][int(tp["run_off"][i]):int(tp["run_off"][i]) + m]
+                exp = o["run_labels"][o_off[ko] + (i - r0) * m:o_off[ko] + (i - r0 + 1) * m]
+                assert np.array_equal(got, exp), (c, int(tp["win_start"][km]), i - r0)
+                n_runs += 1
+            # the third run: the same partition of the window's reads (the oracle numbers the clusters by first appearance before it goes on, :972-981)
+            g3 = tp["third"][int(tp["win_row0"][km]):int(tp["win_row0"][km + 1])]
+            e3 = o["third"][int(o["tap_row0"][ko]):int(o["tap_row0"][ko + 1])]
+            assert np.array_equal(g3 < 0, e3 < 0)
+            pairs = set(zip(g3[g3 >= 0].tolist(), e3[e3 >= 0].tolist()))
+            assert len(pairs) == len(set(p[0] for p in pairs)) == len(set(p[1] for p in pairs)), (c, int(tp["win_start"][km]))
+            n_win += 1
+        assert N >= 0
+    assert n_win > 0 and n_runs > n_win
+
+
 def test_myers_matches_edlib_vectors_and_oracle(built):
     """A1 == edlibAlign distance / first end location (golden vectors from the reference's bundled edlib)."""
     from hairsplitter_amd import api
