@@ -258,12 +258,25 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
     __shared__ int s_stack[4][120];
     __shared__ uint8_t s_first[4][128];
     __shared__ int s_fpos[4][128];
+    // place of every byte key in the iteration order of the reference's hash map while it has not grown past 16 buckets (tests/harness/
+    // rh8_static_order.cpp): up to 6 keys 8 buckets and the first multiplier, 7 to 12 keys 16 buckets and the second one; rank = home bucket << 5 |
+    // 31 - low five hash bits. Keys of different rank iterate in rank order whatever order they were inserted in.
+    __shared__ uint16_t s_rank8[256], s_rank16[256];
+    __shared__ int s_bucket[4][16];
     const int lane = lane_id();
     const int wv = wave_id();
     const int64_t n_cols = header_cols(header);
     int* __restrict__ h = s_hist[wv];
     __shared__ int s_ties[2];
     if (threadIdx.x < 2) s_ties[threadIdx.x] = 0;
+    {
+        unsigned long long x = (unsigned long long)threadIdx.x;
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33;
+        unsigned long long a = x * 0xc4ceb9fe1a85ec53ull; a ^= a >> 33;
+        unsigned long long b = x * (0xc4ceb9fe1a85ec53ull + 0xc4ceb9fe1a85ec54ull); b ^= b >> 33;
+        s_rank8[threadIdx.x] = (uint16_t)((((a >> 5) & 7ull) << 5) | (31ull - (a & 31ull)));
+        s_rank16[threadIdx.x] = (uint16_t)((((b >> 5) & 15ull) << 5) | (31ull - (b & 31ull)));
+    }
     __syncthreads();
     int my_ties = 0, my_big = 0;
     // a wavefront looks at 64 column records at a time and does the ones k_columns_compact left open (since K2 forms the leading codes itself:
@@ -300,7 +313,58 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
         // is all the path uses); a second count of zero means the fillers take part
         const bool tie = c0 == c1 || c1 == c2 || c1 == 0;
         (void)c3;
-        if (tie) {
+        bool settled = false;
+        if (tie && c0 < 8192) {
+            // Equal counts: std::sort on up to 16 pairs is an insertion sort, i.e. stable -- the pairs keep the order in which the hash map
+            // hands them over, and that order is the keys' rank (above) while the map holds at most 12 keys and no key has been pushed six
+            // slots from its bucket. All lanes: key = count << 18 | 1023 - rank << 8 | code, the three largest by wave maxima; two of the
+            // leading keys with the same count AND rank (the insertion order would decide), more keys, a far key: the emulator below.
+            const bool on_a = h[lane] > 0, on_b = h[lane + 64] > 0;
+            const int nd = __popcll(__ballot(on_a)) + __popcll(__ballot(on_b));
+            const int mkeys = nd + 3;      // + the zero-count fillers 0, 1, 2 (:492-494)
+            if (mkeys <= 12) {
+                const bool wide = mkeys > 6;
+                const uint16_t* __restrict__ rt = wide ? s_rank16 : s_rank8;
+                const int ra = rt[lane + 33], rb = lane + 64 + 33 < 256 ? rt[lane + 64 + 33] : 0, rf = rt[lane & 3];
+                bool far = false;
+                if (wide) {      // a key six or more slots from its home bucket takes the map's overflow path (info byte): not the static order
+                    if (lane < 16) s_bucket[wv][lane] = 0;
+                    wave_lds_sync();
+                    if (on_a) atomicAdd(&s_bucket[wv][ra >> 5], 1);
+                    if (on_b) atomicAdd(&s_bucket[wv][rb >> 5], 1);
+                    if (lane < 3) atomicAdd(&s_bucket[wv][rf >> 5], 1);
+                    wave_lds_sync();
+                    int carry = 0;
+                    for (int bkt = 0; bkt < 16; ++bkt) { const int cb = s_bucket[wv][bkt]; if (cb > 0 && carry + cb - 1 >= 6) far = true; carry = carry + cb - 1 > 0 ? carry + cb - 1 : 0; }
+                }
+                if (!far) {
+                    int ka = on_a ? ((h[lane] << 18) | ((1023 - ra) << 8) | (lane + 33)) : -1;
+                    int kb = on_b ? ((h[lane + 64] << 18) | ((1023 - rb) << 8) | (lane + 64 + 33)) : -1;
+                    int kf = lane < 3 ? (((1023 - rf) << 8) | lane) : -1;
+                    int tv[3];
+                    bool amb = false;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        int mine = ka > kb ? ka : kb;
+                        mine = kf > mine ? kf : mine;
+                        const int best = wave_max_i32(mine);
+                        tv[r] = best;
+                        const int same = __popcll(__ballot(ka >= 0 && (ka >> 8) == (best >> 8))) + __popcll(__ballot(kb >= 0 && (kb >> 8) == (best >> 8)))
+                                         + __popcll(__ballot(kf >= 0 && (kf >> 8) == (best >> 8)));
+                        amb = amb || same > 1;
+                        if (ka == best) ka = -1;
+                        if (kb == best) kb = -1;
+                        if (kf == best) kf = -1;
+                    }
+                    if (!amb) {
+                        k0 = tv[0] & 255; k1 = tv[1] & 255; c0 = tv[0] >> 18; c1 = tv[1] >> 18; c2 = tv[2] >> 18;
+                        settled = true;
+                        my_ties++;
+                    }
+                }
+            }
+        }
+        if (tie && !settled) {
             // the column's codes in the order in which its reads bring them: the first position of every code by LDS atomic minima
             // over a coalesced pass (instead of one lane walking the column byte by byte out of global memory), the rank of a code =
             // how many codes appear before it
