@@ -1110,6 +1110,16 @@ static __device__ __forceinline__ bool central_base_test_dev(int k0, int k1) {
 }
 
 // the 2x2 table of one column against one partition; wave-uniform result
+// place of a byte key in the iteration order of the reference's hash map while it has at most 12 keys (tests/harness/rh8_static_order.cpp): up to 6
+// keys 8 buckets and the first multiplier, 7 to 12 keys (`wide`) 16 buckets and the second one; rank = home bucket << 5 | 31 - low five hash bits
+static __device__ __forceinline__ int rh8_rank_dev(int key, bool wide) {
+    unsigned long long x = (unsigned long long)(key & 255);
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33;
+    x *= wide ? (0xc4ceb9fe1a85ec53ull + 0xc4ceb9fe1a85ec54ull) : 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return (int)((((x >> 5) & (wide ? 15ull : 7ull)) << 5) | (31ull - (x & 31ull)));
+}
+
 static __device__ Table2x2 column_vs_partition_dev(const int32_t* __restrict__ idx, const uint8_t* __restrict__ code, int n,
                                                    const int8_t* __restrict__ state, int ref, uint8_t* s_seen /* [128] */,
                                                    uint8_t* s_ord /* [260] */, int* s_ord_n /* [1] */, uint8_t* s_map /* [3 * 512]: the hash map's tables */) {
@@ -1166,9 +1176,38 @@ static __device__ Table2x2 column_vs_partition_dev(const int32_t* __restrict__ i
         if (nbest == 1) {
             second = b0 ? __builtin_amdgcn_readlane(sc[0], __builtin_ctzll(b0)) : __builtin_amdgcn_readlane(sc[1], __builtin_ctzll(b1));
         } else {
-            // tie: first of the tied keys in the hash map's iteration order (keys inserted in first-appearance order, then
-            // ref). One lane replays the insertions on the emulator and publishes the order; the tied slots are then
-            // looked up in that order.
+            // tie: first of the tied keys in the hash map's iteration order (keys inserted in first-appearance order, then ref). While the map has
+            // at most 12 keys that order is the keys' static rank (unless two tied keys share a rank, or a key sits six slots from its bucket) ...
+            bool resolved = false;
+            const int nkeys = nseen + (ref_seen ? 0 : 1);
+            if (nkeys <= 12) {
+                const bool wide = nkeys > 6;
+                const int rk = lane < nseen ? rh8_rank_dev(sc[0], wide) : 0x7fffffff;      // (at most 12 codes: slot 0 of the lanes only)
+                const int rref = rh8_rank_dev(ref, wide);
+                bool far = false;
+                if (wide) {
+                    int carry = 0;
+                    for (int bkt = 0; bkt < 16; ++bkt) {
+                        const int cb = __popcll(__ballot(lane < nseen && (rk >> 5) == bkt)) + ((!ref_seen && (rref >> 5) == bkt) ? 1 : 0);
+                        if (cb > 0 && carry + cb - 1 >= 6) far = true;
+                        carry = carry + cb - 1 > 0 ? carry + cb - 1 : 0;
+                    }
+                }
+                if (!far) {
+                    const bool ref_cand = ref_eligible && !ref_seen && best == 0;
+                    const int mine = key0 == best ? rk : 0x7fffffff;
+                    int lo = -wave_max_i32(-mine);
+                    if (ref_cand && rref < lo) lo = rref;
+                    const int n_lo = __popcll(__ballot(key0 == best && rk == lo)) + ((ref_cand && rref == lo) ? 1 : 0);
+                    if (n_lo == 1) {
+                        const unsigned long long w = __ballot(key0 == best && rk == lo);
+                        second = w ? __builtin_amdgcn_readlane(sc[0], __builtin_ctzll(w)) : ref;
+                        resolved = true;
+                    }
+                }
+            }
+            if (!resolved) {
+            // ... else one lane replays the insertions on the emulator and publishes the order; the tied slots are then looked up in that order.
             if (lane < nseen) s_seen[lane] = (uint8_t)sc[0];
             if (lane + 64 < nseen) s_seen[lane + 64] = (uint8_t)sc[1];
             wave_lds_sync();
@@ -1192,6 +1231,7 @@ static __device__ Table2x2 column_vs_partition_dev(const int32_t* __restrict__ i
                 if (cnt == best) second = k;
             }
             if (second < 0) second = ' ';
+            }
         }
     }
     if (second != ref) {   // c == mostFrequent is tested first in the reference (:899-936): nothing is left for an equal second
