@@ -656,8 +656,8 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
                 job.out_total += (int64_t)st[(size_t)c].N * st[(size_t)c].N;
             }
         }
-        {   // the matrices' rows in the order of the reads' start positions (HS_SIMDIFF_READ_ORDER=1: in read order, every tile computed)
-            static const bool read_order = std::getenv("HS_SIMDIFF_READ_ORDER") != nullptr;
+        {   // the matrices' rows in the order of the reads' start positions
+            const bool read_order = false;
             int64_t rows_all = 0;
             for (int c = 0; c < C; ++c) rows_all = std::max<int64_t>(rows_all, job.read_base[(size_t)c] + job.plane_n[(size_t)c]);
             if (!read_order) job.pos_orig.assign((size_t)rows_all, 0);

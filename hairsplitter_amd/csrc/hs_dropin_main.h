@@ -29,7 +29,6 @@
 #include <sys/wait.h>
 #include "../../include/hairsplitter_hip.h"
 void hs_teardown_probe(void);      /* (diagnostics, not part of the C ABI header) */
-void hs_exit_reset(void);
 void hs_dropin_finish(void);
 void hs_call_variants_epilogue(void);
 void hs_cpuprof_start(const char* out_file);
@@ -88,7 +87,6 @@ static int hs_dropin_run_all(int argc, char** argv) {      /* one process: the s
     if (rc == 0 && hs_dropin_epilogue) { hs_dropin_epilogue(); fflush(NULL); }
     hs_dropin_finish();
     hs_dropin_stamp("leaving");
-    if (getenv("HS_EXIT_RESET")) { const double tp = hs_dropin_now_ms(); hs_exit_reset(); if (getenv("HS_TIMING")) fprintf(stderr, "[hs timing] hipDeviceReset before the exit %.1f ms\n", hs_dropin_now_ms() - tp); }
     return rc;
 }
 /* The stage parses gigabytes into freshly mapped memory and leaves them to the process end: with 4-KB pages that is a million page faults on the way in and

@@ -292,7 +292,7 @@ static Contingency column_vs_partition_bits(const RankPartition& p, const ColVie
     // Few shared reads: the table holds at most `shared` reads, the column can only fit the partition with at least half of its
     // own reads in the table (:624-627) and only correlate with chi-square > 15, which a 2x2 table of N reads cannot exceed N
     // for (14 leaves room for the float rounding) -- neither can happen, the counts are of no consequence
-    static const bool no_skip = std::getenv("HS_LOOP_A_NO_SKIP") != nullptr;      // (diagnostic: form every table)
+    const bool no_skip = false;
     if (!no_skip && shared <= 14 && (size_t)shared < (size_t)cb.n_entries / 2) { LA_STAT(3); return r; }
     if (!no_skip) {   // the same with the shared reads the partition has an opinion on (state +1 / -1): only those enter the table
         int decided = 0;
@@ -644,7 +644,7 @@ void cv_phase_begin(CvContigState& st, int n_reads, int n_candidates, float mean
 // loop A (:590-638) on the host: sequential over the candidate columns of the contig
 void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* read_start, const int32_t* rank_pre, const int32_t* orig_pre) {
     const int n_reads = st.n_reads;
-    const bool tim = std::getenv("HS_TIMING_AB") != nullptr;
+    static const bool tim = []() { const char* e = std::getenv("HS_TIMING"); return e && std::string(e) == "loop_a"; }();      // (HS_TIMING=loop_a: a line per contig)
     auto nowus = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a0 = tim ? nowus() : 0;
     long n_cmp = 0, n_aug = 0;
