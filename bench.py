@@ -659,6 +659,9 @@ def main():
                         if not rc_["identical"]:
                             r["identical"] = False
                             r.setdefault("diffs", []).extend(rc_.get("diffs", []))
+                    keys = ("gro_identical", "col_snps_identical", "col_entries_identical", "error_rate_identical")
+                    r["identical_scope"] = "compared: " + ", ".join(k[:-len("_identical")] for k in keys if r.get(k) is not None) + \
+                        ("; NOT compared: " + ", ".join(k[:-len("_identical")] for k in keys if r.get(k) is None) if any(r.get(k) is None for k in keys) else "")
                     r["seconds"] = round(time.perf_counter() - t_p, 2)
                     return r
                 f2f, base, par = file_to_file(cfg, n_job, list(range(n_sample)), sample_files, job_files, max(1, args.f2f_runs), not args.no_f2f_reference_full, parity_fn)
