@@ -27,7 +27,7 @@ SYMBOLS = [
     "hs_pipeline_run_fused", "hs_realign_paf", "hs_pipeline_set_option", "hs_pipeline_groups", "hs_pipeline_group_range", "hs_pipeline_group_cv", "hs_pipeline_sparse_labels", "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_kernel_stats_every", "hs_host_wait_stats", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
 ]
 
-HS_NKERNELS = 27
+HS_NKERNELS = 28
 
 
 class HsError(RuntimeError):
@@ -778,7 +778,7 @@ class _CvTaps(C.Structure):
                 ("n_cand_words", C.c_int64), ("contig_n_cand", C.POINTER(C.c_int32)), ("contig_mean_distance", C.POINTER(C.c_float))]
 
 
-COLREC_DTYPE = np.dtype([("pos", np.int32), ("contig", np.int32), ("c0", np.uint16), ("c1", np.uint16), ("k0", np.uint8), ("k1", np.uint8), ("flags", np.uint8), ("c2_zero", np.uint8)])
+COLREC_DTYPE = np.dtype([("pos", np.int32), ("contig", np.int32), ("c0", np.uint16), ("c1", np.uint16), ("k0", np.uint8), ("k1", np.uint8), ("flags", np.uint8), ("c2", np.uint8)])
 CANDBITS_DTYPE = np.dtype([("wlo", np.int32), ("n_words", np.uint16), ("n_slots", np.uint16), ("idx_min", np.int32), ("idx_max", np.int32), ("reach", np.int32),
                            ("n_entries", np.int32), ("word_off", np.int64)])
 

@@ -741,7 +741,7 @@ static __device__ __forceinline__ void column_stats_tiled_dw_body(
                 sel_gpos[slot] = tile * 256 + 4 * (int)(t_scan & 63u) + (int)(t_scan >> 6);
                 sel_depth[slot] = d;
                 sel_info[slot] = make_uint2((uint32_t)n0 | ((uint32_t)n1 << 16),
-                                            (uint32_t)k0 | ((uint32_t)k1 << 8) | ((tie ? 32u /* HS_COL_TIE */ : 0u) | (gt5 ? 64u /* HS_COL_C1GT5C2 */ : 0u)) << 16 | (n2 == 0 ? 1u : 0u) << 24 | 0x80000000u);
+                                            (uint32_t)k0 | ((uint32_t)k1 << 8) | ((tie ? 32u /* HS_COL_TIE */ : 0u) | (gt5 ? 64u /* HS_COL_C1GT5C2 */ : 0u)) << 16 | (uint32_t)(n2 < 63 ? n2 : 63) << 24 | 0x80000000u);
             }
             n_kept += __popcll(km);
             e_kept += wave_sum_i32(keep ? d : 0);
@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(1024) void k_column_partition_test(
         const uint8_t* __restrict__ code = col_code + e0;
         const int k0 = col_k0[col], k1 = col_k1[col];
         const bool loop_c = col_is_cand[col] != 0;                                   // loop C (:721-738)
-        const bool loop_d = col_c1[col] >= 5 && central_base_test_dev(k0, k1);     // loop D (:745-764) on the columns that can be rescued
+        const bool loop_d = (col_c1[col] & 0xffff) >= 5 && central_base_test_dev(k0, k1);     // loop D (:745-764) on the columns that can be rescued
         bool kept = false;
         if (loop_c || loop_d) {
             for (int p = p0 + wv; p < p1 && !kept; p += 16) {
@@ -1288,33 +1288,40 @@ __global__ __launch_bounds__(1024) void k_column_partition_test(
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4, fast form: one wavefront per extracted column, LANES = PARTITIONS of the column's contig (blocks of 64).
+// K4, fast form (k_column_partition_lanes below): LANES = (column, partition) PAIRS THAT SHARE A READ.
 // The partition states are read from a per-contig table transposed to [read][partition] (k_partition_transpose), one
-// byte per (read, partition) holding 8 x {0 absent, 1 present with state 0, 2 state +1, 3 state -1}: for a column entry
-// (read r, code c) every lane loads the byte of ITS partition -- 64 consecutive bytes per entry instead of one scattered
-// byte per (entry, partition) -- and adds 1 << byte to an accumulator whose four byte fields count absent / zero / plus /
-// minus reads. Entries are visited code by code (leader loop over ballots), so that after a code's entries each lane knows
-// how many shared reads carry it on either side of its partition: reference code -> n11 / n01, most frequent other code ->
-// n10 / n00 (call_variants.cpp:832-936). The table, chi-square and the verdicts of loops C and D (:721-764) are then formed
-// per lane, i.e. for 64 partitions at once; keep = any lane.
-// Not decided here (keep = 2, re-done by the exact kernel above): a column whose verdict hinges on a partition where the
-// second allele is tied among the shared reads (the reference breaks the tie by hash-map order), reference codes >= 128
-// (signed-char quirk), columns deeper than 255.
+// byte per (read, partition) holding 8 x {0 absent, 1 present with state 0, 2 state +1, 3 state -1}, rows padded to 16
+// partitions; beside it one 16-bit word per (read, block of 16 partitions) saying in which of them the read is present:
+// the OR of those words over a column's reads names the partitions whose table with the column is not empty -- the only
+// ones that can keep it (call_variants.cpp:817-828: no shared read, no verdict).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_partition_transpose(
     const int32_t* __restrict__ part_off, const int64_t* __restrict__ part_state_off, const int8_t* __restrict__ part_state,
-    const int32_t* __restrict__ ctg_n, const int64_t* __restrict__ tab_off, int n_contigs, uint8_t* __restrict__ tab) {
+    const int32_t* __restrict__ ctg_n, const int64_t* __restrict__ tab_off, int n_contigs, uint8_t* __restrict__ tab, uint16_t* __restrict__ pres) {
     const int c = (int)blockIdx.y;
     if (c >= n_contigs) return;
     const int p0 = part_off[c], P = part_off[c + 1] - p0;
     const int N = ctg_n[c];
-    const int ppad = (P + 15) & ~15;
-    const int64_t total = (int64_t)N * ppad;
+    const int nblk = (P + 15) >> 4;
+    const int64_t total = (int64_t)N * nblk;
+    uint4* __restrict__ rows = reinterpret_cast<uint4*>(tab + tab_off[c]);
+    uint16_t* __restrict__ pr = pres + (tab_off[c] >> 4);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int r = (int)(i / ppad), p = (int)(i % ppad);
-        uint8_t e = 0;
-        if (p < P) { const int s = part_state[part_state_off[p0 + p] + r]; e = s == 2 ? 0 : (s == 0 ? 8 : (s == 1 ? 16 : 24)); }
-        tab[tab_off[c] + i] = e;
+        const int blk = (int)(i / N), r = (int)(i % N);      // (reads fastest: the loads of one partition's states are consecutive)
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        uint32_t mask = 0u;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int p = blk * 16 + q;
+            if (p < P) {
+                const int st = part_state[part_state_off[p0 + p] + r];
+                const uint32_t e = st == 2 ? 0u : (st == 0 ? 8u : (st == 1 ? 16u : 24u));
+                if (e) mask |= 1u << q;
+                w[q >> 2] |= e << (8 * (q & 3));
+            }
+        }
+        rows[(int64_t)r * nblk + blk] = make_uint4(w[0], w[1], w[2], w[3]);
+        pr[(int64_t)r * nblk + blk] = (uint16_t)mask;
     }
 }
 
@@ -1380,176 +1387,426 @@ __global__ __launch_bounds__(256) void k_partition_pair_distance(
     }
 }
 
-// 16 lanes per column, four columns per wavefront at a time (a contig rarely ends with more than 16 partitions; more are walked
-// 16 at a time). A wavefront owns 16 consecutive columns: lanes 0..15 read their headers and decide which are tested at all, the
-// tested ones are then taken four per round. Per round and column the wavefront groups the entries by code (ballots; every lane
-// scatters its read index to LDS behind the entries of the codes found before) and the four 16-lane groups then walk their own
-// column: per code one accumulator over that code's entries -- LDS broadcast of the read index, one table byte, one add.
-#define HS_K4_GROUPS 4
-#define HS_K4_MAXCODES 32
+// ------------------------------------------------------------------------------------------------
+// K4, first form (k_column_partition_lanes): 16 lanes per column = the 16 partitions of a block of the table, four columns per wavefront,
+// NO grouping of the entries by code. The four columns' entries go to LDS as they lie (lanes = entries: row offset of the read in the
+// table, class: reference code / the column's own second code k1 / another code); the lanes of a group then walk their column eight
+// entries at a time (four 16-byte LDS reads, eight table bytes in flight, each 16 consecutive bytes per group) and count in one
+// accumulator of 5-bit fields: the reference code's plus / minus reads (-> n11 / n01), k1's zero / plus / minus reads, the other codes'
+// present reads together. Where the partition holds more reads with k1 than any other non-reference code can have -- all of them
+// together, or the column's third count --, k1 IS its most frequent other code (call_variants.cpp:832-844), no tie possible, and the
+// table is exact: chi-square and the verdicts of loops C and D (:721-764) follow as in the grouped kernel below. Where it does not, the
+// table is unknown but bounded (n10 + n00 <= that bound or k1's reads): a pair whose bound cannot reach loop C's "more than half of the
+// column's reads" nor loop D's five reads per side is settled as well; the rest are marked (keep = 2) for k_column_partition_grouped.
+// Columns deeper than 255, with a reference code >= 128, or that do not fit the wavefront's 512 LDS entries go there too.
+// ------------------------------------------------------------------------------------------------
+#define HS_K4L_WAVE 512     // entries of its four columns a wavefront has room for in LDS (each column rounded up to eight)
+// per entry class (reference code / the column's second code k1 / any other code) a word of four shift amounts, one per table byte
+// 0 / 8 / 16 / 24 = absent / zero / plus / minus: the 5-bit field of the accumulator the entry counts in
+//   0 reference plus (n11), 5 reference minus (n01), 10 / 15 / 20 k1 zero / plus / minus, 25 another code and present, 30 nothing
+#define HS_K4L_REF 0x05001E1Eu
+#define HS_K4L_K1 0x140F0A1Eu
+#define HS_K4L_OTHER 0x1919191Eu
+#define HS_K4L_NONE 0x1E1E1E1Eu
 __global__ __launch_bounds__(256) void k_column_partition_lanes(
     const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
     const int32_t* __restrict__ col_contig, const uint8_t* __restrict__ col_k0, const uint8_t* __restrict__ col_k1,
     const int32_t* __restrict__ col_c1, const uint8_t* __restrict__ col_is_cand, int n_cols,
-    const int32_t* __restrict__ part_off, const int64_t* __restrict__ tab_off, const uint8_t* __restrict__ tab,
-    uint8_t* __restrict__ keep, int32_t* __restrict__ undecided_list, int32_t* __restrict__ n_undecided) {
-    __shared__ int32_t s_idx[4][HS_K4_GROUPS][256];
-    __shared__ int16_t s_cstart[4][HS_K4_GROUPS][HS_K4_MAXCODES + 2];
-    __shared__ uint8_t s_ccode[4][HS_K4_GROUPS][HS_K4_MAXCODES];
+    const int32_t* __restrict__ part_off, const int32_t* __restrict__ ctg_n, const int64_t* __restrict__ tab_off, const uint8_t* __restrict__ tab,
+    uint8_t* __restrict__ keep) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_off[4][HS_K4L_WAVE];      // per entry: where its read's row starts in the contig's table
+    __shared__ __attribute__((aligned(16))) uint32_t s_cls[4][HS_K4L_WAVE];      // per entry: the shift amounts of its class
     const int lane = lane_id();
     const int wv = wave_id();
-    const int col_base = ((int)blockIdx.x * 4 + wv) * 16;
-    if (col_base >= n_cols) return;
-    // ---- the 16 column headers: lane l < 16 holds column col_base + l ----
-    const int hc = col_base + (lane & 15);
-    const bool hvalid = lane < 16 && hc < n_cols;
-    int h_c = 0, h_P = 0, h_n = 0, h_k0 = 0, h_flags = 0;      // flags: 1 candidate, 2 loop D
+    const int grp = lane >> 4, pl = lane & 15;
+    const int col = (((int)blockIdx.x * 4 + wv) * 4) + grp;
+    bool tested = false, passed_on = false;
+    int n = 0, k0 = 0, k1 = 0, P = 0, c2 = 0;
+    bool is_cand = false, loop_d = false;
+    int64_t e0 = 0;
+    uint32_t tb = 0u, ppad = 0u;
+    if (col < n_cols) {
+        const int c = col_contig[col];
+        P = part_off[c + 1] - part_off[c];
+        e0 = col_off[col];
+        n = (int)(col_off[col + 1] - e0);
+        k0 = col_k0[col]; k1 = col_k1[col];
+        is_cand = col_is_cand[col] != 0;
+        const int c1w = col_c1[col];
+        loop_d = (c1w & 0xffff) >= 5 && central_base_test_dev(k0, k1);
+        c2 = 63 - ((c1w >> 16) & 63);      // the column's third count (63: that or more, or not known)
+        if (c2 >= 63) c2 = 1 << 20;
+        ppad = (uint32_t)((P + 15) & ~15);
+        const int64_t t0 = tab_off[c];
+        tb = (uint32_t)t0;
+        if (P == 0 || !(is_cand || loop_d) || n == 0) { if (pl == 0) keep[col] = 0; }      // (an empty column shares no read with anything)
+        else if (n > 255 || k0 >= 128 || t0 + (int64_t)ctg_n[c] * ppad > 0xffffffffll) passed_on = true;
+        else tested = true;
+    }
+    if (__ballot(tested || passed_on) == 0ull) return;
+    // ---- the four columns' entries into LDS, lanes = entries (the loads of all four first); a column the wavefront has no room left for is passed on ----
+    int row0 = 0;      // where this group's column starts
+    {
+        int ng[4], og[4]; int64_t eg[4]; uint32_t pg[4]; int kr[4], kk[4]; int32_t rr[4]; int cd[4];
+        int used = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            ng[g] = __builtin_amdgcn_readlane(tested ? n : 0, 16 * g);
+            og[g] = used;
+            if (used + ((ng[g] + 7) & ~7) > HS_K4L_WAVE) { ng[g] = 0; if (grp == g && tested) { tested = false; passed_on = true; } }
+            used += (ng[g] + 7) & ~7;
+            if (grp == g) row0 = og[g];
+            eg[g] = ((int64_t)(unsigned)__builtin_amdgcn_readlane((int)(e0 >> 32), 16 * g) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(e0 & 0xffffffffll), 16 * g);
+            pg[g] = (uint32_t)__builtin_amdgcn_readlane((int)ppad, 16 * g);
+            kr[g] = __builtin_amdgcn_readlane(k0, 16 * g); kk[g] = __builtin_amdgcn_readlane(k1, 16 * g);
+            rr[g] = 0; cd[g] = -1;
+            if (lane < ng[g]) { rr[g] = col_idx[eg[g] + lane]; cd[g] = (int)col_code[eg[g] + lane]; }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (lane < ((ng[g] + 7) & ~7)) {      // (the tail of the last eight counts nowhere)
+                s_off[wv][og[g] + lane] = (uint32_t)rr[g] * pg[g];
+                s_cls[wv][og[g] + lane] = cd[g] < 0 ? HS_K4L_NONE : (cd[g] == kr[g] ? HS_K4L_REF : (cd[g] == kk[g] ? HS_K4L_K1 : HS_K4L_OTHER));
+            }
+            for (int e = 64 + lane; e < ((ng[g] + 7) & ~7); e += 64) {      // (deeper than 64: rare)
+                const bool in = e < ng[g];
+                const int code = in ? (int)col_code[eg[g] + e] : -1;
+                s_off[wv][og[g] + e] = in ? (uint32_t)col_idx[eg[g] + e] * pg[g] : 0u;
+                s_cls[wv][og[g] + e] = code < 0 ? HS_K4L_NONE : (code == kr[g] ? HS_K4L_REF : (code == kk[g] ? HS_K4L_K1 : HS_K4L_OTHER));
+            }
+        }
+    }
+    wave_lds_sync();
+    const uint32_t* __restrict__ so = s_off[wv] + row0;
+    const uint32_t* __restrict__ sc = s_cls[wv] + row0;
+    const unsigned gshift = 16u * (unsigned)grp;
+    const int n8 = (n + 7) & ~7;
+    bool kept = false, unsettled = false;
+    for (uint32_t pb = 0u; __ballot(tested && !kept && pb < ppad) != 0ull; pb += 16u) {
+        const bool on = tested && !kept && pb < ppad;
+        const uint32_t base = tb + pb + (uint32_t)pl;
+        uint32_t acc = 0u;                       // six 5-bit fields: spilled into the wide counters before one can overflow (every 24 entries)
+        uint32_t w_r = 0u, w_k = 0u, w_o = 0u;   // reference plus | minus << 16; k1 zero | plus << 10 | minus << 20; the others, present
+        int since = 0;
+        for (int e = 0; __ballot(on && e < n8) != 0ull; e += 8) {
+            if (on && e < n8) {
+                const uint4 oa = *reinterpret_cast<const uint4*>(so + e), ob = *reinterpret_cast<const uint4*>(so + e + 4);
+                const uint4 ca = *reinterpret_cast<const uint4*>(sc + e), cb = *reinterpret_cast<const uint4*>(sc + e + 4);
+                const uint32_t b0 = tab[base + oa.x], b1 = tab[base + oa.y], b2 = tab[base + oa.z], b3 = tab[base + oa.w];
+                const uint32_t b4 = tab[base + ob.x], b5 = tab[base + ob.y], b6 = tab[base + ob.z], b7 = tab[base + ob.w];
+                acc += (1u << __builtin_amdgcn_ubfe(ca.x, b0, 5u)) + (1u << __builtin_amdgcn_ubfe(ca.y, b1, 5u)) + (1u << __builtin_amdgcn_ubfe(ca.z, b2, 5u)) + (1u << __builtin_amdgcn_ubfe(ca.w, b3, 5u));
+                acc += (1u << __builtin_amdgcn_ubfe(cb.x, b4, 5u)) + (1u << __builtin_amdgcn_ubfe(cb.y, b5, 5u)) + (1u << __builtin_amdgcn_ubfe(cb.z, b6, 5u)) + (1u << __builtin_amdgcn_ubfe(cb.w, b7, 5u));
+            }
+            if (++since == 3) {      // (wave-uniform)
+                w_r += (acc & 31u) | (((acc >> 5) & 31u) << 16);
+                w_k += ((acc >> 10) & 31u) | (((acc >> 15) & 31u) << 10) | (((acc >> 20) & 31u) << 20);
+                w_o += (acc >> 25) & 31u;
+                acc = 0u; since = 0;
+            }
+        }
+        w_r += (acc & 31u) | (((acc >> 5) & 31u) << 16);
+        w_k += ((acc >> 10) & 31u) | (((acc >> 15) & 31u) << 10) | (((acc >> 20) & 31u) << 20);
+        w_o += (acc >> 25) & 31u;
+        bool ok = false, open = false;
+        if (on && (int)(pb + (uint32_t)pl) < P) {
+            const int n11 = (int)(w_r & 0xffffu), n01 = (int)(w_r >> 16);
+            const int n10 = (int)((w_k >> 10) & 1023u), n00 = (int)(w_k >> 20);
+            const int take_k = (int)(w_k & 1023u) + n10 + n00, rest = (int)w_o;
+            const int other_ub = rest < c2 ? rest : c2;      // what one other code can have here at most: all of them together, or the column's third count
+            if (take_k > other_ub) {      // k1 is the partition's most frequent other code, strictly
+                const int total = n00 + n01 + n10 + n11;
+                const bool pre_c = is_cand && 2 * total > n;                       // loop C (:721-738): (double)total > 0.5 * (double)n
+                const bool pre_d = loop_d && n10 + n00 > 4 && n01 + n11 > 4;       // loop D (:745-764)
+                const int r1 = n10 + n11, c1 = n01 + n11;
+                if ((pre_c || pre_d) && r1 > 0 && r1 < total && c1 > 0 && c1 < total) {      // (a margin of 0 or all: chi-square is -1 or 0)
+                    const float det = (float)(n11 * n00 - n10 * n01);
+                    float chi = (float)total * det * det * __builtin_amdgcn_rcpf((float)((r1 * (total - r1)) * (c1 * (total - c1))));
+                    const bool near = (pre_c && fabsf(chi - 15.0f) < 0.05f) || (pre_d && fabsf(chi - 20.0f) < 0.05f);
+                    if (near) { Table2x2 d; d.n00 = n00; d.n01 = n01; d.n10 = n10; d.n11 = n11; chi = chi_square_dev(d); }
+                    ok = (pre_c && chi > 15) || (pre_d && (double)chi > 20.0);
+                }
+            } else {
+                const int ub = other_ub > take_k ? other_ub : take_k;      // what the second allele can have at most
+                open = ub > 0 && ((is_cand && 2 * (n11 + n01 + ub) > n) || (loop_d && ub >= 5 && n01 + n11 > 4));
+            }
+        }
+        kept = kept || ((__ballot(ok) >> gshift) & 0xffffull) != 0ull;
+        unsettled = unsettled || ((__ballot(open) >> gshift) & 0xffffull) != 0ull;
+    }
+    if ((tested || passed_on) && pl == 0) {
+        const bool pass = passed_on || (!kept && unsettled);
+        keep[col] = kept ? 1 : (pass ? 2 : 0);      // (2: k_column_partition_grouped takes the column)
+    }
+}
+
+// K4, second form (k_column_partition_grouped): the columns k_column_partition_lanes could not settle with its three counters (see there), 16
+// of its list per wavefront (= one workgroup).
+//  1. lanes 0..15 read the headers and decide which columns are tested at all;
+//  2. column by column, lanes = entries: the entries' read indices go to LDS grouped by code -- the reference code first (ballot ranks),
+//     the other codes behind it from the next multiple of 8 by a counting sort on LDS counters (rank = the old value of an atomic add,
+//     starts = one wave scan over the 128 counters) with one bit per entry saying "last of its code" --, and per block of 16 partitions
+//     the OR of the reads' presence words names the PAIRS {column, partition that shares a read with it};
+//  3. 64 pending pairs at a time, one per lane: the lane walks its column's grouped entries eight at a time (one 16-byte LDS read, eight
+//     table bytes in flight, 1 << byte added to an accumulator whose byte fields count absent / zero / plus / minus reads): the
+//     reference code -> n11 / n01, then the others with the accumulator evaluated at every code's last entry -> the most frequent
+//     other code's n10 / n00 (call_variants.cpp:832-936), then the table's verdicts for loops C and D (:721-764). No branch depends
+//     on a lane's data inside the walk.
+// chi-square: N (ad - bc)^2 / (r1 r2 c1 c2) in float decides unless it comes within 0.05 of a threshold, then the reference's own
+// sequence of float and double operations (chi_square_dev) does.
+// Not decided here (keep = 2, re-done by the exact kernel above): a column whose verdict hinges on a partition where the second allele is
+// tied among the shared reads (the reference breaks the tie by hash-map order), reference codes >= 128 (signed-char quirk), columns
+// deeper than 255, codes outside 33..160, contigs with more than 65535 reads or partitions or a table beyond 4 GB.
+#define HS_K4_COLS 16
+#define HS_K4_ROW 264             // u16 entries of a column's row in LDS: 255 entries + the gap behind the reference code's + the tail
+#define HS_K4_PAIRS 80
+#ifdef HS_K4_DIAG
+__device__ unsigned long long g_k4_dbg[8];
+#endif
+static __device__ __forceinline__ int wave_or_i32(int v) {
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__global__ __launch_bounds__(64) void k_column_partition_grouped(
+    const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
+    const int32_t* __restrict__ col_contig, const uint8_t* __restrict__ col_k0, const uint8_t* __restrict__ col_k1,
+    const int32_t* __restrict__ col_c1, const uint8_t* __restrict__ col_is_cand, int n_cols,
+    const int32_t* __restrict__ part_off, const int32_t* __restrict__ ctg_n, const int64_t* __restrict__ tab_off, const uint8_t* __restrict__ tab,
+    const uint16_t* __restrict__ pres, uint8_t* __restrict__ keep, int32_t* __restrict__ undecided_list, int32_t* __restrict__ n_undecided) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_idx[HS_K4_COLS * HS_K4_ROW];
+    __shared__ uint32_t s_last[HS_K4_COLS][9];      // bit e: entry e of the row is the last of its code (other codes only)
+    __shared__ uint32_t s_cnt[128];
+    __shared__ uint32_t s_pairs[HS_K4_PAIRS];       // slot << 28 | block << 4 | partition within the block
+    __shared__ uint4 s_hdr[HS_K4_COLS];             // {table offset of the contig, row length, n | flags << 16, entries with the reference code | end of the others << 16}
+    __shared__ uint32_t s_flags;                    // bit s: column s kept; bit 16 + s: undecided
+    const int lane = lane_id();
+    // ---- the 16 column headers: lane l < 16 holds column col_base + l, if the first kernel left it open (keep == 2) ----
+    const int hc = (int)blockIdx.x * HS_K4_COLS + (lane & 15);
+    const bool hvalid = lane < 16 && hc < n_cols && keep[hc] == 2;
+    if (__ballot(hvalid) == 0ull) return;
+    int h_n = 0, h_k0 = 0, h_flags = 0, h_ppad = 0;
+    uint32_t h_tb = 0u;
     int64_t h_e0 = 0;
-    bool tested = false;
+    bool tested = false, h_bad = false;
     if (hvalid) {
-        h_c = col_contig[hc];
-        h_P = part_off[h_c + 1] - part_off[h_c];
+        const int c = col_contig[hc];
+        const int P = part_off[c + 1] - part_off[c];
         h_e0 = col_off[hc];
         h_n = (int)(col_off[hc + 1] - h_e0);
         h_k0 = col_k0[hc];
         const int k1 = col_k1[hc];
         const bool is_cand = col_is_cand[hc] != 0;
-        const bool loop_d = col_c1[hc] >= 5 && central_base_test_dev(h_k0, k1);
+        const bool loop_d = (col_c1[hc] & 0xffff) >= 5 && central_base_test_dev(h_k0, k1);
         h_flags = (is_cand ? 1 : 0) | (loop_d ? 2 : 0);
-        if (h_P == 0 || h_flags == 0) keep[hc] = 0;
-        else if (h_n > 255 || h_k0 >= 128) {      // (the byte fields of the accumulator hold up to 255 entries)
-            keep[hc] = 2; undecided_list[atomicAdd(n_undecided, 1)] = hc;
-        } else tested = true;
+        h_ppad = (P + 15) & ~15;
+        const int64_t tb = tab_off[c];
+        const int N = ctg_n[c];
+        h_tb = (uint32_t)tb;
+        if (P == 0 || h_flags == 0 || h_n == 0) keep[hc] = 0;      // (an empty column shares no read with anything)
+        else if (h_n > 255 || h_k0 >= 128 || N > 65535 || P > 65535 || tb + (int64_t)N * h_ppad > 0xffffffffll) h_bad = true;
+        else tested = true;
     }
+    if (lane < 16) s_hdr[lane] = make_uint4(h_tb, (uint32_t)h_ppad, (uint32_t)h_n | ((uint32_t)h_flags << 16), 0u);
+    if (lane == 0) s_flags = 0u;
+    unsigned bad_cols = (unsigned)(__ballot(h_bad) & 0xffffull);
     unsigned todo = (unsigned)(__ballot(tested) & 0xffffull);
-    const int grp = lane >> 4, pl = lane & 15;
-    while (todo) {
-        // ---- this round's (up to) four columns: group g takes the g-th of the remaining ones ----
-        int src[HS_K4_GROUPS];
-        unsigned t = todo;
+    int npairs = 0;
+    int cur_s = -1;
+    uint32_t cur_blk = 0u, cur_nblk = 0u;
+    int cur_nch = 0;
+    uint32_t prow[4] = {0u, 0u, 0u, 0u};      // per entry of the current column: where its presence words start
+    bool pvalid[4] = {false, false, false, false};
+    for (;;) {
+        // ---- step 2: columns (and their blocks of 16 partitions) until 64 pairs are pending ----
+        while (npairs < 64) {
+            if (cur_s < 0) {
+                if (!todo) break;
+                const int s = __builtin_ctz(todo);
+                todo &= todo - 1u;
+                const int64_t e0 = ((int64_t)(unsigned)__builtin_amdgcn_readlane((int)(h_e0 >> 32), s) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(h_e0 & 0xffffffffll), s);
+                const int n = __builtin_amdgcn_readlane(h_n, s), k0 = __builtin_amdgcn_readlane(h_k0, s);
+                const uint32_t tb16 = (uint32_t)__builtin_amdgcn_readlane((int)h_tb, s) >> 4, ppb = (uint32_t)__builtin_amdgcn_readlane(h_ppad, s) >> 4;
+                const int nch = (n + 63) >> 6;
+                int r_i[4], c_i[4], rank[4];
 #pragma unroll
-        for (int g = 0; g < HS_K4_GROUPS; ++g) { if (t) { src[g] = __builtin_ctz(t); t &= t - 1u; } else src[g] = -1; }
-        todo = t;
-        // ---- entries grouped by code into LDS, one column after the other, all lanes (the loads of all four columns first) ----
-        bool too_many_codes = false;      // per group, valid in the lanes of that group after the loop
-        int r_all[HS_K4_GROUPS][4], c_all[HS_K4_GROUPS][4];
-#pragma unroll
-        for (int g = 0; g < HS_K4_GROUPS; ++g) {
-            const int sg = src[g] < 0 ? 0 : src[g];
-            const int64_t e0 = ((int64_t)(unsigned)__builtin_amdgcn_readlane((int)(h_e0 >> 32), sg) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(h_e0 & 0xffffffffll), sg);
-            const int n = src[g] < 0 ? 0 : __builtin_amdgcn_readlane(h_n, sg);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int e = k * 64 + lane;
-                r_all[g][k] = 0; c_all[g][k] = -1;
-                if (k * 64 < n && e < n) { r_all[g][k] = col_idx[e0 + e]; c_all[g][k] = (int)col_code[e0 + e]; }      // (k * 64 < n: wave-uniform, most columns are one chunk)
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < HS_K4_GROUPS; ++g) {
-            if (src[g] < 0) continue;      // (wave-uniform)
-            int r_i[4], c_i[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { r_i[k] = r_all[g][k]; c_i[k] = c_all[g][k]; }
-            const int nch = (__builtin_amdgcn_readlane(h_n, src[g]) + 63) >> 6;      // chunks of 64 entries the column has (wave-uniform; nearly always one)
-            // what goes to LDS is the entry's ROW OFFSET in the table (read x row length): formed once here instead of by each of the
-            // sixteen lanes that walk the column
-            const int ppad_g = (__builtin_amdgcn_readlane(h_P, src[g]) + 15) & ~15;
-            bool wide = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { const long long pr = (long long)r_i[k] * ppad_g; wide = wide || pr > 0x7fffffffll; r_i[k] = (int)pr; }
-            const bool any_wide = __ballot(wide) != 0ull;
-            unsigned long long rem[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) rem[k] = k < nch ? __ballot(c_i[k] >= 0) : 0ull;
-            int ncodes = 0, filled = 0;
-            for (;;) {
-                int code = -1;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (code < 0 && rem[k]) code = __builtin_amdgcn_readlane(c_i[k], __builtin_ctzll(rem[k]));
-                if (code < 0) break;
-                if (ncodes == HS_K4_MAXCODES) { ncodes++; break; }
-                if (lane == 0) { s_cstart[wv][g][ncodes] = (int16_t)filled; s_ccode[wv][g][ncodes] = (uint8_t)code; }
+                for (int k = 0; k < 4; ++k) {
+                    const int e = k * 64 + lane;
+                    r_i[k] = 0; c_i[k] = -1; rank[k] = 0;
+                    if (k < nch && e < n) { r_i[k] = col_idx[e0 + e]; c_i[k] = (int)col_code[e0 + e]; }      // (k < nch: wave-uniform, most columns are one chunk)
+                }
+                reinterpret_cast<uint2*>(s_cnt)[lane] = make_uint2(0u, 0u);
+                if (lane < 9) s_last[s][lane] = 0u;
+                wave_lds_sync();
+                uint16_t* __restrict__ ix = s_idx + s * HS_K4_ROW;
+                int nref = 0;
+                bool strange = false;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (k >= nch) break;
-                    const unsigned long long m = __ballot(c_i[k] == code);
-                    rem[k] &= ~m;
-                    if (c_i[k] == code) s_idx[wv][g][filled + __popcll(m & ((1ull << lane) - 1ull))] = r_i[k];
-                    filled += __popcll(m);
+                    const bool isref = c_i[k] == k0;
+                    const unsigned long long m = __ballot(isref);
+                    if (isref) ix[nref + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)r_i[k];
+                    nref += __popcll(m);
+                    if (c_i[k] >= 0 && !isref) {
+                        if (c_i[k] < 33 || c_i[k] > 160) strange = true;
+                        else rank[k] = (int)atomicAdd(&s_cnt[c_i[k] - 33], 1u);
+                    }
                 }
-                ncodes++;
-            }
-            if (lane == 0) { s_cstart[wv][g][ncodes <= HS_K4_MAXCODES ? ncodes : HS_K4_MAXCODES] = (int16_t)filled; s_cstart[wv][g][HS_K4_MAXCODES + 1] = (int16_t)ncodes; }
-            if (grp == g) too_many_codes = ncodes > HS_K4_MAXCODES || any_wide;      // (a table beyond 2 GB: the exact kernel)
-        }
-        wave_lds_sync();
-        // ---- the four groups, each on its own column: lanes = partitions ----
-        int my_src = src[0];
+                wave_lds_sync();
+                const uint2 ab = reinterpret_cast<const uint2*>(s_cnt)[lane];
+                const int both = (int)(ab.x + ab.y);
+                const int incl = wave_scan_incl(both);
+                const int o0 = (nref + 7) & ~7, oend = o0 + __builtin_amdgcn_readlane(incl, 63);
+                const uint32_t start_a = (uint32_t)(o0 + incl - both), start_b = start_a + ab.x;
+                if (ab.x > 0u) { const uint32_t last = start_a + ab.x - 1u; atomicOr(&s_last[s][last >> 5], 1u << (last & 31u)); }
+                if (ab.y > 0u) { const uint32_t last = start_b + ab.y - 1u; atomicOr(&s_last[s][last >> 5], 1u << (last & 31u)); }
+                reinterpret_cast<uint2*>(s_cnt)[lane] = make_uint2(start_a, start_b);
+                if (lane < 8) {      // the gap behind the reference code's entries and the tail of the last eight: read 0
+                    if (nref + lane < o0) ix[nref + lane] = 0;
+                    if (oend + lane < ((oend + 7) & ~7)) ix[oend + lane] = 0;
+                }
+                if (lane == 0) s_hdr[s].w = (uint32_t)nref | ((uint32_t)oend << 16);
+                wave_lds_sync();
+                if (__ballot(strange) != 0ull) { bad_cols |= 1u << s; continue; }
 #pragma unroll
-        for (int g = 1; g < HS_K4_GROUPS; ++g) if (grp == g) my_src = src[g];
-        const bool active = my_src >= 0;
-        const int sl = active ? my_src : 0;
-        const int col = col_base + sl;
-        const int c = __shfl(h_c, sl, 64), P = __shfl(h_P, sl, 64), n = __shfl(h_n, sl, 64), k0 = __shfl(h_k0, sl, 64), fl = __shfl(h_flags, sl, 64);
-        const bool is_cand = (fl & 1) != 0, loop_d = (fl & 2) != 0;
-        bool kept = false, undecided = false;
-        if (active && too_many_codes) undecided = true;
-        else if (active) {
-            const int ppad = (P + 15) & ~15;
-            const uint8_t* __restrict__ tb = tab + tab_off[c];
-            const int ncodes = s_cstart[wv][grp][HS_K4_MAXCODES + 1];
-            const int32_t* __restrict__ ix = s_idx[wv][grp];
-            const unsigned gmask_shift = 16u * (unsigned)grp;
-            for (int pb = 0; pb < ppad && !kept; pb += 16) {
-                const uint8_t* __restrict__ tl = tb + pb + pl;
-                int n11 = 0, n01 = 0, n10 = 0, n00 = 0, best = -1;
-                bool tie = false;
-                for (int j = 0; j < ncodes; ++j) {
-                    const int code = s_ccode[wv][grp][j];
-                    int e = s_cstart[wv][grp][j];
-                    const int e1 = s_cstart[wv][grp][j + 1];
-                    unsigned acc = 0u;
-                    for (; e + 4 <= e1; e += 4) {      // four loads in flight before the adds
-                        const int ra = ix[e], rb = ix[e + 1], rc = ix[e + 2], rd = ix[e + 3];
-                        const unsigned sa = tl[ra], sb = tl[rb], sc = tl[rc], sd = tl[rd];
-                        acc += (1u << sa) + (1u << sb) + (1u << sc) + (1u << sd);
-                    }
-                    for (; e < e1; ++e) acc += 1u << (unsigned)tl[ix[e]];
-                    const int plus = (int)((acc >> 16) & 255u), minus = (int)(acc >> 24);
-                    const int take = (int)((acc >> 8) & 255u) + plus + minus;
-                    if (code == k0) { n11 = plus; n01 = minus; }
-                    else if (take > 0) {
-                        if (take > best) { best = take; n10 = plus; n00 = minus; tie = false; }
-                        else if (take == best) tie = true;
-                    }
+                for (int k = 0; k < 4; ++k) {
+                    if (k >= nch) break;
+                    if (c_i[k] >= 0 && c_i[k] != k0) ix[s_cnt[c_i[k] - 33] + (uint32_t)rank[k]] = (uint16_t)r_i[k];
                 }
-                bool ok = false;
-                if (pb + pl < P) {
-                    Table2x2 d; d.n00 = n00; d.n01 = n01; d.n10 = n10; d.n11 = n11;
-                    // a tie among the second alleles only matters where the verdict could depend on which one is taken: loop C needs more
-                    // than half of the column's reads in the table (at most n11 + n01 + best of them are), loop D five reads on the
-                    // second allele (at most best)
-                    const bool tie_matters = tie && ((is_cand && (double)(n11 + n01 + best) > 0.5 * (double)n) || (loop_d && best >= 5));
-                    if (!tie_matters) {
-                        const float chi = chi_square_dev(d);
-                        if (is_cand && (double)(d.n00 + d.n01 + d.n10 + d.n11) > 0.5 * (double)n && chi > 15) ok = true;                 // loop C (:721-738)
-                        if (loop_d && (double)chi > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) ok = true;                           // loop D (:745-764)
-                    }
-                    undecided = undecided || tie_matters;
-                }
-                kept = ((__ballot(ok) >> gmask_shift) & 0xffffull) != 0ull;      // (the 16 lanes of a group run in step)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { prow[k] = tb16 + (uint32_t)r_i[k] * ppb; pvalid[k] = c_i[k] >= 0; }
+                cur_s = s; cur_blk = 0u; cur_nblk = ppb; cur_nch = nch;
+                continue;
             }
+            if (cur_blk == cur_nblk) { cur_s = -1; continue; }
+            int m = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { if (k >= cur_nch) break; if (pvalid[k]) m |= (int)pres[prow[k] + cur_blk]; }
+            m = wave_or_i32(m);
+            if (m) {
+                if (lane < 16 && ((m >> lane) & 1)) s_pairs[npairs + __popc((unsigned)m & ((1u << lane) - 1u))] = ((uint32_t)cur_s << 28) | (cur_blk << 4) | (uint32_t)lane;
+                npairs += __popc((unsigned)m);
+            }
+            ++cur_blk;
         }
-        {
-            const unsigned long long um = __ballot(undecided);
-            undecided = ((um >> (16u * (unsigned)grp)) & 0xffffull) != 0ull;
-        }
-        if (active && pl == 0) {
-            keep[col] = kept ? 1 : (undecided ? 2 : 0);
-            if (!kept && undecided) undecided_list[atomicAdd(n_undecided, 1)] = col;
-        }
+        if (npairs == 0) break;
         wave_lds_sync();
+        // ---- step 3: 64 pairs, one per lane ----
+        {
+            const bool act = lane < npairs;
+            const uint32_t pr = s_pairs[act ? lane : 0];
+            const uint32_t moved = (lane + 64 < npairs) ? s_pairs[lane + 64] : 0u;
+            const int slot = (int)(pr >> 28);
+            const uint4 hd = s_hdr[slot];
+            const uint32_t base = hd.x + (pr & 0xfffffffu), ppad = hd.y;      // (block << 4 | partition = the byte's place in the table row)
+            const int n = (int)(hd.z & 255u);
+            const bool is_cand = (hd.z >> 16) & 1u, loop_d = (hd.z >> 17) & 1u;
+            const int nref = act ? (int)(hd.w & 0xffffu) : 0, oend = act ? (int)(hd.w >> 16) : 0;
+            const int o0 = (nref + 7) & ~7;
+            const uint16_t* __restrict__ ix = s_idx + slot * HS_K4_ROW;
+            // the reference code's entries (the gap up to the next multiple of 8 reads row 0: taken out again below)
+            uint32_t acc = 0u;
+            for (int e0 = 0; __ballot(e0 < nref) != 0ull; e0 += 8) {
+                if (e0 < nref) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(ix + e0);
+                    const uint32_t b0 = tab[base + __umul24(v.x & 0xffffu, ppad)], b1 = tab[base + __umul24(v.x >> 16, ppad)];
+                    const uint32_t b2 = tab[base + __umul24(v.y & 0xffffu, ppad)], b3 = tab[base + __umul24(v.y >> 16, ppad)];
+                    const uint32_t b4 = tab[base + __umul24(v.z & 0xffffu, ppad)], b5 = tab[base + __umul24(v.z >> 16, ppad)];
+                    const uint32_t b6 = tab[base + __umul24(v.w & 0xffffu, ppad)], b7 = tab[base + __umul24(v.w >> 16, ppad)];
+                    acc += (1u << b0) + (1u << b1) + (1u << b2) + (1u << b3) + (1u << b4) + (1u << b5) + (1u << b6) + (1u << b7);
+                }
+            }
+            if (o0 > nref) acc -= (uint32_t)(o0 - nref) << (uint32_t)tab[base];
+            const int n11 = (int)((acc >> 16) & 255u), n01 = (int)(acc >> 24);
+            // the other codes: the accumulator is evaluated where an entry is the last of its code
+            acc = 0u;
+            uint32_t bestkey = 0u, bt = 0u, tie = 0u;
+            const uint8_t* __restrict__ lastb = reinterpret_cast<const uint8_t*>(s_last[slot]);
+            for (int e0 = o0; __ballot(e0 < oend) != 0ull; e0 += 8) {
+                if (e0 < oend) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(ix + e0);
+                    const uint32_t fb = lastb[e0 >> 3];
+                    uint32_t b[8];
+                    b[0] = tab[base + __umul24(v.x & 0xffffu, ppad)]; b[1] = tab[base + __umul24(v.x >> 16, ppad)];
+                    b[2] = tab[base + __umul24(v.y & 0xffffu, ppad)]; b[3] = tab[base + __umul24(v.y >> 16, ppad)];
+                    b[4] = tab[base + __umul24(v.z & 0xffffu, ppad)]; b[5] = tab[base + __umul24(v.z >> 16, ppad)];
+                    b[6] = tab[base + __umul24(v.w & 0xffffu, ppad)]; b[7] = tab[base + __umul24(v.w >> 16, ppad)];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        acc += 1u << b[u];
+                        const bool last = (fb >> u) & 1u;
+                        const uint32_t take = __builtin_amdgcn_sad_u8(acc & 0xffffff00u, 0u, 0u);      // zero + plus + minus: the code's reads the partition holds
+                        const uint32_t key = (take << 16) | (acc >> 16);
+                        const bool gt = last && take > bt, eq = last && take == bt && take != 0u;
+                        bestkey = gt ? key : bestkey;
+                        bt = gt ? take : bt;
+                        tie = gt ? 0u : (eq ? 1u : tie);
+                        acc = last ? 0u : acc;
+                    }
+                }
+            }
+            const int n10 = (int)(bestkey & 255u), n00 = (int)((bestkey >> 8) & 255u), best = (int)bt;
+            bool ok = false, und = false;
+            if (act) {
+                const int total = n00 + n01 + n10 + n11;
+                // a tie among the second alleles only matters where the verdict could depend on which one is taken: loop C needs more
+                // than half of the column's reads in the table (at most n11 + n01 + best of them are), loop D five reads on the
+                // second allele (at most best)
+                const bool tie_matters = tie != 0u && ((is_cand && 2 * (n11 + n01 + best) > n) || (loop_d && best >= 5));
+                if (tie_matters) und = true;
+                else {
+                    const bool pre_c = is_cand && 2 * total > n;                       // loop C (:721-738): (double)total > 0.5 * (double)n
+                    const bool pre_d = loop_d && n10 + n00 > 4 && n01 + n11 > 4;       // loop D (:745-764)
+                    const int r1 = n10 + n11, c1 = n01 + n11;
+                    if ((pre_c || pre_d) && r1 > 0 && r1 < total && c1 > 0 && c1 < total) {      // (a margin of 0 or all: chi-square is -1 or 0)
+                        const float det = (float)(n11 * n00 - n10 * n01);
+                        float chi = (float)total * det * det * __builtin_amdgcn_rcpf((float)((r1 * (total - r1)) * (c1 * (total - c1))));
+                        const bool near = (pre_c && fabsf(chi - 15.0f) < 0.05f) || (pre_d && fabsf(chi - 20.0f) < 0.05f);
+                        if (near) { Table2x2 d; d.n00 = n00; d.n01 = n01; d.n10 = n10; d.n11 = n11; chi = chi_square_dev(d); }
+                        ok = (pre_c && chi > 15) || (pre_d && (double)chi > 20.0);
+                    }
+                }
+            }
+            if (ok) atomicOr(&s_flags, 1u << slot);
+            if (und) atomicOr(&s_flags, 0x10000u << slot);
+#ifdef HS_K4_DIAG
+            {
+                const int total = n00 + n01 + n10 + n11;
+                const bool pre_c = is_cand && 2 * total > n, pre_d = loop_d && n10 + n00 > 4 && n01 + n11 > 4;
+                const int sh_ref = n11 + n01, sh = sh_ref + best;      // (lower bound of the shared reads: zero-state reads of the reference code left out)
+                const unsigned long long a0 = __ballot(act), a1 = __ballot(act && (pre_c || pre_d)), a2 = __ballot(act && ((is_cand && 2 * sh > n) || (loop_d && sh >= 10))), a3 = __ballot(ok);
+                if (lane == 0) { atomicAdd(&g_k4_dbg[0], (unsigned long long)__popcll(a0)); atomicAdd(&g_k4_dbg[1], (unsigned long long)__popcll(a1)); atomicAdd(&g_k4_dbg[2], (unsigned long long)__popcll(a2)); atomicAdd(&g_k4_dbg[3], (unsigned long long)__popcll(a3)); atomicAdd(&g_k4_dbg[4], 1ull);
+                    atomicAdd(&g_k4_dbg[5], (unsigned long long)((__builtin_amdgcn_readfirstlane(0), 0))); }
+                const int mr = wave_max_i32(nref), mo = wave_max_i32(oend - o0);
+                if (lane == 0) { atomicAdd(&g_k4_dbg[5], (unsigned long long)mr); atomicAdd(&g_k4_dbg[6], (unsigned long long)mo); }
+            }
+#endif
+            wave_lds_sync();
+            if (lane + 64 < npairs) s_pairs[lane] = moved;
+            npairs = npairs > 64 ? npairs - 64 : 0;
+            wave_lds_sync();
+        }
+    }
+    wave_lds_sync();
+    const uint32_t fl = s_flags;
+    if (hvalid && (tested || h_bad)) {
+        const bool kept = (fl >> lane) & 1u;
+        const bool undecided = ((fl >> (16 + lane)) & 1u) || ((bad_cols >> lane) & 1u);
+        keep[hc] = kept ? 1 : (undecided ? 2 : 0);
+    }
+    {   // the columns left to the exact kernel: one atomic per wavefront
+        const bool und = hvalid && (tested || h_bad) && !((fl >> lane) & 1u) && ((((fl >> (16 + lane)) & 1u) != 0u) || (((bad_cols >> lane) & 1u) != 0u));
+        const unsigned long long um = __ballot(und);
+        if (um) {
+            int at = 0;
+            if (lane == 0) at = atomicAdd(n_undecided, __popcll(um));
+            at = __builtin_amdgcn_readfirstlane(at);
+            if (und) undecided_list[at + __popcll(um & ((1ull << lane) - 1ull))] = hc;
+        }
     }
 }
 

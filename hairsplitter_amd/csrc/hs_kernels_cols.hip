@@ -29,7 +29,7 @@ struct alignas(16) hs_colrec_dev {
     uint16_t c0, c1;        // counts of the two most frequent codes (saturate at 65535: the depth limit of the path)
     uint8_t k0, k1;         // the codes, reference order of equal counts
     uint8_t flags;          // HS_COL_*
-    uint8_t c2_zero;        // third count is zero
+    uint8_t c2;             // the third count, saturating at 63
 };
 static_assert(sizeof(hs_colrec_dev) == 16, "hs_colrec must be 16 bytes");
 #define HS_COL_CAND 1
@@ -93,12 +93,12 @@ __global__ __launch_bounds__(256) void k_columns_compact(
             col_off[k] = e0 + before + incl - depth;
             col_len[k] = depth;
             hs_colrec_dev r;
-            r.pos = (int32_t)(g - contig_off[lo]); r.contig = lo; r.c0 = 0; r.c1 = 0; r.k0 = 0; r.k1 = 0; r.flags = HS_COL_OPEN; r.c2_zero = 0;
+            r.pos = (int32_t)(g - contig_off[lo]); r.contig = lo; r.c0 = 0; r.c1 = 0; r.k0 = 0; r.k1 = 0; r.flags = HS_COL_OPEN; r.c2 = 63;
             if (scratch_info) {
                 const uint2 inf = scratch_info[t * 256 + slot];
                 if (inf.y & 0x80000000u) {
                     r.c0 = (uint16_t)(inf.x & 0xffffu); r.c1 = (uint16_t)(inf.x >> 16);
-                    r.k0 = (uint8_t)(inf.y & 255u); r.k1 = (uint8_t)((inf.y >> 8) & 255u); r.flags = (uint8_t)((inf.y >> 16) & 255u); r.c2_zero = (uint8_t)((inf.y >> 24) & 1u);
+                    r.k0 = (uint8_t)(inf.y & 255u); r.k1 = (uint8_t)((inf.y >> 8) & 255u); r.flags = (uint8_t)((inf.y >> 16) & 255u); r.c2 = (uint8_t)((inf.y >> 24) & 63u);
                     if (r.flags & HS_COL_TIE) r.flags |= HS_COL_OPEN;      // (k_column_top3_exact orders it as the reference does)
                 }
             }
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_column_top3_exact(const int64_t* __rest
         if (lane == 0) {
             hs_colrec_dev r = col_rec[col];
             r.c0 = (uint16_t)(c0 > 65535 ? 65535 : c0); r.c1 = (uint16_t)(c1 > 65535 ? 65535 : c1);
-            r.k0 = (uint8_t)k0; r.k1 = (uint8_t)k1; r.c2_zero = c2 == 0 ? 1 : 0;
+            r.k0 = (uint8_t)k0; r.k1 = (uint8_t)k1; r.c2 = (uint8_t)(c2 < 63 ? c2 : 63);
             r.flags = tie ? HS_COL_TIE : 0;
             // c1 > c2 * 5 is all the path asks of the third count (call_variants.cpp:526): kept as a bit next to c2 == 0
             if (c1 > c2 * 5) r.flags |= HS_COL_C1GT5C2;
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256) void k_candidates_scan(
         r.flags = f;
         int4 w; __builtin_memcpy(&w, &r, 16);
         reinterpret_cast<int4*>(col_rec)[k] = w;
-        col_contig_local[k] = ci; col_k0[k] = r.k0; col_k1[k] = r.k1; col_c1[k] = r.c1; col_is_cand[k] = cand ? 1 : 0;
+        col_contig_local[k] = ci; col_k0[k] = r.k0; col_k1[k] = r.k1; col_c1[k] = (int32_t)r.c1 | ((63 - (int32_t)r.c2) << 16); col_is_cand[k] = cand ? 1 : 0;      // (bits 16-21 of the count's word: how far the third count lies below 63; 0 = not known)
     }
     // candidates per contig: one atomic per contig and wavefront (a wavefront's columns nearly always lie in one contig)
     unsigned long long m = __ballot(cand);

@@ -62,12 +62,12 @@ int hs_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchron
  * events on the stream it runs on; the elapsed times, the number of launches and the ALGORITHMIC bytes of each launch
  *  are accumulated per kernel family, process-wide, until hs_kernel_stats_reset().
  * ---------------------------------------------------------------------------------------------- */
-#define HS_NKERNELS 27
+#define HS_NKERNELS 28
 enum {   /* one slot per kernel of the path (a slot's helper launches -- prefix scans, block sums -- are counted with it) */
     HS_K_CIGAR_SCAN = 0, HS_K_PILEUP, HS_K_COLUMN_STATS, HS_K_COLUMNS_COMPACT, HS_K_GATHER_COLUMNS, HS_K_COLUMN_TOP3, HS_K_CANDIDATES_SCAN,
     HS_K_PACK_COLUMNS, HS_K_PARTITION_TRANSPOSE, HS_K_PARTITION_LANES, HS_K_PARTITION_TEST, HS_K_SNP_SELECT, HS_K_WINDOW_MASKS,
     HS_K_SNP_PLANES, HS_K_SIMDIFF, HS_K_GRAPH_ROWS, HS_K_GRAPH_CSR, HS_K_VISIT_LISTS, HS_K_CW_SEED_SETS, HS_K_CW_SEEDED, HS_K_CW_SEEDED_WIDE,
-    HS_K_WINDOW_TAIL, HS_K_CW_LOCAL, HS_K_ROBUST_PARTITIONS, HS_K_OTHER, HS_K_CAND_BITS, HS_K_SHIP
+    HS_K_WINDOW_TAIL, HS_K_CW_LOCAL, HS_K_ROBUST_PARTITIONS, HS_K_OTHER, HS_K_CAND_BITS, HS_K_SHIP, HS_K_PARTITION_GROUPED
 };
 typedef struct hs_kernel_stats {
     double ms[HS_NKERNELS];        /* sum of the launch durations (hipEventElapsedTime) */
@@ -295,7 +295,7 @@ typedef struct hs_colrec {
     uint16_t c0, c1;      /* reads carrying the two most frequent codes (call_variants.cpp:497-507) */
     uint8_t k0, k1;       /* those codes, equal counts in the reference's order (robin_hood iteration order + std::sort) */
     uint8_t flags;        /* HS_COL_* */
-    uint8_t c2_zero;      /* the third count is zero */
+    uint8_t c2;           /* the third count, saturating at 63 */
 } hs_colrec;
 #define HS_COL_CAND 1     /* candidate SNP of call_variants.cpp:525-536 */
 #define HS_COL_AUTO 2     /* ... that also passes the automatic threshold (:532) */

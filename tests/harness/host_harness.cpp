@@ -98,7 +98,7 @@ struct OracleCvOps : hs::CvDeviceOps {
                 if (!(c1v > 4 || (c1v == 4 && c2v == 0))) { if (is_cand[p]) { std::cerr << "harness: a candidate outside the extracted columns\n"; return 3; } continue; }
                 XCol x; x.contig = c; x.pos = (int)p;
                 hs_colrec& r = x.rec;
-                r.pos = (int32_t)p; r.contig = c; r.c0 = (uint16_t)cr.c0[p]; r.c1 = (uint16_t)c1v; r.k0 = cr.k0[p]; r.k1 = cr.k1[p]; r.c2_zero = c2v == 0;
+                r.pos = (int32_t)p; r.contig = c; r.c0 = (uint16_t)cr.c0[p]; r.c1 = (uint16_t)c1v; r.k0 = cr.k0[p]; r.k1 = cr.k1[p]; r.c2 = (uint8_t)(c2v < 63 ? c2v : 63);
                 r.flags = 0;
                 if (c1v > 5 * c2v) r.flags |= HS_COL_C1GT5C2;
                 if (is_cand[p]) r.flags |= HS_COL_CAND;
