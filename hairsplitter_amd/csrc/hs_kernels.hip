@@ -1413,7 +1413,7 @@ __global__ __launch_bounds__(256) void k_column_partition_lanes(
     const int32_t* __restrict__ col_contig, const uint8_t* __restrict__ col_k0, const uint8_t* __restrict__ col_k1,
     const int32_t* __restrict__ col_c1, const uint8_t* __restrict__ col_is_cand, int n_cols,
     const int32_t* __restrict__ part_off, const int32_t* __restrict__ ctg_n, const int64_t* __restrict__ tab_off, const uint8_t* __restrict__ tab,
-    uint8_t* __restrict__ keep) {
+    uint8_t* __restrict__ keep, int32_t* __restrict__ grouped_list, int32_t* __restrict__ n_grouped) {
     __shared__ __attribute__((aligned(16))) uint32_t s_off[4][HS_K4L_WAVE];      // per entry: where its read's row starts in the contig's table
     __shared__ __attribute__((aligned(16))) uint32_t s_cls[4][HS_K4L_WAVE];      // per entry: the shift amounts of its class
     const int lane = lane_id();
@@ -1533,35 +1533,49 @@ __global__ __launch_bounds__(256) void k_column_partition_lanes(
         kept = kept || ((__ballot(ok) >> gshift) & 0xffffull) != 0ull;
         unsettled = unsettled || ((__ballot(open) >> gshift) & 0xffffull) != 0ull;
     }
-    if ((tested || passed_on) && pl == 0) {
-        const bool pass = passed_on || (!kept && unsettled);
-        keep[col] = kept ? 1 : (pass ? 2 : 0);      // (2: k_column_partition_grouped takes the column)
+    const bool pass = (tested || passed_on) && pl == 0 && (passed_on || (!kept && unsettled));
+    if ((tested || passed_on) && pl == 0) keep[col] = kept ? 1 : (pass ? 2 : 0);
+    const unsigned long long pm = __ballot(pass);      // the columns left to k_column_partition_grouped: one atomic per wavefront
+    if (pm) {
+        int at = 0;
+        if (lane == 0) at = atomicAdd(n_grouped, __popcll(pm));
+        at = __builtin_amdgcn_readfirstlane(at);
+        if (pass) grouped_list[at + __popcll(pm & ((1ull << lane) - 1ull))] = col;
     }
 }
 
-// K4, second form (k_column_partition_grouped): the columns k_column_partition_lanes could not settle with its three counters (see there), 16
-// of its list per wavefront (= one workgroup).
-//  1. lanes 0..15 read the headers and decide which columns are tested at all;
+// K4, second form (k_column_partition_grouped): the columns k_column_partition_lanes could not settle with its counters (see there), four
+// of its list per wavefront (= one workgroup) at a time.
+//  1. the first lanes read the headers and decide which columns are tested at all;
 //  2. column by column, lanes = entries: the entries' read indices go to LDS grouped by code -- the reference code first (ballot ranks),
 //     the other codes behind it from the next multiple of 8 by a counting sort on LDS counters (rank = the old value of an atomic add,
 //     starts = one wave scan over the 128 counters) with one bit per entry saying "last of its code" --, and per block of 16 partitions
 //     the OR of the reads' presence words names the PAIRS {column, partition that shares a read with it};
 //  3. 64 pending pairs at a time, one per lane: the lane walks its column's grouped entries eight at a time (one 16-byte LDS read, eight
 //     table bytes in flight, 1 << byte added to an accumulator whose byte fields count absent / zero / plus / minus reads): the
-//     reference code -> n11 / n01, then the others with the accumulator evaluated at every code's last entry -> the most frequent
-//     other code's n10 / n00 (call_variants.cpp:832-936), then the table's verdicts for loops C and D (:721-764). No branch depends
-//     on a lane's data inside the walk.
-// chi-square: N (ad - bc)^2 / (r1 r2 c1 c2) in float decides unless it comes within 0.05 of a threshold, then the reference's own
-// sequence of float and double operations (chi_square_dev) does.
-// Not decided here (keep = 2, re-done by the exact kernel above): a column whose verdict hinges on a partition where the second allele is
-// tied among the shared reads (the reference breaks the tie by hash-map order), reference codes >= 128 (signed-char quirk), columns
+//     reference code -> n11 / n01, then the others with the accumulator evaluated at every code's last entry: the table this code would
+//     give as the second allele and its verdict for loops C and D (:721-764, k4_verdict); the codes the partition holds most reads of
+//     are the candidates for the second allele (call_variants.cpp:832-936; the reference breaks their tie by hash-map order).
+// Not decided here (keep = 2, re-done by the exact kernel above): a column with a partition whose tied candidates give different
+// verdicts, reference codes >= 128 (signed-char quirk), columns
 // deeper than 255, codes outside 33..160, contigs with more than 65535 reads or partitions or a table beyond 4 GB.
-#define HS_K4_COLS 16
+// the verdict of loops C (:721-738) and D (:745-764) on one table: chi-square as N (ad - bc)^2 / (r1 r2 c1 c2) in float unless that comes
+// within 0.05 of a threshold, then the reference's own sequence of float and double operations (chi_square_dev)
+static __device__ __noinline__ bool k4_verdict(int n11, int n01, int n10, int n00, int n, bool is_cand, bool loop_d) {
+    const int total = n00 + n01 + n10 + n11;
+    const bool pre_c = is_cand && 2 * total > n;                       // (double)total > 0.5 * (double)n
+    const bool pre_d = loop_d && n10 + n00 > 4 && n01 + n11 > 4;
+    const int r1 = n10 + n11, c1 = n01 + n11;
+    if (!((pre_c || pre_d) && r1 > 0 && r1 < total && c1 > 0 && c1 < total)) return false;      // (a margin of 0 or all: chi-square is -1 or 0)
+    const float det = (float)(n11 * n00 - n10 * n01);
+    float chi = (float)total * det * det * __builtin_amdgcn_rcpf((float)((r1 * (total - r1)) * (c1 * (total - c1))));
+    const bool near = (pre_c && fabsf(chi - 15.0f) < 0.05f) || (pre_d && fabsf(chi - 20.0f) < 0.05f);
+    if (near) { Table2x2 d; d.n00 = n00; d.n01 = n01; d.n10 = n10; d.n11 = n11; chi = chi_square_dev(d); }
+    return (pre_c && chi > 15) || (pre_d && (double)chi > 20.0);
+}
+#define HS_K4_COLS 4              // columns a wavefront takes at a time: their pairs fill about one round of 64
 #define HS_K4_ROW 264             // u16 entries of a column's row in LDS: 255 entries + the gap behind the reference code's + the tail
 #define HS_K4_PAIRS 80
-#ifdef HS_K4_DIAG
-__device__ unsigned long long g_k4_dbg[8];
-#endif
 static __device__ __forceinline__ int wave_or_i32(int v) {
     v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
     v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
@@ -1574,7 +1588,7 @@ static __device__ __forceinline__ int wave_or_i32(int v) {
 __global__ __launch_bounds__(64) void k_column_partition_grouped(
     const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
     const int32_t* __restrict__ col_contig, const uint8_t* __restrict__ col_k0, const uint8_t* __restrict__ col_k1,
-    const int32_t* __restrict__ col_c1, const uint8_t* __restrict__ col_is_cand, int n_cols,
+    const int32_t* __restrict__ col_c1, const uint8_t* __restrict__ col_is_cand, const int32_t* __restrict__ list, const int32_t* __restrict__ n_list,
     const int32_t* __restrict__ part_off, const int32_t* __restrict__ ctg_n, const int64_t* __restrict__ tab_off, const uint8_t* __restrict__ tab,
     const uint16_t* __restrict__ pres, uint8_t* __restrict__ keep, int32_t* __restrict__ undecided_list, int32_t* __restrict__ n_undecided) {
     __shared__ __attribute__((aligned(16))) uint16_t s_idx[HS_K4_COLS * HS_K4_ROW];
@@ -1584,10 +1598,11 @@ __global__ __launch_bounds__(64) void k_column_partition_grouped(
     __shared__ uint4 s_hdr[HS_K4_COLS];             // {table offset of the contig, row length, n | flags << 16, entries with the reference code | end of the others << 16}
     __shared__ uint32_t s_flags;                    // bit s: column s kept; bit 16 + s: undecided
     const int lane = lane_id();
-    // ---- the 16 column headers: lane l < 16 holds column col_base + l, if the first kernel left it open (keep == 2) ----
-    const int hc = (int)blockIdx.x * HS_K4_COLS + (lane & 15);
-    const bool hvalid = lane < 16 && hc < n_cols && keep[hc] == 2;
-    if (__ballot(hvalid) == 0ull) return;
+    const int n_listed = *n_list;
+    for (int first = (int)blockIdx.x * HS_K4_COLS; first < n_listed; first += (int)gridDim.x * HS_K4_COLS) {
+    // ---- the column headers: lane l < HS_K4_COLS holds the l-th listed column of this round ----
+    const bool hvalid = lane < HS_K4_COLS && first + lane < n_listed;
+    const int hc = hvalid ? list[first + lane] : 0;
     int h_n = 0, h_k0 = 0, h_flags = 0, h_ppad = 0;
     uint32_t h_tb = 0u;
     int64_t h_e0 = 0;
@@ -1610,10 +1625,10 @@ __global__ __launch_bounds__(64) void k_column_partition_grouped(
         else if (h_n > 255 || h_k0 >= 128 || N > 65535 || P > 65535 || tb + (int64_t)N * h_ppad > 0xffffffffll) h_bad = true;
         else tested = true;
     }
-    if (lane < 16) s_hdr[lane] = make_uint4(h_tb, (uint32_t)h_ppad, (uint32_t)h_n | ((uint32_t)h_flags << 16), 0u);
+    if (lane < HS_K4_COLS) s_hdr[lane] = make_uint4(h_tb, (uint32_t)h_ppad, (uint32_t)h_n | ((uint32_t)h_flags << 16), 0u);
     if (lane == 0) s_flags = 0u;
-    unsigned bad_cols = (unsigned)(__ballot(h_bad) & 0xffffull);
-    unsigned todo = (unsigned)(__ballot(tested) & 0xffffull);
+    unsigned bad_cols = (unsigned)(__ballot(h_bad) & ((1ull << HS_K4_COLS) - 1ull));
+    unsigned todo = (unsigned)(__ballot(tested) & ((1ull << HS_K4_COLS) - 1ull));
     int npairs = 0;
     int cur_s = -1;
     uint32_t cur_blk = 0u, cur_nblk = 0u;
@@ -1722,9 +1737,12 @@ __global__ __launch_bounds__(64) void k_column_partition_grouped(
             }
             if (o0 > nref) acc -= (uint32_t)(o0 - nref) << (uint32_t)tab[base];
             const int n11 = (int)((acc >> 16) & 255u), n01 = (int)(acc >> 24);
-            // the other codes: the accumulator is evaluated where an entry is the last of its code
+            // the other codes: the accumulator is evaluated where an entry is the last of its code -- the table this code would give as
+            // the second allele and its verdict; the codes the partition holds most of are the candidates for the second allele (the
+            // reference breaks their tie by hash-map order): where all of them give the same verdict, it does not matter which it takes
             acc = 0u;
-            uint32_t bestkey = 0u, bt = 0u, tie = 0u;
+            uint32_t bt = 0u;
+            bool ok_all = false, ok_any = false;
             const uint8_t* __restrict__ lastb = reinterpret_cast<const uint8_t*>(s_last[slot]);
             for (int e0 = o0; __ballot(e0 < oend) != 0ull; e0 += 8) {
                 if (e0 < oend) {
@@ -1738,53 +1756,21 @@ __global__ __launch_bounds__(64) void k_column_partition_grouped(
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         acc += 1u << b[u];
-                        const bool last = (fb >> u) & 1u;
-                        const uint32_t take = __builtin_amdgcn_sad_u8(acc & 0xffffff00u, 0u, 0u);      // zero + plus + minus: the code's reads the partition holds
-                        const uint32_t key = (take << 16) | (acc >> 16);
-                        const bool gt = last && take > bt, eq = last && take == bt && take != 0u;
-                        bestkey = gt ? key : bestkey;
-                        bt = gt ? take : bt;
-                        tie = gt ? 0u : (eq ? 1u : tie);
-                        acc = last ? 0u : acc;
+                        if ((fb >> u) & 1u) {
+                            const uint32_t take = __builtin_amdgcn_sad_u8(acc & 0xffffff00u, 0u, 0u);      // zero + plus + minus: the code's reads the partition holds
+                            if (take >= bt && take > 0u) {
+                                const bool vd = k4_verdict(n11, n01, (int)((acc >> 16) & 255u), (int)(acc >> 24), n, is_cand, loop_d);
+                                if (take > bt) { bt = take; ok_all = vd; ok_any = vd; }
+                                else { ok_all = ok_all && vd; ok_any = ok_any || vd; }
+                            }
+                            acc = 0u;
+                        }
                     }
                 }
             }
-            const int n10 = (int)(bestkey & 255u), n00 = (int)((bestkey >> 8) & 255u), best = (int)bt;
-            bool ok = false, und = false;
-            if (act) {
-                const int total = n00 + n01 + n10 + n11;
-                // a tie among the second alleles only matters where the verdict could depend on which one is taken: loop C needs more
-                // than half of the column's reads in the table (at most n11 + n01 + best of them are), loop D five reads on the
-                // second allele (at most best)
-                const bool tie_matters = tie != 0u && ((is_cand && 2 * (n11 + n01 + best) > n) || (loop_d && best >= 5));
-                if (tie_matters) und = true;
-                else {
-                    const bool pre_c = is_cand && 2 * total > n;                       // loop C (:721-738): (double)total > 0.5 * (double)n
-                    const bool pre_d = loop_d && n10 + n00 > 4 && n01 + n11 > 4;       // loop D (:745-764)
-                    const int r1 = n10 + n11, c1 = n01 + n11;
-                    if ((pre_c || pre_d) && r1 > 0 && r1 < total && c1 > 0 && c1 < total) {      // (a margin of 0 or all: chi-square is -1 or 0)
-                        const float det = (float)(n11 * n00 - n10 * n01);
-                        float chi = (float)total * det * det * __builtin_amdgcn_rcpf((float)((r1 * (total - r1)) * (c1 * (total - c1))));
-                        const bool near = (pre_c && fabsf(chi - 15.0f) < 0.05f) || (pre_d && fabsf(chi - 20.0f) < 0.05f);
-                        if (near) { Table2x2 d; d.n00 = n00; d.n01 = n01; d.n10 = n10; d.n11 = n11; chi = chi_square_dev(d); }
-                        ok = (pre_c && chi > 15) || (pre_d && (double)chi > 20.0);
-                    }
-                }
-            }
+            const bool ok = act && ok_all, und = act && ok_any && !ok_all;
             if (ok) atomicOr(&s_flags, 1u << slot);
             if (und) atomicOr(&s_flags, 0x10000u << slot);
-#ifdef HS_K4_DIAG
-            {
-                const int total = n00 + n01 + n10 + n11;
-                const bool pre_c = is_cand && 2 * total > n, pre_d = loop_d && n10 + n00 > 4 && n01 + n11 > 4;
-                const int sh_ref = n11 + n01, sh = sh_ref + best;      // (lower bound of the shared reads: zero-state reads of the reference code left out)
-                const unsigned long long a0 = __ballot(act), a1 = __ballot(act && (pre_c || pre_d)), a2 = __ballot(act && ((is_cand && 2 * sh > n) || (loop_d && sh >= 10))), a3 = __ballot(ok);
-                if (lane == 0) { atomicAdd(&g_k4_dbg[0], (unsigned long long)__popcll(a0)); atomicAdd(&g_k4_dbg[1], (unsigned long long)__popcll(a1)); atomicAdd(&g_k4_dbg[2], (unsigned long long)__popcll(a2)); atomicAdd(&g_k4_dbg[3], (unsigned long long)__popcll(a3)); atomicAdd(&g_k4_dbg[4], 1ull);
-                    atomicAdd(&g_k4_dbg[5], (unsigned long long)((__builtin_amdgcn_readfirstlane(0), 0))); }
-                const int mr = wave_max_i32(nref), mo = wave_max_i32(oend - o0);
-                if (lane == 0) { atomicAdd(&g_k4_dbg[5], (unsigned long long)mr); atomicAdd(&g_k4_dbg[6], (unsigned long long)mo); }
-            }
-#endif
             wave_lds_sync();
             if (lane + 64 < npairs) s_pairs[lane] = moved;
             npairs = npairs > 64 ? npairs - 64 : 0;
@@ -1808,6 +1794,8 @@ __global__ __launch_bounds__(64) void k_column_partition_grouped(
             if (und) undecided_list[at + __popcll(um & ((1ull << lane) - 1ull))] = hc;
         }
     }
+    wave_lds_sync();
+    }      // (the next listed columns)
 }
 
 }  // namespace hsdev
