@@ -208,6 +208,22 @@ struct ColView {
     }
     int slot_of(uint8_t code) const { for (int k = 0; k < nslots; ++k) if (codes[k] == code) return k; return -1; }
     const uint64_t* slot(int k) const { return slots + (size_t)k * W; }
+    // once per column, for the comparisons with every live partition: where the reference code lies, which other code the column holds
+    // most of (k1_slot, -1 when two share that count) and how many reads the next one has (c2): among ANY subset of the column's reads
+    // no code other than those two has more than c2
+    int ref_slot = -1, k1_slot = -1, c2 = 0;
+    void prepare(uint8_t ref) {
+        ref_slot = slot_of(ref); k1_slot = -1; c2 = 0;
+        int best = 0;
+        for (int k = 0; k < nslots; ++k) {
+            if (k == ref_slot) continue;
+            int c = 0; const uint64_t* bk = slot(k);
+            for (int j = 0; j < W; ++j) c += __builtin_popcountll(bk[j]);
+            if (c > best) { c2 = best; best = c; k1_slot = k; }
+            else { if (c == best) k1_slot = -1; if (c > c2) c2 = c; }
+        }
+        if (k1_slot < 0) c2 = best;
+    }
 };
 
 void cv_rank_reads(int n_reads, const int32_t* read_start, std::vector<int32_t>& rank_of, std::vector<int32_t>& orig_of) {
@@ -305,8 +321,18 @@ static Contingency column_vs_partition_bits(const RankPartition& p, const ColVie
         // than the reference code; a tie of that largest count (the reference then takes the first of the tied codes in the
         // iteration order of its hash map) goes through the general form below
         int best = -1, nbest = 0, best_slot = -1;
-        const int ref_slot = cb.slot_of(ref);
-        for (int k = 0; k < cb.nslots; ++k) {
+        const int ref_slot = cb.ref_slot;
+        bool settled = false;
+        if (cb.k1_slot >= 0) {      // the column's own second code has more shared reads than any other code can have: it is the one, no tie
+            const uint64_t* bk = slot_abs(cb.k1_slot);
+            int ck = 0, cr = 0;
+            for (int w = w0; w <= w1; ++w) ck += __builtin_popcountll(bk[w] & p.present[(size_t)w]);
+            if (ref_slot >= 0) { const uint64_t* br = slot_abs(ref_slot); for (int w = w0; w <= w1; ++w) cr += __builtin_popcountll(br[w] & p.present[(size_t)w]); }
+            const int rest = shared - cr - ck;
+            if (ck > (rest < cb.c2 ? rest : cb.c2)) { best = ck; nbest = 1; best_slot = cb.k1_slot; settled = true; }
+            else if (ck == 0 && rest == 0) { nbest = 0; settled = true; }      // (only the reference code among the shared reads)
+        }
+        for (int k = 0; k < cb.nslots && !settled; ++k) {
             if (k == ref_slot) continue;
             const uint64_t* bk = slot_abs(k);
             int c = 0;
@@ -385,6 +411,21 @@ static float chi_square(const Contingency& d) {
     return (float)(d00 * d00 / (double)e00 + d01 * d01 / (double)e01 + d10 * d10 / (double)e10 + d11 * d11 / (double)e11);
 }
 
+
+// chi_square(d) > 15 for a table whose margins are known to be neither empty nor full: N (ad - bc)^2 / (r1 r2 c1 c2) in double decides unless
+// it comes within 0.05 of the threshold, then the reference's own sequence of float and double operations does
+static inline bool chi_square_above_15(const Contingency& d) {
+    const double n = (double)(d.n00 + d.n01 + d.n10 + d.n11);
+    const double r1 = (double)(d.n10 + d.n11), c1 = (double)(d.n01 + d.n11);
+    const double den = r1 * (n - r1) * c1 * (n - c1);
+    if (den > 0) {
+        const double det = (double)d.n11 * d.n00 - (double)d.n10 * d.n01;
+        const double chi = n * det * det / den;
+        if (chi > 15.05) return true;
+        if (chi < 14.95) return false;
+    }
+    return chi_square(d) > 15;
+}
 
 // Partition::Partition(Column&, pos, ref_base): Partition.cpp:32-83
 static void partition_from_column(RankPartition& p, PartitionArena& arena, int n_reads, const ColView& cb, int pos, uint8_t ref,
@@ -666,7 +707,8 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
         const int pos = cs.rec[ci].pos;
         const uint8_t k0 = cs.rec[ci].k0;
         if (pos - last_position <= 5) continue;
-        const ColView colbits(cs.bits[ci], cs.words);
+        ColView colbits(cs.bits[ci], cs.words);
+        colbits.prepare(k0);
         const int n = colbits.n_entries;
         bool found = false;
         int n_corr = 0;
@@ -701,7 +743,7 @@ void cv_phase_a_host(CvContigState& st, const CandidateSet& cs, const int32_t* r
 #endif
             const int comparable = d.n00 + d.n11 + d.n01 + d.n10;
             if (d.n00 + d.n01 > 0.1 * comparable && d.n00 + d.n01 < 0.9 * comparable && d.n01 + d.n11 > 0.1 * comparable
-                && d.n01 + d.n11 < 0.9 * comparable && chi_square(d) > 15) {
+                && d.n01 + d.n11 < 0.9 * comparable && chi_square_above_15(d)) {
                 n_corr += 1; parts[p].n_corr += 1;
             }
             const bool enough = (size_t)comparable >= (size_t)n / 2;
