@@ -218,42 +218,6 @@ static __device__ int cw_local_wave(const int64_t* __restrict__ off_w /* at the 
     return iters;
 }
 
-// The same run for a window of at most 64 nodes, without memory on the way: lane j holds the label of node j, the neighbours of
-// the visited node are ONE 64-bit mask (k_cw_visit_lists), the vote is a leader loop over the distinct labels of the lanes in
-// that mask (ballot + popcount each), the new label goes to its lane. `lab` (m ints) is read at the start and written at the end.
-static __device__ int cw_local_wave_masks(const unsigned long long* __restrict__ adj_w, const uint32_t* __restrict__ info_w, int n_visit, int m,
-                                          int32_t* lab, int lane) {
-    int L = lane < m ? lab[lane] : -1;
-    int changes = 3, iters = 0;
-    while (changes > 2 && iters < 15) {
-        changes = 0;
-        unsigned long long adj_n = n_visit > 0 ? adj_w[0] : 0ull;
-        uint32_t inf_n = n_visit > 0 ? info_w[0] : 0u;
-        for (int v = 0; v < n_visit; ++v) {
-            const unsigned long long adj = adj_n;
-            const int i = (int)(inf_n & 255u);
-            if (v + 1 < n_visit) { adj_n = adj_w[v + 1]; inf_n = info_w[v + 1]; }
-            unsigned long long rem = adj & __ballot(L >= 0);      // labels < 0 do not vote
-            int best_cnt = 0, best_lab = -1;
-            while (rem) {
-                const int X = __builtin_amdgcn_readlane(L, __builtin_ctzll(rem));
-                const unsigned long long mX = __ballot(L == X) & adj;
-                rem &= ~mX;
-                const int c = __popcll(mX);
-                if (c > best_cnt || (c == best_cnt && X < best_lab)) { best_cnt = c; best_lab = X; }      // lowest label among the most frequent (:272-279)
-            }
-            if (best_cnt > 0) {
-                const int old = __builtin_amdgcn_readlane(L, i);
-                if (old != best_lab) { changes++; if (lane == i) L = best_lab; }
-            }
-        }
-        iters++;
-    }
-    if (lane < m) lab[lane] = L;
-    wave_sync_lds();
-    return iters;
-}
-
 // Seeding of a per-SNP run (separate_reads.cpp:1678-1691): every node starts alone; the nodes that carry the same code at
 // the seeding SNP start in the cluster of the first node (lowest read id) carrying it. `first`: 256 ints of scratch.
 template <int LANES>
@@ -727,6 +691,74 @@ __global__ __launch_bounds__(64) void k_cw_local(
 }
 
 // ------------------------------------------------------------------------------------------------
+// A window of at most 64 nodes with its labels kept TWICE in registers: lane j = node j holds its label L (-1: none), lane l = label l
+// holds the set S of its nodes as a bit mask (labels are node indices renumbered by first appearance: < m <= 64). A vote of a node's
+// neighbours (one bit mask `adj`, k_cw_visit_lists) is then popcount(adj & S) in every lane at once and one wave maximum, instead of a
+// leader loop over the distinct labels among the neighbours.
+// ------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#define HS_OR_STEP(ctrl, rm) lo |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, ctrl, rm, 0xf, false); hi |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, ctrl, rm, 0xf, false);
+    HS_OR_STEP(0x111, 0xf) HS_OR_STEP(0x112, 0xf) HS_OR_STEP(0x114, 0xf) HS_OR_STEP(0x118, 0xf) HS_OR_STEP(0x142, 0xa) HS_OR_STEP(0x143, 0xc)
+#undef HS_OR_STEP
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, 63) << 32) | (unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+}
+static __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffffull), l);
+}
+// S from L: one 64-bit LDS atomic per node (s_sets: 64 words)
+static __device__ __forceinline__ unsigned long long sets_from_labels(int L, unsigned long long* s_sets, int lane) {
+    s_sets[lane] = 0ull;
+    wave_sync_lds();
+    if (L >= 0) atomicOr(&s_sets[L], 1ull << lane);
+    wave_sync_lds();
+    const unsigned long long S = s_sets[lane];
+    wave_sync_lds();
+    return S;
+}
+// labels renumbered by first appearance (the label whose first node comes first becomes 0, ...): returns the number of labels
+static __device__ __forceinline__ int sets_renumber(unsigned long long& S, int& L, unsigned long long* s_sets, int* s_relabel, int lane) {
+    const int f = S ? __builtin_ctzll(S) : 64;
+    const unsigned long long F = wave_or_u64(S ? 1ull << f : 0ull);      // the first nodes of all labels
+    const int nl = S ? __popcll(F & ((1ull << f) - 1ull)) : -1;
+    s_sets[lane] = 0ull; s_relabel[lane] = nl;
+    wave_sync_lds();
+    if (nl >= 0) s_sets[nl] = S;
+    const int Ln = L >= 0 ? s_relabel[L] : -1;
+    wave_sync_lds();
+    S = s_sets[lane]; L = Ln;
+    wave_sync_lds();
+    return __popcll(F);
+}
+// one Chinese-Whispers run (cluster_graph.cpp:240-310; what cw_local_wave does on lists): lane v holds the v-th visit's node and
+// neighbour mask
+static __device__ int cw_run_sets(unsigned long long adjv, int nodev, int n_visit, unsigned long long& S, int& L, int lane) {
+    int changes = 3, iters = 0;
+    while (changes > 2 && iters < 15) {
+        changes = 0;
+        for (int v = 0; v < n_visit; ++v) {
+            const unsigned long long adj = readlane_u64(adjv, v);
+            const int i = __builtin_amdgcn_readlane(nodev, v);
+            const int c = __popcll(adj & S);
+            const int best = wave_max_i32(c ? ((c << 6) | (63 - lane)) : 0);      // most frequent label among the neighbours, the lowest of equals (:272-279)
+            if (best) {
+                const int bl = 63 - (best & 63);
+                const int old = __builtin_amdgcn_readlane(L, i);
+                if (old != bl) {
+                    changes++;
+                    const unsigned long long bit = 1ull << i;
+                    if (lane == old) S &= ~bit;
+                    if (lane == bl) S |= bit;
+                    if (lane == i) L = bl;
+                }
+            }
+        }
+        iters++;
+    }
+    return iters;
+}
+
+// ------------------------------------------------------------------------------------------------
 // id[j] = number of distinct first appearances before first[j], where first[j] = index of the first element equal to
 // element j (or -1: no label). One wavefront, chunks of 64 with a ballot prefix; `pre` is m ints of scratch.
 // ------------------------------------------------------------------------------------------------
@@ -769,6 +801,8 @@ __global__ __launch_bounds__(64) void k_window_tail(
     __shared__ int s_incompat[HS_FIN_GCAP * HS_FIN_GCAP];
     __shared__ int s_link_cnt[HS_FIN_MCAP * HS_FIN_MCAP], s_links_in[HS_FIN_MCAP], s_o2n[HS_FIN_MCAP], s_new_index[HS_FIN_MCAP];
     __shared__ int s_scalar[8];
+    __shared__ unsigned long long s_sets[64];
+    __shared__ int s_relabel[64];
     __shared__ int s_lc1[HS_FIN_LCAP], s_lc2[HS_FIN_LCAP];
     __shared__ double s_lr[HS_FIN_LCAP];
     const int lane = lane_id();
@@ -848,11 +882,89 @@ __global__ __launch_bounds__(64) void k_window_tail(
     }
     first_seen_ids_wave(t0, m, t1, lab, lane);
     HS_TQ(0)
-    // ---- run on the finalize graph (:881) ----
     const bool masks = m <= 64 && prog_adj != nullptr;      // the window's neighbour masks exist (k_cw_visit_lists)
     wave_sync_lds();
-    sweeps += (unsigned long long)(masks ? cw_local_wave_masks(prog_adj + r0, prog_info + r0, n_visit, m, lab, lane)
-                                         : cw_local_wave(off_w, nbr, vis, n_visit, m, lab, cnt, lane));
+    int Kc = 0;
+    if (masks) {
+        // ---- at most 64 nodes: the labels stay in registers, as node -> label and as label -> set of nodes ----
+        const unsigned long long adjv = lane < n_visit ? prog_adj[r0 + lane] : 0ull;
+        const int nodev = lane < n_visit ? (int)(prog_info[r0 + lane] & 255u) : 0;
+        int L = lane < m ? lab[lane] : -1;
+        unsigned long long S = sets_from_labels(L, s_sets, lane);
+        // run on the finalize graph (:881)
+        sweeps += (unsigned long long)cw_run_sets(adjv, nodev, n_visit, S, L, lane);
+        // clusters with fewer than 5 reads become -1, the others are renumbered by first appearance (:924-955)
+        {
+            const bool small = S != 0ull && __popcll(S) < 5;
+            const unsigned long long gone = wave_or_u64(small ? S : 0ull);
+            if (small) S = 0ull;
+            if ((gone >> lane) & 1ull) L = -1;
+            sets_renumber(S, L, s_sets, s_relabel, lane);
+        }
+        // run (:970)
+        sweeps += (unsigned long long)cw_run_sets(adjv, nodev, n_visit, S, L, lane);
+        if (lane < m) l3[lane] = L;
+        if (lane == 0 && stat) {
+            atomicAdd(&stat[0], sweeps);
+            atomicAdd(&stat[1], sweeps * (4ull * (unsigned long long)(off_w[m] - abase) + 8ull * (unsigned long long)m));
+        }
+        if (!finish_on_device) { bail(); return; }
+        HS_TQ(1)
+        // first-seen renumbering (:973-984)
+        Kc = sets_renumber(S, L, s_sets, s_relabel, lane);
+        if (Kc > HS_FIN_KCAP) { bail(); return; }
+        HS_TQ(2)
+        // ---- merge_close_clusters (cluster_graph.cpp:402-501): every cluster in turn (in the order its first node appears) tries to
+        // give its nodes away -- a node goes to the label most of its neighbours carry, or to the runner-up when it is at least half
+        // as strong --; only a cluster that dissolves completely stays dissolved ----
+        {
+            unsigned long long N = S;      // the working copy of the sets (nc); S stays what is committed (lab)
+            int Lw = L;
+            unsigned long long tested = 0ull;
+            for (int j = 0; j < m; ++j) {
+                const int target = __builtin_amdgcn_readlane(L, j);
+                if (target < 0 || ((tested >> target) & 1ull)) continue;
+                int changes = 3, iters = 0;
+                while (changes > 0 && iters < 10) {
+                    changes = 0;
+                    const unsigned long long members = readlane_u64(N, target);      // (a node only leaves the cluster at its own visit)
+                    unsigned long long act = __ballot(lane < n_visit && ((members >> nodev) & 1ull));
+                    while (act) {
+                        const int v = __builtin_ctzll(act);
+                        act &= act - 1ull;
+                        const unsigned long long adj = readlane_u64(adjv, v);
+                        const int i = __builtin_amdgcn_readlane(nodev, v);
+                        const int c = __popcll(adj & N);
+                        // largest and runner-up in ascending label order with strict '>' (:455-470): (count desc, label asc)
+                        const int key = c > 0 ? ((c << 8) | (255 - lane)) : 0;
+                        const int best = wave_max_i32(key);
+                        const int max_value = best >> 8, max_index = best ? 255 - (best & 255) : 0;
+                        const int best2 = wave_max_i32((best && lane == max_index) ? 0 : key);
+                        const int second_value = best2 >> 8, second_index = best2 ? 255 - (best2 & 255) : 0;
+                        int to = -1;
+                        if (max_value > 0 && max_index != target) to = max_index;
+                        else if (max_value > 0 && max_value <= 2 * second_value) to = second_index;
+                        if (to >= 0) {
+                            const unsigned long long bit = 1ull << i;
+                            if (lane == target) N &= ~bit;
+                            if (lane == to) N |= bit;      // (to == target: the node stays, as the reference's counters say)
+                            if (lane == i) Lw = to;
+                            changes++;
+                        }
+                    }
+                    iters++;
+                }
+                const bool dissolved = readlane_u64(N, target) == 0ull;
+                tested |= 1ull << target;
+                if (dissolved) { S = N; L = Lw; } else { N = S; Lw = L; }
+            }
+        }
+        if (lane < m) { lab[lane] = L; nc[lane] = L; }
+        wave_sync_lds();
+    } else {
+    // ---- wider windows: labels in LDS (or global scratch), neighbour lists ----
+    // ---- run on the finalize graph (:881) ----
+    sweeps += (unsigned long long)cw_local_wave(off_w, nbr, vis, n_visit, m, lab, cnt, lane);
     // ---- clusters with fewer than 5 reads become -1, the others are renumbered by first appearance (:924-955) ----
     for (int j = lane; j < m; j += 64) { nc[j] = 0; t1[j] = 0x7fffffff; }
     wave_sync_lds();
@@ -870,8 +982,7 @@ __global__ __launch_bounds__(64) void k_window_tail(
     first_seen_ids_wave(nc, m, t1, lab, lane);
     // ---- run (:970) ----
     wave_sync_lds();
-    sweeps += (unsigned long long)(masks ? cw_local_wave_masks(prog_adj + r0, prog_info + r0, n_visit, m, lab, lane)
-                                         : cw_local_wave(off_w, nbr, vis, n_visit, m, lab, cnt, lane));
+    sweeps += (unsigned long long)cw_local_wave(off_w, nbr, vis, n_visit, m, lab, cnt, lane);
     for (int j = lane; j < m; j += 64) l3[j] = lab[j];
     if (lane == 0 && stat) {
         atomicAdd(&stat[0], sweeps);
@@ -887,7 +998,6 @@ __global__ __launch_bounds__(64) void k_window_tail(
     for (int j = lane; j < m; j += 64) { const int l = lab[j]; if (l >= 0) { if (l >= m) bad_l = true; else atomicMin(&t1[l], j); } }
     wave_sync_lds();
     if (__ballot(bad_l) != 0ull) { bail(); return; }
-    int Kc = 0;
     for (int b0 = 0; b0 < m; b0 += 64) {
         const int j = b0 + lane;
         int f = -1;
@@ -977,6 +1087,8 @@ __global__ __launch_bounds__(64) void k_window_tail(
             for (int q = lane; q < m; q += 64) nc[q] = lab[q];
         }
         wave_sync_lds();
+    }
+
     }
 
     HS_TQ(3)
