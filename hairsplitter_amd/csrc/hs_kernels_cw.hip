@@ -26,6 +26,7 @@ namespace hsdev {
 #define HS_FIN_GCAP 8       // clusters entering merge_wrongly_split
 #define HS_FIN_LCAP 16      // cluster links (std::sort is a plain insertion sort up to 16 elements)
 #define HS_FIN_MCAP (HS_FIN_KCAP + 2)
+#define HS_TAIL_MAP_EXTRA 1024      // bytes of dynamic LDS behind the tail's arrays: the read id -> cluster map of narrow windows
 #define HS_TAIL_BATCH 8     // SNP columns of a window in flight at once in merge_wrongly_split
 #define HS_CWR_CAP 255      // nodes per run in the row-packed kernel (local ids and labels are bytes, 255 = none)
 #ifndef HS_CW_REG_LABELS
@@ -731,26 +732,59 @@ static __device__ __forceinline__ int sets_renumber(unsigned long long& S, int& 
     return __popcll(F);
 }
 // one Chinese-Whispers run (cluster_graph.cpp:240-310; what cw_local_wave does on lists): lane v holds the v-th visit's node and
-// neighbour mask
-static __device__ int cw_run_sets(unsigned long long adjv, int nodev, int n_visit, unsigned long long& S, int& L, int lane) {
+// neighbour mask (adjv, nodev), lane j node j's neighbour mask (adjn). A sweep visits the nodes in order and a node takes the most frequent
+// label among its neighbours, the lowest of equals (:272-279). While many labels are alive a sweep is walked visit by visit (one popcount
+// per lane = label and a wave maximum per visit); with few labels alive, the votes of ALL nodes under the current labels are formed at
+// once (lane = node, a loop over the alive labels) and the sweep jumps to the first node in visiting order that would change -- the
+// nodes before it are stable under these labels and stay so until something changes --, applies that change and votes again.
+#define HS_CW_SPEC_LABELS 8
+static __device__ int cw_run_sets(unsigned long long adjv, int nodev, unsigned long long adjn, int n_visit, unsigned long long& S, int& L, int lane) {
     int changes = 3, iters = 0;
     while (changes > 2 && iters < 15) {
         changes = 0;
-        for (int v = 0; v < n_visit; ++v) {
-            const unsigned long long adj = readlane_u64(adjv, v);
-            const int i = __builtin_amdgcn_readlane(nodev, v);
-            const int c = __popcll(adj & S);
-            const int best = wave_max_i32(c ? ((c << 6) | (63 - lane)) : 0);      // most frequent label among the neighbours, the lowest of equals (:272-279)
-            if (best) {
-                const int bl = 63 - (best & 63);
-                const int old = __builtin_amdgcn_readlane(L, i);
-                if (old != bl) {
-                    changes++;
-                    const unsigned long long bit = 1ull << i;
-                    if (lane == old) S &= ~bit;
-                    if (lane == bl) S |= bit;
-                    if (lane == i) L = bl;
+        unsigned long long alive = __ballot(S != 0ull);
+        if (__popcll(alive) > HS_CW_SPEC_LABELS) {
+            for (int v = 0; v < n_visit; ++v) {
+                const unsigned long long adj = readlane_u64(adjv, v);
+                const int i = __builtin_amdgcn_readlane(nodev, v);
+                const int c = __popcll(adj & S);
+                const int best = wave_max_i32(c ? ((c << 6) | (63 - lane)) : 0);
+                if (best) {
+                    const int bl = 63 - (best & 63);
+                    const int old = __builtin_amdgcn_readlane(L, i);
+                    if (old != bl) {
+                        changes++;
+                        const unsigned long long bit = 1ull << i;
+                        if (lane == old) S &= ~bit;
+                        if (lane == bl) S |= bit;
+                        if (lane == i) L = bl;
+                    }
                 }
+            }
+        } else {
+            int p = 0;      // visits before p are done in this sweep
+            while (p < n_visit) {
+                int best = 0;
+                for (unsigned long long am = alive; am; am &= am - 1ull) {
+                    const int l = __builtin_ctzll(am);
+                    const int c = __popcll(adjn & readlane_u64(S, l));
+                    const int key = c ? ((c << 6) | (63 - l)) : 0;
+                    best = key > best ? key : best;
+                }
+                const int wants = 63 - (best & 63);
+                const unsigned long long U = __ballot(best != 0 && wants != L);                                          // by node
+                const unsigned long long Uv = __ballot(lane >= p && lane < n_visit && ((U >> nodev) & 1ull));          // by visit, from p on
+                if (!Uv) break;
+                const int v0 = __builtin_ctzll(Uv);
+                const int i = __builtin_amdgcn_readlane(nodev, v0);
+                const int bl = __builtin_amdgcn_readlane(wants, i), old = __builtin_amdgcn_readlane(L, i);
+                const unsigned long long bit = 1ull << i;
+                if (lane == old) S &= ~bit;
+                if (lane == bl) S |= bit;
+                if (lane == i) L = bl;
+                changes++;
+                p = v0 + 1;
+                alive = __ballot(S != 0ull);
             }
         }
         iters++;
@@ -787,27 +821,28 @@ __global__ __launch_bounds__(64) void k_window_tail(
     const int32_t* __restrict__ mask_ids, const int32_t* __restrict__ visit, const int32_t* __restrict__ visit_n,
     const uint8_t* __restrict__ win_final_empty, const uint32_t* __restrict__ prog_info, const unsigned long long* __restrict__ prog_adj,
     const int32_t* __restrict__ chain_win, const int64_t* __restrict__ chain_row0, const int64_t* __restrict__ chain_seed_begin,
-    const int64_t* __restrict__ chain_slab0, const int32_t* __restrict__ slab, int n_chain,
+    const int64_t* __restrict__ chain_slab0, const int32_t* __restrict__ slab, const int32_t* __restrict__ chain_list /* the chain windows of this launch */, int n_chain,
     const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
     const int32_t* __restrict__ col_pos, const int64_t* __restrict__ win_snp_first, const int64_t* __restrict__ win_snp_last,
     const int32_t* __restrict__ win_pos_lo, const int32_t* __restrict__ win_pos_hi, int finish_on_device,
     int lds_cap, int32_t* __restrict__ gscratch, const int64_t* __restrict__ gscratch_off,
     int32_t* __restrict__ labels3_out, int32_t* __restrict__ final_out, uint8_t* __restrict__ ok_out, unsigned long long* __restrict__ stat) {
-    extern __shared__ int32_t tail_dyn[];    // [7 * lds_cap] (the doubles first: 8-byte aligned)
+    extern __shared__ int32_t tail_dyn[];    // [7 * lds_cap] (the doubles first: 8-byte aligned), then HS_TAIL_MAP_EXTRA bytes
     __shared__ int s_count[HS_FIN_KCAP], s_initial[HS_FIN_KCAP], s_tested[HS_FIN_KCAP];
     __shared__ int s_index_of[HS_FIN_KCAP], s_slot_of[HS_FIN_KCAP];
-    __shared__ int s_cnts[256];
     __shared__ int s_glist[HS_FIN_GCAP], s_gidx[HS_FIN_GCAP];
     __shared__ int s_incompat[HS_FIN_GCAP * HS_FIN_GCAP];
     __shared__ int s_link_cnt[HS_FIN_MCAP * HS_FIN_MCAP], s_links_in[HS_FIN_MCAP], s_o2n[HS_FIN_MCAP], s_new_index[HS_FIN_MCAP];
+    static_assert(HS_FIN_MCAP * HS_FIN_MCAP >= 256, "the deep-column histogram shares the link matrix's words");
+    int* const s_cnts = s_link_cnt;      // (256-bin histogram of snp_deep: done with before the links are counted)
     __shared__ int s_scalar[8];
     __shared__ unsigned long long s_sets[64];
     __shared__ int s_relabel[64];
     __shared__ int s_lc1[HS_FIN_LCAP], s_lc2[HS_FIN_LCAP];
     __shared__ double s_lr[HS_FIN_LCAP];
     const int lane = lane_id();
-    const int c = (int)blockIdx.x;
-    if (c >= n_chain) return;
+    if ((int)blockIdx.x >= n_chain) return;
+    const int c = chain_list[blockIdx.x];
     const int w = chain_win[c];
     const int64_t r0 = win_row0[w];
     const int m = (int)(win_row0[w + 1] - r0);
@@ -845,6 +880,13 @@ __global__ __launch_bounds__(64) void k_window_tail(
     for (int j = lane; j < m; j += 64) {
         double a = 0.0, f = 1.0;
         int i = 0;
+        for (; i + 16 <= K; i += 16) {      // sixteen labels in flight, added in the reference's order
+            int lv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) lv[u] = sl[(int64_t)(i + u) * m + j];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { a += (double)t1[lv[u]] * f; f *= 2.0; }      // exact powers of two
+        }
         for (; i + 4 <= K; i += 4) {      // four labels in flight, added in the reference's order
             const int l0 = sl[(int64_t)i * m + j], l1 = sl[(int64_t)(i + 1) * m + j], l2 = sl[(int64_t)(i + 2) * m + j], l3v = sl[(int64_t)(i + 3) * m + j];
             a += (double)t1[l0] * f; f *= 2.0; a += (double)t1[l1] * f; f *= 2.0; a += (double)t1[l2] * f; f *= 2.0; a += (double)t1[l3v] * f; f *= 2.0;      // exact powers of two
@@ -885,14 +927,22 @@ __global__ __launch_bounds__(64) void k_window_tail(
     const bool masks = m <= 64 && prog_adj != nullptr;      // the window's neighbour masks exist (k_cw_visit_lists)
     wave_sync_lds();
     int Kc = 0;
+    unsigned long long fin_S = 0ull, fin_adjn = 0ull;      // (narrow windows: the finished label sets and every node's neighbours, for the steps below)
+    int fin_L = -1;
     if (masks) {
         // ---- at most 64 nodes: the labels stay in registers, as node -> label and as label -> set of nodes ----
         const unsigned long long adjv = lane < n_visit ? prog_adj[r0 + lane] : 0ull;
         const int nodev = lane < n_visit ? (int)(prog_info[r0 + lane] & 255u) : 0;
         int L = lane < m ? lab[lane] : -1;
+        s_sets[lane] = 0ull;
+        wave_sync_lds();
+        if (lane < n_visit) s_sets[nodev] = adjv;
+        wave_sync_lds();
+        const unsigned long long adjn = s_sets[lane];      // node j's neighbours (none: not in the visiting list)
+        wave_sync_lds();
         unsigned long long S = sets_from_labels(L, s_sets, lane);
         // run on the finalize graph (:881)
-        sweeps += (unsigned long long)cw_run_sets(adjv, nodev, n_visit, S, L, lane);
+        sweeps += (unsigned long long)cw_run_sets(adjv, nodev, adjn, n_visit, S, L, lane);
         // clusters with fewer than 5 reads become -1, the others are renumbered by first appearance (:924-955)
         {
             const bool small = S != 0ull && __popcll(S) < 5;
@@ -902,7 +952,7 @@ __global__ __launch_bounds__(64) void k_window_tail(
             sets_renumber(S, L, s_sets, s_relabel, lane);
         }
         // run (:970)
-        sweeps += (unsigned long long)cw_run_sets(adjv, nodev, n_visit, S, L, lane);
+        sweeps += (unsigned long long)cw_run_sets(adjv, nodev, adjn, n_visit, S, L, lane);
         if (lane < m) l3[lane] = L;
         if (lane == 0 && stat) {
             atomicAdd(&stat[0], sweeps);
@@ -927,30 +977,37 @@ __global__ __launch_bounds__(64) void k_window_tail(
                 int changes = 3, iters = 0;
                 while (changes > 0 && iters < 10) {
                     changes = 0;
-                    const unsigned long long members = readlane_u64(N, target);      // (a node only leaves the cluster at its own visit)
-                    unsigned long long act = __ballot(lane < n_visit && ((members >> nodev) & 1ull));
-                    while (act) {
-                        const int v = __builtin_ctzll(act);
-                        act &= act - 1ull;
-                        const unsigned long long adj = readlane_u64(adjv, v);
-                        const int i = __builtin_amdgcn_readlane(nodev, v);
-                        const int c = __popcll(adj & N);
-                        // largest and runner-up in ascending label order with strict '>' (:455-470): (count desc, label asc)
-                        const int key = c > 0 ? ((c << 8) | (255 - lane)) : 0;
-                        const int best = wave_max_i32(key);
+                    // where every node of the cluster would go under the current labels (lane = node): largest and runner-up among its
+                    // neighbours' labels in ascending label order with strict '>' (:455-470: count desc, label asc); the sweep jumps to
+                    // the first such node in visiting order, moves it and votes again
+                    int p = 0;
+                    while (p < n_visit) {
+                        const unsigned long long alive = __ballot(N != 0ull);
+                        int best = 0, second = 0;
+                        for (unsigned long long am = alive; am; am &= am - 1ull) {
+                            const int l = __builtin_ctzll(am);
+                            const int c = __popcll(adjn & readlane_u64(N, l));
+                            const int key = c > 0 ? ((c << 8) | (255 - l)) : 0;
+                            if (key > best) { second = best; best = key; } else if (key > second) second = key;
+                        }
                         const int max_value = best >> 8, max_index = best ? 255 - (best & 255) : 0;
-                        const int best2 = wave_max_i32((best && lane == max_index) ? 0 : key);
-                        const int second_value = best2 >> 8, second_index = best2 ? 255 - (best2 & 255) : 0;
+                        const int second_value = second >> 8, second_index = second ? 255 - (second & 255) : 0;
                         int to = -1;
                         if (max_value > 0 && max_index != target) to = max_index;
                         else if (max_value > 0 && max_value <= 2 * second_value) to = second_index;
-                        if (to >= 0) {
-                            const unsigned long long bit = 1ull << i;
-                            if (lane == target) N &= ~bit;
-                            if (lane == to) N |= bit;      // (to == target: the node stays, as the reference's counters say)
-                            if (lane == i) Lw = to;
-                            changes++;
-                        }
+                        const unsigned long long members = readlane_u64(N, target);
+                        const unsigned long long U = __ballot(((members >> lane) & 1ull) && to >= 0);                         // by node
+                        const unsigned long long Uv = __ballot(lane >= p && lane < n_visit && ((U >> nodev) & 1ull));        // by visit, from p on
+                        if (!Uv) break;
+                        const int v0 = __builtin_ctzll(Uv);
+                        const int i = __builtin_amdgcn_readlane(nodev, v0);
+                        const int dst = __builtin_amdgcn_readlane(to, i);
+                        const unsigned long long bit = 1ull << i;
+                        if (lane == target) N &= ~bit;
+                        if (lane == dst) N |= bit;
+                        if (lane == i) Lw = dst;
+                        changes++;
+                        p = v0 + 1;
                     }
                     iters++;
                 }
@@ -960,6 +1017,7 @@ __global__ __launch_bounds__(64) void k_window_tail(
             }
         }
         if (lane < m) { lab[lane] = L; nc[lane] = L; }
+        fin_S = S; fin_L = L; fin_adjn = adjn;
         wave_sync_lds();
     } else {
     // ---- wider windows: labels in LDS (or global scratch), neighbour lists ----
@@ -1095,7 +1153,18 @@ __global__ __launch_bounds__(64) void k_window_tail(
     // ---- merge_wrongly_split_haplotypes (separate_reads.cpp:1007-1327) ----
     if (lane < HS_FIN_KCAP) { s_index_of[lane] = -1; s_slot_of[lane] = -1; }
     wave_sync_lds();
-    if (lane == 0) {
+    if (masks) {      // lane = label: its place in the order of first appearance, its slot among the labels that are left
+        const bool present = fin_S != 0ull;
+        const int f = present ? __builtin_ctzll(fin_S) : 0;
+        const unsigned long long F = wave_or_u64(present ? 1ull << f : 0ull);
+        const unsigned long long pm = __ballot(present);
+        const int index = __popcll(F & ((1ull << f) - 1ull)), slot = __popcll(pm & ((1ull << lane) - 1ull));
+        if (present && lane < HS_FIN_KCAP) {
+            s_index_of[lane] = index;
+            if (slot < HS_FIN_GCAP) { s_slot_of[lane] = slot; s_glist[slot] = lane; s_gidx[slot] = index; }
+        }
+        if (lane == 0) s_scalar[2] = __popcll(pm);
+    } else if (lane == 0) {
         int index = 0;
         for (int j = 0; j < m; ++j) { const int cl = lab[j]; if (cl > -1 && s_index_of[cl] < 0) s_index_of[cl] = index++; }
         int G = 0;
@@ -1120,8 +1189,10 @@ __global__ __launch_bounds__(64) void k_window_tail(
     // one LDS byte per column entry instead of a bisection of the id list
     const int id_lo = m > 0 ? ids_l[0] : 0;
     const long long id_range = m > 0 ? (long long)ids_l[m - 1] - id_lo + 1 : 0;
-    const bool use_map = in_lds && id_range <= 8ll * stride;
-    uint8_t* smap = reinterpret_cast<uint8_t*>(agg);
+    // (the map lies over the `agg` doubles, free by now, or in the extra bytes behind the arrays, whichever is larger)
+    const long long map_cap = in_lds ? (8ll * stride > HS_TAIL_MAP_EXTRA ? 8ll * stride : (long long)HS_TAIL_MAP_EXTRA) : 0ll;
+    const bool use_map = in_lds && id_range <= map_cap;
+    uint8_t* smap = 8ll * stride > HS_TAIL_MAP_EXTRA ? reinterpret_cast<uint8_t*>(agg) : reinterpret_cast<uint8_t*>(tail_dyn + 7 * lds_cap);
     if (use_map) {
         for (int x = lane; x < (int)id_range; x += 64) smap[x] = 0xff;
         wave_sync_lds();
@@ -1279,7 +1350,21 @@ __global__ __launch_bounds__(64) void k_window_tail(
     for (int x = lane; x < M * M; x += 64) s_link_cnt[x] = 0;
     if (lane < M) s_links_in[lane] = 0;
     wave_sync_lds();
-    if (n_visit > 0) {   // (an empty finalize graph has no links)
+    if (masks) {
+        // lane = node q with its neighbour mask: per label c1 (and for the neighbours without a label) how many of q's neighbours carry it
+        const int c2 = fin_L + 2;
+        const unsigned long long any = wave_or_u64(fin_S);
+        const unsigned long long nolabel = ~any & (m >= 64 ? ~0ull : ((1ull << m) - 1ull));
+        {
+            const int k = __popcll(fin_adjn & nolabel);
+            if (k > 0) { if (c2 != 1) atomicAdd(&s_link_cnt[1 * M + c2], k); atomicAdd(&s_links_in[1], k); }
+        }
+        for (unsigned long long am = __ballot(fin_S != 0ull); am; am &= am - 1ull) {
+            const int l = __builtin_ctzll(am);
+            const int k = __popcll(fin_adjn & readlane_u64(fin_S, l));
+            if (k > 0) { if (l + 2 != c2) atomicAdd(&s_link_cnt[(l + 2) * M + c2], k); atomicAdd(&s_links_in[l + 2], k); }
+        }
+    } else if (n_visit > 0) {   // (an empty finalize graph has no links)
         for (int q = lane; q < m; q += 64) {
             const int c2 = lab[q] + 2;
             for (int64_t o = off_w[q]; o < off_w[q + 1]; ++o) {
