@@ -127,6 +127,7 @@ struct Contingency {
     int n00 = 0, n01 = 0, n10 = 0, n11 = 0;
     bool comparable = false;       // numberOfBases != 0 (call_variants.cpp:817)
     uint8_t most = 0, second = ' ';
+    int second_slot = -2;          // the column's slot of `second` when the comparison knows it (-1: the column does not hold it; -2: not known)
 };
 
 float mean_distance_from_counts(int64_t n_err, int64_t n_len) {
@@ -343,6 +344,7 @@ static Contingency column_vs_partition_bits(const RankPartition& p, const ColVie
         if (nbest <= 1) {
             LA_STAT(5);
             r.second = best_slot >= 0 ? cb.codes[best_slot] : (uint8_t)' ';
+            r.second_slot = best_slot;
             if (ref_slot >= 0) {
                 const uint64_t* bm = slot_abs(ref_slot);
                 for (int w = w0; w <= w1; ++w) { r.n11 += __builtin_popcountll(bm[w] & p.plus[(size_t)w]); r.n01 += __builtin_popcountll(bm[w] & p.minus[(size_t)w]); }
@@ -439,7 +441,7 @@ static void partition_from_column(RankPartition& p, PartitionArena& arena, int n
     const int ns = std::min(cb.nslots, 128);
     for (int k = 0; k < ns; ++k) { int c = 0; const uint64_t* bk = cb.slot(k); for (int j = 0; j < cb.W; ++j) c += __builtin_popcountll(bk[j]); cnt[k] = c; }
     const uint8_t second = second_from_seen(cb.codes, cnt, ns, ref, false, false, 0);
-    const int sr = cb.slot_of(ref), ss = second != ref ? cb.slot_of(second) : -1;
+    const int sr = cb.ref_slot, ss = second != ref ? cb.slot_of(second) : -1;
     for (int j = 0; j < cb.W; ++j) {
         const size_t w = (size_t)(cb.wlo + j);
         const uint64_t a = cb.any[j];
@@ -466,7 +468,7 @@ static void augment(RankPartition& p, const ColView& cb, const Contingency& d, i
     std::vector<uint64_t> zheap;
     const uint64_t* zeros = zero_words;
     if (cb.W > 4) { zheap.assign((size_t)cb.W, 0ull); zeros = zheap.data(); }
-    const int sA = cb.slot_of(d.most), sa_ = d.second != d.most ? cb.slot_of(d.second) : -1;
+    const int sA = cb.ref_slot /* (d.most is the reference code) */, sa_ = d.second != d.most ? (d.second_slot != -2 ? d.second_slot : cb.slot_of(d.second)) : -1;
     const uint64_t* A = sA >= 0 ? cb.slot(sA) : zeros;
     const uint64_t* a = sa_ >= 0 ? cb.slot(sa_) : zeros;
     int nA = 0, na = 0;
