@@ -399,12 +399,25 @@ def _partition_test_case(rng, n_contigs, cols_per_contig, mode):
                 part_state_off=np.array(pso, np.int64), part_state=cat(states, np.int8)), nreads
 
 
-@pytest.mark.parametrize("mode", ["snp", "ties", "high", "many"])
+@pytest.mark.parametrize("mode", ["snp", "ties", "high", "many", "snp_third_count", "ties_third_count"])
 def test_column_partition_test_matches_oracle(built, mode):
+    """K4 (k_column_partition_lanes -> _grouped -> _test) == loops C and D of keep_only_robust_variants. The `_third_count` modes hand the
+    kernels what the pipeline does: the column's third count in bits 16-21 of the second count's word (63 - min(c2, 63); 0 = not known),
+    which lets the first kernel settle a pair whose second allele is provably the column's own second code."""
     from hairsplitter_amd import api
-    rng = np.random.default_rng({"snp": 11, "ties": 12, "high": 13, "many": 14}[mode])
-    case, nreads = _partition_test_case(rng, 24 if mode != "many" else 10, 60 if mode != "many" else 40, mode)
+    base = mode.replace("_third_count", "")
+    rng = np.random.default_rng({"snp": 11, "ties": 12, "high": 13, "many": 14}[base])
+    case, nreads = _partition_test_case(rng, 24 if base != "many" else 10, 60 if base != "many" else 40, base)
     want, _, _ = ol.column_partition_test(n_reads_of_contig=nreads, **case)
+    if mode.endswith("_third_count"):
+        c1w = case["col_c1"].copy()
+        for k in range(len(c1w)):
+            e0, e1 = int(case["col_off"][k]), int(case["col_off"][k + 1])
+            vals, cnt = np.unique(case["col_code"][e0:e1], return_counts=True)
+            rest = sorted((int(c) for v, c in zip(vals, cnt) if int(v) not in (int(case["col_k0"][k]), int(case["col_k1"][k]))), reverse=True)
+            c2 = rest[0] if rest else 0
+            c1w[k] = int(c1w[k]) | ((63 - min(c2, 63)) << 16)
+        case = dict(case, col_c1=c1w)
     got = api.column_partition_test(n_reads=nreads, **case)
     assert np.array_equal(got, want)
     assert 0 < int(want.sum()) < len(want)          # both verdicts occur
