@@ -846,66 +846,73 @@ __global__ __launch_bounds__(1024) void k_flag_block_offsets(long long* __restri
 }
 // out_rec[f] = record of the f-th flagged column, out_col[f] = its index in the column list, out_off[f] = first entry in the
 // packed arrays (out_off[n_flagged] = total); entries copied by the wavefront that owns the column
-__global__ __launch_bounds__(256) void k_pack_flagged(
+__global__ __launch_bounds__(1024) void k_pack_flagged(
     const hs_colrec_dev* __restrict__ col_rec, const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_len, const int32_t* __restrict__ col_idx,
     const uint8_t* __restrict__ col_code, const ColumnsHeader* __restrict__ header, int flag, const long long* __restrict__ blk_cnt,
     const long long* __restrict__ blk_ent, hs_colrec_dev* __restrict__ out_rec, int32_t* __restrict__ out_col, int64_t* __restrict__ out_off,
     int32_t* __restrict__ out_idx, uint8_t* __restrict__ out_code, int64_t cap_flagged, int64_t cap_entries,
     int32_t* __restrict__ out_len /* non-NULL: the LIGHT form -- no entry is copied, out_off[f] is the column's place in col_idx / col_code and out_len[f] its length */) {
-    // one workgroup per block of HS_FP_BLOCK columns: wave w walks columns w * 256 .. of the block 64 at a time
+    // one workgroup per block of HS_FP_BLOCK columns, one wavefront per 64 of them (sixteen short chains instead of four long ones: at
+    // eight contig groups a launch is a few hundred wavefronts and lasts as long as one of them)
     const int64_t n_cols = header_cols(header);
     const int64_t base = (int64_t)blockIdx.x * HS_FP_BLOCK;
     if (base >= n_cols) return;
-    __shared__ long long s_wc[4], s_we[4];
+    __shared__ long long s_wc[16], s_we[16];
+    __shared__ int s_incl[16][64];
+    __shared__ int64_t s_src[16][64];
     const int lane = lane_id(), wv = wave_id();
-    // counts of the four quarters first (the order inside the block is quarter by quarter)
-    {
-        int c = 0; long long e = 0;
-        for (int i = lane; i < 256; i += 64) {
-            const int64_t k = base + wv * 256 + i;
-            if (k < n_cols && (col_rec[k].flags & flag)) { c++; e += col_len[k]; }
-        }
-        const int cs = wave_sum_i32(c);
-        long long es = e;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) es += __shfl_xor(es, d, 64);
-        if (lane == 0) { s_wc[wv] = cs; s_we[wv] = es; }
-    }
+    const int64_t k = base + wv * 64 + lane;
+    const bool on = k < n_cols && (col_rec[k].flags & flag);
+    const int len = on ? col_len[k] : 0;
+    const int64_t my_src = on ? col_off[k] : 0;      // (every lane its own column's offset, one coalesced load)
+    const unsigned long long m = __ballot(on);
+    const int incl = wave_scan_incl(len);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (lane == 0) { s_wc[wv] = __popcll(m); s_we[wv] = total; }
+    s_incl[wv][lane] = incl; s_src[wv][lane] = my_src;
     __syncthreads();
     long long f = blk_cnt[blockIdx.x], o = blk_ent[blockIdx.x];
     for (int w = 0; w < wv; ++w) { f += s_wc[w]; o += s_we[w]; }
-    const bool last_block = base + HS_FP_BLOCK >= n_cols;
-    for (int i0 = 0; i0 < 256; i0 += 64) {
-        const int64_t k = base + wv * 256 + i0 + lane;
-        const bool on = k < n_cols && (col_rec[k].flags & flag);
-        const int len = on ? col_len[k] : 0;
-        const int64_t my_src = on ? col_off[k] : 0;      // (every lane its own column's offset, one coalesced load: not one dependent load per column below)
-        const unsigned long long m = __ballot(on);
-        const int incl = wave_scan_incl(len);
-        const long long my_f = f + __popcll(m & ((1ull << lane) - 1ull));
-        const long long my_o = o + incl - len;
-        if (out_len) {      // (the candidates: k_cand_bits reads their entries where they lie)
-            if (on && my_f < cap_flagged) { out_rec[my_f] = col_rec[k]; out_col[my_f] = (int32_t)k; out_off[my_f] = my_src; out_len[my_f] = len; }
-            f += __popcll(m); o += __builtin_amdgcn_readlane(incl, 63);
-            continue;
-        }
+    const long long my_f = f + __popcll(m & ((1ull << lane) - 1ull));
+    const long long my_o = o + incl - len;
+    if (out_len) {      // (the candidates: k_cand_bits reads their entries where they lie)
+        if (on && my_f < cap_flagged) { out_rec[my_f] = col_rec[k]; out_col[my_f] = (int32_t)k; out_off[my_f] = my_src; out_len[my_f] = len; }
+    } else {
         if (on && my_f < cap_flagged) { out_rec[my_f] = col_rec[k]; out_col[my_f] = (int32_t)k; out_off[my_f] = my_o; }
-        // the entries: the wave copies the flagged columns of this step one after the other (four at a time with their loads in
-        // flight together: 0.45 ms per step against 0.36)
-        unsigned long long rem = m;
-        while (rem) {
-            const int l = __builtin_ctzll(rem); rem &= rem - 1ull;
-            const int n = __builtin_amdgcn_readlane(len, l);
-            const uint32_t olo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_o & 0xffffffffll), l), ohi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)my_o >> 32), l);
-            const int64_t dst = (int64_t)(((uint64_t)ohi << 32) | olo);
-            const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_src & 0xffffffffll), l), shi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)my_src >> 32), l);
-            const int64_t src = (int64_t)(((uint64_t)shi << 32) | slo);
-            if (dst + n <= cap_entries)
-                for (int j = lane; j < n; j += 64) { out_idx[dst + j] = col_idx[src + j]; out_code[dst + j] = col_code[src + j]; }
+        // the entries of the wavefront's flagged columns lie one behind the other in the output: lane t, t + 64, ... of that range each
+        // finds its column by bisection of the lengths' prefix sums (LDS) and copies one entry, four in flight per lane
+        if (o + total <= cap_entries) {
+            auto source = [&](int t) -> int64_t {
+                int c = 0;      // the first column whose inclusive prefix exceeds t
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) if (s_incl[wv][c + step - 1] <= t) c += step;
+                return s_src[wv][c] + (t - (c ? s_incl[wv][c - 1] : 0));
+            };
+            int t = lane;
+            for (; t + 192 < total; t += 256) {
+                const int64_t s0 = source(t), s1 = source(t + 64), s2 = source(t + 128), s3 = source(t + 192);
+                const int32_t i0 = col_idx[s0], i1 = col_idx[s1], i2 = col_idx[s2], i3 = col_idx[s3];
+                const uint8_t c0 = col_code[s0], c1 = col_code[s1], c2 = col_code[s2], c3 = col_code[s3];
+                out_idx[o + t] = i0; out_idx[o + t + 64] = i1; out_idx[o + t + 128] = i2; out_idx[o + t + 192] = i3;
+                out_code[o + t] = c0; out_code[o + t + 64] = c1; out_code[o + t + 128] = c2; out_code[o + t + 192] = c3;
+            }
+            for (; t < total; t += 64) { const int64_t s0 = source(t); out_idx[o + t] = col_idx[s0]; out_code[o + t] = col_code[s0]; }
+        } else {      // (the packed block does not hold them all: column by column, each only if it fits whole)
+            unsigned long long rem = m;
+            while (rem) {
+                const int l = __builtin_ctzll(rem); rem &= rem - 1ull;
+                const int n = __builtin_amdgcn_readlane(len, l);
+                const uint32_t olo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_o & 0xffffffffll), l), ohi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)my_o >> 32), l);
+                const int64_t dst = (int64_t)(((uint64_t)ohi << 32) | olo);
+                const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(my_src & 0xffffffffll), l), shi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)my_src >> 32), l);
+                const int64_t src = (int64_t)(((uint64_t)shi << 32) | slo);
+                if (dst + n <= cap_entries)
+                    for (int j = lane; j < n; j += 64) { out_idx[dst + j] = col_idx[src + j]; out_code[dst + j] = col_code[src + j]; }
+            }
         }
-        f += __popcll(m); o += __builtin_amdgcn_readlane(incl, 63);
     }
-    if (last_block && wv == 3 && lane == 0 && f <= cap_flagged) out_off[f] = o;
+    const bool last_block = base + HS_FP_BLOCK >= n_cols;
+    if (last_block && wv == 15 && lane == 0 && f + (long long)__popcll(m) <= cap_flagged) out_off[f + __popcll(m)] = o + total;
 }
 
 // ------------------------------------------------------------------------------------------------
