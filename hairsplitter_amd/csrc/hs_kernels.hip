@@ -768,7 +768,10 @@ __global__ __launch_bounds__(256) void k_column_stats_tiled_dw(
 // ------------------------------------------------------------------------------------------------
 #define HS_SP_WORDS 4
 #define HS_SP_READS 512
-__global__ __launch_bounds__(256) void k_snp_planes(
+#define HS_SP_WAVES 16      // wavefronts of a workgroup: each walks every sixteenth of its 256 columns (sixteen columns in a row, not 64: at eight contig groups
+                           // a launch is a few hundred workgroups and lasts as long as one wavefront's chain)
+#define HS_SP_THREADS (64 * HS_SP_WAVES)
+__global__ __launch_bounds__(HS_SP_THREADS) void k_snp_planes(
     const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
     const uint8_t* __restrict__ snp_ref, const uint8_t* __restrict__ snp_alt, const int32_t* __restrict__ snp_contig,
     const int64_t* __restrict__ contig_snp_base, const int64_t* __restrict__ plane_off, const int32_t* __restrict__ words,
@@ -788,15 +791,15 @@ __global__ __launch_bounds__(256) void k_snp_planes(
     unsigned long long* __restrict__ A = alt + plane_off[c];
     unsigned long long* __restrict__ R = ref + plane_off[c];
     for (int rb = 0; rb < N; rb += HS_SP_READS) {
-        for (int x = tid; x < HS_SP_READS * HS_SP_WORDS; x += 256) { (&s_a[0][0])[x] = 0ull; (&s_r[0][0])[x] = 0ull; }
-        if (read_base) for (int x = tid; x < HS_SP_READS; x += 256) s_p[x] = 0u;
+        for (int x = tid; x < HS_SP_READS * HS_SP_WORDS; x += HS_SP_THREADS) { (&s_a[0][0])[x] = 0ull; (&s_r[0][0])[x] = 0ull; }
+        if (read_base) for (int x = tid; x < HS_SP_READS; x += HS_SP_THREADS) s_p[x] = 0u;
         __syncthreads();
         {
-            // a wavefront takes every fourth column of the workgroup: lane t first reads what column wv + 4 t needs (one round trip for
+            // a wavefront takes every sixteenth column of the workgroup: lane t first reads what column wv + 16 t needs (one round trip for
             // all of them), then the columns go by one after the other, lanes = entries, the next column's entries already on their way
-            const int q_l = wv + 4 * lane;
+            const int q_l = wv + HS_SP_WAVES * lane;
             const int64_t s_l = s0 + q_l;
-            const bool v_l = q_l < 64 * nw && s_l < n_snps && snp_contig[s_l] == c;      // (the contig's last word is partly filled)
+            const bool v_l = lane < 256 / HS_SP_WAVES && q_l < 64 * nw && s_l < n_snps && snp_contig[s_l] == c;      // (the contig's last word is partly filled)
             const int64_t e0_l = v_l ? col_off[s_l] : 0;
             const int n_l = v_l ? (int)(col_off[s_l + 1] - e0_l) : 0;
             const int al_l = v_l ? ((int)snp_ref[s_l] | ((int)snp_alt[s_l] << 8)) : 0;
@@ -811,7 +814,7 @@ __global__ __launch_bounds__(256) void k_snp_planes(
             while (todo) {
                 const int t = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
-                const int q = wv + 4 * t;
+                const int q = wv + HS_SP_WAVES * t;
                 const int64_t e0 = rl_e0(t);
                 const int n = __builtin_amdgcn_readlane(n_l, t);
                 const int al = __builtin_amdgcn_readlane(al_l, t);
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(256) void k_snp_planes(
         }
         __syncthreads();
         const int nr = N - rb < HS_SP_READS ? N - rb : HS_SP_READS;
-        for (int x = tid; x < nr * HS_SP_WORDS; x += 256) {      // (consecutive threads: consecutive words of a row)
+        for (int x = tid; x < nr * HS_SP_WORDS; x += HS_SP_THREADS) {      // (consecutive threads: consecutive words of a row)
             const int r = x / HS_SP_WORDS, wq = x % HS_SP_WORDS;
             if (wq < nw) {
                 const int64_t at = (int64_t)(rb + r) * W + w0 + wq;
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(256) void k_snp_planes(
             }
         }
         if (read_base)
-            for (int r = tid; r < nr; r += 256) {
+            for (int r = tid; r < nr; r += HS_SP_THREADS) {
                 const unsigned int pm = s_p[r];
                 if (pm) {
                     const int64_t at = read_base[c] + rb + r;
