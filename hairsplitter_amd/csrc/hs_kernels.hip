@@ -1290,6 +1290,41 @@ __global__ __launch_bounds__(1024) void k_column_partition_test(
     }
 }
 
+// The same test for listed (column, partition) PAIRS, one wavefront each: the pairs k_column_partition_grouped could not settle (the
+// candidates for the second allele give different verdicts, so the reference's order of equal counts decides). A pair that keeps its
+// column writes keep = 1; nobody writes 0 (the grouped kernel has).
+__global__ __launch_bounds__(256) void k_column_partition_pairs(
+    const int64_t* __restrict__ col_off, const int32_t* __restrict__ col_idx, const uint8_t* __restrict__ col_code,
+    const int32_t* __restrict__ col_contig, const uint8_t* __restrict__ col_k0, const uint8_t* __restrict__ col_k1,
+    const int32_t* __restrict__ col_c1, const uint8_t* __restrict__ col_is_cand, const int32_t* __restrict__ part_off,
+    const int64_t* __restrict__ part_state_off, const int8_t* __restrict__ part_state, uint8_t* __restrict__ keep,
+    const int2* __restrict__ pair_list, const int32_t* __restrict__ n_pairs, int pair_cap) {
+    __shared__ uint8_t s_seen[4][128];
+    __shared__ uint8_t s_ord[4][264];
+    __shared__ uint8_t s_map[4][3 * 512];
+    __shared__ int s_ord_n[4];
+    const int wv = wave_id();
+    const int total = *n_pairs < pair_cap ? *n_pairs : pair_cap;
+    for (int f = (int)blockIdx.x * 4 + wv; f < total; f += (int)gridDim.x * 4) {
+        const int2 pr = pair_list[f];
+        const int col = pr.x;
+        if (keep[col] == 1) continue;      // (another partition has kept the column already)
+        const int c = col_contig[col];
+        const int p = part_off[c] + pr.y;
+        const int64_t e0 = col_off[col];
+        const int n = (int)(col_off[col + 1] - e0);
+        const int k0 = col_k0[col], k1 = col_k1[col];
+        const bool loop_c = col_is_cand[col] != 0;
+        const bool loop_d = (col_c1[col] & 0xffff) >= 5 && central_base_test_dev(k0, k1);
+        const Table2x2 d = column_vs_partition_dev(col_idx + e0, col_code + e0, n, part_state + part_state_off[p], k0, s_seen[wv], s_ord[wv], &s_ord_n[wv], s_map[wv]);
+        const float chi = chi_square_dev(d);
+        bool kept = false;
+        if (loop_c && (double)(d.n00 + d.n01 + d.n10 + d.n11) > 0.5 * (double)n && chi > 15) kept = true;
+        if (loop_d && (double)chi > 20.0 && d.n10 + d.n00 > 4 && d.n01 + d.n11 > 4) kept = true;
+        if (kept && lane_id() == 0) keep[col] = 1;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4, fast form (k_column_partition_lanes below): LANES = (column, partition) PAIRS THAT SHARE A READ.
 // The partition states are read from a per-contig table transposed to [read][partition] (k_partition_transpose), one
@@ -1593,8 +1628,10 @@ __global__ __launch_bounds__(64) void k_column_partition_grouped(
     const int32_t* __restrict__ col_contig, const uint8_t* __restrict__ col_k0, const uint8_t* __restrict__ col_k1,
     const int32_t* __restrict__ col_c1, const uint8_t* __restrict__ col_is_cand, const int32_t* __restrict__ list, const int32_t* __restrict__ n_list,
     const int32_t* __restrict__ part_off, const int32_t* __restrict__ ctg_n, const int64_t* __restrict__ tab_off, const uint8_t* __restrict__ tab,
-    const uint16_t* __restrict__ pres, uint8_t* __restrict__ keep, int32_t* __restrict__ undecided_list, int32_t* __restrict__ n_undecided) {
+    const uint16_t* __restrict__ pres, uint8_t* __restrict__ keep, int32_t* __restrict__ undecided_list, int32_t* __restrict__ n_undecided,
+    int2* __restrict__ pair_list /* {column, partition of its contig}: the pairs whose candidates disagree */, int32_t* __restrict__ n_pairs, int pair_cap) {
     __shared__ __attribute__((aligned(16))) uint16_t s_idx[HS_K4_COLS * HS_K4_ROW];
+    __shared__ int s_col[HS_K4_COLS];
     __shared__ uint32_t s_last[HS_K4_COLS][9];      // bit e: entry e of the row is the last of its code (other codes only)
     __shared__ uint32_t s_cnt[128];
     __shared__ uint32_t s_pairs[HS_K4_PAIRS];       // slot << 28 | block << 4 | partition within the block
@@ -1628,7 +1665,7 @@ __global__ __launch_bounds__(64) void k_column_partition_grouped(
         else if (h_n > 255 || h_k0 >= 128 || N > 65535 || P > 65535 || tb + (int64_t)N * h_ppad > 0xffffffffll) h_bad = true;
         else tested = true;
     }
-    if (lane < HS_K4_COLS) s_hdr[lane] = make_uint4(h_tb, (uint32_t)h_ppad, (uint32_t)h_n | ((uint32_t)h_flags << 16), 0u);
+    if (lane < HS_K4_COLS) { s_hdr[lane] = make_uint4(h_tb, (uint32_t)h_ppad, (uint32_t)h_n | ((uint32_t)h_flags << 16), 0u); s_col[lane] = hc; }
     if (lane == 0) s_flags = 0u;
     unsigned bad_cols = (unsigned)(__ballot(h_bad) & ((1ull << HS_K4_COLS) - 1ull));
     unsigned todo = (unsigned)(__ballot(tested) & ((1ull << HS_K4_COLS) - 1ull));
@@ -1773,7 +1810,17 @@ __global__ __launch_bounds__(64) void k_column_partition_grouped(
             }
             const bool ok = act && ok_all, und = act && ok_any && !ok_all;
             if (ok) atomicOr(&s_flags, 1u << slot);
-            if (und) atomicOr(&s_flags, 0x10000u << slot);
+            {   // a pair whose candidates for the second allele disagree goes to the exact kernel as a pair (one atomic per wavefront); when
+                // the list is full the whole column goes there instead
+                const unsigned long long um = __ballot(und);
+                if (um) {
+                    int at = 0;
+                    if (lane == 0) at = atomicAdd(n_pairs, __popcll(um));
+                    at = __builtin_amdgcn_readfirstlane(at);
+                    const int mine = at + __popcll(um & ((1ull << lane) - 1ull));
+                    if (und) { if (mine < pair_cap) pair_list[mine] = make_int2(s_col[slot], (int)(pr & 0xfffffffu)); else atomicOr(&s_flags, 0x10000u << slot); }
+                }
+            }
             wave_lds_sync();
             if (lane + 64 < npairs) s_pairs[lane] = moved;
             npairs = npairs > 64 ? npairs - 64 : 0;
@@ -1785,9 +1832,9 @@ __global__ __launch_bounds__(64) void k_column_partition_grouped(
     if (hvalid && (tested || h_bad)) {
         const bool kept = (fl >> lane) & 1u;
         const bool undecided = ((fl >> (16 + lane)) & 1u) || ((bad_cols >> lane) & 1u);
-        keep[hc] = kept ? 1 : (undecided ? 2 : 0);
+        keep[hc] = kept ? 1 : (undecided ? 2 : 0);      // (0: unless one of its listed pairs says otherwise)
     }
-    {   // the columns left to the exact kernel: one atomic per wavefront
+    {   // the columns left to the exact kernel WHOLE (not testable here, or the pair list full): one atomic per wavefront
         const bool und = hvalid && (tested || h_bad) && !((fl >> lane) & 1u) && ((((fl >> (16 + lane)) & 1u) != 0u) || (((bad_cols >> lane) & 1u) != 0u));
         const unsigned long long um = __ballot(und);
         if (um) {
