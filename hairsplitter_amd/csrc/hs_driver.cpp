@@ -850,24 +850,33 @@ int sr_run(SrDeviceOps& dev, const hs_sr_contig* contigs, int32_t n_contigs, int
             ch.col_pos.reserve(ch.col_off.size());
             for (int c = 0; c < C; ++c) ch.col_pos.insert(ch.col_pos.end(), contigs[c].snp_pos, contigs[c].snp_pos + contigs[c].n_snps);
         }
+        // the windows of the chain and where their seeds / rows begin (serial, a few thousand additions), then every window's seeds and SNP
+        // range filled in by the group's threads (this sits between K6's launch and the wait for its rows: on the group's chain)
         for (size_t i = 0; i < wrefs.size(); ++i) {
-            SrContigState& s = st[(size_t)wrefs[i].c];
-            SrWindowPlan& w = s.windows[(size_t)wrefs[i].w];
+            const SrWindowPlan& w = st[(size_t)wrefs[i].c].windows[(size_t)wrefs[i].w];
             if (w.local_snps.empty()) continue;          // finalize_clustering :909-919
             chain_index[i] = (int64_t)ch.win.size();
             ch.win.push_back((int32_t)i);
-            for (int snp : w.local_snps) ch.seed_col.push_back(col_base_of_contig[(size_t)wrefs[i].c] + snp);
-            ch.win_seed_begin.push_back((int64_t)ch.seed_col.size());
+            ch.win_seed_begin.push_back(ch.win_seed_begin.back() + (int64_t)w.local_snps.size());
             ch.chain_row0.push_back(ch.chain_row0.back() + (int64_t)w.ids.size());
-            if (ch.finish_on_device) {
-                const hs_sr_contig& hc = contigs[wrefs[i].c];
-                const int64_t base = col_base_of_contig[(size_t)wrefs[i].c];
-                ch.win_snp_first.push_back(base + (std::lower_bound(hc.snp_pos, hc.snp_pos + hc.n_snps, w.final_lo) - hc.snp_pos));
-                ch.win_snp_last.push_back(base + (std::lower_bound(hc.snp_pos, hc.snp_pos + hc.n_snps, w.final_hi) - hc.snp_pos));
-                ch.win_pos_lo.push_back(w.final_lo); ch.win_pos_hi.push_back(w.final_hi);
-            }
             n_cw += (int64_t)w.local_snps.size() + 2;
         }
+        const size_t Wc = ch.win.size();
+        ch.seed_col.resize((size_t)ch.win_seed_begin.back());
+        if (ch.finish_on_device) { ch.win_snp_first.resize(Wc); ch.win_snp_last.resize(Wc); ch.win_pos_lo.resize(Wc); ch.win_pos_hi.resize(Wc); }
+        parallel_for((int)Wc, n_threads, [&](int k) {
+            const size_t i = (size_t)ch.win[(size_t)k];
+            const SrWindowPlan& w = st[(size_t)wrefs[i].c].windows[(size_t)wrefs[i].w];
+            const int64_t base = col_base_of_contig[(size_t)wrefs[i].c];
+            int64_t at = ch.win_seed_begin[(size_t)k];
+            for (int snp : w.local_snps) ch.seed_col[(size_t)at++] = base + snp;
+            if (ch.finish_on_device) {
+                const hs_sr_contig& hc = contigs[wrefs[i].c];
+                ch.win_snp_first[(size_t)k] = base + (std::lower_bound(hc.snp_pos, hc.snp_pos + hc.n_snps, w.final_lo) - hc.snp_pos);
+                ch.win_snp_last[(size_t)k] = base + (std::lower_bound(hc.snp_pos, hc.snp_pos + hc.n_snps, w.final_hi) - hc.snp_pos);
+                ch.win_pos_lo[(size_t)k] = w.final_lo; ch.win_pos_hi[(size_t)k] = w.final_hi;
+            }
+        });
     }
     laps.lap("chain_build");
     if (two_phase) {
