@@ -41,7 +41,8 @@ class CvResult(C.Structure):
                 ("col_off", C.POINTER(C.c_int64)), ("col_idx", C.POINTER(C.c_int32)),
                 ("col_code", C.POINTER(C.c_uint8)), ("error_rate", C.c_float), ("n_contigs_with_error_rate", C.c_int32),
                 ("t_device_ms", C.c_double), ("t_host_ms", C.c_double), ("t_kernel_ms", C.c_float * 4), ("t_kernel_k4_ms", C.c_float),
-                ("n_columns_extracted", C.c_int64), ("n_columns_downloaded", C.c_int64), ("n_columns_downloaded_late", C.c_int64)]
+                ("n_columns_extracted", C.c_int64), ("n_columns_downloaded", C.c_int64), ("n_columns_downloaded_late", C.c_int64),
+                ("entries_borrowed", C.c_int32)]
 
 
 class KernelStats(C.Structure):

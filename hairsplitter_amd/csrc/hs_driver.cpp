@@ -176,7 +176,8 @@ int host_threads() {
 void free_cv_result(hs_cv_result* r) {
     if (!r) return;
     std::free(r->mean_distance); std::free(r->depth); std::free(r->snp_off); std::free(r->snp_pos); std::free(r->snp_ref);
-    std::free(r->snp_alt); std::free(r->snp_n_ref); std::free(r->snp_n_alt); std::free(r->col_off); std::free(r->col_idx); std::free(r->col_code);
+    std::free(r->snp_alt); std::free(r->snp_n_ref); std::free(r->snp_n_alt); std::free(r->col_off);
+    if (!r->entries_borrowed) { std::free(r->col_idx); std::free(r->col_code); }
     std::free(r);
 }
 // The dense label array of a result is tens of megabytes, above the largest mmap threshold glibc accepts: malloc'ed, every
@@ -484,12 +485,16 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& b, const std::vector<int32_t>& 
 }
 
 
-int cv_attach_entries(CvDeviceOps& dev, hs_cv_result* R, int n_threads) {
+int cv_attach_entries(CvDeviceOps& dev, hs_cv_result* R, int n_threads, bool borrow) {
     if (!R || R->col_idx) return HS_OK;      // (nothing deferred: the entries came with the result, or there are none)
     const int64_t S = R->snp_off[R->n_contigs], E = R->col_off[S];
     CvSnpSet snps;
     if (int rc = dev.late_entries(snps)) return rc;
     if (E > 0 && (!snps.idx || !snps.code)) return HS_OK;      // (the implementation kept them on the device only)
+    if (borrow && E > 0) {      // the caller keeps the implementation's block alive as long as the result: no copy, no pages to fault in
+        R->col_idx = const_cast<int32_t*>(snps.idx); R->col_code = const_cast<uint8_t*>(snps.code); R->entries_borrowed = 1;
+        return HS_OK;
+    }
     R->col_idx = (int32_t*)std::malloc(std::max<int64_t>(1, E) * sizeof(int32_t));
     R->col_code = (uint8_t*)std::malloc(std::max<int64_t>(1, E));
     if (n_threads <= 0) n_threads = host_threads();

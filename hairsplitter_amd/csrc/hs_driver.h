@@ -128,7 +128,7 @@ int cv_run_range(CvDeviceOps& dev, const CvMeta& meta, const std::vector<int32_t
 int cv_run(CvDeviceOps& dev, const CvMeta& meta, float automatic_snp_threshold, int n_threads, hs_cv_result** out);
 hs_cv_result* cv_concat_results(hs_cv_result* a, hs_cv_result* b);   // two consecutive contig ranges (both consumed)
 // the entries of the SNP columns of a result whose device interface deferred them (CvDeviceOps::late_entries): col_idx / col_code filled in
-int cv_attach_entries(CvDeviceOps& dev, hs_cv_result* r, int n_threads);
+int cv_attach_entries(CvDeviceOps& dev, hs_cv_result* r, int n_threads, bool borrow = false);      // (borrow: the result points into the implementation's block, which the caller keeps alive)
 
 // Every clustering window of a stage-4 call, each in its own LOCAL index space: node j of window w is the read
 // mask_ids[win_row0[w] + j] (ascending inside a window). "Row" = (window, node); the read graphs of the call are ONE CSR

@@ -328,6 +328,7 @@ typedef struct hs_cv_result {
     int64_t n_columns_extracted;        /* K3: columns of the selected positions (they stay on the device) */
     int64_t n_columns_downloaded;       /* of those, candidate SNPs: the columns the host walks (loops A / B) */
     int64_t n_columns_downloaded_late;  /* columns whose leading codes had equal counts (ordered on the device as the reference orders them) */
+    int32_t entries_borrowed;           /* col_idx / col_code point into a block of the pipeline that made the result (valid until its next call): not freed with it */
 } hs_cv_result;
 
 int hs_cv_run(hs_cv_batch* b, float automatic_snp_threshold, int32_t n_threads, hs_cv_result** out);
