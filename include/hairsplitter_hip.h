@@ -500,7 +500,8 @@ int hs_pipeline_thread_devices(hs_pipeline* p, int32_t* out, int32_t cap);
 /* What a pipeline call leaves with the host besides the labels. Stage 3's SNP columns are handed to stage 4 on the device; with
  * HS_PIPELINE_KEEP_COLUMNS != 0 their entries (.col's payload: read indices and codes of every SNP column, the SNPS lines of
  * call_variants.cpp:1184-1204) are ALSO brought to the host inside the call, and the groups' stage-3 results stay available through
- * hs_pipeline_group_cv until the next call on the pipeline (they are dropped when it starts). Default 0: positions, alleles and
+ * hs_pipeline_group_cv until the next call on the pipeline (they are dropped when it starts; their col_idx / col_code point into pinned
+ * blocks of the pipeline -- hs_cv_result::entries_borrowed -- and are not the caller's to free). Default 0: positions, alleles and
  * counts of the SNPs only. */
 #define HS_PIPELINE_KEEP_COLUMNS 1
 /* HS_PIPELINE_SPARSE_LABELS != 0: the labels come back per window as the reads the window holds and their labels -- what the GROUP lines
