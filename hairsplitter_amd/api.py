@@ -21,7 +21,7 @@ if os.environ.get("HS_LIB_AB"):      # (tools/gpu_ab_lib.sh: another build of th
 SYMBOLS = [
     "hs_cv_batch_set_ploidy", "hs_version", "hs_last_error", "hs_device_count", "hs_warmup", "hs_set_device", "hs_device_synchronize", "hs_malloc", "hs_free",
     "hs_memcpy_h2d", "hs_memcpy_d2h", "hs_memset", "hs_event_create", "hs_event_destroy", "hs_event_record",
-    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_tile_plan", "hs_column_stats_tiled", "hs_cv_column_pass_taps", "hs_cv_taps_destroy", "hs_sr_run_taps", "hs_sr_taps_destroy", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_partition_pair_distance", "hs_snp_planes", "hs_simdiff", "hs_read_graphs",
+    "hs_event_elapsed_ms", "hs_pileup", "hs_pileup_plan", "hs_free_host", "hs_tile_plan", "hs_column_stats_tiled", "hs_cv_column_pass_taps", "hs_cv_taps_destroy", "hs_sr_run_taps", "hs_sr_taps_destroy", "hs_exclusive_scan_i32", "hs_gaf_from_files", "hs_gaf_from_labels", "hs_gro_to_gaf_main", "hs_column_partition_test", "hs_column_partition_last_counts", "hs_partition_pair_distance", "hs_snp_planes", "hs_simdiff", "hs_read_graphs",
     "hs_edit_distance", "hs_cv_batch_create", "hs_cv_batch_destroy", "hs_cv_batch_aligned_bp", "hs_cv_run",
     "hs_cv_result_destroy", "hs_cv_select", "hs_cv_run_range", "hs_cv_selection_destroy", "hs_sr_run", "hs_sr_run_cv", "hs_sr_run_cv_range", "hs_pipeline_create", "hs_pipeline_select", "hs_pipeline_run", "hs_pipeline_destroy", "hs_pipeline_thread_devices", "hs_cv_batch_device", "hs_sr_result_destroy", "hs_sr_window_size", "hs_call_variants_main", "hs_call_variants_epilogue",
     "hs_pipeline_run_fused", "hs_realign_paf", "hs_pipeline_set_option", "hs_pipeline_groups", "hs_pipeline_group_range", "hs_pipeline_group_cv", "hs_pipeline_sparse_labels", "hs_separate_reads_main", "hs_main_process_exits", "hs_kernel_name", "hs_kernel_stats_reset", "hs_kernel_stats_get", "hs_kernel_stats_every", "hs_host_wait_stats", "hs_devices", "hs_cv_run_host", "hs_edlib_hw_align", "hs_reattach_ends", "hs_trim_polished", "hs_free_strings", "hs_cut_gfa", "hs_gfa_to_fasta", "hs_cut_gfa_main", "hs_gfa2fa_main",
@@ -840,6 +840,14 @@ def column_partition_test(col_off, col_idx, col_code, col_contig, col_k0, col_k1
     _check(load().hs_column_partition_test(*[_p(x) for x in d], C.c_int32(n), *[_p(x) for x in q], _hp(nr, C.c_int32), C.c_int32(len(nr)), _p(keep), C.c_void_p(0)))
     torch.cuda.synchronize()
     return keep[:n].cpu().numpy()
+
+
+def column_partition_last_counts():
+    """what the kernels of this thread's last column_partition_test passed on: columns to k_column_partition_grouped, whole columns to
+    k_column_partition_test, (column, partition) pairs to k_column_partition_pairs"""
+    out = (C.c_int32 * 3)()
+    load().hs_column_partition_last_counts(out)
+    return {"to_grouped": int(out[0]), "whole_columns_to_exact": int(out[1]), "pairs_to_exact": int(out[2])}
 
 
 def partition_pair_distance(state, more, less, part_off, part_n, pair_a, pair_b, threshold_p=2):

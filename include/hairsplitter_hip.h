@@ -172,6 +172,10 @@ int hs_column_partition_test(const int64_t* d_col_off, const int32_t* d_col_idx,
                              const int32_t* d_part_off, const int64_t* d_part_state_off, const int8_t* d_part_state,
                              const int32_t* h_contig_n_reads /* HOST, [C]: reads of every contig (length of its state arrays) */, int32_t n_contigs,
                              uint8_t* d_keep, void* stream);
+/* Test tap: what the kernels of the LAST hs_column_partition_test call of this thread left to one another -- out[0] columns the first kernel
+ * (k_column_partition_lanes) passed on to k_column_partition_grouped, out[1] columns that one passed on whole to k_column_partition_test,
+ * out[2] (column, partition) pairs it passed on to k_column_partition_pairs. */
+void hs_column_partition_last_counts(int32_t out[3]);
 
 /* ------------------------------------------------------------------------------------------------
  * V5 -- distance(Partition&, Partition&, threshold_p) of loop B (call_variants.cpp:977-1127) for a list of partition pairs.

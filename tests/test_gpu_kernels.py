@@ -421,6 +421,16 @@ def test_column_partition_test_matches_oracle(built, mode):
     got = api.column_partition_test(n_reads=nreads, **case)
     assert np.array_equal(got, want)
     assert 0 < int(want.sum()) < len(want)          # both verdicts occur
+    # every kernel of the chain had its share: the first one settles most columns but not all, ties reach the pair test, reference codes
+    # >= 128 and columns deeper than 255 the whole-column test
+    cnt = api.column_partition_last_counts()
+    assert 0 < cnt["to_grouped"] < len(want)
+    if base == "ties":
+        assert cnt["pairs_to_exact"] > 0
+    if base in ("high", "many"):
+        assert cnt["whole_columns_to_exact"] > 0
+    if mode == "snp_third_count":
+        assert cnt["to_grouped"] < 0.5 * len(want)      # (with the third count known the first kernel settles most columns on its own)
 
 
 def test_simdiff_matches_oracle(built):
