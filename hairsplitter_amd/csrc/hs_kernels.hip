@@ -1525,21 +1525,27 @@ __global__ __launch_bounds__(256) void k_column_partition_lanes(
         const uint32_t base = tb + pb + (uint32_t)pl;
         uint32_t acc = 0u;                       // six 5-bit fields: spilled into the wide counters before one can overflow (every 24 entries)
         uint32_t w_r = 0u, w_k = 0u, w_o = 0u;   // reference plus | minus << 16; k1 zero | plus << 10 | minus << 20; the others, present
-        int since = 0;
-        for (int e = 0; __ballot(on && e < n8) != 0ull; e += 8) {
-            if (on && e < n8) {
+        for (int e = 0; __ballot(on && e < n8) != 0ull; e += 16) {
+            if (on && e < n8) {      // sixteen entries at a time where the column has them (the second eight under their own test: n8 is a multiple of 8)
+                const bool two = e + 8 < n8;
                 const uint4 oa = *reinterpret_cast<const uint4*>(so + e), ob = *reinterpret_cast<const uint4*>(so + e + 4);
                 const uint4 ca = *reinterpret_cast<const uint4*>(sc + e), cb = *reinterpret_cast<const uint4*>(sc + e + 4);
+                uint4 oc = make_uint4(0u, 0u, 0u, 0u), od = oc, cc = make_uint4(HS_K4L_NONE, HS_K4L_NONE, HS_K4L_NONE, HS_K4L_NONE), cd = cc;
+                if (two) { oc = *reinterpret_cast<const uint4*>(so + e + 8); od = *reinterpret_cast<const uint4*>(so + e + 12); cc = *reinterpret_cast<const uint4*>(sc + e + 8); cd = *reinterpret_cast<const uint4*>(sc + e + 12); }
                 const uint32_t b0 = tab[base + oa.x], b1 = tab[base + oa.y], b2 = tab[base + oa.z], b3 = tab[base + oa.w];
                 const uint32_t b4 = tab[base + ob.x], b5 = tab[base + ob.y], b6 = tab[base + ob.z], b7 = tab[base + ob.w];
+                const uint32_t b8 = tab[base + oc.x], b9 = tab[base + oc.y], b10 = tab[base + oc.z], b11 = tab[base + oc.w];
+                const uint32_t b12 = tab[base + od.x], b13 = tab[base + od.y], b14 = tab[base + od.z], b15 = tab[base + od.w];
                 acc += (1u << __builtin_amdgcn_ubfe(ca.x, b0, 5u)) + (1u << __builtin_amdgcn_ubfe(ca.y, b1, 5u)) + (1u << __builtin_amdgcn_ubfe(ca.z, b2, 5u)) + (1u << __builtin_amdgcn_ubfe(ca.w, b3, 5u));
                 acc += (1u << __builtin_amdgcn_ubfe(cb.x, b4, 5u)) + (1u << __builtin_amdgcn_ubfe(cb.y, b5, 5u)) + (1u << __builtin_amdgcn_ubfe(cb.z, b6, 5u)) + (1u << __builtin_amdgcn_ubfe(cb.w, b7, 5u));
+                acc += (1u << __builtin_amdgcn_ubfe(cc.x, b8, 5u)) + (1u << __builtin_amdgcn_ubfe(cc.y, b9, 5u)) + (1u << __builtin_amdgcn_ubfe(cc.z, b10, 5u)) + (1u << __builtin_amdgcn_ubfe(cc.w, b11, 5u));
+                acc += (1u << __builtin_amdgcn_ubfe(cd.x, b12, 5u)) + (1u << __builtin_amdgcn_ubfe(cd.y, b13, 5u)) + (1u << __builtin_amdgcn_ubfe(cd.z, b14, 5u)) + (1u << __builtin_amdgcn_ubfe(cd.w, b15, 5u));
             }
-            if (++since == 3) {      // (wave-uniform)
+            {      // (at most 16 per field in one round: spilled every round, wave-uniform)
                 w_r += (acc & 31u) | (((acc >> 5) & 31u) << 16);
                 w_k += ((acc >> 10) & 31u) | (((acc >> 15) & 31u) << 10) | (((acc >> 20) & 31u) << 20);
                 w_o += (acc >> 25) & 31u;
-                acc = 0u; since = 0;
+                acc = 0u;
             }
         }
         w_r += (acc & 31u) | (((acc >> 5) & 31u) << 16);
